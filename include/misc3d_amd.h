@@ -1,0 +1,173 @@
+/*
+ * misc3d_amd.h -- C ABI of the MI355X (gfx950) implementation of the Misc3D RANSAC hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one function of the reference
+ * (yuecideng/Misc3D; paths below are relative to its repository root).  Plain pointers and sizes,
+ * no C++/torch types.  Inputs are borrowed for the duration of the call; outputs go to
+ * caller-allocated buffers; nothing allocated inside crosses the ABI except opaque handles that
+ * are released with the matching *_destroy.
+ *
+ * Return convention (mirrors the reference's three outcomes):
+ *     1  reference returned `true`
+ *     0  reference returned `false` (soft failure: params are zeroed by the callers exactly as
+ *        python/py_common.cpp:21-23,39-41,61-63 do; inliers are still returned)
+ *    <0  the reference raises (misc3d::LogError throws std::runtime_error, src/logging.cpp:64-74):
+ *        M3D_ERR_* below; m3d_last_error() gives the reference's message text.
+ * The library never throws and never falls back to a CPU path: without a usable HIP device every
+ * compute entry point returns M3D_ERR_DEVICE.
+ *
+ * Point clouds are Open3D's layout: contiguous N x 3 float64 (open3d::geometry::PointCloud::points_
+ * is std::vector<Eigen::Vector3d>, 24-byte POD elements), so `pcd.points_.data()->data()` can be
+ * passed as is.
+ */
+#ifndef MISC3D_AMD_H
+#define MISC3D_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3D_OK 1
+#define M3D_FALSE 0
+#define M3D_ERR_PROBABILITY (-1) /* "Probability must be > 0 or <= 1.0"          ransac.h:483-485 */
+#define M3D_ERR_TOO_FEW_POINTS (-2) /* "Can not fit model due to lack of points" ransac.h:510-513;
+                                       "The number of points pair is less than 3." transform_estimation.cpp:17-19,130-133 */
+#define M3D_ERR_NO_NORMALS (-3) /* "Fit cylinder requires normals."            py_common.cpp:50-52, ransac.h:356-359 */
+#define M3D_ERR_SIZE_MISMATCH (-4) /* "The number of points pair is not equal." transform_estimation.cpp:20-22 */
+#define M3D_ERR_INVALID_ARG (-5) /* null pointer / out-of-range index / N >= 2^31 */
+#define M3D_ERR_DEVICE (-6) /* no HIP device, HIP runtime error, or out of device memory */
+#define M3D_ERR_INTERNAL (-7) /* self-check failed (counts from the scoring kernel and the refine pass disagree) */
+
+enum m3d_model_kind { M3D_PLANE = 0, M3D_SPHERE = 1, M3D_CYLINDER = 2 };
+
+/* Observable state of misc3d::common::RANSAC after FitModel (ransac.h:616-619 logs fitness and
+ * count) plus counters of this implementation. */
+typedef struct m3d_stats {
+    double fitness;              /* best inlier ratio (ransac.h:617) */
+    double inlier_rmse;          /* best error/sqrt(n) if it had to be evaluated (ties), else NaN */
+    uint64_t count;              /* valid hypotheses evaluated before the adaptive stop ("run {} iterations") */
+    uint64_t iterations;         /* loop index at which the reference loop went idle */
+    int64_t best_index;          /* hypothesis index of the best model, -1 if none */
+    int32_t general_fit_ok;      /* RefineModel's return (ransac.h:548) */
+    int32_t reserved;
+    uint64_t hypotheses_scored;  /* hypotheses the GPU scored (>= iterations: speculative chunks) */
+    uint64_t exact_rmse_evals;   /* serial-order error sums computed to break fitness ties */
+    double ms_sample;            /* host: std::mt19937 sample table */
+    double ms_score;             /* device: minimal fit + scoring + reduce (HIP events) */
+    double ms_refine;            /* device+host: inlier compaction, GeneralFit, copy-out */
+    double ms_total;             /* wall clock of the call */
+} m3d_stats;
+
+/* ---- one-shot fits: python/py_common.cpp:11-67 FitPlane / FitSphere / FitCylinder ------------- */
+/* seed: NULL = std::random_device (reference behaviour, utils.h:74-77); else std::mt19937(*seed).
+ * device: HIP device ordinal.  inliers: capacity n.  params: 4 (plane a,b,c,d; sphere cx,cy,cz,r)
+ * or 7 (cylinder px,py,pz,nx,ny,nz,r).  On return 0 the caller zeroes params (py_common.cpp:21-23). */
+int m3d_fit_plane(const double *xyz, size_t n, double threshold, size_t max_iteration,
+                  double probability, const uint64_t *seed, int device, double params[4],
+                  size_t *inliers, size_t *n_inliers, m3d_stats *stats);
+int m3d_fit_sphere(const double *xyz, size_t n, double threshold, size_t max_iteration,
+                   double probability, const uint64_t *seed, int device, double params[4],
+                   size_t *inliers, size_t *n_inliers, m3d_stats *stats);
+int m3d_fit_cylinder(const double *xyz, const double *normals, size_t n, double threshold,
+                     size_t max_iteration, double probability, const uint64_t *seed, int device,
+                     double params[7], size_t *inliers, size_t *n_inliers, m3d_stats *stats);
+
+/* ---- resident cloud: RANSAC::SetPointCloud (ransac.h:469-475) keeps a copy; here the copy lives
+ *      in HBM as SoA x[],y[],z[] (+ normals) so repeated fits do not re-upload. ------------------ */
+typedef struct m3d_cloud m3d_cloud;
+m3d_cloud *m3d_cloud_create(const double *xyz, const double *normals /* may be NULL */, size_t n,
+                            int device);
+void m3d_cloud_destroy(m3d_cloud *cloud);
+size_t m3d_cloud_size(const m3d_cloud *cloud);
+/* RANSAC::SetProbability + SetMaxIteration + FitModel (ransac.h:482-516) on the resident cloud.
+ * inliers may be NULL (then only *n_inliers is reported). */
+int m3d_cloud_fit(m3d_cloud *cloud, int kind, double threshold, size_t max_iteration,
+                  double probability, const uint64_t *seed, double *params, size_t *inliers,
+                  size_t *n_inliers, m3d_stats *stats);
+
+/* ---- hypothesis-range scoring: the shardable unit (ransac.h:572-590 body for i in [begin,end)).
+ * samples: H x m sample indices (m = 3 plane, 4 sphere, 2 cylinder) as the sequential sampler
+ * (utils.h:81-97) produces them; m3d_draw_samples reproduces that table from a seed.
+ * Outputs (host, length end-begin): valid = MinimalFit's return, counts = inlier_num of
+ * EvaluateModel (ransac.h:626-641), models = (end-begin) x 8 doubles (first 4/7 = parameters).
+ * Any of counts/valid/models may be NULL. */
+int m3d_draw_samples(size_t n_points, int kind, size_t n_hypotheses, uint64_t seed,
+                     uint32_t *samples);
+int m3d_cloud_score_range(m3d_cloud *cloud, int kind, double threshold, const uint32_t *samples,
+                          size_t begin, size_t end, uint32_t *counts, uint8_t *valid,
+                          double *models);
+/* Serial-order error sum of EvaluateModel for ONE model (ransac.h:632-640), used to break
+ * fitness ties exactly as the reference does.  *count is the inlier number, *error the sum. */
+int m3d_cloud_exact_error(m3d_cloud *cloud, int kind, double threshold, const double *model,
+                          uint64_t *count, double *error);
+/* RefineModel (ransac.h:534-549) for a given pre-refinement model: inlier indices (ascending) and
+ * GeneralFit applied in place to params.  Return 1/0 = GeneralFit's return. */
+int m3d_cloud_refine(m3d_cloud *cloud, int kind, double threshold, double *params,
+                     size_t *inliers, size_t *n_inliers);
+/* Sequential replay of the best-update / adaptive-stop rule (ransac.h:573-575,592-613) over
+ * per-hypothesis (valid, count) records in index order; `rmse_cb` is called only for fitness ties.
+ * Pure host logic, usable by distributed drivers after gathering counts. */
+typedef double (*m3d_rmse_fn)(void *user, size_t hypothesis_index);
+typedef struct m3d_replay_state {
+    double best_fitness, best_rmse;
+    int64_t best_index;
+    uint64_t best_count; /* inlier_num of the best hypothesis */
+    uint64_t count, current_iteration, iterations;
+    int32_t best_rmse_known, stopped;
+} m3d_replay_state;
+void m3d_replay_init(m3d_replay_state *st);
+void m3d_replay_chunk(m3d_replay_state *st, size_t n_points, int kind, size_t max_iteration,
+                      double probability, size_t begin, size_t end, const uint8_t *valid,
+                      const uint32_t *counts, m3d_rmse_fn rmse_cb, void *user);
+
+/* ---- segmentation::SegmentPlaneIterative, src/iterative_plane_segmentation.cpp:8-39 ----------- */
+/* planes: 4 x max_clusters; cluster_offsets: max_clusters+1; cluster_indices: capacity n, indices
+ * into the ORIGINAL cloud, ascending inside a cluster (SelectByIndex order).  Round r seeds its
+ * sampler with *seed + r.  Returns 1; 0 when N < 3 (reference: warning + empty result, :13-17);
+ * 2 when a round found no inlier (the reference would spin forever, :29-35). */
+int m3d_segment_plane_iterative(const double *xyz, size_t n, double threshold, int max_iteration,
+                                double min_ratio, const uint64_t *seed, int device,
+                                size_t max_clusters, double *planes, size_t *cluster_offsets,
+                                size_t *cluster_indices, size_t *n_clusters);
+
+/* ---- registration::LeastSquareSolver::Solve, src/transform_estimation.cpp:49-66 (Eigen::umeyama) */
+/* src, dst: n x 3.  T: row-major 4x4. */
+int m3d_kabsch(const double *src, const double *dst, size_t n, int scaling, int device,
+               double T[16]);
+
+/* ---- registration::RANSACSolver::Solve, src/transform_estimation.cpp:124-164 ------------------ */
+typedef struct m3d_reg_stats {
+    double fitness, inlier_rmse;
+    uint64_t validations;
+    int64_t iterations, best_index, est_k;
+    double ms_total;
+} m3d_reg_stats;
+/* corr_src/corr_dst: m index pairs (the std::pair<vector<size_t>,vector<size_t>> of the reference).
+ * confidence: Open3D RANSACConvergenceCriteria::confidence_ (the reference always uses the default
+ * 0.999, transform_estimation.cpp:160-161).  T: row-major 4x4. */
+int m3d_registration_ransac(const double *src, size_t n_src, const double *dst, size_t n_dst,
+                            const size_t *corr_src, const size_t *corr_dst, size_t m,
+                            double threshold, int max_iter, double edge_length_threshold,
+                            double confidence, const uint64_t *seed, int device, double T[16],
+                            m3d_reg_stats *stats);
+
+/* ---- registration::ANNMatcher::Match, src/correspondence_matching.cpp:52-84 ------------------- */
+/* feat_*: Eigen MatrixXd dim x N column-major = N descriptors of dim contiguous doubles.
+ * method: 0 FLANN, 1 ANNOY (correspondence_matching.h MatchMethod); both run the exact mutual
+ * nearest-neighbour search on the GPU.  out_*: capacity n_src.  *k = number of matches. */
+int m3d_match_mutual_nn(const double *feat_src, size_t n_src, const double *feat_dst, size_t n_dst,
+                        int dim, int method, int n_trees, int device, size_t *out_src,
+                        size_t *out_dst, size_t *k);
+
+/* ---- misc -------------------------------------------------------------------------------------- */
+const char *m3d_last_error(void); /* thread-local; reference message text for M3D_ERR_* */
+int m3d_device_count(void);       /* 0 when no HIP device is usable */
+const char *m3d_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISC3D_AMD_H */

@@ -1,0 +1,328 @@
+"""ctypes binding of the C ABI declared in ``include/misc3d_amd.h``.
+
+This is plumbing for the tests, ``bench.py`` and the distributed driver: it loads
+``misc3d_amd/lib/libmisc3d_amd.so`` (built in-tree by ``misc3d_amd/csrc/Makefile``) and exposes each
+``m3d_*`` entry point with numpy in/out.  It contains no arithmetic and no fallback: if the shared
+object is missing, importing fails loudly; if there is no HIP device every compute call raises
+``M3DError`` carrying the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmisc3d_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "misc3d_amd.h")
+
+PLANE, SPHERE, CYLINDER = 0, 1, 2
+MINIMAL_SAMPLE = {PLANE: 3, SPHERE: 4, CYLINDER: 2}
+NUM_PARAMS = {PLANE: 4, SPHERE: 4, CYLINDER: 7}
+MODEL_STRIDE = 8
+
+OK, FALSE = 1, 0
+ERR_PROBABILITY, ERR_TOO_FEW_POINTS, ERR_NO_NORMALS, ERR_SIZE_MISMATCH = -1, -2, -3, -4
+ERR_INVALID_ARG, ERR_DEVICE, ERR_INTERNAL = -5, -6, -7
+
+
+class M3DError(RuntimeError):
+    """Raised for negative return codes; mirrors misc3d::LogError -> std::runtime_error
+    (src/logging.cpp:64-74), message prefixed like the reference's."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[Misc3D Error] {msg}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("count", C.c_uint64),
+                ("iterations", C.c_uint64), ("best_index", C.c_int64), ("general_fit_ok", C.c_int32),
+                ("reserved", C.c_int32), ("hypotheses_scored", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
+                ("ms_sample", C.c_double), ("ms_score", C.c_double), ("ms_refine", C.c_double),
+                ("ms_total", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class RegStats(C.Structure):
+    _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("validations", C.c_uint64),
+                ("iterations", C.c_int64), ("best_index", C.c_int64), ("est_k", C.c_int64),
+                ("ms_total", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class ReplayState(C.Structure):
+    _fields_ = [("best_fitness", C.c_double), ("best_rmse", C.c_double), ("best_index", C.c_int64),
+                ("best_count", C.c_uint64), ("count", C.c_uint64), ("current_iteration", C.c_uint64),
+                ("iterations", C.c_uint64), ("best_rmse_known", C.c_int32), ("stopped", C.c_int32)]
+
+
+RMSE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_size_t)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C misc3d_amd/csrc` (or __graft_entry__.build()); "
+                "misc3d_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.m3d_last_error.restype = C.c_char_p
+        L.m3d_version.restype = C.c_char_p
+        L.m3d_cloud_create.restype = C.c_void_p
+        L.m3d_cloud_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.m3d_cloud_destroy.argtypes = [C.c_void_p]
+        L.m3d_cloud_destroy.restype = None
+        L.m3d_cloud_size.argtypes = [C.c_void_p]
+        L.m3d_cloud_size.restype = C.c_size_t
+        L.m3d_cloud_fit.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_double, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_cloud_score_range.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_size_t,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_cloud_exact_error.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_cloud_refine.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_draw_samples.argtypes = [C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.c_void_p]
+        L.m3d_replay_init.argtypes = [C.c_void_p]
+        L.m3d_replay_init.restype = None
+        L.m3d_replay_chunk.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_double, C.c_size_t,
+                                       C.c_size_t, C.c_void_p, C.c_void_p, RMSE_FN, C.c_void_p]
+        L.m3d_replay_chunk.restype = None
+        for name in ("m3d_fit_plane", "m3d_fit_sphere"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_size_t, C.c_double, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_fit_cylinder.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_size_t, C.c_double,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_segment_plane_iterative.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double,
+                                                  C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]
+        L.m3d_kabsch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.m3d_registration_ransac.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                              C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double, C.c_double,
+                                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.m3d_match_mutual_nn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().m3d_last_error().decode()
+
+
+def device_count() -> int:
+    return int(lib().m3d_device_count())
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        raise M3DError(rc, last_error())
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _seed_ref(seed):
+    if seed is None:
+        return None, None
+    s = C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)
+    return s, C.byref(s)
+
+
+@dataclass
+class Fit:
+    ret: int                 # 1 = reference `true`, 0 = reference `false`
+    params: np.ndarray       # best model AFTER RefineModel (not zeroed; callers zero on ret == 0)
+    inliers: np.ndarray      # uint64, ascending
+    stats: dict
+
+
+class Cloud:
+    """Resident SoA copy of a point cloud in HBM (RANSAC::SetPointCloud, ransac.h:469-475)."""
+
+    def __init__(self, xyz, normals=None, device: int = 0):
+        xyz = _f64(xyz).reshape(-1, 3)
+        nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+        if nrm is not None and len(nrm) != len(xyz):
+            raise ValueError("normals and points differ in length")
+        self.n = len(xyz)
+        self._h = lib().m3d_cloud_create(_p(xyz), _p(nrm), self.n, device)
+        if not self._h:
+            raise M3DError(ERR_DEVICE, last_error())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().m3d_cloud_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def fit(self, kind, threshold=0.01, max_iteration=1000, probability=0.9999, seed=None,
+            want_inliers=True) -> Fit:
+        params = np.zeros(NUM_PARAMS[kind])
+        inl = np.zeros(max(self.n, 1), dtype=np.uint64) if want_inliers else None
+        ni = C.c_size_t(0)
+        st = Stats()
+        _s, sref = _seed_ref(seed)
+        rc = _check(lib().m3d_cloud_fit(self._h, kind, threshold, max_iteration, probability,
+                                        C.cast(sref, C.c_void_p) if sref else None, _p(params), _p(inl),
+                                        C.cast(C.byref(ni), C.c_void_p), C.cast(C.byref(st), C.c_void_p)))
+        inliers = inl[: ni.value].copy() if want_inliers else np.zeros(0, dtype=np.uint64)
+        d = st.asdict()
+        d["n_inliers"] = int(ni.value)
+        return Fit(rc, params, inliers, d)
+
+    def score_range(self, kind, threshold, samples, begin=0, end=None):
+        samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, MINIMAL_SAMPLE[kind])
+        end = len(samples) if end is None else end
+        cnt = np.zeros(end - begin, dtype=np.uint32)
+        val = np.zeros(end - begin, dtype=np.uint8)
+        mod = np.zeros((end - begin, MODEL_STRIDE))
+        _check(lib().m3d_cloud_score_range(self._h, kind, threshold, _p(samples), begin, end, _p(cnt), _p(val),
+                                           _p(mod)))
+        return val, mod[:, : NUM_PARAMS[kind]].copy(), cnt
+
+    def exact_error(self, kind, threshold, model):
+        model = _f64(model)
+        cnt = C.c_uint64(0)
+        err = C.c_double(0)
+        _check(lib().m3d_cloud_exact_error(self._h, kind, threshold, _p(model), C.cast(C.byref(cnt), C.c_void_p),
+                                           C.cast(C.byref(err), C.c_void_p)))
+        return int(cnt.value), float(err.value)
+
+    def refine(self, kind, threshold, params):
+        params = _f64(params).copy()
+        inl = np.zeros(max(self.n, 1), dtype=np.uint64)
+        ni = C.c_size_t(0)
+        rc = _check(lib().m3d_cloud_refine(self._h, kind, threshold, _p(params), _p(inl),
+                                           C.cast(C.byref(ni), C.c_void_p)))
+        return rc, params, inl[: ni.value].copy()
+
+
+def draw_samples(n_points, kind, n_hyp, seed):
+    out = np.zeros((n_hyp, MINIMAL_SAMPLE[kind]), dtype=np.uint32)
+    _check(lib().m3d_draw_samples(n_points, kind, n_hyp, C.c_uint64(seed), _p(out)))
+    return out
+
+
+def fit(kind, xyz, normals=None, threshold=0.01, max_iteration=1000, probability=0.9999, seed=None,
+        device=0) -> Fit:
+    """One-shot m3d_fit_plane / m3d_fit_sphere / m3d_fit_cylinder."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    n = len(xyz)
+    params = np.zeros(NUM_PARAMS[kind])
+    inl = np.zeros(max(n, 1), dtype=np.uint64)
+    ni = C.c_size_t(0)
+    st = Stats()
+    _s, sref = _seed_ref(seed)
+    sp = C.cast(sref, C.c_void_p) if sref else None
+    nip, stp = C.cast(C.byref(ni), C.c_void_p), C.cast(C.byref(st), C.c_void_p)
+    if kind == CYLINDER:
+        nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+        rc = lib().m3d_fit_cylinder(_p(xyz), _p(nrm), n, threshold, max_iteration, probability, sp, device,
+                                    _p(params), _p(inl), nip, stp)
+    else:
+        fn = lib().m3d_fit_plane if kind == PLANE else lib().m3d_fit_sphere
+        rc = fn(_p(xyz), n, threshold, max_iteration, probability, sp, device, _p(params), _p(inl), nip, stp)
+    _check(rc)
+    d = st.asdict()
+    d["n_inliers"] = int(ni.value)
+    return Fit(rc, params, inl[: ni.value].copy(), d)
+
+
+def segment_plane_iterative(xyz, threshold, max_iteration=100, min_ratio=0.05, seed=None, device=0,
+                            max_clusters=4096):
+    xyz = _f64(xyz).reshape(-1, 3)
+    n = len(xyz)
+    planes = np.zeros((max_clusters, 4))
+    offs = np.zeros(max_clusters + 1, dtype=np.uint64)
+    idx = np.zeros(max(n, 1), dtype=np.uint64)
+    k = C.c_size_t(0)
+    _s, sref = _seed_ref(seed)
+    rc = _check(lib().m3d_segment_plane_iterative(_p(xyz), n, threshold, max_iteration, min_ratio,
+                                                  C.cast(sref, C.c_void_p) if sref else None, device, max_clusters,
+                                                  _p(planes), _p(offs), _p(idx), C.cast(C.byref(k), C.c_void_p)))
+    k = k.value
+    return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() for i in range(k)]
+
+
+def kabsch(src, dst, scaling=False, device=0):
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    if len(src) != len(dst):
+        raise M3DError(ERR_SIZE_MISMATCH, "The number of points pair is not equal.")
+    T = np.zeros(16)
+    _check(lib().m3d_kabsch(_p(src), _p(dst), len(src), int(bool(scaling)), device, _p(T)))
+    return T.reshape(4, 4)
+
+
+def registration_ransac(src, dst, corr_src, corr_dst, threshold=0.01, max_iter=100000, edge_length_threshold=0.9,
+                        confidence=0.999, seed=None, device=0):
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    cs = np.ascontiguousarray(corr_src, dtype=np.uint64)
+    cd = np.ascontiguousarray(corr_dst, dtype=np.uint64)
+    if len(cs) != len(cd):
+        raise ValueError("correspondence lists differ in length")
+    T = np.zeros(16)
+    st = RegStats()
+    _s, sref = _seed_ref(seed)
+    _check(lib().m3d_registration_ransac(_p(src), len(src), _p(dst), len(dst), _p(cs), _p(cd), len(cs), threshold,
+                                         max_iter, edge_length_threshold, confidence,
+                                         C.cast(sref, C.c_void_p) if sref else None, device, _p(T),
+                                         C.cast(C.byref(st), C.c_void_p)))
+    return T.reshape(4, 4), st.asdict()
+
+
+def match_mutual_nn(feat_src, feat_dst, method=1, n_trees=4, device=0):
+    """feat_*: (N, dim) C-contiguous == Eigen dim x N column-major."""
+    fs = _f64(feat_src)
+    fd = _f64(feat_dst)
+    if fs.ndim != 2 or fd.ndim != 2 or fs.shape[1] != fd.shape[1]:
+        raise ValueError("descriptor matrices must be (N, dim) with equal dim")
+    o0 = np.zeros(max(len(fs), 1), dtype=np.uint64)
+    o1 = np.zeros(max(len(fs), 1), dtype=np.uint64)
+    k = C.c_size_t(0)
+    _check(lib().m3d_match_mutual_nn(_p(fs), len(fs), _p(fd), len(fd), fs.shape[1], method, n_trees, device, _p(o0),
+                                     _p(o1), C.cast(C.byref(k), C.c_void_p)))
+    return o0[: k.value].copy(), o1[: k.value].copy()
+
+
+def replay(n_points, kind, max_iteration, probability, valid, counts, rmse=None):
+    """Host-only replay of ransac.h:573-575,592-613 over gathered (valid, count) records."""
+    st = ReplayState()
+    lib().m3d_replay_init(C.byref(st))
+    valid = np.ascontiguousarray(valid, dtype=np.uint8)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+
+    def _cb(_user, i):
+        return float(rmse(int(i))) if rmse is not None else 0.0
+
+    cb = RMSE_FN(_cb)
+    lib().m3d_replay_chunk(C.byref(st), n_points, kind, max_iteration, probability, 0, len(valid), _p(valid),
+                           _p(counts), cb, None)
+    return st

@@ -1,0 +1,959 @@
+// m3d_driver.cpp -- host driver behind the C ABI (include/misc3d_amd.h).
+//
+// Mirrors the control flow of misc3d::common::RANSAC (include/misc3d/common/ransac.h:455-664) and
+// segmentation::SegmentPlaneIterative (src/iterative_plane_segmentation.cpp:8-39), with the data-
+// parallel loops moved into the kernels of m3d_kernels.hip:
+//
+//   reference (sequential, OMP_NUM_THREADS=1 semantics)          here
+//   ---------------------------------------------------          ------------------------------------
+//   for i < max_iteration:                                       chunks of hypotheses, geometric sizes
+//     sample = sampler(m)            utils.h:81-97               host std::mt19937 -> sample table -> HBM
+//     MinimalFit(sample)             ransac.h:582                minimal_fit_k   (1 thread / hypothesis)
+//     EvaluateModel(all points)      ransac.h:588,626-654        score_k + reduce_partials_k (counts only)
+//     critical: best update, k       ransac.h:592-613            replay_chunk() on the host, in index order
+//   RefineModel                      ransac.h:534-549            compact_*_k + sum_*_k + closed form
+//
+// `inlier_rmse` (error / sqrt(n), ransac.h:650) only ever decides between hypotheses of EQUAL
+// fitness (ransac.h:595-596) and is never returned, so the serial error sum is evaluated on demand,
+// in point order, only when such a tie occurs (exact_error()).
+//
+// There is no CPU fallback: every entry point needs a HIP device.
+#include "m3d_driver.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <random>
+
+#pragma clang fp contract(off)
+
+namespace m3d {
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(M3D_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+bool DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return true;
+    release();
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    if (hipMalloc(&p, want) != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc failed (" + std::to_string(want) + " bytes)");
+        return false;
+    }
+    cap = want;
+    return true;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+bool PinBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return true;
+    release();
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+        p = nullptr;
+        set_error("hipHostMalloc failed (" + std::to_string(want) + " bytes)");
+        return false;
+    }
+    cap = want;
+    return true;
+}
+void PinBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+#define RESERVE(buf, bytes)                         \
+    do {                                            \
+        if (!(buf).reserve(bytes)) return M3D_ERR_DEVICE; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device context
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_ctx_mu;
+static std::map<int, DeviceCtx*> g_ctx;
+
+DeviceCtx* get_ctx(int device) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) return it->second;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device available (misc3d_amd has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        set_error("invalid HIP device ordinal " + std::to_string(device));
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        set_error("hipSetDevice failed");
+        return nullptr;
+    }
+    DeviceCtx* c = new DeviceCtx();
+    c->device = device;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+        ok = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        set_error("failed to create HIP stream/events");
+        delete c;
+        return nullptr;
+    }
+    g_ctx[device] = c;
+    return c;
+}
+
+static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+static inline int minimal_sample(int kind) { return kind == M3D_PLANE ? 3 : (kind == M3D_SPHERE ? 4 : 2); }
+static inline int num_params(int kind) { return kind == M3D_CYLINDER ? 7 : 4; }
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace m3d
+
+m3d::CloudView m3d_cloud::view() const {
+    m3d::CloudView v;
+    v.x = x.as<double>();
+    v.y = y.as<double>();
+    v.z = z.as<double>();
+    v.nx = has_normals ? nx.as<double>() : nullptr;
+    v.ny = has_normals ? ny.as<double>() : nullptr;
+    v.nz = has_normals ? nz.as<double>() : nullptr;
+    v.n = n;
+    v.n_pad = n_pad;
+    return v;
+}
+
+namespace m3d {
+
+// ------------------------------------------------------------------------------------------------
+// sequential replay of ransac.h:573-575, 592-613
+// ------------------------------------------------------------------------------------------------
+// size_t(double) as gcc/x86-64 evaluates it (cvttsd2si); the C++ conversion is undefined for the
+// NaN / negative / huge values the adaptive bound can take (log(0), 0/0).
+static uint64_t double_to_size_t_x86(double v) {
+    const double two63 = 9223372036854775808.0;
+    if (v >= two63) {
+        const double w = v - two63;
+        if (!(w < two63)) return 0;  // indefinite (0x8000...) xor sign bit
+        return static_cast<uint64_t>(static_cast<int64_t>(w)) ^ 0x8000000000000000ull;
+    }
+    if (!(v > -two63)) return 0x8000000000000000ull;
+    return static_cast<uint64_t>(static_cast<int64_t>(v));
+}
+
+template <class RmseFn, class BestFn>
+static void replay_range(m3d_replay_state* st, size_t n_points, int kind, size_t max_iteration,
+                         double probability, size_t begin, size_t end, const uint8_t* valid,
+                         const uint32_t* counts, RmseFn rmse_of, BestFn on_best) {
+    const int m = minimal_sample(kind);
+    for (size_t i = begin; i < end; ++i) {
+        if (st->stopped) return;
+        if (st->count > st->current_iteration) {  // ransac.h:573-575
+            st->stopped = 1;
+            return;
+        }
+        st->iterations = i + 1;
+        const size_t k = i - begin;
+        if (!valid[k]) continue;  // ransac.h:584-586 (no count++)
+        const uint32_t cnt = counts[k];
+        // EvaluateModel's tail, ransac.h:644-651
+        const double fitness = cnt == 0 ? 0.0 : (double)cnt / (double)n_points;
+        bool better = fitness > st->best_fitness;
+        double trial_rmse = 0.0;
+        bool trial_rmse_known = false;
+        if (!better && fitness == st->best_fitness) {
+            trial_rmse = cnt == 0 ? 1e+10 : rmse_of(i, false);
+            trial_rmse_known = true;
+            if (!st->best_rmse_known) {
+                st->best_rmse = rmse_of((size_t)st->best_index, true);
+                st->best_rmse_known = 1;
+            }
+            better = trial_rmse < st->best_rmse;
+        }
+        if (better) {
+            st->best_fitness = fitness;
+            st->best_rmse = trial_rmse;
+            st->best_rmse_known = trial_rmse_known ? 1 : 0;
+            st->best_index = (int64_t)i;
+            st->best_count = cnt;
+            on_best(i);
+            if (st->best_fitness < 1.0) {  // ransac.h:601-606
+                const double kk =
+                    std::log(1 - probability) / std::log(1 - std::pow(st->best_fitness, (double)m));
+                const double lim = (double)max_iteration;
+                st->current_iteration = double_to_size_t_x86(lim < kk ? lim : kk);
+            } else {
+                st->current_iteration = 0;  // ransac.h:609
+            }
+        }
+        st->count++;  // ransac.h:612
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// chunk machinery
+// ------------------------------------------------------------------------------------------------
+struct SampleSource {
+    // either a seeded sampler (utils.h:71-97) or a caller-provided table
+    std::mt19937 rng;
+    size_t n_points = 0;
+    const uint32_t* table = nullptr;  // H x m, absolute hypothesis index
+    int m = 3;
+    void fill(size_t begin, size_t end, uint32_t* out) {
+        if (table) {
+            std::memcpy(out, table + begin * m, sizeof(uint32_t) * (end - begin) * m);
+            return;
+        }
+        for (size_t h = begin; h < end; ++h) {
+            uint32_t* s = out + (h - begin) * m;
+            int valid = 0;
+            while (valid < m) {  // utils.h:88-95
+                const size_t idx = (size_t)rng() % n_points;
+                bool dup = false;
+                for (int k = 0; k < valid; ++k) dup = dup || (s[k] == idx);
+                if (!dup) s[valid++] = (uint32_t)idx;
+            }
+        }
+    }
+};
+
+static uint32_t pick_splits(uint32_t n_tiles, uint32_t h_pad) {
+    // enough workgroups to fill 256 CUs several times over, while h_pad stays a multiple of 64*s
+    const uint32_t groups = h_pad / 64;
+    uint32_t want = std::max<uint32_t>(1, (4096 + n_tiles - 1) / n_tiles);
+    want = std::min(want, groups);
+    while (groups % want) --want;
+    return want;
+}
+
+static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, int kind, double thr,
+                       size_t begin, size_t end, SampleSource& src, double* ms_sample) {
+    const int m = minimal_sample(kind);
+    const uint32_t count = (uint32_t)(end - begin);
+    const uint32_t h_pad = round_up(count, 64);
+    const uint32_t n_tiles = v.n_pad / kScoreTile;
+    s.begin = begin;
+    s.end = end;
+    s.h_pad = h_pad;
+    RESERVE(s.samples, sizeof(uint32_t) * (size_t)count * m);
+    RESERVE(s.score, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
+    RESERVE(s.params, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
+    RESERVE(s.valid, (size_t)h_pad + 1);
+    RESERVE(s.counts, sizeof(uint32_t) * (size_t)h_pad);
+    RESERVE(s.h_samples, sizeof(uint32_t) * (size_t)count * m);
+    RESERVE(s.h_counts, sizeof(uint32_t) * (size_t)h_pad);
+    RESERVE(s.h_valid, (size_t)h_pad + 1);
+    RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
+    const double t0 = now_ms();
+    src.fill(begin, end, s.h_samples.as<uint32_t>());
+    if (ms_sample) *ms_sample += now_ms() - t0;
+    HIPCHK(hipMemcpyAsync(s.samples.p, s.h_samples.p, sizeof(uint32_t) * (size_t)count * m,
+                          hipMemcpyHostToDevice, ctx->stream));
+    launch_minimal_fit(kind, v, s.samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
+                       s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream);
+    HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
+    launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
+                 ctx->partial.as<uint32_t>(), ctx->stream);
+    launch_reduce_partials(ctx->partial.as<uint32_t>(), n_tiles, h_pad, s.counts.as<uint32_t>(),
+                           ctx->stream);
+    HIPCHK(hipMemcpyAsync(s.h_counts.p, s.counts.p, sizeof(uint32_t) * (size_t)count,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s.h_valid.p, s.valid.p, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s.done, ctx->stream));
+    return M3D_OK;
+}
+
+// EvaluateModel's (inlier_num, error) with the error summed in point order (ransac.h:632-640).
+static int exact_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
+                       const double* model_dev, uint64_t* count, double* error) {
+    const uint32_t nb = (v.n + kCompactTile - 1) / kCompactTile;
+    RESERVE(ctx->dist, sizeof(double) * (size_t)std::max<uint32_t>(v.n, 1));
+    RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)nb + 1));
+    RESERVE(ctx->total, sizeof(uint32_t) * 4);
+    RESERVE(ctx->sums, sizeof(double) * 32);
+    RESERVE(ctx->h_small, 256);
+    launch_compact(kind, v, model_dev, thr, 1, nullptr, nullptr, ctx->dist.as<double>(), nullptr,
+                   nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
+                   ctx->total.as<uint32_t>(), ctx->stream);
+    launch_serial_sum(ctx->dist.as<double>(), ctx->total.as<uint32_t>(), ctx->sums.as<double>() + 16,
+                      ctx->stream);
+    uint8_t* h = ctx->h_small.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(h, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h + 8, ctx->sums.as<double>() + 16, sizeof(double), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t c32;
+    std::memcpy(&c32, h, 4);
+    std::memcpy(error, h + 8, 8);
+    *count = c32;
+    return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GeneralFit closed forms (host; the sums come from sum_*_k)
+// ------------------------------------------------------------------------------------------------
+// PlaneEstimator::GeneralFit, ransac.h:190-211
+static bool plane_from_moments(const double* mean, const double* s, double* out) {
+    const double xx = s[0], xy = s[1], xz = s[2], yy = s[3], yz = s[4], zz = s[5];
+    const double det_x = yy * zz - yz * yz;
+    const double det_y = xx * zz - xz * xz;
+    const double det_z = xx * yy - xy * xy;
+    double a, b, c;
+    if (det_x > det_y && det_x > det_z) {
+        a = det_x;
+        b = xz * yz - xy * zz;
+        c = xy * yz - xz * yy;
+    } else if (det_y > det_z) {
+        a = xz * yz - xy * zz;
+        b = det_y;
+        c = xy * xz - yz * xx;
+    } else {
+        a = xy * yz - xz * yy;
+        b = xy * xz - yz * xx;
+        c = det_z;
+    }
+    const double norm = std::sqrt((a * a + b * b) + c * c);
+    if (norm < 1.0e-8) return false;
+    a /= norm;
+    b /= norm;
+    c /= norm;
+    out[0] = a;
+    out[1] = b;
+    out[2] = c;
+    out[3] = -((a * mean[0] + b * mean[1]) + c * mean[2]);
+    return true;
+}
+
+// SphereEstimator::GeneralFit, ransac.h:296-330: least squares of [2x 2y 2z 1] w = x^2+y^2+z^2.
+// The reference's bdcSvd(FullU) needs an N_inl x N_inl matrix (its own TODO, ransac.h:318-319);
+// here the same least-squares problem is solved from the CENTRED normal equations
+//   4 S c' = 2 sum(p' q),  w3' = sum(q)/n,  q = |p'|^2,  p' = p - mean,
+// then centre = mean + c', r = sqrt(|c'|^2 + w3').  Same minimiser, parameters agree to ~1e-12.
+static bool sphere_from_moments(const double* mean, const double* s, double n, double* out) {
+    double A[3][4] = {{4 * s[0], 4 * s[1], 4 * s[2], 2 * s[6]},
+                      {4 * s[1], 4 * s[3], 4 * s[4], 2 * s[7]},
+                      {4 * s[2], 4 * s[4], 4 * s[5], 2 * s[8]}};
+    for (int col = 0; col < 3; ++col) {  // Gaussian elimination, partial pivoting
+        int piv = col;
+        for (int r = col + 1; r < 3; ++r)
+            if (std::fabs(A[r][col]) > std::fabs(A[piv][col])) piv = r;
+        if (piv != col)
+            for (int k = 0; k < 4; ++k) std::swap(A[piv][k], A[col][k]);
+        if (A[col][col] == 0.0) continue;
+        for (int r = col + 1; r < 3; ++r) {
+            const double f = A[r][col] / A[col][col];
+            for (int k = col; k < 4; ++k) A[r][k] -= f * A[col][k];
+        }
+    }
+    double c[3];
+    for (int r = 2; r >= 0; --r) {
+        double acc = A[r][3];
+        for (int k = r + 1; k < 3; ++k) acc -= A[r][k] * c[k];
+        c[r] = A[r][r] != 0.0 ? acc / A[r][r] : 0.0;
+    }
+    const double w3 = s[9] / n;
+    out[0] = mean[0] + c[0];
+    out[1] = mean[1] + c[1];
+    out[2] = mean[2] + c[2];
+    out[3] = std::sqrt(((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) + w3);
+    return true;
+}
+
+// RefineModel, ransac.h:534-549.  flag_view: cloud the distances are evaluated on; gather_view +
+// orig: when the flags are computed on a compacted cloud (segmentation) the inlier list holds
+// ORIGINAL indices and the GeneralFit sums gather from the original cloud (same values, same order).
+static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_view,
+                  const uint32_t* orig_dev, int kind, double thr, const double* model_dev,
+                  double* params_host /* in: best minimal model, out: refined */, size_t* inliers,
+                  size_t* n_inliers, int* general_fit_ok) {
+    const uint32_t n = flag_view.n;
+    const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
+    RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
+    RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)nb + 1));
+    RESERVE(ctx->total, sizeof(uint32_t) * 4);
+    RESERVE(ctx->sums, sizeof(double) * 32);
+    RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
+    RESERVE(ctx->h_small, 256);
+    launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
+                   nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
+                   ctx->total.as<uint32_t>(), ctx->stream);
+    uint8_t* h = ctx->h_small.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(h, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t ni;
+    std::memcpy(&ni, h, 4);
+    *n_inliers = ni;
+    *general_fit_ok = 1;
+    const bool need_fit = kind != M3D_CYLINDER;  // cylinder GeneralFit is a no-op, ransac.h:427-433
+    const uint32_t min_pts = kind == M3D_PLANE ? 3 : 4;
+    if (need_fit) {
+        if (ni < min_pts) {
+            *general_fit_ok = 0;  // MinimalCheck, ransac.h:166-169, 298-301
+        } else {
+            launch_sum_xyz(gather_view, ctx->idx.as<uint64_t>(), ni, ctx->sum_partial.as<double>(),
+                           ctx->sums.as<double>(), ctx->stream);
+            launch_sum_moments(gather_view, ctx->idx.as<uint64_t>(), ni, ctx->sums.as<double>(),
+                               ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 4, ctx->stream);
+            HIPCHK(hipMemcpyAsync(h + 16, ctx->sums.p, sizeof(double) * 14, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+        }
+    }
+    if (inliers && ni)
+        HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (need_fit && *general_fit_ok) {
+        double sums[14];
+        std::memcpy(sums, h + 16, sizeof(sums));
+        const double mean[3] = {sums[0] / (double)ni, sums[1] / (double)ni, sums[2] / (double)ni};
+        double out[4];
+        bool ok;
+        if (kind == M3D_PLANE)
+            ok = plane_from_moments(mean, sums + 4, out);
+        else
+            ok = sphere_from_moments(mean, sums + 4, (double)ni, out);
+        if (ok)
+            std::memcpy(params_host, out, sizeof(out));  // model refined in place
+        else
+            *general_fit_ok = 0;  // model left as the best minimal model (ransac.h:204-207)
+    }
+    return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RANSAC::FitModelParallel on a resident view.  Leaves the best minimal model in
+// ctx->best_params (device) and best_host.
+// ------------------------------------------------------------------------------------------------
+struct RansacOut {
+    m3d_replay_state st;
+    double best_host[kModelStride];
+    uint64_t hypotheses_scored = 0;
+    uint64_t exact_rmse_evals = 0;
+    double ms_sample = 0, ms_score = 0;
+    int internal_error = 0;
+};
+
+static int run_ransac(DeviceCtx* ctx, const CloudView& v, int kind, double thr, size_t max_iter,
+                      double prob, uint64_t seed, RansacOut* out) {
+    m3d_replay_init(&out->st);
+    std::memset(out->best_host, 0, sizeof(out->best_host));
+    RESERVE(ctx->best_params, sizeof(double) * kModelStride);
+    RESERVE(ctx->h_small, 256);
+    HIPCHK(hipMemsetAsync(ctx->best_params.p, 0, sizeof(double) * kModelStride, ctx->stream));
+    SampleSource src;
+    src.rng.seed((std::mt19937::result_type)(seed & 0xffffffffull));
+    src.n_points = v.n;
+    src.m = minimal_sample(kind);
+
+    const uint32_t n_tiles = std::max<uint32_t>(1, v.n_pad / kScoreTile);
+    // keep the partial-count buffer below 1 GiB
+    size_t chunk_cap = std::min<size_t>(16384, ((size_t)1 << 28) / n_tiles / 64 * 64);
+    chunk_cap = std::max<size_t>(chunk_cap, 64);
+    size_t chunk = prob < 1.0 ? 128 : 1024;
+    chunk = std::min(chunk, chunk_cap);
+
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    int rc = M3D_OK;
+    int cur = 0;
+    size_t next_begin = 0;
+    auto issue_next = [&](int slot_id) -> int {
+        const size_t b = next_begin, e = std::min(max_iter, b + chunk);
+        const int r = issue_chunk(ctx, ctx->slot[slot_id], v, kind, thr, b, e, src, &out->ms_sample);
+        if (r == M3D_OK) {
+            next_begin = e;
+            out->hypotheses_scored += e - b;
+            chunk = std::min(chunk * 2, chunk_cap);
+        }
+        return r;
+    };
+    if (max_iter > 0) {
+        rc = issue_next(0);
+        if (rc != M3D_OK) return rc;
+        for (;;) {
+            ChunkSlot& s = ctx->slot[cur];
+            bool issued = false;
+            if (next_begin < max_iter) {
+                // speculate only when the adaptive bound cannot be reached inside the current chunk
+                const bool safe = prob >= 1.0 || (out->st.best_index >= 0 &&
+                                                  out->st.current_iteration > out->st.count + (s.end - s.begin));
+                if (safe) {
+                    rc = issue_next(cur ^ 1);
+                    if (rc != M3D_OK) break;
+                    issued = true;
+                }
+            }
+            HIPCHK(hipEventSynchronize(s.done));
+            int cb_rc = M3D_OK;
+            auto rmse_of = [&](size_t i, bool is_best) -> double {
+                const double* model = is_best ? ctx->best_params.as<double>()
+                                              : s.params.as<double>() + (i - s.begin) * kModelStride;
+                uint64_t c = 0;
+                double err = 0;
+                const int r = exact_error(ctx, v, kind, thr, model, &c, &err);
+                if (r != M3D_OK) cb_rc = r;
+                out->exact_rmse_evals++;
+                if (!is_best && c != s.h_counts.as<uint32_t>()[i - s.begin]) out->internal_error = 1;
+                return c == 0 ? 1e+10 : err / std::sqrt((double)c);  // ransac.h:644-650
+            };
+            auto on_best = [&](size_t i) {
+                (void)hipMemcpyAsync(ctx->best_params.p, s.params.as<double>() + (i - s.begin) * kModelStride,
+                                     sizeof(double) * kModelStride, hipMemcpyDeviceToDevice, ctx->stream);
+            };
+            replay_range(&out->st, v.n, kind, max_iter, prob, s.begin, s.end, s.h_valid.as<uint8_t>(),
+                         s.h_counts.as<uint32_t>(), rmse_of, on_best);
+            if (cb_rc != M3D_OK) {
+                rc = cb_rc;
+                break;
+            }
+            if (out->st.stopped) break;
+            if (!issued) {
+                if (next_begin >= max_iter) break;
+                rc = issue_next(cur ^ 1);
+                if (rc != M3D_OK) break;
+            }
+            cur ^= 1;
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_small.p, ctx->best_params.p, sizeof(double) * kModelStride,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (rc != M3D_OK) return rc;
+    std::memcpy(out->best_host, ctx->h_small.p, sizeof(double) * kModelStride);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) out->ms_score = ms;
+    if (out->internal_error)
+        return fail(M3D_ERR_INTERNAL, "scoring kernel and exact evaluation disagree on an inlier count");
+    return M3D_OK;
+}
+
+static int validate_fit_args(int kind, size_t n, bool has_normals, double prob) {
+    // order of the reference's checks: FitCylinder normals (py_common.cpp:50-52), SetProbability
+    // (ransac.h:482-487), FitModel's point count (ransac.h:509-513)
+    if (kind == M3D_CYLINDER && !has_normals)
+        return fail(M3D_ERR_NO_NORMALS, "Fit cylinder requires normals.");
+    if (prob <= 0 || prob > 1 || prob != prob)
+        return fail(M3D_ERR_PROBABILITY, "Probability must be > 0 or <= 1.0");
+    if (n < (size_t)minimal_sample(kind))
+        return fail(M3D_ERR_TOO_FEW_POINTS, "Can not fit model due to lack of points");
+    return M3D_OK;
+}
+
+static uint64_t resolve_seed(const uint64_t* seed) {
+    if (seed) return *seed;
+    std::random_device rd;  // utils.h:75
+    return rd();
+}
+
+static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter, double prob,
+                            uint64_t seed, double* params, size_t* inliers, size_t* n_inliers,
+                            m3d_stats* stats) {
+    DeviceCtx* ctx = c->ctx;
+    const double t0 = now_ms();
+    HIPCHK(hipSetDevice(ctx->device));
+    const CloudView v = c->view();
+    RansacOut ro;
+    int rc = run_ransac(ctx, v, kind, thr, max_iter, prob, seed, &ro);
+    if (rc != M3D_OK) return rc;
+    const double t1 = now_ms();
+    double model[kModelStride];
+    std::memcpy(model, ro.best_host, sizeof(model));
+    size_t ni = 0;
+    int gf_ok = 1;
+    rc = refine(ctx, v, v, nullptr, kind, thr, ctx->best_params.as<double>(), model, inliers, &ni,
+                &gf_ok);
+    if (rc != M3D_OK) return rc;
+    if (ro.st.best_index >= 0 && ni != ro.st.best_count)
+        return fail(M3D_ERR_INTERNAL, "refine pass and scoring kernel disagree on the inlier count");
+    if (n_inliers) *n_inliers = ni;
+    std::memcpy(params, model, sizeof(double) * num_params(kind));
+    const double t2 = now_ms();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->fitness = ro.st.best_fitness;
+        stats->inlier_rmse = ro.st.best_rmse_known ? ro.st.best_rmse : std::numeric_limits<double>::quiet_NaN();
+        stats->count = ro.st.count;
+        stats->iterations = ro.st.iterations;
+        stats->best_index = ro.st.best_index;
+        stats->general_fit_ok = gf_ok;
+        stats->hypotheses_scored = ro.hypotheses_scored;
+        stats->exact_rmse_evals = ro.exact_rmse_evals;
+        stats->ms_sample = ro.ms_sample;
+        stats->ms_score = ro.ms_score;
+        stats->ms_refine = t2 - t1;
+        stats->ms_total = t2 - t0;
+    }
+    return gf_ok ? M3D_OK : M3D_FALSE;
+}
+
+}  // namespace m3d
+
+using namespace m3d;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* m3d_last_error(void) { return g_last_error.c_str(); }
+const char* m3d_version(void) { return "misc3d_amd 0.1 (gfx950)"; }
+int m3d_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+void m3d_replay_init(m3d_replay_state* st) {
+    std::memset(st, 0, sizeof(*st));
+    st->best_fitness = 0;  // Clear(), ransac.h:519-522
+    st->best_rmse = 0;
+    st->best_rmse_known = 1;
+    st->best_index = -1;
+    st->current_iteration = std::numeric_limits<uint64_t>::max();  // ransac.h:569
+}
+
+void m3d_replay_chunk(m3d_replay_state* st, size_t n_points, int kind, size_t max_iteration,
+                      double probability, size_t begin, size_t end, const uint8_t* valid,
+                      const uint32_t* counts, m3d_rmse_fn rmse_cb, void* user) {
+    replay_range(
+        st, n_points, kind, max_iteration, probability, begin, end, valid, counts,
+        [&](size_t i, bool) { return rmse_cb ? rmse_cb(user, i) : 0.0; }, [](size_t) {});
+}
+
+m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, int device) {
+    if (!xyz && n > 0) {
+        set_error("xyz is null");
+        return nullptr;
+    }
+    if (n >= ((size_t)1 << 31)) {
+        set_error("point clouds of 2^31 points or more are not supported");
+        return nullptr;
+    }
+    DeviceCtx* ctx = get_ctx(device);
+    if (!ctx) return nullptr;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        set_error("hipSetDevice failed");
+        return nullptr;
+    }
+    m3d_cloud* c = new m3d_cloud();
+    c->ctx = ctx;
+    c->n = (uint32_t)n;
+    c->n_pad = std::max<uint32_t>(round_up((uint32_t)n, kScoreTile), kScoreTile);
+    c->has_normals = normals != nullptr;
+    const size_t bytes = sizeof(double) * (size_t)c->n_pad;
+    DevBuf stage;
+    bool ok = c->x.reserve(bytes) && c->y.reserve(bytes) && c->z.reserve(bytes) &&
+              stage.reserve(sizeof(double) * 3 * std::max<size_t>(n, 1));
+    if (ok && c->has_normals) ok = c->nx.reserve(bytes) && c->ny.reserve(bytes) && c->nz.reserve(bytes);
+    if (ok && n)
+        ok = hipMemcpyAsync(stage.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream) ==
+             hipSuccess;
+    if (ok)
+        launch_aos_to_soa(stage.as<double>(), c->x.as<double>(), c->y.as<double>(), c->z.as<double>(),
+                          c->n, c->n_pad, ctx->stream);
+    if (ok && c->has_normals) {
+        // the staging buffer is reused: stream order keeps the first transpose ahead of this copy
+        if (n)
+            ok = hipMemcpyAsync(stage.p, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice,
+                                ctx->stream) == hipSuccess;
+        if (ok)
+            launch_aos_to_soa(stage.as<double>(), c->nx.as<double>(), c->ny.as<double>(),
+                              c->nz.as<double>(), c->n, c->n_pad, ctx->stream);
+    }
+    ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    stage.release();
+    if (!ok) {
+        if (g_last_error.empty()) set_error("cloud upload failed");
+        c->x.release(); c->y.release(); c->z.release();
+        c->nx.release(); c->ny.release(); c->nz.release();
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void m3d_cloud_destroy(m3d_cloud* c) {
+    if (!c) return;
+    std::lock_guard<std::mutex> lock(c->ctx->mu);
+    (void)hipSetDevice(c->ctx->device);
+    c->x.release(); c->y.release(); c->z.release();
+    c->nx.release(); c->ny.release(); c->nz.release();
+    delete c;
+}
+
+size_t m3d_cloud_size(const m3d_cloud* c) { return c ? c->n : 0; }
+
+int m3d_cloud_fit(m3d_cloud* c, int kind, double threshold, size_t max_iteration, double probability,
+                  const uint64_t* seed, double* params, size_t* inliers, size_t* n_inliers,
+                  m3d_stats* stats) {
+    if (!c || !params || kind < 0 || kind > 2) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    const int vr = validate_fit_args(kind, c->n, c->has_normals, probability);
+    if (vr != M3D_OK) return vr;
+    std::lock_guard<std::mutex> lock(c->ctx->mu);
+    return cloud_fit_locked(c, kind, threshold, max_iteration, probability, resolve_seed(seed), params,
+                            inliers, n_inliers, stats);
+}
+
+static int one_shot_fit(int kind, const double* xyz, const double* normals, size_t n, double thr,
+                        size_t max_iter, double prob, const uint64_t* seed, int device, double* params,
+                        size_t* inliers, size_t* n_inliers, m3d_stats* stats) {
+    if (!params || (!xyz && n)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    const int vr = validate_fit_args(kind, n, normals != nullptr, prob);
+    if (vr != M3D_OK) return vr;
+    m3d_cloud* c = m3d_cloud_create(xyz, normals, n, device);  // SetPointCloud, ransac.h:469-475
+    if (!c) return M3D_ERR_DEVICE;
+    const int rc = m3d_cloud_fit(c, kind, thr, max_iter, prob, seed, params, inliers, n_inliers, stats);
+    m3d_cloud_destroy(c);
+    return rc;
+}
+
+int m3d_fit_plane(const double* xyz, size_t n, double threshold, size_t max_iteration,
+                  double probability, const uint64_t* seed, int device, double params[4],
+                  size_t* inliers, size_t* n_inliers, m3d_stats* stats) {
+    return one_shot_fit(M3D_PLANE, xyz, nullptr, n, threshold, max_iteration, probability, seed, device,
+                        params, inliers, n_inliers, stats);
+}
+int m3d_fit_sphere(const double* xyz, size_t n, double threshold, size_t max_iteration,
+                   double probability, const uint64_t* seed, int device, double params[4],
+                   size_t* inliers, size_t* n_inliers, m3d_stats* stats) {
+    return one_shot_fit(M3D_SPHERE, xyz, nullptr, n, threshold, max_iteration, probability, seed, device,
+                        params, inliers, n_inliers, stats);
+}
+int m3d_fit_cylinder(const double* xyz, const double* normals, size_t n, double threshold,
+                     size_t max_iteration, double probability, const uint64_t* seed, int device,
+                     double params[7], size_t* inliers, size_t* n_inliers, m3d_stats* stats) {
+    return one_shot_fit(M3D_CYLINDER, xyz, normals, n, threshold, max_iteration, probability, seed,
+                        device, params, inliers, n_inliers, stats);
+}
+
+int m3d_draw_samples(size_t n_points, int kind, size_t n_hypotheses, uint64_t seed, uint32_t* samples) {
+    if (kind < 0 || kind > 2 || !samples) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (n_points < (size_t)minimal_sample(kind))
+        return fail(M3D_ERR_TOO_FEW_POINTS, "Can not fit model due to lack of points");
+    SampleSource src;
+    src.rng.seed((std::mt19937::result_type)(seed & 0xffffffffull));
+    src.n_points = n_points;
+    src.m = minimal_sample(kind);
+    src.fill(0, n_hypotheses, samples);
+    return M3D_OK;
+}
+
+int m3d_cloud_score_range(m3d_cloud* c, int kind, double threshold, const uint32_t* samples,
+                          size_t begin, size_t end, uint32_t* counts, uint8_t* valid, double* models) {
+    if (!c || kind < 0 || kind > 2 || !samples || end < begin)
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (kind == M3D_CYLINDER && !c->has_normals)
+        return fail(M3D_ERR_NO_NORMALS, "Fit cylinder requires normals.");
+    if (c->n < (size_t)minimal_sample(kind))
+        return fail(M3D_ERR_TOO_FEW_POINTS, "Can not fit model due to lack of points");
+    DeviceCtx* ctx = c->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const CloudView v = c->view();
+    const int m = minimal_sample(kind);
+    for (size_t h = begin; h < end; ++h)
+        for (int k = 0; k < m; ++k)
+            if (samples[h * m + k] >= v.n) return fail(M3D_ERR_INVALID_ARG, "sample index out of range");
+    SampleSource src;
+    src.table = samples;
+    src.m = m;
+    const uint32_t n_tiles = std::max<uint32_t>(1, v.n_pad / kScoreTile);
+    size_t chunk_cap = std::min<size_t>(16384, ((size_t)1 << 28) / n_tiles / 64 * 64);
+    chunk_cap = std::max<size_t>(chunk_cap, 64);
+    ChunkSlot& s = ctx->slot[0];
+    for (size_t b = begin; b < end; b += chunk_cap) {
+        const size_t e = std::min(end, b + chunk_cap);
+        const int rc = issue_chunk(ctx, s, v, kind, threshold, b, e, src, nullptr);
+        if (rc != M3D_OK) return rc;
+        HIPCHK(hipEventSynchronize(s.done));
+        if (counts) std::memcpy(counts + (b - begin), s.h_counts.p, sizeof(uint32_t) * (e - b));
+        if (valid) std::memcpy(valid + (b - begin), s.h_valid.p, e - b);
+        if (models)
+            HIPCHK(hipMemcpy(models + (b - begin) * kModelStride, s.params.p,
+                             sizeof(double) * kModelStride * (e - b), hipMemcpyDeviceToHost));
+    }
+    return M3D_OK;
+}
+
+int m3d_cloud_exact_error(m3d_cloud* c, int kind, double threshold, const double* model,
+                          uint64_t* count, double* error) {
+    if (!c || kind < 0 || kind > 2 || !model || !count || !error)
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    DeviceCtx* ctx = c->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    RESERVE(ctx->small, 256);
+    double tmp[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::memcpy(tmp, model, sizeof(double) * num_params(kind));
+    HIPCHK(hipMemcpyAsync(ctx->small.p, tmp, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // tmp is a stack buffer
+    return exact_error(ctx, c->view(), kind, threshold, ctx->small.as<double>(), count, error);
+}
+
+int m3d_cloud_refine(m3d_cloud* c, int kind, double threshold, double* params, size_t* inliers,
+                     size_t* n_inliers) {
+    if (!c || kind < 0 || kind > 2 || !params || !n_inliers)
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    DeviceCtx* ctx = c->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    RESERVE(ctx->small, 256);
+    double tmp[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::memcpy(tmp, params, sizeof(double) * num_params(kind));
+    HIPCHK(hipMemcpyAsync(ctx->small.p, tmp, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int gf = 1;
+    const CloudView v = c->view();
+    const int rc = refine(ctx, v, v, nullptr, kind, threshold, ctx->small.as<double>(), tmp, inliers,
+                          n_inliers, &gf);
+    if (rc != M3D_OK) return rc;
+    std::memcpy(params, tmp, sizeof(double) * num_params(kind));
+    return gf ? M3D_OK : M3D_FALSE;
+}
+
+// SegmentPlaneIterative, src/iterative_plane_segmentation.cpp:8-39
+int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, int max_iteration,
+                                double min_ratio, const uint64_t* seed, int device, size_t max_clusters,
+                                double* planes, size_t* cluster_offsets, size_t* cluster_indices,
+                                size_t* n_clusters) {
+    if (!planes || !cluster_offsets || !cluster_indices || !n_clusters || (!xyz && n))
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    *n_clusters = 0;
+    cluster_offsets[0] = 0;
+    if (n < 3) {  // :13-17: LogWarning + empty result
+        set_error("Point cloud size has less than 3.");
+        return M3D_FALSE;
+    }
+    m3d_cloud* c0 = m3d_cloud_create(xyz, nullptr, n, device);
+    if (!c0) return M3D_ERR_DEVICE;
+    DeviceCtx* ctx = c0->ctx;
+    int rc = M3D_OK;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        const uint64_t seed0 = resolve_seed(seed);
+        const CloudView v0 = c0->view();
+        // ping-pong buffers for the shrinking cloud (pcd_copy, :25,:33) + original indices
+        DevBuf bx[2], by[2], bz[2], bo[2];
+        const size_t bytes = sizeof(double) * (size_t)c0->n_pad;
+        bool ok = true;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = bx[k].reserve(bytes) && by[k].reserve(bytes) && bz[k].reserve(bytes) &&
+                 bo[k].reserve(sizeof(uint32_t) * (size_t)c0->n_pad);
+        auto cleanup = [&]() {
+            for (int k = 0; k < 2; ++k) {
+                bx[k].release(); by[k].release(); bz[k].release(); bo[k].release();
+            }
+        };
+        if (!ok) {
+            cleanup();
+            rc = M3D_ERR_DEVICE;
+        } else {
+            launch_iota(bo[0].as<uint32_t>(), c0->n, ctx->stream);
+            CloudView cur = v0;  // round 0 reads the uploaded cloud directly
+            const uint32_t* cur_orig = bo[0].as<uint32_t>();
+            int pp = 0;          // buffers that will RECEIVE the next compaction
+            bool cur_is_v0 = true;
+            size_t count = 0, k = 0;
+            const size_t target = (size_t)((1 - min_ratio) * (double)n);  // :28
+            double plane[4] = {0, 0, 0, 0};  // `plane` persists across rounds (:22)
+            while (count < target && k < max_clusters) {
+                if (cur.n < 3) {  // the reference's FitModel would throw here (ransac.h:510-513)
+                    rc = 2;
+                    break;
+                }
+                RansacOut ro;
+                rc = run_ransac(ctx, cur, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k,
+                                &ro);  // probability stays at the RANSAC default, ransac.h:462
+                if (rc != M3D_OK) break;
+                double model[kModelStride];
+                std::memcpy(model, ro.best_host, sizeof(model));
+                size_t ni = 0;
+                int gf = 1;
+                const size_t off = cluster_offsets[k];
+                rc = refine(ctx, cur, v0, cur_orig, M3D_PLANE, threshold, ctx->best_params.as<double>(),
+                            model, cluster_indices + off, &ni, &gf);
+                if (rc != M3D_OK) break;
+                if (ni == 0) {  // the reference would loop forever (:29,:35)
+                    rc = 2;
+                    break;
+                }
+                std::memcpy(plane, model, sizeof(plane));
+                std::memcpy(planes + 4 * k, plane, sizeof(plane));
+                cluster_offsets[k + 1] = off + ni;
+                count += ni;
+                k++;
+                if (count >= target || k >= max_clusters) break;
+                // pcd_copy = pcd_copy->SelectByIndex(inliers, true), :33
+                const int dst = cur_is_v0 ? 1 : pp;
+                const uint32_t nb = (cur.n + kCompactTile - 1) / kCompactTile;
+                if (!ctx->block_counts.reserve(sizeof(uint32_t) * ((size_t)nb + 1)) ||
+                    !ctx->total.reserve(16)) {
+                    rc = M3D_ERR_DEVICE;
+                    break;
+                }
+                launch_compact(M3D_PLANE, cur, ctx->best_params.as<double>(), threshold, 2, cur_orig,
+                               nullptr, nullptr, bx[dst].as<double>(), by[dst].as<double>(),
+                               bz[dst].as<double>(), bo[dst].as<uint32_t>(), c0->n_pad,
+                               ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream);
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                    rc = fail(M3D_ERR_DEVICE, "stream sync failed");
+                    break;
+                }
+                const uint32_t new_n = cur.n - (uint32_t)ni;
+                cur.x = bx[dst].as<double>();
+                cur.y = by[dst].as<double>();
+                cur.z = bz[dst].as<double>();
+                cur.nx = cur.ny = cur.nz = nullptr;
+                cur.n = new_n;
+                cur.n_pad = std::max<uint32_t>(round_up(new_n, kScoreTile), kScoreTile);
+                cur_orig = bo[dst].as<uint32_t>();
+                if (cur_is_v0) {
+                    cur_is_v0 = false;
+                    pp = 0;  // bo[0] (iota) is free again: next compaction goes to set 0
+                } else {
+                    pp = dst ^ 1;
+                }
+            }
+            *n_clusters = k;
+            (void)hipStreamSynchronize(ctx->stream);
+            cleanup();
+        }
+    }
+    m3d_cloud_destroy(c0);
+    if (rc == 2) return 2;
+    return rc == M3D_OK ? M3D_OK : rc;
+}
+
+}  // extern "C"

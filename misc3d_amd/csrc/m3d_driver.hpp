@@ -1,0 +1,71 @@
+// m3d_driver.hpp -- host side of the C ABI: device context, resident clouds, RANSAC driver.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/misc3d_amd.h"
+#include "m3d_kernels.hpp"
+
+namespace m3d {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+// grow-only device / pinned-host buffers
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t bytes);
+    void release();
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t bytes);
+    void release();
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+// One in-flight chunk of hypotheses (two slots: the next chunk is scored while the host replays
+// the previous one).
+struct ChunkSlot {
+    DevBuf samples, score, params, valid, counts;
+    PinBuf h_samples, h_counts, h_valid;
+    hipEvent_t done = nullptr;
+    size_t begin = 0, end = 0;
+    uint32_t h_pad = 0;
+};
+
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::mutex mu;  // one call at a time per device
+    ChunkSlot slot[2];
+    DevBuf partial, block_counts, total, idx, dist, sum_partial, sums, best_params, small;
+    PinBuf h_small;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+DeviceCtx* get_ctx(int device);  // nullptr + last error when the device is unusable
+
+}  // namespace m3d
+
+struct m3d_cloud {
+    m3d::DeviceCtx* ctx = nullptr;
+    m3d::DevBuf x, y, z, nx, ny, nz;
+    uint32_t n = 0, n_pad = 0;
+    bool has_normals = false;
+    m3d::CloudView view() const;
+};

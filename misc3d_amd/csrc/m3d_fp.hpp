@@ -1,0 +1,323 @@
+// m3d_fp.hpp -- floating-point operation order of the Misc3D hot path, written once for the host
+// driver and the gfx950 kernels.
+//
+// The reference (include/misc3d/common/ransac.h) is built with plain -O3 on x86-64 (no FMA,
+// CMakeLists.txt:16) and evaluates its small dot products through Eigen's packet reductions, so
+// every product and every sum below is individually rounded and the association is fixed:
+//   4-element sums (e0+e2)+(e1+e3), 3-element sums (e0+e1)+e2   
+// This file and everything that includes it MUST be compiled with -ffp-contract=off.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define M3D_HD __host__ __device__ __forceinline__
+#else
+#define M3D_HD inline
+#endif
+
+#pragma clang fp contract(off)
+
+namespace m3d {
+
+constexpr double kEps = 1.0e-8;  // ransac.h:14 EPS
+
+M3D_HD double dot3(double ax, double ay, double az, double bx, double by, double bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+M3D_HD double norm3(double x, double y, double z) { return sqrt(dot3(x, y, z, x, y, z)); }
+M3D_HD double dot4(double a0, double a1, double a2, double a3, double b0, double b1, double b2,
+                   double b3) {
+    return (a0 * b0 + a2 * b2) + (a1 * b1 + a3 * b3);
+}
+
+M3D_HD uint64_t f2u(double v) {
+    uint64_t u;
+    memcpy(&u, &v, 8);
+    return u;
+}
+M3D_HD double u2f(uint64_t u) {
+    double v;
+    memcpy(&v, &u, 8);
+    return v;
+}
+constexpr uint64_t kInfBits = 0x7FF0000000000000ull;
+
+// Non-negative doubles are ordered like their bit patterns.  `pred` must be monotone on
+// [lo, hi]: true on a (possibly empty) prefix, false afterwards.  Precondition: pred(lo) true,
+// pred(hi) false.  Returns the bits of the FIRST value for which pred is false.
+template <class F>
+M3D_HD uint64_t first_false(uint64_t lo, uint64_t hi, F pred) {
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (pred(u2f(mid)))
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return hi;
+}
+// `pred` false on a prefix, true afterwards.  Precondition: pred(lo) false, pred(hi) true.
+// Returns the bits of the FIRST value for which pred is true.
+template <class F>
+M3D_HD uint64_t first_true(uint64_t lo, uint64_t hi, F pred) {
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (pred(u2f(mid)))
+            hi = mid;
+        else
+            lo = mid;
+    }
+    return hi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Plane: ransac.h:134-221
+// ------------------------------------------------------------------------------------------------
+// MinimalFit, ransac.h:138-162.  p0,p1,p2 -> (a,b,c,d).  false = collinear sample.
+M3D_HD bool plane_minimal_fit(const double* p0, const double* p1, const double* p2, double* out) {
+    const double e0x = p1[0] - p0[0], e0y = p1[1] - p0[1], e0z = p1[2] - p0[2];
+    const double e1x = p2[0] - p0[0], e1y = p2[1] - p0[1], e1z = p2[2] - p0[2];
+    double ax = e0y * e1z - e0z * e1y;
+    double ay = e0z * e1x - e0x * e1z;
+    double az = e0x * e1y - e0y * e1x;
+    const double norm = norm3(ax, ay, az);
+    if (norm < kEps) return false;
+    const double n2 = norm3(ax, ay, az);  // ransac.h:154 recomputes abc.norm()
+    ax /= n2;
+    ay /= n2;
+    az /= n2;
+    out[0] = ax;
+    out[1] = ay;
+    out[2] = az;
+    out[3] = -dot3(ax, ay, az, p0[0], p0[1], p0[2]);
+    return true;
+}
+// numerator and denominator of CalcPointToModelDistance, ransac.h:215-220
+M3D_HD double plane_num(double a, double b, double c, double d, double x, double y, double z) {
+    return fabs((a * x + c * z) + (b * y + d));  // d * 1 == d exactly
+}
+M3D_HD double plane_distance(const double* m, double x, double y, double z) {
+    return plane_num(m[0], m[1], m[2], m[3], x, y, z) / norm3(m[0], m[1], m[2]);
+}
+// Exact cut-off: for a fixed model, RN(num / nrm) < thr  <=>  num < T.  RN(num/nrm) is monotone in
+// num, so T is the first double for which the reference's own test fails.
+M3D_HD double plane_cutoff(const double* m, double thr) {
+    const double nrm = norm3(m[0], m[1], m[2]);
+    auto inl = [=](double num) { return num / nrm < thr; };
+    if (!inl(0.0)) return 0.0;  // also NaN threshold / NaN model: nothing is an inlier
+    return u2f(first_false(0, kInfBits, inl));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sphere: ransac.h:223-344
+// ------------------------------------------------------------------------------------------------
+M3D_HD double det4_helper(const double (*m)[4], int j, int k, int a, int b) {
+    return (m[j][0] * m[k][1] - m[k][0] * m[j][1]) * (m[a][2] * m[b][3] - m[b][2] * m[a][3]);
+}
+// Eigen 3.3 determinant_impl<.,4> (Costabel's 30-multiply form)
+M3D_HD double det4(const double (*m)[4]) {
+    return det4_helper(m, 0, 1, 2, 3) - det4_helper(m, 0, 2, 1, 3) + det4_helper(m, 0, 3, 1, 2) +
+           det4_helper(m, 1, 2, 0, 3) - det4_helper(m, 1, 3, 0, 2) + det4_helper(m, 2, 3, 0, 1);
+}
+// ValidationCheck + MinimalFit, ransac.h:225-234,239-294.  p = 4 points (12 doubles).
+M3D_HD bool sphere_minimal_fit(const double* p, double* out) {
+    double plane[4];
+    if (!plane_minimal_fit(p, p + 3, p + 6, plane)) return false;
+    if (plane_distance(plane, p[9], p[10], p[11]) < kEps) return false;
+    double sq[4];
+    for (int i = 0; i < 4; ++i)
+        sq[i] = dot3(p[3 * i], p[3 * i + 1], p[3 * i + 2], p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+    double m[4][4];
+    for (int i = 0; i < 4; ++i) {
+        m[i][0] = p[3 * i];
+        m[i][1] = p[3 * i + 1];
+        m[i][2] = p[3 * i + 2];
+        m[i][3] = 1.0;
+    }
+    const double M11 = det4(m);
+    for (int i = 0; i < 4; ++i) {
+        m[i][0] = sq[i];
+        m[i][1] = p[3 * i + 1];
+        m[i][2] = p[3 * i + 2];
+    }
+    const double M12 = det4(m);
+    for (int i = 0; i < 4; ++i) {
+        m[i][0] = sq[i];
+        m[i][1] = p[3 * i];
+        m[i][2] = p[3 * i + 2];
+    }
+    const double M13 = det4(m);
+    for (int i = 0; i < 4; ++i) {
+        m[i][0] = sq[i];
+        m[i][1] = p[3 * i];
+        m[i][2] = p[3 * i + 1];
+    }
+    const double M14 = det4(m);
+    for (int i = 0; i < 4; ++i) {
+        m[i][0] = sq[i];
+        m[i][1] = p[3 * i];
+        m[i][2] = p[3 * i + 1];
+        m[i][3] = p[3 * i + 2];
+    }
+    const double M15 = det4(m);
+    const double cx = 0.5 * (M12 / M11), cy = -0.5 * (M13 / M11), cz = 0.5 * (M14 / M11);
+    out[0] = cx;
+    out[1] = cy;
+    out[2] = cz;
+    out[3] = sqrt(dot3(cx, cy, cz, cx, cy, cz) - (M15 / M11));
+    return true;
+}
+// squared distance to the centre in the reference's order (the argument of .norm(), ransac.h:336)
+M3D_HD double sphere_s(double cx, double cy, double cz, double x, double y, double z) {
+    const double dx = x - cx, dy = y - cy, dz = z - cz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+M3D_HD double sphere_dist_from_d(double d, double r) { return d <= r ? r - d : d - r; }
+M3D_HD double sphere_distance(const double* m, double x, double y, double z) {
+    return sphere_dist_from_d(sqrt(sphere_s(m[0], m[1], m[2], x, y, z)), m[3]);
+}
+
+// For |d - r| style distances: the set {d >= 0 : dist(d) < thr} is an interval [dA, dB] around r
+// (dist is monotone on both sides of r).  Returns false when it is empty.
+template <class F>
+M3D_HD bool radial_interval(double r, F inl_d, double* dA, double* dB) {
+    if (!(r == r) || fabs(r) == INFINITY) return false;
+    const double d0 = r > 0.0 ? r : 0.0;
+    if (!inl_d(d0)) return false;
+    const uint64_t b0 = f2u(d0);
+    if (b0 == 0 || inl_d(0.0))
+        *dA = 0.0;
+    else
+        *dA = u2f(first_true(0, b0, inl_d));
+    *dB = u2f(first_false(b0, kInfBits, inl_d) - 1);  // inl_d(inf) is always false
+    return true;
+}
+// Monotone map g(t) (t >= 0): interval {t : dA <= g(t) <= dB} as [lo, hi]; false when empty.
+template <class G>
+M3D_HD bool preimage_interval(double dA, double dB, G g, double* lo, double* hi) {
+    auto ge = [=](double t) { return g(t) >= dA; };  // false..false true..true
+    auto le = [=](double t) { return g(t) <= dB; };  // true..true false..false
+    uint64_t blo;
+    if (ge(0.0))
+        blo = 0;
+    else if (!ge(u2f(kInfBits - 1)))
+        return false;
+    else
+        blo = first_true(0, kInfBits - 1, ge);
+    if (!le(u2f(blo))) return false;
+    uint64_t bhi;
+    if (le(u2f(kInfBits - 1)))
+        bhi = kInfBits - 1;
+    else
+        bhi = first_false(blo, kInfBits - 1, le) - 1;
+    *lo = u2f(blo);
+    *hi = u2f(bhi);
+    return true;
+}
+// Exact cut-offs: dist(q) < thr  <=>  s_lo <= s(q) <= s_hi.  Empty -> (NaN, NaN).
+M3D_HD void sphere_cutoffs(const double* m, double thr, double* s_lo, double* s_hi) {
+    const double r = m[3];
+    double dA, dB;
+    const double nan = u2f(0x7FF8000000000000ull);
+    *s_lo = nan;
+    *s_hi = nan;
+    if (!radial_interval(r, [=](double d) { return sphere_dist_from_d(d, r) < thr; }, &dA, &dB))
+        return;
+    double lo, hi;
+    if (!preimage_interval(dA, dB, [](double s) { return sqrt(s); }, &lo, &hi)) return;
+    *s_lo = lo;
+    *s_hi = hi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cylinder: ransac.h:350-446, utils.h:313-322
+// ------------------------------------------------------------------------------------------------
+// CalcPoint2LineDistance pieces: t = |a x b|^2 with a = q - p1, b = q - p2
+M3D_HD double line_t(double p1x, double p1y, double p1z, double p2x, double p2y, double p2z,
+                     double x, double y, double z) {
+    const double ax = x - p1x, ay = y - p1y, az = z - p1z;
+    const double bx = x - p2x, by = y - p2y, bz = z - p2z;
+    const double cx = ay * bz - az * by;
+    const double cy = az * bx - ax * bz;
+    const double cz = ax * by - ay * bx;
+    return (cx * cx + cy * cy) + cz * cz;
+}
+M3D_HD double point2line(const double* q, const double* p1, const double* p2) {
+    const double t = line_t(p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], q[0], q[1], q[2]);
+    const double L = norm3(p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]);
+    return sqrt(t) / L;
+}
+// MinimalFit, ransac.h:354-417.  p = 2 points, n = 2 normals -> 7 params.
+M3D_HD bool cylinder_minimal_fit(const double* p, const double* n, double* out) {
+    // ransac.h:367-374 (comparisons sit INSIDE fabs() in the reference)
+    if ((p[0] - p[3] <= 2.220446049250313e-16) && (fabs(p[1] - p[4]) <= 1.1920928955078125e-07) &&
+        (fabs(p[2] - p[5]) <= 1.1920928955078125e-07))
+        return false;
+    const double p1[4] = {p[0], p[1], p[2], 0.0}, p2[4] = {p[3], p[4], p[5], 0.0};
+    const double n1[4] = {n[0], n[1], n[2], 0.0}, n2[4] = {n[3], n[4], n[5], 0.0};
+    double w[4];
+    for (int k = 0; k < 4; ++k) w[k] = (n1[k] + p1[k]) - p2[k];
+    const double a = dot4(n1[0], n1[1], n1[2], n1[3], n1[0], n1[1], n1[2], n1[3]);
+    const double b = dot4(n1[0], n1[1], n1[2], n1[3], n2[0], n2[1], n2[2], n2[3]);
+    const double c = dot4(n2[0], n2[1], n2[2], n2[3], n2[0], n2[1], n2[2], n2[3]);
+    const double d = dot4(n1[0], n1[1], n1[2], n1[3], w[0], w[1], w[2], w[3]);
+    const double e = dot4(n2[0], n2[1], n2[2], n2[3], w[0], w[1], w[2], w[3]);
+    const double den = a * c - b * b;
+    double sc, tc;
+    if (den < 1e-8) {
+        sc = 0.0;
+        tc = (b > c ? d / b : e / c);
+    } else {
+        sc = (b * e - c * d) / den;
+        tc = (a * e - b * d) / den;
+    }
+    double lp[4], ld[4];
+    for (int k = 0; k < 4; ++k) lp[k] = (p1[k] + n1[k]) + sc * n1[k];
+    for (int k = 0; k < 4; ++k) ld[k] = (p2[k] + tc * n2[k]) - lp[k];
+    const double z = dot4(ld[0], ld[1], ld[2], ld[3], ld[0], ld[1], ld[2], ld[3]);
+    if (z > 0.0) {  // Eigen >= 3.3 normalize()
+        const double s = sqrt(z);
+        for (int k = 0; k < 4; ++k) ld[k] /= s;
+    }
+    out[0] = lp[0];
+    out[1] = lp[1];
+    out[2] = lp[2];
+    out[3] = ld[0];
+    out[4] = ld[1];
+    out[5] = ld[2];
+    out[6] = point2line(p, lp, ld);  // ransac.h:413-414: direction passed as 2nd point
+    return true;
+}
+// CalcPointToModelDistance, ransac.h:435-445: ref = centre + direction (rounded), L = |ref - centre|
+M3D_HD void cylinder_ref(const double* w, double* ref, double* L) {
+    ref[0] = w[0] + w[3];
+    ref[1] = w[1] + w[4];
+    ref[2] = w[2] + w[5];
+    *L = norm3(ref[0] - w[0], ref[1] - w[1], ref[2] - w[2]);
+}
+M3D_HD double cylinder_distance(const double* w, double x, double y, double z) {
+    double ref[3], L;
+    cylinder_ref(w, ref, &L);
+    const double t = line_t(w[0], w[1], w[2], ref[0], ref[1], ref[2], x, y, z);
+    return fabs(sqrt(t) / L - w[6]);
+}
+// dist(q) < thr  <=>  t_lo <= t(q) <= t_hi.  Empty -> (NaN, NaN).
+M3D_HD void cylinder_cutoffs(const double* w, double thr, double* t_lo, double* t_hi) {
+    double ref[3], L;
+    cylinder_ref(w, ref, &L);
+    const double r = w[6];
+    const double nan = u2f(0x7FF8000000000000ull);
+    *t_lo = nan;
+    *t_hi = nan;
+    double dA, dB;
+    if (!radial_interval(r, [=](double d) { return fabs(d - r) < thr; }, &dA, &dB)) return;
+    double lo, hi;
+    if (!preimage_interval(dA, dB, [=](double t) { return sqrt(t) / L; }, &lo, &hi)) return;
+    *t_lo = lo;
+    *t_hi = hi;
+}
+
+}  // namespace m3d

@@ -1,0 +1,559 @@
+// m3d_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels of the Misc3D RANSAC hot path.
+//
+// Replaces these reference loops (paths relative to the Misc3D repository):
+//   minimal_fit_k   include/misc3d/common/ransac.h:576-582 (SelectByIndex + MinimalFit per hypothesis)
+//   score_*_k       ransac.h:626-641 (EvaluateModel's scan over N points) x ransac.h:572 (H hypotheses)
+//   compact_*_k     ransac.h:537-543 (RefineModel's inlier list), src/iterative_plane_segmentation.cpp:32-33
+//   sum_*_k         ransac.h:164-188 (GeneralFit sums)
+//
+// Design notes (DESIGN.md has the long form):
+//   * Scoring is a count-only kernel.  Each lane keeps kScoreP points in VGPRs for the whole launch,
+//     hypothesis records are wave-uniform and come in through scalar loads, the `d < thr` test is
+//     replaced by an EXACT per-hypothesis cut-off on the pre-sqrt / pre-divide quantity
+//     (m3d_fp.hpp), so the inner loop is 6 (plane) / 8 (sphere) / 20 (cylinder) fp64 VALU ops plus
+//     the compare, with v_cmp -> s_bcnt1 -> s_add counting on the scalar unit.
+//   * No FMA contraction anywhere: products and sums round separately like the reference's x86-64
+//     SSE2 build.  The file is compiled with -ffp-contract=off and carries the pragma as well.
+//   * Integer results only (counts, indices) leave the scoring path; fp64 sums that the reference
+//     forms serially are either reproduced serially (serial_sum_k) or are tolerance-checked
+//     parameters (GeneralFit), never inlier decisions.
+#include "m3d_kernels.hpp"
+
+#include "m3d_fp.hpp"
+
+#pragma clang fp contract(off)
+
+namespace m3d {
+
+// ------------------------------------------------------------------------------------------------
+// K0  AoS -> SoA
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aos_to_soa_k(const double* __restrict__ aos,
+                                                     double* __restrict__ x, double* __restrict__ y,
+                                                     double* __restrict__ z, uint32_t n,
+                                                     uint32_t n_pad) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_pad) return;
+    const double nan = u2f(0x7FF8000000000000ull);
+    double px = nan, py = nan, pz = nan;
+    if (i < n) {
+        px = aos[3 * (size_t)i];
+        py = aos[3 * (size_t)i + 1];
+        pz = aos[3 * (size_t)i + 2];
+    }
+    x[i] = px;
+    y[i] = py;
+    z[i] = pz;
+}
+
+void launch_aos_to_soa(const double* aos, double* x, double* y, double* z, uint32_t n,
+                       uint32_t n_pad, hipStream_t s) {
+    if (n_pad == 0) return;
+    aos_to_soa_k<<<(n_pad + 255) / 256, 256, 0, s>>>(aos, x, y, z, n, n_pad);
+}
+
+__global__ void iota_k(uint32_t* v, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+void launch_iota(uint32_t* v, uint32_t n, hipStream_t s) {
+    if (n) iota_k<<<(n + 255) / 256, 256, 0, s>>>(v, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  minimal fit + exact cut-offs, one thread per hypothesis
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t* __restrict__ samples,
+                                                     uint32_t h_count, uint32_t h_pad, double thr,
+                                                     double* __restrict__ score,
+                                                     double* __restrict__ params,
+                                                     uint8_t* __restrict__ valid) {
+    const uint32_t h = blockIdx.x * 64u + threadIdx.x;
+    if (h >= h_pad) return;
+    const double nan = u2f(0x7FF8000000000000ull);
+    double rec[kModelStride];
+    double par[kModelStride];
+    for (int k = 0; k < kModelStride; ++k) {
+        rec[k] = 0.0;
+        par[k] = 0.0;
+    }
+    bool ok = false;
+    if (h < h_count) {
+        if (KIND == 0) {
+            double p[9];
+            for (int s = 0; s < 3; ++s) {
+                const uint32_t i = samples[3 * (size_t)h + s];
+                p[3 * s] = c.x[i];
+                p[3 * s + 1] = c.y[i];
+                p[3 * s + 2] = c.z[i];
+            }
+            ok = plane_minimal_fit(p, p + 3, p + 6, par);
+            if (ok) {
+                rec[0] = par[0];
+                rec[1] = par[1];
+                rec[2] = par[2];
+                rec[3] = par[3];
+                rec[4] = plane_cutoff(par, thr);
+            }
+        } else if (KIND == 1) {
+            double p[12];
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t i = samples[4 * (size_t)h + s];
+                p[3 * s] = c.x[i];
+                p[3 * s + 1] = c.y[i];
+                p[3 * s + 2] = c.z[i];
+            }
+            ok = sphere_minimal_fit(p, par);
+            if (ok) {
+                rec[0] = par[0];
+                rec[1] = par[1];
+                rec[2] = par[2];
+                sphere_cutoffs(par, thr, &rec[3], &rec[4]);
+            }
+        } else {
+            double p[6], nn[6];
+            for (int s = 0; s < 2; ++s) {
+                const uint32_t i = samples[2 * (size_t)h + s];
+                p[3 * s] = c.x[i];
+                p[3 * s + 1] = c.y[i];
+                p[3 * s + 2] = c.z[i];
+                nn[3 * s] = c.nx[i];
+                nn[3 * s + 1] = c.ny[i];
+                nn[3 * s + 2] = c.nz[i];
+            }
+            ok = cylinder_minimal_fit(p, nn, par);
+            if (ok) {
+                double ref[3], L;
+                cylinder_ref(par, ref, &L);
+                rec[0] = par[0];
+                rec[1] = par[1];
+                rec[2] = par[2];
+                rec[3] = ref[0];
+                rec[4] = ref[1];
+                rec[5] = ref[2];
+                cylinder_cutoffs(par, thr, &rec[6], &rec[7]);
+            }
+        }
+    }
+    if (!ok) {  // "no inlier" record: every comparison of the scoring kernels fails
+        for (int k = 0; k < kModelStride; ++k) rec[k] = 0.0;
+        if (KIND == 0) rec[4] = 0.0;  // num < 0 never holds
+        if (KIND == 1) rec[3] = rec[4] = nan;
+        if (KIND == 2) rec[6] = rec[7] = nan;
+        for (int k = 0; k < kModelStride; ++k) par[k] = 0.0;
+    }
+    for (int k = 0; k < kModelStride; ++k) {
+        score[(size_t)h * kModelStride + k] = rec[k];
+        params[(size_t)h * kModelStride + k] = par[k];
+    }
+    valid[h] = ok ? 1 : 0;
+}
+
+void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
+                        uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
+                        hipStream_t s) {
+    if (h_pad == 0) return;
+    const dim3 g((h_pad + 63) / 64), b(64);
+    if (kind == 0)
+        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid);
+    else if (kind == 1)
+        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid);
+    else
+        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  inlier counting: (points of one tile, held in VGPRs) x (hypotheses streamed through SGPRs)
+// ------------------------------------------------------------------------------------------------
+// Workgroup = 256 threads = 4 waves; wave w owns rows of 64 consecutive points, kScoreP rows, so
+// every global load is a fully coalesced 512-B row.  For each hypothesis the wave-uniform record
+// is fetched with scalar loads, each of the P rows costs 6/8/20 fp64 VALU ops + compare(s), the
+// 64-bit compare mask is popcounted on the scalar unit.  The count of hypothesis (hb + j) is
+// parked in lane j of `acc` (one v_cndmask), and every 64 hypotheses the four waves combine through
+// LDS and store one coalesced 256-B row of partial counts.
+template <int KIND>
+__global__ __launch_bounds__(kScoreBlock) void score_k(const double* __restrict__ xs,
+                                                        const double* __restrict__ ys,
+                                                        const double* __restrict__ zs,
+                                                        const double* __restrict__ score,
+                                                        uint32_t h_pad, uint32_t h_per_split,
+                                                        uint32_t* __restrict__ partial) {
+    __shared__ uint32_t red[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const size_t base = (size_t)blockIdx.x * kScoreTile + (size_t)wave * (64 * kScoreP) + lane;
+    double x[kScoreP], y[kScoreP], z[kScoreP];
+#pragma unroll
+    for (int j = 0; j < kScoreP; ++j) {
+        x[j] = xs[base + 64 * j];
+        y[j] = ys[base + 64 * j];
+        z[j] = zs[base + 64 * j];
+    }
+    const uint32_t h0 = blockIdx.y * h_per_split;
+    // Software prefetch of the next hypothesis record: the scalar loads for hypothesis h+1 are
+    // issued before the VALU work of hypothesis h (the score buffer carries one spare record).
+    double rec[kModelStride];
+    {
+        const double* __restrict__ m = score + (size_t)h0 * kModelStride;
+#pragma unroll
+        for (int k = 0; k < kModelStride; ++k) rec[k] = m[k];
+    }
+    for (uint32_t hb = h0; hb < h0 + h_per_split; hb += 64) {
+        uint32_t acc = 0;
+        for (uint32_t hh = 0; hh < 64; ++hh) {
+            const double* __restrict__ mn = score + (size_t)(hb + hh + 1) * kModelStride;
+            double nxt[kModelStride];
+            constexpr int kUsed = KIND == 2 ? 8 : 5;
+#pragma unroll
+            for (int k = 0; k < kUsed; ++k) nxt[k] = mn[k];
+            uint32_t cnt = 0;
+            if (KIND == 0) {
+                const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4];
+#pragma unroll
+                for (int j = 0; j < kScoreP; ++j) {
+                    const double num = plane_num(a, b, c, d, x[j], y[j], z[j]);
+                    cnt += (uint32_t)__popcll(__ballot(num < T));
+                }
+            } else if (KIND == 1) {
+                const double cx = rec[0], cy = rec[1], cz = rec[2], lo = rec[3], hi = rec[4];
+#pragma unroll
+                for (int j = 0; j < kScoreP; ++j) {
+                    const double sv = sphere_s(cx, cy, cz, x[j], y[j], z[j]);
+                    cnt += (uint32_t)__popcll(__ballot(sv >= lo && sv <= hi));
+                }
+            } else {
+                const double cx = rec[0], cy = rec[1], cz = rec[2], rx = rec[3], ry = rec[4],
+                             rz = rec[5];
+                const double lo = rec[6], hi = rec[7];
+#pragma unroll
+                for (int j = 0; j < kScoreP; ++j) {
+                    const double tv = line_t(cx, cy, cz, rx, ry, rz, x[j], y[j], z[j]);
+                    cnt += (uint32_t)__popcll(__ballot(tv >= lo && tv <= hi));
+                }
+            }
+            acc = ((uint32_t)lane == hh) ? cnt : acc;  // lane hh keeps the count of hypothesis hb + hh
+#pragma unroll
+            for (int k = 0; k < kUsed; ++k) rec[k] = nxt[k];
+        }
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0)
+            partial[(size_t)blockIdx.x * h_pad + hb + lane] =
+                (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        __syncthreads();
+    }
+}
+
+void launch_score(int kind, const CloudView& c, const double* score, uint32_t h_pad,
+                  uint32_t h_splits, uint32_t* partial, hipStream_t s) {
+    if (h_pad == 0 || c.n_pad == 0) return;
+    const dim3 g(c.n_pad / kScoreTile, h_splits), b(kScoreBlock);
+    const uint32_t hps = h_pad / h_splits;
+    if (kind == 0)
+        score_k<0><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, partial);
+    else if (kind == 1)
+        score_k<1><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, partial);
+    else
+        score_k<2><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, partial);
+}
+
+// counts[h] += sum over a group of tiles.  Integer atomics: order-independent, exact.
+constexpr int kReduceTilesPerBlock = 64;
+__global__ __launch_bounds__(256) void reduce_partials_k(const uint32_t* __restrict__ partial,
+                                                          uint32_t n_tiles, uint32_t h_pad,
+                                                          uint32_t* __restrict__ counts) {
+    __shared__ uint32_t red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t h = blockIdx.x * 64u + lane;
+    const uint32_t t0 = blockIdx.y * kReduceTilesPerBlock;
+    const uint32_t t1 = min(n_tiles, t0 + kReduceTilesPerBlock);
+    uint32_t acc = 0;
+    for (uint32_t t = t0 + wave; t < t1; t += 4) acc += partial[(size_t)t * h_pad + h];
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (v) atomicAdd(&counts[h], v);
+    }
+}
+
+void launch_reduce_partials(const uint32_t* partial, uint32_t n_tiles, uint32_t h_pad,
+                            uint32_t* counts, hipStream_t s) {
+    if (h_pad == 0 || n_tiles == 0) return;
+    const dim3 g(h_pad / 64, (n_tiles + kReduceTilesPerBlock - 1) / kReduceTilesPerBlock), b(256);
+    reduce_partials_k<<<g, b, 0, s>>>(partial, n_tiles, h_pad, counts);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  ordered compaction with the reference distance (RefineModel, tie-break error, segmentation)
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ double ref_distance(const double* m, double x, double y, double z) {
+    if (KIND == 0) return plane_distance(m, x, y, z);
+    if (KIND == 1) return sphere_distance(m, x, y, z);
+    return cylinder_distance(m, x, y, z);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void compact_count_k(CloudView c, const double* __restrict__ model,
+                                                        double thr, int invert,
+                                                        uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wsum[4];
+    double m[7];
+    for (int k = 0; k < 7; ++k) m[k] = model[k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t cnt = 0;
+    const uint32_t base = blockIdx.x * kCompactTile;
+    for (int r = 0; r < kCompactTile / 256; ++r) {
+        const uint32_t i = base + r * 256 + threadIdx.x;
+        bool f = false;
+        if (i < c.n) {
+            const double d = ref_distance<KIND>(m, c.x[i], c.y[i], c.z[i]);
+            f = (d < thr) != (invert != 0);
+        }
+        cnt += (uint32_t)__popcll(__ballot(f));
+    }
+    if (lane == 0) wsum[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// exclusive scan of block_counts[0..nb) in place; total[0] = sum
+__global__ __launch_bounds__(1024) void scan_blocks_k(uint32_t* __restrict__ v, uint32_t nb,
+                                                       uint32_t* __restrict__ total) {
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t mine = i < nb ? v[i] : 0;
+        buf[threadIdx.x] = mine;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t t = threadIdx.x >= (uint32_t)off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = buf[threadIdx.x];
+        const uint32_t c0 = carry;
+        if (i < nb) v[i] = c0 + incl - mine;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c0 + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256) void compact_write_k(
+    CloudView c, const double* __restrict__ model, double thr, const uint32_t* __restrict__ orig,
+    const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ out_idx,
+    double* __restrict__ out_dist, double* __restrict__ ox, double* __restrict__ oy,
+    double* __restrict__ oz, uint32_t* __restrict__ oorig) {
+    __shared__ uint32_t wsum[4];
+    double m[7];
+    for (int k = 0; k < 7; ++k) m[k] = model[k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t row_base = block_offsets[blockIdx.x];
+    const uint32_t base = blockIdx.x * kCompactTile;
+    for (int r = 0; r < kCompactTile / 256; ++r) {
+        const uint32_t i = base + r * 256 + threadIdx.x;
+        bool f = false;
+        double px = 0, py = 0, pz = 0, d = 0;
+        if (i < c.n) {
+            px = c.x[i];
+            py = c.y[i];
+            pz = c.z[i];
+            d = ref_distance<KIND>(m, px, py, pz);
+            f = (d < thr) != (MODE == 2);
+        }
+        const unsigned long long b = __ballot(f);
+        const uint32_t lane_pre = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t rowtot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (f) {
+            const uint32_t pos = row_base + woff + lane_pre;
+            if (MODE == 0) out_idx[pos] = orig ? (uint64_t)orig[i] : (uint64_t)i;
+            if (MODE == 1) out_dist[pos] = d;
+            if (MODE == 2) {
+                ox[pos] = px;
+                oy[pos] = py;
+                oz[pos] = pz;
+                oorig[pos] = orig[i];
+            }
+        }
+        row_base += rowtot;
+        __syncthreads();
+    }
+}
+
+// NaN padding of a freshly compacted SoA cloud: [n, n_pad)
+__global__ void pad_nan_k(double* x, double* y, double* z, const uint32_t* n_ptr, uint32_t n_pad_cap) {
+    const uint32_t n = n_ptr[0];
+    const uint32_t n_pad = min(n_pad_cap, (n + kScoreTile - 1) / kScoreTile * kScoreTile);
+    const double nan = u2f(0x7FF8000000000000ull);
+    for (uint32_t i = n + blockIdx.x * 256u + threadIdx.x; i < n_pad; i += gridDim.x * 256u) {
+        x[i] = nan;
+        y[i] = nan;
+        z[i] = nan;
+    }
+}
+
+template <int KIND>
+static void launch_compact_kind(const CloudView& c, const double* model, double thr, int mode,
+                                const uint32_t* orig, uint64_t* out_idx, double* out_dist,
+                                double* ox, double* oy, double* oz, uint32_t* oorig,
+                                uint32_t n_pad_out, uint32_t* block_counts, uint32_t* total,
+                                hipStream_t s) {
+    const uint32_t nb = (c.n + kCompactTile - 1) / kCompactTile;
+    if (nb == 0) {
+        (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+        return;
+    }
+    compact_count_k<KIND><<<nb, 256, 0, s>>>(c, model, thr, mode == 2 ? 1 : 0, block_counts);
+    scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total);
+    if (mode == 0)
+        compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
+                                                     nullptr, nullptr, nullptr, nullptr, nullptr);
+    else if (mode == 1)
+        compact_write_k<KIND, 1><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
+                                                     out_dist, nullptr, nullptr, nullptr, nullptr);
+    else {
+        compact_write_k<KIND, 2><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
+                                                     nullptr, ox, oy, oz, oorig);
+        pad_nan_k<<<(kScoreTile + 255) / 256, 256, 0, s>>>(ox, oy, oz, total, n_pad_out);
+    }
+}
+
+void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
+                    const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
+                    double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
+                    uint32_t* block_counts, uint32_t* total, hipStream_t s) {
+    if (kind == 0)
+        launch_compact_kind<0>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
+                               n_pad_out, block_counts, total, s);
+    else if (kind == 1)
+        launch_compact_kind<1>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
+                               n_pad_out, block_counts, total, s);
+    else
+        launch_compact_kind<2>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
+                               n_pad_out, block_counts, total, s);
+}
+
+// EvaluateModel's `error += distance` in point order (ransac.h:637): a genuinely serial fp64 chain.
+// One lane adds; the other 63 lanes of the wave stage the next 64 values through LDS so the chain
+// only ever waits for an LDS read.
+__global__ __launch_bounds__(64) void serial_sum_k(const double* __restrict__ v,
+                                                    const uint32_t* __restrict__ n_ptr,
+                                                    double* __restrict__ out) {
+    __shared__ double stage[2][64];
+    const uint32_t n = n_ptr[0];
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    uint32_t cur = 0;
+    if (lane < (int)n) stage[0][lane] = v[lane];
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+        const uint32_t nxt = b0 + 64 + lane;
+        if (nxt < n) stage[cur ^ 1][lane] = v[nxt];
+        if (lane == 0) {
+            const uint32_t lim = min(64u, n - b0);
+            for (uint32_t k = 0; k < lim; ++k) s += stage[cur][k];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (lane == 0) out[0] = s;
+}
+
+void launch_serial_sum(const double* v, const uint32_t* n, double* out, hipStream_t s) {
+    serial_sum_k<<<1, 64, 0, s>>>(v, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5/K6  GeneralFit sums: fixed-shape two-level tree (deterministic for a given inlier count)
+// ------------------------------------------------------------------------------------------------
+constexpr int kSumBlocks = 256;
+
+template <int NV>
+__device__ __forceinline__ void block_tree_reduce(double (&acc)[NV], double* sm /* NV x 256 */) {
+    for (int k = 0; k < NV; ++k) sm[k * 256 + threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < NV; ++k) sm[k * 256 + threadIdx.x] += sm[k * 256 + threadIdx.x + off];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_xyz_k(CloudView c, const uint64_t* __restrict__ idx,
+                                                  uint32_t n, double* __restrict__ partial) {
+    __shared__ double sm[3 * 256];
+    double acc[3] = {0, 0, 0};
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += kSumBlocks * 256u) {
+        const uint64_t i = idx[k];
+        acc[0] += c.x[i];
+        acc[1] += c.y[i];
+        acc[2] += c.z[i];
+    }
+    block_tree_reduce<3>(acc, sm);
+    if (threadIdx.x < 3) partial[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void sum_final_k(const double* __restrict__ partial,
+                                                    double* __restrict__ sums) {
+    __shared__ double sm[NV * 256];
+    double acc[NV];
+    for (int k = 0; k < NV; ++k) acc[k] = partial[threadIdx.x * 16 + k];  // kSumBlocks == 256
+    block_tree_reduce<NV>(acc, sm);
+    if (threadIdx.x < NV) sums[threadIdx.x] = sm[threadIdx.x * 256];
+}
+
+__global__ __launch_bounds__(256) void sum_moments_k(CloudView c, const uint64_t* __restrict__ idx,
+                                                      uint32_t n,
+                                                      const double* __restrict__ sums_xyz,
+                                                      double* __restrict__ partial) {
+    __shared__ double sm[10 * 256];
+    // mean /= double(num), ransac.h:176
+    const double mx = sums_xyz[0] / (double)n, my = sums_xyz[1] / (double)n,
+                 mz = sums_xyz[2] / (double)n;
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += kSumBlocks * 256u) {
+        const uint64_t i = idx[k];
+        const double r0 = c.x[i] - mx, r1 = c.y[i] - my, r2 = c.z[i] - mz;
+        const double q = (r0 * r0 + r1 * r1) + r2 * r2;
+        acc[0] += r0 * r0;
+        acc[1] += r0 * r1;
+        acc[2] += r0 * r2;
+        acc[3] += r1 * r1;
+        acc[4] += r1 * r2;
+        acc[5] += r2 * r2;
+        acc[6] += r0 * q;
+        acc[7] += r1 * q;
+        acc[8] += r2 * q;
+        acc[9] += q;
+    }
+    block_tree_reduce<10>(acc, sm);
+    if (threadIdx.x < 10) partial[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
+}
+
+void launch_sum_xyz(const CloudView& c, const uint64_t* idx, uint32_t n_idx, double* partial,
+                    double* sums, hipStream_t s) {
+    sum_xyz_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, partial);
+    sum_final_k<3><<<1, 256, 0, s>>>(partial, sums);
+}
+
+void launch_sum_moments(const CloudView& c, const uint64_t* idx, uint32_t n_idx,
+                        const double* sums_xyz, double* partial, double* sums, hipStream_t s) {
+    sum_moments_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, sums_xyz, partial);
+    sum_final_k<10><<<1, 256, 0, s>>>(partial, sums);
+}
+
+}  // namespace m3d

@@ -1,0 +1,78 @@
+// m3d_kernels.hpp -- launch interface of the gfx950 kernels (m3d_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace m3d {
+
+constexpr int kModelStride = 8;     // doubles per hypothesis record (64 B: one s_load_dwordx16)
+constexpr int kScoreP = 8;          // points per lane held in VGPRs by the scoring kernels
+constexpr int kScoreBlock = 256;    // threads per scoring workgroup (4 waves)
+constexpr int kScoreTile = kScoreBlock * kScoreP;  // points per scoring workgroup
+constexpr int kCompactTile = 2048;  // points per compaction workgroup
+
+// SoA view of a resident cloud.  Arrays are padded to a multiple of kScoreTile with NaN so the
+// scoring kernels need no bounds checks (a NaN coordinate is never an inlier).
+struct CloudView {
+    const double* x;
+    const double* y;
+    const double* z;
+    const double* nx;  // may be null
+    const double* ny;
+    const double* nz;
+    uint32_t n;
+    uint32_t n_pad;
+};
+
+// K0: AoS (n x 3) -> SoA, NaN padding up to n_pad.
+void launch_aos_to_soa(const double* aos, double* x, double* y, double* z, uint32_t n,
+                       uint32_t n_pad, hipStream_t s);
+
+// K1: minimal fit of `h_count` hypotheses from their sample indices.  Writes per hypothesis
+//   score[h*8 ..]  = scoring record (plane: a,b,c,d,T | sphere: cx,cy,cz,s_lo,s_hi |
+//                    cylinder: cx,cy,cz,refx,refy,refz,t_lo,t_hi)
+//   params[h*8 ..] = reference model parameters (4 or 7 doubles)
+//   valid[h]       = MinimalFit's return value
+// Records in [h_count, h_pad) are filled with "no inlier" cut-offs.
+void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
+                        uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
+                        hipStream_t s);
+
+// K2: inlier counting.  partial[tile * h_pad + h] = number of points of scoring tile `tile` whose
+// distance to hypothesis h is < thr.  h_pad must be a multiple of 64 * h_splits.
+void launch_score(int kind, const CloudView& c, const double* score, uint32_t h_pad,
+                  uint32_t h_splits, uint32_t* partial, hipStream_t s);
+// counts[h] = sum over tiles of partial[tile][h].  counts must be zero on entry.
+void launch_reduce_partials(const uint32_t* partial, uint32_t n_tiles, uint32_t h_pad,
+                            uint32_t* counts, hipStream_t s);
+
+// K4: ordered compaction with the reference's own distance formula (sqrt and divide per point).
+// mode 0: out_idx[k]  = index (or orig[index] when orig != null) of the k-th inlier, ascending
+// mode 1: out_dist[k] = distance of the k-th inlier
+// mode 2: stable partition of the NON-inliers into (ox,oy,oz,oorig) (segmentation round)
+// block_counts: scratch of ceil(n / kCompactTile) + 1 uint32; total[0] receives the inlier count.
+void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
+                    const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
+                    double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
+                    uint32_t* block_counts, uint32_t* total, hipStream_t s);
+
+// serial-order sum of `n[0]` doubles (EvaluateModel's `error += distance`, ransac.h:637)
+void launch_serial_sum(const double* v, const uint32_t* n, double* out, hipStream_t s);
+
+// K5/K6: deterministic tree reductions over the inlier list for GeneralFit.
+// sums[0..2] = sum of x,y,z over idx (pass 1).  With mean[3] given (pass 2):
+//   plane : sums[0..5]  = xx,xy,xz,yy,yz,zz of residuals               (ransac.h:178-188)
+//   sphere: sums[0..9]  = xx,xy,xz,yy,yz,zz, x*q, y*q, z*q, q  with q = |residual|^2
+// partial: scratch of kSumPartialDoubles doubles.
+constexpr int kSumPartialDoubles = 256 * 16;
+void launch_sum_xyz(const CloudView& c, const uint64_t* idx, uint32_t n_idx, double* partial,
+                    double* sums, hipStream_t s);
+void launch_sum_moments(const CloudView& c, const uint64_t* idx, uint32_t n_idx,
+                        const double* sums_xyz, double* partial, double* sums, hipStream_t s);
+
+// iota for the original-index array of a segmentation run
+void launch_iota(uint32_t* v, uint32_t n, hipStream_t s);
+
+}  // namespace m3d

@@ -1,0 +1,328 @@
+"""CPU oracle for the Misc3D RANSAC hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  The product (``misc3d_amd``) never does.  PARITY UNPINNED: see the header of
+``misc3d_oracle.c`` and DESIGN.md.
+
+The arithmetic lives in plain C (``misc3d_oracle.c``, ``misc3d_oracle_reg.c``); this module is a
+ctypes shim that builds the shared object on demand with ``make -C oracle``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmisc3d_oracle.so")
+RNG_CHECK_PATH = os.path.join(_HERE, "_build", "std_rng_check")
+
+PLANE, SPHERE, CYLINDER = 0, 1, 2
+_M = {PLANE: 3, SPHERE: 4, CYLINDER: 2}
+_NP = {PLANE: 4, SPHERE: 4, CYLINDER: 7}
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("misc3d_oracle.c", "misc3d_oracle_reg.c", "std_rng_check.cpp", "Makefile")]
+    stale = force or not os.path.exists(_LIB_PATH) or not os.path.exists(RNG_CHECK_PATH)
+    if not stale:
+        t = min(os.path.getmtime(_LIB_PATH), os.path.getmtime(RNG_CHECK_PATH))
+        stale = any(os.path.getmtime(s) > t for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+class _Stats(C.Structure):
+    _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("count", C.c_uint64),
+                ("iterations", C.c_uint64), ("best_index", C.c_int64), ("general_fit_ok", C.c_int)]
+
+
+class _Trace(C.Structure):
+    _fields_ = [("samples", C.c_void_p), ("valid", C.c_void_p), ("models", C.c_void_p),
+                ("counts", C.c_void_p), ("errors", C.c_void_p)]
+
+
+class _RegStats(C.Structure):
+    _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("validations", C.c_uint64),
+                ("iterations", C.c_int64), ("best_index", C.c_int64), ("est_k", C.c_int64)]
+
+
+class _RegTrace(C.Structure):
+    _fields_ = [("triples", C.c_void_p), ("T", C.c_void_p), ("passed", C.c_void_p),
+                ("counts", C.c_void_p), ("err2", C.c_void_p)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_plane_distance.restype = C.c_double
+        _lib.orc_sphere_distance.restype = C.c_double
+        _lib.orc_cylinder_distance.restype = C.c_double
+        _lib.orc_point2line.restype = C.c_double
+        _lib.orc_distance.restype = C.c_double
+        _lib.orc_mt_next.restype = C.c_uint32
+        _lib.orc_uniform_int.restype = C.c_uint32
+        _lib.orc_double_to_size_t_x86.restype = C.c_uint64
+        _lib.orc_double_to_size_t_x86.argtypes = [C.c_double]
+        _lib.orc_reg_corr_inlier_ratio.restype = C.c_double
+        _lib.orc_match_mutual_nn.restype = C.c_size_t
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+# ------------------------------------------------------------------------------------------------
+# RNG
+# ------------------------------------------------------------------------------------------------
+class MT19937:
+    def __init__(self, seed: int):
+        self._buf = C.create_string_buffer(624 * 4 + 8)
+        lib().orc_mt_seed(self._buf, C.c_uint64(seed))
+
+    def next(self) -> int:
+        return int(lib().orc_mt_next(self._buf))
+
+    def uniform_int(self, range_incl: int) -> int:
+        return int(lib().orc_uniform_int(self._buf, C.c_uint32(range_incl)))
+
+    def sample(self, size: int, m: int):
+        out = np.zeros(m, dtype=np.uint64)
+        lib().orc_sample(self._buf, C.c_size_t(size), C.c_int(m), _p(out))
+        return out
+
+
+def draw_samples(n: int, m: int, H: int, seed: int):
+    out = np.zeros((H, m), dtype=np.uint64)
+    lib().orc_draw_samples(C.c_size_t(n), C.c_int(m), C.c_size_t(H), C.c_uint64(seed), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# estimators
+# ------------------------------------------------------------------------------------------------
+def plane_minimal_fit(p):
+    p = _f64(p, (9,))
+    out = np.zeros(4)
+    ok = lib().orc_plane_minimal_fit(_p(p), _p(out))
+    return bool(ok), out
+
+
+def sphere_minimal_fit(p):
+    p = _f64(p, (12,))
+    out = np.zeros(4)
+    ok = lib().orc_sphere_minimal_fit(_p(p), _p(out))
+    return bool(ok), out
+
+
+def cylinder_minimal_fit(p, nrm):
+    p = _f64(p, (6,))
+    nrm = _f64(nrm, (6,))
+    out = np.zeros(7)
+    ok = lib().orc_cylinder_minimal_fit(_p(p), _p(nrm), _p(out))
+    return bool(ok), out
+
+
+def distance(kind, q, model):
+    q = _f64(q, (3,))
+    model = _f64(model)
+    return float(lib().orc_distance(C.c_int(kind), _p(q), _p(model)))
+
+
+def plane_general_fit(pts):
+    pts = _f64(pts).reshape(-1, 3)
+    out = np.zeros(4)
+    ok = lib().orc_plane_general_fit(_p(pts), C.c_size_t(len(pts)), _p(out))
+    return bool(ok), out
+
+
+def sphere_general_fit(pts):
+    pts = _f64(pts).reshape(-1, 3)
+    out = np.zeros(4)
+    ok = lib().orc_sphere_general_fit(_p(pts), C.c_size_t(len(pts)), _p(out))
+    return bool(ok), out
+
+
+def evaluate_model(kind, xyz, thr, model):
+    xyz = _f64(xyz).reshape(-1, 3)
+    model = _f64(model)
+    cnt = C.c_uint64(0)
+    err = C.c_double(0)
+    lib().orc_evaluate_model(C.c_int(kind), _p(xyz), C.c_size_t(len(xyz)), C.c_double(thr), _p(model),
+                             C.byref(cnt), C.byref(err))
+    return int(cnt.value), float(err.value)
+
+
+@dataclass
+class FitResult:
+    ret: int
+    params: np.ndarray
+    inliers: np.ndarray
+    fitness: float
+    inlier_rmse: float
+    count: int
+    iterations: int
+    best_index: int
+    trace: dict | None = None
+
+
+def fit(kind, xyz, normals=None, thr=0.01, max_iter=1000, prob=0.9999, seed=0, trace=False) -> FitResult:
+    """Sequential seeded restatement of RANSAC::FitModel (ransac.h:506-624)."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    n = len(xyz)
+    nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+    params = np.zeros(_NP[kind])
+    inl = np.zeros(max(n, 1), dtype=np.uint64)
+    ni = C.c_size_t(0)
+    st = _Stats()
+    tr = None
+    tr_arrays = None
+    if trace:
+        m = _M[kind]
+        tr_arrays = dict(samples=np.zeros((max_iter, m), dtype=np.uint64), valid=np.zeros(max_iter, dtype=np.int32),
+                         models=np.zeros((max_iter, _NP[kind])), counts=np.zeros(max_iter, dtype=np.uint64),
+                         errors=np.zeros(max_iter))
+        tr = _Trace(*[_p(tr_arrays[k]) for k in ("samples", "valid", "models", "counts", "errors")])
+    ret = lib().orc_fit(C.c_int(kind), _p(xyz), _p(nrm), C.c_size_t(n), C.c_double(thr), C.c_size_t(max_iter),
+                        C.c_double(prob), C.c_uint64(seed), _p(params), _p(inl), C.byref(ni), C.byref(st),
+                        C.byref(tr) if tr is not None else None)
+    return FitResult(ret, params, inl[: ni.value].copy(), st.fitness, st.inlier_rmse, int(st.count),
+                     int(st.iterations), int(st.best_index), tr_arrays)
+
+
+def score_samples(kind, xyz, normals, thr, samples):
+    xyz = _f64(xyz).reshape(-1, 3)
+    nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+    samples = np.ascontiguousarray(samples, dtype=np.uint64)
+    H = len(samples)
+    valid = np.zeros(H, dtype=np.int32)
+    models = np.zeros((H, _NP[kind]))
+    counts = np.zeros(H, dtype=np.uint64)
+    errors = np.zeros(H)
+    lib().orc_score_samples(C.c_int(kind), _p(xyz), _p(nrm), C.c_size_t(len(xyz)), C.c_double(thr), _p(samples),
+                            C.c_size_t(H), _p(valid), _p(models), _p(counts), _p(errors))
+    return valid, models, counts, errors
+
+
+def fit_omp_baseline(kind, xyz, normals, thr, H, seed):
+    xyz = _f64(xyz).reshape(-1, 3)
+    nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+    model = np.zeros(_NP[kind])
+    cnt = C.c_uint64(0)
+    bi = C.c_int64(-1)
+    lib().orc_fit_omp_baseline(C.c_int(kind), _p(xyz), _p(nrm), C.c_size_t(len(xyz)), C.c_double(thr),
+                               C.c_size_t(H), C.c_uint64(seed), _p(model), C.byref(cnt), C.byref(bi))
+    return model, int(cnt.value), int(bi.value)
+
+
+def omp_threads() -> int:
+    return int(lib().orc_omp_threads())
+
+
+def segment_plane_iterative(xyz, thr, max_iteration=100, min_ratio=0.05, seed=0, max_clusters=4096):
+    xyz = _f64(xyz).reshape(-1, 3)
+    n = len(xyz)
+    planes = np.zeros((max_clusters, 4))
+    offs = np.zeros(max_clusters + 1, dtype=np.uint64)
+    idx = np.zeros(max(n, 1), dtype=np.uint64)
+    k = C.c_size_t(0)
+    rc = lib().orc_segment_plane_iterative(_p(xyz), C.c_size_t(n), C.c_double(thr), C.c_int(max_iteration),
+                                           C.c_double(min_ratio), C.c_uint64(seed), C.c_size_t(max_clusters),
+                                           _p(planes), _p(offs), _p(idx), C.byref(k))
+    k = k.value
+    return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() for i in range(k)]
+
+
+# ------------------------------------------------------------------------------------------------
+# registration
+# ------------------------------------------------------------------------------------------------
+def k3x3_rotation(sigma):
+    sigma = _f64(sigma, (9,))
+    R = np.zeros(9)
+    sv = np.zeros(3)
+    lib().orc_k3x3_rotation(_p(sigma), _p(R), _p(sv))
+    return R.reshape(3, 3), sv
+
+
+def umeyama(src, dst, with_scaling=False):
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    T = np.zeros(16)
+    lib().orc_umeyama(_p(src), _p(dst), C.c_size_t(len(src)), C.c_int(int(with_scaling)), _p(T))
+    return T.reshape(4, 4)
+
+
+def reg_validate(src, dst, T, thr):
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    T = _f64(T, (16,))
+    cnt = C.c_uint64(0)
+    e2 = C.c_double(0)
+    lib().orc_reg_validate(_p(src), C.c_size_t(len(src)), _p(dst), C.c_size_t(len(dst)), _p(T), C.c_double(thr),
+                           C.byref(cnt), C.byref(e2))
+    return int(cnt.value), float(e2.value)
+
+
+@dataclass
+class RegResult:
+    ret: int
+    T: np.ndarray
+    fitness: float
+    inlier_rmse: float
+    validations: int
+    iterations: int
+    best_index: int
+    est_k: int
+    trace: dict | None = None
+
+
+def registration_ransac(src, dst, corr_src, corr_dst, thr=0.01, max_iter=100000, edge_thr=0.9, confidence=0.999,
+                        seed=0, trace=False) -> RegResult:
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    cs = np.ascontiguousarray(corr_src, dtype=np.int64)
+    cd = np.ascontiguousarray(corr_dst, dtype=np.int64)
+    T = np.zeros(16)
+    st = _RegStats()
+    tr = None
+    arrs = None
+    if trace:
+        arrs = dict(triples=np.zeros((max_iter, 3), dtype=np.int64), T=np.zeros((max_iter, 16)),
+                    passed=np.zeros(max_iter, dtype=np.int32), counts=np.zeros(max_iter, dtype=np.uint64),
+                    err2=np.zeros(max_iter))
+        tr = _RegTrace(*[_p(arrs[k]) for k in ("triples", "T", "passed", "counts", "err2")])
+    ret = lib().orc_registration_ransac(_p(src), C.c_size_t(len(src)), _p(dst), C.c_size_t(len(dst)), _p(cs), _p(cd),
+                                        C.c_size_t(len(cs)), C.c_double(thr), C.c_int(max_iter), C.c_double(edge_thr),
+                                        C.c_double(confidence), C.c_uint64(seed), _p(T), C.byref(st),
+                                        C.byref(tr) if tr is not None else None)
+    return RegResult(ret, T.reshape(4, 4), st.fitness, st.inlier_rmse, int(st.validations), int(st.iterations),
+                     int(st.best_index), int(st.est_k), arrs)
+
+
+def match_mutual_nn(feat_src, feat_dst):
+    """feat_*: (N, dim) row-major == Eigen dim x N column-major (correspondence_matching.h:39-41)."""
+    fs = _f64(feat_src)
+    fd = _f64(feat_dst)
+    ns, dim = fs.shape
+    nd = fd.shape[0]
+    o0 = np.zeros(max(ns, 1), dtype=np.int64)
+    o1 = np.zeros(max(ns, 1), dtype=np.int64)
+    k = lib().orc_match_mutual_nn(_p(fs), C.c_size_t(ns), _p(fd), C.c_size_t(nd), C.c_int(dim), _p(o0), _p(o1))
+    return o0[:k].copy(), o1[:k].copy()

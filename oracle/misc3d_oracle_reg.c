@@ -1,0 +1,413 @@
+/*
+ * misc3d_oracle_reg.c -- CPU restatement of the registration half of the hot path.
+ * TEST INFRASTRUCTURE ONLY (see the header of misc3d_oracle.c; same rules, same build flags).
+ *
+ * PARITY UNPINNED.  The arithmetic of this half lives in third-party code that is NOT under
+ * /root/reference and not installed here:
+ *   - Open3D v0.15.1 (CI pin .github/workflows/ubuntu.yml:39): RegistrationRANSACBasedOnCorrespondence,
+ *     TransformationEstimationPointToPoint, CorrespondenceCheckerBasedOnEdgeLength / ...Distance,
+ *     KDTreeFlann::SearchHybrid, GetRegistrationResultAndCorrespondences,
+ *     EvaluateInlierCorrespondenceRatio  -- call site src/transform_estimation.cpp:124-164
+ *   - Eigen (umeyama, JacobiSVD)          -- call site src/transform_estimation.cpp:59-66
+ *   - nanoflann / Annoy nearest neighbour -- call site src/correspondence_matching.cpp:13-44
+ * Their published algorithms are restated from memory of the pinned versions ([RECALL], SURVEY.md
+ * 8a rows a17-a20).  Reference-side tests for these boundaries: none.
+ *
+ * Canonical sequential semantics: one thread, std::mt19937(seed) + libstdc++
+ * uniform_int_distribution<int>(0, M-1) for the correspondence sampler; sums in index order.
+ *
+ * The 3x3 SVD inside umeyama cannot be restated bit-for-bit (Eigen JacobiSVD internals); the oracle
+ * and the HIP path both implement the SAME fully specified algorithm ("K3x3", below), so that they
+ * agree bit-for-bit with each other and to ~1e-14 with Eigen / numpy.linalg.svd (tests check the
+ * latter with numpy).
+ */
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    uint32_t mt[624];
+    int idx;
+} orc_mt19937;
+void orc_mt_seed(orc_mt19937 *g, uint64_t seed);
+uint32_t orc_mt_next(orc_mt19937 *g);
+uint32_t orc_uniform_int(orc_mt19937 *g, uint32_t range_incl);
+
+static inline double dot3(const double *a, const double *b) {
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* K3x3: rotation part of umeyama from a 3x3 covariance `sigma` (row-major).                    */
+/* One-sided (Hestenes) Jacobi on the columns of A = sigma, V accumulates the rotations:        */
+/*   pairs visited in the order (0,1),(0,2),(1,2); at most 30 sweeps; a pair is skipped when     */
+/*   gamma == 0 or |gamma| <= 2^-52 * sqrt(alpha*beta).                                          */
+/* Singular values = column norms, sorted descending (stable).  u1,u2 = columns / sigma,         */
+/* u3 = u1 x u2 (so det U = +1), and R = u1 v1^T + u2 v2^T + sign(det V) u3 v3^T, which equals    */
+/* Eigen::umeyama's U * diag(1,1,sign(det U det V)) * V^T (src Eigen/src/Geometry/Umeyama.h       */
+/* [RECALL]) including the rank-2 case of three correspondences.                                 */
+/* Outputs: R (row-major 3x3), sv[3] singular values with sv[2] SIGNED by the reflection rule.   */
+/* ------------------------------------------------------------------------------------------- */
+void orc_k3x3_rotation(const double *sigma, double *R, double *sv) {
+    double a[3][3], v[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            a[r][c] = sigma[3 * r + c];
+            v[r][c] = (r == c) ? 1.0 : 0.0;
+        }
+    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        int rotated = 0;
+        for (int k = 0; k < 3; ++k) {
+            const int p = PQ[k][0], q = PQ[k][1];
+            const double alpha = (a[0][p] * a[0][p] + a[1][p] * a[1][p]) + a[2][p] * a[2][p];
+            const double beta = (a[0][q] * a[0][q] + a[1][q] * a[1][q]) + a[2][q] * a[2][q];
+            const double gamma = (a[0][p] * a[0][q] + a[1][p] * a[1][q]) + a[2][p] * a[2][q];
+            if (gamma == 0.0) continue;
+            if (fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta)) continue;
+            rotated = 1;
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t);
+            const double s = c * t;
+            for (int r = 0; r < 3; ++r) {
+                const double ap = a[r][p], aq = a[r][q];
+                a[r][p] = c * ap - s * aq;
+                a[r][q] = s * ap + c * aq;
+                const double vp = v[r][p], vq = v[r][q];
+                v[r][p] = c * vp - s * vq;
+                v[r][q] = s * vp + c * vq;
+            }
+        }
+        if (!rotated) break;
+    }
+    double sg[3];
+    for (int c = 0; c < 3; ++c)
+        sg[c] = sqrt((a[0][c] * a[0][c] + a[1][c] * a[1][c]) + a[2][c] * a[2][c]);
+    int ord[3] = {0, 1, 2};
+    /* stable insertion sort, descending */
+    for (int i = 1; i < 3; ++i) {
+        int j = i;
+        while (j > 0 && sg[ord[j]] > sg[ord[j - 1]]) {
+            int tmp = ord[j];
+            ord[j] = ord[j - 1];
+            ord[j - 1] = tmp;
+            --j;
+        }
+    }
+    const int i1 = ord[0], i2 = ord[1], i3 = ord[2];
+    double u1[3], u2[3], u3[3];
+    if (!(sg[i1] > 0.0)) { /* sigma == 0: all points coincide; rotation undefined -> identity */
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[3 * r + c] = (r == c) ? 1.0 : 0.0;
+        sv[0] = sv[1] = sv[2] = 0.0;
+        return;
+    }
+    for (int r = 0; r < 3; ++r) u1[r] = a[r][i1] / sg[i1];
+    if (sg[i2] > 1e-300 && sg[i2] > 2.220446049250313e-16 * sg[i1]) {
+        for (int r = 0; r < 3; ++r) u2[r] = a[r][i2] / sg[i2];
+    } else { /* rank 1 (collinear input): deterministic completion */
+        int kmin = 0;
+        if (fabs(u1[1]) < fabs(u1[kmin])) kmin = 1;
+        if (fabs(u1[2]) < fabs(u1[kmin])) kmin = 2;
+        double e[3] = {0, 0, 0};
+        e[kmin] = 1.0;
+        const double pr = u1[kmin];
+        double w[3];
+        for (int r = 0; r < 3; ++r) w[r] = e[r] - pr * u1[r];
+        const double nw = sqrt(dot3(w, w));
+        for (int r = 0; r < 3; ++r) u2[r] = w[r] / nw;
+    }
+    u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
+    u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
+    u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+    const double detv = (v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) -
+                         v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0])) +
+                        v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+    const double sgn = detv < 0.0 ? -1.0 : 1.0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            R[3 * r + c] = (u1[r] * v[c][i1] + u2[r] * v[c][i2]) + (sgn * u3[r]) * v[c][i3];
+    const double a3[3] = {a[0][i3], a[1][i3], a[2][i3]};
+    sv[0] = sg[i1];
+    sv[1] = sg[i2];
+    sv[2] = sgn * dot3(u3, a3); /* = S * sigma_3 of umeyama */
+}
+
+/* Eigen::umeyama(src, dst, with_scaling) -- call sites src/transform_estimation.cpp:65 and Open3D
+ * TransformationEstimationPointToPoint::ComputeTransformation.  src/dst: n x 3 AoS.  Sums in index
+ * order.  T: row-major 4x4. */
+void orc_umeyama(const double *src, const double *dst, size_t n, int with_scaling, double *T) {
+    const double one_over_n = 1.0 / (double)n;
+    double ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            ms[k] += src[3 * i + k];
+            md[k] += dst[3 * i + k];
+        }
+    for (int k = 0; k < 3; ++k) {
+        ms[k] *= one_over_n;
+        md[k] *= one_over_n;
+    }
+    double sig[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double var[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        double s[3], d[3];
+        for (int k = 0; k < 3; ++k) {
+            s[k] = src[3 * i + k] - ms[k];
+            d[k] = dst[3 * i + k] - md[k];
+        }
+        for (int r = 0; r < 3; ++r) {
+            var[r] += s[r] * s[r];
+            for (int c = 0; c < 3; ++c) sig[3 * r + c] += d[r] * s[c];
+        }
+    }
+    for (int k = 0; k < 9; ++k) sig[k] *= one_over_n;
+    const double src_var = ((var[0] + var[1]) + var[2]) * one_over_n;
+    double R[9], sv[3];
+    orc_k3x3_rotation(sig, R, sv);
+    double c = 1.0;
+    if (with_scaling) c = 1.0 / src_var * ((sv[0] + sv[1]) + sv[2]);
+    for (int r = 0; r < 3; ++r) {
+        const double rm = (R[3 * r] * ms[0] + R[3 * r + 1] * ms[1]) + R[3 * r + 2] * ms[2];
+        T[4 * r + 3] = md[r] - c * rm;
+        for (int cc = 0; cc < 3; ++cc) T[4 * r + cc] = c * R[3 * r + cc];
+    }
+    T[12] = T[13] = T[14] = 0.0;
+    T[15] = 1.0;
+}
+
+/* Open3D PointCloud::Transform / CorrespondenceCheckerBasedOnDistance: (T * (x,y,z,1)).head<3>(),
+ * fixed-size product accumulated column by column ([RECALL]). */
+static inline void transform_point(const double *T, const double *p, double *o) {
+    for (int r = 0; r < 3; ++r)
+        o[r] = ((T[4 * r] * p[0] + T[4 * r + 1] * p[1]) + T[4 * r + 2] * p[2]) + T[4 * r + 3];
+}
+
+void orc_transform_points(const double *T, const double *p, size_t n, double *o) {
+    for (size_t i = 0; i < n; ++i) transform_point(T, p + 3 * i, o + 3 * i);
+}
+
+/* CorrespondenceCheckerBasedOnEdgeLength::Check then ...BasedOnDistance::Check ([RECALL] Open3D
+ * 0.15.1 CorrespondenceChecker.cpp), on the 3 sampled correspondences. */
+int orc_reg_checkers(const double *src, const double *dst, const int64_t *cs, const int64_t *cd,
+                     const double *T, double edge_thr, double dist_thr) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j) {
+            double es[3], et[3];
+            for (int k = 0; k < 3; ++k) {
+                es[k] = src[3 * cs[i] + k] - src[3 * cs[j] + k];
+                et[k] = dst[3 * cd[i] + k] - dst[3 * cd[j] + k];
+            }
+            const double ds = sqrt(dot3(es, es)), dt = sqrt(dot3(et, et));
+            if (ds < dt * edge_thr || dt < ds * edge_thr) return 0;
+        }
+    for (int i = 0; i < 3; ++i) {
+        double pt[3], df[3];
+        transform_point(T, src + 3 * cs[i], pt);
+        for (int k = 0; k < 3; ++k) df[k] = dst[3 * cd[i] + k] - pt[k];
+        if (sqrt(dot3(df, df)) > dist_thr) return 0;
+    }
+    return 1;
+}
+
+/* GetRegistrationResultAndCorrespondences ([RECALL] Open3D Registration.cpp): for every transformed
+ * source point, KDTreeFlann::SearchHybrid(p, thr, 1): nearest target point, kept iff dist^2 < thr^2
+ * (std::lower_bound on radius*radius).  Brute-force exact nearest neighbour here.  err2 is summed
+ * in source order. */
+void orc_reg_validate(const double *src, size_t ns, const double *dst, size_t nd, const double *T,
+                      double thr, uint64_t *count, double *err2) {
+    const double r2 = thr * thr;
+    double *best = (double *)malloc(sizeof(double) * (ns ? ns : 1));
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)ns; ++i) {
+        double p[3];
+        transform_point(T, src + 3 * i, p);
+        double bd = INFINITY;
+        for (size_t j = 0; j < nd; ++j) {
+            const double dx = p[0] - dst[3 * j], dy = p[1] - dst[3 * j + 1], dz = p[2] - dst[3 * j + 2];
+            const double d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < bd) bd = d2;
+        }
+        best[i] = bd;
+    }
+    uint64_t c = 0;
+    double e = 0;
+    for (size_t i = 0; i < ns; ++i)
+        if (best[i] < r2) {
+            e += best[i];
+            c++;
+        }
+    free(best);
+    *count = c;
+    *err2 = e;
+}
+
+/* EvaluateInlierCorrespondenceRatio ([RECALL] Open3D Registration.cpp) */
+double orc_reg_corr_inlier_ratio(const double *src, const double *dst, const int64_t *cs,
+                                 const int64_t *cd, size_t m, const double *T, double thr) {
+    const double r2 = thr * thr;
+    uint64_t c = 0;
+    for (size_t i = 0; i < m; ++i) {
+        double p[3], df[3];
+        transform_point(T, src + 3 * cs[i], p);
+        for (int k = 0; k < 3; ++k) df[k] = p[k] - dst[3 * cd[i] + k];
+        if (dot3(df, df) < r2) c++;
+    }
+    return (double)c / (double)m;
+}
+
+/* static_cast<int>(std::ceil(v)) as x86-64 cvttsd2si (32-bit) behaves */
+static int ceil_to_int_x86(double v) {
+    const double c = ceil(v);
+    if (!(c > -2147483649.0) || !(c < 2147483648.0)) return INT_MIN;
+    return (int)c;
+}
+
+typedef struct {
+    double fitness;
+    double inlier_rmse;
+    uint64_t validations;  /* total_validation */
+    int64_t iterations;    /* number of itr that drew a sample */
+    int64_t best_index;
+    int64_t est_k;         /* final est_k_global */
+} orc_reg_stats;
+
+typedef struct {           /* optional per-iteration trace, sized max_iter */
+    int64_t *triples;      /* max_iter x 3 correspondence ids */
+    double *T;             /* max_iter x 16 */
+    int *passed;           /* checkers passed */
+    uint64_t *counts;
+    double *err2;
+} orc_reg_trace;
+
+/* RANSACSolver::Solve (src/transform_estimation.cpp:124-164) -> Open3D
+ * RegistrationRANSACBasedOnCorrespondence(ransac_n = 3, PointToPoint(false), checkers
+ * [EdgeLength(edge_thr), Distance(thr)], criteria(max_iter, confidence)) -- [RECALL], 1 thread.
+ * The reference's RANSACSolver leaves edge_length_threshold_ uninitialised
+ * (transform_estimation.h:126, self-initialisation); the oracle honours the constructor argument.
+ * Returns 0 ok; -1 = fewer than 3 points (reference throws, transform_estimation.cpp:130-133). */
+int orc_registration_ransac(const double *src, size_t ns, const double *dst, size_t nd,
+                            const int64_t *cs, const int64_t *cd, size_t m, double thr,
+                            int max_iter, double edge_thr, double confidence, uint64_t seed,
+                            double *T_out, orc_reg_stats *stats, orc_reg_trace *trace) {
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(T_out, I4, sizeof(I4));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (stats) stats->best_index = -1;
+    if (ns < 3 || nd < 3) return -1;
+    if (m < 3 || thr <= 0.0) return 0; /* Open3D returns RegistrationResult() = identity */
+    double best_fit = 0, best_rmse = 0;
+    int est_k_global = max_iter, est_k_local = max_iter;
+    uint64_t total_validation = 0;
+    int64_t iters = 0, best_index = -1;
+    orc_mt19937 rng;
+    orc_mt_seed(&rng, seed);
+    for (int itr = 0; itr < max_iter; ++itr) {
+        if (!(itr < est_k_global)) continue;
+        iters++;
+        int64_t tri[3], s3[3], d3[3];
+        double ps[9], pd[9], T[16];
+        for (int j = 0; j < 3; ++j) {
+            tri[j] = (int64_t)orc_uniform_int(&rng, (uint32_t)(m - 1));
+            s3[j] = cs[tri[j]];
+            d3[j] = cd[tri[j]];
+            memcpy(ps + 3 * j, src + 3 * s3[j], 3 * sizeof(double));
+            memcpy(pd + 3 * j, dst + 3 * d3[j], 3 * sizeof(double));
+        }
+        orc_umeyama(ps, pd, 3, 0, T);
+        const int pass = orc_reg_checkers(src, dst, s3, d3, T, edge_thr, thr);
+        if (trace) {
+            if (trace->triples) memcpy(trace->triples + 3 * (size_t)itr, tri, sizeof(tri));
+            if (trace->T) memcpy(trace->T + 16 * (size_t)itr, T, sizeof(T));
+            if (trace->passed) trace->passed[itr] = pass;
+            if (trace->counts) trace->counts[itr] = 0;
+            if (trace->err2) trace->err2[itr] = 0;
+        }
+        if (!pass) continue;
+        uint64_t cnt;
+        double e2;
+        orc_reg_validate(src, ns, dst, nd, T, thr, &cnt, &e2);
+        if (trace) {
+            if (trace->counts) trace->counts[itr] = cnt;
+            if (trace->err2) trace->err2[itr] = e2;
+        }
+        double fit = 0, rmse = 0;
+        if (cnt > 0) {
+            fit = (double)cnt / (double)ns;
+            rmse = sqrt(e2 / (double)cnt);
+        }
+        if (fit > best_fit || (fit == best_fit && rmse < best_rmse)) {
+            best_fit = fit;
+            best_rmse = rmse;
+            best_index = itr;
+            memcpy(T_out, T, sizeof(T));
+            const double ratio = orc_reg_corr_inlier_ratio(src, dst, cs, cd, m, T, thr);
+            const double est_d = log(1.0 - confidence) / log(1.0 - pow(ratio, 3.0));
+            est_k_local = est_d < (double)est_k_global ? ceil_to_int_x86(est_d) : est_k_local;
+        }
+        total_validation++;
+        if (est_k_local < est_k_global) est_k_global = est_k_local;
+    }
+    if (stats) {
+        stats->fitness = best_fit;
+        stats->inlier_rmse = best_rmse;
+        stats->validations = total_validation;
+        stats->iterations = iters;
+        stats->best_index = best_index;
+        stats->est_k = est_k_global;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* ANNMatcher::Match -- src/correspondence_matching.cpp:52-84                                    */
+/* feat: dim x N column-major (Eigen MatrixXd, correspondence_matching.h:39-41) = N descriptors   */
+/* of `dim` contiguous doubles.  Exact nearest neighbour (the FLANN backend's semantics; the      */
+/* ANNOY backend approximates the same thing and is not restatable: multi-threaded forest build   */
+/* with per-thread seeds, annoylib.h:1144-1146).  L2 accumulated in dimension order (nanoflann    */
+/* L2_Simple_Adaptor [RECALL]); ties -> lowest index.                                             */
+/* ------------------------------------------------------------------------------------------- */
+void orc_nearest(const double *q, size_t nq, const double *db, size_t ndb, int dim, int64_t *nn) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)nq; ++i) {
+        double bd = INFINITY;
+        int64_t bi = -1;
+        for (size_t j = 0; j < ndb; ++j) {
+            double acc = 0;
+            for (int k = 0; k < dim; ++k) {
+                const double df = q[(size_t)i * dim + k] - db[j * dim + k];
+                acc += df * df;
+            }
+            if (acc < bd) {
+                bd = acc;
+                bi = (int64_t)j;
+            }
+        }
+        nn[i] = bi;
+    }
+}
+
+/* cross-check, correspondence_matching.cpp:64-78.  Returns the number of mutual matches. */
+size_t orc_match_mutual_nn(const double *fs, size_t ns, const double *fd, size_t nd, int dim,
+                           int64_t *out_src, int64_t *out_dst) {
+    int64_t *n01 = (int64_t *)malloc(sizeof(int64_t) * (ns ? ns : 1));
+    int64_t *n10 = (int64_t *)malloc(sizeof(int64_t) * (nd ? nd : 1));
+    orc_nearest(fs, ns, fd, nd, dim, n01);
+    orc_nearest(fd, nd, fs, ns, dim, n10);
+    size_t k = 0;
+    for (size_t i = 0; i < ns; ++i) {
+        if (n01[i] >= 0 && n10[n01[i]] == (int64_t)i) {
+            out_src[k] = (int64_t)i;
+            out_dst[k] = n01[i];
+            k++;
+        }
+    }
+    free(n01);
+    free(n10);
+    return k;
+}

@@ -1,0 +1,75 @@
+"""CPU-side check of the drop-in boundary: the C-ABI shared object loads without a GPU and exports
+every function declared in include/misc3d_amd.h; compute entry points fail loudly (no fallback)."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+
+
+def _declared_functions(header_text):
+    text = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)
+    return sorted(set(re.findall(r"\b(m3d_[a-z0-9_]+)\s*\(", text)) - {"m3d_rmse_fn"})
+
+
+def test_header_symbols_exported(capi):
+    names = _declared_functions(open(capi.HEADER_PATH).read())
+    assert len(names) >= 18
+    L = ctypes.CDLL(capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_version_and_error_string(capi):
+    assert b"gfx950" in capi.lib().m3d_version()
+    assert isinstance(capi.last_error(), str)
+
+
+def test_argument_validation_needs_no_gpu(capi):
+    pts = np.zeros((2, 3))
+    with pytest.raises(capi.M3DError) as e:
+        capi.fit(capi.PLANE, pts, seed=1)                      # ransac.h:510-513
+    assert e.value.code == capi.ERR_TOO_FEW_POINTS and "lack of points" in str(e.value)
+    with pytest.raises(capi.M3DError) as e:
+        capi.fit(capi.PLANE, np.zeros((10, 3)), probability=1.5, seed=1)   # ransac.h:483-485
+    assert e.value.code == capi.ERR_PROBABILITY
+    with pytest.raises(capi.M3DError) as e:
+        capi.fit(capi.CYLINDER, np.zeros((10, 3)), normals=None, seed=1)   # py_common.cpp:50-52
+    assert e.value.code == capi.ERR_NO_NORMALS and "requires normals" in str(e.value)
+
+
+def test_no_cpu_fallback(capi):
+    if capi.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(capi.M3DError) as e:
+        capi.fit(capi.PLANE, np.random.default_rng(0).normal(size=(100, 3)), seed=1)
+    assert e.value.code == capi.ERR_DEVICE
+
+
+def test_draw_samples_matches_oracle_sampler(capi, orc):
+    # host-only entry point: std::mt19937 + utils.h:81-97 rejection sampler
+    for kind, n in ((capi.PLANE, 1000), (capi.SPHERE, 37), (capi.CYLINDER, 5)):
+        a = capi.draw_samples(n, kind, 500, 1234)
+        b = orc.draw_samples(n, capi.MINIMAL_SAMPLE[kind], 500, 1234)
+        assert np.array_equal(a.astype(np.uint64), b)
+
+
+def test_replay_matches_oracle_driver(capi, orc):
+    # pure host logic: replay of ransac.h:592-613 over the oracle's per-hypothesis trace
+    from misc3d_amd import synth
+    pts = synth.plane_cloud_c1(3000, seed=3)
+    for prob, max_iter in ((0.9999, 200), (1.0, 64), (0.5, 100)):
+        r = orc.fit(orc.PLANE, pts, thr=0.01, max_iter=max_iter, prob=prob, seed=5, trace=True)
+        tr = r.trace
+        errs = tr["errors"]
+        cnts = tr["counts"]
+
+        def rmse(i):
+            return errs[i] / np.sqrt(float(cnts[i])) if cnts[i] else 1e10
+
+        st = capi.replay(len(pts), capi.PLANE, max_iter, prob, tr["valid"].astype(np.uint8),
+                         cnts.astype(np.uint32), rmse)
+        assert st.best_index == r.best_index
+        assert st.count == r.count
+        assert st.iterations == r.iterations
+        assert st.best_fitness == r.fitness

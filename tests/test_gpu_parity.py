@@ -1,0 +1,196 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bar: bit-exact for everything integer (valid flags, inlier counts, best index, iteration
+counts, inlier index lists) AND for the minimal-fit models (same fp64 operation order, correctly
+rounded sqrt/div on both sides); refined (GeneralFit) parameters within 1e-9 (the reference sums
+serially, the GPU with a fixed tree: north_star tolerance is 1e-5)."""
+import numpy as np
+import pytest
+
+from misc3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PARAM_TOL = 1e-9
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _clouds(kind, n, seed):
+    if kind == 0:
+        return synth.plane_cloud_c1(n, seed), None
+    if kind == 1:
+        return synth.sphere_cloud_c3(n, seed), None
+    return synth.cylinder_cloud_c3(n, seed)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("n", [20000, 4097, 777])
+def test_score_range_bit_exact(capi, orc, kind, n):
+    """minimal_fit_k + score_k + reduce vs MinimalFit + EvaluateModel, hypothesis by hypothesis."""
+    pts, nrm = _clouds(kind, n, seed=10 + kind)
+    H = 300
+    samples = capi.draw_samples(n, kind, H, seed=99)
+    with capi.Cloud(pts, nrm) as c:
+        valid, models, counts = c.score_range(kind, 0.01, samples)
+    ovalid, omodels, ocounts, _ = orc.score_samples(kind, pts, nrm, 0.01, samples.astype(np.uint64))
+    assert np.array_equal(valid.astype(bool), ovalid.astype(bool))
+    v = ovalid.astype(bool)
+    # NaN radii (sphere) compare equal bitwise only if both are NaN: compare with nan-equality
+    assert np.array_equal(_bits(models[v]), _bits(omodels[v])) or np.array_equal(
+        np.nan_to_num(models[v], nan=-7.0), np.nan_to_num(omodels[v], nan=-7.0))
+    assert np.array_equal(counts.astype(np.uint64), ocounts)
+    assert counts[v].max() > 0.2 * n  # the structure was found by some hypothesis
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_exact_error_serial_sum(capi, orc, kind):
+    """compact(mode 1) + serial_sum_k reproduce EvaluateModel's count and serial error sum bitwise."""
+    n = 30000
+    pts, nrm = _clouds(kind, n, seed=20 + kind)
+    samples = capi.draw_samples(n, kind, 40, seed=5)
+    ovalid, omodels, ocounts, oerrs = orc.score_samples(kind, pts, nrm, 0.01, samples.astype(np.uint64))
+    order = np.argsort(-ocounts.astype(np.int64))[:5]
+    with capi.Cloud(pts, nrm) as c:
+        for h in order:
+            cnt, err = c.exact_error(kind, 0.01, omodels[h])
+            assert cnt == int(ocounts[h])
+            assert _bits([err])[0] == _bits([oerrs[h]])[0]
+
+
+@pytest.mark.parametrize("kind,n,max_iter,prob,seed", [
+    (0, 20000, 1000, 0.9999, 7),      # adaptive stop (default arguments of the python API)
+    (0, 20000, 300, 1.0, 11),         # every hypothesis evaluated
+    (0, 5000, 100, 0.9999, 3),        # C1-like plumbing
+    (1, 20000, 400, 0.9999, 13),
+    (1, 6000, 200, 1.0, 2),
+    (2, 20000, 400, 0.9999, 13),
+    (2, 6000, 300, 1.0, 4),
+])
+def test_fit_matches_oracle(capi, orc, kind, n, max_iter, prob, seed):
+    pts, nrm = _clouds(kind, n, seed=30 + kind)
+    o = orc.fit(kind, pts, nrm, thr=0.01, max_iter=max_iter, prob=prob, seed=seed)
+    g = capi.fit(kind, pts, nrm, threshold=0.01, max_iteration=max_iter, probability=prob, seed=seed)
+    assert g.ret == o.ret
+    assert g.stats["best_index"] == o.best_index
+    assert g.stats["count"] == o.count
+    assert g.stats["iterations"] == o.iterations
+    assert g.stats["fitness"] == o.fitness
+    assert np.array_equal(g.inliers, o.inliers)          # bit-exact inlier index set
+    assert np.allclose(g.params, o.params, rtol=0, atol=PARAM_TOL)
+    if kind == 2:  # cylinder GeneralFit is a no-op: the parameters are the minimal model, bit for bit
+        assert np.array_equal(_bits(g.params), _bits(o.params))
+
+
+def test_fit_with_ties_uses_serial_rmse(capi, orc):
+    """Tiny clouds produce many equal-fitness hypotheses; the tie rule (ransac.h:595-596) needs the
+    serial-order error sum."""
+    rng = np.random.default_rng(0)
+    for trial in range(6):
+        n = 60 + 7 * trial
+        pts = np.c_[rng.uniform(-1, 1, (n, 2)), np.round(rng.normal(0, 0.004, n), 3)]
+        o = orc.fit(0, pts, thr=0.01, max_iter=200, prob=1.0, seed=trial)
+        g = capi.fit(0, pts, threshold=0.01, max_iteration=200, probability=1.0, seed=trial)
+        assert g.stats["best_index"] == o.best_index and g.stats["count"] == o.count
+        assert np.array_equal(g.inliers, o.inliers)
+        assert g.stats["exact_rmse_evals"] > 0
+        if not np.isnan(g.stats["inlier_rmse"]):
+            assert g.stats["inlier_rmse"] == o.inlier_rmse
+
+
+def test_edge_cases(capi, orc):
+    rng = np.random.default_rng(1)
+    # exactly 3 points
+    pts = rng.normal(size=(3, 3))
+    o = orc.fit(0, pts, thr=0.01, max_iter=20, prob=0.9999, seed=1)
+    g = capi.fit(0, pts, threshold=0.01, max_iteration=20, probability=0.9999, seed=1)
+    assert g.ret == o.ret and np.array_equal(g.inliers, o.inliers) and g.stats["count"] == o.count
+    # exact plane: fitness 1 -> immediate stop (ransac.h:607-610)
+    xy = rng.integers(-512, 512, size=(5000, 2)) / 256.0
+    pts = np.c_[xy, np.full(5000, 0.25)]
+    o = orc.fit(0, pts, thr=0.01, max_iter=50, prob=0.9999, seed=1)
+    g = capi.fit(0, pts, threshold=0.01, max_iteration=50, probability=0.9999, seed=1)
+    assert g.stats["count"] == o.count == 1 and g.stats["fitness"] == 1.0
+    assert np.array_equal(g.inliers, np.arange(5000, dtype=np.uint64))
+    # NaN / inf coordinates are never inliers but stay in the cloud
+    pts = synth.plane_cloud_c1(3000, seed=2)
+    pts[5] = np.nan
+    pts[17, 1] = np.inf
+    o = orc.fit(0, pts, thr=0.01, max_iter=100, prob=1.0, seed=2)
+    g = capi.fit(0, pts, threshold=0.01, max_iteration=100, probability=1.0, seed=2)
+    assert g.stats["best_index"] == o.best_index and np.array_equal(g.inliers, o.inliers)
+    # vanishing threshold: no inliers at all -> no best model -> soft failure
+    pts = synth.plane_cloud_c1(2000, seed=3)
+    o = orc.fit(0, pts, thr=1e-300, max_iter=30, prob=1.0, seed=2)
+    g = capi.fit(0, pts, threshold=1e-300, max_iteration=30, probability=1.0, seed=2)
+    assert g.ret == o.ret and g.stats["best_index"] == o.best_index and len(g.inliers) == len(o.inliers)
+    # max_iteration = 0
+    g = capi.fit(0, pts, threshold=0.01, max_iteration=0, probability=0.9, seed=2)
+    assert g.ret == 0 and g.stats["best_index"] == -1 and len(g.inliers) == 0
+
+
+def test_threshold_boundary_decisions(capi, orc):
+    """Points placed within a few ulp of the threshold on both sides: the exact cut-off must make the
+    same decision as the reference's divide-then-compare for every one of them."""
+    rng = np.random.default_rng(4)
+    base = rng.uniform(-1, 1, (4000, 3))
+    base[:, 2] = 0.0
+    thr = 0.01
+    offs = thr * (1.0 + rng.integers(-8, 9, size=4000) * 2.0 ** -52)
+    base[:, 2] = np.where(rng.random(4000) < 0.5, offs, -offs)
+    anchors = np.array([[0.0, 0, 0], [1.0, 0, 0], [0, 1.0, 0]])
+    pts = np.concatenate([anchors, base])
+    samples = np.array([[0, 1, 2]], dtype=np.uint32)
+    with capi.Cloud(pts) as c:
+        valid, models, counts = c.score_range(0, thr, samples)
+        rc, params, inl = c.refine(0, thr, models[0])
+    ov, om, oc, _ = orc.score_samples(0, pts, None, thr, samples.astype(np.uint64))
+    assert counts[0] == oc[0] and 3 < oc[0] < len(pts)
+    d = np.array([orc.distance(0, p, om[0]) for p in pts])
+    assert np.array_equal(inl, np.nonzero(d < thr)[0].astype(np.uint64))
+
+
+def test_segmentation_matches_oracle(capi, orc):
+    rng = np.random.default_rng(5)
+    a = np.c_[rng.uniform(-1, 1, (6000, 2)), rng.normal(0, 2e-3, 6000)]
+    b = np.c_[rng.normal(0, 2e-3, 4000) + 2.0, rng.uniform(-1, 1, (4000, 2))]
+    cpts = np.c_[rng.uniform(-1, 1, 3000), rng.normal(0, 2e-3, 3000) - 1.5, rng.uniform(-1, 1, 3000)]
+    noise = rng.uniform(-3, 3, (800, 3))
+    pts = np.concatenate([a, b, cpts, noise])[rng.permutation(13800)]
+    orc_rc, oplanes, oclusters = orc.segment_plane_iterative(pts, 0.01, max_iteration=100, min_ratio=0.1, seed=3)
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=100, min_ratio=0.1, seed=3)
+    assert orc_rc == 0 and rc == 1
+    assert len(planes) == len(oplanes) >= 3
+    for k in range(len(planes)):
+        assert np.array_equal(clusters[k], oclusters[k])
+        assert np.allclose(planes[k], oplanes[k], rtol=0, atol=PARAM_TOL)
+
+
+def test_full_size_properties(capi):
+    """BASELINE config C2 size (1M points): size-independent properties instead of the oracle."""
+    pts = synth.plane_cloud_c2(1_000_000, seed=2)
+    with capi.Cloud(pts) as c:
+        g = c.fit(0, 0.01, 2000, 1.0, seed=11)
+        assert g.ret == 1 and g.stats["iterations"] == 2000
+        n_in = len(g.inliers)
+        assert n_in == g.stats["n_inliers"] == round(g.stats["fitness"] * len(pts))
+        assert 0.45 * len(pts) < n_in < 0.56 * len(pts)
+        assert np.all(np.diff(g.inliers.astype(np.int64)) > 0)          # ascending, unique
+        # plane A of the generator
+        nA = np.array([0.2, -0.3, 0.93]) / np.linalg.norm([0.2, -0.3, 0.93])
+        s = np.sign(g.params[:3] @ nA)
+        assert np.allclose(s * g.params[:3], nA, atol=2e-3) and abs(s * g.params[3] + 0.5) < 2e-3
+        # idempotence: same seed -> identical result; counts are consistent with refine()
+        g2 = c.fit(0, 0.01, 2000, 1.0, seed=11)
+        assert np.array_equal(g.inliers, g2.inliers) and np.array_equal(_bits(g.params), _bits(g2.params))
+        # per-hypothesis counts are independent of how the range is split (shardable unit)
+        samples = capi.draw_samples(len(pts), 0, 256, seed=11)
+        _, m_all, c_all = c.score_range(0, 0.01, samples)
+        _, m_a, c_a = c.score_range(0, 0.01, samples, 0, 100)
+        _, m_b, c_b = c.score_range(0, 0.01, samples, 100, 256)
+        assert np.array_equal(c_all, np.concatenate([c_a, c_b]))
+        assert np.array_equal(_bits(m_all), _bits(np.concatenate([m_a, m_b])))
+        best = int(np.argmax(c_all))
+        cnt, err = c.exact_error(0, 0.01, m_all[best])
+        assert cnt == int(c_all[best]) and 0 < err < 0.01 * cnt
