@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the Misc3D RANSAC hot path on MI355X.
+
+Metric (BASELINE.json): RANSAC hypotheses/sec (+ inlier-score GB/s) on a 1M-point cloud.
+Workload at N = 1 (BASELINE.json configs[1], "C2"): fit_plane, 1 000 000 points, 10 000
+hypotheses, threshold 0.01, probability 1.0 (every hypothesis is evaluated), sampler seed 11.
+A "step" is one complete FitModel: sample table -> minimal fits -> scoring of all H x N pairs ->
+sequential best-model replay -> RefineModel (inlier list + least-squares plane) -> results on the
+host.  The cloud is resident in HBM before the timed region (m3d_cloud_create).
+
+N > 1 (python -m torch.distributed.run ... bench.py --gpus N): weak scaling, H = 10 000 hypotheses
+per GPU of ONE global table of N x 10 000 (misc3d_amd/distributed.py): contiguous slices, one RCCL
+all-gather of the (valid, count) records, identical replay on every rank.  value = N*H / t.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = score_k<plane>.  `achieved` = ALGORITHMIC bytes (24 B per
+               (hypothesis, point) pair) / average launch duration, measured live with
+               HIP events on the library's stream (m3d_cloud_time_score).  The kernel re-uses every
+               point load for all hypotheses from registers, so this figure exceeds the HBM peak by
+               design; `valu` prices the same launch against the fp64 VALU issue peak, which is the
+               roofline that actually bounds it.  `traffic` = HBM bytes per
+               launch from the rocprofv3 PMC pass committed under profiles/ (null if absent).
+  cpu_baseline the oracle's reference-shaped OpenMP port (oracle/misc3d_oracle.c
+               orc_fit_omp_baseline) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (non-FMA ops; FMA peak 78.6 TF)
+ALG_BYTES_PER_PAIR = 24.0      # one fp64 xyz read per (hypothesis, point), SURVEY.md 8(d)
+VALU_OPS_PER_PAIR = {0: 7, 1: 10, 2: 22}   # fp64 VALU instructions per pair incl. compares (m3d_kernels.hip)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--hyp", type=int, default=10_000, help="hypotheses per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def load_pmc_traffic():
+    """HBM bytes per score_k launch from the committed PMC pass (profiles/pmc_score_latest.json)."""
+    p = os.path.join(ROOT, "profiles", "pmc_score_latest.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(pts, thr, seed, budget_s):
+    import oracle
+    threads = oracle.omp_threads()
+    t0 = time.perf_counter()
+    oracle.fit_omp_baseline(0, pts, None, thr, max(threads, 4), seed)   # calibration
+    dt = time.perf_counter() - t0
+    per_h = dt / max(threads, 4)
+    H = int(max(threads * 2, min(200000, budget_s / max(per_h, 1e-9))))
+    H = (H // threads) * threads or threads
+    t0 = time.perf_counter()
+    model, cnt, bi = oracle.fit_omp_baseline(0, pts, None, thr, H, seed)
+    dt = time.perf_counter() - t0
+    return {"value": H / dt, "unit": "hypotheses/s", "cores": threads, "kind": "port",
+            "sample": f"fit_plane {len(pts)} pts x {H} hypotheses (thr {thr}, seed {seed}), "
+                      f"{dt:.1f} s, OpenMP static schedule over hypotheses, -O3 no -march",
+            "inlier_score_GBps": H * len(pts) * ALG_BYTES_PER_PAIR / dt / 1e9}, (model, cnt, bi, H)
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from misc3d_amd import capi, distributed, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    n_gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    dev = torch.device("cuda", local)
+    kind, thr, prob, seed = capi.PLANE, 0.01, 1.0, 11
+    N, H = a.points, a.hyp
+    pts = synth.plane_cloud_c2(N, seed=2)
+    cloud = capi.Cloud(pts, device=local)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        if world == 1:
+            return cloud.fit(kind, thr, H, prob, seed=seed, copy=False)
+        return distributed.fit_sharded(cloud, N, kind, thr, H * world, prob, seed, device=dev)
+
+    for _ in range(a.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    total_h = H * world
+    value = total_h * a.steps / dt
+
+    out = None
+    if rank == 0:
+        n_in = len(res.inliers)
+        best_index = res.stats["best_index"] if world == 1 else res.best_index
+        # live kernel timing of the dominant kernel (N=1 semantics, this rank's GPU)
+        Hk = min(H, 16384)
+        samples = capi.draw_samples(N, kind, Hk, seed)
+        k_ms = cloud.time_score(kind, thr, samples, reps=10)
+        h_pad = -(-Hk // 64) * 64
+        pairs = float(h_pad) * float(-(-N // 2048) * 2048)
+        alg_bytes = Hk * float(N) * ALG_BYTES_PER_PAIR
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        valu_ops = pairs * VALU_OPS_PER_PAIR[kind]
+        valu_tops = valu_ops / (k_ms * 1e-3) / 1e12
+        traffic = load_pmc_traffic()
+        roofline = {"bound": "hbm", "kernel": "m3d::score_k<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "launch_ms": k_ms, "hypotheses_per_launch": Hk,
+                    "note": "algorithmic bytes = 24 B x H x N; points are loaded once per workgroup and re-used "
+                            "from VGPRs for every hypothesis, so achieved > HBM peak by design; the binding "
+                            "roofline is fp64 VALU issue (see valu)",
+                    "valu": {"achieved": valu_tops, "peak": FP64_VALU_PEAK_TOPS, "unit": "Tinstr-lane/s (fp64 VALU)",
+                             "frac": valu_tops / FP64_VALU_PEAK_TOPS, "ops_per_pair": VALU_OPS_PER_PAIR[kind]}}
+        out = {"metric": "RANSAC hypotheses/sec (fit_plane, 1M-pt cloud)", "value": value, "unit": "hypotheses/s",
+               "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
+               "config": {"workload": "C2 fit_plane", "points": N, "hypotheses_per_gpu": H,
+                          "hypotheses_total": total_h, "threshold": thr, "probability": prob, "sampler_seed": seed,
+                          "parallelism": f"hypothesis-sharded x{world}" if world > 1 else "single GPU"},
+               "inlier_score_GBps": total_h * float(N) * ALG_BYTES_PER_PAIR * a.steps / dt / 1e9,
+               "result": {"best_index": int(best_index), "n_inliers": int(n_in),
+                          "params": [float(v) for v in res.params]},
+               "roofline": roofline}
+        if world == 1:
+            out["timing_breakdown_ms"] = {k: res.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "ms_total")}
+        if world == 1 and not a.no_cpu_baseline:
+            cb, (cmodel, ccnt, cbi, ch) = cpu_baseline(pts, thr, seed, a.cpu_seconds)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = value / cb["value"]
+            # cross-check: the GPU's count for the CPU's best hypothesis
+            s2 = capi.draw_samples(N, kind, ch, seed)
+            _, _, c2 = cloud.score_range(kind, thr, s2, cbi, cbi + 1)
+            out["cpu_baseline"]["parity"] = bool(int(c2[0]) == int(ccnt))
+        print(json.dumps(out), flush=True)
+    barrier()
+    cloud.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

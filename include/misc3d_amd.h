@@ -162,6 +162,12 @@ int m3d_match_mutual_nn(const double *feat_src, size_t n_src, const double *feat
                         int dim, int method, int n_trees, int device, size_t *out_src,
                         size_t *out_dst, size_t *k);
 
+/* ---- measurement hook (bench.py `roofline`): average duration in ms of the scoring kernel alone
+ * (score_k, the dominant kernel) over `reps` launches of `n_hypotheses` hypotheses, timed with HIP
+ * events on the library's own stream after one untimed launch.  Not part of the reference. */
+int m3d_cloud_time_score(m3d_cloud *cloud, int kind, double threshold, const uint32_t *samples,
+                         size_t n_hypotheses, int reps, double *ms_avg);
+
 /* ---- misc -------------------------------------------------------------------------------------- */
 const char *m3d_last_error(void); /* thread-local; reference message text for M3D_ERR_* */
 int m3d_device_count(void);       /* 0 when no HIP device is usable */

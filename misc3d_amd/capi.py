@@ -90,6 +90,8 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_exact_error.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_refine.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_cloud_time_score.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int,
+                                           C.c_void_p]
         L.m3d_draw_samples.argtypes = [C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.c_void_p]
         L.m3d_replay_init.argtypes = [C.c_void_p]
         L.m3d_replay_init.restype = None
@@ -182,16 +184,26 @@ class Cloud:
         self.close()
 
     def fit(self, kind, threshold=0.01, max_iteration=1000, probability=0.9999, seed=None,
-            want_inliers=True) -> Fit:
+            want_inliers=True, copy=True) -> Fit:
+        """m3d_cloud_fit.  copy=False returns a view of a per-Cloud output buffer that the next
+        call overwrites (the C ABI writes into caller-allocated memory; this avoids re-allocating
+        8 bytes x N per call)."""
         params = np.zeros(NUM_PARAMS[kind])
-        inl = np.zeros(max(self.n, 1), dtype=np.uint64) if want_inliers else None
+        inl = None
+        if want_inliers:
+            if getattr(self, "_inl_buf", None) is None:
+                self._inl_buf = np.empty(max(self.n, 1), dtype=np.uint64)
+            inl = self._inl_buf
         ni = C.c_size_t(0)
         st = Stats()
         _s, sref = _seed_ref(seed)
         rc = _check(lib().m3d_cloud_fit(self._h, kind, threshold, max_iteration, probability,
                                         C.cast(sref, C.c_void_p) if sref else None, _p(params), _p(inl),
                                         C.cast(C.byref(ni), C.c_void_p), C.cast(C.byref(st), C.c_void_p)))
-        inliers = inl[: ni.value].copy() if want_inliers else np.zeros(0, dtype=np.uint64)
+        if want_inliers:
+            inliers = inl[: ni.value].copy() if copy else inl[: ni.value]
+        else:
+            inliers = np.zeros(0, dtype=np.uint64)
         d = st.asdict()
         d["n_inliers"] = int(ni.value)
         return Fit(rc, params, inliers, d)
@@ -205,6 +217,14 @@ class Cloud:
         _check(lib().m3d_cloud_score_range(self._h, kind, threshold, _p(samples), begin, end, _p(cnt), _p(val),
                                            _p(mod)))
         return val, mod[:, : NUM_PARAMS[kind]].copy(), cnt
+
+    def time_score(self, kind, threshold, samples, reps=5) -> float:
+        """Average duration (ms) of the scoring kernel alone over `reps` launches (HIP events)."""
+        samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, MINIMAL_SAMPLE[kind])
+        ms = C.c_double(0)
+        _check(lib().m3d_cloud_time_score(self._h, kind, threshold, _p(samples), len(samples), reps,
+                                          C.cast(C.byref(ms), C.c_void_p)))
+        return float(ms.value)
 
     def exact_error(self, kind, threshold, model):
         model = _f64(model)

@@ -245,12 +245,10 @@ struct SampleSource {
 };
 
 static uint32_t pick_splits(uint32_t n_tiles, uint32_t h_pad) {
-    // enough workgroups to fill 256 CUs several times over, while h_pad stays a multiple of 64*s
+    // enough workgroups to fill 256 CUs x 8 resident workgroups a couple of times over
     const uint32_t groups = h_pad / 64;
-    uint32_t want = std::max<uint32_t>(1, (4096 + n_tiles - 1) / n_tiles);
-    want = std::min(want, groups);
-    while (groups % want) --want;
-    return want;
+    const uint32_t want = std::max<uint32_t>(1, (4096 + n_tiles - 1) / n_tiles);
+    return std::min(want, groups);
 }
 
 static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, int kind, double thr,
@@ -480,7 +478,11 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, int kind, double thr, 
     // keep the partial-count buffer below 1 GiB
     size_t chunk_cap = std::min<size_t>(16384, ((size_t)1 << 28) / n_tiles / 64 * 64);
     chunk_cap = std::max<size_t>(chunk_cap, 64);
-    size_t chunk = prob < 1.0 ? 128 : 1024;
+    // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
+    // prob == 1: only fitness == 1 can stop it -> few large chunks (the first one is kept moderate
+    // so the host replay of chunk k overlaps the scoring of chunk k+1)
+    size_t chunk = prob < 1.0 ? 128 : 2048;
+    const size_t growth = prob < 1.0 ? 2 : 4;
     chunk = std::min(chunk, chunk_cap);
 
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -493,7 +495,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, int kind, double thr, 
         if (r == M3D_OK) {
             next_begin = e;
             out->hypotheses_scored += e - b;
-            chunk = std::min(chunk * 2, chunk_cap);
+            chunk = std::min(chunk * growth, chunk_cap);
         }
         return r;
     };
@@ -804,6 +806,38 @@ int m3d_cloud_score_range(m3d_cloud* c, int kind, double threshold, const uint32
             HIPCHK(hipMemcpy(models + (b - begin) * kModelStride, s.params.p,
                              sizeof(double) * kModelStride * (e - b), hipMemcpyDeviceToHost));
     }
+    return M3D_OK;
+}
+
+int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_t* samples,
+                         size_t n_hypotheses, int reps, double* ms_avg) {
+    if (!c || kind < 0 || kind > 2 || !samples || !ms_avg || reps < 1 || n_hypotheses == 0 ||
+        n_hypotheses > 65536)
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (kind == M3D_CYLINDER && !c->has_normals)
+        return fail(M3D_ERR_NO_NORMALS, "Fit cylinder requires normals.");
+    DeviceCtx* ctx = c->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const CloudView v = c->view();
+    SampleSource src;
+    src.table = samples;
+    src.m = minimal_sample(kind);
+    ChunkSlot& s = ctx->slot[0];
+    int rc = issue_chunk(ctx, s, v, kind, threshold, 0, n_hypotheses, src, nullptr);  // warm-up + records
+    if (rc != M3D_OK) return rc;
+    const uint32_t n_tiles = v.n_pad / kScoreTile;
+    const uint32_t splits = pick_splits(n_tiles, s.h_pad);
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r)
+        launch_score(kind, v, s.score.as<double>(), s.h_pad, splits, ctx->partial.as<uint32_t>(),
+                     ctx->stream);
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_avg = (double)ms / reps;
     return M3D_OK;
 }
 

@@ -178,6 +178,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_k(const double* __restrict_
                                                         const double* __restrict__ zs,
                                                         const double* __restrict__ score,
                                                         uint32_t h_pad, uint32_t h_per_split,
+                                                        uint32_t h_end,
                                                         uint32_t* __restrict__ partial) {
     __shared__ uint32_t red[4][64];
     const int lane = threadIdx.x & 63;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_k(const double* __restrict_
         z[j] = zs[base + 64 * j];
     }
     const uint32_t h0 = blockIdx.y * h_per_split;
+    const uint32_t h1 = min(h0 + h_per_split, h_end);  // the last split may be shorter
     // Software prefetch of the next hypothesis record: the scalar loads for hypothesis h+1 are
     // issued before the VALU work of hypothesis h (the score buffer carries one spare record).
     double rec[kModelStride];
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_k(const double* __restrict_
 #pragma unroll
         for (int k = 0; k < kModelStride; ++k) rec[k] = m[k];
     }
-    for (uint32_t hb = h0; hb < h0 + h_per_split; hb += 64) {
+    for (uint32_t hb = h0; hb < h1; hb += 64) {
         uint32_t acc = 0;
         for (uint32_t hh = 0; hh < 64; ++hh) {
             const double* __restrict__ mn = score + (size_t)(hb + hh + 1) * kModelStride;
@@ -248,14 +250,18 @@ __global__ __launch_bounds__(kScoreBlock) void score_k(const double* __restrict_
 void launch_score(int kind, const CloudView& c, const double* score, uint32_t h_pad,
                   uint32_t h_splits, uint32_t* partial, hipStream_t s) {
     if (h_pad == 0 || c.n_pad == 0) return;
-    const dim3 g(c.n_pad / kScoreTile, h_splits), b(kScoreBlock);
-    const uint32_t hps = h_pad / h_splits;
+    // every split takes ceil(groups / splits) groups of 64 hypotheses; the last one may be shorter
+    const uint32_t groups = h_pad / 64;
+    const uint32_t gps = (groups + h_splits - 1) / h_splits;
+    const uint32_t splits = (groups + gps - 1) / gps;
+    const dim3 g(c.n_pad / kScoreTile, splits), b(kScoreBlock);
+    const uint32_t hps = gps * 64;
     if (kind == 0)
-        score_k<0><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, partial);
+        score_k<0><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, h_pad, partial);
     else if (kind == 1)
-        score_k<1><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, partial);
+        score_k<1><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, h_pad, partial);
     else
-        score_k<2><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, partial);
+        score_k<2><<<g, b, 0, s>>>(c.x, c.y, c.z, score, h_pad, hps, h_pad, partial);
 }
 
 // counts[h] += sum over a group of tiles.  Integer atomics: order-independent, exact.

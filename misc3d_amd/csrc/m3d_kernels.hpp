@@ -41,7 +41,8 @@ void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, u
                         hipStream_t s);
 
 // K2: inlier counting.  partial[tile * h_pad + h] = number of points of scoring tile `tile` whose
-// distance to hypothesis h is < thr.  h_pad must be a multiple of 64 * h_splits.
+// distance to hypothesis h is < thr.  h_pad must be a multiple of 64; the hypotheses are cut into
+// (at most) h_splits ranges of whole 64-groups (grid.y).
 void launch_score(int kind, const CloudView& c, const double* score, uint32_t h_pad,
                   uint32_t h_splits, uint32_t* partial, hipStream_t s);
 // counts[h] = sum over tiles of partial[tile][h].  counts must be zero on entry.
