@@ -353,6 +353,10 @@ __global__ __launch_bounds__(1024) void scan_blocks_k(uint32_t* __restrict__ v, 
     if (threadIdx.x == 0) total[0] = carry;
 }
 
+void launch_scan_blocks(uint32_t* v, uint32_t nb, uint32_t* total, hipStream_t s) {
+    scan_blocks_k<<<1, 1024, 0, s>>>(v, nb, total);
+}
+
 template <int KIND, int MODE>
 __global__ __launch_bounds__(256) void compact_write_k(
     CloudView c, const double* __restrict__ model, double thr, const uint32_t* __restrict__ orig,

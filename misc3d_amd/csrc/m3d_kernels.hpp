@@ -73,6 +73,9 @@ void launch_sum_xyz(const CloudView& c, const uint64_t* idx, uint32_t n_idx, dou
 void launch_sum_moments(const CloudView& c, const uint64_t* idx, uint32_t n_idx,
                         const double* sums_xyz, double* partial, double* sums, hipStream_t s);
 
+// exclusive scan of v[0..nb) in place by one workgroup; total[0] = sum
+void launch_scan_blocks(uint32_t* v, uint32_t nb, uint32_t* total, hipStream_t s);
+
 // iota for the original-index array of a segmentation run
 void launch_iota(uint32_t* v, uint32_t n, hipStream_t s);
 

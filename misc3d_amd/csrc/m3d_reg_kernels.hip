@@ -1,0 +1,541 @@
+// m3d_reg_kernels.hip -- gfx950 kernels of the correspondence-registration half of the hot path.
+//
+// Replaces (third-party code reached from src/transform_estimation.cpp:124-164 and
+// src/correspondence_matching.cpp:13-84; algorithms per SURVEY.md 8a rows a17-a20):
+//   kabsch3_check_k   Open3D ComputeTransformation (Eigen::umeyama on 3 pairs) + EdgeLength/Distance checkers
+//   grid_*_k          Open3D KDTreeFlann(target) -> uniform grid (cell = 1.001 * threshold), counting sort
+//   reg_count_k       GetRegistrationResultAndCorrespondences: #source points with a target point at
+//                     squared distance < threshold^2, for every surviving hypothesis
+//   reg_min_d2_k      the same per point (min squared distance) for the serial-order rmse of ONE hypothesis
+//   corr_ratio_k      EvaluateInlierCorrespondenceRatio
+//   kabsch_sums*_k    Eigen::umeyama sums for LeastSquareSolver (n correspondences)
+//   nn_k              ANNMatcher NearestSearch: exact nearest neighbour in descriptor space
+#include "m3d_reg_kernels.hpp"
+
+#include "m3d_reg_fp.hpp"
+
+#pragma clang fp contract(off)
+
+namespace m3d {
+
+// ------------------------------------------------------------------------------------------------
+// K8  3-point Kabsch + checkers, one thread per hypothesis
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kabsch3_check_k(CloudView src, CloudView dst,
+                                                       const uint32_t* __restrict__ corr_src,
+                                                       const uint32_t* __restrict__ corr_dst,
+                                                       const uint32_t* __restrict__ triples,
+                                                       uint32_t h_count, double edge_thr, double dist_thr,
+                                                       double* __restrict__ T12,
+                                                       uint8_t* __restrict__ pass) {
+    const uint32_t h = blockIdx.x * 64u + threadIdx.x;
+    if (h >= h_count) return;
+    double ps[9], pd[9];
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t t = triples[3 * (size_t)h + j];
+        const uint32_t si = corr_src[t], di = corr_dst[t];
+        ps[3 * j] = src.x[si];
+        ps[3 * j + 1] = src.y[si];
+        ps[3 * j + 2] = src.z[si];
+        pd[3 * j] = dst.x[di];
+        pd[3 * j + 1] = dst.y[di];
+        pd[3 * j + 2] = dst.z[di];
+    }
+    double T[16];
+    umeyama3(ps, pd, T);
+    const bool ok = reg_checkers(ps, pd, T, edge_thr, dist_thr);
+    for (int k = 0; k < 12; ++k) T12[(size_t)h * kRegTStride + k] = T[k];
+    pass[h] = ok ? 1 : 0;
+}
+
+void launch_kabsch3_check(const CloudView& src, const CloudView& dst, const uint32_t* corr_src,
+                          const uint32_t* corr_dst, const uint32_t* triples, uint32_t h_count,
+                          double edge_thr, double dist_thr, double* T12, uint8_t* pass, hipStream_t s) {
+    if (!h_count) return;
+    kabsch3_check_k<<<(h_count + 63) / 64, 64, 0, s>>>(src, dst, corr_src, corr_dst, triples, h_count,
+                                                        edge_thr, dist_thr, T12, pass);
+}
+
+// gather the transformations of the surviving hypotheses into a dense array (+1 spare record)
+__global__ void gather_T_k(const double* __restrict__ T12, const uint32_t* __restrict__ list,
+                           uint32_t n, uint32_t n_pad, double* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_pad * kRegTStride) return;
+    const uint32_t s = i / kRegTStride, k = i % kRegTStride;
+    out[i] = s < n ? T12[(size_t)list[s] * kRegTStride + k] : u2f(0x7FF8000000000000ull);
+}
+void launch_gather_T(const double* T12, const uint32_t* list, uint32_t n, uint32_t n_pad, double* out,
+                     hipStream_t s) {
+    if (!n_pad) return;
+    gather_T_k<<<(n_pad * kRegTStride + 255) / 256, 256, 0, s>>>(T12, list, n, n_pad, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// uniform grid over the target cloud (counting sort by cell)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cell_of(const GridDesc& g, double x, double y, double z, int lo_pad,
+                                        int* ix, int* iy, int* iz) {
+    const double fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
+    // valid query cells are [lo_pad, n - 1 - lo_pad]; NaN fails every comparison
+    if (!(fx >= (double)lo_pad && fx < (double)(g.nx - lo_pad) && fy >= (double)lo_pad &&
+          fy < (double)(g.ny - lo_pad) && fz >= (double)lo_pad && fz < (double)(g.nz - lo_pad)))
+        return false;
+    *ix = (int)fx;
+    *iy = (int)fy;
+    *iz = (int)fz;
+    return true;
+}
+
+__global__ void grid_count_k(CloudView dst, GridDesc g, uint32_t* __restrict__ cell_of_point,
+                             uint32_t* __restrict__ hist) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= dst.n) return;
+    int ix, iy, iz;
+    uint32_t cid = 0xFFFFFFFFu;  // points with NaN/inf coordinates are left out of the grid
+    if (cell_of(g, dst.x[i], dst.y[i], dst.z[i], 0, &ix, &iy, &iz)) {
+        cid = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
+        atomicAdd(&hist[cid], 1u);
+    }
+    cell_of_point[i] = cid;
+}
+
+// exclusive scan, tile of 2048 per workgroup; tile totals go to tile_sums
+__global__ __launch_bounds__(256) void tile_scan_k(uint32_t* __restrict__ v, uint32_t n,
+                                                    uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * 2048u + threadIdx.x * 8u;
+    uint32_t e[8];
+    uint32_t s = 0;
+    for (int k = 0; k < 8; ++k) {
+        e[k] = base + k < n ? v[base + k] : 0u;
+        s += e[k];
+    }
+    // wave inclusive scan of s
+    uint32_t incl = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    uint32_t run = woff + incl - s;
+    for (int k = 0; k < 8; ++k) {
+        if (base + k < n) v[base + k] = run;
+        run += e[k];
+    }
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = woff + incl;
+}
+__global__ void add_tile_offsets_k(uint32_t* __restrict__ v, uint32_t n, const uint32_t* __restrict__ tile_off,
+                                   const uint32_t* __restrict__ total) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) v[i] += tile_off[i / 2048u];
+    if (i == n) v[n] = total[0];
+}
+
+__global__ void grid_scatter_k(CloudView dst, const uint32_t* __restrict__ cell_of_point,
+                               const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ fill,
+                               double* __restrict__ qx, double* __restrict__ qy, double* __restrict__ qz) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= dst.n) return;
+    const uint32_t cid = cell_of_point[i];
+    if (cid == 0xFFFFFFFFu) return;
+    const uint32_t pos = cell_start[cid] + atomicAdd(&fill[cid], 1u);
+    qx[pos] = dst.x[i];
+    qy[pos] = dst.y[i];
+    qz[pos] = dst.z[i];
+}
+
+void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
+                       uint32_t* cell_start /* ncell + 1 */, uint32_t* fill /* ncell */,
+                       uint32_t* tile_sums, uint32_t* total, double* qx, double* qy, double* qz,
+                       hipStream_t s) {
+    const uint32_t ncell = g.nx * g.ny * g.nz;
+    (void)hipMemsetAsync(cell_start, 0, sizeof(uint32_t) * ((size_t)ncell + 1), s);
+    (void)hipMemsetAsync(fill, 0, sizeof(uint32_t) * (size_t)ncell, s);
+    if (dst.n) grid_count_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, g, cell_of_point, cell_start);
+    const uint32_t nt = (ncell + 2047) / 2048;
+    tile_scan_k<<<nt, 256, 0, s>>>(cell_start, ncell, tile_sums);
+    launch_scan_blocks(tile_sums, nt, total, s);
+    add_tile_offsets_k<<<(ncell + 1 + 255) / 256, 256, 0, s>>>(cell_start, ncell, tile_sums, total);
+    if (dst.n) grid_scatter_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, cell_of_point, cell_start, fill, qx, qy, qz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9  validation counts
+// ------------------------------------------------------------------------------------------------
+// Does a target point at squared distance < r2 exist?  (SearchHybrid(p, r, 1) > 0: nearest
+// neighbour kept iff dist^2 < r*r.)  The 3 x-adjacent cells of a (y,z) row are contiguous in the
+// sorted arrays, so the 27-cell neighbourhood is 9 ranges.
+__device__ __forceinline__ bool has_neighbour(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                              const double* __restrict__ qx, const double* __restrict__ qy,
+                                              const double* __restrict__ qz, double px, double py, double pz) {
+    int ix, iy, iz;
+    if (!cell_of(g, px, py, pz, 1, &ix, &iy, &iz)) return false;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
+            const uint32_t b = cell_start[row - 1], e = cell_start[row + 2];
+            for (uint32_t c = b; c < e; ++c) {
+                const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
+                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                if (d2 < g.r2) return true;
+            }
+        }
+    return false;
+}
+__device__ __forceinline__ double min_d2(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                         const double* __restrict__ qx, const double* __restrict__ qy,
+                                         const double* __restrict__ qz, double px, double py, double pz) {
+    int ix, iy, iz;
+    double best = INFINITY;
+    if (!cell_of(g, px, py, pz, 1, &ix, &iy, &iz)) return best;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
+            const uint32_t b = cell_start[row - 1], e = cell_start[row + 2];
+            for (uint32_t c = b; c < e; ++c) {
+                const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
+                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                if (d2 < best) best = d2;
+            }
+        }
+    return best;
+}
+
+// Same decomposition as score_k: source points stay in VGPRs (kRegP rows of 64 per wave), the
+// transformations of the surviving hypotheses stream through SGPRs, counts via ballot + s_bcnt1.
+__global__ __launch_bounds__(256) void reg_count_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                    const double* __restrict__ sz, const double* __restrict__ Ts,
+                                                    uint32_t s_pad, uint32_t s_per_split, GridDesc g,
+                                                    const uint32_t* __restrict__ cell_start,
+                                                    const double* __restrict__ qx, const double* __restrict__ qy,
+                                                    const double* __restrict__ qz,
+                                                    uint32_t* __restrict__ partial) {
+    __shared__ uint32_t red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t base = (size_t)blockIdx.x * kRegTile + (size_t)wave * (64 * kRegP) + lane;
+    double x[kRegP], y[kRegP], z[kRegP];
+#pragma unroll
+    for (int j = 0; j < kRegP; ++j) {
+        x[j] = sx[base + 64 * j];
+        y[j] = sy[base + 64 * j];
+        z[j] = sz[base + 64 * j];
+    }
+    const uint32_t s0 = blockIdx.y * s_per_split;
+    const uint32_t s1 = min(s0 + s_per_split, s_pad);
+    for (uint32_t sb = s0; sb < s1; sb += 64) {
+        uint32_t acc = 0;
+        for (uint32_t ss = 0; ss < 64; ++ss) {
+            const double* __restrict__ T = Ts + (size_t)(sb + ss) * kRegTStride;
+            double t[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) t[k] = T[k];
+            uint32_t cnt = 0;
+            if (t[0] == t[0]) {  // padding records are NaN (wave-uniform branch)
+#pragma unroll
+                for (int j = 0; j < kRegP; ++j) {
+                    const double px = ((t[0] * x[j] + t[1] * y[j]) + t[2] * z[j]) + t[3];
+                    const double py = ((t[4] * x[j] + t[5] * y[j]) + t[6] * z[j]) + t[7];
+                    const double pz = ((t[8] * x[j] + t[9] * y[j]) + t[10] * z[j]) + t[11];
+                    const bool f = has_neighbour(g, cell_start, qx, qy, qz, px, py, pz);
+                    cnt += (uint32_t)__popcll(__ballot(f));
+                }
+            }
+            acc = ((uint32_t)lane == ss) ? cnt : acc;
+        }
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0)
+            partial[(size_t)blockIdx.x * s_pad + sb + lane] =
+                (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        __syncthreads();
+    }
+}
+
+void launch_reg_count(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t splits,
+                      const GridDesc& g, const uint32_t* cell_start, const double* qx, const double* qy,
+                      const double* qz, uint32_t* partial, hipStream_t s) {
+    if (!s_pad || !src.n_pad) return;
+    const uint32_t groups = s_pad / 64;
+    const uint32_t gps = (groups + splits - 1) / splits;
+    const uint32_t nsplit = (groups + gps - 1) / gps;
+    const dim3 grid(src.n_pad / kRegTile, nsplit), block(256);
+    reg_count_k<<<grid, block, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy, qz,
+                                       partial);
+}
+
+// per-point nearest squared distance for ONE transformation (device pointer to 12 doubles)
+__global__ void reg_min_d2_k(CloudView src, const double* __restrict__ T, GridDesc g,
+                             const uint32_t* __restrict__ cell_start, const double* __restrict__ qx,
+                             const double* __restrict__ qy, const double* __restrict__ qz,
+                             double* __restrict__ best) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= src.n) return;
+    double t[12];
+    for (int k = 0; k < 12; ++k) t[k] = T[k];
+    const double x = src.x[i], y = src.y[i], z = src.z[i];
+    const double px = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
+    const double py = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
+    const double pz = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
+    best[i] = min_d2(g, cell_start, qx, qy, qz, px, py, pz);
+}
+void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
+                       const double* qx, const double* qy, const double* qz, double* best, hipStream_t s) {
+    if (src.n) reg_min_d2_k<<<(src.n + 255) / 256, 256, 0, s>>>(src, T, g, cell_start, qx, qy, qz, best);
+}
+
+// ordered compaction of the values < limit (3 passes, same structure as compact_*_k)
+__global__ __launch_bounds__(256) void vals_count_k(const double* __restrict__ v, uint32_t n, double limit,
+                                                     uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t cnt = 0;
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t i = blockIdx.x * 2048u + r * 256u + threadIdx.x;
+        const bool f = i < n && v[i] < limit;
+        cnt += (uint32_t)__popcll(__ballot(f));
+    }
+    if (lane == 0) wsum[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ __launch_bounds__(256) void vals_write_k(const double* __restrict__ v, uint32_t n, double limit,
+                                                     const uint32_t* __restrict__ block_offsets,
+                                                     double* __restrict__ out) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t row_base = block_offsets[blockIdx.x];
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t i = blockIdx.x * 2048u + r * 256u + threadIdx.x;
+        const double val = i < n ? v[i] : 0.0;
+        const bool f = i < n && val < limit;
+        const unsigned long long b = __ballot(f);
+        const uint32_t lane_pre = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t rowtot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (f) out[row_base + woff + lane_pre] = val;
+        row_base += rowtot;
+        __syncthreads();
+    }
+}
+void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* block_counts, uint32_t* total,
+                         double* out, hipStream_t s) {
+    const uint32_t nb = (n + 2047) / 2048;
+    if (!nb) {
+        (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+        return;
+    }
+    vals_count_k<<<nb, 256, 0, s>>>(v, n, limit, block_counts);
+    launch_scan_blocks(block_counts, nb, total, s);
+    vals_write_k<<<nb, 256, 0, s>>>(v, n, limit, block_counts, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10  inlier ratio of the correspondence set
+// ------------------------------------------------------------------------------------------------
+__global__ void corr_ratio_k(CloudView src, CloudView dst, const uint32_t* __restrict__ corr_src,
+                             const uint32_t* __restrict__ corr_dst, uint32_t m, const double* __restrict__ T,
+                             double r2, uint32_t* __restrict__ count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool f = false;
+    if (i < m) {
+        double t[12];
+        for (int k = 0; k < 12; ++k) t[k] = T[k];
+        const uint32_t si = corr_src[i], di = corr_dst[i];
+        const double x = src.x[si], y = src.y[si], z = src.z[si];
+        const double px = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
+        const double py = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
+        const double pz = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
+        const double ddx = px - dst.x[di], ddy = py - dst.y[di], ddz = pz - dst.z[di];
+        f = ((ddx * ddx + ddy * ddy) + ddz * ddz) < r2;
+    }
+    const uint32_t c = (uint32_t)__popcll(__ballot(f));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+void launch_corr_ratio(const CloudView& src, const CloudView& dst, const uint32_t* corr_src,
+                       const uint32_t* corr_dst, uint32_t m, const double* T, double r2, uint32_t* count,
+                       hipStream_t s) {
+    (void)hipMemsetAsync(count, 0, sizeof(uint32_t), s);
+    if (m) corr_ratio_k<<<(m + 255) / 256, 256, 0, s>>>(src, dst, corr_src, corr_dst, m, T, r2, count);
+}
+
+// ------------------------------------------------------------------------------------------------
+// umeyama sums for n correspondences (LeastSquareSolver): AoS inputs, fixed two-level tree
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void tree_reduce_256(double (&acc)[NV], double* sm) {
+    for (int k = 0; k < NV; ++k) sm[k * 256 + threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < NV; ++k) sm[k * 256 + threadIdx.x] += sm[k * 256 + threadIdx.x + off];
+        __syncthreads();
+    }
+}
+// pass 0: sums of src and dst coordinates (6 values); pass 1: with means -> 9 covariance + 3 variance
+template <int PASS>
+__global__ __launch_bounds__(256) void kabsch_sums_k(const double* __restrict__ src,
+                                                      const double* __restrict__ dst, uint32_t n,
+                                                      const double* __restrict__ sums0,
+                                                      double* __restrict__ partial) {
+    constexpr int NV = PASS == 0 ? 6 : 12;
+    __shared__ double sm[NV * 256];
+    double acc[NV];
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    double ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+    if (PASS == 1) {
+        const double one_over_n = 1.0 / (double)n;
+        for (int k = 0; k < 3; ++k) {
+            ms[k] = sums0[k] * one_over_n;
+            md[k] = sums0[3 + k] * one_over_n;
+        }
+    }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += 256u * 256u) {
+        double s[3], d[3];
+        for (int k = 0; k < 3; ++k) {
+            s[k] = src[3 * (size_t)i + k];
+            d[k] = dst[3 * (size_t)i + k];
+        }
+        if (PASS == 0) {
+            for (int k = 0; k < 3; ++k) {
+                acc[k] += s[k];
+                acc[3 + k] += d[k];
+            }
+        } else {
+            for (int k = 0; k < 3; ++k) {
+                s[k] -= ms[k];
+                d[k] -= md[k];
+            }
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) acc[3 * r + c] += d[r] * s[c];
+                acc[9 + r] += s[r] * s[r];
+            }
+        }
+    }
+    tree_reduce_256<NV>(acc, sm);
+    if (threadIdx.x < NV) partial[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
+}
+template <int NV>
+__global__ __launch_bounds__(256) void kabsch_final_k(const double* __restrict__ partial,
+                                                       double* __restrict__ sums) {
+    __shared__ double sm[NV * 256];
+    double acc[NV];
+    for (int k = 0; k < NV; ++k) acc[k] = partial[threadIdx.x * 16 + k];
+    tree_reduce_256<NV>(acc, sm);
+    if (threadIdx.x < NV) sums[threadIdx.x] = sm[threadIdx.x * 256];
+}
+void launch_kabsch_sums(const double* src, const double* dst, uint32_t n, double* partial,
+                        double* sums /* 6 + 12 */, hipStream_t s) {
+    kabsch_sums_k<0><<<256, 256, 0, s>>>(src, dst, n, nullptr, partial);
+    kabsch_final_k<6><<<1, 256, 0, s>>>(partial, sums);
+    kabsch_sums_k<1><<<256, 256, 0, s>>>(src, dst, n, sums, partial);
+    kabsch_final_k<12><<<1, 256, 0, s>>>(partial, sums + 6);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11  exact nearest neighbour in descriptor space (mutual-NN matcher)
+// ------------------------------------------------------------------------------------------------
+// One query per lane, its DIM coordinates in VGPRs; database descriptors are wave-uniform and come
+// in through scalar loads.  Squared L2 accumulated in dimension order, one rounding per product and
+// per sum (nanoflann L2_Simple_Adaptor order), strict `<` while scanning ascending indices keeps the
+// lowest index among equal distances.  blockIdx.y splits the database; nn_merge_k merges the splits.
+template <int DIM>
+__global__ __launch_bounds__(256) void nn_k(const double* __restrict__ q, uint32_t nq,
+                                             const double* __restrict__ db, uint32_t ndb,
+                                             uint32_t db_per_split, double* __restrict__ best_d,
+                                             uint32_t* __restrict__ best_i) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    double qv[DIM];
+    const uint32_t ii = i < nq ? i : (nq - 1);
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) qv[k] = q[(size_t)ii * DIM + k];
+    const uint32_t j0 = blockIdx.y * db_per_split;
+    const uint32_t j1 = min(ndb, j0 + db_per_split);
+    double bd = INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const double* __restrict__ d = db + (size_t)j * DIM;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            const double df = qv[k] - d[k];
+            acc += df * df;
+        }
+        if (acc < bd) {
+            bd = acc;
+            bi = j;
+        }
+    }
+    if (i < nq) {
+        best_d[(size_t)blockIdx.y * nq + i] = bd;
+        best_i[(size_t)blockIdx.y * nq + i] = bi;
+    }
+}
+// generic dimension: query row staged per lane in LDS (slower; FPFH's 33 uses the template above)
+__global__ __launch_bounds__(64) void nn_generic_k(const double* __restrict__ q, uint32_t nq,
+                                                    const double* __restrict__ db, uint32_t ndb, int dim,
+                                                    uint32_t db_per_split, double* __restrict__ best_d,
+                                                    uint32_t* __restrict__ best_i) {
+    extern __shared__ double qs[];  // dim x 64, column per lane
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t ii = i < nq ? i : (nq - 1);
+    for (int k = 0; k < dim; ++k) qs[k * 64 + threadIdx.x] = q[(size_t)ii * dim + k];
+    const uint32_t j0 = blockIdx.y * db_per_split;
+    const uint32_t j1 = min(ndb, j0 + db_per_split);
+    double bd = INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const double* __restrict__ d = db + (size_t)j * dim;
+        double acc = 0.0;
+        for (int k = 0; k < dim; ++k) {
+            const double df = qs[k * 64 + threadIdx.x] - d[k];
+            acc += df * df;
+        }
+        if (acc < bd) {
+            bd = acc;
+            bi = j;
+        }
+    }
+    if (i < nq) {
+        best_d[(size_t)blockIdx.y * nq + i] = bd;
+        best_i[(size_t)blockIdx.y * nq + i] = bi;
+    }
+}
+__global__ void nn_merge_k(const double* __restrict__ best_d, const uint32_t* __restrict__ best_i,
+                           uint32_t nq, uint32_t splits, uint32_t* __restrict__ nn) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nq) return;
+    double bd = INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t s = 0; s < splits; ++s) {  // ascending index ranges: strict < keeps the lowest index
+        const double d = best_d[(size_t)s * nq + i];
+        if (d < bd) {
+            bd = d;
+            bi = best_i[(size_t)s * nq + i];
+        }
+    }
+    nn[i] = bi;
+}
+
+void launch_nn(const double* q, uint32_t nq, const double* db, uint32_t ndb, int dim, uint32_t splits,
+               double* best_d, uint32_t* best_i, uint32_t* nn, hipStream_t s) {
+    if (!nq) return;
+    const uint32_t per = (ndb + splits - 1) / splits;
+    if (dim == 33) {
+        nn_k<33><<<dim3((nq + 255) / 256, splits), 256, 0, s>>>(q, nq, db, ndb, per, best_d, best_i);
+    } else if (dim == 3) {
+        nn_k<3><<<dim3((nq + 255) / 256, splits), 256, 0, s>>>(q, nq, db, ndb, per, best_d, best_i);
+    } else {
+        nn_generic_k<<<dim3((nq + 63) / 64, splits), 64, sizeof(double) * 64 * dim, s>>>(q, nq, db, ndb, dim, per,
+                                                                                      best_d, best_i);
+    }
+    nn_merge_k<<<(nq + 255) / 256, 256, 0, s>>>(best_d, best_i, nq, splits, nn);
+}
+
+}  // namespace m3d

@@ -1,0 +1,44 @@
+// m3d_reg_kernels.hpp -- launch interface of the registration kernels (m3d_reg_kernels.hip).
+#pragma once
+#include "m3d_kernels.hpp"
+
+namespace m3d {
+
+constexpr int kRegTStride = 12;  // doubles per transformation record (rows 0..2 of the 4x4)
+constexpr int kRegP = 4;         // source points per lane in reg_count_k
+constexpr int kRegTile = 256 * kRegP;
+
+// Uniform grid over the target cloud.  Cell edge h = 1.001 * threshold, origin two cells below the
+// bounding-box minimum, two empty cells above the maximum, so the 3x3x3 neighbourhood of any query
+// cell in [1, n-2] stays inside the arrays and covers every target point closer than threshold.
+struct GridDesc {
+    double ox, oy, oz, inv_h, r2;
+    uint32_t nx, ny, nz;
+};
+
+
+
+void launch_kabsch3_check(const CloudView& src, const CloudView& dst, const uint32_t* corr_src,
+                          const uint32_t* corr_dst, const uint32_t* triples, uint32_t h_count,
+                          double edge_thr, double dist_thr, double* T12, uint8_t* pass, hipStream_t s);
+void launch_gather_T(const double* T12, const uint32_t* list, uint32_t n, uint32_t n_pad, double* out,
+                     hipStream_t s);
+void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
+                       uint32_t* cell_start, uint32_t* fill, uint32_t* tile_sums, uint32_t* total,
+                       double* qx, double* qy, double* qz, hipStream_t s);
+void launch_reg_count(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t splits,
+                      const GridDesc& g, const uint32_t* cell_start, const double* qx, const double* qy,
+                      const double* qz, uint32_t* partial, hipStream_t s);
+void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
+                       const double* qx, const double* qy, const double* qz, double* best, hipStream_t s);
+void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* block_counts, uint32_t* total,
+                         double* out, hipStream_t s);
+void launch_corr_ratio(const CloudView& src, const CloudView& dst, const uint32_t* corr_src,
+                       const uint32_t* corr_dst, uint32_t m, const double* T, double r2, uint32_t* count,
+                       hipStream_t s);
+void launch_kabsch_sums(const double* src, const double* dst, uint32_t n, double* partial, double* sums,
+                        hipStream_t s);
+void launch_nn(const double* q, uint32_t nq, const double* db, uint32_t ndb, int dim, uint32_t splits,
+               double* best_d, uint32_t* best_i, uint32_t* nn, hipStream_t s);
+
+}  // namespace m3d

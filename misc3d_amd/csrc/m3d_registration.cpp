@@ -1,20 +1,502 @@
-// m3d_registration.cpp -- registration entry points (placeholder until the kernels land).
+// m3d_registration.cpp -- host drivers of the registration entry points of the C ABI.
+//
+//   m3d_kabsch               registration::LeastSquareSolver::Solve   src/transform_estimation.cpp:49-66
+//   m3d_registration_ransac  registration::RANSACSolver::Solve        src/transform_estimation.cpp:124-164
+//                            (= Open3D 0.15.1 RegistrationRANSACBasedOnCorrespondence)
+//   m3d_match_mutual_nn      registration::ANNMatcher::Match          src/correspondence_matching.cpp:52-84
+//
+// Sequential (one-thread) semantics of the Open3D loop with an explicit seed: iteration `itr` draws
+// three correspondences from std::uniform_int_distribution<int>(0, M-1) on std::mt19937 iff
+// itr < est_k_global; 3-point umeyama; EdgeLength + Distance checkers; survivors are validated
+// against the whole source cloud (fitness = #points with a target neighbour closer than threshold);
+// best = (fitness, then rmse); every improvement re-estimates est_k from the inlier ratio of the
+// correspondence set.  The data-parallel parts run on the GPU in chunks of iterations; the host
+// replays the sequential rule over each chunk in index order.
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <vector>
+
 #include "m3d_driver.hpp"
+#include "m3d_reg_fp.hpp"
+#include "m3d_reg_kernels.hpp"
+
+#pragma clang fp contract(off)
 
 using namespace m3d;
 
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(M3D_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define RESERVE(buf, bytes)                               \
+    do {                                                  \
+        if (!(buf).reserve(bytes)) return M3D_ERR_DEVICE; \
+    } while (0)
+
+namespace {
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// static_cast<int>(std::ceil(v)) as the x86-64 conversion behaves (cvttsd2si -> INT_MIN when out of range)
+int ceil_to_int_x86(double v) {
+    const double c = std::ceil(v);
+    if (!(c > -2147483649.0) || !(c < 2147483648.0)) return INT_MIN;
+    return (int)c;
+}
+
+struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
+    DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
+        tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio;
+    void release() {
+        for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
+                          &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
+                          &block_counts, &sums, &one_T, &ratio})
+            b->release();
+    }
+};
+
+struct RegCtx {
+    DeviceCtx* ctx;
+    CloudView src, dst;
+    GridDesc g;
+    Scratch* s;
+    uint32_t m;
+    double thr;
+};
+
+// serial-order sum of the nearest squared distances below r^2 (GetRegistrationResult... error2)
+int exact_err2(RegCtx& rc, const double* T_dev, uint64_t* count, double* err2) {
+    DeviceCtx* ctx = rc.ctx;
+    Scratch& s = *rc.s;
+    const uint32_t n = rc.src.n;
+    const uint32_t nb = (n + 2047) / 2048;
+    RESERVE(s.best, sizeof(double) * std::max<uint32_t>(n, 1));
+    RESERVE(s.vals, sizeof(double) * std::max<uint32_t>(n, 1));
+    RESERVE(s.block_counts, sizeof(uint32_t) * ((size_t)nb + 1));
+    RESERVE(s.total, 16);
+    RESERVE(s.sums, sizeof(double) * 4);
+    RESERVE(ctx->h_small, 256);
+    launch_reg_min_d2(rc.src, T_dev, rc.g, s.cell_start.as<uint32_t>(), s.qx.as<double>(), s.qy.as<double>(),
+                      s.qz.as<double>(), s.best.as<double>(), ctx->stream);
+    launch_compact_vals(s.best.as<double>(), n, rc.g.r2, s.block_counts.as<uint32_t>(), s.total.as<uint32_t>(),
+                        s.vals.as<double>(), ctx->stream);
+    launch_serial_sum(s.vals.as<double>(), s.total.as<uint32_t>(), s.sums.as<double>(), ctx->stream);
+    uint8_t* h = ctx->h_small.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(h, s.total.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h + 8, s.sums.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t c;
+    std::memcpy(&c, h, 4);
+    std::memcpy(err2, h + 8, 8);
+    *count = c;
+    return M3D_OK;
+}
+
+int corr_inlier_ratio(RegCtx& rc, const double* T_dev, double* ratio) {
+    DeviceCtx* ctx = rc.ctx;
+    Scratch& s = *rc.s;
+    RESERVE(s.ratio, 16);
+    RESERVE(ctx->h_small, 256);
+    launch_corr_ratio(rc.src, rc.dst, s.corr_src.as<uint32_t>(), s.corr_dst.as<uint32_t>(), rc.m, T_dev,
+                      rc.g.r2, s.ratio.as<uint32_t>(), ctx->stream);
+    HIPCHK(hipMemcpyAsync(ctx->h_small.p, s.ratio.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t c;
+    std::memcpy(&c, ctx->h_small.p, 4);
+    *ratio = (double)c / (double)rc.m;
+    return M3D_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
-int m3d_kabsch(const double*, const double*, size_t, int, int, double*) {
-    return fail(M3D_ERR_INTERNAL, "m3d_kabsch: not implemented yet");
+int m3d_kabsch(const double* src, const double* dst, size_t n, int scaling, int device, double* T) {
+    if (!T || ((!src || !dst) && n)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (n < 3)  // CheckValid, transform_estimation.cpp:27-31
+        return fail(M3D_ERR_TOO_FEW_POINTS, "The number of points pair is less than 3.");
+    if (n >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
+    DeviceCtx* ctx = get_ctx(device);
+    if (!ctx) return M3D_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf ds, dd, partial, sums;
+    int rc = M3D_OK;
+    auto done = [&](int r) {
+        ds.release(); dd.release(); partial.release(); sums.release();
+        return r;
+    };
+    if (!ds.reserve(sizeof(double) * 3 * n) || !dd.reserve(sizeof(double) * 3 * n) ||
+        !partial.reserve(sizeof(double) * 256 * 16) || !sums.reserve(sizeof(double) * 32) ||
+        !ctx->h_small.reserve(256))
+        return done(M3D_ERR_DEVICE);
+    bool ok = hipMemcpyAsync(ds.p, src, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+              hipMemcpyAsync(dd.p, dst, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    if (ok) {
+        launch_kabsch_sums(ds.as<double>(), dd.as<double>(), (uint32_t)n, partial.as<double>(), sums.as<double>(),
+                           ctx->stream);
+        ok = hipMemcpyAsync(ctx->h_small.p, sums.p, sizeof(double) * 18, hipMemcpyDeviceToHost, ctx->stream) ==
+                 hipSuccess &&
+             hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (!ok) return done(fail(M3D_ERR_DEVICE, "m3d_kabsch: HIP error"));
+    double h[18];
+    std::memcpy(h, ctx->h_small.p, sizeof(h));
+    // Eigen::umeyama: means, sigma = (1/n) sum d s^T, src_var = (1/n) sum |s|^2
+    const double one_over_n = 1.0 / (double)n;
+    double ms[3], md[3], sig[9];
+    for (int k = 0; k < 3; ++k) {
+        ms[k] = h[k] * one_over_n;
+        md[k] = h[3 + k] * one_over_n;
+    }
+    for (int k = 0; k < 9; ++k) sig[k] = h[6 + k] * one_over_n;
+    const double src_var = ((h[15] + h[16]) + h[17]) * one_over_n;
+    umeyama_assemble(ms, md, sig, src_var, scaling != 0, T);
+    return done(rc);
 }
-int m3d_registration_ransac(const double*, size_t, const double*, size_t, const size_t*, const size_t*,
-                            size_t, double, int, double, double, const uint64_t*, int, double*,
-                            m3d_reg_stats*) {
-    return fail(M3D_ERR_INTERNAL, "m3d_registration_ransac: not implemented yet");
+
+int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, size_t n_dst,
+                            const size_t* corr_src, const size_t* corr_dst, size_t m, double threshold,
+                            int max_iter, double edge_length_threshold, double confidence,
+                            const uint64_t* seed, int device, double* T_out, m3d_reg_stats* stats) {
+    const double t_begin = now_ms();
+    if (!T_out || ((!src && n_src) || (!dst && n_dst)) || (m && (!corr_src || !corr_dst)))
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(T_out, I4, sizeof(I4));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->best_index = -1;
+    }
+    if (n_src < 3 || n_dst < 3)  // transform_estimation.cpp:130-133
+        return fail(M3D_ERR_TOO_FEW_POINTS, "The number of points pair is less than 3.");
+    if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31) || m >= ((size_t)1 << 31))
+        return fail(M3D_ERR_INVALID_ARG, "too many points");
+    for (size_t i = 0; i < m; ++i)
+        if (corr_src[i] >= n_src || corr_dst[i] >= n_dst)
+            return fail(M3D_ERR_INVALID_ARG, "correspondence index out of range");
+    // Open3D: ransac_n < 3 || corres.size() < ransac_n || max_correspondence_distance <= 0 -> RegistrationResult()
+    if (m < 3 || !(threshold > 0.0)) return M3D_OK;
+
+    m3d_cloud* csrc = m3d_cloud_create(src, nullptr, n_src, device);
+    if (!csrc) return M3D_ERR_DEVICE;
+    m3d_cloud* cdst = m3d_cloud_create(dst, nullptr, n_dst, device);
+    if (!cdst) {
+        m3d_cloud_destroy(csrc);
+        return M3D_ERR_DEVICE;
+    }
+    DeviceCtx* ctx = csrc->ctx;
+    Scratch S;
+    int rc = M3D_OK;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        rc = [&]() -> int {
+            HIPCHK(hipSetDevice(ctx->device));
+            RegCtx R;
+            R.ctx = ctx;
+            R.src = csrc->view();
+            // the count kernel reads whole tiles of kRegTile points: the cloud padding (kScoreTile) covers it
+            static_assert(kScoreTile % kRegTile == 0, "padding of resident clouds must cover the reg tiles");
+            R.dst = cdst->view();
+            R.s = &S;
+            R.m = (uint32_t)m;
+            R.thr = threshold;
+
+            // ---- grid over the target (bounding box on the host: one pass over n_dst points)
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t i = 0; i < n_dst; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    const double v = dst[3 * i + k];
+                    if (std::isfinite(v)) {
+                        lo[k] = std::min(lo[k], v);
+                        hi[k] = std::max(hi[k], v);
+                    }
+                }
+            for (int k = 0; k < 3; ++k)
+                if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;
+            double h = threshold * 1.001;
+            uint64_t dims[3];
+            for (;;) {  // coarsen until the dense cell table fits (a coarser grid still covers radius thr)
+                bool fits = true;
+                uint64_t cells = 1;
+                for (int k = 0; k < 3; ++k) {
+                    const double ext = (hi[k] - lo[k]) / h;
+                    if (!(ext < 1e9)) {
+                        fits = false;
+                        break;
+                    }
+                    dims[k] = (uint64_t)ext + 1 + 4;
+                    cells *= dims[k];
+                    if (cells > ((uint64_t)1 << 27)) fits = false;
+                }
+                if (fits) break;
+                h *= 2.0;
+            }
+            GridDesc g;
+            g.ox = lo[0] - 2.0 * h;
+            g.oy = lo[1] - 2.0 * h;
+            g.oz = lo[2] - 2.0 * h;
+            g.inv_h = 1.0 / h;
+            g.r2 = threshold * threshold;  // radius * radius, KDTreeFlann::SearchHybrid
+            g.nx = (uint32_t)dims[0];
+            g.ny = (uint32_t)dims[1];
+            g.nz = (uint32_t)dims[2];
+            R.g = g;
+            const uint32_t ncell = g.nx * g.ny * g.nz;
+            RESERVE(S.cell_of_point, sizeof(uint32_t) * n_dst);
+            RESERVE(S.cell_start, sizeof(uint32_t) * ((size_t)ncell + 1));
+            RESERVE(S.fill, sizeof(uint32_t) * (size_t)ncell);
+            RESERVE(S.tile_sums, sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1));
+            RESERVE(S.total, 16);
+            RESERVE(S.qx, sizeof(double) * n_dst);
+            RESERVE(S.qy, sizeof(double) * n_dst);
+            RESERVE(S.qz, sizeof(double) * n_dst);
+            launch_grid_build(R.dst, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
+                              S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
+                              S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream);
+
+            // ---- correspondences (CorrespondenceSet of Vector2i, transform_estimation.cpp:135-140)
+            std::vector<uint32_t> cs(m), cd(m);
+            for (size_t i = 0; i < m; ++i) {
+                cs[i] = (uint32_t)corr_src[i];
+                cd[i] = (uint32_t)corr_dst[i];
+            }
+            RESERVE(S.corr_src, sizeof(uint32_t) * m);
+            RESERVE(S.corr_dst, sizeof(uint32_t) * m);
+            HIPCHK(hipMemcpyAsync(S.corr_src.p, cs.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(S.corr_dst.p, cd.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+
+            // ---- RANSAC loop
+            std::random_device rd;
+            std::mt19937 rng((std::mt19937::result_type)((seed ? *seed : (uint64_t)rd()) & 0xffffffffull));
+            std::uniform_int_distribution<int> pick(0, (int)m - 1);  // utility::UniformRandIntGenerator(0, M-1)
+            double best_fit = 0, best_rmse = 0;
+            bool best_rmse_known = true;
+            int64_t best_index = -1;
+            int est_k_global = max_iter, est_k_local = max_iter;
+            uint64_t total_validation = 0;
+            int64_t iters = 0;
+            RESERVE(S.one_T, sizeof(double) * kRegTStride * 2);
+            double* best_T_dev = S.one_T.as<double>();
+            double* trial_T_dev = S.one_T.as<double>() + kRegTStride;
+            double best_T_host[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            const uint32_t n_tiles = R.src.n_pad / kRegTile;
+
+            std::vector<uint32_t> tri, survivors, h_counts;
+            std::vector<uint8_t> pass;
+            std::vector<int> itr_of;  // iteration index of each executed hypothesis of the chunk
+            size_t chunk = 256;
+            int itr = 0;
+            while (itr < max_iter && itr < est_k_global) {
+                // iterations [itr, itr + n_exec) all satisfy itr < est_k_global as of now; est_k can only
+                // shrink while replaying, in which case the tail of the chunk is discarded (its draws
+                // would not have happened: the generator is rewound by re-drawing from a saved state)
+                const int n_exec = (int)std::min<size_t>(chunk, (size_t)(std::min(max_iter, est_k_global) - itr));
+                const std::mt19937 rng_at_chunk_start = rng;
+                tri.resize((size_t)n_exec * 3);
+                for (int k = 0; k < n_exec * 3; ++k) tri[k] = (uint32_t)pick(rng);
+                RESERVE(S.triples, sizeof(uint32_t) * 3 * (size_t)n_exec);
+                RESERVE(S.T12, sizeof(double) * kRegTStride * (size_t)n_exec);
+                RESERVE(S.pass, (size_t)n_exec);
+                HIPCHK(hipMemcpyAsync(S.triples.p, tri.data(), sizeof(uint32_t) * 3 * (size_t)n_exec,
+                                      hipMemcpyHostToDevice, ctx->stream));
+                launch_kabsch3_check(R.src, R.dst, S.corr_src.as<uint32_t>(), S.corr_dst.as<uint32_t>(),
+                                     S.triples.as<uint32_t>(), (uint32_t)n_exec, edge_length_threshold, threshold,
+                                     S.T12.as<double>(), S.pass.as<uint8_t>(), ctx->stream);
+                pass.resize(n_exec);
+                HIPCHK(hipMemcpyAsync(pass.data(), S.pass.p, (size_t)n_exec, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                survivors.clear();
+                for (int k = 0; k < n_exec; ++k)
+                    if (pass[k]) survivors.push_back((uint32_t)k);
+                const uint32_t ns = (uint32_t)survivors.size();
+                h_counts.assign(ns, 0);
+                if (ns) {
+                    const uint32_t s_pad = round_up(ns, 64);
+                    RESERVE(S.list, sizeof(uint32_t) * ns);
+                    RESERVE(S.Ts, sizeof(double) * kRegTStride * ((size_t)s_pad + 1));
+                    RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * s_pad);
+                    RESERVE(S.counts, sizeof(uint32_t) * s_pad);
+                    HIPCHK(hipMemcpyAsync(S.list.p, survivors.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice,
+                                          ctx->stream));
+                    launch_gather_T(S.T12.as<double>(), S.list.as<uint32_t>(), ns, s_pad + 1, S.Ts.as<double>(),
+                                    ctx->stream);
+                    const uint32_t want = std::max<uint32_t>(1, (2048 + n_tiles - 1) / n_tiles);
+                    launch_reg_count(R.src, S.Ts.as<double>(), s_pad, std::min(want, s_pad / 64), g,
+                                     S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
+                                     S.qz.as<double>(), S.partial.as<uint32_t>(), ctx->stream);
+                    HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
+                    launch_reduce_partials(S.partial.as<uint32_t>(), n_tiles, s_pad, S.counts.as<uint32_t>(),
+                                           ctx->stream);
+                    HIPCHK(hipMemcpyAsync(h_counts.data(), S.counts.p, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost,
+                                          ctx->stream));
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                }
+                // ---- sequential replay of the chunk
+                uint32_t sv = 0;
+                int k = 0;
+                for (; k < n_exec; ++k) {
+                    const int it = itr + k;
+                    if (!(it < est_k_global)) break;  // `if (itr < est_k_global)` of the Open3D loop
+                    iters++;
+                    if (!pass[k]) continue;
+                    const uint32_t cnt = h_counts[sv];
+                    const double* T_dev = S.Ts.as<double>() + (size_t)sv * kRegTStride;
+                    sv++;
+                    const double fit = cnt ? (double)cnt / (double)n_src : 0.0;
+                    bool better = fit > best_fit;
+                    double rmse = 0.0;
+                    bool rmse_known = cnt == 0;  // empty correspondence set: rmse = 0
+                    if (!better && fit == best_fit) {
+                        if (!rmse_known) {
+                            uint64_t c2;
+                            double e2;
+                            const int r = exact_err2(R, T_dev, &c2, &e2);
+                            if (r != M3D_OK) return r;
+                            if (c2 != cnt) return fail(M3D_ERR_INTERNAL, "validation count mismatch");
+                            rmse = std::sqrt(e2 / (double)c2);
+                            rmse_known = true;
+                        }
+                        if (!best_rmse_known) {
+                            uint64_t c2;
+                            double e2;
+                            const int r = exact_err2(R, best_T_dev, &c2, &e2);
+                            if (r != M3D_OK) return r;
+                            best_rmse = c2 ? std::sqrt(e2 / (double)c2) : 0.0;
+                            best_rmse_known = true;
+                        }
+                        better = rmse < best_rmse;  // IsBetterRANSACThan
+                    }
+                    if (better) {
+                        best_fit = fit;
+                        best_rmse = rmse;
+                        best_rmse_known = rmse_known;
+                        best_index = it;
+                        HIPCHK(hipMemcpyAsync(best_T_dev, T_dev, sizeof(double) * kRegTStride,
+                                              hipMemcpyDeviceToDevice, ctx->stream));
+                        double ratio;
+                        const int r = corr_inlier_ratio(R, best_T_dev, &ratio);
+                        if (r != M3D_OK) return r;
+                        const double est_d = std::log(1.0 - confidence) / std::log(1.0 - std::pow(ratio, 3.0));
+                        est_k_local = est_d < (double)est_k_global ? ceil_to_int_x86(est_d) : est_k_local;
+                    }
+                    total_validation++;
+                    if (est_k_local < est_k_global) est_k_global = est_k_local;
+                }
+                if (k < n_exec) {
+                    // the loop went idle inside the chunk: nothing after it draws or runs
+                    (void)rng_at_chunk_start;
+                    break;
+                }
+                itr += n_exec;
+                chunk = std::min<size_t>(chunk * 2, 16384);
+            }
+            if (best_index >= 0) {
+                HIPCHK(hipMemcpy(best_T_host, best_T_dev, sizeof(best_T_host), hipMemcpyDeviceToHost));
+                if (!best_rmse_known) {
+                    uint64_t c2;
+                    double e2;
+                    const int r = exact_err2(R, best_T_dev, &c2, &e2);
+                    if (r != M3D_OK) return r;
+                    best_rmse = c2 ? std::sqrt(e2 / (double)c2) : 0.0;
+                }
+                std::memcpy(T_out, best_T_host, sizeof(best_T_host));
+            }
+            (void)trial_T_dev;
+            if (stats) {
+                stats->fitness = best_fit;
+                stats->inlier_rmse = best_rmse;
+                stats->validations = total_validation;
+                stats->iterations = iters;
+                stats->best_index = best_index;
+                stats->est_k = est_k_global;
+            }
+            return M3D_OK;
+        }();
+        (void)hipStreamSynchronize(ctx->stream);
+        S.release();
+    }
+    m3d_cloud_destroy(csrc);
+    m3d_cloud_destroy(cdst);
+    if (stats) stats->ms_total = now_ms() - t_begin;
+    return rc;
 }
-int m3d_match_mutual_nn(const double*, size_t, const double*, size_t, int, int, int, int, size_t*,
-                        size_t*, size_t*) {
-    return fail(M3D_ERR_INTERNAL, "m3d_match_mutual_nn: not implemented yet");
+
+int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat_dst, size_t n_dst, int dim,
+                        int method, int n_trees, int device, size_t* out_src, size_t* out_dst, size_t* k_out) {
+    (void)method;   // FLANN (exact kd-tree) and ANNOY (approximate forest) both map to the exact search
+    (void)n_trees;
+    if (!k_out || dim <= 0 || dim > 1024 || ((!feat_src || !out_src || !out_dst) && n_src) || (!feat_dst && n_dst))
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    *k_out = 0;
+    if (n_src == 0 || n_dst == 0) return M3D_OK;
+    if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
+    DeviceCtx* ctx = get_ctx(device);
+    if (!ctx) return M3D_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf fs, fd, bd, bi, nn01, nn10;
+    auto done = [&](int r) {
+        fs.release(); fd.release(); bd.release(); bi.release(); nn01.release(); nn10.release();
+        return r;
+    };
+    const uint32_t ns = (uint32_t)n_src, nd = (uint32_t)n_dst;
+    // enough (query block x database split) workgroups to fill the chip
+    auto splits_for = [](uint32_t nq, uint32_t ndb) {
+        const uint32_t blocks = (nq + 255) / 256;
+        uint32_t s = std::max<uint32_t>(1, (2048 + blocks - 1) / blocks);
+        return std::min<uint32_t>(s, std::max<uint32_t>(1, ndb / 256));
+    };
+    const uint32_t s01 = splits_for(ns, nd), s10 = splits_for(nd, ns);
+    const size_t part = std::max((size_t)s01 * ns, (size_t)s10 * nd);
+    if (!fs.reserve(sizeof(double) * (size_t)dim * ns) || !fd.reserve(sizeof(double) * (size_t)dim * nd) ||
+        !bd.reserve(sizeof(double) * part) || !bi.reserve(sizeof(uint32_t) * part) ||
+        !nn01.reserve(sizeof(uint32_t) * ns) || !nn10.reserve(sizeof(uint32_t) * nd))
+        return done(M3D_ERR_DEVICE);
+    std::vector<uint32_t> h01(ns), h10(nd);
+    bool ok = hipMemcpyAsync(fs.p, feat_src, sizeof(double) * (size_t)dim * ns, hipMemcpyHostToDevice, ctx->stream) ==
+                  hipSuccess &&
+              hipMemcpyAsync(fd.p, feat_dst, sizeof(double) * (size_t)dim * nd, hipMemcpyHostToDevice, ctx->stream) ==
+                  hipSuccess;
+    if (ok) {
+        // the two std::threads of correspondence_matching.cpp:59-62 become two launches on one stream
+        launch_nn(fs.as<double>(), ns, fd.as<double>(), nd, dim, s01, bd.as<double>(), bi.as<uint32_t>(),
+                  nn01.as<uint32_t>(), ctx->stream);
+        launch_nn(fd.as<double>(), nd, fs.as<double>(), ns, dim, s10, bd.as<double>(), bi.as<uint32_t>(),
+                  nn10.as<uint32_t>(), ctx->stream);
+        ok = hipMemcpyAsync(h01.data(), nn01.p, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(h10.data(), nn10.p, sizeof(uint32_t) * nd, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (!ok) return done(fail(M3D_ERR_DEVICE, "m3d_match_mutual_nn: HIP error"));
+    size_t k = 0;  // cross-check, correspondence_matching.cpp:64-78
+    for (uint32_t i = 0; i < ns; ++i) {
+        const uint32_t j = h01[i];
+        if (j < nd && h10[j] == i) {
+            out_src[k] = i;
+            out_dst[k] = j;
+            ++k;
+        }
+    }
+    *k_out = k;
+    return done(M3D_OK);
 }
-}
+
+}  // extern "C"

@@ -125,9 +125,10 @@ void orc_k3x3_rotation(const double *sigma, double *R, double *sv) {
     u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
     u3[1] = u1[2] * u2[0] - u1[0] * u2[2];
     u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
-    const double detv = (v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) -
-                         v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0])) +
-                        v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+    /* determinant of the SORTED V = [v_i1 v_i2 v_i3] (M[r][c] = v[r][i_c]) */
+    const double detv = (v[0][i1] * (v[1][i2] * v[2][i3] - v[1][i3] * v[2][i2]) -
+                         v[0][i2] * (v[1][i1] * v[2][i3] - v[1][i3] * v[2][i1])) +
+                        v[0][i3] * (v[1][i1] * v[2][i2] - v[1][i2] * v[2][i1]);
     const double sgn = detv < 0.0 ? -1.0 : 1.0;
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)

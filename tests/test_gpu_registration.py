@@ -1,0 +1,118 @@
+"""GPU parity tests of the registration half (through the C ABI) against the oracle:
+3-point Kabsch + checkers + validation counts bit-exact hypothesis by hypothesis (same "K3x3"
+specification on both sides), the RANSAC driver (best index, iteration/validation counts, est_k,
+pose), n-point Kabsch within 1e-9, mutual-NN matcher bit-exact."""
+import numpy as np
+import pytest
+
+from misc3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(n=3000, seed=3, m=800, true_fraction=0.4):
+    d = synth.registration_pair_c4(n, seed=seed, dim=8, true_fraction=true_fraction, sigma=0.001)
+    inv = np.empty(n, dtype=np.int64)
+    inv[d["perm"]] = np.arange(n)
+    rng = np.random.default_rng(seed + 1)
+    cs = rng.integers(0, n, m)
+    cd = np.where(rng.random(m) < true_fraction, inv[cs], rng.integers(0, n, m))
+    return d, cs, cd
+
+
+@pytest.mark.parametrize("conf,max_iter,seed", [(0.999, 3000, 17), (1.0, 700, 5), (0.9, 2000, 2)])
+def test_registration_ransac_matches_oracle(capi, orc, conf, max_iter, seed):
+    d, cs, cd = _problem()
+    o = orc.registration_ransac(d["src"], d["dst"], cs, cd, thr=0.03, max_iter=max_iter, edge_thr=0.9,
+                                confidence=conf, seed=seed)
+    T, st = capi.registration_ransac(d["src"], d["dst"], cs, cd, threshold=0.03, max_iter=max_iter,
+                                     edge_length_threshold=0.9, confidence=conf, seed=seed)
+    assert st["best_index"] == o.best_index >= 0
+    assert st["iterations"] == o.iterations and st["validations"] == o.validations and st["est_k"] == o.est_k
+    assert st["fitness"] == o.fitness
+    assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64))     # same hypothesis, same arithmetic
+    assert st["inlier_rmse"] == pytest.approx(o.inlier_rmse, rel=1e-12)
+    assert np.allclose(T, d["T"], atol=0.02)
+
+
+def test_registration_grid_edge_cases(capi, orc):
+    # target far from the origin, threshold comparable to the extent, points exactly on cell borders
+    rng = np.random.default_rng(7)
+    n = 1200
+    src = rng.integers(-40, 40, size=(n, 3)) * 0.03003          # multiples of the cell size 1.001 * thr
+    T = synth.rigid_transform(10.0, (0, 0, 1), (100.0, -50.0, 7.0))
+    dst = src @ T[:3, :3].T + T[:3, 3]
+    cs = rng.integers(0, n, 300)
+    cd = cs.copy()
+    cd[::3] = rng.integers(0, n, len(cd[::3]))
+    for thr in (0.03, 0.5):
+        o = orc.registration_ransac(src, dst, cs, cd, thr=thr, max_iter=400, confidence=1.0, seed=9)
+        Tg, st = capi.registration_ransac(src, dst, cs, cd, threshold=thr, max_iter=400, confidence=1.0, seed=9)
+        assert st["best_index"] == o.best_index and st["validations"] == o.validations
+        assert st["fitness"] == o.fitness
+        assert np.array_equal(Tg.view(np.uint64), o.T.view(np.uint64))
+
+
+def test_registration_errors_and_identity(capi):
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=(10, 3))
+    with pytest.raises(capi.M3DError) as e:
+        capi.registration_ransac(p[:2], p, [0, 1, 1], [0, 1, 2], seed=1)
+    assert e.value.code == capi.ERR_TOO_FEW_POINTS and "less than 3" in str(e.value)
+    T, st = capi.registration_ransac(p, p, [0, 1], [0, 1], seed=1)              # < 3 correspondences
+    assert np.array_equal(T, np.eye(4)) and st["best_index"] == -1
+    T, st = capi.registration_ransac(p, p, [0, 1, 2], [0, 1, 2], threshold=0.0, seed=1)
+    assert np.array_equal(T, np.eye(4))
+    with pytest.raises(capi.M3DError) as e:
+        capi.registration_ransac(p, p, [0, 1, 99], [0, 1, 2], seed=1)
+    assert e.value.code == capi.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("n", [3, 4, 1000, 100_000])
+def test_kabsch_matches_oracle(capi, orc, n):
+    rng = np.random.default_rng(n)
+    T = synth.rigid_transform(25.0, (0.3, -1, 0.5), (1.0, 2.0, -0.5))
+    src = rng.uniform(-2, 2, (n, 3))
+    dst = src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.01, (n, 3)) * (n > 4)
+    for scaling in (False, True):
+        got = capi.kabsch(src, dst, scaling)
+        ref = orc.umeyama(src, dst, scaling)
+        assert np.allclose(got, ref, rtol=0, atol=1e-9)
+    if n <= 4:
+        assert np.allclose(capi.kabsch(src, dst), T, atol=1e-12)
+    with pytest.raises(capi.M3DError) as e:
+        capi.kabsch(src[:2], dst[:2])
+    assert e.value.code == capi.ERR_TOO_FEW_POINTS
+
+
+@pytest.mark.parametrize("dim,ns,nd", [(33, 3000, 2700), (33, 257, 5000), (8, 1500, 1500), (3, 900, 1000)])
+def test_mutual_nn_matches_oracle(capi, orc, dim, ns, nd):
+    rng = np.random.default_rng(dim + ns)
+    fs = rng.uniform(0, 1, (ns, dim))
+    fd = rng.uniform(0, 1, (nd, dim))
+    k = min(ns, nd) // 3
+    fd[:k] = np.abs(fs[ns - k:] + rng.normal(0, 0.01, (k, dim)))
+    fd[k:k + 5] = fd[:5]                      # exact duplicates: ties go to the lowest index
+    a, b = capi.match_mutual_nn(fs, fd)
+    oa, ob = orc.match_mutual_nn(fs, fd)
+    assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob)
+    assert len(a) > k // 2
+
+
+def test_c4_pipeline_properties(capi):
+    """BASELINE config C4 shape at reduced N (20k): matcher -> RANSAC recovers the generating pose;
+    determinism for a fixed seed."""
+    d = synth.registration_pair_c4(20_000, seed=5)
+    i0, i1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    assert len(i0) > 0.2 * 20_000
+    inv = np.empty(20_000, dtype=np.int64)
+    inv[d["perm"]] = np.arange(20_000)
+    true_frac = np.mean(inv[i0.astype(np.int64)] == i1.astype(np.int64))
+    assert true_frac > 0.5
+    T, st = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=20_000,
+                                     confidence=1.0, seed=17)
+    assert st["iterations"] == 20_000 and st["fitness"] > 0.95
+    assert np.allclose(T, d["T"], atol=5e-3)
+    T2, st2 = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=20_000,
+                                       confidence=1.0, seed=17)
+    assert np.array_equal(T, T2) and st2["best_index"] == st["best_index"]

@@ -1,0 +1,116 @@
+"""Known-answer tests pinning the registration half of the oracle (oracle/misc3d_oracle_reg.c):
+Kabsch/umeyama against numpy.linalg.svd, the RANSAC driver on exactly solvable cases, mutual nearest
+neighbour against scipy's cKDTree.  (Open3D / Eigen are absent: PARITY UNPINNED vs the real
+reference, see the file header.)"""
+import numpy as np
+import pytest
+
+from misc3d_amd import synth
+
+
+def _kabsch_numpy(src, dst, scaling=False):
+    ms, md = src.mean(0), dst.mean(0)
+    s, d = src - ms, dst - md
+    sigma = d.T @ s / len(src)
+    U, S, Vt = np.linalg.svd(sigma)
+    D = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        D[2, 2] = -1
+    R = U @ D @ Vt
+    c = 1.0
+    if scaling:
+        c = (S * np.diag(D)).sum() / ((s ** 2).sum() / len(src))
+    T = np.eye(4)
+    T[:3, :3] = c * R
+    T[:3, 3] = md - c * R @ ms
+    return T
+
+
+def test_k3x3_matches_numpy_svd(orc):
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        A = rng.normal(size=(3, 3))
+        if trial % 4 == 1:
+            A[:, 2] = A[:, 0] * 0.3 - A[:, 1]        # rank 2 (what 3 correspondences always give)
+        if trial % 4 == 2:
+            A = -A @ A.T                             # symmetric negative definite
+        R, sv = orc.k3x3_rotation(A)
+        U, S, Vt = np.linalg.svd(A)
+        D = np.diag([1, 1, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
+        assert np.allclose(R, U @ D @ Vt, atol=1e-9), trial
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and np.linalg.det(R) > 0.999999
+        assert np.allclose(np.abs(sv), S, atol=1e-12 * max(1, S[0]))
+
+
+def test_umeyama_recovers_exact_transform(orc):
+    rng = np.random.default_rng(1)
+    T = synth.rigid_transform(40.0, (1, 1, 1), (0.3, -0.1, 0.2))
+    for n in (3, 4, 10, 1000):
+        src = rng.uniform(-1, 1, (n, 3))
+        dst = src @ T[:3, :3].T + T[:3, 3]
+        got = orc.umeyama(src, dst)
+        assert np.allclose(got, T, atol=1e-12)
+        assert np.allclose(got, _kabsch_numpy(src, dst), atol=1e-12)
+    # with scaling
+    src = rng.uniform(-1, 1, (50, 3))
+    dst = 2.5 * (src @ T[:3, :3].T) + T[:3, 3]
+    got = orc.umeyama(src, dst, True)
+    assert np.allclose(got[:3, :3], 2.5 * T[:3, :3], atol=1e-12) and np.allclose(got[:3, 3], T[:3, 3], atol=1e-12)
+    # reflection: the best ROTATION is returned (det = +1), like Eigen::umeyama
+    dst = src * np.array([1, 1, -1.0])
+    got = orc.umeyama(src, dst)
+    assert np.linalg.det(got[:3, :3]) > 0.999 and np.allclose(got, _kabsch_numpy(src, dst), atol=1e-10)
+    # noisy
+    dst = src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.01, (50, 3))
+    assert np.allclose(orc.umeyama(src, dst), _kabsch_numpy(src, dst), atol=1e-10)
+
+
+def test_validate_counts_strict_radius(orc):
+    dst = np.array([[0, 0, 0], [1, 0, 0], [5, 5, 5.0]])
+    src = np.array([[0.03, 0, 0], [1, 0.05, 0], [9, 9, 9.0], [0, 0.05, 0]])
+    cnt, e2 = orc.reg_validate(src, dst, np.eye(4), 0.05)
+    # |d|^2 < r*r is strict (std::lower_bound on radius*radius): 0.05 away is NOT a correspondence
+    assert cnt == 1 and e2 == pytest.approx(0.03 ** 2, rel=1e-15)
+
+
+def _small_problem(n=1500, seed=3, true_fraction=0.4):
+    d = synth.registration_pair_c4(n, seed=seed, dim=8, true_fraction=true_fraction, sigma=0.001)
+    inv = np.empty(n, dtype=np.int64)
+    inv[d["perm"]] = np.arange(n)
+    rng = np.random.default_rng(seed + 1)
+    m = 600
+    cs = rng.integers(0, n, m)
+    cd = np.where(rng.random(m) < true_fraction, inv[cs], rng.integers(0, n, m))
+    return d, cs, cd
+
+
+def test_registration_ransac_recovers_pose(orc):
+    d, cs, cd = _small_problem()
+    r = orc.registration_ransac(d["src"], d["dst"], cs, cd, thr=0.03, max_iter=2000, edge_thr=0.9,
+                                confidence=0.999, seed=17)
+    assert r.ret == 0 and r.best_index >= 0 and r.fitness > 0.9
+    assert np.allclose(r.T, d["T"], atol=0.02)
+    assert r.iterations <= 2000 and r.est_k <= 2000
+    # confidence 1.0 never shortens the loop
+    r1 = orc.registration_ransac(d["src"], d["dst"], cs, cd, thr=0.03, max_iter=300, confidence=1.0, seed=17)
+    assert r1.iterations == 300 and r1.est_k == 300
+    # degenerate inputs
+    assert orc.registration_ransac(d["src"][:2], d["dst"], cs, cd, seed=1).ret == -1
+    r0 = orc.registration_ransac(d["src"], d["dst"], cs[:2], cd[:2], seed=1)
+    assert r0.ret == 0 and np.array_equal(r0.T, np.eye(4))
+    r0 = orc.registration_ransac(d["src"], d["dst"], cs, cd, thr=0.0, seed=1)
+    assert np.array_equal(r0.T, np.eye(4))
+
+
+def test_mutual_nn_vs_ckdtree(orc):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(5)
+    fs = rng.uniform(0, 1, (700, 33))
+    fd = rng.uniform(0, 1, (650, 33))
+    fd[:200] = fs[100:300] + rng.normal(0, 0.01, (200, 33))
+    a, b = orc.match_mutual_nn(fs, fd)
+    n01 = cKDTree(fd).query(fs)[1]
+    n10 = cKDTree(fs).query(fd)[1]
+    keep = [i for i in range(len(fs)) if n10[n01[i]] == i]
+    assert np.array_equal(a, keep) and np.array_equal(b, n01[keep])
+    assert len(a) >= 190 and np.all(np.diff(a) > 0)
