@@ -1,0 +1,60 @@
+// misc3d/segmentation/iterative_plane_segmentation.h -- mirror of
+// include/misc3d/segmentation/iterative_plane_segmentation.h:25-28 /
+// src/iterative_plane_segmentation.cpp:8-39 over m3d_segment_plane_iterative.
+#pragma once
+#include <utility>
+#include <vector>
+
+#include "../../misc3d_amd.h"
+#include "../geometry.h"
+#include "../logging.h"
+
+namespace misc3d {
+namespace segmentation {
+
+struct PlaneCluster {
+    Vector4d plane;
+    std::vector<size_t> indices;  // into the input cloud, ascending (extension: the reference only
+                                  // returns the points)
+    PointCloud cloud;             // cluster points (what the reference returns)
+};
+
+inline std::vector<PlaneCluster> SegmentPlaneIterativeIndexed(const CloudView& pcd, double threshold,
+                                                               int max_iteration = 100, double min_ratio = 0.05,
+                                                               const uint64_t* seed = nullptr, int device = 0) {
+    std::vector<PlaneCluster> result;
+    if (pcd.n < 3) {  // :13-17
+        LogWarning("Point cloud size has less than 3.");
+        return result;
+    }
+    const size_t max_clusters = 4096;
+    std::vector<double> planes(4 * max_clusters);
+    std::vector<size_t> offsets(max_clusters + 1), indices(pcd.n);
+    size_t k = 0;
+    const int rc = CheckStatus(m3d_segment_plane_iterative(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio,
+                                                           seed, device, max_clusters, planes.data(),
+                                                           offsets.data(), indices.data(), &k));
+    if (rc == 2) LogWarning("segment_plane_iterative: a round found no inlier; stopping early");
+    result.resize(k);
+    for (size_t c = 0; c < k; ++c) {
+        for (int j = 0; j < 4; ++j) result[c].plane[j] = planes[4 * c + j];
+        result[c].indices.assign(indices.begin() + offsets[c], indices.begin() + offsets[c + 1]);
+        result[c].cloud.points_.reserve(result[c].indices.size());
+        for (size_t i : result[c].indices)
+            result[c].cloud.points_.push_back({pcd.xyz[3 * i], pcd.xyz[3 * i + 1], pcd.xyz[3 * i + 2]});
+    }
+    return result;
+}
+
+// same signature and return shape as the reference
+inline std::vector<std::pair<Vector4d, PointCloud>> SegmentPlaneIterative(const CloudView& pcd, double threshold,
+                                                                          int max_iteration = 100,
+                                                                          double min_ratio = 0.05) {
+    std::vector<std::pair<Vector4d, PointCloud>> out;
+    for (auto& c : SegmentPlaneIterativeIndexed(pcd, threshold, max_iteration, min_ratio))
+        out.emplace_back(c.plane, std::move(c.cloud));
+    return out;
+}
+
+}  // namespace segmentation
+}  // namespace misc3d

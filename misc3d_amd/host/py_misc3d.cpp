@@ -1,0 +1,297 @@
+// py_misc3d.cpp -- pybind11 module with the reference's python API for the RANSAC hot path
+// (python/py_misc3d.cpp:25-62 module wiring, python/py_common.cpp:11-78, python/py_registration.cpp:11-107,
+// python/py_segmentation.cpp:87-96), implemented on the host classes of include/misc3d/** which call the
+// C ABI (include/misc3d_amd.h) -> HIP kernels.
+//
+// Same function names, positional order, defaults and return container types as the reference.
+// Keyword-only extras that default to the reference's behaviour: seed=None (std::random_device),
+// device=0, confidence=0.999 (registration).  Open3D is not a dependency: `pc` may be an (N,3) float64
+// array, a (points, normals) tuple, or any object exposing .points / .normals (an
+// open3d.geometry.PointCloud works through numpy.asarray).
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstring>
+#include <optional>
+
+#include <misc3d/common/ransac.h>
+#include <misc3d/logging.h>
+#include <misc3d/registration/correspondence_matching.h>
+#include <misc3d/registration/transform_estimation.h>
+#include <misc3d/segmentation/iterative_plane_segmentation.h>
+
+namespace py = pybind11;
+using arr_d = py::array_t<double, py::array::c_style | py::array::forcecast>;
+
+namespace {
+
+struct HostCloud {
+    arr_d points, normals;
+    bool has_normals = false;
+    misc3d::CloudView view() const {
+        return misc3d::CloudView(points.size() ? points.data() : nullptr, has_normals ? normals.data() : nullptr,
+                                 (size_t)points.shape(0));
+    }
+};
+
+arr_d as_nx3(const py::object& o, const char* what) {
+    py::object np = py::module_::import("numpy");
+    arr_d a = arr_d::ensure(np.attr("asarray")(o, py::arg("dtype") = "float64"));
+    if (!a) throw py::type_error(std::string(what) + ": cannot convert to a float64 array");
+    if (a.ndim() == 2 && a.shape(1) == 3) return a;
+    if (a.ndim() == 2 && a.shape(0) == 0) return arr_d(std::vector<py::ssize_t>{0, 3});
+    if (a.ndim() == 1 && a.shape(0) == 0) return arr_d(std::vector<py::ssize_t>{0, 3});
+    throw py::value_error(std::string(what) + ": expected an (N, 3) array");
+}
+
+HostCloud extract_cloud(const py::object& pc) {
+    HostCloud c;
+    if (py::hasattr(pc, "points")) {  // open3d.geometry.PointCloud or a duck-typed equivalent
+        c.points = as_nx3(pc.attr("points"), "pc.points");
+        if (py::hasattr(pc, "normals")) {
+            py::object n = pc.attr("normals");
+            if (!n.is_none()) {
+                arr_d nn = as_nx3(n, "pc.normals");
+                if (nn.shape(0) == c.points.shape(0) && nn.shape(0) > 0) {
+                    c.normals = nn;
+                    c.has_normals = true;
+                }
+            }
+        }
+    } else if (py::isinstance<py::tuple>(pc) && py::len(pc) == 2) {
+        py::tuple t = pc.cast<py::tuple>();
+        c.points = as_nx3(t[0], "points");
+        if (!t[1].is_none()) {
+            c.normals = as_nx3(t[1], "normals");
+            if (c.normals.shape(0) != c.points.shape(0)) throw py::value_error("points and normals differ in length");
+            c.has_normals = c.normals.shape(0) > 0;
+        }
+    } else {
+        c.points = as_nx3(pc, "pc");
+    }
+    return c;
+}
+
+py::array_t<double> to_array(const std::vector<double>& v) {
+    py::array_t<double> a((py::ssize_t)v.size());
+    if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), sizeof(double) * v.size());
+    return a;
+}
+py::array_t<double> to_mat4(const misc3d::Matrix4d& T) {
+    py::array_t<double> a(std::vector<py::ssize_t>{4, 4});
+    std::memcpy(a.mutable_data(), T.data(), sizeof(double) * 16);
+    return a;
+}
+
+// FitPlane / FitSphere / FitCylinder, python/py_common.cpp:11-67
+template <class Ransac, class ModelT>
+py::tuple fit_impl(const py::object& pc, double threshold, size_t max_iteration, double probability,
+                   const std::optional<uint64_t>& seed, int device, bool needs_normals) {
+    HostCloud c = extract_cloud(pc);
+    if (needs_normals && !c.has_normals) misc3d::LogError("Fit cylinder requires normals.");  // py_common.cpp:50-52
+    Ransac fit;
+    fit.SetDevice(device);
+    fit.SetMaxIteration(max_iteration);
+    fit.SetProbability(probability);
+    if (seed) fit.SetSeed(*seed);
+    ModelT model;
+    std::vector<size_t> inliers;
+    bool ret;
+    {
+        py::gil_scoped_release nogil;  // the reference holds the GIL; releasing it is unobservable
+        // FitModel's own point-count check (ransac.h:509-513) needs the cloud object, so an empty
+        // cloud is passed through: m3d_cloud_fit raises "Can not fit model due to lack of points"
+        fit.SetPointCloud(c.view());
+        ret = fit.FitModel(threshold, model, inliers);
+    }
+    if (!ret) model.parameters_.assign(4, 0.0);  // py_common.cpp:21-23,39-41,61-63 (size 4 for the cylinder too)
+    return py::make_tuple(to_array(model.parameters_), inliers);
+}
+
+arr_d as_descriptor_matrix(const py::object& f) {
+    // open3d Feature (attribute `data`, dim x N) or an ndarray of shape (dim, N)
+    py::object np = py::module_::import("numpy");
+    py::object src = py::hasattr(f, "data") && !py::isinstance<py::array>(f) ? py::object(f.attr("data")) : f;
+    arr_d a = arr_d::ensure(np.attr("asarray")(src, py::arg("dtype") = "float64"));
+    if (!a || a.ndim() != 2) throw py::value_error("descriptors: expected a (dim, N) array or an object with .data");
+    // Eigen dim x N column-major == N x dim row-major
+    return arr_d::ensure(np.attr("ascontiguousarray")(a.attr("T")));
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_py_misc3d, m) {
+    m.doc() = "MI355X-native Misc3D RANSAC hot path (fit_plane/sphere/cylinder, segment_plane_iterative, "
+              "compute_transformation_*, match_correspondence)";
+
+    // ---- common (python/py_common.cpp:69-78)
+    py::module mc = m.def_submodule("common");
+    mc.def(
+        "fit_plane",
+        [](const py::object& pc, double threshold, size_t max_iteration, double probability,
+           std::optional<uint64_t> seed, int device) {
+            return fit_impl<misc3d::common::RANSACPlane, misc3d::common::Plane>(pc, threshold, max_iteration,
+                                                                                 probability, seed, device, false);
+        },
+        "Fit a plane from point clouds", py::arg("pc"), py::arg("threshold") = 0.01,
+        py::arg("max_iteration") = 1000, py::arg("probability") = 0.9999, py::kw_only(),
+        py::arg("seed") = py::none(), py::arg("device") = 0);
+    mc.def(
+        "fit_sphere",
+        [](const py::object& pc, double threshold, size_t max_iteration, double probability,
+           std::optional<uint64_t> seed, int device) {
+            return fit_impl<misc3d::common::RANSACShpere, misc3d::common::Sphere>(pc, threshold, max_iteration,
+                                                                                   probability, seed, device, false);
+        },
+        "Fit a sphere from point clouds", py::arg("pc"), py::arg("threshold") = 0.01,
+        py::arg("max_iteration") = 1000, py::arg("probability") = 0.9999, py::kw_only(),
+        py::arg("seed") = py::none(), py::arg("device") = 0);
+    mc.def(
+        "fit_cylinder",
+        [](const py::object& pc, double threshold, size_t max_iteration, double probability,
+           std::optional<uint64_t> seed, int device) {
+            return fit_impl<misc3d::common::RANSACCylinder, misc3d::common::Cylinder>(
+                pc, threshold, max_iteration, probability, seed, device, true);
+        },
+        "Fit a cylinder from point clouds", py::arg("pc"), py::arg("threshold") = 0.01,
+        py::arg("max_iteration") = 1000, py::arg("probability") = 0.9999, py::kw_only(),
+        py::arg("seed") = py::none(), py::arg("device") = 0);
+
+    // ---- segmentation (python/py_segmentation.cpp:87-96)
+    py::module ms = m.def_submodule("segmentation");
+    ms.def(
+        "segment_plane_iterative",
+        [](const py::object& pcd, double threshold, int max_iteration, double min_ratio,
+           std::optional<uint64_t> seed, int device, bool return_indices) {
+            HostCloud c = extract_cloud(pcd);
+            std::vector<misc3d::segmentation::PlaneCluster> res;
+            {
+                py::gil_scoped_release nogil;
+                uint64_t s = seed ? *seed : 0;
+                res = misc3d::segmentation::SegmentPlaneIterativeIndexed(c.view(), threshold, max_iteration,
+                                                                         min_ratio, seed ? &s : nullptr, device);
+            }
+            py::object o3d = py::none();
+            if (py::hasattr(pcd, "points")) {
+                try {
+                    o3d = py::module_::import("open3d");
+                } catch (py::error_already_set&) {
+                    o3d = py::none();
+                }
+            }
+            py::list out;
+            for (auto& cl : res) {
+                py::array_t<double> plane(4);
+                std::memcpy(plane.mutable_data(), cl.plane.data(), sizeof(double) * 4);
+                py::array_t<double> pts(std::vector<py::ssize_t>{(py::ssize_t)cl.cloud.points_.size(), 3});
+                if (!cl.cloud.points_.empty())
+                    std::memcpy(pts.mutable_data(), cl.cloud.points_[0].data(),
+                                sizeof(double) * 3 * cl.cloud.points_.size());
+                py::object cluster = pts;
+                if (!o3d.is_none())  // list[(ndarray(4), open3d PointCloud)] like the reference
+                    cluster = o3d.attr("geometry").attr("PointCloud")(o3d.attr("utility").attr("Vector3dVector")(pts));
+                if (return_indices)
+                    out.append(py::make_tuple(plane, cluster, cl.indices));
+                else
+                    out.append(py::make_tuple(plane, cluster));
+            }
+            return out;
+        },
+        "Segment plane iteratively using RANSAC plane fitting", py::arg("pcd"), py::arg("threshold"),
+        py::arg("max_iteration") = 100, py::arg("min_ratio") = 0.05, py::kw_only(), py::arg("seed") = py::none(),
+        py::arg("device") = 0, py::arg("return_indices") = false);
+
+    // ---- registration (python/py_registration.cpp:11-107)
+    py::module mr = m.def_submodule("registration");
+    mr.def(
+        "compute_transformation_least_square",
+        [](const py::object& src, const py::object& dst, bool scaling, int device) {
+            auto pts = [](const py::object& o) {
+                if (py::hasattr(o, "points")) return extract_cloud(o).points;
+                py::object np = py::module_::import("numpy");
+                arr_d a = arr_d::ensure(np.attr("asarray")(o, py::arg("dtype") = "float64"));
+                // the ndarray overload is documented as (n, 3) but typed Matrix3Xd (py_registration.cpp:22-27):
+                // accept both orientations
+                if (a && a.ndim() == 2 && a.shape(1) != 3 && a.shape(0) == 3)
+                    return arr_d::ensure(np.attr("ascontiguousarray")(a.attr("T")));
+                return as_nx3(o, "points");
+            };
+            arr_d s = pts(src), d = pts(dst);
+            misc3d::Matrix4d T;
+            {
+                py::gil_scoped_release nogil;
+                misc3d::registration::LeastSquareSolver solver(scaling, device);
+                T = solver.Solve(misc3d::CloudView(s.data(), nullptr, (size_t)s.shape(0)),
+                                 misc3d::CloudView(d.data(), nullptr, (size_t)d.shape(0)));
+            }
+            return to_mat4(T);
+        },
+        "Compute 3D transformation from corresponding point clouds using Least-Square method", py::arg("src"),
+        py::arg("dst"), py::arg("scaling") = false, py::kw_only(), py::arg("device") = 0);
+    mr.def(
+        "compute_transformation_teaser",
+        [](const py::object&, const py::object&, double) -> py::object {
+            throw std::runtime_error(
+                "[Misc3D Error] compute_transformation_teaser (TEASER++, CPU graph solver) is outside the "
+                "MI355X-accelerated hot path of this build; use compute_transformation_ransac or _least_square");
+        },
+        py::arg("src"), py::arg("dst"), py::arg("noise_bound") = 0.01);
+    mr.def(
+        "compute_transformation_ransac",
+        [](const py::object& src, const py::object& dst,
+           const std::pair<std::vector<size_t>, std::vector<size_t>>& corres, double threshold, int max_iter,
+           double edge_length_threshold, std::optional<uint64_t> seed, double confidence, int device) {
+            HostCloud s = extract_cloud(src), d = extract_cloud(dst);
+            misc3d::Matrix4d T;
+            {
+                py::gil_scoped_release nogil;
+                misc3d::registration::RANSACSolver solver(threshold, max_iter, edge_length_threshold);
+                solver.SetConfidence(confidence);
+                solver.SetDevice(device);
+                if (seed) solver.SetSeed(*seed);
+                T = solver.Solve(s.view(), d.view(), corres);
+            }
+            return to_mat4(T);
+        },
+        "Compute 3D rigid transformation from corresponding point clouds using RANSAC", py::arg("src"),
+        py::arg("dst"), py::arg("corres"), py::arg("threshold") = 0.01, py::arg("max_iter") = 100000,
+        py::arg("edge_length_threshold") = 0.9, py::kw_only(), py::arg("seed") = py::none(),
+        py::arg("confidence") = 0.999, py::arg("device") = 0);
+    py::enum_<misc3d::registration::MatchMethod>(mr, "MatchMethod")
+        .value("FLANN", misc3d::registration::MatchMethod::FLANN)
+        .value("ANNOY", misc3d::registration::MatchMethod::ANNOY)
+        .export_values();
+    mr.def(
+        "match_correspondence",
+        [](const py::object& src, const py::object& dst, const misc3d::registration::MatchMethod& method,
+           int n_trees, int device) {
+            arr_d fs = as_descriptor_matrix(src), fd = as_descriptor_matrix(dst);
+            if (fs.shape(1) != fd.shape(1)) throw py::value_error("descriptor dimensions differ");
+            std::pair<std::vector<size_t>, std::vector<size_t>> res;
+            {
+                py::gil_scoped_release nogil;
+                misc3d::registration::ANNMatcher matcher(method, n_trees);
+                matcher.SetDevice(device);
+                misc3d::registration::FeatureView a{fs.data(), (int)fs.shape(1), (size_t)fs.shape(0)};
+                misc3d::registration::FeatureView b{fd.data(), (int)fd.shape(1), (size_t)fd.shape(0)};
+                res = matcher.Match(a, b);
+            }
+            return res;
+        },
+        "Match corresponding point clouds (mutual nearest neighbours in descriptor space)", py::arg("src"),
+        py::arg("dst"), py::arg("method") = misc3d::registration::MatchMethod::ANNOY, py::arg("n_trees") = 4,
+        py::kw_only(), py::arg("device") = 0);
+
+    // ---- logging (python/py_misc3d.cpp:52-62)
+    py::enum_<misc3d::VerbosityLevel>(m, "VerbosityLevel", py::arithmetic(), "VerbosityLevel")
+        .value("Error", misc3d::VerbosityLevel::Error)
+        .value("Warning", misc3d::VerbosityLevel::Warning)
+        .value("Info", misc3d::VerbosityLevel::Info)
+        .value("Debug", misc3d::VerbosityLevel::Debug)
+        .export_values();
+    m.def("set_verbosity_level", &misc3d::SetVerbosityLevel, "Set global verbosity level of Misc3D",
+          py::arg("verbosity_level"));
+    m.def("get_verbosity_level", &misc3d::GetVerbosityLevel, "Get global verbosity level of Misc3D");
+    m.def("device_count", []() { return m3d_device_count(); });
+}

@@ -207,6 +207,18 @@ def fit(kind, xyz, normals=None, thr=0.01, max_iter=1000, prob=0.9999, seed=0, t
                      int(st.iterations), int(st.best_index), tr_arrays)
 
 
+def refine(kind, xyz, thr, model):
+    """RefineModel (ransac.h:534-549): (ret, refined params, inlier indices)."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    m = np.zeros(_NP[kind])
+    m[:] = _f64(model)[: _NP[kind]]
+    inl = np.zeros(max(len(xyz), 1), dtype=np.uint64)
+    ni = C.c_size_t(0)
+    ok = lib().orc_refine(C.c_int(kind), _p(xyz), C.c_size_t(len(xyz)), C.c_double(thr), _p(m), _p(inl),
+                          C.byref(ni))
+    return int(ok), m, inl[: ni.value].copy()
+
+
 def score_samples(kind, xyz, normals, thr, samples):
     xyz = _f64(xyz).reshape(-1, 3)
     nrm = _f64(normals).reshape(-1, 3) if normals is not None else None

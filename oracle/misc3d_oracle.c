@@ -580,6 +580,25 @@ int orc_fit(int kind, const double *xyz, const double *normals, size_t n, double
     return ok ? 1 : 0;
 }
 
+/* RefineModel alone (ransac.h:534-549) for a given pre-refinement model: inlier list + GeneralFit
+ * applied in place.  Returns GeneralFit's return value. */
+int orc_refine(int kind, const double *xyz, size_t n, double thr, double *model, size_t *inliers,
+               size_t *n_inliers) {
+    size_t ni = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double d = orc_distance(kind, xyz + 3 * i, model);
+        if (d < thr) inliers[ni++] = i;
+    }
+    *n_inliers = ni;
+    if (kind == ORC_CYLINDER) return 1;
+    double *sel = (double *)malloc(sizeof(double) * 3 * (ni ? ni : 1));
+    for (size_t k = 0; k < ni; ++k) memcpy(sel + 3 * k, xyz + 3 * inliers[k], 3 * sizeof(double));
+    const int ok = (kind == ORC_PLANE) ? orc_plane_general_fit(sel, ni, model)
+                                       : orc_sphere_general_fit(sel, ni, model);
+    free(sel);
+    return ok;
+}
+
 /* Hypothesis-level helper for kernel parity tests: minimal fit + serial evaluation of H given
  * samples (H x m indices). */
 void orc_score_samples(int kind, const double *xyz, const double *normals, size_t n, double thr,
