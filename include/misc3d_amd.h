@@ -52,9 +52,9 @@ typedef struct m3d_stats {
     uint64_t iterations;         /* loop index at which the reference loop went idle */
     int64_t best_index;          /* hypothesis index of the best model, -1 if none */
     int32_t general_fit_ok;      /* RefineModel's return (ransac.h:548) */
-    int32_t reserved;
+    int32_t ties;                /* equal-fitness comparisons (ransac.h:596) decided during the replay */
     uint64_t hypotheses_scored;  /* hypotheses the GPU scored (>= iterations: speculative chunks) */
-    uint64_t exact_rmse_evals;   /* serial-order error sums computed to break fitness ties */
+    uint64_t exact_rmse_evals;   /* serial-order error sums needed (ties that order-free sums could not decide) */
     double ms_sample;            /* host: std::mt19937 sample table */
     double ms_score;             /* device: minimal fit + scoring + reduce (HIP events) */
     double ms_refine;            /* device+host: inlier compaction, GeneralFit, copy-out */
@@ -144,6 +144,8 @@ typedef struct m3d_reg_stats {
     uint64_t validations;
     int64_t iterations, best_index, est_k;
     double ms_total;
+    uint64_t ties;             /* equal-fitness comparisons decided during the replay */
+    uint64_t exact_rmse_evals; /* of which needed the serial-order sum of squared distances */
 } m3d_reg_stats;
 /* corr_src/corr_dst: m index pairs (the std::pair<vector<size_t>,vector<size_t>> of the reference).
  * confidence: Open3D RANSACConvergenceCriteria::confidence_ (the reference always uses the default

@@ -40,18 +40,18 @@ class M3DError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("count", C.c_uint64),
                 ("iterations", C.c_uint64), ("best_index", C.c_int64), ("general_fit_ok", C.c_int32),
-                ("reserved", C.c_int32), ("hypotheses_scored", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
+                ("ties", C.c_int32), ("hypotheses_scored", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
                 ("ms_sample", C.c_double), ("ms_score", C.c_double), ("ms_refine", C.c_double),
                 ("ms_total", C.c_double)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class RegStats(C.Structure):
     _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("validations", C.c_uint64),
                 ("iterations", C.c_int64), ("best_index", C.c_int64), ("est_k", C.c_int64),
-                ("ms_total", C.c_double)]
+                ("ms_total", C.c_double), ("ties", C.c_uint64), ("exact_rmse_evals", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -168,10 +169,12 @@ static uint64_t double_to_size_t_x86(double v) {
     return static_cast<uint64_t>(static_cast<int64_t>(v));
 }
 
-template <class RmseFn, class BestFn>
+// tie(i, cnt, &trial_rmse, &trial_rmse_known) decides `inlier_rmse < inlier_rmse_` (ransac.h:596) for a
+// trial whose fitness EQUALS the best one; it may fill st->best_rmse when it had to evaluate it.
+template <class TieFn, class BestFn>
 static void replay_range(m3d_replay_state* st, size_t n_points, int kind, size_t max_iteration,
                          double probability, size_t begin, size_t end, const uint8_t* valid,
-                         const uint32_t* counts, RmseFn rmse_of, BestFn on_best) {
+                         const uint32_t* counts, TieFn tie, BestFn on_best) {
     const int m = minimal_sample(kind);
     for (size_t i = begin; i < end; ++i) {
         if (st->stopped) return;
@@ -188,15 +191,7 @@ static void replay_range(m3d_replay_state* st, size_t n_points, int kind, size_t
         bool better = fitness > st->best_fitness;
         double trial_rmse = 0.0;
         bool trial_rmse_known = false;
-        if (!better && fitness == st->best_fitness) {
-            trial_rmse = cnt == 0 ? 1e+10 : rmse_of(i, false);
-            trial_rmse_known = true;
-            if (!st->best_rmse_known) {
-                st->best_rmse = rmse_of((size_t)st->best_index, true);
-                st->best_rmse_known = 1;
-            }
-            better = trial_rmse < st->best_rmse;
-        }
+        if (!better && fitness == st->best_fitness) better = tie(i, cnt, &trial_rmse, &trial_rmse_known);
         if (better) {
             st->best_fitness = fitness;
             st->best_rmse = trial_rmse;
@@ -247,7 +242,12 @@ struct SampleSource {
 static uint32_t pick_splits(uint32_t n_tiles, uint32_t h_pad) {
     // enough workgroups to fill 256 CUs x 8 resident workgroups a couple of times over
     const uint32_t groups = h_pad / 64;
-    const uint32_t want = std::max<uint32_t>(1, (4096 + n_tiles - 1) / n_tiles);
+    static const uint32_t target_wgs = [] {
+        const char* e = std::getenv("M3D_SCORE_WGS");  // tuning knob (default chosen on MI355X)
+        const long v = e ? std::atol(e) : 0;
+        return (uint32_t)(v > 0 ? v : 8192);  // sweep on MI355X: 2048 +5 %, 4096 +1.5 %, 8192..32768 flat
+    }();
+    const uint32_t want = std::max<uint32_t>(1, (target_wgs + n_tiles - 1) / n_tiles);
     return std::min(want, groups);
 }
 
@@ -306,6 +306,29 @@ static int exact_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
     uint8_t* h = ctx->h_small.as<uint8_t>();
     HIPCHK(hipMemcpyAsync(h, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(h + 8, ctx->sums.as<double>() + 16, sizeof(double), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t c32;
+    std::memcpy(&c32, h, 4);
+    std::memcpy(error, h + 8, 8);
+    *count = c32;
+    return M3D_OK;
+}
+
+// Order-free sum of the inlier distances (tree) + count: enough to decide most ties (see tie rule
+// in run_ransac).
+static int approx_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
+                        const double* model_dev, uint64_t* count, double* error) {
+    RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
+    RESERVE(ctx->sums, sizeof(double) * 32);
+    RESERVE(ctx->total, sizeof(uint32_t) * 4);
+    RESERVE(ctx->h_small, 256);
+    launch_error_sum(kind, v, model_dev, thr, ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 20,
+                     ctx->total.as<uint32_t>() + 2, ctx->stream);
+    uint8_t* h = ctx->h_small.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(h, ctx->total.as<uint32_t>() + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h + 8, ctx->sums.as<double>() + 20, sizeof(double), hipMemcpyDeviceToHost,
                           ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -458,6 +481,7 @@ struct RansacOut {
     double best_host[kModelStride];
     uint64_t hypotheses_scored = 0;
     uint64_t exact_rmse_evals = 0;
+    int32_t ties = 0;
     double ms_sample = 0, ms_score = 0;
     int internal_error = 0;
 };
@@ -489,6 +513,8 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, int kind, double thr, 
     int rc = M3D_OK;
     int cur = 0;
     size_t next_begin = 0;
+    double best_approx = 0, pending_approx = 0;  // tree error sums of the current best / the trial
+    bool best_approx_known = false, pending_valid = false;
     auto issue_next = [&](int slot_id) -> int {
         const size_t b = next_begin, e = std::min(max_iter, b + chunk);
         const int r = issue_chunk(ctx, ctx->slot[slot_id], v, kind, thr, b, e, src, &out->ms_sample);
@@ -517,23 +543,72 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, int kind, double thr, 
             }
             HIPCHK(hipEventSynchronize(s.done));
             int cb_rc = M3D_OK;
-            auto rmse_of = [&](size_t i, bool is_best) -> double {
-                const double* model = is_best ? ctx->best_params.as<double>()
-                                              : s.params.as<double>() + (i - s.begin) * kModelStride;
+            // exact EvaluateModel rmse (serial-order error sum), ransac.h:632-650
+            auto exact_rmse = [&](const double* model, uint32_t expect, bool check) -> double {
                 uint64_t c = 0;
                 double err = 0;
                 const int r = exact_error(ctx, v, kind, thr, model, &c, &err);
                 if (r != M3D_OK) cb_rc = r;
                 out->exact_rmse_evals++;
-                if (!is_best && c != s.h_counts.as<uint32_t>()[i - s.begin]) out->internal_error = 1;
-                return c == 0 ? 1e+10 : err / std::sqrt((double)c);  // ransac.h:644-650
+                if (check && c != expect) out->internal_error = 1;
+                return c == 0 ? 1e+10 : err / std::sqrt((double)c);
+            };
+            // Tie rule `inlier_rmse < inlier_rmse_` (ransac.h:596) for equal inlier counts n.  Both rmse
+            // are error/sqrt(n) with the same n, hence monotone in the error sums.  Stage 1: order-free
+            // tree sums A_t, A_b; any summation order of n non-negative terms is within n*u*sum of the
+            // exact value, so the serial sums differ from A by at most 2*n*u*A: if the A's are further
+            // apart than the two margins (x2 safety) the comparison of the serial sums is decided.
+            // Stage 2 (rare: equal or near-equal hypotheses): the serial sums themselves.
+            auto tie = [&](size_t i, uint32_t cnt, double* trial_rmse, bool* trial_known) -> bool {
+                const double* model_t = s.params.as<double>() + (i - s.begin) * kModelStride;
+                *trial_known = false;
+                pending_valid = false;
+                out->ties++;
+                if (cnt == 0) {  // rmse = 1e10 (ransac.h:646) against the initial 0: never better
+                    *trial_rmse = 1e+10;
+                    *trial_known = true;
+                    return *trial_rmse < out->st.best_rmse;
+                }
+                uint64_t c = 0;
+                double a_t = 0;
+                int r = approx_error(ctx, v, kind, thr, model_t, &c, &a_t);
+                if (r != M3D_OK) cb_rc = r;
+                if (c != cnt) out->internal_error = 1;
+                if (!best_approx_known) {
+                    r = approx_error(ctx, v, kind, thr, ctx->best_params.as<double>(), &c, &best_approx);
+                    if (r != M3D_OK) cb_rc = r;
+                    best_approx_known = true;
+                }
+                const double nu4 = 4.0 * (double)cnt * 1.1102230246251565e-16;
+                const double m_t = nu4 * a_t, m_b = nu4 * best_approx;
+                if (a_t + m_t < best_approx - m_b) {
+                    pending_valid = true;
+                    pending_approx = a_t;
+                    return true;
+                }
+                if (a_t - m_t > best_approx + m_b) return false;
+                *trial_rmse = exact_rmse(model_t, cnt, true);
+                *trial_known = true;
+                if (!out->st.best_rmse_known) {
+                    out->st.best_rmse = exact_rmse(ctx->best_params.as<double>(), 0, false);
+                    out->st.best_rmse_known = 1;
+                }
+                if (*trial_rmse < out->st.best_rmse) {
+                    pending_valid = true;
+                    pending_approx = a_t;
+                    return true;
+                }
+                return false;
             };
             auto on_best = [&](size_t i) {
                 (void)hipMemcpyAsync(ctx->best_params.p, s.params.as<double>() + (i - s.begin) * kModelStride,
                                      sizeof(double) * kModelStride, hipMemcpyDeviceToDevice, ctx->stream);
+                best_approx_known = pending_valid;
+                best_approx = pending_approx;
+                pending_valid = false;
             };
             replay_range(&out->st, v.n, kind, max_iter, prob, s.begin, s.end, s.h_valid.as<uint8_t>(),
-                         s.h_counts.as<uint32_t>(), rmse_of, on_best);
+                         s.h_counts.as<uint32_t>(), tie, on_best);
             if (cb_rc != M3D_OK) {
                 rc = cb_rc;
                 break;
@@ -611,6 +686,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         stats->general_fit_ok = gf_ok;
         stats->hypotheses_scored = ro.hypotheses_scored;
         stats->exact_rmse_evals = ro.exact_rmse_evals;
+        stats->ties = ro.ties;
         stats->ms_sample = ro.ms_sample;
         stats->ms_score = ro.ms_score;
         stats->ms_refine = t2 - t1;
@@ -648,9 +724,16 @@ void m3d_replay_init(m3d_replay_state* st) {
 void m3d_replay_chunk(m3d_replay_state* st, size_t n_points, int kind, size_t max_iteration,
                       double probability, size_t begin, size_t end, const uint8_t* valid,
                       const uint32_t* counts, m3d_rmse_fn rmse_cb, void* user) {
-    replay_range(
-        st, n_points, kind, max_iteration, probability, begin, end, valid, counts,
-        [&](size_t i, bool) { return rmse_cb ? rmse_cb(user, i) : 0.0; }, [](size_t) {});
+    auto tie = [&](size_t i, uint32_t cnt, double* trial_rmse, bool* trial_known) -> bool {
+        *trial_rmse = cnt == 0 ? 1e+10 : (rmse_cb ? rmse_cb(user, i) : 0.0);
+        *trial_known = true;
+        if (!st->best_rmse_known) {
+            st->best_rmse = rmse_cb ? rmse_cb(user, (size_t)st->best_index) : 0.0;
+            st->best_rmse_known = 1;
+        }
+        return *trial_rmse < st->best_rmse;
+    };
+    replay_range(st, n_points, kind, max_iteration, probability, begin, end, valid, counts, tie, [](size_t) {});
 }
 
 m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, int device) {

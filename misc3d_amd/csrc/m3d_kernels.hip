@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_k(const double* __restrict_
 #pragma unroll
                 for (int j = 0; j < kScoreP; ++j) {
                     const double sv = sphere_s(cx, cy, cz, x[j], y[j], z[j]);
-                    cnt += (uint32_t)__popcll(__ballot(sv >= lo && sv <= hi));
+                    cnt += (uint32_t)__popcll(__ballot(sv >= lo) & __ballot(sv <= hi));  // two v_cmp + s_and_b64
                 }
             } else {
                 const double cx = rec[0], cy = rec[1], cz = rec[2], rx = rec[3], ry = rec[4],
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kScoreBlock) void score_k(const double* __restrict_
 #pragma unroll
                 for (int j = 0; j < kScoreP; ++j) {
                     const double tv = line_t(cx, cy, cz, rx, ry, rz, x[j], y[j], z[j]);
-                    cnt += (uint32_t)__popcll(__ballot(tv >= lo && tv <= hi));
+                    cnt += (uint32_t)__popcll(__ballot(tv >= lo) & __ballot(tv <= hi));
                 }
             }
             acc = ((uint32_t)lane == hh) ? cnt : acc;  // lane hh keeps the count of hypothesis hb + hh
@@ -457,29 +457,57 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
 }
 
 // EvaluateModel's `error += distance` in point order (ransac.h:637): a genuinely serial fp64 chain.
-// One lane adds; the other 63 lanes of the wave stage the next 64 values through LDS so the chain
-// only ever waits for an LDS read.
+// One wave: each lane loads one value of the next 64 (coalesced, prefetched one tile ahead), the
+// values are broadcast in order with v_readlane (independent of the chain) and EVERY lane performs
+// the same 64 dependent v_add_f64 -- no divergence, no LDS, no barrier; the chain runs at the
+// fp64 add latency.  Lanes past the end contribute +0.0, which leaves the (non-negative) sum as is.
 __global__ __launch_bounds__(64) void serial_sum_k(const double* __restrict__ v,
                                                     const uint32_t* __restrict__ n_ptr,
                                                     double* __restrict__ out) {
-    __shared__ double stage[2][64];
     const uint32_t n = n_ptr[0];
-    const int lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x;
     double s = 0.0;
-    uint32_t cur = 0;
-    if (lane < (int)n) stage[0][lane] = v[lane];
-    __syncthreads();
+    double nxt = lane < n ? v[lane] : 0.0;
     for (uint32_t b0 = 0; b0 < n; b0 += 64) {
-        const uint32_t nxt = b0 + 64 + lane;
-        if (nxt < n) stage[cur ^ 1][lane] = v[nxt];
-        if (lane == 0) {
-            const uint32_t lim = min(64u, n - b0);
-            for (uint32_t k = 0; k < lim; ++k) s += stage[cur][k];
-        }
-        __syncthreads();
-        cur ^= 1;
+        const double cur = nxt;
+        const uint32_t i = b0 + 64 + lane;
+        nxt = i < n ? v[i] : 0.0;
+        const int lo = __double2loint(cur), hi = __double2hiint(cur);
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+            s += __hiloint2double(__builtin_amdgcn_readlane(hi, k), __builtin_amdgcn_readlane(lo, k));
     }
     if (lane == 0) out[0] = s;
+}
+
+// Order-free (tree) sum of the inlier distances + inlier count of one model: the cheap first stage
+// of the tie rule.  |tree - serial| <= 2 n u * sum for n non-negative terms, so a tie is decided
+// from these sums whenever they differ by more than that bound; serial_sum_k runs only otherwise.
+template <int KIND>
+__global__ __launch_bounds__(256) void error_sum_k(CloudView c, const double* __restrict__ model,
+                                                    double thr, double* __restrict__ partial,
+                                                    uint32_t* __restrict__ count) {
+    __shared__ double sm[256];
+    double m[7];
+    for (int k = 0; k < 7; ++k) m[k] = model[k];
+    double acc = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < c.n; i += gridDim.x * 256u) {
+        const double d = ref_distance<KIND>(m, c.x[i], c.y[i], c.z[i]);
+        if (d < thr) {
+            acc += d;
+            cnt++;
+        }
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x * 16] = sm[0];
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(count, cnt);
 }
 
 void launch_serial_sum(const double* v, const uint32_t* n, double* out, hipStream_t s) {
@@ -564,6 +592,18 @@ void launch_sum_moments(const CloudView& c, const uint64_t* idx, uint32_t n_idx,
                         const double* sums_xyz, double* partial, double* sums, hipStream_t s) {
     sum_moments_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, sums_xyz, partial);
     sum_final_k<10><<<1, 256, 0, s>>>(partial, sums);
+}
+
+void launch_error_sum(int kind, const CloudView& c, const double* model, double thr, double* partial,
+                      double* sum_out, uint32_t* count_out, hipStream_t s) {
+    (void)hipMemsetAsync(count_out, 0, sizeof(uint32_t), s);
+    if (kind == 0)
+        error_sum_k<0><<<kSumBlocks, 256, 0, s>>>(c, model, thr, partial, count_out);
+    else if (kind == 1)
+        error_sum_k<1><<<kSumBlocks, 256, 0, s>>>(c, model, thr, partial, count_out);
+    else
+        error_sum_k<2><<<kSumBlocks, 256, 0, s>>>(c, model, thr, partial, count_out);
+    sum_final_k<1><<<1, 256, 0, s>>>(partial, sum_out);
 }
 
 }  // namespace m3d

@@ -73,6 +73,11 @@ void launch_sum_xyz(const CloudView& c, const uint64_t* idx, uint32_t n_idx, dou
 void launch_sum_moments(const CloudView& c, const uint64_t* idx, uint32_t n_idx,
                         const double* sums_xyz, double* partial, double* sums, hipStream_t s);
 
+// order-free sum of the inlier distances of one model + its inlier count (first stage of the tie
+// rule); partial: kSumPartialDoubles doubles.
+void launch_error_sum(int kind, const CloudView& c, const double* model, double thr, double* partial,
+                      double* sum_out, uint32_t* count_out, hipStream_t s);
+
 // exclusive scan of v[0..nb) in place by one workgroup; total[0] = sum
 void launch_scan_blocks(uint32_t* v, uint32_t nb, uint32_t* total, hipStream_t s);
 

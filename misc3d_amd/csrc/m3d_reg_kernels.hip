@@ -3,9 +3,9 @@
 // Replaces (third-party code reached from src/transform_estimation.cpp:124-164 and
 // src/correspondence_matching.cpp:13-84; algorithms per SURVEY.md 8a rows a17-a20):
 //   kabsch3_check_k   Open3D ComputeTransformation (Eigen::umeyama on 3 pairs) + EdgeLength/Distance checkers
-//   grid_*_k          Open3D KDTreeFlann(target) -> uniform grid (cell = 1.001 * threshold), counting sort
-//   reg_count_k       GetRegistrationResultAndCorrespondences: #source points with a target point at
-//                     squared distance < threshold^2, for every surviving hypothesis
+//   grid_*_k          Open3D KDTreeFlann(target) -> uniform grid (cell = 1.001 * threshold / K), counting sort
+//   reg_validate_k    GetRegistrationResultAndCorrespondences: per surviving hypothesis, #source points whose
+//                     nearest target point is at squared distance < threshold^2 and the sum of those distances
 //   reg_min_d2_k      the same per point (min squared distance) for the serial-order rmse of ONE hypothesis
 //   corr_ratio_k      EvaluateInlierCorrespondenceRatio
 //   kabsch_sums*_k    Eigen::umeyama sums for LeastSquareSolver (n correspondences)
@@ -148,6 +148,14 @@ __global__ void grid_scatter_k(CloudView dst, const uint32_t* __restrict__ cell_
     qz[pos] = dst.z[i];
 }
 
+__global__ void fill_nan_k(double* __restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = u2f(0x7FF8000000000000ull);
+}
+void launch_fill_nan(double* p, uint32_t n, hipStream_t s) {
+    if (n) fill_nan_k<<<(n + 255) / 256, 256, 0, s>>>(p, n);
+}
+
 void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
                        uint32_t* cell_start /* ncell + 1 */, uint32_t* fill /* ncell */,
                        uint32_t* tile_sums, uint32_t* total, double* qx, double* qy, double* qz,
@@ -164,34 +172,20 @@ void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_o
 }
 
 // ------------------------------------------------------------------------------------------------
-// K9  validation counts
+// K9  validation: nearest target point of every transformed source point, per surviving hypothesis
 // ------------------------------------------------------------------------------------------------
-// Does a target point at squared distance < r2 exist?  (SearchHybrid(p, r, 1) > 0: nearest
-// neighbour kept iff dist^2 < r*r.)  The 3 x-adjacent cells of a (y,z) row are contiguous in the
-// sorted arrays, so the 27-cell neighbourhood is 9 ranges.
-__device__ __forceinline__ bool has_neighbour(const GridDesc& g, const uint32_t* __restrict__ cell_start,
-                                              const double* __restrict__ qx, const double* __restrict__ qy,
-                                              const double* __restrict__ qz, double px, double py, double pz) {
-    int ix, iy, iz;
-    if (!cell_of(g, px, py, pz, 1, &ix, &iy, &iz)) return false;
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy) {
-            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
-            const uint32_t b = cell_start[row - 1], e = cell_start[row + 2];
-            for (uint32_t c = b; c < e; ++c) {
-                const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < g.r2) return true;
-            }
-        }
-    return false;
-}
-__device__ __forceinline__ double min_d2(const GridDesc& g, const uint32_t* __restrict__ cell_start,
-                                         const double* __restrict__ qx, const double* __restrict__ qy,
-                                         const double* __restrict__ qz, double px, double py, double pz) {
+// Exact nearest squared distance within the search radius (KDTreeFlann::SearchHybrid(p, r, 1)).
+// The grid cell is r/K.  Phase 1 scans the 3x3x3 block around the query's cell (9 contiguous x-rows):
+// every point outside that block is at least one cell edge away, so a hit closer than 0.999 h is the
+// true nearest neighbour -- the common case for an aligned pose.  Phase 2 (nothing that close) scans
+// the (2K+1)^3 block, which covers the whole radius.  `min` is order-free, so the value equals the
+// kd-tree's.  Returns +inf when nothing lies in the scanned block.
+__device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                             const double* __restrict__ qx, const double* __restrict__ qy,
+                                             const double* __restrict__ qz, double px, double py, double pz) {
     int ix, iy, iz;
     double best = INFINITY;
-    if (!cell_of(g, px, py, pz, 1, &ix, &iy, &iz)) return best;
+    if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return best;
     for (int dz = -1; dz <= 1; ++dz)
         for (int dy = -1; dy <= 1; ++dy) {
             const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
@@ -202,19 +196,36 @@ __device__ __forceinline__ double min_d2(const GridDesc& g, const uint32_t* __re
                 if (d2 < best) best = d2;
             }
         }
+    if (best < g.h2_in || g.K == 1) return best;
+    const int K = g.K;
+    for (int dz = -K; dz <= K; ++dz)
+        for (int dy = -K; dy <= K; ++dy) {
+            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
+            const uint32_t b = cell_start[row - K], e = cell_start[row + K + 1];
+            for (uint32_t c = b; c < e; ++c) {
+                const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
+                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                if (d2 < best) best = d2;
+            }
+        }
     return best;
 }
 
 // Same decomposition as score_k: source points stay in VGPRs (kRegP rows of 64 per wave), the
-// transformations of the surviving hypotheses stream through SGPRs, counts via ballot + s_bcnt1.
-__global__ __launch_bounds__(256) void reg_count_k(const double* __restrict__ sx, const double* __restrict__ sy,
-                                                    const double* __restrict__ sz, const double* __restrict__ Ts,
-                                                    uint32_t s_pad, uint32_t s_per_split, GridDesc g,
-                                                    const uint32_t* __restrict__ cell_start,
-                                                    const double* __restrict__ qx, const double* __restrict__ qy,
-                                                    const double* __restrict__ qz,
-                                                    uint32_t* __restrict__ partial) {
+// transformations of the surviving hypotheses stream through SGPRs.  Per hypothesis: the number of
+// source points whose nearest target point is closer than the threshold (ballot + s_bcnt1) and the
+// order-free sum of those squared distances (the rmse numerator; decides fitness ties, see the
+// driver).  partial_cnt / partial_sum: [tile][s_pad].
+__global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                       const double* __restrict__ sz, const double* __restrict__ Ts,
+                                                       uint32_t s_pad, uint32_t s_per_split, GridDesc g,
+                                                       const uint32_t* __restrict__ cell_start,
+                                                       const double* __restrict__ qx, const double* __restrict__ qy,
+                                                       const double* __restrict__ qz,
+                                                       uint32_t* __restrict__ partial_cnt,
+                                                       double* __restrict__ partial_sum) {
     __shared__ uint32_t red[4][64];
+    __shared__ double reds[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t base = (size_t)blockIdx.x * kRegTile + (size_t)wave * (64 * kRegP) + lane;
     double x[kRegP], y[kRegP], z[kRegP];
@@ -228,43 +239,66 @@ __global__ __launch_bounds__(256) void reg_count_k(const double* __restrict__ sx
     const uint32_t s1 = min(s0 + s_per_split, s_pad);
     for (uint32_t sb = s0; sb < s1; sb += 64) {
         uint32_t acc = 0;
+        double acc_sum = 0.0;
         for (uint32_t ss = 0; ss < 64; ++ss) {
             const double* __restrict__ T = Ts + (size_t)(sb + ss) * kRegTStride;
             double t[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) t[k] = T[k];
             uint32_t cnt = 0;
+            double sum = 0.0;
             if (t[0] == t[0]) {  // padding records are NaN (wave-uniform branch)
 #pragma unroll
                 for (int j = 0; j < kRegP; ++j) {
                     const double px = ((t[0] * x[j] + t[1] * y[j]) + t[2] * z[j]) + t[3];
                     const double py = ((t[4] * x[j] + t[5] * y[j]) + t[6] * z[j]) + t[7];
                     const double pz = ((t[8] * x[j] + t[9] * y[j]) + t[10] * z[j]) + t[11];
-                    const bool f = has_neighbour(g, cell_start, qx, qy, qz, px, py, pz);
+                    const double d2 = nearest_d2(g, cell_start, qx, qy, qz, px, py, pz);
+                    const bool f = d2 < g.r2;
                     cnt += (uint32_t)__popcll(__ballot(f));
+                    sum += f ? d2 : 0.0;
                 }
+                for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
             }
             acc = ((uint32_t)lane == ss) ? cnt : acc;
+            acc_sum = ((uint32_t)lane == ss) ? sum : acc_sum;
         }
         red[wave][lane] = acc;
+        reds[wave][lane] = acc_sum;
         __syncthreads();
-        if (wave == 0)
-            partial[(size_t)blockIdx.x * s_pad + sb + lane] =
+        if (wave == 0) {
+            partial_cnt[(size_t)blockIdx.x * s_pad + sb + lane] =
                 (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            partial_sum[(size_t)blockIdx.x * s_pad + sb + lane] =
+                (reds[0][lane] + reds[1][lane]) + (reds[2][lane] + reds[3][lane]);
+        }
         __syncthreads();
     }
 }
 
-void launch_reg_count(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t splits,
-                      const GridDesc& g, const uint32_t* cell_start, const double* qx, const double* qy,
-                      const double* qz, uint32_t* partial, hipStream_t s) {
+// sums[s] = sum over tiles of partial_sum[tile][s] in tile order (deterministic)
+__global__ void reduce_sums_k(const double* __restrict__ partial_sum, uint32_t n_tiles, uint32_t s_pad,
+                              double* __restrict__ sums) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= s_pad) return;
+    double acc = 0.0;
+    for (uint32_t t = 0; t < n_tiles; ++t) acc += partial_sum[(size_t)t * s_pad + s];
+    sums[s] = acc;
+}
+
+void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t splits,
+                         const GridDesc& g, const uint32_t* cell_start, const double* qx, const double* qy,
+                         const double* qz, uint32_t* partial_cnt, double* partial_sum, double* sums,
+                         hipStream_t s) {
     if (!s_pad || !src.n_pad) return;
     const uint32_t groups = s_pad / 64;
     const uint32_t gps = (groups + splits - 1) / splits;
     const uint32_t nsplit = (groups + gps - 1) / gps;
-    const dim3 grid(src.n_pad / kRegTile, nsplit), block(256);
-    reg_count_k<<<grid, block, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy, qz,
-                                       partial);
+    const uint32_t n_tiles = src.n_pad / kRegTile;
+    const dim3 grid(n_tiles, nsplit), block(256);
+    reg_validate_k<<<grid, block, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy, qz,
+                                          partial_cnt, partial_sum);
+    reduce_sums_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_sum, n_tiles, s_pad, sums);
 }
 
 // per-point nearest squared distance for ONE transformation (device pointer to 12 doubles)
@@ -280,7 +314,7 @@ __global__ void reg_min_d2_k(CloudView src, const double* __restrict__ T, GridDe
     const double px = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
     const double py = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
     const double pz = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
-    best[i] = min_d2(g, cell_start, qx, qy, qz, px, py, pz);
+    best[i] = nearest_d2(g, cell_start, qx, qy, qz, px, py, pz);
 }
 void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
                        const double* qx, const double* qy, const double* qz, double* best, hipStream_t s) {

@@ -5,15 +5,18 @@
 namespace m3d {
 
 constexpr int kRegTStride = 12;  // doubles per transformation record (rows 0..2 of the 4x4)
-constexpr int kRegP = 4;         // source points per lane in reg_count_k
+constexpr int kRegP = 4;         // source points per lane in reg_validate_k
 constexpr int kRegTile = 256 * kRegP;
 
-// Uniform grid over the target cloud.  Cell edge h = 1.001 * threshold, origin two cells below the
-// bounding-box minimum, two empty cells above the maximum, so the 3x3x3 neighbourhood of any query
-// cell in [1, n-2] stays inside the arrays and covers every target point closer than threshold.
+// Uniform grid over the target cloud.  Cell edge h = 1.001 * threshold / K (K = 4 unless the dense
+// cell table would not fit), origin K+1 cells below the bounding-box minimum and K+1 empty cells above
+// the maximum, so the (2K+1)^3 neighbourhood of any query cell in [K, n-1-K] stays inside the arrays
+// and covers every target point closer than threshold.
 struct GridDesc {
     double ox, oy, oz, inv_h, r2;
+    double h2_in;  // (0.999 h)^2: a neighbour closer than this inside the 3x3x3 block is the nearest
     uint32_t nx, ny, nz;
+    int K;
 };
 
 
@@ -26,9 +29,11 @@ void launch_gather_T(const double* T12, const uint32_t* list, uint32_t n, uint32
 void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
                        uint32_t* cell_start, uint32_t* fill, uint32_t* tile_sums, uint32_t* total,
                        double* qx, double* qy, double* qz, hipStream_t s);
-void launch_reg_count(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t splits,
-                      const GridDesc& g, const uint32_t* cell_start, const double* qx, const double* qy,
-                      const double* qz, uint32_t* partial, hipStream_t s);
+void launch_fill_nan(double* p, uint32_t n, hipStream_t s);
+void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t splits,
+                         const GridDesc& g, const uint32_t* cell_start, const double* qx, const double* qy,
+                         const double* qz, uint32_t* partial_cnt, double* partial_sum, double* sums,
+                         hipStream_t s);
 void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
                        const double* qx, const double* qy, const double* qz, double* best, hipStream_t s);
 void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* block_counts, uint32_t* total,

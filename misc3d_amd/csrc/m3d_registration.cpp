@@ -58,11 +58,13 @@ int ceil_to_int_x86(double v) {
 
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
-        tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio;
+        tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz;
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
-                          &block_counts, &sums, &one_T, &ratio})
+                          &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
+                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz})
             b->release();
     }
 };
@@ -228,9 +230,12 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                 }
             for (int k = 0; k < 3; ++k)
                 if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;
-            double h = threshold * 1.001;
+            // cell edge h = 1.001 thr / K, K = 4, 2, 1 ... while the dense cell table fits; if even K = 1
+            // does not fit the cell is doubled (a coarser grid with K = 1 still covers radius thr)
+            int K = 4;
+            double h = threshold * 1.001 / K;
             uint64_t dims[3];
-            for (;;) {  // coarsen until the dense cell table fits (a coarser grid still covers radius thr)
+            for (;;) {
                 bool fits = true;
                 uint64_t cells = 1;
                 for (int k = 0; k < 3; ++k) {
@@ -239,19 +244,23 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                         fits = false;
                         break;
                     }
-                    dims[k] = (uint64_t)ext + 1 + 4;
+                    dims[k] = (uint64_t)ext + 1 + 2 * (uint64_t)(K + 1);
                     cells *= dims[k];
                     if (cells > ((uint64_t)1 << 27)) fits = false;
                 }
                 if (fits) break;
+                if (K > 1)
+                    K /= 2;
                 h *= 2.0;
             }
             GridDesc g;
-            g.ox = lo[0] - 2.0 * h;
-            g.oy = lo[1] - 2.0 * h;
-            g.oz = lo[2] - 2.0 * h;
+            g.K = K;
+            g.ox = lo[0] - (K + 1) * h;
+            g.oy = lo[1] - (K + 1) * h;
+            g.oz = lo[2] - (K + 1) * h;
             g.inv_h = 1.0 / h;
             g.r2 = threshold * threshold;  // radius * radius, KDTreeFlann::SearchHybrid
+            g.h2_in = (0.999 * h) * (0.999 * h);
             g.nx = (uint32_t)dims[0];
             g.ny = (uint32_t)dims[1];
             g.nz = (uint32_t)dims[2];
@@ -268,6 +277,60 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
             launch_grid_build(R.dst, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
                               S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
                               S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream);
+
+            // ---- spatially sorted copy of the SOURCE cloud for the validation kernel: counts and
+            // order-free sums do not depend on the point order, and lanes of a wave that hold
+            // neighbouring source points probe the same target cells (L1/L2 hits instead of scattered
+            // gathers).  Same counting sort, 64^3 cells over the source bounding box.  Points with
+            // non-finite coordinates drop out (they can never have a neighbour).
+            CloudView src_sorted = R.src;
+            {
+                double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (size_t i = 0; i < n_src; ++i)
+                    for (int k = 0; k < 3; ++k) {
+                        const double v = src[3 * i + k];
+                        if (std::isfinite(v)) {
+                            slo[k] = std::min(slo[k], v);
+                            shi[k] = std::max(shi[k], v);
+                        }
+                    }
+                double ext = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    if (!(slo[k] <= shi[k])) slo[k] = shi[k] = 0.0;
+                    ext = std::max(ext, shi[k] - slo[k]);
+                }
+                if (ext > 0.0 && std::isfinite(ext)) {
+                    GridDesc gs;
+                    const double hs = ext / 63.0;
+                    gs.K = 0;
+                    gs.ox = slo[0];
+                    gs.oy = slo[1];
+                    gs.oz = slo[2];
+                    gs.inv_h = 1.0 / hs;
+                    gs.r2 = gs.h2_in = 0.0;
+                    gs.nx = (uint32_t)((shi[0] - slo[0]) / hs) + 2;
+                    gs.ny = (uint32_t)((shi[1] - slo[1]) / hs) + 2;
+                    gs.nz = (uint32_t)((shi[2] - slo[2]) / hs) + 2;
+                    const uint32_t ncs = gs.nx * gs.ny * gs.nz;
+                    const uint32_t np = R.src.n_pad;
+                    RESERVE(S.s_cell_of_point, sizeof(uint32_t) * n_src);
+                    RESERVE(S.s_cell_start, sizeof(uint32_t) * ((size_t)ncs + 1));
+                    RESERVE(S.s_fill, sizeof(uint32_t) * (size_t)ncs);
+                    RESERVE(S.s_tile_sums, sizeof(uint32_t) * ((size_t)(ncs + 2047) / 2048 + 1));
+                    RESERVE(S.sx, sizeof(double) * np);
+                    RESERVE(S.sy, sizeof(double) * np);
+                    RESERVE(S.sz, sizeof(double) * np);
+                    launch_fill_nan(S.sx.as<double>(), np, ctx->stream);
+                    launch_fill_nan(S.sy.as<double>(), np, ctx->stream);
+                    launch_fill_nan(S.sz.as<double>(), np, ctx->stream);
+                    launch_grid_build(R.src, gs, S.s_cell_of_point.as<uint32_t>(), S.s_cell_start.as<uint32_t>(),
+                                      S.s_fill.as<uint32_t>(), S.s_tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 2,
+                                      S.sx.as<double>(), S.sy.as<double>(), S.sz.as<double>(), ctx->stream);
+                    src_sorted.x = S.sx.as<double>();
+                    src_sorted.y = S.sy.as<double>();
+                    src_sorted.z = S.sz.as<double>();
+                }
+            }
 
             // ---- correspondences (CorrespondenceSet of Vector2i, transform_estimation.cpp:135-140)
             std::vector<uint32_t> cs(m), cd(m);
@@ -289,7 +352,7 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
             bool best_rmse_known = true;
             int64_t best_index = -1;
             int est_k_global = max_iter, est_k_local = max_iter;
-            uint64_t total_validation = 0;
+            uint64_t total_validation = 0, ties = 0, exact_evals = 0;
             int64_t iters = 0;
             RESERVE(S.one_T, sizeof(double) * kRegTStride * 2);
             double* best_T_dev = S.one_T.as<double>();
@@ -298,6 +361,8 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
             const uint32_t n_tiles = R.src.n_pad / kRegTile;
 
             std::vector<uint32_t> tri, survivors, h_counts;
+            std::vector<double> h_sum2;  // order-free sums of the nearest squared distances per survivor
+            double best_sum2 = 0.0;      // the same for the current best
             std::vector<uint8_t> pass;
             std::vector<int> itr_of;  // iteration index of each executed hypothesis of the chunk
             size_t chunk = 256;
@@ -332,19 +397,25 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                     RESERVE(S.list, sizeof(uint32_t) * ns);
                     RESERVE(S.Ts, sizeof(double) * kRegTStride * ((size_t)s_pad + 1));
                     RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * s_pad);
+                    RESERVE(S.partial_sum, sizeof(double) * (size_t)n_tiles * s_pad);
+                    RESERVE(S.sum2, sizeof(double) * s_pad);
                     RESERVE(S.counts, sizeof(uint32_t) * s_pad);
                     HIPCHK(hipMemcpyAsync(S.list.p, survivors.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice,
                                           ctx->stream));
                     launch_gather_T(S.T12.as<double>(), S.list.as<uint32_t>(), ns, s_pad + 1, S.Ts.as<double>(),
                                     ctx->stream);
                     const uint32_t want = std::max<uint32_t>(1, (2048 + n_tiles - 1) / n_tiles);
-                    launch_reg_count(R.src, S.Ts.as<double>(), s_pad, std::min(want, s_pad / 64), g,
-                                     S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
-                                     S.qz.as<double>(), S.partial.as<uint32_t>(), ctx->stream);
+                    launch_reg_validate(src_sorted, S.Ts.as<double>(), s_pad, std::min(want, s_pad / 64), g,
+                                        S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
+                                        S.qz.as<double>(), S.partial.as<uint32_t>(), S.partial_sum.as<double>(),
+                                        S.sum2.as<double>(), ctx->stream);
                     HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
                     launch_reduce_partials(S.partial.as<uint32_t>(), n_tiles, s_pad, S.counts.as<uint32_t>(),
                                            ctx->stream);
                     HIPCHK(hipMemcpyAsync(h_counts.data(), S.counts.p, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost,
+                                          ctx->stream));
+                    h_sum2.resize(ns);
+                    HIPCHK(hipMemcpyAsync(h_sum2.data(), S.sum2.p, sizeof(double) * ns, hipMemcpyDeviceToHost,
                                           ctx->stream));
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -358,36 +429,49 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                     iters++;
                     if (!pass[k]) continue;
                     const uint32_t cnt = h_counts[sv];
+                    const double a_t = cnt ? h_sum2[sv] : 0.0;
                     const double* T_dev = S.Ts.as<double>() + (size_t)sv * kRegTStride;
                     sv++;
                     const double fit = cnt ? (double)cnt / (double)n_src : 0.0;
                     bool better = fit > best_fit;
                     double rmse = 0.0;
                     bool rmse_known = cnt == 0;  // empty correspondence set: rmse = 0
-                    if (!better && fit == best_fit) {
-                        if (!rmse_known) {
+                    if (!better && fit == best_fit && cnt == 0) {
+                        better = false;  // 0 < best_rmse never holds (both are the empty result)
+                    } else if (!better && fit == best_fit) {
+                        // IsBetterRANSACThan on equal fitness: rmse = sqrt(err2 / n) with the same n on both
+                        // sides, monotone in err2.  Order-free sums decide unless they are closer than the
+                        // summation-order bound 2 n u sum (x2 safety); then the serial-order sums decide.
+                        ties++;
+                        const double nu4 = 4.0 * (double)cnt * 1.1102230246251565e-16;
+                        if (a_t + nu4 * a_t < best_sum2 - nu4 * best_sum2) {
+                            better = true;
+                        } else if (a_t - nu4 * a_t > best_sum2 + nu4 * best_sum2) {
+                            better = false;
+                        } else {
                             uint64_t c2;
                             double e2;
-                            const int r = exact_err2(R, T_dev, &c2, &e2);
+                            int r = exact_err2(R, T_dev, &c2, &e2);
                             if (r != M3D_OK) return r;
                             if (c2 != cnt) return fail(M3D_ERR_INTERNAL, "validation count mismatch");
                             rmse = std::sqrt(e2 / (double)c2);
                             rmse_known = true;
+                            exact_evals++;
+                            if (!best_rmse_known) {
+                                r = exact_err2(R, best_T_dev, &c2, &e2);
+                                if (r != M3D_OK) return r;
+                                best_rmse = c2 ? std::sqrt(e2 / (double)c2) : 0.0;
+                                best_rmse_known = true;
+                                exact_evals++;
+                            }
+                            better = rmse < best_rmse;
                         }
-                        if (!best_rmse_known) {
-                            uint64_t c2;
-                            double e2;
-                            const int r = exact_err2(R, best_T_dev, &c2, &e2);
-                            if (r != M3D_OK) return r;
-                            best_rmse = c2 ? std::sqrt(e2 / (double)c2) : 0.0;
-                            best_rmse_known = true;
-                        }
-                        better = rmse < best_rmse;  // IsBetterRANSACThan
                     }
                     if (better) {
                         best_fit = fit;
                         best_rmse = rmse;
                         best_rmse_known = rmse_known;
+                        best_sum2 = a_t;
                         best_index = it;
                         HIPCHK(hipMemcpyAsync(best_T_dev, T_dev, sizeof(double) * kRegTStride,
                                               hipMemcpyDeviceToDevice, ctx->stream));
@@ -427,6 +511,8 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                 stats->iterations = iters;
                 stats->best_index = best_index;
                 stats->est_k = est_k_global;
+                stats->ties = ties;
+                stats->exact_rmse_evals = exact_evals;
             }
             return M3D_OK;
         }();

@@ -1,0 +1,104 @@
+"""Run every BASELINE.json configuration once at full size on ONE MI355X and print a JSON line per
+config (timings from the C ABI's own clocks + wall clock).  Not the headline bench (that is
+bench.py); these lines feed DESIGN.md section 6 and check that the full sizes run at all.
+
+  C1 fit_plane 50k pts, 100 iters (plumbing)            C2 fit_plane 1M pts, 10k hyp (= bench.py)
+  C3 fit_cylinder + fit_sphere 1M pts, 50k hyp          C4 match + compute_transformation_ransac 200k<->200k, 100k hyp
+  C5 segment_plane_iterative 10M pts (single GPU leg)
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from misc3d_amd import capi, synth  # noqa: E402
+
+which = set(sys.argv[1:]) or {"C1", "C2", "C3", "C4", "C5"}
+
+
+def emit(name, **kw):
+    print(json.dumps({"config": name, **kw}), flush=True)
+
+
+def timed_fit(cloud, kind, thr, H, prob, seed, reps=3):
+    cloud.fit(kind, thr, H, prob, seed=seed, copy=False)
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        g = cloud.fit(kind, thr, H, prob, seed=seed, copy=False)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, g)
+    return best
+
+
+if "C1" in which:
+    pts = synth.plane_cloud_c1(50_000, 1)
+    with capi.Cloud(pts) as c:
+        dt, g = timed_fit(c, 0, 0.01, 100, 0.9999, 7)
+    emit("C1 fit_plane 50k x 100 iters p=0.9999", ms=dt * 1e3, iterations=g.stats["iterations"],
+         n_inliers=g.stats["n_inliers"], params=g.params.tolist())
+
+if "C2" in which:
+    pts = synth.plane_cloud_c2(1_000_000, 2)
+    with capi.Cloud(pts) as c:
+        dt, g = timed_fit(c, 0, 0.01, 10_000, 1.0, 11)
+    emit("C2 fit_plane 1M x 10k hyp", ms=dt * 1e3, hyp_per_s=10_000 / dt, n_inliers=g.stats["n_inliers"],
+         best_index=g.stats["best_index"], stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine")})
+
+if "C3" in which:
+    cp, cn = synth.cylinder_cloud_c3(1_000_000, 3)
+    with capi.Cloud(cp, cn) as c:
+        dt, g = timed_fit(c, 2, 0.01, 50_000, 1.0, 13, reps=2)
+    emit("C3 fit_cylinder 1M x 50k hyp", ms=dt * 1e3, hyp_per_s=50_000 / dt, n_inliers=g.stats["n_inliers"],
+         best_index=g.stats["best_index"], params=g.params.tolist(),
+         stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "exact_rmse_evals")})
+    sp = synth.sphere_cloud_c3(1_000_000, 4)
+    with capi.Cloud(sp) as c:
+        dt, g = timed_fit(c, 1, 0.01, 50_000, 1.0, 13, reps=2)
+    emit("C3 fit_sphere 1M x 50k hyp", ms=dt * 1e3, hyp_per_s=50_000 / dt, n_inliers=g.stats["n_inliers"],
+         best_index=g.stats["best_index"], params=g.params.tolist(),
+         stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "exact_rmse_evals")})
+
+if "C4" in which:
+    n = int(os.environ.get("M3D_C4_POINTS", "200000"))
+    d = synth.registration_pair_c4(n, seed=5)
+    t0 = time.perf_counter()
+    i0, i1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    t_match = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    i0, i1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    t_match2 = time.perf_counter() - t0
+    inv = np.empty(n, dtype=np.int64)
+    inv[d["perm"]] = np.arange(n)
+    true_frac = float(np.mean(inv[i0.astype(np.int64)] == i1.astype(np.int64)))
+    emit("C4 match_correspondence", n=n, dim=33, ms_first=t_match * 1e3, ms=t_match2 * 1e3, matches=len(i0),
+         true_fraction=true_frac, pair_dist_per_s=2.0 * n * n / t_match2)
+    t0 = time.perf_counter()
+    T, st = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=100_000,
+                                     edge_length_threshold=0.9, confidence=1.0, seed=17)
+    dt = time.perf_counter() - t0
+    emit("C4 compute_transformation_ransac 200k<->200k x 100k hyp", ms=dt * 1e3, hyp_per_s=100_000 / dt,
+         validations=st["validations"], fitness=st["fitness"], best_index=st["best_index"],
+         pose_err=float(np.abs(T - d["T"]).max()))
+    t0 = time.perf_counter()
+    T2, st2 = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=100_000,
+                                       edge_length_threshold=0.9, confidence=0.999, seed=17)
+    emit("C4 same with the reference's confidence 0.999", ms=(time.perf_counter() - t0) * 1e3,
+         iterations=st2["iterations"], validations=st2["validations"], pose_err=float(np.abs(T2 - d["T"]).max()))
+
+if "C5" in which:
+    n = int(os.environ.get("M3D_C5_POINTS", "10000000"))
+    pts = synth.room_cloud_c5(n, 6)
+    t0 = time.perf_counter()
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19)
+    dt2 = time.perf_counter() - t0
+    emit("C5 segment_plane_iterative 10M pts (1 GPU, incl. 240 MB upload)", ms_first=dt * 1e3, ms=dt2 * 1e3, rc=rc,
+         clusters=[len(c) for c in clusters], planes=[[round(float(v), 4) for v in p] for p in planes])
