@@ -99,6 +99,21 @@ int m3d_draw_samples(size_t n_points, int kind, size_t n_hypotheses, uint64_t se
 int m3d_cloud_score_range(m3d_cloud *cloud, int kind, double threshold, const uint32_t *samples,
                           size_t begin, size_t end, uint32_t *counts, uint8_t *valid,
                           double *models);
+/* Sequential sampler object = the RandomSampler of ransac.h:570 with an explicit seed; it records
+ * every sample it has drawn (m3d_sampler_table(s, H) draws up to H hypotheses and returns the H x m
+ * table).  m3d_cloud_score_shard scores ONE rank's share of hypotheses [begin,end) of that single
+ * stream: the window is cut into slices of `slice` hypotheses, slice j belongs to rank j % world.
+ * Every rank draws the whole window (identical tables everywhere), kernels for this rank's slices are
+ * launched as soon as their samples exist, so drawing the other ranks' slices overlaps GPU scoring.
+ * counts/valid receive this rank's records in increasing hypothesis order, *n_mine their number. */
+typedef struct m3d_sampler m3d_sampler;
+m3d_sampler *m3d_sampler_create(size_t n_points, int kind, uint64_t seed);
+void m3d_sampler_destroy(m3d_sampler *s);
+size_t m3d_sampler_drawn(const m3d_sampler *s);
+const uint32_t *m3d_sampler_table(m3d_sampler *s, size_t n_hypotheses);
+int m3d_cloud_score_shard(m3d_cloud *cloud, m3d_sampler *sampler, double threshold, size_t begin,
+                          size_t end, size_t slice, uint32_t world, uint32_t rank, uint32_t *counts,
+                          uint8_t *valid, size_t *n_mine);
 /* Serial-order error sum of EvaluateModel for ONE model (ransac.h:632-640), used to break
  * fitness ties exactly as the reference does.  *count is the inlier number, *error the sum. */
 int m3d_cloud_exact_error(m3d_cloud *cloud, int kind, double threshold, const double *model,

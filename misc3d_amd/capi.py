@@ -92,6 +92,16 @@ def lib():
         L.m3d_cloud_refine.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_time_score.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int,
                                            C.c_void_p]
+        L.m3d_sampler_create.restype = C.c_void_p
+        L.m3d_sampler_create.argtypes = [C.c_size_t, C.c_int, C.c_uint64]
+        L.m3d_sampler_destroy.argtypes = [C.c_void_p]
+        L.m3d_sampler_destroy.restype = None
+        L.m3d_sampler_drawn.argtypes = [C.c_void_p]
+        L.m3d_sampler_drawn.restype = C.c_size_t
+        L.m3d_sampler_table.argtypes = [C.c_void_p, C.c_size_t]
+        L.m3d_sampler_table.restype = C.c_void_p
+        L.m3d_cloud_score_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_size_t, C.c_size_t, C.c_size_t,
+                                            C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_draw_samples.argtypes = [C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.c_void_p]
         L.m3d_replay_init.argtypes = [C.c_void_p]
         L.m3d_replay_init.restype = None
@@ -153,8 +163,73 @@ class Fit:
     stats: dict
 
 
+class Sampler:
+    """m3d_sampler: the sequential RandomSampler (utils.h:71-97) with an explicit seed; records its table."""
+
+    def __init__(self, n_points, kind, seed):
+        self.kind = kind
+        self.m = MINIMAL_SAMPLE[kind]
+        self._h = lib().m3d_sampler_create(n_points, kind, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF))
+        if not self._h:
+            raise M3DError(ERR_INVALID_ARG, last_error())
+
+    def table(self, n_hyp):
+        """(n_hyp, m) uint32 view of the first n_hyp samples (drawing them if necessary)."""
+        ptr = lib().m3d_sampler_table(self._h, n_hyp)
+        if n_hyp == 0:
+            return np.zeros((0, self.m), dtype=np.uint32)
+        buf = (C.c_uint32 * (n_hyp * self.m)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(n_hyp, self.m)
+
+    @property
+    def drawn(self):
+        return int(lib().m3d_sampler_drawn(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().m3d_sampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_layout(begin, end, slice_, world):
+    """Index bookkeeping of m3d_cloud_score_shard: for the window [begin, end) cut into slices of
+    `slice_`, returns (mine, order) where mine[r] = global indices owned by rank r (ascending) and the
+    global order is recovered from the rank-major concatenation (padded to max_mine per rank) through
+    `order`: global_records = gathered.reshape(world, max_mine)[order_rank, order_pos]."""
+    g = np.arange(begin, end, dtype=np.int64)
+    j = (g - begin) // slice_
+    owner = (j % world).astype(np.int64)
+    pos = np.empty(len(g), dtype=np.int64)
+    counts = np.zeros(world, dtype=np.int64)
+    for r in range(world):
+        sel = owner == r
+        k = int(sel.sum())
+        pos[sel] = np.arange(k)
+        counts[r] = k
+    return owner, pos, counts
+
+
 class Cloud:
     """Resident SoA copy of a point cloud in HBM (RANSAC::SetPointCloud, ransac.h:469-475)."""
+
+    def make_sampler(self, kind, seed):
+        return Sampler(self.n, kind, seed)
+
+    def score_shard(self, sampler, threshold, begin, end, slice_, world, rank):
+        """m3d_cloud_score_shard -> (valid, counts) of this rank's hypotheses in [begin, end)."""
+        cap = end - begin
+        cnt = np.empty(max(cap, 1), dtype=np.uint32)
+        val = np.empty(max(cap, 1), dtype=np.uint8)
+        n = C.c_size_t(0)
+        _check(lib().m3d_cloud_score_shard(self._h, sampler._h, threshold, begin, end, slice_, world, rank, _p(cnt),
+                                           _p(val), C.cast(C.byref(n), C.c_void_p)))
+        return val[: n.value], cnt[: n.value]
 
     def __init__(self, xyz, normals=None, device: int = 0):
         xyz = _f64(xyz).reshape(-1, 3)
@@ -208,15 +283,16 @@ class Cloud:
         d["n_inliers"] = int(ni.value)
         return Fit(rc, params, inliers, d)
 
-    def score_range(self, kind, threshold, samples, begin=0, end=None):
+    def score_range(self, kind, threshold, samples, begin=0, end=None, want_models=True):
+        """m3d_cloud_score_range -> (valid, models or None, counts) for hypotheses [begin, end)."""
         samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, MINIMAL_SAMPLE[kind])
         end = len(samples) if end is None else end
-        cnt = np.zeros(end - begin, dtype=np.uint32)
-        val = np.zeros(end - begin, dtype=np.uint8)
-        mod = np.zeros((end - begin, MODEL_STRIDE))
+        cnt = np.empty(end - begin, dtype=np.uint32)
+        val = np.empty(end - begin, dtype=np.uint8)
+        mod = np.empty((end - begin, MODEL_STRIDE)) if want_models else None
         _check(lib().m3d_cloud_score_range(self._h, kind, threshold, _p(samples), begin, end, _p(cnt), _p(val),
                                            _p(mod)))
-        return val, mod[:, : NUM_PARAMS[kind]].copy(), cnt
+        return val, (mod[:, : NUM_PARAMS[kind]].copy() if want_models else None), cnt
 
     def time_score(self, kind, threshold, samples, reps=5) -> float:
         """Average duration (ms) of the scoring kernel alone over `reps` launches (HIP events)."""
@@ -234,13 +310,15 @@ class Cloud:
                                            C.cast(C.byref(err), C.c_void_p)))
         return int(cnt.value), float(err.value)
 
-    def refine(self, kind, threshold, params):
+    def refine(self, kind, threshold, params, copy=True):
         params = _f64(params).copy()
-        inl = np.zeros(max(self.n, 1), dtype=np.uint64)
+        if getattr(self, "_inl_buf", None) is None:
+            self._inl_buf = np.empty(max(self.n, 1), dtype=np.uint64)
+        inl = self._inl_buf
         ni = C.c_size_t(0)
         rc = _check(lib().m3d_cloud_refine(self._h, kind, threshold, _p(params), _p(inl),
                                            C.cast(C.byref(ni), C.c_void_p)))
-        return rc, params, inl[: ni.value].copy()
+        return rc, params, (inl[: ni.value].copy() if copy else inl[: ni.value])
 
 
 def draw_samples(n_points, kind, n_hyp, seed):

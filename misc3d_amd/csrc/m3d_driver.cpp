@@ -226,14 +226,21 @@ struct SampleSource {
             std::memcpy(out, table + begin * m, sizeof(uint32_t) * (end - begin) * m);
             return;
         }
+        // `rng_() % size_` (utils.h:89) with a 32-bit generator output and size < 2^31: exact
+        // remainder by multiplication (Lemire's fastmod: M = ceil(2^64 / d);
+        // x mod d = high64((M * x mod 2^64) * d)), ~4x cheaper than the 64-bit divide.
+        const uint32_t d = (uint32_t)n_points;
+        const uint64_t M = UINT64_C(0xFFFFFFFFFFFFFFFF) / d + 1;
         for (size_t h = begin; h < end; ++h) {
             uint32_t* s = out + (h - begin) * m;
             int valid = 0;
             while (valid < m) {  // utils.h:88-95
-                const size_t idx = (size_t)rng() % n_points;
+                const uint32_t x = (uint32_t)rng();
+                const uint64_t low = M * x;
+                const uint32_t idx = (uint32_t)(((unsigned __int128)low * d) >> 64);
                 bool dup = false;
                 for (int k = 0; k < valid; ++k) dup = dup || (s[k] == idx);
-                if (!dup) s[valid++] = (uint32_t)idx;
+                if (!dup) s[valid++] = idx;
             }
         }
     }
@@ -889,6 +896,103 @@ int m3d_cloud_score_range(m3d_cloud* c, int kind, double threshold, const uint32
             HIPCHK(hipMemcpy(models + (b - begin) * kModelStride, s.params.p,
                              sizeof(double) * kModelStride * (e - b), hipMemcpyDeviceToHost));
     }
+    return M3D_OK;
+}
+
+// ---- sequential sampler object + sharded scoring (multi-GPU) -----------------------------------------
+struct m3d_sampler {
+    SampleSource src;
+    int kind = 0;
+    std::vector<uint32_t> table;  // every sample drawn so far, H x m
+    size_t drawn = 0;
+    void draw_until(size_t h_end) {
+        if (h_end <= drawn) return;
+        table.resize(h_end * (size_t)src.m);
+        src.fill(drawn, h_end, table.data() + drawn * (size_t)src.m);
+        drawn = h_end;
+    }
+};
+
+m3d_sampler* m3d_sampler_create(size_t n_points, int kind, uint64_t seed) {
+    if (kind < 0 || kind > 2 || n_points < (size_t)minimal_sample(kind) || n_points >= ((size_t)1 << 31)) {
+        set_error("m3d_sampler_create: invalid argument");
+        return nullptr;
+    }
+    m3d_sampler* s = new m3d_sampler();
+    s->kind = kind;
+    s->src.rng.seed((std::mt19937::result_type)(seed & 0xffffffffull));
+    s->src.n_points = n_points;
+    s->src.m = minimal_sample(kind);
+    return s;
+}
+void m3d_sampler_destroy(m3d_sampler* s) { delete s; }
+size_t m3d_sampler_drawn(const m3d_sampler* s) { return s ? s->drawn : 0; }
+const uint32_t* m3d_sampler_table(m3d_sampler* s, size_t n_hypotheses) {
+    if (!s) return nullptr;
+    s->draw_until(n_hypotheses);
+    return s->table.data();
+}
+
+int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, size_t begin, size_t end,
+                          size_t slice, uint32_t world, uint32_t rank, uint32_t* counts, uint8_t* valid,
+                          size_t* n_mine) {
+    if (!c || !sampler || !counts || !valid || !n_mine || end < begin || slice == 0 || world == 0 ||
+        rank >= world)
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    const int kind = sampler->kind;
+    if (kind == M3D_CYLINDER && !c->has_normals)
+        return fail(M3D_ERR_NO_NORMALS, "Fit cylinder requires normals.");
+    if (sampler->src.n_points != c->n) return fail(M3D_ERR_INVALID_ARG, "sampler and cloud sizes differ");
+    if (sampler->drawn > begin) return fail(M3D_ERR_INVALID_ARG, "sampler is already past `begin`");
+    DeviceCtx* ctx = c->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const CloudView v = c->view();
+    const uint32_t n_tiles = std::max<uint32_t>(1, v.n_pad / kScoreTile);
+    const size_t chunk_cap = std::max<size_t>(64, std::min<size_t>(16384, ((size_t)1 << 28) / n_tiles / 64 * 64));
+    SampleSource tsrc;  // table-backed view of the sampler
+    tsrc.m = sampler->src.m;
+    size_t out = 0;
+    struct Pending {
+        bool active = false;
+        size_t out_pos = 0, n = 0;
+    } pend[2];
+    int cur = 0;
+    auto collect = [&](int k) -> int {
+        if (!pend[k].active) return M3D_OK;
+        ChunkSlot& s = ctx->slot[k];
+        HIPCHK(hipEventSynchronize(s.done));
+        std::memcpy(counts + pend[k].out_pos, s.h_counts.p, sizeof(uint32_t) * pend[k].n);
+        std::memcpy(valid + pend[k].out_pos, s.h_valid.p, pend[k].n);
+        pend[k].active = false;
+        return M3D_OK;
+    };
+    size_t j = 0;
+    for (size_t b = begin; b < end; b += slice, ++j) {
+        const size_t e = std::min(end, b + slice);
+        // every rank draws the whole stream (the host draws the other ranks' slices while this rank's
+        // previous slice is being scored on the GPU)
+        sampler->draw_until(e);
+        if (j % world != rank) continue;
+        for (size_t bb = b; bb < e; bb += chunk_cap) {
+            const size_t ee = std::min(e, bb + chunk_cap);
+            int rc = collect(cur);
+            if (rc != M3D_OK) return rc;
+            tsrc.table = sampler->table.data();
+            rc = issue_chunk(ctx, ctx->slot[cur], v, kind, threshold, bb, ee, tsrc, nullptr);
+            if (rc != M3D_OK) return rc;
+            pend[cur].active = true;
+            pend[cur].out_pos = out;
+            pend[cur].n = ee - bb;
+            out += ee - bb;
+            cur ^= 1;
+        }
+    }
+    int rc = collect(0);
+    if (rc != M3D_OK) return rc;
+    rc = collect(1);
+    if (rc != M3D_OK) return rc;
+    *n_mine = out;
     return M3D_OK;
 }
 

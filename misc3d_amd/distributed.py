@@ -3,15 +3,20 @@
 
 Hypotheses are the independent unit of the reference loop (ransac.h:571-590 has no cross-iteration
 dependency except the best-model reduction, ransac.h:592-613).  Every rank holds a replica of the
-cloud in HBM (10 M points = 240 MB), draws the SAME sample table from the same std::mt19937 seed,
-scores a CONTIGUOUS slice of each global chunk through the C ABI (m3d_cloud_score_range), and one
-all-gather per chunk exchanges the per-hypothesis (valid, inlier count) records -- 4 bytes per
-hypothesis, latency-bound.  Every rank then replays the sequential best-update / adaptive-stop rule
-in index order (m3d_replay_chunk), so the chosen hypothesis, the iteration count and the inlier set
-are identical to the single-GPU run and independent of the number of GPUs.
+cloud in HBM (10 M points = 240 MB) and a sampler seeded identically, so all ranks see ONE sample
+stream.  A window of the stream is cut into slices; slice j is scored by rank j % world through the
+C ABI (m3d_cloud_score_shard: the host draws the other ranks' slices while the GPU scores its own).
+One all-gather per window exchanges the per-hypothesis (valid, inlier count) records -- 4 bytes per
+hypothesis, latency-bound on xGMI.  Every rank then replays the sequential best-update / adaptive-
+stop rule in index order (m3d_replay_chunk), so the chosen hypothesis, the iteration count and the
+inlier set are identical to the single-GPU run and independent of the number of GPUs.
 
 The scorer is injected so the N>1 control path can be tested on CPU with gloo (the tests plug the
-oracle in as the scorer; the product scorer is ``capi.Cloud``).
+oracle in as the scorer; the product scorer is ``capi.Cloud``).  Scorer interface:
+    make_sampler(kind, seed) -> object with .table(n_hyp) -> (n_hyp, m) uint32
+    score_shard(sampler, thr, begin, end, slice, world, rank) -> (valid u8, counts u32) of this rank's share
+    score_range(kind, thr, table, begin, end) -> (valid, models, counts)        (single hypotheses, rare)
+    exact_error(kind, thr, model) -> (count, error);  refine(kind, thr, params, copy) -> (ret, params, inliers)
 """
 from __future__ import annotations
 
@@ -21,6 +26,8 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import capi
+
+SLICE = 2048  # hypotheses per slice: ~0.45 ms of scoring on a 1 M-point cloud, 16 us of sampling
 
 
 @dataclass
@@ -43,32 +50,22 @@ def _world(group):
     return 1, 0, False
 
 
-def _all_gather_records(valid, counts, per_rank, group, device, have_pg):
-    """all_gather of fixed-size (per_rank) records; the valid flag rides in bit 31 of the count
-    (counts < 2^31).  Returns (world*per_rank,) arrays in rank order = global hypothesis order."""
-    if not have_pg:
-        return valid, counts
+def _all_gather_records(rec, group, device):
+    """all_gather of equal-length int32 record arrays -> (world, len) uint32 array."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    rec = (counts | (valid.astype(np.uint32) << np.uint32(31))).view(np.int32)
-    t = torch.from_numpy(rec)
+    t = torch.from_numpy(rec.view(np.int32))
     if device is not None:
         t = t.to(device)
-    out = torch.empty(world * per_rank, dtype=torch.int32, device=t.device)
+    out = torch.empty(world * len(rec), dtype=torch.int32, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
-    full = out.cpu().numpy().view(np.uint32)
-    return (full >> np.uint32(31)).astype(np.uint8), full & np.uint32(0x7FFFFFFF)
+    return out.cpu().numpy().view(np.uint32).reshape(world, len(rec))
 
 
 def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, probability=0.9999, seed=0,
-                group=None, device=None, want_inliers=True) -> ShardedFit:
-    """RANSAC::FitModel with the hypothesis loop sharded over the ranks of `group`.
-
-    scorer: object with score_range(kind, thr, samples, begin, end) -> (valid, models, counts),
-            exact_error(kind, thr, model) -> (count, error), refine(kind, thr, params) -> (ret, params, inliers)
-            (``capi.Cloud`` has exactly this interface).
-    """
+                group=None, device=None, want_inliers=True, copy=True, slice_size=SLICE) -> ShardedFit:
+    """RANSAC::FitModel with the hypothesis loop sharded over the ranks of `group`."""
     world, rank, have_pg = _world(group)
     m = capi.MINIMAL_SAMPLE[kind]
     if probability <= 0 or probability > 1:
@@ -76,28 +73,23 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
     if n_points < m:
         raise capi.M3DError(capi.ERR_TOO_FEW_POINTS, "Can not fit model due to lack of points")
     H = int(max_iteration)
-    table = capi.draw_samples(n_points, kind, H, seed) if H else np.zeros((0, m), dtype=np.uint32)
+    sampler = scorer.make_sampler(kind, seed)
 
     st = capi.ReplayState()
     capi.lib().m3d_replay_init(C.byref(st))
-    if probability >= 1.0:
-        per_rank = max(64, -(-H // world))      # one round: early exit is impossible except fitness == 1
-    else:
-        per_rank = 128
-    cap = 16384
+    # window schedule: everything at once when the loop cannot stop early (probability == 1), else
+    # geometric windows so that little is scored beyond the adaptive stop
+    window = H if probability >= 1.0 else 128 * world
     begin = 0
     scored = 0
     collectives = 0
     best_model = None
-    cur = {"lo": 0, "hi": 0, "models": None}     # this rank's slice of the chunk being replayed
 
     def model_of(i):
         i = int(i)
-        if i == st.best_index and best_model is not None:
-            return best_model
-        if cur["models"] is not None and cur["lo"] <= i < cur["hi"]:
-            return cur["models"][i - cur["lo"]]
-        _, mod, _ = scorer.score_range(kind, threshold, table, i, i + 1)     # another rank's hypothesis: recompute
+        if best_model is not None and i == best_model[0]:
+            return best_model[1]
+        _, mod, _ = scorer.score_range(kind, threshold, sampler.table(i + 1), i, i + 1)   # one-row launch (rare)
         return mod[0]
 
     def rmse_of(_user, i):
@@ -106,42 +98,35 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
 
     cb = capi.RMSE_FN(rmse_of)
     while begin < H and not st.stopped:
-        end = min(H, begin + per_rank * world)
-        lo = min(end, begin + rank * per_rank)
-        hi = min(end, lo + per_rank)
-        valid = np.zeros(per_rank, dtype=np.uint8)
-        counts = np.zeros(per_rank, dtype=np.uint32)
-        cur["lo"], cur["hi"], cur["models"] = lo, hi, None
-        if hi > lo:
-            v, mod, c = scorer.score_range(kind, threshold, table, lo, hi)
-            valid[: hi - lo] = v
-            counts[: hi - lo] = c
-            cur["models"] = mod
-            scored += hi - lo
-        gv, gc = _all_gather_records(valid, counts, per_rank, group, device, have_pg)
-        collectives += 1 if have_pg else 0
-        # records of rank r sit at [r*per_rank, (r+1)*per_rank): global order is contiguous
-        n_chunk = end - begin
-        gv = np.ascontiguousarray(gv[:n_chunk])
-        gc = np.ascontiguousarray(gc[:n_chunk])
+        end = min(H, begin + window)
+        sl = max(1, min(slice_size, -(-(end - begin) // world)))
+        v, c = scorer.score_shard(sampler, threshold, begin, end, sl, world, rank)
+        scored += len(c)
+        owner, pos, per = capi.shard_layout(begin, end, sl, world)
+        if have_pg:
+            width = int(per.max())
+            rec = np.zeros(width, dtype=np.uint32)
+            rec[: len(c)] = c | (v.astype(np.uint32) << np.uint32(31))      # counts < 2^31
+            allrec = _all_gather_records(rec, group, device)
+            collectives += 1
+            g = allrec[owner, pos]
+        else:
+            g = c | (v.astype(np.uint32) << np.uint32(31))
+            g = g[pos]
+        gv = np.ascontiguousarray((g >> np.uint32(31)).astype(np.uint8))
+        gc = np.ascontiguousarray(g & np.uint32(0x7FFFFFFF))
         prev_best = st.best_index
         capi.lib().m3d_replay_chunk(C.byref(st), n_points, kind, H, probability, begin, end,
                                     gv.ctypes.data_as(C.c_void_p), gc.ctypes.data_as(C.c_void_p), cb, None)
-        if st.best_index != prev_best:           # keep the best model across chunks
+        if st.best_index != prev_best:           # keep the best model across windows
             bi = int(st.best_index)
-            if cur["models"] is not None and lo <= bi < hi:
-                best_model = cur["models"][bi - lo].copy()
-            else:
-                best_model = None
-                best_model = model_of(bi).copy()
+            best_model = None
+            best_model = (bi, model_of(bi).copy())
         begin = end
-        per_rank = min(per_rank * 2, cap)
+        window = min(window * 2, 16384 * world)
 
-    if st.best_index >= 0:
-        best = best_model if best_model is not None else model_of(int(st.best_index))
-    else:
-        best = np.zeros(capi.NUM_PARAMS[kind])
-    ret, params, inliers = scorer.refine(kind, threshold, best)
+    best = best_model[1] if (st.best_index >= 0 and best_model is not None) else np.zeros(capi.NUM_PARAMS[kind])
+    ret, params, inliers = scorer.refine(kind, threshold, best, copy=copy)
     if st.best_index >= 0 and len(inliers) != st.best_count:
         raise capi.M3DError(capi.ERR_INTERNAL, "refine pass and gathered counts disagree")
     if not want_inliers:

@@ -1,0 +1,134 @@
+// C++ user of the host mirror (include/misc3d/**): the code shape of the reference's
+// examples/cpp/ransac_and_boundary.cpp:36-41, segment_plane_iterative.cpp:15-19 and
+// transform_estimation.cpp:69-87, with analytic expectations.  Exit code 0 = all checks passed.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include <misc3d/common/ransac.h>
+#include <misc3d/registration/correspondence_matching.h>
+#include <misc3d/registration/transform_estimation.h>
+#include <misc3d/segmentation/iterative_plane_segmentation.h>
+
+#define CHECK(cond)                                                   \
+    do {                                                              \
+        if (!(cond)) {                                                \
+            std::printf("CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            return 1;                                                 \
+        }                                                             \
+    } while (0)
+
+int main() {
+    misc3d::SetVerbosityLevel(misc3d::VerbosityLevel::Warning);
+    std::mt19937 gen(1);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    std::normal_distribution<double> G(0.0, 0.002);
+
+    // ---- RANSACPlane on 60 % plane z = 1 + outliers
+    misc3d::PointCloud pc;
+    for (int i = 0; i < 20000; ++i) {
+        if (i % 5 < 3)
+            pc.points_.push_back({U(gen), U(gen), 1.0 + G(gen)});
+        else
+            pc.points_.push_back({U(gen), U(gen), U(gen)});
+    }
+    misc3d::common::RANSACPlane fit;
+    fit.SetMaxIteration(1000);
+    fit.SetProbability(0.9999);
+    fit.SetSeed(7);
+    fit.SetPointCloud(pc);
+    misc3d::common::Plane plane;
+    std::vector<size_t> inliers;
+    const bool ret = fit.FitModel(0.01, plane, inliers);
+    CHECK(ret);
+    CHECK(plane.parameters_.size() == 4);
+    CHECK(std::fabs(std::fabs(plane.parameters_[2]) - 1.0) < 1e-3);
+    CHECK(std::fabs(std::fabs(plane.parameters_[3]) - 1.0) < 1e-3);
+    CHECK(inliers.size() > 11500 && inliers.size() < 12800);
+    for (size_t k = 1; k < inliers.size(); ++k) CHECK(inliers[k] > inliers[k - 1]);
+    // determinism for a fixed seed
+    misc3d::common::Plane plane2;
+    std::vector<size_t> inliers2;
+    CHECK(fit.FitModel(0.01, plane2, inliers2));
+    CHECK(inliers2 == inliers && plane2.parameters_ == plane.parameters_);
+
+    // ---- error convention: exceptions with the reference's messages
+    bool threw = false;
+    try {
+        fit.SetProbability(1.5);
+    } catch (const std::runtime_error& e) {
+        threw = std::string(e.what()).find("Probability must be") != std::string::npos;
+    }
+    CHECK(threw);
+    threw = false;
+    try {
+        misc3d::common::RANSACCylinder cyl;
+        cyl.SetPointCloud(pc);  // no normals
+        misc3d::common::Cylinder c;
+        std::vector<size_t> idx;
+        cyl.FitModel(0.01, c, idx);
+    } catch (const std::runtime_error& e) {
+        threw = std::string(e.what()).find("requires normals") != std::string::npos;
+    }
+    CHECK(threw);
+
+    // ---- sphere
+    misc3d::PointCloud sp;
+    for (int i = 0; i < 8000; ++i) {
+        double x = G(gen) * 500, y = G(gen) * 500, z = G(gen) * 500;
+        const double n = std::sqrt(x * x + y * y + z * z);
+        if (i % 2 == 0)
+            sp.points_.push_back({0.3 + 0.5 * x / n, -0.2 + 0.5 * y / n, 1.0 + 0.5 * z / n});
+        else
+            sp.points_.push_back({U(gen) * 2, U(gen) * 2, U(gen) * 2});
+    }
+    misc3d::common::RANSACShpere sfit;
+    sfit.SetMaxIteration(500);
+    sfit.SetSeed(3);
+    sfit.SetPointCloud(sp);
+    misc3d::common::Sphere sphere;
+    CHECK(sfit.FitModel(0.01, sphere, inliers));
+    CHECK(std::fabs(sphere.parameters_[0] - 0.3) < 1e-3 && std::fabs(sphere.parameters_[3] - 0.5) < 1e-3);
+
+    // ---- SegmentPlaneIterative: two planes
+    misc3d::PointCloud two;
+    for (int i = 0; i < 6000; ++i) two.points_.push_back({U(gen), U(gen), G(gen)});
+    for (int i = 0; i < 4000; ++i) two.points_.push_back({2.0 + G(gen), U(gen), U(gen)});
+    for (int i = 0; i < 500; ++i) two.points_.push_back({3 * U(gen), 3 * U(gen), 3 * U(gen)});
+    auto seg = misc3d::segmentation::SegmentPlaneIterative(two, 0.01, 100, 0.1);
+    CHECK(seg.size() >= 2);
+    CHECK(std::fabs(std::fabs(seg[0].first[2]) - 1.0) < 1e-2);
+    CHECK(std::fabs(std::fabs(seg[1].first[0]) - 1.0) < 1e-2);
+    CHECK(seg[0].second.points_.size() > 5500 && seg[1].second.points_.size() > 3500);
+
+    // ---- LeastSquareSolver + RANSACSolver + ANNMatcher
+    const double c = std::cos(0.5), s = std::sin(0.5);
+    misc3d::PointCloud src, dst;
+    std::vector<double> fsrc, fdst;
+    for (int i = 0; i < 3000; ++i) {
+        const misc3d::Vector3d p = {U(gen), U(gen), U(gen)};
+        src.points_.push_back(p);
+        dst.points_.push_back({c * p[0] - s * p[1] + 0.3, s * p[0] + c * p[1] - 0.1, p[2] + 0.2});
+        for (int k = 0; k < 8; ++k) {
+            const double f = U(gen);
+            fsrc.push_back(f);
+            fdst.push_back(f + 1e-3 * U(gen));
+        }
+    }
+    misc3d::registration::LeastSquareSolver ls(false);
+    const misc3d::Matrix4d T = ls.Solve(src, dst);
+    CHECK(std::fabs(T[0] - c) < 1e-12 && std::fabs(T[1] + s) < 1e-12 && std::fabs(T[3] - 0.3) < 1e-12);
+    CHECK(std::fabs(T[11] - 0.2) < 1e-12 && T[15] == 1.0);
+    misc3d::registration::ANNMatcher matcher(misc3d::registration::MatchMethod::ANNOY, 4);
+    misc3d::registration::FeatureView fa{fsrc.data(), 8, 3000}, fb{fdst.data(), 8, 3000};
+    auto corres = matcher.Match(fa, fb);
+    CHECK(corres.first.size() > 2900);
+    for (size_t k = 0; k < corres.first.size(); ++k) CHECK(corres.first[k] == corres.second[k]);
+    misc3d::registration::RANSACSolver rs(0.03, 2000, 0.9);
+    rs.SetSeed(17);
+    const misc3d::Matrix4d Tr = rs.Solve(src, dst, corres);
+    CHECK(std::fabs(Tr[0] - c) < 1e-9 && std::fabs(Tr[3] - 0.3) < 1e-9);
+    CHECK(rs.GetStats().fitness == 1.0);
+    std::printf("host api: all checks passed\n");
+    return 0;
+}

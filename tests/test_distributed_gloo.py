@@ -26,15 +26,37 @@ class OracleScorer:
         self.normals = normals
         self.n = len(xyz)
 
-    def score_range(self, kind, thr, samples, begin=0, end=None):
+    class _Table:
+        """stands in for capi.Sampler: the whole table drawn up front by the host-only m3d_draw_samples"""
+
+        def __init__(self, n, kind, seed, cap=4096):
+            from misc3d_amd import capi
+            self.kind = kind
+            self._t = capi.draw_samples(n, kind, cap, seed)
+
+        def table(self, n_hyp):
+            return self._t[:n_hyp]
+
+    def make_sampler(self, kind, seed):
+        return OracleScorer._Table(self.n, kind, seed)
+
+    def score_shard(self, sampler, thr, begin, end, slice_, world, rank):
+        from misc3d_amd import capi
+        owner, pos, per = capi.shard_layout(begin, end, slice_, world)
+        mine = np.nonzero(owner == rank)[0] + begin
+        t = sampler.table(end)
+        v, m, c, _ = self.o.score_samples(sampler.kind, self.xyz, self.normals, thr, t[mine].astype(np.uint64))
+        return v.astype(np.uint8), c.astype(np.uint32)
+
+    def score_range(self, kind, thr, samples, begin=0, end=None, want_models=True):
         end = len(samples) if end is None else end
         v, m, c, _ = self.o.score_samples(kind, self.xyz, self.normals, thr, samples[begin:end].astype(np.uint64))
-        return v.astype(np.uint8), m, c.astype(np.uint32)
+        return v.astype(np.uint8), (m if want_models else None), c.astype(np.uint32)
 
     def exact_error(self, kind, thr, model):
         return self.o.evaluate_model(kind, self.xyz, thr, model)
 
-    def refine(self, kind, thr, params):
+    def refine(self, kind, thr, params, copy=True):
         return self.o.refine(kind, self.xyz, thr, params)
 
 
@@ -56,7 +78,7 @@ def _worker(rank, world, port, kind, n, max_iter, prob, seed, q):
             pts, nrm = synth.plane_cloud_c1(n, 1), None
         else:
             pts, nrm = synth.cylinder_cloud_c3(n, 3)
-        r = distributed.fit_sharded(OracleScorer(pts, nrm), n, kind, 0.01, max_iter, prob, seed)
+        r = distributed.fit_sharded(OracleScorer(pts, nrm), n, kind, 0.01, max_iter, prob, seed, slice_size=37)
         q.put((rank, r.ret, r.best_index, r.count, r.iterations, r.fitness, r.inliers.tolist(),
                r.params.tolist(), r.hypotheses_scored, r.collectives))
     finally:

@@ -143,3 +143,17 @@ def test_segmentation_and_registration_api(m3d, orc):
     inv[d["perm"]] = np.arange(4000)
     Tl = m3d.registration.compute_transformation_least_square(d["src"], d["dst"][inv])
     assert np.allclose(Tl, orc.umeyama(d["src"], d["dst"][inv]), atol=1e-9) and np.allclose(Tl, d["T"], atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_cpp_host_api_executable():
+    """include/misc3d/** used from plain C++ (the shape of the reference's examples/cpp)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "_build", "test_host_api")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
