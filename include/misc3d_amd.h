@@ -183,7 +183,11 @@ int m3d_match_mutual_nn(const double *feat_src, size_t n_src, const double *feat
  * (score_k, the dominant kernel) over `reps` launches of `n_hypotheses` hypotheses, timed with HIP
  * events on the library's own stream after one untimed launch.  Not part of the reference. */
 int m3d_cloud_time_score(m3d_cloud *cloud, int kind, double threshold, const uint32_t *samples,
-                         size_t n_hypotheses, int reps, double *ms_avg);
+                         size_t n_hypotheses, int reps, int mode, double *ms_avg,
+                         uint64_t *listed_pairs);
+/* mode 0: score_list_k (production: counting over the (tile, hypothesis) pairs that survive the box
+ * test); mode 1: cull_k (the box tests); mode 2: score_k (dense: every tile x every hypothesis).
+ * listed_pairs (may be NULL): number of surviving (tile, hypothesis) pairs, tile = 512 points. */
 
 /* ---- misc -------------------------------------------------------------------------------------- */
 const char *m3d_last_error(void); /* thread-local; reference message text for M3D_ERR_* */

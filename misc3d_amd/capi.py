@@ -91,7 +91,7 @@ def lib():
         L.m3d_cloud_exact_error.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_refine.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_time_score.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int,
-                                           C.c_void_p]
+                                           C.c_int, C.c_void_p, C.c_void_p]
         L.m3d_sampler_create.restype = C.c_void_p
         L.m3d_sampler_create.argtypes = [C.c_size_t, C.c_int, C.c_uint64]
         L.m3d_sampler_destroy.argtypes = [C.c_void_p]
@@ -294,13 +294,15 @@ class Cloud:
                                            _p(mod)))
         return val, (mod[:, : NUM_PARAMS[kind]].copy() if want_models else None), cnt
 
-    def time_score(self, kind, threshold, samples, reps=5) -> float:
-        """Average duration (ms) of the scoring kernel alone over `reps` launches (HIP events)."""
+    def time_score(self, kind, threshold, samples, reps=5, mode=0):
+        """(average ms per launch over `reps` launches measured with HIP events, surviving
+        (tile, hypothesis) pairs).  mode 0 = score_list_k, 1 = cull_k, 2 = dense score_k."""
         samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, MINIMAL_SAMPLE[kind])
         ms = C.c_double(0)
-        _check(lib().m3d_cloud_time_score(self._h, kind, threshold, _p(samples), len(samples), reps,
-                                          C.cast(C.byref(ms), C.c_void_p)))
-        return float(ms.value)
+        listed = C.c_uint64(0)
+        _check(lib().m3d_cloud_time_score(self._h, kind, threshold, _p(samples), len(samples), reps, mode,
+                                          C.cast(C.byref(ms), C.c_void_p), C.cast(C.byref(listed), C.c_void_p)))
+        return float(ms.value), int(listed.value)
 
     def exact_error(self, kind, threshold, model):
         model = _f64(model)

@@ -19,6 +19,7 @@
 //
 // There is no CPU fallback: every entry point needs a HIP device.
 #include "m3d_driver.hpp"
+#include "m3d_reg_kernels.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -151,6 +152,16 @@ m3d::CloudView m3d_cloud::view() const {
     return v;
 }
 
+m3d::SortedView m3d_cloud::sorted() const {
+    m3d::SortedView s;
+    s.x = sx.as<double>();
+    s.y = sy.as<double>();
+    s.z = sz.as<double>();
+    s.boxes = boxes.as<double>();
+    s.n_tiles = n_tiles;
+    return s;
+}
+
 namespace m3d {
 
 // ------------------------------------------------------------------------------------------------
@@ -258,12 +269,30 @@ static uint32_t pick_splits(uint32_t n_tiles, uint32_t h_pad) {
     return std::min(want, groups);
 }
 
-static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, int kind, double thr,
-                       size_t begin, size_t end, SampleSource& src, double* ms_sample) {
+// M3D_DENSE=1 selects the dense scoring kernel (score_k: every tile x every hypothesis) instead of the
+// culled path (cull_k + score_list_k); both produce identical counts (tests run both).
+static bool use_dense_scoring() {
+    static const bool dense = [] {
+        const char* e = std::getenv("M3D_DENSE");
+        return e && e[0] == '1';
+    }();
+    return dense;
+}
+
+static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
+    // keep the per-chunk scratch (dense: partial counts, culled: hypothesis lists) below 1 GiB
+    const uint32_t rows = std::max<uint32_t>(1, use_dense_scoring() ? v.n_pad / kScoreTile : sv.n_tiles);
+    const size_t cap = std::min<size_t>(16384, ((size_t)1 << 28) / rows / 64 * 64);
+    return std::max<size_t>(cap, 64);
+}
+
+static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const SortedView& sv, int kind,
+                       double thr, size_t begin, size_t end, SampleSource& src, double* ms_sample) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const uint32_t h_pad = round_up(count, 64);
     const uint32_t n_tiles = v.n_pad / kScoreTile;
+    const bool dense = use_dense_scoring();
     s.begin = begin;
     s.end = end;
     s.h_pad = h_pad;
@@ -275,7 +304,12 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, int kin
     RESERVE(s.h_samples, sizeof(uint32_t) * (size_t)count * m);
     RESERVE(s.h_counts, sizeof(uint32_t) * (size_t)h_pad);
     RESERVE(s.h_valid, (size_t)h_pad + 1);
-    RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
+    if (dense) {
+        RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
+    } else {
+        RESERVE(ctx->lists, sizeof(uint32_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * h_pad);
+        RESERVE(ctx->list_count, sizeof(uint32_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1));
+    }
     const double t0 = now_ms();
     src.fill(begin, end, s.h_samples.as<uint32_t>());
     if (ms_sample) *ms_sample += now_ms() - t0;
@@ -284,10 +318,17 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, int kin
     launch_minimal_fit(kind, v, s.samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream);
     HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
-    launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
-                 ctx->partial.as<uint32_t>(), ctx->stream);
-    launch_reduce_partials(ctx->partial.as<uint32_t>(), n_tiles, h_pad, s.counts.as<uint32_t>(),
-                           ctx->stream);
+    if (dense) {
+        launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
+                     ctx->partial.as<uint32_t>(), ctx->stream);
+        launch_reduce_partials(ctx->partial.as<uint32_t>(), n_tiles, h_pad, s.counts.as<uint32_t>(),
+                               ctx->stream);
+    } else {
+        launch_cull(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, h_pad,
+                    ctx->lists.as<uint32_t>(), ctx->list_count.as<uint32_t>(), ctx->stream);
+        launch_score_list(kind, sv, s.score.as<double>(), ctx->lists.as<uint32_t>(),
+                          ctx->list_count.as<uint32_t>(), h_pad, count, s.counts.as<uint32_t>(), ctx->stream);
+    }
     HIPCHK(hipMemcpyAsync(s.h_counts.p, s.counts.p, sizeof(uint32_t) * (size_t)count,
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(s.h_valid.p, s.valid.p, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
@@ -493,8 +534,8 @@ struct RansacOut {
     int internal_error = 0;
 };
 
-static int run_ransac(DeviceCtx* ctx, const CloudView& v, int kind, double thr, size_t max_iter,
-                      double prob, uint64_t seed, RansacOut* out) {
+static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, int kind, double thr,
+                      size_t max_iter, double prob, uint64_t seed, RansacOut* out) {
     m3d_replay_init(&out->st);
     std::memset(out->best_host, 0, sizeof(out->best_host));
     RESERVE(ctx->best_params, sizeof(double) * kModelStride);
@@ -505,10 +546,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, int kind, double thr, 
     src.n_points = v.n;
     src.m = minimal_sample(kind);
 
-    const uint32_t n_tiles = std::max<uint32_t>(1, v.n_pad / kScoreTile);
-    // keep the partial-count buffer below 1 GiB
-    size_t chunk_cap = std::min<size_t>(16384, ((size_t)1 << 28) / n_tiles / 64 * 64);
-    chunk_cap = std::max<size_t>(chunk_cap, 64);
+    const size_t chunk_cap = chunk_cap_for(v, sv);
     // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
     // prob == 1: only fitness == 1 can stop it -> few large chunks (the first one is kept moderate
     // so the host replay of chunk k overlaps the scoring of chunk k+1)
@@ -524,7 +562,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, int kind, double thr, 
     bool best_approx_known = false, pending_valid = false;
     auto issue_next = [&](int slot_id) -> int {
         const size_t b = next_begin, e = std::min(max_iter, b + chunk);
-        const int r = issue_chunk(ctx, ctx->slot[slot_id], v, kind, thr, b, e, src, &out->ms_sample);
+        const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample);
         if (r == M3D_OK) {
             next_begin = e;
             out->hypotheses_scored += e - b;
@@ -668,7 +706,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     HIPCHK(hipSetDevice(ctx->device));
     const CloudView v = c->view();
     RansacOut ro;
-    int rc = run_ransac(ctx, v, kind, thr, max_iter, prob, seed, &ro);
+    int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro);
     if (rc != M3D_OK) return rc;
     const double t1 = now_ms();
     double model[kModelStride];
@@ -784,12 +822,69 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
             launch_aos_to_soa(stage.as<double>(), c->nx.as<double>(), c->ny.as<double>(),
                               c->nz.as<double>(), c->n, c->n_pad, ctx->stream);
     }
+    // Z-order sorted copy + tile boxes for the culled scoring path (bounding box on the host: one
+    // pass over the caller's array while the upload is in flight)
+    DevBuf t_cell, t_start, t_fill, t_sums, t_total;
+    if (ok) {
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t n_finite = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+            if (std::isfinite(px) && std::isfinite(py) && std::isfinite(pz)) {
+                lo[0] = std::min(lo[0], px); hi[0] = std::max(hi[0], px);
+                lo[1] = std::min(lo[1], py); hi[1] = std::max(hi[1], py);
+                lo[2] = std::min(lo[2], pz); hi[2] = std::max(hi[2], pz);
+                ++n_finite;
+            }
+        }
+        const uint32_t cap = std::max<uint32_t>(round_up((uint32_t)n, kTilePoints), kTilePoints);
+        c->n_tiles = cap / kTilePoints;
+        c->n_sorted = n_finite;
+        ok = c->sx.reserve(sizeof(double) * cap) && c->sy.reserve(sizeof(double) * cap) &&
+             c->sz.reserve(sizeof(double) * cap) && c->boxes.reserve(sizeof(double) * 6 * c->n_tiles);
+        if (ok) {
+            launch_fill_nan(c->sx.as<double>(), cap, ctx->stream);
+            launch_fill_nan(c->sy.as<double>(), cap, ctx->stream);
+            launch_fill_nan(c->sz.as<double>(), cap, ctx->stream);
+        }
+        if (ok && n_finite) {
+            double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+            if (!std::isfinite(ext)) ext = 0.0;  // absurdly large clouds: one cell, culling degenerates gracefully
+            // about 8 points per cell, at most 2^8 cells per axis
+            uint32_t bits = 1;
+            while (bits < 8 && ((uint64_t)1 << (3 * bits)) * 8 < n_finite) ++bits;
+            GridDesc gs;
+            gs.K = 0;
+            static const bool zorder = [] {
+                const char* e = std::getenv("M3D_ORDER");  // "morton" = plain Z-order (comparison only)
+                return e && e[0] == 'm';
+            }();
+            gs.morton_bits = bits | (zorder ? 0u : 0x100u);  // Hilbert order by default
+            gs.nx = gs.ny = gs.nz = 1u << bits;
+            gs.ox = lo[0];
+            gs.oy = lo[1];
+            gs.oz = lo[2];
+            gs.inv_h = ext > 0.0 ? (double)(1u << bits) / (ext * (1.0 + 1e-9)) : 0.0;
+            gs.r2 = gs.h2_in = 0.0;
+            const uint32_t ncell = 1u << (3 * bits);
+            ok = t_cell.reserve(sizeof(uint32_t) * n) && t_start.reserve(sizeof(uint32_t) * ((size_t)ncell + 1)) &&
+                 t_fill.reserve(sizeof(uint32_t) * (size_t)ncell) &&
+                 t_sums.reserve(sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1)) && t_total.reserve(16);
+            if (ok)
+                launch_grid_build(c->view(), gs, t_cell.as<uint32_t>(), t_start.as<uint32_t>(), t_fill.as<uint32_t>(),
+                                  t_sums.as<uint32_t>(), t_total.as<uint32_t>(), c->sx.as<double>(),
+                                  c->sy.as<double>(), c->sz.as<double>(), ctx->stream);
+        }
+        if (ok) launch_tile_boxes(c->sorted(), c->boxes.as<double>(), ctx->stream);
+    }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
     stage.release();
+    t_cell.release(); t_start.release(); t_fill.release(); t_sums.release(); t_total.release();
     if (!ok) {
         if (g_last_error.empty()) set_error("cloud upload failed");
         c->x.release(); c->y.release(); c->z.release();
         c->nx.release(); c->ny.release(); c->nz.release();
+        c->sx.release(); c->sy.release(); c->sz.release(); c->boxes.release();
         delete c;
         return nullptr;
     }
@@ -802,6 +897,7 @@ void m3d_cloud_destroy(m3d_cloud* c) {
     (void)hipSetDevice(c->ctx->device);
     c->x.release(); c->y.release(); c->z.release();
     c->nx.release(); c->ny.release(); c->nz.release();
+    c->sx.release(); c->sy.release(); c->sz.release(); c->boxes.release();
     delete c;
 }
 
@@ -881,13 +977,12 @@ int m3d_cloud_score_range(m3d_cloud* c, int kind, double threshold, const uint32
     SampleSource src;
     src.table = samples;
     src.m = m;
-    const uint32_t n_tiles = std::max<uint32_t>(1, v.n_pad / kScoreTile);
-    size_t chunk_cap = std::min<size_t>(16384, ((size_t)1 << 28) / n_tiles / 64 * 64);
-    chunk_cap = std::max<size_t>(chunk_cap, 64);
+    const SortedView sv = c->sorted();
+    const size_t chunk_cap = chunk_cap_for(v, sv);
     ChunkSlot& s = ctx->slot[0];
     for (size_t b = begin; b < end; b += chunk_cap) {
         const size_t e = std::min(end, b + chunk_cap);
-        const int rc = issue_chunk(ctx, s, v, kind, threshold, b, e, src, nullptr);
+        const int rc = issue_chunk(ctx, s, v, sv, kind, threshold, b, e, src, nullptr);
         if (rc != M3D_OK) return rc;
         HIPCHK(hipEventSynchronize(s.done));
         if (counts) std::memcpy(counts + (b - begin), s.h_counts.p, sizeof(uint32_t) * (e - b));
@@ -948,8 +1043,8 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const CloudView v = c->view();
-    const uint32_t n_tiles = std::max<uint32_t>(1, v.n_pad / kScoreTile);
-    const size_t chunk_cap = std::max<size_t>(64, std::min<size_t>(16384, ((size_t)1 << 28) / n_tiles / 64 * 64));
+    const SortedView sv = c->sorted();
+    const size_t chunk_cap = chunk_cap_for(v, sv);
     SampleSource tsrc;  // table-backed view of the sampler
     tsrc.m = sampler->src.m;
     size_t out = 0;
@@ -979,7 +1074,7 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
             int rc = collect(cur);
             if (rc != M3D_OK) return rc;
             tsrc.table = sampler->table.data();
-            rc = issue_chunk(ctx, ctx->slot[cur], v, kind, threshold, bb, ee, tsrc, nullptr);
+            rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, bb, ee, tsrc, nullptr);
             if (rc != M3D_OK) return rc;
             pend[cur].active = true;
             pend[cur].out_pos = out;
@@ -997,9 +1092,9 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
 }
 
 int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_t* samples,
-                         size_t n_hypotheses, int reps, double* ms_avg) {
+                         size_t n_hypotheses, int reps, int mode, double* ms_avg, uint64_t* listed_pairs) {
     if (!c || kind < 0 || kind > 2 || !samples || !ms_avg || reps < 1 || n_hypotheses == 0 ||
-        n_hypotheses > 65536)
+        n_hypotheses > 16384 || mode < 0 || mode > 2)
         return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     if (kind == M3D_CYLINDER && !c->has_normals)
         return fail(M3D_ERR_NO_NORMALS, "Fit cylinder requires normals.");
@@ -1007,18 +1102,42 @@ int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const CloudView v = c->view();
+    const SortedView sv = c->sorted();
     SampleSource src;
     src.table = samples;
     src.m = minimal_sample(kind);
     ChunkSlot& s = ctx->slot[0];
-    int rc = issue_chunk(ctx, s, v, kind, threshold, 0, n_hypotheses, src, nullptr);  // warm-up + records
+    int rc = issue_chunk(ctx, s, v, sv, kind, threshold, 0, n_hypotheses, src, nullptr);  // warm-up + records
     if (rc != M3D_OK) return rc;
+    const uint32_t count = (uint32_t)n_hypotheses;
     const uint32_t n_tiles = v.n_pad / kScoreTile;
+    // make sure the buffers of the timed mode exist whatever path issue_chunk took
+    RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * s.h_pad);
+    RESERVE(ctx->lists, sizeof(uint32_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * s.h_pad);
+    RESERVE(ctx->list_count, sizeof(uint32_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1));
+    launch_cull(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, s.h_pad, ctx->lists.as<uint32_t>(),
+                ctx->list_count.as<uint32_t>(), ctx->stream);
+    if (listed_pairs) {
+        std::vector<uint32_t> lc(std::max<uint32_t>(sv.n_tiles, 1));
+        HIPCHK(hipMemcpyAsync(lc.data(), ctx->list_count.p, sizeof(uint32_t) * sv.n_tiles, hipMemcpyDeviceToHost,
+                              ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        uint64_t tot = 0;
+        for (uint32_t t = 0; t < sv.n_tiles; ++t) tot += lc[t];
+        *listed_pairs = tot;  // (tile, hypothesis) pairs that survive the box test
+    }
     const uint32_t splits = pick_splits(n_tiles, s.h_pad);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    for (int r = 0; r < reps; ++r)
-        launch_score(kind, v, s.score.as<double>(), s.h_pad, splits, ctx->partial.as<uint32_t>(),
-                     ctx->stream);
+    for (int r = 0; r < reps; ++r) {
+        if (mode == 0)
+            launch_score_list(kind, sv, s.score.as<double>(), ctx->lists.as<uint32_t>(),
+                              ctx->list_count.as<uint32_t>(), s.h_pad, count, s.counts.as<uint32_t>(), ctx->stream);
+        else if (mode == 1)
+            launch_cull(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, s.h_pad,
+                        ctx->lists.as<uint32_t>(), ctx->list_count.as<uint32_t>(), ctx->stream);
+        else
+            launch_score(kind, v, s.score.as<double>(), s.h_pad, splits, ctx->partial.as<uint32_t>(), ctx->stream);
+    }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1087,15 +1206,23 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
         const CloudView v0 = c0->view();
         // ping-pong buffers for the shrinking cloud (pcd_copy, :25,:33) + original indices
         DevBuf bx[2], by[2], bz[2], bo[2];
+        // the Z-order sorted copy shrinks the same way (stable partition keeps it sorted); boxes are
+        // recomputed per round
+        DevBuf sbx[2], sby[2], sbz[2], sboxes;
         const size_t bytes = sizeof(double) * (size_t)c0->n_pad;
+        const uint32_t scap = c0->n_tiles * kTilePoints;
         bool ok = true;
         for (int k = 0; k < 2 && ok; ++k)
             ok = bx[k].reserve(bytes) && by[k].reserve(bytes) && bz[k].reserve(bytes) &&
-                 bo[k].reserve(sizeof(uint32_t) * (size_t)c0->n_pad);
+                 bo[k].reserve(sizeof(uint32_t) * (size_t)c0->n_pad) && sbx[k].reserve(sizeof(double) * scap) &&
+                 sby[k].reserve(sizeof(double) * scap) && sbz[k].reserve(sizeof(double) * scap);
+        ok = ok && sboxes.reserve(sizeof(double) * 6 * c0->n_tiles);
         auto cleanup = [&]() {
             for (int k = 0; k < 2; ++k) {
                 bx[k].release(); by[k].release(); bz[k].release(); bo[k].release();
+                sbx[k].release(); sby[k].release(); sbz[k].release();
             }
+            sboxes.release();
         };
         if (!ok) {
             cleanup();
@@ -1103,6 +1230,9 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
         } else {
             launch_iota(bo[0].as<uint32_t>(), c0->n, ctx->stream);
             CloudView cur = v0;  // round 0 reads the uploaded cloud directly
+            SortedView scur = c0->sorted();
+            uint32_t n_sorted = c0->n_sorted;  // finite points in the sorted copy
+            int spp = 0;                       // sorted buffers that will RECEIVE the next compaction
             const uint32_t* cur_orig = bo[0].as<uint32_t>();
             int pp = 0;          // buffers that will RECEIVE the next compaction
             bool cur_is_v0 = true;
@@ -1115,7 +1245,7 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
                     break;
                 }
                 RansacOut ro;
-                rc = run_ransac(ctx, cur, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k,
+                rc = run_ransac(ctx, cur, scur, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k,
                                 &ro);  // probability stays at the RANSAC default, ransac.h:462
                 if (rc != M3D_OK) break;
                 double model[kModelStride];
@@ -1148,6 +1278,34 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
                                nullptr, nullptr, bx[dst].as<double>(), by[dst].as<double>(),
                                bz[dst].as<double>(), bo[dst].as<uint32_t>(), c0->n_pad,
                                ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream);
+                {   // the same stable partition on the sorted copy (every inlier is a finite point, so the
+                    // sorted copy loses exactly `ni` points), then fresh tile boxes
+                    CloudView sview;
+                    sview.x = scur.x;
+                    sview.y = scur.y;
+                    sview.z = scur.z;
+                    sview.nx = sview.ny = sview.nz = nullptr;
+                    sview.n = n_sorted;
+                    sview.n_pad = scur.n_tiles * kTilePoints;
+                    const uint32_t snb = (n_sorted + kCompactTile - 1) / kCompactTile;
+                    if (!ctx->block_counts.reserve(sizeof(uint32_t) * ((size_t)std::max(nb, snb) + 1))) {
+                        rc = M3D_ERR_DEVICE;
+                        break;
+                    }
+                    launch_compact(M3D_PLANE, sview, ctx->best_params.as<double>(), threshold, 3, nullptr, nullptr,
+                                   nullptr, sbx[spp].as<double>(), sby[spp].as<double>(), sbz[spp].as<double>(),
+                                   nullptr, scap, ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>() + 1,
+                                   ctx->stream);
+                    n_sorted -= (uint32_t)std::min<size_t>(ni, n_sorted);
+                    scur.x = sbx[spp].as<double>();
+                    scur.y = sby[spp].as<double>();
+                    scur.z = sbz[spp].as<double>();
+                    scur.boxes = sboxes.as<double>();
+                    scur.n_tiles = std::max<uint32_t>(1, (n_sorted + kTilePoints - 1) / kTilePoints);
+                    // pad_nan_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
+                    launch_tile_boxes(scur, sboxes.as<double>(), ctx->stream);
+                    spp ^= 1;
+                }
                 if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
                     rc = fail(M3D_ERR_DEVICE, "stream sync failed");
                     break;

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/misc3d_amd.h"
+#include "m3d_cull_kernels.hpp"
 #include "m3d_kernels.hpp"
 
 namespace m3d {
@@ -54,6 +55,7 @@ struct DeviceCtx {
     std::mutex mu;  // one call at a time per device
     ChunkSlot slot[2];
     DevBuf partial, block_counts, total, idx, dist, sum_partial, sums, best_params, small;
+    DevBuf lists, list_count;  // culled scoring: per-tile hypothesis lists
     PinBuf h_small;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -67,5 +69,9 @@ struct m3d_cloud {
     m3d::DevBuf x, y, z, nx, ny, nz;
     uint32_t n = 0, n_pad = 0;
     bool has_normals = false;
+    // Z-order sorted copy for the culled scoring path (m3d_cull_kernels.hip)
+    m3d::DevBuf sx, sy, sz, boxes;
+    uint32_t n_sorted = 0, n_tiles = 0;
     m3d::CloudView view() const;
+    m3d::SortedView sorted() const;
 };

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void compact_write_k(
             py = c.y[i];
             pz = c.z[i];
             d = ref_distance<KIND>(m, px, py, pz);
-            f = (d < thr) != (MODE == 2);
+            f = (d < thr) != (MODE >= 2);
         }
         const unsigned long long b = __ballot(f);
         const uint32_t lane_pre = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
@@ -391,11 +391,11 @@ __global__ __launch_bounds__(256) void compact_write_k(
             const uint32_t pos = row_base + woff + lane_pre;
             if (MODE == 0) out_idx[pos] = orig ? (uint64_t)orig[i] : (uint64_t)i;
             if (MODE == 1) out_dist[pos] = d;
-            if (MODE == 2) {
+            if (MODE >= 2) {
                 ox[pos] = px;
                 oy[pos] = py;
                 oz[pos] = pz;
-                oorig[pos] = orig[i];
+                if (MODE == 2) oorig[pos] = orig[i];
             }
         }
         row_base += rowtot;
@@ -426,7 +426,7 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
         (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
         return;
     }
-    compact_count_k<KIND><<<nb, 256, 0, s>>>(c, model, thr, mode == 2 ? 1 : 0, block_counts);
+    compact_count_k<KIND><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts);
     scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total);
     if (mode == 0)
         compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
@@ -435,8 +435,12 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
         compact_write_k<KIND, 1><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
                                                      out_dist, nullptr, nullptr, nullptr, nullptr);
     else {
-        compact_write_k<KIND, 2><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                     nullptr, ox, oy, oz, oorig);
+        if (mode == 2)
+            compact_write_k<KIND, 2><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
+                                                         nullptr, ox, oy, oz, oorig);
+        else
+            compact_write_k<KIND, 3><<<nb, 256, 0, s>>>(c, model, thr, nullptr, block_counts, nullptr,
+                                                         nullptr, ox, oy, oz, nullptr);
         pad_nan_k<<<(kScoreTile + 255) / 256, 256, 0, s>>>(ox, oy, oz, total, n_pad_out);
     }
 }

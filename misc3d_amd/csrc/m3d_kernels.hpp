@@ -53,6 +53,7 @@ void launch_reduce_partials(const uint32_t* partial, uint32_t n_tiles, uint32_t 
 // mode 0: out_idx[k]  = index (or orig[index] when orig != null) of the k-th inlier, ascending
 // mode 1: out_dist[k] = distance of the k-th inlier
 // mode 2: stable partition of the NON-inliers into (ox,oy,oz,oorig) (segmentation round)
+// mode 3: the same for coordinates only (the Z-order sorted copy)
 // block_counts: scratch of ceil(n / kCompactTile) + 1 uint32; total[0] receives the inlier count.
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,

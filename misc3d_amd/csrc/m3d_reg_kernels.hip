@@ -93,7 +93,54 @@ __global__ void grid_count_k(CloudView dst, GridDesc g, uint32_t* __restrict__ c
     int ix, iy, iz;
     uint32_t cid = 0xFFFFFFFFu;  // points with NaN/inf coordinates are left out of the grid
     if (cell_of(g, dst.x[i], dst.y[i], dst.z[i], 0, &ix, &iy, &iz)) {
-        cid = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
+        if (g.morton_bits) {  // Z-order cell id: consecutive cells form compact cubes
+            auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+                v = (v | (v << 16)) & 0x030000FFu;
+                v = (v | (v << 8)) & 0x0300F00Fu;
+                v = (v | (v << 4)) & 0x030C30C3u;
+                v = (v | (v << 2)) & 0x09249249u;
+                return v;
+            };
+            uint32_t X0 = (uint32_t)ix, X1 = (uint32_t)iy, X2 = (uint32_t)iz;
+            if (g.morton_bits & 0x100u) {
+                // Hilbert curve (Skilling's axes -> transpose): a continuous curve, so runs of consecutive
+                // cells have tighter bounding boxes than Z-order runs.  Only XORs and masked exchanges:
+                // a bijection on b-bit triples whatever the input, which is all the counting sort needs.
+                const uint32_t b = g.morton_bits & 0xFFu;
+                const uint32_t M = 1u << (b - 1);
+                for (uint32_t Q = M; Q > 1; Q >>= 1) {
+                    const uint32_t P = Q - 1;
+                    if (X0 & Q) X0 ^= P;  // i = 0: invert
+                    if (X1 & Q) {
+                        X0 ^= P;
+                    } else {
+                        const uint32_t t = (X0 ^ X1) & P;
+                        X0 ^= t;
+                        X1 ^= t;
+                    }
+                    if (X2 & Q) {
+                        X0 ^= P;
+                    } else {
+                        const uint32_t t = (X0 ^ X2) & P;
+                        X0 ^= t;
+                        X2 ^= t;
+                    }
+                }
+                X1 ^= X0;  // Gray encode
+                X2 ^= X1;
+                uint32_t t = 0;
+                for (uint32_t Q = M; Q > 1; Q >>= 1)
+                    if (X2 & Q) t ^= Q - 1;
+                X0 ^= t;
+                X1 ^= t;
+                X2 ^= t;
+                cid = (spread(X0) << 2) | (spread(X1) << 1) | spread(X2);
+            } else {
+                cid = spread(X0) | (spread(X1) << 1) | (spread(X2) << 2);
+            }
+        } else {
+            cid = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
+        }
         atomicAdd(&hist[cid], 1u);
     }
     cell_of_point[i] = cid;

@@ -17,6 +17,7 @@ struct GridDesc {
     double h2_in;  // (0.999 h)^2: a neighbour closer than this inside the 3x3x3 block is the nearest
     uint32_t nx, ny, nz;
     int K;
+    uint32_t morton_bits;  // != 0: cell ids are Z-order codes of (ix,iy,iz), nx = ny = nz = 2^bits
 };
 
 

@@ -255,6 +255,7 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
             }
             GridDesc g;
             g.K = K;
+            g.morton_bits = 0;
             g.ox = lo[0] - (K + 1) * h;
             g.oy = lo[1] - (K + 1) * h;
             g.oz = lo[2] - (K + 1) * h;
@@ -303,6 +304,7 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                     GridDesc gs;
                     const double hs = ext / 63.0;
                     gs.K = 0;
+                    gs.morton_bits = 0;
                     gs.ox = slo[0];
                     gs.oy = slo[1];
                     gs.oz = slo[2];
