@@ -548,10 +548,15 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
 
     const size_t chunk_cap = chunk_cap_for(v, sv);
     // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
-    // prob == 1: only fitness == 1 can stop it -> few large chunks (the first one is kept moderate
-    // so the host replay of chunk k overlaps the scoring of chunk k+1)
-    size_t chunk = prob < 1.0 ? 128 : 2048;
-    const size_t growth = prob < 1.0 ? 2 : 4;
+    // prob == 1: only fitness == 1 can stop it -> as few, equal chunks as the scratch cap allows
+    // (one chunk up to 16384 hypotheses; more chunks are pipelined two deep)
+    size_t chunk = 128;
+    size_t growth = 2;
+    if (prob >= 1.0 && max_iter > 0) {
+        const size_t n_chunks = (max_iter + chunk_cap - 1) / chunk_cap;
+        chunk = ((max_iter + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+        growth = 1;
+    }
     chunk = std::min(chunk, chunk_cap);
 
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));

@@ -27,7 +27,6 @@ import numpy as np
 
 from . import capi
 
-SLICE = 2048  # hypotheses per slice: ~0.45 ms of scoring on a 1 M-point cloud, 16 us of sampling
 
 
 @dataclass
@@ -64,7 +63,7 @@ def _all_gather_records(rec, group, device):
 
 
 def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, probability=0.9999, seed=0,
-                group=None, device=None, want_inliers=True, copy=True, slice_size=SLICE) -> ShardedFit:
+                group=None, device=None, want_inliers=True, copy=True, slice_size=None) -> ShardedFit:
     """RANSAC::FitModel with the hypothesis loop sharded over the ranks of `group`."""
     world, rank, have_pg = _world(group)
     m = capi.MINIMAL_SAMPLE[kind]
@@ -97,24 +96,28 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
         return 1e10 if cnt == 0 else err / float(np.sqrt(float(cnt)))
 
     cb = capi.RMSE_FN(rmse_of)
+    K = 2   # slices per rank and window: the host draws the other ranks' slices while the GPU scores
     while begin < H and not st.stopped:
         end = min(H, begin + window)
-        sl = max(1, min(slice_size, -(-(end - begin) // world)))
+        n_win = end - begin
+        sl = slice_size if slice_size else max(64, -(-n_win // (K * world)))
+        n_slices = -(-n_win // sl)
+        k_loc = -(-n_slices // world)             # slices per rank (padded)
         v, c = scorer.score_shard(sampler, threshold, begin, end, sl, world, rank)
         scored += len(c)
-        owner, pos, per = capi.shard_layout(begin, end, sl, world)
+        # local records laid out as k_loc slices of `sl` (only the globally last slice can be short,
+        # and slices a rank does not own sit at the tail): zero padding lands beyond `end`
+        rec = np.zeros(k_loc * sl, dtype=np.uint32)
+        rec[: len(c)] = c | (v.astype(np.uint32) << np.uint32(31))      # counts < 2^31
         if have_pg:
-            width = int(per.max())
-            rec = np.zeros(width, dtype=np.uint32)
-            rec[: len(c)] = c | (v.astype(np.uint32) << np.uint32(31))      # counts < 2^31
-            allrec = _all_gather_records(rec, group, device)
+            allrec = _all_gather_records(rec, group, device)             # (world, k_loc * sl)
             collectives += 1
-            g = allrec[owner, pos]
         else:
-            g = c | (v.astype(np.uint32) << np.uint32(31))
-            g = g[pos]
-        gv = np.ascontiguousarray((g >> np.uint32(31)).astype(np.uint8))
-        gc = np.ascontiguousarray(g & np.uint32(0x7FFFFFFF))
+            allrec = rec.reshape(1, -1)
+        # slice j = (local slice j // world of rank j % world)  ->  global hypothesis order
+        g = np.ascontiguousarray(allrec.reshape(world, k_loc, sl).transpose(1, 0, 2)).reshape(-1)[:n_win]
+        gv = (g >> np.uint32(31)).astype(np.uint8)
+        gc = g & np.uint32(0x7FFFFFFF)
         prev_best = st.best_index
         capi.lib().m3d_replay_chunk(C.byref(st), n_points, kind, H, probability, begin, end,
                                     gv.ctypes.data_as(C.c_void_p), gc.ctypes.data_as(C.c_void_p), cb, None)
