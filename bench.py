@@ -139,8 +139,8 @@ def main():
         Hk = min(H, 16384)
         samples = capi.draw_samples(N, kind, Hk, seed)
         cloud.time_score(kind, thr, samples, reps=3, mode=0)            # clocks up
-        k_ms, listed = cloud.time_score(kind, thr, samples, reps=10, mode=0)    # score_list_k (dominant kernel)
-        cull_ms, _ = cloud.time_score(kind, thr, samples, reps=10, mode=1)      # cull_k
+        k_ms, listed = cloud.time_score(kind, thr, samples, reps=10, mode=0)    # score_mask_k (dominant kernel)
+        cull_ms, _ = cloud.time_score(kind, thr, samples, reps=10, mode=1)      # cull_mask_k
         dense_ms, _ = cloud.time_score(kind, thr, samples, reps=5, mode=2)      # score_k: the unculled kernel
         n_tiles = -(-N // 512)
         alg_bytes = Hk * float(N) * ALG_BYTES_PER_PAIR
@@ -150,7 +150,7 @@ def main():
         dense_tops = float(-(-Hk // 64) * 64) * float(-(-N // 2048) * 2048) * VALU_OPS_PER_PAIR[kind] / (
             dense_ms * 1e-3) / 1e12
         traffic = load_pmc_traffic()
-        roofline = {"bound": "hbm", "kernel": "m3d::score_list_k<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "m3d::score_mask_k<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "launch_ms": k_ms, "hypotheses_per_launch": Hk,
                     "note": "algorithmic bytes = 24 B x H x N (what EvaluateModel streams); the kernel re-uses every "

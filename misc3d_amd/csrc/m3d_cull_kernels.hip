@@ -2,20 +2,25 @@
 //
 // EvaluateModel (include/misc3d/common/ransac.h:626-641) visits every point for every hypothesis,
 // but a plane / sphere-shell / cylinder-shell slab of half-width `threshold` only intersects a small
-// part of space.  The resident cloud therefore carries a Z-order sorted copy cut into TILES of 512
+// part of space.  The resident cloud therefore carries a Hilbert-sorted copy cut into TILES of 512
 // consecutive points (one wave: 8 rows of 64) with an axis-aligned bounding box each.  Per chunk of
 // hypotheses:
-//   cull_k        one wave per tile, one hypothesis per lane: conservative box-vs-slab test written
-//                 against the EXACT cut-offs of the scoring record (m3d_fp.hpp) with a margin three
-//                 orders of magnitude above the fp64 rounding of the per-point arithmetic; surviving
-//                 hypothesis ids are appended to the tile's list (ballot + prefix, ascending).
-//   score_list_k  one wave per (tile, list segment): the tile's 512 points stay in VGPRs, the listed
-//                 hypothesis records stream through SGPRs, the per-pair arithmetic and the compare are
-//                 exactly those of score_k (bit-identical decisions), counts go to counts[h] with
-//                 integer atomics (order-free, exact).
-// A culled (tile, hypothesis) pair provably contains no inlier, so the counts equal the dense ones;
-// tests compare both against the oracle.  RefineModel / tie-break passes keep using the
-// original-order arrays, so inlier index lists and serial sums are unaffected by the sort.
+//   cull_mask_k   one wave per (group of 64 hypotheses, range of tiles), one hypothesis per lane with
+//                 its record in registers; the tile boxes stream through SGPRs.  Conservative
+//                 box-vs-slab test written against the EXACT cut-offs of the scoring record
+//                 (m3d_fp.hpp) with a margin three orders of magnitude above the fp64 rounding of the
+//                 per-point arithmetic.  Result: one 64-bit mask per (tile, group) and, per
+//                 hypothesis, the number of tiles it can touch.
+//   keep_mask_k   bound-and-prune: hypotheses whose touched tiles hold fewer points than the best
+//                 inlier count of EARLIER chunks can neither beat nor tie it in the sequential
+//                 replay (ransac.h:595-596); their bits are masked out.
+//   score_mask_k  one wave per (tile, range of groups): the tile's 512 points stay in VGPRs, set
+//                 bits are walked with scalar ops, the hypothesis records stream through SGPRs, the
+//                 per-pair arithmetic and the compare are exactly those of score_k (bit-identical
+//                 decisions), counts go to counts[h] with integer atomics (order-free, exact).
+// A culled (tile, hypothesis) pair provably contains no inlier, so the counts of unpruned hypotheses
+// equal the dense ones; tests compare both paths against the oracle.  RefineModel / tie-break passes
+// keep using the original-order arrays, so inlier index lists and serial sums do not see the sort.
 #include "m3d_cull_kernels.hpp"
 
 #include "m3d_fp.hpp"
@@ -26,7 +31,7 @@ namespace m3d {
 
 // ------------------------------------------------------------------------------------------------
 // tile boxes: one wave per tile; NaN padding is ignored (fmin/fmax drop NaN); an empty tile gets a
-// negative half-extent, which cull_k treats as "never intersects".
+// negative half-extent, which the box test treats as "never intersects".
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ sx, const double* __restrict__ sy,
                                                      const double* __restrict__ sz, uint32_t n_tiles,
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ s
             hi[k] = fmax(hi[k], __shfl_xor(hi[k], off, 64));
         }
     if (lane == 0) {
-        double* b = boxes + (size_t)tile * 6;
+        double* b = boxes + (size_t)tile * kBoxStride;
         const bool empty = !(lo[0] <= hi[0]);
         for (int k = 0; k < 3; ++k) {
             const double c = 0.5 * lo[k] + 0.5 * hi[k];
@@ -57,6 +62,7 @@ __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ s
             // half extent measured from the ROUNDED centre and inflated, so the box contains its points
             b[3 + k] = empty ? -1.0 : fmax(hi[k] - c, c - lo[k]) * (1.0 + 1e-12) + 1e-300;
         }
+        b[6] = b[7] = 0.0;
     }
 }
 
@@ -110,62 +116,95 @@ __device__ __forceinline__ bool box_culled(const double* __restrict__ rec, const
     }
 }
 
+// One wave = 64 hypotheses (one per lane, record in VGPRs) x a range of tiles (boxes are wave-uniform:
+// scalar loads).  masks[tile * n_groups + group] = ballot of the hypotheses that may have inliers in
+// the tile; ub[h] += number of such tiles.
 template <int KIND>
-__global__ __launch_bounds__(256) void cull_k(const double* __restrict__ boxes, uint32_t n_tiles,
-                                               const double* __restrict__ score,
-                                               const uint8_t* __restrict__ valid, uint32_t h_count,
-                                               uint32_t h_cap, uint32_t* __restrict__ lists,
-                                               uint32_t* __restrict__ list_count) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    double box[6];
-    for (int k = 0; k < 6; ++k) box[k] = boxes[(size_t)tile * 6 + k];
-    uint32_t* __restrict__ out = lists + (size_t)tile * h_cap;
-    uint32_t cnt = 0;
-    for (uint32_t h0 = 0; h0 < h_count; h0 += 64) {
-        const uint32_t h = h0 + lane;
-        bool keep = false;
-        if (h < h_count && valid[h]) {
-            double rec[kModelStride];
-            for (int k = 0; k < kModelStride; ++k) rec[k] = score[(size_t)h * kModelStride + k];
-            keep = !box_culled<KIND>(rec, box);
-        }
+__global__ __launch_bounds__(64) void cull_mask_k(const double* __restrict__ boxes, uint32_t n_tiles,
+                                                   uint32_t tiles_per_block, const double* __restrict__ score,
+                                                   const uint8_t* __restrict__ valid, uint32_t h_count,
+                                                   uint32_t n_groups, unsigned long long* __restrict__ masks,
+                                                   uint32_t* __restrict__ ub) {
+    const int lane = threadIdx.x;
+    const uint32_t group = blockIdx.x;
+    const uint32_t h = group * 64u + lane;
+    const bool live = h < h_count && valid[h];
+    double rec[kModelStride];
+    for (int k = 0; k < kModelStride; ++k) rec[k] = live ? score[(size_t)h * kModelStride + k] : 0.0;
+    const uint32_t t0 = blockIdx.y * tiles_per_block;
+    const uint32_t t1 = min(n_tiles, t0 + tiles_per_block);
+    uint32_t touched = 0;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const double* __restrict__ bp = boxes + (size_t)t * kBoxStride;
+        double box[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) box[k] = bp[k];
+        const bool keep = live && !box_culled<KIND>(rec, box);
         const unsigned long long m = __ballot(keep);
-        if (keep) out[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = h;
-        cnt += (uint32_t)__popcll(m);
+        if (lane == 0) masks[(size_t)t * n_groups + group] = m;
+        touched += keep ? 1u : 0u;
     }
-    if (lane == 0) list_count[tile] = cnt;
+    if (ub && touched) atomicAdd(&ub[h], touched);
 }
 
-void launch_cull(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
-                 uint32_t h_cap, uint32_t* lists, uint32_t* list_count, hipStream_t st) {
-    if (!s.n_tiles) return;
-    const dim3 g((s.n_tiles + 3) / 4), b(256);
+void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
+                      uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st) {
+    if (!s.n_tiles || !n_groups) return;
+    if (ub) (void)hipMemsetAsync(ub, 0, sizeof(uint32_t) * (size_t)n_groups * 64, st);
+    // enough waves to fill the chip: split the tile range when there are few hypothesis groups
+    uint32_t splits = std::max<uint32_t>(1, (8192 + n_groups - 1) / n_groups);
+    splits = std::min(splits, s.n_tiles);
+    const uint32_t tpb = (s.n_tiles + splits - 1) / splits;
+    const dim3 g(n_groups, (s.n_tiles + tpb - 1) / tpb), b(64);
     if (kind == 0)
-        cull_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, score, valid, h_count, h_cap, lists, list_count);
+        cull_mask_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub);
     else if (kind == 1)
-        cull_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, score, valid, h_count, h_cap, lists, list_count);
+        cull_mask_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub);
     else
-        cull_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, score, valid, h_count, h_cap, lists, list_count);
+        cull_mask_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub);
+}
+
+// keep[g] = hypotheses of group g that are still worth scoring: ub[h] * 512 >= best_count[0]
+// (best_count null or 0: everything).
+__global__ __launch_bounds__(64) void keep_mask_k(const uint32_t* __restrict__ ub,
+                                                   const uint32_t* __restrict__ best_count_ptr,
+                                                   unsigned long long* __restrict__ keep) {
+    const uint32_t h = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t best = best_count_ptr ? best_count_ptr[0] : 0u;
+    const bool k = best == 0 || (uint64_t)ub[h] * kTilePoints >= best;
+    const unsigned long long m = __ballot(k);
+    if (threadIdx.x == 0) keep[blockIdx.x] = m;
+}
+void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
+                      hipStream_t st) {
+    if (!n_groups) return;
+    if (!ub) {
+        (void)hipMemsetAsync(keep, 0xFF, sizeof(unsigned long long) * n_groups, st);
+        return;
+    }
+    keep_mask_k<<<n_groups, 64, 0, st>>>(ub, best_count, keep);
 }
 
 // ------------------------------------------------------------------------------------------------
 // counting over the surviving (tile, hypothesis) pairs
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ __launch_bounds__(64) void score_list_k(const double* __restrict__ sx, const double* __restrict__ sy,
+__global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx, const double* __restrict__ sy,
                                                     const double* __restrict__ sz,
                                                     const double* __restrict__ score,
-                                                    const uint32_t* __restrict__ lists,
-                                                    const uint32_t* __restrict__ list_count, uint32_t h_cap,
+                                                    const unsigned long long* __restrict__ masks,
+                                                    const unsigned long long* __restrict__ keep,
+                                                    uint32_t n_groups, uint32_t groups_per_block,
                                                     uint32_t* __restrict__ counts) {
     const uint32_t tile = blockIdx.x;
-    const uint32_t n_list = list_count[tile];
-    const uint32_t e0 = blockIdx.y * kListSegment;
-    if (e0 >= n_list) return;
-    const uint32_t e1 = min(n_list, e0 + kListSegment);
+    const uint32_t g0 = blockIdx.y * groups_per_block;
     const int lane = threadIdx.x;
+    // lane l holds the (pruned) mask of group g0 + l; walking the bits is scalar work (readlane)
+    unsigned long long mm = 0;
+    if ((uint32_t)lane < groups_per_block && g0 + lane < n_groups)
+        mm = masks[(size_t)tile * n_groups + g0 + lane] & keep[g0 + lane];
+    if (!__ballot(mm != 0)) return;  // most (tile, range) blocks of a pruned chunk end here
+
     const size_t base = (size_t)tile * kTilePoints + lane;
     constexpr int P = kTilePoints / 64;
     double x[P], y[P], z[P];
@@ -175,73 +214,117 @@ __global__ __launch_bounds__(64) void score_list_k(const double* __restrict__ sx
         y[j] = sy[base + 64 * j];
         z[j] = sz[base + 64 * j];
     }
-    const uint32_t* __restrict__ lst = lists + (size_t)tile * h_cap;
+    const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
     constexpr int kUsed = KIND == 2 ? 8 : 5;
-    // two-deep software pipeline: list entry e+2 and record e+1 are in flight while e is evaluated
-    uint32_t h_cur = lst[e0];
-    uint32_t h_nxt = lst[min(e0 + 1, e1 - 1)];
+    constexpr uint32_t kEnd = 0xFFFFFFFFu;
+    uint32_t gi = 0;
+    unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mm_hi, 0) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane(mm_lo, 0);
+    auto next = [&]() -> uint32_t {  // wave-uniform iterator over the set bits
+        while (m == 0) {
+            if (++gi >= groups_per_block) return kEnd;
+            m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mm_hi, (int)gi) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane(mm_lo, (int)gi);
+        }
+        const uint32_t bit = (uint32_t)__ffsll((long long)m) - 1u;
+        m &= m - 1ull;
+        return (g0 + gi) * 64u + bit;
+    };
+    uint32_t park_cnt = 0, park_h = 0, slot = 0;
+    uint32_t h = next();
     double rec[kModelStride];
     {
-        const double* __restrict__ m = score + (size_t)h_cur * kModelStride;
+        const double* __restrict__ rp = score + (size_t)h * kModelStride;
 #pragma unroll
-        for (int k = 0; k < kUsed; ++k) rec[k] = m[k];
+        for (int k = 0; k < kUsed; ++k) rec[k] = rp[k];
     }
-    uint32_t park_cnt = 0, park_h = 0;
-    for (uint32_t e = e0; e < e1; ++e) {
-        const uint32_t h_nn = lst[min(e + 2, e1 - 1)];
-        const double* __restrict__ mn = score + (size_t)h_nxt * kModelStride;
-        double nxt[kModelStride];
+    {
+        while (h != kEnd) {
+            // software pipeline: the record of the next set bit is in flight while this one is evaluated
+            const uint32_t h_nxt = next();
+            const double* __restrict__ np = score + (size_t)(h_nxt == kEnd ? h : h_nxt) * kModelStride;
+            double nrec[kModelStride];
 #pragma unroll
-        for (int k = 0; k < kUsed; ++k) nxt[k] = mn[k];
-        uint32_t cnt = 0;
-        if (KIND == 0) {
-            const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4];
+            for (int k = 0; k < kUsed; ++k) nrec[k] = np[k];
+            uint32_t cnt = 0;
+            if (KIND == 0) {
+                const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4];
 #pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const double num = plane_num(a, b, c, d, x[j], y[j], z[j]);
-                cnt += (uint32_t)__popcll(__ballot(num < T));
+                for (int j = 0; j < P; ++j) {
+                    const double num = plane_num(a, b, c, d, x[j], y[j], z[j]);
+                    cnt += (uint32_t)__popcll(__ballot(num < T));
+                }
+            } else if (KIND == 1) {
+                const double cx = rec[0], cy = rec[1], cz = rec[2], lo = rec[3], hi = rec[4];
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const double sv = sphere_s(cx, cy, cz, x[j], y[j], z[j]);
+                    cnt += (uint32_t)__popcll(__ballot(sv >= lo) & __ballot(sv <= hi));
+                }
+            } else {
+                const double cx = rec[0], cy = rec[1], cz = rec[2], rx = rec[3], ry = rec[4], rz = rec[5];
+                const double lo = rec[6], hi = rec[7];
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const double tv = line_t(cx, cy, cz, rx, ry, rz, x[j], y[j], z[j]);
+                    cnt += (uint32_t)__popcll(__ballot(tv >= lo) & __ballot(tv <= hi));
+                }
             }
-        } else if (KIND == 1) {
-            const double cx = rec[0], cy = rec[1], cz = rec[2], lo = rec[3], hi = rec[4];
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const double sv = sphere_s(cx, cy, cz, x[j], y[j], z[j]);
-                cnt += (uint32_t)__popcll(__ballot(sv >= lo) & __ballot(sv <= hi));
+            park_cnt = ((uint32_t)lane == slot) ? cnt : park_cnt;
+            park_h = ((uint32_t)lane == slot) ? h : park_h;
+            if (++slot == 64u) {  // wave-uniform: flush the parked counts
+                if (park_cnt) atomicAdd(&counts[park_h], park_cnt);
+                park_cnt = 0;
+                slot = 0;
             }
-        } else {
-            const double cx = rec[0], cy = rec[1], cz = rec[2], rx = rec[3], ry = rec[4], rz = rec[5];
-            const double lo = rec[6], hi = rec[7];
+            h = h_nxt;
 #pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const double tv = line_t(cx, cy, cz, rx, ry, rz, x[j], y[j], z[j]);
-                cnt += (uint32_t)__popcll(__ballot(tv >= lo) & __ballot(tv <= hi));
-            }
+            for (int k = 0; k < kUsed; ++k) rec[k] = nrec[k];
         }
-        const uint32_t slot = (e - e0) & 63u;
-        park_cnt = ((uint32_t)lane == slot) ? cnt : park_cnt;
-        park_h = ((uint32_t)lane == slot) ? h_cur : park_h;
-        if (slot == 63u || e + 1 == e1) {  // wave-uniform: flush the parked counts
-            if ((uint32_t)lane <= slot && park_cnt) atomicAdd(&counts[park_h], park_cnt);
-            park_cnt = 0;
-        }
-        h_cur = h_nxt;
-        h_nxt = h_nn;
-#pragma unroll
-        for (int k = 0; k < kUsed; ++k) rec[k] = nxt[k];
     }
+    if ((uint32_t)lane < slot && park_cnt) atomicAdd(&counts[park_h], park_cnt);
 }
 
-void launch_score_list(int kind, const SortedView& s, const double* score, const uint32_t* lists,
-                       const uint32_t* list_count, uint32_t h_cap, uint32_t h_count, uint32_t* counts,
-                       hipStream_t st) {
-    if (!s.n_tiles || !h_count) return;
-    const dim3 g(s.n_tiles, (h_count + kListSegment - 1) / kListSegment), b(64);
+void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
+                       const unsigned long long* keep, uint32_t n_groups, uint32_t* counts, hipStream_t st) {
+    if (!s.n_tiles || !n_groups) return;
+    const uint32_t gpb = kGroupsPerBlock;
+    const dim3 g(s.n_tiles, (n_groups + gpb - 1) / gpb), b(64);
     if (kind == 0)
-        score_list_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, lists, list_count, h_cap, counts);
+        score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts);
     else if (kind == 1)
-        score_list_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, score, lists, list_count, h_cap, counts);
+        score_mask_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts);
     else
-        score_list_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, score, lists, list_count, h_cap, counts);
+        score_mask_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts);
+}
+
+// best_count[0] = max(best_count[0], max over valid hypotheses of counts[h])
+__global__ void max_count_k(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ valid,
+                            uint32_t h_count, uint32_t* __restrict__ best_count) {
+    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    uint32_t v = (h < h_count && valid[h]) ? counts[h] : 0u;
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(best_count, v);
+}
+void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
+                      hipStream_t st) {
+    if (h_count) max_count_k<<<(h_count + 255) / 256, 256, 0, st>>>(counts, valid, h_count, best_count);
+}
+
+// number of set bits of masks & keep (statistics for the measurement hook)
+__global__ void count_bits_k(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ keep,
+                             uint32_t n_tiles, uint32_t n_groups, unsigned long long* __restrict__ total) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    unsigned long long c = 0;
+    if (i < (size_t)n_tiles * n_groups) c = (unsigned long long)__popcll(masks[i] & keep[i % n_groups]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
+}
+void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,
+                       uint32_t n_groups, unsigned long long* total, hipStream_t st) {
+    (void)hipMemsetAsync(total, 0, sizeof(unsigned long long), st);
+    const size_t n = (size_t)n_tiles * n_groups;
+    if (n) count_bits_k<<<(uint32_t)((n + 255) / 256), 256, 0, st>>>(masks, keep, n_tiles, n_groups, total);
 }
 
 }  // namespace m3d

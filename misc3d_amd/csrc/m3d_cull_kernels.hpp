@@ -4,28 +4,35 @@
 
 namespace m3d {
 
-constexpr int kTilePoints = 512;    // points per tile = one wave x 8 rows of 64 (kept in VGPRs)
-constexpr int kListSegment = 256;   // listed hypotheses per score_list_k workgroup
+constexpr int kTilePoints = 512;      // points per tile = one wave x 8 rows of 64 (kept in VGPRs)
+constexpr int kBoxStride = 8;         // doubles per tile box record (centre xyz, half extents xyz, 2 pad)
+constexpr uint32_t kGroupsPerBlock = 8;  // 64-hypothesis groups per score_mask_k workgroup (<= 64)
 
-// Z-order sorted copy of a resident cloud: SoA padded with NaN to a multiple of kTilePoints, plus
-// one bounding box per tile (centre xyz, half extents xyz; half < 0 marks an empty tile).
+// Hilbert-sorted copy of a resident cloud: SoA padded with NaN to a multiple of kTilePoints, plus one
+// bounding box per tile (half extent < 0 marks an empty tile).
 struct SortedView {
     const double* x;
     const double* y;
     const double* z;
-    const double* boxes;  // n_tiles x 6
+    const double* boxes;  // n_tiles x kBoxStride
     uint32_t n_tiles;
 };
 
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 
-// lists: n_tiles x h_cap uint32 (surviving hypothesis ids per tile, ascending); list_count: n_tiles.
-void launch_cull(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
-                 uint32_t h_cap, uint32_t* lists, uint32_t* list_count, hipStream_t st);
-
-// counts[h] += inliers of hypothesis h inside the listed tiles; counts must be zero on entry.
-void launch_score_list(int kind, const SortedView& s, const double* score, const uint32_t* lists,
-                       const uint32_t* list_count, uint32_t h_cap, uint32_t h_count, uint32_t* counts,
-                       hipStream_t st);
+// masks: n_tiles x n_groups uint64, bit b of masks[t][g] = hypothesis 64 g + b may have inliers in tile t.
+// ub (may be null; n_groups * 64 entries, zeroed here): number of tiles each hypothesis may touch.
+void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
+                      uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st);
+// keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
+void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
+                      hipStream_t st);
+// counts[h] += inliers of hypothesis h in the tiles whose (mask & keep) bit is set; counts zero on entry.
+void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
+                       const unsigned long long* keep, uint32_t n_groups, uint32_t* counts, hipStream_t st);
+void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
+                      hipStream_t st);
+void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,
+                       uint32_t n_groups, unsigned long long* total, hipStream_t st);
 
 }  // namespace m3d

@@ -280,14 +280,18 @@ static bool use_dense_scoring() {
 }
 
 static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
-    // keep the per-chunk scratch (dense: partial counts, culled: hypothesis lists) below 1 GiB
-    const uint32_t rows = std::max<uint32_t>(1, use_dense_scoring() ? v.n_pad / kScoreTile : sv.n_tiles);
+    // keep the per-chunk scratch below 1 GiB (dense: u32 partial count per (tile, hypothesis);
+    // culled: one bit per (tile, hypothesis))
+    (void)sv;
+    if (!use_dense_scoring()) return 16384;
+    const uint32_t rows = std::max<uint32_t>(1, v.n_pad / kScoreTile);
     const size_t cap = std::min<size_t>(16384, ((size_t)1 << 28) / rows / 64 * 64);
     return std::max<size_t>(cap, 64);
 }
 
 static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const SortedView& sv, int kind,
-                       double thr, size_t begin, size_t end, SampleSource& src, double* ms_sample) {
+                       double thr, size_t begin, size_t end, SampleSource& src, double* ms_sample,
+                       bool prune = false) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const uint32_t h_pad = round_up(count, 64);
@@ -307,8 +311,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (dense) {
         RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
     } else {
-        RESERVE(ctx->lists, sizeof(uint32_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * h_pad);
-        RESERVE(ctx->list_count, sizeof(uint32_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1));
+        RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * (h_pad / 64));
+        RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)(h_pad / 64));
     }
     const double t0 = now_ms();
     src.fill(begin, end, s.h_samples.as<uint32_t>());
@@ -324,10 +328,22 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         launch_reduce_partials(ctx->partial.as<uint32_t>(), n_tiles, h_pad, s.counts.as<uint32_t>(),
                                ctx->stream);
     } else {
-        launch_cull(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, h_pad,
-                    ctx->lists.as<uint32_t>(), ctx->list_count.as<uint32_t>(), ctx->stream);
-        launch_score_list(kind, sv, s.score.as<double>(), ctx->lists.as<uint32_t>(),
-                          ctx->list_count.as<uint32_t>(), h_pad, count, s.counts.as<uint32_t>(), ctx->stream);
+        // prune (fits only): hypotheses that cannot reach the best count of EARLIER chunks are masked
+        // out (keep_mask_k); ctx->best_count is the device-side running maximum
+        const uint32_t n_groups = h_pad / 64;
+        uint32_t* ub = nullptr;
+        if (prune) {
+            RESERVE(ctx->ub, sizeof(uint32_t) * (size_t)h_pad);
+            ub = ctx->ub.as<uint32_t>();
+        }
+        auto* masks = ctx->masks.as<unsigned long long>();
+        auto* keep = ctx->keep.as<unsigned long long>();
+        launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream);
+        launch_keep_mask(ub, prune ? ctx->best_count.as<uint32_t>() : nullptr, n_groups, keep, ctx->stream);
+        launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, s.counts.as<uint32_t>(), ctx->stream);
+        if (prune)
+            launch_max_count(s.counts.as<uint32_t>(), s.valid.as<uint8_t>(), count, ctx->best_count.as<uint32_t>(),
+                             ctx->stream);
     }
     HIPCHK(hipMemcpyAsync(s.h_counts.p, s.counts.p, sizeof(uint32_t) * (size_t)count,
                           hipMemcpyDeviceToHost, ctx->stream));
@@ -550,14 +566,23 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
     // prob == 1: only fitness == 1 can stop it -> as few, equal chunks as the scratch cap allows
     // (one chunk up to 16384 hypotheses; more chunks are pipelined two deep)
+    // Either way the first chunk is small: its best inlier count is what lets the later chunks skip
+    // every hypothesis that cannot reach it (bound-and-prune in score_list_k).
     size_t chunk = 128;
     size_t growth = 2;
-    if (prob >= 1.0 && max_iter > 0) {
-        const size_t n_chunks = (max_iter + chunk_cap - 1) / chunk_cap;
-        chunk = ((max_iter + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+    size_t after_first = 0;  // prob == 1: size of the chunks after the first one
+    if (prob >= 1.0 && max_iter > 1024) {
+        chunk = 1024;
+        const size_t rest = max_iter - chunk;
+        const size_t n_chunks = (rest + chunk_cap - 1) / chunk_cap;
+        after_first = ((rest + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+    } else if (prob >= 1.0) {
+        chunk = std::max<size_t>(max_iter, 64);
         growth = 1;
     }
     chunk = std::min(chunk, chunk_cap);
+    RESERVE(ctx->best_count, 16);
+    HIPCHK(hipMemsetAsync(ctx->best_count.p, 0, sizeof(uint32_t), ctx->stream));
 
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rc = M3D_OK;
@@ -567,11 +592,11 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     bool best_approx_known = false, pending_valid = false;
     auto issue_next = [&](int slot_id) -> int {
         const size_t b = next_begin, e = std::min(max_iter, b + chunk);
-        const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample);
+        const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true);
         if (r == M3D_OK) {
             next_begin = e;
             out->hypotheses_scored += e - b;
-            chunk = std::min(chunk * growth, chunk_cap);
+            chunk = after_first ? std::min(after_first, chunk_cap) : std::min(chunk * growth, chunk_cap);
         }
         return r;
     };
@@ -846,7 +871,7 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
         c->n_tiles = cap / kTilePoints;
         c->n_sorted = n_finite;
         ok = c->sx.reserve(sizeof(double) * cap) && c->sy.reserve(sizeof(double) * cap) &&
-             c->sz.reserve(sizeof(double) * cap) && c->boxes.reserve(sizeof(double) * 6 * c->n_tiles);
+             c->sz.reserve(sizeof(double) * cap) && c->boxes.reserve(sizeof(double) * kBoxStride * c->n_tiles);
         if (ok) {
             launch_fill_nan(c->sx.as<double>(), cap, ctx->stream);
             launch_fill_nan(c->sy.as<double>(), cap, ctx->stream);
@@ -1118,28 +1143,30 @@ int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     const uint32_t n_tiles = v.n_pad / kScoreTile;
     // make sure the buffers of the timed mode exist whatever path issue_chunk took
     RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * s.h_pad);
-    RESERVE(ctx->lists, sizeof(uint32_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * s.h_pad);
-    RESERVE(ctx->list_count, sizeof(uint32_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1));
-    launch_cull(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, s.h_pad, ctx->lists.as<uint32_t>(),
-                ctx->list_count.as<uint32_t>(), ctx->stream);
+    const uint32_t n_groups = s.h_pad / 64;
+    RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * n_groups);
+    RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)n_groups);
+    RESERVE(ctx->small, 256);
+    auto* masks = ctx->masks.as<unsigned long long>();
+    auto* keep = ctx->keep.as<unsigned long long>();
+    launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, nullptr, ctx->stream);
+    launch_keep_mask(nullptr, nullptr, n_groups, keep, ctx->stream);
     if (listed_pairs) {
-        std::vector<uint32_t> lc(std::max<uint32_t>(sv.n_tiles, 1));
-        HIPCHK(hipMemcpyAsync(lc.data(), ctx->list_count.p, sizeof(uint32_t) * sv.n_tiles, hipMemcpyDeviceToHost,
-                              ctx->stream));
+        launch_count_bits(masks, keep, sv.n_tiles, n_groups, ctx->small.as<unsigned long long>(), ctx->stream);
+        unsigned long long tot = 0;
+        HIPCHK(hipMemcpyAsync(&tot, ctx->small.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        uint64_t tot = 0;
-        for (uint32_t t = 0; t < sv.n_tiles; ++t) tot += lc[t];
         *listed_pairs = tot;  // (tile, hypothesis) pairs that survive the box test
     }
     const uint32_t splits = pick_splits(n_tiles, s.h_pad);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     for (int r = 0; r < reps; ++r) {
         if (mode == 0)
-            launch_score_list(kind, sv, s.score.as<double>(), ctx->lists.as<uint32_t>(),
-                              ctx->list_count.as<uint32_t>(), s.h_pad, count, s.counts.as<uint32_t>(), ctx->stream);
+            launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, s.counts.as<uint32_t>(),
+                              ctx->stream);
         else if (mode == 1)
-            launch_cull(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, s.h_pad,
-                        ctx->lists.as<uint32_t>(), ctx->list_count.as<uint32_t>(), ctx->stream);
+            launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, nullptr,
+                             ctx->stream);
         else
             launch_score(kind, v, s.score.as<double>(), s.h_pad, splits, ctx->partial.as<uint32_t>(), ctx->stream);
     }
@@ -1221,7 +1248,7 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
             ok = bx[k].reserve(bytes) && by[k].reserve(bytes) && bz[k].reserve(bytes) &&
                  bo[k].reserve(sizeof(uint32_t) * (size_t)c0->n_pad) && sbx[k].reserve(sizeof(double) * scap) &&
                  sby[k].reserve(sizeof(double) * scap) && sbz[k].reserve(sizeof(double) * scap);
-        ok = ok && sboxes.reserve(sizeof(double) * 6 * c0->n_tiles);
+        ok = ok && sboxes.reserve(sizeof(double) * kBoxStride * c0->n_tiles);
         auto cleanup = [&]() {
             for (int k = 0; k < 2; ++k) {
                 bx[k].release(); by[k].release(); bz[k].release(); bo[k].release();

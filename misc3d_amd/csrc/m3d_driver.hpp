@@ -55,7 +55,8 @@ struct DeviceCtx {
     std::mutex mu;  // one call at a time per device
     ChunkSlot slot[2];
     DevBuf partial, block_counts, total, idx, dist, sum_partial, sums, best_params, small;
-    DevBuf lists, list_count;  // culled scoring: per-tile hypothesis lists
+    DevBuf masks, keep;        // culled scoring: (tile, 64-hypothesis group) bit masks, per-group keep masks
+    DevBuf ub, best_count;     // bound-and-prune: surviving tiles per hypothesis, running best count
     PinBuf h_small;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

@@ -219,3 +219,31 @@ def test_sharded_driver_on_gpu_equals_single_call(capi):
             assert s.best_index == g.stats["best_index"] and s.count == g.stats["count"]
             assert s.iterations == g.stats["iterations"]
             assert np.array_equal(s.inliers, g.inliers) and np.array_equal(s.params, g.params)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_culled_scoring_robustness(capi, orc, kind):
+    """The box tests of cull_k must never drop an inlier: clouds far from the origin, tiny and huge
+    scales, degenerate extents, tile-boundary sizes -- counts stay bit-identical to the oracle."""
+    rng = np.random.default_rng(100 + kind)
+    cases = []
+    base, nrm = _clouds(kind, 6000, seed=40 + kind)
+    cases.append((base + np.array([1.0e5, -2.0e5, 3.0e4]), nrm, 0.01))          # far from the origin
+    cases.append((base * 1e-3, nrm, 1e-5))                                        # millimetre-scale scene
+    cases.append((base * 1e3 + 7.0, nrm, 10.0))                                   # kilometre-scale scene
+    for n in (511, 512, 513, 1024, 2049):                                         # tile boundaries
+        p, q = _clouds(kind, n, seed=50 + kind)
+        cases.append((p, q, 0.01))
+    flat = base.copy()
+    flat[:, 2] = 0.25                                                             # zero extent along z
+    cases.append((flat, nrm, 0.01))
+    same = np.tile(base[:1], (700, 1))                                            # all points identical
+    cases.append((same, None if nrm is None else np.tile(nrm[:1], (700, 1)), 0.01))
+    for pts, nn, thr in cases:
+        n = len(pts)
+        samples = capi.draw_samples(n, kind, 200, seed=3)
+        with capi.Cloud(pts, nn) as c:
+            valid, models, counts = c.score_range(kind, thr, samples)
+        ovalid, omodels, ocounts, _ = orc.score_samples(kind, pts, nn, thr, samples.astype(np.uint64))
+        assert np.array_equal(valid.astype(bool), ovalid.astype(bool))
+        assert np.array_equal(counts.astype(np.uint64), ocounts), (kind, n, thr)

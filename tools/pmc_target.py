@@ -15,17 +15,17 @@ H = int(os.environ.get("M3D_PMC_HYP", "10000"))
 pts = synth.plane_cloud_c2(N, 2)
 with capi.Cloud(pts) as c:
     s = capi.draw_samples(N, 0, H, 11)
-    for mode, name in ((0, "score_list_k"), (1, "cull_k"), (2, "score_k dense")):
+    for mode, name in ((0, "score_mask_k"), (1, "cull_mask_k"), (2, "score_k dense")):
         print("plane", name, "ms, listed pairs:", c.time_score(0, 0.01, s, reps=3, mode=mode))
     g = c.fit(0, 0.01, H, 1.0, seed=11)
     print("plane fit:", g.stats)
 sp = synth.sphere_cloud_c3(N, 4)
 with capi.Cloud(sp) as c:
     s = capi.draw_samples(N, 1, H, 13)
-    for mode, name in ((0, "score_list_k"), (1, "cull_k"), (2, "score_k dense")):
+    for mode, name in ((0, "score_mask_k"), (1, "cull_mask_k"), (2, "score_k dense")):
         print("sphere", name, "ms, listed pairs:", c.time_score(1, 0.01, s, reps=3, mode=mode))
 cp, cn = synth.cylinder_cloud_c3(N, 3)
 with capi.Cloud(cp, cn) as c:
     s = capi.draw_samples(N, 2, H, 13)
-    for mode, name in ((0, "score_list_k"), (1, "cull_k"), (2, "score_k dense")):
+    for mode, name in ((0, "score_mask_k"), (1, "cull_mask_k"), (2, "score_k dense")):
         print("cylinder", name, "ms, listed pairs:", c.time_score(2, 0.01, s, reps=3, mode=mode))

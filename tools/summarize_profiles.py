@@ -74,7 +74,7 @@ def main():
         if not os.path.exists(p):
             continue
         for k, cs in counters(p).items():
-            if not (k.startswith("m3d::score_k") or k.startswith("m3d::score_list_k") or k.startswith("m3d::cull_k")):
+            if not (k.startswith("m3d::score_k") or k.startswith("m3d::score_mask_k") or k.startswith("m3d::cull_mask_k")):
                 continue
             d = summary["kernels"].setdefault(k, {})
             for cname, vals in cs.items():
@@ -83,10 +83,10 @@ def main():
                 d.setdefault("pmc_launch_ns", {})[cname] = big[1]
     with open(os.path.join(DST, f"{TAG}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
-    sk = summary["kernels"].get("m3d::score_list_k<0>") or summary["kernels"].get("m3d::score_k<0>")
+    sk = summary["kernels"].get("m3d::score_mask_k<0>") or summary["kernels"].get("m3d::score_k<0>")
     if sk:
         with open(os.path.join(DST, "pmc_score_latest.json"), "w") as f:
-            json.dump({"kernel": "m3d::score_list_k<0>" if "m3d::score_list_k<0>" in summary["kernels"] else "m3d::score_k<0>", "hbm_bytes_per_launch": sk["hbm_bytes"],
+            json.dump({"kernel": "m3d::score_mask_k<0>" if "m3d::score_mask_k<0>" in summary["kernels"] else "m3d::score_k<0>", "hbm_bytes_per_launch": sk["hbm_bytes"],
                        "hbm_read_bytes": sk["hbm_read_bytes"], "hbm_write_bytes": sk["hbm_write_bytes"],
                        "source": f"profiles/{TAG}_pmc_summary.json",
                        "launch": os.environ.get("M3D_PMC_HYP", "10000") + " hypotheses x " + str(n_points) + " points"},
