@@ -153,7 +153,7 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
     if (ub) (void)hipMemsetAsync(ub, 0, sizeof(uint32_t) * (size_t)n_groups * 64, st);
     // enough waves to fill the chip: split the tile range when there are few hypothesis groups
     uint32_t splits = std::max<uint32_t>(1, (8192 + n_groups - 1) / n_groups);
-    splits = std::min(splits, s.n_tiles);
+    splits = std::min(splits, std::max<uint32_t>(1, s.n_tiles / 16));  // >= 16 tiles per wave: the record loads amortise
     const uint32_t tpb = (s.n_tiles + splits - 1) / splits;
     const dim3 g(n_groups, (s.n_tiles + tpb - 1) / tpb), b(64);
     if (kind == 0)
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts, hipStream_t st) {
     if (!s.n_tiles || !n_groups) return;
-    const uint32_t gpb = kGroupsPerBlock;
+    // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
+    const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerBlock, (uint32_t)(((uint64_t)s.n_tiles * n_groups) / 16384)));
     const dim3 g(s.n_tiles, (n_groups + gpb - 1) / gpb), b(64);
     if (kind == 0)
         score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts);

@@ -572,7 +572,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     size_t growth = 2;
     size_t after_first = 0;  // prob == 1: size of the chunks after the first one
     if (prob >= 1.0 && max_iter > 1024) {
-        chunk = 1024;
+        chunk = 256;
         const size_t rest = max_iter - chunk;
         const size_t n_chunks = (rest + chunk_cap - 1) / chunk_cap;
         after_first = ((rest + n_chunks - 1) / n_chunks + 63) / 64 * 64;
@@ -590,6 +590,8 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     size_t next_begin = 0;
     double best_approx = 0, pending_approx = 0;  // tree error sums of the current best / the trial
     bool best_approx_known = false, pending_valid = false;
+    const double* best_dev = ctx->best_params.as<double>();  // device copy of the current best model
+    bool best_in_chunk = false;
     auto issue_next = [&](int slot_id) -> int {
         const size_t b = next_begin, e = std::min(max_iter, b + chunk);
         const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true);
@@ -650,7 +652,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 if (r != M3D_OK) cb_rc = r;
                 if (c != cnt) out->internal_error = 1;
                 if (!best_approx_known) {
-                    r = approx_error(ctx, v, kind, thr, ctx->best_params.as<double>(), &c, &best_approx);
+                    r = approx_error(ctx, v, kind, thr, best_dev, &c, &best_approx);
                     if (r != M3D_OK) cb_rc = r;
                     best_approx_known = true;
                 }
@@ -665,7 +667,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 *trial_rmse = exact_rmse(model_t, cnt, true);
                 *trial_known = true;
                 if (!out->st.best_rmse_known) {
-                    out->st.best_rmse = exact_rmse(ctx->best_params.as<double>(), 0, false);
+                    out->st.best_rmse = exact_rmse(best_dev, 0, false);
                     out->st.best_rmse_known = 1;
                 }
                 if (*trial_rmse < out->st.best_rmse) {
@@ -676,14 +678,22 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 return false;
             };
             auto on_best = [&](size_t i) {
-                (void)hipMemcpyAsync(ctx->best_params.p, s.params.as<double>() + (i - s.begin) * kModelStride,
-                                     sizeof(double) * kModelStride, hipMemcpyDeviceToDevice, ctx->stream);
+                // the model stays in the chunk's slot while the chunk is replayed; ONE device copy per
+                // chunk (below) moves the final best into ctx->best_params
+                best_dev = s.params.as<double>() + (i - s.begin) * kModelStride;
+                best_in_chunk = true;
                 best_approx_known = pending_valid;
                 best_approx = pending_approx;
                 pending_valid = false;
             };
             replay_range(&out->st, v.n, kind, max_iter, prob, s.begin, s.end, s.h_valid.as<uint8_t>(),
                          s.h_counts.as<uint32_t>(), tie, on_best);
+            if (best_in_chunk) {
+                (void)hipMemcpyAsync(ctx->best_params.p, best_dev, sizeof(double) * kModelStride,
+                                     hipMemcpyDeviceToDevice, ctx->stream);
+                best_dev = ctx->best_params.as<double>();
+                best_in_chunk = false;
+            }
             if (cb_rc != M3D_OK) {
                 rc = cb_rc;
                 break;
@@ -1093,24 +1103,33 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
         return M3D_OK;
     };
     size_t j = 0;
+    bool first_piece = true;
+    RESERVE(ctx->best_count, 16);
+    if (begin == 0) HIPCHK(hipMemsetAsync(ctx->best_count.p, 0, sizeof(uint32_t), ctx->stream));  // new fit
     for (size_t b = begin; b < end; b += slice, ++j) {
         const size_t e = std::min(end, b + slice);
         // every rank draws the whole stream (the host draws the other ranks' slices while this rank's
         // previous slice is being scored on the GPU)
         sampler->draw_until(e);
         if (j % world != rank) continue;
-        for (size_t bb = b; bb < e; bb += chunk_cap) {
-            const size_t ee = std::min(e, bb + chunk_cap);
+        // the first piece of the call is small: its best count lets the rest skip hopeless hypotheses
+        // (bound-and-prune against LOWER-index hypotheses of this rank only, which is what the
+        // sequential replay allows; the rank's first hypothesis index is its smallest)
+        for (size_t bb = b; bb < e;) {
+            const size_t piece = first_piece ? std::min<size_t>(256, chunk_cap) : chunk_cap;
+            first_piece = false;
+            const size_t ee = std::min(e, bb + piece);
             int rc = collect(cur);
             if (rc != M3D_OK) return rc;
             tsrc.table = sampler->table.data();
-            rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, bb, ee, tsrc, nullptr);
+            rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, bb, ee, tsrc, nullptr, true);
             if (rc != M3D_OK) return rc;
             pend[cur].active = true;
             pend[cur].out_pos = out;
             pend[cur].n = ee - bb;
             out += ee - bb;
             cur ^= 1;
+            bb = ee;
         }
     }
     int rc = collect(0);
