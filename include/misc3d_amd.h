@@ -178,6 +178,9 @@ int m3d_registration_ransac(const double *src, size_t n_src, const double *dst, 
 int m3d_match_mutual_nn(const double *feat_src, size_t n_src, const double *feat_dst, size_t n_dst,
                         int dim, int method, int n_trees, int device, size_t *out_src,
                         size_t *out_dst, size_t *k);
+/* Diagnostics: number of queries of the last m3d_match_mutual_nn call whose fp32 screen was
+ * inconclusive (candidate list overflow / fp32 range) and that were redone by exact brute force. */
+uint64_t m3d_match_last_fallbacks(void);
 
 /* ---- measurement hook (bench.py `roofline`): average duration in ms of the scoring kernel alone
  * (score_k, the dominant kernel) over `reps` launches of `n_hypotheses` hypotheses, timed with HIP

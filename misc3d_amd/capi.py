@@ -120,6 +120,8 @@ def lib():
         L.m3d_registration_ransac.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                               C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double, C.c_double,
                                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.m3d_match_last_fallbacks.restype = C.c_uint64
+        L.m3d_match_last_fallbacks.argtypes = []
         L.m3d_match_mutual_nn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -396,6 +398,10 @@ def registration_ransac(src, dst, corr_src, corr_dst, threshold=0.01, max_iter=1
                                          C.cast(sref, C.c_void_p) if sref else None, device, _p(T),
                                          C.cast(C.byref(st), C.c_void_p)))
     return T.reshape(4, 4), st.asdict()
+
+
+def match_last_fallbacks():
+    return int(lib().m3d_match_last_fallbacks())
 
 
 def match_mutual_nn(feat_src, feat_dst, method=1, n_trees=4, device=0):

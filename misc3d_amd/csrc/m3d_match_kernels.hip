@@ -1,0 +1,244 @@
+// m3d_match_kernels.hip -- exact nearest neighbour in descriptor space with an fp32 screening pass.
+//
+// Replaces the query loops of registration::NearestSearch (src/correspondence_matching.cpp:13-44)
+// for FPFH-sized descriptors (dim 33).  The result is the EXACT fp64 nearest neighbour of the brute
+// force kernel nn_k (same serial-order accumulation, ties -> lowest index); the speed comes from not
+// evaluating all N x M pairs in fp64:
+//   1. nn32_scan_k     fp32 (packed v_pk_fma_f32) |a|^2 + |b|^2 - 2 a.b over all pairs; per query the running
+//                      minimum m and a ring of the rows seen with d32 <= m + 2 E_q.  E_q bounds |d32 - d_exact|
+//                      (input rounding to fp32 + fp32 arithmetic, ~60 u (|a|^2 + |b|^2) worst case; used:
+//                      E_q = (2 dim + 16) * 2^-24 * 1.5 * (|a|^2 + max|b|^2)).  The exact argmin j* satisfies
+//                      d32(j*) <= d(j*) + E <= d(j~) + E <= m_final + 2E <= m_running + 2E, so it (and every
+//                      exact tie) enters the ring.
+//   2. nn64_verify_k   exact fp64 distances of the ring entries inside the final window, reference accumulation order.
+//   3. nn_exact_one_k  a query whose ring evicted a possibly valid entry, or whose fp32 bound is not finite
+//                      (adversarial data), is redone exactly by a whole wave.
+#include "m3d_reg_kernels.hpp"
+
+#include "m3d_fp.hpp"
+
+#pragma clang fp contract(off)
+
+namespace m3d {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// fp32 row: kScreenDimP floats = 33 values, one zero pad (even count for packed FMAs), |row|^2 of the
+// ROUNDED values at [34], one more pad -> 144 B rows, 16 B aligned for wide scalar loads.
+constexpr int kDotW = 34;
+constexpr int kNormSlot = 34;
+
+__global__ void to_f32_k(const double* __restrict__ f, uint32_t n, float* __restrict__ out,
+                         float* __restrict__ norm2) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.0f;
+    for (int k = 0; k < kDotW; ++k) {
+        const float v = k < 33 ? (float)f[(size_t)i * 33 + k] : 0.0f;
+        out[(size_t)i * kScreenDimP + k] = v;
+        acc = __builtin_fmaf(v, v, acc);
+    }
+    out[(size_t)i * kScreenDimP + kNormSlot] = acc;
+    out[(size_t)i * kScreenDimP + kNormSlot + 1] = 0.0f;
+    norm2[i] = acc;
+}
+
+struct Row32 {
+    f32x2 v[kDotW / 2];
+    float n2;
+};
+
+__device__ __forceinline__ Row32 load_row(const float* __restrict__ d) {
+    Row32 r;
+#pragma unroll
+    for (int k = 0; k < kDotW / 2; ++k) r.v[k] = {d[2 * k], d[2 * k + 1]};
+    r.n2 = d[kNormSlot];
+    return r;
+}
+
+// d32(q, j) = (|q|^2 + |b_j|^2) - 2 q.b_j; two independent packed-FMA chains; one query per lane
+// (row in VGPRs), database rows wave-uniform (scalar loads, prefetched one row ahead by the callers).
+__device__ __forceinline__ float d32_of(const Row32& q, const Row32& d) {
+    f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k + 1 < kDotW / 2; k += 2) {
+        a0 = __builtin_elementwise_fma(q.v[k], d.v[k], a0);
+        a1 = __builtin_elementwise_fma(q.v[k + 1], d.v[k + 1], a1);
+    }
+    a0 = __builtin_elementwise_fma(q.v[kDotW / 2 - 1], d.v[kDotW / 2 - 1], a0);
+    const f32x2 a = a0 + a1;
+    return __builtin_fmaf(-2.0f, a.x + a.y, q.n2 + d.n2);
+}
+
+// One pass over a slice of the database: running fp32 minimum m and every row with d32 <= m + 2E at
+// the time it is seen (a superset of the rows within 2E of the FINAL minimum, because m only falls),
+// kept in a ring of kRing (index, d32) entries.  An entry pushed out of the ring is remembered only
+// through the smallest evicted d32: if that is above the final window the evicted entries were all
+// stale, otherwise the query takes the exact fallback.
+__global__ __launch_bounds__(256) void nn32_scan_k(const float* __restrict__ q, uint32_t nq,
+                                                    const float* __restrict__ db, uint32_t ndb,
+                                                    uint32_t db_per_split, float e_coeff, float max_dn2,
+                                                    uint2* __restrict__ ring, uint32_t* __restrict__ ring_count,
+                                                    float* __restrict__ part_min, float* __restrict__ evict_min) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ii = i < nq ? i : nq - 1;
+    const Row32 qr = load_row(q + (size_t)ii * kScreenDimP);
+    const uint32_t j0 = blockIdx.y * db_per_split, j1 = min(ndb, j0 + db_per_split);
+    // 2E (+ slack for the fp32 evaluation of the window itself); not finite -> the screen proves nothing
+    const float two_e = 2.0f * e_coeff * (qr.n2 + max_dn2) * 1.000001f + 1e-30f;
+    const bool screen_ok = two_e < INFINITY;
+    uint2* __restrict__ my = ring + ((size_t)blockIdx.y * nq + ii) * kRing;
+    float best = INFINITY, win = INFINITY, ev = INFINITY;
+    uint32_t cnt = 0;
+    if (j0 < j1) {
+        Row32 cur = load_row(db + (size_t)j0 * kScreenDimP);
+        for (uint32_t j = j0; j < j1; ++j) {
+            const Row32 nxt = load_row(db + (size_t)(j + 1) * kScreenDimP);   // spare row behind the last one
+            const float dv = d32_of(qr, cur);
+            if (dv <= win && screen_ok && i < nq) {   // also taken while win == +inf
+                const uint32_t slot = cnt % kRing;
+                if (cnt >= (uint32_t)kRing) ev = fminf(ev, __uint_as_float(my[slot].y));
+                my[slot] = make_uint2(j, __float_as_uint(dv));
+                cnt++;
+                if (dv < best) {
+                    best = dv;
+                    win = dv + two_e;
+                }
+            }
+            cur = nxt;
+        }
+    }
+    if (i < nq) {
+        const size_t o = (size_t)blockIdx.y * nq + i;
+        ring_count[o] = cnt;
+        part_min[o] = screen_ok ? best : -INFINITY;   // -inf forces the fallback in the verify kernel
+        evict_min[o] = ev;
+    }
+}
+
+// exact distances of the surviving candidates: serial-order fp64 accumulation (nanoflann
+// L2_Simple_Adaptor order); slices and ring entries are visited in ascending database index and the
+// comparison is strict, so the lowest index wins among equal distances.
+__global__ void nn64_verify_k(const double* __restrict__ q, uint32_t nq, const double* __restrict__ db, int dim,
+                              const uint2* __restrict__ ring, const uint32_t* __restrict__ ring_count,
+                              const float* __restrict__ part_min, const float* __restrict__ evict_min,
+                              uint32_t splits, float e_coeff, float max_dn2, const float* __restrict__ qn2,
+                              uint32_t* __restrict__ nn, uint32_t* __restrict__ overflow_list,
+                              uint32_t* __restrict__ overflow_count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nq) return;
+    float m = INFINITY;
+    bool fallback = false;
+    for (uint32_t s = 0; s < splits; ++s) {
+        const float pm = part_min[(size_t)s * nq + i];
+        if (pm == -INFINITY) fallback = true;
+        m = fminf(m, pm);
+    }
+    const float win = m + (2.0f * e_coeff * (qn2[i] + max_dn2) * 1.000001f + 1e-30f);
+    if (!(win < INFINITY) && m < INFINITY) fallback = true;
+    for (uint32_t s = 0; s < splits; ++s)
+        if (evict_min[(size_t)s * nq + i] <= win) fallback = true;   // a possibly valid candidate was evicted
+    if (fallback) {
+        overflow_list[atomicAdd(overflow_count, 1u)] = i;
+        return;
+    }
+    double bd = INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t s = 0; s < splits; ++s) {
+        const size_t o = (size_t)s * nq + i;
+        const uint32_t c = ring_count[o];
+        const uint32_t live = c < (uint32_t)kRing ? c : (uint32_t)kRing;
+        const uint32_t first = c < (uint32_t)kRing ? 0u : c % kRing;   // oldest retained entry
+        for (uint32_t t = 0; t < live; ++t) {
+            const uint2 e = ring[o * kRing + (first + t) % kRing];
+            if (!(__uint_as_float(e.y) <= win)) continue;   // stale: was only near an earlier running minimum
+            const uint32_t j = e.x;
+            double acc = 0.0;
+            for (int k = 0; k < dim; ++k) {
+                const double df = q[(size_t)i * dim + k] - db[(size_t)j * dim + k];
+                acc += df * df;
+            }
+            if (acc < bd) {
+                bd = acc;
+                bi = j;
+            }
+        }
+    }
+    nn[i] = bi;
+}
+
+// one wave per overflowed query: exact brute force, lanes stride the database, (distance, index)
+// lexicographic minimum across lanes.
+__global__ __launch_bounds__(64) void nn_exact_one_k(const double* __restrict__ q, const double* __restrict__ db,
+                                                      uint32_t ndb, int dim, const uint32_t* __restrict__ list,
+                                                      uint32_t* __restrict__ nn) {
+    const uint32_t i = list[blockIdx.x];
+    const int lane = threadIdx.x;
+    double bd = INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t j = lane; j < ndb; j += 64) {
+        double acc = 0.0;
+        for (int k = 0; k < dim; ++k) {
+            const double df = q[(size_t)i * dim + k] - db[(size_t)j * dim + k];
+            acc += df * df;
+        }
+        if (acc < bd) {
+            bd = acc;
+            bi = j;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(bd, off, 64);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
+        if (od < bd || (od == bd && oi < bi)) {
+            bd = od;
+            bi = oi;
+        }
+    }
+    if (lane == 0) nn[i] = bi;
+}
+
+__global__ void max_f32_k(const float* __restrict__ v, uint32_t n, float* __restrict__ out) {
+    __shared__ float sm[256];
+    float m = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, v[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+void launch_to_f32_33(const double* f, uint32_t n, float* out32, float* norm2, float* max_norm2, hipStream_t s) {
+    if (!n) return;
+    to_f32_k<<<(n + 255) / 256, 256, 0, s>>>(f, n, out32, norm2);
+    max_f32_k<<<1, 256, 0, s>>>(norm2, n, max_norm2);
+}
+
+// Workspace (device): ring splits x nq x kRing uint2, ring_count / part_min / evict_min splits x nq,
+// overflow_list nq u32, overflow_count 1 u32 (zeroed here).  max_dn2 = max |b|^2 over the database (host value).
+// d32 must carry one spare row behind row ndb-1 (prefetch).  *h_overflow = queries that took the exact fallback.
+hipError_t launch_nn_screened33(const double* q, const float* q32, const float* qn, uint32_t nq, const double* db,
+                                const float* d32, uint32_t ndb, float max_dn2, uint32_t splits, uint2* ring,
+                                uint32_t* ring_count, float* part_min, float* evict_min, uint32_t* overflow_list,
+                                uint32_t* overflow_count, uint32_t* nn, uint32_t* h_overflow, hipStream_t s) {
+    constexpr int DIM = 33;
+    *h_overflow = 0;
+    if (!nq || !ndb) return hipSuccess;
+    (void)hipMemsetAsync(overflow_count, 0, sizeof(uint32_t), s);
+    const uint32_t per = (ndb + splits - 1) / splits;
+    const float e_coeff = (2.0f * DIM + 16.0f) * 5.9604645e-08f * 1.5f;
+    nn32_scan_k<<<dim3((nq + 255) / 256, splits), 256, 0, s>>>(q32, nq, d32, ndb, per, e_coeff, max_dn2, ring,
+                                                              ring_count, part_min, evict_min);
+    nn64_verify_k<<<(nq + 255) / 256, 256, 0, s>>>(q, nq, db, DIM, ring, ring_count, part_min, evict_min, splits,
+                                                   e_coeff, max_dn2, qn, nn, overflow_list, overflow_count);
+    hipError_t e = hipMemcpyAsync(h_overflow, overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    if (*h_overflow) nn_exact_one_k<<<*h_overflow, 64, 0, s>>>(q, db, ndb, DIM, overflow_list, nn);
+    return hipGetLastError();
+}
+
+}  // namespace m3d

@@ -47,4 +47,13 @@ void launch_kabsch_sums(const double* src, const double* dst, uint32_t n, double
 void launch_nn(const double* q, uint32_t nq, const double* db, uint32_t ndb, int dim, uint32_t splits,
                double* best_d, uint32_t* best_i, uint32_t* nn, hipStream_t s);
 
+// fp32-screened exact nearest neighbour for dim 33 (m3d_match_kernels.hip)
+constexpr int kScreenDimP = 36;   // fp32 row stride: 33 values, pad, |row|^2, pad (144 B)
+constexpr int kRing = 16;         // candidate ring entries per (query, database slice)
+void launch_to_f32_33(const double* f, uint32_t n, float* out32, float* norm2, float* max_norm2, hipStream_t s);
+hipError_t launch_nn_screened33(const double* q, const float* q32, const float* qn, uint32_t nq, const double* db,
+                                const float* d32, uint32_t ndb, float max_dn2, uint32_t splits, uint2* ring,
+                                uint32_t* ring_count, float* part_min, float* evict_min, uint32_t* overflow_list,
+                                uint32_t* overflow_count, uint32_t* nn, uint32_t* h_overflow, hipStream_t s);
+
 }  // namespace m3d

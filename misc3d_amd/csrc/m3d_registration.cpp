@@ -16,6 +16,7 @@
 #include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <random>
@@ -43,6 +44,8 @@ using namespace m3d;
 namespace {
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+uint64_t g_match_fallbacks = 0;   // queries of the last m3d_match_mutual_nn that took the exact fallback
 
 double now_ms() {
     using namespace std::chrono;
@@ -527,6 +530,8 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
     return rc;
 }
 
+uint64_t m3d_match_last_fallbacks(void) { return g_match_fallbacks; }
+
 int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat_dst, size_t n_dst, int dim,
                         int method, int n_trees, int device, size_t* out_src, size_t* out_dst, size_t* k_out) {
     (void)method;   // FLANN (exact kd-tree) and ANNOY (approximate forest) both map to the exact search
@@ -540,12 +545,17 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     if (!ctx) return M3D_ERR_DEVICE;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    DevBuf fs, fd, bd, bi, nn01, nn10;
+    DevBuf fs, fd, bd, bi, nn01, nn10, fs32, fd32, ns2, nd2, ring, ring_count, evict, over_list, scal;
     auto done = [&](int r) {
-        fs.release(); fd.release(); bd.release(); bi.release(); nn01.release(); nn10.release();
+        for (DevBuf* b : {&fs, &fd, &bd, &bi, &nn01, &nn10, &fs32, &fd32, &ns2, &nd2, &ring, &ring_count, &evict,
+                          &over_list, &scal})
+            b->release();
         return r;
     };
     const uint32_t ns = (uint32_t)n_src, nd = (uint32_t)n_dst;
+    // dim 33 (FPFH): fp32-screened exact search (m3d_match_kernels.hip); other widths: fp64 brute force.
+    const char* brute_env = std::getenv("M3D_MATCH_BRUTE");
+    const bool screened = dim == 33 && !(brute_env && brute_env[0] == '1');
     // enough (query block x database split) workgroups to fill the chip
     auto splits_for = [](uint32_t nq, uint32_t ndb) {
         const uint32_t blocks = (nq + 255) / 256;
@@ -554,25 +564,53 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     };
     const uint32_t s01 = splits_for(ns, nd), s10 = splits_for(nd, ns);
     const size_t part = std::max((size_t)s01 * ns, (size_t)s10 * nd);
+    const uint32_t nmax = std::max(ns, nd);
     if (!fs.reserve(sizeof(double) * (size_t)dim * ns) || !fd.reserve(sizeof(double) * (size_t)dim * nd) ||
         !bd.reserve(sizeof(double) * part) || !bi.reserve(sizeof(uint32_t) * part) ||
         !nn01.reserve(sizeof(uint32_t) * ns) || !nn10.reserve(sizeof(uint32_t) * nd))
+        return done(M3D_ERR_DEVICE);
+    if (screened &&   // fp32 rows carry one spare row (prefetch target of the last iteration)
+        (!fs32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)ns + 1)) ||
+         !fd32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)nd + 1)) || !ns2.reserve(sizeof(float) * ns) ||
+         !nd2.reserve(sizeof(float) * nd) || !ring.reserve(sizeof(uint2) * (size_t)kRing * part) ||
+         !ring_count.reserve(sizeof(uint32_t) * part) || !evict.reserve(sizeof(float) * part) ||
+         !over_list.reserve(sizeof(uint32_t) * nmax) || !scal.reserve(64)))
         return done(M3D_ERR_DEVICE);
     std::vector<uint32_t> h01(ns), h10(nd);
     bool ok = hipMemcpyAsync(fs.p, feat_src, sizeof(double) * (size_t)dim * ns, hipMemcpyHostToDevice, ctx->stream) ==
                   hipSuccess &&
               hipMemcpyAsync(fd.p, feat_dst, sizeof(double) * (size_t)dim * nd, hipMemcpyHostToDevice, ctx->stream) ==
                   hipSuccess;
-    if (ok) {
-        // the two std::threads of correspondence_matching.cpp:59-62 become two launches on one stream
+    if (ok && screened) {
+        float* sc = scal.as<float>();   // [0] max |src|^2, [1] max |dst|^2, [2] overflow counter (u32)
+        launch_to_f32_33(fs.as<double>(), ns, fs32.as<float>(), ns2.as<float>(), sc + 0, ctx->stream);
+        launch_to_f32_33(fd.as<double>(), nd, fd32.as<float>(), nd2.as<float>(), sc + 1, ctx->stream);
+        float h_max[2] = {0.0f, 0.0f};
+        uint32_t over01 = 0, over10 = 0;
+        ok = hipMemcpyAsync(h_max, sc, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+        // the two std::threads of correspondence_matching.cpp:59-62 become two passes on one stream
+        ok = ok && launch_nn_screened33(fs.as<double>(), fs32.as<float>(), ns2.as<float>(), ns, fd.as<double>(),
+                                        fd32.as<float>(), nd, h_max[1], s01, ring.as<uint2>(),
+                                        ring_count.as<uint32_t>(), bd.as<float>(), evict.as<float>(),
+                                        over_list.as<uint32_t>(), scal.as<uint32_t>() + 2, nn01.as<uint32_t>(),
+                                        &over01, ctx->stream) == hipSuccess;
+        ok = ok && launch_nn_screened33(fd.as<double>(), fd32.as<float>(), nd2.as<float>(), nd, fs.as<double>(),
+                                        fs32.as<float>(), ns, h_max[0], s10, ring.as<uint2>(),
+                                        ring_count.as<uint32_t>(), bd.as<float>(), evict.as<float>(),
+                                        over_list.as<uint32_t>(), scal.as<uint32_t>() + 2, nn10.as<uint32_t>(),
+                                        &over10, ctx->stream) == hipSuccess;
+        g_match_fallbacks = (uint64_t)over01 + over10;
+    } else if (ok) {
         launch_nn(fs.as<double>(), ns, fd.as<double>(), nd, dim, s01, bd.as<double>(), bi.as<uint32_t>(),
                   nn01.as<uint32_t>(), ctx->stream);
         launch_nn(fd.as<double>(), nd, fs.as<double>(), ns, dim, s10, bd.as<double>(), bi.as<uint32_t>(),
                   nn10.as<uint32_t>(), ctx->stream);
+    }
+    if (ok)
         ok = hipMemcpyAsync(h01.data(), nn01.p, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
              hipMemcpyAsync(h10.data(), nn10.p, sizeof(uint32_t) * nd, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
              hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-    }
     if (!ok) return done(fail(M3D_ERR_DEVICE, "m3d_match_mutual_nn: HIP error"));
     size_t k = 0;  // cross-check, correspondence_matching.cpp:64-78
     for (uint32_t i = 0; i < ns; ++i) {

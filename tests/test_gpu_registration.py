@@ -2,6 +2,8 @@
 3-point Kabsch + checkers + validation counts bit-exact hypothesis by hypothesis (same "K3x3"
 specification on both sides), the RANSAC driver (best index, iteration/validation counts, est_k,
 pose), n-point Kabsch within 1e-9, mutual-NN matcher bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -97,6 +99,73 @@ def test_mutual_nn_matches_oracle(capi, orc, dim, ns, nd):
     oa, ob = orc.match_mutual_nn(fs, fd)
     assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob)
     assert len(a) > k // 2
+
+
+def _brute(capi, fs, fd):
+    """the fp64 brute-force kernel (M3D_MATCH_BRUTE=1): the unscreened GPU path"""
+    os.environ["M3D_MATCH_BRUTE"] = "1"
+    try:
+        return capi.match_mutual_nn(fs, fd)
+    finally:
+        del os.environ["M3D_MATCH_BRUTE"]
+
+
+@pytest.mark.parametrize("case", ["dups", "lattice", "huge", "tiny", "nan", "offset", "scales"])
+def test_mutual_nn_screen_adversarial(capi, orc, case):
+    """dim-33 inputs built to defeat the fp32 screen: long runs of exact ties (ring eviction -> exact
+    fallback), near-equal distances below fp32 resolution, values outside the fp32 range, NaNs,
+    large common offsets (catastrophic cancellation in |a|^2+|b|^2-2ab).  The result must stay the
+    exact fp64 answer: equal to the oracle and to the unscreened brute-force kernel."""
+    rng = np.random.default_rng(len(case))
+    ns, nd, dim = 700, 900, 33
+    fs = rng.uniform(0, 1, (ns, dim))
+    fd = rng.uniform(0, 1, (nd, dim))
+    fd[:300] = fs[:300] + rng.normal(0, 1e-3, (300, dim))
+    expect_fallback = False
+    if case == "dups":            # 200 identical rows on both sides: every one of them ties
+        fd[100:300] = fd[100]
+        fs[400:600] = fs[400]
+        fs[10] = fd[100]
+        expect_fallback = True
+    elif case == "lattice":       # distances differ only far below the fp32 error bound
+        base = rng.uniform(0, 1, dim)
+        fd[:] = base + 1e-9 * rng.integers(-3, 4, (nd, dim))
+        fs[:] = base + 1e-9 * rng.integers(-3, 4, (ns, dim))
+        expect_fallback = True
+    elif case == "huge":          # squares overflow fp32
+        fs *= 1e25
+        fd *= 1e25
+        expect_fallback = True
+    elif case == "tiny":          # squares underflow fp32
+        fs *= 1e-25
+        fd *= 1e-25
+        expect_fallback = True
+    elif case == "nan":
+        fs[5, 7] = np.nan
+        fd[9, 0] = np.nan
+        fd[11] = np.nan
+    elif case == "offset":        # |a|^2 ~ 3e9 while neighbour distances are ~1: fp32 cancels completely
+        fs += 1e4
+        fd += 1e4
+    elif case == "scales":        # one huge-norm database row inflates the bound of every query
+        fd[500] *= 1e6
+    a, b = capi.match_mutual_nn(fs, fd)
+    falls = capi.match_last_fallbacks()
+    oa, ob = orc.match_mutual_nn(fs, fd)
+    assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob)
+    ba, bb = _brute(capi, fs, fd)
+    assert np.array_equal(a, ba) and np.array_equal(b, bb)
+    if expect_fallback:
+        assert falls > 0
+
+
+def test_mutual_nn_screen_is_used(capi):
+    """on ordinary descriptors the screen decides (almost) every query without the fallback"""
+    d = synth.registration_pair_c4(20_000, seed=9)
+    a, b = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    assert capi.match_last_fallbacks() < 20
+    ba, bb = _brute(capi, d["feat_src"], d["feat_dst"])
+    assert np.array_equal(a, ba) and np.array_equal(b, bb)
 
 
 def test_c4_pipeline_properties(capi):
