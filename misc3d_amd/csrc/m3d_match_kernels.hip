@@ -75,44 +75,67 @@ __device__ __forceinline__ float d32_of(const Row32& q, const Row32& d) {
 // kept in a ring of kRing (index, d32) entries.  An entry pushed out of the ring is remembered only
 // through the smallest evicted d32: if that is above the final window the evicted entries were all
 // stale, otherwise the query takes the exact fallback.
+struct ScanState {
+    float best = INFINITY, win = INFINITY, ev = INFINITY;
+    uint32_t cnt = 0;
+};
+
+__device__ __forceinline__ void scan_step(ScanState& st, float dv, float two_e, bool live, uint32_t j,
+                                          uint2* __restrict__ my) {
+    if (dv <= st.win && live) {   // also taken while win == +inf
+        const uint32_t slot = st.cnt % kRing;
+        if (st.cnt >= (uint32_t)kRing) st.ev = fminf(st.ev, __uint_as_float(my[slot].y));
+        my[slot] = make_uint2(j, __float_as_uint(dv));
+        st.cnt++;
+        if (dv < st.best) {
+            st.best = dv;
+            st.win = dv + two_e;
+        }
+    }
+}
+
+// Two queries per lane (rows in VGPRs): every database row fetched by the scalar unit feeds
+// 2 x 64 distance evaluations.  Block b covers queries [512 b, 512 b + 512): lane t holds 512 b + t and
+// 512 b + 256 + t.
 __global__ __launch_bounds__(256) void nn32_scan_k(const float* __restrict__ q, uint32_t nq,
                                                     const float* __restrict__ db, uint32_t ndb,
                                                     uint32_t db_per_split, float e_coeff, float max_dn2,
                                                     uint2* __restrict__ ring, uint32_t* __restrict__ ring_count,
                                                     float* __restrict__ part_min, float* __restrict__ evict_min) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t ii = i < nq ? i : nq - 1;
-    const Row32 qr = load_row(q + (size_t)ii * kScreenDimP);
+    const uint32_t ia = blockIdx.x * 512u + threadIdx.x, ib = ia + 256u;
+    const uint32_t iia = ia < nq ? ia : nq - 1, iib = ib < nq ? ib : nq - 1;
+    const Row32 qa = load_row(q + (size_t)iia * kScreenDimP);
+    const Row32 qb = load_row(q + (size_t)iib * kScreenDimP);
     const uint32_t j0 = blockIdx.y * db_per_split, j1 = min(ndb, j0 + db_per_split);
     // 2E (+ slack for the fp32 evaluation of the window itself); not finite -> the screen proves nothing
-    const float two_e = 2.0f * e_coeff * (qr.n2 + max_dn2) * 1.000001f + 1e-30f;
-    const bool screen_ok = two_e < INFINITY;
-    uint2* __restrict__ my = ring + ((size_t)blockIdx.y * nq + ii) * kRing;
-    float best = INFINITY, win = INFINITY, ev = INFINITY;
-    uint32_t cnt = 0;
+    const float two_ea = 2.0f * e_coeff * (qa.n2 + max_dn2) * 1.000001f + 1e-30f;
+    const float two_eb = 2.0f * e_coeff * (qb.n2 + max_dn2) * 1.000001f + 1e-30f;
+    const bool live_a = two_ea < INFINITY && ia < nq, live_b = two_eb < INFINITY && ib < nq;
+    uint2* __restrict__ ring_a = ring + ((size_t)blockIdx.y * nq + iia) * kRing;
+    uint2* __restrict__ ring_b = ring + ((size_t)blockIdx.y * nq + iib) * kRing;
+    ScanState sa, sb;
     if (j0 < j1) {
         Row32 cur = load_row(db + (size_t)j0 * kScreenDimP);
         for (uint32_t j = j0; j < j1; ++j) {
             const Row32 nxt = load_row(db + (size_t)(j + 1) * kScreenDimP);   // spare row behind the last one
-            const float dv = d32_of(qr, cur);
-            if (dv <= win && screen_ok && i < nq) {   // also taken while win == +inf
-                const uint32_t slot = cnt % kRing;
-                if (cnt >= (uint32_t)kRing) ev = fminf(ev, __uint_as_float(my[slot].y));
-                my[slot] = make_uint2(j, __float_as_uint(dv));
-                cnt++;
-                if (dv < best) {
-                    best = dv;
-                    win = dv + two_e;
-                }
-            }
+            const float da = d32_of(qa, cur);
+            const float dbv = d32_of(qb, cur);
+            scan_step(sa, da, two_ea, live_a, j, ring_a);
+            scan_step(sb, dbv, two_eb, live_b, j, ring_b);
             cur = nxt;
         }
     }
-    if (i < nq) {
-        const size_t o = (size_t)blockIdx.y * nq + i;
-        ring_count[o] = cnt;
-        part_min[o] = screen_ok ? best : -INFINITY;   // -inf forces the fallback in the verify kernel
-        evict_min[o] = ev;
+    if (ia < nq) {
+        const size_t o = (size_t)blockIdx.y * nq + ia;
+        ring_count[o] = sa.cnt;
+        part_min[o] = two_ea < INFINITY ? sa.best : -INFINITY;   // -inf forces the fallback in the verify kernel
+        evict_min[o] = sa.ev;
+    }
+    if (ib < nq) {
+        const size_t o = (size_t)blockIdx.y * nq + ib;
+        ring_count[o] = sb.cnt;
+        part_min[o] = two_eb < INFINITY ? sb.best : -INFINITY;
+        evict_min[o] = sb.ev;
     }
 }
 
@@ -230,7 +253,7 @@ hipError_t launch_nn_screened33(const double* q, const float* q32, const float* 
     (void)hipMemsetAsync(overflow_count, 0, sizeof(uint32_t), s);
     const uint32_t per = (ndb + splits - 1) / splits;
     const float e_coeff = (2.0f * DIM + 16.0f) * 5.9604645e-08f * 1.5f;
-    nn32_scan_k<<<dim3((nq + 255) / 256, splits), 256, 0, s>>>(q32, nq, d32, ndb, per, e_coeff, max_dn2, ring,
+    nn32_scan_k<<<dim3((nq + 511) / 512, splits), 256, 0, s>>>(q32, nq, d32, ndb, per, e_coeff, max_dn2, ring,
                                                               ring_count, part_min, evict_min);
     nn64_verify_k<<<(nq + 255) / 256, 256, 0, s>>>(q, nq, db, DIM, ring, ring_count, part_min, evict_min, splits,
                                                    e_coeff, max_dn2, qn, nn, overflow_list, overflow_count);

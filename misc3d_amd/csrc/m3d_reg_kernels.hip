@@ -12,6 +12,8 @@
 //   nn_k              ANNMatcher NearestSearch: exact nearest neighbour in descriptor space
 #include "m3d_reg_kernels.hpp"
 
+#include <algorithm>
+
 #include "m3d_reg_fp.hpp"
 
 #pragma clang fp contract(off)
@@ -218,6 +220,55 @@ void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_o
     if (dst.n) grid_scatter_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, cell_of_point, cell_start, fill, qx, qy, qz);
 }
 
+// Neighbour lists: for every interior cell the points of its 3x3x3 block, packed (x, y, z, 0) and
+// contiguous, in the fixed order (dz, dy) rows ascending, cell_start order inside a row.
+__global__ void nl_count_k(GridDesc g, const uint32_t* __restrict__ cell_start, uint32_t ncell,
+                           uint32_t* __restrict__ nl_start) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= ncell) return;
+    const uint32_t ix = c % g.nx, iy = (c / g.nx) % g.ny, iz = c / (g.nx * g.ny);
+    uint32_t cnt = 0;
+    if (ix >= 1 && ix + 1 < g.nx && iy >= 1 && iy + 1 < g.ny && iz >= 1 && iz + 1 < g.nz)
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy) {
+                const uint32_t row = ((iz + dz) * g.ny + (iy + dy)) * g.nx + ix;
+                cnt += cell_start[row + 2] - cell_start[row - 1];
+            }
+    nl_start[c] = cnt;
+}
+__global__ void nl_fill_k(GridDesc g, const uint32_t* __restrict__ cell_start, uint32_t ncell,
+                          const uint32_t* __restrict__ nl_start, const double* __restrict__ qx,
+                          const double* __restrict__ qy, const double* __restrict__ qz,
+                          double4* __restrict__ nl_pts) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= ncell) return;
+    uint32_t pos = nl_start[c];
+    if (nl_start[c + 1] == pos) return;
+    const uint32_t ix = c % g.nx, iy = (c / g.nx) % g.ny, iz = c / (g.nx * g.ny);
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const uint32_t row = ((iz + dz) * g.ny + (iy + dy)) * g.nx + ix;
+            const uint32_t b = cell_start[row - 1], e = cell_start[row + 2];
+            for (uint32_t k = b; k < e; ++k) nl_pts[pos++] = make_double4(qx[k], qy[k], qz[k], 0.0);
+        }
+}
+// step 1: counts + exclusive scan into nl_start[0..ncell]; the caller reads nl_start[ncell] (= entries),
+// allocates nl_pts and calls step 2.
+void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl_start, uint32_t* tile_sums,
+                     uint32_t* total, hipStream_t s) {
+    const uint32_t ncell = g.nx * g.ny * g.nz;
+    nl_count_k<<<(ncell + 255) / 256, 256, 0, s>>>(g, cell_start, ncell, nl_start);
+    const uint32_t nt = (ncell + 2047) / 2048;
+    tile_scan_k<<<nt, 256, 0, s>>>(nl_start, ncell, tile_sums);
+    launch_scan_blocks(tile_sums, nt, total, s);
+    add_tile_offsets_k<<<(ncell + 1 + 255) / 256, 256, 0, s>>>(nl_start, ncell, tile_sums, total);
+}
+void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, const double* qx,
+                    const double* qy, const double* qz, double4* nl_pts, hipStream_t s) {
+    const uint32_t ncell = g.nx * g.ny * g.nz;
+    nl_fill_k<<<(ncell + 255) / 256, 256, 0, s>>>(g, cell_start, ncell, nl_start, qx, qy, qz, nl_pts);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K9  validation: nearest target point of every transformed source point, per surviving hypothesis
 // ------------------------------------------------------------------------------------------------
@@ -233,16 +284,36 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
     int ix, iy, iz;
     double best = INFINITY;
     if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return best;
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy) {
-            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
-            const uint32_t b = cell_start[row - 1], e = cell_start[row + 2];
-            for (uint32_t c = b; c < e; ++c) {
-                const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
+    if (g.nl_start) {
+        // the 3x3x3 block of this cell as ONE contiguous list (nl_fill_k): two dependent loads instead of
+        // nine row ranges + nine gathers; 4 candidates per trip, the tail repeats the last one (min is idempotent)
+        const uint32_t cell = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
+        const uint32_t b = g.nl_start[cell], e = g.nl_start[cell + 1];
+        for (uint32_t c = b; c < e; c += 4) {
+            double d2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = min(c + (uint32_t)k, e - 1);
+                const double4 q = g.nl_pts[i];
+                const double ddx = px - q.x, ddy = py - q.y, ddz = pz - q.z;
+                d2[k] = (ddx * ddx + ddy * ddy) + ddz * ddz;
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (d2[k] < best) best = d2[k];
         }
+    } else {
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy) {
+                const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
+                const uint32_t b = cell_start[row - 1], e = cell_start[row + 2];
+                for (uint32_t c = b; c < e; ++c) {
+                    const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
+                    const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    if (d2 < best) best = d2;
+                }
+            }
+    }
     if (best < g.h2_in || g.K == 1) return best;
     const int K = g.K;
     for (int dz = -K; dz <= K; ++dz)
@@ -270,11 +341,14 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
                                                        const double* __restrict__ qx, const double* __restrict__ qy,
                                                        const double* __restrict__ qz,
                                                        uint32_t* __restrict__ partial_cnt,
-                                                       double* __restrict__ partial_sum) {
+                                                       double* __restrict__ partial_sum, uint32_t tile_stride,
+                                                       uint32_t phase_b, const uint8_t* __restrict__ keep) {
     __shared__ uint32_t red[4][64];
     __shared__ double reds[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t base = (size_t)blockIdx.x * kRegTile + (size_t)wave * (64 * kRegP) + lane;
+    // phase A: tiles 0, stride, 2 stride, ...; phase B: all the others, only for hypotheses still in the race
+    const uint32_t tile = phase_b ? blockIdx.x + blockIdx.x / (tile_stride - 1) + 1 : blockIdx.x * tile_stride;
+    const size_t base = (size_t)tile * kRegTile + (size_t)wave * (64 * kRegP) + lane;
     double x[kRegP], y[kRegP], z[kRegP];
 #pragma unroll
     for (int j = 0; j < kRegP; ++j) {
@@ -294,7 +368,8 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
             for (int k = 0; k < 12; ++k) t[k] = T[k];
             uint32_t cnt = 0;
             double sum = 0.0;
-            if (t[0] == t[0]) {  // padding records are NaN (wave-uniform branch)
+            const bool run = keep ? keep[sb + ss] != 0 : true;
+            if (t[0] == t[0] && run) {  // padding records are NaN (wave-uniform branch)
 #pragma unroll
                 for (int j = 0; j < kRegP; ++j) {
                     const double px = ((t[0] * x[j] + t[1] * y[j]) + t[2] * z[j]) + t[3];
@@ -314,9 +389,9 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
         reds[wave][lane] = acc_sum;
         __syncthreads();
         if (wave == 0) {
-            partial_cnt[(size_t)blockIdx.x * s_pad + sb + lane] =
+            partial_cnt[(size_t)tile * s_pad + sb + lane] =
                 (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-            partial_sum[(size_t)blockIdx.x * s_pad + sb + lane] =
+            partial_sum[(size_t)tile * s_pad + sb + lane] =
                 (reds[0][lane] + reds[1][lane]) + (reds[2][lane] + reds[3][lane]);
         }
         __syncthreads();
@@ -333,18 +408,47 @@ __global__ void reduce_sums_k(const double* __restrict__ partial_sum, uint32_t n
     sums[s] = acc;
 }
 
-void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t splits,
-                         const GridDesc& g, const uint32_t* cell_start, const double* qx, const double* qy,
-                         const double* qz, uint32_t* partial_cnt, double* partial_sum, double* sums,
-                         hipStream_t s) {
+// keep[s] = can hypothesis s still reach `best_cnt` inliers?  count <= (inliers on the phase-A tiles)
+// + (all points of the phase-B tiles).  Hypotheses that cannot are dropped from phase B; their reported
+// count is the phase-A count, which is below best_cnt, so the replay never selects them.
+__global__ void reg_keep_k(const uint32_t* __restrict__ partial_cnt, uint32_t n_tiles, uint32_t tile_stride,
+                           uint32_t s_pad, uint32_t points_b, uint32_t best_cnt, uint8_t* __restrict__ keep) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= s_pad) return;
+    uint32_t a = 0;
+    for (uint32_t t = 0; t < n_tiles; t += tile_stride) a += partial_cnt[(size_t)t * s_pad + s];
+    keep[s] = (uint64_t)a + points_b >= best_cnt ? 1 : 0;
+}
+
+// best_cnt: inlier count of the best hypothesis of EARLIER chunks (0: nothing to prune against).
+// n_points: real source points.  keep: s_pad bytes of scratch.
+void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
+                         const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
+                         uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
+                         uint32_t n_points, uint8_t* keep, hipStream_t s) {
     if (!s_pad || !src.n_pad) return;
     const uint32_t groups = s_pad / 64;
-    const uint32_t gps = (groups + splits - 1) / splits;
-    const uint32_t nsplit = (groups + gps - 1) / gps;
     const uint32_t n_tiles = src.n_pad / kRegTile;
-    const dim3 grid(n_tiles, nsplit), block(256);
-    reg_validate_k<<<grid, block, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy, qz,
-                                          partial_cnt, partial_sum);
+    auto launch = [&](uint32_t tiles, uint32_t stride, uint32_t phase_b, const uint8_t* kp) {
+        const uint32_t want = std::max<uint32_t>(1, (2048 + tiles - 1) / tiles);
+        const uint32_t splits = std::min(want, groups);
+        const uint32_t gps = (groups + splits - 1) / splits;
+        const uint32_t nsplit = (groups + gps - 1) / gps;
+        reg_validate_k<<<dim3(tiles, nsplit), 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx,
+                                                          qy, qz, partial_cnt, partial_sum, stride, phase_b, kp);
+    };
+    const uint32_t stride = kRegPruneStride;
+    if (best_cnt == 0 || n_tiles < 2 * stride) {
+        launch(n_tiles, 1, 0, nullptr);
+    } else {
+        const uint32_t tiles_a = (n_tiles + stride - 1) / stride;
+        // real points on the phase-B tiles: at most every slot of those tiles, and at most all points
+        const uint64_t slots_b = (uint64_t)(n_tiles - tiles_a) * kRegTile;
+        const uint32_t points_b = (uint32_t)std::min<uint64_t>(slots_b, n_points);
+        launch(tiles_a, stride, 0, nullptr);
+        reg_keep_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_cnt, n_tiles, stride, s_pad, points_b, best_cnt, keep);
+        launch(n_tiles - tiles_a, stride, 1, keep);
+    }
     reduce_sums_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_sum, n_tiles, s_pad, sums);
 }
 

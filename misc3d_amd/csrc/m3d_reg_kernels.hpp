@@ -7,6 +7,7 @@ namespace m3d {
 constexpr int kRegTStride = 12;  // doubles per transformation record (rows 0..2 of the 4x4)
 constexpr int kRegP = 4;         // source points per lane in reg_validate_k
 constexpr int kRegTile = 256 * kRegP;
+constexpr int kRegPruneStride = 8;   // validation phase A runs on every 8th source tile
 
 // Uniform grid over the target cloud.  Cell edge h = 1.001 * threshold / K (K = 4 unless the dense
 // cell table would not fit), origin K+1 cells below the bounding-box minimum and K+1 empty cells above
@@ -18,6 +19,9 @@ struct GridDesc {
     uint32_t nx, ny, nz;
     int K;
     uint32_t morton_bits;  // != 0: cell ids are Z-order codes of (ix,iy,iz), nx = ny = nz = 2^bits
+    // optional neighbour lists (validation grid only): points of the 3x3x3 block of every cell, contiguous
+    const uint32_t* nl_start = nullptr;  // ncell + 1
+    const double4* nl_pts = nullptr;
 };
 
 
@@ -31,10 +35,14 @@ void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_o
                        uint32_t* cell_start, uint32_t* fill, uint32_t* tile_sums, uint32_t* total,
                        double* qx, double* qy, double* qz, hipStream_t s);
 void launch_fill_nan(double* p, uint32_t n, hipStream_t s);
-void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t splits,
-                         const GridDesc& g, const uint32_t* cell_start, const double* qx, const double* qy,
-                         const double* qz, uint32_t* partial_cnt, double* partial_sum, double* sums,
-                         hipStream_t s);
+void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl_start, uint32_t* tile_sums,
+                     uint32_t* total, hipStream_t s);
+void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, const double* qx,
+                    const double* qy, const double* qz, double4* nl_pts, hipStream_t s);
+void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
+                         const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
+                         uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
+                         uint32_t n_points, uint8_t* keep, hipStream_t s);
 void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
                        const double* qx, const double* qy, const double* qz, double* best, hipStream_t s);
 void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* block_counts, uint32_t* total,

@@ -62,12 +62,12 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz;
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts;
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
-                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz})
+                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts})
             b->release();
     }
 };
@@ -281,6 +281,26 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
             launch_grid_build(R.dst, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
                               S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
                               S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream);
+            // neighbour lists for phase 1 of the search (27 entries of 32 B per target point: bounded to
+            // 2 M target points; beyond that, or with M3D_REG_NL=0, the row-range search is used)
+            {
+                const char* nl_env = std::getenv("M3D_REG_NL");
+                if (!(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
+                    RESERVE(S.nl_start, sizeof(uint32_t) * ((size_t)ncell + 1));
+                    launch_nl_count(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(),
+                                    S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 1, ctx->stream);
+                    uint32_t entries = 0;
+                    HIPCHK(hipMemcpyAsync(&entries, S.nl_start.as<uint32_t>() + ncell, sizeof(uint32_t),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                    RESERVE(S.nl_pts, sizeof(double4) * std::max<size_t>(entries, 1));
+                    launch_nl_fill(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.qx.as<double>(),
+                                   S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream);
+                    g.nl_start = S.nl_start.as<uint32_t>();
+                    g.nl_pts = S.nl_pts.as<double4>();
+                    R.g = g;
+                }
+            }
 
             // ---- spatially sorted copy of the SOURCE cloud for the validation kernel: counts and
             // order-free sums do not depend on the point order, and lanes of a wave that hold
@@ -354,6 +374,9 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
             std::mt19937 rng((std::mt19937::result_type)((seed ? *seed : (uint64_t)rd()) & 0xffffffffull));
             std::uniform_int_distribution<int> pick(0, (int)m - 1);  // utility::UniformRandIntGenerator(0, M-1)
             double best_fit = 0, best_rmse = 0;
+            uint32_t best_cnt = 0;   // inlier count behind best_fit
+            const char* prune_env = std::getenv("M3D_REG_PRUNE");
+            const bool reg_prune = !(prune_env && prune_env[0] == '0');
             bool best_rmse_known = true;
             int64_t best_index = -1;
             int est_k_global = max_iter, est_k_local = max_iter;
@@ -409,11 +432,12 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                                           ctx->stream));
                     launch_gather_T(S.T12.as<double>(), S.list.as<uint32_t>(), ns, s_pad + 1, S.Ts.as<double>(),
                                     ctx->stream);
-                    const uint32_t want = std::max<uint32_t>(1, (2048 + n_tiles - 1) / n_tiles);
-                    launch_reg_validate(src_sorted, S.Ts.as<double>(), s_pad, std::min(want, s_pad / 64), g,
-                                        S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
-                                        S.qz.as<double>(), S.partial.as<uint32_t>(), S.partial_sum.as<double>(),
-                                        S.sum2.as<double>(), ctx->stream);
+                    RESERVE(S.keep, s_pad);
+                    // bound-and-prune against the best of EARLIER chunks (M3D_REG_PRUNE=0 switches it off)
+                    launch_reg_validate(src_sorted, S.Ts.as<double>(), s_pad, g, S.cell_start.as<uint32_t>(),
+                                        S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
+                                        S.partial.as<uint32_t>(), S.partial_sum.as<double>(), S.sum2.as<double>(),
+                                        reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream);
                     HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
                     launch_reduce_partials(S.partial.as<uint32_t>(), n_tiles, s_pad, S.counts.as<uint32_t>(),
                                            ctx->stream);
@@ -474,6 +498,7 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                     }
                     if (better) {
                         best_fit = fit;
+                        best_cnt = cnt;
                         best_rmse = rmse;
                         best_rmse_known = rmse_known;
                         best_sum2 = a_t;
@@ -558,7 +583,7 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     const bool screened = dim == 33 && !(brute_env && brute_env[0] == '1');
     // enough (query block x database split) workgroups to fill the chip
     auto splits_for = [](uint32_t nq, uint32_t ndb) {
-        const uint32_t blocks = (nq + 255) / 256;
+        const uint32_t blocks = (nq + 511) / 512;   // nn32_scan_k: 512 queries per block (nn_k: 256, more blocks)
         uint32_t s = std::max<uint32_t>(1, (2048 + blocks - 1) / blocks);
         return std::min<uint32_t>(s, std::max<uint32_t>(1, ndb / 256));
     };

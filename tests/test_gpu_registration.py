@@ -37,6 +37,38 @@ def test_registration_ransac_matches_oracle(capi, orc, conf, max_iter, seed):
     assert np.allclose(T, d["T"], atol=0.02)
 
 
+@pytest.mark.parametrize("frac,sigma,edge", [(0.4, 0.001, 0.9), (0.25, 0.004, 0.6)])
+def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
+    """Clouds large enough (>= 16 source tiles) for the two-phase validation: hypotheses that cannot
+    reach the best inlier count of earlier chunks are dropped after every 8th tile.  The result must
+    equal the oracle's and the unpruned run's (M3D_REG_PRUNE=0), partial overlap included."""
+    n = 24_000
+    d = synth.registration_pair_c4(n, seed=21, dim=8, true_fraction=frac, sigma=sigma)
+    dst = d["dst"]
+    src = d["src"].copy()
+    src[src[:, 0] > np.quantile(src[:, 0], 0.65)] += 50.0     # a third of the source has no counterpart
+    inv = np.empty(n, dtype=np.int64)
+    inv[d["perm"]] = np.arange(n)
+    rng = np.random.default_rng(3)
+    cs = rng.integers(0, n, 1500)
+    cd = np.where(rng.random(1500) < frac, inv[cs], rng.integers(0, n, 1500))
+    kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=edge, confidence=1.0, seed=4)
+    T, st = capi.registration_ransac(src, dst, cs, cd, **kw)
+    for env in ("M3D_REG_PRUNE", "M3D_REG_NL"):      # without pruning; without the neighbour lists
+        os.environ[env] = "0"
+        try:
+            T0, st0 = capi.registration_ransac(src, dst, cs, cd, **kw)
+        finally:
+            del os.environ[env]
+        assert np.array_equal(T, T0), env
+        for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse", "ties"):
+            assert st[k] == st0[k], (env, k)
+    assert 0.2 < st["fitness"] < 0.9
+    o = orc.registration_ransac(src, dst, cs, cd, thr=0.03, max_iter=3000, edge_thr=edge, confidence=1.0, seed=4)
+    assert st["best_index"] == o.best_index and st["validations"] == o.validations and st["fitness"] == o.fitness
+    assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64))
+
+
 def test_registration_grid_edge_cases(capi, orc):
     # target far from the origin, threshold comparable to the extent, points exactly on cell borders
     rng = np.random.default_rng(7)
