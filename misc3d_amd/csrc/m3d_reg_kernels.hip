@@ -13,6 +13,7 @@
 #include "m3d_reg_kernels.hpp"
 
 #include <algorithm>
+#include <climits>
 
 #include "m3d_reg_fp.hpp"
 
@@ -272,6 +273,68 @@ void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_
 // ------------------------------------------------------------------------------------------------
 // K9  validation: nearest target point of every transformed source point, per surviving hypothesis
 // ------------------------------------------------------------------------------------------------
+// Phase 2 of the search: the (2K+1)^3 block, which covers the radius -- but only the cells that can hold
+// a point closer than lim = min(best so far, r^2): a point at squared distance >= best cannot lower the
+// minimum, and one at >= r^2 is no correspondence whatever its exact distance (the callers only use
+// values < r^2).  Per axis the gap between the query and a cell offset d is a lower bound of the
+// coordinate difference to every point of that cell (minus a slack for the rounding of the cell
+// assignment, see axis_gap).
+__device__ __forceinline__ double axis_gap(int d, double f, double h) {
+    // query at fraction f in [0,1) of its cell; cells at offset d span [d, d+1) in the same units.
+    // Slack 1e-6 cell edges: cell_of evaluates (x - o) * inv_h with two roundings, relative error < 3 * 2^-53
+    // of a value below 2^27, i.e. below 5e-8 edges, for the query and for the stored point alike.
+    const double g = d > 0 ? (double)d - f : (d < 0 ? f - (double)(d + 1) : 0.0);
+    const double gs = g - 1e-6;
+    return gs > 0.0 ? gs * h : 0.0;
+}
+__device__ __forceinline__ double nearest_phase2(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                                 const double* __restrict__ qx, const double* __restrict__ qy,
+                                                 const double* __restrict__ qz, int ix, int iy, int iz, double px,
+                                                 double py, double pz, double best) {
+    const int K = g.K;
+    const double h = 1.0 / g.inv_h;
+    const double fx = (px - g.ox) * g.inv_h - (double)ix, fy = (py - g.oy) * g.inv_h - (double)iy,
+                 fz = (pz - g.oz) * g.inv_h - (double)iz;
+    for (int dz = -K; dz <= K; ++dz) {
+        const double gz = axis_gap(dz, fz, h);
+        const double gz2 = gz * gz;
+        if (!(gz2 < (best < g.r2 ? best : g.r2))) continue;
+        for (int dy = -K; dy <= K; ++dy) {
+            const double gy = axis_gap(dy, fy, h);
+            const double lim = best < g.r2 ? best : g.r2;
+            const double rem = lim - (gz2 + gy * gy);
+            if (!(rem > 0.0)) continue;
+            // x cells that can still matter: the gap grows with |dx|, so they form one interval
+            int lo = 0, hi = 0;
+            while (lo > -K && axis_gap(lo - 1, fx, h) * axis_gap(lo - 1, fx, h) < rem) --lo;
+            while (hi < K && axis_gap(hi + 1, fx, h) * axis_gap(hi + 1, fx, h) < rem) ++hi;
+            const bool inner = dz >= -1 && dz <= 1 && dy >= -1 && dy <= 1;   // x in [-1, 1] was phase 1
+            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
+            for (int part = 0; part < 2; ++part) {
+                int a, bnd;
+                if (inner) {
+                    a = part == 0 ? lo : 2;
+                    bnd = part == 0 ? -2 : hi;
+                } else {
+                    if (part == 1) break;
+                    a = lo;
+                    bnd = hi;
+                }
+                if (a > bnd) continue;
+                const uint32_t b = cell_start[row + a], e = cell_start[row + bnd + 1];
+                for (uint32_t c = b; c < e; ++c) {
+                    const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
+                    const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    if (d2 < best) best = d2;
+                }
+            }
+        }
+    }
+    return best;
+}
+
+constexpr int kNlBatch = 4;   // neighbour-list candidates per trip
+
 // Exact nearest squared distance within the search radius (KDTreeFlann::SearchHybrid(p, r, 1)).
 // The grid cell is r/K.  Phase 1 scans the 3x3x3 block around the query's cell (9 contiguous x-rows):
 // every point outside that block is at least one cell edge away, so a hit closer than 0.999 h is the
@@ -289,18 +352,24 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
         // nine row ranges + nine gathers; 4 candidates per trip, the tail repeats the last one (min is idempotent)
         const uint32_t cell = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
         const uint32_t b = g.nl_start[cell], e = g.nl_start[cell + 1];
-        for (uint32_t c = b; c < e; c += 4) {
-            double d2[4];
+        if (b < e) {
+            // software pipeline: the loads of trip t+1 are in flight while trip t is evaluated
+            double4 cur[kNlBatch];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t i = min(c + (uint32_t)k, e - 1);
-                const double4 q = g.nl_pts[i];
-                const double ddx = px - q.x, ddy = py - q.y, ddz = pz - q.z;
-                d2[k] = (ddx * ddx + ddy * ddy) + ddz * ddz;
+            for (int k = 0; k < kNlBatch; ++k) cur[k] = g.nl_pts[min(b + (uint32_t)k, e - 1)];
+            for (uint32_t c = b; c < e; c += kNlBatch) {
+                double4 nxt[kNlBatch];
+#pragma unroll
+                for (int k = 0; k < kNlBatch; ++k) nxt[k] = g.nl_pts[min(c + (uint32_t)(kNlBatch + k), e - 1)];
+#pragma unroll
+                for (int k = 0; k < kNlBatch; ++k) {
+                    const double ddx = px - cur[k].x, ddy = py - cur[k].y, ddz = pz - cur[k].z;
+                    const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    if (d2 < best) best = d2;
+                }
+#pragma unroll
+                for (int k = 0; k < kNlBatch; ++k) cur[k] = nxt[k];
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (d2[k] < best) best = d2[k];
         }
     } else {
         for (int dz = -1; dz <= 1; ++dz)
@@ -315,18 +384,7 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
             }
     }
     if (best < g.h2_in || g.K == 1) return best;
-    const int K = g.K;
-    for (int dz = -K; dz <= K; ++dz)
-        for (int dy = -K; dy <= K; ++dy) {
-            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
-            const uint32_t b = cell_start[row - K], e = cell_start[row + K + 1];
-            for (uint32_t c = b; c < e; ++c) {
-                const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-            }
-        }
-    return best;
+    return nearest_phase2(g, cell_start, qx, qy, qz, ix, iy, iz, px, py, pz, best);
 }
 
 // Same decomposition as score_k: source points stay in VGPRs (kRegP rows of 64 per wave), the
@@ -342,12 +400,21 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
                                                        const double* __restrict__ qz,
                                                        uint32_t* __restrict__ partial_cnt,
                                                        double* __restrict__ partial_sum, uint32_t tile_stride,
-                                                       uint32_t phase_b, const uint8_t* __restrict__ keep) {
+                                                       uint32_t phase_b, const uint8_t* __restrict__ keep,
+                                                       uint32_t n_tiles_launch, uint32_t n_split) {
     __shared__ uint32_t red[4][64];
     __shared__ double reds[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // XCD-aware block -> (tile, split) map.  Workgroup w runs on XCD w % 8 and every XCD has its own
+    // 4 MB L2, so all splits of one tile (same source points, different hypotheses -> same target
+    // neighbourhood, because surviving hypotheses are near-identical poses) go to ONE XCD, and an XCD
+    // works through its tiles one after the other: the few tiles in flight per XCD keep their
+    // neighbour lists L2-resident instead of streaming them from the fabric for every hypothesis.
+    const uint32_t xcd = blockIdx.x % 8u, jq = blockIdx.x / 8u;
+    const uint32_t tile_local = (jq / n_split) * 8u + xcd, split = jq % n_split;
+    if (tile_local >= n_tiles_launch) return;   // whole block (uniform)
     // phase A: tiles 0, stride, 2 stride, ...; phase B: all the others, only for hypotheses still in the race
-    const uint32_t tile = phase_b ? blockIdx.x + blockIdx.x / (tile_stride - 1) + 1 : blockIdx.x * tile_stride;
+    const uint32_t tile = phase_b ? tile_local + tile_local / (tile_stride - 1) + 1 : tile_local * tile_stride;
     const size_t base = (size_t)tile * kRegTile + (size_t)wave * (64 * kRegP) + lane;
     double x[kRegP], y[kRegP], z[kRegP];
 #pragma unroll
@@ -356,7 +423,7 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
         y[j] = sy[base + 64 * j];
         z[j] = sz[base + 64 * j];
     }
-    const uint32_t s0 = blockIdx.y * s_per_split;
+    const uint32_t s0 = split * s_per_split;
     const uint32_t s1 = min(s0 + s_per_split, s_pad);
     for (uint32_t sb = s0; sb < s1; sb += 64) {
         uint32_t acc = 0;
@@ -430,12 +497,15 @@ void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad,
     const uint32_t groups = s_pad / 64;
     const uint32_t n_tiles = src.n_pad / kRegTile;
     auto launch = [&](uint32_t tiles, uint32_t stride, uint32_t phase_b, const uint8_t* kp) {
-        const uint32_t want = std::max<uint32_t>(1, (2048 + tiles - 1) / tiles);
+        // enough blocks to fill the chip, and at least ~40 splits per tile so that the ~160 blocks an XCD
+        // holds at a time belong to a handful of tiles (see the block map in the kernel)
+        const uint32_t want = std::max<uint32_t>(kRegMinSplits, (2048 + tiles - 1) / tiles);
         const uint32_t splits = std::min(want, groups);
         const uint32_t gps = (groups + splits - 1) / splits;
         const uint32_t nsplit = (groups + gps - 1) / gps;
-        reg_validate_k<<<dim3(tiles, nsplit), 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx,
-                                                          qy, qz, partial_cnt, partial_sum, stride, phase_b, kp);
+        const uint32_t slots = (tiles + 7) / 8;
+        reg_validate_k<<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy,
+                                                         qz, partial_cnt, partial_sum, stride, phase_b, kp, tiles, nsplit);
     };
     const uint32_t stride = kRegPruneStride;
     if (best_cnt == 0 || n_tiles < 2 * stride) {

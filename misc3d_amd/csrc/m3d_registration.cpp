@@ -305,7 +305,7 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
             // ---- spatially sorted copy of the SOURCE cloud for the validation kernel: counts and
             // order-free sums do not depend on the point order, and lanes of a wave that hold
             // neighbouring source points probe the same target cells (L1/L2 hits instead of scattered
-            // gathers).  Same counting sort, 64^3 cells over the source bounding box.  Points with
+            // gathers).  Same counting sort over the source bounding box.  Points with
             // non-finite coordinates drop out (they can never have a neighbour).
             CloudView src_sorted = R.src;
             {
@@ -325,17 +325,21 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                 }
                 if (ext > 0.0 && std::isfinite(ext)) {
                     GridDesc gs;
-                    const double hs = ext / 63.0;
+                    // Hilbert order over 128^3 cells: the 64 points of a wave form a compact patch, so the
+                    // lanes probe the same few target cells (M3D_REG_SRC_ORDER=rows: x-rows of a 64^3 grid)
+                    const char* ord_env = std::getenv("M3D_REG_SRC_ORDER");
+                    const bool hilbert = !(ord_env && ord_env[0] == 'r');
+                    const double hs = hilbert ? ext / 127.0 : ext / 63.0;
                     gs.K = 0;
-                    gs.morton_bits = 0;
+                    gs.morton_bits = hilbert ? (7u | 0x100u) : 0u;
                     gs.ox = slo[0];
                     gs.oy = slo[1];
                     gs.oz = slo[2];
                     gs.inv_h = 1.0 / hs;
                     gs.r2 = gs.h2_in = 0.0;
-                    gs.nx = (uint32_t)((shi[0] - slo[0]) / hs) + 2;
-                    gs.ny = (uint32_t)((shi[1] - slo[1]) / hs) + 2;
-                    gs.nz = (uint32_t)((shi[2] - slo[2]) / hs) + 2;
+                    gs.nx = hilbert ? 128u : (uint32_t)((shi[0] - slo[0]) / hs) + 2;
+                    gs.ny = hilbert ? 128u : (uint32_t)((shi[1] - slo[1]) / hs) + 2;
+                    gs.nz = hilbert ? 128u : (uint32_t)((shi[2] - slo[2]) / hs) + 2;
                     const uint32_t ncs = gs.nx * gs.ny * gs.nz;
                     const uint32_t np = R.src.n_pad;
                     RESERVE(S.s_cell_of_point, sizeof(uint32_t) * n_src);

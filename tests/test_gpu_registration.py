@@ -54,7 +54,7 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
     cd = np.where(rng.random(1500) < frac, inv[cs], rng.integers(0, n, 1500))
     kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=edge, confidence=1.0, seed=4)
     T, st = capi.registration_ransac(src, dst, cs, cd, **kw)
-    for env in ("M3D_REG_PRUNE", "M3D_REG_NL"):      # without pruning; without the neighbour lists
+    for env in ("M3D_REG_PRUNE", "M3D_REG_NL"):      # each optimisation switched off in turn
         os.environ[env] = "0"
         try:
             T0, st0 = capi.registration_ransac(src, dst, cs, cd, **kw)
