@@ -8,20 +8,23 @@ A "step" is one complete FitModel: sample table -> minimal fits -> scoring of al
 sequential best-model replay -> RefineModel (inlier list + least-squares plane) -> results on the
 host.  The cloud is resident in HBM before the timed region (m3d_cloud_create).
 
-N > 1 (python -m torch.distributed.run ... bench.py --gpus N): weak scaling, H = 10 000 hypotheses
-per GPU of ONE global table of N x 10 000 (misc3d_amd/distributed.py): contiguous slices, one RCCL
-all-gather of the (valid, count) records, identical replay on every rank.  value = N*H / t.
-
 Extra objects on the JSON line:
-  roofline     dominant kernel = score_k<plane>.  `achieved` = ALGORITHMIC bytes (24 B per
-               (hypothesis, point) pair) / average launch duration, measured live with
-               HIP events on the library's stream (m3d_cloud_time_score).  The kernel re-uses every
-               point load for all hypotheses from registers, so this figure exceeds the HBM peak by
-               design; `valu` prices the same launch against the fp64 VALU issue peak, which is the
-               roofline that actually bounds it.  `traffic` = HBM bytes per
-               launch from the rocprofv3 PMC pass committed under profiles/ (null if absent).
-  cpu_baseline the oracle's reference-shaped OpenMP port (oracle/misc3d_oracle.c
-               orc_fit_omp_baseline) timed on this box's host cores on a bounded sample.
+  roofline     dominant kernel = score_mask_k<plane> (m3d_cull_kernels.hip).  `achieved` = ALGORITHMIC bytes
+               (24 B per (hypothesis, point) pair, SURVEY.md 8(d), x the hypotheses one launch covers) / the
+               average duration of THE LAUNCHES INSIDE THE TIMED STEPS, measured live with HIP events on the
+               library's stream (m3d_stats.ms_score_kernel / score_launches; a fit issues one launch per
+               hypothesis chunk) -- the same launches `rocprofv3 --kernel-trace --stats -- python bench.py`
+               averages.  The kernel re-uses every point load for all hypotheses from registers and skips
+               (tile, hypothesis) pairs whose bounding box cannot contain an inlier, so this figure exceeds
+               the HBM peak by design; `valu` prices the surviving pairs against the fp64 VALU issue peak, the
+               roofline that actually bounds it.  `traffic` = HBM bytes per 10 000-
+               hypothesis launch from the rocprofv3 PMC pass committed under profiles/ (null if absent).
+  cpu_baseline the oracle's reference-shaped OpenMP port (oracle/misc3d_oracle.c orc_fit_omp_baseline) timed
+               on this box's host cores on a bounded sample.
+
+N > 1 (python -m torch.distributed.run ... bench.py --gpus N): weak scaling, H = 10 000 hypotheses per GPU
+of ONE global sample stream of N x 10 000 (misc3d_amd/distributed.py): interleaved slices, one RCCL
+all-gather of (valid, count) records per window, identical replay on every rank.  value = N*H / t.
 """
 import argparse
 import json
@@ -50,6 +53,8 @@ def parse():
     ap.add_argument("--hyp", type=int, default=10_000, help="hypotheses per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--kernel-detail", action="store_true",
+                    help="extra stand-alone launches: fp64-VALU fraction on the surviving pairs, cull kernel, dense kernel")
     return ap.parse_args()
 
 
@@ -117,9 +122,14 @@ def main():
     for _ in range(a.warmup):
         res = step()
     barrier()
+    k_ms_sum, k_launches = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
+        st = getattr(res, "stats", None)
+        if st:
+            k_ms_sum += st["ms_score_kernel"]
+            k_launches += st["score_launches"]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -135,35 +145,52 @@ def main():
         n_in = len(res.inliers)
         sharded = not hasattr(res, "stats")
         best_index = res.best_index if sharded else res.stats["best_index"]
-        # live kernel timing of the dominant kernel (N=1 semantics, this rank's GPU)
-        Hk = min(H, 16384)
-        samples = capi.draw_samples(N, kind, Hk, seed)
-        cloud.time_score(kind, thr, samples, reps=3, mode=0)            # clocks up
-        k_ms, listed = cloud.time_score(kind, thr, samples, reps=10, mode=0)    # score_mask_k (dominant kernel)
-        cull_ms, _ = cloud.time_score(kind, thr, samples, reps=10, mode=1)      # cull_mask_k
-        dense_ms, _ = cloud.time_score(kind, thr, samples, reps=5, mode=2)      # score_k: the unculled kernel
+        # live timing of the dominant kernel: the score_mask_k launches of the timed steps themselves
+        # (HIP events inside the library).  The sharded driver does not report them: fall back to
+        # stand-alone launches of the same kernel on this rank's GPU.
         n_tiles = -(-N // 512)
-        alg_bytes = Hk * float(N) * ALG_BYTES_PER_PAIR
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        # fp64 VALU instructions actually issued: only the (tile, hypothesis) pairs that survive the box test
-        valu_tops = listed * 512.0 * VALU_OPS_PER_PAIR[kind] / (k_ms * 1e-3) / 1e12
-        dense_tops = float(-(-Hk // 64) * 64) * float(-(-N // 2048) * 2048) * VALU_OPS_PER_PAIR[kind] / (
-            dense_ms * 1e-3) / 1e12
         traffic = load_pmc_traffic()
+        if k_launches:
+            k_ms = k_ms_sum / k_launches
+            h_per_launch = H * a.steps / k_launches
+            timing = "HIP events around every score_mask_k launch of the timed steps"
+        else:
+            samples = capi.draw_samples(N, kind, min(H, 16384), seed)
+            cloud.time_score(kind, thr, samples, reps=3, mode=0)
+            k_ms, _ = cloud.time_score(kind, thr, samples, reps=10, mode=0)
+            h_per_launch = min(H, 16384)
+            timing = "HIP events, 10 stand-alone launches (sharded driver)"
+        alg_bytes = h_per_launch * float(N) * ALG_BYTES_PER_PAIR
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "m3d::score_mask_k<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "launch_ms": k_ms, "hypotheses_per_launch": Hk,
-                    "note": "algorithmic bytes = 24 B x H x N (what EvaluateModel streams); the kernel re-uses every "
-                            "point load from VGPRs for all listed hypotheses and skips (tile, hypothesis) pairs whose "
-                            "bounding box cannot contain an inlier, so achieved exceeds the HBM peak by design; the "
-                            "binding roofline is fp64 VALU issue on the surviving pairs (see valu)",
-                    "valu": {"achieved": valu_tops, "peak": FP64_VALU_PEAK_TOPS, "unit": "Tinstr-lane/s (fp64 VALU)",
-                             "frac": valu_tops / FP64_VALU_PEAK_TOPS, "ops_per_pair": VALU_OPS_PER_PAIR[kind],
-                             "surviving_tile_hypothesis_pairs": listed,
-                             "surviving_fraction": listed / float(n_tiles * Hk)},
-                    "cull_kernel_ms": cull_ms,
-                    "dense_kernel": {"kernel": "m3d::score_k<0>", "launch_ms": dense_ms,
-                                     "valu_frac": dense_tops / FP64_VALU_PEAK_TOPS}}
+                    "launch_ms": k_ms, "hypotheses_per_launch": h_per_launch, "launches_timed": k_launches,
+                    "timing": timing,
+                    "note": "algorithmic bytes = 24 B x hypotheses x points (what EvaluateModel streams); the kernel "
+                            "re-uses every point load from VGPRs for all hypotheses of a launch, skips (tile, "
+                            "hypothesis) pairs whose bounding box cannot contain an inlier and hypotheses that "
+                            "cannot reach the best count of earlier chunks, so achieved exceeds the HBM peak by "
+                            "design; the binding roofline is fp64 VALU issue on the surviving pairs "
+                            "(--kernel-detail; DESIGN.md section 4)"}
+        if a.kernel_detail:
+            Hk = min(H, 16384)
+            samples = capi.draw_samples(N, kind, Hk, seed)
+            cloud.time_score(kind, thr, samples, reps=3, mode=0)            # clocks up
+            u_ms, listed = cloud.time_score(kind, thr, samples, reps=10, mode=0)   # score_mask_k, nothing pruned
+            cull_ms, _ = cloud.time_score(kind, thr, samples, reps=10, mode=1)      # cull_mask_k
+            dense_ms, _ = cloud.time_score(kind, thr, samples, reps=5, mode=2)      # score_k: the unculled kernel
+            # fp64 VALU instructions actually issued: only the (tile, hypothesis) pairs that survive the box test
+            valu_tops = listed * 512.0 * VALU_OPS_PER_PAIR[kind] / (u_ms * 1e-3) / 1e12
+            dense_tops = float(-(-Hk // 64) * 64) * float(-(-N // 2048) * 2048) * VALU_OPS_PER_PAIR[kind] / (
+                dense_ms * 1e-3) / 1e12
+            roofline["valu"] = {"achieved": valu_tops, "peak": FP64_VALU_PEAK_TOPS,
+                                "unit": "Tinstr-lane/s (fp64 VALU)", "frac": valu_tops / FP64_VALU_PEAK_TOPS,
+                                "ops_per_pair": VALU_OPS_PER_PAIR[kind], "launch_ms_unpruned": u_ms,
+                                "hypotheses": Hk, "surviving_tile_hypothesis_pairs": listed,
+                                "surviving_fraction": listed / float(n_tiles * Hk)}
+            roofline["cull_kernel_ms"] = cull_ms
+            roofline["dense_kernel"] = {"kernel": "m3d::score_k<0>", "launch_ms": dense_ms,
+                                        "valu_frac": dense_tops / FP64_VALU_PEAK_TOPS}
         out = {"metric": "RANSAC hypotheses/sec (fit_plane, 1M-pt cloud)", "value": value, "unit": "hypotheses/s",
                "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",

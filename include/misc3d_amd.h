@@ -59,6 +59,9 @@ typedef struct m3d_stats {
     double ms_score;             /* device: minimal fit + scoring + reduce (HIP events) */
     double ms_refine;            /* device+host: inlier compaction, GeneralFit, copy-out */
     double ms_total;             /* wall clock of the call */
+    double ms_score_kernel;      /* device: sum of the scoring-kernel launches alone (HIP events around each) */
+    uint32_t score_launches;     /* number of scoring-kernel launches (chunks) behind ms_score_kernel */
+    uint32_t reserved0;
 } m3d_stats;
 
 /* ---- one-shot fits: python/py_common.cpp:11-67 FitPlane / FitSphere / FitCylinder ------------- */

@@ -42,7 +42,8 @@ class Stats(C.Structure):
                 ("iterations", C.c_uint64), ("best_index", C.c_int64), ("general_fit_ok", C.c_int32),
                 ("ties", C.c_int32), ("hypotheses_scored", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
                 ("ms_sample", C.c_double), ("ms_score", C.c_double), ("ms_refine", C.c_double),
-                ("ms_total", C.c_double)]
+                ("ms_total", C.c_double), ("ms_score_kernel", C.c_double), ("score_launches", C.c_uint32),
+                ("reserved0", C.c_uint32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -118,7 +118,8 @@ DeviceCtx* get_ctx(int device) {
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     for (int k = 0; k < 2 && ok; ++k)
-        ok = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess;
+        ok = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreate(&c->slot[k].k0) == hipSuccess && hipEventCreate(&c->slot[k].k1) == hipSuccess;
     if (!ok) {
         set_error("failed to create HIP stream/events");
         delete c;
@@ -323,8 +324,10 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream);
     HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     if (dense) {
+        HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
                      ctx->partial.as<uint32_t>(), ctx->stream);
+        HIPCHK(hipEventRecord(s.k1, ctx->stream));
         launch_reduce_partials(ctx->partial.as<uint32_t>(), n_tiles, h_pad, s.counts.as<uint32_t>(),
                                ctx->stream);
     } else {
@@ -340,7 +343,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         auto* keep = ctx->keep.as<unsigned long long>();
         launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream);
         launch_keep_mask(ub, prune ? ctx->best_count.as<uint32_t>() : nullptr, n_groups, keep, ctx->stream);
+        HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, s.counts.as<uint32_t>(), ctx->stream);
+        HIPCHK(hipEventRecord(s.k1, ctx->stream));
         if (prune)
             launch_max_count(s.counts.as<uint32_t>(), s.valid.as<uint8_t>(), count, ctx->best_count.as<uint32_t>(),
                              ctx->stream);
@@ -547,6 +552,8 @@ struct RansacOut {
     uint64_t exact_rmse_evals = 0;
     int32_t ties = 0;
     double ms_sample = 0, ms_score = 0;
+    double ms_score_kernel = 0;   // sum over the chunks' scoring-kernel launches (HIP events k0..k1)
+    uint32_t score_launches = 0;
     int internal_error = 0;
 };
 
@@ -619,6 +626,13 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 }
             }
             HIPCHK(hipEventSynchronize(s.done));
+            {
+                float kms = 0;
+                if (hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess) {
+                    out->ms_score_kernel += kms;
+                    out->score_launches++;
+                }
+            }
             int cb_rc = M3D_OK;
             // exact EvaluateModel rmse (serial-order error sum), ransac.h:632-650
             auto exact_rmse = [&](const double* model, uint32_t expect, bool check) -> double {
@@ -774,6 +788,8 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         stats->ties = ro.ties;
         stats->ms_sample = ro.ms_sample;
         stats->ms_score = ro.ms_score;
+        stats->ms_score_kernel = ro.ms_score_kernel;
+        stats->score_launches = ro.score_launches;
         stats->ms_refine = t2 - t1;
         stats->ms_total = t2 - t0;
     }

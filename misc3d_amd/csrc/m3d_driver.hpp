@@ -45,6 +45,7 @@ struct ChunkSlot {
     DevBuf samples, score, params, valid, counts;
     PinBuf h_samples, h_counts, h_valid;
     hipEvent_t done = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr;  // around the scoring kernel of the chunk (m3d_stats.ms_score_kernel)
     size_t begin = 0, end = 0;
     uint32_t h_pad = 0;
 };

@@ -333,7 +333,7 @@ __device__ __forceinline__ double nearest_phase2(const GridDesc& g, const uint32
     return best;
 }
 
-constexpr int kNlBatch = 4;   // neighbour-list candidates per trip
+constexpr int kNlBatch = 2;   // neighbour-list candidates per trip
 
 // Exact nearest squared distance within the search radius (KDTreeFlann::SearchHybrid(p, r, 1)).
 // The grid cell is r/K.  Phase 1 scans the 3x3x3 block around the query's cell (9 contiguous x-rows):

@@ -5,7 +5,7 @@
 namespace m3d {
 
 constexpr int kRegTStride = 12;  // doubles per transformation record (rows 0..2 of the 4x4)
-constexpr int kRegP = 4;         // source points per lane in reg_validate_k
+constexpr int kRegP = 1;         // source points per lane in reg_validate_k
 constexpr int kRegTile = 256 * kRegP;
 constexpr int kRegMinSplits = 40;    // hypothesis splits per source tile (XCD locality, see reg_validate_k)
 constexpr int kRegPruneStride = 8;   // validation phase A runs on every 8th source tile

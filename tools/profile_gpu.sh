@@ -9,6 +9,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench -o bench -- \
     python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace_bench.err
+# HBM traffic of the SAME launches (the score_mask_k launches inside bench.py's steps): separate PMC passes
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_bench_fetch -o fetch -- \
+    python bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_bench_fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_bench_write -o write -- \
+    python bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/pmc_bench_write.err
+# fp64-VALU fraction / cull / dense kernel figures (stand-alone launches, not under the profiler)
+python bench.py --kernel-detail --no-cpu-baseline > $OUT/bench_kernel_detail.json 2> $OUT/bench_kernel_detail.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_target -o target -- \
     python tools/pmc_target.py > $OUT/target.out 2> $OUT/trace_target.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- \

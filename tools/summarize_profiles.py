@@ -41,6 +41,12 @@ def main():
     p = os.path.join(SRC, "bench_under_rocprof.json")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, f"{TAG}_bench_under_rocprof.json"))
+    for src_rel, dst_name in (("../prof_c4/c4_kernel_stats.csv", f"{TAG}_c4_kernel_stats.csv"),
+                              ("../bench_configs.jsonl", f"{TAG}_bench_configs.jsonl"),
+                              ("../bench_latest.json", f"{TAG}_bench.json")):
+        q = os.path.join(SRC, src_rel)
+        if os.path.exists(q):
+            shutil.copy(q, os.path.join(DST, dst_name))
     p = os.path.join(SRC, "target.out")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, f"{TAG}_pmc_target_stdout.txt"))
@@ -83,14 +89,31 @@ def main():
                 d.setdefault("pmc_launch_ns", {})[cname] = big[1]
     with open(os.path.join(DST, f"{TAG}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
-    sk = summary["kernels"].get("m3d::score_mask_k<0>") or summary["kernels"].get("m3d::score_k<0>")
-    if sk:
-        with open(os.path.join(DST, "pmc_score_latest.json"), "w") as f:
-            json.dump({"kernel": "m3d::score_mask_k<0>" if "m3d::score_mask_k<0>" in summary["kernels"] else "m3d::score_k<0>", "hbm_bytes_per_launch": sk["hbm_bytes"],
-                       "hbm_read_bytes": sk["hbm_read_bytes"], "hbm_write_bytes": sk["hbm_write_bytes"],
-                       "source": f"profiles/{TAG}_pmc_summary.json",
-                       "launch": os.environ.get("M3D_PMC_HYP", "10000") + " hypotheses x " + str(n_points) + " points"},
-                      f, indent=1)
+    # traffic of the dominant kernel PER LAUNCH, averaged over the launches of bench.py itself (the same
+    # launches bench.py times with HIP events and rocprofv3 --stats averages)
+    bf = os.path.join(SRC, "pmc_bench_fetch", "fetch_counter_collection.csv")
+    bw = os.path.join(SRC, "pmc_bench_write", "write_counter_collection.csv")
+    if os.path.exists(bf) and os.path.exists(bw):
+        fv = counters(bf).get("m3d::score_mask_k<0>", {}).get("FETCH_SIZE", [])
+        wv = counters(bw).get("m3d::score_mask_k<0>", {}).get("WRITE_SIZE", [])
+        if fv and wv:
+            rd = sum(t[0] for t in fv) / len(fv) * 1024 * 2
+            wr = sum(t[0] for t in wv) / len(wv) * 1024
+            latest = {"kernel": "m3d::score_mask_k<0>", "hbm_bytes_per_launch": rd + wr, "hbm_read_bytes": rd,
+                      "hbm_write_bytes": wr, "launches_averaged": len(fv),
+                      "avg_launch_ns_under_pmc": sum(t[1] for t in fv) / len(fv),
+                      "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 10 "
+                                 "--warmup 2 --no-cpu-baseline",
+                      "corrections": "KiB -> B; FETCH_SIZE x2 on gfx950 (calibrated on aos_to_soa_k, see "
+                                     f"{TAG}_pmc_summary.json)"}
+            summary["bench_score_mask_k"] = latest
+            with open(os.path.join(DST, "pmc_score_latest.json"), "w") as f:
+                json.dump(latest, f, indent=1)
+            with open(os.path.join(DST, f"{TAG}_pmc_summary.json"), "w") as f:
+                json.dump(summary, f, indent=1, sort_keys=True)
+    q = os.path.join(SRC, "bench_kernel_detail.json")
+    if os.path.exists(q):
+        shutil.copy(q, os.path.join(DST, f"{TAG}_bench_kernel_detail.json"))
     print(json.dumps(summary.get("calibration"), indent=1))
     print({k: (v.get("hbm_bytes"), v.get("launches_seen")) for k, v in summary["kernels"].items()})
 
