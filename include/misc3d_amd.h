@@ -84,7 +84,9 @@ typedef struct m3d_cloud m3d_cloud;
 m3d_cloud *m3d_cloud_create(const double *xyz, const double *normals /* may be NULL */, size_t n,
                             int device);
 void m3d_cloud_destroy(m3d_cloud *cloud);
+/* Points currently in the cloud (shrinks with m3d_cloud_remove_inliers) / points it was created with. */
 size_t m3d_cloud_size(const m3d_cloud *cloud);
+size_t m3d_cloud_original_size(const m3d_cloud *cloud);
 /* RANSAC::SetProbability + SetMaxIteration + FitModel (ransac.h:482-516) on the resident cloud.
  * inliers may be NULL (then only *n_inliers is reported). */
 int m3d_cloud_fit(m3d_cloud *cloud, int kind, double threshold, size_t max_iteration,
@@ -125,6 +127,13 @@ int m3d_cloud_exact_error(m3d_cloud *cloud, int kind, double threshold, const do
  * GeneralFit applied in place to params.  Return 1/0 = GeneralFit's return. */
 int m3d_cloud_refine(m3d_cloud *cloud, int kind, double threshold, double *params,
                      size_t *inliers, size_t *n_inliers);
+/* pcd_copy = pcd_copy->SelectByIndex(inliers, invert=true), src/iterative_plane_segmentation.cpp:33, on
+ * the resident cloud: the inliers of `model` (distance < threshold, RefineModel's rule ransac.h:537-543)
+ * leave the cloud, the rest keeps its order.  Afterwards every entry point works on the remaining
+ * points, and the index lists it returns (m3d_cloud_fit, m3d_cloud_refine) keep referring to the cloud
+ * AS CREATED, which is what SegmentPlaneIterative's callers need.  Clouds without normals only. */
+int m3d_cloud_remove_inliers(m3d_cloud *cloud, int kind, double threshold, const double *model,
+                             size_t *n_removed);
 /* Sequential replay of the best-update / adaptive-stop rule (ransac.h:573-575,592-613) over
  * per-hypothesis (valid, count) records in index order; `rmse_cb` is called only for fitness ties.
  * Pure host logic, usable by distributed drivers after gathering counts. */

@@ -91,6 +91,9 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_exact_error.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_refine.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_cloud_remove_inliers.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.m3d_cloud_original_size.restype = C.c_size_t
+        L.m3d_cloud_original_size.argtypes = [C.c_void_p]
         L.m3d_cloud_time_score.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p]
         L.m3d_sampler_create.restype = C.c_void_p
@@ -239,7 +242,8 @@ class Cloud:
         nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
         if nrm is not None and len(nrm) != len(xyz):
             raise ValueError("normals and points differ in length")
-        self.n = len(xyz)
+        self.n = len(xyz)            # points currently in the cloud (shrinks with remove_inliers)
+        self.n_created = len(xyz)    # index lists refer to the cloud as created
         self._h = lib().m3d_cloud_create(_p(xyz), _p(nrm), self.n, device)
         if not self._h:
             raise M3DError(ERR_DEVICE, last_error())
@@ -270,7 +274,7 @@ class Cloud:
         inl = None
         if want_inliers:
             if getattr(self, "_inl_buf", None) is None:
-                self._inl_buf = np.empty(max(self.n, 1), dtype=np.uint64)
+                self._inl_buf = np.empty(max(self.n_created, 1), dtype=np.uint64)
             inl = self._inl_buf
         ni = C.c_size_t(0)
         st = Stats()
@@ -318,12 +322,20 @@ class Cloud:
     def refine(self, kind, threshold, params, copy=True):
         params = _f64(params).copy()
         if getattr(self, "_inl_buf", None) is None:
-            self._inl_buf = np.empty(max(self.n, 1), dtype=np.uint64)
+            self._inl_buf = np.empty(max(self.n_created, 1), dtype=np.uint64)
         inl = self._inl_buf
         ni = C.c_size_t(0)
         rc = _check(lib().m3d_cloud_refine(self._h, kind, threshold, _p(params), _p(inl),
                                            C.cast(C.byref(ni), C.c_void_p)))
         return rc, params, (inl[: ni.value].copy() if copy else inl[: ni.value])
+
+    def remove_inliers(self, kind, threshold, model):
+        """m3d_cloud_remove_inliers: SelectByIndex(inliers of `model`, invert=True) in place -> #removed."""
+        model = _f64(model).copy()
+        nr = C.c_size_t(0)
+        _check(lib().m3d_cloud_remove_inliers(self._h, kind, threshold, _p(model), C.cast(C.byref(nr), C.c_void_p)))
+        self.n = int(lib().m3d_cloud_size(self._h))
+        return nr.value
 
 
 def draw_samples(n_points, kind, n_hyp, seed):

@@ -140,7 +140,7 @@ static double now_ms() {
 
 }  // namespace m3d
 
-m3d::CloudView m3d_cloud::view() const {
+m3d::CloudView m3d_cloud::base_view() const {
     m3d::CloudView v;
     v.x = x.as<double>();
     v.y = y.as<double>();
@@ -148,12 +148,15 @@ m3d::CloudView m3d_cloud::view() const {
     v.nx = has_normals ? nx.as<double>() : nullptr;
     v.ny = has_normals ? ny.as<double>() : nullptr;
     v.nz = has_normals ? nz.as<double>() : nullptr;
-    v.n = n;
-    v.n_pad = n_pad;
+    v.n = work.active ? n0 : n;
+    v.n_pad = work.active ? n_pad0 : n_pad;
     return v;
 }
 
+m3d::CloudView m3d_cloud::view() const { return work.active && !work.cur_is_v0 ? work.cur : base_view(); }
+
 m3d::SortedView m3d_cloud::sorted() const {
+    if (work.active && !work.cur_is_v0) return work.scur;
     m3d::SortedView s;
     s.x = sx.as<double>();
     s.y = sy.as<double>();
@@ -759,6 +762,8 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     const double t0 = now_ms();
     HIPCHK(hipSetDevice(ctx->device));
     const CloudView v = c->view();
+    const CloudView gather = c->base_view();   // index lists / GeneralFit refer to the cloud as created
+    const uint32_t* orig = c->orig();
     RansacOut ro;
     int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro);
     if (rc != M3D_OK) return rc;
@@ -767,7 +772,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     std::memcpy(model, ro.best_host, sizeof(model));
     size_t ni = 0;
     int gf_ok = 1;
-    rc = refine(ctx, v, v, nullptr, kind, thr, ctx->best_params.as<double>(), model, inliers, &ni,
+    rc = refine(ctx, v, gather, orig, kind, thr, ctx->best_params.as<double>(), model, inliers, &ni,
                 &gf_ok);
     if (rc != M3D_OK) return rc;
     if (ro.st.best_index >= 0 && ni != ro.st.best_count)
@@ -794,6 +799,93 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         stats->ms_total = t2 - t0;
     }
     return gf_ok ? M3D_OK : M3D_FALSE;
+}
+
+// pcd_copy = pcd_copy->SelectByIndex(inliers, true) (iterative_plane_segmentation.cpp:33) on the resident
+// cloud: a stable partition keeps the non-inliers of `model_dev` (distance >= thr, or not comparable) in
+// both copies -- original order (+ the map back to the cloud as created) and Hilbert-sorted (tile boxes
+// recomputed).  The first call allocates the ping-pong buffers.
+static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double* model_dev, size_t* n_removed) {
+    DeviceCtx* ctx = c->ctx;
+    m3d_cloud::Work& w = c->work;
+    if (c->has_normals) return fail(M3D_ERR_INVALID_ARG, "removing points from a cloud with normals is not supported");
+    if (!w.active) {
+        c->n0 = c->n;
+        c->n_pad0 = c->n_pad;
+        c->n_tiles0 = c->n_tiles;
+        const size_t bytes = sizeof(double) * (size_t)c->n_pad;
+        const uint32_t scap = c->n_tiles * kTilePoints;
+        bool ok = true;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = w.bx[k].reserve(bytes) && w.by[k].reserve(bytes) && w.bz[k].reserve(bytes) &&
+                 w.bo[k].reserve(sizeof(uint32_t) * (size_t)c->n_pad) && w.sbx[k].reserve(sizeof(double) * scap) &&
+                 w.sby[k].reserve(sizeof(double) * scap) && w.sbz[k].reserve(sizeof(double) * scap);
+        ok = ok && w.sboxes.reserve(sizeof(double) * kBoxStride * c->n_tiles);
+        if (!ok) return M3D_ERR_DEVICE;
+        launch_iota(w.bo[0].as<uint32_t>(), c->n, ctx->stream);
+        w.cur = c->base_view();   // round 0 reads the uploaded cloud directly
+        w.scur = c->sorted();
+        w.cur_orig = w.bo[0].as<uint32_t>();
+        w.pp = w.spp = 0;
+        w.cur_is_v0 = true;
+        w.active = true;
+    }
+    const CloudView cur = w.cur;
+    const int dst = w.cur_is_v0 ? 1 : w.pp;
+    const uint32_t nb = (cur.n + kCompactTile - 1) / kCompactTile;
+    const uint32_t snb = (c->n_sorted + kCompactTile - 1) / kCompactTile;
+    const uint32_t scap = c->n_tiles0 * kTilePoints;
+    RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)std::max(nb, snb) + 1));
+    RESERVE(ctx->total, 16);
+    RESERVE(ctx->h_small, 256);
+    launch_compact(kind, cur, model_dev, thr, 2, w.cur_orig, nullptr, nullptr, w.bx[dst].as<double>(),
+                   w.by[dst].as<double>(), w.bz[dst].as<double>(), w.bo[dst].as<uint32_t>(), c->n_pad0,
+                   ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream);
+    // the same stable partition on the sorted copy (every inlier is a finite point), then fresh tile boxes
+    CloudView sview;
+    sview.x = w.scur.x;
+    sview.y = w.scur.y;
+    sview.z = w.scur.z;
+    sview.nx = sview.ny = sview.nz = nullptr;
+    sview.n = c->n_sorted;
+    sview.n_pad = w.scur.n_tiles * kTilePoints;
+    launch_compact(kind, sview, model_dev, thr, 3, nullptr, nullptr, nullptr, w.sbx[w.spp].as<double>(),
+                   w.sby[w.spp].as<double>(), w.sbz[w.spp].as<double>(), nullptr, scap,
+                   ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>() + 1, ctx->stream);
+    uint32_t* h = ctx->h_small.as<uint32_t>();
+    HIPCHK(hipMemcpyAsync(h, ctx->total.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t new_n = h[0], new_sorted = h[1];
+    if (new_n > cur.n || new_sorted > c->n_sorted || cur.n - new_n != c->n_sorted - new_sorted)
+        return fail(M3D_ERR_INTERNAL, "the two copies of the cloud disagree on the removed points");
+    if (n_removed) *n_removed = cur.n - new_n;
+    w.scur.x = w.sbx[w.spp].as<double>();
+    w.scur.y = w.sby[w.spp].as<double>();
+    w.scur.z = w.sbz[w.spp].as<double>();
+    w.scur.boxes = w.sboxes.as<double>();
+    w.scur.n_tiles = std::max<uint32_t>(1, (new_sorted + kTilePoints - 1) / kTilePoints);
+    // pad_nan_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
+    launch_tile_boxes(w.scur, w.sboxes.as<double>(), ctx->stream);
+    w.spp ^= 1;
+    w.cur.x = w.bx[dst].as<double>();
+    w.cur.y = w.by[dst].as<double>();
+    w.cur.z = w.bz[dst].as<double>();
+    w.cur.nx = w.cur.ny = w.cur.nz = nullptr;
+    w.cur.n = new_n;
+    w.cur.n_pad = std::max<uint32_t>(round_up(new_n, kScoreTile), kScoreTile);
+    w.cur_orig = w.bo[dst].as<uint32_t>();
+    if (w.cur_is_v0) {
+        w.cur_is_v0 = false;
+        w.pp = 0;  // bo[0] (iota) is free again: the next compaction goes to set 0
+    } else {
+        w.pp = dst ^ 1;
+    }
+    c->n = new_n;
+    c->n_pad = w.cur.n_pad;
+    c->n_sorted = new_sorted;
+    c->n_tiles = w.scur.n_tiles;
+    return M3D_OK;
 }
 
 }  // namespace m3d
@@ -954,6 +1046,11 @@ void m3d_cloud_destroy(m3d_cloud* c) {
     c->x.release(); c->y.release(); c->z.release();
     c->nx.release(); c->ny.release(); c->nz.release();
     c->sx.release(); c->sy.release(); c->sz.release(); c->boxes.release();
+    for (int k = 0; k < 2; ++k) {
+        c->work.bx[k].release(); c->work.by[k].release(); c->work.bz[k].release(); c->work.bo[k].release();
+        c->work.sbx[k].release(); c->work.sby[k].release(); c->work.sbz[k].release();
+    }
+    c->work.sboxes.release();
     delete c;
 }
 
@@ -1243,12 +1340,27 @@ int m3d_cloud_refine(m3d_cloud* c, int kind, double threshold, double* params, s
     HIPCHK(hipStreamSynchronize(ctx->stream));
     int gf = 1;
     const CloudView v = c->view();
-    const int rc = refine(ctx, v, v, nullptr, kind, threshold, ctx->small.as<double>(), tmp, inliers,
+    const int rc = refine(ctx, v, c->base_view(), c->orig(), kind, threshold, ctx->small.as<double>(), tmp, inliers,
                           n_inliers, &gf);
     if (rc != M3D_OK) return rc;
     std::memcpy(params, tmp, sizeof(double) * num_params(kind));
     return gf ? M3D_OK : M3D_FALSE;
 }
+
+int m3d_cloud_remove_inliers(m3d_cloud* c, int kind, double threshold, const double* model, size_t* n_removed) {
+    if (!c || kind < 0 || kind > 2 || !model) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    DeviceCtx* ctx = c->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    RESERVE(ctx->small, 256);
+    double tmp[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::memcpy(tmp, model, sizeof(double) * num_params(kind));
+    HIPCHK(hipMemcpyAsync(ctx->small.p, tmp, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return cloud_remove_locked(c, kind, threshold, ctx->small.as<double>(), n_removed);
+}
+
+size_t m3d_cloud_original_size(const m3d_cloud* c) { return c ? (c->work.active ? c->n0 : c->n) : 0; }
 
 // SegmentPlaneIterative, src/iterative_plane_segmentation.cpp:8-39
 int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, int max_iteration,
@@ -1270,132 +1382,44 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         const uint64_t seed0 = resolve_seed(seed);
-        const CloudView v0 = c0->view();
-        // ping-pong buffers for the shrinking cloud (pcd_copy, :25,:33) + original indices
-        DevBuf bx[2], by[2], bz[2], bo[2];
-        // the Z-order sorted copy shrinks the same way (stable partition keeps it sorted); boxes are
-        // recomputed per round
-        DevBuf sbx[2], sby[2], sbz[2], sboxes;
-        const size_t bytes = sizeof(double) * (size_t)c0->n_pad;
-        const uint32_t scap = c0->n_tiles * kTilePoints;
-        bool ok = true;
-        for (int k = 0; k < 2 && ok; ++k)
-            ok = bx[k].reserve(bytes) && by[k].reserve(bytes) && bz[k].reserve(bytes) &&
-                 bo[k].reserve(sizeof(uint32_t) * (size_t)c0->n_pad) && sbx[k].reserve(sizeof(double) * scap) &&
-                 sby[k].reserve(sizeof(double) * scap) && sbz[k].reserve(sizeof(double) * scap);
-        ok = ok && sboxes.reserve(sizeof(double) * kBoxStride * c0->n_tiles);
-        auto cleanup = [&]() {
-            for (int k = 0; k < 2; ++k) {
-                bx[k].release(); by[k].release(); bz[k].release(); bo[k].release();
-                sbx[k].release(); sby[k].release(); sbz[k].release();
+        size_t count = 0, k = 0;
+        const size_t target = (size_t)((1 - min_ratio) * (double)n);  // :28
+        while (count < target && k < max_clusters) {
+            if (c0->n < 3) {  // the reference's FitModel would throw here (ransac.h:510-513)
+                rc = 2;
+                break;
             }
-            sboxes.release();
-        };
-        if (!ok) {
-            cleanup();
-            rc = M3D_ERR_DEVICE;
-        } else {
-            launch_iota(bo[0].as<uint32_t>(), c0->n, ctx->stream);
-            CloudView cur = v0;  // round 0 reads the uploaded cloud directly
-            SortedView scur = c0->sorted();
-            uint32_t n_sorted = c0->n_sorted;  // finite points in the sorted copy
-            int spp = 0;                       // sorted buffers that will RECEIVE the next compaction
-            const uint32_t* cur_orig = bo[0].as<uint32_t>();
-            int pp = 0;          // buffers that will RECEIVE the next compaction
-            bool cur_is_v0 = true;
-            size_t count = 0, k = 0;
-            const size_t target = (size_t)((1 - min_ratio) * (double)n);  // :28
-            double plane[4] = {0, 0, 0, 0};  // `plane` persists across rounds (:22)
-            while (count < target && k < max_clusters) {
-                if (cur.n < 3) {  // the reference's FitModel would throw here (ransac.h:510-513)
-                    rc = 2;
-                    break;
-                }
-                RansacOut ro;
-                rc = run_ransac(ctx, cur, scur, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k,
-                                &ro);  // probability stays at the RANSAC default, ransac.h:462
-                if (rc != M3D_OK) break;
-                double model[kModelStride];
-                std::memcpy(model, ro.best_host, sizeof(model));
-                size_t ni = 0;
-                int gf = 1;
-                const size_t off = cluster_offsets[k];
-                rc = refine(ctx, cur, v0, cur_orig, M3D_PLANE, threshold, ctx->best_params.as<double>(),
-                            model, cluster_indices + off, &ni, &gf);
-                if (rc != M3D_OK) break;
-                if (ni == 0) {  // the reference would loop forever (:29,:35)
-                    rc = 2;
-                    break;
-                }
-                std::memcpy(plane, model, sizeof(plane));
-                std::memcpy(planes + 4 * k, plane, sizeof(plane));
-                cluster_offsets[k + 1] = off + ni;
-                count += ni;
-                k++;
-                if (count >= target || k >= max_clusters) break;
-                // pcd_copy = pcd_copy->SelectByIndex(inliers, true), :33
-                const int dst = cur_is_v0 ? 1 : pp;
-                const uint32_t nb = (cur.n + kCompactTile - 1) / kCompactTile;
-                if (!ctx->block_counts.reserve(sizeof(uint32_t) * ((size_t)nb + 1)) ||
-                    !ctx->total.reserve(16)) {
-                    rc = M3D_ERR_DEVICE;
-                    break;
-                }
-                launch_compact(M3D_PLANE, cur, ctx->best_params.as<double>(), threshold, 2, cur_orig,
-                               nullptr, nullptr, bx[dst].as<double>(), by[dst].as<double>(),
-                               bz[dst].as<double>(), bo[dst].as<uint32_t>(), c0->n_pad,
-                               ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream);
-                {   // the same stable partition on the sorted copy (every inlier is a finite point, so the
-                    // sorted copy loses exactly `ni` points), then fresh tile boxes
-                    CloudView sview;
-                    sview.x = scur.x;
-                    sview.y = scur.y;
-                    sview.z = scur.z;
-                    sview.nx = sview.ny = sview.nz = nullptr;
-                    sview.n = n_sorted;
-                    sview.n_pad = scur.n_tiles * kTilePoints;
-                    const uint32_t snb = (n_sorted + kCompactTile - 1) / kCompactTile;
-                    if (!ctx->block_counts.reserve(sizeof(uint32_t) * ((size_t)std::max(nb, snb) + 1))) {
-                        rc = M3D_ERR_DEVICE;
-                        break;
-                    }
-                    launch_compact(M3D_PLANE, sview, ctx->best_params.as<double>(), threshold, 3, nullptr, nullptr,
-                                   nullptr, sbx[spp].as<double>(), sby[spp].as<double>(), sbz[spp].as<double>(),
-                                   nullptr, scap, ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>() + 1,
-                                   ctx->stream);
-                    n_sorted -= (uint32_t)std::min<size_t>(ni, n_sorted);
-                    scur.x = sbx[spp].as<double>();
-                    scur.y = sby[spp].as<double>();
-                    scur.z = sbz[spp].as<double>();
-                    scur.boxes = sboxes.as<double>();
-                    scur.n_tiles = std::max<uint32_t>(1, (n_sorted + kTilePoints - 1) / kTilePoints);
-                    // pad_nan_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
-                    launch_tile_boxes(scur, sboxes.as<double>(), ctx->stream);
-                    spp ^= 1;
-                }
-                if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-                    rc = fail(M3D_ERR_DEVICE, "stream sync failed");
-                    break;
-                }
-                const uint32_t new_n = cur.n - (uint32_t)ni;
-                cur.x = bx[dst].as<double>();
-                cur.y = by[dst].as<double>();
-                cur.z = bz[dst].as<double>();
-                cur.nx = cur.ny = cur.nz = nullptr;
-                cur.n = new_n;
-                cur.n_pad = std::max<uint32_t>(round_up(new_n, kScoreTile), kScoreTile);
-                cur_orig = bo[dst].as<uint32_t>();
-                if (cur_is_v0) {
-                    cur_is_v0 = false;
-                    pp = 0;  // bo[0] (iota) is free again: next compaction goes to set 0
-                } else {
-                    pp = dst ^ 1;
-                }
+            // ransac.FitModel(threshold, plane, inliers), :29-31; probability stays at the RANSAC default
+            // (ransac.h:462); inlier indices refer to the cloud as created (c0->orig()).  The return value
+            // (GeneralFit) is ignored by the reference.
+            double plane[4] = {0, 0, 0, 0};
+            size_t ni = 0;
+            const size_t off = cluster_offsets[k];
+            rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
+                                  cluster_indices + off, &ni, nullptr);
+            if (rc < 0) break;
+            rc = M3D_OK;
+            if (ni == 0) {  // the reference would loop forever (:29,:35)
+                rc = 2;
+                break;
             }
-            *n_clusters = k;
-            (void)hipStreamSynchronize(ctx->stream);
-            cleanup();
+            std::memcpy(planes + 4 * k, plane, sizeof(plane));
+            cluster_offsets[k + 1] = off + ni;
+            count += ni;
+            k++;
+            if (count >= target || k >= max_clusters) break;
+            // pcd_copy = pcd_copy->SelectByIndex(inliers, true), :33 -- inliers of the PRE-refinement model,
+            // still in ctx->best_params
+            size_t removed = 0;
+            rc = cloud_remove_locked(c0, M3D_PLANE, threshold, ctx->best_params.as<double>(), &removed);
+            if (rc != M3D_OK) break;
+            if (removed != ni) {
+                rc = fail(M3D_ERR_INTERNAL, "removed points and inlier list disagree");
+                break;
+            }
         }
+        *n_clusters = k;
+        (void)hipStreamSynchronize(ctx->stream);
     }
     m3d_cloud_destroy(c0);
     if (rc == 2) return 2;

@@ -74,6 +74,22 @@ struct m3d_cloud {
     // Z-order sorted copy for the culled scoring path (m3d_cull_kernels.hip)
     m3d::DevBuf sx, sy, sz, boxes;
     uint32_t n_sorted = 0, n_tiles = 0;
-    m3d::CloudView view() const;
+    // In-place shrinking (m3d_cloud_remove_inliers = SelectByIndex(inliers, invert), the tail of a
+    // SegmentPlaneIterative round).  x/y/z above always hold the cloud AS CREATED (n0 points): index lists
+    // and GeneralFit gathers refer to it through `orig`.  Once shrunk, n / n_pad / n_sorted / n_tiles and
+    // view() / sorted() describe the working cloud in the ping-pong buffers below.
+    struct Work {
+        bool active = false;
+        m3d::DevBuf bx[2], by[2], bz[2], bo[2], sbx[2], sby[2], sbz[2], sboxes;
+        m3d::CloudView cur;
+        m3d::SortedView scur;
+        const uint32_t* cur_orig = nullptr;   // working index -> index in the cloud as created
+        int pp = 0, spp = 0;                  // buffer sets that RECEIVE the next compaction
+        bool cur_is_v0 = true;
+    } work;
+    uint32_t n0 = 0, n_pad0 = 0, n_tiles0 = 0;
+    m3d::CloudView view() const;        // working cloud
+    m3d::CloudView base_view() const;   // cloud as created
     m3d::SortedView sorted() const;
+    const uint32_t* orig() const { return work.active ? work.cur_orig : nullptr; }
 };

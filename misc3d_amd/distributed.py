@@ -40,6 +40,7 @@ class ShardedFit:
     fitness: float
     hypotheses_scored: int
     collectives: int
+    best_model: np.ndarray = None     # the pre-refinement (minimal) model RefineModel's inliers belong to
 
 
 def _world(group):
@@ -135,4 +136,51 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
     if not want_inliers:
         inliers = inliers[:0]
     return ShardedFit(ret, params, inliers, int(st.best_index), int(st.count), int(st.iterations),
-                      float(st.best_fitness), scored, collectives)
+                      float(st.best_fitness), scored, collectives, np.asarray(best, dtype=np.float64).copy())
+
+
+@dataclass
+class ShardedSegmentation:
+    ret: int                  # 1 = done, 2 = stopped early (a round found no inlier / fewer than 3 points left), 0 = N < 3
+    planes: np.ndarray        # (k, 4)
+    clusters: list            # k arrays of indices into the cloud as created, ascending
+    collectives: int
+
+
+def segment_plane_iterative_sharded(scorer, threshold, max_iteration=100, min_ratio=0.05, seed=0, group=None,
+                                    device=None, max_clusters=None) -> ShardedSegmentation:
+    """SegmentPlaneIterative (src/iterative_plane_segmentation.cpp:8-39) with every round's hypothesis
+    loop sharded over the ranks: each rank holds a replica of the shrinking cloud,
+    scores its share of the round's hypotheses, one all-gather per window, identical replay -> identical
+    plane; then every rank removes the same inliers from its replica (m3d_cloud_remove_inliers:
+    redundant compute, no point traffic).  Round k uses sampler seed `seed + k`, like the single-GPU
+    m3d_segment_plane_iterative, so the result is independent of the number of GPUs."""
+    n = int(scorer.n)
+    planes, clusters = [], []
+    collectives = 0
+    if n < 3:                                   # :13-17 LogWarning + empty result
+        return ShardedSegmentation(0, np.zeros((0, 4)), clusters, 0)
+    target = int((1.0 - float(min_ratio)) * float(n))          # size_t((1 - min_ratio) * n), :28
+    max_clusters = n if max_clusters is None else int(max_clusters)
+    count, k, ret = 0, 0, 1
+    while count < target and k < max_clusters:
+        if scorer.n < 3:                        # the reference's FitModel would throw (ransac.h:510-513)
+            ret = 2
+            break
+        r = fit_sharded(scorer, int(scorer.n), capi.PLANE, threshold, max_iteration, 0.9999, seed + k, group=group,
+                        device=device, copy=True)
+        collectives += r.collectives
+        ni = len(r.inliers)
+        if ni == 0:                             # the reference would loop forever (:29,:35)
+            ret = 2
+            break
+        planes.append(np.asarray(r.params[:4], dtype=np.float64).copy())
+        clusters.append(np.asarray(r.inliers).astype(np.int64))
+        count += ni
+        k += 1
+        if count >= target or k >= max_clusters:
+            break
+        removed = scorer.remove_inliers(capi.PLANE, threshold, r.best_model)      # SelectByIndex(inliers, true), :33
+        if removed != ni:
+            raise capi.M3DError(capi.ERR_INTERNAL, "removed points and inlier list disagree")
+    return ShardedSegmentation(ret, np.array(planes).reshape(-1, 4), clusters, collectives)

@@ -25,6 +25,7 @@ class OracleScorer:
         self.xyz = xyz
         self.normals = normals
         self.n = len(xyz)
+        self.orig = np.arange(len(xyz), dtype=np.int64)     # working index -> index in the cloud as created
 
     class _Table:
         """stands in for capi.Sampler: the whole table drawn up front by the host-only m3d_draw_samples"""
@@ -57,7 +58,17 @@ class OracleScorer:
         return self.o.evaluate_model(kind, self.xyz, thr, model)
 
     def refine(self, kind, thr, params, copy=True):
-        return self.o.refine(kind, self.xyz, thr, params)
+        ret, p, inl = self.o.refine(kind, self.xyz, thr, params)
+        return ret, p, self.orig[np.asarray(inl, dtype=np.int64)]
+
+    def remove_inliers(self, kind, thr, model):
+        _, _, inl = self.o.refine(kind, self.xyz, thr, model)
+        keep = np.ones(len(self.xyz), dtype=bool)
+        keep[np.asarray(inl, dtype=np.int64)] = False
+        self.xyz = np.ascontiguousarray(self.xyz[keep])
+        self.orig = self.orig[keep]
+        self.n = len(self.xyz)
+        return len(inl)
 
 
 def _free_port():
@@ -126,3 +137,41 @@ def test_fit_sharded_single_process_equals_oracle(orc):
     o = orc.fit(0, pts, thr=0.01, max_iter=200, prob=0.9999, seed=3)
     assert r.best_index == o.best_index and r.count == o.count and np.array_equal(r.inliers, o.inliers)
     assert r.collectives == 0
+
+
+def _seg_worker(rank, world, port, n, thr, max_iter, min_ratio, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from misc3d_amd import distributed
+        pts = synth.room_cloud_c5(n, 6)
+        r = distributed.segment_plane_iterative_sharded(OracleScorer(pts), thr, max_iter, min_ratio, seed)
+        q.put((rank, r.ret, r.planes.tolist(), [c.tolist() for c in r.clusters], r.collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_segment_plane_iterative_sharded_world2_matches_sequential(orc):
+    """SegmentPlaneIterative with every round's hypotheses sharded over two ranks (gloo): same planes and
+    same clusters (indices into the cloud as created) as the sequential oracle, on both ranks."""
+    n, thr, max_iter, min_ratio, seed = 4000, 0.02, 120, 0.15, 19
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seg_worker, args=(r, 2, port, n, thr, max_iter, min_ratio, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pts = synth.room_cloud_c5(n, 6)
+    o_ret, o_planes, o_clusters = orc.segment_plane_iterative(pts, thr, max_iter, min_ratio, seed=seed)
+    assert len(o_planes) >= 3
+    for rank, ret, planes, clusters, n_coll in results:
+        assert o_ret == 0 and ret == 1 and len(planes) == len(o_planes)     # oracle: 0 = ok; product: 1 = done
+        assert np.allclose(np.array(planes), o_planes, rtol=0, atol=1e-12)
+        for c, oc in zip(clusters, o_clusters):
+            assert c == oc.tolist()
+        assert n_coll >= len(planes)

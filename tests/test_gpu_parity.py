@@ -221,6 +221,41 @@ def test_sharded_driver_on_gpu_equals_single_call(capi):
             assert np.array_equal(s.inliers, g.inliers) and np.array_equal(s.params, g.params)
 
 
+def test_cloud_remove_inliers_and_sharded_segmentation(capi, orc):
+    """m3d_cloud_remove_inliers (SelectByIndex(inliers, invert) on the resident cloud) and the sharded
+    SegmentPlaneIterative driver at world size 1 with the product scorer: same planes and clusters as
+    the one-call m3d_segment_plane_iterative and as the oracle; index lists refer to the cloud as created;
+    non-finite points stay in the cloud."""
+    from misc3d_amd import distributed
+    pts = synth.room_cloud_c5(60_000, seed=6)
+    pts[[5, 77, 4000]] = np.nan
+    pts[123, 1] = np.inf
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.02, max_iteration=150, min_ratio=0.1, seed=19)
+    orc_rc, oplanes, oclusters = orc.segment_plane_iterative(pts, 0.02, max_iteration=150, min_ratio=0.1, seed=19)
+    assert rc == 1 and orc_rc == 0 and len(planes) == len(oplanes) >= 4
+    with capi.Cloud(pts) as c:
+        r = distributed.segment_plane_iterative_sharded(c, 0.02, 150, 0.1, seed=19)
+        assert r.ret == 1 and len(r.planes) == len(planes)
+        removed_total = sum(len(x) for x in r.clusters[:-1])
+        assert c.n == len(pts) - removed_total and c.n_created == len(pts)
+        for k in range(len(planes)):
+            assert np.array_equal(r.clusters[k], clusters[k].astype(np.int64))
+            assert np.array_equal(r.clusters[k], oclusters[k].astype(np.int64))
+            assert np.array_equal(r.planes[k], planes[k])
+            assert np.allclose(r.planes[k], oplanes[k], rtol=0, atol=PARAM_TOL)
+        # the shrunk cloud still answers every entry point: a fit on it equals a fit on a fresh upload of
+        # the remaining points (indices mapped through the removal)
+        keep = np.ones(len(pts), dtype=bool)
+        for x in r.clusters[:-1]:
+            keep[x] = False
+        rest = np.nonzero(keep)[0]
+        g = c.fit(0, 0.02, 200, 1.0, seed=5)
+        with capi.Cloud(pts[rest]) as c2:
+            g2 = c2.fit(0, 0.02, 200, 1.0, seed=5)
+        assert g.stats["best_index"] == g2.stats["best_index"] and np.array_equal(g.params, g2.params)
+        assert np.array_equal(g.inliers.astype(np.int64), rest[g2.inliers.astype(np.int64)])
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_culled_scoring_robustness(capi, orc, kind):
     """The box tests of cull_k must never drop an inlier: clouds far from the origin, tiny and huge
