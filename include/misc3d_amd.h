@@ -183,6 +183,27 @@ int m3d_registration_ransac(const double *src, size_t n_src, const double *dst, 
                             double confidence, const uint64_t *seed, int device, double T[16],
                             m3d_reg_stats *stats);
 
+/* The same RANSAC as a session, cut into the steps a multi-GPU driver needs (hypotheses sharded, clouds and
+ * grid replicated on every GPU).  Every rank creates an identical session (same seed):
+ *   m3d_reg_begin_chunk   draws the triples of the next chunk of iterations, 3-point Kabsch + checkers;
+ *                         *n_survivors = hypotheses that need validation.  Return 1 = chunk ready,
+ *                         0 = the loop is over (call m3d_reg_finish), <0 error.
+ *   m3d_reg_validate      (inlier count, sum of squared nearest distances) of survivors [s_begin, s_end) --
+ *                         this rank's shard; s_begin must be a multiple of 64.
+ *   m3d_reg_replay        sequential best-update / est_k rule over the chunk, given the records of ALL its
+ *                         survivors (after the all-gather); identical inputs -> identical state on all ranks.
+ * m3d_registration_ransac is exactly this loop with one shard. */
+typedef struct m3d_reg m3d_reg;
+m3d_reg *m3d_reg_create(const double *src, size_t n_src, const double *dst, size_t n_dst,
+                        const size_t *corr_src, const size_t *corr_dst, size_t m, double threshold,
+                        int max_iter, double edge_length_threshold, double confidence,
+                        const uint64_t *seed, int device);
+void m3d_reg_destroy(m3d_reg *reg);
+int m3d_reg_begin_chunk(m3d_reg *reg, size_t *n_survivors);
+int m3d_reg_validate(m3d_reg *reg, size_t s_begin, size_t s_end, uint32_t *counts, double *sums);
+int m3d_reg_replay(m3d_reg *reg, const uint32_t *counts, const double *sums);
+int m3d_reg_finish(m3d_reg *reg, double T[16], m3d_reg_stats *stats);
+
 /* ---- registration::ANNMatcher::Match, src/correspondence_matching.cpp:52-84 ------------------- */
 /* feat_*: Eigen MatrixXd dim x N column-major = N descriptors of dim contiguous doubles.
  * method: 0 FLANN, 1 ANNOY (correspondence_matching.h MatchMethod); both run the exact mutual

@@ -124,6 +124,15 @@ def lib():
         L.m3d_registration_ransac.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                               C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double, C.c_double,
                                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.m3d_reg_create.restype = C.c_void_p
+        L.m3d_reg_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int]
+        L.m3d_reg_destroy.restype = None
+        L.m3d_reg_destroy.argtypes = [C.c_void_p]
+        L.m3d_reg_begin_chunk.argtypes = [C.c_void_p, C.c_void_p]
+        L.m3d_reg_validate.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.m3d_reg_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_reg_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_match_last_fallbacks.restype = C.c_uint64
         L.m3d_match_last_fallbacks.argtypes = []
         L.m3d_match_mutual_nn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
@@ -411,6 +420,72 @@ def registration_ransac(src, dst, corr_src, corr_dst, threshold=0.01, max_iter=1
                                          C.cast(sref, C.c_void_p) if sref else None, device, _p(T),
                                          C.cast(C.byref(st), C.c_void_p)))
     return T.reshape(4, 4), st.asdict()
+
+
+class RegSession:
+    """m3d_reg: compute_transformation_ransac cut into begin_chunk / validate / replay (multi-GPU driver:
+    misc3d_amd.distributed.registration_ransac_sharded).  Every rank must pass the same explicit seed."""
+
+    def __init__(self, src, dst, corr_src, corr_dst, threshold=0.01, max_iter=100000, edge_length_threshold=0.9,
+                 confidence=0.999, seed=0, device=0):
+        src = _f64(src).reshape(-1, 3)
+        dst = _f64(dst).reshape(-1, 3)
+        cs = np.ascontiguousarray(corr_src, dtype=np.uint64)
+        cd = np.ascontiguousarray(corr_dst, dtype=np.uint64)
+        if len(cs) != len(cd):
+            raise ValueError("correspondence lists differ in length")
+        _s, sref = _seed_ref(seed)
+        self._h = lib().m3d_reg_create(_p(src), len(src), _p(dst), len(dst), _p(cs), _p(cd), len(cs), threshold,
+                                       max_iter, edge_length_threshold, confidence,
+                                       C.cast(sref, C.c_void_p) if sref else None, device)
+        if not self._h:
+            msg = last_error()
+            code = ERR_TOO_FEW_POINTS if "less than 3" in msg else (ERR_DEVICE if "HIP" in msg or "device" in msg
+                                                                     else ERR_INVALID_ARG)
+            raise M3DError(code, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().m3d_reg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def begin_chunk(self):
+        """-> number of survivors of the next chunk, or None when the loop is over"""
+        ns = C.c_size_t(0)
+        rc = _check(lib().m3d_reg_begin_chunk(self._h, C.cast(C.byref(ns), C.c_void_p)))
+        return int(ns.value) if rc == 1 else None
+
+    def validate(self, s_begin, s_end):
+        n = max(s_end - s_begin, 0)
+        counts = np.zeros(max(n, 1), dtype=np.uint32)
+        sums = np.zeros(max(n, 1), dtype=np.float64)
+        _check(lib().m3d_reg_validate(self._h, s_begin, s_end, _p(counts), _p(sums)))
+        return counts[:n], sums[:n]
+
+    def replay(self, counts, sums):
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        sums = np.ascontiguousarray(sums, dtype=np.float64)
+        if len(counts) == 0:
+            counts, sums = np.zeros(1, dtype=np.uint32), np.zeros(1)
+        _check(lib().m3d_reg_replay(self._h, _p(counts), _p(sums)))
+
+    def finish(self):
+        T = np.zeros(16)
+        st = RegStats()
+        _check(lib().m3d_reg_finish(self._h, _p(T), C.cast(C.byref(st), C.c_void_p)))
+        return T.reshape(4, 4), st.asdict()
 
 
 def match_last_fallbacks():

@@ -174,390 +174,743 @@ int m3d_kabsch(const double* src, const double* dst, size_t n, int scaling, int 
     return done(rc);
 }
 
-int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, size_t n_dst,
-                            const size_t* corr_src, const size_t* corr_dst, size_t m, double threshold,
-                            int max_iter, double edge_length_threshold, double confidence,
-                            const uint64_t* seed, int device, double* T_out, m3d_reg_stats* stats) {
-    const double t_begin = now_ms();
-    if (!T_out || ((!src && n_src) || (!dst && n_dst)) || (m && (!corr_src || !corr_dst)))
-        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Registration session: the Open3D RANSAC loop cut into the steps a multi-GPU driver needs
+// (hypotheses sharded, clouds and grid replicated):
+//   begin_chunk   draw the triples of the next chunk of iterations (the generator lives in the session, so
+//                 identically seeded ranks draw identical triples), 3-point Kabsch + checkers for all of
+//                 them, survivor list + their transformations on the device
+//   validate      count + sum of squared nearest distances for survivors [s_begin, s_end) -- the shard
+//   replay        the sequential best-update / est_k rule over the whole chunk, given every survivor's
+//                 (count, sum): identical inputs on every rank -> identical state on every rank
+// m3d_registration_ransac is the single-GPU loop over the same three steps.
+// ------------------------------------------------------------------------------------------------
+struct m3d_reg {
+    DeviceCtx* ctx = nullptr;
+    m3d_cloud *csrc = nullptr, *cdst = nullptr;
+    Scratch S;
+    RegCtx R;
+    GridDesc g;
+    CloudView src_sorted;
+    size_t n_src = 0, n_dst = 0, m = 0;
+    double threshold = 0, edge_length_threshold = 0, confidence = 0;
+    int max_iter = 0;
+    bool trivial = false;   // Open3D returns the default RegistrationResult without looping
+    std::mt19937 rng;
+    std::uniform_int_distribution<int> pick;
+    double best_fit = 0, best_rmse = 0;
+    uint32_t best_cnt = 0;   // inlier count behind best_fit
+    bool reg_prune = true;
+    bool best_rmse_known = true;
+    int64_t best_index = -1;
+    int est_k_global = 0, est_k_local = 0;
+    uint64_t total_validation = 0, ties = 0, exact_evals = 0;
+    int64_t iters = 0;
+    double* best_T_dev = nullptr;
+    double best_T_host[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    uint32_t n_tiles = 0;
+    std::vector<uint32_t> tri, survivors, h_counts;
+    std::vector<double> h_sum2;  // order-free sums of the nearest squared distances per survivor
+    double best_sum2 = 0.0;      // the same for the current best
+    std::vector<uint8_t> pass;
+    size_t chunk = 256;
+    int itr = 0;
+    int n_exec = 0;          // iterations of the chunk in flight
+    bool finished = false;
+    double t_begin = 0;
+};
+
+namespace {
+
+int reg_setup(m3d_reg& q, const double* src, const double* dst, const size_t* corr_src, const size_t* corr_dst,
+              const uint64_t* seed) {
+    DeviceCtx* ctx = q.ctx;
+    Scratch& S = q.S;
+    RegCtx& R = q.R;
+    GridDesc& g = q.g;
+    CloudView& src_sorted = q.src_sorted;
+    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
+    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
+    const int max_iter = q.max_iter;
+    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
+    (void)edge_length_threshold; (void)confidence; (void)max_iter;
+
+    HIPCHK(hipSetDevice(ctx->device));
+    R.ctx = ctx;
+    R.src = q.csrc->view();
+    // the count kernel reads whole tiles of kRegTile points: the cloud padding (kScoreTile) covers it
+    static_assert(kScoreTile % kRegTile == 0, "padding of resident clouds must cover the reg tiles");
+    R.dst = q.cdst->view();
+    R.s = &S;
+    R.m = (uint32_t)m;
+    R.thr = threshold;
+
+    // ---- grid over the target (bounding box on the host: one pass over n_dst points)
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n_dst; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double v = dst[3 * i + k];
+            if (std::isfinite(v)) {
+                lo[k] = std::min(lo[k], v);
+                hi[k] = std::max(hi[k], v);
+            }
+        }
+    for (int k = 0; k < 3; ++k)
+        if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;
+    // cell edge h = 1.001 thr / K, K = 4, 2, 1 ... while the dense cell table fits; if even K = 1
+    // does not fit the cell is doubled (a coarser grid with K = 1 still covers radius thr)
+    int K = 4;
+    double h = threshold * 1.001 / K;
+    uint64_t dims[3];
+    for (;;) {
+        bool fits = true;
+        uint64_t cells = 1;
+        for (int k = 0; k < 3; ++k) {
+            const double ext = (hi[k] - lo[k]) / h;
+            if (!(ext < 1e9)) {
+                fits = false;
+                break;
+            }
+            dims[k] = (uint64_t)ext + 1 + 2 * (uint64_t)(K + 1);
+            cells *= dims[k];
+            if (cells > ((uint64_t)1 << 27)) fits = false;
+        }
+        if (fits) break;
+        if (K > 1)
+            K /= 2;
+        h *= 2.0;
+    }
+    g.K = K;
+    g.morton_bits = 0;
+    g.ox = lo[0] - (K + 1) * h;
+    g.oy = lo[1] - (K + 1) * h;
+    g.oz = lo[2] - (K + 1) * h;
+    g.inv_h = 1.0 / h;
+    g.r2 = threshold * threshold;  // radius * radius, KDTreeFlann::SearchHybrid
+    g.h2_in = (0.999 * h) * (0.999 * h);
+    g.nx = (uint32_t)dims[0];
+    g.ny = (uint32_t)dims[1];
+    g.nz = (uint32_t)dims[2];
+    R.g = g;
+    const uint32_t ncell = g.nx * g.ny * g.nz;
+    RESERVE(S.cell_of_point, sizeof(uint32_t) * n_dst);
+    RESERVE(S.cell_start, sizeof(uint32_t) * ((size_t)ncell + 1));
+    RESERVE(S.fill, sizeof(uint32_t) * (size_t)ncell);
+    RESERVE(S.tile_sums, sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1));
+    RESERVE(S.total, 16);
+    RESERVE(S.qx, sizeof(double) * n_dst);
+    RESERVE(S.qy, sizeof(double) * n_dst);
+    RESERVE(S.qz, sizeof(double) * n_dst);
+    launch_grid_build(R.dst, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
+                      S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
+                      S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream);
+    // neighbour lists for phase 1 of the search (27 entries of 32 B per target point: bounded to
+    // 2 M target points; beyond that, or with M3D_REG_NL=0, the row-range search is used)
+    {
+        const char* nl_env = std::getenv("M3D_REG_NL");
+        if (!(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
+            RESERVE(S.nl_start, sizeof(uint32_t) * ((size_t)ncell + 1));
+            launch_nl_count(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(),
+                            S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 1, ctx->stream);
+            uint32_t entries = 0;
+            HIPCHK(hipMemcpyAsync(&entries, S.nl_start.as<uint32_t>() + ncell, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            RESERVE(S.nl_pts, sizeof(double4) * std::max<size_t>(entries, 1));
+            launch_nl_fill(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.qx.as<double>(),
+                           S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream);
+            g.nl_start = S.nl_start.as<uint32_t>();
+            g.nl_pts = S.nl_pts.as<double4>();
+            R.g = g;
+        }
+    }
+
+    // ---- spatially sorted copy of the SOURCE cloud for the validation kernel: counts and
+    // order-free sums do not depend on the point order, and lanes of a wave that hold
+    // neighbouring source points probe the same target cells (L1/L2 hits instead of scattered
+    // gathers).  Same counting sort over the source bounding box.  Points with
+    // non-finite coordinates drop out (they can never have a neighbour).
+    src_sorted = R.src;
+    {
+        double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = 0; i < n_src; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const double v = src[3 * i + k];
+                if (std::isfinite(v)) {
+                    slo[k] = std::min(slo[k], v);
+                    shi[k] = std::max(shi[k], v);
+                }
+            }
+        double ext = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            if (!(slo[k] <= shi[k])) slo[k] = shi[k] = 0.0;
+            ext = std::max(ext, shi[k] - slo[k]);
+        }
+        if (ext > 0.0 && std::isfinite(ext)) {
+            GridDesc gs;
+            // Hilbert order over 128^3 cells: the 64 points of a wave form a compact patch, so the
+            // lanes probe the same few target cells (M3D_REG_SRC_ORDER=rows: x-rows of a 64^3 grid)
+            const char* ord_env = std::getenv("M3D_REG_SRC_ORDER");
+            const bool hilbert = !(ord_env && ord_env[0] == 'r');
+            const double hs = hilbert ? ext / 127.0 : ext / 63.0;
+            gs.K = 0;
+            gs.morton_bits = hilbert ? (7u | 0x100u) : 0u;
+            gs.ox = slo[0];
+            gs.oy = slo[1];
+            gs.oz = slo[2];
+            gs.inv_h = 1.0 / hs;
+            gs.r2 = gs.h2_in = 0.0;
+            gs.nx = hilbert ? 128u : (uint32_t)((shi[0] - slo[0]) / hs) + 2;
+            gs.ny = hilbert ? 128u : (uint32_t)((shi[1] - slo[1]) / hs) + 2;
+            gs.nz = hilbert ? 128u : (uint32_t)((shi[2] - slo[2]) / hs) + 2;
+            const uint32_t ncs = gs.nx * gs.ny * gs.nz;
+            const uint32_t np = R.src.n_pad;
+            RESERVE(S.s_cell_of_point, sizeof(uint32_t) * n_src);
+            RESERVE(S.s_cell_start, sizeof(uint32_t) * ((size_t)ncs + 1));
+            RESERVE(S.s_fill, sizeof(uint32_t) * (size_t)ncs);
+            RESERVE(S.s_tile_sums, sizeof(uint32_t) * ((size_t)(ncs + 2047) / 2048 + 1));
+            RESERVE(S.sx, sizeof(double) * np);
+            RESERVE(S.sy, sizeof(double) * np);
+            RESERVE(S.sz, sizeof(double) * np);
+            launch_fill_nan(S.sx.as<double>(), np, ctx->stream);
+            launch_fill_nan(S.sy.as<double>(), np, ctx->stream);
+            launch_fill_nan(S.sz.as<double>(), np, ctx->stream);
+            launch_grid_build(R.src, gs, S.s_cell_of_point.as<uint32_t>(), S.s_cell_start.as<uint32_t>(),
+                              S.s_fill.as<uint32_t>(), S.s_tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 2,
+                              S.sx.as<double>(), S.sy.as<double>(), S.sz.as<double>(), ctx->stream);
+            src_sorted.x = S.sx.as<double>();
+            src_sorted.y = S.sy.as<double>();
+            src_sorted.z = S.sz.as<double>();
+        }
+    }
+
+    // ---- correspondences (CorrespondenceSet of Vector2i, transform_estimation.cpp:135-140)
+    std::vector<uint32_t> cs(m), cd(m);
+    for (size_t i = 0; i < m; ++i) {
+        cs[i] = (uint32_t)corr_src[i];
+        cd[i] = (uint32_t)corr_dst[i];
+    }
+    RESERVE(S.corr_src, sizeof(uint32_t) * m);
+    RESERVE(S.corr_dst, sizeof(uint32_t) * m);
+    HIPCHK(hipMemcpyAsync(S.corr_src.p, cs.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(S.corr_dst.p, cd.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+
+    // ---- RANSAC state
+    std::random_device rd;
+    q.rng = std::mt19937((std::mt19937::result_type)((seed ? *seed : (uint64_t)rd()) & 0xffffffffull));
+    q.pick = std::uniform_int_distribution<int>(0, (int)m - 1);  // utility::UniformRandIntGenerator(0, M-1)
+    const char* prune_env = std::getenv("M3D_REG_PRUNE");
+    q.reg_prune = !(prune_env && prune_env[0] == '0');
+    q.est_k_global = q.est_k_local = max_iter;
+    RESERVE(S.one_T, sizeof(double) * kRegTStride * 2);
+    q.best_T_dev = S.one_T.as<double>();
+    q.n_tiles = R.src.n_pad / kRegTile;
+    return M3D_OK;
+}
+
+// returns M3D_OK with *n_survivors set, or M3D_FALSE when the loop is over
+int reg_begin_chunk(m3d_reg& q, size_t* n_survivors) {
+    DeviceCtx* ctx = q.ctx;
+    Scratch& S = q.S;
+    RegCtx& R = q.R;
+    GridDesc& g = q.g;
+    CloudView& src_sorted = q.src_sorted;
+    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
+    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
+    const int max_iter = q.max_iter;
+    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
+    (void)edge_length_threshold; (void)confidence; (void)max_iter;
+    auto& rng = q.rng;
+    auto& pick = q.pick;
+    auto& best_fit = q.best_fit;
+    auto& best_rmse = q.best_rmse;
+    auto& best_cnt = q.best_cnt;
+    const bool reg_prune = q.reg_prune;
+    auto& best_rmse_known = q.best_rmse_known;
+    auto& best_index = q.best_index;
+    auto& est_k_global = q.est_k_global;
+    auto& est_k_local = q.est_k_local;
+    auto& total_validation = q.total_validation;
+    auto& ties = q.ties;
+    auto& exact_evals = q.exact_evals;
+    auto& iters = q.iters;
+    double* const best_T_dev = q.best_T_dev;
+    auto& best_T_host = q.best_T_host;
+    const uint32_t n_tiles = q.n_tiles;
+    auto& tri = q.tri;
+    auto& survivors = q.survivors;
+    auto& h_counts = q.h_counts;
+    auto& h_sum2 = q.h_sum2;
+    auto& best_sum2 = q.best_sum2;
+    auto& pass = q.pass;
+    auto& chunk = q.chunk;
+    auto& itr = q.itr;
+    (void)rng; (void)pick; (void)best_fit; (void)best_rmse; (void)best_cnt; (void)reg_prune; (void)best_rmse_known;
+    (void)best_index; (void)est_k_global; (void)est_k_local; (void)total_validation; (void)ties; (void)exact_evals;
+    (void)iters; (void)best_T_dev; (void)best_T_host; (void)n_tiles; (void)tri; (void)survivors; (void)h_counts;
+    (void)h_sum2; (void)best_sum2; (void)pass; (void)chunk; (void)itr;
+    *n_survivors = 0;
+    if (q.trivial || q.finished || !(itr < max_iter && itr < est_k_global)) {
+        q.finished = true;
+        return M3D_FALSE;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+
+    // iterations [itr, itr + n_exec) all satisfy itr < est_k_global as of now; est_k can only
+    // shrink while replaying, in which case the tail of the chunk is discarded (its draws
+    // would not have happened: the generator is rewound by re-drawing from a saved state)
+    const int n_exec = (int)std::min<size_t>(chunk, (size_t)(std::min(max_iter, est_k_global) - itr));
+    q.n_exec = n_exec;
+    tri.resize((size_t)n_exec * 3);
+    for (int k = 0; k < n_exec * 3; ++k) tri[k] = (uint32_t)pick(rng);
+    RESERVE(S.triples, sizeof(uint32_t) * 3 * (size_t)n_exec);
+    RESERVE(S.T12, sizeof(double) * kRegTStride * (size_t)n_exec);
+    RESERVE(S.pass, (size_t)n_exec);
+    HIPCHK(hipMemcpyAsync(S.triples.p, tri.data(), sizeof(uint32_t) * 3 * (size_t)n_exec,
+                          hipMemcpyHostToDevice, ctx->stream));
+    launch_kabsch3_check(R.src, R.dst, S.corr_src.as<uint32_t>(), S.corr_dst.as<uint32_t>(),
+                         S.triples.as<uint32_t>(), (uint32_t)n_exec, edge_length_threshold, threshold,
+                         S.T12.as<double>(), S.pass.as<uint8_t>(), ctx->stream);
+    pass.resize(n_exec);
+    HIPCHK(hipMemcpyAsync(pass.data(), S.pass.p, (size_t)n_exec, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    survivors.clear();
+    for (int k = 0; k < n_exec; ++k)
+        if (pass[k]) survivors.push_back((uint32_t)k);
+    const uint32_t ns = (uint32_t)survivors.size();
+    h_counts.assign(ns, 0);
+    if (ns) {
+        const uint32_t s_pad = round_up(ns, 64);
+        RESERVE(S.list, sizeof(uint32_t) * ns);
+        RESERVE(S.Ts, sizeof(double) * kRegTStride * ((size_t)s_pad + 1));
+        RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * s_pad);
+        RESERVE(S.partial_sum, sizeof(double) * (size_t)n_tiles * s_pad);
+        RESERVE(S.sum2, sizeof(double) * s_pad);
+        RESERVE(S.counts, sizeof(uint32_t) * s_pad);
+        HIPCHK(hipMemcpyAsync(S.list.p, survivors.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice,
+                              ctx->stream));
+        launch_gather_T(S.T12.as<double>(), S.list.as<uint32_t>(), ns, s_pad + 1, S.Ts.as<double>(),
+                        ctx->stream);
+    }
+    *n_survivors = ns;
+    return M3D_OK;
+}
+
+// (count, sum of squared nearest distances) of survivors [s_begin, s_end) of the chunk in flight;
+// s_begin must be a multiple of 64 (the kernel works on groups of 64 hypotheses)
+int reg_validate(m3d_reg& q, size_t s_begin, size_t s_end, uint32_t* counts_out, double* sums_out) {
+    DeviceCtx* ctx = q.ctx;
+    Scratch& S = q.S;
+    RegCtx& R = q.R;
+    GridDesc& g = q.g;
+    CloudView& src_sorted = q.src_sorted;
+    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
+    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
+    const int max_iter = q.max_iter;
+    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
+    (void)edge_length_threshold; (void)confidence; (void)max_iter;
+    auto& rng = q.rng;
+    auto& pick = q.pick;
+    auto& best_fit = q.best_fit;
+    auto& best_rmse = q.best_rmse;
+    auto& best_cnt = q.best_cnt;
+    const bool reg_prune = q.reg_prune;
+    auto& best_rmse_known = q.best_rmse_known;
+    auto& best_index = q.best_index;
+    auto& est_k_global = q.est_k_global;
+    auto& est_k_local = q.est_k_local;
+    auto& total_validation = q.total_validation;
+    auto& ties = q.ties;
+    auto& exact_evals = q.exact_evals;
+    auto& iters = q.iters;
+    double* const best_T_dev = q.best_T_dev;
+    auto& best_T_host = q.best_T_host;
+    const uint32_t n_tiles = q.n_tiles;
+    auto& tri = q.tri;
+    auto& survivors = q.survivors;
+    auto& h_counts = q.h_counts;
+    auto& h_sum2 = q.h_sum2;
+    auto& best_sum2 = q.best_sum2;
+    auto& pass = q.pass;
+    auto& chunk = q.chunk;
+    auto& itr = q.itr;
+    (void)rng; (void)pick; (void)best_fit; (void)best_rmse; (void)best_cnt; (void)reg_prune; (void)best_rmse_known;
+    (void)best_index; (void)est_k_global; (void)est_k_local; (void)total_validation; (void)ties; (void)exact_evals;
+    (void)iters; (void)best_T_dev; (void)best_T_host; (void)n_tiles; (void)tri; (void)survivors; (void)h_counts;
+    (void)h_sum2; (void)best_sum2; (void)pass; (void)chunk; (void)itr;
+    const uint32_t ns_all = (uint32_t)survivors.size();
+    if (s_begin == s_end) return M3D_OK;
+    if (s_begin > s_end || s_end > ns_all || (s_begin % 64) != 0)
+        return fail(M3D_ERR_INVALID_ARG, "m3d_reg_validate: bad survivor range");
+    const uint32_t ns = (uint32_t)(s_end - s_begin);
+    HIPCHK(hipSetDevice(ctx->device));
+    {
+        const uint32_t s_pad = round_up(ns, 64);
+        const double* Ts = S.Ts.as<double>() + s_begin * kRegTStride;   // records behind the shard are real or NaN padding
+        RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * s_pad);
+        RESERVE(S.partial_sum, sizeof(double) * (size_t)n_tiles * s_pad);
+        RESERVE(S.sum2, sizeof(double) * s_pad);
+        RESERVE(S.counts, sizeof(uint32_t) * s_pad);
+
+        RESERVE(S.keep, s_pad);
+        // bound-and-prune against the best of EARLIER chunks (M3D_REG_PRUNE=0 switches it off)
+        launch_reg_validate(src_sorted, Ts, s_pad, g, S.cell_start.as<uint32_t>(),
+                            S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
+                            S.partial.as<uint32_t>(), S.partial_sum.as<double>(), S.sum2.as<double>(),
+                            reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream);
+        HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
+        launch_reduce_partials(S.partial.as<uint32_t>(), n_tiles, s_pad, S.counts.as<uint32_t>(),
+                               ctx->stream);
+        HIPCHK(hipMemcpyAsync(counts_out, S.counts.p, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost,
+                              ctx->stream));
+        HIPCHK(hipMemcpyAsync(sums_out, S.sum2.p, sizeof(double) * ns, hipMemcpyDeviceToHost,
+                              ctx->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return M3D_OK;
+}
+
+// sequential replay of the chunk in flight; counts / sums: one entry per survivor, in survivor order
+int reg_replay(m3d_reg& q, const uint32_t* counts_in, const double* sums_in) {
+    DeviceCtx* ctx = q.ctx;
+    Scratch& S = q.S;
+    RegCtx& R = q.R;
+    GridDesc& g = q.g;
+    CloudView& src_sorted = q.src_sorted;
+    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
+    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
+    const int max_iter = q.max_iter;
+    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
+    (void)edge_length_threshold; (void)confidence; (void)max_iter;
+    auto& rng = q.rng;
+    auto& pick = q.pick;
+    auto& best_fit = q.best_fit;
+    auto& best_rmse = q.best_rmse;
+    auto& best_cnt = q.best_cnt;
+    const bool reg_prune = q.reg_prune;
+    auto& best_rmse_known = q.best_rmse_known;
+    auto& best_index = q.best_index;
+    auto& est_k_global = q.est_k_global;
+    auto& est_k_local = q.est_k_local;
+    auto& total_validation = q.total_validation;
+    auto& ties = q.ties;
+    auto& exact_evals = q.exact_evals;
+    auto& iters = q.iters;
+    double* const best_T_dev = q.best_T_dev;
+    auto& best_T_host = q.best_T_host;
+    const uint32_t n_tiles = q.n_tiles;
+    auto& tri = q.tri;
+    auto& survivors = q.survivors;
+    auto& h_counts = q.h_counts;
+    auto& h_sum2 = q.h_sum2;
+    auto& best_sum2 = q.best_sum2;
+    auto& pass = q.pass;
+    auto& chunk = q.chunk;
+    auto& itr = q.itr;
+    (void)rng; (void)pick; (void)best_fit; (void)best_rmse; (void)best_cnt; (void)reg_prune; (void)best_rmse_known;
+    (void)best_index; (void)est_k_global; (void)est_k_local; (void)total_validation; (void)ties; (void)exact_evals;
+    (void)iters; (void)best_T_dev; (void)best_T_host; (void)n_tiles; (void)tri; (void)survivors; (void)h_counts;
+    (void)h_sum2; (void)best_sum2; (void)pass; (void)chunk; (void)itr;
+    const int n_exec = q.n_exec;
+    HIPCHK(hipSetDevice(ctx->device));
+    h_counts.assign(counts_in, counts_in + survivors.size());
+    h_sum2.assign(sums_in, sums_in + survivors.size());
+
+    // ---- sequential replay of the chunk
+    uint32_t sv = 0;
+    int k = 0;
+    for (; k < n_exec; ++k) {
+        const int it = itr + k;
+        if (!(it < est_k_global)) break;  // `if (itr < est_k_global)` of the Open3D loop
+        iters++;
+        if (!pass[k]) continue;
+        const uint32_t cnt = h_counts[sv];
+        const double a_t = cnt ? h_sum2[sv] : 0.0;
+        const double* T_dev = S.Ts.as<double>() + (size_t)sv * kRegTStride;
+        sv++;
+        const double fit = cnt ? (double)cnt / (double)n_src : 0.0;
+        bool better = fit > best_fit;
+        double rmse = 0.0;
+        bool rmse_known = cnt == 0;  // empty correspondence set: rmse = 0
+        if (!better && fit == best_fit && cnt == 0) {
+            better = false;  // 0 < best_rmse never holds (both are the empty result)
+        } else if (!better && fit == best_fit) {
+            // IsBetterRANSACThan on equal fitness: rmse = sqrt(err2 / n) with the same n on both
+            // sides, monotone in err2.  Order-free sums decide unless they are closer than the
+            // summation-order bound 2 n u sum (x2 safety); then the serial-order sums decide.
+            ties++;
+            const double nu4 = 4.0 * (double)cnt * 1.1102230246251565e-16;
+            if (a_t + nu4 * a_t < best_sum2 - nu4 * best_sum2) {
+                better = true;
+            } else if (a_t - nu4 * a_t > best_sum2 + nu4 * best_sum2) {
+                better = false;
+            } else {
+                uint64_t c2;
+                double e2;
+                int r = exact_err2(R, T_dev, &c2, &e2);
+                if (r != M3D_OK) return r;
+                if (c2 != cnt) return fail(M3D_ERR_INTERNAL, "validation count mismatch");
+                rmse = std::sqrt(e2 / (double)c2);
+                rmse_known = true;
+                exact_evals++;
+                if (!best_rmse_known) {
+                    r = exact_err2(R, best_T_dev, &c2, &e2);
+                    if (r != M3D_OK) return r;
+                    best_rmse = c2 ? std::sqrt(e2 / (double)c2) : 0.0;
+                    best_rmse_known = true;
+                    exact_evals++;
+                }
+                better = rmse < best_rmse;
+            }
+        }
+        if (better) {
+            best_fit = fit;
+            best_cnt = cnt;
+            best_rmse = rmse;
+            best_rmse_known = rmse_known;
+            best_sum2 = a_t;
+            best_index = it;
+            HIPCHK(hipMemcpyAsync(best_T_dev, T_dev, sizeof(double) * kRegTStride,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+            double ratio;
+            const int r = corr_inlier_ratio(R, best_T_dev, &ratio);
+            if (r != M3D_OK) return r;
+            const double est_d = std::log(1.0 - confidence) / std::log(1.0 - std::pow(ratio, 3.0));
+            est_k_local = est_d < (double)est_k_global ? ceil_to_int_x86(est_d) : est_k_local;
+        }
+        total_validation++;
+        if (est_k_local < est_k_global) est_k_global = est_k_local;
+    }
+    if (k < n_exec) {
+        // the loop went idle inside the chunk: nothing after it draws or runs
+        q.finished = true;
+        return M3D_OK;
+    }
+    itr += n_exec;
+    chunk = std::min<size_t>(chunk * 2, 16384);
+    return M3D_OK;
+}
+
+int reg_finish(m3d_reg& q, double* T_out, m3d_reg_stats* stats) {
+    DeviceCtx* ctx = q.ctx;
+    Scratch& S = q.S;
+    RegCtx& R = q.R;
+    GridDesc& g = q.g;
+    CloudView& src_sorted = q.src_sorted;
+    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
+    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
+    const int max_iter = q.max_iter;
+    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
+    (void)edge_length_threshold; (void)confidence; (void)max_iter;
+    auto& rng = q.rng;
+    auto& pick = q.pick;
+    auto& best_fit = q.best_fit;
+    auto& best_rmse = q.best_rmse;
+    auto& best_cnt = q.best_cnt;
+    const bool reg_prune = q.reg_prune;
+    auto& best_rmse_known = q.best_rmse_known;
+    auto& best_index = q.best_index;
+    auto& est_k_global = q.est_k_global;
+    auto& est_k_local = q.est_k_local;
+    auto& total_validation = q.total_validation;
+    auto& ties = q.ties;
+    auto& exact_evals = q.exact_evals;
+    auto& iters = q.iters;
+    double* const best_T_dev = q.best_T_dev;
+    auto& best_T_host = q.best_T_host;
+    const uint32_t n_tiles = q.n_tiles;
+    auto& tri = q.tri;
+    auto& survivors = q.survivors;
+    auto& h_counts = q.h_counts;
+    auto& h_sum2 = q.h_sum2;
+    auto& best_sum2 = q.best_sum2;
+    auto& pass = q.pass;
+    auto& chunk = q.chunk;
+    auto& itr = q.itr;
+    (void)rng; (void)pick; (void)best_fit; (void)best_rmse; (void)best_cnt; (void)reg_prune; (void)best_rmse_known;
+    (void)best_index; (void)est_k_global; (void)est_k_local; (void)total_validation; (void)ties; (void)exact_evals;
+    (void)iters; (void)best_T_dev; (void)best_T_host; (void)n_tiles; (void)tri; (void)survivors; (void)h_counts;
+    (void)h_sum2; (void)best_sum2; (void)pass; (void)chunk; (void)itr;
     static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::memcpy(T_out, I4, sizeof(I4));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->best_index = -1;
     }
+    if (q.trivial) return M3D_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+
+    if (best_index >= 0) {
+        HIPCHK(hipMemcpy(best_T_host, best_T_dev, sizeof(best_T_host), hipMemcpyDeviceToHost));
+        if (!best_rmse_known) {
+            uint64_t c2;
+            double e2;
+            const int r = exact_err2(R, best_T_dev, &c2, &e2);
+            if (r != M3D_OK) return r;
+            best_rmse = c2 ? std::sqrt(e2 / (double)c2) : 0.0;
+        }
+        std::memcpy(T_out, best_T_host, sizeof(best_T_host));
+    }
+    if (stats) {
+        stats->fitness = best_fit;
+        stats->inlier_rmse = best_rmse;
+        stats->validations = total_validation;
+        stats->iterations = iters;
+        stats->best_index = best_index;
+        stats->est_k = est_k_global;
+        stats->ties = ties;
+        stats->exact_rmse_evals = exact_evals;
+    }
+    if (stats) stats->ms_total = now_ms() - q.t_begin;
+    return M3D_OK;
+}
+
+// argument checks + uploads + grid; *rc_out < 0 on error (session NULL), M3D_OK otherwise
+m3d_reg* reg_create(const double* src, size_t n_src, const double* dst, size_t n_dst, const size_t* corr_src,
+                    const size_t* corr_dst, size_t m, double threshold, int max_iter, double edge_length_threshold,
+                    double confidence, const uint64_t* seed, int device, int* rc_out) {
+    *rc_out = M3D_OK;
+    auto bad = [&](int code) -> m3d_reg* {
+        *rc_out = code;
+        return nullptr;
+    };
+    if (((!src && n_src) || (!dst && n_dst)) || (m && (!corr_src || !corr_dst)))
+        return bad(fail(M3D_ERR_INVALID_ARG, "invalid argument"));
     if (n_src < 3 || n_dst < 3)  // transform_estimation.cpp:130-133
-        return fail(M3D_ERR_TOO_FEW_POINTS, "The number of points pair is less than 3.");
+        return bad(fail(M3D_ERR_TOO_FEW_POINTS, "The number of points pair is less than 3."));
     if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31) || m >= ((size_t)1 << 31))
-        return fail(M3D_ERR_INVALID_ARG, "too many points");
+        return bad(fail(M3D_ERR_INVALID_ARG, "too many points"));
     for (size_t i = 0; i < m; ++i)
         if (corr_src[i] >= n_src || corr_dst[i] >= n_dst)
-            return fail(M3D_ERR_INVALID_ARG, "correspondence index out of range");
+            return bad(fail(M3D_ERR_INVALID_ARG, "correspondence index out of range"));
+    m3d_reg* q = new m3d_reg();
+    q->t_begin = now_ms();
+    q->n_src = n_src;
+    q->n_dst = n_dst;
+    q->m = m;
+    q->threshold = threshold;
+    q->edge_length_threshold = edge_length_threshold;
+    q->confidence = confidence;
+    q->max_iter = max_iter;
     // Open3D: ransac_n < 3 || corres.size() < ransac_n || max_correspondence_distance <= 0 -> RegistrationResult()
-    if (m < 3 || !(threshold > 0.0)) return M3D_OK;
-
-    m3d_cloud* csrc = m3d_cloud_create(src, nullptr, n_src, device);
-    if (!csrc) return M3D_ERR_DEVICE;
-    m3d_cloud* cdst = m3d_cloud_create(dst, nullptr, n_dst, device);
-    if (!cdst) {
-        m3d_cloud_destroy(csrc);
-        return M3D_ERR_DEVICE;
+    if (m < 3 || !(threshold > 0.0)) {
+        q->trivial = true;
+        return q;
     }
-    DeviceCtx* ctx = csrc->ctx;
-    Scratch S;
-    int rc = M3D_OK;
+    q->csrc = m3d_cloud_create(src, nullptr, n_src, device);
+    q->cdst = q->csrc ? m3d_cloud_create(dst, nullptr, n_dst, device) : nullptr;
+    if (!q->csrc || !q->cdst) {
+        if (q->csrc) m3d_cloud_destroy(q->csrc);
+        delete q;
+        return bad(M3D_ERR_DEVICE);
+    }
+    q->ctx = q->csrc->ctx;
+    int rc;
     {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        rc = [&]() -> int {
-            HIPCHK(hipSetDevice(ctx->device));
-            RegCtx R;
-            R.ctx = ctx;
-            R.src = csrc->view();
-            // the count kernel reads whole tiles of kRegTile points: the cloud padding (kScoreTile) covers it
-            static_assert(kScoreTile % kRegTile == 0, "padding of resident clouds must cover the reg tiles");
-            R.dst = cdst->view();
-            R.s = &S;
-            R.m = (uint32_t)m;
-            R.thr = threshold;
-
-            // ---- grid over the target (bounding box on the host: one pass over n_dst points)
-            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (size_t i = 0; i < n_dst; ++i)
-                for (int k = 0; k < 3; ++k) {
-                    const double v = dst[3 * i + k];
-                    if (std::isfinite(v)) {
-                        lo[k] = std::min(lo[k], v);
-                        hi[k] = std::max(hi[k], v);
-                    }
-                }
-            for (int k = 0; k < 3; ++k)
-                if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;
-            // cell edge h = 1.001 thr / K, K = 4, 2, 1 ... while the dense cell table fits; if even K = 1
-            // does not fit the cell is doubled (a coarser grid with K = 1 still covers radius thr)
-            int K = 4;
-            double h = threshold * 1.001 / K;
-            uint64_t dims[3];
-            for (;;) {
-                bool fits = true;
-                uint64_t cells = 1;
-                for (int k = 0; k < 3; ++k) {
-                    const double ext = (hi[k] - lo[k]) / h;
-                    if (!(ext < 1e9)) {
-                        fits = false;
-                        break;
-                    }
-                    dims[k] = (uint64_t)ext + 1 + 2 * (uint64_t)(K + 1);
-                    cells *= dims[k];
-                    if (cells > ((uint64_t)1 << 27)) fits = false;
-                }
-                if (fits) break;
-                if (K > 1)
-                    K /= 2;
-                h *= 2.0;
-            }
-            GridDesc g;
-            g.K = K;
-            g.morton_bits = 0;
-            g.ox = lo[0] - (K + 1) * h;
-            g.oy = lo[1] - (K + 1) * h;
-            g.oz = lo[2] - (K + 1) * h;
-            g.inv_h = 1.0 / h;
-            g.r2 = threshold * threshold;  // radius * radius, KDTreeFlann::SearchHybrid
-            g.h2_in = (0.999 * h) * (0.999 * h);
-            g.nx = (uint32_t)dims[0];
-            g.ny = (uint32_t)dims[1];
-            g.nz = (uint32_t)dims[2];
-            R.g = g;
-            const uint32_t ncell = g.nx * g.ny * g.nz;
-            RESERVE(S.cell_of_point, sizeof(uint32_t) * n_dst);
-            RESERVE(S.cell_start, sizeof(uint32_t) * ((size_t)ncell + 1));
-            RESERVE(S.fill, sizeof(uint32_t) * (size_t)ncell);
-            RESERVE(S.tile_sums, sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1));
-            RESERVE(S.total, 16);
-            RESERVE(S.qx, sizeof(double) * n_dst);
-            RESERVE(S.qy, sizeof(double) * n_dst);
-            RESERVE(S.qz, sizeof(double) * n_dst);
-            launch_grid_build(R.dst, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
-                              S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
-                              S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream);
-            // neighbour lists for phase 1 of the search (27 entries of 32 B per target point: bounded to
-            // 2 M target points; beyond that, or with M3D_REG_NL=0, the row-range search is used)
-            {
-                const char* nl_env = std::getenv("M3D_REG_NL");
-                if (!(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
-                    RESERVE(S.nl_start, sizeof(uint32_t) * ((size_t)ncell + 1));
-                    launch_nl_count(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(),
-                                    S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 1, ctx->stream);
-                    uint32_t entries = 0;
-                    HIPCHK(hipMemcpyAsync(&entries, S.nl_start.as<uint32_t>() + ncell, sizeof(uint32_t),
-                                          hipMemcpyDeviceToHost, ctx->stream));
-                    HIPCHK(hipStreamSynchronize(ctx->stream));
-                    RESERVE(S.nl_pts, sizeof(double4) * std::max<size_t>(entries, 1));
-                    launch_nl_fill(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.qx.as<double>(),
-                                   S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream);
-                    g.nl_start = S.nl_start.as<uint32_t>();
-                    g.nl_pts = S.nl_pts.as<double4>();
-                    R.g = g;
-                }
-            }
-
-            // ---- spatially sorted copy of the SOURCE cloud for the validation kernel: counts and
-            // order-free sums do not depend on the point order, and lanes of a wave that hold
-            // neighbouring source points probe the same target cells (L1/L2 hits instead of scattered
-            // gathers).  Same counting sort over the source bounding box.  Points with
-            // non-finite coordinates drop out (they can never have a neighbour).
-            CloudView src_sorted = R.src;
-            {
-                double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                for (size_t i = 0; i < n_src; ++i)
-                    for (int k = 0; k < 3; ++k) {
-                        const double v = src[3 * i + k];
-                        if (std::isfinite(v)) {
-                            slo[k] = std::min(slo[k], v);
-                            shi[k] = std::max(shi[k], v);
-                        }
-                    }
-                double ext = 0.0;
-                for (int k = 0; k < 3; ++k) {
-                    if (!(slo[k] <= shi[k])) slo[k] = shi[k] = 0.0;
-                    ext = std::max(ext, shi[k] - slo[k]);
-                }
-                if (ext > 0.0 && std::isfinite(ext)) {
-                    GridDesc gs;
-                    // Hilbert order over 128^3 cells: the 64 points of a wave form a compact patch, so the
-                    // lanes probe the same few target cells (M3D_REG_SRC_ORDER=rows: x-rows of a 64^3 grid)
-                    const char* ord_env = std::getenv("M3D_REG_SRC_ORDER");
-                    const bool hilbert = !(ord_env && ord_env[0] == 'r');
-                    const double hs = hilbert ? ext / 127.0 : ext / 63.0;
-                    gs.K = 0;
-                    gs.morton_bits = hilbert ? (7u | 0x100u) : 0u;
-                    gs.ox = slo[0];
-                    gs.oy = slo[1];
-                    gs.oz = slo[2];
-                    gs.inv_h = 1.0 / hs;
-                    gs.r2 = gs.h2_in = 0.0;
-                    gs.nx = hilbert ? 128u : (uint32_t)((shi[0] - slo[0]) / hs) + 2;
-                    gs.ny = hilbert ? 128u : (uint32_t)((shi[1] - slo[1]) / hs) + 2;
-                    gs.nz = hilbert ? 128u : (uint32_t)((shi[2] - slo[2]) / hs) + 2;
-                    const uint32_t ncs = gs.nx * gs.ny * gs.nz;
-                    const uint32_t np = R.src.n_pad;
-                    RESERVE(S.s_cell_of_point, sizeof(uint32_t) * n_src);
-                    RESERVE(S.s_cell_start, sizeof(uint32_t) * ((size_t)ncs + 1));
-                    RESERVE(S.s_fill, sizeof(uint32_t) * (size_t)ncs);
-                    RESERVE(S.s_tile_sums, sizeof(uint32_t) * ((size_t)(ncs + 2047) / 2048 + 1));
-                    RESERVE(S.sx, sizeof(double) * np);
-                    RESERVE(S.sy, sizeof(double) * np);
-                    RESERVE(S.sz, sizeof(double) * np);
-                    launch_fill_nan(S.sx.as<double>(), np, ctx->stream);
-                    launch_fill_nan(S.sy.as<double>(), np, ctx->stream);
-                    launch_fill_nan(S.sz.as<double>(), np, ctx->stream);
-                    launch_grid_build(R.src, gs, S.s_cell_of_point.as<uint32_t>(), S.s_cell_start.as<uint32_t>(),
-                                      S.s_fill.as<uint32_t>(), S.s_tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 2,
-                                      S.sx.as<double>(), S.sy.as<double>(), S.sz.as<double>(), ctx->stream);
-                    src_sorted.x = S.sx.as<double>();
-                    src_sorted.y = S.sy.as<double>();
-                    src_sorted.z = S.sz.as<double>();
-                }
-            }
-
-            // ---- correspondences (CorrespondenceSet of Vector2i, transform_estimation.cpp:135-140)
-            std::vector<uint32_t> cs(m), cd(m);
-            for (size_t i = 0; i < m; ++i) {
-                cs[i] = (uint32_t)corr_src[i];
-                cd[i] = (uint32_t)corr_dst[i];
-            }
-            RESERVE(S.corr_src, sizeof(uint32_t) * m);
-            RESERVE(S.corr_dst, sizeof(uint32_t) * m);
-            HIPCHK(hipMemcpyAsync(S.corr_src.p, cs.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipMemcpyAsync(S.corr_dst.p, cd.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-
-            // ---- RANSAC loop
-            std::random_device rd;
-            std::mt19937 rng((std::mt19937::result_type)((seed ? *seed : (uint64_t)rd()) & 0xffffffffull));
-            std::uniform_int_distribution<int> pick(0, (int)m - 1);  // utility::UniformRandIntGenerator(0, M-1)
-            double best_fit = 0, best_rmse = 0;
-            uint32_t best_cnt = 0;   // inlier count behind best_fit
-            const char* prune_env = std::getenv("M3D_REG_PRUNE");
-            const bool reg_prune = !(prune_env && prune_env[0] == '0');
-            bool best_rmse_known = true;
-            int64_t best_index = -1;
-            int est_k_global = max_iter, est_k_local = max_iter;
-            uint64_t total_validation = 0, ties = 0, exact_evals = 0;
-            int64_t iters = 0;
-            RESERVE(S.one_T, sizeof(double) * kRegTStride * 2);
-            double* best_T_dev = S.one_T.as<double>();
-            double* trial_T_dev = S.one_T.as<double>() + kRegTStride;
-            double best_T_host[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-            const uint32_t n_tiles = R.src.n_pad / kRegTile;
-
-            std::vector<uint32_t> tri, survivors, h_counts;
-            std::vector<double> h_sum2;  // order-free sums of the nearest squared distances per survivor
-            double best_sum2 = 0.0;      // the same for the current best
-            std::vector<uint8_t> pass;
-            std::vector<int> itr_of;  // iteration index of each executed hypothesis of the chunk
-            size_t chunk = 256;
-            int itr = 0;
-            while (itr < max_iter && itr < est_k_global) {
-                // iterations [itr, itr + n_exec) all satisfy itr < est_k_global as of now; est_k can only
-                // shrink while replaying, in which case the tail of the chunk is discarded (its draws
-                // would not have happened: the generator is rewound by re-drawing from a saved state)
-                const int n_exec = (int)std::min<size_t>(chunk, (size_t)(std::min(max_iter, est_k_global) - itr));
-                const std::mt19937 rng_at_chunk_start = rng;
-                tri.resize((size_t)n_exec * 3);
-                for (int k = 0; k < n_exec * 3; ++k) tri[k] = (uint32_t)pick(rng);
-                RESERVE(S.triples, sizeof(uint32_t) * 3 * (size_t)n_exec);
-                RESERVE(S.T12, sizeof(double) * kRegTStride * (size_t)n_exec);
-                RESERVE(S.pass, (size_t)n_exec);
-                HIPCHK(hipMemcpyAsync(S.triples.p, tri.data(), sizeof(uint32_t) * 3 * (size_t)n_exec,
-                                      hipMemcpyHostToDevice, ctx->stream));
-                launch_kabsch3_check(R.src, R.dst, S.corr_src.as<uint32_t>(), S.corr_dst.as<uint32_t>(),
-                                     S.triples.as<uint32_t>(), (uint32_t)n_exec, edge_length_threshold, threshold,
-                                     S.T12.as<double>(), S.pass.as<uint8_t>(), ctx->stream);
-                pass.resize(n_exec);
-                HIPCHK(hipMemcpyAsync(pass.data(), S.pass.p, (size_t)n_exec, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(ctx->stream));
-                survivors.clear();
-                for (int k = 0; k < n_exec; ++k)
-                    if (pass[k]) survivors.push_back((uint32_t)k);
-                const uint32_t ns = (uint32_t)survivors.size();
-                h_counts.assign(ns, 0);
-                if (ns) {
-                    const uint32_t s_pad = round_up(ns, 64);
-                    RESERVE(S.list, sizeof(uint32_t) * ns);
-                    RESERVE(S.Ts, sizeof(double) * kRegTStride * ((size_t)s_pad + 1));
-                    RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * s_pad);
-                    RESERVE(S.partial_sum, sizeof(double) * (size_t)n_tiles * s_pad);
-                    RESERVE(S.sum2, sizeof(double) * s_pad);
-                    RESERVE(S.counts, sizeof(uint32_t) * s_pad);
-                    HIPCHK(hipMemcpyAsync(S.list.p, survivors.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice,
-                                          ctx->stream));
-                    launch_gather_T(S.T12.as<double>(), S.list.as<uint32_t>(), ns, s_pad + 1, S.Ts.as<double>(),
-                                    ctx->stream);
-                    RESERVE(S.keep, s_pad);
-                    // bound-and-prune against the best of EARLIER chunks (M3D_REG_PRUNE=0 switches it off)
-                    launch_reg_validate(src_sorted, S.Ts.as<double>(), s_pad, g, S.cell_start.as<uint32_t>(),
-                                        S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
-                                        S.partial.as<uint32_t>(), S.partial_sum.as<double>(), S.sum2.as<double>(),
-                                        reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream);
-                    HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
-                    launch_reduce_partials(S.partial.as<uint32_t>(), n_tiles, s_pad, S.counts.as<uint32_t>(),
-                                           ctx->stream);
-                    HIPCHK(hipMemcpyAsync(h_counts.data(), S.counts.p, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost,
-                                          ctx->stream));
-                    h_sum2.resize(ns);
-                    HIPCHK(hipMemcpyAsync(h_sum2.data(), S.sum2.p, sizeof(double) * ns, hipMemcpyDeviceToHost,
-                                          ctx->stream));
-                    HIPCHK(hipGetLastError());
-                    HIPCHK(hipStreamSynchronize(ctx->stream));
-                }
-                // ---- sequential replay of the chunk
-                uint32_t sv = 0;
-                int k = 0;
-                for (; k < n_exec; ++k) {
-                    const int it = itr + k;
-                    if (!(it < est_k_global)) break;  // `if (itr < est_k_global)` of the Open3D loop
-                    iters++;
-                    if (!pass[k]) continue;
-                    const uint32_t cnt = h_counts[sv];
-                    const double a_t = cnt ? h_sum2[sv] : 0.0;
-                    const double* T_dev = S.Ts.as<double>() + (size_t)sv * kRegTStride;
-                    sv++;
-                    const double fit = cnt ? (double)cnt / (double)n_src : 0.0;
-                    bool better = fit > best_fit;
-                    double rmse = 0.0;
-                    bool rmse_known = cnt == 0;  // empty correspondence set: rmse = 0
-                    if (!better && fit == best_fit && cnt == 0) {
-                        better = false;  // 0 < best_rmse never holds (both are the empty result)
-                    } else if (!better && fit == best_fit) {
-                        // IsBetterRANSACThan on equal fitness: rmse = sqrt(err2 / n) with the same n on both
-                        // sides, monotone in err2.  Order-free sums decide unless they are closer than the
-                        // summation-order bound 2 n u sum (x2 safety); then the serial-order sums decide.
-                        ties++;
-                        const double nu4 = 4.0 * (double)cnt * 1.1102230246251565e-16;
-                        if (a_t + nu4 * a_t < best_sum2 - nu4 * best_sum2) {
-                            better = true;
-                        } else if (a_t - nu4 * a_t > best_sum2 + nu4 * best_sum2) {
-                            better = false;
-                        } else {
-                            uint64_t c2;
-                            double e2;
-                            int r = exact_err2(R, T_dev, &c2, &e2);
-                            if (r != M3D_OK) return r;
-                            if (c2 != cnt) return fail(M3D_ERR_INTERNAL, "validation count mismatch");
-                            rmse = std::sqrt(e2 / (double)c2);
-                            rmse_known = true;
-                            exact_evals++;
-                            if (!best_rmse_known) {
-                                r = exact_err2(R, best_T_dev, &c2, &e2);
-                                if (r != M3D_OK) return r;
-                                best_rmse = c2 ? std::sqrt(e2 / (double)c2) : 0.0;
-                                best_rmse_known = true;
-                                exact_evals++;
-                            }
-                            better = rmse < best_rmse;
-                        }
-                    }
-                    if (better) {
-                        best_fit = fit;
-                        best_cnt = cnt;
-                        best_rmse = rmse;
-                        best_rmse_known = rmse_known;
-                        best_sum2 = a_t;
-                        best_index = it;
-                        HIPCHK(hipMemcpyAsync(best_T_dev, T_dev, sizeof(double) * kRegTStride,
-                                              hipMemcpyDeviceToDevice, ctx->stream));
-                        double ratio;
-                        const int r = corr_inlier_ratio(R, best_T_dev, &ratio);
-                        if (r != M3D_OK) return r;
-                        const double est_d = std::log(1.0 - confidence) / std::log(1.0 - std::pow(ratio, 3.0));
-                        est_k_local = est_d < (double)est_k_global ? ceil_to_int_x86(est_d) : est_k_local;
-                    }
-                    total_validation++;
-                    if (est_k_local < est_k_global) est_k_global = est_k_local;
-                }
-                if (k < n_exec) {
-                    // the loop went idle inside the chunk: nothing after it draws or runs
-                    (void)rng_at_chunk_start;
-                    break;
-                }
-                itr += n_exec;
-                chunk = std::min<size_t>(chunk * 2, 16384);
-            }
-            if (best_index >= 0) {
-                HIPCHK(hipMemcpy(best_T_host, best_T_dev, sizeof(best_T_host), hipMemcpyDeviceToHost));
-                if (!best_rmse_known) {
-                    uint64_t c2;
-                    double e2;
-                    const int r = exact_err2(R, best_T_dev, &c2, &e2);
-                    if (r != M3D_OK) return r;
-                    best_rmse = c2 ? std::sqrt(e2 / (double)c2) : 0.0;
-                }
-                std::memcpy(T_out, best_T_host, sizeof(best_T_host));
-            }
-            (void)trial_T_dev;
-            if (stats) {
-                stats->fitness = best_fit;
-                stats->inlier_rmse = best_rmse;
-                stats->validations = total_validation;
-                stats->iterations = iters;
-                stats->best_index = best_index;
-                stats->est_k = est_k_global;
-                stats->ties = ties;
-                stats->exact_rmse_evals = exact_evals;
-            }
-            return M3D_OK;
-        }();
-        (void)hipStreamSynchronize(ctx->stream);
-        S.release();
+        std::lock_guard<std::mutex> lock(q->ctx->mu);
+        rc = reg_setup(*q, src, dst, corr_src, corr_dst, seed);
+        (void)hipStreamSynchronize(q->ctx->stream);
     }
-    m3d_cloud_destroy(csrc);
-    m3d_cloud_destroy(cdst);
-    if (stats) stats->ms_total = now_ms() - t_begin;
+    if (rc != M3D_OK) {
+        m3d_reg_destroy(q);
+        return bad(rc);
+    }
+    return q;
+}
+
+}  // namespace
+
+extern "C" {
+
+void m3d_reg_destroy(m3d_reg* q) {
+    if (!q) return;
+    if (q->ctx) {
+        std::lock_guard<std::mutex> lock(q->ctx->mu);
+        (void)hipSetDevice(q->ctx->device);
+        (void)hipStreamSynchronize(q->ctx->stream);
+        q->S.release();
+    }
+    if (q->csrc) m3d_cloud_destroy(q->csrc);
+    if (q->cdst) m3d_cloud_destroy(q->cdst);
+    delete q;
+}
+
+m3d_reg* m3d_reg_create(const double* src, size_t n_src, const double* dst, size_t n_dst, const size_t* corr_src,
+                        const size_t* corr_dst, size_t m, double threshold, int max_iter,
+                        double edge_length_threshold, double confidence, const uint64_t* seed, int device) {
+    int rc;
+    return reg_create(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter, edge_length_threshold,
+                      confidence, seed, device, &rc);
+}
+
+int m3d_reg_begin_chunk(m3d_reg* q, size_t* n_survivors) {
+    if (!q || !n_survivors) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (q->trivial) {
+        *n_survivors = 0;
+        return M3D_FALSE;
+    }
+    std::lock_guard<std::mutex> lock(q->ctx->mu);
+    return reg_begin_chunk(*q, n_survivors);
+}
+
+int m3d_reg_validate(m3d_reg* q, size_t s_begin, size_t s_end, uint32_t* counts, double* sums) {
+    if (!q || q->trivial || (s_end > s_begin && (!counts || !sums))) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    std::lock_guard<std::mutex> lock(q->ctx->mu);
+    return reg_validate(*q, s_begin, s_end, counts, sums);
+}
+
+int m3d_reg_replay(m3d_reg* q, const uint32_t* counts, const double* sums) {
+    if (!q || q->trivial) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (!q->survivors.empty() && (!counts || !sums)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    std::lock_guard<std::mutex> lock(q->ctx->mu);
+    return reg_replay(*q, counts, sums);
+}
+
+int m3d_reg_finish(m3d_reg* q, double* T, m3d_reg_stats* stats) {
+    if (!q || !T) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (q->trivial) return reg_finish(*q, T, stats);
+    std::lock_guard<std::mutex> lock(q->ctx->mu);
+    return reg_finish(*q, T, stats);
+}
+
+int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, size_t n_dst,
+                            const size_t* corr_src, const size_t* corr_dst, size_t m, double threshold,
+                            int max_iter, double edge_length_threshold, double confidence,
+                            const uint64_t* seed, int device, double* T_out, m3d_reg_stats* stats) {
+    if (!T_out) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(T_out, I4, sizeof(I4));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->best_index = -1;
+    }
+    int rc = M3D_OK;
+    m3d_reg* q = reg_create(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter, edge_length_threshold,
+                            confidence, seed, device, &rc);
+    if (!q) return rc;
+    std::vector<uint32_t> counts;
+    std::vector<double> sums;
+    for (;;) {
+        size_t ns = 0;
+        rc = m3d_reg_begin_chunk(q, &ns);
+        if (rc != M3D_OK) break;   // M3D_FALSE: loop over; < 0: error
+        counts.assign(std::max<size_t>(ns, 1), 0);
+        sums.assign(std::max<size_t>(ns, 1), 0.0);
+        rc = m3d_reg_validate(q, 0, ns, counts.data(), sums.data());
+        if (rc != M3D_OK) break;
+        rc = m3d_reg_replay(q, counts.data(), sums.data());
+        if (rc != M3D_OK) break;
+    }
+    if (rc == M3D_FALSE) rc = m3d_reg_finish(q, T_out, stats);
+    m3d_reg_destroy(q);
     return rc;
 }
+
 
 uint64_t m3d_match_last_fallbacks(void) { return g_match_fallbacks; }
 

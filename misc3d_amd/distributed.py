@@ -184,3 +184,66 @@ def segment_plane_iterative_sharded(scorer, threshold, max_iteration=100, min_ra
         if removed != ni:
             raise capi.M3DError(capi.ERR_INTERNAL, "removed points and inlier list disagree")
     return ShardedSegmentation(ret, np.array(planes).reshape(-1, 4), clusters, collectives)
+
+
+
+def reg_shard(ns, world, rank):
+    """Survivor range [s0, s1) of `rank` and the padded shard length: whole groups of 64 hypotheses
+    (the validation kernel's unit), ceil(groups / world) groups per rank, contiguous."""
+    groups = -(-ns // 64)
+    per = -(-groups // world) if groups else 0
+    g0 = min(rank * per, groups)
+    g1 = min(g0 + per, groups)
+    if g0 == g1:
+        return 0, 0, per * 64                  # nothing left for this rank
+    return g0 * 64, min(g1 * 64, ns), per * 64
+
+
+def _all_gather_f64(rec, group, device):
+    """all_gather of equal-shape float64 arrays -> (world, *rec.shape); bit-exact transport."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(np.ascontiguousarray(rec))
+    if device is not None:
+        t = t.to(device)
+    out = torch.empty((world,) + tuple(rec.shape), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=group)
+    return out.cpu().numpy()
+
+
+def registration_ransac_sharded(session, group=None, device=None, gather=None, world=None, rank=None):
+    """compute_transformation_ransac with the validation of every chunk's surviving hypotheses sharded over
+    the ranks: source, target, grid and correspondences are replicated, the sessions are
+    seeded identically (so every rank draws the same triples and keeps the same survivors), rank r validates
+    a contiguous run of 64-hypothesis groups, ONE all-gather per chunk exchanges (count, sum d^2) as float64
+    pairs (counts < 2^31 are exact in float64), every rank replays the whole chunk.  `session`:
+    capi.RegSession (or anything with begin_chunk/validate/replay/finish).  `gather(rec) -> (world, ...)`
+    replaces the torch.distributed all-gather (tests)."""
+    if gather is None:
+        world, rank, have_pg = _world(group)
+        if have_pg:
+            def gather(rec):
+                return _all_gather_f64(rec, group, device)
+        else:
+            def gather(rec):
+                return rec[None]
+    collectives = 0
+    while True:
+        ns = session.begin_chunk()
+        if ns is None:
+            break
+        s0, s1, shard = reg_shard(ns, world, rank)
+        c, s = session.validate(s0, s1)
+        rec = np.zeros((max(shard, 1), 2), dtype=np.float64)
+        rec[: len(c), 0] = c
+        rec[: len(c), 1] = s
+        if shard:                     # ns == 0 on every rank alike: nothing to exchange
+            allrec = np.asarray(gather(rec)).reshape(-1, 2)[:ns]
+            collectives += 1
+        else:
+            allrec = np.zeros((0, 2))
+        session.replay(allrec[:ns, 0].astype(np.uint32), np.ascontiguousarray(allrec[:ns, 1]))
+    T, st = session.finish()
+    st["collectives"] = collectives
+    return T, st

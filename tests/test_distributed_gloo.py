@@ -175,3 +175,69 @@ def test_segment_plane_iterative_sharded_world2_matches_sequential(orc):
         for c, oc in zip(clusters, o_clusters):
             assert c == oc.tolist()
         assert n_coll >= len(planes)
+
+
+class _FakeRegSession:
+    """Stands in for capi.RegSession (which needs a GPU): deterministic per-survivor records, so the test can
+    check that every rank's replay sees the complete, correctly ordered (count, sum) arrays of each chunk."""
+    CHUNKS = [130, 0, 64, 1, 700, 63, 129]
+
+    def __init__(self):
+        self.k = -1
+        self.replayed = []
+
+    @staticmethod
+    def records(k, ns):
+        i = np.arange(ns, dtype=np.uint64)
+        counts = ((i * 2654435761 + k * 97) % 2_000_000_000).astype(np.uint32)
+        sums = np.sqrt(i.astype(np.float64) + 0.1 * (k + 1)) * (1.0 + 1e-13 * i)     # full-precision doubles
+        return counts, sums
+
+    def begin_chunk(self):
+        self.k += 1
+        return self.CHUNKS[self.k] if self.k < len(self.CHUNKS) else None
+
+    def validate(self, s0, s1):
+        assert s0 % 64 == 0 and s0 <= s1 <= self.CHUNKS[self.k], (s0, s1)
+        c, s = self.records(self.k, self.CHUNKS[self.k])
+        return c[s0:s1], s[s0:s1]
+
+    def replay(self, counts, sums):
+        c, s = self.records(self.k, self.CHUNKS[self.k])
+        assert counts.dtype == np.uint32 and np.array_equal(counts, c)
+        assert np.array_equal(sums.view(np.uint64), s.view(np.uint64))               # bit-exact transport
+        self.replayed.append(self.k)
+
+    def finish(self):
+        return np.eye(4), {"chunks": list(self.replayed)}
+
+
+def _reg_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from misc3d_amd import distributed
+        T, st = distributed.registration_ransac_sharded(_FakeRegSession())
+        q.put((rank, st["chunks"], st["collectives"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_registration_sharded_plumbing_world2():
+    """The all-gather / shard layout of registration_ransac_sharded under gloo, world size 2: every rank
+    validates only its 64-aligned shard and replays the complete records of every chunk (asserted inside
+    the fake session), including empty chunks and chunks smaller than one group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, chunks, n_coll in results:
+        assert chunks == list(range(len(_FakeRegSession.CHUNKS)))
+        assert n_coll == sum(1 for c in _FakeRegSession.CHUNKS if c > 0)

@@ -69,6 +69,52 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
     assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64))
 
 
+def test_registration_session_sharded_equals_single_call(capi):
+    """m3d_reg session (begin_chunk / validate / replay) driven by distributed.registration_ransac_sharded:
+    world 1, and two "ranks" simulated by two identically seeded sessions on this GPU in two threads with a
+    barrier-based all-gather -- same pose, same statistics as the one-call m3d_registration_ransac."""
+    import threading
+
+    from misc3d_amd import distributed
+    d, cs, cd = _problem(n=6000, seed=8, m=1500, true_fraction=0.5)
+    kw = dict(threshold=0.03, max_iter=6000, edge_length_threshold=0.9, confidence=1.0, seed=23)
+    T0, st0 = capi.registration_ransac(d["src"], d["dst"], cs, cd, **kw)
+    assert st0["validations"] > 200       # several chunks with more than one 64-group of survivors
+    keys = ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse", "ties")
+    with capi.RegSession(d["src"], d["dst"], cs, cd, **kw) as sess:
+        T1, st1 = distributed.registration_ransac_sharded(sess)
+    assert np.array_equal(T0, T1) and all(st0[k] == st1[k] for k in keys)
+
+    world = 2
+    barrier = threading.Barrier(world)
+    slots = [None] * world
+    out = [None] * world
+    err = []
+
+    def run(rank):
+        def gather(rec):
+            slots[rank] = rec.copy()
+            barrier.wait(timeout=120)
+            allrec = np.stack(slots)
+            barrier.wait(timeout=120)
+            return allrec
+        try:
+            with capi.RegSession(d["src"], d["dst"], cs, cd, **kw) as sess:
+                out[rank] = distributed.registration_ransac_sharded(sess, gather=gather, world=world, rank=rank)
+        except Exception as e:      # pragma: no cover
+            err.append(e)
+            barrier.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not err, err
+    for T2, st2 in out:
+        assert np.array_equal(T0, T2) and all(st0[k] == st2[k] for k in keys)
+
+
 def test_registration_grid_edge_cases(capi, orc):
     # target far from the origin, threshold comparable to the extent, points exactly on cell borders
     rng = np.random.default_rng(7)
