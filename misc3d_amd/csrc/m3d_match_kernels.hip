@@ -140,13 +140,12 @@ __global__ __launch_bounds__(256) void nn32_scan_k(const float* __restrict__ q, 
 }
 
 // exact distances of the surviving candidates: serial-order fp64 accumulation (nanoflann
-// L2_Simple_Adaptor order); slices and ring entries are visited in ascending database index and the
-// comparison is strict, so the lowest index wins among equal distances.
+// L2_Simple_Adaptor order); among equal distances the lowest database index wins, as in a serial scan.
 __global__ void nn64_verify_k(const double* __restrict__ q, uint32_t nq, const double* __restrict__ db, int dim,
                               const uint2* __restrict__ ring, const uint32_t* __restrict__ ring_count,
                               const float* __restrict__ part_min, const float* __restrict__ evict_min,
-                              uint32_t splits, float e_coeff, float max_dn2, const float* __restrict__ qn2,
-                              uint32_t* __restrict__ nn, uint32_t* __restrict__ overflow_list,
+                              uint32_t splits, float e_coeff, float e_abs, float max_dn2,
+                              const float* __restrict__ qn2, uint32_t* __restrict__ nn, uint32_t* __restrict__ overflow_list,
                               uint32_t* __restrict__ overflow_count) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nq) return;
@@ -157,7 +156,7 @@ __global__ void nn64_verify_k(const double* __restrict__ q, uint32_t nq, const d
         if (pm == -INFINITY) fallback = true;
         m = fminf(m, pm);
     }
-    const float win = m + (2.0f * e_coeff * (qn2[i] + max_dn2) * 1.000001f + 1e-30f);
+    const float win = m + (2.0f * (e_coeff * (qn2[i] + max_dn2) + e_abs) * 1.000001f + 1e-30f);
     if (!(win < INFINITY) && m < INFINITY) fallback = true;
     for (uint32_t s = 0; s < splits; ++s)
         if (evict_min[(size_t)s * nq + i] <= win) fallback = true;   // a possibly valid candidate was evicted
@@ -181,7 +180,7 @@ __global__ void nn64_verify_k(const double* __restrict__ q, uint32_t nq, const d
                 const double df = q[(size_t)i * dim + k] - db[(size_t)j * dim + k];
                 acc += df * df;
             }
-            if (acc < bd) {
+            if (acc < bd || (acc == bd && j < bi)) {   // equal distances: the lowest index (first found by a serial scan)
                 bd = acc;
                 bi = j;
             }
@@ -234,6 +233,181 @@ __global__ void max_f32_k(const float* __restrict__ v, uint32_t n, float* __rest
     if (threadIdx.x == 0) out[0] = sm[0];
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA screen (v_mfma_f32_32x32x16_f16): the same candidate rings as nn32_scan_k, ~6x fewer cycles per
+// pair.  d(a, b) = |a|^2 + |b|^2 - 2 a.b is ONE K = 112 contraction of fp16 operands with fp32 accumulate:
+//   k   0.. 32   (-2 a_hi) * b_hi          a = a_hi + a_lo (+ 2^-22 |a|): split fp16, data pre-scaled by a power
+//   k  33.. 65   (-2 a_lo) * b_hi          of two so that max |v| <= 2048 (exact in both directions)
+//   k  66.. 98   (-2 a_hi) * b_lo
+//   k  99..101   |a|^2 / 2^15 in three fp16 pieces * 2^15          (norms of the REPRESENTED rows, from fp64)
+//   k 102..104   2^15 * |b|^2 / 2^15 in three pieces
+//   k 105..111   0
+// Products of two fp16 are exact in fp32; what is lost is a_lo b_lo (<= 2^-22 |a||b|), the split residue
+// and the fp32 accumulation: |d16 - d_exact| <= kMfmaECoeff (|a|^2 + |b|^2) with a wide margin (the bound
+// only has to be valid; the verification is exact).  Database rows are the A operand (M), queries the B
+// operand (N): in the 32x32 accumulator a lane owns ONE query (column lane & 31) and 16 of the 32 rows
+// (row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)), so the running minimum / ring logic is per lane, with the
+// two half-waves of a query treated as two more database slices.  Operands are pre-packed in fragment
+// order (pack_f16_k): one coalesced 16-byte load per lane and K-step.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMfmaK = 112, kMfmaSteps = 7;
+constexpr float kMfmaECoeff = 1.0e-4f;
+// Absolute part of the bound (scaled^2 units; data scaled to max |v| in [1024, 2048)): fp16 underflow.  Values far
+// below the largest one lose their lo piece to the subnormal spacing 2^-24 -- or to zero if the matrix core
+// flushes subnormal inputs (<= 6.1e-5 per element): 2 * 6.1e-5 * sum(|a_k| + |b_k|) <= 16.5, plus two norm
+// remainders <= 6.1e-5 * 2^15 = 2 each.  32 covers it; for well-scaled data it is noise next to the relative
+// part (~1e3), for badly scaled data (one huge row) it correctly sends everything to the exact path.
+constexpr float kMfmaEAbs = 32.0f;
+constexpr float kMfmaC = 32768.0f;   // 2^15
+
+// role 0: database rows (A operand), role 1: queries (B operand).  out: [tile][step][lane] h8.
+// norm2[i] = |represented row|^2 in scaled units (fp32, for the window); rows >= n of the last tile: role 0
+// gets a huge norm (never a candidate), role 1 zeros.
+__global__ void pack_f16_k(const double* __restrict__ f, uint32_t n, uint32_t n_tiles, double scale, int role,
+                           _Float16* __restrict__ out, float* __restrict__ norm2) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_tiles * 32u) return;
+    _Float16 row[kMfmaK];
+    for (int k = 0; k < kMfmaK; ++k) row[k] = (_Float16)0.0f;
+    double nrm = 0.0;
+    if (i < n) {
+        for (int k = 0; k < 33; ++k) {
+            const double v = f[(size_t)i * 33 + k] * scale;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (double)hi);
+            const double rep = (double)hi + (double)lo;
+            nrm += rep * rep;
+            if (role == 0) {
+                row[k] = (_Float16)(-2.0 * (double)hi);
+                row[33 + k] = (_Float16)(-2.0 * (double)lo);
+                row[66 + k] = (_Float16)(-2.0 * (double)hi);
+            } else {
+                row[k] = hi;
+                row[33 + k] = hi;
+                row[66 + k] = lo;
+            }
+        }
+    }
+    double pn = (i < n) ? nrm / (double)kMfmaC : (role == 0 ? 65504.0 : 0.0);
+    const int own = role == 0 ? 99 : 102, other = role == 0 ? 102 : 99;
+    for (int k = 0; k < 3; ++k) {
+        const _Float16 piece = (_Float16)pn;
+        row[own + k] = piece;
+        pn -= (double)piece;
+        row[other + k] = (_Float16)kMfmaC;
+    }
+    if (i < n) norm2[i] = (float)nrm;
+    const uint32_t t = i / 32u, r = i % 32u;
+    for (int k = 0; k < kMfmaK; ++k) {
+        const uint32_t st = k / 16, kk = k % 16, lane = r + 32u * (kk / 8), j = kk % 8;
+        out[(((size_t)t * kMfmaSteps + st) * 64 + lane) * 8 + j] = row[k];
+    }
+}
+
+// max |v| over an n x 33 matrix (non-finite values propagate as +inf so the caller can bail out)
+__global__ void max_abs_k(const double* __restrict__ f, size_t count, double* __restrict__ out) {
+    __shared__ double sm[256];
+    double m = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const double v = fabs(f[i]);
+        m = (v > m || v != v) ? (v != v ? INFINITY : v) : m;
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
+__device__ __forceinline__ void mfma_post(const f32x16& acc, ScanState& st, float two_e, bool live, uint32_t row0,
+                                          uint32_t ndb, uint2* __restrict__ my) {
+    // min(a, b) = med3(a, b, -inf): v_med3_f32 needs no NaN canonicalisation of its inputs (fminf does, which
+    // would triple the VALU work of this steady-state path).  A NaN entry cannot be a candidate anyway.
+    const float ninf = -INFINITY;
+    float t[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] = __builtin_amdgcn_fmed3f(acc[2 * r], acc[2 * r + 1], ninf);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_fmed3f(t[2 * r], t[2 * r + 1], ninf);
+    const float tmin = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(t[0], t[1], ninf),
+                                               __builtin_amdgcn_fmed3f(t[2], t[3], ninf), ninf);
+    if (tmin <= st.win && live) {   // rare once the running minimum has settled
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+            scan_step(st, acc[r], two_e, row < ndb, row, my);
+        }
+    }
+}
+
+// One wave: 64 queries (two 32-column B tiles held in registers for the whole scan) against a slice of
+// the database, one 32-row A tile at a time (next tile's fragments prefetched).
+__global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
+                                                    uint32_t nq, const h8* __restrict__ dA, uint32_t ndb,
+                                                    uint32_t tiles_per_split, float max_dn2,
+                                                    uint2* __restrict__ ring, uint32_t* __restrict__ ring_count,
+                                                    float* __restrict__ part_min, float* __restrict__ evict_min) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t qt0 = (blockIdx.x * 4u + wave) * 2u;   // first of this wave's two query tiles
+    const uint32_t half = lane >> 5;
+    h8 b0[kMfmaSteps], b1[kMfmaSteps];
+#pragma unroll
+    for (int s = 0; s < kMfmaSteps; ++s) {
+        b0[s] = qB[((size_t)qt0 * kMfmaSteps + s) * 64 + lane];
+        b1[s] = qB[((size_t)(qt0 + 1) * kMfmaSteps + s) * 64 + lane];
+    }
+    const uint32_t qa = qt0 * 32u + (lane & 31), qb = qa + 32u;
+    const float na = qa < nq ? qn2[qa] : 0.0f, nb = qb < nq ? qn2[qb] : 0.0f;
+    const float two_ea = 2.0f * (kMfmaECoeff * (na + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
+    const float two_eb = 2.0f * (kMfmaECoeff * (nb + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
+    const bool live_a = two_ea < INFINITY && qa < nq, live_b = two_eb < INFINITY && qb < nq;
+    // slice id = 2 * blockIdx.y + half: the two half-waves of a query see disjoint rows
+    const uint32_t slice = blockIdx.y * 2u + half;
+    uint2* __restrict__ ring_a = ring + ((size_t)slice * nq + (qa < nq ? qa : nq - 1)) * kRing;
+    uint2* __restrict__ ring_b = ring + ((size_t)slice * nq + (qb < nq ? qb : nq - 1)) * kRing;
+    ScanState sa, sb;
+    const uint32_t n_tiles = (ndb + 31u) / 32u;
+    const uint32_t t0 = blockIdx.y * tiles_per_split, t1 = min(n_tiles, t0 + tiles_per_split);
+    if (t0 < t1) {
+        h8 cur[kMfmaSteps];
+#pragma unroll
+        for (int s = 0; s < kMfmaSteps; ++s) cur[s] = dA[((size_t)t0 * kMfmaSteps + s) * 64 + lane];
+        for (uint32_t t = t0; t < t1; ++t) {
+            h8 nxt[kMfmaSteps];
+            const uint32_t tn = t + 1 < t1 ? t + 1 : t;
+#pragma unroll
+            for (int s = 0; s < kMfmaSteps; ++s) nxt[s] = dA[((size_t)tn * kMfmaSteps + s) * 64 + lane];
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int s = 0; s < kMfmaSteps; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], acc1, 0, 0, 0);
+            }
+            const uint32_t row0 = t * 32u + 4u * half;
+            mfma_post(acc0, sa, two_ea, live_a, row0, ndb, ring_a);
+            mfma_post(acc1, sb, two_eb, live_b, row0, ndb, ring_b);
+#pragma unroll
+            for (int s = 0; s < kMfmaSteps; ++s) cur[s] = nxt[s];
+        }
+    }
+    if (qa < nq) {
+        const size_t o = (size_t)slice * nq + qa;
+        ring_count[o] = sa.cnt;
+        part_min[o] = two_ea < INFINITY ? sa.best : -INFINITY;
+        evict_min[o] = sa.ev;
+    }
+    if (qb < nq) {
+        const size_t o = (size_t)slice * nq + qb;
+        ring_count[o] = sb.cnt;
+        part_min[o] = two_eb < INFINITY ? sb.best : -INFINITY;
+        evict_min[o] = sb.ev;
+    }
+}
+
 void launch_to_f32_33(const double* f, uint32_t n, float* out32, float* norm2, float* max_norm2, hipStream_t s) {
     if (!n) return;
     to_f32_k<<<(n + 255) / 256, 256, 0, s>>>(f, n, out32, norm2);
@@ -256,7 +430,48 @@ hipError_t launch_nn_screened33(const double* q, const float* q32, const float* 
     nn32_scan_k<<<dim3((nq + 511) / 512, splits), 256, 0, s>>>(q32, nq, d32, ndb, per, e_coeff, max_dn2, ring,
                                                               ring_count, part_min, evict_min);
     nn64_verify_k<<<(nq + 255) / 256, 256, 0, s>>>(q, nq, db, DIM, ring, ring_count, part_min, evict_min, splits,
-                                                   e_coeff, max_dn2, qn, nn, overflow_list, overflow_count);
+                                                   e_coeff, 0.0f, max_dn2, qn, nn, overflow_list, overflow_count);
+    hipError_t e = hipMemcpyAsync(h_overflow, overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    if (*h_overflow) nn_exact_one_k<<<*h_overflow, 64, 0, s>>>(q, db, ndb, DIM, overflow_list, nn);
+    return hipGetLastError();
+}
+
+// ---- MFMA path launchers -------------------------------------------------------------------------
+uint32_t mfma_tiles(uint32_t n) { return (n + 31u) / 32u; }
+// tiles padded so that a wave's two query tiles always exist
+uint32_t mfma_query_tiles(uint32_t n) { return ((n + 511u) / 512u) * 16u; }
+
+void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s) { max_f32_k<<<1, 256, 0, s>>>(v, n, out); }
+void launch_max_abs(const double* f, size_t count, double* partial /* 256 */, hipStream_t s) {
+    max_abs_k<<<256, 256, 0, s>>>(f, count, partial);
+}
+void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale, int role, void* out, float* norm2,
+                     hipStream_t s) {
+    if (!n_tiles) return;
+    pack_f16_k<<<(n_tiles * 32u + 255) / 256, 256, 0, s>>>(f, n, n_tiles, scale, role,
+                                                           reinterpret_cast<_Float16*>(out), norm2);
+}
+
+// Same workspace as launch_nn_screened33 with 2 * splits slices.  qB: queries packed with role 1
+// (mfma_query_tiles(nq) tiles), dA: database packed with role 0 (mfma_tiles(ndb) tiles); qn: scaled |q|^2.
+hipError_t launch_nn_mfma33(const double* q, const void* qB, const float* qn, uint32_t nq, const double* db,
+                            const void* dA, uint32_t ndb, float max_dn2, uint32_t splits, uint2* ring,
+                            uint32_t* ring_count, float* part_min, float* evict_min, uint32_t* overflow_list,
+                            uint32_t* overflow_count, uint32_t* nn, uint32_t* h_overflow, hipStream_t s) {
+    constexpr int DIM = 33;
+    *h_overflow = 0;
+    if (!nq || !ndb) return hipSuccess;
+    (void)hipMemsetAsync(overflow_count, 0, sizeof(uint32_t), s);
+    const uint32_t n_tiles = mfma_tiles(ndb);
+    const uint32_t per = (n_tiles + splits - 1) / splits;
+    nn16_scan_k<<<dim3((nq + 255) / 256, splits), 256, 0, s>>>(reinterpret_cast<const h8*>(qB), qn, nq,
+                                                              reinterpret_cast<const h8*>(dA), ndb, per, max_dn2,
+                                                              ring, ring_count, part_min, evict_min);
+    nn64_verify_k<<<(nq + 255) / 256, 256, 0, s>>>(q, nq, db, DIM, ring, ring_count, part_min, evict_min, 2 * splits,
+                                                   kMfmaECoeff, kMfmaEAbs, max_dn2, qn, nn, overflow_list,
+                                                   overflow_count);
     hipError_t e = hipMemcpyAsync(h_overflow, overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;

@@ -927,51 +927,104 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     if (!ctx) return M3D_ERR_DEVICE;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    DevBuf fs, fd, bd, bi, nn01, nn10, fs32, fd32, ns2, nd2, ring, ring_count, evict, over_list, scal;
+    DevBuf fs, fd, bd, bi, nn01, nn10, fs32, fd32, ns2, nd2, ring, ring_count, evict, over_list, scal, pA_s, pA_d,
+        pB_s, pB_d;
     auto done = [&](int r) {
         for (DevBuf* b : {&fs, &fd, &bd, &bi, &nn01, &nn10, &fs32, &fd32, &ns2, &nd2, &ring, &ring_count, &evict,
-                          &over_list, &scal})
+                          &over_list, &scal, &pA_s, &pA_d, &pB_s, &pB_d})
             b->release();
         return r;
     };
     const uint32_t ns = (uint32_t)n_src, nd = (uint32_t)n_dst;
-    // dim 33 (FPFH): fp32-screened exact search (m3d_match_kernels.hip); other widths: fp64 brute force.
+    // dim 33 (FPFH): screened exact search (m3d_match_kernels.hip): split-fp16 MFMA screen by default, the fp32
+    // VALU screen with M3D_MATCH_SCREEN=fp32 or when the data does not fit fp16 scaling; M3D_MATCH_BRUTE=1 and
+    // every other width: fp64 brute force.
     const char* brute_env = std::getenv("M3D_MATCH_BRUTE");
+    const char* screen_env = std::getenv("M3D_MATCH_SCREEN");
     const bool screened = dim == 33 && !(brute_env && brute_env[0] == '1');
+    bool use_mfma = screened && !(screen_env && screen_env[0] == 'f');
     // enough (query block x database split) workgroups to fill the chip
-    auto splits_for = [](uint32_t nq, uint32_t ndb) {
-        const uint32_t blocks = (nq + 511) / 512;   // nn32_scan_k: 512 queries per block (nn_k: 256, more blocks)
+    auto splits_for = [](uint32_t nq, uint32_t ndb, uint32_t q_per_block, uint32_t rows_per_unit) {
+        const uint32_t blocks = (nq + q_per_block - 1) / q_per_block;
         uint32_t s = std::max<uint32_t>(1, (2048 + blocks - 1) / blocks);
-        return std::min<uint32_t>(s, std::max<uint32_t>(1, ndb / 256));
+        return std::min<uint32_t>(s, std::max<uint32_t>(1, ndb / rows_per_unit));
     };
-    const uint32_t s01 = splits_for(ns, nd), s10 = splits_for(nd, ns);
-    const size_t part = std::max((size_t)s01 * ns, (size_t)s10 * nd);
-    const uint32_t nmax = std::max(ns, nd);
+    uint32_t s01 = splits_for(ns, nd, 512, 256), s10 = splits_for(nd, ns, 512, 256);
     if (!fs.reserve(sizeof(double) * (size_t)dim * ns) || !fd.reserve(sizeof(double) * (size_t)dim * nd) ||
-        !bd.reserve(sizeof(double) * part) || !bi.reserve(sizeof(uint32_t) * part) ||
-        !nn01.reserve(sizeof(uint32_t) * ns) || !nn10.reserve(sizeof(uint32_t) * nd))
-        return done(M3D_ERR_DEVICE);
-    if (screened &&   // fp32 rows carry one spare row (prefetch target of the last iteration)
-        (!fs32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)ns + 1)) ||
-         !fd32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)nd + 1)) || !ns2.reserve(sizeof(float) * ns) ||
-         !nd2.reserve(sizeof(float) * nd) || !ring.reserve(sizeof(uint2) * (size_t)kRing * part) ||
-         !ring_count.reserve(sizeof(uint32_t) * part) || !evict.reserve(sizeof(float) * part) ||
-         !over_list.reserve(sizeof(uint32_t) * nmax) || !scal.reserve(64)))
+        !nn01.reserve(sizeof(uint32_t) * ns) || !nn10.reserve(sizeof(uint32_t) * nd) || !scal.reserve(8192))
         return done(M3D_ERR_DEVICE);
     std::vector<uint32_t> h01(ns), h10(nd);
     bool ok = hipMemcpyAsync(fs.p, feat_src, sizeof(double) * (size_t)dim * ns, hipMemcpyHostToDevice, ctx->stream) ==
                   hipSuccess &&
               hipMemcpyAsync(fd.p, feat_dst, sizeof(double) * (size_t)dim * nd, hipMemcpyHostToDevice, ctx->stream) ==
                   hipSuccess;
-    if (ok && screened) {
-        float* sc = scal.as<float>();   // [0] max |src|^2, [1] max |dst|^2, [2] overflow counter (u32)
-        launch_to_f32_33(fs.as<double>(), ns, fs32.as<float>(), ns2.as<float>(), sc + 0, ctx->stream);
-        launch_to_f32_33(fd.as<double>(), nd, fd32.as<float>(), nd2.as<float>(), sc + 1, ctx->stream);
+    double scale = 0.0;
+    if (ok && use_mfma) {
+        // power-of-two scale that brings max |v| to <= 2048 (fp16 hi/lo split keeps 22 bits; norms / 2^15 fit)
+        double* part = scal.as<double>() + 16;   // 2 x 256 partial maxima
+        launch_max_abs(fs.as<double>(), (size_t)ns * 33, part, ctx->stream);
+        launch_max_abs(fd.as<double>(), (size_t)nd * 33, part + 256, ctx->stream);
+        std::vector<double> hp(512);
+        ok = hipMemcpyAsync(hp.data(), part, sizeof(double) * 512, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+        double mx = 0.0;
+        for (double v : hp) mx = (v > mx || v != v) ? v : mx;
+        if (ok && mx > 0.0 && std::isfinite(mx) && mx < 1e300 && mx > 1e-300) {
+            int e;
+            (void)std::frexp(mx, &e);            // mx = f * 2^e, f in [0.5, 1)  ->  mx * 2^(11 - e) in [1024, 2048)
+            scale = std::ldexp(1.0, 11 - e);
+        } else {
+            use_mfma = false;                    // zeros / NaN / inf: the fp32 screen's exact fallback handles them
+        }
+    }
+    if (use_mfma) {
+        s01 = splits_for(ns, nd, 256, 256);
+        s10 = splits_for(nd, ns, 256, 256);
+    }
+    const uint32_t slices01 = use_mfma ? 2 * s01 : s01, slices10 = use_mfma ? 2 * s10 : s10;
+    const size_t part = std::max((size_t)slices01 * ns, (size_t)slices10 * nd);
+    const uint32_t nmax = std::max(ns, nd);
+    if (ok && (!bd.reserve(sizeof(double) * part) || !bi.reserve(sizeof(uint32_t) * part))) return done(M3D_ERR_DEVICE);
+    if (ok && screened &&   // fp32 rows carry one spare row (prefetch target of the last iteration)
+        (!ns2.reserve(sizeof(float) * ns) || !nd2.reserve(sizeof(float) * nd) ||
+         !ring.reserve(sizeof(uint2) * (size_t)kRing * part) || !ring_count.reserve(sizeof(uint32_t) * part) ||
+         !evict.reserve(sizeof(float) * part) || !over_list.reserve(sizeof(uint32_t) * nmax)))
+        return done(M3D_ERR_DEVICE);
+    float* sc = scal.as<float>();   // [0] max |src|^2, [1] max |dst|^2, [2] overflow counter (u32)
+    uint32_t over01 = 0, over10 = 0;
+    if (ok && use_mfma) {
+        const size_t tile_bytes = (size_t)kMfmaRowHalfs * 2 * 32;
+        if (!pA_s.reserve(tile_bytes * mfma_tiles(ns)) || !pA_d.reserve(tile_bytes * mfma_tiles(nd)) ||
+            !pB_s.reserve(tile_bytes * mfma_query_tiles(ns)) || !pB_d.reserve(tile_bytes * mfma_query_tiles(nd)))
+            return done(M3D_ERR_DEVICE);
+        launch_pack_f16(fs.as<double>(), ns, mfma_tiles(ns), scale, 0, pA_s.p, ns2.as<float>(), ctx->stream);
+        launch_pack_f16(fd.as<double>(), nd, mfma_tiles(nd), scale, 0, pA_d.p, nd2.as<float>(), ctx->stream);
+        launch_pack_f16(fs.as<double>(), ns, mfma_query_tiles(ns), scale, 1, pB_s.p, ns2.as<float>(), ctx->stream);
+        launch_pack_f16(fd.as<double>(), nd, mfma_query_tiles(nd), scale, 1, pB_d.p, nd2.as<float>(), ctx->stream);
+        launch_max_f32(ns2.as<float>(), ns, sc + 0, ctx->stream);
+        launch_max_f32(nd2.as<float>(), nd, sc + 1, ctx->stream);
         float h_max[2] = {0.0f, 0.0f};
-        uint32_t over01 = 0, over10 = 0;
         ok = hipMemcpyAsync(h_max, sc, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
         // the two std::threads of correspondence_matching.cpp:59-62 become two passes on one stream
+        ok = ok && launch_nn_mfma33(fs.as<double>(), pB_s.p, ns2.as<float>(), ns, fd.as<double>(), pA_d.p, nd, h_max[1],
+                                    s01, ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(),
+                                    evict.as<float>(), over_list.as<uint32_t>(), scal.as<uint32_t>() + 2,
+                                    nn01.as<uint32_t>(), &over01, ctx->stream) == hipSuccess;
+        ok = ok && launch_nn_mfma33(fd.as<double>(), pB_d.p, nd2.as<float>(), nd, fs.as<double>(), pA_s.p, ns, h_max[0],
+                                    s10, ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(),
+                                    evict.as<float>(), over_list.as<uint32_t>(), scal.as<uint32_t>() + 2,
+                                    nn10.as<uint32_t>(), &over10, ctx->stream) == hipSuccess;
+        g_match_fallbacks = (uint64_t)over01 + over10;
+    } else if (ok && screened) {
+        if (!fs32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)ns + 1)) ||
+            !fd32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)nd + 1)))
+            return done(M3D_ERR_DEVICE);
+        launch_to_f32_33(fs.as<double>(), ns, fs32.as<float>(), ns2.as<float>(), sc + 0, ctx->stream);
+        launch_to_f32_33(fd.as<double>(), nd, fd32.as<float>(), nd2.as<float>(), sc + 1, ctx->stream);
+        float h_max[2] = {0.0f, 0.0f};
+        ok = hipMemcpyAsync(h_max, sc, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
         ok = ok && launch_nn_screened33(fs.as<double>(), fs32.as<float>(), ns2.as<float>(), ns, fd.as<double>(),
                                         fd32.as<float>(), nd, h_max[1], s01, ring.as<uint2>(),
                                         ring_count.as<uint32_t>(), bd.as<float>(), evict.as<float>(),

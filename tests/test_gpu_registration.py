@@ -188,9 +188,10 @@ def _brute(capi, fs, fd):
         del os.environ["M3D_MATCH_BRUTE"]
 
 
-@pytest.mark.parametrize("case", ["dups", "lattice", "huge", "tiny", "nan", "offset", "scales"])
-def test_mutual_nn_screen_adversarial(capi, orc, case):
-    """dim-33 inputs built to defeat the fp32 screen: long runs of exact ties (ring eviction -> exact
+@pytest.mark.parametrize("screen", ["mfma", "fp32"])
+@pytest.mark.parametrize("case", ["dups", "lattice", "huge", "tiny", "nan", "offset", "scales", "mixed"])
+def test_mutual_nn_screen_adversarial(capi, orc, case, screen):
+    """dim-33 inputs built to defeat the reduced-precision screens (split-fp16 MFMA, fp32 VALU): long runs of exact ties (ring eviction -> exact
     fallback), near-equal distances below fp32 resolution, values outside the fp32 range, NaNs,
     large common offsets (catastrophic cancellation in |a|^2+|b|^2-2ab).  The result must stay the
     exact fp64 answer: equal to the oracle and to the unscreened brute-force kernel."""
@@ -210,14 +211,14 @@ def test_mutual_nn_screen_adversarial(capi, orc, case):
         fd[:] = base + 1e-9 * rng.integers(-3, 4, (nd, dim))
         fs[:] = base + 1e-9 * rng.integers(-3, 4, (ns, dim))
         expect_fallback = True
-    elif case == "huge":          # squares overflow fp32
+    elif case == "huge":          # squares overflow fp32 (the MFMA screen rescales by a power of two instead)
         fs *= 1e25
         fd *= 1e25
-        expect_fallback = True
+        expect_fallback = screen == "fp32"
     elif case == "tiny":          # squares underflow fp32
         fs *= 1e-25
         fd *= 1e-25
-        expect_fallback = True
+        expect_fallback = screen == "fp32"
     elif case == "nan":
         fs[5, 7] = np.nan
         fd[9, 0] = np.nan
@@ -225,9 +226,19 @@ def test_mutual_nn_screen_adversarial(capi, orc, case):
     elif case == "offset":        # |a|^2 ~ 3e9 while neighbour distances are ~1: fp32 cancels completely
         fs += 1e4
         fd += 1e4
-    elif case == "scales":        # one huge-norm database row inflates the bound of every query
-        fd[500] *= 1e6
-    a, b = capi.match_mutual_nn(fs, fd)
+    elif case == "scales":        # one huge-norm database row inflates the bound of every query, and pushes every
+        fd[500] *= 1e6            # other value below fp16 resolution after the common power-of-two scaling
+    elif case == "mixed":         # six decades of dynamic range inside every row
+        fs[:, ::2] *= 1e-6
+        fd[:, ::2] *= 1e-6
+        fs[:, 1::4] *= 1e-3
+        fd[:, 1::4] *= 1e-3
+    if screen == "fp32":
+        os.environ["M3D_MATCH_SCREEN"] = "fp32"
+    try:
+        a, b = capi.match_mutual_nn(fs, fd)
+    finally:
+        os.environ.pop("M3D_MATCH_SCREEN", None)
     falls = capi.match_last_fallbacks()
     oa, ob = orc.match_mutual_nn(fs, fd)
     assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob)
