@@ -16,6 +16,7 @@
 #include "m3d_reg_kernels.hpp"
 
 #include "m3d_fp.hpp"
+#include "m3d_match_scan.hpp"
 
 #pragma clang fp contract(off)
 
@@ -75,25 +76,6 @@ __device__ __forceinline__ float d32_of(const Row32& q, const Row32& d) {
 // kept in a ring of kRing (index, d32) entries.  An entry pushed out of the ring is remembered only
 // through the smallest evicted d32: if that is above the final window the evicted entries were all
 // stale, otherwise the query takes the exact fallback.
-struct ScanState {
-    float best = INFINITY, win = INFINITY, ev = INFINITY;
-    uint32_t cnt = 0;
-};
-
-__device__ __forceinline__ void scan_step(ScanState& st, float dv, float two_e, bool live, uint32_t j,
-                                          uint2* __restrict__ my) {
-    if (dv <= st.win && live) {   // also taken while win == +inf
-        const uint32_t slot = st.cnt % kRing;
-        if (st.cnt >= (uint32_t)kRing) st.ev = fminf(st.ev, __uint_as_float(my[slot].y));
-        my[slot] = make_uint2(j, __float_as_uint(dv));
-        st.cnt++;
-        if (dv < st.best) {
-            st.best = dv;
-            st.win = dv + two_e;
-        }
-    }
-}
-
 // Two queries per lane (rows in VGPRs): every database row fetched by the scalar unit feeds
 // 2 x 64 distance evaluations.  Block b covers queries [512 b, 512 b + 512): lane t holds 512 b + t and
 // 512 b + 256 + t.
@@ -250,18 +232,6 @@ __global__ void max_f32_k(const float* __restrict__ v, uint32_t n, float* __rest
 // two half-waves of a query treated as two more database slices.  Operands are pre-packed in fragment
 // order (pack_f16_k): one coalesced 16-byte load per lane and K-step.
 // ------------------------------------------------------------------------------------------------
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMfmaK = 112, kMfmaSteps = 7;
-constexpr float kMfmaECoeff = 1.0e-4f;
-// Absolute part of the bound (scaled^2 units; data scaled to max |v| in [1024, 2048)): fp16 underflow.  Values far
-// below the largest one lose their lo piece to the subnormal spacing 2^-24 -- or to zero if the matrix core
-// flushes subnormal inputs (<= 6.1e-5 per element): 2 * 6.1e-5 * sum(|a_k| + |b_k|) <= 16.5, plus two norm
-// remainders <= 6.1e-5 * 2^15 = 2 each.  32 covers it; for well-scaled data it is noise next to the relative
-// part (~1e3), for badly scaled data (one huge row) it correctly sends everything to the exact path.
-constexpr float kMfmaEAbs = 32.0f;
-constexpr float kMfmaC = 32768.0f;   // 2^15
-
 // role 0: database rows (A operand), role 1: queries (B operand).  out: [tile][step][lane] h8.
 // norm2[i] = |represented row|^2 in scaled units (fp32, for the window); rows >= n of the last tile: role 0
 // gets a huge norm (never a candidate), role 1 zeros.
@@ -323,91 +293,6 @@ __global__ void max_abs_k(const double* __restrict__ f, size_t count, double* __
     if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
-__device__ __forceinline__ void mfma_post(const f32x16& acc, ScanState& st, float two_e, bool live, uint32_t row0,
-                                          uint32_t ndb, uint2* __restrict__ my) {
-    // min(a, b) = med3(a, b, -inf): v_med3_f32 needs no NaN canonicalisation of its inputs (fminf does, which
-    // would triple the VALU work of this steady-state path).  A NaN entry cannot be a candidate anyway.
-    const float ninf = -INFINITY;
-    float t[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] = __builtin_amdgcn_fmed3f(acc[2 * r], acc[2 * r + 1], ninf);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_fmed3f(t[2 * r], t[2 * r + 1], ninf);
-    const float tmin = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(t[0], t[1], ninf),
-                                               __builtin_amdgcn_fmed3f(t[2], t[3], ninf), ninf);
-    if (tmin <= st.win && live) {   // rare once the running minimum has settled
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
-            scan_step(st, acc[r], two_e, row < ndb, row, my);
-        }
-    }
-}
-
-// One wave: 64 queries (two 32-column B tiles held in registers for the whole scan) against a slice of
-// the database, one 32-row A tile at a time (next tile's fragments prefetched).
-__global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
-                                                    uint32_t nq, const h8* __restrict__ dA, uint32_t ndb,
-                                                    uint32_t tiles_per_split, float max_dn2,
-                                                    uint2* __restrict__ ring, uint32_t* __restrict__ ring_count,
-                                                    float* __restrict__ part_min, float* __restrict__ evict_min) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t qt0 = (blockIdx.x * 4u + wave) * 2u;   // first of this wave's two query tiles
-    const uint32_t half = lane >> 5;
-    h8 b0[kMfmaSteps], b1[kMfmaSteps];
-#pragma unroll
-    for (int s = 0; s < kMfmaSteps; ++s) {
-        b0[s] = qB[((size_t)qt0 * kMfmaSteps + s) * 64 + lane];
-        b1[s] = qB[((size_t)(qt0 + 1) * kMfmaSteps + s) * 64 + lane];
-    }
-    const uint32_t qa = qt0 * 32u + (lane & 31), qb = qa + 32u;
-    const float na = qa < nq ? qn2[qa] : 0.0f, nb = qb < nq ? qn2[qb] : 0.0f;
-    const float two_ea = 2.0f * (kMfmaECoeff * (na + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
-    const float two_eb = 2.0f * (kMfmaECoeff * (nb + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
-    const bool live_a = two_ea < INFINITY && qa < nq, live_b = two_eb < INFINITY && qb < nq;
-    // slice id = 2 * blockIdx.y + half: the two half-waves of a query see disjoint rows
-    const uint32_t slice = blockIdx.y * 2u + half;
-    uint2* __restrict__ ring_a = ring + ((size_t)slice * nq + (qa < nq ? qa : nq - 1)) * kRing;
-    uint2* __restrict__ ring_b = ring + ((size_t)slice * nq + (qb < nq ? qb : nq - 1)) * kRing;
-    ScanState sa, sb;
-    const uint32_t n_tiles = (ndb + 31u) / 32u;
-    const uint32_t t0 = blockIdx.y * tiles_per_split, t1 = min(n_tiles, t0 + tiles_per_split);
-    if (t0 < t1) {
-        h8 cur[kMfmaSteps];
-#pragma unroll
-        for (int s = 0; s < kMfmaSteps; ++s) cur[s] = dA[((size_t)t0 * kMfmaSteps + s) * 64 + lane];
-        for (uint32_t t = t0; t < t1; ++t) {
-            h8 nxt[kMfmaSteps];
-            const uint32_t tn = t + 1 < t1 ? t + 1 : t;
-#pragma unroll
-            for (int s = 0; s < kMfmaSteps; ++s) nxt[s] = dA[((size_t)tn * kMfmaSteps + s) * 64 + lane];
-            f32x16 acc0 = {0}, acc1 = {0};
-#pragma unroll
-            for (int s = 0; s < kMfmaSteps; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], acc1, 0, 0, 0);
-            }
-            const uint32_t row0 = t * 32u + 4u * half;
-            mfma_post(acc0, sa, two_ea, live_a, row0, ndb, ring_a);
-            mfma_post(acc1, sb, two_eb, live_b, row0, ndb, ring_b);
-#pragma unroll
-            for (int s = 0; s < kMfmaSteps; ++s) cur[s] = nxt[s];
-        }
-    }
-    if (qa < nq) {
-        const size_t o = (size_t)slice * nq + qa;
-        ring_count[o] = sa.cnt;
-        part_min[o] = two_ea < INFINITY ? sa.best : -INFINITY;
-        evict_min[o] = sa.ev;
-    }
-    if (qb < nq) {
-        const size_t o = (size_t)slice * nq + qb;
-        ring_count[o] = sb.cnt;
-        part_min[o] = two_eb < INFINITY ? sb.best : -INFINITY;
-        evict_min[o] = sb.ev;
-    }
-}
-
 void launch_to_f32_33(const double* f, uint32_t n, float* out32, float* norm2, float* max_norm2, hipStream_t s) {
     if (!n) return;
     to_f32_k<<<(n + 255) / 256, 256, 0, s>>>(f, n, out32, norm2);
@@ -457,7 +342,7 @@ void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale
 // Same workspace as launch_nn_screened33 with 2 * splits slices.  qB: queries packed with role 1
 // (mfma_query_tiles(nq) tiles), dA: database packed with role 0 (mfma_tiles(ndb) tiles); qn: scaled |q|^2.
 hipError_t launch_nn_mfma33(const double* q, const void* qB, const float* qn, uint32_t nq, const double* db,
-                            const void* dA, uint32_t ndb, float max_dn2, uint32_t splits, uint2* ring,
+                            const void* dA, uint32_t ndb, float max_dn2, uint32_t splits, float* premin, uint2* ring,
                             uint32_t* ring_count, float* part_min, float* evict_min, uint32_t* overflow_list,
                             uint32_t* overflow_count, uint32_t* nn, uint32_t* h_overflow, hipStream_t s) {
     constexpr int DIM = 33;
@@ -466,9 +351,7 @@ hipError_t launch_nn_mfma33(const double* q, const void* qB, const float* qn, ui
     (void)hipMemsetAsync(overflow_count, 0, sizeof(uint32_t), s);
     const uint32_t n_tiles = mfma_tiles(ndb);
     const uint32_t per = (n_tiles + splits - 1) / splits;
-    nn16_scan_k<<<dim3((nq + 255) / 256, splits), 256, 0, s>>>(reinterpret_cast<const h8*>(qB), qn, nq,
-                                                              reinterpret_cast<const h8*>(dA), ndb, per, max_dn2,
-                                                              ring, ring_count, part_min, evict_min);
+    launch_nn16_scan(qB, qn, nq, dA, ndb, per, splits, max_dn2, premin, ring, ring_count, part_min, evict_min, s);
     nn64_verify_k<<<(nq + 255) / 256, 256, 0, s>>>(q, nq, db, DIM, ring, ring_count, part_min, evict_min, 2 * splits,
                                                    kMfmaECoeff, kMfmaEAbs, max_dn2, qn, nn, overflow_list,
                                                    overflow_count);

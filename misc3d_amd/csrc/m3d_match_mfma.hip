@@ -1,0 +1,174 @@
+// m3d_match_mfma.hip -- the split-fp16 MFMA screen of the matcher (design: m3d_match_kernels.hip header and
+// DESIGN.md "Matcher").  Separate translation unit because it is compiled with -fno-honor-nans: the inputs
+// are finite by construction (the host only takes this path for finite, rescaled data), and without that
+// promise every fminf of the per-tile minimum costs two extra v_max canonicalisations.
+#include "m3d_match_scan.hpp"
+
+#include <algorithm>
+
+#pragma clang fp contract(off)
+
+namespace m3d {
+
+// Per tile and query tile: 16 distances per lane.  The running minimum is updated unconditionally (3 VALU
+// ops); rows are appended when they lie within the window of the minimum INCLUDING this tile (still a
+// superset of the final window).  A wave carries 128 rings, so early in a scan some lane has a new record
+// in most tiles: the append path is entered per wave-uniform branch and, inside, only the rows that any lane
+// needs are touched (one v_cmp + scalar branch per row), instead of 16 divergent blocks.
+template <bool MIN_ONLY>
+__device__ __forceinline__ void mfma_post(const f32x16& acc, ScanState& st, float two_e, bool live, uint32_t row0,
+                                          uint32_t ndb, uint2* __restrict__ my) {
+    float t[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t[r] = fminf(acc[2 * r], acc[2 * r + 1]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = fminf(t[2 * r], t[2 * r + 1]);
+    const float tmin = fminf(fminf(t[0], t[1]), fminf(t[2], t[3]));   // v_min3_f32 chains under -fno-honor-nans
+    st.best = fminf(st.best, tmin);
+    if (MIN_ONLY) return;
+    st.win = st.best + two_e;
+    if (__any(tmin <= st.win && live)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+            const bool hit = acc[r] <= st.win && live && row < ndb;
+            if (__any(hit)) {
+                if (hit) {
+                    const uint32_t slot = st.cnt % kRing;
+                    if (st.cnt >= (uint32_t)kRing) st.ev = fminf(st.ev, __uint_as_float(my[slot].y));
+                    my[slot] = make_uint2(row, __float_as_uint(acc[r]));
+                    st.cnt++;
+                }
+            }
+        }
+    }
+}
+
+// One wave: 64 queries (two 32-column B tiles held in registers for the whole scan) against a slice of
+// the database.  The four waves of a block walk the SAME slice, so the A tiles are staged through LDS once
+// per block (double-buffered, kStageTiles tiles per stage, one barrier per stage) instead of being
+// fetched from L2 by every wave.
+constexpr int kStageTiles = 2;
+constexpr int kStageEntries = kStageTiles * kMfmaSteps * 64;   // h8 entries per stage (14 KB)
+
+// MIN_ONLY = true: warm-up pass over the first tiles of the database, running minimum only (no rings);
+// its per-(slice, query) minima seed the main pass (init_min / init_slices), so that a ring starts with a
+// bound close to its final minimum and "new record" events -- which cost a wave-wide detour each, and a wave
+// carries 128 rings -- become rare instead of happening in most tiles.
+template <bool MIN_ONLY>
+__global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
+                                                    uint32_t nq, const h8* __restrict__ dA, uint32_t ndb,
+                                                    uint32_t tile_end, uint32_t tiles_per_split, float max_dn2,
+                                                    const float* __restrict__ init_min, uint32_t init_slices,
+                                                    uint2* __restrict__ ring, uint32_t* __restrict__ ring_count,
+                                                    float* __restrict__ part_min, float* __restrict__ evict_min) {
+    __shared__ h8 stage[2][kStageEntries];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t qt0 = (blockIdx.x * 4u + wave) * 2u;   // first of this wave's two query tiles
+    const uint32_t half = lane >> 5;
+    h8 b0[kMfmaSteps], b1[kMfmaSteps];
+#pragma unroll
+    for (int s = 0; s < kMfmaSteps; ++s) {
+        b0[s] = qB[((size_t)qt0 * kMfmaSteps + s) * 64 + lane];
+        b1[s] = qB[((size_t)(qt0 + 1) * kMfmaSteps + s) * 64 + lane];
+    }
+    const uint32_t qa = qt0 * 32u + (lane & 31), qb = qa + 32u;
+    const float na = qa < nq ? qn2[qa] : 0.0f, nb = qb < nq ? qn2[qb] : 0.0f;
+    const float two_ea = 2.0f * (kMfmaECoeff * (na + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
+    const float two_eb = 2.0f * (kMfmaECoeff * (nb + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
+    const bool live_a = two_ea < INFINITY && qa < nq, live_b = two_eb < INFINITY && qb < nq;
+    // slice id = 2 * blockIdx.y + half: the two half-waves of a query see disjoint rows
+    const uint32_t slice = blockIdx.y * 2u + half;
+    uint2* __restrict__ ring_a = ring + ((size_t)slice * nq + (qa < nq ? qa : nq - 1)) * kRing;
+    uint2* __restrict__ ring_b = ring + ((size_t)slice * nq + (qb < nq ? qb : nq - 1)) * kRing;
+    ScanState sa, sb;
+    if (!MIN_ONLY && init_min) {
+        for (uint32_t k = 0; k < init_slices; ++k) {
+            if (qa < nq) sa.best = fminf(sa.best, init_min[(size_t)k * nq + qa]);
+            if (qb < nq) sb.best = fminf(sb.best, init_min[(size_t)k * nq + qb]);
+        }
+    }
+    const uint32_t t0 = blockIdx.y * tiles_per_split, t1 = min(tile_end, t0 + tiles_per_split);
+    if (t0 < t1) {   // block-uniform
+        // entry e of a stage = fragment (tile e / 448, step, lane) in packed order: consecutive in memory
+        constexpr int kPerThread = (kStageEntries + 255) / 256;   // 4 (the last one only for tid < 128)
+        const uint32_t last_entry = (t1 - 1) * (uint32_t)(kMfmaSteps * 64) + (kMfmaSteps * 64 - 1);
+        auto fetch = [&](uint32_t t_first, h8 (&r)[kPerThread]) {
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                const uint32_t e = (uint32_t)tid + 256u * k;
+                const uint32_t g = min(t_first * (uint32_t)(kMfmaSteps * 64) + e, last_entry);   // clamp: stay inside the slice
+                r[k] = dA[g];
+            }
+        };
+        auto park = [&](int buf, const h8 (&r)[kPerThread]) {
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) {
+                const uint32_t e = (uint32_t)tid + 256u * k;
+                if (e < (uint32_t)kStageEntries) stage[buf][e] = r[k];
+            }
+        };
+        h8 regs[kPerThread];
+        fetch(t0, regs);
+        park(0, regs);
+        __syncthreads();
+        int buf = 0;
+        for (uint32_t t = t0; t < t1; t += kStageTiles) {
+            const bool more = t + kStageTiles < t1;
+            if (more) fetch(t + kStageTiles, regs);   // in flight while this stage is multiplied
+            const uint32_t in_stage = min((uint32_t)kStageTiles, t1 - t);
+            for (uint32_t u = 0; u < in_stage; ++u) {
+                h8 cur[kMfmaSteps];
+#pragma unroll
+                for (int s = 0; s < kMfmaSteps; ++s) cur[s] = stage[buf][(u * kMfmaSteps + s) * 64 + lane];
+                f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+                for (int s = 0; s < kMfmaSteps; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], acc1, 0, 0, 0);
+                }
+                const uint32_t row0 = (t + u) * 32u + 4u * half;
+                mfma_post<MIN_ONLY>(acc0, sa, two_ea, live_a, row0, ndb, ring_a);
+                mfma_post<MIN_ONLY>(acc1, sb, two_eb, live_b, row0, ndb, ring_b);
+            }
+            if (more) park(buf ^ 1, regs);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    if (MIN_ONLY) {
+        if (qa < nq) part_min[(size_t)slice * nq + qa] = sa.best;
+        if (qb < nq) part_min[(size_t)slice * nq + qb] = sb.best;
+        return;
+    }
+    if (qa < nq) {
+        const size_t o = (size_t)slice * nq + qa;
+        ring_count[o] = sa.cnt;
+        part_min[o] = two_ea < INFINITY ? sa.best : -INFINITY;
+        evict_min[o] = sa.ev;
+    }
+    if (qb < nq) {
+        const size_t o = (size_t)slice * nq + qb;
+        ring_count[o] = sb.cnt;
+        part_min[o] = two_eb < INFINITY ? sb.best : -INFINITY;
+        evict_min[o] = sb.ev;
+    }
+}
+
+void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb,
+                      uint32_t tiles_per_split, uint32_t splits, float max_dn2, float* premin /* 2 splits nq */,
+                      uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min, hipStream_t s) {
+    const h8* q8 = reinterpret_cast<const h8*>(qB);
+    const h8* d8 = reinterpret_cast<const h8*>(dA);
+    const uint32_t n_tiles = (ndb + 31u) / 32u;
+    const dim3 grid((nq + 255) / 256, splits);
+    // warm-up over the first 1/16 of the database (same grid: every slice of the main pass takes a share)
+    const uint32_t warm = std::min<uint32_t>(n_tiles, std::max<uint32_t>(splits, n_tiles / 16));
+    const uint32_t warm_per = (warm + splits - 1) / splits;
+    nn16_scan_k<true><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, warm, warm_per, max_dn2, nullptr, 0, nullptr, nullptr,
+                                          premin, nullptr);
+    nn16_scan_k<false><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, n_tiles, tiles_per_split, max_dn2, premin, 2 * splits,
+                                           ring, ring_count, part_min, evict_min);
+}
+
+}  // namespace m3d

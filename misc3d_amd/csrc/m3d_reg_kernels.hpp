@@ -73,7 +73,7 @@ void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s);
 void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale, int role, void* out, float* norm2,
                      hipStream_t s);
 hipError_t launch_nn_mfma33(const double* q, const void* qB, const float* qn, uint32_t nq, const double* db,
-                            const void* dA, uint32_t ndb, float max_dn2, uint32_t splits, uint2* ring,
+                            const void* dA, uint32_t ndb, float max_dn2, uint32_t splits, float* premin, uint2* ring,
                             uint32_t* ring_count, float* part_min, float* evict_min, uint32_t* overflow_list,
                             uint32_t* overflow_count, uint32_t* nn, uint32_t* h_overflow, hipStream_t s);
 

@@ -928,10 +928,10 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf fs, fd, bd, bi, nn01, nn10, fs32, fd32, ns2, nd2, ring, ring_count, evict, over_list, scal, pA_s, pA_d,
-        pB_s, pB_d;
+        pB_s, pB_d, premin;
     auto done = [&](int r) {
         for (DevBuf* b : {&fs, &fd, &bd, &bi, &nn01, &nn10, &fs32, &fd32, &ns2, &nd2, &ring, &ring_count, &evict,
-                          &over_list, &scal, &pA_s, &pA_d, &pB_s, &pB_d})
+                          &over_list, &scal, &pA_s, &pA_d, &pB_s, &pB_d, &premin})
             b->release();
         return r;
     };
@@ -944,9 +944,10 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     const bool screened = dim == 33 && !(brute_env && brute_env[0] == '1');
     bool use_mfma = screened && !(screen_env && screen_env[0] == 'f');
     // enough (query block x database split) workgroups to fill the chip
-    auto splits_for = [](uint32_t nq, uint32_t ndb, uint32_t q_per_block, uint32_t rows_per_unit) {
+    auto splits_for = [](uint32_t nq, uint32_t ndb, uint32_t q_per_block, uint32_t rows_per_unit,
+                         uint32_t want_blocks = 2048) {
         const uint32_t blocks = (nq + q_per_block - 1) / q_per_block;
-        uint32_t s = std::max<uint32_t>(1, (2048 + blocks - 1) / blocks);
+        uint32_t s = std::max<uint32_t>(1, (want_blocks + blocks - 1) / blocks);
         return std::min<uint32_t>(s, std::max<uint32_t>(1, ndb / rows_per_unit));
     };
     uint32_t s01 = splits_for(ns, nd, 512, 256), s10 = splits_for(nd, ns, 512, 256);
@@ -978,8 +979,9 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
         }
     }
     if (use_mfma) {
-        s01 = splits_for(ns, nd, 256, 256);
-        s10 = splits_for(nd, ns, 256, 256);
+        // ~3 blocks fit a CU (146 VGPRs): aim for >= 10 rounds of 768 blocks so the last round costs little
+        s01 = splits_for(ns, nd, 256, 1024, 8192);
+        s10 = splits_for(nd, ns, 256, 1024, 8192);
     }
     const uint32_t slices01 = use_mfma ? 2 * s01 : s01, slices10 = use_mfma ? 2 * s10 : s10;
     const size_t part = std::max((size_t)slices01 * ns, (size_t)slices10 * nd);
@@ -995,7 +997,8 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     if (ok && use_mfma) {
         const size_t tile_bytes = (size_t)kMfmaRowHalfs * 2 * 32;
         if (!pA_s.reserve(tile_bytes * mfma_tiles(ns)) || !pA_d.reserve(tile_bytes * mfma_tiles(nd)) ||
-            !pB_s.reserve(tile_bytes * mfma_query_tiles(ns)) || !pB_d.reserve(tile_bytes * mfma_query_tiles(nd)))
+            !pB_s.reserve(tile_bytes * mfma_query_tiles(ns)) || !pB_d.reserve(tile_bytes * mfma_query_tiles(nd)) ||
+            !premin.reserve(sizeof(float) * part))
             return done(M3D_ERR_DEVICE);
         launch_pack_f16(fs.as<double>(), ns, mfma_tiles(ns), scale, 0, pA_s.p, ns2.as<float>(), ctx->stream);
         launch_pack_f16(fd.as<double>(), nd, mfma_tiles(nd), scale, 0, pA_d.p, nd2.as<float>(), ctx->stream);
@@ -1008,11 +1011,11 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
              hipStreamSynchronize(ctx->stream) == hipSuccess;
         // the two std::threads of correspondence_matching.cpp:59-62 become two passes on one stream
         ok = ok && launch_nn_mfma33(fs.as<double>(), pB_s.p, ns2.as<float>(), ns, fd.as<double>(), pA_d.p, nd, h_max[1],
-                                    s01, ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(),
+                                    s01, premin.as<float>(), ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(),
                                     evict.as<float>(), over_list.as<uint32_t>(), scal.as<uint32_t>() + 2,
                                     nn01.as<uint32_t>(), &over01, ctx->stream) == hipSuccess;
         ok = ok && launch_nn_mfma33(fd.as<double>(), pB_d.p, nd2.as<float>(), nd, fs.as<double>(), pA_s.p, ns, h_max[0],
-                                    s10, ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(),
+                                    s10, premin.as<float>(), ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(),
                                     evict.as<float>(), over_list.as<uint32_t>(), scal.as<uint32_t>() + 2,
                                     nn10.as<uint32_t>(), &over10, ctx->stream) == hipSuccess;
         g_match_fallbacks = (uint64_t)over01 + over10;
