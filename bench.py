@@ -71,10 +71,11 @@ def load_pmc_traffic():
 def cpu_baseline(pts, thr, seed, budget_s):
     import oracle
     threads = oracle.omp_threads()
+    oracle.fit_omp_baseline(0, pts, None, thr, max(threads, 4), seed)   # thread pool / page warm-up
     t0 = time.perf_counter()
-    oracle.fit_omp_baseline(0, pts, None, thr, max(threads, 4), seed)   # calibration
+    oracle.fit_omp_baseline(0, pts, None, thr, 2 * max(threads, 4), seed)   # calibration: two rounds per thread
     dt = time.perf_counter() - t0
-    per_h = dt / max(threads, 4)
+    per_h = dt / (2 * max(threads, 4))
     H = int(max(threads * 2, min(200000, budget_s / max(per_h, 1e-9))))
     H = (H // threads) * threads or threads
     t0 = time.perf_counter()

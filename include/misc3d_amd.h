@@ -101,6 +101,10 @@ int m3d_cloud_fit(m3d_cloud *cloud, int kind, double threshold, size_t max_itera
  * Any of counts/valid/models may be NULL. */
 int m3d_draw_samples(size_t n_points, int kind, size_t n_hypotheses, uint64_t seed,
                      uint32_t *samples);
+/* Estimator::MinimalFit (ransac.h:138-162, 239-294, 354-417) for one sample on the HOST: pts = m x 3
+ * doubles (m = 3 / 4 / 2), normals = m x 3 (cylinder only).  model: 8 doubles (first 4 / 7 = parameters),
+ * *valid = MinimalFit's return.  Bit-identical to what the device computes for the same sample. */
+int m3d_minimal_fit(int kind, const double *pts, const double *normals, double *model, uint8_t *valid);
 int m3d_cloud_score_range(m3d_cloud *cloud, int kind, double threshold, const uint32_t *samples,
                           size_t begin, size_t end, uint32_t *counts, uint8_t *valid,
                           double *models);

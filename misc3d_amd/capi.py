@@ -84,6 +84,7 @@ def lib():
         L.m3d_cloud_destroy.argtypes = [C.c_void_p]
         L.m3d_cloud_destroy.restype = None
         L.m3d_cloud_size.argtypes = [C.c_void_p]
+        L.m3d_minimal_fit.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_size.restype = C.c_size_t
         L.m3d_cloud_fit.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_double, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -253,6 +254,7 @@ class Cloud:
             raise ValueError("normals and points differ in length")
         self.n = len(xyz)            # points currently in the cloud (shrinks with remove_inliers)
         self.n_created = len(xyz)    # index lists refer to the cloud as created
+        self._host_xyz, self._host_nrm = xyz, nrm     # for minimal_model (host-side MinimalFit of one sample)
         self._h = lib().m3d_cloud_create(_p(xyz), _p(nrm), self.n, device)
         if not self._h:
             raise M3DError(ERR_DEVICE, last_error())
@@ -337,6 +339,21 @@ class Cloud:
         rc = _check(lib().m3d_cloud_refine(self._h, kind, threshold, _p(params), _p(inl),
                                            C.cast(C.byref(ni), C.c_void_p)))
         return rc, params, (inl[: ni.value].copy() if copy else inl[: ni.value])
+
+    def minimal_model(self, kind, threshold, sample_row):
+        """MinimalFit of ONE sample -> 8-double model record.  Host-side (m3d_minimal_fit, bit-identical to the
+        device) while the cloud is as created; after remove_inliers the sample indexes the shrunk device
+        cloud, so the one-row device launch is used."""
+        row = np.ascontiguousarray(sample_row, dtype=np.uint32).reshape(-1)
+        if self.n == self.n_created:
+            pts = np.ascontiguousarray(self._host_xyz[row])
+            nrm = np.ascontiguousarray(self._host_nrm[row]) if self._host_nrm is not None else None
+            model = np.zeros(8)
+            ok = C.c_uint8(0)
+            _check(lib().m3d_minimal_fit(kind, _p(pts), _p(nrm), _p(model), C.cast(C.byref(ok), C.c_void_p)))
+            return model[: NUM_PARAMS[kind]].copy()
+        _, mod, _ = self.score_range(kind, threshold, row.reshape(1, -1), 0, 1)
+        return mod[0]
 
     def remove_inliers(self, kind, threshold, model):
         """m3d_cloud_remove_inliers: SelectByIndex(inliers of `model`, invert=True) in place -> #removed."""

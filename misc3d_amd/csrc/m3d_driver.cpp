@@ -19,6 +19,7 @@
 //
 // There is no CPU fallback: every entry point needs a HIP device.
 #include "m3d_driver.hpp"
+#include "m3d_fp.hpp"
 #include "m3d_reg_kernels.hpp"
 
 #include <algorithm>
@@ -1111,6 +1112,25 @@ int m3d_draw_samples(size_t n_points, int kind, size_t n_hypotheses, uint64_t se
     return M3D_OK;
 }
 
+// MinimalFit on the host for ONE sample (ransac.h:576-582): the same m3d_fp.hpp code the device runs, compiled
+// for the host with the same flags (no contraction), so the model is bit-identical to minimal_fit_k's.
+int m3d_minimal_fit(int kind, const double* pts, const double* normals, double* model, uint8_t* valid) {
+    if (kind < 0 || kind > 2 || !pts || !model || !valid || (kind == M3D_CYLINDER && !normals))
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    double par[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool ok;
+    if (kind == M3D_PLANE)
+        ok = plane_minimal_fit(pts, pts + 3, pts + 6, par);
+    else if (kind == M3D_SPHERE)
+        ok = sphere_minimal_fit(pts, par);
+    else
+        ok = cylinder_minimal_fit(pts, normals, par);
+    if (!ok) std::memset(par, 0, sizeof(par));
+    std::memcpy(model, par, sizeof(par));
+    *valid = ok ? 1 : 0;
+    return M3D_OK;
+}
+
 int m3d_cloud_score_range(m3d_cloud* c, int kind, double threshold, const uint32_t* samples,
                           size_t begin, size_t end, uint32_t* counts, uint8_t* valid, double* models) {
     if (!c || kind < 0 || kind > 2 || !samples || end < begin)
@@ -1222,9 +1242,12 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     for (size_t b = begin; b < end; b += slice, ++j) {
         const size_t e = std::min(end, b + slice);
         // every rank draws the whole stream (the host draws the other ranks' slices while this rank's
-        // previous slice is being scored on the GPU)
-        sampler->draw_until(e);
-        if (j % world != rank) continue;
+        // previous slice is being scored on the GPU); its own slices are drawn piece by piece, so the first
+        // (small) piece is on the GPU before the rest of the slice has been drawn
+        if (j % world != rank) {
+            sampler->draw_until(e);
+            continue;
+        }
         // the first piece of the call is small: its best count lets the rest skip hopeless hypotheses
         // (bound-and-prune against LOWER-index hypotheses of this rank only, which is what the
         // sequential replay allows; the rank's first hypothesis index is its smallest)
@@ -1232,6 +1255,7 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
             const size_t piece = first_piece ? std::min<size_t>(256, chunk_cap) : chunk_cap;
             first_piece = false;
             const size_t ee = std::min(e, bb + piece);
+            sampler->draw_until(ee);
             int rc = collect(cur);
             if (rc != M3D_OK) return rc;
             tsrc.table = sampler->table.data();

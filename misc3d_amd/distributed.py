@@ -89,6 +89,8 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
         i = int(i)
         if best_model is not None and i == best_model[0]:
             return best_model[1]
+        if hasattr(scorer, "minimal_model"):          # host-side MinimalFit of that one sample (no launch)
+            return scorer.minimal_model(kind, threshold, sampler.table(i + 1)[i])
         _, mod, _ = scorer.score_range(kind, threshold, sampler.table(i + 1), i, i + 1)   # one-row launch (rare)
         return mod[0]
 
@@ -97,7 +99,9 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
         return 1e10 if cnt == 0 else err / float(np.sqrt(float(cnt)))
 
     cb = capi.RMSE_FN(rmse_of)
-    K = 2   # slices per rank and window: the host draws the other ranks' slices while the GPU scores
+    # slices per rank and window: with several ranks the host draws the other ranks' slices while the GPU
+    # scores (two interleaved slices per rank keep every GPU busy early); alone, one slice = fewest launches
+    K = 2 if world > 1 else 1
     while begin < H and not st.stopped:
         end = min(H, begin + window)
         n_win = end - begin

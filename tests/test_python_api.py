@@ -157,3 +157,32 @@ def test_cpp_host_api_executable():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_host_minimal_fit_matches_oracle(orc, kind):
+    """m3d_minimal_fit (host-side MinimalFit used by the sharded driver for the winning hypothesis) is
+    bit-identical to the oracle's MinimalFit, degenerate samples included.  Pure host code: no GPU needed."""
+    import ctypes as C
+    from misc3d_amd import capi, synth
+    if kind == 2:
+        pts, nrm = synth.cylinder_cloud_c3(3000, 3)
+    else:
+        pts, nrm = (synth.sphere_cloud_c3(3000, 4) if kind == 1 else synth.plane_cloud_c1(3000, 1)), None
+    m = capi.MINIMAL_SAMPLE[kind]
+    samples = capi.draw_samples(len(pts), kind, 400, 5)
+    samples[7] = samples[7][0]              # degenerate: repeated point
+    v, models, _, _ = orc.score_samples(kind, pts, nrm, 0.01, samples.astype(np.uint64))
+    for h in range(len(samples)):
+        p = np.ascontiguousarray(pts[samples[h]])
+        n = np.ascontiguousarray(nrm[samples[h]]) if nrm is not None else None
+        out = np.zeros(8)
+        ok = C.c_uint8(9)
+        rc = capi.lib().m3d_minimal_fit(kind, p.ctypes.data_as(C.c_void_p),
+                                        n.ctypes.data_as(C.c_void_p) if n is not None else None,
+                                        out.ctypes.data_as(C.c_void_p), C.cast(C.byref(ok), C.c_void_p))
+        assert rc == 1 and ok.value == v[h]
+        if v[h]:
+            k = capi.NUM_PARAMS[kind]
+            assert np.array_equal(out[:k].view(np.uint64), models[h][:k].view(np.uint64)), h
+    assert m in (2, 3, 4)
