@@ -1,0 +1,83 @@
+"""Generate the committed golden vectors of tests/golden/*.npz.
+
+The reference has no tests or golden vectors of its own and cannot be built or
+imported in this image, so these fixtures are produced by the ORACLE (oracle/, the CPU restatement --
+"parity unpinned", see its header) in this container and committed as data: inputs and expected outputs.
+They (1) freeze the oracle against silent changes and platform differences (CPU test), and (2) let the
+HIP path be checked against data without building the oracle (GPU test).
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from misc3d_amd import capi, synth  # noqa: E402
+
+THR = 0.01
+
+
+def fits():
+    out = {}
+    clouds = {0: (synth.plane_cloud_c1(1500, 1), None), 1: (synth.sphere_cloud_c3(1500, 4), None),
+              2: synth.cylinder_cloud_c3(1500, 3)}
+    for kind, (pts, nrm) in clouds.items():
+        pts = np.ascontiguousarray(pts)
+        m = capi.MINIMAL_SAMPLE[kind]
+        samples = capi.draw_samples(len(pts), kind, 200, 21 + kind)           # host-only sampler of the C ABI
+        osamp = oracle.draw_samples(len(pts), m, 200, 21 + kind)
+        assert np.array_equal(samples.astype(np.uint64), np.asarray(osamp, dtype=np.uint64).reshape(samples.shape))
+        v, models, counts, errors = oracle.score_samples(kind, pts, nrm, THR, samples.astype(np.uint64))
+        pre = f"k{kind}_"
+        out[pre + "points"] = pts
+        if nrm is not None:
+            out[pre + "normals"] = np.ascontiguousarray(nrm)
+        out[pre + "samples"] = samples
+        out[pre + "valid"] = np.asarray(v, dtype=np.uint8)
+        out[pre + "models"] = np.asarray(models)
+        out[pre + "counts"] = np.asarray(counts, dtype=np.uint64)
+        for tag, (mi, prob, seed) in {"a": (300, 0.9999, 7), "b": (150, 1.0, 11)}.items():
+            r = oracle.fit(kind, pts, nrm, thr=THR, max_iter=mi, prob=prob, seed=seed)
+            out[pre + tag + "_args"] = np.array([mi, prob, seed], dtype=np.float64)
+            out[pre + tag + "_ret_best_count_iter"] = np.array([r.ret, r.best_index, r.count, r.iterations], dtype=np.int64)
+            out[pre + tag + "_fitness"] = np.array([r.fitness])
+            out[pre + tag + "_params"] = r.params
+            out[pre + tag + "_inliers"] = r.inliers.astype(np.uint64)
+    np.savez_compressed(os.path.join(HERE, "fits.npz"), **out)
+
+
+def segmentation():
+    pts = np.ascontiguousarray(synth.room_cloud_c5(3000, 6))
+    rc, planes, clusters = oracle.segment_plane_iterative(pts, 0.02, 120, 0.15, seed=19)
+    out = {"points": pts, "args": np.array([0.02, 120, 0.15, 19]), "rc": np.array([rc]), "planes": planes,
+           "offsets": np.cumsum([0] + [len(c) for c in clusters]).astype(np.uint64),
+           "indices": np.concatenate(clusters).astype(np.uint64)}
+    np.savez_compressed(os.path.join(HERE, "segmentation.npz"), **out)
+
+
+def registration():
+    d = synth.registration_pair_c4(1200, seed=5, dim=33, true_fraction=0.5, sigma=0.001)
+    a, b = oracle.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    o = oracle.registration_ransac(d["src"], d["dst"], a, b, thr=0.03, max_iter=800, edge_thr=0.9, confidence=1.0, seed=17)
+    T = oracle.umeyama(d["src"][a[:200]], d["dst"][b[:200]], with_scaling=False)
+    Ts = oracle.umeyama(d["src"][a[:200]], 1.5 * d["dst"][b[:200]], with_scaling=True)
+    out = {"src": d["src"], "dst": d["dst"], "feat_src": d["feat_src"], "feat_dst": d["feat_dst"],
+           "match_src": np.asarray(a, dtype=np.uint64), "match_dst": np.asarray(b, dtype=np.uint64),
+           "ransac_args": np.array([0.03, 800, 0.9, 1.0, 17]), "ransac_T": o.T,
+           "ransac_stats": np.array([o.best_index, o.iterations, o.validations, o.est_k], dtype=np.int64),
+           "ransac_fitness_rmse": np.array([o.fitness, o.inlier_rmse]), "kabsch_T": T, "kabsch_T_scaled": Ts}
+    np.savez_compressed(os.path.join(HERE, "registration.npz"), **out)
+
+
+if __name__ == "__main__":
+    fits()
+    segmentation()
+    registration()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
