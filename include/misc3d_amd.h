@@ -208,6 +208,26 @@ int m3d_reg_validate(m3d_reg *reg, size_t s_begin, size_t s_end, uint32_t *count
 int m3d_reg_replay(m3d_reg *reg, const uint32_t *counts, const double *sums);
 int m3d_reg_finish(m3d_reg *reg, double T[16], m3d_reg_stats *stats);
 
+/* ---- point-to-point ICP refinement of the RANSAC pose ----------------------- */
+/* open3d::pipelines::registration::RegistrationICP(source, target, max_correspondence_distance, init,
+ * TransformationEstimationPointToPoint(), ICPConvergenceCriteria(relative_fitness, relative_rmse,
+ * max_iteration)) as the reference's examples call it right after RANSACSolver::Solve
+ * (examples/cpp/transform_estimation.cpp:82-86; defaults 1e-6, 1e-6, 30).  T_init: row-major 4x4 or NULL =
+ * identity.  correspondences (n_src entries, may be NULL): target index of every source point, -1 = none
+ * (Open3D's correspondence_set_). */
+typedef struct m3d_icp_stats {
+    double fitness;            /* correspondences / n_src */
+    double inlier_rmse;        /* sqrt(sum d^2 / correspondences) */
+    uint64_t correspondences;
+    int32_t iterations;        /* ICP iterations executed */
+    int32_t converged;         /* 1 = both relative criteria met before max_iteration */
+    double ms_total;
+} m3d_icp_stats;
+int m3d_registration_icp(const double *src, size_t n_src, const double *dst, size_t n_dst,
+                         double max_correspondence_distance, const double *T_init, int max_iteration,
+                         double relative_fitness, double relative_rmse, int device, double T[16],
+                         m3d_icp_stats *stats, int64_t *correspondences);
+
 /* ---- registration::ANNMatcher::Match, src/correspondence_matching.cpp:52-84 ------------------- */
 /* feat_*: Eigen MatrixXd dim x N column-major = N descriptors of dim contiguous doubles.
  * method: 0 FLANN, 1 ANNOY (correspondence_matching.h MatchMethod); both run the exact mutual

@@ -10,6 +10,7 @@ Drop-in for the reference's python API on this path (module layout of python/py_
     idx      = m3d.registration.match_correspondence(fpfh_src, fpfh_dst)
     T        = m3d.registration.compute_transformation_ransac(src, dst, idx, 0.03, 100000)
     T        = m3d.registration.compute_transformation_least_square(src, dst)
+    T, info  = m3d.registration_icp(src, dst, 0.02, T)      # the Open3D call the reference's examples chain next
 
 Layout (only what the path needs):
   csrc/      HIP kernels, host driver, C ABI            -> lib/libmisc3d_amd.so
@@ -40,5 +41,22 @@ device_count = _ext.device_count
 Error, Warning, Info, Debug = (VerbosityLevel.Error, VerbosityLevel.Warning, VerbosityLevel.Info,
                                VerbosityLevel.Debug)
 
-__all__ = ["common", "registration", "segmentation", "VerbosityLevel", "set_verbosity_level",
+
+
+def registration_icp(source, target, max_correspondence_distance, init=None, max_iteration=30,
+                     relative_fitness=1e-6, relative_rmse=1e-6, device=0):
+    """Point-to-point ICP = open3d.pipelines.registration.registration_icp(source, target,
+    max_correspondence_distance, init, TransformationEstimationPointToPoint(), ICPConvergenceCriteria(...)),
+    which the reference's examples run on the pose of compute_transformation_ransac
+    (examples/cpp/transform_estimation.cpp:82-86).  source / target: (N, 3) arrays or objects with `.points`.
+    Returns (4x4 pose, dict(fitness, inlier_rmse, correspondences, iterations, converged))."""
+    import numpy as _np
+
+    from . import capi as _capi
+    pts = [_np.asarray(getattr(c, "points", c), dtype=_np.float64).reshape(-1, 3) for c in (source, target)]
+    return _capi.registration_icp(pts[0], pts[1], max_correspondence_distance, init, max_iteration,
+                                  relative_fitness, relative_rmse, device)
+
+
+__all__ = ["common", "registration", "segmentation", "registration_icp", "VerbosityLevel", "set_verbosity_level",
            "get_verbosity_level", "device_count"]

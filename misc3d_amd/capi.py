@@ -134,6 +134,8 @@ def lib():
         L.m3d_reg_validate.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.m3d_reg_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_reg_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_registration_icp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.c_int,
+                                           C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_match_last_fallbacks.restype = C.c_uint64
         L.m3d_match_last_fallbacks.argtypes = []
         L.m3d_match_mutual_nn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
@@ -436,6 +438,32 @@ def registration_ransac(src, dst, corr_src, corr_dst, threshold=0.01, max_iter=1
                                          max_iter, edge_length_threshold, confidence,
                                          C.cast(sref, C.c_void_p) if sref else None, device, _p(T),
                                          C.cast(C.byref(st), C.c_void_p)))
+    return T.reshape(4, 4), st.asdict()
+
+
+class IcpStats(C.Structure):
+    _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("correspondences", C.c_uint64),
+                ("iterations", C.c_int32), ("converged", C.c_int32), ("ms_total", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def registration_icp(src, dst, max_correspondence_distance, init=None, max_iteration=30, relative_fitness=1e-6,
+                     relative_rmse=1e-6, device=0, want_correspondences=False):
+    """open3d.pipelines.registration.registration_icp(source, target, max_correspondence_distance, init,
+    TransformationEstimationPointToPoint(), ICPConvergenceCriteria(...)) -> (T, stats[, correspondences])."""
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    Ti = _f64(init).reshape(16).copy() if init is not None else None
+    T = np.zeros(16)
+    st = IcpStats()
+    corr = np.zeros(max(len(src), 1), dtype=np.int64) if want_correspondences else None
+    _check(lib().m3d_registration_icp(_p(src), len(src), _p(dst), len(dst), max_correspondence_distance, _p(Ti),
+                                      max_iteration, relative_fitness, relative_rmse, device, _p(T),
+                                      C.cast(C.byref(st), C.c_void_p), _p(corr)))
+    if want_correspondences:
+        return T.reshape(4, 4), st.asdict(), corr[: len(src)]
     return T.reshape(4, 4), st.asdict()
 
 

@@ -79,7 +79,8 @@ void launch_gather_T(const double* T12, const uint32_t* list, uint32_t n, uint32
 __device__ __forceinline__ bool cell_of(const GridDesc& g, double x, double y, double z, int lo_pad,
                                         int* ix, int* iy, int* iz) {
     const double fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
-    // valid query cells are [lo_pad, n - 1 - lo_pad]; NaN fails every comparison
+    // valid query cells are [lo_pad, n - 1 - lo_pad] (the table carries 2K+1 pad cells per side, so this admits
+    // every query within K cells of the bounding box); NaN fails every comparison
     if (!(fx >= (double)lo_pad && fx < (double)(g.nx - lo_pad) && fy >= (double)lo_pad &&
           fy < (double)(g.ny - lo_pad) && fz >= (double)lo_pad && fz < (double)(g.nz - lo_pad)))
         return false;
@@ -187,7 +188,8 @@ __global__ void add_tile_offsets_k(uint32_t* __restrict__ v, uint32_t n, const u
 
 __global__ void grid_scatter_k(CloudView dst, const uint32_t* __restrict__ cell_of_point,
                                const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ fill,
-                               double* __restrict__ qx, double* __restrict__ qy, double* __restrict__ qz) {
+                               double* __restrict__ qx, double* __restrict__ qy, double* __restrict__ qz,
+                               uint32_t* __restrict__ orig) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= dst.n) return;
     const uint32_t cid = cell_of_point[i];
@@ -196,6 +198,7 @@ __global__ void grid_scatter_k(CloudView dst, const uint32_t* __restrict__ cell_
     qx[pos] = dst.x[i];
     qy[pos] = dst.y[i];
     qz[pos] = dst.z[i];
+    if (orig) orig[pos] = i;
 }
 
 __global__ void fill_nan_k(double* __restrict__ p, uint32_t n) {
@@ -209,7 +212,7 @@ void launch_fill_nan(double* p, uint32_t n, hipStream_t s) {
 void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
                        uint32_t* cell_start /* ncell + 1 */, uint32_t* fill /* ncell */,
                        uint32_t* tile_sums, uint32_t* total, double* qx, double* qy, double* qz,
-                       hipStream_t s) {
+                       hipStream_t s, uint32_t* orig) {
     const uint32_t ncell = g.nx * g.ny * g.nz;
     (void)hipMemsetAsync(cell_start, 0, sizeof(uint32_t) * ((size_t)ncell + 1), s);
     (void)hipMemsetAsync(fill, 0, sizeof(uint32_t) * (size_t)ncell, s);
@@ -218,7 +221,7 @@ void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_o
     tile_scan_k<<<nt, 256, 0, s>>>(cell_start, ncell, tile_sums);
     launch_scan_blocks(tile_sums, nt, total, s);
     add_tile_offsets_k<<<(ncell + 1 + 255) / 256, 256, 0, s>>>(cell_start, ncell, tile_sums, total);
-    if (dst.n) grid_scatter_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, cell_of_point, cell_start, fill, qx, qy, qz);
+    if (dst.n) grid_scatter_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, cell_of_point, cell_start, fill, qx, qy, qz, orig);
 }
 
 // Neighbour lists: for every interior cell the points of its 3x3x3 block, packed (x, y, z, 0) and
@@ -240,7 +243,7 @@ __global__ void nl_count_k(GridDesc g, const uint32_t* __restrict__ cell_start, 
 __global__ void nl_fill_k(GridDesc g, const uint32_t* __restrict__ cell_start, uint32_t ncell,
                           const uint32_t* __restrict__ nl_start, const double* __restrict__ qx,
                           const double* __restrict__ qy, const double* __restrict__ qz,
-                          double4* __restrict__ nl_pts) {
+                          double4* __restrict__ nl_pts, const uint32_t* __restrict__ orig) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= ncell) return;
     uint32_t pos = nl_start[c];
@@ -250,7 +253,8 @@ __global__ void nl_fill_k(GridDesc g, const uint32_t* __restrict__ cell_start, u
         for (int dy = -1; dy <= 1; ++dy) {
             const uint32_t row = ((iz + dz) * g.ny + (iy + dy)) * g.nx + ix;
             const uint32_t b = cell_start[row - 1], e = cell_start[row + 2];
-            for (uint32_t k = b; k < e; ++k) nl_pts[pos++] = make_double4(qx[k], qy[k], qz[k], 0.0);
+            for (uint32_t k = b; k < e; ++k)
+                nl_pts[pos++] = make_double4(qx[k], qy[k], qz[k], orig ? (double)orig[k] : 0.0);
         }
 }
 // step 1: counts + exclusive scan into nl_start[0..ncell]; the caller reads nl_start[ncell] (= entries),
@@ -265,9 +269,9 @@ void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl
     add_tile_offsets_k<<<(ncell + 1 + 255) / 256, 256, 0, s>>>(nl_start, ncell, tile_sums, total);
 }
 void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, const double* qx,
-                    const double* qy, const double* qz, double4* nl_pts, hipStream_t s) {
+                    const double* qy, const double* qz, double4* nl_pts, hipStream_t s, const uint32_t* orig) {
     const uint32_t ncell = g.nx * g.ny * g.nz;
-    nl_fill_k<<<(ncell + 255) / 256, 256, 0, s>>>(g, cell_start, ncell, nl_start, qx, qy, qz, nl_pts);
+    nl_fill_k<<<(ncell + 255) / 256, 256, 0, s>>>(g, cell_start, ncell, nl_start, qx, qy, qz, nl_pts, orig);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -691,6 +695,166 @@ void launch_kabsch_sums(const double* src, const double* dst, uint32_t n, double
     kabsch_final_k<6><<<1, 256, 0, s>>>(partial, sums);
     kabsch_sums_k<1><<<256, 256, 0, s>>>(src, dst, n, sums, partial);
     kabsch_final_k<12><<<1, 256, 0, s>>>(partial, sums + 6);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ICP: nearest target point WITH its index, Kabsch sums over the correspondences,
+// in-place transformation of the moving cloud
+// ------------------------------------------------------------------------------------------------
+// (squared distance, original target index) of the nearest target point; lowest index on exact ties (what a
+// serial scan in index order finds).  Same two phases as nearest_d2; the neighbour lists carry the original
+// index in w, the row scan takes it from cell_orig.
+__device__ __forceinline__ void nearest_idx(const GridDesc& g, const uint32_t* __restrict__ cell_start,
+                                            const double* __restrict__ qx, const double* __restrict__ qy,
+                                            const double* __restrict__ qz, const uint32_t* __restrict__ cell_orig,
+                                            double px, double py, double pz, double* d2_out, uint32_t* idx_out) {
+    int ix, iy, iz;
+    double best = INFINITY;
+    uint32_t bo = 0xFFFFFFFFu;
+    *d2_out = best;
+    *idx_out = bo;
+    if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return;
+    bool need_scan = true;
+    if (g.nl_start) {
+        const uint32_t cell = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
+        const uint32_t b = g.nl_start[cell], e = g.nl_start[cell + 1];
+        for (uint32_t c = b; c < e; ++c) {
+            const double4 q = g.nl_pts[c];
+            const double ddx = px - q.x, ddy = py - q.y, ddz = pz - q.z;
+            const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+            const uint32_t o = (uint32_t)q.w;
+            if (d2 < best || (d2 == best && o < bo)) {
+                best = d2;
+                bo = o;
+            }
+        }
+        need_scan = !(best < g.h2_in) && g.K > 1;
+    }
+    if (need_scan) {
+        // (2K+1)^3 block, only the cells that can hold a point at distance <= min(best, r^2) (see nearest_phase2)
+        const int K = g.K;
+        const double h = 1.0 / g.inv_h;
+        const double fx = (px - g.ox) * g.inv_h - (double)ix, fy = (py - g.oy) * g.inv_h - (double)iy,
+                     fz = (pz - g.oz) * g.inv_h - (double)iz;
+        for (int dz = -K; dz <= K; ++dz) {
+            const double gz = axis_gap(dz, fz, h);
+            const double gz2 = gz * gz;
+            if (!(gz2 <= (best < g.r2 ? best : g.r2))) continue;
+            for (int dy = -K; dy <= K; ++dy) {
+                const double gy = axis_gap(dy, fy, h);
+                const double lim = best < g.r2 ? best : g.r2;
+                const double rem = lim - (gz2 + gy * gy);
+                if (!(rem >= 0.0)) continue;
+                int lo = 0, hi = 0;
+                while (lo > -K && axis_gap(lo - 1, fx, h) * axis_gap(lo - 1, fx, h) <= rem) --lo;
+                while (hi < K && axis_gap(hi + 1, fx, h) * axis_gap(hi + 1, fx, h) <= rem) ++hi;
+                const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
+                const uint32_t b = cell_start[row + lo], e = cell_start[row + hi + 1];
+                for (uint32_t c = b; c < e; ++c) {
+                    const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
+                    const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    const uint32_t o = cell_orig[c];
+                    if (d2 < best || (d2 == best && o < bo)) {
+                        best = d2;
+                        bo = o;
+                    }
+                }
+            }
+        }
+    }
+    *d2_out = best;
+    *idx_out = bo;
+}
+
+// GetRegistrationResultAndCorrespondences, per point: nn[i] = target index or 0xFFFFFFFF, d2[i] = its squared
+// distance (+inf when nothing lies within the radius)
+__global__ void icp_nn_k(const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz,
+                         uint32_t n, GridDesc g, const uint32_t* __restrict__ cell_start,
+                         const double* __restrict__ qx, const double* __restrict__ qy, const double* __restrict__ qz,
+                         const uint32_t* __restrict__ cell_orig, uint32_t* __restrict__ nn, double* __restrict__ d2) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    double best;
+    uint32_t bo;
+    nearest_idx(g, cell_start, qx, qy, qz, cell_orig, px[i], py[i], pz[i], &best, &bo);
+    const bool ok = best < g.r2;
+    nn[i] = ok ? bo : 0xFFFFFFFFu;
+    d2[i] = ok ? best : INFINITY;
+}
+void launch_icp_nn(const double* px, const double* py, const double* pz, uint32_t n, const GridDesc& g,
+                   const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
+                   const uint32_t* cell_orig, uint32_t* nn, double* d2, hipStream_t s) {
+    if (n) icp_nn_k<<<(n + 255) / 256, 256, 0, s>>>(px, py, pz, n, g, cell_start, qx, qy, qz, cell_orig, nn, d2);
+}
+
+// Eigen::umeyama sums over the correspondence set (moving point i, target point nn[i]): PASS 0 = the six
+// coordinate sums, PASS 1 = covariance d s^T (9) and |s|^2 (3) about the means.  Order-free tree sums (the
+// n-point Kabsch parity bar is 1e-9).
+template <int PASS>
+__global__ __launch_bounds__(256) void icp_sums_k(const double* __restrict__ px, const double* __restrict__ py,
+                                                   const double* __restrict__ pz, uint32_t n, CloudView dst,
+                                                   const uint32_t* __restrict__ nn, const uint32_t* __restrict__ count,
+                                                   const double* __restrict__ sums0, double* __restrict__ partial) {
+    constexpr int NV = PASS == 0 ? 6 : 12;
+    __shared__ double sm[NV * 256];
+    double acc[NV];
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    double ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+    if (PASS == 1) {
+        const double one_over_n = 1.0 / (double)count[0];
+        for (int k = 0; k < 3; ++k) {
+            ms[k] = sums0[k] * one_over_n;
+            md[k] = sums0[3 + k] * one_over_n;
+        }
+    }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += 256u * 256u) {
+        const uint32_t j = nn[i];
+        if (j == 0xFFFFFFFFu) continue;
+        double s[3] = {px[i], py[i], pz[i]}, d[3] = {dst.x[j], dst.y[j], dst.z[j]};
+        if (PASS == 0) {
+            for (int k = 0; k < 3; ++k) {
+                acc[k] += s[k];
+                acc[3 + k] += d[k];
+            }
+        } else {
+            for (int k = 0; k < 3; ++k) {
+                s[k] -= ms[k];
+                d[k] -= md[k];
+            }
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) acc[3 * r + c] += d[r] * s[c];
+                acc[9 + r] += s[r] * s[r];
+            }
+        }
+    }
+    tree_reduce_256<NV>(acc, sm);
+    if (threadIdx.x < NV) partial[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
+}
+// sums: 18 doubles laid out like launch_kabsch_sums (6 coordinate sums, 9 covariance sums, 3 squared sums)
+void launch_icp_sums(const double* px, const double* py, const double* pz, uint32_t n, const CloudView& dst,
+                     const uint32_t* nn, const uint32_t* count, double* partial, double* sums, hipStream_t s) {
+    icp_sums_k<0><<<256, 256, 0, s>>>(px, py, pz, n, dst, nn, count, nullptr, partial);
+    kabsch_final_k<6><<<1, 256, 0, s>>>(partial, sums);
+    icp_sums_k<1><<<256, 256, 0, s>>>(px, py, pz, n, dst, nn, count, sums, partial);
+    kabsch_final_k<12><<<1, 256, 0, s>>>(partial, sums + 6);
+}
+
+// PointCloud::Transform(update) on the moving cloud, in place (or out of place for the initial pose)
+__global__ void icp_transform_k(const double* __restrict__ ix, const double* __restrict__ iy,
+                                const double* __restrict__ iz, uint32_t n, const double* __restrict__ T,
+                                double* __restrict__ ox, double* __restrict__ oy, double* __restrict__ oz) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    double t[12];
+    for (int k = 0; k < 12; ++k) t[k] = T[k];
+    const double x = ix[i], y = iy[i], z = iz[i];
+    ox[i] = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
+    oy[i] = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
+    oz[i] = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
+}
+void launch_icp_transform(const double* ix, const double* iy, const double* iz, uint32_t n, const double* T_dev,
+                          double* ox, double* oy, double* oz, hipStream_t s) {
+    if (n) icp_transform_k<<<(n + 255) / 256, 256, 0, s>>>(ix, iy, iz, n, T_dev, ox, oy, oz);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -34,12 +34,13 @@ void launch_gather_T(const double* T12, const uint32_t* list, uint32_t n, uint32
                      hipStream_t s);
 void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
                        uint32_t* cell_start, uint32_t* fill, uint32_t* tile_sums, uint32_t* total,
-                       double* qx, double* qy, double* qz, hipStream_t s);
+                       double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr);
 void launch_fill_nan(double* p, uint32_t n, hipStream_t s);
 void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl_start, uint32_t* tile_sums,
                      uint32_t* total, hipStream_t s);
 void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, const double* qx,
-                    const double* qy, const double* qz, double4* nl_pts, hipStream_t s);
+                    const double* qy, const double* qz, double4* nl_pts, hipStream_t s,
+                    const uint32_t* orig = nullptr);
 void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
                          const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
                          uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
@@ -51,6 +52,13 @@ void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* bl
 void launch_corr_ratio(const CloudView& src, const CloudView& dst, const uint32_t* corr_src,
                        const uint32_t* corr_dst, uint32_t m, const double* T, double r2, uint32_t* count,
                        hipStream_t s);
+void launch_icp_nn(const double* px, const double* py, const double* pz, uint32_t n, const GridDesc& g,
+                   const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
+                   const uint32_t* cell_orig, uint32_t* nn, double* d2, hipStream_t s);
+void launch_icp_sums(const double* px, const double* py, const double* pz, uint32_t n, const CloudView& dst,
+                     const uint32_t* nn, const uint32_t* count, double* partial, double* sums, hipStream_t s);
+void launch_icp_transform(const double* ix, const double* iy, const double* iz, uint32_t n, const double* T_dev,
+                          double* ox, double* oy, double* oz, hipStream_t s);
 void launch_kabsch_sums(const double* src, const double* dst, uint32_t n, double* partial, double* sums,
                         hipStream_t s);
 void launch_nn(const double* q, uint32_t nq, const double* db, uint32_t ndb, int dim, uint32_t splits,

@@ -62,12 +62,12 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts;
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, cell_orig;
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
-                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts})
+                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &cell_orig})
             b->release();
     }
 };
@@ -80,6 +80,94 @@ struct RegCtx {
     uint32_t m;
     double thr;
 };
+
+// Uniform grid over the target cloud for radius-bounded exact nearest-neighbour queries (KDTreeFlann stand-in):
+// cell edge h = 1.001 radius / K, K = 4, 2, 1 while the dense cell table fits (<= 2^27 cells incl. 2K+1 pad
+// cells per side; if even K = 1
+// does not fit the cell is doubled: a coarser grid with K = 1 still covers the radius); points counting-
+// sorted by cell (qx/qy/qz + cell_start), optional neighbour lists (3x3x3 block of every cell, contiguous;
+// bounded to 2 M target points; M3D_REG_NL=0 switches them off).  with_orig: also keep the original index of
+// every sorted point (S.cell_orig) and store it in the w component of the neighbour-list entries.
+int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, const double* dst, size_t n_dst,
+                      double radius, bool with_orig, GridDesc* g_out) {
+    GridDesc g;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n_dst; ++i)   // bounding box on the host: one pass over n_dst points
+        for (int k = 0; k < 3; ++k) {
+            const double v = dst[3 * i + k];
+            if (std::isfinite(v)) {
+                lo[k] = std::min(lo[k], v);
+                hi[k] = std::max(hi[k], v);
+            }
+        }
+    for (int k = 0; k < 3; ++k)
+        if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;
+    int K = 4;
+    double h = radius * 1.001 / K;
+    uint64_t dims[3];
+    for (;;) {
+        bool fits = true;
+        uint64_t cells = 1;
+        for (int k = 0; k < 3; ++k) {
+            const double ext = (hi[k] - lo[k]) / h;
+            if (!(ext < 1e9)) {
+                fits = false;
+                break;
+            }
+            dims[k] = (uint64_t)ext + 1 + 2 * (uint64_t)(2 * K + 1);
+            cells *= dims[k];
+            if (cells > ((uint64_t)1 << 27)) fits = false;
+        }
+        if (fits) break;
+        if (K > 1)
+            K /= 2;
+        h *= 2.0;
+    }
+    g.K = K;
+    g.morton_bits = 0;
+    // 2K+1 pad cells on every side: a query up to one radius (< K cells) outside the bounding box still has its
+    // whole (2K+1)^3 search block inside the table, and anything further out cannot have a neighbour
+    g.ox = lo[0] - (2 * K + 1) * h;
+    g.oy = lo[1] - (2 * K + 1) * h;
+    g.oz = lo[2] - (2 * K + 1) * h;
+    g.inv_h = 1.0 / h;
+    g.r2 = radius * radius;  // radius * radius, KDTreeFlann::SearchHybrid
+    g.h2_in = (0.999 * h) * (0.999 * h);
+    g.nx = (uint32_t)dims[0];
+    g.ny = (uint32_t)dims[1];
+    g.nz = (uint32_t)dims[2];
+    const uint32_t ncell = g.nx * g.ny * g.nz;
+    RESERVE(S.cell_of_point, sizeof(uint32_t) * n_dst);
+    RESERVE(S.cell_start, sizeof(uint32_t) * ((size_t)ncell + 1));
+    RESERVE(S.fill, sizeof(uint32_t) * (size_t)ncell);
+    RESERVE(S.tile_sums, sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1));
+    RESERVE(S.total, 16);
+    RESERVE(S.qx, sizeof(double) * n_dst);
+    RESERVE(S.qy, sizeof(double) * n_dst);
+    RESERVE(S.qz, sizeof(double) * n_dst);
+    if (with_orig) RESERVE(S.cell_orig, sizeof(uint32_t) * n_dst);
+    uint32_t* orig = with_orig ? S.cell_orig.as<uint32_t>() : nullptr;
+    launch_grid_build(dst_view, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
+                      S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
+                      S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream, orig);
+    const char* nl_env = std::getenv("M3D_REG_NL");
+    if (!(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
+        RESERVE(S.nl_start, sizeof(uint32_t) * ((size_t)ncell + 1));
+        launch_nl_count(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.tile_sums.as<uint32_t>(),
+                        S.total.as<uint32_t>() + 1, ctx->stream);
+        uint32_t entries = 0;
+        HIPCHK(hipMemcpyAsync(&entries, S.nl_start.as<uint32_t>() + ncell, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        RESERVE(S.nl_pts, sizeof(double4) * std::max<size_t>(entries, 1));
+        launch_nl_fill(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.qx.as<double>(),
+                       S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream, orig);
+        g.nl_start = S.nl_start.as<uint32_t>();
+        g.nl_pts = S.nl_pts.as<double4>();
+    }
+    *g_out = g;
+    return M3D_OK;
+}
 
 // serial-order sum of the nearest squared distances below r^2 (GetRegistrationResult... error2)
 int exact_err2(RegCtx& rc, const double* T_dev, uint64_t* count, double* err2) {
@@ -247,84 +335,10 @@ int reg_setup(m3d_reg& q, const double* src, const double* dst, const size_t* co
     R.m = (uint32_t)m;
     R.thr = threshold;
 
-    // ---- grid over the target (bounding box on the host: one pass over n_dst points)
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (size_t i = 0; i < n_dst; ++i)
-        for (int k = 0; k < 3; ++k) {
-            const double v = dst[3 * i + k];
-            if (std::isfinite(v)) {
-                lo[k] = std::min(lo[k], v);
-                hi[k] = std::max(hi[k], v);
-            }
-        }
-    for (int k = 0; k < 3; ++k)
-        if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;
-    // cell edge h = 1.001 thr / K, K = 4, 2, 1 ... while the dense cell table fits; if even K = 1
-    // does not fit the cell is doubled (a coarser grid with K = 1 still covers radius thr)
-    int K = 4;
-    double h = threshold * 1.001 / K;
-    uint64_t dims[3];
-    for (;;) {
-        bool fits = true;
-        uint64_t cells = 1;
-        for (int k = 0; k < 3; ++k) {
-            const double ext = (hi[k] - lo[k]) / h;
-            if (!(ext < 1e9)) {
-                fits = false;
-                break;
-            }
-            dims[k] = (uint64_t)ext + 1 + 2 * (uint64_t)(K + 1);
-            cells *= dims[k];
-            if (cells > ((uint64_t)1 << 27)) fits = false;
-        }
-        if (fits) break;
-        if (K > 1)
-            K /= 2;
-        h *= 2.0;
-    }
-    g.K = K;
-    g.morton_bits = 0;
-    g.ox = lo[0] - (K + 1) * h;
-    g.oy = lo[1] - (K + 1) * h;
-    g.oz = lo[2] - (K + 1) * h;
-    g.inv_h = 1.0 / h;
-    g.r2 = threshold * threshold;  // radius * radius, KDTreeFlann::SearchHybrid
-    g.h2_in = (0.999 * h) * (0.999 * h);
-    g.nx = (uint32_t)dims[0];
-    g.ny = (uint32_t)dims[1];
-    g.nz = (uint32_t)dims[2];
-    R.g = g;
-    const uint32_t ncell = g.nx * g.ny * g.nz;
-    RESERVE(S.cell_of_point, sizeof(uint32_t) * n_dst);
-    RESERVE(S.cell_start, sizeof(uint32_t) * ((size_t)ncell + 1));
-    RESERVE(S.fill, sizeof(uint32_t) * (size_t)ncell);
-    RESERVE(S.tile_sums, sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1));
-    RESERVE(S.total, 16);
-    RESERVE(S.qx, sizeof(double) * n_dst);
-    RESERVE(S.qy, sizeof(double) * n_dst);
-    RESERVE(S.qz, sizeof(double) * n_dst);
-    launch_grid_build(R.dst, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
-                      S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
-                      S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream);
-    // neighbour lists for phase 1 of the search (27 entries of 32 B per target point: bounded to
-    // 2 M target points; beyond that, or with M3D_REG_NL=0, the row-range search is used)
     {
-        const char* nl_env = std::getenv("M3D_REG_NL");
-        if (!(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
-            RESERVE(S.nl_start, sizeof(uint32_t) * ((size_t)ncell + 1));
-            launch_nl_count(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(),
-                            S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 1, ctx->stream);
-            uint32_t entries = 0;
-            HIPCHK(hipMemcpyAsync(&entries, S.nl_start.as<uint32_t>() + ncell, sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            RESERVE(S.nl_pts, sizeof(double4) * std::max<size_t>(entries, 1));
-            launch_nl_fill(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.qx.as<double>(),
-                           S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream);
-            g.nl_start = S.nl_start.as<uint32_t>();
-            g.nl_pts = S.nl_pts.as<double4>();
-            R.g = g;
-        }
+        const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, false, &g);
+        if (rc_grid != M3D_OK) return rc_grid;
+        R.g = g;
     }
 
     // ---- spatially sorted copy of the SOURCE cloud for the validation kernel: counts and
@@ -911,6 +925,178 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
     return rc;
 }
 
+
+// Point-to-point ICP: Open3D RegistrationICP with TransformationEstimationPointToPoint, which both registration
+// examples of the reference run on the RANSAC pose (examples/cpp/transform_estimation.cpp:82-86); SURVEY.md 8(f)
+// N1.  [RECALL] of the Open3D 0.15.1 loop: oracle/misc3d_oracle_reg.c orc_registration_icp.  Reuses the
+// registration path's target grid (+ original indices), the serial-order error sum, the Kabsch sums and the
+// K3x3 umeyama assembly.  The moving cloud is transformed in place every iteration, as Open3D does.
+int m3d_registration_icp(const double* src, size_t n_src, const double* dst, size_t n_dst,
+                         double max_correspondence_distance, const double* T_init, int max_iteration,
+                         double relative_fitness, double relative_rmse, int device, double* T_out,
+                         m3d_icp_stats* stats, int64_t* correspondences) {
+    const double t_begin = now_ms();
+    if (!T_out || (!src && n_src) || (!dst && n_dst)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double T[16];
+    std::memcpy(T, T_init ? T_init : I4, sizeof(T));
+    std::memcpy(T_out, T, sizeof(T));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (!(max_correspondence_distance > 0.0))   // Open3D: LogError("Invalid max_correspondence_distance.")
+        return fail(M3D_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
+    if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
+    if (n_src == 0 || n_dst == 0) {   // no correspondences: every update is the identity, fitness 0
+        if (correspondences)
+            for (size_t i = 0; i < n_src; ++i) correspondences[i] = -1;
+        if (stats) {
+            stats->iterations = max_iteration > 0 ? 1 : 0;   // the first repeat already meets both criteria
+            stats->converged = max_iteration > 0;
+        }
+        return M3D_OK;
+    }
+    m3d_cloud* csrc = m3d_cloud_create(src, nullptr, n_src, device);
+    if (!csrc) return M3D_ERR_DEVICE;
+    m3d_cloud* cdst = m3d_cloud_create(dst, nullptr, n_dst, device);
+    if (!cdst) {
+        m3d_cloud_destroy(csrc);
+        return M3D_ERR_DEVICE;
+    }
+    DeviceCtx* ctx = csrc->ctx;
+    Scratch S;
+    DevBuf mx, my, mz, nn, d2;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        rc = [&]() -> int {
+            HIPCHK(hipSetDevice(ctx->device));
+            const CloudView sv = csrc->view(), dv = cdst->view();
+            const uint32_t n = sv.n;
+            GridDesc g;
+            const int rg = build_target_grid(ctx, S, dv, dst, n_dst, max_correspondence_distance, true, &g);
+            if (rg != M3D_OK) return rg;
+            const uint32_t nb = (n + 2047) / 2048;
+            RESERVE(mx, sizeof(double) * n);
+            RESERVE(my, sizeof(double) * n);
+            RESERVE(mz, sizeof(double) * n);
+            RESERVE(nn, sizeof(uint32_t) * n);
+            RESERVE(d2, sizeof(double) * n);
+            RESERVE(S.vals, sizeof(double) * n);
+            RESERVE(S.block_counts, sizeof(uint32_t) * ((size_t)nb + 1));
+            RESERVE(S.total, 16);
+            RESERVE(S.sums, sizeof(double) * 32);
+            RESERVE(S.partial_sum, sizeof(double) * 256 * 16);
+            RESERVE(S.one_T, sizeof(double) * kRegTStride);
+            RESERVE(ctx->h_small, 512);
+            double* px = mx.as<double>();
+            double* py = my.as<double>();
+            double* pz = mz.as<double>();
+            auto upload_T = [&](const double* M) -> int {
+                HIPCHK(hipMemcpyAsync(S.one_T.p, M, sizeof(double) * 12, hipMemcpyHostToDevice, ctx->stream));
+                return M3D_OK;
+            };
+            // pcd = source; if (!init.isIdentity()) pcd.Transform(init)
+            if (std::memcmp(T, I4, sizeof(T)) != 0) {
+                const int r = upload_T(T);
+                if (r != M3D_OK) return r;
+                launch_icp_transform(sv.x, sv.y, sv.z, n, S.one_T.as<double>(), px, py, pz, ctx->stream);
+            } else {
+                HIPCHK(hipMemcpyAsync(px, sv.x, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+                HIPCHK(hipMemcpyAsync(py, sv.y, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+                HIPCHK(hipMemcpyAsync(pz, sv.z, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            uint64_t cnt = 0;
+            double e2 = 0.0;
+            // GetRegistrationResultAndCorrespondences: nearest target point within the radius, error2 in source order
+            auto result = [&]() -> int {
+                launch_icp_nn(px, py, pz, n, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
+                              S.qz.as<double>(), S.cell_orig.as<uint32_t>(), nn.as<uint32_t>(), d2.as<double>(),
+                              ctx->stream);
+                launch_compact_vals(d2.as<double>(), n, g.r2, S.block_counts.as<uint32_t>(), S.total.as<uint32_t>(),
+                                    S.vals.as<double>(), ctx->stream);
+                launch_serial_sum(S.vals.as<double>(), S.total.as<uint32_t>(), S.sums.as<double>() + 24, ctx->stream);
+                uint8_t* h = ctx->h_small.as<uint8_t>();
+                HIPCHK(hipMemcpyAsync(h, S.total.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipMemcpyAsync(h + 8, S.sums.as<double>() + 24, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                uint32_t c;
+                std::memcpy(&c, h, 4);
+                std::memcpy(&e2, h + 8, 8);
+                cnt = c;
+                return M3D_OK;
+            };
+            int r = result();
+            if (r != M3D_OK) return r;
+            double fit = (double)cnt / (double)n_src;
+            double rm = cnt ? std::sqrt(e2 / (double)cnt) : 0.0;
+            int it = 0;
+            bool converged = false;
+            for (; it < max_iteration; ++it) {
+                double U[16];
+                std::memcpy(U, I4, sizeof(U));
+                if (cnt) {   // ComputeTransformation: Eigen::umeyama over the correspondence set, no scaling
+                    launch_icp_sums(px, py, pz, n, dv, nn.as<uint32_t>(), S.total.as<uint32_t>(),
+                                    S.partial_sum.as<double>(), S.sums.as<double>(), ctx->stream);
+                    double h[18];
+                    HIPCHK(hipMemcpyAsync(ctx->h_small.p, S.sums.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                    std::memcpy(h, ctx->h_small.p, sizeof(h));
+                    const double one_over_n = 1.0 / (double)cnt;
+                    double ms[3], md[3], sig[9];
+                    for (int k = 0; k < 3; ++k) {
+                        ms[k] = h[k] * one_over_n;
+                        md[k] = h[3 + k] * one_over_n;
+                    }
+                    for (int k = 0; k < 9; ++k) sig[k] = h[6 + k] * one_over_n;
+                    const double src_var = ((h[15] + h[16]) + h[17]) * one_over_n;
+                    umeyama_assemble(ms, md, sig, src_var, false, U);
+                }
+                // transformation = update * transformation
+                double Tn[16];
+                for (int rr = 0; rr < 4; ++rr)
+                    for (int cc = 0; cc < 4; ++cc)
+                        Tn[4 * rr + cc] = ((U[4 * rr] * T[cc] + U[4 * rr + 1] * T[4 + cc]) + U[4 * rr + 2] * T[8 + cc]) +
+                                          U[4 * rr + 3] * T[12 + cc];
+                std::memcpy(T, Tn, sizeof(T));
+                r = upload_T(U);
+                if (r != M3D_OK) return r;
+                launch_icp_transform(px, py, pz, n, S.one_T.as<double>(), px, py, pz, ctx->stream);   // pcd.Transform(update)
+                const double fit0 = fit, rm0 = rm;
+                r = result();
+                if (r != M3D_OK) return r;
+                fit = (double)cnt / (double)n_src;
+                rm = cnt ? std::sqrt(e2 / (double)cnt) : 0.0;
+                if (std::fabs(fit0 - fit) < relative_fitness && std::fabs(rm0 - rm) < relative_rmse) {
+                    ++it;
+                    converged = true;
+                    break;
+                }
+            }
+            std::memcpy(T_out, T, sizeof(T));
+            if (correspondences) {
+                std::vector<uint32_t> hn(n);
+                HIPCHK(hipMemcpy(hn.data(), nn.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+                for (uint32_t i = 0; i < n; ++i) correspondences[i] = hn[i] == 0xFFFFFFFFu ? -1 : (int64_t)hn[i];
+            }
+            if (stats) {
+                stats->fitness = fit;
+                stats->inlier_rmse = rm;
+                stats->correspondences = cnt;
+                stats->iterations = it;
+                stats->converged = converged ? 1 : 0;
+            }
+            return M3D_OK;
+        }();
+        (void)hipStreamSynchronize(ctx->stream);
+        S.release();
+        mx.release(); my.release(); mz.release(); nn.release(); d2.release();
+    }
+    m3d_cloud_destroy(csrc);
+    m3d_cloud_destroy(cdst);
+    if (stats) stats->ms_total = now_ms() - t_begin;
+    return rc;
+}
 
 uint64_t m3d_match_last_fallbacks(void) { return g_match_fallbacks; }
 

@@ -328,6 +328,22 @@ def registration_ransac(src, dst, corr_src, corr_dst, thr=0.01, max_iter=100000,
                      int(st.best_index), int(st.est_k), arrs)
 
 
+def registration_icp(src, dst, max_dist, T_init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+    """-> (T 4x4, fitness, inlier_rmse, iterations, correspondences (ns,) int64 with -1 = none)"""
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    Ti = _f64(T_init if T_init is not None else np.eye(4)).reshape(16).copy()
+    T = np.zeros(16)
+    fit, rm = C.c_double(0), C.c_double(0)
+    nc = C.c_uint64(0)
+    corr = np.zeros(max(len(src), 1), dtype=np.int64)
+    lib().orc_registration_icp.restype = C.c_int
+    it = lib().orc_registration_icp(_p(src), C.c_size_t(len(src)), _p(dst), C.c_size_t(len(dst)), C.c_double(max_dist),
+                                    _p(Ti), C.c_int(max_iter), C.c_double(rel_fitness), C.c_double(rel_rmse), _p(T),
+                                    C.byref(fit), C.byref(rm), C.byref(nc), _p(corr))
+    return T.reshape(4, 4), float(fit.value), float(rm.value), int(it), corr[: len(src)]
+
+
 def match_mutual_nn(feat_src, feat_dst):
     """feat_*: (N, dim) row-major == Eigen dim x N column-major (correspondence_matching.h:39-41)."""
     fs = _f64(feat_src)

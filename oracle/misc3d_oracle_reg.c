@@ -372,6 +372,117 @@ int orc_registration_ransac(const double *src, size_t ns, const double *dst, siz
 /* ANNOY backend approximates the same thing and is not restatable: multi-threaded forest build   */
 /* with per-thread seeds, annoylib.h:1144-1146).  L2 accumulated in dimension order (nanoflann    */
 /* L2_Simple_Adaptor [RECALL]); ties -> lowest index.                                             */
+/* ---------------------------------------------------------------------------------------------
+ * Point-to-point ICP.  SURVEY.md 8(f) N1: both of the reference's registration examples chain Open3D's
+ * RegistrationICP on the RANSAC pose (examples/cpp/transform_estimation.cpp:82-86 with
+ * TransformationEstimationPointToPoint and the default ICPConvergenceCriteria(1e-6, 1e-6, 30)).
+ * [RECALL] Open3D 0.15.1 Registration.cpp RegistrationICP:
+ *   pcd = source; if init is not identity: pcd.Transform(init)
+ *   result = GetRegistrationResultAndCorrespondences(pcd, target, kdtree, max_dist, init)
+ *   for i < max_iteration:
+ *       update = ComputeTransformation(pcd, target, result.correspondence_set)   (umeyama, no scaling)
+ *       transformation = update * transformation;  pcd.Transform(update)
+ *       backup = result;  result = GetRegistrationResultAndCorrespondences(...)
+ *       if |backup.fitness - result.fitness| < relative_fitness && |backup.rmse - result.rmse| < relative_rmse: break
+ * Canonical choices of this restatement (the reference's are thread- / Eigen-order dependent): error2 and
+ * the umeyama sums in source order; nearest neighbour = smallest squared distance, lowest target index on
+ * exact ties; 4x4 product rows accumulated left to right.
+ * Returns the number of ICP iterations executed; corr (size ns, may be NULL): target index or -1. */
+static void icp_result(const double *pcd, size_t ns, const double *dst, size_t nd, double max_dist,
+                       int64_t *corr, uint64_t *count, double *err2) {
+    const double r2 = max_dist * max_dist;
+    double *best = (double *)malloc(sizeof(double) * (ns ? ns : 1));
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)ns; ++i) {
+        const double *p = pcd + 3 * i;
+        double bd = INFINITY;
+        int64_t bj = -1;
+        for (size_t j = 0; j < nd; ++j) {
+            const double dx = p[0] - dst[3 * j], dy = p[1] - dst[3 * j + 1], dz = p[2] - dst[3 * j + 2];
+            const double d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < bd) {
+                bd = d2;
+                bj = (int64_t)j;
+            }
+        }
+        best[i] = bd;
+        corr[i] = (bd < r2) ? bj : -1;
+    }
+    uint64_t c = 0;
+    double e = 0;
+    for (size_t i = 0; i < ns; ++i)
+        if (corr[i] >= 0) {
+            e += best[i];
+            c++;
+        }
+    free(best);
+    *count = c;
+    *err2 = e;
+}
+
+static void mat4_mul(const double *A, const double *B, double *Cm) {
+    double t[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            t[4 * r + c] = ((A[4 * r] * B[c] + A[4 * r + 1] * B[4 + c]) + A[4 * r + 2] * B[8 + c]) + A[4 * r + 3] * B[12 + c];
+    memcpy(Cm, t, sizeof(t));
+}
+
+int orc_registration_icp(const double *src, size_t ns, const double *dst, size_t nd, double max_dist,
+                         const double *T_init, int max_iter, double rel_fitness, double rel_rmse, double *T_out,
+                         double *fitness, double *rmse, uint64_t *n_corr, int64_t *corr_out) {
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    double T[16];
+    memcpy(T, T_init ? T_init : I4, sizeof(T));
+    double *pcd = (double *)malloc(sizeof(double) * 3 * (ns ? ns : 1));
+    double *gs = (double *)malloc(sizeof(double) * 3 * (ns ? ns : 1));
+    double *gd = (double *)malloc(sizeof(double) * 3 * (ns ? ns : 1));
+    int64_t *corr = (int64_t *)malloc(sizeof(int64_t) * (ns ? ns : 1));
+    memcpy(pcd, src, sizeof(double) * 3 * ns);
+    if (memcmp(T, I4, sizeof(T)) != 0) orc_transform_points(T, src, ns, pcd);
+    uint64_t cnt = 0;
+    double e2 = 0;
+    icp_result(pcd, ns, dst, nd, max_dist, corr, &cnt, &e2);
+    double fit = ns ? (double)cnt / (double)ns : 0.0;
+    double rm = cnt ? sqrt(e2 / (double)cnt) : 0.0;
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        double U[16];
+        memcpy(U, I4, sizeof(U));
+        if (cnt) {   // ComputeTransformation: identity for an empty correspondence set
+            size_t k = 0;
+            for (size_t i = 0; i < ns; ++i)
+                if (corr[i] >= 0) {
+                    memcpy(gs + 3 * k, pcd + 3 * i, 3 * sizeof(double));
+                    memcpy(gd + 3 * k, dst + 3 * corr[i], 3 * sizeof(double));
+                    ++k;
+                }
+            orc_umeyama(gs, gd, k, 0, U);
+        }
+        mat4_mul(U, T, T);
+        orc_transform_points(U, pcd, ns, gs);   // pcd.Transform(update): the cloud itself moves (roundings accumulate)
+        memcpy(pcd, gs, sizeof(double) * 3 * ns);
+        const double fit0 = fit, rm0 = rm;
+        icp_result(pcd, ns, dst, nd, max_dist, corr, &cnt, &e2);
+        fit = ns ? (double)cnt / (double)ns : 0.0;
+        rm = cnt ? sqrt(e2 / (double)cnt) : 0.0;
+        if (fabs(fit0 - fit) < rel_fitness && fabs(rm0 - rm) < rel_rmse) {
+            ++it;
+            break;
+        }
+    }
+    memcpy(T_out, T, sizeof(T));
+    *fitness = fit;
+    *rmse = rm;
+    *n_corr = cnt;
+    if (corr_out) memcpy(corr_out, corr, sizeof(int64_t) * ns);
+    free(pcd);
+    free(gs);
+    free(gd);
+    free(corr);
+    return it;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 void orc_nearest(const double *q, size_t nq, const double *db, size_t ndb, int dim, int64_t *nn) {
 #pragma omp parallel for schedule(static)

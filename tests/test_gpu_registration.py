@@ -115,6 +115,28 @@ def test_registration_session_sharded_equals_single_call(capi):
         assert np.array_equal(T0, T2) and all(st0[k] == st2[k] for k in keys)
 
 
+def test_registration_source_overhangs_target_bbox(capi, orc):
+    """Source points OUTSIDE the target's bounding box but within the threshold of a boundary point are
+    correspondences too (a kd-tree radius search has no box): the grid must carry enough pad cells.  Target =
+    a square patch; source = the same patch grown by up to one threshold on every side."""
+    rng = np.random.default_rng(31)
+    thr = 0.05
+    dst = np.c_[rng.uniform(0, 1, 4000), rng.uniform(0, 1, 4000), rng.normal(0, 1e-3, 4000)]
+    edge = np.c_[rng.uniform(-0.9 * thr, 1 + 0.9 * thr, 3000), rng.uniform(-0.9 * thr, 1 + 0.9 * thr, 3000),
+                 rng.uniform(-0.5 * thr, 0.5 * thr, 3000)]
+    src = np.concatenate([dst[:2000] + rng.normal(0, 1e-3, (2000, 3)), edge])
+    cs = rng.integers(0, 2000, 600)
+    cd = cs.copy()
+    cd[::4] = rng.integers(0, 4000, len(cd[::4]))
+    o = orc.registration_ransac(src, dst, cs, cd, thr=thr, max_iter=300, confidence=1.0, seed=2)
+    T, st = capi.registration_ransac(src, dst, cs, cd, threshold=thr, max_iter=300, confidence=1.0, seed=2)
+    assert st["best_index"] == o.best_index and st["validations"] == o.validations > 20
+    assert st["fitness"] == o.fitness and np.array_equal(T.view(np.uint64), o.T.view(np.uint64))
+    outside = ((src[:, :2] < 0) | (src[:, :2] > 1)).any(axis=1)
+    cnt, _ = orc.reg_validate(src[outside], dst, np.eye(4).ravel(), thr)
+    assert cnt > 100        # the case is real: many overhanging points do have a neighbour
+
+
 def test_registration_grid_edge_cases(capi, orc):
     # target far from the origin, threshold comparable to the extent, points exactly on cell borders
     rng = np.random.default_rng(7)
@@ -274,3 +296,43 @@ def test_c4_pipeline_properties(capi):
     T2, st2 = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=20_000,
                                        confidence=1.0, seed=17)
     assert np.array_equal(T, T2) and st2["best_index"] == st["best_index"]
+
+
+@pytest.mark.parametrize("case", ["refine", "identity_far", "no_convergence", "duplicates", "nonfinite"])
+def test_registration_icp_matches_oracle(capi, orc, case):
+    """Point-to-point ICP (what the reference's examples chain on the RANSAC pose): same
+    correspondence set (index work: bit-exact, lowest target index on exact ties), same iteration count, same
+    fitness; pose within 1e-9 (the n-point Kabsch sums are order-free on the GPU, serial in the oracle)."""
+    d = synth.registration_pair_c4(6000, seed=11, dim=8, sigma=0.001)
+    src, dst = d["src"].copy(), d["dst"].copy()
+    init = d["T"].copy()
+    init[:3, 3] += np.array([0.012, -0.009, 0.006])
+    kw = dict(max_iteration=30, relative_fitness=1e-6, relative_rmse=1e-6)
+    max_dist = 0.02
+    if case == "identity_far":       # poor overlap: the iteration is chaotic (1e-16 differences in an update grow), so
+        init = None                  # only the evaluation of the initial pose and ONE update are compared
+        max_dist = 0.05
+        kw["max_iteration"] = 1
+    elif case == "no_convergence":
+        kw["max_iteration"] = 2
+    elif case == "duplicates":
+        dst = np.concatenate([dst, dst[:2000], dst[100:1100]])        # exact ties: the lowest index must win
+    elif case == "nonfinite":
+        src[[3, 500]] = np.nan
+        dst[[7, 900]] = np.inf
+        dst[11, 2] = np.nan
+    T, st, corr = capi.registration_icp(src, dst, max_dist, init, want_correspondences=True, **kw)
+    oT, ofit, orm, oit, ocorr = orc.registration_icp(src, dst, max_dist, init, max_iter=kw["max_iteration"],
+                                                     rel_fitness=1e-6, rel_rmse=1e-6)
+    assert st["iterations"] == oit
+    assert np.array_equal(corr, ocorr)
+    assert st["correspondences"] == int((ocorr >= 0).sum()) and st["fitness"] == ofit
+    assert st["inlier_rmse"] == pytest.approx(orm, rel=1e-9, abs=1e-15)
+    assert np.allclose(T, oT, rtol=0, atol=1e-9)
+    if case == "refine":
+        assert st["converged"] == 1 and st["fitness"] > 0.99
+        assert np.abs(T - d["T"]).max() < 1e-3
+    if case == "duplicates":
+        assert (corr[corr >= 0] < len(d["dst"])).all()
+    with pytest.raises(capi.M3DError):
+        capi.registration_icp(src, dst, 0.0, init)

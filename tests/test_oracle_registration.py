@@ -114,3 +114,43 @@ def test_mutual_nn_vs_ckdtree(orc):
     keep = [i for i in range(len(fs)) if n10[n01[i]] == i]
     assert np.array_equal(a, keep) and np.array_equal(b, n01[keep])
     assert len(a) >= 190 and np.all(np.diff(a) > 0)
+
+
+def test_oracle_icp_against_scipy(orc):
+    """Independent cross-check of the ICP restatement: the same loop written with scipy's cKDTree and numpy's SVD
+    Kabsch reaches the same pose (1e-9), fitness and iteration count."""
+    from scipy.spatial import cKDTree
+    d = synth.registration_pair_c4(3000, seed=4, dim=8, sigma=0.001)
+    src, dst = d["src"], d["dst"]
+    init = d["T"].copy()
+    init[:3, 3] += np.array([0.01, 0.008, -0.007])
+    T, fit, rm, it, corr = orc.registration_icp(src, dst, 0.02, init)
+    tree = cKDTree(dst)
+    Tn = init.copy()
+    pcd = src @ Tn[:3, :3].T + Tn[:3, 3]
+
+    def result(p):
+        dd, jj = tree.query(p, k=1)
+        ok = dd ** 2 < 0.02 ** 2
+        return ok, jj, (ok.sum() / len(p)), (np.sqrt((dd[ok] ** 2).sum() / ok.sum()) if ok.any() else 0.0)
+
+    ok, jj, f0, r0 = result(pcd)
+    n_it = 0
+    for n_it in range(1, 31):
+        s, t = pcd[ok], dst[jj[ok]]
+        ms, mt = s.mean(0), t.mean(0)
+        U, S, Vt = np.linalg.svd((t - mt).T @ (s - ms) / len(s))
+        D = np.diag([1, 1, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
+        R = U @ D @ Vt
+        upd = np.eye(4)
+        upd[:3, :3], upd[:3, 3] = R, mt - R @ ms
+        Tn = upd @ Tn
+        pcd = pcd @ R.T + upd[:3, 3]
+        ok, jj, f1, r1 = result(pcd)
+        done = abs(f0 - f1) < 1e-6 and abs(r0 - r1) < 1e-6
+        f0, r0 = f1, r1
+        if done:
+            break
+    assert it == n_it and fit == pytest.approx(f0, abs=1e-12) and rm == pytest.approx(r0, rel=1e-9)
+    assert np.allclose(T, Tn, rtol=0, atol=1e-9)
+    assert np.array_equal(corr >= 0, ok) and np.array_equal(corr[ok], jj[ok])

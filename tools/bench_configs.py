@@ -90,6 +90,12 @@ if "C4" in which:
                                        edge_length_threshold=0.9, confidence=0.999, seed=17)
     emit("C4 same with the reference's confidence 0.999", ms=(time.perf_counter() - t0) * 1e3,
          iterations=st2["iterations"], validations=st2["validations"], pose_err=float(np.abs(T2 - d["T"]).max()))
+    # the step the reference's examples chain next: point-to-point ICP on the RANSAC pose (max distance 0.02)
+    t0 = time.perf_counter()
+    T3, st3 = capi.registration_icp(d["src"], d["dst"], 0.02, T2)
+    emit("C4 registration_icp on that pose (point-to-point, 0.02, 30 it)", ms=(time.perf_counter() - t0) * 1e3,
+         iterations=st3["iterations"], fitness=st3["fitness"], rmse=st3["inlier_rmse"],
+         pose_err=float(np.abs(T3 - d["T"]).max()))
 
 if "C5" in which:
     n = int(os.environ.get("M3D_C5_POINTS", "10000000"))
