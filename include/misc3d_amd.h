@@ -208,6 +208,15 @@ int m3d_reg_validate(m3d_reg *reg, size_t s_begin, size_t s_end, uint32_t *count
 int m3d_reg_replay(m3d_reg *reg, const uint32_t *counts, const double *sums);
 int m3d_reg_finish(m3d_reg *reg, double T[16], m3d_reg_stats *stats);
 
+/* ---- misc3d::common::EstimateNormalsFromMap, src/normal_estimation.cpp:180-207 ---- */
+/* xyz: h x w x 3 doubles, the organised point map row by row (pc->points_ with shape = (w, h)); a pixel is
+ * valid iff its z is not NaN (:90).  k: window half-size ((2k+1)^2 neighbourhood, python default 5).
+ * normals: h x w x 3 out; unit eigenvector of the smallest covariance eigenvalue, flipped towards view_point
+ * (:165-171); NaN for invalid pixels (the reference leaves those uninitialised).  *ms_device (may be NULL):
+ * device time of the three kernels.  The caller checks points == w * h like :187-191. */
+int m3d_normals_from_map(const double *xyz, uint32_t w, uint32_t h, uint32_t k, const double view_point[3],
+                         int device, double *normals, double *ms_device);
+
 /* ---- point-to-point ICP refinement of the RANSAC pose ----------------------- */
 /* open3d::pipelines::registration::RegistrationICP(source, target, max_correspondence_distance, init,
  * TransformationEstimationPointToPoint(), ICPConvergenceCriteria(relative_fitness, relative_rmse,

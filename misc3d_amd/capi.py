@@ -136,6 +136,8 @@ def lib():
         L.m3d_reg_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_registration_icp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.c_int,
                                            C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_normals_from_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p]
         L.m3d_match_last_fallbacks.restype = C.c_uint64
         L.m3d_match_last_fallbacks.argtypes = []
         L.m3d_match_mutual_nn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
@@ -439,6 +441,18 @@ def registration_ransac(src, dst, corr_src, corr_dst, threshold=0.01, max_iter=1
                                          C.cast(sref, C.c_void_p) if sref else None, device, _p(T),
                                          C.cast(C.byref(st), C.c_void_p)))
     return T.reshape(4, 4), st.asdict()
+
+
+def normals_from_map(xyz, w, h, k=5, view_point=(0.0, 0.0, 0.0), device=0, want_ms=False):
+    """m3d_normals_from_map: EstimateNormalsFromMap on an organised point map (h*w, 3) -> (h*w, 3) normals."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    if len(xyz) != w * h:
+        raise M3DError(ERR_INVALID_ARG, "The point cloud size is not equal to given point map size.")
+    vp = _f64(view_point).reshape(3).copy()
+    out = np.empty((w * h, 3))
+    ms = C.c_double(0)
+    _check(lib().m3d_normals_from_map(_p(xyz), w, h, k, _p(vp), device, _p(out), C.cast(C.byref(ms), C.c_void_p)))
+    return (out, ms.value) if want_ms else out
 
 
 class IcpStats(C.Structure):

@@ -9,6 +9,8 @@
 // array, a (points, normals) tuple, or any object exposing .points / .normals (an
 // open3d.geometry.PointCloud works through numpy.asarray).
 #include <pybind11/numpy.h>
+#include <array>
+#include <tuple>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -127,6 +129,38 @@ PYBIND11_MODULE(_py_misc3d, m) {
 
     // ---- common (python/py_common.cpp:69-78)
     py::module mc = m.def_submodule("common");
+    // EstimateNormalsFromMap, python/py_common.cpp:79-89.  The reference sets pc.normals_ and returns pc; for an
+    // object with a writable `.normals` (open3d PointCloud) the same happens, for a plain array the (N, 3)
+    // normals are returned.
+    mc.def(
+        "estimate_normals",
+        [](py::object pc, std::tuple<int, int> shape, int k, std::array<double, 3> view_point, int device) -> py::object {
+            HostCloud c = extract_cloud(pc);
+            const int w = std::get<0>(shape), h = std::get<1>(shape);
+            const size_t num = (size_t)c.points.shape(0);
+            if (w < 0 || h < 0 || k < 0 || num != (size_t)w * (size_t)h)
+                misc3d::LogError("The point cloud size is not equal to given point map size.");
+            arr_d normals(std::vector<py::ssize_t>{(py::ssize_t)num, 3});
+            int rc;
+            {
+                py::gil_scoped_release nogil;
+                rc = m3d_normals_from_map(num ? c.points.data() : nullptr, (uint32_t)w, (uint32_t)h, (uint32_t)k,
+                                          view_point.data(), device, num ? normals.mutable_data() : nullptr, nullptr);
+            }
+            if (rc < 0) misc3d::LogError(m3d_last_error());
+            if (py::hasattr(pc, "points") && py::hasattr(pc, "normals")) {
+                py::object value = normals;
+                try {   // open3d wants a Vector3dVector
+                    value = py::module_::import("open3d").attr("utility").attr("Vector3dVector")(normals);
+                } catch (py::error_already_set&) {
+                }
+                py::setattr(pc, "normals", value);
+                return pc;
+            }
+            return std::move(normals);
+        },
+        "Estimate normals from pointmap structure", py::arg("pc"), py::arg("shape"), py::arg("k") = 5,
+        py::arg("view_point") = std::array<double, 3>{0, 0, 0}, py::kw_only(), py::arg("device") = 0);
     mc.def(
         "fit_plane",
         [](const py::object& pc, double threshold, size_t max_iteration, double probability,

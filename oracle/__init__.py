@@ -4,7 +4,7 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 this package.  The product (``misc3d_amd``) never does.  PARITY UNPINNED: see the header of
 ``misc3d_oracle.c`` and DESIGN.md.
 
-The arithmetic lives in plain C (``misc3d_oracle.c``, ``misc3d_oracle_reg.c``); this module is a
+The arithmetic lives in plain C (``misc3d_oracle.c``, ``misc3d_oracle_reg.c``, ``misc3d_oracle_normals.c``); this module is a
 ctypes shim that builds the shared object on demand with ``make -C oracle``.
 """
 from __future__ import annotations
@@ -26,7 +26,7 @@ _NP = {PLANE: 4, SPHERE: 4, CYLINDER: 7}
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("misc3d_oracle.c", "misc3d_oracle_reg.c", "std_rng_check.cpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("misc3d_oracle.c", "misc3d_oracle_reg.c", "misc3d_oracle_normals.c", "std_rng_check.cpp", "Makefile")]
     stale = force or not os.path.exists(_LIB_PATH) or not os.path.exists(RNG_CHECK_PATH)
     if not stale:
         t = min(os.path.getmtime(_LIB_PATH), os.path.getmtime(RNG_CHECK_PATH))
@@ -342,6 +342,23 @@ def registration_icp(src, dst, max_dist, T_init=None, max_iter=30, rel_fitness=1
                                     _p(Ti), C.c_int(max_iter), C.c_double(rel_fitness), C.c_double(rel_rmse), _p(T),
                                     C.byref(fit), C.byref(rm), C.byref(nc), _p(corr))
     return T.reshape(4, 4), float(fit.value), float(rm.value), int(it), corr[: len(src)]
+
+
+def normals_from_map(xyz, w, h, k=5, view_point=(0.0, 0.0, 0.0)):
+    """EstimateNormalsFromMap (src/normal_estimation.cpp:64-207): xyz (h*w, 3) point map -> (h*w, 3) normals."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    assert len(xyz) == w * h
+    vp = _f64(view_point, (3,))
+    out = np.zeros((w * h, 3))
+    lib().orc_normals_from_map(_p(xyz), C.c_uint(w), C.c_uint(h), C.c_uint(k), _p(vp), _p(out))
+    return out
+
+
+def j3x3_smallest_eigvec(A):
+    A = _f64(A, (9,))
+    n = np.zeros(3)
+    lib().orc_j3x3_smallest_eigvec(_p(A), _p(n))
+    return n
 
 
 def match_mutual_nn(feat_src, feat_dst):

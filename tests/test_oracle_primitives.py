@@ -262,3 +262,36 @@ def test_segmentation_two_planes(orc):
         assert np.all(np.diff(c.astype(np.int64)) > 0)         # SelectByIndex keeps order
     rc, planes, clusters = orc.segment_plane_iterative(pts[:2], 0.01)
     assert rc == 1 and len(planes) == 0                        # :13-17
+
+
+def test_oracle_normals_from_map_against_numpy(orc):
+    """EstimateNormalsFromMap restatement vs a direct per-pixel window PCA in numpy (np.cov + eigh): same normals
+    up to the cancellation noise of the E[x^2]-E[x]^2 form; NaN for invalid pixels; J3x3 vs numpy.linalg.eigh."""
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        M = rng.normal(size=(3, 3))
+        A = M @ M.T * rng.uniform(1e-6, 1)
+        n = orc.j3x3_smallest_eigvec(A)
+        wv, v = np.linalg.eigh(A)
+        if (wv[1] - wv[0]) / wv[2] > 1e-6:
+            assert min(np.abs(n - v[:, 0]).max(), np.abs(n + v[:, 0]).max()) < 1e-9
+    w, h, k = 60, 44, 2
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    z = 1.0 + 0.003 * u - 0.002 * v + rng.normal(0, 1e-4, (h, w))
+    xyz = np.stack([(u - 30) / 100.0 * z, (v - 22) / 100.0 * z, z], -1).reshape(-1, 3)
+    hole = rng.random(w * h) < 0.05
+    xyz[hole] = np.nan
+    N = orc.normals_from_map(xyz, w, h, k)
+    assert np.isnan(N[hole]).all()
+    P = xyz.reshape(h, w, 3)
+    worst = 0.0
+    for r in range(h):
+        for c in range(w):
+            if np.isnan(P[r, c, 2]):
+                continue
+            win = P[max(0, r - k): r + k + 1, max(0, c - k): c + k + 1].reshape(-1, 3)
+            win = win[~np.isnan(win[:, 2])]
+            wv, vv = np.linalg.eigh(np.cov(win.T, bias=True))
+            nn = vv[:, 0] if np.dot(-P[r, c], vv[:, 0]) >= 0 else -vv[:, 0]
+            worst = max(worst, np.abs(N[r * w + c] - nn).max())
+    assert worst < 1e-7

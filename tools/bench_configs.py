@@ -97,6 +97,22 @@ if "C4" in which:
          iterations=st3["iterations"], fitness=st3["fitness"], rmse=st3["inlier_rmse"],
          pose_err=float(np.abs(T3 - d["T"]).max()))
 
+if "N3" in which or len(sys.argv) == 1:
+    # EstimateNormalsFromMap at the reference example's size (848 x 480, k = 3) and at 4 Mpixel
+    for (w, h, k) in ((848, 480, 3), (2048, 2048, 5)):
+        rng = np.random.default_rng(1)
+        u, v = np.meshgrid(np.arange(w), np.arange(h))
+        z = 1.0 + 0.001 * u + 0.002 * v + rng.normal(0, 1e-4, (h, w))
+        xyz = np.stack([(u - w / 2) / 500.0 * z, (v - h / 2) / 500.0 * z, z], -1).reshape(-1, 3)
+        capi.normals_from_map(xyz, w, h, k)
+        t0 = time.perf_counter()
+        nrm, ms_dev = capi.normals_from_map(xyz, w, h, k, want_ms=True)
+        dt = time.perf_counter() - t0
+        W, H = w + 2 * k, h + 2 * k
+        bytes_alg = w * h * 24.0 * 2 + W * H * 8.0 * 10 * 3     # map in, normals out, moment images written+read, sums written
+        emit(f"N3 estimate_normals {w}x{h} k={k}", ms_total=dt * 1e3, ms_device=ms_dev, mpixel_per_s=w * h / (ms_dev * 1e3),
+             device_GBps=bytes_alg / (ms_dev * 1e-3) / 1e9)
+
 if "C5" in which:
     n = int(os.environ.get("M3D_C5_POINTS", "10000000"))
     pts = synth.room_cloud_c5(n, 6)
