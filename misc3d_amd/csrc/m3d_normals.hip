@@ -48,39 +48,47 @@ __global__ void nm_moments_k(const double* __restrict__ xyz, uint32_t w, uint32_
 
 // SumDense (:36-62) for padded row r (thread) of image blockIdx.y: first window summed row by row, left to
 // right; every further column starts from its left neighbour and adds, row by row, (entering - leaving).
-// The next column's operands are loaded while the current column's dependent adds run.
-template <int KMAX>
-__global__ __launch_bounds__(256) void nm_box_sum_k(const double* __restrict__ img, uint32_t W, uint32_t H,
-                                                     uint32_t k, size_t WH, double* __restrict__ sum) {
-    const uint32_t r = k + blockIdx.x * 256u + threadIdx.x;
+// The recurrence is a serial fp64 chain ((2k+1) dependent adds per column), so the kernel is latency-bound:
+// the differences of the next DEPTH columns are kept in flight in registers while the chain runs, and a
+// wave per workgroup spreads the few (rows x 10) threads over as many CUs as possible.
+template <int K, int DEPTH>
+__global__ __launch_bounds__(64) void nm_box_sum_k(const double* __restrict__ img, uint32_t W, uint32_t H,
+                                                    size_t WH, double* __restrict__ sum) {
+    constexpr uint32_t k = K;
+    constexpr int N = 2 * K + 1;
+    const uint32_t r = k + blockIdx.x * 64u + threadIdx.x;
     if (r >= H - k) return;
-    const double* __restrict__ d = img + (size_t)blockIdx.y * WH;
-    double* __restrict__ o = sum + (size_t)blockIdx.y * WH;
-    const uint32_t n = 2 * k + 1;
+    const double* __restrict__ d = img + (size_t)blockIdx.y * WH + (r - k);   // row r - k of column 0
+    double* __restrict__ o = sum + (size_t)blockIdx.y * WH + r;
     double acc = 0.0;
-    for (uint32_t r0 = r - k; r0 <= r + k; ++r0)
-        for (uint32_t c0 = 0; c0 < n; ++c0) acc += d[(size_t)c0 * H + r0];
-    o[(size_t)k * H + r] = acc;
-    double in_[2 * KMAX + 1], out_[2 * KMAX + 1];
-    auto fetch = [&](uint32_t c) {
 #pragma unroll
-        for (int j = 0; j < 2 * KMAX + 1; ++j)
-            if ((uint32_t)j < n) {
-                in_[j] = d[(size_t)(c + k) * H + (r - k + j)];
-                out_[j] = d[(size_t)(c - k - 1) * H + (r - k + j)];
-            }
+    for (int j = 0; j < N; ++j)        // rows r - k .. r + k (outer), columns 0 .. 2k (inner)
+        for (int c0 = 0; c0 < N; ++c0) acc += d[(size_t)c0 * H + j];
+    o[(size_t)k * H] = acc;
+    const uint32_t c_end = W - k;
+    if (k + 1 >= c_end) return;
+    // column c: entering = column c + k, leaving = column c - k - 1 (pointers advance by H per column)
+    const uint32_t last = c_end - 1;
+    double df[DEPTH][N];   // ring: differences (entering - leaving) of columns c .. c + DEPTH - 1
+    auto fetch = [&](int slot, uint32_t c) {
+        const uint32_t cc = c < last ? c : last;   // clamped loads past the end are never consumed
+        const double* __restrict__ pin = d + (size_t)(cc + k) * H;
+        const double* __restrict__ pout = d + (size_t)(cc - k - 1) * H;
+#pragma unroll
+        for (int j = 0; j < N; ++j) df[slot][j] = pin[j] - pout[j];
     };
-    if (k + 1 < W - k) fetch(k + 1);
-    for (uint32_t c = k + 1; c < W - k; ++c) {
-        double df[2 * KMAX + 1];
 #pragma unroll
-        for (int j = 0; j < 2 * KMAX + 1; ++j)
-            if ((uint32_t)j < n) df[j] = in_[j] - out_[j];
-        if (c + 1 < W - k) fetch(c + 1);
+    for (int s = 0; s < DEPTH; ++s) fetch(s, k + 1 + s);
+    double* __restrict__ op = o + (size_t)(k + 1) * H;
+    for (uint32_t c = k + 1; c < c_end; c += DEPTH) {
 #pragma unroll
-        for (int j = 0; j < 2 * KMAX + 1; ++j)
-            if ((uint32_t)j < n) acc += df[j];
-        o[(size_t)c * H + r] = acc;
+        for (int s = 0; s < DEPTH; ++s) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += df[s][j];   // past the end: garbage in, never stored
+            if (c + s < c_end) op[(size_t)s * H] = acc;
+            fetch(s, c + s + DEPTH);   // refill this slot for column c + s + DEPTH
+        }
+        op += (size_t)DEPTH * H;
     }
 }
 
@@ -178,13 +186,19 @@ extern "C" int m3d_normals_from_map(const double* xyz, uint32_t w, uint32_t h, u
     if (ok) {
         const uint32_t nb = (uint32_t)((n + 255) / 256);
         nm_moments_k<<<nb, 256, 0, ctx->stream>>>(d_xyz.as<double>(), w, h, k, WH, H, d_img.as<double>());
-        const dim3 grid((h + 255) / 256, kNmImages);
-        if (k <= 3)
-            nm_box_sum_k<3><<<grid, 256, 0, ctx->stream>>>(d_img.as<double>(), W, H, k, WH, d_sum.as<double>());
-        else if (k <= 7)
-            nm_box_sum_k<7><<<grid, 256, 0, ctx->stream>>>(d_img.as<double>(), W, H, k, WH, d_sum.as<double>());
-        else
-            nm_box_sum_any_k<<<grid, 256, 0, ctx->stream>>>(d_img.as<double>(), W, H, k, WH, d_sum.as<double>());
+        const dim3 grid64((h + 63) / 64, kNmImages), grid((h + 255) / 256, kNmImages);
+        const double* im = d_img.as<double>();
+        double* sm = d_sum.as<double>();
+        switch (k) {   // window sizes with a compiled recurrence (python default k = 5, examples use 3)
+            case 1: nm_box_sum_k<1, 8><<<grid64, 64, 0, ctx->stream>>>(im, W, H, WH, sm); break;
+            case 2: nm_box_sum_k<2, 8><<<grid64, 64, 0, ctx->stream>>>(im, W, H, WH, sm); break;
+            case 3: nm_box_sum_k<3, 8><<<grid64, 64, 0, ctx->stream>>>(im, W, H, WH, sm); break;
+            case 4: nm_box_sum_k<4, 6><<<grid64, 64, 0, ctx->stream>>>(im, W, H, WH, sm); break;
+            case 5: nm_box_sum_k<5, 4><<<grid64, 64, 0, ctx->stream>>>(im, W, H, WH, sm); break;
+            case 6: nm_box_sum_k<6, 4><<<grid64, 64, 0, ctx->stream>>>(im, W, H, WH, sm); break;
+            case 7: nm_box_sum_k<7, 4><<<grid64, 64, 0, ctx->stream>>>(im, W, H, WH, sm); break;
+            default: nm_box_sum_any_k<<<grid, 256, 0, ctx->stream>>>(im, W, H, k, WH, sm); break;
+        }
         nm_normals_k<<<nb, 256, 0, ctx->stream>>>(d_img.as<double>(), d_sum.as<double>(), w, h, k, WH, H, view_point[0],
                                                  view_point[1], view_point[2], d_nrm.as<double>());
         ok = hipEventRecord(ctx->ev1, ctx->stream) == hipSuccess &&
