@@ -74,10 +74,30 @@ def registration():
     np.savez_compressed(os.path.join(HERE, "registration.npz"), **out)
 
 
+def next_rows():
+    """SURVEY.md 8(f) rows that are in: normals from an organised map (N3), point-to-point ICP (N1)."""
+    rng = np.random.default_rng(7)
+    w, h, k = 48, 36, 2
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    z = 1.0 + 0.002 * u - 0.001 * v + 0.03 * np.sin(u / 7.0) + rng.normal(0, 1e-4, (h, w))
+    xyz = np.stack([(u - w / 2) / 120.0 * z, (v - h / 2) / 120.0 * z, z], -1).reshape(-1, 3)
+    xyz[rng.random(w * h) < 0.04] = np.nan
+    vp = np.array([0.05, -0.02, -0.3])
+    nrm = oracle.normals_from_map(xyz, w, h, k, vp)
+    d = synth.registration_pair_c4(1500, seed=9, dim=8, sigma=0.001)
+    init = d["T"].copy()
+    init[:3, 3] += np.array([0.01, -0.006, 0.004])
+    T, fit, rm, it, corr = oracle.registration_icp(d["src"], d["dst"], 0.02, init)
+    np.savez_compressed(os.path.join(HERE, "next_rows.npz"), map_xyz=xyz, map_shape_k=np.array([w, h, k]),
+                        map_view_point=vp, map_normals=nrm, icp_src=d["src"], icp_dst=d["dst"], icp_init=init,
+                        icp_T=T, icp_fit_rmse=np.array([fit, rm]), icp_iterations=np.array([it]), icp_corr=corr)
+
+
 if __name__ == "__main__":
     fits()
     segmentation()
     registration()
+    next_rows()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
