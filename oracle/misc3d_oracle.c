@@ -606,7 +606,7 @@ void orc_score_samples(int kind, const double *xyz, const double *normals, size_
                        uint64_t *counts, double *errors) {
     const int m = orc_minimal_sample(kind);
     const int np = orc_num_params(kind);
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) if ((double)H * (double)n > 2e7)
     for (long h = 0; h < (long)H; ++h) {
         double model[7] = {0, 0, 0, 0, 0, 0, 0};
         const int ok = orc_minimal_fit_idx(kind, xyz, normals, samples + (size_t)h * m, model);

@@ -224,7 +224,8 @@ void orc_reg_validate(const double *src, size_t ns, const double *dst, size_t nd
                       double thr, uint64_t *count, double *err2) {
     const double r2 = thr * thr;
     double *best = (double *)malloc(sizeof(double) * (ns ? ns : 1));
-#pragma omp parallel for schedule(static)
+    /* small problems stay on one thread: waking a large OpenMP team costs more than the whole scan */
+#pragma omp parallel for schedule(static) if ((double)ns * (double)nd > 2e7)
     for (long i = 0; i < (long)ns; ++i) {
         double p[3];
         transform_point(T, src + 3 * i, p);
@@ -392,7 +393,7 @@ static void icp_result(const double *pcd, size_t ns, const double *dst, size_t n
                        int64_t *corr, uint64_t *count, double *err2) {
     const double r2 = max_dist * max_dist;
     double *best = (double *)malloc(sizeof(double) * (ns ? ns : 1));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((double)ns * (double)nd > 2e7)
     for (long i = 0; i < (long)ns; ++i) {
         const double *p = pcd + 3 * i;
         double bd = INFINITY;
@@ -485,7 +486,7 @@ int orc_registration_icp(const double *src, size_t ns, const double *dst, size_t
 
 /* ------------------------------------------------------------------------------------------- */
 void orc_nearest(const double *q, size_t nq, const double *db, size_t ndb, int dim, int64_t *nn) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((double)nq * (double)ndb * dim > 2e8)
     for (long i = 0; i < (long)nq; ++i) {
         double bd = INFINITY;
         int64_t bi = -1;
