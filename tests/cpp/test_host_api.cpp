@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <random>
 
+#include <misc3d/common/normal_estimation.h>
 #include <misc3d/common/ransac.h>
 #include <misc3d/registration/correspondence_matching.h>
 #include <misc3d/registration/transform_estimation.h>
@@ -129,6 +130,31 @@ int main() {
     const misc3d::Matrix4d Tr = rs.Solve(src, dst, corres);
     CHECK(std::fabs(Tr[0] - c) < 1e-9 && std::fabs(Tr[3] - 0.3) < 1e-9);
     CHECK(rs.GetStats().fitness == 1.0);
+    // ---- EstimateNormalsFromMap (include/misc3d/common/normal_estimation.h): tilted plane seen from the origin
+    {
+        const int w = 64, h = 48;
+        misc3d::PointCloud map;
+        for (int r = 0; r < h; ++r)
+            for (int c = 0; c < w; ++c) {
+                const double x = (c - w / 2) * 0.01, y = (r - h / 2) * 0.01;
+                map.points_.push_back({x, y, 1.0 + 0.2 * x - 0.1 * y});
+            }
+        map.points_[100][2] = std::nan("");   // one invalid pixel
+        misc3d::common::EstimateNormalsFromMap(map, {w, h}, 3);
+        CHECK(map.normals_.size() == map.points_.size());
+        const double inv = 1.0 / std::sqrt(0.2 * 0.2 + 0.1 * 0.1 + 1.0);
+        const auto& nn = map.normals_[h / 2 * w + w / 2];
+        CHECK(std::fabs(nn[0] - 0.2 * inv) < 1e-6 && std::fabs(nn[1] + 0.1 * inv) < 1e-6 && std::fabs(nn[2] + inv) < 1e-6);
+        CHECK(std::isnan(map.normals_[100][0]));
+        bool threw_size = false;
+        try {
+            misc3d::common::EstimateNormalsFromMap(map, {w + 1, h}, 3);
+        } catch (const std::runtime_error& e) {
+            threw_size = std::string(e.what()).find("not equal to given point map size") != std::string::npos;
+        }
+        CHECK(threw_size);
+    }
+
     std::printf("host api: all checks passed\n");
     return 0;
 }
