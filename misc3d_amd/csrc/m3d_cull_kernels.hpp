@@ -27,9 +27,14 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
 // keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
                       hipStream_t st);
-// counts[h] += inliers of hypothesis h in the tiles whose (mask & keep) bit is set; counts zero on entry.
+// counts_rep[tile % kCountReplicas][h] += inliers of hypothesis h in the tiles whose (mask & keep) bit is set;
+// counts_rep (kCountReplicas x rep_stride u32) zero on entry; launch_sum_replicas folds the replicas.
+constexpr int kCountReplicas = 16;
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
-                       const unsigned long long* keep, uint32_t n_groups, uint32_t* counts, hipStream_t st);
+                       const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
+                       hipStream_t st);
+void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
+                         hipStream_t st);
 void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
                       hipStream_t st);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,

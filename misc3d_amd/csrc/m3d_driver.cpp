@@ -318,6 +318,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     } else {
         RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * (h_pad / 64));
         RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)(h_pad / 64));
+        RESERVE(ctx->counts_rep, sizeof(uint32_t) * (size_t)kCountReplicas * h_pad);
     }
     const double t0 = now_ms();
     src.fill(begin, end, s.h_samples.as<uint32_t>());
@@ -326,7 +327,10 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                           hipMemcpyHostToDevice, ctx->stream));
     launch_minimal_fit(kind, v, s.samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream);
-    HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
+    if (dense)
+        HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
+    else
+        HIPCHK(hipMemsetAsync(ctx->counts_rep.p, 0, sizeof(uint32_t) * (size_t)kCountReplicas * h_pad, ctx->stream));
     if (dense) {
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
@@ -348,8 +352,10 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream);
         launch_keep_mask(ub, prune ? ctx->best_count.as<uint32_t>() : nullptr, n_groups, keep, ctx->stream);
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
-        launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, s.counts.as<uint32_t>(), ctx->stream);
+        launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
+                          ctx->stream);
         HIPCHK(hipEventRecord(s.k1, ctx->stream));
+        launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.counts.as<uint32_t>(), ctx->stream);
         if (prune)
             launch_max_count(s.counts.as<uint32_t>(), s.valid.as<uint8_t>(), count, ctx->best_count.as<uint32_t>(),
                              ctx->stream);
@@ -1302,6 +1308,7 @@ int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     const uint32_t n_groups = s.h_pad / 64;
     RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * n_groups);
     RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)n_groups);
+    RESERVE(ctx->counts_rep, sizeof(uint32_t) * (size_t)kCountReplicas * s.h_pad);
     RESERVE(ctx->small, 256);
     auto* masks = ctx->masks.as<unsigned long long>();
     auto* keep = ctx->keep.as<unsigned long long>();
@@ -1318,8 +1325,8 @@ int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     for (int r = 0; r < reps; ++r) {
         if (mode == 0)
-            launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, s.counts.as<uint32_t>(),
-                              ctx->stream);
+            launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
+                              s.h_pad, ctx->stream);
         else if (mode == 1)
             launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, nullptr,
                              ctx->stream);

@@ -58,6 +58,7 @@ struct DeviceCtx {
     DevBuf partial, block_counts, total, idx, dist, sum_partial, sums, best_params, small;
     DevBuf masks, keep;        // culled scoring: (tile, 64-hypothesis group) bit masks, per-group keep masks
     DevBuf ub, best_count;     // bound-and-prune: surviving tiles per hypothesis, running best count
+    DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
