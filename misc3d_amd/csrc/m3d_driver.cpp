@@ -117,6 +117,8 @@ DeviceCtx* get_ctx(int device) {
     DeviceCtx* c = new DeviceCtx();
     c->device = device;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_compact, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     for (int k = 0; k < 2 && ok; ++k)
         ok = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess &&
@@ -491,10 +493,14 @@ static bool sphere_from_moments(const double* mean, const double* s, double n, d
 // RefineModel, ransac.h:534-549.  flag_view: cloud the distances are evaluated on; gather_view +
 // orig: when the flags are computed on a compacted cloud (segmentation) the inlier list holds
 // ORIGINAL indices and the GeneralFit sums gather from the original cloud (same values, same order).
+// expected_ni >= 0: the inlier count is already known from the scoring pass (the usual case).  Then nothing
+// has to wait for the compaction's own total: the GeneralFit sums run on the main stream while the index list
+// travels to the host on the copy stream, and the total is only CHECKED at the end (a mismatch falls back to
+// the synchronous order; the callers treat it as an internal error anyway).
 static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_view,
                   const uint32_t* orig_dev, int kind, double thr, const double* model_dev,
                   double* params_host /* in: best minimal model, out: refined */, size_t* inliers,
-                  size_t* n_inliers, int* general_fit_ok) {
+                  size_t* n_inliers, int* general_fit_ok, int64_t expected_ni = -1) {
     const uint32_t n = flag_view.n;
     const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
     RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
@@ -508,6 +514,51 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                    ctx->total.as<uint32_t>(), ctx->stream);
     uint8_t* h = ctx->h_small.as<uint8_t>();
     HIPCHK(hipMemcpyAsync(h, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (expected_ni >= 0 && (uint64_t)expected_ni <= n) {
+        const uint32_t ni_e = (uint32_t)expected_ni;
+        const bool need_fit_e = kind != M3D_CYLINDER && ni_e >= (kind == M3D_PLANE ? 3u : 4u);
+        HIPCHK(hipEventRecord(ctx->ev_compact, ctx->stream));
+        if (need_fit_e) {
+            launch_sum_xyz(gather_view, ctx->idx.as<uint64_t>(), ni_e, ctx->sum_partial.as<double>(),
+                           ctx->sums.as<double>(), ctx->stream);
+            launch_sum_moments(gather_view, ctx->idx.as<uint64_t>(), ni_e, ctx->sums.as<double>(),
+                               ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 4, ctx->stream);
+            HIPCHK(hipMemcpyAsync(h + 16, ctx->sums.p, sizeof(double) * 14, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        // last: a copy into the caller's (pageable) buffer keeps the host busy until it is done
+        if (inliers && ni_e) {
+            HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
+            HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost,
+                                  ctx->copy_stream));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+        uint32_t ni_chk;
+        std::memcpy(&ni_chk, h, 4);
+        if (ni_chk != ni_e)   // should not happen: redo in the order that does not rely on the expectation
+            return refine(ctx, flag_view, gather_view, orig_dev, kind, thr, model_dev, params_host, inliers, n_inliers,
+                          general_fit_ok, -1);
+        *n_inliers = ni_e;
+        *general_fit_ok = 1;
+        if (kind != M3D_CYLINDER) {
+            if (!need_fit_e) {
+                *general_fit_ok = 0;  // MinimalCheck, ransac.h:166-169, 298-301
+            } else {
+                double sums[14];
+                std::memcpy(sums, h + 16, sizeof(sums));
+                const double mean[3] = {sums[0] / (double)ni_e, sums[1] / (double)ni_e, sums[2] / (double)ni_e};
+                double out[4];
+                const bool ok = kind == M3D_PLANE ? plane_from_moments(mean, sums + 4, out)
+                                                  : sphere_from_moments(mean, sums + 4, (double)ni_e, out);
+                if (ok)
+                    std::memcpy(params_host, out, sizeof(out));  // model refined in place
+                else
+                    *general_fit_ok = 0;  // model left as the best minimal model (ransac.h:204-207)
+            }
+        }
+        return M3D_OK;
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     uint32_t ni;
@@ -780,7 +831,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     size_t ni = 0;
     int gf_ok = 1;
     rc = refine(ctx, v, gather, orig, kind, thr, ctx->best_params.as<double>(), model, inliers, &ni,
-                &gf_ok);
+                &gf_ok, ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1);
     if (rc != M3D_OK) return rc;
     if (ro.st.best_index >= 0 && ni != ro.st.best_count)
         return fail(M3D_ERR_INTERNAL, "refine pass and scoring kernel disagree on the inlier count");

@@ -53,6 +53,8 @@ struct ChunkSlot {
 struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // RefineModel: the inlier list goes to the host while the GeneralFit sums run
+    hipEvent_t ev_compact = nullptr;
     std::mutex mu;  // one call at a time per device
     ChunkSlot slot[2];
     DevBuf partial, block_counts, total, idx, dist, sum_partial, sums, best_params, small;
