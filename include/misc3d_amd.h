@@ -237,6 +237,13 @@ int m3d_registration_icp(const double *src, size_t n_src, const double *dst, siz
                          double relative_fitness, double relative_rmse, int device, double T[16],
                          m3d_icp_stats *stats, int64_t *correspondences);
 
+/* open3d::pipelines::registration::GetInformationMatrixFromPointClouds(source, target, max_dist, T): the
+ * acceptance test of ReconstructionPipeline::GlobalRegistration, src/pipeline.cpp:818-824.
+ * info: 6 x 6 row-major; info[35] == *n_correspondences (may be NULL). */
+int m3d_information_matrix(const double *src, size_t n_src, const double *dst, size_t n_dst,
+                           double max_correspondence_distance, const double *T, int device, double info[36],
+                           uint64_t *n_correspondences);
+
 /* ---- registration::ANNMatcher::Match, src/correspondence_matching.cpp:52-84 ------------------- */
 /* feat_*: Eigen MatrixXd dim x N column-major = N descriptors of dim contiguous doubles.
  * method: 0 FLANN, 1 ANNOY (correspondence_matching.h MatchMethod); both run the exact mutual

@@ -138,6 +138,8 @@ def lib():
                                            C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_normals_from_map.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_void_p]
+        L.m3d_information_matrix.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p]
         L.m3d_match_last_fallbacks.restype = C.c_uint64
         L.m3d_match_last_fallbacks.argtypes = []
         L.m3d_match_mutual_nn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
@@ -479,6 +481,33 @@ def registration_icp(src, dst, max_correspondence_distance, init=None, max_itera
     if want_correspondences:
         return T.reshape(4, 4), st.asdict(), corr[: len(src)]
     return T.reshape(4, 4), st.asdict()
+
+
+def information_matrix(src, dst, max_correspondence_distance, T, device=0):
+    """GetInformationMatrixFromPointClouds -> (6 x 6 information matrix, correspondence count)."""
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    Tm = _f64(T).reshape(16).copy()
+    info = np.zeros(36)
+    nc = C.c_uint64(0)
+    _check(lib().m3d_information_matrix(_p(src), len(src), _p(dst), len(dst), max_correspondence_distance, _p(Tm),
+                                        device, _p(info), C.cast(C.byref(nc), C.c_void_p)))
+    return info.reshape(6, 6), int(nc.value)
+
+
+def global_registration(src, dst, feat_src, feat_dst, voxel_size, max_iter=100000, seed=None, device=0):
+    """ReconstructionPipeline::GlobalRegistration with the Ransac method (src/pipeline.cpp:790-828): mutual-NN
+    match -> RANSACSolver(1.4 voxel) -> information matrix; rejected when info(5,5) / min(Ns, Nt) < 0.3.
+    Returns (success, pose 4x4, information 6x6)."""
+    max_dis = voxel_size * 1.4
+    i0, i1 = match_mutual_nn(feat_src, feat_dst, device=device)
+    pose, _ = registration_ransac(src, dst, i0, i1, threshold=max_dis, max_iter=max_iter, seed=seed, device=device)
+    if np.allclose(pose, np.eye(4), rtol=0, atol=1e-8):          # pose.isIdentity(1e-8)
+        return True, pose, np.eye(6)
+    info, _ = information_matrix(src, dst, max_dis, pose, device=device)
+    if info[5, 5] / min(len(src), len(dst)) < 0.3:
+        return False, pose, np.eye(6)
+    return True, pose, info
 
 
 class RegSession:

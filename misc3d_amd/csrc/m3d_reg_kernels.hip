@@ -839,6 +839,37 @@ void launch_icp_sums(const double* px, const double* py, const double* pz, uint3
     kabsch_final_k<12><<<1, 256, 0, s>>>(partial, sums + 6);
 }
 
+// GetInformationMatrixFromPointClouds: the nine coordinate moments of the matched TARGET points
+// (x y z xx yy zz xy xz yz); the 6 x 6 matrix is assembled from them and the count on the host.
+__global__ __launch_bounds__(256) void info_sums_k(uint32_t n, CloudView dst, const uint32_t* __restrict__ nn,
+                                                    double* __restrict__ partial) {
+    constexpr int NV = 9;
+    __shared__ double sm[NV * 256];
+    double acc[NV];
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += 256u * 256u) {
+        const uint32_t j = nn[i];
+        if (j == 0xFFFFFFFFu) continue;
+        const double x = dst.x[j], y = dst.y[j], z = dst.z[j];
+        acc[0] += x;
+        acc[1] += y;
+        acc[2] += z;
+        acc[3] += x * x;
+        acc[4] += y * y;
+        acc[5] += z * z;
+        acc[6] += x * y;
+        acc[7] += x * z;
+        acc[8] += y * z;
+    }
+    tree_reduce_256<NV>(acc, sm);
+    if (threadIdx.x < NV) partial[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
+}
+void launch_info_sums(uint32_t n, const CloudView& dst, const uint32_t* nn, double* partial, double* sums,
+                      hipStream_t s) {
+    info_sums_k<<<256, 256, 0, s>>>(n, dst, nn, partial);
+    kabsch_final_k<9><<<1, 256, 0, s>>>(partial, sums);
+}
+
 // PointCloud::Transform(update) on the moving cloud, in place (or out of place for the initial pose)
 __global__ void icp_transform_k(const double* __restrict__ ix, const double* __restrict__ iy,
                                 const double* __restrict__ iz, uint32_t n, const double* __restrict__ T,

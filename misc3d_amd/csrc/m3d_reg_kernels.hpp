@@ -57,6 +57,8 @@ void launch_icp_nn(const double* px, const double* py, const double* pz, uint32_
                    const uint32_t* cell_orig, uint32_t* nn, double* d2, hipStream_t s);
 void launch_icp_sums(const double* px, const double* py, const double* pz, uint32_t n, const CloudView& dst,
                      const uint32_t* nn, const uint32_t* count, double* partial, double* sums, hipStream_t s);
+void launch_info_sums(uint32_t n, const CloudView& dst, const uint32_t* nn, double* partial, double* sums,
+                      hipStream_t s);
 void launch_icp_transform(const double* ix, const double* iy, const double* iz, uint32_t n, const double* T_dev,
                           double* ox, double* oy, double* oz, hipStream_t s);
 void launch_kabsch_sums(const double* src, const double* dst, uint32_t n, double* partial, double* sums,

@@ -1098,6 +1098,102 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
     return rc;
 }
 
+// open3d::pipelines::registration::GetInformationMatrixFromPointClouds(source, target, max_dist, T): what
+// ReconstructionPipeline::GlobalRegistration (src/pipeline.cpp:818-824) uses to accept or reject the RANSAC
+// pose (info(5,5) / min(Ns, Nt) < 0.3 -> reject); SURVEY.md 8(f) N2.  info(5,5) is the correspondence count
+// (exact); the other entries are moment sums of the matched target points (order-free tree sums).
+int m3d_information_matrix(const double* src, size_t n_src, const double* dst, size_t n_dst,
+                           double max_correspondence_distance, const double* T, int device, double* info,
+                           uint64_t* n_correspondences) {
+    if (!info || !T || (!src && n_src) || (!dst && n_dst)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    for (int k = 0; k < 36; ++k) info[k] = 0.0;
+    if (n_correspondences) *n_correspondences = 0;
+    if (!(max_correspondence_distance > 0.0)) return fail(M3D_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
+    if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
+    if (n_src == 0 || n_dst == 0) return M3D_OK;
+    m3d_cloud* csrc = m3d_cloud_create(src, nullptr, n_src, device);
+    if (!csrc) return M3D_ERR_DEVICE;
+    m3d_cloud* cdst = m3d_cloud_create(dst, nullptr, n_dst, device);
+    if (!cdst) {
+        m3d_cloud_destroy(csrc);
+        return M3D_ERR_DEVICE;
+    }
+    DeviceCtx* ctx = csrc->ctx;
+    Scratch S;
+    DevBuf mx, my, mz, nn, d2;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        rc = [&]() -> int {
+            HIPCHK(hipSetDevice(ctx->device));
+            const CloudView sv = csrc->view(), dv = cdst->view();
+            const uint32_t n = sv.n;
+            GridDesc g;
+            const int rg = build_target_grid(ctx, S, dv, dst, n_dst, max_correspondence_distance, true, &g);
+            if (rg != M3D_OK) return rg;
+            RESERVE(mx, sizeof(double) * n);
+            RESERVE(my, sizeof(double) * n);
+            RESERVE(mz, sizeof(double) * n);
+            RESERVE(nn, sizeof(uint32_t) * n);
+            RESERVE(d2, sizeof(double) * n);
+            RESERVE(S.sums, sizeof(double) * 32);
+            RESERVE(S.partial_sum, sizeof(double) * 256 * 16);
+            RESERVE(S.one_T, sizeof(double) * kRegTStride);
+            RESERVE(S.block_counts, sizeof(uint32_t) * ((size_t)(n + 2047) / 2048 + 1));
+            RESERVE(S.total, 16);
+            RESERVE(S.vals, sizeof(double) * n);
+            RESERVE(ctx->h_small, 512);
+            HIPCHK(hipMemcpyAsync(S.one_T.p, T, sizeof(double) * 12, hipMemcpyHostToDevice, ctx->stream));
+            launch_icp_transform(sv.x, sv.y, sv.z, n, S.one_T.as<double>(), mx.as<double>(), my.as<double>(),
+                                 mz.as<double>(), ctx->stream);
+            launch_icp_nn(mx.as<double>(), my.as<double>(), mz.as<double>(), n, g, S.cell_start.as<uint32_t>(),
+                          S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), S.cell_orig.as<uint32_t>(),
+                          nn.as<uint32_t>(), d2.as<double>(), ctx->stream);
+            launch_compact_vals(d2.as<double>(), n, g.r2, S.block_counts.as<uint32_t>(), S.total.as<uint32_t>(),
+                                S.vals.as<double>(), ctx->stream);   // only for the count
+            launch_info_sums(n, dv, nn.as<uint32_t>(), S.partial_sum.as<double>(), S.sums.as<double>(), ctx->stream);
+            uint8_t* h = ctx->h_small.as<uint8_t>();
+            HIPCHK(hipMemcpyAsync(h, S.total.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(h + 8, S.sums.p, sizeof(double) * 9, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            uint32_t c;
+            double m[9];
+            std::memcpy(&c, h, 4);
+            std::memcpy(m, h + 8, sizeof(m));
+            const double cnt = (double)c;
+            const double sx = m[0], sy = m[1], sz = m[2], xx = m[3], yy = m[4], zz = m[5], xy = m[6], xz = m[7], yz = m[8];
+            auto set = [&](int a, int b, double v) {
+                info[6 * a + b] = v;
+                info[6 * b + a] = v;
+            };
+            set(0, 0, yy + zz);
+            set(0, 1, -xy);
+            set(0, 2, -xz);
+            set(0, 4, -sz);
+            set(0, 5, sy);
+            set(1, 1, xx + zz);
+            set(1, 2, -yz);
+            set(1, 3, sz);
+            set(1, 5, -sx);
+            set(2, 2, xx + yy);
+            set(2, 3, -sy);
+            set(2, 4, sx);
+            set(3, 3, cnt);
+            set(4, 4, cnt);
+            set(5, 5, cnt);
+            if (n_correspondences) *n_correspondences = c;
+            return M3D_OK;
+        }();
+        (void)hipStreamSynchronize(ctx->stream);
+        S.release();
+        mx.release(); my.release(); mz.release(); nn.release(); d2.release();
+    }
+    m3d_cloud_destroy(csrc);
+    m3d_cloud_destroy(cdst);
+    return rc;
+}
+
 uint64_t m3d_match_last_fallbacks(void) { return g_match_fallbacks; }
 
 int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat_dst, size_t n_dst, int dim,

@@ -328,6 +328,17 @@ def registration_ransac(src, dst, corr_src, corr_dst, thr=0.01, max_iter=100000,
                      int(st.best_index), int(st.est_k), arrs)
 
 
+def information_matrix(src, dst, max_dist, T):
+    """GetInformationMatrixFromPointClouds -> 6 x 6"""
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    Tm = _f64(T).reshape(16).copy()
+    info = np.zeros(36)
+    lib().orc_information_matrix(_p(src), C.c_size_t(len(src)), _p(dst), C.c_size_t(len(dst)), C.c_double(max_dist),
+                                 _p(Tm), _p(info))
+    return info.reshape(6, 6)
+
+
 def registration_icp(src, dst, max_dist, T_init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
     """-> (T 4x4, fitness, inlier_rmse, iterations, correspondences (ns,) int64 with -1 = none)"""
     src = _f64(src).reshape(-1, 3)

@@ -421,6 +421,34 @@ static void icp_result(const double *pcd, size_t ns, const double *dst, size_t n
     *err2 = e;
 }
 
+/* open3d::pipelines::registration::GetInformationMatrixFromPointClouds(source, target, max_dist, T), the
+ * acceptance test of ReconstructionPipeline::GlobalRegistration (src/pipeline.cpp:818-824: info(5,5) /
+ * min(Ns, Nt) < 0.3 -> reject).  [RECALL] Open3D 0.15.1 Registration.cpp: pcd = source
+ * transformed by T; correspondences as in GetRegistrationResultAndCorrespondences; for every correspondence
+ * with target point t = (x, y, z): G_r = [0 z -y 1 0 0], [-z 0 x 0 1 0], [y -x 0 0 0 1]; GTG += G_r G_r^T
+ * for the three rows in turn.  The reference reduces over OpenMP threads; here: source order, one thread.
+ * info: 6 x 6 row-major.  info[35] is the number of correspondences. */
+void orc_information_matrix(const double *src, size_t ns, const double *dst, size_t nd, double max_dist,
+                            const double *T, double *info) {
+    double *pcd = (double *)malloc(sizeof(double) * 3 * (ns ? ns : 1));
+    int64_t *corr = (int64_t *)malloc(sizeof(int64_t) * (ns ? ns : 1));
+    orc_transform_points(T, src, ns, pcd);
+    uint64_t cnt = 0;
+    double e2 = 0;
+    icp_result(pcd, ns, dst, nd, max_dist, corr, &cnt, &e2);
+    for (int k = 0; k < 36; ++k) info[k] = 0.0;
+    for (size_t i = 0; i < ns; ++i) {
+        if (corr[i] < 0) continue;
+        const double x = dst[3 * corr[i]], y = dst[3 * corr[i] + 1], z = dst[3 * corr[i] + 2];
+        const double G[3][6] = {{0.0, z, -y, 1.0, 0.0, 0.0}, {-z, 0.0, x, 0.0, 1.0, 0.0}, {y, -x, 0.0, 0.0, 0.0, 1.0}};
+        for (int r = 0; r < 3; ++r)
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) info[6 * a + b] += G[r][a] * G[r][b];
+    }
+    free(pcd);
+    free(corr);
+}
+
 static void mat4_mul(const double *A, const double *B, double *Cm) {
     double t[16];
     for (int r = 0; r < 4; ++r)

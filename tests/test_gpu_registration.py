@@ -336,3 +336,23 @@ def test_registration_icp_matches_oracle(capi, orc, case):
         assert (corr[corr >= 0] < len(d["dst"])).all()
     with pytest.raises(capi.M3DError):
         capi.registration_icp(src, dst, 0.0, init)
+
+
+def test_information_matrix_and_global_registration(capi, orc):
+    """GetInformationMatrixFromPointClouds (the acceptance test of GlobalRegistration): the
+    correspondence count info(5,5) is exact, the moment sums agree with the serial-order oracle to 1e-9
+    relative; the composed global_registration accepts the true pose and rejects a wrong one."""
+    d = synth.registration_pair_c4(5000, seed=13, dim=33, sigma=0.001)
+    for T in (d["T"], np.eye(4)):
+        info, nc = capi.information_matrix(d["src"], d["dst"], 0.03, T)
+        ref = orc.information_matrix(d["src"], d["dst"], 0.03, T)
+        assert nc == int(ref[5, 5]) == int(info[5, 5]) and info[3, 3] == info[4, 4] == nc
+        assert np.allclose(info, ref, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(ref).max()))
+        assert np.array_equal(info, info.T)
+    ok, pose, info = capi.global_registration(d["src"], d["dst"], d["feat_src"], d["feat_dst"], voxel_size=0.03 / 1.4,
+                                              max_iter=3000, seed=3)
+    assert ok and np.abs(pose - d["T"]).max() < 0.02 and info[5, 5] > 0.9 * 5000
+    far = d["dst"] + 100.0                                     # nothing overlaps: RANSAC finds no support
+    ok2, pose2, info2 = capi.global_registration(d["src"], far, d["feat_src"], np.random.default_rng(0).uniform(
+        0, 1, d["feat_dst"].shape), voxel_size=0.03 / 1.4, max_iter=500, seed=3)
+    assert (not ok2 and np.array_equal(info2, np.eye(6))) or np.allclose(pose2, np.eye(4))
