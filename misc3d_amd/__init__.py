@@ -11,6 +11,8 @@ Drop-in for the reference's python API on this path (module layout of python/py_
     T        = m3d.registration.compute_transformation_ransac(src, dst, idx, 0.03, 100000)
     T        = m3d.registration.compute_transformation_least_square(src, dst)
     T, info  = m3d.registration_icp(src, dst, 0.02, T)      # the Open3D call the reference's examples chain next
+    index    = m3d.features.detect_boundary_points(plane, ("hybrid", 0.02, 30))
+    normals  = m3d.common.estimate_normals(pcd, (848, 480), 3)
 
 Layout (only what the path needs):
   csrc/      HIP kernels, host driver, C ABI            -> lib/libmisc3d_amd.so
@@ -58,5 +60,46 @@ def registration_icp(source, target, max_correspondence_distance, init=None, max
                                   relative_fitness, relative_rmse, device)
 
 
-__all__ = ["common", "registration", "segmentation", "registration_icp", "VerbosityLevel", "set_verbosity_level",
+class _Features:
+    """misc3d.features (python/py_features.cpp): detect_boundary_points"""
+
+    @staticmethod
+    def detect_boundary_points(pc, param=("hybrid", 0.01, 30), angle_threshold=90.0, device=0):
+        """DetectBoundaryPoints (src/boundary_detection.cpp:68-113).  pc: (N, 3) array, (points, normals) tuple or
+        an object with .points / .normals.  param: an open3d KDTreeSearchParamHybrid / KDTreeSearchParamRadius
+        (anything with .radius and optionally .max_nn), or ("hybrid", radius, max_nn) / ("radius", radius).
+        Returns the list of boundary point indices (ascending)."""
+        import numpy as _np
+
+        from . import capi as _capi
+        if isinstance(pc, tuple) and len(pc) == 2:
+            pts, nrm = pc
+        else:
+            pts, nrm = getattr(pc, "points", pc), getattr(pc, "normals", None)
+        pts = _np.asarray(pts, dtype=_np.float64).reshape(-1, 3)
+        if nrm is not None:
+            nrm = _np.asarray(nrm, dtype=_np.float64).reshape(-1, 3)
+            if len(nrm) != len(pts) or len(nrm) == 0:
+                nrm = None
+        if isinstance(param, tuple):
+            kind = str(param[0]).lower()
+            radius = float(param[1])
+            max_nn = int(param[2]) if len(param) > 2 else 0
+        else:
+            radius = float(param.radius)
+            max_nn = int(getattr(param, "max_nn", 0))
+            kind = "hybrid" if hasattr(param, "max_nn") else "radius"
+        if kind not in ("hybrid", "radius"):
+            raise RuntimeError("[Misc3D Error] only KDTreeSearchParamHybrid / KDTreeSearchParamRadius are supported")
+        search = _capi.SEARCH_HYBRID if kind == "hybrid" else _capi.SEARCH_RADIUS
+        try:
+            idx = _capi.detect_boundary_points(pts, nrm, search, radius, max_nn, angle_threshold, device)
+        except _capi.M3DError as e:
+            raise RuntimeError(str(e)) from e
+        return [int(i) for i in idx]
+
+
+features = _Features()
+
+__all__ = ["common", "registration", "segmentation", "features", "registration_icp", "VerbosityLevel", "set_verbosity_level",
            "get_verbosity_level", "device_count"]

@@ -140,6 +140,8 @@ def lib():
                                            C.c_void_p, C.c_void_p]
         L.m3d_information_matrix.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p]
+        L.m3d_detect_boundary_points.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_double,
+                                                 C.c_int, C.c_void_p, C.c_void_p]
         L.m3d_match_last_fallbacks.restype = C.c_uint64
         L.m3d_match_last_fallbacks.argtypes = []
         L.m3d_match_mutual_nn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
@@ -481,6 +483,23 @@ def registration_icp(src, dst, max_correspondence_distance, init=None, max_itera
     if want_correspondences:
         return T.reshape(4, 4), st.asdict(), corr[: len(src)]
     return T.reshape(4, 4), st.asdict()
+
+
+SEARCH_RADIUS, SEARCH_HYBRID = 1, 2
+
+
+def detect_boundary_points(xyz, normals=None, search=SEARCH_HYBRID, radius=0.01, max_nn=30, angle_threshold=90.0,
+                           device=0):
+    """m3d_detect_boundary_points -> ascending indices (uint64) of the boundary points."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+    if nrm is not None and len(nrm) != len(xyz):
+        raise ValueError("normals and points differ in length")
+    out = np.zeros(max(len(xyz), 1), dtype=np.uint64)
+    k = C.c_size_t(0)
+    _check(lib().m3d_detect_boundary_points(_p(xyz), _p(nrm), len(xyz), search, radius, max_nn, angle_threshold, device,
+                                            _p(out), C.cast(C.byref(k), C.c_void_p)))
+    return out[: k.value].copy()
 
 
 def information_matrix(src, dst, max_correspondence_distance, T, device=0):

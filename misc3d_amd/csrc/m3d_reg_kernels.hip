@@ -16,6 +16,7 @@
 #include <climits>
 
 #include "m3d_reg_fp.hpp"
+#include "m3d_eig3.hpp"
 
 #pragma clang fp contract(off)
 
@@ -886,6 +887,147 @@ __global__ void icp_transform_k(const double* __restrict__ ix, const double* __r
 void launch_icp_transform(const double* ix, const double* iy, const double* iz, uint32_t n, const double* T_dev,
                           double* ox, double* oy, double* oz, hipStream_t s) {
     if (n) icp_transform_k<<<(n + 255) / 256, 256, 0, s>>>(ix, iy, iz, n, T_dev, ox, oy, oz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DetectBoundaryPoints (src/boundary_detection.cpp:21-113), one thread per point
+// ------------------------------------------------------------------------------------------------
+// Eigen's generic unitOrthogonal on (n, 0) + cross3 ([RECALL], same restatement as the oracle); the boundary
+// decision does not depend on the basis (angular gaps are invariant), only its roundings do.
+__device__ __forceinline__ void tangent_basis(const double* n, double* u, double* v) {
+    const double a[4] = {fabs(n[0]), fabs(n[1]), fabs(n[2]), 0.0};
+    int maxi = 0;
+    for (int i = 1; i < 4; ++i)
+        if (a[i] > a[maxi]) maxi = i;
+    int sndi = maxi == 0 ? 1 : 0;
+    for (int i = 0; i < 4; ++i)
+        if (i != maxi && a[i] > a[sndi]) sndi = i;
+    const double src[4] = {n[0], n[1], n[2], 0.0};
+    const double invnm = 1.0 / sqrt(src[sndi] * src[sndi] + src[maxi] * src[maxi]);
+    double p[4] = {0, 0, 0, 0};
+    p[maxi] = -src[sndi] * invnm;
+    p[sndi] = src[maxi] * invnm;
+    v[0] = p[0];
+    v[1] = p[1];
+    v[2] = p[2];
+    u[0] = n[1] * v[2] - n[2] * v[1];
+    u[1] = n[2] * v[0] - n[0] * v[2];
+    u[2] = n[0] * v[1] - n[1] * v[0];
+}
+
+// Neighbourhood = KDTreeFlann::Search with Radius (all d2 <= r^2) or Hybrid (the max_nn nearest with d2 < r^2),
+// kept sorted by (d2, original index); grid cell = 1.001 r, so the 3x3x3 block covers the radius.
+__global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const uint32_t* __restrict__ cell_start,
+                                                  const double* __restrict__ qx, const double* __restrict__ qy,
+                                                  const double* __restrict__ qz, const uint32_t* __restrict__ cell_orig,
+                                                  int search, int max_nn, double angle_thr_rad,
+                                                  uint8_t* __restrict__ flag, uint8_t* __restrict__ overflow) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= c.n) return;
+    const double px = c.x[i], py = c.y[i], pz = c.z[i];
+    int ix, iy, iz;
+    if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return;   // non-finite point: no neighbours
+    double nd[kBoundaryMaxNb];
+    uint32_t ni[kBoundaryMaxNb];
+    int m = 0;
+    const int cap = search == 2 ? max_nn : kBoundaryMaxNb;
+    const int K = g.K;
+    for (int dz = -K; dz <= K; ++dz)
+        for (int dy = -K; dy <= K; ++dy) {
+            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
+            const uint32_t b = cell_start[row - K], e = cell_start[row + K + 1];
+            for (uint32_t t = b; t < e; ++t) {
+                const double ddx = px - qx[t], ddy = py - qy[t], ddz = pz - qz[t];
+                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                if (!(search == 1 ? d2 <= g.r2 : d2 < g.r2)) continue;
+                const uint32_t o = cell_orig[t];
+                int pos;
+                if (m < cap) {
+                    pos = m++;
+                } else {
+                    if (search == 1) {   // Radius search has no bound on the neighbourhood: give up loudly
+                        overflow[0] = 1;
+                        return;
+                    }
+                    if (!(d2 < nd[m - 1] || (d2 == nd[m - 1] && o < ni[m - 1]))) continue;
+                    pos = m - 1;         // replaces the current farthest
+                }
+                while (pos > 0 && (d2 < nd[pos - 1] || (d2 == nd[pos - 1] && o < ni[pos - 1]))) {
+                    nd[pos] = nd[pos - 1];
+                    ni[pos] = ni[pos - 1];
+                    --pos;
+                }
+                nd[pos] = d2;
+                ni[pos] = o;
+            }
+        }
+    if (m < 3) return;   // :96-99
+    double nrm[3];
+    if (c.nx) {
+        nrm[0] = c.nx[i];
+        nrm[1] = c.ny[i];
+        nrm[2] = c.nz[i];
+    } else {   // stand-in for Open3D EstimateNormals(param): covariance of the same neighbourhood, J3x3
+        double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < m; ++t) {
+            const double x = c.x[ni[t]], y = c.y[ni[t]], z = c.z[ni[t]];
+            s[0] += x;
+            s[1] += y;
+            s[2] += z;
+            s[3] += x * x;
+            s[4] += x * y;
+            s[5] += x * z;
+            s[6] += y * y;
+            s[7] += y * z;
+            s[8] += z * z;
+        }
+        const double inv = 1.0 / (double)m;
+        for (int t = 0; t < 9; ++t) s[t] *= inv;
+        double Cm[9];
+        Cm[0] = s[3] - s[0] * s[0];
+        Cm[1] = s[4] - s[0] * s[1];
+        Cm[2] = s[5] - s[0] * s[2];
+        Cm[4] = s[6] - s[1] * s[1];
+        Cm[5] = s[7] - s[1] * s[2];
+        Cm[8] = s[8] - s[2] * s[2];
+        Cm[3] = Cm[1];
+        Cm[6] = Cm[2];
+        Cm[7] = Cm[5];
+        j3x3_smallest_eigvec(Cm, nrm);
+    }
+    double u[3], v[3];
+    tangent_basis(nrm, u, v);
+    // angles of the neighbours in the tangent plane (:33-41), kept sorted as they come
+    double* ang = nd;   // the distances are not needed any more
+    int na = 0;
+    for (int t = 0; t < m; ++t) {
+        const double dx = c.x[ni[t]] - px, dy = c.y[ni[t]] - py, dz = c.z[ni[t]] - pz;
+        if (dx == 0.0 && dy == 0.0 && dz == 0.0) continue;
+        const double a = atan2((v[0] * dx + v[1] * dy) + v[2] * dz, (u[0] * dx + u[1] * dy) + u[2] * dz);
+        int pos = na++;   // na <= t + 1: writing ang[pos] never touches an unread nd[]
+        while (pos > 0 && a < ang[pos - 1]) {
+            ang[pos] = ang[pos - 1];
+            --pos;
+        }
+        ang[pos] = a;
+    }
+    if (na == 0) return;
+    double max_dif = 0.0;
+    for (int t = 0; t + 1 < na; ++t) {
+        const double dif = ang[t + 1] - ang[t];
+        if (max_dif < dif) max_dif = dif;
+    }
+    const double wrap = 2 * 3.14159265358979323846 - ang[na - 1] + ang[0];
+    if (max_dif < wrap) max_dif = wrap;
+    if (max_dif > angle_thr_rad) flag[i] = 1;
+}
+void launch_boundary(const CloudView& c, const GridDesc& g, const uint32_t* cell_start, const double* qx,
+                     const double* qy, const double* qz, const uint32_t* cell_orig, int search, int max_nn,
+                     double angle_threshold_deg, uint8_t* flag, uint8_t* overflow, hipStream_t s) {
+    if (!c.n) return;
+    const double thr = angle_threshold_deg * 3.14159265358979323846 / 180.0;   // :62
+    boundary_k<<<(c.n + 63) / 64, 64, 0, s>>>(c, g, cell_start, qx, qy, qz, cell_orig, search, max_nn, thr, flag,
+                                              overflow);
 }
 
 // ------------------------------------------------------------------------------------------------

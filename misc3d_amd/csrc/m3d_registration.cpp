@@ -89,7 +89,7 @@ struct RegCtx {
 // bounded to 2 M target points; M3D_REG_NL=0 switches them off).  with_orig: also keep the original index of
 // every sorted point (S.cell_orig) and store it in the w component of the neighbour-list entries.
 int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, const double* dst, size_t n_dst,
-                      double radius, bool with_orig, GridDesc* g_out) {
+                      double radius, bool with_orig, GridDesc* g_out, int K0 = 4, bool with_nl = true) {
     GridDesc g;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (size_t i = 0; i < n_dst; ++i)   // bounding box on the host: one pass over n_dst points
@@ -102,7 +102,7 @@ int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, con
         }
     for (int k = 0; k < 3; ++k)
         if (!(lo[k] <= hi[k])) lo[k] = hi[k] = 0.0;
-    int K = 4;
+    int K = K0;
     double h = radius * 1.001 / K;
     uint64_t dims[3];
     for (;;) {
@@ -151,7 +151,7 @@ int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, con
                       S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
                       S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream, orig);
     const char* nl_env = std::getenv("M3D_REG_NL");
-    if (!(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
+    if (with_nl && !(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
         RESERVE(S.nl_start, sizeof(uint32_t) * ((size_t)ncell + 1));
         launch_nl_count(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.tile_sums.as<uint32_t>(),
                         S.total.as<uint32_t>() + 1, ctx->stream);
@@ -1191,6 +1191,57 @@ int m3d_information_matrix(const double* src, size_t n_src, const double* dst, s
     }
     m3d_cloud_destroy(csrc);
     m3d_cloud_destroy(cdst);
+    return rc;
+}
+
+// misc3d::features::DetectBoundaryPoints, src/boundary_detection.cpp:68-113: the step the
+// reference's showcase example runs right after fit_plane (examples/python/ransac_and_boundary.py:35-36).
+int m3d_detect_boundary_points(const double* xyz, const double* normals, size_t n, int search, double radius,
+                               int max_nn, double angle_threshold_deg, int device, size_t* indices, size_t* k_out) {
+    if (!k_out || (!xyz && n) || (!indices && n)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    *k_out = 0;
+    if (n == 0) return fail(M3D_ERR_INVALID_ARG, "No PointCloud data.");   // :72-76 LogError
+    if (search != 1 && search != 2)
+        return fail(M3D_ERR_INVALID_ARG, "only KDTreeSearchParamRadius (1) and KDTreeSearchParamHybrid (2) are supported");
+    if (!(radius > 0.0) || (search == 2 && (max_nn < 1 || max_nn > kBoundaryMaxNb)))
+        return fail(M3D_ERR_INVALID_ARG, "invalid search parameter (radius > 0, 1 <= max_nn <= 128)");
+    if (n >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
+    m3d_cloud* c = m3d_cloud_create(xyz, normals, n, device);
+    if (!c) return M3D_ERR_DEVICE;
+    DeviceCtx* ctx = c->ctx;
+    Scratch S;
+    DevBuf flags;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        rc = [&]() -> int {
+            HIPCHK(hipSetDevice(ctx->device));
+            const CloudView v = c->view();
+            GridDesc g;
+            const int rg = build_target_grid(ctx, S, v, xyz, n, radius, true, &g, /*K0=*/1, /*with_nl=*/false);
+            if (rg != M3D_OK) return rg;
+            RESERVE(flags, (size_t)v.n + 8);
+            HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)v.n + 8, ctx->stream));
+            launch_boundary(v, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
+                            S.cell_orig.as<uint32_t>(), search, max_nn, angle_threshold_deg, flags.as<uint8_t>(),
+                            flags.as<uint8_t>() + v.n, ctx->stream);
+            std::vector<uint8_t> hf((size_t)v.n + 8);
+            HIPCHK(hipMemcpyAsync(hf.data(), flags.p, hf.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (hf[v.n])
+                return fail(M3D_ERR_INVALID_ARG, "more than 128 neighbours within the radius (use KDTreeSearchParamHybrid)");
+            size_t k = 0;
+            for (uint32_t i = 0; i < v.n; ++i)
+                if (hf[i]) indices[k++] = i;   // ascending (the reference's order depends on thread timing)
+            *k_out = k;
+            return M3D_OK;
+        }();
+        (void)hipStreamSynchronize(ctx->stream);
+        S.release();
+        flags.release();
+    }
+    m3d_cloud_destroy(c);
     return rc;
 }
 

@@ -26,7 +26,7 @@ _NP = {PLANE: 4, SPHERE: 4, CYLINDER: 7}
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("misc3d_oracle.c", "misc3d_oracle_reg.c", "misc3d_oracle_normals.c", "std_rng_check.cpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("misc3d_oracle.c", "misc3d_oracle_reg.c", "misc3d_oracle_normals.c", "misc3d_oracle_boundary.c", "std_rng_check.cpp", "Makefile")]
     stale = force or not os.path.exists(_LIB_PATH) or not os.path.exists(RNG_CHECK_PATH)
     if not stale:
         t = min(os.path.getmtime(_LIB_PATH), os.path.getmtime(RNG_CHECK_PATH))
@@ -353,6 +353,17 @@ def registration_icp(src, dst, max_dist, T_init=None, max_iter=30, rel_fitness=1
                                     _p(Ti), C.c_int(max_iter), C.c_double(rel_fitness), C.c_double(rel_rmse), _p(T),
                                     C.byref(fit), C.byref(rm), C.byref(nc), _p(corr))
     return T.reshape(4, 4), float(fit.value), float(rm.value), int(it), corr[: len(src)]
+
+
+def detect_boundary_points(xyz, normals=None, search=2, radius=0.01, max_nn=30, angle_threshold=90.0):
+    """DetectBoundaryPoints (src/boundary_detection.cpp:68-113); search 1 = Radius, 2 = Hybrid -> ascending indices"""
+    xyz = _f64(xyz).reshape(-1, 3)
+    nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+    out = np.zeros(max(len(xyz), 1), dtype=np.int64)
+    lib().orc_detect_boundary_points.restype = C.c_size_t
+    k = lib().orc_detect_boundary_points(_p(xyz), _p(nrm), C.c_size_t(len(xyz)), C.c_int(search), C.c_double(radius),
+                                         C.c_int(max_nn), C.c_double(angle_threshold), _p(out))
+    return out[:k].copy()
 
 
 def normals_from_map(xyz, w, h, k=5, view_point=(0.0, 0.0, 0.0)):

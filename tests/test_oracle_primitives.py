@@ -295,3 +295,23 @@ def test_oracle_normals_from_map_against_numpy(orc):
             nn = vv[:, 0] if np.dot(-P[r, c], vv[:, 0]) >= 0 else -vv[:, 0]
             worst = max(worst, np.abs(N[r * w + c] - nn).max())
     assert worst < 1e-7
+
+
+def test_oracle_boundary_detection_properties(orc):
+    """DetectBoundaryPoints restatement: on a noisy planar patch with a hole every point near the outer edge or the
+    hole's rim is flagged, deep interior points are not; given normals and estimated normals agree (the angular
+    gaps do not depend on the in-plane basis); a larger angle threshold flags fewer points."""
+    rng = np.random.default_rng(2)
+    uv = rng.uniform(0, 1, (4000, 2))
+    uv = uv[np.hypot(uv[:, 0] - 0.5, uv[:, 1] - 0.5) > 0.2]
+    pts = np.c_[uv[:, 0], uv[:, 1], 0.1 * uv[:, 0] + rng.normal(0, 1e-4, len(uv))]
+    nrm = np.tile(np.array([-0.1, 0.0, 1.0]) / np.linalg.norm([-0.1, 0.0, 1.0]), (len(uv), 1))
+    edge = np.minimum.reduce([uv[:, 0], 1 - uv[:, 0], uv[:, 1], 1 - uv[:, 1], np.abs(np.hypot(uv[:, 0] - 0.5, uv[:, 1] - 0.5) - 0.2)])
+    b = orc.detect_boundary_points(pts, nrm, 2, 0.06, 30, 90.0)
+    flagged = np.zeros(len(pts), dtype=bool)
+    flagged[b] = True
+    assert flagged[edge < 0.004].all() and not flagged[edge > 0.07].any()
+    b2 = orc.detect_boundary_points(pts, None, 2, 0.06, 30, 90.0)
+    assert len(set(b.tolist()) ^ set(b2.tolist())) <= 2
+    assert len(orc.detect_boundary_points(pts, nrm, 2, 0.06, 30, 150.0)) < len(b)
+    assert np.array_equal(b, np.sort(b))

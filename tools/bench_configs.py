@@ -113,6 +113,18 @@ if "N3" in which or len(sys.argv) == 1:
         emit(f"N3 estimate_normals {w}x{h} k={k}", ms_total=dt * 1e3, ms_device=ms_dev, mpixel_per_s=w * h / (ms_dev * 1e3),
              device_GBps=bytes_alg / (ms_dev * 1e-3) / 1e9)
 
+if "N4" in which or len(sys.argv) == 1:
+    # DetectBoundaryPoints on a 500 k-point planar patch (the inliers of a fit_plane), Hybrid(0.02, 30)
+    rng = np.random.default_rng(3)
+    nb = 500_000
+    uv = rng.uniform(0, 3.0, (nb, 2))
+    pp = np.c_[uv[:, 0], uv[:, 1], 0.2 * uv[:, 0] + rng.normal(0, 1e-3, nb)]
+    capi.detect_boundary_points(pp[:1000], None, 2, 0.02, 30, 90.0)
+    t0 = time.perf_counter()
+    bidx = capi.detect_boundary_points(pp, None, 2, 0.02, 30, 90.0)
+    emit("N4 detect_boundary_points 500k pts Hybrid(0.02, 30), normals estimated", ms=(time.perf_counter() - t0) * 1e3,
+         boundary_points=len(bidx))
+
 if "C5" in which:
     n = int(os.environ.get("M3D_C5_POINTS", "10000000"))
     pts = synth.room_cloud_c5(n, 6)
