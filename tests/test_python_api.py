@@ -186,3 +186,33 @@ def test_host_minimal_fit_matches_oracle(orc, kind):
             k = capi.NUM_PARAMS[kind]
             assert np.array_equal(out[:k].view(np.uint64), models[h][:k].view(np.uint64)), h
     assert m in (2, 3, 4)
+
+
+def test_ply_reader_writer_roundtrip(tmp_path):
+    """misc3d_amd.io: the Open3D-free PLY reader for the reference's example clouds (binary little-endian doubles,
+    ascii, float/uchar properties, extra elements ignored)."""
+    from misc3d_amd import io
+    rng = np.random.default_rng(0)
+    pts, nrm = rng.normal(size=(257, 3)), rng.normal(size=(257, 3))
+    for binary in (True, False):
+        p = str(tmp_path / f"c{int(binary)}.ply")
+        io.write_ply(p, pts, nrm, binary=binary)
+        d = io.read_ply(p)
+        assert np.array_equal(d["points"], pts) and np.array_equal(d["normals"], nrm) and d["colors"] is None
+    # float xyz + uchar colours + a face element behind the vertices
+    p = str(tmp_path / "mixed.ply")
+    rec = np.zeros(5, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    rec["x"], rec["y"], rec["z"] = np.arange(5), np.arange(5) * 2, np.arange(5) * 3
+    rec["red"], rec["green"], rec["blue"] = 255, 0, 51
+    with open(p, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\ncomment made by a test\nelement vertex 5\nproperty float x\n"
+                b"property float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+                b"element face 1\nproperty list uchar int vertex_indices\nend_header\n")
+        f.write(rec.tobytes())
+        f.write(bytes([3]) + np.array([0, 1, 2], dtype="<i4").tobytes())
+    d = io.read_ply(p)
+    assert np.array_equal(d["points"][:, 1], np.arange(5) * 2.0) and d["normals"] is None
+    assert np.allclose(d["colors"][0], [1.0, 0.0, 0.2])
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.ply").write_bytes(b"plx\n")
+        io.read_ply(str(tmp_path / "bad.ply"))
