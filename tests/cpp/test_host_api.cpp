@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <random>
 
+#include <algorithm>
+
 #include <misc3d/common/normal_estimation.h>
+#include <misc3d/features/boundary_detection.h>
 #include <misc3d/common/ransac.h>
 #include <misc3d/registration/correspondence_matching.h>
 #include <misc3d/registration/transform_estimation.h>
@@ -153,6 +156,22 @@ int main() {
             threw_size = std::string(e.what()).find("not equal to given point map size") != std::string::npos;
         }
         CHECK(threw_size);
+    }
+
+    // ---- DetectBoundaryPoints (include/misc3d/features/boundary_detection.h): a square patch, Hybrid(0.08, 30)
+    {
+        misc3d::PointCloud patch;
+        for (int i = 0; i < 3000; ++i) patch.points_.push_back({0.5 + 0.5 * U(gen), 0.5 + 0.5 * U(gen), 0.001 * U(gen)});
+        const auto b = misc3d::features::DetectBoundaryPoints(patch, misc3d::features::KDTreeSearchParamHybrid(0.08, 30));
+        CHECK(b.size() > 100 && b.size() < 1200);
+        size_t near_edge = 0;
+        for (size_t i : b) {
+            const auto& q = patch.points_[i];
+            const double e = std::min(std::min(q[0], 1.0 - q[0]), std::min(q[1], 1.0 - q[1]));
+            near_edge += e < 0.08;
+        }
+        CHECK(near_edge * 10 > b.size() * 9);   // >= 90 % of the flagged points lie within one radius of the edge
+        for (size_t k = 1; k < b.size(); ++k) CHECK(b[k] > b[k - 1]);
     }
 
     std::printf("host api: all checks passed\n");
