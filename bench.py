@@ -16,8 +16,9 @@ Extra objects on the JSON line:
                hypothesis chunk) -- the same launches `rocprofv3 --kernel-trace --stats -- python bench.py`
                averages.  The kernel re-uses every point load for all hypotheses from registers and skips
                (tile, hypothesis) pairs whose bounding box cannot contain an inlier, so this figure exceeds
-               the HBM peak by design; `valu` prices the surviving pairs against the fp64 VALU issue peak, the
-               roofline that actually bounds it.  `traffic` = HBM bytes per 10 000-
+               the HBM peak by design; `valu` prices the pairs those same launches evaluated (counted inside the
+               kernel, m3d_stats.pairs_scored) against the fp64 VALU issue peak, the roofline that actually
+               bounds it.  `traffic` = HBM bytes per 10 000-
                hypothesis launch from the rocprofv3 PMC pass committed under profiles/ (null if absent).
   cpu_baseline the oracle's reference-shaped OpenMP port (oracle/misc3d_oracle.c orc_fit_omp_baseline) timed
                on this box's host cores on a bounded sample.
@@ -123,7 +124,7 @@ def main():
     for _ in range(a.warmup):
         res = step()
     barrier()
-    k_ms_sum, k_launches = 0.0, 0
+    k_ms_sum, k_launches, k_pairs = 0.0, 0, 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
@@ -131,6 +132,7 @@ def main():
         if st:
             k_ms_sum += st["ms_score_kernel"]
             k_launches += st["score_launches"]
+            k_pairs += st["pairs_scored"]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -173,6 +175,14 @@ def main():
                             "cannot reach the best count of earlier chunks, so achieved exceeds the HBM peak by "
                             "design; the binding roofline is fp64 VALU issue on the surviving pairs "
                             "(--kernel-detail; DESIGN.md section 4)"}
+        if k_launches and k_pairs:
+            # the roofline that actually binds: fp64 VALU issue on the (tile, hypothesis) pairs the timed launches
+            # evaluated (counted inside score_mask_k), 7 instructions per (point, hypothesis) for the plane
+            v_tops = k_pairs * 512.0 * VALU_OPS_PER_PAIR[kind] / (k_ms_sum * 1e-3) / 1e12
+            roofline["valu"] = {"achieved": v_tops, "peak": FP64_VALU_PEAK_TOPS, "unit": "Tinstr-lane/s (fp64 VALU)",
+                                "frac": v_tops / FP64_VALU_PEAK_TOPS, "ops_per_pair": VALU_OPS_PER_PAIR[kind],
+                                "tile_hypothesis_pairs_per_launch": k_pairs / k_launches,
+                                "fraction_of_all_pairs": k_pairs / float(n_tiles * H * a.steps)}
         if a.kernel_detail:
             Hk = min(H, 16384)
             samples = capi.draw_samples(N, kind, Hk, seed)
@@ -184,7 +194,7 @@ def main():
             valu_tops = listed * 512.0 * VALU_OPS_PER_PAIR[kind] / (u_ms * 1e-3) / 1e12
             dense_tops = float(-(-Hk // 64) * 64) * float(-(-N // 2048) * 2048) * VALU_OPS_PER_PAIR[kind] / (
                 dense_ms * 1e-3) / 1e12
-            roofline["valu"] = {"achieved": valu_tops, "peak": FP64_VALU_PEAK_TOPS,
+            roofline["valu_unpruned_launch"] = {"achieved": valu_tops, "peak": FP64_VALU_PEAK_TOPS,
                                 "unit": "Tinstr-lane/s (fp64 VALU)", "frac": valu_tops / FP64_VALU_PEAK_TOPS,
                                 "ops_per_pair": VALU_OPS_PER_PAIR[kind], "launch_ms_unpruned": u_ms,
                                 "hypotheses": Hk, "surviving_tile_hypothesis_pairs": listed,

@@ -62,6 +62,7 @@ typedef struct m3d_stats {
     double ms_score_kernel;      /* device: sum of the scoring-kernel launches alone (HIP events around each) */
     uint32_t score_launches;     /* number of scoring-kernel launches (chunks) behind ms_score_kernel */
     uint32_t reserved0;
+    uint64_t pairs_scored;       /* (512-point tile, hypothesis) pairs those launches evaluated after culling and pruning */
 } m3d_stats;
 
 /* ---- one-shot fits: python/py_common.cpp:11-67 FitPlane / FitSphere / FitCylinder ------------- */

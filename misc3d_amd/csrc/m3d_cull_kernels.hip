@@ -195,7 +195,8 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
                                                     const unsigned long long* __restrict__ masks,
                                                     const unsigned long long* __restrict__ keep,
                                                     uint32_t n_groups, uint32_t groups_per_block,
-                                                    uint32_t* __restrict__ counts_rep, uint32_t rep_stride) {
+                                                    uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                    uint32_t* __restrict__ pair_rep) {
     const uint32_t tile = blockIdx.x;
     // ~430 tiles add to every hypothesis' counter: kCountReplicas copies of the counter array (tile mod R)
     // keep the same-address atomic chains short (they serialise in L2 and dominated small chunks)
@@ -207,6 +208,11 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
     if ((uint32_t)lane < groups_per_block && g0 + lane < n_groups)
         mm = masks[(size_t)tile * n_groups + g0 + lane] & keep[g0 + lane];
     if (!__ballot(mm != 0)) return;  // most (tile, range) blocks of a pruned chunk end here
+    {   // statistics: (tile, hypothesis) pairs this wave evaluates (m3d_stats.pairs_scored), 64 counter replicas
+        uint32_t pc = (uint32_t)__popcll(mm);
+        for (int off = 32; off > 0; off >>= 1) pc += (uint32_t)__shfl_xor((int)pc, off, 64);
+        if (lane == 0) atomicAdd(&pair_rep[tile & 63u], pc);
+    }
 
     const size_t base = (size_t)tile * kTilePoints + lane;
     constexpr int P = kTilePoints / 64;
@@ -288,34 +294,44 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
     if ((uint32_t)lane < slot && park_cnt) atomicAdd(&counts[park_h], park_cnt);
 }
 
-// counts[h] = sum over the replicas
+// counts[h] = sum over the replicas; counts[pairs_slot] = evaluated (tile, hypothesis) pairs of the launch
 __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t rep_stride, uint32_t h_pad,
-                               uint32_t* __restrict__ counts) {
+                               uint32_t* __restrict__ counts, const uint32_t* __restrict__ pair_rep,
+                               uint32_t pairs_slot) {
     const uint32_t h = blockIdx.x * 256u + threadIdx.x;
-    if (h >= h_pad) return;
+    if (h == 0 && pair_rep) {
+        uint32_t p = 0;
+        for (int r = 0; r < 64; ++r) p += pair_rep[r];
+        counts[pairs_slot] = p;
+    }
+    if (h >= h_pad || (pair_rep && h == pairs_slot)) return;
     uint32_t c = 0;
 #pragma unroll
     for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
     counts[h] = c;
 }
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
-                         hipStream_t st) {
-    if (h_pad) sum_replicas_k<<<(h_pad + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_pad, counts);
+                         const uint32_t* pair_rep, uint32_t pairs_slot, hipStream_t st) {
+    if (h_pad)
+        sum_replicas_k<<<(h_pad + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_pad, counts, pair_rep, pairs_slot);
 }
 
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
-                       hipStream_t st) {
+                       uint32_t* pair_rep, hipStream_t st) {
     if (!s.n_tiles || !n_groups) return;
     // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerBlock, (uint32_t)(((uint64_t)s.n_tiles * n_groups) / 16384)));
     const dim3 g(s.n_tiles, (n_groups + gpb - 1) / gpb), b(64);
     if (kind == 0)
-        score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride);
+        score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
+                                         pair_rep);
     else if (kind == 1)
-        score_mask_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride);
+        score_mask_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
+                                         pair_rep);
     else
-        score_mask_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride);
+        score_mask_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
+                                         pair_rep);
 }
 
 // best_count[0] = max(best_count[0], max over valid hypotheses of counts[h])

@@ -32,9 +32,11 @@ void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n
 constexpr int kCountReplicas = 16;
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
-                       hipStream_t st);
+                       uint32_t* pair_rep /* 64 u32, zero on entry: evaluated (tile, hypothesis) pairs */, hipStream_t st);
+// pair_rep != null: counts[pairs_slot] receives the sum of the pair counters (pairs_slot must be >= the number of
+// real hypotheses; that entry is then not a hypothesis count)
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
-                         hipStream_t st);
+                         const uint32_t* pair_rep, uint32_t pairs_slot, hipStream_t st);
 void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
                       hipStream_t st);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,

@@ -311,16 +311,16 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     RESERVE(s.score, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
     RESERVE(s.params, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
     RESERVE(s.valid, (size_t)h_pad + 1);
-    RESERVE(s.counts, sizeof(uint32_t) * (size_t)h_pad);
+    RESERVE(s.counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // + the launch's pair counter behind the counts
     RESERVE(s.h_samples, sizeof(uint32_t) * (size_t)count * m);
-    RESERVE(s.h_counts, sizeof(uint32_t) * (size_t)h_pad);
+    RESERVE(s.h_counts, sizeof(uint32_t) * ((size_t)h_pad + 1));
     RESERVE(s.h_valid, (size_t)h_pad + 1);
     if (dense) {
         RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
     } else {
         RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * (h_pad / 64));
         RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)(h_pad / 64));
-        RESERVE(ctx->counts_rep, sizeof(uint32_t) * (size_t)kCountReplicas * h_pad);
+        RESERVE(ctx->counts_rep, sizeof(uint32_t) * ((size_t)kCountReplicas * h_pad + 64));
     }
     const double t0 = now_ms();
     src.fill(begin, end, s.h_samples.as<uint32_t>());
@@ -332,7 +332,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     else
-        HIPCHK(hipMemsetAsync(ctx->counts_rep.p, 0, sizeof(uint32_t) * (size_t)kCountReplicas * h_pad, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->counts_rep.p, 0, sizeof(uint32_t) * ((size_t)kCountReplicas * h_pad + 64), ctx->stream));
     if (dense) {
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
@@ -354,15 +354,18 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream);
         launch_keep_mask(ub, prune ? ctx->best_count.as<uint32_t>() : nullptr, n_groups, keep, ctx->stream);
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
+        uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
         launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
-                          ctx->stream);
+                          pair_rep, ctx->stream);
         HIPCHK(hipEventRecord(s.k1, ctx->stream));
-        launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.counts.as<uint32_t>(), ctx->stream);
+        launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.counts.as<uint32_t>(), pair_rep, count,
+                            ctx->stream);
         if (prune)
             launch_max_count(s.counts.as<uint32_t>(), s.valid.as<uint8_t>(), count, ctx->best_count.as<uint32_t>(),
                              ctx->stream);
     }
-    HIPCHK(hipMemcpyAsync(s.h_counts.p, s.counts.p, sizeof(uint32_t) * (size_t)count,
+    // counts of the chunk + (culled path) the number of (tile, hypothesis) pairs the launch evaluated
+    HIPCHK(hipMemcpyAsync(s.h_counts.p, s.counts.p, sizeof(uint32_t) * ((size_t)count + (dense ? 0 : 1)),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(s.h_valid.p, s.valid.p, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
@@ -615,6 +618,7 @@ struct RansacOut {
     double ms_sample = 0, ms_score = 0;
     double ms_score_kernel = 0;   // sum over the chunks' scoring-kernel launches (HIP events k0..k1)
     uint32_t score_launches = 0;
+    uint64_t pairs_scored = 0;   // (tile, hypothesis) pairs the scoring launches evaluated (culled path)
     int internal_error = 0;
 };
 
@@ -693,6 +697,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
+                if (!use_dense_scoring()) out->pairs_scored += s.h_counts.as<uint32_t>()[s.end - s.begin];
             }
             int cb_rc = M3D_OK;
             // exact EvaluateModel rmse (serial-order error sum), ransac.h:632-650
@@ -853,6 +858,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         stats->ms_score = ro.ms_score;
         stats->ms_score_kernel = ro.ms_score_kernel;
         stats->score_launches = ro.score_launches;
+        stats->pairs_scored = ro.pairs_scored;
         stats->ms_refine = t2 - t1;
         stats->ms_total = t2 - t0;
     }
@@ -1359,7 +1365,7 @@ int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     const uint32_t n_groups = s.h_pad / 64;
     RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * n_groups);
     RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)n_groups);
-    RESERVE(ctx->counts_rep, sizeof(uint32_t) * (size_t)kCountReplicas * s.h_pad);
+    RESERVE(ctx->counts_rep, sizeof(uint32_t) * ((size_t)kCountReplicas * s.h_pad + 64));
     RESERVE(ctx->small, 256);
     auto* masks = ctx->masks.as<unsigned long long>();
     auto* keep = ctx->keep.as<unsigned long long>();
@@ -1377,7 +1383,7 @@ int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     for (int r = 0; r < reps; ++r) {
         if (mode == 0)
             launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
-                              s.h_pad, ctx->stream);
+                              s.h_pad, ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * s.h_pad, ctx->stream);
         else if (mode == 1)
             launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, nullptr,
                              ctx->stream);
