@@ -788,13 +788,36 @@ void launch_icp_nn(const double* px, const double* py, const double* pz, uint32_
     if (n) icp_nn_k<<<(n + 255) / 256, 256, 0, s>>>(px, py, pz, n, g, cell_start, qx, qy, qz, cell_orig, nn, d2);
 }
 
+// GetRegistrationResultAndCorrespondences' error2 and correspondence count in one pass over the per-point
+// squared distances: out[0] = sum of d2 < r2 (order-free tree sum: ICP only compares rmse differences with
+// 1e-6 and reports rmse at tolerance level; the RANSAC tie rule, which needs the serial order, has its own
+// path), out[1] = their number (exact: a sum of ones below 2^53).
+__global__ __launch_bounds__(256) void icp_err_k(const double* __restrict__ d2, uint32_t n, double r2,
+                                                  double* __restrict__ partial) {
+    __shared__ double sm[2 * 256];
+    double acc[2] = {0.0, 0.0};
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += 256u * 256u) {
+        const double v = d2[i];
+        if (v < r2) {
+            acc[0] += v;
+            acc[1] += 1.0;
+        }
+    }
+    tree_reduce_256<2>(acc, sm);
+    if (threadIdx.x < 2) partial[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
+}
+void launch_icp_err(const double* d2, uint32_t n, double r2, double* partial, double* out2, hipStream_t s) {
+    icp_err_k<<<256, 256, 0, s>>>(d2, n, r2, partial);
+    kabsch_final_k<2><<<1, 256, 0, s>>>(partial, out2);
+}
+
 // Eigen::umeyama sums over the correspondence set (moving point i, target point nn[i]): PASS 0 = the six
 // coordinate sums, PASS 1 = covariance d s^T (9) and |s|^2 (3) about the means.  Order-free tree sums (the
 // n-point Kabsch parity bar is 1e-9).
 template <int PASS>
 __global__ __launch_bounds__(256) void icp_sums_k(const double* __restrict__ px, const double* __restrict__ py,
                                                    const double* __restrict__ pz, uint32_t n, CloudView dst,
-                                                   const uint32_t* __restrict__ nn, const uint32_t* __restrict__ count,
+                                                   const uint32_t* __restrict__ nn, const double* __restrict__ count,
                                                    const double* __restrict__ sums0, double* __restrict__ partial) {
     constexpr int NV = PASS == 0 ? 6 : 12;
     __shared__ double sm[NV * 256];
@@ -802,7 +825,7 @@ __global__ __launch_bounds__(256) void icp_sums_k(const double* __restrict__ px,
     for (int k = 0; k < NV; ++k) acc[k] = 0.0;
     double ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
     if (PASS == 1) {
-        const double one_over_n = 1.0 / (double)count[0];
+        const double one_over_n = 1.0 / count[0];
         for (int k = 0; k < 3; ++k) {
             ms[k] = sums0[k] * one_over_n;
             md[k] = sums0[3 + k] * one_over_n;
@@ -833,7 +856,7 @@ __global__ __launch_bounds__(256) void icp_sums_k(const double* __restrict__ px,
 }
 // sums: 18 doubles laid out like launch_kabsch_sums (6 coordinate sums, 9 covariance sums, 3 squared sums)
 void launch_icp_sums(const double* px, const double* py, const double* pz, uint32_t n, const CloudView& dst,
-                     const uint32_t* nn, const uint32_t* count, double* partial, double* sums, hipStream_t s) {
+                     const uint32_t* nn, const double* count, double* partial, double* sums, hipStream_t s) {
     icp_sums_k<0><<<256, 256, 0, s>>>(px, py, pz, n, dst, nn, count, nullptr, partial);
     kabsch_final_k<6><<<1, 256, 0, s>>>(partial, sums);
     icp_sums_k<1><<<256, 256, 0, s>>>(px, py, pz, n, dst, nn, count, sums, partial);

@@ -55,8 +55,9 @@ void launch_corr_ratio(const CloudView& src, const CloudView& dst, const uint32_
 void launch_icp_nn(const double* px, const double* py, const double* pz, uint32_t n, const GridDesc& g,
                    const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
                    const uint32_t* cell_orig, uint32_t* nn, double* d2, hipStream_t s);
+void launch_icp_err(const double* d2, uint32_t n, double r2, double* partial, double* out2, hipStream_t s);
 void launch_icp_sums(const double* px, const double* py, const double* pz, uint32_t n, const CloudView& dst,
-                     const uint32_t* nn, const uint32_t* count, double* partial, double* sums, hipStream_t s);
+                     const uint32_t* nn, const double* count, double* partial, double* sums, hipStream_t s);
 constexpr int kBoundaryMaxNb = 128;   // neighbours kept per point in boundary_k
 void launch_boundary(const CloudView& c, const GridDesc& g, const uint32_t* cell_start, const double* qx,
                      const double* qy, const double* qz, const uint32_t* cell_orig, int search, int max_nn,

@@ -1006,22 +1006,20 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
             }
             uint64_t cnt = 0;
             double e2 = 0.0;
-            // GetRegistrationResultAndCorrespondences: nearest target point within the radius, error2 in source order
+            // GetRegistrationResultAndCorrespondences: nearest target point within the radius, count + error2
             auto result = [&]() -> int {
                 launch_icp_nn(px, py, pz, n, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
                               S.qz.as<double>(), S.cell_orig.as<uint32_t>(), nn.as<uint32_t>(), d2.as<double>(),
                               ctx->stream);
-                launch_compact_vals(d2.as<double>(), n, g.r2, S.block_counts.as<uint32_t>(), S.total.as<uint32_t>(),
-                                    S.vals.as<double>(), ctx->stream);
-                launch_serial_sum(S.vals.as<double>(), S.total.as<uint32_t>(), S.sums.as<double>() + 24, ctx->stream);
+                launch_icp_err(d2.as<double>(), n, g.r2, S.partial_sum.as<double>(), S.sums.as<double>() + 24, ctx->stream);
                 uint8_t* h = ctx->h_small.as<uint8_t>();
-                HIPCHK(hipMemcpyAsync(h, S.total.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(hipMemcpyAsync(h + 8, S.sums.as<double>() + 24, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipMemcpyAsync(h, S.sums.as<double>() + 24, 16, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipStreamSynchronize(ctx->stream));
-                uint32_t c;
-                std::memcpy(&c, h, 4);
-                std::memcpy(&e2, h + 8, 8);
+                double es[2];
+                std::memcpy(es, h, 16);
+                e2 = es[0];
+                const uint32_t c = (uint32_t)es[1];
                 cnt = c;
                 return M3D_OK;
             };
@@ -1035,7 +1033,7 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
                 double U[16];
                 std::memcpy(U, I4, sizeof(U));
                 if (cnt) {   // ComputeTransformation: Eigen::umeyama over the correspondence set, no scaling
-                    launch_icp_sums(px, py, pz, n, dv, nn.as<uint32_t>(), S.total.as<uint32_t>(),
+                    launch_icp_sums(px, py, pz, n, dv, nn.as<uint32_t>(), S.sums.as<double>() + 25,
                                     S.partial_sum.as<double>(), S.sums.as<double>(), ctx->stream);
                     double h[18];
                     HIPCHK(hipMemcpyAsync(ctx->h_small.p, S.sums.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
