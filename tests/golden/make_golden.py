@@ -88,7 +88,13 @@ def next_rows():
     init = d["T"].copy()
     init[:3, 3] += np.array([0.01, -0.006, 0.004])
     T, fit, rm, it, corr = oracle.registration_icp(d["src"], d["dst"], 0.02, init)
-    np.savez_compressed(os.path.join(HERE, "next_rows.npz"), map_xyz=xyz, map_shape_k=np.array([w, h, k]),
+    info = oracle.information_matrix(d["src"], d["dst"], 0.03, T)
+    uv = rng.uniform(0, 1, (1800, 2))
+    uv = uv[np.hypot(uv[:, 0] - 0.5, uv[:, 1] - 0.5) > 0.2]
+    bpts = np.ascontiguousarray(np.c_[uv[:, 0], uv[:, 1], 0.25 * uv[:, 0] - 0.1 * uv[:, 1] + rng.normal(0, 1e-4, len(uv))])
+    bidx = oracle.detect_boundary_points(bpts, None, 2, 0.07, 30, 90.0)
+    np.savez_compressed(os.path.join(HERE, "next_rows.npz"), info=info, boundary_points=bpts, boundary_index=bidx,
+                        boundary_args=np.array([2, 0.07, 30, 90.0]), map_xyz=xyz, map_shape_k=np.array([w, h, k]),
                         map_view_point=vp, map_normals=nrm, icp_src=d["src"], icp_dst=d["dst"], icp_init=init,
                         icp_T=T, icp_fit_rmse=np.array([fit, rm]), icp_iterations=np.array([it]), icp_corr=corr)
 
