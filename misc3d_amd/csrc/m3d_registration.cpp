@@ -333,29 +333,25 @@ struct m3d_reg {
     int n_exec = 0;          // iterations of the chunk in flight
     bool finished = false;
     double t_begin = 0;
+
+    int setup(const double* src, const double* dst, const size_t* corr_src, const size_t* corr_dst,
+              const uint64_t* seed);
+    int begin_chunk(size_t* n_survivors);   // M3D_OK with *n_survivors set, or M3D_FALSE when the loop is over
+    int validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double* sums_out);
+    int replay(const uint32_t* counts_in, const double* sums_in);
+    int finish(double* T_out, m3d_reg_stats* stats);
 };
 
-namespace {
 
-int reg_setup(m3d_reg& q, const double* src, const double* dst, const size_t* corr_src, const size_t* corr_dst,
-              const uint64_t* seed) {
-    DeviceCtx* ctx = q.ctx;
-    Scratch& S = q.S;
-    RegCtx& R = q.R;
-    GridDesc& g = q.g;
-    CloudView& src_sorted = q.src_sorted;
-    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
-    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
-    const int max_iter = q.max_iter;
-    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
-    (void)edge_length_threshold; (void)confidence; (void)max_iter;
+int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src, const size_t* corr_dst,
+                   const uint64_t* seed) {
 
     HIPCHK(hipSetDevice(ctx->device));
     R.ctx = ctx;
-    R.src = q.csrc->view();
+    R.src = this->csrc->view();
     // the count kernel reads whole tiles of kRegTile points: the cloud padding (kScoreTile) covers it
     static_assert(kScoreTile % kRegTile == 0, "padding of resident clouds must cover the reg tiles");
-    R.dst = q.cdst->view();
+    R.dst = this->cdst->view();
     R.s = &S;
     R.m = (uint32_t)m;
     R.thr = threshold;
@@ -439,61 +435,22 @@ int reg_setup(m3d_reg& q, const double* src, const double* dst, const size_t* co
 
     // ---- RANSAC state
     std::random_device rd;
-    q.rng = std::mt19937((std::mt19937::result_type)((seed ? *seed : (uint64_t)rd()) & 0xffffffffull));
-    q.pick = std::uniform_int_distribution<int>(0, (int)m - 1);  // utility::UniformRandIntGenerator(0, M-1)
+    this->rng = std::mt19937((std::mt19937::result_type)((seed ? *seed : (uint64_t)rd()) & 0xffffffffull));
+    this->pick = std::uniform_int_distribution<int>(0, (int)m - 1);  // utility::UniformRandIntGenerator(0, M-1)
     const char* prune_env = std::getenv("M3D_REG_PRUNE");
-    q.reg_prune = !(prune_env && prune_env[0] == '0');
-    q.est_k_global = q.est_k_local = max_iter;
+    this->reg_prune = !(prune_env && prune_env[0] == '0');
+    this->est_k_global = this->est_k_local = max_iter;
     RESERVE(S.one_T, sizeof(double) * kRegTStride * 2);
-    q.best_T_dev = S.one_T.as<double>();
-    q.n_tiles = R.src.n_pad / kRegTile;
+    this->best_T_dev = S.one_T.as<double>();
+    this->n_tiles = R.src.n_pad / kRegTile;
     return M3D_OK;
 }
 
 // returns M3D_OK with *n_survivors set, or M3D_FALSE when the loop is over
-int reg_begin_chunk(m3d_reg& q, size_t* n_survivors) {
-    DeviceCtx* ctx = q.ctx;
-    Scratch& S = q.S;
-    RegCtx& R = q.R;
-    GridDesc& g = q.g;
-    CloudView& src_sorted = q.src_sorted;
-    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
-    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
-    const int max_iter = q.max_iter;
-    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
-    (void)edge_length_threshold; (void)confidence; (void)max_iter;
-    auto& rng = q.rng;
-    auto& pick = q.pick;
-    auto& best_fit = q.best_fit;
-    auto& best_rmse = q.best_rmse;
-    auto& best_cnt = q.best_cnt;
-    const bool reg_prune = q.reg_prune;
-    auto& best_rmse_known = q.best_rmse_known;
-    auto& best_index = q.best_index;
-    auto& est_k_global = q.est_k_global;
-    auto& est_k_local = q.est_k_local;
-    auto& total_validation = q.total_validation;
-    auto& ties = q.ties;
-    auto& exact_evals = q.exact_evals;
-    auto& iters = q.iters;
-    double* const best_T_dev = q.best_T_dev;
-    auto& best_T_host = q.best_T_host;
-    const uint32_t n_tiles = q.n_tiles;
-    auto& tri = q.tri;
-    auto& survivors = q.survivors;
-    auto& h_counts = q.h_counts;
-    auto& h_sum2 = q.h_sum2;
-    auto& best_sum2 = q.best_sum2;
-    auto& pass = q.pass;
-    auto& chunk = q.chunk;
-    auto& itr = q.itr;
-    (void)rng; (void)pick; (void)best_fit; (void)best_rmse; (void)best_cnt; (void)reg_prune; (void)best_rmse_known;
-    (void)best_index; (void)est_k_global; (void)est_k_local; (void)total_validation; (void)ties; (void)exact_evals;
-    (void)iters; (void)best_T_dev; (void)best_T_host; (void)n_tiles; (void)tri; (void)survivors; (void)h_counts;
-    (void)h_sum2; (void)best_sum2; (void)pass; (void)chunk; (void)itr;
+int m3d_reg::begin_chunk(size_t* n_survivors) {
     *n_survivors = 0;
-    if (q.trivial || q.finished || !(itr < max_iter && itr < est_k_global)) {
-        q.finished = true;
+    if (this->trivial || this->finished || !(itr < max_iter && itr < est_k_global)) {
+        this->finished = true;
         return M3D_FALSE;
     }
     HIPCHK(hipSetDevice(ctx->device));
@@ -501,8 +458,7 @@ int reg_begin_chunk(m3d_reg& q, size_t* n_survivors) {
     // iterations [itr, itr + n_exec) all satisfy itr < est_k_global as of now; est_k can only
     // shrink while replaying, in which case the tail of the chunk is discarded (its draws
     // would not have happened: the generator is rewound by re-drawing from a saved state)
-    const int n_exec = (int)std::min<size_t>(chunk, (size_t)(std::min(max_iter, est_k_global) - itr));
-    q.n_exec = n_exec;
+    n_exec = (int)std::min<size_t>(chunk, (size_t)(std::min(max_iter, est_k_global) - itr));
     tri.resize((size_t)n_exec * 3);
     for (int k = 0; k < n_exec * 3; ++k) tri[k] = (uint32_t)pick(rng);
     RESERVE(S.triples, sizeof(uint32_t) * 3 * (size_t)n_exec);
@@ -541,46 +497,7 @@ int reg_begin_chunk(m3d_reg& q, size_t* n_survivors) {
 
 // (count, sum of squared nearest distances) of survivors [s_begin, s_end) of the chunk in flight;
 // s_begin must be a multiple of 64 (the kernel works on groups of 64 hypotheses)
-int reg_validate(m3d_reg& q, size_t s_begin, size_t s_end, uint32_t* counts_out, double* sums_out) {
-    DeviceCtx* ctx = q.ctx;
-    Scratch& S = q.S;
-    RegCtx& R = q.R;
-    GridDesc& g = q.g;
-    CloudView& src_sorted = q.src_sorted;
-    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
-    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
-    const int max_iter = q.max_iter;
-    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
-    (void)edge_length_threshold; (void)confidence; (void)max_iter;
-    auto& rng = q.rng;
-    auto& pick = q.pick;
-    auto& best_fit = q.best_fit;
-    auto& best_rmse = q.best_rmse;
-    auto& best_cnt = q.best_cnt;
-    const bool reg_prune = q.reg_prune;
-    auto& best_rmse_known = q.best_rmse_known;
-    auto& best_index = q.best_index;
-    auto& est_k_global = q.est_k_global;
-    auto& est_k_local = q.est_k_local;
-    auto& total_validation = q.total_validation;
-    auto& ties = q.ties;
-    auto& exact_evals = q.exact_evals;
-    auto& iters = q.iters;
-    double* const best_T_dev = q.best_T_dev;
-    auto& best_T_host = q.best_T_host;
-    const uint32_t n_tiles = q.n_tiles;
-    auto& tri = q.tri;
-    auto& survivors = q.survivors;
-    auto& h_counts = q.h_counts;
-    auto& h_sum2 = q.h_sum2;
-    auto& best_sum2 = q.best_sum2;
-    auto& pass = q.pass;
-    auto& chunk = q.chunk;
-    auto& itr = q.itr;
-    (void)rng; (void)pick; (void)best_fit; (void)best_rmse; (void)best_cnt; (void)reg_prune; (void)best_rmse_known;
-    (void)best_index; (void)est_k_global; (void)est_k_local; (void)total_validation; (void)ties; (void)exact_evals;
-    (void)iters; (void)best_T_dev; (void)best_T_host; (void)n_tiles; (void)tri; (void)survivors; (void)h_counts;
-    (void)h_sum2; (void)best_sum2; (void)pass; (void)chunk; (void)itr;
+int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double* sums_out) {
     const uint32_t ns_all = (uint32_t)survivors.size();
     if (s_begin == s_end) return M3D_OK;
     if (s_begin > s_end || s_end > ns_all || (s_begin % 64) != 0)
@@ -615,47 +532,7 @@ int reg_validate(m3d_reg& q, size_t s_begin, size_t s_end, uint32_t* counts_out,
 }
 
 // sequential replay of the chunk in flight; counts / sums: one entry per survivor, in survivor order
-int reg_replay(m3d_reg& q, const uint32_t* counts_in, const double* sums_in) {
-    DeviceCtx* ctx = q.ctx;
-    Scratch& S = q.S;
-    RegCtx& R = q.R;
-    GridDesc& g = q.g;
-    CloudView& src_sorted = q.src_sorted;
-    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
-    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
-    const int max_iter = q.max_iter;
-    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
-    (void)edge_length_threshold; (void)confidence; (void)max_iter;
-    auto& rng = q.rng;
-    auto& pick = q.pick;
-    auto& best_fit = q.best_fit;
-    auto& best_rmse = q.best_rmse;
-    auto& best_cnt = q.best_cnt;
-    const bool reg_prune = q.reg_prune;
-    auto& best_rmse_known = q.best_rmse_known;
-    auto& best_index = q.best_index;
-    auto& est_k_global = q.est_k_global;
-    auto& est_k_local = q.est_k_local;
-    auto& total_validation = q.total_validation;
-    auto& ties = q.ties;
-    auto& exact_evals = q.exact_evals;
-    auto& iters = q.iters;
-    double* const best_T_dev = q.best_T_dev;
-    auto& best_T_host = q.best_T_host;
-    const uint32_t n_tiles = q.n_tiles;
-    auto& tri = q.tri;
-    auto& survivors = q.survivors;
-    auto& h_counts = q.h_counts;
-    auto& h_sum2 = q.h_sum2;
-    auto& best_sum2 = q.best_sum2;
-    auto& pass = q.pass;
-    auto& chunk = q.chunk;
-    auto& itr = q.itr;
-    (void)rng; (void)pick; (void)best_fit; (void)best_rmse; (void)best_cnt; (void)reg_prune; (void)best_rmse_known;
-    (void)best_index; (void)est_k_global; (void)est_k_local; (void)total_validation; (void)ties; (void)exact_evals;
-    (void)iters; (void)best_T_dev; (void)best_T_host; (void)n_tiles; (void)tri; (void)survivors; (void)h_counts;
-    (void)h_sum2; (void)best_sum2; (void)pass; (void)chunk; (void)itr;
-    const int n_exec = q.n_exec;
+int m3d_reg::replay(const uint32_t* counts_in, const double* sums_in) {
     HIPCHK(hipSetDevice(ctx->device));
     h_counts.assign(counts_in, counts_in + survivors.size());
     h_sum2.assign(sums_in, sums_in + survivors.size());
@@ -727,7 +604,7 @@ int reg_replay(m3d_reg& q, const uint32_t* counts_in, const double* sums_in) {
     }
     if (k < n_exec) {
         // the loop went idle inside the chunk: nothing after it draws or runs
-        q.finished = true;
+        this->finished = true;
         return M3D_OK;
     }
     itr += n_exec;
@@ -735,53 +612,14 @@ int reg_replay(m3d_reg& q, const uint32_t* counts_in, const double* sums_in) {
     return M3D_OK;
 }
 
-int reg_finish(m3d_reg& q, double* T_out, m3d_reg_stats* stats) {
-    DeviceCtx* ctx = q.ctx;
-    Scratch& S = q.S;
-    RegCtx& R = q.R;
-    GridDesc& g = q.g;
-    CloudView& src_sorted = q.src_sorted;
-    const size_t n_src = q.n_src, n_dst = q.n_dst, m = q.m;
-    const double threshold = q.threshold, edge_length_threshold = q.edge_length_threshold, confidence = q.confidence;
-    const int max_iter = q.max_iter;
-    (void)ctx; (void)S; (void)R; (void)g; (void)src_sorted; (void)n_src; (void)n_dst; (void)m; (void)threshold;
-    (void)edge_length_threshold; (void)confidence; (void)max_iter;
-    auto& rng = q.rng;
-    auto& pick = q.pick;
-    auto& best_fit = q.best_fit;
-    auto& best_rmse = q.best_rmse;
-    auto& best_cnt = q.best_cnt;
-    const bool reg_prune = q.reg_prune;
-    auto& best_rmse_known = q.best_rmse_known;
-    auto& best_index = q.best_index;
-    auto& est_k_global = q.est_k_global;
-    auto& est_k_local = q.est_k_local;
-    auto& total_validation = q.total_validation;
-    auto& ties = q.ties;
-    auto& exact_evals = q.exact_evals;
-    auto& iters = q.iters;
-    double* const best_T_dev = q.best_T_dev;
-    auto& best_T_host = q.best_T_host;
-    const uint32_t n_tiles = q.n_tiles;
-    auto& tri = q.tri;
-    auto& survivors = q.survivors;
-    auto& h_counts = q.h_counts;
-    auto& h_sum2 = q.h_sum2;
-    auto& best_sum2 = q.best_sum2;
-    auto& pass = q.pass;
-    auto& chunk = q.chunk;
-    auto& itr = q.itr;
-    (void)rng; (void)pick; (void)best_fit; (void)best_rmse; (void)best_cnt; (void)reg_prune; (void)best_rmse_known;
-    (void)best_index; (void)est_k_global; (void)est_k_local; (void)total_validation; (void)ties; (void)exact_evals;
-    (void)iters; (void)best_T_dev; (void)best_T_host; (void)n_tiles; (void)tri; (void)survivors; (void)h_counts;
-    (void)h_sum2; (void)best_sum2; (void)pass; (void)chunk; (void)itr;
+int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
     static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::memcpy(T_out, I4, sizeof(I4));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->best_index = -1;
     }
-    if (q.trivial) return M3D_OK;
+    if (this->trivial) return M3D_OK;
     HIPCHK(hipSetDevice(ctx->device));
 
     if (best_index >= 0) {
@@ -809,9 +647,11 @@ int reg_finish(m3d_reg& q, double* T_out, m3d_reg_stats* stats) {
         stats->ties = ties;
         stats->exact_rmse_evals = exact_evals;
     }
-    if (stats) stats->ms_total = now_ms() - q.t_begin;
+    if (stats) stats->ms_total = now_ms() - this->t_begin;
     return M3D_OK;
 }
+
+namespace {
 
 // argument checks + uploads + grid; *rc_out < 0 on error (session NULL), M3D_OK otherwise
 m3d_reg* reg_create(const double* src, size_t n_src, const double* dst, size_t n_dst, const size_t* corr_src,
@@ -856,7 +696,7 @@ m3d_reg* reg_create(const double* src, size_t n_src, const double* dst, size_t n
     int rc;
     {
         std::lock_guard<std::mutex> lock(q->ctx->mu);
-        rc = reg_setup(*q, src, dst, corr_src, corr_dst, seed);
+        rc = q->setup(src, dst, corr_src, corr_dst, seed);
         (void)hipStreamSynchronize(q->ctx->stream);
     }
     if (rc != M3D_OK) {
@@ -898,27 +738,27 @@ int m3d_reg_begin_chunk(m3d_reg* q, size_t* n_survivors) {
         return M3D_FALSE;
     }
     std::lock_guard<std::mutex> lock(q->ctx->mu);
-    return reg_begin_chunk(*q, n_survivors);
+    return q->begin_chunk(n_survivors);
 }
 
 int m3d_reg_validate(m3d_reg* q, size_t s_begin, size_t s_end, uint32_t* counts, double* sums) {
     if (!q || q->trivial || (s_end > s_begin && (!counts || !sums))) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     std::lock_guard<std::mutex> lock(q->ctx->mu);
-    return reg_validate(*q, s_begin, s_end, counts, sums);
+    return q->validate(s_begin, s_end, counts, sums);
 }
 
 int m3d_reg_replay(m3d_reg* q, const uint32_t* counts, const double* sums) {
     if (!q || q->trivial) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     if (!q->survivors.empty() && (!counts || !sums)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     std::lock_guard<std::mutex> lock(q->ctx->mu);
-    return reg_replay(*q, counts, sums);
+    return q->replay(counts, sums);
 }
 
 int m3d_reg_finish(m3d_reg* q, double* T, m3d_reg_stats* stats) {
     if (!q || !T) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    if (q->trivial) return reg_finish(*q, T, stats);
+    if (q->trivial) return q->finish(T, stats);
     std::lock_guard<std::mutex> lock(q->ctx->mu);
-    return reg_finish(*q, T, stats);
+    return q->finish(T, stats);
 }
 
 int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, size_t n_dst,
