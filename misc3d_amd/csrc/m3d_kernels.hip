@@ -468,18 +468,42 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
 __global__ __launch_bounds__(64) void serial_sum_k(const double* __restrict__ v,
                                                     const uint32_t* __restrict__ n_ptr,
                                                     double* __restrict__ out) {
+    // blocks of 1024 values: coalesced loads (16 per lane, next block in flight), parked in LDS, then read
+    // back in order with wave-uniform addresses (LDS broadcast, two values per ds_read_b128) while EVERY lane
+    // runs the same dependent v_add_f64 chain.  Values past the end are +0.0 (the sums are non-negative).
+    __shared__ double buf[2][1024];
     const uint32_t n = n_ptr[0];
     const uint32_t lane = threadIdx.x;
     double s = 0.0;
-    double nxt = lane < n ? v[lane] : 0.0;
-    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
-        const double cur = nxt;
-        const uint32_t i = b0 + 64 + lane;
-        nxt = i < n ? v[i] : 0.0;
-        const int lo = __double2loint(cur), hi = __double2hiint(cur);
+    double r[16];
 #pragma unroll
-        for (int k = 0; k < 64; ++k)
-            s += __hiloint2double(__builtin_amdgcn_readlane(hi, k), __builtin_amdgcn_readlane(lo, k));
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t i = (uint32_t)j * 64u + lane;
+        r[j] = i < n ? v[i] : 0.0;
+    }
+    int cur = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 1024u) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) buf[cur][j * 64 + lane] = r[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {   // next block
+            const uint32_t i = b0 + 1024u + (uint32_t)j * 64u + lane;
+            r[j] = i < n ? v[i] : 0.0;
+        }
+        const double2* __restrict__ p = reinterpret_cast<const double2*>(buf[cur]);
+        for (int k = 0; k < 512; k += 8) {
+            double2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s += t[u].x;
+                s += t[u].y;
+            }
+        }
+        cur ^= 1;
     }
     if (lane == 0) out[0] = s;
 }
