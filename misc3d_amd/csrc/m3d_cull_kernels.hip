@@ -148,9 +148,9 @@ __global__ __launch_bounds__(64) void cull_mask_k(const double* __restrict__ box
 }
 
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
-                      uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st) {
+                      uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st, bool ub_is_zero) {
     if (!s.n_tiles || !n_groups) return;
-    if (ub) (void)hipMemsetAsync(ub, 0, sizeof(uint32_t) * (size_t)n_groups * 64, st);
+    if (ub && !ub_is_zero) (void)hipMemsetAsync(ub, 0, sizeof(uint32_t) * (size_t)n_groups * 64, st);
     // enough waves to fill the chip: split the tile range when there are few hypothesis groups
     uint32_t splits = std::max<uint32_t>(1, (8192 + n_groups - 1) / n_groups);
     splits = std::min(splits, std::max<uint32_t>(1, s.n_tiles / 16));  // >= 16 tiles per wave: the record loads amortise
@@ -295,25 +295,38 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
 }
 
 // counts[h] = sum over the replicas; counts[pairs_slot] = evaluated (tile, hypothesis) pairs of the launch
+// valid != null: bit 31 of counts[h] carries MinimalFit's return (one D2H copy instead of two; counts < 2^31);
+// best_count != null: running maximum over the valid hypotheses (bound-and-prune incumbent).
 __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t rep_stride, uint32_t h_pad,
                                uint32_t* __restrict__ counts, const uint32_t* __restrict__ pair_rep,
-                               uint32_t pairs_slot) {
+                               uint32_t pairs_slot, const uint8_t* __restrict__ valid, uint32_t h_count,
+                               uint32_t* __restrict__ best_count) {
     const uint32_t h = blockIdx.x * 256u + threadIdx.x;
     if (h == 0 && pair_rep) {
         uint32_t p = 0;
         for (int r = 0; r < 64; ++r) p += pair_rep[r];
         counts[pairs_slot] = p;
     }
-    if (h >= h_pad || (pair_rep && h == pairs_slot)) return;
+    const bool mine = h < h_pad && !(pair_rep && h == pairs_slot);
     uint32_t c = 0;
+    if (mine) {
 #pragma unroll
-    for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
-    counts[h] = c;
+        for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
+    }
+    const bool ok = mine && valid && h < h_count && valid[h];
+    if (mine) counts[h] = valid ? (c | (ok ? 0x80000000u : 0u)) : c;
+    if (best_count) {   // wave-uniform
+        uint32_t v = ok ? c : 0u;
+        for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+        if ((threadIdx.x & 63) == 0 && v) atomicMax(best_count, v);
+    }
 }
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
-                         const uint32_t* pair_rep, uint32_t pairs_slot, hipStream_t st) {
+                         const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
+                         uint32_t* best_count, hipStream_t st) {
     if (h_pad)
-        sum_replicas_k<<<(h_pad + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_pad, counts, pair_rep, pairs_slot);
+        sum_replicas_k<<<(h_pad + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_pad, counts, pair_rep, pairs_slot,
+                                                             valid, h_count, best_count);
 }
 
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,

@@ -23,7 +23,8 @@ void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 // masks: n_tiles x n_groups uint64, bit b of masks[t][g] = hypothesis 64 g + b may have inliers in tile t.
 // ub (may be null; n_groups * 64 entries, zeroed here): number of tiles each hypothesis may touch.
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
-                      uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st);
+                      uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st,
+                      bool ub_is_zero = false);
 // keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
                       hipStream_t st);
@@ -35,8 +36,11 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                        uint32_t* pair_rep /* 64 u32, zero on entry: evaluated (tile, hypothesis) pairs */, hipStream_t st);
 // pair_rep != null: counts[pairs_slot] receives the sum of the pair counters (pairs_slot must be >= the number of
 // real hypotheses; that entry is then not a hypothesis count)
+// valid != null: counts[h] |= valid[h] << 31 for h < h_count; best_count != null: atomic running maximum of the
+// valid hypotheses' counts (what launch_max_count does as a separate launch)
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
-                         const uint32_t* pair_rep, uint32_t pairs_slot, hipStream_t st);
+                         const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
+                         uint32_t* best_count, hipStream_t st);
 void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
                       hipStream_t st);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,

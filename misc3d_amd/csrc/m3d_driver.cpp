@@ -327,8 +327,10 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (ms_sample) *ms_sample += now_ms() - t0;
     HIPCHK(hipMemcpyAsync(s.samples.p, s.h_samples.p, sizeof(uint32_t) * (size_t)count * m,
                           hipMemcpyHostToDevice, ctx->stream));
+    if (!dense && prune) RESERVE(ctx->ub, sizeof(uint32_t) * (size_t)h_pad);
     launch_minimal_fit(kind, v, s.samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
-                       s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream);
+                       s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
+                       (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr);   // clears ub[0 .. h_pad) on the way
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     else
@@ -344,33 +346,41 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         // prune (fits only): hypotheses that cannot reach the best count of EARLIER chunks are masked
         // out (keep_mask_k); ctx->best_count is the device-side running maximum
         const uint32_t n_groups = h_pad / 64;
-        uint32_t* ub = nullptr;
-        if (prune) {
-            RESERVE(ctx->ub, sizeof(uint32_t) * (size_t)h_pad);
-            ub = ctx->ub.as<uint32_t>();
-        }
+        uint32_t* ub = prune ? ctx->ub.as<uint32_t>() : nullptr;
         auto* masks = ctx->masks.as<unsigned long long>();
         auto* keep = ctx->keep.as<unsigned long long>();
-        launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream);
+        launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
+                         /*ub_is_zero=*/true);
         launch_keep_mask(ub, prune ? ctx->best_count.as<uint32_t>() : nullptr, n_groups, keep, ctx->stream);
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
         launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
                           pair_rep, ctx->stream);
         HIPCHK(hipEventRecord(s.k1, ctx->stream));
+        // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
         launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.counts.as<uint32_t>(), pair_rep, count,
-                            ctx->stream);
-        if (prune)
-            launch_max_count(s.counts.as<uint32_t>(), s.valid.as<uint8_t>(), count, ctx->best_count.as<uint32_t>(),
-                             ctx->stream);
+                            s.valid.as<uint8_t>(), count, prune ? ctx->best_count.as<uint32_t>() : nullptr, ctx->stream);
     }
     // counts of the chunk + (culled path) the number of (tile, hypothesis) pairs the launch evaluated
     HIPCHK(hipMemcpyAsync(s.h_counts.p, s.counts.p, sizeof(uint32_t) * ((size_t)count + (dense ? 0 : 1)),
                           hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(s.h_valid.p, s.valid.p, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    if (dense) HIPCHK(hipMemcpyAsync(s.h_valid.p, s.valid.p, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.done, ctx->stream));
     return M3D_OK;
+}
+
+// After the slot's `done` event: the culled path ships (valid << 31 | count) in one array (one D2H copy per
+// chunk); split it into the h_valid / h_counts views the replay and the callers read.
+static void unpack_slot(ChunkSlot& s) {
+    if (use_dense_scoring()) return;
+    uint32_t* c = s.h_counts.as<uint32_t>();
+    uint8_t* v = s.h_valid.as<uint8_t>();
+    const size_t n = s.end - s.begin;
+    for (size_t i = 0; i < n; ++i) {
+        v[i] = (uint8_t)(c[i] >> 31);
+        c[i] &= 0x7FFFFFFFu;
+    }
 }
 
 // EvaluateModel's (inlier_num, error) with the error summed in point order (ransac.h:632-640).
@@ -691,6 +701,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 }
             }
             HIPCHK(hipEventSynchronize(s.done));
+            unpack_slot(s);
             {
                 float kms = 0;
                 if (hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess) {
@@ -1221,6 +1232,7 @@ int m3d_cloud_score_range(m3d_cloud* c, int kind, double threshold, const uint32
         const int rc = issue_chunk(ctx, s, v, sv, kind, threshold, b, e, src, nullptr);
         if (rc != M3D_OK) return rc;
         HIPCHK(hipEventSynchronize(s.done));
+        unpack_slot(s);
         if (counts) std::memcpy(counts + (b - begin), s.h_counts.p, sizeof(uint32_t) * (e - b));
         if (valid) std::memcpy(valid + (b - begin), s.h_valid.p, e - b);
         if (models)
@@ -1293,6 +1305,7 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
         if (!pend[k].active) return M3D_OK;
         ChunkSlot& s = ctx->slot[k];
         HIPCHK(hipEventSynchronize(s.done));
+        unpack_slot(s);
         std::memcpy(counts + pend[k].out_pos, s.h_counts.p, sizeof(uint32_t) * pend[k].n);
         std::memcpy(valid + pend[k].out_pos, s.h_valid.p, pend[k].n);
         pend[k].active = false;
