@@ -11,7 +11,11 @@
 namespace misc3d {
 namespace features {
 
-// Stand-ins for open3d::geometry::KDTreeSearchParamRadius / KDTreeSearchParamHybrid (same member names).
+// Stand-ins for open3d::geometry::KDTreeSearchParamKNN / Radius / Hybrid (same member names).
+struct KDTreeSearchParamKNN {
+    int knn_;
+    explicit KDTreeSearchParamKNN(int knn = 30) : knn_(knn) {}
+};
 struct KDTreeSearchParamRadius {
     double radius_;
     explicit KDTreeSearchParamRadius(double radius) : radius_(radius) {}
@@ -47,6 +51,10 @@ inline std::vector<size_t> Detect(const CloudView& pc, int search, double radius
 inline std::vector<size_t> DetectBoundaryPoints(const CloudView& pc, const KDTreeSearchParamHybrid& param,
                                                 double angle_threshold = 90.0, int device = 0) {
     return detail::Detect(pc, 2, param.radius_, param.max_nn_, angle_threshold, device);
+}
+inline std::vector<size_t> DetectBoundaryPoints(const CloudView& pc, const KDTreeSearchParamKNN& param,
+                                                double angle_threshold = 90.0, int device = 0) {
+    return detail::Detect(pc, 0, 0.0, param.knn_, angle_threshold, device);
 }
 inline std::vector<size_t> DetectBoundaryPoints(const CloudView& pc, const KDTreeSearchParamRadius& param,
                                                 double angle_threshold = 90.0, int device = 0) {

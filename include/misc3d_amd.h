@@ -219,8 +219,9 @@ int m3d_normals_from_map(const double *xyz, uint32_t w, uint32_t h, uint32_t k, 
                          int device, double *normals, double *ms_device);
 
 /* ---- misc3d::features::DetectBoundaryPoints, src/boundary_detection.cpp:68-113 -------- */
-/* normals: n x 3 or NULL (then estimated from the same neighbourhood, :82-84).  search: 1 = KDTreeSearchParamRadius
- * (radius), 2 = KDTreeSearchParamHybrid (radius, max_nn <= 128) -- the python default is Hybrid(0.01, 30),
+/* normals: n x 3 or NULL (then estimated from the same neighbourhood, :82-84).  search: 0 = KDTreeSearchParamKNN
+ * (max_nn <= 128; radius ignored), 1 = KDTreeSearchParamRadius (radius), 2 = KDTreeSearchParamHybrid (radius,
+ * max_nn <= 128) -- the python default is Hybrid(0.01, 30),
  * python/py_features.cpp:19.  angle_threshold in degrees (default 90).  indices: capacity n, written in
  * ascending order (the reference's order depends on thread timing); *k = their number. */
 int m3d_detect_boundary_points(const double *xyz, const double *normals, size_t n, int search, double radius,

@@ -66,8 +66,9 @@ class _Features:
     @staticmethod
     def detect_boundary_points(pc, param=("hybrid", 0.01, 30), angle_threshold=90.0, device=0):
         """DetectBoundaryPoints (src/boundary_detection.cpp:68-113).  pc: (N, 3) array, (points, normals) tuple or
-        an object with .points / .normals.  param: an open3d KDTreeSearchParamHybrid / KDTreeSearchParamRadius
-        (anything with .radius and optionally .max_nn), or ("hybrid", radius, max_nn) / ("radius", radius).
+        an object with .points / .normals.  param: an open3d KDTreeSearchParamHybrid / KDTreeSearchParamRadius /
+        KDTreeSearchParamKNN (anything with .radius and optionally .max_nn, or with .knn), or a tuple
+        ("hybrid", radius, max_nn) / ("radius", radius) / ("knn", k).
         Returns the list of boundary point indices (ascending)."""
         import numpy as _np
 
@@ -83,15 +84,20 @@ class _Features:
                 nrm = None
         if isinstance(param, tuple):
             kind = str(param[0]).lower()
-            radius = float(param[1])
-            max_nn = int(param[2]) if len(param) > 2 else 0
+            if kind == "knn":
+                radius, max_nn = 0.0, int(param[1])
+            else:
+                radius = float(param[1])
+                max_nn = int(param[2]) if len(param) > 2 else 0
+        elif hasattr(param, "knn") and not hasattr(param, "radius"):
+            kind, radius, max_nn = "knn", 0.0, int(param.knn)
         else:
             radius = float(param.radius)
             max_nn = int(getattr(param, "max_nn", 0))
             kind = "hybrid" if hasattr(param, "max_nn") else "radius"
-        if kind not in ("hybrid", "radius"):
-            raise RuntimeError("[Misc3D Error] only KDTreeSearchParamHybrid / KDTreeSearchParamRadius are supported")
-        search = _capi.SEARCH_HYBRID if kind == "hybrid" else _capi.SEARCH_RADIUS
+        if kind not in ("hybrid", "radius", "knn"):
+            raise RuntimeError("[Misc3D Error] param: KDTreeSearchParamHybrid / KDTreeSearchParamRadius / KDTreeSearchParamKNN")
+        search = {"hybrid": _capi.SEARCH_HYBRID, "radius": _capi.SEARCH_RADIUS, "knn": _capi.SEARCH_KNN}[kind]
         try:
             idx = _capi.detect_boundary_points(pts, nrm, search, radius, max_nn, angle_threshold, device)
         except _capi.M3DError as e:

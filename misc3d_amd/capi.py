@@ -485,7 +485,7 @@ def registration_icp(src, dst, max_correspondence_distance, init=None, max_itera
     return T.reshape(4, 4), st.asdict()
 
 
-SEARCH_RADIUS, SEARCH_HYBRID = 1, 2
+SEARCH_KNN, SEARCH_RADIUS, SEARCH_HYBRID = 0, 1, 2
 
 
 def detect_boundary_points(xyz, normals=None, search=SEARCH_HYBRID, radius=0.01, max_nn=30, angle_threshold=90.0,

@@ -938,8 +938,9 @@ __device__ __forceinline__ void tangent_basis(const double* n, double* u, double
     u[2] = n[0] * v[1] - n[1] * v[0];
 }
 
-// Neighbourhood = KDTreeFlann::Search with Radius (all d2 <= r^2) or Hybrid (the max_nn nearest with d2 < r^2),
-// kept sorted by (d2, original index); grid cell = 1.001 r, so the 3x3x3 block covers the radius.
+// Neighbourhood = KDTreeFlann::Search with Radius (all d2 <= r^2), Hybrid (the max_nn nearest with d2 < r^2) or KNN
+// (the max_nn nearest), kept sorted by (d2, original index).  Radius / Hybrid: grid cell = 1.001 r, so the 3x3x3
+// block covers the radius; KNN: cell from the point density, shells of cells until the k-th distance is certain.
 __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const uint32_t* __restrict__ cell_start,
                                                   const double* __restrict__ qx, const double* __restrict__ qy,
                                                   const double* __restrict__ qz, const uint32_t* __restrict__ cell_orig,
@@ -953,37 +954,83 @@ __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const 
     double nd[kBoundaryMaxNb];
     uint32_t ni[kBoundaryMaxNb];
     int m = 0;
-    const int cap = search == 2 ? max_nn : kBoundaryMaxNb;
-    const int K = g.K;
-    for (int dz = -K; dz <= K; ++dz)
-        for (int dy = -K; dy <= K; ++dy) {
-            const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
-            const uint32_t b = cell_start[row - K], e = cell_start[row + K + 1];
-            for (uint32_t t = b; t < e; ++t) {
-                const double ddx = px - qx[t], ddy = py - qy[t], ddz = pz - qz[t];
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (!(search == 1 ? d2 <= g.r2 : d2 < g.r2)) continue;
-                const uint32_t o = cell_orig[t];
-                int pos;
-                if (m < cap) {
-                    pos = m++;
-                } else {
-                    if (search == 1) {   // Radius search has no bound on the neighbourhood: give up loudly
+    const int cap = search == 1 ? kBoundaryMaxNb : max_nn;
+    // sorted insertion by (d2, original index); beyond `cap` the farthest entry is replaced (KNN / Hybrid) or
+    // the search gives up loudly (Radius has no bound on the neighbourhood)
+    auto offer = [&](double d2, uint32_t o) -> bool {
+        int pos;
+        if (m < cap) {
+            pos = m++;
+        } else {
+            if (search == 1) return false;
+            if (!(d2 < nd[m - 1] || (d2 == nd[m - 1] && o < ni[m - 1]))) return true;
+            pos = m - 1;
+        }
+        while (pos > 0 && (d2 < nd[pos - 1] || (d2 == nd[pos - 1] && o < ni[pos - 1]))) {
+            nd[pos] = nd[pos - 1];
+            ni[pos] = ni[pos - 1];
+            --pos;
+        }
+        nd[pos] = d2;
+        ni[pos] = o;
+        return true;
+    };
+    if (search == 0) {
+        // KDTreeSearchParamKNN: the max_nn nearest points, no radius.  Shells of cells around the query's cell,
+        // ring after ring; every point outside the (2r+1)^3 block is at least r cell edges away, so the search
+        // is complete as soon as the k-th distance found is within that bound.
+        const double h = 1.0 / g.inv_h;
+        const int rmax = (int)max(g.nx, max(g.ny, g.nz));
+        for (int r = 0; r <= rmax; ++r) {
+            for (int dz = -r; dz <= r; ++dz) {
+                const int cz = iz + dz;
+                if (cz < 0 || cz >= (int)g.nz) continue;
+                for (int dy = -r; dy <= r; ++dy) {
+                    const int cy = iy + dy;
+                    if (cy < 0 || cy >= (int)g.ny) continue;
+                    const bool face = dz == -r || dz == r || dy == -r || dy == r;   // whole x-row is on the shell
+                    const uint32_t row = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx;
+                    const int xl = max(ix - r, 0), xh = min(ix + r, (int)g.nx - 1);
+                    // shell = the full row on the four outer faces, otherwise only its two end cells
+                    for (int part = 0; part < (face || r == 0 ? 1 : 2); ++part) {
+                        int a, b2;
+                        if (face || r == 0) {
+                            a = xl;
+                            b2 = xh;
+                        } else {
+                            a = b2 = part == 0 ? ix - r : ix + r;
+                            if (a < 0 || a >= (int)g.nx) continue;
+                        }
+                        const uint32_t b = cell_start[row + (uint32_t)a], e = cell_start[row + (uint32_t)b2 + 1];
+                        for (uint32_t t = b; t < e; ++t) {
+                            const double ddx = px - qx[t], ddy = py - qy[t], ddz = pz - qz[t];
+                            offer((ddx * ddx + ddy * ddy) + ddz * ddz, cell_orig[t]);
+                        }
+                    }
+                }
+            }
+            // strictly inside the bound (minus the cell-assignment slack): an unseen point can then neither be
+            // closer nor tie with the k-th neighbour
+            const double reach = ((double)r - 1e-6) * h;
+            if (m >= cap && reach > 0.0 && nd[m - 1] < reach * reach) break;
+        }
+    } else {
+        const int K = g.K;
+        for (int dz = -K; dz <= K; ++dz)
+            for (int dy = -K; dy <= K; ++dy) {
+                const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
+                const uint32_t b = cell_start[row - K], e = cell_start[row + K + 1];
+                for (uint32_t t = b; t < e; ++t) {
+                    const double ddx = px - qx[t], ddy = py - qy[t], ddz = pz - qz[t];
+                    const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    if (!(search == 1 ? d2 <= g.r2 : d2 < g.r2)) continue;
+                    if (!offer(d2, cell_orig[t])) {
                         overflow[0] = 1;
                         return;
                     }
-                    if (!(d2 < nd[m - 1] || (d2 == nd[m - 1] && o < ni[m - 1]))) continue;
-                    pos = m - 1;         // replaces the current farthest
                 }
-                while (pos > 0 && (d2 < nd[pos - 1] || (d2 == nd[pos - 1] && o < ni[pos - 1]))) {
-                    nd[pos] = nd[pos - 1];
-                    ni[pos] = ni[pos - 1];
-                    --pos;
-                }
-                nd[pos] = d2;
-                ni[pos] = o;
             }
-        }
+    }
     if (m < 3) return;   // :96-99
     double nrm[3];
     if (c.nx) {

@@ -1068,9 +1068,8 @@ int m3d_detect_boundary_points(const double* xyz, const double* normals, size_t 
     if (!k_out || (!xyz && n) || (!indices && n)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     *k_out = 0;
     if (n == 0) return fail(M3D_ERR_INVALID_ARG, "No PointCloud data.");   // :72-76 LogError
-    if (search != 1 && search != 2)
-        return fail(M3D_ERR_INVALID_ARG, "only KDTreeSearchParamRadius (1) and KDTreeSearchParamHybrid (2) are supported");
-    if (!(radius > 0.0) || (search == 2 && (max_nn < 1 || max_nn > kBoundaryMaxNb)))
+    if (search < 0 || search > 2) return fail(M3D_ERR_INVALID_ARG, "search: 0 = KNN, 1 = Radius, 2 = Hybrid");
+    if ((search != 0 && !(radius > 0.0)) || (search != 1 && (max_nn < 1 || max_nn > kBoundaryMaxNb)))
         return fail(M3D_ERR_INVALID_ARG, "invalid search parameter (radius > 0, 1 <= max_nn <= 128)");
     if (n >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
     m3d_cloud* c = m3d_cloud_create(xyz, normals, n, device);
@@ -1085,7 +1084,26 @@ int m3d_detect_boundary_points(const double* xyz, const double* normals, size_t 
             HIPCHK(hipSetDevice(ctx->device));
             const CloudView v = c->view();
             GridDesc g;
-            const int rg = build_target_grid(ctx, S, v, xyz, n, radius, true, &g, /*K0=*/1, /*with_nl=*/false);
+            double cell = radius;
+            if (search == 0) {   // KNN: a cell that holds ~max_nn / 4 points on average (bounding-box density)
+                double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (size_t i = 0; i < n; ++i)
+                    for (int k = 0; k < 3; ++k)
+                        if (std::isfinite(xyz[3 * i + k])) {
+                            lo[k] = std::min(lo[k], xyz[3 * i + k]);
+                            hi[k] = std::max(hi[k], xyz[3 * i + k]);
+                        }
+                double ext[3], emax = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    ext[k] = lo[k] <= hi[k] ? hi[k] - lo[k] : 0.0;
+                    emax = std::max(emax, ext[k]);
+                }
+                double vol = 1.0;   // flat / degenerate extents count as 1 % of the largest
+                for (int k = 0; k < 3; ++k) vol *= std::max(ext[k], 0.01 * emax);
+                cell = emax > 0.0 ? std::cbrt(vol * (double)max_nn / (4.0 * (double)n)) : 1.0;
+                if (!(cell > 0.0) || !std::isfinite(cell)) cell = 1.0;
+            }
+            const int rg = build_target_grid(ctx, S, v, xyz, n, cell, true, &g, /*K0=*/1, /*with_nl=*/false);
             if (rg != M3D_OK) return rg;
             RESERVE(flags, (size_t)v.n + 8);
             HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)v.n + 8, ctx->stream));

@@ -57,7 +57,8 @@ static void tangent_basis(const double *n, double *u, double *v) {
     u[2] = n[0] * v[1] - n[1] * v[0];
 }
 
-/* search: 1 = Radius (all points with d2 <= r^2), 2 = Hybrid (the max_nn nearest among those with d2 < r^2).
+/* search: 0 = KNN (the max_nn nearest, no radius), 1 = Radius (all points with d2 <= r^2), 2 = Hybrid (the max_nn
+ * nearest among those with d2 < r^2).
  * normals may be NULL.  out: ascending indices of the boundary points.  Returns their number. */
 size_t orc_detect_boundary_points(const double *xyz, const double *normals, size_t n, int search, double radius,
                                   int max_nn, double angle_threshold_deg, int64_t *out) {
@@ -71,14 +72,14 @@ size_t orc_detect_boundary_points(const double *xyz, const double *normals, size
         for (size_t j = 0; j < n; ++j) {
             const double dx = q[0] - xyz[3 * j], dy = q[1] - xyz[3 * j + 1], dz = q[2] - xyz[3 * j + 2];
             const double d2 = (dx * dx + dy * dy) + dz * dz;
-            if (search == 1 ? d2 <= r2 : d2 < r2) {
+            if (search == 0 ? 1 : (search == 1 ? d2 <= r2 : d2 < r2)) {
                 nb[m].d2 = d2;
                 nb[m].idx = (int64_t)j;
                 ++m;
             }
         }
         qsort(nb, m, sizeof(nb_t), nb_cmp);
-        if (search == 2 && m > (size_t)max_nn) m = (size_t)max_nn;
+        if (search != 1 && m > (size_t)max_nn) m = (size_t)max_nn;
         if (m < 3) continue;
         double nrm[3];
         if (normals) {

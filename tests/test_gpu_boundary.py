@@ -16,7 +16,8 @@ def _patch(n, seed, holes=True):
     return np.ascontiguousarray(pts), nrm, uv
 
 
-@pytest.mark.parametrize("search,radius,max_nn", [(2, 0.05, 30), (2, 0.08, 12), (2, 0.03, 128), (1, 0.04, 0)])
+@pytest.mark.parametrize("search,radius,max_nn", [(2, 0.05, 30), (2, 0.08, 12), (2, 0.03, 128), (1, 0.04, 0),
+                                                  (0, 0.0, 30), (0, 0.0, 7), (0, 0.0, 128)])
 @pytest.mark.parametrize("with_normals", [True, False])
 def test_boundary_matches_oracle(capi, orc, search, radius, max_nn, with_normals):
     pts, nrm, uv = _patch(3500, seed=int(radius * 1000) + max_nn)
@@ -44,7 +45,13 @@ def test_boundary_threshold_and_errors(capi, orc):
     with pytest.raises(capi.M3DError):
         capi.detect_boundary_points(pts, None, 1, 0.5, 0, 90.0)            # radius search with > 128 neighbours
     with pytest.raises(capi.M3DError):
-        capi.detect_boundary_points(pts, None, 0, 0.05, 30, 90.0)          # KNN search is not supported
+        capi.detect_boundary_points(pts, None, 0, 0.05, 200, 90.0)         # at most 128 neighbours
+    few = pts[:20]                                                          # fewer points than k: all of them are used
+    assert np.array_equal(capi.detect_boundary_points(few, None, 0, 0.0, 30, 90.0).astype(np.int64),
+                          orc.detect_boundary_points(few, None, 0, 0.0, 30, 90.0))
+    blob = np.ascontiguousarray(np.random.default_rng(4).normal(size=(2500, 3)))   # volume-filling cloud, KNN
+    assert np.array_equal(capi.detect_boundary_points(blob, None, 0, 0.0, 20, 90.0).astype(np.int64),
+                          orc.detect_boundary_points(blob, None, 0, 0.0, 20, 90.0))
 
 
 def test_python_api_detect_boundary_points(capi):
@@ -60,3 +67,9 @@ def test_python_api_detect_boundary_points(capi):
         points, normals = pts, nrm
 
     assert m3d.features.detect_boundary_points(Cloud(), Param()) == ref
+
+    class Knn:                                            # duck-typed open3d.geometry.KDTreeSearchParamKNN
+        knn = 25
+
+    assert m3d.features.detect_boundary_points(Cloud(), Knn()) == capi.detect_boundary_points(pts, nrm, 0, 0.0, 25).tolist()
+    assert m3d.features.detect_boundary_points(pts, ("knn", 25)) == capi.detect_boundary_points(pts, None, 0, 0.0, 25).tolist()
