@@ -208,12 +208,6 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
     if ((uint32_t)lane < groups_per_block && g0 + lane < n_groups)
         mm = masks[(size_t)tile * n_groups + g0 + lane] & keep[g0 + lane];
     if (!__ballot(mm != 0)) return;  // most (tile, range) blocks of a pruned chunk end here
-    {   // statistics: (tile, hypothesis) pairs this wave evaluates (m3d_stats.pairs_scored), 64 counter replicas
-        uint32_t pc = (uint32_t)__popcll(mm);
-        for (int off = 32; off > 0; off >>= 1) pc += (uint32_t)__shfl_xor((int)pc, off, 64);
-        if (lane == 0) atomicAdd(&pair_rep[tile & 63u], pc);
-    }
-
     const size_t base = (size_t)tile * kTilePoints + lane;
     constexpr int P = kTilePoints / 64;
     double x[P], y[P], z[P];
@@ -222,6 +216,11 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
         x[j] = sx[base + 64 * j];
         y[j] = sy[base + 64 * j];
         z[j] = sz[base + 64 * j];
+    }
+    {   // statistics: (tile, hypothesis) pairs this wave evaluates (m3d_stats.pairs_scored)
+        uint32_t pc = (uint32_t)__popcll(mm);
+        for (int off = 32; off > 0; off >>= 1) pc += (uint32_t)__shfl_xor((int)pc, off, 64);
+        if (lane == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairReplicas], pc);
     }
     const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
     constexpr int kUsed = KIND == 2 ? 8 : 5;
@@ -302,10 +301,17 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
                                uint32_t pairs_slot, const uint8_t* __restrict__ valid, uint32_t h_count,
                                uint32_t* __restrict__ best_count) {
     const uint32_t h = blockIdx.x * 256u + threadIdx.x;
-    if (h == 0 && pair_rep) {
+    if (blockIdx.x == 0 && pair_rep) {   // block-uniform
+        __shared__ uint32_t red[256];
         uint32_t p = 0;
-        for (int r = 0; r < 64; ++r) p += pair_rep[r];
-        counts[pairs_slot] = p;
+        for (int r = threadIdx.x; r < kPairReplicas; r += 256) p += pair_rep[r];
+        red[threadIdx.x] = p;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) counts[pairs_slot] = red[0];
     }
     const bool mine = h < h_pad && !(pair_rep && h == pairs_slot);
     uint32_t c = 0;

@@ -31,6 +31,9 @@ void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n
 // counts_rep[tile % kCountReplicas][h] += inliers of hypothesis h in the tiles whose (mask & keep) bit is set;
 // counts_rep (kCountReplicas x rep_stride u32) zero on entry; launch_sum_replicas folds the replicas.
 constexpr int kCountReplicas = 16;
+// replicas of the launch's (tile, hypothesis) pair counter (m3d_stats.pairs_scored): one add per surviving wave,
+// consecutive tiles hit different words so the adds never queue on one address
+constexpr int kPairReplicas = 1024;
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
                        uint32_t* pair_rep /* 64 u32, zero on entry: evaluated (tile, hypothesis) pairs */, hipStream_t st);

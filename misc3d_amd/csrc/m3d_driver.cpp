@@ -320,7 +320,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     } else {
         RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * (h_pad / 64));
         RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)(h_pad / 64));
-        RESERVE(ctx->counts_rep, sizeof(uint32_t) * ((size_t)kCountReplicas * h_pad + 64));
+        RESERVE(ctx->counts_rep, sizeof(uint32_t) * ((size_t)kCountReplicas * h_pad + kPairReplicas));
     }
     const double t0 = now_ms();
     src.fill(begin, end, s.h_samples.as<uint32_t>());
@@ -334,7 +334,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     else
-        HIPCHK(hipMemsetAsync(ctx->counts_rep.p, 0, sizeof(uint32_t) * ((size_t)kCountReplicas * h_pad + 64), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->counts_rep.p, 0, sizeof(uint32_t) * ((size_t)kCountReplicas * h_pad + kPairReplicas), ctx->stream));
     if (dense) {
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
@@ -1378,7 +1378,7 @@ int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     const uint32_t n_groups = s.h_pad / 64;
     RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * n_groups);
     RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)n_groups);
-    RESERVE(ctx->counts_rep, sizeof(uint32_t) * ((size_t)kCountReplicas * s.h_pad + 64));
+    RESERVE(ctx->counts_rep, sizeof(uint32_t) * ((size_t)kCountReplicas * s.h_pad + kPairReplicas));
     RESERVE(ctx->small, 256);
     auto* masks = ctx->masks.as<unsigned long long>();
     auto* keep = ctx->keep.as<unsigned long long>();
