@@ -20,6 +20,7 @@
 // There is no CPU fallback: every entry point needs a HIP device.
 #include "m3d_driver.hpp"
 #include "m3d_fp.hpp"
+#include "m3d_mt19937.hpp"
 #include "m3d_reg_kernels.hpp"
 
 #include <algorithm>
@@ -235,32 +236,22 @@ static void replay_range(m3d_replay_state* st, size_t n_points, int kind, size_t
 // ------------------------------------------------------------------------------------------------
 struct SampleSource {
     // either a seeded sampler (utils.h:71-97) or a caller-provided table
-    std::mt19937 rng;
+    Mt19937Mod rng;       // std::mt19937 stream, a block of 624 draws at a time (m3d_mt19937.hpp)
     size_t n_points = 0;
     const uint32_t* table = nullptr;  // H x m, absolute hypothesis index
     int m = 3;
+    void seed(uint64_t s) { rng.seed((uint32_t)(s & 0xffffffffull)); }   // std::mt19937(seed): seed mod 2^32
     void fill(size_t begin, size_t end, uint32_t* out) {
         if (table) {
             std::memcpy(out, table + begin * m, sizeof(uint32_t) * (end - begin) * m);
             return;
         }
-        // `rng_() % size_` (utils.h:89) with a 32-bit generator output and size < 2^31: exact
-        // remainder by multiplication (Lemire's fastmod: M = ceil(2^64 / d);
-        // x mod d = high64((M * x mod 2^64) * d)), ~4x cheaper than the 64-bit divide.
-        const uint32_t d = (uint32_t)n_points;
-        const uint64_t M = UINT64_C(0xFFFFFFFFFFFFFFFF) / d + 1;
-        for (size_t h = begin; h < end; ++h) {
-            uint32_t* s = out + (h - begin) * m;
-            int valid = 0;
-            while (valid < m) {  // utils.h:88-95
-                const uint32_t x = (uint32_t)rng();
-                const uint64_t low = M * x;
-                const uint32_t idx = (uint32_t)(((unsigned __int128)low * d) >> 64);
-                bool dup = false;
-                for (int k = 0; k < valid; ++k) dup = dup || (s[k] == idx);
-                if (!dup) s[valid++] = idx;
-            }
-        }
+        // `rng_() % size_` (utils.h:89) with a 32-bit generator output and size < 2^32
+        if (rng.d != (uint32_t)n_points) rng.set_modulus((uint32_t)n_points);
+        const size_t n = end - begin;
+        if (m == 3) rng.fill<3>(out, n);
+        else if (m == 2) rng.fill<2>(out, n);
+        else rng.fill<4>(out, n);
     }
 };
 
@@ -640,7 +631,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     RESERVE(ctx->h_small, 256);
     HIPCHK(hipMemsetAsync(ctx->best_params.p, 0, sizeof(double) * kModelStride, ctx->stream));
     SampleSource src;
-    src.rng.seed((std::mt19937::result_type)(seed & 0xffffffffull));
+    src.seed(seed);
     src.n_points = v.n;
     src.m = minimal_sample(kind);
 
@@ -1179,7 +1170,7 @@ int m3d_draw_samples(size_t n_points, int kind, size_t n_hypotheses, uint64_t se
     if (n_points < (size_t)minimal_sample(kind))
         return fail(M3D_ERR_TOO_FEW_POINTS, "Can not fit model due to lack of points");
     SampleSource src;
-    src.rng.seed((std::mt19937::result_type)(seed & 0xffffffffull));
+    src.seed(seed);
     src.n_points = n_points;
     src.m = minimal_sample(kind);
     src.fill(0, n_hypotheses, samples);
@@ -1263,7 +1254,7 @@ m3d_sampler* m3d_sampler_create(size_t n_points, int kind, uint64_t seed) {
     }
     m3d_sampler* s = new m3d_sampler();
     s->kind = kind;
-    s->src.rng.seed((std::mt19937::result_type)(seed & 0xffffffffull));
+    s->src.seed(seed);
     s->src.n_points = n_points;
     s->src.m = minimal_sample(kind);
     return s;

@@ -54,6 +54,25 @@ def test_draw_samples_matches_oracle_sampler(capi, orc):
         assert np.array_equal(a.astype(np.uint64), b)
 
 
+def test_block_sampler_stream_is_the_scalar_stream(capi, orc):
+    # the library draws 624 words at a time with a multiply-shift remainder (m3d_mt19937.hpp); the oracle draws word by
+    # word with `%`.  Tiny clouds force redraws (duplicates) in nearly every sample, sizes around powers of two and
+    # 2^31 exercise the remainder constants, 3000 hypotheses cross many block boundaries at every alignment.
+    sizes = {capi.PLANE: (3, 4, 7, 255, 256, 257, 65535, 65536, 65537, 10**6, 10**7, 2**31 - 1),
+             capi.SPHERE: (4, 5, 9, 1023, 1024, 1025, 999983, 2**30, 2**30 + 1),
+             capi.CYLINDER: (2, 3, 6, 127, 128, 129, 50000, 2**31 - 1)}
+    for kind, ns in sizes.items():
+        for i, n in enumerate(ns):
+            seed = 7919 * i + kind
+            a = capi.draw_samples(n, kind, 3000, seed)
+            b = orc.draw_samples(n, capi.MINIMAL_SAMPLE[kind], 3000, seed)
+            assert np.array_equal(a.astype(np.uint64), b), (kind, n)
+    # seeds are taken mod 2^32 (std::mt19937::seed)
+    a = capi.draw_samples(1000, capi.PLANE, 100, 5)
+    b = capi.draw_samples(1000, capi.PLANE, 100, 5 + 2**32)
+    assert np.array_equal(a, b)
+
+
 def test_replay_matches_oracle_driver(capi, orc):
     # pure host logic: replay of ransac.h:592-613 over the oracle's per-hypothesis trace
     from misc3d_amd import synth
