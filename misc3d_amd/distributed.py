@@ -99,9 +99,11 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
         return 1e10 if cnt == 0 else err / float(np.sqrt(float(cnt)))
 
     cb = capi.RMSE_FN(rmse_of)
-    # slices per rank and window: with several ranks the host draws the other ranks' slices while the GPU
-    # scores (two interleaved slices per rank keep every GPU busy early); alone, one slice = fewest launches
-    K = 2 if world > 1 else 1
+    # one slice per rank and window: the fewest launches per rank.  Rank r starts scoring once the host has walked the
+    # stream to the end of its slice (~15 us per 10 000 hypotheses with the block sampler); interleaving two shorter
+    # slices per rank, which hid the slower word-by-word sampler, costs more in extra launches than it hides
+    # (tools/time_shard_rank.py: world 8, rank 7: 0.48 ms against 0.50 ms; world 2: 0.38 against 0.45)
+    K = 1
     while begin < H and not st.stopped:
         end = min(H, begin + window)
         n_win = end - begin
