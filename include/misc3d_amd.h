@@ -132,6 +132,12 @@ int m3d_cloud_exact_error(m3d_cloud *cloud, int kind, double threshold, const do
  * GeneralFit applied in place to params.  Return 1/0 = GeneralFit's return. */
 int m3d_cloud_refine(m3d_cloud *cloud, int kind, double threshold, double *params,
                      size_t *inliers, size_t *n_inliers);
+/* Same, when the caller already knows the inlier count of `params` from the scoring pass (the record of the best
+ * hypothesis, m3d_cloud_score_shard): the GeneralFit sums and the index-list copy are issued without waiting for
+ * the compaction's own total, which is only checked at the end (a different total silently takes the ordinary
+ * order).  expected_inliers < 0: unknown (= m3d_cloud_refine). */
+int m3d_cloud_refine_expect(m3d_cloud *cloud, int kind, double threshold, double *params,
+                            int64_t expected_inliers, size_t *inliers, size_t *n_inliers);
 /* pcd_copy = pcd_copy->SelectByIndex(inliers, invert=true), src/iterative_plane_segmentation.cpp:33, on
  * the resident cloud: the inliers of `model` (distance < threshold, RefineModel's rule ransac.h:537-543)
  * leave the cloud, the rest keeps its order.  Afterwards every entry point works on the remaining

@@ -92,6 +92,8 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_exact_error.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_refine.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_cloud_refine_expect.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int64, C.c_void_p,
+                                              C.c_void_p]
         L.m3d_cloud_remove_inliers.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.m3d_cloud_original_size.restype = C.c_size_t
         L.m3d_cloud_original_size.argtypes = [C.c_void_p]
@@ -338,14 +340,18 @@ class Cloud:
                                            C.cast(C.byref(err), C.c_void_p)))
         return int(cnt.value), float(err.value)
 
-    def refine(self, kind, threshold, params, copy=True):
+    refine_takes_expected = True
+
+    def refine(self, kind, threshold, params, copy=True, expected=None):
+        """m3d_cloud_refine; expected = inlier count already known from the scoring records (m3d_cloud_refine_expect)"""
         params = _f64(params).copy()
         if getattr(self, "_inl_buf", None) is None:
             self._inl_buf = np.empty(max(self.n_created, 1), dtype=np.uint64)
         inl = self._inl_buf
         ni = C.c_size_t(0)
-        rc = _check(lib().m3d_cloud_refine(self._h, kind, threshold, _p(params), _p(inl),
-                                           C.cast(C.byref(ni), C.c_void_p)))
+        rc = _check(lib().m3d_cloud_refine_expect(self._h, kind, threshold, _p(params),
+                                                  -1 if expected is None else int(expected), _p(inl),
+                                                  C.cast(C.byref(ni), C.c_void_p)))
         return rc, params, (inl[: ni.value].copy() if copy else inl[: ni.value])
 
     def minimal_model(self, kind, threshold, sample_row):

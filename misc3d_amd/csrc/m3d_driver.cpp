@@ -1418,25 +1418,31 @@ int m3d_cloud_exact_error(m3d_cloud* c, int kind, double threshold, const double
     return exact_error(ctx, c->view(), kind, threshold, ctx->small.as<double>(), count, error);
 }
 
-int m3d_cloud_refine(m3d_cloud* c, int kind, double threshold, double* params, size_t* inliers,
-                     size_t* n_inliers) {
+int m3d_cloud_refine_expect(m3d_cloud* c, int kind, double threshold, double* params, int64_t expected_inliers,
+                            size_t* inliers, size_t* n_inliers) {
     if (!c || kind < 0 || kind > 2 || !params || !n_inliers)
         return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     DeviceCtx* ctx = c->ctx;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     RESERVE(ctx->small, 256);
+    RESERVE(ctx->h_small, 256);
     double tmp[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::memcpy(tmp, params, sizeof(double) * num_params(kind));
-    HIPCHK(hipMemcpyAsync(ctx->small.p, tmp, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // staged through pinned memory (bytes 192.. of h_small; refine() uses the first 128): no host wait before the launches
+    std::memcpy(ctx->h_small.as<uint8_t>() + 192, tmp, sizeof(tmp));
+    HIPCHK(hipMemcpyAsync(ctx->small.p, ctx->h_small.as<uint8_t>() + 192, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
     int gf = 1;
     const CloudView v = c->view();
     const int rc = refine(ctx, v, c->base_view(), c->orig(), kind, threshold, ctx->small.as<double>(), tmp, inliers,
-                          n_inliers, &gf);
+                          n_inliers, &gf, expected_inliers);
     if (rc != M3D_OK) return rc;
     std::memcpy(params, tmp, sizeof(double) * num_params(kind));
     return gf ? M3D_OK : M3D_FALSE;
+}
+int m3d_cloud_refine(m3d_cloud* c, int kind, double threshold, double* params, size_t* inliers,
+                     size_t* n_inliers) {
+    return m3d_cloud_refine_expect(c, kind, threshold, params, -1, inliers, n_inliers);
 }
 
 int m3d_cloud_remove_inliers(m3d_cloud* c, int kind, double threshold, const double* model, size_t* n_removed) {

@@ -136,7 +136,10 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
         window = min(window * 2, 16384 * world)
 
     best = best_model[1] if (st.best_index >= 0 and best_model is not None) else np.zeros(capi.NUM_PARAMS[kind])
-    ret, params, inliers = scorer.refine(kind, threshold, best, copy=copy)
+    if st.best_index >= 0 and getattr(scorer, "refine_takes_expected", False):
+        ret, params, inliers = scorer.refine(kind, threshold, best, copy=copy, expected=int(st.best_count))
+    else:
+        ret, params, inliers = scorer.refine(kind, threshold, best, copy=copy)
     if st.best_index >= 0 and len(inliers) != st.best_count:
         raise capi.M3DError(capi.ERR_INTERNAL, "refine pass and gathered counts disagree")
     if not want_inliers:

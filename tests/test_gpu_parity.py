@@ -156,6 +156,11 @@ def test_threshold_boundary_decisions(capi, orc):
     with capi.Cloud(pts) as c:
         valid, models, counts = c.score_range(0, thr, samples)
         rc, params, inl = c.refine(0, thr, models[0])
+        # m3d_cloud_refine_expect: the count known from scoring changes only the order of the work; a wrong
+        # expectation is detected and the ordinary order taken
+        for expected in (int(counts[0]), int(counts[0]) + 5, 0, len(pts) + 10):
+            rc2, params2, inl2 = c.refine(0, thr, models[0], expected=expected)
+            assert rc2 == rc and np.array_equal(params2, params) and np.array_equal(inl2, inl)
     ov, om, oc, _ = orc.score_samples(0, pts, None, thr, samples.astype(np.uint64))
     assert counts[0] == oc[0] and 3 < oc[0] < len(pts)
     d = np.array([orc.distance(0, p, om[0]) for p in pts])
