@@ -99,8 +99,37 @@ def next_rows():
                         icp_T=T, icp_fit_rmse=np.array([fit, rm]), icp_iterations=np.array([it]), icp_corr=corr)
 
 
+def example_cloud():
+    """The reference's example cloud, examples/data/segmentation/test.ply (40 458 points, binary little-endian
+    double xyz written by Open3D) -- a DATA file, committed verbatim as tests/golden/segmentation_test.ply -- run
+    through the calls the reference's examples make on it: SegmentPlaneIterative(pcd, 0.01, 100, 0.1)
+    (examples/cpp/segment_plane_iterative.cpp:12-18) and, on the largest plane, DetectBoundaryPoints with
+    KDTreeSearchParamHybrid(0.02, 30) (examples/cpp/ransac_and_boundary.cpp:44-47).  The examples seed their
+    sampler from random_device; the fixture fixes seed 0.  /root/reference exists only in the build container, so
+    the copy step is skipped when the data file is already in place."""
+    import shutil
+    from misc3d_amd import io
+    dst = os.path.join(HERE, "segmentation_test.ply")
+    src = "/root/reference/examples/data/segmentation/test.ply"
+    if os.path.exists(src):
+        shutil.copyfile(src, dst)
+    pts = np.ascontiguousarray(io.read_ply(dst)["points"])
+    rc, planes, clusters = oracle.segment_plane_iterative(pts, 0.01, 100, 0.1, seed=0)
+    big = max(range(len(clusters)), key=lambda i: len(clusters[i]))
+    plane_pts = np.ascontiguousarray(pts[np.asarray(clusters[big], dtype=np.int64)])
+    bidx = oracle.detect_boundary_points(plane_pts, None, 2, 0.02, 30, 90.0)
+    fit = oracle.fit(0, pts, None, thr=0.01, max_iter=1000, prob=0.9999, seed=0)
+    np.savez_compressed(os.path.join(HERE, "example_cloud.npz"), args=np.array([0.01, 100, 0.1, 0]), rc=np.array([rc]),
+                        planes=planes, offsets=np.cumsum([0] + [len(c) for c in clusters]).astype(np.uint64),
+                        indices=np.concatenate(clusters).astype(np.uint64), largest=np.array([big]),
+                        boundary_index=np.asarray(bidx, dtype=np.uint64),
+                        fit_ret_best_count_iter=np.array([fit.ret, fit.best_index, fit.count, fit.iterations], dtype=np.int64),
+                        fit_params=fit.params, fit_inliers=fit.inliers.astype(np.uint64))
+
+
 if __name__ == "__main__":
     fits()
+    example_cloud()
     segmentation()
     registration()
     next_rows()
