@@ -665,8 +665,19 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     bool best_approx_known = false, pending_valid = false;
     const double* best_dev = ctx->best_params.as<double>();  // device copy of the current best model
     bool best_in_chunk = false;
-    auto issue_next = [&](int slot_id) -> int {
-        const size_t b = next_begin, e = std::min(max_iter, b + chunk);
+    // in_flight: hypotheses already issued whose records have not been replayed yet
+    auto issue_next = [&](int slot_id, size_t in_flight) -> int {
+        size_t want = chunk;
+        if (prob < 1.0 && out->st.best_index >= 0) {
+            // a best model exists: the adaptive bound (ransac.h:605-611) can only shrink from here, so ONE chunk
+            // that covers what is left of it (+6 % for invalid minimal fits, which do not count) ends the loop.
+            // Scoring a few hundred pruned hypotheses too many is cheaper than another chunk's launches.
+            const uint64_t done = out->st.count + in_flight;
+            const uint64_t left = out->st.current_iteration > done ? out->st.current_iteration - done : 0;
+            want = (size_t)((left + left / 16 + 16 + 63) / 64 * 64);
+        }
+        want = std::min(std::max<size_t>(want, 64), chunk_cap);
+        const size_t b = next_begin, e = std::min(max_iter, b + want);
         const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true);
         if (r == M3D_OK) {
             next_begin = e;
@@ -676,7 +687,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         return r;
     };
     if (max_iter > 0) {
-        rc = issue_next(0);
+        rc = issue_next(0, 0);
         if (rc != M3D_OK) return rc;
         for (;;) {
             ChunkSlot& s = ctx->slot[cur];
@@ -686,7 +697,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 const bool safe = prob >= 1.0 || (out->st.best_index >= 0 &&
                                                   out->st.current_iteration > out->st.count + (s.end - s.begin));
                 if (safe) {
-                    rc = issue_next(cur ^ 1);
+                    rc = issue_next(cur ^ 1, s.end - s.begin);
                     if (rc != M3D_OK) break;
                     issued = true;
                 }
@@ -783,7 +794,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             if (out->st.stopped) break;
             if (!issued) {
                 if (next_begin >= max_iter) break;
-                rc = issue_next(cur ^ 1);
+                rc = issue_next(cur ^ 1, 0);
                 if (rc != M3D_OK) break;
             }
             cur ^= 1;

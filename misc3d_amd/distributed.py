@@ -134,6 +134,11 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
             best_model = (bi, model_of(bi).copy())
         begin = end
         window = min(window * 2, 16384 * world)
+        if probability < 1.0 and st.best_index >= 0 and st.current_iteration > st.count:
+            # the adaptive bound only shrinks once a best model exists: one more window that covers what is
+            # left of it (+6 % for invalid minimal fits) ends the loop with one more collective
+            left = int(st.current_iteration) - int(st.count)
+            window = min(-(-(left + left // 16 + 16) // 64) * 64, 16384 * world)
 
     best = best_model[1] if (st.best_index >= 0 and best_model is not None) else np.zeros(capi.NUM_PARAMS[kind])
     if st.best_index >= 0 and getattr(scorer, "refine_takes_expected", False):
