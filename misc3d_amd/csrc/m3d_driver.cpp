@@ -942,7 +942,7 @@ static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double*
     w.scur.z = w.sbz[w.spp].as<double>();
     w.scur.boxes = w.sboxes.as<double>();
     w.scur.n_tiles = std::max<uint32_t>(1, (new_sorted + kTilePoints - 1) / kTilePoints);
-    // pad_nan_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
+    // compact_write_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
     launch_tile_boxes(w.scur, w.sboxes.as<double>(), ctx->stream);
     w.spp ^= 1;
     w.cur.x = w.bx[dst].as<double>();

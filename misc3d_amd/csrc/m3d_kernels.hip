@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void compact_write_k(
     CloudView c, const double* __restrict__ model, double thr, const uint32_t* __restrict__ orig,
     const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ ox, double* __restrict__ oy,
-    double* __restrict__ oz, uint32_t* __restrict__ oorig) {
+    double* __restrict__ oz, uint32_t* __restrict__ oorig, uint32_t n_pad_cap) {
     __shared__ uint32_t wsum[4];
     double m[7];
     for (int k = 0; k < 7; ++k) m[k] = model[k];
@@ -402,17 +402,16 @@ __global__ __launch_bounds__(256) void compact_write_k(
         row_base += rowtot;
         __syncthreads();
     }
-}
-
-// NaN padding of a freshly compacted SoA cloud: [n, n_pad)
-__global__ void pad_nan_k(double* x, double* y, double* z, const uint32_t* n_ptr, uint32_t n_pad_cap) {
-    const uint32_t n = n_ptr[0];
-    const uint32_t n_pad = min(n_pad_cap, (n + kScoreTile - 1) / kScoreTile * kScoreTile);
-    const double nan = u2f(0x7FF8000000000000ull);
-    for (uint32_t i = n + blockIdx.x * 256u + threadIdx.x; i < n_pad; i += gridDim.x * 256u) {
-        x[i] = nan;
-        y[i] = nan;
-        z[i] = nan;
+    // NaN padding of the freshly compacted SoA cloud, [n, n_pad): the last workgroup ends with row_base = n
+    if (MODE >= 2 && blockIdx.x == gridDim.x - 1) {
+        const uint32_t n = row_base;
+        const uint32_t n_pad = min(n_pad_cap, (n + kScoreTile - 1) / kScoreTile * kScoreTile);
+        const double nan = u2f(0x7FF8000000000000ull);
+        for (uint32_t i = n + threadIdx.x; i < n_pad; i += 256u) {
+            ox[i] = nan;
+            oy[i] = nan;
+            oz[i] = nan;
+        }
     }
 }
 
@@ -431,19 +430,16 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
     scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total);
     if (mode == 0)
         compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
-                                                     nullptr, nullptr, nullptr, nullptr, nullptr);
+                                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0);
     else if (mode == 1)
         compact_write_k<KIND, 1><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                     out_dist, nullptr, nullptr, nullptr, nullptr);
-    else {
-        if (mode == 2)
-            compact_write_k<KIND, 2><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                         nullptr, ox, oy, oz, oorig);
-        else
-            compact_write_k<KIND, 3><<<nb, 256, 0, s>>>(c, model, thr, nullptr, block_counts, nullptr,
-                                                         nullptr, ox, oy, oz, nullptr);
-        pad_nan_k<<<(kScoreTile + 255) / 256, 256, 0, s>>>(ox, oy, oz, total, n_pad_out);
-    }
+                                                     out_dist, nullptr, nullptr, nullptr, nullptr, 0);
+    else if (mode == 2)
+        compact_write_k<KIND, 2><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
+                                                     nullptr, ox, oy, oz, oorig, n_pad_out);
+    else
+        compact_write_k<KIND, 3><<<nb, 256, 0, s>>>(c, model, thr, nullptr, block_counts, nullptr,
+                                                     nullptr, ox, oy, oz, nullptr, n_pad_out);
 }
 
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
