@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <random>
@@ -504,7 +505,8 @@ static bool sphere_from_moments(const double* mean, const double* s, double n, d
 static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_view,
                   const uint32_t* orig_dev, int kind, double thr, const double* model_dev,
                   double* params_host /* in: best minimal model, out: refined */, size_t* inliers,
-                  size_t* n_inliers, int* general_fit_ok, int64_t expected_ni = -1) {
+                  size_t* n_inliers, int* general_fit_ok, int64_t expected_ni = -1,
+                  const std::function<int(int64_t)>* before_wait = nullptr) {
     const uint32_t n = flag_view.n;
     const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
     RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
@@ -529,6 +531,13 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                                ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 4, ctx->stream);
             HIPCHK(hipMemcpyAsync(h + 16, ctx->sums.p, sizeof(double) * 14, hipMemcpyDeviceToHost, ctx->stream));
         }
+        // work the caller wants queued behind these kernels before the host waits (segmentation: the removal of
+        // these very inliers), so that ONE wait covers both
+        if (before_wait) {
+            const int hr = (*before_wait)(expected_ni);
+            before_wait = nullptr;
+            if (hr != M3D_OK) return hr;
+        }
         // last: a copy into the caller's (pageable) buffer keeps the host busy until it is done
         if (inliers && ni_e) {
             HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
@@ -542,7 +551,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         std::memcpy(&ni_chk, h, 4);
         if (ni_chk != ni_e)   // should not happen: redo in the order that does not rely on the expectation
             return refine(ctx, flag_view, gather_view, orig_dev, kind, thr, model_dev, params_host, inliers, n_inliers,
-                          general_fit_ok, -1);
+                          general_fit_ok, -1, nullptr);
         *n_inliers = ni_e;
         *general_fit_ok = 1;
         if (kind != M3D_CYLINDER) {
@@ -833,7 +842,7 @@ static uint64_t resolve_seed(const uint64_t* seed) {
 
 static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter, double prob,
                             uint64_t seed, double* params, size_t* inliers, size_t* n_inliers,
-                            m3d_stats* stats) {
+                            m3d_stats* stats, const std::function<int(int64_t)>* before_refine_wait = nullptr) {
     DeviceCtx* ctx = c->ctx;
     const double t0 = now_ms();
     HIPCHK(hipSetDevice(ctx->device));
@@ -849,7 +858,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     size_t ni = 0;
     int gf_ok = 1;
     rc = refine(ctx, v, gather, orig, kind, thr, ctx->best_params.as<double>(), model, inliers, &ni,
-                &gf_ok, ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1);
+                &gf_ok, ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1, before_refine_wait);
     if (rc != M3D_OK) return rc;
     if (ro.st.best_index >= 0 && ni != ro.st.best_count)
         return fail(M3D_ERR_INTERNAL, "refine pass and scoring kernel disagree on the inlier count");
@@ -882,7 +891,12 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
 // cloud: a stable partition keeps the non-inliers of `model_dev` (distance >= thr, or not comparable) in
 // both copies -- original order (+ the map back to the cloud as created) and Hilbert-sorted (tile boxes
 // recomputed).  The first call allocates the ping-pong buffers.
-static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double* model_dev, size_t* n_removed) {
+// Two halves: cloud_remove_issue enqueues the partitions and the copy of their totals (no host wait: the
+// segmentation loop issues it behind RefineModel's kernels and lets RefineModel's own wait cover both),
+// cloud_remove_finish -- after the stream has been waited for -- checks the totals and switches the cloud over.
+// Without the finish nothing has changed for the caller (the partitions went into the spare buffer set).
+constexpr size_t kRemoveTotalsOffset = 160;   // bytes into h_small (refine() uses 0..127 and 192..255)
+static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* model_dev) {
     DeviceCtx* ctx = c->ctx;
     m3d_cloud::Work& w = c->work;
     if (c->has_normals) return fail(M3D_ERR_INVALID_ARG, "removing points from a cloud with normals is not supported");
@@ -929,10 +943,19 @@ static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double*
     launch_compact(kind, sview, model_dev, thr, 3, nullptr, nullptr, nullptr, w.sbx[w.spp].as<double>(),
                    w.sby[w.spp].as<double>(), w.sbz[w.spp].as<double>(), nullptr, scap,
                    ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>() + 1, ctx->stream);
-    uint32_t* h = ctx->h_small.as<uint32_t>();
-    HIPCHK(hipMemcpyAsync(h, ctx->total.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset, ctx->total.p, 2 * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return M3D_OK;
+}
+
+static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed) {
+    DeviceCtx* ctx = c->ctx;
+    m3d_cloud::Work& w = c->work;
+    const CloudView cur = w.cur;
+    const int dst = w.cur_is_v0 ? 1 : w.pp;
+    uint32_t h[2];
+    std::memcpy(h, ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset, sizeof(h));
     const uint32_t new_n = h[0], new_sorted = h[1];
     if (new_n > cur.n || new_sorted > c->n_sorted || cur.n - new_n != c->n_sorted - new_sorted)
         return fail(M3D_ERR_INTERNAL, "the two copies of the cloud disagree on the removed points");
@@ -963,6 +986,13 @@ static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double*
     c->n_sorted = new_sorted;
     c->n_tiles = w.scur.n_tiles;
     return M3D_OK;
+}
+
+static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double* model_dev, size_t* n_removed) {
+    const int rc = cloud_remove_issue(c, kind, thr, model_dev);
+    if (rc != M3D_OK) return rc;
+    HIPCHK(hipStreamSynchronize(c->ctx->stream));
+    return cloud_remove_finish(c, n_removed);
 }
 
 }  // namespace m3d
@@ -1504,8 +1534,17 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
             double plane[4] = {0, 0, 0, 0};
             size_t ni = 0;
             const size_t off = cluster_offsets[k];
+            // The removal of the round's inliers (:33) is queued behind RefineModel's kernels, before RefineModel
+            // waits for them: the pre-refinement model is already on the device and the inlier count is known
+            // from the scoring pass, so the round costs one host wait less.  Not on the last round.
+            bool removal_issued = false;
+            const std::function<int(int64_t)> issue_removal = [&](int64_t expected_ni) -> int {
+                if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) return M3D_OK;
+                removal_issued = true;
+                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->best_params.as<double>());
+            };
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
-                                  cluster_indices + off, &ni, nullptr);
+                                  cluster_indices + off, &ni, nullptr, &issue_removal);
             if (rc < 0) break;
             rc = M3D_OK;
             if (ni == 0) {  // the reference would loop forever (:29,:35)
@@ -1520,7 +1559,8 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
             // pcd_copy = pcd_copy->SelectByIndex(inliers, true), :33 -- inliers of the PRE-refinement model,
             // still in ctx->best_params
             size_t removed = 0;
-            rc = cloud_remove_locked(c0, M3D_PLANE, threshold, ctx->best_params.as<double>(), &removed);
+            rc = removal_issued ? cloud_remove_finish(c0, &removed)
+                                : cloud_remove_locked(c0, M3D_PLANE, threshold, ctx->best_params.as<double>(), &removed);
             if (rc != M3D_OK) break;
             if (removed != ni) {
                 rc = fail(M3D_ERR_INTERNAL, "removed points and inlier list disagree");
