@@ -633,7 +633,7 @@ struct RansacOut {
 };
 
 static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, int kind, double thr,
-                      size_t max_iter, double prob, uint64_t seed, RansacOut* out) {
+                      size_t max_iter, double prob, uint64_t seed, RansacOut* out, size_t iterations_hint = 0) {
     m3d_replay_init(&out->st);
     std::memset(out->best_host, 0, sizeof(out->best_host));
     RESERVE(ctx->best_params, sizeof(double) * kModelStride);
@@ -675,9 +675,11 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     const double* best_dev = ctx->best_params.as<double>();  // device copy of the current best model
     bool best_in_chunk = false;
     // in_flight: hypotheses already issued whose records have not been replayed yet
-    auto issue_next = [&](int slot_id, size_t in_flight) -> int {
+    auto issue_next = [&](int slot_id, size_t in_flight, size_t forced = 0) -> int {
         size_t want = chunk;
-        if (prob < 1.0 && out->st.best_index >= 0) {
+        if (forced) {
+            want = forced;
+        } else if (prob < 1.0 && out->st.best_index >= 0) {
             // a best model exists: the adaptive bound (ransac.h:605-611) can only shrink from here, so ONE chunk
             // that covers what is left of it (+6 % for invalid minimal fits, which do not count) ends the loop.
             // Scoring a few hundred pruned hypotheses too many is cheaper than another chunk's launches.
@@ -698,6 +700,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     if (max_iter > 0) {
         rc = issue_next(0, 0);
         if (rc != M3D_OK) return rc;
+        bool first_pass = true;
         for (;;) {
             ChunkSlot& s = ctx->slot[cur];
             bool issued = false;
@@ -709,8 +712,16 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                     rc = issue_next(cur ^ 1, s.end - s.begin);
                     if (rc != M3D_OK) break;
                     issued = true;
+                } else if (first_pass && prob < 1.0 && iterations_hint > s.end) {
+                    // the caller knows how many iterations a similar fit just took (segmentation rounds): queue
+                    // that many behind the first chunk without waiting for its counts (they prune on the device)
+                    const size_t left = iterations_hint - s.end;
+                    rc = issue_next(cur ^ 1, s.end - s.begin, (left + left / 16 + 16 + 63) / 64 * 64);
+                    if (rc != M3D_OK) break;
+                    issued = true;
                 }
             }
+            first_pass = false;
             HIPCHK(hipEventSynchronize(s.done));
             unpack_slot(s);
             {
@@ -842,7 +853,8 @@ static uint64_t resolve_seed(const uint64_t* seed) {
 
 static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter, double prob,
                             uint64_t seed, double* params, size_t* inliers, size_t* n_inliers,
-                            m3d_stats* stats, const std::function<int(int64_t)>* before_refine_wait = nullptr) {
+                            m3d_stats* stats, const std::function<int(int64_t)>* before_refine_wait = nullptr,
+                            size_t* iterations_hint = nullptr /* in: iterations of a similar fit, out: of this one */) {
     DeviceCtx* ctx = c->ctx;
     const double t0 = now_ms();
     HIPCHK(hipSetDevice(ctx->device));
@@ -850,8 +862,9 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     const CloudView gather = c->base_view();   // index lists / GeneralFit refer to the cloud as created
     const uint32_t* orig = c->orig();
     RansacOut ro;
-    int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro);
+    int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro, iterations_hint ? *iterations_hint : 0);
     if (rc != M3D_OK) return rc;
+    if (iterations_hint) *iterations_hint = (size_t)ro.st.iterations;
     const double t1 = now_ms();
     double model[kModelStride];
     std::memcpy(model, ro.best_host, sizeof(model));
@@ -1522,6 +1535,7 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
         std::lock_guard<std::mutex> lock(ctx->mu);
         const uint64_t seed0 = resolve_seed(seed);
         size_t count = 0, k = 0;
+        size_t iterations_hint = 0;   // iterations the previous round took: sizes this round's second chunk up front
         const size_t target = (size_t)((1 - min_ratio) * (double)n);  // :28
         while (count < target && k < max_clusters) {
             if (c0->n < 3) {  // the reference's FitModel would throw here (ransac.h:510-513)
@@ -1544,7 +1558,7 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
                 return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->best_params.as<double>());
             };
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
-                                  cluster_indices + off, &ni, nullptr, &issue_removal);
+                                  cluster_indices + off, &ni, nullptr, &issue_removal, &iterations_hint);
             if (rc < 0) break;
             rc = M3D_OK;
             if (ni == 0) {  // the reference would loop forever (:29,:35)
