@@ -1090,19 +1090,29 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
             launch_aos_to_soa(stage.as<double>(), c->nx.as<double>(), c->ny.as<double>(),
                               c->nz.as<double>(), c->n, c->n_pad, ctx->stream);
     }
-    // Z-order sorted copy + tile boxes for the culled scoring path (bounding box on the host: one
-    // pass over the caller's array while the upload is in flight)
-    DevBuf t_cell, t_start, t_fill, t_sums, t_total;
+    // Hilbert-sorted copy + tile boxes for the culled scoring path.  The bounding box of the finite points comes
+    // from the device copy (a host pass over the caller's 10 M-point array took 9 ms, as long as the rest of
+    // the upload and sort together)
+    DevBuf t_cell, t_start, t_fill, t_sums, t_total, t_bbox;
     if (ok) {
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         uint32_t n_finite = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
-            if (std::isfinite(px) && std::isfinite(py) && std::isfinite(pz)) {
-                lo[0] = std::min(lo[0], px); hi[0] = std::max(hi[0], px);
-                lo[1] = std::min(lo[1], py); hi[1] = std::max(hi[1], py);
-                lo[2] = std::min(lo[2], pz); hi[2] = std::max(hi[2], pz);
-                ++n_finite;
+        if (n) {
+            double bb[7];
+            ok = t_bbox.reserve(sizeof(double) * (kBboxPartialDoubles + 8));
+            if (ok) {
+                launch_bbox(c->x.as<double>(), c->y.as<double>(), c->z.as<double>(), c->n, t_bbox.as<double>(),
+                            t_bbox.as<double>() + kBboxPartialDoubles, ctx->stream);
+                ok = hipMemcpyAsync(bb, t_bbox.as<double>() + kBboxPartialDoubles, sizeof(bb), hipMemcpyDeviceToHost,
+                                    ctx->stream) == hipSuccess &&
+                     hipStreamSynchronize(ctx->stream) == hipSuccess;
+            }
+            if (ok) {
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = bb[k];
+                    hi[k] = bb[3 + k];
+                }
+                n_finite = (uint32_t)bb[6];
             }
         }
         const uint32_t cap = std::max<uint32_t>(round_up((uint32_t)n, kTilePoints), kTilePoints);

@@ -52,6 +52,66 @@ void launch_aos_to_soa(const double* aos, double* x, double* y, double* z, uint3
     aos_to_soa_k<<<(n_pad + 255) / 256, 256, 0, s>>>(aos, x, y, z, n, n_pad);
 }
 
+// Bounding box of the finite points + their number (the Hilbert sort's grid): per-workgroup partials, then one
+// workgroup folds them.  out[0..2] = lo, out[3..5] = hi, out[6] = count (exact in a double: n < 2^31).
+constexpr int kBboxBlocks = 1024;
+__device__ __forceinline__ void bbox_fold(double (&v)[7], double (*red)[7]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double a = v[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double b = __shfl_xor(a, off, 64);
+            a = k < 3 ? fmin(a, b) : (k < 6 ? fmax(a, b) : a + b);
+        }
+        if (lane == 0) red[wave][k] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double a = red[0][k], b = red[1][k], c = red[2][k], d = red[3][k];
+        v[k] = k < 3 ? fmin(fmin(a, b), fmin(c, d)) : (k < 6 ? fmax(fmax(a, b), fmax(c, d)) : (a + b) + (c + d));
+    }
+}
+__global__ __launch_bounds__(256) void bbox_partial_k(const double* __restrict__ x, const double* __restrict__ y,
+                                                       const double* __restrict__ z, uint32_t n,
+                                                       double* __restrict__ partial) {
+    __shared__ double red[4][7];
+    const double inf = u2f(0x7FF0000000000000ull);
+    double v[7] = {inf, inf, inf, -inf, -inf, -inf, 0.0};
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const double px = x[i], py = y[i], pz = z[i];
+        if (isfinite(px) && isfinite(py) && isfinite(pz)) {
+            v[0] = fmin(v[0], px); v[1] = fmin(v[1], py); v[2] = fmin(v[2], pz);
+            v[3] = fmax(v[3], px); v[4] = fmax(v[4], py); v[5] = fmax(v[5], pz);
+            v[6] += 1.0;
+        }
+    }
+    bbox_fold(v, red);
+    if (threadIdx.x < 7) partial[blockIdx.x * 8 + threadIdx.x] = v[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void bbox_final_k(const double* __restrict__ partial, uint32_t blocks,
+                                                     double* __restrict__ out) {
+    __shared__ double red[4][7];
+    const double inf = u2f(0x7FF0000000000000ull);
+    double v[7] = {inf, inf, inf, -inf, -inf, -inf, 0.0};
+    for (uint32_t b = threadIdx.x; b < blocks; b += 256u) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double t = partial[b * 8 + k];
+            v[k] = k < 3 ? fmin(v[k], t) : (k < 6 ? fmax(v[k], t) : v[k] + t);
+        }
+    }
+    bbox_fold(v, red);
+    if (threadIdx.x < 7) out[threadIdx.x] = v[threadIdx.x];
+}
+void launch_bbox(const double* x, const double* y, const double* z, uint32_t n, double* partial, double* out,
+                 hipStream_t s) {
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(kBboxBlocks, (n + 255) / 256));
+    bbox_partial_k<<<blocks, 256, 0, s>>>(x, y, z, n, partial);
+    bbox_final_k<<<1, 256, 0, s>>>(partial, blocks, out);
+}
+
 __global__ void iota_k(uint32_t* v, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) v[i] = i;

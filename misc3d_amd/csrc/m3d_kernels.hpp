@@ -50,6 +50,12 @@ void launch_score(int kind, const CloudView& c, const double* score, uint32_t h_
 void launch_reduce_partials(const uint32_t* partial, uint32_t n_tiles, uint32_t h_pad,
                             uint32_t* counts, hipStream_t s);
 
+// bounding box of the finite points and their number: out[0..2] = lo, out[3..5] = hi, out[6] = count;
+// partial: scratch of kBboxPartialDoubles doubles
+constexpr int kBboxPartialDoubles = 1024 * 8;
+void launch_bbox(const double* x, const double* y, const double* z, uint32_t n, double* partial, double* out,
+                 hipStream_t s);
+
 // K4: ordered compaction with the reference's own distance formula (sqrt and divide per point).
 // mode 0: out_idx[k]  = index (or orig[index] when orig != null) of the k-th inlier, ascending
 // mode 1: out_dist[k] = distance of the k-th inlier
