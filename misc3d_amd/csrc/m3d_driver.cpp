@@ -506,7 +506,8 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                   const uint32_t* orig_dev, int kind, double thr, const double* model_dev,
                   double* params_host /* in: best minimal model, out: refined */, size_t* inliers,
                   size_t* n_inliers, int* general_fit_ok, int64_t expected_ni = -1,
-                  const std::function<int(int64_t)>* before_wait = nullptr) {
+                  const std::function<int(int64_t)>* before_wait = nullptr,
+                  const double* lazy_in = nullptr /* pinned: the "in" value of params_host arrives with the wait */) {
     const uint32_t n = flag_view.n;
     const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
     RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
@@ -547,11 +548,12 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+        if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
         uint32_t ni_chk;
         std::memcpy(&ni_chk, h, 4);
         if (ni_chk != ni_e)   // should not happen: redo in the order that does not rely on the expectation
             return refine(ctx, flag_view, gather_view, orig_dev, kind, thr, model_dev, params_host, inliers, n_inliers,
-                          general_fit_ok, -1, nullptr);
+                          general_fit_ok, -1, nullptr, nullptr);
         *n_inliers = ni_e;
         *general_fit_ok = 1;
         if (kind != M3D_CYLINDER) {
@@ -573,7 +575,13 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         return M3D_OK;
     }
     HIPCHK(hipGetLastError());
+    if (before_wait) {
+        const int hr = (*before_wait)(-1);
+        before_wait = nullptr;
+        if (hr != M3D_OK) return hr;
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
     uint32_t ni;
     std::memcpy(&ni, h, 4);
     *n_inliers = ni;
@@ -617,11 +625,10 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
 
 // ------------------------------------------------------------------------------------------------
 // RANSAC::FitModelParallel on a resident view.  Leaves the best minimal model in
-// ctx->best_params (device) and best_host.
+// ctx->best_params (device) and on its way to ctx->h_best (pinned host; valid after the next stream wait).
 // ------------------------------------------------------------------------------------------------
 struct RansacOut {
     m3d_replay_state st;
-    double best_host[kModelStride];
     uint64_t hypotheses_scored = 0;
     uint64_t exact_rmse_evals = 0;
     int32_t ties = 0;
@@ -635,7 +642,6 @@ struct RansacOut {
 static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, int kind, double thr,
                       size_t max_iter, double prob, uint64_t seed, RansacOut* out, size_t iterations_hint = 0) {
     m3d_replay_init(&out->st);
-    std::memset(out->best_host, 0, sizeof(out->best_host));
     RESERVE(ctx->best_params, sizeof(double) * kModelStride);
     RESERVE(ctx->h_small, 256);
     HIPCHK(hipMemsetAsync(ctx->best_params.p, 0, sizeof(double) * kModelStride, ctx->stream));
@@ -821,13 +827,16 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_small.p, ctx->best_params.p, sizeof(double) * kModelStride,
+    // The best minimal model travels to the host (pinned ctx->h_best) WITHOUT a wait here: RefineModel's kernels
+    // are queued right behind it and RefineModel's own wait delivers both (one host round trip less per fit).
+    // ms_score is read from ev0..ev1 by the caller after that wait.
+    RESERVE(ctx->h_best, sizeof(double) * kModelStride);
+    HIPCHK(hipMemcpyAsync(ctx->h_best.p, ctx->best_params.p, sizeof(double) * kModelStride,
                           hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (rc != M3D_OK) return rc;
-    std::memcpy(out->best_host, ctx->h_small.p, sizeof(double) * kModelStride);
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) out->ms_score = ms;
+    if (rc != M3D_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
     if (out->internal_error)
         return fail(M3D_ERR_INTERNAL, "scoring kernel and exact evaluation disagree on an inlier count");
     return M3D_OK;
@@ -866,13 +875,17 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     if (rc != M3D_OK) return rc;
     if (iterations_hint) *iterations_hint = (size_t)ro.st.iterations;
     const double t1 = now_ms();
-    double model[kModelStride];
-    std::memcpy(model, ro.best_host, sizeof(model));
+    double model[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};   // filled from ctx->h_best by refine's wait
     size_t ni = 0;
     int gf_ok = 1;
     rc = refine(ctx, v, gather, orig, kind, thr, ctx->best_params.as<double>(), model, inliers, &ni,
-                &gf_ok, ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1, before_refine_wait);
+                &gf_ok, ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1, before_refine_wait,
+                ctx->h_best.as<double>());
     if (rc != M3D_OK) return rc;
+    {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ro.ms_score = ms;
+    }
     if (ro.st.best_index >= 0 && ni != ro.st.best_count)
         return fail(M3D_ERR_INTERNAL, "refine pass and scoring kernel disagree on the inlier count");
     if (n_inliers) *n_inliers = ni;
