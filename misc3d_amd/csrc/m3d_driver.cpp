@@ -206,6 +206,10 @@ static void replay_range(m3d_replay_state* st, size_t n_points, int kind, size_t
         const size_t k = i - begin;
         if (!valid[k]) continue;  // ransac.h:584-586 (no count++)
         const uint32_t cnt = counts[k];
+        if (cnt < st->best_count) {   // fitness = cnt / N is strictly monotone in cnt (N < 2^31): cannot be better or tie
+            st->count++;
+            continue;
+        }
         // EvaluateModel's tail, ransac.h:644-651
         const double fitness = cnt == 0 ? 0.0 : (double)cnt / (double)n_points;
         bool better = fitness > st->best_fitness;
