@@ -354,12 +354,15 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                           pair_rep, ctx->stream);
         HIPCHK(hipEventRecord(s.k1, ctx->stream));
         // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
-        launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.counts.as<uint32_t>(), pair_rep, count,
+        // ... and writes the records straight into the slot's pinned host array (device-visible): no copy command
+        // behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
+        launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.h_counts.as<uint32_t>(), pair_rep, count,
                             s.valid.as<uint8_t>(), count, prune ? ctx->best_count.as<uint32_t>() : nullptr, ctx->stream);
     }
     // counts of the chunk + (culled path) the number of (tile, hypothesis) pairs the launch evaluated
-    HIPCHK(hipMemcpyAsync(s.h_counts.p, s.counts.p, sizeof(uint32_t) * ((size_t)count + (dense ? 0 : 1)),
-                          hipMemcpyDeviceToHost, ctx->stream));
+    if (dense)
+        HIPCHK(hipMemcpyAsync(s.h_counts.p, s.counts.p, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost,
+                              ctx->stream));
     if (dense) HIPCHK(hipMemcpyAsync(s.h_valid.p, s.valid.p, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.done, ctx->stream));
