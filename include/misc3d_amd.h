@@ -85,6 +85,12 @@ typedef struct m3d_cloud m3d_cloud;
 m3d_cloud *m3d_cloud_create(const double *xyz, const double *normals /* may be NULL */, size_t n,
                             int device);
 void m3d_cloud_destroy(m3d_cloud *cloud);
+/* Page-locked host memory for OUTPUT buffers (inlier index lists).  Any host pointer is accepted wherever this
+ * header takes an output buffer; one obtained here lets the library start the device-to-host copy of the index
+ * list as soon as the list exists, overlapped with the GeneralFit sums, instead of last (a copy into pageable
+ * memory occupies the calling thread until it is done).  NULL + m3d_last_error() on failure. */
+void *m3d_host_alloc(size_t bytes);
+void m3d_host_free(void *p);
 /* Points currently in the cloud (shrinks with m3d_cloud_remove_inliers) / points it was created with. */
 size_t m3d_cloud_size(const m3d_cloud *cloud);
 size_t m3d_cloud_original_size(const m3d_cloud *cloud);

@@ -83,6 +83,10 @@ def lib():
         L.m3d_cloud_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.m3d_cloud_destroy.argtypes = [C.c_void_p]
         L.m3d_cloud_destroy.restype = None
+        L.m3d_host_alloc.restype = C.c_void_p
+        L.m3d_host_alloc.argtypes = [C.c_size_t]
+        L.m3d_host_free.restype = None
+        L.m3d_host_free.argtypes = [C.c_void_p]
         L.m3d_cloud_size.argtypes = [C.c_void_p]
         L.m3d_minimal_fit.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_cloud_size.restype = C.c_size_t
@@ -241,6 +245,25 @@ def shard_layout(begin, end, slice_, world):
     return owner, pos, counts
 
 
+class _PinnedU64:
+    """n uint64 of page-locked host memory from m3d_host_alloc, exposed through the array interface so that numpy
+    arrays made from it (and their views) keep it alive."""
+
+    def __init__(self, n):
+        self._ptr = lib().m3d_host_alloc(8 * n)
+        if not self._ptr:
+            raise MemoryError(last_error())
+        self.__array_interface__ = {"shape": (n,), "typestr": "<u8", "data": (self._ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                lib().m3d_host_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+
 class Cloud:
     """Resident SoA copy of a point cloud in HBM (RANSAC::SetPointCloud, ransac.h:469-475)."""
 
@@ -269,10 +292,24 @@ class Cloud:
         if not self._h:
             raise M3DError(ERR_DEVICE, last_error())
 
+    def _out_buf(self):
+        """Per-cloud index-list buffer (n_created uint64), page-locked through m3d_host_alloc when possible: the
+        library then copies the inlier list while the GeneralFit sums run (include/misc3d_amd.h).  The block is
+        owned by the array (and every view of it, e.g. fit(copy=False).inliers): it is released when the last
+        one goes away, not by close()."""
+        if getattr(self, "_inl_buf", None) is None:
+            n = max(self.n_created, 1)
+            try:
+                self._inl_buf = np.asarray(_PinnedU64(n))
+            except MemoryError:
+                self._inl_buf = np.empty(n, dtype=np.uint64)
+        return self._inl_buf
+
     def close(self):
         if getattr(self, "_h", None):
             lib().m3d_cloud_destroy(self._h)
             self._h = None
+        self._inl_buf = None
 
     def __del__(self):
         try:
@@ -294,9 +331,7 @@ class Cloud:
         params = np.zeros(NUM_PARAMS[kind])
         inl = None
         if want_inliers:
-            if getattr(self, "_inl_buf", None) is None:
-                self._inl_buf = np.empty(max(self.n_created, 1), dtype=np.uint64)
-            inl = self._inl_buf
+            inl = self._out_buf()
         ni = C.c_size_t(0)
         st = Stats()
         _s, sref = _seed_ref(seed)
@@ -345,9 +380,7 @@ class Cloud:
     def refine(self, kind, threshold, params, copy=True, expected=None):
         """m3d_cloud_refine; expected = inlier count already known from the scoring records (m3d_cloud_refine_expect)"""
         params = _f64(params).copy()
-        if getattr(self, "_inl_buf", None) is None:
-            self._inl_buf = np.empty(max(self.n_created, 1), dtype=np.uint64)
-        inl = self._inl_buf
+        inl = self._out_buf()
         ni = C.c_size_t(0)
         rc = _check(lib().m3d_cloud_refine_expect(self._h, kind, threshold, _p(params),
                                                   -1 if expected is None else int(expected), _p(inl),

@@ -502,6 +502,17 @@ static bool sphere_from_moments(const double* mean, const double* s, double n, d
     return true;
 }
 
+// m3d_host_alloc registry: is [p, p + bytes) inside a page-locked block handed out by this library?
+static std::mutex g_pinned_mu;
+static std::vector<std::pair<const char*, size_t>> g_pinned;
+static bool is_library_pinned(const void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    const char* q = static_cast<const char*>(p);
+    for (const auto& b : g_pinned)
+        if (q >= b.first && q + bytes <= b.first + b.second) return true;
+    return false;
+}
+
 // RefineModel, ransac.h:534-549.  flag_view: cloud the distances are evaluated on; gather_view +
 // orig: when the flags are computed on a compacted cloud (segmentation) the inlier list holds
 // ORIGINAL indices and the GeneralFit sums gather from the original cloud (same values, same order).
@@ -532,6 +543,13 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         const uint32_t ni_e = (uint32_t)expected_ni;
         const bool need_fit_e = kind != M3D_CYLINDER && ni_e >= (kind == M3D_PLANE ? 3u : 4u);
         HIPCHK(hipEventRecord(ctx->ev_compact, ctx->stream));
+        // page-locked destination (m3d_host_alloc): the index list leaves NOW, on the copy stream, under the sums
+        const bool early_copy = inliers && ni_e && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)ni_e);
+        if (early_copy) {
+            HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
+            HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost,
+                                  ctx->copy_stream));
+        }
         if (need_fit_e) {
             launch_sum_xyz(gather_view, ctx->idx.as<uint64_t>(), ni_e, ctx->sum_partial.as<double>(),
                            ctx->sums.as<double>(), ctx->stream);
@@ -547,7 +565,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
             if (hr != M3D_OK) return hr;
         }
         // last: a copy into the caller's (pageable) buffer keeps the host busy until it is done
-        if (inliers && ni_e) {
+        if (inliers && ni_e && !early_copy) {
             HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
             HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost,
                                   ctx->copy_stream));
@@ -1187,6 +1205,29 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
         return nullptr;
     }
     return c;
+}
+
+void* m3d_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocPortable) != hipSuccess || !p) {
+        set_error("hipHostMalloc failed (" + std::to_string(bytes) + " bytes)");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    g_pinned.emplace_back(static_cast<const char*>(p), std::max<size_t>(bytes, 1));
+    return p;
+}
+void m3d_host_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mu);
+        for (size_t i = 0; i < g_pinned.size(); ++i)
+            if (g_pinned[i].first == p) {
+                g_pinned.erase(g_pinned.begin() + (long)i);
+                break;
+            }
+    }
+    (void)hipHostFree(p);
 }
 
 void m3d_cloud_destroy(m3d_cloud* c) {

@@ -287,3 +287,20 @@ def test_culled_scoring_robustness(capi, orc, kind):
         ovalid, omodels, ocounts, _ = orc.score_samples(kind, pts, nn, thr, samples.astype(np.uint64))
         assert np.array_equal(valid.astype(bool), ovalid.astype(bool))
         assert np.array_equal(counts.astype(np.uint64), ocounts), (kind, n, thr)
+
+
+def test_pinned_output_buffer_same_result(capi):
+    """m3d_host_alloc output buffers only change WHEN the inlier list is copied (early, under the GeneralFit sums),
+    not what is copied; views handed out with copy=False stay valid after the cloud is closed."""
+    from misc3d_amd import synth
+    pts = synth.plane_cloud_c2(200_000, seed=2)
+    plain = capi.fit(0, pts, threshold=0.01, max_iteration=500, probability=1.0, seed=4)   # pageable numpy buffer
+    c = capi.Cloud(pts)
+    g = c.fit(0, 0.01, 500, 1.0, seed=4, copy=False)
+    assert isinstance(c._inl_buf.base, capi._PinnedU64)
+    view = g.inliers
+    c.close()
+    assert np.array_equal(view, plain.inliers) and np.array_equal(g.params, plain.params)
+    ptr = capi.lib().m3d_host_alloc(64)
+    assert ptr
+    capi.lib().m3d_host_free(ptr)
