@@ -536,7 +536,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
     RESERVE(ctx->h_small, 256);
     launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
-                   ctx->total.as<uint32_t>(), ctx->stream);
+                   ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in));
     uint8_t* h = ctx->h_small.as<uint8_t>();
     HIPCHK(hipMemcpyAsync(h, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (expected_ni >= 0 && (uint64_t)expected_ni <= n) {
@@ -852,12 +852,10 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    // The best minimal model travels to the host (pinned ctx->h_best) WITHOUT a wait here: RefineModel's kernels
-    // are queued right behind it and RefineModel's own wait delivers both (one host round trip less per fit).
+    // The best minimal model travels to the host (pinned ctx->h_best) with RefineModel: its first kernel stores the
+    // record there and RefineModel's own wait delivers it (no wait and no copy command here).
     // ms_score is read from ev0..ev1 by the caller after that wait.
     RESERVE(ctx->h_best, sizeof(double) * kModelStride);
-    HIPCHK(hipMemcpyAsync(ctx->h_best.p, ctx->best_params.p, sizeof(double) * kModelStride,
-                          hipMemcpyDeviceToHost, ctx->stream));
     if (rc != M3D_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;

@@ -365,10 +365,13 @@ __device__ __forceinline__ double ref_distance(const double* m, double x, double
 template <int KIND>
 __global__ __launch_bounds__(256) void compact_count_k(CloudView c, const double* __restrict__ model,
                                                         double thr, int invert,
-                                                        uint32_t* __restrict__ block_counts) {
+                                                        uint32_t* __restrict__ block_counts,
+                                                        double* __restrict__ model_copy) {
     __shared__ uint32_t wsum[4];
     double m[7];
     for (int k = 0; k < 7; ++k) m[k] = model[k];
+    // the model record (8 doubles) also goes where the caller wants a copy (pinned host memory): no copy command
+    if (model_copy && blockIdx.x == 0 && threadIdx.x < kModelStride) model_copy[threadIdx.x] = model[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t cnt = 0;
     const uint32_t base = blockIdx.x * kCompactTile;
@@ -480,13 +483,14 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
                                 const uint32_t* orig, uint64_t* out_idx, double* out_dist,
                                 double* ox, double* oy, double* oz, uint32_t* oorig,
                                 uint32_t n_pad_out, uint32_t* block_counts, uint32_t* total,
-                                hipStream_t s) {
+                                hipStream_t s, double* model_copy) {
     const uint32_t nb = (c.n + kCompactTile - 1) / kCompactTile;
     if (nb == 0) {
         (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+        if (model_copy) (void)hipMemcpyAsync(model_copy, model, sizeof(double) * kModelStride, hipMemcpyDeviceToHost, s);
         return;
     }
-    compact_count_k<KIND><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts);
+    compact_count_k<KIND><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts, model_copy);
     scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total);
     if (mode == 0)
         compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
@@ -505,16 +509,16 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
-                    uint32_t* block_counts, uint32_t* total, hipStream_t s) {
+                    uint32_t* block_counts, uint32_t* total, hipStream_t s, double* model_copy) {
     if (kind == 0)
         launch_compact_kind<0>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s);
+                               n_pad_out, block_counts, total, s, model_copy);
     else if (kind == 1)
         launch_compact_kind<1>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s);
+                               n_pad_out, block_counts, total, s, model_copy);
     else
         launch_compact_kind<2>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s);
+                               n_pad_out, block_counts, total, s, model_copy);
 }
 
 // EvaluateModel's `error += distance` in point order (ransac.h:637): a genuinely serial fp64 chain.

@@ -65,7 +65,8 @@ void launch_bbox(const double* x, const double* y, const double* z, uint32_t n, 
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
-                    uint32_t* block_counts, uint32_t* total, hipStream_t s);
+                    uint32_t* block_counts, uint32_t* total, hipStream_t s,
+                    double* model_copy = nullptr /* device-visible (pinned host): receives the 8-double model record */);
 
 // serial-order sum of `n[0]` doubles (EvaluateModel's `error += distance`, ransac.h:637)
 void launch_serial_sum(const double* v, const uint32_t* n, double* out, hipStream_t s);
