@@ -165,24 +165,33 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
 }
 
 // keep[g] = hypotheses of group g that are still worth scoring: ub[h] * 512 >= best_count[0]
-// (best_count null or 0: everything).
+// (ub null: everything; best_count null or 0: everything).  zero != null: the kernel also clears the
+// kCountReplicas x rep_stride counter replicas of its hypotheses and (group 0) the kPairReplicas words behind them,
+// which the scoring kernel that follows adds into -- one command less than a separate memset.
 __global__ __launch_bounds__(64) void keep_mask_k(const uint32_t* __restrict__ ub,
                                                    const uint32_t* __restrict__ best_count_ptr,
-                                                   unsigned long long* __restrict__ keep) {
+                                                   unsigned long long* __restrict__ keep,
+                                                   uint32_t* __restrict__ zero, uint32_t rep_stride) {
     const uint32_t h = blockIdx.x * 64u + threadIdx.x;
     const uint32_t best = best_count_ptr ? best_count_ptr[0] : 0u;
-    const bool k = best == 0 || (uint64_t)ub[h] * kTilePoints >= best;
+    const bool k = !ub || best == 0 || (uint64_t)ub[h] * kTilePoints >= best;
     const unsigned long long m = __ballot(k);
     if (threadIdx.x == 0) keep[blockIdx.x] = m;
+    if (zero) {
+#pragma unroll
+        for (int r = 0; r < kCountReplicas; ++r) zero[(size_t)r * rep_stride + h] = 0u;
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < kPairReplicas; i += 64) zero[(size_t)kCountReplicas * rep_stride + i] = 0u;
+    }
 }
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
-                      hipStream_t st) {
+                      hipStream_t st, uint32_t* zero_counts_rep, uint32_t rep_stride) {
     if (!n_groups) return;
-    if (!ub) {
+    if (!ub && !zero_counts_rep) {
         (void)hipMemsetAsync(keep, 0xFF, sizeof(unsigned long long) * n_groups, st);
         return;
     }
-    keep_mask_k<<<n_groups, 64, 0, st>>>(ub, best_count, keep);
+    keep_mask_k<<<n_groups, 64, 0, st>>>(ub, best_count, keep, zero_counts_rep, rep_stride);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -26,8 +26,9 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
                       uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st,
                       bool ub_is_zero = false);
 // keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
+// zero_counts_rep != null: the same launch clears the kCountReplicas x rep_stride + kPairReplicas counter words.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
-                      hipStream_t st);
+                      hipStream_t st, uint32_t* zero_counts_rep = nullptr, uint32_t rep_stride = 0);
 // counts_rep[tile % kCountReplicas][h] += inliers of hypothesis h in the tiles whose (mask & keep) bit is set;
 // counts_rep (kCountReplicas x rep_stride u32) zero on entry; launch_sum_replicas folds the replicas.
 constexpr int kCountReplicas = 16;

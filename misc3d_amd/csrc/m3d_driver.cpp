@@ -329,8 +329,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                        (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr);   // clears ub[0 .. h_pad) on the way
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
-    else
-        HIPCHK(hipMemsetAsync(ctx->counts_rep.p, 0, sizeof(uint32_t) * ((size_t)kCountReplicas * h_pad + kPairReplicas), ctx->stream));
+    // (culled path: keep_mask_k clears the counter replicas on its way)
     if (dense) {
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
@@ -347,7 +346,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         auto* keep = ctx->keep.as<unsigned long long>();
         launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
                          /*ub_is_zero=*/true);
-        launch_keep_mask(ub, prune ? ctx->best_count.as<uint32_t>() : nullptr, n_groups, keep, ctx->stream);
+        launch_keep_mask(ub, prune ? ctx->best_count.as<uint32_t>() : nullptr, n_groups, keep, ctx->stream,
+                         ctx->counts_rep.as<uint32_t>(), h_pad);
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
         launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
