@@ -1411,7 +1411,7 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     tsrc.m = sampler->src.m;
     size_t out = 0;
     struct Pending {
-        bool active = false;
+        bool active = false, discard = false;
         size_t out_pos = 0, n = 0;
     } pend[2];
     int cur = 0;
@@ -1419,16 +1419,37 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
         if (!pend[k].active) return M3D_OK;
         ChunkSlot& s = ctx->slot[k];
         HIPCHK(hipEventSynchronize(s.done));
-        unpack_slot(s);
-        std::memcpy(counts + pend[k].out_pos, s.h_counts.p, sizeof(uint32_t) * pend[k].n);
-        std::memcpy(valid + pend[k].out_pos, s.h_valid.p, pend[k].n);
-        pend[k].active = false;
+        if (!pend[k].discard) {
+            unpack_slot(s);
+            std::memcpy(counts + pend[k].out_pos, s.h_counts.p, sizeof(uint32_t) * pend[k].n);
+            std::memcpy(valid + pend[k].out_pos, s.h_valid.p, pend[k].n);
+        }
+        pend[k].active = pend[k].discard = false;
         return M3D_OK;
     };
     size_t j = 0;
     bool first_piece = true;
     RESERVE(ctx->best_count, 16);
     if (begin == 0) HIPCHK(hipMemsetAsync(ctx->best_count.p, 0, sizeof(uint32_t), ctx->stream));  // new fit
+    // A rank whose first slice starts late in the window does not wait for the host to walk the stream up to it
+    // before the GPU gets work: the window's FIRST 256 hypotheses (another rank's, lower in the sequence than
+    // anything this rank owns -- exactly what bound-and-prune may use) are scored at once for their best count
+    // only; their records are dropped (the owner reports them).  The rank's own slice then goes in one pruned
+    // launch instead of 256 + rest.
+    {
+        const size_t first_own = begin + (size_t)rank * slice;
+        if (rank > 0 && first_own < end) {
+            const size_t w = std::min<size_t>(std::min<size_t>(256, chunk_cap), first_own - begin);
+            sampler->draw_until(begin + w);
+            tsrc.table = sampler->table.data();
+            const int rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, begin, begin + w, tsrc, nullptr, true);
+            if (rc != M3D_OK) return rc;
+            pend[cur].active = pend[cur].discard = true;
+            pend[cur].n = w;
+            cur ^= 1;
+            first_piece = false;
+        }
+    }
     for (size_t b = begin; b < end; b += slice, ++j) {
         const size_t e = std::min(end, b + slice);
         // every rank draws the whole stream (the host draws the other ranks' slices while this rank's
