@@ -50,17 +50,38 @@ def _world(group):
     return 1, 0, False
 
 
+_AG_CACHE = {}
+
+
 def _all_gather_records(rec, group, device):
-    """all_gather of equal-length int32 record arrays -> (world, len) uint32 array."""
+    """all_gather of equal-length int32 record arrays -> (world, len) uint32 array.  On a GPU group the staging
+    tensors (pinned host in / out, device in / out) are kept per (length, world, device): a fit exchanges a few
+    tens of KB once or twice, so allocations and pageable copies would be most of the cost."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    t = torch.from_numpy(rec.view(np.int32))
-    if device is not None:
-        t = t.to(device)
-    out = torch.empty(world * len(rec), dtype=torch.int32, device=t.device)
-    dist.all_gather_into_tensor(out, t, group=group)
-    return out.cpu().numpy().view(np.uint32).reshape(world, len(rec))
+    n = len(rec)
+    if device is None:
+        t = torch.from_numpy(rec.view(np.int32))
+        out = torch.empty(world * n, dtype=torch.int32)
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out.numpy().view(np.uint32).reshape(world, n)
+    key = (n, world, str(device))
+    bufs = _AG_CACHE.get(key)
+    if bufs is None:
+        if len(_AG_CACHE) > 16:
+            _AG_CACHE.clear()
+        bufs = (torch.empty(n, dtype=torch.int32).pin_memory(), torch.empty(n, dtype=torch.int32, device=device),
+                torch.empty(world * n, dtype=torch.int32, device=device),
+                torch.empty(world * n, dtype=torch.int32).pin_memory())
+        _AG_CACHE[key] = bufs
+    src_pin, src_dev, out_dev, out_pin = bufs
+    src_pin.numpy()[:] = rec.view(np.int32)
+    src_dev.copy_(src_pin, non_blocking=True)
+    dist.all_gather_into_tensor(out_dev, src_dev, group=group)
+    out_pin.copy_(out_dev, non_blocking=True)
+    torch.cuda.current_stream(device).synchronize()
+    return out_pin.numpy().view(np.uint32).reshape(world, n)
 
 
 def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, probability=0.9999, seed=0,
