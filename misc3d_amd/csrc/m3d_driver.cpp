@@ -503,12 +503,20 @@ static bool sphere_from_moments(const double* mean, const double* s, double n, d
 }
 
 // m3d_host_alloc registry: is [p, p + bytes) inside a page-locked block handed out by this library?
-static std::mutex g_pinned_mu;
-static std::vector<std::pair<const char*, size_t>> g_pinned;
+// (never destroyed: m3d_host_free may still be called from a host language's finalisers at process exit)
+struct PinnedRegistry {
+    std::mutex mu;
+    std::vector<std::pair<const char*, size_t>> blocks;
+};
+static PinnedRegistry& pinned_registry() {
+    static PinnedRegistry* r = new PinnedRegistry();
+    return *r;
+}
 static bool is_library_pinned(const void* p, size_t bytes) {
-    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    PinnedRegistry& r = pinned_registry();
+    std::lock_guard<std::mutex> lock(r.mu);
     const char* q = static_cast<const char*>(p);
-    for (const auto& b : g_pinned)
+    for (const auto& b : r.blocks)
         if (q >= b.first && q + bytes <= b.first + b.second) return true;
     return false;
 }
@@ -1211,17 +1219,19 @@ void* m3d_host_alloc(size_t bytes) {
         set_error("hipHostMalloc failed (" + std::to_string(bytes) + " bytes)");
         return nullptr;
     }
-    std::lock_guard<std::mutex> lock(g_pinned_mu);
-    g_pinned.emplace_back(static_cast<const char*>(p), std::max<size_t>(bytes, 1));
+    PinnedRegistry& r = pinned_registry();
+    std::lock_guard<std::mutex> lock(r.mu);
+    r.blocks.emplace_back(static_cast<const char*>(p), std::max<size_t>(bytes, 1));
     return p;
 }
 void m3d_host_free(void* p) {
     if (!p) return;
     {
-        std::lock_guard<std::mutex> lock(g_pinned_mu);
-        for (size_t i = 0; i < g_pinned.size(); ++i)
-            if (g_pinned[i].first == p) {
-                g_pinned.erase(g_pinned.begin() + (long)i);
+        PinnedRegistry& r = pinned_registry();
+        std::lock_guard<std::mutex> lock(r.mu);
+        for (size_t i = 0; i < r.blocks.size(); ++i)
+            if (r.blocks[i].first == p) {
+                r.blocks.erase(r.blocks.begin() + (long)i);
                 break;
             }
     }
