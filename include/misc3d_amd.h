@@ -121,7 +121,9 @@ int m3d_cloud_score_range(m3d_cloud *cloud, int kind, double threshold, const ui
  * stream: the window is cut into slices of `slice` hypotheses, slice j belongs to rank j % world.
  * Every rank draws the whole window (identical tables everywhere), kernels for this rank's slices are
  * launched as soon as their samples exist, so drawing the other ranks' slices overlaps GPU scoring.
- * counts/valid receive this rank's records in increasing hypothesis order, *n_mine their number. */
+ * counts/valid receive this rank's records in increasing hypothesis order, *n_mine their number.
+ * valid == NULL: counts[i] carries MinimalFit's return in bit 31 (counts are < 2^31) -- the 4-byte record the
+ * ranks exchange; m3d_replay_chunk accepts the same form (valid == NULL). */
 typedef struct m3d_sampler m3d_sampler;
 m3d_sampler *m3d_sampler_create(size_t n_points, int kind, uint64_t seed);
 void m3d_sampler_destroy(m3d_sampler *s);
@@ -153,7 +155,8 @@ int m3d_cloud_remove_inliers(m3d_cloud *cloud, int kind, double threshold, const
                              size_t *n_removed);
 /* Sequential replay of the best-update / adaptive-stop rule (ransac.h:573-575,592-613) over
  * per-hypothesis (valid, count) records in index order; `rmse_cb` is called only for fitness ties.
- * Pure host logic, usable by distributed drivers after gathering counts. */
+ * Pure host logic, usable by distributed drivers after gathering counts.  valid == NULL: counts[i] carries
+ * the valid flag in bit 31 (m3d_cloud_score_shard's packed form). */
 typedef double (*m3d_rmse_fn)(void *user, size_t hypothesis_index);
 typedef struct m3d_replay_state {
     double best_fitness, best_rmse;

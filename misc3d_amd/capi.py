@@ -270,6 +270,14 @@ class Cloud:
     def make_sampler(self, kind, seed):
         return Sampler(self.n, kind, seed)
 
+    def score_shard_packed(self, sampler, threshold, begin, end, slice_, world, rank):
+        """m3d_cloud_score_shard with valid == NULL -> uint32 records (valid << 31 | count) of this rank's hypotheses."""
+        rec = np.empty(max(end - begin, 1), dtype=np.uint32)
+        n = C.c_size_t(0)
+        _check(lib().m3d_cloud_score_shard(self._h, sampler._h, threshold, begin, end, slice_, world, rank, _p(rec),
+                                           None, C.cast(C.byref(n), C.c_void_p)))
+        return rec[: n.value]
+
     def score_shard(self, sampler, threshold, begin, end, slice_, world, rank):
         """m3d_cloud_score_shard -> (valid, counts) of this rank's hypotheses in [begin, end)."""
         cap = end - begin

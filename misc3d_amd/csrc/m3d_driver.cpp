@@ -191,10 +191,12 @@ static uint64_t double_to_size_t_x86(double v) {
 
 // tie(i, cnt, &trial_rmse, &trial_rmse_known) decides `inlier_rmse < inlier_rmse_` (ransac.h:596) for a
 // trial whose fitness EQUALS the best one; it may fill st->best_rmse when it had to evaluate it.
+// valid == nullptr: counts[k] carries MinimalFit's return in bit 31 (the form the scoring kernels ship).
 template <class TieFn, class BestFn>
 static void replay_range(m3d_replay_state* st, size_t n_points, int kind, size_t max_iteration,
                          double probability, size_t begin, size_t end, const uint8_t* valid,
                          const uint32_t* counts, TieFn tie, BestFn on_best) {
+    const bool packed = valid == nullptr;
     const int m = minimal_sample(kind);
     for (size_t i = begin; i < end; ++i) {
         if (st->stopped) return;
@@ -204,8 +206,8 @@ static void replay_range(m3d_replay_state* st, size_t n_points, int kind, size_t
         }
         st->iterations = i + 1;
         const size_t k = i - begin;
-        if (!valid[k]) continue;  // ransac.h:584-586 (no count++)
-        const uint32_t cnt = counts[k];
+        if (!(packed ? (counts[k] >> 31) != 0u : valid[k] != 0)) continue;  // ransac.h:584-586 (no count++)
+        const uint32_t cnt = packed ? (counts[k] & 0x7FFFFFFFu) : counts[k];
         if (cnt < st->best_count) {   // fitness = cnt / N is strictly monotone in cnt (N < 2^31): cannot be better or tie
             st->count++;
             continue;
@@ -1403,8 +1405,7 @@ const uint32_t* m3d_sampler_table(m3d_sampler* s, size_t n_hypotheses) {
 int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, size_t begin, size_t end,
                           size_t slice, uint32_t world, uint32_t rank, uint32_t* counts, uint8_t* valid,
                           size_t* n_mine) {
-    if (!c || !sampler || !counts || !valid || !n_mine || end < begin || slice == 0 || world == 0 ||
-        rank >= world)
+    if (!c || !sampler || !counts || !n_mine || end < begin || slice == 0 || world == 0 || rank >= world)
         return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     const int kind = sampler->kind;
     if (kind == M3D_CYLINDER && !c->has_normals)
@@ -1430,9 +1431,18 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
         ChunkSlot& s = ctx->slot[k];
         HIPCHK(hipEventSynchronize(s.done));
         if (!pend[k].discard) {
-            unpack_slot(s);
-            std::memcpy(counts + pend[k].out_pos, s.h_counts.p, sizeof(uint32_t) * pend[k].n);
-            std::memcpy(valid + pend[k].out_pos, s.h_valid.p, pend[k].n);
+            if (valid) {
+                unpack_slot(s);
+                std::memcpy(counts + pend[k].out_pos, s.h_counts.p, sizeof(uint32_t) * pend[k].n);
+                std::memcpy(valid + pend[k].out_pos, s.h_valid.p, pend[k].n);
+            } else if (!use_dense_scoring()) {   // records as shipped: valid << 31 | count
+                std::memcpy(counts + pend[k].out_pos, s.h_counts.p, sizeof(uint32_t) * pend[k].n);
+            } else {
+                const uint32_t* hc = s.h_counts.as<uint32_t>();
+                const uint8_t* hv = s.h_valid.as<uint8_t>();
+                for (size_t i = 0; i < pend[k].n; ++i)
+                    counts[pend[k].out_pos + i] = hc[i] | (hv[i] ? 0x80000000u : 0u);
+            }
         }
         pend[k].active = pend[k].discard = false;
         return M3D_OK;

@@ -125,18 +125,24 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
     # slices per rank, which hid the slower word-by-word sampler, costs more in extra launches than it hides
     # (tools/time_shard_rank.py: world 8, rank 7: 0.48 ms against 0.50 ms; world 2: 0.38 against 0.45)
     K = 1
+    packed = hasattr(scorer, "score_shard_packed")
     while begin < H and not st.stopped:
         end = min(H, begin + window)
         n_win = end - begin
         sl = slice_size if slice_size else max(64, -(-n_win // (K * world)))
         n_slices = -(-n_win // sl)
         k_loc = -(-n_slices // world)             # slices per rank (padded)
-        v, c = scorer.score_shard(sampler, threshold, begin, end, sl, world, rank)
-        scored += len(c)
         # local records laid out as k_loc slices of `sl` (only the globally last slice can be short,
         # and slices a rank does not own sit at the tail): zero padding lands beyond `end`
         rec = np.zeros(k_loc * sl, dtype=np.uint32)
-        rec[: len(c)] = c | (v.astype(np.uint32) << np.uint32(31))      # counts < 2^31
+        if packed:                                   # the C ABI ships and replays (valid << 31 | count) as is
+            mine = scorer.score_shard_packed(sampler, threshold, begin, end, sl, world, rank)
+            rec[: len(mine)] = mine
+            scored += len(mine)
+        else:
+            v, c = scorer.score_shard(sampler, threshold, begin, end, sl, world, rank)
+            scored += len(c)
+            rec[: len(c)] = c | (v.astype(np.uint32) << np.uint32(31))      # counts < 2^31
         if have_pg:
             allrec = _all_gather_records(rec, group, device)             # (world, k_loc * sl)
             collectives += 1
@@ -144,11 +150,16 @@ def fit_sharded(scorer, n_points, kind, threshold=0.01, max_iteration=1000, prob
             allrec = rec.reshape(1, -1)
         # slice j = (local slice j // world of rank j % world)  ->  global hypothesis order
         g = np.ascontiguousarray(allrec.reshape(world, k_loc, sl).transpose(1, 0, 2)).reshape(-1)[:n_win]
-        gv = (g >> np.uint32(31)).astype(np.uint8)
-        gc = g & np.uint32(0x7FFFFFFF)
         prev_best = st.best_index
-        capi.lib().m3d_replay_chunk(C.byref(st), n_points, kind, H, probability, begin, end,
-                                    gv.ctypes.data_as(C.c_void_p), gc.ctypes.data_as(C.c_void_p), cb, None)
+        if packed:
+            g = np.ascontiguousarray(g)
+            capi.lib().m3d_replay_chunk(C.byref(st), n_points, kind, H, probability, begin, end, None,
+                                        g.ctypes.data_as(C.c_void_p), cb, None)
+        else:
+            gv = (g >> np.uint32(31)).astype(np.uint8)
+            gc = g & np.uint32(0x7FFFFFFF)
+            capi.lib().m3d_replay_chunk(C.byref(st), n_points, kind, H, probability, begin, end,
+                                        gv.ctypes.data_as(C.c_void_p), gc.ctypes.data_as(C.c_void_p), cb, None)
         if st.best_index != prev_best:           # keep the best model across windows
             bi = int(st.best_index)
             best_model = None

@@ -92,3 +92,24 @@ def test_replay_matches_oracle_driver(capi, orc):
         assert st.count == r.count
         assert st.iterations == r.iterations
         assert st.best_fitness == r.fitness
+
+
+def test_replay_accepts_packed_records(capi):
+    """valid == NULL: counts carry MinimalFit's return in bit 31 (the record the ranks exchange)"""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    n, H = 5000, 700
+    valid = (rng.random(H) < 0.9).astype(np.uint8)
+    counts = rng.integers(0, n // 2, H).astype(np.uint32)
+    counts[rng.integers(0, H, 40)] = counts.max()            # fitness ties -> the rmse callback is exercised
+    rmse = lambda i: float((i * 2654435761) % 1000) / 1000.0
+    for prob, mi in ((0.99, H), (1.0, H), (0.9999, 300)):
+        a = capi.replay(n, capi.PLANE, mi, prob, valid[:mi], counts[:mi], rmse)
+        st = capi.ReplayState()
+        capi.lib().m3d_replay_init(C.byref(st))
+        packed = np.ascontiguousarray(counts[:mi] | (valid[:mi].astype(np.uint32) << np.uint32(31)))
+        cb = capi.RMSE_FN(lambda _u, i: rmse(int(i)))
+        capi.lib().m3d_replay_chunk(C.byref(st), n, capi.PLANE, mi, prob, 0, mi, None,
+                                    packed.ctypes.data_as(C.c_void_p), cb, None)
+        for f, _ in capi.ReplayState._fields_:
+            assert getattr(a, f) == getattr(st, f), (prob, f)

@@ -13,7 +13,7 @@ def wrap(obj, name):
     def g(*a, **k):
         t = time.perf_counter(); r = f(*a, **k); T[name] = T.get(name, 0.0) + time.perf_counter() - t; return r
     setattr(obj, name, g)
-for n in ("make_sampler", "score_shard", "score_range", "refine", "exact_error"):
+for n in ("make_sampler", "score_shard", "score_shard_packed", "score_range", "refine", "exact_error"):
     wrap(c, n)
 for _ in range(3):
     distributed.fit_sharded(c, N, 0, 0.01, H, 1.0, 11, copy=False)
