@@ -309,9 +309,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     RESERVE(s.score, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
     RESERVE(s.params, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
     RESERVE(s.valid, (size_t)h_pad + 1);
-    RESERVE(s.counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // + the launch's pair counter behind the counts
+    if (dense) RESERVE(s.counts, sizeof(uint32_t) * (size_t)h_pad);   // (culled path: records go straight to h_counts)
     RESERVE(s.h_samples, sizeof(uint32_t) * (size_t)count * m);
-    RESERVE(s.h_counts, sizeof(uint32_t) * ((size_t)h_pad + 1));
+    RESERVE(s.h_counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // + the launch's pair counter behind the counts
     RESERVE(s.h_valid, (size_t)h_pad + 1);
     if (dense) {
         RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
@@ -371,8 +371,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     return M3D_OK;
 }
 
-// After the slot's `done` event: the culled path ships (valid << 31 | count) in one array (one D2H copy per
-// chunk); split it into the h_valid / h_counts views the replay and the callers read.
+// After the slot's `done` event: the culled path ships (valid << 31 | count) in one array (written by
+// sum_replicas_k straight into the pinned h_counts); split it into the h_valid / h_counts views the replay and
+// the callers read.
 static void unpack_slot(ChunkSlot& s) {
     if (use_dense_scoring()) return;
     uint32_t* c = s.h_counts.as<uint32_t>();
