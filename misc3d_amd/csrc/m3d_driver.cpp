@@ -661,7 +661,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
 
 // ------------------------------------------------------------------------------------------------
 // RANSAC::FitModelParallel on a resident view.  Leaves the best minimal model in
-// ctx->best_params (device) and on its way to ctx->h_best (pinned host; valid after the next stream wait).
+// device memory at ctx->last_best_dev; RefineModel's first kernel forwards it to ctx->h_best (pinned host).
 // ------------------------------------------------------------------------------------------------
 struct RansacOut {
     m3d_replay_state st;
@@ -714,10 +714,19 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     size_t next_begin = 0;
     double best_approx = 0, pending_approx = 0;  // tree error sums of the current best / the trial
     bool best_approx_known = false, pending_valid = false;
-    const double* best_dev = ctx->best_params.as<double>();  // device copy of the current best model
-    bool best_in_chunk = false;
+    // device address of the current best model: inside the params of the slot whose chunk produced it, until
+    // that slot is about to be re-issued -- only then is it copied to ctx->best_params (a fit of one or two
+    // chunks never needs the copy; RefineModel reads the record where it lies)
+    const double* best_dev = ctx->best_params.as<double>();
+    int best_slot = -1;
     // in_flight: hypotheses already issued whose records have not been replayed yet
     auto issue_next = [&](int slot_id, size_t in_flight, size_t forced = 0) -> int {
+        if (slot_id == best_slot) {   // the slot holding the best model is recycled: move the record out first
+            HIPCHK(hipMemcpyAsync(ctx->best_params.p, best_dev, sizeof(double) * kModelStride, hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+            best_dev = ctx->best_params.as<double>();
+            best_slot = -1;
+        }
         size_t want = chunk;
         if (forced) {
             want = forced;
@@ -833,22 +842,15 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 return false;
             };
             auto on_best = [&](size_t i) {
-                // the model stays in the chunk's slot while the chunk is replayed; ONE device copy per
-                // chunk (below) moves the final best into ctx->best_params
+                // the model stays in the chunk's slot (issue_next moves it out before the slot is recycled)
                 best_dev = s.params.as<double>() + (i - s.begin) * kModelStride;
-                best_in_chunk = true;
+                best_slot = cur;
                 best_approx_known = pending_valid;
                 best_approx = pending_approx;
                 pending_valid = false;
             };
             replay_range(&out->st, v.n, kind, max_iter, prob, s.begin, s.end, s.h_valid.as<uint8_t>(),
                          s.h_counts.as<uint32_t>(), tie, on_best);
-            if (best_in_chunk) {
-                (void)hipMemcpyAsync(ctx->best_params.p, best_dev, sizeof(double) * kModelStride,
-                                     hipMemcpyDeviceToDevice, ctx->stream);
-                best_dev = ctx->best_params.as<double>();
-                best_in_chunk = false;
-            }
             if (cb_rc != M3D_OK) {
                 rc = cb_rc;
                 break;
@@ -862,6 +864,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             cur ^= 1;
         }
     }
+    ctx->last_best_dev = best_dev;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     // The best minimal model travels to the host (pinned ctx->h_best) with RefineModel: its first kernel stores the
     // record there and RefineModel's own wait delivers it (no wait and no copy command here).
@@ -912,7 +915,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     double model[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};   // filled from ctx->h_best by refine's wait
     size_t ni = 0;
     int gf_ok = 1;
-    rc = refine(ctx, v, gather, orig, kind, thr, ctx->best_params.as<double>(), model, inliers, &ni,
+    rc = refine(ctx, v, gather, orig, kind, thr, ctx->last_best_dev, model, inliers, &ni,
                 &gf_ok, ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1, before_refine_wait,
                 ctx->h_best.as<double>());
     if (rc != M3D_OK) return rc;
@@ -1666,7 +1669,7 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
             const std::function<int(int64_t)> issue_removal = [&](int64_t expected_ni) -> int {
                 if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) return M3D_OK;
                 removal_issued = true;
-                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->best_params.as<double>());
+                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev);
             };
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
                                   cluster_indices + off, &ni, nullptr, &issue_removal, &iterations_hint);
@@ -1682,10 +1685,10 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
             k++;
             if (count >= target || k >= max_clusters) break;
             // pcd_copy = pcd_copy->SelectByIndex(inliers, true), :33 -- inliers of the PRE-refinement model,
-            // still in ctx->best_params
+            // still on the device (ctx->last_best_dev)
             size_t removed = 0;
             rc = removal_issued ? cloud_remove_finish(c0, &removed)
-                                : cloud_remove_locked(c0, M3D_PLANE, threshold, ctx->best_params.as<double>(), &removed);
+                                : cloud_remove_locked(c0, M3D_PLANE, threshold, ctx->last_best_dev, &removed);
             if (rc != M3D_OK) break;
             if (removed != ni) {
                 rc = fail(M3D_ERR_INTERNAL, "removed points and inlier list disagree");

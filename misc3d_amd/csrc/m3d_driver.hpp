@@ -62,6 +62,7 @@ struct DeviceCtx {
     DevBuf ub, best_count;     // bound-and-prune: surviving tiles per hypothesis, running best count
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
+    const double* last_best_dev = nullptr;   // device address of the last fit's best minimal model (a slot's params or best_params)
     PinBuf h_best;             // best minimal model of a fit on its way to the host (read after RefineModel's wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
