@@ -171,27 +171,30 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
 __global__ __launch_bounds__(64) void keep_mask_k(const uint32_t* __restrict__ ub,
                                                    const uint32_t* __restrict__ best_count_ptr,
                                                    unsigned long long* __restrict__ keep,
-                                                   uint32_t* __restrict__ zero, uint32_t rep_stride) {
-    const uint32_t h = blockIdx.x * 64u + threadIdx.x;
+                                                   uint32_t* __restrict__ zero, uint32_t rep_stride,
+                                                   uint32_t group_offset) {
+    const uint32_t g = group_offset + blockIdx.x;
+    const uint32_t h = g * 64u + threadIdx.x;
     const uint32_t best = best_count_ptr ? best_count_ptr[0] : 0u;
     const bool k = !ub || best == 0 || (uint64_t)ub[h] * kTilePoints >= best;
     const unsigned long long m = __ballot(k);
-    if (threadIdx.x == 0) keep[blockIdx.x] = m;
+    if (threadIdx.x == 0) keep[g] = m;
     if (zero) {
 #pragma unroll
         for (int r = 0; r < kCountReplicas; ++r) zero[(size_t)r * rep_stride + h] = 0u;
-        if (blockIdx.x == 0)
+        if (g == 0)
             for (int i = threadIdx.x; i < kPairReplicas; i += 64) zero[(size_t)kCountReplicas * rep_stride + i] = 0u;
     }
 }
+// groups [group_offset, group_offset + n_groups) of the chunk
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
-                      hipStream_t st, uint32_t* zero_counts_rep, uint32_t rep_stride) {
+                      hipStream_t st, uint32_t* zero_counts_rep, uint32_t rep_stride, uint32_t group_offset) {
     if (!n_groups) return;
     if (!ub && !zero_counts_rep) {
-        (void)hipMemsetAsync(keep, 0xFF, sizeof(unsigned long long) * n_groups, st);
+        (void)hipMemsetAsync(keep + group_offset, 0xFF, sizeof(unsigned long long) * n_groups, st);
         return;
     }
-    keep_mask_k<<<n_groups, 64, 0, st>>>(ub, best_count, keep, zero_counts_rep, rep_stride);
+    keep_mask_k<<<n_groups, 64, 0, st>>>(ub, best_count, keep, zero_counts_rep, rep_stride, group_offset);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,18 +206,20 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
                                                     const double* __restrict__ score,
                                                     const unsigned long long* __restrict__ masks,
                                                     const unsigned long long* __restrict__ keep,
-                                                    uint32_t n_groups, uint32_t groups_per_block,
+                                                    uint32_t n_groups /* of the chunk: row length of masks */,
+                                                    uint32_t groups_per_block,
                                                     uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
-                                                    uint32_t* __restrict__ pair_rep) {
+                                                    uint32_t* __restrict__ pair_rep,
+                                                    uint32_t group_begin, uint32_t group_end /* window of this launch */) {
     const uint32_t tile = blockIdx.x;
     // ~430 tiles add to every hypothesis' counter: kCountReplicas copies of the counter array (tile mod R)
     // keep the same-address atomic chains short (they serialise in L2 and dominated small chunks)
     uint32_t* __restrict__ counts = counts_rep + (size_t)(tile % kCountReplicas) * rep_stride;
-    const uint32_t g0 = blockIdx.y * groups_per_block;
+    const uint32_t g0 = group_begin + blockIdx.y * groups_per_block;
     const int lane = threadIdx.x;
     // lane l holds the (pruned) mask of group g0 + l; walking the bits is scalar work (readlane)
     unsigned long long mm = 0;
-    if ((uint32_t)lane < groups_per_block && g0 + lane < n_groups)
+    if ((uint32_t)lane < groups_per_block && g0 + lane < group_end)
         mm = masks[(size_t)tile * n_groups + g0 + lane] & keep[g0 + lane];
     if (!__ballot(mm != 0)) return;  // most (tile, range) blocks of a pruned chunk end here
     const size_t base = (size_t)tile * kTilePoints + lane;
@@ -308,8 +313,8 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
 __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t rep_stride, uint32_t h_pad,
                                uint32_t* __restrict__ counts, const uint32_t* __restrict__ pair_rep,
                                uint32_t pairs_slot, const uint8_t* __restrict__ valid, uint32_t h_count,
-                               uint32_t* __restrict__ best_count) {
-    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+                               uint32_t* __restrict__ best_count, uint32_t h_begin) {
+    const uint32_t h = h_begin + blockIdx.x * 256u + threadIdx.x;   // window [h_begin, h_pad) of the chunk
     if (blockIdx.x == 0 && pair_rep) {   // block-uniform
         __shared__ uint32_t red[256];
         uint32_t p = 0;
@@ -338,28 +343,30 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
 }
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
-                         uint32_t* best_count, hipStream_t st) {
-    if (h_pad)
-        sum_replicas_k<<<(h_pad + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_pad, counts, pair_rep, pairs_slot,
-                                                             valid, h_count, best_count);
+                         uint32_t* best_count, hipStream_t st, uint32_t h_begin) {
+    if (h_pad > h_begin)
+        sum_replicas_k<<<(h_pad - h_begin + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_pad, counts, pair_rep,
+                                                                      pairs_slot, valid, h_count, best_count, h_begin);
 }
 
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
-                       uint32_t* pair_rep, hipStream_t st) {
-    if (!s.n_tiles || !n_groups) return;
+                       uint32_t* pair_rep, hipStream_t st, uint32_t group_begin, uint32_t group_end) {
+    group_end = std::min(group_end, n_groups);
+    if (!s.n_tiles || group_begin >= group_end) return;
+    const uint32_t window = group_end - group_begin;
     // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
-    const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerBlock, (uint32_t)(((uint64_t)s.n_tiles * n_groups) / 16384)));
-    const dim3 g(s.n_tiles, (n_groups + gpb - 1) / gpb), b(64);
+    const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerBlock, (uint32_t)(((uint64_t)s.n_tiles * window) / 16384)));
+    const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);
     if (kind == 0)
         score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
-                                         pair_rep);
+                                         pair_rep, group_begin, group_end);
     else if (kind == 1)
         score_mask_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
-                                         pair_rep);
+                                         pair_rep, group_begin, group_end);
     else
         score_mask_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
-                                         pair_rep);
+                                         pair_rep, group_begin, group_end);
 }
 
 // best_count[0] = max(best_count[0], max over valid hypotheses of counts[h])

@@ -28,7 +28,8 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
 // keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
 // zero_counts_rep != null: the same launch clears the kCountReplicas x rep_stride + kPairReplicas counter words.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
-                      hipStream_t st, uint32_t* zero_counts_rep = nullptr, uint32_t rep_stride = 0);
+                      hipStream_t st, uint32_t* zero_counts_rep = nullptr, uint32_t rep_stride = 0,
+                      uint32_t group_offset = 0 /* the launch covers groups [group_offset, group_offset + n_groups) */);
 // counts_rep[tile % kCountReplicas][h] += inliers of hypothesis h in the tiles whose (mask & keep) bit is set;
 // counts_rep (kCountReplicas x rep_stride u32) zero on entry; launch_sum_replicas folds the replicas.
 constexpr int kCountReplicas = 16;
@@ -37,14 +38,15 @@ constexpr int kCountReplicas = 16;
 constexpr int kPairReplicas = 1024;
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
-                       uint32_t* pair_rep /* 64 u32, zero on entry: evaluated (tile, hypothesis) pairs */, hipStream_t st);
+                       uint32_t* pair_rep /* kPairReplicas u32, zero on entry: evaluated (tile, hypothesis) pairs */,
+                       hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */);
 // pair_rep != null: counts[pairs_slot] receives the sum of the pair counters (pairs_slot must be >= the number of
 // real hypotheses; that entry is then not a hypothesis count)
 // valid != null: counts[h] |= valid[h] << 31 for h < h_count; best_count != null: atomic running maximum of the
 // valid hypotheses' counts (what launch_max_count does as a separate launch)
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
-                         uint32_t* best_count, hipStream_t st);
+                         uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_pad) */);
 void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
                       hipStream_t st);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,

@@ -124,7 +124,8 @@ DeviceCtx* get_ctx(int device) {
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     for (int k = 0; k < 2 && ok; ++k)
         ok = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreate(&c->slot[k].k0) == hipSuccess && hipEventCreate(&c->slot[k].k1) == hipSuccess;
+             hipEventCreate(&c->slot[k].k0) == hipSuccess && hipEventCreate(&c->slot[k].k1) == hipSuccess &&
+             hipEventCreate(&c->slot[k].k2) == hipSuccess && hipEventCreate(&c->slot[k].k3) == hipSuccess;
     if (!ok) {
         set_error("failed to create HIP stream/events");
         delete c;
@@ -296,7 +297,7 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
 
 static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const SortedView& sv, int kind,
                        double thr, size_t begin, size_t end, SampleSource& src, double* ms_sample,
-                       bool prune = false) {
+                       bool prune = false, uint32_t lead = 0) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const uint32_t h_pad = round_up(count, 64);
@@ -348,18 +349,34 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         auto* keep = ctx->keep.as<unsigned long long>();
         launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
                          /*ub_is_zero=*/true);
-        launch_keep_mask(ub, prune ? ctx->best_count.as<uint32_t>() : nullptr, n_groups, keep, ctx->stream,
-                         ctx->counts_rep.as<uint32_t>(), h_pad);
-        HIPCHK(hipEventRecord(s.k0, ctx->stream));
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
+        uint32_t* bc = prune ? ctx->best_count.as<uint32_t>() : nullptr;
+        // lead > 0 (a fit's first chunk): the first `lead` hypotheses are counted on their own, and their best
+        // count then prunes the rest of the SAME chunk -- what a separate small first chunk did, without its
+        // own sample copy, MinimalFit and box-test launches.  The records are complete after the second pass.
+        s.lead_groups = 0;
+        if (prune && lead >= 64 && lead % 64 == 0 && lead + 64 <= count) {
+            const uint32_t ga = lead / 64;
+            s.lead_groups = ga;
+            launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
+            HIPCHK(hipEventRecord(s.k2, ctx->stream));
+            launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
+                              h_pad, pair_rep, ctx->stream, 0, ga);
+            HIPCHK(hipEventRecord(s.k3, ctx->stream));
+            launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.h_counts.as<uint32_t>(), nullptr, count,
+                                s.valid.as<uint8_t>(), count, bc, ctx->stream, 0);
+        }
+        const uint32_t g_lo = s.lead_groups;
+        launch_keep_mask(ub, bc, n_groups - g_lo, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g_lo);
+        HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
-                          pair_rep, ctx->stream);
+                          pair_rep, ctx->stream, g_lo, n_groups);
         HIPCHK(hipEventRecord(s.k1, ctx->stream));
         // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
         // ... and writes the records straight into the slot's pinned host array (device-visible): no copy command
         // behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
         launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.h_counts.as<uint32_t>(), pair_rep, count,
-                            s.valid.as<uint8_t>(), count, prune ? ctx->best_count.as<uint32_t>() : nullptr, ctx->stream);
+                            s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u);
     }
     // counts of the chunk + (culled path) the number of (tile, hypothesis) pairs the launch evaluated
     if (dense)
@@ -690,16 +707,17 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
     // prob == 1: only fitness == 1 can stop it -> as few, equal chunks as the scratch cap allows
     // (one chunk up to 16384 hypotheses; more chunks are pipelined two deep)
-    // Either way the first chunk is small: its best inlier count is what lets the later chunks skip
-    // every hypothesis that cannot reach it (bound-and-prune in score_list_k).
+    // Either way an incumbent exists early -- a small first chunk (prob < 1) or the first 256 hypotheses of
+    // the first chunk counted in a pass of their own (prob == 1): its inlier count lets everything after it
+    // skip the hypotheses that cannot reach it (bound-and-prune).
     size_t chunk = 128;
     size_t growth = 2;
     size_t after_first = 0;  // prob == 1: size of the chunks after the first one
+    uint32_t lead = 0;   // prob == 1: leading hypotheses of the FIRST chunk counted on their own (issue_chunk)
     if (prob >= 1.0 && max_iter > 1024) {
-        chunk = 256;
-        const size_t rest = max_iter - chunk;
-        const size_t n_chunks = (rest + chunk_cap - 1) / chunk_cap;
-        after_first = ((rest + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+        const size_t n_chunks = (max_iter + chunk_cap - 1) / chunk_cap;
+        chunk = after_first = ((max_iter + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+        lead = 256;
     } else if (prob >= 1.0) {
         chunk = std::max<size_t>(max_iter, 64);
         growth = 1;
@@ -740,7 +758,8 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
         want = std::min(std::max<size_t>(want, 64), chunk_cap);
         const size_t b = next_begin, e = std::min(max_iter, b + want);
-        const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true);
+        const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
+                                  b == 0 ? lead : 0);
         if (r == M3D_OK) {
             next_begin = e;
             out->hypotheses_scored += e - b;
@@ -778,6 +797,10 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             {
                 float kms = 0;
                 if (hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess) {
+                    out->ms_score_kernel += kms;
+                    out->score_launches++;
+                }
+                if (s.lead_groups && hipEventElapsedTime(&kms, s.k2, s.k3) == hipSuccess) {
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
@@ -1483,18 +1506,17 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
             sampler->draw_until(e);
             continue;
         }
-        // the first piece of the call is small: its best count lets the rest skip hopeless hypotheses
-        // (bound-and-prune against LOWER-index hypotheses of this rank only, which is what the
-        // sequential replay allows; the rank's first hypothesis index is its smallest)
+        // bound-and-prune against LOWER-index hypotheses only, which is what the sequential replay allows
         for (size_t bb = b; bb < e;) {
-            const size_t piece = first_piece ? std::min<size_t>(256, chunk_cap) : chunk_cap;
+            // the first launch of the call counts its first 256 hypotheses on their own (issue_chunk's `lead`)
+            const uint32_t lead = first_piece ? 256u : 0u;
             first_piece = false;
-            const size_t ee = std::min(e, bb + piece);
+            const size_t ee = std::min(e, bb + chunk_cap);
             sampler->draw_until(ee);
             int rc = collect(cur);
             if (rc != M3D_OK) return rc;
             tsrc.table = sampler->table.data();
-            rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, bb, ee, tsrc, nullptr, true);
+            rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, bb, ee, tsrc, nullptr, true, lead);
             if (rc != M3D_OK) return rc;
             pend[cur].active = true;
             pend[cur].out_pos = out;

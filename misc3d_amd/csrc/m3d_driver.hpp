@@ -46,6 +46,8 @@ struct ChunkSlot {
     PinBuf h_samples, h_counts, h_valid;
     hipEvent_t done = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the scoring kernel of the chunk (m3d_stats.ms_score_kernel)
+    hipEvent_t k2 = nullptr, k3 = nullptr;  // around the scoring launch of the chunk's leading hypotheses (lead_groups > 0)
+    uint32_t lead_groups = 0;
     size_t begin = 0, end = 0;
     uint32_t h_pad = 0;
 };
