@@ -285,6 +285,16 @@ static bool use_dense_scoring() {
     return dense;
 }
 
+// Hypotheses at the head of a probability-1 fit that are counted first, for the incumbent that prunes the rest.
+static uint32_t lead_size() {
+    static const uint32_t lead = [] {
+        const char* e = std::getenv("M3D_LEAD");   // tuning knob (multiple of 64)
+        const long v = e ? std::atol(e) : 0;
+        return (uint32_t)(v >= 64 && v % 64 == 0 ? v : 128);   // sweep on C2: 64 and 128 equal, 256 +2.5 %, 512 +4 %
+    }();
+    return lead;
+}
+
 static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
     // keep the per-chunk scratch below 1 GiB (dense: u32 partial count per (tile, hypothesis);
     // culled: one bit per (tile, hypothesis))
@@ -707,7 +717,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
     // prob == 1: only fitness == 1 can stop it -> as few, equal chunks as the scratch cap allows
     // (one chunk up to 16384 hypotheses; more chunks are pipelined two deep)
-    // Either way an incumbent exists early -- a small first chunk (prob < 1) or the first 256 hypotheses of
+    // Either way an incumbent exists early -- a small first chunk (prob < 1) or the first hypotheses (lead_size()) of
     // the first chunk counted in a pass of their own (prob == 1): its inlier count lets everything after it
     // skip the hypotheses that cannot reach it (bound-and-prune).
     size_t chunk = 128;
@@ -717,7 +727,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     if (prob >= 1.0 && max_iter > 1024) {
         const size_t n_chunks = (max_iter + chunk_cap - 1) / chunk_cap;
         chunk = after_first = ((max_iter + n_chunks - 1) / n_chunks + 63) / 64 * 64;
-        lead = 256;
+        lead = lead_size();
     } else if (prob >= 1.0) {
         chunk = std::max<size_t>(max_iter, 64);
         growth = 1;
@@ -1479,14 +1489,14 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     RESERVE(ctx->best_count, 16);
     if (begin == 0) HIPCHK(hipMemsetAsync(ctx->best_count.p, 0, sizeof(uint32_t), ctx->stream));  // new fit
     // A rank whose first slice starts late in the window does not wait for the host to walk the stream up to it
-    // before the GPU gets work: the window's FIRST 256 hypotheses (another rank's, lower in the sequence than
+    // before the GPU gets work: the window's first hypotheses (lead_size()) (another rank's, lower in the sequence than
     // anything this rank owns -- exactly what bound-and-prune may use) are scored at once for their best count
     // only; their records are dropped (the owner reports them).  The rank's own slice then goes in one pruned
-    // launch instead of 256 + rest.
+    // launch.
     {
         const size_t first_own = begin + (size_t)rank * slice;
         if (rank > 0 && first_own < end) {
-            const size_t w = std::min<size_t>(std::min<size_t>(256, chunk_cap), first_own - begin);
+            const size_t w = std::min<size_t>(std::min<size_t>(lead_size(), chunk_cap), first_own - begin);
             sampler->draw_until(begin + w);
             tsrc.table = sampler->table.data();
             const int rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, begin, begin + w, tsrc, nullptr, true);
@@ -1508,8 +1518,8 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
         }
         // bound-and-prune against LOWER-index hypotheses only, which is what the sequential replay allows
         for (size_t bb = b; bb < e;) {
-            // the first launch of the call counts its first 256 hypotheses on their own (issue_chunk's `lead`)
-            const uint32_t lead = first_piece ? 256u : 0u;
+            // the first launch of the call counts its first lead_size() hypotheses on their own (issue_chunk's `lead`)
+            const uint32_t lead = first_piece ? lead_size() : 0u;
             first_piece = false;
             const size_t ee = std::min(e, bb + chunk_cap);
             sampler->draw_until(ee);
