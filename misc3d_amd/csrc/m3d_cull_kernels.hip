@@ -197,6 +197,47 @@ void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n
     keep_mask_k<<<n_groups, 64, 0, st>>>(ub, best_count, keep, zero_counts_rep, rep_stride, group_offset);
 }
 
+// The lead pass of a chunk (its first `lead` hypotheses, counted on their own) and the keep masks of the rest in
+// ONE launch: every workgroup folds the lead hypotheses' counter replicas again (lead <= 512: a few loads per
+// lane) to know their best count without waiting for another kernel; workgroup 0 also writes their records
+// (count | valid << 31) and raises the running best.  Then the keep_mask_k rule for its own group.
+__global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                        uint32_t lead, const uint8_t* __restrict__ valid, uint32_t h_count,
+                                                        uint32_t* __restrict__ records, uint32_t* __restrict__ best_count,
+                                                        const uint32_t* __restrict__ ub,
+                                                        unsigned long long* __restrict__ keep,
+                                                        uint32_t* __restrict__ zero, uint32_t group_offset) {
+    const uint32_t g = group_offset + blockIdx.x;
+    const uint32_t prev = best_count[0];   // may or may not include this chunk's lead already: max() below either way
+    uint32_t v = 0;
+    for (uint32_t h = threadIdx.x; h < lead; h += 64u) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
+        const bool ok = h < h_count && valid[h];
+        if (blockIdx.x == 0) records[h] = c | (ok ? 0x80000000u : 0u);
+        v = max(v, ok ? c : 0u);
+    }
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && v) atomicMax(best_count, v);
+    const uint32_t best = max(prev, v);
+    const uint32_t h = g * 64u + threadIdx.x;
+    const bool k = !ub || best == 0 || (uint64_t)ub[h] * kTilePoints >= best;
+    const unsigned long long m = __ballot(k);
+    if (threadIdx.x == 0) keep[g] = m;
+    if (zero) {
+#pragma unroll
+        for (int r = 0; r < kCountReplicas; ++r) zero[(size_t)r * rep_stride + h] = 0u;
+    }
+}
+void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
+                           uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
+                           unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st) {
+    if (!n_groups_rest) return;
+    lead_fold_keep_k<<<n_groups_rest, 64, 0, st>>>(counts_rep, rep_stride, lead, valid, h_count, records, best_count, ub,
+                                                   keep, const_cast<uint32_t*>(counts_rep), lead / 64u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // counting over the surviving (tile, hypothesis) pairs
 // ------------------------------------------------------------------------------------------------

@@ -47,6 +47,11 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
                          uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_pad) */);
+// lead pass folded + keep masks (and cleared counters) of groups [lead / 64, lead / 64 + n_groups_rest) in one launch;
+// records[h] = count | valid << 31 for h < lead; best_count (not null) raised by the lead's best valid count.
+void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
+                           uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
+                           unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st);
 void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
                       hipStream_t st);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,

@@ -373,11 +373,13 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
                               h_pad, pair_rep, ctx->stream, 0, ga);
             HIPCHK(hipEventRecord(s.k3, ctx->stream));
-            launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.h_counts.as<uint32_t>(), nullptr, count,
-                                s.valid.as<uint8_t>(), count, bc, ctx->stream, 0);
+            // fold of the lead's counters + keep masks of the rest: one launch
+            launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
+                                  s.h_counts.as<uint32_t>(), bc, ub, keep, n_groups - ga, ctx->stream);
         }
         const uint32_t g_lo = s.lead_groups;
-        launch_keep_mask(ub, bc, n_groups - g_lo, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g_lo);
+        if (!g_lo)
+            launch_keep_mask(ub, bc, n_groups, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
                           pair_rep, ctx->stream, g_lo, n_groups);
