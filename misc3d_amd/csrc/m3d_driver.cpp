@@ -733,8 +733,16 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     } else if (prob >= 1.0) {
         chunk = std::max<size_t>(max_iter, 64);
         growth = 1;
+    } else if (iterations_hint > 2 * (size_t)lead_size()) {
+        // adaptive stop, but the caller knows how many iterations a similar fit just took (segmentation rounds):
+        // ONE chunk of that size whose first hypotheses are counted on their own -- the same device work as a
+        // small first chunk with the second one queued behind it, minus a sample upload, a MinimalFit and a
+        // box-test launch.  Should the bound not be reached, the loop below issues what is left of it.
+        chunk = (iterations_hint + iterations_hint / 16 + 16 + 63) / 64 * 64;
+        lead = lead_size();
+        iterations_hint = 0;   // (consumed: no second chunk queued on the first pass)
     }
-    chunk = std::min(chunk, chunk_cap);
+    chunk = std::min(std::min(chunk, chunk_cap), std::max<size_t>((max_iter + 63) / 64 * 64, 64));
     RESERVE(ctx->best_count, 16);
     HIPCHK(hipMemsetAsync(ctx->best_count.p, 0, sizeof(uint32_t), ctx->stream));
 
