@@ -307,7 +307,7 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
 
 static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const SortedView& sv, int kind,
                        double thr, size_t begin, size_t end, SampleSource& src, double* ms_sample,
-                       bool prune = false, uint32_t lead = 0) {
+                       bool prune = false, uint32_t lead = 0, bool new_fit = false /* clears the running best count */) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const uint32_t h_pad = round_up(count, 64);
@@ -339,7 +339,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (!dense && prune) RESERVE(ctx->ub, sizeof(uint32_t) * (size_t)h_pad);
     launch_minimal_fit(kind, v, s.samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
-                       (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr);   // clears ub[0 .. h_pad) on the way
+                       (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
+                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr);
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     // (culled path: keep_mask_k clears the counter replicas on its way)
@@ -709,7 +710,6 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     m3d_replay_init(&out->st);
     RESERVE(ctx->best_params, sizeof(double) * kModelStride);
     RESERVE(ctx->h_small, 256);
-    HIPCHK(hipMemsetAsync(ctx->best_params.p, 0, sizeof(double) * kModelStride, ctx->stream));
     SampleSource src;
     src.seed(seed);
     src.n_points = v.n;
@@ -743,8 +743,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         iterations_hint = 0;   // (consumed: no second chunk queued on the first pass)
     }
     chunk = std::min(std::min(chunk, chunk_cap), std::max<size_t>((max_iter + 63) / 64 * 64, 64));
-    RESERVE(ctx->best_count, 16);
-    HIPCHK(hipMemsetAsync(ctx->best_count.p, 0, sizeof(uint32_t), ctx->stream));
+    RESERVE(ctx->best_count, 16);   // cleared by the first chunk's minimal_fit_k
 
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rc = M3D_OK;
@@ -779,7 +778,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         want = std::min(std::max<size_t>(want, 64), chunk_cap);
         const size_t b = next_begin, e = std::min(max_iter, b + want);
         const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
-                                  b == 0 ? lead : 0);
+                                  b == 0 ? lead : 0, b == 0);
         if (r == M3D_OK) {
             next_begin = e;
             out->hypotheses_scored += e - b;
@@ -906,6 +905,10 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             }
             cur ^= 1;
         }
+    }
+    if (out->st.best_index < 0) {   // no valid hypothesis at all: the "best model" is all zeros
+        HIPCHK(hipMemsetAsync(ctx->best_params.p, 0, sizeof(double) * kModelStride, ctx->stream));
+        best_dev = ctx->best_params.as<double>();
     }
     ctx->last_best_dev = best_dev;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

@@ -128,10 +128,12 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
                                                      uint32_t h_count, uint32_t h_pad, double thr,
                                                      double* __restrict__ score,
                                                      double* __restrict__ params,
-                                                     uint8_t* __restrict__ valid, uint32_t* __restrict__ zero_u32) {
+                                                     uint8_t* __restrict__ valid, uint32_t* __restrict__ zero_u32,
+                                                     uint32_t* __restrict__ zero_one) {
     const uint32_t h = blockIdx.x * 64u + threadIdx.x;
     if (h >= h_pad) return;
     if (zero_u32 && h + 1 < h_pad) zero_u32[h] = 0;   // per-hypothesis counter cleared on the way (saves a memset launch)
+    if (zero_one && h == 0) zero_one[0] = 0;          // a fit's first chunk: the running best count
     const double nan = u2f(0x7FF8000000000000ull);
     double rec[kModelStride];
     double par[kModelStride];
@@ -213,15 +215,15 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
 
 void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
-                        hipStream_t s, uint32_t* zero_u32) {
+                        hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one) {
     if (h_pad == 0) return;
     const dim3 g((h_pad + 63) / 64), b(64);
     if (kind == 0)
-        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32);
+        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one);
     else if (kind == 1)
-        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32);
+        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one);
     else
-        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32);
+        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -39,7 +39,8 @@ void launch_aos_to_soa(const double* aos, double* x, double* y, double* z, uint3
 void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
                         hipStream_t s,
-                        uint32_t* zero_u32 = nullptr /* h_pad - 1 counters cleared by the same launch */);
+                        uint32_t* zero_u32 = nullptr /* h_pad - 1 counters cleared by the same launch */,
+                        uint32_t* zero_one = nullptr /* one more word cleared by the same launch */);
 
 // K2: inlier counting.  partial[tile * h_pad + h] = number of points of scoring tile `tile` whose
 // distance to hypothesis h is < thr.  h_pad must be a multiple of 64; the hypotheses are cut into
