@@ -23,6 +23,8 @@
 // keep using the original-order arrays, so inlier index lists and serial sums do not see the sort.
 #include "m3d_cull_kernels.hpp"
 
+#include <cstdlib>
+
 #include "m3d_fp.hpp"
 
 #pragma clang fp contract(off)
@@ -333,8 +335,19 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
                     cnt += (uint32_t)__popcll(__ballot(tv >= lo) & __ballot(tv <= hi));
                 }
             }
-            park_cnt = ((uint32_t)lane == slot) ? cnt : park_cnt;
-            park_h = ((uint32_t)lane == slot) ? h : park_h;
+            // cnt, h and slot are wave-uniform: v_writelane drops them into lane `slot` (no compare + select)
+            {
+                const uint32_t cnt_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+                const uint32_t h_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+                const uint32_t slot_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+                // (gfx9: one SGPR operand per VALU instruction, so the lane select travels in m0)
+                // m0 is saved and restored: the compiler keeps it for itself
+                uint32_t m0_save;
+                asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\t"
+                             "v_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+                             : "+v"(park_cnt), "+v"(park_h), "=&s"(m0_save)
+                             : "s"(cnt_s), "s"(h_s), "s"(slot_s));
+            }
             if (++slot == 64u) {  // wave-uniform: flush the parked counts
                 if (park_cnt) atomicAdd(&counts[park_h], park_cnt);
                 park_cnt = 0;
@@ -397,7 +410,17 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     if (!s.n_tiles || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
     // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
-    const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerBlock, (uint32_t)(((uint64_t)s.n_tiles * window) / 16384)));
+    static const uint32_t gpb_max = [] {
+        const char* e = std::getenv("M3D_GPB");   // tuning knob
+        const long v = e ? std::atol(e) : 0;
+        return (uint32_t)(v >= 1 && v <= 64 ? v : kGroupsPerBlock);
+    }();
+    static const uint32_t min_wgs = [] {
+        const char* e = std::getenv("M3D_SCORE_MIN_WGS");   // tuning knob
+        const long v = e ? std::atol(e) : 0;
+        return (uint32_t)(v >= 1 ? v : 16384);
+    }();
+    const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * window) / min_wgs)));
     const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);
     if (kind == 0)
         score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
