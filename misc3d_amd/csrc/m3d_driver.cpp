@@ -574,6 +574,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
     RESERVE(ctx->total, sizeof(uint32_t) * 4);
     RESERVE(ctx->sums, sizeof(double) * 32);
     RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
+    RESERVE(ctx->h_sums, sizeof(double) * kGeneralFitHostDoubles);
     RESERVE(ctx->h_small, 256);
     launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
@@ -592,11 +593,8 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                                   ctx->copy_stream));
         }
         if (need_fit_e) {
-            launch_sum_xyz(gather_view, ctx->idx.as<uint64_t>(), ni_e, ctx->sum_partial.as<double>(),
-                           ctx->sums.as<double>(), ctx->stream);
-            launch_sum_moments(gather_view, ctx->idx.as<uint64_t>(), ni_e, ctx->sums.as<double>(),
-                               ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 4, ctx->stream);
-            HIPCHK(hipMemcpyAsync(h + 16, ctx->sums.p, sizeof(double) * 14, hipMemcpyDeviceToHost, ctx->stream));
+            launch_general_fit_sums(gather_view, ctx->idx.as<uint64_t>(), ni_e, ctx->sum_partial.as<double>(),
+                                    ctx->h_sums.as<double>(), ctx->stream);
         }
         // work the caller wants queued behind these kernels before the host waits (segmentation: the removal of
         // these very inliers), so that ONE wait covers both
@@ -627,7 +625,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                 *general_fit_ok = 0;  // MinimalCheck, ransac.h:166-169, 298-301
             } else {
                 double sums[14];
-                std::memcpy(sums, h + 16, sizeof(sums));
+                general_fit_sums_finish(ctx->h_sums.as<double>(), sums);
                 const double mean[3] = {sums[0] / (double)ni_e, sums[1] / (double)ni_e, sums[2] / (double)ni_e};
                 double out[4];
                 const bool ok = kind == M3D_PLANE ? plane_from_moments(mean, sums + 4, out)
@@ -658,12 +656,8 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         if (ni < min_pts) {
             *general_fit_ok = 0;  // MinimalCheck, ransac.h:166-169, 298-301
         } else {
-            launch_sum_xyz(gather_view, ctx->idx.as<uint64_t>(), ni, ctx->sum_partial.as<double>(),
-                           ctx->sums.as<double>(), ctx->stream);
-            launch_sum_moments(gather_view, ctx->idx.as<uint64_t>(), ni, ctx->sums.as<double>(),
-                               ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 4, ctx->stream);
-            HIPCHK(hipMemcpyAsync(h + 16, ctx->sums.p, sizeof(double) * 14, hipMemcpyDeviceToHost,
-                                  ctx->stream));
+            launch_general_fit_sums(gather_view, ctx->idx.as<uint64_t>(), ni, ctx->sum_partial.as<double>(),
+                                    ctx->h_sums.as<double>(), ctx->stream);
         }
     }
     if (inliers && ni)
@@ -673,7 +667,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (need_fit && *general_fit_ok) {
         double sums[14];
-        std::memcpy(sums, h + 16, sizeof(sums));
+        general_fit_sums_finish(ctx->h_sums.as<double>(), sums);
         const double mean[3] = {sums[0] / (double)ni, sums[1] / (double)ni, sums[2] / (double)ni};
         double out[4];
         bool ok;

@@ -65,6 +65,7 @@ struct DeviceCtx {
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
     const double* last_best_dev = nullptr;   // device address of the last fit's best minimal model (a slot's params or best_params)
+    PinBuf h_sums;             // GeneralFit: per-workgroup moment partials + coordinate sums, written by the kernels
     PinBuf h_best;             // best minimal model of a fit on its way to the host (read after RefineModel's wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

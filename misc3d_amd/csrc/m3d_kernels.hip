@@ -645,14 +645,28 @@ __global__ __launch_bounds__(256) void sum_final_k(const double* __restrict__ pa
     if (threadIdx.x < NV) sums[threadIdx.x] = sm[threadIdx.x * 256];
 }
 
+// Second pass of the GeneralFit sums.  Every workgroup first folds the 256 x/y/z partials of sum_xyz_k itself
+// (same fixed tree as sum_final_k<3>: identical mean everywhere, no kernel in between), then accumulates its
+// share of the centred moments.  `out` is device-visible HOST memory (pinned): the per-workgroup partials
+// (out[block * 16 + k]) and, from workgroup 0, the three coordinate sums (out[kSumBlocks * 16 + k]) land there
+// without a copy command; the host finishes the 256-leaf tree (general_fit_sums_finish, same order).
 __global__ __launch_bounds__(256) void sum_moments_k(CloudView c, const uint64_t* __restrict__ idx,
                                                       uint32_t n,
-                                                      const double* __restrict__ sums_xyz,
-                                                      double* __restrict__ partial) {
+                                                      const double* __restrict__ partial_xyz,
+                                                      double* __restrict__ out) {
     __shared__ double sm[10 * 256];
+    double s3[3];
+    for (int k = 0; k < 3; ++k) s3[k] = partial_xyz[threadIdx.x * 16 + k];  // kSumBlocks == 256
+    block_tree_reduce<3>(s3, sm);
+    const double sx = sm[0], sy = sm[256], sz = sm[512];
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[kSumBlocks * 16 + 0] = sx;
+        out[kSumBlocks * 16 + 1] = sy;
+        out[kSumBlocks * 16 + 2] = sz;
+    }
     // mean /= double(num), ransac.h:176
-    const double mx = sums_xyz[0] / (double)n, my = sums_xyz[1] / (double)n,
-                 mz = sums_xyz[2] / (double)n;
+    const double mx = sx / (double)n, my = sy / (double)n, mz = sz / (double)n;
     double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += kSumBlocks * 256u) {
         const uint64_t i = idx[k];
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(256) void sum_moments_k(CloudView c, const uint64_t
         acc[9] += q;
     }
     block_tree_reduce<10>(acc, sm);
-    if (threadIdx.x < 10) partial[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
+    if (threadIdx.x < 10) out[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
 }
 
 void launch_sum_xyz(const CloudView& c, const uint64_t* idx, uint32_t n_idx, double* partial,
@@ -679,10 +693,24 @@ void launch_sum_xyz(const CloudView& c, const uint64_t* idx, uint32_t n_idx, dou
     sum_final_k<3><<<1, 256, 0, s>>>(partial, sums);
 }
 
-void launch_sum_moments(const CloudView& c, const uint64_t* idx, uint32_t n_idx,
-                        const double* sums_xyz, double* partial, double* sums, hipStream_t s) {
-    sum_moments_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, sums_xyz, partial);
-    sum_final_k<10><<<1, 256, 0, s>>>(partial, sums);
+void launch_general_fit_sums(const CloudView& c, const uint64_t* idx, uint32_t n_idx, double* partial_dev,
+                             double* out_host, hipStream_t s) {
+    sum_xyz_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, partial_dev);
+    sum_moments_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, partial_dev, out_host);
+}
+
+// sums[0..2] = sum of x, y, z; sums[4..13] = the ten centred moments: the last level of the fixed tree, on the host,
+// in block_tree_reduce's order (bit-identical to sum_final_k<10>)
+void general_fit_sums_finish(const double* out_host, double* sums14) {
+    for (int k = 0; k < 3; ++k) sums14[k] = out_host[kSumBlocks * 16 + k];
+    sums14[3] = 0.0;
+    double t[256];
+    for (int k = 0; k < 10; ++k) {
+        for (int b = 0; b < 256; ++b) t[b] = out_host[b * 16 + k];
+        for (int off = 128; off > 0; off >>= 1)
+            for (int b = 0; b < off; ++b) t[b] += t[b + off];
+        sums14[4 + k] = t[0];
+    }
 }
 
 void launch_error_sum(int kind, const CloudView& c, const double* model, double thr, double* partial,
