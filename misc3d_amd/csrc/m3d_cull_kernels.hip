@@ -433,18 +433,6 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                                          pair_rep, group_begin, group_end);
 }
 
-// best_count[0] = max(best_count[0], max over valid hypotheses of counts[h])
-__global__ void max_count_k(const uint32_t* __restrict__ counts, const uint8_t* __restrict__ valid,
-                            uint32_t h_count, uint32_t* __restrict__ best_count) {
-    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
-    uint32_t v = (h < h_count && valid[h]) ? counts[h] : 0u;
-    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(best_count, v);
-}
-void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
-                      hipStream_t st) {
-    if (h_count) max_count_k<<<(h_count + 255) / 256, 256, 0, st>>>(counts, valid, h_count, best_count);
-}
 
 // number of set bits of masks & keep (statistics for the measurement hook)
 __global__ void count_bits_k(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ keep,

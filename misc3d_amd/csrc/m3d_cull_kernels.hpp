@@ -43,7 +43,7 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
 // pair_rep != null: counts[pairs_slot] receives the sum of the pair counters (pairs_slot must be >= the number of
 // real hypotheses; that entry is then not a hypothesis count)
 // valid != null: counts[h] |= valid[h] << 31 for h < h_count; best_count != null: atomic running maximum of the
-// valid hypotheses' counts (what launch_max_count does as a separate launch)
+// valid hypotheses' counts
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
                          uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_pad) */);
@@ -52,8 +52,6 @@ void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32
 void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
                            unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st);
-void launch_max_count(const uint32_t* counts, const uint8_t* valid, uint32_t h_count, uint32_t* best_count,
-                      hipStream_t st);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,
                        uint32_t n_groups, unsigned long long* total, hipStream_t st);
 

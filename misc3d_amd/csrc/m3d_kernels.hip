@@ -687,11 +687,6 @@ __global__ __launch_bounds__(256) void sum_moments_k(CloudView c, const uint64_t
     if (threadIdx.x < 10) out[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
 }
 
-void launch_sum_xyz(const CloudView& c, const uint64_t* idx, uint32_t n_idx, double* partial,
-                    double* sums, hipStream_t s) {
-    sum_xyz_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, partial);
-    sum_final_k<3><<<1, 256, 0, s>>>(partial, sums);
-}
 
 void launch_general_fit_sums(const CloudView& c, const uint64_t* idx, uint32_t n_idx, double* partial_dev,
                              double* out_host, hipStream_t s) {

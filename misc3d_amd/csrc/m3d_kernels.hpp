@@ -78,11 +78,9 @@ void launch_serial_sum(const double* v, const uint32_t* n, double* out, hipStrea
 //   sphere: sums[0..9]  = xx,xy,xz,yy,yz,zz, x*q, y*q, z*q, q  with q = |residual|^2
 // partial: scratch of kSumPartialDoubles doubles.
 constexpr int kSumPartialDoubles = 256 * 16;
-void launch_sum_xyz(const CloudView& c, const uint64_t* idx, uint32_t n_idx, double* partial,
-                    double* sums, hipStream_t s);
 // both passes, two launches: the per-workgroup moment partials and the coordinate sums go straight to `out_host`
 // (device-visible pinned memory, kGeneralFitHostDoubles doubles); general_fit_sums_finish folds them on the host
-// (sums14[0..2] = sum x, y, z; sums14[4..13] = the ten centred moments of launch_sum_moments' layout)
+// (sums14[0..2] = sum x, y, z; sums14[4..13] = the ten centred moments listed above)
 constexpr int kGeneralFitHostDoubles = 256 * 16 + 4;
 void launch_general_fit_sums(const CloudView& c, const uint64_t* idx, uint32_t n_idx, double* partial_dev,
                              double* out_host, hipStream_t s);
