@@ -82,12 +82,11 @@ __device__ __forceinline__ bool box_culled(const double* __restrict__ rec, const
     if (KIND == 0) {
         // inlier <=> |fl(a x + b y + c z + d)| < T.  Over the box, a x + b y + c z + d ranges over
         // [s - r, s + r]; the rounded per-point value differs from the exact one by < 8 u * mag.
-        const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4];
+        const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4], cut = rec[5];
         if (!(T > 0.0)) return true;  // `num < T` can never hold
         const double s = ((a * cx + b * cy) + c * cz) + d;
         const double r = (fabs(a) * hx + fabs(b) * hy) + fabs(c) * hz;
-        const double mag = ((fabs(a * cx) + fabs(b * cy)) + (fabs(c * cz) + fabs(d))) + r;
-        return fabs(s) - r > T + 1e-12 * (mag + T);
+        return fabs(s) - r > cut;     // cut = T + margin (cull_mask_k); inf or NaN keeps the tile
     } else if (KIND == 1) {
         // inlier <=> lo <= |q - c|^2 <= hi
         const double lo = rec[3], hi = rec[4];
@@ -126,13 +125,20 @@ __global__ __launch_bounds__(64) void cull_mask_k(const double* __restrict__ box
                                                    uint32_t tiles_per_block, const double* __restrict__ score,
                                                    const uint8_t* __restrict__ valid, uint32_t h_count,
                                                    uint32_t n_groups, unsigned long long* __restrict__ masks,
-                                                   uint32_t* __restrict__ ub) {
+                                                   uint32_t* __restrict__ ub, double max_abs) {
     const int lane = threadIdx.x;
     const uint32_t group = blockIdx.x;
     const uint32_t h = group * 64u + lane;
     const bool live = h < h_count && valid[h];
     double rec[kModelStride];
     for (int k = 0; k < kModelStride; ++k) rec[k] = live ? score[(size_t)h * kModelStride + k] : 0.0;
+    if (KIND == 0) {
+        // plane: the rounding margin once per hypothesis instead of once per box.  Every |a x|, |b y|, |c z| of the
+        // cloud is at most |.| * max_abs, so mag <= (|a| + |b| + |c|) max_abs + |d| for every box AND every point;
+        // rec[5] = T + 1e-12 (mag + T) is then the one cut-off the box loop compares against.
+        const double mag = ((fabs(rec[0]) + fabs(rec[1])) + fabs(rec[2])) * max_abs + fabs(rec[3]);
+        rec[5] = rec[4] + 1e-12 * (mag + rec[4]);
+    }
     const uint32_t t0 = blockIdx.y * tiles_per_block;
     const uint32_t t1 = min(n_tiles, t0 + tiles_per_block);
     uint32_t touched = 0;
@@ -159,11 +165,11 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
     const uint32_t tpb = (s.n_tiles + splits - 1) / splits;
     const dim3 g(n_groups, (s.n_tiles + tpb - 1) / tpb), b(64);
     if (kind == 0)
-        cull_mask_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub);
+        cull_mask_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs);
     else if (kind == 1)
-        cull_mask_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub);
+        cull_mask_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs);
     else
-        cull_mask_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub);
+        cull_mask_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs);
 }
 
 // keep[g] = hypotheses of group g that are still worth scoring: ub[h] * 512 >= best_count[0]

@@ -16,6 +16,7 @@ struct SortedView {
     const double* z;
     const double* boxes;  // n_tiles x kBoxStride
     uint32_t n_tiles;
+    double max_abs = __builtin_inf();  // >= |coordinate| of every point of the cloud (the box tests' rounding margin); inf = unknown (nothing culled)
 };
 
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);

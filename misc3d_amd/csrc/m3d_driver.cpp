@@ -169,6 +169,7 @@ m3d::SortedView m3d_cloud::sorted() const {
     s.z = sz.as<double>();
     s.boxes = boxes.as<double>();
     s.n_tiles = n_tiles;
+    s.max_abs = max_abs;
     return s;
 }
 
@@ -1203,6 +1204,11 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
                     hi[k] = bb[3 + k];
                 }
                 n_finite = (uint32_t)bb[6];
+                if (n_finite) {
+                    double m = 0.0;
+                    for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+                    c->max_abs = m;   // (stays +inf when something is off: the box tests then keep every tile)
+                }
             }
         }
         const uint32_t cap = std::max<uint32_t>(round_up((uint32_t)n, kTilePoints), kTilePoints);

@@ -82,6 +82,7 @@ struct m3d_cloud {
     // Z-order sorted copy for the culled scoring path (m3d_cull_kernels.hip)
     m3d::DevBuf sx, sy, sz, boxes;
     uint32_t n_sorted = 0, n_tiles = 0;
+    double max_abs = __builtin_inf();   // largest |coordinate| of the finite points (SortedView::max_abs)
     // In-place shrinking (m3d_cloud_remove_inliers = SelectByIndex(inliers, invert), the tail of a
     // SegmentPlaneIterative round).  x/y/z above always hold the cloud AS CREATED (n0 points): index lists
     // and GeneralFit gathers refer to it through `orig`.  Once shrunk, n / n_pad / n_sorted / n_tiles and
