@@ -37,7 +37,7 @@ def test_fuzz_fits(capi, orc, kind):
         n = int(sizes[it % len(sizes)])
         pts, nrm = _cloud(rng, kind, n)
         thr = float(10.0 ** rng.uniform(-3.3, -0.7))
-        max_iter = int(rng.choice([1, 3, 64, 127, 129, 300, 700]))
+        max_iter = int(rng.choice([1, 3, 64, 127, 129, 300, 700, 1100, 2500]))   # > 1024 with prob 1: lead pass inside the chunk
         prob = float(rng.choice([1.0, 0.9999, 0.99, 0.5]))
         seed = int(rng.integers(1 << 31))
         o = orc.fit(kind, pts, nrm, thr=thr, max_iter=max_iter, prob=prob, seed=seed)
@@ -114,3 +114,20 @@ def test_fuzz_normals(capi, orc):
         got, ref = capi.normals_from_map(xyz, w, h, k, vp), orc.normals_from_map(xyz, w, h, k, vp)
         assert np.array_equal(np.isnan(got), np.isnan(ref)), (it, w, h, k)
         assert np.array_equal(np.nan_to_num(got).view(np.uint64), np.nan_to_num(ref).view(np.uint64)), (it, w, h, k)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_lead_pass_and_many_chunks_against_oracle(capi, orc, kind):
+    """probability 1 with more than 1024 hypotheses: the first chunk counts its leading hypotheses on their own and
+    prunes the rest with their best count; 40 000 hypotheses span three chunks.  Same best index, count and inlier
+    list as the sequential oracle."""
+    rng = np.random.default_rng(500 + kind)
+    for n, H in ((3000, 1030), (20000, 5000), (9000, 40000)):
+        pts, nrm = _cloud(rng, kind, n)
+        seed = int(rng.integers(1 << 31))
+        o = orc.fit(kind, pts, nrm, thr=0.01, max_iter=H, prob=1.0, seed=seed)
+        g = capi.fit(kind, pts, nrm, 0.01, H, 1.0, seed=seed)
+        tag = (kind, n, H, seed)
+        assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (
+            o.ret, o.best_index, o.count, o.iterations), tag
+        assert np.array_equal(g.inliers.astype(np.uint64), o.inliers.astype(np.uint64)), tag
