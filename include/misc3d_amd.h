@@ -61,7 +61,8 @@ typedef struct m3d_stats {
     double ms_total;             /* wall clock of the call */
     double ms_score_kernel;      /* device: sum of the scoring-kernel launches alone (HIP events around each) */
     uint32_t score_launches;     /* number of scoring-kernel launches (chunks) behind ms_score_kernel */
-    uint32_t reserved0;
+    uint32_t early_pick_redone;  /* 1: RefineModel had been started on the device's own pick of the winner (probability-1
+                                  * fits) and the sequential replay chose another hypothesis (rmse tie): it was run again */
     uint64_t pairs_scored;       /* (512-point tile, hypothesis) pairs those launches evaluated after culling and pruning */
 } m3d_stats;
 

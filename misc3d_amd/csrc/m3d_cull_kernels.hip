@@ -214,7 +214,8 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
                                                         uint32_t* __restrict__ records, uint32_t* __restrict__ best_count,
                                                         const uint32_t* __restrict__ ub,
                                                         unsigned long long* __restrict__ keep,
-                                                        uint32_t* __restrict__ zero, uint32_t group_offset) {
+                                                        uint32_t* __restrict__ zero, uint32_t group_offset,
+                                                        uint32_t* __restrict__ records_dev) {
     const uint32_t g = group_offset + blockIdx.x;
     const uint32_t prev = best_count[0];   // may or may not include this chunk's lead already: max() below either way
     uint32_t v = 0;
@@ -223,7 +224,10 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
 #pragma unroll
         for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
         const bool ok = h < h_count && valid[h];
-        if (blockIdx.x == 0) records[h] = c | (ok ? 0x80000000u : 0u);
+        if (blockIdx.x == 0) {
+            records[h] = c | (ok ? 0x80000000u : 0u);
+            if (records_dev) records_dev[h] = c | (ok ? 0x80000000u : 0u);
+        }
         v = max(v, ok ? c : 0u);
     }
     for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
@@ -240,10 +244,10 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
 }
 void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
-                           unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st) {
+                           unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st, uint32_t* records_dev) {
     if (!n_groups_rest) return;
     lead_fold_keep_k<<<n_groups_rest, 64, 0, st>>>(counts_rep, rep_stride, lead, valid, h_count, records, best_count, ub,
-                                                   keep, const_cast<uint32_t*>(counts_rep), lead / 64u);
+                                                   keep, const_cast<uint32_t*>(counts_rep), lead / 64u, records_dev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,7 +377,8 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
 __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t rep_stride, uint32_t h_pad,
                                uint32_t* __restrict__ counts, const uint32_t* __restrict__ pair_rep,
                                uint32_t pairs_slot, const uint8_t* __restrict__ valid, uint32_t h_count,
-                               uint32_t* __restrict__ best_count, uint32_t h_begin) {
+                               uint32_t* __restrict__ best_count, uint32_t h_begin,
+                               uint32_t* __restrict__ counts_dev /* device copy of the records, or null */) {
     const uint32_t h = h_begin + blockIdx.x * 256u + threadIdx.x;   // window [h_begin, h_pad) of the chunk
     if (blockIdx.x == 0 && pair_rep) {   // block-uniform
         __shared__ uint32_t red[256];
@@ -394,7 +399,11 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
         for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
     }
     const bool ok = mine && valid && h < h_count && valid[h];
-    if (mine) counts[h] = valid ? (c | (ok ? 0x80000000u : 0u)) : c;
+    if (mine) {
+        const uint32_t rec = valid ? (c | (ok ? 0x80000000u : 0u)) : c;
+        counts[h] = rec;
+        if (counts_dev) counts_dev[h] = rec;
+    }
     if (best_count) {   // wave-uniform
         uint32_t v = ok ? c : 0u;
         for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
@@ -403,10 +412,74 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
 }
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
-                         uint32_t* best_count, hipStream_t st, uint32_t h_begin) {
+                         uint32_t* best_count, hipStream_t st, uint32_t h_begin, uint32_t* counts_dev) {
     if (h_pad > h_begin)
         sum_replicas_k<<<(h_pad - h_begin + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_pad, counts, pair_rep,
-                                                                      pairs_slot, valid, h_count, best_count, h_begin);
+                                                                      pairs_slot, valid, h_count, best_count, h_begin,
+                                                                      counts_dev);
+}
+
+// The hypothesis the sequential replay will most probably end with, chosen on the device: highest inlier count
+// among the valid hypotheses of the chunk, lowest index among equals, against the running pick of earlier chunks
+// (strictly more inliers to replace it).  Fitness ties are decided by rmse on the host, so this is a PREDICTION:
+// the driver starts RefineModel's compaction on pick->params behind the last scoring launch and keeps the result
+// only if the replay names the same hypothesis (m3d_driver.cpp).  One workgroup.
+__global__ __launch_bounds__(1024) void pick_best_k(const uint32_t* __restrict__ records, uint32_t count,
+                                                     unsigned long long index_base, const double* __restrict__ params,
+                                                     int first_chunk, BestPick* __restrict__ pick,
+                                                     BestPickHost* __restrict__ pick_host) {
+    __shared__ uint32_t s_cnt[1024];
+    __shared__ uint32_t s_idx[1024];
+    __shared__ int s_take;
+    uint32_t bc = 0, bi = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < count; i += 1024u) {
+        const uint32_t r = records[i];
+        const uint32_t c = r & 0x7FFFFFFFu;
+        if ((r >> 31) && c > bc) {   // ascending i per thread: the first of equals stays
+            bc = c;
+            bi = i;
+        }
+    }
+    s_cnt[threadIdx.x] = bc;
+    s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const uint32_t c2 = s_cnt[threadIdx.x + off], i2 = s_idx[threadIdx.x + off];
+            const uint32_t c1 = s_cnt[threadIdx.x], i1 = s_idx[threadIdx.x];
+            if (c2 > c1 || (c2 == c1 && i2 < i1)) {
+                s_cnt[threadIdx.x] = c2;
+                s_idx[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool had = !first_chunk && pick->have;
+        const bool take = s_cnt[0] > 0 && (!had || s_cnt[0] > pick->cnt);
+        s_take = take ? 1 : 0;
+        if (take) {
+            pick->have = 1;
+            pick->cnt = s_cnt[0];
+            pick->index = index_base + s_idx[0];
+        } else if (!had) {
+            pick->have = 0;
+            pick->cnt = 0;
+            pick->index = ~0ull;
+        }
+        pick_host->have = pick->have;
+        pick_host->cnt = pick->cnt;
+        pick_host->index = pick->index;
+    }
+    __syncthreads();
+    if (threadIdx.x < kModelStride) {
+        if (s_take) pick->params[threadIdx.x] = params[(size_t)s_idx[0] * kModelStride + threadIdx.x];
+        else if (first_chunk) pick->params[threadIdx.x] = 0.0;
+    }
+}
+void launch_pick_best(const uint32_t* records, uint32_t count, unsigned long long index_base, const double* params,
+                      bool first_chunk, BestPick* pick, BestPickHost* pick_host, hipStream_t st) {
+    pick_best_k<<<1, 1024, 0, st>>>(records, count, index_base, params, first_chunk ? 1 : 0, pick, pick_host);
 }
 
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,

@@ -47,12 +47,26 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
 // valid hypotheses' counts
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
-                         uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_pad) */);
+                         uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_pad) */,
+                         uint32_t* counts_dev = nullptr /* the same records once more, in device memory */);
+// The device's prediction of the hypothesis the replay will end with (pick_best_k, m3d_cull_kernels.hip)
+struct BestPick {
+    unsigned long long index;   // absolute hypothesis index, ~0 when none
+    uint32_t cnt, have;
+    double params[8];           // its parameter record (kModelStride doubles): RefineModel's model
+};
+struct BestPickHost {           // mirror in pinned host memory, written by the same kernel
+    unsigned long long index;
+    uint32_t cnt, have;
+};
+void launch_pick_best(const uint32_t* records, uint32_t count, unsigned long long index_base, const double* params,
+                      bool first_chunk, BestPick* pick, BestPickHost* pick_host, hipStream_t st);
 // lead pass folded + keep masks (and cleared counters) of groups [lead / 64, lead / 64 + n_groups_rest) in one launch;
 // records[h] = count | valid << 31 for h < lead; best_count (not null) raised by the lead's best valid count.
 void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
-                           unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st);
+                           unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st,
+                           uint32_t* records_dev = nullptr);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,
                        uint32_t n_groups, unsigned long long* total, hipStream_t st);
 

@@ -308,7 +308,8 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
 
 static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const SortedView& sv, int kind,
                        double thr, size_t begin, size_t end, SampleSource& src, double* ms_sample,
-                       bool prune = false, uint32_t lead = 0, bool new_fit = false /* clears the running best count */) {
+                       bool prune = false, uint32_t lead = 0, bool new_fit = false /* clears the running best count */,
+                       bool device_records = false /* culled path: keep a device copy of the records in s.counts */) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const uint32_t h_pad = round_up(count, 64);
@@ -321,7 +322,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     RESERVE(s.score, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
     RESERVE(s.params, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
     RESERVE(s.valid, (size_t)h_pad + 1);
-    if (dense) RESERVE(s.counts, sizeof(uint32_t) * (size_t)h_pad);   // (culled path: records go straight to h_counts)
+    if (dense || device_records) RESERVE(s.counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // (culled path: records go straight to h_counts)
+    uint32_t* rec_dev = (!dense && device_records) ? s.counts.as<uint32_t>() : nullptr;
     RESERVE(s.h_samples, sizeof(uint32_t) * (size_t)count * m);
     RESERVE(s.h_counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // + the launch's pair counter behind the counts
     RESERVE(s.h_valid, (size_t)h_pad + 1);
@@ -377,7 +379,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             HIPCHK(hipEventRecord(s.k3, ctx->stream));
             // fold of the lead's counters + keep masks of the rest: one launch
             launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
-                                  s.h_counts.as<uint32_t>(), bc, ub, keep, n_groups - ga, ctx->stream);
+                                  s.h_counts.as<uint32_t>(), bc, ub, keep, n_groups - ga, ctx->stream, rec_dev);
         }
         const uint32_t g_lo = s.lead_groups;
         if (!g_lo)
@@ -390,7 +392,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         // ... and writes the records straight into the slot's pinned host array (device-visible): no copy command
         // behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
         launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.h_counts.as<uint32_t>(), pair_rep, count,
-                            s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u);
+                            s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u, rec_dev);
     }
     // counts of the chunk + (culled path) the number of (tile, hypothesis) pairs the launch evaluated
     if (dense)
@@ -562,26 +564,41 @@ static bool is_library_pinned(const void* p, size_t bytes) {
 // has to wait for the compaction's own total: the GeneralFit sums run on the main stream while the index list
 // travels to the host on the copy stream, and the total is only CHECKED at the end (a mismatch falls back to
 // the synchronous order; the callers treat it as an internal error anyway).
-static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_view,
-                  const uint32_t* orig_dev, int kind, double thr, const double* model_dev,
-                  double* params_host /* in: best minimal model, out: refined */, size_t* inliers,
-                  size_t* n_inliers, int* general_fit_ok, int64_t expected_ni = -1,
-                  const std::function<int(int64_t)>* before_wait = nullptr,
-                  const double* lazy_in = nullptr /* pinned: the "in" value of params_host arrives with the wait */) {
+// First stage of RefineModel: the ordered inlier list of `model_dev` (+ the model record to the pinned `lazy_in`).
+// total_host (pinned) receives the inlier count.  Separate from refine() so that a probability-1 fit can queue it
+// on the device's own prediction of the winner right behind the last scoring launch (run_ransac).
+static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, const uint32_t* orig_dev, int kind,
+                                   double thr, const double* model_dev, const double* lazy_in, void* total_host) {
     const uint32_t n = flag_view.n;
     const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
     RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
     RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)nb + 1));
     RESERVE(ctx->total, sizeof(uint32_t) * 4);
+    launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
+                   nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
+                   ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in));
+    HIPCHK(hipMemcpyAsync(total_host, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return M3D_OK;
+}
+
+static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_view,
+                  const uint32_t* orig_dev, int kind, double thr, const double* model_dev,
+                  double* params_host /* in: best minimal model, out: refined */, size_t* inliers,
+                  size_t* n_inliers, int* general_fit_ok, int64_t expected_ni = -1,
+                  const std::function<int(int64_t)>* before_wait = nullptr,
+                  const double* lazy_in = nullptr /* pinned: the "in" value of params_host arrives with the wait */,
+                  const void* compaction_total = nullptr /* pinned: the compaction is already queued (on model_dev) */) {
+    const uint32_t n = flag_view.n;
     RESERVE(ctx->sums, sizeof(double) * 32);
     RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
     RESERVE(ctx->h_sums, sizeof(double) * kGeneralFitHostDoubles);
     RESERVE(ctx->h_small, 256);
-    launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
-                   nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
-                   ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in));
     uint8_t* h = ctx->h_small.as<uint8_t>();
-    HIPCHK(hipMemcpyAsync(h, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    const uint8_t* h_total = compaction_total ? static_cast<const uint8_t*>(compaction_total) : h;
+    if (!compaction_total) {
+        const int rc = issue_refine_compaction(ctx, flag_view, orig_dev, kind, thr, model_dev, lazy_in, h);
+        if (rc != M3D_OK) return rc;
+    }
     if (expected_ni >= 0 && (uint64_t)expected_ni <= n) {
         const uint32_t ni_e = (uint32_t)expected_ni;
         const bool need_fit_e = kind != M3D_CYLINDER && ni_e >= (kind == M3D_PLANE ? 3u : 4u);
@@ -615,10 +632,10 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         HIPCHK(hipStreamSynchronize(ctx->copy_stream));
         if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
         uint32_t ni_chk;
-        std::memcpy(&ni_chk, h, 4);
+        std::memcpy(&ni_chk, h_total, 4);
         if (ni_chk != ni_e)   // should not happen: redo in the order that does not rely on the expectation
             return refine(ctx, flag_view, gather_view, orig_dev, kind, thr, model_dev, params_host, inliers, n_inliers,
-                          general_fit_ok, -1, nullptr, nullptr);
+                          general_fit_ok, -1, nullptr, nullptr, nullptr);
         *n_inliers = ni_e;
         *general_fit_ok = 1;
         if (kind != M3D_CYLINDER) {
@@ -648,7 +665,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
     uint32_t ni;
-    std::memcpy(&ni, h, 4);
+    std::memcpy(&ni, h_total, 4);
     *n_inliers = ni;
     *general_fit_ok = 1;
     const bool need_fit = kind != M3D_CYLINDER;  // cylinder GeneralFit is a no-op, ransac.h:427-433
@@ -698,13 +715,31 @@ struct RansacOut {
     uint32_t score_launches = 0;
     uint64_t pairs_scored = 0;   // (tile, hypothesis) pairs the scoring launches evaluated (culled path)
     int internal_error = 0;
+    int spec_hits = 0, spec_misses = 0;   // early compaction on the device's pick kept / redone
 };
 
 static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, int kind, double thr,
-                      size_t max_iter, double prob, uint64_t seed, RansacOut* out, size_t iterations_hint = 0) {
+                      size_t max_iter, double prob, uint64_t seed, RansacOut* out, size_t iterations_hint = 0,
+                      const uint32_t* orig_dev = nullptr /* index map of a shrunk cloud (RefineModel's compaction) */) {
     m3d_replay_init(&out->st);
     RESERVE(ctx->best_params, sizeof(double) * kModelStride);
     RESERVE(ctx->h_small, 256);
+    // Probability-1 fits: nothing but fitness == 1 stops the loop, so the winner is (up to rmse ties) the hypothesis
+    // with the most inliers, lowest index first.  The device picks it itself after every chunk (pick_best_k) and,
+    // behind the LAST chunk, RefineModel's compaction is queued on that pick at once -- while the host is still
+    // waking up and replaying the records.  The replay stays the authority: cloud_fit_locked keeps the early
+    // compaction only if it names the same hypothesis.  M3D_SPEC=0 switches the prediction off.
+    static const bool spec_enabled = [] {
+        const char* e = std::getenv("M3D_SPEC");
+        return !(e && e[0] == '0');
+    }();
+    const bool spec = spec_enabled && prob >= 1.0 && !use_dense_scoring() && max_iter > 0;
+    ctx->spec_compaction = false;
+    if (spec) {
+        RESERVE(ctx->pick, sizeof(BestPick));
+        RESERVE(ctx->h_pick, 128);
+        RESERVE(ctx->h_best, sizeof(double) * kModelStride);
+    }
     SampleSource src;
     src.seed(seed);
     src.n_points = v.n;
@@ -772,8 +807,18 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
         want = std::min(std::max<size_t>(want, 64), chunk_cap);
         const size_t b = next_begin, e = std::min(max_iter, b + want);
-        const int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
-                                  b == 0 ? lead : 0, b == 0);
+        int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
+                            b == 0 ? lead : 0, b == 0, spec);
+        if (r == M3D_OK && spec) {
+            ChunkSlot& sl = ctx->slot[slot_id];
+            launch_pick_best(sl.counts.as<uint32_t>(), (uint32_t)(e - b), (unsigned long long)b, sl.params.as<double>(),
+                             b == 0, ctx->pick.as<BestPick>(), ctx->h_pick.as<BestPickHost>(), ctx->stream);
+            if (e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
+                r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
+                                            ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64);
+                ctx->spec_compaction = r == M3D_OK;
+            }
+        }
         if (r == M3D_OK) {
             next_begin = e;
             out->hypotheses_scored += e - b;
@@ -949,17 +994,33 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     const CloudView gather = c->base_view();   // index lists / GeneralFit refer to the cloud as created
     const uint32_t* orig = c->orig();
     RansacOut ro;
-    int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro, iterations_hint ? *iterations_hint : 0);
+    int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro, iterations_hint ? *iterations_hint : 0,
+                        orig);
     if (rc != M3D_OK) return rc;
     if (iterations_hint) *iterations_hint = (size_t)ro.st.iterations;
     const double t1 = now_ms();
     double model[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};   // filled from ctx->h_best by refine's wait
     size_t ni = 0;
     int gf_ok = 1;
-    rc = refine(ctx, v, gather, orig, kind, thr, ctx->last_best_dev, model, inliers, &ni,
-                &gf_ok, ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1, before_refine_wait,
-                ctx->h_best.as<double>());
-    if (rc != M3D_OK) return rc;
+    const int64_t expected = ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1;
+    bool refined = false;
+    if (ctx->spec_compaction) {
+        // the compaction is already running on the device's pick; finish RefineModel on it and keep the result if
+        // the replay named the same hypothesis (it does unless an rmse tie went the other way)
+        rc = refine(ctx, v, gather, orig, kind, thr, ctx->pick.as<BestPick>()->params, model, inliers, &ni, &gf_ok,
+                    expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64);
+        if (rc != M3D_OK) return rc;
+        const BestPickHost* ph = ctx->h_pick.as<BestPickHost>();
+        refined = ro.st.best_index >= 0 ? (ph->have && ph->index == (unsigned long long)ro.st.best_index) : !ph->have;
+        ro.spec_hits = refined ? 1 : 0;
+        ro.spec_misses = refined ? 0 : 1;
+        before_refine_wait = refined ? before_refine_wait : nullptr;   // (a hook has run by now either way)
+    }
+    if (!refined) {
+        rc = refine(ctx, v, gather, orig, kind, thr, ctx->last_best_dev, model, inliers, &ni,
+                    &gf_ok, expected, ctx->spec_compaction ? nullptr : before_refine_wait, ctx->h_best.as<double>());
+        if (rc != M3D_OK) return rc;
+    }
     {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ro.ms_score = ms;
@@ -985,6 +1046,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         stats->ms_score_kernel = ro.ms_score_kernel;
         stats->score_launches = ro.score_launches;
         stats->pairs_scored = ro.pairs_scored;
+        stats->early_pick_redone = (uint32_t)ro.spec_misses;   // 1: the device's early pick lost an rmse tie, RefineModel was redone
         stats->ms_refine = t2 - t1;
         stats->ms_total = t2 - t0;
     }

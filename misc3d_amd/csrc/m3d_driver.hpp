@@ -65,6 +65,9 @@ struct DeviceCtx {
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
     const double* last_best_dev = nullptr;   // device address of the last fit's best minimal model (a slot's params or best_params)
+    DevBuf pick;               // BestPick: the device's prediction of the winning hypothesis (probability-1 fits)
+    PinBuf h_pick;             // BestPickHost mirror (+ at byte 64: inlier total of a compaction started on the prediction)
+    bool spec_compaction = false;   // RefineModel's compaction has already been queued on pick->params
     PinBuf h_sums;             // GeneralFit: per-workgroup moment partials + coordinate sums, written by the kernels
     PinBuf h_best;             // best minimal model of a fit on its way to the host (read after RefineModel's wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

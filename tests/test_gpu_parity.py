@@ -304,3 +304,26 @@ def test_pinned_output_buffer_same_result(capi):
     ptr = capi.lib().m3d_host_alloc(64)
     assert ptr
     capi.lib().m3d_host_free(ptr)
+
+
+def test_early_pick_loses_rmse_tie(capi, orc):
+    """Probability-1 fits start RefineModel's compaction on the device's own pick (most inliers, lowest index).
+    Here a later hypothesis has the SAME inlier count and a lower rmse, so the sequential rule prefers it: the
+    replay overrules the pick (m3d_stats.early_pick_redone == 1) and the result is the oracle's."""
+    rng = np.random.default_rng(12)
+    n = 4000
+    xy = rng.uniform(-1, 1, (n, 2))
+    # two parallel sheets with the same number of points each; the upper one is flatter (lower rmse)
+    z = np.where(np.arange(n) % 2 == 0, 0.0 + rng.uniform(-4e-3, 4e-3, n), 0.5 + rng.uniform(-1e-3, 1e-3, n))
+    pts = np.ascontiguousarray(np.c_[xy, z])
+    # three exact points per sheet make hypothesis planes z = 0 and z = 0.5 whose slabs (thr 0.01) hold a whole sheet
+    pts[0], pts[2], pts[4] = (-1, -1, 0.0), (1, -1, 0.0), (0, 1, 0.0)
+    pts[1], pts[3], pts[5] = (-1, -1, 0.5), (1, -1, 0.5), (0, 1, 0.5)
+    hit = 0
+    for seed in range(40):
+        o = orc.fit(0, pts, None, thr=0.01, max_iter=1500, prob=1.0, seed=seed)
+        g = capi.fit(0, pts, None, 0.01, 1500, 1.0, seed=seed)
+        assert (g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.best_index, o.count, o.iterations)
+        assert np.array_equal(g.inliers.astype(np.uint64), o.inliers.astype(np.uint64))
+        hit += int(g.stats["early_pick_redone"])
+    assert hit > 0      # (39 of the 40 seeds on MI355X)
