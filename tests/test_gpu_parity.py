@@ -327,3 +327,20 @@ def test_early_pick_loses_rmse_tie(capi, orc):
         assert np.array_equal(g.inliers.astype(np.uint64), o.inliers.astype(np.uint64))
         hit += int(g.stats["early_pick_redone"])
     assert hit > 0      # (39 of the 40 seeds on MI355X)
+
+
+@pytest.mark.parametrize("max_iter", [300, 2000, 40000])
+def test_perfect_fit_stops_probability_one_loop(capi, orc, max_iter):
+    """fitness == 1 is the one thing that stops a probability-1 loop (ransac.h:607-609): every point lies on the plane,
+    so the first valid hypothesis ends it -- inside the first chunk, long before the last one, or in a single-chunk
+    fit where the device's early pick has already been acted on.  Iteration count and model as the oracle's."""
+    rng = np.random.default_rng(21)
+    xy = rng.integers(-512, 512, (6000, 2)).astype(np.float64) / 256.0
+    pts = np.ascontiguousarray(np.c_[xy, np.full(len(xy), 0.25)])          # exactly representable: distances are 0
+    for seed in (1, 2, 3):
+        o = orc.fit(0, pts, None, thr=0.01, max_iter=max_iter, prob=1.0, seed=seed)
+        g = capi.fit(0, pts, None, 0.01, max_iter, 1.0, seed=seed)
+        assert o.count <= 3 and len(o.inliers) == len(pts)
+        assert (g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.best_index, o.count, o.iterations)
+        assert np.array_equal(g.inliers.astype(np.uint64), o.inliers.astype(np.uint64))
+        assert np.allclose(g.params, o.params, rtol=0, atol=1e-9)
