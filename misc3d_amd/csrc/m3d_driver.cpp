@@ -1161,6 +1161,37 @@ static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double*
     return cloud_remove_finish(c, n_removed);
 }
 
+// every device buffer a cloud can own, in one place
+template <class F>
+static void for_each_buffer(m3d_cloud* c, F f) {
+    f(c->x); f(c->y); f(c->z); f(c->nx); f(c->ny); f(c->nz);
+    f(c->sx); f(c->sy); f(c->sz); f(c->boxes);
+    for (int k = 0; k < 2; ++k) {
+        f(c->work.bx[k]); f(c->work.by[k]); f(c->work.bz[k]); f(c->work.bo[k]);
+        f(c->work.sbx[k]); f(c->work.sby[k]); f(c->work.sbz[k]);
+    }
+    f(c->work.sboxes);
+}
+static void release_buffers(m3d_cloud* c) {
+    for_each_buffer(c, [](DevBuf& b) { b.release(); });
+}
+static size_t buffer_bytes(m3d_cloud* c) {
+    size_t t = 0;
+    for_each_buffer(c, [&](DevBuf& b) { t += b.cap; });
+    return t;
+}
+// dst (freshly constructed) takes over src's device buffers; src is left empty
+static void adopt_buffers(m3d_cloud* dst, m3d_cloud* src) {
+    std::vector<DevBuf*> d, s_;
+    for_each_buffer(dst, [&](DevBuf& b) { d.push_back(&b); });
+    for_each_buffer(src, [&](DevBuf& b) { s_.push_back(&b); });
+    for (size_t i = 0; i < d.size(); ++i) {
+        *d[i] = *s_[i];
+        s_[i]->p = nullptr;
+        s_[i]->cap = 0;
+    }
+}
+
 }  // namespace m3d
 
 using namespace m3d;
@@ -1219,12 +1250,17 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
         return nullptr;
     }
     m3d_cloud* c = new m3d_cloud();
+    if (ctx->spare_cloud) {   // device buffers of the last destroyed cloud (grow-only: re-allocated only when too small)
+        adopt_buffers(c, ctx->spare_cloud);
+        delete ctx->spare_cloud;
+        ctx->spare_cloud = nullptr;
+    }
     c->ctx = ctx;
     c->n = (uint32_t)n;
     c->n_pad = std::max<uint32_t>(round_up((uint32_t)n, kScoreTile), kScoreTile);
     c->has_normals = normals != nullptr;
     const size_t bytes = sizeof(double) * (size_t)c->n_pad;
-    DevBuf stage;
+    DevBuf& stage = ctx->cc_stage;
     bool ok = c->x.reserve(bytes) && c->y.reserve(bytes) && c->z.reserve(bytes) &&
               stage.reserve(sizeof(double) * 3 * std::max<size_t>(n, 1));
     if (ok && c->has_normals) ok = c->nx.reserve(bytes) && c->ny.reserve(bytes) && c->nz.reserve(bytes);
@@ -1246,7 +1282,8 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
     // Hilbert-sorted copy + tile boxes for the culled scoring path.  The bounding box of the finite points comes
     // from the device copy (a host pass over the caller's 10 M-point array took 9 ms, as long as the rest of
     // the upload and sort together)
-    DevBuf t_cell, t_start, t_fill, t_sums, t_total, t_bbox;
+    DevBuf &t_cell = ctx->cc_cell, &t_start = ctx->cc_start, &t_fill = ctx->cc_fill, &t_sums = ctx->cc_sums,
+           &t_total = ctx->cc_total, &t_bbox = ctx->cc_bbox;
     if (ok) {
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         uint32_t n_finite = 0;
@@ -1314,13 +1351,9 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
         if (ok) launch_tile_boxes(c->sorted(), c->boxes.as<double>(), ctx->stream);
     }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-    stage.release();
-    t_cell.release(); t_start.release(); t_fill.release(); t_sums.release(); t_total.release();
     if (!ok) {
         if (g_last_error.empty()) set_error("cloud upload failed");
-        c->x.release(); c->y.release(); c->z.release();
-        c->nx.release(); c->ny.release(); c->nz.release();
-        c->sx.release(); c->sy.release(); c->sz.release(); c->boxes.release();
+        release_buffers(c);
         delete c;
         return nullptr;
     }
@@ -1354,17 +1387,35 @@ void m3d_host_free(void* p) {
 
 void m3d_cloud_destroy(m3d_cloud* c) {
     if (!c) return;
-    std::lock_guard<std::mutex> lock(c->ctx->mu);
-    (void)hipSetDevice(c->ctx->device);
-    c->x.release(); c->y.release(); c->z.release();
-    c->nx.release(); c->ny.release(); c->nz.release();
-    c->sx.release(); c->sy.release(); c->sz.release(); c->boxes.release();
-    for (int k = 0; k < 2; ++k) {
-        c->work.bx[k].release(); c->work.by[k].release(); c->work.bz[k].release(); c->work.bo[k].release();
-        c->work.sbx[k].release(); c->work.sby[k].release(); c->work.sbz[k].release();
+    DeviceCtx* ctx = c->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    // keep the buffers for the next m3d_cloud_create on this device (one cloud's worth, at most 4 GiB)
+    constexpr size_t kSpareLimit = (size_t)4 << 30;
+    if (!ctx->spare_cloud && buffer_bytes(c) <= kSpareLimit) {
+        (void)hipStreamSynchronize(ctx->stream);
+        m3d_cloud* keep = new m3d_cloud();
+        adopt_buffers(keep, c);
+        ctx->spare_cloud = keep;
+    } else {
+        release_buffers(c);
     }
-    c->work.sboxes.release();
     delete c;
+}
+
+void m3d_release_cached(int device) {
+    DeviceCtx* ctx = get_ctx(device);
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->spare_cloud) {
+        release_buffers(ctx->spare_cloud);
+        delete ctx->spare_cloud;
+        ctx->spare_cloud = nullptr;
+    }
+    ctx->cc_stage.release(); ctx->cc_cell.release(); ctx->cc_start.release(); ctx->cc_fill.release();
+    ctx->cc_sums.release(); ctx->cc_total.release(); ctx->cc_bbox.release();
 }
 
 size_t m3d_cloud_size(const m3d_cloud* c) { return c ? c->n : 0; }

@@ -12,6 +12,8 @@
 #include "m3d_cull_kernels.hpp"
 #include "m3d_kernels.hpp"
 
+struct m3d_cloud;
+
 namespace m3d {
 
 void set_error(const std::string& msg);
@@ -65,6 +67,10 @@ struct DeviceCtx {
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
     const double* last_best_dev = nullptr;   // device address of the last fit's best minimal model (a slot's params or best_params)
+    // m3d_cloud_create's upload / sort scratch, and the buffers of the most recently destroyed cloud: a one-shot
+    // call (upload, fit, destroy) otherwise spends more time in hipMalloc / hipFree than in the fit
+    DevBuf cc_stage, cc_cell, cc_start, cc_fill, cc_sums, cc_total, cc_bbox;
+    m3d_cloud* spare_cloud = nullptr;
     DevBuf pick;               // BestPick: the device's prediction of the winning hypothesis (probability-1 fits)
     PinBuf h_pick;             // BestPickHost mirror (+ at byte 64: inlier total of a compaction started on the prediction)
     bool spec_compaction = false;   // RefineModel's compaction has already been queued on pick->params
