@@ -86,8 +86,9 @@ typedef struct m3d_cloud m3d_cloud;
 m3d_cloud *m3d_cloud_create(const double *xyz, const double *normals /* may be NULL */, size_t n,
                             int device);
 void m3d_cloud_destroy(m3d_cloud *cloud);
-/* The library keeps the device buffers of the most recently destroyed cloud (up to 4 GiB) and its upload scratch
- * for the next m3d_cloud_create / one-shot call on that device; this releases them. */
+/* Device blocks released by the library (destroyed clouds, per-call scratch of the registration / matcher / normals /
+ * boundary entry points) are parked on a per-device free list (at most 8 GiB) and handed out again instead of going
+ * through hipFree / hipMalloc on every call; this returns them, and the upload scratch, to the driver. */
 void m3d_release_cached(int device);
 /* Page-locked host memory for OUTPUT buffers (inlier index lists).  Any host pointer is accepted wherever this
  * header takes an output buffer; one obtained here lets the library start the device-to-host copy of the index

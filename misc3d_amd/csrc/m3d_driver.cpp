@@ -54,22 +54,80 @@ int fail(int code, const std::string& msg) {
             return fail(M3D_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+namespace {
+constexpr int kPoolDevices = 16;
+constexpr size_t kPoolLimit = (size_t)8 << 30;   // bytes parked per device
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void*> blocks[kPoolDevices];
+    size_t bytes[kPoolDevices] = {};
+};
+DevPool& dev_pool() {
+    static DevPool* p = new DevPool();   // never destroyed (buffers may be released from finalisers at exit)
+    return *p;
+}
+}  // namespace
+
 bool DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return true;
     release();
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    if (d >= 0 && d < kPoolDevices) {
+        DevPool& pool = dev_pool();
+        std::lock_guard<std::mutex> lock(pool.mu);
+        auto it = pool.blocks[d].lower_bound(want);
+        if (it != pool.blocks[d].end() && it->first <= 2 * want + ((size_t)1 << 20)) {
+            p = it->second;
+            cap = it->first;
+            dev = d;
+            pool.bytes[d] -= cap;
+            pool.blocks[d].erase(it);
+            return true;
+        }
+    }
     if (hipMalloc(&p, want) != hipSuccess) {
-        p = nullptr;
-        set_error("hipMalloc failed (" + std::to_string(want) + " bytes)");
-        return false;
+        dev_pool_trim(d);   // give the parked blocks back and try once more
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc failed (" + std::to_string(want) + " bytes)");
+            return false;
+        }
     }
     cap = want;
+    dev = d;
     return true;
 }
 void DevBuf::release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+        bool parked = false;
+        if (dev >= 0 && dev < kPoolDevices) {
+            DevPool& pool = dev_pool();
+            std::lock_guard<std::mutex> lock(pool.mu);
+            if (pool.bytes[dev] + cap <= kPoolLimit) {
+                pool.blocks[dev].emplace(cap, p);
+                pool.bytes[dev] += cap;
+                parked = true;
+            }
+        }
+        if (!parked) (void)hipFree(p);
+    }
     p = nullptr;
     cap = 0;
+    dev = -1;
+}
+void dev_pool_trim(int device) {
+    if (device < 0 || device >= kPoolDevices) return;
+    std::vector<void*> drop;
+    {
+        DevPool& pool = dev_pool();
+        std::lock_guard<std::mutex> lock(pool.mu);
+        for (auto& kv : pool.blocks[device]) drop.push_back(kv.second);
+        pool.blocks[device].clear();
+        pool.bytes[device] = 0;
+    }
+    for (void* q : drop) (void)hipFree(q);
 }
 bool PinBuf::reserve(size_t bytes) {
     if (bytes <= cap) return true;
@@ -1175,23 +1233,6 @@ static void for_each_buffer(m3d_cloud* c, F f) {
 static void release_buffers(m3d_cloud* c) {
     for_each_buffer(c, [](DevBuf& b) { b.release(); });
 }
-static size_t buffer_bytes(m3d_cloud* c) {
-    size_t t = 0;
-    for_each_buffer(c, [&](DevBuf& b) { t += b.cap; });
-    return t;
-}
-// dst (freshly constructed) takes over src's device buffers; src is left empty
-static void adopt_buffers(m3d_cloud* dst, m3d_cloud* src) {
-    std::vector<DevBuf*> d, s_;
-    for_each_buffer(dst, [&](DevBuf& b) { d.push_back(&b); });
-    for_each_buffer(src, [&](DevBuf& b) { s_.push_back(&b); });
-    for (size_t i = 0; i < d.size(); ++i) {
-        *d[i] = *s_[i];
-        s_[i]->p = nullptr;
-        s_[i]->cap = 0;
-    }
-}
-
 }  // namespace m3d
 
 using namespace m3d;
@@ -1250,11 +1291,6 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
         return nullptr;
     }
     m3d_cloud* c = new m3d_cloud();
-    if (ctx->spare_cloud) {   // device buffers of the last destroyed cloud (grow-only: re-allocated only when too small)
-        adopt_buffers(c, ctx->spare_cloud);
-        delete ctx->spare_cloud;
-        ctx->spare_cloud = nullptr;
-    }
     c->ctx = ctx;
     c->n = (uint32_t)n;
     c->n_pad = std::max<uint32_t>(round_up((uint32_t)n, kScoreTile), kScoreTile);
@@ -1390,16 +1426,7 @@ void m3d_cloud_destroy(m3d_cloud* c) {
     DeviceCtx* ctx = c->ctx;
     std::lock_guard<std::mutex> lock(ctx->mu);
     (void)hipSetDevice(ctx->device);
-    // keep the buffers for the next m3d_cloud_create on this device (one cloud's worth, at most 4 GiB)
-    constexpr size_t kSpareLimit = (size_t)4 << 30;
-    if (!ctx->spare_cloud && buffer_bytes(c) <= kSpareLimit) {
-        (void)hipStreamSynchronize(ctx->stream);
-        m3d_cloud* keep = new m3d_cloud();
-        adopt_buffers(keep, c);
-        ctx->spare_cloud = keep;
-    } else {
-        release_buffers(c);
-    }
+    release_buffers(c);   // (to the device's free list: the next m3d_cloud_create takes them from there)
     delete c;
 }
 
@@ -1409,13 +1436,9 @@ void m3d_release_cached(int device) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->spare_cloud) {
-        release_buffers(ctx->spare_cloud);
-        delete ctx->spare_cloud;
-        ctx->spare_cloud = nullptr;
-    }
     ctx->cc_stage.release(); ctx->cc_cell.release(); ctx->cc_start.release(); ctx->cc_fill.release();
     ctx->cc_sums.release(); ctx->cc_total.release(); ctx->cc_bbox.release();
+    dev_pool_trim(ctx->device);
 }
 
 size_t m3d_cloud_size(const m3d_cloud* c) { return c ? c->n : 0; }

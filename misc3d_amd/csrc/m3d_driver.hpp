@@ -20,9 +20,14 @@ void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 
 // grow-only device / pinned-host buffers
+// release() hands the block to a per-device free list (bounded) and reserve() looks there first: the one-call entry
+// points (registration, matcher, ICP, normals, boundary detection) allocate a dozen or more buffers per call, and
+// hipMalloc / hipFree cost more than many of those calls' kernels.  All device work of a device runs on its one
+// compute stream, so a recycled block is never touched out of order.  dev_pool_trim(device) frees the list.
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    int dev = -1;
     bool reserve(size_t bytes);
     void release();
     template <class T>
@@ -67,10 +72,9 @@ struct DeviceCtx {
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
     const double* last_best_dev = nullptr;   // device address of the last fit's best minimal model (a slot's params or best_params)
-    // m3d_cloud_create's upload / sort scratch, and the buffers of the most recently destroyed cloud: a one-shot
-    // call (upload, fit, destroy) otherwise spends more time in hipMalloc / hipFree than in the fit
+    // m3d_cloud_create's upload / sort scratch (a one-shot call -- upload, fit, destroy -- otherwise spends more time
+    // in hipMalloc / hipFree than in the fit; the cloud's own buffers come back through DevBuf's free list)
     DevBuf cc_stage, cc_cell, cc_start, cc_fill, cc_sums, cc_total, cc_bbox;
-    m3d_cloud* spare_cloud = nullptr;
     DevBuf pick;               // BestPick: the device's prediction of the winning hypothesis (probability-1 fits)
     PinBuf h_pick;             // BestPickHost mirror (+ at byte 64: inlier total of a compaction started on the prediction)
     bool spec_compaction = false;   // RefineModel's compaction has already been queued on pick->params
@@ -79,6 +83,7 @@ struct DeviceCtx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+void dev_pool_trim(int device);
 DeviceCtx* get_ctx(int device);  // nullptr + last error when the device is unusable
 
 }  // namespace m3d
