@@ -85,15 +85,21 @@ if "C4" in which:
     emit("C4 compute_transformation_ransac 200k<->200k x 100k hyp", ms=dt * 1e3, hyp_per_s=100_000 / dt,
          validations=st["validations"], fitness=st["fitness"], best_index=st["best_index"],
          pose_err=float(np.abs(T - d["T"]).max()))
-    t0 = time.perf_counter()
-    T2, st2 = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=100_000,
-                                       edge_length_threshold=0.9, confidence=0.999, seed=17)
-    emit("C4 same with the reference's confidence 0.999", ms=(time.perf_counter() - t0) * 1e3,
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        T2, st2 = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=100_000,
+                                           edge_length_threshold=0.9, confidence=0.999, seed=17)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    emit("C4 same with the reference's confidence 0.999", ms=sorted(ts)[1], ms_first=ts[0],
          iterations=st2["iterations"], validations=st2["validations"], pose_err=float(np.abs(T2 - d["T"]).max()))
     # the step the reference's examples chain next: point-to-point ICP on the RANSAC pose (max distance 0.02)
-    t0 = time.perf_counter()
-    T3, st3 = capi.registration_icp(d["src"], d["dst"], 0.02, T2)
-    emit("C4 registration_icp on that pose (point-to-point, 0.02, 30 it)", ms=(time.perf_counter() - t0) * 1e3,
+    ts = []
+    for _ in range(3):      # one-call entry point: median of three (the first call also warms the block free list)
+        t0 = time.perf_counter()
+        T3, st3 = capi.registration_icp(d["src"], d["dst"], 0.02, T2)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    emit("C4 registration_icp on that pose (point-to-point, 0.02, 30 it)", ms=sorted(ts)[1], ms_first=ts[0],
          iterations=st3["iterations"], fitness=st3["fitness"], rmse=st3["inlier_rmse"],
          pose_err=float(np.abs(T3 - d["T"]).max()))
 
