@@ -1377,7 +1377,7 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
             gs.r2 = gs.h2_in = 0.0;
             const uint32_t ncell = 1u << (3 * bits);
             ok = t_cell.reserve(sizeof(uint32_t) * n) && t_start.reserve(sizeof(uint32_t) * ((size_t)ncell + 1)) &&
-                 t_fill.reserve(sizeof(uint32_t) * (size_t)ncell) &&
+                 t_fill.reserve(sizeof(uint32_t) * std::max<size_t>(n, 1)) &&   // rank of every point in its cell
                  t_sums.reserve(sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1)) && t_total.reserve(16);
             if (ok)
                 launch_grid_build(c->view(), gs, t_cell.as<uint32_t>(), t_start.as<uint32_t>(), t_fill.as<uint32_t>(),

@@ -91,8 +91,10 @@ __device__ __forceinline__ bool cell_of(const GridDesc& g, double x, double y, d
     return true;
 }
 
+// hist[cell] counts the points of a cell; rank[i] = how many points of its cell had arrived before point i
+// (the value the counting add returns): the scatter then needs no second round of atomics.
 __global__ void grid_count_k(CloudView dst, GridDesc g, uint32_t* __restrict__ cell_of_point,
-                             uint32_t* __restrict__ hist) {
+                             uint32_t* __restrict__ hist, uint32_t* __restrict__ rank) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= dst.n) return;
     int ix, iy, iz;
@@ -146,7 +148,7 @@ __global__ void grid_count_k(CloudView dst, GridDesc g, uint32_t* __restrict__ c
         } else {
             cid = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
         }
-        atomicAdd(&hist[cid], 1u);
+        rank[i] = atomicAdd(&hist[cid], 1u);
     }
     cell_of_point[i] = cid;
 }
@@ -188,14 +190,14 @@ __global__ void add_tile_offsets_k(uint32_t* __restrict__ v, uint32_t n, const u
 }
 
 __global__ void grid_scatter_k(CloudView dst, const uint32_t* __restrict__ cell_of_point,
-                               const uint32_t* __restrict__ cell_start, uint32_t* __restrict__ fill,
+                               const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ rank,
                                double* __restrict__ qx, double* __restrict__ qy, double* __restrict__ qz,
                                uint32_t* __restrict__ orig) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= dst.n) return;
     const uint32_t cid = cell_of_point[i];
     if (cid == 0xFFFFFFFFu) return;
-    const uint32_t pos = cell_start[cid] + atomicAdd(&fill[cid], 1u);
+    const uint32_t pos = cell_start[cid] + rank[i];
     qx[pos] = dst.x[i];
     qy[pos] = dst.y[i];
     qz[pos] = dst.z[i];
@@ -211,18 +213,17 @@ void launch_fill_nan(double* p, uint32_t n, hipStream_t s) {
 }
 
 void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
-                       uint32_t* cell_start /* ncell + 1 */, uint32_t* fill /* ncell */,
+                       uint32_t* cell_start /* ncell + 1 */, uint32_t* rank /* one per point: dst.n */,
                        uint32_t* tile_sums, uint32_t* total, double* qx, double* qy, double* qz,
                        hipStream_t s, uint32_t* orig) {
     const uint32_t ncell = g.nx * g.ny * g.nz;
     (void)hipMemsetAsync(cell_start, 0, sizeof(uint32_t) * ((size_t)ncell + 1), s);
-    (void)hipMemsetAsync(fill, 0, sizeof(uint32_t) * (size_t)ncell, s);
-    if (dst.n) grid_count_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, g, cell_of_point, cell_start);
+    if (dst.n) grid_count_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, g, cell_of_point, cell_start, rank);
     const uint32_t nt = (ncell + 2047) / 2048;
     tile_scan_k<<<nt, 256, 0, s>>>(cell_start, ncell, tile_sums);
     launch_scan_blocks(tile_sums, nt, total, s);
     add_tile_offsets_k<<<(ncell + 1 + 255) / 256, 256, 0, s>>>(cell_start, ncell, tile_sums, total);
-    if (dst.n) grid_scatter_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, cell_of_point, cell_start, fill, qx, qy, qz, orig);
+    if (dst.n) grid_scatter_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, cell_of_point, cell_start, rank, qx, qy, qz, orig);
 }
 
 // Neighbour lists: for every interior cell the points of its 3x3x3 block, packed (x, y, z, 0) and

@@ -33,7 +33,8 @@ void launch_kabsch3_check(const CloudView& src, const CloudView& dst, const uint
 void launch_gather_T(const double* T12, const uint32_t* list, uint32_t n, uint32_t n_pad, double* out,
                      hipStream_t s);
 void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
-                       uint32_t* cell_start, uint32_t* fill, uint32_t* tile_sums, uint32_t* total,
+                       uint32_t* cell_start, uint32_t* rank /* scratch, ONE ENTRY PER POINT (dst.n) */,
+                       uint32_t* tile_sums, uint32_t* total,
                        double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr);
 void launch_fill_nan(double* p, uint32_t n, hipStream_t s);
 void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl_start, uint32_t* tile_sums,

@@ -139,7 +139,7 @@ int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, con
     const uint32_t ncell = g.nx * g.ny * g.nz;
     RESERVE(S.cell_of_point, sizeof(uint32_t) * n_dst);
     RESERVE(S.cell_start, sizeof(uint32_t) * ((size_t)ncell + 1));
-    RESERVE(S.fill, sizeof(uint32_t) * (size_t)ncell);
+    RESERVE(S.fill, sizeof(uint32_t) * std::max<size_t>(dst_view.n, 1));   // rank of every point in its cell
     RESERVE(S.tile_sums, sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1));
     RESERVE(S.total, 16);
     RESERVE(S.qx, sizeof(double) * n_dst);
@@ -404,7 +404,7 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
             const uint32_t np = R.src.n_pad;
             RESERVE(S.s_cell_of_point, sizeof(uint32_t) * n_src);
             RESERVE(S.s_cell_start, sizeof(uint32_t) * ((size_t)ncs + 1));
-            RESERVE(S.s_fill, sizeof(uint32_t) * (size_t)ncs);
+            RESERVE(S.s_fill, sizeof(uint32_t) * std::max<size_t>(R.src.n, 1));   // rank of every point in its cell
             RESERVE(S.s_tile_sums, sizeof(uint32_t) * ((size_t)(ncs + 2047) / 2048 + 1));
             RESERVE(S.sx, sizeof(double) * np);
             RESERVE(S.sy, sizeof(double) * np);
