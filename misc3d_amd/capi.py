@@ -431,7 +431,7 @@ def fit(kind, xyz, normals=None, threshold=0.01, max_iteration=1000, probability
     xyz = _f64(xyz).reshape(-1, 3)
     n = len(xyz)
     params = np.zeros(NUM_PARAMS[kind])
-    inl = np.zeros(max(n, 1), dtype=np.uint64)
+    inl = np.empty(max(n, 1), dtype=np.uint64)     # filled by the library up to n_inliers
     ni = C.c_size_t(0)
     st = Stats()
     _s, sref = _seed_ref(seed)
@@ -456,7 +456,7 @@ def segment_plane_iterative(xyz, threshold, max_iteration=100, min_ratio=0.05, s
     n = len(xyz)
     planes = np.zeros((max_clusters, 4))
     offs = np.zeros(max_clusters + 1, dtype=np.uint64)
-    idx = np.zeros(max(n, 1), dtype=np.uint64)
+    idx = np.empty(max(n, 1), dtype=np.uint64)     # filled by the library up to the last offset
     k = C.c_size_t(0)
     _s, sref = _seed_ref(seed)
     rc = _check(lib().m3d_segment_plane_iterative(_p(xyz), n, threshold, max_iteration, min_ratio,
