@@ -88,6 +88,7 @@ struct RegCtx {
 // sorted by cell (qx/qy/qz + cell_start), optional neighbour lists (3x3x3 block of every cell, contiguous;
 // bounded to 2 M target points; M3D_REG_NL=0 switches them off).  with_orig: also keep the original index of
 // every sorted point (S.cell_orig) and store it in the w component of the neighbour-list entries.
+int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, const uint32_t* orig);
 int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, const double* dst, size_t n_dst,
                       double radius, bool with_orig, GridDesc* g_out, int K0 = 4, bool with_nl = true) {
     GridDesc g;
@@ -150,8 +151,21 @@ int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, con
     launch_grid_build(dst_view, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
                       S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
                       S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream, orig);
+    if (with_nl) {
+        const int rn = add_neighbour_lists(ctx, S, &g, n_dst, orig);
+        if (rn != M3D_OK) return rn;
+    }
+    *g_out = g;
+    return M3D_OK;
+}
+
+// Neighbour lists on top of a grid built by build_target_grid (its cell_start / q arrays in S): g gains nl_start /
+// nl_pts.  Separate because they only pay off once enough queries follow (173 MB for 200 k target points).
+int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, const uint32_t* orig) {
+    GridDesc& g = *gp;
+    const uint32_t ncell = g.nx * g.ny * g.nz;
     const char* nl_env = std::getenv("M3D_REG_NL");
-    if (with_nl && !(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
+    if (!(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
         RESERVE(S.nl_start, sizeof(uint32_t) * ((size_t)ncell + 1));
         launch_nl_count(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.tile_sums.as<uint32_t>(),
                         S.total.as<uint32_t>() + 1, ctx->stream);
@@ -165,7 +179,6 @@ int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, con
         g.nl_start = S.nl_start.as<uint32_t>();
         g.nl_pts = S.nl_pts.as<double4>();
     }
-    *g_out = g;
     return M3D_OK;
 }
 
@@ -328,7 +341,13 @@ struct m3d_reg {
     std::vector<double> h_sum2;  // order-free sums of the nearest squared distances per survivor
     double best_sum2 = 0.0;      // the same for the current best
     std::vector<uint8_t> pass;
-    size_t chunk = 256;
+    // Triples per chunk: starts small and doubles.  A block of reg_validate_k works through its (<= 64) survivors one
+    // after the other at ~45 us each (dependent neighbour-list gathers), and with the reference's default confidence
+    // (0.999) the loop usually ends after two or three dozen iterations: a first chunk of 256 triples validated ~65
+    // survivors (3 ms) of which the replay used 5.
+    size_t chunk = 32;
+    size_t validated_total = 0, n_dst_points = 0;
+    bool nl_built = false;
     int itr = 0;
     int n_exec = 0;          // iterations of the chunk in flight
     bool finished = false;
@@ -357,9 +376,10 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
     R.thr = threshold;
 
     {
-        const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, false, &g);
+        const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, false, &g, 4, /*with_nl=*/false);
         if (rc_grid != M3D_OK) return rc_grid;
         R.g = g;
+        n_dst_points = n_dst;
     }
 
     // ---- spatially sorted copy of the SOURCE cloud for the validation kernel: counts and
@@ -478,6 +498,15 @@ int m3d_reg::begin_chunk(size_t* n_survivors) {
         if (pass[k]) survivors.push_back((uint32_t)k);
     const uint32_t ns = (uint32_t)survivors.size();
     h_counts.assign(ns, 0);
+    // neighbour lists once the call has turned out to validate more than a handful of hypotheses (with the
+    // reference's default confidence it usually has not: ~8 validations, against 0.4 ms to build the lists)
+    validated_total += ns;
+    if (!nl_built && validated_total > 48) {
+        nl_built = true;
+        const int rn = add_neighbour_lists(ctx, S, &g, n_dst_points, nullptr);
+        if (rn != M3D_OK) return rn;
+        R.g = g;
+    }
     if (ns) {
         const uint32_t s_pad = round_up(ns, 64);
         RESERVE(S.list, sizeof(uint32_t) * ns);
