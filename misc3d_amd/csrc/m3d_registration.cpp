@@ -904,18 +904,26 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
             }
             uint64_t cnt = 0;
             double e2 = 0.0;
+            double hs[18];   // sums of the correspondence set for umeyama (filled by result())
             // GetRegistrationResultAndCorrespondences: nearest target point within the radius, count + error2
             auto result = [&]() -> int {
                 launch_icp_nn(px, py, pz, n, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
                               S.qz.as<double>(), S.cell_orig.as<uint32_t>(), nn.as<uint32_t>(), d2.as<double>(),
                               ctx->stream);
                 launch_icp_err(d2.as<double>(), n, g.r2, S.partial_sum.as<double>(), S.sums.as<double>() + 24, ctx->stream);
+                // the sums of the NEXT ComputeTransformation are queued behind it at once (they read the count from
+                // the device): one host wait per iteration instead of two; after the last iteration they go unused
+                launch_icp_sums(px, py, pz, n, dv, nn.as<uint32_t>(), S.sums.as<double>() + 25,
+                                S.partial_sum.as<double>(), S.sums.as<double>(), ctx->stream);
+                RESERVE(ctx->h_small, 256);
                 uint8_t* h = ctx->h_small.as<uint8_t>();
                 HIPCHK(hipMemcpyAsync(h, S.sums.as<double>() + 24, 16, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipMemcpyAsync(h + 32, S.sums.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipStreamSynchronize(ctx->stream));
                 double es[2];
                 std::memcpy(es, h, 16);
+                std::memcpy(hs, h + 32, sizeof(hs));
                 e2 = es[0];
                 const uint32_t c = (uint32_t)es[1];
                 cnt = c;
@@ -931,13 +939,7 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
                 double U[16];
                 std::memcpy(U, I4, sizeof(U));
                 if (cnt) {   // ComputeTransformation: Eigen::umeyama over the correspondence set, no scaling
-                    launch_icp_sums(px, py, pz, n, dv, nn.as<uint32_t>(), S.sums.as<double>() + 25,
-                                    S.partial_sum.as<double>(), S.sums.as<double>(), ctx->stream);
-                    double h[18];
-                    HIPCHK(hipMemcpyAsync(ctx->h_small.p, S.sums.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-                    HIPCHK(hipGetLastError());
-                    HIPCHK(hipStreamSynchronize(ctx->stream));
-                    std::memcpy(h, ctx->h_small.p, sizeof(h));
+                    const double* h = hs;
                     const double one_over_n = 1.0 / (double)cnt;
                     double ms[3], md[3], sig[9];
                     for (int k = 0; k < 3; ++k) {
