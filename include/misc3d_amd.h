@@ -87,7 +87,7 @@ m3d_cloud *m3d_cloud_create(const double *xyz, const double *normals /* may be N
                             int device);
 void m3d_cloud_destroy(m3d_cloud *cloud);
 /* Device blocks released by the library (destroyed clouds, per-call scratch of the registration / matcher / normals /
- * boundary entry points) are parked on a per-device free list (at most 8 GiB) and handed out again instead of going
+ * boundary entry points) are parked on a per-device free list (at most m3d_config.pool_limit_mb, default 4 GiB) and handed out again instead of going
  * through hipFree / hipMalloc on every call; this returns them, and the upload scratch, to the driver. */
 void m3d_release_cached(int device);
 /* Page-locked host memory for OUTPUT buffers (inlier index lists).  Any host pointer is accepted wherever this
@@ -285,15 +285,92 @@ int m3d_match_mutual_nn(const double *feat_src, size_t n_src, const double *feat
  * inconclusive (candidate list overflow / fp32 range) and that were redone by exact brute force. */
 uint64_t m3d_match_last_fallbacks(void);
 
-/* ---- measurement hook (bench.py `roofline`): average duration in ms of the scoring kernel alone
- * (score_k, the dominant kernel) over `reps` launches of `n_hypotheses` hypotheses, timed with HIP
- * events on the library's own stream after one untimed launch.  Not part of the reference. */
-int m3d_cloud_time_score(m3d_cloud *cloud, int kind, double threshold, const uint32_t *samples,
-                         size_t n_hypotheses, int reps, int mode, double *ms_avg,
-                         uint64_t *listed_pairs);
-/* mode 0: score_list_k (production: counting over the (tile, hypothesis) pairs that survive the box
- * test); mode 1: cull_k (the box tests); mode 2: score_k (dense: every tile x every hypothesis).
- * listed_pairs (may be NULL): number of surviving (tile, hypothesis) pairs, tile = 512 points. */
+/* ---- multi-GPU: hypotheses sharded, points replicated ----------------------------------
+ * The hypothesis loop of ransac.h:571-613 carries one dependency across iterations, the best-model update
+ * (:592-613).  Sharded, every rank (one GPU each) holds a replica of the cloud and an identically seeded sampler,
+ * scores a contiguous slice of every window of the ONE hypothesis stream, and a single all-gather per window
+ * exchanges the 4-byte (MinimalFit's return << 31 | inlier count) records; every rank then replays the same
+ * sequence, so best hypothesis, iteration count, inlier list and parameters are identical on every rank and equal
+ * to the one-GPU result for any number of ranks.  No point ever crosses the links.
+ *
+ * m3d_comm is the exchange.  Three ways to get one:
+ *   m3d_comm_create_rccl   one process per GPU: rank 0 calls m3d_comm_unique_id, the launcher's own channel
+ *                          (torch.distributed store, MPI_Bcast, a file) hands the 128 bytes to every rank, every
+ *                          rank calls m3d_comm_create_rccl(id, world, rank, device) -- collective, like
+ *                          ncclCommInitRank.  The all-gather then runs as ncclAllGather on the library's stream,
+ *                          in place on the device record array (RCCL over xGMI; librccl is bound at run time).
+ *   m3d_comm_create_host   the caller supplies the all-gather over host buffers (MPI_Allgather, gloo, tests).
+ *   m3d_comm_create_local  `world` communicators for `world` threads of this process, one device each
+ *                          (m3d_segment_plane_iterative_multi uses it).
+ * A communicator is used by one thread at a time; all ranks must make the same sequence of sharded calls. */
+typedef struct m3d_comm m3d_comm;
+#define M3D_COMM_ID_BYTES 128
+int m3d_comm_unique_id(uint8_t id[M3D_COMM_ID_BYTES]);
+m3d_comm *m3d_comm_create_rccl(const uint8_t id[M3D_COMM_ID_BYTES], int world, int rank, int device);
+/* recv: world x bytes_per_rank, rank-major.  Return 0 on success. */
+typedef int (*m3d_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+m3d_comm *m3d_comm_create_host(int world, int rank, m3d_allgather_fn fn, void *user);
+int m3d_comm_create_local(int world, m3d_comm **comms /* world handles out */);
+void m3d_comm_destroy(m3d_comm *comm);
+int m3d_comm_world(const m3d_comm *comm);
+int m3d_comm_rank(const m3d_comm *comm);
+uint64_t m3d_comm_collectives(const m3d_comm *comm); /* exchanges made so far */
+
+/* m3d_cloud_fit (RANSAC::FitModel, ransac.h:482-516) with the hypothesis loop sharded over the ranks of `comm`.
+ * Every rank passes its own replica of the cloud and the SAME kind / threshold / max_iteration / probability;
+ * seed == NULL: rank 0 draws one from std::random_device and shares it.  Outputs are written on every rank.
+ * comm == NULL is m3d_cloud_fit.  stats->hypotheses_scored counts this rank's share. */
+int m3d_cloud_fit_sharded(m3d_cloud *cloud, m3d_comm *comm, int kind, double threshold, size_t max_iteration,
+                          double probability, const uint64_t *seed, double *params, size_t *inliers,
+                          size_t *n_inliers, m3d_stats *stats);
+/* m3d_segment_plane_iterative with every round's hypothesis loop sharded: each rank uploads the same cloud to its
+ * own `device`, removes the same inliers from its replica after every round (no point traffic), and returns the
+ * same clusters. */
+int m3d_segment_plane_iterative_sharded(const double *xyz, size_t n, double threshold, int max_iteration,
+                                        double min_ratio, const uint64_t *seed, int device, m3d_comm *comm,
+                                        size_t max_clusters, double *planes, size_t *cluster_offsets,
+                                        size_t *cluster_indices, size_t *n_clusters);
+/* The same from ONE process that drives n_dev GPUs (the `devices[], n_dev` form): a thread and a
+ * replica per device, records exchanged through host memory.  devices must be distinct ordinals.  n_dev == 1 is
+ * m3d_segment_plane_iterative on devices[0]. */
+int m3d_segment_plane_iterative_multi(const double *xyz, size_t n, double threshold, int max_iteration,
+                                      double min_ratio, const uint64_t *seed, const int *devices, int n_dev,
+                                      size_t max_clusters, double *planes, size_t *cluster_offsets,
+                                      size_t *cluster_indices, size_t *n_clusters);
+int m3d_fit_multi(int kind, const double *xyz, const double *normals, size_t n, double threshold,
+                  size_t max_iteration, double probability, const uint64_t *seed, const int *devices, int n_dev,
+                  double *params, size_t *inliers, size_t *n_inliers, m3d_stats *stats);
+/* m3d_registration_ransac with the validation of every chunk's surviving hypotheses sharded (contiguous runs of
+ * 64-hypothesis groups per rank, one all-gather of (count, sum d^2) per chunk, identical replay everywhere). */
+int m3d_registration_ransac_sharded(const double *src, size_t n_src, const double *dst, size_t n_dst,
+                                    const size_t *corr_src, const size_t *corr_dst, size_t m, double threshold,
+                                    int max_iter, double edge_length_threshold, double confidence,
+                                    const uint64_t *seed, int device, m3d_comm *comm, double T[16],
+                                    m3d_reg_stats *stats);
+
+/* ---- tunables ---------------------------------------------------------------------------------------------------
+ * Every knob of the library, read ONCE from the environment on first use (variable names in brackets) and
+ * replaceable at run time.  None changes a result: they select between code paths that produce identical output
+ * (the test-suite runs them against each other) or set launch geometry.  m3d_set_config must not race with
+ * compute calls. */
+typedef struct m3d_config {
+    int32_t dense_scoring;          /* [M3D_DENSE=1]        1: score every (tile, hypothesis) pair (score_k) instead of the culled path */
+    int32_t speculative_refine;     /* [M3D_SPEC=0]         default 1: probability-1 fits start RefineModel on the device's own pick */
+    int32_t lead_hypotheses;        /* [M3D_LEAD]           default 128 (multiple of 64): hypotheses counted first for the pruning incumbent */
+    int32_t score_groups_per_block; /* [M3D_GPB]            default 8: 64-hypothesis groups per scoring workgroup (1..64) */
+    int32_t score_min_workgroups;   /* [M3D_SCORE_MIN_WGS]  default 16384: small chunks are cut finer to reach this many workgroups */
+    int32_t dense_workgroups;       /* [M3D_SCORE_WGS]      default 8192: workgroup target of the dense kernel */
+    int32_t morton_order;           /* [M3D_ORDER=morton]   1: plain Z-order instead of the Hilbert curve for the sorted copy */
+    int32_t reg_neighbour_lists;    /* [M3D_REG_NL=0]       default 1: per-cell 3x3x3 neighbour lists for the registration validation */
+    int32_t reg_source_rows;        /* [M3D_REG_SRC_ORDER=rows] 1: source cloud in x-row order instead of Hilbert order */
+    int32_t reg_prune;              /* [M3D_REG_PRUNE=0]    default 1: bound-and-prune of validations against earlier chunks */
+    int32_t match_brute;            /* [M3D_MATCH_BRUTE=1]  1: fp64 brute-force matcher (no screen) */
+    int32_t match_fp32_screen;      /* [M3D_MATCH_SCREEN=fp32] 1: fp32 VALU screen instead of the split-fp16 MFMA screen */
+    int32_t pool_limit_mb;          /* [M3D_POOL_MB]        default 4096: released device blocks parked per device for re-use (0 = none) */
+    int32_t reserved[3];
+} m3d_config;
+void m3d_get_config(m3d_config *out);
+int m3d_set_config(const m3d_config *in);
 
 /* ---- misc -------------------------------------------------------------------------------------- */
 const char *m3d_last_error(void); /* thread-local; reference message text for M3D_ERR_* */

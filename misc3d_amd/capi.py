@@ -65,6 +65,7 @@ class ReplayState(C.Structure):
 
 
 RMSE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_size_t)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 _lib = None
 
@@ -101,8 +102,8 @@ def lib():
         L.m3d_cloud_remove_inliers.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.m3d_cloud_original_size.restype = C.c_size_t
         L.m3d_cloud_original_size.argtypes = [C.c_void_p]
-        L.m3d_cloud_time_score.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int,
-                                           C.c_int, C.c_void_p, C.c_void_p]
+        L.m3d_bench_time_score.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p]     # include/misc3d_amd_bench.h
         L.m3d_sampler_create.restype = C.c_void_p
         L.m3d_sampler_create.argtypes = [C.c_size_t, C.c_int, C.c_uint64]
         L.m3d_sampler_destroy.argtypes = [C.c_void_p]
@@ -152,8 +153,151 @@ def lib():
         L.m3d_match_last_fallbacks.argtypes = []
         L.m3d_match_mutual_nn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        # multi-GPU: communicators and the sharded entry points
+        L.m3d_comm_unique_id.argtypes = [C.c_void_p]
+        L.m3d_comm_create_rccl.restype = C.c_void_p
+        L.m3d_comm_create_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.m3d_comm_create_host.restype = C.c_void_p
+        L.m3d_comm_create_host.argtypes = [C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]
+        L.m3d_comm_create_local.argtypes = [C.c_int, C.c_void_p]
+        L.m3d_comm_destroy.restype = None
+        L.m3d_comm_destroy.argtypes = [C.c_void_p]
+        L.m3d_comm_world.argtypes = [C.c_void_p]
+        L.m3d_comm_rank.argtypes = [C.c_void_p]
+        L.m3d_comm_collectives.restype = C.c_uint64
+        L.m3d_comm_collectives.argtypes = [C.c_void_p]
+        L.m3d_cloud_fit_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_double, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_segment_plane_iterative_sharded.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double,
+                                                          C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_segment_plane_iterative_multi.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double,
+                                                        C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_fit_multi.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_size_t, C.c_double,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_registration_ransac_sharded.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                      C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double,
+                                                      C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p]
+        L.m3d_get_config.restype = None
+        L.m3d_get_config.argtypes = [C.c_void_p]
+        L.m3d_set_config.argtypes = [C.c_void_p]
+        L.m3d_release_cached.restype = None
+        L.m3d_release_cached.argtypes = [C.c_int]
         _lib = L
     return _lib
+
+
+class Config(C.Structure):
+    """m3d_config (include/misc3d_amd.h): the library's tunables."""
+    _fields_ = [(k, C.c_int32) for k in ("dense_scoring", "speculative_refine", "lead_hypotheses",
+                                         "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
+                                         "morton_order", "reg_neighbour_lists", "reg_source_rows", "reg_prune",
+                                         "match_brute", "match_fp32_screen", "pool_limit_mb")] + [("reserved", C.c_int32 * 3)]
+
+
+def get_config() -> Config:
+    c = Config()
+    lib().m3d_get_config(C.byref(c))
+    return c
+
+
+def set_config(**kw) -> Config:
+    """Change some tunables (m3d_set_config); returns the PREVIOUS settings, to be restored with restore_config."""
+    old = get_config()
+    new = get_config()
+    for k, v in kw.items():
+        if not hasattr(new, k) or k == "reserved":
+            raise AttributeError(k)
+        setattr(new, k, int(v))
+    _check(lib().m3d_set_config(C.byref(new)))
+    return old
+
+
+def restore_config(cfg: Config):
+    _check(lib().m3d_set_config(C.byref(cfg)))
+
+
+class Comm:
+    """m3d_comm: the exchange of the hypothesis-sharded entry points (include/misc3d_amd.h).
+
+    Comm.rccl(group, device)   one process per GPU: rank 0's ncclUniqueId travels over `group` (any
+                               torch.distributed group, e.g. gloo), then ncclCommInitRank inside the library.
+    Comm.host(world, rank, fn) fn(send: bytes) -> bytes of world * len(send): caller-supplied all-gather.
+    Comm.torch_host(group)     the same over torch.distributed.all_gather_into_tensor of `group` (tests: gloo)."""
+
+    def __init__(self, handle, keep=None):
+        if not handle:
+            raise M3DError(ERR_DEVICE, last_error())
+        self._h = handle
+        self._keep = keep
+
+    @classmethod
+    def rccl(cls, group=None, device=0, world=None, rank=None):
+        import torch
+        import torch.distributed as dist
+        if world is None:
+            world, rank = (dist.get_world_size(group), dist.get_rank(group)) if dist.is_initialized() else (1, 0)
+        ident = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            _check(lib().m3d_comm_unique_id(_p(ident)))
+        if world > 1:
+            t = torch.from_numpy(ident)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(lib().m3d_comm_create_rccl(_p(ident), world, rank, device))
+
+    @classmethod
+    def host(cls, world, rank, fn):
+        def _cb(_user, send, recv, nbytes):
+            try:
+                out = fn(C.string_at(send, nbytes))
+                if len(out) != nbytes * world:
+                    return 2
+                C.memmove(recv, out, nbytes * world)
+                return 0
+            except Exception:       # noqa: BLE001 -- must not unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLGATHER_FN(_cb)
+        return cls(lib().m3d_comm_create_host(world, rank, cb, None), keep=cb)
+
+    @classmethod
+    def torch_host(cls, group=None):
+        import torch
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def gather(b):
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+            out = torch.empty(world * len(b), dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, t, group=group)
+            return out.numpy().tobytes()
+        return cls.host(world, rank, gather)
+
+    @property
+    def world(self):
+        return int(lib().m3d_comm_world(self._h))
+
+    @property
+    def rank(self):
+        return int(lib().m3d_comm_rank(self._h))
+
+    @property
+    def collectives(self):
+        return int(lib().m3d_comm_collectives(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().m3d_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def last_error() -> str:
@@ -354,6 +498,27 @@ class Cloud:
         d["n_inliers"] = int(ni.value)
         return Fit(rc, params, inliers, d)
 
+    def fit_sharded(self, comm, kind, threshold=0.01, max_iteration=1000, probability=0.9999, seed=None,
+                    want_inliers=True, copy=True) -> Fit:
+        """m3d_cloud_fit_sharded: the same fit with the hypothesis loop sharded over the ranks of `comm` (every
+        rank calls it on its own replica of the cloud and gets the same result)."""
+        params = np.zeros(NUM_PARAMS[kind])
+        inl = self._out_buf() if want_inliers else None
+        ni = C.c_size_t(0)
+        st = Stats()
+        _s, sref = _seed_ref(seed)
+        rc = _check(lib().m3d_cloud_fit_sharded(self._h, comm._h if comm is not None else None, kind, threshold,
+                                                max_iteration, probability,
+                                                C.cast(sref, C.c_void_p) if sref else None, _p(params), _p(inl),
+                                                C.cast(C.byref(ni), C.c_void_p), C.cast(C.byref(st), C.c_void_p)))
+        if want_inliers:
+            inliers = inl[: ni.value].copy() if copy else inl[: ni.value]
+        else:
+            inliers = np.zeros(0, dtype=np.uint64)
+        d = st.asdict()
+        d["n_inliers"] = int(ni.value)
+        return Fit(rc, params, inliers, d)
+
     def score_range(self, kind, threshold, samples, begin=0, end=None, want_models=True):
         """m3d_cloud_score_range -> (valid, models or None, counts) for hypotheses [begin, end)."""
         samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, MINIMAL_SAMPLE[kind])
@@ -371,7 +536,7 @@ class Cloud:
         samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, MINIMAL_SAMPLE[kind])
         ms = C.c_double(0)
         listed = C.c_uint64(0)
-        _check(lib().m3d_cloud_time_score(self._h, kind, threshold, _p(samples), len(samples), reps, mode,
+        _check(lib().m3d_bench_time_score(self._h, kind, threshold, _p(samples), len(samples), reps, mode,
                                           C.cast(C.byref(ms), C.c_void_p), C.cast(C.byref(listed), C.c_void_p)))
         return float(ms.value), int(listed.value)
 
@@ -464,6 +629,82 @@ def segment_plane_iterative(xyz, threshold, max_iteration=100, min_ratio=0.05, s
                                                   _p(planes), _p(offs), _p(idx), C.cast(C.byref(k), C.c_void_p)))
     k = k.value
     return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() for i in range(k)]
+
+
+def segment_plane_iterative_sharded(xyz, comm, threshold, max_iteration=100, min_ratio=0.05, seed=None, device=0,
+                                    max_clusters=4096):
+    """m3d_segment_plane_iterative_sharded (every rank of `comm` calls it with the same cloud)."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    n = len(xyz)
+    planes = np.zeros((max_clusters, 4))
+    offs = np.zeros(max_clusters + 1, dtype=np.uint64)
+    idx = np.empty(max(n, 1), dtype=np.uint64)
+    k = C.c_size_t(0)
+    _s, sref = _seed_ref(seed)
+    rc = _check(lib().m3d_segment_plane_iterative_sharded(_p(xyz), n, threshold, max_iteration, min_ratio,
+                                                          C.cast(sref, C.c_void_p) if sref else None, device,
+                                                          comm._h if comm is not None else None, max_clusters,
+                                                          _p(planes), _p(offs), _p(idx), C.cast(C.byref(k), C.c_void_p)))
+    k = k.value
+    return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() for i in range(k)]
+
+
+def segment_plane_iterative_multi(xyz, devices, threshold, max_iteration=100, min_ratio=0.05, seed=None,
+                                  max_clusters=4096):
+    """m3d_segment_plane_iterative_multi: one process, a thread and a replica per device of `devices`."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    n = len(xyz)
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    planes = np.zeros((max_clusters, 4))
+    offs = np.zeros(max_clusters + 1, dtype=np.uint64)
+    idx = np.empty(max(n, 1), dtype=np.uint64)
+    k = C.c_size_t(0)
+    _s, sref = _seed_ref(seed)
+    rc = _check(lib().m3d_segment_plane_iterative_multi(_p(xyz), n, threshold, max_iteration, min_ratio,
+                                                        C.cast(sref, C.c_void_p) if sref else None, _p(dev), len(dev),
+                                                        max_clusters, _p(planes), _p(offs), _p(idx),
+                                                        C.cast(C.byref(k), C.c_void_p)))
+    k = k.value
+    return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() for i in range(k)]
+
+
+def fit_multi(kind, xyz, devices, normals=None, threshold=0.01, max_iteration=1000, probability=0.9999, seed=None) -> Fit:
+    """m3d_fit_multi: one-shot fit from one process driving the devices of `devices`."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+    n = len(xyz)
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    params = np.zeros(NUM_PARAMS[kind])
+    inl = np.empty(max(n, 1), dtype=np.uint64)
+    ni = C.c_size_t(0)
+    st = Stats()
+    _s, sref = _seed_ref(seed)
+    rc = _check(lib().m3d_fit_multi(kind, _p(xyz), _p(nrm), n, threshold, max_iteration, probability,
+                                    C.cast(sref, C.c_void_p) if sref else None, _p(dev), len(dev), _p(params), _p(inl),
+                                    C.cast(C.byref(ni), C.c_void_p), C.cast(C.byref(st), C.c_void_p)))
+    d = st.asdict()
+    d["n_inliers"] = int(ni.value)
+    return Fit(rc, params, inl[: ni.value].copy(), d)
+
+
+def registration_ransac_sharded(src, dst, corr_src, corr_dst, comm, threshold=0.01, max_iter=100000,
+                                edge_length_threshold=0.9, confidence=0.999, seed=None, device=0):
+    """m3d_registration_ransac_sharded (every rank of `comm` calls it with the same inputs)."""
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    cs = np.ascontiguousarray(corr_src, dtype=np.uint64)
+    cd = np.ascontiguousarray(corr_dst, dtype=np.uint64)
+    if len(cs) != len(cd):
+        raise ValueError("correspondence lists differ in length")
+    T = np.zeros(16)
+    st = RegStats()
+    _s, sref = _seed_ref(seed)
+    _check(lib().m3d_registration_ransac_sharded(_p(src), len(src), _p(dst), len(dst), _p(cs), _p(cd), len(cs),
+                                                 threshold, max_iter, edge_length_threshold, confidence,
+                                                 C.cast(sref, C.c_void_p) if sref else None, device,
+                                                 comm._h if comm is not None else None, _p(T),
+                                                 C.cast(C.byref(st), C.c_void_p)))
+    return T.reshape(4, 4), st.asdict()
 
 
 def kabsch(src, dst, scaling=False, device=0):

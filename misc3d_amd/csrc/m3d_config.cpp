@@ -1,0 +1,72 @@
+// m3d_config.cpp -- environment -> m3d_config, once (see m3d_config.hpp).
+#include "m3d_config.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "m3d_driver.hpp"
+
+namespace m3d {
+namespace {
+m3d_config g_cfg;
+std::once_flag g_once;
+
+long env_long(const char* name, long def) {
+    const char* e = std::getenv(name);
+    if (!e || !*e) return def;
+    char* end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    return end == e ? def : v;
+}
+bool env_is(const char* name, char first) {
+    const char* e = std::getenv(name);
+    return e && e[0] == first;
+}
+void sanitize(m3d_config& c) {
+    if (c.lead_hypotheses < 64 || c.lead_hypotheses % 64) c.lead_hypotheses = 128;
+    if (c.score_groups_per_block < 1 || c.score_groups_per_block > 64) c.score_groups_per_block = 8;
+    if (c.score_min_workgroups < 1) c.score_min_workgroups = 16384;
+    if (c.dense_workgroups < 1) c.dense_workgroups = 8192;
+    if (c.pool_limit_mb < 0) c.pool_limit_mb = 0;
+}
+void load_env() {
+    std::memset(&g_cfg, 0, sizeof(g_cfg));
+    g_cfg.dense_scoring = env_is("M3D_DENSE", '1');
+    g_cfg.speculative_refine = !env_is("M3D_SPEC", '0');
+    g_cfg.lead_hypotheses = (int32_t)env_long("M3D_LEAD", 128);        // sweep on C2: 64 and 128 equal, 256 +2.5 %, 512 +4 %
+    g_cfg.score_groups_per_block = (int32_t)env_long("M3D_GPB", 8);
+    g_cfg.score_min_workgroups = (int32_t)env_long("M3D_SCORE_MIN_WGS", 16384);
+    g_cfg.dense_workgroups = (int32_t)env_long("M3D_SCORE_WGS", 8192);  // sweep on MI355X: 2048 +5 %, 4096 +1.5 %, 8192..32768 flat
+    g_cfg.morton_order = env_is("M3D_ORDER", 'm');
+    g_cfg.reg_neighbour_lists = !env_is("M3D_REG_NL", '0');
+    g_cfg.reg_source_rows = env_is("M3D_REG_SRC_ORDER", 'r');
+    g_cfg.reg_prune = !env_is("M3D_REG_PRUNE", '0');
+    g_cfg.match_brute = env_is("M3D_MATCH_BRUTE", '1');
+    g_cfg.match_fp32_screen = env_is("M3D_MATCH_SCREEN", 'f');
+    g_cfg.pool_limit_mb = (int32_t)env_long("M3D_POOL_MB", 4096);
+    sanitize(g_cfg);
+}
+}  // namespace
+
+const m3d_config& config() {
+    std::call_once(g_once, load_env);
+    return g_cfg;
+}
+void config_store(const m3d_config& c) {
+    std::call_once(g_once, load_env);
+    g_cfg = c;
+    sanitize(g_cfg);
+}
+}  // namespace m3d
+
+extern "C" {
+void m3d_get_config(m3d_config* out) {
+    if (out) *out = m3d::config();
+}
+int m3d_set_config(const m3d_config* in) {
+    if (!in) return m3d::fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    m3d::config_store(*in);
+    return M3D_OK;
+}
+}

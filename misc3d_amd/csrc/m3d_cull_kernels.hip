@@ -25,6 +25,7 @@
 
 #include <cstdlib>
 
+#include "m3d_config.hpp"
 #include "m3d_fp.hpp"
 
 #pragma clang fp contract(off)
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(64) void cull_mask_k(const double* __restrict__ box
                                                    uint32_t tiles_per_block, const double* __restrict__ score,
                                                    const uint8_t* __restrict__ valid, uint32_t h_count,
                                                    uint32_t n_groups, unsigned long long* __restrict__ masks,
-                                                   uint32_t* __restrict__ ub, double max_abs) {
+                                                   uint32_t* __restrict__ ub, double max_abs, uint32_t group_begin) {
     const int lane = threadIdx.x;
-    const uint32_t group = blockIdx.x;
+    const uint32_t group = group_begin + blockIdx.x;
     const uint32_t h = group * 64u + lane;
     const bool live = h < h_count && valid[h];
     double rec[kModelStride];
@@ -156,20 +157,23 @@ __global__ __launch_bounds__(64) void cull_mask_k(const double* __restrict__ box
 }
 
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
-                      uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st, bool ub_is_zero) {
-    if (!s.n_tiles || !n_groups) return;
-    if (ub && !ub_is_zero) (void)hipMemsetAsync(ub, 0, sizeof(uint32_t) * (size_t)n_groups * 64, st);
+                      uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st, bool ub_is_zero,
+                      uint32_t group_begin, uint32_t group_end) {
+    group_end = std::min(group_end, n_groups);
+    if (!s.n_tiles || group_begin >= group_end) return;
+    const uint32_t window = group_end - group_begin;
+    if (ub && !ub_is_zero) (void)hipMemsetAsync(ub + (size_t)group_begin * 64, 0, sizeof(uint32_t) * (size_t)window * 64, st);
     // enough waves to fill the chip: split the tile range when there are few hypothesis groups
-    uint32_t splits = std::max<uint32_t>(1, (8192 + n_groups - 1) / n_groups);
+    uint32_t splits = std::max<uint32_t>(1, (8192 + window - 1) / window);
     splits = std::min(splits, std::max<uint32_t>(1, s.n_tiles / 16));  // >= 16 tiles per wave: the record loads amortise
     const uint32_t tpb = (s.n_tiles + splits - 1) / splits;
-    const dim3 g(n_groups, (s.n_tiles + tpb - 1) / tpb), b(64);
+    const dim3 g(window, (s.n_tiles + tpb - 1) / tpb), b(64);
     if (kind == 0)
-        cull_mask_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs);
+        cull_mask_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin);
     else if (kind == 1)
-        cull_mask_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs);
+        cull_mask_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin);
     else
-        cull_mask_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs);
+        cull_mask_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin);
 }
 
 // keep[g] = hypotheses of group g that are still worth scoring: ub[h] * 512 >= best_count[0]
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(64) void keep_mask_k(const uint32_t* __restrict__ u
     if (zero) {
 #pragma unroll
         for (int r = 0; r < kCountReplicas; ++r) zero[(size_t)r * rep_stride + h] = 0u;
-        if (g == 0)
+        if (blockIdx.x == 0)   // (first workgroup of the launch, whatever its group window)
             for (int i = threadIdx.x; i < kPairReplicas; i += 64) zero[(size_t)kCountReplicas * rep_stride + i] = 0u;
     }
 }
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
         for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
         const bool ok = h < h_count && valid[h];
         if (blockIdx.x == 0) {
-            records[h] = c | (ok ? 0x80000000u : 0u);
+            if (records) records[h] = c | (ok ? 0x80000000u : 0u);
             if (records_dev) records_dev[h] = c | (ok ? 0x80000000u : 0u);
         }
         v = max(v, ok ? c : 0u);
@@ -244,10 +248,13 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
 }
 void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
-                           unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st, uint32_t* records_dev) {
+                           unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st, uint32_t* records_dev,
+                           uint32_t group_begin) {
+    if (group_begin == 0xFFFFFFFFu) group_begin = lead / 64u;
+    // (n_groups_rest == 0 still needs the fold of the lead's counters: one workgroup whose keep word is scratch)
     if (!n_groups_rest) return;
     lead_fold_keep_k<<<n_groups_rest, 64, 0, st>>>(counts_rep, rep_stride, lead, valid, h_count, records, best_count, ub,
-                                                   keep, const_cast<uint32_t*>(counts_rep), lead / 64u, records_dev);
+                                                   keep, const_cast<uint32_t*>(counts_rep), group_begin, records_dev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,16 +378,18 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
     if ((uint32_t)lane < slot && park_cnt) atomicAdd(&counts[park_h], park_cnt);
 }
 
-// counts[h] = sum over the replicas; counts[pairs_slot] = evaluated (tile, hypothesis) pairs of the launch
-// valid != null: bit 31 of counts[h] carries MinimalFit's return (one D2H copy instead of two; counts < 2^31);
+// records[h] = sum over the replicas for h in [h_begin, h_end), written to `counts` (device-visible host memory, may be
+// null) and `counts_dev` (device, may be null); *pairs_out (device-visible, may be null) = evaluated (tile, hypothesis)
+// pairs of the launch.
+// valid != null: bit 31 of the record carries MinimalFit's return (one array instead of two; counts < 2^31);
 // best_count != null: running maximum over the valid hypotheses (bound-and-prune incumbent).
-__global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t rep_stride, uint32_t h_pad,
+__global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t rep_stride, uint32_t h_end,
                                uint32_t* __restrict__ counts, const uint32_t* __restrict__ pair_rep,
-                               uint32_t pairs_slot, const uint8_t* __restrict__ valid, uint32_t h_count,
+                               uint32_t* __restrict__ pairs_out, const uint8_t* __restrict__ valid, uint32_t h_count,
                                uint32_t* __restrict__ best_count, uint32_t h_begin,
                                uint32_t* __restrict__ counts_dev /* device copy of the records, or null */) {
-    const uint32_t h = h_begin + blockIdx.x * 256u + threadIdx.x;   // window [h_begin, h_pad) of the chunk
-    if (blockIdx.x == 0 && pair_rep) {   // block-uniform
+    const uint32_t h = h_begin + blockIdx.x * 256u + threadIdx.x;   // window [h_begin, h_end) of the chunk
+    if (blockIdx.x == 0 && pair_rep && pairs_out) {   // block-uniform
         __shared__ uint32_t red[256];
         uint32_t p = 0;
         for (int r = threadIdx.x; r < kPairReplicas; r += 256) p += pair_rep[r];
@@ -390,9 +399,9 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
             if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
             __syncthreads();
         }
-        if (threadIdx.x == 0) counts[pairs_slot] = red[0];
+        if (threadIdx.x == 0) *pairs_out = red[0];
     }
-    const bool mine = h < h_pad && !(pair_rep && h == pairs_slot);
+    const bool mine = h < h_end;
     uint32_t c = 0;
     if (mine) {
 #pragma unroll
@@ -401,7 +410,7 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
     const bool ok = mine && valid && h < h_count && valid[h];
     if (mine) {
         const uint32_t rec = valid ? (c | (ok ? 0x80000000u : 0u)) : c;
-        counts[h] = rec;
+        if (counts) counts[h] = rec;
         if (counts_dev) counts_dev[h] = rec;
     }
     if (best_count) {   // wave-uniform
@@ -410,12 +419,12 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
         if ((threadIdx.x & 63) == 0 && v) atomicMax(best_count, v);
     }
 }
-void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
-                         const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
+void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_end, uint32_t* counts,
+                         const uint32_t* pair_rep, uint32_t* pairs_out, const uint8_t* valid, uint32_t h_count,
                          uint32_t* best_count, hipStream_t st, uint32_t h_begin, uint32_t* counts_dev) {
-    if (h_pad > h_begin)
-        sum_replicas_k<<<(h_pad - h_begin + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_pad, counts, pair_rep,
-                                                                      pairs_slot, valid, h_count, best_count, h_begin,
+    if (h_end > h_begin)
+        sum_replicas_k<<<(h_end - h_begin + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_end, counts, pair_rep,
+                                                                      pairs_out, valid, h_count, best_count, h_begin,
                                                                       counts_dev);
 }
 
@@ -427,13 +436,15 @@ void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32
 __global__ __launch_bounds__(1024) void pick_best_k(const uint32_t* __restrict__ records, uint32_t count,
                                                      unsigned long long index_base, const double* __restrict__ params,
                                                      int first_chunk, BestPick* __restrict__ pick,
-                                                     BestPickHost* __restrict__ pick_host) {
+                                                     BestPickHost* __restrict__ pick_host,
+                                                     uint32_t* __restrict__ records_host, uint32_t* __restrict__ best_count) {
     __shared__ uint32_t s_cnt[1024];
     __shared__ uint32_t s_idx[1024];
     __shared__ int s_take;
     uint32_t bc = 0, bi = 0xFFFFFFFFu;
     for (uint32_t i = threadIdx.x; i < count; i += 1024u) {
         const uint32_t r = records[i];
+        if (records_host) records_host[i] = r;   // sharded fits: the gathered records reach the host through this kernel
         const uint32_t c = r & 0x7FFFFFFFu;
         if ((r >> 31) && c > bc) {   // ascending i per thread: the first of equals stays
             bc = c;
@@ -455,6 +466,7 @@ __global__ __launch_bounds__(1024) void pick_best_k(const uint32_t* __restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        if (best_count && s_cnt[0]) atomicMax(best_count, s_cnt[0]);   // other ranks' hypotheses raise the incumbent too
         const bool had = !first_chunk && pick->have;
         const bool take = s_cnt[0] > 0 && (!had || s_cnt[0] > pick->cnt);
         s_take = take ? 1 : 0;
@@ -478,8 +490,10 @@ __global__ __launch_bounds__(1024) void pick_best_k(const uint32_t* __restrict__
     }
 }
 void launch_pick_best(const uint32_t* records, uint32_t count, unsigned long long index_base, const double* params,
-                      bool first_chunk, BestPick* pick, BestPickHost* pick_host, hipStream_t st) {
-    pick_best_k<<<1, 1024, 0, st>>>(records, count, index_base, params, first_chunk ? 1 : 0, pick, pick_host);
+                      bool first_chunk, BestPick* pick, BestPickHost* pick_host, hipStream_t st, uint32_t* records_host,
+                      uint32_t* best_count) {
+    pick_best_k<<<1, 1024, 0, st>>>(records, count, index_base, params, first_chunk ? 1 : 0, pick, pick_host,
+                                    records_host, best_count);
 }
 
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
@@ -489,16 +503,8 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     if (!s.n_tiles || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
     // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
-    static const uint32_t gpb_max = [] {
-        const char* e = std::getenv("M3D_GPB");   // tuning knob
-        const long v = e ? std::atol(e) : 0;
-        return (uint32_t)(v >= 1 && v <= 64 ? v : kGroupsPerBlock);
-    }();
-    static const uint32_t min_wgs = [] {
-        const char* e = std::getenv("M3D_SCORE_MIN_WGS");   // tuning knob
-        const long v = e ? std::atol(e) : 0;
-        return (uint32_t)(v >= 1 ? v : 16384);
-    }();
+    const uint32_t gpb_max = (uint32_t)config().score_groups_per_block;
+    const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * window) / min_wgs)));
     const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);
     if (kind == 0)

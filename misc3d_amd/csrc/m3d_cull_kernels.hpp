@@ -25,7 +25,8 @@ void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 // ub (may be null; n_groups * 64 entries, zeroed here): number of tiles each hypothesis may touch.
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
                       uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st,
-                      bool ub_is_zero = false);
+                      bool ub_is_zero = false, uint32_t group_begin = 0,
+                      uint32_t group_end = 0xFFFFFFFFu /* only groups [group_begin, group_end) of the chunk (sharded fits) */);
 // keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
 // zero_counts_rep != null: the same launch clears the kCountReplicas x rep_stride + kPairReplicas counter words.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
@@ -41,13 +42,12 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
                        uint32_t* pair_rep /* kPairReplicas u32, zero on entry: evaluated (tile, hypothesis) pairs */,
                        hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */);
-// pair_rep != null: counts[pairs_slot] receives the sum of the pair counters (pairs_slot must be >= the number of
-// real hypotheses; that entry is then not a hypothesis count)
-// valid != null: counts[h] |= valid[h] << 31 for h < h_count; best_count != null: atomic running maximum of the
-// valid hypotheses' counts
-void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_pad, uint32_t* counts,
-                         const uint32_t* pair_rep, uint32_t pairs_slot, const uint8_t* valid, uint32_t h_count,
-                         uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_pad) */,
+// Folds the replicas of hypotheses [h_begin, h_end): record = count | valid << 31 (valid != null, h < h_count) to
+// `counts` (device-visible host memory, may be null) and `counts_dev` (may be null); *pairs_out (may be null) = sum of
+// the pair counters; best_count != null: atomic running maximum of the valid hypotheses' counts.
+void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_end, uint32_t* counts,
+                         const uint32_t* pair_rep, uint32_t* pairs_out, const uint8_t* valid, uint32_t h_count,
+                         uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_end) */,
                          uint32_t* counts_dev = nullptr /* the same records once more, in device memory */);
 // The device's prediction of the hypothesis the replay will end with (pick_best_k, m3d_cull_kernels.hip)
 struct BestPick {
@@ -60,13 +60,16 @@ struct BestPickHost {           // mirror in pinned host memory, written by the 
     uint32_t cnt, have;
 };
 void launch_pick_best(const uint32_t* records, uint32_t count, unsigned long long index_base, const double* params,
-                      bool first_chunk, BestPick* pick, BestPickHost* pick_host, hipStream_t st);
+                      bool first_chunk, BestPick* pick, BestPickHost* pick_host, hipStream_t st,
+                      uint32_t* records_host = nullptr /* device-visible host copy of the records (sharded fits) */,
+                      uint32_t* best_count = nullptr /* raised to the best valid count among the records */);
 // lead pass folded + keep masks (and cleared counters) of groups [lead / 64, lead / 64 + n_groups_rest) in one launch;
 // records[h] = count | valid << 31 for h < lead; best_count (not null) raised by the lead's best valid count.
 void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
                            unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st,
-                           uint32_t* records_dev = nullptr);
+                           uint32_t* records_dev = nullptr,
+                           uint32_t group_begin = 0xFFFFFFFFu /* first group of the keep window; default lead / 64 */);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,
                        uint32_t n_groups, unsigned long long* total, hipStream_t st);
 

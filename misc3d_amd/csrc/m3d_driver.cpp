@@ -19,6 +19,8 @@
 //
 // There is no CPU fallback: every entry point needs a HIP device.
 #include "m3d_driver.hpp"
+#include "m3d_comm.hpp"
+#include "m3d_config.hpp"
 #include "m3d_fp.hpp"
 #include "m3d_mt19937.hpp"
 #include "m3d_reg_kernels.hpp"
@@ -33,6 +35,7 @@
 #include <limits>
 #include <map>
 #include <random>
+#include <thread>
 
 #pragma clang fp contract(off)
 
@@ -56,7 +59,7 @@ int fail(int code, const std::string& msg) {
 
 namespace {
 constexpr int kPoolDevices = 16;
-constexpr size_t kPoolLimit = (size_t)8 << 30;   // bytes parked per device
+static size_t pool_limit() { return (size_t)config().pool_limit_mb << 20; }   // bytes parked per device
 struct DevPool {
     std::mutex mu;
     std::multimap<size_t, void*> blocks[kPoolDevices];
@@ -105,7 +108,7 @@ void DevBuf::release() {
         if (dev >= 0 && dev < kPoolDevices) {
             DevPool& pool = dev_pool();
             std::lock_guard<std::mutex> lock(pool.mu);
-            if (pool.bytes[dev] + cap <= kPoolLimit) {
+            if (pool.bytes[dev] + cap <= pool_limit()) {
                 pool.blocks[dev].emplace(cap, p);
                 pool.bytes[dev] += cap;
                 parked = true;
@@ -325,34 +328,17 @@ struct SampleSource {
 static uint32_t pick_splits(uint32_t n_tiles, uint32_t h_pad) {
     // enough workgroups to fill 256 CUs x 8 resident workgroups a couple of times over
     const uint32_t groups = h_pad / 64;
-    static const uint32_t target_wgs = [] {
-        const char* e = std::getenv("M3D_SCORE_WGS");  // tuning knob (default chosen on MI355X)
-        const long v = e ? std::atol(e) : 0;
-        return (uint32_t)(v > 0 ? v : 8192);  // sweep on MI355X: 2048 +5 %, 4096 +1.5 %, 8192..32768 flat
-    }();
+    const uint32_t target_wgs = (uint32_t)config().dense_workgroups;
     const uint32_t want = std::max<uint32_t>(1, (target_wgs + n_tiles - 1) / n_tiles);
     return std::min(want, groups);
 }
 
-// M3D_DENSE=1 selects the dense scoring kernel (score_k: every tile x every hypothesis) instead of the
-// culled path (cull_k + score_list_k); both produce identical counts (tests run both).
-static bool use_dense_scoring() {
-    static const bool dense = [] {
-        const char* e = std::getenv("M3D_DENSE");
-        return e && e[0] == '1';
-    }();
-    return dense;
-}
+// m3d_config.dense_scoring selects the dense scoring kernel (score_k: every tile x every hypothesis) instead of the
+// culled path (cull_mask_k + score_mask_k); both produce identical counts (tests/test_gpu_parity.py runs both).
+static bool use_dense_scoring() { return config().dense_scoring != 0; }
 
 // Hypotheses at the head of a probability-1 fit that are counted first, for the incumbent that prunes the rest.
-static uint32_t lead_size() {
-    static const uint32_t lead = [] {
-        const char* e = std::getenv("M3D_LEAD");   // tuning knob (multiple of 64)
-        const long v = e ? std::atol(e) : 0;
-        return (uint32_t)(v >= 64 && v % 64 == 0 ? v : 128);   // sweep on C2: 64 and 128 equal, 256 +2.5 %, 512 +4 %
-    }();
-    return lead;
-}
+static uint32_t lead_size() { return (uint32_t)config().lead_hypotheses; }
 
 static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
     // keep the per-chunk scratch below 1 GiB (dense: u32 partial count per (tile, hypothesis);
@@ -364,15 +350,26 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
     return std::max<size_t>(cap, 64);
 }
 
+// Sharded fits (comm != null): the chunk is the SAME window of the one hypothesis stream on every rank
+// -- sample table, MinimalFit and parameter records for all of it (a thread per hypothesis: microseconds) -- but
+// the box tests and the scoring cover only this rank's slice of `sl_pad` hypotheses (+ the window's leading
+// hypotheses, for the pruning incumbent; their owner is rank 0).  The slices' records are then all-gathered in place
+// in s.counts, so that everything after it (pick_best_k, the replay, the tie rule reading s.params) sees the whole
+// chunk exactly as the one-GPU path does.
 static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const SortedView& sv, int kind,
                        double thr, size_t begin, size_t end, SampleSource& src, double* ms_sample,
                        bool prune = false, uint32_t lead = 0, bool new_fit = false /* clears the running best count */,
-                       bool device_records = false /* culled path: keep a device copy of the records in s.counts */) {
+                       bool device_records = false /* culled path: keep a device copy of the records in s.counts */,
+                       m3d_comm* comm = nullptr) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
-    const uint32_t h_pad = round_up(count, 64);
-    const uint32_t n_tiles = v.n_pad / kScoreTile;
     const bool dense = use_dense_scoring();
+    if (comm && dense) return fail(M3D_ERR_INVALID_ARG, "sharded fits use the culled scoring path (m3d_config.dense_scoring = 0)");
+    const uint32_t world = comm ? (uint32_t)comm->world : 1u, rank = comm ? (uint32_t)comm->rank : 0u;
+    const uint32_t sl_pad = round_up((count + world - 1) / world, 64);   // hypotheses per rank
+    const uint32_t h_pad = comm ? sl_pad * world : round_up(count, 64);
+    const uint32_t n_tiles = v.n_pad / kScoreTile;
+    if (comm) device_records = true;
     s.begin = begin;
     s.end = end;
     s.h_pad = h_pad;
@@ -383,7 +380,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (dense || device_records) RESERVE(s.counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // (culled path: records go straight to h_counts)
     uint32_t* rec_dev = (!dense && device_records) ? s.counts.as<uint32_t>() : nullptr;
     RESERVE(s.h_samples, sizeof(uint32_t) * (size_t)count * m);
-    RESERVE(s.h_counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // + the launch's pair counter behind the counts
+    RESERVE(s.h_counts, sizeof(uint32_t) * ((size_t)h_pad + 2));   // + the launch's pair counter behind the records
     RESERVE(s.h_valid, (size_t)h_pad + 1);
     if (dense) {
         RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
@@ -405,6 +402,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     // (culled path: keep_mask_k clears the counter replicas on its way)
+    s.lead_groups = 0;
+    s.scored = false;
+    uint32_t* h_pairs = s.h_counts.as<uint32_t>() + h_pad;   // pinned, device-visible
     if (dense) {
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
         launch_score(kind, v, s.score.as<double>(), h_pad, pick_splits(n_tiles, h_pad),
@@ -412,45 +412,71 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         HIPCHK(hipEventRecord(s.k1, ctx->stream));
         launch_reduce_partials(ctx->partial.as<uint32_t>(), n_tiles, h_pad, s.counts.as<uint32_t>(),
                                ctx->stream);
+        s.scored = true;
     } else {
-        // prune (fits only): hypotheses that cannot reach the best count of EARLIER chunks are masked
-        // out (keep_mask_k); ctx->best_count is the device-side running maximum
+        // prune (fits only): hypotheses that cannot reach the best count of EARLIER hypotheses are masked
+        // out (keep_mask_k); ctx->best_count is the device-side running maximum of the fit
         const uint32_t n_groups = h_pad / 64;
+        // this rank's groups [g0, g1) of the chunk
+        const uint32_t g0 = comm ? rank * (sl_pad / 64) : 0u, g1 = comm ? g0 + sl_pad / 64 : n_groups;
+        const bool own_real = (size_t)g0 * 64 < count;   // (a short last window can leave the highest ranks without work)
         uint32_t* ub = prune ? ctx->ub.as<uint32_t>() : nullptr;
         auto* masks = ctx->masks.as<unsigned long long>();
         auto* keep = ctx->keep.as<unsigned long long>();
-        launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
-                         /*ub_is_zero=*/true);
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
         uint32_t* bc = prune ? ctx->best_count.as<uint32_t>() : nullptr;
+        uint32_t* rec_host = comm ? nullptr : s.h_counts.as<uint32_t>();   // sharded: the host gets the GATHERED records
         // lead > 0 (a fit's first chunk): the first `lead` hypotheses are counted on their own, and their best
         // count then prunes the rest of the SAME chunk -- what a separate small first chunk did, without its
         // own sample copy, MinimalFit and box-test launches.  The records are complete after the second pass.
-        s.lead_groups = 0;
-        if (prune && lead >= 64 && lead % 64 == 0 && lead + 64 <= count) {
-            const uint32_t ga = lead / 64;
-            s.lead_groups = ga;
-            launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
-            HIPCHK(hipEventRecord(s.k2, ctx->stream));
-            launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
-                              h_pad, pair_rep, ctx->stream, 0, ga);
-            HIPCHK(hipEventRecord(s.k3, ctx->stream));
-            // fold of the lead's counters + keep masks of the rest: one launch
-            launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
-                                  s.h_counts.as<uint32_t>(), bc, ub, keep, n_groups - ga, ctx->stream, rec_dev);
+        const bool use_lead = prune && lead >= 64 && lead % 64 == 0 && lead + 64 <= count && (!comm || sl_pad >= lead + 64);
+        const uint32_t ga = use_lead ? lead / 64 : 0u;
+        if (own_real) {
+            if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
+                launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
+                                 ctx->stream, /*ub_is_zero=*/true, 0, ga);
+            launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
+                             /*ub_is_zero=*/true, g0, g1);
+            uint32_t g_lo = g0;
+            if (ga) {
+                s.lead_groups = ga;
+                g_lo = std::max(g0, ga);
+                launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
+                HIPCHK(hipEventRecord(s.k2, ctx->stream));
+                launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
+                                  h_pad, pair_rep, ctx->stream, 0, ga);
+                HIPCHK(hipEventRecord(s.k3, ctx->stream));
+                // fold of the lead's counters + keep masks of the rest of this rank's groups: one launch
+                launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
+                                      g0 == 0 ? rec_host : nullptr, bc, ub, keep, g1 - g_lo, ctx->stream,
+                                      g0 == 0 ? rec_dev : nullptr, g_lo);
+            } else {
+                launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
+            }
+            HIPCHK(hipEventRecord(s.k0, ctx->stream));
+            launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
+                              pair_rep, ctx->stream, g_lo, g1);
+            HIPCHK(hipEventRecord(s.k1, ctx->stream));
+            // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
+            // ... and (one GPU) write the records straight into the slot's pinned host array (device-visible): no copy
+            // command behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
+            launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, g1 * 64u, rec_host, pair_rep, h_pairs,
+                                s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u, rec_dev);
+            s.scored = true;
+        } else {
+            HIPCHK(hipMemsetAsync(rec_dev + (size_t)g0 * 64, 0, sizeof(uint32_t) * sl_pad, ctx->stream));
+            *h_pairs = 0;
         }
-        const uint32_t g_lo = s.lead_groups;
-        if (!g_lo)
-            launch_keep_mask(ub, bc, n_groups, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
-        HIPCHK(hipEventRecord(s.k0, ctx->stream));
-        launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
-                          pair_rep, ctx->stream, g_lo, n_groups);
-        HIPCHK(hipEventRecord(s.k1, ctx->stream));
-        // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
-        // ... and writes the records straight into the slot's pinned host array (device-visible): no copy command
-        // behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
-        launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, h_pad, s.h_counts.as<uint32_t>(), pair_rep, count,
-                            s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u, rec_dev);
+        if (comm) {
+            // the one exchange of the window: every rank's slice of records, in place (RCCL: ncclAllGather on this
+            // stream, nothing on the host; host transports wait for the stream and leave the records in h_counts)
+            int host_has_all = 0;
+            const int rc = comm->allgather_u32_device(rec_dev, sl_pad, ctx->stream, s.h_counts.as<uint32_t>(), &host_has_all);
+            if (rc != M3D_OK) return rc;
+            if (!host_has_all)
+                HIPCHK(hipMemcpyAsync(s.h_counts.p, rec_dev, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost,
+                                      ctx->stream));
+        }
     }
     // counts of the chunk + (culled path) the number of (tile, hypothesis) pairs the launch evaluated
     if (dense)
@@ -778,7 +804,8 @@ struct RansacOut {
 
 static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, int kind, double thr,
                       size_t max_iter, double prob, uint64_t seed, RansacOut* out, size_t iterations_hint = 0,
-                      const uint32_t* orig_dev = nullptr /* index map of a shrunk cloud (RefineModel's compaction) */) {
+                      const uint32_t* orig_dev = nullptr /* index map of a shrunk cloud (RefineModel's compaction) */,
+                      m3d_comm* comm = nullptr /* hypotheses sharded over its ranks (issue_chunk) */) {
     m3d_replay_init(&out->st);
     RESERVE(ctx->best_params, sizeof(double) * kModelStride);
     RESERVE(ctx->h_small, 256);
@@ -786,11 +813,8 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     // with the most inliers, lowest index first.  The device picks it itself after every chunk (pick_best_k) and,
     // behind the LAST chunk, RefineModel's compaction is queued on that pick at once -- while the host is still
     // waking up and replaying the records.  The replay stays the authority: cloud_fit_locked keeps the early
-    // compaction only if it names the same hypothesis.  M3D_SPEC=0 switches the prediction off.
-    static const bool spec_enabled = [] {
-        const char* e = std::getenv("M3D_SPEC");
-        return !(e && e[0] == '0');
-    }();
+    // compaction only if it names the same hypothesis.  m3d_config.speculative_refine = 0 switches the prediction off.
+    const bool spec_enabled = config().speculative_refine != 0;
     const bool spec = spec_enabled && prob >= 1.0 && !use_dense_scoring() && max_iter > 0;
     ctx->spec_compaction = false;
     if (spec) {
@@ -803,14 +827,16 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     src.n_points = v.n;
     src.m = minimal_sample(kind);
 
-    const size_t chunk_cap = chunk_cap_for(v, sv);
+    // sharded: the cap holds per rank, and the geometric start gives every rank a first slice of 128
+    const size_t n_ranks = comm ? (size_t)comm->world : 1;
+    const size_t chunk_cap = chunk_cap_for(v, sv) * n_ranks;
     // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
     // prob == 1: only fitness == 1 can stop it -> as few, equal chunks as the scratch cap allows
     // (one chunk up to 16384 hypotheses; more chunks are pipelined two deep)
     // Either way an incumbent exists early -- a small first chunk (prob < 1) or the first hypotheses (lead_size()) of
     // the first chunk counted in a pass of their own (prob == 1): its inlier count lets everything after it
     // skip the hypotheses that cannot reach it (bound-and-prune).
-    size_t chunk = 128;
+    size_t chunk = 128 * n_ranks;
     size_t growth = 2;
     size_t after_first = 0;  // prob == 1: size of the chunks after the first one
     uint32_t lead = 0;   // prob == 1: leading hypotheses of the FIRST chunk counted on their own (issue_chunk)
@@ -866,11 +892,13 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         want = std::min(std::max<size_t>(want, 64), chunk_cap);
         const size_t b = next_begin, e = std::min(max_iter, b + want);
         int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
-                            b == 0 ? lead : 0, b == 0, spec);
+                            b == 0 ? lead : 0, b == 0, spec, comm);
         if (r == M3D_OK && spec) {
             ChunkSlot& sl = ctx->slot[slot_id];
+            // (sharded: the records are the gathered ones; the other ranks' counts raise this rank's incumbent too)
             launch_pick_best(sl.counts.as<uint32_t>(), (uint32_t)(e - b), (unsigned long long)b, sl.params.as<double>(),
-                             b == 0, ctx->pick.as<BestPick>(), ctx->h_pick.as<BestPickHost>(), ctx->stream);
+                             b == 0, ctx->pick.as<BestPick>(), ctx->h_pick.as<BestPickHost>(), ctx->stream, nullptr,
+                             comm ? ctx->best_count.as<uint32_t>() : nullptr);
             if (e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
                 r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
                                             ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64);
@@ -879,7 +907,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
         if (r == M3D_OK) {
             next_begin = e;
-            out->hypotheses_scored += e - b;
+            out->hypotheses_scored += (e - b + n_ranks - 1) / n_ranks;   // this rank's share
             chunk = after_first ? std::min(after_first, chunk_cap) : std::min(chunk * growth, chunk_cap);
         }
         return r;
@@ -913,7 +941,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             unpack_slot(s);
             {
                 float kms = 0;
-                if (hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess) {
+                if (s.scored && hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess) {
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
@@ -921,7 +949,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
-                if (!use_dense_scoring()) out->pairs_scored += s.h_counts.as<uint32_t>()[s.end - s.begin];
+                if (!use_dense_scoring()) out->pairs_scored += s.h_counts.as<uint32_t>()[s.h_pad];
             }
             int cb_rc = M3D_OK;
             // exact EvaluateModel rmse (serial-order error sum), ransac.h:632-650
@@ -1044,7 +1072,8 @@ static uint64_t resolve_seed(const uint64_t* seed) {
 static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter, double prob,
                             uint64_t seed, double* params, size_t* inliers, size_t* n_inliers,
                             m3d_stats* stats, const std::function<int(int64_t)>* before_refine_wait = nullptr,
-                            size_t* iterations_hint = nullptr /* in: iterations of a similar fit, out: of this one */) {
+                            size_t* iterations_hint = nullptr /* in: iterations of a similar fit, out: of this one */,
+                            m3d_comm* comm = nullptr) {
     DeviceCtx* ctx = c->ctx;
     const double t0 = now_ms();
     HIPCHK(hipSetDevice(ctx->device));
@@ -1053,7 +1082,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     const uint32_t* orig = c->orig();
     RansacOut ro;
     int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro, iterations_hint ? *iterations_hint : 0,
-                        orig);
+                        orig, comm);
     if (rc != M3D_OK) return rc;
     if (iterations_hint) *iterations_hint = (size_t)ro.st.iterations;
     const double t1 = now_ms();
@@ -1364,10 +1393,7 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
             while (bits < 8 && ((uint64_t)1 << (3 * bits)) * 8 < n_finite) ++bits;
             GridDesc gs;
             gs.K = 0;
-            static const bool zorder = [] {
-                const char* e = std::getenv("M3D_ORDER");  // "morton" = plain Z-order (comparison only)
-                return e && e[0] == 'm';
-            }();
+            const bool zorder = config().morton_order != 0;   // plain Z-order (comparison only)
             gs.morton_bits = bits | (zorder ? 0u : 0x100u);  // Hilbert order by default
             gs.nx = gs.ny = gs.nz = 1u << bits;
             gs.ox = lo[0];
@@ -1452,6 +1478,35 @@ int m3d_cloud_fit(m3d_cloud* c, int kind, double threshold, size_t max_iteration
     std::lock_guard<std::mutex> lock(c->ctx->mu);
     return cloud_fit_locked(c, kind, threshold, max_iteration, probability, resolve_seed(seed), params,
                             inliers, n_inliers, stats);
+}
+
+// std::random_device seeds differ per rank: rank 0's is the fit's (one tiny exchange, only when no seed was given)
+static int agree_seed(m3d_comm* comm, const uint64_t* seed, hipStream_t st, uint64_t* out) {
+    const uint64_t mine = resolve_seed(seed);
+    *out = mine;
+    if (!comm || comm->world == 1 || seed) return M3D_OK;
+    std::vector<uint64_t> all((size_t)comm->world);
+    const int rc = comm->allgather_host(&mine, all.data(), sizeof(uint64_t), st);
+    if (rc == M3D_OK) *out = all[0];
+    return rc;
+}
+
+int m3d_cloud_fit_sharded(m3d_cloud* c, m3d_comm* comm, int kind, double threshold, size_t max_iteration,
+                          double probability, const uint64_t* seed, double* params, size_t* inliers,
+                          size_t* n_inliers, m3d_stats* stats) {
+    if (!comm) return m3d_cloud_fit(c, kind, threshold, max_iteration, probability, seed, params, inliers, n_inliers, stats);
+    if (!c || !params || kind < 0 || kind > 2) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    const int vr = validate_fit_args(kind, c->n, c->has_normals, probability);
+    if (vr != M3D_OK) return vr;
+    if (comm->transport == m3d_comm::kRccl && comm->device != c->ctx->device)
+        return fail(M3D_ERR_INVALID_ARG, "the cloud and the RCCL communicator live on different devices");
+    std::lock_guard<std::mutex> lock(c->ctx->mu);
+    HIPCHK(hipSetDevice(c->ctx->device));
+    uint64_t sd = 0;
+    const int rs = agree_seed(comm, seed, c->ctx->stream, &sd);
+    if (rs != M3D_OK) return rs;
+    return cloud_fit_locked(c, kind, threshold, max_iteration, probability, sd, params, inliers, n_inliers, stats,
+                            nullptr, nullptr, comm);
 }
 
 static int one_shot_fit(int kind, const double* xyz, const double* normals, size_t n, double thr,
@@ -1560,6 +1615,7 @@ struct m3d_sampler {
     int kind = 0;
     std::vector<uint32_t> table;  // every sample drawn so far, H x m
     size_t drawn = 0;
+    uint32_t incumbent = 0;       // best inlier count this rank has seen for the stream so far (bound-and-prune)
     void draw_until(size_t h_end) {
         if (h_end <= drawn) return;
         table.resize(h_end * (size_t)src.m);
@@ -1635,8 +1691,13 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     };
     size_t j = 0;
     bool first_piece = true;
+    // the pruning incumbent belongs to the FIT, i.e. to the sampler whose stream is being scored (another fit may
+    // have used this device between two windows): it travels with the sampler
     RESERVE(ctx->best_count, 16);
-    if (begin == 0) HIPCHK(hipMemsetAsync(ctx->best_count.p, 0, sizeof(uint32_t), ctx->stream));  // new fit
+    RESERVE(ctx->h_inc, 64);
+    if (begin == 0) sampler->incumbent = 0;  // new fit
+    *ctx->h_inc.as<uint32_t>() = sampler->incumbent;
+    HIPCHK(hipMemcpyAsync(ctx->best_count.p, ctx->h_inc.p, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     // A rank whose first slice starts late in the window does not wait for the host to walk the stream up to it
     // before the GPU gets work: the window's first hypotheses (lead_size()) (another rank's, lower in the sequence than
     // anything this rank owns -- exactly what bound-and-prune may use) are scored at once for their best count
@@ -1689,11 +1750,14 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     if (rc != M3D_OK) return rc;
     rc = collect(1);
     if (rc != M3D_OK) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->h_inc.p, ctx->best_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    sampler->incumbent = *ctx->h_inc.as<uint32_t>();
     *n_mine = out;
     return M3D_OK;
 }
 
-int m3d_cloud_time_score(m3d_cloud* c, int kind, double threshold, const uint32_t* samples,
+int m3d_bench_time_score(m3d_cloud* c, int kind, double threshold, const uint32_t* samples,
                          size_t n_hypotheses, int reps, int mode, double* ms_avg, uint64_t* listed_pairs) {
     if (!c || kind < 0 || kind > 2 || !samples || !ms_avg || reps < 1 || n_hypotheses == 0 ||
         n_hypotheses > 16384 || mode < 0 || mode > 2)
@@ -1810,10 +1874,9 @@ int m3d_cloud_remove_inliers(m3d_cloud* c, int kind, double threshold, const dou
 size_t m3d_cloud_original_size(const m3d_cloud* c) { return c ? (c->work.active ? c->n0 : c->n) : 0; }
 
 // SegmentPlaneIterative, src/iterative_plane_segmentation.cpp:8-39
-int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, int max_iteration,
-                                double min_ratio, const uint64_t* seed, int device, size_t max_clusters,
-                                double* planes, size_t* cluster_offsets, size_t* cluster_indices,
-                                size_t* n_clusters) {
+static int segment_impl(const double* xyz, size_t n, double threshold, int max_iteration, double min_ratio,
+                        const uint64_t* seed, int device, m3d_comm* comm, size_t max_clusters, double* planes,
+                        size_t* cluster_offsets, size_t* cluster_indices, size_t* n_clusters) {
     if (!planes || !cluster_offsets || !cluster_indices || !n_clusters || (!xyz && n))
         return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     *n_clusters = 0;
@@ -1828,11 +1891,12 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
     int rc = M3D_OK;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
-        const uint64_t seed0 = resolve_seed(seed);
+        uint64_t seed0 = 0;
+        rc = agree_seed(comm, seed, ctx->stream, &seed0);
         size_t count = 0, k = 0;
         size_t iterations_hint = 0;   // iterations the previous round took: sizes this round's second chunk up front
         const size_t target = (size_t)((1 - min_ratio) * (double)n);  // :28
-        while (count < target && k < max_clusters) {
+        while (rc == M3D_OK && count < target && k < max_clusters) {
             if (c0->n < 3) {  // the reference's FitModel would throw here (ransac.h:510-513)
                 rc = 2;
                 break;
@@ -1853,7 +1917,7 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
                 return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev);
             };
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
-                                  cluster_indices + off, &ni, nullptr, &issue_removal, &iterations_hint);
+                                  cluster_indices + off, &ni, nullptr, &issue_removal, &iterations_hint, comm);
             if (rc < 0) break;
             rc = M3D_OK;
             if (ni == 0) {  // the reference would loop forever (:29,:35)
@@ -1882,6 +1946,103 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
     m3d_cloud_destroy(c0);
     if (rc == 2) return 2;
     return rc == M3D_OK ? M3D_OK : rc;
+}
+
+int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, int max_iteration,
+                                double min_ratio, const uint64_t* seed, int device, size_t max_clusters,
+                                double* planes, size_t* cluster_offsets, size_t* cluster_indices,
+                                size_t* n_clusters) {
+    return segment_impl(xyz, n, threshold, max_iteration, min_ratio, seed, device, nullptr, max_clusters, planes,
+                        cluster_offsets, cluster_indices, n_clusters);
+}
+
+int m3d_segment_plane_iterative_sharded(const double* xyz, size_t n, double threshold, int max_iteration,
+                                        double min_ratio, const uint64_t* seed, int device, m3d_comm* comm,
+                                        size_t max_clusters, double* planes, size_t* cluster_offsets,
+                                        size_t* cluster_indices, size_t* n_clusters) {
+    if (comm && comm->transport == m3d_comm::kRccl && comm->device != device)
+        return fail(M3D_ERR_INVALID_ARG, "the RCCL communicator lives on another device");
+    return segment_impl(xyz, n, threshold, max_iteration, min_ratio, seed, device, comm, max_clusters, planes,
+                        cluster_offsets, cluster_indices, n_clusters);
+}
+
+// ---- one process, several devices: a thread, a replica and a LOCAL communicator per device ----------------------
+namespace {
+int run_on_devices(const int* devices, int n_dev, const std::function<int(int, m3d_comm*)>& per_rank) {
+    if (!devices || n_dev < 1) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    for (int a = 0; a < n_dev; ++a)
+        for (int b = a + 1; b < n_dev; ++b)
+            if (devices[a] == devices[b]) return fail(M3D_ERR_INVALID_ARG, "devices must be distinct");
+    if (n_dev == 1) return per_rank(0, nullptr);
+    std::vector<m3d_comm*> comms((size_t)n_dev, nullptr);
+    int rc = m3d_comm_create_local(n_dev, comms.data());
+    if (rc != M3D_OK) return rc;
+    std::vector<int> rcs((size_t)n_dev, M3D_OK);
+    std::vector<std::string> errs((size_t)n_dev);
+    std::vector<std::thread> th;
+    for (int r = 1; r < n_dev; ++r)
+        th.emplace_back([&, r] {
+            rcs[(size_t)r] = per_rank(r, comms[(size_t)r]);
+            errs[(size_t)r] = m3d_last_error();
+            if (rcs[(size_t)r] < 0) comms[(size_t)r]->local->abort();   // nobody waits for a rank that has given up
+        });
+    rcs[0] = per_rank(0, comms[0]);
+    if (rcs[0] < 0) comms[0]->local->abort();
+    for (auto& t : th) t.join();
+    for (m3d_comm* q : comms) m3d_comm_destroy(q);
+    for (int r = 1; r < n_dev; ++r)
+        if (rcs[(size_t)r] < 0 && rcs[0] >= 0) {   // a helper rank failed: report its error
+            set_error("device " + std::to_string(devices[r]) + ": " + errs[(size_t)r]);
+            return rcs[(size_t)r];
+        }
+    return rcs[0];
+}
+}  // namespace
+
+int m3d_segment_plane_iterative_multi(const double* xyz, size_t n, double threshold, int max_iteration,
+                                      double min_ratio, const uint64_t* seed, const int* devices, int n_dev,
+                                      size_t max_clusters, double* planes, size_t* cluster_offsets,
+                                      size_t* cluster_indices, size_t* n_clusters) {
+    if (!planes || !cluster_offsets || !cluster_indices || !n_clusters || (!xyz && n))
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    const uint64_t seed0 = resolve_seed(seed);   // one seed for all ranks
+    const size_t cap = std::min(max_clusters, n);
+    return run_on_devices(devices, n_dev, [&](int r, m3d_comm* comm) -> int {
+        if (r == 0)
+            return segment_impl(xyz, n, threshold, max_iteration, min_ratio, &seed0, devices[0], comm, max_clusters, planes,
+                                cluster_offsets, cluster_indices, n_clusters);
+        // helper ranks compute the same result into scratch (every rank removes the same inliers from its replica)
+        std::vector<double> pl(4 * std::max<size_t>(cap, 1));
+        std::vector<size_t> off(cap + 2), idx(std::max<size_t>(n, 1));
+        size_t k = 0;
+        return segment_impl(xyz, n, threshold, max_iteration, min_ratio, &seed0, devices[r], comm, max_clusters, pl.data(),
+                            off.data(), idx.data(), &k);
+    });
+}
+
+int m3d_fit_multi(int kind, const double* xyz, const double* normals, size_t n, double threshold, size_t max_iteration,
+                  double probability, const uint64_t* seed, const int* devices, int n_dev, double* params,
+                  size_t* inliers, size_t* n_inliers, m3d_stats* stats) {
+    if (!params || (!xyz && n) || kind < 0 || kind > 2) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    const int vr = validate_fit_args(kind, n, normals != nullptr, probability);
+    if (vr != M3D_OK) return vr;
+    const uint64_t seed0 = resolve_seed(seed);
+    return run_on_devices(devices, n_dev, [&](int r, m3d_comm* comm) -> int {
+        m3d_cloud* c = m3d_cloud_create(xyz, normals, n, devices[r]);
+        if (!c) return M3D_ERR_DEVICE;
+        int rc;
+        if (r == 0) {
+            rc = m3d_cloud_fit_sharded(c, comm, kind, threshold, max_iteration, probability, &seed0, params, inliers,
+                                       n_inliers, stats);
+        } else {
+            double par[kModelStride];
+            size_t ni = 0;
+            rc = m3d_cloud_fit_sharded(c, comm, kind, threshold, max_iteration, probability, &seed0, par, nullptr, &ni,
+                                       nullptr);
+        }
+        m3d_cloud_destroy(c);
+        return rc;
+    });
 }
 
 }  // extern "C"

@@ -55,6 +55,7 @@ struct ChunkSlot {
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the scoring kernel of the chunk (m3d_stats.ms_score_kernel)
     hipEvent_t k2 = nullptr, k3 = nullptr;  // around the scoring launch of the chunk's leading hypotheses (lead_groups > 0)
     uint32_t lead_groups = 0;
+    bool scored = false;   // a scoring launch was issued for the chunk (k0 / k1 recorded)
     size_t begin = 0, end = 0;
     uint32_t h_pad = 0;
 };
@@ -71,6 +72,7 @@ struct DeviceCtx {
     DevBuf ub, best_count;     // bound-and-prune: surviving tiles per hypothesis, running best count
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
+    PinBuf h_inc;              // m3d_cloud_score_shard: the sampler's pruning incumbent on its way to / from the device
     const double* last_best_dev = nullptr;   // device address of the last fit's best minimal model (a slot's params or best_params)
     // m3d_cloud_create's upload / sort scratch (a one-shot call -- upload, fit, destroy -- otherwise spends more time
     // in hipMalloc / hipFree than in the fit; the cloud's own buffers come back through DevBuf's free list)

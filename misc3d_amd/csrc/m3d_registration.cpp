@@ -22,6 +22,8 @@
 #include <random>
 #include <vector>
 
+#include "m3d_comm.hpp"
+#include "m3d_config.hpp"
 #include "m3d_driver.hpp"
 #include "m3d_reg_fp.hpp"
 #include "m3d_reg_kernels.hpp"
@@ -164,8 +166,7 @@ int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, con
 int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, const uint32_t* orig) {
     GridDesc& g = *gp;
     const uint32_t ncell = g.nx * g.ny * g.nz;
-    const char* nl_env = std::getenv("M3D_REG_NL");
-    if (!(nl_env && nl_env[0] == '0') && n_dst <= ((size_t)2 << 20)) {
+    if (config().reg_neighbour_lists && n_dst <= ((size_t)2 << 20)) {
         RESERVE(S.nl_start, sizeof(uint32_t) * ((size_t)ncell + 1));
         launch_nl_count(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.tile_sums.as<uint32_t>(),
                         S.total.as<uint32_t>() + 1, ctx->stream);
@@ -407,8 +408,7 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
             GridDesc gs;
             // Hilbert order over 128^3 cells: the 64 points of a wave form a compact patch, so the
             // lanes probe the same few target cells (M3D_REG_SRC_ORDER=rows: x-rows of a 64^3 grid)
-            const char* ord_env = std::getenv("M3D_REG_SRC_ORDER");
-            const bool hilbert = !(ord_env && ord_env[0] == 'r');
+            const bool hilbert = !config().reg_source_rows;
             const double hs = hilbert ? ext / 127.0 : ext / 63.0;
             gs.K = 0;
             gs.morton_bits = hilbert ? (7u | 0x100u) : 0u;
@@ -457,8 +457,7 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
     std::random_device rd;
     this->rng = std::mt19937((std::mt19937::result_type)((seed ? *seed : (uint64_t)rd()) & 0xffffffffull));
     this->pick = std::uniform_int_distribution<int>(0, (int)m - 1);  // utility::UniformRandIntGenerator(0, M-1)
-    const char* prune_env = std::getenv("M3D_REG_PRUNE");
-    this->reg_prune = !(prune_env && prune_env[0] == '0');
+    this->reg_prune = config().reg_prune != 0;
     this->est_k_global = this->est_k_local = max_iter;
     RESERVE(S.one_T, sizeof(double) * kRegTStride * 2);
     this->best_T_dev = S.one_T.as<double>();
@@ -816,6 +815,92 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
         rc = m3d_reg_validate(q, 0, ns, counts.data(), sums.data());
         if (rc != M3D_OK) break;
         rc = m3d_reg_replay(q, counts.data(), sums.data());
+        if (rc != M3D_OK) break;
+    }
+    if (rc == M3D_FALSE) rc = m3d_reg_finish(q, T_out, stats);
+    m3d_reg_destroy(q);
+    return rc;
+}
+
+// The same loop with every chunk's validations sharded over the ranks of `comm`: sessions are seeded
+// identically, so every rank draws the same triples and keeps the same survivors; rank r validates a contiguous run of
+// whole 64-hypothesis groups (the validation kernel's unit); ONE all-gather per chunk carries (sum d^2, count) as
+// 16-byte records (bit-exact transport); every rank replays the whole chunk.
+int m3d_registration_ransac_sharded(const double* src, size_t n_src, const double* dst, size_t n_dst,
+                                    const size_t* corr_src, const size_t* corr_dst, size_t m, double threshold,
+                                    int max_iter, double edge_length_threshold, double confidence,
+                                    const uint64_t* seed, int device, m3d_comm* comm, double* T_out,
+                                    m3d_reg_stats* stats) {
+    if (!comm)
+        return m3d_registration_ransac(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter,
+                                       edge_length_threshold, confidence, seed, device, T_out, stats);
+    if (!T_out) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (comm->transport == m3d_comm::kRccl && comm->device != device)
+        return fail(M3D_ERR_INVALID_ARG, "the RCCL communicator lives on another device");
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(T_out, I4, sizeof(I4));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->best_index = -1;
+    }
+    DeviceCtx* ctx = get_ctx(device);
+    if (!ctx) return M3D_ERR_DEVICE;
+    // one seed for all ranks: rank 0's when none was given
+    uint64_t sd = 0;
+    {
+        std::random_device rd;
+        const uint64_t mine = seed ? *seed : (uint64_t)rd();
+        sd = mine;
+        if (!seed && comm->world > 1) {
+            std::vector<uint64_t> all((size_t)comm->world);
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            HIPCHK(hipSetDevice(ctx->device));
+            const int rs = comm->allgather_host(&mine, all.data(), sizeof(uint64_t), ctx->stream);
+            if (rs != M3D_OK) return rs;
+            sd = all[0];
+        }
+    }
+    int rc = M3D_OK;
+    m3d_reg* q = reg_create(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter, edge_length_threshold,
+                            confidence, &sd, device, &rc);
+    if (!q) return rc;
+    struct Rec {
+        double sum;
+        uint64_t count;
+    };
+    const size_t world = (size_t)comm->world, rank = (size_t)comm->rank;
+    std::vector<uint32_t> counts, counts_all;
+    std::vector<double> sums, sums_all;
+    std::vector<Rec> mine, all;
+    for (;;) {
+        size_t ns = 0;
+        rc = m3d_reg_begin_chunk(q, &ns);
+        if (rc != M3D_OK) break;   // M3D_FALSE: loop over; < 0: error
+        const size_t groups = (ns + 63) / 64, per = (groups + world - 1) / world;
+        const size_t g0 = std::min(rank * per, groups), g1 = std::min(g0 + per, groups);
+        const size_t s0 = g0 * 64, s1 = std::min(g1 * 64, ns), shard = per * 64;
+        counts.assign(std::max<size_t>(shard, 1), 0);
+        sums.assign(std::max<size_t>(shard, 1), 0.0);
+        rc = m3d_reg_validate(q, s0, std::max(s0, s1), counts.data(), sums.data());
+        if (rc != M3D_OK) break;
+        counts_all.assign(std::max<size_t>(ns, 1), 0);
+        sums_all.assign(std::max<size_t>(ns, 1), 0.0);
+        if (shard) {   // ns == 0 on every rank alike: nothing to exchange
+            mine.assign(shard, Rec{0.0, 0});
+            for (size_t i = 0; i + s0 < s1; ++i) mine[i] = Rec{sums[i], counts[i]};
+            all.assign(shard * world, Rec{0.0, 0});
+            {
+                std::lock_guard<std::mutex> lock(q->ctx->mu);
+                HIPCHK(hipSetDevice(q->ctx->device));
+                rc = comm->allgather_host(mine.data(), all.data(), sizeof(Rec) * shard, q->ctx->stream);
+            }
+            if (rc != M3D_OK) break;
+            for (size_t i = 0; i < ns; ++i) {   // rank-major slices of `shard` = survivor order
+                counts_all[i] = (uint32_t)all[i].count;
+                sums_all[i] = all[i].sum;
+            }
+        }
+        rc = m3d_reg_replay(q, counts_all.data(), sums_all.data());
         if (rc != M3D_OK) break;
     }
     if (rc == M3D_FALSE) rc = m3d_reg_finish(q, T_out, stats);
@@ -1188,10 +1273,8 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     // dim 33 (FPFH): screened exact search (m3d_match_kernels.hip): split-fp16 MFMA screen by default, the fp32
     // VALU screen with M3D_MATCH_SCREEN=fp32 or when the data does not fit fp16 scaling; M3D_MATCH_BRUTE=1 and
     // every other width: fp64 brute force.
-    const char* brute_env = std::getenv("M3D_MATCH_BRUTE");
-    const char* screen_env = std::getenv("M3D_MATCH_SCREEN");
-    const bool screened = dim == 33 && !(brute_env && brute_env[0] == '1');
-    bool use_mfma = screened && !(screen_env && screen_env[0] == 'f');
+    const bool screened = dim == 33 && !config().match_brute;
+    bool use_mfma = screened && !config().match_fp32_screen;
     // enough (query block x database split) workgroups to fill the chip
     auto splits_for = [](uint32_t nq, uint32_t ndb, uint32_t q_per_block, uint32_t rows_per_unit,
                          uint32_t want_blocks = 2048) {
