@@ -2,34 +2,42 @@
 """bench.py -- headline benchmark of the Misc3D RANSAC hot path on MI355X.
 
 Metric (BASELINE.json): RANSAC hypotheses/sec (+ inlier-score GB/s) on a 1M-point cloud.
-Workload at N = 1 (BASELINE.json configs[1], "C2"): fit_plane, 1 000 000 points, 10 000
-hypotheses, threshold 0.01, probability 1.0 (every hypothesis is evaluated), sampler seed 11.
-A "step" is one complete FitModel: sample table -> minimal fits -> scoring of all H x N pairs ->
-sequential best-model replay -> RefineModel (inlier list + least-squares plane) -> results on the
-host.  The cloud is resident in HBM before the timed region (m3d_cloud_create).
+Workload at N = 1 (BASELINE.json configs[1], "C2"): fit_plane, 1 000 000 points, 10 000 hypotheses, threshold 0.01,
+probability 1.0 (every hypothesis takes part), sampler seed 11.  A "step" is one complete FitModel: sample table ->
+minimal fits -> scoring -> sequential best-model replay -> RefineModel (inlier list + least-squares plane) -> results
+on the host.  The cloud is resident in HBM before the timed region (m3d_cloud_create).  `value` counts hypotheses
+DISPOSED OF per second: every hypothesis' outcome in the reference's sequential loop is reproduced exactly, but only
+the (512-point tile, hypothesis) pairs that can hold an inlier are evaluated point by point, and hypotheses whose
+upper bound cannot reach an earlier hypothesis' count are pruned (both exact).
 
-Extra objects on the JSON line:
-  roofline     dominant kernel = score_mask_k<plane> (m3d_cull_kernels.hip).  `achieved` = ALGORITHMIC bytes
-               (24 B per (hypothesis, point) pair, SURVEY.md 8(d), x the hypotheses one launch covers) / the
-               average duration of THE LAUNCHES INSIDE THE TIMED STEPS, measured live with HIP events on the
-               library's stream (m3d_stats.ms_score_kernel / score_launches; a fit issues one launch per
-               hypothesis chunk) -- the same launches `rocprofv3 --kernel-trace --stats -- python bench.py`
-               averages.  The kernel re-uses every point load for all hypotheses from registers and skips
-               (tile, hypothesis) pairs whose bounding box cannot contain an inlier, so this figure exceeds
-               the HBM peak by design; `valu` prices the pairs those same launches evaluated (counted inside the
-               kernel, m3d_stats.pairs_scored) against the fp64 VALU issue peak, the roofline that actually
-               bounds it.  `traffic` = HBM bytes per 10 000-
-               hypothesis launch from the rocprofv3 PMC pass committed under profiles/ (null if absent).
-  cpu_baseline the oracle's reference-shaped OpenMP port (oracle/misc3d_oracle.c orc_fit_omp_baseline) timed
-               on this box's host cores on a bounded sample.
+JSON objects besides the contract's fields:
+  roofline     the bound that actually binds the dominant kernel score_mask_k<plane>: fp64 VALU issue.
+               achieved = (tile, hypothesis) pairs the timed launches evaluated (counted inside the kernel,
+               m3d_stats.pairs_scored) x 512 points x 7 fp64 VALU instructions per (point, hypothesis) / the launches'
+               duration measured live with HIP events on the library's stream (m3d_stats.ms_score_kernel) -- the
+               same launches `rocprofv3 --kernel-trace --stats -- python bench.py` averages (profiles/).
+               peak = 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s (no FMA: the reference's
+               arithmetic rounds every product and sum).  `traffic` = HBM bytes per launch from the PMC pass under
+               profiles/.  `algorithmic_reuse` restates SURVEY.md 8(d)'s 24 B/(hypothesis, point) figure: it is far
+               above the HBM peak because a point load is re-used from VGPRs by every hypothesis of a launch and most
+               pairs are never touched -- not an HBM-bound kernel, so it is NOT the roofline.
+  cpu_baseline the oracle's reference-shaped OpenMP port timed on this box's host cores (bounded sample), plus the
+               same source built -O3 -march=native under "native".
+  strong_scaling (N > 1) fixed TOTAL work, one-GPU time measured in the same job on rank 0: C2 (10 000 hypotheses)
+               and C3 (cylinder / sphere, 1 M points, 50 000 hypotheses).
 
-N > 1 (python -m torch.distributed.run ... bench.py --gpus N): weak scaling, H = 10 000 hypotheses per GPU
-of ONE global sample stream of N x 10 000 (misc3d_amd/distributed.py): interleaved slices, one RCCL
-all-gather of (valid, count) records per window, identical replay on every rank.  value = N*H / t.
+N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run, one per GPU); under an external
+launcher (WORLD_SIZE set) it is one of the ranks.  Control plane (rendezvous, barrier, max over ranks): torch.distributed
+"gloo".  Data path: the C++ driver m3d_cloud_fit_sharded with a library-owned RCCL communicator (ncclAllGather of the
+4-byte records on the library's stream over xGMI), ncclUniqueId handed out through the process group.
+--scaling weak (default): --hyp hypotheses PER GPU of one N x hyp stream, value = N x hyp / t;
+--scaling strong: --hyp hypotheses in total.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,7 +50,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (non-FMA ops; FMA peak 78.6 TF)
 ALG_BYTES_PER_PAIR = 24.0      # one fp64 xyz read per (hypothesis, point), SURVEY.md 8(d)
-VALU_OPS_PER_PAIR = {0: 7, 1: 10, 2: 22}   # fp64 VALU instructions per pair incl. compares (m3d_kernels.hip)
+VALU_OPS_PER_PAIR = {0: 7, 1: 10, 2: 22}   # fp64 VALU instructions per pair incl. compares (m3d_cull_kernels.hip)
+KERNEL_NAME = {0: "m3d::score_mask_k<0>", 1: "m3d::score_mask_k<1>", 2: "m3d::score_mask_k<2>"}
+WORKLOADS = {   # name -> (kind, default hypotheses, threshold, seed, label)
+    "c2": (0, 10_000, 0.01, 11, "C2 fit_plane"),
+    "c3cyl": (2, 50_000, 0.01, 13, "C3 fit_cylinder"),
+    "c3sph": (1, 50_000, 0.01, 13, "C3 fit_sphere"),
+}
 
 
 def parse():
@@ -51,16 +65,31 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=1_000_000)
-    ap.add_argument("--hyp", type=int, default=10_000, help="hypotheses per GPU per step")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--hyp", type=int, default=0, help="hypotheses per step: per GPU (weak) or in total (strong); 0 = the workload's")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-strong-extra", action="store_true", help="N > 1: skip the strong-scaling block")
     ap.add_argument("--kernel-detail", action="store_true",
-                    help="extra stand-alone launches: fp64-VALU fraction on the surviving pairs, cull kernel, dense kernel")
+                    help="extra stand-alone launches: fp64-VALU fraction on the unpruned launch, cull kernel, dense kernel")
     return ap.parse_args()
 
 
+def respawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: become the launcher."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def load_pmc_traffic():
-    """HBM bytes per score_k launch from the committed PMC pass (profiles/pmc_score_latest.json)."""
+    """HBM bytes per score_mask_k launch from the committed PMC pass (profiles/pmc_score_latest.json)."""
     p = os.path.join(ROOT, "profiles", "pmc_score_latest.json")
     try:
         with open(p) as f:
@@ -69,57 +98,119 @@ def load_pmc_traffic():
         return None
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask, capped by the cgroup quota (a container can see 128 CPUs and
+    own 16 of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(pts, thr, seed, budget_s):
+    """Reference-shaped OpenMP port (oracle/misc3d_oracle.c orc_fit_omp_baseline: omp parallel for over hypotheses,
+    per-point virtual-dispatch-like distance with sqrt and divide, -O3 no -march like CMakeLists.txt:7,15-16) and the
+    same source built -O3 -march=native, each on a bounded sample at the thread count that does best here."""
     import oracle
-    threads = oracle.omp_threads()
-    oracle.fit_omp_baseline(0, pts, None, thr, max(threads, 4), seed)   # thread pool / page warm-up
-    t0 = time.perf_counter()
-    oracle.fit_omp_baseline(0, pts, None, thr, 2 * max(threads, 4), seed)   # calibration: two rounds per thread
-    dt = time.perf_counter() - t0
-    per_h = dt / (2 * max(threads, 4))
-    H = int(max(threads * 2, min(200000, budget_s / max(per_h, 1e-9))))
-    H = (H // threads) * threads or threads
-    t0 = time.perf_counter()
-    model, cnt, bi = oracle.fit_omp_baseline(0, pts, None, thr, H, seed)
-    dt = time.perf_counter() - t0
-    return {"value": H / dt, "unit": "hypotheses/s", "cores": threads, "kind": "port",
-            "sample": f"fit_plane {len(pts)} pts x {H} hypotheses (thr {thr}, seed {seed}), "
-                      f"{dt:.1f} s, OpenMP static schedule over hypotheses, -O3 no -march",
-            "inlier_score_GBps": H * len(pts) * ALG_BYTES_PER_PAIR / dt / 1e9}, (model, cnt, bi, H)
+    hw = usable_cpus()
+
+    def time_lib(fit_fn, set_threads, threads, seconds):
+        set_threads(threads)
+        fit_fn(0, pts, None, thr, max(threads, 4), seed)                      # thread pool / page warm-up
+        t0 = time.perf_counter()
+        fit_fn(0, pts, None, thr, 2 * max(threads, 4), seed)                  # calibration: two rounds per thread
+        per_h = (time.perf_counter() - t0) / (2 * max(threads, 4))
+        H = int(max(threads * 2, min(200000, seconds / max(per_h, 1e-9))))
+        H = (H // threads) * threads or threads
+        t0 = time.perf_counter()
+        model, cnt, bi = fit_fn(0, pts, None, thr, H, seed)
+        dt = time.perf_counter() - t0
+        return H / dt, H, dt, (model, cnt, bi)
+
+    out, extra = None, None
+    for kind_name, getter in (("port", lambda: (oracle.fit_omp_baseline, oracle.set_omp_threads)),
+                              ("native", oracle.native_baseline)):
+        try:
+            fit_fn, set_threads = getter()
+        except Exception as e:       # noqa: BLE001 -- the native build needs gcc on the box
+            if kind_name == "native":
+                extra = {"error": f"{type(e).__name__}: {e}"}
+                continue
+            raise
+        # thread-count probe (short), then the bounded sample at the best count
+        cands = sorted({hw, max(1, hw // 2)})
+        probe = {t: time_lib(fit_fn, set_threads, t, budget_s / 12.0)[0] for t in cands}
+        best_t = max(probe, key=probe.get)
+        rate, H, dt, res = time_lib(fit_fn, set_threads, best_t, budget_s / 2.0 if kind_name == "port" else budget_s / 4.0)
+        rec = {"value": rate, "unit": "hypotheses/s", "cores": best_t,
+               "sample": f"fit_plane {len(pts)} pts x {H} hypotheses (thr {thr}, seed {seed}), {dt:.1f} s, OpenMP static "
+                         f"schedule over hypotheses; thread probe {{threads: hyp/s}} = "
+                         + json.dumps({str(k): round(v, 1) for k, v in probe.items()}),
+               "inlier_score_GBps": rate * len(pts) * ALG_BYTES_PER_PAIR / 1e9, "usable_cpus": hw}
+        if kind_name == "port":
+            rec["kind"] = "port"
+            rec["flags"] = "-O3 -ffp-contract=off (no -march), as the reference's CMakeLists.txt"
+            out, out_res = rec, res + (H,)
+        else:
+            rec["flags"] = "-O3 -march=native -ffp-contract=off"
+            extra = rec
+    out["native"] = extra
+    return out, out_res
+
+
+def make_cloud(workload, n, synth):
+    kind = WORKLOADS[workload][0]
+    if kind == 0:
+        return synth.plane_cloud_c2(n, seed=2), None
+    if kind == 1:
+        return synth.sphere_cloud_c3(n, 4), None
+    return synth.cylinder_cloud_c3(n, 3)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_ranks(a.gpus))
     import torch
     import torch.distributed as dist
-    from misc3d_amd import capi, distributed, synth
+    from misc3d_amd import capi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    n_gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    kind, thr, prob, seed = capi.PLANE, 0.01, 1.0, 11
-    N, H = a.points, a.hyp
-    pts = synth.plane_cloud_c2(N, seed=2)
-    cloud = capi.Cloud(pts, device=local)
+    comm = None
+    if world > 1:
+        dist.init_process_group("gloo")                 # control plane only
+        comm = capi.Comm.rccl(device=local)             # data path: library-owned RCCL communicator
+    elif os.environ.get("M3D_BENCH_FORCE_SHARDED") == "1":   # the N > 1 driver on one GPU (world-1 communicator)
+        comm = capi.Comm.rccl(world=1, rank=0, device=local)
+    n_gpus = world
+    kind, H_default, thr, seed, label = WORKLOADS[a.workload]
+    prob = 1.0
+    N = a.points
+    H = a.hyp or H_default
+    H_total = H * world if a.scaling == "weak" else H
+    pts, nrm = make_cloud(a.workload, N, synth)
+    cloud = capi.Cloud(pts, nrm, device=local)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    force_sharded = os.environ.get("M3D_BENCH_FORCE_SHARDED") == "1"   # exercise the N>1 driver on one GPU
-
     def step():
-        if world == 1 and not force_sharded:
-            return cloud.fit(kind, thr, H, prob, seed=seed, copy=False)
-        return distributed.fit_sharded(cloud, N, kind, thr, H * world, prob, seed, device=dev, copy=False)
+        if comm is None:
+            return cloud.fit(kind, thr, H_total, prob, seed=seed, copy=False)
+        return cloud.fit_sharded(comm, kind, thr, H_total, prob, seed=seed, copy=False)
 
     # set-up, before the W warm-up steps: the library allocates its per-device scratch lazily on the first fits, and
     # the GPU leaves its idle clocks only under load; a driver that asks for a very short warm-up would otherwise time both
@@ -138,62 +229,83 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
-        st = getattr(res, "stats", None)
-        if st:
-            k_ms_sum += st["ms_score_kernel"]
-            k_launches += st["score_launches"]
-            k_pairs += st["pairs_scored"]
+        st = res.stats
+        k_ms_sum += st["ms_score_kernel"]
+        k_launches += st["score_launches"]
+        k_pairs += st["pairs_scored"]
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
-    total_h = H * world
-    value = total_h * a.steps / dt
+    value = H_total * a.steps / dt
+    coll_per_step = comm.collectives / float(PRIMING_FITS + a.warmup + a.steps) if comm is not None else 0.0
 
-    out = None
+    # ---- N > 1: strong scaling at fixed total work, one-GPU time measured in the same job (rank 0 alone) ----------
+    strong = None
+    if world > 1 and not a.no_strong_extra:
+        strong = {}
+        for wl in ("c2", "c3cyl", "c3sph"):
+            k2, h2, thr2, seed2, label2 = WORKLOADS[wl]
+            if wl == a.workload:
+                c2 = cloud
+            else:
+                p2, n2 = make_cloud(wl, N, synth)
+                c2 = capi.Cloud(p2, n2, device=local)
+            reps = 20 if wl == "c2" else 6
+            for _ in range(3):
+                c2.fit_sharded(comm, k2, thr2, h2, 1.0, seed=seed2, copy=False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                rs = c2.fit_sharded(comm, k2, thr2, h2, 1.0, seed=seed2, copy=False)
+            barrier()
+            tn = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            t1 = None
+            if rank == 0:
+                for _ in range(3):
+                    r1 = c2.fit(k2, thr2, h2, 1.0, seed=seed2, copy=False)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    r1 = c2.fit(k2, thr2, h2, 1.0, seed=seed2, copy=False)
+                t1 = (time.perf_counter() - t0) / reps * 1e3
+                same = (r1.stats["best_index"] == rs.stats["best_index"] and r1.stats["n_inliers"] == rs.stats["n_inliers"]
+                        and np.array_equal(r1.params, rs.params))
+                strong[wl] = {"workload": f"{label2}, {N} pts, {h2} hypotheses in total", "ms_1gpu": t1,
+                              f"ms_{world}gpu": float(tn.item()) / reps * 1e3,
+                              "speedup": t1 / (float(tn.item()) / reps * 1e3), "identical_to_1gpu": bool(same),
+                              "best_index": int(rs.stats["best_index"]), "n_inliers": int(rs.stats["n_inliers"])}
+            barrier()
+            if c2 is not cloud:
+                c2.close()
+
     if rank == 0:
         n_in = len(res.inliers)
-        sharded = not hasattr(res, "stats")
-        best_index = res.best_index if sharded else res.stats["best_index"]
-        # live timing of the dominant kernel: the score_mask_k launches of the timed steps themselves
-        # (HIP events inside the library).  The sharded driver does not report them: fall back to
-        # stand-alone launches of the same kernel on this rank's GPU.
         n_tiles = -(-N // 512)
-        traffic = load_pmc_traffic()
-        if k_launches:
-            k_ms = k_ms_sum / k_launches
-            h_per_launch = H * a.steps / k_launches
-            timing = "HIP events around every score_mask_k launch of the timed steps"
-        else:
-            samples = capi.draw_samples(N, kind, min(H, 16384), seed)
-            cloud.time_score(kind, thr, samples, reps=3, mode=0)
-            k_ms, _ = cloud.time_score(kind, thr, samples, reps=10, mode=0)
-            h_per_launch = min(H, 16384)
-            timing = "HIP events, 10 stand-alone launches (sharded driver)"
+        traffic = load_pmc_traffic() if a.workload == "c2" else None
+        k_ms = k_ms_sum / max(k_launches, 1)
+        h_rank = H_total / world                                  # hypotheses this rank scores per step
+        h_per_launch = h_rank * a.steps / max(k_launches, 1)
+        v_tops = k_pairs * 512.0 * VALU_OPS_PER_PAIR[kind] / (k_ms_sum * 1e-3) / 1e12
         alg_bytes = h_per_launch * float(N) * ALG_BYTES_PER_PAIR
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "m3d::score_mask_k<0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "launch_ms": k_ms, "hypotheses_per_launch": h_per_launch, "launches_timed": k_launches,
-                    "timing": timing,
-                    "note": "algorithmic bytes = 24 B x hypotheses x points (what EvaluateModel streams); the kernel "
-                            "re-uses every point load from VGPRs for all hypotheses of a launch, skips (tile, "
-                            "hypothesis) pairs whose bounding box cannot contain an inlier and hypotheses that "
-                            "cannot reach the best count of earlier chunks, so achieved exceeds the HBM peak by "
-                            "design; the binding roofline is fp64 VALU issue on the surviving pairs "
-                            "(--kernel-detail; DESIGN.md section 4)"}
-        if k_launches and k_pairs:
-            # the roofline that actually binds: fp64 VALU issue on the (tile, hypothesis) pairs the timed launches
-            # evaluated (counted inside score_mask_k), 7 instructions per (point, hypothesis) for the plane
-            v_tops = k_pairs * 512.0 * VALU_OPS_PER_PAIR[kind] / (k_ms_sum * 1e-3) / 1e12
-            roofline["valu"] = {"achieved": v_tops, "peak": FP64_VALU_PEAK_TOPS, "unit": "Tinstr-lane/s (fp64 VALU)",
-                                "frac": v_tops / FP64_VALU_PEAK_TOPS, "ops_per_pair": VALU_OPS_PER_PAIR[kind],
-                                "tile_hypothesis_pairs_per_launch": k_pairs / k_launches,
-                                "fraction_of_all_pairs": k_pairs / float(n_tiles * H * a.steps)}
+        alg_rate = alg_bytes / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": "fp64-valu", "kernel": KERNEL_NAME[kind], "achieved": v_tops, "peak": FP64_VALU_PEAK_TOPS,
+                    "unit": "T lane-ops/s (fp64 VALU issue)", "frac": v_tops / FP64_VALU_PEAK_TOPS,
+                    "traffic": traffic, "launch_ms": k_ms, "launches_timed": k_launches,
+                    "hypotheses_per_launch": h_per_launch, "ops_per_pair": VALU_OPS_PER_PAIR[kind],
+                    "tile_hypothesis_pairs_per_launch": k_pairs / max(k_launches, 1),
+                    "pairs_evaluated_fraction": k_pairs / float(n_tiles * h_rank * a.steps),
+                    "timing": "HIP events around every score_mask_k launch of the timed steps (rank 0)",
+                    "algorithmic_reuse": {
+                        "bytes_per_launch": alg_bytes, "rate_GBps": alg_rate, "x_hbm_peak": alg_rate / HBM_PEAK_GBS,
+                        "note": "24 B x hypotheses x points of a launch / launch time (what EvaluateModel streams on the "
+                                "CPU).  Exceeds the HBM peak BY CONSTRUCTION: each point load is re-used from VGPRs by "
+                                "all hypotheses of the launch, box-culled (tile, hypothesis) pairs and pruned hypotheses "
+                                "are never evaluated.  Reported for SURVEY.md 8(d); it is not a roofline fraction."}}
         if a.kernel_detail:
             Hk = min(H, 16384)
             samples = capi.draw_samples(N, kind, Hk, seed)
@@ -201,33 +313,37 @@ def main():
             u_ms, listed = cloud.time_score(kind, thr, samples, reps=10, mode=0)   # score_mask_k, nothing pruned
             cull_ms, _ = cloud.time_score(kind, thr, samples, reps=10, mode=1)      # cull_mask_k
             dense_ms, _ = cloud.time_score(kind, thr, samples, reps=5, mode=2)      # score_k: the unculled kernel
-            # fp64 VALU instructions actually issued: only the (tile, hypothesis) pairs that survive the box test
             valu_tops = listed * 512.0 * VALU_OPS_PER_PAIR[kind] / (u_ms * 1e-3) / 1e12
             dense_tops = float(-(-Hk // 64) * 64) * float(-(-N // 2048) * 2048) * VALU_OPS_PER_PAIR[kind] / (
                 dense_ms * 1e-3) / 1e12
-            roofline["valu_unpruned_launch"] = {"achieved": valu_tops, "peak": FP64_VALU_PEAK_TOPS,
-                                "unit": "Tinstr-lane/s (fp64 VALU)", "frac": valu_tops / FP64_VALU_PEAK_TOPS,
-                                "ops_per_pair": VALU_OPS_PER_PAIR[kind], "launch_ms_unpruned": u_ms,
-                                "hypotheses": Hk, "surviving_tile_hypothesis_pairs": listed,
-                                "surviving_fraction": listed / float(n_tiles * Hk)}
+            roofline["unpruned_launch"] = {"achieved": valu_tops, "peak": FP64_VALU_PEAK_TOPS,
+                                           "frac": valu_tops / FP64_VALU_PEAK_TOPS, "launch_ms": u_ms, "hypotheses": Hk,
+                                           "surviving_tile_hypothesis_pairs": listed,
+                                           "surviving_fraction": listed / float(n_tiles * Hk)}
             roofline["cull_kernel_ms"] = cull_ms
-            roofline["dense_kernel"] = {"kernel": "m3d::score_k<0>", "launch_ms": dense_ms,
-                                        "valu_frac": dense_tops / FP64_VALU_PEAK_TOPS}
-        out = {"metric": "RANSAC hypotheses/sec (fit_plane, 1M-pt cloud)", "value": value, "unit": "hypotheses/s",
+            roofline["dense_kernel"] = {"kernel": f"m3d::score_k<{kind}>", "launch_ms": dense_ms,
+                                        "frac": dense_tops / FP64_VALU_PEAK_TOPS}
+        out = {"metric": "RANSAC hypotheses/sec disposed of (scored or exactly pruned; fit on a 1M-pt cloud)",
+               "value": value, "unit": "hypotheses/s",
                "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
                "data": "synthetic",
-               "config": {"workload": "C2 fit_plane", "points": N, "hypotheses_per_gpu": H,
-                          "hypotheses_total": total_h, "threshold": thr, "probability": prob, "sampler_seed": seed,
-                          "parallelism": f"hypothesis-sharded x{world}" if world > 1 else "single GPU",
+               "config": {"workload": label, "points": N, "hypotheses_per_gpu": H_total / world,
+                          "hypotheses_total": H_total, "threshold": thr, "probability": prob, "sampler_seed": seed,
+                          "parallelism": (f"hypothesis-sharded x{world}, C++ driver + RCCL all-gather" if world > 1 else
+                                          ("single GPU through the sharded driver (world-1 RCCL communicator)" if comm
+                                           else "single GPU")),
                           "setup_fits_before_warmup": PRIMING_FITS},
-               "inlier_score_GBps": total_h * float(N) * ALG_BYTES_PER_PAIR * a.steps / dt / 1e9,
-               "result": {"best_index": int(best_index), "n_inliers": int(n_in),
+               "inlier_score_GBps": H_total * float(N) * ALG_BYTES_PER_PAIR * a.steps / dt / 1e9,
+               "result": {"best_index": int(res.stats["best_index"]), "n_inliers": int(n_in),
                           "params": [float(v) for v in res.params]},
-               "roofline": roofline}
-        if not sharded:
-            out["timing_breakdown_ms"] = {k: res.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "ms_total")}
-        if world == 1 and not a.no_cpu_baseline:
+               "roofline": roofline,
+               "timing_breakdown_ms": {k: res.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "ms_total")}}
+        if comm is not None:
+            out["collectives_per_step"] = coll_per_step
+        if strong:
+            out["strong_scaling"] = strong
+        if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
             cb, (cmodel, ccnt, cbi, ch) = cpu_baseline(pts, thr, seed, a.cpu_seconds)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
@@ -238,6 +354,8 @@ def main():
         print(json.dumps(out), flush=True)
     barrier()
     cloud.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -66,6 +66,10 @@ public:
     }
     void ClearSeed() { has_seed_ = false; }
     void SetDevice(int device) { device_ = device; }
+    // One process per GPU: every rank holds its own RANSAC object with the same cloud and settings
+    // and a communicator of the group (m3d_comm_create_rccl / _host); FitModel then shards the hypothesis loop
+    // and returns the same model and inliers on every rank.  nullptr = single GPU.
+    void SetComm(m3d_comm* comm) { comm_ = comm; }
 
     // ransac.h:506-516 -> FitModelParallel + RefineModel
     bool FitModel(double threshold, ModelT& model, std::vector<size_t>& inlier_indices) {
@@ -74,9 +78,9 @@ public:
         inlier_indices.resize(size_);
         size_t ni = 0;
         model.parameters_.assign(KIND == M3D_CYLINDER ? 7 : 4, 0.0);
-        const int rc = CheckStatus(m3d_cloud_fit(cloud_, KIND, threshold, max_iteration_, probability_,
-                                                 has_seed_ ? &seed_ : nullptr, model.parameters_.data(),
-                                                 inlier_indices.data(), &ni, &stats_));
+        const int rc = CheckStatus(m3d_cloud_fit_sharded(cloud_, comm_, KIND, threshold, max_iteration_, probability_,
+                                                         has_seed_ ? &seed_ : nullptr, model.parameters_.data(),
+                                                         inlier_indices.data(), &ni, &stats_));
         inlier_indices.resize(ni);
         char buf[160];  // ransac.h:616-619
         std::snprintf(buf, sizeof(buf), "Find best model with %g%% inliers and run %llu iterations",
@@ -100,6 +104,7 @@ private:
     uint64_t seed_ = 0;
     bool has_seed_ = false;
     int device_ = 0;
+    m3d_comm* comm_ = nullptr;
     m3d_stats stats_{};
 };
 

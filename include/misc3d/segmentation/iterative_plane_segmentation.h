@@ -19,9 +19,14 @@ struct PlaneCluster {
     PointCloud cloud;             // cluster points (what the reference returns)
 };
 
+// devices: more than one ordinal = every round's hypothesis loop sharded over those GPUs from this one process
+// (m3d_segment_plane_iterative_multi: a thread and a replica of the cloud per device).
+// comm: one process per GPU instead (m3d_segment_plane_iterative_sharded; every rank makes the same call).
 inline std::vector<PlaneCluster> SegmentPlaneIterativeIndexed(const CloudView& pcd, double threshold,
                                                                int max_iteration = 100, double min_ratio = 0.05,
-                                                               const uint64_t* seed = nullptr, int device = 0) {
+                                                               const uint64_t* seed = nullptr, int device = 0,
+                                                               const std::vector<int>& devices = {},
+                                                               m3d_comm* comm = nullptr) {
     std::vector<PlaneCluster> result;
     if (pcd.n < 3) {  // :13-17
         LogWarning("Point cloud size has less than 3.");
@@ -31,9 +36,19 @@ inline std::vector<PlaneCluster> SegmentPlaneIterativeIndexed(const CloudView& p
     std::vector<double> planes(4 * max_clusters);
     std::vector<size_t> offsets(max_clusters + 1), indices(pcd.n);
     size_t k = 0;
-    const int rc = CheckStatus(m3d_segment_plane_iterative(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio,
-                                                           seed, device, max_clusters, planes.data(),
-                                                           offsets.data(), indices.data(), &k));
+    int status;
+    if (!devices.empty())
+        status = m3d_segment_plane_iterative_multi(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed,
+                                                   devices.data(), (int)devices.size(), max_clusters, planes.data(),
+                                                   offsets.data(), indices.data(), &k);
+    else if (comm)
+        status = m3d_segment_plane_iterative_sharded(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed, device,
+                                                     comm, max_clusters, planes.data(), offsets.data(),
+                                                     indices.data(), &k);
+    else
+        status = m3d_segment_plane_iterative(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed, device,
+                                             max_clusters, planes.data(), offsets.data(), indices.data(), &k);
+    const int rc = CheckStatus(status);
     if (rc == 2) LogWarning("segment_plane_iterative: a round found no inlier; stopping early");
     result.resize(k);
     for (size_t c = 0; c < k; ++c) {
@@ -52,6 +67,15 @@ inline std::vector<std::pair<Vector4d, PointCloud>> SegmentPlaneIterative(const 
                                                                           double min_ratio = 0.05) {
     std::vector<std::pair<Vector4d, PointCloud>> out;
     for (auto& c : SegmentPlaneIterativeIndexed(pcd, threshold, max_iteration, min_ratio))
+        out.emplace_back(c.plane, std::move(c.cloud));
+    return out;
+}
+// the reference's call on several GPUs of this node (extension: the reference has no device notion)
+inline std::vector<std::pair<Vector4d, PointCloud>> SegmentPlaneIterative(const CloudView& pcd, double threshold,
+                                                                          int max_iteration, double min_ratio,
+                                                                          const std::vector<int>& devices) {
+    std::vector<std::pair<Vector4d, PointCloud>> out;
+    for (auto& c : SegmentPlaneIterativeIndexed(pcd, threshold, max_iteration, min_ratio, nullptr, 0, devices))
         out.emplace_back(c.plane, std::move(c.cloud));
     return out;
 }

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -245,7 +246,20 @@ class Comm:
         if world > 1:
             t = torch.from_numpy(ident)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(lib().m3d_comm_create_rccl(_p(ident), world, rank, device))
+        # librccl prints a version banner to STDOUT on its first communicator; callers (bench.py) own stdout, so the
+        # banner is sent to stderr: fd 1 points at fd 2 for the duration of the call, C stdio flushed on both sides
+        libc = C.CDLL(None)
+        sys.stdout.flush()
+        libc.fflush(None)
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            h = lib().m3d_comm_create_rccl(_p(ident), world, rank, device)
+        finally:
+            libc.fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
+        return cls(h)
 
     @classmethod
     def host(cls, world, rank, fn):

@@ -360,7 +360,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                        double thr, size_t begin, size_t end, SampleSource& src, double* ms_sample,
                        bool prune = false, uint32_t lead = 0, bool new_fit = false /* clears the running best count */,
                        bool device_records = false /* culled path: keep a device copy of the records in s.counts */,
-                       m3d_comm* comm = nullptr) {
+                       m3d_comm* comm = nullptr,
+                       bool caller_ships_records = false /* sharded: pick_best_k, queued by the caller, writes the gathered
+                                                            records to s.h_counts; the caller records s.done behind it */) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const bool dense = use_dense_scoring();
@@ -404,6 +406,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     // (culled path: keep_mask_k clears the counter replicas on its way)
     s.lead_groups = 0;
     s.scored = false;
+    s.host_has_records = true;
     uint32_t* h_pairs = s.h_counts.as<uint32_t>() + h_pad;   // pinned, device-visible
     if (dense) {
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
@@ -473,9 +476,12 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             int host_has_all = 0;
             const int rc = comm->allgather_u32_device(rec_dev, sl_pad, ctx->stream, s.h_counts.as<uint32_t>(), &host_has_all);
             if (rc != M3D_OK) return rc;
-            if (!host_has_all)
+            s.host_has_records = host_has_all != 0;
+            if (!host_has_all && !caller_ships_records) {
                 HIPCHK(hipMemcpyAsync(s.h_counts.p, rec_dev, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost,
                                       ctx->stream));
+                s.host_has_records = true;
+            }
         }
     }
     // counts of the chunk + (culled path) the number of (tile, hypothesis) pairs the launch evaluated
@@ -892,13 +898,19 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         want = std::min(std::max<size_t>(want, 64), chunk_cap);
         const size_t b = next_begin, e = std::min(max_iter, b + want);
         int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
-                            b == 0 ? lead : 0, b == 0, spec, comm);
+                            b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec);
         if (r == M3D_OK && spec) {
             ChunkSlot& sl = ctx->slot[slot_id];
-            // (sharded: the records are the gathered ones; the other ranks' counts raise this rank's incumbent too)
+            // (sharded: the records are the gathered ones; the other ranks' counts raise this rank's incumbent too, and
+            // the kernel passes the records on to the pinned host array the replay reads -- no copy command)
+            const bool ship = comm && !sl.host_has_records;
             launch_pick_best(sl.counts.as<uint32_t>(), (uint32_t)(e - b), (unsigned long long)b, sl.params.as<double>(),
-                             b == 0, ctx->pick.as<BestPick>(), ctx->h_pick.as<BestPickHost>(), ctx->stream, nullptr,
-                             comm ? ctx->best_count.as<uint32_t>() : nullptr);
+                             b == 0, ctx->pick.as<BestPick>(), ctx->h_pick.as<BestPickHost>(), ctx->stream,
+                             ship ? sl.h_counts.as<uint32_t>() : nullptr, comm ? ctx->best_count.as<uint32_t>() : nullptr);
+            if (ship) {
+                HIPCHK(hipEventRecord(sl.done, ctx->stream));
+                sl.host_has_records = true;
+            }
             if (e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
                 r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
                                             ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64);

@@ -248,6 +248,38 @@ def omp_threads() -> int:
     return int(lib().orc_omp_threads())
 
 
+def set_omp_threads(n: int) -> None:
+    lib().orc_set_omp_threads(C.c_int(int(n)))
+
+
+_native = None
+
+
+def native_baseline():
+    """(fit_omp_baseline, set_omp_threads) of the SAME source built `-O3 -march=native` (SURVEY.md 8(d) asks for that
+    number beside the reference-shaped one).  Compiled where it runs -- a binary tuned for this container's CPU need not
+    run on the GPU box's -- into a temporary directory (`make -C oracle native NATIVE_DIR=...`)."""
+    global _native
+    if _native is None:
+        import tempfile
+        d = tempfile.mkdtemp(prefix="m3d_oracle_native_")
+        subprocess.run(["make", "-C", _HERE, "-s", "native", f"NATIVE_DIR={d}"], check=True)
+        L = C.CDLL(os.path.join(d, "libmisc3d_oracle_native.so"))
+
+        def fit(kind, xyz, normals, thr, H, seed):
+            xyz = _f64(xyz).reshape(-1, 3)
+            nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
+            model = np.zeros(_NP[kind])
+            cnt = C.c_uint64(0)
+            bi = C.c_int64(-1)
+            L.orc_fit_omp_baseline(C.c_int(kind), _p(xyz), _p(nrm), C.c_size_t(len(xyz)), C.c_double(thr),
+                                   C.c_size_t(H), C.c_uint64(seed), _p(model), C.byref(cnt), C.byref(bi))
+            return model, int(cnt.value), int(bi.value)
+
+        _native = (fit, lambda n: L.orc_set_omp_threads(C.c_int(int(n))))
+    return _native
+
+
 def segment_plane_iterative(xyz, thr, max_iteration=100, min_ratio=0.05, seed=0, max_clusters=4096):
     xyz = _f64(xyz).reshape(-1, 3)
     n = len(xyz)

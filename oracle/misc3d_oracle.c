@@ -692,6 +692,15 @@ int orc_omp_threads(void) {
 #endif
 }
 
+/* threads of the next parallel regions (bench.py probes which count does best on the box) */
+void orc_set_omp_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* SegmentPlaneIterative -- src/iterative_plane_segmentation.cpp:8-39                           */
 /* ------------------------------------------------------------------------------------------- */

@@ -2,6 +2,7 @@
 // examples/cpp/ransac_and_boundary.cpp:36-41, segment_plane_iterative.cpp:15-19 and
 // transform_estimation.cpp:69-87, with analytic expectations.  Exit code 0 = all checks passed.
 #include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <random>
 
@@ -104,6 +105,48 @@ int main() {
     CHECK(std::fabs(std::fabs(seg[0].first[2]) - 1.0) < 1e-2);
     CHECK(std::fabs(std::fabs(seg[1].first[0]) - 1.0) < 1e-2);
     CHECK(seg[0].second.points_.size() > 5500 && seg[1].second.points_.size() > 3500);
+    // the devices[] form (one process, a replica per GPU; here the one GPU of the test box) and the communicator
+    // form (a world-1 host communicator: the exchange is the caller's function) give the one-call result
+    {
+        const uint64_t sd = 5;
+        auto one = misc3d::segmentation::SegmentPlaneIterativeIndexed(two, 0.01, 100, 0.1, &sd, 0);
+        auto multi = misc3d::segmentation::SegmentPlaneIterativeIndexed(two, 0.01, 100, 0.1, &sd, 0, {0});
+        struct Echo {
+            static int gather(void* user, const void* send, void* recv, size_t bytes) {
+                ++*static_cast<int*>(user);
+                std::memcpy(recv, send, bytes);
+                return 0;
+            }
+        };
+        int exchanges = 0;
+        m3d_comm* comm = m3d_comm_create_host(1, 0, &Echo::gather, &exchanges);
+        CHECK(comm != nullptr && m3d_comm_world(comm) == 1 && m3d_comm_rank(comm) == 0);
+        auto sharded = misc3d::segmentation::SegmentPlaneIterativeIndexed(two, 0.01, 100, 0.1, &sd, 0, {}, comm);
+        CHECK(exchanges > 0 && (uint64_t)exchanges == m3d_comm_collectives(comm));
+        CHECK(one.size() == multi.size() && one.size() == sharded.size() && one.size() >= 2);
+        for (size_t k = 0; k < one.size(); ++k) {
+            CHECK(one[k].indices == multi[k].indices && one[k].indices == sharded[k].indices);
+            for (int j = 0; j < 4; ++j) CHECK(one[k].plane[j] == multi[k].plane[j] && one[k].plane[j] == sharded[k].plane[j]);
+        }
+        misc3d::common::RANSACPlane f1, f2;
+        misc3d::common::Plane p1, p2;
+        std::vector<size_t> i1, i2;
+        f1.SetSeed(9);
+        f2.SetSeed(9);
+        f2.SetComm(comm);
+        f1.SetPointCloud(two);
+        f2.SetPointCloud(two);
+        CHECK(f1.FitModel(0.01, p1, i1) == f2.FitModel(0.01, p2, i2));
+        CHECK(i1 == i2 && p1.parameters_ == p2.parameters_);
+        m3d_comm_destroy(comm);
+        bool threw = false;
+        try {
+            misc3d::segmentation::SegmentPlaneIterativeIndexed(two, 0.01, 100, 0.1, &sd, 0, {0, 0});
+        } catch (const std::runtime_error&) {
+            threw = true;   // devices must be distinct
+        }
+        CHECK(threw);
+    }
 
     // ---- LeastSquareSolver + RANSACSolver + ANNMatcher
     const double c = std::cos(0.5), s = std::sin(0.5);

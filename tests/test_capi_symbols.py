@@ -9,15 +9,44 @@ import pytest
 
 def _declared_functions(header_text):
     text = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)
-    return sorted(set(re.findall(r"\b(m3d_[a-z0-9_]+)\s*\(", text)) - {"m3d_rmse_fn"})
+    return sorted(set(re.findall(r"\b(m3d_[a-z0-9_]+)\s*\(", text)) - {"m3d_rmse_fn", "m3d_allgather_fn"})
 
 
 def test_header_symbols_exported(capi):
+    import os
     names = _declared_functions(open(capi.HEADER_PATH).read())
-    assert len(names) >= 18
+    assert len(names) >= 40
+    for need in ("m3d_cloud_fit_sharded", "m3d_comm_create_rccl", "m3d_segment_plane_iterative_multi",
+                 "m3d_registration_ransac_sharded", "m3d_set_config"):
+        assert need in names
+    # measurement hooks live in their own header: none of them in the product header
+    assert not [n for n in names if n.startswith("m3d_bench_") or "time_score" in n]
+    bench = _declared_functions(open(os.path.join(os.path.dirname(capi.HEADER_PATH), "misc3d_amd_bench.h")).read())
+    assert bench and all(n.startswith("m3d_bench_") for n in bench)
     L = ctypes.CDLL(capi.LIB_PATH)
-    missing = [n for n in names if not hasattr(L, n)]
+    missing = [n for n in names + bench if not hasattr(L, n)]
     assert not missing, missing
+
+
+def test_config_roundtrip_and_env_defaults(capi):
+    c = capi.get_config()
+    assert c.lead_hypotheses % 64 == 0 and c.lead_hypotheses >= 64 and 1 <= c.score_groups_per_block <= 64
+    old = capi.set_config(dense_scoring=1, lead_hypotheses=100, score_groups_per_block=999)   # bad values fall back
+    try:
+        n = capi.get_config()
+        assert n.dense_scoring == 1 and n.lead_hypotheses == 128 and n.score_groups_per_block == 8
+    finally:
+        capi.restore_config(old)
+    assert capi.get_config().dense_scoring == old.dense_scoring
+
+
+def test_host_communicator_needs_no_gpu(capi):
+    seen = []
+    comm = capi.Comm.host(3, 1, lambda b: (seen.append(b), b * 3)[1])
+    assert comm.world == 3 and comm.rank == 1 and comm.collectives == 0
+    comm.close()
+    with pytest.raises(capi.M3DError):
+        capi.Comm.host(2, 5, lambda b: b)        # rank out of range
 
 
 def test_version_and_error_string(capi):

@@ -1,0 +1,141 @@
+"""BASELINE.json configurations C3, C4 and C5 at their FULL sizes (C2 is tests/test_gpu_parity.py::
+test_full_size_properties).  The oracle cannot run these in seconds, so the checks are size-independent properties:
+the generator's parameters are recovered, counts are consistent between the scoring pass and RefineModel, per-hypothesis
+records do not depend on how the hypothesis range is split or chunked (the 16384-hypothesis chunk cap, the multi-chunk
+pipeline and the pruning incumbent all bite only at these sizes), results are deterministic, index lists are
+ascending / disjoint / complete.  The same workloads are compared with the oracle at 3 k - 60 k points elsewhere."""
+import numpy as np
+import pytest
+
+from misc3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _check_fit_invariants(capi, c, kind, g, H, n, thr, seed):
+    assert g.ret == 1 and g.stats["iterations"] == H and g.stats["count"] <= H      # probability 1: nothing stops the loop
+    ni = len(g.inliers)
+    assert ni == g.stats["n_inliers"] == round(g.stats["fitness"] * n)
+    assert np.all(np.diff(g.inliers.astype(np.int64)) > 0) and int(g.inliers[-1]) < n
+    # the best hypothesis' record, recomputed on its own (dense path of the replay: no pruning, no lead pass):
+    # same count, and the hypothesis is the first of the stream to reach it
+    samples = capi.draw_samples(n, kind, H, seed)
+    bi = g.stats["best_index"]
+    v1, m1, c1 = c.score_range(kind, thr, samples, bi, bi + 1)
+    assert v1[0] == 1 and int(c1[0]) == ni
+    # records are independent of chunking: a window that straddles the 16384-hypothesis chunk boundary, scored as one
+    # range and as two halves, and compared with the same hypotheses scored from a fresh table offset
+    lo, hi = 16384 - 96, 16384 + 160
+    va, ma, ca = c.score_range(kind, thr, samples, lo, hi)
+    vb, mb, cb = c.score_range(kind, thr, samples, lo, 16384)
+    vc, mc, cc = c.score_range(kind, thr, samples, 16384, hi)
+    assert np.array_equal(ca, np.concatenate([cb, cc])) and np.array_equal(va, np.concatenate([vb, vc]))
+    assert np.array_equal(_bits(np.nan_to_num(ma, nan=-7.0)), _bits(np.nan_to_num(np.concatenate([mb, mc]), nan=-7.0)))
+    # nobody in a sampled stretch of the stream beats the winner (the replay's strict ">" keeps the first best)
+    vs, _, cs = c.score_range(kind, thr, samples, 0, 4096, want_models=False)
+    assert int(cs[vs.astype(bool)].max()) <= ni
+    if bi < 4096:
+        assert int(cs[bi]) == ni and not np.any(cs[:bi][vs[:bi].astype(bool)] >= ni)
+    # RefineModel on the pre-refinement model gives the same list (exact evaluation vs the cut-off scoring)
+    cnt, err = c.exact_error(kind, thr, m1[0])
+    assert cnt == ni and 0 < err < thr * cnt
+    # determinism
+    g2 = c.fit(kind, thr, H, 1.0, seed=seed)
+    assert g2.stats["best_index"] == bi and np.array_equal(g2.inliers, g.inliers) and np.array_equal(_bits(g2.params), _bits(g.params))
+
+
+def test_c3_cylinder_full_size(capi):
+    n, H, thr, seed = 1_000_000, 50_000, 0.01, 13
+    pts, nrm = synth.cylinder_cloud_c3(n, 3)
+    with capi.Cloud(pts, nrm) as c:
+        g = c.fit(2, thr, H, 1.0, seed=seed)
+        assert g.stats["hypotheses_scored"] == H and g.stats["score_launches"] >= 4      # > 3 chunks of <= 16384 (+ lead pass)
+        assert 0.40 * n < len(g.inliers) < 0.52 * n
+        axis = np.array([1.0, 2.0, 3.0]) / np.linalg.norm([1.0, 2.0, 3.0])
+        p0 = np.array([0.1, 0.2, 0.3])
+        d = g.params[3:6] / np.linalg.norm(g.params[3:6])
+        assert abs(abs(d @ axis) - 1.0) < 5e-4 and abs(g.params[6] - 0.25) < 3e-3
+        w = g.params[:3] - p0
+        assert np.linalg.norm(w - (w @ axis) * axis) < 5e-3                                # axis point lies on the true axis
+        _check_fit_invariants(capi, c, 2, g, H, n, thr, seed)
+
+
+def test_c3_sphere_full_size(capi):
+    n, H, thr, seed = 1_000_000, 50_000, 0.01, 13
+    pts = synth.sphere_cloud_c3(n, 4)
+    with capi.Cloud(pts) as c:
+        g = c.fit(1, thr, H, 1.0, seed=seed)
+        assert g.stats["hypotheses_scored"] == H
+        assert 0.45 * n < len(g.inliers) < 0.53 * n
+        assert np.allclose(g.params[:3], [0.3, -0.2, 1.0], atol=1e-3) and abs(g.params[3] - 0.5) < 1e-3
+        _check_fit_invariants(capi, c, 1, g, H, n, thr, seed)
+
+
+def test_c4_registration_full_size(capi):
+    """200 k <-> 200 k points, FPFH-shaped descriptors (dim 33): matcher -> RANSAC (100 k hypotheses, every one drawn:
+    confidence 1) -> ICP.  Exercises the 173 MB neighbour lists, the u32 pair counters and multi-chunk validation."""
+    n = 200_000
+    d = synth.registration_pair_c4(n, seed=5)
+    i0, i1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    inv = np.empty(n, dtype=np.int64)
+    inv[d["perm"]] = np.arange(n)
+    good = inv[i0.astype(np.int64)] == i1.astype(np.int64)
+    assert len(i0) > 0.25 * n and good.mean() > 0.6
+    assert capi.match_last_fallbacks() < 0.01 * n
+    assert np.all(np.diff(i0.astype(np.int64)) > 0)                       # source indices ascending, each once
+    # every true (noise-free descriptor) pair the generator planted is a mutual nearest neighbour
+    planted = np.nonzero(d["good"])[0]
+    assert np.isin(planted, i0.astype(np.int64)).mean() > 0.99
+    T, st = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=100_000, edge_length_threshold=0.9,
+                                     confidence=1.0, seed=17)
+    assert st["iterations"] == 100_000 and st["validations"] > 5_000 and st["fitness"] > 0.99
+    assert np.abs(T - d["T"]).max() < 5e-3
+    R = T[:3, :3]
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1.0) < 1e-12
+    T2, st2 = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=100_000, edge_length_threshold=0.9,
+                                       confidence=1.0, seed=17)
+    assert np.array_equal(T, T2) and all(st[k] == st2[k] for k in ("best_index", "validations", "fitness", "est_k"))
+    # the reference's own call (confidence 0.999) ends early and lands on the same pose within the noise
+    T3, st3 = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=100_000, confidence=0.999, seed=17)
+    assert st3["iterations"] < 1000 and np.abs(T3 - d["T"]).max() < 2e-2
+    Ti, sti = capi.registration_icp(d["src"], d["dst"], 0.02, T3)
+    assert sti["fitness"] > 0.99 and sti["inlier_rmse"] < 0.006 and np.abs(Ti - d["T"]).max() < 1e-3
+    # the information matrix of that pose counts the same correspondences ICP ended with
+    info, nc = capi.information_matrix(d["src"], d["dst"], 0.02, Ti)
+    assert nc == sti["correspondences"] and info[5, 5] == nc
+
+
+def test_c5_segmentation_full_size(capi):
+    """10 M-point room: cluster sizes follow the generator's fractions, every index appears at most once, index lists
+    ascend inside a cluster, the planes are the room's six; identical clusters on a second call."""
+    n = 10_000_000
+    pts = synth.room_cloud_c5(n, 6)
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19)
+    assert rc == 1 and len(planes) >= 6
+    sizes = np.array([len(c) for c in clusters])
+    assert sizes.sum() >= int((1 - 0.05) * n) and sizes.sum() <= n
+    seen = np.zeros(n, dtype=np.uint8)
+    for c in clusters:
+        ci = c.astype(np.int64)
+        assert np.all(np.diff(ci) > 0)
+        assert not seen[ci].any()
+        seen[ci] = 1
+    # the six big planes of the generator come first (largest remaining support wins each round)
+    expect = [([0, 0, 1], 0.0, 0.25), ([0, 0, 1], -2.5, 0.15), ([1, 0, 0], 3.0, 0.15), ([1, 0, 0], -3.0, 0.15),
+              ([0, 1, 0], 2.0, 0.10), ([0, 1, 0], -2.0, 0.10)]
+    found = 0
+    for nrm, dd, frac in expect:
+        for k in range(6):
+            p = planes[k]
+            s = np.sign(p[:3] @ np.array(nrm, dtype=float))
+            if abs(abs(p[:3] @ np.array(nrm, dtype=float)) - 1.0) < 1e-4 and abs(s * p[3] - dd) < 1.5e-2:
+                assert abs(sizes[k] / n - frac) < 0.02
+                found += 1
+                break
+    assert found == 6
+    rc2, planes2, clusters2 = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19)
+    assert rc2 == rc and np.array_equal(planes, planes2) and all(np.array_equal(a, b) for a, b in zip(clusters, clusters2))

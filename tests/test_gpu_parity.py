@@ -17,6 +17,21 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
+# the scoring paths m3d_config selects between; they must be indistinguishable from outside
+PATHS = {"culled": {}, "dense": {"dense_scoring": 1}, "no_early_pick": {"speculative_refine": 0},
+         "small_blocks": {"score_groups_per_block": 1, "lead_hypotheses": 64}}
+
+
+@pytest.fixture(params=sorted(PATHS))
+def scoring_path(request, capi):
+    """Runs the test once per scoring path: the production culled path (cull_mask_k + score_mask_k with the device's
+    early pick), the dense kernel (score_k: every tile x every hypothesis; the bench's reference point), the culled
+    path without the speculative RefineModel, and the culled path with one hypothesis group per workgroup."""
+    old = capi.set_config(**PATHS[request.param])
+    yield request.param
+    capi.restore_config(old)
+
+
 def _clouds(kind, n, seed):
     if kind == 0:
         return synth.plane_cloud_c1(n, seed), None
@@ -27,7 +42,7 @@ def _clouds(kind, n, seed):
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
 @pytest.mark.parametrize("n", [20000, 4097, 777])
-def test_score_range_bit_exact(capi, orc, kind, n):
+def test_score_range_bit_exact(capi, orc, scoring_path, kind, n):
     """minimal_fit_k + score_k + reduce vs MinimalFit + EvaluateModel, hypothesis by hypothesis."""
     pts, nrm = _clouds(kind, n, seed=10 + kind)
     H = 300
@@ -68,7 +83,7 @@ def test_exact_error_serial_sum(capi, orc, kind):
     (2, 20000, 400, 0.9999, 13),
     (2, 6000, 300, 1.0, 4),
 ])
-def test_fit_matches_oracle(capi, orc, kind, n, max_iter, prob, seed):
+def test_fit_matches_oracle(capi, orc, scoring_path, kind, n, max_iter, prob, seed):
     pts, nrm = _clouds(kind, n, seed=30 + kind)
     o = orc.fit(kind, pts, nrm, thr=0.01, max_iter=max_iter, prob=prob, seed=seed)
     g = capi.fit(kind, pts, nrm, threshold=0.01, max_iteration=max_iter, probability=prob, seed=seed)
@@ -262,7 +277,7 @@ def test_cloud_remove_inliers_and_sharded_segmentation(capi, orc):
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
-def test_culled_scoring_robustness(capi, orc, kind):
+def test_culled_scoring_robustness(capi, orc, scoring_path, kind):
     """The box tests of cull_k must never drop an inlier: clouds far from the origin, tiny and huge
     scales, degenerate extents, tile-boundary sizes -- counts stay bit-identical to the oracle."""
     rng = np.random.default_rng(100 + kind)

@@ -41,7 +41,7 @@ def test_registration_ransac_matches_oracle(capi, orc, conf, max_iter, seed):
 def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
     """Clouds large enough (>= 16 source tiles) for the two-phase validation: hypotheses that cannot
     reach the best inlier count of earlier chunks are dropped after every 8th tile.  The result must
-    equal the oracle's and the unpruned run's (M3D_REG_PRUNE=0), partial overlap included."""
+    equal the oracle's and the unpruned run's (m3d_config.reg_prune = 0), partial overlap included."""
     n = 24_000
     d = synth.registration_pair_c4(n, seed=21, dim=8, true_fraction=frac, sigma=sigma)
     dst = d["dst"]
@@ -54,12 +54,12 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
     cd = np.where(rng.random(1500) < frac, inv[cs], rng.integers(0, n, 1500))
     kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=edge, confidence=1.0, seed=4)
     T, st = capi.registration_ransac(src, dst, cs, cd, **kw)
-    for env in ("M3D_REG_PRUNE", "M3D_REG_NL"):      # each optimisation switched off in turn
-        os.environ[env] = "0"
+    for env in ("reg_prune", "reg_neighbour_lists"):      # each optimisation switched off in turn (m3d_config)
+        old = capi.set_config(**{env: 0})
         try:
             T0, st0 = capi.registration_ransac(src, dst, cs, cd, **kw)
         finally:
-            del os.environ[env]
+            capi.restore_config(old)
         assert np.array_equal(T, T0), env
         for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse", "ties"):
             assert st[k] == st0[k], (env, k)
@@ -202,12 +202,12 @@ def test_mutual_nn_matches_oracle(capi, orc, dim, ns, nd):
 
 
 def _brute(capi, fs, fd):
-    """the fp64 brute-force kernel (M3D_MATCH_BRUTE=1): the unscreened GPU path"""
-    os.environ["M3D_MATCH_BRUTE"] = "1"
+    """the fp64 brute-force kernel (m3d_config.match_brute): the unscreened GPU path"""
+    old = capi.set_config(match_brute=1)
     try:
         return capi.match_mutual_nn(fs, fd)
     finally:
-        del os.environ["M3D_MATCH_BRUTE"]
+        capi.restore_config(old)
 
 
 @pytest.mark.parametrize("screen", ["mfma", "fp32"])
@@ -255,12 +255,11 @@ def test_mutual_nn_screen_adversarial(capi, orc, case, screen):
         fd[:, ::2] *= 1e-6
         fs[:, 1::4] *= 1e-3
         fd[:, 1::4] *= 1e-3
-    if screen == "fp32":
-        os.environ["M3D_MATCH_SCREEN"] = "fp32"
+    old = capi.set_config(match_fp32_screen=1 if screen == "fp32" else 0)
     try:
         a, b = capi.match_mutual_nn(fs, fd)
     finally:
-        os.environ.pop("M3D_MATCH_SCREEN", None)
+        capi.restore_config(old)
     falls = capi.match_last_fallbacks()
     oa, ob = orc.match_mutual_nn(fs, fd)
     assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob)

@@ -56,6 +56,41 @@ def main():
         sess.close()
         check(f"registration conf {conf} T", np.array_equal(T1, T2))
         check(f"registration conf {conf} stats", all(st1[k] == st2[k] for k in ("best_index", "iterations", "validations", "fitness")))
+    # ---- the C++ driver (m3d_cloud_fit_sharded & co., include/misc3d_amd.h) with the records over gloo through the
+    # host transport of m3d_comm: same shard loop, same kernels as under RCCL, only the all-gather differs
+    comm = capi.Comm.torch_host()
+    check("comm geometry", comm.world == world and comm.rank == rank)
+    for kind, (pts, nrm) in clouds.items():
+        for prob, H, seed in ((1.0, 3000, 11), (1.0, 40000, 3), (0.9999, 1000, 5), (0.99, 400, 9), (1.0, 100, 2)):
+            with capi.Cloud(pts, nrm) as c:
+                one = c.fit(kind, 0.01, H, prob, seed=seed)
+                before = comm.collectives
+                r = c.fit_sharded(comm, kind, 0.01, H, prob, seed=seed)
+            tag = f"C++ fit kind {kind} prob {prob} H {H}"
+            check(tag + " index", r.stats["best_index"] == one.stats["best_index"] and r.stats["iterations"] == one.stats["iterations"]
+                  and r.stats["count"] == one.stats["count"])
+            check(tag + " inliers", np.array_equal(r.inliers, one.inliers))
+            check(tag + " params", np.array_equal(np.asarray(r.params), np.asarray(one.params)))
+            check(tag + " collectives", comm.collectives > before)
+            if prob >= 1.0 and H > 128:     # every rank scores its slice only
+                check(tag + " share", r.stats["hypotheses_scored"] < one.stats["hypotheses_scored"])
+    # a fit without a seed: rank 0's random seed is shared, so the ranks still agree
+    with capi.Cloud(*clouds[capi.PLANE]) as c:
+        r = c.fit_sharded(comm, capi.PLANE, 0.01, 500, 0.9999, seed=None)
+    t = torch.tensor([float(r.stats["best_index"]), float(len(r.inliers))], dtype=torch.float64)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    check("unseeded fit agrees across ranks", bool(torch.equal(t, tmax)))
+    rc3, planes3, clusters3 = capi.segment_plane_iterative_sharded(room, comm, 0.01, max_iteration=200, min_ratio=0.05, seed=19)
+    check("C++ segmentation count", rc3 == rc1 and len(planes3) == len(planes1))
+    check("C++ segmentation planes", np.array_equal(planes3, planes1))
+    check("C++ segmentation clusters", all(np.array_equal(a_, b_) for a_, b_ in zip(clusters3, clusters1)))
+    for conf, H in ((1.0, 3000), (0.999, 100000)):
+        T1, st1 = capi.registration_ransac(d["src"], d["dst"], a, b, threshold=0.03, max_iter=H, confidence=conf, seed=17)
+        T3, st3 = capi.registration_ransac_sharded(d["src"], d["dst"], a, b, comm, threshold=0.03, max_iter=H, confidence=conf, seed=17)
+        check(f"C++ registration conf {conf} T", np.array_equal(T1, T3))
+        check(f"C++ registration conf {conf} stats", all(st1[k] == st3[k] for k in ("best_index", "iterations", "validations", "fitness")))
+    comm.close()
     # every rank must have seen no failure
     t = torch.tensor([len(fails)], dtype=torch.int64)
     dist.all_reduce(t)
