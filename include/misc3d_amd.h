@@ -367,7 +367,9 @@ typedef struct m3d_config {
     int32_t match_brute;            /* [M3D_MATCH_BRUTE=1]  1: fp64 brute-force matcher (no screen) */
     int32_t match_fp32_screen;      /* [M3D_MATCH_SCREEN=fp32] 1: fp32 VALU screen instead of the split-fp16 MFMA screen */
     int32_t pool_limit_mb;          /* [M3D_POOL_MB]        default 4096: released device blocks parked per device for re-use (0 = none) */
-    int32_t reserved[3];
+    int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=0] default 1: HIP events around every scoring launch (m3d_stats.ms_score_kernel);
+                                       0 drops those four event commands per chunk from the stream */
+    int32_t reserved[2];
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

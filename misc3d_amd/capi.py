@@ -16,7 +16,10 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmisc3d_amd.so")
+# M3D_FP_ORDER=1|2 in the environment loads the library built for one of the alternative floating-point associations
+# (misc3d_amd/csrc/m3d_fp.hpp; tests/test_fp_orders.py runs the parity suite under each); default 0
+FP_ORDER = int(os.environ.get("M3D_FP_ORDER", "0") or 0)
+LIB_PATH = os.path.join(_HERE, "lib", *([f"order{FP_ORDER}"] if FP_ORDER else []), "libmisc3d_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "misc3d_amd.h")
 
 PLANE, SPHERE, CYLINDER = 0, 1, 2
@@ -195,7 +198,7 @@ class Config(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("dense_scoring", "speculative_refine", "lead_hypotheses",
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
                                          "morton_order", "reg_neighbour_lists", "reg_source_rows", "reg_prune",
-                                         "match_brute", "match_fp32_screen", "pool_limit_mb")] + [("reserved", C.c_int32 * 3)]
+                                         "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing")] + [("reserved", C.c_int32 * 2)]
 
 
 def get_config() -> Config:

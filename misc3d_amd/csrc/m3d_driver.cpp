@@ -366,6 +366,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const bool dense = use_dense_scoring();
+    const bool timing = config().kernel_timing != 0;
     if (comm && dense) return fail(M3D_ERR_INVALID_ARG, "sharded fits use the culled scoring path (m3d_config.dense_scoring = 0)");
     const uint32_t world = comm ? (uint32_t)comm->world : 1u, rank = comm ? (uint32_t)comm->rank : 0u;
     const uint32_t sl_pad = round_up((count + world - 1) / world, 64);   // hypotheses per rank
@@ -445,10 +446,10 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 s.lead_groups = ga;
                 g_lo = std::max(g0, ga);
                 launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
-                HIPCHK(hipEventRecord(s.k2, ctx->stream));
+                if (timing) HIPCHK(hipEventRecord(s.k2, ctx->stream));
                 launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
                                   h_pad, pair_rep, ctx->stream, 0, ga);
-                HIPCHK(hipEventRecord(s.k3, ctx->stream));
+                if (timing) HIPCHK(hipEventRecord(s.k3, ctx->stream));
                 // fold of the lead's counters + keep masks of the rest of this rank's groups: one launch
                 launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
                                       g0 == 0 ? rec_host : nullptr, bc, ub, keep, g1 - g_lo, ctx->stream,
@@ -456,16 +457,16 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             } else {
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
             }
-            HIPCHK(hipEventRecord(s.k0, ctx->stream));
+            if (timing) HIPCHK(hipEventRecord(s.k0, ctx->stream));
             launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
                               pair_rep, ctx->stream, g_lo, g1);
-            HIPCHK(hipEventRecord(s.k1, ctx->stream));
+            if (timing) HIPCHK(hipEventRecord(s.k1, ctx->stream));
             // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
             // ... and (one GPU) write the records straight into the slot's pinned host array (device-visible): no copy
             // command behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
             launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, g1 * 64u, rec_host, pair_rep, h_pairs,
                                 s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u, rec_dev);
-            s.scored = true;
+            s.scored = timing;
         } else {
             HIPCHK(hipMemsetAsync(rec_dev + (size_t)g0 * 64, 0, sizeof(uint32_t) * sl_pad, ctx->stream));
             *h_pairs = 0;
@@ -657,16 +658,30 @@ static bool is_library_pinned(const void* p, size_t bytes) {
 // First stage of RefineModel: the ordered inlier list of `model_dev` (+ the model record to the pinned `lazy_in`).
 // total_host (pinned) receives the inlier count.  Separate from refine() so that a probability-1 fit can queue it
 // on the device's own prediction of the winner right behind the last scoring launch (run_ransac).
+// fused: the model record carries the provisional centre of GeneralFit's sums (a record written by minimal_fit_k), so
+// the compaction's counting pass accumulates the moments as well and no pass over the inlier list follows.
+// idx_host: the caller's page-locked index list; the compaction writes it directly (the 8 bytes per inlier cross the
+// host link while the kernel runs instead of in a copy command the host issues after it has woken up).
 static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, const uint32_t* orig_dev, int kind,
-                                   double thr, const double* model_dev, const double* lazy_in, void* total_host) {
+                                   double thr, const double* model_dev, const double* lazy_in, void* total_host,
+                                   bool fused = false, uint64_t* idx_host = nullptr) {
     const uint32_t n = flag_view.n;
     const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
     RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
     RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)nb + 1));
     RESERVE(ctx->total, sizeof(uint32_t) * 4);
+    fused = fused && kind != M3D_CYLINDER;
+    if (fused) {
+        RESERVE(ctx->moment_partial, sizeof(double) * 16 * (size_t)std::max<uint32_t>(nb, 1));
+        RESERVE(ctx->h_moments, sizeof(double) * kFusedMomentDoubles);
+    }
     launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
-                   ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in));
+                   ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
+                   fused ? ctx->moment_partial.as<double>() : nullptr, fused ? ctx->h_moments.as<double>() : nullptr,
+                   idx_host);
+    ctx->compaction_fused = fused;
+    ctx->compaction_idx_host = idx_host;
     HIPCHK(hipMemcpyAsync(total_host, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     return M3D_OK;
 }
@@ -677,8 +692,10 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                   size_t* n_inliers, int* general_fit_ok, int64_t expected_ni = -1,
                   const std::function<int(int64_t)>* before_wait = nullptr,
                   const double* lazy_in = nullptr /* pinned: the "in" value of params_host arrives with the wait */,
-                  const void* compaction_total = nullptr /* pinned: the compaction is already queued (on model_dev) */) {
+                  const void* compaction_total = nullptr /* pinned: the compaction is already queued (on model_dev) */,
+                  bool fused = false /* model_dev is a minimal_fit_k record: moments ride on the compaction (needs lazy_in) */) {
     const uint32_t n = flag_view.n;
+    fused = fused && lazy_in != nullptr;
     RESERVE(ctx->sums, sizeof(double) * 32);
     RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
     RESERVE(ctx->h_sums, sizeof(double) * kGeneralFitHostDoubles);
@@ -686,21 +703,26 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
     uint8_t* h = ctx->h_small.as<uint8_t>();
     const uint8_t* h_total = compaction_total ? static_cast<const uint8_t*>(compaction_total) : h;
     if (!compaction_total) {
-        const int rc = issue_refine_compaction(ctx, flag_view, orig_dev, kind, thr, model_dev, lazy_in, h);
+        uint64_t* idx_host = inliers && fused && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1))
+                                 ? reinterpret_cast<uint64_t*>(inliers) : nullptr;
+        const int rc = issue_refine_compaction(ctx, flag_view, orig_dev, kind, thr, model_dev, lazy_in, h, fused, idx_host);
         if (rc != M3D_OK) return rc;
     }
+    const bool have_moments = fused && ctx->compaction_fused;
+    const bool idx_on_host = inliers && ctx->compaction_idx_host == reinterpret_cast<uint64_t*>(inliers);
     if (expected_ni >= 0 && (uint64_t)expected_ni <= n) {
         const uint32_t ni_e = (uint32_t)expected_ni;
         const bool need_fit_e = kind != M3D_CYLINDER && ni_e >= (kind == M3D_PLANE ? 3u : 4u);
         HIPCHK(hipEventRecord(ctx->ev_compact, ctx->stream));
         // page-locked destination (m3d_host_alloc): the index list leaves NOW, on the copy stream, under the sums
-        const bool early_copy = inliers && ni_e && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)ni_e);
+        // (or has been written by the compaction itself: idx_on_host)
+        const bool early_copy = !idx_on_host && inliers && ni_e && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)ni_e);
         if (early_copy) {
             HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
             HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost,
                                   ctx->copy_stream));
         }
-        if (need_fit_e) {
+        if (need_fit_e && !have_moments) {
             launch_general_fit_sums(gather_view, ctx->idx.as<uint64_t>(), ni_e, ctx->sum_partial.as<double>(),
                                     ctx->h_sums.as<double>(), ctx->stream);
         }
@@ -712,7 +734,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
             if (hr != M3D_OK) return hr;
         }
         // last: a copy into the caller's (pageable) buffer keeps the host busy until it is done
-        if (inliers && ni_e && !early_copy) {
+        if (inliers && ni_e && !early_copy && !idx_on_host) {
             HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
             HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost,
                                   ctx->copy_stream));
@@ -733,8 +755,17 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                 *general_fit_ok = 0;  // MinimalCheck, ransac.h:166-169, 298-301
             } else {
                 double sums[14];
-                general_fit_sums_finish(ctx->h_sums.as<double>(), sums);
-                const double mean[3] = {sums[0] / (double)ni_e, sums[1] / (double)ni_e, sums[2] / (double)ni_e};
+                double mean[3];
+                if (have_moments) {
+                    // raw moments about the record's provisional centre -> mean + centred moments (m3d_kernels.hip)
+                    const double* rec = lazy_in;
+                    const double c0[3] = {kind == M3D_PLANE ? rec[4] : rec[0], kind == M3D_PLANE ? rec[5] : rec[1],
+                                          kind == M3D_PLANE ? rec[6] : rec[2]};
+                    moments_about_mean(ctx->h_moments.as<double>(), c0, (double)ni_e, mean, sums + 4);
+                } else {
+                    general_fit_sums_finish(ctx->h_sums.as<double>(), sums);
+                    for (int k = 0; k < 3; ++k) mean[k] = sums[k] / (double)ni_e;
+                }
                 double out[4];
                 const bool ok = kind == M3D_PLANE ? plane_from_moments(mean, sums + 4, out)
                                                   : sphere_from_moments(mean, sums + 4, (double)ni_e, out);
@@ -768,7 +799,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                                     ctx->h_sums.as<double>(), ctx->stream);
         }
     }
-    if (inliers && ni)
+    if (inliers && ni && !idx_on_host)
         HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni,
                               hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
@@ -811,7 +842,8 @@ struct RansacOut {
 static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, int kind, double thr,
                       size_t max_iter, double prob, uint64_t seed, RansacOut* out, size_t iterations_hint = 0,
                       const uint32_t* orig_dev = nullptr /* index map of a shrunk cloud (RefineModel's compaction) */,
-                      m3d_comm* comm = nullptr /* hypotheses sharded over its ranks (issue_chunk) */) {
+                      m3d_comm* comm = nullptr /* hypotheses sharded over its ranks (issue_chunk) */,
+                      uint64_t* idx_host = nullptr /* the caller's page-locked index list (early compaction writes it) */) {
     m3d_replay_init(&out->st);
     RESERVE(ctx->best_params, sizeof(double) * kModelStride);
     RESERVE(ctx->h_small, 256);
@@ -913,7 +945,8 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             }
             if (e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
                 r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
-                                            ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64);
+                                            ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true,
+                                            idx_host);
                 ctx->spec_compaction = r == M3D_OK;
             }
         }
@@ -1093,8 +1126,12 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     const CloudView gather = c->base_view();   // index lists / GeneralFit refer to the cloud as created
     const uint32_t* orig = c->orig();
     RansacOut ro;
+    uint64_t* idx_host = inliers && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)std::max<uint32_t>(v.n, 1))
+                             ? reinterpret_cast<uint64_t*>(inliers) : nullptr;
+    ctx->compaction_idx_host = nullptr;
+    ctx->compaction_fused = false;
     int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro, iterations_hint ? *iterations_hint : 0,
-                        orig, comm);
+                        orig, comm, idx_host);
     if (rc != M3D_OK) return rc;
     if (iterations_hint) *iterations_hint = (size_t)ro.st.iterations;
     const double t1 = now_ms();
@@ -1107,7 +1144,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         // the compaction is already running on the device's pick; finish RefineModel on it and keep the result if
         // the replay named the same hypothesis (it does unless an rmse tie went the other way)
         rc = refine(ctx, v, gather, orig, kind, thr, ctx->pick.as<BestPick>()->params, model, inliers, &ni, &gf_ok,
-                    expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64);
+                    expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true);
         if (rc != M3D_OK) return rc;
         const BestPickHost* ph = ctx->h_pick.as<BestPickHost>();
         refined = ro.st.best_index >= 0 ? (ph->have && ph->index == (unsigned long long)ro.st.best_index) : !ph->have;
@@ -1117,7 +1154,8 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     }
     if (!refined) {
         rc = refine(ctx, v, gather, orig, kind, thr, ctx->last_best_dev, model, inliers, &ni,
-                    &gf_ok, expected, ctx->spec_compaction ? nullptr : before_refine_wait, ctx->h_best.as<double>());
+                    &gf_ok, expected, ctx->spec_compaction ? nullptr : before_refine_wait, ctx->h_best.as<double>(), nullptr,
+                    /*fused=*/true);
         if (rc != M3D_OK) return rc;
     }
     {

@@ -82,6 +82,10 @@ struct DeviceCtx {
     PinBuf h_pick;             // BestPickHost mirror (+ at byte 64: inlier total of a compaction started on the prediction)
     bool spec_compaction = false;   // RefineModel's compaction has already been queued on pick->params
     PinBuf h_sums;             // GeneralFit: per-workgroup moment partials + coordinate sums, written by the kernels
+    DevBuf moment_partial;     // fused RefineModel: per-workgroup raw moments of the compaction's counting pass
+    PinBuf h_moments;          // ... folded (scan_blocks_k), device-visible: kFusedMomentDoubles doubles
+    bool compaction_fused = false;            // the compaction in flight carried the moments
+    uint64_t* compaction_idx_host = nullptr;  // ... and wrote the index list to this page-locked destination as well
     PinBuf h_best;             // best minimal model of a fit on its way to the host (read after RefineModel's wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

@@ -6,6 +6,20 @@
 // every product and every sum below is individually rounded and the association is fixed:
 //   4-element sums (e0+e2)+(e1+e3), 3-element sums (e0+e1)+e2   
 // This file and everything that includes it MUST be compiled with -ffp-contract=off.
+//
+// M3D_FP_ORDER (compile time; oracle/misc3d_oracle.c has the same switch as ORC_FP_ORDER) selects which Eigen the
+// association is restated for -- the reference cannot be built here (no Eigen / Open3D in the image), so the
+// association is a [RECALL] and this is the ONE place to flip it once tools/pin_reference shows which one the real
+// build has:
+//   0  Eigen >= 3.3, SSE2 packets, unaligned fixed-size vectorisation (default):
+//        3-element reductions (e0 + e1) + e2 -- one packet (e0, e1) reduced, then the scalar tail;
+//        4x4 determinant = Eigen 3.3 determinant_impl<.,4> (six 2x2 minors, bruteforce_det4_helper)
+//   1  Eigen 3.2 (Vector3d is not vectorised: redux_novec_unroller splits 3 = 1 + 2):
+//        3-element reductions e0 + (e1 + e2); determinant as in 0
+//   2  Eigen 3.4: reductions as in 0; 4x4 determinant = 3.4's determinant_impl<.,4> (det2 / det3 cofactors, pmadd
+//        without FMA = a * b + c)
+// 4-element reductions of aligned Vector4d are (e0 + e2) + (e1 + e3) in all three (two SSE2 packets added, then
+// predux).  The build puts the variants side by side: lib/libmisc3d_amd.so (0), lib/order1/, lib/order2/.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -22,10 +36,26 @@
 
 namespace m3d {
 
+#ifndef M3D_FP_ORDER
+#define M3D_FP_ORDER 0
+#endif
+#if M3D_FP_ORDER < 0 || M3D_FP_ORDER > 2
+#error "M3D_FP_ORDER must be 0 (Eigen >= 3.3), 1 (Eigen 3.2) or 2 (Eigen 3.4)"
+#endif
+constexpr int kFpOrder = M3D_FP_ORDER;
+
 constexpr double kEps = 1.0e-8;  // ransac.h:14 EPS
 
+// the 3-element reduction every dot product / squaredNorm of a Vector3d goes through
+M3D_HD double sum3(double e0, double e1, double e2) {
+#if M3D_FP_ORDER == 1
+    return e0 + (e1 + e2);
+#else
+    return (e0 + e1) + e2;
+#endif
+}
 M3D_HD double dot3(double ax, double ay, double az, double bx, double by, double bz) {
-    return (ax * bx + ay * by) + az * bz;
+    return sum3(ax * bx, ay * by, az * bz);
 }
 M3D_HD double norm3(double x, double y, double z) { return sqrt(dot3(x, y, z, x, y, z)); }
 M3D_HD double dot4(double a0, double a1, double a2, double a3, double b0, double b1, double b2,
@@ -117,11 +147,29 @@ M3D_HD double plane_cutoff(const double* m, double thr) {
 M3D_HD double det4_helper(const double (*m)[4], int j, int k, int a, int b) {
     return (m[j][0] * m[k][1] - m[k][0] * m[j][1]) * (m[a][2] * m[b][3] - m[b][2] * m[a][3]);
 }
+#if M3D_FP_ORDER == 2
+// Eigen 3.4 determinant_impl<.,4> ([RECALL]): 2x2 minors of columns 0-1, 3x3 cofactors along column 2, expansion
+// along column 3; pmadd(a, b, c) = a * b + c (no FMA in the reference build)
+M3D_HD double det4_d2(const double (*m)[4], int i0, int i1) { return m[i0][0] * m[i1][1] - m[i1][0] * m[i0][1]; }
+M3D_HD double det4_d3(const double (*m)[4], int i0, double d0, int i1, double d1, int i2, double d2) {
+    return m[i0][2] * d0 + ((-m[i1][2]) * d1 + m[i2][2] * d2);
+}
+M3D_HD double det4(const double (*m)[4]) {
+    const double d01 = det4_d2(m, 0, 1), d02 = det4_d2(m, 0, 2), d03 = det4_d2(m, 0, 3);
+    const double d12 = det4_d2(m, 1, 2), d13 = det4_d2(m, 1, 3), d23 = det4_d2(m, 2, 3);
+    const double c0 = det4_d3(m, 1, d23, 2, d13, 3, d12);
+    const double c1 = det4_d3(m, 0, d23, 2, d03, 3, d02);
+    const double c2 = det4_d3(m, 0, d13, 1, d03, 3, d01);
+    const double c3 = det4_d3(m, 0, d12, 1, d02, 2, d01);
+    return ((-m[0][3]) * c0 + m[1][3] * c1) + ((-m[2][3]) * c2 + m[3][3] * c3);
+}
+#else
 // Eigen 3.3 determinant_impl<.,4> (Costabel's 30-multiply form)
 M3D_HD double det4(const double (*m)[4]) {
     return det4_helper(m, 0, 1, 2, 3) - det4_helper(m, 0, 2, 1, 3) + det4_helper(m, 0, 3, 1, 2) +
            det4_helper(m, 1, 2, 0, 3) - det4_helper(m, 1, 3, 0, 2) + det4_helper(m, 2, 3, 0, 1);
 }
+#endif
 // ValidationCheck + MinimalFit, ransac.h:225-234,239-294.  p = 4 points (12 doubles).
 M3D_HD bool sphere_minimal_fit(const double* p, double* out) {
     double plane[4];
@@ -173,7 +221,7 @@ M3D_HD bool sphere_minimal_fit(const double* p, double* out) {
 // squared distance to the centre in the reference's order (the argument of .norm(), ransac.h:336)
 M3D_HD double sphere_s(double cx, double cy, double cz, double x, double y, double z) {
     const double dx = x - cx, dy = y - cy, dz = z - cz;
-    return (dx * dx + dy * dy) + dz * dz;
+    return sum3(dx * dx, dy * dy, dz * dz);
 }
 M3D_HD double sphere_dist_from_d(double d, double r) { return d <= r ? r - d : d - r; }
 M3D_HD double sphere_distance(const double* m, double x, double y, double z) {
@@ -243,7 +291,7 @@ M3D_HD double line_t(double p1x, double p1y, double p1z, double p2x, double p2y,
     const double cx = ay * bz - az * by;
     const double cy = az * bx - ax * bz;
     const double cz = ax * by - ay * bx;
-    return (cx * cx + cy * cy) + cz * cz;
+    return sum3(cx * cx, cy * cy, cz * cz);
 }
 M3D_HD double point2line(const double* q, const double* p1, const double* p2) {
     const double t = line_t(p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], q[0], q[1], q[2]);

@@ -153,6 +153,11 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
             }
             ok = plane_minimal_fit(p, p + 3, p + 6, par);
             if (ok) {
+                // spare slots of the PARAMETER record: the first sample point, an inlier of the model -- the provisional
+                // centre RefineModel's fused moment sums are taken about (compact_count_k<.., true>)
+                par[4] = p[0];
+                par[5] = p[1];
+                par[6] = p[2];
                 rec[0] = par[0];
                 rec[1] = par[1];
                 rec[2] = par[2];
@@ -357,6 +362,17 @@ void launch_reduce_partials(const uint32_t* partial, uint32_t n_tiles, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // K4  ordered compaction with the reference distance (RefineModel, tie-break error, segmentation)
 // ------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void block_tree_reduce(double (&acc)[NV], double* sm /* NV x 256 */) {
+    for (int k = 0; k < NV; ++k) sm[k * 256 + threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < NV; ++k) sm[k * 256 + threadIdx.x] += sm[k * 256 + threadIdx.x + off];
+        __syncthreads();
+    }
+}
+
 template <int KIND>
 __device__ __forceinline__ double ref_distance(const double* m, double x, double y, double z) {
     if (KIND == 0) return plane_distance(m, x, y, z);
@@ -364,38 +380,96 @@ __device__ __forceinline__ double ref_distance(const double* m, double x, double
     return cylinder_distance(m, x, y, z);
 }
 
-template <int KIND>
+// SUMS (RefineModel of a plane / sphere fit): the same pass also accumulates, over the INLIERS, the raw moments
+// GeneralFit needs about a provisional centre c0 taken from the model record (plane: the hypothesis' first sample
+// point, slots 4..6; sphere: the minimal model's centre) -- s = p - c0:
+//   [0..2] sum s   [3..8] sum s s^T (xx,xy,xz,yy,yz,zz)   [9..11] sum s |s|^2 (sphere)
+// one 16-double partial per workgroup (fixed tree: deterministic); scan_blocks_k folds the partials.  c0 lies
+// among the inliers, so the shift to the true mean (host, moments_about_mean) cancels at most a few bits.  This
+// replaces two gather passes over the inlier list (ransac.h:170-188, 302-316 read the points once more).
+template <int KIND, bool SUMS>
 __global__ __launch_bounds__(256) void compact_count_k(CloudView c, const double* __restrict__ model,
                                                         double thr, int invert,
                                                         uint32_t* __restrict__ block_counts,
-                                                        double* __restrict__ model_copy) {
+                                                        double* __restrict__ model_copy,
+                                                        double* __restrict__ moment_partial) {
     __shared__ uint32_t wsum[4];
-    double m[7];
-    for (int k = 0; k < 7; ++k) m[k] = model[k];
+    double m[kModelStride];
+    for (int k = 0; k < kModelStride; ++k) m[k] = model[k];
     // the model record (8 doubles) also goes where the caller wants a copy (pinned host memory): no copy command
     if (model_copy && blockIdx.x == 0 && threadIdx.x < kModelStride) model_copy[threadIdx.x] = model[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t cnt = 0;
     const uint32_t base = blockIdx.x * kCompactTile;
+    constexpr int NV = KIND == 1 ? 12 : 9;
+    double acc[NV];
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    const double c0x = KIND == 0 ? m[4] : m[0], c0y = KIND == 0 ? m[5] : m[1], c0z = KIND == 0 ? m[6] : m[2];
     for (int r = 0; r < kCompactTile / 256; ++r) {
         const uint32_t i = base + r * 256 + threadIdx.x;
         bool f = false;
         if (i < c.n) {
-            const double d = ref_distance<KIND>(m, c.x[i], c.y[i], c.z[i]);
+            const double px = c.x[i], py = c.y[i], pz = c.z[i];
+            const double d = ref_distance<KIND>(m, px, py, pz);
             f = (d < thr) != (invert != 0);
+            if (SUMS && f) {
+                const double sx = px - c0x, sy = py - c0y, sz = pz - c0z;
+                acc[0] += sx;
+                acc[1] += sy;
+                acc[2] += sz;
+                acc[3] += sx * sx;
+                acc[4] += sx * sy;
+                acc[5] += sx * sz;
+                acc[6] += sy * sy;
+                acc[7] += sy * sz;
+                acc[8] += sz * sz;
+                if (KIND == 1) {
+                    const double q = (sx * sx + sy * sy) + sz * sz;
+                    acc[9] += sx * q;
+                    acc[10] += sy * q;
+                    acc[11] += sz * q;
+                }
+            }
         }
         cnt += (uint32_t)__popcll(__ballot(f));
     }
     if (lane == 0) wsum[wave] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (SUMS) {
+        __shared__ double sm[NV * 256];
+        __syncthreads();
+        block_tree_reduce<NV>(acc, sm);
+        if (threadIdx.x < 12) moment_partial[(size_t)blockIdx.x * 16 + threadIdx.x] = (int)threadIdx.x < NV ? sm[threadIdx.x * 256] : 0.0;
+    }
 }
 
 // exclusive scan of block_counts[0..nb) in place; total[0] = sum
+// moment_partial != null: nb x 16 doubles from compact_count_k<.., true>; their sums (fixed order: thread t takes blocks
+// t, t + 1024, ..., then a 1024-leaf tree) go to moment_out[0..11] -- device-visible host memory -- and
+// moment_out[12] receives the total as a double.
 __global__ __launch_bounds__(1024) void scan_blocks_k(uint32_t* __restrict__ v, uint32_t nb,
-                                                       uint32_t* __restrict__ total) {
+                                                       uint32_t* __restrict__ total,
+                                                       const double* __restrict__ moment_partial,
+                                                       double* __restrict__ moment_out) {
     __shared__ uint32_t buf[1024];
     __shared__ uint32_t carry;
+    __shared__ double msum[12 * 64];
+    if (moment_partial) {   // block-uniform
+        // 16 lanes-groups of 64 threads: thread (g, l) sums blocks l, l + 64, ... of value g (g < 12)
+        const uint32_t g = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (g < 12) {
+            double a = 0.0;
+            for (uint32_t b = l; b < nb; b += 64) a += moment_partial[(size_t)b * 16 + g];
+            msum[g * 64 + l] = a;
+        }
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) {
+            if (g < 12 && (int)l < off) msum[g * 64 + l] += msum[g * 64 + l + off];
+            __syncthreads();
+        }
+        if (threadIdx.x < 12) moment_out[threadIdx.x] = msum[threadIdx.x * 64];
+    }
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
@@ -416,11 +490,14 @@ __global__ __launch_bounds__(1024) void scan_blocks_k(uint32_t* __restrict__ v, 
         if (threadIdx.x == 1023) carry = c0 + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) total[0] = carry;
+    if (threadIdx.x == 0) {
+        total[0] = carry;
+        if (moment_out) moment_out[12] = (double)carry;
+    }
 }
 
 void launch_scan_blocks(uint32_t* v, uint32_t nb, uint32_t* total, hipStream_t s) {
-    scan_blocks_k<<<1, 1024, 0, s>>>(v, nb, total);
+    scan_blocks_k<<<1, 1024, 0, s>>>(v, nb, total, nullptr, nullptr);
 }
 
 template <int KIND, int MODE>
@@ -428,7 +505,8 @@ __global__ __launch_bounds__(256) void compact_write_k(
     CloudView c, const double* __restrict__ model, double thr, const uint32_t* __restrict__ orig,
     const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ ox, double* __restrict__ oy,
-    double* __restrict__ oz, uint32_t* __restrict__ oorig, uint32_t n_pad_cap) {
+    double* __restrict__ oz, uint32_t* __restrict__ oorig, uint32_t n_pad_cap,
+    uint64_t* __restrict__ out_idx_host /* MODE 0: the caller's page-locked index list, written as well (may be null) */) {
     __shared__ uint32_t wsum[4];
     double m[7];
     for (int k = 0; k < 7; ++k) m[k] = model[k];
@@ -455,7 +533,11 @@ __global__ __launch_bounds__(256) void compact_write_k(
         const uint32_t rowtot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
         if (f) {
             const uint32_t pos = row_base + woff + lane_pre;
-            if (MODE == 0) out_idx[pos] = orig ? (uint64_t)orig[i] : (uint64_t)i;
+            if (MODE == 0) {
+                const uint64_t id = orig ? (uint64_t)orig[i] : (uint64_t)i;
+                if (out_idx) out_idx[pos] = id;
+                if (out_idx_host) out_idx_host[pos] = id;   // 512-B bursts per wave row straight over the host link
+            }
             if (MODE == 1) out_dist[pos] = d;
             if (MODE >= 2) {
                 ox[pos] = px;
@@ -485,42 +567,49 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
                                 const uint32_t* orig, uint64_t* out_idx, double* out_dist,
                                 double* ox, double* oy, double* oz, uint32_t* oorig,
                                 uint32_t n_pad_out, uint32_t* block_counts, uint32_t* total,
-                                hipStream_t s, double* model_copy) {
+                                hipStream_t s, double* model_copy, double* moment_partial, double* moment_out,
+                                uint64_t* out_idx_host) {
     const uint32_t nb = (c.n + kCompactTile - 1) / kCompactTile;
     if (nb == 0) {
         (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
         if (model_copy) (void)hipMemcpyAsync(model_copy, model, sizeof(double) * kModelStride, hipMemcpyDeviceToHost, s);
+        if (moment_out) (void)hipMemsetAsync(moment_out, 0, sizeof(double) * 13, s);
         return;
     }
-    compact_count_k<KIND><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts, model_copy);
-    scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total);
+    const bool sums = moment_partial && moment_out && mode == 0 && KIND != 2;
+    if (sums)
+        compact_count_k<KIND == 2 ? 0 : KIND, true><<<nb, 256, 0, s>>>(c, model, thr, 0, block_counts, model_copy, moment_partial);
+    else
+        compact_count_k<KIND, false><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts, model_copy, nullptr);
+    scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total, sums ? moment_partial : nullptr, sums ? moment_out : nullptr);
     if (mode == 0)
         compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
-                                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+                                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, out_idx_host);
     else if (mode == 1)
         compact_write_k<KIND, 1><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                     out_dist, nullptr, nullptr, nullptr, nullptr, 0);
+                                                     out_dist, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
     else if (mode == 2)
         compact_write_k<KIND, 2><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                     nullptr, ox, oy, oz, oorig, n_pad_out);
+                                                     nullptr, ox, oy, oz, oorig, n_pad_out, nullptr);
     else
         compact_write_k<KIND, 3><<<nb, 256, 0, s>>>(c, model, thr, nullptr, block_counts, nullptr,
-                                                     nullptr, ox, oy, oz, nullptr, n_pad_out);
+                                                     nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr);
 }
 
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
-                    uint32_t* block_counts, uint32_t* total, hipStream_t s, double* model_copy) {
+                    uint32_t* block_counts, uint32_t* total, hipStream_t s, double* model_copy,
+                    double* moment_partial, double* moment_out, uint64_t* out_idx_host) {
     if (kind == 0)
         launch_compact_kind<0>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy);
+                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host);
     else if (kind == 1)
         launch_compact_kind<1>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy);
+                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host);
     else
         launch_compact_kind<2>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy);
+                               n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host);
 }
 
 // EvaluateModel's `error += distance` in point order (ransac.h:637): a genuinely serial fp64 chain.
@@ -610,17 +699,6 @@ void launch_serial_sum(const double* v, const uint32_t* n, double* out, hipStrea
 // ------------------------------------------------------------------------------------------------
 constexpr int kSumBlocks = 256;
 
-template <int NV>
-__device__ __forceinline__ void block_tree_reduce(double (&acc)[NV], double* sm /* NV x 256 */) {
-    for (int k = 0; k < NV; ++k) sm[k * 256 + threadIdx.x] = acc[k];
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int k = 0; k < NV; ++k) sm[k * 256 + threadIdx.x] += sm[k * 256 + threadIdx.x + off];
-        __syncthreads();
-    }
-}
-
 __global__ __launch_bounds__(256) void sum_xyz_k(CloudView c, const uint64_t* __restrict__ idx,
                                                   uint32_t n, double* __restrict__ partial) {
     __shared__ double sm[3 * 256];
@@ -692,6 +770,32 @@ void launch_general_fit_sums(const CloudView& c, const uint64_t* idx, uint32_t n
                              double* out_host, hipStream_t s) {
     sum_xyz_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, partial_dev);
     sum_moments_k<<<kSumBlocks, 256, 0, s>>>(c, idx, n_idx, partial_dev, out_host);
+}
+
+// Raw moments about the provisional centre c0 (compact_count_k<.., true> + scan_blocks_k) -> mean and centred moments.
+// With s = p - c0, m = (sum s) / n, r = s - m, q = |r|^2:
+//   sum r r^T = sum s s^T - n m m^T
+//   sum q     = trace of that
+//   sum r q   = sum s|s|^2 - 2 (sum s s^T) m + m (2 n |m|^2 - trace(sum s s^T))
+// c0 is an inlier (plane) / the minimal centre (sphere), so |m| is at most the inliers' extent and the subtractions
+// lose a few bits at worst.
+void moments_about_mean(const double* mo, const double c0[3], double n, double mean[3], double centred[10]) {
+    const double m[3] = {mo[0] / n, mo[1] / n, mo[2] / n};
+    for (int k = 0; k < 3; ++k) mean[k] = c0[k] + m[k];
+    const double S[6] = {mo[3], mo[4], mo[5], mo[6], mo[7], mo[8]};   // xx xy xz yy yz zz
+    centred[0] = S[0] - n * m[0] * m[0];
+    centred[1] = S[1] - n * m[0] * m[1];
+    centred[2] = S[2] - n * m[0] * m[2];
+    centred[3] = S[3] - n * m[1] * m[1];
+    centred[4] = S[4] - n * m[1] * m[2];
+    centred[5] = S[5] - n * m[2] * m[2];
+    const double trS = (S[0] + S[3]) + S[5];
+    const double mm = (m[0] * m[0] + m[1] * m[1]) + m[2] * m[2];
+    const double Sm[3] = {(S[0] * m[0] + S[1] * m[1]) + S[2] * m[2], (S[1] * m[0] + S[3] * m[1]) + S[4] * m[2],
+                          (S[2] * m[0] + S[4] * m[1]) + S[5] * m[2]};
+    const double f = 2.0 * n * mm - trS;
+    for (int k = 0; k < 3; ++k) centred[6 + k] = (mo[9 + k] - 2.0 * Sm[k]) + m[k] * f;
+    centred[9] = (centred[0] + centred[3]) + centred[5];
 }
 
 // sums[0..2] = sum of x, y, z; sums[4..13] = the ten centred moments: the last level of the fixed tree, on the host,

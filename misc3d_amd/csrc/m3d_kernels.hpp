@@ -67,7 +67,17 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
                     uint32_t* block_counts, uint32_t* total, hipStream_t s,
-                    double* model_copy = nullptr /* device-visible (pinned host): receives the 8-double model record */);
+                    double* model_copy = nullptr /* device-visible (pinned host): receives the 8-double model record */,
+                    double* moment_partial = nullptr /* mode 0, plane / sphere: scratch of ceil(n / kCompactTile) x 16 doubles ... */,
+                    double* moment_out = nullptr /* ... and kFusedMomentDoubles doubles (device-visible host memory): GeneralFit's raw
+                                                    moments over the inliers about the model record's provisional centre */,
+                    uint64_t* out_idx_host = nullptr /* mode 0: page-locked host copy of the index list, written by the kernel */);
+// moment_out layout: [0..2] sum s, [3..8] sum s s^T (xx,xy,xz,yy,yz,zz), [9..11] sum s |s|^2 (sphere), [12] inlier count;
+// s = p - c0, c0 = model[4..6] (plane: the hypothesis' first sample point) or model[0..2] (sphere: the minimal centre).
+constexpr int kFusedMomentDoubles = 16;
+// raw moments about c0 -> what the closed forms take: mean[3] and the ten centred moments (xx,xy,xz,yy,yz,zz, sum r q
+// (3), sum q with q = |r|^2, r = p - mean) -- the same quantities sum_moments_k produces
+void moments_about_mean(const double* moment_out, const double c0[3], double n, double mean[3], double centred[10]);
 
 // serial-order sum of `n[0]` doubles (EvaluateModel's `error += distance`, ransac.h:637)
 void launch_serial_sum(const double* v, const uint32_t* n, double* out, hipStream_t s);

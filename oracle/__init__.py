@@ -17,7 +17,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libmisc3d_oracle.so")
+# M3D_FP_ORDER=1|2: the oracle built for the same alternative floating-point association as the product library
+FP_ORDER = int(os.environ.get("M3D_FP_ORDER", "0") or 0)
+_LIB_PATH = os.path.join(_HERE, "_build", *([f"order{FP_ORDER}"] if FP_ORDER else []), "libmisc3d_oracle.so")
 RNG_CHECK_PATH = os.path.join(_HERE, "_build", "std_rng_check")
 
 PLANE, SPHERE, CYLINDER = 0, 1, 2
@@ -27,6 +29,7 @@ _NP = {PLANE: 4, SPHERE: 4, CYLINDER: 7}
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in ("misc3d_oracle.c", "misc3d_oracle_reg.c", "misc3d_oracle_normals.c", "misc3d_oracle_boundary.c", "std_rng_check.cpp", "Makefile")]
+    srcs = srcs  # (one make builds the default and both alternative associations)
     stale = force or not os.path.exists(_LIB_PATH) or not os.path.exists(RNG_CHECK_PATH)
     if not stale:
         t = min(os.path.getmtime(_LIB_PATH), os.path.getmtime(RNG_CHECK_PATH))

@@ -111,9 +111,22 @@ uint32_t orc_uniform_int(orc_mt19937 *g, uint32_t range_incl) {
 /* ------------------------------------------------------------------------------------------- */
 /* Eigen reduction orders                                                                       */
 /* ------------------------------------------------------------------------------------------- */
-static inline double dot3(const double *a, const double *b) {
-    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; /* (ii) */
+/* ORC_FP_ORDER: which Eigen the association is restated for (the product has the same switch, M3D_FP_ORDER in
+ * misc3d_amd/csrc/m3d_fp.hpp, where the three variants are described): 0 = Eigen >= 3.3 (default), 1 = Eigen 3.2
+ * (3-element reductions e0 + (e1 + e2)), 2 = Eigen 3.4 (its 4x4 determinant).  `make -C oracle orders` builds
+ * _build/order1/ and _build/order2/. */
+#ifndef ORC_FP_ORDER
+#define ORC_FP_ORDER 0
+#endif
+int orc_fp_order(void) { return ORC_FP_ORDER; }
+static inline double sum3(double e0, double e1, double e2) {
+#if ORC_FP_ORDER == 1
+    return e0 + (e1 + e2);
+#else
+    return (e0 + e1) + e2; /* (ii) */
+#endif
 }
+static inline double dot3(const double *a, const double *b) { return sum3(a[0] * b[0], a[1] * b[1], a[2] * b[2]); }
 static inline double norm3(const double *a) { return sqrt(dot3(a, a)); }
 static inline double dot4(const double *a, const double *b) {
     return (a[0] * b[0] + a[2] * b[2]) + (a[1] * b[1] + a[3] * b[3]); /* (i) */
@@ -216,10 +229,29 @@ int orc_plane_general_fit(const double *pts, size_t n, double *out) {
 static double det4_helper(double m[4][4], int j, int k, int a, int b) {
     return (m[j][0] * m[k][1] - m[k][0] * m[j][1]) * (m[a][2] * m[b][3] - m[b][2] * m[a][3]);
 }
+#if ORC_FP_ORDER == 2
+/* Eigen 3.4 determinant_impl<Derived,4> ([RECALL]): det2 minors of columns 0-1, det3 cofactors along column 2,
+ * expansion along column 3; pmadd(a, b, c) = a * b + c without FMA */
+static double det4_d2(double m[4][4], int i0, int i1) { return m[i0][0] * m[i1][1] - m[i1][0] * m[i0][1]; }
+static double det4_d3(double m[4][4], int i0, double d0, int i1, double d1, int i2, double d2) {
+    return m[i0][2] * d0 + ((-m[i1][2]) * d1 + m[i2][2] * d2);
+}
+static double det4(double m[4][4]) {
+    (void)det4_helper;
+    const double d01 = det4_d2(m, 0, 1), d02 = det4_d2(m, 0, 2), d03 = det4_d2(m, 0, 3);
+    const double d12 = det4_d2(m, 1, 2), d13 = det4_d2(m, 1, 3), d23 = det4_d2(m, 2, 3);
+    const double c0 = det4_d3(m, 1, d23, 2, d13, 3, d12);
+    const double c1 = det4_d3(m, 0, d23, 2, d03, 3, d02);
+    const double c2 = det4_d3(m, 0, d13, 1, d03, 3, d01);
+    const double c3 = det4_d3(m, 0, d12, 1, d02, 2, d01);
+    return ((-m[0][3]) * c0 + m[1][3] * c1) + ((-m[2][3]) * c2 + m[3][3] * c3);
+}
+#else
 static double det4(double m[4][4]) {
     return det4_helper(m, 0, 1, 2, 3) - det4_helper(m, 0, 2, 1, 3) + det4_helper(m, 0, 3, 1, 2) +
            det4_helper(m, 1, 2, 0, 3) - det4_helper(m, 1, 3, 0, 2) + det4_helper(m, 2, 3, 0, 1);
 }
+#endif
 
 /* SphereEstimator::ValidationCheck + MinimalFit, ransac.h:225-234, 239-294.  p = 4 points. */
 int orc_sphere_minimal_fit(const double *p, double *out) {
