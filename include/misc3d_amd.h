@@ -198,6 +198,8 @@ typedef struct m3d_reg_stats {
     double ms_total;
     uint64_t ties;             /* equal-fitness comparisons decided during the replay */
     uint64_t exact_rmse_evals; /* of which needed the serial-order sum of squared distances */
+    uint64_t lds_wave_hypotheses;    /* validation work units (64 source points x 1 hypothesis) served from the LDS-staged box */
+    uint64_t global_wave_hypotheses; /* ... that took the global-memory path (pose outside the box, or staging off) */
 } m3d_reg_stats;
 /* corr_src/corr_dst: m index pairs (the std::pair<vector<size_t>,vector<size_t>> of the reference).
  * confidence: Open3D RANSACConvergenceCriteria::confidence_ (the reference always uses the default
@@ -369,7 +371,8 @@ typedef struct m3d_config {
     int32_t pool_limit_mb;          /* [M3D_POOL_MB]        default 4096: released device blocks parked per device for re-use (0 = none) */
     int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=0] default 1: HIP events around every scoring launch (m3d_stats.ms_score_kernel);
                                        0 drops those four event commands per chunk from the stream */
-    int32_t reserved[2];
+    int32_t reg_lds_staging;        /* [M3D_REG_LDS=0]      default 1: registration validation with the target neighbourhood of a source tile staged in LDS */
+    int32_t reserved[1];
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -56,7 +56,8 @@ class Stats(C.Structure):
 class RegStats(C.Structure):
     _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("validations", C.c_uint64),
                 ("iterations", C.c_int64), ("best_index", C.c_int64), ("est_k", C.c_int64),
-                ("ms_total", C.c_double), ("ties", C.c_uint64), ("exact_rmse_evals", C.c_uint64)]
+                ("ms_total", C.c_double), ("ties", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
+                ("lds_wave_hypotheses", C.c_uint64), ("global_wave_hypotheses", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -198,7 +199,7 @@ class Config(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("dense_scoring", "speculative_refine", "lead_hypotheses",
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
                                          "morton_order", "reg_neighbour_lists", "reg_source_rows", "reg_prune",
-                                         "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing")] + [("reserved", C.c_int32 * 2)]
+                                         "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing", "reg_lds_staging")] + [("reserved", C.c_int32 * 1)]
 
 
 def get_config() -> Config:

@@ -36,16 +36,28 @@ void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_o
                        uint32_t* cell_start, uint32_t* rank /* scratch, ONE ENTRY PER POINT (dst.n) */,
                        uint32_t* tile_sums, uint32_t* total,
                        double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr);
+// the two halves of launch_grid_build; pad_to > 1 pads every group of pad_group consecutive cells to a multiple of pad_to
+// slots (the caller pre-fills the arrays: the slots between the runs keep that value); total[0] = length of the layout
+void launch_grid_count_scan(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point, uint32_t* cell_start,
+                            uint32_t* rank, uint32_t* tile_sums, uint32_t* total, hipStream_t s, uint32_t pad_to = 0,
+                            uint32_t pad_group = 1);
+void launch_grid_scatter(const CloudView& dst, const uint32_t* cell_of_point, const uint32_t* cell_start,
+                         const uint32_t* rank, double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr);
 void launch_fill_nan(double* p, uint32_t n, hipStream_t s);
 void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl_start, uint32_t* tile_sums,
                      uint32_t* total, hipStream_t s);
 void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, const double* qx,
                     const double* qy, const double* qz, double4* nl_pts, hipStream_t s,
                     const uint32_t* orig = nullptr);
-void launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
-                         const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
-                         uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
-                         uint32_t n_points, uint8_t* keep, hipStream_t s);
+// partial_cnt / partial_sum: src.n_pad / 64 rows of s_pad entries (the LDS-staged kernel, lds_rows, writes one row
+// per 64 source points; reg_validate_k one per 256).  Returns the rows actually used: what launch_reduce_partials folds.
+constexpr int kRegValidateRows = 4;   // rows per 256 source points
+uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
+                             const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
+                             uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
+                             uint32_t n_points, uint8_t* keep, hipStream_t s,
+                             bool lds_rows = false /* the LDS-staged kernel (source copy row-aligned to coarse cells) */,
+                             unsigned long long* fast_stats = nullptr /* [0] LDS path, [1] global path (wave-hypotheses) */);
 void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
                        const double* qx, const double* qy, const double* qz, double* best, hipStream_t s);
 void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* block_counts, uint32_t* total,

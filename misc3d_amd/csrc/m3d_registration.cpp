@@ -16,6 +16,7 @@
 #include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -64,12 +65,13 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, cell_orig;
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, cell_orig, tile_sph, fast_stats;
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
-                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &cell_orig})
+                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &cell_orig,
+                          &tile_sph, &fast_stats})
             b->release();
     }
 };
@@ -349,6 +351,8 @@ struct m3d_reg {
     size_t chunk = 32;
     size_t validated_total = 0, n_dst_points = 0;
     bool nl_built = false;
+    bool spheres_built = false;   // bounding boxes of the source rows (LDS-staged validation)
+    bool rows_aligned = false;    // the sorted source copy is padded so that no row of 64 spans two coarse cells
     int itr = 0;
     int n_exec = 0;          // iterations of the chunk in flight
     bool finished = false;
@@ -406,38 +410,60 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
         }
         if (ext > 0.0 && std::isfinite(ext)) {
             GridDesc gs;
-            // Hilbert order over 128^3 cells: the 64 points of a wave form a compact patch, so the
-            // lanes probe the same few target cells (M3D_REG_SRC_ORDER=rows: x-rows of a 64^3 grid)
-            const bool hilbert = !config().reg_source_rows;
-            const double hs = hilbert ? ext / 127.0 : ext / 63.0;
+            // LDS-staged validation (reg_validate_lds_k): the source is sorted by COARSE cells of 2 x threshold (Hilbert
+            // order of the cells) and every cell's run is padded to whole rows of 64 points, so a row's bounding box is
+            // at most one coarse cell and its image under a pose + a three-cell halo fits the kernel's local table.
+            // Otherwise: Hilbert order over 128^3 cells (m3d_config.reg_source_rows: x-rows of a 64^3 grid) -- the 64
+            // points of a wave form a compact patch, so the lanes probe the same few target cells.
+            const double D = 2.0 * threshold * 1.001;
+            uint32_t cbits = 1;
+            while (cbits < 6 && (double)(1u << cbits) * D < ext * (1.0 + 1e-9)) ++cbits;
+            // fine Hilbert cells of D / 4 (so that a wave's 64 points stay a compact patch INSIDE the coarse cell too);
+            // the 64 fine cells of a coarse cell are consecutive on the curve and aligned: code >> 6 = coarse cell
+            const bool coarse = config().reg_lds_staging != 0 && (double)(1u << cbits) * D >= ext * (1.0 + 1e-9);
+            const bool hilbert = coarse || !config().reg_source_rows;
+            const uint32_t fbits = coarse ? cbits + 2 : 7u;
+            const double hs = coarse ? D / 4.0 : (hilbert ? ext / 127.0 : ext / 63.0);
             gs.K = 0;
-            gs.morton_bits = hilbert ? (7u | 0x100u) : 0u;
+            gs.morton_bits = hilbert ? (fbits | 0x100u) : 0u;
             gs.ox = slo[0];
             gs.oy = slo[1];
             gs.oz = slo[2];
             gs.inv_h = 1.0 / hs;
             gs.r2 = gs.h2_in = 0.0;
-            gs.nx = hilbert ? 128u : (uint32_t)((shi[0] - slo[0]) / hs) + 2;
-            gs.ny = hilbert ? 128u : (uint32_t)((shi[1] - slo[1]) / hs) + 2;
-            gs.nz = hilbert ? 128u : (uint32_t)((shi[2] - slo[2]) / hs) + 2;
+            const uint32_t side = 1u << fbits;
+            gs.nx = hilbert ? side : (uint32_t)((shi[0] - slo[0]) / hs) + 2;
+            gs.ny = hilbert ? side : (uint32_t)((shi[1] - slo[1]) / hs) + 2;
+            gs.nz = hilbert ? side : (uint32_t)((shi[2] - slo[2]) / hs) + 2;
             const uint32_t ncs = gs.nx * gs.ny * gs.nz;
-            const uint32_t np = R.src.n_pad;
             RESERVE(S.s_cell_of_point, sizeof(uint32_t) * n_src);
             RESERVE(S.s_cell_start, sizeof(uint32_t) * ((size_t)ncs + 1));
             RESERVE(S.s_fill, sizeof(uint32_t) * std::max<size_t>(R.src.n, 1));   // rank of every point in its cell
             RESERVE(S.s_tile_sums, sizeof(uint32_t) * ((size_t)(ncs + 2047) / 2048 + 1));
+            launch_grid_count_scan(R.src, gs, S.s_cell_of_point.as<uint32_t>(), S.s_cell_start.as<uint32_t>(),
+                                   S.s_fill.as<uint32_t>(), S.s_tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 2,
+                                   ctx->stream, coarse ? 64u : 0u, 64u);
+            uint32_t np = R.src.n_pad;
+            if (coarse) {   // the padded layout's length is only known now
+                uint32_t total = 0;
+                HIPCHK(hipMemcpyAsync(&total, S.total.as<uint32_t>() + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                np = std::max<uint32_t>(round_up(total, kRegTile), kRegTile);
+            }
             RESERVE(S.sx, sizeof(double) * np);
             RESERVE(S.sy, sizeof(double) * np);
             RESERVE(S.sz, sizeof(double) * np);
             launch_fill_nan(S.sx.as<double>(), np, ctx->stream);
             launch_fill_nan(S.sy.as<double>(), np, ctx->stream);
             launch_fill_nan(S.sz.as<double>(), np, ctx->stream);
-            launch_grid_build(R.src, gs, S.s_cell_of_point.as<uint32_t>(), S.s_cell_start.as<uint32_t>(),
-                              S.s_fill.as<uint32_t>(), S.s_tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 2,
-                              S.sx.as<double>(), S.sy.as<double>(), S.sz.as<double>(), ctx->stream);
+            launch_grid_scatter(R.src, S.s_cell_of_point.as<uint32_t>(), S.s_cell_start.as<uint32_t>(),
+                                S.s_fill.as<uint32_t>(), S.sx.as<double>(), S.sy.as<double>(), S.sz.as<double>(), ctx->stream);
             src_sorted.x = S.sx.as<double>();
             src_sorted.y = S.sy.as<double>();
             src_sorted.z = S.sz.as<double>();
+            src_sorted.n_pad = np;   // (NaN slots are no queries: counts and sums only see the real points)
+            src_sorted.n = np;
+            rows_aligned = coarse;
         }
     }
 
@@ -461,7 +487,7 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
     this->est_k_global = this->est_k_local = max_iter;
     RESERVE(S.one_T, sizeof(double) * kRegTStride * 2);
     this->best_T_dev = S.one_T.as<double>();
-    this->n_tiles = R.src.n_pad / kRegTile;
+    this->n_tiles = src_sorted.n_pad / kRegTile;
     return M3D_OK;
 }
 
@@ -510,8 +536,8 @@ int m3d_reg::begin_chunk(size_t* n_survivors) {
         const uint32_t s_pad = round_up(ns, 64);
         RESERVE(S.list, sizeof(uint32_t) * ns);
         RESERVE(S.Ts, sizeof(double) * kRegTStride * ((size_t)s_pad + 1));
-        RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * s_pad);
-        RESERVE(S.partial_sum, sizeof(double) * (size_t)n_tiles * s_pad);
+        RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * kRegValidateRows * s_pad);
+        RESERVE(S.partial_sum, sizeof(double) * (size_t)n_tiles * kRegValidateRows * s_pad);
         RESERVE(S.sum2, sizeof(double) * s_pad);
         RESERVE(S.counts, sizeof(uint32_t) * s_pad);
         HIPCHK(hipMemcpyAsync(S.list.p, survivors.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice,
@@ -535,19 +561,29 @@ int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double
     {
         const uint32_t s_pad = round_up(ns, 64);
         const double* Ts = S.Ts.as<double>() + s_begin * kRegTStride;   // records behind the shard are real or NaN padding
-        RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * s_pad);
-        RESERVE(S.partial_sum, sizeof(double) * (size_t)n_tiles * s_pad);
+        RESERVE(S.partial, sizeof(uint32_t) * (size_t)n_tiles * kRegValidateRows * s_pad);
+        RESERVE(S.partial_sum, sizeof(double) * (size_t)n_tiles * kRegValidateRows * s_pad);
         RESERVE(S.sum2, sizeof(double) * s_pad);
         RESERVE(S.counts, sizeof(uint32_t) * s_pad);
 
         RESERVE(S.keep, s_pad);
-        // bound-and-prune against the best of EARLIER chunks (M3D_REG_PRUNE=0 switches it off)
-        launch_reg_validate(src_sorted, Ts, s_pad, g, S.cell_start.as<uint32_t>(),
+        // the LDS-staged kernel needs the source tiles' bounding spheres (once per session) and pays off with the
+        // neighbour lists' condition: a call that validates more than a handful of hypotheses
+        const bool lds = config().reg_lds_staging != 0 && nl_built && rows_aligned;
+        if (lds && !spheres_built) {
+            RESERVE(S.fast_stats, 8 * sizeof(unsigned long long));
+            HIPCHK(hipMemsetAsync(S.fast_stats.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+            spheres_built = true;
+        }
+        // bound-and-prune against the best of EARLIER chunks (m3d_config.reg_prune = 0 switches it off)
+        const uint32_t rows = launch_reg_validate(src_sorted, Ts, s_pad, g, S.cell_start.as<uint32_t>(),
                             S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
                             S.partial.as<uint32_t>(), S.partial_sum.as<double>(), S.sum2.as<double>(),
-                            reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream);
+                            reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream,
+                            lds,
+                            lds ? S.fast_stats.as<unsigned long long>() : nullptr);
         HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
-        launch_reduce_partials(S.partial.as<uint32_t>(), n_tiles, s_pad, S.counts.as<uint32_t>(),
+        launch_reduce_partials(S.partial.as<uint32_t>(), rows, s_pad, S.counts.as<uint32_t>(),
                                ctx->stream);
         HIPCHK(hipMemcpyAsync(counts_out, S.counts.p, sizeof(uint32_t) * ns, hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -674,6 +710,15 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
         stats->est_k = est_k_global;
         stats->ties = ties;
         stats->exact_rmse_evals = exact_evals;
+        if (spheres_built) {
+            unsigned long long fs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            HIPCHK(hipMemcpy(fs, S.fast_stats.p, sizeof(fs), hipMemcpyDeviceToHost));
+            stats->lds_wave_hypotheses = fs[0];
+            stats->global_wave_hypotheses = fs[1];
+            if (std::getenv("M3D_REG_DEBUG"))
+                std::fprintf(stderr, "reg_validate_lds_k: %llu workgroups, %llu with a box beyond the local table, %llu with too many points\n",
+                             fs[2], fs[3], fs[4]);
+        }
     }
     if (stats) stats->ms_total = now_ms() - this->t_begin;
     return M3D_OK;

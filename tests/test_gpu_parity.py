@@ -238,7 +238,10 @@ def test_sharded_driver_on_gpu_equals_single_call(capi):
             s = distributed.fit_sharded(c, len(pts), 0, 0.01, H, prob, seed)
             assert s.best_index == g.stats["best_index"] and s.count == g.stats["count"]
             assert s.iterations == g.stats["iterations"]
-            assert np.array_equal(s.inliers, g.inliers) and np.array_equal(s.params, g.params)
+            assert np.array_equal(s.inliers, g.inliers)
+            # (this python driver refines through m3d_cloud_refine -- GeneralFit sums over the inlier list --, the
+            # one-call fit through the moments fused into the compaction: same least-squares problem, different trees)
+            assert np.allclose(s.params, g.params, rtol=0, atol=1e-12)
 
 
 def test_cloud_remove_inliers_and_sharded_segmentation(capi, orc):
@@ -261,7 +264,7 @@ def test_cloud_remove_inliers_and_sharded_segmentation(capi, orc):
         for k in range(len(planes)):
             assert np.array_equal(r.clusters[k], clusters[k].astype(np.int64))
             assert np.array_equal(r.clusters[k], oclusters[k].astype(np.int64))
-            assert np.array_equal(r.planes[k], planes[k])
+            assert np.allclose(r.planes[k], planes[k], rtol=0, atol=1e-12)
             assert np.allclose(r.planes[k], oplanes[k], rtol=0, atol=PARAM_TOL)
         # the shrunk cloud still answers every entry point: a fit on it equals a fit on a fresh upload of
         # the remaining points (indices mapped through the removal)

@@ -54,7 +54,8 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
     cd = np.where(rng.random(1500) < frac, inv[cs], rng.integers(0, n, 1500))
     kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=edge, confidence=1.0, seed=4)
     T, st = capi.registration_ransac(src, dst, cs, cd, **kw)
-    for env in ("reg_prune", "reg_neighbour_lists"):      # each optimisation switched off in turn (m3d_config)
+    assert st["lds_wave_hypotheses"] > 0                       # the LDS-staged validation kernel really ran
+    for env in ("reg_prune", "reg_neighbour_lists", "reg_lds_staging"):      # each optimisation switched off in turn (m3d_config)
         old = capi.set_config(**{env: 0})
         try:
             T0, st0 = capi.registration_ransac(src, dst, cs, cd, **kw)
