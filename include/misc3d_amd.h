@@ -371,8 +371,8 @@ typedef struct m3d_config {
     int32_t pool_limit_mb;          /* [M3D_POOL_MB]        default 4096: released device blocks parked per device for re-use (0 = none) */
     int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=0] default 1: HIP events around every scoring launch (m3d_stats.ms_score_kernel);
                                        0 drops those four event commands per chunk from the stream */
-    int32_t reg_lds_staging;        /* [M3D_REG_LDS=0]      default 1: registration validation with the target neighbourhood of a source tile staged in LDS */
-    int32_t reserved[1];
+    int32_t reg_lds_staging;        /* [M3D_REG_LDS=0]      default 0: registration validation with the target neighbourhood of a row of source points staged in LDS (bit-identical, not faster: DESIGN.md) */
+    int32_t reg_sorted_lists;       /* [M3D_REG_SORTED=0]   default 1: x-sorted neighbour lists, side columns cut off by the x-distance */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -199,7 +199,7 @@ class Config(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("dense_scoring", "speculative_refine", "lead_hypotheses",
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
                                          "morton_order", "reg_neighbour_lists", "reg_source_rows", "reg_prune",
-                                         "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing", "reg_lds_staging")] + [("reserved", C.c_int32 * 1)]
+                                         "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing", "reg_lds_staging", "reg_sorted_lists")]
 
 
 def get_config() -> Config:
@@ -213,7 +213,7 @@ def set_config(**kw) -> Config:
     old = get_config()
     new = get_config()
     for k, v in kw.items():
-        if not hasattr(new, k) or k == "reserved":
+        if not hasattr(new, k):
             raise AttributeError(k)
         setattr(new, k, int(v))
     _check(lib().m3d_set_config(C.byref(new)))

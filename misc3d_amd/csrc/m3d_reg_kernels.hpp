@@ -23,6 +23,12 @@ struct GridDesc {
     // optional neighbour lists (validation grid only): points of the 3x3x3 block of every cell, contiguous
     const uint32_t* nl_start = nullptr;  // ncell + 1
     const double4* nl_pts = nullptr;
+    // nl_sorted != 0 (launch_nl_fill with sorted = true): every list is laid out as
+    //   [the 9 cells of the query cell's own x-column, ascending x] [the 9 cells one column to the left, DESCENDING x]
+    //   [the 9 cells one column to the right, ascending x],   entry 0's w = n_mid + 65536 * n_left
+    // so that a query evaluates its own column, and then walks the side columns outwards from the cell only while the
+    // x-distance alone is still below the best squared distance found (exact: everything skipped is farther away).
+    int nl_sorted = 0;
 };
 
 
@@ -46,9 +52,11 @@ void launch_grid_scatter(const CloudView& dst, const uint32_t* cell_of_point, co
 void launch_fill_nan(double* p, uint32_t n, hipStream_t s);
 void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl_start, uint32_t* tile_sums,
                      uint32_t* total, hipStream_t s);
-void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, const double* qx,
-                    const double* qy, const double* qz, double4* nl_pts, hipStream_t s,
-                    const uint32_t* orig = nullptr);
+// sorted (orig must be null): the points of every grid cell are first ordered by x IN PLACE (qx / qy / qz), then the lists
+// are written in the three-column layout of GridDesc::nl_sorted; the caller sets g.nl_sorted = 1.
+void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, double* qx,
+                    double* qy, double* qz, double4* nl_pts, hipStream_t s,
+                    const uint32_t* orig = nullptr, bool sorted = false);
 // partial_cnt / partial_sum: src.n_pad / 64 rows of s_pad entries (the LDS-staged kernel, lds_rows, writes one row
 // per 64 source points; reg_validate_k one per 256).  Returns the rows actually used: what launch_reduce_partials folds.
 constexpr int kRegValidateRows = 4;   // rows per 256 source points

@@ -177,10 +177,13 @@ int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, 
                               ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         RESERVE(S.nl_pts, sizeof(double4) * std::max<size_t>(entries, 1));
+        // without original indices riding in w (validation grid): x-sorted three-column lists with early termination
+        const bool sorted = orig == nullptr && config().reg_sorted_lists != 0;
         launch_nl_fill(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.qx.as<double>(),
-                       S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream, orig);
+                       S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream, orig, sorted);
         g.nl_start = S.nl_start.as<uint32_t>();
         g.nl_pts = S.nl_pts.as<double4>();
+        g.nl_sorted = sorted ? 1 : 0;
     }
     return M3D_OK;
 }

@@ -54,9 +54,9 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
     cd = np.where(rng.random(1500) < frac, inv[cs], rng.integers(0, n, 1500))
     kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=edge, confidence=1.0, seed=4)
     T, st = capi.registration_ransac(src, dst, cs, cd, **kw)
-    assert st["lds_wave_hypotheses"] > 0                       # the LDS-staged validation kernel really ran
-    for env in ("reg_prune", "reg_neighbour_lists", "reg_lds_staging"):      # each optimisation switched off in turn (m3d_config)
-        old = capi.set_config(**{env: 0})
+    # each optimisation switched off in turn, and the optional LDS-staged validation kernel switched on (m3d_config)
+    for env, val in (("reg_prune", 0), ("reg_neighbour_lists", 0), ("reg_sorted_lists", 0), ("reg_lds_staging", 1)):
+        old = capi.set_config(**{env: val})
         try:
             T0, st0 = capi.registration_ransac(src, dst, cs, cd, **kw)
         finally:
@@ -64,10 +64,42 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
         assert np.array_equal(T, T0), env
         for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse", "ties"):
             assert st[k] == st0[k], (env, k)
+        # (here the shifted third of the source stretches the cloud beyond what the LDS-staged kernel's coarse source
+        # grid covers: it stands down and the ordinary kernel runs -- test_registration_lds_staging_is_exact has it run)
     assert 0.2 < st["fitness"] < 0.9
     o = orc.registration_ransac(src, dst, cs, cd, thr=0.03, max_iter=3000, edge_thr=edge, confidence=1.0, seed=4)
     assert st["best_index"] == o.best_index and st["validations"] == o.validations and st["fitness"] == o.fitness
     assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64))
+
+
+def test_registration_lds_staging_is_exact(capi, orc):
+    """The optional validation kernel that stages the target neighbourhood of a row of source points in LDS
+    (m3d_config.reg_lds_staging) and the x-sorted neighbour lists with their early cut-off (reg_sorted_lists) are
+    different ways to the same minimum: T, counts, tie decisions and the oracle's result are reproduced bit for bit."""
+    n = 6000
+    d = synth.registration_pair_c4(n, seed=9, dim=8, true_fraction=0.4, sigma=0.001)
+    inv = np.empty(n, dtype=np.int64)
+    inv[d["perm"]] = np.arange(n)
+    rng = np.random.default_rng(3)
+    cs = rng.integers(0, n, 1500)
+    cd = np.where(rng.random(1500) < 0.4, inv[cs], rng.integers(0, n, 1500))
+    kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=0.9, confidence=1.0, seed=4)
+    res = {}
+    for lds in (0, 1):
+        for srt in (0, 1):
+            old = capi.set_config(reg_lds_staging=lds, reg_sorted_lists=srt)
+            try:
+                res[(lds, srt)] = capi.registration_ransac(d["src"], d["dst"], cs, cd, **kw)
+            finally:
+                capi.restore_config(old)
+    T, st = res[(0, 1)]
+    assert st["lds_wave_hypotheses"] == 0 and res[(1, 1)][1]["lds_wave_hypotheses"] > 10 * res[(1, 1)][1]["global_wave_hypotheses"]
+    for key, (T2, st2) in res.items():
+        assert np.array_equal(T, T2), key
+        for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse", "ties", "exact_rmse_evals"):
+            assert st[k] == st2[k], (key, k)
+    o = orc.registration_ransac(d["src"], d["dst"], cs, cd, thr=0.03, max_iter=3000, edge_thr=0.9, confidence=1.0, seed=4)
+    assert np.array_equal(T, o.T) and st["best_index"] == o.best_index and st["validations"] == o.validations
 
 
 def test_registration_session_sharded_equals_single_call(capi):
