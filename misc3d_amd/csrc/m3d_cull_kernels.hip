@@ -118,19 +118,28 @@ __device__ __forceinline__ bool box_culled(const double* __restrict__ rec, const
     }
 }
 
-// One wave = 64 hypotheses (one per lane, record in VGPRs) x a range of tiles (boxes are wave-uniform:
-// scalar loads).  masks[tile * n_groups + group] = ballot of the hypotheses that may have inliers in
-// the tile; ub[h] += number of such tiles.
+// One wave = 64 hypotheses (one per lane, record in VGPRs) x a range of tiles (boxes are wave-uniform: scalar loads);
+// a workgroup = 8 such waves = 8 consecutive hypothesis groups over the SAME tiles.  masks[tile * n_groups + group] =
+// ballot of the hypotheses that may have inliers in the tile; ub[h] += number of such tiles.
+// The words are staged through LDS and written 64 tiles x 8 groups at a time, eight consecutive threads per tile: one
+// 64-byte run per tile instead of one 8-byte store per (tile, group).  (Measured at 10 000 hypotheses x 1954 tiles:
+// 22.5 us against 24 us with the scattered stores, and flat from 8 k to 32 k waves -- for ~7 us of fp64 arithmetic;
+// neither the stores nor the wave count is what it waits for.  Left at that: 5 % of a C2 fit.)
+constexpr int kCullGroups = 8;
 template <int KIND>
-__global__ __launch_bounds__(64) void cull_mask_k(const double* __restrict__ boxes, uint32_t n_tiles,
+__global__ __launch_bounds__(64 * kCullGroups) void cull_mask_k(const double* __restrict__ boxes, uint32_t n_tiles,
                                                    uint32_t tiles_per_block, const double* __restrict__ score,
                                                    const uint8_t* __restrict__ valid, uint32_t h_count,
                                                    uint32_t n_groups, unsigned long long* __restrict__ masks,
-                                                   uint32_t* __restrict__ ub, double max_abs, uint32_t group_begin) {
-    const int lane = threadIdx.x;
-    const uint32_t group = group_begin + blockIdx.x;
+                                                   uint32_t* __restrict__ ub, double max_abs, uint32_t group_begin,
+                                                   uint32_t group_end) {
+    __shared__ unsigned long long stage[64][kCullGroups];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t gbase = group_begin + blockIdx.x * kCullGroups;
+    const uint32_t group = gbase + wave;
+    const bool group_ok = group < group_end;   // wave-uniform
     const uint32_t h = group * 64u + lane;
-    const bool live = h < h_count && valid[h];
+    const bool live = group_ok && h < h_count && valid[h];
     double rec[kModelStride];
     for (int k = 0; k < kModelStride; ++k) rec[k] = live ? score[(size_t)h * kModelStride + k] : 0.0;
     if (KIND == 0) {
@@ -142,16 +151,26 @@ __global__ __launch_bounds__(64) void cull_mask_k(const double* __restrict__ box
     }
     const uint32_t t0 = blockIdx.y * tiles_per_block;
     const uint32_t t1 = min(n_tiles, t0 + tiles_per_block);
+    const uint32_t n_g = min((uint32_t)kCullGroups, group_end - gbase);   // groups of this workgroup that exist
     uint32_t touched = 0;
-    for (uint32_t t = t0; t < t1; ++t) {
-        const double* __restrict__ bp = boxes + (size_t)t * kBoxStride;
-        double box[6];
+    for (uint32_t tb = t0; tb < t1; tb += 64u) {   // block-uniform
+        const uint32_t te = min(t1, tb + 64u);
+        for (uint32_t t = tb; t < te; ++t) {
+            const double* __restrict__ bp = boxes + (size_t)t * kBoxStride;
+            double box[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) box[k] = bp[k];
-        const bool keep = live && !box_culled<KIND>(rec, box);
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) masks[(size_t)t * n_groups + group] = m;
-        touched += keep ? 1u : 0u;
+            for (int k = 0; k < 6; ++k) box[k] = bp[k];
+            const bool keep = live && !box_culled<KIND>(rec, box);
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) stage[t - tb][wave] = m;
+            touched += keep ? 1u : 0u;
+        }
+        __syncthreads();
+        {   // thread i -> (tile tb + i / 8, group gbase + i % 8): consecutive threads write consecutive words
+            const uint32_t tl = threadIdx.x / kCullGroups, gl = threadIdx.x % kCullGroups;
+            if (tb + tl < te && gl < n_g) masks[(size_t)(tb + tl) * n_groups + gbase + gl] = stage[tl][gl];
+        }
+        __syncthreads();
     }
     if (ub && touched) atomicAdd(&ub[h], touched);
 }
@@ -164,16 +183,17 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
     const uint32_t window = group_end - group_begin;
     if (ub && !ub_is_zero) (void)hipMemsetAsync(ub + (size_t)group_begin * 64, 0, sizeof(uint32_t) * (size_t)window * 64, st);
     // enough waves to fill the chip: split the tile range when there are few hypothesis groups
-    uint32_t splits = std::max<uint32_t>(1, (8192 + window - 1) / window);
+    const uint32_t gblocks = (window + kCullGroups - 1) / kCullGroups;
+    uint32_t splits = std::max<uint32_t>(1, (2048 + gblocks - 1) / gblocks);
     splits = std::min(splits, std::max<uint32_t>(1, s.n_tiles / 16));  // >= 16 tiles per wave: the record loads amortise
     const uint32_t tpb = (s.n_tiles + splits - 1) / splits;
-    const dim3 g(window, (s.n_tiles + tpb - 1) / tpb), b(64);
+    const dim3 g(gblocks, (s.n_tiles + tpb - 1) / tpb), b(64 * kCullGroups);
     if (kind == 0)
-        cull_mask_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin);
+        cull_mask_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin, group_end);
     else if (kind == 1)
-        cull_mask_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin);
+        cull_mask_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin, group_end);
     else
-        cull_mask_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin);
+        cull_mask_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin, group_end);
 }
 
 // keep[g] = hypotheses of group g that are still worth scoring: ub[h] * 512 >= best_count[0]
@@ -260,6 +280,46 @@ void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint
 // ------------------------------------------------------------------------------------------------
 // counting over the surviving (tile, hypothesis) pairs
 // ------------------------------------------------------------------------------------------------
+// Inner loop of score_mask_k: inlier count of ONE hypothesis record over the wave's 512 points (wave-uniform result)
+template <int KIND, int P>
+__device__ __forceinline__ uint32_t tile_count(const double (&rec)[kModelStride], const double (&x)[P], const double (&y)[P],
+                                               const double (&z)[P]) {
+    uint32_t cnt = 0;
+    if (KIND == 0) {
+        const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const double num = plane_num(a, b, c, d, x[j], y[j], z[j]);
+            cnt += (uint32_t)__popcll(__ballot(num < T));
+        }
+    } else if (KIND == 1) {
+        const double cx = rec[0], cy = rec[1], cz = rec[2], lo = rec[3], hi = rec[4];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const double sv = sphere_s(cx, cy, cz, x[j], y[j], z[j]);
+            cnt += (uint32_t)__popcll(__ballot(sv >= lo) & __ballot(sv <= hi));
+        }
+    } else {
+        const double cx = rec[0], cy = rec[1], cz = rec[2], rx = rec[3], ry = rec[4], rz = rec[5];
+        const double lo = rec[6], hi = rec[7];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const double tv = line_t(cx, cy, cz, rx, ry, rz, x[j], y[j], z[j]);
+            cnt += (uint32_t)__popcll(__ballot(tv >= lo) & __ballot(tv <= hi));
+        }
+    }
+    return cnt;
+}
+
+// One wave per (tile, <= groups_per_block hypothesis groups).  The surviving hypotheses of the wave's mask words are
+// first COMPACTED into a list of 16-bit ids in LDS (one pass over the words: rank = running total + v_mbcnt, a
+// ds_write per set bit); the loop then takes them 64 at a time -- lane k of `ids` holds the k-th id of the batch, one
+// v_readlane per hypothesis -- with the record of the next hypothesis in flight (scalar loads, two register sets
+// used alternately: no register-to-register copies), counts parked in lane k and flushed with one vector atomic per
+// batch.  Per hypothesis the scalar unit now does the 16 popcount / add instructions of the 8 rows plus ~8 of address
+// arithmetic and loop control -- the bit walk (s_ff1 / s_and / s_add chains, ~10 more), the m0 save / restore of the
+// v_writelane parking and the five 64-bit moves of the record hand-over are gone: 45 -> ~27 scalar instructions against
+// 58 fp64 VALU instructions (the scalar unit issues one instruction per SIMD slot, like the VALU: it was the co-bottleneck).
 template <int KIND>
 __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx, const double* __restrict__ sy,
                                                     const double* __restrict__ sz,
@@ -271,13 +331,14 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
                                                     uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                     uint32_t* __restrict__ pair_rep,
                                                     uint32_t group_begin, uint32_t group_end /* window of this launch */) {
+    __shared__ uint16_t ids[64 * 64];   // groups_per_block <= 64
     const uint32_t tile = blockIdx.x;
     // ~430 tiles add to every hypothesis' counter: kCountReplicas copies of the counter array (tile mod R)
     // keep the same-address atomic chains short (they serialise in L2 and dominated small chunks)
     uint32_t* __restrict__ counts = counts_rep + (size_t)(tile % kCountReplicas) * rep_stride;
     const uint32_t g0 = group_begin + blockIdx.y * groups_per_block;
     const int lane = threadIdx.x;
-    // lane l holds the (pruned) mask of group g0 + l; walking the bits is scalar work (readlane)
+    // lane l holds the (pruned) mask of group g0 + l
     unsigned long long mm = 0;
     if ((uint32_t)lane < groups_per_block && g0 + lane < group_end)
         mm = masks[(size_t)tile * n_groups + g0 + lane] & keep[g0 + lane];
@@ -291,91 +352,45 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
         y[j] = sy[base + 64 * j];
         z[j] = sz[base + 64 * j];
     }
-    {   // statistics: (tile, hypothesis) pairs this wave evaluates (m3d_stats.pairs_scored)
-        uint32_t pc = (uint32_t)__popcll(mm);
-        for (int off = 32; off > 0; off >>= 1) pc += (uint32_t)__shfl_xor((int)pc, off, 64);
-        if (lane == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairReplicas], pc);
-    }
+    // ---- compaction of the set bits into ids[0 .. total): id = 64 * word + bit (relative to g0)
     const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < groups_per_block; ++w) {   // wave-uniform
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(mm_lo, (int)w), hi = (uint32_t)__builtin_amdgcn_readlane(mm_hi, (int)w);
+        if ((lo | hi) == 0u) continue;
+        const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));   // set bits below this lane
+        if ((word >> lane) & 1ull) ids[total + below] = (uint16_t)(w * 64u + (uint32_t)lane);
+        total += (uint32_t)__popcll(word);
+    }
+    __syncthreads();   // (one wave: orders the LDS writes before the reads below)
+    if (lane == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairReplicas], total);   // m3d_stats.pairs_scored
     constexpr int kUsed = KIND == 2 ? 8 : 5;
-    constexpr uint32_t kEnd = 0xFFFFFFFFu;
-    uint32_t gi = 0;
-    unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mm_hi, 0) << 32) |
-                           (uint32_t)__builtin_amdgcn_readlane(mm_lo, 0);
-    auto next = [&]() -> uint32_t {  // wave-uniform iterator over the set bits
-        while (m == 0) {
-            if (++gi >= groups_per_block) return kEnd;
-            m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mm_hi, (int)gi) << 32) |
-                (uint32_t)__builtin_amdgcn_readlane(mm_lo, (int)gi);
-        }
-        const uint32_t bit = (uint32_t)__ffsll((long long)m) - 1u;
-        m &= m - 1ull;
-        return (g0 + gi) * 64u + bit;
+    const double* __restrict__ score0 = score + (size_t)g0 * 64u * kModelStride;
+    auto load_rec = [&](double (&r)[kModelStride], uint32_t id) {   // id wave-uniform -> scalar loads
+        const double* __restrict__ rp = score0 + (size_t)id * kModelStride;
+#pragma unroll
+        for (int k = 0; k < kUsed; ++k) r[k] = rp[k];
     };
-    uint32_t park_cnt = 0, park_h = 0, slot = 0;
-    uint32_t h = next();
-    double rec[kModelStride];
-    {
-        const double* __restrict__ rp = score + (size_t)h * kModelStride;
-#pragma unroll
-        for (int k = 0; k < kUsed; ++k) rec[k] = rp[k];
-    }
-    {
-        while (h != kEnd) {
-            // software pipeline: the record of the next set bit is in flight while this one is evaluated
-            const uint32_t h_nxt = next();
-            const double* __restrict__ np = score + (size_t)(h_nxt == kEnd ? h : h_nxt) * kModelStride;
-            double nrec[kModelStride];
-#pragma unroll
-            for (int k = 0; k < kUsed; ++k) nrec[k] = np[k];
-            uint32_t cnt = 0;
-            if (KIND == 0) {
-                const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4];
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const double num = plane_num(a, b, c, d, x[j], y[j], z[j]);
-                    cnt += (uint32_t)__popcll(__ballot(num < T));
-                }
-            } else if (KIND == 1) {
-                const double cx = rec[0], cy = rec[1], cz = rec[2], lo = rec[3], hi = rec[4];
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const double sv = sphere_s(cx, cy, cz, x[j], y[j], z[j]);
-                    cnt += (uint32_t)__popcll(__ballot(sv >= lo) & __ballot(sv <= hi));
-                }
-            } else {
-                const double cx = rec[0], cy = rec[1], cz = rec[2], rx = rec[3], ry = rec[4], rz = rec[5];
-                const double lo = rec[6], hi = rec[7];
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const double tv = line_t(cx, cy, cz, rx, ry, rz, x[j], y[j], z[j]);
-                    cnt += (uint32_t)__popcll(__ballot(tv >= lo) & __ballot(tv <= hi));
-                }
+    for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
+        const uint32_t nb = min(64u, total - b0);
+        const int my = (b0 + (uint32_t)lane < total) ? (int)ids[b0 + lane] : 0;   // lane k: k-th id of the batch
+        uint32_t park = 0;
+        double ra[kModelStride], rb[kModelStride];
+        load_rec(ra, (uint32_t)__builtin_amdgcn_readlane(my, 0));
+        for (uint32_t k = 0; k < nb; k += 2u) {
+            // two hypotheses per trip, their records in alternating register sets; the next one is always in flight
+            load_rec(rb, (uint32_t)__builtin_amdgcn_readlane(my, (int)min(k + 1u, nb - 1u)));
+            const uint32_t ca = tile_count<KIND, P>(ra, x, y, z);
+            park = ((uint32_t)lane == k) ? ca : park;
+            load_rec(ra, (uint32_t)__builtin_amdgcn_readlane(my, (int)min(k + 2u, nb - 1u)));
+            if (k + 1u < nb) {   // wave-uniform
+                const uint32_t cb = tile_count<KIND, P>(rb, x, y, z);
+                park = ((uint32_t)lane == k + 1u) ? cb : park;
             }
-            // cnt, h and slot are wave-uniform: v_writelane drops them into lane `slot` (no compare + select)
-            {
-                const uint32_t cnt_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
-                const uint32_t h_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-                const uint32_t slot_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-                // (gfx9: one SGPR operand per VALU instruction, so the lane select travels in m0)
-                // m0 is saved and restored: the compiler keeps it for itself
-                uint32_t m0_save;
-                asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\t"
-                             "v_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
-                             : "+v"(park_cnt), "+v"(park_h), "=&s"(m0_save)
-                             : "s"(cnt_s), "s"(h_s), "s"(slot_s));
-            }
-            if (++slot == 64u) {  // wave-uniform: flush the parked counts
-                if (park_cnt) atomicAdd(&counts[park_h], park_cnt);
-                park_cnt = 0;
-                slot = 0;
-            }
-            h = h_nxt;
-#pragma unroll
-            for (int k = 0; k < kUsed; ++k) rec[k] = nrec[k];
         }
+        if ((uint32_t)lane < nb && park) atomicAdd(&counts[g0 * 64u + (uint32_t)my], park);
     }
-    if ((uint32_t)lane < slot && park_cnt) atomicAdd(&counts[park_h], park_cnt);
 }
 
 // records[h] = sum over the replicas for h in [h_begin, h_end), written to `counts` (device-visible host memory, may be

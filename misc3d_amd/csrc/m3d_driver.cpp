@@ -990,7 +990,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
-                if (s.lead_groups && hipEventElapsedTime(&kms, s.k2, s.k3) == hipSuccess) {
+                if (s.scored && s.lead_groups && hipEventElapsedTime(&kms, s.k2, s.k3) == hipSuccess) {
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
