@@ -59,7 +59,7 @@ typedef struct m3d_stats {
     double ms_score;             /* device: minimal fit + scoring + reduce (HIP events) */
     double ms_refine;            /* device+host: inlier compaction, GeneralFit, copy-out */
     double ms_total;             /* wall clock of the call */
-    double ms_score_kernel;      /* device: sum of the scoring-kernel launches alone (HIP events around each) */
+    double ms_score_kernel;      /* device: sum of the scoring-kernel launches alone (HIP events around each; m3d_config.kernel_timing) */
     uint32_t score_launches;     /* number of scoring-kernel launches (chunks) behind ms_score_kernel */
     uint32_t early_pick_redone;  /* 1: RefineModel had been started on the device's own pick of the winner (probability-1
                                   * fits) and the sequential replay chose another hypothesis (rmse tie): it was run again */
@@ -369,8 +369,8 @@ typedef struct m3d_config {
     int32_t match_brute;            /* [M3D_MATCH_BRUTE=1]  1: fp64 brute-force matcher (no screen) */
     int32_t match_fp32_screen;      /* [M3D_MATCH_SCREEN=fp32] 1: fp32 VALU screen instead of the split-fp16 MFMA screen */
     int32_t pool_limit_mb;          /* [M3D_POOL_MB]        default 4096: released device blocks parked per device for re-use (0 = none) */
-    int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=0] default 1: HIP events around every scoring launch (m3d_stats.ms_score_kernel);
-                                       0 drops those four event commands per chunk from the stream */
+    int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=1] default 0; 1: HIP events around every scoring launch fill m3d_stats.ms_score_kernel /
+                                       score_launches (bench.py switches it on: four event commands per chunk, ~11 us per C2 fit) */
     int32_t reg_lds_staging;        /* [M3D_REG_LDS=0]      default 0: registration validation with the target neighbourhood of a row of source points staged in LDS (bit-identical, not faster: DESIGN.md) */
     int32_t reg_sorted_lists;       /* [M3D_REG_SORTED=0]   default 1: x-sorted neighbour lists, side columns cut off by the x-distance */
 } m3d_config;

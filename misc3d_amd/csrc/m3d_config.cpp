@@ -45,7 +45,7 @@ void load_env() {
     g_cfg.match_brute = env_is("M3D_MATCH_BRUTE", '1');
     g_cfg.match_fp32_screen = env_is("M3D_MATCH_SCREEN", 'f');
     g_cfg.pool_limit_mb = (int32_t)env_long("M3D_POOL_MB", 4096);
-    g_cfg.kernel_timing = !env_is("M3D_KERNEL_TIMING", '0');
+    g_cfg.kernel_timing = env_is("M3D_KERNEL_TIMING", '1');
     g_cfg.reg_lds_staging = env_is("M3D_REG_LDS", '1');
     g_cfg.reg_sorted_lists = !env_is("M3D_REG_SORTED", '0');
     sanitize(g_cfg);

@@ -51,9 +51,16 @@ def _check_fit_invariants(capi, c, kind, g, H, n, thr, seed):
 def test_c3_cylinder_full_size(capi):
     n, H, thr, seed = 1_000_000, 50_000, 0.01, 13
     pts, nrm = synth.cylinder_cloud_c3(n, 3)
+    old = capi.set_config(kernel_timing=1)          # m3d_stats.score_launches / ms_score_kernel are filled on request
+    try:
+        with capi.Cloud(pts, nrm) as c:
+            g = c.fit(2, thr, H, 1.0, seed=seed)
+    finally:
+        capi.restore_config(old)
+    assert g.stats["score_launches"] >= 4 and g.stats["ms_score_kernel"] > 0            # > 3 chunks of <= 16384 (+ lead pass)
     with capi.Cloud(pts, nrm) as c:
         g = c.fit(2, thr, H, 1.0, seed=seed)
-        assert g.stats["hypotheses_scored"] == H and g.stats["score_launches"] >= 4      # > 3 chunks of <= 16384 (+ lead pass)
+        assert g.stats["hypotheses_scored"] == H and g.stats["score_launches"] == 0
         assert 0.40 * n < len(g.inliers) < 0.52 * n
         axis = np.array([1.0, 2.0, 3.0]) / np.linalg.norm([1.0, 2.0, 3.0])
         p0 = np.array([0.1, 0.2, 0.3])

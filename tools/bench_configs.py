@@ -19,6 +19,24 @@ from misc3d_amd import capi, synth  # noqa: E402
 
 which = set(sys.argv[1:]) or {"C1", "C2", "C3", "C4", "C5"}
 
+HBM_PEAK_GBS = 8000.0
+FP64_VALU_PEAK_TOPS = 39.3      # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz, non-FMA ops (bench.py)
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA (MI355X_MICROARCH.md)
+VALU_OPS_PER_PAIR = {0: 7, 1: 10, 2: 22}
+capi.set_config(kernel_timing=1)  # the fit rooflines need m3d_stats.ms_score_kernel (HIP events around the scoring launches)
+
+
+def fit_roofline(kind, st):
+    """fp64-VALU-issue roofline of the scoring launches of ONE fit, from the library's own counters: (tile, hypothesis)
+    pairs evaluated x 512 points x fp64 VALU instructions per pair / time of the score_mask_k launches (HIP events).
+    Recomputable from profiles/r02_configs_kernel_stats.csv (same launches, AverageNs x Calls of score_mask_k<kind>)."""
+    if not st["ms_score_kernel"]:
+        return None
+    tops = st["pairs_scored"] * 512.0 * VALU_OPS_PER_PAIR[kind] / (st["ms_score_kernel"] * 1e-3) / 1e12
+    return {"bound": "fp64-valu", "kernel": f"m3d::score_mask_k<{kind}>", "achieved": tops, "peak": FP64_VALU_PEAK_TOPS,
+            "unit": "T lane-ops/s (fp64 VALU issue)", "frac": tops / FP64_VALU_PEAK_TOPS, "ops_per_pair": VALU_OPS_PER_PAIR[kind],
+            "launches": st["score_launches"], "kernel_ms_total": st["ms_score_kernel"], "tile_hypothesis_pairs": st["pairs_scored"]}
+
 
 def emit(name, **kw):
     print(json.dumps({"config": name, **kw}), flush=True)
@@ -48,7 +66,8 @@ if "C2" in which:
     with capi.Cloud(pts) as c:
         dt, g = timed_fit(c, 0, 0.01, 10_000, 1.0, 11)
     emit("C2 fit_plane 1M x 10k hyp", ms=dt * 1e3, hyp_per_s=10_000 / dt, n_inliers=g.stats["n_inliers"],
-         best_index=g.stats["best_index"], stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine")})
+         best_index=g.stats["best_index"], stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine")},
+         roofline=fit_roofline(0, g.stats))
 
 if "C3" in which:
     cp, cn = synth.cylinder_cloud_c3(1_000_000, 3)
@@ -56,13 +75,15 @@ if "C3" in which:
         dt, g = timed_fit(c, 2, 0.01, 50_000, 1.0, 13, reps=2)
     emit("C3 fit_cylinder 1M x 50k hyp", ms=dt * 1e3, hyp_per_s=50_000 / dt, n_inliers=g.stats["n_inliers"],
          best_index=g.stats["best_index"], params=g.params.tolist(),
-         stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "exact_rmse_evals")})
+         stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "exact_rmse_evals")},
+         roofline=fit_roofline(2, g.stats))
     sp = synth.sphere_cloud_c3(1_000_000, 4)
     with capi.Cloud(sp) as c:
         dt, g = timed_fit(c, 1, 0.01, 50_000, 1.0, 13, reps=2)
     emit("C3 fit_sphere 1M x 50k hyp", ms=dt * 1e3, hyp_per_s=50_000 / dt, n_inliers=g.stats["n_inliers"],
          best_index=g.stats["best_index"], params=g.params.tolist(),
-         stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "exact_rmse_evals")})
+         stats={k: g.stats[k] for k in ("ms_sample", "ms_score", "ms_refine", "exact_rmse_evals")},
+         roofline=fit_roofline(1, g.stats))
 
 if "C4" in which:
     n = int(os.environ.get("M3D_C4_POINTS", "200000"))
@@ -76,15 +97,30 @@ if "C4" in which:
     inv = np.empty(n, dtype=np.int64)
     inv[d["perm"]] = np.arange(n)
     true_frac = float(np.mean(inv[i0.astype(np.int64)] == i1.astype(np.int64)))
+    # the screen is one K = 112 fp16 contraction per (query, row) pair and direction: 2 x n x n x 112 x 2 flop.  Priced with
+    # the WHOLE call's wall clock (106 MB of descriptors over PCIe, packing, the fp64 verification): a lower bound of the
+    # kernel's own fraction, which profiles/r02_c4_kernel_stats.csv gives (nn16_scan_k TotalDurationNs / 3 calls)
+    mm_flop = 2.0 * n * n * 112 * 2
     emit("C4 match_correspondence", n=n, dim=33, ms_first=t_match * 1e3, ms=t_match2 * 1e3, matches=len(i0),
-         true_fraction=true_frac, pair_dist_per_s=2.0 * n * n / t_match2)
+         true_fraction=true_frac, pair_dist_per_s=2.0 * n * n / t_match2,
+         roofline={"bound": "mfma", "kernel": "m3d::nn16_scan_k", "achieved": mm_flop / t_match2 / 1e12,
+                   "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA, whole call's wall clock)",
+                   "frac": mm_flop / t_match2 / 1e12 / MFMA_F16_PEAK_TFLOPS, "flop": mm_flop})
     t0 = time.perf_counter()
     T, st = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=100_000,
                                      edge_length_threshold=0.9, confidence=1.0, seed=17)
     dt = time.perf_counter() - t0
+    # every validation = one exact nearest-neighbour query per source point.  SURVEY.md 8(d)'s unit is 24 B per (hypothesis,
+    # point); the kernel is bound by fp64 VALU issue + L2 gathers of the per-cell candidate lists, not by HBM (DESIGN.md
+    # section 4; VALU busy fraction and FETCH_SIZE of reg_validate_k: profiles/r02_pmc_reg_validate.txt)
+    queries = float(st["validations"]) * n
     emit("C4 compute_transformation_ransac 200k<->200k x 100k hyp", ms=dt * 1e3, hyp_per_s=100_000 / dt,
          validations=st["validations"], fitness=st["fitness"], best_index=st["best_index"],
-         pose_err=float(np.abs(T - d["T"]).max()))
+         pose_err=float(np.abs(T - d["T"]).max()),
+         roofline={"bound": "hbm (algorithmic unit of SURVEY 8(d)); the binding limits are fp64 VALU issue and L2 gather latency",
+                   "kernel": "m3d::reg_validate_k", "achieved": queries * 24.0 / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": queries * 24.0 / dt / 1e9 / HBM_PEAK_GBS, "queries": queries, "queries_per_s": queries / dt,
+                   "note": "whole call's wall clock (setup, grid, 173 MB of neighbour lists, replay included)"})
     ts = []
     for _ in range(3):
         t0 = time.perf_counter()
@@ -140,5 +176,18 @@ if "C5" in which:
     t0 = time.perf_counter()
     rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19)
     dt2 = time.perf_counter() - t0
+    # HBM-bound by construction (a round = a few hundred hypotheses on what is left of the cloud, then compaction + removal
+    # passes over it): algorithmic bytes = per round 24 B x remaining points x 4 (RefineModel's counting and writing pass,
+    # the removal's read of both copies) + 24 B x kept points x 2 (both copies written) + the 240 MB upload and transpose
+    rem, alg = n, 24.0 * n * 3
+    for cidx in clusters:
+        alg += 24.0 * rem * 4 + 24.0 * (rem - len(cidx)) * 2
+        rem -= len(cidx)
     emit("C5 segment_plane_iterative 10M pts (1 GPU, incl. 240 MB upload)", ms_first=dt * 1e3, ms=dt2 * 1e3, rc=rc,
-         clusters=[len(c) for c in clusters], planes=[[round(float(v), 4) for v in p] for p in planes])
+         clusters=[len(c) for c in clusters][:12] + ["... %d more" % max(0, len(clusters) - 12)], planes=len(planes),
+         roofline={"bound": "hbm", "kernel": "compact_count_k / compact_write_k / cull_mask_k over the remaining cloud, per round",
+                   "achieved": alg / dt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dt2 / 1e9 / HBM_PEAK_GBS,
+                   "algorithmic_bytes": alg, "rounds": len(clusters),
+                   "note": "whole call (PCIe upload of 240 MB and 76 MB of index lists back included); with ~170 rounds of "
+                           "5-10 launches each on a shrinking cloud the call is launch- and host-round-trip-bound after the "
+                           "first six rounds"})

@@ -13,7 +13,7 @@ import numpy as np
 from misc3d_amd import capi, synth
 d = synth.registration_pair_c4(200000, seed=5)
 i0, i1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
-capi.set_config(reg_lds_staging=int(os.environ["M3D_LDS"]))
+capi.set_config(reg_lds_staging=int(os.environ.get("M3D_LDS", "0")))
 T, st = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=20000, edge_length_threshold=0.9, confidence=1.0, seed=17)
 print(st)
 PY

@@ -42,8 +42,12 @@ def main():
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, f"{TAG}_bench_under_rocprof.json"))
     for src_rel, dst_name in (("../prof_c4/c4_kernel_stats.csv", f"{TAG}_c4_kernel_stats.csv"),
+                              ("../prof_cfg/cfg_kernel_stats.csv", f"{TAG}_configs_kernel_stats.csv"),
                               ("../bench_configs.jsonl", f"{TAG}_bench_configs.jsonl"),
-                              ("../bench_latest.json", f"{TAG}_bench.json")):
+                              ("../bench_latest.json", f"{TAG}_bench.json"),
+                              ("../bench_sharded_world1.json", f"{TAG}_bench_sharded_world1.json"),
+                              ("../pmc_reg_validate.txt", f"{TAG}_pmc_reg_validate.txt"),
+                              ("../step_timeline.txt", f"{TAG}_c2_step_timeline.txt")):
         q = os.path.join(SRC, src_rel)
         if os.path.exists(q):
             shutil.copy(q, os.path.join(DST, dst_name))
