@@ -528,6 +528,19 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             const int rc = comm->allgather_u32_device(rec_dev, sl_pad, ctx->stream, s.h_counts.as<uint32_t>(), &host_has_all);
             if (rc != M3D_OK) return rc;
             s.host_has_records = host_has_all != 0;
+            if (!host_has_all && caller_ships_records) {
+                // the gathered window (world x slice records: hundreds of KB at 8 ranks) goes to the host through the copy
+                // engine, on the copy stream, while pick_best_k and the early compaction run on the main stream; s.done
+                // then sits on the copy stream.  (pick_best_k's one workgroup would need 40 us for 80 000 records.)
+                HIPCHK(hipEventRecord(ctx->ev_compact, ctx->stream));
+                HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
+                HIPCHK(hipMemcpyAsync(s.h_counts.p, rec_dev, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost,
+                                      ctx->copy_stream));
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(s.done, ctx->copy_stream));
+                s.host_has_records = true;
+                return M3D_OK;
+            }
             if (!host_has_all && !caller_ships_records) {
                 HIPCHK(hipMemcpyAsync(s.h_counts.p, rec_dev, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost,
                                       ctx->stream));
@@ -729,10 +742,9 @@ static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, c
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
                    ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
                    fused ? ctx->moment_partial.as<double>() : nullptr, fused ? ctx->h_moments.as<double>() : nullptr,
-                   idx_host);
+                   idx_host, static_cast<uint32_t*>(total_host) /* pinned: the scan kernel writes the total there itself */);
     ctx->compaction_fused = fused;
     ctx->compaction_idx_host = idx_host;
-    HIPCHK(hipMemcpyAsync(total_host, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     return M3D_OK;
 }
 
@@ -983,8 +995,8 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                             b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec);
         if (r == M3D_OK && spec) {
             ChunkSlot& sl = ctx->slot[slot_id];
-            // (sharded: the records are the gathered ones; the other ranks' counts raise this rank's incumbent too, and
-            // the kernel passes the records on to the pinned host array the replay reads -- no copy command)
+            // (sharded: the records are the gathered ones; the other ranks' counts raise this rank's incumbent too.  Should the
+            // records not be on their way to the host yet, the kernel passes them on to the pinned array the replay reads.)
             const bool ship = comm && !sl.host_has_records;
             launch_pick_best(sl.counts.as<uint32_t>(), (uint32_t)(e - b), (unsigned long long)b, sl.params.as<double>(),
                              b == 0, ctx->pick.as<BestPick>(), ctx->h_pick.as<BestPickHost>(), ctx->stream,

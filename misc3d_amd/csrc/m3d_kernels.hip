@@ -451,7 +451,8 @@ __global__ __launch_bounds__(256) void compact_count_k(CloudView c, const double
 __global__ __launch_bounds__(1024) void scan_blocks_k(uint32_t* __restrict__ v, uint32_t nb,
                                                        uint32_t* __restrict__ total,
                                                        const double* __restrict__ moment_partial,
-                                                       double* __restrict__ moment_out) {
+                                                       double* __restrict__ moment_out,
+                                                       uint32_t* __restrict__ total_host /* device-visible copy of total[0], or null */) {
     __shared__ uint32_t buf[1024];
     __shared__ uint32_t carry;
     __shared__ double msum[12 * 64];
@@ -492,12 +493,13 @@ __global__ __launch_bounds__(1024) void scan_blocks_k(uint32_t* __restrict__ v, 
     }
     if (threadIdx.x == 0) {
         total[0] = carry;
+        if (total_host) total_host[0] = carry;
         if (moment_out) moment_out[12] = (double)carry;
     }
 }
 
 void launch_scan_blocks(uint32_t* v, uint32_t nb, uint32_t* total, hipStream_t s) {
-    scan_blocks_k<<<1, 1024, 0, s>>>(v, nb, total, nullptr, nullptr);
+    scan_blocks_k<<<1, 1024, 0, s>>>(v, nb, total, nullptr, nullptr, nullptr);
 }
 
 template <int KIND, int MODE>
@@ -568,10 +570,11 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
                                 double* ox, double* oy, double* oz, uint32_t* oorig,
                                 uint32_t n_pad_out, uint32_t* block_counts, uint32_t* total,
                                 hipStream_t s, double* model_copy, double* moment_partial, double* moment_out,
-                                uint64_t* out_idx_host) {
+                                uint64_t* out_idx_host, uint32_t* total_host) {
     const uint32_t nb = (c.n + kCompactTile - 1) / kCompactTile;
     if (nb == 0) {
         (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+        if (total_host) (void)hipMemcpyAsync(total_host, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (model_copy) (void)hipMemcpyAsync(model_copy, model, sizeof(double) * kModelStride, hipMemcpyDeviceToHost, s);
         if (moment_out) (void)hipMemsetAsync(moment_out, 0, sizeof(double) * 13, s);
         return;
@@ -581,7 +584,7 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
         compact_count_k<KIND == 2 ? 0 : KIND, true><<<nb, 256, 0, s>>>(c, model, thr, 0, block_counts, model_copy, moment_partial);
     else
         compact_count_k<KIND, false><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts, model_copy, nullptr);
-    scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total, sums ? moment_partial : nullptr, sums ? moment_out : nullptr);
+    scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total, sums ? moment_partial : nullptr, sums ? moment_out : nullptr, total_host);
     if (mode == 0)
         compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
                                                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, out_idx_host);
@@ -600,16 +603,16 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
                     uint32_t* block_counts, uint32_t* total, hipStream_t s, double* model_copy,
-                    double* moment_partial, double* moment_out, uint64_t* out_idx_host) {
+                    double* moment_partial, double* moment_out, uint64_t* out_idx_host, uint32_t* total_host) {
     if (kind == 0)
         launch_compact_kind<0>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host);
+                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host);
     else if (kind == 1)
         launch_compact_kind<1>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host);
+                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host);
     else
         launch_compact_kind<2>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host);
+                               n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host, total_host);
 }
 
 // EvaluateModel's `error += distance` in point order (ransac.h:637): a genuinely serial fp64 chain.

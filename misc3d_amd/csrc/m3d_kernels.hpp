@@ -71,7 +71,8 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
                     double* moment_partial = nullptr /* mode 0, plane / sphere: scratch of ceil(n / kCompactTile) x 16 doubles ... */,
                     double* moment_out = nullptr /* ... and kFusedMomentDoubles doubles (device-visible host memory): GeneralFit's raw
                                                     moments over the inliers about the model record's provisional centre */,
-                    uint64_t* out_idx_host = nullptr /* mode 0: page-locked host copy of the index list, written by the kernel */);
+                    uint64_t* out_idx_host = nullptr /* mode 0: page-locked host copy of the index list, written by the kernel */,
+                    uint32_t* total_host = nullptr /* device-visible host word that receives total[0] as well (no copy command) */);
 // moment_out layout: [0..2] sum s, [3..8] sum s s^T (xx,xy,xz,yy,yz,zz), [9..11] sum s |s|^2 (sphere), [12] inlier count;
 // s = p - c0, c0 = model[4..6] (plane: the hypothesis' first sample point) or model[0..2] (sphere: the minimal centre).
 constexpr int kFusedMomentDoubles = 16;
