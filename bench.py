@@ -183,6 +183,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 flow on a box with ONE GPU (tests/test_gpu_bench_multirank.py): every rank on device 0 and the
+    # records over the process group through m3d_comm's host transport -- RCCL refuses two ranks on one device.  The
+    # JSON line says so (config.parallelism); never a number to quote.
+    rehearsal = os.environ.get("M3D_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local)
@@ -190,7 +196,8 @@ def main():
     comm = None
     if world > 1:
         dist.init_process_group("gloo")                 # control plane only
-        comm = capi.Comm.rccl(device=local)             # data path: library-owned RCCL communicator
+        # data path: library-owned RCCL communicator (rehearsal: the caller-supplied all-gather over gloo)
+        comm = capi.Comm.torch_host() if rehearsal else capi.Comm.rccl(device=local)
     elif os.environ.get("M3D_BENCH_FORCE_SHARDED") == "1":   # the N > 1 driver on one GPU (world-1 communicator)
         comm = capi.Comm.rccl(world=1, rank=0, device=local)
     n_gpus = world
@@ -350,7 +357,8 @@ def main():
                "data": "synthetic",
                "config": {"workload": label, "points": N, "hypotheses_per_gpu": H_total / world,
                           "hypotheses_total": H_total, "threshold": thr, "probability": prob, "sampler_seed": seed,
-                          "parallelism": (f"hypothesis-sharded x{world}, C++ driver + RCCL all-gather" if world > 1 else
+                          "parallelism": (f"hypothesis-sharded x{world}, C++ driver + " + ("gloo all-gather, ALL RANKS ON ONE GPU (rehearsal)"
+                                                                                       if rehearsal else "RCCL all-gather") if world > 1 else
                                           ("single GPU through the sharded driver (world-1 RCCL communicator)" if comm
                                            else "single GPU")),
                           "setup_fits_before_warmup": PRIMING_FITS},

@@ -1,0 +1,29 @@
+"""`python bench.py --gpus 2` end to end on a one-GPU box: bench.py starts its own ranks (torch.distributed.run), the
+control plane comes up, every rank runs the sharded C++ driver, the strong-scaling block runs, rank 0 prints ONE JSON
+line.  M3D_BENCH_REHEARSAL=1 puts every rank on device 0 with the records over gloo (RCCL refuses two ranks on one
+device); everything else is the code path the 8-GPU run takes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_prints_one_json_line():
+    env = dict(os.environ, M3D_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--points", "200000"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["hypotheses_total"] == 20000
+    assert "rehearsal" in d["config"]["parallelism"] and d["collectives_per_step"] >= 1
+    assert d["value"] > 0 and 0 < d["roofline"]["frac"] <= 1
+    st = d["strong_scaling"]
+    assert set(st) == {"c2", "c3cyl", "c3sph"} and all(v["identical_to_1gpu"] for v in st.values())
