@@ -162,9 +162,12 @@ if "N4" in which or len(sys.argv) == 1:
     uv = rng.uniform(0, 3.0, (nb, 2))
     pp = np.c_[uv[:, 0], uv[:, 1], 0.2 * uv[:, 0] + rng.normal(0, 1e-3, nb)]
     capi.detect_boundary_points(pp[:1000], None, 2, 0.02, 30, 90.0)
-    t0 = time.perf_counter()
-    bidx = capi.detect_boundary_points(pp, None, 2, 0.02, 30, 90.0)
-    emit("N4 detect_boundary_points 500k pts Hybrid(0.02, 30), normals estimated", ms=(time.perf_counter() - t0) * 1e3,
+    ts = []
+    for _ in range(3):      # one-call entry point: median of three (the first full-size call also sizes the block free list)
+        t0 = time.perf_counter()
+        bidx = capi.detect_boundary_points(pp, None, 2, 0.02, 30, 90.0)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    emit("N4 detect_boundary_points 500k pts Hybrid(0.02, 30), normals estimated", ms=sorted(ts)[1], ms_first=ts[0],
          boundary_points=len(bidx))
 
 if "C5" in which:
