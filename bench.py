@@ -333,6 +333,15 @@ def main():
                                 "CPU).  Exceeds the HBM peak BY CONSTRUCTION: each point load is re-used from VGPRs by "
                                 "all hypotheses of the launch, box-culled (tile, hypothesis) pairs and pruned hypotheses "
                                 "are never evaluated.  Reported for SURVEY.md 8(d); it is not a roofline fraction."}}
+        try:
+            # what the chip SUSTAINS on independent fp64 mul / add chains (it clocks below 2.4 GHz under that load):
+            # the attainable counterpart of `peak`, measured here, right after the timed steps
+            att, att_ms = capi.fp64_issue_rate(local, 3.0)
+            roofline["attainable"] = {"peak_measured": att, "unit": roofline["unit"], "frac_of_measured_peak": v_tops / att,
+                                      "probe": f"m3d_bench_fp64_issue_rate: 2048 workgroups x 256 threads of independent v_mul_f64 / "
+                                               f"v_add_f64 chains for {att_ms:.2f} ms; `frac` above stays quoted on the nominal peak"}
+        except Exception as e:      # noqa: BLE001 -- a probe, never fatal
+            roofline["attainable"] = {"error": str(e)}
         if a.kernel_detail:
             Hk = min(H, 16384)
             samples = capi.draw_samples(N, kind, Hk, seed)

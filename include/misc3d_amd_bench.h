@@ -23,6 +23,11 @@ int m3d_bench_time_score(m3d_cloud *cloud, int kind, double threshold, const uin
  * listed_pairs (may be NULL): number of surviving (tile, hypothesis) pairs, tile = 512 points. */
 
 
+/* fp64 VALU issue rate the device sustains (independent v_mul_f64 / v_add_f64 chains, no FMA, no memory traffic) over
+ * about `ms_target` milliseconds of that load, in 1e12 lane-operations per second: the attainable counterpart of the
+ * nominal 39.3 (256 CU x 4 SIMD x 16 lanes x 2.4 GHz) -- the chip clocks below 2.4 GHz under sustained fp64 load. */
+int m3d_bench_fp64_issue_rate(int device, double ms_target, double *tera_lane_ops_per_s, double *ms_measured);
+
 #ifdef __cplusplus
 }
 #endif

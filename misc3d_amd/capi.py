@@ -185,6 +185,7 @@ def lib():
                                                       C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double,
                                                       C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                       C.c_void_p]
+        L.m3d_bench_fp64_issue_rate.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.m3d_get_config.restype = None
         L.m3d_get_config.argtypes = [C.c_void_p]
         L.m3d_set_config.argtypes = [C.c_void_p]
@@ -200,6 +201,13 @@ class Config(C.Structure):
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
                                          "morton_order", "reg_neighbour_lists", "reg_source_rows", "reg_prune",
                                          "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing", "reg_lds_staging", "reg_sorted_lists")]
+
+
+def fp64_issue_rate(device=0, ms_target=2.0):
+    """m3d_bench_fp64_issue_rate (include/misc3d_amd_bench.h) -> (1e12 fp64 lane-ops/s the device sustains, ms measured)"""
+    t, ms = C.c_double(0), C.c_double(0)
+    _check(lib().m3d_bench_fp64_issue_rate(device, ms_target, C.cast(C.byref(t), C.c_void_p), C.cast(C.byref(ms), C.c_void_p)))
+    return float(t.value), float(ms.value)
 
 
 def get_config() -> Config:

@@ -1934,6 +1934,39 @@ int m3d_bench_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     return M3D_OK;
 }
 
+int m3d_bench_fp64_issue_rate(int device, double ms_target, double* tops, double* ms_measured) {
+    if (!tops) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    DeviceCtx* ctx = get_ctx(device);
+    if (!ctx) return M3D_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    RESERVE(ctx->small, 256);
+    const int blocks = 256 * 8;   // 8 workgroups of 4 waves per CU: every SIMD holds 8 waves
+    // one wave issues 16 * iters instructions of 4 cycles; a SIMD interleaves its 8 waves
+    auto run = [&](int iters, float* ms) -> int {
+        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+        launch_fp64_issue_probe(ctx->small.as<double>(), blocks, iters, ctx->stream);
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+        return M3D_OK;
+    };
+    float ms = 0;
+    int rc = run(256, &ms);   // warm-up + calibration
+    if (rc != M3D_OK) return rc;
+    rc = run(2048, &ms);
+    if (rc != M3D_OK) return rc;
+    const double per_iter = (double)ms / 2048.0;
+    const int iters = (int)std::min(4.0e6, std::max(1024.0, (ms_target > 0 ? ms_target : 2.0) / std::max(per_iter, 1e-9)));
+    rc = run(iters, &ms);
+    if (rc != M3D_OK) return rc;
+    const double ops = (double)blocks * 256.0 * 16.0 * (double)iters;
+    *tops = ops / ((double)ms * 1e-3) / 1e12;
+    if (ms_measured) *ms_measured = ms;
+    return M3D_OK;
+}
+
 int m3d_cloud_exact_error(m3d_cloud* c, int kind, double threshold, const double* model,
                           uint64_t* count, double* error) {
     if (!c || kind < 0 || kind > 2 || !model || !count || !error)

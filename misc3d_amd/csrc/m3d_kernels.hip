@@ -828,3 +828,32 @@ void launch_error_sum(int kind, const CloudView& c, const double* model, double 
 }
 
 }  // namespace m3d
+
+// ------------------------------------------------------------------------------------------------
+// measurement probe (include/misc3d_amd_bench.h): what the chip sustains on the instruction mix the scoring kernels
+// are bound by -- independent v_mul_f64 / v_add_f64 chains, no FMA, no memory -- at the clock it settles to under
+// that load.  bench.py quotes the scoring kernel against the nominal 2.4 GHz peak (roofline.frac) and, beside it,
+// against this measured rate.
+// ------------------------------------------------------------------------------------------------
+namespace m3d {
+__global__ __launch_bounds__(256) void fp64_issue_probe_k(double* __restrict__ out, int iters, double seed) {
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = seed + (double)(threadIdx.x + k);
+    const double m = 1.0000000001, c = 1e-9;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] = a[k] * m;   // v_mul_f64
+            a[k] = a[k] + c;   // v_add_f64 (separately rounded: -ffp-contract=off)
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += a[k];
+    if (s == 12345.678) out[0] = s;   // keeps the chains alive, never true in practice
+}
+void launch_fp64_issue_probe(double* out, int blocks, int iters, hipStream_t st) {
+    fp64_issue_probe_k<<<blocks, 256, 0, st>>>(out, iters, 1.0);
+}
+}  // namespace m3d

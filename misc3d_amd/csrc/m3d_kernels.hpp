@@ -105,6 +105,9 @@ void launch_error_sum(int kind, const CloudView& c, const double* model, double 
 // exclusive scan of v[0..nb) in place by one workgroup; total[0] = sum
 void launch_scan_blocks(uint32_t* v, uint32_t nb, uint32_t* total, hipStream_t s);
 
+// fp64 VALU issue probe: blocks x 256 threads, each 16 * iters independent fp64 mul / add instructions
+void launch_fp64_issue_probe(double* out, int blocks, int iters, hipStream_t s);
+
 // iota for the original-index array of a segmentation run
 void launch_iota(uint32_t* v, uint32_t n, hipStream_t s);
 
