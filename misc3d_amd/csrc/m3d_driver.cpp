@@ -445,10 +445,10 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     const double t0 = now_ms();
     src.fill(begin, end, s.h_samples.as<uint32_t>());
     if (ms_sample) *ms_sample += now_ms() - t0;
-    HIPCHK(hipMemcpyAsync(s.samples.p, s.h_samples.p, sizeof(uint32_t) * (size_t)count * m,
-                          hipMemcpyHostToDevice, ctx->stream));
+    // the sample table is read by minimal_fit_k straight from the slot's page-locked host array (device-visible): 12 bytes
+    // per hypothesis over the host link inside the kernel instead of a copy command in front of it
     if (!dense && prune) RESERVE(ctx->ub, sizeof(uint32_t) * (size_t)h_pad);
-    launch_minimal_fit(kind, v, s.samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
+    launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
                        (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
                        new_fit ? ctx->best_count.as<uint32_t>() : nullptr);
