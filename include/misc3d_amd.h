@@ -56,7 +56,7 @@ typedef struct m3d_stats {
     uint64_t hypotheses_scored;  /* hypotheses the GPU scored (>= iterations: speculative chunks) */
     uint64_t exact_rmse_evals;   /* serial-order error sums needed (ties that order-free sums could not decide) */
     double ms_sample;            /* host: std::mt19937 sample table */
-    double ms_score;             /* device: minimal fit + scoring + reduce (HIP events) */
+    double ms_score;             /* device: minimal fit + scoring + reduce (HIP events; filled with m3d_config.kernel_timing) */
     double ms_refine;            /* device+host: inlier compaction, GeneralFit, copy-out */
     double ms_total;             /* wall clock of the call */
     double ms_score_kernel;      /* device: sum of the scoring-kernel launches alone (HIP events around each; m3d_config.kernel_timing) */

@@ -411,8 +411,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                        bool prune = false, uint32_t lead = 0, bool new_fit = false /* clears the running best count */,
                        bool device_records = false /* culled path: keep a device copy of the records in s.counts */,
                        m3d_comm* comm = nullptr,
-                       bool caller_ships_records = false /* sharded: pick_best_k, queued by the caller, writes the gathered
-                                                            records to s.h_counts; the caller records s.done behind it */) {
+                       bool caller_ships_records = false /* the caller queues pick_best_k behind the chunk and records s.done
+                                                            behind THAT (an event between two kernels costs a ~5 us
+                                                            gap on this stream; behind pick_best_k nothing follows at once) */) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const bool dense = use_dense_scoring();
@@ -448,16 +449,30 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     // the sample table is read by minimal_fit_k straight from the slot's page-locked host array (device-visible): 12 bytes
     // per hypothesis over the host link inside the kernel instead of a copy command in front of it
     if (!dense && prune) RESERVE(ctx->ub, sizeof(uint32_t) * (size_t)h_pad);
+    // (decided here because minimal_fit_k prepares the lead pass of a NEW fit itself: see LeadPrep)
+    const bool use_lead = !dense && prune && lead >= 64 && lead % 64 == 0 && lead + 64 <= count && (!comm || sl_pad >= lead + 64);
+    const bool own_real_ = !comm || (size_t)rank * sl_pad < count;
+    LeadPrep lp;
+    const bool lead_prepared = use_lead && new_fit && own_real_ && lead <= h_pad && (uint32_t)kPairReplicas <= h_pad;
+    if (lead_prepared) {
+        lp.counts_rep = ctx->counts_rep.as<uint32_t>();
+        lp.keep = ctx->keep.as<unsigned long long>();
+        lp.rep_stride = h_pad;
+        lp.n_rep = kCountReplicas;
+        lp.n_lead = lead;
+        lp.n_pair = kPairReplicas;
+    }
     launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
                        (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
-                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr);
+                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr, lead_prepared ? &lp : nullptr);
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     // (culled path: keep_mask_k clears the counter replicas on its way)
     s.lead_groups = 0;
     s.scored = false;
     s.host_has_records = true;
+    s.done_on_copy_stream = false;
     uint32_t* h_pairs = s.h_counts.as<uint32_t>() + h_pad;   // pinned, device-visible
     if (dense) {
         HIPCHK(hipEventRecord(s.k0, ctx->stream));
@@ -483,7 +498,6 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         // lead > 0 (a fit's first chunk): the first `lead` hypotheses are counted on their own, and their best
         // count then prunes the rest of the SAME chunk -- what a separate small first chunk did, without its
         // own sample copy, MinimalFit and box-test launches.  The records are complete after the second pass.
-        const bool use_lead = prune && lead >= 64 && lead % 64 == 0 && lead + 64 <= count && (!comm || sl_pad >= lead + 64);
         const uint32_t ga = use_lead ? lead / 64 : 0u;
         if (own_real) {
             if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
@@ -495,7 +509,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             if (ga) {
                 s.lead_groups = ga;
                 g_lo = std::max(g0, ga);
-                launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
+                if (!lead_prepared)   // (a new fit: minimal_fit_k has done it)
+                    launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
                 if (timing) HIPCHK(hipEventRecord(s.k2, ctx->stream));
                 launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
                                   h_pad, pair_rep, ctx->stream, 0, ga);
@@ -539,6 +554,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(s.done, ctx->copy_stream));
                 s.host_has_records = true;
+                s.done_on_copy_stream = true;
                 return M3D_OK;
             }
             if (!host_has_all && !caller_ships_records) {
@@ -554,7 +570,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                               ctx->stream));
     if (dense) HIPCHK(hipMemcpyAsync(s.h_valid.p, s.valid.p, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s.done, ctx->stream));
+    if (!caller_ships_records) HIPCHK(hipEventRecord(s.done, ctx->stream));
     return M3D_OK;
 }
 
@@ -959,7 +975,8 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     chunk = std::min(std::min(chunk, chunk_cap), std::max<size_t>((max_iter + 63) / 64 * 64, 64));
     RESERVE(ctx->best_count, 16);   // cleared by the first chunk's minimal_fit_k
 
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    const bool timing_events = config().kernel_timing != 0;   // (m3d_stats.ms_score / ms_score_kernel)
+    if (timing_events) HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rc = M3D_OK;
     int cur = 0;
     size_t next_begin = 0;
@@ -1001,10 +1018,8 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             launch_pick_best(sl.counts.as<uint32_t>(), (uint32_t)(e - b), (unsigned long long)b, sl.params.as<double>(),
                              b == 0, ctx->pick.as<BestPick>(), ctx->h_pick.as<BestPickHost>(), ctx->stream,
                              ship ? sl.h_counts.as<uint32_t>() : nullptr, comm ? ctx->best_count.as<uint32_t>() : nullptr);
-            if (ship) {
-                HIPCHK(hipEventRecord(sl.done, ctx->stream));
-                sl.host_has_records = true;
-            }
+            if (ship) sl.host_has_records = true;
+            if (!sl.done_on_copy_stream) HIPCHK(hipEventRecord(sl.done, ctx->stream));
             if (e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
                 r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
                                             ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true,
@@ -1150,7 +1165,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         best_dev = ctx->best_params.as<double>();
     }
     ctx->last_best_dev = best_dev;
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (timing_events) HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     // The best minimal model travels to the host (pinned ctx->h_best) with RefineModel: its first kernel stores the
     // record there and RefineModel's own wait delivers it (no wait and no copy command here).
     // ms_score is read from ev0..ev1 by the caller after that wait.
@@ -1228,7 +1243,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     }
     {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ro.ms_score = ms;
+        if (config().kernel_timing != 0 && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ro.ms_score = ms;
     }
     if (ro.st.best_index >= 0 && ni != ro.st.best_count)
         return fail(M3D_ERR_INTERNAL, "refine pass and scoring kernel disagree on the inlier count");

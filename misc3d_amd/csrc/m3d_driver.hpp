@@ -56,6 +56,7 @@ struct ChunkSlot {
     hipEvent_t k2 = nullptr, k3 = nullptr;  // around the scoring launch of the chunk's leading hypotheses (lead_groups > 0)
     uint32_t lead_groups = 0;
     bool host_has_records = true;   // sharded: the gathered records are (being) written to h_counts
+    bool done_on_copy_stream = false;   // sharded RCCL windows: `done` follows the record copy on the copy stream
     bool scored = false;   // a scoring launch was issued for the chunk (k0 / k1 recorded)
     size_t begin = 0, end = 0;
     uint32_t h_pad = 0;

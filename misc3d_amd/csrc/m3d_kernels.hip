@@ -129,11 +129,20 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
                                                      double* __restrict__ score,
                                                      double* __restrict__ params,
                                                      uint8_t* __restrict__ valid, uint32_t* __restrict__ zero_u32,
-                                                     uint32_t* __restrict__ zero_one) {
+                                                     uint32_t* __restrict__ zero_one, LeadPrep lead) {
     const uint32_t h = blockIdx.x * 64u + threadIdx.x;
     if (h >= h_pad) return;
     if (zero_u32 && h + 1 < h_pad) zero_u32[h] = 0;   // per-hypothesis counter cleared on the way (saves a memset launch)
     if (zero_one && h == 0) zero_one[0] = 0;          // a fit's first chunk: the running best count
+    if (lead.counts_rep) {
+        // a fit's first chunk: what keep_mask_k would do for the leading hypotheses (nothing to prune against yet: keep
+        // everything; clear their counter replicas and the launch's pair counters) -- one launch less in front of the lead pass
+        if (h < lead.n_lead) {
+            for (uint32_t r = 0; r < lead.n_rep; ++r) lead.counts_rep[(size_t)r * lead.rep_stride + h] = 0u;
+            if ((h & 63u) == 0u) lead.keep[h >> 6] = ~0ull;
+        }
+        if (h < lead.n_pair) lead.counts_rep[(size_t)lead.n_rep * lead.rep_stride + h] = 0u;
+    }
     const double nan = u2f(0x7FF8000000000000ull);
     double rec[kModelStride];
     double par[kModelStride];
@@ -220,15 +229,17 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
 
 void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
-                        hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one) {
+                        hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one, const LeadPrep* lead) {
     if (h_pad == 0) return;
     const dim3 g((h_pad + 63) / 64), b(64);
+    LeadPrep lp;
+    if (lead) lp = *lead;
     if (kind == 0)
-        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one);
+        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp);
     else if (kind == 1)
-        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one);
+        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp);
     else
-        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one);
+        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -36,11 +36,19 @@ void launch_aos_to_soa(const double* aos, double* x, double* y, double* z, uint3
 //   params[h*8 ..] = reference model parameters (4 or 7 doubles)
 //   valid[h]       = MinimalFit's return value
 // Records in [h_count, h_pad) are filled with "no inlier" cut-offs.
+// Optional extra of launch_minimal_fit on a fit's first chunk: the set-up keep_mask_k would do for the leading hypotheses
+// (keep words all ones, their counter replicas and the launch's n_pair pair counters behind them cleared).
+struct LeadPrep {
+    uint32_t* counts_rep = nullptr;   // n_rep x rep_stride counters, then n_pair pair counters
+    unsigned long long* keep = nullptr;
+    uint32_t rep_stride = 0, n_rep = 0, n_lead = 0, n_pair = 0;
+};
 void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
                         hipStream_t s,
                         uint32_t* zero_u32 = nullptr /* h_pad - 1 counters cleared by the same launch */,
-                        uint32_t* zero_one = nullptr /* one more word cleared by the same launch */);
+                        uint32_t* zero_one = nullptr /* one more word cleared by the same launch */,
+                        const LeadPrep* lead = nullptr);
 
 // K2: inlier counting.  partial[tile * h_pad + h] = number of points of scoring tile `tile` whose
 // distance to hypothesis h is < thr.  h_pad must be a multiple of 64; the hypotheses are cut into
