@@ -78,30 +78,31 @@ void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
 __device__ __forceinline__ bool box_culled(const double* __restrict__ rec, const double* __restrict__ box) {
+    // branch-free: every sub-condition is evaluated and OR-ed (the record conditions are wave-uniform, the empty-box
+    // condition per lane; early returns cost the loop of cull_tiles_k more in exec-mask bookkeeping than they save)
     const double cx = box[0], cy = box[1], cz = box[2], hx = box[3], hy = box[4], hz = box[5];
-    if (hx < 0.0) return true;  // empty tile
+    const bool empty = hx < 0.0;  // empty tile
     if (KIND == 0) {
         // inlier <=> |fl(a x + b y + c z + d)| < T.  Over the box, a x + b y + c z + d ranges over
         // [s - r, s + r]; the rounded per-point value differs from the exact one by < 8 u * mag.
         const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4], cut = rec[5];
-        if (!(T > 0.0)) return true;  // `num < T` can never hold
         const double s = ((a * cx + b * cy) + c * cz) + d;
         const double r = (fabs(a) * hx + fabs(b) * hy) + fabs(c) * hz;
-        return fabs(s) - r > cut;     // cut = T + margin (cull_mask_k); inf or NaN keeps the tile
+        // !(T > 0): `num < T` can never hold.  cut = T + margin (minimal_fit_k); inf or NaN keeps the tile
+        return empty | !(T > 0.0) | (fabs(s) - r > cut);
     } else if (KIND == 1) {
         // inlier <=> lo <= |q - c|^2 <= hi
         const double lo = rec[3], hi = rec[4];
-        if (!(lo <= hi)) return true;  // NaN cut-offs = "no inlier" record
         const double dx = fabs(rec[0] - cx), dy = fabs(rec[1] - cy), dz = fabs(rec[2] - cz);
         const double nx = fmax(0.0, dx - hx), ny = fmax(0.0, dy - hy), nz = fmax(0.0, dz - hz);
         const double fx = dx + hx, fy = dy + hy, fz = dz + hz;
         const double dmin2 = (nx * nx + ny * ny) + nz * nz;
         const double dmax2 = (fx * fx + fy * fy) + fz * fz;
-        return dmax2 * (1.0 + 1e-12) < lo || dmin2 * (1.0 - 1e-12) > hi;
+        // !(lo <= hi): NaN cut-offs = "no inlier" record
+        return empty | !(lo <= hi) | (dmax2 * (1.0 + 1e-12) < lo) | (dmin2 * (1.0 - 1e-12) > hi);
     } else {
         // inlier <=> t_lo <= |(q - c) x (q - ref)|^2 <= t_hi, and |(q - c) x (q - ref)| = dist(q, axis) * |ref - c|
         const double t_lo = rec[6], t_hi = rec[7];
-        if (!(t_lo <= t_hi)) return true;
         const double ax = cx - rec[0], ay = cy - rec[1], az = cz - rec[2];
         const double bx = cx - rec[3], by = cy - rec[4], bz = cz - rec[5];
         const double ux = rec[3] - rec[0], uy = rec[4] - rec[1], uz = rec[5] - rec[2];
@@ -114,86 +115,86 @@ __device__ __forceinline__ bool box_culled(const double* __restrict__ rec, const
         const double tmax = dmax * dmax * L2, tmin = dmin * dmin * L2;
         const double D = (sqrt((ax * ax + ay * ay) + az * az) + sqrt(L2)) + R;  // >= |q - c|, |q - ref|
         const double marg = 1e-12 * ((D * D) * (D * D)) + 1e-12 * tmax;
-        return tmax + marg < t_lo || tmin - marg > t_hi;  // NaN anywhere -> false -> kept
+        // NaN anywhere in the last two -> false -> kept
+        return empty | !(t_lo <= t_hi) | (tmax + marg < t_lo) | (tmin - marg > t_hi);
     }
 }
 
-// One wave = 64 hypotheses (one per lane, record in VGPRs) x a range of tiles (boxes are wave-uniform: scalar loads);
-// a workgroup = 8 such waves = 8 consecutive hypothesis groups over the SAME tiles.  masks[tile * n_groups + group] =
-// ballot of the hypotheses that may have inliers in the tile; ub[h] += number of such tiles.
-// The words are staged through LDS and written 64 tiles x 8 groups at a time, eight consecutive threads per tile: one
-// 64-byte run per tile instead of one 8-byte store per (tile, group).  (Measured at 10 000 hypotheses x 1954 tiles:
-// 22.5 us against 24 us with the scattered stores, and flat from 8 k to 32 k waves -- for ~7 us of fp64 arithmetic;
-// neither the stores nor the wave count is what it waits for.  Left at that: 5 % of a C2 fit.)
-constexpr int kCullGroups = 8;
+// One wave = 64 TILES (one per lane, its box in VGPRs, loaded once, coalesced) x a few groups of 64 hypotheses whose
+// records stream through SGPRs (scalar loads, the next record in flight) -- the decomposition of the scoring kernel.
+// masks[tile * n_groups + group] = hypotheses of the group that may have inliers in the tile: lane `tile` ORs bit h
+// into its own word as hypothesis h goes by (no transposition step); ub[h] += number of such tiles (the ballot's
+// popcount, parked in lane h, one vector atomic per group).  Invalid and padding hypotheses carry "no inlier"
+// records (minimal_fit_k), which every test below rejects, so `valid` is not read.
+// Round 1's layout was the transpose (lane = hypothesis, boxes through scalar loads, one ballot + one 8-byte store per
+// (tile, group)): 24 us for ~7 us of arithmetic at 10 000 hypotheses x 1954 tiles, whatever the launch geometry.
 template <int KIND>
-__global__ __launch_bounds__(64 * kCullGroups) void cull_mask_k(const double* __restrict__ boxes, uint32_t n_tiles,
-                                                   uint32_t tiles_per_block, const double* __restrict__ score,
-                                                   const uint8_t* __restrict__ valid, uint32_t h_count,
-                                                   uint32_t n_groups, unsigned long long* __restrict__ masks,
-                                                   uint32_t* __restrict__ ub, double max_abs, uint32_t group_begin,
-                                                   uint32_t group_end) {
-    __shared__ unsigned long long stage[64][kCullGroups];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t gbase = group_begin + blockIdx.x * kCullGroups;
-    const uint32_t group = gbase + wave;
-    const bool group_ok = group < group_end;   // wave-uniform
-    const uint32_t h = group * 64u + lane;
-    const bool live = group_ok && h < h_count && valid[h];
-    double rec[kModelStride];
-    for (int k = 0; k < kModelStride; ++k) rec[k] = live ? score[(size_t)h * kModelStride + k] : 0.0;
-    if (KIND == 0) {
-        // plane: the rounding margin once per hypothesis instead of once per box.  Every |a x|, |b y|, |c z| of the
-        // cloud is at most |.| * max_abs, so mag <= (|a| + |b| + |c|) max_abs + |d| for every box AND every point;
-        // rec[5] = T + 1e-12 (mag + T) is then the one cut-off the box loop compares against.
-        const double mag = ((fabs(rec[0]) + fabs(rec[1])) + fabs(rec[2])) * max_abs + fabs(rec[3]);
-        rec[5] = rec[4] + 1e-12 * (mag + rec[4]);
-    }
-    const uint32_t t0 = blockIdx.y * tiles_per_block;
-    const uint32_t t1 = min(n_tiles, t0 + tiles_per_block);
-    const uint32_t n_g = min((uint32_t)kCullGroups, group_end - gbase);   // groups of this workgroup that exist
-    uint32_t touched = 0;
-    for (uint32_t tb = t0; tb < t1; tb += 64u) {   // block-uniform
-        const uint32_t te = min(t1, tb + 64u);
-        for (uint32_t t = tb; t < te; ++t) {
-            const double* __restrict__ bp = boxes + (size_t)t * kBoxStride;
-            double box[6];
+__global__ __launch_bounds__(64) void cull_tiles_k(const double* __restrict__ boxes, uint32_t n_tiles,
+                                                    const double* __restrict__ score, uint32_t n_groups,
+                                                    uint32_t groups_per_wave, unsigned long long* __restrict__ masks,
+                                                    uint32_t* __restrict__ ub, uint32_t group_begin, uint32_t group_end) {
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x * 64u + (uint32_t)lane;
+    const bool tile_ok = tile < n_tiles;
+    double box[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) box[k] = bp[k];
-            const bool keep = live && !box_culled<KIND>(rec, box);
+    for (int k = 0; k < 6; ++k) box[k] = tile_ok ? boxes[(size_t)tile * kBoxStride + k] : (k >= 3 ? -1.0 : 0.0);   // (hx < 0: empty)
+    const uint32_t g0 = group_begin + blockIdx.y * groups_per_wave;
+    const uint32_t g1 = min(group_end, g0 + groups_per_wave);
+    constexpr int kUsed = KIND == 0 ? 6 : (KIND == 1 ? 5 : 8);   // record words the box test reads
+    for (uint32_t g = g0; g < g1; ++g) {
+        uint32_t w[2] = {0u, 0u}, ubv = 0u;
+        const double* __restrict__ rp = score + (size_t)g * 64u * kModelStride;
+        auto load_rec = [&](double (&r)[kModelStride], uint32_t hh) {   // hh wave-uniform -> scalar loads
+            const double* __restrict__ q = rp + (size_t)hh * kModelStride;
+#pragma unroll
+            for (int k = 0; k < kUsed; ++k) r[k] = q[k];
+        };
+        auto test = [&](const double (&r)[kModelStride], uint32_t hh, int half, uint32_t b) {
+            const bool keep = !box_culled<KIND>(r, box);
             const unsigned long long m = __ballot(keep);
-            if (lane == 0) stage[t - tb][wave] = m;
-            touched += keep ? 1u : 0u;
+            w[half] |= keep ? (1u << b) : 0u;
+            ubv = ((uint32_t)lane == hh) ? (uint32_t)__popcll(m) : ubv;
+        };
+        // two hypotheses per trip, their records in alternating register sets (no register-to-register copies: the
+        // scalar unit, not the VALU, was what the first version of this loop kept busy); the next record is always in flight
+        double ra[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0}, rb[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
+        load_rec(ra, 0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            for (uint32_t b = 0; b < 32u; b += 2u) {
+                const uint32_t hh = (uint32_t)half * 32u + b;
+                load_rec(rb, hh + 1u);
+                test(ra, hh, half, b);
+                load_rec(ra, min(hh + 2u, 63u));
+                test(rb, hh + 1u, half, b + 1u);
+            }
         }
-        __syncthreads();
-        {   // thread i -> (tile tb + i / 8, group gbase + i % 8): consecutive threads write consecutive words
-            const uint32_t tl = threadIdx.x / kCullGroups, gl = threadIdx.x % kCullGroups;
-            if (tb + tl < te && gl < n_g) masks[(size_t)(tb + tl) * n_groups + gbase + gl] = stage[tl][gl];
-        }
-        __syncthreads();
+        if (tile_ok) masks[(size_t)tile * n_groups + g] = ((unsigned long long)w[1] << 32) | w[0];
+        if (ub && ubv) atomicAdd(&ub[g * 64u + (uint32_t)lane], ubv);
     }
-    if (ub && touched) atomicAdd(&ub[h], touched);
 }
 
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
                       uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st, bool ub_is_zero,
                       uint32_t group_begin, uint32_t group_end) {
+    (void)valid;     // (invalid and padding hypotheses are "no inlier" records)
+    (void)h_count;
     group_end = std::min(group_end, n_groups);
     if (!s.n_tiles || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
     if (ub && !ub_is_zero) (void)hipMemsetAsync(ub + (size_t)group_begin * 64, 0, sizeof(uint32_t) * (size_t)window * 64, st);
-    // enough waves to fill the chip: split the tile range when there are few hypothesis groups
-    const uint32_t gblocks = (window + kCullGroups - 1) / kCullGroups;
-    uint32_t splits = std::max<uint32_t>(1, (2048 + gblocks - 1) / gblocks);
-    splits = std::min(splits, std::max<uint32_t>(1, s.n_tiles / 16));  // >= 16 tiles per wave: the record loads amortise
-    const uint32_t tpb = (s.n_tiles + splits - 1) / splits;
-    const dim3 g(gblocks, (s.n_tiles + tpb - 1) / tpb), b(64 * kCullGroups);
+    const uint32_t tblocks = (s.n_tiles + 63) / 64;
+    // a few thousand waves at least; beyond that several groups per wave amortise the box loads
+    uint32_t gpw = std::max<uint32_t>(1, (uint32_t)(((uint64_t)tblocks * window) / 8192));
+    gpw = std::min<uint32_t>(gpw, 8);
+    const dim3 g(tblocks, (window + gpw - 1) / gpw), b(64);
     if (kind == 0)
-        cull_mask_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin, group_end);
+        cull_tiles_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, score, n_groups, gpw, masks, ub, group_begin, group_end);
     else if (kind == 1)
-        cull_mask_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin, group_end);
+        cull_tiles_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, score, n_groups, gpw, masks, ub, group_begin, group_end);
     else
-        cull_mask_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, tpb, score, valid, h_count, n_groups, masks, ub, s.max_abs, group_begin, group_end);
+        cull_tiles_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, score, n_groups, gpw, masks, ub, group_begin, group_end);
 }
 
 // keep[g] = hypotheses of group g that are still worth scoring: ub[h] * 512 >= best_count[0]

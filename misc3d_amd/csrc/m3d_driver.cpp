@@ -465,7 +465,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
                        (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
-                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr, lead_prepared ? &lp : nullptr);
+                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr, lead_prepared ? &lp : nullptr, sv.max_abs);
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     // (culled path: keep_mask_k clears the counter replicas on its way)

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
                                                      double* __restrict__ score,
                                                      double* __restrict__ params,
                                                      uint8_t* __restrict__ valid, uint32_t* __restrict__ zero_u32,
-                                                     uint32_t* __restrict__ zero_one, LeadPrep lead) {
+                                                     uint32_t* __restrict__ zero_one, LeadPrep lead, double cull_max_abs) {
     const uint32_t h = blockIdx.x * 64u + threadIdx.x;
     if (h >= h_pad) return;
     if (zero_u32 && h + 1 < h_pad) zero_u32[h] = 0;   // per-hypothesis counter cleared on the way (saves a memset launch)
@@ -172,6 +172,13 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
                 rec[2] = par[2];
                 rec[3] = par[3];
                 rec[4] = plane_cutoff(par, thr);
+                // cut-off of the BOX tests (cull_tiles_k), the rounding margin taken once per hypothesis: every |a x|,
+                // |b y|, |c z| of the cloud is at most |.| * max_abs, so mag <= (|a| + |b| + |c|) max_abs + |d| for every
+                // box AND every point; a box is culled when |s| - r > T + 1e-12 (mag + T)
+                {
+                    const double mag = ((fabs(par[0]) + fabs(par[1])) + fabs(par[2])) * cull_max_abs + fabs(par[3]);
+                    rec[5] = rec[4] + 1e-12 * (mag + rec[4]);
+                }
             }
         } else if (KIND == 1) {
             double p[12];
@@ -229,17 +236,17 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
 
 void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
-                        hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one, const LeadPrep* lead) {
+                        hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one, const LeadPrep* lead, double cull_max_abs) {
     if (h_pad == 0) return;
     const dim3 g((h_pad + 63) / 64), b(64);
     LeadPrep lp;
     if (lead) lp = *lead;
     if (kind == 0)
-        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp);
+        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs);
     else if (kind == 1)
-        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp);
+        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs);
     else
-        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp);
+        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs);
 }
 
 // ------------------------------------------------------------------------------------------------

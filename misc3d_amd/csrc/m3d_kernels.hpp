@@ -48,7 +48,9 @@ void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, u
                         hipStream_t s,
                         uint32_t* zero_u32 = nullptr /* h_pad - 1 counters cleared by the same launch */,
                         uint32_t* zero_one = nullptr /* one more word cleared by the same launch */,
-                        const LeadPrep* lead = nullptr);
+                        const LeadPrep* lead = nullptr,
+                        double cull_max_abs = __builtin_inf() /* SortedView::max_abs: the plane record's slot 5 receives the
+                                                                 cut-off of the box tests (inf: nothing is ever culled) */);
 
 // K2: inlier counting.  partial[tile * h_pad + h] = number of points of scoring tile `tile` whose
 // distance to hypothesis h is < thr.  h_pad must be a multiple of 64; the hypotheses are cut into
