@@ -11,13 +11,16 @@ the (512-point tile, hypothesis) pairs that can hold an inlier are evaluated poi
 upper bound cannot reach an earlier hypothesis' count are pruned (both exact).
 
 JSON objects besides the contract's fields:
-  roofline     the bound that actually binds the dominant kernel score_mask_k<plane>: fp64 VALU issue.
+  roofline     the bound that actually binds the dominant kernel score_screen_k<plane>: VALU issue.
                achieved = (tile, hypothesis) pairs the timed launches evaluated (counted inside the kernel,
-               m3d_stats.pairs_scored) x 512 points x 7 fp64 VALU instructions per (point, hypothesis) / the launches'
+               m3d_stats.pairs_scored) x 512 points x VALU instructions per (point, hypothesis) / the launches'
                duration measured live with HIP events on the library's stream (m3d_stats.ms_score_kernel) -- the
                same launches `rocprofv3 --kernel-trace --stats -- python bench.py` averages (profiles/).
-               peak = 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s (no FMA: the reference's
-               arithmetic rounds every product and sum).  `traffic` = HBM bytes per launch from the PMC pass under
+               Instructions per (point, hypothesis): 4 for the plane's packed-fp32 screen (per pair of points 4 v_pk_fma,
+               2 v_alignbit, 1.5 v_min = 7.5, + v_bcnt and the v_cmp per 8 points; the fp64 loop it replaced: 7), 6 for
+               the sphere's, 22 for the cylinder's fp64 loop.
+               peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T lane-instructions/s: a wave64 VALU instruction
+               (fp64, fp32, packed fp32 or integer alike) occupies its SIMD for 4 cycles.  `traffic` = HBM bytes per launch from the PMC pass under
                profiles/.  `algorithmic_reuse` restates SURVEY.md 8(d)'s 24 B/(hypothesis, point) figure: it is far
                above the HBM peak because a point load is re-used from VGPRs by every hypothesis of a launch and most
                pairs are never touched -- not an HBM-bound kernel, so it is NOT the roofline.
@@ -50,8 +53,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (non-FMA ops; FMA peak 78.6 TF)
 ALG_BYTES_PER_PAIR = 24.0      # one fp64 xyz read per (hypothesis, point), SURVEY.md 8(d)
-VALU_OPS_PER_PAIR = {0: 7, 1: 10, 2: 22}   # fp64 VALU instructions per pair incl. compares (m3d_cull_kernels.hip)
-KERNEL_NAME = {0: "m3d::score_mask_k<0>", 1: "m3d::score_mask_k<1>", 2: "m3d::score_mask_k<2>"}
+VALU_OPS_FP64 = {0: 7, 1: 10, 2: 22}      # fp64 VALU instructions per (point, hypothesis) incl. compares: score_mask_k, score_k
+VALU_OPS_SCREEN = {0: 4, 1: 6, 2: 22}     # score_screen_k: packed-fp32 screen (m3d_cull_kernels.hip); cylinders stay on score_mask_k
+KERNEL_FP64 = {0: "m3d::score_mask_k<0>", 1: "m3d::score_mask_k<1>", 2: "m3d::score_mask_k<2>"}
+KERNEL_SCREEN = {0: "m3d::score_screen_k<0>", 1: "m3d::score_screen_k<1>", 2: "m3d::score_mask_k<2>"}
 WORKLOADS = {   # name -> (kind, default hypotheses, threshold, seed, label)
     "c2": (0, 10_000, 0.01, 11, "C2 fit_plane"),
     "c3cyl": (2, 50_000, 0.01, 13, "C3 fit_cylinder"),
@@ -232,7 +237,7 @@ def main():
     for _ in range(a.warmup):
         res = step()
     barrier()
-    k_ms_sum, k_launches, k_pairs = 0.0, 0, 0
+    k_ms_sum, k_launches, k_pairs, k_exact = 0.0, 0, 0, 0
     # the interpreter's cyclic collector stays out of the timed region (as timeit does): with torch imported a
     # full collection takes tens of milliseconds, ~100 steps' worth
     gc.disable()
@@ -243,6 +248,7 @@ def main():
         k_ms_sum += st["ms_score_kernel"]
         k_launches += st["score_launches"]
         k_pairs += st["pairs_scored"]
+        k_exact += st["pairs_exact"]
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -317,16 +323,22 @@ def main():
         k_ms = k_ms_sum / max(k_launches, 1)
         h_rank = H_total / world                                  # hypotheses this rank scores per step
         h_per_launch = h_rank * a.steps / max(k_launches, 1)
-        v_tops = k_pairs * 512.0 * VALU_OPS_PER_PAIR[kind] / (k_ms_sum * 1e-3) / 1e12
+        screened = bool(capi.get_config().score_fp32_screen) and kind != 2
+        ops = (VALU_OPS_SCREEN if screened else VALU_OPS_FP64)[kind]
+        kname = (KERNEL_SCREEN if screened else KERNEL_FP64)[kind]
+        v_tops = k_pairs * 512.0 * ops / (k_ms_sum * 1e-3) / 1e12
         alg_bytes = h_per_launch * float(N) * ALG_BYTES_PER_PAIR
         alg_rate = alg_bytes / (k_ms * 1e-3) / 1e9
-        roofline = {"bound": "fp64-valu", "kernel": KERNEL_NAME[kind], "achieved": v_tops, "peak": FP64_VALU_PEAK_TOPS,
-                    "unit": "T lane-ops/s (fp64 VALU issue)", "frac": v_tops / FP64_VALU_PEAK_TOPS,
+        roofline = {"bound": "valu-issue", "kernel": kname, "achieved": v_tops, "peak": FP64_VALU_PEAK_TOPS,
+                    "unit": "T lane-instructions/s (VALU issue)", "frac": v_tops / FP64_VALU_PEAK_TOPS,
                     "traffic": traffic, "launch_ms": k_ms, "launches_timed": k_launches,
-                    "hypotheses_per_launch": h_per_launch, "ops_per_pair": VALU_OPS_PER_PAIR[kind],
+                    "hypotheses_per_launch": h_per_launch, "ops_per_pair": ops,
+                    "arithmetic": ("packed fp32 screen with a rounding bound (v_pk_fma_f32), exact fp64 recount of the undecided pairs"
+                                   if screened else "fp64"),
+                    "pairs_recounted_in_fp64_fraction": k_exact / max(k_pairs, 1),
                     "tile_hypothesis_pairs_per_launch": k_pairs / max(k_launches, 1),
                     "pairs_evaluated_fraction": k_pairs / float(n_tiles * h_rank * a.steps),
-                    "timing": "HIP events around every score_mask_k launch of the timed steps (rank 0)",
+                    "timing": "HIP events around every scoring launch of the timed steps (rank 0)",
                     "algorithmic_reuse": {
                         "bytes_per_launch": alg_bytes, "rate_GBps": alg_rate, "x_hbm_peak": alg_rate / HBM_PEAK_GBS,
                         "note": "24 B x hypotheses x points of a launch / launch time (what EvaluateModel streams on the "
@@ -349,8 +361,8 @@ def main():
             u_ms, listed = cloud.time_score(kind, thr, samples, reps=10, mode=0)   # score_mask_k, nothing pruned
             cull_ms, _ = cloud.time_score(kind, thr, samples, reps=10, mode=1)      # cull_mask_k
             dense_ms, _ = cloud.time_score(kind, thr, samples, reps=5, mode=2)      # score_k: the unculled kernel
-            valu_tops = listed * 512.0 * VALU_OPS_PER_PAIR[kind] / (u_ms * 1e-3) / 1e12
-            dense_tops = float(-(-Hk // 64) * 64) * float(-(-N // 2048) * 2048) * VALU_OPS_PER_PAIR[kind] / (
+            valu_tops = listed * 512.0 * ops / (u_ms * 1e-3) / 1e12
+            dense_tops = float(-(-Hk // 64) * 64) * float(-(-N // 2048) * 2048) * VALU_OPS_FP64[kind] / (
                 dense_ms * 1e-3) / 1e12
             roofline["unpruned_launch"] = {"achieved": valu_tops, "peak": FP64_VALU_PEAK_TOPS,
                                            "frac": valu_tops / FP64_VALU_PEAK_TOPS, "launch_ms": u_ms, "hypotheses": Hk,

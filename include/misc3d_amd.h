@@ -64,6 +64,7 @@ typedef struct m3d_stats {
     uint32_t early_pick_redone;  /* 1: RefineModel had been started on the device's own pick of the winner (probability-1
                                   * fits) and the sequential replay chose another hypothesis (rmse tie): it was run again */
     uint64_t pairs_scored;       /* (512-point tile, hypothesis) pairs those launches evaluated after culling and pruning */
+    uint64_t pairs_exact;        /* ... of which the fp32 screen (m3d_config.score_fp32_screen) left to the exact fp64 code */
 } m3d_stats;
 
 /* ---- one-shot fits: python/py_common.cpp:11-67 FitPlane / FitSphere / FitCylinder ------------- */
@@ -373,6 +374,9 @@ typedef struct m3d_config {
                                        score_launches (bench.py switches it on: four event commands per chunk, ~11 us per C2 fit) */
     int32_t reg_lds_staging;        /* [M3D_REG_LDS=0]      default 0: registration validation with the target neighbourhood of a row of source points staged in LDS (bit-identical, not faster: DESIGN.md) */
     int32_t reg_sorted_lists;       /* [M3D_REG_SORTED=0]   default 1: x-sorted neighbour lists, side columns cut off by the x-distance */
+    int32_t score_fp32_screen;      /* [M3D_SCORE_SCREEN=0] default 1: planes and spheres are counted by score_screen_k (packed-fp32 screen with a
+                                       rounding bound in front of the exact fp64 test: identical counts); 0: fp64 only (score_mask_k) */
+    int32_t reserved[7];            /* zero */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

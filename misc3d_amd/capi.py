@@ -47,7 +47,7 @@ class Stats(C.Structure):
                 ("ties", C.c_int32), ("hypotheses_scored", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
                 ("ms_sample", C.c_double), ("ms_score", C.c_double), ("ms_refine", C.c_double),
                 ("ms_total", C.c_double), ("ms_score_kernel", C.c_double), ("score_launches", C.c_uint32),
-                ("early_pick_redone", C.c_uint32), ("pairs_scored", C.c_uint64)]
+                ("early_pick_redone", C.c_uint32), ("pairs_scored", C.c_uint64), ("pairs_exact", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -200,7 +200,8 @@ class Config(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("dense_scoring", "speculative_refine", "lead_hypotheses",
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
                                          "morton_order", "reg_neighbour_lists", "reg_source_rows", "reg_prune",
-                                         "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing", "reg_lds_staging", "reg_sorted_lists")]
+                                         "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing", "reg_lds_staging", "reg_sorted_lists",
+                                         "score_fp32_screen")] + [("reserved", C.c_int32 * 7)]
 
 
 def fp64_issue_rate(device=0, ms_target=2.0):

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
         total += (uint32_t)__popcll(word);
     }
     __syncthreads();   // (one wave: orders the LDS writes before the reads below)
-    if (lane == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairReplicas], total);   // m3d_stats.pairs_scored
+    if (lane == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairMain], total);   // m3d_stats.pairs_scored
     constexpr int kUsed = KIND == 2 ? 8 : 5;
     const double* __restrict__ score0 = score + (size_t)g0 * 64u * kModelStride;
     auto load_rec = [&](double (&r)[kModelStride], uint32_t id) {   // id wave-uniform -> scalar loads
@@ -394,6 +394,200 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// score_screen_k: score_mask_k for planes and spheres with a packed-fp32 SCREEN in front of the fp64 test.
+//
+// The fp64 loop of score_mask_k issues 7 (plane) / 10 (sphere) VALU instructions per point and hypothesis, and the
+// VALU is what bounds it.  Almost every point is nowhere near the cut-off: an fp32 evaluation with a rigorous error
+// bound decides it (m3d_fp.hpp derives the bound), and v_pk_fma_f32 handles two points per lane and instruction.
+//   * The wave keeps its 512 points as fp32 offsets from the tile's box centre (12 register pairs; the subtraction is
+//     done in fp64, so the offsets are as accurate as fp32 gets).
+//   * Per batch of <= 64 surviving hypotheses lane k prepares the record of hypothesis k FOR THIS TILE (fp64: the
+//     model moved to the box centre, the rounding bound from the box's extent) and parks it in LDS; the loop reads it
+//     back as a broadcast (two ds_reads per hypothesis, the next one always in flight; no scalar loads).
+//   * Per pair of points (plane): 3 v_pk_fma for the plane value, 1 v_pk_fma for q = s^2 - T^2, 2 v_alignbit shifting
+//     the sign bits of q (inside <=> q < 0) into a per-lane bit string, 1.5 v_min keeping min |q|: 7.5 instructions
+//     for two points instead of 14, and none of them on the scalar unit (the v_cmp -> s_bcnt1 -> s_add counting of the
+//     fp64 loop costs two scalar instructions per row).
+//   * After the 8 points of a lane: v_bcnt gives the lane's count (0..8), one ds_write_b8 parks it in row k of an
+//     LDS table; `!(min |q| >= h)` over the wave says whether any point was too close to call -- then the tile's
+//     fp64 points are fetched again and the pair is counted by tile_count, the exact code (m3d_stats.pairs_exact).
+//   * Every 64 hypotheses lane k adds up row k (4 ds_read_b128 + 16 v_dot4) and issues the batch's one vector
+//     atomic, as before.
+// A tile with a non-finite coordinate (the NaN padding of the last tile, or the caller's own) is never screened.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kScreenMaxGroups = 16;   // 64-hypothesis groups per workgroup (the id list: 2 KB of LDS)
+constexpr int kCntStride = 64;              // bytes per row of the count table
+
+// bits: 8 sign bits (point inside <=> 1); m: min over the lane's points of the distance to the decision boundary
+template <int KIND, int Q>
+__device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, const f32x2 (&xf)[Q], const f32x2 (&yf)[Q],
+                                            const f32x2 (&zf)[Q], uint32_t& bits, float& m) {
+    uint32_t acc = 0;
+    float mn = __builtin_inff();
+    if (KIND == 0) {   // ra = (a, b, c, mid2), rb = (D, h, -, -)
+        const f32x2 A = {ra.x, ra.x}, B = {ra.y, ra.y}, C = {ra.z, ra.z}, D = {rb.x, rb.x}, M2 = {-ra.w, -ra.w};
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const f32x2 s = __builtin_elementwise_fma(A, xf[j], __builtin_elementwise_fma(B, yf[j], __builtin_elementwise_fma(C, zf[j], D)));
+            const f32x2 q = __builtin_elementwise_fma(s, s, M2);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(q.x), 31);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(q.y), 31);
+            mn = __builtin_fminf(mn, __builtin_fminf(__builtin_fabsf(q.x), __builtin_fabsf(q.y)));
+        }
+    } else {           // ra = (mid, half, -, -), rb = (Cx, Cy, Cz, h)
+        const f32x2 CX = {rb.x, rb.x}, CY = {rb.y, rb.y}, CZ = {rb.z, rb.z}, MID = {-ra.x, -ra.x};
+        const float half = ra.y;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const f32x2 dx = xf[j] - CX, dy = yf[j] - CY, dz = zf[j] - CZ;
+            const f32x2 t = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, MID)));
+            const float va = __builtin_fabsf(t.x) - half, vb = __builtin_fabsf(t.y) - half;
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(va), 31);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(vb), 31);
+            mn = __builtin_fminf(mn, __builtin_fminf(__builtin_fabsf(va), __builtin_fabsf(vb)));
+        }
+    }
+    bits = acc;
+    m = mn;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                      const double* __restrict__ sz,
+                                                      const double* __restrict__ boxes, double max_abs,
+                                                      const double* __restrict__ score,
+                                                      const unsigned long long* __restrict__ masks,
+                                                      const unsigned long long* __restrict__ keep,
+                                                      uint32_t n_groups, uint32_t groups_per_block /* <= kScreenMaxGroups */,
+                                                      uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                      uint32_t* __restrict__ pair_rep,
+                                                      uint32_t group_begin, uint32_t group_end) {
+    __shared__ uint16_t ids[kScreenMaxGroups * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t cnt8[64 * kCntStride];
+    __shared__ float4 loc[64][2];   // the batch's (tile, hypothesis) records
+    const uint32_t tile = blockIdx.x;
+    uint32_t* __restrict__ counts = counts_rep + (size_t)(tile % kCountReplicas) * rep_stride;
+    const uint32_t g0 = group_begin + blockIdx.y * groups_per_block;
+    const int lane = threadIdx.x;
+    unsigned long long mm = 0;
+    if ((uint32_t)lane < groups_per_block && g0 + lane < group_end)
+        mm = masks[(size_t)tile * n_groups + g0 + lane] & keep[g0 + lane];
+    if (!__ballot(mm != 0)) return;
+    const size_t base = (size_t)tile * kTilePoints + lane;
+    constexpr int P = kTilePoints / 64, Q = P / 2;
+    double box[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) box[k] = boxes[(size_t)tile * kBoxStride + k];   // (wave-uniform: scalar loads)
+    // rows 2 j and 2 j + 1 of the tile share a register pair
+    f32x2 xf[Q], yf[Q], zf[Q];
+    float chk = 0.0f;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        xf[j] = {(float)(sx[base + 128 * j] - box[0]), (float)(sx[base + 128 * j + 64] - box[0])};
+        yf[j] = {(float)(sy[base + 128 * j] - box[1]), (float)(sy[base + 128 * j + 64] - box[1])};
+        zf[j] = {(float)(sz[base + 128 * j] - box[2]), (float)(sz[base + 128 * j + 64] - box[2])};
+        chk += ((xf[j].x + xf[j].y) + (yf[j].x + yf[j].y)) + (zf[j].x + zf[j].y);
+    }
+    // inf or NaN anywhere (also an offset beyond the fp32 range) makes chk * 0 a NaN
+    const bool tile_screened = __ballot(!(chk * 0.0f == 0.0f)) == 0ull;
+    // ---- compaction of the set bits into ids[0 .. total): id = 64 * word + bit (relative to g0)
+    const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < groups_per_block; ++w) {   // wave-uniform
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(mm_lo, (int)w), hi = (uint32_t)__builtin_amdgcn_readlane(mm_hi, (int)w);
+        if ((lo | hi) == 0u) continue;
+        const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+        if ((word >> lane) & 1ull) ids[total + below] = (uint16_t)(w * 64u + (uint32_t)lane);
+        total += (uint32_t)__popcll(word);
+    }
+    __syncthreads();
+    if (lane == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairMain], total);
+    const double* __restrict__ score0 = score + (size_t)g0 * 64u * kModelStride;
+    // the exact count of one (tile, hypothesis) pair: the fp64 points come back from memory (L2), four rows at a time
+    auto exact_count = [&](uint32_t id) -> uint32_t {
+        double rec[kModelStride];
+        const double* __restrict__ rp = score0 + (size_t)id * kModelStride;   // id wave-uniform -> scalar loads
+#pragma unroll
+        for (int k = 0; k < kModelStride; ++k) rec[k] = rp[k];
+        uint32_t c = 0;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            double x[P / 2], y[P / 2], z[P / 2];
+#pragma unroll
+            for (int j = 0; j < P / 2; ++j) {
+                x[j] = sx[base + 64 * (half * (P / 2) + j)];
+                y[j] = sy[base + 64 * (half * (P / 2) + j)];
+                z[j] = sz[base + 64 * (half * (P / 2) + j)];
+            }
+            c += tile_count<KIND, P / 2>(rec, x, y, z);
+        }
+        return c;
+    };
+    for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
+        const uint32_t nb = min(64u, total - b0);
+        const int my = (b0 + (uint32_t)lane < total) ? (int)ids[b0 + lane] : 0;   // lane k: k-th id of the batch
+        {   // lane k: the record of hypothesis k at this tile
+            const double* __restrict__ rp = score0 + (size_t)my * kModelStride;
+            double rec[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) rec[k] = rp[k];
+            float sr[8];
+            if (KIND == 0) plane_screen_record(rec, box, max_abs, sr);
+            else sphere_screen_record(rec, box, max_abs, sr);
+            loc[lane][0] = make_float4(sr[0], sr[1], sr[2], sr[3]);
+            loc[lane][1] = make_float4(sr[4], sr[5], sr[6], sr[7]);
+        }
+        __syncthreads();
+        uint32_t park = 0;   // lane k: exact count of hypothesis k when the screen could not decide it
+        auto step = [&](const float4 ra, const float4 rb, uint32_t k) {
+            uint32_t bits = 0;
+            float m = 0.0f;
+            bool exact = !tile_screened;
+            if (tile_screened) {
+                screen_eval<KIND, Q>(ra, rb, xf, yf, zf, bits, m);
+                exact = __ballot(!(m >= (KIND == 0 ? rb.y : rb.w))) != 0ull;   // (h = NaN: the record is not screened)
+            }
+            uint32_t c = (uint32_t)__popc(bits);
+            if (exact) {   // wave-uniform, rare
+                const uint32_t e = exact_count((uint32_t)__builtin_amdgcn_readlane(my, (int)k));
+                if (lane == 0) atomicAdd(&pair_rep[(uint32_t)kPairMain + tile % (uint32_t)(kPairReplicas - kPairMain)], 1u);
+                park = ((uint32_t)lane == k) ? e : park;
+                c = 0;
+            }
+            cnt8[k * kCntStride + (uint32_t)lane] = (uint8_t)c;
+        };
+        float4 a0 = loc[0][0], a1 = loc[0][1], b0r, b1r;
+        for (uint32_t k = 0; k < nb; k += 2u) {
+            // two hypotheses per trip, their records in alternating register sets; the next one is always in flight
+            const uint32_t k1 = min(k + 1u, nb - 1u), k2 = min(k + 2u, nb - 1u);
+            b0r = loc[k1][0];
+            b1r = loc[k1][1];
+            step(a0, a1, k);
+            a0 = loc[k2][0];
+            a1 = loc[k2][1];
+            if (k + 1u < nb) step(b0r, b1r, k + 1u);
+        }
+        __syncthreads();   // (one wave: the table is complete)
+        if ((uint32_t)lane < nb) {
+            const uint4* row = reinterpret_cast<const uint4*>(cnt8 + (uint32_t)lane * kCntStride);
+            uint32_t sum = park;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 v = row[i];
+                sum = __builtin_amdgcn_udot4(v.x, 0x01010101u, sum, false);
+                sum = __builtin_amdgcn_udot4(v.y, 0x01010101u, sum, false);
+                sum = __builtin_amdgcn_udot4(v.z, 0x01010101u, sum, false);
+                sum = __builtin_amdgcn_udot4(v.w, 0x01010101u, sum, false);
+            }
+            if (sum) atomicAdd(&counts[g0 * 64u + (uint32_t)my], sum);
+        }
+        __syncthreads();   // (the next batch overwrites the tables)
+    }
+}
+
 // records[h] = sum over the replicas for h in [h_begin, h_end), written to `counts` (device-visible host memory, may be
 // null) and `counts_dev` (device, may be null); *pairs_out (device-visible, may be null) = evaluated (tile, hypothesis)
 // pairs of the launch.
@@ -408,14 +602,19 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
     if (blockIdx.x == 0 && pair_rep && pairs_out) {   // block-uniform
         __shared__ uint32_t red[256];
         uint32_t p = 0;
-        for (int r = threadIdx.x; r < kPairReplicas; r += 256) p += pair_rep[r];
+        for (int r = threadIdx.x; r < kPairMain; r += 256) p += pair_rep[r];
         red[threadIdx.x] = p;
         __syncthreads();
         for (int w = 128; w > 0; w >>= 1) {
             if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
             __syncthreads();
         }
-        if (threadIdx.x == 0) *pairs_out = red[0];
+        if (threadIdx.x == 0) {
+            uint32_t e = 0;
+            for (int r = kPairMain; r < kPairReplicas; ++r) e += pair_rep[r];
+            pairs_out[0] = red[0];
+            pairs_out[1] = e;   // pairs score_screen_k recounted in fp64
+        }
     }
     const bool mine = h < h_end;
     uint32_t c = 0;
@@ -519,11 +718,18 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     if (!s.n_tiles || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
     // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
-    const uint32_t gpb_max = (uint32_t)config().score_groups_per_block;
+    const bool screened = kind != 2 && config().score_fp32_screen != 0;
+    const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, screened ? kScreenMaxGroups : 64u);
     const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * window) / min_wgs)));
     const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);
-    if (kind == 0)
+    if (screened && kind == 0)
+        score_screen_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep,
+                                           rep_stride, pair_rep, group_begin, group_end);
+    else if (screened)
+        score_screen_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep,
+                                           rep_stride, pair_rep, group_begin, group_end);
+    else if (kind == 0)
         score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
                                          pair_rep, group_begin, group_end);
     else if (kind == 1)

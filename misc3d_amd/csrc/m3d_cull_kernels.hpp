@@ -38,13 +38,17 @@ constexpr int kCountReplicas = 16;
 // replicas of the launch's (tile, hypothesis) pair counter (m3d_stats.pairs_scored): one add per surviving wave,
 // consecutive tiles hit different words so the adds never queue on one address
 constexpr int kPairReplicas = 1024;
+// ... of which the last kPairReplicas - kPairMain count the pairs the fp32 screen handed to the exact fp64 code
+// (score_screen_k; m3d_stats.pairs_exact)
+constexpr int kPairMain = 1008;
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
                        uint32_t* pair_rep /* kPairReplicas u32, zero on entry: evaluated (tile, hypothesis) pairs */,
                        hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */);
+// (planes and spheres go through score_screen_k unless m3d_config.score_fp32_screen is 0)
 // Folds the replicas of hypotheses [h_begin, h_end): record = count | valid << 31 (valid != null, h < h_count) to
-// `counts` (device-visible host memory, may be null) and `counts_dev` (may be null); *pairs_out (may be null) = sum of
-// the pair counters; best_count != null: atomic running maximum of the valid hypotheses' counts.
+// `counts` (device-visible host memory, may be null) and `counts_dev` (may be null); pairs_out (may be null; TWO words) =
+// sums of the pair counters (all pairs, pairs recounted in fp64); best_count != null: atomic running maximum of the valid hypotheses' counts.
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_end, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t* pairs_out, const uint8_t* valid, uint32_t h_count,
                          uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_end) */,

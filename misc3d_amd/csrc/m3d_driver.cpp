@@ -534,7 +534,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             s.scored = timing;
         } else {
             HIPCHK(hipMemsetAsync(rec_dev + (size_t)g0 * 64, 0, sizeof(uint32_t) * sl_pad, ctx->stream));
-            *h_pairs = 0;
+            h_pairs[0] = h_pairs[1] = 0;
         }
         if (comm) {
             // the one exchange of the window: every rank's slice of records, in place (RCCL: ncclAllGather on this
@@ -913,6 +913,7 @@ struct RansacOut {
     double ms_score_kernel = 0;   // sum over the chunks' scoring-kernel launches (HIP events k0..k1)
     uint32_t score_launches = 0;
     uint64_t pairs_scored = 0;   // (tile, hypothesis) pairs the scoring launches evaluated (culled path)
+    uint64_t pairs_exact = 0;    // ... of which the fp32 screen could not decide (recounted in fp64)
     int internal_error = 0;
     int spec_hits = 0, spec_misses = 0;   // early compaction on the device's pick kept / redone
 };
@@ -1071,7 +1072,10 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
-                if (!use_dense_scoring()) out->pairs_scored += s.h_counts.as<uint32_t>()[s.h_pad];
+                if (!use_dense_scoring()) {
+                    out->pairs_scored += s.h_counts.as<uint32_t>()[s.h_pad];
+                    out->pairs_exact += s.h_counts.as<uint32_t>()[s.h_pad + 1];
+                }
             }
             int cb_rc = M3D_OK;
             // exact EvaluateModel rmse (serial-order error sum), ransac.h:632-650
@@ -1266,6 +1270,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         stats->ms_score_kernel = ro.ms_score_kernel;
         stats->score_launches = ro.score_launches;
         stats->pairs_scored = ro.pairs_scored;
+        stats->pairs_exact = ro.pairs_exact;
         stats->early_pick_redone = (uint32_t)ro.spec_misses;   // 1: the device's early pick lost an rmse tie, RefineModel was redone
         stats->ms_refine = t2 - t1;
         stats->ms_total = t2 - t0;

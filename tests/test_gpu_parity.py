@@ -19,14 +19,16 @@ def _bits(a):
 
 # the scoring paths m3d_config selects between; they must be indistinguishable from outside
 PATHS = {"culled": {}, "dense": {"dense_scoring": 1}, "no_early_pick": {"speculative_refine": 0},
-         "small_blocks": {"score_groups_per_block": 1, "lead_hypotheses": 64}}
+         "small_blocks": {"score_groups_per_block": 1, "lead_hypotheses": 64},
+         "fp64_only": {"score_fp32_screen": 0}}
 
 
 @pytest.fixture(params=sorted(PATHS))
 def scoring_path(request, capi):
-    """Runs the test once per scoring path: the production culled path (cull_mask_k + score_mask_k with the device's
-    early pick), the dense kernel (score_k: every tile x every hypothesis; the bench's reference point), the culled
-    path without the speculative RefineModel, and the culled path with one hypothesis group per workgroup."""
+    """Runs the test once per scoring path: the production culled path (cull_tiles_k + score_screen_k / score_mask_k
+    with the device's early pick), the dense kernel (score_k: every tile x every hypothesis; the bench's reference
+    point), the culled path without the speculative RefineModel, the culled path with one hypothesis group per
+    workgroup, and the culled path without the fp32 screen (score_mask_k for every model)."""
     old = capi.set_config(**PATHS[request.param])
     yield request.param
     capi.restore_config(old)
@@ -362,3 +364,91 @@ def test_perfect_fit_stops_probability_one_loop(capi, orc, max_iter):
         assert (g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.best_index, o.count, o.iterations)
         assert np.array_equal(g.inliers.astype(np.uint64), o.inliers.astype(np.uint64))
         assert np.allclose(g.params, o.params, rtol=0, atol=1e-9)
+
+
+def _screen_case(capi, orc, kind, pts, thr, samples, min_exact=None, max_exact_frac=None):
+    """counts of the screened scoring == oracle == unscreened scoring; returns (pairs, pairs recounted in fp64)"""
+    ov, om, oc, _ = orc.score_samples(kind, pts, None, thr, samples.astype(np.uint64))
+    with capi.Cloud(pts) as c:
+        valid, models, counts = c.score_range(kind, thr, samples)
+        old = capi.set_config(score_fp32_screen=0)
+        try:
+            valid0, models0, counts0 = c.score_range(kind, thr, samples)
+        finally:
+            capi.restore_config(old)
+    assert np.array_equal(valid.astype(bool), ov.astype(bool))
+    assert np.array_equal(counts.astype(np.uint64), oc), (kind, thr)
+    assert np.array_equal(counts0, counts)
+
+
+def test_fp32_screen_points_at_the_cut_off(capi, orc):
+    """score_screen_k decides in fp32 only what its rounding bound allows: points a few fp64 ulps, a few fp32 ulps and
+    a few bounds away from the threshold, on both sides, must all be counted as the fp64 test counts them."""
+    rng = np.random.default_rng(14)
+    thr = 0.01
+    n = 6000
+    base = rng.uniform(-1, 1, (n, 3))
+    rel = np.concatenate([rng.integers(-8, 9, n // 3) * 2.0 ** -52,          # fp64 ulps
+                          rng.integers(-64, 65, n // 3) * 2.0 ** -24,        # fp32 ulps: inside the screen's band
+                          rng.uniform(-3e-5, 3e-5, n - 2 * (n // 3))])       # around the edge of the band
+    base[:, 2] = np.where(rng.random(n) < 0.5, 1.0, -1.0) * thr * (1.0 + rel)
+    anchors = np.array([[0.0, 0, 0], [1.0, 0, 0], [0, 1.0, 0]])
+    pts = np.concatenate([anchors, base])
+    samples = np.concatenate([np.array([[0, 1, 2]], dtype=np.uint32), capi.draw_samples(len(pts), 0, 63, seed=8)])
+    _screen_case(capi, orc, 0, pts, thr, samples)
+    # the same cloud tilted and moved away from the origin (the bound grows with the coordinates)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    for shift in (0.0, 30.0, 4.0e4):
+        _screen_case(capi, orc, 0, pts @ q.T + shift, thr, samples)
+    # sphere: radial offsets around r +- thr
+    r = 0.5
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rad = r + np.where(rng.random(n) < 0.5, 1.0, -1.0) * thr * (1.0 + rel)
+    sph = np.array([0.3, -0.2, 1.0]) + d * rad[:, None]
+    on = np.array([0.3, -0.2, 1.0]) + r * np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [-1.0, 0, 0]])
+    pts = np.concatenate([on, sph])
+    samples = np.concatenate([np.array([[0, 1, 2, 3]], dtype=np.uint32), capi.draw_samples(len(pts), 1, 63, seed=9)])
+    for shift in (0.0, 25.0):
+        _screen_case(capi, orc, 1, pts + shift, thr, samples)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_fp32_screen_unscreenable_inputs(capi, orc, kind):
+    """Inputs the fp32 pass cannot represent go to the exact code, pair by pair or tile by tile: non-finite points,
+    coordinates beyond the fp32 range, thresholds below the rounding bound, degenerate thresholds."""
+    pts, _ = _clouds(kind, 5000, seed=70 + kind)
+    samples = capi.draw_samples(len(pts), kind, 128, seed=4)
+    bad = pts.copy()
+    bad[17] = [np.nan, 0.0, 0.0]
+    bad[600] = [np.inf, 1.0, 1.0]
+    bad[601] = [0.0, -np.inf, 1.0]
+    bad[1300] = [1.0e39, 0.0, 0.0]        # finite, beyond fp32
+    bad[2900] = [0.0, 0.0, -3.0e300]
+    ok_rows = np.ones(len(pts), bool)
+    ok_rows[[17, 600, 601, 1300, 2900]] = False
+    smp = samples[np.all(ok_rows[samples], axis=1)]
+    _screen_case(capi, orc, kind, bad, 0.01, smp)
+    _screen_case(capi, orc, kind, pts, 1e-9, samples)        # threshold far below the fp32 bound
+    _screen_case(capi, orc, kind, pts, 1e-300, samples)
+    _screen_case(capi, orc, kind, pts, 1e6, samples)         # everything is an inlier
+    _screen_case(capi, orc, kind, pts * 1e-25, 1e-27, samples)   # fp32 denormal territory for the squares
+    _screen_case(capi, orc, kind, pts * 1e20, 1e18, samples)     # squares overflow fp32
+
+
+def test_fp32_screen_recount_rate(capi):
+    """The screen is worth having only if the exact recount is rare: on the C2-like cloud a fraction of a percent of the
+    (tile, hypothesis) pairs."""
+    pts = synth.plane_cloud_c2(200_000, seed=2)
+    g = capi.fit(0, pts, threshold=0.01, max_iteration=2000, probability=1.0, seed=1)
+    st = g.stats
+    assert st["pairs_scored"] > 0
+    assert st["pairs_exact"] <= 0.005 * st["pairs_scored"], st
+    old = capi.set_config(score_fp32_screen=0)
+    try:
+        g0 = capi.fit(0, pts, threshold=0.01, max_iteration=2000, probability=1.0, seed=1)
+    finally:
+        capi.restore_config(old)
+    assert g0.stats["pairs_exact"] == 0
+    assert g0.stats["best_index"] == st["best_index"] and g0.stats["count"] == st["count"]
+    assert np.array_equal(g0.inliers, g.inliers)

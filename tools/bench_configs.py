@@ -22,19 +22,24 @@ which = set(sys.argv[1:]) or {"C1", "C2", "C3", "C4", "C5"}
 HBM_PEAK_GBS = 8000.0
 FP64_VALU_PEAK_TOPS = 39.3      # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz, non-FMA ops (bench.py)
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA (MI355X_MICROARCH.md)
-VALU_OPS_PER_PAIR = {0: 7, 1: 10, 2: 22}
+VALU_OPS_FP64 = {0: 7, 1: 10, 2: 22}    # score_mask_k: fp64 VALU instructions per (point, hypothesis)
+VALU_OPS_SCREEN = {0: 4, 1: 6, 2: 22}   # score_screen_k: packed-fp32 screen (planes, spheres); bench.py has the count
 capi.set_config(kernel_timing=1)  # the fit rooflines need m3d_stats.ms_score_kernel (HIP events around the scoring launches)
 
 
 def fit_roofline(kind, st):
-    """fp64-VALU-issue roofline of the scoring launches of ONE fit, from the library's own counters: (tile, hypothesis)
-    pairs evaluated x 512 points x fp64 VALU instructions per pair / time of the score_mask_k launches (HIP events).
-    Recomputable from profiles/r02_configs_kernel_stats.csv (same launches, AverageNs x Calls of score_mask_k<kind>)."""
+    """VALU-issue roofline of the scoring launches of ONE fit, from the library's own counters: (tile, hypothesis)
+    pairs evaluated x 512 points x VALU instructions per (point, hypothesis) / time of the scoring launches (HIP events).
+    Recomputable from profiles/r02_configs_kernel_stats.csv (same launches, AverageNs x Calls of score_screen_k<kind> /
+    score_mask_k<2>)."""
     if not st["ms_score_kernel"]:
         return None
-    tops = st["pairs_scored"] * 512.0 * VALU_OPS_PER_PAIR[kind] / (st["ms_score_kernel"] * 1e-3) / 1e12
-    return {"bound": "fp64-valu", "kernel": f"m3d::score_mask_k<{kind}>", "achieved": tops, "peak": FP64_VALU_PEAK_TOPS,
-            "unit": "T lane-ops/s (fp64 VALU issue)", "frac": tops / FP64_VALU_PEAK_TOPS, "ops_per_pair": VALU_OPS_PER_PAIR[kind],
+    screened = bool(capi.get_config().score_fp32_screen) and kind != 2
+    ops = (VALU_OPS_SCREEN if screened else VALU_OPS_FP64)[kind]
+    tops = st["pairs_scored"] * 512.0 * ops / (st["ms_score_kernel"] * 1e-3) / 1e12
+    return {"bound": "valu-issue", "kernel": f"m3d::score_{'screen' if screened else 'mask'}_k<{kind}>", "achieved": tops,
+            "peak": FP64_VALU_PEAK_TOPS, "unit": "T lane-instructions/s (VALU issue)", "frac": tops / FP64_VALU_PEAK_TOPS,
+            "ops_per_pair": ops, "pairs_recounted_in_fp64": st["pairs_exact"],
             "launches": st["score_launches"], "kernel_ms_total": st["ms_score_kernel"], "tile_hypothesis_pairs": st["pairs_scored"]}
 
 

@@ -84,7 +84,7 @@ def main():
         if not os.path.exists(p):
             continue
         for k, cs in counters(p).items():
-            if not (k.startswith("m3d::score_k") or k.startswith("m3d::score_mask_k") or k.startswith("m3d::cull_mask_k")):
+            if not (k.startswith("m3d::score_k") or k.startswith("m3d::score_mask_k") or k.startswith("m3d::score_screen_k") or k.startswith("m3d::cull_")):
                 continue
             d = summary["kernels"].setdefault(k, {})
             for cname, vals in cs.items():
@@ -98,12 +98,12 @@ def main():
     bf = os.path.join(SRC, "pmc_bench_fetch", "fetch_counter_collection.csv")
     bw = os.path.join(SRC, "pmc_bench_write", "write_counter_collection.csv")
     if os.path.exists(bf) and os.path.exists(bw):
-        fv = counters(bf).get("m3d::score_mask_k<0>", {}).get("FETCH_SIZE", [])
-        wv = counters(bw).get("m3d::score_mask_k<0>", {}).get("WRITE_SIZE", [])
+        fv = counters(bf).get("m3d::score_screen_k<0>", {}).get("FETCH_SIZE", [])
+        wv = counters(bw).get("m3d::score_screen_k<0>", {}).get("WRITE_SIZE", [])
         if fv and wv:
             rd = sum(t[0] for t in fv) / len(fv) * 1024 * 2
             wr = sum(t[0] for t in wv) / len(wv) * 1024
-            latest = {"kernel": "m3d::score_mask_k<0>", "hbm_bytes_per_launch": rd + wr, "hbm_read_bytes": rd,
+            latest = {"kernel": "m3d::score_screen_k<0>", "hbm_bytes_per_launch": rd + wr, "hbm_read_bytes": rd,
                       "hbm_write_bytes": wr, "launches_averaged": len(fv),
                       "avg_launch_ns_under_pmc": sum(t[1] for t in fv) / len(fv),
                       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 10 "
