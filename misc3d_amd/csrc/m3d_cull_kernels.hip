@@ -240,10 +240,12 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
                                                         const uint32_t* __restrict__ ub,
                                                         unsigned long long* __restrict__ keep,
                                                         uint32_t* __restrict__ zero, uint32_t group_offset,
-                                                        uint32_t* __restrict__ records_dev) {
+                                                        uint32_t* __restrict__ records_dev,
+                                                        unsigned long long* __restrict__ pick_key) {
     const uint32_t g = group_offset + blockIdx.x;
     const uint32_t prev = best_count[0];   // may or may not include this chunk's lead already: max() below either way
     uint32_t v = 0;
+    unsigned long long key = 0;   // (count << 32 | ~index): highest count, lowest index among equals
     for (uint32_t h = threadIdx.x; h < lead; h += 64u) {
         uint32_t c = 0;
 #pragma unroll
@@ -254,9 +256,14 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
             if (records_dev) records_dev[h] = c | (ok ? 0x80000000u : 0u);
         }
         v = max(v, ok ? c : 0u);
+        if (ok && c) key = max(key, ((unsigned long long)c << 32) | (0xFFFFFFFFu - h));
     }
     for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
     if (blockIdx.x == 0 && threadIdx.x == 0 && v) atomicMax(best_count, v);
+    if (pick_key && blockIdx.x == 0) {   // block-uniform
+        for (int off = 32; off > 0; off >>= 1) key = max(key, (unsigned long long)__shfl_xor((long long)key, off, 64));
+        if (threadIdx.x == 0 && key) atomicMax(pick_key, key);
+    }
     const uint32_t best = max(prev, v);
     const uint32_t h = g * 64u + threadIdx.x;
     const bool k = !ub || best == 0 || (uint64_t)ub[h] * kTilePoints >= best;
@@ -270,12 +277,12 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
 void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
                            unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st, uint32_t* records_dev,
-                           uint32_t group_begin) {
+                           uint32_t group_begin, unsigned long long* pick_key) {
     if (group_begin == 0xFFFFFFFFu) group_begin = lead / 64u;
     // (n_groups_rest == 0 still needs the fold of the lead's counters: one workgroup whose keep word is scratch)
     if (!n_groups_rest) return;
     lead_fold_keep_k<<<n_groups_rest, 64, 0, st>>>(counts_rep, rep_stride, lead, valid, h_count, records, best_count, ub,
-                                                   keep, const_cast<uint32_t*>(counts_rep), group_begin, records_dev);
+                                                   keep, const_cast<uint32_t*>(counts_rep), group_begin, records_dev, pick_key);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -597,7 +604,7 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
                                uint32_t* __restrict__ counts, const uint32_t* __restrict__ pair_rep,
                                uint32_t* __restrict__ pairs_out, const uint8_t* __restrict__ valid, uint32_t h_count,
                                uint32_t* __restrict__ best_count, uint32_t h_begin,
-                               uint32_t* __restrict__ counts_dev /* device copy of the records, or null */) {
+                               uint32_t* __restrict__ counts_dev /* device copy of the records, or null */, PickFinal pf) {
     const uint32_t h = h_begin + blockIdx.x * 256u + threadIdx.x;   // window [h_begin, h_end) of the chunk
     if (blockIdx.x == 0 && pair_rep && pairs_out) {   // block-uniform
         __shared__ uint32_t red[256];
@@ -633,14 +640,70 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
         for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
         if ((threadIdx.x & 63) == 0 && v) atomicMax(best_count, v);
     }
+    if (!pf.pick) return;   // (kernel argument: uniform)
+    // ---- pick_best_k's decision, without its launch: every wave contributes its best (count, index) key; the
+    // workgroup that finishes last compares the chunk's best with the running pick
+    __shared__ uint32_t s_last, s_take, s_idx;
+    {
+        unsigned long long key = (ok && c) ? (((unsigned long long)c << 32) | (0xFFFFFFFFu - h)) : 0ull;
+        for (int off = 32; off > 0; off >>= 1) key = max(key, (unsigned long long)__shfl_xor((long long)key, off, 64));
+        if ((threadIdx.x & 63) == 0 && key) atomicMax(pf.key, key);
+    }
+    // this workgroup's records (host memory) and its key are out before its ticket.  (Waiting for the stores with
+    // s_waitcnt alone is NOT enough: with two processes sharing the GPU the host saw the completion word before some
+    // records -- the system-scope release is what orders them.  Every wave first waits until its own stores have
+    // been taken by the L2, so that thread 0's write-back covers them.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        s_last = __hip_atomic_fetch_add(pf.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        const unsigned long long key = __hip_atomic_load(pf.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t cnt = (uint32_t)(key >> 32), idx = 0xFFFFFFFFu - (uint32_t)key;
+        BestPick* pick = pf.pick;
+        const bool had = !pf.first_chunk && pick->have;
+        const bool take = cnt > 0 && (!had || cnt > pick->cnt);
+        s_take = take ? 1u : 0u;
+        s_idx = idx;
+        if (take) {
+            pick->have = 1;
+            pick->cnt = cnt;
+            pick->index = pf.index_base + idx;
+        } else if (!had) {
+            pick->have = 0;
+            pick->cnt = 0;
+            pick->index = ~0ull;
+        }
+        pf.pick_host->have = pick->have;
+        pf.pick_host->cnt = pick->cnt;
+        pf.pick_host->index = pick->index;
+        *pf.key = 0ull;      // (for the next chunk)
+        *pf.ticket = 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < kModelStride) {
+        if (s_take) pf.pick->params[threadIdx.x] = pf.params[(size_t)s_idx * kModelStride + threadIdx.x];
+        else if (pf.first_chunk) pf.pick->params[threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&pf.pick_host->seq, pf.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_end, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t* pairs_out, const uint8_t* valid, uint32_t h_count,
-                         uint32_t* best_count, hipStream_t st, uint32_t h_begin, uint32_t* counts_dev) {
+                         uint32_t* best_count, hipStream_t st, uint32_t h_begin, uint32_t* counts_dev, const PickFinal* pick) {
+    PickFinal pf;
+    if (pick) pf = *pick;
     if (h_end > h_begin)
         sum_replicas_k<<<(h_end - h_begin + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_end, counts, pair_rep,
                                                                       pairs_out, valid, h_count, best_count, h_begin,
-                                                                      counts_dev);
+                                                                      counts_dev, pf);
 }
 
 // The hypothesis the sequential replay will most probably end with, chosen on the device: highest inlier count

@@ -46,13 +46,6 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                        uint32_t* pair_rep /* kPairReplicas u32, zero on entry: evaluated (tile, hypothesis) pairs */,
                        hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */);
 // (planes and spheres go through score_screen_k unless m3d_config.score_fp32_screen is 0)
-// Folds the replicas of hypotheses [h_begin, h_end): record = count | valid << 31 (valid != null, h < h_count) to
-// `counts` (device-visible host memory, may be null) and `counts_dev` (may be null); pairs_out (may be null; TWO words) =
-// sums of the pair counters (all pairs, pairs recounted in fp64); best_count != null: atomic running maximum of the valid hypotheses' counts.
-void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_end, uint32_t* counts,
-                         const uint32_t* pair_rep, uint32_t* pairs_out, const uint8_t* valid, uint32_t h_count,
-                         uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_end) */,
-                         uint32_t* counts_dev = nullptr /* the same records once more, in device memory */);
 // The device's prediction of the hypothesis the replay will end with (pick_best_k, m3d_cull_kernels.hip)
 struct BestPick {
     unsigned long long index;   // absolute hypothesis index, ~0 when none
@@ -62,7 +55,28 @@ struct BestPick {
 struct BestPickHost {           // mirror in pinned host memory, written by the same kernel
     unsigned long long index;
     uint32_t cnt, have;
+    uint32_t seq, pad;          // PickFinal::seq, stored last: the host's completion word of the chunk
 };
+// Optional tail of launch_sum_replicas (one-GPU fits): pick_best_k's decision taken by the workgroup of sum_replicas_k
+// that finishes last -- no pick_best_k launch, and no event behind it: the host waits for pick_host->seq.
+struct PickFinal {
+    unsigned long long* key = nullptr;   // device: max over the chunk of (count << 32 | ~index); zero on entry and on exit
+    uint32_t* ticket = nullptr;          // device: finished workgroups; zero on entry and on exit
+    const double* params = nullptr;      // the chunk's parameter records
+    unsigned long long index_base = 0;
+    int first_chunk = 0;
+    BestPick* pick = nullptr;
+    BestPickHost* pick_host = nullptr;
+    uint32_t seq = 0;
+};
+// Folds the replicas of hypotheses [h_begin, h_end): record = count | valid << 31 (valid != null, h < h_count) to
+// `counts` (device-visible host memory, may be null) and `counts_dev` (may be null); pairs_out (may be null; TWO words) =
+// sums of the pair counters (all pairs, pairs recounted in fp64); best_count != null: atomic running maximum of the valid hypotheses' counts.
+void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_end, uint32_t* counts,
+                         const uint32_t* pair_rep, uint32_t* pairs_out, const uint8_t* valid, uint32_t h_count,
+                         uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_end) */,
+                         uint32_t* counts_dev = nullptr /* the same records once more, in device memory */,
+                         const PickFinal* pick = nullptr);
 void launch_pick_best(const uint32_t* records, uint32_t count, unsigned long long index_base, const double* params,
                       bool first_chunk, BestPick* pick, BestPickHost* pick_host, hipStream_t st,
                       uint32_t* records_host = nullptr /* device-visible host copy of the records (sharded fits) */,
@@ -73,7 +87,8 @@ void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
                            unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st,
                            uint32_t* records_dev = nullptr,
-                           uint32_t group_begin = 0xFFFFFFFFu /* first group of the keep window; default lead / 64 */);
+                           uint32_t group_begin = 0xFFFFFFFFu /* first group of the keep window; default lead / 64 */,
+                           unsigned long long* pick_key = nullptr /* PickFinal::key: the lead's best goes in */);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,
                        uint32_t n_groups, unsigned long long* total, hipStream_t st);
 

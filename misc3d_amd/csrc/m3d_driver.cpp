@@ -26,6 +26,7 @@
 #include "m3d_reg_kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -413,7 +414,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                        m3d_comm* comm = nullptr,
                        bool caller_ships_records = false /* the caller queues pick_best_k behind the chunk and records s.done
                                                             behind THAT (an event between two kernels costs a ~5 us
-                                                            gap on this stream; behind pick_best_k nothing follows at once) */) {
+                                                            gap on this stream; behind pick_best_k nothing follows at once) */,
+                       const PickFinal* pick_final = nullptr /* one GPU: the chunk's last kernel takes pick_best_k's decision
+                                                                and stores the completion word the host polls (no event) */) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const bool dense = use_dense_scoring();
@@ -471,6 +474,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     // (culled path: keep_mask_k clears the counter replicas on its way)
     s.lead_groups = 0;
     s.scored = false;
+    s.poll_seq = 0;
     s.host_has_records = true;
     s.done_on_copy_stream = false;
     uint32_t* h_pairs = s.h_counts.as<uint32_t>() + h_pad;   // pinned, device-visible
@@ -495,6 +499,11 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
         uint32_t* bc = prune ? ctx->best_count.as<uint32_t>() : nullptr;
         uint32_t* rec_host = comm ? nullptr : s.h_counts.as<uint32_t>();   // sharded: the host gets the GATHERED records
+        PickFinal pfin;
+        if (pick_final) {
+            pfin = *pick_final;
+            pfin.params = s.params.as<double>();
+        }
         // lead > 0 (a fit's first chunk): the first `lead` hypotheses are counted on their own, and their best
         // count then prunes the rest of the SAME chunk -- what a separate small first chunk did, without its
         // own sample copy, MinimalFit and box-test launches.  The records are complete after the second pass.
@@ -518,7 +527,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 // fold of the lead's counters + keep masks of the rest of this rank's groups: one launch
                 launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
                                       g0 == 0 ? rec_host : nullptr, bc, ub, keep, g1 - g_lo, ctx->stream,
-                                      g0 == 0 ? rec_dev : nullptr, g_lo);
+                                      g0 == 0 ? rec_dev : nullptr, g_lo, pick_final ? pick_final->key : nullptr);
             } else {
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
             }
@@ -530,7 +539,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             // ... and (one GPU) write the records straight into the slot's pinned host array (device-visible): no copy
             // command behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
             launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, g1 * 64u, rec_host, pair_rep, h_pairs,
-                                s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u, rec_dev);
+                                s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u, rec_dev, pick_final ? &pfin : nullptr);
+            if (pick_final) s.poll_seq = pick_final->seq;
             s.scored = timing;
         } else {
             HIPCHK(hipMemsetAsync(rec_dev + (size_t)g0 * 64, 0, sizeof(uint32_t) * sl_pad, ctx->stream));
@@ -570,7 +580,30 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                               ctx->stream));
     if (dense) HIPCHK(hipMemcpyAsync(s.h_valid.p, s.valid.p, (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
-    if (!caller_ships_records) HIPCHK(hipEventRecord(s.done, ctx->stream));
+    if (!caller_ships_records && !s.poll_seq) HIPCHK(hipEventRecord(s.done, ctx->stream));
+    return M3D_OK;
+}
+
+// Completion of a chunk issued with a PickFinal: the last kernel of the chunk stores `seq` into the pinned
+// BestPickHost behind everything else it (and the kernels before it) wrote to host memory.  A spin on that word
+// replaces an event record between two kernels (a ~5 us bubble on the stream) and the event wait.
+static int wait_pick_seq(DeviceCtx* ctx, uint32_t seq) {
+    const volatile uint32_t* p = &ctx->h_pick.as<BestPickHost>()->seq;
+    for (uint32_t spins = 1;; ++spins) {
+        if ((int32_t)(*p - seq) >= 0) break;
+        if ((spins & 0xFFFFu) == 0) {   // a fault on the device would leave the word unwritten
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if ((int32_t)(*p - seq) >= 0) break;
+                return fail(M3D_ERR_INTERNAL, "the scoring chunk finished without its completion word");
+            }
+            if (q != hipErrorNotReady) return fail(M3D_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        }
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return M3D_OK;
 }
 
@@ -936,7 +969,10 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     ctx->spec_compaction = false;
     if (spec) {
         RESERVE(ctx->pick, sizeof(BestPick));
-        RESERVE(ctx->h_pick, 128);
+        if (!ctx->h_pick.p) {
+            RESERVE(ctx->h_pick, 128);
+            std::memset(ctx->h_pick.p, 0, 128);   // (BestPickHost::seq starts at 0; wait_pick_seq's values never are)
+        }
         RESERVE(ctx->h_best, sizeof(double) * kModelStride);
     }
     SampleSource src;
@@ -1009,9 +1045,30 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
         want = std::min(std::max<size_t>(want, 64), chunk_cap);
         const size_t b = next_begin, e = std::min(max_iter, b + want);
+        // one GPU: the chunk's last kernel (sum_replicas_k) picks the device's best itself and stores the completion word
+        PickFinal pf;
+        const bool fused_pick = spec && !comm;
+        if (fused_pick) {
+            pf.key = reinterpret_cast<unsigned long long*>(ctx->best_count.as<uint32_t>() + 2);
+            pf.ticket = ctx->best_count.as<uint32_t>() + 1;
+            pf.index_base = (unsigned long long)b;
+            pf.first_chunk = b == 0 ? 1 : 0;
+            pf.pick = ctx->pick.as<BestPick>();
+            pf.pick_host = ctx->h_pick.as<BestPickHost>();
+            if (++ctx->pick_seq == 0) ++ctx->pick_seq;
+            pf.seq = ctx->pick_seq;
+            // (pf.params: issue_chunk fills in the slot's parameter array once it has reserved it)
+        }
         int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
-                            b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec);
-        if (r == M3D_OK && spec) {
+                            b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec && !fused_pick,
+                            fused_pick ? &pf : nullptr);
+        if (r == M3D_OK && fused_pick && e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
+            r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
+                                        ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true,
+                                        idx_host);
+            ctx->spec_compaction = r == M3D_OK;
+        }
+        if (r == M3D_OK && spec && !fused_pick) {
             ChunkSlot& sl = ctx->slot[slot_id];
             // (sharded: the records are the gathered ones; the other ranks' counts raise this rank's incumbent too.  Should the
             // records not be on their way to the host yet, the kernel passes them on to the pinned array the replay reads.)
@@ -1060,7 +1117,12 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 }
             }
             first_pass = false;
-            HIPCHK(hipEventSynchronize(s.done));
+            if (s.poll_seq) {
+                const int wrc = wait_pick_seq(ctx, s.poll_seq);
+                if (wrc != M3D_OK) return wrc;
+            } else {
+                HIPCHK(hipEventSynchronize(s.done));
+            }
             if (use_dense_scoring()) unpack_slot(s);   // (culled path: the replay reads the packed records as shipped)
             {
                 float kms = 0;

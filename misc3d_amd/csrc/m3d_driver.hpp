@@ -58,6 +58,7 @@ struct ChunkSlot {
     bool host_has_records = true;   // sharded: the gathered records are (being) written to h_counts
     bool done_on_copy_stream = false;   // sharded RCCL windows: `done` follows the record copy on the copy stream
     bool scored = false;   // a scoring launch was issued for the chunk (k0 / k1 recorded)
+    uint32_t poll_seq = 0;   // != 0: no `done` event; completion = BestPickHost::seq reaching this value (PickFinal)
     size_t begin = 0, end = 0;
     uint32_t h_pad = 0;
 };
@@ -75,6 +76,7 @@ struct DeviceCtx {
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
     PinBuf h_inc;              // m3d_cloud_score_shard: the sampler's pruning incumbent on its way to / from the device
+    uint32_t pick_seq = 0;     // last PickFinal::seq handed out (completion words of one-GPU speculative chunks)
     const double* last_best_dev = nullptr;   // device address of the last fit's best minimal model (a slot's params or best_params)
     // m3d_cloud_create's upload / sort scratch (a one-shot call -- upload, fit, destroy -- otherwise spends more time
     // in hipMalloc / hipFree than in the fit; the cloud's own buffers come back through DevBuf's free list)

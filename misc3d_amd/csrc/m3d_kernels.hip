@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
     const uint32_t h = blockIdx.x * 64u + threadIdx.x;
     if (h >= h_pad) return;
     if (zero_u32 && h + 1 < h_pad) zero_u32[h] = 0;   // per-hypothesis counter cleared on the way (saves a memset launch)
-    if (zero_one && h == 0) zero_one[0] = 0;          // a fit's first chunk: the running best count
+    if (zero_one && h < 4) zero_one[h] = 0;           // a fit's first chunk: the running best count + the pick's ticket and key (PickFinal)
     if (lead.counts_rep) {
         // a fit's first chunk: what keep_mask_k would do for the leading hypotheses (nothing to prune against yet: keep
         // everything; clear their counter replicas and the launch's pair counters) -- one launch less in front of the lead pass
