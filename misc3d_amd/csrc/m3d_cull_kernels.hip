@@ -435,25 +435,47 @@ __device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, co
     float mn = __builtin_inff();
     if (KIND == 0) {   // ra = (a, b, c, mid2), rb = (D, h, -, -)
         const f32x2 A = {ra.x, ra.x}, B = {ra.y, ra.y}, C = {ra.z, ra.z}, D = {rb.x, rb.x}, M2 = {-ra.w, -ra.w};
+        // the four row pairs advance together: dependent v_pk_fma_f32 need a wait state that independent ones fill
+        f32x2 s[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) s[j] = __builtin_elementwise_fma(C, zf[j], D);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) s[j] = __builtin_elementwise_fma(B, yf[j], s[j]);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) s[j] = __builtin_elementwise_fma(A, xf[j], s[j]);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) s[j] = __builtin_elementwise_fma(s[j], s[j], M2);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            const f32x2 s = __builtin_elementwise_fma(A, xf[j], __builtin_elementwise_fma(B, yf[j], __builtin_elementwise_fma(C, zf[j], D)));
-            const f32x2 q = __builtin_elementwise_fma(s, s, M2);
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(q.x), 31);
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(q.y), 31);
-            mn = __builtin_fminf(mn, __builtin_fminf(__builtin_fabsf(q.x), __builtin_fabsf(q.y)));
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s[j].x), 31);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s[j].y), 31);
+            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(s[j].x)), __builtin_fabsf(s[j].y));   // one v_min3_f32
         }
     } else {           // ra = (mid, half, -, -), rb = (Cx, Cy, Cz, h)
         const f32x2 CX = {rb.x, rb.x}, CY = {rb.y, rb.y}, CZ = {rb.z, rb.z}, MID = {-ra.x, -ra.x};
         const float half = ra.y;
+        f32x2 t[Q];
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            const f32x2 dx = xf[j] - CX, dy = yf[j] - CY, dz = zf[j] - CZ;
-            const f32x2 t = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, MID)));
-            const float va = __builtin_fabsf(t.x) - half, vb = __builtin_fabsf(t.y) - half;
+            const f32x2 dx = xf[j] - CX;
+            t[j] = __builtin_elementwise_fma(dx, dx, MID);
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const f32x2 dy = yf[j] - CY;
+            t[j] = __builtin_elementwise_fma(dy, dy, t[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const f32x2 dz = zf[j] - CZ;
+            t[j] = __builtin_elementwise_fma(dz, dz, t[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const float va = __builtin_fabsf(t[j].x) - half, vb = __builtin_fabsf(t[j].y) - half;
             acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(va), 31);
             acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(vb), 31);
-            mn = __builtin_fminf(mn, __builtin_fminf(__builtin_fabsf(va), __builtin_fabsf(vb)));
+            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(va)), __builtin_fabsf(vb));
         }
     }
     bits = acc;
