@@ -16,9 +16,9 @@ JSON objects besides the contract's fields:
                m3d_stats.pairs_scored) x 512 points x VALU instructions per (point, hypothesis) / the launches'
                duration measured live with HIP events on the library's stream (m3d_stats.ms_score_kernel) -- the
                same launches `rocprofv3 --kernel-trace --stats -- python bench.py` averages (profiles/).
-               Instructions per (point, hypothesis): 4 for the plane's packed-fp32 screen (per pair of points 4 v_pk_fma,
-               2 v_alignbit, 1.5 v_min = 7.5, + v_bcnt and the v_cmp per 8 points; the fp64 loop it replaced: 7), 6 for
-               the sphere's, 22 for the cylinder's fp64 loop.
+               Instructions per (point, hypothesis): 3.75 for the plane's packed-fp32 screen (30 per lane and hypothesis for
+               the lane's 8 points: 16 v_pk_fma, 8 v_alignbit, 4 v_min3, v_bcnt, v_cmp -- the ISA of the loop, not an
+               estimate; the fp64 loop it replaced: 7), 5.75 for the sphere's (46 per 8 points; fp64: 10), 6.75 for the cylinder (54; fp64: 22).
                peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T lane-instructions/s: a wave64 VALU instruction
                (fp64, fp32, packed fp32 or integer alike) occupies its SIMD for 4 cycles.  `traffic` = HBM bytes per launch from the PMC pass under
                profiles/.  `algorithmic_reuse` restates SURVEY.md 8(d)'s 24 B/(hypothesis, point) figure: it is far
@@ -54,9 +54,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (non-FMA ops; FMA peak 78.6 TF)
 ALG_BYTES_PER_PAIR = 24.0      # one fp64 xyz read per (hypothesis, point), SURVEY.md 8(d)
 VALU_OPS_FP64 = {0: 7, 1: 10, 2: 22}      # fp64 VALU instructions per (point, hypothesis) incl. compares: score_mask_k, score_k
-VALU_OPS_SCREEN = {0: 4, 1: 6, 2: 22}     # score_screen_k: packed-fp32 screen (m3d_cull_kernels.hip); cylinders stay on score_mask_k
+VALU_OPS_SCREEN = {0: 3.75, 1: 5.75, 2: 6.75}     # score_screen_k: packed-fp32 screen (m3d_cull_kernels.hip): 30 / 46 / 54 instructions per 8 points
 KERNEL_FP64 = {0: "m3d::score_mask_k<0>", 1: "m3d::score_mask_k<1>", 2: "m3d::score_mask_k<2>"}
-KERNEL_SCREEN = {0: "m3d::score_screen_k<0>", 1: "m3d::score_screen_k<1>", 2: "m3d::score_mask_k<2>"}
+KERNEL_SCREEN = {0: "m3d::score_screen_k<0>", 1: "m3d::score_screen_k<1>", 2: "m3d::score_screen_k<2>"}
 WORKLOADS = {   # name -> (kind, default hypotheses, threshold, seed, label)
     "c2": (0, 10_000, 0.01, 11, "C2 fit_plane"),
     "c3cyl": (2, 50_000, 0.01, 13, "C3 fit_cylinder"),
@@ -323,7 +323,7 @@ def main():
         k_ms = k_ms_sum / max(k_launches, 1)
         h_rank = H_total / world                                  # hypotheses this rank scores per step
         h_per_launch = h_rank * a.steps / max(k_launches, 1)
-        screened = bool(capi.get_config().score_fp32_screen) and kind != 2
+        screened = bool(capi.get_config().score_fp32_screen)
         ops = (VALU_OPS_SCREEN if screened else VALU_OPS_FP64)[kind]
         kname = (KERNEL_SCREEN if screened else KERNEL_FP64)[kind]
         v_tops = k_pairs * 512.0 * ops / (k_ms_sum * 1e-3) / 1e12

@@ -429,8 +429,8 @@ constexpr int kCntStride = 64;              // bytes per row of the count table
 
 // bits: 8 sign bits (point inside <=> 1); m: min over the lane's points of the distance to the decision boundary
 template <int KIND, int Q>
-__device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, const f32x2 (&xf)[Q], const f32x2 (&yf)[Q],
-                                            const f32x2 (&zf)[Q], uint32_t& bits, float& m) {
+__device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, const float4 rc, const f32x2 (&xf)[Q],
+                                            const f32x2 (&yf)[Q], const f32x2 (&zf)[Q], uint32_t& bits, float& m) {
     uint32_t acc = 0;
     float mn = __builtin_inff();
     if (KIND == 0) {   // ra = (a, b, c, mid2), rb = (D, h, -, -)
@@ -450,6 +450,39 @@ __device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, co
             acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s[j].x), 31);
             acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s[j].y), 31);
             mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(s[j].x)), __builtin_fabsf(s[j].y));   // one v_min3_f32
+        }
+    } else if (KIND == 2) {   // ra = (E1x, E1y, E1z, D1), rb = (E2x, E2y, E2z, D2), rc = (mid, half, h, -)
+        // t = (E1 . q + D1)^2 + (E2 . q + D2)^2: two plane values (m3d_fp.hpp: the exact code's |(q - p1) x (q - p2)|^2)
+        const f32x2 AX = {ra.x, ra.x}, AY = {ra.y, ra.y}, AZ = {ra.z, ra.z}, AD = {ra.w, ra.w};
+        const f32x2 BX = {rb.x, rb.x}, BY = {rb.y, rb.y}, BZ = {rb.z, rb.z}, BD = {rb.w, rb.w};
+        const f32x2 MID = {-rc.x, -rc.x};
+        const float half = rc.y;
+        f32x2 d1[Q], d2[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            d1[j] = __builtin_elementwise_fma(AZ, zf[j], AD);
+            d2[j] = __builtin_elementwise_fma(BZ, zf[j], BD);
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            d1[j] = __builtin_elementwise_fma(AY, yf[j], d1[j]);
+            d2[j] = __builtin_elementwise_fma(BY, yf[j], d2[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            d1[j] = __builtin_elementwise_fma(AX, xf[j], d1[j]);
+            d2[j] = __builtin_elementwise_fma(BX, xf[j], d2[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) d1[j] = __builtin_elementwise_fma(d1[j], d1[j], MID);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) d1[j] = __builtin_elementwise_fma(d2[j], d2[j], d1[j]);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const float va = __builtin_fabsf(d1[j].x) - half, vb = __builtin_fabsf(d1[j].y) - half;
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(va), 31);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(vb), 31);
+            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(va)), __builtin_fabsf(vb));
         }
     } else {           // ra = (mid, half, -, -), rb = (Cx, Cy, Cz, h)
         const f32x2 CX = {rb.x, rb.x}, CY = {rb.y, rb.y}, CZ = {rb.z, rb.z}, MID = {-ra.x, -ra.x};
@@ -495,7 +528,8 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
                                                       uint32_t group_begin, uint32_t group_end) {
     __shared__ uint16_t ids[kScreenMaxGroups * 64];
     __shared__ __attribute__((aligned(16))) uint8_t cnt8[64 * kCntStride];
-    __shared__ float4 loc[64][2];   // the batch's (tile, hypothesis) records
+    constexpr int NL = KIND == 2 ? 3 : 2;
+    __shared__ float4 loc[64][NL];   // the batch's (tile, hypothesis) records
     const uint32_t tile = blockIdx.x;
     uint32_t* __restrict__ counts = counts_rep + (size_t)(tile % kCountReplicas) * rep_stride;
     const uint32_t g0 = group_begin + blockIdx.y * groups_per_block;
@@ -560,24 +594,27 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
         const int my = (b0 + (uint32_t)lane < total) ? (int)ids[b0 + lane] : 0;   // lane k: k-th id of the batch
         {   // lane k: the record of hypothesis k at this tile
             const double* __restrict__ rp = score0 + (size_t)my * kModelStride;
-            double rec[5];
+            constexpr int kRec = KIND == 2 ? 8 : 5;
+            double rec[kRec];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) rec[k] = rp[k];
-            float sr[8];
+            for (int k = 0; k < kRec; ++k) rec[k] = rp[k];
+            float sr[12];
             if (KIND == 0) plane_screen_record(rec, box, max_abs, sr);
-            else sphere_screen_record(rec, box, max_abs, sr);
+            else if (KIND == 1) sphere_screen_record(rec, box, max_abs, sr);
+            else cylinder_screen_record(rec, box, max_abs, sr);
             loc[lane][0] = make_float4(sr[0], sr[1], sr[2], sr[3]);
             loc[lane][1] = make_float4(sr[4], sr[5], sr[6], sr[7]);
+            if (KIND == 2) loc[lane][NL - 1] = make_float4(sr[8], sr[9], sr[10], sr[11]);
         }
         __syncthreads();
         uint32_t park = 0;   // lane k: exact count of hypothesis k when the screen could not decide it
-        auto step = [&](const float4 ra, const float4 rb, uint32_t k) {
+        auto step = [&](const float4 ra, const float4 rb, const float4 rc, uint32_t k) {
             uint32_t bits = 0;
             float m = 0.0f;
             bool exact = !tile_screened;
             if (tile_screened) {
-                screen_eval<KIND, Q>(ra, rb, xf, yf, zf, bits, m);
-                exact = __ballot(!(m >= (KIND == 0 ? rb.y : rb.w))) != 0ull;   // (h = NaN: the record is not screened)
+                screen_eval<KIND, Q>(ra, rb, rc, xf, yf, zf, bits, m);
+                exact = __ballot(!(m >= (KIND == 0 ? rb.y : (KIND == 1 ? rb.w : rc.z)))) != 0ull;   // (h = NaN: the record is not screened)
             }
             uint32_t c = (uint32_t)__popc(bits);
             if (exact) {   // wave-uniform, rare
@@ -588,16 +625,18 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
             }
             cnt8[k * kCntStride + (uint32_t)lane] = (uint8_t)c;
         };
-        float4 a0 = loc[0][0], a1 = loc[0][1], b0r, b1r;
+        float4 a0 = loc[0][0], a1 = loc[0][1], a2 = loc[0][NL - 1], b0r, b1r, b2r;
         for (uint32_t k = 0; k < nb; k += 2u) {
             // two hypotheses per trip, their records in alternating register sets; the next one is always in flight
             const uint32_t k1 = min(k + 1u, nb - 1u), k2 = min(k + 2u, nb - 1u);
             b0r = loc[k1][0];
             b1r = loc[k1][1];
-            step(a0, a1, k);
+            b2r = loc[k1][NL - 1];
+            step(a0, a1, a2, k);
             a0 = loc[k2][0];
             a1 = loc[k2][1];
-            if (k + 1u < nb) step(b0r, b1r, k + 1u);
+            a2 = loc[k2][NL - 1];
+            if (k + 1u < nb) step(b0r, b1r, b2r, k + 1u);
         }
         __syncthreads();   // (one wave: the table is complete)
         if ((uint32_t)lane < nb) {
@@ -803,7 +842,7 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     if (!s.n_tiles || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
     // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
-    const bool screened = kind != 2 && config().score_fp32_screen != 0;
+    const bool screened = config().score_fp32_screen != 0;
     const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, screened ? kScreenMaxGroups : 64u);
     const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * window) / min_wgs)));
@@ -811,8 +850,11 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     if (screened && kind == 0)
         score_screen_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep,
                                            rep_stride, pair_rep, group_begin, group_end);
-    else if (screened)
+    else if (screened && kind == 1)
         score_screen_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep,
+                                           rep_stride, pair_rep, group_begin, group_end);
+    else if (screened)
+        score_screen_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep,
                                            rep_stride, pair_rep, group_begin, group_end);
     else if (kind == 0)
         score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,

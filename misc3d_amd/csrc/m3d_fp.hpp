@@ -421,8 +421,10 @@ M3D_HD void cylinder_cutoffs(const double* w, double thr, double* t_lo, double* 
 // Sphere.  Exact test lo <= sv64 <= hi  <=>  |sv64 - mid| <= half.  With C = fl32(fl64(c - o)) the kernel forms
 // d~ = fl32(xr - C), within 2.01 u W_l (+ 3 * 2^-53 W_g) of x - c, W_l = max_k (e_k + |c_k - o_k|), W_g = A + max |c_k|;
 // sum d~_k^2 is then within 12.2 u W_l^2 of the real sum, the three fmas of t = fma(dz, dz, fma(dy, dy,
-// fma(dx, dx, -mid32))) add at most 3.01 u (3 W_l^2 + mid), the rounding of mid u mid: E_t = 24 u W_l^2 + 5 u mid +
-// 2e-14 W_g^2.  The kernel forms v = |t| - half32; the pair is certain when |v| >= h, h >= (E_t + u half) / (1 - u).
+// fma(dx, dx, -mid32))) add at most 3.01 u (3 W_l^2 + mid), the rounding of mid u mid; the fp64 roundings (c - o:
+// 2^-53 * 2 W_g per component, times 2 |x - c| <= 2 W_l, three components; sv64 itself: 6 * 2^-53 W_l^2) stay below
+// 2e-15 W_l (W_g + W_l): E_t = 24 u W_l^2 + 5 u mid + 1e-14 W_l (W_g + W_l).  The kernel forms v = |t| - half32; the
+// pair is certain when |v| >= h, h >= (E_t + u half) / (1 - u).
 //
 // A record that cannot be screened (non-finite or huge values, a cut-off below the rounding bound) carries h = NaN:
 // `!(m >= h)` then sends every pair of that hypothesis to the exact code.
@@ -471,7 +473,7 @@ M3D_HD void sphere_screen_record(const double* rec, const double* box, double ma
     const double Wg = max_abs + fmax(fmax(fabs(rec[0]), fabs(rec[1])), fabs(rec[2]));
     const bool ok = (lo <= hi) && (lo >= 0.0) && (hi < 1e36) && (Wg < 1e18) && (Wl < 1e18);
     const double mid = 0.5 * lo + 0.5 * hi, half = 0.5 * hi - 0.5 * lo;
-    const double Et = ((24.0 * kU32 * (Wl * Wl) + 5.0 * kU32 * mid) + 2e-14 * (Wg * Wg)) + 1e-30 * (Wl + 1.0);
+    const double Et = ((24.0 * kU32 * (Wl * Wl) + 5.0 * kU32 * mid) + 1e-14 * (Wl * (Wg + Wl))) + 1e-30 * (Wl + 1.0);
     const double h = ((Et + kU32 * half) + 1e-15 * (mid + half)) * 1.001;
     out[0] = ok ? (float)mid : 0.0f;
     out[1] = ok ? (float)half : 0.0f;
@@ -480,6 +482,68 @@ M3D_HD void sphere_screen_record(const double* rec, const double* box, double ma
     out[5] = ok ? (float)cy : 0.0f;
     out[6] = ok ? (float)cz : 0.0f;
     out[7] = ok ? f32_round_up_pos(h > 1e-30 ? h : 1e-30) : f32_nan();
+}
+
+// rec = the cylinder's scoring record (p1 = centre (3), p2 = ref (3), t_lo, t_hi).  The exact code forms
+// t = |(q - p1) x (q - p2)|^2 = |L|^2 dist(q, axis)^2, L = p2 - p1.  With two vectors E1, E2 of length |L|, orthogonal to
+// L and to each other, t = (E1 . (q - c'))^2 + (E2 . (q - c'))^2 for ANY point c' of the axis: two plane evaluations.
+// The record takes c' = the axis point nearest to the box centre o and moves everything there in fp64:
+// d_i = E_i . (q - o) + D_i, D_i = E_i . (o - c').  The kernel forms d_i with three v_pk_fma each (as for a plane: at most
+// five factors (1 + delta) per term, |d_i~ - d_i| <= gamma_5 M_i, M_i = |E_ix| ex + |E_iy| ey + |E_iz| ez + |D_i|) and
+// t' = fma(d2, d2, fma(d1, d1, -mid32)): within 10.1 u (M_1^2 + M_2^2) + 2.02 u (2 M^2 + mid) + u mid of t - mid:
+// E_t = 32 u M^2 + 4 u mid, M = max(M_1, M_2).  fp64 roundings: E_1, E_2 are orthonormal-times-|L| to 4e-16, which lets
+// 4e-16 of the along-axis part of q - c' (<= W_l) into d_i: <= 1.6e-15 (|L| W_l)^2 on t; the exact code's own t (a cross
+// product of two LONG differences: components within 8 * 2^-53 W_m^2, W_m = max(A + |p1|, A + |p2|), of real ones of
+// size <= K = 2 |L| W_l) and the moved point (within 12 * 2^-53 W_m of the axis): <= 2.2e-14 K W_m^2.
+// E_t += 1e-13 (|L| W_l)^2 + 5e-14 K W_m^2 + 1e-27 W_m^4.
+// (First version: t = |L x (q - c')|^2 from the rounded differences, 15 packed instructions per two points and a bound
+// of 200 u (|L| W_l)^2 -- 2.8 % of the pairs of the C3 fit went back to the exact code; this form: 11 and a sixth of it.)
+// out = (E1x, E1y, E1z, D1, E2x, E2y, E2z, D2, mid, half, h, -)
+M3D_HD void cylinder_screen_record(const double* rec, const double* box, double max_abs, float* out) {
+    const double lo = rec[6], hi = rec[7];
+    const double L[3] = {rec[3] - rec[0], rec[4] - rec[1], rec[5] - rec[2]};
+    const double L2 = (L[0] * L[0] + L[1] * L[1]) + L[2] * L[2];
+    const double Ln = sqrt(L2);
+    // E1 = |L| (L x a) / |L x a| with a = the coordinate axis L leans on least; E2 = L x E1 / |L|
+    const double ax = fabs(L[0]), ay = fabs(L[1]), az = fabs(L[2]);
+    const int i0 = (ax <= ay && ax <= az) ? 0 : (ay <= az ? 1 : 2);
+    const double a[3] = {i0 == 0 ? 1.0 : 0.0, i0 == 1 ? 1.0 : 0.0, i0 == 2 ? 1.0 : 0.0};
+    double v[3] = {L[1] * a[2] - L[2] * a[1], L[2] * a[0] - L[0] * a[2], L[0] * a[1] - L[1] * a[0]};
+    const double vn = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    const double E1[3] = {v[0] / vn * Ln, v[1] / vn * Ln, v[2] / vn * Ln};
+    const double E2[3] = {(L[1] * E1[2] - L[2] * E1[1]) / Ln, (L[2] * E1[0] - L[0] * E1[2]) / Ln, (L[0] * E1[1] - L[1] * E1[0]) / Ln};
+    // c' = p1 + ((o - p1) . L / |L|^2) L, relative to o
+    const double s = (((box[0] - rec[0]) * L[0] + (box[1] - rec[1]) * L[1]) + (box[2] - rec[2]) * L[2]) / L2;
+    const double c[3] = {(rec[0] + s * L[0]) - box[0], (rec[1] + s * L[1]) - box[1], (rec[2] + s * L[2]) - box[2]};
+    const double D1 = -((E1[0] * c[0] + E1[1] * c[1]) + E1[2] * c[2]);
+    const double D2 = -((E2[0] * c[0] + E2[1] * c[1]) + E2[2] * c[2]);
+    const double M1 = ((fabs(E1[0]) * box[3] + fabs(E1[1]) * box[4]) + fabs(E1[2]) * box[5]) + fabs(D1);
+    const double M2 = ((fabs(E2[0]) * box[3] + fabs(E2[1]) * box[4]) + fabs(E2[2]) * box[5]) + fabs(D2);
+    const double M = fmax(M1, M2);
+    const double Wl = fmax(fmax(box[3] + fabs(c[0]), box[4] + fabs(c[1])), box[5] + fabs(c[2]));
+    const double Wa = max_abs + fmax(fmax(fabs(rec[0]), fabs(rec[1])), fabs(rec[2]));
+    const double Wb = max_abs + fmax(fmax(fabs(rec[3]), fabs(rec[4])), fabs(rec[5]));
+    const double Wm = fmax(Wa, Wb);
+    const double G = Wm * Wm;
+    const double LW = Ln * Wl;
+    const bool ok = (lo <= hi) && (lo >= 0.0) && (hi < 1e36) && (L2 > 0.0) && (vn > 0.0) && (M < 1e9) && (LW < 1e9) &&
+                    (G < 1e15) && (fabs(s) < 1e15);
+    const double mid = 0.5 * lo + 0.5 * hi, half = 0.5 * hi - 0.5 * lo;
+    const double Et = ((32.0 * kU32 * (M * M) + 4.0 * kU32 * mid) + (1e-13 * (LW * LW) + 5e-14 * (2.0 * LW) * G + 1e-27 * (G * G))) +
+                      1e-30 * (M + 1.0);
+    const double h = ((Et + kU32 * half) + 1e-15 * (mid + half)) * 1.001;
+    out[0] = ok ? (float)E1[0] : 0.0f;
+    out[1] = ok ? (float)E1[1] : 0.0f;
+    out[2] = ok ? (float)E1[2] : 0.0f;
+    out[3] = ok ? (float)D1 : 0.0f;
+    out[4] = ok ? (float)E2[0] : 0.0f;
+    out[5] = ok ? (float)E2[1] : 0.0f;
+    out[6] = ok ? (float)E2[2] : 0.0f;
+    out[7] = ok ? (float)D2 : 0.0f;
+    out[8] = ok ? (float)mid : 0.0f;
+    out[9] = ok ? (float)half : 0.0f;
+    out[10] = ok ? f32_round_up_pos(h > 1e-30 ? h : 1e-30) : f32_nan();
+    out[11] = 0.0f;
 }
 
 }  // namespace m3d

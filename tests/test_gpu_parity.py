@@ -366,10 +366,10 @@ def test_perfect_fit_stops_probability_one_loop(capi, orc, max_iter):
         assert np.allclose(g.params, o.params, rtol=0, atol=1e-9)
 
 
-def _screen_case(capi, orc, kind, pts, thr, samples, min_exact=None, max_exact_frac=None):
-    """counts of the screened scoring == oracle == unscreened scoring; returns (pairs, pairs recounted in fp64)"""
-    ov, om, oc, _ = orc.score_samples(kind, pts, None, thr, samples.astype(np.uint64))
-    with capi.Cloud(pts) as c:
+def _screen_case(capi, orc, kind, pts, thr, samples, nrm=None):
+    """counts of the screened scoring == oracle == unscreened scoring"""
+    ov, om, oc, _ = orc.score_samples(kind, pts, nrm, thr, samples.astype(np.uint64))
+    with capi.Cloud(pts, nrm) as c:
         valid, models, counts = c.score_range(kind, thr, samples)
         old = capi.set_config(score_fp32_screen=0)
         try:
@@ -411,13 +411,32 @@ def test_fp32_screen_points_at_the_cut_off(capi, orc):
     samples = np.concatenate([np.array([[0, 1, 2, 3]], dtype=np.uint32), capi.draw_samples(len(pts), 1, 63, seed=9)])
     for shift in (0.0, 25.0):
         _screen_case(capi, orc, 1, pts + shift, thr, samples)
+    # cylinder: radial offsets around r +- thr from the axis through a along dirn; the first two points + normals
+    # give MinimalFit exactly that axis (ransac.h:354-417: the normals of two surface points meet on it)
+    r = 0.25
+    a = np.array([0.1, 0.2, 0.3])
+    dirn = np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0)
+    e1 = np.cross(dirn, [0.0, 0.0, 1.0])
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(dirn, e1)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    along = rng.uniform(-1, 1, n)
+    radial = np.cos(ang)[:, None] * e1 + np.sin(ang)[:, None] * e2
+    rad = r + np.where(rng.random(n) < 0.5, 1.0, -1.0) * thr * (1.0 + rel)
+    cyl = a + along[:, None] * dirn + rad[:, None] * radial
+    first = a + np.array([[-0.5], [0.7]]) * dirn + r * np.stack([e1, e2])
+    pts = np.concatenate([first, cyl])
+    nrm = np.concatenate([np.stack([e1, e2]), radial])
+    samples = np.concatenate([np.array([[0, 1]], dtype=np.uint32), capi.draw_samples(len(pts), 2, 63, seed=10)])
+    for shift in (0.0, 25.0):
+        _screen_case(capi, orc, 2, pts + shift, thr, samples, nrm)
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2])
 def test_fp32_screen_unscreenable_inputs(capi, orc, kind):
     """Inputs the fp32 pass cannot represent go to the exact code, pair by pair or tile by tile: non-finite points,
     coordinates beyond the fp32 range, thresholds below the rounding bound, degenerate thresholds."""
-    pts, _ = _clouds(kind, 5000, seed=70 + kind)
+    pts, nrm = _clouds(kind, 5000, seed=70 + kind)
     samples = capi.draw_samples(len(pts), kind, 128, seed=4)
     bad = pts.copy()
     bad[17] = [np.nan, 0.0, 0.0]
@@ -428,12 +447,12 @@ def test_fp32_screen_unscreenable_inputs(capi, orc, kind):
     ok_rows = np.ones(len(pts), bool)
     ok_rows[[17, 600, 601, 1300, 2900]] = False
     smp = samples[np.all(ok_rows[samples], axis=1)]
-    _screen_case(capi, orc, kind, bad, 0.01, smp)
-    _screen_case(capi, orc, kind, pts, 1e-9, samples)        # threshold far below the fp32 bound
-    _screen_case(capi, orc, kind, pts, 1e-300, samples)
-    _screen_case(capi, orc, kind, pts, 1e6, samples)         # everything is an inlier
-    _screen_case(capi, orc, kind, pts * 1e-25, 1e-27, samples)   # fp32 denormal territory for the squares
-    _screen_case(capi, orc, kind, pts * 1e20, 1e18, samples)     # squares overflow fp32
+    _screen_case(capi, orc, kind, bad, 0.01, smp, nrm)
+    _screen_case(capi, orc, kind, pts, 1e-9, samples, nrm)        # threshold far below the fp32 bound
+    _screen_case(capi, orc, kind, pts, 1e-300, samples, nrm)
+    _screen_case(capi, orc, kind, pts, 1e6, samples, nrm)         # everything is an inlier
+    _screen_case(capi, orc, kind, pts * 1e-25, 1e-27, samples, nrm)   # fp32 denormal territory for the squares
+    _screen_case(capi, orc, kind, pts * 1e20, 1e18, samples, nrm)     # squares overflow fp32
 
 
 def test_fp32_screen_recount_rate(capi):
