@@ -376,7 +376,9 @@ typedef struct m3d_config {
     int32_t reg_sorted_lists;       /* [M3D_REG_SORTED=0]   default 1: x-sorted neighbour lists, side columns cut off by the x-distance */
     int32_t score_fp32_screen;      /* [M3D_SCORE_SCREEN=0] default 1: planes and spheres are counted by score_screen_k (packed-fp32 screen with a
                                        rounding bound in front of the exact fp64 test: identical counts); 0: fp64 only (score_mask_k) */
-    int32_t reserved[7];            /* zero */
+    int32_t cull_fp32;              /* [M3D_CULL_FP32=0]    default 1: the box tests of the culled path run in fp32 with outward-rounded margins
+                                       (cull_tiles32_k: conservative, identical results); 0: fp64 box tests (cull_tiles_k) */
+    int32_t reserved[6];            /* zero */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -32,13 +32,15 @@
 
 namespace m3d {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------------------------------------
 // tile boxes: one wave per tile; NaN padding is ignored (fmin/fmax drop NaN); an empty tile gets a
 // negative half-extent, which the box test treats as "never intersects".
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ sx, const double* __restrict__ sy,
                                                      const double* __restrict__ sz, uint32_t n_tiles,
-                                                     double* __restrict__ boxes) {
+                                                     double* __restrict__ boxes, double ox, double oy, double oz) {
     const int lane = threadIdx.x & 63;
     const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
@@ -66,11 +68,22 @@ __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ s
             b[3 + k] = empty ? -1.0 : fmax(hi[k] - c, c - lo[k]) * (1.0 + 1e-12) + 1e-300;
         }
         b[6] = b[7] = 0.0;
+        // the same box in fp32, relative to the cloud's origin (cull_tiles32_k): centre rounded to nearest, half extents
+        // enlarged by the rounding of the centre and rounded outwards, so that the fp32 box contains the fp64 one
+        float* f = reinterpret_cast<float*>(b + 8);
+        const double o[3] = {ox, oy, oz};
+        for (int k = 0; k < 3; ++k) {
+            const double cr = b[k] - o[k];
+            const float c32 = (float)cr;
+            const double hh = (b[3 + k] + fabs(cr - (double)c32)) * (1.0 + 1e-6) + 1e-30;
+            f[k] = empty ? 0.0f : c32;
+            f[3 + k] = empty ? -1.0f : f32_round_up(hh);
+        }
     }
 }
 
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st) {
-    if (s.n_tiles) tile_boxes_k<<<(s.n_tiles + 3) / 4, 256, 0, st>>>(s.x, s.y, s.z, s.n_tiles, boxes);
+    if (s.n_tiles) tile_boxes_k<<<(s.n_tiles + 3) / 4, 256, 0, st>>>(s.x, s.y, s.z, s.n_tiles, boxes, s.origin[0], s.origin[1], s.origin[2]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -175,9 +188,109 @@ __global__ __launch_bounds__(64) void cull_tiles_k(const double* __restrict__ bo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// cull_tiles32_k: the box tests in fp32 (records and margins: m3d_fp.hpp, "fp32 records of the BOX tests").
+// Same decomposition as cull_tiles_k -- lane = tile, its fp32 box (relative to the cloud's origin) in six VGPRs, the
+// hypothesis records through scalar loads -- but TWO hypotheses per packed instruction (the records are stored
+// pairwise interleaved, so a scalar load delivers the operand pairs), the test value's SIGN BIT is the verdict
+// (negative = dropped; v_alignbit shifts it into the lane's mask word, no compare / select), and no fp64 sqrt or
+// divide for the cylinder.  Plane: 6 v_pk_fma per pair of hypotheses + 2 v_sub + 2 v_alignbit + the ballots of the
+// per-hypothesis tile count = ~9 VALU instructions per hypothesis against ~43 of the fp64 kernel.
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ void cull32_pair(const float* __restrict__ rp /* 24 floats, wave-uniform */, float bx, float by,
+                                            float bz, float hx, float hy, float hz, float rb, float& ta, float& tb) {
+    const f32x2 BX = {bx, bx}, BY = {by, by}, BZ = {bz, bz};
+    if (KIND == 0) {
+        const f32x2 A = {rp[0], rp[1]}, B = {rp[2], rp[3]}, C = {rp[4], rp[5]}, D = {rp[6], rp[7]};
+        const f32x2 AA = {rp[8], rp[9]}, AB = {rp[10], rp[11]}, AC = {rp[12], rp[13]}, K = {rp[14], rp[15]};
+        const f32x2 HX = {hx, hx}, HY = {hy, hy}, HZ = {hz, hz};
+        const f32x2 s = __builtin_elementwise_fma(A, BX, __builtin_elementwise_fma(B, BY, __builtin_elementwise_fma(C, BZ, D)));
+        const f32x2 r = __builtin_elementwise_fma(AA, HX, __builtin_elementwise_fma(AB, HY, __builtin_elementwise_fma(AC, HZ, K)));
+        ta = r.x - __builtin_fabsf(s.x);
+        tb = r.y - __builtin_fabsf(s.y);
+    } else if (KIND == 1) {
+        // dmin^2 / dmax^2 of the box to the centre, per hypothesis (no packed abs / max: plain VALU)
+        auto one = [&](int i) -> float {
+            const float dx = __builtin_fabsf(rp[0 + i] - bx), dy = __builtin_fabsf(rp[2 + i] - by), dz = __builtin_fabsf(rp[4 + i] - bz);
+            const float nx = __builtin_fmaxf(0.0f, dx - hx), ny = __builtin_fmaxf(0.0f, dy - hy), nz = __builtin_fmaxf(0.0f, dz - hz);
+            const float fx = dx + hx, fy = dy + hy, fz = dz + hz;
+            const float dmin2 = __builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx));
+            const float dmax2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+            const float t1 = dmax2 - rp[6 + i], t2 = rp[8 + i] - dmin2;   // loM, hiM
+            return __uint_as_float(__float_as_uint(t1) | __float_as_uint(t2));   // negative if either is
+        };
+        ta = one(0);
+        tb = one(1);
+    } else {
+        const f32x2 E1X = {rp[0], rp[1]}, E1Y = {rp[2], rp[3]}, E1Z = {rp[4], rp[5]}, D1 = {rp[6], rp[7]};
+        const f32x2 E2X = {rp[8], rp[9]}, E2Y = {rp[10], rp[11]}, E2Z = {rp[12], rp[13]}, D2 = {rp[14], rp[15]};
+        const f32x2 d1 = __builtin_elementwise_fma(E1X, BX, __builtin_elementwise_fma(E1Y, BY, __builtin_elementwise_fma(E1Z, BZ, D1)));
+        const f32x2 d2 = __builtin_elementwise_fma(E2X, BX, __builtin_elementwise_fma(E2Y, BY, __builtin_elementwise_fma(E2Z, BZ, D2)));
+        const f32x2 tt = __builtin_elementwise_fma(d2, d2, d1 * d1);
+        auto one = [&](float t, int i) -> float {
+            const float dist = __builtin_sqrtf(t);
+            const float rt = rp[16 + i] * rb;                  // |L| x the box's bounding radius
+            const float t1 = (rp[18 + i] + rt) - dist;          // sHiM
+            const float t2 = (dist + rt) - rp[20 + i];          // sLoM
+            return __uint_as_float(__float_as_uint(t1) | __float_as_uint(t2));
+        };
+        ta = one(tt.x, 0);
+        tb = one(tt.y, 1);
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void cull_tiles32_k(const double* __restrict__ boxes, uint32_t n_tiles,
+                                                      const float* __restrict__ cull32, uint32_t n_groups,
+                                                      uint32_t groups_per_wave, unsigned long long* __restrict__ masks,
+                                                      uint32_t* __restrict__ ub, uint32_t group_begin, uint32_t group_end) {
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x * 64u + (uint32_t)lane;
+    const bool tile_ok = tile < n_tiles;
+    float bx = 0.0f, by = 0.0f, bz = 0.0f, hx = -1.0f, hy = -1.0f, hz = -1.0f;
+    if (tile_ok) {
+        const float* __restrict__ f = reinterpret_cast<const float*>(boxes + (size_t)tile * kBoxStride + 8);
+        bx = f[0];
+        by = f[1];
+        bz = f[2];
+        hx = f[3];
+        hy = f[4];
+        hz = f[5];
+    }
+    const bool live = tile_ok && hx >= 0.0f;   // (hx < 0: empty tile)
+    const unsigned long long live_mask = __ballot(live);
+    if (!live) hx = hy = hz = 0.0f;
+    // bounding radius of the box, rounded outwards (cylinder)
+    const float rb = __builtin_sqrtf(__builtin_fmaf(hz, hz, __builtin_fmaf(hy, hy, hx * hx))) * 1.000001f;
+    const uint32_t g0 = group_begin + blockIdx.y * groups_per_wave;
+    const uint32_t g1 = min(group_end, g0 + groups_per_wave);
+    for (uint32_t g = g0; g < g1; ++g) {
+        uint32_t w[2] = {0u, 0u}, ubv = 0u;
+        const float* __restrict__ rp = cull32 + (size_t)g * 32u * 24u;   // 32 pairs of hypotheses
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t drop = 0u;   // bit (31 - b): hypothesis half * 32 + b dropped this lane's tile
+            for (uint32_t b = 0; b < 32u; b += 2u) {
+                const uint32_t hh = (uint32_t)half * 32u + b;
+                float ta, tb;
+                cull32_pair<KIND>(rp + (size_t)(hh >> 1) * 24u, bx, by, bz, hx, hy, hz, rb, ta, tb);
+                drop = __builtin_amdgcn_alignbit(drop, __float_as_uint(ta), 31);
+                drop = __builtin_amdgcn_alignbit(drop, __float_as_uint(tb), 31);
+                const unsigned long long ma = __ballot(!(ta < 0.0f)) & live_mask, mb = __ballot(!(tb < 0.0f)) & live_mask;
+                ubv = ((uint32_t)lane == hh) ? (uint32_t)__popcll(ma) : ubv;
+                ubv = ((uint32_t)lane == hh + 1u) ? (uint32_t)__popcll(mb) : ubv;
+            }
+            w[half] = ~__builtin_bitreverse32(drop);
+        }
+        if (tile_ok) masks[(size_t)tile * n_groups + g] = live ? (((unsigned long long)w[1] << 32) | w[0]) : 0ull;
+        if (ub && ubv) atomicAdd(&ub[g * 64u + (uint32_t)lane], ubv);
+    }
+}
+
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
                       uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st, bool ub_is_zero,
-                      uint32_t group_begin, uint32_t group_end) {
+                      uint32_t group_begin, uint32_t group_end, const float* cull32) {
     (void)valid;     // (invalid and padding hypotheses are "no inlier" records)
     (void)h_count;
     group_end = std::min(group_end, n_groups);
@@ -189,6 +302,15 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
     uint32_t gpw = std::max<uint32_t>(1, (uint32_t)(((uint64_t)tblocks * window) / 8192));
     gpw = std::min<uint32_t>(gpw, 8);
     const dim3 g(tblocks, (window + gpw - 1) / gpw), b(64);
+    if (cull32 && s.radius < 1e18 && config().cull_fp32 != 0) {
+        if (kind == 0)
+            cull_tiles32_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end);
+        else if (kind == 1)
+            cull_tiles32_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end);
+        else
+            cull_tiles32_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end);
+        return;
+    }
     if (kind == 0)
         cull_tiles_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, score, n_groups, gpw, masks, ub, group_begin, group_end);
     else if (kind == 1)
@@ -423,7 +545,6 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
 //     atomic, as before.
 // A tile with a non-finite coordinate (the NaN padding of the last tile, or the caller's own) is never screened.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr uint32_t kScreenMaxGroups = 16;   // 64-hypothesis groups per workgroup (the id list: 2 KB of LDS)
 constexpr int kCntStride = 64;              // bytes per row of the count table
 

@@ -5,7 +5,9 @@
 namespace m3d {
 
 constexpr int kTilePoints = 512;      // points per tile = one wave x 8 rows of 64 (kept in VGPRs)
-constexpr int kBoxStride = 8;         // doubles per tile box record (centre xyz, half extents xyz, 2 pad)
+constexpr int kBoxStride = 12;        // doubles per tile box record: centre xyz, half extents xyz, 2 pad, then SIX FLOATS (doubles 8..10):
+                                      // the same box relative to SortedView::origin, half extents rounded outwards (cull_tiles32_k)
+constexpr int kCull32Stride = 12;     // floats per fp32 box-test record of a hypothesis (minimal_fit_k -> cull_tiles32_k)
 constexpr uint32_t kGroupsPerBlock = 8;  // 64-hypothesis groups per score_mask_k workgroup (<= 64)
 
 // Hilbert-sorted copy of a resident cloud: SoA padded with NaN to a multiple of kTilePoints, plus one
@@ -17,6 +19,10 @@ struct SortedView {
     const double* boxes;  // n_tiles x kBoxStride
     uint32_t n_tiles;
     double max_abs = __builtin_inf();  // >= |coordinate| of every point of the cloud (the box tests' rounding margin); inf = unknown (nothing culled)
+    // centre of the cloud's bounding box and the largest |coordinate - origin| (fp32 box tests work relative to it);
+    // radius = inf: unknown, the fp64 box tests are used
+    double origin[3] = {0.0, 0.0, 0.0};
+    double radius = __builtin_inf();
 };
 
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
@@ -26,7 +32,9 @@ void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
                       uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st,
                       bool ub_is_zero = false, uint32_t group_begin = 0,
-                      uint32_t group_end = 0xFFFFFFFFu /* only groups [group_begin, group_end) of the chunk (sharded fits) */);
+                      uint32_t group_end = 0xFFFFFFFFu /* only groups [group_begin, group_end) of the chunk (sharded fits) */,
+                      const float* cull32 = nullptr /* minimal_fit_k's fp32 box-test records (kCull32Stride floats per
+                                                       hypothesis): cull_tiles32_k instead of the fp64 tests (m3d_config.cull_fp32) */);
 // keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
 // zero_counts_rep != null: the same launch clears the kCountReplicas x rep_stride + kPairReplicas counter words.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,

@@ -232,6 +232,8 @@ m3d::SortedView m3d_cloud::sorted() const {
     s.boxes = boxes.as<double>();
     s.n_tiles = n_tiles;
     s.max_abs = max_abs;
+    for (int k = 0; k < 3; ++k) s.origin[k] = origin[k];
+    s.radius = radius;
     return s;
 }
 
@@ -434,6 +436,14 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     RESERVE(s.score, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
     RESERVE(s.params, sizeof(double) * kModelStride * ((size_t)h_pad + 1));
     RESERVE(s.valid, (size_t)h_pad + 1);
+    Cull32Out c32;
+    const bool cull32 = !dense && config().cull_fp32 != 0 && sv.radius < 1e18;
+    if (cull32) {
+        RESERVE(s.cull32, sizeof(float) * 24 * ((size_t)h_pad / 2 + 1));
+        c32.out = s.cull32.as<float>();
+        for (int k = 0; k < 3; ++k) c32.origin[k] = sv.origin[k];
+        c32.radius = sv.radius;
+    }
     if (dense || device_records) RESERVE(s.counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // (culled path: records go straight to h_counts)
     uint32_t* rec_dev = (!dense && device_records) ? s.counts.as<uint32_t>() : nullptr;
     RESERVE(s.h_samples, sizeof(uint32_t) * (size_t)count * m);
@@ -468,7 +478,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
                        (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
-                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr, lead_prepared ? &lp : nullptr, sv.max_abs);
+                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr, lead_prepared ? &lp : nullptr, sv.max_abs,
+                       cull32 ? &c32 : nullptr);
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     // (culled path: keep_mask_k clears the counter replicas on its way)
@@ -511,9 +522,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         if (own_real) {
             if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
                 launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
-                                 ctx->stream, /*ub_is_zero=*/true, 0, ga);
+                                 ctx->stream, /*ub_is_zero=*/true, 0, ga, c32.out);
             launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
-                             /*ub_is_zero=*/true, g0, g1);
+                             /*ub_is_zero=*/true, g0, g1, c32.out);
             uint32_t g_lo = g0;
             if (ga) {
                 s.lead_groups = ga;
@@ -1572,6 +1583,13 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
                     double m = 0.0;
                     for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
                     c->max_abs = m;   // (stays +inf when something is off: the box tests then keep every tile)
+                    double r = 0.0;
+                    for (int k = 0; k < 3; ++k) {
+                        c->origin[k] = 0.5 * lo[k] + 0.5 * hi[k];
+                        r = std::max(r, std::max(hi[k] - c->origin[k], c->origin[k] - lo[k]));
+                    }
+                    if (std::isfinite(r) && std::isfinite(c->origin[0]) && std::isfinite(c->origin[1]) && std::isfinite(c->origin[2]))
+                        c->radius = r * (1.0 + 1e-12);   // (stays +inf otherwise: fp64 box tests)
                 }
             }
         }
@@ -1986,7 +2004,9 @@ int m3d_bench_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     RESERVE(ctx->small, 256);
     auto* masks = ctx->masks.as<unsigned long long>();
     auto* keep = ctx->keep.as<unsigned long long>();
-    launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, nullptr, ctx->stream);
+    const float* c32 = (!use_dense_scoring() && config().cull_fp32 != 0 && sv.radius < 1e18) ? s.cull32.as<float>() : nullptr;
+    launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, nullptr, ctx->stream, false, 0,
+                     0xFFFFFFFFu, c32);
     launch_keep_mask(nullptr, nullptr, n_groups, keep, ctx->stream);
     if (listed_pairs) {
         launch_count_bits(masks, keep, sv.n_tiles, n_groups, ctx->small.as<unsigned long long>(), ctx->stream);
@@ -2003,7 +2023,7 @@ int m3d_bench_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
                               s.h_pad, ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * s.h_pad, ctx->stream);
         else if (mode == 1)
             launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, nullptr,
-                             ctx->stream);
+                             ctx->stream, false, 0, 0xFFFFFFFFu, c32);
         else
             launch_score(kind, v, s.score.as<double>(), s.h_pad, splits, ctx->partial.as<uint32_t>(), ctx->stream);
     }

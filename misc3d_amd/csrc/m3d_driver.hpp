@@ -50,6 +50,7 @@ struct PinBuf {
 // the previous one).
 struct ChunkSlot {
     DevBuf samples, score, params, valid, counts;
+    DevBuf cull32;   // fp32 records of the box tests (cull_tiles32_k), pairwise interleaved
     PinBuf h_samples, h_counts, h_valid;
     hipEvent_t done = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the scoring kernel of the chunk (m3d_stats.ms_score_kernel)
@@ -107,6 +108,8 @@ struct m3d_cloud {
     m3d::DevBuf sx, sy, sz, boxes;
     uint32_t n_sorted = 0, n_tiles = 0;
     double max_abs = __builtin_inf();   // largest |coordinate| of the finite points (SortedView::max_abs)
+    double origin[3] = {0.0, 0.0, 0.0};   // centre of the bounding box of the finite points (SortedView::origin)
+    double radius = __builtin_inf();    // largest |coordinate - origin| (inf: unknown -> fp64 box tests)
     // In-place shrinking (m3d_cloud_remove_inliers = SelectByIndex(inliers, invert), the tail of a
     // SegmentPlaneIterative round).  x/y/z above always hold the cloud AS CREATED (n0 points): index lists
     // and GeneralFit gathers refer to it through `orig`.  Once shrunk, n / n_pad / n_sorted / n_tiles and

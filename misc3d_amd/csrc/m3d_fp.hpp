@@ -499,19 +499,29 @@ M3D_HD void sphere_screen_record(const double* rec, const double* box, double ma
 // (First version: t = |L x (q - c')|^2 from the rounded differences, 15 packed instructions per two points and a bound
 // of 200 u (|L| W_l)^2 -- 2.8 % of the pairs of the C3 fit went back to the exact code; this form: 11 and a sixth of it.)
 // out = (E1x, E1y, E1z, D1, E2x, E2y, E2z, D2, mid, half, h, -)
-M3D_HD void cylinder_screen_record(const double* rec, const double* box, double max_abs, float* out) {
-    const double lo = rec[6], hi = rec[7];
-    const double L[3] = {rec[3] - rec[0], rec[4] - rec[1], rec[5] - rec[2]};
+// L = p2 - p1, Ln = |L|, E1 = |L| (L x a) / |L x a| with a = the coordinate axis L leans on least, E2 = L x E1 / |L|;
+// *vn = |L x a| (0: no axis)
+M3D_HD void cylinder_frame(const double* rec, double* L, double* Ln, double* E1, double* E2, double* vn) {
+    L[0] = rec[3] - rec[0];
+    L[1] = rec[4] - rec[1];
+    L[2] = rec[5] - rec[2];
     const double L2 = (L[0] * L[0] + L[1] * L[1]) + L[2] * L[2];
-    const double Ln = sqrt(L2);
-    // E1 = |L| (L x a) / |L x a| with a = the coordinate axis L leans on least; E2 = L x E1 / |L|
+    *Ln = sqrt(L2);
     const double ax = fabs(L[0]), ay = fabs(L[1]), az = fabs(L[2]);
     const int i0 = (ax <= ay && ax <= az) ? 0 : (ay <= az ? 1 : 2);
     const double a[3] = {i0 == 0 ? 1.0 : 0.0, i0 == 1 ? 1.0 : 0.0, i0 == 2 ? 1.0 : 0.0};
-    double v[3] = {L[1] * a[2] - L[2] * a[1], L[2] * a[0] - L[0] * a[2], L[0] * a[1] - L[1] * a[0]};
-    const double vn = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
-    const double E1[3] = {v[0] / vn * Ln, v[1] / vn * Ln, v[2] / vn * Ln};
-    const double E2[3] = {(L[1] * E1[2] - L[2] * E1[1]) / Ln, (L[2] * E1[0] - L[0] * E1[2]) / Ln, (L[0] * E1[1] - L[1] * E1[0]) / Ln};
+    const double v[3] = {L[1] * a[2] - L[2] * a[1], L[2] * a[0] - L[0] * a[2], L[0] * a[1] - L[1] * a[0]};
+    *vn = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    for (int k = 0; k < 3; ++k) E1[k] = v[k] / *vn * *Ln;
+    E2[0] = (L[1] * E1[2] - L[2] * E1[1]) / *Ln;
+    E2[1] = (L[2] * E1[0] - L[0] * E1[2]) / *Ln;
+    E2[2] = (L[0] * E1[1] - L[1] * E1[0]) / *Ln;
+}
+M3D_HD void cylinder_screen_record(const double* rec, const double* box, double max_abs, float* out) {
+    const double lo = rec[6], hi = rec[7];
+    double L[3], Ln, E1[3], E2[3], vn;
+    cylinder_frame(rec, L, &Ln, E1, E2, &vn);
+    const double L2 = Ln * Ln;
     // c' = p1 + ((o - p1) . L / |L|^2) L, relative to o
     const double s = (((box[0] - rec[0]) * L[0] + (box[1] - rec[1]) * L[1]) + (box[2] - rec[2]) * L[2]) / L2;
     const double c[3] = {(rec[0] + s * L[0]) - box[0], (rec[1] + s * L[1]) - box[1], (rec[2] + s * L[2]) - box[2]};
@@ -544,6 +554,131 @@ M3D_HD void cylinder_screen_record(const double* rec, const double* box, double 
     out[9] = ok ? (float)half : 0.0f;
     out[10] = ok ? f32_round_up_pos(h > 1e-30 ? h : 1e-30) : f32_nan();
     out[11] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 records of the BOX tests (cull_tiles32_k).  The box tests only have to be conservative -- a tile is dropped
+// when it provably holds no inlier of the exact fp64 test -- so they can run in fp32 (two hypotheses per packed
+// instruction, no fp64 sqrt / divide for the cylinder) as long as every rounding goes into the margin.  Coordinates are
+// taken relative to the centre O of the cloud's bounding box (R = largest |coordinate - O|): tile_boxes_k stores each
+// box as fp32 (centre, half extents rounded OUTWARDS so that the fp32 box contains the fp64 one).
+// A tile is dropped when the test value is NEGATIVE (its sign bit is what the kernel collects):
+//   plane     (r + K) - |s|,  s = a bx + b by + c bz + d' (d' = the model's value at O), r = |a| hx + |b| hy + |c| hz,
+//             K = the fp64 box test's cut-off + 10 u M' (M' = (|a| + |b| + |c|) R + |d'|: five roundings on s, four on r)
+//   sphere    dmax2 - loM  or  hiM - dmin2,  loM = lo - E, hiM = hi + E, E = 40 u W^2, W = max |c - O| + R
+//   cylinder  (sHiM + Rt) - dist  or  (dist + Rt) - sLoM,  dist = sqrt(d1^2 + d2^2) with the two plane values of
+//             cylinder_screen_record taken at the box centre, Rt = |L| x the box's bounding radius, sHiM / sLoM =
+//             sqrt(t_hi + slack) + E_d / sqrt(t_lo - slack) - E_d, E_d = 24 u M', slack = the exact code's own fp64 rounding.
+// "No inlier" records drop every tile (K = -inf ...); records with non-finite or huge values keep every tile.
+// Records are stored PAIRWISE interleaved (hypotheses 2 j and 2 j + 1: v0 v0' v1 v1' ...) so that one scalar load
+// delivers the operand pairs of the packed instructions.
+// ------------------------------------------------------------------------------------------------
+M3D_HD float f32_inf() {
+    const uint32_t b = 0x7F800000u;
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+M3D_HD float f32_round_down(double v) {   // largest float <= v (finite v)
+    float f = (float)v;
+    if ((double)f > v) {
+        uint32_t b;
+        __builtin_memcpy(&b, &f, 4);
+        if (f > 0.0f) --b;
+        else if (f < 0.0f) ++b;
+        else b = 0x80000001u;   // below +0: the smallest negative denormal
+        __builtin_memcpy(&f, &b, 4);
+    }
+    return f;
+}
+M3D_HD float f32_round_up(double v) { return -f32_round_down(-v); }
+// plane: (a, b, c, d', |a|, |b|, |c|, K)
+M3D_HD void plane_cull32_record(const double* rec, bool valid, const double* o, double radius, double max_abs, float* out) {
+    for (int k = 0; k < 12; ++k) out[k] = 0.0f;
+    const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4], cutB = rec[5];
+    if (!valid || !(T > 0.0)) {
+        out[7] = -f32_inf();
+        return;
+    }
+    const double dp = ((a * o[0] + b * o[1]) + c * o[2]) + d;
+    const double sa = (fabs(a) + fabs(b)) + fabs(c);
+    const double Mp = sa * radius + fabs(dp), Mg = sa * max_abs + fabs(d);
+    const double K = cutB + ((10.0 * kU32 * Mp + 1e-15 * Mg) + 1e-36 * (sa + 1.0));
+    if (!(Mp < 1e18) || !(sa < 1e18) || !(radius < 1e18) || !(K < 1e30)) {   // (also NaN)
+        out[7] = f32_inf();
+        return;
+    }
+    out[0] = (float)a;
+    out[1] = (float)b;
+    out[2] = (float)c;
+    out[3] = (float)dp;
+    out[4] = fabsf(out[0]);
+    out[5] = fabsf(out[1]);
+    out[6] = fabsf(out[2]);
+    out[7] = f32_round_up(K);
+}
+// sphere: (c'x, c'y, c'z, loM, hiM)
+M3D_HD void sphere_cull32_record(const double* rec, bool valid, const double* o, double radius, double max_abs, float* out) {
+    for (int k = 0; k < 12; ++k) out[k] = 0.0f;
+    const double lo = rec[3], hi = rec[4];
+    if (!valid || !(lo <= hi)) {
+        out[3] = f32_inf();
+        out[4] = -f32_inf();
+        return;
+    }
+    const double c[3] = {rec[0] - o[0], rec[1] - o[1], rec[2] - o[2]};
+    const double W = fmax(fmax(fabs(c[0]), fabs(c[1])), fabs(c[2])) + radius;
+    const double Wg = max_abs + fmax(fmax(fabs(rec[0]), fabs(rec[1])), fabs(rec[2]));
+    const double E = 40.0 * kU32 * (W * W) + 1e-14 * (W * Wg);
+    if (!(W < 1e18) || !(Wg < 1e18) || !(hi < 1e36)) {
+        out[3] = -f32_inf();
+        out[4] = f32_inf();
+        return;
+    }
+    out[0] = (float)c[0];
+    out[1] = (float)c[1];
+    out[2] = (float)c[2];
+    out[3] = f32_round_down(lo - E);
+    out[4] = f32_round_up(hi + E);
+}
+// cylinder: (E1x, E1y, E1z, D1', E2x, E2y, E2z, D2', Ln, sHiM, sLoM)
+M3D_HD void cylinder_cull32_record(const double* rec, bool valid, const double* o, double radius, double max_abs, float* out) {
+    for (int k = 0; k < 12; ++k) out[k] = 0.0f;
+    const double lo = rec[6], hi = rec[7];
+    if (!valid || !(lo <= hi)) {
+        out[9] = -f32_inf();
+        out[10] = -f32_inf();
+        return;
+    }
+    double L[3], Ln, E1[3], E2[3], vn;
+    cylinder_frame(rec, L, &Ln, E1, E2, &vn);
+    const double q[3] = {o[0] - rec[0], o[1] - rec[1], o[2] - rec[2]};
+    const double D1 = (E1[0] * q[0] + E1[1] * q[1]) + E1[2] * q[2];
+    const double D2 = (E2[0] * q[0] + E2[1] * q[1]) + E2[2] * q[2];
+    const double M1 = ((fabs(E1[0]) + fabs(E1[1])) + fabs(E1[2])) * radius + fabs(D1);
+    const double M2 = ((fabs(E2[0]) + fabs(E2[1])) + fabs(E2[2])) * radius + fabs(D2);
+    const double M = fmax(M1, M2);
+    const double Wa = max_abs + fmax(fmax(fabs(rec[0]), fabs(rec[1])), fabs(rec[2]));
+    const double Wb = max_abs + fmax(fmax(fabs(rec[3]), fabs(rec[4])), fabs(rec[5]));
+    const double Wm = fmax(Wa, Wb), G = Wm * Wm;
+    const double slack = 5e-14 * (3.0 * M) * G + 1e-27 * (G * G);
+    const double Ed = 24.0 * kU32 * M + 1e-14 * (Ln * Wm);
+    const bool ok = (Ln > 0.0) && (vn > 0.0) && (M < 1e15) && (G < 1e15) && (hi < 1e30) && (radius < 1e18) && (Ln < 1e15);
+    if (!ok) {
+        out[9] = f32_inf();
+        out[10] = -f32_inf();
+        return;
+    }
+    const double tlo = lo - slack > 0.0 ? lo - slack : 0.0;
+    for (int k = 0; k < 3; ++k) {
+        out[k] = (float)E1[k];
+        out[4 + k] = (float)E2[k];
+    }
+    out[3] = (float)D1;
+    out[7] = (float)D2;
+    out[8] = f32_round_up(Ln * (1.0 + 1e-6));
+    out[9] = f32_round_up(sqrt(hi + slack) * (1.0 + 1e-12) + Ed);
+    out[10] = f32_round_down(sqrt(tlo) * (1.0 - 1e-12) - Ed);
 }
 
 }  // namespace m3d

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
                                                      double* __restrict__ score,
                                                      double* __restrict__ params,
                                                      uint8_t* __restrict__ valid, uint32_t* __restrict__ zero_u32,
-                                                     uint32_t* __restrict__ zero_one, LeadPrep lead, double cull_max_abs) {
+                                                     uint32_t* __restrict__ zero_one, LeadPrep lead, double cull_max_abs,
+                                                     Cull32Out c32) {
     const uint32_t h = blockIdx.x * 64u + threadIdx.x;
     if (h >= h_pad) return;
     if (zero_u32 && h + 1 < h_pad) zero_u32[h] = 0;   // per-hypothesis counter cleared on the way (saves a memset launch)
@@ -232,21 +233,34 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
         params[(size_t)h * kModelStride + k] = par[k];
     }
     valid[h] = ok ? 1 : 0;
+    if (c32.out) {
+        // fp32 record of the box tests, interleaved with the neighbour's: floats 2 k + (h & 1) of the pair's 24
+        float cr[12];
+        if (KIND == 0) plane_cull32_record(rec, ok, c32.origin, c32.radius, cull_max_abs, cr);
+        else if (KIND == 1) sphere_cull32_record(rec, ok, c32.origin, c32.radius, cull_max_abs, cr);
+        else cylinder_cull32_record(rec, ok, c32.origin, c32.radius, cull_max_abs, cr);
+        float* dst = c32.out + (size_t)(h >> 1) * 24u + (h & 1u);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dst[2 * k] = cr[k];
+    }
 }
 
 void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
-                        hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one, const LeadPrep* lead, double cull_max_abs) {
+                        hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one, const LeadPrep* lead, double cull_max_abs,
+                        const Cull32Out* cull32) {
     if (h_pad == 0) return;
     const dim3 g((h_pad + 63) / 64), b(64);
     LeadPrep lp;
     if (lead) lp = *lead;
+    Cull32Out c32;
+    if (cull32) c32 = *cull32;
     if (kind == 0)
-        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs);
+        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32);
     else if (kind == 1)
-        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs);
+        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32);
     else
-        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs);
+        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -38,6 +38,13 @@ void launch_aos_to_soa(const double* aos, double* x, double* y, double* z, uint3
 // Records in [h_count, h_pad) are filled with "no inlier" cut-offs.
 // Optional extra of launch_minimal_fit on a fit's first chunk: the set-up keep_mask_k would do for the leading hypotheses
 // (keep words all ones, their counter replicas and the launch's n_pair pair counters behind them cleared).
+// Optional output of launch_minimal_fit: the fp32 records of the box tests (cull_tiles32_k; m3d_fp.hpp), relative to
+// the cloud's origin (SortedView::origin / radius), kCull32Stride floats per hypothesis, pairwise interleaved
+struct Cull32Out {
+    float* out = nullptr;
+    double origin[3] = {0.0, 0.0, 0.0};
+    double radius = 0.0;
+};
 struct LeadPrep {
     uint32_t* counts_rep = nullptr;   // n_rep x rep_stride counters, then n_pair pair counters
     unsigned long long* keep = nullptr;
@@ -50,7 +57,8 @@ void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, u
                         uint32_t* zero_one = nullptr /* FOUR more words cleared by the same launch */,
                         const LeadPrep* lead = nullptr,
                         double cull_max_abs = __builtin_inf() /* SortedView::max_abs: the plane record's slot 5 receives the
-                                                                 cut-off of the box tests (inf: nothing is ever culled) */);
+                                                                 cut-off of the box tests (inf: nothing is ever culled) */,
+                        const Cull32Out* cull32 = nullptr);
 
 // K2: inlier counting.  partial[tile * h_pad + h] = number of points of scoring tile `tile` whose
 // distance to hypothesis h is < thr.  h_pad must be a multiple of 64; the hypotheses are cut into
