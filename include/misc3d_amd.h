@@ -201,10 +201,6 @@ typedef struct m3d_reg_stats {
     uint64_t exact_rmse_evals; /* of which needed the serial-order sum of squared distances */
     uint64_t lds_wave_hypotheses;    /* validation work units (64 source points x 1 hypothesis) served from the LDS-staged box */
     uint64_t global_wave_hypotheses; /* ... that took the global-memory path (pose outside the box, or staging off) */
-    uint64_t ref_pairs_fast;         /* (256-point source tile, hypothesis) pairs validated against the candidate lists of a reference pose */
-    uint64_t ref_pairs_all;          /* ... out of this many pairs of the calls that had a reference pose */
-    uint64_t ref_list_entries;       /* size of the last candidate-list array; ref_list_builds: how often it was built */
-    uint64_t ref_list_builds;
 } m3d_reg_stats;
 /* corr_src/corr_dst: m index pairs (the std::pair<vector<size_t>,vector<size_t>> of the reference).
  * confidence: Open3D RANSACConvergenceCriteria::confidence_ (the reference always uses the default
@@ -382,9 +378,7 @@ typedef struct m3d_config {
                                        rounding bound in front of the exact fp64 test: identical counts); 0: fp64 only (score_mask_k) */
     int32_t cull_fp32;              /* [M3D_CULL_FP32=0]    default 1: the box tests of the culled path run in fp32 with outward-rounded margins
                                        (cull_tiles32_k: conservative, identical results); 0: fp64 box tests (cull_tiles_k) */
-    int32_t reg_ref_lists;          /* [M3D_REG_REF=0]      default 50: registration validation of near-identical poses against candidate lists of the
-                                       best pose so far; the value is the pose-deviation budget in per cent of a grid cell (0: off) */
-    int32_t reserved[5];            /* zero */
+    int32_t reserved[6];            /* zero */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -57,9 +57,7 @@ class RegStats(C.Structure):
     _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("validations", C.c_uint64),
                 ("iterations", C.c_int64), ("best_index", C.c_int64), ("est_k", C.c_int64),
                 ("ms_total", C.c_double), ("ties", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
-                ("lds_wave_hypotheses", C.c_uint64), ("global_wave_hypotheses", C.c_uint64),
-                ("ref_pairs_fast", C.c_uint64), ("ref_pairs_all", C.c_uint64), ("ref_list_entries", C.c_uint64),
-                ("ref_list_builds", C.c_uint64)]
+                ("lds_wave_hypotheses", C.c_uint64), ("global_wave_hypotheses", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -203,7 +201,7 @@ class Config(C.Structure):
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
                                          "morton_order", "reg_neighbour_lists", "reg_source_rows", "reg_prune",
                                          "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing", "reg_lds_staging", "reg_sorted_lists",
-                                         "score_fp32_screen", "cull_fp32", "reg_ref_lists")] + [("reserved", C.c_int32 * 5)]
+                                         "score_fp32_screen", "cull_fp32")] + [("reserved", C.c_int32 * 6)]
 
 
 def fp64_issue_rate(device=0, ms_target=2.0):

@@ -29,7 +29,6 @@ void sanitize(m3d_config& c) {
     if (c.score_min_workgroups < 1) c.score_min_workgroups = 16384;
     if (c.dense_workgroups < 1) c.dense_workgroups = 8192;
     if (c.pool_limit_mb < 0) c.pool_limit_mb = 0;
-    if (c.reg_ref_lists < 0 || c.reg_ref_lists > 100) c.reg_ref_lists = 50;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -51,7 +50,6 @@ void load_env() {
     g_cfg.reg_sorted_lists = !env_is("M3D_REG_SORTED", '0');
     g_cfg.score_fp32_screen = !env_is("M3D_SCORE_SCREEN", '0');
     g_cfg.cull_fp32 = !env_is("M3D_CULL_FP32", '0');
-    g_cfg.reg_ref_lists = (int32_t)env_long("M3D_REG_REF", 50);
     sanitize(g_cfg);
 }
 }  // namespace

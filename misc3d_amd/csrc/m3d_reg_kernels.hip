@@ -539,9 +539,7 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
                                                        uint32_t* __restrict__ partial_cnt,
                                                        double* __restrict__ partial_sum, uint32_t tile_stride,
                                                        uint32_t phase_b, const uint8_t* __restrict__ keep,
-                                                       uint32_t n_tiles_launch, uint32_t n_split,
-                                                       const unsigned long long* __restrict__ skip /* (tile, hypothesis) pairs
-                                                       reg_validate_ref_k has already done: [tile][s_pad / 64] words, or null */) {
+                                                       uint32_t n_tiles_launch, uint32_t n_split) {
     __shared__ uint32_t red[4][64];
     __shared__ double reds[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -568,7 +566,6 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
     for (uint32_t sb = s0; sb < s1; sb += 64) {
         uint32_t acc = 0;
         double acc_sum = 0.0;
-        const unsigned long long skipw = skip ? skip[(size_t)tile * (s_pad / 64u) + sb / 64u] : 0ull;
         for (uint32_t ss = 0; ss < 64; ++ss) {
             const double* __restrict__ T = Ts + (size_t)(sb + ss) * kRegTStride;
             double t[12];
@@ -576,7 +573,7 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
             for (int k = 0; k < 12; ++k) t[k] = T[k];
             uint32_t cnt = 0;
             double sum = 0.0;
-            const bool run = (keep ? keep[sb + ss] != 0 : true) && !((skipw >> ss) & 1ull);
+            const bool run = keep ? keep[sb + ss] != 0 : true;
             if (t[0] == t[0] && run) {  // padding records are NaN (wave-uniform branch)
 #pragma unroll
                 for (int j = 0; j < kRegP; ++j) {
@@ -596,7 +593,7 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
         red[wave][lane] = acc;
         reds[wave][lane] = acc_sum;
         __syncthreads();
-        if (wave == 0 && !((skipw >> lane) & 1ull)) {
+        if (wave == 0) {
             partial_cnt[(size_t)tile * s_pad + sb + lane] =
                 (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
             partial_sum[(size_t)tile * s_pad + sb + lane] =
@@ -900,7 +897,7 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
                              const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
                              uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
                              uint32_t n_points, uint8_t* keep, hipStream_t s, bool lds_rows,
-                             unsigned long long* fast_stats, const unsigned long long* skip) {
+                             unsigned long long* fast_stats) {
     if (!s_pad || !src.n_pad) return 0;
     const uint32_t groups = s_pad / 64;
     const bool lds = lds_rows;
@@ -937,7 +934,7 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         const uint32_t nsplit = (groups + gps - 1) / gps;
         const uint32_t slots = (tiles + 7) / 8;
         reg_validate_k<<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy,
-                                                         qz, partial_cnt, partial_sum, stride, phase_b, kp, tiles, nsplit, skip);
+                                                         qz, partial_cnt, partial_sum, stride, phase_b, kp, tiles, nsplit);
     };
     const uint32_t stride = kRegPruneStride;
     if (best_cnt == 0 || n_tiles < 2 * stride) {
@@ -954,296 +951,6 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
     }
     reduce_sums_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_sum, n_tiles * rows_per_tile, s_pad, sums);
     return n_tiles * rows_per_tile;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K9c  validation of NEAR-IDENTICAL poses against per-point candidate lists of a reference pose
-// ------------------------------------------------------------------------------------------------
-// The survivors of a registration chunk are overwhelmingly near-identical poses: every triple of true correspondences
-// gives the true pose up to the noise of three points, and on data with good descriptors that is most of what the
-// checkers let through (C4: 26 % of the triples survive, 90 % of the survivors match EVERY source point).  Pruning cannot
-// touch them -- equal fitness is decided by rmse, so each needs its exact sum -- and reg_validate_k spends ~1000
-// wave-instructions per (64 points, hypothesis) on them: two dependent loads, a divergent scan of ~17 candidates per lane.
-//
-// For a reference pose T_ref (the best so far) and a budget Delta, list_i = ALL target points within
-//     rho_i = min(d_nn(T_ref p_i) + 2 Delta, r + Delta)
-// of x_ref = T_ref p_i.  For any pose T_h with |T_h p_i - T_ref p_i| <= Delta the nearest target point of x_h = T_h p_i
-// is in list_i: |x_h - q_h| <= |x_h - q*| <= d_nn + Delta (q* = the reference's nearest), so |x_ref - q_h| <= d_nn +
-// 2 Delta; and a match closer than r to x_h is closer than r + Delta to x_ref.  The minimum of the SAME d2 expression
-// over a superset of candidates that contains the minimiser is the same number, so counts and per-point distances are
-// those of the grid search, bit for bit (the per-hypothesis sums are order-free by design).
-//
-// reg_validate_ref_k turns the decomposition around: lane = HYPOTHESIS (its transformation in VGPRs), the wave walks
-// the 256 source points of a tile; point, list bounds and candidates are wave-uniform (scalar loads, one stream of
-// consecutive 32-byte entries for the whole tile), every lane evaluates every candidate: no divergence, no gathers,
-// no cross-lane reduction (count and sum stay in the lane).  24 + 9 L instructions per (point, hypothesis) for a list
-// of L candidates.  Which (tile, hypothesis) pairs qualify is decided per tile from the tile's bounding sphere:
-// |T_h p - T_ref p| <= |R_h - R_ref|_F rad + |T_h c - T_ref c|  (ref_fast_mask_k); everything else stays with
-// reg_validate_k, which skips the pairs of the mask.
-struct RefPose {
-    double t[12];
-};
-
-// bounding sphere of every source tile (kRegTile points): (cx, cy, cz, radius); radius < 0: no finite point
-__global__ __launch_bounds__(256) void ref_tile_sphere_k(const double* __restrict__ sx, const double* __restrict__ sy,
-                                                          const double* __restrict__ sz, uint32_t n_tiles,
-                                                          double* __restrict__ out) {
-    __shared__ double red[4][7];
-    const uint32_t tile = blockIdx.x;
-    const size_t i = (size_t)tile * kRegTile + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double x = sx[i], y = sy[i], z = sz[i];
-    const bool ok = isfinite(x) && isfinite(y) && isfinite(z);
-    const double inf = u2f(0x7FF0000000000000ull);
-    double v[6] = {ok ? x : inf, ok ? y : inf, ok ? z : inf, ok ? x : -inf, ok ? y : -inf, ok ? z : -inf};
-    for (int off = 32; off > 0; off >>= 1)
-        for (int k = 0; k < 6; ++k) {
-            const double o = __shfl_xor(v[k], off, 64);
-            v[k] = k < 3 ? fmin(v[k], o) : fmax(v[k], o);
-        }
-    if (lane == 0)
-        for (int k = 0; k < 6; ++k) red[wave][k] = v[k];
-    __syncthreads();
-    double c[3];
-    bool any = true;
-    for (int k = 0; k < 3; ++k) {
-        const double lo = fmin(fmin(red[0][k], red[1][k]), fmin(red[2][k], red[3][k]));
-        const double hi = fmax(fmax(red[0][3 + k], red[1][3 + k]), fmax(red[2][3 + k], red[3][3 + k]));
-        any = any && lo <= hi;
-        c[k] = 0.5 * lo + 0.5 * hi;
-    }
-    __syncthreads();
-    double d = 0.0;
-    if (ok && any) {
-        const double dx = x - c[0], dy = y - c[1], dz = z - c[2];
-        d = sqrt((dx * dx + dy * dy) + dz * dz);
-    }
-    for (int off = 32; off > 0; off >>= 1) d = fmax(d, __shfl_xor(d, off, 64));
-    if (lane == 0) red[wave][6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double r = fmax(fmax(red[0][6], red[1][6]), fmax(red[2][6], red[3][6]));
-        out[4 * (size_t)tile + 0] = any ? c[0] : 0.0;
-        out[4 * (size_t)tile + 1] = any ? c[1] : 0.0;
-        out[4 * (size_t)tile + 2] = any ? c[2] : 0.0;
-        out[4 * (size_t)tile + 3] = any ? r * (1.0 + 1e-12) + 1e-300 : -1.0;
-    }
-}
-
-// every target point within sqrt(rho2) of (px, py, pz): f(index)
-template <class F>
-__device__ __forceinline__ void ball_scan(const GridDesc& g, const uint32_t* __restrict__ cell_start,
-                                          const double* __restrict__ qx, const double* __restrict__ qy,
-                                          const double* __restrict__ qz, double px, double py, double pz, double rho,
-                                          double rho2, F f) {
-    // cells whose cube can meet the ball, clamped to the table (points only live inside it)
-    const double fx = (px - g.ox) * g.inv_h, fy = (py - g.oy) * g.inv_h, fz = (pz - g.oz) * g.inv_h, fr = rho * g.inv_h + 1e-6;
-    if (!(fx == fx && fy == fy && fz == fz && fr == fr)) return;
-    auto lo_of = [](double v, uint32_t n) { const double t = floor(v); return t < 0.0 ? 0 : (t > (double)(n - 1) ? (int)n : (int)t); };
-    auto hi_of = [](double v, uint32_t n) { const double t = floor(v); return t < 0.0 ? -1 : (t > (double)(n - 1) ? (int)(n - 1) : (int)t); };
-    const int x0 = lo_of(fx - fr, g.nx), x1 = hi_of(fx + fr, g.nx);
-    const int y0 = lo_of(fy - fr, g.ny), y1 = hi_of(fy + fr, g.ny);
-    const int z0 = lo_of(fz - fr, g.nz), z1 = hi_of(fz + fr, g.nz);
-    if (x0 > x1 || y0 > y1 || z0 > z1) return;
-    for (int iz = z0; iz <= z1; ++iz)
-        for (int iy = y0; iy <= y1; ++iy) {
-            const uint32_t row = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx;
-            const uint32_t b = cell_start[row + (uint32_t)x0], e = cell_start[row + (uint32_t)x1 + 1u];
-            for (uint32_t c = b; c < e; ++c) {
-                const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 <= rho2) f(c);
-            }
-        }
-}
-
-// pass 1: radius of every source point's candidate ball under the reference pose, and the number of candidates
-__global__ void ref_count_k(CloudView src, RefPose T, GridDesc g, const uint32_t* __restrict__ cell_start,
-                            const double* __restrict__ qx, const double* __restrict__ qy, const double* __restrict__ qz,
-                            double delta, double* __restrict__ rho_out, uint32_t* __restrict__ cnt_out) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= src.n_pad) return;
-    const double x = src.x[i], y = src.y[i], z = src.z[i];
-    const double* t = T.t;
-    const double px = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
-    const double py = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
-    const double pz = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
-    uint32_t cnt = 0;
-    double rho = 0.0;
-    if (px == px && py == py && pz == pz) {
-        const double d2 = nearest_d2(g, cell_start, qx, qy, qz, px, py, pz);   // +inf: nothing within the radius
-        const double r = sqrt(g.r2);
-        rho = fmin(sqrt(d2) + 2.0 * delta, r + delta);
-        rho = rho * (1.0 + 1e-9) + 1e-12 * ((fabs(px) + fabs(py)) + (fabs(pz) + 1.0));
-        ball_scan(g, cell_start, qx, qy, qz, px, py, pz, rho, rho * rho, [&](uint32_t) { ++cnt; });
-    }
-    rho_out[i] = rho;
-    cnt_out[i] = cnt;
-}
-// pass 2: the candidates themselves, (x, y, z, 0) each, at cl_start[i] ...
-__global__ void ref_fill_k(CloudView src, RefPose T, GridDesc g, const uint32_t* __restrict__ cell_start,
-                           const double* __restrict__ qx, const double* __restrict__ qy, const double* __restrict__ qz,
-                           const double* __restrict__ rho_in, const uint32_t* __restrict__ cl_start,
-                           double4* __restrict__ cl_pts) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= src.n_pad) return;
-    uint32_t pos = cl_start[i];
-    if (cl_start[i + 1] == pos) return;
-    const double x = src.x[i], y = src.y[i], z = src.z[i];
-    const double* t = T.t;
-    const double px = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
-    const double py = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
-    const double pz = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
-    const double rho = rho_in[i];
-    ball_scan(g, cell_start, qx, qy, qz, px, py, pz, rho, rho * rho, [&](uint32_t c) {
-        cl_pts[pos++] = make_double4(qx[c], qy[c], qz[c], 0.0);
-    });
-}
-
-// fastmask[tile * groups + group]: bit l = hypothesis 64 group + l moves every point of the tile by at most delta
-// against the reference pose.  One wave per (group, range of tiles), the transformation in registers.
-__global__ __launch_bounds__(64) void ref_fast_mask_k(const double* __restrict__ Ts, uint32_t groups, RefPose Tr,
-                                                       const double* __restrict__ tile_sph, uint32_t n_tiles,
-                                                       uint32_t tiles_per_wave, double delta,
-                                                       unsigned long long* __restrict__ fastmask,
-                                                       unsigned long long* __restrict__ total /* fast (tile, hypothesis) pairs */) {
-    const uint32_t group = blockIdx.x, lane = threadIdx.x;
-    const uint32_t s = group * 64u + lane;
-    double t[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) t[k] = Ts[(size_t)s * kRegTStride + k];   // (padding records are NaN: never fast)
-    const double* r = Tr.t;
-    double fro = 0.0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k)
-        if ((k & 3) != 3) {
-            const double d = t[k] - r[k];
-            fro += d * d;
-        }
-    fro = sqrt(fro);
-    const uint32_t t0 = blockIdx.y * tiles_per_wave, t1 = min(n_tiles, t0 + tiles_per_wave);
-    unsigned long long cnt = 0;
-    for (uint32_t tile = t0; tile < t1; ++tile) {
-        const double cx = tile_sph[4 * (size_t)tile], cy = tile_sph[4 * (size_t)tile + 1], cz = tile_sph[4 * (size_t)tile + 2],
-                     rad = tile_sph[4 * (size_t)tile + 3];
-        // T_h c - T_ref c, component by component
-        const double dx = (((t[0] - r[0]) * cx + (t[1] - r[1]) * cy) + (t[2] - r[2]) * cz) + (t[3] - r[3]);
-        const double dy = (((t[4] - r[4]) * cx + (t[5] - r[5]) * cy) + (t[6] - r[6]) * cz) + (t[7] - r[7]);
-        const double dz = (((t[8] - r[8]) * cx + (t[9] - r[9]) * cy) + (t[10] - r[10]) * cz) + (t[11] - r[11]);
-        const double mag = ((fabs(cx) + fabs(cy)) + fabs(cz)) + rad;   // (rounding of the transformed coordinates themselves)
-        const double dev = (fro * rad + sqrt((dx * dx + dy * dy) + dz * dz)) * (1.0 + 1e-9) + 1e-12 * (mag + 1.0);
-        const bool ok = rad >= 0.0 && dev <= delta;   // NaN -> false
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) fastmask[(size_t)tile * groups + group] = m;
-        cnt += (unsigned long long)__popcll(m);
-    }
-    if (lane == 0 && total && cnt) atomicAdd(total, cnt);
-}
-
-__global__ __launch_bounds__(64) void reg_validate_ref_k(const double* __restrict__ sx, const double* __restrict__ sy,
-                                                          const double* __restrict__ sz, const double* __restrict__ Ts,
-                                                          uint32_t s_pad, const uint32_t* __restrict__ cl_start,
-                                                          const double4* __restrict__ cl_pts,
-                                                          const unsigned long long* __restrict__ fastmask, uint32_t groups,
-                                                          double r2, uint32_t* __restrict__ partial_cnt,
-                                                          double* __restrict__ partial_sum) {
-    const uint32_t group = blockIdx.x % groups, tile = blockIdx.x / groups;
-    const unsigned long long m = fastmask[(size_t)tile * groups + group];
-    if (m == 0ull) return;
-    const uint32_t lane = threadIdx.x, s = group * 64u + lane;
-    double t[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) t[k] = Ts[(size_t)s * kRegTStride + k];
-    uint32_t cnt = 0;
-    double sum = 0.0;
-    const uint32_t i0 = tile * (uint32_t)kRegTile;
-    uint32_t e_prev = cl_start[i0];
-    for (uint32_t j = 0; j < (uint32_t)kRegTile; ++j) {   // wave-uniform: point, bounds and candidates are scalar loads
-        const uint32_t i = i0 + j;
-        const uint32_t b = e_prev, e = cl_start[i + 1];
-        e_prev = e;
-        if (b == e) continue;   // no target point anywhere near (or a padding slot): no match under any of these poses
-        const double x = sx[i], y = sy[i], z = sz[i];
-        const double px = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
-        const double py = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
-        const double pz = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
-        double best = INFINITY;
-        for (uint32_t c = b; c < e; c += 4u) {
-            // four candidates per trip (the tail repeats the last one: min is idempotent)
-            const double4 q0 = cl_pts[c], q1 = cl_pts[min(c + 1u, e - 1u)], q2 = cl_pts[min(c + 2u, e - 1u)],
-                          q3 = cl_pts[min(c + 3u, e - 1u)];
-            {
-                const double ddx = px - q0.x, ddy = py - q0.y, ddz = pz - q0.z;
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-            }
-            {
-                const double ddx = px - q1.x, ddy = py - q1.y, ddz = pz - q1.z;
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-            }
-            {
-                const double ddx = px - q2.x, ddy = py - q2.y, ddz = pz - q2.z;
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-            }
-            {
-                const double ddx = px - q3.x, ddy = py - q3.y, ddz = pz - q3.z;
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-            }
-        }
-        const bool f = best < r2;
-        cnt += f ? 1u : 0u;
-        sum += f ? best : 0.0;
-    }
-    if ((m >> lane) & 1ull) {
-        partial_cnt[(size_t)tile * s_pad + s] = cnt;
-        partial_sum[(size_t)tile * s_pad + s] = sum;
-    }
-}
-
-void launch_ref_tile_spheres(const CloudView& src, double* tile_sph, hipStream_t s) {
-    const uint32_t n_tiles = src.n_pad / kRegTile;
-    if (n_tiles) ref_tile_sphere_k<<<n_tiles, 256, 0, s>>>(src.x, src.y, src.z, n_tiles, tile_sph);
-}
-void launch_ref_lists_count(const CloudView& src, const double* T12, const GridDesc& g, const uint32_t* cell_start,
-                            const double* qx, const double* qy, const double* qz, double delta, double* rho,
-                            uint32_t* cl_start, uint32_t* tile_sums, uint32_t* total, hipStream_t s) {
-    RefPose T;
-    for (int k = 0; k < 12; ++k) T.t[k] = T12[k];
-    const uint32_t n = src.n_pad;
-    if (!n) return;
-    ref_count_k<<<(n + 255) / 256, 256, 0, s>>>(src, T, g, cell_start, qx, qy, qz, delta, rho, cl_start);
-    const uint32_t nt = (n + 2047) / 2048;
-    tile_scan_k<<<nt, 256, 0, s>>>(cl_start, n, tile_sums);
-    launch_scan_blocks(tile_sums, nt, total, s);
-    add_tile_offsets_k<<<(n + 1 + 255) / 256, 256, 0, s>>>(cl_start, n, tile_sums, total);
-}
-void launch_ref_lists_fill(const CloudView& src, const double* T12, const GridDesc& g, const uint32_t* cell_start,
-                           const double* qx, const double* qy, const double* qz, const double* rho,
-                           const uint32_t* cl_start, double4* cl_pts, hipStream_t s) {
-    RefPose T;
-    for (int k = 0; k < 12; ++k) T.t[k] = T12[k];
-    const uint32_t n = src.n_pad;
-    if (n) ref_fill_k<<<(n + 255) / 256, 256, 0, s>>>(src, T, g, cell_start, qx, qy, qz, rho, cl_start, cl_pts);
-}
-void launch_ref_fast_mask(const double* Ts, uint32_t s_pad, const double* T12, const double* tile_sph, uint32_t n_tiles,
-                          double delta, unsigned long long* fastmask, unsigned long long* total, hipStream_t s) {
-    RefPose T;
-    for (int k = 0; k < 12; ++k) T.t[k] = T12[k];
-    const uint32_t groups = s_pad / 64;
-    if (!groups || !n_tiles) return;
-    const uint32_t tpw = 32;
-    ref_fast_mask_k<<<dim3(groups, (n_tiles + tpw - 1) / tpw), 64, 0, s>>>(Ts, groups, T, tile_sph, n_tiles, tpw, delta, fastmask, total);
-}
-void launch_reg_validate_ref(const CloudView& src, const double* Ts, uint32_t s_pad, const uint32_t* cl_start,
-                             const double4* cl_pts, const unsigned long long* fastmask, double r2, uint32_t* partial_cnt,
-                             double* partial_sum, hipStream_t s) {
-    const uint32_t groups = s_pad / 64, n_tiles = src.n_pad / kRegTile;
-    if (!groups || !n_tiles) return;
-    reg_validate_ref_k<<<n_tiles * groups, 64, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, cl_start, cl_pts, fastmask, groups, r2,
-                                                      partial_cnt, partial_sum);
 }
 
 // per-point nearest squared distance for ONE transformation (device pointer to 12 doubles)

@@ -65,24 +65,7 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
                              uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
                              uint32_t n_points, uint8_t* keep, hipStream_t s,
                              bool lds_rows = false /* the LDS-staged kernel (source copy row-aligned to coarse cells) */,
-                             unsigned long long* fast_stats = nullptr /* [0] LDS path, [1] global path (wave-hypotheses) */,
-                             const unsigned long long* skip = nullptr /* [tile][s_pad / 64]: pairs launch_reg_validate_ref has done */);
-// Validation of near-identical poses against candidate lists of a reference pose (m3d_reg_kernels.hip, K9c).
-// T12: 12 doubles (rows 0..2 of the reference pose) on the HOST.  cl_start: src.n_pad + 1 offsets; rho: src.n_pad doubles.
-void launch_ref_tile_spheres(const CloudView& src, double* tile_sph /* 4 per tile of kRegTile points */, hipStream_t s);
-void launch_ref_lists_count(const CloudView& src, const double* T12, const GridDesc& g, const uint32_t* cell_start,
-                            const double* qx, const double* qy, const double* qz, double delta, double* rho,
-                            uint32_t* cl_start, uint32_t* tile_sums, uint32_t* total /* [0] = number of list entries */,
-                            hipStream_t s);
-void launch_ref_lists_fill(const CloudView& src, const double* T12, const GridDesc& g, const uint32_t* cell_start,
-                           const double* qx, const double* qy, const double* qz, const double* rho,
-                           const uint32_t* cl_start, double4* cl_pts, hipStream_t s);
-void launch_ref_fast_mask(const double* Ts, uint32_t s_pad, const double* T12, const double* tile_sph, uint32_t n_tiles,
-                          double delta, unsigned long long* fastmask /* [tile][s_pad / 64] */,
-                          unsigned long long* total /* += fast pairs (may be null) */, hipStream_t s);
-void launch_reg_validate_ref(const CloudView& src, const double* Ts, uint32_t s_pad, const uint32_t* cl_start,
-                             const double4* cl_pts, const unsigned long long* fastmask, double r2, uint32_t* partial_cnt,
-                             double* partial_sum, hipStream_t s);
+                             unsigned long long* fast_stats = nullptr /* [0] LDS path, [1] global path (wave-hypotheses) */);
 void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
                        const double* qx, const double* qy, const double* qz, double* best, hipStream_t s);
 void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* block_counts, uint32_t* total,

@@ -65,14 +65,13 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, cell_orig, tile_sph, fast_stats,
-        ref_sph, ref_rho, ref_start, ref_pts, ref_mask, ref_total, ref_sums;
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, cell_orig, tile_sph, fast_stats;
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
                           &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &cell_orig,
-                          &tile_sph, &fast_stats, &ref_sph, &ref_rho, &ref_start, &ref_pts, &ref_mask, &ref_total, &ref_sums})
+                          &tile_sph, &fast_stats})
             b->release();
     }
 };
@@ -355,14 +354,6 @@ struct m3d_reg {
     size_t chunk = 32;
     size_t validated_total = 0, n_dst_points = 0;
     bool nl_built = false;
-    // candidate lists of a reference pose (launch_reg_validate_ref: the validation of near-identical poses)
-    bool ref_built = false, ref_spheres = false;
-    int64_t ref_index = -1;       // best_index the lists were built for
-    double ref_T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    double ref_delta = 0.0;
-    double ref_coverage = 1.0;    // fast (tile, hypothesis) pairs / all pairs of the last validate call
-    uint64_t ref_pairs_fast = 0, ref_pairs_all = 0, ref_entries = 0, ref_builds = 0;
-    int build_ref_lists();
     bool spheres_built = false;   // bounding boxes of the source rows (LDS-staged validation)
     bool rows_aligned = false;    // the sorted source copy is padded so that no row of 64 spans two coarse cells
     int itr = 0;
@@ -587,38 +578,13 @@ int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double
             HIPCHK(hipMemsetAsync(S.fast_stats.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
             spheres_built = true;
         }
-        // near-identical poses first: everything that stays within ref_delta of the reference pose on a source tile is
-        // validated against that pose's candidate lists (reg_validate_ref_k); reg_validate_k skips those pairs
-        const unsigned long long* skip = nullptr;
-        const int ref_cfg = config().reg_ref_lists;
-        if (ref_cfg > 0 && !lds && best_index >= 0 && best_cnt > 0 && s_pad >= 64) {
-            // (re)build: no lists yet, or the last call found most pairs too far from a reference that is no longer the best
-            if (ref_built && ref_coverage < 0.5 && ref_index != best_index) ref_built = false;
-            if (!ref_built) {
-                const int rb = build_ref_lists();
-                if (rb != M3D_OK) return rb;
-            }
-            const uint32_t groups = s_pad / 64;
-            RESERVE(S.ref_mask, sizeof(unsigned long long) * (size_t)n_tiles * groups);
-            HIPCHK(hipMemsetAsync(S.ref_total.as<unsigned long long>() + 1, 0, sizeof(unsigned long long), ctx->stream));
-            launch_ref_fast_mask(Ts, s_pad, ref_T, S.ref_sph.as<double>(), n_tiles, ref_delta,
-                                 S.ref_mask.as<unsigned long long>(), S.ref_total.as<unsigned long long>() + 1, ctx->stream);
-            launch_reg_validate_ref(src_sorted, Ts, s_pad, S.ref_start.as<uint32_t>(), S.ref_pts.as<double4>(),
-                                    S.ref_mask.as<unsigned long long>(), g.r2, S.partial.as<uint32_t>(),
-                                    S.partial_sum.as<double>(), ctx->stream);
-            skip = S.ref_mask.as<unsigned long long>();
-        }
         // bound-and-prune against the best of EARLIER chunks (m3d_config.reg_prune = 0 switches it off)
         const uint32_t rows = launch_reg_validate(src_sorted, Ts, s_pad, g, S.cell_start.as<uint32_t>(),
                             S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
                             S.partial.as<uint32_t>(), S.partial_sum.as<double>(), S.sum2.as<double>(),
                             reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream,
                             lds,
-                            lds ? S.fast_stats.as<unsigned long long>() : nullptr, skip);
-        unsigned long long fast_pairs = 0;
-        if (skip)
-            HIPCHK(hipMemcpyAsync(&fast_pairs, S.ref_total.as<unsigned long long>() + 1, sizeof(fast_pairs),
-                                  hipMemcpyDeviceToHost, ctx->stream));
+                            lds ? S.fast_stats.as<unsigned long long>() : nullptr);
         HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
         launch_reduce_partials(S.partial.as<uint32_t>(), rows, s_pad, S.counts.as<uint32_t>(),
                                ctx->stream);
@@ -628,64 +594,7 @@ int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double
                               ctx->stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (skip) {
-            const uint64_t all = (uint64_t)n_tiles * ns;
-            // (the mask also covers the NaN padding of the last group: never fast)
-            ref_pairs_fast += fast_pairs;
-            ref_pairs_all += all;
-            ref_coverage = all ? (double)fast_pairs / (double)all : 1.0;
-        }
-        if (std::getenv("M3D_REG_DEBUG")) {
-            if (skip) std::fprintf(stderr, "validate: reference lists cover %.1f %% of the (tile, hypothesis) pairs\n", 100.0 * ref_coverage);
-            std::vector<uint8_t> k(s_pad);
-            (void)hipMemcpy(k.data(), S.keep.p, s_pad, hipMemcpyDeviceToHost);
-            size_t kept = 0, full = 0;
-            for (uint32_t i = 0; i < ns; ++i) {
-                kept += k[i] != 0;
-                full += counts_out[i] == n_src;
-            }
-            std::fprintf(stderr, "validate: %u survivors, best_cnt %u, %zu kept for phase B, %zu with every point matched\n", ns,
-                         reg_prune ? best_cnt : 0u, kept, full);
-        }
     }
-    return M3D_OK;
-}
-
-// Candidate lists of the current best pose (m3d_reg_kernels.hip, K9c): two passes over the source points (count, fill)
-// with one host round trip in between for the size of the list array.
-int m3d_reg::build_ref_lists() {
-    HIPCHK(hipMemcpy(ref_T, best_T_dev, sizeof(ref_T), hipMemcpyDeviceToHost));
-    ref_index = best_index;
-    // budget: m3d_config.reg_ref_lists per cent of a grid cell (default 50: cells are a quarter of the radius)
-    ref_delta = 0.01 * (double)config().reg_ref_lists / g.inv_h;
-    const uint32_t n = src_sorted.n_pad;
-    if (!ref_spheres) {
-        RESERVE(S.ref_sph, sizeof(double) * 4 * std::max<uint32_t>(n_tiles, 1));
-        launch_ref_tile_spheres(src_sorted, S.ref_sph.as<double>(), ctx->stream);
-        ref_spheres = true;
-    }
-    RESERVE(S.ref_rho, sizeof(double) * n);
-    RESERVE(S.ref_start, sizeof(uint32_t) * ((size_t)n + 1));
-    RESERVE(S.ref_sums, sizeof(uint32_t) * ((size_t)(n + 2047) / 2048 + 1));
-    RESERVE(S.ref_total, 16);
-    launch_ref_lists_count(src_sorted, ref_T, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
-                           S.qz.as<double>(), ref_delta, S.ref_rho.as<double>(), S.ref_start.as<uint32_t>(),
-                           S.ref_sums.as<uint32_t>(), reinterpret_cast<uint32_t*>(S.ref_total.p), ctx->stream);
-    uint32_t entries = 0;
-    HIPCHK(hipMemcpyAsync(&entries, S.ref_total.p, sizeof(entries), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    RESERVE(S.ref_pts, sizeof(double) * 4 * std::max<size_t>(entries, 1));
-    launch_ref_lists_fill(src_sorted, ref_T, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
-                          S.qz.as<double>(), S.ref_rho.as<double>(), S.ref_start.as<uint32_t>(), S.ref_pts.as<double4>(),
-                          ctx->stream);
-    HIPCHK(hipGetLastError());
-    ref_entries = entries;
-    ref_builds++;
-    ref_built = true;
-    ref_coverage = 1.0;
-    if (std::getenv("M3D_REG_DEBUG"))
-        std::fprintf(stderr, "reference lists: %u entries for %zu source points (%.1f per point), delta %.3g\n", entries, n_src,
-                     n_src ? (double)entries / (double)n_src : 0.0, ref_delta);
     return M3D_OK;
 }
 
@@ -804,10 +713,6 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
         stats->est_k = est_k_global;
         stats->ties = ties;
         stats->exact_rmse_evals = exact_evals;
-        stats->ref_pairs_fast = ref_pairs_fast;
-        stats->ref_pairs_all = ref_pairs_all;
-        stats->ref_list_entries = ref_entries;
-        stats->ref_list_builds = ref_builds;
         if (spheres_built) {
             unsigned long long fs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCHK(hipMemcpy(fs, S.fast_stats.p, sizeof(fs), hipMemcpyDeviceToHost));
