@@ -197,7 +197,8 @@ typedef struct m3d_reg_stats {
     uint64_t validations;
     int64_t iterations, best_index, est_k;
     double ms_total;
-    uint64_t ties;             /* equal-fitness comparisons decided during the replay */
+    uint64_t ties;             /* equal-fitness comparisons decided during the replay (hypotheses the validation dropped early
+                                * on their partial count or sum never get that far) */
     uint64_t exact_rmse_evals; /* of which needed the serial-order sum of squared distances */
     uint64_t lds_wave_hypotheses;    /* validation work units (64 source points x 1 hypothesis) served from the LDS-staged box */
     uint64_t global_wave_hypotheses; /* ... that took the global-memory path (pose outside the box, or staging off) */

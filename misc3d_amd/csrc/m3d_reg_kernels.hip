@@ -525,6 +525,14 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
     return nearest_phase2(g, cell_start, qx, qy, qz, ix, iy, iz, px, py, pz, best);
 }
 
+// the tile_local-th tile whose index mod 8 is in res_mask (tiles in ascending order)
+__device__ __forceinline__ uint32_t phase_tile(uint32_t tile_local, uint32_t res_mask) {
+    const uint32_t k = (uint32_t)__popc(res_mask);
+    uint32_t m = res_mask;
+    for (uint32_t j = tile_local % k; j > 0; --j) m &= m - 1u;   // drop the j lowest set bits
+    return (tile_local / k) * 8u + (uint32_t)(__ffs(m) - 1);
+}
+
 // Same decomposition as score_k: source points stay in VGPRs (kRegP rows of 64 per wave), the
 // transformations of the surviving hypotheses stream through SGPRs.  Per hypothesis: the number of
 // source points whose nearest target point is closer than the threshold (ballot + s_bcnt1) and the
@@ -537,8 +545,8 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
                                                        const double* __restrict__ qx, const double* __restrict__ qy,
                                                        const double* __restrict__ qz,
                                                        uint32_t* __restrict__ partial_cnt,
-                                                       double* __restrict__ partial_sum, uint32_t tile_stride,
-                                                       uint32_t phase_b, const uint8_t* __restrict__ keep,
+                                                       double* __restrict__ partial_sum, uint32_t res_mask,
+                                                       uint32_t n_tiles_total, const uint8_t* __restrict__ keep,
                                                        uint32_t n_tiles_launch, uint32_t n_split) {
     __shared__ uint32_t red[4][64];
     __shared__ double reds[4][64];
@@ -551,8 +559,9 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
     const uint32_t xcd = blockIdx.x % 8u, jq = blockIdx.x / 8u;
     const uint32_t tile_local = (jq / n_split) * 8u + xcd, split = jq % n_split;
     if (tile_local >= n_tiles_launch) return;   // whole block (uniform)
-    // phase A: tiles 0, stride, 2 stride, ...; phase B: all the others, only for hypotheses still in the race
-    const uint32_t tile = phase_b ? tile_local + tile_local / (tile_stride - 1) + 1 : tile_local * tile_stride;
+    // a launch covers the tiles whose index mod 8 is in res_mask (the pruning phases: launch_reg_validate)
+    const uint32_t tile = phase_tile(tile_local, res_mask);
+    if (tile >= n_tiles_total) return;
     const size_t base = (size_t)tile * kRegTile + (size_t)wave * (64 * kRegP) + lane;
     double x[kRegP], y[kRegP], z[kRegP];
 #pragma unroll
@@ -664,7 +673,7 @@ __global__ __launch_bounds__(1024) void reg_validate_lds_k(
     const double* __restrict__ Ts, uint32_t s_pad, uint32_t s_per_split, GridDesc g,
     const uint32_t* __restrict__ cell_start, const double* __restrict__ qx, const double* __restrict__ qy,
     const double* __restrict__ qz, uint32_t* __restrict__ partial_cnt, double* __restrict__ partial_sum,
-    uint32_t tile_stride, uint32_t phase_b, const uint8_t* __restrict__ keep, uint32_t n_tiles_launch, uint32_t n_split,
+    uint32_t res_mask, uint32_t n_tiles_total, const uint8_t* __restrict__ keep, uint32_t n_tiles_launch, uint32_t n_split,
     unsigned long long* __restrict__ fast_stats /* [0] += wave-hypotheses on the LDS path, [1] += on the global path,
                                                    [2] workgroups, [3] box larger than the local table, [4] more points than the staging arrays */) {
     extern __shared__ unsigned char lds_raw[];
@@ -682,7 +691,8 @@ __global__ __launch_bounds__(1024) void reg_validate_lds_k(
     const uint32_t xcd = blockIdx.x % 8u, jq = blockIdx.x / 8u;   // XCD-aware (tile, split) map, as reg_validate_k
     const uint32_t tile_local = (jq / n_split) * 8u + xcd, split = jq % n_split;
     if (tile_local >= n_tiles_launch) return;   // whole block (uniform)
-    const uint32_t tile = phase_b ? tile_local + tile_local / (tile_stride - 1) + 1 : tile_local * tile_stride;
+    const uint32_t tile = phase_tile(tile_local, res_mask);
+    if (tile >= n_tiles_total) return;
     const uint32_t s0 = split * s_per_split;
     const uint32_t s1 = min(s0 + s_per_split, s_pad);
     const int K = g.K;
@@ -875,35 +885,46 @@ __global__ void reduce_sums_k(const double* __restrict__ partial_sum, uint32_t n
     sums[s] = acc;
 }
 
-// keep[s] = can hypothesis s still reach `best_cnt` inliers?  count <= (inliers on the phase-A tiles)
-// + (all points of the phase-B tiles).  Hypotheses that cannot are dropped from phase B; their reported
-// count is the phase-A count, which is below best_cnt, so the replay never selects them.
-__global__ void reg_keep_k(const uint32_t* __restrict__ partial_cnt, uint32_t n_tiles, uint32_t tile_stride,
-                           uint32_t s_pad, uint32_t points_b, uint32_t best_cnt, uint8_t* __restrict__ keep,
-                           uint32_t rows_per_tile) {
+// Bound-and-prune inside a chunk, against the best hypothesis of EARLIER chunks (count best_cnt, order-free sum of squared
+// distances best_sum2).  After the tiles whose index mod 8 is in done_mask: a = matches so far, q = sum so far, rem = real
+// source points on the tiles still to come.  The hypothesis stays in the race when it can still reach MORE than best_cnt
+// matches, or exactly best_cnt with a smaller sum -- the replay's order is (fitness, then rmse = sqrt(sum / count)), the
+// sum only grows, so q above the incumbent's sum decides a tie against it.  A dropped hypothesis reports its partial
+// count, which is below best_cnt, so the replay never selects it.  limit = best_sum2 widened by far more than the
+// summation-order tolerance of the replay's comparison.  (On C4 this second rule drops little: the survivors are good
+// poses whose sums lie within a factor of two of each other -- the nearest-neighbour distance on a densely sampled
+// surface hardly grows with a tangential shift.)
+__global__ void reg_keep_k(const uint32_t* __restrict__ partial_cnt, const double* __restrict__ partial_sum,
+                           uint32_t n_tiles, uint32_t done_mask, uint32_t s_pad, uint32_t points_rem, bool rem_exact,
+                           uint32_t best_cnt, double limit, uint8_t* __restrict__ keep, int first) {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= s_pad) return;
+    if (!first && !keep[s]) return;
     uint32_t a = 0;
-    for (uint32_t t = 0; t < n_tiles; t += tile_stride)
-        for (uint32_t r = 0; r < rows_per_tile; ++r) a += partial_cnt[((size_t)t * rows_per_tile + r) * s_pad + s];
-    keep[s] = (uint64_t)a + points_b >= best_cnt ? 1 : 0;
+    double q = 0.0;
+    for (uint32_t t = 0; t < n_tiles; ++t)
+        if ((done_mask >> (t & 7u)) & 1u) {
+            a += partial_cnt[(size_t)t * s_pad + s];
+            q += partial_sum[(size_t)t * s_pad + s];
+        }
+    const uint64_t bound = (uint64_t)a + points_rem;
+    keep[s] = (bound > best_cnt || (bound == best_cnt && (!rem_exact || q <= limit))) ? 1 : 0;
 }
 
-// best_cnt: inlier count of the best hypothesis of EARLIER chunks (0: nothing to prune against).
-// n_points: real source points.  keep: s_pad bytes of scratch.
+// best_cnt / best_sum2: inlier count and order-free sum of squared distances of the best hypothesis of EARLIER chunks
+// (best_cnt 0: nothing to prune against).  n_points: real source points.  keep: s_pad bytes of scratch.
 // lds_rows: the LDS-staged kernel, whose unit is a row of 64 points (the source copy must be row-aligned to coarse cells,
 // m3d_registration.cpp); the partial arrays then hold one row per 64 points.  Returns the number of partial rows (what the reduce kernels fold).
 uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
                              const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
                              uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
                              uint32_t n_points, uint8_t* keep, hipStream_t s, bool lds_rows,
-                             unsigned long long* fast_stats) {
+                             unsigned long long* fast_stats, double best_sum2) {
     if (!s_pad || !src.n_pad) return 0;
     const uint32_t groups = s_pad / 64;
     const bool lds = lds_rows;
     const uint32_t n_tiles = lds ? src.n_pad / 64 : src.n_pad / kRegTile;
     const uint32_t tile_points = lds ? 64u : (uint32_t)kRegTile;
-    const uint32_t rows_per_tile = 1u;
     if (lds) {
         static bool attr_set = false;   // (idempotent; a race would set the same value twice)
         if (!attr_set) {
@@ -912,7 +933,9 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
             attr_set = true;
         }
     }
-    auto launch = [&](uint32_t tiles, uint32_t stride, uint32_t phase_b, const uint8_t* kp) {
+    auto launch = [&](uint32_t res_mask, const uint8_t* kp) {
+        // (upper bound of the tiles of the launch; the kernel drops indices past the last tile)
+        const uint32_t tiles = (n_tiles + 7) / 8 * (uint32_t)__builtin_popcount(res_mask);
         if (lds) {
             // a workgroup = 4 hypothesis streams on one staged box: few, long hypothesis ranges per tile (the staging is
             // paid once per workgroup), still enough workgroups to fill the chip twice over
@@ -923,7 +946,7 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
             const uint32_t slots = (tiles + 7) / 8;
             reg_validate_lds_k<<<slots * 8 * nsplit, 1024, kRegLdsBytes, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64,
                                                                              g, cell_start, qx, qy, qz, partial_cnt, partial_sum,
-                                                                             stride, phase_b, kp, tiles, nsplit, fast_stats);
+                                                                             res_mask, n_tiles, kp, tiles, nsplit, fast_stats);
             return;
         }
         // enough blocks to fill the chip, and at least ~40 splits per tile so that the ~160 blocks an XCD
@@ -934,23 +957,37 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         const uint32_t nsplit = (groups + gps - 1) / gps;
         const uint32_t slots = (tiles + 7) / 8;
         reg_validate_k<<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy,
-                                                         qz, partial_cnt, partial_sum, stride, phase_b, kp, tiles, nsplit);
+                                                         qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit);
     };
-    const uint32_t stride = kRegPruneStride;
-    if (best_cnt == 0 || n_tiles < 2 * stride) {
-        launch(n_tiles, 1, 0, nullptr);
+    if (best_cnt == 0 || n_tiles < 16) {
+        launch(0xFFu, nullptr);
     } else {
-        const uint32_t tiles_a = (n_tiles + stride - 1) / stride;
-        // real points on the phase-B tiles: at most every slot of those tiles, and at most all points
-        const uint64_t slots_b = (uint64_t)(n_tiles - tiles_a) * tile_points;
-        const uint32_t points_b = (uint32_t)std::min<uint64_t>(slots_b, n_points);
-        launch(tiles_a, stride, 0, nullptr);
-        reg_keep_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_cnt, n_tiles, stride, s_pad, points_b, best_cnt, keep,
-                                                       rows_per_tile);
-        launch(n_tiles - tiles_a, stride, 1, keep);
+        // four phases: an eighth of the tiles, another eighth, a quarter, the remaining half; the hypotheses still in
+        // the race are re-assessed in between (reg_keep_k)
+        static const uint32_t kPhase[4] = {0x01u, 0x10u, 0x44u, 0xAAu};
+        // real source points on the tiles of a residue class: exact when the real points are the first n_points slots
+        // (the row-aligned layout of the LDS-staged kernel pads in between: every slot is counted there, an upper bound)
+        auto points_on = [&](uint32_t mask) {
+            uint64_t n = 0;
+            for (uint32_t t = 0; t < n_tiles; ++t)
+                if ((mask >> (t & 7u)) & 1u) {
+                    const uint64_t lo = (uint64_t)t * tile_points;
+                    n += lds ? tile_points : (uint64_t)std::min<uint64_t>(tile_points, n_points > lo ? n_points - lo : 0);
+                }
+            return (uint32_t)std::min<uint64_t>(n, n_points);
+        };
+        const double limit = best_sum2 * (1.0 + 1e-6);
+        uint32_t done = 0;
+        for (int ph = 0; ph < 4; ++ph) {
+            launch(kPhase[ph], ph == 0 ? nullptr : keep);
+            done |= kPhase[ph];
+            if (ph < 3)
+                reg_keep_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_cnt, partial_sum, n_tiles, done, s_pad,
+                                                               points_on(0xFFu & ~done), !lds, best_cnt, limit, keep, ph == 0 ? 1 : 0);
+        }
     }
-    reduce_sums_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_sum, n_tiles * rows_per_tile, s_pad, sums);
-    return n_tiles * rows_per_tile;
+    reduce_sums_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_sum, n_tiles, s_pad, sums);
+    return n_tiles;
 }
 
 // per-point nearest squared distance for ONE transformation (device pointer to 12 doubles)

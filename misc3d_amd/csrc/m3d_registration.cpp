@@ -535,6 +535,7 @@ int m3d_reg::begin_chunk(size_t* n_survivors) {
         if (rn != M3D_OK) return rn;
         R.g = g;
     }
+
     if (ns) {
         const uint32_t s_pad = round_up(ns, 64);
         RESERVE(S.list, sizeof(uint32_t) * ns);
@@ -584,7 +585,7 @@ int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double
                             S.partial.as<uint32_t>(), S.partial_sum.as<double>(), S.sum2.as<double>(),
                             reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream,
                             lds,
-                            lds ? S.fast_stats.as<unsigned long long>() : nullptr);
+                            lds ? S.fast_stats.as<unsigned long long>() : nullptr, best_sum2);
         HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
         launch_reduce_partials(S.partial.as<uint32_t>(), rows, s_pad, S.counts.as<uint32_t>(),
                                ctx->stream);

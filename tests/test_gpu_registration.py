@@ -96,7 +96,9 @@ def test_registration_lds_staging_is_exact(capi, orc):
     assert st["lds_wave_hypotheses"] == 0 and res[(1, 1)][1]["lds_wave_hypotheses"] > 10 * res[(1, 1)][1]["global_wave_hypotheses"]
     for key, (T2, st2) in res.items():
         assert np.array_equal(T, T2), key
-        for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse", "ties", "exact_rmse_evals"):
+        # (`ties` / `exact_rmse_evals` count comparisons the replay makes; the in-chunk pruning on partial sums drops
+        # hypotheses before they get there, and how many depends on the source layout of the kernel in use)
+        for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse"):
             assert st[k] == st2[k], (key, k)
     o = orc.registration_ransac(d["src"], d["dst"], cs, cd, thr=0.03, max_iter=3000, edge_thr=0.9, confidence=1.0, seed=4)
     assert np.array_equal(T, o.T) and st["best_index"] == o.best_index and st["validations"] == o.validations

@@ -16,7 +16,7 @@ for lds in (1, 0, 1):
     capi.restore_config(old)
     print(f"lds={lds}: {dt*1e3:.1f} ms  validations {st['validations']} fitness {st['fitness']:.4f} best {st['best_index']} "
           f"lds/global wave-hyps {st['lds_wave_hypotheses']}/{st['global_wave_hypotheses']}  pose err {np.abs(T - d['T']).max():.2e}", flush=True)
-    res.setdefault(lds, (T, {k: st[k] for k in ("best_index", "validations", "fitness", "est_k", "inlier_rmse", "ties")}))
+    res.setdefault(lds, (T, {k: st[k] for k in ("best_index", "validations", "fitness", "est_k", "inlier_rmse")}))
     assert np.array_equal(res[lds][0], T)
 assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1], (res[0][1], res[1][1])
 print("identical with and without LDS staging")
