@@ -1,0 +1,16 @@
+"""The rounding bounds of the fp32 screen (score_screen_k) and of the fp32 box tests (cull_tiles32_k), checked on the HOST:
+tests/cpp/test_screen_bounds.cpp restates the device arithmetic with fmaf / float operations and runs millions of points --
+random scenes over eight orders of magnitude, offsets from the origin up to 1e5 scene sizes, points placed 1e-16 ... 1e-3
+thresholds from the cut-off on both sides -- through the screen and through the exact fp64 test.  No GPU needed."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fp32_screen_and_box_test_bounds_hold_on_the_host():
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["make", "-C", cpp, "_build/test_screen_bounds"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(cpp, "_build", "test_screen_bounds"), "12000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout and "wrong 0;" in r.stdout
