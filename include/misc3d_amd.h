@@ -285,8 +285,8 @@ int m3d_information_matrix(const double *src, size_t n_src, const double *dst, s
 int m3d_match_mutual_nn(const double *feat_src, size_t n_src, const double *feat_dst, size_t n_dst,
                         int dim, int method, int n_trees, int device, size_t *out_src,
                         size_t *out_dst, size_t *k);
-/* Diagnostics: number of queries of the last m3d_match_mutual_nn call whose fp32 screen was
- * inconclusive (candidate list overflow / fp32 range) and that were redone by exact brute force. */
+/* Diagnostics: number of queries of the calling thread's last m3d_match_mutual_nn call whose reduced-precision
+ * screen was inconclusive (candidate list overflow / fp32 range) and that were redone by exact brute force. */
 uint64_t m3d_match_last_fallbacks(void);
 
 /* ---- multi-GPU: hypotheses sharded, points replicated ----------------------------------

@@ -48,7 +48,8 @@ namespace {
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
-uint64_t g_match_fallbacks = 0;   // queries of the last m3d_match_mutual_nn that took the exact fallback
+thread_local uint64_t g_match_fallbacks = 0;   // queries of the CALLING THREAD's last m3d_match_mutual_nn that took the exact fallback
+                                               // (thread-local: concurrent calls on different devices used to race on one global)
 
 double now_ms() {
     using namespace std::chrono;

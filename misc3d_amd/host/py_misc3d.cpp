@@ -266,9 +266,10 @@ PYBIND11_MODULE(_py_misc3d, m) {
     mr.def(
         "compute_transformation_teaser",
         [](const py::object&, const py::object&, double) -> py::object {
-            throw std::runtime_error(
-                "[Misc3D Error] compute_transformation_teaser (TEASER++, CPU graph solver) is outside the "
-                "MI355X-accelerated hot path of this build; use compute_transformation_ransac or _least_square");
+            // (through LogError like every other failure of this module: "[Misc3D Error] ..." as a RuntimeError)
+            misc3d::LogError(
+                "compute_transformation_teaser (TEASER++, CPU graph solver) is outside the MI355X-accelerated hot path of "
+                "this build; use compute_transformation_ransac or compute_transformation_least_square");
         },
         py::arg("src"), py::arg("dst"), py::arg("noise_bound") = 0.01);
     mr.def(
@@ -313,7 +314,11 @@ PYBIND11_MODULE(_py_misc3d, m) {
             }
             return res;
         },
-        "Match corresponding point clouds (mutual nearest neighbours in descriptor space)", py::arg("src"),
+        "Match corresponding point clouds (mutual nearest neighbours in descriptor space).  The search is EXACT for both "
+        "methods: MatchMethod.ANNOY (the reference's default, an approximate random-projection forest) and n_trees are "
+        "accepted for compatibility and give the FLANN result; on real descriptors the reference's ANNOY set can differ "
+        "from it by the forest's misses.",
+        py::arg("src"),
         py::arg("dst"), py::arg("method") = misc3d::registration::MatchMethod::ANNOY, py::arg("n_trees") = 4,
         py::kw_only(), py::arg("device") = 0);
 
