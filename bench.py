@@ -338,7 +338,7 @@ def main():
                     "pairs_recounted_in_fp64_fraction": k_exact / max(k_pairs, 1),
                     "tile_hypothesis_pairs_per_launch": k_pairs / max(k_launches, 1),
                     "pairs_evaluated_fraction": k_pairs / float(n_tiles * h_rank * a.steps),
-                    "timing": "HIP events around every scoring launch of the timed steps (rank 0)",
+                    "timing": "HIP events attached to every scoring launch of the timed steps (hipExtLaunchKernel start / stop events on the library's stream, rank 0)",
                     "algorithmic_reuse": {
                         "bytes_per_launch": alg_bytes, "rate_GBps": alg_rate, "x_hbm_peak": alg_rate / HBM_PEAK_GBS,
                         "note": "24 B x hypotheses x points of a launch / launch time (what EvaluateModel streams on the "

@@ -371,8 +371,9 @@ typedef struct m3d_config {
     int32_t match_brute;            /* [M3D_MATCH_BRUTE=1]  1: fp64 brute-force matcher (no screen) */
     int32_t match_fp32_screen;      /* [M3D_MATCH_SCREEN=fp32] 1: fp32 VALU screen instead of the split-fp16 MFMA screen */
     int32_t pool_limit_mb;          /* [M3D_POOL_MB]        default 4096: released device blocks parked per device for re-use (0 = none) */
-    int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=1] default 0; 1: HIP events around every scoring launch fill m3d_stats.ms_score_kernel /
-                                       score_launches (bench.py switches it on: four event commands per chunk, ~11 us per C2 fit) */
+    int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=1] default 0; 1: HIP events attached to every scoring launch (hipExtLaunchKernel: the
+                                       launch's own start / stop times, no barrier packets) fill m3d_stats.ms_score_kernel /
+                                       score_launches, two more around the chunk fill ms_score (bench.py switches it on: ~4 us per C2 fit) */
     int32_t reg_lds_staging;        /* [M3D_REG_LDS=0]      default 0: registration validation with the target neighbourhood of a row of source points staged in LDS (bit-identical, not faster: DESIGN.md) */
     int32_t reg_sorted_lists;       /* [M3D_REG_SORTED=0]   default 1: x-sorted neighbour lists, side columns cut off by the x-distance */
     int32_t score_fp32_screen;      /* [M3D_SCORE_SCREEN=0] default 1: planes and spheres are counted by score_screen_k (packed-fp32 screen with a

@@ -23,6 +23,8 @@
 // keep using the original-order arrays, so inlier index lists and serial sums do not see the sort.
 #include "m3d_cull_kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 
 #include "m3d_config.hpp"
@@ -958,7 +960,8 @@ void launch_pick_best(const uint32_t* records, uint32_t count, unsigned long lon
 
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
-                       uint32_t* pair_rep, hipStream_t st, uint32_t group_begin, uint32_t group_end) {
+                       uint32_t* pair_rep, hipStream_t st, uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start,
+                       hipEvent_t ev_stop) {
     group_end = std::min(group_end, n_groups);
     if (!s.n_tiles || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
@@ -968,24 +971,31 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * window) / min_wgs)));
     const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);
-    if (screened && kind == 0)
-        score_screen_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep,
-                                           rep_stride, pair_rep, group_begin, group_end);
-    else if (screened && kind == 1)
-        score_screen_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep,
-                                           rep_stride, pair_rep, group_begin, group_end);
-    else if (screened)
-        score_screen_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep,
-                                           rep_stride, pair_rep, group_begin, group_end);
-    else if (kind == 0)
-        score_mask_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
-                                         pair_rep, group_begin, group_end);
-    else if (kind == 1)
-        score_mask_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
-                                         pair_rep, group_begin, group_end);
-    else
-        score_mask_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride,
-                                         pair_rep, group_begin, group_end);
+    // ev_start / ev_stop: the launch's OWN start and stop times (hipExtLaunchKernelGGL attaches the events to the kernel's
+    // dispatch packet: no barrier packets in front of and behind the kernel, which is what two hipEventRecord calls
+    // cost -- ~5 us of bubble each on this stream)
+    auto go = [&](auto kernel, auto... args) {
+        if (ev_start && ev_stop) hipExtLaunchKernelGGL(kernel, g, b, 0, st, ev_start, ev_stop, 0, args...);
+        else kernel<<<g, b, 0, st>>>(args...);
+    };
+    if (screened) {
+        if (kind == 0)
+            go(score_screen_k<0>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
+               group_begin, group_end);
+        else if (kind == 1)
+            go(score_screen_k<1>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
+               group_begin, group_end);
+        else
+            go(score_screen_k<2>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
+               group_begin, group_end);
+    } else {
+        if (kind == 0)
+            go(score_mask_k<0>, s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep, group_begin, group_end);
+        else if (kind == 1)
+            go(score_mask_k<1>, s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep, group_begin, group_end);
+        else
+            go(score_mask_k<2>, s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep, group_begin, group_end);
+    }
 }
 
 

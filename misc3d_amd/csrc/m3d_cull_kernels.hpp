@@ -52,7 +52,9 @@ constexpr int kPairMain = 1008;
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
                        uint32_t* pair_rep /* kPairReplicas u32, zero on entry: evaluated (tile, hypothesis) pairs */,
-                       hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */);
+                       hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */,
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* both set: receive the launch's own start / stop
+                       times (m3d_stats.ms_score_kernel) */);
 // (planes and spheres go through score_screen_k unless m3d_config.score_fp32_screen is 0)
 // The device's prediction of the hypothesis the replay will end with (pick_best_k, m3d_cull_kernels.hip)
 struct BestPick {

@@ -531,10 +531,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 g_lo = std::max(g0, ga);
                 if (!lead_prepared)   // (a new fit: minimal_fit_k has done it)
                     launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
-                if (timing) HIPCHK(hipEventRecord(s.k2, ctx->stream));
                 launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
-                                  h_pad, pair_rep, ctx->stream, 0, ga);
-                if (timing) HIPCHK(hipEventRecord(s.k3, ctx->stream));
+                                  h_pad, pair_rep, ctx->stream, 0, ga, timing ? s.k2 : nullptr, timing ? s.k3 : nullptr);
                 // fold of the lead's counters + keep masks of the rest of this rank's groups: one launch
                 launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
                                       g0 == 0 ? rec_host : nullptr, bc, ub, keep, g1 - g_lo, ctx->stream,
@@ -542,10 +540,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             } else {
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
             }
-            if (timing) HIPCHK(hipEventRecord(s.k0, ctx->stream));
             launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
-                              pair_rep, ctx->stream, g_lo, g1);
-            if (timing) HIPCHK(hipEventRecord(s.k1, ctx->stream));
+                              pair_rep, ctx->stream, g_lo, g1, timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
             // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
             // ... and (one GPU) write the records straight into the slot's pinned host array (device-visible): no copy
             // command behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
