@@ -199,10 +199,31 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm = None
+    transport_note = ""
     if world > 1:
         dist.init_process_group("gloo")                 # control plane only
-        # data path: library-owned RCCL communicator (rehearsal: the caller-supplied all-gather over gloo)
-        comm = capi.Comm.torch_host() if rehearsal else capi.Comm.rccl(device=local)
+        # data path: library-owned RCCL communicator (rehearsal: the caller-supplied all-gather over gloo).  Should RCCL
+        # not come up on some rank -- or its first exchange fail -- EVERY rank falls back to the host transport (the same
+        # shard loop and kernels, the records over gloo), and the JSON line says so: a slower number beats none
+        fake_failure = os.environ.get("M3D_BENCH_FAKE_RCCL_FAILURE") == "1"   # (test hook: exercises the fallback)
+        if rehearsal and not fake_failure:
+            comm = capi.Comm.torch_host()
+        else:
+            ok, why = 1, ""
+            try:
+                if fake_failure:
+                    raise RuntimeError("simulated (M3D_BENCH_FAKE_RCCL_FAILURE)")
+                comm = capi.Comm.rccl(device=local)
+            except Exception as e:   # noqa: BLE001
+                comm, ok, why = None, 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = capi.Comm.torch_host()
+                transport_note = "RCCL communicator unavailable (" + (why or "on another rank") + ")"
+                print(f"[bench] rank {rank}: {transport_note}; records go over gloo", file=sys.stderr)
     elif os.environ.get("M3D_BENCH_FORCE_SHARDED") == "1":   # the N > 1 driver on one GPU (world-1 communicator)
         comm = capi.Comm.rccl(world=1, rank=0, device=local)
     n_gpus = world
@@ -232,6 +253,20 @@ def main():
     PRIMING_FITS = 10
     import gc
     gc.collect()          # here, not next to the timed region: a full collection idles the GPU for tens of milliseconds
+    if world > 1 and not rehearsal and not transport_note:
+        # the first exchange over the RCCL communicator, guarded: if it fails on any rank, all of them switch transports
+        ok, why = 1, ""
+        try:
+            step()
+        except Exception as e:   # noqa: BLE001
+            ok, why = 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            comm._h = None                  # (the broken communicator is left alone: destroying it may hang too)
+            comm = capi.Comm.torch_host()
+            transport_note = "the first RCCL exchange failed (" + (why or "on another rank") + ")"
+            print(f"[bench] rank {rank}: {transport_note}; records go over gloo", file=sys.stderr)
     for _ in range(PRIMING_FITS):
         step()
     for _ in range(a.warmup):
@@ -379,7 +414,7 @@ def main():
                "config": {"workload": label, "points": N, "hypotheses_per_gpu": H_total / world,
                           "hypotheses_total": H_total, "threshold": thr, "probability": prob, "sampler_seed": seed,
                           "parallelism": (f"hypothesis-sharded x{world}, C++ driver + " + ("gloo all-gather, ALL RANKS ON ONE GPU (rehearsal)"
-                                                                                       if rehearsal else "RCCL all-gather") if world > 1 else
+                                                                                       if rehearsal else ("gloo all-gather over host memory -- " + transport_note if transport_note else "RCCL all-gather")) if world > 1 else
                                           ("single GPU through the sharded driver (world-1 RCCL communicator)" if comm
                                            else "single GPU")),
                           "setup_fits_before_warmup": PRIMING_FITS},

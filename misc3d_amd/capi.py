@@ -254,11 +254,21 @@ class Comm:
         if world is None:
             world, rank = (dist.get_world_size(group), dist.get_rank(group)) if dist.is_initialized() else (1, 0)
         ident = np.zeros(128, dtype=np.uint8)
+        status = np.zeros(129, dtype=np.uint8)     # the id + one byte that says rank 0 got one (nobody waits for a rank that raised)
+        err = None
         if rank == 0:
-            _check(lib().m3d_comm_unique_id(_p(ident)))
+            try:
+                _check(lib().m3d_comm_unique_id(_p(ident)))
+                status[:128] = ident
+                status[128] = 1
+            except M3DError as e:
+                err = e
         if world > 1:
-            t = torch.from_numpy(ident)
+            t = torch.from_numpy(status)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not status[128]:
+            raise err if err is not None else M3DError(-6, "rank 0 could not create an RCCL unique id")
+        ident = np.ascontiguousarray(status[:128])
         # librccl prints a version banner to STDOUT on its first communicator; callers (bench.py) own stdout, so the
         # banner is sent to stderr: fd 1 points at fd 2 for the duration of the call, C stdio flushed on both sides
         libc = C.CDLL(None)

@@ -27,3 +27,19 @@ def test_bench_starts_its_own_ranks_and_prints_one_json_line():
     assert d["value"] > 0 and 0 < d["roofline"]["frac"] <= 1
     st = d["strong_scaling"]
     assert set(st) == {"c2", "c3cyl", "c3sph"} and all(v["identical_to_1gpu"] for v in st.values())
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_the_host_transport_when_rccl_does_not_come_up():
+    """If the RCCL communicator cannot be created on some rank (simulated), every rank switches to the host transport (same
+    shard loop and kernels, records over gloo) and the JSON line says so -- a slower number, not a crash."""
+    env = dict(os.environ, M3D_BENCH_REHEARSAL="1", M3D_BENCH_FAKE_RCCL_FAILURE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                        "--points", "100000"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "RCCL communicator unavailable" in d["config"]["parallelism"] or "rehearsal" in d["config"]["parallelism"]
