@@ -179,10 +179,10 @@ if "C5" in which:
     n = int(os.environ.get("M3D_C5_POINTS", "10000000"))
     pts = synth.room_cloud_c5(n, 6)
     t0 = time.perf_counter()
-    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19)
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19, copy=False)
     dt = time.perf_counter() - t0
     t0 = time.perf_counter()
-    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19)
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19, copy=False)
     dt2 = time.perf_counter() - t0
     # HBM-bound by construction (a round = a few hundred hypotheses on what is left of the cloud, then compaction + removal
     # passes over it): algorithmic bytes = per round 24 B x remaining points x 4 (RefineModel's counting and writing pass,
