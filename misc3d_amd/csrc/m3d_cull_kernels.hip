@@ -5,19 +5,20 @@
 // part of space.  The resident cloud therefore carries a Hilbert-sorted copy cut into TILES of 512
 // consecutive points (one wave: 8 rows of 64) with an axis-aligned bounding box each.  Per chunk of
 // hypotheses:
-//   cull_mask_k   one wave per (group of 64 hypotheses, range of tiles), one hypothesis per lane with
-//                 its record in registers; the tile boxes stream through SGPRs.  Conservative
-//                 box-vs-slab test written against the EXACT cut-offs of the scoring record
-//                 (m3d_fp.hpp) with a margin three orders of magnitude above the fp64 rounding of the
-//                 per-point arithmetic.  Result: one 64-bit mask per (tile, group) and, per
-//                 hypothesis, the number of tiles it can touch.
-//   keep_mask_k   bound-and-prune: hypotheses whose touched tiles hold fewer points than the best
-//                 inlier count of EARLIER chunks can neither beat nor tie it in the sequential
-//                 replay (ransac.h:595-596); their bits are masked out.
-//   score_mask_k  one wave per (tile, range of groups): the tile's 512 points stay in VGPRs, set
-//                 bits are walked with scalar ops, the hypothesis records stream through SGPRs, the
-//                 per-pair arithmetic and the compare are exactly those of score_k (bit-identical
-//                 decisions), counts go to counts[h] with integer atomics (order-free, exact).
+//   cull_tiles32_k  one wave per (64 tiles, a few groups of 64 hypotheses): lane = tile with its fp32 box in registers,
+//                   the hypotheses' fp32 box-test records stream through scalar loads, two per packed instruction.
+//                   CONSERVATIVE box-vs-slab test: every rounding is in the margin (m3d_fp.hpp), the sign bit of the
+//                   test value is the verdict.  Result: one 64-bit mask per (tile, group) and, per hypothesis, the
+//                   number of tiles it can touch.  (cull_tiles_k: the same in fp64, m3d_config.cull_fp32 = 0.)
+//   keep_mask_k     bound-and-prune: hypotheses whose touched tiles hold fewer points than the best
+//                   inlier count of EARLIER hypotheses can neither beat nor tie it in the sequential
+//                   replay (ransac.h:595-596); their bits are masked out.
+//   score_screen_k  one wave per (tile, range of groups): the tile's 512 points stay in VGPRs as fp32 offsets from the
+//                   box centre; a packed-fp32 pass with a rigorous rounding bound decides all but the points within
+//                   the bound of the cut-off, and a (tile, hypothesis) pair with such a point is counted again by
+//                   the exact fp64 code (tile_count: the per-pair arithmetic and compare of score_k, bit-identical
+//                   decisions); counts go to counts[h] with integer atomics (order-free, exact).
+//                   (score_mask_k: fp64 only, m3d_config.score_fp32_screen = 0.)
 // A culled (tile, hypothesis) pair provably contains no inlier, so the counts of unpruned hypotheses
 // equal the dense ones; tests compare both paths against the oracle.  RefineModel / tie-break passes
 // keep using the original-order arrays, so inlier index lists and serial sums do not see the sort.
