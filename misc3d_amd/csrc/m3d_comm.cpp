@@ -126,10 +126,6 @@ int m3d_comm::allgather_host(const void* send, void* recv, size_t bytes, hipStre
 int m3d_comm::allgather_u32_device(uint32_t* buf, size_t count, hipStream_t st, uint32_t* host_scratch,
                                    int* host_has_all) {
     *host_has_all = 0;
-    if (world == 1 && transport == kRccl) {   // a one-rank gather is the identity: no launch
-        collectives++;
-        return M3D_OK;
-    }
     if (transport == kRccl) {
         collectives++;
         RcclApi& a = rccl();

@@ -509,7 +509,11 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         auto* keep = ctx->keep.as<unsigned long long>();
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
         uint32_t* bc = prune ? ctx->best_count.as<uint32_t>() : nullptr;
-        uint32_t* rec_host = comm ? nullptr : s.h_counts.as<uint32_t>();   // sharded: the host gets the GATHERED records
+        // sharded: the host gets the GATHERED records -- unless the communicator has ONE rank: its slice is the window, the
+        // gather the identity, and the records go to the host the way the one-GPU path sends them (written by the folding
+        // kernels themselves: no copy command, no detour over the copy stream)
+        const bool solo = comm && comm->world == 1 && comm->transport == m3d_comm::kRccl;   // (a caller-supplied all-gather is always called)
+        uint32_t* rec_host = (comm && !solo) ? nullptr : s.h_counts.as<uint32_t>();
         PickFinal pfin;
         if (pick_final) {
             pfin = *pick_final;
@@ -553,7 +557,10 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             HIPCHK(hipMemsetAsync(rec_dev + (size_t)g0 * 64, 0, sizeof(uint32_t) * sl_pad, ctx->stream));
             h_pairs[0] = h_pairs[1] = 0;
         }
-        if (comm) {
+        if (solo) {
+            comm->collectives++;   // (the window's exchange, degenerate)
+            s.host_has_records = true;
+        } else if (comm) {
             // the one exchange of the window: every rank's slice of records, in place (RCCL: ncclAllGather on this
             // stream, nothing on the host; host transports wait for the stream and leave the records in h_counts)
             int host_has_all = 0;
