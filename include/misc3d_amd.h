@@ -380,7 +380,10 @@ typedef struct m3d_config {
                                        rounding bound in front of the exact fp64 test: identical counts); 0: fp64 only (score_mask_k) */
     int32_t cull_fp32;              /* [M3D_CULL_FP32=0]    default 1: the box tests of the culled path run in fp32 with outward-rounded margins
                                        (cull_tiles32_k: conservative, identical results); 0: fp64 box tests (cull_tiles_k) */
-    int32_t reserved[6];            /* zero */
+    int32_t reg_fp32_screen;        /* [M3D_REG_SCREEN=0]   default 1: the nearest-neighbour search of the registration validation finds its
+                                       candidate in fp32 (16-byte list entries relative to the cell, rounding bound) and evaluates the winner
+                                       in fp64; a query whose runner-up is within the bound takes the fp64 walk: identical distances */
+    int32_t reserved[5];            /* zero */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

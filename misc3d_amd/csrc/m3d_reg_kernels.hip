@@ -312,14 +312,23 @@ __global__ void sort_cells_by_x_k(const uint32_t* __restrict__ cell_start, uint3
 __global__ void nl_fill_sorted_k(GridDesc g, const uint32_t* __restrict__ cell_start, uint32_t ncell,
                                  const uint32_t* __restrict__ nl_start, const double* __restrict__ qx,
                                  const double* __restrict__ qy, const double* __restrict__ qz,
-                                 double4* __restrict__ nl_pts) {
+                                 double4* __restrict__ nl_pts, uint32_t* __restrict__ nl_hdr,
+                                 float4* __restrict__ nl32, uint4* __restrict__ nl_rec, uint32_t* __restrict__ overflow,
+                                 const uint32_t* __restrict__ nl32_start) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= ncell) return;
     const uint32_t pos0 = nl_start[c];
-    if (nl_start[c + 1] == pos0) return;
+    if (nl_start[c + 1] == pos0) {
+        if (nl_hdr) nl_hdr[c] = 0u;
+        if (nl_rec) nl_rec[c] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     const uint32_t ix = c % g.nx, iy = (c / g.nx) % g.ny, iz = c / (g.nx * g.ny);
     uint32_t pos = pos0, n_col[3] = {0, 0, 0};
     const int col_dx[3] = {0, -1, 1};
+    // (the expressions sorted_walk32 uses for the cell's corner)
+    const double hc = 1.0 / g.inv_h;
+    const double Ox = g.ox + (double)(int)ix * hc, Oy = g.oy + (double)(int)iy * hc, Oz = g.oz + (double)(int)iz * hc;
     for (int col = 0; col < 3; ++col) {
         uint32_t p[9], e[9];
         for (int k = 0; k < 9; ++k) {
@@ -347,6 +356,73 @@ __global__ void nl_fill_sorted_k(GridDesc g, const uint32_t* __restrict__ cell_s
         }
     }
     nl_pts[pos0].w = (double)(n_col[0] + 65536u * n_col[1]);   // (a list holds far fewer than 65536 points)
+    if (nl_hdr) nl_hdr[c] = n_col[0] + 65536u * n_col[1];
+    if (!nl32) return;
+    // the screen's copy (sorted_walk32): the three columns merged in ascending fp32 x (left column reversed, own, right --
+    // a merge because the columns may overlap by a rounding at the cell faces), w = index of the fp64 entry; sentinels
+    // at both ends
+    const uint32_t n_mid = n_col[0], n_lr = n_col[0] + n_col[1], n_tot = n_lr + n_col[2];
+    if (n_tot > 65535u) {
+        atomicOr(overflow, 1u);   // (the 16-bit offsets of nl_rec: the caller drops the screen)
+        return;
+    }
+    const uint32_t q0 = nl32_start[c] + (uint32_t)kWalkPad;   // first real entry
+    for (int k = 0; k < kWalkPad; ++k) {
+        nl32[q0 - 1u - (uint32_t)k] = make_float4(-3e38f, 0.0f, 0.0f, 0.0f);
+        nl32[q0 + n_tot + (uint32_t)k] = make_float4(3e38f, 0.0f, 0.0f, 0.0f);
+    }
+    uint32_t il = n_lr, im = 0u, ir = n_lr;   // left: entries il - 1 down to n_mid
+    auto off32 = [&](uint32_t rel) {
+        const double4 q = nl_pts[pos0 + rel];
+        return make_float4((float)(q.x - Ox), (float)(q.y - Oy), (float)(q.z - Oz), __uint_as_float(pos0 + rel));
+    };
+    float thr[5];
+    for (int k = 0; k < 5; ++k) thr[k] = (float)((double)k * hc * 0.25);
+    uint32_t offs[5] = {0u, 0u, 0u, 0u, 0u};
+    float4 fl, fm, fr;
+    if (il > n_mid) fl = off32(il - 1u);
+    if (im < n_mid) fm = off32(im);
+    if (ir < n_tot) fr = off32(ir);
+    for (uint32_t o = 0; o < n_tot; ++o) {
+        const bool hl = il > n_mid, hm = im < n_mid, hr = ir < n_tot;
+        int pick = hl ? 0 : (hm ? 1 : 2);
+        float bx = hl ? fl.x : (hm ? fm.x : fr.x);
+        if (pick == 0 && hm && fm.x < bx) {
+            pick = 1;
+            bx = fm.x;
+        }
+        if (pick != 2 && hr && fr.x < bx) pick = 2;
+        float4 v;
+        if (pick == 0) {
+            v = fl;
+            if (--il > n_mid) fl = off32(il - 1u);
+        } else if (pick == 1) {
+            v = fm;
+            if (++im < n_mid) fm = off32(im);
+        } else {
+            v = fr;
+            if (++ir < n_tot) fr = off32(ir);
+        }
+        nl32[q0 + o] = v;
+        for (int k = 0; k < 5; ++k) offs[k] += v.x < thr[k] ? 1u : 0u;
+    }
+    nl_rec[c] = make_uint4(q0, offs[0] | (offs[1] << 16), offs[2] | (offs[3] << 16), offs[4] | (n_tot << 16));
+}
+
+// nl32_start[0..ncell]: exclusive scan of (entries + 2 kWalkPad) over the non-empty lists; total[0] = the array's length
+__global__ void nl32_count_k(const uint32_t* __restrict__ nl_start, uint32_t ncell, uint32_t* __restrict__ out) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= ncell) return;
+    const uint32_t cnt = nl_start[c + 1] - nl_start[c];
+    out[c] = cnt ? cnt + 2u * (uint32_t)kWalkPad : 0u;
+}
+void launch_nl32_offsets(const uint32_t* nl_start, uint32_t ncell, uint32_t* nl32_start, uint32_t* tile_sums,
+                         uint32_t* total, hipStream_t s) {
+    nl32_count_k<<<(ncell + 255) / 256, 256, 0, s>>>(nl_start, ncell, nl32_start);
+    const uint32_t nt = (ncell + 2047) / 2048;
+    tile_scan_k<<<nt, 256, 0, s>>>(nl32_start, ncell, tile_sums);
+    launch_scan_blocks(tile_sums, nt, total, s);
+    add_tile_offsets_k<<<(ncell + 1 + 255) / 256, 256, 0, s>>>(nl32_start, ncell, tile_sums, total);
 }
 
 // step 1: counts + exclusive scan into nl_start[0..ncell]; the caller reads nl_start[ncell] (= entries),
@@ -361,11 +437,12 @@ void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl
     add_tile_offsets_k<<<(ncell + 1 + 255) / 256, 256, 0, s>>>(nl_start, ncell, tile_sums, total);
 }
 void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, double* qx,
-                    double* qy, double* qz, double4* nl_pts, hipStream_t s, const uint32_t* orig, bool sorted) {
+                    double* qy, double* qz, double4* nl_pts, hipStream_t s, const uint32_t* orig, bool sorted,
+                    uint32_t* nl_hdr, float4* nl32, uint4* nl_rec, uint32_t* overflow, const uint32_t* nl32_start) {
     const uint32_t ncell = g.nx * g.ny * g.nz;
     if (sorted && !orig) {
         sort_cells_by_x_k<<<(ncell + 255) / 256, 256, 0, s>>>(cell_start, ncell, qx, qy, qz);
-        nl_fill_sorted_k<<<(ncell + 255) / 256, 256, 0, s>>>(g, cell_start, ncell, nl_start, qx, qy, qz, nl_pts);
+        nl_fill_sorted_k<<<(ncell + 255) / 256, 256, 0, s>>>(g, cell_start, ncell, nl_start, qx, qy, qz, nl_pts, nl_hdr, nl32, nl_rec, overflow, nl32_start);
         return;
     }
     nl_fill_k<<<(ncell + 255) / 256, 256, 0, s>>>(g, cell_start, ncell, nl_start, qx, qy, qz, nl_pts, orig);
@@ -435,6 +512,152 @@ __device__ __forceinline__ double nearest_phase2(const GridDesc& g, const uint32
 }
 
 constexpr int kNlBatch = 2;   // neighbour-list candidates per trip
+constexpr int kNlAhead = 4;   // own-column entries per trip of the sorted walk (one batch evaluated, one in flight)
+
+// The walk over a three-column list (GridDesc::nl_sorted) in fp64: the own column in full, in batches of kNlAhead
+// entries with the next batch in flight; then the left column from the cell outwards (descending x) and the right one
+// (ascending x) only while the x-distance ALONE is below the best squared distance so far -- every entry behind the cut
+// is farther away than `best`, so the minimum is the same as over the whole 3x3x3 block.  A batch may run past the end
+// of its column into the next one: every entry of the list is a point of the block, evaluating more of them than the
+// cut requires leaves the minimum what it is.  (nl_hdr: all three column bounds after ONE round trip.)
+__device__ __forceinline__ double sorted_walk64(const GridDesc& g, uint32_t cell, double px, double py, double pz) {
+    double best = INFINITY;
+    const uint32_t b = g.nl_start[cell], e = g.nl_start[cell + 1], hdr = g.nl_hdr[cell];
+    if (b >= e) return best;
+    const uint32_t last = e - 1u;
+    const uint32_t m_end = b + (hdr & 0xFFFFu), l_end = m_end + (hdr >> 16);
+    struct P3 {
+        double x, y, z;
+    };
+    auto ld = [&](uint32_t i) {
+        const double4* __restrict__ p = g.nl_pts + min(i, last);
+        return P3{p->x, p->y, p->z};
+    };
+    auto eval = [&](const P3& q) {
+        const double ddx = px - q.x, ddy = py - q.y, ddz = pz - q.z;
+        const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+        if (d2 < best) best = d2;
+    };
+    P3 cur[kNlAhead], nxt[kNlAhead];
+#pragma unroll
+    for (int k = 0; k < kNlAhead; ++k) cur[k] = ld(b + (uint32_t)k);
+    P3 lf = ld(m_end), rf = ld(l_end);
+    for (uint32_t c = b; c < m_end; c += kNlAhead) {
+#pragma unroll
+        for (int k = 0; k < kNlAhead; ++k) nxt[k] = ld(c + (uint32_t)(kNlAhead + k));
+#pragma unroll
+        for (int k = 0; k < kNlAhead; ++k) eval(cur[k]);
+#pragma unroll
+        for (int k = 0; k < kNlAhead; ++k) cur[k] = nxt[k];
+    }
+    for (uint32_t c = m_end; c < l_end; ++c) {   // left column, descending x
+        const P3 nx = ld(c + 1u);
+        const double ddx = px - lf.x;
+        if (!(ddx * ddx < best)) break;
+        eval(lf);
+        lf = nx;
+    }
+    for (uint32_t c = l_end; c < e; ++c) {       // right column, ascending x
+        const P3 nx = ld(c + 1u);
+        const double ddx = px - rf.x;
+        if (!(ddx * ddx < best)) break;
+        eval(rf);
+        rf = nx;
+    }
+    return best;
+}
+// The fp32 SCREEN of the neighbour search (GridDesc::nl32 / nl_rec).  Counters first: with fp64 entries the kernel was
+// bound by the L1's tag look-ups (TCP busy 70 % + 14 % tag-conflict stalls; a gather of one list entry costs a look-up
+// per distinct cell among the lanes -- ~27 per instruction -- whatever its size), and behind that by the number of
+// DEPENDENT round trips of a walk.  So: visit fewer entries, fetch each with ONE load, several per round trip.
+//   * nl32 holds every list a second time as 16-byte entries (x, y, z as fp32 offsets from the min corner O of the
+//     list's own cell, w = the index of the fp64 entry in nl_pts), all 27 cells MERGED in ascending x, with
+//     kWalkPad sentinel entries (x = -+3e38: squared distance +inf) in front of and behind every list.
+//   * nl_rec[cell] = (start, five 16-bit offsets, entries): offset k = the first entry with x >= k h / 4.  A query
+//     starts at the offset nearest to it and walks right (ascending x) and left (descending x) AT THE SAME TIME,
+//     kWalkB entries per side and trip, the next batch of each side in flight; a side goes on only while the x-distance
+//     ALONE of the batch's last entry can still beat the best candidate: ~13 entries instead of ~19, ~8 round trips
+//     instead of ~15.
+//   * Rounding: entries lie in [-h, 2h), the query in [0, h); with u = 2^-24 a coordinate difference carries an error
+//     below 6 u h (two conversions of values below 2h and h, one subtraction of a value below 3h; the fp64 roundings of O
+//     and of the subtractions stay below 0.01 u h by the host's admission test).  s = fma(dz, dz, fma(dy, dy, dx dx))
+//     then differs from the distance d2 the fp64 walk computes by at most 12 u h (|dx| + |dy| + |dz|) + 108 u^2 h^2 +
+//     3.1 u s <= 10.4 u (d2 + h^2) + 3.1 u s + ..., i.e. |s - d2| <= E(s) := 2^-18 s + 2^-18 h^2 + 1e-36 with a margin of
+//     four (the last term: a flushed subnormal).
+//   * The walk keeps the smallest s (m1, at entry i1) and the second smallest (m2).  If m2 > m1 + E(m1) + E(m2), entry
+//     i1 is strictly nearer in fp64 than every other visited entry (s - E(s) is increasing), and the result is ITS fp64
+//     distance, evaluated with the fp64 walk's expression on the fp64 entry.  Otherwise (exact ties, duplicates, near
+//     ties: a few queries in 10^5) the query takes the fp64 walk.
+//   * A side stops after a batch whose last entry lies on that side of the query with dx^2 >= m1 + 2 E(m1), m1 taken
+//     BEFORE the batch (larger: later): the list is sorted by the very fp32 x the test uses and fl(x - ux) is monotone in
+//     x, so the true x-distance squared of everything behind that entry is at least m1 + E(m1) >= the fp64 distance of
+//     entry i1.  Where the walks start affects their length only: right covers [start, n), left [0, start), every entry
+//     is visited at most once, a sentinel changes nothing (s = inf) and stops its side.
+__device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell, int ix, int iy, int iz, double px,
+                                                double py, double pz) {
+    const uint4 rec = g.nl_rec[cell];
+    if ((rec.w >> 16) == 0u) return INFINITY;   // empty list
+    const double h = 1.0 / g.inv_h;
+    const float ux = (float)(px - (g.ox + (double)ix * h)), uy = (float)(py - (g.oy + (double)iy * h)),
+                uz = (float)(pz - (g.oz + (double)iz * h));
+    const float h2 = (float)(h * h);
+    const float e0 = __builtin_fmaf(h2, 0x1p-18f, 1e-36f);
+    const int ke = min(4, max(0, (int)__builtin_fmaf(ux, (float)(4.0 * g.inv_h), 0.5f)));   // nearest quarter boundary
+    const uint32_t offw = ke < 2 ? rec.y : (ke < 4 ? rec.z : rec.w);
+    const uint32_t start = (ke & 1) ? offw >> 16 : offw & 0xFFFFu;
+    const char* __restrict__ base = reinterpret_cast<const char*>(g.nl32 + rec.x + start);
+    auto ld = [&](int i) { return *reinterpret_cast<const float4*>(base + (ptrdiff_t)i * 16); };
+    float m1 = __builtin_inff(), m2 = __builtin_inff();
+    uint32_t i1 = 0u;
+    auto visit = [&](const float4 q) {
+        const float dx = q.x - ux, dy = q.y - uy, dz = q.z - uz;
+        const float s = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        i1 = s < m1 ? __float_as_uint(q.w) : i1;
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, s);   // (m1 <= m2: the median is the new runner-up)
+        m1 = __builtin_fminf(m1, s);
+    };
+    float4 rb[kWalkB], lb[kWalkB];
+#pragma unroll
+    for (int k = 0; k < kWalkB; ++k) {
+        rb[k] = ld(k);
+        lb[k] = ld(-1 - k);
+    }
+    int cr = 0, cl = 0;   // entries visited on either side
+    bool ar = true, al = true;
+    while (ar || al) {
+        const float thr = __builtin_fmaf(m1, 1.0f + 0x1p-17f, 2.0f * e0);
+        if (ar) {
+            float4 nx[kWalkB];
+#pragma unroll
+            for (int k = 0; k < kWalkB; ++k) nx[k] = ld(cr + kWalkB + k);
+#pragma unroll
+            for (int k = 0; k < kWalkB; ++k) visit(rb[k]);
+            const float dx = rb[kWalkB - 1].x - ux;
+            ar = !(dx > 0.0f && !(dx * dx < thr));
+            cr += kWalkB;
+#pragma unroll
+            for (int k = 0; k < kWalkB; ++k) rb[k] = nx[k];
+        }
+        if (al) {
+            float4 nx[kWalkB];
+#pragma unroll
+            for (int k = 0; k < kWalkB; ++k) nx[k] = ld(-1 - (cl + kWalkB + k));
+#pragma unroll
+            for (int k = 0; k < kWalkB; ++k) visit(lb[k]);
+            const float dx = lb[kWalkB - 1].x - ux;
+            al = !(dx < 0.0f && !(dx * dx < thr));
+            cl += kWalkB;
+#pragma unroll
+            for (int k = 0; k < kWalkB; ++k) lb[k] = nx[k];
+        }
+    }
+    const float bound = __builtin_fmaf(m1 + m2, 0x1p-18f, 2.0f * e0);   // E(m1) + E(m2)
+    const bool decided = m2 == __builtin_inff() ? m1 < __builtin_inff() /* one candidate */ : m2 > m1 + bound * 1.0001f;
+    if (!decided) return sorted_walk64(g, cell, px, py, pz);
+    const double4* __restrict__ w = g.nl_pts + i1;
+    const double ddx = px - w->x, ddy = py - w->y, ddz = pz - w->z;
+    return (ddx * ddx + ddy * ddy) + ddz * ddz;
+}
 
 // Exact nearest squared distance within the search radius (KDTreeFlann::SearchHybrid(p, r, 1)).
 // The grid cell is r/K.  Phase 1 scans the 3x3x3 block around the query's cell (9 contiguous x-rows):
@@ -442,49 +665,21 @@ constexpr int kNlBatch = 2;   // neighbour-list candidates per trip
 // true nearest neighbour -- the common case for an aligned pose.  Phase 2 (nothing that close) scans
 // the (2K+1)^3 block, which covers the whole radius.  `min` is order-free, so the value equals the
 // kd-tree's.  Returns +inf when nothing lies in the scanned block.
+// SCREEN: the caller has checked that g.nl32 is there (launch_reg_validate picks the instantiation; the others pass false
+// and walk in fp64).
+template <bool SCREEN = false>
 __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* __restrict__ cell_start,
                                              const double* __restrict__ qx, const double* __restrict__ qy,
                                              const double* __restrict__ qz, double px, double py, double pz) {
     int ix, iy, iz;
     double best = INFINITY;
     if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return best;
-    if (g.nl_start && g.nl_sorted) {
-        // three-column list (GridDesc::nl_sorted): the query cell's own x-column in full, then the left column from the
-        // cell outwards (descending x) and the right column (ascending x) only while the x-distance ALONE is below the
-        // best squared distance so far -- every entry behind the cut is farther away than `best`, so the minimum is
-        // the same as over the whole 3x3x3 block.  A typical aligned query evaluates ~a third of the block.
+    if (SCREEN) {
         const uint32_t cell = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
-        const uint32_t b = g.nl_start[cell], e = g.nl_start[cell + 1];
-        if (b < e) {
-            double4 cur = g.nl_pts[b];
-            const uint32_t hdr = (uint32_t)cur.w;
-            const uint32_t n_mid = hdr & 0xFFFFu, n_left = hdr >> 16;
-            const uint32_t m_end = b + n_mid, l_end = m_end + n_left;
-            for (uint32_t c = b; c < m_end; ++c) {
-                const double4 nxt = g.nl_pts[min(c + 1, e - 1)];   // one entry ahead
-                const double ddx = px - cur.x, ddy = py - cur.y, ddz = pz - cur.z;
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-                cur = nxt;
-            }
-            // (cur = first entry of the left column, or of the right one, or a repeat of the last entry)
-            for (uint32_t c = m_end; c < l_end; ++c) {
-                const double4 p4 = g.nl_pts[c];
-                const double ddx = px - p4.x;
-                if (!(ddx * ddx < best)) break;   // descending x: everything further left is farther still
-                const double ddy = py - p4.y, ddz = pz - p4.z;
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-            }
-            for (uint32_t c = l_end; c < e; ++c) {
-                const double4 p4 = g.nl_pts[c];
-                const double ddx = px - p4.x;
-                if (!(ddx * ddx < best)) break;   // ascending x
-                const double ddy = py - p4.y, ddz = pz - p4.z;
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-            }
-        }
+        best = sorted_walk32(g, cell, ix, iy, iz, px, py, pz);
+    } else if (g.nl_start && g.nl_sorted) {
+        const uint32_t cell = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
+        best = sorted_walk64(g, cell, px, py, pz);
     } else if (g.nl_start) {
         // the 3x3x3 block of this cell as ONE contiguous list (nl_fill_k): two dependent loads instead of
         // nine row ranges + nine gathers; 4 candidates per trip, the tail repeats the last one (min is idempotent)
@@ -538,6 +733,7 @@ __device__ __forceinline__ uint32_t phase_tile(uint32_t tile_local, uint32_t res
 // source points whose nearest target point is closer than the threshold (ballot + s_bcnt1) and the
 // order-free sum of those squared distances (the rmse numerator; decides fitness ties, see the
 // driver).  partial_cnt / partial_sum: [tile][s_pad].
+template <bool SCREEN>
 __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__ sx, const double* __restrict__ sy,
                                                        const double* __restrict__ sz, const double* __restrict__ Ts,
                                                        uint32_t s_pad, uint32_t s_per_split, GridDesc g,
@@ -589,7 +785,7 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
                     const double px = ((t[0] * x[j] + t[1] * y[j]) + t[2] * z[j]) + t[3];
                     const double py = ((t[4] * x[j] + t[5] * y[j]) + t[6] * z[j]) + t[7];
                     const double pz = ((t[8] * x[j] + t[9] * y[j]) + t[10] * z[j]) + t[11];
-                    const double d2 = nearest_d2(g, cell_start, qx, qy, qz, px, py, pz);
+                    const double d2 = nearest_d2<SCREEN>(g, cell_start, qx, qy, qz, px, py, pz);
                     const bool f = d2 < g.r2;
                     cnt += (uint32_t)__popcll(__ballot(f));
                     sum += f ? d2 : 0.0;
@@ -956,8 +1152,12 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         const uint32_t gps = (groups + splits - 1) / splits;
         const uint32_t nsplit = (groups + gps - 1) / gps;
         const uint32_t slots = (tiles + 7) / 8;
-        reg_validate_k<<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy,
-                                                         qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit);
+        if (g.nl32 && g.nl_rec && g.nl_sorted && g.nl_start && g.nl_hdr)
+            reg_validate_k<true><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy,
+                                                                   qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit);
+        else
+            reg_validate_k<false><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy,
+                                                                    qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit);
     };
     if (best_cnt == 0 || n_tiles < 16) {
         launch(0xFFu, nullptr);

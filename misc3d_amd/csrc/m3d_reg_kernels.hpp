@@ -14,6 +14,9 @@ constexpr int kRegPruneStride = 8;   // validation phase A runs on every 8th sou
 // cell table would not fit), origin K+1 cells below the bounding-box minimum and K+1 empty cells above
 // the maximum, so the (2K+1)^3 neighbourhood of any query cell in [K, n-1-K] stays inside the arrays
 // and covers every target point closer than threshold.
+constexpr int kWalkB = 2;             // sorted_walk32: list entries per side and trip
+constexpr int kWalkPad = 2 * kWalkB;  // sentinels at either end of a list of GridDesc::nl32 (a side's look-ahead reaches at most
+                                      // 2 kWalkB - 1 entries past the end)
 struct GridDesc {
     double ox, oy, oz, inv_h, r2;
     double h2_in;  // (0.999 h)^2: a neighbour closer than this inside the 3x3x3 block is the nearest
@@ -29,6 +32,16 @@ struct GridDesc {
     // so that a query evaluates its own column, and then walks the side columns outwards from the cell only while the
     // x-distance alone is still below the best squared distance found (exact: everything skipped is farther away).
     int nl_sorted = 0;
+    const uint32_t* nl_hdr = nullptr;   // nl_sorted: n_mid + 65536 * n_left per cell once more, next to nl_start (the query knows
+                                         // all three column bounds after ONE round trip and can fetch from all of them at once)
+    // nl_sorted, optional: the fp32 screen of the search (sorted_walk32 in m3d_reg_kernels.hip).  nl32: every list once
+    // more as 16-byte entries -- fp32 offsets from the min corner of the list's OWN cell, w = index of the fp64 entry in
+    // nl_pts -- with the 27 cells merged in ascending x and sentinels at both ends (its own layout: launch_nl32_offsets);
+    // nl_rec[cell] = (first real entry, 5 x 16-bit offsets of the first entry at or right of each quarter boundary of the
+    // cell, entries in the top half of w).  The walk finds the nearest candidate and the runner-up in fp32 and evaluates
+    // the winner in fp64; a runner-up within the rounding bound sends the query down the fp64 walk.
+    const float4* nl32 = nullptr;
+    const uint4* nl_rec = nullptr;
 };
 
 
@@ -56,7 +69,13 @@ void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl
 // are written in the three-column layout of GridDesc::nl_sorted; the caller sets g.nl_sorted = 1.
 void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, double* qx,
                     double* qy, double* qz, double4* nl_pts, hipStream_t s,
-                    const uint32_t* orig = nullptr, bool sorted = false);
+                    const uint32_t* orig = nullptr, bool sorted = false, uint32_t* nl_hdr = nullptr /* sorted: ncell words */,
+                    float4* nl32 = nullptr /* sorted, optional: as many entries as nl_pts */, uint4* nl_rec = nullptr /* ncell */,
+                    uint32_t* overflow = nullptr /* one word, zero on entry: set when a list is too long for nl_rec */,
+                    const uint32_t* nl32_start = nullptr /* launch_nl32_offsets */);
+// layout of GridDesc::nl32: nl32_start[0..ncell] (scratch of ncell + 1 words), total[0] = entries incl. sentinels
+void launch_nl32_offsets(const uint32_t* nl_start, uint32_t ncell, uint32_t* nl32_start, uint32_t* tile_sums,
+                         uint32_t* total, hipStream_t s);
 // partial_cnt / partial_sum: src.n_pad / 64 rows of s_pad entries (the LDS-staged kernel, lds_rows, writes one row
 // per 64 source points; reg_validate_k one per 256).  Returns the rows actually used: what launch_reduce_partials folds.
 constexpr int kRegValidateRows = 4;   // rows per 256 source points

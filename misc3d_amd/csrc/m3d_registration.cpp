@@ -66,12 +66,12 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, cell_orig, tile_sph, fast_stats;
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, cell_orig, tile_sph, fast_stats;
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
-                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &cell_orig,
+                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &nl_hdr, &nl32, &nl_rec, &nl32_start, &cell_orig,
                           &tile_sph, &fast_stats})
             b->release();
     }
@@ -180,8 +180,39 @@ int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, 
         RESERVE(S.nl_pts, sizeof(double4) * std::max<size_t>(entries, 1));
         // without original indices riding in w (validation grid): x-sorted three-column lists with early termination
         const bool sorted = orig == nullptr && config().reg_sorted_lists != 0;
+        if (sorted) RESERVE(S.nl_hdr, sizeof(uint32_t) * (size_t)ncell);
+        // fp32 copies of the entries (GridDesc::nl32) when the offsets from a cell corner are good to fp32's last bit: the
+        // corner g.o + i h and the subtraction are rounded in fp64, which must stay far below 2^-24 h
+        double far = 0.0;
+        for (double v : {g.ox, g.oy, g.oz}) far = std::max(far, std::fabs(v));
+        far += (double)std::max(g.nx, std::max(g.ny, g.nz)) / g.inv_h;
+        bool screen = sorted && config().reg_fp32_screen != 0 && far * 0x1p-50 <= 0x1p-24 / g.inv_h * 0.01 &&
+                      1.0 / g.inv_h > 1e-15 && 1.0 / g.inv_h < 1e15 && ncell <= (1u << 24) && entries < (1u << 28);
+        uint32_t* overflow = S.total.as<uint32_t>() + 3;
+        if (screen) {
+            RESERVE(S.nl32_start, sizeof(uint32_t) * ((size_t)ncell + 1));
+            launch_nl32_offsets(S.nl_start.as<uint32_t>(), ncell, S.nl32_start.as<uint32_t>(), S.tile_sums.as<uint32_t>(),
+                                overflow, ctx->stream);   // (the word receives the length first, then serves as the flag)
+            uint32_t entries32 = 0;
+            HIPCHK(hipMemcpyAsync(&entries32, overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            RESERVE(S.nl32, sizeof(float4) * std::max<size_t>(entries32, 1));
+            RESERVE(S.nl_rec, sizeof(uint4) * (size_t)ncell);
+            HIPCHK(hipMemsetAsync(overflow, 0, sizeof(uint32_t), ctx->stream));
+        }
         launch_nl_fill(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.qx.as<double>(),
-                       S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream, orig, sorted);
+                       S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream, orig, sorted,
+                       sorted ? S.nl_hdr.as<uint32_t>() : nullptr, screen ? S.nl32.as<float4>() : nullptr,
+                       screen ? S.nl_rec.as<uint4>() : nullptr, overflow, screen ? S.nl32_start.as<uint32_t>() : nullptr);
+        if (screen) {   // a list beyond the 16-bit offsets of nl_rec: no screen for this grid
+            uint32_t over = 0;
+            HIPCHK(hipMemcpyAsync(&over, overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            screen = over == 0;
+        }
+        g.nl_hdr = sorted ? S.nl_hdr.as<uint32_t>() : nullptr;
+        g.nl32 = screen ? S.nl32.as<float4>() : nullptr;
+        g.nl_rec = screen ? S.nl_rec.as<uint4>() : nullptr;
         g.nl_start = S.nl_start.as<uint32_t>();
         g.nl_pts = S.nl_pts.as<double4>();
         g.nl_sorted = sorted ? 1 : 0;
