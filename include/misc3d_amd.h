@@ -202,6 +202,9 @@ typedef struct m3d_reg_stats {
     uint64_t exact_rmse_evals; /* of which needed the serial-order sum of squared distances */
     uint64_t lds_wave_hypotheses;    /* validation work units (64 source points x 1 hypothesis) served from the LDS-staged box */
     uint64_t global_wave_hypotheses; /* ... that took the global-memory path (pose outside the box, or staging off) */
+    uint64_t nn_fp32_screen;         /* 1: the validation's neighbour search ran behind the fp32 screen (m3d_config.reg_fp32_screen and a
+                                      * grid the screen admits: cell edge and offsets within fp32's reach) */
+    uint64_t nn_screen_fallbacks;    /* queries whose runner-up lay within the rounding bound of the winner: decided by the fp64 walk */
 } m3d_reg_stats;
 /* corr_src/corr_dst: m index pairs (the std::pair<vector<size_t>,vector<size_t>> of the reference).
  * confidence: Open3D RANSACConvergenceCriteria::confidence_ (the reference always uses the default

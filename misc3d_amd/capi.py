@@ -57,7 +57,8 @@ class RegStats(C.Structure):
     _fields_ = [("fitness", C.c_double), ("inlier_rmse", C.c_double), ("validations", C.c_uint64),
                 ("iterations", C.c_int64), ("best_index", C.c_int64), ("est_k", C.c_int64),
                 ("ms_total", C.c_double), ("ties", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
-                ("lds_wave_hypotheses", C.c_uint64), ("global_wave_hypotheses", C.c_uint64)]
+                ("lds_wave_hypotheses", C.c_uint64), ("global_wave_hypotheses", C.c_uint64),
+                ("nn_fp32_screen", C.c_uint64), ("nn_screen_fallbacks", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

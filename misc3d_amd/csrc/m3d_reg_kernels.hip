@@ -653,7 +653,10 @@ __device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell
     }
     const float bound = __builtin_fmaf(m1 + m2, 0x1p-18f, 2.0f * e0);   // E(m1) + E(m2)
     const bool decided = m2 == __builtin_inff() ? m1 < __builtin_inff() /* one candidate */ : m2 > m1 + bound * 1.0001f;
-    if (!decided) return sorted_walk64(g, cell, px, py, pz);
+    if (!decided) {
+        if (g.nl32_fallbacks) atomicAdd(g.nl32_fallbacks, 1ull);
+        return sorted_walk64(g, cell, px, py, pz);
+    }
     const double4* __restrict__ w = g.nl_pts + i1;
     const double ddx = px - w->x, ddy = py - w->y, ddz = pz - w->z;
     return (ddx * ddx + ddy * ddy) + ddz * ddz;
@@ -1145,9 +1148,10 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
                                                                              res_mask, n_tiles, kp, tiles, nsplit, fast_stats);
             return;
         }
-        // enough blocks to fill the chip, and at least ~40 splits per tile so that the ~160 blocks an XCD
-        // holds at a time belong to a handful of tiles (see the block map in the kernel)
-        const uint32_t want = std::max<uint32_t>(kRegMinSplits, (2048 + tiles - 1) / tiles);
+        // enough blocks to fill the chip several times over (the pruning phases launch an eighth of the tiles: 16 384 blocks
+        // instead of 2048 is 4 % on C4), and at least ~40 splits per tile so that the ~160 blocks an XCD holds at a time
+        // belong to a handful of tiles (see the block map in the kernel)
+        const uint32_t want = std::max<uint32_t>(kRegMinSplits, (16384 + tiles - 1) / tiles);
         const uint32_t splits = std::min(want, groups);
         const uint32_t gps = (groups + splits - 1) / splits;
         const uint32_t nsplit = (groups + gps - 1) / gps;

@@ -42,6 +42,7 @@ struct GridDesc {
     // the winner in fp64; a runner-up within the rounding bound sends the query down the fp64 walk.
     const float4* nl32 = nullptr;
     const uint4* nl_rec = nullptr;
+    unsigned long long* nl32_fallbacks = nullptr;   // optional counter: queries the screen handed to the fp64 walk
 };
 
 

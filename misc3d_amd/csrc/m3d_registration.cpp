@@ -66,12 +66,12 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, cell_orig, tile_sph, fast_stats;
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, nl32_fallbacks, cell_orig, tile_sph, fast_stats;
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
-                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &nl_hdr, &nl32, &nl_rec, &nl32_start, &cell_orig,
+                          &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &nl_hdr, &nl32, &nl_rec, &nl32_start, &nl32_fallbacks, &cell_orig,
                           &tile_sph, &fast_stats})
             b->release();
     }
@@ -187,7 +187,7 @@ int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, 
         for (double v : {g.ox, g.oy, g.oz}) far = std::max(far, std::fabs(v));
         far += (double)std::max(g.nx, std::max(g.ny, g.nz)) / g.inv_h;
         bool screen = sorted && config().reg_fp32_screen != 0 && far * 0x1p-50 <= 0x1p-24 / g.inv_h * 0.01 &&
-                      1.0 / g.inv_h > 1e-15 && 1.0 / g.inv_h < 1e15 && ncell <= (1u << 24) && entries < (1u << 28);
+                      1.0 / g.inv_h > 1e-15 && 1.0 / g.inv_h < 1e15 && entries < (1u << 28);
         uint32_t* overflow = S.total.as<uint32_t>() + 3;
         if (screen) {
             RESERVE(S.nl32_start, sizeof(uint32_t) * ((size_t)ncell + 1));
@@ -213,6 +213,11 @@ int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, 
         g.nl_hdr = sorted ? S.nl_hdr.as<uint32_t>() : nullptr;
         g.nl32 = screen ? S.nl32.as<float4>() : nullptr;
         g.nl_rec = screen ? S.nl_rec.as<uint4>() : nullptr;
+        if (screen) {
+            RESERVE(S.nl32_fallbacks, sizeof(unsigned long long));
+            HIPCHK(hipMemsetAsync(S.nl32_fallbacks.p, 0, sizeof(unsigned long long), ctx->stream));
+            g.nl32_fallbacks = S.nl32_fallbacks.as<unsigned long long>();
+        }
         g.nl_start = S.nl_start.as<uint32_t>();
         g.nl_pts = S.nl_pts.as<double4>();
         g.nl_sorted = sorted ? 1 : 0;
@@ -746,6 +751,14 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
         stats->est_k = est_k_global;
         stats->ties = ties;
         stats->exact_rmse_evals = exact_evals;
+        stats->lds_wave_hypotheses = stats->global_wave_hypotheses = 0;
+        stats->nn_fp32_screen = g.nl32 ? 1 : 0;
+        stats->nn_screen_fallbacks = 0;
+        if (g.nl32_fallbacks) {
+            unsigned long long fb = 0;
+            HIPCHK(hipMemcpy(&fb, g.nl32_fallbacks, sizeof(fb), hipMemcpyDeviceToHost));
+            stats->nn_screen_fallbacks = fb;
+        }
         if (spheres_built) {
             unsigned long long fs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIPCHK(hipMemcpy(fs, S.fast_stats.p, sizeof(fs), hipMemcpyDeviceToHost));

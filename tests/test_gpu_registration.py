@@ -55,7 +55,9 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
     kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=edge, confidence=1.0, seed=4)
     T, st = capi.registration_ransac(src, dst, cs, cd, **kw)
     # each optimisation switched off in turn, and the optional LDS-staged validation kernel switched on (m3d_config)
-    for env, val in (("reg_prune", 0), ("reg_neighbour_lists", 0), ("reg_sorted_lists", 0), ("reg_lds_staging", 1)):
+    assert st["nn_fp32_screen"] == (1 if st["validations"] > 48 else 0)    # (the lists are built once a call validates in earnest)
+    for env, val in (("reg_prune", 0), ("reg_neighbour_lists", 0), ("reg_sorted_lists", 0), ("reg_lds_staging", 1),
+                     ("reg_fp32_screen", 0)):
         old = capi.set_config(**{env: val})
         try:
             T0, st0 = capi.registration_ransac(src, dst, cs, cd, **kw)
@@ -102,6 +104,104 @@ def test_registration_lds_staging_is_exact(capi, orc):
             assert st[k] == st2[k], (key, k)
     o = orc.registration_ransac(d["src"], d["dst"], cs, cd, thr=0.03, max_iter=3000, edge_thr=0.9, confidence=1.0, seed=4)
     assert np.array_equal(T, o.T) and st["best_index"] == o.best_index and st["validations"] == o.validations
+
+
+def _first_chunk_records(capi, src, dst, cs, cd, **kw):
+    with capi.RegSession(src, dst, cs, cd, **kw) as sess:
+        n = sess.begin_chunk()
+        counts, sums = sess.validate(0, n)
+        sess.replay(counts, sums)
+        while (m := sess.begin_chunk()) is not None:
+            c2, s2 = sess.validate(0, m)
+            sess.replay(c2, s2)
+        T, st = sess.finish()
+    return counts.copy(), sums.copy(), T, st
+
+
+@pytest.mark.parametrize("case", ["lattice", "dups", "near_ties", "far_offset", "tiny_scale", "one_cell", "dense"])
+def test_registration_nn_screen_adversarial(capi, orc, case):
+    """The fp32 screen of the validation's neighbour search (m3d_config.reg_fp32_screen: 16-byte list entries relative
+    to the cell, winner evaluated in fp64, near ties handed to the fp64 walk) must leave every per-hypothesis inlier count
+    and every sum of squared distances what the fp64 walk makes them -- each nearest distance is the same double -- on
+    inputs built to confuse it: exact ties (lattice, duplicates), ties within 1e-9, scenes beyond
+    what fp32 offsets can carry (the screen must stand down), everything in one cell, 100 points per cell."""
+    rng = np.random.default_rng(12)
+    thr, scale, shift, partner = 0.03, 1.0, np.zeros(3), None      # partner: src row i came from dst row partner[i] (default i)
+    if case == "lattice":       # every query midway between lattice points: 2, 4 or 8 nearest neighbours at the SAME distance
+        g = np.arange(-12, 12) * 0.005
+        dst = np.stack(np.meshgrid(g, g, g[:6], indexing="ij"), -1).reshape(-1, 3)
+        partner = rng.choice(len(dst), 2500, replace=False)
+        src = dst[partner] + rng.choice([0.0, 0.0025], size=(2500, 3))
+    elif case == "dups":
+        base = rng.uniform(-0.2, 0.2, (1500, 3)) * [1, 1, 0.02]
+        dst = np.concatenate([base, base, base[:500]])
+        src = base[:1200] + rng.normal(0, 1e-3, (1200, 3))
+    elif case == "near_ties":   # queries on the bisector of two target points, off it by 1e-9 .. 1e-13 of the spacing
+        a = rng.uniform(-0.2, 0.2, (1500, 3)) * [1, 1, 0.05]
+        d = rng.normal(size=(1500, 3))
+        d *= 0.004 / np.linalg.norm(d, axis=1)[:, None]
+        dst = np.concatenate([a - d, a + d])
+        src = a + d * (10.0 ** rng.uniform(-13, -9, (1500, 1))) * rng.choice([-1, 1], (1500, 1))
+    elif case == "far_offset":
+        dst = rng.uniform(-0.2, 0.2, (3000, 3)) * [1, 1, 0.02]
+        src = dst[:2000] + rng.normal(0, 1e-3, (2000, 3))
+        shift = np.array([3.0e5, -2.0e5, 1.0e5])
+    elif case == "tiny_scale":
+        dst = rng.uniform(-0.2, 0.2, (3000, 3)) * [1, 1, 0.02]
+        src = dst[:2000] + rng.normal(0, 1e-3, (2000, 3))
+        scale = 1e-18
+    elif case == "one_cell":    # the whole target inside one grid cell, the threshold a hundred times its extent
+        dst = rng.uniform(0, 1e-4, (300, 3))
+        src = dst[:200] + rng.normal(0, 1e-6, (200, 3))
+    else:                       # dense: ~100 points per cell, lists of ~900 entries
+        dst = rng.uniform(-0.05, 0.05, (60000, 3)) * [1, 1, 0.01]
+        src = dst[:3000] + rng.normal(0, 3e-4, (3000, 3))
+    Tm = synth.rigid_transform(25.0, (0.2, -0.3, 1.0), (0.05, -0.02, 0.01))
+    src = src @ np.linalg.inv(Tm)[:3, :3].T + np.linalg.inv(Tm)[:3, 3]     # dst = Tm(src)
+    src, dst, thr = (src + shift) * scale, (dst + shift) * scale, thr * scale
+    ns = len(src)
+    # correspondences: the partner, a third of them random
+    cs = rng.integers(0, ns, 400)
+    cd = cs.copy() if partner is None else partner[cs]
+    cd[::3] = rng.integers(0, len(dst), len(cd[::3]))
+    kw = dict(threshold=thr, max_iter=1500, edge_length_threshold=0.5, confidence=1.0, seed=5)
+    res = {}
+    for screen in (1, 0):
+        old = capi.set_config(reg_fp32_screen=screen)
+        try:
+            res[screen] = _first_chunk_records(capi, src, dst, cs, cd, **kw)
+        finally:
+            capi.restore_config(old)
+    c1, s1, T1, st1 = res[1]
+    c0, s0, T0, st0 = res[0]
+    assert len(c1) >= 3 and c1.max() > 0.5 * ns
+    # (the sums are order-free: the counting sorts place the points of a cell in the order their atomics land, so the last
+    # bits of a sum differ from run to run with or without the screen; inlier_rmse below is the serial-order sum)
+    assert np.array_equal(c1, c0) and np.allclose(s1, s0, rtol=1e-12, atol=0.0)
+    assert np.array_equal(T1, T0)
+    for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse"):
+        assert st1[k] == st0[k], k
+    assert st0["nn_fp32_screen"] == 0 and st0["nn_screen_fallbacks"] == 0
+    if case in ("far_offset", "tiny_scale"):
+        assert st1["nn_fp32_screen"] == 0          # offsets from a cell corner would not be good to fp32's last bit
+    else:
+        assert st1["nn_fp32_screen"] == 1
+        if case in ("lattice", "dups"):
+            assert st1["nn_screen_fallbacks"] > 100     # the ties were seen and handed over
+        # (near_ties: the three-point poses are off by more than the 1e-9 the construction leaves -- few ties survive)
+    if case not in ("tiny_scale", "dense"):
+        o = orc.registration_ransac(src, dst, cs, cd, thr=thr, max_iter=1500, edge_thr=0.5, confidence=1.0, seed=5)
+        assert st1["best_index"] == o.best_index and st1["validations"] == o.validations and st1["fitness"] == o.fitness
+        assert np.array_equal(T1.view(np.uint64), o.T.view(np.uint64))
+
+
+def test_registration_nn_screen_fallback_rate(capi):
+    """On ordinary data the screen decides practically every query itself."""
+    d, cs, cd = _problem(n=20000, seed=4, m=1200, true_fraction=0.5)
+    T, st = capi.registration_ransac(d["src"], d["dst"], cs, cd, threshold=0.03, max_iter=2000, edge_length_threshold=0.9,
+                                     confidence=1.0, seed=3)
+    assert st["nn_fp32_screen"] == 1 and st["validations"] > 100
+    assert st["nn_screen_fallbacks"] < 2e-4 * st["validations"] * 20000
 
 
 def test_registration_session_sharded_equals_single_call(capi):
