@@ -1075,13 +1075,23 @@ __global__ __launch_bounds__(1024) void reg_validate_lds_k(
 }
 
 // sums[s] = sum over tiles of partial_sum[tile][s] in tile order (deterministic)
-__global__ void reduce_sums_k(const double* __restrict__ partial_sum, uint32_t n_tiles, uint32_t s_pad,
-                              double* __restrict__ sums) {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s >= s_pad) return;
+// (workgroup = 64 hypotheses x kFoldSlices interleaved slices of the tiles, folded in LDS in a fixed order: a thread per
+// hypothesis walking all ~800 tiles alone took 0.2 ms per call)
+constexpr int kFoldSlices = 16;
+__global__ __launch_bounds__(64 * kFoldSlices) void reduce_sums_k(const double* __restrict__ partial_sum, uint32_t n_tiles,
+                                                                  uint32_t s_pad, double* __restrict__ sums) {
+    __shared__ double sm[kFoldSlices][64];
+    const uint32_t lane = threadIdx.x & 63u, sl = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x * 64u + lane;   // (s_pad is a multiple of 64)
     double acc = 0.0;
-    for (uint32_t t = 0; t < n_tiles; ++t) acc += partial_sum[(size_t)t * s_pad + s];
-    sums[s] = acc;
+    for (uint32_t t = sl; t < n_tiles; t += kFoldSlices) acc += partial_sum[(size_t)t * s_pad + s];
+    sm[sl][lane] = acc;
+    __syncthreads();
+    if (sl == 0) {
+        double a = 0.0;
+        for (int k = 0; k < kFoldSlices; ++k) a += sm[k][lane];
+        sums[s] = a;
+    }
 }
 
 // Bound-and-prune inside a chunk, against the best hypothesis of EARLIER chunks (count best_cnt, order-free sum of squared
@@ -1093,21 +1103,37 @@ __global__ void reduce_sums_k(const double* __restrict__ partial_sum, uint32_t n
 // summation-order tolerance of the replay's comparison.  (On C4 this second rule drops little: the survivors are good
 // poses whose sums lie within a factor of two of each other -- the nearest-neighbour distance on a densely sampled
 // surface hardly grows with a tangential shift.)
-__global__ void reg_keep_k(const uint32_t* __restrict__ partial_cnt, const double* __restrict__ partial_sum,
-                           uint32_t n_tiles, uint32_t done_mask, uint32_t s_pad, uint32_t points_rem, bool rem_exact,
-                           uint32_t best_cnt, double limit, uint8_t* __restrict__ keep, int first) {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s >= s_pad) return;
-    if (!first && !keep[s]) return;
+__global__ __launch_bounds__(64 * kFoldSlices) void reg_keep_k(const uint32_t* __restrict__ partial_cnt,
+                                                               const double* __restrict__ partial_sum, uint32_t n_tiles,
+                                                               uint32_t done_mask, uint32_t s_pad, uint32_t points_rem,
+                                                               bool rem_exact, uint32_t best_cnt, double limit,
+                                                               uint8_t* __restrict__ keep, int first) {
+    __shared__ double smq[kFoldSlices][64];
+    __shared__ uint32_t sma[kFoldSlices][64];
+    const uint32_t lane = threadIdx.x & 63u, sl = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x * 64u + lane;   // (s_pad is a multiple of 64)
+    const bool live = first || keep[s];
     uint32_t a = 0;
     double q = 0.0;
-    for (uint32_t t = 0; t < n_tiles; ++t)
-        if ((done_mask >> (t & 7u)) & 1u) {
-            a += partial_cnt[(size_t)t * s_pad + s];
-            q += partial_sum[(size_t)t * s_pad + s];
+    if (live)
+        for (uint32_t t = sl; t < n_tiles; t += kFoldSlices)
+            if ((done_mask >> (t & 7u)) & 1u) {
+                a += partial_cnt[(size_t)t * s_pad + s];
+                q += partial_sum[(size_t)t * s_pad + s];
+            }
+    sma[sl][lane] = a;
+    smq[sl][lane] = q;
+    __syncthreads();
+    if (sl == 0 && live) {
+        a = 0;
+        q = 0.0;
+        for (int k = 0; k < kFoldSlices; ++k) {
+            a += sma[k][lane];
+            q += smq[k][lane];
         }
-    const uint64_t bound = (uint64_t)a + points_rem;
-    keep[s] = (bound > best_cnt || (bound == best_cnt && (!rem_exact || q <= limit))) ? 1 : 0;
+        const uint64_t bound = (uint64_t)a + points_rem;
+        keep[s] = (bound > best_cnt || (bound == best_cnt && (!rem_exact || q <= limit))) ? 1 : 0;
+    }
 }
 
 // best_cnt / best_sum2: inlier count and order-free sum of squared distances of the best hypothesis of EARLIER chunks
@@ -1186,11 +1212,11 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
             launch(kPhase[ph], ph == 0 ? nullptr : keep);
             done |= kPhase[ph];
             if (ph < 3)
-                reg_keep_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_cnt, partial_sum, n_tiles, done, s_pad,
+                reg_keep_k<<<s_pad / 64, 64 * kFoldSlices, 0, s>>>(partial_cnt, partial_sum, n_tiles, done, s_pad,
                                                                points_on(0xFFu & ~done), !lds, best_cnt, limit, keep, ph == 0 ? 1 : 0);
         }
     }
-    reduce_sums_k<<<(s_pad + 255) / 256, 256, 0, s>>>(partial_sum, n_tiles, s_pad, sums);
+    reduce_sums_k<<<s_pad / 64, 64 * kFoldSlices, 0, s>>>(partial_sum, n_tiles, s_pad, sums);
     return n_tiles;
 }
 
