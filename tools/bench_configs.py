@@ -116,14 +116,16 @@ if "C4" in which:
                                      edge_length_threshold=0.9, confidence=1.0, seed=17)
     dt = time.perf_counter() - t0
     # every validation = one exact nearest-neighbour query per source point.  SURVEY.md 8(d)'s unit is 24 B per (hypothesis,
-    # point); the kernel is bound by fp64 VALU issue + L2 gathers of the per-cell candidate lists, not by HBM (DESIGN.md
-    # section 4; VALU busy fraction and FETCH_SIZE of reg_validate_k: profiles/r02_pmc_reg_validate.txt)
+    # point); the kernel is bound by the L1's tag look-ups (a list-entry gather touches ~29 cache lines per instruction:
+    # ~0.9 look-ups per cycle and CU) with VALU issue at ~60 % behind it, not by HBM (TA / TCP / SQ
+    # counters of reg_validate_k: profiles/r02_pmc_reg_validate.txt)
     queries = float(st["validations"]) * n
     emit("C4 compute_transformation_ransac 200k<->200k x 100k hyp", ms=dt * 1e3, hyp_per_s=100_000 / dt,
          validations=st["validations"], fitness=st["fitness"], best_index=st["best_index"],
          pose_err=float(np.abs(T - d["T"]).max()),
-         roofline={"bound": "hbm (algorithmic unit of SURVEY 8(d)); the binding limits are fp64 VALU issue and L2 gather latency",
-                   "kernel": "m3d::reg_validate_k", "achieved": queries * 24.0 / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         nn_fp32_screen=st["nn_fp32_screen"], nn_screen_fallbacks=st["nn_screen_fallbacks"],
+         roofline={"bound": "hbm (algorithmic unit of SURVEY 8(d)); the binding limits are the L1's tag look-ups (gathers) and VALU issue",
+                   "kernel": "m3d::reg_validate_k<true>", "achieved": queries * 24.0 / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": queries * 24.0 / dt / 1e9 / HBM_PEAK_GBS, "queries": queries, "queries_per_s": queries / dt,
                    "note": "whole call's wall clock (setup, grid, 173 MB of neighbour lists, replay included)"})
     ts = []

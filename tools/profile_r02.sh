@@ -27,5 +27,7 @@ for f in glob.glob("gpurun_out/pmc_reg_fetch/**/f_counter_collection.csv", recur
 print(f"reg_validate_k FETCH_SIZE over {n} launches (20 000 iterations of C4): {tot:.0f} KiB -> x1024 x2 (gfx950) = {tot*2048/1e9:.2f} GB")
 PY
 M3D_C4_ENV=1 python gpurun_out/pmc_reg_0/run.py >> gpurun_out/pmc_reg_validate.txt 2>&1
+echo "---- memory pipeline (tools/pmc_reg_mem.sh)" >> gpurun_out/pmc_reg_validate.txt
+bash tools/pmc_reg_mem.sh >> gpurun_out/pmc_reg_validate.txt 2>&1
 python tools/step_timeline.py gpurun_out/prof/trace_bench/bench_kernel_trace.csv > gpurun_out/step_timeline.txt 2>&1
 ls gpurun_out/prof gpurun_out/prof_c4 gpurun_out/prof_cfg
