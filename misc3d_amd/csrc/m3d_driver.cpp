@@ -790,7 +790,7 @@ static bool is_library_pinned(const void* p, size_t bytes) {
 // host link while the kernel runs instead of in a copy command the host issues after it has woken up).
 static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, const uint32_t* orig_dev, int kind,
                                    double thr, const double* model_dev, const double* lazy_in, void* total_host,
-                                   bool fused = false, uint64_t* idx_host = nullptr) {
+                                   bool fused = false, uint64_t* idx_host = nullptr, const PartitionOut* part = nullptr) {
     const uint32_t n = flag_view.n;
     const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
     RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
@@ -805,7 +805,7 @@ static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, c
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
                    ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
                    fused ? ctx->moment_partial.as<double>() : nullptr, fused ? ctx->h_moments.as<double>() : nullptr,
-                   idx_host, static_cast<uint32_t*>(total_host) /* pinned: the scan kernel writes the total there itself */);
+                   idx_host, static_cast<uint32_t*>(total_host) /* pinned: the scan kernel writes the total there itself */, part);
     ctx->compaction_fused = fused;
     ctx->compaction_idx_host = idx_host;
     return M3D_OK;
@@ -830,7 +830,8 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
     if (!compaction_total) {
         uint64_t* idx_host = inliers && fused && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1))
                                  ? reinterpret_cast<uint64_t*>(inliers) : nullptr;
-        const int rc = issue_refine_compaction(ctx, flag_view, orig_dev, kind, thr, model_dev, lazy_in, h, fused, idx_host);
+        const PartitionOut* part = ctx->partition_hook && orig_dev ? (*ctx->partition_hook)(expected_ni) : nullptr;
+        const int rc = issue_refine_compaction(ctx, flag_view, orig_dev, kind, thr, model_dev, lazy_in, h, fused, idx_host, part);
         if (rc != M3D_OK) return rc;
     }
     const bool have_moments = fused && ctx->compaction_fused;
@@ -981,7 +982,10 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     const bool spec_enabled = config().speculative_refine != 0;
     const bool spec = spec_enabled && prob >= 1.0 && !use_dense_scoring() && max_iter > 0;
     ctx->spec_compaction = false;
-    if (spec) {
+    // one GPU, culled path: every chunk ends with the completion word of sum_replicas_k's tail (and its pick, which only
+    // probability-1 fits act on) -- the host polls pinned memory instead of waiting for an event
+    const bool poll_done = !comm && !use_dense_scoring() && max_iter > 0;
+    if (spec || poll_done) {
         RESERVE(ctx->pick, sizeof(BestPick));
         if (!ctx->h_pick.p) {
             RESERVE(ctx->h_pick, 128);
@@ -1061,7 +1065,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         const size_t b = next_begin, e = std::min(max_iter, b + want);
         // one GPU: the chunk's last kernel (sum_replicas_k) picks the device's best itself and stores the completion word
         PickFinal pf;
-        const bool fused_pick = spec && !comm;
+        const bool fused_pick = poll_done;
         if (fused_pick) {
             pf.key = reinterpret_cast<unsigned long long*>(ctx->best_count.as<uint32_t>() + 2);
             pf.ticket = ctx->best_count.as<uint32_t>() + 1;
@@ -1076,7 +1080,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
                             b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec && !fused_pick,
                             fused_pick ? &pf : nullptr);
-        if (r == M3D_OK && fused_pick && e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
+        if (r == M3D_OK && fused_pick && spec && e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
             r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
                                         ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true,
                                         idx_host);
@@ -1363,7 +1367,9 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
 // cloud_remove_finish -- after the stream has been waited for -- checks the totals and switches the cloud over.
 // Without the finish nothing has changed for the caller (the partitions went into the spare buffer set).
 constexpr size_t kRemoveTotalsOffset = 160;   // bytes into h_small (refine() uses 0..127 and 192..255)
-static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* model_dev) {
+// cloud_remove_prepare: buffers + the destination of the next partition of the cloud in creation order (what mode 2 of
+// launch_compact, or a mode-0 compaction with a PartitionOut, writes)
+static int cloud_remove_prepare(m3d_cloud* c, PartitionOut* out) {
     DeviceCtx* ctx = c->ctx;
     m3d_cloud::Work& w = c->work;
     if (c->has_normals) return fail(M3D_ERR_INVALID_ARG, "removing points from a cloud with normals is not supported");
@@ -1388,17 +1394,32 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
         w.cur_is_v0 = true;
         w.active = true;
     }
-    const CloudView cur = w.cur;
     const int dst = w.cur_is_v0 ? 1 : w.pp;
+    out->ox = w.bx[dst].as<double>();
+    out->oy = w.by[dst].as<double>();
+    out->oz = w.bz[dst].as<double>();
+    out->oorig = w.bo[dst].as<uint32_t>();
+    out->n_pad_cap = c->n_pad0;
+    return M3D_OK;
+}
+// partition_done: the partition in creation order has been written by RefineModel's own compaction (PartitionOut)
+static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* model_dev, bool partition_done = false) {
+    DeviceCtx* ctx = c->ctx;
+    m3d_cloud::Work& w = c->work;
+    PartitionOut po;
+    const int rp = cloud_remove_prepare(c, &po);
+    if (rp != M3D_OK) return rp;
+    const CloudView cur = w.cur;
     const uint32_t nb = (cur.n + kCompactTile - 1) / kCompactTile;
     const uint32_t snb = (c->n_sorted + kCompactTile - 1) / kCompactTile;
     const uint32_t scap = c->n_tiles0 * kTilePoints;
     RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)std::max(nb, snb) + 1));
     RESERVE(ctx->total, 16);
     RESERVE(ctx->h_small, 256);
-    launch_compact(kind, cur, model_dev, thr, 2, w.cur_orig, nullptr, nullptr, w.bx[dst].as<double>(),
-                   w.by[dst].as<double>(), w.bz[dst].as<double>(), w.bo[dst].as<uint32_t>(), c->n_pad0,
-                   ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream);
+    w.partition_done = partition_done;
+    if (!partition_done)
+        launch_compact(kind, cur, model_dev, thr, 2, w.cur_orig, nullptr, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap,
+                       ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream);
     // the same stable partition on the sorted copy (every inlier is a finite point), then fresh tile boxes
     CloudView sview;
     sview.x = w.scur.x;
@@ -1423,7 +1444,12 @@ static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed) {
     const int dst = w.cur_is_v0 ? 1 : w.pp;
     uint32_t h[2];
     std::memcpy(h, ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset, sizeof(h));
-    const uint32_t new_n = h[0], new_sorted = h[1];
+    const uint32_t new_sorted = h[1];
+    // (a partition written by RefineModel's compaction has no total of its own: the sorted copy's removal count stands
+    // in, and the caller checks it against the length of the inlier list)
+    const uint32_t new_n = w.partition_done ? (new_sorted <= c->n_sorted && c->n_sorted - new_sorted <= cur.n
+                                                   ? cur.n - (c->n_sorted - new_sorted) : 0xFFFFFFFFu)
+                                            : h[0];
     if (new_n > cur.n || new_sorted > c->n_sorted || cur.n - new_n != c->n_sorted - new_sorted)
         return fail(M3D_ERR_INTERNAL, "the two copies of the cloud disagree on the removed points");
     if (n_removed) *n_removed = cur.n - new_n;
@@ -2166,14 +2192,25 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             // The removal of the round's inliers (:33) is queued behind RefineModel's kernels, before RefineModel
             // waits for them: the pre-refinement model is already on the device and the inlier count is known
             // from the scoring pass, so the round costs one host wait less.  Not on the last round.
-            bool removal_issued = false;
+            bool removal_issued = false, partition_fused = false;
+            PartitionOut part_out;
+            // RefineModel's compaction evaluates the very flags the removal needs: it writes the partition of the cloud
+            // in creation order as well (one count, one scan and one write launch less per round)
+            const std::function<const PartitionOut*(int64_t)> partition_hook = [&](int64_t expected_ni) -> const PartitionOut* {
+                if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) return nullptr;
+                if (cloud_remove_prepare(c0, &part_out) != M3D_OK) return nullptr;
+                partition_fused = true;
+                return &part_out;
+            };
             const std::function<int(int64_t)> issue_removal = [&](int64_t expected_ni) -> int {
                 if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) return M3D_OK;
                 removal_issued = true;
-                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev);
+                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev, partition_fused);
             };
+            ctx->partition_hook = &partition_hook;
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
                                   cluster_indices + off, &ni, nullptr, &issue_removal, &iterations_hint, comm);
+            ctx->partition_hook = nullptr;
             if (rc < 0) break;
             rc = M3D_OK;
             if (ni == 0) {  // the reference would loop forever (:29,:35)
@@ -2188,6 +2225,10 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             // pcd_copy = pcd_copy->SelectByIndex(inliers, true), :33 -- inliers of the PRE-refinement model,
             // still on the device (ctx->last_best_dev)
             size_t removed = 0;
+            if (partition_fused && !removal_issued) {   // (the two hooks take the same decision from the same count)
+                rc = fail(M3D_ERR_INTERNAL, "partition written without the removal being queued");
+                break;
+            }
             rc = removal_issued ? cloud_remove_finish(c0, &removed)
                                 : cloud_remove_locked(c0, M3D_PLANE, threshold, ctx->last_best_dev, &removed);
             if (rc != M3D_OK) break;

@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -90,6 +91,9 @@ struct DeviceCtx {
     PinBuf h_moments;          // ... folded (scan_blocks_k), device-visible: kFusedMomentDoubles doubles
     bool compaction_fused = false;            // the compaction in flight carried the moments
     uint64_t* compaction_idx_host = nullptr;  // ... and wrote the index list to this page-locked destination as well
+    // segmentation: asked by refine() right before it queues RefineModel's compaction -- given the inlier count the scoring
+    // pass reported, where should the partition of the NON-inliers go (null: no partition in this pass)?
+    const std::function<const m3d::PartitionOut*(int64_t)>* partition_hook = nullptr;
     PinBuf h_best;             // best minimal model of a fit on its way to the host (read after RefineModel's wait)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -122,6 +126,7 @@ struct m3d_cloud {
         const uint32_t* cur_orig = nullptr;   // working index -> index in the cloud as created
         int pp = 0, spp = 0;                  // buffer sets that RECEIVE the next compaction
         bool cur_is_v0 = true;
+        bool partition_done = false;   // the removal in flight found its creation-order partition already written (PartitionOut)
     } work;
     uint32_t n0 = 0, n_pad0 = 0, n_tiles0 = 0;
     m3d::CloudView view() const;        // working cloud

@@ -540,13 +540,72 @@ __global__ __launch_bounds__(256) void compact_write_k(
     const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ ox, double* __restrict__ oy,
     double* __restrict__ oz, uint32_t* __restrict__ oorig, uint32_t n_pad_cap,
-    uint64_t* __restrict__ out_idx_host /* MODE 0: the caller's page-locked index list, written as well (may be null) */) {
+    uint64_t* __restrict__ out_idx_host /* MODE 0 / 4: the caller's page-locked index list, written as well (may be null) */) {
     __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum2[4];
     double m[7];
     for (int k = 0; k < 7; ++k) m[k] = model[k];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t row_base = block_offsets[blockIdx.x];
     const uint32_t base = blockIdx.x * kCompactTile;
+    if (MODE == 4) {
+        // inlier list (mode 0) AND the partition of the rest (mode 2) from one evaluation of the distance.  Every
+        // workgroup before this one holds kCompactTile points of the cloud, so the others start at base - row_base.
+        uint32_t rest_base = base - row_base;
+        for (int r = 0; r < kCompactTile / 256; ++r) {
+            const uint32_t i = base + r * 256 + threadIdx.x;
+            bool f = false, g = false;
+            double px = 0, py = 0, pz = 0;
+            if (i < c.n) {
+                px = c.x[i];
+                py = c.y[i];
+                pz = c.z[i];
+                f = ref_distance<KIND>(m, px, py, pz) < thr;
+                g = !f;
+            }
+            const unsigned long long bf = __ballot(f), bg = __ballot(g);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (lane == 0) {
+                wsum[wave] = (uint32_t)__popcll(bf);
+                wsum2[wave] = (uint32_t)__popcll(bg);
+            }
+            __syncthreads();
+            uint32_t woff = 0, woff2 = 0;
+            for (int w = 0; w < wave; ++w) {
+                woff += wsum[w];
+                woff2 += wsum2[w];
+            }
+            const uint32_t rowtot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+            const uint32_t rowtot2 = (wsum2[0] + wsum2[1]) + (wsum2[2] + wsum2[3]);
+            if (f) {
+                const uint32_t pos = row_base + woff + (uint32_t)__popcll(bf & below);
+                const uint64_t id = (uint64_t)orig[i];
+                if (out_idx) out_idx[pos] = id;
+                if (out_idx_host) out_idx_host[pos] = id;
+            }
+            if (g) {
+                const uint32_t pos = rest_base + woff2 + (uint32_t)__popcll(bg & below);
+                ox[pos] = px;
+                oy[pos] = py;
+                oz[pos] = pz;
+                oorig[pos] = orig[i];
+            }
+            row_base += rowtot;
+            rest_base += rowtot2;
+            __syncthreads();
+        }
+        if (blockIdx.x == gridDim.x - 1) {   // NaN padding of the partition, as below
+            const uint32_t n = rest_base;
+            const uint32_t n_pad = min(n_pad_cap, (n + kScoreTile - 1) / kScoreTile * kScoreTile);
+            const double nan = u2f(0x7FF8000000000000ull);
+            for (uint32_t i = n + threadIdx.x; i < n_pad; i += 256u) {
+                ox[i] = nan;
+                oy[i] = nan;
+                oz[i] = nan;
+            }
+        }
+        return;
+    }
     for (int r = 0; r < kCompactTile / 256; ++r) {
         const uint32_t i = base + r * 256 + threadIdx.x;
         bool f = false;
@@ -556,7 +615,7 @@ __global__ __launch_bounds__(256) void compact_write_k(
             py = c.y[i];
             pz = c.z[i];
             d = ref_distance<KIND>(m, px, py, pz);
-            f = (d < thr) != (MODE >= 2);
+            f = (d < thr) != (MODE == 2 || MODE == 3);
         }
         const unsigned long long b = __ballot(f);
         const uint32_t lane_pre = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
@@ -573,7 +632,7 @@ __global__ __launch_bounds__(256) void compact_write_k(
                 if (out_idx_host) out_idx_host[pos] = id;   // 512-B bursts per wave row straight over the host link
             }
             if (MODE == 1) out_dist[pos] = d;
-            if (MODE >= 2) {
+            if (MODE == 2 || MODE == 3) {
                 ox[pos] = px;
                 oy[pos] = py;
                 oz[pos] = pz;
@@ -584,7 +643,7 @@ __global__ __launch_bounds__(256) void compact_write_k(
         __syncthreads();
     }
     // NaN padding of the freshly compacted SoA cloud, [n, n_pad): the last workgroup ends with row_base = n
-    if (MODE >= 2 && blockIdx.x == gridDim.x - 1) {
+    if ((MODE == 2 || MODE == 3) && blockIdx.x == gridDim.x - 1) {
         const uint32_t n = row_base;
         const uint32_t n_pad = min(n_pad_cap, (n + kScoreTile - 1) / kScoreTile * kScoreTile);
         const double nan = u2f(0x7FF8000000000000ull);
@@ -602,7 +661,7 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
                                 double* ox, double* oy, double* oz, uint32_t* oorig,
                                 uint32_t n_pad_out, uint32_t* block_counts, uint32_t* total,
                                 hipStream_t s, double* model_copy, double* moment_partial, double* moment_out,
-                                uint64_t* out_idx_host, uint32_t* total_host) {
+                                uint64_t* out_idx_host, uint32_t* total_host, const PartitionOut* part) {
     const uint32_t nb = (c.n + kCompactTile - 1) / kCompactTile;
     if (nb == 0) {
         (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
@@ -617,7 +676,10 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
     else
         compact_count_k<KIND, false><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts, model_copy, nullptr);
     scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total, sums ? moment_partial : nullptr, sums ? moment_out : nullptr, total_host);
-    if (mode == 0)
+    if (mode == 0 && part && orig)
+        compact_write_k<KIND, 4><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx, nullptr, part->ox, part->oy,
+                                                     part->oz, part->oorig, part->n_pad_cap, out_idx_host);
+    else if (mode == 0)
         compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
                                                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, out_idx_host);
     else if (mode == 1)
@@ -635,16 +697,17 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
                     uint32_t* block_counts, uint32_t* total, hipStream_t s, double* model_copy,
-                    double* moment_partial, double* moment_out, uint64_t* out_idx_host, uint32_t* total_host) {
+                    double* moment_partial, double* moment_out, uint64_t* out_idx_host, uint32_t* total_host,
+                    const PartitionOut* part) {
     if (kind == 0)
         launch_compact_kind<0>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host);
+                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part);
     else if (kind == 1)
         launch_compact_kind<1>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host);
+                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part);
     else
         launch_compact_kind<2>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host, total_host);
+                               n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host, total_host, part);
 }
 
 // EvaluateModel's `error += distance` in point order (ransac.h:637): a genuinely serial fp64 chain.

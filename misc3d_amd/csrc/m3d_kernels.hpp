@@ -81,6 +81,13 @@ void launch_bbox(const double* x, const double* y, const double* z, uint32_t n, 
 // mode 2: stable partition of the NON-inliers into (ox,oy,oz,oorig) (segmentation round)
 // mode 3: the same for coordinates only (the Z-order sorted copy)
 // block_counts: scratch of ceil(n / kCompactTile) + 1 uint32; total[0] receives the inlier count.
+// Optional second output of a mode-0 compaction (segmentation round): the same pass also writes the stable partition of the
+// NON-inliers (mode 2's output) -- the flags are the same, so the round saves a count, a scan and a write launch.
+struct PartitionOut {
+    double *ox = nullptr, *oy = nullptr, *oz = nullptr;
+    uint32_t* oorig = nullptr;
+    uint32_t n_pad_cap = 0;
+};
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
@@ -90,7 +97,8 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
                     double* moment_out = nullptr /* ... and kFusedMomentDoubles doubles (device-visible host memory): GeneralFit's raw
                                                     moments over the inliers about the model record's provisional centre */,
                     uint64_t* out_idx_host = nullptr /* mode 0: page-locked host copy of the index list, written by the kernel */,
-                    uint32_t* total_host = nullptr /* device-visible host word that receives total[0] as well (no copy command) */);
+                    uint32_t* total_host = nullptr /* device-visible host word that receives total[0] as well (no copy command) */,
+                    const PartitionOut* part = nullptr /* mode 0 with orig != null: the non-inliers' partition rides along */);
 // moment_out layout: [0..2] sum s, [3..8] sum s s^T (xx,xy,xz,yy,yz,zz), [9..11] sum s |s|^2 (sphere), [12] inlier count;
 // s = p - c0, c0 = model[4..6] (plane: the hypothesis' first sample point) or model[0..2] (sphere: the minimal centre).
 constexpr int kFusedMomentDoubles = 16;
