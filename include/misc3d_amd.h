@@ -56,7 +56,7 @@ typedef struct m3d_stats {
     uint64_t hypotheses_scored;  /* hypotheses the GPU scored (>= iterations: speculative chunks) */
     uint64_t exact_rmse_evals;   /* serial-order error sums needed (ties that order-free sums could not decide) */
     double ms_sample;            /* host: std::mt19937 sample table */
-    double ms_score;             /* device: minimal fit + scoring + reduce (HIP events; filled with m3d_config.kernel_timing) */
+    double ms_score;             /* host clock: sampling, minimal fit, scoring and replay, from the first launch to the last replayed chunk (filled with m3d_config.kernel_timing) */
     double ms_refine;            /* device+host: inlier compaction, GeneralFit, copy-out */
     double ms_total;             /* wall clock of the call */
     double ms_score_kernel;      /* device: sum of the scoring-kernel launches alone (HIP events around each; m3d_config.kernel_timing) */
@@ -376,7 +376,7 @@ typedef struct m3d_config {
     int32_t pool_limit_mb;          /* [M3D_POOL_MB]        default 4096: released device blocks parked per device for re-use (0 = none) */
     int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=1] default 0; 1: HIP events attached to every scoring launch (hipExtLaunchKernel: the
                                        launch's own start / stop times, no barrier packets) fill m3d_stats.ms_score_kernel /
-                                       score_launches, two more around the chunk fill ms_score (bench.py switches it on: ~4 us per C2 fit) */
+                                       score_launches (bench.py switches it on: ~4 us per C2 fit); ms_score becomes a host clock around the scoring phase */
     int32_t reg_lds_staging;        /* [M3D_REG_LDS=0]      default 0: registration validation with the target neighbourhood of a row of source points staged in LDS (bit-identical, not faster: DESIGN.md) */
     int32_t reg_sorted_lists;       /* [M3D_REG_SORTED=0]   default 1: x-sorted neighbour lists, side columns cut off by the x-distance */
     int32_t score_fp32_screen;      /* [M3D_SCORE_SCREEN=0] default 1: planes and spheres are counted by score_screen_k (packed-fp32 screen with a

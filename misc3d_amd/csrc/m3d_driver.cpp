@@ -1031,7 +1031,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     RESERVE(ctx->best_count, 16);   // cleared by the first chunk's minimal_fit_k
 
     const bool timing_events = config().kernel_timing != 0;   // (m3d_stats.ms_score / ms_score_kernel)
-    if (timing_events) HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    const double t_score0 = now_ms();   // (m3d_stats.ms_score: a host clock -- an event pair here cost a fit ~8 us)
     int rc = M3D_OK;
     int cur = 0;
     size_t next_begin = 0;
@@ -1249,10 +1249,9 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         best_dev = ctx->best_params.as<double>();
     }
     ctx->last_best_dev = best_dev;
-    if (timing_events) HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (timing_events) out->ms_score = now_ms() - t_score0;
     // The best minimal model travels to the host (pinned ctx->h_best) with RefineModel: its first kernel stores the
     // record there and RefineModel's own wait delivers it (no wait and no copy command here).
-    // ms_score is read from ev0..ev1 by the caller after that wait.
     RESERVE(ctx->h_best, sizeof(double) * kModelStride);
     if (rc != M3D_OK) {
         (void)hipStreamSynchronize(ctx->stream);
@@ -1324,10 +1323,6 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
                     &gf_ok, expected, ctx->spec_compaction ? nullptr : before_refine_wait, ctx->h_best.as<double>(), nullptr,
                     /*fused=*/true);
         if (rc != M3D_OK) return rc;
-    }
-    {
-        float ms = 0;
-        if (config().kernel_timing != 0 && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ro.ms_score = ms;
     }
     if (ro.st.best_index >= 0 && ni != ro.st.best_count)
         return fail(M3D_ERR_INTERNAL, "refine pass and scoring kernel disagree on the inlier count");
