@@ -91,6 +91,23 @@ __device__ __forceinline__ bool cell_of(const GridDesc& g, double x, double y, d
     return true;
 }
 
+// cell_of + the position inside the cell as a fraction of its edge (the scaled coordinate's own fractional part: what
+// (int) dropped), for the fp32 offsets of sorted_walk32
+__device__ __forceinline__ bool cell_of_frac(const GridDesc& g, double x, double y, double z, int lo_pad, int* ix, int* iy,
+                                             int* iz, double* frx, double* fry, double* frz) {
+    const double fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
+    if (!(fx >= (double)lo_pad && fx < (double)(g.nx - lo_pad) && fy >= (double)lo_pad &&
+          fy < (double)(g.ny - lo_pad) && fz >= (double)lo_pad && fz < (double)(g.nz - lo_pad)))
+        return false;
+    *ix = (int)fx;
+    *iy = (int)fy;
+    *iz = (int)fz;
+    *frx = fx - (double)*ix;   // (exact: fx >= 1 here, and both share their leading bits)
+    *fry = fy - (double)*iy;
+    *frz = fz - (double)*iz;
+    return true;
+}
+
 // hist[cell] counts the points of a cell; rank[i] = how many points of its cell had arrived before point i
 // (the value the counting add returns): the scatter then needs no second round of atomics.
 __global__ void grid_count_k(CloudView dst, GridDesc g, uint32_t* __restrict__ cell_of_point,
@@ -593,16 +610,20 @@ __device__ __forceinline__ double sorted_walk64(const GridDesc& g, uint32_t cell
 //     x, so the true x-distance squared of everything behind that entry is at least m1 + E(m1) >= the fp64 distance of
 //     entry i1.  Where the walks start affects their length only: right covers [start, n), left [0, start), every entry
 //     is visited at most once, a sentinel changes nothing (s = inf) and stops its side.
-__device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell, int ix, int iy, int iz, double px,
-                                                double py, double pz) {
-    const uint4 rec = g.nl_rec[cell];
+__device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell, double frx, double fry, double frz,
+                                                double px, double py, double pz) {
+    uint4 rec = g.nl_rec[cell];
+    // (all four words are needed at once: without this the compiler fetches w first, tests it, and fetches the rest in a
+    // second, dependent round trip)
+    asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));
     if ((rec.w >> 16) == 0u) return INFINITY;   // empty list
     const double h = 1.0 / g.inv_h;
-    const float ux = (float)(px - (g.ox + (double)ix * h)), uy = (float)(py - (g.oy + (double)iy * h)),
-                uz = (float)(pz - (g.oz + (double)iz * h));
+    // offsets from the cell's min corner: fraction x edge.  (The list's entries were written as q - (o + i h); the two
+    // differ by the fp64 roundings of either expression, ~1e-13 h: the 0.01 u h of the admission test covers them.)
+    const float ux = (float)(frx * h), uy = (float)(fry * h), uz = (float)(frz * h);
     const float h2 = (float)(h * h);
     const float e0 = __builtin_fmaf(h2, 0x1p-18f, 1e-36f);
-    const int ke = min(4, max(0, (int)__builtin_fmaf(ux, (float)(4.0 * g.inv_h), 0.5f)));   // nearest quarter boundary
+    const int ke = min(4, max(0, (int)__builtin_fmaf((float)frx, 4.0f, 0.5f)));   // nearest quarter boundary
     const uint32_t offw = ke < 2 ? rec.y : (ke < 4 ? rec.z : rec.w);
     const uint32_t start = (ke & 1) ? offw >> 16 : offw & 0xFFFFu;
     const char* __restrict__ base = reinterpret_cast<const char*>(g.nl32 + rec.x + start);
@@ -676,10 +697,13 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
                                              const double* __restrict__ qz, double px, double py, double pz) {
     int ix, iy, iz;
     double best = INFINITY;
-    if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return best;
     if (SCREEN) {
+        double frx, fry, frz;
+        if (!cell_of_frac(g, px, py, pz, g.K, &ix, &iy, &iz, &frx, &fry, &frz)) return best;
         const uint32_t cell = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
-        best = sorted_walk32(g, cell, ix, iy, iz, px, py, pz);
+        best = sorted_walk32(g, cell, frx, fry, frz, px, py, pz);
+    } else if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) {
+        return best;
     } else if (g.nl_start && g.nl_sorted) {
         const uint32_t cell = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
         best = sorted_walk64(g, cell, px, py, pz);
