@@ -1662,12 +1662,16 @@ __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const 
                                                   const double* __restrict__ qx, const double* __restrict__ qy,
                                                   const double* __restrict__ qz, const uint32_t* __restrict__ cell_orig,
                                                   int search, int max_nn, double angle_thr_rad,
-                                                  uint8_t* __restrict__ flag, uint8_t* __restrict__ overflow) {
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= c.n) return;
-    const double px = c.x[i], py = c.y[i], pz = c.z[i];
+                                                  uint8_t* __restrict__ flag, uint8_t* __restrict__ overflow,
+                                                  const uint32_t* __restrict__ n_sorted) {
+    // thread t takes the t-th point IN GRID ORDER (the points the grid holds: the finite ones; a non-finite point has no
+    // neighbours and no flag): the lanes of a wave sit in the same few cells and scan the same rows
+    const uint32_t t_sorted = blockIdx.x * 64u + threadIdx.x;
+    if (t_sorted >= n_sorted[0]) return;
+    const uint32_t i = cell_orig[t_sorted];
+    const double px = qx[t_sorted], py = qy[t_sorted], pz = qz[t_sorted];
     int ix, iy, iz;
-    if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return;   // non-finite point: no neighbours
+    if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return;
     double nd[kBoundaryMaxNb];
     uint32_t ni[kBoundaryMaxNb];
     int m = 0;
@@ -1810,11 +1814,11 @@ __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const 
 }
 void launch_boundary(const CloudView& c, const GridDesc& g, const uint32_t* cell_start, const double* qx,
                      const double* qy, const double* qz, const uint32_t* cell_orig, int search, int max_nn,
-                     double angle_threshold_deg, uint8_t* flag, uint8_t* overflow, hipStream_t s) {
+                     double angle_threshold_deg, uint8_t* flag, uint8_t* overflow, hipStream_t s, const uint32_t* n_sorted) {
     if (!c.n) return;
     const double thr = angle_threshold_deg * 3.14159265358979323846 / 180.0;   // :62
     boundary_k<<<(c.n + 63) / 64, 64, 0, s>>>(c, g, cell_start, qx, qy, qz, cell_orig, search, max_nn, thr, flag,
-                                              overflow);
+                                              overflow, n_sorted);
 }
 
 // ------------------------------------------------------------------------------------------------

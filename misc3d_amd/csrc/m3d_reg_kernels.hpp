@@ -103,7 +103,8 @@ void launch_icp_sums(const double* px, const double* py, const double* pz, uint3
 constexpr int kBoundaryMaxNb = 128;   // neighbours kept per point in boundary_k
 void launch_boundary(const CloudView& c, const GridDesc& g, const uint32_t* cell_start, const double* qx,
                      const double* qy, const double* qz, const uint32_t* cell_orig, int search, int max_nn,
-                     double angle_threshold_deg, uint8_t* flag, uint8_t* overflow, hipStream_t s);
+                     double angle_threshold_deg, uint8_t* flag, uint8_t* overflow, hipStream_t s,
+                     const uint32_t* n_sorted /* device: points the grid holds (launch_grid_build's total) */);
 void launch_info_sums(uint32_t n, const CloudView& dst, const uint32_t* nn, double* partial, double* sums,
                       hipStream_t s);
 void launch_icp_transform(const double* ix, const double* iy, const double* iz, uint32_t n, const double* T_dev,

@@ -1319,7 +1319,7 @@ int m3d_detect_boundary_points(const double* xyz, const double* normals, size_t 
             HIPCHK(hipMemsetAsync(flags.p, 0, (size_t)v.n + 8, ctx->stream));
             launch_boundary(v, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
                             S.cell_orig.as<uint32_t>(), search, max_nn, angle_threshold_deg, flags.as<uint8_t>(),
-                            flags.as<uint8_t>() + v.n, ctx->stream);
+                            flags.as<uint8_t>() + v.n, ctx->stream, S.total.as<uint32_t>());
             std::vector<uint8_t> hf((size_t)v.n + 8);
             HIPCHK(hipMemcpyAsync(hf.data(), flags.p, hf.size(), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipGetLastError());
