@@ -1658,6 +1658,10 @@ __device__ __forceinline__ void tangent_basis(const double* n, double* u, double
 // Neighbourhood = KDTreeFlann::Search with Radius (all d2 <= r^2), Hybrid (the max_nn nearest with d2 < r^2) or KNN
 // (the max_nn nearest), kept sorted by (d2, original index).  Radius / Hybrid: grid cell = 1.001 r, so the 3x3x3
 // block covers the radius; KNN: cell from the point density, shells of cells until the k-th distance is certain.
+// LDS32: at most 32 neighbours are kept (KNN / Hybrid with max_nn <= 32): the per-thread lists live in LDS ([slot][lane]: no
+// bank conflicts between lanes at the same slot) instead of scratch memory -- the sorted insertion moves ~15 entries per
+// offer, and that traffic was what the kernel's time went into
+template <bool LDS32>
 __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const uint32_t* __restrict__ cell_start,
                                                   const double* __restrict__ qx, const double* __restrict__ qy,
                                                   const double* __restrict__ qz, const uint32_t* __restrict__ cell_orig,
@@ -1672,8 +1676,19 @@ __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const 
     const double px = qx[t_sorted], py = qy[t_sorted], pz = qz[t_sorted];
     int ix, iy, iz;
     if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) return;
-    double nd[kBoundaryMaxNb];
-    uint32_t ni[kBoundaryMaxNb];
+    __shared__ double s_nd[LDS32 ? 32 * 64 : 1];
+    __shared__ uint32_t s_ni[LDS32 ? 32 * 64 : 1];
+    double nd_l[LDS32 ? 1 : kBoundaryMaxNb];
+    uint32_t ni_l[LDS32 ? 1 : kBoundaryMaxNb];
+    const int lane_ = (int)threadIdx.x;
+    auto ND = [&](int k) -> double& {
+        if constexpr (LDS32) return s_nd[k * 64 + lane_];
+        else return nd_l[k];
+    };
+    auto NI = [&](int k) -> uint32_t& {
+        if constexpr (LDS32) return s_ni[k * 64 + lane_];
+        else return ni_l[k];
+    };
     int m = 0;
     const int cap = search == 1 ? kBoundaryMaxNb : max_nn;
     // sorted insertion by (d2, original index); beyond `cap` the farthest entry is replaced (KNN / Hybrid) or
@@ -1684,16 +1699,16 @@ __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const 
             pos = m++;
         } else {
             if (search == 1) return false;
-            if (!(d2 < nd[m - 1] || (d2 == nd[m - 1] && o < ni[m - 1]))) return true;
+            if (!(d2 < ND(m - 1) || (d2 == ND(m - 1) && o < NI(m - 1)))) return true;
             pos = m - 1;
         }
-        while (pos > 0 && (d2 < nd[pos - 1] || (d2 == nd[pos - 1] && o < ni[pos - 1]))) {
-            nd[pos] = nd[pos - 1];
-            ni[pos] = ni[pos - 1];
+        while (pos > 0 && (d2 < ND(pos - 1) || (d2 == ND(pos - 1) && o < NI(pos - 1)))) {
+            ND(pos) = ND(pos - 1);
+            NI(pos) = NI(pos - 1);
             --pos;
         }
-        nd[pos] = d2;
-        ni[pos] = o;
+        ND(pos) = d2;
+        NI(pos) = o;
         return true;
     };
     if (search == 0) {
@@ -1733,7 +1748,7 @@ __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const 
             // strictly inside the bound (minus the cell-assignment slack): an unseen point can then neither be
             // closer nor tie with the k-th neighbour
             const double reach = ((double)r - 1e-6) * h;
-            if (m >= cap && reach > 0.0 && nd[m - 1] < reach * reach) break;
+            if (m >= cap && reach > 0.0 && ND(m - 1) < reach * reach) break;
         }
     } else {
         const int K = g.K;
@@ -1761,7 +1776,7 @@ __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const 
     } else {   // stand-in for Open3D EstimateNormals(param): covariance of the same neighbourhood, J3x3
         double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int t = 0; t < m; ++t) {
-            const double x = c.x[ni[t]], y = c.y[ni[t]], z = c.z[ni[t]];
+            const double x = c.x[NI(t)], y = c.y[NI(t)], z = c.z[NI(t)];
             s[0] += x;
             s[1] += y;
             s[2] += z;
@@ -1789,26 +1804,26 @@ __global__ __launch_bounds__(64) void boundary_k(CloudView c, GridDesc g, const 
     double u[3], v[3];
     tangent_basis(nrm, u, v);
     // angles of the neighbours in the tangent plane (:33-41), kept sorted as they come
-    double* ang = nd;   // the distances are not needed any more
+    // (the angles go where the distances were: those are not needed any more)
     int na = 0;
     for (int t = 0; t < m; ++t) {
-        const double dx = c.x[ni[t]] - px, dy = c.y[ni[t]] - py, dz = c.z[ni[t]] - pz;
+        const double dx = c.x[NI(t)] - px, dy = c.y[NI(t)] - py, dz = c.z[NI(t)] - pz;
         if (dx == 0.0 && dy == 0.0 && dz == 0.0) continue;
         const double a = atan2((v[0] * dx + v[1] * dy) + v[2] * dz, (u[0] * dx + u[1] * dy) + u[2] * dz);
-        int pos = na++;   // na <= t + 1: writing ang[pos] never touches an unread nd[]
-        while (pos > 0 && a < ang[pos - 1]) {
-            ang[pos] = ang[pos - 1];
+        int pos = na++;   // na <= t + 1: writing ND(pos) never touches an unread nd[]
+        while (pos > 0 && a < ND(pos - 1)) {
+            ND(pos) = ND(pos - 1);
             --pos;
         }
-        ang[pos] = a;
+        ND(pos) = a;
     }
     if (na == 0) return;
     double max_dif = 0.0;
     for (int t = 0; t + 1 < na; ++t) {
-        const double dif = ang[t + 1] - ang[t];
+        const double dif = ND(t + 1) - ND(t);
         if (max_dif < dif) max_dif = dif;
     }
-    const double wrap = 2 * 3.14159265358979323846 - ang[na - 1] + ang[0];
+    const double wrap = 2 * 3.14159265358979323846 - ND(na - 1) + ND(0);
     if (max_dif < wrap) max_dif = wrap;
     if (max_dif > angle_thr_rad) flag[i] = 1;
 }
@@ -1817,8 +1832,12 @@ void launch_boundary(const CloudView& c, const GridDesc& g, const uint32_t* cell
                      double angle_threshold_deg, uint8_t* flag, uint8_t* overflow, hipStream_t s, const uint32_t* n_sorted) {
     if (!c.n) return;
     const double thr = angle_threshold_deg * 3.14159265358979323846 / 180.0;   // :62
-    boundary_k<<<(c.n + 63) / 64, 64, 0, s>>>(c, g, cell_start, qx, qy, qz, cell_orig, search, max_nn, thr, flag,
-                                              overflow, n_sorted);
+    if (search != 1 && max_nn <= 32)
+        boundary_k<true><<<(c.n + 63) / 64, 64, 0, s>>>(c, g, cell_start, qx, qy, qz, cell_orig, search, max_nn, thr, flag,
+                                                        overflow, n_sorted);
+    else
+        boundary_k<false><<<(c.n + 63) / 64, 64, 0, s>>>(c, g, cell_start, qx, qy, qz, cell_orig, search, max_nn, thr, flag,
+                                                         overflow, n_sorted);
 }
 
 // ------------------------------------------------------------------------------------------------
