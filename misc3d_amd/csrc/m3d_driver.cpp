@@ -854,9 +854,11 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         }
         // work the caller wants queued behind these kernels before the host waits (segmentation: the removal of
         // these very inliers), so that ONE wait covers both
+        bool hooked = false;
         if (before_wait) {
             const int hr = (*before_wait)(expected_ni);
             before_wait = nullptr;
+            hooked = true;
             if (hr != M3D_OK) return hr;
         }
         // last: a copy into the caller's (pageable) buffer keeps the host busy until it is done
@@ -866,7 +868,13 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                                   ctx->copy_stream));
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        // everything RefineModel reads is complete at ev_compact when the moments rode on the compaction (or no fit is
+        // due): what the hook queued behind it (segmentation: the removal of these inliers, tens of microseconds of
+        // kernels) is not waited for -- the caller goes on preparing the next round under it
+        if (hooked && (have_moments || !need_fit_e))
+            HIPCHK(hipEventSynchronize(ctx->ev_compact));
+        else
+            HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->copy_stream));
         if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
         uint32_t ni_chk;
@@ -1426,25 +1434,42 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
     launch_compact(kind, sview, model_dev, thr, 3, nullptr, nullptr, nullptr, w.sbx[w.spp].as<double>(),
                    w.sby[w.spp].as<double>(), w.sbz[w.spp].as<double>(), nullptr, scap,
                    ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>() + 1, ctx->stream);
-    HIPCHK(hipMemcpyAsync(ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset, ctx->total.p, 2 * sizeof(uint32_t),
-                          hipMemcpyDeviceToHost, ctx->stream));
+    w.totals_slot ^= 1;   // (two slots: a deferred check reads the previous removal's totals after the next one has been queued)
+    HIPCHK(hipMemcpyAsync(ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot, ctx->total.p,
+                          2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
     return M3D_OK;
 }
 
-static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed) {
+// known_removed == null: the stream has been waited for, the totals are read and checked now.
+// known_removed != null: the caller knows how many points the removal drops (the inlier count RefineModel reported) and has
+// NOT waited for the removal's kernels: the cloud is switched over from that count, and the totals are checked by
+// cloud_remove_check_pending once the stream is known to have passed them.
+static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed, const size_t* known_removed = nullptr) {
     DeviceCtx* ctx = c->ctx;
     m3d_cloud::Work& w = c->work;
     const CloudView cur = w.cur;
     const int dst = w.cur_is_v0 ? 1 : w.pp;
-    uint32_t h[2];
-    std::memcpy(h, ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset, sizeof(h));
-    const uint32_t new_sorted = h[1];
-    // (a partition written by RefineModel's compaction has no total of its own: the sorted copy's removal count stands
-    // in, and the caller checks it against the length of the inlier list)
-    const uint32_t new_n = w.partition_done ? (new_sorted <= c->n_sorted && c->n_sorted - new_sorted <= cur.n
-                                                   ? cur.n - (c->n_sorted - new_sorted) : 0xFFFFFFFFu)
-                                            : h[0];
+    uint32_t new_n, new_sorted;
+    if (known_removed) {
+        if (*known_removed > cur.n || *known_removed > c->n_sorted) return fail(M3D_ERR_INTERNAL, "more inliers than points");
+        new_n = cur.n - (uint32_t)*known_removed;
+        new_sorted = c->n_sorted - (uint32_t)*known_removed;
+        w.pending = true;
+        w.pending_slot = w.totals_slot;
+        w.pending_partition_done = w.partition_done;
+        w.pending_new_n = new_n;
+        w.pending_new_sorted = new_sorted;
+    } else {
+        uint32_t h[2];
+        std::memcpy(h, ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot, sizeof(h));
+        new_sorted = h[1];
+        // (a partition written by RefineModel's compaction has no total of its own: the sorted copy's removal count stands
+        // in, and the caller checks it against the length of the inlier list)
+        new_n = w.partition_done ? (new_sorted <= c->n_sorted && c->n_sorted - new_sorted <= cur.n
+                                        ? cur.n - (c->n_sorted - new_sorted) : 0xFFFFFFFFu)
+                                 : h[0];
+    }
     if (new_n > cur.n || new_sorted > c->n_sorted || cur.n - new_n != c->n_sorted - new_sorted)
         return fail(M3D_ERR_INTERNAL, "the two copies of the cloud disagree on the removed points");
     if (n_removed) *n_removed = cur.n - new_n;
@@ -1473,6 +1498,18 @@ static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed) {
     c->n_pad = w.cur.n_pad;
     c->n_sorted = new_sorted;
     c->n_tiles = w.scur.n_tiles;
+    return M3D_OK;
+}
+
+// the totals of a removal finished from a known count (cloud_remove_finish), once the stream has passed their copy
+static int cloud_remove_check_pending(m3d_cloud* c) {
+    m3d_cloud::Work& w = c->work;
+    if (!w.pending) return M3D_OK;
+    w.pending = false;
+    uint32_t h[2];
+    std::memcpy(h, c->ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.pending_slot, sizeof(h));
+    if (h[1] != w.pending_new_sorted || (!w.pending_partition_done && h[0] != w.pending_new_n))
+        return fail(M3D_ERR_INTERNAL, "removed points and inlier list disagree");
     return M3D_OK;
 }
 
@@ -2207,7 +2244,8 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
                                   cluster_indices + off, &ni, nullptr, &issue_removal, &iterations_hint, comm);
             ctx->partition_hook = nullptr;
             if (rc < 0) break;
-            rc = M3D_OK;
+            rc = cloud_remove_check_pending(c0);   // (the previous round's removal: this round's wait lay behind it)
+            if (rc != M3D_OK) break;
             if (ni == 0) {  // the reference would loop forever (:29,:35)
                 rc = 2;
                 break;
@@ -2224,7 +2262,9 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
                 rc = fail(M3D_ERR_INTERNAL, "partition written without the removal being queued");
                 break;
             }
-            rc = removal_issued ? cloud_remove_finish(c0, &removed)
+            // (a removal queued by the hook is NOT waited for: its size is the inlier count; its totals are checked after
+            // the next round's wait, which the stream reaches behind them)
+            rc = removal_issued ? cloud_remove_finish(c0, &removed, &ni)
                                 : cloud_remove_locked(c0, M3D_PLANE, threshold, ctx->last_best_dev, &removed);
             if (rc != M3D_OK) break;
             if (removed != ni) {
@@ -2234,6 +2274,7 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         }
         *n_clusters = k;
         (void)hipStreamSynchronize(ctx->stream);
+        if (rc == M3D_OK) rc = cloud_remove_check_pending(c0);
     }
     m3d_cloud_destroy(c0);
     if (rc == 2) return 2;

@@ -127,6 +127,11 @@ struct m3d_cloud {
         int pp = 0, spp = 0;                  // buffer sets that RECEIVE the next compaction
         bool cur_is_v0 = true;
         bool partition_done = false;   // the removal in flight found its creation-order partition already written (PartitionOut)
+        int totals_slot = 0;           // which of the two pinned slots receives the totals of the removal in flight
+        // a removal finished from a known count, its totals still to be checked (cloud_remove_check_pending)
+        bool pending = false, pending_partition_done = false;
+        int pending_slot = 0;
+        uint32_t pending_new_n = 0, pending_new_sorted = 0;
     } work;
     uint32_t n0 = 0, n_pad0 = 0, n_tiles0 = 0;
     m3d::CloudView view() const;        // working cloud
