@@ -14,3 +14,15 @@ def test_fp32_screen_and_box_test_bounds_hold_on_the_host():
     r = subprocess.run([os.path.join(cpp, "_build", "test_screen_bounds"), "12000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout and "wrong 0;" in r.stdout
+
+
+def test_nn_screen_walk_is_exact_on_the_host():
+    """tests/cpp/test_nn_screen.cpp replays sorted_walk32 (the fp32 screen of the registration validation's neighbour search)
+    with float operations on the host: random grids over nine orders of magnitude, origins at the edge of what the library
+    admits, lists with duplicates, reflections (equal distances) and distances 1e-16 apart.  A query the walk calls decided
+    must have found the exact fp64 minimum; the rounding bound must hold for every entry; ordinary lists must be decided."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["make", "-C", cpp, "_build/test_nn_screen"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(cpp, "_build", "test_nn_screen"), "60000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout and "wrong 0;" in r.stdout and "bound violations 0," in r.stdout
