@@ -798,14 +798,27 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
     for (uint32_t sb = s0; sb < s1; sb += 64) {
         uint32_t acc = 0;
         double acc_sum = 0.0;
+        // the 64 keep flags of the block in one load (a byte load + wait per hypothesis stalled the wave for a memory
+        // latency each), and the next hypothesis' transformation requested while this one is evaluated
+        const unsigned long long keep_mask = keep ? __ballot(keep[sb + (uint32_t)lane] != 0) : ~0ull;
+        double tn[12];
+        {
+            const double* __restrict__ T = Ts + (size_t)sb * kRegTStride;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) tn[k] = T[k];
+        }
         for (uint32_t ss = 0; ss < 64; ++ss) {
-            const double* __restrict__ T = Ts + (size_t)(sb + ss) * kRegTStride;
             double t[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) t[k] = T[k];
+            for (int k = 0; k < 12; ++k) t[k] = tn[k];
+            {   // (the record behind the last one exists: Ts holds s_pad + 1 records)
+                const double* __restrict__ T = Ts + (size_t)(sb + ss + 1u) * kRegTStride;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) tn[k] = T[k];
+            }
             uint32_t cnt = 0;
             double sum = 0.0;
-            const bool run = keep ? keep[sb + ss] != 0 : true;
+            const bool run = (keep_mask >> ss) & 1ull;
             if (t[0] == t[0] && run) {  // padding records are NaN (wave-uniform branch)
 #pragma unroll
                 for (int j = 0; j < kRegP; ++j) {
