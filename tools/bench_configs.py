@@ -160,7 +160,12 @@ if "N3" in which or len(sys.argv) == 1:
         W, H = w + 2 * k, h + 2 * k
         bytes_alg = w * h * 24.0 * 2 + W * H * 8.0 * 10 * 3     # map in, normals out, moment images written+read, sums written
         emit(f"N3 estimate_normals {w}x{h} k={k}", ms_total=dt * 1e3, ms_device=ms_dev, mpixel_per_s=w * h / (ms_dev * 1e3),
-             device_GBps=bytes_alg / (ms_dev * 1e-3) / 1e9)
+             device_GBps=bytes_alg / (ms_dev * 1e-3) / 1e9,
+             roofline={"bound": "hbm", "kernel": "m3d::nm_box_sum_k + nm_normals_k + nm_moments_k", "achieved": bytes_alg / (ms_dev * 1e-3) / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_alg / (ms_dev * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "note": "device time of the three kernels (HIP events); the box sums keep the reference's summation order "
+                               "(a serial recurrence along every row and column), which is what holds them below the bandwidth; "
+                               "the whole call is bound by the host link (map in, normals out)"})
 
 if "N4" in which or len(sys.argv) == 1:
     # DetectBoundaryPoints on a 500 k-point planar patch (the inliers of a fit_plane), Hybrid(0.02, 30)
@@ -174,8 +179,10 @@ if "N4" in which or len(sys.argv) == 1:
         t0 = time.perf_counter()
         bidx = capi.detect_boundary_points(pp, None, 2, 0.02, 30, 90.0)
         ts.append((time.perf_counter() - t0) * 1e3)
+    # per point: a hybrid search (27 cells, ~60 candidates, sorted insertion of the 30 nearest), a 3x3 eigen-problem for the
+    # normal, 30 atan2 and their sort -- latency- and LDS-bound per thread; no bandwidth or issue roofline applies cleanly
     emit("N4 detect_boundary_points 500k pts Hybrid(0.02, 30), normals estimated", ms=sorted(ts)[1], ms_first=ts[0],
-         boundary_points=len(bidx))
+         boundary_points=len(bidx), points_per_s=nb / (sorted(ts)[1] * 1e-3))
 
 if "C5" in which:
     n = int(os.environ.get("M3D_C5_POINTS", "10000000"))
