@@ -65,6 +65,9 @@ typedef struct m3d_stats {
                                   * fits) and the sequential replay chose another hypothesis (rmse tie): it was run again */
     uint64_t pairs_scored;       /* (512-point tile, hypothesis) pairs those launches evaluated after culling and pruning */
     uint64_t pairs_exact;        /* ... of which the fp32 screen (m3d_config.score_fp32_screen) left to the exact fp64 code */
+    uint64_t pairs_timed;        /* ... of pairs_scored: evaluated by the launches behind ms_score_kernel / score_launches.  Smaller than
+                                    pairs_scored when the leading hypotheses of a fit's first chunk were counted inside cull_lead_k
+                                    (one launch for the box tests and the lead pass: one GPU, fp32 paths on), which is not timed */
 } m3d_stats;
 
 /* ---- one-shot fits: python/py_common.cpp:11-67 FitPlane / FitSphere / FitCylinder ------------- */

@@ -47,7 +47,7 @@ class Stats(C.Structure):
                 ("ties", C.c_int32), ("hypotheses_scored", C.c_uint64), ("exact_rmse_evals", C.c_uint64),
                 ("ms_sample", C.c_double), ("ms_score", C.c_double), ("ms_refine", C.c_double),
                 ("ms_total", C.c_double), ("ms_score_kernel", C.c_double), ("score_launches", C.c_uint32),
-                ("early_pick_redone", C.c_uint32), ("pairs_scored", C.c_uint64), ("pairs_exact", C.c_uint64)]
+                ("early_pick_redone", C.c_uint32), ("pairs_scored", C.c_uint64), ("pairs_exact", C.c_uint64), ("pairs_timed", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -243,13 +243,43 @@ __device__ __forceinline__ void cull32_pair(const float* __restrict__ rp /* 24 f
     }
 }
 
+// one hypothesis against one box: the arithmetic of cull32_pair, component by component (same operations, same roundings:
+// the lead pass of cull_lead_k computes ITS box tests with it, lane = hypothesis, and gets the bits cull_tiles32_k writes)
 template <int KIND>
-__global__ __launch_bounds__(64) void cull_tiles32_k(const double* __restrict__ boxes, uint32_t n_tiles,
-                                                      const float* __restrict__ cull32, uint32_t n_groups,
-                                                      uint32_t groups_per_wave, unsigned long long* __restrict__ masks,
-                                                      uint32_t* __restrict__ ub, uint32_t group_begin, uint32_t group_end) {
+__device__ __forceinline__ float cull32_one(const float* __restrict__ rp /* the pair's 24 floats */, int i /* 0 / 1 */, float bx,
+                                            float by, float bz, float hx, float hy, float hz, float rb) {
+    if (KIND == 0) {
+        const float s = __builtin_fmaf(rp[0 + i], bx, __builtin_fmaf(rp[2 + i], by, __builtin_fmaf(rp[4 + i], bz, rp[6 + i])));
+        const float r = __builtin_fmaf(rp[8 + i], hx, __builtin_fmaf(rp[10 + i], hy, __builtin_fmaf(rp[12 + i], hz, rp[14 + i])));
+        return r - __builtin_fabsf(s);
+    } else if (KIND == 1) {
+        const float dx = __builtin_fabsf(rp[0 + i] - bx), dy = __builtin_fabsf(rp[2 + i] - by), dz = __builtin_fabsf(rp[4 + i] - bz);
+        const float nx = __builtin_fmaxf(0.0f, dx - hx), ny = __builtin_fmaxf(0.0f, dy - hy), nz = __builtin_fmaxf(0.0f, dz - hz);
+        const float fx = dx + hx, fy = dy + hy, fz = dz + hz;
+        const float dmin2 = __builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx));
+        const float dmax2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+        const float t1 = dmax2 - rp[6 + i], t2 = rp[8 + i] - dmin2;
+        return __uint_as_float(__float_as_uint(t1) | __float_as_uint(t2));
+    } else {
+        const float d1 = __builtin_fmaf(rp[0 + i], bx, __builtin_fmaf(rp[2 + i], by, __builtin_fmaf(rp[4 + i], bz, rp[6 + i])));
+        const float d2 = __builtin_fmaf(rp[8 + i], bx, __builtin_fmaf(rp[10 + i], by, __builtin_fmaf(rp[12 + i], bz, rp[14 + i])));
+        const float tt = __builtin_fmaf(d2, d2, d1 * d1);
+        const float dist = __builtin_sqrtf(tt);
+        const float rt = rp[16 + i] * rb;
+        const float t1 = (rp[18 + i] + rt) - dist;
+        const float t2 = (dist + rt) - rp[20 + i];
+        return __uint_as_float(__float_as_uint(t1) | __float_as_uint(t2));
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ void cull32_body(const double* __restrict__ boxes, uint32_t n_tiles,
+                                            const float* __restrict__ cull32, uint32_t n_groups,
+                                            uint32_t groups_per_wave, unsigned long long* __restrict__ masks,
+                                            uint32_t* __restrict__ ub, uint32_t group_begin, uint32_t group_end,
+                                            uint32_t block_x, uint32_t block_y) {
     const int lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x * 64u + (uint32_t)lane;
+    const uint32_t tile = block_x * 64u + (uint32_t)lane;
     const bool tile_ok = tile < n_tiles;
     float bx = 0.0f, by = 0.0f, bz = 0.0f, hx = -1.0f, hy = -1.0f, hz = -1.0f;
     if (tile_ok) {
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(64) void cull_tiles32_k(const double* __restrict__ 
     if (!live) hx = hy = hz = 0.0f;
     // bounding radius of the box, rounded outwards (cylinder)
     const float rb = __builtin_sqrtf(__builtin_fmaf(hz, hz, __builtin_fmaf(hy, hy, hx * hx))) * 1.000001f;
-    const uint32_t g0 = group_begin + blockIdx.y * groups_per_wave;
+    const uint32_t g0 = group_begin + block_y * groups_per_wave;
     const uint32_t g1 = min(group_end, g0 + groups_per_wave);
     for (uint32_t g = g0; g < g1; ++g) {
         uint32_t w[2] = {0u, 0u}, ubv = 0u;
@@ -289,6 +319,13 @@ __global__ __launch_bounds__(64) void cull_tiles32_k(const double* __restrict__ 
         if (tile_ok) masks[(size_t)tile * n_groups + g] = live ? (((unsigned long long)w[1] << 32) | w[0]) : 0ull;
         if (ub && ubv) atomicAdd(&ub[g * 64u + (uint32_t)lane], ubv);
     }
+}
+template <int KIND>
+__global__ __launch_bounds__(64) void cull_tiles32_k(const double* __restrict__ boxes, uint32_t n_tiles,
+                                                      const float* __restrict__ cull32, uint32_t n_groups,
+                                                      uint32_t groups_per_wave, unsigned long long* __restrict__ masks,
+                                                      uint32_t* __restrict__ ub, uint32_t group_begin, uint32_t group_end) {
+    cull32_body<KIND>(boxes, n_tiles, cull32, n_groups, groups_per_wave, masks, ub, group_begin, group_end, blockIdx.x, blockIdx.y);
 }
 
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
@@ -385,6 +422,13 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
     }
     for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
     if (blockIdx.x == 0 && threadIdx.x == 0 && v) atomicMax(best_count, v);
+    if (zero && blockIdx.x == 0) {   // block-uniform: what the pair counters hold now is the lead pass' share (m3d_stats.pairs_lead)
+        uint32_t* __restrict__ pair_rep = zero + (size_t)kCountReplicas * rep_stride;
+        uint32_t p = 0;
+        for (int r = threadIdx.x; r < kPairMain; r += 64) p += pair_rep[r];
+        for (int off = 32; off > 0; off >>= 1) p += (uint32_t)__shfl_xor((int)p, off, 64);
+        if (threadIdx.x == 0) pair_rep[kPairLead] = p;
+    }
     if (pick_key && blockIdx.x == 0) {   // block-uniform
         for (int off = 32; off > 0; off >>= 1) key = max(key, (unsigned long long)__shfl_xor((long long)key, off, 64));
         if (threadIdx.x == 0 && key) atomicMax(pick_key, key);
@@ -639,28 +683,47 @@ __device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, co
     m = mn;
 }
 
-template <int KIND>
-__global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ sx, const double* __restrict__ sy,
-                                                      const double* __restrict__ sz,
-                                                      const double* __restrict__ boxes, double max_abs,
-                                                      const double* __restrict__ score,
-                                                      const unsigned long long* __restrict__ masks,
-                                                      const unsigned long long* __restrict__ keep,
-                                                      uint32_t n_groups, uint32_t groups_per_block /* <= kScreenMaxGroups */,
-                                                      uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
-                                                      uint32_t* __restrict__ pair_rep,
-                                                      uint32_t group_begin, uint32_t group_end) {
+// OWN_BOX_TESTS (the lead pass inside cull_lead_k): no mask word has been written for these groups yet -- the wave runs
+// the fp32 box test of its tile against the 64 hypotheses of each group itself (lane = hypothesis, cull32_one: the bits
+// cull_tiles32_k would have written) and stores the word for whoever reads the masks later.
+template <int KIND, bool OWN_BOX_TESTS>
+__device__ __forceinline__ void score_screen_body(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                  const double* __restrict__ sz,
+                                                  const double* __restrict__ boxes, double max_abs,
+                                                  const double* __restrict__ score,
+                                                  unsigned long long* __restrict__ masks,
+                                                  const unsigned long long* __restrict__ keep,
+                                                  uint32_t n_groups, uint32_t groups_per_block /* <= kScreenMaxGroups */,
+                                                  uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                  uint32_t* __restrict__ pair_rep,
+                                                  uint32_t group_begin, uint32_t group_end, uint32_t block_x, uint32_t block_y,
+                                                  const float* __restrict__ cull32) {
     __shared__ uint16_t ids[kScreenMaxGroups * 64];
     __shared__ __attribute__((aligned(16))) uint8_t cnt8[64 * kCntStride];
     constexpr int NL = KIND == 2 ? 3 : 2;
     __shared__ float4 loc[64][NL];   // the batch's (tile, hypothesis) records
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = block_x;
     uint32_t* __restrict__ counts = counts_rep + (size_t)(tile % kCountReplicas) * rep_stride;
-    const uint32_t g0 = group_begin + blockIdx.y * groups_per_block;
+    const uint32_t g0 = group_begin + block_y * groups_per_block;
     const int lane = threadIdx.x;
     unsigned long long mm = 0;
-    if ((uint32_t)lane < groups_per_block && g0 + lane < group_end)
+    if (OWN_BOX_TESTS) {
+        const float* __restrict__ f = reinterpret_cast<const float*>(boxes + (size_t)tile * kBoxStride + 8);   // (wave-uniform)
+        const float bx = f[0], by = f[1], bz = f[2];
+        float hx = f[3], hy = f[4], hz = f[5];
+        const bool live = hx >= 0.0f;   // (hx < 0: empty tile)
+        if (!live) hx = hy = hz = 0.0f;
+        const float rb = __builtin_sqrtf(__builtin_fmaf(hz, hz, __builtin_fmaf(hy, hy, hx * hx))) * 1.000001f;
+        for (uint32_t w = 0; w < groups_per_block && g0 + w < group_end; ++w) {
+            const uint32_t h = (g0 + w) * 64u + (uint32_t)lane;
+            const float t = cull32_one<KIND>(cull32 + (size_t)(h >> 1) * 24u, (int)(h & 1u), bx, by, bz, hx, hy, hz, rb);
+            const unsigned long long word = live ? __ballot(!(t < 0.0f)) : 0ull;
+            if (lane == 0) masks[(size_t)tile * n_groups + g0 + w] = word;
+            if ((uint32_t)lane == w) mm = word & keep[g0 + w];
+        }
+    } else if ((uint32_t)lane < groups_per_block && g0 + lane < group_end) {
         mm = masks[(size_t)tile * n_groups + g0 + lane] & keep[g0 + lane];
+    }
     if (!__ballot(mm != 0)) return;
     const size_t base = (size_t)tile * kTilePoints + lane;
     constexpr int P = kTilePoints / 64, Q = P / 2;
@@ -691,7 +754,7 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
         total += (uint32_t)__popcll(word);
     }
     __syncthreads();
-    if (lane == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairMain], total);
+    if (lane == 0) atomicAdd(&pair_rep[(tile + block_y * 67u) % (uint32_t)kPairMain], total);
     const double* __restrict__ score0 = score + (size_t)g0 * 64u * kModelStride;
     // the exact count of one (tile, hypothesis) pair: the fp64 points come back from memory (L2), four rows at a time
     auto exact_count = [&](uint32_t id) -> uint32_t {
@@ -743,7 +806,7 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
             uint32_t c = (uint32_t)__popc(bits);
             if (exact) {   // wave-uniform, rare
                 const uint32_t e = exact_count((uint32_t)__builtin_amdgcn_readlane(my, (int)k));
-                if (lane == 0) atomicAdd(&pair_rep[(uint32_t)kPairMain + tile % (uint32_t)(kPairReplicas - kPairMain)], 1u);
+                if (lane == 0) atomicAdd(&pair_rep[(uint32_t)kPairMain + tile % (uint32_t)(kPairLead - kPairMain)], 1u);
                 park = ((uint32_t)lane == k) ? e : park;
                 c = 0;
             }
@@ -779,6 +842,47 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
         __syncthreads();   // (the next batch overwrites the tables)
     }
 }
+template <int KIND>
+__global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                      const double* __restrict__ sz,
+                                                      const double* __restrict__ boxes, double max_abs,
+                                                      const double* __restrict__ score,
+                                                      const unsigned long long* __restrict__ masks,
+                                                      const unsigned long long* __restrict__ keep,
+                                                      uint32_t n_groups, uint32_t groups_per_block /* <= kScreenMaxGroups */,
+                                                      uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                      uint32_t* __restrict__ pair_rep,
+                                                      uint32_t group_begin, uint32_t group_end) {
+    score_screen_body<KIND, false>(sx, sy, sz, boxes, max_abs, score, const_cast<unsigned long long*>(masks), keep, n_groups,
+                                   groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, blockIdx.x,
+                                   blockIdx.y, nullptr);
+}
+
+// cull_lead_k: ONE launch for the two latency-bound steps at the head of a fit's first chunk -- the box tests of the
+// chunk's hypotheses (cull_tiles32_k's workgroups) and the counting of its leading hypotheses (score_screen_k's, with
+// their own box tests: they cannot wait for a mask another workgroup of the same launch writes).  Back to back the two
+// launches took 15 + 15 us on a 1 M-point cloud and left most of the chip idle; together they take about as long as one.
+// Workgroups [0, n_lead_wgs): lead pass, tile = id % n_tiles (the longer-running ones first); the rest: box tests of
+// groups [cull_begin, cull_end).
+template <int KIND>
+__global__ __launch_bounds__(64) void cull_lead_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                   const double* __restrict__ sz, const double* __restrict__ boxes,
+                                                   uint32_t n_tiles, double max_abs, const double* __restrict__ score,
+                                                   const float* __restrict__ cull32, unsigned long long* __restrict__ masks,
+                                                   const unsigned long long* __restrict__ keep, uint32_t n_groups,
+                                                   uint32_t lead_groups, uint32_t lead_gpb, uint32_t n_lead_wgs,
+                                                   uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                   uint32_t* __restrict__ pair_rep, uint32_t* __restrict__ ub,
+                                                   uint32_t cull_begin, uint32_t cull_end, uint32_t cull_gpw, uint32_t cull_tblocks) {
+    if (blockIdx.x < n_lead_wgs) {   // (workgroup-uniform)
+        score_screen_body<KIND, true>(sx, sy, sz, boxes, max_abs, score, masks, keep, n_groups, lead_gpb, counts_rep, rep_stride,
+                                      pair_rep, 0u, lead_groups, blockIdx.x % n_tiles, blockIdx.x / n_tiles, cull32);
+    } else {
+        const uint32_t b = blockIdx.x - n_lead_wgs;
+        cull32_body<KIND>(boxes, n_tiles, cull32, n_groups, cull_gpw, masks, ub, cull_begin, cull_end, b % cull_tblocks,
+                          b / cull_tblocks);
+    }
+}
 
 // records[h] = sum over the replicas for h in [h_begin, h_end), written to `counts` (device-visible host memory, may be
 // null) and `counts_dev` (device, may be null); *pairs_out (device-visible, may be null) = evaluated (tile, hypothesis)
@@ -803,9 +907,10 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
         }
         if (threadIdx.x == 0) {
             uint32_t e = 0;
-            for (int r = kPairMain; r < kPairReplicas; ++r) e += pair_rep[r];
+            for (int r = kPairMain; r < kPairLead; ++r) e += pair_rep[r];
             pairs_out[0] = red[0];
             pairs_out[1] = e;   // pairs score_screen_k recounted in fp64
+            pairs_out[2] = pair_rep[kPairLead];   // pairs of the chunk's lead pass (0: the chunk had none)
         }
     }
     const bool mine = h < h_end;
@@ -889,6 +994,38 @@ void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32
         sum_replicas_k<<<(h_end - h_begin + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_end, counts, pair_rep,
                                                                       pairs_out, valid, h_count, best_count, h_begin,
                                                                       counts_dev, pf);
+}
+
+bool launch_cull_lead(int kind, const SortedView& s, const double* score, const float* cull32, unsigned long long* masks,
+                      const unsigned long long* keep, uint32_t n_groups, uint32_t lead_groups, uint32_t* counts_rep,
+                      uint32_t rep_stride, uint32_t* pair_rep, uint32_t* ub, uint32_t cull_end, hipStream_t st) {
+    cull_end = std::min(cull_end, n_groups);
+    if (!s.n_tiles || !cull32 || !(s.radius < 1e18) || config().cull_fp32 == 0 || config().score_fp32_screen == 0 ||
+        lead_groups == 0 || lead_groups > (uint32_t)kScreenMaxGroups || lead_groups >= cull_end)
+        return false;
+    // the lead pass: the geometry launch_score_mask would choose for groups [0, lead_groups)
+    const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, kScreenMaxGroups);
+    const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
+    const uint32_t lead_gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * lead_groups) / min_wgs)));
+    const uint32_t lead_y = (lead_groups + lead_gpb - 1) / lead_gpb;
+    const uint32_t n_lead_wgs = s.n_tiles * lead_y;
+    // the box tests of the rest: launch_cull_mask's geometry
+    const uint32_t window = cull_end - lead_groups;
+    const uint32_t tblocks = (s.n_tiles + 63) / 64;
+    uint32_t gpw = std::max<uint32_t>(1, (uint32_t)(((uint64_t)tblocks * window) / 8192));
+    gpw = std::min<uint32_t>(gpw, 8);
+    const uint32_t cull_y = (window + gpw - 1) / gpw;
+    const dim3 g(n_lead_wgs + tblocks * cull_y), b(64);
+    if (kind == 0)
+        cull_lead_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
+                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks);
+    else if (kind == 1)
+        cull_lead_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
+                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks);
+    else
+        cull_lead_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
+                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks);
+    return true;
 }
 
 // The hypothesis the sequential replay will most probably end with, chosen on the device: highest inlier count

@@ -46,6 +46,7 @@ constexpr int kCountReplicas = 16;
 // replicas of the launch's (tile, hypothesis) pair counter (m3d_stats.pairs_scored): one add per surviving wave,
 // consecutive tiles hit different words so the adds never queue on one address
 constexpr int kPairReplicas = 1024;
+constexpr int kPairLead = kPairReplicas - 1;   // the last word: pairs the LEAD pass of the chunk evaluated (lead_fold_keep_k)
 // ... of which the last kPairReplicas - kPairMain count the pairs the fp32 screen handed to the exact fp64 code
 // (score_screen_k; m3d_stats.pairs_exact)
 constexpr int kPairMain = 1008;
@@ -55,6 +56,14 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                        hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* both set: receive the launch's own start / stop
                        times (m3d_stats.ms_score_kernel) */);
+// cull_lead_k: the box tests of groups [lead_groups, cull_end) and the counting of the leading groups [0, lead_groups) (which
+// run their own box tests) in ONE launch -- the head of a fit's first chunk on one GPU.  keep[0 .. lead_groups) and the
+// counter replicas must be prepared (minimal_fit_k's LeadPrep or keep_mask_k); ub is not written for the leading groups
+// (nothing reads it).  Returns false, having launched nothing, when the fp32 box tests / the fp32 screen are off or the
+// geometry does not fit: the caller then issues launch_cull_mask + launch_score_mask as before.
+bool launch_cull_lead(int kind, const SortedView& s, const double* score, const float* cull32, unsigned long long* masks,
+                      const unsigned long long* keep, uint32_t n_groups, uint32_t lead_groups, uint32_t* counts_rep,
+                      uint32_t rep_stride, uint32_t* pair_rep, uint32_t* ub, uint32_t cull_end, hipStream_t st);
 // (planes and spheres go through score_screen_k unless m3d_config.score_fp32_screen is 0)
 // The device's prediction of the hypothesis the replay will end with (pick_best_k, m3d_cull_kernels.hip)
 struct BestPick {

@@ -447,7 +447,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (dense || device_records) RESERVE(s.counts, sizeof(uint32_t) * ((size_t)h_pad + 1));   // (culled path: records go straight to h_counts)
     uint32_t* rec_dev = (!dense && device_records) ? s.counts.as<uint32_t>() : nullptr;
     RESERVE(s.h_samples, sizeof(uint32_t) * (size_t)count * m);
-    RESERVE(s.h_counts, sizeof(uint32_t) * ((size_t)h_pad + 2));   // + the launch's pair counter behind the records
+    RESERVE(s.h_counts, sizeof(uint32_t) * ((size_t)h_pad + 4));   // + the launch's pair counters behind the records
     RESERVE(s.h_valid, (size_t)h_pad + 1);
     if (dense) {
         RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
@@ -484,6 +484,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     // (culled path: keep_mask_k clears the counter replicas on its way)
     s.lead_groups = 0;
+    s.lead_fused = false;
     s.scored = false;
     s.poll_seq = 0;
     s.host_has_records = true;
@@ -524,19 +525,33 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         // own sample copy, MinimalFit and box-test launches.  The records are complete after the second pass.
         const uint32_t ga = use_lead ? lead / 64 : 0u;
         if (own_real) {
-            if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
-                launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
-                                 ctx->stream, /*ub_is_zero=*/true, 0, ga, c32.out);
-            launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
-                             /*ub_is_zero=*/true, g0, g1, c32.out);
+            // one GPU, fp32 box tests and fp32 screen on: the box tests of the chunk and the counting of its leading groups
+            // share ONE launch (cull_lead_k; the lead pass runs its own box tests) -- two latency-bound launches less the
+            // time of one.  It is not among the timed scoring launches (s.lead_fused: m3d_stats.pairs_timed).
+            s.lead_fused = false;
+            if (ga && !comm && g0 == 0 && c32.out) {
+                if (!lead_prepared)   // (a new fit: minimal_fit_k has done it)
+                    launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
+                s.lead_fused = launch_cull_lead(kind, sv, s.score.as<double>(), c32.out, masks, keep, n_groups, ga,
+                                                ctx->counts_rep.as<uint32_t>(), h_pad, pair_rep, ub, g1, ctx->stream);
+            }
+            if (!s.lead_fused) {
+                if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
+                    launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
+                                     ctx->stream, /*ub_is_zero=*/true, 0, ga, c32.out);
+                launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
+                                 /*ub_is_zero=*/true, g0, g1, c32.out);
+            }
             uint32_t g_lo = g0;
             if (ga) {
                 s.lead_groups = ga;
                 g_lo = std::max(g0, ga);
-                if (!lead_prepared)   // (a new fit: minimal_fit_k has done it)
-                    launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
-                launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
-                                  h_pad, pair_rep, ctx->stream, 0, ga, timing ? s.k2 : nullptr, timing ? s.k3 : nullptr);
+                if (!s.lead_fused) {
+                    if (!lead_prepared)   // (a new fit: minimal_fit_k has done it)
+                        launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
+                    launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(),
+                                      h_pad, pair_rep, ctx->stream, 0, ga, timing ? s.k2 : nullptr, timing ? s.k3 : nullptr);
+                }
                 // fold of the lead's counters + keep masks of the rest of this rank's groups: one launch
                 launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
                                       g0 == 0 ? rec_host : nullptr, bc, ub, keep, g1 - g_lo, ctx->stream,
@@ -555,7 +570,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             s.scored = timing;
         } else {
             HIPCHK(hipMemsetAsync(rec_dev + (size_t)g0 * 64, 0, sizeof(uint32_t) * sl_pad, ctx->stream));
-            h_pairs[0] = h_pairs[1] = 0;
+            h_pairs[0] = h_pairs[1] = h_pairs[2] = 0;
         }
         if (solo) {
             comm->collectives++;   // (the window's exchange, degenerate)
@@ -970,6 +985,7 @@ struct RansacOut {
     uint32_t score_launches = 0;
     uint64_t pairs_scored = 0;   // (tile, hypothesis) pairs the scoring launches evaluated (culled path)
     uint64_t pairs_exact = 0;    // ... of which the fp32 screen could not decide (recounted in fp64)
+    uint64_t pairs_timed = 0;    // ... of pairs_scored: evaluated by the launches behind ms_score_kernel (a lead pass inside cull_lead_k is not)
     int internal_error = 0;
     int spec_hits = 0, spec_misses = 0;   // early compaction on the device's pick kept / redone
 };
@@ -1156,13 +1172,14 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
-                if (s.scored && s.lead_groups && hipEventElapsedTime(&kms, s.k2, s.k3) == hipSuccess) {
+                if (s.scored && s.lead_groups && !s.lead_fused && hipEventElapsedTime(&kms, s.k2, s.k3) == hipSuccess) {
                     out->ms_score_kernel += kms;
                     out->score_launches++;
                 }
                 if (!use_dense_scoring()) {
                     out->pairs_scored += s.h_counts.as<uint32_t>()[s.h_pad];
                     out->pairs_exact += s.h_counts.as<uint32_t>()[s.h_pad + 1];
+                    out->pairs_timed += s.h_counts.as<uint32_t>()[s.h_pad] - (s.lead_fused ? s.h_counts.as<uint32_t>()[s.h_pad + 2] : 0u);
                 }
             }
             int cb_rc = M3D_OK;
@@ -1354,6 +1371,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         stats->score_launches = ro.score_launches;
         stats->pairs_scored = ro.pairs_scored;
         stats->pairs_exact = ro.pairs_exact;
+        stats->pairs_timed = ro.pairs_timed;
         stats->early_pick_redone = (uint32_t)ro.spec_misses;   // 1: the device's early pick lost an rmse tie, RefineModel was redone
         stats->ms_refine = t2 - t1;
         stats->ms_total = t2 - t0;

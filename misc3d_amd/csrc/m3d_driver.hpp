@@ -53,6 +53,7 @@ struct ChunkSlot {
     DevBuf samples, score, params, valid, counts;
     DevBuf cull32;   // fp32 records of the box tests (cull_tiles32_k), pairwise interleaved
     PinBuf h_samples, h_counts, h_valid;
+    bool lead_fused = false;   // the chunk's lead pass ran inside cull_lead_k (no launch, no timing events of its own)
     hipEvent_t done = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the scoring kernel of the chunk (m3d_stats.ms_score_kernel)
     hipEvent_t k2 = nullptr, k3 = nullptr;  // around the scoring launch of the chunk's leading hypotheses (lead_groups > 0)
