@@ -525,11 +525,11 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         // own sample copy, MinimalFit and box-test launches.  The records are complete after the second pass.
         const uint32_t ga = use_lead ? lead / 64 : 0u;
         if (own_real) {
-            // one GPU, fp32 box tests and fp32 screen on: the box tests of the chunk and the counting of its leading groups
+            // fp32 box tests and fp32 screen on: the box tests of the chunk (this rank's slice) and the counting of its leading groups
             // share ONE launch (cull_lead_k; the lead pass runs its own box tests) -- two latency-bound launches less the
             // time of one.  It is not among the timed scoring launches (s.lead_fused: m3d_stats.pairs_timed).
             s.lead_fused = false;
-            if (ga && !comm && g0 == 0 && c32.out) {
+            if (ga && g0 == 0 && c32.out) {   // (sharded fits: the rank that owns the leading groups)
                 if (!lead_prepared)   // (a new fit: minimal_fit_k has done it)
                     launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
                 s.lead_fused = launch_cull_lead(kind, sv, s.score.as<double>(), c32.out, masks, keep, n_groups, ga,
