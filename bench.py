@@ -13,9 +13,11 @@ upper bound cannot reach an earlier hypothesis' count are pruned (both exact, DE
 JSON objects besides the contract's fields:
   roofline     the bound that actually binds the dominant kernel score_screen_k<plane>: VALU issue.
                achieved = (tile, hypothesis) pairs the timed launches evaluated (counted inside the kernel,
-               m3d_stats.pairs_scored) x 512 points x VALU instructions per (point, hypothesis) / the launches'
+               m3d_stats.pairs_timed) x 512 points x VALU instructions per (point, hypothesis) / the launches'
                duration measured live with HIP events on the library's stream (m3d_stats.ms_score_kernel) -- the
-               same launches `rocprofv3 --kernel-trace --stats -- python bench.py` averages (profiles/).
+               same launches `rocprofv3 --kernel-trace --stats -- python bench.py` averages (profiles/).  One launch of
+               this kernel per fit: the 128 leading hypotheses (3.5 % of the pairs) are counted inside cull_lead_k, the
+               launch that also runs the box tests; neither their pairs nor its time are in this object.
                Instructions per (point, hypothesis): 3.75 for the plane's packed-fp32 screen (30 per lane and hypothesis for
                the lane's 8 points: 16 v_pk_fma, 8 v_alignbit, 4 v_min3, v_bcnt, v_cmp -- the ISA of the loop, not an
                estimate; the fp64 loop it replaced: 7), 5.75 for the sphere's (46 per 8 points; fp64: 10), 6.75 for the cylinder (54; fp64: 22).
