@@ -1003,11 +1003,10 @@ bool launch_cull_lead(int kind, const SortedView& s, const double* score, const 
     if (!s.n_tiles || !cull32 || !(s.radius < 1e18) || config().cull_fp32 == 0 || config().score_fp32_screen == 0 ||
         lead_groups == 0 || lead_groups > (uint32_t)kScreenMaxGroups || lead_groups >= cull_end)
         return false;
-    // the lead pass: the geometry launch_score_mask would choose for groups [0, lead_groups)
-    const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, kScreenMaxGroups);
-    const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
-    const uint32_t lead_gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * lead_groups) / min_wgs)));
-    const uint32_t lead_y = (lead_groups + lead_gpb - 1) / lead_gpb;
+    // the lead pass: ALL leading groups of a tile in one workgroup (the tile's 12 KB are loaded once; the launch has the
+    // box-test workgroups to fill the chip with)
+    const uint32_t lead_gpb = lead_groups;
+    const uint32_t lead_y = 1;
     const uint32_t n_lead_wgs = s.n_tiles * lead_y;
     // the box tests of the rest: launch_cull_mask's geometry
     const uint32_t window = cull_end - lead_groups;
