@@ -1659,6 +1659,8 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
                 }
                 n_finite = (uint32_t)bb[6];
                 if (n_finite) {
+                    for (int k = 0; k < 6; ++k) c->bb[k] = bb[k];
+                    c->bb_known = true;
                     double m = 0.0;
                     for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
                     c->max_abs = m;   // (stays +inf when something is off: the box tests then keep every tile)

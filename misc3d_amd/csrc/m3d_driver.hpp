@@ -115,6 +115,8 @@ struct m3d_cloud {
     double max_abs = __builtin_inf();   // largest |coordinate| of the finite points (SortedView::max_abs)
     double origin[3] = {0.0, 0.0, 0.0};   // centre of the bounding box of the finite points (SortedView::origin)
     double radius = __builtin_inf();    // largest |coordinate - origin| (inf: unknown -> fp64 box tests)
+    double bb[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the points with three finite coordinates as created (lo, hi)
+    bool bb_known = false;              // ... valid (there is such a point)
     // In-place shrinking (m3d_cloud_remove_inliers = SelectByIndex(inliers, invert), the tail of a
     // SegmentPlaneIterative round).  x/y/z above always hold the cloud AS CREATED (n0 points): index lists
     // and GeneralFit gathers refer to it through `orig`.  Once shrunk, n / n_pad / n_sorted / n_tiles and

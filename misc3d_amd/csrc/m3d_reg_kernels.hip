@@ -793,8 +793,13 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
         y[j] = sy[base + 64 * j];
         z[j] = sz[base + 64 * j];
     }
-    const uint32_t s0 = split * s_per_split;
-    const uint32_t s1 = min(s0 + s_per_split, s_pad);
+    // s_per_split < 64 (a call with a handful of hypotheses -- the reference's default confidence validates ~5: one group,
+    // which one workgroup per tile would walk serially on a quarter-filled chip): the splits cut the ONE group, split k
+    // takes hypotheses [k s_per_split, (k + 1) s_per_split) of it, the last one the padding behind them as well
+    const bool sub = s_per_split < 64u;
+    const uint32_t s0 = sub ? 0u : split * s_per_split;
+    const uint32_t s1 = sub ? min(64u, s_pad) : min(s0 + s_per_split, s_pad);
+    const uint32_t ss0 = sub ? split * s_per_split : 0u, ss1 = sub && split + 1u < n_split ? ss0 + s_per_split : 64u;
     for (uint32_t sb = s0; sb < s1; sb += 64) {
         uint32_t acc = 0;
         double acc_sum = 0.0;
@@ -803,11 +808,11 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
         const unsigned long long keep_mask = keep ? __ballot(keep[sb + (uint32_t)lane] != 0) : ~0ull;
         double tn[12];
         {
-            const double* __restrict__ T = Ts + (size_t)sb * kRegTStride;
+            const double* __restrict__ T = Ts + (size_t)(sb + ss0) * kRegTStride;
 #pragma unroll
             for (int k = 0; k < 12; ++k) tn[k] = T[k];
         }
-        for (uint32_t ss = 0; ss < 64; ++ss) {
+        for (uint32_t ss = ss0; ss < ss1; ++ss) {
             double t[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) t[k] = tn[k];
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
         red[wave][lane] = acc;
         reds[wave][lane] = acc_sum;
         __syncthreads();
-        if (wave == 0) {
+        if (wave == 0 && (uint32_t)lane >= ss0 && (uint32_t)lane < ss1) {
             partial_cnt[(size_t)tile * s_pad + sb + lane] =
                 (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
             partial_sum[(size_t)tile * s_pad + sb + lane] =
@@ -1181,7 +1186,7 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
                              const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
                              uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
                              uint32_t n_points, uint8_t* keep, hipStream_t s, bool lds_rows,
-                             unsigned long long* fast_stats, double best_sum2) {
+                             unsigned long long* fast_stats, double best_sum2, uint32_t n_hyp) {
     if (!s_pad || !src.n_pad) return 0;
     const uint32_t groups = s_pad / 64;
     const bool lds = lds_rows;
@@ -1217,13 +1222,18 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         const uint32_t want = std::max<uint32_t>(kRegMinSplits, (16384 + tiles - 1) / tiles);
         const uint32_t splits = std::min(want, groups);
         const uint32_t gps = (groups + splits - 1) / splits;
-        const uint32_t nsplit = (groups + gps - 1) / gps;
+        uint32_t nsplit = (groups + gps - 1) / gps;
+        uint32_t per_split = gps * 64;
+        if (groups == 1 && n_hyp && n_hyp <= 32) {   // a handful of hypotheses: cut the one group (see the kernel)
+            per_split = std::max<uint32_t>(1, n_hyp / 8);
+            nsplit = (n_hyp + per_split - 1) / per_split;
+        }
         const uint32_t slots = (tiles + 7) / 8;
         if (g.nl32 && g.nl_rec && g.nl_sorted && g.nl_start && g.nl_hdr)
-            reg_validate_k<true><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy,
+            reg_validate_k<true><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, per_split, g, cell_start, qx, qy,
                                                                    qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit);
         else
-            reg_validate_k<false><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64, g, cell_start, qx, qy,
+            reg_validate_k<false><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, per_split, g, cell_start, qx, qy,
                                                                     qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit);
     };
     if (best_cnt == 0 || n_tiles < 16) {

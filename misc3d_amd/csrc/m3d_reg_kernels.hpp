@@ -86,7 +86,8 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
                              uint32_t n_points, uint8_t* keep, hipStream_t s,
                              bool lds_rows = false /* the LDS-staged kernel (source copy row-aligned to coarse cells) */,
                              unsigned long long* fast_stats = nullptr /* [0] LDS path, [1] global path (wave-hypotheses) */,
-                             double best_sum2 = 0.0 /* order-free sum of squared distances of the hypothesis behind best_cnt */);
+                             double best_sum2 = 0.0 /* order-free sum of squared distances of the hypothesis behind best_cnt */,
+                             uint32_t n_hyp = 0 /* real hypotheses among the s_pad records (0: unknown); a handful is spread over more workgroups */);
 void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
                        const double* qx, const double* qy, const double* qz, double* best, hipStream_t s);
 void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* block_counts, uint32_t* total,
