@@ -1594,6 +1594,11 @@ void m3d_replay_chunk(m3d_replay_state* st, size_t n_points, int kind, size_t ma
 }
 
 m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, int device) {
+    return m3d_cloud_create_impl(xyz, normals, n, device, /*with_sorted_copy=*/1);
+}
+// with_sorted_copy == 0: no Hilbert-sorted copy and no tile boxes -- what the registration, ICP and boundary entry points
+// need of a resident cloud is its SoA arrays and its bounding box (they sort by their own grids); the fits need the copy
+m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_t n, int device, int with_sorted_copy) {
     if (!xyz && n > 0) {
         set_error("xyz is null");
         return nullptr;
@@ -1675,11 +1680,13 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
             }
         }
         const uint32_t cap = std::max<uint32_t>(round_up((uint32_t)n, kTilePoints), kTilePoints);
-        c->n_tiles = cap / kTilePoints;
+        c->n_tiles = with_sorted_copy ? cap / kTilePoints : 0;
         c->n_sorted = n_finite;
-        ok = c->sx.reserve(sizeof(double) * cap) && c->sy.reserve(sizeof(double) * cap) &&
-             c->sz.reserve(sizeof(double) * cap) && c->boxes.reserve(sizeof(double) * kBoxStride * c->n_tiles);
-        if (ok) {
+        if (ok && !with_sorted_copy) n_finite = 0;   // (skips the sort below; c->n_sorted keeps the count)
+        ok = ok && (!with_sorted_copy ||
+                    (c->sx.reserve(sizeof(double) * cap) && c->sy.reserve(sizeof(double) * cap) &&
+                     c->sz.reserve(sizeof(double) * cap) && c->boxes.reserve(sizeof(double) * kBoxStride * c->n_tiles)));
+        if (ok && with_sorted_copy) {
             launch_fill_nan(c->sx.as<double>(), cap, ctx->stream);
             launch_fill_nan(c->sy.as<double>(), cap, ctx->stream);
             launch_fill_nan(c->sz.as<double>(), cap, ctx->stream);
@@ -1709,7 +1716,7 @@ m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, 
                                   t_sums.as<uint32_t>(), t_total.as<uint32_t>(), c->sx.as<double>(),
                                   c->sy.as<double>(), c->sz.as<double>(), ctx->stream);
         }
-        if (ok) launch_tile_boxes(c->sorted(), c->boxes.as<double>(), ctx->stream);
+        if (ok && with_sorted_copy) launch_tile_boxes(c->sorted(), c->boxes.as<double>(), ctx->stream);
     }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (!ok) {

@@ -142,3 +142,6 @@ struct m3d_cloud {
     m3d::SortedView sorted() const;
     const uint32_t* orig() const { return work.active ? work.cur_orig : nullptr; }
 };
+
+// m3d_cloud_create with the Hilbert-sorted copy optional (m3d_driver.cpp)
+extern "C" m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_t n, int device, int with_sorted_copy);

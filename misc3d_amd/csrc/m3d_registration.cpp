@@ -825,8 +825,8 @@ m3d_reg* reg_create(const double* src, size_t n_src, const double* dst, size_t n
         q->trivial = true;
         return q;
     }
-    q->csrc = m3d_cloud_create(src, nullptr, n_src, device);
-    q->cdst = q->csrc ? m3d_cloud_create(dst, nullptr, n_dst, device) : nullptr;
+    q->csrc = m3d_cloud_create_impl(src, nullptr, n_src, device, 0);
+    q->cdst = q->csrc ? m3d_cloud_create_impl(dst, nullptr, n_dst, device, 0) : nullptr;
     if (!q->csrc || !q->cdst) {
         if (q->csrc) m3d_cloud_destroy(q->csrc);
         delete q;
@@ -1049,9 +1049,9 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
         }
         return M3D_OK;
     }
-    m3d_cloud* csrc = m3d_cloud_create(src, nullptr, n_src, device);
+    m3d_cloud* csrc = m3d_cloud_create_impl(src, nullptr, n_src, device, 0);
     if (!csrc) return M3D_ERR_DEVICE;
-    m3d_cloud* cdst = m3d_cloud_create(dst, nullptr, n_dst, device);
+    m3d_cloud* cdst = m3d_cloud_create_impl(dst, nullptr, n_dst, device, 0);
     if (!cdst) {
         m3d_cloud_destroy(csrc);
         return M3D_ERR_DEVICE;
@@ -1206,9 +1206,9 @@ int m3d_information_matrix(const double* src, size_t n_src, const double* dst, s
     if (!(max_correspondence_distance > 0.0)) return fail(M3D_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
     if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
     if (n_src == 0 || n_dst == 0) return M3D_OK;
-    m3d_cloud* csrc = m3d_cloud_create(src, nullptr, n_src, device);
+    m3d_cloud* csrc = m3d_cloud_create_impl(src, nullptr, n_src, device, 0);
     if (!csrc) return M3D_ERR_DEVICE;
-    m3d_cloud* cdst = m3d_cloud_create(dst, nullptr, n_dst, device);
+    m3d_cloud* cdst = m3d_cloud_create_impl(dst, nullptr, n_dst, device, 0);
     if (!cdst) {
         m3d_cloud_destroy(csrc);
         return M3D_ERR_DEVICE;
@@ -1300,7 +1300,7 @@ int m3d_detect_boundary_points(const double* xyz, const double* normals, size_t 
     if ((search != 0 && !(radius > 0.0)) || (search != 1 && (max_nn < 1 || max_nn > kBoundaryMaxNb)))
         return fail(M3D_ERR_INVALID_ARG, "invalid search parameter (radius > 0, 1 <= max_nn <= 128)");
     if (n >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
-    m3d_cloud* c = m3d_cloud_create(xyz, normals, n, device);
+    m3d_cloud* c = m3d_cloud_create_impl(xyz, normals, n, device, 0);
     if (!c) return M3D_ERR_DEVICE;
     DeviceCtx* ctx = c->ctx;
     Scratch S;
