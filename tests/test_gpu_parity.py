@@ -471,3 +471,38 @@ def test_fp32_screen_recount_rate(capi):
     assert g0.stats["pairs_exact"] == 0
     assert g0.stats["best_index"] == st["best_index"] and g0.stats["count"] == st["count"]
     assert np.array_equal(g0.inliers, g.inliers)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_lead_pass_inside_the_box_test_launch(capi, kind):
+    """cull_lead_k: on one GPU with the fp32 paths on, the leading hypotheses of a fit's first chunk are counted inside the
+    launch that runs the chunk's box tests.  Same fit as with the separate launches (fp64 box tests switch the fusion
+    off), same evaluated pairs, and the pairs of the lead pass are not among those of the timed launches."""
+    pts = synth.plane_cloud_c2(150_000, seed=4) if kind == 0 else None
+    nrm = None
+    if pts is None:
+        rng = np.random.default_rng(4)
+        if kind == 1:
+            d = rng.normal(size=(150_000, 3))
+            d /= np.linalg.norm(d, axis=1)[:, None]
+            pts = np.r_[0.3 * d[:90_000] + rng.normal(0, 1e-3, (90_000, 3)), rng.uniform(-1, 1, (60_000, 3))]
+        else:
+            t = rng.uniform(0, 2 * np.pi, 150_000)
+            z = rng.uniform(-1, 1, 150_000)
+            pts = np.c_[0.2 * np.cos(t), 0.2 * np.sin(t), z] + rng.normal(0, 1e-3, (150_000, 3))
+            nrm = np.c_[np.cos(t), np.sin(t), np.zeros_like(t)]
+            pts[100_000:] = rng.uniform(-1, 1, (50_000, 3))
+    kw = dict(threshold=0.01, max_iteration=3000, probability=1.0, seed=3)
+    old = capi.set_config(kernel_timing=1)
+    try:
+        g = capi.fit(kind, pts, nrm, **kw)
+        capi.set_config(kernel_timing=1, cull_fp32=0)
+        g0 = capi.fit(kind, pts, nrm, **kw)
+    finally:
+        capi.restore_config(old)
+    st, st0 = g.stats, g0.stats
+    assert st["best_index"] == st0["best_index"] and st["count"] == st0["count"] and np.array_equal(g.inliers, g0.inliers)
+    assert st["pairs_scored"] > 0 and st0["pairs_scored"] > 0
+    assert 0 < st["pairs_timed"] < st["pairs_scored"]          # the lead pass ran inside cull_lead_k, untimed
+    assert st0["pairs_timed"] == st0["pairs_scored"]           # separate launches: everything is timed
+    assert st["score_launches"] + 1 == st0["score_launches"]   # one timed launch less (the lead's)
