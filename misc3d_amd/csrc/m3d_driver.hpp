@@ -78,6 +78,8 @@ struct DeviceCtx {
     DevBuf ub, best_count;     // bound-and-prune: surviving tiles per hypothesis, running best count
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
+    void* seg_staging = nullptr;   // page-locked staging (m3d_host_alloc) for segmentation's index lists when the caller's array is pageable
+    size_t seg_staging_cap = 0;    // ... in uint64 entries
     PinBuf h_inc;              // m3d_cloud_score_shard: the sampler's pruning incumbent on its way to / from the device
     uint32_t pick_seq = 0;     // last PickFinal::seq handed out (completion words of one-GPU speculative chunks)
     const double* last_best_dev = nullptr;   // device address of the last fit's best minimal model (a slot's params or best_params)

@@ -7,6 +7,6 @@ pts = synth.room_cloud_c5(int(os.environ.get("M3D_C5_POINTS", "10000000")), 6)
 ts = []
 for rep in range(6):
     t0 = time.perf_counter()
-    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, 1000, 0.05, seed=19, copy=False)
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, 1000, 0.05, seed=19)
     ts.append(1e3 * (time.perf_counter() - t0))
 print(" ".join(f"{t:.1f}" for t in ts), "ms; clusters", len(clusters), "points", int(sum(len(c) for c in clusters)))
