@@ -635,7 +635,11 @@ def fit(kind, xyz, normals=None, threshold=0.01, max_iteration=1000, probability
     xyz = _f64(xyz).reshape(-1, 3)
     n = len(xyz)
     params = np.zeros(NUM_PARAMS[kind])
-    inl = np.empty(max(n, 1), dtype=np.uint64)     # filled by the library up to n_inliers
+    # filled by the library up to n_inliers, copied out below: the thread's page-locked scratch when there is one (the
+    # compaction kernel then stores the index list straight into it)
+    inl = _seg_scratch(max(n, 1))
+    if inl is None:
+        inl = np.empty(max(n, 1), dtype=np.uint64)
     ni = C.c_size_t(0)
     st = Stats()
     _s, sref = _seed_ref(seed)
