@@ -522,7 +522,11 @@ class Cloud:
         params = np.zeros(NUM_PARAMS[kind])
         inl = None
         if want_inliers:
-            inl = self._out_buf()
+            # copy=True: the list is copied out anyway -- the thread's page-locked scratch serves every cloud (a buffer per
+            # cloud costs a hipHostMalloc of 8 bytes x N: 14 ms for 10 M points, paid by the first fit on it)
+            inl = _seg_scratch(max(self.n_created, 1)) if copy else None
+            if inl is None:
+                inl = self._out_buf()
         ni = C.c_size_t(0)
         st = Stats()
         _s, sref = _seed_ref(seed)
