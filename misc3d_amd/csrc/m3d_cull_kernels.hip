@@ -19,6 +19,9 @@
 //                   the exact fp64 code (tile_count: the per-pair arithmetic and compare of score_k, bit-identical
 //                   decisions); counts go to counts[h] with integer atomics (order-free, exact).
 //                   (score_mask_k: fp64 only, m3d_config.score_fp32_screen = 0.)
+//   cull_lead_k     the head of a fit's first chunk in ONE launch: cull_tiles32_k's workgroups for the chunk's groups and
+//                   score_screen_k's for its leading hypotheses, whose best count prunes the rest -- the lead pass runs
+//                   the box tests of its own (tile, group) pairs itself (cull32_one: the same arithmetic, the same bits).
 // A culled (tile, hypothesis) pair provably contains no inlier, so the counts of unpruned hypotheses
 // equal the dense ones; tests compare both paths against the oracle.  RefineModel / tie-break passes
 // keep using the original-order arrays, so inlier index lists and serial sums do not see the sort.
