@@ -46,15 +46,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ sx, const double* __restrict__ sy,
                                                      const double* __restrict__ sz, uint32_t n_tiles,
-                                                     double* __restrict__ boxes, double ox, double oy, double oz) {
+                                                     double* __restrict__ boxes, double ox, double oy, double oz,
+                                                     float* __restrict__ tile_f32) {
     const int lane = threadIdx.x & 63;
     const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (tile >= n_tiles) return;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double pts[kTilePoints / 64][3];
+#pragma unroll
     for (int j = 0; j < kTilePoints / 64; ++j) {
         const size_t i = (size_t)tile * kTilePoints + j * 64 + lane;
         const double p[3] = {sx[i], sy[i], sz[i]};
         for (int k = 0; k < 3; ++k) {
+            pts[j][k] = p[k];
             lo[k] = fmin(lo[k], p[k]);
             hi[k] = fmax(hi[k], p[k]);
         }
@@ -64,6 +68,25 @@ __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ s
             lo[k] = fmin(lo[k], __shfl_xor(lo[k], off, 64));
             hi[k] = fmax(hi[k], __shfl_xor(hi[k], off, 64));
         }
+    // score_screen_k's view of the tile: offsets from the box centre in fp32 (the subtraction in fp64: as accurate as
+    // fp32 gets), rows 2j and 2j + 1 side by side; a tile with a non-finite offset (NaN padding, a coordinate beyond the
+    // fp32 range) is not screened (box slot 6)
+    bool finite = true;
+    if (tile_f32) {
+        const bool empty_t = !(lo[0] <= hi[0]);
+        f32x2* __restrict__ t2 = reinterpret_cast<f32x2*>(tile_f32 + (size_t)tile * kTileF32Floats);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double c = empty_t ? 0.0 : 0.5 * lo[k] + 0.5 * hi[k];   // (the centre as stored below)
+#pragma unroll
+            for (int j = 0; j < kTilePoints / 128; ++j) {
+                const f32x2 v = {(float)(pts[2 * j][k] - c), (float)(pts[2 * j + 1][k] - c)};
+                t2[(k * (kTilePoints / 128) + j) * 64 + lane] = v;
+                finite = finite && (v.x * 0.0f == 0.0f) && (v.y * 0.0f == 0.0f);
+            }
+        }
+    }
+    const bool screenable = tile_f32 && __ballot(!finite) == 0ull;
     if (lane == 0) {
         double* b = boxes + (size_t)tile * kBoxStride;
         const bool empty = !(lo[0] <= hi[0]);
@@ -73,7 +96,8 @@ __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ s
             // half extent measured from the ROUNDED centre and inflated, so the box contains its points
             b[3 + k] = empty ? -1.0 : fmax(hi[k] - c, c - lo[k]) * (1.0 + 1e-12) + 1e-300;
         }
-        b[6] = b[7] = 0.0;
+        b[6] = screenable ? 1.0 : 0.0;   // (SortedView::tile_f32)
+        b[7] = 0.0;
         // the same box in fp32, relative to the cloud's origin (cull_tiles32_k): centre rounded to nearest, half extents
         // enlarged by the rounding of the centre and rounded outwards, so that the fp32 box contains the fp64 one
         float* f = reinterpret_cast<float*>(b + 8);
@@ -89,7 +113,7 @@ __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ s
 }
 
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st) {
-    if (s.n_tiles) tile_boxes_k<<<(s.n_tiles + 3) / 4, 256, 0, st>>>(s.x, s.y, s.z, s.n_tiles, boxes, s.origin[0], s.origin[1], s.origin[2]);
+    if (s.n_tiles) tile_boxes_k<<<(s.n_tiles + 3) / 4, 256, 0, st>>>(s.x, s.y, s.z, s.n_tiles, boxes, s.origin[0], s.origin[1], s.origin[2], s.tile_f32);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,7 +724,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
                                                   uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                   uint32_t* __restrict__ pair_rep,
                                                   uint32_t group_begin, uint32_t group_end, uint32_t block_x, uint32_t block_y,
-                                                  const float* __restrict__ cull32) {
+                                                  const float* __restrict__ cull32, const float* __restrict__ tile_f32) {
     __shared__ uint16_t ids[kScreenMaxGroups * 64];
     __shared__ __attribute__((aligned(16))) uint8_t cnt8[64 * kCntStride];
     constexpr int NL = KIND == 2 ? 3 : 2;
@@ -735,16 +759,28 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
     for (int k = 0; k < 6; ++k) box[k] = boxes[(size_t)tile * kBoxStride + k];   // (wave-uniform: scalar loads)
     // rows 2 j and 2 j + 1 of the tile share a register pair
     f32x2 xf[Q], yf[Q], zf[Q];
-    float chk = 0.0f;
+    bool tile_screened;
+    if (tile_f32) {   // (kernel argument: uniform) tile_boxes_k has prepared the offsets and the verdict
+        const f32x2* __restrict__ t2 = reinterpret_cast<const f32x2*>(tile_f32 + (size_t)tile * kTileF32Floats) + lane;
 #pragma unroll
-    for (int j = 0; j < Q; ++j) {
-        xf[j] = {(float)(sx[base + 128 * j] - box[0]), (float)(sx[base + 128 * j + 64] - box[0])};
-        yf[j] = {(float)(sy[base + 128 * j] - box[1]), (float)(sy[base + 128 * j + 64] - box[1])};
-        zf[j] = {(float)(sz[base + 128 * j] - box[2]), (float)(sz[base + 128 * j + 64] - box[2])};
-        chk += ((xf[j].x + xf[j].y) + (yf[j].x + yf[j].y)) + (zf[j].x + zf[j].y);
+        for (int j = 0; j < Q; ++j) {
+            xf[j] = t2[(0 * Q + j) * 64];
+            yf[j] = t2[(1 * Q + j) * 64];
+            zf[j] = t2[(2 * Q + j) * 64];
+        }
+        tile_screened = boxes[(size_t)tile * kBoxStride + 6] != 0.0;
+    } else {
+        float chk = 0.0f;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            xf[j] = {(float)(sx[base + 128 * j] - box[0]), (float)(sx[base + 128 * j + 64] - box[0])};
+            yf[j] = {(float)(sy[base + 128 * j] - box[1]), (float)(sy[base + 128 * j + 64] - box[1])};
+            zf[j] = {(float)(sz[base + 128 * j] - box[2]), (float)(sz[base + 128 * j + 64] - box[2])};
+            chk += ((xf[j].x + xf[j].y) + (yf[j].x + yf[j].y)) + (zf[j].x + zf[j].y);
+        }
+        // inf or NaN anywhere (also an offset beyond the fp32 range) makes chk * 0 a NaN
+        tile_screened = __ballot(!(chk * 0.0f == 0.0f)) == 0ull;
     }
-    // inf or NaN anywhere (also an offset beyond the fp32 range) makes chk * 0 a NaN
-    const bool tile_screened = __ballot(!(chk * 0.0f == 0.0f)) == 0ull;
     // ---- compaction of the set bits into ids[0 .. total): id = 64 * word + bit (relative to g0)
     const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
     uint32_t total = 0;
@@ -855,10 +891,11 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
                                                       uint32_t n_groups, uint32_t groups_per_block /* <= kScreenMaxGroups */,
                                                       uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                       uint32_t* __restrict__ pair_rep,
-                                                      uint32_t group_begin, uint32_t group_end) {
+                                                      uint32_t group_begin, uint32_t group_end,
+                                                      const float* __restrict__ tile_f32) {
     score_screen_body<KIND, false>(sx, sy, sz, boxes, max_abs, score, const_cast<unsigned long long*>(masks), keep, n_groups,
                                    groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, blockIdx.x,
-                                   blockIdx.y, nullptr);
+                                   blockIdx.y, nullptr, tile_f32);
 }
 
 // cull_lead_k: ONE launch for the two latency-bound steps at the head of a fit's first chunk -- the box tests of the
@@ -876,10 +913,11 @@ __global__ __launch_bounds__(64) void cull_lead_k(const double* __restrict__ sx,
                                                    uint32_t lead_groups, uint32_t lead_gpb, uint32_t n_lead_wgs,
                                                    uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                    uint32_t* __restrict__ pair_rep, uint32_t* __restrict__ ub,
-                                                   uint32_t cull_begin, uint32_t cull_end, uint32_t cull_gpw, uint32_t cull_tblocks) {
+                                                   uint32_t cull_begin, uint32_t cull_end, uint32_t cull_gpw, uint32_t cull_tblocks,
+                                                   const float* __restrict__ tile_f32) {
     if (blockIdx.x < n_lead_wgs) {   // (workgroup-uniform)
         score_screen_body<KIND, true>(sx, sy, sz, boxes, max_abs, score, masks, keep, n_groups, lead_gpb, counts_rep, rep_stride,
-                                      pair_rep, 0u, lead_groups, blockIdx.x % n_tiles, blockIdx.x / n_tiles, cull32);
+                                      pair_rep, 0u, lead_groups, blockIdx.x % n_tiles, blockIdx.x / n_tiles, cull32, tile_f32);
     } else {
         const uint32_t b = blockIdx.x - n_lead_wgs;
         cull32_body<KIND>(boxes, n_tiles, cull32, n_groups, cull_gpw, masks, ub, cull_begin, cull_end, b % cull_tblocks,
@@ -1020,13 +1058,16 @@ bool launch_cull_lead(int kind, const SortedView& s, const double* score, const 
     const dim3 g(n_lead_wgs + tblocks * cull_y), b(64);
     if (kind == 0)
         cull_lead_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
-                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks);
+                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
+                                        (const float*)s.tile_f32);
     else if (kind == 1)
         cull_lead_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
-                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks);
+                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
+                                        (const float*)s.tile_f32);
     else
         cull_lead_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
-                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks);
+                                        lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
+                                        (const float*)s.tile_f32);
     return true;
 }
 
@@ -1121,13 +1162,13 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     if (screened) {
         if (kind == 0)
             go(score_screen_k<0>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end);
+               group_begin, group_end, (const float*)s.tile_f32);
         else if (kind == 1)
             go(score_screen_k<1>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end);
+               group_begin, group_end, (const float*)s.tile_f32);
         else
             go(score_screen_k<2>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end);
+               group_begin, group_end, (const float*)s.tile_f32);
     } else {
         if (kind == 0)
             go(score_mask_k<0>, s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep, group_begin, group_end);

@@ -18,6 +18,11 @@ struct SortedView {
     const double* z;
     const double* boxes;  // n_tiles x kBoxStride
     uint32_t n_tiles;
+    // optional, written by tile_boxes_k: every tile's points once more as fp32 offsets from the tile's box centre, in the
+    // register layout of score_screen_k (kTileF32Floats floats per tile: [coordinate][row pair][lane] x (row 2j, row 2j + 1));
+    // box slot 6 then says whether the tile can be screened (every offset finite).  A wave of score_screen_k loads 6 KB
+    // ready to use instead of 12 KB of doubles it has to shift and convert.
+    float* tile_f32 = nullptr;
     double max_abs = __builtin_inf();  // >= |coordinate| of every point of the cloud (the box tests' rounding margin); inf = unknown (nothing culled)
     // centre of the cloud's bounding box and the largest |coordinate - origin| (fp32 box tests work relative to it);
     // radius = inf: unknown, the fp64 box tests are used
@@ -25,6 +30,7 @@ struct SortedView {
     double radius = __builtin_inf();
 };
 
+constexpr int kTileF32Floats = 3 * kTilePoints;
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 
 // masks: n_tiles x n_groups uint64, bit b of masks[t][g] = hypothesis 64 g + b may have inliers in tile t.

@@ -230,6 +230,7 @@ m3d::SortedView m3d_cloud::sorted() const {
     s.y = sy.as<double>();
     s.z = sz.as<double>();
     s.boxes = boxes.as<double>();
+    s.tile_f32 = tile_f32.as<float>();
     s.n_tiles = n_tiles;
     s.max_abs = max_abs;
     for (int k = 0; k < 3; ++k) s.origin[k] = origin[k];
@@ -1405,7 +1406,8 @@ static int cloud_remove_prepare(m3d_cloud* c, PartitionOut* out) {
             ok = w.bx[k].reserve(bytes) && w.by[k].reserve(bytes) && w.bz[k].reserve(bytes) &&
                  w.bo[k].reserve(sizeof(uint32_t) * (size_t)c->n_pad) && w.sbx[k].reserve(sizeof(double) * scap) &&
                  w.sby[k].reserve(sizeof(double) * scap) && w.sbz[k].reserve(sizeof(double) * scap);
-        ok = ok && w.sboxes.reserve(sizeof(double) * kBoxStride * c->n_tiles);
+        ok = ok && w.sboxes.reserve(sizeof(double) * kBoxStride * c->n_tiles) &&
+             w.stile_f32.reserve(sizeof(float) * kTileF32Floats * (size_t)c->n_tiles);
         if (!ok) return M3D_ERR_DEVICE;
         launch_iota(w.bo[0].as<uint32_t>(), c->n, ctx->stream);
         w.cur = c->base_view();   // round 0 reads the uploaded cloud directly
@@ -1495,6 +1497,7 @@ static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed, const size_t* kn
     w.scur.y = w.sby[w.spp].as<double>();
     w.scur.z = w.sbz[w.spp].as<double>();
     w.scur.boxes = w.sboxes.as<double>();
+    w.scur.tile_f32 = w.stile_f32.as<float>();
     w.scur.n_tiles = std::max<uint32_t>(1, (new_sorted + kTilePoints - 1) / kTilePoints);
     // compact_write_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
     launch_tile_boxes(w.scur, w.sboxes.as<double>(), ctx->stream);
@@ -1542,12 +1545,12 @@ static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double*
 template <class F>
 static void for_each_buffer(m3d_cloud* c, F f) {
     f(c->x); f(c->y); f(c->z); f(c->nx); f(c->ny); f(c->nz);
-    f(c->sx); f(c->sy); f(c->sz); f(c->boxes);
+    f(c->sx); f(c->sy); f(c->sz); f(c->boxes); f(c->tile_f32);
     for (int k = 0; k < 2; ++k) {
         f(c->work.bx[k]); f(c->work.by[k]); f(c->work.bz[k]); f(c->work.bo[k]);
         f(c->work.sbx[k]); f(c->work.sby[k]); f(c->work.sbz[k]);
     }
-    f(c->work.sboxes);
+    f(c->work.sboxes); f(c->work.stile_f32);
 }
 static void release_buffers(m3d_cloud* c) {
     for_each_buffer(c, [](DevBuf& b) { b.release(); });
@@ -1685,7 +1688,8 @@ m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_
         if (ok && !with_sorted_copy) n_finite = 0;   // (skips the sort below; c->n_sorted keeps the count)
         ok = ok && (!with_sorted_copy ||
                     (c->sx.reserve(sizeof(double) * cap) && c->sy.reserve(sizeof(double) * cap) &&
-                     c->sz.reserve(sizeof(double) * cap) && c->boxes.reserve(sizeof(double) * kBoxStride * c->n_tiles)));
+                     c->sz.reserve(sizeof(double) * cap) && c->boxes.reserve(sizeof(double) * kBoxStride * c->n_tiles) &&
+                     c->tile_f32.reserve(sizeof(float) * kTileF32Floats * (size_t)c->n_tiles)));
         if (ok && with_sorted_copy) {
             launch_fill_nan(c->sx.as<double>(), cap, ctx->stream);
             launch_fill_nan(c->sy.as<double>(), cap, ctx->stream);

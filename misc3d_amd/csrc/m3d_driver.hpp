@@ -113,6 +113,7 @@ struct m3d_cloud {
     bool has_normals = false;
     // Z-order sorted copy for the culled scoring path (m3d_cull_kernels.hip)
     m3d::DevBuf sx, sy, sz, boxes;
+    m3d::DevBuf tile_f32;   // SortedView::tile_f32 (n_tiles x kTileF32Floats floats)
     uint32_t n_sorted = 0, n_tiles = 0;
     double max_abs = __builtin_inf();   // largest |coordinate| of the finite points (SortedView::max_abs)
     double origin[3] = {0.0, 0.0, 0.0};   // centre of the bounding box of the finite points (SortedView::origin)
@@ -125,7 +126,7 @@ struct m3d_cloud {
     // view() / sorted() describe the working cloud in the ping-pong buffers below.
     struct Work {
         bool active = false;
-        m3d::DevBuf bx[2], by[2], bz[2], bo[2], sbx[2], sby[2], sbz[2], sboxes;
+        m3d::DevBuf bx[2], by[2], bz[2], bo[2], sbx[2], sby[2], sbz[2], sboxes, stile_f32;
         m3d::CloudView cur;
         m3d::SortedView scur;
         const uint32_t* cur_orig = nullptr;   // working index -> index in the cloud as created
