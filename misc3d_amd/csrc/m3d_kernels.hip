@@ -534,19 +534,65 @@ void launch_scan_blocks(uint32_t* v, uint32_t nb, uint32_t* total, hipStream_t s
     scan_blocks_k<<<1, 1024, 0, s>>>(v, nb, total, nullptr, nullptr, nullptr);
 }
 
+// what scan_blocks_k used to deliver between the counting and the writing pass, now produced by compact_write_k itself
+struct CompactTail {
+    uint32_t* total = nullptr;         // device: [0] = number of flagged points
+    uint32_t* total_host = nullptr;    // device-visible host copy (may be null)
+    const double* moment_partial = nullptr;   // compact_count_k<.., true>'s per-workgroup partials (may be null)
+    double* moment_out = nullptr;      // ... folded: [0..11], [12] = the total as a double
+    uint32_t nb = 0;
+};
+__device__ __forceinline__ void compact_tail_total(const CompactTail& t, uint32_t total) {
+    if (t.total) t.total[0] = total;
+    if (t.total_host) t.total_host[0] = total;
+    if (t.moment_out) t.moment_out[12] = (double)total;
+}
+
 template <int KIND, int MODE>
 __global__ __launch_bounds__(256) void compact_write_k(
     CloudView c, const double* __restrict__ model, double thr, const uint32_t* __restrict__ orig,
     const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ ox, double* __restrict__ oy,
     double* __restrict__ oz, uint32_t* __restrict__ oorig, uint32_t n_pad_cap,
-    uint64_t* __restrict__ out_idx_host /* MODE 0 / 4: the caller's page-locked index list, written as well (may be null) */) {
+    uint64_t* __restrict__ out_idx_host /* MODE 0 / 4: the caller's page-locked index list, written as well (may be null) */,
+    CompactTail tail) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t wsum2[4];
     double m[7];
     for (int k = 0; k < 7; ++k) m[k] = model[k];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t row_base = block_offsets[blockIdx.x];
+    // This workgroup's offset = the counts of the workgroups before it, summed here (block_offsets holds compact_count_k's
+    // RAW counts): a few hundred loads per workgroup, all workgroups at once, against a one-workgroup scan kernel and its
+    // launch gap (7 us) between the counting and the writing pass.
+    uint32_t row_base;
+    {
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256u) part += block_offsets[i];
+        for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off, 64);
+        if (lane == 0) wsum[wave] = part;
+        __syncthreads();
+        row_base = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        __syncthreads();
+    }
+    // workgroup 0 also folds RefineModel's moment partials (what scan_blocks_k did: thread (g, l) sums workgroups l, l + 64,
+    // ... of value g, then a 64-leaf tree -- the same order, the same sums)
+    if (tail.moment_partial && blockIdx.x == 0) {   // (workgroup-uniform)
+        __shared__ double msum[4 * 64];
+        const uint32_t gq = threadIdx.x >> 6, l = threadIdx.x & 63u;
+        for (uint32_t g0 = 0; g0 < 12u; g0 += 4u) {
+            const uint32_t g = g0 + gq;
+            double a = 0.0;
+            for (uint32_t b = l; b < tail.nb; b += 64u) a += tail.moment_partial[(size_t)b * 16 + g];
+            msum[gq * 64 + l] = a;
+            __syncthreads();
+            for (int off = 32; off > 0; off >>= 1) {
+                if ((int)l < off) msum[gq * 64 + l] += msum[gq * 64 + l + off];
+                __syncthreads();
+            }
+            if (l == 0) tail.moment_out[g] = msum[gq * 64];
+            __syncthreads();
+        }
+    }
     const uint32_t base = blockIdx.x * kCompactTile;
     if (MODE == 4) {
         // inlier list (mode 0) AND the partition of the rest (mode 2) from one evaluation of the distance.  Every
@@ -594,6 +640,7 @@ __global__ __launch_bounds__(256) void compact_write_k(
             rest_base += rowtot2;
             __syncthreads();
         }
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) compact_tail_total(tail, row_base);
         if (blockIdx.x == gridDim.x - 1) {   // NaN padding of the partition, as below
             const uint32_t n = rest_base;
             const uint32_t n_pad = min(n_pad_cap, (n + kScoreTile - 1) / kScoreTile * kScoreTile);
@@ -642,6 +689,7 @@ __global__ __launch_bounds__(256) void compact_write_k(
         row_base += rowtot;
         __syncthreads();
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) compact_tail_total(tail, row_base);   // (the last workgroup ends with the total)
     // NaN padding of the freshly compacted SoA cloud, [n, n_pad): the last workgroup ends with row_base = n
     if ((MODE == 2 || MODE == 3) && blockIdx.x == gridDim.x - 1) {
         const uint32_t n = row_base;
@@ -675,22 +723,27 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
         compact_count_k<KIND == 2 ? 0 : KIND, true><<<nb, 256, 0, s>>>(c, model, thr, 0, block_counts, model_copy, moment_partial);
     else
         compact_count_k<KIND, false><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts, model_copy, nullptr);
-    scan_blocks_k<<<1, 1024, 0, s>>>(block_counts, nb, total, sums ? moment_partial : nullptr, sums ? moment_out : nullptr, total_host);
+    CompactTail tail;
+    tail.total = total;
+    tail.total_host = total_host;
+    tail.moment_partial = sums ? moment_partial : nullptr;
+    tail.moment_out = sums ? moment_out : nullptr;
+    tail.nb = nb;
     if (mode == 0 && part && orig)
         compact_write_k<KIND, 4><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx, nullptr, part->ox, part->oy,
-                                                     part->oz, part->oorig, part->n_pad_cap, out_idx_host);
+                                                     part->oz, part->oorig, part->n_pad_cap, out_idx_host, tail);
     else if (mode == 0)
         compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
-                                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, out_idx_host);
+                                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, out_idx_host, tail);
     else if (mode == 1)
         compact_write_k<KIND, 1><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                     out_dist, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+                                                     out_dist, nullptr, nullptr, nullptr, nullptr, 0, nullptr, tail);
     else if (mode == 2)
         compact_write_k<KIND, 2><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                     nullptr, ox, oy, oz, oorig, n_pad_out, nullptr);
+                                                     nullptr, ox, oy, oz, oorig, n_pad_out, nullptr, tail);
     else
         compact_write_k<KIND, 3><<<nb, 256, 0, s>>>(c, model, thr, nullptr, block_counts, nullptr,
-                                                     nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr);
+                                                     nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr, tail);
 }
 
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
