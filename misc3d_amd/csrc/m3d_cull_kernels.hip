@@ -30,6 +30,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "m3d_config.hpp"
 #include "m3d_fp.hpp"
@@ -728,7 +729,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
     __shared__ uint16_t ids[kScreenMaxGroups * 64];
     __shared__ __attribute__((aligned(16))) uint8_t cnt8[64 * kCntStride];
     constexpr int NL = KIND == 2 ? 3 : 2;
-    __shared__ float4 loc[64][NL];   // the batch's (tile, hypothesis) records
+    __shared__ float4 loc[64 + 1][NL];   // the batch's (tile, hypothesis) records (+ one row the loop's look-ahead may read)
     const uint32_t tile = block_x;
     uint32_t* __restrict__ counts = counts_rep + (size_t)(tile % kCountReplicas) * rep_stride;
     const uint32_t g0 = group_begin + block_y * groups_per_block;
@@ -834,36 +835,59 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         }
         __syncthreads();
         uint32_t park = 0;   // lane k: exact count of hypothesis k when the screen could not decide it
-        auto step = [&](const float4 ra, const float4 rb, const float4 rc, uint32_t k) {
+        // SCREENED is the tile's verdict (wave-uniform, fixed for the workgroup): a compile-time flag of the loop so that
+        // the screened loop carries no branch and no register initialisation for the other case
+        auto step = [&](auto screened, const float4 ra, const float4 rb, const float4 rc, uint32_t k, uint8_t* cnt_row) {
+            constexpr bool SCREENED = decltype(screened)::value;
             uint32_t bits = 0;
-            float m = 0.0f;
-            bool exact = !tile_screened;
-            if (tile_screened) {
+            bool exact = true;
+            if (SCREENED) {
+                float m;
                 screen_eval<KIND, Q>(ra, rb, rc, xf, yf, zf, bits, m);
                 exact = __ballot(!(m >= (KIND == 0 ? rb.y : (KIND == 1 ? rb.w : rc.z)))) != 0ull;   // (h = NaN: the record is not screened)
             }
             uint32_t c = (uint32_t)__popc(bits);
-            if (exact) {   // wave-uniform, rare
+            if (__builtin_expect(exact && k < nb, 0)) {   // wave-uniform, rare
                 const uint32_t e = exact_count((uint32_t)__builtin_amdgcn_readlane(my, (int)k));
                 if (lane == 0) atomicAdd(&pair_rep[(uint32_t)kPairMain + tile % (uint32_t)(kPairLead - kPairMain)], 1u);
                 park = ((uint32_t)lane == k) ? e : park;
                 c = 0;
             }
-            cnt8[k * kCntStride + (uint32_t)lane] = (uint8_t)c;
+            *cnt_row = (uint8_t)c;
         };
-        float4 a0 = loc[0][0], a1 = loc[0][1], a2 = loc[0][NL - 1], b0r, b1r, b2r;
-        for (uint32_t k = 0; k < nb; k += 2u) {
-            // two hypotheses per trip, their records in alternating register sets; the next one is always in flight
-            const uint32_t k1 = min(k + 1u, nb - 1u), k2 = min(k + 2u, nb - 1u);
-            b0r = loc[k1][0];
-            b1r = loc[k1][1];
-            b2r = loc[k1][NL - 1];
-            step(a0, a1, a2, k);
-            a0 = loc[k2][0];
-            a1 = loc[k2][1];
-            a2 = loc[k2][NL - 1];
-            if (k + 1u < nb) step(b0r, b1r, b2r, k + 1u);
-        }
+        // four hypotheses per trip, their records in alternating register sets with the next one always in flight.  The
+        // trip count is rounded up: rows nb .. of `loc` hold valid records (every lane wrote one), their counts land in
+        // rows of the table nobody adds up -- which keeps every LDS address of a trip at a constant offset from one
+        // register: the two byte offsets below live in VGPRs the compiler cannot see through (it would otherwise rebuild
+        // each address from the scalar loop counter: two VALU instructions per hypothesis)
+        auto batch = [&](auto screened) {
+            uint32_t rec_off = 0, cnt_off = (uint32_t)lane;
+            asm volatile("" : "+v"(rec_off), "+v"(cnt_off));
+            const char* const loc_b = reinterpret_cast<const char*>(&loc[0][0]);
+            auto fetch = [&](int i, float4& r0, float4& r1, float4& r2) {
+                const float4* __restrict__ r = reinterpret_cast<const float4*>(loc_b + rec_off) + i * NL;
+                r0 = r[0];
+                r1 = r[1];
+                r2 = r[NL - 1];
+                __builtin_amdgcn_sched_barrier(0);   // (the reads are issued HERE, ahead of the arithmetic of the step before them)
+            };
+            float4 a0, a1, a2, b0r, b1r, b2r;
+            fetch(0, a0, a1, a2);
+            for (uint32_t k = 0; k < nb; k += 4u) {
+                fetch(1, b0r, b1r, b2r);
+                step(screened, a0, a1, a2, k, cnt8 + cnt_off);
+                fetch(2, a0, a1, a2);
+                step(screened, b0r, b1r, b2r, k + 1u, cnt8 + cnt_off + kCntStride);
+                fetch(3, b0r, b1r, b2r);
+                step(screened, a0, a1, a2, k + 2u, cnt8 + cnt_off + 2 * kCntStride);
+                fetch(4, a0, a1, a2);   // (row 64: the padding row, read by the last trip and never used)
+                step(screened, b0r, b1r, b2r, k + 3u, cnt8 + cnt_off + 3 * kCntStride);
+                rec_off += 4u * NL * (uint32_t)sizeof(float4);
+                cnt_off += 4u * kCntStride;
+            }
+        };
+        if (tile_screened) batch(std::true_type{});
+        else batch(std::false_type{});
         __syncthreads();   // (one wave: the table is complete)
         if ((uint32_t)lane < nb) {
             const uint4* row = reinterpret_cast<const uint4*>(cnt8 + (uint32_t)lane * kCntStride);
