@@ -613,14 +613,19 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
 //     the sign bits of q (inside <=> q < 0) into a per-lane bit string, 1.5 v_min keeping min |q|: 7.5 instructions
 //     for two points instead of 14, and none of them on the scalar unit (the v_cmp -> s_bcnt1 -> s_add counting of the
 //     fp64 loop costs two scalar instructions per row).
-//   * After the 8 points of a lane: v_bcnt gives the lane's count (0..8), one ds_write_b8 parks it in row k of an
-//     LDS table; `!(min |q| >= h)` over the wave says whether any point was too close to call -- then the tile's
-//     fp64 points are fetched again and the pair is counted by tile_count, the exact code (m3d_stats.pairs_exact).
-//   * Every 64 hypotheses lane k adds up row k (4 ds_read_b128 + 16 v_dot4) and issues the batch's one vector
-//     atomic, as before.
+//   * After the 8 points of a lane: one ds_write_b8 parks the lane's 8 inside-bits in row k of an LDS table;
+//     `!(min |q| >= h)` over the wave says whether any point was too close to call -- then the tile's fp64 points are
+//     fetched again and the pair is counted by tile_count, the exact code (m3d_stats.pairs_exact).
+//   * Every 64 hypotheses lane k adds up the bits of row k (4 ds_read_b128 + 16 v_bcnt) and issues the batch's one
+//     vector atomic, as before.
+//   * Four hypotheses per trip of the loop: 29 VALU instructions each (16 v_pk_fma, 8 shifts, 4 v_min3, 1 compare: what
+//     ops_per_pair in bench.py counts) and three more per trip (two address additions, a register copy).
 // A tile with a non-finite coordinate (the NaN padding of the last tile, or the caller's own) is never screened.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kScreenMaxGroups = 16;   // 64-hypothesis groups per workgroup (the id list: 2 KB of LDS)
+#ifndef M3D_SCREEN_MAX_GROUPS
+#define M3D_SCREEN_MAX_GROUPS 8
+#endif
+constexpr uint32_t kScreenMaxGroups = M3D_SCREEN_MAX_GROUPS;   // 64-hypothesis groups per workgroup (the id list: 1 KB of LDS; 7.2 KB in all: 22 workgroups per CU)
 constexpr int kCntStride = 64;              // bytes per row of the count table
 
 // bits: 8 sign bits (point inside <=> 1); m: min over the lane's points of the distance to the decision boundary
@@ -846,14 +851,13 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
                 screen_eval<KIND, Q>(ra, rb, rc, xf, yf, zf, bits, m);
                 exact = __ballot(!(m >= (KIND == 0 ? rb.y : (KIND == 1 ? rb.w : rc.z)))) != 0ull;   // (h = NaN: the record is not screened)
             }
-            uint32_t c = (uint32_t)__popc(bits);
-            if (__builtin_expect(exact && k < nb, 0)) {   // wave-uniform, rare
+            if (__builtin_expect(exact, 0)) {   // wave-uniform, rare
                 const uint32_t e = exact_count((uint32_t)__builtin_amdgcn_readlane(my, (int)k));
                 if (lane == 0) atomicAdd(&pair_rep[(uint32_t)kPairMain + tile % (uint32_t)(kPairLead - kPairMain)], 1u);
                 park = ((uint32_t)lane == k) ? e : park;
-                c = 0;
+                bits = 0;
             }
-            *cnt_row = (uint8_t)c;
+            *cnt_row = (uint8_t)bits;   // (the lane's 8 inside-bits: whoever adds up the row counts them)
         };
         // four hypotheses per trip, their records in alternating register sets with the next one always in flight.  The
         // trip count is rounded up: rows nb .. of `loc` hold valid records (every lane wrote one), their counts land in
@@ -877,11 +881,11 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
                 fetch(1, b0r, b1r, b2r);
                 step(screened, a0, a1, a2, k, cnt8 + cnt_off);
                 fetch(2, a0, a1, a2);
-                step(screened, b0r, b1r, b2r, k + 1u, cnt8 + cnt_off + kCntStride);
+                if (k + 1u < nb) step(screened, b0r, b1r, b2r, k + 1u, cnt8 + cnt_off + kCntStride);   // (scalar branches)
                 fetch(3, b0r, b1r, b2r);
-                step(screened, a0, a1, a2, k + 2u, cnt8 + cnt_off + 2 * kCntStride);
+                if (k + 2u < nb) step(screened, a0, a1, a2, k + 2u, cnt8 + cnt_off + 2 * kCntStride);
                 fetch(4, a0, a1, a2);   // (row 64: the padding row, read by the last trip and never used)
-                step(screened, b0r, b1r, b2r, k + 3u, cnt8 + cnt_off + 3 * kCntStride);
+                if (k + 3u < nb) step(screened, b0r, b1r, b2r, k + 3u, cnt8 + cnt_off + 3 * kCntStride);
                 rec_off += 4u * NL * (uint32_t)sizeof(float4);
                 cnt_off += 4u * kCntStride;
             }
@@ -895,10 +899,10 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = row[i];
-                sum = __builtin_amdgcn_udot4(v.x, 0x01010101u, sum, false);
-                sum = __builtin_amdgcn_udot4(v.y, 0x01010101u, sum, false);
-                sum = __builtin_amdgcn_udot4(v.z, 0x01010101u, sum, false);
-                sum = __builtin_amdgcn_udot4(v.w, 0x01010101u, sum, false);
+                sum += (uint32_t)__popc(v.x);   // (v_bcnt_u32_b32 adds its second operand)
+                sum += (uint32_t)__popc(v.y);
+                sum += (uint32_t)__popc(v.z);
+                sum += (uint32_t)__popc(v.w);
             }
             if (sum) atomicAdd(&counts[g0 * 64u + (uint32_t)my], sum);
         }
