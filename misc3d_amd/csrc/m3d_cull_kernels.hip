@@ -794,8 +794,8 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(mm_lo, (int)w), hi = (uint32_t)__builtin_amdgcn_readlane(mm_hi, (int)w);
         if ((lo | hi) == 0u) continue;
         const unsigned long long word = ((unsigned long long)hi << 32) | lo;
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-        if ((word >> lane) & 1ull) ids[total + below] = (uint16_t)(w * 64u + (uint32_t)lane);
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, total));
+        if (__builtin_amdgcn_inverse_ballot_w64(word)) ids[slot] = (uint16_t)(w * 64u + (uint32_t)lane);   // (exec = word)
         total += (uint32_t)__popcll(word);
     }
     __syncthreads();
