@@ -389,7 +389,10 @@ typedef struct m3d_config {
     int32_t reg_fp32_screen;        /* [M3D_REG_SCREEN=0]   default 1: the nearest-neighbour search of the registration validation finds its
                                        candidate in fp32 (16-byte list entries relative to the cell, rounding bound) and evaluates the winner
                                        in fp64; a query whose runner-up is within the bound takes the fp64 walk: identical distances */
-    int32_t reserved[5];            /* zero */
+    int32_t fused_compaction;       /* [M3D_FUSED_COMPACT=1] default 0: counting launch + writing launch for RefineModel's inlier list
+                                       (compact_count_k, compact_write_k); 1: ONE launch whose workgroups hand their counts to each other
+                                       (compact_fused_k): the same list and sums, the same time on one MI355X */
+    int32_t reserved[4];            /* zero */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -817,11 +817,28 @@ static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, c
         RESERVE(ctx->moment_partial, sizeof(double) * 16 * (size_t)std::max<uint32_t>(nb, 1));
         RESERVE(ctx->h_moments, sizeof(double) * kFusedMomentDoubles);
     }
+    // one launch (compact_fused_k): a word per workgroup and a ticket, zero when new, told apart by the launch's epoch
+    FusedScan fs;
+    {
+        const size_t want = sizeof(unsigned long long) * ((size_t)nb + 1);
+        if (ctx->compact_state.cap < want) {
+            RESERVE(ctx->compact_state, std::max<size_t>(2 * want, (size_t)1 << 16));
+            HIPCHK(hipMemsetAsync(ctx->compact_state.p, 0, ctx->compact_state.cap, ctx->stream));
+            ctx->compact_epoch = 0;
+        }
+        if (++ctx->compact_epoch == 0) ctx->compact_epoch = 1;   // (a wrap would need 2^32 launches without a reallocation;
+                                                                 //  the words of that long ago all carry other epochs)
+        const size_t words = ctx->compact_state.cap / sizeof(unsigned long long);
+        fs.state = ctx->compact_state.as<unsigned long long>();
+        fs.ticket = reinterpret_cast<uint32_t*>(fs.state + (words - 1));
+        fs.epoch = ctx->compact_epoch;
+    }
     launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
                    ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
                    fused ? ctx->moment_partial.as<double>() : nullptr, fused ? ctx->h_moments.as<double>() : nullptr,
-                   idx_host, static_cast<uint32_t*>(total_host) /* pinned: the scan kernel writes the total there itself */, part);
+                   idx_host, static_cast<uint32_t*>(total_host) /* pinned: the kernel writes the total there itself */, part,
+                   config().fused_compaction ? &fs : nullptr);
     ctx->compaction_fused = fused;
     ctx->compaction_idx_host = idx_host;
     return M3D_OK;
