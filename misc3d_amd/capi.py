@@ -574,16 +574,13 @@ class Cloud:
         st = Stats()
         _s, sref = _seed_ref(seed)
         rc = _check(lib().m3d_cloud_fit_sharded(self._h, comm._h if comm is not None else None, kind, threshold,
-                                                max_iteration, probability,
-                                                C.cast(sref, C.c_void_p) if sref else None, _p(params), _p(inl),
-                                                C.cast(C.byref(ni), C.c_void_p), C.cast(C.byref(st), C.c_void_p)))
+                                                max_iteration, probability, sref, _addr(params), _addr(inl),
+                                                C.byref(ni), C.byref(st)))
         if want_inliers:
             inliers = inl[: ni.value].copy() if copy else inl[: ni.value]
         else:
             inliers = np.zeros(0, dtype=np.uint64)
-        d = st.asdict()
-        d["n_inliers"] = int(ni.value)
-        return Fit(rc, params, inliers, d)
+        return Fit(rc, params, inliers, (st, ni.value))
 
     def score_range(self, kind, threshold, samples, begin=0, end=None, want_models=True):
         """m3d_cloud_score_range -> (valid, models or None, counts) for hypotheses [begin, end)."""
