@@ -28,6 +28,13 @@ int m3d_bench_time_score(m3d_cloud *cloud, int kind, double threshold, const uin
  * nominal 39.3 (256 CU x 4 SIMD x 16 lanes x 2.4 GHz) -- the chip clocks below 2.4 GHz under sustained fp64 load. */
 int m3d_bench_fp64_issue_rate(int device, double ms_target, double *tera_lane_ops_per_s, double *ms_measured);
 
+/* TEST hook (tests/fp_order_worker.py): the EdgeLength + Distance checkers of the registration path evaluated on the
+ * HOST by the very code the kernels compile (m3d_reg_fp.hpp reg_checkers): ps / pd = the 3 sampled source / target
+ * points (3 x 3 doubles each), T = 4 x 4 row-major.  Returns 1 = pass, 0 = rejected.  Lets a box without a GPU check
+ * that a library built for another M3D_FP_ORDER carries that association into the registration code as well. */
+int m3d_bench_reg_checkers(const double *ps, const double *pd, const double *T, double edge_threshold,
+                           double distance_threshold);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,6 +188,7 @@ def lib():
                                                       C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                       C.c_void_p]
         L.m3d_bench_fp64_issue_rate.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.m3d_bench_reg_checkers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
         L.m3d_get_config.restype = None
         L.m3d_get_config.argtypes = [C.c_void_p]
         L.m3d_set_config.argtypes = [C.c_void_p]

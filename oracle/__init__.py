@@ -186,8 +186,10 @@ class FitResult:
     trace: dict | None = None
 
 
-def fit(kind, xyz, normals=None, thr=0.01, max_iter=1000, prob=0.9999, seed=0, trace=False) -> FitResult:
-    """Sequential seeded restatement of RANSAC::FitModel (ransac.h:506-624)."""
+def fit(kind, xyz, normals=None, thr=0.01, max_iter=1000, prob=0.9999, seed=0, trace=False, lookahead=1) -> FitResult:
+    """Sequential seeded restatement of RANSAC::FitModel (ransac.h:506-624).  lookahead > 1: the same loop with the
+    records of the next `lookahead` hypotheses computed ahead by an OpenMP team (orc_fit_parallel; identical outputs,
+    for the full-size BASELINE configurations)."""
     xyz = _f64(xyz).reshape(-1, 3)
     n = len(xyz)
     nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
@@ -203,9 +205,13 @@ def fit(kind, xyz, normals=None, thr=0.01, max_iter=1000, prob=0.9999, seed=0, t
                          models=np.zeros((max_iter, _NP[kind])), counts=np.zeros(max_iter, dtype=np.uint64),
                          errors=np.zeros(max_iter))
         tr = _Trace(*[_p(tr_arrays[k]) for k in ("samples", "valid", "models", "counts", "errors")])
-    ret = lib().orc_fit(C.c_int(kind), _p(xyz), _p(nrm), C.c_size_t(n), C.c_double(thr), C.c_size_t(max_iter),
-                        C.c_double(prob), C.c_uint64(seed), _p(params), _p(inl), C.byref(ni), C.byref(st),
-                        C.byref(tr) if tr is not None else None)
+    args = (C.c_int(kind), _p(xyz), _p(nrm), C.c_size_t(n), C.c_double(thr), C.c_size_t(max_iter),
+            C.c_double(prob), C.c_uint64(seed), _p(params), _p(inl), C.byref(ni), C.byref(st),
+            C.byref(tr) if tr is not None else None)
+    if lookahead > 1:
+        ret = lib().orc_fit_parallel(*args, C.c_size_t(lookahead))
+    else:
+        ret = lib().orc_fit(*args)
     return FitResult(ret, params, inl[: ni.value].copy(), st.fitness, st.inlier_rmse, int(st.count),
                      int(st.iterations), int(st.best_index), tr_arrays)
 
@@ -283,16 +289,19 @@ def native_baseline():
     return _native
 
 
-def segment_plane_iterative(xyz, thr, max_iteration=100, min_ratio=0.05, seed=0, max_clusters=4096):
+def segment_plane_iterative(xyz, thr, max_iteration=100, min_ratio=0.05, seed=0, max_clusters=4096, lookahead=1):
     xyz = _f64(xyz).reshape(-1, 3)
     n = len(xyz)
     planes = np.zeros((max_clusters, 4))
     offs = np.zeros(max_clusters + 1, dtype=np.uint64)
     idx = np.zeros(max(n, 1), dtype=np.uint64)
     k = C.c_size_t(0)
-    rc = lib().orc_segment_plane_iterative(_p(xyz), C.c_size_t(n), C.c_double(thr), C.c_int(max_iteration),
-                                           C.c_double(min_ratio), C.c_uint64(seed), C.c_size_t(max_clusters),
-                                           _p(planes), _p(offs), _p(idx), C.byref(k))
+    args = (_p(xyz), C.c_size_t(n), C.c_double(thr), C.c_int(max_iteration), C.c_double(min_ratio), C.c_uint64(seed),
+            C.c_size_t(max_clusters), _p(planes), _p(offs), _p(idx), C.byref(k))
+    if lookahead > 1:
+        rc = lib().orc_segment_plane_iterative_parallel(*args, C.c_size_t(lookahead))
+    else:
+        rc = lib().orc_segment_plane_iterative(*args)
     k = k.value
     return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() for i in range(k)]
 
@@ -314,6 +323,15 @@ def umeyama(src, dst, with_scaling=False):
     T = np.zeros(16)
     lib().orc_umeyama(_p(src), _p(dst), C.c_size_t(len(src)), C.c_int(int(with_scaling)), _p(T))
     return T.reshape(4, 4)
+
+
+def reg_checkers(ps, pd, T, edge_thr, dist_thr):
+    """orc_reg_checkers on the 3 sampled correspondences given as points (3 x 3 each) -> bool"""
+    ps = _f64(ps, (9,))
+    pd = _f64(pd, (9,))
+    T = _f64(T, (16,))
+    ids = np.arange(3, dtype=np.int64)
+    return bool(lib().orc_reg_checkers(_p(ps), _p(pd), _p(ids), _p(ids), _p(T), C.c_double(edge_thr), C.c_double(dist_thr)))
 
 
 def reg_validate(src, dst, T, thr):

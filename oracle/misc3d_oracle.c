@@ -527,9 +527,35 @@ typedef struct {
  * throws (LogError): -1 probability out of (0,1] (ransac.h:483-485), -2 too few points
  * (ransac.h:510-513), -3 cylinder without normals (ransac.h:356-359, py_common.cpp:50-52).
  * params receives best_model after RefineModel (refined in place when GeneralFit succeeds). */
+static int fit_impl(int kind, const double *xyz, const double *normals, size_t n, double thr,
+                    size_t max_iter, double prob, uint64_t seed, double *params, size_t *inliers,
+                    size_t *n_inliers, orc_stats *stats, orc_trace *trace, size_t lookahead);
+
 int orc_fit(int kind, const double *xyz, const double *normals, size_t n, double thr,
             size_t max_iter, double prob, uint64_t seed, double *params, size_t *inliers,
             size_t *n_inliers, orc_stats *stats, orc_trace *trace) {
+    return fit_impl(kind, xyz, normals, n, thr, max_iter, prob, seed, params, inliers, n_inliers,
+                    stats, trace, 1);
+}
+
+/* The SAME sequential loop, for clouds too big to scan hypothesis by hypothesis on one core (the
+ * full-size BASELINE configurations): the minimal fit + EvaluateModel of the next `lookahead`
+ * hypotheses are computed ahead by an OpenMP team -- a hypothesis' record depends only on its
+ * sample, and the samples are the same prefix of the one mt19937 stream, drawn in order --
+ * and the loop below consumes them in index order with the reference's own update / stop rules.
+ * Records computed past an early stop are discarded (the sampler's extra draws with them: nothing
+ * reads the generator afterwards).  Every output, including the serial error sums, is the
+ * sequential loop's bit for bit (tests/test_oracle_primitives.py compares the two). */
+int orc_fit_parallel(int kind, const double *xyz, const double *normals, size_t n, double thr,
+                     size_t max_iter, double prob, uint64_t seed, double *params, size_t *inliers,
+                     size_t *n_inliers, orc_stats *stats, orc_trace *trace, size_t lookahead) {
+    return fit_impl(kind, xyz, normals, n, thr, max_iter, prob, seed, params, inliers, n_inliers,
+                    stats, trace, lookahead < 1 ? 1 : lookahead);
+}
+
+static int fit_impl(int kind, const double *xyz, const double *normals, size_t n, double thr,
+                    size_t max_iter, double prob, uint64_t seed, double *params, size_t *inliers,
+                    size_t *n_inliers, orc_stats *stats, orc_trace *trace, size_t lookahead) {
     const int m = orc_minimal_sample(kind);
     const int np = orc_num_params(kind);
     if (prob <= 0 || prob > 1) return -1;
@@ -546,13 +572,48 @@ int orc_fit(int kind, const double *xyz, const double *normals, size_t n, double
     orc_mt_seed(&rng, seed);
 
     /* ransac.h:572: `for (int i = 0; i < max_iteration_; ++i)` */
+    /* look-ahead window [w0, w1) of records computed ahead (lookahead == 1: none, the plain loop) */
+    size_t w0 = 0, w1 = 0;
+    size_t *w_samples = NULL;
+    int *w_valid = NULL;
+    double *w_models = NULL, *w_errors = NULL;
+    uint64_t *w_counts = NULL;
+    if (lookahead > 1) {
+        w_samples = (size_t *)malloc(sizeof(size_t) * lookahead * 4);
+        w_valid = (int *)malloc(sizeof(int) * lookahead);
+        w_models = (double *)malloc(sizeof(double) * lookahead * 7);
+        w_errors = (double *)malloc(sizeof(double) * lookahead);
+        w_counts = (uint64_t *)malloc(sizeof(uint64_t) * lookahead);
+    }
     for (size_t i = 0; i < max_iter; ++i) {
         if (count > current_iteration) break; /* ransac.h:573-575: every later i is skipped too */
         last_run = i + 1;
         size_t sample[4];
-        orc_sample(&rng, n, m, sample);
         double model[7] = {0, 0, 0, 0, 0, 0, 0};
-        const int ok = orc_minimal_fit_idx(kind, xyz, normals, sample, model);
+        int ok;
+        if (lookahead > 1) {
+            if (i >= w1) {
+                w0 = i;
+                w1 = i + lookahead < max_iter ? i + lookahead : max_iter;
+                for (size_t j = w0; j < w1; ++j) orc_sample(&rng, n, m, w_samples + (j - w0) * 4);
+#pragma omp parallel for schedule(dynamic, 1)
+                for (long j = 0; j < (long)(w1 - w0); ++j) {
+                    double *mj = w_models + 7 * j;
+                    for (int q = 0; q < 7; ++q) mj[q] = 0;
+                    w_valid[j] = orc_minimal_fit_idx(kind, xyz, normals, w_samples + j * 4, mj);
+                    w_counts[j] = 0;
+                    w_errors[j] = 0;
+                    if (w_valid[j])
+                        orc_evaluate_model(kind, xyz, n, thr, mj, &w_counts[j], &w_errors[j]);
+                }
+            }
+            memcpy(sample, w_samples + (i - w0) * 4, sizeof(size_t) * 4);
+            memcpy(model, w_models + 7 * (i - w0), sizeof(double) * 7);
+            ok = w_valid[i - w0];
+        } else {
+            orc_sample(&rng, n, m, sample);
+            ok = orc_minimal_fit_idx(kind, xyz, normals, sample, model);
+        }
         if (trace) {
             if (trace->samples) memcpy(trace->samples + i * m, sample, sizeof(size_t) * m);
             if (trace->valid) trace->valid[i] = ok;
@@ -563,7 +624,12 @@ int orc_fit(int kind, const double *xyz, const double *normals, size_t n, double
         if (!ok) continue; /* ransac.h:584-586: no count++ */
         uint64_t cnt;
         double err, fitness, rmse;
-        orc_evaluate_model(kind, xyz, n, thr, model, &cnt, &err);
+        if (lookahead > 1) {
+            cnt = w_counts[i - w0];
+            err = w_errors[i - w0];
+        } else {
+            orc_evaluate_model(kind, xyz, n, thr, model, &cnt, &err);
+        }
         if (trace) {
             if (trace->counts) trace->counts[i] = cnt;
             if (trace->errors) trace->errors[i] = err;
@@ -584,6 +650,11 @@ int orc_fit(int kind, const double *xyz, const double *normals, size_t n, double
         }
         count++;
     }
+    free(w_samples);
+    free(w_valid);
+    free(w_models);
+    free(w_errors);
+    free(w_counts);
 
     /* RefineModel, ransac.h:534-549 */
     size_t ni = 0;
@@ -742,10 +813,33 @@ void orc_set_omp_threads(int n) {
  * ascending inside a cluster (SelectByIndex keeps order).  The reference loops forever when a
  * round finds no inlier (:29,:35); the oracle stops there and reports it via return value 2.
  * Returns 0 ok, 1 = N<3 (reference: warning + empty result, :13-17), 2 = stalled. */
+static int segment_impl(const double *xyz, size_t n, double thr, int max_iteration,
+                        double min_ratio, uint64_t seed, size_t max_clusters, double *planes,
+                        size_t *cluster_offsets, size_t *cluster_indices, size_t *n_clusters,
+                        size_t lookahead);
+
 int orc_segment_plane_iterative(const double *xyz, size_t n, double thr, int max_iteration,
                                 double min_ratio, uint64_t seed, size_t max_clusters,
                                 double *planes, size_t *cluster_offsets, size_t *cluster_indices,
                                 size_t *n_clusters) {
+    return segment_impl(xyz, n, thr, max_iteration, min_ratio, seed, max_clusters, planes,
+                        cluster_offsets, cluster_indices, n_clusters, 1);
+}
+
+/* the same rounds with orc_fit_parallel's look-ahead inside every fit (10 M-point scenes) */
+int orc_segment_plane_iterative_parallel(const double *xyz, size_t n, double thr,
+                                         int max_iteration, double min_ratio, uint64_t seed,
+                                         size_t max_clusters, double *planes,
+                                         size_t *cluster_offsets, size_t *cluster_indices,
+                                         size_t *n_clusters, size_t lookahead) {
+    return segment_impl(xyz, n, thr, max_iteration, min_ratio, seed, max_clusters, planes,
+                        cluster_offsets, cluster_indices, n_clusters, lookahead < 1 ? 1 : lookahead);
+}
+
+static int segment_impl(const double *xyz, size_t n, double thr, int max_iteration,
+                        double min_ratio, uint64_t seed, size_t max_clusters, double *planes,
+                        size_t *cluster_offsets, size_t *cluster_indices, size_t *n_clusters,
+                        size_t lookahead) {
     *n_clusters = 0;
     cluster_offsets[0] = 0;
     if (n < 3) return 1;
@@ -762,8 +856,8 @@ int orc_segment_plane_iterative(const double *xyz, size_t n, double thr, int max
         size_t ni = 0;
         orc_stats st;
         /* probability stays at the RANSAC default 0.9999 (ransac.h:462) */
-        int r = orc_fit(ORC_PLANE, cur, NULL, cur_n, thr, (size_t)max_iteration, 0.9999,
-                        seed + k, plane, inl, &ni, &st, NULL);
+        int r = fit_impl(ORC_PLANE, cur, NULL, cur_n, thr, (size_t)max_iteration, 0.9999,
+                         seed + k, plane, inl, &ni, &st, NULL, lookahead);
         if (r < 0) { /* reference would throw (fewer than 3 points left) */
             rc = 2;
             break;

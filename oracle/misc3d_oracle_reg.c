@@ -40,6 +40,19 @@ uint32_t orc_uniform_int(orc_mt19937 *g, uint32_t range_incl);
 static inline double dot3(const double *a, const double *b) {
     return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
 }
+/* Eigen::Vector3d reductions of the Open3D checkers (`.norm()`): the association follows ORC_FP_ORDER like the fits'
+ * (misc3d_oracle.c "Eigen reduction orders"; product: m3d_fp.hpp sum3 through m3d_reg_fp.hpp reg_checkers).  K3x3 and
+ * the nearest-neighbour distances are this repository's own fully specified order on both sides and do not switch. */
+#ifndef ORC_FP_ORDER
+#define ORC_FP_ORDER 0
+#endif
+static inline double eig_dot3(const double *a, const double *b) {
+#if ORC_FP_ORDER == 1
+    return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]);
+#else
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------- */
 /* K3x3: rotation part of umeyama from a 3x3 covariance `sigma` (row-major).                    */
@@ -204,14 +217,14 @@ int orc_reg_checkers(const double *src, const double *dst, const int64_t *cs, co
                 es[k] = src[3 * cs[i] + k] - src[3 * cs[j] + k];
                 et[k] = dst[3 * cd[i] + k] - dst[3 * cd[j] + k];
             }
-            const double ds = sqrt(dot3(es, es)), dt = sqrt(dot3(et, et));
+            const double ds = sqrt(eig_dot3(es, es)), dt = sqrt(eig_dot3(et, et));
             if (ds < dt * edge_thr || dt < ds * edge_thr) return 0;
         }
     for (int i = 0; i < 3; ++i) {
         double pt[3], df[3];
         transform_point(T, src + 3 * cs[i], pt);
         for (int k = 0; k < 3; ++k) df[k] = dst[3 * cd[i] + k] - pt[k];
-        if (sqrt(dot3(df, df)) > dist_thr) return 0;
+        if (sqrt(eig_dot3(df, df)) > dist_thr) return 0;
     }
     return 1;
 }

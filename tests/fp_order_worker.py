@@ -47,4 +47,26 @@ for kind, m, fit in ((0, 3, oracle.plane_minimal_fit), (1, 4, oracle.sphere_mini
             h.update(a.tobytes())
     assert bad == 0, (kind, bad)
     digest[kind] = h.hexdigest()[:16]
-print("FP_ORDER_OK", order, digest[0], digest[1], digest[2])
+# the registration checkers (m3d_reg_fp.hpp reg_checkers <-> orc_reg_checkers): Eigen Vector3d norms behind an
+# edge-length ratio test.  Triples whose edge ratio sits ON the threshold (dt = ds / thr up to a few ulps), so that the
+# last bit of a norm decides: product == oracle under this association, and the decisions depend on the association
+import ctypes as C  # noqa: E402
+h = hashlib.sha256()
+bad = 0
+thr = 0.9
+for t in range(6000):
+    ps = rng.normal(size=(3, 3))
+    pd = ps.copy()
+    # stretch ONE edge of the target triangle so that |e_dst| * thr ~= |e_src| within an ulp or two
+    e = ps[1] - ps[0]
+    pd[1] = pd[0] + e / thr * (1.0 + rng.integers(-3, 4) * 2.0 ** -52)
+    T = np.eye(4)
+    g = capi.lib().m3d_bench_reg_checkers(ps.ctypes.data_as(C.c_void_p), pd.ctypes.data_as(C.c_void_p),
+                                          T.ctypes.data_as(C.c_void_p), thr, 1e9)
+    o = oracle.reg_checkers(ps, pd, T, thr, 1e9)
+    assert g in (0, 1)
+    bad += int(bool(g) != bool(o))
+    h.update(bytes([g]))
+assert bad == 0, ("reg_checkers", bad)
+digest[3] = h.hexdigest()[:16]
+print("FP_ORDER_OK", order, digest[0], digest[1], digest[2], digest[3])

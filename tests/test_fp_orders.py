@@ -21,7 +21,7 @@ def _run_worker(order):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("FP_ORDER_OK")][-1].split()
     assert int(line[1]) == order
-    return line[2:]      # digests of the plane / sphere / cylinder models
+    return line[2:]      # digests of the plane / sphere / cylinder models and of the registration checkers' verdicts
 
 
 def test_host_minimal_fit_matches_oracle_under_every_association():
@@ -30,6 +30,9 @@ def test_host_minimal_fit_matches_oracle_under_every_association():
     assert d1[0] != d0[0] and d1[1] != d0[1] and d1[2] != d0[2]
     # Eigen 3.4 differs from 3.3 in the 4x4 determinant only: sphere models move, plane and cylinder stay
     assert d2[0] == d0[0] and d2[2] == d0[2] and d2[1] != d0[1]
+    # the registration checkers' Vector3d norms follow the switch as well (every source that includes
+    # m3d_fp.hpp is rebuilt per association; the worker compares them with the oracle built the same way)
+    assert d1[3] != d0[3] and d2[3] == d0[3]
 
 
 def test_pin_reference_tool_selftest(tmp_path):

@@ -1,0 +1,135 @@
+"""BASELINE.json configurations C2, C3 and C5 compared with the ORACLE at their FULL sizes ("Next round" 1).
+
+The oracle's sequential driver with an OpenMP look-ahead (orc_fit_parallel: the records of the next hypotheses are
+computed ahead by a thread team and consumed in index order -- outputs identical to orc_fit bit for bit,
+tests/test_oracle_primitives.py::test_fit_lookahead_is_the_sequential_loop) does C2 in a few seconds and C3 in tens of
+seconds on the GPU box's host cores.  Compared per configuration:
+
+  * the fit: ret, best_index, number of valid hypotheses, iterations run, the FULL inlier index list (array_equal),
+    refined parameters within 1e-9 (the GeneralFit sums are order-free on the GPU);
+  * ALL per-hypothesis records of the dense path (m3d_cloud_score_range: no culling-based pruning): valid flags,
+    counts, minimal models bit for bit;
+  * the records of the production path (tile culling + bound-and-prune, m3d_cloud_score_shard): a record is either the
+    oracle's count, or it was pruned (reported as 0) -- and then the oracle's count does not exceed the best count of the
+    hypotheses before it, i.e. the pruned hypothesis could not have changed the replay.
+
+C5: the 10 M-point room through segment_plane_iterative -- the whole call with the reference's default
+max_iteration = 100, and the first rounds with BASELINE's 1000 per round -- cluster index lists bit-equal.
+"""
+import numpy as np
+import pytest
+
+from misc3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(np.nan_to_num(np.asarray(a, dtype=np.float64), nan=-7.0)).view(np.uint64)
+
+
+def _compare_fit_and_records(capi, orc, kind, pts, nrm, thr, H, seed, lookahead=512):
+    n = len(pts)
+    o = orc.fit(kind, pts, nrm, thr=thr, max_iter=H, prob=1.0, seed=seed, trace=True, lookahead=lookahead)
+    assert o.iterations == H                                    # probability 1: the loop runs to the end
+    with capi.Cloud(pts, nrm) as c:
+        g = c.fit(kind, thr, H, 1.0, seed=seed)
+        # --- the fit -------------------------------------------------------------------------------------------------
+        assert g.ret == o.ret
+        assert g.stats["best_index"] == o.best_index
+        assert g.stats["count"] == o.count and g.stats["iterations"] == o.iterations
+        assert g.stats["fitness"] == o.fitness
+        assert len(g.inliers) == len(o.inliers) == round(o.fitness * n)
+        assert np.array_equal(g.inliers, o.inliers)             # the full list, e.g. 502 332 indices on C2
+        assert np.allclose(g.params, o.params, rtol=0, atol=1e-9)
+        # --- every hypothesis' record, dense path ----------------------------------------------------------------------
+        samples = capi.draw_samples(n, kind, H, seed)
+        assert np.array_equal(samples.astype(np.uint64), o.trace["samples"][:, : samples.shape[1]])
+        val, mod, cnt = c.score_range(kind, thr, samples, 0, H)
+        assert np.array_equal(val.astype(np.int32), o.trace["valid"])
+        assert np.array_equal(cnt.astype(np.uint64), o.trace["counts"])
+        ok = o.trace["valid"].astype(bool)
+        assert np.array_equal(_bits(mod[ok]), _bits(o.trace["models"][ok]))
+        # --- the production path's records (culled, pruned) ------------------------------------------------------------
+        sm = c.make_sampler(kind, seed)
+        try:
+            v2, c2 = c.score_shard(sm, thr, 0, H, H, 1, 0)
+        finally:
+            sm.close()
+        assert len(c2) == H and np.array_equal(v2.astype(np.int32), o.trace["valid"])
+        oc = o.trace["counts"].astype(np.int64)
+        exact = c2.astype(np.int64) == oc
+        best_before = np.concatenate([[0], np.maximum.accumulate(oc)[:-1]])
+        pruned = ~exact
+        assert np.all(c2[pruned] == 0) and np.all(oc[pruned] <= best_before[pruned])
+        assert exact[o.best_index]
+        # the serial error sum of the winner (the tie rule's input, ransac.h:637) is the oracle's, bit for bit
+        _, err = c.exact_error(kind, thr, o.trace["models"][o.best_index])
+        assert np.float64(err).view(np.uint64) == np.float64(o.trace["errors"][o.best_index]).view(np.uint64)
+    return o, g, int(pruned.sum())
+
+
+def test_c2_full_size_vs_oracle(capi, orc):
+    """BASELINE configs[1]: fit_plane, 1 M points, 10 000 hypotheses, thr 0.01, probability 1, sampler seed 11."""
+    pts = synth.plane_cloud_c2(1_000_000, 2)
+    o, g, n_pruned = _compare_fit_and_records(capi, orc, 0, pts, None, 0.01, 10_000, 11)
+    assert len(o.inliers) > 490_000 and n_pruned > 1000          # the pruning really was exercised
+
+
+def test_c3_sphere_full_size_vs_oracle(capi, orc):
+    """BASELINE configs[2], sphere: 1 M points, 50 000 hypotheses."""
+    pts = synth.sphere_cloud_c3(1_000_000, 4)
+    o, g, n_pruned = _compare_fit_and_records(capi, orc, 1, pts, None, 0.01, 50_000, 13)
+    assert len(o.inliers) > 450_000 and n_pruned > 1000
+
+
+def test_c3_cylinder_full_size_vs_oracle(capi, orc):
+    """BASELINE configs[2], cylinder: 1 M points with normals, 50 000 hypotheses."""
+    pts, nrm = synth.cylinder_cloud_c3(1_000_000, 3)
+    o, g, n_pruned = _compare_fit_and_records(capi, orc, 2, pts, nrm, 0.01, 50_000, 13)
+    assert len(o.inliers) > 400_000 and n_pruned > 1000
+
+
+def test_c2_adaptive_stop_full_size_vs_oracle(capi, orc):
+    """The same cloud through the reference's own defaults (probability 0.9999: the adaptive bound ends the loop after a
+    few dozen hypotheses) -- the chunked pipeline's early stop against the sequential loop."""
+    pts = synth.plane_cloud_c2(1_000_000, 2)
+    with capi.Cloud(pts) as c:
+        for seed in (11, 12, 13):
+            o = orc.fit(0, pts, None, thr=0.01, max_iter=1000, prob=0.9999, seed=seed, lookahead=16)
+            g = c.fit(0, 0.01, 1000, 0.9999, seed=seed)
+            assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (
+                o.ret, o.best_index, o.count, o.iterations)
+            assert o.iterations < 1000
+            assert np.array_equal(g.inliers, o.inliers) and np.allclose(g.params, o.params, rtol=0, atol=1e-9)
+
+
+@pytest.fixture(scope="module")
+def room():
+    return synth.room_cloud_c5(10_000_000, 6)
+
+
+def test_c5_default_iterations_full_size_vs_oracle(capi, orc, room):
+    """BASELINE configs[4]'s 10 M-point scene through SegmentPlaneIterative with the reference's default
+    max_iteration = 100 (iterative_plane_segmentation.h:25-28): EVERY cluster's index list equals the oracle's."""
+    n = len(room)
+    ro, po, co = orc.segment_plane_iterative(room, 0.01, max_iteration=100, min_ratio=0.05, seed=19, lookahead=100)
+    rg, pg, cg = capi.segment_plane_iterative(room, 0.01, max_iteration=100, min_ratio=0.05, seed=19)
+    assert ro == 0 and rg == 1 and len(co) == len(cg) >= 6
+    for a, b in zip(co, cg):
+        assert np.array_equal(a, b)
+    assert np.allclose(po, pg, rtol=0, atol=1e-9)
+    assert sum(len(x) for x in cg) >= int(0.95 * n)
+
+
+def test_c5_first_rounds_full_size_vs_oracle(capi, orc, room):
+    """BASELINE's own setting, 1000 hypotheses per round: the oracle affords the first eight rounds of it (the six big planes and two picks out of the clutter; the planes
+    are 10^10 pair evaluations each); the GPU is stopped at the same number of clusters."""
+    rounds = 8
+    ro, po, co = orc.segment_plane_iterative(room, 0.01, max_iteration=1000, min_ratio=0.05, seed=19, max_clusters=rounds,
+                                             lookahead=250)
+    rg, pg, cg = capi.segment_plane_iterative(room, 0.01, max_iteration=1000, min_ratio=0.05, seed=19, max_clusters=rounds)
+    assert len(co) == len(cg) == rounds
+    for a, b in zip(co, cg):
+        assert np.array_equal(a, b)
+    assert np.allclose(po, pg, rtol=0, atol=1e-9)

@@ -315,3 +315,46 @@ def test_oracle_boundary_detection_properties(orc):
     assert len(set(b.tolist()) ^ set(b2.tolist())) <= 2
     assert len(orc.detect_boundary_points(pts, nrm, 2, 0.06, 30, 150.0)) < len(b)
     assert np.array_equal(b, np.sort(b))
+
+
+# ------------------------------------------------------------------------------------------------
+# the look-ahead (OpenMP) form of the sequential driver the full-size GPU tests use
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("prob,lookahead", [(0.9999, 7), (0.9999, 64), (1.0, 33), (0.5, 16)])
+def test_fit_lookahead_is_the_sequential_loop(orc, kind, prob, lookahead):
+    """orc_fit_parallel computes records ahead with an OpenMP team and consumes them in index order: every output of
+    orc_fit -- best index, valid-hypothesis count, iterations run (early stop), rmse from the SERIAL error sum, inlier
+    list, refined parameters and the per-hypothesis trace -- must come out bit for bit."""
+    from misc3d_amd import synth
+    if kind == 0:
+        pts, nrm = synth.plane_cloud_c1(6000, 1), None
+    elif kind == 1:
+        pts, nrm = synth.sphere_cloud_c3(6000, 4), None
+    else:
+        pts, nrm = synth.cylinder_cloud_c3(6000, 3)
+    a = orc.fit(kind, pts, nrm, thr=0.01, max_iter=300, prob=prob, seed=5, trace=True)
+    b = orc.fit(kind, pts, nrm, thr=0.01, max_iter=300, prob=prob, seed=5, trace=True, lookahead=lookahead)
+    assert (a.ret, a.best_index, a.count, a.iterations) == (b.ret, b.best_index, b.count, b.iterations)
+    assert a.fitness == b.fitness and a.inlier_rmse == b.inlier_rmse
+    assert np.array_equal(a.inliers, b.inliers)
+    assert np.array_equal(a.params.view(np.uint64), b.params.view(np.uint64))
+    k = a.iterations
+    for key in ("samples", "valid", "counts"):
+        assert np.array_equal(a.trace[key][:k], b.trace[key][:k]), key
+    assert np.array_equal(a.trace["errors"][:k].view(np.uint64), b.trace["errors"][:k].view(np.uint64))
+    assert np.array_equal(np.nan_to_num(a.trace["models"][:k], nan=-7.0).view(np.uint64),
+                          np.nan_to_num(b.trace["models"][:k], nan=-7.0).view(np.uint64))
+
+
+def test_segmentation_lookahead_is_the_sequential_loop(orc):
+    from misc3d_amd import synth
+    pts = synth.room_cloud_c5(30000, 6)
+    ra, pa, ca = orc.segment_plane_iterative(pts, 0.01, max_iteration=60, min_ratio=0.05, seed=3)
+    rb, pb, cb = orc.segment_plane_iterative(pts, 0.01, max_iteration=60, min_ratio=0.05, seed=3, lookahead=24)
+    assert ra == rb and len(ca) == len(cb) >= 6
+    assert np.array_equal(pa.view(np.uint64), pb.view(np.uint64))
+    assert all(np.array_equal(x, y) for x, y in zip(ca, cb))
+    # max_clusters cuts the same run short
+    rc, pc, cc = orc.segment_plane_iterative(pts, 0.01, max_iteration=60, min_ratio=0.05, seed=3, max_clusters=3, lookahead=24)
+    assert len(cc) == 3 and all(np.array_equal(x, y) for x, y in zip(ca[:3], cc))
