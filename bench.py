@@ -35,8 +35,18 @@ N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run, 
 launcher (WORLD_SIZE set) it is one of the ranks.  Control plane (rendezvous, barrier, max over ranks): torch.distributed
 "gloo".  Data path: the C++ driver m3d_cloud_fit_sharded with a library-owned RCCL communicator (ncclAllGather of the
 4-byte records on the library's stream over xGMI), ncclUniqueId handed out through the process group.
---scaling weak (default): --hyp hypotheses PER GPU of one N x hyp stream, value = N x hyp / t;
---scaling strong: --hyp hypotheses in total.
+--scaling strong (default at N > 1, the north_star's question): --hyp hypotheses in total, value = hyp / t; a
+`weak_scaling` block (N x hyp hypotheses of one stream) and the `strong_scaling` block of C2 / C3 ride along.
+--scaling weak (default at N = 1, where the two coincide): --hyp hypotheses PER GPU, value = N x hyp / t.
+
+More objects of the N = 1 line:
+  fp64_only    the same K steps with m3d_config.score_fp32_screen = 0, cull_fp32 = 0 (the reference's arithmetic only) and
+               the VALU-issue fraction of score_mask_k on them: `value` read on the reference's own arithmetic.
+  setup_ms     m3d_cloud_create (SetPointCloud's copy: upload, transpose, Hilbert sort, tile boxes), which the timed steps
+               do NOT contain (cloud resident), with its phases.
+  oneshot_ms   m3d_fit_plane from host arrays: create + fit + destroy per call, the reference's FitPlane shape.
+  cpu_baseline.parity   the CPU port run on the GPU's own job (same cloud, same 10 000 hypotheses): best_index, count,
+               the full inlier list and the refined parameters compared.
 """
 import argparse
 import json
@@ -74,7 +84,8 @@ def parse():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--hyp", type=int, default=0, help="hypotheses per step: per GPU (weak) or in total (strong); 0 = the workload's")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: strong at N > 1 (the north_star's question; a weak block rides along), weak at N = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-strong-extra", action="store_true", help="N > 1: skip the strong-scaling block")
@@ -119,27 +130,37 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(pts, thr, seed, budget_s):
+def cpu_baseline(pts, thr, seed, budget_s, H_gpu):
     """Reference-shaped OpenMP port (oracle/misc3d_oracle.c orc_fit_omp_baseline: omp parallel for over hypotheses,
     per-point virtual-dispatch-like distance with sqrt and divide, -O3 no -march like CMakeLists.txt:7,15-16) and the
-    same source built -O3 -march=native, each on a bounded sample at the thread count that does best here."""
+    same source built -O3 -march=native.  The port's timed sample is the GPU's OWN workload -- the same cloud, exactly
+    H_gpu hypotheses of the same sampler stream -- whenever that fits the budget (C2: ~2.5 s on 16 cores), so its result
+    is directly comparable with the GPU's (`parity`); otherwise, and for the native build, a bounded prefix of it."""
     import oracle
     hw = usable_cpus()
 
-    def time_lib(fit_fn, set_threads, threads, seconds):
+    def run(fit_fn, set_threads, threads, H):
         set_threads(threads)
-        fit_fn(0, pts, None, thr, max(threads, 4), seed)                      # thread pool / page warm-up
-        t0 = time.perf_counter()
-        fit_fn(0, pts, None, thr, 2 * max(threads, 4), seed)                  # calibration: two rounds per thread
-        per_h = (time.perf_counter() - t0) / (2 * max(threads, 4))
-        H = int(max(threads * 2, min(200000, seconds / max(per_h, 1e-9))))
-        H = (H // threads) * threads or threads
         t0 = time.perf_counter()
         model, cnt, bi = fit_fn(0, pts, None, thr, H, seed)
         dt = time.perf_counter() - t0
         return H / dt, H, dt, (model, cnt, bi)
 
-    out, extra = None, None
+    def calibrate(fit_fn, set_threads, threads):
+        """seconds per hypothesis at this thread count: a short run to size a ~1 s one (a 30 ms probe picked the wrong
+        count on a busy box)"""
+        set_threads(threads)
+        fit_fn(0, pts, None, thr, max(threads, 4), seed)                      # thread pool / page warm-up
+        t0 = time.perf_counter()
+        fit_fn(0, pts, None, thr, 2 * max(threads, 4), seed)
+        per_h = (time.perf_counter() - t0) / (2 * max(threads, 4))
+        H1 = int(max(2 * threads, min(4000, (budget_s / 12.0) / max(per_h, 1e-9))))
+        H1 = (H1 // threads) * threads or threads
+        t0 = time.perf_counter()
+        fit_fn(0, pts, None, thr, H1, seed)
+        return (time.perf_counter() - t0) / H1
+
+    out, extra, out_res = None, None, None
     for kind_name, getter in (("port", lambda: (oracle.fit_omp_baseline, oracle.set_omp_threads)),
                               ("native", oracle.native_baseline)):
         try:
@@ -149,15 +170,19 @@ def cpu_baseline(pts, thr, seed, budget_s):
                 extra = {"error": f"{type(e).__name__}: {e}"}
                 continue
             raise
-        # thread-count probe (short), then the bounded sample at the best count
         cands = sorted({hw, max(1, hw // 2)})
-        probe = {t: time_lib(fit_fn, set_threads, t, budget_s / 12.0)[0] for t in cands}
-        best_t = max(probe, key=probe.get)
-        rate, H, dt, res = time_lib(fit_fn, set_threads, best_t, budget_s / 2.0 if kind_name == "port" else budget_s / 4.0)
+        per_h = {t: calibrate(fit_fn, set_threads, t) for t in cands}
+        best_t = min(per_h, key=per_h.get)
+        share = budget_s * (0.6 if kind_name == "port" else 0.25)
+        H = H_gpu if (kind_name == "port" and per_h[best_t] * H_gpu <= 1.5 * share) else int(
+            max(best_t * 2, min(H_gpu, share / max(per_h[best_t], 1e-9))))
+        if H != H_gpu:
+            H = (H // best_t) * best_t or best_t
+        rate, H, dt, res = run(fit_fn, set_threads, best_t, H)
         rec = {"value": rate, "unit": "hypotheses/s", "cores": best_t,
-               "sample": f"fit_plane {len(pts)} pts x {H} hypotheses (thr {thr}, seed {seed}), {dt:.1f} s, OpenMP static "
-                         f"schedule over hypotheses; thread probe {{threads: hyp/s}} = "
-                         + json.dumps({str(k): round(v, 1) for k, v in probe.items()}),
+               "sample": f"fit_plane {len(pts)} pts x {H} hypotheses (thr {thr}, seed {seed}; the GPU's step has {H_gpu}), "
+                         f"{dt:.1f} s, OpenMP static schedule over hypotheses; thread probe {{threads: hyp/s}} = "
+                         + json.dumps({str(k): round(1.0 / v, 1) for k, v in per_h.items()}),
                "inlier_score_GBps": rate * len(pts) * ALG_BYTES_PER_PAIR / 1e9, "usable_cpus": hw}
         if kind_name == "port":
             rec["kind"] = "port"
@@ -183,6 +208,8 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_ranks(a.gpus))
+    if a.scaling is None:
+        a.scaling = "strong" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "weak"
     import torch
     import torch.distributed as dist
     from misc3d_amd import capi, synth
@@ -315,6 +342,79 @@ def main():
         dt_plain = float(t.item())
     capi.set_config(kernel_timing=1)
 
+    # ---- N = 1: the same steps on the reference's own arithmetic, the set-up the timed steps do not contain, and the
+    # reference-shaped call (host arrays in, results out: py_common.cpp:11-27 has no resident handle) ----------------
+    fp64_only, setup, oneshot = None, None, None
+    if world == 1 and comm is None:
+        old_cfg = capi.set_config(score_fp32_screen=0, cull_fp32=0)
+        try:
+            for _ in range(5):
+                step()
+            barrier()
+            f_ms, f_launch, f_pairs = 0.0, 0, 0
+            gc.disable()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                r64 = step()
+                f_ms += r64.stats["ms_score_kernel"]
+                f_launch += r64.stats["score_launches"]
+                f_pairs += r64.stats["pairs_timed"]
+            barrier()
+            dt64 = time.perf_counter() - t0
+            gc.enable()
+            same64 = (r64.stats["best_index"] == res.stats["best_index"] and np.array_equal(r64.inliers, res.inliers)
+                      and np.array_equal(r64.params, res.params))
+            v64 = f_pairs * 512.0 * VALU_OPS_FP64[kind] / (f_ms * 1e-3) / 1e12
+            fp64_only = {"ms_per_step": dt64 / a.steps * 1e3, "value": H_total * a.steps / dt64,
+                         "config": "m3d_config.score_fp32_screen = 0, cull_fp32 = 0: box tests and point tests in fp64 only, the "
+                                   "reference's arithmetic instruction for instruction (score_mask_k, cull_tiles_k)",
+                         "identical_result": bool(same64),
+                         "roofline": {"bound": "valu-issue", "kernel": KERNEL_FP64[kind], "achieved": v64,
+                                      "peak": FP64_VALU_PEAK_TOPS, "frac": v64 / FP64_VALU_PEAK_TOPS,
+                                      "ops_per_pair": VALU_OPS_FP64[kind], "launch_ms": f_ms / max(f_launch, 1),
+                                      "launches_per_step": f_launch / float(a.steps),
+                                      "tile_hypothesis_pairs_per_step": f_pairs / float(a.steps)}}
+        finally:
+            capi.restore_config(old_cfg)
+        # set-up: m3d_cloud_create = SetPointCloud's copy (ransac.h:469-475) -- upload, transpose, Hilbert sort, tile boxes
+        capi.set_config(kernel_timing=0)
+        tot = []
+        for i in range(6):
+            c_tmp = capi.Cloud(pts, nrm, device=local)
+            if i:
+                tot.append(c_tmp.setup_ms()["total"])
+            c_tmp.close()
+        capi.set_config(kernel_timing=1)
+        ph = []
+        for i in range(4):
+            c_tmp = capi.Cloud(pts, nrm, device=local)
+            if i:
+                ph.append(c_tmp.setup_ms())
+            c_tmp.close()
+        setup = {"ms": float(np.mean(tot)), "ms_min": float(np.min(tot)),
+                 "phases_ms": {k: float(np.mean([q[k] for q in ph])) for k in ph[0] if k != "total"},
+                 "bytes_uploaded": int(pts.nbytes + (nrm.nbytes if nrm is not None else 0)),
+                 "note": "m3d_cloud_create from the caller's pageable numpy array, not inside `value` (SURVEY.md 8(d): cloud "
+                         "resident, upload reported separately); phases measured in separate creations with a stream "
+                         "synchronisation after each phase"}
+        # one-shot: m3d_fit_plane(xyz, n, ...) -- create + fit + destroy per call, what a drop-in FitPlane caller pays
+        capi.set_config(kernel_timing=0)
+        for _ in range(3):
+            capi.fit(kind, pts, nrm, thr, H_total, prob, seed=seed, copy=False)
+        barrier()
+        one = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            r1 = capi.fit(kind, pts, nrm, thr, H_total, prob, seed=seed, copy=False)
+            one.append((time.perf_counter() - t0) * 1e3)
+        same1 = (r1.stats["best_index"] == res.stats["best_index"] and np.array_equal(r1.inliers, res.inliers)
+                 and np.array_equal(r1.params, res.params))
+        oneshot = {"ms": float(np.mean(one)), "ms_min": float(np.min(one)), "value": H_total / (float(np.mean(one)) * 1e-3),
+                   "identical_result": bool(same1),
+                   "call": "m3d_fit_plane / _sphere / _cylinder from host arrays (pageable numpy in, parameters + index list "
+                           "out), the shape of the reference's FitPlane (python/py_common.cpp:11-27)"}
+        capi.set_config(kernel_timing=1)
+
     # ---- N > 1: strong scaling at fixed total work, one-GPU time measured in the same job (rank 0 alone) ----------
     strong = None
     if world > 1 and not a.no_strong_extra:
@@ -353,6 +453,22 @@ def main():
             barrier()
             if c2 is not cloud:
                 c2.close()
+
+    # ---- N > 1 with the strong headline: the weak-scaling number rides along (N x hyp hypotheses of one stream) ---------
+    weak = None
+    if world > 1 and a.scaling == "strong" and not a.no_strong_extra:
+        Hw = H * world
+        for _ in range(3):
+            cloud.fit_sharded(comm, kind, thr, Hw, prob, seed=seed, copy=False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            cloud.fit_sharded(comm, kind, thr, Hw, prob, seed=seed, copy=False)
+        barrier()
+        tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak = {"workload": f"{label}, {N} pts, {H} hypotheses per GPU ({Hw} in total)", "ms_per_step": float(tw.item()) / 20 * 1e3,
+                "value": Hw * 20 / float(tw.item()), "unit": "hypotheses/s"}
 
     if rank == 0:
         n_in = len(res.inliers)
@@ -415,7 +531,8 @@ def main():
         out = {"metric": "RANSAC hypotheses/sec disposed of (scored or exactly pruned; fit on a 1M-pt cloud)",
                "value": value, "unit": "hypotheses/s",
                "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
+               "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+               "dtype": ("f64 decisions (fp32 screen + fp64 recount)" if screened else "f64"),
                "data": "synthetic",
                "config": {"workload": label, "points": N, "hypotheses_per_gpu": H_total / world,
                           "hypotheses_total": H_total, "threshold": thr, "probability": prob, "sampler_seed": seed,
@@ -433,18 +550,40 @@ def main():
                                                 "note": "the same K steps again with m3d_config.kernel_timing = 0, the library's "
                                                         "default: `value` above carries the four HIP-event commands per chunk "
                                                         "that `roofline.launch_ms` is measured with"}}
+        if fp64_only:
+            out["fp64_only"] = fp64_only
+        if setup:
+            out["setup_ms"] = setup
+        if oneshot:
+            out["oneshot_ms"] = oneshot
         if comm is not None:
             out["collectives_per_step"] = coll_per_step
         if strong:
             out["strong_scaling"] = strong
+        if weak:
+            out["weak_scaling"] = weak
         if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
-            cb, (cmodel, ccnt, cbi, ch) = cpu_baseline(pts, thr, seed, a.cpu_seconds)
+            import oracle
+            cb, (cmodel, ccnt, cbi, ch) = cpu_baseline(pts, thr, seed, a.cpu_seconds, H_total)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = value / cb["value"]
-            # cross-check: the GPU's count for the CPU's best hypothesis
-            s2 = capi.draw_samples(N, kind, ch, seed)
-            _, _, c2 = cloud.score_range(kind, thr, s2, cbi, cbi + 1)
-            out["cpu_baseline"]["parity"] = bool(int(c2[0]) == int(ccnt))
+            # parity of the step just timed with the CPU run of the SAME job (same cloud, same H hypotheses of the same
+            # stream): best hypothesis, its inlier count, and -- RefineModel of the CPU's best model, oracle.refine --
+            # the full inlier index list and the refined parameters
+            if ch == H_total:
+                _ok, cpar, cinl = oracle.refine(kind, pts, thr, cmodel)
+                out["cpu_baseline"]["parity"] = {
+                    "best_index": bool(cbi == int(res.stats["best_index"])),
+                    "count": bool(int(ccnt) == int(n_in)),
+                    "inliers_equal": bool(np.array_equal(cinl, np.asarray(res.inliers))),
+                    "params_max_abs_diff": float(np.max(np.abs(cpar - res.params))),
+                    "cpu": {"best_index": int(cbi), "count": int(ccnt)},
+                    "gpu": {"best_index": int(res.stats["best_index"]), "count": int(n_in)}}
+            else:   # the CPU could not afford the whole job inside the budget: one record of its prefix instead
+                s2 = capi.draw_samples(N, kind, ch, seed)
+                _, _, c2 = cloud.score_range(kind, thr, s2, cbi, cbi + 1)
+                out["cpu_baseline"]["parity"] = {"prefix_only": True, "hypotheses": int(ch),
+                                                 "count_of_cpu_best": bool(int(c2[0]) == int(ccnt))}
         print(json.dumps(out), flush=True)
     barrier()
     cloud.close()

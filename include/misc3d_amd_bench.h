@@ -28,6 +28,12 @@ int m3d_bench_time_score(m3d_cloud *cloud, int kind, double threshold, const uin
  * nominal 39.3 (256 CU x 4 SIMD x 16 lanes x 2.4 GHz) -- the chip clocks below 2.4 GHz under sustained fp64 load. */
 int m3d_bench_fp64_issue_rate(int device, double ms_target, double *tera_lane_ops_per_s, double *ms_measured);
 
+/* m3d_cloud_create's own wall clock in ms: out[0] = the whole call (always); with m3d_config.kernel_timing set when the
+ * cloud was created also the phases, each closed by a stream synchronisation: out[1] = host-to-device copies of the
+ * caller's arrays + AoS -> SoA transposes, out[2] = bounding box of the device copy incl. its round trip, out[3] =
+ * Hilbert counting sort, out[4] = tile boxes + the tiles' fp32 offsets ("report upload separately"). */
+int m3d_bench_cloud_setup_ms(const m3d_cloud *cloud, double out[5]);
+
 /* TEST hook (tests/fp_order_worker.py): the EdgeLength + Distance checkers of the registration path evaluated on the
  * HOST by the very code the kernels compile (m3d_reg_fp.hpp reg_checkers): ps / pd = the 3 sampled source / target
  * points (3 x 3 doubles each), T = 4 x 4 row-major.  Returns 1 = pass, 0 = rejected.  Lets a box without a GPU check

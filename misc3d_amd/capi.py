@@ -188,6 +188,7 @@ def lib():
                                                       C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                       C.c_void_p]
         L.m3d_bench_fp64_issue_rate.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.m3d_bench_cloud_setup_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.m3d_bench_reg_checkers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
         L.m3d_get_config.restype = None
         L.m3d_get_config.argtypes = [C.c_void_p]
@@ -508,6 +509,13 @@ class Cloud:
         if not self._h:
             raise M3DError(ERR_DEVICE, last_error())
 
+    def setup_ms(self):
+        """m3d_bench_cloud_setup_ms -> dict(total, upload_transpose, bbox, sort, tile_boxes) in ms (the phases are filled
+        when m3d_config.kernel_timing was set at creation)."""
+        out = np.zeros(5)
+        _check(lib().m3d_bench_cloud_setup_ms(self._h, _p(out)))
+        return dict(zip(("total", "upload_transpose", "bbox", "sort", "tile_boxes"), (float(v) for v in out)))
+
     def _out_buf(self):
         """Per-cloud index-list buffer (n_created uint64), page-locked through m3d_host_alloc when possible: the
         library then copies the inlier list while the GeneralFit sums run (include/misc3d_amd.h).  The block is
@@ -655,8 +663,9 @@ def draw_samples(n_points, kind, n_hyp, seed):
 
 
 def fit(kind, xyz, normals=None, threshold=0.01, max_iteration=1000, probability=0.9999, seed=None,
-        device=0) -> Fit:
-    """One-shot m3d_fit_plane / m3d_fit_sphere / m3d_fit_cylinder."""
+        device=0, copy=True) -> Fit:
+    """One-shot m3d_fit_plane / m3d_fit_sphere / m3d_fit_cylinder.  copy=False: the inlier list is a view of the
+    thread's page-locked scratch (overwritten by the next call)."""
     xyz = _f64(xyz).reshape(-1, 3)
     n = len(xyz)
     params = np.zeros(NUM_PARAMS[kind])
@@ -680,7 +689,7 @@ def fit(kind, xyz, normals=None, threshold=0.01, max_iteration=1000, probability
     _check(rc)
     d = st.asdict()
     d["n_inliers"] = int(ni.value)
-    return Fit(rc, params, inl[: ni.value].copy(), d)
+    return Fit(rc, params, inl[: ni.value].copy() if copy else inl[: ni.value], d)
 
 
 _seg_tls = threading.local()

@@ -1636,6 +1636,16 @@ m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_
     }
     m3d_cloud* c = new m3d_cloud();
     c->ctx = ctx;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_last = t_begin;
+    const bool phase_timing = config().kernel_timing != 0;
+    auto mark = [&](int slot) {   // (phase clocks drain the stream: only on request)
+        if (!phase_timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto t = std::chrono::steady_clock::now();
+        c->setup_ms[slot] += std::chrono::duration<double, std::milli>(t - t_last).count();
+        t_last = t;
+    };
     c->n = (uint32_t)n;
     c->n_pad = std::max<uint32_t>(round_up((uint32_t)n, kScoreTile), kScoreTile);
     c->has_normals = normals != nullptr;
@@ -1659,6 +1669,7 @@ m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_
             launch_aos_to_soa(stage.as<double>(), c->nx.as<double>(), c->ny.as<double>(),
                               c->nz.as<double>(), c->n, c->n_pad, ctx->stream);
     }
+    mark(1);
     // Hilbert-sorted copy + tile boxes for the culled scoring path.  The bounding box of the finite points comes
     // from the device copy (a host pass over the caller's 10 M-point array took 9 ms, as long as the rest of
     // the upload and sort together)
@@ -1699,6 +1710,7 @@ m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_
                 }
             }
         }
+        mark(2);
         const uint32_t cap = std::max<uint32_t>(round_up((uint32_t)n, kTilePoints), kTilePoints);
         c->n_tiles = with_sorted_copy ? cap / kTilePoints : 0;
         c->n_sorted = n_finite;
@@ -1737,9 +1749,12 @@ m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_
                                   t_sums.as<uint32_t>(), t_total.as<uint32_t>(), c->sx.as<double>(),
                                   c->sy.as<double>(), c->sz.as<double>(), ctx->stream);
         }
+        mark(3);
         if (ok && with_sorted_copy) launch_tile_boxes(c->sorted(), c->boxes.as<double>(), ctx->stream);
     }
     ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    mark(4);
+    c->setup_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (!ok) {
         if (g_last_error.empty()) set_error("cloud upload failed");
         release_buffers(c);
@@ -2145,6 +2160,12 @@ int m3d_bench_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ms_avg = (double)ms / reps;
+    return M3D_OK;
+}
+
+int m3d_bench_cloud_setup_ms(const m3d_cloud* c, double out[5]) {
+    if (!c || !out) return fail(M3D_ERR_INVALID_ARG, "null argument");
+    for (int k = 0; k < 5; ++k) out[k] = c->setup_ms[k];
     return M3D_OK;
 }
 

@@ -122,6 +122,9 @@ struct m3d_cloud {
     double radius = __builtin_inf();    // largest |coordinate - origin| (inf: unknown -> fp64 box tests)
     double bb[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the points with three finite coordinates as created (lo, hi)
     bool bb_known = false;              // ... valid (there is such a point)
+    // m3d_cloud_create's own clock (m3d_bench_cloud_setup_ms): total, and with m3d_config.kernel_timing the phases --
+    // host-to-device copies + transposes, bounding box (incl. its round trip), Hilbert sort, tile boxes
+    double setup_ms[5] = {0, 0, 0, 0, 0};
     // In-place shrinking (m3d_cloud_remove_inliers = SelectByIndex(inliers, invert), the tail of a
     // SegmentPlaneIterative round).  x/y/z above always hold the cloud AS CREATED (n0 points): index lists
     // and GeneralFit gathers refer to it through `orig`.  Once shrunk, n / n_pad / n_sorted / n_tiles and

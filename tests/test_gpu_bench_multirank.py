@@ -22,7 +22,9 @@ def test_bench_starts_its_own_ranks_and_prints_one_json_line():
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["hypotheses_total"] == 20000
+    # N > 1: the headline is STRONG scaling (10 000 hypotheses in total), the weak number rides along
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["hypotheses_total"] == 10000
+    assert d["weak_scaling"]["value"] > 0 and "20000 in total" in d["weak_scaling"]["workload"]
     assert "rehearsal" in d["config"]["parallelism"] and d["collectives_per_step"] >= 1
     assert d["value"] > 0 and 0 < d["roofline"]["frac"] <= 1
     st = d["strong_scaling"]
