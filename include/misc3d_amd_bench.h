@@ -34,6 +34,12 @@ int m3d_bench_fp64_issue_rate(int device, double ms_target, double *tera_lane_op
  * Hilbert counting sort, out[4] = tile boxes + the tiles' fp32 offsets ("report upload separately"). */
 int m3d_bench_cloud_setup_ms(const m3d_cloud *cloud, double out[5]);
 
+/* Wall clock of the calling thread's LAST m3d_segment_plane_iterative* call in ms: out[0] the whole call, out[1]
+ * m3d_cloud_create (upload, sort, tile boxes), out[2] the round loop, out[3] the final copy of the index lists out of
+ * the page-locked staging array (0 when the caller's array is page-locked), out[4] of the round loop: the rounds on more
+ * than an eighth of the cloud, out[5] = their number + 1e-4 x all rounds. */
+int m3d_bench_last_segment_ms(double out[6]);
+
 /* TEST hook (tests/fp_order_worker.py): the EdgeLength + Distance checkers of the registration path evaluated on the
  * HOST by the very code the kernels compile (m3d_reg_fp.hpp reg_checkers): ps / pd = the 3 sampled source / target
  * points (3 x 3 doubles each), T = 4 x 4 row-major.  Returns 1 = pass, 0 = rejected.  Lets a box without a GPU check

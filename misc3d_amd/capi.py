@@ -189,6 +189,7 @@ def lib():
                                                       C.c_void_p]
         L.m3d_bench_fp64_issue_rate.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.m3d_bench_cloud_setup_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.m3d_bench_last_segment_ms.argtypes = [C.c_void_p]
         L.m3d_bench_reg_checkers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
         L.m3d_get_config.restype = None
         L.m3d_get_config.argtypes = [C.c_void_p]
@@ -734,6 +735,14 @@ def segment_plane_iterative(xyz, threshold, max_iteration=100, min_ratio=0.05, s
     k = k.value
     return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() if copy else idx[int(offs[i]): int(offs[i + 1])]
                                    for i in range(k)]
+
+
+def last_segment_ms():
+    """m3d_bench_last_segment_ms -> dict of the calling thread's last segmentation call (ms)"""
+    out = np.zeros(6)
+    _check(lib().m3d_bench_last_segment_ms(_p(out)))
+    return {"total": out[0], "cloud_create": out[1], "rounds": out[2], "final_copy": out[3], "big_rounds": out[4],
+            "n_big_rounds": int(out[5]), "n_rounds": int(round((out[5] - int(out[5])) * 1e4))}
 
 
 def segment_plane_iterative_sharded(xyz, comm, threshold, max_iteration=100, min_ratio=0.05, seed=None, device=0,

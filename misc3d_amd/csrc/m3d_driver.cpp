@@ -2163,6 +2163,14 @@ int m3d_bench_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     return M3D_OK;
 }
 
+// m3d_bench_last_segment_ms: where the calling thread's last segmentation call spent its wall clock
+static thread_local double g_seg_ms[6] = {0, 0, 0, 0, 0, 0};
+int m3d_bench_last_segment_ms(double out[6]) {
+    if (!out) return fail(M3D_ERR_INVALID_ARG, "null argument");
+    for (int k = 0; k < 6; ++k) out[k] = g_seg_ms[k];
+    return M3D_OK;
+}
+
 int m3d_bench_cloud_setup_ms(const m3d_cloud* c, double out[5]) {
     if (!c || !out) return fail(M3D_ERR_INVALID_ARG, "null argument");
     for (int k = 0; k < 5; ++k) out[k] = c->setup_ms[k];
@@ -2271,10 +2279,15 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         set_error("Point cloud size has less than 3.");
         return M3D_FALSE;
     }
+    const double t_call = now_ms();
     m3d_cloud* c0 = m3d_cloud_create(xyz, nullptr, n, device);
     if (!c0) return M3D_ERR_DEVICE;
     DeviceCtx* ctx = c0->ctx;
     int rc = M3D_OK;
+    const double t_created = now_ms();
+    double t_rounds = t_created, t_copied = t_created;
+    size_t rounds_done = 0, big_rounds = 0;
+    double t_big = 0;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         uint64_t seed0 = 0;
@@ -2307,6 +2320,8 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             double plane[4] = {0, 0, 0, 0};
             size_t ni = 0;
             const size_t off = cluster_offsets[k];
+            const double t_round0 = now_ms();
+            const bool big_round = c0->n > (uint32_t)(n / 8);
             // The removal of the round's inliers (:33) is queued behind RefineModel's kernels, before RefineModel
             // waits for them: the pre-refinement model is already on the device and the inlier count is known
             // from the scoring pass, so the round costs one host wait less.  Not on the last round.
@@ -2340,6 +2355,11 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             cluster_offsets[k + 1] = off + ni;
             count += ni;
             k++;
+            rounds_done++;
+            if (big_round) {
+                big_rounds++;
+                t_big += now_ms() - t_round0;
+            }
             if (count >= target || k >= max_clusters) break;
             // pcd_copy = pcd_copy->SelectByIndex(inliers, true), :33 -- inliers of the PRE-refinement model,
             // still on the device (ctx->last_best_dev)
@@ -2361,9 +2381,17 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         *n_clusters = k;
         (void)hipStreamSynchronize(ctx->stream);
         if (rc == M3D_OK) rc = cloud_remove_check_pending(c0);
+        t_rounds = now_ms();
         if (idx_out != cluster_indices && k) std::memcpy(cluster_indices, idx_out, sizeof(size_t) * cluster_offsets[k]);
+        t_copied = now_ms();
     }
     m3d_cloud_destroy(c0);
+    g_seg_ms[0] = now_ms() - t_call;
+    g_seg_ms[1] = t_created - t_call;
+    g_seg_ms[2] = t_rounds - t_created;
+    g_seg_ms[3] = t_copied - t_rounds;
+    g_seg_ms[4] = t_big;
+    g_seg_ms[5] = (double)big_rounds + 1e-4 * (double)rounds_done;
     if (rc == 2) return 2;
     return rc == M3D_OK ? M3D_OK : rc;
 }
