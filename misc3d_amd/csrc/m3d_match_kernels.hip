@@ -15,6 +15,9 @@
 //                      (adversarial data), is redone exactly by a whole wave.
 #include "m3d_reg_kernels.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "m3d_fp.hpp"
 #include "m3d_match_scan.hpp"
 
@@ -328,7 +331,24 @@ uint32_t mfma_tiles(uint32_t n) { return (n + 31u) / 32u; }
 // tiles padded so that a wave's two query tiles always exist
 uint32_t mfma_query_tiles(uint32_t n) { return ((n + 511u) / 512u) * 16u; }
 
-void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s) { max_f32_k<<<1, 256, 0, s>>>(v, n, out); }
+// many workgroups, one atomicMax on the bit pattern per workgroup (the values are >= 0: their order is the integers';
+// a NaN is skipped, as fmaxf does).  The one-workgroup kernel took 113 us for 200 000 values.
+__global__ void max_f32_wide_k(const float* __restrict__ v, uint32_t n, uint32_t* __restrict__ out_bits) {
+    __shared__ float sm[256];
+    float m = 0.0f;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) m = fmaxf(m, v[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(fmaxf(sm[0], 0.0f)));
+}
+void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s) {
+    (void)hipMemsetAsync(out, 0, sizeof(float), s);
+    if (n) max_f32_wide_k<<<std::min<uint32_t>((n + 255) / 256, 256), 256, 0, s>>>(v, n, reinterpret_cast<uint32_t*>(out));
+}
 void launch_max_abs(const double* f, size_t count, double* partial /* 256 */, hipStream_t s) {
     max_abs_k<<<256, 256, 0, s>>>(f, count, partial);
 }
@@ -339,26 +359,148 @@ void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale
                                                            reinterpret_cast<_Float16*>(out), norm2);
 }
 
-// Same workspace as launch_nn_screened33 with 2 * splits slices.  qB: queries packed with role 1
-// (mfma_query_tiles(nq) tiles), dA: database packed with role 0 (mfma_tiles(ndb) tiles); qn: scaled |q|^2.
-hipError_t launch_nn_mfma33(const double* q, const void* qB, const float* qn, uint32_t nq, const double* db,
-                            const void* dA, uint32_t ndb, float max_dn2, uint32_t splits, float* premin, uint2* ring,
-                            uint32_t* ring_count, float* part_min, float* evict_min, uint32_t* overflow_list,
-                            uint32_t* overflow_count, uint32_t* nn, uint32_t* h_overflow, hipStream_t s) {
+// ---- both directions of ANNMatcher::Match in ONE scan (m3d_match_scan.hpp, RevOut) ------------------------------
+// thresholds of the reverse search from its warm-up minima: thr[j] = min over slices + 2 E_j (E as in the forward
+// windows, with the roles exchanged); a row without a usable bound gets thr = -inf and a counter past the cap, which
+// sends it to the exact fallback.  Rows >= n of the last tile: -inf.
+__global__ void rev_threshold_k(const float* __restrict__ premin, uint32_t slices, uint32_t n, uint32_t n_pad,
+                                const float* __restrict__ n2, float max_other_n2, float* __restrict__ thr,
+                                uint32_t* __restrict__ cnt) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_pad) return;
+    if (j >= n) {
+        thr[j] = -INFINITY;
+        return;
+    }
+    float m = INFINITY;
+    for (uint32_t s = 0; s < slices; ++s) m = fminf(m, premin[(size_t)s * n + j]);
+    const float two_e = 2.0f * (kMfmaECoeff * (n2[j] + max_other_n2) + kMfmaEAbs) * 1.000001f + 1e-30f;
+    const float t = m + two_e;
+    const bool usable = t < INFINITY && m == m;
+    thr[j] = usable ? t : -INFINITY;
+    cnt[j] = usable ? 0u : 0x80000000u;
+}
+// thr4[g] = max of thr[4g .. 4g + 3]: what the scan's fast path tests the minimum of a run of four rows against
+__global__ void rev_threshold4_k(const float* __restrict__ thr, uint32_t n_groups, float* __restrict__ thr4) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_groups) return;
+    const float4 t = reinterpret_cast<const float4*>(thr)[g];
+    thr4[g] = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
+}
+
+// the scan's per-(slice, query) candidate lists sorted by database row: entry (row, d16) of query q -> slot of row
+__global__ void rev_bin_k(const uint2* __restrict__ list, const uint32_t* __restrict__ list_cnt, uint32_t nq, size_t lists,
+                          uint32_t* __restrict__ cnt, uint2* __restrict__ cand) {
+    const size_t o = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (o >= lists) return;
+    const uint32_t c = list_cnt[o];   // <= kRevLane (a full list sends the rest straight to the rows' slots)
+    const uint32_t q = (uint32_t)(o % nq);
+    for (uint32_t t = 0; t < c; ++t) {
+        const uint2 e = list[o * kRevLane + t];
+        const uint32_t slot = atomicAdd(cnt + e.x, 1u) & 0x7FFFFFFFu;
+        if (slot < (uint32_t)kRevCap) cand[(size_t)e.x * kRevCap + slot] = make_uint2(q, e.y);
+    }
+}
+
+// exact distances of a row's candidates (serial-order fp64 accumulation, lowest index among equal distances: what
+// NearestSearch(dst, src) returns for query j).  Eight lanes per row: first the smallest screen value m of the list,
+// then only the candidates inside the final window m + 2 E_j are evaluated exactly (the list was collected against the
+// looser threshold of the sample), the lanes taking them in turn; (distance, index) minimum across the eight.
+// An overflowed or empty list takes the exact fallback.
+__global__ __launch_bounds__(256) void nn64_verify_rev_k(const double* __restrict__ q, uint32_t nq, const double* __restrict__ db,
+                                                          int dim, const uint32_t* __restrict__ cnt,
+                                                          const uint2* __restrict__ cand, const float* __restrict__ qn2,
+                                                          float max_dn2, uint32_t* __restrict__ nn,
+                                                          uint32_t* __restrict__ overflow_list,
+                                                          uint32_t* __restrict__ overflow_count) {
+    const uint32_t j = blockIdx.x * 32u + (threadIdx.x >> 3), sub = threadIdx.x & 7u;
+    if (j >= nq) return;   // (whole groups of eight lanes)
+    const uint32_t c = cnt[j];
+    if (c == 0u || c > (uint32_t)kRevCap) {   // (bit 31: flagged by rev_threshold_k)
+        if (sub == 0) overflow_list[atomicAdd(overflow_count, 1u)] = j;
+        return;
+    }
+    const uint2* __restrict__ my = cand + (size_t)j * kRevCap;
+    float m = INFINITY;
+    for (uint32_t t = sub; t < c; t += 8) m = fminf(m, __uint_as_float(my[t].y));
+    for (int off = 4; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+    const float win = m + (2.0f * (kMfmaECoeff * (qn2[j] + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f);
+    double bd = INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t t = sub; t < c; t += 8) {
+        const uint2 e = my[t];
+        if (!(__uint_as_float(e.y) <= win)) continue;
+        const uint32_t i = e.x;
+        double acc = 0.0;
+        for (int k = 0; k < dim; ++k) {
+            const double df = q[(size_t)j * dim + k] - db[(size_t)i * dim + k];
+            acc += df * df;
+        }
+        if (acc < bd || (acc == bd && i < bi)) {
+            bd = acc;
+            bi = i;
+        }
+    }
+    for (int off = 4; off > 0; off >>= 1) {
+        const double od = __shfl_xor(bd, off, 64);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
+        if (od < bd || (od == bd && oi < bi)) {
+            bd = od;
+            bi = oi;
+        }
+    }
+    if (sub == 0) nn[j] = bi;
+}
+
+// src -> dst AND dst -> src nearest neighbours from one pass over the 32 x 32 product tiles.
+//   forward: queries = a (qB_a, role 1), database = b (dA_b, role 0): rings of 2 * splits slices + nn64_verify_k;
+//   reverse: the warm-up minima of b's rows over the first tiles of a (qB_b against dA_a) give the per-row thresholds
+//            the main scan tests its accumulators against; nn64_verify_rev_k evaluates the collected candidates.
+// Workspace beyond launch_nn_screened33's (with 2 * splits slices): premin 2 splits x na floats, rev_premin 2 splits_r x nb floats, rthr mfma_tiles(nb) * 40 floats, rcnt nb u32,
+// rcand nb x kRevCap uint2, rlist 2 splits x na x kRevLane uint2 + rlist_cnt 2 splits x na, a second overflow list / counter.
+hipError_t launch_nn_mfma33_both(const double* a, const void* qB_a, const void* dA_a, const float* an2, uint32_t na,
+                                 float max_an2, const double* b, const void* qB_b, const void* dA_b, const float* bn2,
+                                 uint32_t nb, float max_bn2, uint32_t splits, uint32_t splits_r, float* premin, uint2* ring,
+                                 uint32_t* ring_count, float* part_min, float* evict_min, float* rev_premin, float* rthr,
+                                 uint32_t* rcnt, uint2* rcand, uint2* rlist, uint32_t* rlist_cnt, uint32_t* overflow_list,
+                                 uint32_t* overflow_count, uint32_t* overflow_list_r, uint32_t* overflow_count_r,
+                                 uint32_t* nn_ab, uint32_t* nn_ba, uint32_t* h_overflow /* [2] */, hipStream_t s) {
     constexpr int DIM = 33;
-    *h_overflow = 0;
-    if (!nq || !ndb) return hipSuccess;
+    h_overflow[0] = h_overflow[1] = 0;
+    if (!na || !nb) return hipSuccess;
     (void)hipMemsetAsync(overflow_count, 0, sizeof(uint32_t), s);
-    const uint32_t n_tiles = mfma_tiles(ndb);
-    const uint32_t per = (n_tiles + splits - 1) / splits;
-    launch_nn16_scan(qB, qn, nq, dA, ndb, per, splits, max_dn2, premin, ring, ring_count, part_min, evict_min, s);
-    nn64_verify_k<<<(nq + 255) / 256, 256, 0, s>>>(q, nq, db, DIM, ring, ring_count, part_min, evict_min, 2 * splits,
-                                                   kMfmaECoeff, kMfmaEAbs, max_dn2, qn, nn, overflow_list,
+    (void)hipMemsetAsync(overflow_count_r, 0, sizeof(uint32_t), s);
+    // reverse warm-up: every row of b against the first 1/8 of a (1/16: twice the candidates and slow-path detours of the
+    // main scan for half the warm-up: 17.3 against 16.9 ms on 200 k x 200 k; 1/4: 17.0)
+    const uint32_t a_tiles = mfma_tiles(na), b_tiles = mfma_tiles(nb);
+    const uint32_t warm_r = std::min<uint32_t>(a_tiles, std::max<uint32_t>(splits_r, a_tiles / 8));
+    launch_nn16_warm(qB_b, bn2, nb, dA_a, na, warm_r, splits_r, max_an2, rev_premin, s);
+    rev_threshold_k<<<(b_tiles * 32u + 255) / 256, 256, 0, s>>>(rev_premin, 2 * splits_r, nb, b_tiles * 32u, bn2, max_an2,
+                                                               rthr, rcnt);
+    float* rthr4 = rthr + (size_t)b_tiles * 32u;   // (the caller's rthr holds 40 floats per tile)
+    rev_threshold4_k<<<(b_tiles * 8u + 255) / 256, 256, 0, s>>>(rthr, b_tiles * 8u, rthr4);
+    RevOut rev;
+    rev.thr = rthr;
+    rev.thr4 = rthr4;
+    rev.cnt = rcnt;
+    rev.cand = rcand;
+    rev.list = rlist;
+    rev.list_cnt = rlist_cnt;
+    const uint32_t per = (b_tiles + splits - 1) / splits;
+    launch_nn16_scan(qB_a, an2, na, dA_b, nb, per, splits, max_bn2, premin, ring, ring_count, part_min, evict_min, s, &rev);
+    nn64_verify_k<<<(na + 255) / 256, 256, 0, s>>>(a, na, b, DIM, ring, ring_count, part_min, evict_min, 2 * splits,
+                                                   kMfmaECoeff, kMfmaEAbs, max_bn2, an2, nn_ab, overflow_list,
                                                    overflow_count);
+    const size_t lists = (size_t)2 * splits * na;
+    rev_bin_k<<<(uint32_t)((lists + 255) / 256), 256, 0, s>>>(rlist, rlist_cnt, na, lists, rcnt, rcand);
+    nn64_verify_rev_k<<<(nb + 31) / 32, 256, 0, s>>>(b, nb, a, DIM, rcnt, rcand, bn2, max_an2, nn_ba, overflow_list_r,
+                                                     overflow_count_r);
     hipError_t e = hipMemcpyAsync(h_overflow, overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_overflow + 1, overflow_count_r, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
-    if (*h_overflow) nn_exact_one_k<<<*h_overflow, 64, 0, s>>>(q, db, ndb, DIM, overflow_list, nn);
+    if (h_overflow[0]) nn_exact_one_k<<<h_overflow[0], 64, 0, s>>>(a, b, nb, DIM, overflow_list, nn_ab);
+    if (h_overflow[1]) nn_exact_one_k<<<h_overflow[1], 64, 0, s>>>(b, a, na, DIM, overflow_list_r, nn_ba);
     return hipGetLastError();
 }
 

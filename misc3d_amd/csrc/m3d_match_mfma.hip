@@ -10,20 +10,22 @@
 
 namespace m3d {
 
-// Per tile and query tile: 16 distances per lane.  The running minimum is updated unconditionally (3 VALU
-// ops); rows are appended when they lie within the window of the minimum INCLUDING this tile (still a
-// superset of the final window).  A wave carries 128 rings, so early in a scan some lane has a new record
-// in most tiles: the append path is entered per wave-uniform branch and, inside, only the rows that any lane
-// needs are touched (one v_cmp + scalar branch per row), instead of 16 divergent blocks.
+// Per tile and query tile: 16 distances per lane.  The running minimum is updated unconditionally; rows are
+// appended when they lie within the window of the minimum INCLUDING this tile (still a superset of the final
+// window).  A wave carries 128 rings, so early in a scan some lane has a new record in most tiles: the append path is
+// entered per wave-uniform branch and, inside, only the rows that any lane needs are touched (one v_cmp + scalar
+// branch per row), instead of 16 divergent blocks.
+// group_min: the minima of the lane's four runs of four rows (acc[4g .. 4g + 3] = rows 8g + 4 half + 0..3 of the tile):
+// the first two levels of the 16-value minimum, kept because the reverse search tests them against the runs'
+// thresholds (two instructions per run: v_min + v_min3 under -fno-honor-nans).
+__device__ __forceinline__ void group_min(const f32x16& acc, float (&g)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = fminf(fminf(acc[4 * k], acc[4 * k + 1]), fminf(acc[4 * k + 2], acc[4 * k + 3]));
+}
 template <bool MIN_ONLY>
-__device__ __forceinline__ void mfma_post(const f32x16& acc, ScanState& st, float two_e, bool live, uint32_t row0,
-                                          uint32_t ndb, uint2* __restrict__ my) {
-    float t[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) t[r] = fminf(acc[2 * r], acc[2 * r + 1]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[r] = fminf(t[2 * r], t[2 * r + 1]);
-    const float tmin = fminf(fminf(t[0], t[1]), fminf(t[2], t[3]));   // v_min3_f32 chains under -fno-honor-nans
+__device__ __forceinline__ void mfma_post(const f32x16& acc, const float (&g)[4], ScanState& st, float two_e, bool live,
+                                          uint32_t row0, uint32_t ndb, uint2* __restrict__ my) {
+    const float tmin = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
     st.best = fminf(st.best, tmin);
     if (MIN_ONLY) return;
     st.win = st.best + two_e;
@@ -44,6 +46,32 @@ __device__ __forceinline__ void mfma_post(const f32x16& acc, ScanState& st, floa
     }
 }
 
+// The reverse search's share of a tile (m3d_match_scan.hpp, RevOut).  Fast path: the four run minima against the four
+// run thresholds (thr4 = the largest of the run's four row thresholds: conservative) -- 4 compares per side and tile.
+// Behind the wave-uniform branch, per run that some lane hit: the four rows' own thresholds (one ds_read_b128), a
+// ballot and scalar branch per row, a plain store into the lane's own list per candidate.
+template <int G>
+__device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, bool ok, uint32_t row0, uint2* __restrict__ my,
+                                        uint32_t& cnt, const RevOut& rev, uint32_t q) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t = k & 2 ? (k & 1 ? th.w : th.z) : (k & 1 ? th.y : th.x);
+        const float v = acc[4 * G + k];
+        const bool hit = ok && v <= t;
+        if (__ballot(hit) != 0ull) {
+            if (hit) {
+                const uint32_t row = row0 + (uint32_t)(k + 8 * G);
+                if (cnt < (uint32_t)kRevLane) {
+                    my[cnt++] = make_uint2(row, __float_as_uint(v));
+                } else {   // list full: straight into the row's slots (what rev_bin_k does with the listed ones)
+                    const uint32_t slot = atomicAdd(rev.cnt + row, 1u) & 0x7FFFFFFFu;
+                    if (slot < (uint32_t)kRevCap) rev.cand[(size_t)row * kRevCap + slot] = make_uint2(q, __float_as_uint(v));
+                }
+            }
+        }
+    }
+}
+
 // One wave: 64 queries (two 32-column B tiles held in registers for the whole scan) against a slice of
 // the database.  The four waves of a block walk the SAME slice, so the A tiles are staged through LDS once
 // per block (double-buffered, kStageTiles tiles per stage, one barrier per stage) instead of being
@@ -55,14 +83,17 @@ constexpr int kStageEntries = kStageTiles * kMfmaSteps * 64;   // h8 entries per
 // its per-(slice, query) minima seed the main pass (init_min / init_slices), so that a ring starts with a
 // bound close to its final minimum and "new record" events -- which cost a wave-wide detour each, and a wave
 // carries 128 rings -- become rare instead of happening in most tiles.
-template <bool MIN_ONLY>
+template <bool MIN_ONLY, bool REV>
 __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
                                                     uint32_t nq, const h8* __restrict__ dA, uint32_t ndb,
                                                     uint32_t tile_end, uint32_t tiles_per_split, float max_dn2,
                                                     const float* __restrict__ init_min, uint32_t init_slices,
                                                     uint2* __restrict__ ring, uint32_t* __restrict__ ring_count,
-                                                    float* __restrict__ part_min, float* __restrict__ evict_min) {
+                                                    float* __restrict__ part_min, float* __restrict__ evict_min,
+                                                    RevOut rev) {
     __shared__ h8 stage[2][kStageEntries];
+    __shared__ __attribute__((aligned(16))) float sthr[2][kStageTiles * 32];   // REV: the staged tiles' row thresholds
+    __shared__ __attribute__((aligned(16))) float sthr4[2][kStageTiles * 8];   // ... and run thresholds, [tile][half][run]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t qt0 = (blockIdx.x * 4u + wave) * 2u;   // first of this wave's two query tiles
     const uint32_t half = lane >> 5;
@@ -81,6 +112,10 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
     const uint32_t slice = blockIdx.y * 2u + half;
     uint2* __restrict__ ring_a = ring + ((size_t)slice * nq + (qa < nq ? qa : nq - 1)) * kRing;
     uint2* __restrict__ ring_b = ring + ((size_t)slice * nq + (qb < nq ? qb : nq - 1)) * kRing;
+    // REV: this lane's candidate lists of the reverse search (one per query and slice, like the rings)
+    uint2* __restrict__ rl_a = REV ? rev.list + ((size_t)slice * nq + (qa < nq ? qa : nq - 1)) * kRevLane : nullptr;
+    uint2* __restrict__ rl_b = REV ? rev.list + ((size_t)slice * nq + (qb < nq ? qb : nq - 1)) * kRevLane : nullptr;
+    uint32_t rc_a = 0, rc_b = 0;
     ScanState sa, sb;
     if (!MIN_ONLY && init_min) {
         for (uint32_t k = 0; k < init_slices; ++k) {
@@ -93,12 +128,18 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
         // entry e of a stage = fragment (tile e / 448, step, lane) in packed order: consecutive in memory
         constexpr int kPerThread = (kStageEntries + 255) / 256;   // 4 (the last one only for tid < 128)
         const uint32_t last_entry = (t1 - 1) * (uint32_t)(kMfmaSteps * 64) + (kMfmaSteps * 64 - 1);
+        float rthr = 0.0f;   // REV: threads 0 .. 32 kStageTiles - 1 carry one row threshold of the stage each
         auto fetch = [&](uint32_t t_first, h8 (&r)[kPerThread]) {
 #pragma unroll
             for (int k = 0; k < kPerThread; ++k) {
                 const uint32_t e = (uint32_t)tid + 256u * k;
                 const uint32_t g = min(t_first * (uint32_t)(kMfmaSteps * 64) + e, last_entry);   // clamp: stay inside the slice
                 r[k] = dA[g];
+            }
+            if (REV && tid < kStageTiles * 32) rthr = rev.thr[min(t_first * 32u + (uint32_t)tid, t1 * 32u - 1u)];
+            if (REV && tid >= 64 && tid < 64 + kStageTiles * 8) {   // slot [tile u][half][run g] <- run 2 g + half of tile u
+                const uint32_t k = (uint32_t)tid - 64u, u = k >> 3, hf = (k >> 2) & 1u, g = k & 3u;
+                rthr = rev.thr4[min((t_first + u) * 8u + 2u * g + hf, t1 * 8u - 1u)];
             }
         };
         auto park = [&](int buf, const h8 (&r)[kPerThread]) {
@@ -107,6 +148,8 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
                 const uint32_t e = (uint32_t)tid + 256u * k;
                 if (e < (uint32_t)kStageEntries) stage[buf][e] = r[k];
             }
+            if (REV && tid < kStageTiles * 32) sthr[buf][tid] = rthr;
+            if (REV && tid >= 64 && tid < 64 + kStageTiles * 8) sthr4[buf][tid - 64] = rthr;
         };
         h8 regs[kPerThread];
         fetch(t0, regs);
@@ -128,8 +171,31 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], acc1, 0, 0, 0);
                 }
                 const uint32_t row0 = (t + u) * 32u + 4u * half;
-                mfma_post<MIN_ONLY>(acc0, sa, two_ea, live_a, row0, ndb, ring_a);
-                mfma_post<MIN_ONLY>(acc1, sb, two_eb, live_b, row0, ndb, ring_b);
+                // one side after the other: the run minima of a side are dead before the other side's are formed
+                auto side = [&](const f32x16& acc, ScanState& st, float two_e, bool live, uint2* __restrict__ rg, uint32_t q,
+                                uint2* __restrict__ rl, uint32_t& rc) {
+                    float g4[4];
+                    group_min(acc, g4);
+                    mfma_post<MIN_ONLY>(acc, g4, st, two_e, live, row0, ndb, rg);
+                    if (REV) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
+                        const bool h = q < nq && (g4[0] <= t4.x || g4[1] <= t4.y || g4[2] <= t4.z || g4[3] <= t4.w);
+                        if (__ballot(h) != 0ull) {
+                            const float* rows = &sthr[buf][u * 32u + 4u * half];
+                            const bool okq = q < nq;
+                            if (__ballot(okq && g4[0] <= t4.x) != 0ull)
+                                rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), okq, row0, rl, rc, rev, q);
+                            if (__ballot(okq && g4[1] <= t4.y) != 0ull)
+                                rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), okq, row0, rl, rc, rev, q);
+                            if (__ballot(okq && g4[2] <= t4.z) != 0ull)
+                                rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), okq, row0, rl, rc, rev, q);
+                            if (__ballot(okq && g4[3] <= t4.w) != 0ull)
+                                rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), okq, row0, rl, rc, rev, q);
+                        }
+                    }
+                };
+                side(acc0, sa, two_ea, live_a, ring_a, qa, rl_a, rc_a);
+                side(acc1, sb, two_eb, live_b, ring_b, qb, rl_b, rc_b);
             }
             if (more) park(buf ^ 1, regs);
             __syncthreads();
@@ -140,6 +206,10 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
         if (qa < nq) part_min[(size_t)slice * nq + qa] = sa.best;
         if (qb < nq) part_min[(size_t)slice * nq + qb] = sb.best;
         return;
+    }
+    if (REV) {
+        if (qa < nq) rev.list_cnt[(size_t)slice * nq + qa] = rc_a;
+        if (qb < nq) rev.list_cnt[(size_t)slice * nq + qb] = rc_b;
     }
     if (qa < nq) {
         const size_t o = (size_t)slice * nq + qa;
@@ -155,20 +225,32 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
     }
 }
 
+void launch_nn16_warm(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb, uint32_t warm_tiles,
+                      uint32_t splits, float max_dn2, float* part_min, hipStream_t s) {
+    const dim3 grid((nq + 255) / 256, splits);
+    const uint32_t warm_per = (warm_tiles + splits - 1) / splits;
+    nn16_scan_k<true, false><<<grid, 256, 0, s>>>(reinterpret_cast<const h8*>(qB), qn, nq, reinterpret_cast<const h8*>(dA), ndb,
+                                                  warm_tiles, warm_per, max_dn2, nullptr, 0, nullptr, nullptr, part_min,
+                                                  nullptr, RevOut());
+}
+
 void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb,
                       uint32_t tiles_per_split, uint32_t splits, float max_dn2, float* premin /* 2 splits nq */,
-                      uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min, hipStream_t s) {
+                      uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min, hipStream_t s,
+                      const RevOut* rev) {
     const h8* q8 = reinterpret_cast<const h8*>(qB);
     const h8* d8 = reinterpret_cast<const h8*>(dA);
     const uint32_t n_tiles = (ndb + 31u) / 32u;
     const dim3 grid((nq + 255) / 256, splits);
     // warm-up over the first 1/16 of the database (same grid: every slice of the main pass takes a share)
     const uint32_t warm = std::min<uint32_t>(n_tiles, std::max<uint32_t>(splits, n_tiles / 16));
-    const uint32_t warm_per = (warm + splits - 1) / splits;
-    nn16_scan_k<true><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, warm, warm_per, max_dn2, nullptr, 0, nullptr, nullptr,
-                                          premin, nullptr);
-    nn16_scan_k<false><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, n_tiles, tiles_per_split, max_dn2, premin, 2 * splits,
-                                           ring, ring_count, part_min, evict_min);
+    launch_nn16_warm(qB, qn, nq, dA, ndb, warm, splits, max_dn2, premin, s);
+    if (rev)
+        nn16_scan_k<false, true><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, n_tiles, tiles_per_split, max_dn2, premin,
+                                                      2 * splits, ring, ring_count, part_min, evict_min, *rev);
+    else
+        nn16_scan_k<false, false><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, n_tiles, tiles_per_split, max_dn2, premin,
+                                                       2 * splits, ring, ring_count, part_min, evict_min, RevOut());
 }
 
 }  // namespace m3d

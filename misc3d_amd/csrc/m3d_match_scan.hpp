@@ -37,8 +37,37 @@ __device__ __forceinline__ void scan_step(ScanState& st, float dv, float two_e, 
     }
 }
 
+// The REVERSE search riding on the same product tiles (ANNMatcher::Match runs both directions,
+// src/correspondence_matching.cpp:59-62): the scan that finds every query's nearest database row also sees every
+// distance the opposite search needs -- database row j against all queries.  Per database row a threshold
+// thr[j] = u_j + 2 E_j, u_j = the screen's minimum over a SAMPLE of the queries (a warm-up pass with the roles swapped);
+// every (query, row) pair of the main pass with d16 <= thr[row] is a candidate of row j.  The exact nearest query of
+// row j and every exact tie are among them: d16(i*, j) <= d(i*, j) + E <= d(i_s, j) + E <= u_j + 2E for the sample's
+// best i_s.  thr = -inf: nothing is collected for that row (padding rows; rows whose bound is not finite).
+// A lane of the scan owns one query and keeps its candidates in a list of its own -- kRevLane (row, d16) entries per
+// (slice, query), a plain store each: an atomic slot counter per ROW inside the scan cost the wave a memory round trip
+// per candidate and doubled the scan's time -- and rev_bin_k sorts the lists by row afterwards (the atomics, all
+// independent, in a kernel of their own).  A lane whose list is full (a query near very many rows: a few lists in a
+// thousand) appends to the row's slots directly.  A row with more than kRevCap candidates takes the exact fallback
+// (with thresholds from a 1/8 sample the count is geometric with mean 8: (7/8)^256 = 1e-15 for unclustered data).
+constexpr int kRevCap = kMatchRevCap;   // candidates kept per database row (m3d_reg_kernels.hpp)
+constexpr int kRevLane = 8;             // candidates a (slice, query) list holds
+struct RevOut {
+    const float* thr = nullptr;   // mfma_tiles(ndb) * 32 thresholds (scaled^2 units)
+    const float* thr4 = nullptr;  // mfma_tiles(ndb) * 8: the largest threshold of every run of four rows
+    uint32_t* cnt = nullptr;      // ndb counters: low 31 bits candidates binned so far, bit 31 = take the exact fallback
+    uint2* cand = nullptr;        // ndb x kRevCap slots (query, d16 bits): filled by rev_bin_k, and by full lists directly
+    uint2* list = nullptr;        // slices x nq x kRevLane entries (row, d16 bits)
+    uint32_t* list_cnt = nullptr; // slices x nq
+};
+
 void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb,
                       uint32_t tiles_per_split, uint32_t splits, float max_dn2, float* premin /* 2 splits nq */,
-                      uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min, hipStream_t s);
+                      uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min, hipStream_t s,
+                      const RevOut* rev = nullptr);
+// the warm-up pass alone (running minimum over the first `warm_tiles` tiles of the database, per (slice, query)):
+// part_min receives 2 * splits x nq values
+void launch_nn16_warm(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb, uint32_t warm_tiles,
+                      uint32_t splits, float max_dn2, float* part_min, hipStream_t s);
 
 }  // namespace m3d

@@ -131,9 +131,15 @@ void launch_max_abs(const double* f, size_t count, double* partial /* 256 double
 void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s);
 void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale, int role, void* out, float* norm2,
                      hipStream_t s);
-hipError_t launch_nn_mfma33(const double* q, const void* qB, const float* qn, uint32_t nq, const double* db,
-                            const void* dA, uint32_t ndb, float max_dn2, uint32_t splits, float* premin, uint2* ring,
-                            uint32_t* ring_count, float* part_min, float* evict_min, uint32_t* overflow_list,
-                            uint32_t* overflow_count, uint32_t* nn, uint32_t* h_overflow, hipStream_t s);
+// both directions (a -> b and b -> a) from ONE pass over the product tiles (m3d_match_scan.hpp, RevOut)
+constexpr int kMatchRevCap = 256;    // = kRevCap (m3d_match_scan.hpp): candidates kept per row of b
+constexpr int kMatchRevLane = 8;     // = kRevLane: candidates per (slice, query) list of the scan
+hipError_t launch_nn_mfma33_both(const double* a, const void* qB_a, const void* dA_a, const float* an2, uint32_t na,
+                                 float max_an2, const double* b, const void* qB_b, const void* dA_b, const float* bn2,
+                                 uint32_t nb, float max_bn2, uint32_t splits, uint32_t splits_r, float* premin, uint2* ring,
+                                 uint32_t* ring_count, float* part_min, float* evict_min, float* rev_premin, float* rthr,
+                                 uint32_t* rcnt, uint2* rcand, uint2* rlist, uint32_t* rlist_cnt, uint32_t* overflow_list, uint32_t* overflow_count,
+                                 uint32_t* overflow_list_r, uint32_t* overflow_count_r, uint32_t* nn_ab, uint32_t* nn_ba,
+                                 uint32_t* h_overflow /* [2] */, hipStream_t s);
 
 }  // namespace m3d

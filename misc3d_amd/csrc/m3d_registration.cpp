@@ -1375,10 +1375,11 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf fs, fd, bd, bi, nn01, nn10, fs32, fd32, ns2, nd2, ring, ring_count, evict, over_list, scal, pA_s, pA_d,
-        pB_s, pB_d, premin;
+        pB_s, pB_d, premin, rev_premin, rthr, rcnt, rcand, rlist, rlist_cnt, over_list_r;
     auto done = [&](int r) {
         for (DevBuf* b : {&fs, &fd, &bd, &bi, &nn01, &nn10, &fs32, &fd32, &ns2, &nd2, &ring, &ring_count, &evict,
-                          &over_list, &scal, &pA_s, &pA_d, &pB_s, &pB_d, &premin})
+                          &over_list, &scal, &pA_s, &pA_d, &pB_s, &pB_d, &premin, &rev_premin, &rthr, &rcnt, &rcand,
+                          &rlist, &rlist_cnt, &over_list_r})
             b->release();
         return r;
     };
@@ -1428,8 +1429,10 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
         s01 = splits_for(ns, nd, 256, 1024, 8192);
         s10 = splits_for(nd, ns, 256, 1024, 8192);
     }
+    // MFMA screen: one scan serves both directions (m3d_match_scan.hpp, RevOut)
+    const bool one_pass = use_mfma;
     const uint32_t slices01 = use_mfma ? 2 * s01 : s01, slices10 = use_mfma ? 2 * s10 : s10;
-    const size_t part = std::max((size_t)slices01 * ns, (size_t)slices10 * nd);
+    const size_t part = one_pass ? (size_t)slices01 * ns : std::max((size_t)slices01 * ns, (size_t)slices10 * nd);
     const uint32_t nmax = std::max(ns, nd);
     if (ok && (!bd.reserve(sizeof(double) * part) || !bi.reserve(sizeof(uint32_t) * part))) return done(M3D_ERR_DEVICE);
     if (ok && screened &&   // fp32 rows carry one spare row (prefetch target of the last iteration)
@@ -1454,15 +1457,27 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
         float h_max[2] = {0.0f, 0.0f};
         ok = hipMemcpyAsync(h_max, sc, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
-        // the two std::threads of correspondence_matching.cpp:59-62 become two passes on one stream
-        ok = ok && launch_nn_mfma33(fs.as<double>(), pB_s.p, ns2.as<float>(), ns, fd.as<double>(), pA_d.p, nd, h_max[1],
-                                    s01, premin.as<float>(), ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(),
-                                    evict.as<float>(), over_list.as<uint32_t>(), scal.as<uint32_t>() + 2,
-                                    nn01.as<uint32_t>(), &over01, ctx->stream) == hipSuccess;
-        ok = ok && launch_nn_mfma33(fd.as<double>(), pB_d.p, nd2.as<float>(), nd, fs.as<double>(), pA_s.p, ns, h_max[0],
-                                    s10, premin.as<float>(), ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(),
-                                    evict.as<float>(), over_list.as<uint32_t>(), scal.as<uint32_t>() + 2,
-                                    nn10.as<uint32_t>(), &over10, ctx->stream) == hipSuccess;
+        if (ok) {
+            // the two std::threads of correspondence_matching.cpp:59-62 become ONE pass over the product tiles: the scan
+            // of the source queries against the target rows also collects, per target row, the source rows that can be
+            // its nearest neighbour (thresholds from a warm-up pass with the roles exchanged)
+            const uint32_t d_tiles = mfma_tiles(nd);
+            if (!rev_premin.reserve(sizeof(float) * (size_t)slices10 * nd) || !rthr.reserve(sizeof(float) * 40 * (size_t)d_tiles) ||
+                !rcnt.reserve(sizeof(uint32_t) * nd) || !rcand.reserve(sizeof(uint2) * (size_t)kMatchRevCap * nd) ||
+                !rlist.reserve(sizeof(uint2) * (size_t)kMatchRevLane * slices01 * ns) ||
+                !rlist_cnt.reserve(sizeof(uint32_t) * (size_t)slices01 * ns) || !over_list_r.reserve(sizeof(uint32_t) * nd))
+                return done(M3D_ERR_DEVICE);
+            uint32_t over[2] = {0, 0};
+            ok = launch_nn_mfma33_both(fs.as<double>(), pB_s.p, pA_s.p, ns2.as<float>(), ns, h_max[0], fd.as<double>(),
+                                       pB_d.p, pA_d.p, nd2.as<float>(), nd, h_max[1], s01, s10, premin.as<float>(),
+                                       ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(), evict.as<float>(),
+                                       rev_premin.as<float>(), rthr.as<float>(), rcnt.as<uint32_t>(), rcand.as<uint2>(),
+                                       rlist.as<uint2>(), rlist_cnt.as<uint32_t>(), over_list.as<uint32_t>(), scal.as<uint32_t>() + 2, over_list_r.as<uint32_t>(),
+                                       scal.as<uint32_t>() + 3, nn01.as<uint32_t>(), nn10.as<uint32_t>(), over,
+                                       ctx->stream) == hipSuccess;
+            over01 = over[0];
+            over10 = over[1];
+        }
         g_match_fallbacks = (uint64_t)over01 + over10;
     } else if (ok && screened) {
         if (!fs32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)ns + 1)) ||

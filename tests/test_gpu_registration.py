@@ -404,11 +404,48 @@ def test_mutual_nn_screen_adversarial(capi, orc, case, screen):
         assert falls > 0
 
 
+@pytest.mark.parametrize("case", ["row_overflow", "hub_query", "ragged", "tiny_sides"])
+def test_mutual_nn_one_pass_reverse_lists(capi, orc, case):
+    """The MFMA screen finds BOTH directions in one scan: the target rows' candidates are collected in per-lane lists
+    (8 entries per query and slice), binned by row (256 slots) and verified in fp64.  Built to overflow each of them:
+    row_overflow -- 700 source rows at the same distance from one target row (more candidates than slots: the row takes
+    the exact fallback); hub_query -- one source row that is the nearest of 400 target rows (its lane lists overflow:
+    direct appends); ragged / tiny_sides -- sizes that are no multiple of the 32-row tiles, a side smaller than a tile."""
+    rng = np.random.default_rng(7 + len(case))
+    dim = 33
+    if case == "row_overflow":
+        ns, nd = 3000, 1200
+        fs = rng.uniform(0, 1, (ns, dim))
+        fd = rng.uniform(0, 1, (nd, dim))
+        fs[1000:1700] = fd[77] + 1e-3 * np.sign(rng.normal(size=(700, dim)))      # 700 rows at one exact distance from target 77
+    elif case == "hub_query":
+        ns, nd = 2500, 3000
+        fs = rng.uniform(0, 1, (ns, dim))
+        fd = rng.uniform(0, 1, (nd, dim))
+        fd[500:900] = fs[42] + rng.normal(0, 1e-4, (400, dim))                     # source 42 is the nearest of 400 targets
+    elif case == "ragged":
+        ns, nd = 1033, 2051
+        fs = rng.uniform(0, 1, (ns, dim))
+        fd = rng.uniform(0, 1, (nd, dim))
+        fd[:500] = fs[:500] + rng.normal(0, 1e-3, (500, dim))
+    else:
+        ns, nd = 5, 1500
+        fs = rng.uniform(0, 1, (ns, dim))
+        fd = rng.uniform(0, 1, (nd, dim))
+    for a_, b_ in ((fs, fd), (fd, fs)):                                            # each side once as the scan's queries
+        a, b = capi.match_mutual_nn(a_, b_)
+        falls = capi.match_last_fallbacks()
+        oa, ob = orc.match_mutual_nn(a_, b_)
+        assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob)
+        if case == "row_overflow" and a_ is fs:
+            assert falls >= 1                                                      # target row 77 could not keep its candidates
+
+
 def test_mutual_nn_screen_is_used(capi):
     """on ordinary descriptors the screen decides (almost) every query without the fallback"""
     d = synth.registration_pair_c4(20_000, seed=9)
     a, b = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
-    assert capi.match_last_fallbacks() < 20
+    assert capi.match_last_fallbacks() < 40      # (of 40 000 searches: both directions)
     ba, bb = _brute(capi, d["feat_src"], d["feat_dst"])
     assert np.array_equal(a, ba) and np.array_equal(b, bb)
 
