@@ -370,9 +370,7 @@ typedef struct m3d_config {
     int32_t score_groups_per_block; /* [M3D_GPB]            default 8: 64-hypothesis groups per scoring workgroup (1..64; the fp32-screen kernels take at most 8) */
     int32_t score_min_workgroups;   /* [M3D_SCORE_MIN_WGS]  default 16384: small chunks are cut finer to reach this many workgroups */
     int32_t dense_workgroups;       /* [M3D_SCORE_WGS]      default 8192: workgroup target of the dense kernel */
-    int32_t morton_order;           /* [M3D_ORDER=morton]   1: plain Z-order instead of the Hilbert curve for the sorted copy */
     int32_t reg_neighbour_lists;    /* [M3D_REG_NL=0]       default 1: per-cell 3x3x3 neighbour lists for the registration validation */
-    int32_t reg_source_rows;        /* [M3D_REG_SRC_ORDER=rows] 1: source cloud in x-row order instead of Hilbert order */
     int32_t reg_prune;              /* [M3D_REG_PRUNE=0]    default 1: bound-and-prune of validations against earlier chunks */
     int32_t match_brute;            /* [M3D_MATCH_BRUTE=1]  1: fp64 brute-force matcher (no screen) */
     int32_t match_fp32_screen;      /* [M3D_MATCH_SCREEN=fp32] 1: fp32 VALU screen instead of the split-fp16 MFMA screen */
@@ -380,7 +378,6 @@ typedef struct m3d_config {
     int32_t kernel_timing;          /* [M3D_KERNEL_TIMING=1] default 0; 1: HIP events attached to every scoring launch (hipExtLaunchKernel: the
                                        launch's own start / stop times, no barrier packets) fill m3d_stats.ms_score_kernel /
                                        score_launches (bench.py switches it on: ~4 us per C2 fit); ms_score becomes a host clock around the scoring phase */
-    int32_t reg_lds_staging;        /* [M3D_REG_LDS=0]      default 0: registration validation with the target neighbourhood of a row of source points staged in LDS (bit-identical, not faster: DESIGN.md) */
     int32_t reg_sorted_lists;       /* [M3D_REG_SORTED=0]   default 1: x-sorted neighbour lists, side columns cut off by the x-distance */
     int32_t score_fp32_screen;      /* [M3D_SCORE_SCREEN=0] default 1: planes and spheres are counted by score_screen_k (packed-fp32 screen with a
                                        rounding bound in front of the exact fp64 test: identical counts); 0: fp64 only (score_mask_k) */
@@ -389,10 +386,8 @@ typedef struct m3d_config {
     int32_t reg_fp32_screen;        /* [M3D_REG_SCREEN=0]   default 1: the nearest-neighbour search of the registration validation finds its
                                        candidate in fp32 (16-byte list entries relative to the cell, rounding bound) and evaluates the winner
                                        in fp64; a query whose runner-up is within the bound takes the fp64 walk: identical distances */
-    int32_t fused_compaction;       /* [M3D_FUSED_COMPACT=1] default 0: counting launch + writing launch for RefineModel's inlier list
-                                       (compact_count_k, compact_write_k); 1: ONE launch whose workgroups hand their counts to each other
-                                       (compact_fused_k): the same list and sums, the same time on one MI355X */
-    int32_t reserved[4];            /* zero */
+    int32_t reserved[8];            /* zero (round 3 dropped four switches whose paths lost and were deleted: Z-order sort,
+                                       x-row source order, LDS-staged validation, one-launch compaction -- DESIGN.md 7) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

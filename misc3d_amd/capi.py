@@ -204,9 +204,9 @@ class Config(C.Structure):
     """m3d_config (include/misc3d_amd.h): the library's tunables."""
     _fields_ = [(k, C.c_int32) for k in ("dense_scoring", "speculative_refine", "lead_hypotheses",
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
-                                         "morton_order", "reg_neighbour_lists", "reg_source_rows", "reg_prune",
-                                         "match_brute", "match_fp32_screen", "pool_limit_mb", "kernel_timing", "reg_lds_staging", "reg_sorted_lists",
-                                         "score_fp32_screen", "cull_fp32", "reg_fp32_screen", "fused_compaction")] + [("reserved", C.c_int32 * 4)]
+                                         "reg_neighbour_lists", "reg_prune", "match_brute", "match_fp32_screen",
+                                         "pool_limit_mb", "kernel_timing", "reg_sorted_lists", "score_fp32_screen",
+                                         "cull_fp32", "reg_fp32_screen")] + [("reserved", C.c_int32 * 8)]
 
 
 def fp64_issue_rate(device=0, ms_target=2.0):
@@ -275,10 +275,15 @@ class Comm:
             raise err if err is not None else M3DError(-6, "rank 0 could not create an RCCL unique id")
         ident = np.ascontiguousarray(status[:128])
         # librccl prints a version banner to STDOUT on its first communicator; callers (bench.py) own stdout, so the
-        # banner is sent to stderr: fd 1 points at fd 2 for the duration of the call, C stdio flushed on both sides
+        # banner is sent to stderr: fd 1 points at fd 2 for the duration of the call, C stdio flushed on both sides.
+        # SIDE EFFECT: the redirection is process-wide and not thread-safe -- whatever another thread writes
+        # to stdout while ncclCommInitRank runs (it can take seconds) lands on stderr; M3D_RCCL_KEEP_STDOUT=1 skips it
+        # (the banner then goes where librccl sends it)
         libc = C.CDLL(None)
         sys.stdout.flush()
         libc.fflush(None)
+        if os.environ.get("M3D_RCCL_KEEP_STDOUT") == "1":
+            return cls(lib().m3d_comm_create_rccl(_p(ident), world, rank, device))
         saved = os.dup(1)
         os.dup2(2, 1)
         try:

@@ -2,7 +2,19 @@
 #include "m3d_comm.hpp"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and enums only: the entry points are bound with dlsym (no link-time dependency)
+// types and enums only: the entry points are bound with dlsym (no link-time dependency).  A ROCm installation without
+// the RCCL development headers still builds the library: the handful of declarations this file needs are ABI-stable
+// (nccl.h: 128-byte unique id, ncclSuccess == 0, ncclUint8 == 1, ncclUint32 == 3)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3 } ncclDataType_t;
+}
+#endif
 
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +70,21 @@ RcclApi& rccl() {
         if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
             dlclose(api.handle);
             api.handle = nullptr;
+            return;
+        }
+        // the streams and device pointers this library hands to ncclAllGather belong to the HIP runtime IT is linked
+        // against; a librccl whose own HIP dependency resolved to another copy of libamdhip64 (a host process can hold
+        // two: PyTorch wheels bundle theirs) would take them for foreign handles.  Compare the two runtimes' load
+        // addresses and refuse the binding when they differ -- the callers then fall back to the host transport.
+        if (void* theirs = dlsym(api.handle, "hipMalloc")) {
+            Dl_info di_theirs{}, di_ours{};
+            void* ours = reinterpret_cast<void*>(static_cast<hipError_t (*)(void**, size_t)>(&hipMalloc));
+            if (dladdr(theirs, &di_theirs) && dladdr(ours, &di_ours) && di_theirs.dli_fbase != di_ours.dli_fbase) {
+                api.error = std::string("librccl is bound to another HIP runtime (") + (di_theirs.dli_fname ? di_theirs.dli_fname : "?") +
+                            ") than this library (" + (di_ours.dli_fname ? di_ours.dli_fname : "?") + ")";
+                dlclose(api.handle);
+                api.handle = nullptr;
+            }
         }
     });
     return api;

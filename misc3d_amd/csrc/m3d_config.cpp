@@ -38,20 +38,16 @@ void load_env() {
     g_cfg.score_groups_per_block = (int32_t)env_long("M3D_GPB", 8);
     g_cfg.score_min_workgroups = (int32_t)env_long("M3D_SCORE_MIN_WGS", 16384);
     g_cfg.dense_workgroups = (int32_t)env_long("M3D_SCORE_WGS", 8192);  // sweep on MI355X: 2048 +5 %, 4096 +1.5 %, 8192..32768 flat
-    g_cfg.morton_order = env_is("M3D_ORDER", 'm');
     g_cfg.reg_neighbour_lists = !env_is("M3D_REG_NL", '0');
-    g_cfg.reg_source_rows = env_is("M3D_REG_SRC_ORDER", 'r');
     g_cfg.reg_prune = !env_is("M3D_REG_PRUNE", '0');
     g_cfg.match_brute = env_is("M3D_MATCH_BRUTE", '1');
     g_cfg.match_fp32_screen = env_is("M3D_MATCH_SCREEN", 'f');
     g_cfg.pool_limit_mb = (int32_t)env_long("M3D_POOL_MB", 4096);
     g_cfg.kernel_timing = env_is("M3D_KERNEL_TIMING", '1');
-    g_cfg.reg_lds_staging = env_is("M3D_REG_LDS", '1');
     g_cfg.reg_sorted_lists = !env_is("M3D_REG_SORTED", '0');
     g_cfg.score_fp32_screen = !env_is("M3D_SCORE_SCREEN", '0');
     g_cfg.cull_fp32 = !env_is("M3D_CULL_FP32", '0');
     g_cfg.reg_fp32_screen = !env_is("M3D_REG_SCREEN", '0');
-    g_cfg.fused_compaction = env_is("M3D_FUSED_COMPACT", '1');
     sanitize(g_cfg);
 }
 }  // namespace

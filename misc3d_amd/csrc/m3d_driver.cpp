@@ -617,10 +617,14 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
 // Completion of a chunk issued with a PickFinal: the last kernel of the chunk stores `seq` into the pinned
 // BestPickHost behind everything else it (and the kernels before it) wrote to host memory.  A spin on that word
 // replaces an event record between two kernels (a ~5 us bubble on the stream) and the event wait.
+// The spin is bounded: a chunk on one million points is done in a few hundred microseconds, but one on ten million can
+// take tens of milliseconds, and a thread that spins that long starves the host work it shares a core (or a cgroup CPU
+// quota) with -- after ~30 us of pure spinning the loop yields its time slice between looks.
 static int wait_pick_seq(DeviceCtx* ctx, uint32_t seq) {
     const volatile uint32_t* p = &ctx->h_pick.as<BestPickHost>()->seq;
     for (uint32_t spins = 1;; ++spins) {
         if ((int32_t)(*p - seq) >= 0) break;
+        if (spins > 4096u) std::this_thread::yield();   // (~30 us of pause instructions have passed)
         if ((spins & 0xFFFFu) == 0) {   // a fault on the device would leave the word unwritten
             const hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) {
@@ -817,28 +821,11 @@ static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, c
         RESERVE(ctx->moment_partial, sizeof(double) * 16 * (size_t)std::max<uint32_t>(nb, 1));
         RESERVE(ctx->h_moments, sizeof(double) * kFusedMomentDoubles);
     }
-    // one launch (compact_fused_k): a word per workgroup and a ticket, zero when new, told apart by the launch's epoch
-    FusedScan fs;
-    {
-        const size_t want = sizeof(unsigned long long) * ((size_t)nb + 1);
-        if (ctx->compact_state.cap < want) {
-            RESERVE(ctx->compact_state, std::max<size_t>(2 * want, (size_t)1 << 16));
-            HIPCHK(hipMemsetAsync(ctx->compact_state.p, 0, ctx->compact_state.cap, ctx->stream));
-            ctx->compact_epoch = 0;
-        }
-        if (++ctx->compact_epoch == 0) ctx->compact_epoch = 1;   // (a wrap would need 2^32 launches without a reallocation;
-                                                                 //  the words of that long ago all carry other epochs)
-        const size_t words = ctx->compact_state.cap / sizeof(unsigned long long);
-        fs.state = ctx->compact_state.as<unsigned long long>();
-        fs.ticket = reinterpret_cast<uint32_t*>(fs.state + (words - 1));
-        fs.epoch = ctx->compact_epoch;
-    }
     launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
                    ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
                    fused ? ctx->moment_partial.as<double>() : nullptr, fused ? ctx->h_moments.as<double>() : nullptr,
-                   idx_host, static_cast<uint32_t*>(total_host) /* pinned: the kernel writes the total there itself */, part,
-                   config().fused_compaction ? &fs : nullptr);
+                   idx_host, static_cast<uint32_t*>(total_host) /* pinned: the kernel writes the total there itself */, part);
     ctx->compaction_fused = fused;
     ctx->compaction_idx_host = idx_host;
     return M3D_OK;
@@ -1732,8 +1719,7 @@ m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_
             while (bits < 8 && ((uint64_t)1 << (3 * bits)) * 8 < n_finite) ++bits;
             GridDesc gs;
             gs.K = 0;
-            const bool zorder = config().morton_order != 0;   // plain Z-order (comparison only)
-            gs.morton_bits = bits | (zorder ? 0u : 0x100u);  // Hilbert order by default
+            gs.morton_bits = bits | 0x100u;   // Hilbert order (plain Z-order, bits alone, measured slower: DESIGN.md)
             gs.nx = gs.ny = gs.nz = 1u << bits;
             gs.ox = lo[0];
             gs.oy = lo[1];

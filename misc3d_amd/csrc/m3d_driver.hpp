@@ -74,8 +74,6 @@ struct DeviceCtx {
     std::mutex mu;  // one call at a time per device
     ChunkSlot slot[2];
     DevBuf partial, block_counts, total, idx, dist, sum_partial, sums, best_params, small;
-    DevBuf compact_state;          // compact_fused_k: one word per workgroup + the ticket (zeroed when (re)allocated)
-    uint32_t compact_epoch = 0;    // launches of compact_fused_k on this context
     DevBuf masks, keep;        // culled scoring: (tile, 64-hypothesis group) bit masks, per-group keep masks
     DevBuf ub, best_count;     // bound-and-prune: surviving tiles per hypothesis, running best count
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)

@@ -703,193 +703,13 @@ __global__ __launch_bounds__(256) void compact_write_k(
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// compact_fused_k: the mode-0 compaction (inlier list, optionally RefineModel's moments and the segmentation round's
-// partition of the rest) in ONE pass over the cloud -- count, offset and write of a workgroup's 2048 points without a
-// second launch and a second read of the points.
-//   * The workgroup evaluates its flags (kept as ballots), publishes its count as ONE 64-bit word (launch epoch << 32 |
-//     count: no fence needed, the payload is the flag) and then adds up the words of the workgroups before it, waiting for
-//     those not yet published.  Workgroups are dispatched in the order of their ids and publish before they wait, so the
-//     lowest unfinished one never waits: no deadlock whatever the occupancy.  Offsets are sums of integers: the list is
-//     the one compact_count_k + compact_write_k wrote, bit for bit.
-//   * Moments: per-workgroup partials as compact_count_k<.., true> forms them; the LAST workgroup to hand its partial in
-//     (ticket) folds them in scan_blocks_k's order -- the same sums.
-// The state words are never reset: a launch only accepts words of its own epoch (the caller counts launches).
-// ------------------------------------------------------------------------------------------------
-template <int KIND, bool SUMS, bool PART>
-__global__ __launch_bounds__(256) void compact_fused_k(CloudView c, const double* __restrict__ model, double thr,
-                                                        const uint32_t* __restrict__ orig, FusedScan fs,
-                                                        uint64_t* __restrict__ out_idx, uint64_t* __restrict__ out_idx_host,
-                                                        double* __restrict__ model_copy, double* __restrict__ moment_partial,
-                                                        PartitionOut part, CompactTail tail) {
-    constexpr int R = kCompactTile / 256;
-    constexpr int NV = KIND == 1 ? 12 : 9;
-    __shared__ uint32_t wcnt[R][4];
-    __shared__ uint32_t wcnt2[PART ? R : 1][4];
-    __shared__ uint32_t red[4];
-    __shared__ uint32_t is_last;
-    double m[kModelStride];
-    for (int k = 0; k < kModelStride; ++k) m[k] = model[k];
-    if (model_copy && blockIdx.x == 0 && threadIdx.x < kModelStride) model_copy[threadIdx.x] = model[threadIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * kCompactTile;
-    unsigned long long bf[R], bg[PART ? R : 1];
-    double qx[PART ? R : 1], qy[PART ? R : 1], qz[PART ? R : 1];
-    double acc[NV];   // (SUMS only)
-    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
-    const double c0x = KIND == 0 ? m[4] : m[0], c0y = KIND == 0 ? m[5] : m[1], c0z = KIND == 0 ? m[6] : m[2];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t i = base + r * 256 + threadIdx.x;
-        bool f = false;
-        double px = 0, py = 0, pz = 0;
-        if (i < c.n) {
-            px = c.x[i];
-            py = c.y[i];
-            pz = c.z[i];
-            f = ref_distance<KIND>(m, px, py, pz) < thr;
-            if constexpr (SUMS) if (f) {   // (the statements of compact_count_k<.., true>: the same partial sums)
-                const double sx = px - c0x, sy = py - c0y, sz = pz - c0z;
-                acc[0] += sx;
-                acc[1] += sy;
-                acc[2] += sz;
-                acc[3] += sx * sx;
-                acc[4] += sx * sy;
-                acc[5] += sx * sz;
-                acc[6] += sy * sy;
-                acc[7] += sy * sz;
-                acc[8] += sz * sz;
-                if (KIND == 1) {
-                    const double q = (sx * sx + sy * sy) + sz * sz;
-                    acc[9] += sx * q;
-                    acc[10] += sy * q;
-                    acc[11] += sz * q;
-                }
-            }
-        }
-        bf[r] = __ballot(f);
-        if (lane == 0) wcnt[r][wave] = (uint32_t)__popcll(bf[r]);
-        if (PART) {
-            qx[r] = px;
-            qy[r] = py;
-            qz[r] = pz;
-            bg[r] = __ballot(i < c.n && !f);
-            if (lane == 0) wcnt2[r][wave] = (uint32_t)__popcll(bg[r]);
-        }
-    }
-    __syncthreads();
-    uint32_t mine = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) mine += (wcnt[r][0] + wcnt[r][1]) + (wcnt[r][2] + wcnt[r][3]);
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&fs.state[blockIdx.x], ((unsigned long long)fs.epoch << 32) | (unsigned long long)mine,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (SUMS) {
-        __shared__ double sm[NV * 256];
-        block_tree_reduce<NV>(acc, sm);
-        // The partials go out as device-scope atomic stores (written through) and are complete before the ticket is
-        // drawn: no fence -- a fence would write back and invalidate the whole L2, which by then holds the index lists
-        // of the workgroups that are already writing.
-        if (threadIdx.x < 12) {
-            const double v = (int)threadIdx.x < NV ? sm[threadIdx.x * 256] : 0.0;
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&moment_partial[(size_t)blockIdx.x * 16 + threadIdx.x]),
-                               (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t before = atomicAdd(fs.ticket, 1u);
-            is_last = before == gridDim.x - 1u ? 1u : 0u;
-            if (is_last) atomicExch(fs.ticket, 0u);   // (ready for the next launch)
-        }
-        __syncthreads();
-        if (is_last) {   // (workgroup-uniform) every partial is in: fold them, thread (g, l) sums workgroups l, l + 64, ...
-            double* msum = sm;
-            const uint32_t gq = threadIdx.x >> 6, l = threadIdx.x & 63u;
-            for (uint32_t g0 = 0; g0 < 12u; g0 += 4u) {
-                const uint32_t g = g0 + gq;
-                double a = 0.0;
-                for (uint32_t b = l; b < gridDim.x; b += 64u)
-                    a += __longlong_as_double((long long)__hip_atomic_load(
-                        reinterpret_cast<const unsigned long long*>(&moment_partial[(size_t)b * 16 + g]), __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_AGENT));
-                msum[gq * 64 + l] = a;
-                __syncthreads();
-                for (int off = 32; off > 0; off >>= 1) {
-                    if ((int)l < off) msum[gq * 64 + l] += msum[gq * 64 + l + off];
-                    __syncthreads();
-                }
-                if (l == 0) tail.moment_out[g] = msum[gq * 64];
-                __syncthreads();
-            }
-        }
-    }
-    // the inliers of the workgroups before this one
-    uint32_t row_base;
-    {
-        uint32_t partsum = 0;
-        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256u) {
-            unsigned long long v = __hip_atomic_load(&fs.state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while ((uint32_t)(v >> 32) != fs.epoch) {
-                __builtin_amdgcn_s_sleep(4);
-                v = __hip_atomic_load(&fs.state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            partsum += (uint32_t)v;
-        }
-        for (int off = 32; off > 0; off >>= 1) partsum += (uint32_t)__shfl_xor((int)partsum, off, 64);
-        if (lane == 0) red[wave] = partsum;
-        __syncthreads();
-        row_base = (red[0] + red[1]) + (red[2] + red[3]);
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) compact_tail_total(tail, row_base + mine);
-    uint32_t rest_base = base - row_base;   // (every workgroup before this one holds kCompactTile points)
-    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t i = base + r * 256 + threadIdx.x;
-        uint32_t woff = 0, woff2 = 0;
-        for (int w = 0; w < wave; ++w) {
-            woff += wcnt[r][w];
-            if (PART) woff2 += wcnt2[r][w];
-        }
-        if ((bf[r] >> lane) & 1ull) {
-            const uint32_t pos = row_base + woff + (uint32_t)__popcll(bf[r] & below);
-            const uint64_t id = orig ? (uint64_t)orig[i] : (uint64_t)i;
-            if (out_idx) out_idx[pos] = id;
-            if (out_idx_host) out_idx_host[pos] = id;   // 512-B bursts per wave row straight over the host link
-        }
-        row_base += (wcnt[r][0] + wcnt[r][1]) + (wcnt[r][2] + wcnt[r][3]);
-        if (PART) {
-            if ((bg[r] >> lane) & 1ull) {
-                const uint32_t pos = rest_base + woff2 + (uint32_t)__popcll(bg[r] & below);
-                part.ox[pos] = qx[r];
-                part.oy[pos] = qy[r];
-                part.oz[pos] = qz[r];
-                part.oorig[pos] = orig[i];
-            }
-            rest_base += (wcnt2[r][0] + wcnt2[r][1]) + (wcnt2[r][2] + wcnt2[r][3]);
-        }
-    }
-    if (PART && blockIdx.x == gridDim.x - 1) {   // NaN padding of the partition (compact_write_k)
-        const uint32_t n = rest_base;
-        const uint32_t n_pad = min(part.n_pad_cap, (n + kScoreTile - 1) / kScoreTile * kScoreTile);
-        const double nan = u2f(0x7FF8000000000000ull);
-        for (uint32_t i = n + threadIdx.x; i < n_pad; i += 256u) {
-            part.ox[i] = nan;
-            part.oy[i] = nan;
-            part.oz[i] = nan;
-        }
-    }
-}
-
 template <int KIND>
 static void launch_compact_kind(const CloudView& c, const double* model, double thr, int mode,
                                 const uint32_t* orig, uint64_t* out_idx, double* out_dist,
                                 double* ox, double* oy, double* oz, uint32_t* oorig,
                                 uint32_t n_pad_out, uint32_t* block_counts, uint32_t* total,
                                 hipStream_t s, double* model_copy, double* moment_partial, double* moment_out,
-                                uint64_t* out_idx_host, uint32_t* total_host, const PartitionOut* part,
-                                const FusedScan* fs) {
+                                uint64_t* out_idx_host, uint32_t* total_host, const PartitionOut* part) {
     const uint32_t nb = (c.n + kCompactTile - 1) / kCompactTile;
     if (nb == 0) {
         (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
@@ -899,23 +719,6 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
         return;
     }
     const bool sums = moment_partial && moment_out && mode == 0 && KIND != 2;
-    if (mode == 0 && fs && fs->state && (!part || orig)) {   // one pass
-        CompactTail tail;
-        tail.total = total;
-        tail.total_host = total_host;
-        tail.moment_out = sums ? moment_out : nullptr;
-        tail.nb = nb;
-        const PartitionOut po = part ? *part : PartitionOut();
-        auto go = [&](auto kernel) {
-            kernel<<<nb, 256, 0, s>>>(c, model, thr, orig, *fs, out_idx, out_idx_host, model_copy, moment_partial, po, tail);
-        };
-        constexpr int SK = KIND == 2 ? 0 : KIND;   // (no moments for cylinders: `sums` is false)
-        if (sums && part) go(compact_fused_k<SK, true, true>);
-        else if (sums) go(compact_fused_k<SK, true, false>);
-        else if (part) go(compact_fused_k<KIND, false, true>);
-        else go(compact_fused_k<KIND, false, false>);
-        return;
-    }
     if (sums)
         compact_count_k<KIND == 2 ? 0 : KIND, true><<<nb, 256, 0, s>>>(c, model, thr, 0, block_counts, model_copy, moment_partial);
     else
@@ -948,16 +751,16 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
                     uint32_t* block_counts, uint32_t* total, hipStream_t s, double* model_copy,
                     double* moment_partial, double* moment_out, uint64_t* out_idx_host, uint32_t* total_host,
-                    const PartitionOut* part, const FusedScan* fs) {
+                    const PartitionOut* part) {
     if (kind == 0)
         launch_compact_kind<0>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part, fs);
+                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part);
     else if (kind == 1)
         launch_compact_kind<1>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part, fs);
+                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part);
     else
         launch_compact_kind<2>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host, total_host, part, fs);
+                               n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host, total_host, part);
 }
 
 // EvaluateModel's `error += distance` in point order (ransac.h:637): a genuinely serial fp64 chain.

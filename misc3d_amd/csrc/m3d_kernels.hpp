@@ -88,14 +88,6 @@ struct PartitionOut {
     uint32_t* oorig = nullptr;
     uint32_t n_pad_cap = 0;
 };
-// State of the one-pass mode-0 compaction (compact_fused_k): one 64-bit word per workgroup (launch epoch << 32 | the
-// workgroup's count) and a ticket word, both zero before the first use and never reset by the caller; `epoch` differs
-// from launch to launch on the same state (and is never 0).
-struct FusedScan {
-    unsigned long long* state = nullptr;
-    uint32_t* ticket = nullptr;
-    uint32_t epoch = 0;
-};
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
@@ -106,8 +98,7 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
                                                     moments over the inliers about the model record's provisional centre */,
                     uint64_t* out_idx_host = nullptr /* mode 0: page-locked host copy of the index list, written by the kernel */,
                     uint32_t* total_host = nullptr /* device-visible host word that receives total[0] as well (no copy command) */,
-                    const PartitionOut* part = nullptr /* mode 0 with orig != null: the non-inliers' partition rides along */,
-                    const FusedScan* fs = nullptr /* mode 0: count, offsets and write in one launch (compact_fused_k) */);
+                    const PartitionOut* part = nullptr /* mode 0 with orig != null: the non-inliers' partition rides along */);
 // moment_out layout: [0..2] sum s, [3..8] sum s s^T (xx,xy,xz,yy,yz,zz), [9..11] sum s |s|^2 (sphere), [12] inlier count;
 // s = p - c0, c0 = model[4..6] (plane: the hypothesis' first sample point) or model[0..2] (sphere: the minimal centre).
 constexpr int kFusedMomentDoubles = 16;

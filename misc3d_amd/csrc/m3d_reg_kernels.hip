@@ -854,268 +854,6 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// K9b  the same validation with the target neighbourhood of a source tile STAGED IN LDS
-// ------------------------------------------------------------------------------------------------
-// reg_validate_k above is bound by dependent gathers: per (hypothesis, point) two loads of the neighbour-list
-// bounds and then ~17 candidates of 32 bytes from L2 -- 5.3 G queries on BASELINE config C4 at 11 G queries/s,
-// twenty times below what the arithmetic costs.  But the survivors of a chunk are overwhelmingly NEAR-IDENTICAL
-// poses (three true correspondences with millimetre noise), and a source tile is 256 Hilbert-consecutive points
-// (a patch a few centimetres across): under all of those poses the tile lands on the same few hundred target
-// cells.  So a workgroup stages that neighbourhood ONCE -- the target points of a box of at most kRegLdsL^3 grid
-// cells around the image of ONE ROW of 64 source points under the first pose of its hypothesis range, as a local
-// dense cell table (start offsets, x fastest) + the points in cell order -- and then streams all its hypotheses against
-// it: 16 waves = 16 hypothesis streams over the same 64 points, transformations through SGPRs as before, every
-// candidate read from LDS.  (Rows, not 256-point tiles: runs of a space-filling curve over a SURFACE jump, and two
-// thirds of the 256-point tiles of C4 had boxes beyond any local table; the session therefore sorts the source by coarse
-// cells and pads every cell to whole rows, which bounds a row's box by the cell.)  A hypothesis under which some point of the wave leaves the box minus the
-// box (a false pose that merely passed the checkers, or the rare outlier) takes the global path above for
-// that wave: same candidate sets, same d2 expression, `min` is order-free -- counts and sums are bit-identical.
-constexpr int kRegLdsL = 24;           // local grid edge in cells (a row's image spans <= 14, typically 8-10, + 2 (2 + spread) halo)
-constexpr int kRegLdsPts = 1792;       // staged target points (cap; a box with more takes the global path): 79 KB of LDS, two workgroups per CU
-constexpr int kRegLdsStreams = 16;     // hypothesis streams per workgroup (one wave each: the row's 64 points)
-constexpr int kRegLdsSpread = 1;       // cells of pose spread the box allows beyond halo and tile extent (true poses differ by millimetres)
-constexpr size_t kRegLdsBytes = sizeof(double) * 3 * kRegLdsPts + sizeof(uint16_t) * kRegLdsL * kRegLdsL * (kRegLdsL + 1) +
-                                sizeof(uint32_t) * (3 * kRegLdsL * kRegLdsL + 2) + 64;
-
-struct LdsBox {
-    const uint16_t* start;   // (lz * Ly + ly) * (Lx + 1) + lx -> offset of the cell's first point; entry Lx closes the row
-    const double *x, *y, *z;
-    int lox, loy, loz, Lx, Ly, Lz;
-};
-
-// nearest_d2 with phase 1 (the 3x3x3 block around the query's cell: the common case, a neighbour closer than one cell
-// edge) served from the staged box.  Precondition: the query's cell lies at least ONE cell inside the box on every
-// side.  Phase 2 (nothing that close: 0.1 - 0.5 % of the queries) goes to the global grid as before.
-__device__ __forceinline__ double nearest_d2_lds(const GridDesc& g, const LdsBox& b, const uint32_t* __restrict__ cell_start,
-                                                 const double* __restrict__ qx, const double* __restrict__ qy,
-                                                 const double* __restrict__ qz, int ix, int iy, int iz, double px,
-                                                 double py, double pz) {
-    const int cx = ix - b.lox, cy = iy - b.loy, cz = iz - b.loz, W = b.Lx + 1;
-    double best = INFINITY;
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int r = ((cz + dz) * b.Ly + (cy + dy)) * W + cx;
-            const uint32_t c0 = b.start[r - 1], c1 = b.start[r + 2];
-            for (uint32_t c = c0; c < c1; ++c) {
-                const double ddx = px - b.x[c], ddy = py - b.y[c], ddz = pz - b.z[c];
-                const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                if (d2 < best) best = d2;
-            }
-        }
-    if (best < g.h2_in || g.K == 1) return best;
-    return nearest_phase2(g, cell_start, qx, qy, qz, ix, iy, iz, px, py, pz, best);
-}
-
-// partial_cnt / partial_sum: [row][s_pad] -- a wave owns whole hypotheses of its row: no cross-wave reduction inside the
-// kernel.  "tile" below = row of 64 points.
-__global__ __launch_bounds__(1024) void reg_validate_lds_k(
-    const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ sz,
-    const double* __restrict__ Ts, uint32_t s_pad, uint32_t s_per_split, GridDesc g,
-    const uint32_t* __restrict__ cell_start, const double* __restrict__ qx, const double* __restrict__ qy,
-    const double* __restrict__ qz, uint32_t* __restrict__ partial_cnt, double* __restrict__ partial_sum,
-    uint32_t res_mask, uint32_t n_tiles_total, const uint8_t* __restrict__ keep, uint32_t n_tiles_launch, uint32_t n_split,
-    unsigned long long* __restrict__ fast_stats /* [0] += wave-hypotheses on the LDS path, [1] += on the global path,
-                                                   [2] workgroups, [3] box larger than the local table, [4] more points than the staging arrays */) {
-    extern __shared__ unsigned char lds_raw[];
-    double* lpx = reinterpret_cast<double*>(lds_raw);
-    double* lpy = lpx + kRegLdsPts;
-    double* lpz = lpy + kRegLdsPts;
-    uint32_t* row_gb = reinterpret_cast<uint32_t*>(lpz + kRegLdsPts);          // global index of a row's first point
-    uint32_t* row_off = row_gb + kRegLdsL * kRegLdsL;                           // its offset in the staged arrays (+ total)
-    uint32_t* row_cnt = row_off + kRegLdsL * kRegLdsL + 1;
-    int* reg = reinterpret_cast<int*>(row_cnt + kRegLdsL * kRegLdsL);           // lox loy loz Lx Ly Lz ok
-    uint16_t* lstart = reinterpret_cast<uint16_t*>(reg + 8);
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int stream = wave;
-    const uint32_t xcd = blockIdx.x % 8u, jq = blockIdx.x / 8u;   // XCD-aware (tile, split) map, as reg_validate_k
-    const uint32_t tile_local = (jq / n_split) * 8u + xcd, split = jq % n_split;
-    if (tile_local >= n_tiles_launch) return;   // whole block (uniform)
-    const uint32_t tile = phase_tile(tile_local, res_mask);
-    if (tile >= n_tiles_total) return;
-    const uint32_t s0 = split * s_per_split;
-    const uint32_t s1 = min(s0 + s_per_split, s_pad);
-    const int K = g.K;
-
-    // ---- 1. the box: bounding box of the row's 64 points UNDER the first real pose of the range, + halo + spread
-    if (wave == 0) {
-        uint32_t sr = s0;
-        while (sr < s1 && !(Ts[(size_t)sr * kRegTStride] == Ts[(size_t)sr * kRegTStride])) ++sr;   // skip NaN padding (uniform)
-        double lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
-        if (sr < s1) {
-            const double* T = Ts + (size_t)sr * kRegTStride;
-            const size_t i = (size_t)tile * 64 + lane;
-            const double x = sx[i], y = sy[i], z = sz[i];
-            const double p[3] = {((T[0] * x + T[1] * y) + T[2] * z) + T[3], ((T[4] * x + T[5] * y) + T[6] * z) + T[7],
-                                 ((T[8] * x + T[9] * y) + T[10] * z) + T[11]};
-            for (int k = 0; k < 3; ++k) lo3[k] = hi3[k] = p[k];   // NaN padding slots drop out of fmin / fmax below
-        }
-        for (int off = 32; off > 0; off >>= 1)
-            for (int k = 0; k < 3; ++k) {
-                lo3[k] = fmin(lo3[k], __shfl_xor(lo3[k], off, 64));
-                hi3[k] = fmax(hi3[k], __shfl_xor(hi3[k], off, 64));
-            }
-        if (lane == 0) {
-            int ok = (sr < s1 && lo3[0] <= hi3[0] && lo3[1] <= hi3[1] && lo3[2] <= hi3[2]) ? 1 : 0, lo[3] = {0, 0, 0}, L[3] = {0, 0, 0};
-            if (ok) {
-                const double h = 1.0 / g.inv_h;
-                const double halo = (double)(2 + kRegLdsSpread) * h;   // 3x3x3 block + cell-assignment slack + pose spread
-                const double o[3] = {g.ox, g.oy, g.oz};
-                const int nmax[3] = {(int)g.nx, (int)g.ny, (int)g.nz};
-                for (int k = 0; k < 3; ++k) {
-                    const double flo = (lo3[k] - halo - o[k]) * g.inv_h, fhi = (hi3[k] + halo - o[k]) * g.inv_h;
-                    if (!(flo == flo) || !(fhi == fhi) || fhi < 0.0 || flo >= (double)nmax[k]) {
-                        ok = 0;   // non-finite pose, or the image lies outside the grid: nothing to stage
-                        break;
-                    }
-                    const int a = flo < 0.0 ? 0 : (int)flo;
-                    const int b = fhi >= (double)nmax[k] ? nmax[k] - 1 : (int)fhi;
-                    lo[k] = a;
-                    L[k] = b - a + 1;
-                    if (L[k] > kRegLdsL || L[k] < 3) ok = 0;
-                }
-            }
-            reg[0] = lo[0];
-            reg[1] = lo[1];
-            reg[2] = lo[2];
-            reg[3] = L[0];
-            reg[4] = L[1];
-            reg[5] = L[2];
-            reg[6] = ok;
-            if (fast_stats) {   // diagnostics: workgroups, and those whose box does not fit the local table
-                atomicAdd(&fast_stats[2], 1ull);
-                if (!ok) atomicAdd(&fast_stats[3], 1ull);
-            }
-        }
-    }
-    __syncthreads();
-    const int lox = reg[0], loy = reg[1], loz = reg[2], Lx = reg[3], Ly = reg[4], Lz = reg[5];
-    int box_ok = reg[6];
-    const int nrows = Ly * Lz, W = Lx + 1;
-    if (box_ok) {
-        // ---- 2. points per (z, y) row of the box: the cells lox .. lox + Lx - 1 of a row are contiguous in the sorted arrays
-        for (int r = threadIdx.x; r < nrows; r += 1024) {
-            const int z = r / Ly, y = r - z * Ly;
-            const size_t rb = ((size_t)(loz + z) * g.ny + (size_t)(loy + y)) * g.nx + (size_t)lox;
-            const uint32_t gb = cell_start[rb], ge = cell_start[rb + Lx];
-            row_gb[r] = gb;
-            row_cnt[r] = ge - gb;
-        }
-        __syncthreads();
-        if (wave == 0) {   // exclusive scan of <= 576 row counts by one wave: 9 consecutive rows per lane
-            constexpr int kPer = (kRegLdsL * kRegLdsL + 63) / 64;
-            uint32_t loc[kPer], sum = 0;
-            for (int k = 0; k < kPer; ++k) {
-                const int r = lane * kPer + k;
-                loc[k] = r < nrows ? row_cnt[r] : 0u;
-                sum += loc[k];
-            }
-            uint32_t incl = sum;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            uint32_t run = incl - sum;
-            for (int k = 0; k < kPer; ++k) {
-                const int r = lane * kPer + k;
-                if (r < nrows) row_off[r] = run;
-                run += loc[k];
-            }
-            if (lane == 63) {
-                row_off[nrows] = incl;
-                if (incl > (uint32_t)kRegLdsPts) {   // too many points for the staging arrays
-                    reg[6] = 0;
-                    if (fast_stats) atomicAdd(&fast_stats[4], 1ull);
-                }
-            }
-        }
-        __syncthreads();
-        box_ok = reg[6];
-    }
-    if (box_ok) {
-        // ---- 3. the local cell table and the points
-        for (int i = threadIdx.x; i < nrows * W; i += 1024) {
-            const int r = i / W, x = i - r * W;
-            const int z = r / Ly, y = r - z * Ly;
-            const size_t rb = ((size_t)(loz + z) * g.ny + (size_t)(loy + y)) * g.nx + (size_t)lox;
-            lstart[i] = (uint16_t)(row_off[r] + (cell_start[rb + x] - row_gb[r]));
-        }
-        const uint32_t total = row_off[nrows];
-        for (uint32_t l = threadIdx.x; l < total; l += 1024) {
-            int a = 0, b = nrows;   // last row with row_off <= l
-            while (b - a > 1) {
-                const int m = (a + b) >> 1;
-                if (row_off[m] <= l) a = m; else b = m;
-            }
-            const uint32_t c = row_gb[a] + (l - row_off[a]);
-            lpx[l] = qx[c];
-            lpy[l] = qy[c];
-            lpz[l] = qz[c];
-        }
-    }
-    __syncthreads();
-    LdsBox box;
-    box.start = lstart;
-    box.x = lpx;
-    box.y = lpy;
-    box.z = lpz;
-    box.lox = lox;
-    box.loy = loy;
-    box.loz = loz;
-    box.Lx = Lx;
-    box.Ly = Ly;
-    box.Lz = Lz;
-
-    // ---- 4. hypotheses: stream (= wave) k takes the 64-groups s0 + 64 (k + 16 i)
-    const size_t base = (size_t)tile * 64 + lane;
-    const double x = sx[base], y = sy[base], z = sz[base];
-    uint32_t n_fast = 0, n_slow = 0;
-    for (uint32_t sb = s0 + 64u * (uint32_t)stream; sb < s1; sb += 64u * kRegLdsStreams) {
-        uint32_t acc = 0;
-        double acc_sum = 0.0;
-        for (uint32_t ss = 0; ss < 64; ++ss) {
-            const double* __restrict__ T = Ts + (size_t)(sb + ss) * kRegTStride;
-            double t[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) t[k] = T[k];
-            uint32_t cnt = 0;
-            double sum = 0.0;
-            const bool run = keep ? keep[sb + ss] != 0 : true;
-            if (t[0] == t[0] && run) {  // padding records are NaN (wave-uniform branch)
-                const double px = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
-                const double py = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
-                const double pz = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
-                int ix = 0, iy = 0, iz = 0;
-                const bool in_grid = cell_of(g, px, py, pz, K, &ix, &iy, &iz);   // false: no neighbour within the radius
-                const bool in_box = ix - lox >= 1 && ix - lox < Lx - 1 && iy - loy >= 1 && iy - loy < Ly - 1 &&
-                                    iz - loz >= 1 && iz - loz < Lz - 1;
-                double d2;
-                if (box_ok && __ballot(in_grid && !in_box) == 0ull) {   // wave-uniform
-                    d2 = in_grid ? nearest_d2_lds(g, box, cell_start, qx, qy, qz, ix, iy, iz, px, py, pz) : INFINITY;
-                    n_fast++;
-                } else {
-                    d2 = nearest_d2(g, cell_start, qx, qy, qz, px, py, pz);
-                    n_slow++;
-                }
-                const bool f = d2 < g.r2;
-                cnt = (uint32_t)__popcll(__ballot(f));
-                sum = f ? d2 : 0.0;
-                for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-            }
-            acc = ((uint32_t)lane == ss) ? cnt : acc;
-            acc_sum = ((uint32_t)lane == ss) ? sum : acc_sum;
-        }
-        const size_t row = (size_t)tile * s_pad + sb + lane;
-        partial_cnt[row] = acc;
-        partial_sum[row] = acc_sum;
-    }
-    if (fast_stats && lane == 0) {
-        if (n_fast) atomicAdd(&fast_stats[0], (unsigned long long)n_fast);
-        if (n_slow) atomicAdd(&fast_stats[1], (unsigned long long)n_slow);
-    }
-}
-
 // sums[s] = sum over tiles of partial_sum[tile][s] in tile order (deterministic)
 // (workgroup = 64 hypotheses x kFoldSlices interleaved slices of the tiles, folded in LDS in a fixed order: a thread per
 // hypothesis walking all ~800 tiles alone took 0.2 ms per call)
@@ -1180,42 +918,18 @@ __global__ __launch_bounds__(64 * kFoldSlices) void reg_keep_k(const uint32_t* _
 
 // best_cnt / best_sum2: inlier count and order-free sum of squared distances of the best hypothesis of EARLIER chunks
 // (best_cnt 0: nothing to prune against).  n_points: real source points.  keep: s_pad bytes of scratch.
-// lds_rows: the LDS-staged kernel, whose unit is a row of 64 points (the source copy must be row-aligned to coarse cells,
-// m3d_registration.cpp); the partial arrays then hold one row per 64 points.  Returns the number of partial rows (what the reduce kernels fold).
+// Returns the number of partial rows (what the reduce kernels fold).
 uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
                              const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
                              uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
-                             uint32_t n_points, uint8_t* keep, hipStream_t s, bool lds_rows,
-                             unsigned long long* fast_stats, double best_sum2, uint32_t n_hyp) {
+                             uint32_t n_points, uint8_t* keep, hipStream_t s, double best_sum2, uint32_t n_hyp) {
     if (!s_pad || !src.n_pad) return 0;
     const uint32_t groups = s_pad / 64;
-    const bool lds = lds_rows;
-    const uint32_t n_tiles = lds ? src.n_pad / 64 : src.n_pad / kRegTile;
-    const uint32_t tile_points = lds ? 64u : (uint32_t)kRegTile;
-    if (lds) {
-        static bool attr_set = false;   // (idempotent; a race would set the same value twice)
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reg_validate_lds_k),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRegLdsBytes);
-            attr_set = true;
-        }
-    }
+    const uint32_t n_tiles = src.n_pad / kRegTile;
+    const uint32_t tile_points = (uint32_t)kRegTile;
     auto launch = [&](uint32_t res_mask, const uint8_t* kp) {
         // (upper bound of the tiles of the launch; the kernel drops indices past the last tile)
         const uint32_t tiles = (n_tiles + 7) / 8 * (uint32_t)__builtin_popcount(res_mask);
-        if (lds) {
-            // a workgroup = 4 hypothesis streams on one staged box: few, long hypothesis ranges per tile (the staging is
-            // paid once per workgroup), still enough workgroups to fill the chip twice over
-            const uint32_t want = std::max<uint32_t>(1, (768 + tiles - 1) / tiles);
-            const uint32_t splits = std::min(want, std::max<uint32_t>(1, groups / kRegLdsStreams));
-            const uint32_t gps = (groups + splits - 1) / splits;
-            const uint32_t nsplit = (groups + gps - 1) / gps;
-            const uint32_t slots = (tiles + 7) / 8;
-            reg_validate_lds_k<<<slots * 8 * nsplit, 1024, kRegLdsBytes, s>>>(src.x, src.y, src.z, Ts, s_pad, gps * 64,
-                                                                             g, cell_start, qx, qy, qz, partial_cnt, partial_sum,
-                                                                             res_mask, n_tiles, kp, tiles, nsplit, fast_stats);
-            return;
-        }
         // enough blocks to fill the chip several times over (the pruning phases launch an eighth of the tiles: 16 384 blocks
         // instead of 2048 is 4 % on C4), and at least ~40 splits per tile so that the ~160 blocks an XCD holds at a time
         // belong to a handful of tiles (see the block map in the kernel)
@@ -1242,14 +956,13 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         // four phases: an eighth of the tiles, another eighth, a quarter, the remaining half; the hypotheses still in
         // the race are re-assessed in between (reg_keep_k)
         static const uint32_t kPhase[4] = {0x01u, 0x10u, 0x44u, 0xAAu};
-        // real source points on the tiles of a residue class: exact when the real points are the first n_points slots
-        // (the row-aligned layout of the LDS-staged kernel pads in between: every slot is counted there, an upper bound)
+        // real source points on the tiles of a residue class (the real points are the first n_points slots)
         auto points_on = [&](uint32_t mask) {
             uint64_t n = 0;
             for (uint32_t t = 0; t < n_tiles; ++t)
                 if ((mask >> (t & 7u)) & 1u) {
                     const uint64_t lo = (uint64_t)t * tile_points;
-                    n += lds ? tile_points : (uint64_t)std::min<uint64_t>(tile_points, n_points > lo ? n_points - lo : 0);
+                    n += (uint64_t)std::min<uint64_t>(tile_points, n_points > lo ? n_points - lo : 0);
                 }
             return (uint32_t)std::min<uint64_t>(n, n_points);
         };
@@ -1260,7 +973,7 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
             done |= kPhase[ph];
             if (ph < 3)
                 reg_keep_k<<<s_pad / 64, 64 * kFoldSlices, 0, s>>>(partial_cnt, partial_sum, n_tiles, done, s_pad,
-                                                               points_on(0xFFu & ~done), !lds, best_cnt, limit, keep, ph == 0 ? 1 : 0);
+                                                               points_on(0xFFu & ~done), true, best_cnt, limit, keep, ph == 0 ? 1 : 0);
         }
     }
     reduce_sums_k<<<s_pad / 64, 64 * kFoldSlices, 0, s>>>(partial_sum, n_tiles, s_pad, sums);

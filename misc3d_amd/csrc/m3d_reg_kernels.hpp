@@ -77,15 +77,13 @@ void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_
 // layout of GridDesc::nl32: nl32_start[0..ncell] (scratch of ncell + 1 words), total[0] = entries incl. sentinels
 void launch_nl32_offsets(const uint32_t* nl_start, uint32_t ncell, uint32_t* nl32_start, uint32_t* tile_sums,
                          uint32_t* total, hipStream_t s);
-// partial_cnt / partial_sum: src.n_pad / 64 rows of s_pad entries (the LDS-staged kernel, lds_rows, writes one row
-// per 64 source points; reg_validate_k one per 256).  Returns the rows actually used: what launch_reduce_partials folds.
+// partial_cnt / partial_sum: rows of s_pad entries, reg_validate_k writes one per 256 source points (the arrays are
+// sized for kRegValidateRows per 256).  Returns the rows actually used: what launch_reduce_partials folds.
 constexpr int kRegValidateRows = 4;   // rows per 256 source points
 uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
                              const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
                              uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
                              uint32_t n_points, uint8_t* keep, hipStream_t s,
-                             bool lds_rows = false /* the LDS-staged kernel (source copy row-aligned to coarse cells) */,
-                             unsigned long long* fast_stats = nullptr /* [0] LDS path, [1] global path (wave-hypotheses) */,
                              double best_sum2 = 0.0 /* order-free sum of squared distances of the hypothesis behind best_cnt */,
                              uint32_t n_hyp = 0 /* real hypotheses among the s_pad records (0: unknown); a handful is spread over more workgroups */);
 void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,

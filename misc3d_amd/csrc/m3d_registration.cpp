@@ -67,13 +67,13 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, nl32_fallbacks, cell_orig, tile_sph, fast_stats;
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, nl32_fallbacks, cell_orig, tile_sph;
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
                           &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &nl_hdr, &nl32, &nl_rec, &nl32_start, &nl32_fallbacks, &cell_orig,
-                          &tile_sph, &fast_stats})
+                          &tile_sph})
             b->release();
     }
 };
@@ -402,8 +402,6 @@ struct m3d_reg {
     size_t chunk = 32;
     size_t validated_total = 0, n_dst_points = 0;
     bool nl_built = false;
-    bool spheres_built = false;   // bounding boxes of the source rows (LDS-staged validation)
-    bool rows_aligned = false;    // the sorted source copy is padded so that no row of 64 spans two coarse cells
     int itr = 0;
     int n_exec = 0;          // iterations of the chunk in flight
     bool finished = false;
@@ -469,31 +467,19 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
         }
         if (ext > 0.0 && std::isfinite(ext)) {
             GridDesc gs;
-            // LDS-staged validation (reg_validate_lds_k): the source is sorted by COARSE cells of 2 x threshold (Hilbert
-            // order of the cells) and every cell's run is padded to whole rows of 64 points, so a row's bounding box is
-            // at most one coarse cell and its image under a pose + a three-cell halo fits the kernel's local table.
-            // Otherwise: Hilbert order over 128^3 cells (m3d_config.reg_source_rows: x-rows of a 64^3 grid) -- the 64
-            // points of a wave form a compact patch, so the lanes probe the same few target cells.
-            const double D = 2.0 * threshold * 1.001;
-            uint32_t cbits = 1;
-            while (cbits < 6 && (double)(1u << cbits) * D < ext * (1.0 + 1e-9)) ++cbits;
-            // fine Hilbert cells of D / 4 (so that a wave's 64 points stay a compact patch INSIDE the coarse cell too);
-            // the 64 fine cells of a coarse cell are consecutive on the curve and aligned: code >> 6 = coarse cell
-            const bool coarse = config().reg_lds_staging != 0 && (double)(1u << cbits) * D >= ext * (1.0 + 1e-9);
-            const bool hilbert = coarse || !config().reg_source_rows;
-            const uint32_t fbits = coarse ? cbits + 2 : 7u;
-            const double hs = coarse ? D / 4.0 : (hilbert ? ext / 127.0 : ext / 63.0);
+            // Hilbert order over 128^3 cells: the 64 points of a wave form a compact patch, so the lanes probe the same few
+            // target cells
+            const uint32_t fbits = 7u;
+            const double hs = ext / 127.0;
             gs.K = 0;
-            gs.morton_bits = hilbert ? (fbits | 0x100u) : 0u;
+            gs.morton_bits = fbits | 0x100u;
             gs.ox = slo[0];
             gs.oy = slo[1];
             gs.oz = slo[2];
             gs.inv_h = 1.0 / hs;
             gs.r2 = gs.h2_in = 0.0;
             const uint32_t side = 1u << fbits;
-            gs.nx = hilbert ? side : (uint32_t)((shi[0] - slo[0]) / hs) + 2;
-            gs.ny = hilbert ? side : (uint32_t)((shi[1] - slo[1]) / hs) + 2;
-            gs.nz = hilbert ? side : (uint32_t)((shi[2] - slo[2]) / hs) + 2;
+            gs.nx = gs.ny = gs.nz = side;
             const uint32_t ncs = gs.nx * gs.ny * gs.nz;
             RESERVE(S.s_cell_of_point, sizeof(uint32_t) * n_src);
             RESERVE(S.s_cell_start, sizeof(uint32_t) * ((size_t)ncs + 1));
@@ -501,14 +487,8 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
             RESERVE(S.s_tile_sums, sizeof(uint32_t) * ((size_t)(ncs + 2047) / 2048 + 1));
             launch_grid_count_scan(R.src, gs, S.s_cell_of_point.as<uint32_t>(), S.s_cell_start.as<uint32_t>(),
                                    S.s_fill.as<uint32_t>(), S.s_tile_sums.as<uint32_t>(), S.total.as<uint32_t>() + 2,
-                                   ctx->stream, coarse ? 64u : 0u, 64u);
-            uint32_t np = R.src.n_pad;
-            if (coarse) {   // the padded layout's length is only known now
-                uint32_t total = 0;
-                HIPCHK(hipMemcpyAsync(&total, S.total.as<uint32_t>() + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(hipStreamSynchronize(ctx->stream));
-                np = std::max<uint32_t>(round_up(total, kRegTile), kRegTile);
-            }
+                                   ctx->stream);
+            const uint32_t np = R.src.n_pad;
             RESERVE(S.sx, sizeof(double) * np);
             RESERVE(S.sy, sizeof(double) * np);
             RESERVE(S.sz, sizeof(double) * np);
@@ -522,7 +502,6 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
             src_sorted.z = S.sz.as<double>();
             src_sorted.n_pad = np;   // (NaN slots are no queries: counts and sums only see the real points)
             src_sorted.n = np;
-            rows_aligned = coarse;
         }
     }
 
@@ -627,21 +606,11 @@ int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double
         RESERVE(S.counts, sizeof(uint32_t) * s_pad);
 
         RESERVE(S.keep, s_pad);
-        // the LDS-staged kernel needs the source tiles' bounding spheres (once per session) and pays off with the
-        // neighbour lists' condition: a call that validates more than a handful of hypotheses
-        const bool lds = config().reg_lds_staging != 0 && nl_built && rows_aligned;
-        if (lds && !spheres_built) {
-            RESERVE(S.fast_stats, 8 * sizeof(unsigned long long));
-            HIPCHK(hipMemsetAsync(S.fast_stats.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
-            spheres_built = true;
-        }
         // bound-and-prune against the best of EARLIER chunks (m3d_config.reg_prune = 0 switches it off)
         const uint32_t rows = launch_reg_validate(src_sorted, Ts, s_pad, g, S.cell_start.as<uint32_t>(),
                             S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
                             S.partial.as<uint32_t>(), S.partial_sum.as<double>(), S.sum2.as<double>(),
-                            reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream,
-                            lds,
-                            lds ? S.fast_stats.as<unsigned long long>() : nullptr, best_sum2, ns);
+                            reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream, best_sum2, ns);
         HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
         launch_reduce_partials(S.partial.as<uint32_t>(), rows, s_pad, S.counts.as<uint32_t>(),
                                ctx->stream);
@@ -777,15 +746,6 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
             unsigned long long fb = 0;
             HIPCHK(hipMemcpy(&fb, g.nl32_fallbacks, sizeof(fb), hipMemcpyDeviceToHost));
             stats->nn_screen_fallbacks = fb;
-        }
-        if (spheres_built) {
-            unsigned long long fs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            HIPCHK(hipMemcpy(fs, S.fast_stats.p, sizeof(fs), hipMemcpyDeviceToHost));
-            stats->lds_wave_hypotheses = fs[0];
-            stats->global_wave_hypotheses = fs[1];
-            if (std::getenv("M3D_REG_DEBUG"))
-                std::fprintf(stderr, "reg_validate_lds_k: %llu workgroups, %llu with a box beyond the local table, %llu with too many points\n",
-                             fs[2], fs[3], fs[4]);
         }
     }
     if (stats) stats->ms_total = now_ms() - this->t_begin;
@@ -994,20 +954,37 @@ int m3d_registration_ransac_sharded(const double* src, size_t n_src, const doubl
         const size_t s0 = g0 * 64, s1 = std::min(g1 * 64, ns), shard = per * 64;
         counts.assign(std::max<size_t>(shard, 1), 0);
         sums.assign(std::max<size_t>(shard, 1), 0.0);
-        rc = m3d_reg_validate(q, s0, std::max(s0, s1), counts.data(), sums.data());
-        if (rc != M3D_OK) break;
+        // A rank whose validation fails (a device error: the one step of the loop that is not the same host logic on
+        // every rank) still takes part in the window's exchange, with a poisoned first record, so that its peers leave
+        // the loop with an error instead of waiting for it in the all-gather forever.  Failures elsewhere
+        // (begin_chunk, the exchange itself) happen on every rank alike or are fatal to the group, as with any collective.
+        const int vrc = m3d_reg_validate(q, s0, std::max(s0, s1), counts.data(), sums.data());
+        if (vrc != M3D_OK && !shard) {
+            rc = vrc;
+            break;
+        }
         counts_all.assign(std::max<size_t>(ns, 1), 0);
         sums_all.assign(std::max<size_t>(ns, 1), 0.0);
         if (shard) {   // ns == 0 on every rank alike: nothing to exchange
+            constexpr uint64_t kPoison = ~(uint64_t)0;
             mine.assign(shard, Rec{0.0, 0});
             for (size_t i = 0; i + s0 < s1; ++i) mine[i] = Rec{sums[i], counts[i]};
+            if (vrc != M3D_OK) mine[0].count = kPoison;
             all.assign(shard * world, Rec{0.0, 0});
             {
                 std::lock_guard<std::mutex> lock(q->ctx->mu);
-                HIPCHK(hipSetDevice(q->ctx->device));
-                rc = comm->allgather_host(mine.data(), all.data(), sizeof(Rec) * shard, q->ctx->stream);
+                rc = hipSetDevice(q->ctx->device) == hipSuccess
+                         ? comm->allgather_host(mine.data(), all.data(), sizeof(Rec) * shard, q->ctx->stream)
+                         : fail(M3D_ERR_DEVICE, "hipSetDevice failed");
             }
+            if (rc == M3D_OK && vrc != M3D_OK) rc = vrc;
             if (rc != M3D_OK) break;
+            bool peer_failed = false;
+            for (size_t r = 0; r < world; ++r) peer_failed = peer_failed || all[r * shard].count == kPoison;
+            if (peer_failed) {
+                rc = fail(M3D_ERR_DEVICE, "m3d_registration_ransac_sharded: another rank's validation failed");
+                break;
+            }
             for (size_t i = 0; i < ns; ++i) {   // rank-major slices of `shard` = survivor order
                 counts_all[i] = (uint32_t)all[i].count;
                 sums_all[i] = all[i].sum;

@@ -506,49 +506,3 @@ def test_lead_pass_inside_the_box_test_launch(capi, kind):
     assert 0 < st["pairs_timed"] < st["pairs_scored"]          # the lead pass ran inside cull_lead_k, untimed
     assert st0["pairs_timed"] == st0["pairs_scored"]           # separate launches: everything is timed
     assert st["score_launches"] + 1 == st0["score_launches"]   # one timed launch less (the lead's)
-
-
-@pytest.mark.parametrize("kind", [0, 1, 2])
-def test_one_pass_compaction_same_results(capi, kind):
-    """m3d_config.fused_compaction: RefineModel's inlier list, count and moment sums out of compact_fused_k (one launch, the
-    workgroups hand their counts to each other) are those of the counting + writing launches -- index list, inlier count
-    and refined parameters bit for bit; a segmentation (the partition of the rest rides on the same launch) gives the
-    same planes and clusters."""
-    rng = np.random.default_rng(8)
-    nrm = None
-    if kind == 0:
-        pts = synth.plane_cloud_c2(300_001, seed=8)
-    elif kind == 1:
-        d = rng.normal(size=(200_003, 3))
-        d /= np.linalg.norm(d, axis=1)[:, None]
-        pts = np.r_[0.3 * d[:120_000] + rng.normal(0, 1e-3, (120_000, 3)), rng.uniform(-1, 1, (80_003, 3))]
-    else:
-        t = rng.uniform(0, 2 * np.pi, 150_000)
-        z = rng.uniform(-1, 1, 150_000)
-        pts = np.c_[0.2 * np.cos(t), 0.2 * np.sin(t), z] + rng.normal(0, 1e-3, (150_000, 3))
-        nrm = np.c_[np.cos(t), np.sin(t), np.zeros_like(t)]
-        pts[100_000:] = rng.uniform(-1, 1, (50_000, 3))
-    kw = dict(threshold=0.01, max_iteration=2000, probability=1.0, seed=5)
-    old = capi.set_config(fused_compaction=0)
-    try:
-        a = [capi.fit(kind, pts, nrm, **kw) for _ in range(2)]
-        seg_a = capi.segment_plane_iterative(pts, 0.01, max_iteration=100, min_ratio=0.05, seed=3) if kind == 0 else None
-        capi.set_config(fused_compaction=1)
-        b = [capi.fit(kind, pts, nrm, **kw) for _ in range(3)]   # (several launches on the same state words)
-        seg_b = capi.segment_plane_iterative(pts, 0.01, max_iteration=100, min_ratio=0.05, seed=3) if kind == 0 else None
-        small = capi.fit(kind, pts[:5000], None if nrm is None else nrm[:5000], **kw)   # (a shorter grid after a longer one)
-        capi.set_config(fused_compaction=0)
-        small0 = capi.fit(kind, pts[:5000], None if nrm is None else nrm[:5000], **kw)
-    finally:
-        capi.restore_config(old)
-    for g in b:
-        assert g.stats["best_index"] == a[0].stats["best_index"] and g.stats["count"] == a[0].stats["count"]
-        assert np.array_equal(g.inliers, a[0].inliers)
-        assert np.array_equal(_bits(g.params), _bits(a[0].params))
-    assert np.array_equal(small.inliers, small0.inliers) and np.array_equal(_bits(small.params), _bits(small0.params))
-    if kind == 0:
-        (rc_a, planes_a, clusters_a), (rc_b, planes_b, clusters_b) = seg_a, seg_b
-        assert rc_a == rc_b and len(clusters_a) == len(clusters_b) > 0
-        assert np.array_equal(_bits(np.asarray(planes_a)), _bits(np.asarray(planes_b)))
-        for ca, cb in zip(clusters_a, clusters_b):
-            assert np.array_equal(ca, cb)

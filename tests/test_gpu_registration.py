@@ -54,10 +54,9 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
     cd = np.where(rng.random(1500) < frac, inv[cs], rng.integers(0, n, 1500))
     kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=edge, confidence=1.0, seed=4)
     T, st = capi.registration_ransac(src, dst, cs, cd, **kw)
-    # each optimisation switched off in turn, and the optional LDS-staged validation kernel switched on (m3d_config)
+    # each optimisation switched off in turn (m3d_config)
     assert st["nn_fp32_screen"] == (1 if st["validations"] > 48 else 0)    # (the lists are built once a call validates in earnest)
-    for env, val in (("reg_prune", 0), ("reg_neighbour_lists", 0), ("reg_sorted_lists", 0), ("reg_lds_staging", 1),
-                     ("reg_fp32_screen", 0)):
+    for env, val in (("reg_prune", 0), ("reg_neighbour_lists", 0), ("reg_sorted_lists", 0), ("reg_fp32_screen", 0)):
         old = capi.set_config(**{env: val})
         try:
             T0, st0 = capi.registration_ransac(src, dst, cs, cd, **kw)
@@ -66,17 +65,14 @@ def test_registration_prune_is_exact(capi, orc, frac, sigma, edge):
         assert np.array_equal(T, T0), env
         for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse", "ties"):
             assert st[k] == st0[k], (env, k)
-        # (here the shifted third of the source stretches the cloud beyond what the LDS-staged kernel's coarse source
-        # grid covers: it stands down and the ordinary kernel runs -- test_registration_lds_staging_is_exact has it run)
     assert 0.2 < st["fitness"] < 0.9
     o = orc.registration_ransac(src, dst, cs, cd, thr=0.03, max_iter=3000, edge_thr=edge, confidence=1.0, seed=4)
     assert st["best_index"] == o.best_index and st["validations"] == o.validations and st["fitness"] == o.fitness
     assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64))
 
 
-def test_registration_lds_staging_is_exact(capi, orc):
-    """The optional validation kernel that stages the target neighbourhood of a row of source points in LDS
-    (m3d_config.reg_lds_staging) and the x-sorted neighbour lists with their early cut-off (reg_sorted_lists) are
+def test_registration_sorted_lists_are_exact(capi, orc):
+    """The x-sorted neighbour lists with their early cut-off (m3d_config.reg_sorted_lists) and the plain lists are
     different ways to the same minimum: T, counts, tie decisions and the oracle's result are reproduced bit for bit."""
     n = 6000
     d = synth.registration_pair_c4(n, seed=9, dim=8, true_fraction=0.4, sigma=0.001)
@@ -87,21 +83,17 @@ def test_registration_lds_staging_is_exact(capi, orc):
     cd = np.where(rng.random(1500) < 0.4, inv[cs], rng.integers(0, n, 1500))
     kw = dict(threshold=0.03, max_iter=3000, edge_length_threshold=0.9, confidence=1.0, seed=4)
     res = {}
-    for lds in (0, 1):
-        for srt in (0, 1):
-            old = capi.set_config(reg_lds_staging=lds, reg_sorted_lists=srt)
-            try:
-                res[(lds, srt)] = capi.registration_ransac(d["src"], d["dst"], cs, cd, **kw)
-            finally:
-                capi.restore_config(old)
-    T, st = res[(0, 1)]
-    assert st["lds_wave_hypotheses"] == 0 and res[(1, 1)][1]["lds_wave_hypotheses"] > 10 * res[(1, 1)][1]["global_wave_hypotheses"]
-    for key, (T2, st2) in res.items():
-        assert np.array_equal(T, T2), key
-        # (`ties` / `exact_rmse_evals` count comparisons the replay makes; the in-chunk pruning on partial sums drops
-        # hypotheses before they get there, and how many depends on the source layout of the kernel in use)
-        for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse"):
-            assert st[k] == st2[k], (key, k)
+    for srt in (0, 1):
+        old = capi.set_config(reg_sorted_lists=srt)
+        try:
+            res[srt] = capi.registration_ransac(d["src"], d["dst"], cs, cd, **kw)
+        finally:
+            capi.restore_config(old)
+    T, st = res[1]
+    T2, st2 = res[0]
+    assert np.array_equal(T, T2)
+    for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse"):
+        assert st[k] == st2[k], k
     o = orc.registration_ransac(d["src"], d["dst"], cs, cd, thr=0.03, max_iter=3000, edge_thr=0.9, confidence=1.0, seed=4)
     assert np.array_equal(T, o.T) and st["best_index"] == o.best_index and st["validations"] == o.validations
 

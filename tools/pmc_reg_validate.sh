@@ -1,10 +1,9 @@
 #!/bin/bash
 # SQ counters of the registration validation kernels on C4 (one counter group per pass; --kernel-trace only, as the
-# pool requires).  Usage on the GPU box: bash tools/pmc_reg_validate.sh [0|1]   (m3d_config.reg_lds_staging)
+# pool requires).  Usage on the GPU box: bash tools/pmc_reg_validate.sh
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-LDS=${1:-1}
-OUT=gpurun_out/pmc_reg_$LDS
+OUT=gpurun_out/pmc_reg_0
 rm -rf $OUT; mkdir -p $OUT
 cat > $OUT/run.py <<'PY'
 import sys, os
@@ -13,14 +12,13 @@ import numpy as np
 from misc3d_amd import capi, synth
 d = synth.registration_pair_c4(200000, seed=5)
 i0, i1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
-capi.set_config(reg_lds_staging=int(os.environ.get("M3D_LDS", "0")))
 T, st = capi.registration_ransac(d["src"], d["dst"], i0, i1, threshold=0.03, max_iter=20000, edge_length_threshold=0.9, confidence=1.0, seed=17)
 print(st)
 PY
 i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INST_CYCLES_VMEM_RD"; do
   i=$((i+1))
-  M3D_LDS=$LDS timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o r -- python $OUT/run.py > $OUT/g$i.out 2> $OUT/g$i.err
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -o r -- python $OUT/run.py > $OUT/g$i.out 2> $OUT/g$i.err
 done
 python - "$OUT" <<'PY'
 import csv, collections, glob, sys

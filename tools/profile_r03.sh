@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-2 evidence, run ON THE GPU BOX (gpurun): everything lands under gpurun_out/prof/ (+ prof_c4, prof_cfg), and
-# tools/summarize_profiles.py r02 condenses it into profiles/.  PMC passes are separate runs with --kernel-trace only.
+# Round-3 evidence, run ON THE GPU BOX (gpurun): everything lands under gpurun_out/prof/ (+ prof_c4, prof_cfg), and
+# tools/summarize_profiles.py r03 condenses it into profiles/.  PMC passes are separate runs with --kernel-trace only.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -15,7 +15,7 @@ python tools/bench_configs.py > gpurun_out/bench_configs.jsonl 2> gpurun_out/ben
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cfg -o cfg -- python tools/bench_configs.py C2 C3 C5 > gpurun_out/prof_cfg/cfg.out 2> gpurun_out/prof_cfg/cfg.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c4 -o c4 -- python tools/bench_configs.py C4 > gpurun_out/prof_c4/c4.out 2> gpurun_out/prof_c4/c4.err
 # counters of the registration validation kernel
-bash tools/pmc_reg_validate.sh 0 > gpurun_out/pmc_reg_validate.txt 2>&1
+bash tools/pmc_reg_validate.sh > gpurun_out/pmc_reg_validate.txt 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_reg_fetch -o f -- python gpurun_out/pmc_reg_0/run.py > /dev/null 2>&1
 python - <<'PY' >> gpurun_out/pmc_reg_validate.txt
 import csv, glob
