@@ -705,6 +705,38 @@ static int approx_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr
     return M3D_OK;
 }
 
+// The tie rule's first comparison needs the order-free sums of BOTH models (trial and incumbent): one wait for the two
+// (a segmentation of a 10 M-point room meets ~20 equal counts: two ~65 us round trips each became one).
+static int approx_error_pair(DeviceCtx* ctx, const CloudView& v, int kind, double thr, const double* model_a,
+                             const double* model_b, uint64_t* count_a, double* error_a, uint64_t* count_b, double* error_b) {
+    RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
+    RESERVE(ctx->sums, sizeof(double) * 32);
+    RESERVE(ctx->total, sizeof(uint32_t) * 4);
+    RESERVE(ctx->tie_scratch, sizeof(double) * (kSumPartialDoubles + 4));
+    RESERVE(ctx->h_tie, 64);
+    double* part_b = ctx->tie_scratch.as<double>();
+    double* sum_b = part_b + kSumPartialDoubles;
+    uint32_t* cnt_b = reinterpret_cast<uint32_t*>(sum_b + 2);
+    launch_error_sum(kind, v, model_a, thr, ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 20,
+                     ctx->total.as<uint32_t>() + 2, ctx->stream);
+    launch_error_sum(kind, v, model_b, thr, part_b, sum_b, cnt_b, ctx->stream);
+    uint8_t* h = ctx->h_tie.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(h, ctx->total.as<uint32_t>() + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h + 8, ctx->sums.as<double>() + 20, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h + 16, cnt_b, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h + 24, sum_b, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t c32;
+    std::memcpy(&c32, h, 4);
+    *count_a = c32;
+    std::memcpy(error_a, h + 8, 8);
+    std::memcpy(&c32, h + 16, 4);
+    *count_b = c32;
+    std::memcpy(error_b, h + 24, 8);
+    return M3D_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // GeneralFit closed forms (host; the sums come from sum_*_k)
 // ------------------------------------------------------------------------------------------------
@@ -1216,14 +1248,16 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                 }
                 uint64_t c = 0;
                 double a_t = 0;
-                int r = approx_error(ctx, v, kind, thr, model_t, &c, &a_t);
-                if (r != M3D_OK) cb_rc = r;
-                if (c != cnt) out->internal_error = 1;
-                if (!best_approx_known) {
-                    r = approx_error(ctx, v, kind, thr, best_dev, &c, &best_approx);
+                if (!best_approx_known) {   // both sums behind one wait
+                    uint64_t cb = 0;
+                    const int r = approx_error_pair(ctx, v, kind, thr, model_t, best_dev, &c, &a_t, &cb, &best_approx);
                     if (r != M3D_OK) cb_rc = r;
                     best_approx_known = true;
+                } else {
+                    const int r = approx_error(ctx, v, kind, thr, model_t, &c, &a_t);
+                    if (r != M3D_OK) cb_rc = r;
                 }
+                if (c != cnt) out->internal_error = 1;
                 const double nu4 = 4.0 * (double)cnt * 1.1102230246251565e-16;
                 const double m_t = nu4 * a_t, m_b = nu4 * best_approx;
                 if (a_t + m_t < best_approx - m_b) {
@@ -1444,9 +1478,14 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
     RESERVE(ctx->total, 16);
     RESERVE(ctx->h_small, 256);
     w.partition_done = partition_done;
+    // the totals go to pinned host memory from the compaction kernels' own tails (two slots: a deferred check reads the
+    // previous removal's totals after the next one has been queued) -- a copy command per round less
+    w.totals_slot ^= 1;
+    uint32_t* h_totals = reinterpret_cast<uint32_t*>(ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot);
     if (!partition_done)
         launch_compact(kind, cur, model_dev, thr, 2, w.cur_orig, nullptr, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap,
-                       ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream);
+                       ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream, nullptr, nullptr, nullptr,
+                       nullptr, h_totals);
     // the same stable partition on the sorted copy (every inlier is a finite point), then fresh tile boxes
     CloudView sview;
     sview.x = w.scur.x;
@@ -1457,10 +1496,8 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
     sview.n_pad = w.scur.n_tiles * kTilePoints;
     launch_compact(kind, sview, model_dev, thr, 3, nullptr, nullptr, nullptr, w.sbx[w.spp].as<double>(),
                    w.sby[w.spp].as<double>(), w.sbz[w.spp].as<double>(), nullptr, scap,
-                   ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>() + 1, ctx->stream);
-    w.totals_slot ^= 1;   // (two slots: a deferred check reads the previous removal's totals after the next one has been queued)
-    HIPCHK(hipMemcpyAsync(ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot, ctx->total.p,
-                          2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                   ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>() + 1, ctx->stream, nullptr, nullptr, nullptr,
+                   nullptr, h_totals + 1);
     HIPCHK(hipGetLastError());
     return M3D_OK;
 }

@@ -78,6 +78,8 @@ struct DeviceCtx {
     DevBuf ub, best_count;     // bound-and-prune: surviving tiles per hypothesis, running best count
     DevBuf counts_rep;         // kCountReplicas copies of the per-hypothesis counters (short atomic chains)
     PinBuf h_small;
+    PinBuf h_tie;              // approx_error_pair: two (count, error sum) results
+    DevBuf tie_scratch;        // ... and the second error sum's partials / results
     void* seg_staging = nullptr;   // page-locked staging (m3d_host_alloc) for segmentation's index lists when the caller's array is pageable
     size_t seg_staging_cap = 0;    // ... in uint64 entries
     PinBuf h_inc;              // m3d_cloud_score_shard: the sampler's pruning incumbent on its way to / from the device
