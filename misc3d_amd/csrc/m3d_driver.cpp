@@ -389,7 +389,10 @@ static uint32_t pick_splits(uint32_t n_tiles, uint32_t h_pad) {
 
 // m3d_config.dense_scoring selects the dense scoring kernel (score_k: every tile x every hypothesis) instead of the
 // culled path (cull_mask_k + score_mask_k); both produce identical counts (tests/test_gpu_parity.py runs both).
-static bool use_dense_scoring() { return config().dense_scoring != 0; }
+// A cloud created WITHOUT the Hilbert-sorted copy (one-shot fits of few hypotheses: one_shot_fit) can only be scored
+// densely: the fit sets this flag of its own thread for its duration.
+static thread_local int t_dense_fit = 0;
+static bool use_dense_scoring() { return t_dense_fit != 0 || config().dense_scoring != 0; }
 
 // Hypotheses at the head of a probability-1 fit that are counted first, for the incumbent that prunes the rest.
 static uint32_t lead_size() { return (uint32_t)config().lead_hypotheses; }
@@ -1352,6 +1355,11 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     DeviceCtx* ctx = c->ctx;
     const double t0 = now_ms();
     HIPCHK(hipSetDevice(ctx->device));
+    struct DenseGuard {
+        int saved;
+        explicit DenseGuard(bool on) : saved(t_dense_fit) { if (on) t_dense_fit = 1; }
+        ~DenseGuard() { t_dense_fit = saved; }
+    } dense_guard(c->n_tiles == 0 && !c->work.active);   // no sorted copy: dense scoring (m3d_cloud_create_impl)
     const CloudView v = c->view();
     const CloudView gather = c->base_view();   // index lists / GeneralFit refer to the cloud as created
     const uint32_t* orig = c->orig();
@@ -1883,7 +1891,13 @@ static int one_shot_fit(int kind, const double* xyz, const double* normals, size
     if (!params || (!xyz && n)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     const int vr = validate_fit_args(kind, n, normals != nullptr, prob);
     if (vr != M3D_OK) return vr;
-    m3d_cloud* c = m3d_cloud_create(xyz, normals, n, device);  // SetPointCloud, ransac.h:469-475
+    // SetPointCloud, ransac.h:469-475.  The Hilbert-sorted copy and its tile boxes (0.2 ms per million points) pay for
+    // themselves from about a thousand hypotheses on: a call that cannot run more -- the README's fit_plane(pcd, 0.01,
+    // 100), the default 1000 with the adaptive stop (a few dozen iterations on a cloud with a dominant plane) -- gets a
+    // cloud without them and the dense scoring kernel (identical results: tests/test_gpu_parity.py runs both paths).
+    // 1 M points, defaults: 0.84 -> 0.67 ms.
+    const bool few = max_iter <= 1024;
+    m3d_cloud* c = m3d_cloud_create_impl(xyz, normals, n, device, few ? 0 : 1);
     if (!c) return M3D_ERR_DEVICE;
     const int rc = m3d_cloud_fit(c, kind, thr, max_iter, prob, seed, params, inliers, n_inliers, stats);
     m3d_cloud_destroy(c);
