@@ -26,7 +26,7 @@ bool env_is(const char* name, char first) {
 void sanitize(m3d_config& c) {
     if (c.lead_hypotheses < 64 || c.lead_hypotheses % 64) c.lead_hypotheses = 128;
     if (c.score_groups_per_block < 1 || c.score_groups_per_block > 64) c.score_groups_per_block = 8;
-    if (c.score_min_workgroups < 1) c.score_min_workgroups = 16384;
+    if (c.score_min_workgroups < 1) c.score_min_workgroups = 8192;
     if (c.dense_workgroups < 1) c.dense_workgroups = 8192;
     if (c.pool_limit_mb < 0) c.pool_limit_mb = 0;
 }
@@ -36,7 +36,7 @@ void load_env() {
     g_cfg.speculative_refine = !env_is("M3D_SPEC", '0');
     g_cfg.lead_hypotheses = (int32_t)env_long("M3D_LEAD", 128);        // sweep on C2: 64 and 128 equal, 256 +2.5 %, 512 +4 %
     g_cfg.score_groups_per_block = (int32_t)env_long("M3D_GPB", 8);
-    g_cfg.score_min_workgroups = (int32_t)env_long("M3D_SCORE_MIN_WGS", 16384);
+    g_cfg.score_min_workgroups = (int32_t)env_long("M3D_SCORE_MIN_WGS", 8192);   // C5 (1000 hypotheses per round on ~1 M points): 4096 32.7, 8192 31.8, 16384 34.0 ms; C2 flat
     g_cfg.dense_workgroups = (int32_t)env_long("M3D_SCORE_WGS", 8192);  // sweep on MI355X: 2048 +5 %, 4096 +1.5 %, 8192..32768 flat
     g_cfg.reg_neighbour_lists = !env_is("M3D_REG_NL", '0');
     g_cfg.reg_prune = !env_is("M3D_REG_PRUNE", '0');
