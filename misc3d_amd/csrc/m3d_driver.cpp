@@ -1043,8 +1043,14 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     // behind the LAST chunk, RefineModel's compaction is queued on that pick at once -- while the host is still
     // waking up and replaying the records.  The replay stays the authority: cloud_fit_locked keeps the early
     // compaction only if it names the same hypothesis.  m3d_config.speculative_refine = 0 switches the prediction off.
+    bool hinted_chunk = false;   // the adaptive-stop fit got ONE chunk sized from the caller's iteration hint (below)
     const bool spec_enabled = config().speculative_refine != 0;
     const bool spec = spec_enabled && prob >= 1.0 && !use_dense_scoring() && max_iter > 0;
+    // Adaptive stop (probability < 1) with a caller's hint that the loop will run to max_iter (a segmentation round on
+    // clutter: fitness ~0.005, the bound never bites): the hinted chunk covers the whole loop, so the device's pick behind
+    // it IS the replay's winner unless the loop stops early after all or an rmse tie goes to a later hypothesis -- the
+    // compaction (and the round's partition) is queued on the pick at once, and the host's ~15 us of waking up, replaying
+    // and launching disappear from the round.  A miss redoes RefineModel, exactly as on the probability-1 path.
     ctx->spec_compaction = false;
     // one GPU, culled path: every chunk ends with the completion word of sum_replicas_k's tail (and its pick, which only
     // probability-1 fits act on) -- the host polls pinned memory instead of waiting for an event
@@ -1082,7 +1088,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     } else if (prob >= 1.0) {
         chunk = std::max<size_t>(max_iter, 64);
         growth = 1;
-    } else if (iterations_hint > 2 * (size_t)lead_size()) {
+    } else if ((hinted_chunk = iterations_hint > 2 * (size_t)lead_size())) {
         // adaptive stop, but the caller knows how many iterations a similar fit just took (segmentation rounds):
         // ONE chunk of that size whose first hypotheses are counted on their own -- the same device work as a
         // small first chunk with the second one queued behind it, minus a sample upload, a MinimalFit and a
@@ -1144,10 +1150,13 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
                             b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec && !fused_pick,
                             fused_pick ? &pf : nullptr);
-        if (r == M3D_OK && fused_pick && spec && e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
+        const bool spec_adaptive = spec_enabled && prob < 1.0 && hinted_chunk && b == 0 && !comm && !use_dense_scoring();
+        if (r == M3D_OK && fused_pick && (spec || spec_adaptive) && e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
+            // (a segmentation round: the partition of the rest rides along, decided without the inlier count: -2)
+            const PartitionOut* part = spec_adaptive && ctx->partition_hook && orig_dev ? (*ctx->partition_hook)(-2) : nullptr;
             r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
                                         ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true,
-                                        idx_host);
+                                        idx_host, part);
             ctx->spec_compaction = r == M3D_OK;
         }
         if (r == M3D_OK && spec && !fused_pick) {
@@ -1379,20 +1388,39 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     const int64_t expected = ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1;
     bool refined = false;
     if (ctx->spec_compaction) {
-        // the compaction is already running on the device's pick; finish RefineModel on it and keep the result if
-        // the replay named the same hypothesis (it does unless an rmse tie went the other way)
-        rc = refine(ctx, v, gather, orig, kind, thr, ctx->pick.as<BestPick>()->params, model, inliers, &ni, &gf_ok,
-                    expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true);
-        if (rc != M3D_OK) return rc;
+        // the compaction is already running on the device's pick (its record reached pinned memory with the chunk's
+        // completion word): RefineModel is finished on it if the replay named the same hypothesis -- it does unless an rmse
+        // tie went the other way or, on the adaptive path, the loop stopped early after all.  Otherwise the speculative
+        // launches are left to drain (their outputs are rewritten below, later in stream order) and RefineModel runs on
+        // the replay's model with the caller's hooks untouched.
         const BestPickHost* ph = ctx->h_pick.as<BestPickHost>();
+        const bool hit = ro.st.best_index >= 0 ? (ph->have && ph->index == (unsigned long long)ro.st.best_index) : !ph->have;
+        ro.spec_hits = hit ? 1 : 0;
+        ro.spec_misses = hit ? 0 : 1;
+        if (hit) {
+            rc = refine(ctx, v, gather, orig, kind, thr, ctx->pick.as<BestPick>()->params, model, inliers, &ni, &gf_ok,
+                        expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true);
+            if (rc != M3D_OK) return rc;
+            refined = true;
+        }
+    }
+    if (ctx->spec_compaction && comm) {
+        // sharded fits: pick_best_k's record is only known to have landed once the stream has been waited for (its
+        // chunk's event may sit on the copy stream, in front of it) -- the decision above is re-taken after that wait
+        const BestPickHost* ph = ctx->h_pick.as<BestPickHost>();
+        if (!refined) {   // (judged a miss on a record that may not have arrived yet)
+            rc = refine(ctx, v, gather, orig, kind, thr, ctx->pick.as<BestPick>()->params, model, inliers, &ni, &gf_ok,
+                        expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true);
+            if (rc != M3D_OK) return rc;
+        }
+        before_refine_wait = nullptr;   // (a speculative RefineModel has run its hook by now, in either branch)
         refined = ro.st.best_index >= 0 ? (ph->have && ph->index == (unsigned long long)ro.st.best_index) : !ph->have;
         ro.spec_hits = refined ? 1 : 0;
         ro.spec_misses = refined ? 0 : 1;
-        before_refine_wait = refined ? before_refine_wait : nullptr;   // (a hook has run by now either way)
     }
     if (!refined) {
         rc = refine(ctx, v, gather, orig, kind, thr, ctx->last_best_dev, model, inliers, &ni,
-                    &gf_ok, expected, ctx->spec_compaction ? nullptr : before_refine_wait, ctx->h_best.as<double>(), nullptr,
+                    &gf_ok, expected, before_refine_wait, ctx->h_best.as<double>(), nullptr,
                     /*fused=*/true);
         if (rc != M3D_OK) return rc;
     }
@@ -2367,7 +2395,13 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             // RefineModel's compaction evaluates the very flags the removal needs: it writes the partition of the cloud
             // in creation order as well (one count, one scan and one write launch less per round)
             const std::function<const PartitionOut*(int64_t)> partition_hook = [&](int64_t expected_ni) -> const PartitionOut* {
-                if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) return nullptr;
+                // -2: asked before the inlier count is known (compaction queued on the device's own pick, run_ransac): the
+                // partition goes to the spare buffers and is simply not used should this turn out to be the last round
+                if (expected_ni == -2) {
+                    if (k + 1 >= max_clusters) return nullptr;
+                } else if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) {
+                    return nullptr;
+                }
                 if (cloud_remove_prepare(c0, &part_out) != M3D_OK) return nullptr;
                 partition_fused = true;
                 return &part_out;

@@ -102,15 +102,20 @@ if "C4" in which:
     inv = np.empty(n, dtype=np.int64)
     inv[d["perm"]] = np.arange(n)
     true_frac = float(np.mean(inv[i0.astype(np.int64)] == i1.astype(np.int64)))
-    # the screen is one K = 112 fp16 contraction per (query, row) pair and direction: 2 x n x n x 112 x 2 flop.  Priced with
-    # the WHOLE call's wall clock (106 MB of descriptors over PCIe, packing, the fp64 verification): a lower bound of the
-    # kernel's own fraction, which profiles/r02_c4_kernel_stats.csv gives (nn16_scan_k TotalDurationNs / 3 calls)
-    mm_flop = 2.0 * n * n * 112 * 2
+    # the screen is ONE K = 112 fp16 contraction over all (query, row) pairs -- since round 3 a single scan serves both search
+    # directions -- plus the two warm-up passes (1/16 and 1/8 of it): n x n x 112 x 2 x (1 + 3/16) flop.  Priced with the
+    # WHOLE call's wall clock (106 MB of descriptors over PCIe, packing, binning, the fp64 verifications): a lower bound of
+    # the kernel's own fraction (profiles/r03_match_kernel_stats.txt: nn16_scan_k<false, true> 11.5 ms = 0.31 of the peak;
+    # SQ_VALU_MFMA_BUSY_CYCLES share: profiles/r03_pmc_match.txt).  pair_dist_per_s counts both directions' distances.
+    mm_flop = float(n) * n * 112 * 2 * (1.0 + 3.0 / 16.0)
     emit("C4 match_correspondence", n=n, dim=33, ms_first=t_match * 1e3, ms=t_match2 * 1e3, matches=len(i0),
          true_fraction=true_frac, pair_dist_per_s=2.0 * n * n / t_match2,
-         roofline={"bound": "mfma", "kernel": "m3d::nn16_scan_k", "achieved": mm_flop / t_match2 / 1e12,
+         roofline={"bound": "mfma", "kernel": "m3d::nn16_scan_k<false, true> (one scan, both directions)",
+                   "achieved": mm_flop / t_match2 / 1e12,
                    "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA, whole call's wall clock)",
-                   "frac": mm_flop / t_match2 / 1e12 / MFMA_F16_PEAK_TFLOPS, "flop": mm_flop})
+                   "frac": mm_flop / t_match2 / 1e12 / MFMA_F16_PEAK_TFLOPS, "flop": mm_flop,
+                   "note": "round 2 ran the contraction once per direction (22.2 ms, 0.32 on twice the flop); the work per "
+                           "call halved, so the fraction on the SMALLER flop count is lower although the call is 1.36x faster"})
     dts = []
     for _ in range(2):      # (the first call of a process also sizes the device's block free list: ~10 ms)
         t0 = time.perf_counter()
@@ -205,15 +210,38 @@ if "C5" in which:
     # HBM-bound by construction (a round = a few hundred hypotheses on what is left of the cloud, then compaction + removal
     # passes over it): algorithmic bytes = per round 24 B x remaining points x 4 (RefineModel's counting and writing pass,
     # the removal's read of both copies) + 24 B x kept points x 2 (both copies written) + the 240 MB upload and transpose
+    br = capi.last_segment_ms()       # the library's own clock of the last call: create / round loop / its big rounds
     rem, alg = n, 24.0 * n * 3
+    alg_big = alg_tail = 0.0
     for cidx in clusters:
-        alg += 24.0 * rem * 4 + 24.0 * (rem - len(cidx)) * 2
+        b = 24.0 * rem * 4 + 24.0 * (rem - len(cidx)) * 2
+        alg += b
+        if rem > n / 8:
+            alg_big += b
+        else:
+            alg_tail += b
         rem -= len(cidx)
+    n_tail = max(br["n_rounds"] - br["n_big_rounds"], 1)
+    t_tail = (br["rounds"] - br["big_rounds"]) * 1e-3
     emit("C5 segment_plane_iterative 10M pts (1 GPU, incl. 240 MB upload)", ms_first=dt * 1e3, ms=dt2 * 1e3, rc=rc,
          clusters=[len(c) for c in clusters][:12] + ["... %d more" % max(0, len(clusters) - 12)], planes=len(planes),
          roofline={"bound": "hbm", "kernel": "compact_count_k / compact_write_k / cull_mask_k over the remaining cloud, per round",
                    "achieved": alg / dt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dt2 / 1e9 / HBM_PEAK_GBS,
                    "algorithmic_bytes": alg, "rounds": len(clusters),
-                   "note": "whole call (PCIe upload of 240 MB and 76 MB of index lists back included); with ~170 rounds of "
-                           "5-10 launches each on a shrinking cloud the call is launch- and host-round-trip-bound after the "
-                           "first six rounds"})
+                   "phases": {
+                       "inside_the_library_ms": br["total"], "binding_ms": dt2 * 1e3 - br["total"],
+                       "cloud_create": {"ms": br["cloud_create"], "bytes": 24.0 * n * 3,
+                                        "GBps": 24.0 * n * 3 / (br["cloud_create"] * 1e-3) / 1e9,
+                                        "bound": "PCIe: 240 MB from the caller's pageable array at ~52 GB/s = 4.6 ms of it"},
+                       "big_rounds": {"rounds": br["n_big_rounds"], "ms": br["big_rounds"], "algorithmic_bytes": alg_big,
+                                      "GBps": alg_big / (br["big_rounds"] * 1e-3) / 1e9,
+                                      "frac": alg_big / (br["big_rounds"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "rounds on more than an eighth of the cloud (the six walls, floor, ceiling)"},
+                       "tail_rounds": {"rounds": n_tail, "ms": t_tail * 1e3, "us_per_round": t_tail * 1e6 / n_tail,
+                                       "algorithmic_bytes": alg_tail, "GBps": alg_tail / t_tail / 1e9,
+                                       "frac": alg_tail / t_tail / 1e9 / HBM_PEAK_GBS,
+                                       "note": "1000 hypotheses on ~1 M clutter points each: ~63 us of box tests and scoring "
+                                               "(latency-bound launches, 8 % of the (tile, hypothesis) pairs survive), ~15 us of "
+                                               "host turn-around, ~55 us of compaction / partition / tile-box passes that run at "
+                                               "2.5-4.7 TB/s (profiles/r03_c5_round_timeline.txt)"}},
+                   "note": "whole call (PCIe upload of 240 MB and 76 MB of index lists back included)"})

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 rm -rf gpurun_out/pmc_match; mkdir -p gpurun_out/pmc_match
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES"; do
   tag=$(echo $set | cut -d' ' -f1)
-  M3D_C4_ONLY_MATCH=1 timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_match/$tag -o m -- python tools/bench_configs.py C4 > /dev/null 2> gpurun_out/pmc_match/$tag.err
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_match/$tag -o m -- python tools/time_match.py > /dev/null 2> gpurun_out/pmc_match/$tag.err
 done
 python - <<'PY'
 import csv, glob, collections

@@ -29,5 +29,12 @@ PY
 M3D_C4_ENV=1 python gpurun_out/pmc_reg_0/run.py >> gpurun_out/pmc_reg_validate.txt 2>&1
 echo "---- memory pipeline (tools/pmc_reg_mem.sh)" >> gpurun_out/pmc_reg_validate.txt
 bash tools/pmc_reg_mem.sh >> gpurun_out/pmc_reg_validate.txt 2>&1
-python tools/step_timeline.py gpurun_out/prof/trace_bench/bench_kernel_trace.csv > gpurun_out/step_timeline.txt 2>&1
+python tools/step_timeline.py gpurun_out/prof/trace_bench/bench_kernel_trace.csv minimal_fit_k 15 > gpurun_out/step_timeline.txt 2>&1; python tools/step_timeline.py gpurun_out/prof/trace_bench/bench_kernel_trace.csv >> gpurun_out/step_timeline.txt 2>&1
 ls gpurun_out/prof gpurun_out/prof_c4 gpurun_out/prof_cfg
+# matcher: kernel stats + the MFMA-busy share of the one-pass scan
+bash tools/prof_match.sh prof_match > gpurun_out/prof_match.txt 2>&1
+bash tools/pmc_match.sh > gpurun_out/pmc_match.txt 2>&1
+# C5: per-round timeline + the library's own breakdown
+bash tools/c5_round_timeline.sh c5t 200 > /dev/null 2>&1
+python tools/time_c5_plain.py > gpurun_out/c5_plain.txt 2>&1
+python tools/time_oneshot.py > gpurun_out/oneshot.txt 2>&1

@@ -1,5 +1,7 @@
 """Per-kernel timeline of ONE bench step from a rocprofv3 kernel trace (csv): start offset, duration and the gap to the
-previous kernel, for the last complete step of the trace.  Usage: python tools/step_timeline.py <trace.csv> [first-kernel-substring]"""
+previous kernel, for one step of the trace.  Usage: python tools/step_timeline.py <trace.csv> [first-kernel-substring] [step index]
+(default: the last complete step; bench.py ends with its one-shot fits, so the resident-cloud step wants an index,
+e.g. 15 = inside the timed region)"""
 import csv
 import sys
 
@@ -9,7 +11,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 if len(starts) < 3:
     raise SystemExit("not enough steps in the trace")
-a, b = starts[-3], starts[-2]
+k = int(sys.argv[3]) if len(sys.argv) > 3 else len(starts) - 3
+a, b = starts[k], starts[k + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
 for r in rows[a:b]:
