@@ -26,3 +26,15 @@ def test_nn_screen_walk_is_exact_on_the_host():
     r = subprocess.run([os.path.join(cpp, "_build", "test_nn_screen"), "60000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout and "wrong 0;" in r.stdout and "bound violations 0," in r.stdout
+
+
+def test_guided_cut_off_searches_equal_the_unguided_ones():
+    """tests/cpp/test_cutoffs.cpp: sphere_cutoffs / cylinder_cutoffs narrow their four bisections around computed guesses
+    (r -+ thr and their squares); the results must be the unguided searches' bit for bit on random models over twelve
+    orders of magnitude (zero / NaN radii, empty and degenerate intervals included), and the defining property
+    `dist(q) < thr <=> lo <= s(q) <= hi` must hold for the values next to both ends."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["make", "-C", cpp, "_build/test_cutoffs"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(cpp, "_build", "test_cutoffs"), "30000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout and "guided != unguided 0;" in r.stdout
