@@ -117,17 +117,10 @@ def load_pmc_traffic():
 
 
 def usable_cpus():
-    """CPUs this process may really use: affinity mask, capped by the cgroup quota (a container can see 128 CPUs and
-    own 16 of them)."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q, p = f.read().split()
-        if q != "max":
-            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
-    except Exception:
-        pass
-    return n
+    """CPUs this process may really use (oracle.usable_cpus: affinity mask capped by the cgroup quota).  The oracle is
+    imported here, inside the cpu_baseline leg's helper, and nowhere else in this file."""
+    import oracle
+    return oracle.usable_cpus()
 
 
 def cpu_baseline(pts, thr, seed, budget_s, H_gpu):

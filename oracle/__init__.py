@@ -62,11 +62,28 @@ class _RegTrace(C.Structure):
                 ("counts", C.c_void_p), ("err2", C.c_void_p)]
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a container can see 128 CPUs
+    and own 16 of them; an OpenMP team of 128 on a quota of 16 spends its time in barriers: the look-ahead fit took
+    9.9 s instead of 0.1 s on the GPU box)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
         _lib = C.CDLL(_LIB_PATH)
+        if "OMP_NUM_THREADS" not in os.environ:      # (an explicit setting wins)
+            _lib.orc_set_omp_threads(C.c_int(usable_cpus()))
         _lib.orc_plane_distance.restype = C.c_double
         _lib.orc_sphere_distance.restype = C.c_double
         _lib.orc_cylinder_distance.restype = C.c_double

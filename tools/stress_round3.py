@@ -1,0 +1,63 @@
+"""Randomised stress of the paths round 3 added, against the oracle (run on the GPU box; minutes, not part of the suite):
+the one-scan mutual matcher (random sizes incl. tiny and ragged ones, clustered descriptors, duplicated rows), the
+segmentation with the speculative RefineModel of rounds that run to max_iteration, one-shot fits on the dense path."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import oracle  # noqa: E402
+from misc3d_amd import capi, synth  # noqa: E402
+
+rng = np.random.default_rng(int(os.environ.get("M3D_STRESS_SEED", "1")))
+budget = float(os.environ.get("M3D_STRESS_SECONDS", "240"))
+t_end = time.time() + budget
+n_match = n_seg = n_fit = 0
+while time.time() < t_end:
+    # ---- matcher
+    ns, nd = (int(v) for v in rng.integers(1, 6000, 2))
+    if rng.random() < 0.2:
+        ns = int(rng.integers(1, 40))
+    fs = rng.uniform(0, 1, (ns, 33))
+    fd = rng.uniform(0, 1, (nd, 33))
+    k = min(ns, nd) // 2
+    if k:
+        fd[:k] = fs[rng.permutation(ns)[:k]] + rng.normal(0, 10.0 ** rng.integers(-6, -1), (k, 33))
+    if rng.random() < 0.3 and nd > 10:          # clusters: many near-duplicates of a few rows
+        c = int(rng.integers(2, 10))
+        fd[rng.integers(0, nd, nd // 3)] = fd[rng.integers(0, nd, c)][rng.integers(0, c, nd // 3)] + rng.normal(0, 1e-7, (nd // 3, 33))
+    if rng.random() < 0.2 and ns > 300:         # one exact duplicate block
+        fs[100:100 + 280] = fs[100]
+    a, b = capi.match_mutual_nn(fs, fd)
+    oa, ob = oracle.match_mutual_nn(fs, fd)
+    assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob), ("match", ns, nd)
+    n_match += 1
+    # ---- segmentation (adaptive stop never bites in the clutter rounds: speculative RefineModel)
+    n = int(rng.integers(20_000, 120_000))
+    pts = synth.room_cloud_c5(n, int(rng.integers(0, 1000)))
+    mi = int(rng.choice([50, 100, 300, 1000]))
+    mr = float(rng.choice([0.03, 0.05, 0.1]))
+    sd = int(rng.integers(0, 10_000))
+    ro, po, co = oracle.segment_plane_iterative(pts, 0.01, max_iteration=mi, min_ratio=mr, seed=sd, lookahead=64)
+    rg, pg, cg = capi.segment_plane_iterative(pts, 0.01, max_iteration=mi, min_ratio=mr, seed=sd)
+    assert len(co) == len(cg) and all(np.array_equal(x, y) for x, y in zip(co, cg)), ("segment", n, mi, mr, sd)
+    assert np.allclose(po, pg, rtol=0, atol=1e-9)
+    n_seg += 1
+    # ---- one-shot fits, few hypotheses (dense path) and many (sorted path)
+    kind = int(rng.integers(0, 3))
+    m = int(rng.integers(3_000, 40_000))
+    if kind == 0:
+        p, nr = synth.plane_cloud_c1(m, sd), None
+    elif kind == 1:
+        p, nr = synth.sphere_cloud_c3(m, sd), None
+    else:
+        p, nr = synth.cylinder_cloud_c3(m, sd)
+    for it, prob in ((int(rng.integers(1, 1025)), float(rng.choice([0.9999, 1.0, 0.5]))), (int(rng.integers(1025, 3000)), 1.0)):
+        g = capi.fit(kind, p, nr, 0.01, it, prob, seed=sd)
+        o = oracle.fit(kind, p, nr, thr=0.01, max_iter=it, prob=prob, seed=sd, lookahead=32)
+        assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.ret, o.best_index, o.count, o.iterations), ("fit", kind, m, it, prob, sd)
+        assert np.array_equal(g.inliers, o.inliers) and np.allclose(g.params, o.params, rtol=0, atol=1e-9)
+        n_fit += 1
+print(f"stress ok: {n_match} matcher cases, {n_seg} segmentations, {n_fit} fits in {budget:.0f} s")
