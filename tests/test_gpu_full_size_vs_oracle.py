@@ -1,4 +1,4 @@
-"""BASELINE.json configurations C2, C3 and C5 compared with the ORACLE at their FULL sizes ("Next round" 1).
+"""BASELINE.json configurations C2, C3, C4 and C5 compared with the ORACLE at their FULL sizes ("Next round" 1).
 
 The oracle's sequential driver with an OpenMP look-ahead (orc_fit_parallel: the records of the next hypotheses are
 computed ahead by a thread team and consumed in index order -- outputs identical to orc_fit bit for bit,
@@ -133,3 +133,25 @@ def test_c5_baseline_iterations_full_size_vs_oracle(capi, orc, room):
     for a, b in zip(co, cg):
         assert np.array_equal(a, b)
     assert np.allclose(po, pg, rtol=0, atol=1e-9)
+
+
+def test_c4_full_size_vs_oracle(capi, orc):
+    """BASELINE configs[3] at full size: the mutual matcher on 200 k x 200 k x 33 descriptors against the oracle's fp64
+    brute force (ALL pairs; ~1 minute of the box's host cores), then compute_transformation_ransac on those correspondences
+    with the reference's own confidence (0.999: 24 iterations, 5 validations -- each a 200 k x 200 k exact search in the
+    oracle): T bit for bit, iterations, validations, est_k, fitness.  (The first 300 iterations of the forced
+    100 000-iteration run -- 76 validations, two minutes of oracle -- are compared by tools/c4_full_size_vs_oracle.py;
+    profiles/r03_c4_full_size_vs_oracle.txt.)"""
+    n = 200_000
+    d = synth.registration_pair_c4(n, seed=5)
+    g0, g1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    o0, o1 = orc.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    assert len(o0) > 0.25 * n
+    assert np.array_equal(g0.astype(np.int64), o0) and np.array_equal(g1.astype(np.int64), o1)
+    assert capi.match_last_fallbacks() < 0.001 * n
+    kw = dict(threshold=0.03, max_iter=100_000, edge_length_threshold=0.9, confidence=0.999, seed=17)
+    T, st = capi.registration_ransac(d["src"], d["dst"], g0, g1, **kw)
+    o = orc.registration_ransac(d["src"], d["dst"], o0, o1, thr=0.03, max_iter=100_000, edge_thr=0.9, confidence=0.999, seed=17)
+    assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64))
+    assert (st["iterations"], st["validations"], st["est_k"], st["best_index"]) == (o.iterations, o.validations, o.est_k, o.best_index)
+    assert st["fitness"] == o.fitness and abs(st["inlier_rmse"] - o.inlier_rmse) <= 1e-12
