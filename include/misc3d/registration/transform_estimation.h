@@ -58,6 +58,10 @@ public:
     }
     void SetConfidence(double c) { confidence_ = c; }  // Open3D RANSACConvergenceCriteria default 0.999
     void SetDevice(int device) { device_ = device; }
+    // false: the call only returns the pose (what the reference's RANSACSolver::Solve does, transform_estimation.cpp:163);
+    // the winner's deterministic inlier_rmse -- one more nearest-neighbour pass over the source -- is then not formed and
+    // GetStats() is all zeros
+    void SetWantStats(bool want) { want_stats_ = want; }
     Matrix4d Solve(const CloudView& src, const CloudView& dst,
                    const std::pair<std::vector<size_t>, std::vector<size_t>>& corres) const {
         if (corres.first.size() != corres.second.size()) LogError("correspondence lists differ in length");
@@ -65,12 +69,13 @@ public:
         CheckStatus(m3d_registration_ransac(src.xyz, src.n, dst.xyz, dst.n, corres.first.data(),
                                             corres.second.data(), corres.first.size(), threshold_, max_iter_,
                                             edge_length_threshold_, confidence_, has_seed_ ? &seed_ : nullptr,
-                                            device_, T.data(), &stats_));
+                                            device_, T.data(), want_stats_ ? &stats_ : nullptr));
         return T;
     }
     const m3d_reg_stats& GetStats() const { return stats_; }
 
 private:
+    bool want_stats_ = true;
     double threshold_;
     int max_iter_;
     double edge_length_threshold_;

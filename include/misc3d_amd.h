@@ -203,15 +203,16 @@ typedef struct m3d_reg_stats {
     uint64_t ties;             /* equal-fitness comparisons decided during the replay (hypotheses the validation dropped early
                                 * on their partial count or sum never get that far) */
     uint64_t exact_rmse_evals; /* of which needed the serial-order sum of squared distances */
-    uint64_t lds_wave_hypotheses;    /* validation work units (64 source points x 1 hypothesis) served from the LDS-staged box */
-    uint64_t global_wave_hypotheses; /* ... that took the global-memory path (pose outside the box, or staging off) */
+    uint64_t lds_wave_hypotheses;    /* always 0 (round 2's LDS-staged validation kernel was deleted; the slot keeps the layout) */
+    uint64_t global_wave_hypotheses; /* always 0 */
     uint64_t nn_fp32_screen;         /* 1: the validation's neighbour search ran behind the fp32 screen (m3d_config.reg_fp32_screen and a
                                       * grid the screen admits: cell edge and offsets within fp32's reach) */
     uint64_t nn_screen_fallbacks;    /* queries whose runner-up lay within the rounding bound of the winner: decided by the fp64 walk */
 } m3d_reg_stats;
 /* corr_src/corr_dst: m index pairs (the std::pair<vector<size_t>,vector<size_t>> of the reference).
  * confidence: Open3D RANSACConvergenceCriteria::confidence_ (the reference always uses the default
- * 0.999, transform_estimation.cpp:160-161).  T: row-major 4x4. */
+ * 0.999, transform_estimation.cpp:160-161).  T: row-major 4x4.  stats may be NULL: the call then returns the pose only (all
+ * RANSACSolver::Solve returns) and skips the pass that forms the winner's deterministic inlier_rmse. */
 int m3d_registration_ransac(const double *src, size_t n_src, const double *dst, size_t n_dst,
                             const size_t *corr_src, const size_t *corr_dst, size_t m,
                             double threshold, int max_iter, double edge_length_threshold,

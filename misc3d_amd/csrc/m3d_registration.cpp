@@ -720,7 +720,7 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
         // the reported inlier_rmse: a deterministic tree sum over the points in their original order (Open3D's own
         // value depends on its OpenMP reduction order; the serial-order sum is only formed when a fitness tie
         // needs it, and then best_rmse is that value)
-        if (!best_rmse_known) {
+        if (!best_rmse_known && stats) {   // (stats == NULL: the caller wants the pose only -- RANSACSolver::Solve's own return)
             uint64_t c2;
             double e2;
             const int r = tree_err2(R, best_T_dev, &c2, &e2);

@@ -115,13 +115,36 @@ arr_d as_descriptor_matrix(const py::object& f) {
     // open3d Feature (attribute `data`, dim x N) or an ndarray of shape (dim, N)
     py::object np = py::module_::import("numpy");
     py::object src = py::hasattr(f, "data") && !py::isinstance<py::array>(f) ? py::object(f.attr("data")) : f;
-    arr_d a = arr_d::ensure(np.attr("asarray")(src, py::arg("dtype") = "float64"));
+    // (a plain py::array here: arr_d would force a C-ordered copy of the (dim, N) array first -- a strided 53 MB
+    //  transposition for 200 k FPFH descriptors -- only for the next line to transpose it back)
+    py::array a = py::array::ensure(np.attr("asarray")(src, py::arg("dtype") = "float64"));
     if (!a || a.ndim() != 2) throw py::value_error("descriptors: expected a (dim, N) array or an object with .data");
-    // Eigen dim x N column-major == N x dim row-major
+    // Eigen dim x N column-major == N x dim row-major: a Fortran-ordered (dim, N) array -- what Open3D's Feature.data is, and
+    // what `descriptors_of_shape_N_dim.T` is -- passes through without a copy
     return arr_d::ensure(np.attr("ascontiguousarray")(a.attr("T")));
 }
 
 }  // namespace
+
+// index lists of the reference's API (std::vector<size_t> <-> python list): a numpy integer array is taken by one memcpy
+// instead of an element-by-element conversion (94 k correspondences: 2.7 ms of a 4.1 ms compute_transformation_ransac call)
+static std::vector<size_t> to_index_vector(const py::handle& o) {
+    if (py::isinstance<py::array>(o)) {
+        auto a = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(py::reinterpret_borrow<py::object>(o));
+        if (a && a.ndim() == 1) {
+            std::vector<size_t> v((size_t)a.shape(0));
+            static_assert(sizeof(size_t) == sizeof(int64_t), "size_t is 64 bits on this platform");
+            if (!v.empty()) std::memcpy(v.data(), a.data(), sizeof(size_t) * v.size());
+            return v;
+        }
+    }
+    return py::cast<std::vector<size_t>>(o);
+}
+static py::array_t<int64_t> index_array(const std::vector<size_t>& v) {
+    py::array_t<int64_t> a((py::ssize_t)v.size());
+    if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), sizeof(size_t) * v.size());
+    return a;
+}
 
 PYBIND11_MODULE(_py_misc3d, m) {
     m.doc() = "MI355X-native Misc3D RANSAC hot path (fit_plane/sphere/cylinder, segment_plane_iterative, "
@@ -274,10 +297,13 @@ PYBIND11_MODULE(_py_misc3d, m) {
         py::arg("src"), py::arg("dst"), py::arg("noise_bound") = 0.01);
     mr.def(
         "compute_transformation_ransac",
-        [](const py::object& src, const py::object& dst,
-           const std::pair<std::vector<size_t>, std::vector<size_t>>& corres, double threshold, int max_iter,
+        [](const py::object& src, const py::object& dst, const py::object& corres_obj, double threshold, int max_iter,
            double edge_length_threshold, std::optional<uint64_t> seed, double confidence, int device) {
             HostCloud s = extract_cloud(src), d = extract_cloud(dst);
+            // (list, list) as in the reference, or two integer arrays (what match_correspondence(..., as_arrays=True) returns)
+            const py::sequence cs = py::reinterpret_borrow<py::sequence>(corres_obj);
+            if (py::len(cs) != 2) throw py::value_error("corres must be a pair (indices into src, indices into dst)");
+            std::pair<std::vector<size_t>, std::vector<size_t>> corres{to_index_vector(cs[0]), to_index_vector(cs[1])};
             misc3d::Matrix4d T;
             {
                 py::gil_scoped_release nogil;
@@ -285,6 +311,7 @@ PYBIND11_MODULE(_py_misc3d, m) {
                 solver.SetConfidence(confidence);
                 solver.SetDevice(device);
                 if (seed) solver.SetSeed(*seed);
+                solver.SetWantStats(false);   // (the reference's function returns the pose and nothing else)
                 T = solver.Solve(s.view(), d.view(), corres);
             }
             return to_mat4(T);
@@ -300,7 +327,7 @@ PYBIND11_MODULE(_py_misc3d, m) {
     mr.def(
         "match_correspondence",
         [](const py::object& src, const py::object& dst, const misc3d::registration::MatchMethod& method,
-           int n_trees, int device) {
+           int n_trees, int device, bool as_arrays) -> py::object {
             arr_d fs = as_descriptor_matrix(src), fd = as_descriptor_matrix(dst);
             if (fs.shape(1) != fd.shape(1)) throw py::value_error("descriptor dimensions differ");
             std::pair<std::vector<size_t>, std::vector<size_t>> res;
@@ -312,7 +339,8 @@ PYBIND11_MODULE(_py_misc3d, m) {
                 misc3d::registration::FeatureView b{fd.data(), (int)fd.shape(1), (size_t)fd.shape(0)};
                 res = matcher.Match(a, b);
             }
-            return res;
+            if (as_arrays) return py::make_tuple(index_array(res.first), index_array(res.second));
+            return py::cast(res);   // (list, list), as the reference returns them
         },
         "Match corresponding point clouds (mutual nearest neighbours in descriptor space).  The search is EXACT for both "
         "methods: MatchMethod.ANNOY (the reference's default, an approximate random-projection forest) and n_trees are "
@@ -320,7 +348,7 @@ PYBIND11_MODULE(_py_misc3d, m) {
         "from it by the forest's misses.",
         py::arg("src"),
         py::arg("dst"), py::arg("method") = misc3d::registration::MatchMethod::ANNOY, py::arg("n_trees") = 4,
-        py::kw_only(), py::arg("device") = 0);
+        py::kw_only(), py::arg("device") = 0, py::arg("as_arrays") = false);
 
     // ---- logging (python/py_misc3d.cpp:52-62)
     py::enum_<misc3d::VerbosityLevel>(m, "VerbosityLevel", py::arithmetic(), "VerbosityLevel")

@@ -139,6 +139,16 @@ def test_segmentation_and_registration_api(m3d, orc):
                                                        confidence=1.0)
     o = orc.registration_ransac(d["src"], d["dst"], oa, ob, thr=0.03, max_iter=3000, confidence=1.0, seed=17)
     assert T.shape == (4, 4) and np.array_equal(T, o.T) and np.allclose(T, d["T"], atol=0.01)
+    # the same through integer arrays (keyword-only extra as_arrays; the lists of the reference's API cost an element-by-
+    # element conversion each way): identical pairs, identical pose; int32 and uint64 arrays are accepted as well
+    a0, a1 = m3d.registration.match_correspondence(d["feat_src"].T, d["feat_dst"].T, as_arrays=True)
+    assert isinstance(a0, np.ndarray) and a0.dtype == np.int64 and a0.tolist() == i0 and a1.tolist() == i1
+    for conv in (lambda v: v, lambda v: v.astype(np.int32), lambda v: v.astype(np.uint64)):
+        T2 = m3d.registration.compute_transformation_ransac(d["src"], d["dst"], (conv(a0), conv(a1)), 0.03, 3000, seed=17,
+                                                            confidence=1.0)
+        assert np.array_equal(T, T2)
+    with pytest.raises(ValueError):
+        m3d.registration.compute_transformation_ransac(d["src"], d["dst"], (i0, i1, i1), 0.03, 3000)
     inv = np.empty(4000, dtype=np.int64)
     inv[d["perm"]] = np.arange(4000)
     Tl = m3d.registration.compute_transformation_least_square(d["src"], d["dst"][inv])
