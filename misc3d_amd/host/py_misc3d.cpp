@@ -86,29 +86,66 @@ py::array_t<double> to_mat4(const misc3d::Matrix4d& T) {
     return a;
 }
 
-// FitPlane / FitSphere / FitCylinder, python/py_common.cpp:11-67
-template <class Ransac, class ModelT>
+// page-locked scratch for index lists, one per thread, grown on demand: the library's compaction kernel stores the list
+// straight into it (a pageable destination is reached through a staged copy into pages that fault on first touch)
+struct PinnedScratch {
+    size_t* p = nullptr;
+    size_t cap = 0;
+    size_t* get(size_t n) {
+        if (n > cap) {
+            if (p) m3d_host_free(p);
+            p = static_cast<size_t*>(m3d_host_alloc(sizeof(size_t) * n));
+            cap = p ? n : 0;
+        }
+        return p;
+    }
+    // (no destructor: a thread-local object of the main thread dies at process exit, possibly after the HIP runtime)
+};
+
+// FitPlane / FitSphere / FitCylinder, python/py_common.cpp:11-67: construct, SetMaxIteration, SetProbability,
+// SetPointCloud, FitModel -- one call of the one-shot C entry point (m3d_fit_plane / _sphere / _cylinder: the same checks in
+// the same order, and no resident cloud to keep: a python call fits once).  as_arrays (keyword-only extra): the inlier
+// indices as an int64 array instead of the reference's list[int] (half a million Python ints cost ~15 ms to build).
+template <int KIND>
 py::tuple fit_impl(const py::object& pc, double threshold, size_t max_iteration, double probability,
-                   const std::optional<uint64_t>& seed, int device, bool needs_normals) {
+                   const std::optional<uint64_t>& seed, int device, bool as_arrays) {
     HostCloud c = extract_cloud(pc);
-    if (needs_normals && !c.has_normals) misc3d::LogError("Fit cylinder requires normals.");  // py_common.cpp:50-52
-    Ransac fit;
-    fit.SetDevice(device);
-    fit.SetMaxIteration(max_iteration);
-    fit.SetProbability(probability);
-    if (seed) fit.SetSeed(*seed);
-    ModelT model;
-    std::vector<size_t> inliers;
-    bool ret;
+    if (KIND == M3D_CYLINDER && !c.has_normals) misc3d::LogError("Fit cylinder requires normals.");  // py_common.cpp:50-52
+    const misc3d::CloudView v = c.view();
+    std::vector<double> params(KIND == M3D_CYLINDER ? 7 : 4, 0.0);
+    static thread_local PinnedScratch scratch;
+    std::vector<size_t> pageable;
+    size_t* idx = nullptr;
+    size_t ni = 0;
+    m3d_stats st{};
+    int rc;
     {
         py::gil_scoped_release nogil;  // the reference holds the GIL; releasing it is unobservable
-        // FitModel's own point-count check (ransac.h:509-513) needs the cloud object, so an empty
-        // cloud is passed through: m3d_cloud_fit raises "Can not fit model due to lack of points"
-        fit.SetPointCloud(c.view());
-        ret = fit.FitModel(threshold, model, inliers);
+        idx = scratch.get(v.n ? v.n : 1);
+        if (!idx) {   // (pinning failed: any host buffer will do)
+            pageable.resize(v.n ? v.n : 1);
+            idx = pageable.data();
+        }
+        const uint64_t sd = seed ? *seed : 0;
+        if (KIND == M3D_CYLINDER)
+            rc = m3d_fit_cylinder(v.xyz, v.normals, v.n, threshold, max_iteration, probability, seed ? &sd : nullptr, device,
+                                  params.data(), idx, &ni, &st);
+        else
+            rc = (KIND == M3D_PLANE ? m3d_fit_plane : m3d_fit_sphere)(v.xyz, v.n, threshold, max_iteration, probability,
+                                                                      seed ? &sd : nullptr, device, params.data(), idx, &ni, &st);
     }
-    if (!ret) model.parameters_.assign(4, 0.0);  // py_common.cpp:21-23,39-41,61-63 (size 4 for the cylinder too)
-    return py::make_tuple(to_array(model.parameters_), inliers);
+    misc3d::CheckStatus(rc);   // "[Misc3D Error] ..." with the reference's texts (probability, lack of points)
+    char buf[160];             // ransac.h:616-619
+    std::snprintf(buf, sizeof(buf), "Find best model with %g%% inliers and run %llu iterations", st.fitness * 100,
+                  (unsigned long long)st.count);
+    misc3d::LogInfo(buf);
+    if (rc != M3D_OK) params.assign(4, 0.0);  // py_common.cpp:21-23,39-41,61-63 (size 4 for the cylinder too)
+    if (as_arrays) {
+        py::array_t<int64_t> a((py::ssize_t)ni);
+        if (ni) std::memcpy(a.mutable_data(), idx, sizeof(size_t) * ni);
+        return py::make_tuple(to_array(params), a);
+    }
+    return py::make_tuple(to_array(params), std::vector<size_t>(idx, idx + ni));
 }
 
 arr_d as_descriptor_matrix(const py::object& f) {
@@ -187,33 +224,30 @@ PYBIND11_MODULE(_py_misc3d, m) {
     mc.def(
         "fit_plane",
         [](const py::object& pc, double threshold, size_t max_iteration, double probability,
-           std::optional<uint64_t> seed, int device) {
-            return fit_impl<misc3d::common::RANSACPlane, misc3d::common::Plane>(pc, threshold, max_iteration,
-                                                                                 probability, seed, device, false);
+           std::optional<uint64_t> seed, int device, bool as_arrays) {
+            return fit_impl<M3D_PLANE>(pc, threshold, max_iteration, probability, seed, device, as_arrays);
         },
         "Fit a plane from point clouds", py::arg("pc"), py::arg("threshold") = 0.01,
         py::arg("max_iteration") = 1000, py::arg("probability") = 0.9999, py::kw_only(),
-        py::arg("seed") = py::none(), py::arg("device") = 0);
+        py::arg("seed") = py::none(), py::arg("device") = 0, py::arg("as_arrays") = false);
     mc.def(
         "fit_sphere",
         [](const py::object& pc, double threshold, size_t max_iteration, double probability,
-           std::optional<uint64_t> seed, int device) {
-            return fit_impl<misc3d::common::RANSACShpere, misc3d::common::Sphere>(pc, threshold, max_iteration,
-                                                                                   probability, seed, device, false);
+           std::optional<uint64_t> seed, int device, bool as_arrays) {
+            return fit_impl<M3D_SPHERE>(pc, threshold, max_iteration, probability, seed, device, as_arrays);
         },
         "Fit a sphere from point clouds", py::arg("pc"), py::arg("threshold") = 0.01,
         py::arg("max_iteration") = 1000, py::arg("probability") = 0.9999, py::kw_only(),
-        py::arg("seed") = py::none(), py::arg("device") = 0);
+        py::arg("seed") = py::none(), py::arg("device") = 0, py::arg("as_arrays") = false);
     mc.def(
         "fit_cylinder",
         [](const py::object& pc, double threshold, size_t max_iteration, double probability,
-           std::optional<uint64_t> seed, int device) {
-            return fit_impl<misc3d::common::RANSACCylinder, misc3d::common::Cylinder>(
-                pc, threshold, max_iteration, probability, seed, device, true);
+           std::optional<uint64_t> seed, int device, bool as_arrays) {
+            return fit_impl<M3D_CYLINDER>(pc, threshold, max_iteration, probability, seed, device, as_arrays);
         },
         "Fit a cylinder from point clouds", py::arg("pc"), py::arg("threshold") = 0.01,
         py::arg("max_iteration") = 1000, py::arg("probability") = 0.9999, py::kw_only(),
-        py::arg("seed") = py::none(), py::arg("device") = 0);
+        py::arg("seed") = py::none(), py::arg("device") = 0, py::arg("as_arrays") = false);
 
     // ---- segmentation (python/py_segmentation.cpp:87-96)
     py::module ms = m.def_submodule("segmentation");

@@ -100,6 +100,14 @@ def test_fit_functions_match_oracle(m3d, orc):
     assert w.shape == (7,) and idx == o.inliers.tolist() and np.array_equal(w, o.params)
     w2, idx2 = m3d.common.fit_cylinder((cp, cn), 0.01, 200, seed=5)
     assert np.array_equal(w, w2) and idx == idx2
+    # keyword-only extra: the indices as an int64 array instead of the reference's list[int]; many hypotheses take the
+    # Hilbert-sorted path, few the dense one (same results)
+    for it in (100, 3000):
+        wa, ia = m3d.common.fit_plane(pts, 0.01, it, 1.0, seed=7, as_arrays=True)
+        wl, il = m3d.common.fit_plane(pts, 0.01, it, 1.0, seed=7)
+        ob = orc.fit(orc.PLANE, pts, thr=0.01, max_iter=it, prob=1.0, seed=7)
+        assert isinstance(ia, np.ndarray) and ia.dtype == np.int64 and ia.tolist() == il == ob.inliers.tolist()
+        assert np.array_equal(wa, wl) and np.allclose(wa, ob.params, atol=1e-9)
     # unseeded call (reference behaviour: std::random_device) still finds the plane
     w, idx = m3d.common.fit_plane(pts)
     assert abs(abs(w[2]) - 1) < 1e-2 and len(idx) > 0.5 * len(pts)
