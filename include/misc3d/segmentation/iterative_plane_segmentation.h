@@ -2,6 +2,8 @@
 // include/misc3d/segmentation/iterative_plane_segmentation.h:25-28 /
 // src/iterative_plane_segmentation.cpp:8-39 over m3d_segment_plane_iterative.
 #pragma once
+#include <cstring>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -35,6 +37,7 @@ inline std::vector<PlaneCluster> SegmentPlaneIterativeIndexed(const CloudView& p
     const size_t max_clusters = 4096;
     std::vector<double> planes(4 * max_clusters);
     std::vector<size_t> offsets(max_clusters + 1), indices(pcd.n);
+    std::unique_ptr<double[]> gathered;
     size_t k = 0;
     int status;
     if (!devices.empty())
@@ -45,18 +48,29 @@ inline std::vector<PlaneCluster> SegmentPlaneIterativeIndexed(const CloudView& p
         status = m3d_segment_plane_iterative_sharded(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed, device,
                                                      comm, max_clusters, planes.data(), offsets.data(),
                                                      indices.data(), &k);
-    else
-        status = m3d_segment_plane_iterative(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed, device,
-                                             max_clusters, planes.data(), offsets.data(), indices.data(), &k);
+    else {
+        // one device: the clusters' points are gathered on the device (m3d_segment_plane_iterative_clouds)
+        gathered.reset(new double[3 * pcd.n]);
+        status = m3d_segment_plane_iterative_clouds(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed, device,
+                                                    max_clusters, planes.data(), offsets.data(), indices.data(),
+                                                    gathered.get(), &k);
+    }
     const int rc = CheckStatus(status);
     if (rc == 2) LogWarning("segment_plane_iterative: a round found no inlier; stopping early");
     result.resize(k);
+    static_assert(sizeof(Vector3d) == 3 * sizeof(double), "Vector3d is three packed doubles");
     for (size_t c = 0; c < k; ++c) {
         for (int j = 0; j < 4; ++j) result[c].plane[j] = planes[4 * c + j];
-        result[c].indices.assign(indices.begin() + offsets[c], indices.begin() + offsets[c + 1]);
-        result[c].cloud.points_.reserve(result[c].indices.size());
-        for (size_t i : result[c].indices)
-            result[c].cloud.points_.push_back({pcd.xyz[3 * i], pcd.xyz[3 * i + 1], pcd.xyz[3 * i + 2]});
+        const size_t lo = offsets[c], cnt = offsets[c + 1] - offsets[c];
+        result[c].indices.assign(indices.begin() + lo, indices.begin() + lo + cnt);
+        auto& P = result[c].cloud.points_;
+        if (gathered) {
+            P.resize(cnt);
+            if (cnt) std::memcpy(static_cast<void*>(P.data()), gathered.get() + 3 * lo, sizeof(double) * 3 * cnt);
+        } else {
+            P.reserve(cnt);
+            for (size_t i : result[c].indices) P.push_back({pcd.xyz[3 * i], pcd.xyz[3 * i + 1], pcd.xyz[3 * i + 2]});
+        }
     }
     return result;
 }

@@ -175,6 +175,9 @@ def lib():
         L.m3d_comm_collectives.argtypes = [C.c_void_p]
         L.m3d_cloud_fit_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_double, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.m3d_segment_plane_iterative_clouds.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double,
+                                                          C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p]
         L.m3d_segment_plane_iterative_sharded.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double,
                                                           C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                                           C.c_void_p, C.c_void_p, C.c_void_p]
@@ -717,8 +720,9 @@ def _seg_scratch(n):
 
 
 def segment_plane_iterative(xyz, threshold, max_iteration=100, min_ratio=0.05, seed=None, device=0,
-                            max_clusters=4096, copy=True):
-    """m3d_segment_plane_iterative.  copy=True (default): the library writes the index lists into a page-locked scratch
+                            max_clusters=4096, copy=True, with_points=False):
+    """m3d_segment_plane_iterative (with_points: m3d_segment_plane_iterative_clouds -- a fourth return value, the list of
+    the clusters' (count, 3) point arrays, views of one array gathered on the device).  copy=True (default): the library writes the index lists into a page-locked scratch
     the binding keeps per thread, every cluster is returned as an array of its own.  copy=False returns the clusters as
     views of ONE pageable index array instead (no copies, but the library then reaches the array through staged copies
     and fresh pages: on 10 M points 43 ms against 37)."""
@@ -734,12 +738,21 @@ def segment_plane_iterative(xyz, threshold, max_iteration=100, min_ratio=0.05, s
         idx = np.empty(max(n, 1), dtype=np.uint64)
     k = C.c_size_t(0)
     _s, sref = _seed_ref(seed)
-    rc = _check(lib().m3d_segment_plane_iterative(_p(xyz), n, threshold, max_iteration, min_ratio,
-                                                  C.cast(sref, C.c_void_p) if sref else None, device, max_clusters,
-                                                  _p(planes), _p(offs), _p(idx), C.cast(C.byref(k), C.c_void_p)))
+    if with_points:
+        cpts = np.empty((max(n, 1), 3))
+        rc = _check(lib().m3d_segment_plane_iterative_clouds(_p(xyz), n, threshold, max_iteration, min_ratio,
+                                                             C.cast(sref, C.c_void_p) if sref else None, device,
+                                                             max_clusters, _p(planes), _p(offs), _p(idx), _p(cpts),
+                                                             C.cast(C.byref(k), C.c_void_p)))
+    else:
+        rc = _check(lib().m3d_segment_plane_iterative(_p(xyz), n, threshold, max_iteration, min_ratio,
+                                                      C.cast(sref, C.c_void_p) if sref else None, device, max_clusters,
+                                                      _p(planes), _p(offs), _p(idx), C.cast(C.byref(k), C.c_void_p)))
     k = k.value
-    return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() if copy else idx[int(offs[i]): int(offs[i + 1])]
-                                   for i in range(k)]
+    clusters = [idx[int(offs[i]): int(offs[i + 1])].copy() if copy else idx[int(offs[i]): int(offs[i + 1])] for i in range(k)]
+    if with_points:
+        return rc, planes[:k].copy(), clusters, [cpts[int(offs[i]): int(offs[i + 1])] for i in range(k)]
+    return rc, planes[:k].copy(), clusters
 
 
 def last_segment_ms():

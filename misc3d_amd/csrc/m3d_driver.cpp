@@ -2335,7 +2335,8 @@ size_t m3d_cloud_original_size(const m3d_cloud* c) { return c ? (c->work.active 
 // SegmentPlaneIterative, src/iterative_plane_segmentation.cpp:8-39
 static int segment_impl(const double* xyz, size_t n, double threshold, int max_iteration, double min_ratio,
                         const uint64_t* seed, int device, m3d_comm* comm, size_t max_clusters, double* planes,
-                        size_t* cluster_offsets, size_t* cluster_indices, size_t* n_clusters) {
+                        size_t* cluster_offsets, size_t* cluster_indices, size_t* n_clusters,
+                        double* cluster_points = nullptr /* n x 3: the xyz of cluster_indices[i] at 3 i (may be null) */) {
     if (!planes || !cluster_offsets || !cluster_indices || !n_clusters || (!xyz && n))
         return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     *n_clusters = 0;
@@ -2453,6 +2454,21 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         (void)hipStreamSynchronize(ctx->stream);
         if (rc == M3D_OK) rc = cloud_remove_check_pending(c0);
         t_rounds = now_ms();
+        // the clusters' points (SelectByIndex, :32): gathered from the resident cloud as created, one copy back
+        if ((rc == M3D_OK || rc == 2) && cluster_points && k && cluster_offsets[k]) {
+            const size_t total = cluster_offsets[k];
+            DevBuf d_idx, d_out;
+            bool ok = d_idx.reserve(sizeof(uint64_t) * total) && d_out.reserve(sizeof(double) * 3 * total);
+            ok = ok && hipMemcpyAsync(d_idx.p, idx_out, sizeof(uint64_t) * total, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+            if (ok) {
+                launch_gather_points(c0->base_view(), d_idx.as<uint64_t>(), total, d_out.as<double>(), ctx->stream);
+                ok = hipMemcpyAsync(cluster_points, d_out.p, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                     hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+            }
+            d_idx.release();
+            d_out.release();
+            if (!ok) rc = fail(M3D_ERR_DEVICE, "gathering the clusters' points failed");
+        }
         if (idx_out != cluster_indices && k) std::memcpy(cluster_indices, idx_out, sizeof(size_t) * cluster_offsets[k]);
         t_copied = now_ms();
     }
@@ -2473,6 +2489,14 @@ int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, i
                                 size_t* n_clusters) {
     return segment_impl(xyz, n, threshold, max_iteration, min_ratio, seed, device, nullptr, max_clusters, planes,
                         cluster_offsets, cluster_indices, n_clusters);
+}
+
+int m3d_segment_plane_iterative_clouds(const double* xyz, size_t n, double threshold, int max_iteration,
+                                       double min_ratio, const uint64_t* seed, int device, size_t max_clusters,
+                                       double* planes, size_t* cluster_offsets, size_t* cluster_indices,
+                                       double* cluster_points, size_t* n_clusters) {
+    return segment_impl(xyz, n, threshold, max_iteration, min_ratio, seed, device, nullptr, max_clusters, planes,
+                        cluster_offsets, cluster_indices, n_clusters, cluster_points);
 }
 
 int m3d_segment_plane_iterative_sharded(const double* xyz, size_t n, double threshold, int max_iteration,

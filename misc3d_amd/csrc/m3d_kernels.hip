@@ -763,6 +763,21 @@ void launch_compact(int kind, const CloudView& c, const double* model, double th
                                n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host, total_host, part);
 }
 
+// cluster = pcd_copy->SelectByIndex(inliers) (iterative_plane_segmentation.cpp:32): the points of an index list, AoS, in
+// list order.  On the host this is a strided walk over the whole input per big cluster (140 ms for the clusters of a
+// 10 M-point room); on the device the resident SoA copy is gathered at HBM speed and shipped in one copy.
+__global__ void gather_points_k(CloudView c, const uint64_t* __restrict__ idx, size_t total, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t j = idx[i];
+    out[3 * i] = c.x[j];
+    out[3 * i + 1] = c.y[j];
+    out[3 * i + 2] = c.z[j];
+}
+void launch_gather_points(const CloudView& c, const uint64_t* idx, size_t total, double* out, hipStream_t s) {
+    if (total) gather_points_k<<<(uint32_t)((total + 255) / 256), 256, 0, s>>>(c, idx, total, out);
+}
+
 // EvaluateModel's `error += distance` in point order (ransac.h:637): a genuinely serial fp64 chain.
 // One wave: each lane loads one value of the next 64 (coalesced, prefetched one tile ahead), the
 // values are broadcast in order with v_readlane (independent of the chain) and EVERY lane performs

@@ -88,6 +88,8 @@ struct PartitionOut {
     uint32_t* oorig = nullptr;
     uint32_t n_pad_cap = 0;
 };
+// out[3 i ..] = the point idx[i] of the cloud (AoS xyz), i < total
+void launch_gather_points(const CloudView& c, const uint64_t* idx, size_t total, double* out, hipStream_t s);
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,

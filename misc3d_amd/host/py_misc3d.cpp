@@ -255,14 +255,34 @@ PYBIND11_MODULE(_py_misc3d, m) {
         "segment_plane_iterative",
         [](const py::object& pcd, double threshold, int max_iteration, double min_ratio,
            std::optional<uint64_t> seed, int device, bool return_indices) {
+            // One call of m3d_segment_plane_iterative_clouds (what SegmentPlaneIterativeIndexed makes, without the
+            // PlaneCluster copies in between): the clusters' points arrive gathered by the device in ONE (total, 3) array
+            // and each cluster is a view of its rows; return_indices: its rows of the one int64 index array.
             HostCloud c = extract_cloud(pcd);
-            std::vector<misc3d::segmentation::PlaneCluster> res;
+            const misc3d::CloudView v = c.view();
+            py::list out;
+            if (v.n < 3) {  // iterative_plane_segmentation.cpp:13-17
+                misc3d::LogWarning("Point cloud size has less than 3.");
+                return out;
+            }
+            const size_t max_clusters = 4096;
+            std::vector<double> planes(4 * max_clusters);
+            std::vector<size_t> offsets(max_clusters + 1);
+            py::array_t<int64_t> indices((py::ssize_t)v.n);
+            arr_d points(std::vector<py::ssize_t>{(py::ssize_t)v.n, 3});
+            static_assert(sizeof(size_t) == sizeof(int64_t), "index arrays are 64-bit");
+            size_t k = 0;
+            int status;
             {
                 py::gil_scoped_release nogil;
                 uint64_t s = seed ? *seed : 0;
-                res = misc3d::segmentation::SegmentPlaneIterativeIndexed(c.view(), threshold, max_iteration,
-                                                                         min_ratio, seed ? &s : nullptr, device);
+                status = m3d_segment_plane_iterative_clouds(v.xyz, v.n, threshold, max_iteration, min_ratio,
+                                                            seed ? &s : nullptr, device, max_clusters, planes.data(),
+                                                            offsets.data(), reinterpret_cast<size_t*>(indices.mutable_data()),
+                                                            points.mutable_data(), &k);
             }
+            if (misc3d::CheckStatus(status) == 2)
+                misc3d::LogWarning("segment_plane_iterative: a round found no inlier; stopping early");
             py::object o3d = py::none();
             if (py::hasattr(pcd, "points")) {
                 try {
@@ -271,19 +291,15 @@ PYBIND11_MODULE(_py_misc3d, m) {
                     o3d = py::none();
                 }
             }
-            py::list out;
-            for (auto& cl : res) {
+            for (size_t cix = 0; cix < k; ++cix) {
                 py::array_t<double> plane(4);
-                std::memcpy(plane.mutable_data(), cl.plane.data(), sizeof(double) * 4);
-                py::array_t<double> pts(std::vector<py::ssize_t>{(py::ssize_t)cl.cloud.points_.size(), 3});
-                if (!cl.cloud.points_.empty())
-                    std::memcpy(pts.mutable_data(), cl.cloud.points_[0].data(),
-                                sizeof(double) * 3 * cl.cloud.points_.size());
-                py::object cluster = pts;
+                std::memcpy(plane.mutable_data(), &planes[4 * cix], sizeof(double) * 4);
+                const py::slice rows((py::ssize_t)offsets[cix], (py::ssize_t)offsets[cix + 1], 1);
+                py::object cluster = points[rows];
                 if (!o3d.is_none())  // list[(ndarray(4), open3d PointCloud)] like the reference
-                    cluster = o3d.attr("geometry").attr("PointCloud")(o3d.attr("utility").attr("Vector3dVector")(pts));
+                    cluster = o3d.attr("geometry").attr("PointCloud")(o3d.attr("utility").attr("Vector3dVector")(cluster));
                 if (return_indices)
-                    out.append(py::make_tuple(plane, cluster, cl.indices));
+                    out.append(py::make_tuple(plane, cluster, indices[rows]));
                 else
                     out.append(py::make_tuple(plane, cluster));
             }

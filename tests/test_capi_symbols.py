@@ -16,7 +16,7 @@ def test_header_symbols_exported(capi):
     import os
     names = _declared_functions(open(capi.HEADER_PATH).read())
     assert len(names) >= 40
-    for need in ("m3d_cloud_fit_sharded", "m3d_comm_create_rccl", "m3d_segment_plane_iterative_multi",
+    for need in ("m3d_cloud_fit_sharded", "m3d_comm_create_rccl", "m3d_segment_plane_iterative_multi", "m3d_segment_plane_iterative_clouds",
                  "m3d_registration_ransac_sharded", "m3d_set_config"):
         assert need in names
     # measurement hooks live in their own header: none of them in the product header

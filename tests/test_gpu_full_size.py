@@ -146,3 +146,18 @@ def test_c5_segmentation_full_size(capi):
     assert found == 6
     rc2, planes2, clusters2 = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.05, seed=19)
     assert rc2 == rc and np.array_equal(planes, planes2) and all(np.array_equal(a, b) for a, b in zip(clusters, clusters2))
+
+
+def test_c5_cluster_points_full_size(capi):
+    """The reference's return shape (plane, cluster CLOUD): m3d_segment_plane_iterative_clouds gathers the clusters' points
+    on the device -- SelectByIndex (iterative_plane_segmentation.cpp:32) bit for bit, the planes and index lists those of the
+    index-only call."""
+    n = 10_000_000
+    pts = synth.room_cloud_c5(n, 6)
+    rc, planes, clusters = capi.segment_plane_iterative(pts, 0.01, max_iteration=100, min_ratio=0.05, seed=19)
+    rc2, planes2, clusters2, clouds = capi.segment_plane_iterative(pts, 0.01, max_iteration=100, min_ratio=0.05, seed=19,
+                                                                   with_points=True)
+    assert rc2 == rc and np.array_equal(planes, planes2) and len(clouds) == len(clusters) >= 6
+    for a, b, p in zip(clusters, clusters2, clouds):
+        assert np.array_equal(a, b)
+        assert p.shape == (len(a), 3) and np.array_equal(p.view(np.uint64), pts[a.astype(np.int64)].view(np.uint64))

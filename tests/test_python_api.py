@@ -134,7 +134,9 @@ def test_segmentation_and_registration_api(m3d, orc):
     rc, oplanes, oclusters = orc.segment_plane_iterative(pts, 0.01, 100, 0.1, seed=3)
     assert len(res) == len(oplanes) >= 2
     for (plane, cloud, idx), op, oc in zip(res, oplanes, oclusters):
-        assert np.allclose(plane, op, atol=1e-9) and idx == oc.tolist()
+        assert np.allclose(plane, op, atol=1e-9)
+        assert idx.dtype == np.int64 and np.array_equal(idx, oc.astype(np.int64))     # (rows of one index array)
+        # the cluster's points are gathered on the device (m3d_segment_plane_iterative_clouds): SelectByIndex, bit for bit
         assert np.array_equal(np.asarray(cloud), pts[oc.astype(np.int64)])
     res2 = m3d.segmentation.segment_plane_iterative(pts, 0.01, 100, 0.1, seed=3)
     assert len(res2[0]) == 2
