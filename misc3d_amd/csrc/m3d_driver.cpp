@@ -685,59 +685,31 @@ static int exact_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
     return M3D_OK;
 }
 
-// Order-free sum of the inlier distances (tree) + count: enough to decide most ties (see tie rule
-// in run_ransac).
-static int approx_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
-                        const double* model_dev, uint64_t* count, double* error) {
-    RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
-    RESERVE(ctx->sums, sizeof(double) * 32);
-    RESERVE(ctx->total, sizeof(uint32_t) * 4);
-    RESERVE(ctx->h_small, 256);
-    launch_error_sum(kind, v, model_dev, thr, ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 20,
-                     ctx->total.as<uint32_t>() + 2, ctx->stream);
-    uint8_t* h = ctx->h_small.as<uint8_t>();
-    HIPCHK(hipMemcpyAsync(h, ctx->total.as<uint32_t>() + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(h + 8, ctx->sums.as<double>() + 20, sizeof(double), hipMemcpyDeviceToHost,
-                          ctx->stream));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    uint32_t c32;
-    std::memcpy(&c32, h, 4);
-    std::memcpy(error, h + 8, 8);
-    *count = c32;
-    return M3D_OK;
-}
-
-// The tie rule's first comparison needs the order-free sums of BOTH models (trial and incumbent): one wait for the two
-// (a segmentation of a 10 M-point room meets ~20 equal counts: two ~65 us round trips each became one).
+// Order-free sums of the inlier distances (tree) + counts of the trial model and, when its sum is not known yet, of the
+// incumbent (model_b != null): enough to decide most ties (see the tie rule in run_ransac).  ONE pass over the cloud for
+// both, the results stored into pinned memory by the kernel's last workgroup: one launch and one wait per tie.
 static int approx_error_pair(DeviceCtx* ctx, const CloudView& v, int kind, double thr, const double* model_a,
                              const double* model_b, uint64_t* count_a, double* error_a, uint64_t* count_b, double* error_b) {
-    RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
-    RESERVE(ctx->sums, sizeof(double) * 32);
-    RESERVE(ctx->total, sizeof(uint32_t) * 4);
-    RESERVE(ctx->tie_scratch, sizeof(double) * (kSumPartialDoubles + 4));
+    const bool fresh = ctx->tie_scratch.cap == 0;
+    RESERVE(ctx->tie_scratch, sizeof(double) * (kErrorSumScratchDoubles + 2));
     RESERVE(ctx->h_tie, 64);
-    double* part_b = ctx->tie_scratch.as<double>();
-    double* sum_b = part_b + kSumPartialDoubles;
-    uint32_t* cnt_b = reinterpret_cast<uint32_t*>(sum_b + 2);
-    launch_error_sum(kind, v, model_a, thr, ctx->sum_partial.as<double>(), ctx->sums.as<double>() + 20,
-                     ctx->total.as<uint32_t>() + 2, ctx->stream);
-    launch_error_sum(kind, v, model_b, thr, part_b, sum_b, cnt_b, ctx->stream);
-    uint8_t* h = ctx->h_tie.as<uint8_t>();
-    HIPCHK(hipMemcpyAsync(h, ctx->total.as<uint32_t>() + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(h + 8, ctx->sums.as<double>() + 20, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(h + 16, cnt_b, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(h + 24, sum_b, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(ctx->tie_scratch.as<double>() + kErrorSumScratchDoubles);
+    if (fresh) HIPCHK(hipMemsetAsync(ticket, 0, sizeof(uint32_t), ctx->stream));
+    double* h = ctx->h_tie.as<double>();
+    launch_error_sum(kind, v, model_a, model_b, thr, ctx->tie_scratch.as<double>(), ticket, h, ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    uint32_t c32;
-    std::memcpy(&c32, h, 4);
-    *count_a = c32;
-    std::memcpy(error_a, h + 8, 8);
-    std::memcpy(&c32, h + 16, 4);
-    *count_b = c32;
-    std::memcpy(error_b, h + 24, 8);
+    *count_a = (uint64_t)h[0];
+    *error_a = h[1];
+    if (model_b) {
+        *count_b = (uint64_t)h[2];
+        *error_b = h[3];
+    }
     return M3D_OK;
+}
+static int approx_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
+                        const double* model_dev, uint64_t* count, double* error) {
+    return approx_error_pair(ctx, v, kind, thr, model_dev, nullptr, count, error, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -125,10 +125,12 @@ void launch_general_fit_sums(const CloudView& c, const uint64_t* idx, uint32_t n
                              double* out_host, hipStream_t s);
 void general_fit_sums_finish(const double* out_host, double* sums14);
 
-// order-free sum of the inlier distances of one model + its inlier count (first stage of the tie
-// rule); partial: kSumPartialDoubles doubles.
-void launch_error_sum(int kind, const CloudView& c, const double* model, double thr, double* partial,
-                      double* sum_out, uint32_t* count_out, hipStream_t s);
+// order-free sums of the inlier distances of one or two models (model_b may be null) + their inlier counts, one pass
+// (first stage of the tie rule).  out_host (device-visible host memory, 4 doubles) = (count_a, sum_a, count_b, sum_b),
+// stored by the launch's last workgroup; partial: kErrorSumScratchDoubles doubles; ticket: a zeroed u32 the kernel resets.
+constexpr int kErrorSumScratchDoubles = 1024 * 4;
+void launch_error_sum(int kind, const CloudView& c, const double* model_a, const double* model_b, double thr,
+                      double* partial, uint32_t* ticket, double* out_host, hipStream_t s);
 
 // exclusive scan of v[0..nb) in place by one workgroup; total[0] = sum
 void launch_scan_blocks(uint32_t* v, uint32_t nb, uint32_t* total, hipStream_t s);
