@@ -866,7 +866,8 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
     if (expected_ni >= 0 && (uint64_t)expected_ni <= n) {
         const uint32_t ni_e = (uint32_t)expected_ni;
         const bool need_fit_e = kind != M3D_CYLINDER && ni_e >= (kind == M3D_PLANE ? 3u : 4u);
-        HIPCHK(hipEventRecord(ctx->ev_compact, ctx->stream));
+        if (!(compaction_total && ctx->ev_compact_early)) HIPCHK(hipEventRecord(ctx->ev_compact, ctx->stream));
+        ctx->ev_compact_early = false;
         // page-locked destination (m3d_host_alloc): the index list leaves NOW, on the copy stream, under the sums
         // (or has been written by the compaction itself: idx_on_host)
         const bool early_copy = !idx_on_host && inliers && ni_e && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)ni_e);
@@ -1130,6 +1131,13 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
                                         ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true,
                                         idx_host, part);
             ctx->spec_compaction = r == M3D_OK;
+            // ... and so does the removal of the same inliers from the sorted copy (-3): by the time the host has replayed
+            // the round and learnt the inlier count, the device is already through both
+            // (RefineModel waits for ev_compact: recorded here, in front of the removal, not when refine() gets to run)
+            if (r == M3D_OK && part && hipEventRecord(ctx->ev_compact, ctx->stream) == hipSuccess) {
+                ctx->ev_compact_early = true;
+                (void)(*ctx->partition_hook)(-3);
+            }
         }
         if (r == M3D_OK && spec && !fused_pick) {
             ChunkSlot& sl = ctx->slot[slot_id];
@@ -1349,6 +1357,8 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
                              ? reinterpret_cast<uint64_t*>(inliers) : nullptr;
     ctx->compaction_idx_host = nullptr;
     ctx->compaction_fused = false;
+    ctx->spec_hit = false;
+    ctx->ev_compact_early = false;
     int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro, iterations_hint ? *iterations_hint : 0,
                         orig, comm, idx_host);
     if (rc != M3D_OK) return rc;
@@ -1369,6 +1379,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         const bool hit = ro.st.best_index >= 0 ? (ph->have && ph->index == (unsigned long long)ro.st.best_index) : !ph->have;
         ro.spec_hits = hit ? 1 : 0;
         ro.spec_misses = hit ? 0 : 1;
+        ctx->spec_hit = hit;
         if (hit) {
             rc = refine(ctx, v, gather, orig, kind, thr, ctx->pick.as<BestPick>()->params, model, inliers, &ni, &gf_ok,
                         expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true);
@@ -1472,7 +1483,10 @@ static int cloud_remove_prepare(m3d_cloud* c, PartitionOut* out) {
     return M3D_OK;
 }
 // partition_done: the partition in creation order has been written by RefineModel's own compaction (PartitionOut)
-static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* model_dev, bool partition_done = false) {
+// same_slot: a second issue of the SAME round (the first one, queued on the device's early pick, named another model): the
+// totals go where the first one's went -- the other slot still belongs to the previous round's deferred check
+static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* model_dev, bool partition_done = false,
+                              bool same_slot = false) {
     DeviceCtx* ctx = c->ctx;
     m3d_cloud::Work& w = c->work;
     PartitionOut po;
@@ -1488,7 +1502,7 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
     w.partition_done = partition_done;
     // the totals go to pinned host memory from the compaction kernels' own tails (two slots: a deferred check reads the
     // previous removal's totals after the next one has been queued) -- a copy command per round less
-    w.totals_slot ^= 1;
+    if (!same_slot) w.totals_slot ^= 1;
     uint32_t* h_totals = reinterpret_cast<uint32_t*>(ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot);
     if (!partition_done)
         launch_compact(kind, cur, model_dev, thr, 2, w.cur_orig, nullptr, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap,
@@ -2363,13 +2377,19 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             // The removal of the round's inliers (:33) is queued behind RefineModel's kernels, before RefineModel
             // waits for them: the pre-refinement model is already on the device and the inlier count is known
             // from the scoring pass, so the round costs one host wait less.  Not on the last round.
-            bool removal_issued = false, partition_fused = false;
+            bool removal_issued = false, partition_fused = false, spec_removal = false;
             PartitionOut part_out;
             // RefineModel's compaction evaluates the very flags the removal needs: it writes the partition of the cloud
             // in creation order as well (one count, one scan and one write launch less per round)
             const std::function<const PartitionOut*(int64_t)> partition_hook = [&](int64_t expected_ni) -> const PartitionOut* {
                 // -2: asked before the inlier count is known (compaction queued on the device's own pick, run_ransac): the
                 // partition goes to the spare buffers and is simply not used should this turn out to be the last round
+                if (expected_ni == -3) {   // the speculative compaction has been queued: the sorted copy's removal behind it
+                    if (partition_fused && !spec_removal &&
+                        cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->pick.as<BestPick>()->params, true) == M3D_OK)
+                        spec_removal = true;
+                    return nullptr;
+                }
                 if (expected_ni == -2) {
                     if (k + 1 >= max_clusters) return nullptr;
                 } else if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) {
@@ -2382,7 +2402,8 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             const std::function<int(int64_t)> issue_removal = [&](int64_t expected_ni) -> int {
                 if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) return M3D_OK;
                 removal_issued = true;
-                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev, partition_fused);
+                if (spec_removal && ctx->spec_hit) return M3D_OK;   // (queued on the device's pick, which the replay confirmed)
+                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev, partition_fused, /*same_slot=*/spec_removal);
             };
             ctx->partition_hook = &partition_hook;
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,

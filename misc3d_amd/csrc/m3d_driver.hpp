@@ -91,6 +91,8 @@ struct DeviceCtx {
     DevBuf pick;               // BestPick: the device's prediction of the winning hypothesis (probability-1 fits)
     PinBuf h_pick;             // BestPickHost mirror (+ at byte 64: inlier total of a compaction started on the prediction)
     bool spec_compaction = false;   // RefineModel's compaction has already been queued on pick->params
+    bool ev_compact_early = false;  // ... and ev_compact was recorded right behind it (a removal has been queued after it)
+    bool spec_hit = false;          // ... and the replay named the same hypothesis (cloud_fit_locked)
     PinBuf h_sums;             // GeneralFit: per-workgroup moment partials + coordinate sums, written by the kernels
     DevBuf moment_partial;     // fused RefineModel: per-workgroup raw moments of the compaction's counting pass
     PinBuf h_moments;          // ... folded (scan_blocks_k), device-visible: kFusedMomentDoubles doubles
