@@ -20,7 +20,7 @@ JSON objects besides the contract's fields:
                launch that also runs the box tests; neither their pairs nor its time are in this object.
                Instructions per (point, hypothesis): 3.625 for the plane's packed-fp32 screen (29 per lane and hypothesis for
                the lane's 8 points: 16 v_pk_fma, 8 v_alignbit, 4 v_min3, v_cmp -- the ISA of the loop, not an
-               estimate; the fp64 loop it replaced: 7), 5.625 for the sphere's (45 per 8 points; fp64: 10), 6.625 for the cylinder (53; fp64: 22).
+               estimate; the fp64 loop it replaced: 7), 4.125 for the sphere (33 per 8 points in the expanded form; fp64: 10), 6.125 for the cylinder (49; fp64: 22).
                peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T lane-instructions/s: a wave64 VALU instruction
                (fp64, fp32, packed fp32 or integer alike) occupies its SIMD for 4 cycles.  `traffic` = HBM bytes per launch from the PMC pass under
                profiles/.  `algorithmic_reuse` restates SURVEY.md 8(d)'s 24 B/(hypothesis, point) figure: it is far
@@ -66,7 +66,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (non-FMA ops; FMA peak 78.6 TF)
 ALG_BYTES_PER_PAIR = 24.0      # one fp64 xyz read per (hypothesis, point), SURVEY.md 8(d)
 VALU_OPS_FP64 = {0: 7, 1: 10, 2: 22}      # fp64 VALU instructions per (point, hypothesis) incl. compares: score_mask_k, score_k
-VALU_OPS_SCREEN = {0: 3.625, 1: 5.625, 2: 6.625}     # score_screen_k: packed-fp32 screen (m3d_cull_kernels.hip): 29 / 45 / 53 instructions per 8 points
+VALU_OPS_SCREEN = {0: 3.625, 1: 4.125, 2: 6.125}     # score_screen_k: packed-fp32 screen (m3d_cull_kernels.hip): 29 / 33 / 49 instructions per 8 points
 KERNEL_FP64 = {0: "m3d::score_mask_k<0>", 1: "m3d::score_mask_k<1>", 2: "m3d::score_mask_k<2>"}
 KERNEL_SCREEN = {0: "m3d::score_screen_k<0>", 1: "m3d::score_screen_k<1>", 2: "m3d::score_screen_k<2>"}
 WORKLOADS = {   # name -> (kind, default hypotheses, threshold, seed, label)

@@ -631,7 +631,8 @@ constexpr int kCntStride = 64;              // bytes per row of the count table
 // bits: 8 sign bits (point inside <=> 1); m: min over the lane's points of the distance to the decision boundary
 template <int KIND, int Q>
 __device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, const float4 rc, const f32x2 (&xf)[Q],
-                                            const f32x2 (&yf)[Q], const f32x2 (&zf)[Q], uint32_t& bits, float& m) {
+                                            const f32x2 (&yf)[Q], const f32x2 (&zf)[Q], const f32x2 (&wf)[Q] /* sphere: |x~|^2 */,
+                                            uint32_t& bits, float& m) {
     uint32_t acc = 0;
     float mn = __builtin_inff();
     if (KIND == 0) {   // ra = (a, b, c, mid2), rb = (D, h, -, -)
@@ -652,12 +653,11 @@ __device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, co
             acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(s[j].y), 31);
             mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(s[j].x)), __builtin_fabsf(s[j].y));   // one v_min3_f32
         }
-    } else if (KIND == 2) {   // ra = (E1x, E1y, E1z, D1), rb = (E2x, E2y, E2z, D2), rc = (mid, half, h, -)
+    } else if (KIND == 2) {   // ra = (E1x, E1y, E1z, D1), rb = (E2x, E2y, E2z, D2), rc = (mid, half^2, h, -)
         // t = (E1 . q + D1)^2 + (E2 . q + D2)^2: two plane values (m3d_fp.hpp: the exact code's |(q - p1) x (q - p2)|^2)
         const f32x2 AX = {ra.x, ra.x}, AY = {ra.y, ra.y}, AZ = {ra.z, ra.z}, AD = {ra.w, ra.w};
         const f32x2 BX = {rb.x, rb.x}, BY = {rb.y, rb.y}, BZ = {rb.z, rb.z}, BD = {rb.w, rb.w};
-        const f32x2 MID = {-rc.x, -rc.x};
-        const float half = rc.y;
+        const f32x2 MID = {-rc.x, -rc.x}, H2 = {-rc.y, -rc.y};
         f32x2 d1[Q], d2[Q];
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
@@ -677,39 +677,33 @@ __device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, co
 #pragma unroll
         for (int j = 0; j < Q; ++j) d1[j] = __builtin_elementwise_fma(d1[j], d1[j], MID);
 #pragma unroll
-        for (int j = 0; j < Q; ++j) d1[j] = __builtin_elementwise_fma(d2[j], d2[j], d1[j]);
+        for (int j = 0; j < Q; ++j) d1[j] = __builtin_elementwise_fma(d2[j], d2[j], d1[j]);   // t - mid
+#pragma unroll
+        for (int j = 0; j < Q; ++j) d1[j] = __builtin_elementwise_fma(d1[j], d1[j], H2);     // q = (t - mid)^2 - half^2
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            const float va = __builtin_fabsf(d1[j].x) - half, vb = __builtin_fabsf(d1[j].y) - half;
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(va), 31);
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(vb), 31);
-            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(va)), __builtin_fabsf(vb));
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d1[j].x), 31);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d1[j].y), 31);
+            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(d1[j].x)), __builtin_fabsf(d1[j].y));
         }
-    } else {           // ra = (mid, half, -, -), rb = (Cx, Cy, Cz, h)
-        const f32x2 CX = {rb.x, rb.x}, CY = {rb.y, rb.y}, CZ = {rb.z, rb.z}, MID = {-ra.x, -ra.x};
-        const float half = ra.y;
+    } else {           // ra = (K, half^2, -, -), rb = (-2 Cx, -2 Cy, -2 Cz, h): the expanded form (sphere_screen_record)
+        const f32x2 CX = {rb.x, rb.x}, CY = {rb.y, rb.y}, CZ = {rb.z, rb.z}, KK = {ra.x, ra.x}, H2 = {-ra.y, -ra.y};
         f32x2 t[Q];
 #pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            const f32x2 dx = xf[j] - CX;
-            t[j] = __builtin_elementwise_fma(dx, dx, MID);
-        }
+        for (int j = 0; j < Q; ++j) t[j] = wf[j] + KK;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) t[j] = __builtin_elementwise_fma(CX, xf[j], t[j]);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) t[j] = __builtin_elementwise_fma(CY, yf[j], t[j]);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) t[j] = __builtin_elementwise_fma(CZ, zf[j], t[j]);   // |x~ - C|^2 - mid
+#pragma unroll
+        for (int j = 0; j < Q; ++j) t[j] = __builtin_elementwise_fma(t[j], t[j], H2);     // q = (t - mid)^2 - half^2
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            const f32x2 dy = yf[j] - CY;
-            t[j] = __builtin_elementwise_fma(dy, dy, t[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            const f32x2 dz = zf[j] - CZ;
-            t[j] = __builtin_elementwise_fma(dz, dz, t[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            const float va = __builtin_fabsf(t[j].x) - half, vb = __builtin_fabsf(t[j].y) - half;
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(va), 31);
-            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(vb), 31);
-            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(va)), __builtin_fabsf(vb));
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(t[j].x), 31);
+            acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(t[j].y), 31);
+            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(t[j].x)), __builtin_fabsf(t[j].y));
         }
     }
     bits = acc;
@@ -787,6 +781,16 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         // inf or NaN anywhere (also an offset beyond the fp32 range) makes chk * 0 a NaN
         tile_screened = __ballot(!(chk * 0.0f == 0.0f)) == 0ull;
     }
+    // the sphere's screen works on the expanded square: w = |x~|^2 once per point and tile (sphere_screen_record)
+    f32x2 wf[Q];   // (only the sphere reads it)
+    if (KIND == 1) {
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            f32x2 w = xf[j] * xf[j];
+            w = __builtin_elementwise_fma(yf[j], yf[j], w);
+            wf[j] = __builtin_elementwise_fma(zf[j], zf[j], w);
+        }
+    }
     // ---- compaction of the set bits into ids[0 .. total): id = 64 * word + bit (relative to g0)
     const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
     uint32_t total = 0;
@@ -848,7 +852,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
             bool exact = true;
             if (SCREENED) {
                 float m;
-                screen_eval<KIND, Q>(ra, rb, rc, xf, yf, zf, bits, m);
+                screen_eval<KIND, Q>(ra, rb, rc, xf, yf, zf, wf, bits, m);
                 exact = __ballot(!(m >= (KIND == 0 ? rb.y : (KIND == 1 ? rb.w : rc.z)))) != 0ull;   // (h = NaN: the record is not screened)
             }
             if (__builtin_expect(exact, 0)) {   // wave-uniform, rare

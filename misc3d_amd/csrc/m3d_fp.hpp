@@ -476,6 +476,9 @@ M3D_HD void cylinder_cutoffs(const double* w, double thr, double* t_lo, double* 
 // `!(m >= h)` then sends every pair of that hypothesis to the exact code.
 // ------------------------------------------------------------------------------------------------
 constexpr double kU32 = 5.9604644775390625e-8;   // 2^-24
+#ifndef M3D_SCREEN_BOUND_DIVISOR   // tests/test_screen_bounds.py builds the host check with 16: it must then FAIL
+#define M3D_SCREEN_BOUND_DIVISOR 1.0
+#endif
 M3D_HD float f32_round_up_pos(double v) {   // smallest float >= v, v > 0 finite and far below the fp32 overflow
     float f = (float)v;
     if ((double)f < v) {
@@ -500,7 +503,7 @@ M3D_HD void plane_screen_record(const double* rec, const double* box, double max
     const double sa = (fabs(a) + fabs(b)) + fabs(c);
     const double Ml = ((fabs(a) * box[3] + fabs(b) * box[4]) + fabs(c) * box[5]) + fabs(s_o);
     const double Mg = sa * max_abs + fabs(d);
-    const double E = (8.0 * kU32 * Ml + 1e-15 * Mg) + 4e-38 * ((3.0 * max_abs + sa) + 4.0);
+    const double E = ((8.0 * kU32 * Ml + 1e-15 * Mg) + 4e-38 * ((3.0 * max_abs + sa) + 4.0)) / M3D_SCREEN_BOUND_DIVISOR;
     const bool ok = (Mg < 1e18) && (sa < 1e18) && (max_abs < 1e18) && (T > E) && (T > 1e-15) && (T < 1e18);
     const double h = ((2.0 * T * E + E * E) + 2.0 * kU32 * (T * T)) * 1.001;
     out[0] = ok ? (float)a : 0.0f;
@@ -511,22 +514,50 @@ M3D_HD void plane_screen_record(const double* rec, const double* box, double max
     out[5] = ok ? f32_round_up_pos(h > 1e-30 ? h : 1e-30) : f32_nan();
     out[6] = out[7] = 0.0f;
 }
-// rec = the sphere's scoring record (cx, cy, cz, lo, hi).  out = (mid, half, -, -, Cx, Cy, Cz, h)
+// rec = the sphere's scoring record (cx, cy, cz, lo, hi).  out = (K, half^2, -, -, -2 Cx, -2 Cy, -2 Cz, h)
+// EXPANDED form.  x~ = the tile's fp32 offsets from the box centre, C = the sphere's centre relative to the box centre
+// ROUNDED to fp32 (so that the expansion is an identity of the numbers the kernel holds):
+//     |x~ - C|^2 - mid = w + C~ . x~ + K,      w = |x~|^2 (once per point and tile),  C~ = -2 C,  K = |C|^2 - mid.
+// The kernel forms u = fma(C~z, z~, fma(C~y, y~, fma(C~x, x~, w + K))) -- 4 packed instructions per two points where
+// (x~ - C)^2 summed took 6 -- and q = fma(u, u, -half^2): inside <=> lo <= t <= hi <=> |t - mid| <= half <=> q <= 0 (the
+// plane's trick; `|u| - half` per point cost two unpacked subtractions).  33 VALU instructions per hypothesis, 45 before.
+// Error of u against t - mid, t the exact code's |q - c|^2:
+//   * inputs: x~_k = x_k (1 + d), C_k = c_k (1 + d'): (x~_k - C_k) is within u W_k of x_k - c_k, W_k = h_k + |c_k| >=
+//     |x_k - c_k|: <= 2.01 u Ws on the sum of squares, Ws = sum W_k^2;
+//   * w = fl(fl(fl(x~^2) + y~^2) + z~^2) <= gamma_3 |x~|^2 <= 3.1 u Hs, Hs = sum h_k^2;  K32 = K (1 + d): u |K|;
+//   * the chain: four roundings, the earliest term passing all four: <= gamma_4 (w + |K| + sum |C~_k x~_k|)
+//     <= 4.1 u (Hs + |K| + 2 P), P = sum h_k |c_k|.
+//   E = 2.1 u Ws + 7.5 u Hs + 5.5 u |K| + 8.5 u P (+ the fp64 side: the exact code's own rounding on coordinates of
+//   size Wg, the box centre's subtraction, mid / half / |C|^2; + flushed denormals).
+// For a tile near the sphere's surface (|c| ~ r >> h) that is ~2 u r^2: the direct form's bound was 24 u (r + h)^2.
+// q against q* = (t - mid)^2 - half^2 as for the plane: |q32| >= h = 2 half E + E^2 + 2 u half^2 => same sign.
 M3D_HD void sphere_screen_record(const double* rec, const double* box, double max_abs, float* out) {
     const double lo = rec[3], hi = rec[4];
     const double cx = rec[0] - box[0], cy = rec[1] - box[1], cz = rec[2] - box[2];
-    const double Wl = fmax(fmax(box[3] + fabs(cx), box[4] + fabs(cy)), box[5] + fabs(cz));
-    const double Wg = max_abs + fmax(fmax(fabs(rec[0]), fabs(rec[1])), fabs(rec[2]));
-    const bool ok = (lo <= hi) && (lo >= 0.0) && (hi < 1e36) && (Wg < 1e18) && (Wl < 1e18);
+    const float c32[3] = {(float)cx, (float)cy, (float)cz};
+    const double Cx = (double)c32[0], Cy = (double)c32[1], Cz = (double)c32[2];
     const double mid = 0.5 * lo + 0.5 * hi, half = 0.5 * hi - 0.5 * lo;
-    const double Et = ((24.0 * kU32 * (Wl * Wl) + 5.0 * kU32 * mid) + 1e-14 * (Wl * (Wg + Wl))) + 1e-30 * (Wl + 1.0);
-    const double h = ((Et + kU32 * half) + 1e-15 * (mid + half)) * 1.001;
-    out[0] = ok ? (float)mid : 0.0f;
-    out[1] = ok ? (float)half : 0.0f;
+    const double Cs = (Cx * Cx + Cy * Cy) + Cz * Cz;
+    const double K = Cs - mid;
+    const double hx = box[3], hy = box[4], hz = box[5];
+    const double wx = hx + fabs(cx), wy = hy + fabs(cy), wz = hz + fabs(cz);
+    const double Ws = (wx * wx + wy * wy) + wz * wz;
+    const double Hs = (hx * hx + hy * hy) + hz * hz;
+    const double P = (hx * fabs(cx) + hy * fabs(cy)) + hz * fabs(cz);
+    const double Wl = fmax(fmax(wx, wy), wz);
+    const double Wg = max_abs + fmax(fmax(fabs(rec[0]), fabs(rec[1])), fabs(rec[2]));
+    const double E = ((((2.1 * kU32 * Ws + 7.5 * kU32 * Hs) + (5.5 * kU32 * fabs(K) + 8.5 * kU32 * P)) +
+                       (1e-14 * (Wl * (Wg + Wl)) + 1e-15 * ((mid + half) + Cs))) +
+                      (1e-30 * (Wl + 1.0) + 1e-37 * (4.0 + 4.0 * ((wx + wy) + wz)))) / M3D_SCREEN_BOUND_DIVISOR;
+    const bool ok = (lo <= hi) && (lo >= 0.0) && (hi < 1e17) && (Wg < 1e18) && (Ws < 1e17) && (half > E) && (half > 1e-15) &&
+                    (hx >= 0.0);
+    const double h = ((2.0 * half * E + E * E) + 2.0 * kU32 * (half * half)) * 1.001;
+    out[0] = ok ? (float)K : 0.0f;
+    out[1] = ok ? (float)(half * half) : 0.0f;
     out[2] = out[3] = 0.0f;
-    out[4] = ok ? (float)cx : 0.0f;
-    out[5] = ok ? (float)cy : 0.0f;
-    out[6] = ok ? (float)cz : 0.0f;
+    out[4] = ok ? -2.0f * c32[0] : 0.0f;
+    out[5] = ok ? -2.0f * c32[1] : 0.0f;
+    out[6] = ok ? -2.0f * c32[2] : 0.0f;
     out[7] = ok ? f32_round_up_pos(h > 1e-30 ? h : 1e-30) : f32_nan();
 }
 
@@ -544,7 +575,7 @@ M3D_HD void sphere_screen_record(const double* rec, const double* box, double ma
 // E_t += 1e-13 (|L| W_l)^2 + 5e-14 K W_m^2 + 1e-27 W_m^4.
 // (First version: t = |L x (q - c')|^2 from the rounded differences, 15 packed instructions per two points and a bound
 // of 200 u (|L| W_l)^2 -- 2.8 % of the pairs of the C3 fit went back to the exact code; this form: 11 and a sixth of it.)
-// out = (E1x, E1y, E1z, D1, E2x, E2y, E2z, D2, mid, half, h, -)
+// out = (E1x, E1y, E1z, D1, E2x, E2y, E2z, D2, mid, half^2, h, -)
 // L = p2 - p1, Ln = |L|, E1 = |L| (L x a) / |L x a| with a = the coordinate axis L leans on least, E2 = L x E1 / |L|;
 // *vn = |L x a| (0: no axis)
 M3D_HD void cylinder_frame(const double* rec, double* L, double* Ln, double* E1, double* E2, double* vn) {
@@ -582,12 +613,15 @@ M3D_HD void cylinder_screen_record(const double* rec, const double* box, double 
     const double Wm = fmax(Wa, Wb);
     const double G = Wm * Wm;
     const double LW = Ln * Wl;
-    const bool ok = (lo <= hi) && (lo >= 0.0) && (hi < 1e36) && (L2 > 0.0) && (vn > 0.0) && (M < 1e9) && (LW < 1e9) &&
-                    (G < 1e15) && (fabs(s) < 1e15);
     const double mid = 0.5 * lo + 0.5 * hi, half = 0.5 * hi - 0.5 * lo;
-    const double Et = ((32.0 * kU32 * (M * M) + 4.0 * kU32 * mid) + (1e-13 * (LW * LW) + 5e-14 * (2.0 * LW) * G + 1e-27 * (G * G))) +
-                      1e-30 * (M + 1.0);
-    const double h = ((Et + kU32 * half) + 1e-15 * (mid + half)) * 1.001;
+    bool ok = (lo <= hi) && (lo >= 0.0) && (hi < 1e17) && (L2 > 0.0) && (vn > 0.0) && (M < 1e8) && (LW < 1e9) &&
+              (G < 1e15) && (fabs(s) < 1e15) && (half > 1e-15);
+    // u = t' (within Et of t - mid, above), q = fma(u, u, -half^2): inside <=> q <= 0, decided when |q| >= h -- as for the
+    // plane (one packed instruction for two points where `|u| - half` took two unpacked ones)
+    const double Et = ((((32.0 * kU32 * (M * M) + 4.0 * kU32 * mid) + (1e-13 * (LW * LW) + 5e-14 * (2.0 * LW) * G + 1e-27 * (G * G))) +
+                        1e-30 * (M + 1.0)) + 1e-15 * (mid + half)) / M3D_SCREEN_BOUND_DIVISOR;
+    const double h = ((2.0 * half * Et + Et * Et) + 2.0 * kU32 * (half * half)) * 1.001;
+    ok = ok && (half > Et);
     out[0] = ok ? (float)E1[0] : 0.0f;
     out[1] = ok ? (float)E1[1] : 0.0f;
     out[2] = ok ? (float)E1[2] : 0.0f;
@@ -597,7 +631,7 @@ M3D_HD void cylinder_screen_record(const double* rec, const double* box, double 
     out[6] = ok ? (float)E2[2] : 0.0f;
     out[7] = ok ? (float)D2 : 0.0f;
     out[8] = ok ? (float)mid : 0.0f;
-    out[9] = ok ? (float)half : 0.0f;
+    out[9] = ok ? (float)(half * half) : 0.0f;
     out[10] = ok ? f32_round_up_pos(h > 1e-30 ? h : 1e-30) : f32_nan();
     out[11] = 0.0f;
 }

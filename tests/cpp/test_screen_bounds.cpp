@@ -51,6 +51,7 @@ void make_box(Tile& t, const double* origin) {
 }
 
 long long n_points = 0, n_decided = 0, n_wrong = 0, n_tiles = 0, n_culled = 0, n_cull_wrong = 0;
+long long k_points[3] = {0, 0, 0}, k_decided[3] = {0, 0, 0}, k_wrong[3] = {0, 0, 0};   // per kind (valid models only)
 
 // ---- the device arithmetic, restated -----------------------------------------------------------
 bool screen_plane(const float* r, float xr, float yr, float zr, bool* inside) {
@@ -60,19 +61,19 @@ bool screen_plane(const float* r, float xr, float yr, float zr, bool* inside) {
     return std::fabs(q) >= r[5];   // h = NaN -> false
 }
 bool screen_sphere(const float* r, float xr, float yr, float zr, bool* inside) {
-    const float dx = xr - r[4], dy = yr - r[5], dz = zr - r[6];
-    const float t = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, -r[0])));
-    const float v = std::fabs(t) - r[1];
-    *inside = std::signbit(v);
-    return std::fabs(v) >= r[7];
+    const float w = fmaf(zr, zr, fmaf(yr, yr, xr * xr));                            // once per point and tile
+    const float u = fmaf(r[6], zr, fmaf(r[5], yr, fmaf(r[4], xr, w + r[0])));      // |x~ - C|^2 - mid, expanded
+    const float q = fmaf(u, u, -r[1]);
+    *inside = std::signbit(q);
+    return std::fabs(q) >= r[7];
 }
 bool screen_cylinder(const float* r, float xr, float yr, float zr, bool* inside) {
     const float d1 = fmaf(r[0], xr, fmaf(r[1], yr, fmaf(r[2], zr, r[3])));
     const float d2 = fmaf(r[4], xr, fmaf(r[5], yr, fmaf(r[6], zr, r[7])));
     const float t = fmaf(d2, d2, fmaf(d1, d1, -r[8]));
-    const float v = std::fabs(t) - r[9];
-    *inside = std::signbit(v);
-    return std::fabs(v) >= r[10];
+    const float q = fmaf(t, t, -r[9]);
+    *inside = std::signbit(q);
+    return std::fabs(q) >= r[10];
 }
 float cull_value(int kind, const float* c, const float* b) {   // negative = the tile is dropped
     const float bx = b[0], by = b[1], bz = b[2], hx = b[3], hy = b[4], hz = b[5];
@@ -138,11 +139,14 @@ void check_pair(int kind, const double* score_rec, bool valid, const Tile& t, co
         else if (kind == 1) decided = screen_sphere(sr, xr, yr, zr, &inside);
         else decided = screen_cylinder(sr, xr, yr, zr, &inside);
         n_points++;
+        if (valid) k_points[kind]++;
         if (valid && decided) {
             n_decided++;
+            k_decided[kind]++;
             if (inside != exact) {
                 if (n_wrong < 5) std::fprintf(stderr, "WRONG kind %d: point (%.17g %.17g %.17g) screen %d exact %d\n", kind, x, y, z, inside, exact);
                 n_wrong++;
+                k_wrong[kind]++;
             }
         }
     }
@@ -272,6 +276,8 @@ int main(int argc, char** argv) {
     }
     std::printf("points %lld, decided by the screen %lld (%.2f %%), wrong %lld; tiles %lld, dropped by the box test %lld, wrongly %lld\n",
                 n_points, n_decided, 100.0 * (double)n_decided / (double)(n_points ? n_points : 1), n_wrong, n_tiles, n_culled, n_cull_wrong);
+    for (int k = 0; k < 3; ++k)
+        std::printf("kind %d: decided %.2f %% of %lld points, wrong %lld\n", k, 100.0 * (double)k_decided[k] / (double)(k_points[k] ? k_points[k] : 1), k_points[k], k_wrong[k]);
     if (n_wrong || n_cull_wrong || n_points < 1000) return 1;
     std::printf("all checks passed\n");
     return 0;

@@ -16,6 +16,19 @@ def test_fp32_screen_and_box_test_bounds_hold_on_the_host():
     assert "all checks passed" in r.stdout and "wrong 0;" in r.stdout
 
 
+def test_screen_bounds_are_not_slack_by_16():
+    """The mutation check of the test above: the same program built with every screen bound (plane, sphere in expanded
+    form, cylinder) divided by 16 (M3D_SCREEN_BOUND_DIVISOR) must report wrong verdicts for ALL THREE kinds -- i.e. the
+    points placed around the cut-offs really do probe the bounds, and the bounds are within 16x of what is needed."""
+    import re
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["make", "-C", cpp, "_build/test_screen_bounds_div16"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(cpp, "_build", "test_screen_bounds_div16"), "12000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "all checks passed" not in r.stdout
+    wrong = {int(k): int(w) for k, w in re.findall(r"kind (\d): decided [0-9.]+ % of \d+ points, wrong (\d+)", r.stdout)}
+    assert set(wrong) == {0, 1, 2} and all(w > 0 for w in wrong.values()), r.stdout
+
+
 def test_nn_screen_walk_is_exact_on_the_host():
     """tests/cpp/test_nn_screen.cpp replays sorted_walk32 (the fp32 screen of the registration validation's neighbour search)
     with float operations on the host: random grids over nine orders of magnitude, origins at the edge of what the library

@@ -23,7 +23,7 @@ HBM_PEAK_GBS = 8000.0
 FP64_VALU_PEAK_TOPS = 39.3      # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz, non-FMA ops (bench.py)
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA (MI355X_MICROARCH.md)
 VALU_OPS_FP64 = {0: 7, 1: 10, 2: 22}    # score_mask_k: fp64 VALU instructions per (point, hypothesis)
-VALU_OPS_SCREEN = {0: 3.625, 1: 5.625, 2: 6.625}   # score_screen_k: packed-fp32 screen (planes, spheres); bench.py has the count
+VALU_OPS_SCREEN = {0: 3.625, 1: 4.125, 2: 6.125}   # score_screen_k: packed-fp32 screen, 29 / 33 / 49 instructions per 8 points; bench.py has the count
 capi.set_config(kernel_timing=1)  # the fit rooflines need m3d_stats.ms_score_kernel (HIP events around the scoring launches)
 
 
