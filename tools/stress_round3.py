@@ -54,10 +54,16 @@ while time.time() < t_end:
         p, nr = synth.sphere_cloud_c3(m, sd), None
     else:
         p, nr = synth.cylinder_cloud_c3(m, sd)
+    # (the fp32 screens work on tile-local offsets: a scene scaled and moved far from the origin probes their bounds)
+    sc = float(10.0 ** rng.uniform(-2, 2))
+    p = p * sc + rng.uniform(-1, 1, 3) * sc * float(10.0 ** rng.uniform(0, 3))
+    thr = 0.01 * sc
     for it, prob in ((int(rng.integers(1, 1025)), float(rng.choice([0.9999, 1.0, 0.5]))), (int(rng.integers(1025, 3000)), 1.0)):
-        g = capi.fit(kind, p, nr, 0.01, it, prob, seed=sd)
-        o = oracle.fit(kind, p, nr, thr=0.01, max_iter=it, prob=prob, seed=sd, lookahead=32)
+        g = capi.fit(kind, p, nr, thr, it, prob, seed=sd)
+        o = oracle.fit(kind, p, nr, thr=thr, max_iter=it, prob=prob, seed=sd, lookahead=32)
         assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.ret, o.best_index, o.count, o.iterations), ("fit", kind, m, it, prob, sd)
-        assert np.array_equal(g.inliers, o.inliers) and np.allclose(g.params, o.params, rtol=0, atol=1e-9)
+        assert np.array_equal(g.inliers, o.inliers), ("fit inliers", kind, m, it, prob, sd, sc)
+        mag = float(np.abs(p).max())
+        assert np.allclose(g.params, o.params, rtol=1e-9, atol=1e-9 * mag), ("fit params", kind, m, it, prob, sd, sc, g.params, o.params)
         n_fit += 1
 print(f"stress ok: {n_match} matcher cases, {n_seg} segmentations, {n_fit} fits in {budget:.0f} s")
