@@ -38,3 +38,5 @@ bash tools/pmc_match.sh > gpurun_out/pmc_match.txt 2>&1
 bash tools/c5_round_timeline.sh c5t 200 > /dev/null 2>&1
 python tools/time_c5_plain.py > gpurun_out/c5_plain.txt 2>&1
 python tools/time_oneshot.py > gpurun_out/oneshot.txt 2>&1
+# SQ counters of the sphere's / cylinder's scoring launches (the C3 fractions)
+M3D_PMC_CMD="python tools/bench_configs.py C3" bash tools/pmc_score_bench.sh > gpurun_out/pmc_score_c3.txt 2>&1

@@ -47,7 +47,13 @@ def main():
                               ("../bench_latest.json", f"{TAG}_bench.json"),
                               ("../bench_sharded_world1.json", f"{TAG}_bench_sharded_world1.json"),
                               ("../pmc_reg_validate.txt", f"{TAG}_pmc_reg_validate.txt"),
-                              ("../step_timeline.txt", f"{TAG}_c2_step_timeline.txt")):
+                              ("../step_timeline.txt", f"{TAG}_c2_step_timeline.txt"),
+                              ("../pmc_score_c3.txt", f"{TAG}_pmc_score_c3.txt"),
+                              ("../prof_match.txt", f"{TAG}_match_kernel_stats.txt"),
+                              ("../pmc_match.txt", f"{TAG}_pmc_match.txt"),
+                              ("../c5t_timeline.txt", f"{TAG}_c5_round_timeline.txt"),
+                              ("../c5_plain.txt", f"{TAG}_c5_plain.txt"),
+                              ("../oneshot.txt", f"{TAG}_oneshot.txt")):
         q = os.path.join(SRC, src_rel)
         if os.path.exists(q):
             shutil.copy(q, os.path.join(DST, dst_name))
