@@ -126,6 +126,11 @@ int main() {
         CHECK(one.size() == multi.size() && one.size() == sharded.size() && one.size() >= 2);
         for (size_t k = 0; k < one.size(); ++k) {
             CHECK(one[k].indices == multi[k].indices && one[k].indices == sharded[k].indices);
+            // the cluster cloud is SelectByIndex of the list (iterative_plane_segmentation.cpp:32): gathered on the device in
+            // the one-GPU form (m3d_segment_plane_iterative_clouds), on the host in the other two -- bit for bit the same
+            CHECK(one[k].cloud.points_.size() == one[k].indices.size());
+            CHECK(one[k].cloud.points_ == multi[k].cloud.points_ && one[k].cloud.points_ == sharded[k].cloud.points_);
+            for (size_t i = 0; i < one[k].indices.size(); i += 97) CHECK(one[k].cloud.points_[i] == two.points_[one[k].indices[i]]);
             for (int j = 0; j < 4; ++j) CHECK(one[k].plane[j] == multi[k].plane[j] && one[k].plane[j] == sharded[k].plane[j]);
         }
         misc3d::common::RANSACPlane f1, f2;
