@@ -396,7 +396,10 @@ typedef struct m3d_config {
     int32_t reg_fp32_screen;        /* [M3D_REG_SCREEN=0]   default 1: the nearest-neighbour search of the registration validation finds its
                                        candidate in fp32 (16-byte list entries relative to the cell, rounding bound) and evaluates the winner
                                        in fp64; a query whose runner-up is within the bound takes the fp64 walk: identical distances */
-    int32_t reserved[8];            /* zero (round 3 dropped four switches whose paths lost and were deleted: Z-order sort,
+    int32_t sorted_tombstones;      /* [M3D_TOMBSTONES=0]   default 1: a segmentation round that removes a sliver of the cloud kills its inliers
+                                       in place in the Hilbert-sorted copy (x = NaN: never an inlier; the screen masks the lane) instead
+                                       of partitioning the copy; a real compaction follows when an eighth of the copy is dead */
+    int32_t reserved[7];            /* zero (round 3 dropped four switches whose paths lost and were deleted: Z-order sort,
                                        x-row source order, LDS-staged validation, one-launch compaction -- DESIGN.md 7) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);

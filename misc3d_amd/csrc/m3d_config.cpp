@@ -48,6 +48,7 @@ void load_env() {
     g_cfg.score_fp32_screen = !env_is("M3D_SCORE_SCREEN", '0');
     g_cfg.cull_fp32 = !env_is("M3D_CULL_FP32", '0');
     g_cfg.reg_fp32_screen = !env_is("M3D_REG_SCREEN", '0');
+    g_cfg.sorted_tombstones = !env_is("M3D_TOMBSTONES", '0');
     sanitize(g_cfg);
 }
 }  // namespace

@@ -118,6 +118,60 @@ void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// TOMBSTONES.  A segmentation round in the clutter removes ~0.5 % of the cloud; the stable partition of the sorted copy
+// rewrote all of it (count + write + fresh tile boxes: 24 us of a 116 us round on 1 M points).  Counts do not depend on
+// the order or the presence of points that are nobody's inlier, so such a round KILLS its inliers in place instead:
+// x := NaN in the fp64 copy (the exact code's `|s| < T` is false for a NaN) and in the tile's fp32 offsets (score_screen_k
+// masks the lane's bit).  Boxes go stale -- they still contain every live point, which is all the box tests need.
+// One wave per tile; a tile the plane's slab misses (the box test of the scoring pass, same record) is not read.
+// The driver compacts for real (compact_write_k mode 3 drops NaN) when the dead are an eighth of the copy.
+// *total accumulates the kills of all launches (checked by the driver against the inlier lists, later).
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ bool box_culled(const double* __restrict__ rec, const double* __restrict__ box);
+__global__ __launch_bounds__(256) void poison_plane_inliers_k(double* __restrict__ sx, const double* __restrict__ sy,
+                                                               const double* __restrict__ sz, const double* __restrict__ boxes,
+                                                               uint32_t n_tiles, float* __restrict__ tile_f32,
+                                                               const double* __restrict__ model, double thr, double max_abs,
+                                                               uint32_t* __restrict__ total /* running sum of the kills */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * 4u + (uint32_t)wave;
+    double m[4];
+    for (int k = 0; k < 4; ++k) m[k] = model[k];
+    // the scoring record of this model (minimal_fit_k): the exact cut-off and the box test's margin
+    double rec[6];
+    rec[0] = m[0];
+    rec[1] = m[1];
+    rec[2] = m[2];
+    rec[3] = m[3];
+    rec[4] = plane_cutoff(m, thr);
+    rec[5] = rec[4] + 1e-12 * ((((fabs(m[0]) + fabs(m[1])) + fabs(m[2])) * max_abs + fabs(m[3])) + rec[4]);
+    uint32_t kills = 0;
+    if (tile < n_tiles && !box_culled<0>(rec, boxes + (size_t)tile * kBoxStride)) {   // (wave-uniform)
+        const double nan = u2f(0x7FF8000000000000ull);
+        float* __restrict__ tf = tile_f32 ? tile_f32 + (size_t)tile * kTileF32Floats : nullptr;
+#pragma unroll
+        for (int r = 0; r < kTilePoints / 64; ++r) {
+            const size_t i = (size_t)tile * kTilePoints + (size_t)r * 64 + lane;
+            const bool inl = plane_distance(m, sx[i], sy[i], sz[i]) < thr;   // RefineModel's own predicate (NaN: false)
+            if (inl) {
+                sx[i] = nan;
+                if (tf) tf[(((r >> 1) * 64) + lane) * 2 + (r & 1)] = f32_nan();   // x offsets: rows 2 j, 2 j + 1 side by side
+            }
+            kills += (uint32_t)__popcll(__ballot(inl));
+        }
+    }
+    // (kills are counted by waves that killed: ~250 of ~2000 in a clutter round.  Nobody waits for the sum -- the driver
+    // checks it against the inlier lists at the next real compaction, whose kept count it fixes, and at the end of the call)
+    if (lane == 0 && kills) atomicAdd(total, kills);
+}
+void launch_poison_plane_inliers(const SortedView& s, const double* model, double thr, uint32_t* total, hipStream_t st) {
+    if (!s.n_tiles) return;
+    poison_plane_inliers_k<<<(s.n_tiles + 3) / 4, 256, 0, st>>>(const_cast<double*>(s.x), s.y, s.z, s.boxes, s.n_tiles,
+                                                                const_cast<float*>(s.tile_f32), model, thr, s.max_abs, total);
+}
+
+// ------------------------------------------------------------------------------------------------
 // conservative box tests.  `true` = the box cannot contain an inlier of this hypothesis.
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
@@ -791,6 +845,17 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
             wf[j] = __builtin_elementwise_fma(zf[j], zf[j], w);
         }
     }
+    // DEAD points (poison_plane_inliers_k: a segmentation round's inliers killed in place, x = NaN in both copies of the
+    // tile): their bit of the lane's inside-string is masked out -- a NaN's sign bit is nobody's business -- and the
+    // minimum over |q| skips them (v_min3_f32 returns the non-NaN operands; were it not so, the pair would be recounted
+    // in fp64, where NaN < T is false: slower, never wrong).  dead8 in the order screen_eval shifts the bits in.
+    uint32_t dead8 = 0;
+    bool tile_has_dead = false;
+    if (tile_f32) {   // (kernel argument: uniform)
+#pragma unroll
+        for (int j = 0; j < Q; ++j) dead8 = (dead8 << 2) | (xf[j].x != xf[j].x ? 2u : 0u) | (xf[j].y != xf[j].y ? 1u : 0u);
+        tile_has_dead = tile_screened && __ballot(dead8 != 0u) != 0ull;
+    }
     // ---- compaction of the set bits into ids[0 .. total): id = 64 * word + bit (relative to g0)
     const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
     uint32_t total = 0;
@@ -846,13 +911,15 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         uint32_t park = 0;   // lane k: exact count of hypothesis k when the screen could not decide it
         // SCREENED is the tile's verdict (wave-uniform, fixed for the workgroup): a compile-time flag of the loop so that
         // the screened loop carries no branch and no register initialisation for the other case
-        auto step = [&](auto screened, const float4 ra, const float4 rb, const float4 rc, uint32_t k, uint8_t* cnt_row) {
+        auto step = [&](auto screened, auto dead, const float4 ra, const float4 rb, const float4 rc, uint32_t k, uint8_t* cnt_row) {
             constexpr bool SCREENED = decltype(screened)::value;
+            constexpr bool DEAD = decltype(dead)::value;
             uint32_t bits = 0;
             bool exact = true;
             if (SCREENED) {
                 float m;
                 screen_eval<KIND, Q>(ra, rb, rc, xf, yf, zf, wf, bits, m);
+                if (DEAD) bits &= ~dead8;
                 exact = __ballot(!(m >= (KIND == 0 ? rb.y : (KIND == 1 ? rb.w : rc.z)))) != 0ull;   // (h = NaN: the record is not screened)
             }
             if (__builtin_expect(exact, 0)) {   // wave-uniform, rare
@@ -868,7 +935,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         // rows of the table nobody adds up -- which keeps every LDS address of a trip at a constant offset from one
         // register: the two byte offsets below live in VGPRs the compiler cannot see through (it would otherwise rebuild
         // each address from the scalar loop counter: two VALU instructions per hypothesis)
-        auto batch = [&](auto screened) {
+        auto batch = [&](auto screened, auto dead) {
             uint32_t rec_off = 0, cnt_off = (uint32_t)lane;
             asm volatile("" : "+v"(rec_off), "+v"(cnt_off));
             const char* const loc_b = reinterpret_cast<const char*>(&loc[0][0]);
@@ -883,19 +950,20 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
             fetch(0, a0, a1, a2);
             for (uint32_t k = 0; k < nb; k += 4u) {
                 fetch(1, b0r, b1r, b2r);
-                step(screened, a0, a1, a2, k, cnt8 + cnt_off);
+                step(screened, dead, a0, a1, a2, k, cnt8 + cnt_off);
                 fetch(2, a0, a1, a2);
-                if (k + 1u < nb) step(screened, b0r, b1r, b2r, k + 1u, cnt8 + cnt_off + kCntStride);   // (scalar branches)
+                if (k + 1u < nb) step(screened, dead, b0r, b1r, b2r, k + 1u, cnt8 + cnt_off + kCntStride);   // (scalar branches)
                 fetch(3, b0r, b1r, b2r);
-                if (k + 2u < nb) step(screened, a0, a1, a2, k + 2u, cnt8 + cnt_off + 2 * kCntStride);
+                if (k + 2u < nb) step(screened, dead, a0, a1, a2, k + 2u, cnt8 + cnt_off + 2 * kCntStride);
                 fetch(4, a0, a1, a2);   // (row 64: the padding row, read by the last trip and never used)
-                if (k + 3u < nb) step(screened, b0r, b1r, b2r, k + 3u, cnt8 + cnt_off + 3 * kCntStride);
+                if (k + 3u < nb) step(screened, dead, b0r, b1r, b2r, k + 3u, cnt8 + cnt_off + 3 * kCntStride);
                 rec_off += 4u * NL * (uint32_t)sizeof(float4);
                 cnt_off += 4u * kCntStride;
             }
         };
-        if (tile_screened) batch(std::true_type{});
-        else batch(std::false_type{});
+        if (tile_screened && !tile_has_dead) batch(std::true_type{}, std::false_type{});
+        else if (tile_screened) batch(std::true_type{}, std::true_type{});
+        else batch(std::false_type{}, std::false_type{});
         __syncthreads();   // (one wave: the table is complete)
         if ((uint32_t)lane < nb) {
             const uint4* row = reinterpret_cast<const uint4*>(cnt8 + (uint32_t)lane * kCntStride);

@@ -1485,8 +1485,18 @@ static int cloud_remove_prepare(m3d_cloud* c, PartitionOut* out) {
 // partition_done: the partition in creation order has been written by RefineModel's own compaction (PartitionOut)
 // same_slot: a second issue of the SAME round (the first one, queued on the device's early pick, named another model): the
 // totals go where the first one's went -- the other slot still belongs to the previous round's deferred check
+// A removal of `removed` points may kill them in place in the sorted copy instead of partitioning it when it is a sliver
+// (a sixteenth of the live points) and the dead stay below an eighth of the copy
+static bool poison_fits(const m3d_cloud* c, uint64_t removed) {
+    const m3d_cloud::Work& w = c->work;
+    if (!w.tombstones || !w.active || c->has_normals || !config().sorted_tombstones) return false;
+    const uint64_t alive = c->n_sorted - w.sorted_dead;
+    return removed * 16 <= alive && ((uint64_t)w.sorted_dead + removed) * 8 <= c->n_sorted;
+}
+// expected_removed >= 0: the size of this removal is known (the scoring pass counted the inliers): planes may then be
+// removed from the sorted copy by tombstones (poison_fits)
 static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* model_dev, bool partition_done = false,
-                              bool same_slot = false) {
+                              bool same_slot = false, int64_t expected_removed = -1) {
     DeviceCtx* ctx = c->ctx;
     m3d_cloud::Work& w = c->work;
     PartitionOut po;
@@ -1508,7 +1518,18 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
         launch_compact(kind, cur, model_dev, thr, 2, w.cur_orig, nullptr, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap,
                        ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream, nullptr, nullptr, nullptr,
                        nullptr, h_totals);
-    // the same stable partition on the sorted copy (every inlier is a finite point), then fresh tile boxes
+    w.issue_poison = kind == M3D_PLANE && expected_removed >= 0 && poison_fits(c, (uint64_t)expected_removed);
+    if (w.issue_poison) {
+        // (the kills add up in ctx->poison_total, cleared by the owner of the cloud -- segment_impl -- which compares the sum
+        // with the inlier lists at the end; a real compaction in between checks the live count it leaves)
+        RESERVE(ctx->poison_total, 16);
+        launch_poison_plane_inliers(w.scur, model_dev, thr, ctx->poison_total.as<uint32_t>(), ctx->stream);
+        w.poison_expected += (uint64_t)expected_removed;
+        HIPCHK(hipGetLastError());
+        return M3D_OK;
+    }
+    // the same stable partition on the sorted copy (every inlier is a finite point; the copy's dead points go too), then
+    // fresh tile boxes
     CloudView sview;
     sview.x = w.scur.x;
     sview.y = w.scur.y;
@@ -1534,37 +1555,49 @@ static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed, const size_t* kn
     const CloudView cur = w.cur;
     const int dst = w.cur_is_v0 ? 1 : w.pp;
     uint32_t new_n, new_sorted;
+    const uint32_t alive = c->n_sorted - w.sorted_dead;   // live points of the sorted copy
     if (known_removed) {
-        if (*known_removed > cur.n || *known_removed > c->n_sorted) return fail(M3D_ERR_INTERNAL, "more inliers than points");
+        if (*known_removed > cur.n || *known_removed > alive) return fail(M3D_ERR_INTERNAL, "more inliers than points");
         new_n = cur.n - (uint32_t)*known_removed;
-        new_sorted = c->n_sorted - (uint32_t)*known_removed;
+        new_sorted = alive - (uint32_t)*known_removed;
         w.pending = true;
         w.pending_slot = w.totals_slot;
         w.pending_partition_done = w.partition_done;
         w.pending_new_n = new_n;
         w.pending_new_sorted = new_sorted;
+        w.pending_poison = w.issue_poison;   // (a kill has no total of its own: cloud_remove_check_pending skips it)
     } else {
+        if (w.issue_poison) return fail(M3D_ERR_INTERNAL, "a removal by tombstones needs its size");
         uint32_t h[2];
         std::memcpy(h, ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot, sizeof(h));
         new_sorted = h[1];
         // (a partition written by RefineModel's compaction has no total of its own: the sorted copy's removal count stands
         // in, and the caller checks it against the length of the inlier list)
-        new_n = w.partition_done ? (new_sorted <= c->n_sorted && c->n_sorted - new_sorted <= cur.n
-                                        ? cur.n - (c->n_sorted - new_sorted) : 0xFFFFFFFFu)
+        new_n = w.partition_done ? (new_sorted <= alive && alive - new_sorted <= cur.n
+                                        ? cur.n - (alive - new_sorted) : 0xFFFFFFFFu)
                                  : h[0];
     }
-    if (new_n > cur.n || new_sorted > c->n_sorted || cur.n - new_n != c->n_sorted - new_sorted)
+    if (new_n > cur.n || new_sorted > alive || cur.n - new_n != alive - new_sorted)
         return fail(M3D_ERR_INTERNAL, "the two copies of the cloud disagree on the removed points");
     if (n_removed) *n_removed = cur.n - new_n;
-    w.scur.x = w.sbx[w.spp].as<double>();
-    w.scur.y = w.sby[w.spp].as<double>();
-    w.scur.z = w.sbz[w.spp].as<double>();
-    w.scur.boxes = w.sboxes.as<double>();
-    w.scur.tile_f32 = w.stile_f32.as<float>();
-    w.scur.n_tiles = std::max<uint32_t>(1, (new_sorted + kTilePoints - 1) / kTilePoints);
-    // compact_write_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
-    launch_tile_boxes(w.scur, w.sboxes.as<double>(), ctx->stream);
-    w.spp ^= 1;
+    w.last_removed = cur.n - new_n;
+    if (w.issue_poison) {
+        // killed in place: same arrays, same tiles, same (now slightly generous) boxes
+        w.sorted_dead += cur.n - new_n;
+    } else {
+        w.scur.x = w.sbx[w.spp].as<double>();
+        w.scur.y = w.sby[w.spp].as<double>();
+        w.scur.z = w.sbz[w.spp].as<double>();
+        w.scur.boxes = w.sboxes.as<double>();
+        w.scur.tile_f32 = w.stile_f32.as<float>();
+        w.scur.n_tiles = std::max<uint32_t>(1, (new_sorted + kTilePoints - 1) / kTilePoints);
+        // compact_write_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
+        launch_tile_boxes(w.scur, w.sboxes.as<double>(), ctx->stream);
+        w.spp ^= 1;
+        w.sorted_dead = 0;
+        c->n_sorted = new_sorted;
+        c->n_tiles = w.scur.n_tiles;
+    }
     w.cur.x = w.bx[dst].as<double>();
     w.cur.y = w.by[dst].as<double>();
     w.cur.z = w.bz[dst].as<double>();
@@ -1580,8 +1613,6 @@ static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed, const size_t* kn
     }
     c->n = new_n;
     c->n_pad = w.cur.n_pad;
-    c->n_sorted = new_sorted;
-    c->n_tiles = w.scur.n_tiles;
     return M3D_OK;
 }
 
@@ -1592,7 +1623,7 @@ static int cloud_remove_check_pending(m3d_cloud* c) {
     w.pending = false;
     uint32_t h[2];
     std::memcpy(h, c->ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.pending_slot, sizeof(h));
-    if (h[1] != w.pending_new_sorted || (!w.pending_partition_done && h[0] != w.pending_new_n))
+    if ((!w.pending_poison && h[1] != w.pending_new_sorted) || (!w.pending_partition_done && h[0] != w.pending_new_n))
         return fail(M3D_ERR_INTERNAL, "removed points and inlier list disagree");
     return M3D_OK;
 }
@@ -2335,6 +2366,8 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
     m3d_cloud* c0 = m3d_cloud_create(xyz, nullptr, n, device);
     if (!c0) return M3D_ERR_DEVICE;
     DeviceCtx* ctx = c0->ctx;
+    c0->work.tombstones = true;   // (a private cloud, planes only: the sorted copy may carry dead points between rounds)
+    bool poison_ready = false;
     int rc = M3D_OK;
     const double t_created = now_ms();
     double t_rounds = t_created, t_copied = t_created;
@@ -2344,6 +2377,8 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         std::lock_guard<std::mutex> lock(ctx->mu);
         uint64_t seed0 = 0;
         rc = agree_seed(comm, seed, ctx->stream, &seed0);
+        poison_ready = ctx->poison_total.reserve(16) && hipMemsetAsync(ctx->poison_total.p, 0, 16, ctx->stream) == hipSuccess;
+        if (!poison_ready) c0->work.tombstones = false;
         // A pageable destination is reached through staged copies, a blocking one per round, into pages that fault on first
         // touch (10 M points: 43 ms against 37): the rounds write into a page-locked staging array the device context keeps
         // -- the compaction kernels store the index lists straight into it -- and the lists are copied over at the end.
@@ -2385,7 +2420,9 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
                 // -2: asked before the inlier count is known (compaction queued on the device's own pick, run_ransac): the
                 // partition goes to the spare buffers and is simply not used should this turn out to be the last round
                 if (expected_ni == -3) {   // the speculative compaction has been queued: the sorted copy's removal behind it
-                    if (partition_fused && !spec_removal &&
+                    // (a round that will kill its inliers in place cannot do so on a guess: the kill is queued once the
+                    // replay has confirmed the pick -- still in front of the device, which is busy with the compaction)
+                    if (partition_fused && !spec_removal && !poison_fits(c0, c0->work.last_removed) &&
                         cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->pick.as<BestPick>()->params, true) == M3D_OK)
                         spec_removal = true;
                     return nullptr;
@@ -2403,7 +2440,8 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
                 if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) return M3D_OK;
                 removal_issued = true;
                 if (spec_removal && ctx->spec_hit) return M3D_OK;   // (queued on the device's pick, which the replay confirmed)
-                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev, partition_fused, /*same_slot=*/spec_removal);
+                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev, partition_fused, /*same_slot=*/spec_removal,
+                                          expected_ni);
             };
             ctx->partition_hook = &partition_hook;
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
@@ -2444,8 +2482,14 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             }
         }
         *n_clusters = k;
+        // the points killed in place in the sorted copy over the whole call against the inlier lists of those rounds
+        uint32_t killed = 0;
+        if (poison_ready && c0->work.poison_expected)
+            (void)hipMemcpyAsync(&killed, ctx->poison_total.p, sizeof(killed), hipMemcpyDeviceToHost, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
         if (rc == M3D_OK) rc = cloud_remove_check_pending(c0);
+        if ((rc == M3D_OK || rc == 2) && poison_ready && (uint64_t)killed != c0->work.poison_expected)
+            rc = fail(M3D_ERR_INTERNAL, "the sorted copy's tombstones and the inlier lists disagree");
         t_rounds = now_ms();
         // the clusters' points (SelectByIndex, :32): gathered from the resident cloud as created, one copy back
         if ((rc == M3D_OK || rc == 2) && cluster_points && k && cluster_offsets[k]) {

@@ -91,6 +91,7 @@ struct DeviceCtx {
     DevBuf pick;               // BestPick: the device's prediction of the winning hypothesis (probability-1 fits)
     PinBuf h_pick;             // BestPickHost mirror (+ at byte 64: inlier total of a compaction started on the prediction)
     bool spec_compaction = false;   // RefineModel's compaction has already been queued on pick->params
+    DevBuf poison_total;            // launch_poison_plane_inliers' running count
     bool ev_compact_early = false;  // ... and ev_compact was recorded right behind it (a removal has been queued after it)
     bool spec_hit = false;          // ... and the replay named the same hypothesis (cloud_fit_locked)
     PinBuf h_sums;             // GeneralFit: per-workgroup moment partials + coordinate sums, written by the kernels
@@ -145,6 +146,15 @@ struct m3d_cloud {
         bool pending = false, pending_partition_done = false;
         int pending_slot = 0;
         uint32_t pending_new_n = 0, pending_new_sorted = 0;
+        // tombstones (segmentation rounds in the clutter): the sorted copy's inliers are killed in place (x = NaN,
+        // launch_poison_plane_inliers) instead of partitioned away; n_sorted stays the copy's PHYSICAL size, sorted_dead of
+        // them are dead; a real compaction (mode 3 drops them) resets the count
+        bool tombstones = false;        // the owner allows it (m3d_segment_plane_iterative's private cloud)
+        uint32_t sorted_dead = 0;
+        bool issue_poison = false;      // the removal in flight is a kill, not a partition (its total = points killed)
+        bool pending_poison = false;
+        uint32_t last_removed = 0;      // size of the previous removal (the speculative issue's only hint)
+        uint64_t poison_expected = 0;   // points the kills of this cloud's lifetime should have removed
     } work;
     uint32_t n0 = 0, n_pad0 = 0, n_tiles0 = 0;
     m3d::CloudView view() const;        // working cloud

@@ -443,7 +443,9 @@ __global__ __launch_bounds__(256) void compact_count_k(CloudView c, const double
         if (i < c.n) {
             const double px = c.x[i], py = c.y[i], pz = c.z[i];
             const double d = ref_distance<KIND>(m, px, py, pz);
-            f = (d < thr) != (invert != 0);
+            // invert 1: the points a removal keeps (not inliers); 2: ... of the SORTED copy, whose dead points (x = NaN:
+            // poison_plane_inliers_k) go as well -- it holds no other non-finite point (grid_count_k leaves them out)
+            f = (d < thr) != (invert != 0) && (invert != 2 || px == px);
             if (SUMS && f) {
                 const double sx = px - c0x, sy = py - c0y, sz = pz - c0z;
                 acc[0] += sx;
@@ -618,7 +620,8 @@ __global__ __launch_bounds__(256) void compact_write_k(
         if (MODE == 1) dd[r] = d;
         const bool inl = in && d < thr;
         // f: what modes 0 / 1 / 4 list (the inliers) resp. what modes 2 / 3 keep (the rest); g (mode 4): the rest
-        const bool f = (MODE == 2 || MODE == 3) ? (in && !inl) : inl;
+        // (mode 3, the sorted copy: its dead points -- x = NaN, poison_plane_inliers_k -- are dropped with the inliers)
+        const bool f = MODE == 3 ? (in && !inl && px[r] == px[r]) : (MODE == 2 ? (in && !inl) : inl);
         bf[r] = __ballot(f);
         if (MODE == 4) bg[r] = __ballot(in && !inl);
         if (lane == 0) {
@@ -693,7 +696,7 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
     if (sums)
         compact_count_k<KIND == 2 ? 0 : KIND, true><<<nb, 256, 0, s>>>(c, model, thr, 0, block_counts, model_copy, moment_partial);
     else
-        compact_count_k<KIND, false><<<nb, 256, 0, s>>>(c, model, thr, mode >= 2 ? 1 : 0, block_counts, model_copy, nullptr);
+        compact_count_k<KIND, false><<<nb, 256, 0, s>>>(c, model, thr, mode == 3 ? 2 : (mode >= 2 ? 1 : 0), block_counts, model_copy, nullptr);
     CompactTail tail;
     tail.total = total;
     tail.total_host = total_host;

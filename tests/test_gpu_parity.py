@@ -200,6 +200,34 @@ def test_segmentation_matches_oracle(capi, orc):
         assert np.allclose(planes[k], oplanes[k], rtol=0, atol=PARAM_TOL)
 
 
+def test_segmentation_tombstones_vs_partition_vs_oracle(capi, orc):
+    """Rounds that remove a sliver of the cloud kill their inliers in place in the sorted copy (x = NaN in the fp64 array and
+    in the tiles' fp32 offsets: poison_plane_inliers_k; score_screen_k masks the dead lanes) instead of partitioning it; a
+    real compaction follows when an eighth of the copy is dead.  A room with ~60 clutter rounds goes through several such
+    cycles: clusters and planes must be the oracle's, and the partition-every-round path's (sorted_tombstones = 0), bit for
+    bit -- with the speculative RefineModel (rounds that run to max_iteration) and without it (adaptive stop)."""
+    pts = synth.room_cloud_c5(300_000, 17)
+    for max_it, min_ratio, seed in ((300, 0.02, 5), (1000, 0.03, 6)):
+        ro, po, co = orc.segment_plane_iterative(pts, 0.01, max_iteration=max_it, min_ratio=min_ratio, seed=seed, lookahead=128)
+        r1, p1, c1 = capi.segment_plane_iterative(pts, 0.01, max_iteration=max_it, min_ratio=min_ratio, seed=seed)
+        old = capi.set_config(sorted_tombstones=0)
+        try:
+            r0, p0, c0 = capi.segment_plane_iterative(pts, 0.01, max_iteration=max_it, min_ratio=min_ratio, seed=seed)
+        finally:
+            capi.restore_config(old)
+        assert len(co) == len(c1) == len(c0) > 30
+        for a, b, c in zip(co, c1, c0):
+            assert np.array_equal(a, b) and np.array_equal(a, c)
+        assert np.array_equal(p1, p0) and np.allclose(po, p1, rtol=0, atol=PARAM_TOL)
+    # the fp64-only scoring path (no screen: every pair through the exact code, where a dead point's NaN is never `< T`)
+    old = capi.set_config(score_fp32_screen=0, cull_fp32=0)
+    try:
+        r2, p2, c2 = capi.segment_plane_iterative(pts, 0.01, max_iteration=1000, min_ratio=0.03, seed=6)
+    finally:
+        capi.restore_config(old)
+    assert len(c2) == len(c1) and all(np.array_equal(a, b) for a, b in zip(c1, c2)) and np.array_equal(p1, p2)
+
+
 def test_full_size_properties(capi):
     """BASELINE config C2 size (1M points): size-independent properties instead of the oracle."""
     pts = synth.plane_cloud_c2(1_000_000, seed=2)
