@@ -815,6 +815,12 @@ static bool is_library_pinned(const void* p, size_t bytes) {
 // the compaction's counting pass accumulates the moments as well and no pass over the inlier list follows.
 // idx_host: the caller's page-locked index list; the compaction writes it directly (the 8 bytes per inlier cross the
 // host link while the kernel runs instead of in a copy command the host issues after it has woken up).
+// the pinned words RefineModel's kernels write, per slot (DeviceCtx::defer_refine; slot 0 otherwise)
+static int refine_slot(const DeviceCtx* ctx) { return ctx->defer_refine ? ctx->refine_slot : 0; }
+static double* h_best_at(DeviceCtx* ctx) { return ctx->h_best.as<double>() + (size_t)refine_slot(ctx) * kModelStride; }
+static uint8_t* h_total_at(DeviceCtx* ctx) { return ctx->h_pick.as<uint8_t>() + 64 + 8 * refine_slot(ctx); }
+static double* h_moments_at(DeviceCtx* ctx) { return ctx->h_moments.as<double>() + (size_t)refine_slot(ctx) * kFusedMomentDoubles; }
+
 static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, const uint32_t* orig_dev, int kind,
                                    double thr, const double* model_dev, const double* lazy_in, void* total_host,
                                    bool fused = false, uint64_t* idx_host = nullptr, const PartitionOut* part = nullptr) {
@@ -826,12 +832,12 @@ static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, c
     fused = fused && kind != M3D_CYLINDER;
     if (fused) {
         RESERVE(ctx->moment_partial, sizeof(double) * 16 * (size_t)std::max<uint32_t>(nb, 1));
-        RESERVE(ctx->h_moments, sizeof(double) * kFusedMomentDoubles);
+        RESERVE(ctx->h_moments, sizeof(double) * 2 * kFusedMomentDoubles);
     }
     launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
                    ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
-                   fused ? ctx->moment_partial.as<double>() : nullptr, fused ? ctx->h_moments.as<double>() : nullptr,
+                   fused ? ctx->moment_partial.as<double>() : nullptr, fused ? h_moments_at(ctx) : nullptr,
                    idx_host, static_cast<uint32_t*>(total_host) /* pinned: the kernel writes the total there itself */, part);
     ctx->compaction_fused = fused;
     ctx->compaction_idx_host = idx_host;
@@ -923,7 +929,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
                     const double* rec = lazy_in;
                     const double c0[3] = {kind == M3D_PLANE ? rec[4] : rec[0], kind == M3D_PLANE ? rec[5] : rec[1],
                                           kind == M3D_PLANE ? rec[6] : rec[2]};
-                    moments_about_mean(ctx->h_moments.as<double>(), c0, (double)ni_e, mean, sums + 4);
+                    moments_about_mean(h_moments_at(ctx), c0, (double)ni_e, mean, sums + 4);
                 } else {
                     general_fit_sums_finish(ctx->h_sums.as<double>(), sums);
                     for (int k = 0; k < 3; ++k) mean[k] = sums[k] / (double)ni_e;
@@ -1034,7 +1040,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             RESERVE(ctx->h_pick, 128);
             std::memset(ctx->h_pick.p, 0, 128);   // (BestPickHost::seq starts at 0; wait_pick_seq's values never are)
         }
-        RESERVE(ctx->h_best, sizeof(double) * kModelStride);
+        RESERVE(ctx->h_best, sizeof(double) * 2 * kModelStride);
     }
     SampleSource src;
     src.seed(seed);
@@ -1128,13 +1134,16 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             // (a segmentation round: the partition of the rest rides along, decided without the inlier count: -2)
             const PartitionOut* part = spec_adaptive && ctx->partition_hook && orig_dev ? (*ctx->partition_hook)(-2) : nullptr;
             r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
-                                        ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true,
+                                        h_best_at(ctx), h_total_at(ctx), /*fused=*/true,
                                         idx_host, part);
             ctx->spec_compaction = r == M3D_OK;
             // ... and so does the removal of the same inliers from the sorted copy (-3): by the time the host has replayed
             // the round and learnt the inlier count, the device is already through both
             // (RefineModel waits for ev_compact: recorded here, in front of the removal, not when refine() gets to run)
-            if (r == M3D_OK && part && hipEventRecord(ctx->ev_compact, ctx->stream) == hipSuccess) {
+            // (a round that may finish its RefineModel later -- DeviceCtx::defer_refine -- waits for no event at all)
+            if (r == M3D_OK && part && ctx->defer_refine) {
+                (void)(*ctx->partition_hook)(-3);
+            } else if (r == M3D_OK && part && hipEventRecord(ctx->ev_compact, ctx->stream) == hipSuccess) {
                 ctx->ev_compact_early = true;
                 (void)(*ctx->partition_hook)(-3);
             }
@@ -1151,7 +1160,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
             if (!sl.done_on_copy_stream) HIPCHK(hipEventRecord(sl.done, ctx->stream));
             if (e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
                 r = issue_refine_compaction(ctx, v, orig_dev, kind, thr, ctx->pick.as<BestPick>()->params,
-                                            ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true,
+                                            h_best_at(ctx), h_total_at(ctx), /*fused=*/true,
                                             idx_host);
                 ctx->spec_compaction = r == M3D_OK;
             }
@@ -1308,7 +1317,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     if (timing_events) out->ms_score = now_ms() - t_score0;
     // The best minimal model travels to the host (pinned ctx->h_best) with RefineModel: its first kernel stores the
     // record there and RefineModel's own wait delivers it (no wait and no copy command here).
-    RESERVE(ctx->h_best, sizeof(double) * kModelStride);
+    RESERVE(ctx->h_best, sizeof(double) * 2 * kModelStride);
     if (rc != M3D_OK) {
         (void)hipStreamSynchronize(ctx->stream);
         return rc;
@@ -1336,6 +1345,24 @@ static uint64_t resolve_seed(const uint64_t* seed) {
     return rd();
 }
 
+// GeneralFit of a round whose RefineModel was left running (DeviceCtx::deferred): the stream has passed its kernels
+static int finalize_deferred_refine(DeviceCtx* ctx) {
+    DeviceCtx::DeferredRefine& d = ctx->deferred;
+    if (!d.pending) return M3D_OK;
+    d.pending = false;
+    const double* rec = ctx->h_best.as<double>() + (size_t)d.slot * kModelStride;
+    uint32_t ni_chk;
+    std::memcpy(&ni_chk, ctx->h_pick.as<uint8_t>() + 64 + 8 * d.slot, 4);
+    if (ni_chk != d.ni) return fail(M3D_ERR_INTERNAL, "refine pass and scoring kernel disagree on the inlier count");
+    double model[4] = {rec[0], rec[1], rec[2], rec[3]};   // the best minimal model, refined in place when GeneralFit succeeds
+    const double c0[3] = {rec[4], rec[5], rec[6]};
+    double mean[3], sums[14], out[4];
+    moments_about_mean(ctx->h_moments.as<double>() + (size_t)d.slot * kFusedMomentDoubles, c0, (double)d.ni, mean, sums + 4);
+    if (plane_from_moments(mean, sums + 4, out)) std::memcpy(model, out, sizeof(out));
+    std::memcpy(d.params_out, model, sizeof(model));
+    return M3D_OK;
+}
+
 static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter, double prob,
                             uint64_t seed, double* params, size_t* inliers, size_t* n_inliers,
                             m3d_stats* stats, const std::function<int(int64_t)>* before_refine_wait = nullptr,
@@ -1359,8 +1386,12 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     ctx->compaction_fused = false;
     ctx->spec_hit = false;
     ctx->ev_compact_early = false;
+    if (ctx->defer_refine) ctx->refine_slot ^= 1;   // (the previous fit's words may still be waiting for finalize_deferred_refine)
     int rc = run_ransac(ctx, v, c->sorted(), kind, thr, max_iter, prob, seed, &ro, iterations_hint ? *iterations_hint : 0,
                         orig, comm, idx_host);
+    if (rc != M3D_OK) return rc;
+    // (this fit's records have arrived: the stream is past the previous fit's RefineModel)
+    rc = finalize_deferred_refine(ctx);
     if (rc != M3D_OK) return rc;
     if (iterations_hint) *iterations_hint = (size_t)ro.st.iterations;
     const double t1 = now_ms();
@@ -1368,7 +1399,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     size_t ni = 0;
     int gf_ok = 1;
     const int64_t expected = ro.st.best_index >= 0 ? (int64_t)ro.st.best_count : -1;
-    bool refined = false;
+    bool refined = false, deferred_now = false;
     if (ctx->spec_compaction) {
         // the compaction is already running on the device's pick (its record reached pinned memory with the chunk's
         // completion word): RefineModel is finished on it if the replay named the same hypothesis -- it does unless an rmse
@@ -1380,9 +1411,24 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         ro.spec_hits = hit ? 1 : 0;
         ro.spec_misses = hit ? 0 : 1;
         ctx->spec_hit = hit;
-        if (hit) {
+        const bool defer = hit && ctx->defer_refine && !comm && kind == M3D_PLANE && expected >= 3 && ctx->compaction_fused &&
+                           inliers && ctx->compaction_idx_host == reinterpret_cast<uint64_t*>(inliers) && before_refine_wait &&
+                           (uint64_t)expected <= v.n;
+        if (defer) {
+            // nothing of RefineModel is needed to go on: the count is the scoring pass's, the list is on its way to the
+            // caller's pinned array, the refined plane is only reported
+            const int hr = (*before_refine_wait)(expected);
+            before_refine_wait = nullptr;
+            if (hr != M3D_OK) return hr;
+            ctx->deferred.pending = true;
+            ctx->deferred.slot = refine_slot(ctx);
+            ctx->deferred.ni = (uint32_t)expected;
+            ctx->deferred.params_out = params;
+            ni = (size_t)expected;
+            refined = deferred_now = true;
+        } else if (hit) {
             rc = refine(ctx, v, gather, orig, kind, thr, ctx->pick.as<BestPick>()->params, model, inliers, &ni, &gf_ok,
-                        expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true);
+                        expected, before_refine_wait, h_best_at(ctx), h_total_at(ctx), /*fused=*/true);
             if (rc != M3D_OK) return rc;
             refined = true;
         }
@@ -1393,7 +1439,7 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         const BestPickHost* ph = ctx->h_pick.as<BestPickHost>();
         if (!refined) {   // (judged a miss on a record that may not have arrived yet)
             rc = refine(ctx, v, gather, orig, kind, thr, ctx->pick.as<BestPick>()->params, model, inliers, &ni, &gf_ok,
-                        expected, before_refine_wait, ctx->h_best.as<double>(), ctx->h_pick.as<uint8_t>() + 64, /*fused=*/true);
+                        expected, before_refine_wait, h_best_at(ctx), h_total_at(ctx), /*fused=*/true);
             if (rc != M3D_OK) return rc;
         }
         before_refine_wait = nullptr;   // (a speculative RefineModel has run its hook by now, in either branch)
@@ -1403,14 +1449,14 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     }
     if (!refined) {
         rc = refine(ctx, v, gather, orig, kind, thr, ctx->last_best_dev, model, inliers, &ni,
-                    &gf_ok, expected, before_refine_wait, ctx->h_best.as<double>(), nullptr,
+                    &gf_ok, expected, before_refine_wait, h_best_at(ctx), nullptr,
                     /*fused=*/true);
         if (rc != M3D_OK) return rc;
     }
     if (ro.st.best_index >= 0 && ni != ro.st.best_count)
         return fail(M3D_ERR_INTERNAL, "refine pass and scoring kernel disagree on the inlier count");
     if (n_inliers) *n_inliers = ni;
-    std::memcpy(params, model, sizeof(double) * num_params(kind));
+    if (!deferred_now) std::memcpy(params, model, sizeof(double) * num_params(kind));   // (deferred: finalize_deferred_refine writes them)
     const double t2 = now_ms();
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -2379,6 +2425,8 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         rc = agree_seed(comm, seed, ctx->stream, &seed0);
         poison_ready = ctx->poison_total.reserve(16) && hipMemsetAsync(ctx->poison_total.p, 0, 16, ctx->stream) == hipSuccess;
         if (!poison_ready) c0->work.tombstones = false;
+        ctx->deferred.pending = false;
+        ctx->defer_refine = !comm && config().speculative_refine != 0;   // (one GPU: DeviceCtx::deferred)
         // A pageable destination is reached through staged copies, a blocking one per round, into pages that fault on first
         // touch (10 M points: 43 ms against 37): the rounds write into a page-locked staging array the device context keeps
         // -- the compaction kernels store the index lists straight into it -- and the lists are copied over at the end.
@@ -2404,7 +2452,8 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             // ransac.FitModel(threshold, plane, inliers), :29-31; probability stays at the RANSAC default
             // (ransac.h:462); inlier indices refer to the cloud as created (c0->orig()).  The return value
             // (GeneralFit) is ignored by the reference.
-            double plane[4] = {0, 0, 0, 0};
+            double* plane = planes + 4 * k;   // (written by the fit, or -- a deferred RefineModel -- while the next round runs)
+            plane[0] = plane[1] = plane[2] = plane[3] = 0.0;
             size_t ni = 0;
             const size_t off = cluster_offsets[k];
             const double t_round0 = now_ms();
@@ -2454,7 +2503,6 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
                 rc = 2;
                 break;
             }
-            std::memcpy(planes + 4 * k, plane, sizeof(plane));
             cluster_offsets[k + 1] = off + ni;
             count += ni;
             k++;
@@ -2487,6 +2535,12 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         if (poison_ready && c0->work.poison_expected)
             (void)hipMemcpyAsync(&killed, ctx->poison_total.p, sizeof(killed), hipMemcpyDeviceToHost, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
+        ctx->defer_refine = false;
+        if (rc == M3D_OK || rc == 2) {   // the last round's RefineModel
+            const int fr = finalize_deferred_refine(ctx);
+            if (fr != M3D_OK) rc = fr;
+        }
+        ctx->deferred.pending = false;
         if (rc == M3D_OK) rc = cloud_remove_check_pending(c0);
         if ((rc == M3D_OK || rc == 2) && poison_ready && (uint64_t)killed != c0->work.poison_expected)
             rc = fail(M3D_ERR_INTERNAL, "the sorted copy's tombstones and the inlier lists disagree");

@@ -91,6 +91,18 @@ struct DeviceCtx {
     DevBuf pick;               // BestPick: the device's prediction of the winning hypothesis (probability-1 fits)
     PinBuf h_pick;             // BestPickHost mirror (+ at byte 64: inlier total of a compaction started on the prediction)
     bool spec_compaction = false;   // RefineModel's compaction has already been queued on pick->params
+    // Deferred RefineModel (m3d_segment_plane_iterative on one GPU): a round whose early compaction ran on the hypothesis
+    // the replay then named does not wait for it -- the inlier count is the scoring pass's, the index list goes to the
+    // caller's pinned array by itself -- and its GeneralFit is finished from the pinned sums while the NEXT round's records
+    // are awaited (two slots of h_best / h_moments / the total word: the next round's compaction is queued before that)
+    bool defer_refine = false;
+    int refine_slot = 0;
+    struct DeferredRefine {
+        bool pending = false;
+        int slot = 0;
+        uint32_t ni = 0;
+        double* params_out = nullptr;
+    } deferred;
     DevBuf poison_total;            // launch_poison_plane_inliers' running count
     bool ev_compact_early = false;  // ... and ev_compact was recorded right behind it (a removal has been queued after it)
     bool spec_hit = false;          // ... and the replay named the same hypothesis (cloud_fit_locked)
