@@ -778,7 +778,8 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
                                                   uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                   uint32_t* __restrict__ pair_rep,
                                                   uint32_t group_begin, uint32_t group_end, uint32_t block_x, uint32_t block_y,
-                                                  const float* __restrict__ cull32, const float* __restrict__ tile_f32) {
+                                                  const float* __restrict__ cull32, const float* __restrict__ tile_f32,
+                                                  uint32_t has_dead /* SortedView::has_dead: some points are tombstones */) {
     __shared__ uint16_t ids[kScreenMaxGroups * 64];
     __shared__ __attribute__((aligned(16))) uint8_t cnt8[64 * kCntStride];
     constexpr int NL = KIND == 2 ? 3 : 2;
@@ -851,7 +852,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
     // in fp64, where NaN < T is false: slower, never wrong).  dead8 in the order screen_eval shifts the bits in.
     uint32_t dead8 = 0;
     bool tile_has_dead = false;
-    if (tile_f32) {   // (kernel argument: uniform)
+    if (KIND == 0 && has_dead && tile_f32) {   // (kernel arguments: uniform; only a segmentation's working cloud has any)
 #pragma unroll
         for (int j = 0; j < Q; ++j) dead8 = (dead8 << 2) | (xf[j].x != xf[j].x ? 2u : 0u) | (xf[j].y != xf[j].y ? 1u : 0u);
         tile_has_dead = tile_screened && __ballot(dead8 != 0u) != 0ull;
@@ -992,10 +993,10 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
                                                       uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                       uint32_t* __restrict__ pair_rep,
                                                       uint32_t group_begin, uint32_t group_end,
-                                                      const float* __restrict__ tile_f32) {
+                                                      const float* __restrict__ tile_f32, uint32_t has_dead) {
     score_screen_body<KIND, false>(sx, sy, sz, boxes, max_abs, score, const_cast<unsigned long long*>(masks), keep, n_groups,
                                    groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, blockIdx.x,
-                                   blockIdx.y, nullptr, tile_f32);
+                                   blockIdx.y, nullptr, tile_f32, has_dead);
 }
 
 // cull_lead_k: ONE launch for the two latency-bound steps at the head of a fit's first chunk -- the box tests of the
@@ -1014,10 +1015,10 @@ __global__ __launch_bounds__(64) void cull_lead_k(const double* __restrict__ sx,
                                                    uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                    uint32_t* __restrict__ pair_rep, uint32_t* __restrict__ ub,
                                                    uint32_t cull_begin, uint32_t cull_end, uint32_t cull_gpw, uint32_t cull_tblocks,
-                                                   const float* __restrict__ tile_f32) {
+                                                   const float* __restrict__ tile_f32, uint32_t has_dead) {
     if (blockIdx.x < n_lead_wgs) {   // (workgroup-uniform)
         score_screen_body<KIND, true>(sx, sy, sz, boxes, max_abs, score, masks, keep, n_groups, lead_gpb, counts_rep, rep_stride,
-                                      pair_rep, 0u, lead_groups, blockIdx.x % n_tiles, blockIdx.x / n_tiles, cull32, tile_f32);
+                                      pair_rep, 0u, lead_groups, blockIdx.x % n_tiles, blockIdx.x / n_tiles, cull32, tile_f32, has_dead);
     } else {
         const uint32_t b = blockIdx.x - n_lead_wgs;
         cull32_body<KIND>(boxes, n_tiles, cull32, n_groups, cull_gpw, masks, ub, cull_begin, cull_end, b % cull_tblocks,
@@ -1159,15 +1160,15 @@ bool launch_cull_lead(int kind, const SortedView& s, const double* score, const 
     if (kind == 0)
         cull_lead_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
                                         lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
-                                        (const float*)s.tile_f32);
+                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
     else if (kind == 1)
         cull_lead_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
                                         lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
-                                        (const float*)s.tile_f32);
+                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
     else
         cull_lead_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
                                         lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
-                                        (const float*)s.tile_f32);
+                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
     return true;
 }
 
@@ -1262,13 +1263,13 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     if (screened) {
         if (kind == 0)
             go(score_screen_k<0>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end, (const float*)s.tile_f32);
+               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
         else if (kind == 1)
             go(score_screen_k<1>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end, (const float*)s.tile_f32);
+               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
         else
             go(score_screen_k<2>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end, (const float*)s.tile_f32);
+               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
     } else {
         if (kind == 0)
             go(score_mask_k<0>, s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep, group_begin, group_end);

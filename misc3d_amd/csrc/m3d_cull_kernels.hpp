@@ -23,6 +23,7 @@ struct SortedView {
     // box slot 6 then says whether the tile can be screened (every offset finite).  A wave of score_screen_k loads 6 KB
     // ready to use instead of 12 KB of doubles it has to shift and convert.
     float* tile_f32 = nullptr;
+    bool has_dead = false;   // some points are tombstones (x = NaN in both copies: launch_poison_plane_inliers); planes only
     double max_abs = __builtin_inf();  // >= |coordinate| of every point of the cloud (the box tests' rounding margin); inf = unknown (nothing culled)
     // centre of the cloud's bounding box and the largest |coordinate - origin| (fp32 box tests work relative to it);
     // radius = inf: unknown, the fp64 box tests are used

@@ -1630,7 +1630,9 @@ static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed, const size_t* kn
     if (w.issue_poison) {
         // killed in place: same arrays, same tiles, same (now slightly generous) boxes
         w.sorted_dead += cur.n - new_n;
+        w.scur.has_dead = true;
     } else {
+        w.scur.has_dead = false;
         w.scur.x = w.sbx[w.spp].as<double>();
         w.scur.y = w.sby[w.spp].as<double>();
         w.scur.z = w.sbz[w.spp].as<double>();
