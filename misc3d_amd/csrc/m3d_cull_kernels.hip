@@ -26,6 +26,7 @@
 // equal the dense ones; tests compare both paths against the oracle.  RefineModel / tie-break passes
 // keep using the original-order arrays, so inlier index lists and serial sums do not see the sort.
 #include "m3d_cull_kernels.hpp"
+#include "m3d_poison.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -127,48 +128,25 @@ void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st) {
 // The driver compacts for real (compact_write_k mode 3 drops NaN) when the dead are an eighth of the copy.
 // *total accumulates the kills of all launches (checked by the driver against the inlier lists, later).
 // ------------------------------------------------------------------------------------------------
-template <int KIND>
-__device__ __forceinline__ bool box_culled(const double* __restrict__ rec, const double* __restrict__ box);
-__global__ __launch_bounds__(256) void poison_plane_inliers_k(double* __restrict__ sx, const double* __restrict__ sy,
-                                                               const double* __restrict__ sz, const double* __restrict__ boxes,
-                                                               uint32_t n_tiles, float* __restrict__ tile_f32,
-                                                               const double* __restrict__ model, double thr, double max_abs,
-                                                               uint32_t* __restrict__ total /* running sum of the kills */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t tile = blockIdx.x * 4u + (uint32_t)wave;
-    double m[4];
-    for (int k = 0; k < 4; ++k) m[k] = model[k];
-    // the scoring record of this model (minimal_fit_k): the exact cut-off and the box test's margin
-    double rec[6];
-    rec[0] = m[0];
-    rec[1] = m[1];
-    rec[2] = m[2];
-    rec[3] = m[3];
-    rec[4] = plane_cutoff(m, thr);
-    rec[5] = rec[4] + 1e-12 * ((((fabs(m[0]) + fabs(m[1])) + fabs(m[2])) * max_abs + fabs(m[3])) + rec[4]);
-    uint32_t kills = 0;
-    if (tile < n_tiles && !box_culled<0>(rec, boxes + (size_t)tile * kBoxStride)) {   // (wave-uniform)
-        const double nan = u2f(0x7FF8000000000000ull);
-        float* __restrict__ tf = tile_f32 ? tile_f32 + (size_t)tile * kTileF32Floats : nullptr;
-#pragma unroll
-        for (int r = 0; r < kTilePoints / 64; ++r) {
-            const size_t i = (size_t)tile * kTilePoints + (size_t)r * 64 + lane;
-            const bool inl = plane_distance(m, sx[i], sy[i], sz[i]) < thr;   // RefineModel's own predicate (NaN: false)
-            if (inl) {
-                sx[i] = nan;
-                if (tf) tf[(((r >> 1) * 64) + lane) * 2 + (r & 1)] = f32_nan();   // x offsets: rows 2 j, 2 j + 1 side by side
-            }
-            kills += (uint32_t)__popcll(__ballot(inl));
-        }
-    }
-    // (kills are counted by waves that killed: ~250 of ~2000 in a clutter round.  Nobody waits for the sum -- the driver
-    // checks it against the inlier lists at the next real compaction, whose kept count it fixes, and at the end of the call)
-    if (lane == 0 && kills) atomicAdd(total, kills);
+__global__ __launch_bounds__(256) void poison_plane_inliers_k(PoisonJob job) {
+    poison_tile(job, blockIdx.x * 4u + (threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
-void launch_poison_plane_inliers(const SortedView& s, const double* model, double thr, uint32_t* total, hipStream_t st) {
-    if (!s.n_tiles) return;
-    poison_plane_inliers_k<<<(s.n_tiles + 3) / 4, 256, 0, st>>>(const_cast<double*>(s.x), s.y, s.z, s.boxes, s.n_tiles,
-                                                                const_cast<float*>(s.tile_f32), model, thr, s.max_abs, total);
+PoisonJob make_poison_job(const SortedView& s, const double* model, double thr, uint32_t* total) {
+    PoisonJob j;
+    j.sx = const_cast<double*>(s.x);
+    j.sy = s.y;
+    j.sz = s.z;
+    j.boxes = s.boxes;
+    j.n_tiles = s.n_tiles;
+    j.tile_f32 = const_cast<float*>(s.tile_f32);
+    j.model = model;
+    j.thr = thr;
+    j.max_abs = s.max_abs;
+    j.total = total;
+    return j;
+}
+void launch_poison_plane_inliers(const PoisonJob& job, hipStream_t st) {
+    if (job.n_tiles) poison_plane_inliers_k<<<(job.n_tiles + 3) / 4, 256, 0, st>>>(job);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,11 +161,8 @@ __device__ __forceinline__ bool box_culled(const double* __restrict__ rec, const
     if (KIND == 0) {
         // inlier <=> |fl(a x + b y + c z + d)| < T.  Over the box, a x + b y + c z + d ranges over
         // [s - r, s + r]; the rounded per-point value differs from the exact one by < 8 u * mag.
-        const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4], cut = rec[5];
-        const double s = ((a * cx + b * cy) + c * cz) + d;
-        const double r = (fabs(a) * hx + fabs(b) * hy) + fabs(c) * hz;
-        // !(T > 0): `num < T` can never hold.  cut = T + margin (minimal_fit_k); inf or NaN keeps the tile
-        return empty | !(T > 0.0) | (fabs(s) - r > cut);
+        (void)cx; (void)cy; (void)cz; (void)hy; (void)hz; (void)empty;
+        return plane_box_culled(rec, box);   // (m3d_poison.hpp: shared with the tombstone pass)
     } else if (KIND == 1) {
         // inlier <=> lo <= |q - c|^2 <= hi
         const double lo = rec[3], hi = rec[4];

@@ -33,10 +33,10 @@ struct SortedView {
 
 constexpr int kTileF32Floats = 3 * kTilePoints;
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
-// Tombstones (segmentation rounds that remove a sliver): the plane's inliers (plane_distance < thr) are killed in place in
-// the sorted copy -- x := NaN in the fp64 array and in the tile's fp32 offsets; boxes untouched.  *total (device, zeroed by
-// the caller once) accumulates the number of points killed over all launches.
-void launch_poison_plane_inliers(const SortedView& s, const double* model, double thr, uint32_t* total, hipStream_t st);
+// Tombstones (m3d_poison.hpp): the job that kills the inliers of the plane `model` (device) in place in the sorted copy
+// `s`; *total (device, cleared by the owner) accumulates the number of points killed over all launches.
+PoisonJob make_poison_job(const SortedView& s, const double* model, double thr, uint32_t* total);
+void launch_poison_plane_inliers(const PoisonJob& job, hipStream_t st);
 
 
 // masks: n_tiles x n_groups uint64, bit b of masks[t][g] = hypothesis 64 g + b may have inliers in tile t.

@@ -483,7 +483,11 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
                        (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
                        new_fit ? ctx->best_count.as<uint32_t>() : nullptr, lead_prepared ? &lp : nullptr, sv.max_abs,
-                       cull32 ? &c32 : nullptr);
+                       cull32 ? &c32 : nullptr, (ctx->poison_pending && kind == M3D_PLANE) ? &ctx->pending_poison : nullptr);
+    if (ctx->poison_pending && kind == M3D_PLANE) {   // (the previous round's tombstone pass went with it)
+        ctx->poison_pending = false;
+        if (ctx->poison_expected_at) *ctx->poison_expected_at += ctx->poison_pending_count;
+    }
     if (dense)
         HIPCHK(hipMemsetAsync(s.counts.p, 0, sizeof(uint32_t) * (size_t)h_pad, ctx->stream));
     // (culled path: keep_mask_k clears the counter replicas on its way)
@@ -1569,8 +1573,21 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
         // (the kills add up in ctx->poison_total, cleared by the owner of the cloud -- segment_impl -- which compares the sum
         // with the inlier lists at the end; a real compaction in between checks the live count it leaves)
         RESERVE(ctx->poison_total, 16);
-        launch_poison_plane_inliers(w.scur, model_dev, thr, ctx->poison_total.as<uint32_t>(), ctx->stream);
-        w.poison_expected += (uint64_t)expected_removed;
+        // A round that does not wait for its RefineModel (DeviceCtx::deferred) goes straight on to the next fit: its kill
+        // rides in that fit's minimal_fit_k launch.  The model is then read from the device's pick record, which stays put
+        // until the next fit's records are folded (the winner's slot of the parameter array is rewritten by that launch).
+        const bool ride = ctx->defer_refine && ctx->spec_hit && !ctx->poison_pending;
+        const PoisonJob job = make_poison_job(w.scur, ride ? ctx->pick.as<BestPick>()->params : model_dev, thr,
+                                              ctx->poison_total.as<uint32_t>());
+        if (ride) {
+            ctx->pending_poison = job;
+            ctx->poison_pending = true;
+            ctx->poison_expected_at = &w.poison_expected;
+            ctx->poison_pending_count = (uint64_t)expected_removed;
+        } else {
+            launch_poison_plane_inliers(job, ctx->stream);
+            w.poison_expected += (uint64_t)expected_removed;
+        }
         HIPCHK(hipGetLastError());
         return M3D_OK;
     }
@@ -2428,6 +2445,7 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         poison_ready = ctx->poison_total.reserve(16) && hipMemsetAsync(ctx->poison_total.p, 0, 16, ctx->stream) == hipSuccess;
         if (!poison_ready) c0->work.tombstones = false;
         ctx->deferred.pending = false;
+        ctx->poison_pending = false;
         ctx->defer_refine = !comm && config().speculative_refine != 0;   // (one GPU: DeviceCtx::deferred)
         // A pageable destination is reached through staged copies, a blocking one per round, into pages that fault on first
         // touch (10 M points: 43 ms against 37): the rounds write into a page-locked staging array the device context keeps
@@ -2538,6 +2556,7 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             (void)hipMemcpyAsync(&killed, ctx->poison_total.p, sizeof(killed), hipMemcpyDeviceToHost, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
         ctx->defer_refine = false;
+        ctx->poison_pending = false;   // (the last round's kill has nobody left to serve)
         if (rc == M3D_OK || rc == 2) {   // the last round's RefineModel
             const int fr = finalize_deferred_refine(ctx);
             if (fr != M3D_OK) rc = fr;

@@ -103,6 +103,10 @@ struct DeviceCtx {
         uint32_t ni = 0;
         double* params_out = nullptr;
     } deferred;
+    // a tombstone pass that waits for the next fit's minimal_fit_k launch to ride in (cloud_remove_issue -> issue_chunk)
+    PoisonJob pending_poison;
+    bool poison_pending = false;
+    uint64_t* poison_expected_at = nullptr, poison_pending_count = 0;   // m3d_cloud::Work::poison_expected, credited at launch
     DevBuf poison_total;            // launch_poison_plane_inliers' running count
     bool ev_compact_early = false;  // ... and ev_compact was recorded right behind it (a removal has been queued after it)
     bool spec_hit = false;          // ... and the replay named the same hypothesis (cloud_fit_locked)

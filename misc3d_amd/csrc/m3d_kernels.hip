@@ -18,6 +18,7 @@
 //     forms serially are either reproduced serially (serial_sum_k) or are tolerance-checked
 //     parameters (GeneralFit), never inlier decisions.
 #include "m3d_kernels.hpp"
+#include "m3d_poison.hpp"
 
 #include "m3d_fp.hpp"
 
@@ -130,7 +131,13 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
                                                      double* __restrict__ params,
                                                      uint8_t* __restrict__ valid, uint32_t* __restrict__ zero_u32,
                                                      uint32_t* __restrict__ zero_one, LeadPrep lead, double cull_max_abs,
-                                                     Cull32Out c32) {
+                                                     Cull32Out c32, PoisonJob poison, uint32_t fit_blocks) {
+    // workgroups behind the fit's own: the previous segmentation round's tombstone pass, one wave per tile of the sorted
+    // copy (m3d_poison.hpp) -- two latency-bound launches in the time of the longer one
+    if (KIND == 0 && blockIdx.x >= fit_blocks) {   // (workgroup-uniform)
+        poison_tile(poison, blockIdx.x - fit_blocks, (int)threadIdx.x);
+        return;
+    }
     const uint32_t h = blockIdx.x * 64u + threadIdx.x;
     if (h >= h_pad) return;
     if (zero_u32 && h + 1 < h_pad) zero_u32[h] = 0;   // per-hypothesis counter cleared on the way (saves a memset launch)
@@ -248,19 +255,22 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
 void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
                         hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one, const LeadPrep* lead, double cull_max_abs,
-                        const Cull32Out* cull32) {
+                        const Cull32Out* cull32, const PoisonJob* poison) {
     if (h_pad == 0) return;
-    const dim3 g((h_pad + 63) / 64), b(64);
+    const uint32_t fit_blocks = (h_pad + 63) / 64;
+    const dim3 g(fit_blocks + (kind == 0 && poison ? poison->n_tiles : 0u)), b(64);
     LeadPrep lp;
     if (lead) lp = *lead;
     Cull32Out c32;
     if (cull32) c32 = *cull32;
+    PoisonJob pj;
+    if (kind == 0 && poison) pj = *poison;
     if (kind == 0)
-        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32);
+        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
     else if (kind == 1)
-        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32);
+        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
     else
-        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32);
+        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------

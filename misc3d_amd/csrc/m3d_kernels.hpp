@@ -45,6 +45,17 @@ struct Cull32Out {
     double origin[3] = {0.0, 0.0, 0.0};
     double radius = 0.0;
 };
+// The tombstone pass of a segmentation round (m3d_poison.hpp): the plane `model`'s inliers are killed in place in the sorted
+// copy.  Launched on its own (launch_poison_plane_inliers) or as extra workgroups of the NEXT round's minimal_fit_k<0>.
+struct PoisonJob {
+    double* sx = nullptr;
+    const double *sy = nullptr, *sz = nullptr, *boxes = nullptr;
+    uint32_t n_tiles = 0;
+    float* tile_f32 = nullptr;
+    const double* model = nullptr;   // device: (a, b, c, d)
+    double thr = 0.0, max_abs = 0.0;
+    uint32_t* total = nullptr;       // device: running sum of the points killed
+};
 struct LeadPrep {
     uint32_t* counts_rep = nullptr;   // n_rep x rep_stride counters, then n_pair pair counters
     unsigned long long* keep = nullptr;
@@ -58,7 +69,9 @@ void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, u
                         const LeadPrep* lead = nullptr,
                         double cull_max_abs = __builtin_inf() /* SortedView::max_abs: the plane record's slot 5 receives the
                                                                  cut-off of the box tests (inf: nothing is ever culled) */,
-                        const Cull32Out* cull32 = nullptr);
+                        const Cull32Out* cull32 = nullptr,
+                        const PoisonJob* poison = nullptr /* planes: the previous round's tombstone pass rides in the launch (one
+                                                             extra 64-thread workgroup per tile of the sorted copy) */);
 
 // K2: inlier counting.  partial[tile * h_pad + h] = number of points of scoring tile `tile` whose
 // distance to hypothesis h is < thr.  h_pad must be a multiple of 64; the hypotheses are cut into
