@@ -207,6 +207,8 @@ def test_segmentation_tombstones_vs_partition_vs_oracle(capi, orc):
     cycles: clusters and planes must be the oracle's, and the partition-every-round path's (sorted_tombstones = 0), bit for
     bit -- with the speculative RefineModel (rounds that run to max_iteration) and without it (adaptive stop)."""
     pts = synth.room_cloud_c5(300_000, 17)
+    pts[[5, 77, 4000, 250_000]] = np.nan      # non-finite input points stay in the cloud (and out of the sorted copy, whose
+    pts[123, 1] = np.inf                        # only NaN are the tombstones)
     for max_it, min_ratio, seed in ((300, 0.02, 5), (1000, 0.03, 6)):
         ro, po, co = orc.segment_plane_iterative(pts, 0.01, max_iteration=max_it, min_ratio=min_ratio, seed=seed, lookahead=128)
         r1, p1, c1 = capi.segment_plane_iterative(pts, 0.01, max_iteration=max_it, min_ratio=min_ratio, seed=seed)
