@@ -15,6 +15,7 @@
 #include <pybind11/stl.h>
 
 #include <cstring>
+#include <mutex>
 #include <optional>
 
 #include <misc3d/common/ransac.h>
@@ -100,6 +101,65 @@ struct PinnedScratch {
         return p;
     }
     // (no destructor: a thread-local object of the main thread dies at process exit, possibly after the HIP runtime)
+};
+
+// Page-locked result blocks for calls that return hundreds of megabytes (segment_plane_iterative's cluster clouds): taken
+// from / given back to a pool of at most two free blocks (a loop that rebinds its result keeps two alive in turn), so a
+// steady caller pins nothing after its second call.  Never destroyed (capsules may outlive the module at exit).
+struct PinnedPool {
+    struct Block {
+        void* p;
+        size_t bytes;
+    };
+    struct State {
+        std::mutex mu;
+        std::vector<Block> free_blocks, live;
+    };
+    static State& state() {
+        static State* s = new State();
+        return *s;
+    }
+    static void* take(size_t bytes) {
+        State& st = state();
+        {
+            std::lock_guard<std::mutex> lock(st.mu);
+            for (size_t i = 0; i < st.free_blocks.size(); ++i) {
+                const Block b = st.free_blocks[i];
+                if (b.bytes >= bytes && b.bytes <= 2 * bytes + ((size_t)1 << 20)) {
+                    st.free_blocks.erase(st.free_blocks.begin() + (long)i);
+                    st.live.push_back(b);
+                    return b.p;
+                }
+            }
+        }
+        void* p = m3d_host_alloc(bytes);
+        if (p) {
+            std::lock_guard<std::mutex> lock(st.mu);
+            st.live.push_back({p, bytes});
+        }
+        return p;
+    }
+    static void give(void* p) {
+        if (!p) return;
+        State& st = state();
+        Block b{p, 0};
+        void* drop = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(st.mu);
+            for (size_t i = 0; i < st.live.size(); ++i)
+                if (st.live[i].p == p) {
+                    b = st.live[i];
+                    st.live.erase(st.live.begin() + (long)i);
+                    break;
+                }
+            if (st.free_blocks.size() < 4) {   // (two result arrays x two generations)
+                st.free_blocks.push_back(b);
+            } else {
+                drop = p;
+            }
+        }
+        if (drop) m3d_host_free(drop);
+    }
 };
 
 // FitPlane / FitSphere / FitCylinder, python/py_common.cpp:11-67: construct, SetMaxIteration, SetProbability,
@@ -268,9 +328,23 @@ PYBIND11_MODULE(_py_misc3d, m) {
             const size_t max_clusters = 4096;
             std::vector<double> planes(4 * max_clusters);
             std::vector<size_t> offsets(max_clusters + 1);
-            py::array_t<int64_t> indices((py::ssize_t)v.n);
-            arr_d points(std::vector<py::ssize_t>{(py::ssize_t)v.n, 3});
             static_assert(sizeof(size_t) == sizeof(int64_t), "index arrays are 64-bit");
+            // Large clouds: the two result arrays are PAGE-LOCKED blocks of a small pool (PinnedPool) -- the library's
+            // kernels store the index lists straight into them and the 228 MB of cluster points of a 10 M-point room
+            // arrive at the host link's rate (4 ms) instead of through staged copies into fresh pageable pages (25 ms);
+            // a block goes back to the pool when the last view of it dies.
+            const size_t pts_bytes = sizeof(double) * 3 * v.n, idx_bytes = sizeof(size_t) * v.n;
+            const bool pinned = pts_bytes >= ((size_t)4 << 20);
+            void* pts_block = pinned ? PinnedPool::take(pts_bytes) : nullptr;
+            void* idx_block = pinned && pts_block ? PinnedPool::take(idx_bytes) : nullptr;
+            if (pts_block && !idx_block) {
+                PinnedPool::give(pts_block);
+                pts_block = nullptr;
+            }
+            py::array_t<int64_t> indices_pageable(pts_block ? (py::ssize_t)0 : (py::ssize_t)v.n);
+            arr_d points_pageable(std::vector<py::ssize_t>{pts_block ? (py::ssize_t)0 : (py::ssize_t)v.n, 3});
+            size_t* idx_ptr = pts_block ? static_cast<size_t*>(idx_block) : reinterpret_cast<size_t*>(indices_pageable.mutable_data());
+            double* pts_ptr = pts_block ? static_cast<double*>(pts_block) : points_pageable.mutable_data();
             size_t k = 0;
             int status;
             {
@@ -278,8 +352,16 @@ PYBIND11_MODULE(_py_misc3d, m) {
                 uint64_t s = seed ? *seed : 0;
                 status = m3d_segment_plane_iterative_clouds(v.xyz, v.n, threshold, max_iteration, min_ratio,
                                                             seed ? &s : nullptr, device, max_clusters, planes.data(),
-                                                            offsets.data(), reinterpret_cast<size_t*>(indices.mutable_data()),
-                                                            points.mutable_data(), &k);
+                                                            offsets.data(), idx_ptr, pts_ptr, &k);
+            }
+            py::object points = points_pageable, indices = indices_pageable;
+            if (pts_block) {   // (wrapped before anything can throw: the capsules own the blocks from here on)
+                const py::ssize_t total = status >= 0 ? (py::ssize_t)offsets[k] : 0;
+                points = py::array_t<double>(std::vector<py::ssize_t>{total, 3}, std::vector<py::ssize_t>{24, 8}, pts_ptr,
+                                             py::capsule(pts_block, [](void* p) { PinnedPool::give(p); }));
+                indices = py::array_t<int64_t>(std::vector<py::ssize_t>{total}, std::vector<py::ssize_t>{8},
+                                               reinterpret_cast<int64_t*>(idx_ptr),
+                                               py::capsule(idx_block, [](void* p) { PinnedPool::give(p); }));
             }
             if (misc3d::CheckStatus(status) == 2)
                 misc3d::LogWarning("segment_plane_iterative: a round found no inlier; stopping early");
@@ -295,7 +377,7 @@ PYBIND11_MODULE(_py_misc3d, m) {
                 py::array_t<double> plane(4);
                 std::memcpy(plane.mutable_data(), &planes[4 * cix], sizeof(double) * 4);
                 const py::slice rows((py::ssize_t)offsets[cix], (py::ssize_t)offsets[cix + 1], 1);
-                py::object cluster = points[rows];
+                py::object cluster = points[rows];   // (a view: keeps the block alive)
                 if (!o3d.is_none())  // list[(ndarray(4), open3d PointCloud)] like the reference
                     cluster = o3d.attr("geometry").attr("PointCloud")(o3d.attr("utility").attr("Vector3dVector")(cluster));
                 if (return_indices)
