@@ -36,24 +36,51 @@ inline std::vector<PlaneCluster> SegmentPlaneIterativeIndexed(const CloudView& p
     }
     const size_t max_clusters = 4096;
     std::vector<double> planes(4 * max_clusters);
-    std::vector<size_t> offsets(max_clusters + 1), indices(pcd.n);
-    std::unique_ptr<double[]> gathered;
+    std::vector<size_t> offsets(max_clusters + 1);
+    // Large clouds: index lists and gathered points land in page-locked scratch this thread keeps (the kernels store the
+    // lists straight into it, the points arrive at the host link's rate), and are copied into the clusters from there.
+    struct PinnedScratch {
+        void* p = nullptr;
+        size_t cap = 0;
+        void* get(size_t bytes) {
+            if (bytes > cap) {
+                if (p) m3d_host_free(p);
+                p = m3d_host_alloc(bytes);
+                cap = p ? bytes : 0;
+            }
+            return p;
+        }
+        // (no destructor: a thread-local of the main thread dies at process exit, possibly after the HIP runtime)
+    };
+    static thread_local PinnedScratch pin_idx, pin_pts;
+    const bool big = pcd.n >= ((size_t)1 << 17);
+    std::vector<size_t> indices_pageable;
+    size_t* indices = big ? static_cast<size_t*>(pin_idx.get(sizeof(size_t) * pcd.n)) : nullptr;
+    if (!indices) {
+        indices_pageable.resize(pcd.n);
+        indices = indices_pageable.data();
+    }
+    std::unique_ptr<double[]> gathered_pageable;
+    double* gathered = nullptr;
     size_t k = 0;
     int status;
     if (!devices.empty())
         status = m3d_segment_plane_iterative_multi(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed,
                                                    devices.data(), (int)devices.size(), max_clusters, planes.data(),
-                                                   offsets.data(), indices.data(), &k);
+                                                   offsets.data(), indices, &k);
     else if (comm)
         status = m3d_segment_plane_iterative_sharded(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed, device,
                                                      comm, max_clusters, planes.data(), offsets.data(),
-                                                     indices.data(), &k);
+                                                     indices, &k);
     else {
         // one device: the clusters' points are gathered on the device (m3d_segment_plane_iterative_clouds)
-        gathered.reset(new double[3 * pcd.n]);
+        gathered = big ? static_cast<double*>(pin_pts.get(sizeof(double) * 3 * pcd.n)) : nullptr;
+        if (!gathered) {
+            gathered_pageable.reset(new double[3 * pcd.n]);
+            gathered = gathered_pageable.get();
+        }
         status = m3d_segment_plane_iterative_clouds(pcd.xyz, pcd.n, threshold, max_iteration, min_ratio, seed, device,
-                                                    max_clusters, planes.data(), offsets.data(), indices.data(),
-                                                    gathered.get(), &k);
+                                                    max_clusters, planes.data(), offsets.data(), indices, gathered, &k);
     }
     const int rc = CheckStatus(status);
     if (rc == 2) LogWarning("segment_plane_iterative: a round found no inlier; stopping early");
@@ -62,11 +89,11 @@ inline std::vector<PlaneCluster> SegmentPlaneIterativeIndexed(const CloudView& p
     for (size_t c = 0; c < k; ++c) {
         for (int j = 0; j < 4; ++j) result[c].plane[j] = planes[4 * c + j];
         const size_t lo = offsets[c], cnt = offsets[c + 1] - offsets[c];
-        result[c].indices.assign(indices.begin() + lo, indices.begin() + lo + cnt);
+        result[c].indices.assign(indices + lo, indices + lo + cnt);
         auto& P = result[c].cloud.points_;
         if (gathered) {
             P.resize(cnt);
-            if (cnt) std::memcpy(static_cast<void*>(P.data()), gathered.get() + 3 * lo, sizeof(double) * 3 * cnt);
+            if (cnt) std::memcpy(static_cast<void*>(P.data()), gathered + 3 * lo, sizeof(double) * 3 * cnt);
         } else {
             P.reserve(cnt);
             for (size_t i : result[c].indices) P.push_back({pcd.xyz[3 * i], pcd.xyz[3 * i + 1], pcd.xyz[3 * i + 2]});
