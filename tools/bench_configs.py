@@ -240,8 +240,5 @@ if "C5" in which:
                        "tail_rounds": {"rounds": n_tail, "ms": t_tail * 1e3, "us_per_round": t_tail * 1e6 / n_tail,
                                        "algorithmic_bytes": alg_tail, "GBps": alg_tail / t_tail / 1e9,
                                        "frac": alg_tail / t_tail / 1e9 / HBM_PEAK_GBS,
-                                       "note": "1000 hypotheses on ~1 M clutter points each: ~63 us of box tests and scoring "
-                                               "(latency-bound launches, 8 % of the (tile, hypothesis) pairs survive), ~15 us of "
-                                               "host turn-around, ~55 us of compaction / partition / tile-box passes that run at "
-                                               "2.5-4.7 TB/s (profiles/r03_c5_round_timeline.txt)"}},
+                                       "note": "1000 hypotheses on ~1 M clutter points each, the round's kernels back to back: ~58 us of box tests and scoring (latency-bound launches, 8 % of the (tile, hypothesis) pairs survive), ~24 us of RefineModel's compaction + the partition in creation order at 3.6 TB/s, ~8 us for the previous round's tombstone pass riding in minimal_fit_k's launch; no host wait but the records' (profiles/r03_c5_round_timeline.txt)"}},
                    "note": "whole call (PCIe upload of 240 MB and 76 MB of index lists back included)"})
