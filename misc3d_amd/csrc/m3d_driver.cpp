@@ -422,7 +422,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                                                             behind THAT (an event between two kernels costs a ~5 us
                                                             gap on this stream; behind pick_best_k nothing follows at once) */,
                        const PickFinal* pick_final = nullptr /* one GPU: the chunk's last kernel takes pick_best_k's decision
-                                                                and stores the completion word the host polls (no event) */) {
+                                                                and stores the completion word the host polls (no event) */,
+                       bool nothing_to_prune = false /* the fit's ONLY chunk, issued without a lead pass: no incumbent will
+                                                        ever exist while it runs */) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const bool dense = use_dense_scoring();
@@ -471,18 +473,22 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     const bool own_real_ = !comm || (size_t)rank * sl_pad < count;
     LeadPrep lp;
     const bool lead_prepared = use_lead && new_fit && own_real_ && lead <= h_pad && (uint32_t)kPairReplicas <= h_pad;
-    if (lead_prepared) {
+    // no lead pass and nothing to prune against (a new fit's only chunk on one GPU, DeviceCtx::no_prune_hint): the same
+    // set-up for ALL groups -- keep everything, clear every counter replica -- and no keep_mask_k launch below
+    const bool all_prepared = nothing_to_prune && !use_lead && lead == 0 && !dense && prune && new_fit && !comm &&
+                              (uint32_t)kPairReplicas <= h_pad;
+    if (lead_prepared || all_prepared) {
         lp.counts_rep = ctx->counts_rep.as<uint32_t>();
         lp.keep = ctx->keep.as<unsigned long long>();
         lp.rep_stride = h_pad;
         lp.n_rep = kCountReplicas;
-        lp.n_lead = lead;
+        lp.n_lead = all_prepared ? h_pad : lead;
         lp.n_pair = kPairReplicas;
     }
     launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
                        (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
-                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr, lead_prepared ? &lp : nullptr, sv.max_abs,
+                       new_fit ? ctx->best_count.as<uint32_t>() : nullptr, (lead_prepared || all_prepared) ? &lp : nullptr, sv.max_abs,
                        cull32 ? &c32 : nullptr, (ctx->poison_pending && kind == M3D_PLANE) ? &ctx->pending_poison : nullptr);
     if (ctx->poison_pending && kind == M3D_PLANE) {   // (the previous round's tombstone pass went with it)
         ctx->poison_pending = false;
@@ -564,7 +570,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
                                       g0 == 0 ? rec_host : nullptr, bc, ub, keep, g1 - g_lo, ctx->stream,
                                       g0 == 0 ? rec_dev : nullptr, g_lo, pick_final ? pick_final->key : nullptr);
-            } else {
+            } else if (!all_prepared) {   // (all_prepared: minimal_fit_k has done it)
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
             }
             launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
@@ -1077,7 +1083,10 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         // small first chunk with the second one queued behind it, minus a sample upload, a MinimalFit and a
         // box-test launch.  Should the bound not be reached, the loop below issues what is left of it.
         chunk = (iterations_hint + iterations_hint / 16 + 16 + 63) / 64 * 64;
-        lead = lead_size();
+        // (a segmentation round in the clutter: the best plane holds well under a percent of the cloud while every
+        // hypothesis' bound -- the population of the tiles its slab meets -- is tens of times that: nothing is ever pruned,
+        // and the lead pass that exists to prune costs a launch and a fold.  The caller says so: DeviceCtx::no_prune_hint.)
+        lead = ctx->no_prune_hint ? 0u : lead_size();
         iterations_hint = 0;   // (consumed: no second chunk queued on the first pass)
     }
     chunk = std::min(std::min(chunk, chunk_cap), std::max<size_t>((max_iter + 63) / 64 * 64, 64));
@@ -1132,7 +1141,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
         int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
                             b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec && !fused_pick,
-                            fused_pick ? &pf : nullptr);
+                            fused_pick ? &pf : nullptr, /*nothing_to_prune=*/b == 0 && e == max_iter && lead == 0 && !comm);
         const bool spec_adaptive = spec_enabled && prob < 1.0 && hinted_chunk && b == 0 && !comm && !use_dense_scoring();
         if (r == M3D_OK && fused_pick && (spec || spec_adaptive) && e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
             // (a segmentation round: the partition of the rest rides along, decided without the inlier count: -2)
@@ -2513,9 +2522,11 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
                                           expected_ni);
             };
             ctx->partition_hook = &partition_hook;
+            ctx->no_prune_hint = !comm && k > 0 && (uint64_t)c0->work.last_removed * 32 < c0->n;   // (the previous round's plane: < 3 % of the cloud)
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
                                   idx_out + off, &ni, nullptr, &issue_removal, &iterations_hint, comm);
             ctx->partition_hook = nullptr;
+            ctx->no_prune_hint = false;
             if (rc < 0) break;
             rc = cloud_remove_check_pending(c0);   // (the previous round's removal: this round's wait lay behind it)
             if (rc != M3D_OK) break;

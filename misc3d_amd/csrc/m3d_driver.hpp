@@ -95,6 +95,7 @@ struct DeviceCtx {
     // the replay then named does not wait for it -- the inlier count is the scoring pass's, the index list goes to the
     // caller's pinned array by itself -- and its GeneralFit is finished from the pinned sums while the NEXT round's records
     // are awaited (two slots of h_best / h_moments / the total word: the next round's compaction is queued before that)
+    bool no_prune_hint = false;     // segment_impl: the next fit's chunk will prune nothing (no lead pass, no keep masks)
     bool defer_refine = false;
     int refine_slot = 0;
     struct DeferredRefine {
