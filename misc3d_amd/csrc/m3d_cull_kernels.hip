@@ -1147,6 +1147,37 @@ bool launch_cull_lead(int kind, const SortedView& s, const double* score, const 
     return true;
 }
 
+// The WHOLE chunk through cull_lead_k's first kind of workgroup: every scoring workgroup runs the fp32 box tests of its
+// tile against its own groups (lane = hypothesis) and counts the survivors -- no box-test launch in front of the scoring
+// launch.  For chunks that prune nothing (keep = all ones, prepared by minimal_fit_k): a segmentation round in the clutter,
+// 1000 hypotheses on ~2000 tiles, where cull_tiles32_k was 9 us of launch latency in front of a 34 us scoring launch.
+bool launch_score_own_tests(int kind, const SortedView& s, const double* score, const float* cull32, unsigned long long* masks,
+                            const unsigned long long* keep, uint32_t n_groups, uint32_t groups, uint32_t* counts_rep,
+                            uint32_t rep_stride, uint32_t* pair_rep, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    groups = std::min(groups, n_groups);
+    if (!s.n_tiles || !cull32 || !(s.radius < 1e18) || config().cull_fp32 == 0 || config().score_fp32_screen == 0 || groups == 0)
+        return false;
+    const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, kScreenMaxGroups);
+    const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
+    const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * groups) / min_wgs)));
+    const uint32_t n_wgs = s.n_tiles * ((groups + gpb - 1) / gpb);
+    const dim3 g(n_wgs), b(64);
+    auto go = [&](auto kernel) {
+        if (ev_start && ev_stop)
+            hipExtLaunchKernelGGL(kernel, g, b, 0, st, ev_start, ev_stop, 0, s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32,
+                                  masks, keep, n_groups, groups, gpb, n_wgs, counts_rep, rep_stride, pair_rep, (uint32_t*)nullptr,
+                                  groups, groups, 1u, 1u, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+        else
+            kernel<<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, groups, gpb, n_wgs,
+                                    counts_rep, rep_stride, pair_rep, (uint32_t*)nullptr, groups, groups, 1u, 1u,
+                                    (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+    };
+    if (kind == 0) go(cull_lead_k<0>);
+    else if (kind == 1) go(cull_lead_k<1>);
+    else go(cull_lead_k<2>);
+    return true;
+}
+
 // The hypothesis the sequential replay will most probably end with, chosen on the device: highest inlier count
 // among the valid hypotheses of the chunk, lowest index among equals, against the running pick of earlier chunks
 // (strictly more inliers to replace it).  Fitness ties are decided by rmse on the host, so this is a PREDICTION:

@@ -76,6 +76,12 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
 bool launch_cull_lead(int kind, const SortedView& s, const double* score, const float* cull32, unsigned long long* masks,
                       const unsigned long long* keep, uint32_t n_groups, uint32_t lead_groups, uint32_t* counts_rep,
                       uint32_t rep_stride, uint32_t* pair_rep, uint32_t* ub, uint32_t cull_end, hipStream_t st);
+// The chunk's box tests INSIDE its scoring launch (every workgroup tests its tile against its own groups): for chunks that
+// prune nothing (keep all ones).  false: preconditions not met (fp32 box tests / screen off), nothing launched.
+bool launch_score_own_tests(int kind, const SortedView& s, const double* score, const float* cull32, unsigned long long* masks,
+                            const unsigned long long* keep, uint32_t n_groups, uint32_t groups, uint32_t* counts_rep,
+                            uint32_t rep_stride, uint32_t* pair_rep, hipStream_t st, hipEvent_t ev_start = nullptr,
+                            hipEvent_t ev_stop = nullptr);
 // (planes and spheres go through score_screen_k unless m3d_config.score_fp32_screen is 0)
 // The device's prediction of the hypothesis the replay will end with (pick_best_k, m3d_cull_kernels.hip)
 struct BestPick {

@@ -549,7 +549,13 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 s.lead_fused = launch_cull_lead(kind, sv, s.score.as<double>(), c32.out, masks, keep, n_groups, ga,
                                                 ctx->counts_rep.as<uint32_t>(), h_pad, pair_rep, ub, g1, ctx->stream);
             }
-            if (!s.lead_fused) {
+            // nothing to prune and every group prepared by minimal_fit_k: the box tests run inside the scoring launch
+            bool scored_with_own_tests = false;
+            if (all_prepared && c32.out)
+                scored_with_own_tests = launch_score_own_tests(kind, sv, s.score.as<double>(), c32.out, masks, keep, n_groups, g1,
+                                                               ctx->counts_rep.as<uint32_t>(), h_pad, pair_rep, ctx->stream,
+                                                               timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
+            if (!s.lead_fused && !scored_with_own_tests) {
                 if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
                     launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
                                      ctx->stream, /*ub_is_zero=*/true, 0, ga, c32.out);
@@ -573,8 +579,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             } else if (!all_prepared) {   // (all_prepared: minimal_fit_k has done it)
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
             }
-            launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
-                              pair_rep, ctx->stream, g_lo, g1, timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
+            if (!scored_with_own_tests)
+                launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
+                                  pair_rep, ctx->stream, g_lo, g1, timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
             // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
             // ... and (one GPU) write the records straight into the slot's pinned host array (device-visible): no copy
             // command behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
