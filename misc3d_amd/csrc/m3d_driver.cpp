@@ -832,6 +832,8 @@ static bool is_library_pinned(const void* p, size_t bytes) {
 // the compaction's counting pass accumulates the moments as well and no pass over the inlier list follows.
 // idx_host: the caller's page-locked index list; the compaction writes it directly (the 8 bytes per inlier cross the
 // host link while the kernel runs instead of in a copy command the host issues after it has woken up).
+// where the compaction puts the ordered inlier list on the device (DeviceCtx::idx_out_override)
+static uint64_t* idx_dev(DeviceCtx* ctx) { return ctx->idx_out_override ? ctx->idx_out_override : ctx->idx.as<uint64_t>(); }
 // the pinned words RefineModel's kernels write, per slot (DeviceCtx::defer_refine; slot 0 otherwise)
 static int refine_slot(const DeviceCtx* ctx) { return ctx->defer_refine ? ctx->refine_slot : 0; }
 static double* h_best_at(DeviceCtx* ctx) { return ctx->h_best.as<double>() + (size_t)refine_slot(ctx) * kModelStride; }
@@ -851,7 +853,8 @@ static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, c
         RESERVE(ctx->moment_partial, sizeof(double) * 16 * (size_t)std::max<uint32_t>(nb, 1));
         RESERVE(ctx->h_moments, sizeof(double) * 2 * kFusedMomentDoubles);
     }
-    launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev, ctx->idx.as<uint64_t>(), nullptr,
+    launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev,
+                   idx_dev(ctx), nullptr,
                    nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
                    ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
                    fused ? ctx->moment_partial.as<double>() : nullptr, fused ? h_moments_at(ctx) : nullptr,
@@ -878,7 +881,8 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
     uint8_t* h = ctx->h_small.as<uint8_t>();
     const uint8_t* h_total = compaction_total ? static_cast<const uint8_t*>(compaction_total) : h;
     if (!compaction_total) {
-        uint64_t* idx_host = inliers && fused && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1))
+        uint64_t* idx_host = inliers && fused && !ctx->idx_out_override &&
+                                     is_library_pinned(inliers, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1))
                                  ? reinterpret_cast<uint64_t*>(inliers) : nullptr;
         const PartitionOut* part = ctx->partition_hook && orig_dev ? (*ctx->partition_hook)(expected_ni) : nullptr;
         const int rc = issue_refine_compaction(ctx, flag_view, orig_dev, kind, thr, model_dev, lazy_in, h, fused, idx_host, part);
@@ -896,11 +900,11 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         const bool early_copy = !idx_on_host && inliers && ni_e && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)ni_e);
         if (early_copy) {
             HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
-            HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost,
-                                  ctx->copy_stream));
+            HIPCHK(hipMemcpyAsync(inliers, (void*)idx_dev(ctx),
+                                  sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost, ctx->copy_stream));
         }
         if (need_fit_e && !have_moments) {
-            launch_general_fit_sums(gather_view, ctx->idx.as<uint64_t>(), ni_e, ctx->sum_partial.as<double>(),
+            launch_general_fit_sums(gather_view, idx_dev(ctx), ni_e, ctx->sum_partial.as<double>(),
                                     ctx->h_sums.as<double>(), ctx->stream);
         }
         // work the caller wants queued behind these kernels before the host waits (segmentation: the removal of
@@ -915,8 +919,8 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         // last: a copy into the caller's (pageable) buffer keeps the host busy until it is done
         if (inliers && ni_e && !early_copy && !idx_on_host) {
             HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
-            HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost,
-                                  ctx->copy_stream));
+            HIPCHK(hipMemcpyAsync(inliers, (void*)idx_dev(ctx),
+                                  sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost, ctx->copy_stream));
         }
         HIPCHK(hipGetLastError());
         // everything RefineModel reads is complete at ev_compact when the moments rode on the compaction (or no fit is
@@ -926,7 +930,7 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
             HIPCHK(hipEventSynchronize(ctx->ev_compact));
         else
             HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+        if (!(ctx->defer_copy_sync && ctx->idx_out_override)) HIPCHK(hipStreamSynchronize(ctx->copy_stream));
         if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
         uint32_t ni_chk;
         std::memcpy(&ni_chk, h_total, 4);
@@ -980,12 +984,12 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         if (ni < min_pts) {
             *general_fit_ok = 0;  // MinimalCheck, ransac.h:166-169, 298-301
         } else {
-            launch_general_fit_sums(gather_view, ctx->idx.as<uint64_t>(), ni, ctx->sum_partial.as<double>(),
+            launch_general_fit_sums(gather_view, idx_dev(ctx), ni, ctx->sum_partial.as<double>(),
                                     ctx->h_sums.as<double>(), ctx->stream);
         }
     }
     if (inliers && ni && !idx_on_host)
-        HIPCHK(hipMemcpyAsync(inliers, ctx->idx.p, sizeof(uint64_t) * (size_t)ni,
+        HIPCHK(hipMemcpyAsync(inliers, (void*)idx_dev(ctx), sizeof(uint64_t) * (size_t)ni,
                               hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1400,7 +1404,8 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     const CloudView gather = c->base_view();   // index lists / GeneralFit refer to the cloud as created
     const uint32_t* orig = c->orig();
     RansacOut ro;
-    uint64_t* idx_host = inliers && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)std::max<uint32_t>(v.n, 1))
+    uint64_t* idx_host = inliers && !ctx->idx_out_override &&
+                                 is_library_pinned(inliers, sizeof(uint64_t) * (size_t)std::max<uint32_t>(v.n, 1))
                              ? reinterpret_cast<uint64_t*>(inliers) : nullptr;
     ctx->compaction_idx_host = nullptr;
     ctx->compaction_fused = false;
@@ -2477,6 +2482,11 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
             }
             if (ctx->seg_staging) idx_out = static_cast<size_t*>(ctx->seg_staging);
         }
+        // rounds on a large part of the cloud: lists of megabytes leave through the copy engine (DeviceCtx::idx_out_override)
+        DevBuf seg_idx_dev;
+        const bool lists_by_copy_engine = rc == M3D_OK && !comm && is_library_pinned(idx_out, sizeof(size_t) * n) &&
+                                          n >= ((size_t)1 << 20) && seg_idx_dev.reserve(sizeof(uint64_t) * n);
+        ctx->defer_copy_sync = lists_by_copy_engine;
         size_t count = 0, k = 0;
         size_t iterations_hint = 0;   // iterations the previous round took: sizes this round's second chunk up front
         const size_t target = (size_t)((1 - min_ratio) * (double)n);  // :28
@@ -2529,10 +2539,12 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
                                           expected_ni);
             };
             ctx->partition_hook = &partition_hook;
+            ctx->idx_out_override = lists_by_copy_engine && big_round ? seg_idx_dev.as<uint64_t>() + off : nullptr;
             ctx->no_prune_hint = !comm && k > 0 && (uint64_t)c0->work.last_removed * 32 < c0->n;   // (the previous round's plane: < 3 % of the cloud)
             rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
                                   idx_out + off, &ni, nullptr, &issue_removal, &iterations_hint, comm);
             ctx->partition_hook = nullptr;
+            ctx->idx_out_override = nullptr;
             ctx->no_prune_hint = false;
             if (rc < 0) break;
             rc = cloud_remove_check_pending(c0);   // (the previous round's removal: this round's wait lay behind it)
@@ -2573,6 +2585,9 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
         if (poison_ready && c0->work.poison_expected)
             (void)hipMemcpyAsync(&killed, ctx->poison_total.p, sizeof(killed), hipMemcpyDeviceToHost, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
+        if (lists_by_copy_engine) (void)hipStreamSynchronize(ctx->copy_stream);   // (the big rounds' lists)
+        ctx->defer_copy_sync = false;
+        seg_idx_dev.release();
         ctx->defer_refine = false;
         ctx->poison_pending = false;   // (the last round's kill has nobody left to serve)
         if (rc == M3D_OK || rc == 2) {   // the last round's RefineModel

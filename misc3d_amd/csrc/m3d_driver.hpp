@@ -95,6 +95,12 @@ struct DeviceCtx {
     // the replay then named does not wait for it -- the inlier count is the scoring pass's, the index list goes to the
     // caller's pinned array by itself -- and its GeneralFit is finished from the pinned sums while the NEXT round's records
     // are awaited (two slots of h_best / h_moments / the total word: the next round's compaction is queued before that)
+    // segment_impl, rounds on a large part of the cloud: the inlier list (megabytes) is written to device memory
+    // (idx_out_override, the cluster's slice of a per-call buffer) and shipped by the copy engine under the rounds that
+    // follow, instead of being stored over the host link by the compaction kernel itself (which then runs at the link's
+    // rate: 370 us for 2.5 M indices); the copy stream is waited for once, at the end of the call
+    uint64_t* idx_out_override = nullptr;
+    bool defer_copy_sync = false;
     bool no_prune_hint = false;     // segment_impl: the next fit's chunk will prune nothing (no lead pass, no keep masks)
     bool defer_refine = false;
     int refine_slot = 0;
