@@ -930,7 +930,10 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
             HIPCHK(hipEventSynchronize(ctx->ev_compact));
         else
             HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (!(ctx->defer_copy_sync && ctx->idx_out_override)) HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+        // (the copy stream is waited for when THIS call put the list on it -- and not even then when the caller collects
+        // its lists at the end: DeviceCtx::defer_copy_sync)
+        const bool list_on_copy_stream = inliers && ni_e && !idx_on_host;
+        if (list_on_copy_stream && !(ctx->defer_copy_sync && ctx->idx_out_override)) HIPCHK(hipStreamSynchronize(ctx->copy_stream));
         if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
         uint32_t ni_chk;
         std::memcpy(&ni_chk, h_total, 4);
