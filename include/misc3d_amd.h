@@ -394,8 +394,9 @@ typedef struct m3d_config {
     int32_t cull_fp32;              /* [M3D_CULL_FP32=0]    default 1: the box tests of the culled path run in fp32 with outward-rounded margins
                                        (cull_tiles32_k: conservative, identical results); 0: fp64 box tests (cull_tiles_k) */
     int32_t reg_fp32_screen;        /* [M3D_REG_SCREEN=0]   default 1: the nearest-neighbour search of the registration validation finds its
-                                       candidate in fp32 (16-byte list entries relative to the cell, rounding bound) and evaluates the winner
-                                       in fp64; a query whose runner-up is within the bound takes the fp64 walk: identical distances */
+                                       candidate in fp32 on 8-byte list entries (16-bit fixed-point coordinates over the cell's 3-cell
+                                       block + the entry's position, rounding bound) and evaluates the winner in fp64; a query whose
+                                       runner-up is within the bound takes the fp64 walk: identical distances */
     int32_t sorted_tombstones;      /* [M3D_TOMBSTONES=0]   default 1: a segmentation round that removes a sliver of the cloud kills its inliers
                                        in place in the Hilbert-sorted copy (x = NaN: never an inlier; the screen masks the lane) instead
                                        of partitioning the copy; a real compaction follows when an eighth of the copy is dead */

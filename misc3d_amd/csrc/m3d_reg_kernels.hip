@@ -330,7 +330,7 @@ __global__ void nl_fill_sorted_k(GridDesc g, const uint32_t* __restrict__ cell_s
                                  const uint32_t* __restrict__ nl_start, const double* __restrict__ qx,
                                  const double* __restrict__ qy, const double* __restrict__ qz,
                                  double4* __restrict__ nl_pts, uint32_t* __restrict__ nl_hdr,
-                                 float4* __restrict__ nl32, uint4* __restrict__ nl_rec, uint32_t* __restrict__ overflow,
+                                 uint2* __restrict__ nl32, uint4* __restrict__ nl_rec, uint32_t* __restrict__ overflow,
                                  const uint32_t* __restrict__ nl32_start) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= ncell) return;
@@ -376,22 +376,29 @@ __global__ void nl_fill_sorted_k(GridDesc g, const uint32_t* __restrict__ cell_s
     if (nl_hdr) nl_hdr[c] = n_col[0] + 65536u * n_col[1];
     if (!nl32) return;
     // the screen's copy (sorted_walk32): the three columns merged in ascending fp32 x (left column reversed, own, right --
-    // a merge because the columns may overlap by a rounding at the cell faces), w = index of the fp64 entry; sentinels
-    // at both ends
+    // a merge because the columns may overlap by a rounding at the cell faces), every entry 8 BYTES: x, y, z as 16-bit
+    // fixed point over the block [-h, 2h) of the list's own cell -- q = rint(v S + 21845), S = 21845 / h, monotone in v:
+    // the order is kept -- and the 16-bit position of the fp64 entry in the list; pads at both ends that lie farther from
+    // every query of the cell than the search radius (corner of the block), position 0
     const uint32_t n_mid = n_col[0], n_lr = n_col[0] + n_col[1], n_tot = n_lr + n_col[2];
     if (n_tot > 65535u) {
-        atomicOr(overflow, 1u);   // (the 16-bit offsets of nl_rec: the caller drops the screen)
+        atomicOr(overflow, 1u);   // (the 16-bit offsets of nl_rec and of the entries: the caller drops the screen)
         return;
     }
     const uint32_t q0 = nl32_start[c] + (uint32_t)kWalkPad;   // first real entry
     for (int k = 0; k < kWalkPad; ++k) {
-        nl32[q0 - 1u - (uint32_t)k] = make_float4(-3e38f, 0.0f, 0.0f, 0.0f);
-        nl32[q0 + n_tot + (uint32_t)k] = make_float4(3e38f, 0.0f, 0.0f, 0.0f);
+        nl32[q0 - 1u - (uint32_t)k] = make_uint2(0u, 0u);
+        nl32[q0 + n_tot + (uint32_t)k] = make_uint2(0xFFFFFFFFu, 0x0000FFFFu);
     }
     uint32_t il = n_lr, im = 0u, ir = n_lr;   // left: entries il - 1 down to n_mid
     auto off32 = [&](uint32_t rel) {
         const double4 q = nl_pts[pos0 + rel];
-        return make_float4((float)(q.x - Ox), (float)(q.y - Oy), (float)(q.z - Oz), __uint_as_float(pos0 + rel));
+        return make_float4((float)(q.x - Ox), (float)(q.y - Oy), (float)(q.z - Oz), __uint_as_float(rel));
+    };
+    const float S32 = (float)(21845.0 * g.inv_h);
+    auto quant = [&](float v) {
+        const float f = __builtin_rintf(__builtin_fmaf(v, S32, 21845.0f));
+        return (uint32_t)__builtin_fminf(65535.0f, __builtin_fmaxf(0.0f, f));
     };
     float thr[5];
     for (int k = 0; k < 5; ++k) thr[k] = (float)((double)k * hc * 0.25);
@@ -420,7 +427,7 @@ __global__ void nl_fill_sorted_k(GridDesc g, const uint32_t* __restrict__ cell_s
             v = fr;
             if (++ir < n_tot) fr = off32(ir);
         }
-        nl32[q0 + o] = v;
+        nl32[q0 + o] = make_uint2(quant(v.x) | (quant(v.y) << 16), quant(v.z) | (__float_as_uint(v.w) << 16));
         for (int k = 0; k < 5; ++k) offs[k] += v.x < thr[k] ? 1u : 0u;
     }
     nl_rec[c] = make_uint4(q0, offs[0] | (offs[1] << 16), offs[2] | (offs[3] << 16), offs[4] | (n_tot << 16));
@@ -455,7 +462,7 @@ void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl
 }
 void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, double* qx,
                     double* qy, double* qz, double4* nl_pts, hipStream_t s, const uint32_t* orig, bool sorted,
-                    uint32_t* nl_hdr, float4* nl32, uint4* nl_rec, uint32_t* overflow, const uint32_t* nl32_start) {
+                    uint32_t* nl_hdr, uint2* nl32, uint4* nl_rec, uint32_t* overflow, const uint32_t* nl32_start) {
     const uint32_t ncell = g.nx * g.ny * g.nz;
     if (sorted && !orig) {
         sort_cells_by_x_k<<<(ncell + 255) / 256, 256, 0, s>>>(cell_start, ncell, qx, qy, qz);
@@ -583,102 +590,112 @@ __device__ __forceinline__ double sorted_walk64(const GridDesc& g, uint32_t cell
     }
     return best;
 }
-// The fp32 SCREEN of the neighbour search (GridDesc::nl32 / nl_rec).  Counters first: with fp64 entries the kernel was
+// The SCREEN of the neighbour search (GridDesc::nl32 / nl_rec).  Counters first: with fp64 entries the kernel was
 // bound by the L1's tag look-ups (TCP busy 70 % + 14 % tag-conflict stalls; a gather of one list entry costs a look-up
 // per distinct cell among the lanes -- ~27 per instruction -- whatever its size), and behind that by the number of
-// DEPENDENT round trips of a walk.  So: visit fewer entries, fetch each with ONE load, several per round trip.
-//   * nl32 holds every list a second time as 16-byte entries (x, y, z as fp32 offsets from the min corner O of the
-//     list's own cell, w = the index of the fp64 entry in nl_pts), all 27 cells MERGED in ascending x, with
-//     kWalkPad sentinel entries (x = -+3e38: squared distance +inf) in front of and behind every list.
+// DEPENDENT round trips of a walk.  So: visit fewer entries, fetch SEVERAL with one load, several per round trip.
+//   * nl32 holds every list a second time as 8-BYTE entries: x, y, z as 16-bit fixed point over the 3-cell block
+//     [-h, 2h) of the list's own cell -- q = rint(v S + 21845), S = 21845 / h, one unit = 3 h / 65535 -- and the 16-bit
+//     position of the fp64 entry in the list (lists of more than 65535 entries drop the screen); all 27 cells MERGED in
+//     ascending x (quantisation is monotone: the order by fp32 x is kept), kWalkPad pad entries at either end (the
+//     block's corners: farther from every query of the cell than the search radius).  Round 2 had 16-byte entries (fp32
+//     offsets + a 32-bit index): two entries per 16-byte load halve the gather instructions -- TCP_TOTAL_CACHE_ACCESSES
+//     15.9 G -> 10.3 G on 20 000 iterations of C4, the forced 100 000-iteration call 159 -> 142 ms.
 //   * nl_rec[cell] = (start, five 16-bit offsets, entries): offset k = the first entry with x >= k h / 4.  A query
-//     starts at the offset nearest to it and walks right (ascending x) and left (descending x) AT THE SAME TIME,
-//     kWalkB entries per side and trip, the next batch of each side in flight; a side goes on only while the x-distance
-//     ALONE of the batch's last entry can still beat the best candidate: ~13 entries instead of ~19, ~8 round trips
-//     instead of ~15.
-//   * Rounding: entries lie in [-h, 2h), the query in [0, h); with u = 2^-24 a coordinate difference carries an error
-//     below 6 u h (two conversions of values below 2h and h, one subtraction of a value below 3h; the fp64 roundings of O
-//     and of the subtractions stay below 0.01 u h by the host's admission test).  s = fma(dz, dz, fma(dy, dy, dx dx))
-//     then differs from the distance d2 the fp64 walk computes by at most 12 u h (|dx| + |dy| + |dz|) + 108 u^2 h^2 +
-//     3.1 u s <= 10.4 u (d2 + h^2) + 3.1 u s + ..., i.e. |s - d2| <= E(s) := 2^-18 s + 2^-18 h^2 + 1e-36 with a margin of
-//     four (the last term: a flushed subnormal).
+//     starts at the offset nearest to it and walks right (ascending x) and left (descending x) AT THE SAME TIME, two
+//     entries (ONE load) per side and trip, the next batch of each side in flight; a side goes on only while the
+//     x-distance ALONE of the batch's last entry can still beat the best candidate, and while it has entries left.
+//   * Rounding, in units: an entry's q is within 0.55 of (v + h) S (rint: 0.5; the fp32 offset v and the product: < 0.05),
+//     the query's (u + h) S within 0.01, their difference rounds by < 0.005: every coordinate difference is within
+//     eps = 0.57 of the truth.  s = fma(dz, dz, fma(dy, dy, dx dx)) then differs from the true squared distance (in
+//     units^2: the fp64 walk's d2 times S^2) by at most 2 eps (|dx| + |dy| + |dz|) + 3 eps^2 + 3.1 u s
+//     <= 1.98 sqrt(s) + 1 + 2^-18 s:  E(s) := 2.1 sqrt(s) + 2 + 2^-18 s (walk_err_bound; tests/cpp/test_nn_screen.cpp replays
+//     the walk on the host: worst |s - d2| / E(s) = 0.79 over millions of entries, and a decided query's winner is the
+//     fp64 minimum to the last bit).
 //   * The walk keeps the smallest s (m1, at entry i1) and the second smallest (m2).  If m2 > m1 + E(m1) + E(m2), entry
-//     i1 is strictly nearer in fp64 than every other visited entry (s - E(s) is increasing), and the result is ITS fp64
-//     distance, evaluated with the fp64 walk's expression on the fp64 entry.  Otherwise (exact ties, duplicates, near
-//     ties: a few queries in 10^5) the query takes the fp64 walk.
-//   * A side stops after a batch whose last entry lies on that side of the query with dx^2 >= m1 + 2 E(m1), m1 taken
-//     BEFORE the batch (larger: later): the list is sorted by the very fp32 x the test uses and fl(x - ux) is monotone in
-//     x, so the true x-distance squared of everything behind that entry is at least m1 + E(m1) >= the fp64 distance of
-//     entry i1.  Where the walks start affects their length only: right covers [start, n), left [0, start), every entry
-//     is visited at most once, a sentinel changes nothing (s = inf) and stops its side.
+//     i1 is strictly nearer in fp64 than every other visited entry, and the result is ITS fp64 distance, evaluated with
+//     the fp64 walk's expression on the fp64 entry.  Otherwise (exact ties, duplicates, near ties: 4.5 queries in 10^4 on
+//     C4) the query takes the fp64 walk.
+//   * A side stops after a batch whose last entry lies on that side of the query with (|dx| - 0.6)^2 >= m1 + E(m1), m1
+//     taken BEFORE the batch (larger: later): the list is sorted by the very q the test uses, so the true x-distance of
+//     everything behind that entry is at least |dx| - eps, i.e. at least the true distance of entry i1.  For this CUT
+//     E(m1) is replaced by the square-root-free m1 (2^-9 + 2^-18) + 567 >= E(m1) (AM-GM): a cut 0.1 % later.  Where the
+//     walks start affects their length only: right covers [start, n), left [0, start), every entry is visited at most
+//     once; a pad that shares the last batch lies beyond the search radius and can only win when nothing real is within
+//     it (its position is 0: the result is then a real entry's distance, larger than the radius like the true minimum).
+__device__ __forceinline__ float walk_err_bound(float s) {   // E(s), units^2 (tests/cpp/test_nn_screen.cpp checks it)
+    return __builtin_fmaf(s, 0x1p-18f, __builtin_fmaf(2.1f, __builtin_sqrtf(s), 2.0f));
+}
 __device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell, double frx, double fry, double frz,
                                                 double px, double py, double pz) {
     uint4 rec = g.nl_rec[cell];
+    const uint32_t pos0 = g.nl_start[cell];   // (the list's fp64 entries: independent of rec, the same round trip)
     // (all four words are needed at once: without this the compiler fetches w first, tests it, and fetches the rest in a
     // second, dependent round trip)
     asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));
-    if ((rec.w >> 16) == 0u) return INFINITY;   // empty list
+    const int n_tot = (int)(rec.w >> 16);
+    if (n_tot == 0) return INFINITY;   // empty list
     const double h = 1.0 / g.inv_h;
-    // offsets from the cell's min corner: fraction x edge.  (The list's entries were written as q - (o + i h); the two
-    // differ by the fp64 roundings of either expression, ~1e-13 h: the 0.01 u h of the admission test covers them.)
-    const float ux = (float)(frx * h), uy = (float)(fry * h), uz = (float)(frz * h);
-    const float h2 = (float)(h * h);
-    const float e0 = __builtin_fmaf(h2, 0x1p-18f, 1e-36f);
+    // the query in the entries' units: (offset from the cell's min corner + h) * S, S = 21845 / h
+    const float S32 = (float)(21845.0 * g.inv_h);
+    const float ux = __builtin_fmaf((float)(frx * h), S32, 21845.0f), uy = __builtin_fmaf((float)(fry * h), S32, 21845.0f),
+                uz = __builtin_fmaf((float)(frz * h), S32, 21845.0f);
     const int ke = min(4, max(0, (int)__builtin_fmaf((float)frx, 4.0f, 0.5f)));   // nearest quarter boundary
     const uint32_t offw = ke < 2 ? rec.y : (ke < 4 ? rec.z : rec.w);
-    const uint32_t start = (ke & 1) ? offw >> 16 : offw & 0xFFFFu;
-    const char* __restrict__ base = reinterpret_cast<const char*>(g.nl32 + rec.x + start);
-    auto ld = [&](int i) { return *reinterpret_cast<const float4*>(base + (ptrdiff_t)i * 16); };
+    const int start = (int)((ke & 1) ? offw >> 16 : offw & 0xFFFFu);
+    const char* __restrict__ base = reinterpret_cast<const char*>(g.nl32 + rec.x + (uint32_t)start);
+    typedef uint4 pair_t __attribute__((aligned(8)));   // two entries, ONE load (8-byte aligned: an odd start)
+    auto ld2 = [&](int i) { return *reinterpret_cast<const pair_t*>(base + (ptrdiff_t)i * 8); };   // entries i, i + 1
     float m1 = __builtin_inff(), m2 = __builtin_inff();
     uint32_t i1 = 0u;
-    auto visit = [&](const float4 q) {
-        const float dx = q.x - ux, dy = q.y - uy, dz = q.z - uz;
-        const float s = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        i1 = s < m1 ? __float_as_uint(q.w) : i1;
-        m2 = __builtin_amdgcn_fmed3f(m1, m2, s);   // (m1 <= m2: the median is the new runner-up)
-        m1 = __builtin_fminf(m1, s);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t U_x = {ux, ux}, U_y = {uy, uy}, U_z = {uz, uz};
+    // two entries (A first) with packed fp32 arithmetic -- the same IEEE operations per entry as one at a time; returns
+    // the dx of entry B
+    auto visit2 = [&](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) -> float {
+        const f32x2_t X = {(float)(a0 & 0xFFFFu), (float)(b0 & 0xFFFFu)}, Y = {(float)(a0 >> 16), (float)(b0 >> 16)},
+                      Z = {(float)(a1 & 0xFFFFu), (float)(b1 & 0xFFFFu)};
+        const f32x2_t dx = X - U_x, dy = Y - U_y, dz = Z - U_z;
+        const f32x2_t s = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        i1 = s.x < m1 ? (a1 >> 16) : i1;
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, s.x);   // (m1 <= m2: the median is the new runner-up)
+        m1 = __builtin_fminf(m1, s.x);
+        i1 = s.y < m1 ? (b1 >> 16) : i1;
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, s.y);
+        m1 = __builtin_fminf(m1, s.y);
+        return dx.y;
     };
-    float4 rb[kWalkB], lb[kWalkB];
-#pragma unroll
-    for (int k = 0; k < kWalkB; ++k) {
-        rb[k] = ld(k);
-        lb[k] = ld(-1 - k);
-    }
+    static_assert(kWalkB == 2, "one 16-byte load per side and trip holds the batch");
+    uint4 rb = ld2(0), lb = ld2(-2);
     int cr = 0, cl = 0;   // entries visited on either side
-    bool ar = true, al = true;
+    bool ar = start < n_tot, al = start > 0;
     while (ar || al) {
-        const float thr = __builtin_fmaf(m1, 1.0f + 0x1p-17f, 2.0f * e0);
+        // everything behind a batch's last entry is at least (|dx| - 0.6)^2 away in truth, the winner so far at most
+        // m1 + E(m1) (m1 taken before the batch: larger, later).  For the CUT a bound without the square root serves:
+        // 2.1 sqrt(s) <= s / 512 + 565 (AM-GM), so E(s) <= s (2^-9 + 2^-18) + 567 -- a cut that comes 0.1 % later
+        const float thr = __builtin_fmaf(m1, 1.0f + 0x1p-9f + 0x1p-18f, 567.0f);
         if (ar) {
-            float4 nx[kWalkB];
-#pragma unroll
-            for (int k = 0; k < kWalkB; ++k) nx[k] = ld(cr + kWalkB + k);
-#pragma unroll
-            for (int k = 0; k < kWalkB; ++k) visit(rb[k]);
-            const float dx = rb[kWalkB - 1].x - ux;
-            ar = !(dx > 0.0f && !(dx * dx < thr));
-            cr += kWalkB;
-#pragma unroll
-            for (int k = 0; k < kWalkB; ++k) rb[k] = nx[k];
+            const uint4 nx = ld2(cr + 2);
+            const float t = visit2(rb.x, rb.y, rb.z, rb.w) - 0.6f;
+            cr += 2;
+            ar = !(t > 0.0f && !(t * t < thr)) && start + cr < n_tot;
+            rb = nx;
         }
         if (al) {
-            float4 nx[kWalkB];
-#pragma unroll
-            for (int k = 0; k < kWalkB; ++k) nx[k] = ld(-1 - (cl + kWalkB + k));
-#pragma unroll
-            for (int k = 0; k < kWalkB; ++k) visit(lb[k]);
-            const float dx = lb[kWalkB - 1].x - ux;
-            al = !(dx < 0.0f && !(dx * dx < thr));
-            cl += kWalkB;
-#pragma unroll
-            for (int k = 0; k < kWalkB; ++k) lb[k] = nx[k];
+            const uint4 nx = ld2(-4 - cl);
+            const float t = -visit2(lb.z, lb.w, lb.x, lb.y) - 0.6f;   // entry -1 - cl, then -2 - cl
+            cl += 2;
+            al = !(t > 0.0f && !(t * t < thr)) && cl < start;
+            lb = nx;
         }
     }
-    const float bound = __builtin_fmaf(m1 + m2, 0x1p-18f, 2.0f * e0);   // E(m1) + E(m2)
+    const float bound = walk_err_bound(m1) + walk_err_bound(m2);   // E(m1) + E(m2)
     const bool decided = m2 == __builtin_inff() ? m1 < __builtin_inff() /* one candidate */ : m2 > m1 + bound * 1.0001f;
     if (!decided) {
         if (g.nl32_fallbacks) atomicAdd(g.nl32_fallbacks, 1ull);
         return sorted_walk64(g, cell, px, py, pz);
     }
-    const double4* __restrict__ w = g.nl_pts + i1;
+    const double4* __restrict__ w = g.nl_pts + pos0 + i1;
     const double ddx = px - w->x, ddy = py - w->y, ddz = pz - w->z;
     return (ddx * ddx + ddy * ddy) + ddz * ddz;
 }

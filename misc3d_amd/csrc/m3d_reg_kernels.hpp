@@ -34,13 +34,14 @@ struct GridDesc {
     int nl_sorted = 0;
     const uint32_t* nl_hdr = nullptr;   // nl_sorted: n_mid + 65536 * n_left per cell once more, next to nl_start (the query knows
                                          // all three column bounds after ONE round trip and can fetch from all of them at once)
-    // nl_sorted, optional: the fp32 screen of the search (sorted_walk32 in m3d_reg_kernels.hip).  nl32: every list once
-    // more as 16-byte entries -- fp32 offsets from the min corner of the list's OWN cell, w = index of the fp64 entry in
-    // nl_pts -- with the 27 cells merged in ascending x and sentinels at both ends (its own layout: launch_nl32_offsets);
-    // nl_rec[cell] = (first real entry, 5 x 16-bit offsets of the first entry at or right of each quarter boundary of the
-    // cell, entries in the top half of w).  The walk finds the nearest candidate and the runner-up in fp32 and evaluates
-    // the winner in fp64; a runner-up within the rounding bound sends the query down the fp64 walk.
-    const float4* nl32 = nullptr;
+    // nl_sorted, optional: the screen of the search (sorted_walk32 in m3d_reg_kernels.hip).  nl32: every list once more as
+    // 8-byte entries -- x, y, z as 16-bit fixed point over the 3-cell block [-h, 2h) of the list's OWN cell, and the 16-bit
+    // position of the fp64 entry in the list -- with the 27 cells merged in ascending x and pads at both ends (its own
+    // layout: launch_nl32_offsets); nl_rec[cell] = (first real entry, 5 x 16-bit offsets of the first entry at or right of
+    // each quarter boundary of the cell, entries in the top half of w).  The walk finds the nearest candidate and the
+    // runner-up in fp32 on the quantised coordinates and evaluates the winner in fp64; a runner-up within the rounding
+    // bound sends the query down the fp64 walk.
+    const uint2* nl32 = nullptr;
     const uint4* nl_rec = nullptr;
     unsigned long long* nl32_fallbacks = nullptr;   // optional counter: queries the screen handed to the fp64 walk
 };
@@ -71,7 +72,7 @@ void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl
 void launch_nl_fill(const GridDesc& g, const uint32_t* cell_start, const uint32_t* nl_start, double* qx,
                     double* qy, double* qz, double4* nl_pts, hipStream_t s,
                     const uint32_t* orig = nullptr, bool sorted = false, uint32_t* nl_hdr = nullptr /* sorted: ncell words */,
-                    float4* nl32 = nullptr /* sorted, optional: as many entries as nl_pts */, uint4* nl_rec = nullptr /* ncell */,
+                    uint2* nl32 = nullptr /* sorted, optional: as many entries as nl_pts */, uint4* nl_rec = nullptr /* ncell */,
                     uint32_t* overflow = nullptr /* one word, zero on entry: set when a list is too long for nl_rec */,
                     const uint32_t* nl32_start = nullptr /* launch_nl32_offsets */);
 // layout of GridDesc::nl32: nl32_start[0..ncell] (scratch of ncell + 1 words), total[0] = entries incl. sentinels

@@ -207,13 +207,13 @@ int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, 
             uint32_t entries32 = 0;
             HIPCHK(hipMemcpyAsync(&entries32, overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            RESERVE(S.nl32, sizeof(float4) * std::max<size_t>(entries32, 1));
+            RESERVE(S.nl32, sizeof(uint2) * std::max<size_t>(entries32, 1));
             RESERVE(S.nl_rec, sizeof(uint4) * (size_t)ncell);
             HIPCHK(hipMemsetAsync(overflow, 0, sizeof(uint32_t), ctx->stream));
         }
         launch_nl_fill(g, S.cell_start.as<uint32_t>(), S.nl_start.as<uint32_t>(), S.qx.as<double>(),
                        S.qy.as<double>(), S.qz.as<double>(), S.nl_pts.as<double4>(), ctx->stream, orig, sorted,
-                       sorted ? S.nl_hdr.as<uint32_t>() : nullptr, screen ? S.nl32.as<float4>() : nullptr,
+                       sorted ? S.nl_hdr.as<uint32_t>() : nullptr, screen ? S.nl32.as<uint2>() : nullptr,
                        screen ? S.nl_rec.as<uint4>() : nullptr, overflow, screen ? S.nl32_start.as<uint32_t>() : nullptr);
         if (screen) {   // a list beyond the 16-bit offsets of nl_rec: no screen for this grid
             uint32_t over = 0;
@@ -222,7 +222,7 @@ int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, 
             screen = over == 0;
         }
         g.nl_hdr = sorted ? S.nl_hdr.as<uint32_t>() : nullptr;
-        g.nl32 = screen ? S.nl32.as<float4>() : nullptr;
+        g.nl32 = screen ? S.nl32.as<uint2>() : nullptr;
         g.nl_rec = screen ? S.nl_rec.as<uint4>() : nullptr;
         if (screen) {
             RESERVE(S.nl32_fallbacks, sizeof(unsigned long long));

@@ -1,8 +1,10 @@
-// Host-side check of the fp32 SCREEN of the registration validation's neighbour search (sorted_walk32 in
-// misc3d_amd/csrc/m3d_reg_kernels.hip): the device arithmetic is restated with float operations and fmaf (IEEE single
-// precision, the same operations in the same order), the walk itself is replayed -- the merged x-sorted list with its
-// sentinels, the start at the nearest quarter boundary, two entries per side and trip, the cut on the x-distance of a
-// batch's last entry with m1 taken before the batch, smallest and second smallest distance -- on random grids: cell edges
+// Host-side check of the SCREEN of the registration validation's neighbour search (sorted_walk32 in
+// misc3d_amd/csrc/m3d_reg_kernels.hip): 8-byte list entries -- x, y, z as 16-bit fixed point over the list's 3-cell block
+// [-h, 2h), and the 16-bit position of the fp64 entry -- evaluated in fp32 in units of 3h / 65535.  The device arithmetic
+// is restated with float operations and fmaf (IEEE single precision, the same operations in the same order), the walk
+// itself is replayed -- the merged x-sorted list with its pads, the start at the nearest quarter boundary, two entries per
+// side and trip (ONE 16-byte load), the cut on the x-distance of a batch's last entry with m1 taken before the batch, the
+// count guards, smallest and second smallest distance -- on random grids: cell edges
 // over nine orders of magnitude, origins as far out as the host's admission test lets them be, lists of 1 .. 200 points with
 // exact duplicates, points at equal distance from the query and points 1e-7 .. 1e-16 (relative) apart in distance.
 // Property: whenever the walk calls a query DECIDED, the fp64 distance of its winner is the minimum of the fp64 distances
@@ -23,10 +25,15 @@ double uni(double a, double b) { return std::uniform_real_distribution<double>(a
 double logu(double a, double b) { return std::exp(uni(std::log(a), std::log(b))); }
 
 constexpr int kWalkB = 2, kWalkPad = 2 * kWalkB;
-struct E32 {
+struct E32 {      // (the fill kernel's intermediate: fp32 offsets from the cell's corner + the fp64 entry's position)
     float x, y, z;
     uint32_t w;
 };
+struct E16 {      // the 8-byte entry
+    uint16_t x, y, z, w;
+};
+constexpr float kUnitsPerCell = 21845.0f;   // 65535 / 3: the block [-h, 2h) maps to [0, 65535]
+float quant_err_bound(float s) { return fmaf(s, 0x1p-18f, fmaf(2.1f, std::sqrt(s), 2.0f)); }   // E(s), units^2 (walk_err_bound)
 struct P3 {
     double x, y, z;
 };
@@ -89,39 +96,46 @@ int main(int argc, char** argv) {
             list.push_back({(float)(pts[k].x - Ox), (float)(pts[k].y - Oy), (float)(pts[k].z - Oz), (uint32_t)k});
         std::stable_sort(list.begin(), list.end(), [](const E32& a, const E32& b) { return a.x < b.x; });
         const int nt = (int)list.size();
+        if (nt > 65535) continue;
         uint32_t offs[5];
         for (int k = 0; k < 5; ++k) {
             const float thr = (float)((double)k * hc * 0.25);
             offs[k] = 0;
             for (const E32& e : list) offs[k] += e.x < thr ? 1u : 0u;
         }
-        std::vector<E32> mem(nt + 2 * kWalkPad);
+        // quantisation: q = rint(v * S + 21845), S = 21845 / h (monotone in v: the order by fp32 x is kept)
+        const float S32 = (float)(21845.0 / hc);
+        auto quant = [&](float v) {
+            const float f = std::rint(fmaf(v, S32, kUnitsPerCell));
+            return (uint16_t)std::min(65535.0f, std::max(0.0f, f));
+        };
+        std::vector<E16> mem(nt + 2 * kWalkPad);
         for (int k = 0; k < kWalkPad; ++k) {
-            mem[k] = {-3e38f, 0.0f, 0.0f, 0u};
-            mem[kWalkPad + nt + k] = {3e38f, 0.0f, 0.0f, 0u};
+            mem[k] = {0, 0, 0, 0};                                    // farther than the search radius from any query of the cell
+            mem[kWalkPad + nt + k] = {65535, 65535, 65535, 0};
         }
-        for (int k = 0; k < nt; ++k) mem[kWalkPad + k] = list[k];
+        for (int k = 0; k < nt; ++k) mem[kWalkPad + k] = {quant(list[k].x), quant(list[k].y), quant(list[k].z), (uint16_t)list[k].w};
         // ---- the query side: cell_of_frac + sorted_walk32
         const double fx = (p.x - o[0]) * inv_h, fy = (p.y - o[1]) * inv_h, fz = (p.z - o[2]) * inv_h;
         if ((int)fx != ix || (int)fy != iy || (int)fz != iz) continue;   // (a rounding put it into the next cell: another list)
         const double frx = fx - (double)(int)fx, fry = fy - (double)(int)fy, frz = fz - (double)(int)fz;
-        const float ux = (float)(frx * hc), uy = (float)(fry * hc), uz = (float)(frz * hc);
-        const float h2 = (float)(hc * hc);
-        const float e0 = fmaf(h2, 0x1p-18f, 1e-36f);
+        const float ux = fmaf((float)(frx * hc), S32, kUnitsPerCell), uy = fmaf((float)(fry * hc), S32, kUnitsPerCell),
+                    uz = fmaf((float)(frz * hc), S32, kUnitsPerCell);
+        const double S2 = (21845.0 / hc) * (21845.0 / hc);   // units^2 per length^2
         const int ke = std::min(4, std::max(0, (int)fmaf((float)frx, 4.0f, 0.5f)));
         const int start = (int)offs[ke];
-        const E32* base = mem.data() + kWalkPad + start;
+        const E16* base = mem.data() + kWalkPad + start;
         float m1 = INFINITY, m2 = INFINITY;
         uint32_t i1 = 0;
         auto d2_exact = [&](uint32_t k) {
             const double ddx = p.x - pts[k].x, ddy = p.y - pts[k].y, ddz = p.z - pts[k].z;
             return (ddx * ddx + ddy * ddy) + ddz * ddz;
         };
-        auto visit = [&](const E32& q, bool real) {
-            const float dx = q.x - ux, dy = q.y - uy, dz = q.z - uz;
+        auto visit = [&](const E16& q, bool real) {
+            const float dx = (float)q.x - ux, dy = (float)q.y - uy, dz = (float)q.z - uz;
             const float s = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             if (real) {   // the bound, entry by entry
-                const double d2 = d2_exact(q.w), E = (double)fmaf(s, 0x1p-18f, e0);
+                const double d2 = d2_exact(q.w) * S2, E = (double)quant_err_bound(s);
                 const double ratio = std::fabs((double)s - d2) / E;
                 worst_ratio = std::max(worst_ratio, ratio);
                 if (!(ratio <= 1.0)) ++n_bound_viol;
@@ -134,27 +148,30 @@ int main(int argc, char** argv) {
             m1 = std::min(m1, s);
         };
         int cr = 0, cl = 0;
-        bool ar = true, al = true;
+        bool ar = start < nt, al = start > 0;
         while (ar || al) {
-            const float thr = fmaf(m1, 1.0f + 0x1p-17f, 2.0f * e0);
+            // everything behind a batch's last entry is at least (|dx| - 0.6)^2 away IN TRUTH; the winner so far is at most
+            // m1 + E(m1) away in truth
+            // (for the cut a bound without the square root: 2.1 sqrt(s) <= s / 512 + 565, E(s) <= s (2^-9 + 2^-18) + 567)
+            const float thr = fmaf(m1, 1.0f + 0x1p-9f + 0x1p-18f, 567.0f);
             if (ar) {
                 for (int k = 0; k < kWalkB; ++k) visit(base[cr + k], start + cr + k < nt);
-                const float dx = base[cr + kWalkB - 1].x - ux;
-                ar = !(dx > 0.0f && !(dx * dx < thr));
+                const float t = ((float)base[cr + kWalkB - 1].x - ux) - 0.6f;
                 cr += kWalkB;
+                ar = !(t > 0.0f && !(t * t < thr)) && start + cr < nt;
             }
             if (al) {
                 for (int k = 0; k < kWalkB; ++k) visit(base[-1 - (cl + k)], start - 1 - (cl + k) >= 0);
-                const float dx = base[-1 - (cl + kWalkB - 1)].x - ux;
-                al = !(dx < 0.0f && !(dx * dx < thr));
+                const float t = (ux - (float)base[-1 - (cl + kWalkB - 1)].x) - 0.6f;
                 cl += kWalkB;
+                al = !(t > 0.0f && !(t * t < thr)) && cl < start;
             }
             if (cr > nt + kWalkPad || cl > nt + kWalkPad) {
-                std::printf("walk ran past its sentinels\n");
+                std::printf("walk ran past its pads\n");
                 return 1;
             }
         }
-        const float bound = fmaf(m1 + m2, 0x1p-18f, 2.0f * e0);
+        const float bound = quant_err_bound(m1) + quant_err_bound(m2);
         const bool decided = m2 == INFINITY ? m1 < INFINITY : m2 > m1 + bound * 1.0001f;
         ++n_queries;
         n_entries += nt;
