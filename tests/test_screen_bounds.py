@@ -30,8 +30,8 @@ def test_screen_bounds_are_not_slack_by_16():
 
 
 def test_nn_screen_walk_is_exact_on_the_host():
-    """tests/cpp/test_nn_screen.cpp replays sorted_walk32 (the fp32 screen of the registration validation's neighbour search)
-    with float operations on the host: random grids over nine orders of magnitude, origins at the edge of what the library
+    """tests/cpp/test_nn_screen.cpp replays sorted_walk32 (the screen of the registration validation's neighbour search: fp32
+    arithmetic on 8-byte list entries with 16-bit fixed-point coordinates) with float operations on the host: random grids over nine orders of magnitude, origins at the edge of what the library
     admits, lists with duplicates, reflections (equal distances) and distances 1e-16 apart.  A query the walk calls decided
     must have found the exact fp64 minimum; the rounding bound must hold for every entry; ordinary lists must be decided."""
     cpp = os.path.join(ROOT, "tests", "cpp")
