@@ -53,7 +53,8 @@ def main():
                               ("../pmc_match.txt", f"{TAG}_pmc_match.txt"),
                               ("../c5t_timeline.txt", f"{TAG}_c5_round_timeline.txt"),
                               ("../c5_plain.txt", f"{TAG}_c5_plain.txt"),
-                              ("../oneshot.txt", f"{TAG}_oneshot.txt")):
+                              ("../oneshot.txt", f"{TAG}_oneshot.txt"),
+                              ("../c4_full_size_vs_oracle.txt", f"{TAG}_c4_full_size_vs_oracle.txt")):
         q = os.path.join(SRC, src_rel)
         if os.path.exists(q):
             shutil.copy(q, os.path.join(DST, dst_name))
