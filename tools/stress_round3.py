@@ -67,3 +67,28 @@ while time.time() < t_end:
         assert np.allclose(g.params, o.params, rtol=1e-9, atol=1e-9 * mag), ("fit params", kind, m, it, prob, sd, sc, g.params, o.params)
         n_fit += 1
 print(f"stress ok: {n_match} matcher cases, {n_seg} segmentations, {n_fit} fits in {budget:.0f} s")
+# ---- registration RANSAC: the validation's neighbour search screens on 8-byte quantised list entries (16-bit coordinates
+# over the cell block): scenes of random size, scale and offset, thresholds that move the grid's cell edge
+t_end = time.time() + float(os.environ.get("M3D_STRESS_REG_SECONDS", "0"))
+n_reg = 0
+while time.time() < t_end:
+    n = int(rng.integers(800, 5000))
+    d = synth.registration_pair_c4(n, seed=int(rng.integers(0, 10_000)))
+    sc = float(10.0 ** rng.uniform(-2, 2))
+    off = rng.uniform(-1, 1, 3) * sc * float(10.0 ** rng.uniform(0, 2.5))
+    src, dst = d["src"] * sc + off, d["dst"] * sc + off
+    i0, i1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
+    if len(i0) < 3:
+        continue
+    thr = sc * float(rng.choice([0.01, 0.03, 0.07, 0.2]))
+    mi = int(rng.choice([300, 1000, 2500]))
+    conf = float(rng.choice([1.0, 0.999]))
+    sd = int(rng.integers(0, 10_000))
+    T, st = capi.registration_ransac(src, dst, i0, i1, threshold=thr, max_iter=mi, edge_length_threshold=0.9, confidence=conf, seed=sd)
+    o = oracle.registration_ransac(src, dst, i0.astype(np.int64), i1.astype(np.int64), thr=thr, max_iter=mi, edge_thr=0.9, confidence=conf, seed=sd)
+    assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64)), ("reg T", n, sc, thr, mi, conf, sd)
+    assert (st["iterations"], st["validations"], st["est_k"], st["best_index"]) == (o.iterations, o.validations, o.est_k, o.best_index), ("reg counters", n, sc, thr, mi, conf, sd)
+    assert st["fitness"] == o.fitness
+    n_reg += 1
+if n_reg:
+    print(f"stress ok: {n_reg} registrations identical to the oracle (T bit for bit, iterations, validations, est_k)")
