@@ -895,18 +895,8 @@ __global__ __launch_bounds__(256) void sum_xyz_k(CloudView c, const uint64_t* __
     if (threadIdx.x < 3) partial[blockIdx.x * 16 + threadIdx.x] = sm[threadIdx.x * 256];
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void sum_final_k(const double* __restrict__ partial,
-                                                    double* __restrict__ sums) {
-    __shared__ double sm[NV * 256];
-    double acc[NV];
-    for (int k = 0; k < NV; ++k) acc[k] = partial[threadIdx.x * 16 + k];  // kSumBlocks == 256
-    block_tree_reduce<NV>(acc, sm);
-    if (threadIdx.x < NV) sums[threadIdx.x] = sm[threadIdx.x * 256];
-}
-
 // Second pass of the GeneralFit sums.  Every workgroup first folds the 256 x/y/z partials of sum_xyz_k itself
-// (same fixed tree as sum_final_k<3>: identical mean everywhere, no kernel in between), then accumulates its
+// (one fixed 256-leaf tree, block_tree_reduce: identical mean everywhere, no kernel in between), then accumulates its
 // share of the centred moments.  `out` is device-visible HOST memory (pinned): the per-workgroup partials
 // (out[block * 16 + k]) and, from workgroup 0, the three coordinate sums (out[kSumBlocks * 16 + k]) land there
 // without a copy command; the host finishes the 256-leaf tree (general_fit_sums_finish, same order).
@@ -981,7 +971,7 @@ void moments_about_mean(const double* mo, const double c0[3], double n, double m
 }
 
 // sums[0..2] = sum of x, y, z; sums[4..13] = the ten centred moments: the last level of the fixed tree, on the host,
-// in block_tree_reduce's order (bit-identical to sum_final_k<10>)
+// in block_tree_reduce's order (bit-identical to the one-workgroup folding kernel it replaced)
 void general_fit_sums_finish(const double* out_host, double* sums14) {
     for (int k = 0; k < 3; ++k) sums14[k] = out_host[kSumBlocks * 16 + k];
     sums14[3] = 0.0;
