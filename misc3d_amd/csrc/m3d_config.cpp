@@ -29,6 +29,7 @@ void sanitize(m3d_config& c) {
     if (c.score_min_workgroups < 1) c.score_min_workgroups = 8192;
     if (c.dense_workgroups < 1) c.dense_workgroups = 8192;
     if (c.pool_limit_mb < 0) c.pool_limit_mb = 0;
+    if (c.score_mfma_groups < 1 || c.score_mfma_groups > 64) c.score_mfma_groups = 64;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -49,6 +50,8 @@ void load_env() {
     g_cfg.cull_fp32 = !env_is("M3D_CULL_FP32", '0');
     g_cfg.reg_fp32_screen = !env_is("M3D_REG_SCREEN", '0');
     g_cfg.sorted_tombstones = !env_is("M3D_TOMBSTONES", '0');
+    g_cfg.score_mfma = !env_is("M3D_SCORE_MFMA", '0');
+    g_cfg.score_mfma_groups = (int32_t)env_long("M3D_MFMA_GPB", 64);
     sanitize(g_cfg);
 }
 }  // namespace

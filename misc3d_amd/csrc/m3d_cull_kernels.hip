@@ -35,6 +35,7 @@
 
 #include "m3d_config.hpp"
 #include "m3d_fp.hpp"
+#include "m3d_tile_count.hpp"
 
 #pragma clang fp contract(off)
 
@@ -514,37 +515,6 @@ void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint
 // ------------------------------------------------------------------------------------------------
 // counting over the surviving (tile, hypothesis) pairs
 // ------------------------------------------------------------------------------------------------
-// Inner loop of score_mask_k: inlier count of ONE hypothesis record over the wave's 512 points (wave-uniform result)
-template <int KIND, int P>
-__device__ __forceinline__ uint32_t tile_count(const double (&rec)[kModelStride], const double (&x)[P], const double (&y)[P],
-                                               const double (&z)[P]) {
-    uint32_t cnt = 0;
-    if (KIND == 0) {
-        const double a = rec[0], b = rec[1], c = rec[2], d = rec[3], T = rec[4];
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const double num = plane_num(a, b, c, d, x[j], y[j], z[j]);
-            cnt += (uint32_t)__popcll(__ballot(num < T));
-        }
-    } else if (KIND == 1) {
-        const double cx = rec[0], cy = rec[1], cz = rec[2], lo = rec[3], hi = rec[4];
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const double sv = sphere_s(cx, cy, cz, x[j], y[j], z[j]);
-            cnt += (uint32_t)__popcll(__ballot(sv >= lo) & __ballot(sv <= hi));
-        }
-    } else {
-        const double cx = rec[0], cy = rec[1], cz = rec[2], rx = rec[3], ry = rec[4], rz = rec[5];
-        const double lo = rec[6], hi = rec[7];
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const double tv = line_t(cx, cy, cz, rx, ry, rz, x[j], y[j], z[j]);
-            cnt += (uint32_t)__popcll(__ballot(tv >= lo) & __ballot(tv <= hi));
-        }
-    }
-    return cnt;
-}
-
 // One wave per (tile, <= groups_per_block hypothesis groups).  The surviving hypotheses of the wave's mask words are
 // first COMPACTED into a list of 16-bit ids in LDS (one pass over the words: rank = running total + v_mbcnt, a
 // ds_write per set bit); the loop then takes them 64 at a time -- lane k of `ids` holds the k-th id of the batch, one
@@ -1250,6 +1220,8 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
                        uint32_t* pair_rep, hipStream_t st, uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start,
                        hipEvent_t ev_stop) {
+    if (launch_score_mfma(kind, s, score, masks, keep, n_groups, counts_rep, rep_stride, pair_rep, st, group_begin, group_end, ev_start, ev_stop))
+        return;
     group_end = std::min(group_end, n_groups);
     if (!s.n_tiles || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;

@@ -68,6 +68,17 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                        hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* both set: receive the launch's own start / stop
                        times (m3d_stats.ms_score_kernel) */);
+// score_mfma_k (m3d_score_mfma.hip): the same counting with the screen on the matrix pipe -- planes, m3d_config.score_mfma.
+// false: not applicable (another kind, tombstones in the copy, no fp32 tile offsets, switched off), nothing launched;
+// launch_score_mask calls it first.
+bool launch_score_mfma(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
+                       const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
+                       uint32_t* pair_rep, hipStream_t st, uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start,
+                       hipEvent_t ev_stop);
+// test probe of the MFMA screen: one tile (512 x 3 doubles, device), its box (6 doubles, device), n_h plane records ->
+// out_q[n_h][512] = q_pipe / Sigma_h, out_h[n_h][2] = (h, Sigma_h), out_off[512][3] = the fp32 offsets
+void launch_mfma_probe(const double* pts, const double* box, double max_abs, const double* recs, uint32_t n_h, double* out_q,
+                       double* out_h, float* out_off, hipStream_t st);
 // cull_lead_k: the box tests of groups [lead_groups, cull_end) and the counting of the leading groups [0, lead_groups) (which
 // run their own box tests) in ONE launch -- the head of a fit's first chunk on one GPU.  keep[0 .. lead_groups) and the
 // counter replicas must be prepared (minimal_fit_k's LeadPrep or keep_mask_k); ub is not written for the leading groups

@@ -2381,6 +2381,41 @@ int m3d_bench_fp64_issue_rate(int device, double ms_target, double* tops, double
     return M3D_OK;
 }
 
+int m3d_bench_mfma_probe(int device, const double* xyz512, const double box[6], double max_abs, const double* records, size_t n_h,
+                         double* out_q, double* out_h, float* out_off) {
+    if (!xyz512 || !box || !records || !n_h || !out_q || !out_h || !out_off || n_h > (1u << 20)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    DeviceCtx* ctx = get_ctx(device);
+    if (!ctx) return M3D_ERR_DEVICE;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    struct Bufs {   // (a test hook: its scratch does not outlive the call)
+        DevBuf pts, box, rec, q, h, off;
+        ~Bufs() {
+            pts.release(); box.release(); rec.release(); q.release(); h.release(); off.release();
+        }
+    } bufs;
+    DevBuf &d_pts = bufs.pts, &d_box = bufs.box, &d_rec = bufs.rec, &d_q = bufs.q, &d_h = bufs.h, &d_off = bufs.off;
+    RESERVE(d_pts, sizeof(double) * 512 * 3);
+    RESERVE(d_box, sizeof(double) * 6);
+    RESERVE(d_rec, sizeof(double) * kModelStride * n_h);
+    RESERVE(d_q, sizeof(double) * 512 * n_h);
+    RESERVE(d_h, sizeof(double) * 2 * n_h);
+    RESERVE(d_off, sizeof(float) * 512 * 3);
+    HIPCHK(hipMemcpyAsync(d_pts.p, xyz512, sizeof(double) * 512 * 3, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_box.p, box, sizeof(double) * 6, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_rec.p, records, sizeof(double) * kModelStride * n_h, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_q.p, 0xFF, sizeof(double) * 512 * n_h, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_h.p, 0xFF, sizeof(double) * 2 * n_h, ctx->stream));
+    launch_mfma_probe(d_pts.as<double>(), d_box.as<double>(), max_abs, d_rec.as<double>(), (uint32_t)n_h, d_q.as<double>(),
+                      d_h.as<double>(), d_off.as<float>(), ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_q, d_q.p, sizeof(double) * 512 * n_h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_h, d_h.p, sizeof(double) * 2 * n_h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_off, d_off.p, sizeof(float) * 512 * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return M3D_OK;
+}
+
 int m3d_cloud_exact_error(m3d_cloud* c, int kind, double threshold, const double* model,
                           uint64_t* count, double* error) {
     if (!c || kind < 0 || kind > 2 || !model || !count || !error)
