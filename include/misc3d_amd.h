@@ -400,9 +400,10 @@ typedef struct m3d_config {
     int32_t sorted_tombstones;      /* [M3D_TOMBSTONES=0]   default 1: a segmentation round that removes a sliver of the cloud kills its inliers
                                        in place in the Hilbert-sorted copy (x = NaN: never an inlier; the screen masks the lane) instead
                                        of partitioning the copy; a real compaction follows when an eighth of the copy is dead */
-    int32_t score_mfma;             /* [M3D_SCORE_MFMA=0]   default 1: plane hypotheses are counted by score_mfma_k -- the screen's value
-                                       q = T^2 - S^2 as a quadratic form on the matrix pipe (split-fp16 operands, rounding bound, exact
-                                       fp64 recount of the undecided pairs: identical counts); 0: score_screen_k (packed fp32 VALU) */
+    int32_t score_mfma;             /* [M3D_SCORE_MFMA=1]   default 0; 1: plane hypotheses are counted by score_mfma_k -- the screen's two
+                                       one-sided values T - S and T + S on the matrix pipe (split-fp16 operands, rounding bound, exact
+                                       fp64 recount of the undecided pairs: identical counts) instead of score_screen_k (packed fp32
+                                       VALU); measured slower on C2 as it stands (m3d_score_mfma.hip, STATUS) */
     int32_t score_mfma_groups;      /* [M3D_MFMA_GPB]       default 64: 64-hypothesis groups per workgroup of score_mfma_k (1..64) */
     int32_t reserved[5];            /* zero.  Fields are only ever APPENDED in front of this array (which shrinks): the offsets of
                                        existing fields do not move (round 3 itself had re-used four slots in place) */

@@ -50,8 +50,9 @@ int m3d_bench_reg_checkers(const double *ps, const double *pd, const double *T, 
 /* TEST hook (tests/test_gpu_mfma_screen.py): the MFMA screen of the plane scoring (score_mfma_k) on ONE tile -- 512 points
  * xyz (row-major doubles), their box (centre xyz, half extents xyz: every |x - centre| <= half extent), n_h plane records
  * (a, b, c, d, T, 0, 0, 0) -- through the production kernel's own operand builders and the matrix pipe:
- * out_q[h][i] = the screen's value for hypothesis h and point i, unscaled (its sign is the verdict when |out_q| >= out_h[h][0]),
- * out_h[h] = (band h, scale Sigma_h) (h = NaN: the record is not screened), out_off[i] = the fp32 offsets the pipe was fed. */
+ * out_q[h][i] = (u1, u2) = the pipe's T - S and T + S for hypothesis h and point i, unscaled (inside <=> u1 u2 > 0, decided when
+ * |u1 u2| >= out_h[h][0]), out_h[h] = (band h on the product, scale Sigma_h, the bound E_p on either u) (h = NaN: the record
+ * is not screened), out_off[i] = the fp32 offsets the pipe was fed.  Sizes: out_q n_h x 512 x 2, out_h n_h x 3, out_off 512 x 3. */
 int m3d_bench_mfma_probe(int device, const double *xyz512, const double box[6], double max_abs, const double *records,
                          size_t n_h, double *out_q, double *out_h, float *out_off);
 

@@ -221,20 +221,21 @@ def fp64_issue_rate(device=0, ms_target=2.0):
 
 def mfma_probe(xyz512, box, max_abs, records, device=0):
     """m3d_bench_mfma_probe (include/misc3d_amd_bench.h): the MFMA screen's values for one tile of 512 points and plane
-    records (a, b, c, d, T) -> (q[n_h, 512], h[n_h], sigma[n_h], offsets32[512, 3])"""
+    records (a, b, c, d, T) -> (u[n_h, 512, 2] = the pipe's (T - S, T + S), h[n_h] = the band on their product, sigma[n_h],
+    e_p[n_h] = the bound on either u, offsets32[512, 3])"""
     xyz = np.ascontiguousarray(xyz512, dtype=np.float64).reshape(512, 3)
     bx = np.ascontiguousarray(box, dtype=np.float64).reshape(6)
     rec = np.zeros((len(records), 8), dtype=np.float64)
     rec[:, :5] = np.asarray(records, dtype=np.float64).reshape(-1, 5)
-    q = np.empty((len(rec), 512), dtype=np.float64)
-    h = np.empty((len(rec), 2), dtype=np.float64)
+    q = np.empty((len(rec), 512, 2), dtype=np.float64)
+    h = np.empty((len(rec), 3), dtype=np.float64)
     off = np.empty((512, 3), dtype=np.float32)
     f = lib().m3d_bench_mfma_probe
     f.restype = C.c_int
     f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     _check(f(device, xyz.ctypes.data, bx.ctypes.data, float(max_abs), rec.ctypes.data, len(rec), q.ctypes.data, h.ctypes.data,
              off.ctypes.data))
-    return q, h[:, 0].copy(), h[:, 1].copy(), off
+    return q, h[:, 0].copy(), h[:, 1].copy(), h[:, 2].copy(), off
 
 
 def get_config() -> Config:

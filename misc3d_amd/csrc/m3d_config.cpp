@@ -50,7 +50,7 @@ void load_env() {
     g_cfg.cull_fp32 = !env_is("M3D_CULL_FP32", '0');
     g_cfg.reg_fp32_screen = !env_is("M3D_REG_SCREEN", '0');
     g_cfg.sorted_tombstones = !env_is("M3D_TOMBSTONES", '0');
-    g_cfg.score_mfma = !env_is("M3D_SCORE_MFMA", '0');
+    g_cfg.score_mfma = env_is("M3D_SCORE_MFMA", '1');
     g_cfg.score_mfma_groups = (int32_t)env_long("M3D_MFMA_GPB", 64);
     sanitize(g_cfg);
 }

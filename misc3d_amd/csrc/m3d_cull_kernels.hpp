@@ -76,7 +76,7 @@ bool launch_score_mfma(int kind, const SortedView& s, const double* score, const
                        uint32_t* pair_rep, hipStream_t st, uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start,
                        hipEvent_t ev_stop);
 // test probe of the MFMA screen: one tile (512 x 3 doubles, device), its box (6 doubles, device), n_h plane records ->
-// out_q[n_h][512] = q_pipe / Sigma_h, out_h[n_h][2] = (h, Sigma_h), out_off[512][3] = the fp32 offsets
+// out_q[n_h][512][2] = (u1, u2) / Sigma_h, out_h[n_h][3] = (h, Sigma_h, E_p), out_off[512][3] = the fp32 offsets
 void launch_mfma_probe(const double* pts, const double* box, double max_abs, const double* recs, uint32_t n_h, double* out_q,
                        double* out_h, float* out_off, hipStream_t st);
 // cull_lead_k: the box tests of groups [lead_groups, cull_end) and the counting of the leading groups [0, lead_groups) (which

@@ -2398,19 +2398,19 @@ int m3d_bench_mfma_probe(int device, const double* xyz512, const double box[6], 
     RESERVE(d_pts, sizeof(double) * 512 * 3);
     RESERVE(d_box, sizeof(double) * 6);
     RESERVE(d_rec, sizeof(double) * kModelStride * n_h);
-    RESERVE(d_q, sizeof(double) * 512 * n_h);
-    RESERVE(d_h, sizeof(double) * 2 * n_h);
+    RESERVE(d_q, sizeof(double) * 1024 * n_h);
+    RESERVE(d_h, sizeof(double) * 3 * n_h);
     RESERVE(d_off, sizeof(float) * 512 * 3);
     HIPCHK(hipMemcpyAsync(d_pts.p, xyz512, sizeof(double) * 512 * 3, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_box.p, box, sizeof(double) * 6, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_rec.p, records, sizeof(double) * kModelStride * n_h, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(d_q.p, 0xFF, sizeof(double) * 512 * n_h, ctx->stream));
-    HIPCHK(hipMemsetAsync(d_h.p, 0xFF, sizeof(double) * 2 * n_h, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_q.p, 0xFF, sizeof(double) * 1024 * n_h, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_h.p, 0xFF, sizeof(double) * 3 * n_h, ctx->stream));
     launch_mfma_probe(d_pts.as<double>(), d_box.as<double>(), max_abs, d_rec.as<double>(), (uint32_t)n_h, d_q.as<double>(),
                       d_h.as<double>(), d_off.as<float>(), ctx->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_q, d_q.p, sizeof(double) * 512 * n_h, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_h, d_h.p, sizeof(double) * 2 * n_h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_q, d_q.p, sizeof(double) * 1024 * n_h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_h, d_h.p, sizeof(double) * 3 * n_h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(out_off, d_off.p, sizeof(float) * 512 * 3, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return M3D_OK;

@@ -637,97 +637,81 @@ M3D_HD void cylinder_screen_record(const double* rec, const double* box, double 
 }
 
 // ------------------------------------------------------------------------------------------------
-// QUADRIC records of the MFMA screen (score_mfma_k, m3d_score_mfma.hip).
+// Records of the MFMA screen (score_mfma_k, m3d_score_mfma.hip).
 //
 // tools/ubench/valu_rates.hip (profiles/r04_ubench_valu_rates.txt) settled what an instruction costs on gfx950: every VOP3
-// instruction -- packed fp32, fp64, v_alignbit, v_min3 -- occupies its SIMD for ~4.15 cycles per wave, and a
-// v_mfma_f32_32x32x16_f16 issued between them costs ~10 more while the matrix pipe works in the VALU's shadow.  The packed
-// screen pays 3.6 VALU instructions per (point, hypothesis); if the matrix pipe delivers, per point and hypothesis, ONE fp32
-// number whose sign is the verdict, the VALU is left with the shift that collects the sign (1) and the running minimum of
-// |value| that says whether any point was too close to call (0.5).
+// instruction -- packed fp32, fp64, v_alignbit, v_min3 -- occupies its SIMD for ~4.15 cycles per wave, a VOP2 v_mul_f32 2.3,
+// and a v_mfma_f32_32x32x16_f16 issued between them ~10 while the matrix pipe works in the VALU's shadow.  The packed screen
+// pays 3.6 VALU instructions per (point, hypothesis).  Here the matrix pipe delivers, per point and hypothesis, the two
+// numbers u1 = T - S and u2 = T + S (S = alpha . x~ + D on the tile's fp32 offsets x~, D = the model's value at the box
+// centre): inside <=> both positive <=> t = u1 u2 > 0 -- the VALU is left with one v_mul_f32, the shift that collects t's sign
+// and half a v_min3 for "was any |t| too small to call".
 //
-// Plane.  inside <=> |S| < T <=> q = T^2 - S^2 > 0, and with the tile's fp32 offsets x~ from its box centre o,
-// S = alpha . x~ + D (D = the model's value at o), q is a QUADRATIC FORM in x~:
-//     q = sum_{i<=j} c_ij x~_i x~_j + sum_i l_i x~_i + k,   c_ii = -alpha_i^2, c_ij = -2 alpha_i alpha_j, l_i = -2 D alpha_i,
-//     k = (T - D)(T + D)
-// -- a contraction over ten monomials, i.e. a matrix product [points x monomials] . [monomials x hypotheses].  fp16 operands
-// carry 11 bits, so every monomial m and coefficient b is split in two pieces (m = mh + ml, |ml| <= 2^-11 |m|; the same for b) and
-// m b ~ mh bh + mh bl + ml bh: three K-slots per monomial, 27 + 3 (the constant: 2048 against three pieces of k) = 30 of
-// K = 32: two MFMAs per 32 points x 32 hypotheses.  Products of fp16 numbers are exact in the pipe's fp32 accumulation.
+// Operands.  fp16 carries 11 bits, so every coordinate X = x~ sigma and coefficient b is cut in two pieces (X = Xh + Xl,
+// |Xl| <= 2^-11 |X|; the same for b) and X b ~ Xh bh + Xh bl + Xl bh: three K-slots per coordinate, nine + three for the
+// constant (2048 against three pieces of (T -+ D) Sigma / 2048: 33 bits) = 12 of K = 16, ONE MFMA per column and 32 x 32
+// block.  Products of fp16 numbers are exact in the pipe's fp32 accumulation.  Scaling by powers of two (exact): tile,
+// sigma = 2^p with e_max sigma in (2^10, 2^11]; coefficients, 1024 alpha (unit normals: below 2^10.1; the pieces of alpha are
+// then the hypothesis' own, whatever the tile); the pipe's unit is Sigma = 1024 sigma, the same for every hypothesis of a
+// tile, and the constant's pieces are cut from (T -+ D) sigma / 2.  An fp16 piece below 2^-14 is subnormal and the pipe may
+// flush it (tools/ubench/mfma_f16_error.hip): it meets a partner of at most 2^11.1 -- below 0.3 per K-slot, 4 in all.
+// (First form of the round, in the history: q = T^2 - S^2 as ONE quadratic form over ten monomials, K = 32 -- 1.5 VALU
+// instructions per pair instead of 2.5, but the expanded form carries terms of size (r + |D|)^2 for a result that matters at
+// size T^2: its band was 35 x the packed screen's and 23 % of the C2 pairs went back to the exact code.  A linear form's error
+// scales with r + |D|, like the packed screen's.)
 //
-// Scaling (all by powers of two, exact).  Tile: sigma = 2^p with e_max sigma in (2^6, 2^7] (e_max = the box's largest half
-// extent): X = x~ sigma; quadratic monomials X_i X_j <= 2^14, linear ones 16 X <= 2^11, the constant's A-side value 2048.
-// Hypothesis: Sigma_h = 2^s with its largest scaled coefficient in [2^10, 2^11).  An fp16 piece below 2^-14 is subnormal and
-// the pipe may flush it (tools/ubench/mfma_f16_error.hip): such a piece meets a partner of at most 2^14.1 -- at most 1.2 per
-// K-slot in the scaled output, 40 in all, against terms of ~2^24.
-//
-// Bound.  u = 2^-24; r = sum |alpha_i| e_i; G = (r + |D|)^2 + |T^2 - D^2| >= sum of |terms| of q over the box.
-//   * monomials: X_i X_j is one fp32 product of exact scalings of x~: u per term (3.1 u budgeted);
-//   * pieces: m b - (mh bh + mh bl + ml bh) = ml bl + (rounding of ml) b + m (rounding of bl): 3 * 2^-22 |m b| = 12 u |m b| (12.5 u);
-//   * the pipe's accumulation of 32 exact products: measured <= 9.2 u sum|terms| over 8 M outputs of adversarial operands
-//     (heavy cancellation, one huge term, subnormal pieces: profiles/r04_ubench_mfma_f16_error.txt); budgeted kMfmaAcc = 16 u.
-//   E_q = (3.1 + 12.5 + 16) u G + 40 / Sigma_h bounds |q_pipe / Sigma_h - q~|, q~ = T^2 - S~^2 in real arithmetic on the
-//   fp32 offsets the kernel holds.  S~ is within E_in = u r + 1e-15 M_g of the exact code's fp64 value s64 (the offsets'
-//   rounding; the fp64 roundings of o, D and s64 itself, as for plane_screen_record).
-//   q_pipe >= h Sigma_h  =>  S~^2 <= T^2 - (h - E_q)  =>  (|S~| + E_in)^2 < T^2 when h - E_q > 2 T E_in + E_in^2: |s64| < T;
-//   q_pipe <= -h Sigma_h =>  S~^2 >= T^2 + (h - E_q) >= (T + 2 E_in)^2 when h - E_q >= 4 T E_in + 4 E_in^2: |s64| >= T.
-//   h = (E_q + 4 T E_in + 4 E_in^2) 1.001.  A pair with min |q_pipe| < h Sigma_h over its 512 points is recounted by the
-//   exact code; a record that cannot be screened carries h = NaN.
-// tests/test_gpu_mfma_screen.py measures |q_pipe / Sigma_h - q~| against E_q on the GPU (m3d_bench_mfma_probe).
+// Bound.  u = 2^-24; r = sum |alpha_i| e_i; G = r + T + |D| >= the sum of |terms| of either column over the box.
+//   * coefficients: 1024 alpha_i is rounded to fp32 before it is cut: u |X b| (1 u);
+//   * pieces: X b - (Xh bh + Xh bl + Xl bh) = Xl bl + (rounding of Xl) b + X (rounding of bl): 3 * 2^-22 |X b| = 12 u |X b| (12.5 u);
+//   * the pipe's accumulation of 16 exact products: measured <= 5.5 u sum|terms| for operands in the normal range, 9.2 with
+//     subnormal pieces in a chain of two (profiles/r04_ubench_mfma_f16_error.txt); budgeted kMfmaAcc = 12 u;
+//   E_p = 25.5 u G + 4 / Sigma bounds |u_i / Sigma - (T -+ S~)|, S~ = alpha . x~ + D in real arithmetic on the offsets the
+//   kernel holds; S~ is within E_in = u r + 1e-15 M_g of the exact code's fp64 value s64 (the offsets' rounding; the fp64
+//   roundings of the centre, D and s64 itself, as for plane_screen_record).  E = E_p + E_in.
+//   t >= h > 0: the factors have one sign, and u1 + u2 = 2 T +- 2 E_p > 0 makes it the positive one; were |u1| <= E, |u2| would
+//   be <= 2 T + 3 E and t <= E (2 T + 3 E): with h = E (2 T + 3 E) 1.001 both |u_i| > E, i.e. T - s64 > 0 and T + s64 > 0: inside.
+//   t <= -h: opposite signs, and by the same argument the negative factor is below -E: |s64| > T.
+//   (t itself is one fp32 product of the two: relative 2^-24, inside the 1.001.)
+// A pair with min |t| < h over its 512 points is recounted by the exact code; a record that cannot be screened carries h = NaN.
+// tests/test_gpu_mfma_screen.py measures |u_i / Sigma - (T -+ S~)| against E_p on the GPU (m3d_bench_mfma_probe).
 // ------------------------------------------------------------------------------------------------
-constexpr double kMfmaAcc = 16.0;      // accumulation error of v_mfma_f32_32x32x16_f16 x 2, in u x sum |terms|
+constexpr double kMfmaAcc = 12.0;      // accumulation error of one v_mfma_f32_32x32x16_f16, in u x sum |terms|
 constexpr double kMfmaConstA = 2048.0; // A-side value of the constant's three K-slots
-constexpr double kMfmaLin = 16.0;      // linear monomials carry 16 x the tile scale
+constexpr double kMfmaCoef = 1024.0;   // B-side scale of the plane's normal
 constexpr int kMfmaNoTile = -100000;   // mfma_tile_exp: the tile cannot be screened
-// p with e_max 2^p in (2^6, 2^7]; kMfmaNoTile for an empty / non-finite / astronomically large box
+// p with e_max 2^p in (2^10, 2^11]; kMfmaNoTile for an empty / non-finite / astronomically large or small box
 M3D_HD int mfma_tile_exp(const double* box) {
     const double e = fmax(fmax(box[3], box[4]), box[5]);
-    if (!(e > 0.0) || !(e < 1e30)) return kMfmaNoTile;
+    if (!(e > 1e-30) || !(e < 1e30)) return kMfmaNoTile;
     int ex;
     (void)__builtin_frexp(e, &ex);   // e = f 2^ex, f in [0.5, 1)
-    const int p = 7 - ex;
-    return p > 100 ? 100 : p;        // (a box of < 2^-93: the offsets are just smaller numbers)
+    return 11 - ex;
 }
 // rec = the plane's scoring record (a, b, c, d, T), box = (centre, half extents), p = mfma_tile_exp(box).
-// b[0..9] = the scaled coefficients of (xx, yy, zz, xy, xz, yz, x, y, z, 1) as the B operand's pieces are cut from;
-// *hs = the scaled band h Sigma_h (NaN: not screened, b = 0).
-M3D_HD void plane_quadric_record(const double* rec, const double* box, double max_abs, int p, double* b, double* hs,
-                                 double* sigma_h = nullptr /* Sigma_h (1 when not screened) */) {
+// k[0] = (T - D) sigma / 2, k[1] = (T + D) sigma / 2: what the constants' pieces are cut from (column u1 = T - S takes -1024 alpha,
+// column u2 = T + S takes +1024 alpha); *hs = the band on t = u1 u2 in the pipe's units, h Sigma^2 (NaN: not screened).
+M3D_HD void plane_mfma_record(const double* rec, const double* box, double max_abs, int p, double* k, double* hs,
+                              double* e_p = nullptr /* E_p, unscaled */) {
     const double a = rec[0], bb = rec[1], c = rec[2], d = rec[3], T = rec[4];
     const double D = ((a * box[0] + bb * box[1]) + c * box[2]) + d;
     const double sa = (fabs(a) + fabs(bb)) + fabs(c);
     const double r = (fabs(a) * box[3] + fabs(bb) * box[4]) + fabs(c) * box[5];
     const double Mg = sa * max_abs + fabs(d);
-    const double is2 = __builtin_ldexp(1.0, -2 * p), il = __builtin_ldexp(1.0, -p) / kMfmaLin;   // 1 / sigma^2, 1 / (16 sigma)
-    double v[10];
-    v[0] = -(a * a) * is2;
-    v[1] = -(bb * bb) * is2;
-    v[2] = -(c * c) * is2;
-    v[3] = -2.0 * (a * bb) * is2;
-    v[4] = -2.0 * (a * c) * is2;
-    v[5] = -2.0 * (bb * c) * is2;
-    v[6] = -2.0 * (D * a) * il;
-    v[7] = -2.0 * (D * bb) * il;
-    v[8] = -2.0 * (D * c) * il;
-    v[9] = ((T - D) * (T + D)) / kMfmaConstA;
-    double m = 0.0;
-    for (int i = 0; i < 10; ++i) m = fmax(m, fabs(v[i]));
-    const double G = (r + fabs(D)) * (r + fabs(D)) + fabs((T - D) * (T + D));
-    const double Ein = kU32 * r + 1e-15 * Mg;
-    bool ok = (p != kMfmaNoTile) && (m > 0.0) && (m < 1e300) && (Mg < 1e18) && (sa < 1e18) && (max_abs < 1e18) && (T > 1e-15) &&
-              (T < 1e18) && (T > 2.0 * Ein) && (G < 1e300);
-    int em = 0;
-    (void)__builtin_frexp(ok ? m : 1.0, &em);          // m = f 2^em, f in [0.5, 1)
-    const int sexp = 11 - em;                           // m Sigma_h in [2^10, 2^11)
-    ok = ok && sexp > -900 && sexp < 900;
-    const double Sg = __builtin_ldexp(1.0, ok ? sexp : 0);
-    const double Eq = ((3.1 + 12.5 + kMfmaAcc) * kU32 * G + 40.0 / Sg) / M3D_SCREEN_BOUND_DIVISOR;
-    const double h = ((Eq + 4.0 * T * Ein) + 4.0 * Ein * Ein) * 1.001;
-    const double hsc = h * Sg;
-    ok = ok && (h < T * T) && (hsc < 1e37) && (hsc > 0.0);
-    for (int i = 0; i < 10; ++i) b[i] = ok ? v[i] * Sg : 0.0;
+    const int pe = p == kMfmaNoTile ? 0 : p;
+    const double sig = __builtin_ldexp(1.0, pe), Sg = kMfmaCoef * sig, iSg = __builtin_ldexp(1.0 / kMfmaCoef, -pe);
+    const double G = (r + T) + fabs(D);
+    const double Ep = ((13.5 + kMfmaAcc) * kU32 * G + 4.0 * iSg) / M3D_SCREEN_BOUND_DIVISOR;
+    const double E = Ep + (kU32 * r + 1e-15 * Mg);
+    const double h = (E * (2.0 * T + 3.0 * E)) * 1.001;
+    const double hsc = (h * Sg) * Sg;
+    const double k1 = (T - D) * (0.5 * sig), k2 = (T + D) * (0.5 * sig);
+    // |1024 alpha| and the constants' first pieces must be fp16 numbers (65504); T > 2 E: something is left to decide
+    const bool ok = (p != kMfmaNoTile) && (sa < 30.0) && (Mg < 1e18) && (max_abs < 1e18) && (T > 1e-15) && (T < 1e18) &&
+                    (fabs(k1) < 6.0e4) && (fabs(k2) < 6.0e4) && (T > 2.0 * E) && (hsc < 1e37) && (hsc > 0.0);
+    k[0] = ok ? k1 : 0.0;
+    k[1] = ok ? k2 : 0.0;
     *hs = ok ? (double)f32_round_up_pos(hsc > 1e-30 ? hsc : 1e-30) : (double)f32_nan();
-    if (sigma_h) *sigma_h = ok ? Sg : 1.0;
+    if (e_p) *e_p = Ep;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -4,21 +4,32 @@
 // below the threshold.  score_screen_k (m3d_cull_kernels.hip) answers it with 3.6 packed-fp32 VALU instructions per pair and
 // sends the pairs its rounding bound cannot decide to the exact fp64 code.  On gfx950 every such instruction occupies its
 // SIMD for ~4.15 cycles (tools/ubench/valu_rates.hip) -- but a v_mfma_f32_32x32x16_f16 between them costs ~10 cycles of
-// issue and then works beside the VALU.  The plane's verdict is the sign of q = T^2 - S^2, a quadratic form in the tile's
-// offsets, i.e. a contraction over ten monomials: the matrix pipe evaluates it for 32 points x 32 hypotheses per pair of
-// MFMAs (split-fp16 operands, 30 of K = 32 slots: m3d_fp.hpp, "QUADRIC records"), and the VALU is left with 1.5 instructions
-// per pair -- the shift that collects the sign bit and half a v_min3 for "was any point too close to call".  Decisions are the
-// fp64 code's, bit for bit: a (tile, hypothesis) pair with a point inside the bound is recounted by tile_count.
+// issue and then works beside the VALU.  Here the matrix pipe evaluates, for 32 points x 32 hypotheses per instruction, the
+// plane's two one-sided values u1 = T - S and u2 = T + S (split-fp16 operands, 12 of K = 16 slots: m3d_fp.hpp, "Records of the
+// MFMA screen"); inside <=> t = u1 u2 > 0, and the VALU is left with 2.5 instructions per pair -- one VOP2 multiply, the shift
+// that collects t's sign bit, half a v_min3 for "was any |t| too small to call".  Decisions are the fp64 code's, bit for bit: a
+// (tile, hypothesis) pair with a point inside the bound is recounted by tile_count.
 //
-//   * A operand (points): per 32-point block and lane 8 halfs x 2 K-steps, made from the tile's fp32 offsets
-//     (SortedView::tile_f32) when the wave starts: X = x~ sigma, four products + the linear z per lane (the two half-waves
-//     hold different monomials of the same point), each cut into an fp16 pair by v_cvt_pk_f16_f32: 128 VGPRs for the tile.
-//   * B operand (hypotheses): lane k prepares hypothesis k's coefficients FOR THIS TILE in fp64 (plane_quadric_record), cuts
-//     them and hands the upper K-halves to lane k +- 32 with v_permlane32_swap: two sub-batches of 32 columns per 64 lanes.
-//   * per sub-batch: 16 blocks x (2 MFMA + 16 v_alignbit + 8 v_min3); the lane's 256 sign bits are counted by v_bcnt every
-//     32, the two half-waves' counts meet through one more swap; one vector atomic per 32 hypotheses.
-// A workgroup is one wave and takes up to 64 groups of 64 hypotheses of its tile: the operand build (~2000 cycles) wants
-// hundreds of surviving hypotheses behind it.
+//   * A workgroup = one tile x up to 64 groups of 64 hypotheses, FOUR waves.  A operand (points): per 32-point block and lane
+//     8 halfs, made from the tile's fp32 offsets (SortedView::tile_f32): X = x~ sigma cut into fp16 pairs by v_cvt_pk_f16_f32;
+//     the lower half-wave holds the pieces of x, y, z, the upper one z's third slot and the constant's.  Each wave builds four
+//     of the sixteen blocks into LDS (16 KB per tile); every wave then reads a block's operand back (one ds_read_b128) right
+//     before the MFMAs that take it.
+//   * the surviving hypotheses of the workgroup's groups are compacted into one id list (wave 0: lane = mask word); the waves
+//     take its batches of 64 in turn, so the four are balanced whatever the masks look like.
+//   * B operands (hypotheses, two columns each): lane k prepares hypothesis k's constants FOR THIS TILE in fp64
+//     (plane_mfma_record), cuts them and hands the upper K-halves to lane k +- 32 with v_permlane32_swap: two sub-batches of
+//     32 hypotheses per 64 lanes.  The records of the wave's NEXT batch are requested before the current one is evaluated.
+//   * per sub-batch: 16 blocks x (2 MFMA + 16 v_mul + 16 v_alignbit + 8 v_min3), the MFMAs of block i + 1 issued before the
+//     post-processing of block i; the lane's 256 sign bits are counted by v_bcnt every 32, the two half-waves' counts meet
+//     through one more swap; one vector atomic per 32 hypotheses.
+//
+// STATUS (round 4, MI355X, C2 = 1 M points x 10 000 planes; profiles/r04_score_mfma.txt): OPT-IN (m3d_config.score_mfma = 1).
+// Counts are identical (the parity suite runs this path), the loop is what the micro-benchmark promised -- the launch takes
+// 0.087 ms against score_screen_k's 0.100 when the undecided pairs are ignored -- but its band is ~4 x the packed screen's
+// (25.5 u (r + T + |D|) against 8 u M_l: the pieces' and the pipe's rounding), 1.7 % of the pairs instead of 0.23 % go to the
+// exact code, and those concentrate in the tiles of the winning plane: the workgroups that own them run 0.2 ms longer than
+// everybody else and the launch takes 0.31 ms.  What would make it the default is spelled out in DESIGN.md 4 ("MFMA screen").
 #include "m3d_cull_kernels.hpp"
 
 #include <hip/hip_ext.h>
@@ -67,55 +78,47 @@ __device__ __forceinline__ void pieces3(double v, float& p1, float& p2, float& p
     p3 = (float)(r1 - (double)p2);
 }
 
-// The A operand of one 32-point block for this lane (row = lane % 32; `upper` = lane >= 32 holds K-slots 8..15 of each step):
-//   step 0: (P0h, P1h | P0h, P1h | P0l, P1l | Zh, Zl)      lower half-wave: P0 = xx, P1 = yy;     upper: P0 = xz, P1 = yz
-//   step 1: (P2h, P3h | P2h, P3h | P2l, P3l | 2048, 2048)   lower half-wave: P2 = zz, P3 = xy;     upper: P2 = 16 x, P3 = 16 y
-// with Z = 16 z (the linear monomial); the B operand pairs (bh, bl, bh) with the first three registers (b_record).
-__device__ __forceinline__ void a_block(float x, float y, float z, float sig, bool upper, uint32_t cc, u32x4& a0, u32x4& a1) {
+// The A operand of one 32-point block for this lane (row = lane % 32; `upper` = lane >= 32 holds K-slots 8..15):
+//   lower half-wave: (xh, yh | xh, yh | xl, yl | zh, zl)        upper half-wave: (zh, 2048 | 2048, 2048 | 0, 0 | 0, 0)
+// against the B column  (bxh, byh | bxl, byl | bxh, byh | bzh, bzh)   and   (bzl, k1 | k2, k3 | 0, 0 | 0, 0)   (b_record).
+constexpr uint32_t kC16 = 0x6800u;   // 2048 as fp16
+__device__ __forceinline__ u32x4 a_block(float x, float y, float z, float sig, bool upper) {
     const float X = x * sig, Y = y * sig, Z = z * sig;   // (powers of two: exact)
-    const float v0 = upper ? Z : X, v1 = upper ? Z : Y;
-    const float w2a = upper ? X : Z, w2b = upper ? (float)kMfmaLin : Z;
-    const float w3a = upper ? Y : X, w3b = upper ? (float)kMfmaLin : Y;
-    const float P0 = X * v0, P1 = Y * v1, P2 = w2a * w2b, P3 = w3a * w3b;
-    const float ZL = Z * (float)kMfmaLin;
-    uint32_t H01, L01, H23, L23;
-    split_pair(P0, P1, H01, L01);
-    split_pair(P2, P3, H23, L23);
-    const float zh = (float)(_Float16)ZL;
-    const uint32_t ZZ = pk16(ZL, ZL - zh);
-    a0 = u32x4{H01, H01, L01, ZZ};
-    a1 = u32x4{H23, H23, L23, cc};
+    uint32_t H, L;
+    split_pair(X, Y, H, L);
+    const float zh = (float)(_Float16)Z;
+    const uint32_t ZZ = pk16(Z, Z - zh);
+    const uint32_t zc = (ZZ & 0xFFFFu) | (kC16 << 16), cc = kC16 | (kC16 << 16);
+    return u32x4{upper ? zc : H, upper ? cc : H, upper ? 0u : L, upper ? 0u : ZZ};
 }
 
-// The B operand pieces of one hypothesis, as its own lane holds them before the exchange: four octets (step, K-half)
-//   step 0 lower: (xx_h, yy_h | xx_l, yy_l | xx_h, yy_h | z_h, z_h)      step 0 upper: (xz.., yz.. | .. | .. | z_l, 0)
-//   step 1 lower: (zz_h, xy_h | zz_l, xy_l | zz_h, xy_h | k1, k2)         step 1 upper: (x.., y.. | .. | .. | k3, 0)
+// The B operand pieces of one hypothesis, as its own lane holds them before the exchange: per column (u1 = T - S, u2 = T + S)
+// a lower octet (K-slots 0..7) and an upper one (8..15)
 struct BPieces {
-    u32x4 s0l, s0u, s1l, s1u;
+    u32x4 c1l, c1u, c2l, c2u;
     float hs;
 };
-__device__ __forceinline__ BPieces b_record(const double* __restrict__ rec, const double (&box)[6], double max_abs, int p, bool live) {
-    double b[10], hs;
-    plane_quadric_record(rec, box, max_abs, p, b, &hs);
-    float h[9], l[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) pieces2(b[i], h[i], l[i]);
-    float k1, k2, k3;
-    pieces3(b[9], k1, k2, k3);
+__device__ __forceinline__ BPieces b_record(const double (&rec)[5], const double (&box)[6], double max_abs, int p, bool live) {
+    double k[2], hs;
+    plane_mfma_record(rec, box, max_abs, p, k, &hs);
+    // 1024 alpha: rounded to fp32 (part of the bound), then cut in two
+    const float af[3] = {(float)(rec[0] * kMfmaCoef), (float)(rec[1] * kMfmaCoef), (float)(rec[2] * kMfmaCoef)};
+    uint32_t hh, ll;
+    split_pair(af[0], af[1], hh, ll);
+    const float zh = (float)(_Float16)af[2], zl = af[2] - zh;
+    float k1[3], k2[3];
+    pieces3(k[0], k1[0], k1[1], k1[2]);
+    pieces3(k[1], k2[0], k2[1], k2[2]);
     BPieces o;
-    // monomial order of b: xx, yy, zz, xy, xz, yz, x, y, z
-    auto octet = [&](int i, int j, uint32_t last) {
-        const uint32_t hh = pk16(h[i], h[j]), ll = pk16(l[i], l[j]);
-        return u32x4{hh, ll, hh, last};
-    };
-    o.s0l = octet(0, 1, pk16(h[8], h[8]));
-    o.s0u = octet(4, 5, pk16(l[8], 0.0f));
-    o.s1l = octet(2, 3, pk16(k1, k2));
-    o.s1u = octet(6, 7, pk16(k3, 0.0f));
-    if (!live) {   // no hypothesis in this lane: a zero column (its verdicts are not read)
-        o.s0l = o.s0u = o.s1l = o.s1u = u32x4{0u, 0u, 0u, 0u};
-        hs = 0.0;
-    }
+    const uint32_t zz = pk16(zh, zh);
+    constexpr uint32_t neg = 0x80008000u;
+    o.c2l = u32x4{hh, ll, hh, zz};
+    o.c1l = u32x4{hh ^ neg, ll ^ neg, hh ^ neg, zz ^ neg};
+    o.c2u = u32x4{pk16(zl, k2[0]), pk16(k2[1], k2[2]), 0u, 0u};
+    o.c1u = u32x4{pk16(-zl, k1[0]), pk16(k1[1], k1[2]), 0u, 0u};
+    const bool screened = hs == hs;   // (h = NaN: the record is not screened -- keep its column finite)
+    if (!live || !screened) o.c1l = o.c1u = o.c2l = o.c2u = u32x4{0u, 0u, 0u, 0u};
+    if (!live) hs = 0.0;   // no hypothesis in this lane: zero columns, their verdicts are not read
     o.hs = (float)hs;
     return o;
 }
@@ -137,29 +140,80 @@ __device__ __forceinline__ void swap32(u32x4& a, u32x4& b) {
     }
 }
 
+// one sub-batch: 32 hypotheses (B1, B2) against the tile's 16 blocks; As = the workgroup's A operands in LDS.
+// out: the lane's number of OUTSIDE points among its 256, the smallest |t|
+__device__ __forceinline__ void sub_batch(const u32x4* __restrict__ As, int lane, const h16x8 B1, const h16x8 B2, uint32_t& outside, float& mn_out) {
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t bits = 0, cnt = 0;
+    float mn = __builtin_inff();
+    // The operands never change while the workgroup runs, and an MFMA depends on nothing but its operands: left alone, the
+    // compiler reads all sixteen blocks up front (64 registers) and issues all 32 MFMAs before the first v_mul (512 registers
+    // of results).  The lane's LDS index is therefore laundered through an empty asm that also takes the sign string of the
+    // block finished last: block i + 2's operand cannot be read, and its MFMAs cannot be issued, before block i - 1 is done.
+    uint32_t li = (uint32_t)lane;
+    asm volatile("" : "+v"(li));
+    h16x8 a = __builtin_bit_cast(h16x8, As[li]);
+    f32x16 u1n = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B1, zero16, 0, 0, 0);
+    f32x16 u2n = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B2, zero16, 0, 0, 0);
+    h16x8 an = __builtin_bit_cast(h16x8, As[64 + li]);
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk) {
+        const f32x16 u1 = u1n, u2 = u2n;
+        if (blk < 15) {   // the next block's MFMAs go first: the matrix pipe works under this block's VALU instructions
+            u1n = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, B1, zero16, 0, 0, 0);
+            u2n = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, B2, zero16, 0, 0, 0);
+        }
+        if (blk < 14) {   // ... and the operand of the block after it is requested (bits: the block BEFORE this one is done)
+            asm volatile("" : "+v"(li) : "v"(bits));
+            an = __builtin_bit_cast(h16x8, As[(blk + 2) * 64 + li]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            t[j] = u1[j] * u2[j];
+            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(t[j]), 31);   // t < 0: outside
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(t[j])), __builtin_fabsf(t[j + 1]));
+        if (blk & 1) cnt += (uint32_t)__popc(bits);
+        asm volatile("" : "+v"(mn));   // (a minimum is associative: left alone, the compiler keeps all 256 products for one tree at the end)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    outside = cnt;
+    mn_out = mn;
+}
+
 template <int KIND>
-__global__ __launch_bounds__(64) void score_mfma_k(const double* __restrict__ sx, const double* __restrict__ sy,
-                                                    const double* __restrict__ sz, const double* __restrict__ boxes,
-                                                    double max_abs, const double* __restrict__ score,
-                                                    const unsigned long long* __restrict__ masks,
-                                                    const unsigned long long* __restrict__ keep, uint32_t n_groups,
-                                                    uint32_t groups_per_block /* <= kMfmaMaxGroups */,
-                                                    uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
-                                                    uint32_t* __restrict__ pair_rep, uint32_t group_begin, uint32_t group_end,
-                                                    const float* __restrict__ tile_f32) {
-    static_assert(KIND == 0, "planes only (sphere / cylinder: two quadric columns, not built yet)");
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void score_mfma_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                     const double* __restrict__ sz, const double* __restrict__ boxes,
+                                                     double max_abs, const double* __restrict__ score,
+                                                     const unsigned long long* __restrict__ masks,
+                                                     const unsigned long long* __restrict__ keep, uint32_t n_groups,
+                                                     uint32_t groups_per_block /* <= kMfmaMaxGroups */,
+                                                     uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                     uint32_t* __restrict__ pair_rep, uint32_t group_begin, uint32_t group_end,
+                                                     const float* __restrict__ tile_f32) {
+    static_assert(KIND == 0, "planes only");
     __shared__ uint16_t ids[kMfmaMaxGroups * 64];
+    __shared__ u32x4 As[16 * 64];   // the tile's A operands: [block][lane]
+    __shared__ uint32_t s_total;
     const uint32_t tile = blockIdx.x;
     uint32_t* __restrict__ counts = counts_rep + (size_t)(tile % kCountReplicas) * rep_stride;
     const uint32_t g0 = group_begin + blockIdx.y * groups_per_block;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (the wave's index: uniform, in an SGPR)
     const bool upper = lane >= 32;
+    // every wave looks at the workgroup's mask words itself: a uniform exit without a barrier
     unsigned long long mm = 0;
     if ((uint32_t)lane < groups_per_block && g0 + lane < group_end) mm = masks[(size_t)tile * n_groups + g0 + lane] & keep[g0 + lane];
     if (!__ballot(mm != 0)) return;
-    // ---- the surviving hypotheses' ids (relative to g0), ascending: lane l expands its own word behind the words before it
-    uint32_t total;
-    {
+    double box[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) box[k] = boxes[(size_t)tile * kBoxStride + k];   // (wave-uniform: scalar loads)
+    const int p = mfma_tile_exp(box);
+    const bool tile_screened = boxes[(size_t)tile * kBoxStride + 6] != 0.0 && p != kMfmaNoTile;
+    // ---- wave 0: the surviving hypotheses' ids (relative to g0), ascending: lane l expands its own word behind the words before it
+    if (wave == 0) {
         const uint32_t pc = (uint32_t)__popcll(mm);
         uint32_t incl = pc;
 #pragma unroll
@@ -167,7 +221,7 @@ __global__ __launch_bounds__(64) void score_mfma_k(const double* __restrict__ sx
             const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
             if (lane >= off) incl += t;
         }
-        total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (lane == 63) s_total = incl;
         uint32_t at = incl - pc;
         unsigned long long w = mm;
         while (w) {
@@ -175,13 +229,23 @@ __global__ __launch_bounds__(64) void score_mfma_k(const double* __restrict__ sx
             w &= w - 1ull;
         }
     }
-    __syncthreads();
-    if (lane == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairMain], total);
-    double box[6];
+    // ---- the tile's A operands: block = 32 consecutive lanes of one row of the tile; wave w builds the blocks of row pair w;
+    // tile_f32 holds [coordinate][row pair j][lane] x (row 2 j, row 2 j + 1)
+    if (tile_screened) {
+        const float sig = __builtin_ldexpf(1.0f, p);
+        const f32x2* __restrict__ t2 = reinterpret_cast<const f32x2*>(tile_f32 + (size_t)tile * kTileF32Floats) + (lane & 31);
+        constexpr int Q = kTilePoints / 128;
+        const int j = wave;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) box[k] = boxes[(size_t)tile * kBoxStride + k];   // (wave-uniform: scalar loads)
-    const int p = mfma_tile_exp(box);
-    const bool tile_screened = boxes[(size_t)tile * kBoxStride + 6] != 0.0 && p != kMfmaNoTile;
+        for (int hb = 0; hb < 2; ++hb) {
+            const f32x2 xv = t2[(0 * Q + j) * 64 + hb * 32], yv = t2[(1 * Q + j) * 64 + hb * 32], zv = t2[(2 * Q + j) * 64 + hb * 32];
+            As[(4 * j + hb) * 64 + lane] = a_block(xv.x, yv.x, zv.x, sig, upper);       // row 2 j
+            As[(4 * j + 2 + hb) * 64 + lane] = a_block(xv.y, yv.y, zv.y, sig, upper);   // row 2 j + 1
+        }
+    }
+    __syncthreads();
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_total);
+    if (threadIdx.x == 0) atomicAdd(&pair_rep[(tile + blockIdx.y * 67u) % (uint32_t)kPairMain], total);
     const double* __restrict__ score0 = score + (size_t)g0 * 64u * kModelStride;
     const size_t base = (size_t)tile * kTilePoints + lane;
     constexpr int P = kTilePoints / 64;
@@ -205,103 +269,69 @@ __global__ __launch_bounds__(64) void score_mfma_k(const double* __restrict__ sx
         }
         return c;
     };
-    if (!tile_screened) {   // (wave-uniform) NaN padding / non-finite offsets: every pair of the tile through the exact code
-        for (uint32_t i = 0; i < total; ++i) {
-            const uint32_t id = ids[i];
-            const uint32_t e = exact_count(id);
-            if (lane == 0) {
-                atomicAdd(&pair_rep[(uint32_t)kPairMain + tile % (uint32_t)(kPairLead - kPairMain)], 1u);
-                if (e) atomicAdd(&counts[g0 * 64u + id], e);
-            }
-        }
-        return;
-    }
-    // ---- the tile's A operands: block blk = points blk * 32 .. + 31 = row blk / 2, lanes (blk % 2) * 32 .. of the tile;
-    // tile_f32 holds [coordinate][row pair j][lane] x (row 2 j, row 2 j + 1)
-    u32x4 A0[16], A1[16];
-    {
-        const float sig = __builtin_ldexpf(1.0f, p);
-        const uint32_t cc = upper ? pk16((float)kMfmaConstA, (float)kMfmaConstA) : pk16((float)kMfmaConstA, (float)kMfmaConstA);
-        const f32x2* __restrict__ t2 = reinterpret_cast<const f32x2*>(tile_f32 + (size_t)tile * kTileF32Floats) + (lane & 31);
-        constexpr int Q = kTilePoints / 128;
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                const f32x2 xv = t2[(0 * Q + j) * 64 + hb * 32], yv = t2[(1 * Q + j) * 64 + hb * 32], zv = t2[(2 * Q + j) * 64 + hb * 32];
-                // rows 2 j (component x) and 2 j + 1 (component y); block = 2 row + hb
-                a_block(xv.x, yv.x, zv.x, sig, upper, cc, A0[4 * j + hb], A1[4 * j + hb]);
-                a_block(xv.y, yv.y, zv.y, sig, upper, cc, A0[4 * j + 2 + hb], A1[4 * j + 2 + hb]);
-            }
-        }
-    }
-    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
+    // ---- batches of 64 ids, the waves in turn; the NEXT batch's records are in flight while this one is evaluated
+    auto fetch = [&](uint32_t b0, int& my, double (&rec)[5]) {
         const bool live = b0 + (uint32_t)lane < total;
-        const int my = live ? (int)ids[b0 + lane] : 0;   // lane k: k-th id of the batch
-        BPieces bp = b_record(score0 + (size_t)my * kModelStride, box, max_abs, p, live);
-        // columns 0..31 = hypotheses of lanes 0..31 (sub-batch 0), then those of lanes 32..63 (sub-batch 1)
-        swap32(bp.s0l, bp.s0u);
-        swap32(bp.s1l, bp.s1u);
-        uint32_t hq0 = __float_as_uint(bp.hs), hq1 = hq0;
-        swap32(hq0, hq1);
-        uint32_t result[2];
-        unsigned long long undecided[2];
+        my = live ? (int)ids[b0 + lane] : 0;   // lane k: k-th id of the batch (b0 >= total: id 0, a valid address)
+        const double* __restrict__ rp = score0 + (size_t)my * kModelStride;
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            if (sb == 1 && b0 + 32u >= total) {   // (wave-uniform) no hypothesis in the second half of the batch
-                result[1] = 0;
-                undecided[1] = 0;
-                break;
+        for (int k = 0; k < 5; ++k) rec[k] = rp[k];
+    };
+    int my_n;
+    double rec_n[5];
+    fetch((uint32_t)wave * 64u, my_n, rec_n);
+    for (uint32_t b0 = (uint32_t)wave * 64u; b0 < total; b0 += 256u) {
+        const bool live = b0 + (uint32_t)lane < total;
+        const int my = my_n;
+        uint32_t park = 0;            // lane k: the count of the batch's k-th hypothesis
+        unsigned long long und = 0;   // bit k: it goes to the exact code
+        if (tile_screened) {          // (uniform)
+            BPieces bp = b_record(rec_n, box, max_abs, p, live);
+            fetch(b0 + 256u, my_n, rec_n);
+            // columns 0..31 = hypotheses of lanes 0..31 (sub-batch 0), then those of lanes 32..63 (sub-batch 1)
+            swap32(bp.c1l, bp.c1u);
+            swap32(bp.c2l, bp.c2u);
+            uint32_t hq0 = __float_as_uint(bp.hs), hq1 = hq0;
+            swap32(hq0, hq1);
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                if (sb == 1 && b0 + 32u >= total) break;   // (wave-uniform) no hypothesis in the second half of the batch
+                const h16x8 B1 = __builtin_bit_cast(h16x8, sb ? bp.c1u : bp.c1l), B2 = __builtin_bit_cast(h16x8, sb ? bp.c2u : bp.c2l);
+                const float hq = __uint_as_float(sb ? hq1 : hq0);
+                uint32_t outside;
+                float mn;
+                sub_batch(As, lane, B1, B2, outside, mn);
+                // the two half-waves hold the two halves of the column's 512 points
+                uint32_t oa = outside, ob = outside;
+                swap32(oa, ob);
+                park = (upper == (sb == 1)) ? (uint32_t)kTilePoints - (oa + ob) : park;   // (both half-waves hold the column's total)
+                const unsigned long long u = __ballot(!(mn >= hq));   // (h = NaN: the record is not screened)
+                und |= (unsigned long long)((uint32_t)u | (uint32_t)(u >> 32)) << (32 * sb);
             }
-            const h16x8 B0 = __builtin_bit_cast(h16x8, sb ? bp.s0u : bp.s0l), B1 = __builtin_bit_cast(h16x8, sb ? bp.s1u : bp.s1l);
-            const float hq = __uint_as_float(sb ? hq1 : hq0);
-            uint32_t bits = 0, outside = 0;
-            float mn = __builtin_inff();
-#pragma unroll
-            for (int blk = 0; blk < 16; ++blk) {
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A0[blk]), B0, zero16, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A1[blk]), B1, acc, 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(acc[j]), 31);   // q < 0: outside
-#pragma unroll
-                for (int j = 0; j < 16; j += 2) mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fabsf(acc[j])), __builtin_fabsf(acc[j + 1]));
-                if (blk & 1) outside += (uint32_t)__popc(bits);
-            }
-            // the two half-waves hold the two halves of the column's 512 points
-            uint32_t oa = outside, ob = outside;
-            swap32(oa, ob);
-            result[sb] = (uint32_t)kTilePoints - (oa + ob);
-            undecided[sb] = __ballot(!(mn >= hq));   // (h = NaN: the record is not screened)
+            und &= __ballot(live);
+        } else {   // NaN padding / non-finite offsets: every pair of the tile through the exact code
+            fetch(b0 + 256u, my_n, rec_n);
+            und = __ballot(live);
         }
-        // hypotheses the screen could not decide: the exact code (rare)
-        uint32_t park = 0;   // lane n < 32: sub-batch 0's hypothesis n; lane 32 + n: sub-batch 1's
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            uint32_t und = ((uint32_t)undecided[sb] | (uint32_t)(undecided[sb] >> 32));
-            const uint32_t n_here = min(32u, total - min(total, b0 + 32u * (uint32_t)sb));
-            und &= n_here >= 32u ? 0xFFFFFFFFu : ((1u << n_here) - 1u);
-            const uint32_t r = result[sb];
-            park = (upper == (sb == 1)) ? r : park;   // (both half-waves hold the column's total)
-            while (und) {   // wave-uniform
-                const uint32_t n = (uint32_t)__builtin_ctz(und);
-                und &= und - 1u;
-                const uint32_t e = exact_count((uint32_t)__builtin_amdgcn_readlane(my, (int)(32u * (uint32_t)sb + n)));
-                if (lane == 0) atomicAdd(&pair_rep[(uint32_t)kPairMain + tile % (uint32_t)(kPairLead - kPairMain)], 1u);
-                park = ((uint32_t)lane == 32u * (uint32_t)sb + n) ? e : park;
-            }
+        while (und) {   // wave-uniform; rare on screened tiles
+            const uint32_t n = (uint32_t)__builtin_ctzll(und);
+            und &= und - 1ull;
+            const uint32_t e = exact_count((uint32_t)__builtin_amdgcn_readlane(my, (int)n));
+            if (lane == 0) atomicAdd(&pair_rep[(uint32_t)kPairMain + tile % (uint32_t)(kPairLead - kPairMain)], 1u);
+            park = ((uint32_t)lane == n) ? e : park;
         }
         if (live && park) atomicAdd(&counts[g0 * 64u + (uint32_t)my], park);
     }
 }
 
-// ---- test probe (m3d_bench_mfma_probe): the screen's value for ONE tile of 512 points and n_h plane records, as the
-// production kernel's own device functions produce it -- q_pipe / Sigma_h per (hypothesis, point) and the unscaled band h --
-// so that a test can hold them against q~ = T^2 - S~^2 evaluated in exact arithmetic (tests/test_gpu_mfma_screen.py).
+// ---- test probe (m3d_bench_mfma_probe): the screen's values for ONE tile of 512 points and n_h plane records, as the
+// production kernel's own device functions produce them -- u1 / Sigma_h, u2 / Sigma_h per (hypothesis, point), the band on
+// their product and E_p -- so that a test can hold them against T -+ S~ evaluated in exact arithmetic
+// (tests/test_gpu_mfma_screen.py).
 __global__ __launch_bounds__(64) void mfma_probe_k(const double* __restrict__ pts /* 512 x 3 */, const double* __restrict__ boxp /* 6 */,
                                                    double max_abs, const double* __restrict__ recs /* n_h x kModelStride */,
-                                                   uint32_t n_h, double* __restrict__ out_q /* n_h x 512 */,
-                                                   double* __restrict__ out_h /* n_h x 2: h, Sigma_h */,
+                                                   uint32_t n_h, double* __restrict__ out_u /* n_h x 512 x 2 */,
+                                                   double* __restrict__ out_h /* n_h x 3: h (on t, unscaled), Sigma_h, E_p */,
                                                    float* __restrict__ out_off /* 512 x 3: the fp32 offsets */) {
     const int lane = threadIdx.x;
     const bool upper = lane >= 32;
@@ -311,8 +341,7 @@ __global__ __launch_bounds__(64) void mfma_probe_k(const double* __restrict__ pt
     const int p = mfma_tile_exp(box);
     if (p == kMfmaNoTile) return;
     const float sig = __builtin_ldexpf(1.0f, p);
-    const uint32_t cc = pk16((float)kMfmaConstA, (float)kMfmaConstA);
-    u32x4 A0[16], A1[16];
+    u32x4 A[16];
 #pragma unroll
     for (int blk = 0; blk < 16; ++blk) {   // block blk = points 32 blk .. 32 blk + 31
         const int pt = blk * 32 + (lane & 31);
@@ -322,38 +351,42 @@ __global__ __launch_bounds__(64) void mfma_probe_k(const double* __restrict__ pt
             out_off[pt * 3 + 1] = y;
             out_off[pt * 3 + 2] = z;
         }
-        a_block(x, y, z, sig, upper, cc, A0[blk], A1[blk]);
+        A[blk] = a_block(x, y, z, sig, upper);
     }
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t b0 = 0; b0 < n_h; b0 += 64u) {
         const bool live = b0 + (uint32_t)lane < n_h;
         const uint32_t my = live ? b0 + (uint32_t)lane : 0u;
-        BPieces bp = b_record(recs + (size_t)my * kModelStride, box, max_abs, p, live);
+        double rec[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) rec[k] = recs[(size_t)my * kModelStride + k];
+        BPieces bp = b_record(rec, box, max_abs, p, live);
+        const double sg = kMfmaCoef * __builtin_ldexp(1.0, p);   // the pipe's unit
         if (live) {
-            double b[10], hs, sg = 0.0;
-            plane_quadric_record(recs + (size_t)my * kModelStride, box, max_abs, p, b, &hs, &sg);
-            out_h[2 * my] = hs / sg;   // (NaN stays NaN)
-            out_h[2 * my + 1] = sg;
+            double k2[2], hs, ep = 0.0;
+            plane_mfma_record(rec, box, max_abs, p, k2, &hs, &ep);
+            out_h[3 * my] = (hs / sg) / sg;   // (NaN stays NaN)
+            out_h[3 * my + 1] = sg;
+            out_h[3 * my + 2] = ep;
         }
-        swap32(bp.s0l, bp.s0u);
-        swap32(bp.s1l, bp.s1u);
+        swap32(bp.c1l, bp.c1u);
+        swap32(bp.c2l, bp.c2u);
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
-            const h16x8 B0 = __builtin_bit_cast(h16x8, sb ? bp.s0u : bp.s0l), B1 = __builtin_bit_cast(h16x8, sb ? bp.s1u : bp.s1l);
+            const h16x8 B1 = __builtin_bit_cast(h16x8, sb ? bp.c1u : bp.c1l), B2 = __builtin_bit_cast(h16x8, sb ? bp.c2u : bp.c2l);
             const uint32_t hyp = b0 + 32u * (uint32_t)sb + (uint32_t)(lane & 31);
-            double sg = 1.0;
-            if (hyp < n_h) {
-                double b[10], hs;
-                plane_quadric_record(recs + (size_t)hyp * kModelStride, box, max_abs, p, b, &hs, &sg);
-            }
 #pragma unroll
             for (int blk = 0; blk < 16; ++blk) {
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A0[blk]), B0, zero16, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, A1[blk]), B1, acc, 0, 0, 0);
+                const h16x8 a = __builtin_bit_cast(h16x8, A[blk]);
+                const f32x16 u1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B1, zero16, 0, 0, 0);
+                const f32x16 u2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B2, zero16, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int row = (j & 3) + 8 * (j >> 2) + (upper ? 4 : 0);
-                    if (hyp < n_h) out_q[(size_t)hyp * 512 + blk * 32 + row] = (double)acc[j] / sg;
+                    if (hyp < n_h) {
+                        out_u[((size_t)hyp * 512 + blk * 32 + row) * 2] = (double)u1[j] / sg;
+                        out_u[((size_t)hyp * 512 + blk * 32 + row) * 2 + 1] = (double)u2[j] / sg;
+                    }
                 }
             }
         }
@@ -373,7 +406,7 @@ bool launch_score_mfma(int kind, const SortedView& s, const double* score, const
     if (!s.n_tiles || group_begin >= group_end) return true;
     const uint32_t window = group_end - group_begin;
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)config().score_mfma_groups, kMfmaMaxGroups));
-    const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);
+    const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(256);
     if (ev_start && ev_stop)
         hipExtLaunchKernelGGL(score_mfma_k<0>, g, b, 0, st, ev_start, ev_stop, 0, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep,
                               n_groups, gpb, counts_rep, rep_stride, pair_rep, group_begin, group_end, (const float*)s.tile_f32);

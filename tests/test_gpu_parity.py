@@ -20,7 +20,8 @@ def _bits(a):
 # the scoring paths m3d_config selects between; they must be indistinguishable from outside
 PATHS = {"culled": {}, "dense": {"dense_scoring": 1}, "no_early_pick": {"speculative_refine": 0},
          "small_blocks": {"score_groups_per_block": 1, "lead_hypotheses": 64},
-         "fp64_only": {"score_fp32_screen": 0, "cull_fp32": 0}}
+         "fp64_only": {"score_fp32_screen": 0, "cull_fp32": 0},
+         "mfma": {"score_mfma": 1}}   # planes: score_mfma_k, the screen on the matrix pipe
 
 
 @pytest.fixture(params=sorted(PATHS))
@@ -28,7 +29,8 @@ def scoring_path(request, capi):
     """Runs the test once per scoring path: the production culled path (cull_tiles_k + score_screen_k / score_mask_k
     with the device's early pick), the dense kernel (score_k: every tile x every hypothesis; the bench's reference
     point), the culled path without the speculative RefineModel, the culled path with one hypothesis group per
-    workgroup, and the culled path without any fp32 (fp64 box tests cull_tiles_k, score_mask_k for every model)."""
+    workgroup, the culled path without any fp32 (fp64 box tests cull_tiles_k, score_mask_k for every model), and the
+    culled path with the planes' screen on the matrix pipe (score_mfma_k)."""
     old = capi.set_config(**PATHS[request.param])
     yield request.param
     capi.restore_config(old)

@@ -1,8 +1,8 @@
 """The MFMA screen's values on hand-made tiles against exact arithmetic (run on the GPU box).
 
-q~ = T^2 - (alpha . x~ + D)^2 is evaluated with python Fractions on the fp32 offsets the kernel reports (so the comparison
-isolates the matrix pipe and the operand pieces); prints the worst |q_pipe - q~| in units of the record's band h, the
-fraction of (point, hypothesis) values inside the band, and what a tight band would have been.
+T -+ S~, S~ = alpha . x~ + D, is evaluated with python Fractions on the fp32 offsets the kernel reports (so the comparison
+isolates the matrix pipe and the operand pieces); prints the worst |u_i - (T -+ S~)| in units of the record's bound E_p, the
+fraction of (point, hypothesis) products inside the band, and wrong verdicts among the decided ones (must be 0).
 """
 import sys
 from fractions import Fraction
@@ -26,31 +26,29 @@ def tile(rng, extent, centre, flat=None):
 
 
 def run(name, pts, box, recs, max_abs):
-    q, h, sg, off = capi.mfma_probe(pts, box, max_abs, recs)
+    u, h, sg, ep, off = capi.mfma_probe(pts, box, max_abs, recs)
     worst = 0.0
-    inband = 0
-    decided_wrong = 0
-    n = 0
-    tight = []
+    inband = decided_wrong = n = 0
     for k, (a, b, c, d, T) in enumerate(recs):
         if not np.isfinite(h[k]):
             print(f"  record {k}: not screened")
             continue
-        D = Fraction(a) * Fraction(box[0]) + Fraction(b) * Fraction(box[1]) + Fraction(c) * Fraction(box[2]) + Fraction(d)
-        # (the kernel's D is the fp64 rounding of this; the difference is part of E_in, far below the band)
-        for i in range(0, 512, 7):
-            S = Fraction(a) * Fraction(float(off[i, 0])) + Fraction(b) * Fraction(float(off[i, 1])) + Fraction(c) * Fraction(float(off[i, 2])) + D
-            qe = float(Fraction(T) ** 2 - S * S)
-            err = abs(q[k, i] - qe)
-            worst = max(worst, err / h[k])
-            tight.append(err)
-            if abs(q[k, i]) < h[k]:
+        D = float(Fraction(a) * Fraction(box[0]) + Fraction(b) * Fraction(box[1]) + Fraction(c) * Fraction(box[2]) + Fraction(d))
+        # (the kernel's D: the fp64 evaluation of the same; the difference is part of E_in)
+        for i in range(0, 512, 5):
+            S = Fraction(a) * Fraction(float(off[i, 0])) + Fraction(b) * Fraction(float(off[i, 1])) + Fraction(c) * Fraction(float(off[i, 2])) + Fraction(D)
+            e1 = abs(u[k, i, 0] - float(Fraction(T) - S))
+            e2 = abs(u[k, i, 1] - float(Fraction(T) + S))
+            worst = max(worst, e1 / ep[k], e2 / ep[k])
+            t = u[k, i, 0] * u[k, i, 1]
+            if abs(t) < h[k]:
                 inband += 1
-            elif (q[k, i] > 0) != (qe > 0):
+            elif (t > 0) != (abs(S) < T):
                 decided_wrong += 1
             n += 1
-    print(f"{name}: worst |q_pipe - q~| = {worst:.4f} h   in-band {inband}/{n} = {inband / max(n, 1):.4%}   wrong verdicts {decided_wrong}"
-          f"   median h/T^2 = {np.nanmedian(h / np.asarray(recs)[:, 4] ** 2):.3e}   max err / T^2 = {max(tight) / recs[0][4] ** 2:.3e}")
+    T = recs[0][4]
+    print(f"{name}: worst |u - (T -+ S~)| = {worst:.4f} E_p   in-band {inband}/{n} = {inband / max(n, 1):.4%}   wrong verdicts {decided_wrong}"
+          f"   median band in distance h / 2T = {np.nanmedian(h) / (2 * T):.3e} (T = {T})")
 
 
 def main():

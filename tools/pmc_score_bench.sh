@@ -19,7 +19,7 @@ n = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(out + "/g*/r_counter_collection.csv") + glob.glob(out + "/g*/*/r_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "score_screen_k" not in k and "cull_lead_k" not in k:
+        if "score_screen_k" not in k and "cull_lead_k" not in k and "score_mfma_k" not in k:
             continue
         key = (k, r["Grid_Size"])
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
