@@ -21,9 +21,11 @@ JSON objects besides the contract's fields:
                Instructions per (point, hypothesis): 3.625 for the plane's packed-fp32 screen (29 per lane and hypothesis for
                the lane's 8 points: 16 v_pk_fma, 8 v_alignbit, 4 v_min3, v_cmp -- the ISA of the loop, not an
                estimate; the fp64 loop it replaced: 7), 4.125 for the sphere (33 per 8 points in the expanded form; fp64: 10), 6.125 for the cylinder (49; fp64: 22).
-               peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T lane-instructions/s: a wave64 VALU instruction
-               (fp64, fp32, packed fp32 or integer alike) occupies its SIMD for 4 cycles.  `traffic` = HBM bytes per launch from the PMC pass under
-               profiles/.  `algorithmic_reuse` restates SURVEY.md 8(d)'s 24 B/(hypothesis, point) figure: it is far
+               `frac` = the SIMD cycles the loop's instructions need at their MEASURED issue cost per class (peak_model:
+               v_pk_fma_f32 4.20, v_alignbit 4.13, v_min3 4.15, v_cmp 4.21 cycles per wave instruction -- tools/ubench/valu_rates.hip,
+               profiles/r04_ubench_valu_rates.txt; nothing in these loops issues in 2) over the cycles the launch had on 1024 SIMDs at 2.4 GHz;
+               `peak` = the lane-instruction rate that corresponds to.  `traffic` = HBM bytes per launch from the committed PMC pass
+               (`traffic_source`: counters cannot be collected inside a timed run).  `algorithmic_reuse` restates SURVEY.md 8(d)'s 24 B/(hypothesis, point) figure: it is far
                above the HBM peak because a point load is re-used from VGPRs by every hypothesis of a launch and most
                pairs are never touched -- not an HBM-bound kernel, so it is NOT the roofline.
   cpu_baseline the oracle's reference-shaped OpenMP port timed on this box's host cores (bounded sample), plus the
@@ -63,7 +65,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (non-FMA ops; FMA peak 78.6 TF)
+FP64_VALU_PEAK_TOPS = 39.3     # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (non-FMA ops; FMA peak 78.6 TF): 4 cycles per wave instruction
+# What a wave64 instruction of each class costs its SIMD, measured (tools/ubench/valu_rates.hip, 8 waves per SIMD, launch wall
+# time at the sustained clock: profiles/r04_ubench_valu_rates.txt).  VERDICT r3 asked whether the plain fp32 / integer
+# instructions issue in 2 cycles (MI355X_MICROARCH.md's v_fma_f32 row): they do not -- every VOP3-encoded instruction takes ~4.15,
+# only 32-bit-encoded VOP2 integer / mul / add reach 2.3, and the scoring loops contain none of those.
+CLASS_CYCLES = {"v_pk_fma_f32": 4.20, "v_pk_add_f32": 4.14, "v_alignbit_b32": 4.13, "v_min3_f32": 4.15, "v_cmp_f32": 4.21,
+                "v_lshrrev_b32": 2.27, "v_mul_f32_e32": 2.31, "f64": 4.17, "v_cmp_f64": 4.19}
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+# instructions per hypothesis and lane (8 points) of the loops, as the ISA has them (m3d_cull_kernels.hip, screen_eval / tile_count)
+MIX_SCREEN = {0: {"v_pk_fma_f32": 16, "v_alignbit_b32": 8, "v_min3_f32": 4, "v_cmp_f32": 1},
+              1: {"v_pk_fma_f32": 16, "v_pk_add_f32": 4, "v_alignbit_b32": 7, "v_min3_f32": 4, "v_cmp_f32": 1, "v_lshrrev_b32": 1},
+              2: {"v_pk_fma_f32": 36, "v_alignbit_b32": 8, "v_min3_f32": 4, "v_cmp_f32": 1}}
+MIX_FP64 = {0: {"f64": 48, "v_cmp_f64": 8}, 1: {"f64": 64, "v_cmp_f64": 16}, 2: {"f64": 160, "v_cmp_f64": 16}}
+
+
+def peak_model(mix):
+    """(instructions per 8 points, SIMD cycles per 8 points, the per-class table) of an instruction mix"""
+    n = sum(mix.values())
+    cyc = sum(k * CLASS_CYCLES[c] for c, k in mix.items())
+    return n, cyc, {c: {"per_8_points": k, "cycles": CLASS_CYCLES[c]} for c, k in mix.items()}
 ALG_BYTES_PER_PAIR = 24.0      # one fp64 xyz read per (hypothesis, point), SURVEY.md 8(d)
 VALU_OPS_FP64 = {0: 7, 1: 10, 2: 22}      # fp64 VALU instructions per (point, hypothesis) incl. compares: score_mask_k, score_k
 VALU_OPS_SCREEN = {0: 3.625, 1: 4.125, 2: 6.125}     # score_screen_k: packed-fp32 screen (m3d_cull_kernels.hip): 29 / 33 / 49 instructions per 8 points
@@ -107,13 +128,17 @@ def respawn_ranks(n):
 
 
 def load_pmc_traffic():
-    """HBM bytes per score_mask_k launch from the committed PMC pass (profiles/pmc_score_latest.json)."""
+    """(HBM bytes per scoring launch, where the number comes from): the committed PMC pass profiles/pmc_score_latest.json --
+    counters cannot be collected inside a timed run, so `roofline.traffic` is NOT measured by this process."""
     p = os.path.join(ROOT, "profiles", "pmc_score_latest.json")
     try:
         with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            d = json.load(f)
+        return d.get("hbm_bytes_per_launch"), {"file": "profiles/pmc_score_latest.json", "kernel": d.get("kernel"),
+                                                "measured_at_commit": d.get("measured_at_commit"), "command": d.get("command"),
+                                                "corrections": d.get("corrections")}
     except Exception:
-        return None
+        return None, None
 
 
 def usable_cpus():
@@ -363,7 +388,8 @@ def main():
                                    "reference's arithmetic instruction for instruction (score_mask_k, cull_tiles_k)",
                          "identical_result": bool(same64),
                          "roofline": {"bound": "valu-issue", "kernel": KERNEL_FP64[kind], "achieved": v64,
-                                      "peak": FP64_VALU_PEAK_TOPS, "frac": v64 / FP64_VALU_PEAK_TOPS,
+                                      "peak": SIMDS * 64.0 * CLOCK_HZ / (peak_model(MIX_FP64[kind])[1] / peak_model(MIX_FP64[kind])[0]) / 1e12,
+                                      "frac": f_pairs * peak_model(MIX_FP64[kind])[1] / (f_ms * 1e-3 * SIMDS * CLOCK_HZ),
                                       "ops_per_pair": VALU_OPS_FP64[kind], "launch_ms": f_ms / max(f_launch, 1),
                                       "launches_per_step": f_launch / float(a.steps),
                                       "tile_hypothesis_pairs_per_step": f_pairs / float(a.steps)}}
@@ -466,7 +492,7 @@ def main():
     if rank == 0:
         n_in = len(res.inliers)
         n_tiles = -(-N // 512)
-        traffic = load_pmc_traffic() if a.workload == "c2" else None
+        traffic, traffic_source = load_pmc_traffic() if a.workload == "c2" else (None, None)
         k_ms = k_ms_sum / max(k_launches, 1)
         h_rank = H_total / world                                  # hypotheses this rank scores per step
         h_per_launch = h_rank * a.steps / max(k_launches, 1)
@@ -476,9 +502,19 @@ def main():
         v_tops = k_pairs * 512.0 * ops / (k_ms_sum * 1e-3) / 1e12
         alg_bytes = h_per_launch * float(N) * ALG_BYTES_PER_PAIR
         alg_rate = alg_bytes / (k_ms * 1e-3) / 1e9
-        roofline = {"bound": "valu-issue", "kernel": kname, "achieved": v_tops, "peak": FP64_VALU_PEAK_TOPS,
-                    "unit": "T lane-instructions/s (VALU issue)", "frac": v_tops / FP64_VALU_PEAK_TOPS,
-                    "traffic": traffic, "launch_ms": k_ms, "launches_timed": k_launches,
+        # the peak is priced per instruction class: a (tile, hypothesis) pair costs its wave the loop's
+        # instruction mix once; the SIMD cycles that takes at the measured issue costs, over the cycles the launch had
+        n_mix, cyc_mix, mix_table = peak_model((MIX_SCREEN if screened else MIX_FP64)[kind])
+        peak_tops = SIMDS * 64.0 * CLOCK_HZ / (cyc_mix / n_mix) / 1e12
+        frac = k_pairs * cyc_mix / (k_ms_sum * 1e-3 * SIMDS * CLOCK_HZ)
+        roofline = {"bound": "valu-issue", "kernel": kname, "achieved": v_tops, "peak": peak_tops,
+                    "unit": "T lane-instructions/s (VALU issue)", "frac": frac,
+                    "peak_model": {"instructions_per_8_points": n_mix, "simd_cycles_per_8_points": cyc_mix, "classes": mix_table,
+                                   "simds": SIMDS, "clock_hz": CLOCK_HZ,
+                                   "source": "profiles/r04_ubench_valu_rates.txt (tools/ubench/valu_rates.hip: cycles per wave "
+                                             "instruction per SIMD, 8 waves per SIMD, at the sustained clock)",
+                                   "frac_if_every_instruction_took_4_cycles": v_tops / FP64_VALU_PEAK_TOPS},
+                    "traffic": traffic, "traffic_source": traffic_source, "launch_ms": k_ms, "launches_timed": k_launches,
                     "hypotheses_per_launch": h_per_launch, "ops_per_pair": ops,
                     "arithmetic": ("packed fp32 screen with a rounding bound (v_pk_fma_f32), exact fp64 recount of the undecided pairs"
                                    if screened else "fp64"),
@@ -491,6 +527,8 @@ def main():
                               "runs the box tests: their pairs (pairs_outside_the_timed_launches) and its time are not in this object",
                     "algorithmic_reuse": {
                         "bytes_per_launch": alg_bytes, "rate_GBps": alg_rate, "x_hbm_peak": alg_rate / HBM_PEAK_GBS,
+                        "inlier_score_GBps_whole_step": H_total * float(N) * ALG_BYTES_PER_PAIR * a.steps / dt / 1e9,
+                        "hypotheses": "disposed of: scored, or pruned by a bound that proves they cannot win (their records are then 0)",
                         "note": "24 B x hypotheses x points of a launch / launch time (what EvaluateModel streams on the "
                                 "CPU).  Exceeds the HBM peak BY CONSTRUCTION: each point load is re-used from VGPRs by "
                                 "all hypotheses of the launch, box-culled (tile, hypothesis) pairs and pruned hypotheses "
@@ -521,10 +559,10 @@ def main():
             roofline["cull_kernel_ms"] = cull_ms
             roofline["dense_kernel"] = {"kernel": f"m3d::score_k<{kind}>", "launch_ms": dense_ms,
                                         "frac": dense_tops / FP64_VALU_PEAK_TOPS}
-        out = {"metric": "RANSAC hypotheses/sec disposed of (scored or exactly pruned; fit on a 1M-pt cloud)",
+        out = {"metric": "RANSAC hypotheses/sec, 1M-pt cloud (inlier-score GB/s: roofline.algorithmic_reuse)",
                "value": value, "unit": "hypotheses/s",
                "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+               "higher_is_better": True, "scaling": (a.scaling if world > 1 else "none"), "vs_baseline": None,
                "dtype": ("f64 decisions (fp32 screen + fp64 recount)" if screened else "f64"),
                "data": "synthetic",
                "config": {"workload": label, "points": N, "hypotheses_per_gpu": H_total / world,
@@ -534,7 +572,6 @@ def main():
                                           ("single GPU through the sharded driver (world-1 RCCL communicator)" if comm
                                            else "single GPU")),
                           "setup_fits_before_warmup": PRIMING_FITS},
-               "inlier_score_GBps": H_total * float(N) * ALG_BYTES_PER_PAIR * a.steps / dt / 1e9,
                "result": {"best_index": int(res.stats["best_index"]), "n_inliers": int(n_in),
                           "params": [float(v) for v in res.params]},
                "roofline": roofline,

@@ -5,6 +5,8 @@
 // takes a non-owning CloudView, constructible from misc3d::PointCloud below (same member names as
 // Open3D's class) or, with MISC3D_WITH_OPEN3D defined, directly from an Open3D cloud without a copy.
 #pragma once
+#include "../misc3d_amd.h"
+
 #include <array>
 #include <cstddef>
 #include <vector>
@@ -65,5 +67,45 @@ struct CloudView {
           n(pc.points_.size()) {}
 #endif
 };
+
+// ---- page-locked scratch of the host mirrors ---------------------------------------------------------------------------------
+// Large results (index lists, gathered cluster points) land in page-locked blocks the CALLING THREAD keeps between calls: the
+// kernels store into them directly and the next call of the same size pins nothing.  Retention is bounded: a block
+// is given back when a request needs less than a quarter of it, a thread keeps at most kHostScratchBudget bytes, and
+// ReleaseHostScratch() frees the calling thread's blocks at once (a long-lived host calls it after its last big cloud).
+namespace detail {
+constexpr size_t kHostScratchBudget = (size_t)1 << 30;   // 1 GiB of page-locked memory per thread, at most
+struct PinnedScratch {
+    void* p = nullptr;
+    size_t cap = 0;
+    void release() {
+        if (p) m3d_host_free(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // nullptr: over the budget or the allocation failed -- the caller falls back to pageable memory
+    void* get(size_t bytes) {
+        if (bytes > kHostScratchBudget) {
+            release();
+            return nullptr;
+        }
+        if (bytes > cap || (cap > ((size_t)64 << 20) && bytes < cap / 4)) {
+            release();
+            p = m3d_host_alloc(bytes);
+            cap = p ? bytes : 0;
+        }
+        return p;
+    }
+    // (no destructor: a thread-local of the main thread dies at process exit, possibly after the HIP runtime)
+};
+inline PinnedScratch& host_scratch(int which) {   // 0: index lists, 1: gathered points
+    static thread_local PinnedScratch s[2];
+    return s[which & 1];
+}
+}  // namespace detail
+inline void ReleaseHostScratch() {
+    detail::host_scratch(0).release();
+    detail::host_scratch(1).release();
+}
 
 }  // namespace misc3d

@@ -66,6 +66,7 @@ public:
                    const std::pair<std::vector<size_t>, std::vector<size_t>>& corres) const {
         if (corres.first.size() != corres.second.size()) LogError("correspondence lists differ in length");
         Matrix4d T;
+        if (!want_stats_) stats_ = m3d_reg_stats{};   // (not an earlier call's values)
         CheckStatus(m3d_registration_ransac(src.xyz, src.n, dst.xyz, dst.n, corres.first.data(),
                                             corres.second.data(), corres.first.size(), threshold_, max_iter_,
                                             edge_length_threshold_, confidence_, has_seed_ ? &seed_ : nullptr,

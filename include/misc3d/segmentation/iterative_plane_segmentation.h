@@ -39,20 +39,8 @@ inline std::vector<PlaneCluster> SegmentPlaneIterativeIndexed(const CloudView& p
     std::vector<size_t> offsets(max_clusters + 1);
     // Large clouds: index lists and gathered points land in page-locked scratch this thread keeps (the kernels store the
     // lists straight into it, the points arrive at the host link's rate), and are copied into the clusters from there.
-    struct PinnedScratch {
-        void* p = nullptr;
-        size_t cap = 0;
-        void* get(size_t bytes) {
-            if (bytes > cap) {
-                if (p) m3d_host_free(p);
-                p = m3d_host_alloc(bytes);
-                cap = p ? bytes : 0;
-            }
-            return p;
-        }
-        // (no destructor: a thread-local of the main thread dies at process exit, possibly after the HIP runtime)
-    };
-    static thread_local PinnedScratch pin_idx, pin_pts;
+    // Bounded and releasable: detail::PinnedScratch / misc3d::ReleaseHostScratch (geometry.h).
+    detail::PinnedScratch &pin_idx = detail::host_scratch(0), &pin_pts = detail::host_scratch(1);
     const bool big = pcd.n >= ((size_t)1 << 17);
     std::vector<size_t> indices_pageable;
     size_t* indices = big ? static_cast<size_t*>(pin_idx.get(sizeof(size_t) * pcd.n)) : nullptr;

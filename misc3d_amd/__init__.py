@@ -38,6 +38,7 @@ registration = _ext.registration
 segmentation = _ext.segmentation
 VerbosityLevel = _ext.VerbosityLevel
 set_verbosity_level = _ext.set_verbosity_level
+release_host_scratch = _ext.release_host_scratch   # frees the page-locked blocks kept between calls ("Page-locked memory")
 get_verbosity_level = _ext.get_verbosity_level
 device_count = _ext.device_count
 Error, Warning, Info, Debug = (VerbosityLevel.Error, VerbosityLevel.Warning, VerbosityLevel.Info,

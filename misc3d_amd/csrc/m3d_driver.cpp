@@ -2029,8 +2029,10 @@ static int one_shot_fit(int kind, const double* xyz, const double* normals, size
     // themselves from about a thousand hypotheses on: a call that cannot run more -- the README's fit_plane(pcd, 0.01,
     // 100), the default 1000 with the adaptive stop (a few dozen iterations on a cloud with a dominant plane) -- gets a
     // cloud without them and the dense scoring kernel (identical results: tests/test_gpu_parity.py runs both paths).
-    // 1 M points, defaults: 0.84 -> 0.67 ms.
-    const bool few = max_iter <= 1024;
+    // 1 M points, defaults: 0.84 -> 0.67 ms.  With probability 1 every one of the max_iter hypotheses is a full fp64 pass over the
+    // cloud (4.9 T pairs/s): beyond ~2e9 pairs -- 2 M points x 1000 -- the sort (0.2 ms per million points) is the cheaper
+    // way even for a thousand hypotheses (the cut-over was on max_iter alone).
+    const bool few = max_iter <= 1024 && (prob < 1.0 || (double)n * (double)max_iter <= 2.0e9);
     m3d_cloud* c = m3d_cloud_create_impl(xyz, normals, n, device, few ? 0 : 1);
     if (!c) return M3D_ERR_DEVICE;
     const int rc = m3d_cloud_fit(c, kind, thr, max_iter, prob, seed, params, inliers, n_inliers, stats);

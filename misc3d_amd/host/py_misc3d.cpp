@@ -87,34 +87,30 @@ py::array_t<double> to_mat4(const misc3d::Matrix4d& T) {
     return a;
 }
 
-// page-locked scratch for index lists, one per thread, grown on demand: the library's compaction kernel stores the list
-// straight into it (a pageable destination is reached through a staged copy into pages that fault on first touch)
-struct PinnedScratch {
-    size_t* p = nullptr;
-    size_t cap = 0;
-    size_t* get(size_t n) {
-        if (n > cap) {
-            if (p) m3d_host_free(p);
-            p = static_cast<size_t*>(m3d_host_alloc(sizeof(size_t) * n));
-            cap = p ? n : 0;
-        }
-        return p;
-    }
-    // (no destructor: a thread-local object of the main thread dies at process exit, possibly after the HIP runtime)
-};
-
 // Page-locked result blocks for calls that return hundreds of megabytes (segment_plane_iterative's cluster clouds): taken
-// from / given back to a pool of at most two free blocks (a loop that rebinds its result keeps two alive in turn), so a
-// steady caller pins nothing after its second call.  Never destroyed (capsules may outlive the module at exit).
+// from / given back to a pool of at most TWO free blocks and kPoolBudget bytes (a loop that rebinds its result keeps one
+// generation alive while the next is produced), so a steady caller pins nothing after its second call and an idle process
+// holds at most that much (it was four blocks, ~900 MB after one 10 M-point room); release_host_scratch() empties
+// the pool.  Never destroyed (capsules may outlive the module at exit).
 struct PinnedPool {
     struct Block {
         void* p;
         size_t bytes;
     };
+    static constexpr size_t kPoolBudget = (size_t)512 << 20;
     struct State {
         std::mutex mu;
         std::vector<Block> free_blocks, live;
     };
+    static void release_free() {
+        State& st = state();
+        std::vector<Block> drop;
+        {
+            std::lock_guard<std::mutex> lock(st.mu);
+            drop.swap(st.free_blocks);
+        }
+        for (const Block& b : drop) m3d_host_free(b.p);
+    }
     static State& state() {
         static State* s = new State();
         return *s;
@@ -152,7 +148,9 @@ struct PinnedPool {
                     st.live.erase(st.live.begin() + (long)i);
                     break;
                 }
-            if (st.free_blocks.size() < 4) {   // (two result arrays x two generations)
+            size_t held = b.bytes;
+            for (const Block& f : st.free_blocks) held += f.bytes;
+            if (st.free_blocks.size() < 2 && held <= kPoolBudget) {   // (the two result arrays of one generation)
                 st.free_blocks.push_back(b);
             } else {
                 drop = p;
@@ -173,7 +171,7 @@ py::tuple fit_impl(const py::object& pc, double threshold, size_t max_iteration,
     if (KIND == M3D_CYLINDER && !c.has_normals) misc3d::LogError("Fit cylinder requires normals.");  // py_common.cpp:50-52
     const misc3d::CloudView v = c.view();
     std::vector<double> params(KIND == M3D_CYLINDER ? 7 : 4, 0.0);
-    static thread_local PinnedScratch scratch;
+    misc3d::detail::PinnedScratch& scratch = misc3d::detail::host_scratch(0);   // (bounded, releasable: geometry.h)
     std::vector<size_t> pageable;
     size_t* idx = nullptr;
     size_t ni = 0;
@@ -181,7 +179,7 @@ py::tuple fit_impl(const py::object& pc, double threshold, size_t max_iteration,
     int rc;
     {
         py::gil_scoped_release nogil;  // the reference holds the GIL; releasing it is unobservable
-        idx = scratch.get(v.n ? v.n : 1);
+        idx = static_cast<size_t*>(scratch.get(sizeof(size_t) * (v.n ? v.n : 1)));
         if (!idx) {   // (pinning failed: any host buffer will do)
             pageable.resize(v.n ? v.n : 1);
             idx = pageable.data();
@@ -226,12 +224,21 @@ arr_d as_descriptor_matrix(const py::object& f) {
 // index lists of the reference's API (std::vector<size_t> <-> python list): a numpy integer array is taken by one memcpy
 // instead of an element-by-element conversion (94 k correspondences: 2.7 ms of a 4.1 ms compute_transformation_ransac call)
 static std::vector<size_t> to_index_vector(const py::handle& o) {
+    // (an ndarray must hold integers, and no negative ones: forcecast would truncate floats and wrap -1 to 2^64 - 1 --
+    // ADVICE r3; the reference's vector<size_t> conversion raises for both)
     if (py::isinstance<py::array>(o)) {
-        auto a = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(py::reinterpret_borrow<py::object>(o));
+        const py::array arr = py::reinterpret_borrow<py::array>(o);
+        const char kind = arr.dtype().kind();
+        if (kind != 'i' && kind != 'u') throw py::type_error("correspondence indices must be integers");
+        auto a = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(arr);
         if (a && a.ndim() == 1) {
             std::vector<size_t> v((size_t)a.shape(0));
             static_assert(sizeof(size_t) == sizeof(int64_t), "size_t is 64 bits on this platform");
-            if (!v.empty()) std::memcpy(v.data(), a.data(), sizeof(size_t) * v.size());
+            const int64_t* src = a.data();
+            for (size_t i = 0; i < v.size(); ++i) {
+                if (src[i] < 0) throw py::value_error("correspondence indices must not be negative");
+                v[i] = (size_t)src[i];
+            }
             return v;
         }
     }
@@ -493,4 +500,8 @@ PYBIND11_MODULE(_py_misc3d, m) {
           py::arg("verbosity_level"));
     m.def("get_verbosity_level", &misc3d::GetVerbosityLevel, "Get global verbosity level of Misc3D");
     m.def("device_count", []() { return m3d_device_count(); });
+    m.def("release_host_scratch", []() {
+        misc3d::ReleaseHostScratch();
+        PinnedPool::release_free();
+    }, "Free the page-locked blocks the calling thread and the result pool keep between calls");
 }

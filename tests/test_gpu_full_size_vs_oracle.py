@@ -139,9 +139,9 @@ def test_c4_full_size_vs_oracle(capi, orc):
     """BASELINE configs[3] at full size: the mutual matcher on 200 k x 200 k x 33 descriptors against the oracle's fp64
     brute force (ALL pairs; ~1 minute of the box's host cores), then compute_transformation_ransac on those correspondences
     with the reference's own confidence (0.999: 24 iterations, 5 validations -- each a 200 k x 200 k exact search in the
-    oracle): T bit for bit, iterations, validations, est_k, fitness.  (The first 300 iterations of the forced
-    100 000-iteration run -- 76 validations, two minutes of oracle -- are compared by tools/c4_full_size_vs_oracle.py;
-    profiles/r03_c4_full_size_vs_oracle.txt.)"""
+    oracle): T bit for bit, iterations, validations, est_k, fitness; then the first 100 iterations of BASELINE's FORCED run
+    (confidence 1.0: ~25 validations, ~40 s of oracle) the same way.  (300 iterations / 76 validations:
+    tools/c4_full_size_vs_oracle.py, profiles/r03_c4_full_size_vs_oracle.txt.)"""
     n = 200_000
     d = synth.registration_pair_c4(n, seed=5)
     g0, g1 = capi.match_mutual_nn(d["feat_src"], d["feat_dst"])
@@ -155,3 +155,11 @@ def test_c4_full_size_vs_oracle(capi, orc):
     assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64))
     assert (st["iterations"], st["validations"], st["est_k"], st["best_index"]) == (o.iterations, o.validations, o.est_k, o.best_index)
     assert st["fitness"] == o.fitness and abs(st["inlier_rmse"] - o.inlier_rmse) <= 1e-12
+    # the forced run: no early stop, every hypothesis that passes the checkers is validated
+    T, st = capi.registration_ransac(d["src"], d["dst"], g0, g1, threshold=0.03, max_iter=100, edge_length_threshold=0.9,
+                                     confidence=1.0, seed=17)
+    o = orc.registration_ransac(d["src"], d["dst"], o0, o1, thr=0.03, max_iter=100, edge_thr=0.9, confidence=1.0, seed=17)
+    assert o.iterations == 100 and o.validations >= 10
+    assert np.array_equal(T.view(np.uint64), o.T.view(np.uint64))
+    assert (st["iterations"], st["validations"], st["est_k"], st["best_index"]) == (o.iterations, o.validations, o.est_k, o.best_index)
+    assert st["fitness"] == o.fitness

@@ -102,6 +102,19 @@ def test_fit_matches_oracle(capi, orc, scoring_path, kind, n, max_iter, prob, se
         assert np.array_equal(_bits(g.params), _bits(o.params))
 
 
+def test_c1_baseline_config_verbatim(capi, orc):
+    """BASELINE.json configs[0] as SURVEY.md 8(d) spells it: the 50 000-point plumbing cloud (60 % on the plane, data seed 1),
+    fit_plane with 100 iterations, threshold 0.01, the reference's default probability, sampler seed 7 -- HIP path against the
+    oracle: the whole result."""
+    pts = synth.plane_cloud_c1(50_000, 1)
+    o = orc.fit(0, pts, None, thr=0.01, max_iter=100, prob=0.9999, seed=7)
+    g = capi.fit(0, pts, None, threshold=0.01, max_iteration=100, probability=0.9999, seed=7)
+    assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.ret, o.best_index, o.count, o.iterations)
+    assert g.stats["fitness"] == o.fitness
+    assert np.array_equal(g.inliers, o.inliers) and len(o.inliers) > 25_000
+    assert np.allclose(g.params, o.params, rtol=0, atol=PARAM_TOL)
+
+
 def test_fit_with_ties_uses_serial_rmse(capi, orc):
     """Tiny clouds produce many equal-fitness hypotheses; the tie rule (ransac.h:595-596) needs the
     serial-order error sum."""

@@ -66,6 +66,12 @@ def test_error_convention_without_gpu(m3d):
     assert m3d.segmentation.segment_plane_iterative(pts[:2], 0.01) == []            # :13-17: warning + empty list
     with pytest.raises((ValueError, TypeError)):
         m3d.common.fit_plane(np.zeros((5, 2)))
+    # correspondence indices as arrays: integers only, no negative values (they would wrap to 2^64 - 1)
+    with pytest.raises(TypeError, match="integers"):
+        m3d.registration.compute_transformation_ransac(pts, pts, (np.array([0.0, 1.0, 2.0]), np.array([0, 1, 2])))
+    with pytest.raises(ValueError, match="negative"):
+        m3d.registration.compute_transformation_ransac(pts, pts, (np.array([0, -1, 2]), np.array([0, 1, 2])))
+    m3d.release_host_scratch()   # (nothing pinned without a device: a no-op that must not fail)
 
 
 def test_no_silent_fallback_without_gpu(m3d):

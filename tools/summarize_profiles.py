@@ -116,7 +116,8 @@ def main():
                       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 10 "
                                  "--warmup 2 --no-cpu-baseline",
                       "corrections": "KiB -> B; FETCH_SIZE x2 on gfx950 (calibrated on aos_to_soa_k, see "
-                                     f"{TAG}_pmc_summary.json)"}
+                                     f"{TAG}_pmc_summary.json)",
+                      "measured_at_commit": os.environ.get("M3D_PROFILE_COMMIT", f"round {TAG} (set M3D_PROFILE_COMMIT to the hash)")}
             summary["bench_score_mask_k"] = latest
             with open(os.path.join(DST, "pmc_score_latest.json"), "w") as f:
                 json.dump(latest, f, indent=1)
