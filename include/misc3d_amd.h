@@ -405,7 +405,12 @@ typedef struct m3d_config {
                                        fp64 recount of the undecided pairs: identical counts) instead of score_screen_k (packed fp32
                                        VALU); measured slower on C2 as it stands (m3d_score_mfma.hip, STATUS) */
     int32_t score_mfma_groups;      /* [M3D_MFMA_GPB]       default 64: 64-hypothesis groups per workgroup of score_mfma_k (1..64) */
-    int32_t reserved[5];            /* zero.  Fields are only ever APPENDED in front of this array (which shrinks): the offsets of
+    int32_t score_waves4;           /* [M3D_SCORE_WAVES4=1]  default 0; 1: scoring windows of 24 groups and more run score_screen4_k -- four-wave
+                                       workgroups over up to score_waves4_groups groups of a tile that share ONE compacted list of the
+                                       surviving hypotheses and take its batches of 64 in turn (VERDICT r3 item 2's decomposition: measured
+                                       4 % slower than one wave per (tile, 8 groups) on C2, equal on C3 -- profiles/r04_score_waves4.txt) */
+    int32_t score_waves4_groups;    /* [M3D_WAVES4_GPB]     default 64 (1..64) */
+    int32_t reserved[3];            /* zero.  Fields are only ever APPENDED in front of this array (which shrinks): the offsets of
                                        existing fields do not move (round 3 itself had re-used four slots in place) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);

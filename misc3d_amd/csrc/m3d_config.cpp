@@ -30,6 +30,7 @@ void sanitize(m3d_config& c) {
     if (c.dense_workgroups < 1) c.dense_workgroups = 8192;
     if (c.pool_limit_mb < 0) c.pool_limit_mb = 0;
     if (c.score_mfma_groups < 1 || c.score_mfma_groups > 64) c.score_mfma_groups = 64;
+    if (c.score_waves4_groups < 1 || c.score_waves4_groups > 64) c.score_waves4_groups = 64;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -52,6 +53,8 @@ void load_env() {
     g_cfg.sorted_tombstones = !env_is("M3D_TOMBSTONES", '0');
     g_cfg.score_mfma = env_is("M3D_SCORE_MFMA", '1');
     g_cfg.score_mfma_groups = (int32_t)env_long("M3D_MFMA_GPB", 64);
+    g_cfg.score_waves4 = env_is("M3D_SCORE_WAVES4", '1');   // C2 0.1059 ms against 0.1020 (one-wave workgroups), C3 equal: off
+    g_cfg.score_waves4_groups = (int32_t)env_long("M3D_WAVES4_GPB", 64);
     sanitize(g_cfg);
 }
 }  // namespace

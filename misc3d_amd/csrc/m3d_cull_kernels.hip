@@ -624,6 +624,7 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
 #ifndef M3D_SCREEN_MAX_GROUPS
 #define M3D_SCREEN_MAX_GROUPS 8
 #endif
+constexpr uint32_t kScreen4MaxGroups = 64;   // score_screen4_k: groups per four-wave workgroup (lane = mask word; the id list: 8 KB)
 constexpr uint32_t kScreenMaxGroups = M3D_SCREEN_MAX_GROUPS;   // 64-hypothesis groups per workgroup (the id list: 1 KB of LDS; 7.2 KB in all: 22 workgroups per CU)
 constexpr int kCntStride = 64;              // bytes per row of the count table
 
@@ -712,7 +713,10 @@ __device__ __forceinline__ void screen_eval(const float4 ra, const float4 rb, co
 // OWN_BOX_TESTS (the lead pass inside cull_lead_k): no mask word has been written for these groups yet -- the wave runs
 // the fp32 box test of its tile against the 64 hypotheses of each group itself (lane = hypothesis, cull32_one: the bits
 // cull_tiles32_k would have written) and stores the word for whoever reads the masks later.
-template <int KIND, bool OWN_BOX_TESTS>
+// WAVES = 4 (score_screen4_k): one workgroup = one tile x up to kScreen4MaxGroups groups; the surviving hypotheses of ALL its
+// groups are compacted into ONE id list (wave 0, lane = mask word) and the four waves take its batches of 64 in turn -- full
+// batches whatever the masks look like, a tile's offsets loaded by 12 waves instead of 20, one mask read per 64 groups.
+template <int KIND, bool OWN_BOX_TESTS, int WAVES = 1>
 __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx, const double* __restrict__ sy,
                                                   const double* __restrict__ sz,
                                                   const double* __restrict__ boxes, double max_abs,
@@ -725,14 +729,31 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
                                                   uint32_t group_begin, uint32_t group_end, uint32_t block_x, uint32_t block_y,
                                                   const float* __restrict__ cull32, const float* __restrict__ tile_f32,
                                                   uint32_t has_dead /* SortedView::has_dead: some points are tombstones */) {
-    __shared__ uint16_t ids[kScreenMaxGroups * 64];
-    __shared__ __attribute__((aligned(16))) uint8_t cnt8[64 * kCntStride];
+    static_assert(WAVES == 1 || !OWN_BOX_TESTS, "the lead pass keeps one-wave workgroups");
+    constexpr uint32_t kMaxGroups = WAVES == 1 ? kScreenMaxGroups : kScreen4MaxGroups;
+    __shared__ uint16_t ids[kMaxGroups * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t cnt8_all[WAVES][64 * kCntStride];
     constexpr int NL = KIND == 2 ? 3 : 2;
-    __shared__ float4 loc[64 + 1][NL];   // the batch's (tile, hypothesis) records (+ one row the loop's look-ahead may read)
+    __shared__ float4 loc_all[WAVES][64 + 1][NL];   // the batch's (tile, hypothesis) records (+ one row the loop's look-ahead may read)
+    __shared__ uint32_t s_total;
+    const int lane = threadIdx.x & 63;
+    const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: an SGPR)
+    uint8_t* const cnt8 = cnt8_all[wave];
+    float4 (*const loc)[NL] = loc_all[wave];
+    // LDS traffic between the lanes of ONE wave needs no barrier (a wave's LDS instructions complete in order): a fence keeps
+    // the compiler from moving them.  With four waves a __syncthreads here would also deadlock (their batch counts differ).
+    auto wave_sync = [&]() {
+        if (WAVES == 1) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    };
     const uint32_t tile = block_x;
     uint32_t* __restrict__ counts = counts_rep + (size_t)(tile % kCountReplicas) * rep_stride;
     const uint32_t g0 = group_begin + block_y * groups_per_block;
-    const int lane = threadIdx.x;
     unsigned long long mm = 0;
     if (OWN_BOX_TESTS) {
         const float* __restrict__ f = reinterpret_cast<const float*>(boxes + (size_t)tile * kBoxStride + 8);   // (wave-uniform)
@@ -803,18 +824,39 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         tile_has_dead = tile_screened && __ballot(dead8 != 0u) != 0ull;
     }
     // ---- compaction of the set bits into ids[0 .. total): id = 64 * word + bit (relative to g0)
-    const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
     uint32_t total = 0;
-    for (uint32_t w = 0; w < groups_per_block; ++w) {   // wave-uniform
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(mm_lo, (int)w), hi = (uint32_t)__builtin_amdgcn_readlane(mm_hi, (int)w);
-        if ((lo | hi) == 0u) continue;
-        const unsigned long long word = ((unsigned long long)hi << 32) | lo;
-        const uint32_t slot = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, total));
-        if (__builtin_amdgcn_inverse_ballot_w64(word)) ids[slot] = (uint16_t)(w * 64u + (uint32_t)lane);   // (exec = word)
-        total += (uint32_t)__popcll(word);
+    if (WAVES == 1) {
+        const int mm_lo = (int)(uint32_t)mm, mm_hi = (int)(uint32_t)(mm >> 32);
+        for (uint32_t w = 0; w < groups_per_block; ++w) {   // wave-uniform
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(mm_lo, (int)w), hi = (uint32_t)__builtin_amdgcn_readlane(mm_hi, (int)w);
+            if ((lo | hi) == 0u) continue;
+            const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, total));
+            if (__builtin_amdgcn_inverse_ballot_w64(word)) ids[slot] = (uint16_t)(w * 64u + (uint32_t)lane);   // (exec = word)
+            total += (uint32_t)__popcll(word);
+        }
+        __syncthreads();
+    } else {
+        if (wave == 0) {   // lane l expands its own word behind the words before it (ascending ids)
+            const uint32_t pc = (uint32_t)__popcll(mm);
+            uint32_t incl = pc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) s_total = incl;
+            uint32_t at = incl - pc;
+            unsigned long long w = mm;
+            while (w) {
+                ids[at++] = (uint16_t)((uint32_t)lane * 64u + (uint32_t)__builtin_ctzll(w));
+                w &= w - 1ull;
+            }
+        }
+        __syncthreads();   // (every wave of the workgroup is here: the exit above is workgroup-uniform)
+        total = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_total);
     }
-    __syncthreads();
-    if (lane == 0) atomicAdd(&pair_rep[(tile + block_y * 67u) % (uint32_t)kPairMain], total);
+    if (threadIdx.x == 0) atomicAdd(&pair_rep[(tile + block_y * 67u) % (uint32_t)kPairMain], total);
     const double* __restrict__ score0 = score + (size_t)g0 * 64u * kModelStride;
     // the exact count of one (tile, hypothesis) pair: the fp64 points come back from memory (L2), four rows at a time
     auto exact_count = [&](uint32_t id) -> uint32_t {
@@ -836,7 +878,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         }
         return c;
     };
-    for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
+    for (uint32_t b0 = (uint32_t)wave * 64u; b0 < total; b0 += (uint32_t)WAVES * 64u) {   // (the waves take the batches in turn)
         const uint32_t nb = min(64u, total - b0);
         const int my = (b0 + (uint32_t)lane < total) ? (int)ids[b0 + lane] : 0;   // lane k: k-th id of the batch
         {   // lane k: the record of hypothesis k at this tile
@@ -853,7 +895,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
             loc[lane][1] = make_float4(sr[4], sr[5], sr[6], sr[7]);
             if (KIND == 2) loc[lane][NL - 1] = make_float4(sr[8], sr[9], sr[10], sr[11]);
         }
-        __syncthreads();
+        wave_sync();
         uint32_t park = 0;   // lane k: exact count of hypothesis k when the screen could not decide it
         // SCREENED is the tile's verdict (wave-uniform, fixed for the workgroup): a compile-time flag of the loop so that
         // the screened loop carries no branch and no register initialisation for the other case
@@ -910,7 +952,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         if (tile_screened && !tile_has_dead) batch(std::true_type{}, std::false_type{});
         else if (tile_screened) batch(std::true_type{}, std::true_type{});
         else batch(std::false_type{}, std::false_type{});
-        __syncthreads();   // (one wave: the table is complete)
+        wave_sync();   // (the table is complete)
         if ((uint32_t)lane < nb) {
             const uint4* row = reinterpret_cast<const uint4*>(cnt8 + (uint32_t)lane * kCntStride);
             uint32_t sum = park;
@@ -924,7 +966,7 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
             }
             if (sum) atomicAdd(&counts[g0 * 64u + (uint32_t)my], sum);
         }
-        __syncthreads();   // (the next batch overwrites the tables)
+        wave_sync();   // (the next batch overwrites the tables)
     }
 }
 template <int KIND>
@@ -942,6 +984,24 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
     score_screen_body<KIND, false>(sx, sy, sz, boxes, max_abs, score, const_cast<unsigned long long*>(masks), keep, n_groups,
                                    groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, blockIdx.x,
                                    blockIdx.y, nullptr, tile_f32, has_dead);
+}
+
+// score_screen4_k: the same counting with four-wave workgroups that share one compacted id list (score_screen_body, WAVES = 4)
+template <int KIND>
+__global__ __launch_bounds__(256) void score_screen4_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                        const double* __restrict__ sz,
+                                                        const double* __restrict__ boxes, double max_abs,
+                                                        const double* __restrict__ score,
+                                                        const unsigned long long* __restrict__ masks,
+                                                        const unsigned long long* __restrict__ keep,
+                                                        uint32_t n_groups, uint32_t groups_per_block /* <= kScreen4MaxGroups */,
+                                                        uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                        uint32_t* __restrict__ pair_rep,
+                                                        uint32_t group_begin, uint32_t group_end,
+                                                        const float* __restrict__ tile_f32, uint32_t has_dead) {
+    score_screen_body<KIND, false, 4>(sx, sy, sz, boxes, max_abs, score, const_cast<unsigned long long*>(masks), keep, n_groups,
+                                      groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, blockIdx.x,
+                                      blockIdx.y, nullptr, tile_f32, has_dead);
 }
 
 // cull_lead_k: ONE launch for the two latency-bound steps at the head of a fit's first chunk -- the box tests of the
@@ -1238,6 +1298,23 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
         if (ev_start && ev_stop) hipExtLaunchKernelGGL(kernel, g, b, 0, st, ev_start, ev_stop, 0, args...);
         else kernel<<<g, b, 0, st>>>(args...);
     };
+    // windows of many groups: four-wave workgroups over up to 64 groups each (m3d_config.score_waves4)
+    const uint32_t gpb4 = std::min<uint32_t>(kScreen4MaxGroups, (uint32_t)std::max(1, config().score_waves4_groups));
+    if (screened && config().score_waves4 != 0 && window >= 24u) {
+        const dim3 g4(s.n_tiles, (window + gpb4 - 1) / gpb4), b4(256);
+        auto go4 = [&](auto kernel) {
+            if (ev_start && ev_stop)
+                hipExtLaunchKernelGGL(kernel, g4, b4, 0, st, ev_start, ev_stop, 0, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups,
+                                      gpb4, counts_rep, rep_stride, pair_rep, group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+            else
+                kernel<<<g4, b4, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb4, counts_rep, rep_stride, pair_rep,
+                                          group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+        };
+        if (kind == 0) go4(score_screen4_k<0>);
+        else if (kind == 1) go4(score_screen4_k<1>);
+        else go4(score_screen4_k<2>);
+        return;
+    }
     if (screened) {
         if (kind == 0)
             go(score_screen_k<0>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
