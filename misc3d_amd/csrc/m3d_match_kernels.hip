@@ -234,7 +234,11 @@ __global__ void max_f32_k(const float* __restrict__ v, uint32_t n, float* __rest
 
 // ------------------------------------------------------------------------------------------------
 // MFMA screen (v_mfma_f32_32x32x16_f16): the same candidate rings as nn32_scan_k, ~6x fewer cycles per
-// pair.  d(a, b) = |a|^2 + |b|^2 - 2 a.b is ONE K = 112 contraction of fp16 operands with fp32 accumulate:
+// pair.  Round 4 (M3D_MATCH_HI_ONLY = 1, the default: m3d_match_scan.hpp): the screen contracts the HI halves only --
+// k 0..32 (-2 a_hi) b_hi, k 33..38 the norms' pieces, K = 48: three MFMA steps per tile pair instead of seven -- with the
+// bound's coefficient at 1.1e-3 instead of 1e-4; 200 k x 200 k x 33: scan 11.3 -> 7.4 ms, call 16.4 -> 12.2 ms, the same
+// 94 279 pairs, no fallback (profiles/r04_match_kernel_stats.txt).  The full split below is the M3D_MATCH_HI_ONLY = 0 build:
+// d(a, b) = |a|^2 + |b|^2 - 2 a.b is ONE K = 112 contraction of fp16 operands with fp32 accumulate:
 //   k   0.. 32   (-2 a_hi) * b_hi          a = a_hi + a_lo (+ 2^-22 |a|): split fp16, data pre-scaled by a power
 //   k  33.. 65   (-2 a_lo) * b_hi          of two so that max |v| <= 2048 (exact in both directions)
 //   k  66.. 98   (-2 a_hi) * b_lo
@@ -268,17 +272,21 @@ __global__ void pack_f16_k(const double* __restrict__ f, uint32_t n, uint32_t n_
             nrm += rep * rep;
             if (role == 0) {
                 row[k] = (_Float16)(-2.0 * (double)hi);
-                row[33 + k] = (_Float16)(-2.0 * (double)lo);
-                row[66 + k] = (_Float16)(-2.0 * (double)hi);
+                if (!kMfmaHiOnly) {
+                    row[33 + k] = (_Float16)(-2.0 * (double)lo);
+                    row[66 + k] = (_Float16)(-2.0 * (double)hi);
+                }
             } else {
                 row[k] = hi;
-                row[33 + k] = hi;
-                row[66 + k] = lo;
+                if (!kMfmaHiOnly) {
+                    row[33 + k] = hi;
+                    row[66 + k] = lo;
+                }
             }
         }
     }
     double pn = (i < n) ? nrm / (double)kMfmaC : (role == 0 ? 65504.0 : 0.0);
-    const int own = role == 0 ? 99 : 102, other = role == 0 ? 102 : 99;
+    const int own = role == 0 ? kMfmaNormAt : kMfmaNormAt + 3, other = role == 0 ? kMfmaNormAt + 3 : kMfmaNormAt;
     for (int k = 0; k < 3; ++k) {
         const _Float16 piece = (_Float16)pn;
         row[own + k] = piece;
