@@ -37,8 +37,14 @@ def fit_roofline(kind, st):
     screened = bool(capi.get_config().score_fp32_screen)
     ops = (VALU_OPS_SCREEN if screened else VALU_OPS_FP64)[kind]
     tops = st["pairs_timed"] * 512.0 * ops / (st["ms_score_kernel"] * 1e-3) / 1e12   # (pairs of the timed launches: m3d_stats.pairs_timed)
+    # the peak priced per instruction class (bench.py: CLASS_CYCLES from tools/ubench/valu_rates.hip, the loops' instruction mixes)
+    import bench as _b
+    n_mix, cyc_mix, _ = _b.peak_model((_b.MIX_SCREEN if screened else _b.MIX_FP64)[kind])
+    peak = _b.SIMDS * 64.0 * _b.CLOCK_HZ / (cyc_mix / n_mix) / 1e12
+    frac = st["pairs_timed"] * cyc_mix / (st["ms_score_kernel"] * 1e-3 * _b.SIMDS * _b.CLOCK_HZ)
     return {"bound": "valu-issue", "kernel": f"m3d::score_{'screen' if screened else 'mask'}_k<{kind}>", "achieved": tops,
-            "peak": FP64_VALU_PEAK_TOPS, "unit": "T lane-instructions/s (VALU issue)", "frac": tops / FP64_VALU_PEAK_TOPS,
+            "peak": peak, "unit": "T lane-instructions/s (VALU issue)", "frac": frac,
+            "frac_if_every_instruction_took_4_cycles": tops / FP64_VALU_PEAK_TOPS,
             "ops_per_pair": ops, "pairs_recounted_in_fp64": st["pairs_exact"],
             "launches": st["score_launches"], "kernel_ms_total": st["ms_score_kernel"], "tile_hypothesis_pairs": st["pairs_timed"], "pairs_of_the_untimed_lead_pass": st["pairs_scored"] - st["pairs_timed"]}
 
