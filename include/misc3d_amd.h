@@ -410,7 +410,12 @@ typedef struct m3d_config {
                                        surviving hypotheses and take its batches of 64 in turn (VERDICT r3 item 2's decomposition: measured
                                        4 % slower than one wave per (tile, 8 groups) on C2, equal on C3 -- profiles/r04_score_waves4.txt) */
     int32_t score_waves4_groups;    /* [M3D_WAVES4_GPB]     default 64 (1..64) */
-    int32_t reserved[3];            /* zero.  Fields are only ever APPENDED in front of this array (which shrinks): the offsets of
+    int32_t score_phases;           /* [M3D_SCORE_PHASES]   default -1 = 3 for cylinders, 0 for planes and spheres (measured: m3d_cull_kernels.hip,
+                                       "PHASED scoring"); 2 / 3 (every kind): a window that has an incumbent is counted on a quarter of the
+                                       tiles, re-pruned with what every hypothesis collected (count so far + 512 per tile it can still touch
+                                       against the incumbent: exact), (3: counted on a second quarter, re-pruned,) and only the survivors
+                                       see the rest; 0: one launch over all tiles */
+    int32_t reserved[2];            /* zero.  Fields are only ever APPENDED in front of this array (which shrinks): the offsets of
                                        existing fields do not move (round 3 itself had re-used four slots in place) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);

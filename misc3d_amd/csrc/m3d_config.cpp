@@ -31,6 +31,7 @@ void sanitize(m3d_config& c) {
     if (c.pool_limit_mb < 0) c.pool_limit_mb = 0;
     if (c.score_mfma_groups < 1 || c.score_mfma_groups > 64) c.score_mfma_groups = 64;
     if (c.score_waves4_groups < 1 || c.score_waves4_groups > 64) c.score_waves4_groups = 64;
+    if (c.score_phases < -1 || c.score_phases == 1 || c.score_phases > 3) c.score_phases = -1;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -55,6 +56,7 @@ void load_env() {
     g_cfg.score_mfma_groups = (int32_t)env_long("M3D_MFMA_GPB", 64);
     g_cfg.score_waves4 = env_is("M3D_SCORE_WAVES4", '1');   // C2 0.1059 ms against 0.1020 (one-wave workgroups), C3 equal: off
     g_cfg.score_waves4_groups = (int32_t)env_long("M3D_WAVES4_GPB", 64);
+    g_cfg.score_phases = (int32_t)env_long("M3D_SCORE_PHASES", -1);
     sanitize(g_cfg);
 }
 }  // namespace

@@ -335,7 +335,8 @@ __device__ __forceinline__ void cull32_body(const double* __restrict__ boxes, ui
                                             const float* __restrict__ cull32, uint32_t n_groups,
                                             uint32_t groups_per_wave, unsigned long long* __restrict__ masks,
                                             uint32_t* __restrict__ ub, uint32_t group_begin, uint32_t group_end,
-                                            uint32_t block_x, uint32_t block_y) {
+                                            uint32_t block_x, uint32_t block_y,
+                                            uint32_t* __restrict__ ubp = nullptr /* phased scoring: touched tiles with index % 4 == 0 (low half) / == 1 (high half) */) {
     const int lane = threadIdx.x;
     const uint32_t tile = block_x * 64u + (uint32_t)lane;
     const bool tile_ok = tile < n_tiles;
@@ -357,7 +358,7 @@ __device__ __forceinline__ void cull32_body(const double* __restrict__ boxes, ui
     const uint32_t g0 = group_begin + block_y * groups_per_wave;
     const uint32_t g1 = min(group_end, g0 + groups_per_wave);
     for (uint32_t g = g0; g < g1; ++g) {
-        uint32_t w[2] = {0u, 0u}, ubv = 0u;
+        uint32_t w[2] = {0u, 0u}, ubv = 0u, ubpv = 0u;
         const float* __restrict__ rp = cull32 + (size_t)g * 32u * 24u;   // 32 pairs of hypotheses
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -371,24 +372,32 @@ __device__ __forceinline__ void cull32_body(const double* __restrict__ boxes, ui
                 const unsigned long long ma = __ballot(!(ta < 0.0f)) & live_mask, mb = __ballot(!(tb < 0.0f)) & live_mask;
                 ubv = ((uint32_t)lane == hh) ? (uint32_t)__popcll(ma) : ubv;
                 ubv = ((uint32_t)lane == hh + 1u) ? (uint32_t)__popcll(mb) : ubv;
+                if (ubp) {   // (kernel argument: uniform) lane = tile and the wave starts at a multiple of 64: tile % 4 = lane % 4
+                    const uint32_t pa = (uint32_t)__popcll(ma & 0x1111111111111111ull) | ((uint32_t)__popcll(ma & 0x2222222222222222ull) << 16);
+                    const uint32_t pb = (uint32_t)__popcll(mb & 0x1111111111111111ull) | ((uint32_t)__popcll(mb & 0x2222222222222222ull) << 16);
+                    ubpv = ((uint32_t)lane == hh) ? pa : ubpv;
+                    ubpv = ((uint32_t)lane == hh + 1u) ? pb : ubpv;
+                }
             }
             w[half] = ~__builtin_bitreverse32(drop);
         }
         if (tile_ok) masks[(size_t)tile * n_groups + g] = live ? (((unsigned long long)w[1] << 32) | w[0]) : 0ull;
         if (ub && ubv) atomicAdd(&ub[g * 64u + (uint32_t)lane], ubv);
+        if (ubp && ubpv) atomicAdd(&ubp[g * 64u + (uint32_t)lane], ubpv);
     }
 }
 template <int KIND>
 __global__ __launch_bounds__(64) void cull_tiles32_k(const double* __restrict__ boxes, uint32_t n_tiles,
                                                       const float* __restrict__ cull32, uint32_t n_groups,
                                                       uint32_t groups_per_wave, unsigned long long* __restrict__ masks,
-                                                      uint32_t* __restrict__ ub, uint32_t group_begin, uint32_t group_end) {
-    cull32_body<KIND>(boxes, n_tiles, cull32, n_groups, groups_per_wave, masks, ub, group_begin, group_end, blockIdx.x, blockIdx.y);
+                                                      uint32_t* __restrict__ ub, uint32_t group_begin, uint32_t group_end,
+                                                      uint32_t* __restrict__ ubp) {
+    cull32_body<KIND>(boxes, n_tiles, cull32, n_groups, groups_per_wave, masks, ub, group_begin, group_end, blockIdx.x, blockIdx.y, ubp);
 }
 
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
                       uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st, bool ub_is_zero,
-                      uint32_t group_begin, uint32_t group_end, const float* cull32) {
+                      uint32_t group_begin, uint32_t group_end, const float* cull32, uint32_t* ubp) {
     (void)valid;     // (invalid and padding hypotheses are "no inlier" records)
     (void)h_count;
     group_end = std::min(group_end, n_groups);
@@ -402,11 +411,11 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
     const dim3 g(tblocks, (window + gpw - 1) / gpw), b(64);
     if (cull32 && s.radius < 1e18 && config().cull_fp32 != 0) {
         if (kind == 0)
-            cull_tiles32_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end);
+            cull_tiles32_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end, ubp);
         else if (kind == 1)
-            cull_tiles32_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end);
+            cull_tiles32_k<1><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end, ubp);
         else
-            cull_tiles32_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end);
+            cull_tiles32_k<2><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end, ubp);
         return;
     }
     if (kind == 0)
@@ -969,6 +978,15 @@ __device__ __forceinline__ void score_screen_body(const double* __restrict__ sx,
         wave_sync();   // (the next batch overwrites the tables)
     }
 }
+// the bx-th tile whose index mod 4 is in res_mask (ascending); may lie behind the last tile
+__device__ __forceinline__ uint32_t phase_tile4(uint32_t bx, uint32_t res_mask) {
+    const uint32_t k = (uint32_t)__popc(res_mask);
+    uint32_t m = res_mask;
+    for (uint32_t j = bx % k; j > 0; --j) m &= m - 1u;   // drop the j lowest set bits
+    return (bx / k) * 4u + (uint32_t)(__ffs(m) - 1);
+}
+// res_mask = 0xF: every tile (blockIdx.x = tile).  Otherwise ONE PHASE of a phased scoring (launch_score_phased): the tiles
+// whose index mod 4 is in res_mask, grid.x = ceil(n_tiles / 4) * popcount(res_mask).
 template <int KIND>
 __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ sx, const double* __restrict__ sy,
                                                       const double* __restrict__ sz,
@@ -980,10 +998,44 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
                                                       uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                       uint32_t* __restrict__ pair_rep,
                                                       uint32_t group_begin, uint32_t group_end,
-                                                      const float* __restrict__ tile_f32, uint32_t has_dead) {
+                                                      const float* __restrict__ tile_f32, uint32_t has_dead,
+                                                      uint32_t n_tiles, uint32_t res_mask) {
+    uint32_t tile = blockIdx.x;
+    if (res_mask != 0xFu) {   // (kernel argument: uniform)
+        tile = phase_tile4(blockIdx.x, res_mask);
+        if (tile >= n_tiles) return;
+    }
     score_screen_body<KIND, false>(sx, sy, sz, boxes, max_abs, score, const_cast<unsigned long long*>(masks), keep, n_groups,
-                                   groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, blockIdx.x,
+                                   groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, tile,
                                    blockIdx.y, nullptr, tile_f32, has_dead);
+}
+
+// Between two phases of a phased scoring: a hypothesis stays only if what it has collected so far plus 512 per tile it can
+// still touch reaches the best count of EARLIER hypotheses -- otherwise its final count is below that count whatever the
+// remaining tiles hold, it can neither beat nor tie the incumbent in the sequential replay (ransac.h:595-596), and its record
+// is reported as 0 like any pruned hypothesis' (launch_sum_replicas masks it with the final keep words).
+// done_mask: residues (tile index mod 4) scored so far; ubp[h] = touched tiles of residue 0 (low half) and 1 (high half).
+__global__ __launch_bounds__(64) void phase_keep_k(const uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
+                                                    const uint32_t* __restrict__ ub, const uint32_t* __restrict__ ubp,
+                                                    const uint32_t* __restrict__ best_count_ptr,
+                                                    unsigned long long* __restrict__ keep, uint32_t group_offset, uint32_t done_mask) {
+    const uint32_t g = group_offset + blockIdx.x;
+    const uint32_t h = g * 64u + threadIdx.x;
+    const unsigned long long kw = keep[g];
+    if (kw == 0ull) return;   // (uniform)
+    const uint32_t best = best_count_ptr[0];
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
+    const uint32_t ab = ubp[h];
+    uint32_t done = 0;
+    if (done_mask & 1u) done += ab & 0xFFFFu;
+    if (done_mask & 2u) done += ab >> 16;
+    // (residues 2 and 3 are only ever the LAST phase: nothing is decided after them)
+    const uint32_t rem = ub[h] - done;
+    const bool k = ((kw >> threadIdx.x) & 1ull) && (best == 0u || (uint64_t)c + (uint64_t)rem * kTilePoints >= best);
+    const unsigned long long m = __ballot(k);
+    if (threadIdx.x == 0) keep[g] = m;
 }
 
 // score_screen4_k: the same counting with four-wave workgroups that share one compacted id list (score_screen_body, WAVES = 4)
@@ -1020,14 +1072,14 @@ __global__ __launch_bounds__(64) void cull_lead_k(const double* __restrict__ sx,
                                                    uint32_t* __restrict__ counts_rep, uint32_t rep_stride,
                                                    uint32_t* __restrict__ pair_rep, uint32_t* __restrict__ ub,
                                                    uint32_t cull_begin, uint32_t cull_end, uint32_t cull_gpw, uint32_t cull_tblocks,
-                                                   const float* __restrict__ tile_f32, uint32_t has_dead) {
+                                                   const float* __restrict__ tile_f32, uint32_t has_dead, uint32_t* __restrict__ ubp) {
     if (blockIdx.x < n_lead_wgs) {   // (workgroup-uniform)
         score_screen_body<KIND, true>(sx, sy, sz, boxes, max_abs, score, masks, keep, n_groups, lead_gpb, counts_rep, rep_stride,
                                       pair_rep, 0u, lead_groups, blockIdx.x % n_tiles, blockIdx.x / n_tiles, cull32, tile_f32, has_dead);
     } else {
         const uint32_t b = blockIdx.x - n_lead_wgs;
         cull32_body<KIND>(boxes, n_tiles, cull32, n_groups, cull_gpw, masks, ub, cull_begin, cull_end, b % cull_tblocks,
-                          b / cull_tblocks);
+                          b / cull_tblocks, ubp);
     }
 }
 
@@ -1040,7 +1092,9 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
                                uint32_t* __restrict__ counts, const uint32_t* __restrict__ pair_rep,
                                uint32_t* __restrict__ pairs_out, const uint8_t* __restrict__ valid, uint32_t h_count,
                                uint32_t* __restrict__ best_count, uint32_t h_begin,
-                               uint32_t* __restrict__ counts_dev /* device copy of the records, or null */, PickFinal pf) {
+                               uint32_t* __restrict__ counts_dev /* device copy of the records, or null */, PickFinal pf,
+                               const unsigned long long* __restrict__ keep_final /* phased scoring: hypotheses dropped between
+                               phases carry partial counts -- reported as 0 (pruned); null: none */) {
     const uint32_t h = h_begin + blockIdx.x * 256u + threadIdx.x;   // window [h_begin, h_end) of the chunk
     if (blockIdx.x == 0 && pair_rep && pairs_out) {   // block-uniform
         __shared__ uint32_t red[256];
@@ -1065,6 +1119,7 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
     if (mine) {
 #pragma unroll
         for (int r = 0; r < kCountReplicas; ++r) c += counts_rep[(size_t)r * rep_stride + h];
+        if (keep_final && !((keep_final[h >> 6] >> (h & 63u)) & 1ull)) c = 0u;
     }
     const bool ok = mine && valid && h < h_count && valid[h];
     if (mine) {
@@ -1134,18 +1189,19 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
 }
 void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t h_end, uint32_t* counts,
                          const uint32_t* pair_rep, uint32_t* pairs_out, const uint8_t* valid, uint32_t h_count,
-                         uint32_t* best_count, hipStream_t st, uint32_t h_begin, uint32_t* counts_dev, const PickFinal* pick) {
+                         uint32_t* best_count, hipStream_t st, uint32_t h_begin, uint32_t* counts_dev, const PickFinal* pick,
+                         const unsigned long long* keep_final) {
     PickFinal pf;
     if (pick) pf = *pick;
     if (h_end > h_begin)
         sum_replicas_k<<<(h_end - h_begin + 255) / 256, 256, 0, st>>>(counts_rep, rep_stride, h_end, counts, pair_rep,
                                                                       pairs_out, valid, h_count, best_count, h_begin,
-                                                                      counts_dev, pf);
+                                                                      counts_dev, pf, keep_final);
 }
 
 bool launch_cull_lead(int kind, const SortedView& s, const double* score, const float* cull32, unsigned long long* masks,
                       const unsigned long long* keep, uint32_t n_groups, uint32_t lead_groups, uint32_t* counts_rep,
-                      uint32_t rep_stride, uint32_t* pair_rep, uint32_t* ub, uint32_t cull_end, hipStream_t st) {
+                      uint32_t rep_stride, uint32_t* pair_rep, uint32_t* ub, uint32_t cull_end, hipStream_t st, uint32_t* ubp) {
     cull_end = std::min(cull_end, n_groups);
     if (!s.n_tiles || !cull32 || !(s.radius < 1e18) || config().cull_fp32 == 0 || config().score_fp32_screen == 0 ||
         lead_groups == 0 || lead_groups > (uint32_t)kScreenMaxGroups || lead_groups >= cull_end)
@@ -1165,15 +1221,15 @@ bool launch_cull_lead(int kind, const SortedView& s, const double* score, const 
     if (kind == 0)
         cull_lead_k<0><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
                                         lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
-                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u, ubp);
     else if (kind == 1)
         cull_lead_k<1><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
                                         lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
-                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u, ubp);
     else
         cull_lead_k<2><<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, lead_groups,
                                         lead_gpb, n_lead_wgs, counts_rep, rep_stride, pair_rep, ub, lead_groups, cull_end, gpw, tblocks,
-                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+                                        (const float*)s.tile_f32, s.has_dead ? 1u : 0u, ubp);
     return true;
 }
 
@@ -1196,11 +1252,11 @@ bool launch_score_own_tests(int kind, const SortedView& s, const double* score, 
         if (ev_start && ev_stop)
             hipExtLaunchKernelGGL(kernel, g, b, 0, st, ev_start, ev_stop, 0, s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32,
                                   masks, keep, n_groups, groups, gpb, n_wgs, counts_rep, rep_stride, pair_rep, (uint32_t*)nullptr,
-                                  groups, groups, 1u, 1u, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+                                  groups, groups, 1u, 1u, (const float*)s.tile_f32, s.has_dead ? 1u : 0u, (uint32_t*)nullptr);
         else
             kernel<<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.n_tiles, s.max_abs, score, cull32, masks, keep, n_groups, groups, gpb, n_wgs,
                                     counts_rep, rep_stride, pair_rep, (uint32_t*)nullptr, groups, groups, 1u, 1u,
-                                    (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+                                    (const float*)s.tile_f32, s.has_dead ? 1u : 0u, (uint32_t*)nullptr);
     };
     if (kind == 0) go(cull_lead_k<0>);
     else if (kind == 1) go(cull_lead_k<1>);
@@ -1318,13 +1374,13 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     if (screened) {
         if (kind == 0)
             go(score_screen_k<0>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u, s.n_tiles, 0xFu);
         else if (kind == 1)
             go(score_screen_k<1>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u, s.n_tiles, 0xFu);
         else
             go(score_screen_k<2>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,
-               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u);
+               group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u, s.n_tiles, 0xFu);
     } else {
         if (kind == 0)
             go(score_mask_k<0>, s.x, s.y, s.z, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep, group_begin, group_end);
@@ -1335,6 +1391,59 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     }
 }
 
+
+// PHASED scoring (m3d_config.score_phases): the window's hypotheses are counted on a quarter of the tiles (index % 4 == 0: the
+// copy is Hilbert-sorted, so that is a uniform sample of space), re-pruned with what they collected (phase_keep_k), counted on the
+// next quarter, re-pruned, and only the survivors see the remaining half.  On C2 about half of the hypotheses that survive the
+// first pruning hold less than 64 % of the incumbent's inliers and leave after the first quarter.  Exact: see phase_keep_k.
+// Needs ub / ubp from the fp32 box tests of the SAME window, a pruning incumbent (best_count) and the fp32 screen; returns false,
+// having launched nothing, otherwise.  keep[] is rewritten; pass it to launch_sum_replicas as keep_final.
+// Measured (profiles/r04_score_phases.txt, 1 M points): cylinders 50 000 hypotheses 9.62 M -> 4.83 M pairs, scoring launches
+// 1.42 -> 0.885 ms, the fit 1.84 -> 1.29 ms; planes 10 000: 1.45 M -> 1.02 M pairs but 0.100 -> 0.106 ms (three launch tails and
+// two re-pruning kernels cost what the pairs save); spheres 50 000: 3.32 M -> 2.95 M, 0.332 -> 0.405 ms.  Hence the default
+// (m3d_config.score_phases = -1): three phases for cylinders, one launch for planes and spheres.
+int score_phases_for(int kind) {
+    const int c = config().score_phases;
+    if (c == 2 || c == 3) return c;
+    return (c < 0 && kind == 2) ? 3 : 0;
+}
+bool launch_score_phased(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
+                         unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
+                         uint32_t* pair_rep, const uint32_t* ub, const uint32_t* ubp, const uint32_t* best_count, hipStream_t st,
+                         uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    group_end = std::min(group_end, n_groups);
+    if (!ub || !ubp || !best_count || !s.tile_f32 || s.n_tiles < 256u || s.n_tiles > 200000u || score_phases_for(kind) == 0 ||
+        config().score_fp32_screen == 0 || group_begin >= group_end || group_end - group_begin < 32u)
+        return false;
+    const uint32_t window = group_end - group_begin;
+    const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, kScreenMaxGroups);
+    const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
+    const int n_ph = score_phases_for(kind);
+    const uint32_t res[3] = {0x1u, n_ph == 3 ? 0x2u : 0xEu, 0xCu};
+    uint32_t done = 0;
+    for (int ph = 0; ph < n_ph; ++ph) {
+        const uint32_t k = (uint32_t)__builtin_popcount(res[ph]);
+        const uint32_t tiles_x = (s.n_tiles + 3u) / 4u * k;
+        const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)tiles_x * window) / min_wgs)));
+        const dim3 g(tiles_x, (window + gpb - 1) / gpb), b(64);
+        hipEvent_t e0 = ph == 0 ? ev_start : nullptr, e1 = ph == n_ph - 1 ? ev_stop : nullptr;
+        auto go = [&](auto kernel) {
+            if (ev_start && ev_stop && (e0 || e1))
+                hipExtLaunchKernelGGL(kernel, g, b, 0, st, e0, e1, 0, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks,
+                                      (const unsigned long long*)keep, n_groups, gpb, counts_rep, rep_stride, pair_rep, group_begin, group_end,
+                                      (const float*)s.tile_f32, s.has_dead ? 1u : 0u, s.n_tiles, res[ph]);
+            else
+                kernel<<<g, b, 0, st>>>(s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, (const unsigned long long*)keep, n_groups, gpb, counts_rep,
+                                        rep_stride, pair_rep, group_begin, group_end, (const float*)s.tile_f32, s.has_dead ? 1u : 0u, s.n_tiles, res[ph]);
+        };
+        if (kind == 0) go(score_screen_k<0>);
+        else if (kind == 1) go(score_screen_k<1>);
+        else go(score_screen_k<2>);
+        done |= res[ph];
+        if (ph + 1 < n_ph) phase_keep_k<<<window, 64, 0, st>>>(counts_rep, rep_stride, ub, ubp, best_count, keep, group_begin, done);
+    }
+    return true;
+}
 
 // number of set bits of masks & keep (statistics for the measurement hook)
 __global__ void count_bits_k(const unsigned long long* __restrict__ masks, const unsigned long long* __restrict__ keep,

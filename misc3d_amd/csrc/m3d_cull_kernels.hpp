@@ -46,7 +46,9 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
                       bool ub_is_zero = false, uint32_t group_begin = 0,
                       uint32_t group_end = 0xFFFFFFFFu /* only groups [group_begin, group_end) of the chunk (sharded fits) */,
                       const float* cull32 = nullptr /* minimal_fit_k's fp32 box-test records (kCull32Stride floats per
-                                                       hypothesis): cull_tiles32_k instead of the fp64 tests (m3d_config.cull_fp32) */);
+                                                       hypothesis): cull_tiles32_k instead of the fp64 tests (m3d_config.cull_fp32) */,
+                      uint32_t* ubp = nullptr /* phased scoring (launch_score_phased): per hypothesis the touched tiles with index % 4 == 0
+                                                 (low 16 bits) and == 1 (high 16 bits); zero on entry; fp32 box tests only */);
 // keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
 // zero_counts_rep != null: the same launch clears the kCountReplicas x rep_stride + kPairReplicas counter words.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
@@ -86,7 +88,13 @@ void launch_mfma_probe(const double* pts, const double* box, double max_abs, con
 // geometry does not fit: the caller then issues launch_cull_mask + launch_score_mask as before.
 bool launch_cull_lead(int kind, const SortedView& s, const double* score, const float* cull32, unsigned long long* masks,
                       const unsigned long long* keep, uint32_t n_groups, uint32_t lead_groups, uint32_t* counts_rep,
-                      uint32_t rep_stride, uint32_t* pair_rep, uint32_t* ub, uint32_t cull_end, hipStream_t st);
+                      uint32_t rep_stride, uint32_t* pair_rep, uint32_t* ub, uint32_t cull_end, hipStream_t st, uint32_t* ubp = nullptr);
+int score_phases_for(int kind);   // 0 / 2 / 3: what m3d_config.score_phases means for this model kind
+// the scoring of a window in phases with re-pruning in between (m3d_cull_kernels.hip, "PHASED scoring"); false: not applicable
+bool launch_score_phased(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
+                         unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
+                         uint32_t* pair_rep, const uint32_t* ub, const uint32_t* ubp, const uint32_t* best_count, hipStream_t st,
+                         uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start, hipEvent_t ev_stop);
 // The chunk's box tests INSIDE its scoring launch (every workgroup tests its tile against its own groups): for chunks that
 // prune nothing (keep all ones).  false: preconditions not met (fp32 box tests / screen off), nothing launched.
 bool launch_score_own_tests(int kind, const SortedView& s, const double* score, const float* cull32, unsigned long long* masks,
@@ -124,7 +132,8 @@ void launch_sum_replicas(const uint32_t* counts_rep, uint32_t rep_stride, uint32
                          const uint32_t* pair_rep, uint32_t* pairs_out, const uint8_t* valid, uint32_t h_count,
                          uint32_t* best_count, hipStream_t st, uint32_t h_begin = 0 /* hypotheses [h_begin, h_end) */,
                          uint32_t* counts_dev = nullptr /* the same records once more, in device memory */,
-                         const PickFinal* pick = nullptr);
+                         const PickFinal* pick = nullptr,
+                         const unsigned long long* keep_final = nullptr /* phased scoring: hypotheses whose bit is clear report 0 */);
 void launch_pick_best(const uint32_t* records, uint32_t count, unsigned long long index_base, const double* params,
                       bool first_chunk, BestPick* pick, BestPickHost* pick_host, hipStream_t st,
                       uint32_t* records_host = nullptr /* device-visible host copy of the records (sharded fits) */,

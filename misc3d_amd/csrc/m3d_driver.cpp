@@ -467,7 +467,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (ms_sample) *ms_sample += now_ms() - t0;
     // the sample table is read by minimal_fit_k straight from the slot's page-locked host array (device-visible): 12 bytes
     // per hypothesis over the host link inside the kernel instead of a copy command in front of it
-    if (!dense && prune) RESERVE(ctx->ub, sizeof(uint32_t) * (size_t)h_pad);
+    if (!dense && prune) RESERVE(ctx->ub, sizeof(uint32_t) * 2 * (size_t)h_pad);   // ub[h_pad], then the phase counters ubp[h_pad]
     // (decided here because minimal_fit_k prepares the lead pass of a NEW fit itself: see LeadPrep)
     const bool use_lead = !dense && prune && lead >= 64 && lead % 64 == 0 && lead + 64 <= count && (!comm || sl_pad >= lead + 64);
     const bool own_real_ = !comm || (size_t)rank * sl_pad < count;
@@ -489,7 +489,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                        s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
                        (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
                        new_fit ? ctx->best_count.as<uint32_t>() : nullptr, (lead_prepared || all_prepared) ? &lp : nullptr, sv.max_abs,
-                       cull32 ? &c32 : nullptr, (ctx->poison_pending && kind == M3D_PLANE) ? &ctx->pending_poison : nullptr);
+                       cull32 ? &c32 : nullptr, (ctx->poison_pending && kind == M3D_PLANE) ? &ctx->pending_poison : nullptr,
+                       (!dense && prune) ? ctx->ub.as<uint32_t>() + h_pad : nullptr);
     if (ctx->poison_pending && kind == M3D_PLANE) {   // (the previous round's tombstone pass went with it)
         ctx->poison_pending = false;
         if (ctx->poison_expected_at) *ctx->poison_expected_at += ctx->poison_pending_count;
@@ -520,6 +521,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         const uint32_t g0 = comm ? rank * (sl_pad / 64) : 0u, g1 = comm ? g0 + sl_pad / 64 : n_groups;
         const bool own_real = (size_t)g0 * 64 < count;   // (a short last window can leave the highest ranks without work)
         uint32_t* ub = prune ? ctx->ub.as<uint32_t>() : nullptr;
+        // phased scoring (launch_score_phased): one GPU, a lead pass in front (an incumbent exists), the fp32 box tests (they count
+        // the touched tiles per phase), no tombstones
+        uint32_t* ubp = (prune && !comm && (use_lead || !new_fit) && c32.out && !sv.has_dead && score_phases_for(kind) != 0) ? ub + h_pad : nullptr;   // (an incumbent exists: this chunk's lead pass, or earlier chunks)
         auto* masks = ctx->masks.as<unsigned long long>();
         auto* keep = ctx->keep.as<unsigned long long>();
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
@@ -547,7 +551,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 if (!lead_prepared)   // (a new fit: minimal_fit_k has done it)
                     launch_keep_mask(ub, bc, ga, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, 0);
                 s.lead_fused = launch_cull_lead(kind, sv, s.score.as<double>(), c32.out, masks, keep, n_groups, ga,
-                                                ctx->counts_rep.as<uint32_t>(), h_pad, pair_rep, ub, g1, ctx->stream);
+                                                ctx->counts_rep.as<uint32_t>(), h_pad, pair_rep, ub, g1, ctx->stream, ubp);
             }
             // nothing to prune and every group prepared by minimal_fit_k: the box tests run inside the scoring launch
             bool scored_with_own_tests = false;
@@ -560,7 +564,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                     launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
                                      ctx->stream, /*ub_is_zero=*/true, 0, ga, c32.out);
                 launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
-                                 /*ub_is_zero=*/true, g0, g1, c32.out);
+                                 /*ub_is_zero=*/true, g0, g1, c32.out, ubp);
             }
             uint32_t g_lo = g0;
             if (ga) {
@@ -579,14 +583,19 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             } else if (!all_prepared) {   // (all_prepared: minimal_fit_k has done it)
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
             }
-            if (!scored_with_own_tests)
+            bool phased = false;
+            if (!scored_with_own_tests && ubp)
+                phased = launch_score_phased(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
+                                             pair_rep, ub, ubp, bc, ctx->stream, g_lo, g1, timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
+            if (!scored_with_own_tests && !phased)
                 launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
                                   pair_rep, ctx->stream, g_lo, g1, timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
             // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
             // ... and (one GPU) write the records straight into the slot's pinned host array (device-visible): no copy
             // command behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
             launch_sum_replicas(ctx->counts_rep.as<uint32_t>(), h_pad, g1 * 64u, rec_host, pair_rep, h_pairs,
-                                s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u, rec_dev, pick_final ? &pfin : nullptr);
+                                s.valid.as<uint8_t>(), count, bc, ctx->stream, g_lo * 64u, rec_dev, pick_final ? &pfin : nullptr,
+                                phased ? keep : nullptr);
             if (pick_final) s.poll_seq = pick_final->seq;
             s.scored = timing;
         } else {

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
                                                      uint32_t h_count, uint32_t h_pad, double thr,
                                                      double* __restrict__ score,
                                                      double* __restrict__ params,
-                                                     uint8_t* __restrict__ valid, uint32_t* __restrict__ zero_u32,
+                                                     uint8_t* __restrict__ valid, uint32_t* __restrict__ zero_u32, uint32_t* __restrict__ zero_u32b,
                                                      uint32_t* __restrict__ zero_one, LeadPrep lead, double cull_max_abs,
                                                      Cull32Out c32, PoisonJob poison, uint32_t fit_blocks) {
     // workgroups behind the fit's own: the previous segmentation round's tombstone pass, one wave per tile of the sorted
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
     const uint32_t h = blockIdx.x * 64u + threadIdx.x;
     if (h >= h_pad) return;
     if (zero_u32 && h + 1 < h_pad) zero_u32[h] = 0;   // per-hypothesis counter cleared on the way (saves a memset launch)
+    if (zero_u32b && h + 1 < h_pad) zero_u32b[h] = 0;   // (the phase counters of the box tests: launch_score_phased)
     if (zero_one && h < 4) zero_one[h] = 0;           // a fit's first chunk: the running best count + the pick's ticket and key (PickFinal)
     if (lead.counts_rep) {
         // a fit's first chunk: what keep_mask_k would do for the leading hypotheses (nothing to prune against yet: keep
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
 void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
                         hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one, const LeadPrep* lead, double cull_max_abs,
-                        const Cull32Out* cull32, const PoisonJob* poison) {
+                        const Cull32Out* cull32, const PoisonJob* poison, uint32_t* zero_u32b) {
     if (h_pad == 0) return;
     const uint32_t fit_blocks = (h_pad + 63) / 64;
     const dim3 g(fit_blocks + (kind == 0 && poison ? poison->n_tiles : 0u)), b(64);
@@ -266,11 +267,11 @@ void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, u
     PoisonJob pj;
     if (kind == 0 && poison) pj = *poison;
     if (kind == 0)
-        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
+        minimal_fit_k<0><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_u32b, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
     else if (kind == 1)
-        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
+        minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_u32b, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
     else
-        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
+        minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_u32b, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -71,7 +71,8 @@ void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, u
                                                                  cut-off of the box tests (inf: nothing is ever culled) */,
                         const Cull32Out* cull32 = nullptr,
                         const PoisonJob* poison = nullptr /* planes: the previous round's tombstone pass rides in the launch (one
-                                                             extra 64-thread workgroup per tile of the sorted copy) */);
+                                                             extra 64-thread workgroup per tile of the sorted copy) */,
+                        uint32_t* zero_u32b = nullptr /* a second array of h_pad - 1 counters cleared by the same launch */);
 
 // K2: inlier counting.  partial[tile * h_pad + h] = number of points of scoring tile `tile` whose
 // distance to hypothesis h is < thr.  h_pad must be a multiple of 64; the hypotheses are cut into

@@ -22,7 +22,9 @@ PATHS = {"culled": {}, "dense": {"dense_scoring": 1}, "no_early_pick": {"specula
          "small_blocks": {"score_groups_per_block": 1, "lead_hypotheses": 64},
          "fp64_only": {"score_fp32_screen": 0, "cull_fp32": 0},
          "mfma": {"score_mfma": 1},   # planes: score_mfma_k, the screen on the matrix pipe
-         "four_wave_wgs": {"score_waves4": 1}}   # score_screen4_k: four waves share a tile's compacted id list
+         "four_wave_wgs": {"score_waves4": 1},
+         "single_launch": {"score_phases": 0},   # (default -1: cylinders in three phases with re-pruning in between, the others in one)
+         "two_phases": {"score_phases": 2}, "three_phases": {"score_phases": 3}}   # score_screen4_k: four waves share a tile's compacted id list
 
 
 @pytest.fixture(params=sorted(PATHS))
