@@ -105,6 +105,28 @@ def test_fit_matches_oracle(capi, orc, scoring_path, kind, n, max_iter, prob, se
         assert np.array_equal(_bits(g.params), _bits(o.params))
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("phases", [2, 3])
+def test_phased_scoring_matches_oracle(capi, orc, kind, phases):
+    """launch_score_phased needs >= 256 tiles and a window of >= 32 groups to engage: 150 000 points x 3000 hypotheses.  The fit
+    must be the oracle's, and the phased run must really have evaluated fewer (tile, hypothesis) pairs than the one-launch run
+    (hypotheses that leave after a quarter or a half of their tiles)."""
+    pts, nrm = _clouds(kind, 150_000, seed=70 + kind)
+    o = orc.fit(kind, pts, nrm, thr=0.01, max_iter=3000, prob=1.0, seed=5, lookahead=256)
+    res = {}
+    for ph in (0, phases):
+        old = capi.set_config(score_phases=ph)
+        try:
+            g = capi.fit(kind, pts, nrm, threshold=0.01, max_iteration=3000, probability=1.0, seed=5)
+        finally:
+            capi.restore_config(old)
+        assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.ret, o.best_index, o.count, o.iterations)
+        assert np.array_equal(g.inliers, o.inliers)
+        assert np.allclose(g.params, o.params, rtol=0, atol=PARAM_TOL)
+        res[ph] = g.stats["pairs_scored"]
+    assert res[phases] < res[0], res
+
+
 def test_c1_baseline_config_verbatim(capi, orc):
     """BASELINE.json configs[0] as SURVEY.md 8(d) spells it: the 50 000-point plumbing cloud (60 % on the plane, data seed 1),
     fit_plane with 100 iterations, threshold 0.01, the reference's default probability, sampler seed 7 -- HIP path against the
