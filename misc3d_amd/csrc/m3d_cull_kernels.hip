@@ -1412,8 +1412,11 @@ bool launch_score_phased(int kind, const SortedView& s, const double* score, con
                          uint32_t* pair_rep, const uint32_t* ub, const uint32_t* ubp, const uint32_t* best_count, hipStream_t st,
                          uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start, hipEvent_t ev_stop) {
     group_end = std::min(group_end, n_groups);
-    if (!ub || !ubp || !best_count || !s.tile_f32 || s.n_tiles < 256u || s.n_tiles > 200000u || score_phases_for(kind) == 0 ||
-        config().score_fp32_screen == 0 || group_begin >= group_end || group_end - group_begin < 32u)
+    // (the size guards are where the phases start to pay; an EXPLICIT m3d_config.score_phases = 2 / 3 -- the test-suite's paths --
+    // engages them on small clouds and windows too)
+    const bool forced = config().score_phases >= 2;
+    if (!ub || !ubp || !best_count || !s.tile_f32 || s.n_tiles < (forced ? 8u : 256u) || s.n_tiles > 200000u || score_phases_for(kind) == 0 ||
+        config().score_fp32_screen == 0 || group_begin >= group_end || group_end - group_begin < (forced ? 2u : 32u))
         return false;
     const uint32_t window = group_end - group_begin;
     const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, kScreenMaxGroups);

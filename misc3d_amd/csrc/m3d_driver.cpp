@@ -521,9 +521,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         const uint32_t g0 = comm ? rank * (sl_pad / 64) : 0u, g1 = comm ? g0 + sl_pad / 64 : n_groups;
         const bool own_real = (size_t)g0 * 64 < count;   // (a short last window can leave the highest ranks without work)
         uint32_t* ub = prune ? ctx->ub.as<uint32_t>() : nullptr;
-        // phased scoring (launch_score_phased): one GPU, a lead pass in front (an incumbent exists), the fp32 box tests (they count
-        // the touched tiles per phase), no tombstones
-        uint32_t* ubp = (prune && !comm && (use_lead || !new_fit) && c32.out && !sv.has_dead && score_phases_for(kind) != 0) ? ub + h_pad : nullptr;   // (an incumbent exists: this chunk's lead pass, or earlier chunks)
+        // phased scoring (launch_score_phased): an incumbent exists, the fp32 box tests run (they count the touched tiles per
+        // phase), no tombstones
+        uint32_t* ubp = (prune && (use_lead || !new_fit) && c32.out && !sv.has_dead && score_phases_for(kind) != 0) ? ub + h_pad : nullptr;   // (an incumbent exists: this chunk's lead pass, or earlier chunks / windows -- sharded fits included: every rank prunes its slice against the same incumbent)
         auto* masks = ctx->masks.as<unsigned long long>();
         auto* keep = ctx->keep.as<unsigned long long>();
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;

@@ -36,6 +36,21 @@ def test_fit_sharded_rccl_world1(rccl1, kind):
         assert _same(c.fit(kind, 0.01, 500, 0.9999, seed=3), c.fit_sharded(None, kind, 0.01, 500, 0.9999, seed=3))
 
 
+def test_fit_sharded_phased_scoring(rccl1):
+    """The phased scoring of cylinders (the default from 131 k points on) inside the sharded loop: same incumbent on every rank,
+    same result as the one-call fit."""
+    pts, nrm = synth.cylinder_cloud_c3(150_000, 3)
+    with capi.Cloud(pts, nrm) as c:
+        a = c.fit(capi.CYLINDER, 0.01, 6000, 1.0, seed=13)
+        b = c.fit_sharded(rccl1, capi.CYLINDER, 0.01, 6000, 1.0, seed=13)
+        assert _same(a, b)
+        old = capi.set_config(score_phases=0)
+        try:
+            assert _same(a, c.fit_sharded(rccl1, capi.CYLINDER, 0.01, 6000, 1.0, seed=13))
+        finally:
+            capi.restore_config(old)
+
+
 def test_fit_sharded_host_transport_and_errors(rccl1):
     pts = synth.plane_cloud_c2(60000, seed=2)
     calls = []

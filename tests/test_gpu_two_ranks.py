@@ -17,9 +17,13 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_drivers_on_one_gpu(world):
+@pytest.mark.parametrize("world,phases", [(2, None), (3, None), (2, "3")])
+def test_sharded_drivers_on_one_gpu(world, phases):
+    """phases = "3": M3D_SCORE_PHASES=3 in the workers -- every window of every rank scored in three phases with re-pruning in
+    between (the explicit setting engages them on the workers' small clouds too); the results must still equal the one-GPU ones."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    if phases:
+        env["M3D_SCORE_PHASES"] = phases
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "two_rank_gpu_worker.py")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
