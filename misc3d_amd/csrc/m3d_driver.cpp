@@ -1097,6 +1097,22 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         const size_t n_chunks = (max_iter + chunk_cap - 1) / chunk_cap;
         chunk = after_first = ((max_iter + n_chunks - 1) / n_chunks + 63) / 64 * 64;
         lead = lead_size();
+        // Several chunks: a SHORT first one.  What prunes chunk k is the best count of chunks 0 .. k - 1, and the first chunk has
+        // only its 128 leading hypotheses to prune against -- on C3's cylinders (50 000 hypotheses, four chunks) its scoring
+        // launches took 353 us where each later chunk took 169.  A first chunk of 2048 puts a good incumbent in front of 96 %
+        // of the hypotheses instead of 75 %, with the same number of chunks when the rest still fits them.
+        static const size_t first_small = [] {
+            const char* e = std::getenv("M3D_FIRST_CHUNK");
+            const long v = e && *e ? std::strtol(e, nullptr, 10) : 2048;
+            return (size_t)(v <= 0 ? 0 : (v + 63) / 64 * 64);
+        }();
+        if (n_chunks >= 2 && first_small >= 2 * (size_t)lead && first_small * n_ranks < chunk) {
+            const size_t first = first_small * n_ranks;
+            const size_t rest = max_iter - first;
+            const size_t n_rest = (rest + chunk_cap - 1) / chunk_cap;
+            chunk = first;
+            after_first = ((rest + n_rest - 1) / n_rest + 63) / 64 * 64;
+        }
     } else if (prob >= 1.0) {
         chunk = std::max<size_t>(max_iter, 64);
         growth = 1;
