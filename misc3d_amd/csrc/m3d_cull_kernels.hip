@@ -470,11 +470,12 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
                                                         unsigned long long* __restrict__ keep,
                                                         uint32_t* __restrict__ zero, uint32_t group_offset,
                                                         uint32_t* __restrict__ records_dev,
-                                                        unsigned long long* __restrict__ pick_key) {
+                                                        unsigned long long* __restrict__ pick_key,
+                                                        unsigned long long* __restrict__ pick_key2) {
     const uint32_t g = group_offset + blockIdx.x;
     const uint32_t prev = best_count[0];   // may or may not include this chunk's lead already: max() below either way
     uint32_t v = 0;
-    unsigned long long key = 0;   // (count << 32 | ~index): highest count, lowest index among equals
+    unsigned long long key = 0, key2 = 0;   // (count << 32 | ~index): highest count, lowest index among equals; key2: highest index
     for (uint32_t h = threadIdx.x; h < lead; h += 64u) {
         uint32_t c = 0;
 #pragma unroll
@@ -486,6 +487,7 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
         }
         v = max(v, ok ? c : 0u);
         if (ok && c) key = max(key, ((unsigned long long)c << 32) | (0xFFFFFFFFu - h));
+        if (ok && c) key2 = max(key2, ((unsigned long long)c << 32) | h);
     }
     for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
     if (blockIdx.x == 0 && threadIdx.x == 0 && v) atomicMax(best_count, v);
@@ -499,6 +501,10 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
     if (pick_key && blockIdx.x == 0) {   // block-uniform
         for (int off = 32; off > 0; off >>= 1) key = max(key, (unsigned long long)__shfl_xor((long long)key, off, 64));
         if (threadIdx.x == 0 && key) atomicMax(pick_key, key);
+        if (pick_key2) {
+            for (int off = 32; off > 0; off >>= 1) key2 = max(key2, (unsigned long long)__shfl_xor((long long)key2, off, 64));
+            if (threadIdx.x == 0 && key2) atomicMax(pick_key2, key2);
+        }
     }
     const uint32_t best = max(prev, v);
     const uint32_t h = g * 64u + threadIdx.x;
@@ -513,12 +519,12 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
 void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
                            unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st, uint32_t* records_dev,
-                           uint32_t group_begin, unsigned long long* pick_key) {
+                           uint32_t group_begin, unsigned long long* pick_key, unsigned long long* pick_key2) {
     if (group_begin == 0xFFFFFFFFu) group_begin = lead / 64u;
     // (n_groups_rest == 0 still needs the fold of the lead's counters: one workgroup whose keep word is scratch)
     if (!n_groups_rest) return;
     lead_fold_keep_k<<<n_groups_rest, 64, 0, st>>>(counts_rep, rep_stride, lead, valid, h_count, records, best_count, ub,
-                                                   keep, const_cast<uint32_t*>(counts_rep), group_begin, records_dev, pick_key);
+                                                   keep, const_cast<uint32_t*>(counts_rep), group_begin, records_dev, pick_key, pick_key2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1135,11 +1141,16 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
     if (!pf.pick) return;   // (kernel argument: uniform)
     // ---- pick_best_k's decision, without its launch: every wave contributes its best (count, index) key; the
     // workgroup that finishes last compares the chunk's best with the running pick
-    __shared__ uint32_t s_last, s_take, s_idx;
+    __shared__ uint32_t s_last, s_take, s_idx, s_tie;
     {
         unsigned long long key = (ok && c) ? (((unsigned long long)c << 32) | (0xFFFFFFFFu - h)) : 0ull;
         for (int off = 32; off > 0; off >>= 1) key = max(key, (unsigned long long)__shfl_xor((long long)key, off, 64));
         if ((threadIdx.x & 63) == 0 && key) atomicMax(pf.key, key);
+        if (pf.key2) {   // (kernel argument: uniform) the HIGHEST index among the best counts: differs from the lowest = a tie
+            unsigned long long key2 = (ok && c) ? (((unsigned long long)c << 32) | h) : 0ull;
+            for (int off = 32; off > 0; off >>= 1) key2 = max(key2, (unsigned long long)__shfl_xor((long long)key2, off, 64));
+            if ((threadIdx.x & 63) == 0 && key2) atomicMax(pf.key2, key2);
+        }
     }
     // this workgroup's records (host memory) and its key are out before its ticket.  (Waiting for the stores with
     // s_waitcnt alone is NOT enough: with two processes sharing the GPU the host saw the completion word before some
@@ -1159,8 +1170,23 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
         BestPick* pick = pf.pick;
         const bool had = !pf.first_chunk && pick->have;
         const bool take = cnt > 0 && (!had || cnt > pick->cnt);
+        // COUNT TIES.  The device's pick is "highest count, lowest index"; the replay breaks equal counts by rmse
+        // (ransac.h:595-596), so with two hypotheses at the top the pick is a coin toss -- and a wrong pick costs the fit a
+        // second RefineModel compaction (4 MB over the host link: C3's sphere fit, 0.13 of 0.82 ms).  key2 holds the HIGHEST
+        // index among the chunk's best counts: if it differs from the lowest, or the chunk's best equals the running pick's
+        // count, the pick is marked `tie`, its model record is poisoned (NaN: the speculative compaction queued behind this
+        // kernel then finds no inlier and ships nothing) and the host treats the speculation as a miss.
+        uint32_t tie = (pf.first_chunk || !had) ? 0u : pick->tie;
+        if (pf.key2) {
+            const unsigned long long k2 = __hip_atomic_load(pf.key2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool inner = cnt > 0 && (uint32_t)k2 != idx;
+            if (take) tie = inner ? 1u : 0u;
+            else if (had && cnt > 0 && cnt == pick->cnt) tie = 1u;
+            *pf.key2 = 0ull;
+        }
         s_take = take ? 1u : 0u;
         s_idx = idx;
+        s_tie = tie;
         if (take) {
             pick->have = 1;
             pick->cnt = cnt;
@@ -1170,9 +1196,11 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
             pick->cnt = 0;
             pick->index = ~0ull;
         }
+        pick->tie = tie;
         pf.pick_host->have = pick->have;
         pf.pick_host->cnt = pick->cnt;
         pf.pick_host->index = pick->index;
+        pf.pick_host->tie = tie;
         *pf.key = 0ull;      // (for the next chunk)
         *pf.ticket = 0u;
     }
@@ -1180,6 +1208,7 @@ __global__ void sum_replicas_k(const uint32_t* __restrict__ counts_rep, uint32_t
     if (threadIdx.x < kModelStride) {
         if (s_take) pf.pick->params[threadIdx.x] = pf.params[(size_t)s_idx * kModelStride + threadIdx.x];
         else if (pf.first_chunk) pf.pick->params[threadIdx.x] = 0.0;
+        if (s_tie && threadIdx.x == 0) pf.pick->params[0] = __builtin_nan("");
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1318,6 +1347,8 @@ __global__ __launch_bounds__(1024) void pick_best_k(const uint32_t* __restrict__
         pick_host->have = pick->have;
         pick_host->cnt = pick->cnt;
         pick_host->index = pick->index;
+        pick->tie = 0;   // (ties are only tracked by sum_replicas_k's PickFinal tail: one-GPU fits)
+        pick_host->tie = 0;
     }
     __syncthreads();
     if (threadIdx.x < kModelStride) {

@@ -106,17 +106,19 @@ bool launch_score_own_tests(int kind, const SortedView& s, const double* score, 
 struct BestPick {
     unsigned long long index;   // absolute hypothesis index, ~0 when none
     uint32_t cnt, have;
-    double params[8];           // its parameter record (kModelStride doubles): RefineModel's model
+    double params[8];           // its parameter record (kModelStride doubles): RefineModel's model -- NaN in slot 0 while `tie`
+    uint32_t tie, pad;          // another hypothesis holds the same count: the replay's rmse rule decides, not the device
 };
 struct BestPickHost {           // mirror in pinned host memory, written by the same kernel
     unsigned long long index;
     uint32_t cnt, have;
-    uint32_t seq, pad;          // PickFinal::seq, stored last: the host's completion word of the chunk
+    uint32_t seq, tie;          // PickFinal::seq, stored last: the host's completion word of the chunk; tie: see BestPick
 };
 // Optional tail of launch_sum_replicas (one-GPU fits): pick_best_k's decision taken by the workgroup of sum_replicas_k
 // that finishes last -- no pick_best_k launch, and no event behind it: the host waits for pick_host->seq.
 struct PickFinal {
     unsigned long long* key = nullptr;   // device: max over the chunk of (count << 32 | ~index); zero on entry and on exit
+    unsigned long long* key2 = nullptr;  // device: max over the chunk of (count << 32 | index): a different index = a count tie
     uint32_t* ticket = nullptr;          // device: finished workgroups; zero on entry and on exit
     const double* params = nullptr;      // the chunk's parameter records
     unsigned long long index_base = 0;
@@ -145,7 +147,8 @@ void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint
                            unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st,
                            uint32_t* records_dev = nullptr,
                            uint32_t group_begin = 0xFFFFFFFFu /* first group of the keep window; default lead / 64 */,
-                           unsigned long long* pick_key = nullptr /* PickFinal::key: the lead's best goes in */);
+                           unsigned long long* pick_key = nullptr /* PickFinal::key: the lead's best goes in */,
+                           unsigned long long* pick_key2 = nullptr /* PickFinal::key2 */);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,
                        uint32_t n_groups, unsigned long long* total, hipStream_t st);
 

@@ -579,7 +579,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 // fold of the lead's counters + keep masks of the rest of this rank's groups: one launch
                 launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
                                       g0 == 0 ? rec_host : nullptr, bc, ub, keep, g1 - g_lo, ctx->stream,
-                                      g0 == 0 ? rec_dev : nullptr, g_lo, pick_final ? pick_final->key : nullptr);
+                                      g0 == 0 ? rec_dev : nullptr, g_lo, pick_final ? pick_final->key : nullptr,
+                                      pick_final ? pick_final->key2 : nullptr);
             } else if (!all_prepared) {   // (all_prepared: minimal_fit_k has done it)
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
             }
@@ -1129,7 +1130,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         iterations_hint = 0;   // (consumed: no second chunk queued on the first pass)
     }
     chunk = std::min(std::min(chunk, chunk_cap), std::max<size_t>((max_iter + 63) / 64 * 64, 64));
-    RESERVE(ctx->best_count, 16);   // cleared by the first chunk's minimal_fit_k
+    RESERVE(ctx->best_count, 32);   // cleared by the first chunk's minimal_fit_k (six words: best count, ticket, key, key2)
 
     const bool timing_events = config().kernel_timing != 0;   // (m3d_stats.ms_score / ms_score_kernel)
     const double t_score0 = now_ms();   // (m3d_stats.ms_score: a host clock -- an event pair here cost a fit ~8 us)
@@ -1169,6 +1170,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         const bool fused_pick = poll_done;
         if (fused_pick) {
             pf.key = reinterpret_cast<unsigned long long*>(ctx->best_count.as<uint32_t>() + 2);
+            pf.key2 = reinterpret_cast<unsigned long long*>(ctx->best_count.as<uint32_t>() + 4);
             pf.ticket = ctx->best_count.as<uint32_t>() + 1;
             pf.index_base = (unsigned long long)b;
             pf.first_chunk = b == 0 ? 1 : 0;
@@ -1460,7 +1462,8 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         // launches are left to drain (their outputs are rewritten below, later in stream order) and RefineModel runs on
         // the replay's model with the caller's hooks untouched.
         const BestPickHost* ph = ctx->h_pick.as<BestPickHost>();
-        const bool hit = ro.st.best_index >= 0 ? (ph->have && ph->index == (unsigned long long)ro.st.best_index) : !ph->have;
+        // (a pick marked `tie` shipped nothing: its model record was poisoned -- sum_replicas_k, "COUNT TIES")
+        const bool hit = !ph->tie && (ro.st.best_index >= 0 ? (ph->have && ph->index == (unsigned long long)ro.st.best_index) : !ph->have);
         ro.spec_hits = hit ? 1 : 0;
         ro.spec_misses = hit ? 0 : 1;
         ctx->spec_hit = hit;
@@ -2236,7 +2239,7 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     bool first_piece = true;
     // the pruning incumbent belongs to the FIT, i.e. to the sampler whose stream is being scored (another fit may
     // have used this device between two windows): it travels with the sampler
-    RESERVE(ctx->best_count, 16);
+    RESERVE(ctx->best_count, 32);
     RESERVE(ctx->h_inc, 64);
     if (begin == 0) sampler->incumbent = 0;  // new fit
     *ctx->h_inc.as<uint32_t>() = sampler->incumbent;
