@@ -520,8 +520,8 @@ def main():
     transports = None
     if world > 1:
         mine = {"rank": rank, "device": local,
-                "transport": ("gloo all-gather over host memory (rehearsal)" if rehearsal else
-                              ("gloo all-gather over host memory: " + transport_note if transport_note else "RCCL ncclAllGather on the library's stream")),
+                "transport": ("gloo all-gather over host memory: " + transport_note if transport_note else
+                              ("gloo all-gather over host memory (rehearsal)" if rehearsal else "RCCL ncclAllGather on the library's stream")),
                 "rccl_init_ms": rccl_init_ms}
         transports = [None] * world
         dist.all_gather_object(transports, mine)
