@@ -184,8 +184,14 @@ DeviceCtx* get_ctx(int device) {
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_compact, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    {   // (a high-priority stream: its short latency-bound kernels get in between the scoring workgroups)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        ok = ok && hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, hi) == hipSuccess;
+    }
     for (int k = 0; k < 2 && ok; ++k)
-        ok = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess &&
+        ok = hipEventCreateWithFlags(&c->slot[k].pre_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreate(&c->slot[k].k0) == hipSuccess && hipEventCreate(&c->slot[k].k1) == hipSuccess &&
              hipEventCreate(&c->slot[k].k2) == hipSuccess && hipEventCreate(&c->slot[k].k3) == hipSuccess;
     if (!ok) {
@@ -424,7 +430,10 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                        const PickFinal* pick_final = nullptr /* one GPU: the chunk's last kernel takes pick_best_k's decision
                                                                 and stores the completion word the host polls (no event) */,
                        bool nothing_to_prune = false /* the fit's ONLY chunk, issued without a lead pass: no incumbent will
-                                                        ever exist while it runs */) {
+                                                        ever exist while it runs */,
+                       bool pre = false /* a later chunk of a one-GPU fit: MinimalFit and the box tests go to ctx->pre_stream and
+                                           run under the scoring launches of the chunk before (the main stream waits for
+                                           s.pre_done in front of the keep masks) */) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const bool dense = use_dense_scoring();
@@ -458,7 +467,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (dense) {
         RESERVE(ctx->partial, sizeof(uint32_t) * (size_t)n_tiles * h_pad);
     } else {
-        RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * (h_pad / 64));
+        RESERVE(s.masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * (h_pad / 64));
         RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)(h_pad / 64));
         RESERVE(ctx->counts_rep, sizeof(uint32_t) * ((size_t)kCountReplicas * h_pad + kPairReplicas));
     }
@@ -467,7 +476,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (ms_sample) *ms_sample += now_ms() - t0;
     // the sample table is read by minimal_fit_k straight from the slot's page-locked host array (device-visible): 12 bytes
     // per hypothesis over the host link inside the kernel instead of a copy command in front of it
-    if (!dense && prune) RESERVE(ctx->ub, sizeof(uint32_t) * 2 * (size_t)h_pad);   // ub[h_pad], then the phase counters ubp[h_pad]
+    if (!dense && prune) RESERVE(s.ub, sizeof(uint32_t) * 2 * (size_t)h_pad);   // ub[h_pad], then the phase counters ubp[h_pad]
     // (decided here because minimal_fit_k prepares the lead pass of a NEW fit itself: see LeadPrep)
     const bool use_lead = !dense && prune && lead >= 64 && lead % 64 == 0 && lead + 64 <= count && (!comm || sl_pad >= lead + 64);
     const bool own_real_ = !comm || (size_t)rank * sl_pad < count;
@@ -485,12 +494,14 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         lp.n_lead = all_prepared ? h_pad : lead;
         lp.n_pair = kPairReplicas;
     }
+    pre = pre && !dense && prune && !new_fit && !comm && lead == 0 && !ctx->poison_pending && ctx->pre_stream && s.pre_done;
+    hipStream_t st_pre = pre ? ctx->pre_stream : ctx->stream;
     launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
-                       s.params.as<double>(), s.valid.as<uint8_t>(), ctx->stream,
-                       (!dense && prune) ? ctx->ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
+                       s.params.as<double>(), s.valid.as<uint8_t>(), st_pre,
+                       (!dense && prune) ? s.ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
                        new_fit ? ctx->best_count.as<uint32_t>() : nullptr, (lead_prepared || all_prepared) ? &lp : nullptr, sv.max_abs,
                        cull32 ? &c32 : nullptr, (ctx->poison_pending && kind == M3D_PLANE) ? &ctx->pending_poison : nullptr,
-                       (!dense && prune) ? ctx->ub.as<uint32_t>() + h_pad : nullptr);
+                       (!dense && prune) ? s.ub.as<uint32_t>() + h_pad : nullptr);
     if (ctx->poison_pending && kind == M3D_PLANE) {   // (the previous round's tombstone pass went with it)
         ctx->poison_pending = false;
         if (ctx->poison_expected_at) *ctx->poison_expected_at += ctx->poison_pending_count;
@@ -520,11 +531,11 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         // this rank's groups [g0, g1) of the chunk
         const uint32_t g0 = comm ? rank * (sl_pad / 64) : 0u, g1 = comm ? g0 + sl_pad / 64 : n_groups;
         const bool own_real = (size_t)g0 * 64 < count;   // (a short last window can leave the highest ranks without work)
-        uint32_t* ub = prune ? ctx->ub.as<uint32_t>() : nullptr;
+        uint32_t* ub = prune ? s.ub.as<uint32_t>() : nullptr;
         // phased scoring (launch_score_phased): an incumbent exists, the fp32 box tests run (they count the touched tiles per
         // phase), no tombstones
         uint32_t* ubp = (prune && (use_lead || !new_fit) && c32.out && !sv.has_dead && score_phases_for(kind) != 0) ? ub + h_pad : nullptr;   // (an incumbent exists: this chunk's lead pass, or earlier chunks / windows -- sharded fits included: every rank prunes its slice against the same incumbent)
-        auto* masks = ctx->masks.as<unsigned long long>();
+        auto* masks = s.masks.as<unsigned long long>();
         auto* keep = ctx->keep.as<unsigned long long>();
         uint32_t* pair_rep = ctx->counts_rep.as<uint32_t>() + (size_t)kCountReplicas * h_pad;
         uint32_t* bc = prune ? ctx->best_count.as<uint32_t>() : nullptr;
@@ -563,8 +574,12 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
                     launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
                                      ctx->stream, /*ub_is_zero=*/true, 0, ga, c32.out);
-                launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, ctx->stream,
+                launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, st_pre,
                                  /*ub_is_zero=*/true, g0, g1, c32.out, ubp);
+            }
+            if (pre) {   // everything below needs the records, the masks and ub: the main stream picks up here
+                HIPCHK(hipEventRecord(s.pre_done, ctx->pre_stream));
+                HIPCHK(hipStreamWaitEvent(ctx->stream, s.pre_done, 0));
             }
             uint32_t g_lo = g0;
             if (ga) {
@@ -1145,10 +1160,18 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     const double* best_dev = ctx->best_params.as<double>();
     int best_slot = -1;
     // in_flight: hypotheses already issued whose records have not been replayed yet
+    static const bool prestream_on = [] {
+        const char* e = std::getenv("M3D_PRESTREAM");
+        return !(e && e[0] == '0');
+    }();
     auto issue_next = [&](int slot_id, size_t in_flight, size_t forced = 0) -> int {
+        // a later chunk of a probability-1 fit on one GPU: its MinimalFit and box tests run on pre_stream, under the scoring
+        // launches of the chunk before (issue_chunk, `pre`)
+        const bool pre = prestream_on && prob >= 1.0 && !comm && next_begin > 0 && !use_dense_scoring() && !ctx->poison_pending;
         if (slot_id == best_slot) {   // the slot holding the best model is recycled: move the record out first
+            // (on the stream that is about to overwrite the slot: MinimalFit of the new chunk)
             HIPCHK(hipMemcpyAsync(ctx->best_params.p, best_dev, sizeof(double) * kModelStride, hipMemcpyDeviceToDevice,
-                                  ctx->stream));
+                                  pre ? ctx->pre_stream : ctx->stream));
             best_dev = ctx->best_params.as<double>();
             best_slot = -1;
         }
@@ -1182,7 +1205,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
         int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
                             b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec && !fused_pick,
-                            fused_pick ? &pf : nullptr, /*nothing_to_prune=*/b == 0 && e == max_iter && lead == 0 && !comm);
+                            fused_pick ? &pf : nullptr, /*nothing_to_prune=*/b == 0 && e == max_iter && lead == 0 && !comm, pre);
         const bool spec_adaptive = spec_enabled && prob < 1.0 && hinted_chunk && b == 0 && !comm && !use_dense_scoring();
         if (r == M3D_OK && fused_pick && (spec || spec_adaptive) && e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
             // (a segmentation round: the partition of the rest rides along, decided without the inlier count: -2)

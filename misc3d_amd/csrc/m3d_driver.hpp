@@ -52,6 +52,9 @@ struct PinBuf {
 struct ChunkSlot {
     DevBuf samples, score, params, valid, counts;
     DevBuf cull32;   // fp32 records of the box tests (cull_tiles32_k), pairwise interleaved
+    DevBuf masks, ub;   // the chunk's (tile, group) bit masks and touched-tile counters: per SLOT, so that the next chunk's box
+                        // tests can run (DeviceCtx::pre_stream) while this chunk is being scored
+    hipEvent_t pre_done = nullptr;   // MinimalFit + box tests of the chunk finished on pre_stream
     PinBuf h_samples, h_counts, h_valid;
     bool lead_fused = false;   // the chunk's lead pass ran inside cull_lead_k (no launch, no timing events of its own)
     hipEvent_t done = nullptr;
@@ -70,6 +73,7 @@ struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // RefineModel: the inlier list goes to the host while the GeneralFit sums run
+    hipStream_t pre_stream = nullptr;    // MinimalFit + box tests of chunk k + 1 under the scoring launches of chunk k (fits of several chunks)
     hipEvent_t ev_compact = nullptr;
     std::mutex mu;  // one call at a time per device
     ChunkSlot slot[2];
