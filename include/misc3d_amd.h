@@ -415,7 +415,12 @@ typedef struct m3d_config {
                                        tiles, re-pruned with what every hypothesis collected (count so far + 512 per tile it can still touch
                                        against the incumbent: exact), (3: counted on a second quarter, re-pruned,) and only the survivors
                                        see the rest; 0: one launch over all tiles */
-    int32_t reserved[2];            /* zero.  Fields are only ever APPENDED in front of this array (which shrinks): the offsets of
+    int32_t compact_one_pass;       /* [M3D_COMPACT_ONE_PASS=1]  default 0; 1: RefineModel's / a removal's ordered compaction of up to 1024 tiles
+                                       (2 M points) is ONE launch -- a workgroup publishes its tile's count and waits for the counts of the
+                                       tiles below it (compact_write_k, ONE) -- instead of a counting launch and a writing launch.  Same
+                                       output, position for position; measured SLOWER (a count crossing the XCDs' L2s costs more than the
+                                       launch boundary it replaces: profiles/r04_compact_one_pass.txt) */
+    int32_t reserved[1];            /* zero.  Fields are only ever APPENDED in front of this array (which shrinks): the offsets of
                                        existing fields do not move (round 3 itself had re-used four slots in place) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);

@@ -57,6 +57,7 @@ void load_env() {
     g_cfg.score_waves4 = env_is("M3D_SCORE_WAVES4", '1');   // C2 0.1059 ms against 0.1020 (one-wave workgroups), C3 equal: off
     g_cfg.score_waves4_groups = (int32_t)env_long("M3D_WAVES4_GPB", 64);
     g_cfg.score_phases = (int32_t)env_long("M3D_SCORE_PHASES", -1);
+    g_cfg.compact_one_pass = env_is("M3D_COMPACT_ONE_PASS", '1');   // C5 rounds 17.4 against 15.3 ms, C2 step +8 us: off (profiles/r04_compact_one_pass.txt)
     sanitize(g_cfg);
 }
 }  // namespace
@@ -68,6 +69,7 @@ const m3d_config& config() {
 void config_store(const m3d_config& c) {
     std::call_once(g_once, load_env);
     g_cfg = c;
+    g_cfg.compact_one_pass = env_is("M3D_COMPACT_ONE_PASS", '1');   // C5 rounds 17.4 against 15.3 ms, C2 step +8 us: off (profiles/r04_compact_one_pass.txt)
     sanitize(g_cfg);
 }
 }  // namespace m3d

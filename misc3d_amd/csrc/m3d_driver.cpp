@@ -700,17 +700,32 @@ static void unpack_slot(ChunkSlot& s) {
     }
 }
 
+// Scratch of launch_compact (m3d_kernels.hpp, CompactScratch): one slot per compaction workgroup, zero when the buffer is
+// (re)allocated and when the epoch counter starts over; every launch gets the next epoch.
+static int compact_scratch(DeviceCtx* ctx, uint32_t nb, CompactScratch* out) {
+    const size_t need = sizeof(uint32_t) * ((size_t)nb + 1);
+    const bool grow = ctx->block_counts.cap < need;
+    if (grow) RESERVE(ctx->block_counts, need);
+    if (ctx->compact_epoch >= kCompactEpochs) ctx->compact_epoch = 0;
+    if (grow || ctx->compact_epoch == 0)
+        HIPCHK(hipMemsetAsync(ctx->block_counts.p, 0, ctx->block_counts.cap, ctx->stream));
+    out->slots = ctx->block_counts.as<uint32_t>();
+    out->tag = ++ctx->compact_epoch << 12;
+    return M3D_OK;
+}
+
 // EvaluateModel's (inlier_num, error) with the error summed in point order (ransac.h:632-640).
 static int exact_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
                        const double* model_dev, uint64_t* count, double* error) {
     const uint32_t nb = (v.n + kCompactTile - 1) / kCompactTile;
     RESERVE(ctx->dist, sizeof(double) * (size_t)std::max<uint32_t>(v.n, 1));
-    RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)nb + 1));
+    CompactScratch scratch;
+    if (const int rc = compact_scratch(ctx, nb, &scratch); rc != M3D_OK) return rc;
     RESERVE(ctx->total, sizeof(uint32_t) * 4);
     RESERVE(ctx->sums, sizeof(double) * 32);
     RESERVE(ctx->h_small, 256);
     launch_compact(kind, v, model_dev, thr, 1, nullptr, nullptr, ctx->dist.as<double>(), nullptr,
-                   nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
+                   nullptr, nullptr, nullptr, 0, scratch,
                    ctx->total.as<uint32_t>(), ctx->stream);
     launch_serial_sum(ctx->dist.as<double>(), ctx->total.as<uint32_t>(), ctx->sums.as<double>() + 16,
                       ctx->stream);
@@ -871,7 +886,8 @@ static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, c
     const uint32_t n = flag_view.n;
     const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
     RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
-    RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)nb + 1));
+    CompactScratch scratch;
+    if (const int rc = compact_scratch(ctx, nb, &scratch); rc != M3D_OK) return rc;
     RESERVE(ctx->total, sizeof(uint32_t) * 4);
     fused = fused && kind != M3D_CYLINDER;
     if (fused) {
@@ -880,7 +896,7 @@ static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, c
     }
     launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev,
                    idx_dev(ctx), nullptr,
-                   nullptr, nullptr, nullptr, nullptr, 0, ctx->block_counts.as<uint32_t>(),
+                   nullptr, nullptr, nullptr, nullptr, 0, scratch,
                    ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
                    fused ? ctx->moment_partial.as<double>() : nullptr, fused ? h_moments_at(ctx) : nullptr,
                    idx_host, static_cast<uint32_t*>(total_host) /* pinned: the kernel writes the total there itself */, part);
@@ -1631,7 +1647,8 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
     const uint32_t nb = (cur.n + kCompactTile - 1) / kCompactTile;
     const uint32_t snb = (c->n_sorted + kCompactTile - 1) / kCompactTile;
     const uint32_t scap = c->n_tiles0 * kTilePoints;
-    RESERVE(ctx->block_counts, sizeof(uint32_t) * ((size_t)std::max(nb, snb) + 1));
+    CompactScratch scratch;
+    if (const int rc = compact_scratch(ctx, std::max(nb, snb), &scratch); rc != M3D_OK) return rc;
     RESERVE(ctx->total, 16);
     RESERVE(ctx->h_small, 256);
     w.partition_done = partition_done;
@@ -1641,7 +1658,7 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
     uint32_t* h_totals = reinterpret_cast<uint32_t*>(ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot);
     if (!partition_done)
         launch_compact(kind, cur, model_dev, thr, 2, w.cur_orig, nullptr, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap,
-                       ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>(), ctx->stream, nullptr, nullptr, nullptr,
+                       scratch, ctx->total.as<uint32_t>(), ctx->stream, nullptr, nullptr, nullptr,
                        nullptr, h_totals);
     w.issue_poison = kind == M3D_PLANE && expected_removed >= 0 && poison_fits(c, (uint64_t)expected_removed);
     if (w.issue_poison) {
@@ -1675,9 +1692,10 @@ static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* 
     sview.nx = sview.ny = sview.nz = nullptr;
     sview.n = c->n_sorted;
     sview.n_pad = w.scur.n_tiles * kTilePoints;
+    if (const int rc = compact_scratch(ctx, std::max(nb, snb), &scratch); rc != M3D_OK) return rc;   // (a launch of its own: the next epoch)
     launch_compact(kind, sview, model_dev, thr, 3, nullptr, nullptr, nullptr, w.sbx[w.spp].as<double>(),
                    w.sby[w.spp].as<double>(), w.sbz[w.spp].as<double>(), nullptr, scap,
-                   ctx->block_counts.as<uint32_t>(), ctx->total.as<uint32_t>() + 1, ctx->stream, nullptr, nullptr, nullptr,
+                   scratch, ctx->total.as<uint32_t>() + 1, ctx->stream, nullptr, nullptr, nullptr,
                    nullptr, h_totals + 1);
     HIPCHK(hipGetLastError());
     return M3D_OK;

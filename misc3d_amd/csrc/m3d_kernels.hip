@@ -17,7 +17,10 @@
 //   * Integer results only (counts, indices) leave the scoring path; fp64 sums that the reference
 //     forms serially are either reproduced serially (serial_sum_k) or are tolerance-checked
 //     parameters (GeneralFit), never inlier decisions.
+#include <cstdio>
+#include <cstdlib>
 #include "m3d_kernels.hpp"
+#include "m3d_config.hpp"
 #include "m3d_poison.hpp"
 
 #include "m3d_fp.hpp"
@@ -561,51 +564,62 @@ __device__ __forceinline__ void compact_tail_total(const CompactTail& t, uint32_
     if (t.moment_out) t.moment_out[12] = (double)total;
 }
 
-template <int KIND, int MODE>
+// RefineModel's moment partials folded by ONE workgroup of 256 threads (what scan_blocks_k did: thread (g, l) sums workgroups
+// l, l + 64, ... of value g, then a 64-leaf tree -- the same order, the same sums)
+__device__ __forceinline__ void fold_moment_partials(const CompactTail& tail) {
+    __shared__ double msum[4 * 64];
+    const uint32_t gq = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    for (uint32_t g0 = 0; g0 < 12u; g0 += 4u) {
+        const uint32_t g = g0 + gq;
+        double a = 0.0;
+        for (uint32_t b = l; b < tail.nb; b += 64u) a += tail.moment_partial[(size_t)b * 16 + g];
+        msum[gq * 64 + l] = a;
+        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) {
+            if ((int)l < off) msum[gq * 64 + l] += msum[gq * 64 + l + off];
+            __syncthreads();
+        }
+        if (l == 0) tail.moment_out[g] = msum[gq * 64];
+        __syncthreads();
+    }
+}
+
+// ONE = true: the counting pass rides in THIS launch (compact_count_k and its launch tail are gone).  A workgroup classifies
+// its tile, PUBLISHES the count in slots[tile] -- tagged with the launch's epoch (host counter, `tag`), the count in the low 12
+// bits -- and waits for the tagged counts of the tiles below it while it sums them: the tiles of a launch classify at the
+// same time, a tile's wait ends with the slowest of the tiles below it, and nothing a workgroup waits for waits for a higher
+// tile.  The launcher uses this form only while EVERY workgroup of the launch is resident at once (kCompactOnePassMaxTiles),
+// so no assumption about the dispatch order is made.  No ticket either: a same-address atomic per workgroup costs ~30 ns,
+// serialised -- 489 of them cost more than the launch they replace (measured: the first form of this kernel, with a tile
+// ticket and a completion ticket, made the C2 step 28 us SLOWER).  SUMS: a tile's moment partial is written (and released)
+// BEFORE its count, so the last tile, once it has seen every count, folds the partials -- in compact_count_k<.., true>'s
+// order: the same sums.  The output is the two-pass output, position for position.
+// MEASURED (profiles/r04_compact_one_pass.txt): slower than the two launches -- a segmentation round on ~1 M points 101 us
+// against 89, the C2 step +8 us: a published count reaches the other XCDs through memory, and the ~490 workgroups' waits for
+// it cost more than the ~5 us launch boundary.  Opt-in (m3d_config.compact_one_pass), kept as the tested alternative.
+// ONE = false: `slots` holds compact_count_k's raw counts (m3d_config.compact_one_pass = 0, or more tiles than fit the chip).
+template <int KIND, int MODE, bool ONE, bool SUMS>
 __global__ __launch_bounds__(256) void compact_write_k(
     CloudView c, const double* __restrict__ model, double thr, const uint32_t* __restrict__ orig,
-    const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ out_idx,
+    uint32_t* __restrict__ slots, uint32_t tag, uint64_t* __restrict__ out_idx,
     double* __restrict__ out_dist, double* __restrict__ ox, double* __restrict__ oy,
     double* __restrict__ oz, uint32_t* __restrict__ oorig, uint32_t n_pad_cap,
     uint64_t* __restrict__ out_idx_host /* MODE 0 / 4: the caller's page-locked index list, written as well (may be null) */,
-    CompactTail tail) {
+    CompactTail tail, double* __restrict__ model_copy, double* moment_partial) {
+    static_assert(!SUMS || (ONE && KIND != 2 && (MODE == 0 || MODE == 4)), "the moments ride in a one-pass inlier compaction");
+    static_assert(kCompactTile < (1 << 12), "a tile's count shares its slot with the epoch tag");
     __shared__ uint32_t wsum[4];
-    double m[7];
-    for (int k = 0; k < 7; ++k) m[k] = model[k];
+    constexpr uint32_t kCountMask = 0xFFFu;
+    const uint32_t tile = blockIdx.x;
+    constexpr int NM = ONE ? kModelStride : 7;
+    double m[NM];
+    for (int k = 0; k < NM; ++k) m[k] = model[k];
+    // the model record (8 doubles) also goes where the caller wants a copy (pinned host memory): no copy command
+    if (ONE && model_copy && tile == 0 && threadIdx.x < kModelStride) model_copy[threadIdx.x] = model[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // This workgroup's offset = the counts of the workgroups before it, summed here (block_offsets holds compact_count_k's
-    // RAW counts): a few hundred loads per workgroup, all workgroups at once, against a one-workgroup scan kernel and its
-    // launch gap (7 us) between the counting and the writing pass.
-    uint32_t row_base;
-    {
-        uint32_t part = 0;
-        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256u) part += block_offsets[i];
-        for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off, 64);
-        if (lane == 0) wsum[wave] = part;
-        __syncthreads();
-        row_base = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        __syncthreads();
-    }
-    // workgroup 0 also folds RefineModel's moment partials (what scan_blocks_k did: thread (g, l) sums workgroups l, l + 64,
-    // ... of value g, then a 64-leaf tree -- the same order, the same sums)
-    if (tail.moment_partial && blockIdx.x == 0) {   // (workgroup-uniform)
-        __shared__ double msum[4 * 64];
-        const uint32_t gq = threadIdx.x >> 6, l = threadIdx.x & 63u;
-        for (uint32_t g0 = 0; g0 < 12u; g0 += 4u) {
-            const uint32_t g = g0 + gq;
-            double a = 0.0;
-            for (uint32_t b = l; b < tail.nb; b += 64u) a += tail.moment_partial[(size_t)b * 16 + g];
-            msum[gq * 64 + l] = a;
-            __syncthreads();
-            for (int off = 32; off > 0; off >>= 1) {
-                if ((int)l < off) msum[gq * 64 + l] += msum[gq * 64 + l + off];
-                __syncthreads();
-            }
-            if (l == 0) tail.moment_out[g] = msum[gq * 64];
-            __syncthreads();
-        }
-    }
-    const uint32_t base = blockIdx.x * kCompactTile;
+    // ONE = false: workgroup 0 also folds RefineModel's moment partials
+    if (!ONE && tail.moment_partial && blockIdx.x == 0) fold_moment_partials(tail);   // (workgroup-uniform)
+    const uint32_t base = tile * kCompactTile;
     // All of the workgroup's rows are loaded and classified FIRST (8 rows x 3 coordinates in flight per thread), the
     // per-row wave counts meet in LDS behind ONE barrier, then every row is written.  (A barrier per row serialised
     // eight load -> ballot -> store round trips: mode 4 ran at 2.3 TB/s, 23 us per segmentation round on 1 M points.)
@@ -623,6 +637,13 @@ __global__ __launch_bounds__(256) void compact_write_k(
         pz[r] = in ? c.z[i] : 0.0;
         og[r] = (MODE == 0 || MODE == 2 || MODE == 4) ? (in && orig ? orig[i] : i) : 0u;
     }
+    // SUMS: GeneralFit's raw moments over the inliers (compact_count_k<.., true>: the same expressions, the same per-thread
+    // row order, the same tree)
+    constexpr int NV = SUMS ? (KIND == 1 ? 12 : 9) : 1;
+    double acc[NV];
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    const double c0x = SUMS ? (KIND == 0 ? m[4] : m[0]) : 0.0, c0y = SUMS ? (KIND == 0 ? m[5] : m[1]) : 0.0,
+                 c0z = SUMS ? (KIND == 0 ? m[6] : m[2]) : 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = base + r * 256 + threadIdx.x;
@@ -633,6 +654,24 @@ __global__ __launch_bounds__(256) void compact_write_k(
         // f: what modes 0 / 1 / 4 list (the inliers) resp. what modes 2 / 3 keep (the rest); g (mode 4): the rest
         // (mode 3, the sorted copy: its dead points -- x = NaN, poison_plane_inliers_k -- are dropped with the inliers)
         const bool f = MODE == 3 ? (in && !inl && px[r] == px[r]) : (MODE == 2 ? (in && !inl) : inl);
+        if (SUMS && f) {
+            const double sx = px[r] - c0x, sy = py[r] - c0y, sz = pz[r] - c0z;
+            acc[0] += sx;
+            acc[1] += sy;
+            acc[2] += sz;
+            acc[3] += sx * sx;
+            acc[4] += sx * sy;
+            acc[5] += sx * sz;
+            acc[6] += sy * sy;
+            acc[7] += sy * sz;
+            acc[8] += sz * sz;
+            if (KIND == 1) {
+                const double q = (sx * sx + sy * sy) + sz * sz;
+                acc[9] += sx * q;
+                acc[10] += sy * q;
+                acc[11] += sz * q;
+            }
+        }
         bf[r] = __ballot(f);
         if (MODE == 4) bg[r] = __ballot(in && !inl);
         if (lane == 0) {
@@ -641,6 +680,53 @@ __global__ __launch_bounds__(256) void compact_write_k(
         }
     }
     __syncthreads();
+    // This workgroup's offset = the counts of the tiles below it, summed here: a few hundred loads per workgroup, all
+    // workgroups at once, against a one-workgroup scan kernel and its launch gap (7 us) between two passes.
+    uint32_t row_base;
+    {
+        if (SUMS) {   // the tile's moment partial, out before its count
+            __shared__ double sm[NV * 256];
+            block_tree_reduce<NV>(acc, sm);
+            if (threadIdx.x < 12) {
+                moment_partial[(size_t)tile * 16 + threadIdx.x] = (int)threadIdx.x < NV ? sm[threadIdx.x * 256] : 0.0;
+                __threadfence();   // (release / acquire at agent scope around the count: the partials cross L2s, error_sum_k)
+            }
+            __syncthreads();
+        }
+        if (ONE && threadIdx.x == 0) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) mine += (wf[r][0] + wf[r][1]) + (wf[r][2] + wf[r][3]);
+            __hip_atomic_store(slots + tile, tag | mine, SUMS ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t part = 0;
+        if (ONE) {
+            // every thread asks for ALL its slots first (kCompactOnePassMaxTiles / 256 of them), then goes back to the ones
+            // that were not out yet
+            constexpr int kMine = (kCompactOnePassMaxTiles + 255) / 256;
+            uint32_t v[kMine];
+#pragma unroll
+            for (int k = 0; k < kMine; ++k) {
+                const uint32_t i = threadIdx.x + 256u * (uint32_t)k;
+                v[k] = i < tile ? __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+            }
+#pragma unroll
+            for (int k = 0; k < kMine; ++k) {
+                const uint32_t i = threadIdx.x + 256u * (uint32_t)k;
+                while ((v[k] & ~kCountMask) != tag) {
+                    __builtin_amdgcn_s_sleep(1);
+                    v[k] = __hip_atomic_load(slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                part += v[k] & kCountMask;
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < tile; i += 256u) part += slots[i];
+        }
+        for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off, 64);
+        if (lane == 0) wsum[wave] = part;
+        __syncthreads();
+        row_base = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t rest_base = base - row_base;   // (mode 4: every workgroup before this one holds kCompactTile points of the cloud)
 #pragma unroll
@@ -674,9 +760,9 @@ __global__ __launch_bounds__(256) void compact_write_k(
         row_base += (wf[r][0] + wf[r][1]) + (wf[r][2] + wf[r][3]);
         if (MODE == 4) rest_base += (wg[r][0] + wg[r][1]) + (wg[r][2] + wg[r][3]);
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) compact_tail_total(tail, row_base);   // (the last workgroup ends with the total)
-    // NaN padding of the freshly compacted SoA cloud, [n, n_pad): the last workgroup ends with row_base / rest_base = n
-    if ((MODE == 2 || MODE == 3 || MODE == 4) && blockIdx.x == gridDim.x - 1) {
+    if (tile == gridDim.x - 1 && threadIdx.x == 0) compact_tail_total(tail, row_base);   // (the last tile ends with the total)
+    // NaN padding of the freshly compacted SoA cloud, [n, n_pad): the last tile ends with row_base / rest_base = n
+    if ((MODE == 2 || MODE == 3 || MODE == 4) && tile == gridDim.x - 1) {
         const uint32_t n = MODE == 4 ? rest_base : row_base;
         const uint32_t n_pad = min(n_pad_cap, (n + kScoreTile - 1) / kScoreTile * kScoreTile);
         const double nan = u2f(0x7FF8000000000000ull);
@@ -686,13 +772,17 @@ __global__ __launch_bounds__(256) void compact_write_k(
             oz[i] = nan;
         }
     }
+    if (SUMS && tile == gridDim.x - 1) {   // (workgroup-uniform) every count has been seen: every partial is out
+        __threadfence();
+        fold_moment_partials(tail);
+    }
 }
 
 template <int KIND>
 static void launch_compact_kind(const CloudView& c, const double* model, double thr, int mode,
                                 const uint32_t* orig, uint64_t* out_idx, double* out_dist,
                                 double* ox, double* oy, double* oz, uint32_t* oorig,
-                                uint32_t n_pad_out, uint32_t* block_counts, uint32_t* total,
+                                uint32_t n_pad_out, const CompactScratch& scratch, uint32_t* total,
                                 hipStream_t s, double* model_copy, double* moment_partial, double* moment_out,
                                 uint64_t* out_idx_host, uint32_t* total_host, const PartitionOut* part) {
     const uint32_t nb = (c.n + kCompactTile - 1) / kCompactTile;
@@ -704,48 +794,62 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
         return;
     }
     const bool sums = moment_partial && moment_out && mode == 0 && KIND != 2;
-    if (sums)
-        compact_count_k<KIND == 2 ? 0 : KIND, true><<<nb, 256, 0, s>>>(c, model, thr, 0, block_counts, model_copy, moment_partial);
-    else
-        compact_count_k<KIND, false><<<nb, 256, 0, s>>>(c, model, thr, mode == 3 ? 2 : (mode >= 2 ? 1 : 0), block_counts, model_copy, nullptr);
+    const bool one = config().compact_one_pass != 0 && nb <= kCompactOnePassMaxTiles && scratch.tag != 0u;
+    uint32_t* block_counts = scratch.slots;
+    const uint32_t tag = scratch.tag;
+    if (!one) {
+        if (sums)
+            compact_count_k<KIND == 2 ? 0 : KIND, true><<<nb, 256, 0, s>>>(c, model, thr, 0, block_counts, model_copy, moment_partial);
+        else
+            compact_count_k<KIND, false><<<nb, 256, 0, s>>>(c, model, thr, mode == 3 ? 2 : (mode >= 2 ? 1 : 0), block_counts, model_copy, nullptr);
+    }
     CompactTail tail;
     tail.total = total;
     tail.total_host = total_host;
     tail.moment_partial = sums ? moment_partial : nullptr;
     tail.moment_out = sums ? moment_out : nullptr;
     tail.nb = nb;
-    if (mode == 0 && part && orig)
-        compact_write_k<KIND, 4><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx, nullptr, part->ox, part->oy,
-                                                     part->oz, part->oorig, part->n_pad_cap, out_idx_host, tail);
-    else if (mode == 0)
-        compact_write_k<KIND, 0><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, out_idx,
-                                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, out_idx_host, tail);
-    else if (mode == 1)
-        compact_write_k<KIND, 1><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                     out_dist, nullptr, nullptr, nullptr, nullptr, 0, nullptr, tail);
-    else if (mode == 2)
-        compact_write_k<KIND, 2><<<nb, 256, 0, s>>>(c, model, thr, orig, block_counts, nullptr,
-                                                     nullptr, ox, oy, oz, oorig, n_pad_out, nullptr, tail);
-    else
-        compact_write_k<KIND, 3><<<nb, 256, 0, s>>>(c, model, thr, nullptr, block_counts, nullptr,
-                                                     nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr, tail);
+    const PartitionOut none;
+    const PartitionOut& po = part ? *part : none;
+    constexpr int KS = KIND == 2 ? 0 : KIND;   // (the moments are a plane's or a sphere's: `sums` is false for cylinders)
+#define M3D_COMPACT_GO(MODE_, ONE_, SUMS_, K_, ...) \
+    compact_write_k<K_, MODE_, ONE_, SUMS_><<<nb, 256, 0, s>>>(c, model, thr, __VA_ARGS__, tail, model_copy, moment_partial)
+    if (mode == 0 && part && orig) {
+        if (one && sums) M3D_COMPACT_GO(4, true, true, KS, orig, block_counts, tag, out_idx, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap, out_idx_host);
+        else if (one) M3D_COMPACT_GO(4, true, false, KIND, orig, block_counts, tag, out_idx, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap, out_idx_host);
+        else M3D_COMPACT_GO(4, false, false, KIND, orig, block_counts, tag, out_idx, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap, out_idx_host);
+    } else if (mode == 0) {
+        if (one && sums) M3D_COMPACT_GO(0, true, true, KS, orig, block_counts, tag, out_idx, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, out_idx_host);
+        else if (one) M3D_COMPACT_GO(0, true, false, KIND, orig, block_counts, tag, out_idx, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, out_idx_host);
+        else M3D_COMPACT_GO(0, false, false, KIND, orig, block_counts, tag, out_idx, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, out_idx_host);
+    } else if (mode == 1) {
+        if (one) M3D_COMPACT_GO(1, true, false, KIND, orig, block_counts, tag, nullptr, out_dist, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
+        else M3D_COMPACT_GO(1, false, false, KIND, orig, block_counts, tag, nullptr, out_dist, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
+    } else if (mode == 2) {
+        if (one) M3D_COMPACT_GO(2, true, false, KIND, orig, block_counts, tag, nullptr, nullptr, ox, oy, oz, oorig, n_pad_out, nullptr);
+        else M3D_COMPACT_GO(2, false, false, KIND, orig, block_counts, tag, nullptr, nullptr, ox, oy, oz, oorig, n_pad_out, nullptr);
+    } else {
+        if (one) M3D_COMPACT_GO(3, true, false, KIND, nullptr, block_counts, tag, nullptr, nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr);
+        else M3D_COMPACT_GO(3, false, false, KIND, nullptr, block_counts, tag, nullptr, nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr);
+    }
+#undef M3D_COMPACT_GO
 }
 
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
-                    uint32_t* block_counts, uint32_t* total, hipStream_t s, double* model_copy,
+                    const CompactScratch& scratch, uint32_t* total, hipStream_t s, double* model_copy,
                     double* moment_partial, double* moment_out, uint64_t* out_idx_host, uint32_t* total_host,
                     const PartitionOut* part) {
     if (kind == 0)
         launch_compact_kind<0>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part);
+                               n_pad_out, scratch, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part);
     else if (kind == 1)
         launch_compact_kind<1>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part);
+                               n_pad_out, scratch, total, s, model_copy, moment_partial, moment_out, out_idx_host, total_host, part);
     else
         launch_compact_kind<2>(c, model, thr, mode, orig, out_idx, out_dist, ox, oy, oz, oorig,
-                               n_pad_out, block_counts, total, s, model_copy, nullptr, nullptr, out_idx_host, total_host, part);
+                               n_pad_out, scratch, total, s, model_copy, nullptr, nullptr, out_idx_host, total_host, part);
 }
 
 // cluster = pcd_copy->SelectByIndex(inliers) (iterative_plane_segmentation.cpp:32): the points of an index list, AoS, in

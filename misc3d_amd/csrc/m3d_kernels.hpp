@@ -94,9 +94,17 @@ void launch_bbox(const double* x, const double* y, const double* z, uint32_t n, 
 // mode 1: out_dist[k] = distance of the k-th inlier
 // mode 2: stable partition of the NON-inliers into (ox,oy,oz,oorig) (segmentation round)
 // mode 3: the same for coordinates only (the Z-order sorted copy)
-// block_counts: scratch of ceil(n / kCompactTile) + 1 uint32; total[0] receives the inlier count.
-// Optional second output of a mode-0 compaction (segmentation round): the same pass also writes the stable partition of the
-// NON-inliers (mode 2's output) -- the flags are the same, so the round saves a count, a scan and a write launch.
+// scratch: one uint32 slot per compaction workgroup (ceil(n / kCompactTile)), ZERO when the buffer is allocated and whenever the
+// owner's epoch counter starts over; tag = the launch's epoch (1 .. 2^20 - 1, a different one for every launch on the buffer) in
+// bits 12..31 -- what the one-pass form marks a published count with (compact_write_k); tag 0: two passes.
+// total[0] receives the inlier count.
+// The one-pass form needs every workgroup of the launch resident at once: 5 workgroups fit a CU (92 VGPRs, 21 KB of LDS).
+constexpr uint32_t kCompactOnePassMaxTiles = 1024;
+constexpr uint32_t kCompactEpochs = 0xFFFFFu;
+struct CompactScratch {
+    uint32_t* slots = nullptr;
+    uint32_t tag = 0;
+};
 struct PartitionOut {
     double *ox = nullptr, *oy = nullptr, *oz = nullptr;
     uint32_t* oorig = nullptr;
@@ -107,7 +115,7 @@ void launch_gather_points(const CloudView& c, const uint64_t* idx, size_t total,
 void launch_compact(int kind, const CloudView& c, const double* model, double thr, int mode,
                     const uint32_t* orig, uint64_t* out_idx, double* out_dist, double* ox,
                     double* oy, double* oz, uint32_t* oorig, uint32_t n_pad_out,
-                    uint32_t* block_counts, uint32_t* total, hipStream_t s,
+                    const CompactScratch& scratch, uint32_t* total, hipStream_t s,
                     double* model_copy = nullptr /* device-visible (pinned host): receives the 8-double model record */,
                     double* moment_partial = nullptr /* mode 0, plane / sphere: scratch of ceil(n / kCompactTile) x 16 doubles ... */,
                     double* moment_out = nullptr /* ... and kFusedMomentDoubles doubles (device-visible host memory): GeneralFit's raw

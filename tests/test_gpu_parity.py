@@ -24,7 +24,8 @@ PATHS = {"culled": {}, "dense": {"dense_scoring": 1}, "no_early_pick": {"specula
          "mfma": {"score_mfma": 1},   # planes: score_mfma_k, the screen on the matrix pipe
          "four_wave_wgs": {"score_waves4": 1},
          "single_launch": {"score_phases": 0},   # (default -1: cylinders in three phases with re-pruning in between, the others in one)
-         "two_phases": {"score_phases": 2}, "three_phases": {"score_phases": 3}}   # score_screen4_k: four waves share a tile's compacted id list
+         "two_phases": {"score_phases": 2}, "three_phases": {"score_phases": 3},
+         "one_pass_compaction": {"compact_one_pass": 1}}   # compact_write_k, ONE: counts published and awaited inside the launch
 
 
 @pytest.fixture(params=sorted(PATHS))
