@@ -377,7 +377,8 @@ typedef struct m3d_config {
     int32_t dense_scoring;          /* [M3D_DENSE=1]        1: score every (tile, hypothesis) pair (score_k) instead of the culled path */
     int32_t speculative_refine;     /* [M3D_SPEC=0]         default 1: probability-1 fits start RefineModel on the device's own pick */
     int32_t lead_hypotheses;        /* [M3D_LEAD]           default 128 (multiple of 64): hypotheses counted first for the pruning incumbent */
-    int32_t score_groups_per_block; /* [M3D_GPB]            default 8: 64-hypothesis groups per scoring workgroup (1..64; the fp32-screen kernels take at most 8) */
+    int32_t score_groups_per_block; /* [M3D_GPB]            default 8: 64-hypothesis groups per scoring workgroup (1..64); the fp32-screen kernels take twice that for
+                                       windows of 192 groups and more, and at most 16 */
     int32_t score_min_workgroups;   /* [M3D_SCORE_MIN_WGS]  default 8192: small chunks are cut finer to reach this many workgroups */
     int32_t dense_workgroups;       /* [M3D_SCORE_WGS]      default 8192: workgroup target of the dense kernel */
     int32_t reg_neighbour_lists;    /* [M3D_REG_NL=0]       default 1: per-cell 3x3x3 neighbour lists for the registration validation */

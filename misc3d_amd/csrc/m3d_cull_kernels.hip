@@ -637,10 +637,19 @@ __global__ __launch_bounds__(64) void score_mask_k(const double* __restrict__ sx
 // A tile with a non-finite coordinate (the NaN padding of the last tile, or the caller's own) is never screened.
 // ------------------------------------------------------------------------------------------------
 #ifndef M3D_SCREEN_MAX_GROUPS
-#define M3D_SCREEN_MAX_GROUPS 8
+#define M3D_SCREEN_MAX_GROUPS 16
 #endif
 constexpr uint32_t kScreen4MaxGroups = 64;   // score_screen4_k: groups per four-wave workgroup (lane = mask word; the id list: 8 KB)
-constexpr uint32_t kScreenMaxGroups = M3D_SCREEN_MAX_GROUPS;   // 64-hypothesis groups per workgroup (the id list: 1 KB of LDS; 7.2 KB in all: 22 workgroups per CU)
+constexpr uint32_t kScreenMaxGroups = M3D_SCREEN_MAX_GROUPS;   // 64-hypothesis groups per workgroup (the id list: 2 KB of LDS; 8.2 KB in all: 19 workgroups per CU)
+// Groups per scoring workgroup: m3d_config.score_groups_per_block (8), and TWICE that for windows of 192 groups and more.  What a
+// workgroup pays per batch of <= 64 surviving hypotheses -- 64 lanes preparing records, the tile's offsets, the id list -- is
+// worth sharing among more of them where the pruning leaves few per (tile, 8 groups): C3's chunks of 250 groups (~16
+// survivors per workgroup) score_screen_k<2> 0.846 -> 0.801 ms, <1> 0.396 -> 0.377, the fits 1.09 -> 1.05 / 0.72 -> 0.71 ms; C2's
+// window of 155 groups loses 2 % of its launch with 16 (fewer, longer workgroups: the tail) and keeps 8.
+static uint32_t screen_gpb_max(uint32_t window) {
+    const uint32_t g = (uint32_t)config().score_groups_per_block;
+    return std::min<uint32_t>(window >= 192u ? 2u * g : g, kScreenMaxGroups);
+}
 constexpr int kCntStride = 64;              // bytes per row of the count table
 
 // bits: 8 sign bits (point inside <=> 1); m: min over the lane's points of the distance to the decision boundary
@@ -1374,7 +1383,7 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     const uint32_t window = group_end - group_begin;
     // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
     const bool screened = config().score_fp32_screen != 0;
-    const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, screened ? kScreenMaxGroups : 64u);
+    const uint32_t gpb_max = screened ? screen_gpb_max(window) : std::min<uint32_t>((uint32_t)config().score_groups_per_block, 64u);
     const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * window) / min_wgs)));
     const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);
@@ -1450,7 +1459,7 @@ bool launch_score_phased(int kind, const SortedView& s, const double* score, con
         config().score_fp32_screen == 0 || group_begin >= group_end || group_end - group_begin < (forced ? 2u : 32u))
         return false;
     const uint32_t window = group_end - group_begin;
-    const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, kScreenMaxGroups);
+    const uint32_t gpb_max = screen_gpb_max(window);
     const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
     const int n_ph = score_phases_for(kind);
     const uint32_t res[3] = {0x1u, n_ph == 3 ? 0x2u : 0xEu, 0xCu};

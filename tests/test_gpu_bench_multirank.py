@@ -32,6 +32,8 @@ def test_bench_starts_its_own_ranks_and_prints_one_json_line():
     assert all("model_predicted_speedup" in v for v in st.values()) and st["c3cyl"]["model_predicted_speedup"]["exchange_30us"] > 1
     tr = d["transport"]
     assert len(tr["per_rank"]) == 2 and tr["valid_headline"] and "c5_note" in d
+    # N independent fits in flight (no collective): what the GPUs deliver when the jobs do not share a hypothesis stream
+    assert d["replicas"]["collectives"] == 0 and d["replicas"]["value"] > 0
 
 
 @pytest.mark.gpu
