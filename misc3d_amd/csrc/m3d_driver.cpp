@@ -182,7 +182,8 @@ DeviceCtx* get_ctx(int device) {
     c->device = device;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_compact, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&c->ev_compact, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_pre_gate, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     {   // (a high-priority stream: its short latency-bound kernels get in between the scoring workgroups)
         int lo = 0, hi = 0;
@@ -413,6 +414,15 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
     return std::max<size_t>(cap, 64);
 }
 
+// pre_stream runs the head of a fit's later chunks (issue_chunk, `pre`) beside the main stream: whatever the main stream holds
+// when the fit starts -- a removal's compaction of this very cloud, another fit's tail -- must be behind those kernels too.
+static int pre_stream_gate(DeviceCtx* ctx) {
+    if (!ctx->pre_stream || !ctx->ev_pre_gate) return M3D_OK;
+    HIPCHK(hipEventRecord(ctx->ev_pre_gate, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->pre_stream, ctx->ev_pre_gate, 0));
+    return M3D_OK;
+}
+
 // Sharded fits (comm != null): the chunk is the SAME window of the one hypothesis stream on every rank
 // -- sample table, MinimalFit and parameter records for all of it (a thread per hypothesis: microseconds) -- but
 // the box tests and the scoring cover only this rank's slice of `sl_pad` hypotheses (+ the window's leading
@@ -496,13 +506,14 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     }
     pre = pre && !dense && prune && !new_fit && !comm && lead == 0 && !ctx->poison_pending && ctx->pre_stream && s.pre_done;
     hipStream_t st_pre = pre ? ctx->pre_stream : ctx->stream;
-    launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
+    const bool fit_launched =
+        launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), st_pre,
                        (!dense && prune) ? s.ub.as<uint32_t>() : nullptr,    // clears ub[0 .. h_pad) on the way
                        new_fit ? ctx->best_count.as<uint32_t>() : nullptr, (lead_prepared || all_prepared) ? &lp : nullptr, sv.max_abs,
                        cull32 ? &c32 : nullptr, (ctx->poison_pending && kind == M3D_PLANE) ? &ctx->pending_poison : nullptr,
                        (!dense && prune) ? s.ub.as<uint32_t>() + h_pad : nullptr);
-    if (ctx->poison_pending && kind == M3D_PLANE) {   // (the previous round's tombstone pass went with it)
+    if (fit_launched && ctx->poison_pending && kind == M3D_PLANE) {   // (the previous round's tombstone pass went with it)
         ctx->poison_pending = false;
         if (ctx->poison_expected_at) *ctx->poison_expected_at += ctx->poison_pending_count;
     }
@@ -1266,6 +1277,10 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         return r;
     };
     if (max_iter > 0) {
+        if (prestream_on && prob >= 1.0 && !comm && max_iter > chunk && !use_dense_scoring()) {   // (a fit of several chunks)
+            rc = pre_stream_gate(ctx);
+            if (rc != M3D_OK) return rc;
+        }
         rc = issue_next(0, 0);
         if (rc != M3D_OK) return rc;
         bool first_pass = true;
@@ -2278,6 +2293,19 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     };
     size_t j = 0;
     bool first_piece = true;
+    // Slices of several pieces (what a low world size leaves a rank): a SHORT first own piece -- its best count is what prunes
+    // the pieces behind it (run_ransac's short first chunk) -- and MinimalFit + box tests of every later piece on pre_stream,
+    // under the scoring launches of the piece before (issue_chunk, `pre`).
+    static const bool prestream_on = [] {
+        const char* e = std::getenv("M3D_PRESTREAM");
+        return !(e && e[0] == '0');
+    }();
+    constexpr size_t kFirstPiece = 2048;
+    bool first_own = true;
+    if (prestream_on && !use_dense_scoring()) {
+        const int grc = pre_stream_gate(ctx);
+        if (grc != M3D_OK) return grc;
+    }
     // the pruning incumbent belongs to the FIT, i.e. to the sampler whose stream is being scored (another fit may
     // have used this device between two windows): it travels with the sampler
     RESERVE(ctx->best_count, 32);
@@ -2318,12 +2346,16 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
             // the first launch of the call counts its first lead_size() hypotheses on their own (issue_chunk's `lead`)
             const uint32_t lead = first_piece ? lead_size() : 0u;
             first_piece = false;
-            const size_t ee = std::min(e, bb + chunk_cap);
+            const bool short_first = first_own && e - bb > chunk_cap && kFirstPiece >= 2 * (size_t)lead_size();
+            const size_t ee = std::min(e, bb + (short_first ? kFirstPiece : chunk_cap));
+            const bool pre = prestream_on && !first_own && lead == 0;
+            first_own = false;
             sampler->draw_until(ee);
             int rc = collect(cur);
             if (rc != M3D_OK) return rc;
             tsrc.table = sampler->table.data();
-            rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, bb, ee, tsrc, nullptr, true, lead);
+            rc = issue_chunk(ctx, ctx->slot[cur], v, sv, kind, threshold, bb, ee, tsrc, nullptr, true, lead, false, false, nullptr, false,
+                             nullptr, false, pre);
             if (rc != M3D_OK) return rc;
             pend[cur].active = true;
             pend[cur].out_pos = out;
@@ -2570,6 +2602,24 @@ static int segment_impl(const double* xyz, size_t n, double threshold, int max_i
     double t_big = 0;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
+        // The cross-round state of a segmentation (a tombstone pass waiting to ride in the next fit, a RefineModel finished one
+        // round late, lists leaving through the copy engine) lives on the device context and points into THIS call's cloud and
+        // the caller's buffers: however the block is left, the context goes back to idle and keeps none of those pointers
+        // (the explicit resets below stay where their order matters).
+        struct StateGuard {
+            DeviceCtx* ctx;
+            ~StateGuard() {
+                ctx->defer_refine = false;
+                ctx->defer_copy_sync = false;
+                ctx->idx_out_override = nullptr;
+                ctx->poison_pending = false;
+                ctx->poison_expected_at = nullptr;
+                ctx->poison_pending_count = 0;
+                ctx->deferred.pending = false;
+                ctx->deferred.params_out = nullptr;
+                ctx->spec_hit = false;
+            }
+        } state_guard{ctx};
         uint64_t seed0 = 0;
         rc = agree_seed(comm, seed, ctx->stream, &seed0);
         poison_ready = ctx->poison_total.reserve(16) && hipMemsetAsync(ctx->poison_total.p, 0, 16, ctx->stream) == hipSuccess;

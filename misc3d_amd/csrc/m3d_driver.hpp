@@ -124,6 +124,7 @@ struct DeviceCtx {
     PinBuf h_sums;             // GeneralFit: per-workgroup moment partials + coordinate sums, written by the kernels
     DevBuf moment_partial;     // fused RefineModel: per-workgroup raw moments of the compaction's counting pass
     PinBuf h_moments;          // ... folded (scan_blocks_k), device-visible: kFusedMomentDoubles doubles
+    hipEvent_t ev_pre_gate = nullptr;         // recorded on `stream` where a fit starts; pre_stream waits for it (pre_stream_gate)
     uint32_t compact_epoch = 0;               // launch counter of the compaction scratch (compact_scratch)
     bool compaction_fused = false;            // the compaction in flight carried the moments
     uint64_t* compaction_idx_host = nullptr;  // ... and wrote the index list to this page-locked destination as well

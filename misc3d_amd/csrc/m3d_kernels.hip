@@ -256,11 +256,11 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
     }
 }
 
-void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
+bool launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
                         hipStream_t s, uint32_t* zero_u32, uint32_t* zero_one, const LeadPrep* lead, double cull_max_abs,
                         const Cull32Out* cull32, const PoisonJob* poison, uint32_t* zero_u32b) {
-    if (h_pad == 0) return;
+    if (h_pad == 0) return false;
     const uint32_t fit_blocks = (h_pad + 63) / 64;
     const dim3 g(fit_blocks + (kind == 0 && poison ? poison->n_tiles : 0u)), b(64);
     LeadPrep lp;
@@ -275,6 +275,7 @@ void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, u
         minimal_fit_k<1><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_u32b, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
     else
         minimal_fit_k<2><<<g, b, 0, s>>>(c, samples, h_count, h_pad, thr, score, params, valid, zero_u32, zero_u32b, zero_one, lp, cull_max_abs, c32, pj, fit_blocks);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------

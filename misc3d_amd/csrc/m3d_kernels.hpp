@@ -61,7 +61,8 @@ struct LeadPrep {
     unsigned long long* keep = nullptr;
     uint32_t rep_stride = 0, n_rep = 0, n_lead = 0, n_pair = 0;
 };
-void launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
+// returns whether a kernel was launched (h_pad == 0: nothing to do -- and nothing a riding PoisonJob could ride in)
+bool launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, uint32_t h_count,
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
                         hipStream_t s,
                         uint32_t* zero_u32 = nullptr /* h_pad - 1 counters cleared by the same launch */,
