@@ -689,6 +689,21 @@ __device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell
             lb = nx;
         }
     }
+#ifdef M3D_REG_TRIP_STATS
+    if (g.nl32_fallbacks) {   // (diagnostic build: tools only)
+        const uint32_t trips = (uint32_t)max((cr + 1) / 2, (cl + 1) / 2);
+        uint32_t wmax = 0;
+        for (uint32_t k = 1; k < 64u; ++k)
+            if (__ballot(trips >= k) != 0ull) wmax = k;   // (over the lanes that are here)
+        atomicAdd(g.nl32_fallbacks + 8, 1ull);
+        atomicAdd(g.nl32_fallbacks + 9, (unsigned long long)trips);
+        atomicAdd(g.nl32_fallbacks + 16 + min(trips, 23u), 1ull);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {   // first active lane
+            atomicAdd(g.nl32_fallbacks + 10, 1ull);
+            atomicAdd(g.nl32_fallbacks + 11, (unsigned long long)wmax);
+        }
+    }
+#endif
     const float bound = walk_err_bound(m1) + walk_err_bound(m2);   // E(m1) + E(m2)
     const bool decided = m2 == __builtin_inff() ? m1 < __builtin_inff() /* one candidate */ : m2 > m1 + bound * 1.0001f;
     if (!decided) {

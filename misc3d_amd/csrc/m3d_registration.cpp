@@ -225,8 +225,8 @@ int add_neighbour_lists(DeviceCtx* ctx, Scratch& S, GridDesc* gp, size_t n_dst, 
         g.nl32 = screen ? S.nl32.as<uint2>() : nullptr;
         g.nl_rec = screen ? S.nl_rec.as<uint4>() : nullptr;
         if (screen) {
-            RESERVE(S.nl32_fallbacks, sizeof(unsigned long long));
-            HIPCHK(hipMemsetAsync(S.nl32_fallbacks.p, 0, sizeof(unsigned long long), ctx->stream));
+            RESERVE(S.nl32_fallbacks, sizeof(unsigned long long) * 64);   // [0] the counter; [8 ..): M3D_REG_TRIP_STATS builds
+            HIPCHK(hipMemsetAsync(S.nl32_fallbacks.p, 0, sizeof(unsigned long long) * 64, ctx->stream));
             g.nl32_fallbacks = S.nl32_fallbacks.as<unsigned long long>();
         }
         g.nl_start = S.nl_start.as<uint32_t>();
@@ -430,7 +430,12 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
     R.thr = threshold;
 
     {
-        const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, false, &g, 4, /*with_nl=*/false,
+        static const int k0 = [] {   // cells per radius of the validation grid (M3D_REG_K: experiments)
+            const char* e = std::getenv("M3D_REG_K");
+            const long v = e && *e ? std::strtol(e, nullptr, 10) : 4;
+            return (int)std::min<long>(std::max<long>(v, 1), 16);
+        }();
+        const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, false, &g, k0, /*with_nl=*/false,
                                               cdst->bb_known ? cdst->bb : nullptr);
         if (rc_grid != M3D_OK) return rc_grid;
         R.g = g;
@@ -746,6 +751,16 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
             unsigned long long fb = 0;
             HIPCHK(hipMemcpy(&fb, g.nl32_fallbacks, sizeof(fb), hipMemcpyDeviceToHost));
             stats->nn_screen_fallbacks = fb;
+#ifdef M3D_REG_TRIP_STATS
+            {   // the walk's trip counts (sorted_walk32): lane trips, wave maxima, histogram of the lanes' counts
+                unsigned long long t[64];
+                HIPCHK(hipMemcpy(t, g.nl32_fallbacks, sizeof(t), hipMemcpyDeviceToHost));
+                fprintf(stderr, "walk trips: queries %llu lane-trips %llu (mean %.2f) wave-queries %llu sum of wave maxima %llu (mean %.2f); lanes by trips:",
+                        t[8], t[9], (double)t[9] / (double)(t[8] ? t[8] : 1), t[10], t[11], (double)t[11] / (double)(t[10] ? t[10] : 1));
+                for (int k = 0; k < 24; ++k) fprintf(stderr, " %d:%.3f", k, (double)t[16 + k] / (double)(t[8] ? t[8] : 1));
+                fprintf(stderr, "\n");
+            }
+#endif
         }
     }
     if (stats) stats->ms_total = now_ms() - this->t_begin;
