@@ -371,8 +371,91 @@ void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s) {
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
     if (n) max_f32_wide_k<<<std::min<uint32_t>((n + 255) / 256, 256), 256, 0, s>>>(v, n, reinterpret_cast<uint32_t*>(out));
 }
-void launch_max_abs(const double* f, size_t count, double* partial /* 256 */, hipStream_t s) {
-    max_abs_k<<<256, 256, 0, s>>>(f, count, partial);
+void launch_max_abs(const double* f, size_t count, double* partial /* kMaxAbsPartials */, hipStream_t s) {
+    // (256 workgroups read 52.8 MB at 1.1 TB/s: 48 us per matrix; 2048 of them at 3.5 TB/s)
+    max_abs_k<<<kMaxAbsPartials, 256, 0, s>>>(f, count, partial);
+}
+// pack_f16_k for BOTH roles in one pass, a wave per tile of 32 rows (hi-only operands, K = 48).  pack_f16_k gives every row to
+// one thread: 264-byte strides on the way in, 48 two-byte stores per row on the way out -- 108 us per 200 000 rows and layout,
+// four launches per call.  Here the tile's 32 x 33 doubles arrive as ONE contiguous 8.4 KB block (coalesced), are split in LDS,
+// and every lane stores its MFMA fragment -- eight consecutive K-slots of one row -- as one 16-byte word per step and layout.
+// The same values bit for bit: hi = RN16(v scale), the norm summed over k = 0 .. 32 in order from hi + lo in fp64.
+#if M3D_MATCH_HI_ONLY
+__global__ __launch_bounds__(256) void pack_f16_both_k(const double* __restrict__ f, uint32_t n, uint32_t tiles_a, uint32_t tiles_b,
+                                                        double scale, h8* __restrict__ out_a, h8* __restrict__ out_b,
+                                                        float* __restrict__ norm2) {
+    static_assert(kMfmaHiOnly && kMfmaK == 48 && kMfmaNormAt == 33, "the cooperative packer writes the hi-only layout");
+    __shared__ _Float16 hi16[4][32][kMfmaK];   // [wave][row][K-slot]: data 0 .. 32, the row's norm pieces 33 .. 35, zero behind
+    __shared__ double sq[4][32][34];            // (hi + lo)^2 per element (34: the rows of a half-wave fall on different banks)
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t t = blockIdx.x * 4u + wave;
+    if (t >= max(tiles_a, tiles_b)) return;   // (wave-uniform; no barrier below: a wave only talks to itself)
+    const size_t first = (size_t)t * 32u * 33u, total = (size_t)n * 33u;
+    for (uint32_t e = lane; e < 32u * 33u; e += 64u) {
+        const uint32_t r = e / 33u, k = e % 33u;
+        _Float16 hi = (_Float16)0.0f;
+        double rep2 = 0.0;
+        if (first + e < total) {
+            const double v = f[first + e] * scale;
+            hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (double)hi);
+            const double rep = (double)hi + (double)lo;
+            rep2 = rep * rep;
+        }
+        hi16[wave][r][k] = hi;
+        sq[wave][r][k] = rep2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < 32u) {   // lane r: the norm of row r, summed in pack_f16_k's order
+        const uint32_t i = t * 32u + lane;
+        double nrm = 0.0;
+        for (int k = 0; k < 33; ++k) nrm += sq[wave][lane][k];
+        if (i < n) norm2[i] = (float)nrm;
+        // the norm's three fp16 pieces (role 0 pads with 65504: a padding row of the database is never the nearest)
+        double pa = i < n ? nrm / (double)kMfmaC : 65504.0, pb = i < n ? nrm / (double)kMfmaC : 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const _Float16 qa = (_Float16)pa, qb = (_Float16)pb;
+            hi16[wave][lane][33 + k] = qa;        // role 0's own pieces
+            hi16[wave][lane][36 + k] = qb;        // role 1's own pieces (equal to role 0's for a real row)
+            pa -= (double)qa;
+            pb -= (double)qb;
+        }
+        for (int k = 39; k < kMfmaK; ++k) hi16[wave][lane][k] = (_Float16)0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t r = lane & 31u, hb = lane >> 5;
+    const bool real = t * 32u + r < n;   // (a padding row's data slots are +0 in both layouts)
+    const _Float16 c = (_Float16)kMfmaC;
+#pragma unroll
+    for (int st = 0; st < kMfmaSteps; ++st) {
+        h8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = st * 16 + (int)hb * 8 + j;
+            const _Float16 v = hi16[wave][r][k];
+            // role 0 (database rows): -2 hi, own norm pieces at 33 .. 35, 2^15 at 36 .. 38;  role 1 (queries): hi, 2^15 at 33 .. 35, own
+            // pieces at 36 .. 38
+            a[j] = k < 33 ? (real ? (_Float16)(-2.0 * (double)v) : (_Float16)0.0f) : (k < 36 ? v : (k < 39 ? c : (_Float16)0.0f));
+            b[j] = k < 33 ? v : (k < 36 ? c : (k < 39 ? v : (_Float16)0.0f));
+        }
+        if (t < tiles_a) out_a[((size_t)t * kMfmaSteps + st) * 64 + lane] = a;
+        if (t < tiles_b) out_b[((size_t)t * kMfmaSteps + st) * 64 + lane] = b;
+    }
+}
+#endif
+void launch_pack_f16_both(const double* f, uint32_t n, double scale, void* out_a, void* out_b, float* norm2, hipStream_t s) {
+    const uint32_t ta = mfma_tiles(n), tb = mfma_query_tiles(n), tm = std::max(ta, tb);
+    if (!tm) return;
+#if M3D_MATCH_HI_ONLY
+    pack_f16_both_k<<<(tm + 3) / 4, 256, 0, s>>>(f, n, ta, tb, scale, reinterpret_cast<h8*>(out_a), reinterpret_cast<h8*>(out_b), norm2);
+#else
+    launch_pack_f16(f, n, ta, scale, 0, out_a, norm2, s);
+    launch_pack_f16(f, n, tb, scale, 1, out_b, norm2, s);
+#endif
 }
 void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale, int role, void* out, float* norm2,
                      hipStream_t s) {

@@ -126,8 +126,12 @@ hipError_t launch_nn_screened33(const double* q, const float* q32, const float* 
 constexpr int kMfmaRowHalfs = 112;   // fp16 values per packed row
 uint32_t mfma_tiles(uint32_t n);
 uint32_t mfma_query_tiles(uint32_t n);
-void launch_max_abs(const double* f, size_t count, double* partial /* 256 doubles */, hipStream_t s);
+constexpr int kMaxAbsPartials = 2048;   // workgroups of launch_max_abs = doubles it writes
+void launch_max_abs(const double* f, size_t count, double* partial /* kMaxAbsPartials doubles */, hipStream_t s);
 void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s);
+// both layouts of a matrix in one pass: out_a = mfma_tiles(n) tiles in the database (role 0) layout, out_b = mfma_query_tiles(n) tiles
+// in the query (role 1) layout, norm2[n]
+void launch_pack_f16_both(const double* f, uint32_t n, double scale, void* out_a, void* out_b, float* norm2, hipStream_t s);
 void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale, int role, void* out, float* norm2,
                      hipStream_t s);
 // both directions (a -> b and b -> a) from ONE pass over the product tiles (m3d_match_scan.hpp, RevOut)

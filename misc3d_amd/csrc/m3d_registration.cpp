@@ -1390,7 +1390,8 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     };
     uint32_t s01 = splits_for(ns, nd, 512, 256), s10 = splits_for(nd, ns, 512, 256);
     if (!fs.reserve(sizeof(double) * (size_t)dim * ns) || !fd.reserve(sizeof(double) * (size_t)dim * nd) ||
-        !nn01.reserve(sizeof(uint32_t) * ns) || !nn10.reserve(sizeof(uint32_t) * nd) || !scal.reserve(8192))
+        !nn01.reserve(sizeof(uint32_t) * ns) || !nn10.reserve(sizeof(uint32_t) * nd) ||
+        !scal.reserve(8192 + sizeof(double) * 2 * kMaxAbsPartials))
         return done(M3D_ERR_DEVICE);
     std::vector<uint32_t> h01(ns), h10(nd);
     bool ok = hipMemcpyAsync(fs.p, feat_src, sizeof(double) * (size_t)dim * ns, hipMemcpyHostToDevice, ctx->stream) ==
@@ -1400,11 +1401,11 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     double scale = 0.0;
     if (ok && use_mfma) {
         // power-of-two scale that brings max |v| to <= 2048 (fp16 hi/lo split keeps 22 bits; norms / 2^15 fit)
-        double* part = scal.as<double>() + 16;   // 2 x 256 partial maxima
+        double* part = scal.as<double>() + 16;   // 2 x kMaxAbsPartials partial maxima
         launch_max_abs(fs.as<double>(), (size_t)ns * 33, part, ctx->stream);
-        launch_max_abs(fd.as<double>(), (size_t)nd * 33, part + 256, ctx->stream);
-        std::vector<double> hp(512);
-        ok = hipMemcpyAsync(hp.data(), part, sizeof(double) * 512, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+        launch_max_abs(fd.as<double>(), (size_t)nd * 33, part + kMaxAbsPartials, ctx->stream);
+        std::vector<double> hp(2 * kMaxAbsPartials);
+        ok = hipMemcpyAsync(hp.data(), part, sizeof(double) * 2 * kMaxAbsPartials, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
         double mx = 0.0;
         for (double v : hp) mx = (v > mx || v != v) ? v : mx;
@@ -1440,10 +1441,8 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
             !pB_s.reserve(tile_bytes * mfma_query_tiles(ns)) || !pB_d.reserve(tile_bytes * mfma_query_tiles(nd)) ||
             !premin.reserve(sizeof(float) * part))
             return done(M3D_ERR_DEVICE);
-        launch_pack_f16(fs.as<double>(), ns, mfma_tiles(ns), scale, 0, pA_s.p, ns2.as<float>(), ctx->stream);
-        launch_pack_f16(fd.as<double>(), nd, mfma_tiles(nd), scale, 0, pA_d.p, nd2.as<float>(), ctx->stream);
-        launch_pack_f16(fs.as<double>(), ns, mfma_query_tiles(ns), scale, 1, pB_s.p, ns2.as<float>(), ctx->stream);
-        launch_pack_f16(fd.as<double>(), nd, mfma_query_tiles(nd), scale, 1, pB_d.p, nd2.as<float>(), ctx->stream);
+        launch_pack_f16_both(fs.as<double>(), ns, scale, pA_s.p, pB_s.p, ns2.as<float>(), ctx->stream);
+        launch_pack_f16_both(fd.as<double>(), nd, scale, pA_d.p, pB_d.p, nd2.as<float>(), ctx->stream);
         launch_max_f32(ns2.as<float>(), ns, sc + 0, ctx->stream);
         launch_max_f32(nd2.as<float>(), nd, sc + 1, ctx->stream);
         float h_max[2] = {0.0f, 0.0f};
