@@ -76,7 +76,13 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, boo
 // the database.  The four waves of a block walk the SAME slice, so the A tiles are staged through LDS once
 // per block (double-buffered, kStageTiles tiles per stage, one barrier per stage) instead of being
 // fetched from L2 by every wave.
-constexpr int kStageTiles = 2;
+// tiles per stage = database tiles between two barriers of the workgroup: 2: nn16_scan_k<false, true> 7.50 ms on 200 k x 200 k,
+// 3: 7.19, 4: 6.86, 6: 7.96 (five staging registers per thread)
+#ifndef M3D_MATCH_STAGE_TILES
+#define M3D_MATCH_STAGE_TILES 4
+#endif
+constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
+static_assert(kStageTiles * 32 <= 256, "a thread carries at most one row threshold (and one run threshold) of the stage");
 constexpr int kStageEntries = kStageTiles * kMfmaSteps * 64;   // h8 entries per stage (14 KB)
 
 // MIN_ONLY = true: warm-up pass over the first tiles of the database, running minimum only (no rings);
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
         // entry e of a stage = fragment (tile e / 448, step, lane) in packed order: consecutive in memory
         constexpr int kPerThread = (kStageEntries + 255) / 256;   // 4 (the last one only for tid < 128)
         const uint32_t last_entry = (t1 - 1) * (uint32_t)(kMfmaSteps * 64) + (kMfmaSteps * 64 - 1);
-        float rthr = 0.0f;   // REV: threads 0 .. 32 kStageTiles - 1 carry one row threshold of the stage each
+        float rthr = 0.0f, rthr4 = 0.0f;   // REV: threads 0 .. 32 kStageTiles - 1 carry one row threshold of the stage each, the first 8 kStageTiles a run threshold too
         auto fetch = [&](uint32_t t_first, h8 (&r)[kPerThread]) {
 #pragma unroll
             for (int k = 0; k < kPerThread; ++k) {
@@ -137,9 +143,9 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
                 r[k] = dA[g];
             }
             if (REV && tid < kStageTiles * 32) rthr = rev.thr[min(t_first * 32u + (uint32_t)tid, t1 * 32u - 1u)];
-            if (REV && tid >= 64 && tid < 64 + kStageTiles * 8) {   // slot [tile u][half][run g] <- run 2 g + half of tile u
-                const uint32_t k = (uint32_t)tid - 64u, u = k >> 3, hf = (k >> 2) & 1u, g = k & 3u;
-                rthr = rev.thr4[min((t_first + u) * 8u + 2u * g + hf, t1 * 8u - 1u)];
+            if (REV && tid < kStageTiles * 8) {   // slot [tile u][half][run g] <- run 2 g + half of tile u
+                const uint32_t k = (uint32_t)tid, u = k >> 3, hf = (k >> 2) & 1u, g = k & 3u;
+                rthr4 = rev.thr4[min((t_first + u) * 8u + 2u * g + hf, t1 * 8u - 1u)];
             }
         };
         auto park = [&](int buf, const h8 (&r)[kPerThread]) {
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
                 if (e < (uint32_t)kStageEntries) stage[buf][e] = r[k];
             }
             if (REV && tid < kStageTiles * 32) sthr[buf][tid] = rthr;
-            if (REV && tid >= 64 && tid < 64 + kStageTiles * 8) sthr4[buf][tid - 64] = rthr;
+            if (REV && tid < kStageTiles * 8) sthr4[buf][tid] = rthr4;
         };
         h8 regs[kPerThread];
         fetch(t0, regs);
