@@ -1139,7 +1139,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     if (prob >= 1.0 && max_iter > 1024) {
         const size_t n_chunks = (max_iter + chunk_cap - 1) / chunk_cap;
         chunk = after_first = ((max_iter + n_chunks - 1) / n_chunks + 63) / 64 * 64;
-        lead = lead_size();
+        lead = lead_size();   // (C2 without it: 22 % of the (tile, hypothesis) pairs evaluated instead of 7.7 %, the step 0.44 ms instead of 0.28)
         // Several chunks: a SHORT first one.  What prunes chunk k is the best count of chunks 0 .. k - 1, and the first chunk has
         // only its 128 leading hypotheses to prune against -- on C3's cylinders (50 000 hypotheses, four chunks) its scoring
         // launches took 353 us where each later chunk took 169.  A first chunk of 2048 puts a good incumbent in front of 96 %
