@@ -324,7 +324,10 @@ def main():
 
     # set-up, before the W warm-up steps: the library allocates its per-device scratch lazily on the first fits, and
     # the GPU leaves its idle clocks only under load; a driver that asks for a very short warm-up would otherwise time both
-    PRIMING_FITS = 10
+    # (measured with --steps 20 --warmup 5, what a driver may ask for: 10 set-up fits leave the clocks on their way up --
+    # 0.295 ms per step, the scoring launch 108-110 us; 100 and 400 give the steady state the default 200-step run sees -- 0.280 ms,
+    # 100 us.  150 fits = 45 ms of set-up.)
+    PRIMING_FITS = int(os.environ.get("M3D_BENCH_PRIMING", "150"))
     import gc
     gc.collect()          # here, not next to the timed region: a full collection idles the GPU for tens of milliseconds
     if world > 1 and not rehearsal and not transport_note:
