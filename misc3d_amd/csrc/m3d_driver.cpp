@@ -408,7 +408,19 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
     // keep the per-chunk scratch below 1 GiB (dense: u32 partial count per (tile, hypothesis);
     // culled: one bit per (tile, hypothesis))
     (void)sv;
-    if (!use_dense_scoring()) return 16384;
+    if (!use_dense_scoring()) {
+        // hypotheses per chunk (M3D_CHUNK_CAP).  A chunk boundary costs ~35 us (sum_replicas_k, keep_mask_k, their launch
+        // boundaries), a chunk's sample table must be drawn while the chunk before it is on the GPU (a sphere's four draws per
+        // hypothesis: 1.9 ns against ~7.5 ns of scoring), and the first chunk of a long fit is short (2048).  C3's 50 000
+        // hypotheses: 16384 (four chunks) cylinder 0.998 / sphere 0.665 ms, 24576 (three) 0.985 / 0.659, 49152 (two) 0.944 / 0.689 --
+        // the sphere's second chunk then waits for its samples.
+        static const size_t cap = [] {
+            const char* e = std::getenv("M3D_CHUNK_CAP");
+            const long v = e && *e ? std::strtol(e, nullptr, 10) : 24576;
+            return (size_t)std::min<long>(std::max<long>((v + 63) / 64 * 64, 1024), 262144);
+        }();
+        return cap;
+    }
     const uint32_t rows = std::max<uint32_t>(1, v.n_pad / kScoreTile);
     const size_t cap = std::min<size_t>(16384, ((size_t)1 << 28) / rows / 64 * 64);
     return std::max<size_t>(cap, 64);
@@ -1128,7 +1140,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     const size_t chunk_cap = chunk_cap_for(v, sv) * n_ranks;
     // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
     // prob == 1: only fitness == 1 can stop it -> as few, equal chunks as the scratch cap allows
-    // (one chunk up to 16384 hypotheses; more chunks are pipelined two deep)
+    // (one chunk up to chunk_cap hypotheses; more chunks are pipelined two deep)
     // Either way an incumbent exists early -- a small first chunk (prob < 1) or the first hypotheses (lead_size()) of
     // the first chunk counted in a pass of their own (prob == 1): its inlier count lets everything after it
     // skip the hypotheses that cannot reach it (bound-and-prune).
