@@ -428,6 +428,13 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
 
 // pre_stream runs the head of a fit's later chunks (issue_chunk, `pre`) beside the main stream: whatever the main stream holds
 // when the fit starts -- a removal's compaction of this very cloud, another fit's tail -- must be behind those kernels too.
+static bool prestream_enabled() {   // (M3D_PRESTREAM=0: everything on the main stream)
+    static const bool on = [] {
+        const char* e = std::getenv("M3D_PRESTREAM");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 static int pre_stream_gate(DeviceCtx* ctx) {
     if (!ctx->pre_stream || !ctx->ev_pre_gate) return M3D_OK;
     HIPCHK(hipEventRecord(ctx->ev_pre_gate, ctx->stream));
@@ -1199,10 +1206,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     const double* best_dev = ctx->best_params.as<double>();
     int best_slot = -1;
     // in_flight: hypotheses already issued whose records have not been replayed yet
-    static const bool prestream_on = [] {
-        const char* e = std::getenv("M3D_PRESTREAM");
-        return !(e && e[0] == '0');
-    }();
+    const bool prestream_on = prestream_enabled();
     auto issue_next = [&](int slot_id, size_t in_flight, size_t forced = 0) -> int {
         // a later chunk of a probability-1 fit on one GPU: its MinimalFit and box tests run on pre_stream, under the scoring
         // launches of the chunk before (issue_chunk, `pre`)
@@ -2308,10 +2312,7 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     // Slices of several pieces (what a low world size leaves a rank): a SHORT first own piece -- its best count is what prunes
     // the pieces behind it (run_ransac's short first chunk) -- and MinimalFit + box tests of every later piece on pre_stream,
     // under the scoring launches of the piece before (issue_chunk, `pre`).
-    static const bool prestream_on = [] {
-        const char* e = std::getenv("M3D_PRESTREAM");
-        return !(e && e[0] == '0');
-    }();
+    const bool prestream_on = prestream_enabled();
     constexpr size_t kFirstPiece = 2048;
     bool first_own = true;
     if (prestream_on && !use_dense_scoring()) {

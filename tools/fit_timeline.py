@@ -6,10 +6,16 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 kind = sys.argv[2] if len(sys.argv) > 2 else "2"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-fits = [i for i, r in enumerate(rows) if f"compact_write_k<{kind}, 0>" in r["Kernel_Name"]]
-if len(fits) < 2:
-    raise SystemExit("not enough fits of that kind in the trace")
-a, b = fits[-2] + 1, fits[-1] + 1
+fits = [i for i, r in enumerate(rows) if f"compact_write_k<{kind}, 0" in r["Kernel_Name"]]
+# the last stretch between two compactions of that kind that holds a whole fit (a RefineModel retry or a consensus-only call leaves
+# stretches of two or three kernels)
+a = b = None
+for j in range(len(fits) - 1, 0, -1):
+    if fits[j] - fits[j - 1] > 12:
+        a, b = fits[j - 1] + 1, fits[j] + 1
+        break
+if a is None:
+    raise SystemExit("no complete fit of that kind in the trace")
 t0 = int(rows[a]["Start_Timestamp"])
 prev = t0
 for r in rows[a:b]:
