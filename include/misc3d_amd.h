@@ -421,8 +421,11 @@ typedef struct m3d_config {
                                        tiles below it (compact_write_k, ONE) -- instead of a counting launch and a writing launch.  Same
                                        output, position for position; measured SLOWER (a count crossing the XCDs' L2s costs more than the
                                        launch boundary it replaces: profiles/r04_compact_one_pass.txt) */
-    int32_t reserved[1];            /* zero.  Fields are only ever APPENDED in front of this array (which shrinks): the offsets of
-                                       existing fields do not move (round 3 itself had re-used four slots in place) */
+    int32_t plane_bound;            /* [M3D_PLANE_BOUND=0]  default 1: plane fits with an incumbent prune with a per-tile HISTOGRAM upper bound of
+                                       every (tile, hypothesis) pair's inlier count (tile_frames_k / plane_bound_k, m3d_bound.hip) instead of
+                                       512 per touched tile (clouds of >= 64 tiles, fits of >= 2048 hypotheses; 2: whatever the size); same results, fewer
+                                       hypotheses counted point by point.  (The last of the
+                                       reserved slots: fields are only ever appended, the offsets of existing fields do not move -- ADVICE r3) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -209,7 +209,7 @@ class Config(C.Structure):
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
                                          "reg_neighbour_lists", "reg_prune", "match_brute", "match_fp32_screen",
                                          "pool_limit_mb", "kernel_timing", "reg_sorted_lists", "score_fp32_screen",
-                                         "cull_fp32", "reg_fp32_screen", "sorted_tombstones", "score_mfma", "score_mfma_groups", "score_waves4", "score_waves4_groups", "score_phases", "compact_one_pass")] + [("reserved", C.c_int32 * 1)]
+                                         "cull_fp32", "reg_fp32_screen", "sorted_tombstones", "score_mfma", "score_mfma_groups", "score_waves4", "score_waves4_groups", "score_phases", "compact_one_pass", "plane_bound")]
 
 
 def fp64_issue_rate(device=0, ms_target=2.0):

@@ -1,0 +1,395 @@
+// m3d_bound.hip -- histogram upper bounds for plane hypotheses (round 4).
+//
+// Bound-and-prune (keep_mask_k) drops a hypothesis whose touched tiles cannot hold the incumbent's count: 512 points per
+// tile the box tests could not exclude.  On a cloud with a dominant plane that bound is useless for the hypotheses that
+// matter -- ~1400 of C2's 10 000 have all three samples on the plane, touch the same ~1000 tiles and are then counted point
+// by point, although all but a few hundred of them end tens of thousands of inliers below the incumbent.  A tile that lies
+// on a surface is THIN along one direction, and a plane hypothesis cuts a slab out of that direction:
+//
+//   tile_frames_k   once per resident cloud (lazily, at its first long plane fit): one wave per tile of the sorted copy
+//                   finds a robust local frame (c; e, u, v) -- least-quantile search over 64 candidate planes through
+//                   triples of the tile's own points, then three rounds of trimmed PCA -- and stores, for w_p = e . (p - c),
+//                   a cumulative HISTOGRAM of the tile's points over 128 bins of w together with U >= |u . (p - c)|,
+//                   V >= |v . (p - c)|, W >= |w_p| and R >= the residual of the decomposition.
+//   plane_bound_k   per fit window, after the keep masks: lane = surviving hypothesis, tiles stream through scalar loads.
+//                   For every touched (tile, hypothesis) pair, with S(p) = n . p + d the plane value,
+//                       S(p) = S(c) + (n . e) w_p + (n . u) u_p + (n . v) v_p + n . res_p            (an identity),
+//                   so |S(p)| < T forces (n . e) w_p into an interval of half width T + a around -S(c),
+//                   a = |n . u| U + |n . v| V + |n|_1 R + rounding terms: the histogram's mass over the bins that interval
+//                   meets is an UPPER BOUND of the pair's inlier count (every rounding of the evaluation is inside a; the bin
+//                   function is the same monotone fp64 expression in both kernels).  Summed per hypothesis: ubsum[h].
+//   bound_keep_k    keep[g] &= (ubsum[h] >= best count of EARLIER hypotheses): the rule of keep_mask_k with a bound that is
+//                   within ~10 % of the true count for hypotheses near a surface instead of 512 per tile.
+//
+// A hypothesis dropped here has count <= ubsum < best count of hypotheses before it: it can neither beat nor tie the incumbent
+// in the sequential replay (ransac.h:595-596); its record is reported as 0 like any pruned hypothesis'.  Nothing else
+// changes: the survivors are counted by the same kernels.  Dead points (tombstones) only lower counts: the bound stays valid.
+// Frames belong to the tiles they were built on: a sorted copy that is re-partitioned drops them (SortedView::frames = null).
+#include "m3d_cull_kernels.hpp"
+
+#include <cstdlib>
+
+#include "m3d_config.hpp"
+#include "m3d_eig3.hpp"
+#include "m3d_fp.hpp"
+
+#pragma clang fp contract(off)
+
+namespace m3d {
+
+// bin of a coordinate w along the tile's thin direction: 0 = below the histogram's range, 1 .. kBoundBins inside,
+// kBoundBins + 1 = above.  MONOTONE in w (a subtraction, a multiplication by a positive number, floor, clamp) and the SAME
+// expression in tile_frames_k and plane_bound_k: w1 <= w2 => bound_bin(w1) <= bound_bin(w2), which is all the bound needs.
+__device__ __forceinline__ int bound_bin(double w, double wlo, double invd) {
+    const double t = floor((w - wlo) * invd);
+    return (int)fmin(fmax(t, -1.0), (double)kBoundBins) + 1;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+constexpr int kFrameLevels = 12;   // residual levels of the candidate search: factor 2 each, from extent / 2^11 to extent
+
+__global__ __launch_bounds__(64) void tile_frames_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                     const double* __restrict__ sz, uint32_t n_tiles,
+                                                     double* __restrict__ frames, uint16_t* __restrict__ cum) {
+    __shared__ float pf[3][kTilePoints];
+    __shared__ uint32_t hist[kBoundBins + 2];
+    const int lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    constexpr int P = kTilePoints / 64;
+    double px[P], py[P], pz[P];
+    bool fin[P];
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, mabs = 0.0, nf = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const size_t i = (size_t)tile * kTilePoints + j * 64 + lane;
+        px[j] = sx[i];
+        py[j] = sy[i];
+        pz[j] = sz[i];
+        fin[j] = (px[j] * 0.0 == 0.0) && (py[j] * 0.0 == 0.0) && (pz[j] * 0.0 == 0.0);
+        if (fin[j]) {
+            lo[0] = fmin(lo[0], px[j]); hi[0] = fmax(hi[0], px[j]);
+            lo[1] = fmin(lo[1], py[j]); hi[1] = fmax(hi[1], py[j]);
+            lo[2] = fmin(lo[2], pz[j]); hi[2] = fmax(hi[2], pz[j]);
+            mabs = fmax(mabs, fmax(fabs(px[j]), fmax(fabs(py[j]), fabs(pz[j]))));
+            nf += 1.0;
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = wave_min(lo[k]);
+        hi[k] = wave_max(hi[k]);
+    }
+    mabs = wave_max(mabs);
+    nf = wave_sum(nf);
+    double* __restrict__ fr = frames + (size_t)tile * kFrameStride;
+    uint16_t* __restrict__ cm = cum + (size_t)tile * kCumStride;
+    const double ext = fmax(hi[0] - lo[0], fmax(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(nf >= 16.0) || !(ext > 1e-290) || !(ext < 1e30) || !(mabs < 1e30)) {   // (wave-uniform) no frame: every touched pair counts 512
+        if (lane < kFrameStride) fr[lane] = 0.0;
+        return;
+    }
+    const double bc[3] = {0.5 * lo[0] + 0.5 * hi[0], 0.5 * lo[1] + 0.5 * hi[1], 0.5 * lo[2] + 0.5 * hi[2]};
+    const float qnan = __uint_as_float(0x7FC00000u);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        pf[0][j * 64 + lane] = fin[j] ? (float)(px[j] - bc[0]) : qnan;
+        pf[1][j * 64 + lane] = fin[j] ? (float)(py[j] - bc[1]) : qnan;
+        pf[2][j * 64 + lane] = fin[j] ? (float)(pz[j] - bc[2]) : qnan;
+    }
+    for (int i = lane; i < kBoundBins + 2; i += 64) hist[i] = 0u;
+    __syncthreads();
+    // ---- least-quantile search: lane = candidate plane through three of the tile's points (pseudo-random positions along the
+    // Hilbert order: a tile that is part surface, part clutter consists of runs), scored by the smallest residual level
+    // that holds a fifth of the points, then by how many it holds
+    const uint32_t i0 = ((uint32_t)lane * 8u + 3u) & 511u;
+    const uint32_t i1 = (i0 + 29u + (((uint32_t)lane * 2654435761u) >> 16) % 170u) & 511u;
+    const uint32_t i2 = (i1 + 31u + ((((uint32_t)lane * 40503u + 77u) * 2246822519u) >> 16) % 170u) & 511u;
+    const float q0[3] = {pf[0][i0], pf[1][i0], pf[2][i0]};
+    const float ax = pf[0][i1] - q0[0], ay = pf[1][i1] - q0[1], az = pf[2][i1] - q0[2];
+    const float bx = pf[0][i2] - q0[0], by = pf[1][i2] - q0[1], bz = pf[2][i2] - q0[2];
+    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const float len = __builtin_sqrtf(nx * nx + ny * ny + nz * nz);
+    const float extf = (float)ext;
+    const bool cand_ok = len > 1e-6f * extf * extf && len * 0.0f == 0.0f;
+    const float il = cand_ok ? 1.0f / len : 0.0f;
+    nx *= il;
+    ny *= il;
+    nz *= il;
+    const float d0 = nx * q0[0] + ny * q0[1] + nz * q0[2];
+    int ex;
+    (void)__builtin_frexp(ext, &ex);                  // ext = f 2^ex, f in [0.5, 1): ilogb(ext) = ex - 1
+    const int emin = (ex - 1) - kFrameLevels + 1;     // level l: residuals in [2^(emin + l), 2^(emin + l + 1)); 0 also takes everything below
+    unsigned long long clo = 0ull, chi = 0ull;        // six 10-bit counters each (a count is at most 512)
+    for (int i = 0; i < kTilePoints; ++i) {
+        const float r = __builtin_fabsf(__builtin_fmaf(nx, pf[0][i], __builtin_fmaf(ny, pf[1][i], nz * pf[2][i])) - d0);
+        const int eb = (int)((__float_as_uint(r) >> 23) & 0xFFu) - 127;   // (NaN: 128 -> the top level, which holds every point anyway)
+        const int lev = min(max(eb - emin, 0), kFrameLevels - 1);
+        const bool up = lev >= 6;
+        const unsigned long long one = 1ull << (10 * (up ? lev - 6 : lev));
+        clo += up ? 0ull : one;
+        chi += up ? one : 0ull;
+    }
+    const uint32_t need = max(16u, (uint32_t)(0.2 * nf));
+    uint32_t acc = 0, lev_s = kFrameLevels - 1, cnt_s = 0;
+    bool found = false;
+#pragma unroll
+    for (int l = 0; l < kFrameLevels; ++l) {
+        acc += (uint32_t)(((l >= 6 ? chi : clo) >> (10 * (l >= 6 ? l - 6 : l))) & 1023ull);
+        if (!found && acc >= need) {
+            found = true;
+            lev_s = (uint32_t)l;
+            cnt_s = acc;
+        }
+    }
+    uint32_t key = (cand_ok && found) ? ((lev_s << 16) | ((1023u - min(cnt_s, 1023u)) << 6) | (uint32_t)lane) : 0xFFFFFFFFu;
+    for (int off = 32; off > 0; off >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, off, 64));
+    double e[3] = {0.0, 0.0, 1.0}, c[3] = {bc[0], bc[1], bc[2]}, band = INFINITY;
+    if (key != 0xFFFFFFFFu) {   // (wave-uniform)
+        const int kb = (int)(key & 63u);
+        e[0] = (double)__shfl(nx, kb, 64);
+        e[1] = (double)__shfl(ny, kb, 64);
+        e[2] = (double)__shfl(nz, kb, 64);
+        c[0] = bc[0] + (double)__shfl(q0[0], kb, 64);
+        c[1] = bc[1] + (double)__shfl(q0[1], kb, 64);
+        c[2] = bc[2] + (double)__shfl(q0[2], kb, 64);
+        band = 3.0 * __builtin_ldexp(1.0, emin + (int)(key >> 16) + 1);
+    }
+    // ---- trimmed PCA: the points within `band` of the current plane give the next one; band = 3.5 rms afterwards
+    double s = 0.25 * ext;
+    for (int it = 0; it < 3; ++it) {
+        double m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const double dx = px[j] - c[0], dy = py[j] - c[1], dz = pz[j] - c[2];
+            const double w = (dx * e[0] + dy * e[1]) + dz * e[2];
+            if (fin[j] && fabs(w) < band) {
+                m[0] += 1.0;
+                m[1] += dx; m[2] += dy; m[3] += dz;
+                m[4] += dx * dx; m[5] += dx * dy; m[6] += dx * dz;
+                m[7] += dy * dy; m[8] += dy * dz; m[9] += dz * dz;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) m[k] = wave_sum(m[k]);
+        if (!(m[0] >= 8.0)) break;   // (wave-uniform)
+        const double in = 1.0 / m[0];
+        const double mx = m[1] * in, my = m[2] * in, mz = m[3] * in;
+        const double A[9] = {m[4] * in - mx * mx, m[5] * in - mx * my, m[6] * in - mx * mz,
+                             m[5] * in - mx * my, m[7] * in - my * my, m[8] * in - my * mz,
+                             m[6] * in - mx * mz, m[8] * in - my * mz, m[9] * in - mz * mz};
+        double en[3];
+        j3x3_smallest_eigvec(A, en);
+        if (!((en[0] + en[1] + en[2]) * 0.0 == 0.0)) break;   // (degenerate covariance: keep the frame in hand)
+        e[0] = en[0]; e[1] = en[1]; e[2] = en[2];
+        c[0] += mx; c[1] += my; c[2] += mz;
+        const double q = (e[0] * (A[0] * e[0] + A[1] * e[1] + A[2] * e[2]) + e[1] * (A[3] * e[0] + A[4] * e[1] + A[5] * e[2])) +
+                         e[2] * (A[6] * e[0] + A[7] * e[1] + A[8] * e[2]);
+        s = sqrt(fmax(q, 0.0));
+        s = fmax(s, 1e-7 * ext);
+        band = 3.5 * s;
+    }
+    // ---- the frame's other two directions (any orthonormal completion serves the identity)
+    const int kmin = (fabs(e[0]) <= fabs(e[1]) && fabs(e[0]) <= fabs(e[2])) ? 0 : (fabs(e[1]) <= fabs(e[2]) ? 1 : 2);
+    const double a3[3] = {kmin == 0 ? 1.0 : 0.0, kmin == 1 ? 1.0 : 0.0, kmin == 2 ? 1.0 : 0.0};
+    double u[3] = {e[1] * a3[2] - e[2] * a3[1], e[2] * a3[0] - e[0] * a3[2], e[0] * a3[1] - e[1] * a3[0]};
+    const double ul = sqrt((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2]);
+    u[0] /= ul; u[1] /= ul; u[2] /= ul;
+    const double v[3] = {e[1] * u[2] - e[2] * u[1], e[2] * u[0] - e[0] * u[2], e[0] * u[1] - e[1] * u[0]};
+    const double wlo = -5.0 * s, invd = (double)kBoundBins / (10.0 * s);
+    double U = 0.0, V = 0.0, W = 0.0, R = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        if (!fin[j]) continue;
+        const double dx = px[j] - c[0], dy = py[j] - c[1], dz = pz[j] - c[2];
+        const double w = (dx * e[0] + dy * e[1]) + dz * e[2];
+        const double uu = (dx * u[0] + dy * u[1]) + dz * u[2];
+        const double vv = (dx * v[0] + dy * v[1]) + dz * v[2];
+        const double rx = ((dx - w * e[0]) - uu * u[0]) - vv * v[0];
+        const double ry = ((dy - w * e[1]) - uu * u[1]) - vv * v[1];
+        const double rz = ((dz - w * e[2]) - uu * u[2]) - vv * v[2];
+        U = fmax(U, fabs(uu));
+        V = fmax(V, fabs(vv));
+        W = fmax(W, fabs(w));
+        R = fmax(R, fmax(fabs(rx), fmax(fabs(ry), fabs(rz))));
+        atomicAdd(&hist[bound_bin(w, wlo, invd)], 1u);
+    }
+    U = wave_max(U);
+    V = wave_max(V);
+    W = wave_max(W);
+    R = wave_max(R);
+    __syncthreads();
+    {   // cum[k] = points with bin < k, k = 0 .. kBoundBins + 2
+        const uint32_t h0 = hist[2 * lane], h1 = hist[2 * lane + 1];
+        uint32_t incl = h0 + h1;
+        const uint32_t own = incl;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        const uint32_t excl = incl - own;
+        cm[2 * lane] = (uint16_t)excl;
+        cm[2 * lane + 1] = (uint16_t)(excl + h0);
+        if (lane == 63) cm[kBoundBins + 2] = (uint16_t)incl;
+    }
+    // the residual as computed carries its own rounding (a dozen operations on numbers of size <= mabs + ext)
+    const double Rm = R + 1e-13 * (mabs + ext);
+    const bool ok = (U + V + W + Rm) * 0.0 == 0.0 && (invd * 0.0 == 0.0) && invd > 0.0;
+    if (lane == 0) {
+        fr[0] = c[0]; fr[1] = c[1]; fr[2] = c[2];
+        fr[3] = e[0]; fr[4] = e[1]; fr[5] = e[2];
+        fr[6] = u[0]; fr[7] = u[1]; fr[8] = u[2];
+        fr[9] = v[0]; fr[10] = v[1]; fr[11] = v[2];
+        fr[12] = U; fr[13] = V; fr[14] = Rm; fr[15] = wlo; fr[16] = invd; fr[17] = W; fr[18] = nf;
+        fr[19] = ok ? 1.0 : 0.0;
+    }
+}
+
+void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipStream_t st) {
+    if (s.n_tiles) tile_frames_k<<<s.n_tiles, 64, 0, st>>>(s.x, s.y, s.z, s.n_tiles, frames, cum);
+}
+
+// One workgroup (four waves) = 64 SURVIVING hypotheses of the window (compacted from the keep words; the blocks of 64 are dealt
+// out along block x, grid-stride) x a range of tiles (block y), the waves taking the range's tiles in turn.  Everything per
+// pair in fp64: ~70 instructions; what the kernel waits for is memory latency (the tile's frame through scalar loads, the mask
+// word and two histogram entries per lane), so it runs ~10 waves per SIMD and its loop is free of branches.
+constexpr int kBoundWaves = 4;
+__global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* __restrict__ frames, const uint16_t* __restrict__ cum,
+                                                                   uint32_t n_tiles, uint32_t tiles_per_block, double max_abs,
+                                                                   const double* __restrict__ score,
+                                                                   const unsigned long long* __restrict__ masks,
+                                                                   const unsigned long long* __restrict__ keep, uint32_t n_groups,
+                                                                   uint32_t group_begin, uint32_t group_end,
+                                                                   uint32_t* __restrict__ ubsum) {
+    __shared__ uint32_t ids[64];
+    __shared__ uint32_t wsum[kBoundWaves][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t window = group_end - group_begin;
+    const uint32_t per = (window + 63u) / 64u;   // keep words per lane (a contiguous run)
+    const uint32_t w0 = (uint32_t)lane * per;
+    uint32_t own = 0;
+    for (uint32_t i = 0; i < per; ++i)
+        if (w0 + i < window) own += (uint32_t)__popcll(keep[group_begin + w0 + i]);
+    uint32_t incl = own;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    const uint32_t t0 = blockIdx.y * tiles_per_block, t1 = min(n_tiles, t0 + tiles_per_block);
+    for (uint32_t first = blockIdx.x * 64u; first < total; first += gridDim.x * 64u) {   // (workgroup-uniform)
+        __syncthreads();   // (the previous block's ids and sums have been read)
+        if (wave == 0) {
+            uint32_t r = incl - own;
+            if (r < first + 64u && r + own > first) {
+                for (uint32_t i = 0; i < per && w0 + i < window; ++i) {
+                    unsigned long long m = keep[group_begin + w0 + i];
+                    while (m) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                        if (r >= first && r < first + 64u) ids[r - first] = (group_begin + w0 + i) * 64u + b;
+                        ++r;
+                        m &= m - 1ull;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nb = min(64u, total - first);
+        const bool has = (uint32_t)lane < nb;
+        const uint32_t h = has ? ids[lane] : group_begin * 64u;
+        const double* __restrict__ rp = score + (size_t)h * kModelStride;
+        const double a = rp[0], b = rp[1], c = rp[2], d = rp[3], T = rp[4];
+        const double n1 = (fabs(a) + fabs(b)) + fabs(c);
+        const double Mg = n1 * max_abs + fabs(d);
+        const double eps1 = 4e-15 * n1;
+        const bool rec_ok = has && (T > 0.0) && ((n1 + Mg + T) * 0.0 == 0.0);
+        const unsigned long long bit = 1ull << (h & 63u);
+        const unsigned long long* __restrict__ mrow = masks + (size_t)(h >> 6);
+        uint32_t ub = 0;
+#pragma unroll 4
+        for (uint32_t t = t0 + (uint32_t)wave; t < t1; t += (uint32_t)kBoundWaves) {
+            const bool touched = has && (mrow[(size_t)t * n_groups] & bit) != 0ull;
+            const double* __restrict__ fr = frames + (size_t)t * kFrameStride;   // (wave-uniform: scalar loads)
+            const double sc0 = ((a * fr[0] + b * fr[1]) + c * fr[2]) + d;
+            const double g0 = (a * fr[3] + b * fr[4]) + c * fr[5];
+            const double nu = (a * fr[6] + b * fr[7]) + c * fr[8];
+            const double nv = (a * fr[9] + b * fr[10]) + c * fr[11];
+            double aa = (((fabs(nu) + eps1) * fr[12] + (fabs(nv) + eps1) * fr[13]) + n1 * fr[14]) + (eps1 * fr[17] + 1e-14 * Mg);
+            aa += 1e-12 * ((T + aa) + fabs(sc0));
+            const double g = fabs(g0), sc = g0 < 0.0 ? -sc0 : sc0;
+            const double ig = 1.0 / g;   // (g = 0: +-inf or, with a zero numerator, NaN -- caught below)
+            // the quotient rounds: both ends move outwards by far more than that (1e-12 of their own size, against 2^-52)
+            double L = ((-T - aa) - sc) * ig, H = ((T + aa) - sc) * ig;
+            L -= 1e-12 * fabs(L);
+            H += 1e-12 * fabs(H);
+            const bool framed = fr[19] != 0.0 && rec_ok;
+            const bool whole = !(L == L) || !(H == H);   // (0 x inf: the direction says nothing -- every finite point of the tile)
+            const int bl = bound_bin(whole ? 0.0 : L, fr[15], fr[16]), bh = bound_bin(whole ? 0.0 : H, fr[15], fr[16]);
+            const uint16_t* __restrict__ cm = cum + (size_t)t * kCumStride;
+            const int lo_c = (int)cm[bl], hi_c = (int)cm[bh + 1];
+            uint32_t u_t = (uint32_t)max(hi_c - lo_c, 0);
+            u_t = whole ? (uint32_t)fr[18] : u_t;
+            u_t = framed ? u_t : (uint32_t)kTilePoints;
+            ub += touched ? u_t : 0u;
+        }
+        wsum[wave][lane] = ub;
+        __syncthreads();
+        if (wave == 0 && has) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < kBoundWaves; ++w) tot += wsum[w][lane];
+            if (tot) atomicAdd(&ubsum[h], tot);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void bound_keep_k(const uint32_t* __restrict__ ubsum, const uint32_t* __restrict__ best_count,
+                                                    unsigned long long* __restrict__ keep, uint32_t group_begin,
+                                                    uint32_t* __restrict__ dropped) {
+    const uint32_t g = group_begin + blockIdx.x;
+    const uint32_t best = best_count[0];
+    const unsigned long long old = keep[g];
+    const bool k = best == 0u || ubsum[g * 64u + threadIdx.x] >= best;
+    const unsigned long long m = __ballot(k) & old;
+    if (threadIdx.x == 0) {
+        keep[g] = m;
+        if (dropped && m != old) atomicAdd(dropped, (uint32_t)__popcll(old & ~m));
+    }
+}
+
+void launch_plane_bound(const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
+                        uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
+                        const uint32_t* best_count, hipStream_t st, uint32_t* dropped) {
+    group_end = std::min(group_end, n_groups);
+    if (!s.frames || !s.frame_cum || !s.n_tiles || group_begin >= group_end) return;
+    const uint32_t window = group_end - group_begin;
+    static const uint32_t tpb = [] {   // tiles per workgroup (M3D_BOUND_TPB)
+        const char* e = std::getenv("M3D_BOUND_TPB");
+        const long v = e && *e ? std::strtol(e, nullptr, 10) : 32;   // C2: 8 / 16 / 32 / 64 -> 0.2756 / 0.2681 / 0.2612 / 0.2911 ms per step
+        return (uint32_t)std::min<long>(std::max<long>(v, 1), 4096);
+    }();
+    static const uint32_t gdiv = [] {   // one block of 64 survivors per `gdiv` groups of the window to begin with (M3D_BOUND_GDIV)
+        const char* e = std::getenv("M3D_BOUND_GDIV");
+        const long v = e && *e ? std::strtol(e, nullptr, 10) : 6;
+        return (uint32_t)std::min<long>(std::max<long>(v, 1), 64);
+    }();
+    const uint32_t gx = std::min<uint32_t>(window, std::max<uint32_t>(4u, (window + gdiv - 1) / gdiv));
+    const dim3 g(gx, (s.n_tiles + tpb - 1) / tpb), b(64 * kBoundWaves);
+    plane_bound_k<<<g, b, 0, st>>>(s.frames, s.frame_cum, s.n_tiles, tpb, s.max_abs, score, masks, keep, n_groups, group_begin,
+                                   group_end, ubsum);
+    bound_keep_k<<<window, 64, 0, st>>>(ubsum, best_count, keep, group_begin, dropped);
+}
+
+}  // namespace m3d

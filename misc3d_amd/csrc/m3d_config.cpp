@@ -32,6 +32,7 @@ void sanitize(m3d_config& c) {
     if (c.score_mfma_groups < 1 || c.score_mfma_groups > 64) c.score_mfma_groups = 64;
     if (c.score_waves4_groups < 1 || c.score_waves4_groups > 64) c.score_waves4_groups = 64;
     if (c.score_phases < -1 || c.score_phases == 1 || c.score_phases > 3) c.score_phases = -1;
+    if (c.plane_bound < 0 || c.plane_bound > 2) c.plane_bound = 1;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -58,6 +59,7 @@ void load_env() {
     g_cfg.score_waves4_groups = (int32_t)env_long("M3D_WAVES4_GPB", 64);
     g_cfg.score_phases = (int32_t)env_long("M3D_SCORE_PHASES", -1);
     g_cfg.compact_one_pass = env_is("M3D_COMPACT_ONE_PASS", '1');   // C5 rounds 17.4 against 15.3 ms, C2 step +8 us: off (profiles/r04_compact_one_pass.txt)
+    g_cfg.plane_bound = (int32_t)env_long("M3D_PLANE_BOUND", 1);
     sanitize(g_cfg);
 }
 }  // namespace
@@ -69,7 +71,6 @@ const m3d_config& config() {
 void config_store(const m3d_config& c) {
     std::call_once(g_once, load_env);
     g_cfg = c;
-    g_cfg.compact_one_pass = env_is("M3D_COMPACT_ONE_PASS", '1');   // C5 rounds 17.4 against 15.3 ms, C2 step +8 us: off (profiles/r04_compact_one_pass.txt)
     sanitize(g_cfg);
 }
 }  // namespace m3d

@@ -23,6 +23,11 @@ struct SortedView {
     // box slot 6 then says whether the tile can be screened (every offset finite).  A wave of score_screen_k loads 6 KB
     // ready to use instead of 12 KB of doubles it has to shift and convert.
     float* tile_f32 = nullptr;
+    // optional, written by tile_frames_k (m3d_bound.hip): a robust local frame and a histogram per tile, from which plane_bound_k
+    // takes an upper bound of a plane hypothesis' inlier count per (tile, hypothesis) pair.  They describe THESE tiles: a copy that
+    // is re-partitioned drops them.
+    const double* frames = nullptr;        // n_tiles x kFrameStride
+    const uint16_t* frame_cum = nullptr;   // n_tiles x kCumStride
     bool has_dead = false;   // some points are tombstones (x = NaN in both copies: launch_poison_plane_inliers); planes only
     double max_abs = __builtin_inf();  // >= |coordinate| of every point of the cloud (the box tests' rounding margin); inf = unknown (nothing culled)
     // centre of the cloud's bounding box and the largest |coordinate - origin| (fp32 box tests work relative to it);
@@ -32,6 +37,15 @@ struct SortedView {
 };
 
 constexpr int kTileF32Floats = 3 * kTilePoints;
+constexpr int kFrameStride = 20;      // doubles per tile frame: c, e, u, v (3 each), U, V, R, wlo, invd, W, finite points, valid
+constexpr int kBoundBins = 126;       // interior bins of a tile's histogram (bin 0 / kBoundBins + 1: below / above its range)
+constexpr int kCumStride = 132;       // uint16 per tile: cum[0 .. kBoundBins + 2] (+ padding to 264 bytes)
+void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipStream_t st);
+// ubsum[h] += upper bound of hypothesis h's inliers over the tiles whose mask bit is set (hypotheses with their keep bit set, groups
+// [group_begin, group_end); ubsum zero on entry); then keep[g] &= (ubsum[h] >= best_count[0]).  Planes only; needs s.frames.
+void launch_plane_bound(const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
+                        uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
+                        const uint32_t* best_count, hipStream_t st, uint32_t* dropped = nullptr);
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 // Tombstones (m3d_poison.hpp): the job that kills the inliers of the plane `model` (device) in place in the sorted copy
 // `s`; *total (device, cleared by the owner) accumulates the number of points killed over all launches.

@@ -238,6 +238,10 @@ m3d::SortedView m3d_cloud::sorted() const {
     s.z = sz.as<double>();
     s.boxes = boxes.as<double>();
     s.tile_f32 = tile_f32.as<float>();
+    if (frames_ready) {
+        s.frames = frames.as<double>();
+        s.frame_cum = frame_cum.as<uint16_t>();
+    }
     s.n_tiles = n_tiles;
     s.max_abs = max_abs;
     for (int k = 0; k < 3; ++k) s.origin[k] = origin[k];
@@ -629,6 +633,12 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             } else if (!all_prepared) {   // (all_prepared: minimal_fit_k has done it)
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
             }
+            // planes with an incumbent and tile frames: a histogram upper bound per touched (tile, hypothesis) pair replaces
+            // "512 per touched tile" in the keep rule (m3d_bound.hip); ubsum is the slot's phase-counter array, zeroed by
+            // minimal_fit_k and unused when the scoring is not phased
+            if (kind == M3D_PLANE && prune && bc && !ubp && sv.frames && config().plane_bound != 0 && (use_lead || !new_fit) &&
+                !scored_with_own_tests && g_lo < g1)
+                launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, g_lo, g1, ub + h_pad, bc, ctx->stream);
             bool phased = false;
             if (!scored_with_own_tests && ubp)
                 phased = launch_score_phased(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
@@ -1487,6 +1497,26 @@ static int finalize_deferred_refine(DeviceCtx* ctx) {
     return M3D_OK;
 }
 
+// Tile frames + histograms for plane_bound_k (m3d_bound.hip): a property of the resident cloud's sorted copy like its tile
+// boxes, but only plane fits with an incumbent to prune against use them -- built by the first such fit that is long enough to
+// pay for it (one launch, ~0.05 ms on 1 M points), kept for the cloud's lifetime.  The working cloud of a segmentation
+// (re-partitioned between rounds) has none.
+static int ensure_plane_frames(m3d_cloud* c, int kind, size_t n_hypotheses) {
+    const int mode = config().plane_bound;   // 1: clouds of >= 64 tiles, fits of >= 2048 hypotheses; 2: always (tests)
+    if (kind != M3D_PLANE || c->frames_ready || mode == 0 || c->work.active || c->n_tiles == 0 ||
+        (mode == 1 && (c->n_tiles < 64 || n_hypotheses < 2048)))
+        return M3D_OK;
+    DeviceCtx* ctx = c->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!c->frames.reserve(sizeof(double) * kFrameStride * (size_t)c->n_tiles) ||
+        !c->frame_cum.reserve(sizeof(uint16_t) * kCumStride * (size_t)c->n_tiles))
+        return fail(M3D_ERR_DEVICE, "out of device memory (tile frames)");
+    launch_tile_frames(c->sorted(), c->frames.as<double>(), c->frame_cum.as<uint16_t>(), ctx->stream);
+    HIPCHK(hipGetLastError());
+    c->frames_ready = true;
+    return M3D_OK;
+}
+
 static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter, double prob,
                             uint64_t seed, double* params, size_t* inliers, size_t* n_inliers,
                             m3d_stats* stats, const std::function<int(int64_t)>* before_refine_wait = nullptr,
@@ -1500,6 +1530,10 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
         explicit DenseGuard(bool on) : saved(t_dense_fit) { if (on) t_dense_fit = 1; }
         ~DenseGuard() { t_dense_fit = saved; }
     } dense_guard(c->n_tiles == 0 && !c->work.active);   // no sorted copy: dense scoring (m3d_cloud_create_impl)
+    {
+        const int frc = ensure_plane_frames(c, kind, max_iter);
+        if (frc != M3D_OK) return frc;
+    }
     const CloudView v = c->view();
     const CloudView gather = c->base_view();   // index lists / GeneralFit refer to the cloud as created
     const uint32_t* orig = c->orig();
@@ -1779,6 +1813,8 @@ static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed, const size_t* kn
         w.scur.z = w.sbz[w.spp].as<double>();
         w.scur.boxes = w.sboxes.as<double>();
         w.scur.tile_f32 = w.stile_f32.as<float>();
+        w.scur.frames = nullptr;   // (new tiles: the frames of the copy as created do not describe them)
+        w.scur.frame_cum = nullptr;
         w.scur.n_tiles = std::max<uint32_t>(1, (new_sorted + kTilePoints - 1) / kTilePoints);
         // compact_write_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
         launch_tile_boxes(w.scur, w.sboxes.as<double>(), ctx->stream);
@@ -1828,7 +1864,7 @@ static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double*
 template <class F>
 static void for_each_buffer(m3d_cloud* c, F f) {
     f(c->x); f(c->y); f(c->z); f(c->nx); f(c->ny); f(c->nz);
-    f(c->sx); f(c->sy); f(c->sz); f(c->boxes); f(c->tile_f32);
+    f(c->sx); f(c->sy); f(c->sz); f(c->boxes); f(c->tile_f32); f(c->frames); f(c->frame_cum);
     for (int k = 0; k < 2; ++k) {
         f(c->work.bx[k]); f(c->work.by[k]); f(c->work.bz[k]); f(c->work.bo[k]);
         f(c->work.sbx[k]); f(c->work.sby[k]); f(c->work.sbz[k]);
@@ -2275,6 +2311,10 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     DeviceCtx* ctx = c->ctx;
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
+    {
+        const int frc = ensure_plane_frames(c, kind, end - begin);
+        if (frc != M3D_OK) return frc;
+    }
     const CloudView v = c->view();
     const SortedView sv = c->sorted();
     const size_t chunk_cap = chunk_cap_for(v, sv);

@@ -25,7 +25,9 @@ PATHS = {"culled": {}, "dense": {"dense_scoring": 1}, "no_early_pick": {"specula
          "four_wave_wgs": {"score_waves4": 1},
          "single_launch": {"score_phases": 0},   # (default -1: cylinders in three phases with re-pruning in between, the others in one)
          "two_phases": {"score_phases": 2}, "three_phases": {"score_phases": 3},
-         "one_pass_compaction": {"compact_one_pass": 1}}   # compact_write_k, ONE: counts published and awaited inside the launch
+         "one_pass_compaction": {"compact_one_pass": 1},   # compact_write_k, ONE: counts published and awaited inside the launch
+         "plane_bound_always": {"plane_bound": 2},   # planes: the histogram bound (m3d_bound.hip) at every size (default: long fits of large clouds)
+         "plane_bound_off": {"plane_bound": 0}}
 
 
 @pytest.fixture(params=sorted(PATHS))

@@ -1,0 +1,102 @@
+"""The planes' histogram bound (m3d_bound.hip: tile_frames_k, plane_bound_k, bound_keep_k) against the oracle.
+
+A hypothesis the bound drops must be one the sequential loop (ransac.h:571-613) could not have noticed: its record is 0
+and the oracle's count for it does not exceed the best count of the hypotheses before it.  Everything the fit returns
+must be the oracle's, with the bound on, off and forced -- and the bound must really have spared work.
+"""
+import numpy as np
+import pytest
+
+from misc3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit_all_modes(capi, orc, pts, thr, H, seed, lookahead=256):
+    o = orc.fit(0, pts, None, thr=thr, max_iter=H, prob=1.0, seed=seed, trace=True, lookahead=lookahead)
+    pairs = {}
+    for mode in (0, 1, 2):
+        old = capi.set_config(plane_bound=mode)
+        try:
+            with capi.Cloud(pts) as c:
+                g = c.fit(0, thr, H, 1.0, seed=seed)
+                sm = c.make_sampler(0, seed)
+                try:
+                    v2, c2 = c.score_shard(sm, thr, 0, H, H, 1, 0)
+                finally:
+                    sm.close()
+        finally:
+            capi.restore_config(old)
+        assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.ret, o.best_index, o.count, o.iterations), mode
+        assert np.array_equal(g.inliers, o.inliers), mode
+        assert np.allclose(g.params, o.params, rtol=0, atol=1e-9 * max(1.0, float(np.abs(o.params).max()))), mode   # (order-free GeneralFit sums)
+        oc = o.trace["counts"].astype(np.int64)
+        exact = c2.astype(np.int64) == oc
+        best_before = np.concatenate([[0], np.maximum.accumulate(oc)[:-1]])
+        assert np.array_equal(v2.astype(np.int32), o.trace["valid"]), mode
+        assert np.all(c2[~exact] == 0) and np.all(oc[~exact] <= best_before[~exact]), mode
+        if o.best_index >= 0:
+            assert exact[o.best_index], mode
+        pairs[mode] = (g.stats["pairs_scored"], int((~exact).sum()))
+    return o, pairs
+
+
+def test_bound_prunes_and_matches_oracle_c2_shape(capi, orc):
+    """C2's cloud at a size the oracle finishes in seconds: 150 000 points (293 tiles), 3000 hypotheses."""
+    pts = synth.plane_cloud_c2(150_000, 2)
+    o, pairs = _fit_all_modes(capi, orc, pts, 0.01, 3000, 11)
+    assert len(o.inliers) > 70_000
+    assert pairs[2][0] < 0.8 * pairs[0][0], pairs          # fewer (tile, hypothesis) pairs counted point by point
+    assert pairs[2][1] > pairs[0][1], pairs                # ... because more hypotheses were pruned
+    assert abs(pairs[1][0] - pairs[2][0]) < 0.02 * pairs[2][0], pairs   # (3000 hypotheses on 293 tiles: the default engages too)
+
+
+@pytest.mark.parametrize("case", ["exact_plane", "nan_points", "two_planes", "duplicates", "tiny_threshold", "huge_offset"])
+def test_bound_degenerate_clouds(capi, orc, case):
+    rng = np.random.default_rng(3)
+    n = 40_000
+    if case == "exact_plane":        # zero thickness: the frame's scale is floored, every point in one bin
+        xy = rng.uniform(-1, 1, size=(n, 2))
+        pts = np.column_stack([xy, 0.25 * xy[:, 0] - 0.5 * xy[:, 1] + 0.125])
+        pts[: n // 4] = rng.uniform(-1, 1, size=(n // 4, 3))
+    elif case == "nan_points":
+        pts = synth.plane_cloud_c1(n, 5)
+        pts[rng.integers(0, n, 3000), rng.integers(0, 3, 3000)] = np.nan
+        pts[rng.integers(0, n, 50), 0] = np.inf
+    elif case == "two_planes":       # tiles on the intersection line hold two surfaces
+        pts = synth.plane_cloud_c2(n, 9)
+    elif case == "duplicates":       # whole tiles of one repeated point (extent 0: no frame)
+        pts = synth.plane_cloud_c1(n, 6)
+        pts[: n // 2] = pts[0]
+    elif case == "tiny_threshold":
+        pts = synth.plane_cloud_c1(n, 7)
+    else:                            # coordinates far from the origin: the rounding terms of the bound matter
+        pts = synth.plane_cloud_c1(n, 8) + np.array([4.0e5, -3.0e5, 2.0e5])
+    thr = 1e-5 if case == "tiny_threshold" else 0.01
+    _fit_all_modes(capi, orc, np.ascontiguousarray(pts), thr, 2500, 21, lookahead=128)
+
+
+def test_bound_in_sharded_windows(capi, orc):
+    """m3d_cloud_score_shard, three ranks' slices in turn: every slice prunes with the bound against the same incumbent."""
+    pts = synth.plane_cloud_c2(150_000, 4)
+    H = 3000
+    o = orc.fit(0, pts, None, thr=0.01, max_iter=H, prob=1.0, seed=5, trace=True, lookahead=256)
+    oc = o.trace["counts"].astype(np.int64)
+    best_before = np.concatenate([[0], np.maximum.accumulate(oc)[:-1]])
+    old = capi.set_config(plane_bound=2)
+    try:
+        with capi.Cloud(pts) as c:
+            sl = 512
+            for rank in range(3):
+                sm = c.make_sampler(0, 5)
+                try:
+                    v2, c2 = c.score_shard(sm, 0.01, 0, H, sl, 3, rank)
+                finally:
+                    sm.close()
+                mine = np.concatenate([np.arange(j * sl, min(H, (j + 1) * sl)) for j in range(rank, -(-H // sl), 3)])
+                got = c2.astype(np.int64)
+                assert len(got) == len(mine)
+                exact = got == oc[mine]
+                assert np.all(got[~exact] == 0) and np.all(oc[mine][~exact] <= best_before[mine][~exact]), rank
+    finally:
+        capi.restore_config(old)
