@@ -18,7 +18,8 @@
 //                   a = |n . u| U + |n . v| V + |n|_1 R + rounding terms: the histogram's mass over the bins that interval
 //                   meets is an UPPER BOUND of the pair's inlier count (every rounding of the evaluation is inside a; the bin
 //                   function is the same monotone fp64 expression in both kernels).  Summed per hypothesis: ubsum[h].
-//   bound_keep_k    keep[g] &= (ubsum[h] >= best count of EARLIER hypotheses): the rule of keep_mask_k with a bound that is
+//                   The workgroup that finishes a block of 64 hypotheses last (a ticket per block) applies the keep rule:
+//                   keep bit off where ubsum[h] < best count of EARLIER hypotheses -- keep_mask_k's rule with a bound that is
 //                   within ~10 % of the true count for hypotheses near a surface instead of 512 per tile.
 //
 // A hypothesis dropped here has count <= ubsum < best count of hypotheses before it: it can neither beat nor tie the incumbent
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(64) void tile_frames_k(const double* __restrict__ s
     }
     // the residual as computed carries its own rounding (a dozen operations on numbers of size <= mabs + ext)
     const double Rm = R + 1e-13 * (mabs + ext);
-    const bool ok = (U + V + W + Rm) * 0.0 == 0.0 && (invd * 0.0 == 0.0) && invd > 0.0;
+    // (plane_bound_k evaluates in fp32: sizes it can hold without leaving the normal range)
+    const bool ok = (U + V + W + Rm) < 1e12 && invd > 0.0 && invd < 1e30 && ext > 1e-12 && mabs < 1e12;
     if (lane == 0) {
         fr[0] = c[0]; fr[1] = c[1]; fr[2] = c[2];
         fr[3] = e[0]; fr[4] = e[1]; fr[5] = e[2];
@@ -260,136 +262,193 @@ void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipS
     if (s.n_tiles) tile_frames_k<<<s.n_tiles, 64, 0, st>>>(s.x, s.y, s.z, s.n_tiles, frames, cum);
 }
 
-// One workgroup (four waves) = 64 SURVIVING hypotheses of the window (compacted from the keep words; the blocks of 64 are dealt
-// out along block x, grid-stride) x a range of tiles (block y), the waves taking the range's tiles in turn.  Everything per
-// pair in fp64: ~70 instructions; what the kernel waits for is memory latency (the tile's frame through scalar loads, the mask
-// word and two histogram entries per lane), so it runs ~10 waves per SIMD and its loop is free of branches.
+// One workgroup (four waves) = 64 hypotheses of the survivor list (written by the keep kernels: emit_survivors; the blocks of 64
+// are dealt out along block x, grid-stride) x a range of tiles (block y), the waves taking the tiles in turn.  The frames and
+// histograms of the range go to LDS in one cooperative sweep while the list and the hypotheses' records arrive, a lane's mask
+// words are fetched together, and the loop reads LDS only; a tile none of the 64 hypotheses touches is skipped.
+//
+// Arithmetic.  The value at the tile's centre, S(c) = n . c + d, cancels (|n . c| and |d| are of the cloud's size, S(c) of the
+// tile's) and is formed in fp64; everything after it runs in fp32 -- the first form of the kernel was fp64 throughout, ~150
+// instructions per pair with its division, and VALU-bound at 16-20 us.  Every fp32 number is pushed in the safe direction
+// by far more than its rounding: coefficients g = |n . e|, n . u, n . v computed from operands rounded to fp32 are off by at most
+// 4 x 2^-24 |n|_1 (e32 = 5e-7 |n|_1: it enters the slack with W, U, V -- the computed g is then THE coefficient of the
+// inequality, exactly); U, V, W, R are rounded up when staged; the slack is inflated by 1e-5 of itself and of (T + a + |S(c)|)
+// (against ~1e-6 for a dozen fp32 operations), the interval's ends by 1e-5 of their size (the reciprocal and the product);
+// and the bins are taken one further out on both sides (the fp32 bin coordinate is within 1e-4 bins of bound_bin's).
+// Numbers outside [1e-12, 1e12] (an fp32 product could leave the normal range) are not bounded at all: 512 per touched tile.
 constexpr int kBoundWaves = 4;
+template <int kBoundTpw /* tiles per wave */>
 __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* __restrict__ frames, const uint16_t* __restrict__ cum,
-                                                                   uint32_t n_tiles, uint32_t tiles_per_block, double max_abs,
+                                                                   uint32_t n_tiles, double max_abs,
                                                                    const double* __restrict__ score,
-                                                                   const unsigned long long* __restrict__ masks,
-                                                                   const unsigned long long* __restrict__ keep, uint32_t n_groups,
-                                                                   uint32_t group_begin, uint32_t group_end,
-                                                                   uint32_t* __restrict__ ubsum) {
-    __shared__ uint32_t ids[64];
+                                                                   const unsigned long long* __restrict__ masks, uint32_t n_groups,
+                                                                   const double* __restrict__ boxes, const float* __restrict__ cull32,
+                                                                   uint32_t* __restrict__ surv_count,
+                                                                   const uint32_t* __restrict__ surv,
+                                                                   uint32_t* __restrict__ ubsum, const uint32_t* __restrict__ best_count,
+                                                                   unsigned long long* __restrict__ keep,
+                                                                   uint32_t* __restrict__ tickets /* [0]: finished blocks; [1 + block] */) {
+    constexpr int kBoundTpb = kBoundWaves * kBoundTpw;     // tiles per workgroup
+    __shared__ float bx_s[kBoundTpb][6];                   // the tile's fp32 box (cull_tiles32_k's)
+    __shared__ double c_s[kBoundTpb][3];
+    __shared__ float f_s[kBoundTpb][kFrameStride];         // slots 3 .. 19 of the frame in fp32 (U, V, R, W rounded up)
+    __shared__ __attribute__((aligned(8))) uint16_t cm_s[kBoundTpb][kCumStride];
     __shared__ uint32_t wsum[kBoundWaves][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t window = group_end - group_begin;
-    const uint32_t per = (window + 63u) / 64u;   // keep words per lane (a contiguous run)
-    const uint32_t w0 = (uint32_t)lane * per;
-    uint32_t own = 0;
-    for (uint32_t i = 0; i < per; ++i)
-        if (w0 + i < window) own += (uint32_t)__popcll(keep[group_begin + w0 + i]);
-    uint32_t incl = own;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
-        if (lane >= off) incl += t;
+    const uint32_t total = surv_count[0];
+    if (blockIdx.x * 64u >= total) return;   // (workgroup-uniform)
+    const uint32_t t0 = blockIdx.y * (uint32_t)kBoundTpb, nt = min((uint32_t)kBoundTpb, n_tiles - t0);
+    {
+        const double* __restrict__ src = frames + (size_t)t0 * kFrameStride;
+        for (uint32_t i = threadIdx.x; i < nt * (uint32_t)kFrameStride; i += 64u * kBoundWaves) {
+            const uint32_t tl = i / (uint32_t)kFrameStride, k = i % (uint32_t)kFrameStride;
+            const double v = src[i];
+            if (k < 3u) c_s[tl][k] = v;
+            const bool up = k == 12u || k == 13u || k == 14u || k == 17u;   // U, V, R, W: rounded up
+            f_s[tl][k] = (float)(up ? v * (1.0 + 1e-6) : v);
+        }
+        if (cull32)
+            for (uint32_t i = threadIdx.x; i < nt * 6u; i += 64u * kBoundWaves)
+                bx_s[i / 6u][i % 6u] = reinterpret_cast<const float*>(boxes + (size_t)(t0 + i / 6u) * kBoxStride + 8)[i % 6u];
+        const uint32_t* __restrict__ csrc = reinterpret_cast<const uint32_t*>(cum + (size_t)t0 * kCumStride);
+        uint32_t* cdst = reinterpret_cast<uint32_t*>(&cm_s[0][0]);
+        for (uint32_t i = threadIdx.x; i < nt * (uint32_t)(kCumStride / 2); i += 64u * kBoundWaves) cdst[i] = csrc[i];
     }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-    const uint32_t t0 = blockIdx.y * tiles_per_block, t1 = min(n_tiles, t0 + tiles_per_block);
     for (uint32_t first = blockIdx.x * 64u; first < total; first += gridDim.x * 64u) {   // (workgroup-uniform)
-        __syncthreads();   // (the previous block's ids and sums have been read)
+        const uint32_t nb = min(64u, total - first);
+        const bool has = (uint32_t)lane < nb;
+        const uint32_t h = surv[first + (has ? (uint32_t)lane : 0u)];
+        const double* __restrict__ rp = score + (size_t)h * kModelStride;
+        const double a = rp[0], b = rp[1], c = rp[2], d = rp[3], T = rp[4];
+        const unsigned long long bit = 1ull << (h & 63u);
+        const unsigned long long* __restrict__ mrow = masks + (size_t)(h >> 6);
+        // touched or not: the box test itself, from the hypothesis' fp32 record and the tile's fp32 box (the arithmetic of
+        // cull32_one<0>, m3d_cull_kernels.hip: the bits cull_tiles32_k wrote) -- the mask words are 8 useful bytes per 128-byte
+        // line for this kernel's lanes (6.5 of its 18 us); without fp32 records (m3d_config.cull_fp32 = 0) it reads them
+        bool tch[kBoundTpw];
+        float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (cull32) {   // (kernel argument: uniform)
+            const float* __restrict__ qp = cull32 + (size_t)(h >> 1) * 24u + (h & 1u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] = qp[2 * k];
+        } else {
+#pragma unroll
+            for (int i = 0; i < kBoundTpw; ++i) {
+                const uint32_t tl = (uint32_t)(wave + kBoundWaves * i);
+                tch[i] = (has && tl < nt) ? (mrow[(size_t)(t0 + tl) * n_groups] & bit) != 0ull : false;
+            }
+        }
+        const double n1d = (fabs(a) + fabs(b)) + fabs(c);
+        const double Mg = n1d * max_abs + fabs(d);
+        const bool rec_ok = has && (T > 1e-12) && (T < 1e12) && (n1d > 1e-12) && (n1d < 1e12) && (Mg < 1e12);
+        const float af = (float)a, bf = (float)b, cf = (float)c;
+        const float n1 = (float)(n1d * (1.0 + 1e-6));
+        const float e32 = 5e-7f * n1;
+        const float Tf = (float)(T * (1.0 + 1e-6));
+        const float mgf = (float)(1e-14 * Mg * (1.0 + 1e-6));
+        __syncthreads();   // (the frames are in LDS; the previous block's sums have been read)
+        uint32_t ub = 0;
+#pragma unroll
+        for (int i = 0; i < kBoundTpw; ++i) {
+            const int tl = wave + kBoundWaves * i;
+            if (cull32) {
+                const float* bx = bx_s[tl];
+                const float sv = __builtin_fmaf(q[0], bx[0], __builtin_fmaf(q[1], bx[1], __builtin_fmaf(q[2], bx[2], q[3])));
+                const float hx = __builtin_fmaxf(bx[3], 0.0f), hy = __builtin_fmaxf(bx[4], 0.0f), hz = __builtin_fmaxf(bx[5], 0.0f);
+                const float rv = __builtin_fmaf(q[4], hx, __builtin_fmaf(q[5], hy, __builtin_fmaf(q[6], hz, q[7])));
+                tch[i] = has && (uint32_t)tl < nt && bx[3] >= 0.0f && !(rv - __builtin_fabsf(sv) < 0.0f);
+            }
+            if (__ballot(tch[i]) == 0ull) continue;   // (wave-uniform)
+            const float* f = f_s[tl];   // (wave-uniform address: broadcast reads)
+            const double sc0 = ((a * c_s[tl][0] + b * c_s[tl][1]) + c * c_s[tl][2]) + d;
+            const float g0 = af * f[3] + bf * f[4] + cf * f[5];
+            const float nu = af * f[6] + bf * f[7] + cf * f[8];
+            const float nv = af * f[9] + bf * f[10] + cf * f[11];
+            const float U = f[12], V = f[13], R = f[14], W = f[17];
+            const float scf = (float)sc0;
+            float aa = (__builtin_fabsf(nu) + e32) * U + (__builtin_fabsf(nv) + e32) * V + n1 * R + e32 * W + mgf;
+            aa = aa * 1.00001f + 1e-5f * ((Tf + aa) + __builtin_fabsf(scf));
+            const float g = __builtin_fabsf(g0), sc = g0 < 0.0f ? -scf : scf;
+            const float ig = __builtin_amdgcn_rcpf(g);   // (g = 0: inf; with a zero numerator NaN -- caught below)
+            float L = ((-Tf - aa) - sc) * ig, H = ((Tf + aa) - sc) * ig;
+            L -= 1e-5f * __builtin_fabsf(L);
+            H += 1e-5f * __builtin_fabsf(H);
+            const bool framed = f[19] != 0.0f && rec_ok;
+            const float wlo = f[15], invd = f[16];
+            const float tL = __builtin_floorf((L - wlo) * invd) - 1.0f, tH = __builtin_floorf((H - wlo) * invd) + 1.0f;
+            const bool whole = !(tL == tL) || !(tH == tH);   // (0 x inf, inf - inf: the direction says nothing -- every finite point of the tile)
+            const int bl = (int)__builtin_fminf(__builtin_fmaxf(whole ? 0.0f : tL, -1.0f), (float)kBoundBins) + 1;
+            const int bh = (int)__builtin_fminf(__builtin_fmaxf(whole ? 0.0f : tH, -1.0f), (float)kBoundBins) + 1;
+            const int lo_c = (int)cm_s[tl][bl], hi_c = (int)cm_s[tl][bh + 1];
+            uint32_t u_t = (uint32_t)max(hi_c - lo_c, 0);
+            u_t = whole ? (uint32_t)f[18] : u_t;
+            u_t = framed ? u_t : (uint32_t)kTilePoints;
+            ub += tch[i] ? u_t : 0u;
+        }
+        wsum[wave][lane] = ub;
+        __syncthreads();
         if (wave == 0) {
-            uint32_t r = incl - own;
-            if (r < first + 64u && r + own > first) {
-                for (uint32_t i = 0; i < per && w0 + i < window; ++i) {
-                    unsigned long long m = keep[group_begin + w0 + i];
-                    while (m) {
-                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                        if (r >= first && r < first + 64u) ids[r - first] = (group_begin + w0 + i) * 64u + b;
-                        ++r;
-                        m &= m - 1ull;
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < kBoundWaves; ++w) tot += wsum[w][lane];
+            if (has && tot) atomicAdd(&ubsum[h], tot);
+            // the keep rule, by whichever workgroup of this block of 64 hypotheses finishes last (a ticket per block: nobody
+            // waits): keep bit off where the bound stays below the best count of earlier hypotheses
+            __threadfence();
+            const uint32_t blk = first / 64u;
+            uint32_t old = 0;
+            if (lane == 0) old = atomicAdd(&tickets[1u + blk], 1u);
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            if (old == gridDim.y - 1u) {   // (wave-uniform)
+                __threadfence();
+                const uint32_t best = best_count[0];
+                const uint32_t sum = has ? atomicAdd(&ubsum[h], 0u) : 0u;   // (the other workgroups' adds, at the memory side)
+                if (has && best != 0u && sum < best) atomicAnd(&keep[h >> 6], ~bit);
+                uint32_t done = 0;
+                if (lane == 0) {
+                    tickets[1u + blk] = 0u;
+                    done = atomicAdd(&tickets[0], 1u);
+                    if (done == (total + 63u) / 64u - 1u) {   // the last block of the launch: the list is consumed
+                        tickets[0] = 0u;
+                        surv_count[0] = 0u;
                     }
                 }
             }
         }
-        __syncthreads();
-        const uint32_t nb = min(64u, total - first);
-        const bool has = (uint32_t)lane < nb;
-        const uint32_t h = has ? ids[lane] : group_begin * 64u;
-        const double* __restrict__ rp = score + (size_t)h * kModelStride;
-        const double a = rp[0], b = rp[1], c = rp[2], d = rp[3], T = rp[4];
-        const double n1 = (fabs(a) + fabs(b)) + fabs(c);
-        const double Mg = n1 * max_abs + fabs(d);
-        const double eps1 = 4e-15 * n1;
-        const bool rec_ok = has && (T > 0.0) && ((n1 + Mg + T) * 0.0 == 0.0);
-        const unsigned long long bit = 1ull << (h & 63u);
-        const unsigned long long* __restrict__ mrow = masks + (size_t)(h >> 6);
-        uint32_t ub = 0;
-#pragma unroll 4
-        for (uint32_t t = t0 + (uint32_t)wave; t < t1; t += (uint32_t)kBoundWaves) {
-            const bool touched = has && (mrow[(size_t)t * n_groups] & bit) != 0ull;
-            const double* __restrict__ fr = frames + (size_t)t * kFrameStride;   // (wave-uniform: scalar loads)
-            const double sc0 = ((a * fr[0] + b * fr[1]) + c * fr[2]) + d;
-            const double g0 = (a * fr[3] + b * fr[4]) + c * fr[5];
-            const double nu = (a * fr[6] + b * fr[7]) + c * fr[8];
-            const double nv = (a * fr[9] + b * fr[10]) + c * fr[11];
-            double aa = (((fabs(nu) + eps1) * fr[12] + (fabs(nv) + eps1) * fr[13]) + n1 * fr[14]) + (eps1 * fr[17] + 1e-14 * Mg);
-            aa += 1e-12 * ((T + aa) + fabs(sc0));
-            const double g = fabs(g0), sc = g0 < 0.0 ? -sc0 : sc0;
-            const double ig = 1.0 / g;   // (g = 0: +-inf or, with a zero numerator, NaN -- caught below)
-            // the quotient rounds: both ends move outwards by far more than that (1e-12 of their own size, against 2^-52)
-            double L = ((-T - aa) - sc) * ig, H = ((T + aa) - sc) * ig;
-            L -= 1e-12 * fabs(L);
-            H += 1e-12 * fabs(H);
-            const bool framed = fr[19] != 0.0 && rec_ok;
-            const bool whole = !(L == L) || !(H == H);   // (0 x inf: the direction says nothing -- every finite point of the tile)
-            const int bl = bound_bin(whole ? 0.0 : L, fr[15], fr[16]), bh = bound_bin(whole ? 0.0 : H, fr[15], fr[16]);
-            const uint16_t* __restrict__ cm = cum + (size_t)t * kCumStride;
-            const int lo_c = (int)cm[bl], hi_c = (int)cm[bh + 1];
-            uint32_t u_t = (uint32_t)max(hi_c - lo_c, 0);
-            u_t = whole ? (uint32_t)fr[18] : u_t;
-            u_t = framed ? u_t : (uint32_t)kTilePoints;
-            ub += touched ? u_t : 0u;
-        }
-        wsum[wave][lane] = ub;
-        __syncthreads();
-        if (wave == 0 && has) {
-            uint32_t tot = 0;
-#pragma unroll
-            for (int w = 0; w < kBoundWaves; ++w) tot += wsum[w][lane];
-            if (tot) atomicAdd(&ubsum[h], tot);
-        }
-    }
-}
-
-__global__ __launch_bounds__(64) void bound_keep_k(const uint32_t* __restrict__ ubsum, const uint32_t* __restrict__ best_count,
-                                                    unsigned long long* __restrict__ keep, uint32_t group_begin,
-                                                    uint32_t* __restrict__ dropped) {
-    const uint32_t g = group_begin + blockIdx.x;
-    const uint32_t best = best_count[0];
-    const unsigned long long old = keep[g];
-    const bool k = best == 0u || ubsum[g * 64u + threadIdx.x] >= best;
-    const unsigned long long m = __ballot(k) & old;
-    if (threadIdx.x == 0) {
-        keep[g] = m;
-        if (dropped && m != old) atomicAdd(dropped, (uint32_t)__popcll(old & ~m));
     }
 }
 
 void launch_plane_bound(const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
                         uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
-                        const uint32_t* best_count, hipStream_t st, uint32_t* dropped) {
+                        const uint32_t* best_count, uint32_t* surv_count, const uint32_t* surv, uint32_t* tickets,
+                        const float* cull32, hipStream_t st) {
     group_end = std::min(group_end, n_groups);
-    if (!s.frames || !s.frame_cum || !s.n_tiles || group_begin >= group_end) return;
+    if (!s.frames || !s.frame_cum || !s.n_tiles || !surv || !surv_count || !tickets || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
-    static const uint32_t tpb = [] {   // tiles per workgroup (M3D_BOUND_TPB)
-        const char* e = std::getenv("M3D_BOUND_TPB");
-        const long v = e && *e ? std::strtol(e, nullptr, 10) : 32;   // C2: 8 / 16 / 32 / 64 -> 0.2756 / 0.2681 / 0.2612 / 0.2911 ms per step
-        return (uint32_t)std::min<long>(std::max<long>(v, 1), 4096);
-    }();
     static const uint32_t gdiv = [] {   // one block of 64 survivors per `gdiv` groups of the window to begin with (M3D_BOUND_GDIV)
         const char* e = std::getenv("M3D_BOUND_GDIV");
         const long v = e && *e ? std::strtol(e, nullptr, 10) : 6;
         return (uint32_t)std::min<long>(std::max<long>(v, 1), 64);
     }();
     const uint32_t gx = std::min<uint32_t>(window, std::max<uint32_t>(4u, (window + gdiv - 1) / gdiv));
+    static const int tpw = [] {   // tiles per wave (M3D_BOUND_TPW: 8 / 12 / 16 / 24 / 32)
+        const char* e = std::getenv("M3D_BOUND_TPW");
+        const long v = e && *e ? std::strtol(e, nullptr, 10) : 16;
+        return v <= 8 ? 8 : (v <= 12 ? 12 : (v <= 16 ? 16 : (v <= 24 ? 24 : 32)));
+    }();
+    const uint32_t tpb = (uint32_t)(kBoundWaves * tpw);
     const dim3 g(gx, (s.n_tiles + tpb - 1) / tpb), b(64 * kBoundWaves);
-    plane_bound_k<<<g, b, 0, st>>>(s.frames, s.frame_cum, s.n_tiles, tpb, s.max_abs, score, masks, keep, n_groups, group_begin,
-                                   group_end, ubsum);
-    bound_keep_k<<<window, 64, 0, st>>>(ubsum, best_count, keep, group_begin, dropped);
+    if (s.radius >= 1e18) cull32 = nullptr;   // (no fp32 boxes: launch_cull_mask's condition)
+    auto go = [&](auto kernel) {
+        kernel<<<g, b, 0, st>>>(s.frames, s.frame_cum, s.n_tiles, s.max_abs, score, masks, n_groups, s.boxes, cull32, surv_count, surv,
+                                ubsum, best_count, keep, tickets);
+    };
+    if (tpw == 8) go(plane_bound_k<8>);
+    else if (tpw == 12) go(plane_bound_k<12>);
+    else if (tpw == 16) go(plane_bound_k<16>);
+    else if (tpw == 24) go(plane_bound_k<24>);
+    else go(plane_bound_k<32>);
 }
 
 }  // namespace m3d

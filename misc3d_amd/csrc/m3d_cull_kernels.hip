@@ -430,17 +430,33 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
 // (ub null: everything; best_count null or 0: everything).  zero != null: the kernel also clears the
 // kCountReplicas x rep_stride counter replicas of its hypotheses and (group 0) the kPairReplicas words behind them,
 // which the scoring kernel that follows adds into -- one command less than a separate memset.
+// Optional by-product of the keep rules (plane_bound_k's input, m3d_bound.hip): the kept hypotheses of the launch as a LIST, in no
+// particular order (one atomic per group of 64) -- *surv_count its length (zero before the launch: cleared by a fit's first
+// minimal_fit_k and by bound_keep_k, which consumes the list).
+struct SurvOut {
+    uint32_t* count = nullptr;
+    uint32_t* ids = nullptr;
+};
+__device__ __forceinline__ void emit_survivors(const SurvOut surv, unsigned long long m, bool k, uint32_t h) {
+    if (!surv.count || !m) return;   // (m: wave-uniform)
+    uint32_t base = 0;
+    if (threadIdx.x == 0) base = atomicAdd(surv.count, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (k) surv.ids[base + rank] = h;
+}
 __global__ __launch_bounds__(64) void keep_mask_k(const uint32_t* __restrict__ ub,
                                                    const uint32_t* __restrict__ best_count_ptr,
                                                    unsigned long long* __restrict__ keep,
                                                    uint32_t* __restrict__ zero, uint32_t rep_stride,
-                                                   uint32_t group_offset) {
+                                                   uint32_t group_offset, SurvOut surv) {
     const uint32_t g = group_offset + blockIdx.x;
     const uint32_t h = g * 64u + threadIdx.x;
     const uint32_t best = best_count_ptr ? best_count_ptr[0] : 0u;
     const bool k = !ub || best == 0 || (uint64_t)ub[h] * kTilePoints >= best;
     const unsigned long long m = __ballot(k);
     if (threadIdx.x == 0) keep[g] = m;
+    emit_survivors(surv, m, k, h);
     if (zero) {
 #pragma unroll
         for (int r = 0; r < kCountReplicas; ++r) zero[(size_t)r * rep_stride + h] = 0u;
@@ -450,13 +466,13 @@ __global__ __launch_bounds__(64) void keep_mask_k(const uint32_t* __restrict__ u
 }
 // groups [group_offset, group_offset + n_groups) of the chunk
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
-                      hipStream_t st, uint32_t* zero_counts_rep, uint32_t rep_stride, uint32_t group_offset) {
+                      hipStream_t st, uint32_t* zero_counts_rep, uint32_t rep_stride, uint32_t group_offset, uint32_t* surv_count, uint32_t* surv) {
     if (!n_groups) return;
-    if (!ub && !zero_counts_rep) {
+    if (!ub && !zero_counts_rep && !surv_count) {
         (void)hipMemsetAsync(keep + group_offset, 0xFF, sizeof(unsigned long long) * n_groups, st);
         return;
     }
-    keep_mask_k<<<n_groups, 64, 0, st>>>(ub, best_count, keep, zero_counts_rep, rep_stride, group_offset);
+    keep_mask_k<<<n_groups, 64, 0, st>>>(ub, best_count, keep, zero_counts_rep, rep_stride, group_offset, SurvOut{surv_count, surv});
 }
 
 // The lead pass of a chunk (its first `lead` hypotheses, counted on their own) and the keep masks of the rest in
@@ -471,7 +487,8 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
                                                         uint32_t* __restrict__ zero, uint32_t group_offset,
                                                         uint32_t* __restrict__ records_dev,
                                                         unsigned long long* __restrict__ pick_key,
-                                                        unsigned long long* __restrict__ pick_key2) {
+                                                        unsigned long long* __restrict__ pick_key2,
+                                                        SurvOut surv) {
     const uint32_t g = group_offset + blockIdx.x;
     const uint32_t prev = best_count[0];   // may or may not include this chunk's lead already: max() below either way
     uint32_t v = 0;
@@ -511,6 +528,7 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
     const bool k = !ub || best == 0 || (uint64_t)ub[h] * kTilePoints >= best;
     const unsigned long long m = __ballot(k);
     if (threadIdx.x == 0) keep[g] = m;
+    emit_survivors(surv, m, k, h);
     if (zero) {
 #pragma unroll
         for (int r = 0; r < kCountReplicas; ++r) zero[(size_t)r * rep_stride + h] = 0u;
@@ -519,12 +537,12 @@ __global__ __launch_bounds__(64) void lead_fold_keep_k(const uint32_t* __restric
 void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint32_t lead, const uint8_t* valid,
                            uint32_t h_count, uint32_t* records, uint32_t* best_count, const uint32_t* ub,
                            unsigned long long* keep, uint32_t n_groups_rest, hipStream_t st, uint32_t* records_dev,
-                           uint32_t group_begin, unsigned long long* pick_key, unsigned long long* pick_key2) {
+                           uint32_t group_begin, unsigned long long* pick_key, unsigned long long* pick_key2, uint32_t* surv_count, uint32_t* surv) {
     if (group_begin == 0xFFFFFFFFu) group_begin = lead / 64u;
     // (n_groups_rest == 0 still needs the fold of the lead's counters: one workgroup whose keep word is scratch)
     if (!n_groups_rest) return;
     lead_fold_keep_k<<<n_groups_rest, 64, 0, st>>>(counts_rep, rep_stride, lead, valid, h_count, records, best_count, ub,
-                                                   keep, const_cast<uint32_t*>(counts_rep), group_begin, records_dev, pick_key, pick_key2);
+                                                   keep, const_cast<uint32_t*>(counts_rep), group_begin, records_dev, pick_key, pick_key2, SurvOut{surv_count, surv});
 }
 
 // ------------------------------------------------------------------------------------------------

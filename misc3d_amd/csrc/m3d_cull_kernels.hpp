@@ -41,11 +41,15 @@ constexpr int kFrameStride = 20;      // doubles per tile frame: c, e, u, v (3 e
 constexpr int kBoundBins = 126;       // interior bins of a tile's histogram (bin 0 / kBoundBins + 1: below / above its range)
 constexpr int kCumStride = 132;       // uint16 per tile: cum[0 .. kBoundBins + 2] (+ padding to 264 bytes)
 void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipStream_t st);
-// ubsum[h] += upper bound of hypothesis h's inliers over the tiles whose mask bit is set (hypotheses with their keep bit set, groups
-// [group_begin, group_end); ubsum zero on entry); then keep[g] &= (ubsum[h] >= best_count[0]).  Planes only; needs s.frames.
+// ubsum[h] += upper bound of hypothesis h's inliers over the tiles it can touch, for the hypotheses of the list `surv` (written by
+// the keep kernels of groups [group_begin, group_end): *surv_count ids; ubsum zero on entry); the keep bit of a hypothesis whose
+// bound stays below best_count[0] is cleared, *surv_count ends at 0.  tickets: 1 + (hypotheses of the window / 64) words, zero
+// before the first launch (the kernel leaves them zero).  cull32: the window's fp32 box-test records (null: the masks are
+// read instead).  Planes only; needs s.frames.
 void launch_plane_bound(const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
                         uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
-                        const uint32_t* best_count, hipStream_t st, uint32_t* dropped = nullptr);
+                        const uint32_t* best_count, uint32_t* surv_count, const uint32_t* surv, uint32_t* tickets,
+                        const float* cull32, hipStream_t st);
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 // Tombstones (m3d_poison.hpp): the job that kills the inliers of the plane `model` (device) in place in the sorted copy
 // `s`; *total (device, cleared by the owner) accumulates the number of points killed over all launches.
@@ -67,7 +71,9 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
 // zero_counts_rep != null: the same launch clears the kCountReplicas x rep_stride + kPairReplicas counter words.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,
                       hipStream_t st, uint32_t* zero_counts_rep = nullptr, uint32_t rep_stride = 0,
-                      uint32_t group_offset = 0 /* the launch covers groups [group_offset, group_offset + n_groups) */);
+                      uint32_t group_offset = 0 /* the launch covers groups [group_offset, group_offset + n_groups) */,
+                      uint32_t* surv_count = nullptr, uint32_t* surv = nullptr /* the kept hypotheses as a list as well (emit_survivors:
+                                                                                  plane_bound_k's input; *surv_count zero before the launch) */);
 // counts_rep[tile % kCountReplicas][h] += inliers of hypothesis h in the tiles whose (mask & keep) bit is set;
 // counts_rep (kCountReplicas x rep_stride u32) zero on entry; launch_sum_replicas folds the replicas.
 constexpr int kCountReplicas = 16;
@@ -162,7 +168,8 @@ void launch_lead_fold_keep(const uint32_t* counts_rep, uint32_t rep_stride, uint
                            uint32_t* records_dev = nullptr,
                            uint32_t group_begin = 0xFFFFFFFFu /* first group of the keep window; default lead / 64 */,
                            unsigned long long* pick_key = nullptr /* PickFinal::key: the lead's best goes in */,
-                           unsigned long long* pick_key2 = nullptr /* PickFinal::key2 */);
+                           unsigned long long* pick_key2 = nullptr /* PickFinal::key2 */,
+                           uint32_t* surv_count = nullptr, uint32_t* surv = nullptr /* the kept hypotheses as a list as well */);
 void launch_count_bits(const unsigned long long* masks, const unsigned long long* keep, uint32_t n_tiles,
                        uint32_t n_groups, unsigned long long* total, hipStream_t st);
 

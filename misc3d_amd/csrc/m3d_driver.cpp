@@ -604,6 +604,21 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 scored_with_own_tests = launch_score_own_tests(kind, sv, s.score.as<double>(), c32.out, masks, keep, n_groups, g1,
                                                                ctx->counts_rep.as<uint32_t>(), h_pad, pair_rep, ctx->stream,
                                                                timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
+            // planes with an incumbent and tile frames: a histogram upper bound per touched (tile, hypothesis) pair replaces
+            // "512 per touched tile" in the keep rule (m3d_bound.hip).  The keep kernels below hand plane_bound_k the kept
+            // hypotheses as a list (its length: word 6 of best_count); ubsum is the slot's phase-counter array, zeroed by
+            // minimal_fit_k and unused when the scoring is not phased.
+            const bool bound_on = kind == M3D_PLANE && prune && bc && !ubp && sv.frames && config().plane_bound != 0 &&
+                                  (use_lead || !new_fit) && !scored_with_own_tests && std::max(g0, ga) < g1;
+            if (bound_on) {   // the list, and behind it the tickets of plane_bound_k (zero between launches: cleared when the block is new)
+                const size_t words = (size_t)h_pad + 64 + (size_t)h_pad / 64 + 64;
+                if (ctx->surv_list.cap < sizeof(uint32_t) * words) {
+                    RESERVE(ctx->surv_list, sizeof(uint32_t) * words * 2);
+                    HIPCHK(hipMemsetAsync(ctx->surv_list.p, 0, ctx->surv_list.cap, ctx->stream));
+                }
+            }
+            uint32_t* const surv_count = bound_on ? bc + 6 : nullptr;
+            uint32_t* const surv = bound_on ? ctx->surv_list.as<uint32_t>() : nullptr;
             if (!s.lead_fused && !scored_with_own_tests) {
                 if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
                     launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
@@ -629,16 +644,13 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 launch_lead_fold_keep(ctx->counts_rep.as<uint32_t>(), h_pad, lead, s.valid.as<uint8_t>(), count,
                                       g0 == 0 ? rec_host : nullptr, bc, ub, keep, g1 - g_lo, ctx->stream,
                                       g0 == 0 ? rec_dev : nullptr, g_lo, pick_final ? pick_final->key : nullptr,
-                                      pick_final ? pick_final->key2 : nullptr);
+                                      pick_final ? pick_final->key2 : nullptr, surv_count, surv);
             } else if (!all_prepared) {   // (all_prepared: minimal_fit_k has done it)
-                launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0);
+                launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0, surv_count, surv);
             }
-            // planes with an incumbent and tile frames: a histogram upper bound per touched (tile, hypothesis) pair replaces
-            // "512 per touched tile" in the keep rule (m3d_bound.hip); ubsum is the slot's phase-counter array, zeroed by
-            // minimal_fit_k and unused when the scoring is not phased
-            if (kind == M3D_PLANE && prune && bc && !ubp && sv.frames && config().plane_bound != 0 && (use_lead || !new_fit) &&
-                !scored_with_own_tests && g_lo < g1)
-                launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, g_lo, g1, ub + h_pad, bc, ctx->stream);
+            if (bound_on)
+                launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, g_lo, g1, ub + h_pad, bc, surv_count, surv,
+                                   surv + ((size_t)h_pad + 64), c32.out, ctx->stream);
             bool phased = false;
             if (!scored_with_own_tests && ubp)
                 phased = launch_score_phased(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
@@ -2366,6 +2378,7 @@ int m3d_cloud_score_shard(m3d_cloud* c, m3d_sampler* sampler, double threshold, 
     if (begin == 0) sampler->incumbent = 0;  // new fit
     *ctx->h_inc.as<uint32_t>() = sampler->incumbent;
     HIPCHK(hipMemcpyAsync(ctx->best_count.p, ctx->h_inc.p, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->best_count.as<uint32_t>() + 6, 0, sizeof(uint32_t), ctx->stream));   // (the survivor list's length: plane_bound_k)
     // A rank whose first slice starts late in the window does not wait for the host to walk the stream up to it
     // before the GPU gets work: the window's first hypotheses (lead_size()) (another rank's, lower in the sequence than
     // anything this rank owns -- exactly what bound-and-prune may use) are scored at once for their best count

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void minimal_fit_k(CloudView c, const uint32_t*
     if (h >= h_pad) return;
     if (zero_u32 && h + 1 < h_pad) zero_u32[h] = 0;   // per-hypothesis counter cleared on the way (saves a memset launch)
     if (zero_u32b && h + 1 < h_pad) zero_u32b[h] = 0;   // (the phase counters of the box tests: launch_score_phased)
-    if (zero_one && h < 6) zero_one[h] = 0;           // a fit's first chunk: the running best count + the pick's ticket, key and key2 (PickFinal)
+    if (zero_one && h < 8) zero_one[h] = 0;           // a fit's first chunk: the running best count + the pick's ticket, key and key2 (PickFinal), the survivor list's length (plane_bound_k)
     if (lead.counts_rep) {
         // a fit's first chunk: what keep_mask_k would do for the leading hypotheses (nothing to prune against yet: keep
         // everything; clear their counter replicas and the launch's pair counters) -- one launch less in front of the lead pass

@@ -66,7 +66,7 @@ bool launch_minimal_fit(int kind, const CloudView& c, const uint32_t* samples, u
                         uint32_t h_pad, double thr, double* score, double* params, uint8_t* valid,
                         hipStream_t s,
                         uint32_t* zero_u32 = nullptr /* h_pad - 1 counters cleared by the same launch */,
-                        uint32_t* zero_one = nullptr /* SIX more words cleared by the same launch */,
+                        uint32_t* zero_one = nullptr /* EIGHT more words cleared by the same launch */,
                         const LeadPrep* lead = nullptr,
                         double cull_max_abs = __builtin_inf() /* SortedView::max_abs: the plane record's slot 5 receives the
                                                                  cut-off of the box tests (inf: nothing is ever culled) */,
