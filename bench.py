@@ -392,7 +392,7 @@ def main():
 
     # ---- N = 1: the same steps on the reference's own arithmetic, the set-up the timed steps do not contain, and the
     # reference-shaped call (host arrays in, results out: py_common.cpp:11-27 has no resident handle) ----------------
-    fp64_only, setup, oneshot = None, None, None
+    fp64_only, setup, oneshot, plane_bound = None, None, None, None
     if world == 1 and comm is None:
         old_cfg = capi.set_config(score_fp32_screen=0, cull_fp32=0)
         try:
@@ -425,6 +425,52 @@ def main():
                                       "tile_hypothesis_pairs_per_step": f_pairs / float(a.steps)}}
         finally:
             capi.restore_config(old_cfg)
+        # the planes' histogram bound (m3d_bound.hip) switched off: the same K steps, same result, what the bound is worth
+        if kind == 0 and capi.get_config().plane_bound != 0:
+            old_cfg = capi.set_config(plane_bound=0)
+            try:
+                for _ in range(5):
+                    step()
+                barrier()
+                b_ms, b_launch, b_pairs = 0.0, 0, 0
+                gc.disable()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    rb = step()
+                    b_ms += rb.stats["ms_score_kernel"]
+                    b_launch += rb.stats["score_launches"]
+                    b_pairs += rb.stats["pairs_timed"]
+                barrier()
+                dtb = time.perf_counter() - t0
+                gc.enable()
+                sameb = (rb.stats["best_index"] == res.stats["best_index"] and np.array_equal(rb.inliers, res.inliers)
+                         and np.array_equal(rb.params, res.params))
+                plane_bound = {"without": {"ms_per_step": dtb / a.steps * 1e3, "value": H_total * a.steps / dtb,
+                                           "launch_ms": b_ms / max(b_launch, 1),
+                                           "tile_hypothesis_pairs_per_launch": b_pairs / max(b_launch, 1),
+                                           "frac": b_pairs * peak_model(MIX_SCREEN[kind])[1] / (b_ms * 1e-3 * SIMDS * CLOCK_HZ),
+                                           "identical_result": bool(sameb)},
+                               "note": "m3d_config.plane_bound = 0: the keep rule prices a hypothesis at 512 points per tile its slab "
+                                       "can touch; with the bound (the headline) at a per-tile histogram's mass over the slab "
+                                       "(tile_frames_k once per resident cloud, plane_bound_k per fit: inside ms_per_step)"}
+            finally:
+                capi.restore_config(old_cfg)
+            # what the first long plane fit of a cloud pays for the tile frames (one launch of tile_frames_k)
+            capi.set_config(kernel_timing=0)
+            first, second = [], []
+            for i in range(4):
+                c_tmp = capi.Cloud(pts, nrm, device=local)
+                barrier()
+                t0 = time.perf_counter(); c_tmp.fit(kind, thr, H_total, prob, seed=seed, copy=False); barrier()
+                t1 = time.perf_counter(); c_tmp.fit(kind, thr, H_total, prob, seed=seed, copy=False); barrier()
+                t2 = time.perf_counter()
+                if i:
+                    first.append((t1 - t0) * 1e3)
+                    second.append((t2 - t1) * 1e3)
+                c_tmp.close()
+            capi.set_config(kernel_timing=1)
+            plane_bound["first_fit_of_a_cloud_ms"] = float(np.mean(first))
+            plane_bound["second_fit_ms"] = float(np.mean(second))
         # set-up: m3d_cloud_create = SetPointCloud's copy (ransac.h:469-475) -- upload, transpose, Hilbert sort, tile boxes
         capi.set_config(kernel_timing=0)
         tot = []
@@ -582,6 +628,15 @@ def main():
                     "timing": "HIP events attached to every launch of this kernel inside the timed steps (hipExtLaunchKernel start / stop events on the "
                               "library's stream, rank 0).  The 128 leading hypotheses of a fit are counted inside cull_lead_k, the launch that also "
                               "runs the box tests: their pairs (pairs_outside_the_timed_launches) and its time are not in this object",
+                    "step_composition": {
+                        "note": "with the histogram bound the scoring launch is no longer the longest kernel of a C2 step: "
+                                "compact_write_k<0,0> (RefineModel's index list, ransac.h:537-543: n_inliers x 8 bytes written straight "
+                                "into the caller's page-locked buffer) takes ~79 us at the host link's rate; the roofline object "
+                                "stays on the scoring kernel -- the EvaluateModel loop (ransac.h:626-654) is the path's arithmetic",
+                        "host_link": {"kernel": "m3d::compact_write_k<0, 0>", "bytes_per_step": int(n_in) * 8,
+                                      "duration_us": 79.0, "duration_source": "profiles/ (rocprofv3 kernel stats of this command)",
+                                      "rate_GBps": int(n_in) * 8 / 79.0e-6 / 1e9, "peak_GBps": 63.0,
+                                      "peak_source": "PCIe 5.0 x16, one direction: 32 GT/s x 16 lanes x 128/130 / 8"}},
                     "algorithmic_reuse": {
                         "bytes_per_launch": alg_bytes, "rate_GBps": alg_rate, "x_hbm_peak": alg_rate / HBM_PEAK_GBS,
                         "inlier_score_GBps_whole_step": H_total * float(N) * ALG_BYTES_PER_PAIR * a.steps / dt / 1e9,
@@ -639,6 +694,8 @@ def main():
                                                         "that `roofline.launch_ms` is measured with"}}
         if fp64_only:
             out["fp64_only"] = fp64_only
+        if plane_bound:
+            out["plane_bound"] = plane_bound
         if setup:
             out["setup_ms"] = setup
         if oneshot:

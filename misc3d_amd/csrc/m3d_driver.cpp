@@ -1514,9 +1514,12 @@ static int finalize_deferred_refine(DeviceCtx* ctx) {
 // pay for it (one launch, ~0.05 ms on 1 M points), kept for the cloud's lifetime.  The working cloud of a segmentation
 // (re-partitioned between rounds) has none.
 static int ensure_plane_frames(m3d_cloud* c, int kind, size_t n_hypotheses) {
-    const int mode = config().plane_bound;   // 1: clouds of >= 64 tiles, fits of >= 2048 hypotheses; 2: always (tests)
+    // 1: clouds of >= 64 tiles, fits of >= 2048 hypotheses -- 65 536 for a cloud that lives for one call (tile_frames_k takes
+    // ~0.09 ms per million points, the bound saves ~0.02 ms per 10 000 hypotheses on them: m3d_fit_plane 0.95 -> 1.04 ms otherwise);
+    // 2: always (tests)
+    const int mode = config().plane_bound;
     if (kind != M3D_PLANE || c->frames_ready || mode == 0 || c->work.active || c->n_tiles == 0 ||
-        (mode == 1 && (c->n_tiles < 64 || n_hypotheses < 2048)))
+        (mode == 1 && (c->n_tiles < 64 || n_hypotheses < (c->one_shot ? 65536u : 2048u))))
         return M3D_OK;
     DeviceCtx* ctx = c->ctx;
     HIPCHK(hipSetDevice(ctx->device));
@@ -2183,6 +2186,7 @@ static int one_shot_fit(int kind, const double* xyz, const double* normals, size
     const bool few = max_iter <= 1024 && (prob < 1.0 || (double)n * (double)max_iter <= 2.0e9);
     m3d_cloud* c = m3d_cloud_create_impl(xyz, normals, n, device, few ? 0 : 1);
     if (!c) return M3D_ERR_DEVICE;
+    c->one_shot = true;
     const int rc = m3d_cloud_fit(c, kind, thr, max_iter, prob, seed, params, inliers, n_inliers, stats);
     m3d_cloud_destroy(c);
     return rc;

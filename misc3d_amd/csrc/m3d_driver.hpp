@@ -151,6 +151,7 @@ struct m3d_cloud {
     m3d::DevBuf tile_f32;   // SortedView::tile_f32 (n_tiles x kTileF32Floats floats)
     m3d::DevBuf frames, frame_cum;   // SortedView::frames / frame_cum (m3d_bound.hip), built by the first long plane fit (ensure_plane_frames)
     bool frames_ready = false;
+    bool one_shot = false;           // created for ONE fit (one_shot_fit): set-up that pays off over several fits is skipped
     uint32_t n_sorted = 0, n_tiles = 0;
     double max_abs = __builtin_inf();   // largest |coordinate| of the finite points (SortedView::max_abs)
     double origin[3] = {0.0, 0.0, 0.0};   // centre of the bounding box of the finite points (SortedView::origin)
