@@ -294,6 +294,8 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
     __shared__ float f_s[kBoundTpb][kFrameStride];         // slots 3 .. 19 of the frame in fp32 (U, V, R, W rounded up)
     __shared__ __attribute__((aligned(8))) uint16_t cm_s[kBoundTpb][kCumStride];
     __shared__ uint32_t wsum[kBoundWaves][64];
+    __shared__ double rec_s[64][9];    // (+ 1: the lanes' rows fall into different banks)
+    __shared__ float q_s[64][9];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t total = surv_count[0];
@@ -319,8 +321,22 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
         const uint32_t nb = min(64u, total - first);
         const bool has = (uint32_t)lane < nb;
         const uint32_t h = surv[first + (has ? (uint32_t)lane : 0u)];
-        const double* __restrict__ rp = score + (size_t)h * kModelStride;
-        const double a = rp[0], b = rp[1], c = rp[2], d = rp[3], T = rp[4];
+        // the 64 hypotheses' records reach the four waves through LDS, fetched ONCE and eight lanes to a record: every wave
+        // reading its own lane's record took 13 load instructions of 64 cache lines each, four times over (3.6 M line
+        // requests per launch)
+        __syncthreads();   // (the previous block's records and sums have been read)
+        {
+            const uint32_t sv = threadIdx.x >> 3, k = threadIdx.x & 7u;   // survivors sv, sv + 32; word k of the record
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t si = sv + 32u * (uint32_t)r;
+                const uint32_t hh = surv[first + min(si, nb - 1u)];
+                rec_s[si][k] = score[(size_t)hh * kModelStride + k];
+                if (cull32) q_s[si][k] = cull32[(size_t)(hh >> 1) * 24u + (hh & 1u) + 2u * k];
+            }
+        }
+        __syncthreads();   // (records -- and, the first time round, the frames -- are in LDS)
+        const double a = rec_s[lane][0], b = rec_s[lane][1], c = rec_s[lane][2], d = rec_s[lane][3], T = rec_s[lane][4];
         const unsigned long long bit = 1ull << (h & 63u);
         const unsigned long long* __restrict__ mrow = masks + (size_t)(h >> 6);
         // touched or not: the box test itself, from the hypothesis' fp32 record and the tile's fp32 box (the arithmetic of
@@ -329,9 +345,8 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
         bool tch[kBoundTpw];
         float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (cull32) {   // (kernel argument: uniform)
-            const float* __restrict__ qp = cull32 + (size_t)(h >> 1) * 24u + (h & 1u);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) q[k] = qp[2 * k];
+            for (int k = 0; k < 8; ++k) q[k] = q_s[lane][k];
         } else {
 #pragma unroll
             for (int i = 0; i < kBoundTpw; ++i) {
@@ -347,7 +362,6 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
         const float e32 = 5e-7f * n1;
         const float Tf = (float)(T * (1.0 + 1e-6));
         const float mgf = (float)(1e-14 * Mg * (1.0 + 1e-6));
-        __syncthreads();   // (the frames are in LDS; the previous block's sums have been read)
         uint32_t ub = 0;
 #pragma unroll
         for (int i = 0; i < kBoundTpw; ++i) {
@@ -362,13 +376,13 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             if (__ballot(tch[i]) == 0ull) continue;   // (wave-uniform)
             const float* f = f_s[tl];   // (wave-uniform address: broadcast reads)
             const double sc0 = ((a * c_s[tl][0] + b * c_s[tl][1]) + c * c_s[tl][2]) + d;
-            const float g0 = af * f[3] + bf * f[4] + cf * f[5];
-            const float nu = af * f[6] + bf * f[7] + cf * f[8];
-            const float nv = af * f[9] + bf * f[10] + cf * f[11];
+            const float g0 = __builtin_fmaf(af, f[3], __builtin_fmaf(bf, f[4], cf * f[5]));   // (fused: fewer roundings than e32 allows for)
+            const float nu = __builtin_fmaf(af, f[6], __builtin_fmaf(bf, f[7], cf * f[8]));
+            const float nv = __builtin_fmaf(af, f[9], __builtin_fmaf(bf, f[10], cf * f[11]));
             const float U = f[12], V = f[13], R = f[14], W = f[17];
             const float scf = (float)sc0;
-            float aa = (__builtin_fabsf(nu) + e32) * U + (__builtin_fabsf(nv) + e32) * V + n1 * R + e32 * W + mgf;
-            aa = aa * 1.00001f + 1e-5f * ((Tf + aa) + __builtin_fabsf(scf));
+            float aa = __builtin_fmaf(__builtin_fabsf(nu) + e32, U, __builtin_fmaf(__builtin_fabsf(nv) + e32, V, __builtin_fmaf(n1, R, __builtin_fmaf(e32, W, mgf))));
+            aa = __builtin_fmaf(aa, 1.00001f, 1e-5f * ((Tf + aa) + __builtin_fabsf(scf)));
             const float g = __builtin_fabsf(g0), sc = g0 < 0.0f ? -scf : scf;
             const float ig = __builtin_amdgcn_rcpf(g);   // (g = 0: inf; with a zero numerator NaN -- caught below)
             float L = ((-Tf - aa) - sc) * ig, H = ((Tf + aa) - sc) * ig;
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             H += 1e-5f * __builtin_fabsf(H);
             const bool framed = f[19] != 0.0f && rec_ok;
             const float wlo = f[15], invd = f[16];
-            const float tL = __builtin_floorf((L - wlo) * invd) - 1.0f, tH = __builtin_floorf((H - wlo) * invd) + 1.0f;
+            const float tL = __builtin_floorf((L - wlo) * invd) - 1.0f, tH = __builtin_floorf((H - wlo) * invd) + 1.0f;   // (one bin further out: see above)
             const bool whole = !(tL == tL) || !(tH == tH);   // (0 x inf, inf - inf: the direction says nothing -- every finite point of the tile)
             const int bl = (int)__builtin_fminf(__builtin_fmaxf(whole ? 0.0f : tL, -1.0f), (float)kBoundBins) + 1;
             const int bh = (int)__builtin_fminf(__builtin_fmaxf(whole ? 0.0f : tH, -1.0f), (float)kBoundBins) + 1;
