@@ -34,6 +34,12 @@ int m3d_bench_fp64_issue_rate(int device, double ms_target, double *tera_lane_op
  * Hilbert counting sort, out[4] = tile boxes + the tiles' fp32 offsets ("report upload separately"). */
 int m3d_bench_cloud_setup_ms(const m3d_cloud *cloud, double out[5]);
 
+/* plane_bound_k (m3d_bound.hip) on its own: ub_out[h] = the histogram upper bound of hypothesis h's inlier count, for EVERY
+ * hypothesis of the sample table (n_hypotheses x 3 indices, at most 16 384; nothing is pruned).  What
+ * tests/test_gpu_plane_bound.py holds against the exact counts of m3d_cloud_score_range: ub >= count, hypothesis by hypothesis.
+ * Builds the cloud's tile frames if it has none yet. */
+int m3d_bench_plane_upper_bounds(m3d_cloud *cloud, double threshold, const uint32_t *samples, size_t n_hypotheses,
+                                 uint32_t *ub_out);
 /* Wall clock of the calling thread's LAST m3d_segment_plane_iterative* call in ms: out[0] the whole call, out[1]
  * m3d_cloud_create (upload, sort, tile boxes), out[2] the round loop, out[3] the final copy of the index lists out of
  * the page-locked staging array (0 when the caller's array is page-locked), out[4] of the round loop: the rounds on more

@@ -111,6 +111,7 @@ def lib():
         L.m3d_cloud_original_size.argtypes = [C.c_void_p]
         L.m3d_bench_time_score.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p]     # include/misc3d_amd_bench.h
+        L.m3d_bench_plane_upper_bounds.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p]
         L.m3d_sampler_create.restype = C.c_void_p
         L.m3d_sampler_create.argtypes = [C.c_size_t, C.c_int, C.c_uint64]
         L.m3d_sampler_destroy.argtypes = [C.c_void_p]
@@ -639,6 +640,13 @@ class Cloud:
         _check(lib().m3d_bench_time_score(self._h, kind, threshold, _p(samples), len(samples), reps, mode,
                                           C.cast(C.byref(ms), C.c_void_p), C.cast(C.byref(listed), C.c_void_p)))
         return float(ms.value), int(listed.value)
+
+    def plane_upper_bounds(self, threshold, samples):
+        """m3d_bench_plane_upper_bounds -> uint32 upper bound of every plane hypothesis' inlier count (plane_bound_k, nothing pruned)"""
+        samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, 3)
+        ub = np.zeros(len(samples), dtype=np.uint32)
+        _check(lib().m3d_bench_plane_upper_bounds(self._h, threshold, _p(samples), len(samples), _p(ub)))
+        return ub
 
     def exact_error(self, kind, threshold, model):
         model = _f64(model)

@@ -446,6 +446,17 @@ static int pre_stream_gate(DeviceCtx* ctx) {
     return M3D_OK;
 }
 
+// plane_bound_k's scratch: the survivor list (h_pad + 64 ids) and behind it the kernel's tickets, which it leaves zero between
+// launches -- cleared here when the block is new
+static int reserve_survivor_scratch(DeviceCtx* ctx, uint32_t h_pad) {
+    const size_t words = (size_t)h_pad + 64 + (size_t)h_pad / 64 + 64;
+    if (ctx->surv_list.cap < sizeof(uint32_t) * words) {
+        RESERVE(ctx->surv_list, sizeof(uint32_t) * words * 2);
+        HIPCHK(hipMemsetAsync(ctx->surv_list.p, 0, ctx->surv_list.cap, ctx->stream));
+    }
+    return M3D_OK;
+}
+
 // Sharded fits (comm != null): the chunk is the SAME window of the one hypothesis stream on every rank
 // -- sample table, MinimalFit and parameter records for all of it (a thread per hypothesis: microseconds) -- but
 // the box tests and the scoring cover only this rank's slice of `sl_pad` hypotheses (+ the window's leading
@@ -610,12 +621,9 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             // minimal_fit_k and unused when the scoring is not phased.
             const bool bound_on = kind == M3D_PLANE && prune && bc && !ubp && sv.frames && config().plane_bound != 0 &&
                                   (use_lead || !new_fit) && !scored_with_own_tests && std::max(g0, ga) < g1;
-            if (bound_on) {   // the list, and behind it the tickets of plane_bound_k (zero between launches: cleared when the block is new)
-                const size_t words = (size_t)h_pad + 64 + (size_t)h_pad / 64 + 64;
-                if (ctx->surv_list.cap < sizeof(uint32_t) * words) {
-                    RESERVE(ctx->surv_list, sizeof(uint32_t) * words * 2);
-                    HIPCHK(hipMemsetAsync(ctx->surv_list.p, 0, ctx->surv_list.cap, ctx->stream));
-                }
+            if (bound_on) {
+                const int src = reserve_survivor_scratch(ctx, h_pad);
+                if (src != M3D_OK) return src;
             }
             uint32_t* const surv_count = bound_on ? bc + 6 : nullptr;
             uint32_t* const surv = bound_on ? ctx->surv_list.as<uint32_t>() : nullptr;
@@ -2504,6 +2512,56 @@ int m3d_bench_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ms_avg = (double)ms / reps;
+    return M3D_OK;
+}
+
+// m3d_bench_plane_upper_bounds: plane_bound_k on its own -- the histogram upper bound of EVERY hypothesis of a sample table
+// (nothing pruned, every hypothesis on the list), for the test that holds it against the exact counts
+int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t* samples, size_t n_hypotheses, uint32_t* ub_out) {
+    if (!c || !samples || !ub_out || n_hypotheses == 0 || n_hypotheses > 16384)
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    DeviceCtx* ctx = c->ctx;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (c->work.active || c->n_tiles == 0) return fail(M3D_ERR_INVALID_ARG, "the cloud has no sorted copy of its own");
+    if (!c->frames_ready) {
+        if (!c->frames.reserve(sizeof(double) * kFrameStride * (size_t)c->n_tiles) ||
+            !c->frame_cum.reserve(sizeof(uint16_t) * kCumStride * (size_t)c->n_tiles))
+            return fail(M3D_ERR_DEVICE, "out of device memory (tile frames)");
+        launch_tile_frames(c->sorted(), c->frames.as<double>(), c->frame_cum.as<uint16_t>(), ctx->stream);
+        c->frames_ready = true;
+    }
+    const CloudView v = c->view();
+    const SortedView sv = c->sorted();
+    SampleSource src;
+    src.table = samples;
+    src.m = 3;
+    ChunkSlot& s = ctx->slot[0];
+    int rc = issue_chunk(ctx, s, v, sv, M3D_PLANE, threshold, 0, n_hypotheses, src, nullptr);   // records (+ fp32 box-test records)
+    if (rc != M3D_OK) return rc;
+    const uint32_t n_groups = s.h_pad / 64;
+    RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * n_groups);
+    RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)n_groups);
+    RESERVE(ctx->small, 256);
+    RESERVE(s.ub, sizeof(uint32_t) * 2 * (size_t)s.h_pad);
+    rc = reserve_survivor_scratch(ctx, s.h_pad);
+    if (rc != M3D_OK) return rc;
+    auto* masks = ctx->masks.as<unsigned long long>();
+    auto* keep = ctx->keep.as<unsigned long long>();
+    uint32_t* ubsum = s.ub.as<uint32_t>() + s.h_pad;
+    uint32_t* ctl = ctx->small.as<uint32_t>();   // [0]: an incumbent of 0 (the keep rule stays inert); [1]: the list's length
+    uint32_t* surv = ctx->surv_list.as<uint32_t>();
+    const float* c32 = (!use_dense_scoring() && config().cull_fp32 != 0 && sv.radius < 1e18) ? s.cull32.as<float>() : nullptr;
+    HIPCHK(hipMemsetAsync(ubsum, 0, sizeof(uint32_t) * (size_t)s.h_pad, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctl, 0, 8, ctx->stream));
+    launch_cull_mask(M3D_PLANE, sv, s.score.as<double>(), s.valid.as<uint8_t>(), (uint32_t)n_hypotheses, n_groups, masks, nullptr,
+                     ctx->stream, false, 0, 0xFFFFFFFFu, c32);
+    launch_keep_mask(nullptr, nullptr, n_groups, keep, ctx->stream, nullptr, 0, 0, ctl + 1, surv);
+    launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, 0, n_groups, ubsum, ctl, ctl + 1, surv,
+                       surv + ((size_t)s.h_pad + 64), c32, ctx->stream);
+    HIPCHK(hipMemcpyAsync(ub_out, ubsum, sizeof(uint32_t) * n_hypotheses, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return M3D_OK;
 }
 

@@ -100,3 +100,49 @@ def test_bound_in_sharded_windows(capi, orc):
                 assert np.all(got[~exact] == 0) and np.all(oc[mine][~exact] <= best_before[mine][~exact]), rank
     finally:
         capi.restore_config(old)
+
+
+def _cloud_for(case, n, rng):
+    if case == "c2":
+        return synth.plane_cloud_c2(n, 2)
+    if case == "c1":
+        return synth.plane_cloud_c1(n, 5)
+    if case == "exact_plane":
+        xy = rng.uniform(-1, 1, size=(n, 2))
+        pts = np.column_stack([xy, 0.25 * xy[:, 0] - 0.5 * xy[:, 1] + 0.125])
+        pts[: n // 4] = rng.uniform(-1, 1, size=(n // 4, 3))
+        return pts
+    if case == "nan_points":
+        pts = synth.plane_cloud_c1(n, 5)
+        pts[rng.integers(0, n, 3000), rng.integers(0, 3, 3000)] = np.nan
+        return pts
+    if case == "huge_offset":
+        return synth.plane_cloud_c1(n, 8) + np.array([4.0e5, -3.0e5, 2.0e5])
+    if case == "clutter":            # no structure at all: every frame is arbitrary
+        return rng.uniform(-1, 1, size=(n, 3))
+    if case == "curved":             # a sphere's shell: tiles are thin but not flat
+        return synth.sphere_cloud_c3(n, 4)
+    raise ValueError(case)
+
+
+@pytest.mark.parametrize("case,thr", [("c2", 0.01), ("c2", 0.002), ("c2", 0.05), ("c1", 0.01), ("exact_plane", 0.01),
+                                      ("nan_points", 0.01), ("huge_offset", 0.01), ("clutter", 0.02), ("curved", 0.01)])
+def test_upper_bound_is_an_upper_bound(capi, case, thr):
+    """plane_bound_k on its own (m3d_bench_plane_upper_bounds: every hypothesis on the list, nothing pruned) against the exact
+    counts of the dense path: ub >= count for EVERY hypothesis -- and tight where it should be (the best hypothesis of a
+    cloud with a dominant plane: within a fifth of its count)."""
+    rng = np.random.default_rng(17)
+    n, H = 120_000, 4096
+    pts = np.ascontiguousarray(_cloud_for(case, n, rng))
+    samples = capi.draw_samples(n, 0, H, 23)
+    with capi.Cloud(pts) as c:
+        ub = c.plane_upper_bounds(thr, samples).astype(np.int64)
+        val, _, cnt = c.score_range(0, thr, samples, 0, H, want_models=False)
+    cnt = cnt.astype(np.int64)
+    ok = val.astype(bool)
+    assert ok.sum() > 0.9 * H or case in ("nan_points",)
+    bad = np.nonzero(ok & (ub < cnt))[0]
+    assert len(bad) == 0, (case, thr, bad[:5], ub[bad[:5]], cnt[bad[:5]])
+    if case in ("c2", "c1", "exact_plane") and thr == 0.01:
+        b = int(np.argmax(np.where(ok, cnt, -1)))
+        assert cnt[b] > 0.3 * n and ub[b] - cnt[b] < 0.2 * cnt[b], (case, int(cnt[b]), int(ub[b]))
