@@ -27,7 +27,8 @@ PATHS = {"culled": {}, "dense": {"dense_scoring": 1}, "no_early_pick": {"specula
          "two_phases": {"score_phases": 2}, "three_phases": {"score_phases": 3},
          "one_pass_compaction": {"compact_one_pass": 1},   # compact_write_k, ONE: counts published and awaited inside the launch
          "plane_bound_always": {"plane_bound": 2},   # planes: the histogram bound (m3d_bound.hip) at every size (default: long fits of large clouds)
-         "plane_bound_off": {"plane_bound": 0}}
+         "plane_bound_off": {"plane_bound": 0},
+         "plane_bound_fp64_paths": {"plane_bound": 2, "score_fp32_screen": 0, "cull_fp32": 0}}   # (no fp32 box-test records: plane_bound_k reads the mask words)
 
 
 @pytest.fixture(params=sorted(PATHS))

@@ -146,3 +146,37 @@ def test_upper_bound_is_an_upper_bound(capi, case, thr):
     if case in ("c2", "c1", "exact_plane") and thr == 0.01:
         b = int(np.argmax(np.where(ok, cnt, -1)))
         assert cnt[b] > 0.3 * n and ub[b] - cnt[b] < 0.2 * cnt[b], (case, int(cnt[b]), int(ub[b]))
+
+
+def test_bound_soak_scaled_and_shifted_scenes(capi, orc):
+    """Fixed seed, fixed budget (20 s): plane clouds of random size, scaled by 10^-2 .. 10^2 and moved up to 10^3 scene sizes
+    from the origin (the bound evaluates in fp32 beside an fp64 centre value: its margins), thresholds from a third of the
+    noise to ten times it, the bound forced on -- the fit must be the oracle's and every upper bound an upper bound."""
+    import time
+    rng = np.random.default_rng(20260930)
+    old = capi.set_config(plane_bound=2)
+    t_end, n_cases = time.time() + 20.0, 0
+    try:
+        while time.time() < t_end:
+            n = int(rng.integers(15_000, 150_000))
+            sd = int(rng.integers(0, 10_000))
+            pts = synth.plane_cloud_c2(n, sd) if rng.random() < 0.6 else synth.plane_cloud_c1(n, sd)
+            sc = float(10.0 ** rng.uniform(-2, 2))
+            pts = np.ascontiguousarray(pts * sc + rng.uniform(-1, 1, 3) * sc * float(10.0 ** rng.uniform(0, 3)))
+            thr = float(rng.choice([0.001, 0.003, 0.01, 0.03])) * sc
+            H = int(rng.integers(300, 3000))
+            o = orc.fit(0, pts, None, thr=thr, max_iter=H, prob=1.0, seed=sd, lookahead=128)
+            samples = capi.draw_samples(n, 0, min(H, 2048), sd)
+            with capi.Cloud(pts) as c:
+                g = c.fit(0, thr, H, 1.0, seed=sd)
+                ub = c.plane_upper_bounds(thr, samples).astype(np.int64)
+                val, _, cnt = c.score_range(0, thr, samples, 0, len(samples), want_models=False)
+            case = (n, sd, sc, thr, H)
+            assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.ret, o.best_index, o.count, o.iterations), case
+            assert np.array_equal(g.inliers, o.inliers), case
+            ok = val.astype(bool)
+            assert np.all(ub[ok] >= cnt.astype(np.int64)[ok]), case
+            n_cases += 1
+    finally:
+        capi.restore_config(old)
+    assert n_cases >= 5, n_cases
