@@ -664,9 +664,11 @@ constexpr uint32_t kScreenMaxGroups = M3D_SCREEN_MAX_GROUPS;   // 64-hypothesis 
 // worth sharing among more of them where the pruning leaves few per (tile, 8 groups): C3's chunks of 250 groups (~16
 // survivors per workgroup) score_screen_k<2> 0.846 -> 0.801 ms, <1> 0.396 -> 0.377, the fits 1.09 -> 1.05 / 0.72 -> 0.71 ms; C2's
 // window of 155 groups loses 2 % of its launch with 16 (fewer, longer workgroups: the tail) and keeps 8.
-static uint32_t screen_gpb_max(uint32_t window) {
+// `thinned`: the planes' histogram bound has pruned the window (m3d_bound.hip: about half of the survivors are gone) -- half as
+// many groups again per workgroup (C2: 8 / 12 / 16 groups -> launch 0.0603 / 0.0591 / 0.0604 ms, step 0.2622 / 0.2587 / 0.2605).
+static uint32_t screen_gpb_max(uint32_t window, bool thinned = false) {
     const uint32_t g = (uint32_t)config().score_groups_per_block;
-    return std::min<uint32_t>(window >= 192u ? 2u * g : g, kScreenMaxGroups);
+    return std::min<uint32_t>(window >= 192u ? 2u * g : (thinned ? g + g / 2u : g), kScreenMaxGroups);
 }
 constexpr int kCntStride = 64;              // bytes per row of the count table
 
@@ -1393,7 +1395,7 @@ void launch_pick_best(const uint32_t* records, uint32_t count, unsigned long lon
 void launch_score_mask(int kind, const SortedView& s, const double* score, const unsigned long long* masks,
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
                        uint32_t* pair_rep, hipStream_t st, uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start,
-                       hipEvent_t ev_stop) {
+                       hipEvent_t ev_stop, bool thinned) {
     if (launch_score_mfma(kind, s, score, masks, keep, n_groups, counts_rep, rep_stride, pair_rep, st, group_begin, group_end, ev_start, ev_stop))
         return;
     group_end = std::min(group_end, n_groups);
@@ -1401,7 +1403,7 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     const uint32_t window = group_end - group_begin;
     // at least ~16k workgroups when the chunk is small, at most kGroupsPerBlock groups each
     const bool screened = config().score_fp32_screen != 0;
-    const uint32_t gpb_max = screened ? screen_gpb_max(window) : std::min<uint32_t>((uint32_t)config().score_groups_per_block, 64u);
+    const uint32_t gpb_max = screened ? screen_gpb_max(window, thinned) : std::min<uint32_t>((uint32_t)config().score_groups_per_block, 64u);
     const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * window) / min_wgs)));
     const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);

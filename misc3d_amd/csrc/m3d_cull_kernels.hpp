@@ -89,7 +89,8 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                        uint32_t* pair_rep /* kPairReplicas u32, zero on entry: evaluated (tile, hypothesis) pairs */,
                        hipStream_t st, uint32_t group_begin = 0, uint32_t group_end = 0xFFFFFFFFu /* window of the chunk's groups */,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr /* both set: receive the launch's own start / stop
-                       times (m3d_stats.ms_score_kernel) */);
+                       times (m3d_stats.ms_score_kernel) */,
+                       bool thinned = false /* plane_bound_k has pruned the window: more groups per workgroup */);
 // score_mfma_k (m3d_score_mfma.hip): the same counting with the screen on the matrix pipe -- planes, m3d_config.score_mfma.
 // false: not applicable (another kind, tombstones in the copy, no fp32 tile offsets, switched off), nothing launched;
 // launch_score_mask calls it first.

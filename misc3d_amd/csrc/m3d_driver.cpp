@@ -665,7 +665,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                                              pair_rep, ub, ubp, bc, ctx->stream, g_lo, g1, timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
             if (!scored_with_own_tests && !phased)
                 launch_score_mask(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
-                                  pair_rep, ctx->stream, g_lo, g1, timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
+                                  pair_rep, ctx->stream, g_lo, g1, timing ? s.k0 : nullptr, timing ? s.k1 : nullptr, bound_on);
             // one launch: fold the counter replicas, tag MinimalFit's return into bit 31, update the incumbent
             // ... and (one GPU) write the records straight into the slot's pinned host array (device-visible): no copy
             // command behind the kernel (a 39 KB D2H copy started ~20 us after the kernel that fed it)
