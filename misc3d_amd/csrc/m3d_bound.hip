@@ -16,8 +16,8 @@
 //                       S(p) = S(c) + (n . e) w_p + (n . u) u_p + (n . v) v_p + n . res_p            (an identity),
 //                   so |S(p)| < T forces (n . e) w_p into an interval of half width T + a around -S(c),
 //                   a = |n . u| U + |n . v| V + |n|_1 R + rounding terms: the histogram's mass over the bins that interval
-//                   meets is an UPPER BOUND of the pair's inlier count (every rounding of the evaluation is inside a; the bin
-//                   function is the same monotone fp64 expression in both kernels).  Summed per hypothesis: ubsum[h].
+//                   meets is an UPPER BOUND of the pair's inlier count (every rounding of the evaluation is inside a; the bins
+//                   are monotone in w and taken one further out on both sides).  Summed per hypothesis: ubsum[h].
 //                   The workgroup that finishes a block of 64 hypotheses last (a ticket per block) applies the keep rule:
 //                   keep bit off where ubsum[h] < best count of EARLIER hypotheses -- keep_mask_k's rule with a bound that is
 //                   within ~10 % of the true count for hypotheses near a surface instead of 512 per tile.
@@ -39,8 +39,9 @@
 namespace m3d {
 
 // bin of a coordinate w along the tile's thin direction: 0 = below the histogram's range, 1 .. kBoundBins inside,
-// kBoundBins + 1 = above.  MONOTONE in w (a subtraction, a multiplication by a positive number, floor, clamp) and the SAME
-// expression in tile_frames_k and plane_bound_k: w1 <= w2 => bound_bin(w1) <= bound_bin(w2), which is all the bound needs.
+// kBoundBins + 1 = above.  MONOTONE in w (a subtraction, a multiplication by a positive number, floor, clamp):
+// w1 <= w2 => bound_bin(w1) <= bound_bin(w2), which is all the bound needs -- plane_bound_k evaluates the same expression in fp32
+// for the ends of its interval and steps one bin outwards (its coordinate is within 1e-4 bins of this one).
 __device__ __forceinline__ int bound_bin(double w, double wlo, double invd) {
     const double t = floor((w - wlo) * invd);
     return (int)fmin(fmax(t, -1.0), (double)kBoundBins) + 1;
@@ -264,8 +265,8 @@ void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipS
 
 // One workgroup (four waves) = 64 hypotheses of the survivor list (written by the keep kernels: emit_survivors; the blocks of 64
 // are dealt out along block x, grid-stride) x a range of tiles (block y), the waves taking the tiles in turn.  The frames and
-// histograms of the range go to LDS in one cooperative sweep while the list and the hypotheses' records arrive, a lane's mask
-// words are fetched together, and the loop reads LDS only; a tile none of the 64 hypotheses touches is skipped.
+// histograms and fp32 boxes of the range go to LDS in one cooperative sweep, the 64 hypotheses' records in another (eight lanes
+// to a record), and the loop reads LDS only; a tile none of the 64 hypotheses touches is skipped.
 //
 // Arithmetic.  The value at the tile's centre, S(c) = n . c + d, cancels (|n . c| and |d| are of the cloud's size, S(c) of the
 // tile's) and is formed in fp64; everything after it runs in fp32 -- the first form of the kernel was fp64 throughout, ~150
