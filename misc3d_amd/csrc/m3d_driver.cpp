@@ -446,16 +446,21 @@ static int pre_stream_gate(DeviceCtx* ctx) {
     return M3D_OK;
 }
 
-// plane_bound_k's scratch: the survivor list (h_pad + 64 ids) and behind it the kernel's tickets, which it leaves zero between
-// launches -- cleared here when the block is new
+// plane_bound_k's scratch: its tickets -- kBoundTicketWords words at the FRONT of the block, which the kernel leaves zero between
+// launches (cleared here when the block is new; at a fixed place: behind a list whose length changes from fit to fit they would
+// land on old ids) -- and behind them the survivor list (h_pad + 64 ids)
+constexpr size_t kBoundTicketWords = 8192;   // 1 + hypotheses of a window / 64 (M3D_CHUNK_CAP <= 262 144: 4097)
 static int reserve_survivor_scratch(DeviceCtx* ctx, uint32_t h_pad) {
-    const size_t words = (size_t)h_pad + 64 + (size_t)h_pad / 64 + 64;
+    const size_t words = kBoundTicketWords + (size_t)h_pad + 64;
+    if ((size_t)h_pad / 64 + 2 > kBoundTicketWords) return fail(M3D_ERR_INTERNAL, "window too large for the bound's tickets");
     if (ctx->surv_list.cap < sizeof(uint32_t) * words) {
-        RESERVE(ctx->surv_list, sizeof(uint32_t) * words * 2);
+        RESERVE(ctx->surv_list, sizeof(uint32_t) * (kBoundTicketWords + 2 * ((size_t)h_pad + 64)));
         HIPCHK(hipMemsetAsync(ctx->surv_list.p, 0, ctx->surv_list.cap, ctx->stream));
     }
     return M3D_OK;
 }
+static uint32_t* bound_tickets(DeviceCtx* ctx) { return ctx->surv_list.as<uint32_t>(); }
+static uint32_t* bound_list(DeviceCtx* ctx) { return ctx->surv_list.as<uint32_t>() + kBoundTicketWords; }
 
 // Sharded fits (comm != null): the chunk is the SAME window of the one hypothesis stream on every rank
 // -- sample table, MinimalFit and parameter records for all of it (a thread per hypothesis: microseconds) -- but
@@ -626,7 +631,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 if (src != M3D_OK) return src;
             }
             uint32_t* const surv_count = bound_on ? bc + 6 : nullptr;
-            uint32_t* const surv = bound_on ? ctx->surv_list.as<uint32_t>() : nullptr;
+            uint32_t* const surv = bound_on ? bound_list(ctx) : nullptr;
             if (!s.lead_fused && !scored_with_own_tests) {
                 if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
                     launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
@@ -658,7 +663,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             }
             if (bound_on)
                 launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, g_lo, g1, ub + h_pad, bc, surv_count, surv,
-                                   surv + ((size_t)h_pad + 64), c32.out, ctx->stream);
+                                   bound_tickets(ctx), c32.out, ctx->stream);
             bool phased = false;
             if (!scored_with_own_tests && ubp)
                 phased = launch_score_phased(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
@@ -2550,7 +2555,7 @@ int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t*
     auto* keep = ctx->keep.as<unsigned long long>();
     uint32_t* ubsum = s.ub.as<uint32_t>() + s.h_pad;
     uint32_t* ctl = ctx->small.as<uint32_t>();   // [0]: an incumbent of 0 (the keep rule stays inert); [1]: the list's length
-    uint32_t* surv = ctx->surv_list.as<uint32_t>();
+    uint32_t* surv = bound_list(ctx);
     const float* c32 = (!use_dense_scoring() && config().cull_fp32 != 0 && sv.radius < 1e18) ? s.cull32.as<float>() : nullptr;
     HIPCHK(hipMemsetAsync(ubsum, 0, sizeof(uint32_t) * (size_t)s.h_pad, ctx->stream));
     HIPCHK(hipMemsetAsync(ctl, 0, 8, ctx->stream));
@@ -2558,7 +2563,7 @@ int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t*
                      ctx->stream, false, 0, 0xFFFFFFFFu, c32);
     launch_keep_mask(nullptr, nullptr, n_groups, keep, ctx->stream, nullptr, 0, 0, ctl + 1, surv);
     launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, 0, n_groups, ubsum, ctl, ctl + 1, surv,
-                       surv + ((size_t)s.h_pad + 64), c32, ctx->stream);
+                       bound_tickets(ctx), c32, ctx->stream);
     HIPCHK(hipMemcpyAsync(ub_out, ubsum, sizeof(uint32_t) * n_hypotheses, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -180,3 +180,29 @@ def test_bound_soak_scaled_and_shifted_scenes(capi, orc):
     finally:
         capi.restore_config(old)
     assert n_cases >= 5, n_cases
+
+
+def test_bound_over_several_chunks(capi, orc):
+    """40 000 hypotheses = a short first chunk + two long ones (M3D_CHUNK_CAP 24 576): the later chunks prune against the
+    incumbent of the earlier ones (keep_mask_k writes the survivor list, MinimalFit and the box tests run on the pre-stream)."""
+    pts = synth.plane_cloud_c2(200_000, 6)
+    o, pairs = _fit_all_modes(capi, orc, pts, 0.01, 40_000, 17, lookahead=512)
+    assert len(o.inliers) > 95_000
+    assert pairs[1][0] < 0.8 * pairs[0][0], pairs
+
+
+def test_bound_after_a_longer_fit(capi, orc):
+    """The bound's scratch (survivor list, tickets) is shared by the fits of a device: a window of 3000 hypotheses, then one of
+    1500, then 700, then 3000 again -- each must be the oracle's (round 4 kept the tickets BEHIND the list: a shorter window found
+    an older list's ids where it expected zeros, and a block's first workgroup applied the keep rule to a partial sum)."""
+    pts = synth.plane_cloud_c2(150_000, 3)
+    old = capi.set_config(plane_bound=2)
+    try:
+        with capi.Cloud(pts) as c:
+            for H, seed in ((3000, 5), (1500, 6), (700, 7), (3000, 8), (1100, 9)):
+                o = orc.fit(0, pts, None, thr=0.01, max_iter=H, prob=1.0, seed=seed, lookahead=128)
+                g = c.fit(0, 0.01, H, 1.0, seed=seed)
+                assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.ret, o.best_index, o.count, o.iterations), (H, seed)
+                assert np.array_equal(g.inliers, o.inliers), (H, seed)
+    finally:
+        capi.restore_config(old)
