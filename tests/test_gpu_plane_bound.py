@@ -206,3 +206,28 @@ def test_bound_after_a_longer_fit(capi, orc):
                 assert np.array_equal(g.inliers, o.inliers), (H, seed)
     finally:
         capi.restore_config(old)
+
+
+def test_bound_on_a_cloud_that_shrinks(capi, orc):
+    """A held cloud: fit (the frames are built), remove the winning minimal model's inliers (SelectByIndex(inliers, invert): the
+    sorted copy is re-partitioned, its tiles change, the frames must go), fit again, remove, fit -- every fit the oracle's fit of
+    the points that are left, index lists in terms of the cloud as created."""
+    pts = synth.plane_cloud_c2(150_000, 12)
+    old = capi.set_config(plane_bound=2)
+    try:
+        with capi.Cloud(pts) as c:
+            keep = np.ones(len(pts), dtype=bool)
+            for rnd, seed in enumerate((5, 6, 7)):
+                rest = np.nonzero(keep)[0]
+                o = orc.fit(0, pts[rest], None, thr=0.01, max_iter=2500, prob=1.0, seed=seed, lookahead=128)
+                g = c.fit(0, 0.01, 2500, 1.0, seed=seed)
+                assert (g.ret, g.stats["best_index"], g.stats["iterations"]) == (o.ret, o.best_index, o.iterations), rnd
+                mine = g.inliers.astype(np.int64)
+                assert np.array_equal(mine, rest[o.inliers.astype(np.int64)]), rnd
+                # RefineModel's list IS the winning minimal model's inlier set (ransac.h:537-543): removing that model's inliers
+                # removes exactly the list
+                model = c.minimal_model(0, 0.01, capi.draw_samples(len(rest), 0, 2500, seed)[o.best_index])
+                assert c.remove_inliers(0, 0.01, model) == len(mine), rnd
+                keep[mine] = False
+    finally:
+        capi.restore_config(old)
