@@ -751,6 +751,50 @@ static int wait_pick_seq(DeviceCtx* ctx, uint32_t seq) {
     return M3D_OK;
 }
 
+// The end of a fit's device work, waited for by spinning on a word the stream's last (one-thread) kernel stores into page-locked
+// memory instead of hipStreamSynchronize: the runtime's wait wakes the caller 10-20 us after the stream has drained
+// (M3D_SPIN_SYNC=0: the runtime's wait).  Bounded like wait_pick_seq: yields after ~30 us of spinning, asks the runtime now and
+// then whether the device is still alive.
+static bool spin_sync_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("M3D_SPIN_SYNC");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+static int stream_wait_spin(DeviceCtx* ctx) {
+    if (!spin_sync_enabled()) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return M3D_OK;
+    }
+    if (!ctx->h_sync.p) {
+        RESERVE(ctx->h_sync, 64);
+        std::memset(ctx->h_sync.p, 0, 64);
+    }
+    if (++ctx->sync_seq == 0) ++ctx->sync_seq;   // (never 0: the word's initial value)
+    const uint32_t seq = ctx->sync_seq;
+    launch_signal_host(ctx->h_sync.as<uint32_t>(), seq, ctx->stream);
+    HIPCHK(hipGetLastError());
+    const volatile uint32_t* p = ctx->h_sync.as<uint32_t>();
+    for (uint32_t spins = 1;; ++spins) {
+        if (*p == seq) break;
+        if (spins > 4096u) std::this_thread::yield();
+        if ((spins & 0xFFFFu) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (*p == seq) break;
+                return fail(M3D_ERR_INTERNAL, "the stream drained without its completion word");
+            }
+            if (q != hipErrorNotReady) return fail(M3D_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        }
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return M3D_OK;
+}
+
 // After the slot's `done` event: the culled path ships (valid << 31 | count) in one array (written by
 // sum_replicas_k straight into the pinned h_counts); split it into the h_valid / h_counts views the replay and
 // the callers read.
@@ -1032,10 +1076,12 @@ static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& g
         // everything RefineModel reads is complete at ev_compact when the moments rode on the compaction (or no fit is
         // due): what the hook queued behind it (segmentation: the removal of these inliers, tens of microseconds of
         // kernels) is not waited for -- the caller goes on preparing the next round under it
-        if (hooked && (have_moments || !need_fit_e))
+        if (hooked && (have_moments || !need_fit_e)) {
             HIPCHK(hipEventSynchronize(ctx->ev_compact));
-        else
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+        } else {
+            const int wrc = stream_wait_spin(ctx);
+            if (wrc != M3D_OK) return wrc;
+        }
         // (the copy stream is waited for when THIS call put the list on it -- and not even then when the caller collects
         // its lists at the end: DeviceCtx::defer_copy_sync)
         const bool list_on_copy_stream = inliers && ni_e && !idx_on_host;

@@ -225,6 +225,14 @@ __global__ void fill_nan_k(double* __restrict__ p, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) p[i] = u2f(0x7FF8000000000000ull);
 }
+// one thread stores `value` into a page-locked host word: queued behind a stream's work, it is the completion signal a host
+// thread spins on (stream_wait_spin, m3d_driver.cpp) -- everything the kernels before it wrote to host memory is visible first
+__global__ void signal_host_k(volatile uint32_t* __restrict__ word, uint32_t value) {
+    __threadfence_system();
+    *word = value;
+}
+void launch_signal_host(uint32_t* word, uint32_t value, hipStream_t st) { signal_host_k<<<1, 1, 0, st>>>(word, value); }
+
 void launch_fill_nan(double* p, uint32_t n, hipStream_t s) {
     if (n) fill_nan_k<<<(n + 255) / 256, 256, 0, s>>>(p, n);
 }

@@ -64,6 +64,7 @@ void launch_grid_count_scan(const CloudView& dst, const GridDesc& g, uint32_t* c
                             uint32_t pad_group = 1);
 void launch_grid_scatter(const CloudView& dst, const uint32_t* cell_of_point, const uint32_t* cell_start,
                          const uint32_t* rank, double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr);
+void launch_signal_host(uint32_t* word /* page-locked, device-visible */, uint32_t value, hipStream_t st);
 void launch_fill_nan(double* p, uint32_t n, hipStream_t s);
 void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl_start, uint32_t* tile_sums,
                      uint32_t* total, hipStream_t s);
