@@ -288,7 +288,8 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
                                                                    const uint32_t* __restrict__ surv,
                                                                    uint32_t* __restrict__ ubsum, const uint32_t* __restrict__ best_count,
                                                                    unsigned long long* __restrict__ keep,
-                                                                   uint32_t* __restrict__ tickets /* [0]: finished blocks; [1 + block] */) {
+                                                                   uint32_t* __restrict__ tickets /* [0]: finished blocks; [1 + block] */,
+                                                                   uint32_t max_list) {
     constexpr int kBoundTpb = kBoundWaves * kBoundTpw;     // tiles per workgroup
     __shared__ float bx_s[kBoundTpb][6];                   // the tile's fp32 box (cull_tiles32_k's)
     __shared__ double c_s[kBoundTpb][3];
@@ -300,6 +301,12 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t total = surv_count[0];
+    if (total > max_list) {   // (uniform) the old rule kept most of the window: no incumbent worth the name, or a cloud without
+        // structure -- the bound would be computed for thousands of hypotheses to drop none (a launch of ~7 us per 1000
+        // of them); the list is discarded, every keep bit stays
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) surv_count[0] = 0u;
+        return;
+    }
     if (blockIdx.x * 64u >= total) return;   // (workgroup-uniform)
     const uint32_t t0 = blockIdx.y * (uint32_t)kBoundTpb, nt = min((uint32_t)kBoundTpb, n_tiles - t0);
     {
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
 void launch_plane_bound(const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
                         uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
                         const uint32_t* best_count, uint32_t* surv_count, const uint32_t* surv, uint32_t* tickets,
-                        const float* cull32, hipStream_t st) {
+                        const float* cull32, hipStream_t st, bool always) {
     group_end = std::min(group_end, n_groups);
     if (!s.frames || !s.frame_cum || !s.n_tiles || !surv || !surv_count || !tickets || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
@@ -453,11 +460,12 @@ void launch_plane_bound(const SortedView& s, const double* score, const unsigned
         return v <= 8 ? 8 : (v <= 12 ? 12 : (v <= 16 ? 16 : (v <= 24 ? 24 : 32)));
     }();
     const uint32_t tpb = (uint32_t)(kBoundWaves * tpw);
+    const uint32_t max_list = always ? 0xFFFFFFFFu : window * 32u;   // half of the window's hypotheses
     const dim3 g(gx, (s.n_tiles + tpb - 1) / tpb), b(64 * kBoundWaves);
     if (s.radius >= 1e18) cull32 = nullptr;   // (no fp32 boxes: launch_cull_mask's condition)
     auto go = [&](auto kernel) {
         kernel<<<g, b, 0, st>>>(s.frames, s.frame_cum, s.n_tiles, s.max_abs, score, masks, n_groups, s.boxes, cull32, surv_count, surv,
-                                ubsum, best_count, keep, tickets);
+                                ubsum, best_count, keep, tickets, max_list);
     };
     if (tpw == 8) go(plane_bound_k<8>);
     else if (tpw == 12) go(plane_bound_k<12>);

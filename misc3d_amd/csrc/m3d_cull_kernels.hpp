@@ -49,7 +49,8 @@ void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipS
 void launch_plane_bound(const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
                         uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
                         const uint32_t* best_count, uint32_t* surv_count, const uint32_t* surv, uint32_t* tickets,
-                        const float* cull32, hipStream_t st);
+                        const float* cull32, hipStream_t st,
+                        bool always = false /* false: a list longer than half of the window is discarded unbounded (nothing worth pruning against) */);
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 // Tombstones (m3d_poison.hpp): the job that kills the inliers of the plane `model` (device) in place in the sorted copy
 // `s`; *total (device, cleared by the owner) accumulates the number of points killed over all launches.

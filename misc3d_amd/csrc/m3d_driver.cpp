@@ -663,7 +663,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             }
             if (bound_on)
                 launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, g_lo, g1, ub + h_pad, bc, surv_count, surv,
-                                   bound_tickets(ctx), c32.out, ctx->stream);
+                                   bound_tickets(ctx), c32.out, ctx->stream, config().plane_bound == 2);
             bool phased = false;
             if (!scored_with_own_tests && ubp)
                 phased = launch_score_phased(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
@@ -2609,7 +2609,7 @@ int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t*
                      ctx->stream, false, 0, 0xFFFFFFFFu, c32);
     launch_keep_mask(nullptr, nullptr, n_groups, keep, ctx->stream, nullptr, 0, 0, ctl + 1, surv);
     launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, 0, n_groups, ubsum, ctl, ctl + 1, surv,
-                       bound_tickets(ctx), c32, ctx->stream);
+                       bound_tickets(ctx), c32, ctx->stream, /*always=*/true);
     HIPCHK(hipMemcpyAsync(ub_out, ubsum, sizeof(uint32_t) * n_hypotheses, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -231,3 +231,22 @@ def test_bound_on_a_cloud_that_shrinks(capi, orc):
                 keep[mine] = False
     finally:
         capi.restore_config(old)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_bound_on_a_cloud_without_structure(capi, orc, mode):
+    """Uniform clutter: the lead's best count is a few hundred, the old rule keeps every hypothesis -- in the default mode
+    plane_bound_k discards a list that long (nothing worth pruning against), forced it bounds all of them and drops none that
+    matters; the fit is the oracle's either way."""
+    rng = np.random.default_rng(4)
+    pts = np.ascontiguousarray(rng.uniform(-1, 1, size=(120_000, 3)))
+    o = orc.fit(0, pts, None, thr=0.01, max_iter=2500, prob=1.0, seed=3, lookahead=128)
+    old = capi.set_config(plane_bound=mode)
+    try:
+        with capi.Cloud(pts) as c:
+            for _ in range(2):
+                g = c.fit(0, 0.01, 2500, 1.0, seed=3)
+                assert (g.ret, g.stats["best_index"], g.stats["count"], g.stats["iterations"]) == (o.ret, o.best_index, o.count, o.iterations)
+                assert np.array_equal(g.inliers, o.inliers)
+    finally:
+        capi.restore_config(old)
