@@ -423,8 +423,8 @@ typedef struct m3d_config {
                                        launch boundary it replaces: profiles/r04_compact_one_pass.txt) */
     int32_t plane_bound;            /* [M3D_PLANE_BOUND=0]  default 1: plane fits with an incumbent prune with a per-tile HISTOGRAM upper bound of
                                        every (tile, hypothesis) pair's inlier count (tile_frames_k / plane_bound_k, m3d_bound.hip) instead of
-                                       512 per touched tile (clouds of >= 64 tiles, fits of >= 2048 hypotheses; 2: whatever the size); same results, fewer
-                                       hypotheses counted point by point.  (The last of the
+                                       512 per touched tile, where that pays (windows of >= 8192 hypotheses on tiles x hypotheses >= 1.5e7, measured: m3d_driver.cpp
+                                       bound_pays; 2: whatever the size); same results, fewer hypotheses counted point by point.  (The last of the
                                        reserved slots: fields are only ever appended, the offsets of existing fields do not move -- ADVICE r3) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);

@@ -430,6 +430,16 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
     return std::max<size_t>(cap, 64);
 }
 
+// Where the planes' histogram bound is worth its launch: plane_bound_k costs 12-25 us per window whatever it prunes, and it halves
+// a scoring launch -- worth it when that launch is long.  Measured on C2-shaped clouds, resident, ms per fit without / with:
+//   points x hypotheses   50 k x 3000 0.103 / 0.135   150 k x 10 000 0.166 / 0.178   150 k x 40 000 0.325 / 0.377   400 k x 10 000 0.176 / 0.175
+//   400 k x 40 000 0.413 / 0.386   1 M x 3000 0.207 / 0.213   1 M x 10 000 0.300 / 0.274   1 M x 40 000 0.654 / 0.606
+//   4 M x 3000 0.530 / 0.569   4 M x 10 000 0.864 / 0.809   4 M x 40 000 1.876 / 1.671
+// i.e. windows of 8192 hypotheses and more on tiles x hypotheses >= 1.5e7.
+static bool bound_pays(uint32_t n_tiles, size_t window_hypotheses) {
+    return window_hypotheses >= 8192 && (double)n_tiles * (double)window_hypotheses >= 1.5e7;
+}
+
 // pre_stream runs the head of a fit's later chunks (issue_chunk, `pre`) beside the main stream: whatever the main stream holds
 // when the fit starts -- a removal's compaction of this very cloud, another fit's tail -- must be behind those kernels too.
 static bool prestream_enabled() {   // (M3D_PRESTREAM=0: everything on the main stream)
@@ -625,6 +635,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             // hypotheses as a list (its length: word 6 of best_count); ubsum is the slot's phase-counter array, zeroed by
             // minimal_fit_k and unused when the scoring is not phased.
             const bool bound_on = kind == M3D_PLANE && prune && bc && !ubp && sv.frames && config().plane_bound != 0 &&
+                                  (config().plane_bound == 2 || bound_pays(sv.n_tiles, comm ? sl_pad : count)) &&
                                   (use_lead || !new_fit) && !scored_with_own_tests && std::max(g0, ga) < g1;
             if (bound_on) {
                 const int src = reserve_survivor_scratch(ctx, h_pad);
@@ -1573,12 +1584,13 @@ static int finalize_deferred_refine(DeviceCtx* ctx) {
 // pay for it (one launch, ~0.05 ms on 1 M points), kept for the cloud's lifetime.  The working cloud of a segmentation
 // (re-partitioned between rounds) has none.
 static int ensure_plane_frames(m3d_cloud* c, int kind, size_t n_hypotheses) {
-    // 1: clouds of >= 64 tiles, fits of >= 2048 hypotheses -- 65 536 for a cloud that lives for one call (tile_frames_k takes
-    // ~0.09 ms per million points, the bound saves ~0.02 ms per 10 000 hypotheses on them: m3d_fit_plane 0.95 -> 1.04 ms otherwise);
-    // 2: always (tests)
+    // 1: where it pays (bound_pays, below) -- and from 65 536 hypotheses on for a cloud that lives for one call (tile_frames_k
+    // takes ~0.09 ms per million points, the bound saves ~0.02 ms per 10 000 hypotheses on them: m3d_fit_plane 0.95 -> 1.04 ms
+    // otherwise); 2: always (tests)
     const int mode = config().plane_bound;
     if (kind != M3D_PLANE || c->frames_ready || mode == 0 || c->work.active || c->n_tiles == 0 ||
-        (mode == 1 && (c->n_tiles < 64 || n_hypotheses < (c->one_shot ? 65536u : 2048u))))
+        (mode == 1 && (!bound_pays(c->n_tiles, std::min<size_t>(n_hypotheses, chunk_cap_for(c->view(), c->sorted()))) ||
+                       (c->one_shot && n_hypotheses < 65536u))))
         return M3D_OK;
     DeviceCtx* ctx = c->ctx;
     HIPCHK(hipSetDevice(ctx->device));

@@ -119,7 +119,7 @@ def test_phased_scoring_matches_oracle(capi, orc, kind, phases):
     o = orc.fit(kind, pts, nrm, thr=0.01, max_iter=3000, prob=1.0, seed=5, lookahead=256)
     res = {}
     for ph in (0, phases):
-        old = capi.set_config(score_phases=ph, plane_bound=0)   # (the planes' histogram bound prunes on its own account and steps aside for the phases)
+        old = capi.set_config(score_phases=ph, plane_bound=0)   # (the planes' histogram bound -- where it engages -- prunes on its own account and steps aside for the phases)
         try:
             g = capi.fit(kind, pts, nrm, threshold=0.01, max_iteration=3000, probability=1.0, seed=5)
         finally:
