@@ -30,6 +30,7 @@
 
 #include <cstdlib>
 
+#include "m3d_bound_fp.hpp"
 #include "m3d_config.hpp"
 #include "m3d_eig3.hpp"
 #include "m3d_fp.hpp"
@@ -37,15 +38,6 @@
 #pragma clang fp contract(off)
 
 namespace m3d {
-
-// bin of a coordinate w along the tile's thin direction: 0 = below the histogram's range, 1 .. kBoundBins inside,
-// kBoundBins + 1 = above.  MONOTONE in w (a subtraction, a multiplication by a positive number, floor, clamp):
-// w1 <= w2 => bound_bin(w1) <= bound_bin(w2), which is all the bound needs -- plane_bound_k evaluates the same expression in fp32
-// for the ends of its interval and steps one bin outwards (its coordinate is within 1e-4 bins of this one).
-__device__ __forceinline__ int bound_bin(double w, double wlo, double invd) {
-    const double t = floor((w - wlo) * invd);
-    return (int)fmin(fmax(t, -1.0), (double)kBoundBins) + 1;
-}
 
 __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -268,15 +260,8 @@ void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipS
 // histograms and fp32 boxes of the range go to LDS in one cooperative sweep, the 64 hypotheses' records in another (eight lanes
 // to a record), and the loop reads LDS only; a tile none of the 64 hypotheses touches is skipped.
 //
-// Arithmetic.  The value at the tile's centre, S(c) = n . c + d, cancels (|n . c| and |d| are of the cloud's size, S(c) of the
-// tile's) and is formed in fp64; everything after it runs in fp32 -- the first form of the kernel was fp64 throughout, ~150
-// instructions per pair with its division, and VALU-bound at 16-20 us.  Every fp32 number is pushed in the safe direction
-// by far more than its rounding: coefficients g = |n . e|, n . u, n . v computed from operands rounded to fp32 are off by at most
-// 4 x 2^-24 |n|_1 (e32 = 5e-7 |n|_1: it enters the slack with W, U, V -- the computed g is then THE coefficient of the
-// inequality, exactly); U, V, W, R are rounded up when staged; the slack is inflated by 1e-5 of itself and of (T + a + |S(c)|)
-// (against ~1e-6 for a dozen fp32 operations), the interval's ends by 1e-5 of their size (the reciprocal and the product);
-// and the bins are taken one further out on both sides (the fp32 bin coordinate is within 1e-4 bins of bound_bin's).
-// Numbers outside [1e-12, 1e12] (an fp32 product could leave the normal range) are not bounded at all: 512 per touched tile.
+// Arithmetic and its margins: m3d_bound_fp.hpp (plane_pair_ub: the value at the tile's centre in fp64, the rest in fp32 with every
+// number pushed outwards; tests/cpp/test_plane_bound.cpp runs the same code on the host against exact counts).
 constexpr int kBoundWaves = 4;
 template <int kBoundTpw /* tiles per wave */>
 __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* __restrict__ frames, const uint16_t* __restrict__ cum,
@@ -315,8 +300,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             const uint32_t tl = i / (uint32_t)kFrameStride, k = i % (uint32_t)kFrameStride;
             const double v = src[i];
             if (k < 3u) c_s[tl][k] = v;
-            const bool up = k == 12u || k == 13u || k == 14u || k == 17u;   // U, V, R, W: rounded up
-            f_s[tl][k] = (float)(up ? v * (1.0 + 1e-6) : v);
+            f_s[tl][k] = frame_to_f32(v, k);
         }
         if (cull32)
             for (uint32_t i = threadIdx.x; i < nt * 6u; i += 64u * kBoundWaves)
@@ -344,12 +328,13 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             }
         }
         __syncthreads();   // (records -- and, the first time round, the frames -- are in LDS)
-        const double a = rec_s[lane][0], b = rec_s[lane][1], c = rec_s[lane][2], d = rec_s[lane][3], T = rec_s[lane][4];
+        PlaneBoundRec pr = plane_bound_record(rec_s[lane], max_abs);
+        pr.ok = pr.ok && has;
         const unsigned long long bit = 1ull << (h & 63u);
         const unsigned long long* __restrict__ mrow = masks + (size_t)(h >> 6);
         // touched or not: the box test itself, from the hypothesis' fp32 record and the tile's fp32 box (the arithmetic of
         // cull32_one<0>, m3d_cull_kernels.hip: the bits cull_tiles32_k wrote) -- the mask words are 8 useful bytes per 128-byte
-        // line for this kernel's lanes (6.5 of its 18 us); without fp32 records (m3d_config.cull_fp32 = 0) it reads them
+        // line for this kernel's lanes; without fp32 records (m3d_config.cull_fp32 = 0) it reads them
         bool tch[kBoundTpw];
         float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (cull32) {   // (kernel argument: uniform)
@@ -362,14 +347,6 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
                 tch[i] = (has && tl < nt) ? (mrow[(size_t)(t0 + tl) * n_groups] & bit) != 0ull : false;
             }
         }
-        const double n1d = (fabs(a) + fabs(b)) + fabs(c);
-        const double Mg = n1d * max_abs + fabs(d);
-        const bool rec_ok = has && (T > 1e-12) && (T < 1e12) && (n1d > 1e-12) && (n1d < 1e12) && (Mg < 1e12);
-        const float af = (float)a, bf = (float)b, cf = (float)c;
-        const float n1 = (float)(n1d * (1.0 + 1e-6));
-        const float e32 = 5e-7f * n1;
-        const float Tf = (float)(T * (1.0 + 1e-6));
-        const float mgf = (float)(1e-14 * Mg * (1.0 + 1e-6));
         uint32_t ub = 0;
 #pragma unroll
         for (int i = 0; i < kBoundTpw; ++i) {
@@ -382,30 +359,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
                 tch[i] = has && (uint32_t)tl < nt && bx[3] >= 0.0f && !(rv - __builtin_fabsf(sv) < 0.0f);
             }
             if (__ballot(tch[i]) == 0ull) continue;   // (wave-uniform)
-            const float* f = f_s[tl];   // (wave-uniform address: broadcast reads)
-            const double sc0 = ((a * c_s[tl][0] + b * c_s[tl][1]) + c * c_s[tl][2]) + d;
-            const float g0 = __builtin_fmaf(af, f[3], __builtin_fmaf(bf, f[4], cf * f[5]));   // (fused: fewer roundings than e32 allows for)
-            const float nu = __builtin_fmaf(af, f[6], __builtin_fmaf(bf, f[7], cf * f[8]));
-            const float nv = __builtin_fmaf(af, f[9], __builtin_fmaf(bf, f[10], cf * f[11]));
-            const float U = f[12], V = f[13], R = f[14], W = f[17];
-            const float scf = (float)sc0;
-            float aa = __builtin_fmaf(__builtin_fabsf(nu) + e32, U, __builtin_fmaf(__builtin_fabsf(nv) + e32, V, __builtin_fmaf(n1, R, __builtin_fmaf(e32, W, mgf))));
-            aa = __builtin_fmaf(aa, 1.00001f, 1e-5f * ((Tf + aa) + __builtin_fabsf(scf)));
-            const float g = __builtin_fabsf(g0), sc = g0 < 0.0f ? -scf : scf;
-            const float ig = __builtin_amdgcn_rcpf(g);   // (g = 0: inf; with a zero numerator NaN -- caught below)
-            float L = ((-Tf - aa) - sc) * ig, H = ((Tf + aa) - sc) * ig;
-            L -= 1e-5f * __builtin_fabsf(L);
-            H += 1e-5f * __builtin_fabsf(H);
-            const bool framed = f[19] != 0.0f && rec_ok;
-            const float wlo = f[15], invd = f[16];
-            const float tL = __builtin_floorf((L - wlo) * invd) - 1.0f, tH = __builtin_floorf((H - wlo) * invd) + 1.0f;   // (one bin further out: see above)
-            const bool whole = !(tL == tL) || !(tH == tH);   // (0 x inf, inf - inf: the direction says nothing -- every finite point of the tile)
-            const int bl = (int)__builtin_fminf(__builtin_fmaxf(whole ? 0.0f : tL, -1.0f), (float)kBoundBins) + 1;
-            const int bh = (int)__builtin_fminf(__builtin_fmaxf(whole ? 0.0f : tH, -1.0f), (float)kBoundBins) + 1;
-            const int lo_c = (int)cm_s[tl][bl], hi_c = (int)cm_s[tl][bh + 1];
-            uint32_t u_t = (uint32_t)max(hi_c - lo_c, 0);
-            u_t = whole ? (uint32_t)f[18] : u_t;
-            u_t = framed ? u_t : (uint32_t)kTilePoints;
+            const uint32_t u_t = plane_pair_ub(pr, c_s[tl], f_s[tl], cm_s[tl]);   // (wave-uniform addresses: broadcast reads)
             ub += tch[i] ? u_t : 0u;
         }
         wsum[wave][lane] = ub;

@@ -1,5 +1,6 @@
 // m3d_cull_kernels.hpp -- launch interface of the spatially culled scoring path (m3d_cull_kernels.hip).
 #pragma once
+#include "m3d_bound_fp.hpp"   // kFrameStride, kBoundBins, kCumStride
 #include "m3d_kernels.hpp"
 
 namespace m3d {
@@ -37,9 +38,6 @@ struct SortedView {
 };
 
 constexpr int kTileF32Floats = 3 * kTilePoints;
-constexpr int kFrameStride = 20;      // doubles per tile frame: c, e, u, v (3 each), U, V, R, wlo, invd, W, finite points, valid
-constexpr int kBoundBins = 126;       // interior bins of a tile's histogram (bin 0 / kBoundBins + 1: below / above its range)
-constexpr int kCumStride = 132;       // uint16 per tile: cum[0 .. kBoundBins + 2] (+ padding to 264 bytes)
 void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipStream_t st);
 // ubsum[h] += upper bound of hypothesis h's inliers over the tiles it can touch, for the hypotheses of the list `surv` (written by
 // the keep kernels of groups [group_begin, group_end): *surv_count ids; ubsum zero on entry); the keep bit of a hypothesis whose

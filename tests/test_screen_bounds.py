@@ -51,3 +51,19 @@ def test_guided_cut_off_searches_equal_the_unguided_ones():
     r = subprocess.run([os.path.join(cpp, "_build", "test_cutoffs"), "30000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout and "guided != unguided 0;" in r.stdout
+
+
+def test_plane_histogram_bound_holds_on_the_host():
+    """tests/cpp/test_plane_bound.cpp runs plane_pair_ub (misc3d_amd/csrc/m3d_bound_fp.hpp: the code plane_bound_k runs on the
+    device, compiled by g++) on random tiles -- plane patches with clutter, exact planes, two planes, clutter only; scenes scaled
+    by 1e-2 .. 1e2 and moved up to 1e4 scene sizes from the origin; good frames and arbitrary ones -- against the exact count of
+    the reference's fp64 test: the bound must never be below it.  The second build drops the slack and the outward bins
+    (M3D_BOUND_NO_SLACK): it must report violations, i.e. the pairs generated really do probe the margins."""
+    import re
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.run(["make", "-C", cpp, "_build/test_plane_bound", "_build/test_plane_bound_no_slack"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(cpp, "_build", "test_plane_bound"), "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all checks passed" in r.stdout and "violations 0" in r.stdout, r.stdout + r.stderr
+    m = subprocess.run([os.path.join(cpp, "_build", "test_plane_bound_no_slack"), "20000"], capture_output=True, text=True, timeout=300)
+    assert m.returncode != 0 and "all checks passed" not in m.stdout
+    assert int(re.search(r"violations (\d+)", m.stdout).group(1)) > 1000, m.stdout
