@@ -255,14 +255,14 @@ void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipS
     if (s.n_tiles) tile_frames_k<<<s.n_tiles, 64, 0, st>>>(s.x, s.y, s.z, s.n_tiles, frames, cum);
 }
 
-// One workgroup (four waves) = 64 hypotheses of the survivor list (written by the keep kernels: emit_survivors; the blocks of 64
+// One workgroup (eight waves) = 64 hypotheses of the survivor list (written by the keep kernels: emit_survivors; the blocks of 64
 // are dealt out along block x, grid-stride) x a range of tiles (block y), the waves taking the tiles in turn.  The frames and
 // histograms and fp32 boxes of the range go to LDS in one cooperative sweep, the 64 hypotheses' records in another (eight lanes
 // to a record), and the loop reads LDS only; a tile none of the 64 hypotheses touches is skipped.
 //
 // Arithmetic and its margins: m3d_bound_fp.hpp (plane_pair_ub: the value at the tile's centre in fp64, the rest in fp32 with every
 // number pushed outwards; tests/cpp/test_plane_bound.cpp runs the same code on the host against exact counts).
-constexpr int kBoundWaves = 4;
+constexpr int kBoundWaves = 8;   // (4 waves x 16 tiles each: step 0.2594-0.2621 ms; 8 x 8: 0.2570-0.2572)
 template <int kBoundTpw /* tiles per wave */>
 __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* __restrict__ frames, const uint16_t* __restrict__ cum,
                                                                    uint32_t n_tiles, double max_abs,
@@ -318,10 +318,9 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
         // requests per launch)
         __syncthreads();   // (the previous block's records and sums have been read)
         {
-            const uint32_t sv = threadIdx.x >> 3, k = threadIdx.x & 7u;   // survivors sv, sv + 32; word k of the record
+            const uint32_t k = threadIdx.x & 7u;   // word k of the record of survivors threadIdx.x / 8, + threads / 8, ...
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t si = sv + 32u * (uint32_t)r;
+            for (uint32_t si = threadIdx.x >> 3; si < 64u; si += (64u * kBoundWaves) >> 3) {
                 const uint32_t hh = surv[first + min(si, nb - 1u)];
                 rec_s[si][k] = score[(size_t)hh * kModelStride + k];
                 if (cull32) q_s[si][k] = cull32[(size_t)(hh >> 1) * 24u + (hh & 1u) + 2u * k];
@@ -410,7 +409,7 @@ void launch_plane_bound(const SortedView& s, const double* score, const unsigned
     const uint32_t gx = std::min<uint32_t>(window, std::max<uint32_t>(4u, (window + gdiv - 1) / gdiv));
     static const int tpw = [] {   // tiles per wave (M3D_BOUND_TPW: 8 / 12 / 16 / 24 / 32)
         const char* e = std::getenv("M3D_BOUND_TPW");
-        const long v = e && *e ? std::strtol(e, nullptr, 10) : 16;
+        const long v = e && *e ? std::strtol(e, nullptr, 10) : 8;
         return v <= 8 ? 8 : (v <= 12 ? 12 : (v <= 16 ? 16 : (v <= 24 ? 24 : 32)));
     }();
     const uint32_t tpb = (uint32_t)(kBoundWaves * tpw);
