@@ -294,6 +294,49 @@ int m3d_information_matrix(const double *src, size_t n_src, const double *dst, s
                            double max_correspondence_distance, const double *T, int device, double info[36],
                            uint64_t *n_correspondences);
 
+/* ---- ReconstructionPipeline::GlobalRegistration (Ransac method), src/pipeline.cpp:790-828, and its caller's shape: one
+ * std::thread per fragment pair, src/pipeline.cpp:428-439 ----------------------------------------------
+ * match (ANNMatcher::Match, :800-802) -> RANSACSolver(1.4 voxel_size).Solve (:806-807) -> pose.isIdentity(1e-8) ? (true,
+ * pose, I6) (:814-816) -> GetInformationMatrixFromPointClouds (:818-820) -> info(5,5) / min(Ns, Nt) < 0.3 ? (false, pose,
+ * I6) : (true, pose, info) (:821-825).  The whole pair runs on ONE lane of the device; the two clouds are uploaded once and
+ * serve the solver and the information matrix.
+ * feat_*: one descriptor of `dim` contiguous doubles per point (Feature::data_, Eigen dim x N column-major).
+ * max_iter / edge_length_threshold: RANSACSolver's (defaults 100000 / 0.9, transform_estimation.h:121-123); confidence:
+ * Open3D RANSACConvergenceCriteria's (0.999).  seed: NULL = std::random_device.
+ * Returns M3D_OK = (true, ...), M3D_FALSE = (false, pose, I6), < 0 = the reference throws (fewer than 3 points) / device error.
+ * T: 4 x 4 row-major, info: 6 x 6 row-major; both always written (identity on error). */
+typedef struct m3d_global_reg_stats {
+    uint64_t n_matches;              /* mutual pairs the matcher returned */
+    uint64_t n_info_correspondences; /* info(5,5): correspondences within 1.4 voxel_size under the pose (0 when not evaluated) */
+    int32_t identity_shortcut;       /* 1: pose.isIdentity(1e-8) ended the call (:814-816) */
+    int32_t device, lane;            /* where the pair ran */
+    int32_t reserved_;
+    double ms_match, ms_ransac, ms_info, ms_total;   /* host clock */
+    m3d_reg_stats ransac;
+} m3d_global_reg_stats;
+int m3d_global_registration(const double *src, size_t n_src, const double *dst, size_t n_dst, const double *feat_src,
+                            const double *feat_dst, int dim, double voxel_size, int max_iter, double edge_length_threshold,
+                            double confidence, const uint64_t *seed, int device, double T[16], double info[36],
+                            m3d_global_reg_stats *stats);
+/* BuildPoseGraphForScene's loop over fragment pairs (src/pipeline.cpp:428-439: one std::thread per pair, joined): pair k
+ * runs on devices[k % n_dev]; every device works on up to `inflight` (<= 0: m3d_config.lanes) of its pairs at a time, each on a
+ * lane of its own, so one pair's uploads and host-side steps (cross-check, RANSAC replay) run under another's kernels.
+ * Pairs are independent: no collective, results identical to n_pairs calls of m3d_global_registration with the same seeds.
+ * Every pair's rc / T / info / stats are written; the call returns the first failed pair's (negative) code, else M3D_OK. */
+typedef struct m3d_fragment_pair {
+    const double *src, *dst;           /* n x 3 */
+    size_t n_src, n_dst;
+    const double *feat_src, *feat_dst; /* n x dim */
+    uint64_t seed;
+    int32_t has_seed;                  /* 0: std::random_device */
+    int32_t rc;                        /* out: M3D_OK accepted / M3D_FALSE rejected / < 0 error */
+    double T[16], info[36];            /* out */
+    m3d_global_reg_stats stats;        /* out */
+} m3d_fragment_pair;
+int m3d_global_registration_batch(m3d_fragment_pair *pairs, size_t n_pairs, int dim, double voxel_size, int max_iter,
+                                  double edge_length_threshold, double confidence, const int *devices, int n_dev,
+                                  int inflight);
+
 /* ---- registration::ANNMatcher::Match, src/correspondence_matching.cpp:52-84 ------------------- */
 /* feat_*: Eigen MatrixXd dim x N column-major = N descriptors of dim contiguous doubles.
  * method: 0 FLANN, 1 ANNOY (correspondence_matching.h MatchMethod); both run the exact mutual
@@ -424,8 +467,21 @@ typedef struct m3d_config {
     int32_t plane_bound;            /* [M3D_PLANE_BOUND=0]  default 1: plane fits with an incumbent prune with a per-tile HISTOGRAM upper bound of
                                        every (tile, hypothesis) pair's inlier count (tile_frames_k / plane_bound_k, m3d_bound.hip) instead of
                                        512 per touched tile, where that pays (windows of >= 8192 hypotheses on tiles x hypotheses >= 1.5e7, measured: m3d_driver.cpp
-                                       bound_pays; 2: whatever the size); same results, fewer hypotheses counted point by point.  (The last of the
-                                       reserved slots: fields are only ever appended, the offsets of existing fields do not move -- ADVICE r3) */
+                                       bound_pays; 2: whatever the size); same results, fewer hypotheses counted point by point.  (Fields are
+                                       only ever appended, the offsets of existing fields do not move -- ADVICE r3) */
+    int32_t lanes;                  /* [M3D_LANES]          default 4 (1..8): calls a device runs side by side -- every lane has its own streams and
+                                       scratch, a call holds one from entry to return, host threads are dealt lanes in the order they arrive
+                                       (a single-threaded caller lives on lane 0); 1 = one call at a time per device (rounds 1-4) */
+    int32_t wait_spin_us;           /* [M3D_SPIN_US]        default 500: the end of a fit's device work is waited for by polling a completion word in
+                                       page-locked memory (the runtime's wait wakes the caller 10-20 us late) for at most this many
+                                       microseconds, then by hipStreamSynchronize (a blocked thread, no core burnt: long calls, hosts with
+                                       more fitting threads than cores); 0 = the runtime's wait only */
+    int32_t prestream;              /* [M3D_PRESTREAM=0]    default 1: MinimalFit + box tests of a fit's chunk k + 1 run on a second stream under the
+                                       scoring launches of chunk k; 0: everything on the lane's main stream (same records) */
+    int32_t chunk_cap;              /* [M3D_CHUNK_CAP]      default 24576 (1024..262144, multiple of 64): hypotheses per chunk of the culled path */
+    int32_t first_chunk;            /* [M3D_FIRST_CHUNK]    default 2048 (0 = off): length of the short first chunk of a fit of several chunks (the
+                                       incumbent that prunes the rest) */
+    int32_t reg_cells_per_radius;   /* [M3D_REG_K]          default 4 (1..16): cells per search radius of the registration validation's grid */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -13,6 +13,8 @@ Drop-in for the reference's python API on this path (module layout of python/py_
     T, info  = m3d.registration_icp(src, dst, 0.02, T)      # the Open3D call the reference's examples chain next
     index    = m3d.features.detect_boundary_points(plane, ("hybrid", 0.02, 30))
     normals  = m3d.common.estimate_normals(pcd, (848, 480), 3)
+    ok, T, info = m3d.reconstruction.global_registration(frag_s, frag_t, fpfh_s, fpfh_t, voxel_size)   # pipeline.cpp:790-828
+    results  = m3d.reconstruction.register_fragment_pairs(fragments, fpfhs, voxel_size=voxel_size)     # pipeline.cpp:428-439
 
 Layout (only what the path needs):
   csrc/      HIP kernels, host driver, C ABI            -> lib/libmisc3d_amd.so
@@ -108,5 +110,66 @@ class _Features:
 
 features = _Features()
 
-__all__ = ["common", "registration", "segmentation", "features", "registration_icp", "VerbosityLevel", "set_verbosity_level",
+
+def _xyz(c):
+    import numpy as _np
+    return _np.ascontiguousarray(_np.asarray(getattr(c, "points", c), dtype=_np.float64).reshape(-1, 3))
+
+
+def _feat(f, n):
+    """open3d Feature (.data: dim x N) or an ndarray, (N, dim) or (dim, N) -> (N, dim) C-contiguous"""
+    import numpy as _np
+    a = _np.asarray(getattr(f, "data", f), dtype=_np.float64)
+    if hasattr(f, "data") or (a.ndim == 2 and a.shape[0] != n and a.shape[1] == n):
+        a = a.T          # Eigen dim x N column-major == (N, dim) row-major: a transposed VIEW of the same memory
+    return _np.ascontiguousarray(a)
+
+
+class _Reconstruction:
+    """misc3d.reconstruction, the loop-closure half of ReconstructionPipeline (src/pipeline.cpp): GlobalRegistration
+    (:790-828) and the loop over fragment pairs that calls it (:428-439).  Calls release the GIL: Python threads that call
+    global_registration / fit_* / match_correspondence side by side run side by side on the device (lanes)."""
+
+    @staticmethod
+    def global_registration(source, target, feature_source, feature_target, voxel_size, max_iter=100000,
+                            edge_length_threshold=0.9, confidence=0.999, *, seed=None, device=0):
+        """ReconstructionPipeline::GlobalRegistration with the Ransac method: match_correspondence ->
+        compute_transformation_ransac(1.4 voxel_size) -> information matrix -> accepted unless info[5, 5] / min(Ns, Nt) < 0.3.
+        Returns (success, 4x4 pose, 6x6 information)."""
+        from . import capi as _capi
+        src, dst = _xyz(source), _xyz(target)
+        try:
+            return _capi.global_registration(src, dst, _feat(feature_source, len(src)), _feat(feature_target, len(dst)),
+                                             voxel_size, max_iter, edge_length_threshold, confidence, seed, device)
+        except _capi.M3DError as e:
+            raise RuntimeError(str(e)) from e
+
+    @staticmethod
+    def register_fragment_pairs(fragments, features, pairs=None, voxel_size=0.01, max_iter=100000,
+                                edge_length_threshold=0.9, confidence=0.999, *, seeds=None, devices=(0,), inflight=0):
+        """BuildPoseGraphForScene's loop closures: every (s, t) of `pairs` (default: all s < t) through global_registration,
+        dealt to `devices`, `inflight` pairs at a time per device.  Returns [(s, t, success, pose, information), ...]."""
+        from . import capi as _capi
+        pts = [_xyz(f) for f in fragments]
+        fts = [_feat(f, len(p)) for f, p in zip(features, pts)]
+        if pairs is None:
+            pairs = [(s, t) for s in range(len(pts)) for t in range(s + 1, len(pts))]
+        try:
+            res = _capi.global_registration_batch([(pts[s], pts[t], fts[s], fts[t]) for s, t in pairs], voxel_size, max_iter,
+                                                  edge_length_threshold, confidence, seeds, devices, inflight)
+        except _capi.M3DError as e:
+            raise RuntimeError(str(e)) from e
+        return [(s, t) + r for (s, t), r in zip(pairs, res)]
+
+
+reconstruction = _Reconstruction()
+
+
+def registration_session(*args, **kwargs):
+    """capi.RegSession: compute_transformation_ransac cut into begin_chunk / validate / replay, the unit
+    misc3d_amd.distributed.registration_ransac_sharded shards over ranks."""
+    from . import capi as _capi
+    return _capi.RegSession(*args, **kwargs)
+
+__all__ = ["common", "registration", "segmentation", "features", "reconstruction", "registration_icp", "registration_session", "VerbosityLevel", "set_verbosity_level",
            "get_verbosity_level", "device_count"]

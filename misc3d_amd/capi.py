@@ -210,7 +210,8 @@ class Config(C.Structure):
                                          "score_groups_per_block", "score_min_workgroups", "dense_workgroups",
                                          "reg_neighbour_lists", "reg_prune", "match_brute", "match_fp32_screen",
                                          "pool_limit_mb", "kernel_timing", "reg_sorted_lists", "score_fp32_screen",
-                                         "cull_fp32", "reg_fp32_screen", "sorted_tombstones", "score_mfma", "score_mfma_groups", "score_waves4", "score_waves4_groups", "score_phases", "compact_one_pass", "plane_bound")]
+                                         "cull_fp32", "reg_fp32_screen", "sorted_tombstones", "score_mfma", "score_mfma_groups", "score_waves4", "score_waves4_groups", "score_phases", "compact_one_pass", "plane_bound",
+                                         "lanes", "wait_spin_us", "prestream", "chunk_cap", "first_chunk", "reg_cells_per_radius")]
 
 
 def fp64_issue_rate(device=0, ms_target=2.0):
@@ -961,19 +962,85 @@ def information_matrix(src, dst, max_correspondence_distance, T, device=0):
     return info.reshape(6, 6), int(nc.value)
 
 
-def global_registration(src, dst, feat_src, feat_dst, voxel_size, max_iter=100000, seed=None, device=0):
-    """ReconstructionPipeline::GlobalRegistration with the Ransac method (src/pipeline.cpp:790-828): mutual-NN
-    match -> RANSACSolver(1.4 voxel) -> information matrix; rejected when info(5,5) / min(Ns, Nt) < 0.3.
-    Returns (success, pose 4x4, information 6x6)."""
-    max_dis = voxel_size * 1.4
-    i0, i1 = match_mutual_nn(feat_src, feat_dst, device=device)
-    pose, _ = registration_ransac(src, dst, i0, i1, threshold=max_dis, max_iter=max_iter, seed=seed, device=device)
-    if np.allclose(pose, np.eye(4), rtol=0, atol=1e-8):          # pose.isIdentity(1e-8)
-        return True, pose, np.eye(6)
-    info, _ = information_matrix(src, dst, max_dis, pose, device=device)
-    if info[5, 5] / min(len(src), len(dst)) < 0.3:
-        return False, pose, np.eye(6)
-    return True, pose, info
+class GlobalRegStats(C.Structure):
+    """m3d_global_reg_stats"""
+    _fields_ = [("n_matches", C.c_uint64), ("n_info_correspondences", C.c_uint64), ("identity_shortcut", C.c_int32),
+                ("device", C.c_int32), ("lane", C.c_int32), ("reserved_", C.c_int32), ("ms_match", C.c_double),
+                ("ms_ransac", C.c_double), ("ms_info", C.c_double), ("ms_total", C.c_double), ("ransac", RegStats)]
+
+    def asdict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("ransac", "reserved_")}
+        d["ransac"] = self.ransac.asdict()
+        return d
+
+
+class FragmentPair(C.Structure):
+    """m3d_fragment_pair"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n_src", C.c_size_t), ("n_dst", C.c_size_t),
+                ("feat_src", C.c_void_p), ("feat_dst", C.c_void_p), ("seed", C.c_uint64), ("has_seed", C.c_int32),
+                ("rc", C.c_int32), ("T", C.c_double * 16), ("info", C.c_double * 36), ("stats", GlobalRegStats)]
+
+
+def _pair_arrays(src, dst, feat_src, feat_dst):
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    fs = _f64(feat_src)
+    fd = _f64(feat_dst)
+    if fs.ndim != 2 or fd.ndim != 2 or fs.shape[1] != fd.shape[1] or len(fs) != len(src) or len(fd) != len(dst):
+        raise ValueError("descriptor matrices must be (N, dim), one row per point, equal dim")
+    return src, dst, fs, fd
+
+
+def global_registration(src, dst, feat_src, feat_dst, voxel_size, max_iter=100000, edge_length_threshold=0.9,
+                        confidence=0.999, seed=None, device=0, want_stats=False):
+    """m3d_global_registration = ReconstructionPipeline::GlobalRegistration with the Ransac method
+    (src/pipeline.cpp:790-828): mutual-NN match -> RANSACSolver(1.4 voxel) -> isIdentity shortcut -> information matrix;
+    rejected when info(5,5) / min(Ns, Nt) < 0.3.  Returns (success, pose 4x4, information 6x6[, stats])."""
+    src, dst, fs, fd = _pair_arrays(src, dst, feat_src, feat_dst)
+    T = np.zeros(16)
+    info = np.zeros(36)
+    st = GlobalRegStats()
+    _s, sref = _seed_ref(seed)
+    f = lib().m3d_global_registration
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
+                  C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = _check(f(_p(src), len(src), _p(dst), len(dst), _p(fs), _p(fd), fs.shape[1], float(voxel_size), int(max_iter),
+                  float(edge_length_threshold), float(confidence), C.cast(sref, C.c_void_p) if sref else None, device,
+                  _p(T), _p(info), C.cast(C.byref(st), C.c_void_p)))
+    out = (rc == 1, T.reshape(4, 4), info.reshape(6, 6))
+    return out + (st.asdict(),) if want_stats else out
+
+
+def global_registration_batch(pairs, voxel_size, max_iter=100000, edge_length_threshold=0.9, confidence=0.999, seeds=None,
+                              devices=(0,), inflight=0, want_stats=False):
+    """m3d_global_registration_batch: pairs = [(src, dst, feat_src, feat_dst), ...] (BuildPoseGraphForScene's loop over
+    fragment pairs, src/pipeline.cpp:428-439) -> [(success, pose, information[, stats]), ...] in the order given.
+    seeds: one per pair or None."""
+    arrs = [_pair_arrays(*p) for p in pairs]
+    n = len(arrs)
+    if n == 0:
+        return []
+    dim = arrs[0][2].shape[1]
+    if any(a[2].shape[1] != dim for a in arrs):
+        raise ValueError("every pair must use descriptors of the same width")
+    fp = (FragmentPair * n)()
+    for k, (src, dst, fs, fd) in enumerate(arrs):
+        fp[k].src, fp[k].dst, fp[k].n_src, fp[k].n_dst = _addr(src), _addr(dst), len(src), len(dst)
+        fp[k].feat_src, fp[k].feat_dst = _addr(fs), _addr(fd)
+        if seeds is not None and seeds[k] is not None:
+            fp[k].seed, fp[k].has_seed = int(seeds[k]) & 0xFFFFFFFFFFFFFFFF, 1
+    dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+    f = lib().m3d_global_registration_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_int]
+    _check(f(C.cast(fp, C.c_void_p), n, dim, float(voxel_size), int(max_iter), float(edge_length_threshold),
+             float(confidence), C.cast(dev, C.c_void_p), len(devices), int(inflight)))
+    out = []
+    for k in range(n):
+        r = (fp[k].rc == 1, np.array(fp[k].T).reshape(4, 4), np.array(fp[k].info).reshape(6, 6))
+        out.append(r + (fp[k].stats.asdict(),) if want_stats else r)
+    return out
 
 
 class RegSession:

@@ -401,17 +401,9 @@ void launch_plane_bound(const SortedView& s, const double* score, const unsigned
     group_end = std::min(group_end, n_groups);
     if (!s.frames || !s.frame_cum || !s.n_tiles || !surv || !surv_count || !tickets || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
-    static const uint32_t gdiv = [] {   // one block of 64 survivors per `gdiv` groups of the window to begin with (M3D_BOUND_GDIV)
-        const char* e = std::getenv("M3D_BOUND_GDIV");
-        const long v = e && *e ? std::strtol(e, nullptr, 10) : 6;
-        return (uint32_t)std::min<long>(std::max<long>(v, 1), 64);
-    }();
+    constexpr uint32_t gdiv = 6;   // one block of 64 survivors per 6 groups of the window to begin with (4 .. 8 equal, measured r4)
     const uint32_t gx = std::min<uint32_t>(window, std::max<uint32_t>(4u, (window + gdiv - 1) / gdiv));
-    static const int tpw = [] {   // tiles per wave (M3D_BOUND_TPW: 8 / 12 / 16 / 24 / 32)
-        const char* e = std::getenv("M3D_BOUND_TPW");
-        const long v = e && *e ? std::strtol(e, nullptr, 10) : 8;
-        return v <= 8 ? 8 : (v <= 12 ? 12 : (v <= 16 ? 16 : (v <= 24 ? 24 : 32)));
-    }();
+    constexpr int tpw = 8;   // tiles per wave (12 .. 32 measured slower: profiles/r04_plane_bound.txt; 24 and 32 need > 64 KB of LDS)
     const uint32_t tpb = (uint32_t)(kBoundWaves * tpw);
     const uint32_t max_list = always ? 0xFFFFFFFFu : window * 32u;   // half of the window's hypotheses
     const dim3 g(gx, (s.n_tiles + tpb - 1) / tpb), b(64 * kBoundWaves);
@@ -420,11 +412,7 @@ void launch_plane_bound(const SortedView& s, const double* score, const unsigned
         kernel<<<g, b, 0, st>>>(s.frames, s.frame_cum, s.n_tiles, s.max_abs, score, masks, n_groups, s.boxes, cull32, surv_count, surv,
                                 ubsum, best_count, keep, tickets, max_list);
     };
-    if (tpw == 8) go(plane_bound_k<8>);
-    else if (tpw == 12) go(plane_bound_k<12>);
-    else if (tpw == 16) go(plane_bound_k<16>);
-    else if (tpw == 24) go(plane_bound_k<24>);
-    else go(plane_bound_k<32>);
+    go(plane_bound_k<tpw>);
 }
 
 }  // namespace m3d

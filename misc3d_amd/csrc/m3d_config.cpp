@@ -1,6 +1,7 @@
 // m3d_config.cpp -- environment -> m3d_config, once (see m3d_config.hpp).
 #include "m3d_config.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -33,6 +34,12 @@ void sanitize(m3d_config& c) {
     if (c.score_waves4_groups < 1 || c.score_waves4_groups > 64) c.score_waves4_groups = 64;
     if (c.score_phases < -1 || c.score_phases == 1 || c.score_phases > 3) c.score_phases = -1;
     if (c.plane_bound < 0 || c.plane_bound > 2) c.plane_bound = 1;
+    if (c.lanes < 1 || c.lanes > 8) c.lanes = 4;
+    if (c.wait_spin_us < 0) c.wait_spin_us = 500;
+    c.prestream = c.prestream != 0;
+    c.chunk_cap = (int32_t)std::min<long>(std::max<long>(((long)c.chunk_cap + 63) / 64 * 64, 1024), 262144);
+    c.first_chunk = c.first_chunk <= 0 ? 0 : (int32_t)std::min<long>(((long)c.first_chunk + 63) / 64 * 64, 1 << 20);
+    if (c.reg_cells_per_radius < 1 || c.reg_cells_per_radius > 16) c.reg_cells_per_radius = 4;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -60,6 +67,12 @@ void load_env() {
     g_cfg.score_phases = (int32_t)env_long("M3D_SCORE_PHASES", -1);
     g_cfg.compact_one_pass = env_is("M3D_COMPACT_ONE_PASS", '1');   // C5 rounds 17.4 against 15.3 ms, C2 step +8 us: off (profiles/r04_compact_one_pass.txt)
     g_cfg.plane_bound = (int32_t)env_long("M3D_PLANE_BOUND", 1);
+    g_cfg.lanes = (int32_t)env_long("M3D_LANES", 4);
+    g_cfg.wait_spin_us = (int32_t)env_long("M3D_SPIN_US", 500);
+    g_cfg.prestream = !env_is("M3D_PRESTREAM", '0');
+    g_cfg.chunk_cap = (int32_t)env_long("M3D_CHUNK_CAP", 24576);
+    g_cfg.first_chunk = (int32_t)env_long("M3D_FIRST_CHUNK", 2048);
+    g_cfg.reg_cells_per_radius = (int32_t)env_long("M3D_REG_K", 4);
     sanitize(g_cfg);
 }
 }  // namespace

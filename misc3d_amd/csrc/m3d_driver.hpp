@@ -21,14 +21,17 @@ void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 
 // grow-only device / pinned-host buffers
-// release() hands the block to a per-device free list (bounded) and reserve() looks there first: the one-call entry
+// release() hands the block to a free list (bounded) and reserve() looks there first: the one-call entry
 // points (registration, matcher, ICP, normals, boundary detection) allocate a dozen or more buffers per call, and
-// hipMalloc / hipFree cost more than many of those calls' kernels.  All device work of a device runs on its one
-// compute stream, so a recycled block is never touched out of order.  dev_pool_trim(device) frees the list.
+// hipMalloc / hipFree cost more than many of those calls' kernels.  The lists are per (device, LANE): all device work of
+// a lane runs on that lane's compute stream (DeviceCtx below), a block goes back to the list of the lane it was taken
+// for and only that lane takes it again, so a recycled block is never touched out of order although several calls
+// run on one device at a time.  dev_pool_trim(device) frees the lists of every lane of the device.
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int dev = -1;
+    int lane = 0;
     bool reserve(size_t bytes);
     void release();
     template <class T>
@@ -69,13 +72,20 @@ struct ChunkSlot {
     uint32_t h_pad = 0;
 };
 
+// One LANE of a device: a compute stream with everything a call needs beside its arguments (streams, events, scratch,
+// pinned words).  A device has up to m3d_config.lanes of them (created on demand); a call holds ONE lane from entry to
+// return (`mu`), so calls on different lanes -- other host threads -- run side by side on the device: one thread's upload
+// and host-side replay under another's kernels (SURVEY.md 8(b) "Threading"; the caller this is for:
+// /root/reference/src/pipeline.cpp:428-439, one std::thread per fragment pair).  Resident objects (m3d_cloud, m3d_reg)
+// stay on the lane they were created on.
 struct DeviceCtx {
     int device = -1;
+    int lane = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // RefineModel: the inlier list goes to the host while the GeneralFit sums run
     hipStream_t pre_stream = nullptr;    // MinimalFit + box tests of chunk k + 1 under the scoring launches of chunk k (fits of several chunks)
     hipEvent_t ev_compact = nullptr;
-    std::mutex mu;  // one call at a time per device
+    std::mutex mu;  // one call at a time per lane (CtxLock / LaneLock)
     ChunkSlot slot[2];
     DevBuf partial, block_counts, total, idx, dist, sum_partial, sums, best_params, small;
     DevBuf masks, keep;        // culled scoring: (tile, 64-hypothesis group) bit masks, per-group keep masks
@@ -138,8 +148,50 @@ struct DeviceCtx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+constexpr int kMaxLanes = 8;
+// entry points' bodies on a lane the caller already holds (m3d_registration.cpp); arguments checked by the callers
+int match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src, const double* feat_dst, size_t n_dst, int dim,
+                       size_t* out_src, size_t* out_dst, size_t* k_out);
+int registration_ransac_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, const double* src, size_t n_src,
+                           const double* dst, size_t n_dst, const size_t* corr_src, const size_t* corr_dst, size_t m,
+                           double threshold, int max_iter, double edge_length_threshold, double confidence,
+                           const uint64_t* seed, double* T_out, m3d_reg_stats* stats);
+int information_matrix_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, const double* dst, size_t n_dst,
+                          double max_correspondence_distance, const double* T, double* info, uint64_t* n_correspondences);
+
 void dev_pool_trim(int device);
-DeviceCtx* get_ctx(int device);  // nullptr + last error when the device is unusable
+DeviceCtx* get_ctx(int device);  // lane 0 of the device; nullptr + last error when the device is unusable
+DeviceCtx* get_lane(int device, int lane);
+int lane_count();                // m3d_config.lanes, clamped to [1, kMaxLanes]
+
+// Holds a lane for the calling thread: locks its mutex and makes it the lane DevBuf::reserve takes blocks for.
+// (hipSetDevice stays with the callers: they report its failure.)
+class CtxLock {
+public:
+    explicit CtxLock(DeviceCtx* c);
+    ~CtxLock();
+    CtxLock(const CtxLock&) = delete;
+    CtxLock& operator=(const CtxLock&) = delete;
+
+private:
+    DeviceCtx* ctx_;
+    int prev_lane_;
+};
+// A lane of `device` for one call: the calling thread's own lane when it is free (threads are dealt lanes in the order
+// they first arrive, so a single-threaded program lives on lane 0 and its scratch stays warm), else the lowest free one,
+// else it waits for its own.  prefer >= 0: that lane instead of the thread's own (the batch entry points' workers).
+// ctx == nullptr (+ last error) when the device is unusable.
+class LaneLock {
+public:
+    explicit LaneLock(int device, int prefer = -1);
+    ~LaneLock();
+    LaneLock(const LaneLock&) = delete;
+    LaneLock& operator=(const LaneLock&) = delete;
+    DeviceCtx* ctx = nullptr;
+
+private:
+    int prev_lane_ = 0;
+};
 
 }  // namespace m3d
 
@@ -200,3 +252,6 @@ struct m3d_cloud {
 
 // m3d_cloud_create with the Hilbert-sorted copy optional (m3d_driver.cpp)
 extern "C" m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_t n, int device, int with_sorted_copy);
+// ... on a lane the caller already holds (CtxLock / LaneLock): the registration session's two clouds share its lane
+m3d_cloud* m3d_cloud_create_on(m3d::DeviceCtx* ctx, const double* xyz, const double* normals, size_t n, int with_sorted_copy);
+void m3d_cloud_destroy_on(m3d_cloud* c);

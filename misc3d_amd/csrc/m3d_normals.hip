@@ -165,9 +165,9 @@ extern "C" int m3d_normals_from_map(const double* xyz, uint32_t w, uint32_t h, u
     if (ms_device) *ms_device = 0.0;
     if (w == 0 || h == 0) return M3D_OK;
     if ((uint64_t)w * h >= ((uint64_t)1 << 31) || k > 4096) return fail(M3D_ERR_INVALID_ARG, "map too large");
-    DeviceCtx* ctx = get_ctx(device);
+    LaneLock lane(device);
+    DeviceCtx* ctx = lane.ctx;
     if (!ctx) return M3D_ERR_DEVICE;
-    std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const uint32_t W = w + 2 * k, H = h + 2 * k;
     const size_t WH = (size_t)W * H, n = (size_t)w * h;

@@ -315,9 +315,9 @@ int m3d_kabsch(const double* src, const double* dst, size_t n, int scaling, int 
     if (n < 3)  // CheckValid, transform_estimation.cpp:27-31
         return fail(M3D_ERR_TOO_FEW_POINTS, "The number of points pair is less than 3.");
     if (n >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
-    DeviceCtx* ctx = get_ctx(device);
+    LaneLock lane(device);
+    DeviceCtx* ctx = lane.ctx;
     if (!ctx) return M3D_ERR_DEVICE;
-    std::lock_guard<std::mutex> lock(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf ds, dd, partial, sums;
     int rc = M3D_OK;
@@ -370,6 +370,7 @@ int m3d_kabsch(const double* src, const double* dst, size_t n, int scaling, int 
 struct m3d_reg {
     DeviceCtx* ctx = nullptr;
     m3d_cloud *csrc = nullptr, *cdst = nullptr;
+    bool own_clouds = true;   // false: the caller's resident clouds (global_registration_on), left alone by the destructor
     Scratch S;
     RegCtx R;
     GridDesc g;
@@ -430,11 +431,7 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
     R.thr = threshold;
 
     {
-        static const int k0 = [] {   // cells per radius of the validation grid (M3D_REG_K: experiments)
-            const char* e = std::getenv("M3D_REG_K");
-            const long v = e && *e ? std::strtol(e, nullptr, 10) : 4;
-            return (int)std::min<long>(std::max<long>(v, 1), 16);
-        }();
+        const int k0 = config().reg_cells_per_radius;   // cells per radius of the validation grid
         const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, false, &g, k0, /*with_nl=*/false,
                                               cdst->bb_known ? cdst->bb : nullptr);
         if (rc_grid != M3D_OK) return rc_grid;
@@ -769,24 +766,38 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
 
 namespace {
 
-// argument checks + uploads + grid; *rc_out < 0 on error (session NULL), M3D_OK otherwise
-m3d_reg* reg_create(const double* src, size_t n_src, const double* dst, size_t n_dst, const size_t* corr_src,
-                    const size_t* corr_dst, size_t m, double threshold, int max_iter, double edge_length_threshold,
-                    double confidence, const uint64_t* seed, int device, int* rc_out) {
+// The session's argument checks, in front of any device work: < 0 = error (the reference throws), M3D_FALSE = the trivial
+// session (Open3D returns the default RegistrationResult without looping: no device needed), M3D_OK = a real one.
+int reg_check_args(const double* src, size_t n_src, const double* dst, size_t n_dst, const size_t* corr_src,
+                   const size_t* corr_dst, size_t m, double threshold) {
+    if (((!src && n_src) || (!dst && n_dst)) || (m && (!corr_src || !corr_dst)))
+        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (n_src < 3 || n_dst < 3)  // transform_estimation.cpp:130-133
+        return fail(M3D_ERR_TOO_FEW_POINTS, "The number of points pair is less than 3.");
+    if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31) || m >= ((size_t)1 << 31))
+        return fail(M3D_ERR_INVALID_ARG, "too many points");
+    for (size_t i = 0; i < m; ++i)
+        if (corr_src[i] >= n_src || corr_dst[i] >= n_dst)
+            return fail(M3D_ERR_INVALID_ARG, "correspondence index out of range");
+    // Open3D: ransac_n < 3 || corres.size() < ransac_n || max_correspondence_distance <= 0 -> RegistrationResult()
+    return (m < 3 || !(threshold > 0.0)) ? M3D_FALSE : M3D_OK;
+}
+
+// Caller holds the lane (no locks below; ctx may be null for a trivial session).  argument checks + uploads + grid; *rc_out < 0 on error (session NULL),
+// M3D_OK otherwise.  csrc_in / cdst_in: the clouds already resident on this lane (borrowed), or null: uploaded here.
+void reg_destroy_on(m3d_reg* q);
+m3d_reg* reg_create_on(DeviceCtx* ctx, m3d_cloud* csrc_in, m3d_cloud* cdst_in, const double* src, size_t n_src,
+                       const double* dst, size_t n_dst, const size_t* corr_src, const size_t* corr_dst, size_t m,
+                       double threshold, int max_iter, double edge_length_threshold, double confidence,
+                       const uint64_t* seed, int* rc_out) {
     *rc_out = M3D_OK;
     auto bad = [&](int code) -> m3d_reg* {
         *rc_out = code;
         return nullptr;
     };
-    if (((!src && n_src) || (!dst && n_dst)) || (m && (!corr_src || !corr_dst)))
-        return bad(fail(M3D_ERR_INVALID_ARG, "invalid argument"));
-    if (n_src < 3 || n_dst < 3)  // transform_estimation.cpp:130-133
-        return bad(fail(M3D_ERR_TOO_FEW_POINTS, "The number of points pair is less than 3."));
-    if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31) || m >= ((size_t)1 << 31))
-        return bad(fail(M3D_ERR_INVALID_ARG, "too many points"));
-    for (size_t i = 0; i < m; ++i)
-        if (corr_src[i] >= n_src || corr_dst[i] >= n_dst)
-            return bad(fail(M3D_ERR_INVALID_ARG, "correspondence index out of range"));
+    const int chk = reg_check_args(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold);
+    if (chk < 0) return bad(chk);
+    if (chk == M3D_OK && !ctx) return bad(fail(M3D_ERR_DEVICE, "no lane"));
     m3d_reg* q = new m3d_reg();
     q->t_begin = now_ms();
     q->n_src = n_src;
@@ -796,55 +807,107 @@ m3d_reg* reg_create(const double* src, size_t n_src, const double* dst, size_t n
     q->edge_length_threshold = edge_length_threshold;
     q->confidence = confidence;
     q->max_iter = max_iter;
-    // Open3D: ransac_n < 3 || corres.size() < ransac_n || max_correspondence_distance <= 0 -> RegistrationResult()
-    if (m < 3 || !(threshold > 0.0)) {
+    if (chk == M3D_FALSE) {
         q->trivial = true;
         return q;
     }
-    q->csrc = m3d_cloud_create_impl(src, nullptr, n_src, device, 0);
-    q->cdst = q->csrc ? m3d_cloud_create_impl(dst, nullptr, n_dst, device, 0) : nullptr;
-    if (!q->csrc || !q->cdst) {
-        if (q->csrc) m3d_cloud_destroy(q->csrc);
-        delete q;
-        return bad(M3D_ERR_DEVICE);
+    if (csrc_in && cdst_in) {
+        q->csrc = csrc_in;
+        q->cdst = cdst_in;
+        q->own_clouds = false;
+    } else {
+        q->csrc = m3d_cloud_create_on(ctx, src, nullptr, n_src, 0);
+        q->cdst = q->csrc ? m3d_cloud_create_on(ctx, dst, nullptr, n_dst, 0) : nullptr;
+        if (!q->csrc || !q->cdst) {
+            if (q->csrc) m3d_cloud_destroy_on(q->csrc);
+            delete q;
+            return bad(M3D_ERR_DEVICE);
+        }
     }
-    q->ctx = q->csrc->ctx;
-    int rc;
-    {
-        std::lock_guard<std::mutex> lock(q->ctx->mu);
-        rc = q->setup(src, dst, corr_src, corr_dst, seed);
-        (void)hipStreamSynchronize(q->ctx->stream);
-    }
+    q->ctx = ctx;
+    const int rc = q->setup(src, dst, corr_src, corr_dst, seed);
+    (void)hipStreamSynchronize(ctx->stream);
     if (rc != M3D_OK) {
-        m3d_reg_destroy(q);
+        reg_destroy_on(q);
         return bad(rc);
     }
     return q;
 }
+void reg_destroy_on(m3d_reg* q) {
+    if (!q) return;
+    if (q->ctx) {
+        (void)hipSetDevice(q->ctx->device);
+        (void)hipStreamSynchronize(q->ctx->stream);
+        q->S.release();
+    }
+    if (q->own_clouds) {
+        if (q->csrc) m3d_cloud_destroy_on(q->csrc);
+        if (q->cdst) m3d_cloud_destroy_on(q->cdst);
+    }
+    delete q;
+}
 
 }  // namespace
+
+// compute_transformation_ransac on a lane the caller holds (m3d_registration_ransac, global_registration_on): the
+// session's three steps in a loop, the lane kept from the uploads to the result.
+int m3d::registration_ransac_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, const double* src, size_t n_src,
+                                const double* dst, size_t n_dst, const size_t* corr_src, const size_t* corr_dst, size_t m,
+                                double threshold, int max_iter, double edge_length_threshold, double confidence,
+                                const uint64_t* seed, double* T_out, m3d_reg_stats* stats) {
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(T_out, I4, sizeof(I4));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->best_index = -1;
+    }
+    int rc = M3D_OK;
+    m3d_reg* q = reg_create_on(ctx, csrc, cdst, src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter,
+                               edge_length_threshold, confidence, seed, &rc);
+    if (!q) return rc;
+    std::vector<uint32_t> counts;
+    std::vector<double> sums;
+    while (!q->trivial) {
+        size_t ns = 0;
+        rc = q->begin_chunk(&ns);
+        if (rc != M3D_OK) break;   // M3D_FALSE: loop over; < 0: error
+        counts.assign(std::max<size_t>(ns, 1), 0);
+        sums.assign(std::max<size_t>(ns, 1), 0.0);
+        rc = q->validate(0, ns, counts.data(), sums.data());
+        if (rc != M3D_OK) break;
+        rc = q->replay(counts.data(), sums.data());
+        if (rc != M3D_OK) break;
+    }
+    if (q->trivial || rc == M3D_FALSE) rc = q->finish(T_out, stats);
+    reg_destroy_on(q);
+    return rc;
+}
 
 extern "C" {
 
 void m3d_reg_destroy(m3d_reg* q) {
     if (!q) return;
     if (q->ctx) {
-        std::lock_guard<std::mutex> lock(q->ctx->mu);
-        (void)hipSetDevice(q->ctx->device);
-        (void)hipStreamSynchronize(q->ctx->stream);
-        q->S.release();
+        CtxLock lock(q->ctx);
+        reg_destroy_on(q);
+    } else {
+        reg_destroy_on(q);
     }
-    if (q->csrc) m3d_cloud_destroy(q->csrc);
-    if (q->cdst) m3d_cloud_destroy(q->cdst);
-    delete q;
 }
 
 m3d_reg* m3d_reg_create(const double* src, size_t n_src, const double* dst, size_t n_dst, const size_t* corr_src,
                         const size_t* corr_dst, size_t m, double threshold, int max_iter,
                         double edge_length_threshold, double confidence, const uint64_t* seed, int device) {
     int rc;
-    return reg_create(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter, edge_length_threshold,
-                      confidence, seed, device, &rc);
+    const int chk = reg_check_args(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold);
+    if (chk < 0) return nullptr;
+    if (chk == M3D_FALSE)
+        return reg_create_on(nullptr, nullptr, nullptr, src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter,
+                             edge_length_threshold, confidence, seed, &rc);
+    LaneLock lane(device);
+    if (!lane.ctx) return nullptr;
+    return reg_create_on(lane.ctx, nullptr, nullptr, src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter,
+                         edge_length_threshold, confidence, seed, &rc);
 }
 
 int m3d_reg_begin_chunk(m3d_reg* q, size_t* n_survivors) {
@@ -853,27 +916,27 @@ int m3d_reg_begin_chunk(m3d_reg* q, size_t* n_survivors) {
         *n_survivors = 0;
         return M3D_FALSE;
     }
-    std::lock_guard<std::mutex> lock(q->ctx->mu);
+    CtxLock lock(q->ctx);
     return q->begin_chunk(n_survivors);
 }
 
 int m3d_reg_validate(m3d_reg* q, size_t s_begin, size_t s_end, uint32_t* counts, double* sums) {
     if (!q || q->trivial || (s_end > s_begin && (!counts || !sums))) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    std::lock_guard<std::mutex> lock(q->ctx->mu);
+    CtxLock lock(q->ctx);
     return q->validate(s_begin, s_end, counts, sums);
 }
 
 int m3d_reg_replay(m3d_reg* q, const uint32_t* counts, const double* sums) {
     if (!q || q->trivial) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     if (!q->survivors.empty() && (!counts || !sums)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    std::lock_guard<std::mutex> lock(q->ctx->mu);
+    CtxLock lock(q->ctx);
     return q->replay(counts, sums);
 }
 
 int m3d_reg_finish(m3d_reg* q, double* T, m3d_reg_stats* stats) {
     if (!q || !T) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     if (q->trivial) return q->finish(T, stats);
-    std::lock_guard<std::mutex> lock(q->ctx->mu);
+    CtxLock lock(q->ctx);
     return q->finish(T, stats);
 }
 
@@ -882,32 +945,15 @@ int m3d_registration_ransac(const double* src, size_t n_src, const double* dst, 
                             int max_iter, double edge_length_threshold, double confidence,
                             const uint64_t* seed, int device, double* T_out, m3d_reg_stats* stats) {
     if (!T_out) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    std::memcpy(T_out, I4, sizeof(I4));
-    if (stats) {
-        std::memset(stats, 0, sizeof(*stats));
-        stats->best_index = -1;
-    }
-    int rc = M3D_OK;
-    m3d_reg* q = reg_create(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter, edge_length_threshold,
-                            confidence, seed, device, &rc);
-    if (!q) return rc;
-    std::vector<uint32_t> counts;
-    std::vector<double> sums;
-    for (;;) {
-        size_t ns = 0;
-        rc = m3d_reg_begin_chunk(q, &ns);
-        if (rc != M3D_OK) break;   // M3D_FALSE: loop over; < 0: error
-        counts.assign(std::max<size_t>(ns, 1), 0);
-        sums.assign(std::max<size_t>(ns, 1), 0.0);
-        rc = m3d_reg_validate(q, 0, ns, counts.data(), sums.data());
-        if (rc != M3D_OK) break;
-        rc = m3d_reg_replay(q, counts.data(), sums.data());
-        if (rc != M3D_OK) break;
-    }
-    if (rc == M3D_FALSE) rc = m3d_reg_finish(q, T_out, stats);
-    m3d_reg_destroy(q);
-    return rc;
+    const int chk = reg_check_args(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold);
+    if (chk < 0) return chk;
+    if (chk == M3D_FALSE)   // the trivial session: identity, no device
+        return registration_ransac_on(nullptr, nullptr, nullptr, src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold,
+                                      max_iter, edge_length_threshold, confidence, seed, T_out, stats);
+    LaneLock lane(device);
+    if (!lane.ctx) return M3D_ERR_DEVICE;
+    return registration_ransac_on(lane.ctx, nullptr, nullptr, src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold,
+                                  max_iter, edge_length_threshold, confidence, seed, T_out, stats);
 }
 
 // The same loop with every chunk's validations sharded over the ranks of `comm`: sessions are seeded
@@ -931,8 +977,6 @@ int m3d_registration_ransac_sharded(const double* src, size_t n_src, const doubl
         std::memset(stats, 0, sizeof(*stats));
         stats->best_index = -1;
     }
-    DeviceCtx* ctx = get_ctx(device);
-    if (!ctx) return M3D_ERR_DEVICE;
     // one seed for all ranks: rank 0's when none was given
     uint64_t sd = 0;
     {
@@ -941,7 +985,9 @@ int m3d_registration_ransac_sharded(const double* src, size_t n_src, const doubl
         sd = mine;
         if (!seed && comm->world > 1) {
             std::vector<uint64_t> all((size_t)comm->world);
-            std::lock_guard<std::mutex> lock(ctx->mu);
+            LaneLock lane(device);
+            DeviceCtx* ctx = lane.ctx;
+            if (!ctx) return M3D_ERR_DEVICE;
             HIPCHK(hipSetDevice(ctx->device));
             const int rs = comm->allgather_host(&mine, all.data(), sizeof(uint64_t), ctx->stream);
             if (rs != M3D_OK) return rs;
@@ -949,8 +995,18 @@ int m3d_registration_ransac_sharded(const double* src, size_t n_src, const doubl
         }
     }
     int rc = M3D_OK;
-    m3d_reg* q = reg_create(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter, edge_length_threshold,
-                            confidence, &sd, device, &rc);
+    m3d_reg* q = nullptr;
+    const int chk = reg_check_args(src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold);
+    if (chk < 0) return chk;
+    if (chk == M3D_FALSE) {
+        q = reg_create_on(nullptr, nullptr, nullptr, src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter,
+                          edge_length_threshold, confidence, &sd, &rc);
+    } else {
+        LaneLock lane(device);
+        if (!lane.ctx) return M3D_ERR_DEVICE;
+        q = reg_create_on(lane.ctx, nullptr, nullptr, src, n_src, dst, n_dst, corr_src, corr_dst, m, threshold, max_iter,
+                          edge_length_threshold, confidence, &sd, &rc);
+    }
     if (!q) return rc;
     struct Rec {
         double sum;
@@ -987,7 +1043,7 @@ int m3d_registration_ransac_sharded(const double* src, size_t n_src, const doubl
             if (vrc != M3D_OK) mine[0].count = kPoison;
             all.assign(shard * world, Rec{0.0, 0});
             {
-                std::lock_guard<std::mutex> lock(q->ctx->mu);
+                CtxLock lock(q->ctx);
                 rc = hipSetDevice(q->ctx->device) == hipSuccess
                          ? comm->allgather_host(mine.data(), all.data(), sizeof(Rec) * shard, q->ctx->stream)
                          : fail(M3D_ERR_DEVICE, "hipSetDevice failed");
@@ -1042,19 +1098,20 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
         }
         return M3D_OK;
     }
-    m3d_cloud* csrc = m3d_cloud_create_impl(src, nullptr, n_src, device, 0);
+    LaneLock lane(device);
+    DeviceCtx* ctx = lane.ctx;
+    if (!ctx) return M3D_ERR_DEVICE;
+    m3d_cloud* csrc = m3d_cloud_create_on(ctx, src, nullptr, n_src, 0);
     if (!csrc) return M3D_ERR_DEVICE;
-    m3d_cloud* cdst = m3d_cloud_create_impl(dst, nullptr, n_dst, device, 0);
+    m3d_cloud* cdst = m3d_cloud_create_on(ctx, dst, nullptr, n_dst, 0);
     if (!cdst) {
-        m3d_cloud_destroy(csrc);
+        m3d_cloud_destroy_on(csrc);
         return M3D_ERR_DEVICE;
     }
-    DeviceCtx* ctx = csrc->ctx;
     Scratch S;
     DevBuf mx, my, mz, nn, d2;
     int rc;
     {
-        std::lock_guard<std::mutex> lock(ctx->mu);
         rc = [&]() -> int {
             HIPCHK(hipSetDevice(ctx->device));
             const CloudView sv = csrc->view(), dv = cdst->view();
@@ -1180,8 +1237,8 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
         S.release();
         mx.release(); my.release(); mz.release(); nn.release(); d2.release();
     }
-    m3d_cloud_destroy(csrc);
-    m3d_cloud_destroy(cdst);
+    m3d_cloud_destroy_on(csrc);
+    m3d_cloud_destroy_on(cdst);
     if (stats) stats->ms_total = now_ms() - t_begin;
     return rc;
 }
@@ -1199,25 +1256,38 @@ int m3d_information_matrix(const double* src, size_t n_src, const double* dst, s
     if (!(max_correspondence_distance > 0.0)) return fail(M3D_ERR_INVALID_ARG, "Invalid max_correspondence_distance.");
     if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
     if (n_src == 0 || n_dst == 0) return M3D_OK;
-    m3d_cloud* csrc = m3d_cloud_create_impl(src, nullptr, n_src, device, 0);
+    LaneLock lane(device);
+    DeviceCtx* ctx = lane.ctx;
+    if (!ctx) return M3D_ERR_DEVICE;
+    m3d_cloud* csrc = m3d_cloud_create_on(ctx, src, nullptr, n_src, 0);
     if (!csrc) return M3D_ERR_DEVICE;
-    m3d_cloud* cdst = m3d_cloud_create_impl(dst, nullptr, n_dst, device, 0);
+    m3d_cloud* cdst = m3d_cloud_create_on(ctx, dst, nullptr, n_dst, 0);
     if (!cdst) {
-        m3d_cloud_destroy(csrc);
+        m3d_cloud_destroy_on(csrc);
         return M3D_ERR_DEVICE;
     }
-    DeviceCtx* ctx = csrc->ctx;
+    const int rc = information_matrix_on(ctx, csrc, cdst, dst, n_dst, max_correspondence_distance, T, info, n_correspondences);
+    m3d_cloud_destroy_on(csrc);
+    m3d_cloud_destroy_on(cdst);
+    return rc;
+}
+}  // extern "C"
+
+// ... on a lane the caller holds, for two clouds resident on it (m3d_information_matrix, global_registration_on)
+int m3d::information_matrix_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, const double* dst, size_t n_dst,
+                               double max_correspondence_distance, const double* T, double* info,
+                               uint64_t* n_correspondences) {
     Scratch S;
     DevBuf mx, my, mz, nn, d2;
     int rc;
     {
-        std::lock_guard<std::mutex> lock(ctx->mu);
         rc = [&]() -> int {
             HIPCHK(hipSetDevice(ctx->device));
             const CloudView sv = csrc->view(), dv = cdst->view();
             const uint32_t n = sv.n;
             GridDesc g;
-            const int rg = build_target_grid(ctx, S, dv, dst, n_dst, max_correspondence_distance, true, &g);
+            const int rg = build_target_grid(ctx, S, dv, dst, n_dst, max_correspondence_distance, true, &g, 4, true,
+                                             cdst->bb_known ? cdst->bb : nullptr);
             if (rg != M3D_OK) return rg;
             RESERVE(mx, sizeof(double) * n);
             RESERVE(my, sizeof(double) * n);
@@ -1277,10 +1347,9 @@ int m3d_information_matrix(const double* src, size_t n_src, const double* dst, s
         S.release();
         mx.release(); my.release(); mz.release(); nn.release(); d2.release();
     }
-    m3d_cloud_destroy(csrc);
-    m3d_cloud_destroy(cdst);
     return rc;
 }
+extern "C" {
 
 // misc3d::features::DetectBoundaryPoints, src/boundary_detection.cpp:68-113: the step the
 // reference's showcase example runs right after fit_plane (examples/python/ransac_and_boundary.py:35-36).
@@ -1293,14 +1362,15 @@ int m3d_detect_boundary_points(const double* xyz, const double* normals, size_t 
     if ((search != 0 && !(radius > 0.0)) || (search != 1 && (max_nn < 1 || max_nn > kBoundaryMaxNb)))
         return fail(M3D_ERR_INVALID_ARG, "invalid search parameter (radius > 0, 1 <= max_nn <= 128)");
     if (n >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
-    m3d_cloud* c = m3d_cloud_create_impl(xyz, normals, n, device, 0);
+    LaneLock lane(device);
+    DeviceCtx* ctx = lane.ctx;
+    if (!ctx) return M3D_ERR_DEVICE;
+    m3d_cloud* c = m3d_cloud_create_on(ctx, xyz, normals, n, 0);
     if (!c) return M3D_ERR_DEVICE;
-    DeviceCtx* ctx = c->ctx;
     Scratch S;
     DevBuf flags;
     int rc;
     {
-        std::lock_guard<std::mutex> lock(ctx->mu);
         rc = [&]() -> int {
             HIPCHK(hipSetDevice(ctx->device));
             const CloudView v = c->view();
@@ -1347,7 +1417,7 @@ int m3d_detect_boundary_points(const double* xyz, const double* normals, size_t 
         S.release();
         flags.release();
     }
-    m3d_cloud_destroy(c);
+    m3d_cloud_destroy_on(c);
     return rc;
 }
 
@@ -1362,9 +1432,15 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     *k_out = 0;
     if (n_src == 0 || n_dst == 0) return M3D_OK;
     if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
-    DeviceCtx* ctx = get_ctx(device);
-    if (!ctx) return M3D_ERR_DEVICE;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    LaneLock lane(device);
+    if (!lane.ctx) return M3D_ERR_DEVICE;
+    return match_mutual_nn_on(lane.ctx, feat_src, n_src, feat_dst, n_dst, dim, out_src, out_dst, k_out);
+}
+}  // extern "C"
+
+// ... on a lane the caller holds (m3d_match_mutual_nn, global_registration_on); arguments already checked
+int m3d::match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src, const double* feat_dst, size_t n_dst,
+                            int dim, size_t* out_src, size_t* out_dst, size_t* k_out) {
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf fs, fd, bd, bi, nn01, nn10, fs32, fd32, ns2, nd2, ring, ring_count, evict, over_list, scal, pA_s, pA_d,
         pB_s, pB_d, premin, rev_premin, rthr, rcnt, rcand, rlist, rlist_cnt, over_list_r;
@@ -1514,6 +1590,7 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     return done(M3D_OK);
 }
 
+extern "C" {
 // test hook (include/misc3d_amd_bench.h): the checkers as this library's M3D_FP_ORDER compiles them, on the host
 int m3d_bench_reg_checkers(const double* ps, const double* pd, const double* T, double edge_threshold,
                            double distance_threshold) {

@@ -409,6 +409,28 @@ def information_matrix(src, dst, max_dist, T):
     return info.reshape(6, 6)
 
 
+def global_registration(src, dst, feat_src, feat_dst, voxel_size, max_iter=100000, edge_thr=0.9, confidence=0.999, seed=0):
+    """ReconstructionPipeline::GlobalRegistration, Ransac method (src/pipeline.cpp:790-828) -> (success, T 4x4, info 6x6,
+    number of mutual matches); raises ValueError where the solver throws (fewer than 3 points)."""
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    fs = _f64(feat_src)
+    fd = _f64(feat_dst)
+    if len(fs) != len(src) or len(fd) != len(dst) or fs.shape[1] != fd.shape[1]:
+        raise ValueError("one descriptor per point, equal widths")
+    T = np.zeros(16)
+    info = np.zeros(36)
+    nm = C.c_uint64(0)
+    f = lib().orc_global_registration
+    f.restype = C.c_int
+    r = f(_p(src), C.c_size_t(len(src)), _p(dst), C.c_size_t(len(dst)), _p(fs), _p(fd), C.c_int(fs.shape[1]),
+          C.c_double(voxel_size), C.c_int(max_iter), C.c_double(edge_thr), C.c_double(confidence), C.c_uint64(seed), _p(T),
+          _p(info), C.byref(nm))
+    if r < 0:
+        raise ValueError("The number of points pair is less than 3.")
+    return bool(r), T.reshape(4, 4), info.reshape(6, 6), int(nm.value)
+
+
 def registration_icp(src, dst, max_dist, T_init=None, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
     """-> (T 4x4, fitness, inlier_rmse, iterations, correspondences (ns,) int64 with -1 = none)"""
     src = _f64(src).reshape(-1, 3)

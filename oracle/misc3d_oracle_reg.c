@@ -565,3 +565,56 @@ size_t orc_match_mutual_nn(const double *fs, size_t ns, const double *fd, size_t
     free(n10);
     return k;
 }
+
+/* Eigen::MatrixBase::isIdentity(prec) on a 4 x 4 row-major matrix (pipeline.cpp:814): diagonal entries
+ * internal::isApprox(x, 1, prec) = |x - 1| <= min(|x|, 1) prec, the others internal::isMuchSmallerThan(x, 1, prec)
+ * = |x| <= prec.  [RECALL] Eigen/src/Core/CwiseNullaryOp.h, MathFunctions.h. */
+int orc_is_identity4(const double *T, double prec) {
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            const double x = T[4 * r + c];
+            if (r == c) {
+                const double ax = fabs(x), m = ax < 1.0 ? ax : 1.0;
+                if (!(fabs(x - 1.0) <= m * prec)) return 0;
+            } else if (!(fabs(x) <= 1.0 * prec)) {
+                return 0;
+            }
+        }
+    return 1;
+}
+
+/* ReconstructionPipeline::GlobalRegistration with GlobalRegistrationMethod::Ransac (src/pipeline.cpp:790-828), the
+ * only in-library caller of the matcher and the RANSAC solver:
+ *   max_dis = voxel_size * 1.4                                            :796
+ *   matched_list = ANNMatcher(ANNOY).Match(fpfh_s, fpfh_t)               :800-802
+ *   pose = RANSACSolver(max_dis).Solve(pcd_s, pcd_t, matched_list)       :806-807  (max_iter 100000, edge 0.9: the
+ *          solver's defaults, transform_estimation.h:121-123; confidence 0.999: RANSACConvergenceCriteria's)
+ *   pose.isIdentity(1e-8) -> (true, pose, I6)                            :814-816
+ *   info = GetInformationMatrixFromPointClouds(pcd_s, pcd_t, max_dis, pose)   :818-820
+ *   info(5,5) / min(Ns, Nt) < 0.3 -> (false, pose, I6)                   :821-824  (size_t min, the quotient in double)
+ *   else (true, pose, info)                                              :825
+ * The caller passes max_iter / edge_thr / confidence explicitly so that tests can bound the run.
+ * Returns 1 = success, 0 = rejected, -1 = fewer than 3 points (the solver throws).  T 4 x 4, info 6 x 6 row-major;
+ * n_matches: mutual pairs the matcher found. */
+int orc_global_registration(const double *src, size_t ns, const double *dst, size_t nd, const double *fs,
+                            const double *fd, int dim, double voxel_size, int max_iter, double edge_thr,
+                            double confidence, uint64_t seed, double *T, double *info, uint64_t *n_matches) {
+    const double max_dis = voxel_size * 1.4;
+    int64_t *cs = (int64_t *)malloc(sizeof(int64_t) * (ns ? ns : 1));
+    int64_t *cd = (int64_t *)malloc(sizeof(int64_t) * (ns ? ns : 1));
+    const size_t m = orc_match_mutual_nn(fs, ns, fd, nd, dim, cs, cd);
+    if (n_matches) *n_matches = m;
+    for (int k = 0; k < 36; ++k) info[k] = (k % 7 == 0) ? 1.0 : 0.0;
+    const int rr = orc_registration_ransac(src, ns, dst, nd, cs, cd, m, max_dis, max_iter, edge_thr, confidence, seed, T,
+                                           NULL, NULL);
+    free(cs);
+    free(cd);
+    if (rr < 0) return -1;
+    if (orc_is_identity4(T, 1e-8)) return 1;
+    double gi[36];
+    orc_information_matrix(src, ns, dst, nd, max_dis, T, gi);
+    const size_t mn = ns < nd ? ns : nd;
+    if (gi[35] / (double)mn < 0.3) return 0;
+    memcpy(info, gi, sizeof(gi));
+    return 1;
+}

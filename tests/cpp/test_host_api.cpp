@@ -5,12 +5,14 @@
 #include <cstring>
 #include <cstdio>
 #include <random>
+#include <thread>
 
 #include <algorithm>
 
 #include <misc3d/common/normal_estimation.h>
 #include <misc3d/features/boundary_detection.h>
 #include <misc3d/common/ransac.h>
+#include <misc3d/reconstruction/global_registration.h>
 #include <misc3d/registration/correspondence_matching.h>
 #include <misc3d/registration/transform_estimation.h>
 #include <misc3d/segmentation/iterative_plane_segmentation.h>
@@ -181,6 +183,55 @@ int main() {
     const misc3d::Matrix4d Tr = rs.Solve(src, dst, corres);
     CHECK(std::fabs(Tr[0] - c) < 1e-9 && std::fabs(Tr[3] - 0.3) < 1e-9);
     CHECK(rs.GetStats().fitness == 1.0);
+    // ---- GlobalRegistration + RegisterFragmentPairs (include/misc3d/reconstruction/global_registration.h): the shape of
+    // src/pipeline.cpp:428-439 -- three fragments, every pair; one call per std::thread, and the batch entry point
+    {
+        std::vector<misc3d::PointCloud> frag(3);
+        std::vector<std::vector<double>> feat(3);
+        const double ang[3] = {0.0, 0.5, -0.3};
+        for (int i = 0; i < 2500; ++i) {
+            // a scene without symmetries: two orthogonal wall patches and a blob
+            misc3d::Vector3d p;
+            if (i % 3 == 0) p = {U(gen), U(gen) * 0.6, 0.1 * U(gen) * U(gen)};
+            else if (i % 3 == 1) p = {0.9 + 0.05 * U(gen), U(gen) * 0.7, 0.5 + 0.5 * U(gen)};
+            else p = {0.3 * U(gen) - 0.4, 0.2 * U(gen) + 0.3, 0.3 * U(gen) + 0.4};
+            double f[8];
+            for (int k = 0; k < 8; ++k) f[k] = U(gen);
+            for (int j = 0; j < 3; ++j) {
+                const double cj = std::cos(ang[j]), sj = std::sin(ang[j]);
+                frag[j].points_.push_back({cj * p[0] - sj * p[1] + 0.1 * j, sj * p[0] + cj * p[1] - 0.05 * j, p[2] + 0.02 * j});
+                for (int k = 0; k < 8; ++k) feat[j].push_back(f[k] + 1e-3 * U(gen));
+            }
+        }
+        std::vector<misc3d::CloudView> views(frag.begin(), frag.end());
+        std::vector<misc3d::registration::FeatureView> fviews;
+        for (int j = 0; j < 3; ++j) fviews.push_back({feat[j].data(), 8, frag[j].points_.size()});
+        const std::vector<std::pair<int, int>> pairs = {{0, 1}, {0, 2}, {1, 2}};
+        const std::vector<uint64_t> seeds = {5, 6, 7};
+        misc3d::reconstruction::GlobalRegistrationOption opt;
+        opt.voxel_size = 0.03 / 1.4;
+        opt.max_iter = 2000;
+        const auto batch = misc3d::reconstruction::RegisterFragmentPairs(views, fviews, pairs, opt, seeds, {0}, 3);
+        CHECK(batch.size() == 3);
+        // the same three pairs, one std::thread each (the reference's own loop)
+        std::vector<std::tuple<bool, misc3d::Matrix4d, misc3d::reconstruction::Matrix6d>> single(3);
+        std::vector<std::thread> th;
+        for (int k = 0; k < 3; ++k)
+            th.emplace_back([&, k] {
+                single[k] = misc3d::reconstruction::GlobalRegistration(views[pairs[k].first], views[pairs[k].second],
+                                                                       fviews[pairs[k].first], fviews[pairs[k].second], opt,
+                                                                       &seeds[k]);
+            });
+        for (auto& t : th) t.join();
+        for (int k = 0; k < 3; ++k) {
+            CHECK(batch[k].success_ && std::get<0>(single[k]));
+            CHECK(batch[k].transformation_ == std::get<1>(single[k]) && batch[k].information_ == std::get<2>(single[k]));
+            const double da = ang[pairs[k].second] - ang[pairs[k].first];
+            CHECK(std::fabs(batch[k].transformation_[0] - std::cos(da)) < 1e-6 && std::fabs(batch[k].transformation_[4] - std::sin(da)) < 1e-6);
+            CHECK(batch[k].information_[35] == 2500.0 && batch[k].stats_.n_matches > 2400);
+        }
+    }
+
     // ---- EstimateNormalsFromMap (include/misc3d/common/normal_estimation.h): tilted plane seen from the origin
     {
         const int w = 64, h = 48;
