@@ -53,6 +53,11 @@ int m3d_bench_last_segment_ms(double out[6]);
 int m3d_bench_reg_checkers(const double *ps, const double *pd, const double *T, double edge_threshold,
                            double distance_threshold);
 
+/* 1: the library was built with -DM3D_EXPERIMENTAL -- round 4's three refuted variants (score_mfma_k, score_screen4_k,
+ * compact_write_k<.., ONE>) are compiled in and m3d_config.score_mfma / score_waves4 / compact_one_pass switch them on;
+ * 0 (the product build): those switches are ignored and m3d_bench_mfma_probe returns an error. */
+int m3d_bench_experimental(void);
+
 /* TEST hook (tests/test_gpu_mfma_screen.py): the MFMA screen of the plane scoring (score_mfma_k) on ONE tile -- 512 points
  * xyz (row-major doubles), their box (centre xyz, half extents xyz: every |x - centre| <= half extent), n_h plane records
  * (a, b, c, d, T, 0, 0, 0) -- through the production kernel's own operand builders and the matrix pipe:

@@ -240,6 +240,14 @@ def mfma_probe(xyz512, box, max_abs, records, device=0):
     return q, h[:, 0].copy(), h[:, 1].copy(), h[:, 2].copy(), off
 
 
+def experimental() -> bool:
+    """m3d_bench_experimental: was the library built with -DM3D_EXPERIMENTAL (round 4's refuted variants compiled in)?"""
+    f = lib().m3d_bench_experimental
+    f.restype = C.c_int
+    f.argtypes = []
+    return bool(f())
+
+
 def get_config() -> Config:
     c = Config()
     lib().m3d_get_config(C.byref(c))

@@ -34,6 +34,7 @@ void sanitize(m3d_config& c) {
     if (c.score_waves4_groups < 1 || c.score_waves4_groups > 64) c.score_waves4_groups = 64;
     if (c.score_phases < -1 || c.score_phases == 1 || c.score_phases > 3) c.score_phases = -1;
     if (c.plane_bound < 0 || c.plane_bound > 2) c.plane_bound = 1;
+    if (!kExperimentalBuild) c.score_mfma = c.score_waves4 = c.compact_one_pass = 0;   // (not compiled in: m3d_kernels.hpp)
     if (c.lanes < 1 || c.lanes > 8) c.lanes = 4;
     if (c.wait_spin_us < 0) c.wait_spin_us = 500;
     c.prestream = c.prestream != 0;

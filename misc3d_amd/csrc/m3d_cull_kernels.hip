@@ -1073,6 +1073,7 @@ __global__ __launch_bounds__(64) void phase_keep_k(const uint32_t* __restrict__ 
     if (threadIdx.x == 0) keep[g] = m;
 }
 
+#ifdef M3D_EXPERIMENTAL
 // score_screen4_k: the same counting with four-wave workgroups that share one compacted id list (score_screen_body, WAVES = 4)
 template <int KIND>
 __global__ __launch_bounds__(256) void score_screen4_k(const double* __restrict__ sx, const double* __restrict__ sy,
@@ -1090,6 +1091,7 @@ __global__ __launch_bounds__(256) void score_screen4_k(const double* __restrict_
                                       groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, blockIdx.x,
                                       blockIdx.y, nullptr, tile_f32, has_dead);
 }
+#endif   // M3D_EXPERIMENTAL
 
 // cull_lead_k: ONE launch for the two latency-bound steps at the head of a fit's first chunk -- the box tests of the
 // chunk's hypotheses (cull_tiles32_k's workgroups) and the counting of its leading hypotheses (score_screen_k's, with
@@ -1396,8 +1398,10 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
                        const unsigned long long* keep, uint32_t n_groups, uint32_t* counts_rep, uint32_t rep_stride,
                        uint32_t* pair_rep, hipStream_t st, uint32_t group_begin, uint32_t group_end, hipEvent_t ev_start,
                        hipEvent_t ev_stop, bool thinned) {
+#ifdef M3D_EXPERIMENTAL
     if (launch_score_mfma(kind, s, score, masks, keep, n_groups, counts_rep, rep_stride, pair_rep, st, group_begin, group_end, ev_start, ev_stop))
         return;
+#endif
     group_end = std::min(group_end, n_groups);
     if (!s.n_tiles || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
@@ -1414,6 +1418,7 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
         if (ev_start && ev_stop) hipExtLaunchKernelGGL(kernel, g, b, 0, st, ev_start, ev_stop, 0, args...);
         else kernel<<<g, b, 0, st>>>(args...);
     };
+#ifdef M3D_EXPERIMENTAL
     // windows of many groups: four-wave workgroups over up to 64 groups each (m3d_config.score_waves4)
     const uint32_t gpb4 = std::min<uint32_t>(kScreen4MaxGroups, (uint32_t)std::max(1, config().score_waves4_groups));
     if (screened && config().score_waves4 != 0 && window >= 24u) {
@@ -1431,6 +1436,7 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
         else go4(score_screen4_k<2>);
         return;
     }
+#endif   // M3D_EXPERIMENTAL
     if (screened) {
         if (kind == 0)
             go(score_screen_k<0>, s.x, s.y, s.z, s.boxes, s.max_abs, score, masks, keep, n_groups, gpb, counts_rep, rep_stride, pair_rep,

@@ -2740,6 +2740,11 @@ int m3d_bench_fp64_issue_rate(int device, double ms_target, double* tops, double
 int m3d_bench_mfma_probe(int device, const double* xyz512, const double box[6], double max_abs, const double* records, size_t n_h,
                          double* out_q, double* out_h, float* out_off) {
     if (!xyz512 || !box || !records || !n_h || !out_q || !out_h || !out_off || n_h > (1u << 20)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+#ifndef M3D_EXPERIMENTAL
+    (void)device;
+    (void)max_abs;
+    return fail(M3D_ERR_INVALID_ARG, "the MFMA screen is compiled with -DM3D_EXPERIMENTAL only (m3d_bench_experimental() == 0)");
+#else
     LaneLock lane(device);
     DeviceCtx* ctx = lane.ctx;
     if (!ctx) return M3D_ERR_DEVICE;
@@ -2770,7 +2775,10 @@ int m3d_bench_mfma_probe(int device, const double* xyz512, const double box[6], 
     HIPCHK(hipMemcpyAsync(out_off, d_off.p, sizeof(float) * 512 * 3, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return M3D_OK;
+#endif
 }
+
+int m3d_bench_experimental(void) { return kExperimentalBuild ? 1 : 0; }
 
 int m3d_cloud_exact_error(m3d_cloud* c, int kind, double threshold, const double* model,
                           uint64_t* count, double* error) {

@@ -597,7 +597,7 @@ __device__ __forceinline__ void fold_moment_partials(const CompactTail& tail) {
 // order: the same sums.  The output is the two-pass output, position for position.
 // MEASURED (profiles/r04_compact_one_pass.txt): slower than the two launches -- a segmentation round on ~1 M points 101 us
 // against 89, the C2 step +8 us: a published count reaches the other XCDs through memory, and the ~490 workgroups' waits for
-// it cost more than the ~5 us launch boundary.  Opt-in (m3d_config.compact_one_pass), kept as the tested alternative.
+// it cost more than the ~5 us launch boundary.  Compiled with -DM3D_EXPERIMENTAL only (then m3d_config.compact_one_pass switches it on).
 // ONE = false: `slots` holds compact_count_k's raw counts (m3d_config.compact_one_pass = 0, or more tiles than fit the chip).
 template <int KIND, int MODE, bool ONE, bool SUMS>
 __global__ __launch_bounds__(256) void compact_write_k(
@@ -795,7 +795,7 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
         return;
     }
     const bool sums = moment_partial && moment_out && mode == 0 && KIND != 2;
-    const bool one = config().compact_one_pass != 0 && nb <= kCompactOnePassMaxTiles && scratch.tag != 0u;
+    const bool one = kExperimentalBuild && config().compact_one_pass != 0 && nb <= kCompactOnePassMaxTiles && scratch.tag != 0u;
     uint32_t* block_counts = scratch.slots;
     const uint32_t tag = scratch.tag;
     if (!one) {
@@ -815,24 +815,34 @@ static void launch_compact_kind(const CloudView& c, const double* model, double 
     constexpr int KS = KIND == 2 ? 0 : KIND;   // (the moments are a plane's or a sphere's: `sums` is false for cylinders)
 #define M3D_COMPACT_GO(MODE_, ONE_, SUMS_, K_, ...) \
     compact_write_k<K_, MODE_, ONE_, SUMS_><<<nb, 256, 0, s>>>(c, model, thr, __VA_ARGS__, tail, model_copy, moment_partial)
-    if (mode == 0 && part && orig) {
-        if (one && sums) M3D_COMPACT_GO(4, true, true, KS, orig, block_counts, tag, out_idx, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap, out_idx_host);
-        else if (one) M3D_COMPACT_GO(4, true, false, KIND, orig, block_counts, tag, out_idx, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap, out_idx_host);
-        else M3D_COMPACT_GO(4, false, false, KIND, orig, block_counts, tag, out_idx, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap, out_idx_host);
-    } else if (mode == 0) {
-        if (one && sums) M3D_COMPACT_GO(0, true, true, KS, orig, block_counts, tag, out_idx, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, out_idx_host);
-        else if (one) M3D_COMPACT_GO(0, true, false, KIND, orig, block_counts, tag, out_idx, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, out_idx_host);
-        else M3D_COMPACT_GO(0, false, false, KIND, orig, block_counts, tag, out_idx, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, out_idx_host);
-    } else if (mode == 1) {
-        if (one) M3D_COMPACT_GO(1, true, false, KIND, orig, block_counts, tag, nullptr, out_dist, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
-        else M3D_COMPACT_GO(1, false, false, KIND, orig, block_counts, tag, nullptr, out_dist, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
-    } else if (mode == 2) {
-        if (one) M3D_COMPACT_GO(2, true, false, KIND, orig, block_counts, tag, nullptr, nullptr, ox, oy, oz, oorig, n_pad_out, nullptr);
-        else M3D_COMPACT_GO(2, false, false, KIND, orig, block_counts, tag, nullptr, nullptr, ox, oy, oz, oorig, n_pad_out, nullptr);
-    } else {
-        if (one) M3D_COMPACT_GO(3, true, false, KIND, nullptr, block_counts, tag, nullptr, nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr);
-        else M3D_COMPACT_GO(3, false, false, KIND, nullptr, block_counts, tag, nullptr, nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr);
-    }
+    // the one-launch forms exist in experimental builds only (kExperimentalBuild: the branch is discarded, not instantiated)
+#define M3D_COMPACT_PICK(MODE_, WITH_SUMS_, ...)                                              \
+    do {                                                                                      \
+        if constexpr (kExperimentalBuild) {                                                   \
+            if constexpr (WITH_SUMS_) {                                                       \
+                if (one && sums) {                                                            \
+                    M3D_COMPACT_GO(MODE_, true, true, KS, __VA_ARGS__);                       \
+                    break;                                                                    \
+                }                                                                             \
+            }                                                                                 \
+            if (one) {                                                                        \
+                M3D_COMPACT_GO(MODE_, true, false, KIND, __VA_ARGS__);                        \
+                break;                                                                        \
+            }                                                                                 \
+        }                                                                                     \
+        M3D_COMPACT_GO(MODE_, false, false, KIND, __VA_ARGS__);                               \
+    } while (0)
+    if (mode == 0 && part && orig)
+        M3D_COMPACT_PICK(4, true, orig, block_counts, tag, out_idx, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap, out_idx_host);
+    else if (mode == 0)
+        M3D_COMPACT_PICK(0, true, orig, block_counts, tag, out_idx, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, out_idx_host);
+    else if (mode == 1)
+        M3D_COMPACT_PICK(1, false, orig, block_counts, tag, nullptr, out_dist, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
+    else if (mode == 2)
+        M3D_COMPACT_PICK(2, false, orig, block_counts, tag, nullptr, nullptr, ox, oy, oz, oorig, n_pad_out, nullptr);
+    else
+        M3D_COMPACT_PICK(3, false, nullptr, block_counts, tag, nullptr, nullptr, ox, oy, oz, nullptr, n_pad_out, nullptr);
+#undef M3D_COMPACT_PICK
 #undef M3D_COMPACT_GO
 }
 

@@ -13,6 +13,17 @@ constexpr int kScoreBlock = 256;    // threads per scoring workgroup (4 waves)
 constexpr int kScoreTile = kScoreBlock * kScoreP;  // points per scoring workgroup
 constexpr int kCompactTile = 2048;  // points per compaction workgroup
 
+// -DM3D_EXPERIMENTAL (make DEFS=-DM3D_EXPERIMENTAL): the three variants round 4 built, measured and refuted are compiled in
+// and m3d_config.score_mfma / score_waves4 / compact_one_pass switch them on -- score_mfma_k (m3d_score_mfma.hip: the planes'
+// screen on the matrix pipe, profiles/r04_score_mfma.txt), score_screen4_k (four-wave scoring workgroups,
+// profiles/r04_score_waves4.txt), compact_write_k<.., ONE> (the ordered compaction as one launch,
+// profiles/r04_compact_one_pass.txt).  The product library is built without them: the three switches are then ignored.
+#ifdef M3D_EXPERIMENTAL
+constexpr bool kExperimentalBuild = true;
+#else
+constexpr bool kExperimentalBuild = false;
+#endif
+
 // SoA view of a resident cloud.  Arrays are padded to a multiple of kScoreTile with NaN so the
 // scoring kernels need no bounds checks (a NaN coordinate is never an inlier).
 struct CloudView {

@@ -1279,6 +1279,8 @@ int m3d::information_matrix_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst,
                                uint64_t* n_correspondences) {
     Scratch S;
     DevBuf mx, my, mz, nn, d2;
+    for (int k = 0; k < 36; ++k) info[k] = 0.0;   // (the entries the sums below do not touch are zeros of the matrix)
+    if (n_correspondences) *n_correspondences = 0;
     int rc;
     {
         rc = [&]() -> int {

@@ -28,6 +28,7 @@ def _same_result(g, o, n_min):
     assert ok == ook
     assert np.array_equal(T.view(np.uint64), oT.view(np.uint64))          # same hypothesis, same arithmetic
     assert info[5, 5] == oinfo[5, 5]                                      # the correspondence count is exact
+    assert np.array_equal(info == 0.0, oinfo == 0.0)                      # the structural zeros are zeros
     assert np.allclose(info, oinfo, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(oinfo).max()))
     if ok and not np.array_equal(oinfo, np.eye(6)):
         assert info[5, 5] / n_min >= 0.3

@@ -14,6 +14,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _needs_experimental_build(capi):
+    if not capi.experimental():
+        pytest.skip("score_mfma_k is compiled with -DM3D_EXPERIMENTAL only (misc3d_amd/csrc/m3d_kernels.hpp)")
+
+
 def _tile(rng, extent, centre, flat=None):
     pts = centre + (rng.random((512, 3)) - 0.5) * 2 * np.asarray(extent)
     if flat is not None:

@@ -21,14 +21,23 @@ def _bits(a):
 PATHS = {"culled": {}, "dense": {"dense_scoring": 1}, "no_early_pick": {"speculative_refine": 0},
          "small_blocks": {"score_groups_per_block": 1, "lead_hypotheses": 64},
          "fp64_only": {"score_fp32_screen": 0, "cull_fp32": 0},
-         "mfma": {"score_mfma": 1},   # planes: score_mfma_k, the screen on the matrix pipe
-         "four_wave_wgs": {"score_waves4": 1},
          "single_launch": {"score_phases": 0},   # (default -1: cylinders in three phases with re-pruning in between, the others in one)
          "two_phases": {"score_phases": 2}, "three_phases": {"score_phases": 3},
-         "one_pass_compaction": {"compact_one_pass": 1},   # compact_write_k, ONE: counts published and awaited inside the launch
          "plane_bound_always": {"plane_bound": 2},   # planes: the histogram bound (m3d_bound.hip) at every size (default: long fits of large clouds)
          "plane_bound_off": {"plane_bound": 0},
          "plane_bound_fp64_paths": {"plane_bound": 2, "score_fp32_screen": 0, "cull_fp32": 0}}   # (no fp32 box-test records: plane_bound_k reads the mask words)
+
+# round 4's refuted variants: compiled with `make DEFS=-DM3D_EXPERIMENTAL` only (m3d_kernels.hpp) -- their rows join the matrix
+# when the library under test is such a build
+EXPERIMENTAL_PATHS = {"mfma": {"score_mfma": 1},   # planes: score_mfma_k, the screen on the matrix pipe
+                      "four_wave_wgs": {"score_waves4": 1},
+                      "one_pass_compaction": {"compact_one_pass": 1}}   # compact_write_k, ONE: counts published and awaited inside the launch
+try:
+    from misc3d_amd import capi as _capi_probe
+    if _capi_probe.experimental():
+        PATHS.update(EXPERIMENTAL_PATHS)
+except Exception:      # noqa: BLE001  (no library: the GPU tests cannot run anyway)
+    pass
 
 
 @pytest.fixture(params=sorted(PATHS))

@@ -13,7 +13,7 @@ spec = importlib.util.spec_from_file_location("stress_round3", os.path.join(ROOT
 mod = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(mod)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
-for seed, cfg in ((201, {}), (202, {"plane_bound": 2}), (203, {"plane_bound": 2, "compact_one_pass": 1}),
+for seed, cfg in ((201, {}), (202, {"plane_bound": 2}), (203, {"plane_bound": 2, "lanes": 1}),
                   (204, {"plane_bound": 2, "score_fp32_screen": 0, "cull_fp32": 0})):
     old = capi.set_config(**cfg)
     try:
