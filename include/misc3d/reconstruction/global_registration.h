@@ -54,7 +54,7 @@ struct MatchingResult {
 
 // The loop-closure part of BuildPoseGraphForScene (pipeline.cpp:415-440): every pair (s, t) of `pairs` registered with
 // GlobalRegistration -- the reference spawns one std::thread per pair; here the pairs are dealt to `devices` and every
-// device keeps `inflight` of them in flight on lanes of its own (m3d_global_registration_batch).  seeds: one per pair, or
+// device keeps `inflight` of them in flight on lanes of its own, its fragments resident (m3d_register_fragment_pairs).  seeds: one per pair, or
 // empty for std::random_device.  A failed pair (success_ false) carries identity pose / information, as
 // RegisterFragmentPair leaves it (pipeline.cpp:770-775).
 inline std::vector<MatchingResult> RegisterFragmentPairs(const std::vector<CloudView>& fragments,
@@ -65,31 +65,32 @@ inline std::vector<MatchingResult> RegisterFragmentPairs(const std::vector<Cloud
                                                          const std::vector<int>& devices = {0}, int inflight = 0) {
     if (fragments.size() != features.size()) LogError("one feature set per fragment is required");
     if (!seeds.empty() && seeds.size() != pairs.size()) LogError("one seed per pair (or none) is required");
-    std::vector<m3d_fragment_pair> fp(pairs.size());
-    int dim = features.empty() ? 0 : features[0].dim;
+    std::vector<m3d_fragment_view> fv(fragments.size());
+    const int dim = features.empty() ? 0 : features[0].dim;
+    for (size_t i = 0; i < fragments.size(); ++i) {
+        if (features[i].dim != dim || features[i].n != fragments[i].n)
+            LogError("one descriptor per point and equal descriptor widths are required");
+        fv[i].xyz = fragments[i].xyz;
+        fv[i].feat = features[i].data;
+        fv[i].n = fragments[i].n;
+    }
+    std::vector<m3d_pair_result> fp(pairs.size());
     for (size_t k = 0; k < pairs.size(); ++k) {
         const int s = pairs[k].first, t = pairs[k].second;
         if (s < 0 || t < 0 || (size_t)s >= fragments.size() || (size_t)t >= fragments.size())
             LogError("fragment index out of range");
-        if (features[s].dim != dim || features[t].dim != dim || features[s].n != fragments[s].n ||
-            features[t].n != fragments[t].n)
-            LogError("one descriptor per point and equal descriptor widths are required");
-        m3d_fragment_pair& p = fp[k];
-        p = m3d_fragment_pair{};
-        p.src = fragments[s].xyz;
-        p.n_src = fragments[s].n;
-        p.dst = fragments[t].xyz;
-        p.n_dst = fragments[t].n;
-        p.feat_src = features[s].data;
-        p.feat_dst = features[t].data;
+        fp[k] = m3d_pair_result{};
+        fp[k].s = s;
+        fp[k].t = t;
         if (!seeds.empty()) {
-            p.seed = seeds[k];
-            p.has_seed = 1;
+            fp[k].seed = seeds[k];
+            fp[k].has_seed = 1;
         }
     }
-    CheckStatus(m3d_global_registration_batch(fp.data(), fp.size(), dim, opt.voxel_size, opt.max_iter,
-                                              opt.edge_length_threshold, opt.confidence, devices.data(), (int)devices.size(),
-                                              inflight));
+    // every fragment is uploaded once per device and stays resident for the call (m3d_register_fragment_pairs)
+    CheckStatus(m3d_register_fragment_pairs(fv.data(), fv.size(), dim, fp.data(), fp.size(), opt.voxel_size, opt.max_iter,
+                                            opt.edge_length_threshold, opt.confidence, devices.data(), (int)devices.size(),
+                                            inflight));
     std::vector<MatchingResult> out(pairs.size());
     static const Matrix4d I4 = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (size_t k = 0; k < pairs.size(); ++k) {

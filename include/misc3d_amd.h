@@ -337,6 +337,28 @@ int m3d_global_registration_batch(m3d_fragment_pair *pairs, size_t n_pairs, int 
                                   double edge_length_threshold, double confidence, const int *devices, int n_dev,
                                   int inflight);
 
+/* The same loop as the reference holds its data (preprocessed_fragment_lists_ / fragment_features_ + pairs (s, t) by index,
+ * src/pipeline.cpp:415-440): every fragment a device needs is uploaded to it ONCE, by the first pair that asks for it, and
+ * stays resident for the call -- a fragment of the all-pairs loop is otherwise uploaded n - 1 times.  Pair k runs on
+ * devices[k % n_dev], `inflight` pairs at a time per device.  Results: those of m3d_global_registration on the same arrays
+ * and seeds.  Returns the first failed pair's (negative) code, else M3D_OK; every pair carries its own rc. */
+typedef struct m3d_fragment_view {
+    const double *xyz;  /* n x 3 */
+    const double *feat; /* n x dim */
+    size_t n;
+} m3d_fragment_view;
+typedef struct m3d_pair_result {
+    int32_t s, t;                /* in: fragment indices (source, target) */
+    int32_t has_seed;            /* in: 0 = std::random_device */
+    int32_t rc;                  /* out: M3D_OK accepted / M3D_FALSE rejected / < 0 error */
+    uint64_t seed;               /* in */
+    double T[16], info[36];      /* out */
+    m3d_global_reg_stats stats;  /* out */
+} m3d_pair_result;
+int m3d_register_fragment_pairs(const m3d_fragment_view *frags, size_t n_frags, int dim, m3d_pair_result *pairs,
+                                size_t n_pairs, double voxel_size, int max_iter, double edge_length_threshold,
+                                double confidence, const int *devices, int n_dev, int inflight);
+
 /* ---- registration::ANNMatcher::Match, src/correspondence_matching.cpp:52-84 ------------------- */
 /* feat_*: Eigen MatrixXd dim x N column-major = N descriptors of dim contiguous doubles.
  * method: 0 FLANN, 1 ANNOY (correspondence_matching.h MatchMethod); both run the exact mutual

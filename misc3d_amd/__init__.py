@@ -119,8 +119,9 @@ def _xyz(c):
 def _feat(f, n):
     """open3d Feature (.data: dim x N) or an ndarray, (N, dim) or (dim, N) -> (N, dim) C-contiguous"""
     import numpy as _np
-    a = _np.asarray(getattr(f, "data", f), dtype=_np.float64)
-    if hasattr(f, "data") or (a.ndim == 2 and a.shape[0] != n and a.shape[1] == n):
+    is_feature = not isinstance(f, _np.ndarray) and hasattr(f, "data")      # (an ndarray has a .data of its own: its buffer)
+    a = _np.asarray(f.data if is_feature else f, dtype=_np.float64)
+    if is_feature or (a.ndim == 2 and a.shape[0] != n and a.shape[1] == n):
         a = a.T          # Eigen dim x N column-major == (N, dim) row-major: a transposed VIEW of the same memory
     return _np.ascontiguousarray(a)
 
@@ -154,9 +155,9 @@ class _Reconstruction:
         fts = [_feat(f, len(p)) for f, p in zip(features, pts)]
         if pairs is None:
             pairs = [(s, t) for s in range(len(pts)) for t in range(s + 1, len(pts))]
-        try:
-            res = _capi.global_registration_batch([(pts[s], pts[t], fts[s], fts[t]) for s, t in pairs], voxel_size, max_iter,
-                                                  edge_length_threshold, confidence, seeds, devices, inflight)
+        try:   # (every fragment is uploaded once per device and stays resident for the call)
+            res = _capi.register_fragment_pairs(pts, fts, pairs, voxel_size, max_iter, edge_length_threshold, confidence,
+                                                seeds, devices, inflight)
         except _capi.M3DError as e:
             raise RuntimeError(str(e)) from e
         return [(s, t) + r for (s, t), r in zip(pairs, res)]

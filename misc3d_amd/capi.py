@@ -1051,6 +1051,52 @@ def global_registration_batch(pairs, voxel_size, max_iter=100000, edge_length_th
     return out
 
 
+class FragmentView(C.Structure):
+    """m3d_fragment_view"""
+    _fields_ = [("xyz", C.c_void_p), ("feat", C.c_void_p), ("n", C.c_size_t)]
+
+
+class PairResult(C.Structure):
+    """m3d_pair_result"""
+    _fields_ = [("s", C.c_int32), ("t", C.c_int32), ("has_seed", C.c_int32), ("rc", C.c_int32), ("seed", C.c_uint64),
+                ("T", C.c_double * 16), ("info", C.c_double * 36), ("stats", GlobalRegStats)]
+
+
+def register_fragment_pairs(fragments, features, pairs, voxel_size, max_iter=100000, edge_length_threshold=0.9,
+                            confidence=0.999, seeds=None, devices=(0,), inflight=0, want_stats=False):
+    """m3d_register_fragment_pairs: fragments[i] (N_i, 3), features[i] (N_i, dim), pairs = [(s, t), ...] -> [(success, pose,
+    information[, stats]), ...]; every fragment is uploaded once per device and stays resident for the call."""
+    pts = [_f64(f).reshape(-1, 3) for f in fragments]
+    fts = [_f64(f) for f in features]
+    if len(pts) != len(fts) or any(f.ndim != 2 or len(f) != len(p) for f, p in zip(fts, pts)):
+        raise ValueError("one (N, dim) descriptor matrix per fragment")
+    if not pairs:
+        return []
+    dim = fts[0].shape[1]
+    if any(f.shape[1] != dim for f in fts):
+        raise ValueError("every fragment must use descriptors of the same width")
+    fv = (FragmentView * max(len(pts), 1))()
+    for i, (p_, f_) in enumerate(zip(pts, fts)):
+        fv[i].xyz, fv[i].feat, fv[i].n = _addr(p_), _addr(f_), len(p_)
+    pr = (PairResult * len(pairs))()
+    for k, (s_, t_) in enumerate(pairs):
+        pr[k].s, pr[k].t = int(s_), int(t_)
+        if seeds is not None and seeds[k] is not None:
+            pr[k].seed, pr[k].has_seed = int(seeds[k]) & 0xFFFFFFFFFFFFFFFF, 1
+    dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+    f = lib().m3d_register_fragment_pairs
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_double, C.c_double,
+                  C.c_void_p, C.c_int, C.c_int]
+    _check(f(C.cast(fv, C.c_void_p), len(pts), dim, C.cast(pr, C.c_void_p), len(pairs), float(voxel_size), int(max_iter),
+             float(edge_length_threshold), float(confidence), C.cast(dev, C.c_void_p), len(devices), int(inflight)))
+    out = []
+    for k in range(len(pairs)):
+        r = (pr[k].rc == 1, np.array(pr[k].T).reshape(4, 4), np.array(pr[k].info).reshape(6, 6))
+        out.append(r + (pr[k].stats.asdict(),) if want_stats else r)
+    return out
+
+
 class RegSession:
     """m3d_reg: compute_transformation_ransac cut into begin_chunk / validate / replay (multi-GPU driver:
     misc3d_amd.distributed.registration_ransac_sharded).  Every rank must pass the same explicit seed."""

@@ -476,15 +476,16 @@ static uint32_t lead_size() { return (uint32_t)config().lead_hypotheses; }
 static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
     // keep the per-chunk scratch below 1 GiB (dense: u32 partial count per (tile, hypothesis);
     // culled: one bit per (tile, hypothesis))
-    (void)sv;
     if (!use_dense_scoring()) {
         // hypotheses per chunk (m3d_config.chunk_cap).  A chunk boundary costs ~35 us (sum_replicas_k, keep_mask_k, their launch
         // boundaries), a chunk's sample table must be drawn while the chunk before it is on the GPU (a sphere's four draws per
         // hypothesis: 1.9 ns against ~7.5 ns of scoring), and the first chunk of a long fit is short (2048).  C3's 50 000
         // hypotheses: 16384 (four chunks) cylinder 0.998 / sphere 0.665 ms, 24576 (three) 0.985 / 0.659, 49152 (two) 0.944 / 0.689 --
         // the sphere's second chunk then waits for its samples.
-        const size_t cap = (size_t)config().chunk_cap;
-        return cap;
+        // ... and the slot's mask scratch (one bit per (tile, hypothesis), twice: two slots) stays below 1 GiB per slot whatever
+        // the cloud's size: 24576 hypotheses reach that at 350 000 tiles (180 M points) -- ADVICE r4
+        const size_t by_masks = sv.n_tiles ? std::max<size_t>(((size_t)1 << 30) / ((size_t)sv.n_tiles * 8), 16) * 64 : ~(size_t)0;
+        return std::min<size_t>((size_t)config().chunk_cap, by_masks);
     }
     const uint32_t rows = std::max<uint32_t>(1, v.n_pad / kScoreTile);
     const size_t cap = std::min<size_t>(16384, ((size_t)1 << 28) / rows / 64 * 64);
@@ -547,10 +548,19 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                                                         ever exist while it runs */,
                        bool pre = false /* a later chunk of a one-GPU fit: MinimalFit and the box tests go to ctx->pre_stream and
                                            run under the scoring launches of the chunk before (the main stream waits for
-                                           s.pre_done in front of the keep masks) */) {
+                                           s.pre_done in front of the keep masks) */,
+                       const double* move_best_from = nullptr /* the fit's best minimal model lives in THIS slot's params, which
+                                                                 the chunk is about to overwrite: moved to ctx->best_params
+                                                                 first, on the stream MinimalFit will run on */) {
     const int m = minimal_sample(kind);
     const uint32_t count = (uint32_t)(end - begin);
     const bool dense = use_dense_scoring();
+    // where the chunk's head runs -- decided ONCE, here, in front of everything that depends on it (the record
+    // move used to repeat a part of this condition in the caller)
+    pre = pre && !dense && prune && !new_fit && !comm && lead == 0 && !ctx->poison_pending && ctx->pre_stream && s.pre_done;
+    hipStream_t st_pre = pre ? ctx->pre_stream : ctx->stream;
+    if (move_best_from)   // (before the slot's buffers are touched: a RESERVE below may hand the old block back)
+        HIPCHK(hipMemcpyAsync(ctx->best_params.p, move_best_from, sizeof(double) * kModelStride, hipMemcpyDeviceToDevice, st_pre));
     const bool timing = config().kernel_timing != 0;
     if (comm && dense) return fail(M3D_ERR_INVALID_ARG, "sharded fits use the culled scoring path (m3d_config.dense_scoring = 0)");
     const uint32_t world = comm ? (uint32_t)comm->world : 1u, rank = comm ? (uint32_t)comm->rank : 0u;
@@ -608,8 +618,6 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
         lp.n_lead = all_prepared ? h_pad : lead;
         lp.n_pair = kPairReplicas;
     }
-    pre = pre && !dense && prune && !new_fit && !comm && lead == 0 && !ctx->poison_pending && ctx->pre_stream && s.pre_done;
-    hipStream_t st_pre = pre ? ctx->pre_stream : ctx->stream;
     const bool fit_launched =
         launch_minimal_fit(kind, v, s.h_samples.as<uint32_t>(), count, h_pad + 1, thr, s.score.as<double>(),
                        s.params.as<double>(), s.valid.as<uint8_t>(), st_pre,
@@ -1355,13 +1363,9 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         // a later chunk of a probability-1 fit on one GPU: its MinimalFit and box tests run on pre_stream, under the scoring
         // launches of the chunk before (issue_chunk, `pre`)
         const bool pre = prestream_on && prob >= 1.0 && !comm && next_begin > 0 && !use_dense_scoring() && !ctx->poison_pending;
-        if (slot_id == best_slot) {   // the slot holding the best model is recycled: move the record out first
-            // (on the stream that is about to overwrite the slot: MinimalFit of the new chunk)
-            HIPCHK(hipMemcpyAsync(ctx->best_params.p, best_dev, sizeof(double) * kModelStride, hipMemcpyDeviceToDevice,
-                                  pre ? ctx->pre_stream : ctx->stream));
-            best_dev = ctx->best_params.as<double>();
-            best_slot = -1;
-        }
+        // the slot holding the best model is recycled: issue_chunk moves the record out first, on the stream that is about
+        // to overwrite the slot (MinimalFit of the new chunk)
+        const double* move_best_from = slot_id == best_slot ? best_dev : nullptr;
         size_t want = chunk;
         if (forced) {
             want = forced;
@@ -1392,7 +1396,12 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         }
         int r = issue_chunk(ctx, ctx->slot[slot_id], v, sv, kind, thr, b, e, src, &out->ms_sample, true,
                             b == 0 ? lead : 0, b == 0, spec, comm, /*caller_ships_records=*/spec && !fused_pick,
-                            fused_pick ? &pf : nullptr, /*nothing_to_prune=*/b == 0 && e == max_iter && lead == 0 && !comm, pre);
+                            fused_pick ? &pf : nullptr, /*nothing_to_prune=*/b == 0 && e == max_iter && lead == 0 && !comm, pre,
+                            move_best_from);
+        if (move_best_from && r == M3D_OK) {
+            best_dev = ctx->best_params.as<double>();
+            best_slot = -1;
+        }
         const bool spec_adaptive = spec_enabled && prob < 1.0 && hinted_chunk && b == 0 && !comm && !use_dense_scoring();
         if (r == M3D_OK && fused_pick && (spec || spec_adaptive) && e == max_iter) {   // last chunk: RefineModel's first stage on the prediction, now
             // (a segmentation round: the partition of the rest rides along, decided without the inlier count: -2)
@@ -1640,15 +1649,22 @@ static int ensure_plane_frames(m3d_cloud* c, int kind, size_t n_hypotheses) {
     // takes ~0.09 ms per million points, the bound saves ~0.02 ms per 10 000 hypotheses on them: m3d_fit_plane 0.95 -> 1.04 ms
     // otherwise); 2: always (tests)
     const int mode = config().plane_bound;
-    if (kind != M3D_PLANE || c->frames_ready || mode == 0 || c->work.active || c->n_tiles == 0 ||
+    if (kind != M3D_PLANE || c->frames_ready || c->frames_failed || mode == 0 || c->work.active || c->n_tiles == 0 ||
         (mode == 1 && (!bound_pays(c->n_tiles, std::min<size_t>(n_hypotheses, chunk_cap_for(c->view(), c->sorted()))) ||
                        (c->one_shot && n_hypotheses < 65536u))))
         return M3D_OK;
     DeviceCtx* ctx = c->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     if (!c->frames.reserve(sizeof(double) * kFrameStride * (size_t)c->n_tiles) ||
-        !c->frame_cum.reserve(sizeof(uint16_t) * kCumStride * (size_t)c->n_tiles))
-        return fail(M3D_ERR_DEVICE, "out of device memory (tile frames)");
+        !c->frame_cum.reserve(sizeof(uint16_t) * kCumStride * (size_t)c->n_tiles)) {
+        // the bound is an optimisation: without it the keep rule prices a hypothesis at 512 points per touched tile and the
+        // fit returns the same result -- a cloud that cannot have its frames (memory pressure) fits without, and is not
+        // asked again
+        c->frames.release();
+        c->frame_cum.release();
+        c->frames_failed = true;
+        return M3D_OK;
+    }
     launch_tile_frames(c->sorted(), c->frames.as<double>(), c->frame_cum.as<uint16_t>(), ctx->stream);
     HIPCHK(hipGetLastError());
     c->frames_ready = true;

@@ -150,8 +150,17 @@ struct DeviceCtx {
 
 constexpr int kMaxLanes = 8;
 // entry points' bodies on a lane the caller already holds (m3d_registration.cpp); arguments checked by the callers
-int match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src, const double* feat_dst, size_t n_dst, int dim,
+// one side of a match: the caller's array (uploaded by the call), or descriptors already resident on the device (dev != null;
+// max_abs: their largest |value|, NaN if any, < 0 when unknown)
+struct MatchSide {
+    const double* host;
+    const double* dev;
+    double max_abs;
+};
+int match_mutual_nn_on(DeviceCtx* ctx, const MatchSide& feat_src, size_t n_src, const MatchSide& feat_dst, size_t n_dst, int dim,
                        size_t* out_src, size_t* out_dst, size_t* k_out);
+// largest |value| of n doubles on the device (NaN if any is NaN), with a round trip; the lane's stream
+int device_max_abs(DeviceCtx* ctx, const double* dev, size_t n, double* out);
 int registration_ransac_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, const double* src, size_t n_src,
                            const double* dst, size_t n_dst, const size_t* corr_src, const size_t* corr_dst, size_t m,
                            double threshold, int max_iter, double edge_length_threshold, double confidence,
@@ -205,6 +214,7 @@ struct m3d_cloud {
     m3d::DevBuf tile_f32;   // SortedView::tile_f32 (n_tiles x kTileF32Floats floats)
     m3d::DevBuf frames, frame_cum;   // SortedView::frames / frame_cum (m3d_bound.hip), built by the first long plane fit (ensure_plane_frames)
     bool frames_ready = false;
+    bool frames_failed = false;      // their allocation failed once: this cloud's plane fits go without the histogram bound
     bool one_shot = false;           // created for ONE fit (one_shot_fit): set-up that pays off over several fits is skipped
     uint32_t n_sorted = 0, n_tiles = 0;
     double max_abs = __builtin_inf();   // largest |coordinate| of the finite points (SortedView::max_abs)

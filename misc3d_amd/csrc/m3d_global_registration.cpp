@@ -19,6 +19,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -65,11 +67,25 @@ int check_pair_args(const double* src, size_t n_src, const double* dst, size_t n
     return M3D_OK;
 }
 
-// the pair on a lane the caller holds; arguments checked
+// A fragment resident on a device for the length of a batch call (m3d_register_fragment_pairs): its points as an m3d_cloud
+// (SoA + bounding box: what the solver and the information matrix read) and its descriptors as uploaded, with their largest
+// |value| (what the matcher's screen scales by).  Read-only once `ready`: any lane of the device may use it.
+struct ResidentFragment {
+    std::mutex mu;            // held while the fragment is being uploaded (the first pair that needs it does that)
+    bool ready = false, failed = false;
+    std::string error;
+    m3d_cloud* cloud = nullptr;
+    DevBuf feat;
+    double max_abs = -1.0;
+};
+
+// the pair on a lane the caller holds; arguments checked.  rs / rt: the pair's fragments if they are resident (else null:
+// uploaded here from src / dst / feat_*).
 int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, const double* dst, size_t n_dst,
                            const double* feat_src, const double* feat_dst, int dim, double voxel_size, int max_iter,
                            double edge_length_threshold, double confidence, const uint64_t* seed, double* T, double* info,
-                           m3d_global_reg_stats* stats) {
+                           m3d_global_reg_stats* stats, const ResidentFragment* rs = nullptr,
+                           const ResidentFragment* rt = nullptr) {
     const double t0 = now_ms();
     const double max_dis = voxel_size * 1.4;   // pipeline.cpp:796
     static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -88,7 +104,9 @@ int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, cons
     // ---- ANNMatcher::Match (:800-802)
     std::vector<size_t> cs(n_src), cd(n_src);
     size_t m = 0;
-    int rc = match_mutual_nn_on(ctx, feat_src, n_src, feat_dst, n_dst, dim, cs.data(), cd.data(), &m);
+    const MatchSide ms = rs ? MatchSide{nullptr, rs->feat.as<double>(), rs->max_abs} : MatchSide{feat_src, nullptr, -1.0};
+    const MatchSide mt = rt ? MatchSide{nullptr, rt->feat.as<double>(), rt->max_abs} : MatchSide{feat_dst, nullptr, -1.0};
+    int rc = match_mutual_nn_on(ctx, ms, n_src, mt, n_dst, dim, cs.data(), cd.data(), &m);
     if (rc != M3D_OK) return leave(rc);
     st.n_matches = m;
     const double t1 = now_ms();
@@ -96,12 +114,12 @@ int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, cons
     // ---- RANSACSolver(max_dis).Solve (:806-807).  With fewer than 3 matches or max_dis <= 0 Open3D returns the default
     // RegistrationResult -- the identity -- without touching the clouds: the shortcut below (:814-816) ends the call.
     const bool trivial = m < 3 || !(max_dis > 0.0);
-    m3d_cloud *csrc = nullptr, *cdst = nullptr;
+    m3d_cloud *csrc = rs ? rs->cloud : nullptr, *cdst = rt ? rt->cloud : nullptr;
     if (!trivial) {
-        csrc = m3d_cloud_create_on(ctx, src, nullptr, n_src, 0);
-        cdst = csrc ? m3d_cloud_create_on(ctx, dst, nullptr, n_dst, 0) : nullptr;
+        if (!csrc) csrc = m3d_cloud_create_on(ctx, src, nullptr, n_src, 0);
+        if (csrc && !cdst) cdst = m3d_cloud_create_on(ctx, dst, nullptr, n_dst, 0);
         if (!csrc || !cdst) {
-            if (csrc) m3d_cloud_destroy_on(csrc);
+            if (csrc && !rs) m3d_cloud_destroy_on(csrc);
             return leave(M3D_ERR_DEVICE);
         }
     }
@@ -126,8 +144,8 @@ int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, cons
             st.ms_info = now_ms() - t2;
         }
     }
-    if (csrc) m3d_cloud_destroy_on(csrc);
-    if (cdst) m3d_cloud_destroy_on(cdst);
+    if (csrc && !rs) m3d_cloud_destroy_on(csrc);
+    if (cdst && !rt) m3d_cloud_destroy_on(cdst);
     return leave(rc);
 }
 
@@ -196,6 +214,112 @@ int m3d_global_registration_batch(m3d_fragment_pair* pairs, size_t n_pairs, int 
     for (auto& t : th) t.join();
     for (size_t k = 0; k < n_pairs; ++k)
         if (pairs[k].rc < 0) {   // the first failed pair's message is the call's; every pair keeps its own code
+            set_error("pair " + std::to_string(k) + ": " + errs[k]);
+            return pairs[k].rc;
+        }
+    return M3D_OK;
+}
+
+// BuildPoseGraphForScene as the reference holds its data: n fragments, pairs by index.  Every fragment a device needs is
+// uploaded to it ONCE -- by the first pair that asks for it, on that pair's lane -- and stays resident for the call (288 GB of
+// HBM: 58 MB per 200 000-point fragment with 33-D descriptors); a pair then costs no host-to-device traffic beyond its
+// correspondences.  Results are those of m3d_global_registration on the same arrays and seeds.
+int m3d_register_fragment_pairs(const m3d_fragment_view* frags, size_t n_frags, int dim, m3d_pair_result* pairs,
+                                size_t n_pairs, double voxel_size, int max_iter, double edge_length_threshold,
+                                double confidence, const int* devices, int n_dev, int inflight) {
+    if ((!frags && n_frags) || (!pairs && n_pairs) || !devices || n_dev < 1) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    for (int a = 0; a < n_dev; ++a)
+        for (int b = a + 1; b < n_dev; ++b)
+            if (devices[a] == devices[b]) return fail(M3D_ERR_INVALID_ARG, "devices must be distinct");
+    static const double I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (size_t k = 0; k < n_pairs; ++k) {
+        pairs[k].rc = M3D_ERR_INTERNAL;
+        std::memcpy(pairs[k].T, I4, sizeof(I4));
+        identity6(pairs[k].info);
+        std::memset(&pairs[k].stats, 0, sizeof(pairs[k].stats));
+        if (pairs[k].s < 0 || pairs[k].t < 0 || (size_t)pairs[k].s >= n_frags || (size_t)pairs[k].t >= n_frags)
+            return fail(M3D_ERR_INVALID_ARG, "pair " + std::to_string(k) + ": fragment index out of range");
+    }
+    if (n_pairs == 0) return M3D_OK;
+    for (int d = 0; d < n_dev; ++d)
+        if (!get_ctx(devices[d])) return M3D_ERR_DEVICE;
+    const int lanes = lane_count();
+    const int per_dev = std::min(inflight > 0 ? inflight : lanes, lanes);
+    std::vector<std::unique_ptr<ResidentFragment[]>> resident((size_t)n_dev);
+    for (auto& r : resident) r.reset(new ResidentFragment[n_frags]);
+    // the fragment on this device, uploaded now if nobody has yet (the caller holds lane `ctx`)
+    auto fetch = [&](int d, DeviceCtx* ctx, size_t i, const ResidentFragment** out) -> int {
+        ResidentFragment& r = resident[(size_t)d][i];
+        std::lock_guard<std::mutex> lock(r.mu);
+        if (!r.ready && !r.failed) {
+            const m3d_fragment_view& f = frags[i];
+            int rc = M3D_OK;
+            r.cloud = m3d_cloud_create_on(ctx, f.xyz, nullptr, f.n, 0);
+            if (!r.cloud) rc = M3D_ERR_DEVICE;
+            const size_t bytes = sizeof(double) * (size_t)dim * f.n;
+            if (rc == M3D_OK && !r.feat.reserve(std::max<size_t>(bytes, 8))) rc = M3D_ERR_DEVICE;
+            if (rc == M3D_OK &&
+                (hipMemcpyAsync(r.feat.p, f.feat, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                 hipStreamSynchronize(ctx->stream) != hipSuccess))
+                rc = fail(M3D_ERR_DEVICE, "fragment upload failed");
+            if (rc == M3D_OK && dim == 33) rc = device_max_abs(ctx, r.feat.as<double>(), f.n * 33, &r.max_abs);
+            if (rc == M3D_OK) {
+                r.ready = true;
+            } else {
+                r.failed = true;
+                r.error = m3d_last_error();
+            }
+        }
+        if (r.failed) return fail(M3D_ERR_DEVICE, "fragment " + std::to_string(i) + ": " + r.error);
+        *out = &r;
+        return M3D_OK;
+    };
+    std::vector<std::atomic<size_t>> next((size_t)n_dev);
+    for (auto& a : next) a.store(0);
+    std::vector<std::string> errs(n_pairs);
+    auto worker = [&](int d, int w) {
+        for (;;) {
+            const size_t j = next[(size_t)d].fetch_add(1);
+            const size_t k = j * (size_t)n_dev + (size_t)d;
+            if (k >= n_pairs) break;
+            m3d_pair_result& p = pairs[k];
+            const m3d_fragment_view &fs = frags[p.s], &ft = frags[p.t];
+            int rc = check_pair_args(fs.xyz, fs.n, ft.xyz, ft.n, fs.feat, ft.feat, dim, voxel_size, p.T, p.info);
+            if (rc == M3D_OK) {
+                LaneLock lane(devices[d], w);
+                const ResidentFragment *rs = nullptr, *rt = nullptr;
+                if (!lane.ctx) rc = M3D_ERR_DEVICE;
+                if (rc == M3D_OK) rc = fetch(d, lane.ctx, (size_t)p.s, &rs);
+                if (rc == M3D_OK) rc = fetch(d, lane.ctx, (size_t)p.t, &rt);
+                if (rc == M3D_OK)
+                    rc = global_registration_on(lane.ctx, fs.xyz, fs.n, ft.xyz, ft.n, fs.feat, ft.feat, dim, voxel_size, max_iter,
+                                                edge_length_threshold, confidence, p.has_seed ? &p.seed : nullptr, p.T, p.info,
+                                                &p.stats, rs, rt);
+            }
+            p.rc = rc;
+            if (rc < 0) errs[k] = m3d_last_error();
+        }
+    };
+    std::vector<std::thread> th;
+    const size_t busiest = (n_pairs + (size_t)n_dev - 1) / (size_t)n_dev;
+    for (int d = 0; d < n_dev; ++d)
+        for (int w = 0; w < per_dev && (size_t)w < busiest; ++w)
+            if (d || w) th.emplace_back(worker, d, w);
+    worker(0, 0);
+    for (auto& t : th) t.join();
+    for (int d = 0; d < n_dev; ++d) {   // every lane of the call has drained (each pair ends with its stream idle)
+        (void)hipSetDevice(devices[d]);
+        for (size_t i = 0; i < n_frags; ++i) {
+            ResidentFragment& r = resident[(size_t)d][i];
+            if (r.cloud) {
+                CtxLock lock(r.cloud->ctx);
+                m3d_cloud_destroy_on(r.cloud);
+            }
+            r.feat.release();
+        }
+    }
+    for (size_t k = 0; k < n_pairs; ++k)
+        if (pairs[k].rc < 0) {
             set_error("pair " + std::to_string(k) + ": " + errs[k]);
             return pairs[k].rc;
         }

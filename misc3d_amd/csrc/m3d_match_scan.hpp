@@ -10,7 +10,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // M3D_MATCH_HI_ONLY: the screen contracts the HI halves only -- K = 48, three MFMA steps per tile pair
 // instead of seven -- and pays with a wider bound: what is left out is 2 (a_hi . b_lo + a_lo . b_hi + a_lo . b_lo) with
-// |x_lo| <= 2^-11 |x| per element, i.e. at most 2^-9 |a| |b| <= 2^-10 (|a|^2 + |b|^2) = 9.8e-4 (...): kMfmaECoeff 1.1e-3.  The lo
+// |x_lo| <= 2^-11 |x| per element, i.e. at most 2^-9 |a| |b| <= 2^-10 (|a|^2 + |b|^2) = 9.8e-4, plus the 1e-4 of the full-width
+// screen's own rounding = 1.08e-3: kMfmaECoeff 1.2e-3 (11 % above the derived bound; 1.1e-3 left 2 % -- ADVICE r4).  The lo
 // halves then only matter to the verification kernels, which are fp64 anyway.
 #ifndef M3D_MATCH_HI_ONLY
 #define M3D_MATCH_HI_ONLY 1
@@ -18,7 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr bool kMfmaHiOnly = M3D_MATCH_HI_ONLY != 0;
 constexpr int kMfmaK = kMfmaHiOnly ? 48 : 112, kMfmaSteps = kMfmaK / 16;
 constexpr int kMfmaNormAt = kMfmaHiOnly ? 33 : 99;   // first K-slot of the norms' six pieces
-constexpr float kMfmaECoeff = kMfmaHiOnly ? 1.1e-3f : 1.0e-4f;
+constexpr float kMfmaECoeff = kMfmaHiOnly ? 1.2e-3f : 1.0e-4f;
 // Absolute part of the bound (scaled^2 units; data scaled to max |v| in [1024, 2048)): fp16 underflow.  Values far
 // below the largest one lose their lo piece to the subnormal spacing 2^-24 -- or to zero if the matrix core
 // flushes subnormal inputs (<= 6.1e-5 per element): 2 * 6.1e-5 * sum(|a_k| + |b_k|) <= 16.5, plus two norm

@@ -1436,14 +1436,17 @@ int m3d_match_mutual_nn(const double* feat_src, size_t n_src, const double* feat
     if (n_src >= ((size_t)1 << 31) || n_dst >= ((size_t)1 << 31)) return fail(M3D_ERR_INVALID_ARG, "too many points");
     LaneLock lane(device);
     if (!lane.ctx) return M3D_ERR_DEVICE;
-    return match_mutual_nn_on(lane.ctx, feat_src, n_src, feat_dst, n_dst, dim, out_src, out_dst, k_out);
+    return match_mutual_nn_on(lane.ctx, MatchSide{feat_src, nullptr, -1.0}, n_src, MatchSide{feat_dst, nullptr, -1.0}, n_dst, dim,
+                              out_src, out_dst, k_out);
 }
 }  // extern "C"
 
 // ... on a lane the caller holds (m3d_match_mutual_nn, global_registration_on); arguments already checked
-int m3d::match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src, const double* feat_dst, size_t n_dst,
+int m3d::match_mutual_nn_on(DeviceCtx* ctx, const MatchSide& side_src, size_t n_src, const MatchSide& side_dst, size_t n_dst,
                             int dim, size_t* out_src, size_t* out_dst, size_t* k_out) {
     HIPCHK(hipSetDevice(ctx->device));
+    const double* feat_src = side_src.host;
+    const double* feat_dst = side_dst.host;
     DevBuf fs, fd, bd, bi, nn01, nn10, fs32, fd32, ns2, nd2, ring, ring_count, evict, over_list, scal, pA_s, pA_d,
         pB_s, pB_d, premin, rev_premin, rthr, rcnt, rcand, rlist, rlist_cnt, over_list_r;
     auto done = [&](int r) {
@@ -1467,24 +1470,33 @@ int m3d::match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src
         return std::min<uint32_t>(s, std::max<uint32_t>(1, ndb / rows_per_unit));
     };
     uint32_t s01 = splits_for(ns, nd, 512, 256), s10 = splits_for(nd, ns, 512, 256);
-    if (!fs.reserve(sizeof(double) * (size_t)dim * ns) || !fd.reserve(sizeof(double) * (size_t)dim * nd) ||
+    // a side that is resident already (MatchSide::dev: a fragment's descriptors, m3d_global_registration.cpp) is not uploaded
+    if ((!side_src.dev && !fs.reserve(sizeof(double) * (size_t)dim * ns)) || (!side_dst.dev && !fd.reserve(sizeof(double) * (size_t)dim * nd)) ||
         !nn01.reserve(sizeof(uint32_t) * ns) || !nn10.reserve(sizeof(uint32_t) * nd) ||
         !scal.reserve(8192 + sizeof(double) * 2 * kMaxAbsPartials))
         return done(M3D_ERR_DEVICE);
     std::vector<uint32_t> h01(ns), h10(nd);
-    bool ok = hipMemcpyAsync(fs.p, feat_src, sizeof(double) * (size_t)dim * ns, hipMemcpyHostToDevice, ctx->stream) ==
-                  hipSuccess &&
-              hipMemcpyAsync(fd.p, feat_dst, sizeof(double) * (size_t)dim * nd, hipMemcpyHostToDevice, ctx->stream) ==
-                  hipSuccess;
+    const double* fs_p = side_src.dev ? side_src.dev : fs.as<double>();
+    const double* fd_p = side_dst.dev ? side_dst.dev : fd.as<double>();
+    bool ok = (side_src.dev || hipMemcpyAsync(fs.p, feat_src, sizeof(double) * (size_t)dim * ns, hipMemcpyHostToDevice, ctx->stream) ==
+                                   hipSuccess) &&
+              (side_dst.dev || hipMemcpyAsync(fd.p, feat_dst, sizeof(double) * (size_t)dim * nd, hipMemcpyHostToDevice, ctx->stream) ==
+                                   hipSuccess);
     double scale = 0.0;
     if (ok && use_mfma) {
         // power-of-two scale that brings max |v| to <= 2048 (fp16 hi/lo split keeps 22 bits; norms / 2^15 fit)
         double* part = scal.as<double>() + 16;   // 2 x kMaxAbsPartials partial maxima
-        launch_max_abs(fs.as<double>(), (size_t)ns * 33, part, ctx->stream);
-        launch_max_abs(fd.as<double>(), (size_t)nd * 33, part + kMaxAbsPartials, ctx->stream);
-        std::vector<double> hp(2 * kMaxAbsPartials);
-        ok = hipMemcpyAsync(hp.data(), part, sizeof(double) * 2 * kMaxAbsPartials, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-             hipStreamSynchronize(ctx->stream) == hipSuccess;
+        std::vector<double> hp(2 * kMaxAbsPartials, 0.0);
+        const bool known_s = side_src.dev && side_src.max_abs >= 0.0, known_d = side_dst.dev && side_dst.max_abs >= 0.0;
+        if (known_s && known_d) {   // (a resident side knows its max |v|, NaN included: no pass, no round trip)
+            hp[0] = side_src.max_abs;
+            hp[1] = side_dst.max_abs;
+        } else {
+            launch_max_abs(fs_p, (size_t)ns * 33, part, ctx->stream);
+            launch_max_abs(fd_p, (size_t)nd * 33, part + kMaxAbsPartials, ctx->stream);
+            ok = hipMemcpyAsync(hp.data(), part, sizeof(double) * 2 * kMaxAbsPartials, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                 hipStreamSynchronize(ctx->stream) == hipSuccess;
+        }
         double mx = 0.0;
         for (double v : hp) mx = (v > mx || v != v) ? v : mx;
         if (ok && mx > 0.0 && std::isfinite(mx) && mx < 1e300 && mx > 1e-300) {
@@ -1519,8 +1531,8 @@ int m3d::match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src
             !pB_s.reserve(tile_bytes * mfma_query_tiles(ns)) || !pB_d.reserve(tile_bytes * mfma_query_tiles(nd)) ||
             !premin.reserve(sizeof(float) * part))
             return done(M3D_ERR_DEVICE);
-        launch_pack_f16_both(fs.as<double>(), ns, scale, pA_s.p, pB_s.p, ns2.as<float>(), ctx->stream);
-        launch_pack_f16_both(fd.as<double>(), nd, scale, pA_d.p, pB_d.p, nd2.as<float>(), ctx->stream);
+        launch_pack_f16_both(fs_p, ns, scale, pA_s.p, pB_s.p, ns2.as<float>(), ctx->stream);
+        launch_pack_f16_both(fd_p, nd, scale, pA_d.p, pB_d.p, nd2.as<float>(), ctx->stream);
         launch_max_f32(ns2.as<float>(), ns, sc + 0, ctx->stream);
         launch_max_f32(nd2.as<float>(), nd, sc + 1, ctx->stream);
         float h_max[2] = {0.0f, 0.0f};
@@ -1537,7 +1549,7 @@ int m3d::match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src
                 !rlist_cnt.reserve(sizeof(uint32_t) * (size_t)slices01 * ns) || !over_list_r.reserve(sizeof(uint32_t) * nd))
                 return done(M3D_ERR_DEVICE);
             uint32_t over[2] = {0, 0};
-            ok = launch_nn_mfma33_both(fs.as<double>(), pB_s.p, pA_s.p, ns2.as<float>(), ns, h_max[0], fd.as<double>(),
+            ok = launch_nn_mfma33_both(fs_p, pB_s.p, pA_s.p, ns2.as<float>(), ns, h_max[0], fd_p,
                                        pB_d.p, pA_d.p, nd2.as<float>(), nd, h_max[1], s01, s10, premin.as<float>(),
                                        ring.as<uint2>(), ring_count.as<uint32_t>(), bd.as<float>(), evict.as<float>(),
                                        rev_premin.as<float>(), rthr.as<float>(), rcnt.as<uint32_t>(), rcand.as<uint2>(),
@@ -1552,26 +1564,26 @@ int m3d::match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src
         if (!fs32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)ns + 1)) ||
             !fd32.reserve(sizeof(float) * (size_t)kScreenDimP * ((size_t)nd + 1)))
             return done(M3D_ERR_DEVICE);
-        launch_to_f32_33(fs.as<double>(), ns, fs32.as<float>(), ns2.as<float>(), sc + 0, ctx->stream);
-        launch_to_f32_33(fd.as<double>(), nd, fd32.as<float>(), nd2.as<float>(), sc + 1, ctx->stream);
+        launch_to_f32_33(fs_p, ns, fs32.as<float>(), ns2.as<float>(), sc + 0, ctx->stream);
+        launch_to_f32_33(fd_p, nd, fd32.as<float>(), nd2.as<float>(), sc + 1, ctx->stream);
         float h_max[2] = {0.0f, 0.0f};
         ok = hipMemcpyAsync(h_max, sc, sizeof(h_max), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
-        ok = ok && launch_nn_screened33(fs.as<double>(), fs32.as<float>(), ns2.as<float>(), ns, fd.as<double>(),
+        ok = ok && launch_nn_screened33(fs_p, fs32.as<float>(), ns2.as<float>(), ns, fd_p,
                                         fd32.as<float>(), nd, h_max[1], s01, ring.as<uint2>(),
                                         ring_count.as<uint32_t>(), bd.as<float>(), evict.as<float>(),
                                         over_list.as<uint32_t>(), scal.as<uint32_t>() + 2, nn01.as<uint32_t>(),
                                         &over01, ctx->stream) == hipSuccess;
-        ok = ok && launch_nn_screened33(fd.as<double>(), fd32.as<float>(), nd2.as<float>(), nd, fs.as<double>(),
+        ok = ok && launch_nn_screened33(fd_p, fd32.as<float>(), nd2.as<float>(), nd, fs_p,
                                         fs32.as<float>(), ns, h_max[0], s10, ring.as<uint2>(),
                                         ring_count.as<uint32_t>(), bd.as<float>(), evict.as<float>(),
                                         over_list.as<uint32_t>(), scal.as<uint32_t>() + 2, nn10.as<uint32_t>(),
                                         &over10, ctx->stream) == hipSuccess;
         g_match_fallbacks = (uint64_t)over01 + over10;
     } else if (ok) {
-        launch_nn(fs.as<double>(), ns, fd.as<double>(), nd, dim, s01, bd.as<double>(), bi.as<uint32_t>(),
+        launch_nn(fs_p, ns, fd_p, nd, dim, s01, bd.as<double>(), bi.as<uint32_t>(),
                   nn01.as<uint32_t>(), ctx->stream);
-        launch_nn(fd.as<double>(), nd, fs.as<double>(), ns, dim, s10, bd.as<double>(), bi.as<uint32_t>(),
+        launch_nn(fd_p, nd, fs_p, ns, dim, s10, bd.as<double>(), bi.as<uint32_t>(),
                   nn10.as<uint32_t>(), ctx->stream);
     }
     if (ok)
@@ -1590,6 +1602,22 @@ int m3d::match_mutual_nn_on(DeviceCtx* ctx, const double* feat_src, size_t n_src
     }
     *k_out = k;
     return done(M3D_OK);
+}
+
+int m3d::device_max_abs(DeviceCtx* ctx, const double* dev, size_t n, double* out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf part;
+    RESERVE(part, sizeof(double) * kMaxAbsPartials);
+    launch_max_abs(dev, n, part.as<double>(), ctx->stream);
+    std::vector<double> hp(kMaxAbsPartials, 0.0);
+    const bool ok = hipMemcpyAsync(hp.data(), part.p, sizeof(double) * kMaxAbsPartials, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    part.release();
+    if (!ok) return fail(M3D_ERR_DEVICE, "device_max_abs: HIP error");
+    double mx = 0.0;
+    for (double v : hp) mx = (v > mx || v != v) ? v : mx;
+    *out = mx;
+    return M3D_OK;
 }
 
 extern "C" {

@@ -101,6 +101,44 @@ def test_global_registration_batch_equals_single_calls(capi, orc):
         capi.global_registration_batch(bad, vox, max_iter=500, seeds=seeds[:3])
 
 
+def test_register_fragment_pairs_resident_equals_pairwise_calls(capi, orc):
+    """m3d_register_fragment_pairs (fragments resident for the call, pairs by index: src/pipeline.cpp:415-440) == the same pairs
+    through m3d_global_registration from host arrays, bit for bit; one pair against the oracle; dim != 33 (brute-force matcher,
+    no cached maximum) as well; the shipped python API on top of it."""
+    vox = 0.03 / 1.4
+    for dim in (33, 8):
+        base = synth.registration_pair_c4(3000, seed=70 + dim, dim=dim, sigma=0.001)
+        # five "fragments": the source and four differently transformed / permuted / noised copies of it
+        rng = np.random.default_rng(dim)
+        frags, feats = [base["src"]], [base["feat_src"]]
+        for k in range(4):
+            Tk = synth.rigid_transform(20.0 + 15.0 * k, (1, k + 1, 2), (0.1 * k, -0.2, 0.05 * k))
+            perm = rng.permutation(3000)
+            frags.append(np.ascontiguousarray((base["src"] @ Tk[:3, :3].T + Tk[:3, 3] + rng.normal(0, 0.001, (3000, 3)))[perm]))
+            feats.append(np.ascontiguousarray(np.abs(base["feat_src"] + rng.normal(0, 0.01, base["feat_src"].shape))[perm]))
+        pairs = [(s, t) for s in range(5) for t in range(s + 1, 5)]
+        seeds = [300 + k for k in range(len(pairs))]
+        res = capi.register_fragment_pairs(frags, feats, pairs, vox, max_iter=1500, seeds=seeds, inflight=4, want_stats=True)
+        for (s, t), sd, r in zip(pairs, seeds, res):
+            g = capi.global_registration(frags[s], frags[t], feats[s], feats[t], vox, max_iter=1500, seed=sd)
+            assert r[0] == g[0] and np.array_equal(r[1], g[1]) and np.array_equal(r[2], g[2]), (dim, s, t)
+            assert r[0] and r[3]["n_matches"] > 2500
+        o = orc.global_registration(frags[1], frags[3], feats[1], feats[3], vox, max_iter=1500, seed=seeds[pairs.index((1, 3))])
+        _same_result(res[pairs.index((1, 3))], o, 3000)
+        if dim == 33:
+            import misc3d_amd as m3d
+            api = m3d.reconstruction.register_fragment_pairs(frags, [f.T for f in feats], voxel_size=vox, max_iter=1500,
+                                                             seeds=seeds)      # (dim, N) matrices, as open3d Feature.data
+            assert [(a[0], a[1]) for a in api] == pairs
+            for a, r in zip(api, res):
+                assert a[2] == r[0] and np.array_equal(a[3], r[1]) and np.array_equal(a[4], r[2])
+            ok, T, info = m3d.reconstruction.global_registration(frags[0], frags[2], feats[0], feats[2], vox, 1500, seed=seeds[1])
+            assert ok == res[1][0] and np.array_equal(T, res[1][1]) and np.array_equal(info, res[1][2])
+    with pytest.raises(capi.M3DError, match="out of range"):
+        capi.register_fragment_pairs(frags, feats, [(0, 7)], vox)
+    assert capi.register_fragment_pairs(frags, feats, [], vox) == []
+
+
 def test_concurrent_mixed_calls_match_the_oracle(capi, orc):
     """The pipeline.cpp:428-439 pattern: ten host threads, each running its own mix of entry points against device 0 at the
     same time, several rounds; every result is compared with the oracle's."""

@@ -205,11 +205,27 @@ if "N2" in which or len(sys.argv) == 1:
         same = all(a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) for a, b in zip(ref, res))
         rows[inflight] = {"ms": best * 1e3, "pairs_per_s": len(pairs) / best, "identical_to_serial": bool(same),
                           "lanes_used": len({r[3]["lane"] for r in res})}
+    # the same 24 pairs as the reference holds them: 12 fragments resident for the call, pairs by index
+    frs = [b["src"] for b in base] + [b["dst"] for b in base]
+    fes = [b["feat_src"] for b in base] + [b["feat_dst"] for b in base]
+    ipairs = [(k, 6 + k) for k in range(6)] * 4
+    resident = {}
+    for inflight in (1, 4, 8):
+        capi.register_fragment_pairs(frs, fes, ipairs[:inflight * 2], vox, seeds=seeds[:inflight * 2], inflight=inflight)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = capi.register_fragment_pairs(frs, fes, ipairs, vox, seeds=seeds, inflight=inflight)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        same = all(a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) for a, b in zip(ref, res))
+        resident[inflight] = {"ms": best * 1e3, "pairs_per_s": len(ipairs) / best, "identical_to_serial": bool(same)}
     capi.restore_config(old_lanes)
     st = ref[0][3]
     emit(f"N2 global_registration_batch {len(pairs)} pairs of {nfrag} pts x 33-D, one device", accepted=int(sum(r[0] for r in ref)),
          per_pair_serial_ms={k: st[k] for k in ("ms_match", "ms_ransac", "ms_info", "ms_total")}, matches=st["n_matches"],
          in_flight=rows, speedup_over_serial={k: rows[1]["ms"] / v["ms"] for k, v in rows.items()},
+         fragments_resident=resident, resident_speedup_over_serial_batch={k: rows[1]["ms"] / v["ms"] for k, v in resident.items()},
          note="pairs are independent (no collective); what overlaps is one pair's uploads and host-side steps (cross-check, "
               "RANSAC replay, grid set-up) with another pair's kernels")
 
