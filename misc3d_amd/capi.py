@@ -20,7 +20,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # M3D_FP_ORDER=1|2 in the environment loads the library built for one of the alternative floating-point associations
 # (misc3d_amd/csrc/m3d_fp.hpp; tests/test_fp_orders.py runs the parity suite under each); default 0
 FP_ORDER = int(os.environ.get("M3D_FP_ORDER", "0") or 0)
-LIB_PATH = os.path.join(_HERE, "lib", *([f"order{FP_ORDER}"] if FP_ORDER else []), "libmisc3d_amd.so")
+# M3D_LIB_VARIANT=<dir>: a diagnostic build under misc3d_amd/lib/<dir>/ (tools/reg_query_fates.sh: -DM3D_REG_TRIP_STATS)
+_VARIANT = os.environ.get("M3D_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "lib", *([_VARIANT] if _VARIANT else ([f"order{FP_ORDER}"] if FP_ORDER else [])), "libmisc3d_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "misc3d_amd.h")
 
 PLANE, SPHERE, CYLINDER = 0, 1, 2

@@ -739,7 +739,12 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
     double best = INFINITY;
     if (SCREEN) {
         double frx, fry, frz;
-        if (!cell_of_frac(g, px, py, pz, g.K, &ix, &iy, &iz, &frx, &fry, &frz)) return best;
+        if (!cell_of_frac(g, px, py, pz, g.K, &ix, &iy, &iz, &frx, &fry, &frz)) {
+#ifdef M3D_REG_TRIP_STATS
+            if (g.nl32_fallbacks) atomicAdd(g.nl32_fallbacks + 41, 1ull);
+#endif
+            return best;
+        }
         const uint32_t cell = ((uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix;
         best = sorted_walk32(g, cell, frx, fry, frz, px, py, pz);
     } else if (!cell_of(g, px, py, pz, g.K, &ix, &iy, &iz)) {
@@ -783,6 +788,26 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
                 }
             }
     }
+#ifdef M3D_REG_TRIP_STATS
+    if (SCREEN && g.nl32_fallbacks) {   // (diagnostic build: where do the queries end?  profiles/r05_reg_query_fates.txt)
+        const bool p2 = !(best < g.h2_in || g.K == 1);
+        const double fin = p2 ? nearest_phase2(g, cell_start, qx, qy, qz, ix, iy, iz, px, py, pz, best) : best;
+        atomicAdd(g.nl32_fallbacks + 40, 1ull);
+        if (best == INFINITY) atomicAdd(g.nl32_fallbacks + 42, 1ull);
+        if (p2) atomicAdd(g.nl32_fallbacks + 43, 1ull);
+        if (p2 && fin < g.r2) atomicAdd(g.nl32_fallbacks + 44, 1ull);
+        if (fin < g.r2) atomicAdd(g.nl32_fallbacks + 45, 1ull);
+        const unsigned long long here = __ballot(true), m_any = __ballot(fin < g.r2), p_any = __ballot(p2), w_any = __ballot(best < INFINITY);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
+            atomicAdd(g.nl32_fallbacks + 46, 1ull);
+            if (m_any == 0ull) atomicAdd(g.nl32_fallbacks + 47, 1ull);
+            if (p_any != 0ull) atomicAdd(g.nl32_fallbacks + 48, 1ull);
+            if (w_any == 0ull) atomicAdd(g.nl32_fallbacks + 49, 1ull);
+            atomicAdd(g.nl32_fallbacks + 50, (unsigned long long)__popcll(here));
+        }
+        return fin;
+    }
+#endif
     if (best < g.h2_in || g.K == 1) return best;
     return nearest_phase2(g, cell_start, qx, qy, qz, ix, iy, iz, px, py, pz, best);
 }

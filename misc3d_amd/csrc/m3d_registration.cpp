@@ -756,6 +756,10 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
                         t[8], t[9], (double)t[9] / (double)(t[8] ? t[8] : 1), t[10], t[11], (double)t[11] / (double)(t[10] ? t[10] : 1));
                 for (int k = 0; k < 24; ++k) fprintf(stderr, " %d:%.3f", k, (double)t[16 + k] / (double)(t[8] ? t[8] : 1));
                 fprintf(stderr, "\n");
+                fprintf(stderr, "query fates: in grid %llu, outside the grid %llu; empty 3x3x3 list %llu, second phase entered %llu (matched there %llu), "
+                                "matched in the end %llu; wave-queries %llu (lanes %llu): no lane matched %llu, some lane in the second phase %llu, "
+                                "no lane with a list %llu\n",
+                        t[40], t[41], t[42], t[43], t[44], t[45], t[46], t[50], t[47], t[48], t[49]);
             }
 #endif
         }
