@@ -655,7 +655,7 @@ __device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell
     typedef uint4 pair_t __attribute__((aligned(8)));   // two entries, ONE load (8-byte aligned: an odd start)
     auto ld2 = [&](int i) { return *reinterpret_cast<const pair_t*>(base + (ptrdiff_t)i * 8); };   // entries i, i + 1
     float m1 = __builtin_inff(), m2 = __builtin_inff();
-    uint32_t i1 = 0u;
+    uint32_t w1 = 0u;   // the winner's second word (z | position << 16): the position is cut out once, after the walk
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     const f32x2_t U_x = {ux, ux}, U_y = {uy, uy}, U_z = {uz, uz};
     // two entries (A first) with packed fp32 arithmetic -- the same IEEE operations per entry as one at a time; returns
@@ -665,17 +665,29 @@ __device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell
                       Z = {(float)(a1 & 0xFFFFu), (float)(b1 & 0xFFFFu)};
         const f32x2_t dx = X - U_x, dy = Y - U_y, dz = Z - U_z;
         const f32x2_t s = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        i1 = s.x < m1 ? (a1 >> 16) : i1;
+        // (the new minimum as a select on the comparison the winner's word needs anyway: fminf would first canonicalise m1)
+        const bool ca = s.x < m1;
+        w1 = ca ? a1 : w1;
         m2 = __builtin_amdgcn_fmed3f(m1, m2, s.x);   // (m1 <= m2: the median is the new runner-up)
-        m1 = __builtin_fminf(m1, s.x);
-        i1 = s.y < m1 ? (b1 >> 16) : i1;
+        m1 = ca ? s.x : m1;
+        const bool cb = s.y < m1;
+        w1 = cb ? b1 : w1;
         m2 = __builtin_amdgcn_fmed3f(m1, m2, s.y);
-        m1 = __builtin_fminf(m1, s.y);
+        m1 = cb ? s.y : m1;
         return dx.y;
     };
     static_assert(kWalkB == 2, "one 16-byte load per side and trip holds the batch");
-    uint4 rb = ld2(0), lb = ld2(-2);
-    int cr = 0, cl = 0;   // entries visited on either side
+    // Round 5: of the loop's 33 VALU instructions per side and trip (ISA of round 4) 3 formed an address from a signed index and 2
+    // cut the position out of every entry.  Now: running pointers (one 64-bit add per side and trip) and the winner's word kept
+    // whole.  Same loads, same values, same order.  (Two trips per iteration on alternating registers, to save the two moves of
+    // the prefetched batch as well, made the compiler shuffle seven registers per side instead: not kept.)
+    const char* pr = base;        // the batch `right` evaluates next: entries cr, cr + 1
+    const char* pl = base - 16;   // ... and `left`: entries -2 - cl, -1 - cl
+    auto ldp = [](const char* q) { return *reinterpret_cast<const pair_t*>(q); };
+    uint4 rb = ldp(pr), lb = ldp(pl);
+    // right has entries left while pr < pr_end, left while pl > pl_end (one 64-bit comparison instead of a counter and its test)
+    const char* const pr_end = base + (ptrdiff_t)(n_tot - start) * 8;
+    const char* const pl_end = base - 16 - (ptrdiff_t)start * 8;
     bool ar = start < n_tot, al = start > 0;
     while (ar || al) {
         // everything behind a batch's last entry is at least (|dx| - 0.6)^2 away in truth, the winner so far at most
@@ -683,23 +695,24 @@ __device__ __forceinline__ double sorted_walk32(const GridDesc& g, uint32_t cell
         // 2.1 sqrt(s) <= s / 512 + 565 (AM-GM), so E(s) <= s (2^-9 + 2^-18) + 567 -- a cut that comes 0.1 % later
         const float thr = __builtin_fmaf(m1, 1.0f + 0x1p-9f + 0x1p-18f, 567.0f);
         if (ar) {
-            const uint4 nx = ld2(cr + 2);
+            pr += 16;
+            const uint4 nx = ldp(pr);
             const float t = visit2(rb.x, rb.y, rb.z, rb.w) - 0.6f;
-            cr += 2;
-            ar = !(t > 0.0f && !(t * t < thr)) && start + cr < n_tot;
+            ar = !(t > 0.0f && !(t * t < thr)) && pr < pr_end;
             rb = nx;
         }
         if (al) {
-            const uint4 nx = ld2(-4 - cl);
-            const float t = -visit2(lb.z, lb.w, lb.x, lb.y) - 0.6f;   // entry -1 - cl, then -2 - cl
-            cl += 2;
-            al = !(t > 0.0f && !(t * t < thr)) && cl < start;
+            pl -= 16;
+            const uint4 nx = ldp(pl);
+            const float t = -visit2(lb.z, lb.w, lb.x, lb.y) - 0.6f;   // the nearer entry of the batch first
+            al = !(t > 0.0f && !(t * t < thr)) && pl > pl_end;
             lb = nx;
         }
     }
+    const uint32_t i1 = w1 >> 16;
 #ifdef M3D_REG_TRIP_STATS
     if (g.nl32_fallbacks) {   // (diagnostic build: tools only)
-        const uint32_t trips = (uint32_t)max((cr + 1) / 2, (cl + 1) / 2);
+        const uint32_t trips = (uint32_t)max((int)((pr - base) / 16), (int)((base - 16 - pl) / 16));
         uint32_t wmax = 0;
         for (uint32_t k = 1; k < 64u; ++k)
             if (__ballot(trips >= k) != 0ull) wmax = k;   // (over the lanes that are here)
