@@ -37,9 +37,12 @@ N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run, 
 launcher (WORLD_SIZE set) it is one of the ranks.  Control plane (rendezvous, barrier, max over ranks): torch.distributed
 "gloo".  Data path: the C++ driver m3d_cloud_fit_sharded with a library-owned RCCL communicator (ncclAllGather of the
 4-byte records on the library's stream over xGMI), ncclUniqueId handed out through the process group.
---scaling strong (default at N > 1, the north_star's question): --hyp hypotheses in total, value = hyp / t; a
-`weak_scaling` block (N x hyp hypotheses of one stream) and the `strong_scaling` block of C2 / C3 ride along.
---scaling weak (default at N = 1, where the two coincide): --hyp hypotheses PER GPU, value = N x hyp / t.
+--scaling weak (the DEFAULT at every N: ONE headline workload, per-GPU work fixed, so that the driver can derive an efficiency
+from the per-N values): --hyp hypotheses PER GPU of one stream, value = N x hyp / t.  `scaling: "weak"` in the line says so:
+the per-N values are NOT the north_star's strong-scaling curve.  That question -- fixed TOTAL work -- is answered by the
+`strong_scaling` block every N > 1 line carries (C2, C3 cylinder, C3 sphere: one-GPU time measured in the same job, the
+term-by-term model's prediction beside each), and what N GPUs deliver on independent jobs by the `replicas` block (no collective).
+--scaling strong: --hyp hypotheses in total, value = hyp / t; a `weak_scaling` block rides along instead.
 
 More objects of the N = 1 line:
   fp64_only    the same K steps with m3d_config.score_fp32_screen = 0, cull_fp32 = 0 (the reference's arithmetic only) and
@@ -344,6 +347,30 @@ def main():
             comm = capi.Comm.torch_host()
             transport_note = "the first RCCL exchange failed (" + (why or "on another rank") + ")"
             print(f"[bench] rank {rank}: {transport_note}; records go over gloo", file=sys.stderr)
+    # ---- `cold`: what a caller sees who has just created the cloud -- the first fit, then W warm-up and K timed steps with NO
+    # priming in front of them (clocks on their way up, the lane's scratch allocated by the first fit).  Measured first, so that
+    # nothing has warmed anything; the contract's steady-state value follows behind the priming fits.
+    cold = None
+    if world == 1 and comm is None:
+        barrier()
+        t0 = time.perf_counter()
+        step()
+        first_ms = (time.perf_counter() - t0) * 1e3
+        for _ in range(a.warmup):
+            step()
+        barrier()
+        gc.disable()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        barrier()
+        dtc = time.perf_counter() - t0
+        gc.enable()
+        cold = {"first_fit_ms": first_ms, "ms_per_step": dtc / a.steps * 1e3, "value": H_total * a.steps / dtc, "steps": a.steps,
+                "warmup": a.warmup,
+                "note": "the same W + K steps BEFORE the priming fits (M3D_BENCH_PRIMING, default 150) that precede the contract's "
+                        "timed region: the cloud's first fit (scratch allocation, tile frames), then steps on a GPU whose clocks "
+                        "are still rising"}
     for _ in range(PRIMING_FITS):
         step()
     for _ in range(a.warmup):
@@ -695,6 +722,8 @@ def main():
                                                         "that `roofline.launch_ms` is measured with"}}
         if fp64_only:
             out["fp64_only"] = fp64_only
+        if cold:
+            out["cold"] = cold
         if plane_bound:
             out["plane_bound"] = plane_bound
         if setup:

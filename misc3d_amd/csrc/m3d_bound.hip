@@ -403,7 +403,10 @@ void launch_plane_bound(const SortedView& s, const double* score, const unsigned
     const uint32_t window = group_end - group_begin;
     constexpr uint32_t gdiv = 6;   // one block of 64 survivors per 6 groups of the window to begin with (4 .. 8 equal, measured r4)
     const uint32_t gx = std::min<uint32_t>(window, std::max<uint32_t>(4u, (window + gdiv - 1) / gdiv));
-    constexpr int tpw = 8;   // tiles per wave (12 .. 32 measured slower: profiles/r04_plane_bound.txt; 24 and 32 need > 64 KB of LDS)
+    // tiles per wave (12 .. 32 measured slower: profiles/r04_plane_bound.txt).  Round 5 (profiles/r05_c2_front_end.txt): 4 -- twice
+    // the workgroups, half the tile loop -- 19.5 -> 31.5 us, and by ablation the tile loop is 1.5 us of the launch's 19, the adds /
+    // fence / ticket behind it 6.5, the rest dependent loads of data the kernel before has just written (~2 us a round trip)
+    constexpr int tpw = 8;
     const uint32_t tpb = (uint32_t)(kBoundWaves * tpw);
     const uint32_t max_list = always ? 0xFFFFFFFFu : window * 32u;   // half of the window's hypotheses
     const dim3 g(gx, (s.n_tiles + tpb - 1) / tpb), b(64 * kBoundWaves);

@@ -357,30 +357,79 @@ __device__ __forceinline__ void cull32_body(const double* __restrict__ boxes, ui
     const float rb = __builtin_sqrtf(__builtin_fmaf(hz, hz, __builtin_fmaf(hy, hy, hx * hx))) * 1.000001f;
     const uint32_t g0 = group_begin + block_y * groups_per_wave;
     const uint32_t g1 = min(group_end, g0 + groups_per_wave);
+    // The group's 32 record pairs (3 KB) come in with ONE round trip -- three coalesced 16-byte loads per lane, parked in LDS
+    // and read back as broadcasts -- instead of one scalar load per pair, each waited for before its pair was evaluated: the
+    // records were written by minimal_fit_k a moment ago, mostly through another XCD's L2, and 32 dependent round trips of
+    // ~1400 cycles were what this kernel's 28 us on C2 consisted of (round 5: tools/sweep_lead.sh shows the launch's time
+    // does not depend on the lead pass it is fused with).  One wave per workgroup: the barrier is a formality.
+    __shared__ float4 rec_s[192];
+    float4 v0, v1, v2;   // the NEXT group's records, on their way while this group's pairs are evaluated
+    auto fetch = [&](uint32_t g) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(cull32 + (size_t)g * 32u * 24u);
+        v0 = src[lane];
+        v1 = src[lane + 64];
+        v2 = src[lane + 128];
+    };
+    if (g0 < g1) fetch(g0);
     for (uint32_t g = g0; g < g1; ++g) {
         uint32_t w[2] = {0u, 0u}, ubv = 0u, ubpv = 0u;
-        const float* __restrict__ rp = cull32 + (size_t)g * 32u * 24u;   // 32 pairs of hypotheses
+        __syncthreads();   // (the previous group's reads are done)
+        rec_s[lane] = v0;
+        rec_s[lane + 64] = v1;
+        rec_s[lane + 128] = v2;
+        __syncthreads();
+        if (g + 1u < g1) fetch(g + 1u);
+        // 32 pairs of hypotheses, 24 floats each (a kind's own share of them: 16 / 10 / 22), read as broadcasts ONE PAIR AHEAD
+        // of the pair being evaluated (the LDS latency of a pair's operands was otherwise waited for 32 times per group)
+        constexpr int kQuads = KIND == 0 ? 4 : (KIND == 1 ? 3 : 6);
+        struct PairRec {
+            float4 q[kQuads];
+        };
+        auto load_pair = [&](uint32_t pair) {
+            PairRec r;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            uint32_t drop = 0u;   // bit (31 - b): hypothesis half * 32 + b dropped this lane's tile
-            for (uint32_t b = 0; b < 32u; b += 2u) {
-                const uint32_t hh = (uint32_t)half * 32u + b;
-                float ta, tb;
-                cull32_pair<KIND>(rp + (size_t)(hh >> 1) * 24u, bx, by, bz, hx, hy, hz, rb, ta, tb);
-                drop = __builtin_amdgcn_alignbit(drop, __float_as_uint(ta), 31);
-                drop = __builtin_amdgcn_alignbit(drop, __float_as_uint(tb), 31);
-                const unsigned long long ma = __ballot(!(ta < 0.0f)) & live_mask, mb = __ballot(!(tb < 0.0f)) & live_mask;
-                ubv = ((uint32_t)lane == hh) ? (uint32_t)__popcll(ma) : ubv;
-                ubv = ((uint32_t)lane == hh + 1u) ? (uint32_t)__popcll(mb) : ubv;
-                if (ubp) {   // (kernel argument: uniform) lane = tile and the wave starts at a multiple of 64: tile % 4 = lane % 4
-                    const uint32_t pa = (uint32_t)__popcll(ma & 0x1111111111111111ull) | ((uint32_t)__popcll(ma & 0x2222222222222222ull) << 16);
-                    const uint32_t pb = (uint32_t)__popcll(mb & 0x1111111111111111ull) | ((uint32_t)__popcll(mb & 0x2222222222222222ull) << 16);
-                    ubpv = ((uint32_t)lane == hh) ? pa : ubpv;
-                    ubpv = ((uint32_t)lane == hh + 1u) ? pb : ubpv;
+            for (int k = 0; k < kQuads; ++k) r.q[k] = rec_s[pair * 6u + (uint32_t)k];
+            return r;
+        };
+        // (the phase counters are a kernel argument: decided once per group, not inside the pairs' loop, where the branch kept
+        //  the compiler from overlapping one pair's LDS reads with the pair before)
+        auto pairs = [&](auto with_ubp) {
+            PairRec nxt = load_pair(0u);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint32_t drop = 0u;   // bit (31 - b): hypothesis half * 32 + b dropped this lane's tile
+#pragma unroll
+                for (uint32_t b = 0; b < 32u; b += 2u) {
+                    const uint32_t hh = (uint32_t)half * 32u + b;
+                    const PairRec cur = nxt;
+                    nxt = load_pair(min((hh >> 1) + 1u, 31u));
+                    float rp[24];
+#pragma unroll
+                    for (int k = 0; k < kQuads; ++k) {
+                        rp[4 * k] = cur.q[k].x;
+                        rp[4 * k + 1] = cur.q[k].y;
+                        rp[4 * k + 2] = cur.q[k].z;
+                        rp[4 * k + 3] = cur.q[k].w;
+                    }
+                    float ta, tb;
+                    cull32_pair<KIND>(rp, bx, by, bz, hx, hy, hz, rb, ta, tb);
+                    drop = __builtin_amdgcn_alignbit(drop, __float_as_uint(ta), 31);
+                    drop = __builtin_amdgcn_alignbit(drop, __float_as_uint(tb), 31);
+                    const unsigned long long ma = __ballot(!(ta < 0.0f)) & live_mask, mb = __ballot(!(tb < 0.0f)) & live_mask;
+                    ubv = ((uint32_t)lane == hh) ? (uint32_t)__popcll(ma) : ubv;
+                    ubv = ((uint32_t)lane == hh + 1u) ? (uint32_t)__popcll(mb) : ubv;
+                    if (decltype(with_ubp)::value) {   // lane = tile and the wave starts at a multiple of 64: tile % 4 = lane % 4
+                        const uint32_t pa = (uint32_t)__popcll(ma & 0x1111111111111111ull) | ((uint32_t)__popcll(ma & 0x2222222222222222ull) << 16);
+                        const uint32_t pb = (uint32_t)__popcll(mb & 0x1111111111111111ull) | ((uint32_t)__popcll(mb & 0x2222222222222222ull) << 16);
+                        ubpv = ((uint32_t)lane == hh) ? pa : ubpv;
+                        ubpv = ((uint32_t)lane == hh + 1u) ? pb : ubpv;
+                    }
                 }
+                w[half] = ~__builtin_bitreverse32(drop);
             }
-            w[half] = ~__builtin_bitreverse32(drop);
-        }
+        };
+        if (ubp) pairs(std::true_type());
+        else pairs(std::false_type());
         if (tile_ok) masks[(size_t)tile * n_groups + g] = live ? (((unsigned long long)w[1] << 32) | w[0]) : 0ull;
         if (ub && ubv) atomicAdd(&ub[g * 64u + (uint32_t)lane], ubv);
         if (ubp && ubpv) atomicAdd(&ubp[g * 64u + (uint32_t)lane], ubpv);
