@@ -488,7 +488,7 @@ typedef struct m3d_config {
                                        launch boundary it replaces: profiles/r04_compact_one_pass.txt) */
     int32_t plane_bound;            /* [M3D_PLANE_BOUND=0]  default 1: plane fits with an incumbent prune with a per-tile HISTOGRAM upper bound of
                                        every (tile, hypothesis) pair's inlier count (tile_frames_k / plane_bound_k, m3d_bound.hip) instead of
-                                       512 per touched tile, where that pays (windows of >= 8192 hypotheses on tiles x hypotheses >= 1.5e7, measured: m3d_driver.cpp
+                                       512 per touched tile, where that pays (windows of >= 8192 hypotheses on tiles x hypotheses >= 1.5e7, measured: m3d_fit.cpp
                                        bound_pays; 2: whatever the size); same results, fewer hypotheses counted point by point.  (Fields are
                                        only ever appended, the offsets of existing fields do not move -- ADVICE r3) */
     int32_t lanes;                  /* [M3D_LANES]          default 4 (1..8): calls a device runs side by side -- every lane has its own streams and

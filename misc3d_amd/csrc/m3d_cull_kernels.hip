@@ -1377,7 +1377,7 @@ bool launch_score_own_tests(int kind, const SortedView& s, const double* score, 
 // among the valid hypotheses of the chunk, lowest index among equals, against the running pick of earlier chunks
 // (strictly more inliers to replace it).  Fitness ties are decided by rmse on the host, so this is a PREDICTION:
 // the driver starts RefineModel's compaction on pick->params behind the last scoring launch and keeps the result
-// only if the replay names the same hypothesis (m3d_driver.cpp).  One workgroup.
+// only if the replay names the same hypothesis (m3d_fit.cpp).  One workgroup.
 __global__ __launch_bounds__(1024) void pick_best_k(const uint32_t* __restrict__ records, uint32_t count,
                                                      unsigned long long index_base, const double* __restrict__ params,
                                                      int first_chunk, BestPick* __restrict__ pick,

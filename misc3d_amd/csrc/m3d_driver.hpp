@@ -260,7 +260,7 @@ struct m3d_cloud {
     const uint32_t* orig() const { return work.active ? work.cur_orig : nullptr; }
 };
 
-// m3d_cloud_create with the Hilbert-sorted copy optional (m3d_driver.cpp)
+// m3d_cloud_create with the Hilbert-sorted copy optional (m3d_device.cpp)
 extern "C" m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_t n, int device, int with_sorted_copy);
 // ... on a lane the caller already holds (CtxLock / LaneLock): the registration session's two clouds share its lane
 m3d_cloud* m3d_cloud_create_on(m3d::DeviceCtx* ctx, const double* xyz, const double* normals, size_t n, int with_sorted_copy);

@@ -1,4 +1,4 @@
-// m3d_driver.cpp -- host driver behind the C ABI (include/misc3d_amd.h).
+// m3d_fit.cpp -- the RANSAC loop of the host driver behind the C ABI (include/misc3d_amd.h).
 //
 // Mirrors the control flow of misc3d::common::RANSAC (include/misc3d/common/ransac.h:455-664) and
 // segmentation::SegmentPlaneIterative (src/iterative_plane_segmentation.cpp:8-39), with the data-
@@ -18,301 +18,9 @@
 // in point order, only when such a tie occurs (exact_error()).
 //
 // There is no CPU fallback: every entry point needs a HIP device.
-#include "m3d_driver.hpp"
-#include "m3d_comm.hpp"
-#include "m3d_config.hpp"
-#include "m3d_fp.hpp"
-#include "m3d_mt19937.hpp"
-#include "m3d_reg_kernels.hpp"
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <limits>
-#include <map>
-#include <random>
-#include <thread>
+#include "m3d_driver_internal.hpp"
 
 #pragma clang fp contract(off)
-
-namespace m3d {
-
-// ------------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
-void set_error(const std::string& msg) { g_last_error = msg; }
-int fail(int code, const std::string& msg) {
-    g_last_error = msg;
-    return code;
-}
-#define HIPCHK(expr)                                                                       \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
-            return fail(M3D_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-namespace {
-constexpr int kPoolDevices = 16;
-constexpr int kPools = kPoolDevices * kMaxLanes;   // one free list per (device, lane)
-static size_t pool_limit() { return (size_t)config().pool_limit_mb << 20; }   // bytes parked per list
-struct DevPool {
-    std::mutex mu;
-    std::multimap<size_t, void*> blocks[kPools];
-    size_t bytes[kPools] = {};
-};
-DevPool& dev_pool() {
-    static DevPool* p = new DevPool();   // never destroyed (buffers may be released from finalisers at exit)
-    return *p;
-}
-thread_local int t_lane = 0;   // the lane the calling thread holds (CtxLock / LaneLock); 0 outside of any
-inline int pool_index(int dev, int lane) { return dev * kMaxLanes + lane; }
-}  // namespace
-
-bool DevBuf::reserve(size_t bytes) {
-    if (bytes <= cap) return true;
-    release();
-    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess) d = 0;
-    const int ln = (t_lane >= 0 && t_lane < kMaxLanes) ? t_lane : 0;
-    if (d >= 0 && d < kPoolDevices) {
-        DevPool& pool = dev_pool();
-        const int pi = pool_index(d, ln);
-        std::lock_guard<std::mutex> lock(pool.mu);
-        auto it = pool.blocks[pi].lower_bound(want);
-        if (it != pool.blocks[pi].end() && it->first <= 2 * want + ((size_t)1 << 20)) {
-            p = it->second;
-            cap = it->first;
-            dev = d;
-            lane = ln;
-            pool.bytes[pi] -= cap;
-            pool.blocks[pi].erase(it);
-            return true;
-        }
-    }
-    if (hipMalloc(&p, want) != hipSuccess) {
-        dev_pool_trim(d);   // give the parked blocks back and try once more
-        if (hipMalloc(&p, want) != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc failed (" + std::to_string(want) + " bytes)");
-            return false;
-        }
-    }
-    cap = want;
-    dev = d;
-    lane = ln;
-    return true;
-}
-void DevBuf::release() {
-    if (p) {
-        bool parked = false;
-        if (dev >= 0 && dev < kPoolDevices && lane >= 0 && lane < kMaxLanes) {
-            DevPool& pool = dev_pool();
-            const int pi = pool_index(dev, lane);
-            std::lock_guard<std::mutex> lock(pool.mu);
-            if (pool.bytes[pi] + cap <= pool_limit()) {
-                pool.blocks[pi].emplace(cap, p);
-                pool.bytes[pi] += cap;
-                parked = true;
-            }
-        }
-        if (!parked) (void)hipFree(p);
-    }
-    p = nullptr;
-    cap = 0;
-    dev = -1;
-    lane = 0;
-}
-// Frees every parked block of the device.  hipFree waits for the device, so a block another lane parked a moment ago
-// (its kernels possibly still running: a lane's list is ordered by that lane's stream only) is idle when it goes.
-void dev_pool_trim(int device) {
-    if (device < 0 || device >= kPoolDevices) return;
-    std::vector<void*> drop;
-    {
-        DevPool& pool = dev_pool();
-        std::lock_guard<std::mutex> lock(pool.mu);
-        for (int ln = 0; ln < kMaxLanes; ++ln) {
-            const int pi = pool_index(device, ln);
-            for (auto& kv : pool.blocks[pi]) drop.push_back(kv.second);
-            pool.blocks[pi].clear();
-            pool.bytes[pi] = 0;
-        }
-    }
-    for (void* q : drop) (void)hipFree(q);
-}
-bool PinBuf::reserve(size_t bytes) {
-    if (bytes <= cap) return true;
-    release();
-    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
-        p = nullptr;
-        set_error("hipHostMalloc failed (" + std::to_string(want) + " bytes)");
-        return false;
-    }
-    cap = want;
-    return true;
-}
-void PinBuf::release() {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    cap = 0;
-}
-#define RESERVE(buf, bytes)                         \
-    do {                                            \
-        if (!(buf).reserve(bytes)) return M3D_ERR_DEVICE; \
-    } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// device context
-// ------------------------------------------------------------------------------------------------
-static std::mutex g_ctx_mu;
-static std::map<int, DeviceCtx*> g_ctx;   // key: device * kMaxLanes + lane
-
-int lane_count() { return std::min(std::max((int)config().lanes, 1), kMaxLanes); }
-
-DeviceCtx* get_lane(int device, int lane) {
-    std::lock_guard<std::mutex> lock(g_ctx_mu);
-    if (lane < 0 || lane >= kMaxLanes) lane = 0;
-    auto it = g_ctx.find(device * kMaxLanes + lane);
-    if (it != g_ctx.end()) return it->second;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
-        set_error("no HIP device available (misc3d_amd has no CPU fallback)");
-        return nullptr;
-    }
-    if (device < 0 || device >= count) {
-        set_error("invalid HIP device ordinal " + std::to_string(device));
-        return nullptr;
-    }
-    if (hipSetDevice(device) != hipSuccess) {
-        set_error("hipSetDevice failed");
-        return nullptr;
-    }
-    DeviceCtx* c = new DeviceCtx();
-    c->device = device;
-    c->lane = lane;
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_compact, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_pre_gate, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
-    {   // (a high-priority stream: its short latency-bound kernels get in between the scoring workgroups)
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        ok = ok && hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, hi) == hipSuccess;
-    }
-    for (int k = 0; k < 2 && ok; ++k)
-        ok = hipEventCreateWithFlags(&c->slot[k].pre_done, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreate(&c->slot[k].k0) == hipSuccess && hipEventCreate(&c->slot[k].k1) == hipSuccess &&
-             hipEventCreate(&c->slot[k].k2) == hipSuccess && hipEventCreate(&c->slot[k].k3) == hipSuccess;
-    if (!ok) {
-        set_error("failed to create HIP stream/events");
-        delete c;
-        return nullptr;
-    }
-    g_ctx[device * kMaxLanes + lane] = c;
-    return c;
-}
-DeviceCtx* get_ctx(int device) { return get_lane(device, 0); }
-static DeviceCtx* find_lane(int device, int lane) {   // an existing lane, or nullptr
-    std::lock_guard<std::mutex> lock(g_ctx_mu);
-    auto it = g_ctx.find(device * kMaxLanes + lane);
-    return it == g_ctx.end() ? nullptr : it->second;
-}
-
-CtxLock::CtxLock(DeviceCtx* c) : ctx_(c), prev_lane_(t_lane) {
-    ctx_->mu.lock();
-    t_lane = ctx_->lane;
-}
-CtxLock::~CtxLock() {
-    t_lane = prev_lane_;
-    ctx_->mu.unlock();
-}
-
-namespace {
-std::atomic<int> g_thread_arrivals{0};
-thread_local int t_home_lane = -1;   // dealt on the thread's first LaneLock
-}  // namespace
-
-LaneLock::LaneLock(int device, int prefer) : prev_lane_(t_lane) {
-    const int lanes = lane_count();
-    if (prefer < 0 && t_home_lane < 0) t_home_lane = g_thread_arrivals.fetch_add(1, std::memory_order_relaxed);
-    const int home = (prefer >= 0 ? prefer : t_home_lane) % lanes;
-    DeviceCtx* mine = get_lane(device, home);
-    if (!mine) return;
-    if (mine->mu.try_lock()) {
-        ctx = mine;
-    } else {
-        for (int ln = 0; ln < lanes && !ctx; ++ln) {
-            if (ln == home) continue;
-            DeviceCtx* c = get_lane(device, ln);
-            if (c && c->mu.try_lock()) ctx = c;
-        }
-        if (!ctx) {
-            mine->mu.lock();
-            ctx = mine;
-        }
-    }
-    t_lane = ctx->lane;
-}
-LaneLock::~LaneLock() {
-    if (!ctx) return;
-    t_lane = prev_lane_;
-    ctx->mu.unlock();
-}
-
-static inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
-static inline int minimal_sample(int kind) { return kind == M3D_PLANE ? 3 : (kind == M3D_SPHERE ? 4 : 2); }
-static inline int num_params(int kind) { return kind == M3D_CYLINDER ? 7 : 4; }
-
-static double now_ms() {
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
-}  // namespace m3d
-
-m3d::CloudView m3d_cloud::base_view() const {
-    m3d::CloudView v;
-    v.x = x.as<double>();
-    v.y = y.as<double>();
-    v.z = z.as<double>();
-    v.nx = has_normals ? nx.as<double>() : nullptr;
-    v.ny = has_normals ? ny.as<double>() : nullptr;
-    v.nz = has_normals ? nz.as<double>() : nullptr;
-    v.n = work.active ? n0 : n;
-    v.n_pad = work.active ? n_pad0 : n_pad;
-    return v;
-}
-
-m3d::CloudView m3d_cloud::view() const { return work.active && !work.cur_is_v0 ? work.cur : base_view(); }
-
-m3d::SortedView m3d_cloud::sorted() const {
-    if (work.active && !work.cur_is_v0) return work.scur;
-    m3d::SortedView s;
-    s.x = sx.as<double>();
-    s.y = sy.as<double>();
-    s.z = sz.as<double>();
-    s.boxes = boxes.as<double>();
-    s.tile_f32 = tile_f32.as<float>();
-    if (frames_ready) {
-        s.frames = frames.as<double>();
-        s.frame_cum = frame_cum.as<uint16_t>();
-    }
-    s.n_tiles = n_tiles;
-    s.max_abs = max_abs;
-    for (int k = 0; k < 3; ++k) s.origin[k] = origin[k];
-    s.radius = radius;
-    return s;
-}
 
 namespace m3d {
 
@@ -838,7 +546,7 @@ static int wait_pick_seq(DeviceCtx* ctx, uint32_t seq) {
 // memory instead of hipStreamSynchronize: the runtime's wait wakes the caller 10-20 us after the stream has drained.  Bounded
 // in TIME (m3d_config.wait_spin_us, default 500 us; 0: the runtime's wait only): a wait that lasts longer -- a 10 M-point call,
 // a device another lane keeps busy -- becomes a blocked thread instead of a core at 100 % (VERDICT r4 / ADVICE r4).
-static int stream_wait_spin(DeviceCtx* ctx) {
+int stream_wait_spin(DeviceCtx* ctx) {
     const int spin_us = config().wait_spin_us;
     if (spin_us <= 0) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -886,361 +594,6 @@ static void unpack_slot(ChunkSlot& s) {
 
 // Scratch of launch_compact (m3d_kernels.hpp, CompactScratch): one slot per compaction workgroup, zero when the buffer is
 // (re)allocated and when the epoch counter starts over; every launch gets the next epoch.
-static int compact_scratch(DeviceCtx* ctx, uint32_t nb, CompactScratch* out) {
-    const size_t need = sizeof(uint32_t) * ((size_t)nb + 1);
-    const bool grow = ctx->block_counts.cap < need;
-    if (grow) RESERVE(ctx->block_counts, need);
-    if (ctx->compact_epoch >= kCompactEpochs) ctx->compact_epoch = 0;
-    if (grow || ctx->compact_epoch == 0)
-        HIPCHK(hipMemsetAsync(ctx->block_counts.p, 0, ctx->block_counts.cap, ctx->stream));
-    out->slots = ctx->block_counts.as<uint32_t>();
-    out->tag = ++ctx->compact_epoch << 12;
-    return M3D_OK;
-}
-
-// EvaluateModel's (inlier_num, error) with the error summed in point order (ransac.h:632-640).
-static int exact_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
-                       const double* model_dev, uint64_t* count, double* error) {
-    const uint32_t nb = (v.n + kCompactTile - 1) / kCompactTile;
-    RESERVE(ctx->dist, sizeof(double) * (size_t)std::max<uint32_t>(v.n, 1));
-    CompactScratch scratch;
-    if (const int rc = compact_scratch(ctx, nb, &scratch); rc != M3D_OK) return rc;
-    RESERVE(ctx->total, sizeof(uint32_t) * 4);
-    RESERVE(ctx->sums, sizeof(double) * 32);
-    RESERVE(ctx->h_small, 256);
-    launch_compact(kind, v, model_dev, thr, 1, nullptr, nullptr, ctx->dist.as<double>(), nullptr,
-                   nullptr, nullptr, nullptr, 0, scratch,
-                   ctx->total.as<uint32_t>(), ctx->stream);
-    launch_serial_sum(ctx->dist.as<double>(), ctx->total.as<uint32_t>(), ctx->sums.as<double>() + 16,
-                      ctx->stream);
-    uint8_t* h = ctx->h_small.as<uint8_t>();
-    HIPCHK(hipMemcpyAsync(h, ctx->total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(h + 8, ctx->sums.as<double>() + 16, sizeof(double), hipMemcpyDeviceToHost,
-                          ctx->stream));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    uint32_t c32;
-    std::memcpy(&c32, h, 4);
-    std::memcpy(error, h + 8, 8);
-    *count = c32;
-    return M3D_OK;
-}
-
-// Order-free sums of the inlier distances (tree) + counts of the trial model and, when its sum is not known yet, of the
-// incumbent (model_b != null): enough to decide most ties (see the tie rule in run_ransac).  ONE pass over the cloud for
-// both, the results stored into pinned memory by the kernel's last workgroup: one launch and one wait per tie.
-static int approx_error_pair(DeviceCtx* ctx, const CloudView& v, int kind, double thr, const double* model_a,
-                             const double* model_b, uint64_t* count_a, double* error_a, uint64_t* count_b, double* error_b) {
-    const bool fresh = ctx->tie_scratch.cap == 0;
-    RESERVE(ctx->tie_scratch, sizeof(double) * (kErrorSumScratchDoubles + 2));
-    RESERVE(ctx->h_tie, 64);
-    uint32_t* ticket = reinterpret_cast<uint32_t*>(ctx->tie_scratch.as<double>() + kErrorSumScratchDoubles);
-    if (fresh) HIPCHK(hipMemsetAsync(ticket, 0, sizeof(uint32_t), ctx->stream));
-    double* h = ctx->h_tie.as<double>();
-    launch_error_sum(kind, v, model_a, model_b, thr, ctx->tie_scratch.as<double>(), ticket, h, ctx->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    *count_a = (uint64_t)h[0];
-    *error_a = h[1];
-    if (model_b) {
-        *count_b = (uint64_t)h[2];
-        *error_b = h[3];
-    }
-    return M3D_OK;
-}
-static int approx_error(DeviceCtx* ctx, const CloudView& v, int kind, double thr,
-                        const double* model_dev, uint64_t* count, double* error) {
-    return approx_error_pair(ctx, v, kind, thr, model_dev, nullptr, count, error, nullptr, nullptr);
-}
-
-// ------------------------------------------------------------------------------------------------
-// GeneralFit closed forms (host; the sums come from sum_*_k)
-// ------------------------------------------------------------------------------------------------
-// PlaneEstimator::GeneralFit, ransac.h:190-211
-static bool plane_from_moments(const double* mean, const double* s, double* out) {
-    const double xx = s[0], xy = s[1], xz = s[2], yy = s[3], yz = s[4], zz = s[5];
-    const double det_x = yy * zz - yz * yz;
-    const double det_y = xx * zz - xz * xz;
-    const double det_z = xx * yy - xy * xy;
-    double a, b, c;
-    if (det_x > det_y && det_x > det_z) {
-        a = det_x;
-        b = xz * yz - xy * zz;
-        c = xy * yz - xz * yy;
-    } else if (det_y > det_z) {
-        a = xz * yz - xy * zz;
-        b = det_y;
-        c = xy * xz - yz * xx;
-    } else {
-        a = xy * yz - xz * yy;
-        b = xy * xz - yz * xx;
-        c = det_z;
-    }
-    const double norm = std::sqrt((a * a + b * b) + c * c);
-    if (norm < 1.0e-8) return false;
-    a /= norm;
-    b /= norm;
-    c /= norm;
-    out[0] = a;
-    out[1] = b;
-    out[2] = c;
-    out[3] = -((a * mean[0] + b * mean[1]) + c * mean[2]);
-    return true;
-}
-
-// SphereEstimator::GeneralFit, ransac.h:296-330: least squares of [2x 2y 2z 1] w = x^2+y^2+z^2.
-// The reference's bdcSvd(FullU) needs an N_inl x N_inl matrix (its own TODO, ransac.h:318-319);
-// here the same least-squares problem is solved from the CENTRED normal equations
-//   4 S c' = 2 sum(p' q),  w3' = sum(q)/n,  q = |p'|^2,  p' = p - mean,
-// then centre = mean + c', r = sqrt(|c'|^2 + w3').  Same minimiser, parameters agree to ~1e-12.
-static bool sphere_from_moments(const double* mean, const double* s, double n, double* out) {
-    double A[3][4] = {{4 * s[0], 4 * s[1], 4 * s[2], 2 * s[6]},
-                      {4 * s[1], 4 * s[3], 4 * s[4], 2 * s[7]},
-                      {4 * s[2], 4 * s[4], 4 * s[5], 2 * s[8]}};
-    for (int col = 0; col < 3; ++col) {  // Gaussian elimination, partial pivoting
-        int piv = col;
-        for (int r = col + 1; r < 3; ++r)
-            if (std::fabs(A[r][col]) > std::fabs(A[piv][col])) piv = r;
-        if (piv != col)
-            for (int k = 0; k < 4; ++k) std::swap(A[piv][k], A[col][k]);
-        if (A[col][col] == 0.0) continue;
-        for (int r = col + 1; r < 3; ++r) {
-            const double f = A[r][col] / A[col][col];
-            for (int k = col; k < 4; ++k) A[r][k] -= f * A[col][k];
-        }
-    }
-    double c[3];
-    for (int r = 2; r >= 0; --r) {
-        double acc = A[r][3];
-        for (int k = r + 1; k < 3; ++k) acc -= A[r][k] * c[k];
-        c[r] = A[r][r] != 0.0 ? acc / A[r][r] : 0.0;
-    }
-    const double w3 = s[9] / n;
-    out[0] = mean[0] + c[0];
-    out[1] = mean[1] + c[1];
-    out[2] = mean[2] + c[2];
-    out[3] = std::sqrt(((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) + w3);
-    return true;
-}
-
-// m3d_host_alloc registry: is [p, p + bytes) inside a page-locked block handed out by this library?
-// (never destroyed: m3d_host_free may still be called from a host language's finalisers at process exit)
-struct PinnedRegistry {
-    std::mutex mu;
-    std::vector<std::pair<const char*, size_t>> blocks;
-};
-static PinnedRegistry& pinned_registry() {
-    static PinnedRegistry* r = new PinnedRegistry();
-    return *r;
-}
-static bool is_library_pinned(const void* p, size_t bytes) {
-    PinnedRegistry& r = pinned_registry();
-    std::lock_guard<std::mutex> lock(r.mu);
-    const char* q = static_cast<const char*>(p);
-    for (const auto& b : r.blocks)
-        if (q >= b.first && q + bytes <= b.first + b.second) return true;
-    return false;
-}
-
-// RefineModel, ransac.h:534-549.  flag_view: cloud the distances are evaluated on; gather_view +
-// orig: when the flags are computed on a compacted cloud (segmentation) the inlier list holds
-// ORIGINAL indices and the GeneralFit sums gather from the original cloud (same values, same order).
-// expected_ni >= 0: the inlier count is already known from the scoring pass (the usual case).  Then nothing
-// has to wait for the compaction's own total: the GeneralFit sums run on the main stream while the index list
-// travels to the host on the copy stream, and the total is only CHECKED at the end (a mismatch falls back to
-// the synchronous order; the callers treat it as an internal error anyway).
-// First stage of RefineModel: the ordered inlier list of `model_dev` (+ the model record to the pinned `lazy_in`).
-// total_host (pinned) receives the inlier count.  Separate from refine() so that a probability-1 fit can queue it
-// on the device's own prediction of the winner right behind the last scoring launch (run_ransac).
-// fused: the model record carries the provisional centre of GeneralFit's sums (a record written by minimal_fit_k), so
-// the compaction's counting pass accumulates the moments as well and no pass over the inlier list follows.
-// idx_host: the caller's page-locked index list; the compaction writes it directly (the 8 bytes per inlier cross the
-// host link while the kernel runs instead of in a copy command the host issues after it has woken up).
-// where the compaction puts the ordered inlier list on the device (DeviceCtx::idx_out_override)
-static uint64_t* idx_dev(DeviceCtx* ctx) { return ctx->idx_out_override ? ctx->idx_out_override : ctx->idx.as<uint64_t>(); }
-// the pinned words RefineModel's kernels write, per slot (DeviceCtx::defer_refine; slot 0 otherwise)
-static int refine_slot(const DeviceCtx* ctx) { return ctx->defer_refine ? ctx->refine_slot : 0; }
-static double* h_best_at(DeviceCtx* ctx) { return ctx->h_best.as<double>() + (size_t)refine_slot(ctx) * kModelStride; }
-static uint8_t* h_total_at(DeviceCtx* ctx) { return ctx->h_pick.as<uint8_t>() + 64 + 8 * refine_slot(ctx); }
-static double* h_moments_at(DeviceCtx* ctx) { return ctx->h_moments.as<double>() + (size_t)refine_slot(ctx) * kFusedMomentDoubles; }
-
-static int issue_refine_compaction(DeviceCtx* ctx, const CloudView& flag_view, const uint32_t* orig_dev, int kind,
-                                   double thr, const double* model_dev, const double* lazy_in, void* total_host,
-                                   bool fused = false, uint64_t* idx_host = nullptr, const PartitionOut* part = nullptr) {
-    const uint32_t n = flag_view.n;
-    const uint32_t nb = (n + kCompactTile - 1) / kCompactTile;
-    RESERVE(ctx->idx, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1));
-    CompactScratch scratch;
-    if (const int rc = compact_scratch(ctx, nb, &scratch); rc != M3D_OK) return rc;
-    RESERVE(ctx->total, sizeof(uint32_t) * 4);
-    fused = fused && kind != M3D_CYLINDER;
-    if (fused) {
-        RESERVE(ctx->moment_partial, sizeof(double) * 16 * (size_t)std::max<uint32_t>(nb, 1));
-        RESERVE(ctx->h_moments, sizeof(double) * 2 * kFusedMomentDoubles);
-    }
-    launch_compact(kind, flag_view, model_dev, thr, 0, orig_dev,
-                   idx_dev(ctx), nullptr,
-                   nullptr, nullptr, nullptr, nullptr, 0, scratch,
-                   ctx->total.as<uint32_t>(), ctx->stream, const_cast<double*>(lazy_in),
-                   fused ? ctx->moment_partial.as<double>() : nullptr, fused ? h_moments_at(ctx) : nullptr,
-                   idx_host, static_cast<uint32_t*>(total_host) /* pinned: the kernel writes the total there itself */, part);
-    ctx->compaction_fused = fused;
-    ctx->compaction_idx_host = idx_host;
-    return M3D_OK;
-}
-
-static int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_view,
-                  const uint32_t* orig_dev, int kind, double thr, const double* model_dev,
-                  double* params_host /* in: best minimal model, out: refined */, size_t* inliers,
-                  size_t* n_inliers, int* general_fit_ok, int64_t expected_ni = -1,
-                  const std::function<int(int64_t)>* before_wait = nullptr,
-                  const double* lazy_in = nullptr /* pinned: the "in" value of params_host arrives with the wait */,
-                  const void* compaction_total = nullptr /* pinned: the compaction is already queued (on model_dev) */,
-                  bool fused = false /* model_dev is a minimal_fit_k record: moments ride on the compaction (needs lazy_in) */) {
-    const uint32_t n = flag_view.n;
-    fused = fused && lazy_in != nullptr;
-    RESERVE(ctx->sums, sizeof(double) * 32);
-    RESERVE(ctx->sum_partial, sizeof(double) * kSumPartialDoubles);
-    RESERVE(ctx->h_sums, sizeof(double) * kGeneralFitHostDoubles);
-    RESERVE(ctx->h_small, 256);
-    uint8_t* h = ctx->h_small.as<uint8_t>();
-    const uint8_t* h_total = compaction_total ? static_cast<const uint8_t*>(compaction_total) : h;
-    if (!compaction_total) {
-        uint64_t* idx_host = inliers && fused && !ctx->idx_out_override &&
-                                     is_library_pinned(inliers, sizeof(uint64_t) * (size_t)std::max<uint32_t>(n, 1))
-                                 ? reinterpret_cast<uint64_t*>(inliers) : nullptr;
-        const PartitionOut* part = ctx->partition_hook && orig_dev ? (*ctx->partition_hook)(expected_ni) : nullptr;
-        const int rc = issue_refine_compaction(ctx, flag_view, orig_dev, kind, thr, model_dev, lazy_in, h, fused, idx_host, part);
-        if (rc != M3D_OK) return rc;
-    }
-    const bool have_moments = fused && ctx->compaction_fused;
-    const bool idx_on_host = inliers && ctx->compaction_idx_host == reinterpret_cast<uint64_t*>(inliers);
-    if (expected_ni >= 0 && (uint64_t)expected_ni <= n) {
-        const uint32_t ni_e = (uint32_t)expected_ni;
-        const bool need_fit_e = kind != M3D_CYLINDER && ni_e >= (kind == M3D_PLANE ? 3u : 4u);
-        if (!(compaction_total && ctx->ev_compact_early)) HIPCHK(hipEventRecord(ctx->ev_compact, ctx->stream));
-        ctx->ev_compact_early = false;
-        // page-locked destination (m3d_host_alloc): the index list leaves NOW, on the copy stream, under the sums
-        // (or has been written by the compaction itself: idx_on_host)
-        const bool early_copy = !idx_on_host && inliers && ni_e && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)ni_e);
-        if (early_copy) {
-            HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
-            HIPCHK(hipMemcpyAsync(inliers, (void*)idx_dev(ctx),
-                                  sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost, ctx->copy_stream));
-        }
-        if (need_fit_e && !have_moments) {
-            launch_general_fit_sums(gather_view, idx_dev(ctx), ni_e, ctx->sum_partial.as<double>(),
-                                    ctx->h_sums.as<double>(), ctx->stream);
-        }
-        // work the caller wants queued behind these kernels before the host waits (segmentation: the removal of
-        // these very inliers), so that ONE wait covers both
-        bool hooked = false;
-        if (before_wait) {
-            const int hr = (*before_wait)(expected_ni);
-            before_wait = nullptr;
-            hooked = true;
-            if (hr != M3D_OK) return hr;
-        }
-        // last: a copy into the caller's (pageable) buffer keeps the host busy until it is done
-        if (inliers && ni_e && !early_copy && !idx_on_host) {
-            HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
-            HIPCHK(hipMemcpyAsync(inliers, (void*)idx_dev(ctx),
-                                  sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost, ctx->copy_stream));
-        }
-        HIPCHK(hipGetLastError());
-        // everything RefineModel reads is complete at ev_compact when the moments rode on the compaction (or no fit is
-        // due): what the hook queued behind it (segmentation: the removal of these inliers, tens of microseconds of
-        // kernels) is not waited for -- the caller goes on preparing the next round under it
-        if (hooked && (have_moments || !need_fit_e)) {
-            HIPCHK(hipEventSynchronize(ctx->ev_compact));
-        } else {
-            const int wrc = stream_wait_spin(ctx);
-            if (wrc != M3D_OK) return wrc;
-        }
-        // (the copy stream is waited for when THIS call put the list on it -- and not even then when the caller collects
-        // its lists at the end: DeviceCtx::defer_copy_sync)
-        const bool list_on_copy_stream = inliers && ni_e && !idx_on_host;
-        if (list_on_copy_stream && !(ctx->defer_copy_sync && ctx->idx_out_override)) HIPCHK(hipStreamSynchronize(ctx->copy_stream));
-        if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
-        uint32_t ni_chk;
-        std::memcpy(&ni_chk, h_total, 4);
-        if (ni_chk != ni_e)   // should not happen: redo in the order that does not rely on the expectation
-            return refine(ctx, flag_view, gather_view, orig_dev, kind, thr, model_dev, params_host, inliers, n_inliers,
-                          general_fit_ok, -1, nullptr, nullptr, nullptr);
-        *n_inliers = ni_e;
-        *general_fit_ok = 1;
-        if (kind != M3D_CYLINDER) {
-            if (!need_fit_e) {
-                *general_fit_ok = 0;  // MinimalCheck, ransac.h:166-169, 298-301
-            } else {
-                double sums[14];
-                double mean[3];
-                if (have_moments) {
-                    // raw moments about the record's provisional centre -> mean + centred moments (m3d_kernels.hip)
-                    const double* rec = lazy_in;
-                    const double c0[3] = {kind == M3D_PLANE ? rec[4] : rec[0], kind == M3D_PLANE ? rec[5] : rec[1],
-                                          kind == M3D_PLANE ? rec[6] : rec[2]};
-                    moments_about_mean(h_moments_at(ctx), c0, (double)ni_e, mean, sums + 4);
-                } else {
-                    general_fit_sums_finish(ctx->h_sums.as<double>(), sums);
-                    for (int k = 0; k < 3; ++k) mean[k] = sums[k] / (double)ni_e;
-                }
-                double out[4];
-                const bool ok = kind == M3D_PLANE ? plane_from_moments(mean, sums + 4, out)
-                                                  : sphere_from_moments(mean, sums + 4, (double)ni_e, out);
-                if (ok)
-                    std::memcpy(params_host, out, sizeof(out));  // model refined in place
-                else
-                    *general_fit_ok = 0;  // model left as the best minimal model (ransac.h:204-207)
-            }
-        }
-        return M3D_OK;
-    }
-    HIPCHK(hipGetLastError());
-    if (before_wait) {
-        const int hr = (*before_wait)(-1);
-        before_wait = nullptr;
-        if (hr != M3D_OK) return hr;
-    }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
-    uint32_t ni;
-    std::memcpy(&ni, h_total, 4);
-    *n_inliers = ni;
-    *general_fit_ok = 1;
-    const bool need_fit = kind != M3D_CYLINDER;  // cylinder GeneralFit is a no-op, ransac.h:427-433
-    const uint32_t min_pts = kind == M3D_PLANE ? 3 : 4;
-    if (need_fit) {
-        if (ni < min_pts) {
-            *general_fit_ok = 0;  // MinimalCheck, ransac.h:166-169, 298-301
-        } else {
-            launch_general_fit_sums(gather_view, idx_dev(ctx), ni, ctx->sum_partial.as<double>(),
-                                    ctx->h_sums.as<double>(), ctx->stream);
-        }
-    }
-    if (inliers && ni && !idx_on_host)
-        HIPCHK(hipMemcpyAsync(inliers, (void*)idx_dev(ctx), sizeof(uint64_t) * (size_t)ni,
-                              hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (need_fit && *general_fit_ok) {
-        double sums[14];
-        general_fit_sums_finish(ctx->h_sums.as<double>(), sums);
-        const double mean[3] = {sums[0] / (double)ni, sums[1] / (double)ni, sums[2] / (double)ni};
-        double out[4];
-        bool ok;
-        if (kind == M3D_PLANE)
-            ok = plane_from_moments(mean, sums + 4, out);
-        else
-            ok = sphere_from_moments(mean, sums + 4, (double)ni, out);
-        if (ok)
-            std::memcpy(params_host, out, sizeof(out));  // model refined in place
-        else
-            *general_fit_ok = 0;  // model left as the best minimal model (ransac.h:204-207)
-    }
-    return M3D_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // RANSAC::FitModelParallel on a resident view.  Leaves the best minimal model in
 // device memory at ctx->last_best_dev; RefineModel's first kernel forwards it to ctx->h_best (pinned host).
@@ -1604,7 +957,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
     return M3D_OK;
 }
 
-static int validate_fit_args(int kind, size_t n, bool has_normals, double prob) {
+int validate_fit_args(int kind, size_t n, bool has_normals, double prob) {
     // order of the reference's checks: FitCylinder normals (py_common.cpp:50-52), SetProbability
     // (ransac.h:482-487), FitModel's point count (ransac.h:509-513)
     if (kind == M3D_CYLINDER && !has_normals)
@@ -1616,14 +969,14 @@ static int validate_fit_args(int kind, size_t n, bool has_normals, double prob) 
     return M3D_OK;
 }
 
-static uint64_t resolve_seed(const uint64_t* seed) {
+uint64_t resolve_seed(const uint64_t* seed) {
     if (seed) return *seed;
     std::random_device rd;  // utils.h:75
     return rd();
 }
 
 // GeneralFit of a round whose RefineModel was left running (DeviceCtx::deferred): the stream has passed its kernels
-static int finalize_deferred_refine(DeviceCtx* ctx) {
+int finalize_deferred_refine(DeviceCtx* ctx) {
     DeviceCtx::DeferredRefine& d = ctx->deferred;
     if (!d.pending) return M3D_OK;
     d.pending = false;
@@ -1671,11 +1024,11 @@ static int ensure_plane_frames(m3d_cloud* c, int kind, size_t n_hypotheses) {
     return M3D_OK;
 }
 
-static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter, double prob,
+int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter, double prob,
                             uint64_t seed, double* params, size_t* inliers, size_t* n_inliers,
-                            m3d_stats* stats, const std::function<int(int64_t)>* before_refine_wait = nullptr,
-                            size_t* iterations_hint = nullptr /* in: iterations of a similar fit, out: of this one */,
-                            m3d_comm* comm = nullptr) {
+                            m3d_stats* stats, const std::function<int(int64_t)>* before_refine_wait,
+                            size_t* iterations_hint /* in: iterations of a similar fit, out: of this one */,
+                            m3d_comm* comm) {
     DeviceCtx* ctx = c->ctx;
     const double t0 = now_ms();
     HIPCHK(hipSetDevice(ctx->device));
@@ -1796,254 +1149,11 @@ static int cloud_fit_locked(m3d_cloud* c, int kind, double thr, size_t max_iter,
     }
     return gf_ok ? M3D_OK : M3D_FALSE;
 }
-
-// pcd_copy = pcd_copy->SelectByIndex(inliers, true) (iterative_plane_segmentation.cpp:33) on the resident
-// cloud: a stable partition keeps the non-inliers of `model_dev` (distance >= thr, or not comparable) in
-// both copies -- original order (+ the map back to the cloud as created) and Hilbert-sorted (tile boxes
-// recomputed).  The first call allocates the ping-pong buffers.
-// Two halves: cloud_remove_issue enqueues the partitions and the copy of their totals (no host wait: the
-// segmentation loop issues it behind RefineModel's kernels and lets RefineModel's own wait cover both),
-// cloud_remove_finish -- after the stream has been waited for -- checks the totals and switches the cloud over.
-// Without the finish nothing has changed for the caller (the partitions went into the spare buffer set).
-constexpr size_t kRemoveTotalsOffset = 160;   // bytes into h_small (refine() uses 0..127 and 192..255)
-// cloud_remove_prepare: buffers + the destination of the next partition of the cloud in creation order (what mode 2 of
-// launch_compact, or a mode-0 compaction with a PartitionOut, writes)
-static int cloud_remove_prepare(m3d_cloud* c, PartitionOut* out) {
-    DeviceCtx* ctx = c->ctx;
-    m3d_cloud::Work& w = c->work;
-    if (c->has_normals) return fail(M3D_ERR_INVALID_ARG, "removing points from a cloud with normals is not supported");
-    if (!w.active) {
-        c->n0 = c->n;
-        c->n_pad0 = c->n_pad;
-        c->n_tiles0 = c->n_tiles;
-        const size_t bytes = sizeof(double) * (size_t)c->n_pad;
-        const uint32_t scap = c->n_tiles * kTilePoints;
-        bool ok = true;
-        for (int k = 0; k < 2 && ok; ++k)
-            ok = w.bx[k].reserve(bytes) && w.by[k].reserve(bytes) && w.bz[k].reserve(bytes) &&
-                 w.bo[k].reserve(sizeof(uint32_t) * (size_t)c->n_pad) && w.sbx[k].reserve(sizeof(double) * scap) &&
-                 w.sby[k].reserve(sizeof(double) * scap) && w.sbz[k].reserve(sizeof(double) * scap);
-        ok = ok && w.sboxes.reserve(sizeof(double) * kBoxStride * c->n_tiles) &&
-             w.stile_f32.reserve(sizeof(float) * kTileF32Floats * (size_t)c->n_tiles);
-        if (!ok) return M3D_ERR_DEVICE;
-        launch_iota(w.bo[0].as<uint32_t>(), c->n, ctx->stream);
-        w.cur = c->base_view();   // round 0 reads the uploaded cloud directly
-        w.scur = c->sorted();
-        w.cur_orig = w.bo[0].as<uint32_t>();
-        w.pp = w.spp = 0;
-        w.cur_is_v0 = true;
-        w.active = true;
-    }
-    const int dst = w.cur_is_v0 ? 1 : w.pp;
-    out->ox = w.bx[dst].as<double>();
-    out->oy = w.by[dst].as<double>();
-    out->oz = w.bz[dst].as<double>();
-    out->oorig = w.bo[dst].as<uint32_t>();
-    out->n_pad_cap = c->n_pad0;
-    return M3D_OK;
-}
-// partition_done: the partition in creation order has been written by RefineModel's own compaction (PartitionOut)
-// same_slot: a second issue of the SAME round (the first one, queued on the device's early pick, named another model): the
-// totals go where the first one's went -- the other slot still belongs to the previous round's deferred check
-// A removal of `removed` points may kill them in place in the sorted copy instead of partitioning it when it is a sliver
-// (a sixteenth of the live points) and the dead stay below an eighth of the copy
-static bool poison_fits(const m3d_cloud* c, uint64_t removed) {
-    const m3d_cloud::Work& w = c->work;
-    if (!w.tombstones || !w.active || c->has_normals || !config().sorted_tombstones) return false;
-    const uint64_t alive = c->n_sorted - w.sorted_dead;
-    return removed * 16 <= alive && ((uint64_t)w.sorted_dead + removed) * 8 <= c->n_sorted;
-}
-// expected_removed >= 0: the size of this removal is known (the scoring pass counted the inliers): planes may then be
-// removed from the sorted copy by tombstones (poison_fits)
-static int cloud_remove_issue(m3d_cloud* c, int kind, double thr, const double* model_dev, bool partition_done = false,
-                              bool same_slot = false, int64_t expected_removed = -1) {
-    DeviceCtx* ctx = c->ctx;
-    m3d_cloud::Work& w = c->work;
-    PartitionOut po;
-    const int rp = cloud_remove_prepare(c, &po);
-    if (rp != M3D_OK) return rp;
-    const CloudView cur = w.cur;
-    const uint32_t nb = (cur.n + kCompactTile - 1) / kCompactTile;
-    const uint32_t snb = (c->n_sorted + kCompactTile - 1) / kCompactTile;
-    const uint32_t scap = c->n_tiles0 * kTilePoints;
-    CompactScratch scratch;
-    if (const int rc = compact_scratch(ctx, std::max(nb, snb), &scratch); rc != M3D_OK) return rc;
-    RESERVE(ctx->total, 16);
-    RESERVE(ctx->h_small, 256);
-    w.partition_done = partition_done;
-    // the totals go to pinned host memory from the compaction kernels' own tails (two slots: a deferred check reads the
-    // previous removal's totals after the next one has been queued) -- a copy command per round less
-    if (!same_slot) w.totals_slot ^= 1;
-    uint32_t* h_totals = reinterpret_cast<uint32_t*>(ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot);
-    if (!partition_done)
-        launch_compact(kind, cur, model_dev, thr, 2, w.cur_orig, nullptr, nullptr, po.ox, po.oy, po.oz, po.oorig, po.n_pad_cap,
-                       scratch, ctx->total.as<uint32_t>(), ctx->stream, nullptr, nullptr, nullptr,
-                       nullptr, h_totals);
-    w.issue_poison = kind == M3D_PLANE && expected_removed >= 0 && poison_fits(c, (uint64_t)expected_removed);
-    if (w.issue_poison) {
-        // (the kills add up in ctx->poison_total, cleared by the owner of the cloud -- segment_impl -- which compares the sum
-        // with the inlier lists at the end; a real compaction in between checks the live count it leaves)
-        RESERVE(ctx->poison_total, 16);
-        // A round that does not wait for its RefineModel (DeviceCtx::deferred) goes straight on to the next fit: its kill
-        // rides in that fit's minimal_fit_k launch.  The model is then read from the device's pick record, which stays put
-        // until the next fit's records are folded (the winner's slot of the parameter array is rewritten by that launch).
-        const bool ride = ctx->defer_refine && ctx->spec_hit && !ctx->poison_pending;
-        const PoisonJob job = make_poison_job(w.scur, ride ? ctx->pick.as<BestPick>()->params : model_dev, thr,
-                                              ctx->poison_total.as<uint32_t>());
-        if (ride) {
-            ctx->pending_poison = job;
-            ctx->poison_pending = true;
-            ctx->poison_expected_at = &w.poison_expected;
-            ctx->poison_pending_count = (uint64_t)expected_removed;
-        } else {
-            launch_poison_plane_inliers(job, ctx->stream);
-            w.poison_expected += (uint64_t)expected_removed;
-        }
-        HIPCHK(hipGetLastError());
-        return M3D_OK;
-    }
-    // the same stable partition on the sorted copy (every inlier is a finite point; the copy's dead points go too), then
-    // fresh tile boxes
-    CloudView sview;
-    sview.x = w.scur.x;
-    sview.y = w.scur.y;
-    sview.z = w.scur.z;
-    sview.nx = sview.ny = sview.nz = nullptr;
-    sview.n = c->n_sorted;
-    sview.n_pad = w.scur.n_tiles * kTilePoints;
-    if (const int rc = compact_scratch(ctx, std::max(nb, snb), &scratch); rc != M3D_OK) return rc;   // (a launch of its own: the next epoch)
-    launch_compact(kind, sview, model_dev, thr, 3, nullptr, nullptr, nullptr, w.sbx[w.spp].as<double>(),
-                   w.sby[w.spp].as<double>(), w.sbz[w.spp].as<double>(), nullptr, scap,
-                   scratch, ctx->total.as<uint32_t>() + 1, ctx->stream, nullptr, nullptr, nullptr,
-                   nullptr, h_totals + 1);
-    HIPCHK(hipGetLastError());
-    return M3D_OK;
-}
-
-// known_removed == null: the stream has been waited for, the totals are read and checked now.
-// known_removed != null: the caller knows how many points the removal drops (the inlier count RefineModel reported) and has
-// NOT waited for the removal's kernels: the cloud is switched over from that count, and the totals are checked by
-// cloud_remove_check_pending once the stream is known to have passed them.
-static int cloud_remove_finish(m3d_cloud* c, size_t* n_removed, const size_t* known_removed = nullptr) {
-    DeviceCtx* ctx = c->ctx;
-    m3d_cloud::Work& w = c->work;
-    const CloudView cur = w.cur;
-    const int dst = w.cur_is_v0 ? 1 : w.pp;
-    uint32_t new_n, new_sorted;
-    const uint32_t alive = c->n_sorted - w.sorted_dead;   // live points of the sorted copy
-    if (known_removed) {
-        if (*known_removed > cur.n || *known_removed > alive) return fail(M3D_ERR_INTERNAL, "more inliers than points");
-        new_n = cur.n - (uint32_t)*known_removed;
-        new_sorted = alive - (uint32_t)*known_removed;
-        w.pending = true;
-        w.pending_slot = w.totals_slot;
-        w.pending_partition_done = w.partition_done;
-        w.pending_new_n = new_n;
-        w.pending_new_sorted = new_sorted;
-        w.pending_poison = w.issue_poison;   // (a kill has no total of its own: cloud_remove_check_pending skips it)
-    } else {
-        if (w.issue_poison) return fail(M3D_ERR_INTERNAL, "a removal by tombstones needs its size");
-        uint32_t h[2];
-        std::memcpy(h, ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.totals_slot, sizeof(h));
-        new_sorted = h[1];
-        // (a partition written by RefineModel's compaction has no total of its own: the sorted copy's removal count stands
-        // in, and the caller checks it against the length of the inlier list)
-        new_n = w.partition_done ? (new_sorted <= alive && alive - new_sorted <= cur.n
-                                        ? cur.n - (alive - new_sorted) : 0xFFFFFFFFu)
-                                 : h[0];
-    }
-    if (new_n > cur.n || new_sorted > alive || cur.n - new_n != alive - new_sorted)
-        return fail(M3D_ERR_INTERNAL, "the two copies of the cloud disagree on the removed points");
-    if (n_removed) *n_removed = cur.n - new_n;
-    w.last_removed = cur.n - new_n;
-    if (w.issue_poison) {
-        // killed in place: same arrays, same tiles, same (now slightly generous) boxes
-        w.sorted_dead += cur.n - new_n;
-        w.scur.has_dead = true;
-    } else {
-        w.scur.has_dead = false;
-        w.scur.x = w.sbx[w.spp].as<double>();
-        w.scur.y = w.sby[w.spp].as<double>();
-        w.scur.z = w.sbz[w.spp].as<double>();
-        w.scur.boxes = w.sboxes.as<double>();
-        w.scur.tile_f32 = w.stile_f32.as<float>();
-        w.scur.frames = nullptr;   // (new tiles: the frames of the copy as created do not describe them)
-        w.scur.frame_cum = nullptr;
-        w.scur.n_tiles = std::max<uint32_t>(1, (new_sorted + kTilePoints - 1) / kTilePoints);
-        // compact_write_k pads to a multiple of 2048 (capped at the buffer size): whole tiles are NaN-clean
-        launch_tile_boxes(w.scur, w.sboxes.as<double>(), ctx->stream);
-        w.spp ^= 1;
-        w.sorted_dead = 0;
-        c->n_sorted = new_sorted;
-        c->n_tiles = w.scur.n_tiles;
-    }
-    w.cur.x = w.bx[dst].as<double>();
-    w.cur.y = w.by[dst].as<double>();
-    w.cur.z = w.bz[dst].as<double>();
-    w.cur.nx = w.cur.ny = w.cur.nz = nullptr;
-    w.cur.n = new_n;
-    w.cur.n_pad = std::max<uint32_t>(round_up(new_n, kScoreTile), kScoreTile);
-    w.cur_orig = w.bo[dst].as<uint32_t>();
-    if (w.cur_is_v0) {
-        w.cur_is_v0 = false;
-        w.pp = 0;  // bo[0] (iota) is free again: the next compaction goes to set 0
-    } else {
-        w.pp = dst ^ 1;
-    }
-    c->n = new_n;
-    c->n_pad = w.cur.n_pad;
-    return M3D_OK;
-}
-
-// the totals of a removal finished from a known count (cloud_remove_finish), once the stream has passed their copy
-static int cloud_remove_check_pending(m3d_cloud* c) {
-    m3d_cloud::Work& w = c->work;
-    if (!w.pending) return M3D_OK;
-    w.pending = false;
-    uint32_t h[2];
-    std::memcpy(h, c->ctx->h_small.as<uint8_t>() + kRemoveTotalsOffset + 16 * w.pending_slot, sizeof(h));
-    if ((!w.pending_poison && h[1] != w.pending_new_sorted) || (!w.pending_partition_done && h[0] != w.pending_new_n))
-        return fail(M3D_ERR_INTERNAL, "removed points and inlier list disagree");
-    return M3D_OK;
-}
-
-static int cloud_remove_locked(m3d_cloud* c, int kind, double thr, const double* model_dev, size_t* n_removed) {
-    const int rc = cloud_remove_issue(c, kind, thr, model_dev);
-    if (rc != M3D_OK) return rc;
-    HIPCHK(hipStreamSynchronize(c->ctx->stream));
-    return cloud_remove_finish(c, n_removed);
-}
-
-// every device buffer a cloud can own, in one place
-template <class F>
-static void for_each_buffer(m3d_cloud* c, F f) {
-    f(c->x); f(c->y); f(c->z); f(c->nx); f(c->ny); f(c->nz);
-    f(c->sx); f(c->sy); f(c->sz); f(c->boxes); f(c->tile_f32); f(c->frames); f(c->frame_cum);
-    for (int k = 0; k < 2; ++k) {
-        f(c->work.bx[k]); f(c->work.by[k]); f(c->work.bz[k]); f(c->work.bo[k]);
-        f(c->work.sbx[k]); f(c->work.sby[k]); f(c->work.sbz[k]);
-    }
-    f(c->work.sboxes); f(c->work.stile_f32);
-}
-static void release_buffers(m3d_cloud* c) {
-    for_each_buffer(c, [](DevBuf& b) { b.release(); });
-}
 }  // namespace m3d
 
 using namespace m3d;
 
-// ================================================================================================
-// C ABI
-// ================================================================================================
 extern "C" {
-
-const char* m3d_last_error(void) { return g_last_error.c_str(); }
-const char* m3d_version(void) { return "misc3d_amd 0.1 (gfx950)"; }
-int m3d_device_count(void) {
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
-    return count;
-}
 
 void m3d_replay_init(m3d_replay_state* st) {
     std::memset(st, 0, sizeof(*st));
@@ -2069,216 +1179,6 @@ void m3d_replay_chunk(m3d_replay_state* st, size_t n_points, int kind, size_t ma
     replay_range(st, n_points, kind, max_iteration, probability, begin, end, valid, counts, tie, [](size_t) {});
 }
 
-m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, int device) {
-    return m3d_cloud_create_impl(xyz, normals, n, device, /*with_sorted_copy=*/1);
-}
-// with_sorted_copy == 0: no Hilbert-sorted copy and no tile boxes -- what the registration, ICP and boundary entry points
-// need of a resident cloud is its SoA arrays and its bounding box (they sort by their own grids); the fits need the copy
-m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_t n, int device, int with_sorted_copy) {
-    LaneLock lane(device);
-    if (!lane.ctx) return nullptr;
-    return m3d_cloud_create_on(lane.ctx, xyz, normals, n, with_sorted_copy);
-}
-}  // extern "C"
-m3d_cloud* m3d_cloud_create_on(m3d::DeviceCtx* ctx, const double* xyz, const double* normals, size_t n, int with_sorted_copy) {
-    if (!xyz && n > 0) {
-        set_error("xyz is null");
-        return nullptr;
-    }
-    if (n >= ((size_t)1 << 31)) {
-        set_error("point clouds of 2^31 points or more are not supported");
-        return nullptr;
-    }
-    if (hipSetDevice(ctx->device) != hipSuccess) {
-        set_error("hipSetDevice failed");
-        return nullptr;
-    }
-    m3d_cloud* c = new m3d_cloud();
-    c->ctx = ctx;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto t_last = t_begin;
-    const bool phase_timing = config().kernel_timing != 0;
-    auto mark = [&](int slot) {   // (phase clocks drain the stream: only on request)
-        if (!phase_timing) return;
-        (void)hipStreamSynchronize(ctx->stream);
-        const auto t = std::chrono::steady_clock::now();
-        c->setup_ms[slot] += std::chrono::duration<double, std::milli>(t - t_last).count();
-        t_last = t;
-    };
-    c->n = (uint32_t)n;
-    c->n_pad = std::max<uint32_t>(round_up((uint32_t)n, kScoreTile), kScoreTile);
-    c->has_normals = normals != nullptr;
-    const size_t bytes = sizeof(double) * (size_t)c->n_pad;
-    DevBuf& stage = ctx->cc_stage;
-    bool ok = c->x.reserve(bytes) && c->y.reserve(bytes) && c->z.reserve(bytes) &&
-              stage.reserve(sizeof(double) * 3 * std::max<size_t>(n, 1));
-    if (ok && c->has_normals) ok = c->nx.reserve(bytes) && c->ny.reserve(bytes) && c->nz.reserve(bytes);
-    if (ok && n)
-        ok = hipMemcpyAsync(stage.p, xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream) ==
-             hipSuccess;
-    if (ok)
-        launch_aos_to_soa(stage.as<double>(), c->x.as<double>(), c->y.as<double>(), c->z.as<double>(),
-                          c->n, c->n_pad, ctx->stream);
-    if (ok && c->has_normals) {
-        // the staging buffer is reused: stream order keeps the first transpose ahead of this copy
-        if (n)
-            ok = hipMemcpyAsync(stage.p, normals, sizeof(double) * 3 * n, hipMemcpyHostToDevice,
-                                ctx->stream) == hipSuccess;
-        if (ok)
-            launch_aos_to_soa(stage.as<double>(), c->nx.as<double>(), c->ny.as<double>(),
-                              c->nz.as<double>(), c->n, c->n_pad, ctx->stream);
-    }
-    mark(1);
-    // Hilbert-sorted copy + tile boxes for the culled scoring path.  The bounding box of the finite points comes
-    // from the device copy (a host pass over the caller's 10 M-point array took 9 ms, as long as the rest of
-    // the upload and sort together)
-    DevBuf &t_cell = ctx->cc_cell, &t_start = ctx->cc_start, &t_fill = ctx->cc_fill, &t_sums = ctx->cc_sums,
-           &t_total = ctx->cc_total, &t_bbox = ctx->cc_bbox;
-    if (ok) {
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        uint32_t n_finite = 0;
-        if (n) {
-            double bb[7];
-            ok = t_bbox.reserve(sizeof(double) * (kBboxPartialDoubles + 8));
-            if (ok) {
-                launch_bbox(c->x.as<double>(), c->y.as<double>(), c->z.as<double>(), c->n, t_bbox.as<double>(),
-                            t_bbox.as<double>() + kBboxPartialDoubles, ctx->stream);
-                ok = hipMemcpyAsync(bb, t_bbox.as<double>() + kBboxPartialDoubles, sizeof(bb), hipMemcpyDeviceToHost,
-                                    ctx->stream) == hipSuccess &&
-                     hipStreamSynchronize(ctx->stream) == hipSuccess;
-            }
-            if (ok) {
-                for (int k = 0; k < 3; ++k) {
-                    lo[k] = bb[k];
-                    hi[k] = bb[3 + k];
-                }
-                n_finite = (uint32_t)bb[6];
-                if (n_finite) {
-                    for (int k = 0; k < 6; ++k) c->bb[k] = bb[k];
-                    c->bb_known = true;
-                    double m = 0.0;
-                    for (int k = 0; k < 3; ++k) m = std::max(m, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
-                    c->max_abs = m;   // (stays +inf when something is off: the box tests then keep every tile)
-                    double r = 0.0;
-                    for (int k = 0; k < 3; ++k) {
-                        c->origin[k] = 0.5 * lo[k] + 0.5 * hi[k];
-                        r = std::max(r, std::max(hi[k] - c->origin[k], c->origin[k] - lo[k]));
-                    }
-                    if (std::isfinite(r) && std::isfinite(c->origin[0]) && std::isfinite(c->origin[1]) && std::isfinite(c->origin[2]))
-                        c->radius = r * (1.0 + 1e-12);   // (stays +inf otherwise: fp64 box tests)
-                }
-            }
-        }
-        mark(2);
-        const uint32_t cap = std::max<uint32_t>(round_up((uint32_t)n, kTilePoints), kTilePoints);
-        c->n_tiles = with_sorted_copy ? cap / kTilePoints : 0;
-        c->n_sorted = n_finite;
-        if (ok && !with_sorted_copy) n_finite = 0;   // (skips the sort below; c->n_sorted keeps the count)
-        ok = ok && (!with_sorted_copy ||
-                    (c->sx.reserve(sizeof(double) * cap) && c->sy.reserve(sizeof(double) * cap) &&
-                     c->sz.reserve(sizeof(double) * cap) && c->boxes.reserve(sizeof(double) * kBoxStride * c->n_tiles) &&
-                     c->tile_f32.reserve(sizeof(float) * kTileF32Floats * (size_t)c->n_tiles)));
-        if (ok && with_sorted_copy) {
-            launch_fill_nan(c->sx.as<double>(), cap, ctx->stream);
-            launch_fill_nan(c->sy.as<double>(), cap, ctx->stream);
-            launch_fill_nan(c->sz.as<double>(), cap, ctx->stream);
-        }
-        if (ok && n_finite) {
-            double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-            if (!std::isfinite(ext)) ext = 0.0;  // absurdly large clouds: one cell, culling degenerates gracefully
-            // about 8 points per cell, at most 2^8 cells per axis
-            uint32_t bits = 1;
-            while (bits < 8 && ((uint64_t)1 << (3 * bits)) * 8 < n_finite) ++bits;
-            GridDesc gs;
-            gs.K = 0;
-            gs.morton_bits = bits | 0x100u;   // Hilbert order (plain Z-order, bits alone, measured slower: DESIGN.md)
-            gs.nx = gs.ny = gs.nz = 1u << bits;
-            gs.ox = lo[0];
-            gs.oy = lo[1];
-            gs.oz = lo[2];
-            gs.inv_h = ext > 0.0 ? (double)(1u << bits) / (ext * (1.0 + 1e-9)) : 0.0;
-            gs.r2 = gs.h2_in = 0.0;
-            const uint32_t ncell = 1u << (3 * bits);
-            ok = t_cell.reserve(sizeof(uint32_t) * n) && t_start.reserve(sizeof(uint32_t) * ((size_t)ncell + 1)) &&
-                 t_fill.reserve(sizeof(uint32_t) * std::max<size_t>(n, 1)) &&   // rank of every point in its cell
-                 t_sums.reserve(sizeof(uint32_t) * ((size_t)(ncell + 2047) / 2048 + 1)) && t_total.reserve(16);
-            if (ok)
-                launch_grid_build(c->view(), gs, t_cell.as<uint32_t>(), t_start.as<uint32_t>(), t_fill.as<uint32_t>(),
-                                  t_sums.as<uint32_t>(), t_total.as<uint32_t>(), c->sx.as<double>(),
-                                  c->sy.as<double>(), c->sz.as<double>(), ctx->stream);
-        }
-        mark(3);
-        if (ok && with_sorted_copy) launch_tile_boxes(c->sorted(), c->boxes.as<double>(), ctx->stream);
-    }
-    ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-    mark(4);
-    c->setup_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    if (!ok) {
-        if (g_last_error.empty()) set_error("cloud upload failed");
-        release_buffers(c);
-        delete c;
-        return nullptr;
-    }
-    return c;
-}
-void m3d_cloud_destroy_on(m3d_cloud* c) {
-    if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
-    release_buffers(c);   // (to the lane's free list: the next m3d_cloud_create takes them from there)
-    delete c;
-}
-extern "C" {
-
-void* m3d_host_alloc(size_t bytes) {
-    void* p = nullptr;
-    if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocPortable) != hipSuccess || !p) {
-        set_error("hipHostMalloc failed (" + std::to_string(bytes) + " bytes)");
-        return nullptr;
-    }
-    PinnedRegistry& r = pinned_registry();
-    std::lock_guard<std::mutex> lock(r.mu);
-    r.blocks.emplace_back(static_cast<const char*>(p), std::max<size_t>(bytes, 1));
-    return p;
-}
-void m3d_host_free(void* p) {
-    if (!p) return;
-    {
-        PinnedRegistry& r = pinned_registry();
-        std::lock_guard<std::mutex> lock(r.mu);
-        for (size_t i = 0; i < r.blocks.size(); ++i)
-            if (r.blocks[i].first == p) {
-                r.blocks.erase(r.blocks.begin() + (long)i);
-                break;
-            }
-    }
-    (void)hipHostFree(p);
-}
-
-void m3d_cloud_destroy(m3d_cloud* c) {
-    if (!c) return;
-    CtxLock lock(c->ctx);
-    m3d_cloud_destroy_on(c);
-}
-
-void m3d_release_cached(int device) {
-    if (!get_ctx(device)) return;
-    for (int ln = 0; ln < kMaxLanes; ++ln) {   // every lane the device has (none is created here)
-        DeviceCtx* ctx = find_lane(device, ln);
-        if (!ctx) continue;
-        CtxLock lock(ctx);
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-        ctx->cc_stage.release(); ctx->cc_cell.release(); ctx->cc_start.release(); ctx->cc_fill.release();
-        ctx->cc_sums.release(); ctx->cc_total.release(); ctx->cc_bbox.release();
-        if (ctx->seg_staging) m3d_host_free(ctx->seg_staging);
-        ctx->seg_staging = nullptr;
-        ctx->seg_staging_cap = 0;
-    }
-    dev_pool_trim(device);
-}
-
-size_t m3d_cloud_size(const m3d_cloud* c) { return c ? c->n : 0; }
-
 int m3d_cloud_fit(m3d_cloud* c, int kind, double threshold, size_t max_iteration, double probability,
                   const uint64_t* seed, double* params, size_t* inliers, size_t* n_inliers,
                   m3d_stats* stats) {
@@ -2290,8 +1190,10 @@ int m3d_cloud_fit(m3d_cloud* c, int kind, double threshold, size_t max_iteration
                             inliers, n_inliers, stats);
 }
 
+}  // extern "C"
+namespace m3d {
 // std::random_device seeds differ per rank: rank 0's is the fit's (one tiny exchange, only when no seed was given)
-static int agree_seed(m3d_comm* comm, const uint64_t* seed, hipStream_t st, uint64_t* out) {
+int agree_seed(m3d_comm* comm, const uint64_t* seed, hipStream_t st, uint64_t* out) {
     const uint64_t mine = resolve_seed(seed);
     *out = mine;
     if (!comm || comm->world == 1 || seed) return M3D_OK;
@@ -2300,6 +1202,9 @@ static int agree_seed(m3d_comm* comm, const uint64_t* seed, hipStream_t st, uint
     if (rc == M3D_OK) *out = all[0];
     return rc;
 }
+
+}  // namespace m3d
+extern "C" {
 
 int m3d_cloud_fit_sharded(m3d_cloud* c, m3d_comm* comm, int kind, double threshold, size_t max_iteration,
                           double probability, const uint64_t* seed, double* params, size_t* inliers,
@@ -2707,466 +1612,5 @@ int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t*
 }
 
 // m3d_bench_last_segment_ms: where the calling thread's last segmentation call spent its wall clock
-static thread_local double g_seg_ms[6] = {0, 0, 0, 0, 0, 0};
-int m3d_bench_last_segment_ms(double out[6]) {
-    if (!out) return fail(M3D_ERR_INVALID_ARG, "null argument");
-    for (int k = 0; k < 6; ++k) out[k] = g_seg_ms[k];
-    return M3D_OK;
-}
-
-int m3d_bench_cloud_setup_ms(const m3d_cloud* c, double out[5]) {
-    if (!c || !out) return fail(M3D_ERR_INVALID_ARG, "null argument");
-    for (int k = 0; k < 5; ++k) out[k] = c->setup_ms[k];
-    return M3D_OK;
-}
-
-int m3d_bench_fp64_issue_rate(int device, double ms_target, double* tops, double* ms_measured) {
-    if (!tops) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    LaneLock lane(device);
-    DeviceCtx* ctx = lane.ctx;
-    if (!ctx) return M3D_ERR_DEVICE;
-    HIPCHK(hipSetDevice(ctx->device));
-    RESERVE(ctx->small, 256);
-    const int blocks = 256 * 8;   // 8 workgroups of 4 waves per CU: every SIMD holds 8 waves
-    // one wave issues 16 * iters instructions of 4 cycles; a SIMD interleaves its 8 waves
-    auto run = [&](int iters, float* ms) -> int {
-        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-        launch_fp64_issue_probe(ctx->small.as<double>(), blocks, iters, ctx->stream);
-        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-        return M3D_OK;
-    };
-    float ms = 0;
-    int rc = run(256, &ms);   // warm-up + calibration
-    if (rc != M3D_OK) return rc;
-    rc = run(2048, &ms);
-    if (rc != M3D_OK) return rc;
-    const double per_iter = (double)ms / 2048.0;
-    const int iters = (int)std::min(4.0e6, std::max(1024.0, (ms_target > 0 ? ms_target : 2.0) / std::max(per_iter, 1e-9)));
-    rc = run(iters, &ms);
-    if (rc != M3D_OK) return rc;
-    const double ops = (double)blocks * 256.0 * 16.0 * (double)iters;
-    *tops = ops / ((double)ms * 1e-3) / 1e12;
-    if (ms_measured) *ms_measured = ms;
-    return M3D_OK;
-}
-
-int m3d_bench_mfma_probe(int device, const double* xyz512, const double box[6], double max_abs, const double* records, size_t n_h,
-                         double* out_q, double* out_h, float* out_off) {
-    if (!xyz512 || !box || !records || !n_h || !out_q || !out_h || !out_off || n_h > (1u << 20)) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-#ifndef M3D_EXPERIMENTAL
-    (void)device;
-    (void)max_abs;
-    return fail(M3D_ERR_INVALID_ARG, "the MFMA screen is compiled with -DM3D_EXPERIMENTAL only (m3d_bench_experimental() == 0)");
-#else
-    LaneLock lane(device);
-    DeviceCtx* ctx = lane.ctx;
-    if (!ctx) return M3D_ERR_DEVICE;
-    HIPCHK(hipSetDevice(ctx->device));
-    struct Bufs {   // (a test hook: its scratch does not outlive the call)
-        DevBuf pts, box, rec, q, h, off;
-        ~Bufs() {
-            pts.release(); box.release(); rec.release(); q.release(); h.release(); off.release();
-        }
-    } bufs;
-    DevBuf &d_pts = bufs.pts, &d_box = bufs.box, &d_rec = bufs.rec, &d_q = bufs.q, &d_h = bufs.h, &d_off = bufs.off;
-    RESERVE(d_pts, sizeof(double) * 512 * 3);
-    RESERVE(d_box, sizeof(double) * 6);
-    RESERVE(d_rec, sizeof(double) * kModelStride * n_h);
-    RESERVE(d_q, sizeof(double) * 1024 * n_h);
-    RESERVE(d_h, sizeof(double) * 3 * n_h);
-    RESERVE(d_off, sizeof(float) * 512 * 3);
-    HIPCHK(hipMemcpyAsync(d_pts.p, xyz512, sizeof(double) * 512 * 3, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_box.p, box, sizeof(double) * 6, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_rec.p, records, sizeof(double) * kModelStride * n_h, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(d_q.p, 0xFF, sizeof(double) * 1024 * n_h, ctx->stream));
-    HIPCHK(hipMemsetAsync(d_h.p, 0xFF, sizeof(double) * 3 * n_h, ctx->stream));
-    launch_mfma_probe(d_pts.as<double>(), d_box.as<double>(), max_abs, d_rec.as<double>(), (uint32_t)n_h, d_q.as<double>(),
-                      d_h.as<double>(), d_off.as<float>(), ctx->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_q, d_q.p, sizeof(double) * 1024 * n_h, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_h, d_h.p, sizeof(double) * 3 * n_h, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_off, d_off.p, sizeof(float) * 512 * 3, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return M3D_OK;
-#endif
-}
-
-int m3d_bench_experimental(void) { return kExperimentalBuild ? 1 : 0; }
-
-int m3d_cloud_exact_error(m3d_cloud* c, int kind, double threshold, const double* model,
-                          uint64_t* count, double* error) {
-    if (!c || kind < 0 || kind > 2 || !model || !count || !error)
-        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    DeviceCtx* ctx = c->ctx;
-    CtxLock lock(ctx);
-    HIPCHK(hipSetDevice(ctx->device));
-    RESERVE(ctx->small, 256);
-    double tmp[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
-    std::memcpy(tmp, model, sizeof(double) * num_params(kind));
-    HIPCHK(hipMemcpyAsync(ctx->small.p, tmp, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));  // tmp is a stack buffer
-    return exact_error(ctx, c->view(), kind, threshold, ctx->small.as<double>(), count, error);
-}
-
-int m3d_cloud_refine_expect(m3d_cloud* c, int kind, double threshold, double* params, int64_t expected_inliers,
-                            size_t* inliers, size_t* n_inliers) {
-    if (!c || kind < 0 || kind > 2 || !params || !n_inliers)
-        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    DeviceCtx* ctx = c->ctx;
-    CtxLock lock(ctx);
-    HIPCHK(hipSetDevice(ctx->device));
-    RESERVE(ctx->small, 256);
-    RESERVE(ctx->h_small, 256);
-    double tmp[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
-    std::memcpy(tmp, params, sizeof(double) * num_params(kind));
-    // staged through pinned memory (bytes 192.. of h_small; refine() uses the first 128): no host wait before the launches
-    std::memcpy(ctx->h_small.as<uint8_t>() + 192, tmp, sizeof(tmp));
-    HIPCHK(hipMemcpyAsync(ctx->small.p, ctx->h_small.as<uint8_t>() + 192, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
-    int gf = 1;
-    const CloudView v = c->view();
-    const int rc = refine(ctx, v, c->base_view(), c->orig(), kind, threshold, ctx->small.as<double>(), tmp, inliers,
-                          n_inliers, &gf, expected_inliers);
-    if (rc != M3D_OK) return rc;
-    std::memcpy(params, tmp, sizeof(double) * num_params(kind));
-    return gf ? M3D_OK : M3D_FALSE;
-}
-int m3d_cloud_refine(m3d_cloud* c, int kind, double threshold, double* params, size_t* inliers,
-                     size_t* n_inliers) {
-    return m3d_cloud_refine_expect(c, kind, threshold, params, -1, inliers, n_inliers);
-}
-
-int m3d_cloud_remove_inliers(m3d_cloud* c, int kind, double threshold, const double* model, size_t* n_removed) {
-    if (!c || kind < 0 || kind > 2 || !model) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    DeviceCtx* ctx = c->ctx;
-    CtxLock lock(ctx);
-    HIPCHK(hipSetDevice(ctx->device));
-    RESERVE(ctx->small, 256);
-    double tmp[kModelStride] = {0, 0, 0, 0, 0, 0, 0, 0};
-    std::memcpy(tmp, model, sizeof(double) * num_params(kind));
-    HIPCHK(hipMemcpyAsync(ctx->small.p, tmp, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return cloud_remove_locked(c, kind, threshold, ctx->small.as<double>(), n_removed);
-}
-
-size_t m3d_cloud_original_size(const m3d_cloud* c) { return c ? (c->work.active ? c->n0 : c->n) : 0; }
-
-// SegmentPlaneIterative, src/iterative_plane_segmentation.cpp:8-39
-static int segment_impl(const double* xyz, size_t n, double threshold, int max_iteration, double min_ratio,
-                        const uint64_t* seed, int device, m3d_comm* comm, size_t max_clusters, double* planes,
-                        size_t* cluster_offsets, size_t* cluster_indices, size_t* n_clusters,
-                        double* cluster_points = nullptr /* n x 3: the xyz of cluster_indices[i] at 3 i (may be null) */) {
-    if (!planes || !cluster_offsets || !cluster_indices || !n_clusters || (!xyz && n))
-        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    *n_clusters = 0;
-    cluster_offsets[0] = 0;
-    if (n < 3) {  // :13-17: LogWarning + empty result
-        set_error("Point cloud size has less than 3.");
-        return M3D_FALSE;
-    }
-    const double t_call = now_ms();
-    m3d_cloud* c0 = m3d_cloud_create(xyz, nullptr, n, device);
-    if (!c0) return M3D_ERR_DEVICE;
-    DeviceCtx* ctx = c0->ctx;
-    c0->work.tombstones = true;   // (a private cloud, planes only: the sorted copy may carry dead points between rounds)
-    bool poison_ready = false;
-    int rc = M3D_OK;
-    const double t_created = now_ms();
-    double t_rounds = t_created, t_copied = t_created;
-    size_t rounds_done = 0, big_rounds = 0;
-    double t_big = 0;
-    {
-        CtxLock lock(ctx);
-        // The cross-round state of a segmentation (a tombstone pass waiting to ride in the next fit, a RefineModel finished one
-        // round late, lists leaving through the copy engine) lives on the device context and points into THIS call's cloud and
-        // the caller's buffers: however the block is left, the context goes back to idle and keeps none of those pointers
-        // (the explicit resets below stay where their order matters).
-        struct StateGuard {
-            DeviceCtx* ctx;
-            ~StateGuard() {
-                ctx->defer_refine = false;
-                ctx->defer_copy_sync = false;
-                ctx->idx_out_override = nullptr;
-                ctx->poison_pending = false;
-                ctx->poison_expected_at = nullptr;
-                ctx->poison_pending_count = 0;
-                ctx->deferred.pending = false;
-                ctx->deferred.params_out = nullptr;
-                ctx->spec_hit = false;
-            }
-        } state_guard{ctx};
-        uint64_t seed0 = 0;
-        rc = agree_seed(comm, seed, ctx->stream, &seed0);
-        poison_ready = ctx->poison_total.reserve(16) && hipMemsetAsync(ctx->poison_total.p, 0, 16, ctx->stream) == hipSuccess;
-        if (!poison_ready) c0->work.tombstones = false;
-        ctx->deferred.pending = false;
-        ctx->poison_pending = false;
-        ctx->defer_refine = !comm && config().speculative_refine != 0;   // (one GPU: DeviceCtx::deferred)
-        // A pageable destination is reached through staged copies, a blocking one per round, into pages that fault on first
-        // touch (10 M points: 43 ms against 37): the rounds write into a page-locked staging array the device context keeps
-        // -- the compaction kernels store the index lists straight into it -- and the lists are copied over at the end.
-        size_t* idx_out = cluster_indices;
-        constexpr size_t kStagingMax = (size_t)1 << 25;   // entries (256 MB); larger clouds keep the direct path
-        if (n <= kStagingMax && !is_library_pinned(cluster_indices, sizeof(size_t) * n)) {
-            if (ctx->seg_staging_cap < n) {
-                if (ctx->seg_staging) m3d_host_free(ctx->seg_staging);
-                ctx->seg_staging_cap = 0;
-                ctx->seg_staging = m3d_host_alloc(sizeof(size_t) * (n + n / 4));
-                if (ctx->seg_staging) ctx->seg_staging_cap = n + n / 4;
-            }
-            if (ctx->seg_staging) idx_out = static_cast<size_t*>(ctx->seg_staging);
-        }
-        // rounds on a large part of the cloud: lists of megabytes leave through the copy engine (DeviceCtx::idx_out_override)
-        DevBuf seg_idx_dev;
-        const bool lists_by_copy_engine = rc == M3D_OK && !comm && is_library_pinned(idx_out, sizeof(size_t) * n) &&
-                                          n >= ((size_t)1 << 20) && seg_idx_dev.reserve(sizeof(uint64_t) * n);
-        ctx->defer_copy_sync = lists_by_copy_engine;
-        size_t count = 0, k = 0;
-        size_t iterations_hint = 0;   // iterations the previous round took: sizes this round's second chunk up front
-        const size_t target = (size_t)((1 - min_ratio) * (double)n);  // :28
-        while (rc == M3D_OK && count < target && k < max_clusters) {
-            if (c0->n < 3) {  // the reference's FitModel would throw here (ransac.h:510-513)
-                rc = 2;
-                break;
-            }
-            // ransac.FitModel(threshold, plane, inliers), :29-31; probability stays at the RANSAC default
-            // (ransac.h:462); inlier indices refer to the cloud as created (c0->orig()).  The return value
-            // (GeneralFit) is ignored by the reference.
-            double* plane = planes + 4 * k;   // (written by the fit, or -- a deferred RefineModel -- while the next round runs)
-            plane[0] = plane[1] = plane[2] = plane[3] = 0.0;
-            size_t ni = 0;
-            const size_t off = cluster_offsets[k];
-            const double t_round0 = now_ms();
-            const bool big_round = c0->n > (uint32_t)(n / 8);
-            // The removal of the round's inliers (:33) is queued behind RefineModel's kernels, before RefineModel
-            // waits for them: the pre-refinement model is already on the device and the inlier count is known
-            // from the scoring pass, so the round costs one host wait less.  Not on the last round.
-            bool removal_issued = false, partition_fused = false, spec_removal = false;
-            PartitionOut part_out;
-            // RefineModel's compaction evaluates the very flags the removal needs: it writes the partition of the cloud
-            // in creation order as well (one count, one scan and one write launch less per round)
-            const std::function<const PartitionOut*(int64_t)> partition_hook = [&](int64_t expected_ni) -> const PartitionOut* {
-                // -2: asked before the inlier count is known (compaction queued on the device's own pick, run_ransac): the
-                // partition goes to the spare buffers and is simply not used should this turn out to be the last round
-                if (expected_ni == -3) {   // the speculative compaction has been queued: the sorted copy's removal behind it
-                    // (a round that will kill its inliers in place cannot do so on a guess: the kill is queued once the
-                    // replay has confirmed the pick -- still in front of the device, which is busy with the compaction)
-                    if (partition_fused && !spec_removal && !poison_fits(c0, c0->work.last_removed) &&
-                        cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->pick.as<BestPick>()->params, true) == M3D_OK)
-                        spec_removal = true;
-                    return nullptr;
-                }
-                if (expected_ni == -2) {
-                    if (k + 1 >= max_clusters) return nullptr;
-                } else if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) {
-                    return nullptr;
-                }
-                if (cloud_remove_prepare(c0, &part_out) != M3D_OK) return nullptr;
-                partition_fused = true;
-                return &part_out;
-            };
-            const std::function<int(int64_t)> issue_removal = [&](int64_t expected_ni) -> int {
-                if (expected_ni <= 0 || count + (size_t)expected_ni >= target || k + 1 >= max_clusters) return M3D_OK;
-                removal_issued = true;
-                if (spec_removal && ctx->spec_hit) return M3D_OK;   // (queued on the device's pick, which the replay confirmed)
-                return cloud_remove_issue(c0, M3D_PLANE, threshold, ctx->last_best_dev, partition_fused, /*same_slot=*/spec_removal,
-                                          expected_ni);
-            };
-            ctx->partition_hook = &partition_hook;
-            ctx->idx_out_override = lists_by_copy_engine && big_round ? seg_idx_dev.as<uint64_t>() + off : nullptr;
-            ctx->no_prune_hint = !comm && k > 0 && (uint64_t)c0->work.last_removed * 32 < c0->n;   // (the previous round's plane: < 3 % of the cloud)
-            rc = cloud_fit_locked(c0, M3D_PLANE, threshold, (size_t)max_iteration, 0.9999, seed0 + k, plane,
-                                  idx_out + off, &ni, nullptr, &issue_removal, &iterations_hint, comm);
-            ctx->partition_hook = nullptr;
-            ctx->idx_out_override = nullptr;
-            ctx->no_prune_hint = false;
-            if (rc < 0) break;
-            rc = cloud_remove_check_pending(c0);   // (the previous round's removal: this round's wait lay behind it)
-            if (rc != M3D_OK) break;
-            if (ni == 0) {  // the reference would loop forever (:29,:35)
-                rc = 2;
-                break;
-            }
-            cluster_offsets[k + 1] = off + ni;
-            count += ni;
-            k++;
-            rounds_done++;
-            if (big_round) {
-                big_rounds++;
-                t_big += now_ms() - t_round0;
-            }
-            if (count >= target || k >= max_clusters) break;
-            // pcd_copy = pcd_copy->SelectByIndex(inliers, true), :33 -- inliers of the PRE-refinement model,
-            // still on the device (ctx->last_best_dev)
-            size_t removed = 0;
-            if (partition_fused && !removal_issued) {   // (the two hooks take the same decision from the same count)
-                rc = fail(M3D_ERR_INTERNAL, "partition written without the removal being queued");
-                break;
-            }
-            // (a removal queued by the hook is NOT waited for: its size is the inlier count; its totals are checked after
-            // the next round's wait, which the stream reaches behind them)
-            rc = removal_issued ? cloud_remove_finish(c0, &removed, &ni)
-                                : cloud_remove_locked(c0, M3D_PLANE, threshold, ctx->last_best_dev, &removed);
-            if (rc != M3D_OK) break;
-            if (removed != ni) {
-                rc = fail(M3D_ERR_INTERNAL, "removed points and inlier list disagree");
-                break;
-            }
-        }
-        *n_clusters = k;
-        // the points killed in place in the sorted copy over the whole call against the inlier lists of those rounds
-        uint32_t killed = 0;
-        if (poison_ready && c0->work.poison_expected)
-            (void)hipMemcpyAsync(&killed, ctx->poison_total.p, sizeof(killed), hipMemcpyDeviceToHost, ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream);
-        if (lists_by_copy_engine) (void)hipStreamSynchronize(ctx->copy_stream);   // (the big rounds' lists)
-        ctx->defer_copy_sync = false;
-        seg_idx_dev.release();
-        ctx->defer_refine = false;
-        ctx->poison_pending = false;   // (the last round's kill has nobody left to serve)
-        if (rc == M3D_OK || rc == 2) {   // the last round's RefineModel
-            const int fr = finalize_deferred_refine(ctx);
-            if (fr != M3D_OK) rc = fr;
-        }
-        ctx->deferred.pending = false;
-        if (rc == M3D_OK) rc = cloud_remove_check_pending(c0);
-        if ((rc == M3D_OK || rc == 2) && poison_ready && (uint64_t)killed != c0->work.poison_expected)
-            rc = fail(M3D_ERR_INTERNAL, "the sorted copy's tombstones and the inlier lists disagree");
-        t_rounds = now_ms();
-        // the clusters' points (SelectByIndex, :32): gathered from the resident cloud as created, one copy back
-        if ((rc == M3D_OK || rc == 2) && cluster_points && k && cluster_offsets[k]) {
-            const size_t total = cluster_offsets[k];
-            DevBuf d_idx, d_out;
-            bool ok = d_idx.reserve(sizeof(uint64_t) * total) && d_out.reserve(sizeof(double) * 3 * total);
-            ok = ok && hipMemcpyAsync(d_idx.p, idx_out, sizeof(uint64_t) * total, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-            if (ok) {
-                launch_gather_points(c0->base_view(), d_idx.as<uint64_t>(), total, d_out.as<double>(), ctx->stream);
-                ok = hipMemcpyAsync(cluster_points, d_out.p, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                     hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-            }
-            d_idx.release();
-            d_out.release();
-            if (!ok) rc = fail(M3D_ERR_DEVICE, "gathering the clusters' points failed");
-        }
-        if (idx_out != cluster_indices && k) std::memcpy(cluster_indices, idx_out, sizeof(size_t) * cluster_offsets[k]);
-        t_copied = now_ms();
-    }
-    m3d_cloud_destroy(c0);
-    g_seg_ms[0] = now_ms() - t_call;
-    g_seg_ms[1] = t_created - t_call;
-    g_seg_ms[2] = t_rounds - t_created;
-    g_seg_ms[3] = t_copied - t_rounds;
-    g_seg_ms[4] = t_big;
-    g_seg_ms[5] = (double)big_rounds + 1e-4 * (double)rounds_done;
-    if (rc == 2) return 2;
-    return rc == M3D_OK ? M3D_OK : rc;
-}
-
-int m3d_segment_plane_iterative(const double* xyz, size_t n, double threshold, int max_iteration,
-                                double min_ratio, const uint64_t* seed, int device, size_t max_clusters,
-                                double* planes, size_t* cluster_offsets, size_t* cluster_indices,
-                                size_t* n_clusters) {
-    return segment_impl(xyz, n, threshold, max_iteration, min_ratio, seed, device, nullptr, max_clusters, planes,
-                        cluster_offsets, cluster_indices, n_clusters);
-}
-
-int m3d_segment_plane_iterative_clouds(const double* xyz, size_t n, double threshold, int max_iteration,
-                                       double min_ratio, const uint64_t* seed, int device, size_t max_clusters,
-                                       double* planes, size_t* cluster_offsets, size_t* cluster_indices,
-                                       double* cluster_points, size_t* n_clusters) {
-    return segment_impl(xyz, n, threshold, max_iteration, min_ratio, seed, device, nullptr, max_clusters, planes,
-                        cluster_offsets, cluster_indices, n_clusters, cluster_points);
-}
-
-int m3d_segment_plane_iterative_sharded(const double* xyz, size_t n, double threshold, int max_iteration,
-                                        double min_ratio, const uint64_t* seed, int device, m3d_comm* comm,
-                                        size_t max_clusters, double* planes, size_t* cluster_offsets,
-                                        size_t* cluster_indices, size_t* n_clusters) {
-    if (comm && comm->transport == m3d_comm::kRccl && comm->device != device)
-        return fail(M3D_ERR_INVALID_ARG, "the RCCL communicator lives on another device");
-    return segment_impl(xyz, n, threshold, max_iteration, min_ratio, seed, device, comm, max_clusters, planes,
-                        cluster_offsets, cluster_indices, n_clusters);
-}
-
-// ---- one process, several devices: a thread, a replica and a LOCAL communicator per device ----------------------
-namespace {
-int run_on_devices(const int* devices, int n_dev, const std::function<int(int, m3d_comm*)>& per_rank) {
-    if (!devices || n_dev < 1) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    for (int a = 0; a < n_dev; ++a)
-        for (int b = a + 1; b < n_dev; ++b)
-            if (devices[a] == devices[b]) return fail(M3D_ERR_INVALID_ARG, "devices must be distinct");
-    if (n_dev == 1) return per_rank(0, nullptr);
-    std::vector<m3d_comm*> comms((size_t)n_dev, nullptr);
-    int rc = m3d_comm_create_local(n_dev, comms.data());
-    if (rc != M3D_OK) return rc;
-    std::vector<int> rcs((size_t)n_dev, M3D_OK);
-    std::vector<std::string> errs((size_t)n_dev);
-    std::vector<std::thread> th;
-    for (int r = 1; r < n_dev; ++r)
-        th.emplace_back([&, r] {
-            rcs[(size_t)r] = per_rank(r, comms[(size_t)r]);
-            errs[(size_t)r] = m3d_last_error();
-            if (rcs[(size_t)r] < 0) comms[(size_t)r]->local->abort();   // nobody waits for a rank that has given up
-        });
-    rcs[0] = per_rank(0, comms[0]);
-    if (rcs[0] < 0) comms[0]->local->abort();
-    for (auto& t : th) t.join();
-    for (m3d_comm* q : comms) m3d_comm_destroy(q);
-    for (int r = 1; r < n_dev; ++r)
-        if (rcs[(size_t)r] < 0 && rcs[0] >= 0) {   // a helper rank failed: report its error
-            set_error("device " + std::to_string(devices[r]) + ": " + errs[(size_t)r]);
-            return rcs[(size_t)r];
-        }
-    return rcs[0];
-}
-}  // namespace
-
-int m3d_segment_plane_iterative_multi(const double* xyz, size_t n, double threshold, int max_iteration,
-                                      double min_ratio, const uint64_t* seed, const int* devices, int n_dev,
-                                      size_t max_clusters, double* planes, size_t* cluster_offsets,
-                                      size_t* cluster_indices, size_t* n_clusters) {
-    if (!planes || !cluster_offsets || !cluster_indices || !n_clusters || (!xyz && n))
-        return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    const uint64_t seed0 = resolve_seed(seed);   // one seed for all ranks
-    const size_t cap = std::min(max_clusters, n);
-    return run_on_devices(devices, n_dev, [&](int r, m3d_comm* comm) -> int {
-        if (r == 0)
-            return segment_impl(xyz, n, threshold, max_iteration, min_ratio, &seed0, devices[0], comm, max_clusters, planes,
-                                cluster_offsets, cluster_indices, n_clusters);
-        // helper ranks compute the same result into scratch (every rank removes the same inliers from its replica)
-        std::vector<double> pl(4 * std::max<size_t>(cap, 1));
-        std::vector<size_t> off(cap + 2), idx(std::max<size_t>(n, 1));
-        size_t k = 0;
-        return segment_impl(xyz, n, threshold, max_iteration, min_ratio, &seed0, devices[r], comm, max_clusters, pl.data(),
-                            off.data(), idx.data(), &k);
-    });
-}
-
-int m3d_fit_multi(int kind, const double* xyz, const double* normals, size_t n, double threshold, size_t max_iteration,
-                  double probability, const uint64_t* seed, const int* devices, int n_dev, double* params,
-                  size_t* inliers, size_t* n_inliers, m3d_stats* stats) {
-    if (!params || (!xyz && n) || kind < 0 || kind > 2) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
-    const int vr = validate_fit_args(kind, n, normals != nullptr, probability);
-    if (vr != M3D_OK) return vr;
-    const uint64_t seed0 = resolve_seed(seed);
-    return run_on_devices(devices, n_dev, [&](int r, m3d_comm* comm) -> int {
-        m3d_cloud* c = m3d_cloud_create(xyz, normals, n, devices[r]);
-        if (!c) return M3D_ERR_DEVICE;
-        int rc;
-        if (r == 0) {
-            rc = m3d_cloud_fit_sharded(c, comm, kind, threshold, max_iteration, probability, &seed0, params, inliers,
-                                       n_inliers, stats);
-        } else {
-            double par[kModelStride];
-            size_t ni = 0;
-            rc = m3d_cloud_fit_sharded(c, comm, kind, threshold, max_iteration, probability, &seed0, par, nullptr, &ni,
-                                       nullptr);
-        }
-        m3d_cloud_destroy(c);
-        return rc;
-    });
-}
 
 }  // extern "C"

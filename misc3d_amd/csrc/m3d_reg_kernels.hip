@@ -226,7 +226,7 @@ __global__ void fill_nan_k(double* __restrict__ p, uint32_t n) {
     if (i < n) p[i] = u2f(0x7FF8000000000000ull);
 }
 // one thread stores `value` into a page-locked host word: queued behind a stream's work, it is the completion signal a host
-// thread spins on (stream_wait_spin, m3d_driver.cpp) -- everything the kernels before it wrote to host memory is visible first
+// thread spins on (stream_wait_spin, m3d_fit.cpp) -- everything the kernels before it wrote to host memory is visible first
 __global__ void signal_host_k(volatile uint32_t* __restrict__ word, uint32_t value) {
     __threadfence_system();
     *word = value;
