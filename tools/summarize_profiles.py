@@ -54,7 +54,11 @@ def main():
                               ("../c5t_timeline.txt", f"{TAG}_c5_round_timeline.txt"),
                               ("../c5_plain.txt", f"{TAG}_c5_plain.txt"),
                               ("../oneshot.txt", f"{TAG}_oneshot.txt"),
-                              ("../c4_full_size_vs_oracle.txt", f"{TAG}_c4_full_size_vs_oracle.txt")):
+                              ("../c4_full_size_vs_oracle.txt", f"{TAG}_c4_full_size_vs_oracle.txt"),
+                              ("../strong_scaling_model.jsonl", f"{TAG}_strong_scaling_model.jsonl"),
+                              ("../n2_pairs_in_flight.jsonl", f"{TAG}_n2_pairs_in_flight.jsonl"),
+                              ("../c3_timeline.txt", f"{TAG}_c3_timeline.txt"),
+                              ("../bench_driver_style.json", f"{TAG}_bench_driver_style.json")):
         q = os.path.join(SRC, src_rel)
         if os.path.exists(q):
             shutil.copy(q, os.path.join(DST, dst_name))
