@@ -215,13 +215,16 @@ if "N2" in which or len(sys.argv) == 1:
         best = None
         for _ in range(3):
             t0 = time.perf_counter()
-            res = capi.register_fragment_pairs(frs, fes, ipairs, vox, seeds=seeds, inflight=inflight)
+            res = capi.register_fragment_pairs(frs, fes, ipairs, vox, seeds=seeds, inflight=inflight, want_stats=True)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         same = all(a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) for a, b in zip(ref, res))
         resident[inflight] = {"ms": best * 1e3, "pairs_per_s": len(ipairs) / best, "identical_to_serial": bool(same)}
+        if inflight == 1:   # a pair alone on resident fragments (the later ones of the call: their fragments are there already)
+            late = [r[3] for r in res[12:]]
+            resident[inflight]["per_pair_ms"] = {k: float(np.median([st[k] for st in late])) for k in ("ms_match", "ms_ransac", "ms_info", "ms_total")}
     capi.restore_config(old_lanes)
-    st = ref[0][3]
+    st = {k: float(np.median([r[3][k] for r in ref])) if k != "n_matches" else ref[0][3][k] for k in ("ms_match", "ms_ransac", "ms_info", "ms_total", "n_matches")}
     emit(f"N2 global_registration_batch {len(pairs)} pairs of {nfrag} pts x 33-D, one device", accepted=int(sum(r[0] for r in ref)),
          per_pair_serial_ms={k: st[k] for k in ("ms_match", "ms_ransac", "ms_info", "ms_total")}, matches=st["n_matches"],
          in_flight=rows, speedup_over_serial={k: rows[1]["ms"] / v["ms"] for k, v in rows.items()},
