@@ -74,6 +74,23 @@ def registration():
     np.savez_compressed(os.path.join(HERE, "registration.npz"), **out)
 
 
+def global_registration():
+    """ReconstructionPipeline::GlobalRegistration (src/pipeline.cpp:790-828) on registration.npz's pair: accepted, and rejected
+    when three quarters of the source are replaced by points that overlap nothing.  Inputs: registration.npz (+ the replacement)."""
+    d = synth.registration_pair_c4(1200, seed=5, dim=33, true_fraction=0.5, sigma=0.001)
+    args = dict(max_iter=1500, edge_thr=0.9, confidence=0.999, seed=23)
+    vox = 0.03 / 1.4
+    ok, T, info, nm = oracle.global_registration(d["src"], d["dst"], d["feat_src"], d["feat_dst"], vox, **args)
+    far = np.random.default_rng(2).uniform(40.0, 60.0, size=(900, 3))
+    cut = d["src"].copy()
+    cut[300:] = far
+    ok2, T2, info2, nm2 = oracle.global_registration(cut, d["dst"], d["feat_src"], d["feat_dst"], vox, **args)
+    assert ok and not ok2
+    np.savez_compressed(os.path.join(HERE, "global_registration.npz"), args=np.array([vox, 1500, 0.9, 0.999, 23]),
+                        ok=np.array([ok, ok2]), T=np.stack([T, T2]), info=np.stack([info, info2]), matches=np.array([nm, nm2]),
+                        far=far)
+
+
 def next_rows():
     """SURVEY.md 8(f) rows that are in: normals from an organised map (N3), point-to-point ICP (N1)."""
     rng = np.random.default_rng(7)
@@ -132,6 +149,7 @@ if __name__ == "__main__":
     example_cloud()
     segmentation()
     registration()
+    global_registration()
     next_rows()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

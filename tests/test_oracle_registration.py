@@ -154,3 +154,68 @@ def test_oracle_icp_against_scipy(orc):
     assert it == n_it and fit == pytest.approx(f0, abs=1e-12) and rm == pytest.approx(r0, rel=1e-9)
     assert np.allclose(T, Tn, rtol=0, atol=1e-9)
     assert np.array_equal(corr >= 0, ok) and np.array_equal(corr[ok], jj[ok])
+
+
+def test_is_identity_follows_eigen(orc):
+    """Eigen::MatrixBase::isIdentity(1e-8) (src/pipeline.cpp:814): diagonal |x - 1| <= min(|x|, 1) prec, off-diagonal
+    |x| <= prec -- boundary cases in exact binary fractions around prec."""
+    import ctypes as C
+    f = orc.lib().orc_is_identity4
+    f.restype = C.c_int
+
+    def ident(T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        return bool(f(T.ctypes.data_as(C.c_void_p), C.c_double(1e-8)))
+
+    assert ident(np.eye(4))
+    for r, c in ((0, 3), (2, 1), (3, 0)):
+        T = np.eye(4); T[r, c] = 1e-8
+        assert ident(T)                        # <= : the bound itself passes
+        T[r, c] = -1.0000001e-8
+        assert not ident(T)
+    T = np.eye(4); T[1, 1] = 1.0 + 9e-9
+    assert ident(T)
+    T[1, 1] = 1.0 + 2e-8
+    assert not ident(T)
+    T = np.eye(4); T[2, 2] = 1.0 - 9e-9       # min(|x|, 1) = |x| < 1: the bound scales with x
+    assert ident(T)
+    T[2, 2] = 0.0
+    assert not ident(T)
+    T = np.eye(4); T[0, 0] = np.nan
+    assert not ident(T)
+
+
+def test_global_registration_is_the_composition(orc):
+    """orc_global_registration (src/pipeline.cpp:790-828) against its parts called one by one: match -> RANSAC at 1.4 voxel ->
+    identity shortcut -> information matrix -> info(5,5) / min(N) < 0.3; accept, reject and shortcut cases."""
+    d = synth.registration_pair_c4(1500, seed=3, dim=33, sigma=0.001)
+    vox = 0.03 / 1.4
+
+    def by_parts(src, dst, fs, fd, **kw):
+        cs, cd = orc.match_mutual_nn(fs, fd)
+        r = orc.registration_ransac(src, dst, cs, cd, thr=vox * 1.4, **kw)
+        T = r.T
+        if np.allclose(T, np.eye(4), rtol=0, atol=1e-8):
+            return True, T, np.eye(6), len(cs)
+        info = orc.information_matrix(src, dst, vox * 1.4, T)
+        if info[5, 5] / min(len(src), len(dst)) < 0.3:
+            return False, T, np.eye(6), len(cs)
+        return True, T, info, len(cs)
+
+    kw = dict(max_iter=600, edge_thr=0.9, confidence=0.999, seed=4)
+    cut = d["src"].copy()
+    cut[400:] = np.random.default_rng(1).uniform(40.0, 60.0, size=(1100, 3))
+    fs0 = np.zeros_like(d["feat_src"]); fs0[:, 1] = np.arange(1500) + 10.0
+    fd0 = np.zeros_like(d["feat_dst"]); fd0[:, 0] = np.arange(1500) + 10.0
+    cases = {"accept": (d["src"], d["dst"], d["feat_src"], d["feat_dst"]), "reject": (cut, d["dst"], d["feat_src"], d["feat_dst"]),
+             "no matches": (d["src"], d["dst"], fs0, fd0)}
+    seen = set()
+    for name, args in cases.items():
+        g = orc.global_registration(*args, vox, **kw)
+        p = by_parts(*args, **kw)
+        assert g[0] == p[0] and g[3] == p[3], name
+        assert np.array_equal(g[1], p[1]) and np.array_equal(g[2], p[2]), name
+        seen.add((g[0], bool(np.array_equal(g[2], np.eye(6))), bool(np.array_equal(g[1], np.eye(4)))))
+    assert seen == {(True, False, False), (False, True, False), (True, True, True)}
+    with pytest.raises(ValueError):
+        orc.global_registration(d["src"][:2], d["dst"], d["feat_src"][:2], d["feat_dst"], vox)
