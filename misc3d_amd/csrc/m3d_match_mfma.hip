@@ -82,6 +82,13 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, boo
 #define M3D_MATCH_STAGE_TILES 4
 #endif
 constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
+// M3D_MATCH_PIPELINE=1 (round 5, measured and refuted: 6.87 -> 8.33-8.40 ms on 200 k x 200 k, with and without scheduling
+// barriers, unrolled by two and by four): tile u + 1's MFMAs issued before tile u's post-processing, on a second accumulator
+// set.  The matrix pipe of a SIMD is shared by its three waves, which already fill it under each other's VALU work; issuing a
+// wave's MFMAs earlier only lengthens the time its 32 accumulator registers are live (146 -> 156 VGPRs).  Off; not compiled.
+#ifndef M3D_MATCH_PIPELINE
+#define M3D_MATCH_PIPELINE 0
+#endif
 static_assert(kStageTiles * 32 <= 256, "a thread carries at most one row threshold (and one run threshold) of the stage");
 constexpr int kStageEntries = kStageTiles * kMfmaSteps * 64;   // h8 entries per stage (14 KB)
 
@@ -166,43 +173,72 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
             const bool more = t + kStageTiles < t1;
             if (more) fetch(t + kStageTiles, regs);   // in flight while this stage is multiplied
             const uint32_t in_stage = min((uint32_t)kStageTiles, t1 - t);
-            for (uint32_t u = 0; u < in_stage; ++u) {
+            // one side after the other: the run minima of a side are dead before the other side's are formed
+            auto side = [&](const f32x16& acc, ScanState& st, float two_e, bool live, uint2* __restrict__ rg, uint32_t q,
+                            uint2* __restrict__ rl, uint32_t& rc, uint32_t u) {
+                const uint32_t row0 = (t + u) * 32u + 4u * half;
+                float g4[4];
+                group_min(acc, g4);
+                mfma_post<MIN_ONLY>(acc, g4, st, two_e, live, row0, ndb, rg);
+                if (REV) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
+                    const bool h = q < nq && (g4[0] <= t4.x || g4[1] <= t4.y || g4[2] <= t4.z || g4[3] <= t4.w);
+                    if (__ballot(h) != 0ull) {
+                        const float* rows = &sthr[buf][u * 32u + 4u * half];
+                        const bool okq = q < nq;
+                        if (__ballot(okq && g4[0] <= t4.x) != 0ull)
+                            rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), okq, row0, rl, rc, rev, q);
+                        if (__ballot(okq && g4[1] <= t4.y) != 0ull)
+                            rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), okq, row0, rl, rc, rev, q);
+                        if (__ballot(okq && g4[2] <= t4.z) != 0ull)
+                            rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), okq, row0, rl, rc, rev, q);
+                        if (__ballot(okq && g4[3] <= t4.w) != 0ull)
+                            rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), okq, row0, rl, rc, rev, q);
+                    }
+                }
+            };
+            // the six MFMAs of database tile u of the stage (both query tiles of the wave)
+            auto multiply = [&](uint32_t u, f32x16& a0, f32x16& a1) {
                 h8 cur[kMfmaSteps];
 #pragma unroll
                 for (int s = 0; s < kMfmaSteps; ++s) cur[s] = stage[buf][(u * kMfmaSteps + s) * 64 + lane];
-                f32x16 acc0 = {0}, acc1 = {0};
+                a0 = f32x16{0};
+                a1 = f32x16{0};
 #pragma unroll
                 for (int s = 0; s < kMfmaSteps; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], acc1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], a1, 0, 0, 0);
                 }
-                const uint32_t row0 = (t + u) * 32u + 4u * half;
-                // one side after the other: the run minima of a side are dead before the other side's are formed
-                auto side = [&](const f32x16& acc, ScanState& st, float two_e, bool live, uint2* __restrict__ rg, uint32_t q,
-                                uint2* __restrict__ rl, uint32_t& rc) {
-                    float g4[4];
-                    group_min(acc, g4);
-                    mfma_post<MIN_ONLY>(acc, g4, st, two_e, live, row0, ndb, rg);
-                    if (REV) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
-                        const bool h = q < nq && (g4[0] <= t4.x || g4[1] <= t4.y || g4[2] <= t4.z || g4[3] <= t4.w);
-                        if (__ballot(h) != 0ull) {
-                            const float* rows = &sthr[buf][u * 32u + 4u * half];
-                            const bool okq = q < nq;
-                            if (__ballot(okq && g4[0] <= t4.x) != 0ull)
-                                rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), okq, row0, rl, rc, rev, q);
-                            if (__ballot(okq && g4[1] <= t4.y) != 0ull)
-                                rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), okq, row0, rl, rc, rev, q);
-                            if (__ballot(okq && g4[2] <= t4.z) != 0ull)
-                                rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), okq, row0, rl, rc, rev, q);
-                            if (__ballot(okq && g4[3] <= t4.w) != 0ull)
-                                rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), okq, row0, rl, rc, rev, q);
-                        }
+            };
+#if M3D_MATCH_PIPELINE
+            // (the refuted variant: see M3D_MATCH_PIPELINE above)
+            f32x16 accA0, accA1, accB0, accB1;
+            multiply(0u, accA0, accA1);
+            for (uint32_t u = 0; u < in_stage; u += 2u) {   // two tiles per trip: the sets alternate without moves, the code stays two copies
+                const bool odd = u + 1u < in_stage;   // (workgroup-uniform)
+                if (odd) {
+                    multiply(u + 1u, accB0, accB1);
+                    // (no scheduling barrier)
+                }
+                side(accA0, sa, two_ea, live_a, ring_a, qa, rl_a, rc_a, u);
+                side(accA1, sb, two_eb, live_b, ring_b, qb, rl_b, rc_b, u);
+                if (odd) {
+                    if (u + 2u < in_stage) {
+                        multiply(u + 2u, accA0, accA1);
+                        // (no scheduling barrier)
                     }
-                };
-                side(acc0, sa, two_ea, live_a, ring_a, qa, rl_a, rc_a);
-                side(acc1, sb, two_eb, live_b, ring_b, qb, rl_b, rc_b);
+                    side(accB0, sa, two_ea, live_a, ring_a, qa, rl_a, rc_a, u + 1u);
+                    side(accB1, sb, two_eb, live_b, ring_b, qb, rl_b, rc_b, u + 1u);
+                }
             }
+#else
+            for (uint32_t u = 0; u < in_stage; ++u) {
+                f32x16 acc0, acc1;
+                multiply(u, acc0, acc1);
+                side(acc0, sa, two_ea, live_a, ring_a, qa, rl_a, rc_a, u);
+                side(acc1, sb, two_eb, live_b, ring_b, qb, rl_b, rc_b, u);
+            }
+#endif
             if (more) park(buf ^ 1, regs);
             __syncthreads();
             buf ^= 1;
