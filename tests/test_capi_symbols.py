@@ -17,7 +17,8 @@ def test_header_symbols_exported(capi):
     names = _declared_functions(open(capi.HEADER_PATH).read())
     assert len(names) >= 40
     for need in ("m3d_cloud_fit_sharded", "m3d_comm_create_rccl", "m3d_segment_plane_iterative_multi", "m3d_segment_plane_iterative_clouds",
-                 "m3d_registration_ransac_sharded", "m3d_set_config"):
+                 "m3d_registration_ransac_sharded", "m3d_set_config", "m3d_global_registration", "m3d_global_registration_batch",
+                 "m3d_register_fragment_pairs"):
         assert need in names
     # measurement hooks live in their own header: none of them in the product header
     assert not [n for n in names if n.startswith("m3d_bench_") or "time_score" in n]
@@ -65,6 +66,41 @@ def test_argument_validation_needs_no_gpu(capi):
     with pytest.raises(capi.M3DError) as e:
         capi.fit(capi.CYLINDER, np.zeros((10, 3)), normals=None, seed=1)   # py_common.cpp:50-52
     assert e.value.code == capi.ERR_NO_NORMALS and "requires normals" in str(e.value)
+
+
+def test_global_registration_argument_validation_needs_no_gpu(capi):
+    """m3d_global_registration / _batch / m3d_register_fragment_pairs check their arguments in front of any device work:
+    the solver's LogError (fewer than 3 points, src/transform_estimation.cpp:130-133), distinct devices, index ranges."""
+    rng = np.random.default_rng(0)
+    pts, feat = rng.normal(size=(50, 3)), rng.uniform(size=(50, 33))
+    with pytest.raises(capi.M3DError) as e:
+        capi.global_registration(pts[:2], pts, feat[:2], feat, 0.01)
+    assert e.value.code == capi.ERR_TOO_FEW_POINTS and "less than 3" in str(e.value)
+    with pytest.raises(capi.M3DError) as e:
+        capi.global_registration_batch([(pts, pts, feat, feat)], 0.01, devices=(0, 0))
+    assert e.value.code == capi.ERR_INVALID_ARG and "distinct" in str(e.value)
+    with pytest.raises(capi.M3DError) as e:
+        capi.register_fragment_pairs([pts, pts], [feat, feat], [(0, 2)], 0.01)
+    assert e.value.code == capi.ERR_INVALID_ARG and "out of range" in str(e.value)
+    assert capi.global_registration_batch([], 0.01) == [] and capi.register_fragment_pairs([pts], [feat], [], 0.01) == []
+    with pytest.raises(ValueError):
+        capi.global_registration(pts, pts, feat[:10], feat, 0.01)       # one descriptor per point
+
+
+def test_round5_config_fields(capi):
+    """lanes, wait_spin_us, prestream, chunk_cap, first_chunk, reg_cells_per_radius: defaults and sanitising (appended fields)."""
+    c = capi.get_config()
+    assert (c.lanes, c.wait_spin_us, c.prestream, c.chunk_cap, c.first_chunk, c.reg_cells_per_radius) == (4, 500, 1, 24576, 2048, 4)
+    old = capi.set_config(lanes=99, wait_spin_us=-5, chunk_cap=100, first_chunk=-1, reg_cells_per_radius=0, prestream=7)
+    try:
+        n = capi.get_config()
+        assert (n.lanes, n.wait_spin_us, n.prestream, n.chunk_cap, n.first_chunk, n.reg_cells_per_radius) == (4, 500, 1, 1024, 0, 4)
+        if not capi.experimental():      # the product build ignores the refuted variants' switches (m3d_kernels.hpp)
+            capi.set_config(score_mfma=1, score_waves4=1, compact_one_pass=1)
+            n = capi.get_config()
+            assert (n.score_mfma, n.score_waves4, n.compact_one_pass) == (0, 0, 0)
+    finally:
+        capi.restore_config(old)
 
 
 def test_no_cpu_fallback(capi):
