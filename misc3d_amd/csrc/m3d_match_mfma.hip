@@ -84,8 +84,9 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, boo
 constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
 // M3D_MATCH_PIPELINE=1 (round 5, measured and refuted: 6.87 -> 8.33-8.40 ms on 200 k x 200 k, with and without scheduling
 // barriers, unrolled by two and by four): tile u + 1's MFMAs issued before tile u's post-processing, on a second accumulator
-// set.  The matrix pipe of a SIMD is shared by its three waves, which already fill it under each other's VALU work; issuing a
-// wave's MFMAs earlier only lengthens the time its 32 accumulator registers are live (146 -> 156 VGPRs).  Off; not compiled.
+// set.  A wave issues in order: its VALU work cannot start before the last of the six MFMAs -- two dependent chains of three --
+// has ISSUED, so nothing overlaps inside the wave and the second accumulator set only lengthens live ranges (146 -> 156 VGPRs).
+// (Also measured: a start offset per workgroup against lockstep phases of a SIMD's three waves: 6.865 ms, nothing.)  Off; not compiled.
 #ifndef M3D_MATCH_PIPELINE
 #define M3D_MATCH_PIPELINE 0
 #endif
