@@ -288,7 +288,9 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
     const uint32_t total = surv_count[0];
     if (total > max_list) {   // (uniform) the old rule kept most of the window: no incumbent worth the name, or a cloud without
         // structure -- the bound would be computed for thousands of hypotheses to drop none (a launch of ~7 us per 1000
-        // of them); the list is discarded, every keep bit stays
+        // of them); the list is discarded, every keep bit stays.  (Workgroup (0, 0) resets the count while others may still be
+        // reading it: harmless ONLY because every outcome of that read returns at once -- `total` too long: here; 0: the next
+        // line.  Nothing may be done with `total` in front of these two exits: ADVICE r4.)
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) surv_count[0] = 0u;
         return;
     }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
         const uint32_t nb = min(64u, total - first);
         const bool has = (uint32_t)lane < nb;
         const uint32_t h = surv[first + (has ? (uint32_t)lane : 0u)];
-        // the 64 hypotheses' records reach the four waves through LDS, fetched ONCE and eight lanes to a record: every wave
+        // the 64 hypotheses' records reach the eight waves through LDS, fetched ONCE and eight lanes to a record: every wave
         // reading its own lane's record took 13 load instructions of 64 cache lines each, four times over (3.6 M line
         // requests per launch)
         __syncthreads();   // (the previous block's records and sums have been read)

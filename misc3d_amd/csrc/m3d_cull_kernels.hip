@@ -481,7 +481,7 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
 // which the scoring kernel that follows adds into -- one command less than a separate memset.
 // Optional by-product of the keep rules (plane_bound_k's input, m3d_bound.hip): the kept hypotheses of the launch as a LIST, in no
 // particular order (one atomic per group of 64) -- *surv_count its length (zero before the launch: cleared by a fit's first
-// minimal_fit_k and by bound_keep_k, which consumes the list).
+// minimal_fit_k and by plane_bound_k, which consumes the list -- the last of its workgroups resets the count).
 struct SurvOut {
     uint32_t* count = nullptr;
     uint32_t* ids = nullptr;

@@ -696,7 +696,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
         iterations_hint = 0;   // (consumed: no second chunk queued on the first pass)
     }
     chunk = std::min(std::min(chunk, chunk_cap), std::max<size_t>((max_iter + 63) / 64 * 64, 64));
-    RESERVE(ctx->best_count, 32);   // cleared by the first chunk's minimal_fit_k (six words: best count, ticket, key, key2)
+    RESERVE(ctx->best_count, 32);   // cleared by the first chunk's minimal_fit_k (eight words: best count, ticket, key, key2, the survivor list's length at word 6)
 
     const bool timing_events = config().kernel_timing != 0;   // (m3d_stats.ms_score / ms_score_kernel)
     const double t_score0 = now_ms();   // (m3d_stats.ms_score: a host clock -- an event pair here cost a fit ~8 us)
