@@ -471,6 +471,9 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
             GridDesc gs;
             // Hilbert order over 128^3 cells: the 64 points of a wave form a compact patch, so the lanes probe the same few
             // target cells
+            // (round 5: 64^3 / 128^3 / 256^3 / 512^3 cells: the forced C4 run 142.3 / 138.5 / 136.8 / 139.0 ms -- and with the source
+            //  pre-aligned to the target's axes, so that a wave's points share target cells, 135.2: the number of DISTINCT cells
+            //  among a wave's lanes is not what the validation kernel's time goes with; profiles/r05_reg_validate_findings.txt)
             const uint32_t fbits = 7u;
             const double hs = ext / 127.0;
             gs.K = 0;
