@@ -203,7 +203,8 @@ def test_concurrent_mixed_calls_match_the_oracle(capi, orc):
         assert g[1] == int(oinfo[5, 5]) and np.allclose(g[0], oinfo, rtol=1e-9, atol=1e-9 * np.abs(oinfo).max())
     jobs.append(("info", lambda: capi.information_matrix(src, dst, 0.03, oreg.T), check_info))
 
-    n_threads, rounds = 10, 6
+    import os
+    n_threads, rounds = 10, int(os.environ.get("M3D_CONCURRENCY_ROUNDS", "6"))   # (a soak: M3D_CONCURRENCY_ROUNDS=100)
     start = threading.Barrier(n_threads)
     errors, done = [], [0] * n_threads
 
