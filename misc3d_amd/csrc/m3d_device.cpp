@@ -154,16 +154,15 @@ DeviceCtx* get_lane(int device, int lane) {
     DeviceCtx* c = new DeviceCtx();
     c->device = device;
     c->lane = lane;
+    // ONE stream per lane to begin with: the runtime deals a process's streams round-robin onto a handful of hardware queues
+    // (GPU_MAX_HW_QUEUES, default 4), and two lanes whose compute streams share a queue run one after the other.  With a copy
+    // and a pre stream per lane created up front, lanes 0 and 1 collided (tools/ubench/lanes_fit.cpp: two threads on two lanes
+    // 1.24x of one, 2.0x when the lanes' streams fell on different queues); both are now created by the first call that needs
+    // them (copy_stream_of / pre_stream_of: fits that ship a list through the copy engine, fits of several chunks).
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&c->ev_compact, hipEventDisableTiming) == hipSuccess &&
+    ok = ok && hipEventCreateWithFlags(&c->ev_compact, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_pre_gate, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
-    {   // (a high-priority stream: its short latency-bound kernels get in between the scoring workgroups)
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        ok = ok && hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, hi) == hipSuccess;
-    }
     for (int k = 0; k < 2 && ok; ++k)
         ok = hipEventCreateWithFlags(&c->slot[k].pre_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming) == hipSuccess &&
@@ -178,6 +177,25 @@ DeviceCtx* get_lane(int device, int lane) {
     return c;
 }
 DeviceCtx* get_ctx(int device) { return get_lane(device, 0); }
+// the lane's secondary streams, created on first use (the caller holds the lane); nullptr + last error on failure
+hipStream_t copy_stream_of(DeviceCtx* ctx) {
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        ctx->copy_stream = nullptr;
+        set_error("failed to create the lane's copy stream");
+    }
+    return ctx->copy_stream;
+}
+hipStream_t pre_stream_of(DeviceCtx* ctx) {
+    if (!ctx->pre_stream) {   // (high priority: its short latency-bound kernels get in between the scoring workgroups)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&ctx->pre_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+            ctx->pre_stream = nullptr;
+            set_error("failed to create the lane's pre stream");
+        }
+    }
+    return ctx->pre_stream;
+}
 static DeviceCtx* find_lane(int device, int lane) {   // an existing lane, or nullptr
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     auto it = g_ctx.find(device * kMaxLanes + lane);

@@ -171,6 +171,8 @@ int information_matrix_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, cons
 void dev_pool_trim(int device);
 DeviceCtx* get_ctx(int device);  // lane 0 of the device; nullptr + last error when the device is unusable
 DeviceCtx* get_lane(int device, int lane);
+hipStream_t copy_stream_of(DeviceCtx* ctx);   // the lane's copy / pre streams, created by the first call that needs them
+hipStream_t pre_stream_of(DeviceCtx* ctx);
 int lane_count();                // m3d_config.lanes, clamped to [1, kMaxLanes]
 
 // Holds a lane for the calling thread: locks its mutex and makes it the lane DevBuf::reserve takes blocks for.

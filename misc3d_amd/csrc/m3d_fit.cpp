@@ -214,7 +214,7 @@ static bool bound_pays(uint32_t n_tiles, size_t window_hypotheses) {
 // when the fit starts -- a removal's compaction of this very cloud, another fit's tail -- must be behind those kernels too.
 static bool prestream_enabled() { return config().prestream != 0; }   // (0: everything on the main stream)
 static int pre_stream_gate(DeviceCtx* ctx) {
-    if (!ctx->pre_stream || !ctx->ev_pre_gate) return M3D_OK;
+    if (!pre_stream_of(ctx) || !ctx->ev_pre_gate) return M3D_OK;   // (created here, by the lane's first fit of several chunks)
     HIPCHK(hipEventRecord(ctx->ev_pre_gate, ctx->stream));
     HIPCHK(hipStreamWaitEvent(ctx->pre_stream, ctx->ev_pre_gate, 0));
     return M3D_OK;
@@ -480,11 +480,11 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 // engine, on the copy stream, while pick_best_k and the early compaction run on the main stream; s.done
                 // then sits on the copy stream.  (pick_best_k's one workgroup would need 40 us for 80 000 records.)
                 HIPCHK(hipEventRecord(ctx->ev_compact, ctx->stream));
-                HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
+                HIPCHK(hipStreamWaitEvent(copy_stream_of(ctx), ctx->ev_compact, 0));
                 HIPCHK(hipMemcpyAsync(s.h_counts.p, rec_dev, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost,
-                                      ctx->copy_stream));
+                                      copy_stream_of(ctx)));
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipEventRecord(s.done, ctx->copy_stream));
+                HIPCHK(hipEventRecord(s.done, copy_stream_of(ctx)));
                 s.host_has_records = true;
                 s.done_on_copy_stream = true;
                 return M3D_OK;

@@ -230,9 +230,9 @@ int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_v
         // (or has been written by the compaction itself: idx_on_host)
         const bool early_copy = !idx_on_host && inliers && ni_e && is_library_pinned(inliers, sizeof(uint64_t) * (size_t)ni_e);
         if (early_copy) {
-            HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
+            HIPCHK(hipStreamWaitEvent(copy_stream_of(ctx), ctx->ev_compact, 0));
             HIPCHK(hipMemcpyAsync(inliers, (void*)idx_dev(ctx),
-                                  sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost, ctx->copy_stream));
+                                  sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost, copy_stream_of(ctx)));
         }
         if (need_fit_e && !have_moments) {
             launch_general_fit_sums(gather_view, idx_dev(ctx), ni_e, ctx->sum_partial.as<double>(),
@@ -249,9 +249,9 @@ int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_v
         }
         // last: a copy into the caller's (pageable) buffer keeps the host busy until it is done
         if (inliers && ni_e && !early_copy && !idx_on_host) {
-            HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compact, 0));
+            HIPCHK(hipStreamWaitEvent(copy_stream_of(ctx), ctx->ev_compact, 0));
             HIPCHK(hipMemcpyAsync(inliers, (void*)idx_dev(ctx),
-                                  sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost, ctx->copy_stream));
+                                  sizeof(uint64_t) * (size_t)ni_e, hipMemcpyDeviceToHost, copy_stream_of(ctx)));
         }
         HIPCHK(hipGetLastError());
         // everything RefineModel reads is complete at ev_compact when the moments rode on the compaction (or no fit is
@@ -266,7 +266,7 @@ int refine(DeviceCtx* ctx, const CloudView& flag_view, const CloudView& gather_v
         // (the copy stream is waited for when THIS call put the list on it -- and not even then when the caller collects
         // its lists at the end: DeviceCtx::defer_copy_sync)
         const bool list_on_copy_stream = inliers && ni_e && !idx_on_host;
-        if (list_on_copy_stream && !(ctx->defer_copy_sync && ctx->idx_out_override)) HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+        if (list_on_copy_stream && !(ctx->defer_copy_sync && ctx->idx_out_override)) HIPCHK(hipStreamSynchronize(copy_stream_of(ctx)));
         if (lazy_in) std::memcpy(params_host, lazy_in, sizeof(double) * kModelStride);
         uint32_t ni_chk;
         std::memcpy(&ni_chk, h_total, 4);

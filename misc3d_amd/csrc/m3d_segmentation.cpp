@@ -419,7 +419,7 @@ int segment_impl(const double* xyz, size_t n, double threshold, int max_iteratio
         if (poison_ready && c0->work.poison_expected)
             (void)hipMemcpyAsync(&killed, ctx->poison_total.p, sizeof(killed), hipMemcpyDeviceToHost, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
-        if (lists_by_copy_engine) (void)hipStreamSynchronize(ctx->copy_stream);   // (the big rounds' lists)
+        if (lists_by_copy_engine) (void)hipStreamSynchronize(copy_stream_of(ctx));   // (the big rounds' lists)
         ctx->defer_copy_sync = false;
         seg_idx_dev.release();
         ctx->defer_refine = false;

@@ -232,6 +232,50 @@ if "N2" in which or len(sys.argv) == 1:
          note="pairs are independent (no collective); what overlaps is one pair's uploads and host-side steps (cross-check, "
               "RANSAC replay, grid set-up) with another pair's kernels")
 
+if "LANES" in which or len(sys.argv) == 1:
+    # lanes (m3d_driver.hpp): independent callers on ONE device -- T host threads, each with its own resident 200 000-point cloud,
+    # each running fit_plane(thr 0.01, 1000 iterations, probability 0.9999) in a loop, and the same with the one-shot m3d_fit_plane
+    # from host arrays (upload + fit + list back per call); fits per second of all threads together.
+    import threading
+    npts = 200_000
+    clouds_xyz = [synth.plane_cloud_c1(npts, 100 + t) for t in range(8)]
+    old_cfg = capi.set_config(lanes=8, kernel_timing=0)
+    rows = {}
+    for mode in ("resident", "one_shot"):
+        rows[mode] = {}
+        for T in (1, 2, 4, 8):
+            clouds = [capi.Cloud(clouds_xyz[t]) for t in range(T)] if mode == "resident" else None
+            reps = 300 if mode == "resident" else 100
+            start = threading.Barrier(T + 1)
+
+            def work(t):
+                f = (lambda: clouds[t].fit(0, 0.01, 1000, 0.9999, seed=7, copy=False)) if mode == "resident" else \
+                    (lambda: capi.fit(0, clouds_xyz[t], None, 0.01, 1000, 0.9999, seed=7, copy=False))
+                for _ in range(10):
+                    f()
+                start.wait()
+                for _ in range(reps):
+                    f()
+                start.wait()
+
+            ths = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            for th in ths:
+                th.start()
+            start.wait()
+            t0 = time.perf_counter()
+            start.wait()
+            dt = time.perf_counter() - t0
+            for th in ths:
+                th.join()
+            rows[mode][T] = {"fits_per_s": T * reps / dt, "ms_per_fit_per_thread": dt / reps * 1e3}
+            if clouds:
+                for c in clouds:
+                    c.close()
+    capi.restore_config(old_cfg)
+    capi.set_config(kernel_timing=1)
+    emit(f"LANES fit_plane {npts} pts x 1000 iterations (adaptive stop), T threads on one device", **rows,
+         speedup={m: {T: rows[m][T]["fits_per_s"] / rows[m][1]["fits_per_s"] for T in rows[m]} for m in rows})
+
 if "N3" in which or len(sys.argv) == 1:
     # EstimateNormalsFromMap at the reference example's size (848 x 480, k = 3) and at 4 Mpixel
     for (w, h, k) in ((848, 480, 3), (2048, 2048, 5)):
