@@ -504,6 +504,10 @@ typedef struct m3d_config {
     int32_t first_chunk;            /* [M3D_FIRST_CHUNK]    default 2048 (0 = off): length of the short first chunk of a fit of several chunks (the
                                        incumbent that prunes the rest) */
     int32_t reg_cells_per_radius;   /* [M3D_REG_K]          default 4 (1..16): cells per search radius of the registration validation's grid */
+    int32_t match_pipeline;         /* [M3D_MATCH_PIPELINE] default 1: a match of two large host matrices (>= 65 536 rows each) uploads them in slices (two of
+                                       the queries, four of the database) and scans block (i, j) while the next slice is on the link (same result:
+                                       tests/test_gpu_match_sliced.py) -- when the call is alone on the device (other calls' kernels fill the gap
+                                       anyway); 0: both matrices uploaded first; 2: sliced whatever the size and the company (the tests' switch) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -58,6 +58,12 @@ int m3d_bench_reg_checkers(const double *ps, const double *pd, const double *T, 
  * 0 (the product build): those switches are ignored and m3d_bench_mfma_probe returns an error. */
 int m3d_bench_experimental(void);
 
+/* TEST hook (tests/test_gpu_match_sliced.py): which way the CALLING THREAD's last m3d_match_mutual_nn went -- bit 0: the split-fp16
+ * MFMA screen produced the result, bit 1: the matrices went up in slices under the scan (m3d_config.match_pipeline), bit 2: a
+ * later slice did not fit the scale chosen from the first ones and the search was redone whole on the resident matrices,
+ * bit 3: the fp32 screen, bit 4: fp64 brute force. */
+unsigned m3d_bench_match_last_path(void);
+
 /* TEST hook (tests/test_gpu_mfma_screen.py): the MFMA screen of the plane scoring (score_mfma_k) on ONE tile -- 512 points
  * xyz (row-major doubles), their box (centre xyz, half extents xyz: every |x - centre| <= half extent), n_h plane records
  * (a, b, c, d, T, 0, 0, 0) -- through the production kernel's own operand builders and the matrix pipe:

@@ -213,7 +213,7 @@ class Config(C.Structure):
                                          "reg_neighbour_lists", "reg_prune", "match_brute", "match_fp32_screen",
                                          "pool_limit_mb", "kernel_timing", "reg_sorted_lists", "score_fp32_screen",
                                          "cull_fp32", "reg_fp32_screen", "sorted_tombstones", "score_mfma", "score_mfma_groups", "score_waves4", "score_waves4_groups", "score_phases", "compact_one_pass", "plane_bound",
-                                         "lanes", "wait_spin_us", "prestream", "chunk_cap", "first_chunk", "reg_cells_per_radius")]
+                                         "lanes", "wait_spin_us", "prestream", "chunk_cap", "first_chunk", "reg_cells_per_radius", "match_pipeline")]
 
 
 def fp64_issue_rate(device=0, ms_target=2.0):
@@ -240,6 +240,14 @@ def mfma_probe(xyz512, box, max_abs, records, device=0):
     _check(f(device, xyz.ctypes.data, bx.ctypes.data, float(max_abs), rec.ctypes.data, len(rec), q.ctypes.data, h.ctypes.data,
              off.ctypes.data))
     return q, h[:, 0].copy(), h[:, 1].copy(), h[:, 2].copy(), off
+
+
+def match_last_path() -> int:
+    """m3d_bench_match_last_path: bit 0 MFMA screen, 1 sliced uploads, 2 redone whole, 3 fp32 screen, 4 brute force (the calling thread's last match)"""
+    f = lib().m3d_bench_match_last_path
+    f.restype = C.c_uint
+    f.argtypes = []
+    return int(f())
 
 
 def experimental() -> bool:

@@ -41,6 +41,7 @@ void sanitize(m3d_config& c) {
     c.chunk_cap = (int32_t)std::min<long>(std::max<long>(((long)c.chunk_cap + 63) / 64 * 64, 1024), 262144);
     c.first_chunk = c.first_chunk <= 0 ? 0 : (int32_t)std::min<long>(((long)c.first_chunk + 63) / 64 * 64, 1 << 20);
     if (c.reg_cells_per_radius < 1 || c.reg_cells_per_radius > 16) c.reg_cells_per_radius = 4;
+    if (c.match_pipeline < 0 || c.match_pipeline > 2) c.match_pipeline = 1;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -74,6 +75,7 @@ void load_env() {
     g_cfg.chunk_cap = (int32_t)env_long("M3D_CHUNK_CAP", 24576);
     g_cfg.first_chunk = (int32_t)env_long("M3D_FIRST_CHUNK", 2048);
     g_cfg.reg_cells_per_radius = (int32_t)env_long("M3D_REG_K", 4);
+    g_cfg.match_pipeline = (int32_t)env_long("M3D_MATCH_PIPELINE", 1);
     sanitize(g_cfg);
 }
 }  // namespace

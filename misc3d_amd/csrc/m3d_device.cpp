@@ -202,13 +202,31 @@ static DeviceCtx* find_lane(int device, int lane) {   // an existing lane, or nu
     return it == g_ctx.end() ? nullptr : it->second;
 }
 
+// calls holding a lane right now, all devices (a hint for calls that would rather spread over several streams when alone)
+static std::atomic<int> g_lanes_held{0};
+int lanes_held() { return g_lanes_held.load(std::memory_order_relaxed); }
+
 CtxLock::CtxLock(DeviceCtx* c) : ctx_(c), prev_lane_(t_lane) {
     ctx_->mu.lock();
+    g_lanes_held.fetch_add(1, std::memory_order_relaxed);
     t_lane = ctx_->lane;
 }
 CtxLock::~CtxLock() {
     t_lane = prev_lane_;
+    g_lanes_held.fetch_sub(1, std::memory_order_relaxed);
     ctx_->mu.unlock();
+}
+// event k of the lane's spare events (no timing), created on first use; nullptr + last error on failure
+hipEvent_t aux_event_of(DeviceCtx* ctx, size_t k) {
+    while (ctx->aux_events.size() <= k) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            set_error("failed to create an event");
+            return nullptr;
+        }
+        ctx->aux_events.push_back(e);
+    }
+    return ctx->aux_events[k];
 }
 
 namespace {
@@ -235,11 +253,13 @@ LaneLock::LaneLock(int device, int prefer) : prev_lane_(t_lane) {
             ctx = mine;
         }
     }
+    g_lanes_held.fetch_add(1, std::memory_order_relaxed);
     t_lane = ctx->lane;
 }
 LaneLock::~LaneLock() {
     if (!ctx) return;
     t_lane = prev_lane_;
+    g_lanes_held.fetch_sub(1, std::memory_order_relaxed);
     ctx->mu.unlock();
 }
 

@@ -146,6 +146,7 @@ struct DeviceCtx {
     uint32_t sync_seq = 0;
     DevBuf surv_list;          // plane_bound_k's input: the hypotheses the keep kernels kept (its length: best_count word 6)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> aux_events;   // aux_event_of: the matcher's upload / part / scan events
 };
 
 constexpr int kMaxLanes = 8;
@@ -173,6 +174,8 @@ DeviceCtx* get_ctx(int device);  // lane 0 of the device; nullptr + last error w
 DeviceCtx* get_lane(int device, int lane);
 hipStream_t copy_stream_of(DeviceCtx* ctx);   // the lane's copy / pre streams, created by the first call that needs them
 hipStream_t pre_stream_of(DeviceCtx* ctx);
+hipEvent_t aux_event_of(DeviceCtx* ctx, size_t k);   // the lane's k-th spare event (no timing), created on first use
+int lanes_held();                              // calls holding a lane right now (all devices)
 int lane_count();                // m3d_config.lanes, clamped to [1, kMaxLanes]
 
 // Holds a lane for the calling thread: locks its mutex and makes it the lane DevBuf::reserve takes blocks for.

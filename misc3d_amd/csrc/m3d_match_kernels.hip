@@ -131,11 +131,14 @@ __global__ __launch_bounds__(256) void nn32_scan_k(const float* __restrict__ q, 
 __global__ __launch_bounds__(256) void nn64_verify_k(const double* __restrict__ q, uint32_t nq, const double* __restrict__ db, int dim,
                               const uint2* __restrict__ ring, const uint32_t* __restrict__ ring_count,
                               const float* __restrict__ part_min, const float* __restrict__ evict_min,
-                              uint32_t splits, float e_coeff, float e_abs, float max_dn2,
+                              uint32_t splits, float e_coeff, float e_abs, float max_dn2_v, const float* __restrict__ max_dn2_p,
                               const float* __restrict__ qn2, uint32_t* __restrict__ nn, uint32_t* __restrict__ overflow_list,
-                              uint32_t* __restrict__ overflow_count) {
+                              uint32_t* __restrict__ overflow_count, uint32_t q_base) {
+    // (q, qn2, nn and the per-query arrays address the launch's nq queries, the first of which is query q_base of the whole matrix --
+    // what the overflow list carries; max |row|^2 of the database: the device cell when there is one, else the host's value)
     const uint32_t i = blockIdx.x * 32u + (threadIdx.x >> 3), sub = threadIdx.x & 7u;
     if (i >= nq) return;   // (whole groups of eight lanes)
+    const float max_dn2 = max_dn2_p ? *max_dn2_p : max_dn2_v;
     float m = INFINITY;
     bool fallback = false;
     for (uint32_t s = sub; s < splits; s += 8) {
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void nn64_verify_k(const double* __restrict__ 
     const unsigned long long fb = __ballot(fallback);
     const uint32_t grp = (threadIdx.x & 63u) >> 3;
     if ((fb >> (8u * grp)) & 0xFFull) {
-        if (sub == 0) overflow_list[atomicAdd(overflow_count, 1u)] = i;
+        if (sub == 0) overflow_list[atomicAdd(overflow_count, 1u)] = q_base + i;
         return;
     }
     double bd = INFINITY;
@@ -340,7 +343,7 @@ hipError_t launch_nn_screened33(const double* q, const float* q32, const float* 
     nn32_scan_k<<<dim3((nq + 511) / 512, splits), 256, 0, s>>>(q32, nq, d32, ndb, per, e_coeff, max_dn2, ring,
                                                               ring_count, part_min, evict_min);
     nn64_verify_k<<<(nq + 31) / 32, 256, 0, s>>>(q, nq, db, DIM, ring, ring_count, part_min, evict_min, splits,
-                                                   e_coeff, 0.0f, max_dn2, qn, nn, overflow_list, overflow_count);
+                                                   e_coeff, 0.0f, max_dn2, nullptr, qn, nn, overflow_list, overflow_count, 0u);
     hipError_t e = hipMemcpyAsync(h_overflow, overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
@@ -367,8 +370,8 @@ __global__ void max_f32_wide_k(const float* __restrict__ v, uint32_t n, uint32_t
     }
     if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(fmaxf(sm[0], 0.0f)));
 }
-void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s) {
-    (void)hipMemsetAsync(out, 0, sizeof(float), s);
+void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s, bool accumulate) {
+    if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float), s);
     if (n) max_f32_wide_k<<<std::min<uint32_t>((n + 255) / 256, 256), 256, 0, s>>>(v, n, reinterpret_cast<uint32_t*>(out));
 }
 void launch_max_abs(const double* f, size_t count, double* partial /* kMaxAbsPartials */, hipStream_t s) {
@@ -469,8 +472,8 @@ void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale
 // windows, with the roles exchanged); a row without a usable bound gets thr = -inf and a counter past the cap, which
 // sends it to the exact fallback.  Rows >= n of the last tile: -inf.
 __global__ void rev_threshold_k(const float* __restrict__ premin, uint32_t slices, uint32_t n, uint32_t n_pad,
-                                const float* __restrict__ n2, float max_other_n2, float* __restrict__ thr,
-                                uint32_t* __restrict__ cnt) {
+                                const float* __restrict__ n2, const float* __restrict__ max_other_n2_p, float* __restrict__ thr,
+                                uint32_t* __restrict__ cnt, bool first_set) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= n_pad) return;
     if (j >= n) {
@@ -479,11 +482,13 @@ __global__ void rev_threshold_k(const float* __restrict__ premin, uint32_t slice
     }
     float m = INFINITY;
     for (uint32_t s = 0; s < slices; ++s) m = fminf(m, premin[(size_t)s * n + j]);
-    const float two_e = 2.0f * (kMfmaECoeff * (n2[j] + max_other_n2) + kMfmaEAbs) * 1.000001f + 1e-30f;
+    const float two_e = 2.0f * (kMfmaECoeff * (n2[j] + *max_other_n2_p) + kMfmaEAbs) * 1.000001f + 1e-30f;
     const float t = m + two_e;
     const bool usable = t < INFINITY && m == m;
     thr[j] = usable ? t : -INFINITY;
-    cnt[j] = usable ? 0u : 0x80000000u;
+    // (a later set of thresholds -- the same minima under the norm bound of more queries -- keeps the counters of the scans so far)
+    if (first_set) cnt[j] = usable ? 0u : 0x80000000u;
+    else if (!usable) atomicOr(cnt + j, 0x80000000u);
 }
 // thr4[g] = max of thr[4g .. 4g + 3]: what the scan's fast path tests the minimum of a run of four rows against
 __global__ void rev_threshold4_k(const float* __restrict__ thr, uint32_t n_groups, float* __restrict__ thr4) {
@@ -495,11 +500,11 @@ __global__ void rev_threshold4_k(const float* __restrict__ thr, uint32_t n_group
 
 // the scan's per-(slice, query) candidate lists sorted by database row: entry (row, d16) of query q -> slot of row
 __global__ void rev_bin_k(const uint2* __restrict__ list, const uint32_t* __restrict__ list_cnt, uint32_t nq, size_t lists,
-                          uint32_t* __restrict__ cnt, uint2* __restrict__ cand) {
+                          uint32_t* __restrict__ cnt, uint2* __restrict__ cand, uint32_t q_base) {
     const size_t o = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (o >= lists) return;
     const uint32_t c = list_cnt[o];   // <= kRevLane (a full list sends the rest straight to the rows' slots)
-    const uint32_t q = (uint32_t)(o % nq);
+    const uint32_t q = q_base + (uint32_t)(o % nq);
     for (uint32_t t = 0; t < c; ++t) {
         const uint2 e = list[o * kRevLane + t];
         const uint32_t slot = atomicAdd(cnt + e.x, 1u) & 0x7FFFFFFFu;
@@ -515,7 +520,7 @@ __global__ void rev_bin_k(const uint2* __restrict__ list, const uint32_t* __rest
 __global__ __launch_bounds__(256) void nn64_verify_rev_k(const double* __restrict__ q, uint32_t nq, const double* __restrict__ db,
                                                           int dim, const uint32_t* __restrict__ cnt,
                                                           const uint2* __restrict__ cand, const float* __restrict__ qn2,
-                                                          float max_dn2, uint32_t* __restrict__ nn,
+                                                          const float* __restrict__ max_dn2_p, uint32_t* __restrict__ nn,
                                                           uint32_t* __restrict__ overflow_list,
                                                           uint32_t* __restrict__ overflow_count) {
     const uint32_t j = blockIdx.x * 32u + (threadIdx.x >> 3), sub = threadIdx.x & 7u;
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(256) void nn64_verify_rev_k(const double* __restric
     float m = INFINITY;
     for (uint32_t t = sub; t < c; t += 8) m = fminf(m, __uint_as_float(my[t].y));
     for (int off = 4; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-    const float win = m + (2.0f * (kMfmaECoeff * (qn2[j] + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f);
+    const float win = m + (2.0f * (kMfmaECoeff * (qn2[j] + *max_dn2_p) + kMfmaEAbs) * 1.000001f + 1e-30f);
     double bd = INFINITY;
     uint32_t bi = 0xFFFFFFFFu;
     for (uint32_t t = sub; t < c; t += 8) {
@@ -557,55 +562,78 @@ __global__ __launch_bounds__(256) void nn64_verify_rev_k(const double* __restric
     if (sub == 0) nn[j] = bi;
 }
 
-// src -> dst AND dst -> src nearest neighbours from one pass over the 32 x 32 product tiles.
+// src -> dst AND dst -> src nearest neighbours from one pass over the 32 x 32 product tiles (MatchWork, m3d_reg_kernels.hpp).
 //   forward: queries = a (qB_a, role 1), database = b (dA_b, role 0): rings of 2 * splits slices + nn64_verify_k;
 //   reverse: the warm-up minima of b's rows over the first tiles of a (qB_b against dA_a) give the per-row thresholds
 //            the main scan tests its accumulators against; nn64_verify_rev_k evaluates the collected candidates.
-// Workspace beyond launch_nn_screened33's (with 2 * splits slices): premin 2 splits x na floats, rev_premin 2 splits_r x nb floats, rthr mfma_tiles(nb) * 40 floats, rcnt nb u32,
-// rcand nb x kRevCap uint2, rlist 2 splits x na x kRevLane uint2 + rlist_cnt 2 splits x na, a second overflow list / counter.
-hipError_t launch_nn_mfma33_both(const double* a, const void* qB_a, const void* dA_a, const float* an2, uint32_t na,
-                                 float max_an2, const double* b, const void* qB_b, const void* dA_b, const float* bn2,
-                                 uint32_t nb, float max_bn2, uint32_t splits, uint32_t splits_r, float* premin, uint2* ring,
-                                 uint32_t* ring_count, float* part_min, float* evict_min, float* rev_premin, float* rthr,
-                                 uint32_t* rcnt, uint2* rcand, uint2* rlist, uint32_t* rlist_cnt, uint32_t* overflow_list,
-                                 uint32_t* overflow_count, uint32_t* overflow_list_r, uint32_t* overflow_count_r,
-                                 uint32_t* nn_ab, uint32_t* nn_ba, uint32_t* h_overflow /* [2] */, hipStream_t s) {
-    constexpr int DIM = 33;
-    h_overflow[0] = h_overflow[1] = 0;
-    if (!na || !nb) return hipSuccess;
-    (void)hipMemsetAsync(overflow_count, 0, sizeof(uint32_t), s);
-    (void)hipMemsetAsync(overflow_count_r, 0, sizeof(uint32_t), s);
-    // reverse warm-up: every row of b against the first 1/8 of a (1/16: twice the candidates and slow-path detours of the
-    // main scan for half the warm-up: 17.3 against 16.9 ms on 200 k x 200 k; 1/4: 17.0)
-    const uint32_t a_tiles = mfma_tiles(na), b_tiles = mfma_tiles(nb);
-    const uint32_t warm_r = std::min<uint32_t>(a_tiles, std::max<uint32_t>(splits_r, a_tiles / 8));
-    launch_nn16_warm(qB_b, bn2, nb, dA_a, na, warm_r, splits_r, max_an2, rev_premin, s);
-    rev_threshold_k<<<(b_tiles * 32u + 255) / 256, 256, 0, s>>>(rev_premin, 2 * splits_r, nb, b_tiles * 32u, bn2, max_an2,
-                                                               rthr, rcnt);
-    float* rthr4 = rthr + (size_t)b_tiles * 32u;   // (the caller's rthr holds 40 floats per tile)
-    rev_threshold4_k<<<(b_tiles * 8u + 255) / 256, 256, 0, s>>>(rthr, b_tiles * 8u, rthr4);
+// The steps are launched one by one by the host (m3d_registration.cpp: match_mfma): a call whose matrices come from the host
+// runs them per slice of the queries and part of the database while the next slice is on the link.
+static size_t mfma_tile_entries() { return (size_t)kMfmaSteps * 64; }   // h8 entries of a packed tile
+void match_pack(const MatchWork& w, int side, uint32_t row0, uint32_t rows, double scale, hipStream_t s) {
+    const double* f = (side == 0 ? w.a : w.b) + (size_t)row0 * 33;
+    h8* dA = reinterpret_cast<h8*>(side == 0 ? w.dA_a : w.dA_b) + (size_t)(row0 / 32u) * mfma_tile_entries();
+    h8* qB = reinterpret_cast<h8*>(side == 0 ? w.qB_a : w.qB_b) + (size_t)(row0 / 32u) * mfma_tile_entries();
+    float* n2 = (side == 0 ? w.an2 : w.bn2) + row0;
+    launch_pack_f16_both(f, rows, scale, dA, qB, n2, s);
+    launch_max_f32(n2, rows, side == 0 ? w.max_an2 : w.max_bn2, s, true);
+}
+void match_forward_warm(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s) {
+    const h8* qB = reinterpret_cast<const h8*>(w.qB_a) + (size_t)(q0 / 32u) * mfma_tile_entries();
+    const uint32_t n_tiles = mfma_tiles(w.nb);
+    // the first 1/16 of the database (same grid as the main pass: every slice of it takes a share)
+    const uint32_t warm = std::min<uint32_t>(n_tiles, std::max<uint32_t>(w.splits, n_tiles / 16));
+    launch_nn16_warm(qB, w.an2 + q0, nq, w.dA_b, w.nb, warm, w.splits, w.max_bn2, w.premin + (size_t)2 * w.splits * q0, s);
+}
+void match_reverse_thresholds(const MatchWork& w, uint32_t row0, uint32_t rows, int set, hipStream_t s) {
+    const uint32_t a_tiles = mfma_tiles(w.na), b_tiles = mfma_tiles(w.nb);
+    float* premin = w.rev_premin + (size_t)2 * w.splits_r * row0;
+    if (set == 0) {
+        // reverse warm-up: the rows against the first 1/8 of a (1/16: twice the candidates and slow-path detours of the
+        // main scan for half the warm-up: 17.3 against 16.9 ms on 200 k x 200 k; 1/4: 17.0)
+        const uint32_t warm_r = std::min<uint32_t>(a_tiles, std::max<uint32_t>(w.splits_r, a_tiles / 8));
+        const h8* qB = reinterpret_cast<const h8*>(w.qB_b) + (size_t)(row0 / 32u) * mfma_tile_entries();
+        launch_nn16_warm(qB, w.bn2 + row0, rows, w.dA_a, w.na, warm_r, w.splits_r, w.max_an2, premin, s);
+    }
+    float* thr = w.rthr + (size_t)set * 40u * b_tiles;   // (a set: 32 row + 8 run thresholds per tile of b)
+    float* thr4 = thr + (size_t)b_tiles * 32u;
+    const uint32_t pad = ((rows + 31u) / 32u) * 32u;
+    rev_threshold_k<<<(pad + 255) / 256, 256, 0, s>>>(premin, 2 * w.splits_r, rows, pad, w.bn2 + row0, w.max_an2, thr + row0,
+                                                       w.rcnt + row0, set == 0);
+    rev_threshold4_k<<<(pad / 4u + 255) / 256, 256, 0, s>>>(thr + row0, pad / 4u, thr4 + row0 / 4u);
+}
+void match_scan(const MatchWork& w, uint32_t q0, uint32_t nq, uint32_t split0, uint32_t splits, uint32_t tile_end, int set,
+                hipStream_t s) {
+    const uint32_t b_tiles = mfma_tiles(w.nb);
+    const size_t base = (size_t)2 * w.splits * q0;   // per-(slice, query) arrays of the queries from q0: [slice][nq] behind those of the queries before
     RevOut rev;
-    rev.thr = rthr;
-    rev.thr4 = rthr4;
-    rev.cnt = rcnt;
-    rev.cand = rcand;
-    rev.list = rlist;
-    rev.list_cnt = rlist_cnt;
-    const uint32_t per = (b_tiles + splits - 1) / splits;
-    launch_nn16_scan(qB_a, an2, na, dA_b, nb, per, splits, max_bn2, premin, ring, ring_count, part_min, evict_min, s, &rev);
-    nn64_verify_k<<<(na + 31) / 32, 256, 0, s>>>(a, na, b, DIM, ring, ring_count, part_min, evict_min, 2 * splits,
-                                                   kMfmaECoeff, kMfmaEAbs, max_bn2, an2, nn_ab, overflow_list,
-                                                   overflow_count);
-    const size_t lists = (size_t)2 * splits * na;
-    rev_bin_k<<<(uint32_t)((lists + 255) / 256), 256, 0, s>>>(rlist, rlist_cnt, na, lists, rcnt, rcand);
-    nn64_verify_rev_k<<<(nb + 31) / 32, 256, 0, s>>>(b, nb, a, DIM, rcnt, rcand, bn2, max_an2, nn_ba, overflow_list_r,
-                                                     overflow_count_r);
-    hipError_t e = hipMemcpyAsync(h_overflow, overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_overflow + 1, overflow_count_r, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return e;
-    if (h_overflow[0]) nn_exact_one_k<<<h_overflow[0], 64, 0, s>>>(a, b, nb, DIM, overflow_list, nn_ab);
-    if (h_overflow[1]) nn_exact_one_k<<<h_overflow[1], 64, 0, s>>>(b, a, na, DIM, overflow_list_r, nn_ba);
+    rev.thr = w.rthr + (size_t)set * 40u * b_tiles;
+    rev.thr4 = rev.thr + (size_t)b_tiles * 32u;
+    rev.cnt = w.rcnt;
+    rev.cand = w.rcand;
+    rev.list = w.rlist + base * kRevLane;
+    rev.list_cnt = w.rlist_cnt + base;
+    rev.q_base = q0;
+    const h8* qB = reinterpret_cast<const h8*>(w.qB_a) + (size_t)(q0 / 32u) * mfma_tile_entries();
+    launch_nn16_scan(qB, w.an2 + q0, nq, w.dA_b, w.nb, std::min(tile_end, b_tiles), w.plan, split0, splits, 2 * w.splits, w.max_bn2,
+                     w.premin + base, w.ring + base * kRing, w.ring_count + base, w.part_min + base, w.evict_min + base, s, &rev);
+}
+void match_verify_forward(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s) {
+    const size_t base = (size_t)2 * w.splits * q0;
+    nn64_verify_k<<<(nq + 31) / 32, 256, 0, s>>>(w.a + (size_t)q0 * 33, nq, w.b, 33, w.ring + base * kRing, w.ring_count + base,
+                                                   w.part_min + base, w.evict_min + base, 2 * w.splits, kMfmaECoeff, kMfmaEAbs, 0.0f,
+                                                   w.max_bn2, w.an2 + q0, w.nn_ab + q0, w.overflow_list, w.overflow_count, q0);
+}
+void match_reverse_bin(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s) {
+    const size_t base = (size_t)2 * w.splits * q0, lists = (size_t)2 * w.splits * nq;
+    rev_bin_k<<<(uint32_t)((lists + 255) / 256), 256, 0, s>>>(w.rlist + base * kRevLane, w.rlist_cnt + base, nq, lists, w.rcnt, w.rcand, q0);
+}
+void match_verify_reverse(const MatchWork& w, hipStream_t s) {
+    nn64_verify_rev_k<<<(w.nb + 31) / 32, 256, 0, s>>>(w.b, w.nb, w.a, 33, w.rcnt, w.rcand, w.bn2, w.max_an2, w.nn_ba,
+                                                        w.overflow_list_r, w.overflow_count_r);
+}
+hipError_t match_exact_fallbacks(const MatchWork& w, const uint32_t* h_overflow /* [2] */, hipStream_t s) {
+    if (h_overflow[0]) nn_exact_one_k<<<h_overflow[0], 64, 0, s>>>(w.a, w.b, w.nb, 33, w.overflow_list, w.nn_ab);
+    if (h_overflow[1]) nn_exact_one_k<<<h_overflow[1], 64, 0, s>>>(w.b, w.a, w.na, 33, w.overflow_list_r, w.nn_ba);
     return hipGetLastError();
 }
 

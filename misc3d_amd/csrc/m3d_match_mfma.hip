@@ -65,7 +65,7 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, boo
                     my[cnt++] = make_uint2(row, __float_as_uint(v));
                 } else {   // list full: straight into the row's slots (what rev_bin_k does with the listed ones)
                     const uint32_t slot = atomicAdd(rev.cnt + row, 1u) & 0x7FFFFFFFu;
-                    if (slot < (uint32_t)kRevCap) rev.cand[(size_t)row * kRevCap + slot] = make_uint2(q, __float_as_uint(v));
+                    if (slot < (uint32_t)kRevCap) rev.cand[(size_t)row * kRevCap + slot] = make_uint2(rev.q_base + q, __float_as_uint(v));
                 }
             }
         }
@@ -100,11 +100,15 @@ constexpr int kStageEntries = kStageTiles * kMfmaSteps * 64;   // h8 entries per
 template <bool MIN_ONLY, bool REV>
 __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
                                                     uint32_t nq, const h8* __restrict__ dA, uint32_t ndb,
-                                                    uint32_t tile_end, uint32_t tiles_per_split, float max_dn2,
+                                                    uint32_t tile_end, SplitPlan plan, uint32_t split0,
+                                                    const float* __restrict__ max_dn2_p,
                                                     const float* __restrict__ init_min, uint32_t init_slices,
                                                     uint2* __restrict__ ring, uint32_t* __restrict__ ring_count,
                                                     float* __restrict__ part_min, float* __restrict__ evict_min,
                                                     RevOut rev) {
+    // (nq queries starting at rev.q_base of the whole query matrix: every per-query pointer is the slice's own; splits
+    // split0 .. split0 + gridDim.y - 1 of the database: a launch may cover a part of either side, MatchWork in m3d_reg_kernels.hpp)
+    const float max_dn2 = *max_dn2_p;   // the largest |row|^2 of the database rows packed so far (>= this launch's rows')
     __shared__ h8 stage[2][kStageEntries];
     __shared__ __attribute__((aligned(16))) float sthr[2][kStageTiles * 32];   // REV: the staged tiles' row thresholds
     __shared__ __attribute__((aligned(16))) float sthr4[2][kStageTiles * 8];   // ... and run thresholds, [tile][half][run]
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
     const float two_eb = 2.0f * (kMfmaECoeff * (nb + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
     const bool live_a = two_ea < INFINITY && qa < nq, live_b = two_eb < INFINITY && qb < nq;
     // slice id = 2 * blockIdx.y + half: the two half-waves of a query see disjoint rows
-    const uint32_t slice = blockIdx.y * 2u + half;
+    const uint32_t slice = (split0 + blockIdx.y) * 2u + half;
     uint2* __restrict__ ring_a = ring + ((size_t)slice * nq + (qa < nq ? qa : nq - 1)) * kRing;
     uint2* __restrict__ ring_b = ring + ((size_t)slice * nq + (qb < nq ? qb : nq - 1)) * kRing;
     // REV: this lane's candidate lists of the reverse search (one per query and slice, like the rings)
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
             if (qb < nq) sb.best = fminf(sb.best, init_min[(size_t)k * nq + qb]);
         }
     }
-    const uint32_t t0 = blockIdx.y * tiles_per_split, t1 = min(tile_end, t0 + tiles_per_split);
+    const uint32_t t0 = plan.begin(split0 + blockIdx.y), t1 = min(tile_end, plan.end(split0 + blockIdx.y));
     if (t0 < t1) {   // block-uniform
         // entry e of a stage = fragment (tile e / 448, step, lane) in packed order: consecutive in memory
         constexpr int kPerThread = (kStageEntries + 255) / 256;   // 4 (the last one only for tid < 128)
@@ -269,31 +273,29 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
 }
 
 void launch_nn16_warm(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb, uint32_t warm_tiles,
-                      uint32_t splits, float max_dn2, float* part_min, hipStream_t s) {
+                      uint32_t splits, const float* max_dn2, float* part_min, hipStream_t s) {
     const dim3 grid((nq + 255) / 256, splits);
-    const uint32_t warm_per = (warm_tiles + splits - 1) / splits;
+    SplitPlan even;
+    even.per = (warm_tiles + splits - 1) / splits;
+    even.full = splits;
     nn16_scan_k<true, false><<<grid, 256, 0, s>>>(reinterpret_cast<const h8*>(qB), qn, nq, reinterpret_cast<const h8*>(dA), ndb,
-                                                  warm_tiles, warm_per, max_dn2, nullptr, 0, nullptr, nullptr, part_min,
+                                                  warm_tiles, even, 0u, max_dn2, nullptr, 0, nullptr, nullptr, part_min,
                                                   nullptr, RevOut());
 }
 
-void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb,
-                      uint32_t tiles_per_split, uint32_t splits, float max_dn2, float* premin /* 2 splits nq */,
-                      uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min, hipStream_t s,
-                      const RevOut* rev) {
+void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb, uint32_t tile_end,
+                      const SplitPlan& plan, uint32_t split0, uint32_t splits, uint32_t init_slices, const float* max_dn2,
+                      const float* premin, uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min,
+                      hipStream_t s, const RevOut* rev) {
     const h8* q8 = reinterpret_cast<const h8*>(qB);
     const h8* d8 = reinterpret_cast<const h8*>(dA);
-    const uint32_t n_tiles = (ndb + 31u) / 32u;
     const dim3 grid((nq + 255) / 256, splits);
-    // warm-up over the first 1/16 of the database (same grid: every slice of the main pass takes a share)
-    const uint32_t warm = std::min<uint32_t>(n_tiles, std::max<uint32_t>(splits, n_tiles / 16));
-    launch_nn16_warm(qB, qn, nq, dA, ndb, warm, splits, max_dn2, premin, s);
     if (rev)
-        nn16_scan_k<false, true><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, n_tiles, tiles_per_split, max_dn2, premin,
-                                                      2 * splits, ring, ring_count, part_min, evict_min, *rev);
+        nn16_scan_k<false, true><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, tile_end, plan, split0, max_dn2, premin,
+                                                      init_slices, ring, ring_count, part_min, evict_min, *rev);
     else
-        nn16_scan_k<false, false><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, n_tiles, tiles_per_split, max_dn2, premin,
-                                                       2 * splits, ring, ring_count, part_min, evict_min, RevOut());
+        nn16_scan_k<false, false><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, tile_end, plan, split0, max_dn2, premin,
+                                                       init_slices, ring, ring_count, part_min, evict_min, RevOut());
 }
 
 }  // namespace m3d

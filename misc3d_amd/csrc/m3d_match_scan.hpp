@@ -69,15 +69,18 @@ struct RevOut {
     uint2* cand = nullptr;        // ndb x kRevCap slots (query, d16 bits): filled by rev_bin_k, and by full lists directly
     uint2* list = nullptr;        // slices x nq x kRevLane entries (row, d16 bits)
     uint32_t* list_cnt = nullptr; // slices x nq
+    uint32_t q_base = 0;          // index of the launch's first query in the whole query matrix (what cand's entries carry)
 };
 
-void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb,
-                      uint32_t tiles_per_split, uint32_t splits, float max_dn2, float* premin /* 2 splits nq */,
-                      uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min, hipStream_t s,
-                      const RevOut* rev = nullptr);
+// the main pass over splits split0 .. split0 + splits - 1 of the database (plan; tiles below tile_end), for the nq queries
+// whose per-query arrays the pointers address; premin = init_slices x nq warm-up minima (launch_nn16_warm); max_dn2: device cell
+void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb, uint32_t tile_end,
+                      const SplitPlan& plan, uint32_t split0, uint32_t splits, uint32_t init_slices, const float* max_dn2,
+                      const float* premin, uint2* ring, uint32_t* ring_count, float* part_min, float* evict_min,
+                      hipStream_t s, const RevOut* rev = nullptr);
 // the warm-up pass alone (running minimum over the first `warm_tiles` tiles of the database, per (slice, query)):
 // part_min receives 2 * splits x nq values
 void launch_nn16_warm(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb, uint32_t warm_tiles,
-                      uint32_t splits, float max_dn2, float* part_min, hipStream_t s);
+                      uint32_t splits, const float* max_dn2, float* part_min, hipStream_t s);
 
 }  // namespace m3d

@@ -129,7 +129,7 @@ uint32_t mfma_tiles(uint32_t n);
 uint32_t mfma_query_tiles(uint32_t n);
 constexpr int kMaxAbsPartials = 2048;   // workgroups of launch_max_abs = doubles it writes
 void launch_max_abs(const double* f, size_t count, double* partial /* kMaxAbsPartials doubles */, hipStream_t s);
-void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s);
+void launch_max_f32(const float* v, uint32_t n, float* out, hipStream_t s, bool accumulate = false);   // accumulate: out keeps max(out, v[...])
 // both layouts of a matrix in one pass: out_a = mfma_tiles(n) tiles in the database (role 0) layout, out_b = mfma_query_tiles(n) tiles
 // in the query (role 1) layout, norm2[n]
 void launch_pack_f16_both(const double* f, uint32_t n, double scale, void* out_a, void* out_b, float* norm2, hipStream_t s);
@@ -138,12 +138,60 @@ void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale
 // both directions (a -> b and b -> a) from ONE pass over the product tiles (m3d_match_scan.hpp, RevOut)
 constexpr int kMatchRevCap = 256;    // = kRevCap (m3d_match_scan.hpp): candidates kept per row of b
 constexpr int kMatchRevLane = 8;     // = kRevLane: candidates per (slice, query) list of the scan
-hipError_t launch_nn_mfma33_both(const double* a, const void* qB_a, const void* dA_a, const float* an2, uint32_t na,
-                                 float max_an2, const double* b, const void* qB_b, const void* dA_b, const float* bn2,
-                                 uint32_t nb, float max_bn2, uint32_t splits, uint32_t splits_r, float* premin, uint2* ring,
-                                 uint32_t* ring_count, float* part_min, float* evict_min, float* rev_premin, float* rthr,
-                                 uint32_t* rcnt, uint2* rcand, uint2* rlist, uint32_t* rlist_cnt, uint32_t* overflow_list, uint32_t* overflow_count,
-                                 uint32_t* overflow_list_r, uint32_t* overflow_count_r, uint32_t* nn_ab, uint32_t* nn_ba,
-                                 uint32_t* h_overflow /* [2] */, hipStream_t s);
+// The database splits of a scan.  Equal splits leave the chip part-empty for a whole split's length at the end (200 000 queries x 11
+// splits = 8 602 workgroups over 768 resident ones: 11.2 rounds take 12) -- so the LAST full-length share of the tiles is cut into
+// four splits of 1/2, 1/4, 1/8, 1/8 of it, dispatched last (blockIdx.y-major): the chip runs dry for an eighth of a split instead.
+// splits = full + tail; split y begins at tile split_begin(y); the last one ends at (full + (tail ? 1 : 0)) per.
+struct SplitPlan {
+    uint32_t per = 1;    // tiles of a full-length split
+    uint32_t full = 1;   // full-length splits
+    uint32_t tail = 0;   // 0 or 4
+    __host__ __device__ uint32_t count() const { return full + tail; }
+    __host__ __device__ uint32_t begin(uint32_t y) const { return y <= full ? y * per : full * per + per - (per >> (y - full)); }
+    __host__ __device__ uint32_t end(uint32_t y) const { return y + 1u >= full + tail ? (full + (tail ? 1u : 0u)) * per : begin(y + 1u); }
+};
+
+// One mutual search on the MFMA screen, step by step (m3d_match_kernels.hip; the host's order: m3d_registration.cpp match_mfma).
+// Device pointers.  a = queries of the forward search (na x 33 fp64), b = its database.  The forward scan cuts b's tiles into `splits`
+// splits of `per` tiles (two slices each: the half-waves of a query see disjoint rows); every per-(slice, query) array is laid out
+// [slice][query] PER QUERY SLICE: the arrays of queries q0 .. q0 + nq - 1 start 2 splits q0 entries in, so that a launch over a
+// slice of the queries addresses its own block.  max_an2 / max_bn2: device cells holding the largest |row|^2 packed so far.
+struct MatchWork {
+    const double* a = nullptr;
+    const double* b = nullptr;
+    uint32_t na = 0, nb = 0;
+    void *qB_a = nullptr, *dA_a = nullptr, *qB_b = nullptr, *dA_b = nullptr;   // packed operands (role 1 / role 0 layouts)
+    float *an2 = nullptr, *bn2 = nullptr, *max_an2 = nullptr, *max_bn2 = nullptr;
+    SplitPlan plan;                 // forward scan: the splits of b's tiles
+    uint32_t splits = 1;            // = plan.count()
+    uint32_t splits_r = 1;          // reverse warm-up: splits of a's first tiles
+    float* premin = nullptr;        // 2 splits x na   forward warm-up minima
+    uint2* ring = nullptr;          // 2 splits x na x kRing
+    uint32_t* ring_count = nullptr; // 2 splits x na
+    float* part_min = nullptr;      // 2 splits x na
+    float* evict_min = nullptr;     // 2 splits x na
+    float* rev_premin = nullptr;    // 2 splits_r x nb   reverse warm-up minima, [slice][row] per part of b
+    float* rthr = nullptr;          // sets x mfma_tiles(nb) x 40: thresholds of the reverse search, one set per query slice
+    uint32_t* rcnt = nullptr;       // nb
+    uint2* rcand = nullptr;         // nb x kMatchRevCap
+    uint2* rlist = nullptr;         // 2 splits x na x kMatchRevLane
+    uint32_t* rlist_cnt = nullptr;  // 2 splits x na
+    uint32_t *overflow_list = nullptr, *overflow_count = nullptr, *overflow_list_r = nullptr, *overflow_count_r = nullptr;
+    uint32_t *nn_ab = nullptr, *nn_ba = nullptr;
+};
+// rows row0 .. row0 + rows - 1 of side 0 (a) / 1 (b): both packed layouts, the norms, the side's norm maximum (row0: multiple of 512)
+void match_pack(const MatchWork& w, int side, uint32_t row0, uint32_t rows, double scale, hipStream_t s);
+// forward warm-up of queries q0 .. q0 + nq - 1 over the first tiles of b (which must be packed)
+void match_forward_warm(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s);
+// thresholds of rows row0 .. of b for the scans of query slice `set`: set 0 runs the reverse warm-up (the first 1/8 of a must be packed),
+// later sets re-derive the thresholds from the same minima under the norm bound of the queries packed by then
+void match_reverse_thresholds(const MatchWork& w, uint32_t row0, uint32_t rows, int set, hipStream_t s);
+// main pass: queries q0 .. q0 + nq - 1 against splits split0 .. split0 + splits - 1 (tiles below tile_end)
+void match_scan(const MatchWork& w, uint32_t q0, uint32_t nq, uint32_t split0, uint32_t splits, uint32_t tile_end, int set,
+                hipStream_t s);
+void match_verify_forward(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s);
+void match_reverse_bin(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s);
+void match_verify_reverse(const MatchWork& w, hipStream_t s);
+hipError_t match_exact_fallbacks(const MatchWork& w, const uint32_t* h_overflow /* [2]: the two counters, on the host */, hipStream_t s);
 
 }  // namespace m3d
