@@ -146,6 +146,7 @@ struct DeviceCtx {
     uint32_t sync_seq = 0;
     DevBuf surv_list;          // plane_bound_k's input: the hypotheses the keep kernels kept (its length: best_count word 6)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    PinBuf h_match;            // the matcher's cross-checked pairs (launch_mutual_pairs): count at byte 0, (src, dst) u32 pairs from byte 64
     std::vector<hipEvent_t> aux_events;   // aux_event_of: the matcher's upload / part / scan events
 };
 

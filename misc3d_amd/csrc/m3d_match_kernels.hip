@@ -351,6 +351,87 @@ hipError_t launch_nn_screened33(const double* q, const float* q32, const float* 
     return hipGetLastError();
 }
 
+// ---- cross-check (src/correspondence_matching.cpp:64-78) on the device ------------------------------------------------------------
+// pair (i, nn_ab[i]) is kept when nn_ba[nn_ab[i]] == i; pairs in the order of i, as the reference's loop pushes them.  Three small
+// launches (count per 1024 queries, offsets, write); the pairs go straight to page-locked host memory (u32 x 2, ~0.75 MB for 200 000
+// queries) instead of both index arrays (1.6 MB) + a host loop whose branch mispredicts every other query (0.3 ms together).
+constexpr uint32_t kMutualPerThread = 4, kMutualPerBlock = 256 * kMutualPerThread;
+__device__ __forceinline__ uint32_t mutual_flags(const uint32_t* __restrict__ nn_ab, const uint32_t* __restrict__ nn_ba, uint32_t na,
+                                                 uint32_t nb, uint32_t i0, uint32_t (&j)[kMutualPerThread]) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kMutualPerThread; ++k) {
+        const uint32_t i = i0 + k;
+        j[k] = i < na ? nn_ab[i] : 0xFFFFFFFFu;
+        if (j[k] < nb && nn_ba[j[k]] == i) bits |= 1u << k;
+    }
+    return bits;
+}
+__global__ __launch_bounds__(256) void mutual_count_k(const uint32_t* __restrict__ nn_ab, const uint32_t* __restrict__ nn_ba, uint32_t na,
+                                                       uint32_t nb, uint32_t* __restrict__ block_count) {
+    __shared__ uint32_t wsum[4];
+    uint32_t j[kMutualPerThread];
+    uint32_t c = __popc(mutual_flags(nn_ab, nn_ba, na, nb, blockIdx.x * kMutualPerBlock + threadIdx.x * kMutualPerThread, j));
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// exclusive offsets in place, the total to *total (one workgroup; a few hundred blocks)
+__global__ __launch_bounds__(256) void mutual_offsets_k(uint32_t* __restrict__ block_count, uint32_t n_blocks, uint32_t* __restrict__ total) {
+    __shared__ uint32_t part[256];
+    const uint32_t per = (n_blocks + 255u) / 256u, b0 = threadIdx.x * per, b1 = min(n_blocks, b0 + per);
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; ++b) sum += block_count[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const uint32_t v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t v = block_count[b];
+        block_count[b] = run;
+        run += v;
+    }
+}
+__global__ __launch_bounds__(256) void mutual_write_k(const uint32_t* __restrict__ nn_ab, const uint32_t* __restrict__ nn_ba, uint32_t na,
+                                                       uint32_t nb, const uint32_t* __restrict__ block_offset, uint2* __restrict__ out) {
+    __shared__ uint32_t wsum[4];
+    uint32_t j[kMutualPerThread];
+    const uint32_t i0 = blockIdx.x * kMutualPerBlock + threadIdx.x * kMutualPerThread;
+    const uint32_t bits = mutual_flags(nn_ab, nn_ba, na, nb, i0, j);
+    const uint32_t c = __popc(bits), lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = c;   // inclusive prefix over the wave's lanes
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += v;
+    }
+    if (lane == 63u) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t at = block_offset[blockIdx.x] + incl - c;
+    for (uint32_t w = 0; w < wave; ++w) at += wsum[w];
+#pragma unroll
+    for (uint32_t k = 0; k < kMutualPerThread; ++k)
+        if (bits & (1u << k)) out[at++] = make_uint2(i0 + k, j[k]);
+}
+void launch_mutual_pairs(const uint32_t* nn_ab, const uint32_t* nn_ba, uint32_t na, uint32_t nb, uint32_t* block_scratch, uint32_t* total,
+                         uint2* out, hipStream_t s) {
+    const uint32_t blocks = mutual_blocks(na);
+    if (!blocks) return;
+    mutual_count_k<<<blocks, 256, 0, s>>>(nn_ab, nn_ba, na, nb, block_scratch);
+    mutual_offsets_k<<<1, 256, 0, s>>>(block_scratch, blocks, total);
+    mutual_write_k<<<blocks, 256, 0, s>>>(nn_ab, nn_ba, na, nb, block_scratch, out);
+}
+uint32_t mutual_blocks(uint32_t na) { return (na + kMutualPerBlock - 1) / kMutualPerBlock; }
+
 // ---- MFMA path launchers -------------------------------------------------------------------------
 uint32_t mfma_tiles(uint32_t n) { return (n + 31u) / 32u; }
 // tiles padded so that a wave's two query tiles always exist

@@ -115,6 +115,11 @@ void launch_kabsch_sums(const double* src, const double* dst, uint32_t n, double
 void launch_nn(const double* q, uint32_t nq, const double* db, uint32_t ndb, int dim, uint32_t splits,
                double* best_d, uint32_t* best_i, uint32_t* nn, hipStream_t s);
 
+// the matcher's cross-check on the device: pairs (i, nn_ab[i]) with nn_ba[nn_ab[i]] == i, in the order of i, to `out` (device-visible:
+// page-locked host memory) and their number to *total; block_scratch: mutual_blocks(na) u32 on the device
+uint32_t mutual_blocks(uint32_t na);
+void launch_mutual_pairs(const uint32_t* nn_ab, const uint32_t* nn_ba, uint32_t na, uint32_t nb, uint32_t* block_scratch, uint32_t* total,
+                         uint2* out, hipStream_t s);
 // fp32-screened exact nearest neighbour for dim 33 (m3d_match_kernels.hip)
 constexpr int kScreenDimP = 36;   // fp32 row stride: 33 values, pad, |row|^2, pad (144 B)
 constexpr int kRing = 16;         // candidate ring entries per (query, database slice)
