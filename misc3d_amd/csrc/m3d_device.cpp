@@ -133,11 +133,25 @@ static std::map<int, DeviceCtx*> g_ctx;   // key: device * kMaxLanes + lane
 
 int lane_count() { return std::min(std::max((int)config().lanes, 1), kMaxLanes); }
 
+static DeviceCtx* create_lane_locked(int device, int lane);
 DeviceCtx* get_lane(int device, int lane) {
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     if (lane < 0 || lane >= kMaxLanes) lane = 0;
     auto it = g_ctx.find(device * kMaxLanes + lane);
     if (it != g_ctx.end()) return it->second;
+    // the first call at a device creates ALL its lanes' main streams, in lane order: the runtime hands a new stream the least-used of
+    // its few hardware queues, so the lanes' compute streams spread over them before any lane's copy / pre stream exists (a sliced
+    // match on lane 0 creating those first put lane 1's compute stream on lane 0's queue: two pairs in flight 459 -> 324 pairs/s)
+    DeviceCtx* mine = nullptr;
+    for (int ln = 0; ln <= std::max(lane, lane_count() - 1); ++ln) {
+        if (g_ctx.count(device * kMaxLanes + ln)) continue;
+        DeviceCtx* c = create_lane_locked(device, ln);
+        if (ln == lane) mine = c;
+        if (!c) break;
+    }
+    return mine ? mine : (g_ctx.count(device * kMaxLanes + lane) ? g_ctx[device * kMaxLanes + lane] : nullptr);
+}
+static DeviceCtx* create_lane_locked(int device, int lane) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         set_error("no HIP device available (misc3d_amd has no CPU fallback)");
