@@ -22,6 +22,10 @@ __device__ __forceinline__ void group_min(const f32x16& acc, float (&g)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[k] = fminf(fminf(acc[4 * k], acc[4 * k + 1]), fminf(acc[4 * k + 2], acc[4 * k + 3]));
 }
+// "does any lane ...": the lane mask straight from the compare (__any / __ballot take an int: the flag is first materialised in a
+// VGPR and compared again -- two VALU instructions and their latency in front of every wave-uniform branch of the scan)
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 template <bool MIN_ONLY>
 __device__ __forceinline__ void mfma_post(const f32x16& acc, const float (&g)[4], ScanState& st, float two_e, bool live,
                                           uint32_t row0, uint32_t ndb, uint2* __restrict__ my) {
@@ -29,17 +33,25 @@ __device__ __forceinline__ void mfma_post(const f32x16& acc, const float (&g)[4]
     st.best = fminf(st.best, tmin);
     if (MIN_ONLY) return;
     st.win = st.best + two_e;
-    if (__any(tmin <= st.win && live)) {
+    // One tile pair in five gets here (some lane of the 64 has a row inside its window: a new record of its running minimum, mostly),
+    // nearly always for ONE row of one lane: first the four runs' minima, then the four rows of a run that some lane needs
+    // (16 row tests per entry before: 150 instructions, a third of the scan's VALU and most of its SALU work)
+    if (any_lane(tmin <= st.win && live)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
-            const bool hit = acc[r] <= st.win && live && row < ndb;
-            if (__any(hit)) {
-                if (hit) {
-                    const uint32_t slot = st.cnt % kRing;
-                    if (st.cnt >= (uint32_t)kRing) st.ev = fminf(st.ev, __uint_as_float(my[slot].y));
-                    my[slot] = make_uint2(row, __float_as_uint(acc[r]));
-                    st.cnt++;
+        for (int k = 0; k < 4; ++k) {
+            if (any_lane(g[k] <= st.win && live)) {
+#pragma unroll
+                for (int r = 4 * k; r < 4 * k + 4; ++r) {
+                    const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+                    const bool hit = acc[r] <= st.win && live && row < ndb;
+                    if (any_lane(hit)) {
+                        if (hit) {
+                            const uint32_t slot = st.cnt % kRing;
+                            if (st.cnt >= (uint32_t)kRing) st.ev = fminf(st.ev, __uint_as_float(my[slot].y));
+                            my[slot] = make_uint2(row, __float_as_uint(acc[r]));
+                            st.cnt++;
+                        }
+                    }
                 }
             }
         }
@@ -58,7 +70,7 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, boo
         const float t = k & 2 ? (k & 1 ? th.w : th.z) : (k & 1 ? th.y : th.x);
         const float v = acc[4 * G + k];
         const bool hit = ok && v <= t;
-        if (__ballot(hit) != 0ull) {
+        if (any_lane(hit)) {
             if (hit) {
                 const uint32_t row = row0 + (uint32_t)(k + 8 * G);
                 if (cnt < (uint32_t)kRevLane) {
@@ -188,16 +200,16 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
                 if (REV) {
                     const float4 t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
                     const bool h = q < nq && (g4[0] <= t4.x || g4[1] <= t4.y || g4[2] <= t4.z || g4[3] <= t4.w);
-                    if (__ballot(h) != 0ull) {
+                    if (any_lane(h)) {
                         const float* rows = &sthr[buf][u * 32u + 4u * half];
                         const bool okq = q < nq;
-                        if (__ballot(okq && g4[0] <= t4.x) != 0ull)
+                        if (any_lane(okq && g4[0] <= t4.x))
                             rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), okq, row0, rl, rc, rev, q);
-                        if (__ballot(okq && g4[1] <= t4.y) != 0ull)
+                        if (any_lane(okq && g4[1] <= t4.y))
                             rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), okq, row0, rl, rc, rev, q);
-                        if (__ballot(okq && g4[2] <= t4.z) != 0ull)
+                        if (any_lane(okq && g4[2] <= t4.z))
                             rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), okq, row0, rl, rc, rev, q);
-                        if (__ballot(okq && g4[3] <= t4.w) != 0ull)
+                        if (any_lane(okq && g4[3] <= t4.w))
                             rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), okq, row0, rl, rc, rev, q);
                     }
                 }
