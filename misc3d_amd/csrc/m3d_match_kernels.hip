@@ -257,8 +257,8 @@ __global__ void max_f32_k(const float* __restrict__ v, uint32_t n, float* __rest
 // order (pack_f16_k): one coalesced 16-byte load per lane and K-step.
 // ------------------------------------------------------------------------------------------------
 // role 0: database rows (A operand), role 1: queries (B operand).  out: [tile][step][lane] h8.
-// norm2[i] = |represented row|^2 in scaled units (fp32, for the window); rows >= n of the last tile: role 0
-// gets a huge norm (never a candidate), role 1 zeros.
+// norm2[i] = |represented row|^2 in scaled units (fp32, for the window); rows >= n of the last tile get a huge norm in
+// both roles (never a candidate, never inside a threshold).
 __global__ void pack_f16_k(const double* __restrict__ f, uint32_t n, uint32_t n_tiles, double scale, int role,
                            _Float16* __restrict__ out, float* __restrict__ norm2) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -288,7 +288,7 @@ __global__ void pack_f16_k(const double* __restrict__ f, uint32_t n, uint32_t n_
             }
         }
     }
-    double pn = (i < n) ? nrm / (double)kMfmaC : (role == 0 ? 65504.0 : 0.0);
+    double pn = (i < n) ? nrm / (double)kMfmaC : 65504.0;   // (both roles: m3d_match_mfma.hip, mfma_post)
     const int own = role == 0 ? kMfmaNormAt : kMfmaNormAt + 3, other = role == 0 ? kMfmaNormAt + 3 : kMfmaNormAt;
     for (int k = 0; k < 3; ++k) {
         const _Float16 piece = (_Float16)pn;
@@ -497,8 +497,9 @@ __global__ __launch_bounds__(256) void pack_f16_both_k(const double* __restrict_
         double nrm = 0.0;
         for (int k = 0; k < 33; ++k) nrm += sq[wave][lane][k];
         if (i < n) norm2[i] = (float)nrm;
-        // the norm's three fp16 pieces (role 0 pads with 65504: a padding row of the database is never the nearest)
-        double pa = i < n ? nrm / (double)kMfmaC : 65504.0, pb = i < n ? nrm / (double)kMfmaC : 0.0;
+        // the norm's three fp16 pieces (padding rows carry 65504 in both roles: as a database row never the nearest, as a query beyond
+        // every threshold of the reverse search -- the scan's hot predicates then need no "is this a real row / query" term)
+        double pa = i < n ? nrm / (double)kMfmaC : 65504.0, pb = pa;
         for (int k = 0; k < 3; ++k) {
             const _Float16 qa = (_Float16)pa, qb = (_Float16)pb;
             hi16[wave][lane][33 + k] = qa;        // role 0's own pieces

@@ -26,9 +26,13 @@ __device__ __forceinline__ void group_min(const f32x16& acc, float (&g)[4]) {
 // VGPR and compared again -- two VALU instructions and their latency in front of every wave-uniform branch of the scan)
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
+// The hot predicates are single compares, so that their lane masks come straight out of v_cmp (a compound condition is first
+// materialised per lane and compared again): a lane without a live query carries two_e = -inf -- its window is -inf, nothing is
+// inside --, a padding query's packed norm is 65504 x 2^15 (pack_f16_both_k: every distance of it is beyond any threshold), a
+// padding row of the database likewise (beyond any window; the append still checks row < ndb).
 template <bool MIN_ONLY>
-__device__ __forceinline__ void mfma_post(const f32x16& acc, const float (&g)[4], ScanState& st, float two_e, bool live,
-                                          uint32_t row0, uint32_t ndb, uint2* __restrict__ my) {
+__device__ __forceinline__ void mfma_post(const f32x16& acc, const float (&g)[4], ScanState& st, float two_e, uint32_t row0,
+                                          uint32_t ndb, uint2* __restrict__ my) {
     const float tmin = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
     st.best = fminf(st.best, tmin);
     if (MIN_ONLY) return;
@@ -36,16 +40,16 @@ __device__ __forceinline__ void mfma_post(const f32x16& acc, const float (&g)[4]
     // One tile pair in five gets here (some lane of the 64 has a row inside its window: a new record of its running minimum, mostly),
     // nearly always for ONE row of one lane: first the four runs' minima, then the four rows of a run that some lane needs
     // (16 row tests per entry before: 150 instructions, a third of the scan's VALU and most of its SALU work)
-    if (any_lane(tmin <= st.win && live)) {
+    if (any_lane(tmin <= st.win)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (any_lane(g[k] <= st.win && live)) {
+            if (any_lane(g[k] <= st.win)) {
 #pragma unroll
                 for (int r = 4 * k; r < 4 * k + 4; ++r) {
-                    const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
-                    const bool hit = acc[r] <= st.win && live && row < ndb;
+                    const bool hit = acc[r] <= st.win;
                     if (any_lane(hit)) {
-                        if (hit) {
+                        const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+                        if (hit && row < ndb) {
                             const uint32_t slot = st.cnt % kRing;
                             if (st.cnt >= (uint32_t)kRing) st.ev = fminf(st.ev, __uint_as_float(my[slot].y));
                             my[slot] = make_uint2(row, __float_as_uint(acc[r]));
@@ -63,13 +67,13 @@ __device__ __forceinline__ void mfma_post(const f32x16& acc, const float (&g)[4]
 // Behind the wave-uniform branch, per run that some lane hit: the four rows' own thresholds (one ds_read_b128), a
 // ballot and scalar branch per row, a plain store into the lane's own list per candidate.
 template <int G>
-__device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, bool ok, uint32_t row0, uint2* __restrict__ my,
+__device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, uint32_t row0, uint2* __restrict__ my,
                                         uint32_t& cnt, const RevOut& rev, uint32_t q) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float t = k & 2 ? (k & 1 ? th.w : th.z) : (k & 1 ? th.y : th.x);
         const float v = acc[4 * G + k];
-        const bool hit = ok && v <= t;
+        const bool hit = v <= t;   // (a padding query's distances are beyond every threshold, a padding row's threshold is -inf)
         if (any_lane(hit)) {
             if (hit) {
                 const uint32_t row = row0 + (uint32_t)(k + 8 * G);
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
     const float two_ea = 2.0f * (kMfmaECoeff * (na + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
     const float two_eb = 2.0f * (kMfmaECoeff * (nb + max_dn2) + kMfmaEAbs) * 1.000001f + 1e-30f;
     const bool live_a = two_ea < INFINITY && qa < nq, live_b = two_eb < INFINITY && qb < nq;
+    const float win_ea = live_a ? two_ea : -INFINITY, win_eb = live_b ? two_eb : -INFINITY;   // (mfma_post: no window for a dead lane)
     // slice id = 2 * blockIdx.y + half: the two half-waves of a query see disjoint rows
     const uint32_t slice = (split0 + blockIdx.y) * 2u + half;
     uint2* __restrict__ ring_a = ring + ((size_t)slice * nq + (qa < nq ? qa : nq - 1)) * kRing;
@@ -191,26 +196,23 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
             if (more) fetch(t + kStageTiles, regs);   // in flight while this stage is multiplied
             const uint32_t in_stage = min((uint32_t)kStageTiles, t1 - t);
             // one side after the other: the run minima of a side are dead before the other side's are formed
-            auto side = [&](const f32x16& acc, ScanState& st, float two_e, bool live, uint2* __restrict__ rg, uint32_t q,
+            auto side = [&](const f32x16& acc, ScanState& st, float two_e, uint2* __restrict__ rg, uint32_t q,
                             uint2* __restrict__ rl, uint32_t& rc, uint32_t u) {
                 const uint32_t row0 = (t + u) * 32u + 4u * half;
                 float g4[4];
                 group_min(acc, g4);
-                mfma_post<MIN_ONLY>(acc, g4, st, two_e, live, row0, ndb, rg);
+                mfma_post<MIN_ONLY>(acc, g4, st, two_e, row0, ndb, rg);
                 if (REV) {
                     const float4 t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
-                    const bool h = q < nq && (g4[0] <= t4.x || g4[1] <= t4.y || g4[2] <= t4.z || g4[3] <= t4.w);
-                    if (any_lane(h)) {
+                    // (one lane mask per run, straight from its compare; their union decides the branch on the scalar unit)
+                    const uint64_t m0 = __builtin_amdgcn_ballot_w64(g4[0] <= t4.x), m1 = __builtin_amdgcn_ballot_w64(g4[1] <= t4.y),
+                                   m2 = __builtin_amdgcn_ballot_w64(g4[2] <= t4.z), m3 = __builtin_amdgcn_ballot_w64(g4[3] <= t4.w);
+                    if ((m0 | m1 | m2 | m3) != 0ull) {
                         const float* rows = &sthr[buf][u * 32u + 4u * half];
-                        const bool okq = q < nq;
-                        if (any_lane(okq && g4[0] <= t4.x))
-                            rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), okq, row0, rl, rc, rev, q);
-                        if (any_lane(okq && g4[1] <= t4.y))
-                            rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), okq, row0, rl, rc, rev, q);
-                        if (any_lane(okq && g4[2] <= t4.z))
-                            rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), okq, row0, rl, rc, rev, q);
-                        if (any_lane(okq && g4[3] <= t4.w))
-                            rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), okq, row0, rl, rc, rev, q);
+                        if (m0) rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), row0, rl, rc, rev, q);
+                        if (m1) rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), row0, rl, rc, rev, q);
+                        if (m2) rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), row0, rl, rc, rev, q);
+                        if (m3) rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), row0, rl, rc, rev, q);
                     }
                 }
             };
@@ -237,23 +239,23 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
                     multiply(u + 1u, accB0, accB1);
                     // (no scheduling barrier)
                 }
-                side(accA0, sa, two_ea, live_a, ring_a, qa, rl_a, rc_a, u);
-                side(accA1, sb, two_eb, live_b, ring_b, qb, rl_b, rc_b, u);
+                side(accA0, sa, win_ea, ring_a, qa, rl_a, rc_a, u);
+                side(accA1, sb, win_eb, ring_b, qb, rl_b, rc_b, u);
                 if (odd) {
                     if (u + 2u < in_stage) {
                         multiply(u + 2u, accA0, accA1);
                         // (no scheduling barrier)
                     }
-                    side(accB0, sa, two_ea, live_a, ring_a, qa, rl_a, rc_a, u + 1u);
-                    side(accB1, sb, two_eb, live_b, ring_b, qb, rl_b, rc_b, u + 1u);
+                    side(accB0, sa, win_ea, ring_a, qa, rl_a, rc_a, u + 1u);
+                    side(accB1, sb, win_eb, ring_b, qb, rl_b, rc_b, u + 1u);
                 }
             }
 #else
             for (uint32_t u = 0; u < in_stage; ++u) {
                 f32x16 acc0, acc1;
                 multiply(u, acc0, acc1);
-                side(acc0, sa, two_ea, live_a, ring_a, qa, rl_a, rc_a, u);
-                side(acc1, sb, two_eb, live_b, ring_b, qb, rl_b, rc_b, u);
+                side(acc0, sa, win_ea, ring_a, qa, rl_a, rc_a, u);
+                side(acc1, sb, win_eb, ring_b, qb, rl_b, rc_b, u);
             }
 #endif
             if (more) park(buf ^ 1, regs);
