@@ -107,7 +107,29 @@ constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
 #define M3D_MATCH_PIPELINE 0
 #endif
 static_assert(kStageTiles * 32 <= 256, "a thread carries at most one row threshold (and one run threshold) of the stage");
-constexpr int kStageEntries = kStageTiles * kMfmaSteps * 64;   // h8 entries per stage (14 KB)
+constexpr int kStageEntries = kStageTiles * kMfmaSteps * 64;   // h8 entries per stage (12 KB)
+static_assert(kStageEntries % 256 == 0, "every thread copies the same number of entries per stage");
+// Staging (round 5): the tiles go from global memory STRAIGHT into the LDS (global_load_lds_dwordx4: lane l's 16 bytes land at
+// M0 + 16 l -- tools/ubench/lds_dma_check.hip), three buffers deep: the copy of stage s + 2 is issued when stage s begins.  Through
+// registers and two buffers the copy had ONE stage (~0.7 us) to arrive -- less than a trip to L2 and back under load: 0.6 ms of the
+// 3.2 ms the MFMAs + minima alone take -- and held 12 VGPRs.  Issued as inline assembly: the compiler orders every LDS read behind
+// ALL outstanding copies it knows of (it cannot tell the buffers apart), which would make each stage wait for the copies just issued;
+// the waits are written by hand (a wave's copies complete in issue order, so "at most the next stage's copies outstanding" means this
+// stage's have landed; other memory operations in flight only make the wait longer, never shorter).
+constexpr int kStageBufs = 3;
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void lds_copy16(const void* g, uint32_t lds_wave_base) {   // lane l: 16 bytes from g -> LDS lds_wave_base + 16 l
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_copy4(const void* g, uint32_t lds_wave_base) {    // lane l: 4 bytes -> LDS lds_wave_base + 4 l
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_wave_base) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void wait_copies_but() {   // until at most N of this wave's memory operations are outstanding
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 // MIN_ONLY = true: warm-up pass over the first tiles of the database, running minimum only (no rings);
 // its per-(slice, query) minima seed the main pass (init_min / init_slices), so that a ring starts with a
@@ -125,9 +147,9 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
     // (nq queries starting at rev.q_base of the whole query matrix: every per-query pointer is the slice's own; splits
     // split0 .. split0 + gridDim.y - 1 of the database: a launch may cover a part of either side, MatchWork in m3d_reg_kernels.hpp)
     const float max_dn2 = *max_dn2_p;   // the largest |row|^2 of the database rows packed so far (>= this launch's rows')
-    __shared__ h8 stage[2][kStageEntries];
-    __shared__ __attribute__((aligned(16))) float sthr[2][kStageTiles * 32];   // REV: the staged tiles' row thresholds
-    __shared__ __attribute__((aligned(16))) float sthr4[2][kStageTiles * 8];   // ... and run thresholds, [tile][half][run]
+    __shared__ h8 stage[kStageBufs][kStageEntries];
+    __shared__ __attribute__((aligned(16))) float sthr[kStageBufs][kStageTiles * 32];   // REV: the staged tiles' row thresholds
+    __shared__ __attribute__((aligned(16))) float sthr4[kStageBufs][kStageTiles * 8];   // ... and run thresholds, [tile][half][run]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t qt0 = (blockIdx.x * 4u + wave) * 2u;   // first of this wave's two query tiles
     const uint32_t half = lane >> 5;
@@ -160,40 +182,41 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
     }
     const uint32_t t0 = plan.begin(split0 + blockIdx.y), t1 = min(tile_end, plan.end(split0 + blockIdx.y));
     if (t0 < t1) {   // block-uniform
-        // entry e of a stage = fragment (tile e / 448, step, lane) in packed order: consecutive in memory
-        constexpr int kPerThread = (kStageEntries + 255) / 256;   // 4 (the last one only for tid < 128)
+        // entry e of a stage = fragment (tile, step, lane) in packed order: consecutive in memory, 64 entries of a wave = 1 KB of the LDS
+        constexpr int kPerThread = kStageEntries / 256;
+        constexpr int kCopies = kPerThread + (REV ? 2 : 0);   // copy instructions a wave issues per stage (the same for every wave)
         const uint32_t last_entry = (t1 - 1) * (uint32_t)(kMfmaSteps * 64) + (kMfmaSteps * 64 - 1);
-        float rthr = 0.0f, rthr4 = 0.0f;   // REV: threads 0 .. 32 kStageTiles - 1 carry one row threshold of the stage each, the first 8 kStageTiles a run threshold too
-        auto fetch = [&](uint32_t t_first, h8 (&r)[kPerThread]) {
+        const uint32_t wave_first = (uint32_t)(tid & ~63);
+        auto fetch = [&](uint32_t t_first, int buf) {
 #pragma unroll
             for (int k = 0; k < kPerThread; ++k) {
                 const uint32_t e = (uint32_t)tid + 256u * k;
                 const uint32_t g = min(t_first * (uint32_t)(kMfmaSteps * 64) + e, last_entry);   // clamp: stay inside the slice
-                r[k] = dA[g];
+                lds_copy16(dA + g, __builtin_amdgcn_readfirstlane(lds_offset(&stage[buf][wave_first + 256u * k])));
             }
-            if (REV && tid < kStageTiles * 32) rthr = rev.thr[min(t_first * 32u + (uint32_t)tid, t1 * 32u - 1u)];
-            if (REV && tid < kStageTiles * 8) {   // slot [tile u][half][run g] <- run 2 g + half of tile u
-                const uint32_t k = (uint32_t)tid, u = k >> 3, hf = (k >> 2) & 1u, g = k & 3u;
-                rthr4 = rev.thr4[min((t_first + u) * 8u + 2u * g + hf, t1 * 8u - 1u)];
+            if (REV) {
+                // the stage's row thresholds (kStageTiles * 32 of them: waves 2 and 3 copy what waves 0 and 1 copy -- every wave
+                // issues the same number of copies, which is what its wait counts) and run thresholds (the first half-wave of each
+                // wave; slot [tile u][half][run g] <- run 2 g + half of tile u)
+                const uint32_t i = (uint32_t)tid & (kStageTiles * 32u - 1u);
+                lds_copy4(rev.thr + min(t_first * 32u + i, t1 * 32u - 1u), __builtin_amdgcn_readfirstlane(lds_offset(&sthr[buf][i & ~63u])));
+                if (lane < kStageTiles * 8) {
+                    const uint32_t k = (uint32_t)lane, u = k >> 3, hf = (k >> 2) & 1u, g = k & 3u;
+                    lds_copy4(rev.thr4 + min((t_first + u) * 8u + 2u * g + hf, t1 * 8u - 1u), lds_offset(&sthr4[buf][0]));
+                }
             }
         };
-        auto park = [&](int buf, const h8 (&r)[kPerThread]) {
-#pragma unroll
-            for (int k = 0; k < kPerThread; ++k) {
-                const uint32_t e = (uint32_t)tid + 256u * k;
-                if (e < (uint32_t)kStageEntries) stage[buf][e] = r[k];
-            }
-            if (REV && tid < kStageTiles * 32) sthr[buf][tid] = rthr;
-            if (REV && tid < kStageTiles * 8) sthr4[buf][tid] = rthr4;
-        };
-        h8 regs[kPerThread];
-        fetch(t0, regs);
-        park(0, regs);
-        __syncthreads();
+        static_assert(kStageTiles * 32 == 128 && kStageTiles * 8 <= 64, "the threshold copies assume four tiles per stage");
+        fetch(t0, 0);
+        if (t0 + kStageTiles < t1) fetch(t0 + kStageTiles, 1);
         int buf = 0;
         for (uint32_t t = t0; t < t1; t += kStageTiles) {
-            const bool more = t + kStageTiles < t1;
-            if (more) fetch(t + kStageTiles, regs);   // in flight while this stage is multiplied
+            // this stage's copies have landed when at most the next stage's are outstanding; the barrier publishes them -- and says that
+            // every wave is done with the stage before this one, whose buffer the copy of the stage after next may now overwrite
+            if (t + kStageTiles < t1) wait_copies_but<kCopies>();
+            else wait_copies_but<0>();
+            __syncthreads();
+            if (t + 2 * kStageTiles < t1) fetch(t + 2 * kStageTiles, buf >= 1 ? buf - 1 : kStageBufs - 1);
             const uint32_t in_stage = min((uint32_t)kStageTiles, t1 - t);
             // one side after the other: the run minima of a side are dead before the other side's are formed
             auto side = [&](const f32x16& acc, ScanState& st, float two_e, uint2* __restrict__ rg, uint32_t q,
@@ -258,9 +281,7 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
                 side(acc1, sb, win_eb, ring_b, qb, rl_b, rc_b, u);
             }
 #endif
-            if (more) park(buf ^ 1, regs);
-            __syncthreads();
-            buf ^= 1;
+            buf = buf + 1 == kStageBufs ? 0 : buf + 1;
         }
     }
     if (MIN_ONLY) {
