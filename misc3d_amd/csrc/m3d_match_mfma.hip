@@ -95,7 +95,7 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, uin
 // tiles per stage = database tiles between two barriers of the workgroup: 2: nn16_scan_k<false, true> 7.50 ms on 200 k x 200 k,
 // 3: 7.19, 4: 6.86, 6: 7.96 (five staging registers per thread)
 #ifndef M3D_MATCH_STAGE_TILES
-#define M3D_MATCH_STAGE_TILES 4
+#define M3D_MATCH_STAGE_TILES 8
 #endif
 constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
 // M3D_MATCH_PIPELINE=1 (round 5, measured and refuted: 6.87 -> 8.33-8.40 ms on 200 k x 200 k, with and without scheduling
@@ -106,9 +106,14 @@ constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
 #ifndef M3D_MATCH_PIPELINE
 #define M3D_MATCH_PIPELINE 0
 #endif
-static_assert(kStageTiles * 32 <= 256, "a thread carries at most one row threshold (and one run threshold) of the stage");
+// queries per workgroup = 64 x waves: every wave of a workgroup reads the same staged tiles, so the staging traffic per query goes
+// with 1 / waves (four waves: 14.7 GB from L2 per 200 k x 200 k scan, a fifth of the scan's time)
+#ifndef M3D_MATCH_BLOCK_WAVES
+#define M3D_MATCH_BLOCK_WAVES 8
+#endif
+constexpr int kBlockWaves = M3D_MATCH_BLOCK_WAVES, kBlockThreads = 64 * kBlockWaves;
 constexpr int kStageEntries = kStageTiles * kMfmaSteps * 64;   // h8 entries per stage (12 KB)
-static_assert(kStageEntries % 256 == 0, "every thread copies the same number of entries per stage");
+static_assert(kStageEntries % kBlockThreads == 0, "every thread copies the same number of entries per stage");
 // Staging (round 5): the tiles go from global memory STRAIGHT into the LDS (global_load_lds_dwordx4: lane l's 16 bytes land at
 // M0 + 16 l -- tools/ubench/lds_dma_check.hip), three buffers deep: the copy of stage s + 2 is issued when stage s begins.  Through
 // registers and two buffers the copy had ONE stage (~0.7 us) to arrive -- less than a trip to L2 and back under load: 0.6 ms of the
@@ -136,7 +141,7 @@ __device__ __forceinline__ void wait_copies_but() {   // until at most N of this
 // bound close to its final minimum and "new record" events -- which cost a wave-wide detour each, and a wave
 // carries 128 rings -- become rare instead of happening in most tiles.
 template <bool MIN_ONLY, bool REV>
-__global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
+__global__ __launch_bounds__(kBlockThreads) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
                                                     uint32_t nq, const h8* __restrict__ dA, uint32_t ndb,
                                                     uint32_t tile_end, SplitPlan plan, uint32_t split0,
                                                     const float* __restrict__ max_dn2_p,
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
     __shared__ __attribute__((aligned(16))) float sthr[kStageBufs][kStageTiles * 32];   // REV: the staged tiles' row thresholds
     __shared__ __attribute__((aligned(16))) float sthr4[kStageBufs][kStageTiles * 8];   // ... and run thresholds, [tile][half][run]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t qt0 = (blockIdx.x * 4u + wave) * 2u;   // first of this wave's two query tiles
+    const uint32_t qt0 = (blockIdx.x * (uint32_t)kBlockWaves + wave) * 2u;   // first of this wave's two query tiles
     const uint32_t half = lane >> 5;
     h8 b0[kMfmaSteps], b1[kMfmaSteps];
 #pragma unroll
@@ -183,19 +188,19 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
     const uint32_t t0 = plan.begin(split0 + blockIdx.y), t1 = min(tile_end, plan.end(split0 + blockIdx.y));
     if (t0 < t1) {   // block-uniform
         // entry e of a stage = fragment (tile, step, lane) in packed order: consecutive in memory, 64 entries of a wave = 1 KB of the LDS
-        constexpr int kPerThread = kStageEntries / 256;
+        constexpr int kPerThread = kStageEntries / kBlockThreads;
         constexpr int kCopies = kPerThread + (REV ? 2 : 0);   // copy instructions a wave issues per stage (the same for every wave)
         const uint32_t last_entry = (t1 - 1) * (uint32_t)(kMfmaSteps * 64) + (kMfmaSteps * 64 - 1);
         const uint32_t wave_first = (uint32_t)(tid & ~63);
         auto fetch = [&](uint32_t t_first, int buf) {
 #pragma unroll
             for (int k = 0; k < kPerThread; ++k) {
-                const uint32_t e = (uint32_t)tid + 256u * k;
+                const uint32_t e = (uint32_t)tid + (uint32_t)kBlockThreads * k;
                 const uint32_t g = min(t_first * (uint32_t)(kMfmaSteps * 64) + e, last_entry);   // clamp: stay inside the slice
-                lds_copy16(dA + g, __builtin_amdgcn_readfirstlane(lds_offset(&stage[buf][wave_first + 256u * k])));
+                lds_copy16(dA + g, __builtin_amdgcn_readfirstlane(lds_offset(&stage[buf][wave_first + (uint32_t)kBlockThreads * k])));
             }
             if (REV) {
-                // the stage's row thresholds (kStageTiles * 32 of them: waves 2 and 3 copy what waves 0 and 1 copy -- every wave
+                // the stage's row thresholds (kStageTiles * 32 of them: the later waves copy what the first ones copy -- every wave
                 // issues the same number of copies, which is what its wait counts) and run thresholds (the first half-wave of each
                 // wave; slot [tile u][half][run g] <- run 2 g + half of tile u)
                 const uint32_t i = (uint32_t)tid & (kStageTiles * 32u - 1u);
@@ -206,7 +211,9 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
                 }
             }
         };
-        static_assert(kStageTiles * 32 == 128 && kStageTiles * 8 <= 64, "the threshold copies assume four tiles per stage");
+        static_assert((kStageTiles * 32) % 64 == 0 && ((kStageTiles * 32) & (kStageTiles * 32 - 1)) == 0 && kStageTiles * 32 <= kBlockThreads &&
+                          kStageTiles * 8 <= 64,
+                      "the threshold copies: whole waves of row thresholds, one (half-)wave of run thresholds");
         fetch(t0, 0);
         if (t0 + kStageTiles < t1) fetch(t0 + kStageTiles, 1);
         int buf = 0;
@@ -309,11 +316,11 @@ __global__ __launch_bounds__(256) void nn16_scan_k(const h8* __restrict__ qB, co
 
 void launch_nn16_warm(const void* qB, const float* qn, uint32_t nq, const void* dA, uint32_t ndb, uint32_t warm_tiles,
                       uint32_t splits, const float* max_dn2, float* part_min, hipStream_t s) {
-    const dim3 grid((nq + 255) / 256, splits);
+    const dim3 grid((nq + kBlockThreads - 1) / kBlockThreads, splits);
     SplitPlan even;
     even.per = (warm_tiles + splits - 1) / splits;
     even.full = splits;
-    nn16_scan_k<true, false><<<grid, 256, 0, s>>>(reinterpret_cast<const h8*>(qB), qn, nq, reinterpret_cast<const h8*>(dA), ndb,
+    nn16_scan_k<true, false><<<grid, kBlockThreads, 0, s>>>(reinterpret_cast<const h8*>(qB), qn, nq, reinterpret_cast<const h8*>(dA), ndb,
                                                   warm_tiles, even, 0u, max_dn2, nullptr, 0, nullptr, nullptr, part_min,
                                                   nullptr, RevOut());
 }
@@ -324,12 +331,12 @@ void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* 
                       hipStream_t s, const RevOut* rev) {
     const h8* q8 = reinterpret_cast<const h8*>(qB);
     const h8* d8 = reinterpret_cast<const h8*>(dA);
-    const dim3 grid((nq + 255) / 256, splits);
+    const dim3 grid((nq + kBlockThreads - 1) / kBlockThreads, splits);
     if (rev)
-        nn16_scan_k<false, true><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, tile_end, plan, split0, max_dn2, premin,
+        nn16_scan_k<false, true><<<grid, kBlockThreads, 0, s>>>(q8, qn, nq, d8, ndb, tile_end, plan, split0, max_dn2, premin,
                                                       init_slices, ring, ring_count, part_min, evict_min, *rev);
     else
-        nn16_scan_k<false, false><<<grid, 256, 0, s>>>(q8, qn, nq, d8, ndb, tile_end, plan, split0, max_dn2, premin,
+        nn16_scan_k<false, false><<<grid, kBlockThreads, 0, s>>>(q8, qn, nq, d8, ndb, tile_end, plan, split0, max_dn2, premin,
                                                        init_slices, ring, ring_count, part_min, evict_min, RevOut());
 }
 
