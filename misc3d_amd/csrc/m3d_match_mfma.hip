@@ -125,11 +125,20 @@ constexpr int kStageBufs = 3;
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
+// (M0 carries the LDS base of the copy; the statement puts back what it found there, so M0 is no clobber)
 __device__ __forceinline__ void lds_copy16(const void* g, uint32_t lds_wave_base) {   // lane l: 16 bytes from g -> LDS lds_wave_base + 16 l
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "memory", "m0");
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_wave_base)
+                 : "memory");
 }
 __device__ __forceinline__ void lds_copy4(const void* g, uint32_t lds_wave_base) {    // lane l: 4 bytes -> LDS lds_wave_base + 4 l
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_wave_base) : "memory", "m0");
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_wave_base)
+                 : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_copies_but() {   // until at most N of this wave's memory operations are outstanding
