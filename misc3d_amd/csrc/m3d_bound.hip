@@ -263,7 +263,7 @@ void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipS
 // Arithmetic and its margins: m3d_bound_fp.hpp (plane_pair_ub: the value at the tile's centre in fp64, the rest in fp32 with every
 // number pushed outwards; tests/cpp/test_plane_bound.cpp runs the same code on the host against exact counts).
 constexpr int kBoundWaves = 8;   // (4 waves x 16 tiles each: step 0.2594-0.2621 ms; 8 x 8: 0.2570-0.2572)
-template <int kBoundTpw /* tiles per wave */>
+template <int KIND /* 0 plane, 2 cylinder (cyl_pair_ub: the shell as a slab per tile) */, int kBoundTpw /* tiles per wave */>
 __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* __restrict__ frames, const uint16_t* __restrict__ cum,
                                                                    uint32_t n_tiles, double max_abs,
                                                                    const double* __restrict__ score,
@@ -304,6 +304,10 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             if (k < 3u) c_s[tl][k] = v;
             f_s[tl][k] = frame_to_f32(v, k);
         }
+        if (KIND == 2) {   // cylinders: the tile's bounding radius about its centre, once per tile (slot 0: the centre's fp32 copy is not used)
+            __syncthreads();
+            if (threadIdx.x < nt) f_s[threadIdx.x][0] = cyl_tile_rho(f_s[threadIdx.x]);
+        }
         if (cull32)
             for (uint32_t i = threadIdx.x; i < nt * 6u; i += 64u * kBoundWaves)
                 bx_s[i / 6u][i % 6u] = reinterpret_cast<const float*>(boxes + (size_t)(t0 + i / 6u) * kBoxStride + 8)[i % 6u];
@@ -329,8 +333,15 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             }
         }
         __syncthreads();   // (records -- and, the first time round, the frames -- are in LDS)
-        PlaneBoundRec pr = plane_bound_record(rec_s[lane], max_abs);
-        pr.ok = pr.ok && has;
+        PlaneBoundRec pr;
+        CylBoundRec cr;
+        if (KIND == 0) {
+            pr = plane_bound_record(rec_s[lane], max_abs);
+            pr.ok = pr.ok && has;
+        } else {
+            cr = cyl_bound_record(rec_s[lane], max_abs);
+            cr.ok = cr.ok && has;
+        }
         const unsigned long long bit = 1ull << (h & 63u);
         const unsigned long long* __restrict__ mrow = masks + (size_t)(h >> 6);
         // touched or not: the box test itself, from the hypothesis' fp32 record and the tile's fp32 box (the arithmetic of
@@ -360,7 +371,8 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
                 tch[i] = has && (uint32_t)tl < nt && bx[3] >= 0.0f && !(rv - __builtin_fabsf(sv) < 0.0f);
             }
             if (__ballot(tch[i]) == 0ull) continue;   // (wave-uniform)
-            const uint32_t u_t = plane_pair_ub(pr, c_s[tl], f_s[tl], cm_s[tl]);   // (wave-uniform addresses: broadcast reads)
+            const uint32_t u_t = KIND == 0 ? plane_pair_ub(pr, c_s[tl], f_s[tl], cm_s[tl])   // (wave-uniform addresses: broadcast reads)
+                                           : cyl_pair_ub(cr, c_s[tl], f_s[tl], f_s[tl][0], cm_s[tl]);
             ub += tch[i] ? u_t : 0u;
         }
         wsum[wave][lane] = ub;
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
     }
 }
 
-void launch_plane_bound(const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
+void launch_plane_bound(int kind, const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
                         uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
                         const uint32_t* best_count, uint32_t* surv_count, const uint32_t* surv, uint32_t* tickets,
                         const float* cull32, hipStream_t st, bool always) {
@@ -408,16 +420,19 @@ void launch_plane_bound(const SortedView& s, const double* score, const unsigned
     // tiles per wave (12 .. 32 measured slower: profiles/r04_plane_bound.txt).  Round 5 (profiles/r05_c2_front_end.txt): 4 -- twice
     // the workgroups, half the tile loop -- 19.5 -> 31.5 us, and by ablation the tile loop is 1.5 us of the launch's 19, the adds /
     // fence / ticket behind it 6.5, the rest dependent loads of data the kernel before has just written (~2 us a round trip)
-    constexpr int tpw = 8;
-    const uint32_t tpb = (uint32_t)(kBoundWaves * tpw);
+    // Cylinders: 16 -- their survivor lists are long (a quarter of a C3 window: every hypothesis with both samples on the surface),
+    // so a workgroup's chain of dependent loads is worth twice the tiles: 8 / 16 / 32 tiles per wave 80 / 60 / 75 us per window.
+    constexpr int tpw = 8, tpw_cyl = 16;
+    const uint32_t tpb = (uint32_t)(kBoundWaves * (kind == 0 ? tpw : tpw_cyl));
     const uint32_t max_list = always ? 0xFFFFFFFFu : window * 32u;   // half of the window's hypotheses
     const dim3 g(gx, (s.n_tiles + tpb - 1) / tpb), b(64 * kBoundWaves);
-    if (s.radius >= 1e18) cull32 = nullptr;   // (no fp32 boxes: launch_cull_mask's condition)
+    if (s.radius >= 1e18 || kind != 0) cull32 = nullptr;   // (no fp32 boxes: launch_cull_mask's condition; cylinders: the box tests' mask words are read)
     auto go = [&](auto kernel) {
         kernel<<<g, b, 0, st>>>(s.frames, s.frame_cum, s.n_tiles, s.max_abs, score, masks, n_groups, s.boxes, cull32, surv_count, surv,
                                 ubsum, best_count, keep, tickets, max_list);
     };
-    go(plane_bound_k<tpw>);
+    if (kind == 0) go(plane_bound_k<0, tpw>);
+    else go(plane_bound_k<2, tpw_cyl>);
 }
 
 }  // namespace m3d

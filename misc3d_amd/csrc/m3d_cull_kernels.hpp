@@ -43,8 +43,8 @@ void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipS
 // the keep kernels of groups [group_begin, group_end): *surv_count ids; ubsum zero on entry); the keep bit of a hypothesis whose
 // bound stays below best_count[0] is cleared, *surv_count ends at 0.  tickets: 1 + (hypotheses of the window / 64) words, zero
 // before the first launch (the kernel leaves them zero).  cull32: the window's fp32 box-test records (null: the masks are
-// read instead).  Planes only; needs s.frames.
-void launch_plane_bound(const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
+// read instead).  kind: planes (0) and cylinders (2: the shell over a tile as a slab, m3d_bound_fp.hpp); needs s.frames.
+void launch_plane_bound(int kind, const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
                         uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
                         const uint32_t* best_count, uint32_t* surv_count, const uint32_t* surv, uint32_t* tickets,
                         const float* cull32, hipStream_t st,

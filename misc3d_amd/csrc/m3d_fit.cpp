@@ -308,7 +308,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
     if (ms_sample) *ms_sample += now_ms() - t0;
     // the sample table is read by minimal_fit_k straight from the slot's page-locked host array (device-visible): 12 bytes
     // per hypothesis over the host link inside the kernel instead of a copy command in front of it
-    if (!dense && prune) RESERVE(s.ub, sizeof(uint32_t) * 2 * (size_t)h_pad);   // ub[h_pad], then the phase counters ubp[h_pad]
+    if (!dense && prune) RESERVE(s.ub, sizeof(uint32_t) * 3 * (size_t)h_pad);   // ub[h_pad], then the phase counters ubp[h_pad], then the cylinders' histogram bound sums
     // (decided here because minimal_fit_k prepares the lead pass of a NEW fit itself: see LeadPrep)
     const bool use_lead = !dense && prune && lead >= 64 && lead % 64 == 0 && lead + 64 <= count && (!comm || sl_pad >= lead + 64);
     const bool own_real_ = !comm || (size_t)rank * sl_pad < count;
@@ -405,12 +405,16 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             // "512 per touched tile" in the keep rule (m3d_bound.hip).  The keep kernels below hand plane_bound_k the kept
             // hypotheses as a list (its length: word 6 of best_count); ubsum is the slot's phase-counter array, zeroed by
             // minimal_fit_k and unused when the scoring is not phased.
-            const bool bound_on = kind == M3D_PLANE && prune && bc && !ubp && sv.frames && config().plane_bound != 0 &&
+            // Cylinders (round 5): the same bound with the shell taken as a slab per tile (cyl_pair_ub), in front of the phased scoring
+            // -- whose phase counters sit where the planes' bound sums go, so the cylinders' sums get the block behind them.
+            const bool bound_on = (kind == M3D_PLANE ? !ubp : kind == M3D_CYLINDER) && prune && bc && sv.frames && config().plane_bound != 0 &&
                                   (config().plane_bound == 2 || bound_pays(sv.n_tiles, comm ? sl_pad : count)) &&
                                   (use_lead || !new_fit) && !scored_with_own_tests && std::max(g0, ga) < g1;
+            uint32_t* const ubsum = kind == M3D_PLANE ? ub + h_pad : ub + 2 * (size_t)h_pad;
             if (bound_on) {
                 const int src = reserve_survivor_scratch(ctx, h_pad);
                 if (src != M3D_OK) return src;
+                if (kind != M3D_PLANE) HIPCHK(hipMemsetAsync(ubsum, 0, sizeof(uint32_t) * h_pad, ctx->stream));   // (the planes' block is cleared by minimal_fit_k)
             }
             uint32_t* const surv_count = bound_on ? bc + 6 : nullptr;
             uint32_t* const surv = bound_on ? bound_list(ctx) : nullptr;
@@ -444,7 +448,7 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
                 launch_keep_mask(ub, bc, g1 - g0, keep, ctx->stream, ctx->counts_rep.as<uint32_t>(), h_pad, g0, surv_count, surv);
             }
             if (bound_on)
-                launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, g_lo, g1, ub + h_pad, bc, surv_count, surv,
+                launch_plane_bound(kind, sv, s.score.as<double>(), masks, keep, n_groups, g_lo, g1, ubsum, bc, surv_count, surv,
                                    bound_tickets(ctx), c32.out, ctx->stream, config().plane_bound == 2);
             bool phased = false;
             if (!scored_with_own_tests && ubp)
@@ -1002,7 +1006,7 @@ static int ensure_plane_frames(m3d_cloud* c, int kind, size_t n_hypotheses) {
     // takes ~0.09 ms per million points, the bound saves ~0.02 ms per 10 000 hypotheses on them: m3d_fit_plane 0.95 -> 1.04 ms
     // otherwise); 2: always (tests)
     const int mode = config().plane_bound;
-    if (kind != M3D_PLANE || c->frames_ready || c->frames_failed || mode == 0 || c->work.active || c->n_tiles == 0 ||
+    if ((kind != M3D_PLANE && kind != M3D_CYLINDER) || c->frames_ready || c->frames_failed || mode == 0 || c->work.active || c->n_tiles == 0 ||
         (mode == 1 && (!bound_pays(c->n_tiles, std::min<size_t>(n_hypotheses, chunk_cap_for(c->view(), c->sorted()))) ||
                        (c->one_shot && n_hypotheses < 65536u))))
         return M3D_OK;
@@ -1603,7 +1607,7 @@ int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t*
     launch_cull_mask(M3D_PLANE, sv, s.score.as<double>(), s.valid.as<uint8_t>(), (uint32_t)n_hypotheses, n_groups, masks, nullptr,
                      ctx->stream, false, 0, 0xFFFFFFFFu, c32);
     launch_keep_mask(nullptr, nullptr, n_groups, keep, ctx->stream, nullptr, 0, 0, ctl + 1, surv);
-    launch_plane_bound(sv, s.score.as<double>(), masks, keep, n_groups, 0, n_groups, ubsum, ctl, ctl + 1, surv,
+    launch_plane_bound(M3D_PLANE, sv, s.score.as<double>(), masks, keep, n_groups, 0, n_groups, ubsum, ctl, ctl + 1, surv,
                        bound_tickets(ctx), c32, ctx->stream, /*always=*/true);
     HIPCHK(hipMemcpyAsync(ub_out, ubsum, sizeof(uint32_t) * n_hypotheses, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());

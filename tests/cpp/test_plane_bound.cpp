@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../misc3d_amd/csrc/m3d_bound_fp.hpp"
+#include "../../misc3d_amd/csrc/m3d_fp.hpp"
 
 using namespace m3d;
 
@@ -32,7 +33,7 @@ int main(int argc, char** argv) {
     std::uniform_real_distribution<double> U01(0.0, 1.0);
     std::normal_distribution<double> N01(0.0, 1.0);
     auto rdir = [&](double* v) { v[0] = N01(rng); v[1] = N01(rng); v[2] = N01(rng); unit(v); };
-    long long pairs = 0, violations = 0;
+    long long pairs = 0, violations = 0, cyl_pairs = 0, cyl_sum_ub = 0, cyl_sum_exact = 0;
     for (int t = 0; t < trials; ++t) {
         const double sc = std::pow(10.0, -2.0 + 4.0 * U01(rng));
         double off[3];
@@ -136,7 +137,57 @@ int main(int argc, char** argv) {
                 ++violations;
             }
         }
+        // ---- cylinder hypotheses (cyl_pair_ub): the patch as a piece of the shell (axis in the patch's plane direction a0, one
+        // radius below it, radius and axis slightly off), shells that cut the patch anywhere, axes through the tile itself; radii
+        // from a third of the tile's extent to a hundred times it; the exact count is the reference's own test
+        // fabs(dist(q, axis) - r) < threshold (m3d_fp.hpp cylinder_distance, ransac.h:435-445), the record what the scoring
+        // kernels get (centre, centre + direction, the two cut-offs on t)
+        for (int hq = 0; hq < 24; ++hq) {
+            double w7[7], dir[3];
+            const int how = hq % 3;
+            const double rad = ext * std::pow(10.0, -0.5 + 2.5 * U01(rng));
+            if (how == 0) {
+                double dd[3]; rdir(dd);
+                for (int k = 0; k < 3; ++k) dir[k] = a0[k] + 0.03 * U01(rng) * dd[k];
+                unit(dir);
+                const double shift = 3.0 * sigma * N01(rng), along = ext * (2 * U01(rng) - 1);
+                for (int k = 0; k < 3; ++k) w7[k] = off[k] - rad * n0[k] + shift * n0[k] + along * dir[k];
+                w7[6] = rad * (1.0 + 0.02 * (2 * U01(rng) - 1));
+            } else if (how == 1) {
+                rdir(dir);
+                double away[3]; rdir(away);
+                const double dist = rad * (0.5 + U01(rng));
+                for (int k = 0; k < 3; ++k) w7[k] = off[k] + ext * (2 * U01(rng) - 1) + dist * away[k];
+                w7[6] = rad;
+            } else {
+                rdir(dir);
+                const int i0 = (int)(U01(rng) * 511);
+                for (int k = 0; k < 3; ++k) w7[k] = P[3 * i0 + k] + 0.1 * ext * (2 * U01(rng) - 1);
+                w7[6] = rad;
+            }
+            const double dl = std::pow(10.0, -1.0 + 2.0 * U01(rng));   // (the reference's direction is not a unit vector)
+            for (int k = 0; k < 3; ++k) w7[3 + k] = dir[k] * dl;
+            const double base = sigma > 0 ? sigma : 1e-3 * sc;
+            const double T = base * std::pow(10.0, -0.5 + 2.0 * U01(rng));
+            double ref[3], Lc, tlo, thi;
+            cylinder_ref(w7, ref, &Lc);
+            cylinder_cutoffs(w7, T, &tlo, &thi);
+            const double rec[8] = {w7[0], w7[1], w7[2], ref[0], ref[1], ref[2], tlo, thi};
+            int exact = 0;
+            for (int i = 0; i < 512; ++i) exact += cylinder_distance(w7, P[3 * i], P[3 * i + 1], P[3 * i + 2]) < T;
+            const CylBoundRec cr = cyl_bound_record(rec, mabs);
+            const uint32_t ub = cyl_pair_ub(cr, c, f, cyl_tile_rho(f), cum.data());
+            ++pairs;
+            ++cyl_pairs;
+            cyl_sum_ub += ub;
+            cyl_sum_exact += exact;
+            if ((long long)ub < exact) {
+                if (violations < 5) std::printf("VIOLATION (cylinder) trial %d hyp %d: ub %u < exact %d (kind %d, how %d, sc %.3g, far %.3g, sigma %.3g, T %.3g, r %.3g)\n", t, hq, ub, exact, kindt, how, sc, far, sigma, T, rad);
+                ++violations;
+            }
+        }
     }
+    std::printf("cylinders: %lld pairs, sum of bounds %lld, sum of exact counts %lld\n", cyl_pairs, cyl_sum_ub, cyl_sum_exact);
     std::printf("%lld (tile, hypothesis) pairs, violations %lld\n", pairs, violations);
     if (violations == 0) std::printf("all checks passed\n");
     return violations == 0 ? 0 : 1;
