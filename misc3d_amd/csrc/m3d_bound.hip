@@ -263,7 +263,7 @@ void launch_tile_frames(const SortedView& s, double* frames, uint16_t* cum, hipS
 // Arithmetic and its margins: m3d_bound_fp.hpp (plane_pair_ub: the value at the tile's centre in fp64, the rest in fp32 with every
 // number pushed outwards; tests/cpp/test_plane_bound.cpp runs the same code on the host against exact counts).
 constexpr int kBoundWaves = 8;   // (4 waves x 16 tiles each: step 0.2594-0.2621 ms; 8 x 8: 0.2570-0.2572)
-template <int KIND /* 0 plane, 2 cylinder (cyl_pair_ub: the shell as a slab per tile) */, int kBoundTpw /* tiles per wave */>
+template <int KIND /* 0 plane, 1 sphere, 2 cylinder (cyl_pair_ub: the shell as a slab per tile) */, int kBoundTpw /* tiles per wave */>
 __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* __restrict__ frames, const uint16_t* __restrict__ cum,
                                                                    uint32_t n_tiles, double max_abs,
                                                                    const double* __restrict__ score,
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             if (k < 3u) c_s[tl][k] = v;
             f_s[tl][k] = frame_to_f32(v, k);
         }
-        if (KIND == 2) {   // cylinders: the tile's bounding radius about its centre, once per tile (slot 0: the centre's fp32 copy is not used)
+        if (KIND != 0) {   // spheres, cylinders: the tile's bounding radius about its centre, once per tile (slot 0: the centre's fp32 copy is not used)
             __syncthreads();
             if (threadIdx.x < nt) f_s[threadIdx.x][0] = cyl_tile_rho(f_s[threadIdx.x]);
         }
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             pr = plane_bound_record(rec_s[lane], max_abs);
             pr.ok = pr.ok && has;
         } else {
-            cr = cyl_bound_record(rec_s[lane], max_abs);
+            cr = KIND == 1 ? sphere_bound_record(rec_s[lane], max_abs) : cyl_bound_record(rec_s[lane], max_abs);
             cr.ok = cr.ok && has;
         }
         const unsigned long long bit = 1ull << (h & 63u);
@@ -432,6 +432,7 @@ void launch_plane_bound(int kind, const SortedView& s, const double* score, cons
                                 ubsum, best_count, keep, tickets, max_list);
     };
     if (kind == 0) go(plane_bound_k<0, tpw>);
+    else if (kind == 1) go(plane_bound_k<1, tpw_cyl>);
     else go(plane_bound_k<2, tpw_cyl>);
 }
 

@@ -168,6 +168,26 @@ M3D_HD CylBoundRec cyl_bound_record(const double* rec /* p1 (3), p2 (3), t_lo, t
     r.ok = r.ok && (dhi < 1e12);
     return r;
 }
+// A SPHERE is the same with no axis to project out: record (centre, s_lo, s_hi), inlier <=> s_lo <= |q - centre|^2 <= s_hi
+// (m3d_fp.hpp sphere_cutoffs, ransac.h:332-343); m = c - centre, d = 0.
+M3D_HD CylBoundRec sphere_bound_record(const double* rec /* centre (3), s_lo, s_hi */, double max_abs) {
+    CylBoundRec r;
+    const double Wm = 2.0 * max_abs + ((fabs(rec[0]) + fabs(rec[1])) + fabs(rec[2]));
+    const double Es = 1e-12 * (Wm * Wm);   // (the fp64 evaluation of s: three squares of differences <= W, two additions)
+    const double slo = rec[3], shi = rec[4];
+    r.ok = (slo == slo) && (shi == shi) && (shi >= 0.0) && (Wm < 1e12) && (shi < 1e30);
+    for (int k = 0; k < 3; ++k) {
+        r.p1[k] = rec[k];
+        r.df[k] = 0.0f;
+    }
+    const double dhi = sqrt(shi + Es) * (1.0 + 1e-12);
+    const double sl = slo - Es;
+    const double dlo = sl > 0.0 ? sqrt(sl) * (1.0 - 1e-12) : 0.0;
+    r.dhif = (float)(dhi * (1.0 + 1e-6));
+    r.dlof = (float)(dlo * (1.0 - 1e-6));
+    r.mg = (float)(1e-13 * Wm * (1.0 + 1e-6));
+    return r;
+}
 M3D_HD float bound_sqrt(float x) {   // (the device's v_sqrt_f32: within 1 ulp for normal arguments, the margins below take 3e-7)
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sqrtf(x);

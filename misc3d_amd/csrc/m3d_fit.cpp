@@ -405,16 +405,18 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             // "512 per touched tile" in the keep rule (m3d_bound.hip).  The keep kernels below hand plane_bound_k the kept
             // hypotheses as a list (its length: word 6 of best_count); ubsum is the slot's phase-counter array, zeroed by
             // minimal_fit_k and unused when the scoring is not phased.
-            // Cylinders (round 5): the same bound with the shell taken as a slab per tile (cyl_pair_ub), in front of the phased scoring
-            // -- whose phase counters sit where the planes' bound sums go, so the cylinders' sums get the block behind them.
-            const bool bound_on = (kind == M3D_PLANE ? !ubp : kind == M3D_CYLINDER) && prune && bc && sv.frames && config().plane_bound != 0 &&
-                                  (config().plane_bound == 2 || bound_pays(sv.n_tiles, comm ? sl_pad : count)) &&
+            // Spheres and cylinders (round 5): the same bound with the shell taken as a slab per tile (cyl_pair_ub); cylinders in front of
+            // the phased scoring -- whose phase counters sit where the bound sums go otherwise, so theirs get the block behind them.
+            // (Spheres: C3's fit loses a third of its (tile, hypothesis) pairs and gains nothing -- 0.77 ms with and without, the bound's
+            // launch costs what it saves; theirs runs when the bound is forced, m3d_config.plane_bound = 2, i.e. in the tests.)
+            const bool bound_on = (kind == M3D_CYLINDER || !ubp) && prune && bc && sv.frames && config().plane_bound != 0 &&
+                                  (config().plane_bound == 2 || (kind != M3D_SPHERE && bound_pays(sv.n_tiles, comm ? sl_pad : count))) &&
                                   (use_lead || !new_fit) && !scored_with_own_tests && std::max(g0, ga) < g1;
-            uint32_t* const ubsum = kind == M3D_PLANE ? ub + h_pad : ub + 2 * (size_t)h_pad;
+            uint32_t* const ubsum = ubp ? ub + 2 * (size_t)h_pad : ub + h_pad;
             if (bound_on) {
                 const int src = reserve_survivor_scratch(ctx, h_pad);
                 if (src != M3D_OK) return src;
-                if (kind != M3D_PLANE) HIPCHK(hipMemsetAsync(ubsum, 0, sizeof(uint32_t) * h_pad, ctx->stream));   // (the planes' block is cleared by minimal_fit_k)
+                if (ubp) HIPCHK(hipMemsetAsync(ubsum, 0, sizeof(uint32_t) * h_pad, ctx->stream));   // (the block behind ub is cleared by minimal_fit_k)
             }
             uint32_t* const surv_count = bound_on ? bc + 6 : nullptr;
             uint32_t* const surv = bound_on ? bound_list(ctx) : nullptr;
@@ -1006,7 +1008,7 @@ static int ensure_plane_frames(m3d_cloud* c, int kind, size_t n_hypotheses) {
     // takes ~0.09 ms per million points, the bound saves ~0.02 ms per 10 000 hypotheses on them: m3d_fit_plane 0.95 -> 1.04 ms
     // otherwise); 2: always (tests)
     const int mode = config().plane_bound;
-    if ((kind != M3D_PLANE && kind != M3D_CYLINDER) || c->frames_ready || c->frames_failed || mode == 0 || c->work.active || c->n_tiles == 0 ||
+    if ((kind == M3D_SPHERE && mode != 2) || c->frames_ready || c->frames_failed || mode == 0 || c->work.active || c->n_tiles == 0 ||
         (mode == 1 && (!bound_pays(c->n_tiles, std::min<size_t>(n_hypotheses, chunk_cap_for(c->view(), c->sorted()))) ||
                        (c->one_shot && n_hypotheses < 65536u))))
         return M3D_OK;

@@ -177,6 +177,25 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 512; ++i) exact += cylinder_distance(w7, P[3 * i], P[3 * i + 1], P[3 * i + 2]) < T;
             const CylBoundRec cr = cyl_bound_record(rec, mabs);
             const uint32_t ub = cyl_pair_ub(cr, c, f, cyl_tile_rho(f), cum.data());
+            // ... and the sphere of the same radius on the same side of the patch (sphere_bound_record; the reference's test
+            // fabs(|q - centre| - r) < threshold, ransac.h:332-343)
+            {
+                double sp[4] = {w7[0], w7[1], w7[2], w7[6]}, slo, shi;
+                sphere_cutoffs(sp, T, &slo, &shi);
+                const double srec[5] = {sp[0], sp[1], sp[2], slo, shi};
+                int sexact = 0;
+                for (int i = 0; i < 512; ++i) sexact += sphere_distance(sp, P[3 * i], P[3 * i + 1], P[3 * i + 2]) < T;
+                const CylBoundRec sr = sphere_bound_record(srec, mabs);
+                const uint32_t sub = cyl_pair_ub(sr, c, f, cyl_tile_rho(f), cum.data());
+                ++pairs;
+                ++cyl_pairs;
+                cyl_sum_ub += sub;
+                cyl_sum_exact += sexact;
+                if ((long long)sub < sexact) {
+                    if (violations < 5) std::printf("VIOLATION (sphere) trial %d hyp %d: ub %u < exact %d (kind %d, how %d, sc %.3g, far %.3g, sigma %.3g, T %.3g, r %.3g)\n", t, hq, sub, sexact, kindt, how, sc, far, sigma, T, rad);
+                    ++violations;
+                }
+            }
             ++pairs;
             ++cyl_pairs;
             cyl_sum_ub += ub;
@@ -187,7 +206,7 @@ int main(int argc, char** argv) {
             }
         }
     }
-    std::printf("cylinders: %lld pairs, sum of bounds %lld, sum of exact counts %lld\n", cyl_pairs, cyl_sum_ub, cyl_sum_exact);
+    std::printf("cylinders and spheres: %lld pairs, sum of bounds %lld, sum of exact counts %lld\n", cyl_pairs, cyl_sum_ub, cyl_sum_exact);
     std::printf("%lld (tile, hypothesis) pairs, violations %lld\n", pairs, violations);
     if (violations == 0) std::printf("all checks passed\n");
     return violations == 0 ? 0 : 1;
