@@ -486,10 +486,11 @@ typedef struct m3d_config {
                                        tiles below it (compact_write_k, ONE) -- instead of a counting launch and a writing launch.  Same
                                        output, position for position; measured SLOWER (a count crossing the XCDs' L2s costs more than the
                                        launch boundary it replaces: profiles/r04_compact_one_pass.txt) */
-    int32_t plane_bound;            /* [M3D_PLANE_BOUND=0]  default 1: plane fits with an incumbent prune with a per-tile HISTOGRAM upper bound of
+    int32_t plane_bound;            /* [M3D_PLANE_BOUND=0]  default 1: plane fits -- and since round 5 cylinder fits: the shell over a tile is a slab up to a
+                                       sagitta -- with an incumbent prune with a per-tile HISTOGRAM upper bound of
                                        every (tile, hypothesis) pair's inlier count (tile_frames_k / plane_bound_k, m3d_bound.hip) instead of
                                        512 per touched tile, where that pays (windows of >= 8192 hypotheses on tiles x hypotheses >= 1.5e7, measured: m3d_fit.cpp
-                                       bound_pays; 2: whatever the size); same results, fewer hypotheses counted point by point.  (Fields are
+                                       bound_pays; 2: whatever the size, and sphere fits too); same results, fewer hypotheses counted point by point.  (Fields are
                                        only ever appended, the offsets of existing fields do not move -- ADVICE r3) */
     int32_t lanes;                  /* [M3D_LANES]          default 4 (1..8): calls a device runs side by side -- every lane has its own streams and
                                        scratch, a call holds one from entry to return, host threads are dealt lanes in the order they arrive
