@@ -139,17 +139,19 @@ DeviceCtx* get_lane(int device, int lane) {
     if (lane < 0 || lane >= kMaxLanes) lane = 0;
     auto it = g_ctx.find(device * kMaxLanes + lane);
     if (it != g_ctx.end()) return it->second;
-    // the first call at a device creates ALL its lanes' main streams, in lane order: the runtime hands a new stream the least-used of
-    // its few hardware queues, so the lanes' compute streams spread over them before any lane's copy / pre stream exists (a sliced
-    // match on lane 0 creating those first put lane 1's compute stream on lane 0's queue: two pairs in flight 459 -> 324 pairs/s)
+    // A device's first call creates lanes 0 AND 1 (see the stream layout below): the second lane's compute stream gets its hardware
+    // queue before lane 0's copy stream can take it.
     DeviceCtx* mine = nullptr;
-    for (int ln = 0; ln <= std::max(lane, lane_count() - 1); ++ln) {
+    for (int ln = 0; ln <= std::max(lane, std::min(2, lane_count()) - 1); ++ln) {
         if (g_ctx.count(device * kMaxLanes + ln)) continue;
         DeviceCtx* c = create_lane_locked(device, ln);
         if (ln == lane) mine = c;
         if (!c) break;
     }
-    return mine ? mine : (g_ctx.count(device * kMaxLanes + lane) ? g_ctx[device * kMaxLanes + lane] : nullptr);
+    if (mine) return mine;
+    it = g_ctx.find(device * kMaxLanes + lane);
+    if (it != g_ctx.end()) return it->second;
+    return create_lane_locked(device, lane);
 }
 static DeviceCtx* create_lane_locked(int device, int lane) {
     int count = 0;
@@ -168,11 +170,17 @@ static DeviceCtx* create_lane_locked(int device, int lane) {
     DeviceCtx* c = new DeviceCtx();
     c->device = device;
     c->lane = lane;
-    // ONE stream per lane to begin with: the runtime deals a process's streams round-robin onto a handful of hardware queues
-    // (GPU_MAX_HW_QUEUES, default 4), and two lanes whose compute streams share a queue run one after the other.  With a copy
-    // and a pre stream per lane created up front, lanes 0 and 1 collided (tools/ubench/lanes_fit.cpp: two threads on two lanes
-    // 1.24x of one, 2.0x when the lanes' streams fell on different queues); both are now created by the first call that needs
-    // them (copy_stream_of / pre_stream_of: fits that ship a list through the copy engine, fits of several chunks).
+    // The lanes' streams and the runtime's hardware queues (tools/ubench/stream_queues.hip prints the map): a process gets FOUR queues
+    // per stream priority; a new stream takes a free one and, once all four are taken, shares one -- two streams on one queue run
+    // their kernels one after the other.  A lane has a compute stream, and a copy stream (normal priority) and a pre-stream (high
+    // priority: a pool of its own) that the first call that needs them creates (copy_stream_of / pre_stream_of).  What was measured
+    // (profiles/r05_stream_layouts.txt; single-threaded C3 / C5 fits, the loop over fragment pairs after a sliced match, threads of
+    // plain fits): the three streams created with the lane -- lanes 0 and 1 took turns (two threads 1.24x of one); secondaries on
+    // demand, lanes on demand -- fine unless lane 0's copy stream exists before lane 1 does (two pairs in flight 350 pairs/s instead
+    // of 500); every lane's compute stream created by a device's first call -- the multi-threaded cases fine, single-threaded fits
+    // of several chunks lost 15-20 % (C3 fit_sphere 0.64 -> 0.79 ms: the copy stream then shares a queue with an idle lane's
+    // stream); a copy stream at high or low priority -- threads of fits 1.1-1.3x of one.  Kept: lanes 0 and 1 created by a device's
+    // first call (get_lane), the others on demand, both secondaries on demand at the priorities above.
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_compact, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&c->ev_pre_gate, hipEventDisableTiming) == hipSuccess;
@@ -193,9 +201,11 @@ static DeviceCtx* create_lane_locked(int device, int lane) {
 DeviceCtx* get_ctx(int device) { return get_lane(device, 0); }
 // the lane's secondary streams, created on first use (the caller holds the lane); nullptr + last error on failure
 hipStream_t copy_stream_of(DeviceCtx* ctx) {
-    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
-        ctx->copy_stream = nullptr;
-        set_error("failed to create the lane's copy stream");
+    if (!ctx->copy_stream) {
+        if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+            ctx->copy_stream = nullptr;
+            set_error("failed to create the lane's copy stream");
+        }
     }
     return ctx->copy_stream;
 }
