@@ -98,13 +98,13 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, uin
 #define M3D_MATCH_STAGE_TILES 8
 #endif
 constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
-// M3D_MATCH_PIPELINE=1 (round 5, measured and refuted: 6.87 -> 8.33-8.40 ms on 200 k x 200 k, with and without scheduling
+// M3D_MATCH_SW_PIPELINE=1 (round 5, measured and refuted: 6.87 -> 8.33-8.40 ms on 200 k x 200 k, with and without scheduling
 // barriers, unrolled by two and by four): tile u + 1's MFMAs issued before tile u's post-processing, on a second accumulator
 // set.  A wave issues in order: its VALU work cannot start before the last of the six MFMAs -- two dependent chains of three --
 // has ISSUED, so nothing overlaps inside the wave and the second accumulator set only lengthens live ranges (146 -> 156 VGPRs).
 // (Also measured: a start offset per workgroup against lockstep phases of a SIMD's three waves: 6.865 ms, nothing.)  Off; not compiled.
-#ifndef M3D_MATCH_PIPELINE
-#define M3D_MATCH_PIPELINE 0
+#ifndef M3D_MATCH_SW_PIPELINE
+#define M3D_MATCH_SW_PIPELINE 0
 #endif
 // queries per workgroup = 64 x waves: every wave of a workgroup reads the same staged tiles, so the staging traffic per query goes
 // with 1 / waves (four waves: 14.7 GB from L2 per 200 k x 200 k scan, a fifth of the scan's time)
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(kBlockThreads) void nn16_scan_k(const h8* __restric
                     a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], a1, 0, 0, 0);
                 }
             };
-#if M3D_MATCH_PIPELINE
-            // (the refuted variant: see M3D_MATCH_PIPELINE above)
+#if M3D_MATCH_SW_PIPELINE
+            // (the refuted variant: see M3D_MATCH_SW_PIPELINE above)
             f32x16 accA0, accA1, accB0, accB1;
             multiply(0u, accA0, accA1);
             for (uint32_t u = 0; u < in_stage; u += 2u) {   // two tiles per trip: the sets alternate without moves, the code stays two copies

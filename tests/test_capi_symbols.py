@@ -88,13 +88,13 @@ def test_global_registration_argument_validation_needs_no_gpu(capi):
 
 
 def test_round5_config_fields(capi):
-    """lanes, wait_spin_us, prestream, chunk_cap, first_chunk, reg_cells_per_radius: defaults and sanitising (appended fields)."""
+    """lanes, wait_spin_us, prestream, chunk_cap, first_chunk, reg_cells_per_radius, match_pipeline: defaults and sanitising (appended fields)."""
     c = capi.get_config()
-    assert (c.lanes, c.wait_spin_us, c.prestream, c.chunk_cap, c.first_chunk, c.reg_cells_per_radius) == (4, 500, 1, 24576, 2048, 4)
-    old = capi.set_config(lanes=99, wait_spin_us=-5, chunk_cap=100, first_chunk=-1, reg_cells_per_radius=0, prestream=7)
+    assert (c.lanes, c.wait_spin_us, c.prestream, c.chunk_cap, c.first_chunk, c.reg_cells_per_radius, c.match_pipeline) == (4, 500, 1, 24576, 2048, 4, 1)
+    old = capi.set_config(lanes=99, wait_spin_us=-5, chunk_cap=100, first_chunk=-1, reg_cells_per_radius=0, prestream=7, match_pipeline=9)
     try:
         n = capi.get_config()
-        assert (n.lanes, n.wait_spin_us, n.prestream, n.chunk_cap, n.first_chunk, n.reg_cells_per_radius) == (4, 500, 1, 1024, 0, 4)
+        assert (n.lanes, n.wait_spin_us, n.prestream, n.chunk_cap, n.first_chunk, n.reg_cells_per_radius, n.match_pipeline) == (4, 500, 1, 1024, 0, 4, 1)
         if not capi.experimental():      # the product build ignores the refuted variants' switches (m3d_kernels.hpp)
             capi.set_config(score_mfma=1, score_waves4=1, compact_one_pass=1)
             n = capi.get_config()
