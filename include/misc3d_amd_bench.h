@@ -40,6 +40,10 @@ int m3d_bench_cloud_setup_ms(const m3d_cloud *cloud, double out[5]);
  * Builds the cloud's tile frames if it has none yet. */
 int m3d_bench_plane_upper_bounds(m3d_cloud *cloud, double threshold, const uint32_t *samples, size_t n_hypotheses,
                                  uint32_t *ub_out);
+/* ... for any kind (M3D_PLANE / M3D_SPHERE / M3D_CYLINDER; samples: n_hypotheses x 3 / 4 / 2 indices): spheres and cylinders are
+ * bounded through the slab their shell is over one tile (m3d_bound_fp.hpp cyl_pair_ub). */
+int m3d_bench_upper_bounds(m3d_cloud *cloud, int kind, double threshold, const uint32_t *samples, size_t n_hypotheses,
+                           uint32_t *ub_out);
 /* Wall clock of the calling thread's LAST m3d_segment_plane_iterative* call in ms: out[0] the whole call, out[1]
  * m3d_cloud_create (upload, sort, tile boxes), out[2] the round loop, out[3] the final copy of the index lists out of
  * the page-locked staging array (0 when the caller's array is page-locked), out[4] of the round loop: the rounds on more

@@ -114,6 +114,7 @@ def lib():
         L.m3d_bench_time_score.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p]     # include/misc3d_amd_bench.h
         L.m3d_bench_plane_upper_bounds.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.m3d_bench_upper_bounds.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p]
         L.m3d_sampler_create.restype = C.c_void_p
         L.m3d_sampler_create.argtypes = [C.c_size_t, C.c_int, C.c_uint64]
         L.m3d_sampler_destroy.argtypes = [C.c_void_p]
@@ -665,6 +666,13 @@ class Cloud:
         samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, 3)
         ub = np.zeros(len(samples), dtype=np.uint32)
         _check(lib().m3d_bench_plane_upper_bounds(self._h, threshold, _p(samples), len(samples), _p(ub)))
+        return ub
+
+    def upper_bounds(self, kind, threshold, samples):
+        """m3d_bench_upper_bounds -> uint32 upper bound of every hypothesis' inlier count (plane_bound_k<kind>, nothing pruned)"""
+        samples = np.ascontiguousarray(samples, dtype=np.uint32).reshape(-1, MINIMAL_SAMPLE[kind])
+        ub = np.zeros(len(samples), dtype=np.uint32)
+        _check(lib().m3d_bench_upper_bounds(self._h, kind, threshold, _p(samples), len(samples), _p(ub)))
         return ub
 
     def exact_error(self, kind, threshold, model):

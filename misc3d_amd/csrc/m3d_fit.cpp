@@ -1569,9 +1569,15 @@ int m3d_bench_time_score(m3d_cloud* c, int kind, double threshold, const uint32_
 
 // m3d_bench_plane_upper_bounds: plane_bound_k on its own -- the histogram upper bound of EVERY hypothesis of a sample table
 // (nothing pruned, every hypothesis on the list), for the test that holds it against the exact counts
+int m3d_bench_upper_bounds(m3d_cloud* c, int kind, double threshold, const uint32_t* samples, size_t n_hypotheses, uint32_t* ub_out);
 int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t* samples, size_t n_hypotheses, uint32_t* ub_out) {
-    if (!c || !samples || !ub_out || n_hypotheses == 0 || n_hypotheses > 16384)
+    return m3d_bench_upper_bounds(c, M3D_PLANE, threshold, samples, n_hypotheses, ub_out);
+}
+// ... for any kind (spheres and cylinders: cyl_pair_ub)
+int m3d_bench_upper_bounds(m3d_cloud* c, int kind, double threshold, const uint32_t* samples, size_t n_hypotheses, uint32_t* ub_out) {
+    if (!c || !samples || !ub_out || n_hypotheses == 0 || n_hypotheses > 16384 || kind < M3D_PLANE || kind > M3D_CYLINDER)
         return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    if (kind == M3D_CYLINDER && !c->has_normals) return fail(M3D_ERR_INVALID_ARG, "cylinder hypotheses need normals");
     DeviceCtx* ctx = c->ctx;
     CtxLock lock(ctx);
     HIPCHK(hipSetDevice(ctx->device));
@@ -1587,15 +1593,15 @@ int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t*
     const SortedView sv = c->sorted();
     SampleSource src;
     src.table = samples;
-    src.m = 3;
+    src.m = (uint32_t)minimal_sample(kind);
     ChunkSlot& s = ctx->slot[0];
-    int rc = issue_chunk(ctx, s, v, sv, M3D_PLANE, threshold, 0, n_hypotheses, src, nullptr);   // records (+ fp32 box-test records)
+    int rc = issue_chunk(ctx, s, v, sv, kind, threshold, 0, n_hypotheses, src, nullptr);   // records (+ fp32 box-test records)
     if (rc != M3D_OK) return rc;
     const uint32_t n_groups = s.h_pad / 64;
     RESERVE(ctx->masks, sizeof(uint64_t) * (size_t)std::max<uint32_t>(sv.n_tiles, 1) * n_groups);
     RESERVE(ctx->keep, sizeof(uint64_t) * (size_t)n_groups);
     RESERVE(ctx->small, 256);
-    RESERVE(s.ub, sizeof(uint32_t) * 2 * (size_t)s.h_pad);
+    RESERVE(s.ub, sizeof(uint32_t) * 3 * (size_t)s.h_pad);
     rc = reserve_survivor_scratch(ctx, s.h_pad);
     if (rc != M3D_OK) return rc;
     auto* masks = ctx->masks.as<unsigned long long>();
@@ -1606,10 +1612,10 @@ int m3d_bench_plane_upper_bounds(m3d_cloud* c, double threshold, const uint32_t*
     const float* c32 = (!use_dense_scoring() && config().cull_fp32 != 0 && sv.radius < 1e18) ? s.cull32.as<float>() : nullptr;
     HIPCHK(hipMemsetAsync(ubsum, 0, sizeof(uint32_t) * (size_t)s.h_pad, ctx->stream));
     HIPCHK(hipMemsetAsync(ctl, 0, 8, ctx->stream));
-    launch_cull_mask(M3D_PLANE, sv, s.score.as<double>(), s.valid.as<uint8_t>(), (uint32_t)n_hypotheses, n_groups, masks, nullptr,
+    launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), (uint32_t)n_hypotheses, n_groups, masks, nullptr,
                      ctx->stream, false, 0, 0xFFFFFFFFu, c32);
     launch_keep_mask(nullptr, nullptr, n_groups, keep, ctx->stream, nullptr, 0, 0, ctl + 1, surv);
-    launch_plane_bound(M3D_PLANE, sv, s.score.as<double>(), masks, keep, n_groups, 0, n_groups, ubsum, ctl, ctl + 1, surv,
+    launch_plane_bound(kind, sv, s.score.as<double>(), masks, keep, n_groups, 0, n_groups, ubsum, ctl, ctl + 1, surv,
                        bound_tickets(ctx), c32, ctx->stream, /*always=*/true);
     HIPCHK(hipMemcpyAsync(ub_out, ubsum, sizeof(uint32_t) * n_hypotheses, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());

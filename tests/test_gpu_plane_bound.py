@@ -148,6 +148,45 @@ def test_upper_bound_is_an_upper_bound(capi, case, thr):
         assert cnt[b] > 0.3 * n and ub[b] - cnt[b] < 0.2 * cnt[b], (case, int(cnt[b]), int(ub[b]))
 
 
+@pytest.mark.parametrize("kind,case,thr", [(2, "cylinder_c3", 0.01), (2, "cylinder_c3", 0.003), (2, "cylinder_c3", 0.04), (2, "cylinder_far", 0.01),
+                                           (2, "clutter", 0.02), (1, "sphere_c3", 0.01), (1, "sphere_c3", 0.002), (1, "sphere_far", 0.01),
+                                           (1, "clutter", 0.02), (1, "cylinder_c3", 0.01), (2, "sphere_c3", 0.01)])
+def test_shell_upper_bound_is_an_upper_bound(capi, kind, case, thr):
+    """plane_bound_k<1> / <2> on their own (m3d_bench_upper_bounds: every hypothesis on the list, nothing pruned): over one tile a
+    sphere's or a cylinder's shell is a slab up to a sagitta (m3d_bound_fp.hpp cyl_pair_ub).  Against the exact counts of the dense
+    path: ub >= count for EVERY hypothesis -- scenes at the origin and 300 scene sizes away, thresholds from the noise's size to
+    four times the baseline's, clouds of the other shape and clutter -- and tight where it should be (the best hypothesis of a
+    cloud with a dominant shell: within 30 % / 40 % of its count)."""
+    rng = np.random.default_rng(19 + kind)
+    n, H = 150_000, 4096
+    nrm = None
+    if case.startswith("cylinder"):
+        pts, nrm = synth.cylinder_cloud_c3(n, 3)
+    elif case.startswith("sphere"):
+        pts = synth.sphere_cloud_c3(n, 4)
+    else:
+        pts = rng.uniform(-1, 1, size=(n, 3))
+    if kind == 2 and nrm is None:          # cylinder hypotheses need normals: random ones on a cloud of another shape
+        nrm = rng.normal(size=(n, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    if case.endswith("far"):
+        pts = pts + np.array([900.0, -700.0, 400.0])
+    pts = np.ascontiguousarray(pts)
+    samples = capi.draw_samples(n, kind, H, 29)
+    with capi.Cloud(pts, nrm if kind == 2 else None) as c:
+        ub = c.upper_bounds(kind, thr, samples).astype(np.int64)
+        val, _, cnt = c.score_range(kind, thr, samples, 0, H, want_models=False)
+    cnt = cnt.astype(np.int64)
+    ok = val.astype(bool)
+    bad = np.nonzero(ok & (ub < cnt))[0]
+    assert len(bad) == 0, (kind, case, thr, bad[:5], ub[bad[:5]], cnt[bad[:5]])
+    if (kind, case) in ((2, "cylinder_c3"), (1, "sphere_c3"), (2, "cylinder_far"), (1, "sphere_far")) and thr == 0.01:
+        b = int(np.argmax(np.where(ok, cnt, -1)))
+        # (at 150 000 points a tile on the shell is ~15 cm across on a radius of 25 cm -- cylinder -- or 50 cm -- sphere --: its own
+        # sagitta is of the threshold's size, which the slab has to take in; at C3's million points a tile is 5 cm)
+        assert cnt[b] > 0.3 * n and ub[b] - cnt[b] < (0.4 if kind == 2 else 0.3) * cnt[b], (kind, case, int(cnt[b]), int(ub[b]))
+
+
 def test_bound_soak_scaled_and_shifted_scenes(capi, orc):
     """Fixed seed, fixed budget (20 s): plane clouds of random size, scaled by 10^-2 .. 10^2 and moved up to 10^3 scene sizes
     from the origin (the bound evaluates in fp32 beside an fp64 centre value: its margins), thresholds from a third of the
