@@ -191,16 +191,63 @@ __global__ __launch_bounds__(256) void nn64_verify_k(const double* __restrict__ 
     if (sub == 0) nn[i] = bi;
 }
 
-// one wave per overflowed query: exact brute force, lanes stride the database, (distance, index)
-// lexicographic minimum across lanes.
-__global__ __launch_bounds__(64) void nn_exact_one_k(const double* __restrict__ q, const double* __restrict__ db,
-                                                      uint32_t ndb, int dim, const uint32_t* __restrict__ list,
-                                                      uint32_t* __restrict__ nn) {
+// one workgroup of sixteen waves per overflowed query: exact brute force, threads stride the database, (distance, index)
+// lexicographic minimum across the workgroup.  (One wave per query until round 5: 25 ms for ONE query against 200 000 rows -- a
+// single row whose candidates overflow turned a 7 ms match into a 32 ms one.)
+constexpr int kExactThreads = 1024;
+__global__ __launch_bounds__(kExactThreads) void nn_exact_one_k(const double* __restrict__ q, const double* __restrict__ db,
+                                                                 uint32_t ndb, int dim, const uint32_t* __restrict__ list,
+                                                                 uint32_t* __restrict__ nn) {
+    __shared__ double wd[kExactThreads / 64];
+    __shared__ uint32_t wi[kExactThreads / 64];
     const uint32_t i = list[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double bd = INFINITY;
     uint32_t bi = 0xFFFFFFFFu;
-    for (uint32_t j = lane; j < ndb; j += 64) {
+    for (uint32_t j = threadIdx.x; j < ndb; j += kExactThreads) {
+        double acc = 0.0;
+        for (int k = 0; k < dim; ++k) {
+            const double df = q[(size_t)i * dim + k] - db[(size_t)j * dim + k];
+            acc += df * df;
+        }
+        if (acc < bd) {   // (a thread's rows come in ascending order: the first of equal distances stays)
+            bd = acc;
+            bi = j;
+        }
+    }
+    auto take = [&](double od, uint32_t oi) {
+        if (od < bd || (od == bd && oi < bi)) {
+            bd = od;
+            bi = oi;
+        }
+    };
+    for (int off = 32; off > 0; off >>= 1) take(__shfl_xor(bd, off, 64), (uint32_t)__shfl_xor((int)bi, off, 64));
+    if (lane == 0) {
+        wd[wave] = bd;
+        wi[wave] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kExactThreads / 64; ++w) take(wd[w], wi[w]);
+        nn[i] = bi;
+    }
+}
+
+// ... and spread over the chip: kExactSlices workgroups per overflowed query, each over a slice of the rows; the partial minima
+// (distance, index) meet in nn_exact_reduce_k.  Same distances bit for bit (a row's sum is one thread's, in the order of k), same
+// tie rule (the lowest index among equal distances).  One query against 200 000 rows: 1 ms on one CU, ~20 us on 64.
+constexpr uint32_t kExactSlices = 64;
+__global__ __launch_bounds__(256) void nn_exact_part_k(const double* __restrict__ q, const double* __restrict__ db, uint32_t ndb,
+                                                        int dim, const uint32_t* __restrict__ list, double* __restrict__ part_d,
+                                                        uint32_t* __restrict__ part_i) {
+    __shared__ double wd[4];
+    __shared__ uint32_t wi[4];
+    const uint32_t i = list[blockIdx.x];
+    const uint32_t per = (ndb + kExactSlices - 1) / kExactSlices, j0 = blockIdx.y * per, j1 = min(ndb, j0 + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double bd = INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t j = j0 + threadIdx.x; j < j1; j += 256u) {
         double acc = 0.0;
         for (int k = 0; k < dim; ++k) {
             const double df = q[(size_t)i * dim + k] - db[(size_t)j * dim + k];
@@ -211,6 +258,29 @@ __global__ __launch_bounds__(64) void nn_exact_one_k(const double* __restrict__ 
             bi = j;
         }
     }
+    auto take = [&](double od, uint32_t oi) {
+        if (od < bd || (od == bd && oi < bi)) {
+            bd = od;
+            bi = oi;
+        }
+    };
+    for (int off = 32; off > 0; off >>= 1) take(__shfl_xor(bd, off, 64), (uint32_t)__shfl_xor((int)bi, off, 64));
+    if (lane == 0) {
+        wd[wave] = bd;
+        wi[wave] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) take(wd[w], wi[w]);
+        part_d[(size_t)blockIdx.x * kExactSlices + blockIdx.y] = bd;
+        part_i[(size_t)blockIdx.x * kExactSlices + blockIdx.y] = bi;
+    }
+}
+__global__ __launch_bounds__(64) void nn_exact_reduce_k(const double* __restrict__ part_d, const uint32_t* __restrict__ part_i,
+                                                         const uint32_t* __restrict__ list, uint32_t* __restrict__ nn) {
+    static_assert(kExactSlices == 64, "one lane per slice");
+    double bd = part_d[(size_t)blockIdx.x * kExactSlices + threadIdx.x];
+    uint32_t bi = part_i[(size_t)blockIdx.x * kExactSlices + threadIdx.x];
     for (int off = 32; off > 0; off >>= 1) {
         const double od = __shfl_xor(bd, off, 64);
         const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, 64);
@@ -219,7 +289,20 @@ __global__ __launch_bounds__(64) void nn_exact_one_k(const double* __restrict__ 
             bi = oi;
         }
     }
-    if (lane == 0) nn[i] = bi;
+    if (threadIdx.x == 0) nn[list[blockIdx.x]] = bi;
+}
+size_t nn_exact_scratch_bytes(uint32_t n_overflow) { return (size_t)n_overflow * kExactSlices * (sizeof(double) + sizeof(uint32_t)); }
+void launch_nn_exact(const double* q, const double* db, uint32_t ndb, int dim, const uint32_t* list, uint32_t n_overflow, uint32_t* nn,
+                     void* scratch /* nn_exact_scratch_bytes(n_overflow), or null: one workgroup per query */, hipStream_t s) {
+    if (!n_overflow) return;
+    if (!scratch || ndb < 16384u) {
+        nn_exact_one_k<<<n_overflow, kExactThreads, 0, s>>>(q, db, ndb, dim, list, nn);
+        return;
+    }
+    double* pd = static_cast<double*>(scratch);
+    uint32_t* pi = reinterpret_cast<uint32_t*>(pd + (size_t)n_overflow * kExactSlices);
+    nn_exact_part_k<<<dim3(n_overflow, kExactSlices), 256, 0, s>>>(q, db, ndb, dim, list, pd, pi);
+    nn_exact_reduce_k<<<n_overflow, 64, 0, s>>>(pd, pi, list, nn);
 }
 
 __global__ void max_f32_k(const float* __restrict__ v, uint32_t n, float* __restrict__ out) {
@@ -347,7 +430,7 @@ hipError_t launch_nn_screened33(const double* q, const float* q32, const float* 
     hipError_t e = hipMemcpyAsync(h_overflow, overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
-    if (*h_overflow) nn_exact_one_k<<<*h_overflow, 64, 0, s>>>(q, db, ndb, DIM, overflow_list, nn);
+    if (*h_overflow) nn_exact_one_k<<<*h_overflow, kExactThreads, 0, s>>>(q, db, ndb, DIM, overflow_list, nn);
     return hipGetLastError();
 }
 
@@ -713,9 +796,9 @@ void match_verify_reverse(const MatchWork& w, hipStream_t s) {
     nn64_verify_rev_k<<<(w.nb + 31) / 32, 256, 0, s>>>(w.b, w.nb, w.a, 33, w.rcnt, w.rcand, w.bn2, w.max_an2, w.nn_ba,
                                                         w.overflow_list_r, w.overflow_count_r);
 }
-hipError_t match_exact_fallbacks(const MatchWork& w, const uint32_t* h_overflow /* [2] */, hipStream_t s) {
-    if (h_overflow[0]) nn_exact_one_k<<<h_overflow[0], 64, 0, s>>>(w.a, w.b, w.nb, 33, w.overflow_list, w.nn_ab);
-    if (h_overflow[1]) nn_exact_one_k<<<h_overflow[1], 64, 0, s>>>(w.b, w.a, w.na, 33, w.overflow_list_r, w.nn_ba);
+hipError_t match_exact_fallbacks(const MatchWork& w, const uint32_t* h_overflow /* [2] */, void* scratch, hipStream_t s) {
+    launch_nn_exact(w.a, w.b, w.nb, 33, w.overflow_list, h_overflow[0], w.nn_ab, scratch, s);
+    launch_nn_exact(w.b, w.a, w.na, 33, w.overflow_list_r, h_overflow[1], w.nn_ba, scratch, s);   // (stream order: the scratch is free again)
     return hipGetLastError();
 }
 

@@ -197,6 +197,9 @@ void match_scan(const MatchWork& w, uint32_t q0, uint32_t nq, uint32_t split0, u
 void match_verify_forward(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s);
 void match_reverse_bin(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s);
 void match_verify_reverse(const MatchWork& w, hipStream_t s);
-hipError_t match_exact_fallbacks(const MatchWork& w, const uint32_t* h_overflow /* [2]: the two counters, on the host */, hipStream_t s);
+// exact brute force for the queries on the overflow lists; scratch: nn_exact_scratch_bytes(max of the two counters) device bytes (the
+// queries' rows are then spread over 64 workgroups each), or null (one workgroup per query)
+size_t nn_exact_scratch_bytes(uint32_t n_overflow);
+hipError_t match_exact_fallbacks(const MatchWork& w, const uint32_t* h_overflow /* [2]: the two counters, on the host */, void* scratch, hipStream_t s);
 
 }  // namespace m3d

@@ -1725,7 +1725,15 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
                               nb, up_a, up_b, false, nn_ab, nn_ba, fallbacks);
         }
     }
-    if (match_exact_fallbacks(w, over, s) != hipSuccess) return done(M3D_ERR_DEVICE);
+    DevBuf exact_scratch;   // (a handful of queries as a rule; without the block the fall-back runs one workgroup per query)
+    const uint32_t over_max = std::max(over[0], over[1]);
+    const bool have_scratch = over_max && exact_scratch.reserve(nn_exact_scratch_bytes(over_max));
+    const hipError_t fe = match_exact_fallbacks(w, over, have_scratch ? exact_scratch.p : nullptr, s);
+    if (have_scratch) {
+        (void)hipStreamSynchronize(s);   // (the block goes back to the lane's list below)
+        exact_scratch.release();
+    }
+    if (fe != hipSuccess) return done(M3D_ERR_DEVICE);
     *fallbacks = (uint64_t)over[0] + over[1];
     g_match_path |= 1u | (sliced ? 2u : 0u);
     return done(0);
