@@ -36,9 +36,19 @@ def run(budget=240.0, reg_budget=0.0, seed=1, log=print):
             fd[rng.integers(0, nd, nd // 3)] = fd[rng.integers(0, nd, c)][rng.integers(0, c, nd // 3)] + rng.normal(0, 1e-7, (nd // 3, 33))
         if rng.random() < 0.2 and ns > 300:         # one exact duplicate block
             fs[100:100 + 280] = fs[100]
-        a, b = capi.match_mutual_nn(fs, fd)
+        # (round 5: a third of the cases with the matrices going up in slices under the scan, whatever their size -- and then now
+        # and then a late slice that does not fit the scale chosen from the first ones)
+        sliced = rng.random() < 0.35
+        if sliced and rng.random() < 0.3 and ns > 600:
+            fs[ns - 50:] *= float(rng.choice([1.9, 3.0, 6.0]))
+        old_cfg = capi.set_config(match_pipeline=2) if sliced else None
+        try:
+            a, b = capi.match_mutual_nn(fs, fd)
+        finally:
+            if old_cfg is not None:
+                capi.restore_config(old_cfg)
         oa, ob = oracle.match_mutual_nn(fs, fd)
-        assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob), ("match", ns, nd)
+        assert np.array_equal(a.astype(np.int64), oa) and np.array_equal(b.astype(np.int64), ob), ("match", ns, nd, sliced)
         n_match += 1
         # ---- segmentation (adaptive stop never bites in the clutter rounds: speculative RefineModel)
         n = int(rng.integers(20_000, 120_000))
