@@ -1532,8 +1532,13 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
     w.a = side_a.dev ? side_a.dev : up_a;
     w.b = side_b.dev ? side_b.dev : up_b;
     const uint32_t a_tiles = mfma_tiles(na), b_tiles = mfma_tiles(nb);
-    w.splits = splits_for(na, nb, 256, 1024, 8192);
-    w.splits_r = splits_for(nb, na, 256, 1024, 8192);
+    // ... but a split should hold an eighth of a mid-sized database at least (1024 .. 6144 rows): with the 512-query workgroups of
+    // round 5 a 50 000 x 50 000 search was cut into 42 splits of 37 tiles -- prologue, 84 warm-up minima per query, 84 slices for
+    // the verification to read -- and took 1.85 ms; with 8 splits 1.39 (35 000: 1.25 -> 1.11, 70 000: 2.43 -> 2.35; 10 000 and
+    // 100 000 upwards unchanged)
+    const auto rows_per_split = [](uint32_t ndb) { return std::min(6144u, std::max(1024u, ndb / 8u)); };
+    w.splits = splits_for(na, nb, 256, rows_per_split(nb), 8192);
+    w.splits_r = splits_for(nb, na, 256, rows_per_split(na), 8192);
     if (PB > 1) w.splits = (w.splits + PB - 1) / PB * PB;
     // the last full-length share of the tiles in four splits of 1/2, 1/4, 1/8, 1/8 (SplitPlan): splits - 3 shares in all
     w.plan.tail = w.splits >= 8 ? 4u : 0u;
