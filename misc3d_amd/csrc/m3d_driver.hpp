@@ -166,9 +166,13 @@ int device_max_abs(DeviceCtx* ctx, const double* dev, size_t n, double* out);
 int registration_ransac_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, const double* src, size_t n_src,
                            const double* dst, size_t n_dst, const size_t* corr_src, const size_t* corr_dst, size_t m,
                            double threshold, int max_iter, double edge_length_threshold, double confidence,
-                           const uint64_t* seed, double* T_out, m3d_reg_stats* stats);
+                           const uint64_t* seed, double* T_out, m3d_reg_stats* stats,
+                           m3d_reg** session_out = nullptr /* the finished session (its target grid with original indices kept) for
+                                                             information_matrix_on; the caller then calls reg_session_release */);
 int information_matrix_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, const double* dst, size_t n_dst,
-                          double max_correspondence_distance, const double* T, double* info, uint64_t* n_correspondences);
+                          double max_correspondence_distance, const double* T, double* info, uint64_t* n_correspondences,
+                          m3d_reg* session = nullptr);
+void reg_session_release(m3d_reg* q);   // ... of a session handed out through session_out (the caller holds the lane)
 
 void dev_pool_trim(int device);
 DeviceCtx* get_ctx(int device);  // lane 0 of the device; nullptr + last error when the device is unusable

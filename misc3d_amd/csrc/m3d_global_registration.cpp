@@ -123,8 +123,9 @@ int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, cons
             return leave(M3D_ERR_DEVICE);
         }
     }
+    m3d_reg* session = nullptr;   // (the solver's session stays for the information matrix: one target grid for both)
     rc = registration_ransac_on(trivial ? nullptr : ctx, csrc, cdst, src, n_src, dst, n_dst, cs.data(), cd.data(), m, max_dis,
-                                max_iter, edge_length_threshold, confidence, seed, T, &st.ransac);
+                                max_iter, edge_length_threshold, confidence, seed, T, &st.ransac, &session);
     const double t2 = now_ms();
     st.ms_ransac = t2 - t1;
     if (rc == M3D_OK) {
@@ -133,7 +134,7 @@ int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, cons
         } else {
             double gi[36];
             uint64_t nc = 0;
-            rc = information_matrix_on(ctx, csrc, cdst, dst, n_dst, max_dis, T, gi, &nc);   // :818-820
+            rc = information_matrix_on(ctx, csrc, cdst, dst, n_dst, max_dis, T, gi, &nc, session);   // :818-820
             st.n_info_correspondences = nc;
             if (rc == M3D_OK) {
                 if (gi[35] / (double)std::min(n_src, n_dst) < 0.3)   // :821-824
@@ -144,6 +145,7 @@ int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, cons
             st.ms_info = now_ms() - t2;
         }
     }
+    if (session) reg_session_release(session);
     if (csrc && !rs) m3d_cloud_destroy_on(csrc);
     if (cdst && !rt) m3d_cloud_destroy_on(cdst);
     return leave(rc);
