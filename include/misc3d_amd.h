@@ -504,7 +504,8 @@ typedef struct m3d_config {
     int32_t chunk_cap;              /* [M3D_CHUNK_CAP]      default 24576 (1024..262144, multiple of 64): hypotheses per chunk of the culled path */
     int32_t first_chunk;            /* [M3D_FIRST_CHUNK]    default 2048 (0 = off): length of the short first chunk of a fit of several chunks (the
                                        incumbent that prunes the rest) */
-    int32_t reg_cells_per_radius;   /* [M3D_REG_K]          default 4 (1..16): cells per search radius of the registration validation's grid */
+    int32_t reg_cells_per_radius;   /* [M3D_REG_K]          default 4 (1..16): cells per search radius of the registration validation's grid for a target of
+                                       200 000 points and more; smaller targets get coarser cells (cube root of the size ratio) */
     int32_t match_pipeline;         /* [M3D_MATCH_PIPELINE] default 1: a match of two large host matrices (>= 65 536 rows each) uploads them in slices (two of
                                        the queries, four of the database) and scans block (i, j) while the next slice is on the link (same result:
                                        tests/test_gpu_match_sliced.py) -- when the call is alone on the device (other calls' kernels fill the gap

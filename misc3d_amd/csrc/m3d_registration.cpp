@@ -433,7 +433,12 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
     R.thr = threshold;
 
     {
-        const int k0 = config().reg_cells_per_radius;   // cells per radius of the validation grid
+        // cells per radius of the validation grid: m3d_config.reg_cells_per_radius (4) is the figure for a 200 000-point target; a
+        // smaller one gets coarser cells in proportion to the cube root (about the same points per cell: a 50 000-point target
+        // builds its grid and is searched in 0.64 ms per default-confidence call with 3 cells per radius, 0.77 with 4; 200 000
+        // points: 1.33 with 4, 1.51 with 3, 2.09 with 2)
+        const int k_cfg = config().reg_cells_per_radius;
+        const int k0 = std::max(1, std::min(k_cfg, (int)std::lround(k_cfg * std::cbrt((double)n_dst / 200000.0))));
         const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, keep_orig, &g, k0, /*with_nl=*/false,
                                               cdst->bb_known ? cdst->bb : nullptr);
         if (rc_grid != M3D_OK) return rc_grid;
