@@ -212,8 +212,9 @@ typedef struct m3d_reg_stats {
     uint64_t ties;             /* equal-fitness comparisons decided during the replay (hypotheses the validation dropped early
                                 * on their partial count or sum never get that far) */
     uint64_t exact_rmse_evals; /* of which needed the serial-order sum of squared distances */
-    uint64_t lds_wave_hypotheses;    /* always 0 (round 2's LDS-staged validation kernel was deleted; the slot keeps the layout) */
-    uint64_t global_wave_hypotheses; /* always 0 */
+    uint64_t lds_wave_hypotheses;    /* round 6: (256-point source tile, hypothesis) pairs whose queries the validation's candidate cache answered
+                                      * from registers (m3d_config.reg_cache; the field's name is round 2's, the slot keeps the layout) */
+    uint64_t global_wave_hypotheses; /* round 6: pairs the cache could not certify and the neighbour-list walk evaluated after it (0 / 0: no cache) */
     uint64_t nn_fp32_screen;         /* 1: the validation's neighbour search ran behind the fp32 screen (m3d_config.reg_fp32_screen and a
                                       * grid the screen admits: cell edge and offsets within fp32's reach) */
     uint64_t nn_screen_fallbacks;    /* queries whose runner-up lay within the rounding bound of the winner: decided by the fp64 walk */
@@ -510,6 +511,17 @@ typedef struct m3d_config {
                                        the queries, four of the database) and scans block (i, j) while the next slice is on the link (same result:
                                        tests/test_gpu_match_sliced.py) -- when the call is alone on the device (other calls' kernels fill the gap
                                        anyway); 0: both matrices uploaded first; 2: sliced whatever the size and the company (the tests' switch) */
+    int32_t reg_cache;              /* [M3D_REG_CACHE]      default 1: a registration RANSAC that validates many hypotheses keeps, per source point, the 32
+                                       target points nearest to its position under the incumbent pose in registers and answers a hypothesis'
+                                       nearest-neighbour queries from them wherever a certificate holds (every other target point provably
+                                       farther); the other (tile, hypothesis) pairs take the neighbour-list walk.  Same counts, sums and pose
+                                       (m3d_reg_cache.hip).  0: the walk only; 2: the cache as soon as an incumbent exists (the tests' switch) */
+    int32_t device_aliases;         /* [M3D_DEVICE_ALIASES] default 0; N > 0: device ordinals 0 .. max(N, physical devices) - 1 are valid, ordinal d living
+                                       on physical device d % physical -- each with its own lanes, streams, scratch, free lists and
+                                       resident tables, as a further physical device would have.  For executing the multi-device entry
+                                       points (devices[] forms, m3d_fit_multi, m3d_register_fragment_pairs) on a box with fewer GPUs than
+                                       the code path wants: it exercises the dealing, the per-device state and the in-process exchange,
+                                       NOT peer traffic or RCCL across devices.  m3d_device_count() then returns the logical count (<= 16) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

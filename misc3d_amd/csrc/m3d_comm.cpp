@@ -202,7 +202,7 @@ m3d_comm* m3d_comm_create_rccl(const uint8_t id[M3D_COMM_ID_BYTES], int world, i
     }
     DeviceCtx* ctx = get_ctx(device);   // (checks the ordinal, creates the library stream)
     if (!ctx) return nullptr;
-    if (hipSetDevice(device) != hipSuccess) {
+    if (hipSetDevice(ctx->device) != hipSuccess) {
         set_error("hipSetDevice failed");
         return nullptr;
     }
@@ -256,7 +256,10 @@ void m3d_comm_destroy(m3d_comm* q) {
     if (!q) return;
     if (q->transport == m3d_comm::kRccl && q->nccl) {
         RcclApi& a = rccl();
-        if (q->device >= 0) (void)hipSetDevice(q->device);
+        if (q->device >= 0) {
+            const int phys = physical_device(q->device);   // (q->device: the ordinal the caller used)
+            if (phys >= 0) (void)hipSetDevice(phys);
+        }
         if (a.handle) (void)a.CommDestroy(static_cast<ncclComm_t>(q->nccl));
     }
     q->stage.release();

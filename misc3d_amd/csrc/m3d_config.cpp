@@ -42,6 +42,9 @@ void sanitize(m3d_config& c) {
     c.first_chunk = c.first_chunk <= 0 ? 0 : (int32_t)std::min<long>(((long)c.first_chunk + 63) / 64 * 64, 1 << 20);
     if (c.reg_cells_per_radius < 1 || c.reg_cells_per_radius > 16) c.reg_cells_per_radius = 4;
     if (c.match_pipeline < 0 || c.match_pipeline > 2) c.match_pipeline = 1;
+    if (c.reg_cache < 0 || c.reg_cache > 2) c.reg_cache = 1;
+    if (c.device_aliases < 0) c.device_aliases = 0;
+    if (c.device_aliases > 16) c.device_aliases = 16;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -76,6 +79,8 @@ void load_env() {
     g_cfg.first_chunk = (int32_t)env_long("M3D_FIRST_CHUNK", 2048);
     g_cfg.reg_cells_per_radius = (int32_t)env_long("M3D_REG_K", 4);
     g_cfg.match_pipeline = (int32_t)env_long("M3D_MATCH_PIPELINE", 1);
+    g_cfg.reg_cache = (int32_t)env_long("M3D_REG_CACHE", 1);
+    g_cfg.device_aliases = (int32_t)env_long("M3D_DEVICE_ALIASES", 0);
     sanitize(g_cfg);
 }
 }  // namespace

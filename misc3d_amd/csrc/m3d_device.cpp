@@ -32,6 +32,8 @@ DevPool& dev_pool() {
     return *p;
 }
 thread_local int t_lane = 0;   // the lane the calling thread holds (CtxLock / LaneLock); 0 outside of any
+thread_local int t_dev = -1;   // ... and its LOGICAL device (free lists are per logical device: two aliases of one physical device
+                               // have streams of their own, and a list is ordered by one stream only); -1 outside of any: hipGetDevice
 inline int pool_index(int dev, int lane) { return dev * kMaxLanes + lane; }
 }  // namespace
 
@@ -39,8 +41,8 @@ bool DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return true;
     release();
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    int d = t_dev;
+    if (d < 0 && hipGetDevice(&d) != hipSuccess) d = 0;
     const int ln = (t_lane >= 0 && t_lane < kMaxLanes) ? t_lane : 0;
     if (d >= 0 && d < kPoolDevices) {
         DevPool& pool = dev_pool();
@@ -133,6 +135,34 @@ static std::map<int, DeviceCtx*> g_ctx;   // key: device * kMaxLanes + lane
 
 int lane_count() { return std::min(std::max((int)config().lanes, 1), kMaxLanes); }
 
+// Logical devices.  m3d_config.device_aliases = N > 0 makes ordinals 0 .. max(N, physical) - 1 valid, ordinal d living on
+// physical device d % physical: what a one-GPU box needs to EXECUTE the code that deals work to several devices
+// (run_on_devices, m3d_global_registration_batch, m3d_register_fragment_pairs) -- every logical device has its own lanes,
+// streams, scratch, free lists and resident-fragment table, exactly as a second physical device would.  It proves the
+// dealing, the per-device tables and the in-process exchange; it does NOT exercise peer traffic or RCCL across devices.
+static int physical_count() {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+int logical_device_count() {
+    const int phys = physical_count();
+    if (phys <= 0) return 0;
+    return std::max(phys, std::min((int)config().device_aliases, kPoolDevices));
+}
+int physical_device(int logical) {
+    const int phys = physical_count();
+    if (phys <= 0) {
+        set_error("no HIP device available (misc3d_amd has no CPU fallback)");
+        return -1;
+    }
+    if (logical < 0 || logical >= logical_device_count()) {
+        set_error("invalid HIP device ordinal " + std::to_string(logical));
+        return -1;
+    }
+    return logical % phys;
+}
+
 static DeviceCtx* create_lane_locked(int device, int lane);
 DeviceCtx* get_lane(int device, int lane) {
     std::lock_guard<std::mutex> lock(g_ctx_mu);
@@ -154,21 +184,15 @@ DeviceCtx* get_lane(int device, int lane) {
     return create_lane_locked(device, lane);
 }
 static DeviceCtx* create_lane_locked(int device, int lane) {
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
-        set_error("no HIP device available (misc3d_amd has no CPU fallback)");
-        return nullptr;
-    }
-    if (device < 0 || device >= count) {
-        set_error("invalid HIP device ordinal " + std::to_string(device));
-        return nullptr;
-    }
-    if (hipSetDevice(device) != hipSuccess) {
+    const int phys = physical_device(device);
+    if (phys < 0) return nullptr;
+    if (hipSetDevice(phys) != hipSuccess) {
         set_error("hipSetDevice failed");
         return nullptr;
     }
     DeviceCtx* c = new DeviceCtx();
-    c->device = device;
+    c->device = phys;
+    c->logical = device;
     c->lane = lane;
     // The lanes' streams and the runtime's hardware queues (tools/ubench/stream_queues.hip prints the map): a process gets FOUR queues
     // per stream priority; a new stream takes a free one and, once all four are taken, shares one -- two streams on one queue run
@@ -230,13 +254,15 @@ static DeviceCtx* find_lane(int device, int lane) {   // an existing lane, or nu
 static std::atomic<int> g_lanes_held{0};
 int lanes_held() { return g_lanes_held.load(std::memory_order_relaxed); }
 
-CtxLock::CtxLock(DeviceCtx* c) : ctx_(c), prev_lane_(t_lane) {
+CtxLock::CtxLock(DeviceCtx* c) : ctx_(c), prev_lane_(t_lane), prev_dev_(t_dev) {
     ctx_->mu.lock();
     g_lanes_held.fetch_add(1, std::memory_order_relaxed);
     t_lane = ctx_->lane;
+    t_dev = ctx_->logical;
 }
 CtxLock::~CtxLock() {
     t_lane = prev_lane_;
+    t_dev = prev_dev_;
     g_lanes_held.fetch_sub(1, std::memory_order_relaxed);
     ctx_->mu.unlock();
 }
@@ -258,7 +284,7 @@ std::atomic<int> g_thread_arrivals{0};
 thread_local int t_home_lane = -1;   // dealt on the thread's first LaneLock
 }  // namespace
 
-LaneLock::LaneLock(int device, int prefer) : prev_lane_(t_lane) {
+LaneLock::LaneLock(int device, int prefer) : prev_lane_(t_lane), prev_dev_(t_dev) {
     const int lanes = lane_count();
     if (prefer < 0 && t_home_lane < 0) t_home_lane = g_thread_arrivals.fetch_add(1, std::memory_order_relaxed);
     const int home = (prefer >= 0 ? prefer : t_home_lane) % lanes;
@@ -279,10 +305,12 @@ LaneLock::LaneLock(int device, int prefer) : prev_lane_(t_lane) {
     }
     g_lanes_held.fetch_add(1, std::memory_order_relaxed);
     t_lane = ctx->lane;
+    t_dev = ctx->logical;
 }
 LaneLock::~LaneLock() {
     if (!ctx) return;
     t_lane = prev_lane_;
+    t_dev = prev_dev_;
     g_lanes_held.fetch_sub(1, std::memory_order_relaxed);
     ctx->mu.unlock();
 }
@@ -363,11 +391,7 @@ extern "C" {
 
 const char* m3d_last_error(void) { return g_last_error.c_str(); }
 const char* m3d_version(void) { return "misc3d_amd 0.1 (gfx950)"; }
-int m3d_device_count(void) {
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
-    return count;
-}
+int m3d_device_count(void) { return logical_device_count(); }
 
 m3d_cloud* m3d_cloud_create(const double* xyz, const double* normals, size_t n, int device) {
     return m3d_cloud_create_impl(xyz, normals, n, device, /*with_sorted_copy=*/1);

@@ -79,7 +79,9 @@ struct ChunkSlot {
 // /root/reference/src/pipeline.cpp:428-439, one std::thread per fragment pair).  Resident objects (m3d_cloud, m3d_reg)
 // stay on the lane they were created on.
 struct DeviceCtx {
-    int device = -1;
+    int device = -1;    // PHYSICAL HIP ordinal (hipSetDevice)
+    int logical = -1;   // the ordinal the caller used: the same unless m3d_config.device_aliases maps several logical devices to one
+                        // physical one -- each with lanes, streams, scratch, free lists and resident tables of its own
     int lane = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // RefineModel: the inlier list goes to the host while the GeneralFit sums run
@@ -175,6 +177,8 @@ int information_matrix_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst, cons
 void reg_session_release(m3d_reg* q);   // ... of a session handed out through session_out (the caller holds the lane)
 
 void dev_pool_trim(int device);
+int logical_device_count();           // what m3d_device_count returns: max(physical devices, m3d_config.device_aliases)
+int physical_device(int logical);     // logical ordinal -> HIP ordinal (logical % physical devices under aliases); -1 + last error if invalid
 DeviceCtx* get_ctx(int device);  // lane 0 of the device; nullptr + last error when the device is unusable
 DeviceCtx* get_lane(int device, int lane);
 hipStream_t copy_stream_of(DeviceCtx* ctx);   // the lane's copy / pre streams, created by the first call that needs them
@@ -194,7 +198,7 @@ public:
 
 private:
     DeviceCtx* ctx_;
-    int prev_lane_;
+    int prev_lane_, prev_dev_;
 };
 // A lane of `device` for one call: the calling thread's own lane when it is free (threads are dealt lanes in the order
 // they first arrive, so a single-threaded program lives on lane 0 and its scratch stays warm), else the lowest free one,
@@ -209,7 +213,7 @@ public:
     DeviceCtx* ctx = nullptr;
 
 private:
-    int prev_lane_ = 0;
+    int prev_lane_ = 0, prev_dev_ = -1;
 };
 
 }  // namespace m3d

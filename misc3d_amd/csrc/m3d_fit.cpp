@@ -1219,7 +1219,7 @@ int m3d_cloud_fit_sharded(m3d_cloud* c, m3d_comm* comm, int kind, double thresho
     if (!c || !params || kind < 0 || kind > 2) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
     const int vr = validate_fit_args(kind, c->n, c->has_normals, probability);
     if (vr != M3D_OK) return vr;
-    if (comm->transport == m3d_comm::kRccl && comm->device != c->ctx->device)
+    if (comm->transport == m3d_comm::kRccl && comm->device != c->ctx->logical)
         return fail(M3D_ERR_INVALID_ARG, "the cloud and the RCCL communicator live on different devices");
     CtxLock lock(c->ctx);
     HIPCHK(hipSetDevice(c->ctx->device));

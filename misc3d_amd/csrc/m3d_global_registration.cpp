@@ -310,7 +310,10 @@ int m3d_register_fragment_pairs(const m3d_fragment_view* frags, size_t n_frags, 
     worker(0, 0);
     for (auto& t : th) t.join();
     for (int d = 0; d < n_dev; ++d) {   // every lane of the call has drained (each pair ends with its stream idle)
-        (void)hipSetDevice(devices[d]);
+        {
+            const int phys = physical_device(devices[d]);
+            if (phys >= 0) (void)hipSetDevice(phys);
+        }
         for (size_t i = 0; i < n_frags; ++i) {
             ResidentFragment& r = resident[(size_t)d][i];
             if (r.cloud) {

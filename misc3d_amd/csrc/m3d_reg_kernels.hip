@@ -848,7 +848,8 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
                                                        uint32_t* __restrict__ partial_cnt,
                                                        double* __restrict__ partial_sum, uint32_t res_mask,
                                                        uint32_t n_tiles_total, const uint8_t* __restrict__ keep,
-                                                       uint32_t n_tiles_launch, uint32_t n_split) {
+                                                       uint32_t n_tiles_launch, uint32_t n_split,
+                                                       const uint8_t* __restrict__ redo /* [tile][s_pad] or null: only the flagged pairs (m3d_reg_cache.hip) */) {
     __shared__ uint32_t red[4][64];
     __shared__ double reds[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -883,7 +884,10 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
         double acc_sum = 0.0;
         // the 64 keep flags of the block in one load (a byte load + wait per hypothesis stalled the wave for a memory
         // latency each), and the next hypothesis' transformation requested while this one is evaluated
-        const unsigned long long keep_mask = keep ? __ballot(keep[sb + (uint32_t)lane] != 0) : ~0ull;
+        unsigned long long keep_mask = keep ? __ballot(keep[sb + (uint32_t)lane] != 0) : ~0ull;
+        const unsigned long long redo_mask = redo ? __ballot(redo[(size_t)tile * s_pad + sb + (uint32_t)lane] != 0) : ~0ull;
+        keep_mask &= redo_mask;
+        if (redo && keep_mask == 0ull) continue;   // (wave-uniform, the same in all four waves: no barrier is skipped by one of them alone)
         double tn[12];
         {
             const double* __restrict__ T = Ts + (size_t)(sb + ss0) * kRegTStride;
@@ -921,7 +925,7 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
         red[wave][lane] = acc;
         reds[wave][lane] = acc_sum;
         __syncthreads();
-        if (wave == 0 && (uint32_t)lane >= ss0 && (uint32_t)lane < ss1) {
+        if (wave == 0 && (uint32_t)lane >= ss0 && (uint32_t)lane < ss1 && ((redo_mask >> lane) & 1ull)) {
             partial_cnt[(size_t)tile * s_pad + sb + lane] =
                 (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
             partial_sum[(size_t)tile * s_pad + sb + lane] =
@@ -1000,12 +1004,16 @@ __global__ __launch_bounds__(64 * kFoldSlices) void reg_keep_k(const uint32_t* _
 uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_pad, const GridDesc& g,
                              const uint32_t* cell_start, const double* qx, const double* qy, const double* qz,
                              uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
-                             uint32_t n_points, uint8_t* keep, hipStream_t s, double best_sum2, uint32_t n_hyp) {
+                             uint32_t n_points, uint8_t* keep, hipStream_t s, double best_sum2, uint32_t n_hyp,
+                             const RegCache* cache) {
     if (!s_pad || !src.n_pad) return 0;
     const uint32_t groups = s_pad / 64;
     const uint32_t n_tiles = src.n_pad / kRegTile;
     const uint32_t tile_points = (uint32_t)kRegTile;
-    auto launch = [&](uint32_t res_mask, const uint8_t* kp) {
+    // walk = false: the candidate cache alone (m3d_reg_cache.hip) -- exact records where every query of the pair holds a
+    // certificate, an upper bound of the count and a lower bound of the sum (and a flag in cache->redo) where not; walk = true
+    // without a cache: reg_validate_k on every pair; with one: on the flagged pairs only (`resolve`)
+    auto launch = [&](uint32_t res_mask, const uint8_t* kp, bool resolve) {
         // (upper bound of the tiles of the launch; the kernel drops indices past the last tile)
         const uint32_t tiles = (n_tiles + 7) / 8 * (uint32_t)__builtin_popcount(res_mask);
         // enough blocks to fill the chip several times over (the pruning phases launch an eighth of the tiles: 16 384 blocks
@@ -1016,24 +1024,34 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         const uint32_t gps = (groups + splits - 1) / splits;
         uint32_t nsplit = (groups + gps - 1) / gps;
         uint32_t per_split = gps * 64;
-        if (groups == 1 && n_hyp && n_hyp <= 32) {   // a handful of hypotheses: cut the one group (see the kernel)
+        if (groups == 1 && n_hyp && n_hyp <= 32 && !cache) {   // a handful of hypotheses: cut the one group (see the kernel; the cache works on whole groups)
             per_split = std::max<uint32_t>(1, n_hyp / 8);
             nsplit = (n_hyp + per_split - 1) / per_split;
         }
         const uint32_t slots = (tiles + 7) / 8;
+        if (cache && !resolve) {
+            launch_reg_validate_cached(src, Ts, s_pad, per_split, nsplit, slots, g.r2, *cache, partial_cnt, partial_sum, res_mask,
+                                       n_tiles, kp, tiles, cache->redo, s);
+            return;
+        }
+        const uint8_t* redo = cache ? cache->redo : nullptr;
         if (g.nl32 && g.nl_rec && g.nl_sorted && g.nl_start && g.nl_hdr)
             reg_validate_k<true><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, per_split, g, cell_start, qx, qy,
-                                                                   qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit);
+                                                                   qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit, redo);
         else
             reg_validate_k<false><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, per_split, g, cell_start, qx, qy,
-                                                                    qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit);
+                                                                    qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit, redo);
     };
     if (best_cnt == 0 || n_tiles < 16) {
-        launch(0xFFu, nullptr);
+        launch(0xFFu, nullptr, false);
+        if (cache) launch(0xFFu, nullptr, true);   // nothing to prune against: every flagged pair is walked
     } else {
         // four phases: an eighth of the tiles, another eighth, a quarter, the remaining half; the hypotheses still in
         // the race are re-assessed in between (reg_keep_k)
-        static const uint32_t kPhase[4] = {0x01u, 0x10u, 0x44u, 0xAAu};
+        static const uint32_t kPhase4[4] = {0x01u, 0x10u, 0x44u, 0xAAu};
+        static const uint32_t kPhase8[8] = {0x01u, 0x10u, 0x04u, 0x40u, 0x02u, 0x20u, 0x08u, 0x80u};   // (experiment: M3D_DBG_PHASES=8)
+        static const int n_phases = std::getenv("M3D_DBG_PHASES") ? std::atoi(std::getenv("M3D_DBG_PHASES")) : 4;
+        const uint32_t* kPhase = n_phases == 8 ? kPhase8 : kPhase4;
         // real source points on the tiles of a residue class (the real points are the first n_points slots)
         auto points_on = [&](uint32_t mask) {
             uint64_t n = 0;
@@ -1046,12 +1064,26 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         };
         const double limit = best_sum2 * (1.0 + 1e-6);
         uint32_t done = 0;
-        for (int ph = 0; ph < 4; ++ph) {
-            launch(kPhase[ph], ph == 0 ? nullptr : keep);
+        const int last = (n_phases == 8 ? 8 : 4) - 1;
+        for (int ph = 0; ph <= last; ++ph) {
+            launch(kPhase[ph], ph == 0 ? nullptr : keep, false);
             done |= kPhase[ph];
-            if (ph < 3)
-                reg_keep_k<<<s_pad / 64, 64 * kFoldSlices, 0, s>>>(partial_cnt, partial_sum, n_tiles, done, s_pad,
-                                                               points_on(0xFFu & ~done), true, best_cnt, limit, keep, ph == 0 ? 1 : 0);
+            const uint32_t rem = points_on(0xFFu & ~done);
+            auto assess = [&](int first) {
+                reg_keep_k<<<s_pad / 64, 64 * kFoldSlices, 0, s>>>(partial_cnt, partial_sum, n_tiles, done, s_pad, rem, true, best_cnt,
+                                                               limit, keep, first);
+            };
+            if (cache) {
+                // The records of a flagged pair are BOUNDS (count from above, sum from below): reg_keep_k's rule is as exact on them
+                // as on the values themselves -- what it drops can neither beat nor tie the incumbent, and is never walked.  The
+                // flagged pairs of the hypotheses still standing are walked now (their bounds may be what keeps them standing)
+                // and the hypotheses re-assessed on the values.
+                assess(ph == 0 ? 1 : 0);
+                launch(kPhase[ph], keep, true);
+                if (ph < last) assess(0);
+            } else if (ph < last) {
+                assess(ph == 0 ? 1 : 0);
+            }
         }
     }
     reduce_sums_k<<<s_pad / 64, 64 * kFoldSlices, 0, s>>>(partial_sum, n_tiles, s_pad, sums);

@@ -48,6 +48,26 @@ struct GridDesc {
 
 
 
+// The candidate cache of the validation (m3d_reg_cache.hip): per sorted source point, under a reference pose, its position
+// xa, up to kRegCacheK nearest target points (fp32 offsets from xa in pairs, fp64 coordinates) and a radius R >= 0 that
+// every unlisted target point keeps from xa (R < 0: the slot holds no query).  Layouts: cx / cy / cz [tile][pair][256],
+// c64 [tile][slot][256], xa / ya / za / R [n_pad]; stats[0 / 1]: (tile, hypothesis) pairs answered from the cache / handed to the walk.
+constexpr int kRegCacheK = 32;
+struct RegCache {
+    float2 *cx = nullptr, *cy = nullptr, *cz = nullptr;
+    double4* c64 = nullptr;
+    double *xa = nullptr, *ya = nullptr, *za = nullptr;
+    float* R = nullptr;
+    unsigned long long* stats = nullptr;
+    uint8_t* redo = nullptr;   // [n_tiles][s_pad] scratch of a launch_reg_validate call: pairs the cache could not certify
+};
+void launch_reg_cache_build(const CloudView& src_sorted, const double* T_dev, const GridDesc& g, const uint32_t* cell_start,
+                            const double* qx, const double* qy, const double* qz, const RegCache& c, hipStream_t s);
+void launch_reg_validate_cached(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t per_split, uint32_t nsplit,
+                                uint32_t slots, double r2, const RegCache& c, uint32_t* partial_cnt, double* partial_sum,
+                                uint32_t res_mask, uint32_t n_tiles, const uint8_t* keep, uint32_t tiles, uint8_t* redo,
+                                hipStream_t s);
+
 void launch_kabsch3_check(const CloudView& src, const CloudView& dst, const uint32_t* corr_src,
                           const uint32_t* corr_dst, const uint32_t* triples, uint32_t h_count,
                           double edge_thr, double dist_thr, double* T12, uint8_t* pass, hipStream_t s);
@@ -87,7 +107,8 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
                              uint32_t* partial_cnt, double* partial_sum, double* sums, uint32_t best_cnt,
                              uint32_t n_points, uint8_t* keep, hipStream_t s,
                              double best_sum2 = 0.0 /* order-free sum of squared distances of the hypothesis behind best_cnt */,
-                             uint32_t n_hyp = 0 /* real hypotheses among the s_pad records (0: unknown); a handful is spread over more workgroups */);
+                             uint32_t n_hyp = 0 /* real hypotheses among the s_pad records (0: unknown); a handful is spread over more workgroups */,
+                             const RegCache* cache = nullptr /* built for a pose near the hypotheses': the pairs it certifies skip the walk (same results) */);
 void launch_reg_min_d2(const CloudView& src, const double* T, const GridDesc& g, const uint32_t* cell_start,
                        const double* qx, const double* qy, const double* qz, double* best, hipStream_t s);
 void launch_compact_vals(const double* v, uint32_t n, double limit, uint32_t* block_counts, uint32_t* total,

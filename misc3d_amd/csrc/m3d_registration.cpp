@@ -68,13 +68,14 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, nl32_fallbacks, cell_orig, tile_sph;
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, nl32_fallbacks, cell_orig, tile_sph,
+        cc_x, cc_y, cc_z, cc_64, cc_xa, cc_ya, cc_za, cc_R, cc_stats, cc_redo;   // the validation's candidate cache (m3d_reg_cache.hip)
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
                           &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &nl_hdr, &nl32, &nl_rec, &nl32_start, &nl32_fallbacks, &cell_orig,
-                          &tile_sph})
+                          &tile_sph, &cc_x, &cc_y, &cc_z, &cc_64, &cc_xa, &cc_ya, &cc_za, &cc_R, &cc_stats, &cc_redo})
             b->release();
     }
 };
@@ -405,6 +406,13 @@ struct m3d_reg {
     size_t chunk = 32;
     size_t validated_total = 0, n_dst_points = 0;
     bool nl_built = false;
+    // the candidate cache (m3d_reg_cache.hip): built for the incumbent of some earlier chunk, rebuilt when the incumbent has moved on
+    RegCache cache;
+    bool cache_valid = false;
+    int64_t cache_ref_index = -1;
+    uint32_t cache_ref_cnt = 0, cache_builds = 0;
+    double cache_ref_sum2 = 0.0;
+    int ensure_cache(uint32_t s_pad);
     int itr = 0;
     int n_exec = 0;          // iterations of the chunk in flight
     bool finished = false;
@@ -442,6 +450,7 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
         const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, keep_orig, &g, k0, /*with_nl=*/false,
                                               cdst->bb_known ? cdst->bb : nullptr);
         if (rc_grid != M3D_OK) return rc_grid;
+        if (std::getenv("M3D_DBG_NO_P2")) g.h2_in = INFINITY;   // (timing experiment only: the search never leaves the 3x3x3 block -- WRONG results)
         R.g = g;
         n_dst_points = n_dst;
     }
@@ -600,6 +609,47 @@ int m3d_reg::begin_chunk(size_t* n_survivors) {
     return M3D_OK;
 }
 
+// The candidate cache for the incumbent's pose (best_T_dev), (re)built when there is none yet or the incumbent has improved
+// by more than a little since the last build (the hypotheses worth a full evaluation are near-copies of the best pose; an
+// early incumbent 30 % worse in rmse certifies almost as many pairs as the final one: profiles/r06_reg_cache.txt).
+int m3d_reg::ensure_cache(uint32_t s_pad) {
+    const size_t np = src_sorted.n_pad, nt = np / kRegTile;
+    const bool moved = cache_valid && best_index != cache_ref_index &&
+                       ((double)best_cnt > 1.02 * (double)cache_ref_cnt || best_sum2 < 0.7 * cache_ref_sum2);
+    RESERVE(S.cc_redo, nt * (size_t)s_pad);
+    cache.redo = S.cc_redo.as<uint8_t>();
+    if (cache_valid && !moved) return M3D_OK;
+    RESERVE(S.cc_x, sizeof(float2) * nt * (kRegCacheK / 2) * 256);
+    RESERVE(S.cc_y, sizeof(float2) * nt * (kRegCacheK / 2) * 256);
+    RESERVE(S.cc_z, sizeof(float2) * nt * (kRegCacheK / 2) * 256);
+    RESERVE(S.cc_64, sizeof(double4) * nt * kRegCacheK * 256);
+    RESERVE(S.cc_xa, sizeof(double) * np);
+    RESERVE(S.cc_ya, sizeof(double) * np);
+    RESERVE(S.cc_za, sizeof(double) * np);
+    RESERVE(S.cc_R, sizeof(float) * np);
+    if (!S.cc_stats.p) {
+        RESERVE(S.cc_stats, sizeof(unsigned long long) * 2);
+        HIPCHK(hipMemsetAsync(S.cc_stats.p, 0, sizeof(unsigned long long) * 2, ctx->stream));
+    }
+    cache.cx = S.cc_x.as<float2>();
+    cache.cy = S.cc_y.as<float2>();
+    cache.cz = S.cc_z.as<float2>();
+    cache.c64 = S.cc_64.as<double4>();
+    cache.xa = S.cc_xa.as<double>();
+    cache.ya = S.cc_ya.as<double>();
+    cache.za = S.cc_za.as<double>();
+    cache.R = S.cc_R.as<float>();
+    cache.stats = S.cc_stats.as<unsigned long long>();
+    launch_reg_cache_build(src_sorted, best_T_dev, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
+                           S.qz.as<double>(), cache, ctx->stream);
+    cache_valid = true;
+    cache_ref_index = best_index;
+    cache_ref_cnt = best_cnt;
+    cache_ref_sum2 = best_sum2;
+    cache_builds++;
+    return M3D_OK;
+}
+
 // (count, sum of squared nearest distances) of survivors [s_begin, s_end) of the chunk in flight;
 // s_begin must be a multiple of 64 (the kernel works on groups of 64 hypotheses)
 int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double* sums_out) {
@@ -618,11 +668,25 @@ int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double
         RESERVE(S.counts, sizeof(uint32_t) * s_pad);
 
         RESERVE(S.keep, s_pad);
+        // the candidate cache: once the call has turned out long (the neighbour lists are built), has an incumbent, and the shard
+        // is large enough to fill whole 64-hypothesis groups per workgroup (m3d_config.reg_cache: 0 off, 1 auto, 2 whenever an
+        // incumbent exists -- the tests' switch)
+        const int cc = config().reg_cache;
+        // (a cell edge within [1e-12, 1e12]: the cache's fp32 squares neither underflow below its rounding bound nor reach the
+        //  empty slots' 1e18 -- m3d_reg_cache.hip)
+        const double h_cell = 1.0 / g.inv_h;
+        const bool use_cache = best_index >= 0 && src_sorted.n_pad <= ((size_t)4 << 20) && h_cell > 1e-12 && h_cell < 1e12 &&
+                               (cc == 2 || (cc == 1 && nl_built && ns >= 192));
+        if (use_cache) {
+            const int rcache = ensure_cache(s_pad);
+            if (rcache != M3D_OK) return rcache;
+        }
         // bound-and-prune against the best of EARLIER chunks (m3d_config.reg_prune = 0 switches it off)
         const uint32_t rows = launch_reg_validate(src_sorted, Ts, s_pad, g, S.cell_start.as<uint32_t>(),
                             S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(),
                             S.partial.as<uint32_t>(), S.partial_sum.as<double>(), S.sum2.as<double>(),
-                            reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream, best_sum2, ns);
+                            reg_prune ? best_cnt : 0u, (uint32_t)n_src, S.keep.as<uint8_t>(), ctx->stream, best_sum2, ns,
+                            use_cache ? &cache : nullptr);
         HIPCHK(hipMemsetAsync(S.counts.p, 0, sizeof(uint32_t) * s_pad, ctx->stream));
         launch_reduce_partials(S.partial.as<uint32_t>(), rows, s_pad, S.counts.as<uint32_t>(),
                                ctx->stream);
@@ -752,6 +816,12 @@ int m3d_reg::finish(double* T_out, m3d_reg_stats* stats) {
         stats->ties = ties;
         stats->exact_rmse_evals = exact_evals;
         stats->lds_wave_hypotheses = stats->global_wave_hypotheses = 0;
+        if (cache.stats) {   // (tile, hypothesis) pairs the candidate cache answered / handed to the list walk
+            unsigned long long cs2[2] = {0, 0};
+            HIPCHK(hipMemcpy(cs2, cache.stats, sizeof(cs2), hipMemcpyDeviceToHost));
+            stats->lds_wave_hypotheses = cs2[0];
+            stats->global_wave_hypotheses = cs2[1];
+        }
         stats->nn_fp32_screen = g.nl32 ? 1 : 0;
         stats->nn_screen_fallbacks = 0;
         if (g.nl32_fallbacks) {

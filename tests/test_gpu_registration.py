@@ -187,6 +187,119 @@ def test_registration_nn_screen_adversarial(capi, orc, case):
         assert np.array_equal(T1.view(np.uint64), o.T.view(np.uint64))
 
 
+def _all_chunk_records(capi, src, dst, cs, cd, **kw):
+    counts, sums = [], []
+    with capi.RegSession(src, dst, cs, cd, **kw) as sess:
+        while (m := sess.begin_chunk()) is not None:
+            c2, s2 = sess.validate(0, m)
+            counts.append(c2.copy())
+            sums.append(s2.copy())
+            sess.replay(c2, s2)
+        T, st = sess.finish()
+    return np.concatenate(counts), np.concatenate(sums), T, st
+
+
+@pytest.mark.parametrize("case", ["overlap", "partial", "lattice", "dups", "near_ties", "far_offset", "tiny_scale", "dense", "sparse_target"])
+def test_registration_candidate_cache_is_exact(capi, orc, case):
+    """The validation's candidate cache (m3d_config.reg_cache, m3d_reg_cache.hip: per source point the 32 target points nearest
+    to its position under the incumbent pose, held in registers, with a certificate that every other target point is farther)
+    must leave every hypothesis' count and sum what the neighbour-list walk makes them: forced on from the first incumbent
+    (reg_cache = 2) against off (0), every chunk's records, on ordinary data (where it must answer most pairs itself), partial
+    overlap (source points with nothing near: the no-match certificate), exact ties and duplicates (the identity certificate
+    must hand them over), coordinates beyond fp32's reach, scales the fp32 squares cannot carry (the cache must stand down),
+    lists of hundreds of entries, and a target far sparser than the source."""
+    rng = np.random.default_rng(31)
+    thr, scale, shift, partner = 0.03, 1.0, np.zeros(3), None
+    n_corr, edge = 500, 0.5
+    if case in ("overlap", "partial", "sparse_target"):
+        n = 12_000
+        d = synth.registration_pair_c4(n, seed=23, dim=8, true_fraction=0.4, sigma=0.001)
+        src, dst = d["src"].copy(), d["dst"]
+        inv = np.empty(n, dtype=np.int64)
+        inv[d["perm"]] = np.arange(n)
+        if case == "partial":
+            src[src[:, 0] > np.quantile(src[:, 0], 0.6)] += 50.0      # 40 % of the source has no counterpart at all
+            src[::7] += 0.033                                          # ... and a seventh sits just outside the radius
+        cs = rng.integers(0, n, n_corr)
+        cd = np.where(rng.random(n_corr) < 0.5, inv[cs], rng.integers(0, n, n_corr))
+        if case == "sparse_target":
+            keep = np.sort(rng.choice(n, n // 20, replace=False))      # a twentieth of the target: fewer than 32 points within two cells
+            remap = -np.ones(n, dtype=np.int64)
+            remap[keep] = np.arange(len(keep))
+            dst = dst[keep]
+            ok = remap[cd] >= 0
+            cs, cd = cs[ok], remap[cd[ok]]
+            edge = 0.9
+        Tm = None
+    elif case == "lattice":
+        g = np.arange(-12, 12) * 0.005
+        dst = np.stack(np.meshgrid(g, g, g[:6], indexing="ij"), -1).reshape(-1, 3)
+        partner = rng.choice(len(dst), 2500, replace=False)
+        src = dst[partner] + rng.choice([0.0, 0.0025], size=(2500, 3))
+    elif case == "dups":
+        base = rng.uniform(-0.2, 0.2, (1500, 3)) * [1, 1, 0.02]
+        dst = np.concatenate([base, base, base[:500]])
+        src = base[:1200] + rng.normal(0, 1e-3, (1200, 3))
+    elif case == "near_ties":
+        a = rng.uniform(-0.2, 0.2, (1500, 3)) * [1, 1, 0.05]
+        dd = rng.normal(size=(1500, 3))
+        dd *= 0.004 / np.linalg.norm(dd, axis=1)[:, None]
+        dst = np.concatenate([a - dd, a + dd])
+        src = a + dd * (10.0 ** rng.uniform(-13, -9, (1500, 1))) * rng.choice([-1, 1], (1500, 1))
+    elif case == "far_offset":
+        dst = rng.uniform(-0.2, 0.2, (3000, 3)) * [1, 1, 0.02]
+        src = dst[:2000] + rng.normal(0, 1e-3, (2000, 3))
+        shift = np.array([3.0e5, -2.0e5, 1.0e5])
+    elif case == "tiny_scale":
+        dst = rng.uniform(-0.2, 0.2, (3000, 3)) * [1, 1, 0.02]
+        src = dst[:2000] + rng.normal(0, 1e-3, (2000, 3))
+        scale = 1e-18
+    else:                       # dense: ~100 points per cell
+        dst = rng.uniform(-0.05, 0.05, (60000, 3)) * [1, 1, 0.01]
+        src = dst[:3000] + rng.normal(0, 3e-4, (3000, 3))
+    if case not in ("overlap", "partial", "sparse_target"):
+        Tm = synth.rigid_transform(25.0, (0.2, -0.3, 1.0), (0.05, -0.02, 0.01))
+        src = src @ np.linalg.inv(Tm)[:3, :3].T + np.linalg.inv(Tm)[:3, 3]     # dst = Tm(src)
+        src, dst, thr = (src + shift) * scale, (dst + shift) * scale, thr * scale
+        cs = rng.integers(0, len(src), 400)
+        cd = cs.copy() if partner is None else partner[cs]
+        cd[::3] = rng.integers(0, len(dst), len(cd[::3]))
+    kw = dict(threshold=thr, max_iter=2500, edge_length_threshold=edge, confidence=1.0, seed=5)
+    # Every chunk's records with the pruning phases off -- a hypothesis the phases drop reports the sum over the tiles it saw, and
+    # which points share a tile varies from session to session (the source's counting sort places the points of a cell in the
+    # order their atomics land) -- and the call's results with them on.
+    res = {}
+    for prune in (0, 1):
+        for cc in (2, 0):
+            old = capi.set_config(reg_cache=cc, reg_prune=prune)
+            try:
+                res[prune, cc] = _all_chunk_records(capi, src, dst, cs, cd, **kw)
+            finally:
+                capi.restore_config(old)
+    c1, s1, T1, st1 = res[0, 2]
+    c0, s0, T0, st0 = res[0, 0]
+    assert len(c1) >= 20 and c1.max() > {"partial": 0.3, "sparse_target": 0.1}.get(case, 0.5) * len(src)
+    assert np.array_equal(c1, c0) and np.allclose(s1, s0, rtol=1e-12, atol=0.0)
+    for prune in (0, 1):
+        _, _, Ta, sta = res[prune, 2]
+        _, _, Tb, stb = res[prune, 0]
+        assert np.array_equal(Ta, Tb) and np.array_equal(Ta, T1)
+        for k in ("best_index", "iterations", "validations", "est_k", "fitness", "inlier_rmse"):
+            assert sta[k] == stb[k] == st1[k], (prune, k)
+    assert st0["lds_wave_hypotheses"] == 0 and st0["global_wave_hypotheses"] == 0
+    answered, walked = st1["lds_wave_hypotheses"], st1["global_wave_hypotheses"]
+    if case == "tiny_scale":
+        assert answered == 0 and walked == 0           # the cache stood down (cell edge 1e-20)
+    else:
+        assert answered + walked > 0
+        if case in ("overlap", "partial", "far_offset", "sparse_target"):
+            assert answered > 0.3 * (answered + walked), (answered, walked)
+    if case not in ("tiny_scale", "dense"):
+        o = orc.registration_ransac(src, dst, cs, cd, thr=thr, max_iter=2500, edge_thr=edge, confidence=1.0, seed=5)
+        assert st1["best_index"] == o.best_index and st1["validations"] == o.validations and st1["fitness"] == o.fitness
+        assert np.array_equal(T1.view(np.uint64), o.T.view(np.uint64))
+
+
 def test_registration_nn_screen_fallback_rate(capi):
     """On ordinary data the screen decides practically every query itself."""
     d, cs, cd = _problem(n=20000, seed=4, m=1200, true_fraction=0.5)
