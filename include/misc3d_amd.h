@@ -212,9 +212,11 @@ typedef struct m3d_reg_stats {
     uint64_t ties;             /* equal-fitness comparisons decided during the replay (hypotheses the validation dropped early
                                 * on their partial count or sum never get that far) */
     uint64_t exact_rmse_evals; /* of which needed the serial-order sum of squared distances */
-    uint64_t lds_wave_hypotheses;    /* round 6: (256-point source tile, hypothesis) pairs whose queries the validation's candidate cache answered
-                                      * from registers (m3d_config.reg_cache; the field's name is round 2's, the slot keeps the layout) */
-    uint64_t global_wave_hypotheses; /* round 6: pairs the cache could not certify and the neighbour-list walk evaluated after it (0 / 0: no cache) */
+    uint64_t lds_wave_hypotheses;    /* round 6: (256-point source tile, hypothesis) pairs whose record the validation's candidate cache made EXACT -- every
+                                      * query answered from registers under a certificate (m3d_config.reg_cache; the field's name is round 2's, the
+                                      * slot keeps the layout) */
+    uint64_t global_wave_hypotheses; /* round 6: pairs it left as BOUNDS (count from above, sum from below); the neighbour-list walk evaluated those of
+                                      * them whose hypothesis the pruning could not drop on the bounds (0 / 0: the cache did not run) */
     uint64_t nn_fp32_screen;         /* 1: the validation's neighbour search ran behind the fp32 screen (m3d_config.reg_fp32_screen and a
                                       * grid the screen admits: cell edge and offsets within fp32's reach) */
     uint64_t nn_screen_fallbacks;    /* queries whose runner-up lay within the rounding bound of the winner: decided by the fp64 walk */

@@ -825,12 +825,12 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
     return nearest_phase2(g, cell_start, qx, qy, qz, ix, iy, iz, px, py, pz, best);
 }
 
-// the tile_local-th tile whose index mod 8 is in res_mask (tiles in ascending order)
+// the tile_local-th tile whose index mod 32 is in res_mask (tiles in ascending order)
 __device__ __forceinline__ uint32_t phase_tile(uint32_t tile_local, uint32_t res_mask) {
     const uint32_t k = (uint32_t)__popc(res_mask);
     uint32_t m = res_mask;
     for (uint32_t j = tile_local % k; j > 0; --j) m &= m - 1u;   // drop the j lowest set bits
-    return (tile_local / k) * 8u + (uint32_t)(__ffs(m) - 1);
+    return (tile_local / k) * 32u + (uint32_t)(__ffs(m) - 1);
 }
 
 // Same decomposition as score_k: source points stay in VGPRs (kRegP rows of 64 per wave), the
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
     const uint32_t xcd = blockIdx.x % 8u, jq = blockIdx.x / 8u;
     const uint32_t tile_local = (jq / n_split) * 8u + xcd, split = jq % n_split;
     if (tile_local >= n_tiles_launch) return;   // whole block (uniform)
-    // a launch covers the tiles whose index mod 8 is in res_mask (the pruning phases: launch_reg_validate)
+    // a launch covers the tiles whose index mod 32 is in res_mask (the pruning phases: launch_reg_validate)
     const uint32_t tile = phase_tile(tile_local, res_mask);
     if (tile >= n_tiles_total) return;
     const size_t base = (size_t)tile * kRegTile + (size_t)wave * (64 * kRegP) + lane;
@@ -936,6 +936,69 @@ __global__ __launch_bounds__(256) void reg_validate_k(const double* __restrict__
 }
 
 
+// The walk on a LIST of (tile, hypothesis) pairs -- the pairs the candidate cache has flagged, of the hypotheses still in the race
+// (m3d_reg_cache.hip).  reg_validate_k's own arithmetic and record (same per-wave count and sum, same fold over the four waves),
+// but one pair per workgroup trip instead of one (tile, 64 hypotheses) block walking its few flagged hypotheses one after the
+// other: the flagged pairs are the far poses' -- the dearest walks there are -- and a handful per block.
+__global__ __launch_bounds__(256) void redo_pairs_k(const uint8_t* __restrict__ redo, const uint8_t* __restrict__ keep, uint32_t s_pad,
+                                                    uint32_t res_mask, uint32_t n_tiles_total, uint32_t n_tiles_launch,
+                                                    uint32_t* __restrict__ pairs, uint32_t* __restrict__ n_pairs) {
+    const uint32_t tile_local = blockIdx.y;
+    if (tile_local >= n_tiles_launch) return;
+    const uint32_t tile = phase_tile(tile_local, res_mask);
+    if (tile >= n_tiles_total) return;
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    const bool take = s < s_pad && (!keep || keep[s]) && redo[(size_t)tile * s_pad + s];
+    const unsigned long long m = __ballot(take);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(n_pairs, (uint32_t)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (take) pairs[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = tile * s_pad + s;
+}
+template <bool SCREEN>
+__global__ __launch_bounds__(256) void reg_validate_pairs_k(const double* __restrict__ sx, const double* __restrict__ sy,
+                                                             const double* __restrict__ sz, const double* __restrict__ Ts,
+                                                             uint32_t s_pad, GridDesc g, const uint32_t* __restrict__ cell_start,
+                                                             const double* __restrict__ qx, const double* __restrict__ qy,
+                                                             const double* __restrict__ qz, uint32_t* __restrict__ partial_cnt,
+                                                             double* __restrict__ partial_sum, const uint32_t* __restrict__ pairs,
+                                                             const uint32_t* __restrict__ n_pairs) {
+    __shared__ uint32_t red[4];
+    __shared__ double reds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = *n_pairs;
+    for (uint32_t p = blockIdx.x; p < n; p += gridDim.x) {
+        const uint32_t e = pairs[p], tile = e / s_pad, s = e % s_pad;
+        const size_t base = (size_t)tile * kRegTile + (size_t)wave * 64 + lane;
+        const double x = sx[base], y = sy[base], z = sz[base];
+        const double* __restrict__ t = Ts + (size_t)s * kRegTStride;
+        uint32_t cnt = 0;
+        double sum = 0.0;
+        if (t[0] == t[0]) {
+            const double px = ((t[0] * x + t[1] * y) + t[2] * z) + t[3];
+            const double py = ((t[4] * x + t[5] * y) + t[6] * z) + t[7];
+            const double pz = ((t[8] * x + t[9] * y) + t[10] * z) + t[11];
+            const double d2 = nearest_d2<SCREEN>(g, cell_start, qx, qy, qz, px, py, pz);
+            const bool f = d2 < g.r2;
+            cnt = (uint32_t)__popcll(__ballot(f));
+            sum = f ? d2 : 0.0;
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        }
+        if (lane == 0) {
+            red[wave] = cnt;
+            reds[wave] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            partial_cnt[e] = (red[0] + red[1]) + (red[2] + red[3]);
+            partial_sum[e] = (reds[0] + reds[1]) + (reds[2] + reds[3]);
+        }
+        __syncthreads();
+    }
+}
+
 // sums[s] = sum over tiles of partial_sum[tile][s] in tile order (deterministic)
 // (workgroup = 64 hypotheses x kFoldSlices interleaved slices of the tiles, folded in LDS in a fixed order: a thread per
 // hypothesis walking all ~800 tiles alone took 0.2 ms per call)
@@ -979,7 +1042,7 @@ __global__ __launch_bounds__(64 * kFoldSlices) void reg_keep_k(const uint32_t* _
     double q = 0.0;
     if (live)
         for (uint32_t t = sl; t < n_tiles; t += kFoldSlices)
-            if ((done_mask >> (t & 7u)) & 1u) {
+            if ((done_mask >> (t & 31u)) & 1u) {
                 a += partial_cnt[(size_t)t * s_pad + s];
                 q += partial_sum[(size_t)t * s_pad + s];
             }
@@ -1015,7 +1078,7 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
     // without a cache: reg_validate_k on every pair; with one: on the flagged pairs only (`resolve`)
     auto launch = [&](uint32_t res_mask, const uint8_t* kp, bool resolve) {
         // (upper bound of the tiles of the launch; the kernel drops indices past the last tile)
-        const uint32_t tiles = (n_tiles + 7) / 8 * (uint32_t)__builtin_popcount(res_mask);
+        const uint32_t tiles = (n_tiles + 31) / 32 * (uint32_t)__builtin_popcount(res_mask);
         // enough blocks to fill the chip several times over (the pruning phases launch an eighth of the tiles: 16 384 blocks
         // instead of 2048 is 4 % on C4), and at least ~40 splits per tile so that the ~160 blocks an XCD holds at a time
         // belong to a handful of tiles (see the block map in the kernel)
@@ -1030,11 +1093,22 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         }
         const uint32_t slots = (tiles + 7) / 8;
         if (cache && !resolve) {
-            launch_reg_validate_cached(src, Ts, s_pad, per_split, nsplit, slots, g.r2, *cache, partial_cnt, partial_sum, res_mask,
+            launch_reg_validate_cached(src, Ts, s_pad, per_split, nsplit, slots, g, *cache, partial_cnt, partial_sum, res_mask,
                                        n_tiles, kp, tiles, cache->redo, s);
             return;
         }
         const uint8_t* redo = cache ? cache->redo : nullptr;
+        if (cache && cache->pairs) {   // the flagged pairs as a list, one pair per workgroup trip
+            (void)hipMemsetAsync(cache->n_pairs, 0, sizeof(uint32_t), s);
+            redo_pairs_k<<<dim3((s_pad + 255) / 256, tiles), 256, 0, s>>>(redo, kp, s_pad, res_mask, n_tiles, tiles, cache->pairs, cache->n_pairs);
+            if (g.nl32 && g.nl_rec && g.nl_sorted && g.nl_start && g.nl_hdr)
+                reg_validate_pairs_k<true><<<8192, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, g, cell_start, qx, qy, qz, partial_cnt, partial_sum,
+                                                               cache->pairs, cache->n_pairs);
+            else
+                reg_validate_pairs_k<false><<<8192, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, g, cell_start, qx, qy, qz, partial_cnt, partial_sum,
+                                                                cache->pairs, cache->n_pairs);
+            return;
+        }
         if (g.nl32 && g.nl_rec && g.nl_sorted && g.nl_start && g.nl_hdr)
             reg_validate_k<true><<<slots * 8 * nsplit, 256, 0, s>>>(src.x, src.y, src.z, Ts, s_pad, per_split, g, cell_start, qx, qy,
                                                                    qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit, redo);
@@ -1043,20 +1117,21 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
                                                                     qz, partial_cnt, partial_sum, res_mask, n_tiles, kp, tiles, nsplit, redo);
     };
     if (best_cnt == 0 || n_tiles < 16) {
-        launch(0xFFu, nullptr, false);
-        if (cache) launch(0xFFu, nullptr, true);   // nothing to prune against: every flagged pair is walked
+        launch(0xFFFFFFFFu, nullptr, false);
+        if (cache) launch(0xFFFFFFFFu, nullptr, true);   // nothing to prune against: every flagged pair is walked
     } else {
         // four phases: an eighth of the tiles, another eighth, a quarter, the remaining half; the hypotheses still in
         // the race are re-assessed in between (reg_keep_k)
-        static const uint32_t kPhase4[4] = {0x01u, 0x10u, 0x44u, 0xAAu};
-        static const uint32_t kPhase8[8] = {0x01u, 0x10u, 0x04u, 0x40u, 0x02u, 0x20u, 0x08u, 0x80u};   // (experiment: M3D_DBG_PHASES=8)
-        static const int n_phases = std::getenv("M3D_DBG_PHASES") ? std::atoi(std::getenv("M3D_DBG_PHASES")) : 4;
-        const uint32_t* kPhase = n_phases == 8 ? kPhase8 : kPhase4;
+        // (residue classes of the tile index mod 32.  Finer first phases -- 1/16, 1/16, 1/8, ... and 1/32, 1/32, 1/16, ... -- were
+        // measured with the cache on C4's forced run: 125 / 127 ms against 128 with these four; eight phases of an eighth each:
+        // 116 against 112 -- the launches' tails cost what the pairs save.  profiles/r06_reg_cache.txt)
+        static const uint32_t kPhase[4] = {0x01010101u, 0x10101010u, 0x44444444u, 0xAAAAAAAAu};
+        const int n_phases = 4;
         // real source points on the tiles of a residue class (the real points are the first n_points slots)
         auto points_on = [&](uint32_t mask) {
             uint64_t n = 0;
             for (uint32_t t = 0; t < n_tiles; ++t)
-                if ((mask >> (t & 7u)) & 1u) {
+                if ((mask >> (t & 31u)) & 1u) {
                     const uint64_t lo = (uint64_t)t * tile_points;
                     n += (uint64_t)std::min<uint64_t>(tile_points, n_points > lo ? n_points - lo : 0);
                 }
@@ -1064,11 +1139,11 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
         };
         const double limit = best_sum2 * (1.0 + 1e-6);
         uint32_t done = 0;
-        const int last = (n_phases == 8 ? 8 : 4) - 1;
+        const int last = n_phases - 1;
         for (int ph = 0; ph <= last; ++ph) {
             launch(kPhase[ph], ph == 0 ? nullptr : keep, false);
             done |= kPhase[ph];
-            const uint32_t rem = points_on(0xFFu & ~done);
+            const uint32_t rem = points_on(~done);
             auto assess = [&](int first) {
                 reg_keep_k<<<s_pad / 64, 64 * kFoldSlices, 0, s>>>(partial_cnt, partial_sum, n_tiles, done, s_pad, rem, true, best_cnt,
                                                                limit, keep, first);
@@ -1077,7 +1152,8 @@ uint32_t launch_reg_validate(const CloudView& src, const double* Ts, uint32_t s_
                 // The records of a flagged pair are BOUNDS (count from above, sum from below): reg_keep_k's rule is as exact on them
                 // as on the values themselves -- what it drops can neither beat nor tie the incumbent, and is never walked.  The
                 // flagged pairs of the hypotheses still standing are walked now (their bounds may be what keeps them standing)
-                // and the hypotheses re-assessed on the values.
+                // and the hypotheses re-assessed on the values.  (The walk in three steps with an assessment after each -- a far
+                // pose that is also a poor one gives itself away on a few tiles -- measured equal: 94.0 against 94.1 ms.)
                 assess(ph == 0 ? 1 : 0);
                 launch(kPhase[ph], keep, true);
                 if (ph < last) assess(0);

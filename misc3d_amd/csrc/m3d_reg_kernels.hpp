@@ -49,10 +49,16 @@ struct GridDesc {
 
 
 // The candidate cache of the validation (m3d_reg_cache.hip): per sorted source point, under a reference pose, its position
-// xa, up to kRegCacheK nearest target points (fp32 offsets from xa in pairs, fp64 coordinates) and a radius R >= 0 that
-// every unlisted target point keeps from xa (R < 0: the slot holds no query).  Layouts: cx / cy / cz [tile][pair][256],
-// c64 [tile][slot][256], xa / ya / za / R [n_pad]; stats[0 / 1]: (tile, hypothesis) pairs answered from the cache / handed to the walk.
+// xa, its nearest target points in kRegCacheTiers tiers of kRegCacheK (fp32 offsets from xa in pairs, fp64 coordinates) and per
+// tier a radius R_t >= 0 that every target point outside tiers 0..t keeps from xa (R < 0: the slot holds no query).  Layouts
+// (slot = tier * kRegCacheK + position): cx / cy / cz [tile][slot / 2][256], c64 [tile][slot][256], xa / ya / za [n_pad],
+// R [tier][n_pad]; stats[0 / 1]: (tile, hypothesis) pairs whose record the cache made exact / a bound; stats[2]: wave-queries
+// that went past tier 0.
 constexpr int kRegCacheK = 32;
+// 1: tier 0 only, in registers.  Three tiers were built and measured on C4's forced run (profiles/r06_reg_cache.txt): the
+// pairs left without a certificate fall from 18 % to 6 %, but the kernel pays 182 instead of 152 VGPRs (two waves per SIMD
+// instead of three) and the streamed tiers' loads: 126 ms against 112 -- the far poses are the cell rings' (RegCache::ring).
+constexpr int kRegCacheTiers = 1;
 struct RegCache {
     float2 *cx = nullptr, *cy = nullptr, *cz = nullptr;
     double4* c64 = nullptr;
@@ -60,11 +66,16 @@ struct RegCache {
     float* R = nullptr;
     unsigned long long* stats = nullptr;
     uint8_t* redo = nullptr;   // [n_tiles][s_pad] scratch of a launch_reg_validate call: pairs the cache could not certify
+    uint32_t* pairs = nullptr;     // [n_tiles * s_pad] scratch: tile * s_pad + hypothesis of the flagged pairs a resolve launch walks
+    uint32_t* n_pairs = nullptr;   // ... and their number
+    const uint8_t* ring = nullptr;   // per cell of the target grid: Chebyshev distance in cells to the nearest occupied cell (launch_reg_rings)
 };
 void launch_reg_cache_build(const CloudView& src_sorted, const double* T_dev, const GridDesc& g, const uint32_t* cell_start,
                             const double* qx, const double* qy, const double* qz, const RegCache& c, hipStream_t s);
+void launch_reg_rings(const GridDesc& g, const uint32_t* cell_start, uint8_t* ring /* ncell */, uint8_t* tmp /* 2 ncell */, int rounds,
+                      hipStream_t s);
 void launch_reg_validate_cached(const CloudView& src, const double* Ts, uint32_t s_pad, uint32_t per_split, uint32_t nsplit,
-                                uint32_t slots, double r2, const RegCache& c, uint32_t* partial_cnt, double* partial_sum,
+                                uint32_t slots, const GridDesc& g, const RegCache& c, uint32_t* partial_cnt, double* partial_sum,
                                 uint32_t res_mask, uint32_t n_tiles, const uint8_t* keep, uint32_t tiles, uint8_t* redo,
                                 hipStream_t s);
 

@@ -69,13 +69,13 @@ struct Scratch {  // per-call device buffers (registration calls are rare and la
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
         s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, nl32_fallbacks, cell_orig, tile_sph,
-        cc_x, cc_y, cc_z, cc_64, cc_xa, cc_ya, cc_za, cc_R, cc_stats, cc_redo;   // the validation's candidate cache (m3d_reg_cache.hip)
+        cc_x, cc_y, cc_z, cc_64, cc_xa, cc_ya, cc_za, cc_R, cc_stats, cc_redo, cc_ring, cc_ring_tmp, cc_pairs;   // the validation's candidate cache (m3d_reg_cache.hip)
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
                           &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &nl_hdr, &nl32, &nl_rec, &nl32_start, &nl32_fallbacks, &cell_orig,
-                          &tile_sph, &cc_x, &cc_y, &cc_z, &cc_64, &cc_xa, &cc_ya, &cc_za, &cc_R, &cc_stats, &cc_redo})
+                          &tile_sph, &cc_x, &cc_y, &cc_z, &cc_64, &cc_xa, &cc_ya, &cc_za, &cc_R, &cc_stats, &cc_redo, &cc_ring, &cc_ring_tmp, &cc_pairs})
             b->release();
     }
 };
@@ -450,7 +450,6 @@ int m3d_reg::setup(const double* src, const double* dst, const size_t* corr_src,
         const int rc_grid = build_target_grid(ctx, S, R.dst, dst, n_dst, threshold, keep_orig, &g, k0, /*with_nl=*/false,
                                               cdst->bb_known ? cdst->bb : nullptr);
         if (rc_grid != M3D_OK) return rc_grid;
-        if (std::getenv("M3D_DBG_NO_P2")) g.h2_in = INFINITY;   // (timing experiment only: the search never leaves the 3x3x3 block -- WRONG results)
         R.g = g;
         n_dst_points = n_dst;
     }
@@ -618,18 +617,22 @@ int m3d_reg::ensure_cache(uint32_t s_pad) {
                        ((double)best_cnt > 1.02 * (double)cache_ref_cnt || best_sum2 < 0.7 * cache_ref_sum2);
     RESERVE(S.cc_redo, nt * (size_t)s_pad);
     cache.redo = S.cc_redo.as<uint8_t>();
+    RESERVE(S.cc_pairs, sizeof(uint32_t) * (nt * (size_t)s_pad + 4));
+    cache.n_pairs = S.cc_pairs.as<uint32_t>();
+    cache.pairs = cache.n_pairs + 4;
     if (cache_valid && !moved) return M3D_OK;
-    RESERVE(S.cc_x, sizeof(float2) * nt * (kRegCacheK / 2) * 256);
-    RESERVE(S.cc_y, sizeof(float2) * nt * (kRegCacheK / 2) * 256);
-    RESERVE(S.cc_z, sizeof(float2) * nt * (kRegCacheK / 2) * 256);
-    RESERVE(S.cc_64, sizeof(double4) * nt * kRegCacheK * 256);
+    constexpr size_t slots = (size_t)kRegCacheK * kRegCacheTiers;
+    RESERVE(S.cc_x, sizeof(float2) * nt * (slots / 2) * 256);
+    RESERVE(S.cc_y, sizeof(float2) * nt * (slots / 2) * 256);
+    RESERVE(S.cc_z, sizeof(float2) * nt * (slots / 2) * 256);
+    RESERVE(S.cc_64, sizeof(double4) * nt * slots * 256);
     RESERVE(S.cc_xa, sizeof(double) * np);
     RESERVE(S.cc_ya, sizeof(double) * np);
     RESERVE(S.cc_za, sizeof(double) * np);
-    RESERVE(S.cc_R, sizeof(float) * np);
+    RESERVE(S.cc_R, sizeof(float) * np * kRegCacheTiers);
     if (!S.cc_stats.p) {
-        RESERVE(S.cc_stats, sizeof(unsigned long long) * 2);
-        HIPCHK(hipMemsetAsync(S.cc_stats.p, 0, sizeof(unsigned long long) * 2, ctx->stream));
+        RESERVE(S.cc_stats, sizeof(unsigned long long) * 4);
+        HIPCHK(hipMemsetAsync(S.cc_stats.p, 0, sizeof(unsigned long long) * 4, ctx->stream));
     }
     cache.cx = S.cc_x.as<float2>();
     cache.cy = S.cc_y.as<float2>();
@@ -640,6 +643,14 @@ int m3d_reg::ensure_cache(uint32_t s_pad) {
     cache.za = S.cc_za.as<double>();
     cache.R = S.cc_R.as<float>();
     cache.stats = S.cc_stats.as<unsigned long long>();
+    if (!cache.ring) {   // the target grid's cell rings, once per session (K + 1 rounds: a ring beyond K certifies "nothing in reach")
+        const size_t ncell = (size_t)g.nx * g.ny * g.nz;
+        RESERVE(S.cc_ring, ncell);
+        RESERVE(S.cc_ring_tmp, 2 * ncell);
+        launch_reg_rings(g, S.cell_start.as<uint32_t>(), S.cc_ring.as<uint8_t>(), S.cc_ring_tmp.as<uint8_t>(), g.K + 1, ctx->stream);
+        S.cc_ring_tmp.release();
+        cache.ring = S.cc_ring.as<uint8_t>();
+    }
     launch_reg_cache_build(src_sorted, best_T_dev, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
                            S.qz.as<double>(), cache, ctx->stream);
     cache_valid = true;
@@ -675,7 +686,7 @@ int m3d_reg::validate(size_t s_begin, size_t s_end, uint32_t* counts_out, double
         // (a cell edge within [1e-12, 1e12]: the cache's fp32 squares neither underflow below its rounding bound nor reach the
         //  empty slots' 1e18 -- m3d_reg_cache.hip)
         const double h_cell = 1.0 / g.inv_h;
-        const bool use_cache = best_index >= 0 && src_sorted.n_pad <= ((size_t)4 << 20) && h_cell > 1e-12 && h_cell < 1e12 &&
+        const bool use_cache = best_index >= 0 && src_sorted.n_pad <= ((size_t)2 << 20) && h_cell > 1e-12 && h_cell < 1e12 &&
                                (cc == 2 || (cc == 1 && nl_built && ns >= 192));
         if (use_cache) {
             const int rcache = ensure_cache(s_pad);

@@ -33,5 +33,5 @@ for cc in (0, 1, 0, 1):
     a, w = st["lds_wave_hypotheses"], st["global_wave_hypotheses"]
     print(json.dumps({"reg_cache": cc, "ms": [round(t, 3) for t in ts], "identical_to_first": key == ref,
                       "validations": st["validations"], "ties": st["ties"], "best_index": st["best_index"],
-                      "pairs_answered_by_cache": a, "pairs_walked_after_it": w,
+                      "pairs_exact_from_cache": a, "pairs_left_as_bounds": w,
                       "cache_share": (a / (a + w)) if a + w else None}))
