@@ -439,8 +439,10 @@ int m3d_registration_ransac_sharded(const double *src, size_t n_src, const doubl
 /* ---- tunables ---------------------------------------------------------------------------------------------------
  * Every knob of the library, read ONCE from the environment on first use (variable names in brackets) and
  * replaceable at run time.  None changes a result: they select between code paths that produce identical output
- * (the test-suite runs them against each other) or set launch geometry.  m3d_set_config must not race with
- * compute calls. */
+ * (the test-suite runs them against each other) or set launch geometry.  m3d_set_config may be called while other threads
+ * compute: a call works with the settings as they were when it took its lane (a snapshot per call), the new ones apply to calls
+ * that start afterwards.  Returns M3D_ERR_INVALID_ARG for score_mfma / score_waves4 / compact_one_pass != 0 on a build without
+ * those kernels (m3d_bench_experimental() == 0). */
 typedef struct m3d_config {
     int32_t dense_scoring;          /* [M3D_DENSE=1]        1: score every (tile, hypothesis) pair (score_k) instead of the culled path */
     int32_t speculative_refine;     /* [M3D_SPEC=0]         default 1: probability-1 fits start RefineModel on the device's own pick */
@@ -469,12 +471,13 @@ typedef struct m3d_config {
     int32_t sorted_tombstones;      /* [M3D_TOMBSTONES=0]   default 1: a segmentation round that removes a sliver of the cloud kills its inliers
                                        in place in the Hilbert-sorted copy (x = NaN: never an inlier; the screen masks the lane) instead
                                        of partitioning the copy; a real compaction follows when an eighth of the copy is dead */
-    int32_t score_mfma;             /* [M3D_SCORE_MFMA=1]   default 0; 1: plane hypotheses are counted by score_mfma_k -- the screen's two
+    int32_t score_mfma;             /* [M3D_SCORE_MFMA=1]   EXPERIMENTAL BUILDS ONLY (make DEFS=-DM3D_EXPERIMENTAL; elsewhere the slot is kept for the layout and
+                                       must be 0).  default 0; 1: plane hypotheses are counted by score_mfma_k -- the screen's two
                                        one-sided values T - S and T + S on the matrix pipe (split-fp16 operands, rounding bound, exact
                                        fp64 recount of the undecided pairs: identical counts) instead of score_screen_k (packed fp32
                                        VALU); measured slower on C2 as it stands (m3d_score_mfma.hip, STATUS) */
     int32_t score_mfma_groups;      /* [M3D_MFMA_GPB]       default 64: 64-hypothesis groups per workgroup of score_mfma_k (1..64) */
-    int32_t score_waves4;           /* [M3D_SCORE_WAVES4=1]  default 0; 1: scoring windows of 24 groups and more run score_screen4_k -- four-wave
+    int32_t score_waves4;           /* [M3D_SCORE_WAVES4=1]  EXPERIMENTAL BUILDS ONLY (must be 0 elsewhere).  default 0; 1: scoring windows of 24 groups and more run score_screen4_k -- four-wave
                                        workgroups over up to score_waves4_groups groups of a tile that share ONE compacted list of the
                                        surviving hypotheses and take its batches of 64 in turn (VERDICT r3 item 2's decomposition: measured
                                        4 % slower than one wave per (tile, 8 groups) on C2, equal on C3 -- profiles/r04_score_waves4.txt) */
@@ -484,7 +487,7 @@ typedef struct m3d_config {
                                        tiles, re-pruned with what every hypothesis collected (count so far + 512 per tile it can still touch
                                        against the incumbent: exact), (3: counted on a second quarter, re-pruned,) and only the survivors
                                        see the rest; 0: one launch over all tiles */
-    int32_t compact_one_pass;       /* [M3D_COMPACT_ONE_PASS=1]  default 0; 1: RefineModel's / a removal's ordered compaction of up to 1024 tiles
+    int32_t compact_one_pass;       /* [M3D_COMPACT_ONE_PASS=1]  EXPERIMENTAL BUILDS ONLY (must be 0 elsewhere).  default 0; 1: RefineModel's / a removal's ordered compaction of up to 1024 tiles
                                        (2 M points) is ONE launch -- a workgroup publishes its tile's count and waits for the counts of the
                                        tiles below it (compact_write_k, ONE) -- instead of a counting launch and a writing launch.  Same
                                        output, position for position; measured SLOWER (a count crossing the XCDs' L2s costs more than the

@@ -148,13 +148,16 @@ class _Reconstruction:
     @staticmethod
     def register_fragment_pairs(fragments, features, pairs=None, voxel_size=0.01, max_iter=100000,
                                 edge_length_threshold=0.9, confidence=0.999, *, seeds=None, devices=(0,), inflight=0):
-        """BuildPoseGraphForScene's loop closures: every (s, t) of `pairs` (default: all s < t) through global_registration,
-        dealt to `devices`, `inflight` pairs at a time per device.  Returns [(s, t, success, pose, information), ...]."""
+        """BuildPoseGraphForScene's loop closures: every (s, t) of `pairs` through global_registration, dealt to `devices`,
+        `inflight` pairs at a time per device.  Default pairs: all s < t with t > s + 1 -- the reference sends ADJACENT fragments
+        (t == s + 1) to the multi-scale ICP odometry seeded from the fragment pose graph, never to GlobalRegistration
+        (src/pipeline.cpp:752-764); pass `pairs` explicitly to register those here as well.
+        Returns [(s, t, success, pose, information), ...]."""
         from . import capi as _capi
         pts = [_xyz(f) for f in fragments]
         fts = [_feat(f, len(p)) for f, p in zip(features, pts)]
         if pairs is None:
-            pairs = [(s, t) for s in range(len(pts)) for t in range(s + 1, len(pts))]
+            pairs = [(s, t) for s in range(len(pts)) for t in range(s + 2, len(pts))]
         try:   # (every fragment is uploaded once per device and stays resident for the call)
             res = _capi.register_fragment_pairs(pts, fts, pairs, voxel_size, max_iter, edge_length_threshold, confidence,
                                                 seeds, devices, inflight)

@@ -35,8 +35,10 @@ struct LocalGroup {
     std::vector<uint8_t> buf[2];   // world x bytes_per_rank of the exchange in flight (by generation parity)
     size_t bytes_per_rank = 0;
     bool aborted = false;          // a rank failed outside an exchange: the others must not wait for it
-    void abort() {
+    int first_failed = -1;         // ... and which one gave up first (its error is the call's; the others' is "another rank failed")
+    void abort(int rank = -1) {
         std::lock_guard<std::mutex> lock(mu);
+        if (!aborted) first_failed = rank;
         aborted = true;
         cv.notify_all();
     }

@@ -12,6 +12,9 @@ namespace m3d {
 namespace {
 m3d_config g_cfg;
 std::once_flag g_once;
+std::mutex g_cfg_mu;                 // guards g_cfg against m3d_set_config
+thread_local m3d_config t_cfg;       // the calling thread's view (pinned: the snapshot; else refreshed by every config())
+thread_local int t_cfg_pins = 0;
 
 long env_long(const char* name, long def) {
     const char* e = std::getenv(name);
@@ -87,12 +90,27 @@ void load_env() {
 
 const m3d_config& config() {
     std::call_once(g_once, load_env);
-    return g_cfg;
+    if (t_cfg_pins > 0) return t_cfg;
+    std::lock_guard<std::mutex> lock(g_cfg_mu);
+    t_cfg = g_cfg;
+    return t_cfg;
+}
+void config_pin() {
+    std::call_once(g_once, load_env);
+    if (t_cfg_pins++ == 0) {
+        std::lock_guard<std::mutex> lock(g_cfg_mu);
+        t_cfg = g_cfg;
+    }
+}
+void config_unpin() {
+    if (t_cfg_pins > 0) --t_cfg_pins;
 }
 void config_store(const m3d_config& c) {
     std::call_once(g_once, load_env);
-    g_cfg = c;
-    sanitize(g_cfg);
+    m3d_config n = c;
+    sanitize(n);
+    std::lock_guard<std::mutex> lock(g_cfg_mu);
+    g_cfg = n;
 }
 }  // namespace m3d
 
@@ -102,6 +120,12 @@ void m3d_get_config(m3d_config* out) {
 }
 int m3d_set_config(const m3d_config* in) {
     if (!in) return m3d::fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    // the three switches of round 4's refuted variants select kernels a product build does not contain (m3d_kernels.hpp): asking
+    // for one is an error, not a silent no-op; their slots stay for the layout of the fields behind them
+    if (!m3d::kExperimentalBuild && (in->score_mfma || in->score_waves4 || in->compact_one_pass))
+        return m3d::fail(M3D_ERR_INVALID_ARG,
+                         "score_mfma / score_waves4 / compact_one_pass: these kernels are compiled with -DM3D_EXPERIMENTAL only "
+                         "(m3d_bench_experimental() == 0)");
     m3d::config_store(*in);
     return M3D_OK;
 }

@@ -5,6 +5,11 @@
 #include "../../include/misc3d_amd.h"
 
 namespace m3d {
-const m3d_config& config();        // current settings
+// The settings the calling thread works with.  While the thread holds a lane (CtxLock / LaneLock: config_pin) that is the
+// SNAPSHOT taken when it took the lane -- m3d_set_config from another thread does not change the switches of a call in
+// flight (a fit that started with the histogram bound finishes with it) -- otherwise a copy of the current ones.
+const m3d_config& config();
 void config_store(const m3d_config& c);
+void config_pin();     // nested pins keep the outermost snapshot
+void config_unpin();
 }  // namespace m3d

@@ -259,8 +259,10 @@ CtxLock::CtxLock(DeviceCtx* c) : ctx_(c), prev_lane_(t_lane), prev_dev_(t_dev) {
     g_lanes_held.fetch_add(1, std::memory_order_relaxed);
     t_lane = ctx_->lane;
     t_dev = ctx_->logical;
+    config_pin();
 }
 CtxLock::~CtxLock() {
+    config_unpin();
     t_lane = prev_lane_;
     t_dev = prev_dev_;
     g_lanes_held.fetch_sub(1, std::memory_order_relaxed);
@@ -306,9 +308,11 @@ LaneLock::LaneLock(int device, int prefer) : prev_lane_(t_lane), prev_dev_(t_dev
     g_lanes_held.fetch_add(1, std::memory_order_relaxed);
     t_lane = ctx->lane;
     t_dev = ctx->logical;
+    config_pin();
 }
 LaneLock::~LaneLock() {
     if (!ctx) return;
+    config_unpin();
     t_lane = prev_lane_;
     t_dev = prev_dev_;
     g_lanes_held.fetch_sub(1, std::memory_order_relaxed);

@@ -94,7 +94,7 @@ int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, cons
     m3d_global_reg_stats st;
     std::memset(&st, 0, sizeof(st));
     st.ransac.best_index = -1;
-    st.device = ctx->device;
+    st.device = ctx->logical;   // (the ordinal the caller dealt the pair to: under m3d_config.device_aliases several share a physical device)
     st.lane = ctx->lane;
     auto leave = [&](int rc) {
         st.ms_total = now_ms() - t0;
@@ -149,6 +149,35 @@ int global_registration_on(DeviceCtx* ctx, const double* src, size_t n_src, cons
     if (csrc && !rs) m3d_cloud_destroy_on(csrc);
     if (cdst && !rt) m3d_cloud_destroy_on(cdst);
     return leave(rc);
+}
+
+// The batch entry points' workers: worker(d, w) drains device d's share of the pairs.  extern "C" code must not let an
+// exception out: a worker that throws (bad_alloc in a pair's buffers) is caught and its pair keeps
+// M3D_ERR_INTERNAL; a thread that cannot be created is done without -- whoever runs drains the device's queue, and the
+// calling thread sweeps every device once more at the end.  The caller's current HIP device is put back.
+template <class W>
+void run_pair_workers(int n_dev, int per_dev, size_t n_pairs, W&& worker) {
+    int caller_dev = -1;
+    if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
+    auto guarded = [&](int d, int w) {
+        try {
+            worker(d, w);
+        } catch (...) {
+            set_error("an exception in a pair's worker (out of memory?)");
+        }
+    };
+    std::vector<std::thread> th;
+    const size_t busiest = (n_pairs + (size_t)n_dev - 1) / (size_t)n_dev;
+    try {
+        for (int d = 0; d < n_dev; ++d)
+            for (int w = 0; w < per_dev && (size_t)w < busiest; ++w)
+                if (d || w) th.emplace_back(guarded, d, w);
+    } catch (...) {   // (std::system_error: no more threads)
+    }
+    guarded(0, 0);
+    for (auto& t : th) t.join();
+    for (int d = 0; d < n_dev; ++d) guarded(d, 0);   // (nothing left unless a thread was missing)
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
 }
 
 }  // namespace
@@ -207,13 +236,7 @@ int m3d_global_registration_batch(m3d_fragment_pair* pairs, size_t n_pairs, int 
             if (p.rc < 0) errs[k] = m3d_last_error();
         }
     };
-    std::vector<std::thread> th;
-    const size_t busiest = (n_pairs + (size_t)n_dev - 1) / (size_t)n_dev;
-    for (int d = 0; d < n_dev; ++d)
-        for (int w = 0; w < per_dev && (size_t)w < busiest; ++w)
-            if (d || w) th.emplace_back(worker, d, w);
-    worker(0, 0);
-    for (auto& t : th) t.join();
+    run_pair_workers(n_dev, per_dev, n_pairs, worker);
     for (size_t k = 0; k < n_pairs; ++k)
         if (pairs[k].rc < 0) {   // the first failed pair's message is the call's; every pair keeps its own code
             set_error("pair " + std::to_string(k) + ": " + errs[k]);
@@ -239,9 +262,13 @@ int m3d_register_fragment_pairs(const m3d_fragment_view* frags, size_t n_frags, 
         std::memcpy(pairs[k].T, I4, sizeof(I4));
         identity6(pairs[k].info);
         std::memset(&pairs[k].stats, 0, sizeof(pairs[k].stats));
-        if (pairs[k].s < 0 || pairs[k].t < 0 || (size_t)pairs[k].s >= n_frags || (size_t)pairs[k].t >= n_frags)
-            return fail(M3D_ERR_INVALID_ARG, "pair " + std::to_string(k) + ": fragment index out of range");
     }
+    // (every pair initialised before the first is judged: the header promises each its own rc -- ADVICE r5)
+    for (size_t k = 0; k < n_pairs; ++k)
+        if (pairs[k].s < 0 || pairs[k].t < 0 || (size_t)pairs[k].s >= n_frags || (size_t)pairs[k].t >= n_frags) {
+            pairs[k].rc = M3D_ERR_INVALID_ARG;
+            return fail(M3D_ERR_INVALID_ARG, "pair " + std::to_string(k) + ": fragment index out of range");
+        }
     if (n_pairs == 0) return M3D_OK;
     for (int d = 0; d < n_dev; ++d)
         if (!get_ctx(devices[d])) return M3D_ERR_DEVICE;
@@ -268,12 +295,15 @@ int m3d_register_fragment_pairs(const m3d_fragment_view* frags, size_t n_frags, 
             if (rc == M3D_OK) {
                 r.ready = true;
             } else {
-                r.failed = true;
-                r.error = m3d_last_error();
+                // Not latched: whatever was taken goes back, this pair uploads its own copies like
+                // m3d_global_registration_batch does (*out stays null), and a later pair may try again -- residency is an
+                // optimisation, a device short of memory is not a failed loop closure.
+                if (r.cloud) m3d_cloud_destroy_on(r.cloud);
+                r.cloud = nullptr;
+                r.feat.release();
             }
         }
-        if (r.failed) return fail(M3D_ERR_DEVICE, "fragment " + std::to_string(i) + ": " + r.error);
-        *out = &r;
+        *out = r.ready ? &r : nullptr;
         return M3D_OK;
     };
     std::vector<std::atomic<size_t>> next((size_t)n_dev);
@@ -302,13 +332,9 @@ int m3d_register_fragment_pairs(const m3d_fragment_view* frags, size_t n_frags, 
             if (rc < 0) errs[k] = m3d_last_error();
         }
     };
-    std::vector<std::thread> th;
-    const size_t busiest = (n_pairs + (size_t)n_dev - 1) / (size_t)n_dev;
-    for (int d = 0; d < n_dev; ++d)
-        for (int w = 0; w < per_dev && (size_t)w < busiest; ++w)
-            if (d || w) th.emplace_back(worker, d, w);
-    worker(0, 0);
-    for (auto& t : th) t.join();
+    int caller_dev = -1;
+    if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
+    run_pair_workers(n_dev, per_dev, n_pairs, worker);
     for (int d = 0; d < n_dev; ++d) {   // every lane of the call has drained (each pair ends with its stream idle)
         {
             const int phys = physical_device(devices[d]);
@@ -323,6 +349,7 @@ int m3d_register_fragment_pairs(const m3d_fragment_view* frags, size_t n_frags, 
             r.feat.release();
         }
     }
+    if (caller_dev >= 0) (void)hipSetDevice(caller_dev);
     for (size_t k = 0; k < n_pairs; ++k)
         if (pairs[k].rc < 0) {
             set_error("pair " + std::to_string(k) + ": " + errs[k]);

@@ -21,19 +21,35 @@ int run_on_devices(const int* devices, int n_dev, const std::function<int(int, m
     if (rc != M3D_OK) return rc;
     std::vector<int> rcs((size_t)n_dev, M3D_OK);
     std::vector<std::string> errs((size_t)n_dev);
-    std::vector<std::thread> th;
-    for (int r = 1; r < n_dev; ++r)
-        th.emplace_back([&, r] {
+    auto rank_body = [&](int r) {
+        try {
             rcs[(size_t)r] = per_rank(r, comms[(size_t)r]);
-            errs[(size_t)r] = m3d_last_error();
-            if (rcs[(size_t)r] < 0) comms[(size_t)r]->local->abort();   // nobody waits for a rank that has given up
-        });
-    rcs[0] = per_rank(0, comms[0]);
-    if (rcs[0] < 0) comms[0]->local->abort();
+        } catch (...) {   // (extern "C" above us: no exception may pass -- bad_alloc in a rank's buffers)
+            rcs[(size_t)r] = fail(M3D_ERR_INTERNAL, "an exception in a rank's thread (out of memory?)");
+        }
+        errs[(size_t)r] = m3d_last_error();
+        if (rcs[(size_t)r] < 0) comms[(size_t)r]->local->abort(r);   // nobody waits for a rank that has given up
+    };
+    std::vector<std::thread> th;
+    int started = 1;
+    try {
+        for (int r = 1; r < n_dev; ++r, ++started) th.emplace_back(rank_body, r);
+    } catch (...) {   // (no more threads: the ranks that exist must not wait for the ones that do not)
+        comms[0]->local->abort(started);
+        rcs[(size_t)started] = M3D_ERR_INTERNAL;
+        errs[(size_t)started] = "could not start a thread for the device";
+    }
+    rank_body(0);
     for (auto& t : th) t.join();
+    // the error of the rank that gave up FIRST is the call's: the others only report that somebody did
+    const int first = comms[0]->local->first_failed;
     for (m3d_comm* q : comms) m3d_comm_destroy(q);
-    for (int r = 1; r < n_dev; ++r)
-        if (rcs[(size_t)r] < 0 && rcs[0] >= 0) {   // a helper rank failed: report its error
+    if (first >= 0 && first < n_dev && rcs[(size_t)first] < 0) {
+        set_error("device " + std::to_string(devices[first]) + ": " + errs[(size_t)first]);
+        return rcs[(size_t)first];
+    }
+    for (int r = 0; r < n_dev; ++r)
+        if (rcs[(size_t)r] < 0) {
             set_error("device " + std::to_string(devices[r]) + ": " + errs[(size_t)r]);
             return rcs[(size_t)r];
         }

@@ -1741,6 +1741,14 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
     };
 
     // ---- the first slices, and the scale --------------------------------------------------------------------------------------
+    // The copy stream writes into blocks just taken from the lane's free list, which is ordered by the lane's MAIN stream only:
+    // the copy (and second compute) stream start behind whatever the main stream still has queued (today every call
+    // leaves its main stream idle before it parks a block; this makes the invariant explicit instead of assumed).
+    if (sliced) {
+        const hipEvent_t e0 = mark(s);
+        wait_for(cs, e0);
+        if (s2 && s2 != s) wait_for(s2, e0);
+    }
     ok = ok && hipMemsetAsync(mabs.p, 0, sizeof(double) * kMaxAbsPartials * n_cuts, s) == hipSuccess;   // (cuts without rows, resident sides: no pass)
     wait_for(s, upload(0, qa[0]));
     wait_for(s, upload(1, pb[0]));

@@ -95,8 +95,10 @@ def test_round5_config_fields(capi):
     try:
         n = capi.get_config()
         assert (n.lanes, n.wait_spin_us, n.prestream, n.chunk_cap, n.first_chunk, n.reg_cells_per_radius, n.match_pipeline) == (4, 500, 1, 1024, 0, 4, 1)
-        if not capi.experimental():      # the product build ignores the refuted variants' switches (m3d_kernels.hpp)
-            capi.set_config(score_mfma=1, score_waves4=1, compact_one_pass=1)
+        if not capi.experimental():      # the product build REJECTS the refuted variants' switches (m3d_kernels.hpp)
+            for k in ("score_mfma", "score_waves4", "compact_one_pass"):
+                with pytest.raises(capi.M3DError, match="EXPERIMENTAL"):
+                    capi.set_config(**{k: 1})
             n = capi.get_config()
             assert (n.score_mfma, n.score_waves4, n.compact_one_pass) == (0, 0, 0)
     finally:

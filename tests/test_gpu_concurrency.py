@@ -127,9 +127,12 @@ def test_register_fragment_pairs_resident_equals_pairwise_calls(capi, orc):
         _same_result(res[pairs.index((1, 3))], o, 3000)
         if dim == 33:
             import misc3d_amd as m3d
-            api = m3d.reconstruction.register_fragment_pairs(frags, [f.T for f in feats], voxel_size=vox, max_iter=1500,
+            api = m3d.reconstruction.register_fragment_pairs(frags, [f.T for f in feats], pairs=pairs, voxel_size=vox, max_iter=1500,
                                                              seeds=seeds)      # (dim, N) matrices, as open3d Feature.data
             assert [(a[0], a[1]) for a in api] == pairs
+            # the default: loop closures only -- adjacent fragments are the odometry's (src/pipeline.cpp:752-764)
+            dflt = m3d.reconstruction.register_fragment_pairs(frags, [f.T for f in feats], voxel_size=vox, max_iter=300)
+            assert [(a[0], a[1]) for a in dflt] == [(s, t) for (s, t) in pairs if t > s + 1]
             for a, r in zip(api, res):
                 assert a[2] == r[0] and np.array_equal(a[3], r[1]) and np.array_equal(a[4], r[2])
             ok, T, info = m3d.reconstruction.global_registration(frags[0], frags[2], feats[0], feats[2], vox, 1500, seed=seeds[1])
@@ -247,3 +250,53 @@ def test_lanes_one_is_the_serial_library(capi, orc):
     assert {b[3]["lane"] for b in one} == {0}
     for a, b in zip(ref, one):
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_set_config_while_other_threads_compute(capi, orc):
+    """m3d_set_config from one thread while four others fit: a call works with the settings as they were when it
+    took its lane -- a snapshot per call -- so flipping the scoring switches (histogram bound, phases, pre-stream, fp32 screen, box
+    tests) under running fits changes which kernels the NEXT calls use and never a result.  Every fit against the oracle's."""
+    import threading
+    clouds = {0: (synth.plane_cloud_c1(150_000, 3), None), 2: synth.cylinder_cloud_c3(120_000, 5), 1: (synth.sphere_cloud_c3(100_000, 4), None)}
+    H = {0: 12_000, 1: 6_000, 2: 9_000}
+    ref = {k: orc.fit(k, p, n, thr=0.01, max_iter=H[k], prob=1.0, seed=31) for k, (p, n) in clouds.items()}
+    resident = {k: capi.Cloud(p, n) for k, (p, n) in clouds.items()}
+    stop = threading.Event()
+    errors, done = [], [0]
+    old = capi.get_config()
+
+    def flipper():
+        rng = np.random.default_rng(1)
+        while not stop.is_set():
+            capi.set_config(plane_bound=int(rng.integers(0, 3)), score_phases=int(rng.choice([-1, 0, 2, 3])),
+                            prestream=int(rng.integers(0, 2)), score_fp32_screen=int(rng.integers(0, 2)),
+                            cull_fp32=int(rng.integers(0, 2)), first_chunk=int(rng.choice([0, 2048, 4096])),
+                            speculative_refine=int(rng.integers(0, 2)))
+
+    def fitter(tid):
+        try:
+            for it in range(12):
+                k = (tid + it) % 3
+                g = resident[k].fit(k, 0.01, H[k], 1.0, seed=31)
+                o = ref[k]
+                if not (g.ret == o.ret and g.stats["best_index"] == o.best_index and np.array_equal(g.inliers, o.inliers)
+                        and np.allclose(g.params, o.params, rtol=0, atol=1e-9)):
+                    errors.append((tid, it, k, g.stats["best_index"], o.best_index))
+                done[0] += 1
+        except Exception as e:      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    fl = threading.Thread(target=flipper)
+    th = [threading.Thread(target=fitter, args=(t,)) for t in range(4)]
+    fl.start()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    stop.set()
+    fl.join()
+    capi.restore_config(old)
+    for c in resident.values():
+        c.close()
+    assert not errors, errors[:5]
+    assert done[0] == 48
