@@ -485,3 +485,20 @@ def match_mutual_nn(feat_src, feat_dst):
     o1 = np.zeros(max(ns, 1), dtype=np.int64)
     k = lib().orc_match_mutual_nn(_p(fs), C.c_size_t(ns), _p(fd), C.c_size_t(nd), C.c_int(dim), _p(o0), _p(o1))
     return o0[:k].copy(), o1[:k].copy()
+
+
+def reg_validate_kdtree(src, dst, T, thr, workers=-1, tree=None):
+    """GetRegistrationResultAndCorrespondences with a kd-tree, as the reference runs it (Open3D's KDTreeFlann::SearchHybrid(p, thr,
+    1) under transform_estimation.cpp:154-161): scipy's cKDTree stands in for nanoflann.  Same (count, err2) as orc_reg_validate's
+    brute force (tests/test_oracle_primitives.py holds them against each other) at O(n log n) -- the CPU baseline of the
+    registration's validation in tools/cpu_baselines.py, NOT part of the parity chain (scipy's tie order is its own)."""
+    from scipy.spatial import cKDTree
+    src = _f64(src).reshape(-1, 3)
+    dst = _f64(dst).reshape(-1, 3)
+    T = _f64(T).reshape(4, 4)
+    if tree is None:
+        tree = cKDTree(dst)
+    p = src @ T[:3, :3].T + T[:3, 3]
+    d, _ = tree.query(p, k=1, distance_upper_bound=thr, workers=workers)
+    ok = np.isfinite(d) & (d * d < thr * thr)
+    return int(ok.sum()), float((d[ok] ** 2).sum())

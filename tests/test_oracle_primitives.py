@@ -358,3 +358,16 @@ def test_segmentation_lookahead_is_the_sequential_loop(orc):
     # max_clusters cuts the same run short
     rc, pc, cc = orc.segment_plane_iterative(pts, 0.01, max_iteration=60, min_ratio=0.05, seed=3, max_clusters=3, lookahead=24)
     assert len(cc) == 3 and all(np.array_equal(x, y) for x, y in zip(ca[:3], cc))
+
+
+def test_reg_validate_kdtree_equals_brute_force():
+    """tools/cpu_baselines.py times the validation with a kd-tree (what the reference runs: KDTreeFlann); it must count what the
+    oracle's brute force counts."""
+    import oracle as orc
+    from misc3d_amd import synth
+    d = synth.registration_pair_c4(4000, seed=3, dim=8)
+    T = d["T"].copy()
+    T[0, 3] += 0.004
+    c0, e0 = orc.reg_validate(d["src"], d["dst"], T, 0.01)
+    c1, e1 = orc.reg_validate_kdtree(d["src"], d["dst"], T, 0.01, workers=1)
+    assert c0 == c1 > 100 and abs(e0 - e1) <= 1e-12 * e0
