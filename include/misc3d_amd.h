@@ -109,6 +109,29 @@ int m3d_cloud_fit(m3d_cloud *cloud, int kind, double threshold, size_t max_itera
                   double probability, const uint64_t *seed, double *params, size_t *inliers,
                   size_t *n_inliers, m3d_stats *stats);
 
+/* ---- many short fits in ONE call (round 6).  The reference's fits are called one at a time from Python
+ * (python/py_common.cpp:11-78 under its callers' loops); a resident fit of a few dozen hypotheses takes ~80 us on the device, and
+ * threads of such calls are serialised by what the binding does per call under the interpreter's lock, not by the library's
+ * lanes.  A batch hands the loop over: the jobs of one cloud run in the order given, clouds that live on different lanes of a
+ * device (m3d_cloud_create_lane) or on different devices run side by side on threads of the library -- one call, one release of
+ * the interpreter's lock.  Every job carries its own rc (m3d_cloud_fit's: 1 / 0 / < 0) and outputs; the call returns M3D_OK, or
+ * the first failing job's error code with m3d_last_error() = "job <k>: ...".  inflight: lanes worked at a time (0 = all). */
+typedef struct m3d_fit_job {
+    m3d_cloud *cloud;
+    int32_t kind, has_seed;
+    double threshold, probability;
+    uint64_t max_iteration, seed;
+    size_t *inliers;           /* capacity: the cloud's size; may be NULL (then only n_inliers is reported) */
+    double params[8];          /* out */
+    uint64_t n_inliers;        /* out */
+    int32_t rc, reserved_;     /* out */
+    m3d_stats stats;           /* out */
+} m3d_fit_job;
+int m3d_cloud_fit_batch(m3d_fit_job *jobs, size_t n_jobs, int inflight);
+/* m3d_cloud_create on a lane of the caller's choice (0 .. m3d_config.lanes - 1; < 0: the calling thread's own, as m3d_cloud_create):
+ * a single-threaded caller that wants its clouds' fits to overlap (m3d_cloud_fit_batch) spreads them over the lanes itself. */
+m3d_cloud *m3d_cloud_create_lane(const double *xyz, const double *normals /* may be NULL */, size_t n, int device, int lane);
+
 /* ---- hypothesis-range scoring: the shardable unit (ransac.h:572-590 body for i in [begin,end)).
  * samples: H x m sample indices (m = 3 plane, 4 sphere, 2 cylinder) as the sequential sampler
  * (utils.h:81-97) produces them; m3d_draw_samples reproduces that table from a seed.

@@ -546,7 +546,9 @@ class Cloud:
                                            _p(val), C.cast(C.byref(n), C.c_void_p)))
         return val[: n.value], cnt[: n.value]
 
-    def __init__(self, xyz, normals=None, device: int = 0):
+    def __init__(self, xyz, normals=None, device: int = 0, lane: int = -1):
+        """lane >= 0: m3d_cloud_create_lane -- the cloud lives on THAT lane of the device (a single-threaded caller spreads its
+        clouds over the lanes so that fit_batch can run their fits side by side); -1: the calling thread's own lane."""
         xyz = _f64(xyz).reshape(-1, 3)
         nrm = _f64(normals).reshape(-1, 3) if normals is not None else None
         if nrm is not None and len(nrm) != len(xyz):
@@ -554,7 +556,13 @@ class Cloud:
         self.n = len(xyz)            # points currently in the cloud (shrinks with remove_inliers)
         self.n_created = len(xyz)    # index lists refer to the cloud as created
         self._host_xyz, self._host_nrm = xyz, nrm     # for minimal_model (host-side MinimalFit of one sample)
-        self._h = lib().m3d_cloud_create(_p(xyz), _p(nrm), self.n, device)
+        if lane >= 0:
+            f = lib().m3d_cloud_create_lane
+            f.restype = C.c_void_p
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+            self._h = f(_p(xyz), _p(nrm), self.n, device, int(lane))
+        else:
+            self._h = lib().m3d_cloud_create(_p(xyz), _p(nrm), self.n, device)
         if not self._h:
             raise M3DError(ERR_DEVICE, last_error())
 
@@ -852,6 +860,47 @@ def segment_plane_iterative_multi(xyz, devices, threshold, max_iteration=100, mi
                                                         C.cast(C.byref(k), C.c_void_p)))
     k = k.value
     return rc, planes[:k].copy(), [idx[int(offs[i]): int(offs[i + 1])].copy() for i in range(k)]
+
+
+class FitJob(C.Structure):
+    """m3d_fit_job (include/misc3d_amd.h)"""
+    _fields_ = [("cloud", C.c_void_p), ("kind", C.c_int32), ("has_seed", C.c_int32), ("threshold", C.c_double),
+                ("probability", C.c_double), ("max_iteration", C.c_uint64), ("seed", C.c_uint64), ("inliers", C.c_void_p),
+                ("params", C.c_double * 8), ("n_inliers", C.c_uint64), ("rc", C.c_int32), ("reserved_", C.c_int32), ("stats", Stats)]
+
+
+def fit_batch(jobs, inflight=0, want_inliers=True):
+    """m3d_cloud_fit_batch: jobs = [(cloud, kind, threshold, max_iteration, probability, seed), ...] -> [Fit, ...] in the order
+    given.  ONE call into the library (one release of the interpreter's lock): the jobs of a cloud run in order, clouds on
+    different lanes (Cloud(..., lane=k)) or devices side by side."""
+    n = len(jobs)
+    if n == 0:
+        return []
+    arr = (FitJob * n)()
+    bufs = []
+    for k, (cloud, kind, thr, it, prob, seed) in enumerate(jobs):
+        j = arr[k]
+        j.cloud, j.kind, j.threshold, j.max_iteration, j.probability = cloud._h, int(kind), float(thr), int(it), float(prob)
+        if seed is not None:
+            j.seed, j.has_seed = int(seed) & 0xFFFFFFFFFFFFFFFF, 1
+        if want_inliers:
+            b = np.empty(max(cloud.n_created, 1), dtype=np.uint64)      # (one list per job: they are all alive at the end)
+            bufs.append(b)
+            j.inliers = b.ctypes.data
+        else:
+            bufs.append(None)
+    f = lib().m3d_cloud_fit_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    _check(f(C.cast(arr, C.c_void_p), n, int(inflight)))
+    out = []
+    for k in range(n):
+        j = arr[k]
+        inl = bufs[k][: j.n_inliers] if want_inliers else np.zeros(0, dtype=np.uint64)
+        st = j.stats.asdict()
+        st["n_inliers"] = int(j.n_inliers)
+        out.append(Fit(int(j.rc), np.array(j.params[: NUM_PARAMS[int(j.kind)]]), inl, st))
+    return out
 
 
 def fit_multi(kind, xyz, devices, normals=None, threshold=0.01, max_iteration=1000, probability=0.9999, seed=None) -> Fit:

@@ -407,6 +407,17 @@ m3d_cloud* m3d_cloud_create_impl(const double* xyz, const double* normals, size_
     if (!lane.ctx) return nullptr;
     return m3d_cloud_create_on(lane.ctx, xyz, normals, n, with_sorted_copy);
 }
+m3d_cloud* m3d_cloud_create_lane(const double* xyz, const double* normals, size_t n, int device, int lane) {
+    if (lane < 0) return m3d_cloud_create(xyz, normals, n, device);
+    if (lane >= lane_count()) {
+        set_error("m3d_cloud_create_lane: lane " + std::to_string(lane) + " of " + std::to_string(lane_count()) + " (m3d_config.lanes)");
+        return nullptr;
+    }
+    DeviceCtx* ctx = get_lane(device, lane);   // THIS lane, waited for if busy (a LaneLock would move on to a free one)
+    if (!ctx) return nullptr;
+    CtxLock lock(ctx);
+    return m3d_cloud_create_on(ctx, xyz, normals, n, 1);
+}
 
 }  // extern "C"
 

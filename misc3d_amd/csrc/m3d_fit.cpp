@@ -1196,6 +1196,75 @@ int m3d_cloud_fit(m3d_cloud* c, int kind, double threshold, size_t max_iteration
                             inliers, n_inliers, stats);
 }
 
+// python/py_common.cpp:11-78's callers' loops as ONE call: see the header.  Jobs are grouped by the lane their cloud lives on;
+// a worker thread per group (at most `inflight` at a time) holds the lane for its whole group.
+int m3d_cloud_fit_batch(m3d_fit_job* jobs, size_t n_jobs, int inflight) {
+    if (!jobs && n_jobs) return fail(M3D_ERR_INVALID_ARG, "invalid argument");
+    std::vector<DeviceCtx*> lanes;
+    std::vector<std::vector<size_t>> groups;
+    for (size_t k = 0; k < n_jobs; ++k) {
+        m3d_fit_job& j = jobs[k];
+        j.rc = M3D_ERR_INTERNAL;
+        j.n_inliers = 0;
+        std::memset(j.params, 0, sizeof(j.params));
+        std::memset(&j.stats, 0, sizeof(j.stats));
+        if (!j.cloud || j.kind < 0 || j.kind > 2) {
+            j.rc = M3D_ERR_INVALID_ARG;
+            return fail(M3D_ERR_INVALID_ARG, "job " + std::to_string(k) + ": invalid argument");
+        }
+    }
+    for (size_t k = 0; k < n_jobs; ++k) {
+        size_t g = 0;
+        while (g < lanes.size() && lanes[g] != jobs[k].cloud->ctx) ++g;
+        if (g == lanes.size()) {
+            lanes.push_back(jobs[k].cloud->ctx);
+            groups.emplace_back();
+        }
+        groups[g].push_back(k);
+    }
+    std::vector<std::string> errs(n_jobs);
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t g = next.fetch_add(1);
+            if (g >= groups.size()) break;
+            try {
+                CtxLock lock(lanes[g]);
+                for (size_t k : groups[g]) {
+                    m3d_fit_job& j = jobs[k];
+                    int rc = validate_fit_args(j.kind, j.cloud->n, j.cloud->has_normals, j.probability);
+                    size_t ni = 0;
+                    if (rc == M3D_OK) {
+                        const uint64_t sd = j.seed;
+                        rc = cloud_fit_locked(j.cloud, j.kind, j.threshold, (size_t)j.max_iteration, j.probability,
+                                              resolve_seed(j.has_seed ? &sd : nullptr), j.params, j.inliers, &ni, &j.stats);
+                    }
+                    j.n_inliers = ni;
+                    j.rc = rc;
+                    if (rc < 0) errs[k] = m3d_last_error();
+                }
+            } catch (...) {   // (extern "C": nothing may pass; the group's remaining jobs keep M3D_ERR_INTERNAL)
+                for (size_t k : groups[g])
+                    if (jobs[k].rc == M3D_ERR_INTERNAL && errs[k].empty()) errs[k] = "an exception in the batch worker (out of memory?)";
+            }
+        }
+    };
+    const size_t want = std::min<size_t>(groups.size(), inflight > 0 ? (size_t)inflight : groups.size());
+    std::vector<std::thread> th;
+    try {
+        for (size_t t = 1; t < want; ++t) th.emplace_back(worker);
+    } catch (...) {   // (no more threads: the calling thread drains the queue)
+    }
+    worker();
+    for (auto& t : th) t.join();
+    for (size_t k = 0; k < n_jobs; ++k)
+        if (jobs[k].rc < 0) {
+            set_error("job " + std::to_string(k) + ": " + errs[k]);
+            return jobs[k].rc;
+        }
+    return M3D_OK;
+}
+
 }  // extern "C"
 namespace m3d {
 // std::random_device seeds differ per rank: rank 0's is the fit's (one tiny exchange, only when no seed was given)

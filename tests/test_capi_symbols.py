@@ -18,7 +18,7 @@ def test_header_symbols_exported(capi):
     assert len(names) >= 40
     for need in ("m3d_cloud_fit_sharded", "m3d_comm_create_rccl", "m3d_segment_plane_iterative_multi", "m3d_segment_plane_iterative_clouds",
                  "m3d_registration_ransac_sharded", "m3d_set_config", "m3d_global_registration", "m3d_global_registration_batch",
-                 "m3d_register_fragment_pairs"):
+                 "m3d_register_fragment_pairs", "m3d_cloud_fit_batch", "m3d_cloud_create_lane"):
         assert need in names
     # measurement hooks live in their own header: none of them in the product header
     assert not [n for n in names if n.startswith("m3d_bench_") or "time_score" in n]

@@ -300,3 +300,40 @@ def test_set_config_while_other_threads_compute(capi, orc):
         c.close()
     assert not errors, errors[:5]
     assert done[0] == 48
+
+
+def test_fit_batch_equals_single_fits(capi, orc):
+    """m3d_cloud_fit_batch (python/py_common.cpp:11-78's callers' loops as ONE call): clouds placed on lanes of the caller's
+    choice (m3d_cloud_create_lane), 36 jobs of mixed kinds -- every result equal to m3d_cloud_fit on the same cloud, three of them
+    to the oracle's; jobs of one cloud run in the order given (a removal between two of them would be seen); a bad job fails with
+    its index and the others keep their results; probability errors come back per job."""
+    data = [(0, synth.plane_cloud_c1(60_000, 1), None), (1, synth.sphere_cloud_c3(50_000, 4), None),
+            (2,) + synth.cylinder_cloud_c3(50_000, 3), (0, synth.plane_cloud_c1(200_000, 7), None)]
+    clouds = [capi.Cloud(p, n, lane=k % capi.get_config().lanes) for k, (_, p, n) in enumerate(data)]
+    jobs = []
+    for rep in range(9):
+        for k, (kind, _, _) in enumerate(data):
+            jobs.append((clouds[k], kind, 0.01, 800 + 100 * rep, 0.9999 if rep % 2 else 1.0, 40 + rep))
+    res = capi.fit_batch(jobs, inflight=0)
+    assert len(res) == len(jobs)
+    for (c, kind, thr, it, prob, seed), r in zip(jobs, res):
+        one = c.fit(kind, thr, it, prob, seed=seed)
+        assert r.ret == one.ret and r.stats["best_index"] == one.stats["best_index"] and r.stats["iterations"] == one.stats["iterations"]
+        assert np.array_equal(r.inliers, one.inliers) and np.array_equal(r.params, one.params)
+    for k in (0, 1, 2):
+        kind, p, n = data[k]
+        o = orc.fit(kind, p, n, thr=0.01, max_iter=800, prob=1.0, seed=40)
+        assert res[k].stats["best_index"] == o.best_index and np.array_equal(res[k].inliers, o.inliers)
+    # one lane at a time gives the same
+    res1 = capi.fit_batch(jobs[:8], inflight=1)
+    for a, b in zip(res[:8], res1):
+        assert np.array_equal(a.inliers, b.inliers) and np.array_equal(a.params, b.params)
+    assert capi.fit_batch([]) == []
+    bad = list(jobs[:4])
+    bad[2] = (clouds[2], 2, 0.01, 100, 1.5, 1)          # SetProbability's range check, job 2
+    with pytest.raises(capi.M3DError, match="job 2"):
+        capi.fit_batch(bad)
+    with pytest.raises(capi.M3DError):
+        capi.Cloud(data[0][1], lane=99)
+    for c in clouds:
+        c.close()

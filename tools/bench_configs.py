@@ -342,6 +342,23 @@ if "LANES" in which or ALL:
             if clouds:
                 for c in clouds:
                     c.close()
+    # ... and the same fits handed over as ONE call from ONE python thread: m3d_cloud_fit_batch, the clouds on lanes of their own
+    # (m3d_cloud_create_lane) -- the loop runs on threads of the library, the interpreter's lock is released once
+    rows["batch"] = {}
+    for T in (1, 2, 4, 8):
+        clouds = [capi.Cloud(clouds_xyz[t], lane=t) for t in range(T)]
+        per = 200
+        jobs = [(clouds[t], 0, 0.01, 1000, 0.9999, 7) for _ in range(per) for t in range(T)]
+        capi.fit_batch(jobs[: 10 * T], want_inliers=False)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = capi.fit_batch(jobs, want_inliers=False)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        rows["batch"][T] = {"fits_per_s": len(jobs) / best, "ms_per_fit_per_lane": best / per * 1e3}
+        for c in clouds:
+            c.close()
     capi.restore_config(old_cfg)
     capi.set_config(kernel_timing=1)
     def lanes_cpu():
