@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
     __shared__ __attribute__((aligned(8))) uint16_t cm_s[kBoundTpb][kCumStride];
     __shared__ uint32_t wsum[kBoundWaves][64];
     __shared__ double rec_s[64][9];    // (+ 1: the lanes' rows fall into different banks)
-    __shared__ float q_s[64][9];
+    __shared__ float q_s[64][13];   // the hypothesis' fp32 box-test record: 8 words (planes) / 11 (cylinders); odd stride: the lanes' rows fall into different banks
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t total = surv_count[0];
@@ -329,7 +329,10 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
             for (uint32_t si = threadIdx.x >> 3; si < 64u; si += (64u * kBoundWaves) >> 3) {
                 const uint32_t hh = surv[first + min(si, nb - 1u)];
                 rec_s[si][k] = score[(size_t)hh * kModelStride + k];
-                if (cull32) q_s[si][k] = cull32[(size_t)(hh >> 1) * 24u + (hh & 1u) + 2u * k];
+                if (cull32) {
+                    q_s[si][k] = cull32[(size_t)(hh >> 1) * 24u + (hh & 1u) + 2u * k];
+                    if (KIND == 2 && k < 3u) q_s[si][8u + k] = cull32[(size_t)(hh >> 1) * 24u + (hh & 1u) + 2u * (8u + k)];
+                }
             }
         }
         __syncthreads();   // (records -- and, the first time round, the frames -- are in LDS)
@@ -348,10 +351,10 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
         // cull32_one<0>, m3d_cull_kernels.hip: the bits cull_tiles32_k wrote) -- the mask words are 8 useful bytes per 128-byte
         // line for this kernel's lanes; without fp32 records (m3d_config.cull_fp32 = 0) it reads them
         bool tch[kBoundTpw];
-        float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float q[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (cull32) {   // (kernel argument: uniform)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) q[k] = q_s[lane][k];
+            for (int k = 0; k < (KIND == 2 ? 11 : 8); ++k) q[k] = q_s[lane][k];
         } else {
 #pragma unroll
             for (int i = 0; i < kBoundTpw; ++i) {
@@ -363,12 +366,29 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
 #pragma unroll
         for (int i = 0; i < kBoundTpw; ++i) {
             const int tl = wave + kBoundWaves * i;
-            if (cull32) {
+            if (cull32 && KIND == 0) {
                 const float* bx = bx_s[tl];
                 const float sv = __builtin_fmaf(q[0], bx[0], __builtin_fmaf(q[1], bx[1], __builtin_fmaf(q[2], bx[2], q[3])));
                 const float hx = __builtin_fmaxf(bx[3], 0.0f), hy = __builtin_fmaxf(bx[4], 0.0f), hz = __builtin_fmaxf(bx[5], 0.0f);
                 const float rv = __builtin_fmaf(q[4], hx, __builtin_fmaf(q[5], hy, __builtin_fmaf(q[6], hz, q[7])));
                 tch[i] = has && (uint32_t)tl < nt && bx[3] >= 0.0f && !(rv - __builtin_fabsf(sv) < 0.0f);
+            } else if (cull32 && KIND == 2) {
+                // cull32_one<2> (m3d_cull_kernels.hip), operation for operation: the bit cull_tiles32_k wrote for this (tile,
+                // hypothesis) -- round 6: until now the cylinders read the mask words (16 gathers of 8 useful bytes per line and
+                // wave, a chain of dependent loads per block of 64 survivors: 61 us per C3 window)
+                const float* bx = bx_s[tl];
+                const bool live = bx[3] >= 0.0f;
+                const float hx = live ? bx[3] : 0.0f, hy = live ? bx[4] : 0.0f, hz = live ? bx[5] : 0.0f;
+                const float rb = __builtin_sqrtf(__builtin_fmaf(hz, hz, __builtin_fmaf(hy, hy, hx * hx))) * 1.000001f;
+                const float d1 = __builtin_fmaf(q[0], bx[0], __builtin_fmaf(q[1], bx[1], __builtin_fmaf(q[2], bx[2], q[3])));
+                const float d2 = __builtin_fmaf(q[4], bx[0], __builtin_fmaf(q[5], bx[1], __builtin_fmaf(q[6], bx[2], q[7])));
+                const float tt = __builtin_fmaf(d2, d2, d1 * d1);
+                const float dist = __builtin_sqrtf(tt);
+                const float rt = q[8] * rb;
+                const float t1 = (q[9] + rt) - dist;
+                const float t2 = (dist + rt) - q[10];
+                const float t = __uint_as_float(__float_as_uint(t1) | __float_as_uint(t2));
+                tch[i] = has && (uint32_t)tl < nt && live && !(t < 0.0f);
             }
             if (__ballot(tch[i]) == 0ull) continue;   // (wave-uniform)
             const uint32_t u_t = KIND == 0 ? plane_pair_ub(pr, c_s[tl], f_s[tl], cm_s[tl])   // (wave-uniform addresses: broadcast reads)
@@ -426,7 +446,7 @@ void launch_plane_bound(int kind, const SortedView& s, const double* score, cons
     const uint32_t tpb = (uint32_t)(kBoundWaves * (kind == 0 ? tpw : tpw_cyl));
     const uint32_t max_list = always ? 0xFFFFFFFFu : window * 32u;   // half of the window's hypotheses
     const dim3 g(gx, (s.n_tiles + tpb - 1) / tpb), b(64 * kBoundWaves);
-    if (s.radius >= 1e18 || kind != 0) cull32 = nullptr;   // (no fp32 boxes: launch_cull_mask's condition; cylinders: the box tests' mask words are read)
+    if (s.radius >= 1e18 || kind == 1) cull32 = nullptr;   // (no fp32 boxes: launch_cull_mask's condition; spheres: the box tests' mask words are read)
     auto go = [&](auto kernel) {
         kernel<<<g, b, 0, st>>>(s.frames, s.frame_cum, s.n_tiles, s.max_abs, score, masks, n_groups, s.boxes, cull32, surv_count, surv,
                                 ubsum, best_count, keep, tickets, max_list);

@@ -822,6 +822,9 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
     }
 #endif
     if (best < g.h2_in || g.K == 1) return best;
+    // (round 6) more than K empty rings around the query's cell: every target point is at least K h = 1.001 r away -- what the
+    // scan below would establish cell by cell.  best is then the 3x3x3 block's (empty: +inf), and the callers only use values < r^2.
+    if (g.ring && g.ring[((size_t)(uint32_t)iz * g.ny + (uint32_t)iy) * g.nx + (uint32_t)ix] > (uint32_t)g.K) return best;
     return nearest_phase2(g, cell_start, qx, qy, qz, ix, iy, iz, px, py, pz, best);
 }
 

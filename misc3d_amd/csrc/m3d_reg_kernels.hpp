@@ -44,6 +44,10 @@ struct GridDesc {
     const uint2* nl32 = nullptr;
     const uint4* nl_rec = nullptr;
     unsigned long long* nl32_fallbacks = nullptr;   // optional counter: queries the screen handed to the fp64 walk
+    // optional (round 6, launch_reg_rings): per cell the Chebyshev distance in cells to the nearest occupied cell (255: none within
+    // K + 1).  A query more than K rings out has no target point within the radius: the search returns at once instead of
+    // scanning (2K + 1)^3 cells to find that out.
+    const uint8_t* ring = nullptr;
 };
 
 

@@ -650,6 +650,8 @@ int m3d_reg::ensure_cache(uint32_t s_pad) {
         launch_reg_rings(g, S.cell_start.as<uint32_t>(), S.cc_ring.as<uint8_t>(), S.cc_ring_tmp.as<uint8_t>(), g.K + 1, ctx->stream);
         S.cc_ring_tmp.release();
         cache.ring = S.cc_ring.as<uint8_t>();
+        g.ring = cache.ring;     // the walk's outer search looks them up as well (nearest_d2)
+        R.g = g;
     }
     launch_reg_cache_build(src_sorted, best_T_dev, g, S.cell_start.as<uint32_t>(), S.qx.as<double>(), S.qy.as<double>(),
                            S.qz.as<double>(), cache, ctx->stream);
