@@ -5,7 +5,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 rm -rf gpurun_out/c3t
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/c3t -o t -- python tools/bench_configs.py C3 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/c3t -o t -- python tools/bench_configs.py C3 --no-cpu-baseline > /dev/null 2>&1
 f=$(find gpurun_out/c3t -name 't_kernel_trace.csv' | head -1)
 echo "== fit_cylinder"; python tools/fit_timeline.py "$f" 2
 echo "== fit_sphere"; python tools/fit_timeline.py "$f" 1

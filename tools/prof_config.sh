@@ -2,7 +2,7 @@
 # kernel stats of ONE configuration of tools/bench_configs.py on the GPU box: bash tools/prof_config.sh C5 [top-N]
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 cfg=${1:-C5}; top=${2:-16}
-rm -rf gpurun_out/pc_$cfg; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc_$cfg -o t -- python tools/bench_configs.py $cfg > gpurun_out/pc_$cfg.out 2> gpurun_out/pc_$cfg.err
+rm -rf gpurun_out/pc_$cfg; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc_$cfg -o t -- python tools/bench_configs.py $cfg --no-cpu-baseline > gpurun_out/pc_$cfg.out 2> gpurun_out/pc_$cfg.err
 f=$(find gpurun_out/pc_$cfg -name 't_kernel_stats.csv' | head -1)
 python - "$f" "$top" <<'PY'
 import csv, sys

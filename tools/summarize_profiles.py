@@ -58,7 +58,9 @@ def main():
                               ("../strong_scaling_model.jsonl", f"{TAG}_strong_scaling_model.jsonl"),
                               ("../n2_pairs_in_flight.jsonl", f"{TAG}_n2_pairs_in_flight.jsonl"),
                               ("../c3_timeline.txt", f"{TAG}_c3_timeline.txt"),
-                              ("../bench_driver_style.json", f"{TAG}_bench_driver_style.json")):
+                              ("../bench_driver_style.json", f"{TAG}_bench_driver_style.json"),
+                              ("../c4_forced_cache_ab.txt", f"{TAG}_c4_forced_cache_ab.txt"),
+                              ("../pmc_boundary.txt", f"{TAG}_pmc_boundary.txt")):
         q = os.path.join(SRC, src_rel)
         if os.path.exists(q):
             shutil.copy(q, os.path.join(DST, dst_name))
