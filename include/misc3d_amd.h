@@ -550,6 +550,11 @@ typedef struct m3d_config {
                                        points (devices[] forms, m3d_fit_multi, m3d_register_fragment_pairs) on a box with fewer GPUs than
                                        the code path wants: it exercises the dealing, the per-device state and the in-process exchange,
                                        NOT peer traffic or RCCL across devices.  m3d_device_count() then returns the logical count (<= 16) */
+    int32_t lanes_eager;            /* [M3D_LANES_EAGER]    default 2 (1..lanes): lanes whose compute streams a device's FIRST call creates; the others appear when
+                                       a call needs them.  Streams take hardware queues in creation order, and a lane created after another lane's
+                                       copy / pre stream shares a queue with it (its calls take turns with that lane's): a process that runs many
+                                       calls side by side (m3d_cloud_fit_batch over four lanes, fragment pairs in flight) sets 4 before its first
+                                       call; a single-threaded caller keeps 2 (its fits of several chunks are 10-20 % faster that way) */
 } m3d_config;
 void m3d_get_config(m3d_config *out);
 int m3d_set_config(const m3d_config *in);

@@ -214,7 +214,7 @@ class Config(C.Structure):
                                          "reg_neighbour_lists", "reg_prune", "match_brute", "match_fp32_screen",
                                          "pool_limit_mb", "kernel_timing", "reg_sorted_lists", "score_fp32_screen",
                                          "cull_fp32", "reg_fp32_screen", "sorted_tombstones", "score_mfma", "score_mfma_groups", "score_waves4", "score_waves4_groups", "score_phases", "compact_one_pass", "plane_bound",
-                                         "lanes", "wait_spin_us", "prestream", "chunk_cap", "first_chunk", "reg_cells_per_radius", "match_pipeline", "reg_cache", "device_aliases")]
+                                         "lanes", "wait_spin_us", "prestream", "chunk_cap", "first_chunk", "reg_cells_per_radius", "match_pipeline", "reg_cache", "device_aliases", "lanes_eager")]
 
 
 def fp64_issue_rate(device=0, ms_target=2.0):

@@ -48,6 +48,7 @@ void sanitize(m3d_config& c) {
     if (c.reg_cache < 0 || c.reg_cache > 2) c.reg_cache = 1;
     if (c.device_aliases < 0) c.device_aliases = 0;
     if (c.device_aliases > 16) c.device_aliases = 16;
+    if (c.lanes_eager < 1 || c.lanes_eager > 8) c.lanes_eager = 2;
 }
 void load_env() {
     std::memset(&g_cfg, 0, sizeof(g_cfg));
@@ -84,6 +85,7 @@ void load_env() {
     g_cfg.match_pipeline = (int32_t)env_long("M3D_MATCH_PIPELINE", 1);
     g_cfg.reg_cache = (int32_t)env_long("M3D_REG_CACHE", 1);
     g_cfg.device_aliases = (int32_t)env_long("M3D_DEVICE_ALIASES", 0);
+    g_cfg.lanes_eager = (int32_t)env_long("M3D_LANES_EAGER", 2);
     sanitize(g_cfg);
 }
 }  // namespace

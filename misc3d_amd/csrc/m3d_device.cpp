@@ -172,7 +172,13 @@ DeviceCtx* get_lane(int device, int lane) {
     // A device's first call creates lanes 0 AND 1 (see the stream layout below): the second lane's compute stream gets its hardware
     // queue before lane 0's copy stream can take it.
     DeviceCtx* mine = nullptr;
-    for (int ln = 0; ln <= std::max(lane, std::min(2, lane_count()) - 1); ++ln) {
+    // (m3d_config.lanes_eager, default 2: how many lanes' compute streams a device's first call creates.  Streams take hardware queues
+    //  in the order they are created: a lane born AFTER another lane's copy / pre stream shares a queue and its calls take turns with
+    //  that lane's -- a process that will run many calls side by side asks for all its lanes up front (4: batches of fits over four
+    //  lanes 48 k fits/s instead of 15 k after a sliced match has run, four fragment pairs in flight 964 instead of 813 pairs/s;
+    //  the price: single-threaded fits of several chunks 10-20 % slower -- C3 0.84 -> 0.94 / 0.64 -> 0.77 ms: profiles/r06_lanes_eager.txt))
+    const int eager = std::min(std::max((int)config().lanes_eager, 1), kMaxLanes);
+    for (int ln = 0; ln <= std::max(lane, std::min(eager, lane_count()) - 1); ++ln) {
         if (g_ctx.count(device * kMaxLanes + ln)) continue;
         DeviceCtx* c = create_lane_locked(device, ln);
         if (ln == lane) mine = c;
