@@ -1352,9 +1352,7 @@ bool launch_score_own_tests(int kind, const SortedView& s, const double* score, 
         return false;
     const uint32_t gpb_max = std::min<uint32_t>((uint32_t)config().score_groups_per_block, kScreenMaxGroups);
     const uint32_t min_wgs = (uint32_t)config().score_min_workgroups;
-    uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * groups) / min_wgs)));
-    static const int dbg_gpb = std::getenv("M3D_DBG_OWN_GPB") ? std::atoi(std::getenv("M3D_DBG_OWN_GPB")) : 0;   // (experiment)
-    if (dbg_gpb > 0) gpb = std::min<uint32_t>((uint32_t)dbg_gpb, kScreenMaxGroups);
+    const uint32_t gpb = std::max<uint32_t>(1, std::min<uint32_t>(gpb_max, (uint32_t)(((uint64_t)s.n_tiles * groups) / min_wgs)));
     const uint32_t n_wgs = s.n_tiles * ((groups + gpb - 1) / gpb);
     const dim3 g(n_wgs), b(64);
     auto go = [&](auto kernel) {

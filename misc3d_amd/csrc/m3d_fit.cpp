@@ -397,7 +397,13 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             }
             // nothing to prune and every group prepared by minimal_fit_k: the box tests run inside the scoring launch
             bool scored_with_own_tests = false;
-            if (all_prepared && c32.out)
+            // (Round 6: OFF.  Fusing the box tests into the scoring launch paid in round 3, when cull_tiles32_k was 9 us of dependent
+            //  scalar loads; since round 5's staged records the two launches are the faster way round again -- C5's 165 clutter rounds
+            //  15.1 against 16.1 ms.  And the other direction is closed as well: ALL of a tile's groups in one scoring workgroup
+            //   -- with its own box tests 22.0 ms, behind precomputed masks 21.6 ms: 1528 one-wave workgroups leave
+            //  every wave's chain of dependent loads exposed, 12 228 of them hide it.  profiles/r06_c5_tail_rounds.txt)
+            constexpr bool kScoreWithOwnTests = false;
+            if (kScoreWithOwnTests && all_prepared && c32.out)
                 scored_with_own_tests = launch_score_own_tests(kind, sv, s.score.as<double>(), c32.out, masks, keep, n_groups, g1,
                                                                ctx->counts_rep.as<uint32_t>(), h_pad, pair_rep, ctx->stream,
                                                                timing ? s.k0 : nullptr, timing ? s.k1 : nullptr);
