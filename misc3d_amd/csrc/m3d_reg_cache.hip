@@ -10,16 +10,15 @@
 // validation are near-copies of one another (they passed the checkers), and a wave keeps its 64 source points for all the
 // hypotheses of its split: under a REFERENCE pose A (the incumbent) source point p sits at xa = A p, and under a hypothesis B
 // at x = B p, delta = |x - xa| of a few millimetres.  So, once per reference pose and source point (reg_cache_build_k):
-//   * the target points nearest to xa in TIERS of 32 -- the nearest 32, the next 32, the next 32 -- as fp32 offsets from xa, and
-//   * per tier a radius R_t with a CERTIFICATE: every target point that is NOT in tiers 0..t lies at least R_t from xa
+//   * the 32 target points nearest to xa as fp32 offsets from xa (in general: RINGS of kRegCacheK, kRegCacheTiers of them), and
+//   * per ring a radius R_t with a CERTIFICATE: every target point that is NOT in rings 0..t lies at least R_t from xa
 // (the target grid's (2B+1)^3 block around xa covers the ball of radius B h; a nine-way search on the radius finds the
 // largest R_t whose ball holds <= 32 (t + 1) points).  Then for any pose B every unlisted target point is at least R_t - delta
 // from x, and if the lists' minimum is below that, it is the minimum over the WHOLE target -- what the kd-tree returns.
 //
-// reg_validate_cached_k holds the 32 x 3 offsets of tier 0 of its lane's source point in 96 VGPRs across the whole hypothesis
-// loop and evaluates them with packed fp32 arithmetic, no memory access at all; a wave some of whose queries tier 0 cannot
-// certify (a pose further from the reference) streams the next tier from memory -- one coalesced 8-byte load per lane and
-// candidate pair -- and tries again with R_1, then R_2.  The winner's distance is formed in fp64 from the winner's fp64
+// reg_validate_cached_k holds the 32 x 3 offsets of its lane's source point in 96 VGPRs across the whole hypothesis loop and
+// evaluates them with packed fp32 arithmetic, no memory access at all (with several rings: ring by ring, a wave stopping as soon
+// as all its queries are settled).  The winner's distance is formed in fp64 from the winner's fp64
 // coordinates with reg_validate_k's own expression (one 32-byte gather per query), so counts AND sums are the same bits.
 // Certificates per query (s_j = fp32 squared distance to candidate j, m1 <= m2 the two smallest so far, E(s) the rounding
 // bound below, t = R (1 - 2^-20) - |u| (1 + 2^-20), u = fl32(x - xa)):
@@ -52,7 +51,8 @@ namespace {
 constexpr int kTierK = kRegCacheK;          // candidates per tier
 constexpr int kTiers = kRegCacheTiers;
 constexpr int kSlots = kTierK * kTiers;     // <= 128: the slot rides in seven mantissa bits
-static_assert(kSlots <= 128 && kTierK == 32, "slot packing / pad loop");
+static_assert(kSlots <= 128 && kSlots % 2 == 0 && kTierK % 2 == 0, "slot packing");
+// (every ring lives in registers: kSlots candidates in 3 kSlots VGPRs)
 
 __device__ __forceinline__ bool cache_cell_of(const GridDesc& g, double x, double y, double z, int lo_pad, int* ix, int* iy,
                                               int* iz) {   // (m3d_reg_kernels.hip: cell_of)
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int t = 0; t < kTiers; ++t) Rt[t] = c.R[(size_t)t * n_pad + base];
     const bool query = Rt[0] >= 0.0f;   // (false: padding, a non-finite point -- no match under any pose)
     const size_t cb = (size_t)tile * (kSlots / 2) * 256u + threadIdx.x;
-    f32x2_t CX[kTierK / 2], CY[kTierK / 2], CZ[kTierK / 2];   // tier 0 stays in registers
+    f32x2_t CX[kSlots / 2], CY[kSlots / 2], CZ[kSlots / 2];   // every tier stays in registers
 #pragma unroll
-    for (int k = 0; k < kTierK / 2; ++k) {
+    for (int k = 0; k < kSlots / 2; ++k) {
         const float2 a = c.cx[cb + (size_t)k * 256u], b = c.cy[cb + (size_t)k * 256u], d = c.cz[cb + (size_t)k * 256u];
         CX[k] = f32x2_t{a.x, a.y};
         CY[k] = f32x2_t{b.x, b.y};
@@ -400,12 +400,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const float du = __builtin_amdgcn_sqrtf(uu) * (1.0f + 0x1p-20f);   // |u| rounded up (v_sqrt_f32: 1 ulp, inside the 2^-20)
                 const f32x2_t U_x = {ux, ux}, U_y = {uy, uy}, U_z = {uz, uz};
                 uint32_t m1 = 0x7F800000u, m2 = 0x7F800000u;
-                // (a wave all of whose queries the pose has carried beyond their radius learns nothing from the lists: 18 % of the
-                //  wave-queries of C4's forced run, 260 instructions each)
-                if (__ballot(query && du < Rt[kTiers - 1]) != 0ull) {
-#pragma unroll
-                    for (int k = 0; k < kTierK / 2; ++k) cache_visit2(CX[k], CY[k], CZ[k], U_x, U_y, U_z, (uint32_t)(2 * k), m1, m2);
-                }
                 bool exact = !query, inl = false;
                 float lb2 = 0.0f;
                 double d2 = INFINITY;
@@ -436,28 +430,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         lb2 = l == l ? l : 0.0f;
                     }
                 };
-                certify(Rt[0]);
-#pragma unroll 1
-                for (int tier = 1; tier < kTiers; ++tier) {
-                    if (__ballot(!exact) == 0ull) break;   // (wave-uniform)
-                    n_tier++;
-                    // the next 32 candidates, streamed: one coalesced 8-byte load per lane, coordinate and pair, two pairs at a time
-#pragma unroll 1
-                    for (int k0 = 0; k0 < kTierK / 2; k0 += 2) {
-                        float2 ax[2], ay[2], az[2];
+                // (a wave all of whose queries the pose has carried beyond the outermost radius learns nothing from the lists)
+                if (__ballot(query && du < Rt[kTiers - 1]) != 0ull) {
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const size_t o = cb + (size_t)(tier * (kTierK / 2) + k0 + k) * 256u;
-                            ax[k] = c.cx[o];
-                            ay[k] = c.cy[o];
-                            az[k] = c.cz[o];
+                    for (int tier = 0; tier < kTiers; ++tier) {
+                        if (tier > 0) {
+                            if (__ballot(!exact) == 0ull) break;   // (wave-uniform: every query is settled by the nearer rings)
+                            n_tier++;
                         }
 #pragma unroll
-                        for (int k = 0; k < 2; ++k)
-                            cache_visit2(f32x2_t{ax[k].x, ax[k].y}, f32x2_t{ay[k].x, ay[k].y}, f32x2_t{az[k].x, az[k].y}, U_x, U_y, U_z,
-                                         (uint32_t)(tier * kTierK + 2 * (k0 + k)), m1, m2);
+                        for (int k = tier * (kTierK / 2); k < (tier + 1) * (kTierK / 2); ++k)
+                            cache_visit2(CX[k], CY[k], CZ[k], U_x, U_y, U_z, (uint32_t)(2 * k), m1, m2);
+                        certify(Rt[tier]);
                     }
-                    certify(Rt[tier]);
                 }
                 // The cell rings for what the lists could not settle: (ring - 1) whole empty cells lie between the query and every
                 // target point -- at least K of them: nothing within the search radius (exact); fewer: a lower bound

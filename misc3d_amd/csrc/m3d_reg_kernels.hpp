@@ -58,10 +58,12 @@ struct GridDesc {
 // (slot = tier * kRegCacheK + position): cx / cy / cz [tile][slot / 2][256], c64 [tile][slot][256], xa / ya / za [n_pad],
 // R [tier][n_pad]; stats[0 / 1]: (tile, hypothesis) pairs whose record the cache made exact / a bound; stats[2]: wave-queries
 // that went past tier 0.
+// One ring of 32, in registers (96 VGPRs).  Measured on C4's forced run (profiles/r06_reg_cache.txt): 95 ms.  THREE rings of 32
+// with the outer two streamed from memory: the pairs left without a certificate fall from 18 % to 6 %, but 182 instead of 152
+// VGPRs -- two waves per SIMD instead of three -- and the streamed loads: 126 ms.  TWO rings of 16, both in registers, the outer
+// skipped by a wave whose 64 queries are all settled by the inner: 94.4 ms and 9 spilled registers -- a wave rarely has all 64
+// settled at 16.  The kernels keep the rings general (slot = ring * kRegCacheK + position, cumulative packing).
 constexpr int kRegCacheK = 32;
-// 1: tier 0 only, in registers.  Three tiers were built and measured on C4's forced run (profiles/r06_reg_cache.txt): the
-// pairs left without a certificate fall from 18 % to 6 %, but the kernel pays 182 instead of 152 VGPRs (two waves per SIMD
-// instead of three) and the streamed tiers' loads: 126 ms against 112 -- the far poses are the cell rings' (RegCache::ring).
 constexpr int kRegCacheTiers = 1;
 struct RegCache {
     float2 *cx = nullptr, *cy = nullptr, *cz = nullptr;
