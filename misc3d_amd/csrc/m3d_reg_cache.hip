@@ -42,6 +42,7 @@
 #include <algorithm>
 #include <cstdint>
 
+#include "m3d_reg_cache_fp.hpp"
 #include "m3d_reg_kernels.hpp"
 
 namespace m3d {
@@ -315,8 +316,8 @@ __device__ __forceinline__ void cache_visit2(const f32x2_t cx, const f32x2_t cy,
                                              const f32x2_t U_y, const f32x2_t U_z, uint32_t slot0, uint32_t& m1, uint32_t& m2) {
     const f32x2_t dx = cx - U_x, dy = cy - U_y, dz = cz - U_z;
     const f32x2_t s = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-    const uint32_t a = (__float_as_uint(s.x) & ~127u) | slot0;
-    const uint32_t b = (__float_as_uint(s.y) & ~127u) | (slot0 + 1u);
+    const uint32_t a = (__float_as_uint(s.x) & ~kCacheSlotMask) | slot0;   // (cache_packed_s, two candidates per instruction)
+    const uint32_t b = (__float_as_uint(s.y) & ~kCacheSlotMask) | (slot0 + 1u);
     const uint32_t lo = min(a, b), hi = max(a, b);
     m2 = min(min(max(m1, lo), m2), hi);   // (m1 <= m2, lo <= hi): the second smallest of the four
     m1 = min(m1, lo);
@@ -404,30 +405,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 float lb2 = 0.0f;
                 double d2 = INFINITY;
                 // the certificates of a tier (radius R) on the minima so far, for the lanes that hold none yet
-                auto certify = [&](float R) {
+                auto certify = [&](float R) {   // (m3d_reg_cache_fp.hpp: cache_certify, the code tests/cpp/test_reg_cache.cpp checks)
                     if (exact) return;
-                    // what every UNLISTED target point keeps from the query, rounded down; a pose that carries the query beyond R --
-                    // or a NaN / inf pose -- leaves 0: no information
-                    const float tt = __builtin_fmaxf(R * (1.0f - 0x1p-20f) - du, 0.0f);
-                    const float f1 = __uint_as_float(m1), f2 = __uint_as_float(m2);   // (a NaN pose: NaN patterns, every test below fails)
-                    const float ER = R * R * 0x1p-23f;
-                    const float e1 = __builtin_fmaf(f1, 0x1p-15f, ER), e2 = __builtin_fmaf(f2, 0x1p-15f, ER);
-                    const float t2 = tt * tt;
-                    const bool covered = f1 + e1 < t2;                       // the nearest target point is in the lists
-                    const bool unique = f2 - e2 > f1 + e1;                   // ... and it is candidate j1, in fp64 as well
-                    const bool nothing = t2 >= r2hi && f1 - e1 >= r2hi;      // no target point within the search radius
-                    if (covered && unique) {
-                        const double4 w = c64[(size_t)(m1 & 127u) * 256u];
+                    const CacheVerdict v = cache_certify(m1, m2, R, du, r2hi);
+                    if (v.winner) {
+                        const double4 w = c64[(size_t)(m1 & kCacheSlotMask) * 256u];
                         const double ddx = px - w.x, ddy = py - w.y, ddz = pz - w.z;
                         d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                         inl = d2 < r2;
                         exact = true;
-                    } else if (!covered && nothing) {
+                    } else if (v.nothing) {
                         exact = true;
                     } else {
-                        // no certificate: min(f1 - e1, t^2) bounds the squared distance of the nearest target point from below
-                        const float l = __builtin_fmaxf(__builtin_fminf(f1 - e1, t2) * (1.0f - 0x1p-20f), 0.0f);
-                        lb2 = l == l ? l : 0.0f;
+                        lb2 = v.lb2;
                     }
                 };
                 // (a wave all of whose queries the pose has carried beyond the outermost radius learns nothing from the lists)

@@ -3,6 +3,7 @@ tests/cpp/test_screen_bounds.cpp restates the device arithmetic with fmaf / floa
 random scenes over eight orders of magnitude, offsets from the origin up to 1e5 scene sizes, points placed 1e-16 ... 1e-3
 thresholds from the cut-off on both sides -- through the screen and through the exact fp64 test.  No GPU needed."""
 import os
+import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,3 +68,22 @@ def test_plane_histogram_bound_holds_on_the_host():
     m = subprocess.run([os.path.join(cpp, "_build", "test_plane_bound_no_slack"), "20000"], capture_output=True, text=True, timeout=300)
     assert m.returncode != 0 and "all checks passed" not in m.stdout
     assert int(re.search(r"violations (\d+)", m.stdout).group(1)) > 1000, m.stdout
+
+
+def test_candidate_cache_certificates_hold_on_the_host():
+    """tests/cpp/test_reg_cache.cpp runs the candidate cache's arithmetic (misc3d_amd/csrc/m3d_reg_cache_fp.hpp: the code
+    reg_validate_cached_k runs, compiled by g++) against an exact nearest-neighbour search over ALL target points in long double --
+    noisy patches, lattices with exact ties, duplicates, clutter; coordinates at 0, 1e3 and 3e5 scene units; scales 1e-3 .. 1e3; poses
+    from a tenth of the list's radius to beyond it.  A certified winner must be THE nearest point (an exact tie must not be
+    certified), "nothing" must mean nothing within the radius, a bound must stay below the truth.  Two mutations -- the radius
+    taken 10 % too large, the rounding bound set to zero -- must be caught."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    for target in ("test_reg_cache", "test_reg_cache_inflate_r", "test_reg_cache_no_slack"):
+        subprocess.run(["make", "-C", cpp, "_build/" + target], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(cpp, "_build", "test_reg_cache"), "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "violations 0" in r.stdout, r.stdout + r.stderr
+    m = re.search(r"winner certified (\d+), nothing (\d+), bounds (\d+)", r.stdout)
+    assert m and int(m.group(1)) > 100_000 and int(m.group(2)) > 100 and int(m.group(3)) > 10_000, r.stdout
+    for target in ("test_reg_cache_inflate_r", "test_reg_cache_no_slack"):
+        r = subprocess.run([os.path.join(cpp, "_build", target), "300"], capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "violations 0" not in r.stdout, (target, r.stdout)

@@ -13,11 +13,13 @@ spec = importlib.util.spec_from_file_location("stress_round3", os.path.join(ROOT
 mod = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(mod)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+# (round 6: + the validation's candidate cache forced on from the first incumbent, with most of the time on registrations)
 for seed, cfg in ((201, {}), (202, {"plane_bound": 2}), (203, {"plane_bound": 2, "lanes": 1}),
-                  (204, {"plane_bound": 2, "score_fp32_screen": 0, "cull_fp32": 0})):
+                  (204, {"plane_bound": 2, "score_fp32_screen": 0, "cull_fp32": 0}), (205, {"reg_cache": 2}), (206, {"reg_cache": 2, "reg_prune": 0})):
+    reg_share = 0.7 if "reg_cache" in cfg else 0.2
     old = capi.set_config(**cfg)
     try:
-        n = mod.run(budget=budget * 0.8, reg_budget=budget * 0.2, seed=seed, log=lambda s: None)
+        n = mod.run(budget=budget * (1.0 - reg_share), reg_budget=budget * reg_share, seed=seed, log=lambda s: None)
     finally:
         capi.restore_config(old)
     print(seed, cfg, n, flush=True)
