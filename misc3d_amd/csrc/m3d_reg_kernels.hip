@@ -209,16 +209,18 @@ __global__ void add_tile_offsets_k(uint32_t* __restrict__ v, uint32_t n, const u
 __global__ void grid_scatter_k(CloudView dst, const uint32_t* __restrict__ cell_of_point,
                                const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ rank,
                                double* __restrict__ qx, double* __restrict__ qy, double* __restrict__ qz,
-                               uint32_t* __restrict__ orig) {
+                               uint32_t* __restrict__ orig, double4* __restrict__ q4) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= dst.n) return;
     const uint32_t cid = cell_of_point[i];
     if (cid == 0xFFFFFFFFu) return;
     const uint32_t pos = cell_start[cid] + rank[i];
-    qx[pos] = dst.x[i];
-    qy[pos] = dst.y[i];
-    qz[pos] = dst.z[i];
+    const double x = dst.x[i], y = dst.y[i], z = dst.z[i];
+    qx[pos] = x;
+    qy[pos] = y;
+    qz[pos] = z;
     if (orig) orig[pos] = i;
+    if (q4) q4[pos] = make_double4(x, y, z, 0.0);
 }
 
 __global__ void fill_nan_k(double* __restrict__ p, uint32_t n) {
@@ -269,15 +271,15 @@ void launch_grid_count_scan(const CloudView& dst, const GridDesc& g, uint32_t* c
     add_tile_offsets_k<<<(ncell + 1 + 255) / 256, 256, 0, s>>>(cell_start, ncell, tile_sums, total);
 }
 void launch_grid_scatter(const CloudView& dst, const uint32_t* cell_of_point, const uint32_t* cell_start,
-                         const uint32_t* rank, double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig) {
-    if (dst.n) grid_scatter_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, cell_of_point, cell_start, rank, qx, qy, qz, orig);
+                         const uint32_t* rank, double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig, double4* q4) {
+    if (dst.n) grid_scatter_k<<<(dst.n + 255) / 256, 256, 0, s>>>(dst, cell_of_point, cell_start, rank, qx, qy, qz, orig, q4);
 }
 void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
                        uint32_t* cell_start /* ncell + 1 */, uint32_t* rank /* one per point: dst.n */,
                        uint32_t* tile_sums, uint32_t* total, double* qx, double* qy, double* qz,
-                       hipStream_t s, uint32_t* orig) {
+                       hipStream_t s, uint32_t* orig, double4* q4) {
     launch_grid_count_scan(dst, g, cell_of_point, cell_start, rank, tile_sums, total, s, 0, 1);
-    launch_grid_scatter(dst, cell_of_point, cell_start, rank, qx, qy, qz, s, orig);
+    launch_grid_scatter(dst, cell_of_point, cell_start, rank, qx, qy, qz, s, orig, q4);
 }
 
 // Neighbour lists: for every interior cell the points of its 3x3x3 block, packed (x, y, z, 0) and
@@ -790,16 +792,41 @@ __device__ __forceinline__ double nearest_d2(const GridDesc& g, const uint32_t* 
             }
         }
     } else {
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy) {
-                const uint32_t row = ((uint32_t)(iz + dz) * g.ny + (uint32_t)(iy + dy)) * g.nx + (uint32_t)ix;
-                const uint32_t b = cell_start[row - 1], e = cell_start[row + 2];
-                for (uint32_t c = b; c < e; ++c) {
+        // (no lists: a call that validates a handful of hypotheses -- the reference's default confidence.  Round 6: the nine rows'
+        //  bounds requested together, the candidates as 32-byte records, four in flight per trip: on C4's default-confidence call
+        //  reg_min_d2_k 152 -> 87 us, reg_validate_k<false> 350 -> 315 us -- it is the record format that paid, the loads'
+        //  order did not: with the source in its original order a wave's 64 queries touch 64 different cells.)
+        uint32_t rb[9], re[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const uint32_t row = ((uint32_t)(iz + k / 3 - 1) * g.ny + (uint32_t)(iy + k % 3 - 1)) * g.nx + (uint32_t)ix;
+            rb[k] = cell_start[row - 1];
+            re[k] = cell_start[row + 2];
+        }
+        if (g.q4) {   // (x, y, z) of a candidate in ONE 32-byte gather, four candidates in flight per trip (the tail repeats the
+                      // row's last one: min is idempotent) -- one candidate per trip was a chain of ~45 dependent round trips per query
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                for (uint32_t c = rb[k]; c < re[k]; c += 4u) {
+                    double4 q[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) q[j] = g.q4[min(c + j, re[k] - 1u)];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const double ddx = px - q[j].x, ddy = py - q[j].y, ddz = pz - q[j].z;
+                        const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                        if (d2 < best) best = d2;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                for (uint32_t c = rb[k]; c < re[k]; ++c) {
                     const double ddx = px - qx[c], ddy = py - qy[c], ddz = pz - qz[c];
                     const double d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                     if (d2 < best) best = d2;
                 }
-            }
+        }
     }
 #ifdef M3D_REG_TRIP_STATS
     if (SCREEN && g.nl32_fallbacks) {   // (diagnostic build: where do the queries end?  profiles/r05_reg_query_fates.txt)

@@ -48,6 +48,9 @@ struct GridDesc {
     // K + 1).  A query more than K rings out has no target point within the radius: the search returns at once instead of
     // scanning (2K + 1)^3 cells to find that out.
     const uint8_t* ring = nullptr;
+    // optional (round 6): the cell-sorted points once more as (x, y, z, 0) records -- ONE 32-byte gather per candidate instead of
+    // three 8-byte ones in the list-free search (a call that validates a handful of hypotheses never builds the lists)
+    const double4* q4 = nullptr;
 };
 
 
@@ -93,14 +96,15 @@ void launch_gather_T(const double* T12, const uint32_t* list, uint32_t n, uint32
 void launch_grid_build(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point,
                        uint32_t* cell_start, uint32_t* rank /* scratch, ONE ENTRY PER POINT (dst.n) */,
                        uint32_t* tile_sums, uint32_t* total,
-                       double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr);
+                       double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr, double4* q4 = nullptr /* GridDesc::q4 */);
 // the two halves of launch_grid_build; pad_to > 1 pads every group of pad_group consecutive cells to a multiple of pad_to
 // slots (the caller pre-fills the arrays: the slots between the runs keep that value); total[0] = length of the layout
 void launch_grid_count_scan(const CloudView& dst, const GridDesc& g, uint32_t* cell_of_point, uint32_t* cell_start,
                             uint32_t* rank, uint32_t* tile_sums, uint32_t* total, hipStream_t s, uint32_t pad_to = 0,
                             uint32_t pad_group = 1);
 void launch_grid_scatter(const CloudView& dst, const uint32_t* cell_of_point, const uint32_t* cell_start,
-                         const uint32_t* rank, double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr);
+                         const uint32_t* rank, double* qx, double* qy, double* qz, hipStream_t s, uint32_t* orig = nullptr,
+                         double4* q4 = nullptr);
 void launch_signal_host(uint32_t* word /* page-locked, device-visible */, uint32_t value, hipStream_t st);
 void launch_fill_nan(double* p, uint32_t n, hipStream_t s);
 void launch_nl_count(const GridDesc& g, const uint32_t* cell_start, uint32_t* nl_start, uint32_t* tile_sums,

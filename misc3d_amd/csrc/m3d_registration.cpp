@@ -64,14 +64,14 @@ int ceil_to_int_x86(double v) {
 struct Scratch {  // per-call device buffers (registration calls are rare and large: no caching)
     DevBuf corr_src, corr_dst, triples, T12, pass, list, Ts, partial, counts, cell_of_point, cell_start, fill,
         tile_sums, total, qx, qy, qz, best, vals, block_counts, sums, one_T, ratio, partial_sum, sum2,
-        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, nl32_fallbacks, cell_orig, tile_sph,
+        s_cell_of_point, s_cell_start, s_fill, s_tile_sums, sx, sy, sz, keep, nl_start, nl_pts, nl_hdr, nl32, nl_rec, nl32_start, nl32_fallbacks, cell_orig, tile_sph, q4,
         cc_x, cc_y, cc_z, cc_64, cc_xa, cc_ya, cc_za, cc_R, cc_stats, cc_redo, cc_ring, cc_ring_tmp, cc_pairs;   // the validation's candidate cache (m3d_reg_cache.hip)
     void release() {
         for (DevBuf* b : {&corr_src, &corr_dst, &triples, &T12, &pass, &list, &Ts, &partial, &counts,
                           &cell_of_point, &cell_start, &fill, &tile_sums, &total, &qx, &qy, &qz, &best, &vals,
                           &block_counts, &sums, &one_T, &ratio, &partial_sum, &sum2, &s_cell_of_point,
                           &s_cell_start, &s_fill, &s_tile_sums, &sx, &sy, &sz, &keep, &nl_start, &nl_pts, &nl_hdr, &nl32, &nl_rec, &nl32_start, &nl32_fallbacks, &cell_orig,
-                          &tile_sph, &cc_x, &cc_y, &cc_z, &cc_64, &cc_xa, &cc_ya, &cc_za, &cc_R, &cc_stats, &cc_redo, &cc_ring, &cc_ring_tmp, &cc_pairs})
+                          &tile_sph, &q4, &cc_x, &cc_y, &cc_z, &cc_64, &cc_xa, &cc_ya, &cc_za, &cc_R, &cc_stats, &cc_redo, &cc_ring, &cc_ring_tmp, &cc_pairs})
             b->release();
     }
 };
@@ -162,9 +162,11 @@ int build_target_grid(DeviceCtx* ctx, Scratch& S, const CloudView& dst_view, con
     RESERVE(S.qz, sizeof(double) * n_dst);
     if (with_orig) RESERVE(S.cell_orig, sizeof(uint32_t) * n_dst);
     uint32_t* orig = with_orig ? S.cell_orig.as<uint32_t>() : nullptr;
+    RESERVE(S.q4, sizeof(double4) * std::max<size_t>(n_dst, 1));
+    g.q4 = S.q4.as<double4>();
     launch_grid_build(dst_view, g, S.cell_of_point.as<uint32_t>(), S.cell_start.as<uint32_t>(),
                       S.fill.as<uint32_t>(), S.tile_sums.as<uint32_t>(), S.total.as<uint32_t>(),
-                      S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream, orig);
+                      S.qx.as<double>(), S.qy.as<double>(), S.qz.as<double>(), ctx->stream, orig, S.q4.as<double4>());
     if (with_nl) {
         const int rn = add_neighbour_lists(ctx, S, &g, n_dst, orig);
         if (rn != M3D_OK) return rn;
