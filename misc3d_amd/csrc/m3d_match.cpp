@@ -133,7 +133,7 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
         if (!s2 || !cs || !aux_event_of(ctx, 2 * (QA + PB))) return M3D_ERR_DEVICE;
     }
     DevBuf part_min, ns2, nd2, ring, ring_count, evict, over_list, scal, pA_s, pA_d, pB_s, pB_d, premin, rev_premin, rthr, rcnt, rcand,
-        rlist, rlist_cnt, over_list_r, mabs;
+        rlist, rlist_cnt, over_list_r, mabs, rperm;
     bool in_flight = false;   // work queued on s2 / cs that s has not been made to wait for
     auto done = [&](int r) {
         if (r != 0 && in_flight) {   // a failure half-way: nothing of this call may still run when its blocks go back
@@ -142,7 +142,7 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
             (void)hipStreamSynchronize(s);
         }
         for (DevBuf* b : {&part_min, &ns2, &nd2, &ring, &ring_count, &evict, &over_list, &scal, &pA_s, &pA_d, &pB_s, &pB_d, &premin,
-                          &rev_premin, &rthr, &rcnt, &rcand, &rlist, &rlist_cnt, &over_list_r, &mabs})
+                          &rev_premin, &rthr, &rcnt, &rcand, &rlist, &rlist_cnt, &over_list_r, &mabs, &rperm})
             b->release();
         return r;
     };
@@ -198,7 +198,8 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
         !rev_premin.reserve(sizeof(float) * (size_t)2 * w.splits_r * nb) || !rthr.reserve(sizeof(float) * 40 * (size_t)b_tiles * qa.size()) ||
         !rcnt.reserve(sizeof(uint32_t) * nb) || !rcand.reserve(sizeof(uint2) * (size_t)kMatchRevCap * nb) ||
         !rlist.reserve(sizeof(uint2) * (size_t)kMatchRevLane * part) || !rlist_cnt.reserve(sizeof(uint32_t) * part) ||
-        !over_list_r.reserve(sizeof(uint32_t) * nb) || !mabs.reserve(sizeof(double) * kMaxAbsPartials * n_cuts))
+        !over_list_r.reserve(sizeof(uint32_t) * nb) || !mabs.reserve(sizeof(double) * kMaxAbsPartials * n_cuts) ||
+        !rperm.reserve(sizeof(uint32_t) * 32 * (size_t)b_tiles))
         return done(M3D_ERR_DEVICE);
     w.qB_a = pB_s.p;
     w.dA_a = pA_s.p;
@@ -219,6 +220,7 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
     w.rev_premin = rev_premin.as<float>();
     w.rthr = rthr.as<float>();
     w.rcnt = rcnt.as<uint32_t>();
+    w.rperm = rperm.as<uint32_t>();
     w.rcand = rcand.as<uint2>();
     w.rlist = rlist.as<uint2>();
     w.rlist_cnt = rlist_cnt.as<uint32_t>();
@@ -301,6 +303,7 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
     int e2;
     (void)std::frexp(mx0, &e2);   // mx0 = f * 2^e2, f in [0.5, 1)
     const double scale = std::ldexp(1.0, (sliced ? 10 : 11) - e2);
+    w.scale = scale;
 
     // ---- pack / warm up / scan, block by block --------------------------------------------------------------------------------
     ok = ok && hipMemsetAsync(sc, 0, 4 * sizeof(float), s) == hipSuccess;
@@ -316,7 +319,10 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
         }
         if (pb[p].rows) match_pack(w, 1, pb[p].row0, pb[p].rows, scale, st);
         if (p == 0) match_forward_warm(w, qa[0].row0, qa[0].rows, st);
-        if (pb[p].rows) match_reverse_thresholds(w, pb[p].row0, pb[p].rows, 0, st);
+        if (pb[p].rows) {
+            match_reverse_thresholds(w, pb[p].row0, pb[p].rows, 0, st);
+            match_order_part(w, pb[p].row0, pb[p].rows, st);   // (the part's database layout once more, in the thresholds' order)
+        }
         prev = mark(st);
         match_scan(w, qa[0].row0, qa[0].rows, (uint32_t)p * spp, spp, w.plan.end((uint32_t)(p + 1) * spp - 1), 0, st);
         if (st != s) scanned.push_back(mark(st));

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void nn64_verify_k(const double* __restrict__ 
                               const float* __restrict__ part_min, const float* __restrict__ evict_min,
                               uint32_t splits, float e_coeff, float e_abs, float max_dn2_v, const float* __restrict__ max_dn2_p,
                               const float* __restrict__ qn2, uint32_t* __restrict__ nn, uint32_t* __restrict__ overflow_list,
-                              uint32_t* __restrict__ overflow_count, uint32_t q_base) {
+                              uint32_t* __restrict__ overflow_count, uint32_t q_base, const uint32_t* __restrict__ perm) {
+    // (perm: the rings carry positions in the packed database, perm[position] = row -- match_order_part; null: rows)
     // (q, qn2, nn and the per-query arrays address the launch's nq queries, the first of which is query q_base of the whole matrix --
     // what the overflow list carries; max |row|^2 of the database: the device cell when there is one, else the host's value)
     const uint32_t i = blockIdx.x * 32u + (threadIdx.x >> 3), sub = threadIdx.x & 7u;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void nn64_verify_k(const double* __restrict__ 
         for (uint32_t t = 0; t < live; ++t) {
             const uint2 e = ring[o * kRing + (first + t) % kRing];
             if (!(__uint_as_float(e.y) <= win)) continue;   // stale: was only near an earlier running minimum
-            const uint32_t j = e.x;
+            const uint32_t j = perm ? perm[e.x] : e.x;
             double acc = 0.0;
             for (int k = 0; k < dim; ++k) {
                 const double df = q[(size_t)i * dim + k] - db[(size_t)j * dim + k];
@@ -426,7 +427,7 @@ hipError_t launch_nn_screened33(const double* q, const float* q32, const float* 
     nn32_scan_k<<<dim3((nq + 511) / 512, splits), 256, 0, s>>>(q32, nq, d32, ndb, per, e_coeff, max_dn2, ring,
                                                               ring_count, part_min, evict_min);
     nn64_verify_k<<<(nq + 31) / 32, 256, 0, s>>>(q, nq, db, DIM, ring, ring_count, part_min, evict_min, splits,
-                                                   e_coeff, 0.0f, max_dn2, nullptr, qn, nn, overflow_list, overflow_count, 0u);
+                                                   e_coeff, 0.0f, max_dn2, nullptr, qn, nn, overflow_list, overflow_count, 0u, nullptr);
     hipError_t e = hipMemcpyAsync(h_overflow, overflow_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return e;
@@ -548,9 +549,11 @@ void launch_max_abs(const double* f, size_t count, double* partial /* kMaxAbsPar
 // and every lane stores its MFMA fragment -- eight consecutive K-slots of one row -- as one 16-byte word per step and layout.
 // The same values bit for bit: hi = RN16(v scale), the norm summed over k = 0 .. 32 in order from hi + lo in fp64.
 #if M3D_MATCH_HI_ONLY
+// perm (match_order_part): row r of tile t is row perm[32 t + r] - perm_base of f, only the database layout is written, no norms
 __global__ __launch_bounds__(256) void pack_f16_both_k(const double* __restrict__ f, uint32_t n, uint32_t tiles_a, uint32_t tiles_b,
                                                         double scale, h8* __restrict__ out_a, h8* __restrict__ out_b,
-                                                        float* __restrict__ norm2) {
+                                                        float* __restrict__ norm2, const uint32_t* __restrict__ perm,
+                                                        uint32_t perm_base) {
     static_assert(kMfmaHiOnly && kMfmaK == 48 && kMfmaNormAt == 33, "the cooperative packer writes the hi-only layout");
     __shared__ _Float16 hi16[4][32][kMfmaK];   // [wave][row][K-slot]: data 0 .. 32, the row's norm pieces 33 .. 35, zero behind
     __shared__ double sq[4][32][34];            // (hi + lo)^2 per element (34: the rows of a half-wave fall on different banks)
@@ -562,8 +565,9 @@ __global__ __launch_bounds__(256) void pack_f16_both_k(const double* __restrict_
         const uint32_t r = e / 33u, k = e % 33u;
         _Float16 hi = (_Float16)0.0f;
         double rep2 = 0.0;
-        if (first + e < total) {
-            const double v = f[first + e] * scale;
+        const uint32_t src = perm ? perm[t * 32u + r] - perm_base : t * 32u + r;   // (one tile's 32 entries: broadcast loads)
+        if (perm ? src < n : first + e < total) {
+            const double v = f[perm ? (size_t)src * 33u + k : first + e] * scale;
             hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (double)hi);
             const double rep = (double)hi + (double)lo;
@@ -576,10 +580,10 @@ __global__ __launch_bounds__(256) void pack_f16_both_k(const double* __restrict_
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (lane < 32u) {   // lane r: the norm of row r, summed in pack_f16_k's order
-        const uint32_t i = t * 32u + lane;
+        const uint32_t i = perm ? perm[t * 32u + lane] - perm_base : t * 32u + lane;
         double nrm = 0.0;
         for (int k = 0; k < 33; ++k) nrm += sq[wave][lane][k];
-        if (i < n) norm2[i] = (float)nrm;
+        if (i < n && !perm) norm2[i] = (float)nrm;
         // the norm's three fp16 pieces (padding rows carry 65504 in both roles: as a database row never the nearest, as a query beyond
         // every threshold of the reverse search -- the scan's hot predicates then need no "is this a real row / query" term)
         double pa = i < n ? nrm / (double)kMfmaC : 65504.0, pb = pa;
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(256) void pack_f16_both_k(const double* __restrict_
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint32_t r = lane & 31u, hb = lane >> 5;
-    const bool real = t * 32u + r < n;   // (a padding row's data slots are +0 in both layouts)
+    const bool real = (perm ? perm[t * 32u + r] - perm_base : t * 32u + r) < n;   // (a padding row's data slots are +0 in both layouts)
     const _Float16 c = (_Float16)kMfmaC;
 #pragma unroll
     for (int st = 0; st < kMfmaSteps; ++st) {
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256) void pack_f16_both_k(const double* __restrict_
             b[j] = k < 33 ? v : (k < 36 ? c : (k < 39 ? v : (_Float16)0.0f));
         }
         if (t < tiles_a) out_a[((size_t)t * kMfmaSteps + st) * 64 + lane] = a;
-        if (t < tiles_b) out_b[((size_t)t * kMfmaSteps + st) * 64 + lane] = b;
+        if (t < tiles_b && !perm) out_b[((size_t)t * kMfmaSteps + st) * 64 + lane] = b;
     }
 }
 #endif
@@ -619,7 +623,8 @@ void launch_pack_f16_both(const double* f, uint32_t n, double scale, void* out_a
     const uint32_t ta = mfma_tiles(n), tb = mfma_query_tiles(n), tm = std::max(ta, tb);
     if (!tm) return;
 #if M3D_MATCH_HI_ONLY
-    pack_f16_both_k<<<(tm + 3) / 4, 256, 0, s>>>(f, n, ta, tb, scale, reinterpret_cast<h8*>(out_a), reinterpret_cast<h8*>(out_b), norm2);
+    pack_f16_both_k<<<(tm + 3) / 4, 256, 0, s>>>(f, n, ta, tb, scale, reinterpret_cast<h8*>(out_a), reinterpret_cast<h8*>(out_b), norm2,
+                                                 nullptr, 0u);
 #else
     launch_pack_f16(f, n, ta, scale, 0, out_a, norm2, s);
     launch_pack_f16(f, n, tb, scale, 1, out_b, norm2, s);
@@ -638,11 +643,13 @@ void launch_pack_f16(const double* f, uint32_t n, uint32_t n_tiles, double scale
 // sends it to the exact fallback.  Rows >= n of the last tile: -inf.
 __global__ void rev_threshold_k(const float* __restrict__ premin, uint32_t slices, uint32_t n, uint32_t n_pad,
                                 const float* __restrict__ n2, const float* __restrict__ max_other_n2_p, float* __restrict__ thr,
-                                uint32_t* __restrict__ cnt, bool first_set) {
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= n_pad) return;
+                                uint32_t* __restrict__ cnt, bool first_set, const uint32_t* __restrict__ perm, uint32_t perm_base) {
+    // (perm: thr[p] is the threshold of the row at position p of the ordered part, perm[p] - perm_base of the part's rows)
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_pad) return;
+    const uint32_t j = perm ? perm[p] - perm_base : p;
     if (j >= n) {
-        thr[j] = -INFINITY;
+        thr[p] = -INFINITY;
         return;
     }
     float m = INFINITY;
@@ -650,7 +657,7 @@ __global__ void rev_threshold_k(const float* __restrict__ premin, uint32_t slice
     const float two_e = 2.0f * (kMfmaECoeff * (n2[j] + *max_other_n2_p) + kMfmaEAbs) * 1.000001f + 1e-30f;
     const float t = m + two_e;
     const bool usable = t < INFINITY && m == m;
-    thr[j] = usable ? t : -INFINITY;
+    thr[p] = usable ? t : -INFINITY;
     // (a later set of thresholds -- the same minima under the norm bound of more queries -- keeps the counters of the scans so far)
     if (first_set) cnt[j] = usable ? 0u : 0x80000000u;
     else if (!usable) atomicOr(cnt + j, 0x80000000u);
@@ -663,17 +670,61 @@ __global__ void rev_threshold4_k(const float* __restrict__ thr, uint32_t n_group
     thr4[g] = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
 }
 
+// The rows of a part ordered by threshold within chunks of kOrderChunk consecutive rows (one workgroup per chunk, a bitonic
+// network in the LDS; descending, equal thresholds by row: the order is a function of the thresholds alone).  Why: the scan tests a
+// lane's minimum over 16 rows against the LARGEST of their thresholds; in the caller's order the thresholds of neighbouring rows
+// differ by octaves (they follow the local density of the descriptors) and the test let 11.4 M of 39 M side-tiles into the slow
+// path for 2.4 M candidates (200 k x 200 k, tools/gpu/scan_sorted_probe.py); ordered, 2.4 M.  Within chunks only: ordered as a
+// whole, the dense rows come last and every query's running minimum keeps improving to the end (ring appends 3.5 M -> 9.2 M).
+constexpr uint32_t kOrderChunk = 1024;
+__global__ __launch_bounds__(256) void rev_order_k(float* __restrict__ thr, uint32_t n_pad, uint32_t* __restrict__ perm, uint32_t perm_base) {
+    __shared__ unsigned long long key[kOrderChunk];
+    const uint32_t c0 = blockIdx.x * kOrderChunk;
+    for (uint32_t i = threadIdx.x; i < kOrderChunk; i += 256u) {
+        unsigned long long k = ~0ull;   // (past the part's end: behind everything)
+        if (c0 + i < n_pad) {
+            const uint32_t b = __float_as_uint(thr[c0 + i]);
+            const uint32_t asc = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // the floats' order as unsigned integers
+            k = ((unsigned long long)(~asc) << 32) | i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= kOrderChunk; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < kOrderChunk / 2; t += 256u) {
+                const uint32_t lo = 2u * t - (t & (stride - 1u)), hi = lo + stride;
+                const bool up = (lo & size) == 0u;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) {
+                    key[lo] = b;
+                    key[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < kOrderChunk; i += 256u) {
+        if (c0 + i >= n_pad) continue;
+        const unsigned long long k = key[i];
+        const uint32_t asc = ~(uint32_t)(k >> 32);
+        thr[c0 + i] = __uint_as_float(asc ^ ((asc >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        perm[c0 + i] = perm_base + c0 + (uint32_t)k;
+    }
+}
+
 // the scan's per-(slice, query) candidate lists sorted by database row: entry (row, d16) of query q -> slot of row
 __global__ void rev_bin_k(const uint2* __restrict__ list, const uint32_t* __restrict__ list_cnt, uint32_t nq, size_t lists,
-                          uint32_t* __restrict__ cnt, uint2* __restrict__ cand, uint32_t q_base) {
+                          uint32_t* __restrict__ cnt, uint2* __restrict__ cand, uint32_t q_base, const uint32_t* __restrict__ perm) {
     const size_t o = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (o >= lists) return;
     const uint32_t c = list_cnt[o];   // <= kRevLane (a full list sends the rest straight to the rows' slots)
     const uint32_t q = q_base + (uint32_t)(o % nq);
     for (uint32_t t = 0; t < c; ++t) {
         const uint2 e = list[o * kRevLane + t];
-        const uint32_t slot = atomicAdd(cnt + e.x, 1u) & 0x7FFFFFFFu;
-        if (slot < (uint32_t)kRevCap) cand[(size_t)e.x * kRevCap + slot] = make_uint2(q, e.y);
+        const uint32_t row = perm[e.x];   // (the lists carry positions in the packed database)
+        const uint32_t slot = atomicAdd(cnt + row, 1u) & 0x7FFFFFFFu;
+        if (slot < (uint32_t)kRevCap) cand[(size_t)row * kRevCap + slot] = make_uint2(q, e.y);
     }
 }
 
@@ -762,9 +813,20 @@ void match_reverse_thresholds(const MatchWork& w, uint32_t row0, uint32_t rows, 
     float* thr = w.rthr + (size_t)set * 40u * b_tiles;   // (a set: 32 row + 8 run thresholds per tile of b)
     float* thr4 = thr + (size_t)b_tiles * 32u;
     const uint32_t pad = ((rows + 31u) / 32u) * 32u;
+    // set 0: in the rows' order (match_order_part orders them next); later sets: straight into the order set 0 found
     rev_threshold_k<<<(pad + 255) / 256, 256, 0, s>>>(premin, 2 * w.splits_r, rows, pad, w.bn2 + row0, w.max_an2, thr + row0,
-                                                       w.rcnt + row0, set == 0);
+                                                       w.rcnt + row0, set == 0, set == 0 ? nullptr : w.rperm + row0, row0);
+    if (set != 0) rev_threshold4_k<<<(pad / 4u + 255) / 256, 256, 0, s>>>(thr + row0, pad / 4u, thr4 + row0 / 4u);
+}
+void match_order_part(const MatchWork& w, uint32_t row0, uint32_t rows, hipStream_t s) {
+    const uint32_t b_tiles = mfma_tiles(w.nb), pad = ((rows + 31u) / 32u) * 32u;
+    float* thr = w.rthr;   // (set 0)
+    float* thr4 = thr + (size_t)b_tiles * 32u;
+    rev_order_k<<<(pad + kOrderChunk - 1) / kOrderChunk, 256, 0, s>>>(thr + row0, pad, w.rperm + row0, row0);
     rev_threshold4_k<<<(pad / 4u + 255) / 256, 256, 0, s>>>(thr + row0, pad / 4u, thr4 + row0 / 4u);
+    h8* dA = reinterpret_cast<h8*>(w.dA_b) + (size_t)(row0 / 32u) * mfma_tile_entries();
+    const uint32_t ta = pad / 32u;
+    pack_f16_both_k<<<(ta + 3) / 4, 256, 0, s>>>(w.b + (size_t)row0 * 33, rows, ta, 0u, w.scale, dA, nullptr, nullptr, w.rperm + row0, row0);
 }
 void match_scan(const MatchWork& w, uint32_t q0, uint32_t nq, uint32_t split0, uint32_t splits, uint32_t tile_end, int set,
                 hipStream_t s) {
@@ -778,6 +840,7 @@ void match_scan(const MatchWork& w, uint32_t q0, uint32_t nq, uint32_t split0, u
     rev.list = w.rlist + base * kRevLane;
     rev.list_cnt = w.rlist_cnt + base;
     rev.q_base = q0;
+    rev.perm = w.rperm;
     const h8* qB = reinterpret_cast<const h8*>(w.qB_a) + (size_t)(q0 / 32u) * mfma_tile_entries();
     launch_nn16_scan(qB, w.an2 + q0, nq, w.dA_b, w.nb, std::min(tile_end, b_tiles), w.plan, split0, splits, 2 * w.splits, w.max_bn2,
                      w.premin + base, w.ring + base * kRing, w.ring_count + base, w.part_min + base, w.evict_min + base, s, &rev);
@@ -786,11 +849,11 @@ void match_verify_forward(const MatchWork& w, uint32_t q0, uint32_t nq, hipStrea
     const size_t base = (size_t)2 * w.splits * q0;
     nn64_verify_k<<<(nq + 31) / 32, 256, 0, s>>>(w.a + (size_t)q0 * 33, nq, w.b, 33, w.ring + base * kRing, w.ring_count + base,
                                                    w.part_min + base, w.evict_min + base, 2 * w.splits, kMfmaECoeff, kMfmaEAbs, 0.0f,
-                                                   w.max_bn2, w.an2 + q0, w.nn_ab + q0, w.overflow_list, w.overflow_count, q0);
+                                                   w.max_bn2, w.an2 + q0, w.nn_ab + q0, w.overflow_list, w.overflow_count, q0, w.rperm);
 }
 void match_reverse_bin(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_t s) {
     const size_t base = (size_t)2 * w.splits * q0, lists = (size_t)2 * w.splits * nq;
-    rev_bin_k<<<(uint32_t)((lists + 255) / 256), 256, 0, s>>>(w.rlist + base * kRevLane, w.rlist_cnt + base, nq, lists, w.rcnt, w.rcand, q0);
+    rev_bin_k<<<(uint32_t)((lists + 255) / 256), 256, 0, s>>>(w.rlist + base * kRevLane, w.rlist_cnt + base, nq, lists, w.rcnt, w.rcand, q0, w.rperm);
 }
 void match_verify_reverse(const MatchWork& w, hipStream_t s) {
     nn64_verify_rev_k<<<(w.nb + 31) / 32, 256, 0, s>>>(w.b, w.nb, w.a, 33, w.rcnt, w.rcand, w.bn2, w.max_an2, w.nn_ba,

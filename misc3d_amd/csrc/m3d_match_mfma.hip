@@ -10,6 +10,18 @@
 
 namespace m3d {
 
+#ifdef M3D_SCAN_STATS   // (diagnostic build: how often the slow paths are entered)
+__device__ unsigned long long g_scan_stats[8];
+#define SCAN_STAT(i) atomicAdd(&g_scan_stats[i], 1ull)
+__global__ void scan_stats_print_k() {
+    printf("scan stats: side-tiles with a ring entry %llu, with a rev entry %llu, rev runs entered %llu, rev candidates (lane-rows) %llu, "
+           "ring appends (lane-rows) %llu, side-tiles where tmin <= max of the 4 run thresholds %llu\n",
+           g_scan_stats[0], g_scan_stats[1], g_scan_stats[2], g_scan_stats[3], g_scan_stats[4], g_scan_stats[5]);
+    for (int i = 0; i < 8; ++i) g_scan_stats[i] = 0;
+}
+#else
+#define SCAN_STAT(i) ((void)0)
+#endif
 // Per tile and query tile: 16 distances per lane.  The running minimum is updated unconditionally; rows are
 // appended when they lie within the window of the minimum INCLUDING this tile (still a superset of the final
 // window).  A wave carries 128 rings, so early in a scan some lane has a new record in most tiles: the append path is
@@ -76,15 +88,102 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, uin
         const bool hit = v <= t;   // (a padding query's distances are beyond every threshold, a padding row's threshold is -inf)
         if (any_lane(hit)) {
             if (hit) {
+                SCAN_STAT(3);
                 const uint32_t row = row0 + (uint32_t)(k + 8 * G);
                 if (cnt < (uint32_t)kRevLane) {
                     my[cnt++] = make_uint2(row, __float_as_uint(v));
                 } else {   // list full: straight into the row's slots (what rev_bin_k does with the listed ones)
-                    const uint32_t slot = atomicAdd(rev.cnt + row, 1u) & 0x7FFFFFFFu;
-                    if (slot < (uint32_t)kRevCap) rev.cand[(size_t)row * kRevCap + slot] = make_uint2(rev.q_base + q, __float_as_uint(v));
+                    const uint32_t orig = rev.perm[row];
+                    const uint32_t slot = atomicAdd(rev.cnt + orig, 1u) & 0x7FFFFFFFu;
+                    if (slot < (uint32_t)kRevCap) rev.cand[(size_t)orig * kRevCap + slot] = make_uint2(rev.q_base + q, __float_as_uint(v));
                 }
             }
         }
+    }
+}
+
+// ---- the interleaved loop's pieces (M3D_SCAN_INTERLEAVE) ------------------------------------------------------------------
+// What a side's fast path leaves behind: the run minima and five lane masks (SGPR pairs).  Everything branch-free, so that
+// it can stand BETWEEN the matrix instructions of the other side's chain.
+struct FastOut {
+    float g[4];
+    uint64_t ring = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+};
+template <bool MIN_ONLY, bool REV>
+__device__ __forceinline__ void post_fast_b(FastOut& f, ScanState& st, float two_e, const float4& t4) {
+    const float tmin = fminf(fminf(f.g[0], f.g[1]), fminf(f.g[2], f.g[3]));
+    st.best = fminf(st.best, tmin);
+    if (!MIN_ONLY) {
+        st.win = st.best + two_e;
+        f.ring = __builtin_amdgcn_ballot_w64(tmin <= st.win);
+    }
+    if (REV) {
+#if M3D_SCAN_REV_TILE_TEST
+        // ONE test per side: the rows come ordered by threshold (rev_order_k), the largest of a lane's sixteen is hardly above the
+        // others -- 2.8 M side-tiles of 39 M pass it for 2.4 M with a candidate (four run tests: 2.5 M)
+        f.r0 = __builtin_amdgcn_ballot_w64(tmin <= t4.x);   // (t4.x: the caller's maximum of the four run thresholds)
+#else
+        f.r0 = __builtin_amdgcn_ballot_w64(f.g[0] <= t4.x);
+        f.r1 = __builtin_amdgcn_ballot_w64(f.g[1] <= t4.y);
+        f.r2 = __builtin_amdgcn_ballot_w64(f.g[2] <= t4.z);
+        f.r3 = __builtin_amdgcn_ballot_w64(f.g[3] <= t4.w);
+#endif
+#ifdef M3D_SCAN_STATS
+        if (any_lane(tmin <= fmaxf(fmaxf(t4.x, t4.y), fmaxf(t4.z, t4.w))) && (threadIdx.x & 63) == 0) SCAN_STAT(5);
+#endif
+    }
+}
+// the slow paths of a side: mfma_post's append and the reverse search's rows, behind ONE wave-uniform branch
+template <bool REV>
+__device__ __forceinline__ void post_slow(const f32x16& acc, const FastOut& f, ScanState& st, uint32_t row0, uint32_t ndb,
+                                          uint2* __restrict__ rg, const float* __restrict__ rows, uint2* __restrict__ rl,
+                                          uint32_t& rc, const RevOut& rev, uint32_t q) {
+#ifdef M3D_SCAN_ABL_NOSLOW
+    return;   // (timing only: wrong results)
+#endif
+#ifdef M3D_SCAN_STATS
+    if (REV && (threadIdx.x & 63) == 0) {
+        if (f.ring) SCAN_STAT(0);
+        if (f.r0 | f.r1 | f.r2 | f.r3) SCAN_STAT(1);
+        for (int k = 0; k < 4; ++k)
+            if (k == 0 ? f.r0 : k == 1 ? f.r1 : k == 2 ? f.r2 : f.r3) SCAN_STAT(2);
+    }
+#endif
+    if ((f.ring | f.r0 | f.r1 | f.r2 | f.r3) == 0ull) return;
+#ifdef M3D_SCAN_ABL_NORING
+    if (false) {
+#else
+    if (f.ring) {
+#endif
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (any_lane(f.g[k] <= st.win)) {
+#pragma unroll
+                for (int r = 4 * k; r < 4 * k + 4; ++r) {
+                    const bool hit = acc[r] <= st.win;
+                    if (any_lane(hit)) {
+                        const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+                        if (hit && row < ndb) {
+                            SCAN_STAT(4);
+                            const uint32_t slot = st.cnt % kRing;
+                            if (st.cnt >= (uint32_t)kRing) st.ev = fminf(st.ev, __uint_as_float(rg[slot].y));
+                            rg[slot] = make_uint2(row, __float_as_uint(acc[r]));
+                            st.cnt++;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#ifdef M3D_SCAN_ABL_NOREV
+    if (false) {
+#else
+    if (REV) {
+#endif
+        if (f.r0) rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), row0, rl, rc, rev, q);
+        if (f.r1) rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), row0, rl, rc, rev, q);
+        if (f.r2) rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), row0, rl, rc, rev, q);
+        if (f.r3) rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), row0, rl, rc, rev, q);
     }
 }
 
@@ -105,6 +204,12 @@ constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
 // (Also measured: a start offset per workgroup against lockstep phases of a SIMD's three waves: 6.865 ms, nothing.)  Off; not compiled.
 #ifndef M3D_MATCH_SW_PIPELINE
 #define M3D_MATCH_SW_PIPELINE 0
+#endif
+#ifndef M3D_SCAN_INTERLEAVE
+#define M3D_SCAN_INTERLEAVE 1
+#endif
+#ifndef M3D_SCAN_REV_TILE_TEST
+#define M3D_SCAN_REV_TILE_TEST 0
 #endif
 // queries per workgroup = 64 x waves: every wave of a workgroup reads the same staged tiles, so the staging traffic per query goes
 // with 1 / waves (four waves: 14.7 GB from L2 per 200 k x 200 k scan, a fifth of the scan's time)
@@ -236,13 +341,12 @@ __global__ __launch_bounds__(kBlockThreads) void nn16_scan_k(const h8* __restric
             const uint32_t in_stage = min((uint32_t)kStageTiles, t1 - t);
             // one side after the other: the run minima of a side are dead before the other side's are formed
             auto side = [&](const f32x16& acc, ScanState& st, float two_e, uint2* __restrict__ rg, uint32_t q,
-                            uint2* __restrict__ rl, uint32_t& rc, uint32_t u) {
+                            uint2* __restrict__ rl, uint32_t& rc, uint32_t u, const float4& t4) {
                 const uint32_t row0 = (t + u) * 32u + 4u * half;
                 float g4[4];
                 group_min(acc, g4);
                 mfma_post<MIN_ONLY>(acc, g4, st, two_e, row0, ndb, rg);
                 if (REV) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
                     // (one lane mask per run, straight from its compare; their union decides the branch on the scalar unit)
                     const uint64_t m0 = __builtin_amdgcn_ballot_w64(g4[0] <= t4.x), m1 = __builtin_amdgcn_ballot_w64(g4[1] <= t4.y),
                                    m2 = __builtin_amdgcn_ballot_w64(g4[2] <= t4.z), m3 = __builtin_amdgcn_ballot_w64(g4[3] <= t4.w);
@@ -268,6 +372,14 @@ __global__ __launch_bounds__(kBlockThreads) void nn16_scan_k(const h8* __restric
                     a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], a1, 0, 0, 0);
                 }
             };
+            // the tile's run thresholds: the same for both sides
+            auto thresholds = [&](uint32_t u) {
+                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (REV) {
+                    t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
+                }
+                return t4;
+            };
 #if M3D_MATCH_SW_PIPELINE
             // (the refuted variant: see M3D_MATCH_SW_PIPELINE above)
             f32x16 accA0, accA1, accB0, accB1;
@@ -278,23 +390,78 @@ __global__ __launch_bounds__(kBlockThreads) void nn16_scan_k(const h8* __restric
                     multiply(u + 1u, accB0, accB1);
                     // (no scheduling barrier)
                 }
-                side(accA0, sa, win_ea, ring_a, qa, rl_a, rc_a, u);
-                side(accA1, sb, win_eb, ring_b, qb, rl_b, rc_b, u);
+                side(accA0, sa, win_ea, ring_a, qa, rl_a, rc_a, u, thresholds(u));
+                side(accA1, sb, win_eb, ring_b, qb, rl_b, rc_b, u, thresholds(u));
                 if (odd) {
                     if (u + 2u < in_stage) {
                         multiply(u + 2u, accA0, accA1);
                         // (no scheduling barrier)
                     }
-                    side(accB0, sa, win_ea, ring_a, qa, rl_a, rc_a, u + 1u);
-                    side(accB1, sb, win_eb, ring_b, qb, rl_b, rc_b, u + 1u);
+                    side(accB0, sa, win_ea, ring_a, qa, rl_a, rc_a, u + 1u, thresholds(u + 1u));
+                    side(accB1, sb, win_eb, ring_b, qb, rl_b, rc_b, u + 1u, thresholds(u + 1u));
                 }
+            }
+#elif M3D_SCAN_INTERLEAVE
+            // One side's chain of three matrix instructions with the OTHER side's fast path between them: a wave issues in order,
+            // so VALU work overlaps its own matrix instructions only where it stands between them in the program
+            // (tools/ubench/mfma_chain.hip: a dependent chain issues at the pipe's rate; six v_min after each of its MFMAs cost
+            // a tenth of what they cost behind the six).  posted = the other side's accumulators, complete since its own chain.
+            auto chain_under = [&](const h8 (&c)[kMfmaSteps], const h8 (&b)[kMfmaSteps], f32x16& out, const f32x16& posted,
+                                   FastOut& f, ScanState& st, float two_e, const float4& t4) {
+                static_assert(kMfmaSteps == 3, "three matrix instructions per chain");
+                __builtin_amdgcn_sched_barrier(0);
+                out = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], b[0], f32x16{0}, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                group_min(posted, f.g);
+                __builtin_amdgcn_sched_barrier(0);
+                out = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[1], b[1], out, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                post_fast_b<MIN_ONLY, REV>(f, st, two_e, t4);
+                __builtin_amdgcn_sched_barrier(0);
+                out = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], b[2], out, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto fragments = [&](uint32_t u, h8 (&c)[kMfmaSteps]) {
+#pragma unroll
+                for (int s = 0; s < kMfmaSteps; ++s) c[s] = stage[buf][(u * kMfmaSteps + s) * 64 + lane];
+            };
+            {
+                f32x16 acc0, acc1;
+                h8 cur[kMfmaSteps];
+                fragments(0u, cur);
+                float4 t4 = thresholds(0u);
+                acc0 = f32x16{0};
+#pragma unroll
+                for (int s = 0; s < kMfmaSteps; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], acc0, 0, 0, 0);
+                uint32_t u = 0;
+                FastOut fa, fb;
+                for (;;) {
+                    // side b's chain of tile u under side a's fast path of tile u
+                    chain_under(cur, b1, acc1, acc0, fa, sa, win_ea, t4);
+                    // tile u + 1's fragments and thresholds: requested now, they arrive under side a's slow path and side b's ...
+                    const uint32_t un = min(u + 1u, (uint32_t)kStageTiles - 1u);   // (past the stage's end: a tile nobody uses)
+                    fragments(un, cur);   // (tile u's are dead: side b's chain has issued)
+                    const float4 t4n = thresholds(un);
+                    post_slow<REV>(acc0, fa, sa, (t + u) * 32u + 4u * half, ndb, ring_a, &sthr[buf][u * 32u + 4u * half], rl_a, rc_a, rev, qa);
+                    if (u + 1u >= in_stage) break;   // (workgroup-uniform)
+                    // side a's chain of tile u + 1 under side b's fast path of tile u
+                    chain_under(cur, b0, acc0, acc1, fb, sb, win_eb, t4);
+                    post_slow<REV>(acc1, fb, sb, (t + u) * 32u + 4u * half, ndb, ring_b, &sthr[buf][u * 32u + 4u * half], rl_b, rc_b, rev, qb);
+                    t4 = t4n;
+                    ++u;
+                }
+                // the stage's last tile, side b: nothing left to stand under
+                group_min(acc1, fb.g);
+                post_fast_b<MIN_ONLY, REV>(fb, sb, win_eb, t4);
+                post_slow<REV>(acc1, fb, sb, (t + u) * 32u + 4u * half, ndb, ring_b, &sthr[buf][u * 32u + 4u * half], rl_b, rc_b, rev, qb);
             }
 #else
             for (uint32_t u = 0; u < in_stage; ++u) {
                 f32x16 acc0, acc1;
+                const float4 t4 = thresholds(u);
                 multiply(u, acc0, acc1);
-                side(acc0, sa, win_ea, ring_a, qa, rl_a, rc_a, u);
-                side(acc1, sb, win_eb, ring_b, qb, rl_b, rc_b, u);
+                side(acc0, sa, win_ea, ring_a, qa, rl_a, rc_a, u, t4);
+                side(acc1, sb, win_eb, ring_b, qb, rl_b, rc_b, u, t4);
             }
 #endif
             buf = buf + 1 == kStageBufs ? 0 : buf + 1;
@@ -341,9 +508,13 @@ void launch_nn16_scan(const void* qB, const float* qn, uint32_t nq, const void* 
     const h8* q8 = reinterpret_cast<const h8*>(qB);
     const h8* d8 = reinterpret_cast<const h8*>(dA);
     const dim3 grid((nq + kBlockThreads - 1) / kBlockThreads, splits);
-    if (rev)
+    if (rev) {
         nn16_scan_k<false, true><<<grid, kBlockThreads, 0, s>>>(q8, qn, nq, d8, ndb, tile_end, plan, split0, max_dn2, premin,
                                                       init_slices, ring, ring_count, part_min, evict_min, *rev);
+#ifdef M3D_SCAN_STATS
+        scan_stats_print_k<<<1, 1, 0, s>>>();
+#endif
+    }
     else
         nn16_scan_k<false, false><<<grid, kBlockThreads, 0, s>>>(q8, qn, nq, d8, ndb, tile_end, plan, split0, max_dn2, premin,
                                                        init_slices, ring, ring_count, part_min, evict_min, RevOut());

@@ -69,6 +69,7 @@ struct RevOut {
     uint2* cand = nullptr;        // ndb x kRevCap slots (query, d16 bits): filled by rev_bin_k, and by full lists directly
     uint2* list = nullptr;        // slices x nq x kRevLane entries (row, d16 bits)
     uint32_t* list_cnt = nullptr; // slices x nq
+    const uint32_t* perm = nullptr;   // position in the packed database -> row (what cnt / cand are indexed by); lists and rings carry positions
     uint32_t q_base = 0;          // index of the launch's first query in the whole query matrix (what cand's entries carry)
 };
 

@@ -219,6 +219,8 @@ struct MatchWork {
     float* evict_min = nullptr;     // 2 splits x na
     float* rev_premin = nullptr;    // 2 splits_r x nb   reverse warm-up minima, [slice][row] per part of b
     float* rthr = nullptr;          // sets x mfma_tiles(nb) x 40: thresholds of the reverse search, one set per query slice
+    uint32_t* rperm = nullptr;      // mfma_tiles(nb) x 32: position in the packed database -> row of b (match_order_part)
+    double scale = 0.0;             // the call's power-of-two scale (match_order_part packs again)
     uint32_t* rcnt = nullptr;       // nb
     uint2* rcand = nullptr;         // nb x kMatchRevCap
     uint2* rlist = nullptr;         // 2 splits x na x kMatchRevLane
@@ -233,6 +235,9 @@ void match_forward_warm(const MatchWork& w, uint32_t q0, uint32_t nq, hipStream_
 // thresholds of rows row0 .. of b for the scans of query slice `set`: set 0 runs the reverse warm-up (the first 1/8 of a must be packed),
 // later sets re-derive the thresholds from the same minima under the norm bound of the queries packed by then
 void match_reverse_thresholds(const MatchWork& w, uint32_t row0, uint32_t rows, int set, hipStream_t s);
+// after set 0's thresholds of a part: its rows ordered by threshold within chunks of 1024 (w.rperm), the part's database layout
+// packed again in that order, the run thresholds of the ordered rows
+void match_order_part(const MatchWork& w, uint32_t row0, uint32_t rows, hipStream_t s);
 // main pass: queries q0 .. q0 + nq - 1 against splits split0 .. split0 + splits - 1 (tiles below tile_end)
 void match_scan(const MatchWork& w, uint32_t q0, uint32_t nq, uint32_t split0, uint32_t splits, uint32_t tile_end, int set,
                 hipStream_t s);
