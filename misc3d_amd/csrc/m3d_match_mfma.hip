@@ -14,70 +14,55 @@ namespace m3d {
 __device__ unsigned long long g_scan_stats[8];
 #define SCAN_STAT(i) atomicAdd(&g_scan_stats[i], 1ull)
 __global__ void scan_stats_print_k() {
-    printf("scan stats: side-tiles with a ring entry %llu, with a rev entry %llu, rev runs entered %llu, rev candidates (lane-rows) %llu, "
-           "ring appends (lane-rows) %llu, side-tiles where tmin <= max of the 4 run thresholds %llu\n",
-           g_scan_stats[0], g_scan_stats[1], g_scan_stats[2], g_scan_stats[3], g_scan_stats[4], g_scan_stats[5]);
+    printf("scan stats: side-tiles with a ring entry %llu, with a rev entry %llu, rev candidates (lane-rows) %llu, ring appends (lane-rows) %llu\n",
+           g_scan_stats[0], g_scan_stats[1], g_scan_stats[3], g_scan_stats[4]);
     for (int i = 0; i < 8; ++i) g_scan_stats[i] = 0;
 }
 #else
 #define SCAN_STAT(i) ((void)0)
 #endif
-// Per tile and query tile: 16 distances per lane.  The running minimum is updated unconditionally; rows are
-// appended when they lie within the window of the minimum INCLUDING this tile (still a superset of the final
-// window).  A wave carries 128 rings, so early in a scan some lane has a new record in most tiles: the append path is
-// entered per wave-uniform branch and, inside, only the rows that any lane needs are touched (one v_cmp + scalar
-// branch per row), instead of 16 divergent blocks.
-// group_min: the minima of the lane's four runs of four rows (acc[4g .. 4g + 3] = rows 8g + 4 half + 0..3 of the tile):
-// the first two levels of the 16-value minimum, kept because the reverse search tests them against the runs'
-// thresholds (two instructions per run: v_min + v_min3 under -fno-honor-nans).
+// Per tile and query tile: 16 distances per lane (acc[4g .. 4g + 3] = rows 8g + 4 half + 0..3 of the tile).
+// "does any lane ...": the lane mask straight from the compare (__any / __ballot take an int: the flag is first materialised in a
+// VGPR and compared again -- two VALU instructions and their latency in front of every wave-uniform branch of the scan)
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// the minima of the lane's four runs of four rows: what the slow paths test first (v_min + v_min3 per run under -fno-honor-nans)
 __device__ __forceinline__ void group_min(const f32x16& acc, float (&g)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[k] = fminf(fminf(acc[4 * k], acc[4 * k + 1]), fminf(acc[4 * k + 2], acc[4 * k + 3]));
 }
-// "does any lane ...": the lane mask straight from the compare (__any / __ballot take an int: the flag is first materialised in a
-// VGPR and compared again -- two VALU instructions and their latency in front of every wave-uniform branch of the scan)
-__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-// The hot predicates are single compares, so that their lane masks come straight out of v_cmp (a compound condition is first
-// materialised per lane and compared again): a lane without a live query carries two_e = -inf -- its window is -inf, nothing is
-// inside --, a padding query's packed norm is 65504 x 2^15 (pack_f16_both_k: every distance of it is beyond any threshold), a
-// padding row of the database likewise (beyond any window; the append still checks row < ndb).
-template <bool MIN_ONLY>
-__device__ __forceinline__ void mfma_post(const f32x16& acc, const float (&g)[4], ScanState& st, float two_e, uint32_t row0,
-                                          uint32_t ndb, uint2* __restrict__ my) {
-    const float tmin = fminf(fminf(g[0], g[1]), fminf(g[2], g[3]));
-    st.best = fminf(st.best, tmin);
-    if (MIN_ONLY) return;
-    st.win = st.best + two_e;
-    // One tile pair in five gets here (some lane of the 64 has a row inside its window: a new record of its running minimum, mostly),
-    // nearly always for ONE row of one lane: first the four runs' minima, then the four rows of a run that some lane needs
-    // (16 row tests per entry before: 150 instructions, a third of the scan's VALU and most of its SALU work)
-    if (any_lane(tmin <= st.win)) {
+// ---- a side's FAST path: ten VALU instructions, no branch -- so that it can stand BETWEEN the matrix instructions of the
+// other side's chain (nn16_scan_k) --, leaving the lane's minimum and two lane masks (SGPR pairs) behind.
+// Round 6; before: 26 instructions and two to four branches per side (run minima, the running minimum and its window every tile,
+// four run tests of the reverse search).  What made the single tests sharp enough:
+//   forward  tmin <= win, the window of the running minimum BEFORE this tile: a new record (tmin < best <= win) passes it like a
+//            row inside the window does, so best and win need an update in the slow path only;
+//   reverse  tmin <= t16, the largest threshold of the lane's sixteen rows: the rows come ordered by threshold within chunks
+//            of 1024 (rev_order_k), so t16 is hardly above the others -- 2.7 M side-tiles of 39 M pass for 2.4 M with a candidate
+//            (in the caller's order the four run tests let 11.4 M pass).
+// The hot predicates are single compares, their lane masks come straight out of v_cmp: a lane without a live query carries
+// two_e = -inf (its window is -inf), a padding query's packed norm is 65504 x 2^15 (pack_f16_both_k: every distance of it is
+// beyond any threshold), a padding row of the database likewise (beyond any window; the append still checks row < ndb).
+struct FastOut {
+    float tmin = INFINITY;
+    uint64_t ring = 0, rev = 0;
+};
+__device__ __forceinline__ void post_fast_a(const f32x16& a, float (&m)[5]) {   // fifteen of the sixteen values: five v_min3
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (any_lane(g[k] <= st.win)) {
-#pragma unroll
-                for (int r = 4 * k; r < 4 * k + 4; ++r) {
-                    const bool hit = acc[r] <= st.win;
-                    if (any_lane(hit)) {
-                        const uint32_t row = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
-                        if (hit && row < ndb) {
-                            const uint32_t slot = st.cnt % kRing;
-                            if (st.cnt >= (uint32_t)kRing) st.ev = fminf(st.ev, __uint_as_float(my[slot].y));
-                            my[slot] = make_uint2(row, __float_as_uint(acc[r]));
-                            st.cnt++;
-                        }
-                    }
-                }
-            }
-        }
-    }
+    for (int k = 0; k < 5; ++k) m[k] = fminf(fminf(a[3 * k], a[3 * k + 1]), a[3 * k + 2]);
 }
-
-// The reverse search's share of a tile (m3d_match_scan.hpp, RevOut).  Fast path: the four run minima against the four
-// run thresholds (thr4 = the largest of the run's four row thresholds: conservative) -- 4 compares per side and tile.
-// Behind the wave-uniform branch, per run that some lane hit: the four rows' own thresholds (one ds_read_b128), a
-// ballot and scalar branch per row, a plain store into the lane's own list per candidate.
+template <bool MIN_ONLY, bool REV>
+__device__ __forceinline__ void post_fast_b(const f32x16& a, const float (&m)[5], FastOut& f, ScanState& st, float t16) {
+    f.tmin = fminf(fminf(fminf(m[0], m[1]), a[15]), fminf(fminf(m[2], m[3]), m[4]));   // v_min3, v_min3, v_min
+    if (MIN_ONLY) {
+        st.best = fminf(st.best, f.tmin);
+        return;
+    }
+    f.ring = __builtin_amdgcn_ballot_w64(f.tmin <= st.win);
+    if (REV) f.rev = __builtin_amdgcn_ballot_w64(f.tmin <= t16);
+}
+// The reverse search's rows of one run (m3d_match_scan.hpp, RevOut): the four rows' own thresholds, a ballot and scalar branch
+// per row, a plain store into the lane's own list per candidate.
 template <int G>
 __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, uint32_t row0, uint2* __restrict__ my,
                                         uint32_t& cnt, const RevOut& rev, uint32_t q) {
@@ -89,7 +74,7 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, uin
         if (any_lane(hit)) {
             if (hit) {
                 SCAN_STAT(3);
-                const uint32_t row = row0 + (uint32_t)(k + 8 * G);
+                const uint32_t row = row0 + (uint32_t)(k + 8 * G);   // (a POSITION in the ordered database: rev_bin_k translates)
                 if (cnt < (uint32_t)kRevLane) {
                     my[cnt++] = make_uint2(row, __float_as_uint(v));
                 } else {   // list full: straight into the row's slots (what rev_bin_k does with the listed ones)
@@ -101,63 +86,29 @@ __device__ __forceinline__ void rev_run(const f32x16& acc, const float4& th, uin
         }
     }
 }
-
-// ---- the interleaved loop's pieces (M3D_SCAN_INTERLEAVE) ------------------------------------------------------------------
-// What a side's fast path leaves behind: the run minima and five lane masks (SGPR pairs).  Everything branch-free, so that
-// it can stand BETWEEN the matrix instructions of the other side's chain.
-struct FastOut {
-    float g[4];
-    uint64_t ring = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-};
-template <bool MIN_ONLY, bool REV>
-__device__ __forceinline__ void post_fast_b(FastOut& f, ScanState& st, float two_e, const float4& t4) {
-    const float tmin = fminf(fminf(f.g[0], f.g[1]), fminf(f.g[2], f.g[3]));
-    st.best = fminf(st.best, tmin);
-    if (!MIN_ONLY) {
-        st.win = st.best + two_e;
-        f.ring = __builtin_amdgcn_ballot_w64(tmin <= st.win);
-    }
-    if (REV) {
-#if M3D_SCAN_REV_TILE_TEST
-        // ONE test per side: the rows come ordered by threshold (rev_order_k), the largest of a lane's sixteen is hardly above the
-        // others -- 2.8 M side-tiles of 39 M pass it for 2.4 M with a candidate (four run tests: 2.5 M)
-        f.r0 = __builtin_amdgcn_ballot_w64(tmin <= t4.x);   // (t4.x: the caller's maximum of the four run thresholds)
-#else
-        f.r0 = __builtin_amdgcn_ballot_w64(f.g[0] <= t4.x);
-        f.r1 = __builtin_amdgcn_ballot_w64(f.g[1] <= t4.y);
-        f.r2 = __builtin_amdgcn_ballot_w64(f.g[2] <= t4.z);
-        f.r3 = __builtin_amdgcn_ballot_w64(f.g[3] <= t4.w);
-#endif
-#ifdef M3D_SCAN_STATS
-        if (any_lane(tmin <= fmaxf(fmaxf(t4.x, t4.y), fmaxf(t4.z, t4.w))) && (threadIdx.x & 63) == 0) SCAN_STAT(5);
-#endif
-    }
-}
-// the slow paths of a side: mfma_post's append and the reverse search's rows, behind ONE wave-uniform branch
+// ---- a side's SLOW paths behind ONE wave-uniform branch (6 % + 8 % of the side-tiles).  Forward: the running minimum and its
+// window INCLUDING this tile (still a superset of the final window), then the runs and rows that some lane needs (one v_cmp +
+// scalar branch each: nearly always ONE row of one lane).  Reverse: the four run thresholds, then rev_run.
+// t4 / rows: the tile's run and row thresholds of this lane's half, in the LDS.
 template <bool REV>
-__device__ __forceinline__ void post_slow(const f32x16& acc, const FastOut& f, ScanState& st, uint32_t row0, uint32_t ndb,
-                                          uint2* __restrict__ rg, const float* __restrict__ rows, uint2* __restrict__ rl,
-                                          uint32_t& rc, const RevOut& rev, uint32_t q) {
-#ifdef M3D_SCAN_ABL_NOSLOW
-    return;   // (timing only: wrong results)
-#endif
+__device__ __forceinline__ void post_slow(const f32x16& acc, const FastOut& f, ScanState& st, float two_e, uint32_t row0, uint32_t ndb,
+                                          uint2* __restrict__ rg, const float* __restrict__ t4, const float* __restrict__ rows,
+                                          uint2* __restrict__ rl, uint32_t& rc, const RevOut& rev, uint32_t q) {
 #ifdef M3D_SCAN_STATS
     if (REV && (threadIdx.x & 63) == 0) {
         if (f.ring) SCAN_STAT(0);
-        if (f.r0 | f.r1 | f.r2 | f.r3) SCAN_STAT(1);
-        for (int k = 0; k < 4; ++k)
-            if (k == 0 ? f.r0 : k == 1 ? f.r1 : k == 2 ? f.r2 : f.r3) SCAN_STAT(2);
+        if (f.rev) SCAN_STAT(1);
     }
 #endif
-    if ((f.ring | f.r0 | f.r1 | f.r2 | f.r3) == 0ull) return;
-#ifdef M3D_SCAN_ABL_NORING
-    if (false) {
-#else
+    if ((f.ring | f.rev) == 0ull) return;
+    float g[4];
+    group_min(acc, g);
     if (f.ring) {
-#endif
+        st.best = fminf(st.best, f.tmin);   // (a lane outside the mask: tmin > win >= best, nothing changes)
+        st.win = st.best + two_e;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (any_lane(f.g[k] <= st.win)) {
+            if (any_lane(g[k] <= st.win)) {
 #pragma unroll
                 for (int r = 4 * k; r < 4 * k + 4; ++r) {
                     const bool hit = acc[r] <= st.win;
@@ -175,15 +126,12 @@ __device__ __forceinline__ void post_slow(const f32x16& acc, const FastOut& f, S
             }
         }
     }
-#ifdef M3D_SCAN_ABL_NOREV
-    if (false) {
-#else
-    if (REV) {
-#endif
-        if (f.r0) rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), row0, rl, rc, rev, q);
-        if (f.r1) rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), row0, rl, rc, rev, q);
-        if (f.r2) rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), row0, rl, rc, rev, q);
-        if (f.r3) rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), row0, rl, rc, rev, q);
+    if (REV && f.rev) {
+        const float4 th = *reinterpret_cast<const float4*>(t4);
+        if (any_lane(g[0] <= th.x)) { rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), row0, rl, rc, rev, q); }
+        if (any_lane(g[1] <= th.y)) { rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), row0, rl, rc, rev, q); }
+        if (any_lane(g[2] <= th.z)) { rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), row0, rl, rc, rev, q); }
+        if (any_lane(g[3] <= th.w)) { rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), row0, rl, rc, rev, q); }
     }
 }
 
@@ -197,20 +145,9 @@ __device__ __forceinline__ void post_slow(const f32x16& acc, const FastOut& f, S
 #define M3D_MATCH_STAGE_TILES 8
 #endif
 constexpr int kStageTiles = M3D_MATCH_STAGE_TILES;
-// M3D_MATCH_SW_PIPELINE=1 (round 5, measured and refuted: 6.87 -> 8.33-8.40 ms on 200 k x 200 k, with and without scheduling
-// barriers, unrolled by two and by four): tile u + 1's MFMAs issued before tile u's post-processing, on a second accumulator
-// set.  A wave issues in order: its VALU work cannot start before the last of the six MFMAs -- two dependent chains of three --
-// has ISSUED, so nothing overlaps inside the wave and the second accumulator set only lengthens live ranges (146 -> 156 VGPRs).
-// (Also measured: a start offset per workgroup against lockstep phases of a SIMD's three waves: 6.865 ms, nothing.)  Off; not compiled.
-#ifndef M3D_MATCH_SW_PIPELINE
-#define M3D_MATCH_SW_PIPELINE 0
-#endif
-#ifndef M3D_SCAN_INTERLEAVE
-#define M3D_SCAN_INTERLEAVE 1
-#endif
-#ifndef M3D_SCAN_REV_TILE_TEST
-#define M3D_SCAN_REV_TILE_TEST 0
-#endif
+// (Round 5, measured and refuted: tile u + 1's six MFMAs issued before tile u's post-processing on a second accumulator set --
+//  6.87 -> 8.33 ms: a wave issues in order, VALU work BEHIND the MFMAs cannot start before the last of them has issued.  Round 6
+//  put the VALU work BETWEEN them instead: chain_under below.)
 // queries per workgroup = 64 x waves: every wave of a workgroup reads the same staged tiles, so the staging traffic per query goes
 // with 1 / waves (four waves: 14.7 GB from L2 per 200 k x 200 k scan, a fifth of the scan's time)
 #ifndef M3D_MATCH_BLOCK_WAVES
@@ -255,7 +192,7 @@ __device__ __forceinline__ void wait_copies_but() {   // until at most N of this
 // bound close to its final minimum and "new record" events -- which cost a wave-wide detour each, and a wave
 // carries 128 rings -- become rare instead of happening in most tiles.
 template <bool MIN_ONLY, bool REV>
-__global__ __launch_bounds__(kBlockThreads) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void nn16_scan_k(const h8* __restrict__ qB, const float* __restrict__ qn2,
                                                     uint32_t nq, const h8* __restrict__ dA, uint32_t ndb,
                                                     uint32_t tile_end, SplitPlan plan, uint32_t split0,
                                                     const float* __restrict__ max_dn2_p,
@@ -299,6 +236,11 @@ __global__ __launch_bounds__(kBlockThreads) void nn16_scan_k(const h8* __restric
             if (qb < nq) sb.best = fminf(sb.best, init_min[(size_t)k * nq + qb]);
         }
     }
+    // (the window of the seeded minimum; unseeded: +inf, the first tile enters the slow path and sets both)
+    if (!MIN_ONLY) {
+        sa.win = sa.best + win_ea;
+        sb.win = sb.best + win_eb;
+    }
     const uint32_t t0 = plan.begin(split0 + blockIdx.y), t1 = min(tile_end, plan.end(split0 + blockIdx.y));
     if (t0 < t1) {   // block-uniform
         // entry e of a stage = fragment (tile, step, lane) in packed order: consecutive in memory, 64 entries of a wave = 1 KB of the LDS
@@ -339,131 +281,85 @@ __global__ __launch_bounds__(kBlockThreads) void nn16_scan_k(const h8* __restric
             __syncthreads();
             if (t + 2 * kStageTiles < t1) fetch(t + 2 * kStageTiles, buf >= 1 ? buf - 1 : kStageBufs - 1);
             const uint32_t in_stage = min((uint32_t)kStageTiles, t1 - t);
-            // one side after the other: the run minima of a side are dead before the other side's are formed
-            auto side = [&](const f32x16& acc, ScanState& st, float two_e, uint2* __restrict__ rg, uint32_t q,
-                            uint2* __restrict__ rl, uint32_t& rc, uint32_t u, const float4& t4) {
-                const uint32_t row0 = (t + u) * 32u + 4u * half;
-                float g4[4];
-                group_min(acc, g4);
-                mfma_post<MIN_ONLY>(acc, g4, st, two_e, row0, ndb, rg);
-                if (REV) {
-                    // (one lane mask per run, straight from its compare; their union decides the branch on the scalar unit)
-                    const uint64_t m0 = __builtin_amdgcn_ballot_w64(g4[0] <= t4.x), m1 = __builtin_amdgcn_ballot_w64(g4[1] <= t4.y),
-                                   m2 = __builtin_amdgcn_ballot_w64(g4[2] <= t4.z), m3 = __builtin_amdgcn_ballot_w64(g4[3] <= t4.w);
-                    if ((m0 | m1 | m2 | m3) != 0ull) {
-                        const float* rows = &sthr[buf][u * 32u + 4u * half];
-                        if (m0) rev_run<0>(acc, *reinterpret_cast<const float4*>(rows), row0, rl, rc, rev, q);
-                        if (m1) rev_run<1>(acc, *reinterpret_cast<const float4*>(rows + 8), row0, rl, rc, rev, q);
-                        if (m2) rev_run<2>(acc, *reinterpret_cast<const float4*>(rows + 16), row0, rl, rc, rev, q);
-                        if (m3) rev_run<3>(acc, *reinterpret_cast<const float4*>(rows + 24), row0, rl, rc, rev, q);
-                    }
-                }
-            };
-            // the six MFMAs of database tile u of the stage (both query tiles of the wave)
-            auto multiply = [&](uint32_t u, f32x16& a0, f32x16& a1) {
-                h8 cur[kMfmaSteps];
-#pragma unroll
-                for (int s = 0; s < kMfmaSteps; ++s) cur[s] = stage[buf][(u * kMfmaSteps + s) * 64 + lane];
-                a0 = f32x16{0};
-                a1 = f32x16{0};
-#pragma unroll
-                for (int s = 0; s < kMfmaSteps; ++s) {
-                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b1[s], a1, 0, 0, 0);
-                }
-            };
-            // the tile's run thresholds: the same for both sides
-            auto thresholds = [&](uint32_t u) {
-                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (REV) {
-                    t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
-                }
-                return t4;
-            };
-#if M3D_MATCH_SW_PIPELINE
-            // (the refuted variant: see M3D_MATCH_SW_PIPELINE above)
-            f32x16 accA0, accA1, accB0, accB1;
-            multiply(0u, accA0, accA1);
-            for (uint32_t u = 0; u < in_stage; u += 2u) {   // two tiles per trip: the sets alternate without moves, the code stays two copies
-                const bool odd = u + 1u < in_stage;   // (workgroup-uniform)
-                if (odd) {
-                    multiply(u + 1u, accB0, accB1);
-                    // (no scheduling barrier)
-                }
-                side(accA0, sa, win_ea, ring_a, qa, rl_a, rc_a, u, thresholds(u));
-                side(accA1, sb, win_eb, ring_b, qb, rl_b, rc_b, u, thresholds(u));
-                if (odd) {
-                    if (u + 2u < in_stage) {
-                        multiply(u + 2u, accA0, accA1);
-                        // (no scheduling barrier)
-                    }
-                    side(accB0, sa, win_ea, ring_a, qa, rl_a, rc_a, u + 1u, thresholds(u + 1u));
-                    side(accB1, sb, win_eb, ring_b, qb, rl_b, rc_b, u + 1u, thresholds(u + 1u));
-                }
-            }
-#elif M3D_SCAN_INTERLEAVE
             // One side's chain of three matrix instructions with the OTHER side's fast path between them: a wave issues in order,
             // so VALU work overlaps its own matrix instructions only where it stands between them in the program
             // (tools/ubench/mfma_chain.hip: a dependent chain issues at the pipe's rate; six v_min after each of its MFMAs cost
-            // a tenth of what they cost behind the six).  posted = the other side's accumulators, complete since its own chain.
-            auto chain_under = [&](const h8 (&c)[kMfmaSteps], const h8 (&b)[kMfmaSteps], f32x16& out, const f32x16& posted,
-                                   FastOut& f, ScanState& st, float two_e, const float4& t4) {
+            // a tenth of what they cost behind all six).  posted = the other side's accumulators, complete since its own chain.
+            // (Measured and not kept: every fragment register loaded again right behind its own MFMA with what the NEXT chain needs in
+            //  that place -- three MFMAs of lead for the LDS round trip, no second register set, but every tile read twice: 3.94 ms
+            //  against 3.82 on 200 k x 200 k, same box, twice.  The tile's fragments are requested once, behind its second chain.)
+            auto fragment = [&](uint32_t u, int s) { return stage[buf][(u * kMfmaSteps + s) * 64 + lane]; };
+            // (t16n: tile `next`'s largest threshold, requested in front of the chain and folded behind its second MFMA; null: not wanted)
+            auto chain_under = [&](h8 (&c)[kMfmaSteps], const h8 (&b)[kMfmaSteps], f32x16& out, const f32x16& posted, FastOut& f,
+                                   ScanState& st, float t16, uint32_t next, float* t16n, bool last_use) {
                 static_assert(kMfmaSteps == 3, "three matrix instructions per chain");
+                float m[5];
+                float4 t4n = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (REV && t16n) t4n = *reinterpret_cast<const float4*>(&sthr4[buf][next * 8u + 4u * half]);
                 __builtin_amdgcn_sched_barrier(0);
                 out = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], b[0], f32x16{0}, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                group_min(posted, f.g);
+                post_fast_a(posted, m);
                 __builtin_amdgcn_sched_barrier(0);
                 out = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[1], b[1], out, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                post_fast_b<MIN_ONLY, REV>(f, st, two_e, t4);
+                post_fast_b<MIN_ONLY, REV>(posted, m, f, st, t16);
+                if (REV && t16n) *t16n = fmaxf(fmaxf(t4n.x, t4n.y), fmaxf(t4n.z, t4n.w));
                 __builtin_amdgcn_sched_barrier(0);
                 out = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], b[2], out, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            };
-            auto fragments = [&](uint32_t u, h8 (&c)[kMfmaSteps]) {
+                if (last_use) {   // (tile `next`'s fragments: the tile's second chain has issued)
 #pragma unroll
-                for (int s = 0; s < kMfmaSteps; ++s) c[s] = stage[buf][(u * kMfmaSteps + s) * 64 + lane];
-            };
-            {
-                f32x16 acc0, acc1;
-                h8 cur[kMfmaSteps];
-                fragments(0u, cur);
-                float4 t4 = thresholds(0u);
-                acc0 = f32x16{0};
-#pragma unroll
-                for (int s = 0; s < kMfmaSteps; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], acc0, 0, 0, 0);
-                uint32_t u = 0;
-                FastOut fa, fb;
-                for (;;) {
-                    // side b's chain of tile u under side a's fast path of tile u
-                    chain_under(cur, b1, acc1, acc0, fa, sa, win_ea, t4);
-                    // tile u + 1's fragments and thresholds: requested now, they arrive under side a's slow path and side b's ...
-                    const uint32_t un = min(u + 1u, (uint32_t)kStageTiles - 1u);   // (past the stage's end: a tile nobody uses)
-                    fragments(un, cur);   // (tile u's are dead: side b's chain has issued)
-                    const float4 t4n = thresholds(un);
-                    post_slow<REV>(acc0, fa, sa, (t + u) * 32u + 4u * half, ndb, ring_a, &sthr[buf][u * 32u + 4u * half], rl_a, rc_a, rev, qa);
-                    if (u + 1u >= in_stage) break;   // (workgroup-uniform)
-                    // side a's chain of tile u + 1 under side b's fast path of tile u
-                    chain_under(cur, b0, acc0, acc1, fb, sb, win_eb, t4);
-                    post_slow<REV>(acc1, fb, sb, (t + u) * 32u + 4u * half, ndb, ring_b, &sthr[buf][u * 32u + 4u * half], rl_b, rc_b, rev, qb);
-                    t4 = t4n;
-                    ++u;
+                    for (int k = 0; k < kMfmaSteps; ++k) c[k] = fragment(next, k);
                 }
-                // the stage's last tile, side b: nothing left to stand under
-                group_min(acc1, fb.g);
-                post_fast_b<MIN_ONLY, REV>(fb, sb, win_eb, t4);
-                post_slow<REV>(acc1, fb, sb, (t + u) * 32u + 4u * half, ndb, ring_b, &sthr[buf][u * 32u + 4u * half], rl_b, rc_b, rev, qb);
-            }
-#else
-            for (uint32_t u = 0; u < in_stage; ++u) {
-                f32x16 acc0, acc1;
-                const float4 t4 = thresholds(u);
-                multiply(u, acc0, acc1);
-                side(acc0, sa, win_ea, ring_a, qa, rl_a, rc_a, u, t4);
-                side(acc1, sb, win_eb, ring_b, qb, rl_b, rc_b, u, t4);
-            }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // the largest threshold of this lane's sixteen rows of tile u (post_fast_b)
+            auto threshold16 = [&](uint32_t u) {
+                if (!REV) return 0.0f;
+                const float4 t4 = *reinterpret_cast<const float4*>(&sthr4[buf][u * 8u + 4u * half]);
+                return fmaxf(fmaxf(t4.x, t4.y), fmaxf(t4.z, t4.w));
+            };
+            auto slow = [&](const f32x16& acc, const FastOut& f, ScanState& st, float two_e, uint32_t u, uint2* __restrict__ rg,
+                            uint2* __restrict__ rl, uint32_t& rc, uint32_t q) {
+                if (MIN_ONLY) return;
+#ifdef M3D_SCAN_ABL_NOSLOW
+                if ((f.ring ^ f.rev) != 0x5DEADBEEF1234567ull) return;   // (timing only: wrong results)
 #endif
+                post_slow<REV>(acc, f, st, two_e, (t + u) * 32u + 4u * half, ndb, rg, &sthr4[buf][u * 8u + 4u * half],
+                               &sthr[buf][u * 32u + 4u * half], rl, rc, rev, q);
+            };
+            f32x16 acc0, acc1;
+            h8 cur[kMfmaSteps];
+#pragma unroll
+            for (int s = 0; s < kMfmaSteps; ++s) cur[s] = fragment(0u, s);
+            float t16 = threshold16(0u);
+            acc0 = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < kMfmaSteps; ++s) {   // the stage's first chain: nothing to stand over yet
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], b0[s], acc0, 0, 0, 0);
+            }
+            uint32_t u = 0;
+            FastOut fa, fb;
+            for (;;) {
+                const uint32_t un = min(u + 1u, (uint32_t)kStageTiles - 1u);   // (past the stage's end: a tile nobody uses)
+                // side b's chain of tile u under side a's fast path of tile u; the fragments behind it: tile u + 1's
+                float t16n = 0.0f;
+                chain_under(cur, b1, acc1, acc0, fa, sa, t16, un, &t16n, true);
+                slow(acc0, fa, sa, win_ea, u, ring_a, rl_a, rc_a, qa);
+                if (u + 1u >= in_stage) break;   // (workgroup-uniform)
+                // side a's chain of tile u + 1 under side b's fast path of tile u
+                chain_under(cur, b0, acc0, acc1, fb, sb, t16, un, nullptr, false);
+                slow(acc1, fb, sb, win_eb, u, ring_b, rl_b, rc_b, qb);
+                t16 = t16n;
+                ++u;
+            }
+            {   // the stage's last tile, side b: nothing left to stand under
+                float m[5];
+                post_fast_a(acc1, m);
+                post_fast_b<MIN_ONLY, REV>(acc1, m, fb, sb, t16);
+                slow(acc1, fb, sb, win_eb, u, ring_b, rl_b, rc_b, qb);
+            }
             buf = buf + 1 == kStageBufs ? 0 : buf + 1;
         }
     }
