@@ -287,7 +287,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4
             // a tenth of what they cost behind all six).  posted = the other side's accumulators, complete since its own chain.
             // (Measured and not kept: every fragment register loaded again right behind its own MFMA with what the NEXT chain needs in
             //  that place -- three MFMAs of lead for the LDS round trip, no second register set, but every tile read twice: 3.94 ms
-            //  against 3.82 on 200 k x 200 k, same box, twice.  The tile's fragments are requested once, behind its second chain.)
+            //  against 3.82 on 200 k x 200 k, same box, twice.  The tile's fragments are requested once, behind its second chain.
+            //  s_setprio 1 / 3 for the length of a chain: 4.01 / 3.96 against 3.94 ms.)
             auto fragment = [&](uint32_t u, int s) { return stage[buf][(u * kMfmaSteps + s) * 64 + lane]; };
             // (t16n: tile `next`'s largest threshold, requested in front of the chain and folded behind its second MFMA; null: not wanted)
             auto chain_under = [&](h8 (&c)[kMfmaSteps], const h8 (&b)[kMfmaSteps], f32x16& out, const f32x16& posted, FastOut& f,
