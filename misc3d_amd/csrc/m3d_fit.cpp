@@ -181,7 +181,7 @@ static bool use_dense_scoring() { return t_dense_fit != 0 || config().dense_scor
 // Hypotheses at the head of a probability-1 fit that are counted first, for the incumbent that prunes the rest.
 static uint32_t lead_size() { return (uint32_t)config().lead_hypotheses; }
 
-static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
+static size_t chunk_cap_for(const CloudView& v, const SortedView& sv, size_t times = 1) {
     // keep the per-chunk scratch below 1 GiB (dense: u32 partial count per (tile, hypothesis);
     // culled: one bit per (tile, hypothesis))
     if (!use_dense_scoring()) {
@@ -193,7 +193,13 @@ static size_t chunk_cap_for(const CloudView& v, const SortedView& sv) {
         // ... and the slot's mask scratch (one bit per (tile, hypothesis), twice: two slots) stays below 1 GiB per slot whatever
         // the cloud's size: 24576 hypotheses reach that at 350 000 tiles (180 M points) -- ADVICE r4
         const size_t by_masks = sv.n_tiles ? std::max<size_t>(((size_t)1 << 30) / ((size_t)sv.n_tiles * 8), 16) * 64 : ~(size_t)0;
-        return std::min<size_t>((size_t)config().chunk_cap, by_masks);
+        // times = 2: a CYLINDER fit with a forced iteration count (m3d_fit_on).  A window of cylinders costs ~120 us before its first
+        // pair is counted (keep_mask_k, plane_bound_k<2> 60 us, three phases with their tails and re-prunings, sum_replicas_k) where a
+        // window of planes or spheres costs ~35, and the incumbent of the 2048-hypothesis first chunk already prunes as well as a
+        // whole window's would: C3's 50 000 cylinders in one window of 47 952 instead of two of 23 976 evaluate the same 1.93 M pairs,
+        // the fit 0.861 -> 0.791 ms (round 6, profiles/r06_c3_chunk_cap.txt; the sphere loses: 0.66 -> 0.73, its second chunk's
+        // box tests no longer run under the first one's scoring)
+        return std::min<size_t>(std::min<size_t>((size_t)config().chunk_cap * times, 262144), by_masks);
     }
     const uint32_t rows = std::max<uint32_t>(1, v.n_pad / kScoreTile);
     const size_t cap = std::min<size_t>(16384, ((size_t)1 << 28) / rows / 64 * 64);
@@ -665,7 +671,7 @@ static int run_ransac(DeviceCtx* ctx, const CloudView& v, const SortedView& sv, 
 
     // sharded: the cap holds per rank, and the geometric start gives every rank a first slice of 128
     const size_t n_ranks = comm ? (size_t)comm->world : 1;
-    const size_t chunk_cap = chunk_cap_for(v, sv) * n_ranks;
+    const size_t chunk_cap = chunk_cap_for(v, sv, kind == M3D_CYLINDER && prob >= 1.0 ? 2 : 1) * n_ranks;
     // prob < 1: the adaptive bound usually stops the loop after O(100) hypotheses -> start small;
     // prob == 1: only fitness == 1 can stop it -> as few, equal chunks as the scratch cap allows
     // (one chunk up to chunk_cap hypotheses; more chunks are pipelined two deep)
