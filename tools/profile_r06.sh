@@ -48,3 +48,6 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/bench_driver_style.json 2> /d
 # round 6: the validation's candidate cache on / off, the LANES batch mode is part of bench_configs; boundary_k's counters
 python tools/time_c4_forced.py > gpurun_out/c4_forced_cache_ab.txt 2>&1
 bash tools/pmc_boundary.sh > gpurun_out/pmc_boundary.txt 2>&1
+# the matcher's one-launch scan: counters per wave-tile-pair; the default-confidence C4 call
+bash tools/pmc_match_scan.sh > gpurun_out/pmc_match_scan.txt 2>&1
+python tools/time_c4_default.py > gpurun_out/c4_default.txt 2>&1

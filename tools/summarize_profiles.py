@@ -60,7 +60,9 @@ def main():
                               ("../c3_timeline.txt", f"{TAG}_c3_timeline.txt"),
                               ("../bench_driver_style.json", f"{TAG}_bench_driver_style.json"),
                               ("../c4_forced_cache_ab.txt", f"{TAG}_c4_forced_cache_ab.txt"),
-                              ("../pmc_boundary.txt", f"{TAG}_pmc_boundary.txt")):
+                              ("../pmc_boundary.txt", f"{TAG}_pmc_boundary.txt"),
+                              ("../pmc_match_scan.txt", f"{TAG}_pmc_match_scan.txt"),
+                              ("../c4_default.txt", f"{TAG}_c4_default_times.txt")):
         q = os.path.join(SRC, src_rel)
         if os.path.exists(q):
             shutil.copy(q, os.path.join(DST, dst_name))
