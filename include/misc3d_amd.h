@@ -486,7 +486,8 @@ typedef struct m3d_config {
     int32_t score_fp32_screen;      /* [M3D_SCORE_SCREEN=0] default 1: planes and spheres are counted by score_screen_k (packed-fp32 screen with a
                                        rounding bound in front of the exact fp64 test: identical counts); 0: fp64 only (score_mask_k) */
     int32_t cull_fp32;              /* [M3D_CULL_FP32=0]    default 1: the box tests of the culled path run in fp32 with outward-rounded margins
-                                       (cull_tiles32_k: conservative, identical results); 0: fp64 box tests (cull_tiles_k) */
+                                       (cull_tiles32_k, and cull_hyp32_k for windows of 128 groups and more: conservative, identical results); 0: fp64 box tests
+                                       (cull_tiles_k); 2: fp32, always with a lane per tile (cull_tiles32_k: the tests' switch) */
     int32_t reg_fp32_screen;        /* [M3D_REG_SCREEN=0]   default 1: the nearest-neighbour search of the registration validation finds its
                                        candidate in fp32 on 8-byte list entries (16-bit fixed-point coordinates over the cell's 3-cell
                                        block + the entry's position, rounding bound) and evaluates the winner in fp64; a query whose

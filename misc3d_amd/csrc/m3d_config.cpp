@@ -37,6 +37,7 @@ void sanitize(m3d_config& c) {
     if (c.score_waves4_groups < 1 || c.score_waves4_groups > 64) c.score_waves4_groups = 64;
     if (c.score_phases < -1 || c.score_phases == 1 || c.score_phases > 3) c.score_phases = -1;
     if (c.plane_bound < 0 || c.plane_bound > 2) c.plane_bound = 1;
+    if (c.cull_fp32 < 0 || c.cull_fp32 > 2) c.cull_fp32 = 1;
     if (!kExperimentalBuild) c.score_mfma = c.score_waves4 = c.compact_one_pass = 0;   // (not compiled in: m3d_kernels.hpp)
     if (c.lanes < 1 || c.lanes > 8) c.lanes = 4;
     if (c.wait_spin_us < 0) c.wait_spin_us = 500;
@@ -66,7 +67,7 @@ void load_env() {
     g_cfg.kernel_timing = env_is("M3D_KERNEL_TIMING", '1');
     g_cfg.reg_sorted_lists = !env_is("M3D_REG_SORTED", '0');
     g_cfg.score_fp32_screen = !env_is("M3D_SCORE_SCREEN", '0');
-    g_cfg.cull_fp32 = !env_is("M3D_CULL_FP32", '0');
+    g_cfg.cull_fp32 = env_is("M3D_CULL_FP32", '0') ? 0 : (env_is("M3D_CULL_FP32", '2') ? 2 : 1);
     g_cfg.reg_fp32_screen = !env_is("M3D_REG_SCREEN", '0');
     g_cfg.sorted_tombstones = !env_is("M3D_TOMBSTONES", '0');
     g_cfg.score_mfma = env_is("M3D_SCORE_MFMA", '1');

@@ -112,6 +112,11 @@ __global__ __launch_bounds__(256) void tile_boxes_k(const double* __restrict__ s
             f[k] = empty ? 0.0f : c32;
             f[3 + k] = empty ? -1.0f : f32_round_up(hh);
         }
+        // ... and the fp32 box's bounding radius as the box tests compute it (cull32_body), for the kernel that reads a tile's box
+        // through the scalar unit and has no lane to spare for it (cull_hyp32_k)
+        const float hx = empty ? 0.0f : f[3], hy = empty ? 0.0f : f[4], hz = empty ? 0.0f : f[5];
+        f[6] = __builtin_sqrtf(__builtin_fmaf(hz, hz, __builtin_fmaf(hy, hy, hx * hx))) * 1.000001f;
+        f[7] = 0.0f;
     }
 }
 
@@ -444,6 +449,72 @@ __global__ __launch_bounds__(64) void cull_tiles32_k(const double* __restrict__ 
     cull32_body<KIND>(boxes, n_tiles, cull32, n_groups, groups_per_wave, masks, ub, group_begin, group_end, blockIdx.x, blockIdx.y, ubp);
 }
 
+// The same box tests with LANE = HYPOTHESIS (round 6): a wave holds the 64 records of one group in registers and walks a block of
+// tiles whose boxes come through the scalar unit.  cull_tiles32_k (lane = tile) needs a ballot and up to three scalar popcounts per
+// HYPOTHESIS for the touched-tile counters, two selects to park them in the hypothesis' lane, and the records staged through the LDS:
+// ~17-21 VALU + ~10 SALU instructions per box test.  Here a test's verdict is a lane's own (the counters are lane-local additions, the
+// residues of the phase counters compile-time constants of the loop unrolled by four), the ballot IS the tile's mask word: ~17 VALU + 2
+// SALU.  Same arithmetic, same roundings (cull32_one: what cull_lead_k's lead pass has always run), same words and counters.
+// C3's window of 47 952 cylinders x 1954 tiles: 111 -> 81 us (what is left is the cylinder's correctly rounded sqrt: 15 of its 31 VALU
+// instructions per test), the fit 0.765 -> 0.75 ms; spheres' windows 40 -> 41 / 108 -> 51 us (under the scoring either way).  For
+// windows of many groups (launch_cull_mask): a wave's 11-22 record loads want a block of tiles behind them.
+template <int KIND>
+__global__ __launch_bounds__(64) void cull_hyp32_k(const double* __restrict__ boxes, uint32_t n_tiles, const float* __restrict__ cull32,
+                                                    uint32_t n_groups, uint32_t tiles_per_wave /* a multiple of 4 */,
+                                                    unsigned long long* __restrict__ masks, uint32_t* __restrict__ ub, uint32_t group_begin,
+                                                    uint32_t group_end, uint32_t* __restrict__ ubp) {
+    const uint32_t g = group_begin + blockIdx.y;
+    if (g >= group_end) return;
+    const int lane = threadIdx.x;
+    const uint32_t h = g * 64u + (uint32_t)lane;
+    float rr[24];   // the lane's record where cull32_one looks for hypothesis 0 of a pair (only the slots its KIND reads stay)
+    {
+        const float* __restrict__ rp = cull32 + (size_t)(h >> 1) * 24u + (h & 1u);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            rr[2 * k] = rp[2 * k];
+            rr[2 * k + 1] = 0.0f;
+        }
+    }
+    const uint32_t t0 = blockIdx.x * tiles_per_wave, t1 = min(n_tiles, t0 + tiles_per_wave);
+    uint32_t cnt = 0, c0 = 0, c1 = 0;
+    for (uint32_t t = t0; t < t1; t += 4u) {
+        // the four tiles' boxes in one go (wave-uniform addresses: scalar loads; past the block's end: its last tile once more)
+        float bx[4][7];
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; ++r) {
+            const float* __restrict__ f = reinterpret_cast<const float*>(boxes + (size_t)min(t + r, t1 - 1u) * kBoxStride + 8);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) bx[r][k] = f[k];
+        }
+        uint32_t w_lo = 0u, w_hi = 0u;   // lane r: the mask word of tile t + r
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; ++r) {   // (t0 is a multiple of 4: tile % 4 = r)
+            unsigned long long word = 0ull;
+            if (bx[r][3] >= 0.0f) {   // (wave-uniform; hx < 0: empty tile)
+                const float tv = cull32_one<KIND>(rr, 0, bx[r][0], bx[r][1], bx[r][2], bx[r][3], bx[r][4], bx[r][5], bx[r][6]);
+                // the WORD takes the sign bit, the COUNTERS the comparison -- as cull_tiles32_k has them (a sphere's or cylinder's
+                // verdict is the OR of two floats' bits: with the sign set it may be a NaN, which no comparison calls negative)
+                word = __builtin_amdgcn_ballot_w64((int)__float_as_uint(tv) >= 0);
+                const bool touched = !(tv < 0.0f) && t + r < t1;
+                cnt += touched ? 1u : 0u;
+                if (r == 0u) c0 += touched ? 1u : 0u;
+                if (r == 1u) c1 += touched ? 1u : 0u;
+            }
+            // (v_writelane_b32: the scalar word into lane r of the pair of registers the four-lane store below sends)
+            const uint32_t wl = (uint32_t)word, wh = (uint32_t)(word >> 32);
+            if (r == 0u) asm volatile("v_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %3, 0" : "+v"(w_lo), "+v"(w_hi) : "s"(wl), "s"(wh));
+            if (r == 1u) asm volatile("v_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %1, %3, 1" : "+v"(w_lo), "+v"(w_hi) : "s"(wl), "s"(wh));
+            if (r == 2u) asm volatile("v_writelane_b32 %0, %2, 2\n\tv_writelane_b32 %1, %3, 2" : "+v"(w_lo), "+v"(w_hi) : "s"(wl), "s"(wh));
+            if (r == 3u) asm volatile("v_writelane_b32 %0, %2, 3\n\tv_writelane_b32 %1, %3, 3" : "+v"(w_lo), "+v"(w_hi) : "s"(wl), "s"(wh));
+        }
+        if ((uint32_t)lane < 4u && t + (uint32_t)lane < t1)
+            masks[(size_t)(t + (uint32_t)lane) * n_groups + g] = ((unsigned long long)w_hi << 32) | w_lo;
+    }
+    if (ub && cnt) atomicAdd(&ub[h], cnt);
+    if (ubp && (c0 | c1)) atomicAdd(&ubp[h], c0 | (c1 << 16));
+}
+
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
                       uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st, bool ub_is_zero,
                       uint32_t group_begin, uint32_t group_end, const float* cull32, uint32_t* ubp) {
@@ -459,6 +530,15 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
     gpw = std::min<uint32_t>(gpw, 8);
     const dim3 g(tblocks, (window + gpw - 1) / gpw), b(64);
     if (cull32 && s.radius < 1e18 && config().cull_fp32 != 0) {
+        // windows of many groups: lane = hypothesis (cull_hyp32_k); m3d_config.cull_fp32 = 2: always lane = tile (the tests' switch)
+        if (window >= 128u && config().cull_fp32 != 2) {
+            const uint32_t tpw = 64u;
+            const dim3 gh((s.n_tiles + tpw - 1) / tpw, window);
+            if (kind == 0) cull_hyp32_k<0><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp);
+            else if (kind == 1) cull_hyp32_k<1><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp);
+            else cull_hyp32_k<2><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp);
+            return;
+        }
         if (kind == 0)
             cull_tiles32_k<0><<<g, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, gpw, masks, ub, group_begin, group_end, ubp);
         else if (kind == 1)

@@ -119,6 +119,28 @@ def test_fit_matches_oracle(capi, orc, scoring_path, kind, n, max_iter, prob, se
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
+def test_box_tests_by_hypothesis_and_by_tile_match_oracle(capi, orc, kind):
+    """Windows of 128 groups and more take their fp32 box tests with a lane per HYPOTHESIS (cull_hyp32_k, round 6), smaller ones and
+    m3d_config.cull_fp32 = 2 with a lane per tile (cull_tiles32_k): same words, same counters, and either way the oracle's fit.
+    20 000 hypotheses: a first chunk of 2048, then one window of 281 groups."""
+    pts, nrm = _clouds(kind, 60_000, seed=40 + kind)
+    H, seed = 20_000, 21 + kind
+    o = orc.fit(kind, pts, nrm, thr=0.01, max_iter=H, prob=1.0, seed=seed, lookahead=512)
+    got = []
+    for mode in (1, 2):
+        old = capi.set_config(cull_fp32=mode)
+        try:
+            g = capi.fit(kind, pts, nrm, threshold=0.01, max_iteration=H, probability=1.0, seed=seed)
+        finally:
+            capi.restore_config(old)
+        assert g.ret == o.ret and g.stats["best_index"] == o.best_index and g.stats["count"] == o.count
+        assert np.array_equal(g.inliers, o.inliers)
+        assert np.allclose(g.params, o.params, rtol=0, atol=PARAM_TOL)
+        got.append(g)
+    assert np.array_equal(_bits(got[0].params), _bits(got[1].params))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
 @pytest.mark.parametrize("phases", [2, 3])
 def test_phased_scoring_matches_oracle(capi, orc, kind, phases):
     """launch_score_phased needs >= 256 tiles and a window of >= 32 groups to engage: 150 000 points x 3000 hypotheses.  The fit
