@@ -15,7 +15,8 @@ spec.loader.exec_module(mod)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 # (round 6: + the validation's candidate cache forced on from the first incumbent, with most of the time on registrations)
 for seed, cfg in ((201, {}), (202, {"plane_bound": 2}), (203, {"plane_bound": 2, "lanes": 1}),
-                  (204, {"plane_bound": 2, "score_fp32_screen": 0, "cull_fp32": 0}), (205, {"reg_cache": 2}), (206, {"reg_cache": 2, "reg_prune": 0})):
+                  (204, {"plane_bound": 2, "score_fp32_screen": 0, "cull_fp32": 0}), (205, {"reg_cache": 2}), (206, {"reg_cache": 2, "reg_prune": 0}),
+                  (207, {"cull_fp32": 2, "match_pipeline": 2})):   # (round 6, later: box tests with a lane per tile at every size, every match sliced)
     reg_share = 0.7 if "reg_cache" in cfg else 0.2
     old = capi.set_config(**cfg)
     try:
