@@ -428,10 +428,106 @@ __global__ __launch_bounds__(64 * kBoundWaves) void plane_bound_k(const double* 
     }
 }
 
+// plane_bound_k's sums for CYLINDERS whose box tests left a word per hypothesis and 64 tiles (cull_hyp32_k, `touched`): round 6.
+// plane_bound_k gives 64 survivors to a workgroup of eight waves that share them and split the tiles, and repeats the box test of every
+// (survivor, tile): on a C3 window (47 952 hypotheses, ~13 000 survivors, 1954 tiles) 104 us -- 13 of them the box tests (31 VALU
+// instructions with a correctly rounded sqrt, 19 more for the box's radius), and per 64 survivors and 128 tiles a workgroup's staging of
+// frames and histograms, the records through the LDS, the bound records in fp64 by all eight waves, the cross-wave sum, the ticket.
+// Here a WAVE owns 64 survivors and walks a block of kCylTpb tiles whose frames the workgroup has staged once for its 512 survivors;
+// a lane's touched tiles are the bits of ONE word, every record is prepared once per tile block, nothing crosses waves: 104 -> 78 us,
+// which is cyl_pair_ub's ~100 instructions on every (wave of survivors, tile) some lane touches -- all of them: a survivor touches
+// a tenth of the tiles.  The same cyl_pair_ub on the same pairs; the sums are integer additions: order-free.
+constexpr int kCylTpb = 64;    // tiles per workgroup (one word per lane; 128: two)
+__global__ __launch_bounds__(64 * kBoundWaves) void cyl_bound_words_k(const double* __restrict__ frames, const uint16_t* __restrict__ cum,
+                                                                       uint32_t n_tiles, double max_abs, const double* __restrict__ score,
+                                                                       uint32_t* __restrict__ surv_count, const uint32_t* __restrict__ surv,
+                                                                       uint32_t* __restrict__ ubsum, const uint32_t* __restrict__ best_count,
+                                                                       unsigned long long* __restrict__ keep, uint32_t* __restrict__ tickets,
+                                                                       uint32_t max_list, const unsigned long long* __restrict__ touched,
+                                                                       uint32_t touched_stride) {
+    __shared__ double c_s[kCylTpb][3];
+    __shared__ float f_s[kCylTpb][kFrameStride];
+    __shared__ __attribute__((aligned(8))) uint16_t cm_s[kCylTpb][kCumStride];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t total = surv_count[0];
+    if (total > max_list) {   // (uniform; plane_bound_k's rule and its reasons)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) surv_count[0] = 0u;
+        return;
+    }
+    if (blockIdx.x * (64u * kBoundWaves) >= total) return;   // (workgroup-uniform)
+    const uint32_t t0 = blockIdx.y * (uint32_t)kCylTpb, nt = min((uint32_t)kCylTpb, n_tiles - t0);
+    {
+        const double* __restrict__ src = frames + (size_t)t0 * kFrameStride;
+        for (uint32_t i = threadIdx.x; i < nt * (uint32_t)kFrameStride; i += 64u * kBoundWaves) {
+            const uint32_t tl = i / (uint32_t)kFrameStride, k = i % (uint32_t)kFrameStride;
+            const double v = src[i];
+            if (k < 3u) c_s[tl][k] = v;
+            f_s[tl][k] = frame_to_f32(v, k);
+        }
+        __syncthreads();
+        if (threadIdx.x < nt) f_s[threadIdx.x][0] = cyl_tile_rho(f_s[threadIdx.x]);   // (slot 0: the centre's fp32 copy is not used)
+        const uint32_t* __restrict__ csrc = reinterpret_cast<const uint32_t*>(cum + (size_t)t0 * kCumStride);
+        uint32_t* cdst = reinterpret_cast<uint32_t*>(&cm_s[0][0]);
+        for (uint32_t i = threadIdx.x; i < nt * (uint32_t)(kCumStride / 2); i += 64u * kBoundWaves) cdst[i] = csrc[i];
+        __syncthreads();
+    }
+    // (no barrier below: every wave goes its own way)
+    for (uint32_t first = (blockIdx.x * kBoundWaves + wave) * 64u; first < total; first += gridDim.x * (64u * kBoundWaves)) {   // (wave-uniform)
+        const uint32_t nb = min(64u, total - first);
+        const bool has = (uint32_t)lane < nb;
+        const uint32_t h = surv[first + (has ? (uint32_t)lane : 0u)];
+        double rec[8];
+        {
+            const double2* __restrict__ rp = reinterpret_cast<const double2*>(score + (size_t)h * kModelStride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double2 v = rp[k];
+                rec[2 * k] = v.x;
+                rec[2 * k + 1] = v.y;
+            }
+        }
+        CylBoundRec cr = cyl_bound_record(rec, max_abs);
+        cr.ok = cr.ok && has;
+        unsigned long long w0 = has ? touched[(size_t)(t0 / 64u) * touched_stride + h] : 0ull;
+        unsigned long long w1 = (has && t0 + 64u < n_tiles) ? touched[(size_t)(t0 / 64u + 1u) * touched_stride + h] : 0ull;
+        uint32_t ub = 0;
+        // (measured and not kept: every lane popping ITS next touched tile -- one pair per lane and trip, the tile's frame gathered from the
+        //  LDS per lane: ~20 scattered LDS reads per trip cost more than the idle lanes of a tile-uniform trip, 127 against 91 us)
+        for (uint32_t tl = 0; tl < nt; ++tl) {   // (wave-uniform: the tile's frame and histogram are broadcast reads)
+            const bool mine = (((tl < 64u ? w0 : w1) >> (tl & 63u)) & 1ull) != 0ull;
+            if (__builtin_amdgcn_ballot_w64(mine) == 0ull) continue;
+            const uint32_t u_t = cyl_pair_ub(cr, c_s[tl], f_s[tl], f_s[tl][0], cm_s[tl]);
+            ub += mine ? u_t : 0u;
+        }
+        if (has && ub) atomicAdd(&ubsum[h], ub);
+        // the keep rule, by whichever wave of this block of 64 hypotheses finishes last over the tile blocks (plane_bound_k's tail)
+        __threadfence();
+        const uint32_t blk = first / 64u;
+        uint32_t old = 0;
+        if (lane == 0) old = atomicAdd(&tickets[1u + blk], 1u);
+        old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+        if (old == gridDim.y - 1u) {   // (wave-uniform)
+            __threadfence();
+            const uint32_t best = best_count[0];
+            const uint32_t sum = has ? atomicAdd(&ubsum[h], 0u) : 0u;   // (the other workgroups' adds, at the memory side)
+            if (has && best != 0u && sum < best) atomicAnd(&keep[h >> 6], ~(1ull << (h & 63u)));
+            if (lane == 0) {
+                tickets[1u + blk] = 0u;
+                const uint32_t done = atomicAdd(&tickets[0], 1u);
+                if (done == (total + 63u) / 64u - 1u) {   // the last block of the launch: the list is consumed
+                    tickets[0] = 0u;
+                    surv_count[0] = 0u;
+                }
+            }
+        }
+    }
+}
+
 void launch_plane_bound(int kind, const SortedView& s, const double* score, const unsigned long long* masks, unsigned long long* keep,
                         uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
                         const uint32_t* best_count, uint32_t* surv_count, const uint32_t* surv, uint32_t* tickets,
-                        const float* cull32, hipStream_t st, bool always) {
+                        const float* cull32, hipStream_t st, bool always, const unsigned long long* touched, uint32_t touched_stride) {
     group_end = std::min(group_end, n_groups);
     if (!s.frames || !s.frame_cum || !s.n_tiles || !surv || !surv_count || !tickets || group_begin >= group_end) return;
     const uint32_t window = group_end - group_begin;
@@ -445,6 +541,12 @@ void launch_plane_bound(int kind, const SortedView& s, const double* score, cons
     constexpr int tpw = 8, tpw_cyl = 16;
     const uint32_t tpb = (uint32_t)(kBoundWaves * (kind == 0 ? tpw : tpw_cyl));
     const uint32_t max_list = always ? 0xFFFFFFFFu : window * 32u;   // half of the window's hypotheses
+    if (kind == 2 && touched && s.radius < 1e18) {   // a wave per 64 survivors: a workgroup per 8 groups of the window covers a list of every hypothesis
+        const dim3 gw((window + kBoundWaves - 1) / kBoundWaves, (s.n_tiles + kCylTpb - 1) / kCylTpb);
+        cyl_bound_words_k<<<gw, 64 * kBoundWaves, 0, st>>>(s.frames, s.frame_cum, s.n_tiles, s.max_abs, score, surv_count, surv, ubsum, best_count,
+                                                           keep, tickets, max_list, touched, touched_stride);
+        return;
+    }
     const dim3 g(gx, (s.n_tiles + tpb - 1) / tpb), b(64 * kBoundWaves);
     if (s.radius >= 1e18 || kind == 1) cull32 = nullptr;   // (no fp32 boxes: launch_cull_mask's condition; spheres: the box tests' mask words are read)
     auto go = [&](auto kernel) {

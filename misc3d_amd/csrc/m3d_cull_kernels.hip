@@ -462,7 +462,9 @@ template <int KIND>
 __global__ __launch_bounds__(64) void cull_hyp32_k(const double* __restrict__ boxes, uint32_t n_tiles, const float* __restrict__ cull32,
                                                     uint32_t n_groups, uint32_t tiles_per_wave /* a multiple of 4 */,
                                                     unsigned long long* __restrict__ masks, uint32_t* __restrict__ ub, uint32_t group_begin,
-                                                    uint32_t group_end, uint32_t* __restrict__ ubp) {
+                                                    uint32_t group_end, uint32_t* __restrict__ ubp,
+                                                    unsigned long long* __restrict__ touched /* [blockIdx.x][touched_stride], or null; tiles_per_wave = 64 */,
+                                                    uint32_t touched_stride) {
     const uint32_t g = group_begin + blockIdx.y;
     if (g >= group_end) return;
     const int lane = threadIdx.x;
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(64) void cull_hyp32_k(const double* __restrict__ bo
     }
     const uint32_t t0 = blockIdx.x * tiles_per_wave, t1 = min(n_tiles, t0 + tiles_per_wave);
     uint32_t cnt = 0, c0 = 0, c1 = 0;
+    uint32_t tw_lo = 0u, tw_hi = 0u;   // the lane's own word: bit (tile - t0) = the mask bit of (tile, this hypothesis)
     for (uint32_t t = t0; t < t1; t += 4u) {
         // the four tiles' boxes in one go (wave-uniform addresses: scalar loads; past the block's end: its last tile once more)
         float bx[4][7];
@@ -495,11 +498,17 @@ __global__ __launch_bounds__(64) void cull_hyp32_k(const double* __restrict__ bo
                 const float tv = cull32_one<KIND>(rr, 0, bx[r][0], bx[r][1], bx[r][2], bx[r][3], bx[r][4], bx[r][5], bx[r][6]);
                 // the WORD takes the sign bit, the COUNTERS the comparison -- as cull_tiles32_k has them (a sphere's or cylinder's
                 // verdict is the OR of two floats' bits: with the sign set it may be a NaN, which no comparison calls negative)
-                word = __builtin_amdgcn_ballot_w64((int)__float_as_uint(tv) >= 0);
-                const bool touched = !(tv < 0.0f) && t + r < t1;
-                cnt += touched ? 1u : 0u;
-                if (r == 0u) c0 += touched ? 1u : 0u;
-                if (r == 1u) c1 += touched ? 1u : 0u;
+                const bool bit_on = (int)__float_as_uint(tv) >= 0;
+                word = __builtin_amdgcn_ballot_w64(bit_on);
+                if (touched) {   // (kernel argument: uniform)
+                    const uint32_t b = (t - t0) + r, one = 1u << (b & 31u);   // (scalar)
+                    if (b < 32u) tw_lo |= (bit_on && t + r < t1) ? one : 0u;
+                    else tw_hi |= (bit_on && t + r < t1) ? one : 0u;
+                }
+                const bool touched_now = !(tv < 0.0f) && t + r < t1;
+                cnt += touched_now ? 1u : 0u;
+                if (r == 0u) c0 += touched_now ? 1u : 0u;
+                if (r == 1u) c1 += touched_now ? 1u : 0u;
             }
             // (v_writelane_b32: the scalar word into lane r of the pair of registers the four-lane store below sends)
             const uint32_t wl = (uint32_t)word, wh = (uint32_t)(word >> 32);
@@ -513,11 +522,14 @@ __global__ __launch_bounds__(64) void cull_hyp32_k(const double* __restrict__ bo
     }
     if (ub && cnt) atomicAdd(&ub[h], cnt);
     if (ubp && (c0 | c1)) atomicAdd(&ubp[h], c0 | (c1 << 16));
+    if (touched) touched[(size_t)blockIdx.x * touched_stride + h] = ((unsigned long long)tw_hi << 32) | tw_lo;
 }
 
 void launch_cull_mask(int kind, const SortedView& s, const double* score, const uint8_t* valid, uint32_t h_count,
                       uint32_t n_groups, unsigned long long* masks, uint32_t* ub, hipStream_t st, bool ub_is_zero,
-                      uint32_t group_begin, uint32_t group_end, const float* cull32, uint32_t* ubp) {
+                      uint32_t group_begin, uint32_t group_end, const float* cull32, uint32_t* ubp, unsigned long long* touched,
+                      uint32_t touched_stride, bool* touched_written) {
+    if (touched_written) *touched_written = false;
     (void)valid;     // (invalid and padding hypotheses are "no inlier" records)
     (void)h_count;
     group_end = std::min(group_end, n_groups);
@@ -534,9 +546,10 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
         if (window >= 128u && config().cull_fp32 != 2) {
             const uint32_t tpw = 64u;
             const dim3 gh((s.n_tiles + tpw - 1) / tpw, window);
-            if (kind == 0) cull_hyp32_k<0><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp);
-            else if (kind == 1) cull_hyp32_k<1><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp);
-            else cull_hyp32_k<2><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp);
+            if (kind == 0) cull_hyp32_k<0><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp, touched, touched_stride);
+            else if (kind == 1) cull_hyp32_k<1><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp, touched, touched_stride);
+            else cull_hyp32_k<2><<<gh, b, 0, st>>>(s.boxes, s.n_tiles, cull32, n_groups, tpw, masks, ub, group_begin, group_end, ubp, touched, touched_stride);
+            if (touched_written) *touched_written = touched != nullptr;
             return;
         }
         if (kind == 0)

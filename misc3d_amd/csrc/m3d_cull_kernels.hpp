@@ -48,7 +48,10 @@ void launch_plane_bound(int kind, const SortedView& s, const double* score, cons
                         uint32_t n_groups, uint32_t group_begin, uint32_t group_end, uint32_t* ubsum,
                         const uint32_t* best_count, uint32_t* surv_count, const uint32_t* surv, uint32_t* tickets,
                         const float* cull32, hipStream_t st,
-                        bool always = false /* false: a list longer than half of the window is discarded unbounded (nothing worth pruning against) */);
+                        bool always = false /* false: a list longer than half of the window is discarded unbounded (nothing worth pruning against) */,
+                        const unsigned long long* touched = nullptr /* launch_cull_mask's per-hypothesis words for these groups (cylinders: read
+                                                                       instead of repeating the box tests) */,
+                        uint32_t touched_stride = 0);
 void launch_tile_boxes(const SortedView& s, double* boxes, hipStream_t st);
 // Tombstones (m3d_poison.hpp): the job that kills the inliers of the plane `model` (device) in place in the sorted copy
 // `s`; *total (device, cleared by the owner) accumulates the number of points killed over all launches.
@@ -65,7 +68,11 @@ void launch_cull_mask(int kind, const SortedView& s, const double* score, const 
                       const float* cull32 = nullptr /* minimal_fit_k's fp32 box-test records (kCull32Stride floats per
                                                        hypothesis): cull_tiles32_k instead of the fp64 tests (m3d_config.cull_fp32) */,
                       uint32_t* ubp = nullptr /* phased scoring (launch_score_phased): per hypothesis the touched tiles with index % 4 == 0
-                                                 (low 16 bits) and == 1 (high 16 bits); zero on entry; fp32 box tests only */);
+                                                 (low 16 bits) and == 1 (high 16 bits); zero on entry; fp32 box tests only */,
+                      unsigned long long* touched = nullptr /* optional, ceil(n_tiles / 64) x touched_stride words: bit b of
+                                                               touched[k][h] = hypothesis h of the chunk may have inliers in tile 64 k + b --
+                                                               the masks once more, a word per HYPOTHESIS (plane_bound_k's view) */,
+                      uint32_t touched_stride = 0, bool* touched_written = nullptr /* set when the launch wrote them (cull_hyp32_k only) */);
 // keep[g]: hypotheses still worth scoring (ub[h] * 512 >= best_count[0]); ub == null -> all ones.
 // zero_counts_rep != null: the same launch clears the kCountReplicas x rep_stride + kPairReplicas counter words.
 void launch_keep_mask(const uint32_t* ub, const uint32_t* best_count, uint32_t n_groups, unsigned long long* keep,

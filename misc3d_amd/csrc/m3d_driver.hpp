@@ -55,6 +55,7 @@ struct PinBuf {
 struct ChunkSlot {
     DevBuf samples, score, params, valid, counts;
     DevBuf cull32;   // fp32 records of the box tests (cull_tiles32_k), pairwise interleaved
+    DevBuf touched;     // cylinders with the histogram bound: the masks once more, a word per hypothesis and 64 tiles (launch_cull_mask)
     DevBuf masks, ub;   // the chunk's (tile, group) bit masks and touched-tile counters: per SLOT, so that the next chunk's box
                         // tests can run (DeviceCtx::pre_stream) while this chunk is being scored
     hipEvent_t pre_done = nullptr;   // MinimalFit + box tests of the chunk finished on pre_stream

@@ -432,12 +432,20 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             }
             uint32_t* const surv_count = bound_on ? bc + 6 : nullptr;
             uint32_t* const surv = bound_on ? bound_list(ctx) : nullptr;
+            // cylinders in front of the bound: the box tests also leave a word per hypothesis and 64 tiles (cull_hyp32_k), which
+            // plane_bound_k reads instead of repeating the tests
+            unsigned long long* touched = nullptr;
+            bool touched_written = false;
+            if (bound_on && kind == M3D_CYLINDER && c32.out && !s.lead_fused && !scored_with_own_tests && !(ga && g0 >= ga) && g1 - g0 >= 128u) {
+                RESERVE(s.touched, sizeof(uint64_t) * (size_t)((sv.n_tiles + 63u) / 64u) * h_pad);
+                touched = s.touched.as<unsigned long long>();
+            }
             if (!s.lead_fused && !scored_with_own_tests) {
                 if (ga && g0 >= ga)   // (rank > 0: the lead is somebody else's slice)
                     launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub,
                                      ctx->stream, /*ub_is_zero=*/true, 0, ga, c32.out);
                 launch_cull_mask(kind, sv, s.score.as<double>(), s.valid.as<uint8_t>(), count, n_groups, masks, ub, st_pre,
-                                 /*ub_is_zero=*/true, g0, g1, c32.out, ubp);
+                                 /*ub_is_zero=*/true, g0, g1, c32.out, ubp, touched, h_pad, &touched_written);
             }
             if (pre) {   // everything below needs the records, the masks and ub: the main stream picks up here
                 HIPCHK(hipEventRecord(s.pre_done, ctx->pre_stream));
@@ -463,7 +471,8 @@ static int issue_chunk(DeviceCtx* ctx, ChunkSlot& s, const CloudView& v, const S
             }
             if (bound_on)
                 launch_plane_bound(kind, sv, s.score.as<double>(), masks, keep, n_groups, g_lo, g1, ubsum, bc, surv_count, surv,
-                                   bound_tickets(ctx), c32.out, ctx->stream, config().plane_bound == 2);
+                                   bound_tickets(ctx), c32.out, ctx->stream, config().plane_bound == 2,
+                                   touched_written && g_lo == g0 ? touched : nullptr, h_pad);
             bool phased = false;
             if (!scored_with_own_tests && ubp)
                 phased = launch_score_phased(kind, sv, s.score.as<double>(), masks, keep, n_groups, ctx->counts_rep.as<uint32_t>(), h_pad,
