@@ -162,7 +162,9 @@ if "C4" in which:
                    "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA, whole call's wall clock)",
                    "frac": mm_flop / t_match2 / 1e12 / MFMA_F16_PEAK_TFLOPS, "flop": mm_flop,
                    "note": "K = 48 since round 4 (hi halves only; K = 112 before): 3/7 of the flop per pair, so the fraction on the "
-                           "smaller count is lower although the call is faster; the scan is bound by its VALU epilogue (DESIGN 4)"},
+                           "smaller count is lower although the call is faster.  The scan ALONE, in one launch (profiles/r06_match_scan_findings.txt): "
+                                   "3.8 ms = 0.40 of the peak on the nominal 3.84 TFLOP; matrix pipe busy 0.535 of the SIMD cycles, the VALU port "
+                                   "nearly full at that rate (DESIGN 4)"},
          cpu_baseline=cpu("match_baseline", d["feat_src"], d["feat_dst"], 6.0))
     dts = []
     for _ in range(2):      # (the first call of a process also sizes the device's block free list: ~10 ms)
