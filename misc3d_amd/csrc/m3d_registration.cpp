@@ -28,6 +28,10 @@
 #include "m3d_config.hpp"
 #include "m3d_driver.hpp"
 #include "m3d_reg_fp.hpp"
+
+namespace m3d {
+int stream_wait_spin(DeviceCtx* ctx);   // (m3d_fit.cpp: the end of the stream's work, polled in page-locked memory)
+}
 #include "m3d_reg_kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -257,7 +261,7 @@ int exact_err2(RegCtx& rc, const double* T_dev, uint64_t* count, double* err2) {
     HIPCHK(hipMemcpyAsync(h, s.total.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(h + 8, s.sums.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (const int wr = stream_wait_spin(ctx); wr != M3D_OK) return wr;   // (results in page-locked memory: a polled word instead of the runtime's wait, which wakes 10-20 us late)
     uint32_t c;
     std::memcpy(&c, h, 4);
     std::memcpy(err2, h + 8, 8);
@@ -282,7 +286,7 @@ int tree_err2(RegCtx& rc, const double* T_dev, uint64_t* count, double* err2) {
     uint8_t* h = ctx->h_small.as<uint8_t>();
     HIPCHK(hipMemcpyAsync(h, s.sums.as<double>() + 24, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (const int wr = stream_wait_spin(ctx); wr != M3D_OK) return wr;   // (results in page-locked memory: a polled word instead of the runtime's wait, which wakes 10-20 us late)
     double es[2];
     std::memcpy(es, h, 16);
     *err2 = es[0];
@@ -299,7 +303,7 @@ int corr_inlier_ratio(RegCtx& rc, const double* T_dev, double* ratio) {
                       rc.g.r2, s.ratio.as<uint32_t>(), ctx->stream);
     HIPCHK(hipMemcpyAsync(ctx->h_small.p, s.ratio.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (const int wr = stream_wait_spin(ctx); wr != M3D_OK) return wr;   // (results in page-locked memory: a polled word instead of the runtime's wait, which wakes 10-20 us late)
     uint32_t c;
     std::memcpy(&c, ctx->h_small.p, 4);
     *ratio = (double)c / (double)rc.m;
