@@ -146,6 +146,7 @@ struct DeviceCtx {
     const std::function<const m3d::PartitionOut*(int64_t)>* partition_hook = nullptr;
     PinBuf h_best;             // best minimal model of a fit on its way to the host (read after RefineModel's wait)
     PinBuf h_sync;             // stream_wait_spin's completion word
+    PinBuf h_reg;              // registration: a chunk's pass flags / counts and sums on their way to the host (polled, not waited for)
     uint32_t sync_seq = 0;
     DevBuf surv_list;          // plane_bound_k's input: the hypotheses the keep kernels kept (its length: best_count word 6)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
