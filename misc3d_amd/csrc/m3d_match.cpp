@@ -20,6 +20,10 @@
 #include "m3d_driver.hpp"
 #include "m3d_reg_kernels.hpp"
 
+namespace m3d {
+int stream_wait_spin(DeviceCtx* ctx);   // (m3d_fit.cpp: the end of the stream's work, polled in page-locked memory)
+}
+
 #pragma clang fp contract(off)
 
 using namespace m3d;
@@ -289,12 +293,19 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
     if (known_b) hp[kMaxAbsPartials * qa.size()] = side_b.max_abs;
     if (!known_a) slice_max(0, qa[0], 0, s);
     if (!known_b) slice_max(1, pb[0], qa.size(), s);
+    // (the call's two waits go through page-locked memory and a polled word -- stream_wait_spin --: a copy into pageable memory is
+    //  staged, and the runtime's wait wakes the caller 10-20 us after the stream has drained)
+    const size_t hp_bytes = sizeof(double) * hp.size();
+    ok = ok && ctx->h_reg.reserve(hp_bytes + 16);
+    double* hp_pin = ok ? reinterpret_cast<double*>(ctx->h_reg.as<uint8_t>() + 16) : nullptr;
     if (ok && !(known_a && known_b)) {
-        if (!known_a) ok = ok && hipMemcpyAsync(hp.data(), mabs.p, sizeof(double) * kMaxAbsPartials, hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (!known_a) ok = ok && hipMemcpyAsync(hp_pin, mabs.p, sizeof(double) * kMaxAbsPartials, hipMemcpyDeviceToHost, s) == hipSuccess;
         if (!known_b)
-            ok = ok && hipMemcpyAsync(hp.data() + kMaxAbsPartials * qa.size(), mabs.as<double>() + kMaxAbsPartials * qa.size(),
+            ok = ok && hipMemcpyAsync(hp_pin + kMaxAbsPartials * qa.size(), mabs.as<double>() + kMaxAbsPartials * qa.size(),
                                       sizeof(double) * kMaxAbsPartials, hipMemcpyDeviceToHost, s) == hipSuccess;
-        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        ok = ok && hipGetLastError() == hipSuccess && stream_wait_spin(ctx) == M3D_OK;
+        if (ok && !known_a) std::memcpy(hp.data(), hp_pin, sizeof(double) * kMaxAbsPartials);
+        if (ok && !known_b) std::memcpy(hp.data() + kMaxAbsPartials * qa.size(), hp_pin + kMaxAbsPartials * qa.size(), sizeof(double) * kMaxAbsPartials);
     }
     if (!ok) return done(M3D_ERR_DEVICE);
     MATCH_MARK("max |v| of the first slices known");
@@ -360,13 +371,15 @@ int match_mfma(DeviceCtx* ctx, const MatchSide& side_a, uint32_t na, const Match
         launch_mutual_pairs(nn_ab, nn_ba, na, nb, pairs->block_scratch, pairs->host, reinterpret_cast<uint2*>(pairs->host + 16), s);
     }
     uint32_t over[2] = {0, 0};
-    ok = ok && hipMemcpyAsync(over, w.overflow_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
-    if (sliced) ok = ok && hipMemcpyAsync(hp.data(), mabs.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, s) == hipSuccess;
-    ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    ok = ok && hipMemcpyAsync(ctx->h_reg.p, w.overflow_count, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (sliced) ok = ok && hipMemcpyAsync(hp_pin, mabs.p, hp_bytes, hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok = ok && hipGetLastError() == hipSuccess && stream_wait_spin(ctx) == M3D_OK;
     if (!ok) {
         in_flight = true;
         return done(M3D_ERR_DEVICE);
     }
+    std::memcpy(over, ctx->h_reg.p, sizeof(over));
+    if (sliced) std::memcpy(hp.data(), hp_pin, hp_bytes);
     MATCH_MARK("scans and verification done");
     if (sliced) {   // did every slice fit the scale chosen from the first ones?
         if (known_a) hp[0] = side_a.max_abs;
