@@ -1279,7 +1279,7 @@ int m3d_registration_icp(const double* src, size_t n_src, const double* dst, siz
                 HIPCHK(hipMemcpyAsync(h, S.sums.as<double>() + 24, 16, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(hipMemcpyAsync(h + 32, S.sums.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(ctx->stream));
+                if (const int wr = stream_wait_spin(ctx); wr != M3D_OK) return wr;   // (an iteration's one wait: polled, see corr_inlier_ratio)
                 double es[2];
                 std::memcpy(es, h, 16);
                 std::memcpy(hs, h + 32, sizeof(hs));
@@ -1438,7 +1438,7 @@ int m3d::information_matrix_on(DeviceCtx* ctx, m3d_cloud* csrc, m3d_cloud* cdst,
             HIPCHK(hipMemcpyAsync(h, S.total.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipMemcpyAsync(h + 8, S.sums.p, sizeof(double) * 9, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (const int wr = stream_wait_spin(ctx); wr != M3D_OK) return wr;
             uint32_t c;
             double m[9];
             std::memcpy(&c, h, 4);
